@@ -1,0 +1,1002 @@
+// sz3_amd/csrc/sz3hip_api.cpp — host side of libsz3hip.so: the C ABI declared in include/sz3hip.h and include/sz3c.h.
+//
+// Mirrors, for the GPU path, what these reference pieces do on the CPU (paths relative to /root/reference):
+//   include/SZ3/api/sz.hpp:43-82,117-157        container: 16-byte header + payload + Config trailer
+//   include/SZ3/utils/Config.hpp:161-177,312-413 Config::setDims / save / load
+//   include/SZ3/api/impl/SZDispatcher.hpp:13-100 eb-mode conversion, eb==0 => lossless, lossless fallback,
+//                                                "ratio < 3 => also try zstd alone"
+//   include/SZ3/lossless/Lossless_zstd.hpp:29-45 [u64 rawLen][zstd frames]  (we emit several concatenated frames,
+//                                                compressed by a thread pool; any zstd decoder reads them)
+//   tools/sz3c/src/sz3c.cpp:11-94                SZ_compress_args / SZ_decompress / free_buf
+// There is NO CPU implementation of the predictor/quantizer/Huffman stages in this library: if the HIP device
+// or kernels are unavailable every entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/sz3c.h"
+#include "../../include/sz3hip.h"
+#include "sz3hip_format.h"
+#include "sz3hip_kernels.h"
+
+// ------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512];
+static int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+extern "C" const char *sz3hip_last_error(void) { return g_err; }
+extern "C" const char *sz3hip_version(void) { return "sz3hip 0.1 (gfx950; data format SZ3 3.3.2 container, payload SZH1)"; }
+
+#define HIPCHK(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return fail(SZ3HIP_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------------------
+// libzstd (third-party, the reference's lossless stage; not vendored there either — CMakeLists.txt:69-75).
+// zstd.h is not installed in /usr/include of this image, so the five prototypes are declared here and the
+// library is dlopen'ed; a missing library is a hard error.
+// ------------------------------------------------------------------------------------------------------------
+namespace zs {
+typedef size_t (*compress_fn)(void *, size_t, const void *, size_t, int);
+typedef size_t (*decompress_fn)(void *, size_t, const void *, size_t);
+typedef size_t (*bound_fn)(size_t);
+typedef unsigned (*iserr_fn)(size_t);
+typedef size_t (*framesize_fn)(const void *, size_t);
+typedef unsigned long long (*contentsize_fn)(const void *, size_t);
+static void *h;
+static compress_fn compress;
+static decompress_fn decompress;
+static bound_fn bound;
+static iserr_fn is_error;
+static framesize_fn frame_csize;
+static contentsize_fn frame_content;
+static std::once_flag once;
+static bool ok;
+static void load_once() {
+    const char *names[] = {"libzstd.so.1", "libzstd.so", "/usr/lib/x86_64-linux-gnu/libzstd.so.1", nullptr};
+    for (int i = 0; names[i] && !h; i++) h = dlopen(names[i], RTLD_NOW);
+    if (!h) return;
+    compress = (compress_fn)dlsym(h, "ZSTD_compress");
+    decompress = (decompress_fn)dlsym(h, "ZSTD_decompress");
+    bound = (bound_fn)dlsym(h, "ZSTD_compressBound");
+    is_error = (iserr_fn)dlsym(h, "ZSTD_isError");
+    frame_csize = (framesize_fn)dlsym(h, "ZSTD_findFrameCompressedSize");
+    frame_content = (contentsize_fn)dlsym(h, "ZSTD_getFrameContentSize");
+    ok = compress && decompress && bound && is_error;
+}
+static int load() {
+    std::call_once(once, load_once);
+    return ok ? 0 : fail(SZ3HIP_EZSTD, "libzstd.so.1 not found or incomplete");
+}
+static const size_t FRAME = 4u << 20;  // bytes of input per zstd frame
+static unsigned nthreads() {
+    const char *e = getenv("SZ3HIP_ZSTD_THREADS");
+    unsigned n = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    return n;
+}
+static size_t bound_frames(size_t n) {
+    size_t nf = (n + FRAME - 1) / FRAME;
+    if (nf == 0) nf = 1;
+    return nf * bound(std::min(n, FRAME)) + 8;
+}
+// [u64 srcLen][frame]...  level 3 (lossless/Lossless_zstd.hpp:48); returns 0 on error
+static size_t compress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {
+    if (load()) return 0;
+    if (cap < 8) {
+        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+        return 0;
+    }
+    uint64_t len = n;
+    memcpy(dst, &len, 8);
+    const size_t nf = std::max<size_t>(1, (n + FRAME - 1) / FRAME);
+    const size_t fb = bound(std::min(n, FRAME));
+    std::vector<std::vector<uint8_t>> out(nf);
+    std::vector<size_t> sz(nf, 0);
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    auto work = [&]() {
+        for (;;) {
+            size_t f = next.fetch_add(1);
+            if (f >= nf) break;
+            size_t lo = f * FRAME, l = std::min(FRAME, n - lo);
+            out[f].resize(fb);
+            size_t r = compress(out[f].data(), fb, src + lo, l, 3);
+            if (is_error(r)) bad = 1;
+            sz[f] = r;
+        }
+    };
+    unsigned nt = (unsigned)std::min<size_t>(nthreads(), nf);
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (bad) {
+        fail(SZ3HIP_EZSTD, "ZSTD_compress failed");
+        return 0;
+    }
+    size_t total = 8;
+    for (size_t f = 0; f < nf; f++) total += sz[f];
+    if (total > cap) {
+        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+        return 0;
+    }
+    uint8_t *p = dst + 8;
+    for (size_t f = 0; f < nf; f++) {
+        memcpy(p, out[f].data(), sz[f]);
+        p += sz[f];
+    }
+    return total;
+}
+// inverse; frames are located with ZSTD_findFrameCompressedSize and decoded in parallel. returns bytes produced
+static size_t decompress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {
+    if (load()) return 0;
+    if (n < 8) {
+        fail(SZ3HIP_EFORMAT, "truncated lossless block");
+        return 0;
+    }
+    uint64_t len;
+    memcpy(&len, src, 8);
+    if (len > cap) {
+        fail(SZ3HIP_ECAPACITY, "lossless block larger than the destination");
+        return 0;
+    }
+    const uint8_t *p = src + 8;
+    size_t rem = n - 8;
+    struct Fr { const uint8_t *p; size_t c, off, d; };
+    std::vector<Fr> frames;
+    bool split = frame_csize && frame_content;
+    if (split) {
+        size_t off = 0;
+        while (rem > 0) {
+            size_t c = frame_csize(p, rem);
+            if (is_error(c)) { split = false; break; }
+            unsigned long long d = frame_content(p, c);
+            if (d == (unsigned long long)-1 || d == (unsigned long long)-2) { split = false; break; }
+            frames.push_back({p, c, off, (size_t)d});
+            off += (size_t)d;
+            p += c;
+            rem -= c;
+        }
+        if (split && off != len) split = false;
+    }
+    if (!split || frames.size() <= 1) {
+        size_t r = decompress(dst, (size_t)len, src + 8, n - 8);
+        if (is_error(r) || r != len) {
+            fail(SZ3HIP_EZSTD, "ZSTD_decompress failed");
+            return 0;
+        }
+        return r;
+    }
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    auto work = [&]() {
+        for (;;) {
+            size_t f = next.fetch_add(1);
+            if (f >= frames.size()) break;
+            size_t r = decompress(dst + frames[f].off, frames[f].d, frames[f].p, frames[f].c);
+            if (is_error(r) || r != frames[f].d) bad = 1;
+        }
+    };
+    unsigned nt = (unsigned)std::min<size_t>(nthreads(), frames.size());
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (bad) {
+        fail(SZ3HIP_EZSTD, "ZSTD_decompress failed");
+        return 0;
+    }
+    return (size_t)len;
+}
+}  // namespace zs
+
+// ------------------------------------------------------------------------------------------------------------
+// Config (include/SZ3/utils/Config.hpp)
+// ------------------------------------------------------------------------------------------------------------
+extern "C" void sz3hip_config_init(sz3hip_config *c, int ndims, const uint64_t *dims) {
+    memset(c, 0, sizeof(*c));
+    int n = 0;
+    for (int i = 0; i < ndims && n < 4; i++)  // setDims drops extents of 1 (Config.hpp:164-168)
+        if (dims[i] > 1) c->dims[n++] = dims[i];
+    if (n == 0) c->dims[n++] = 1;
+    c->N = n;
+    c->num = 1;
+    for (int i = 0; i < n; i++) c->num *= c->dims[i];
+    c->predDim = (uint8_t)n;
+    c->blockSize = n == 1 ? 128 : (n == 2 ? 16 : 6);  // Config.hpp:175
+    c->cmprAlgo = SZ3HIP_ALGO_INTERP_LORENZO;           // defaults Config.hpp:452-478
+    c->errorBoundMode = SZ3HIP_EB_ABS;
+    c->absErrorBound = 1e-3;
+    c->quantbinCnt = 65536;
+    c->dataType = SZ3HIP_FLOAT;
+    c->lorenzo = 1;
+    c->regression = 1;
+    c->interpAlgo = 1;
+    c->interpAnchorStride = -1;
+    c->interpAlpha = 1.25;
+    c->interpBeta = 2.0;
+}
+
+namespace {
+struct Writer {
+    unsigned char *p;
+    template <class V> void put(V v) {
+        memcpy(p, &v, sizeof(V));
+        p += sizeof(V);
+    }
+};
+struct Reader {
+    const unsigned char *p;
+    template <class V> V get() {
+        V v;
+        memcpy(&v, p, sizeof(V));
+        p += sizeof(V);
+        return v;
+    }
+};
+}  // namespace
+
+extern "C" size_t sz3hip_config_save(const sz3hip_config *c, unsigned char *out) {  // Config.hpp:312-354
+    Writer w{out + 1};
+    w.put<int8_t>((int8_t)c->N);
+    uint64_t mx = 0;
+    for (int i = 0; i < c->N; i++) mx = std::max(mx, c->dims[i]);
+    uint8_t bw = 0;  // vector_bit_width, utils/ByteUtil.hpp:195-204
+    for (; mx > 0; mx >>= 1) bw++;
+    w.put<uint8_t>(bw);
+    const size_t nbytes = ((size_t)bw * (size_t)c->N + 7) / 8;  // vector2bytes, ByteUtil.hpp:206-238 (LSB first)
+    memset(w.p, 0, nbytes);
+    for (int i = 0; i < c->N; i++)
+        for (int j = 0; j < bw; j++)
+            if ((c->dims[i] >> j) & 1) {
+                size_t bit = (size_t)i * bw + j;
+                w.p[bit >> 3] |= (unsigned char)(1u << (bit & 7));
+            }
+    w.p += nbytes;
+    w.put<uint64_t>(c->num);
+    w.put<uint8_t>(c->cmprAlgo);
+    w.put<uint8_t>(c->errorBoundMode);
+    switch (c->errorBoundMode) {
+        case SZ3HIP_EB_ABS: w.put<double>(c->absErrorBound); break;
+        case SZ3HIP_EB_REL: w.put<double>(c->relErrorBound); break;
+        case SZ3HIP_EB_PSNR: w.put<double>(c->psnrErrorBound); break;
+        case SZ3HIP_EB_L2NORM: w.put<double>(c->l2normErrorBound); break;
+        case SZ3HIP_EB_ABS_AND_REL:
+        case SZ3HIP_EB_ABS_OR_REL:
+            w.put<double>(c->absErrorBound);
+            w.put<double>(c->relErrorBound);
+            break;
+        default: break;
+    }
+    w.put<uint8_t>((uint8_t)((c->lorenzo & 1) << 7 | (c->lorenzo2 & 1) << 6 | (c->regression & 1) << 5 |
+                             (c->regression2 & 1) << 4 | (c->openmp & 1) << 3));
+    w.put<uint8_t>(c->dataType);
+    w.put<int32_t>(c->quantbinCnt);
+    w.put<int32_t>(c->blockSize);
+    w.put<uint8_t>(c->predDim);
+    out[0] = (unsigned char)(w.p - out);
+    return (size_t)(w.p - out);
+}
+
+extern "C" size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in) {  // Config.hpp:361-413
+    Reader r{in};
+    const uint8_t conf_size = r.get<uint8_t>();
+    const unsigned char *end = r.p + conf_size;
+    uint64_t one = 1;
+    sz3hip_config_init(c, 1, &one);
+    c->N = r.get<int8_t>();
+    if (c->N < 0 || c->N > 4) c->N = 0;
+    const uint8_t bw = r.get<uint8_t>();
+    const size_t nbytes = ((size_t)bw * (size_t)c->N + 7) / 8;
+    for (int i = 0; i < c->N; i++) {  // bytes2vector, ByteUtil.hpp:240-264
+        uint64_t v = 0;
+        for (int j = 0; j < bw && j < 64; j++) {
+            size_t bit = (size_t)i * bw + j;
+            v |= (uint64_t)((r.p[bit >> 3] >> (bit & 7)) & 1) << j;
+        }
+        c->dims[i] = v;
+    }
+    r.p += nbytes;
+    c->num = r.get<uint64_t>();
+    c->cmprAlgo = r.get<uint8_t>();
+    c->errorBoundMode = r.get<uint8_t>();
+    switch (c->errorBoundMode) {
+        case SZ3HIP_EB_ABS: c->absErrorBound = r.get<double>(); break;
+        case SZ3HIP_EB_REL: c->relErrorBound = r.get<double>(); break;
+        case SZ3HIP_EB_PSNR: c->psnrErrorBound = r.get<double>(); break;
+        case SZ3HIP_EB_L2NORM: c->l2normErrorBound = r.get<double>(); break;
+        case SZ3HIP_EB_ABS_AND_REL:
+        case SZ3HIP_EB_ABS_OR_REL:
+            c->absErrorBound = r.get<double>();
+            c->relErrorBound = r.get<double>();
+            break;
+        default: break;
+    }
+    if (r.p < end) {
+        uint8_t b = r.get<uint8_t>();
+        c->lorenzo = (b >> 7) & 1;
+        c->lorenzo2 = (b >> 6) & 1;
+        c->regression = (b >> 5) & 1;
+        c->regression2 = (b >> 4) & 1;
+        c->openmp = (b >> 3) & 1;
+    }
+    if (r.p < end) c->dataType = r.get<uint8_t>();
+    if (r.p < end) c->quantbinCnt = r.get<int32_t>();
+    if (r.p < end) c->blockSize = r.get<int32_t>();
+    if (r.p < end) c->predDim = r.get<uint8_t>();
+    return (size_t)(r.p - in);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// device context
+// ------------------------------------------------------------------------------------------------------------
+enum { ST_K1 = 0, ST_CODEBOOK, ST_ENCODE, ST_ASSEMBLE, ST_DEC_HUFF, ST_DEC_RECON, ST_COUNT };
+static const char *const kStageNames[ST_COUNT] = {"lorenzo_quant_hist", "codebook", "encode", "assemble",
+                                                  "huffman_decode",     "reconstruct"};
+
+struct sz3hip_ctx {
+    int device;
+    int dtype;
+    uint64_t max_n, out_cap, max_chunks;
+    // device buffers
+    uint16_t *d_codes;
+    uint64_t *d_hist;
+    uint64_t *d_counters;  // [0]=n_vout [1]=n_dout [2]=total_words
+    uint64_t *d_vout_idx, *d_dout_idx;
+    void *d_vout_val, *d_dout_val;
+    uint32_t *d_enc;
+    uint8_t *d_lens;
+    uint64_t *d_keys, *d_ifreq;
+    uint16_t *d_syms, *d_pleaf, *d_pint, *d_depth;
+    szk_cb_info *d_info;
+    uint16_t *d_chunk_words;
+    uint64_t *d_chunk_off;
+    szk_state *d_state;
+    szk_dec_tables *d_tables;
+    void *d_segtot;
+    double *d_minmax;
+    szk_state *h_state;  // pinned
+    double *h_minmax;    // pinned
+    // pending compress
+    szh_header proto;
+    bool stage1_done, stage2_done;
+    sz3hip_stats stats;
+    // profiling
+    bool profiling;
+    hipEvent_t ev[ST_COUNT][2];
+    bool ev_used[ST_COUNT];
+};
+
+static void ctx_free(sz3hip_ctx *c) {
+    if (!c) return;
+    void *bufs[] = {c->d_codes, c->d_hist, c->d_counters, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
+                    c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_info,
+                    c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->h_state) (void)hipHostFree(c->h_state);
+    if (c->h_minmax) (void)hipHostFree(c->h_minmax);
+    for (int i = 0; i < ST_COUNT; i++)
+        for (int j = 0; j < 2; j++)
+            if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
+    delete c;
+}
+
+extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dataType) {
+    if (dataType != SZ3HIP_FLOAT && dataType != SZ3HIP_DOUBLE) {
+        fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float / double only)", dataType);
+        return nullptr;
+    }
+    if (max_elems == 0) max_elems = 1;
+    if (hipSetDevice(device) != hipSuccess) {
+        fail(SZ3HIP_EHIP, "hipSetDevice(%d) failed — no usable HIP device; this library has no CPU path", device);
+        return nullptr;
+    }
+    sz3hip_ctx *c = new sz3hip_ctx();
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    c->dtype = dataType;
+    c->max_n = max_elems;
+    c->out_cap = std::max<uint64_t>(4096, max_elems / 32);
+    c->max_chunks = (max_elems + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
+    const size_t tsz = dataType == SZ3HIP_FLOAT ? 4 : 8;
+    bool ok = true;
+    auto alloc = [&](void **p, size_t bytes) {
+        if (!ok) return;
+        if (hipMalloc(p, bytes ? bytes : 16) != hipSuccess) {
+            ok = false;
+            fail(SZ3HIP_EHIP, "hipMalloc of %zu bytes failed", bytes);
+        }
+    };
+    alloc((void **)&c->d_codes, (max_elems + 64) * 2);
+    alloc((void **)&c->d_hist, SZH_HIST_BINS * 8);
+    alloc((void **)&c->d_counters, 64);
+    alloc((void **)&c->d_vout_idx, c->out_cap * 8);
+    alloc((void **)&c->d_dout_idx, c->out_cap * 8);
+    alloc(&c->d_vout_val, c->out_cap * 8);
+    alloc(&c->d_dout_val, c->out_cap * 8);
+    alloc((void **)&c->d_enc, SZH_HIST_BINS * 4);
+    alloc((void **)&c->d_lens, SZH_HIST_BINS);
+    alloc((void **)&c->d_keys, SZH_HIST_BINS * 8);
+    alloc((void **)&c->d_ifreq, SZH_HIST_BINS * 8);
+    alloc((void **)&c->d_syms, SZH_HIST_BINS * 2);
+    alloc((void **)&c->d_pleaf, SZH_HIST_BINS * 2);
+    alloc((void **)&c->d_pint, SZH_HIST_BINS * 2);
+    alloc((void **)&c->d_depth, SZH_HIST_BINS * 2);
+    alloc((void **)&c->d_info, sizeof(szk_cb_info));
+    alloc((void **)&c->d_chunk_words, (c->max_chunks + 8) * 2);
+    alloc((void **)&c->d_chunk_off, (c->max_chunks + 8) * 8);
+    alloc((void **)&c->d_state, sizeof(szk_state));
+    alloc((void **)&c->d_tables, sizeof(szk_dec_tables));
+    alloc(&c->d_segtot, (4 * max_elems / 16384 + 65536) * 8);
+    alloc((void **)&c->d_minmax, (2 * 1024 + 2) * 8);
+    if (ok && hipHostMalloc((void **)&c->h_state, sizeof(szk_state)) != hipSuccess) ok = false;
+    if (ok && hipHostMalloc((void **)&c->h_minmax, 16) != hipSuccess) ok = false;
+    (void)tsz;
+    if (!ok) {
+        if (!g_err[0]) fail(SZ3HIP_EHIP, "device allocation failed");
+        ctx_free(c);
+        return nullptr;
+    }
+    return c;
+}
+extern "C" void sz3hip_ctx_destroy(sz3hip_ctx *ctx) {
+    if (ctx) (void)hipSetDevice(ctx->device);
+    ctx_free(ctx);
+}
+
+static size_t payload_bound_n(uint64_t n, uint64_t out_cap) {
+    const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
+    return (size_t)(sizeof(szh_header) + SZH_HIST_BINS + 16 + 2 * n_chunks + 16 + 2 * (out_cap * 16 + 16) +
+                    4 * n_chunks * (SZH_CHUNK_SYMS * SZH_MAX_LEN / 32) + 64);
+}
+extern "C" size_t sz3hip_payload_bound(const sz3hip_ctx *ctx, uint64_t n) { return payload_bound_n(n, ctx->out_cap); }
+extern "C" void *sz3hip_histogram_ptr(sz3hip_ctx *ctx) { return ctx->d_hist; }
+extern "C" size_t sz3hip_histogram_len(const sz3hip_ctx *) { return SZH_HIST_BINS; }
+extern "C" void sz3hip_set_profiling(sz3hip_ctx *ctx, int on) {
+    ctx->profiling = on != 0;
+    if (on)
+        for (int i = 0; i < ST_COUNT; i++)
+            for (int j = 0; j < 2; j++)
+                if (!ctx->ev[i][j]) (void)hipEventCreate(&ctx->ev[i][j]);
+}
+static void prof_begin(sz3hip_ctx *c, int st, hipStream_t s) {
+    if (c->profiling) {
+        (void)hipEventRecord(c->ev[st][0], s);
+        c->ev_used[st] = true;
+    }
+}
+static void prof_end(sz3hip_ctx *c, int st, hipStream_t s) {
+    if (c->profiling) (void)hipEventRecord(c->ev[st][1], s);
+}
+extern "C" int sz3hip_get_stage_times(sz3hip_ctx *ctx, const char **names, float *ms, int max) {
+    int k = 0;
+    if (!ctx->profiling) return 0;
+    for (int i = 0; i < ST_COUNT && k < max; i++) {
+        if (!ctx->ev_used[i]) continue;
+        float t = 0;
+        if (hipEventElapsedTime(&t, ctx->ev[i][0], ctx->ev[i][1]) != hipSuccess) continue;
+        names[k] = kStageNames[i];
+        ms[k] = t;
+        k++;
+    }
+    return k;
+}
+
+extern "C" int sz3hip_minmax_device(sz3hip_ctx *ctx, const void *d_in, uint64_t n, double *mn, double *mx, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return fail(SZ3HIP_EINVAL, "empty array");
+    int rc = szk_launch_minmax(ctx->dtype, d_in, n, ctx->d_minmax + 2, ctx->d_minmax, s);
+    if (rc) return fail(SZ3HIP_EHIP, "minmax kernel launch failed (%d)", rc);
+    HIPCHK(hipMemcpyAsync(ctx->h_minmax, ctx->d_minmax, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *mn = ctx->h_minmax[0];
+    *mx = ctx->h_minmax[1];
+    return 0;
+}
+
+extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (conf->N < 1 || conf->N > 4) return fail(SZ3HIP_EINVAL, "Data dimension higher than 4 is not supported.");
+    uint64_t num = 1;
+    for (int i = 0; i < conf->N; i++) num *= conf->dims[i];
+    if (num != conf->num || num == 0) return fail(SZ3HIP_EINVAL, "conf.num does not match conf.dims");
+    if (num > ctx->max_n) return fail(SZ3HIP_EINVAL, "array of %llu elements exceeds the context capacity %llu",
+                                      (unsigned long long)num, (unsigned long long)ctx->max_n);
+    if (conf->errorBoundMode != SZ3HIP_EB_ABS) return fail(SZ3HIP_EINVAL, "stage1 needs an absolute error bound");
+    const double eb = conf->absErrorBound;
+    if (!(eb > 0) || !isfinite(eb)) return fail(SZ3HIP_EINVAL, "absErrorBound must be positive and finite");
+    const int radius = conf->quantbinCnt / 2;  // api/impl/SZAlgoLorenzoReg.hpp:72
+    if (radius < 2 || radius > 32768) return fail(SZ3HIP_EINVAL, "quantbinCnt must be in [4, 65536]");
+
+    HIPCHK(hipMemsetAsync(ctx->d_hist, 0, SZH_HIST_BINS * 8, s));
+    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 64, s));
+    szk_k1_params p;
+    memset(&p, 0, sizeof(p));
+    for (int i = 0; i < 4; i++) p.d[i] = 1;
+    for (int i = 0; i < conf->N; i++) p.d[4 - conf->N + i] = conf->dims[i];
+    p.two_eb = 2.0 * eb;
+    p.recip = 1.0 / p.two_eb;
+    p.eb = eb;
+    p.radius = (uint32_t)radius;
+    p.out_cap = ctx->out_cap;
+    p.hist = ctx->d_hist;
+    p.n_vout = ctx->d_counters + 0;
+    p.n_dout = ctx->d_counters + 1;
+    p.vout_idx = ctx->d_vout_idx;
+    p.dout_idx = ctx->d_dout_idx;
+    p.vout_val = ctx->d_vout_val;
+    p.dout_val = ctx->d_dout_val;
+    prof_begin(ctx, ST_K1, s);
+    int rc = szk_launch_k1(ctx->dtype, conf->N, d_in, ctx->d_codes, &p, s);
+    prof_end(ctx, ST_K1, s);
+    if (rc) return fail(SZ3HIP_EHIP, "lorenzo_quant kernel launch failed (%d)", rc);
+
+    szh_header &h = ctx->proto;
+    memset(&h, 0, sizeof(h));
+    h.magic = SZH_MAGIC;
+    h.version = SZH_VERSION;
+    h.dtype = (uint8_t)ctx->dtype;
+    h.ndim = (uint8_t)conf->N;
+    h.qbytes = ctx->dtype == SZ3HIP_FLOAT ? 4 : 8;
+    h.radius = (uint32_t)radius;
+    for (int i = 0; i < 4; i++) h.dims[i] = p.d[i];
+    h.eb = eb;
+    h.n = num;
+    h.chunk_syms = SZH_CHUNK_SYMS;
+    h.n_chunks = (num + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
+    ctx->stage1_done = true;
+    ctx->stage2_done = false;
+    return 0;
+}
+
+extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t cap, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->stage1_done) return fail(SZ3HIP_EINVAL, "stage2 called before stage1");
+    const uint64_t n = ctx->proto.n;
+    if (cap < payload_bound_n(n, ctx->out_cap))
+        return fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+    szk_cb_params cb;
+    cb.enc = ctx->d_enc;
+    cb.lens = ctx->d_lens;
+    cb.keys = ctx->d_keys;
+    cb.syms = ctx->d_syms;
+    cb.ifreq = ctx->d_ifreq;
+    cb.pleaf = ctx->d_pleaf;
+    cb.pint = ctx->d_pint;
+    cb.depth = ctx->d_depth;
+    cb.info = ctx->d_info;
+    prof_begin(ctx, ST_CODEBOOK, s);
+    int rc = szk_launch_codebook(ctx->d_hist, &cb, s);
+    if (rc) return fail(SZ3HIP_EHIP, "codebook kernel launch failed (%d)", rc);
+    szk_layout_params lp;
+    lp.proto = ctx->proto;
+    lp.n_vout = ctx->d_counters + 0;
+    lp.n_dout = ctx->d_counters + 1;
+    lp.out_cap = ctx->out_cap;
+    lp.info = ctx->d_info;
+    lp.state = ctx->d_state;
+    rc = szk_launch_layout_pre(&lp, s);
+    prof_end(ctx, ST_CODEBOOK, s);
+    if (rc) return fail(SZ3HIP_EHIP, "layout kernel launch failed (%d)", rc);
+    prof_begin(ctx, ST_ENCODE, s);
+    rc = szk_launch_encode(ctx->d_codes, n, ctx->d_enc, (int)ctx->proto.radius, ctx->d_chunk_words, ctx->d_chunk_off,
+                           ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, s);
+    prof_end(ctx, ST_ENCODE, s);
+    if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
+    szk_asm_params ap;
+    ap.state = ctx->d_state;
+    ap.payload = (uint8_t *)d_payload;
+    ap.cap = cap;
+    ap.total_words = ctx->d_counters + 2;
+    ap.lens = ctx->d_lens;
+    ap.chunk_words = ctx->d_chunk_words;
+    ap.vout_idx = ctx->d_vout_idx;
+    ap.dout_idx = ctx->d_dout_idx;
+    ap.vout_val = ctx->d_vout_val;
+    ap.dout_val = ctx->d_dout_val;
+    prof_begin(ctx, ST_ASSEMBLE, s);
+    rc = szk_launch_assemble(&ap, s);
+    prof_end(ctx, ST_ASSEMBLE, s);
+    if (rc) return fail(SZ3HIP_EHIP, "assemble kernel launch failed (%d)", rc);
+    HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(szk_state), hipMemcpyDeviceToHost, s));
+    ctx->stage2_done = true;
+    return 0;
+}
+
+extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->stage2_done) return fail(SZ3HIP_EINVAL, "finish called before stage2");
+    HIPCHK(hipStreamSynchronize(s));
+    ctx->stage1_done = ctx->stage2_done = false;
+    const szk_state &st = *ctx->h_state;
+    if (st.hdr.magic != SZH_MAGIC) return fail(SZ3HIP_EHIP, "device did not produce a payload header (kernel fault?)");
+    ctx->stats.n = st.hdr.n;
+    ctx->stats.n_value_outliers = st.hdr.n_vout;
+    ctx->stats.n_delta_outliers = st.hdr.n_dout;
+    ctx->stats.n_chunks = st.hdr.n_chunks;
+    ctx->stats.bitstream_bytes = st.hdr.bitstream_words * 4;
+    ctx->stats.payload_bytes = st.hdr.payload_bytes;
+    ctx->stats.max_code_len = st.hdr.max_len;
+    ctx->stats.n_symbols = 0;
+    if (st.overflow)
+        return fail(SZ3HIP_EOUTLIERS, "outlier capacity exceeded (%llu per list): data not compressible at this bound",
+                    (unsigned long long)ctx->out_cap);
+    if (st.cap_exceeded) return fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+    if (payload_size) *payload_size = (size_t)st.hdr.payload_bytes;
+    return 0;
+}
+
+extern "C" int sz3hip_compress_device(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, void *d_payload,
+                                      size_t cap, size_t *payload_size, void *stream) {
+    int rc = sz3hip_compress_stage1(ctx, conf, d_in, stream);
+    if (rc) return rc;
+    rc = sz3hip_compress_stage2(ctx, d_payload, cap, stream);
+    if (rc) return rc;
+    return sz3hip_compress_finish(ctx, payload_size, stream);
+}
+
+extern "C" int sz3hip_get_stats(sz3hip_ctx *ctx, sz3hip_stats *st) {
+    *st = ctx->stats;
+    return 0;
+}
+extern "C" int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, uint64_t n) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n > ctx->max_n) return fail(SZ3HIP_EINVAL, "n exceeds capacity");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(host_codes, ctx->d_codes, n * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, size_t payload_size, void *d_out,
+                                        void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (payload_size < sizeof(szh_header)) return fail(SZ3HIP_EFORMAT, "payload shorter than its header");
+    szh_header h;
+    HIPCHK(hipMemcpyAsync(&ctx->h_state->hdr, d_payload, sizeof(szh_header), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h = ctx->h_state->hdr;
+    if (h.magic != SZH_MAGIC || h.version != SZH_VERSION) return fail(SZ3HIP_EFORMAT, "not an SZH1 payload");
+    if (h.dtype != ctx->dtype) return fail(SZ3HIP_EINVAL, "payload data type does not match the context");
+    if (h.n == 0 || h.n > ctx->max_n) return fail(SZ3HIP_EINVAL, "payload element count exceeds the context capacity");
+    if (h.dims[0] * h.dims[1] * h.dims[2] * h.dims[3] != h.n || h.chunk_syms != SZH_CHUNK_SYMS ||
+        h.n_chunks != (h.n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS || h.sym_count > SZH_HIST_BINS ||
+        h.sym_min + h.sym_count > SZH_HIST_BINS || h.max_len > SZH_MAX_LEN || h.radius < 2 || h.radius > 32768 ||
+        h.qbytes != (h.dtype == 0 ? 4 : 8))
+        return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header");
+    szh_offsets o;
+    szk_host_offsets(&h, &o);
+    if (o.end > payload_size || h.payload_bytes != o.end) return fail(SZ3HIP_EFORMAT, "truncated SZH1 payload");
+    const uint8_t *pl = (const uint8_t *)d_payload;
+    prof_begin(ctx, ST_DEC_HUFF, s);
+    int rc = szk_launch_dec_tables(pl + o.lens, h.sym_min, h.sym_count, ctx->d_tables, s);
+    if (rc) return fail(SZ3HIP_EHIP, "dec_tables kernel launch failed (%d)", rc);
+    szk_dec_params dp;
+    dp.n = h.n;
+    dp.n_chunks = h.n_chunks;
+    dp.bitstream_off = o.bitstream;
+    dp.chunk_words = (const uint16_t *)(pl + o.chunkwords);
+    dp.chunk_off = ctx->d_chunk_off;
+    dp.tables = ctx->d_tables;
+    dp.single_sym = h.sym_min;
+    rc = szk_launch_decode(pl, &dp, ctx->d_codes, ctx->d_chunk_off, ctx->d_counters + 3, s);
+    prof_end(ctx, ST_DEC_HUFF, s);
+    if (rc) return fail(SZ3HIP_EHIP, "decode kernel launch failed (%d)", rc);
+    prof_begin(ctx, ST_DEC_RECON, s);
+    rc = szk_launch_reconstruct(pl, &h, &o, ctx->d_codes, d_out, ctx->d_segtot, s);
+    prof_end(ctx, ST_DEC_RECON, s);
+    if (rc) return fail(SZ3HIP_EHIP, "reconstruct kernel launch failed (%d)", rc);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host-buffer API: SZ_compress<T> / SZ_decompress<T> equivalents
+// ------------------------------------------------------------------------------------------------------------
+static const uint32_t kMagic = 0xF342F310u;                          // include/SZ3/version.hpp.in:10
+static const uint32_t kDataVer = (3u << 24) | (3u << 16) | (2u << 8);  // SZ3_DATA_VERSION 3.3.2 (CMakeLists.txt:7)
+
+extern "C" size_t sz3hip_compress_bound(const sz3hip_config *c, int dataType) {  // api/impl/SZImpl.hpp:34-44
+    if (zs::load()) return 0;
+    unsigned char tmp[160];
+    const size_t es = dataType == SZ3HIP_FLOAT ? 4 : 8;
+    return 4096 + sz3hip_config_save(c, tmp) + zs::bound_frames((size_t)c->num * es);
+}
+
+namespace {
+// one cached context per (device, dtype); grown on demand. The host API is serialised per process.
+std::mutex g_ctx_mu;
+sz3hip_ctx *g_ctx[2];
+void *g_dev_in[2], *g_dev_payload[2];
+size_t g_dev_in_bytes[2], g_dev_payload_bytes[2];
+
+int host_device() {
+    const char *e = getenv("SZ3HIP_DEVICE");
+    return e ? atoi(e) : 0;
+}
+sz3hip_ctx *get_ctx(int dtype, uint64_t n) {
+    sz3hip_ctx *&c = g_ctx[dtype];
+    if (c && c->max_n >= n) return c;
+    if (c) sz3hip_ctx_destroy(c);
+    c = sz3hip_ctx_create(host_device(), n, dtype);
+    return c;
+}
+int ensure_dev(void **p, size_t *have, size_t want) {
+    if (*have >= want) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    HIPCHK(hipMalloc(p, want));
+    *have = want;
+    return 0;
+}
+}  // namespace
+
+// utils/Statistic.hpp:32-56 with the range taken from the device min/max kernel
+static int cal_abs_eb(sz3hip_config &conf, sz3hip_ctx *ctx, const void *d_in) {
+    if (conf.errorBoundMode == SZ3HIP_EB_ABS) return 0;
+    double range = 0;
+    if (conf.errorBoundMode != SZ3HIP_EB_L2NORM) {
+        double mn, mx;
+        int rc = sz3hip_minmax_device(ctx, d_in, conf.num, &mn, &mx, nullptr);
+        if (rc) return rc;
+        // data_range computes max - min in T (Statistic.hpp:12-21)
+        range = ctx->dtype == SZ3HIP_FLOAT ? (double)((float)mx - (float)mn) : mx - mn;
+    }
+    switch (conf.errorBoundMode) {
+        case SZ3HIP_EB_REL: conf.absErrorBound = conf.relErrorBound * range; break;
+        case SZ3HIP_EB_PSNR: {  // computeABSErrBoundFromPSNR, Statistic.hpp:25-30, threshold 0.99
+            double v1 = conf.psnrErrorBound + 10 * log10(1 - 2.0 / 3.0 * 0.99);
+            conf.absErrorBound = range * pow(10, v1 / (-20));
+            break;
+        }
+        case SZ3HIP_EB_L2NORM: conf.absErrorBound = sqrt(3.0 / (double)conf.num) * conf.l2normErrorBound; break;
+        case SZ3HIP_EB_ABS_AND_REL: conf.absErrorBound = std::min(conf.absErrorBound, conf.relErrorBound * range); break;
+        case SZ3HIP_EB_ABS_OR_REL: conf.absErrorBound = std::max(conf.absErrorBound, conf.relErrorBound * range); break;
+        default: return fail(SZ3HIP_EINVAL, "Error bound mode not supported");
+    }
+    conf.errorBoundMode = SZ3HIP_EB_ABS;
+    return 0;
+}
+
+extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, const void *data, char *cmpData,
+                                  size_t cmpCap) {
+    if (dataType != SZ3HIP_FLOAT && dataType != SZ3HIP_DOUBLE) {
+        fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float / double only)", dataType);
+        return 0;
+    }
+    sz3hip_config conf = *config;  // sz.hpp:45
+    if (conf.N < 1 || conf.N > 4) {
+        fail(SZ3HIP_EINVAL, "Data dimension higher than 4 is not supported.");
+        return 0;
+    }
+    if (zs::load()) return 0;
+    if (cmpCap < sz3hip_compress_bound(&conf, dataType)) {  // sz.hpp:47-49
+        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+        return 0;
+    }
+    const size_t es = dataType == SZ3HIP_FLOAT ? 4 : 8;
+    const size_t raw_bytes = (size_t)conf.num * es;
+    unsigned char *out = reinterpret_cast<unsigned char *>(cmpData);
+    Writer w{out};
+    w.put<uint32_t>(kMagic);
+    w.put<uint32_t>(kDataVer);
+    unsigned char *size_pos = w.p;
+    w.p += 8;
+    unsigned char tmp[160];
+    const size_t payload_cap = cmpCap - 16 - 2 * sz3hip_config_save(&conf, tmp);
+    size_t payload_size = 0;
+
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    bool lossless = conf.cmprAlgo == SZ3HIP_ALGO_LOSSLESS;
+    if (!lossless) {
+        sz3hip_ctx *ctx = get_ctx(dataType, conf.num);
+        if (!ctx) return 0;
+        if (ensure_dev(&g_dev_in[dataType], &g_dev_in_bytes[dataType], raw_bytes)) return 0;
+        const size_t pb = sz3hip_payload_bound(ctx, conf.num);
+        if (ensure_dev(&g_dev_payload[dataType], &g_dev_payload_bytes[dataType], pb)) return 0;
+        if (hipMemcpy(g_dev_in[dataType], data, raw_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            fail(SZ3HIP_EHIP, "host->device copy failed");
+            return 0;
+        }
+        if (cal_abs_eb(conf, ctx, g_dev_in[dataType])) return 0;
+        if (conf.absErrorBound == 0) lossless = true;  // SZDispatcher.hpp:19-21
+        if (!lossless) {
+            // every lossy algorithm id of the reference maps to the HIP Lorenzo stream in this release
+            size_t dsize = 0;
+            int rc = sz3hip_compress_device(ctx, &conf, g_dev_in[dataType], g_dev_payload[dataType], pb, &dsize, nullptr);
+            if (rc == SZ3HIP_EOUTLIERS) {
+                lossless = true;  // same policy as the reference's length_error fallback, SZDispatcher.hpp:44-59
+            } else if (rc) {
+                return 0;
+            } else {
+                std::vector<uint8_t> host_payload(dsize);
+                if (hipMemcpy(host_payload.data(), g_dev_payload[dataType], dsize, hipMemcpyDeviceToHost) != hipSuccess) {
+                    fail(SZ3HIP_EHIP, "device->host copy failed");
+                    return 0;
+                }
+                payload_size = zs::compress_frames(host_payload.data(), dsize, w.p, payload_cap);
+                if (!payload_size) return 0;
+                conf.cmprAlgo = SZ3HIP_ALGO_HIP_LORENZO;
+                if ((double)raw_bytes / (double)payload_size < 3) {  // SZDispatcher.hpp:62-74
+                    std::vector<uint8_t> z(zs::bound_frames(raw_bytes) + 8);
+                    size_t zsz = zs::compress_frames((const uint8_t *)data, raw_bytes, z.data(), z.size());
+                    if (zsz && zsz < payload_size && zsz <= payload_cap) {
+                        memcpy(w.p, z.data(), zsz);
+                        payload_size = zsz;
+                        conf.cmprAlgo = SZ3HIP_ALGO_LOSSLESS;
+                    }
+                }
+            }
+        }
+    }
+    if (lossless) {
+        conf.cmprAlgo = SZ3HIP_ALGO_LOSSLESS;
+        payload_size = zs::compress_frames((const uint8_t *)data, raw_bytes, w.p, payload_cap);
+        if (!payload_size) return 0;
+    }
+    uint64_t ps = payload_size;
+    memcpy(size_pos, &ps, 8);
+    w.p += payload_size;
+    conf.openmp = 0;
+    w.p += sz3hip_config_save(&conf, w.p);
+    return (size_t)(w.p - out);
+}
+
+extern "C" int sz3hip_peek_config(sz3hip_config *conf, const char *cmpData, size_t cmpSize) {
+    if (cmpSize < 16 + 8) return fail(SZ3HIP_EFORMAT, "compressed buffer too small");
+    Reader r{reinterpret_cast<const unsigned char *>(cmpData)};
+    if (r.get<uint32_t>() != kMagic)  // sz.hpp:122-125
+        return fail(SZ3HIP_EFORMAT, "magic number mismatch, the input data is not compressed by SZ3");
+    const uint32_t ver = r.get<uint32_t>();
+    if ((ver >> 8) != (kDataVer >> 8))  // sz.hpp:127-135 compares major.minor.patch
+        return fail(SZ3HIP_EFORMAT, "Please use SZ3 v%u.%u.%u to decompress the data", ver >> 24, (ver >> 16) & 255,
+                    (ver >> 8) & 255);
+    const uint64_t payload = r.get<uint64_t>();
+    if (payload > cmpSize - 16) return fail(SZ3HIP_EFORMAT, "payload size exceeds the buffer");
+    sz3hip_config_load(conf, r.p + payload);
+    return 0;
+}
+
+extern "C" int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *cmpData, size_t cmpSize, void *decData) {
+    if (dataType != SZ3HIP_FLOAT && dataType != SZ3HIP_DOUBLE)
+        return fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float / double only)", dataType);
+    int rc = sz3hip_peek_config(conf, cmpData, cmpSize);
+    if (rc) return rc;
+    if (zs::load()) return SZ3HIP_EZSTD;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(cmpData) + 8;
+    uint64_t payload;
+    memcpy(&payload, p, 8);
+    p += 8;
+    const size_t es = dataType == SZ3HIP_FLOAT ? 4 : 8;
+    const size_t raw_bytes = (size_t)conf->num * es;
+    if (conf->cmprAlgo == SZ3HIP_ALGO_LOSSLESS) {  // SZDispatcher.hpp:81-88
+        uint64_t len = 0;
+        if (payload >= 8) memcpy(&len, p, 8);
+        if (len != raw_bytes)
+            return fail(SZ3HIP_EFORMAT, "Decompressed data size does not match the original data size");
+        return zs::decompress_frames(p, payload, (uint8_t *)decData, raw_bytes) == raw_bytes ? 0 : SZ3HIP_EZSTD;
+    }
+    if (conf->cmprAlgo != SZ3HIP_ALGO_HIP_LORENZO)
+        return fail(SZ3HIP_EUNSUPPORTED,
+                    "stream uses cmprAlgo %d of the CPU reference; this library decodes only its own GPU streams (id %d) "
+                    "and ALGO_LOSSLESS",
+                    conf->cmprAlgo, SZ3HIP_ALGO_HIP_LORENZO);
+    if (payload < 8) return fail(SZ3HIP_EFORMAT, "truncated payload");
+    uint64_t raw_len;
+    memcpy(&raw_len, p, 8);
+    std::vector<uint8_t> host_payload(raw_len);
+    if (zs::decompress_frames(p, payload, host_payload.data(), raw_len) != raw_len) return SZ3HIP_EZSTD;
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    sz3hip_ctx *ctx = get_ctx(dataType, conf->num);
+    if (!ctx) return SZ3HIP_EHIP;
+    if ((rc = ensure_dev(&g_dev_in[dataType], &g_dev_in_bytes[dataType], raw_bytes))) return rc;
+    if ((rc = ensure_dev(&g_dev_payload[dataType], &g_dev_payload_bytes[dataType], raw_len + 64))) return rc;
+    HIPCHK(hipMemcpy(g_dev_payload[dataType], host_payload.data(), raw_len, hipMemcpyHostToDevice));
+    rc = sz3hip_decompress_device(ctx, g_dev_payload[dataType], raw_len, g_dev_in[dataType], nullptr);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    if (ctx->h_state->hdr.n != conf->num) return fail(SZ3HIP_EFORMAT, "payload element count does not match the trailer");
+    HIPCHK(hipMemcpy(decData, g_dev_in[dataType], raw_bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the reference's C ABI (tools/sz3c/include/sz3c.h:52-59, tools/sz3c/src/sz3c.cpp:11-94)
+// ------------------------------------------------------------------------------------------------------------
+extern "C" unsigned char *SZ_compress_args(int dataType, void *data, size_t *outSize, int errBoundMode,
+                                           double absErrBound, double relBoundRatio, double pwrBoundRatio, size_t r5,
+                                           size_t r4, size_t r3, size_t r2, size_t r1) {
+    (void)pwrBoundRatio;  // sz3c.cpp:29 ignores it too
+    uint64_t d[4];
+    int nd;
+    if (r2 == 0) { nd = 1; d[0] = r1; }
+    else if (r3 == 0) { nd = 2; d[0] = r2; d[1] = r1; }
+    else if (r4 == 0) { nd = 3; d[0] = r3; d[1] = r2; d[2] = r1; }
+    else if (r5 == 0) { nd = 4; d[0] = r4; d[1] = r3; d[2] = r2; d[3] = r1; }
+    else { nd = 4; d[0] = r5 * r4; d[1] = r3; d[2] = r2; d[3] = r1; }  // sz3c.cpp:24
+    sz3hip_config conf;
+    sz3hip_config_init(&conf, nd, d);
+    conf.absErrorBound = absErrBound;
+    conf.relErrorBound = relBoundRatio;
+    if (errBoundMode == ABS) conf.errorBoundMode = SZ3HIP_EB_ABS;
+    else if (errBoundMode == REL) conf.errorBoundMode = SZ3HIP_EB_REL;
+    else if (errBoundMode == ABS_AND_REL) conf.errorBoundMode = SZ3HIP_EB_ABS_AND_REL;
+    else if (errBoundMode == ABS_OR_REL) conf.errorBoundMode = SZ3HIP_EB_ABS_OR_REL;
+    else {
+        printf("errBoundMode %d not support\n ", errBoundMode);  // sz3c.cpp:39-40
+        exit(0);
+    }
+    if (dataType != SZ_FLOAT && dataType != SZ_DOUBLE) {
+        printf("dataType %d not support\n", dataType);  // sz3c.cpp:51-52
+        exit(0);
+    }
+    const size_t cap = sz3hip_compress_bound(&conf, dataType);
+    unsigned char *buf = static_cast<unsigned char *>(malloc(cap));  // C memory, released by free_buf (sz3c.cpp:56-58)
+    if (!buf) return nullptr;
+    const size_t n = sz3hip_compress(&conf, dataType, data, reinterpret_cast<char *>(buf), cap);
+    if (n == 0) {
+        fprintf(stderr, "SZ_compress_args: %s\n", sz3hip_last_error());
+        free(buf);
+        *outSize = 0;
+        return nullptr;
+    }
+    *outSize = n;
+    unsigned char *shrunk = static_cast<unsigned char *>(realloc(buf, n));
+    return shrunk ? shrunk : buf;
+}
+
+extern "C" void *SZ_decompress(int dataType, unsigned char *bytes, size_t byteLength, size_t r5, size_t r4, size_t r3,
+                               size_t r2, size_t r1) {
+    size_t n;  // sz3c.cpp:66-77
+    if (r2 == 0) n = r1;
+    else if (r3 == 0) n = r1 * r2;
+    else if (r4 == 0) n = r1 * r2 * r3;
+    else if (r5 == 0) n = r1 * r2 * r3 * r4;
+    else n = r1 * r2 * r3 * r4 * r5;
+    if (dataType != SZ_FLOAT && dataType != SZ_DOUBLE) {
+        printf("dataType %d not support\n", dataType);  // sz3c.cpp:90-91
+        exit(0);
+    }
+    sz3hip_config conf;
+    if (sz3hip_peek_config(&conf, reinterpret_cast<const char *>(bytes), byteLength)) {
+        fprintf(stderr, "SZ_decompress: %s\n", sz3hip_last_error());
+        return nullptr;
+    }
+    if (conf.num > n) n = (size_t)conf.num;
+    void *dec = malloc(n * (dataType == SZ_FLOAT ? 4 : 8));
+    if (!dec) return nullptr;
+    if (sz3hip_decompress(&conf, dataType, reinterpret_cast<const char *>(bytes), byteLength, dec)) {
+        fprintf(stderr, "SZ_decompress: %s\n", sz3hip_last_error());
+        free(dec);
+        return nullptr;
+    }
+    return dec;
+}
+
+extern "C" void free_buf(void *p) { free(p); }  // sz3c.cpp:94

@@ -1,0 +1,84 @@
+// sz3_amd/csrc/sz3hip_kernels.h — parameter blocks and host launchers of the gfx950 kernels (sz3hip_kernels.hip)
+#ifndef SZ3HIP_KERNELS_H
+#define SZ3HIP_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sz3hip_format.h"
+
+struct szk_k1_params {
+    uint64_t d[4];  // extents slowest first, left-padded with 1: [w][z][y][x]
+    double recip;   // 1 / (2 eb)
+    double two_eb, eb;
+    uint32_t radius;
+    uint64_t out_cap;  // capacity of each outlier list
+    uint64_t *hist;    // [SZH_HIST_BINS]
+    uint64_t *n_vout, *n_dout;
+    uint64_t *vout_idx, *dout_idx;
+    void *vout_val, *dout_val;
+};
+
+struct szk_cb_info {
+    uint32_t n_symbols, max_len, sym_min, sym_count;
+};
+struct szk_cb_params {
+    uint32_t *enc;   // [65536] (code << 5) | len
+    uint8_t *lens;   // [65536]
+    uint64_t *keys;  // [65536] scratch (freq << 16 | sym)
+    uint16_t *syms;  // [65536] compacted alphabet in symbol order
+    uint64_t *ifreq;
+    uint16_t *pleaf, *pint, *depth;  // [65536] scratch for alphabets > 2048 symbols
+    szk_cb_info *info;
+};
+
+struct szk_state {
+    szh_header hdr;
+    szh_offsets off;
+    uint32_t overflow, cap_exceeded;
+};
+struct szk_layout_params {
+    szh_header proto;
+    const uint64_t *n_vout, *n_dout;
+    uint64_t out_cap;
+    const szk_cb_info *info;
+    szk_state *state;
+};
+struct szk_asm_params {
+    szk_state *state;
+    uint8_t *payload;
+    uint64_t cap;
+    const uint64_t *total_words;
+    const uint8_t *lens;
+    const uint16_t *chunk_words;
+    const uint64_t *vout_idx, *dout_idx;
+    const void *vout_val, *dout_val;
+};
+
+struct szk_dec_tables {
+    uint32_t first_code[SZH_MAX_LEN + 2], first_rank[SZH_MAX_LEN + 2], count[SZH_MAX_LEN + 2];
+    uint32_t max_len, n_coded;
+    uint16_t sorted_syms[65536];
+};
+struct szk_dec_params {
+    uint64_t n, n_chunks;
+    uint64_t bitstream_off;
+    const uint16_t *chunk_words;  // inside the payload
+    const uint64_t *chunk_off;
+    const szk_dec_tables *tables;
+    uint32_t single_sym;
+};
+
+int szk_launch_minmax(int dtype, const void *d_in, uint64_t n, double *d_partial /*[2*1024]*/, double *d_out /*[2]*/, hipStream_t s);
+int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, const szk_k1_params *p, hipStream_t s);
+int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStream_t s);
+int szk_launch_layout_pre(const szk_layout_params *p, hipStream_t s);
+int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, int radius, uint16_t *chunk_words,
+                      uint64_t *chunk_off, uint64_t *total_words, const szk_state *state, uint8_t *payload, hipStream_t s);
+int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
+int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, hipStream_t s);
+int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t *codes, uint64_t *chunk_off,
+                      uint64_t *total_words, hipStream_t s);
+int szk_launch_reconstruct(const uint8_t *payload, const szh_header *h, const szh_offsets *o, const uint16_t *codes,
+                           void *d_out, void *d_segtot, hipStream_t s);
+void szk_host_offsets(const szh_header *h, szh_offsets *o);
+
+#endif

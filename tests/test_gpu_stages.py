@@ -1,0 +1,103 @@
+"""GPU stage-level tests (-m gpu): every stage of the HIP path against the numpy model of the SZH1 format
+(tests/szh_ref.py), through the C ABI with device pointers."""
+import numpy as np
+import pytest
+
+import sz3_amd
+from fields import field1d, field2d, field3d, field4d
+import szh_ref
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _conf(shape, eb):
+    c = sz3_amd.Config(*shape)
+    c.errorBoundMode = sz3_amd.EB_ABS
+    c.absErrorBound = eb
+    return c
+
+
+def _roundtrip_device(a, eb):
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    cap = dc.payload_bound(a.size)
+    payload = torch.empty(cap, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    size = dc.compress(_conf(a.shape, eb), t.data_ptr(), payload.data_ptr(), cap, stream)
+    codes = dc.debug_codes(a.size)
+    pl = payload[:size].cpu().numpy()
+    out = torch.empty_like(t)
+    dc.decompress(payload.data_ptr(), size, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    return codes, pl, out.cpu().numpy(), dc.stats()
+
+
+CASES = [
+    ("1d", lambda: field1d(70001), 1e-3),
+    ("1d-long", lambda: field1d(300000), 1e-4),
+    ("2d", lambda: field2d((123, 257)), 1e-3),
+    ("3d", lambda: field3d((33, 47, 50)), 1e-3),
+    ("3d-f64", lambda: field3d((20, 30, 37), np.float64, sigma=2e-6), 1e-6),
+    ("4d", lambda: field4d((7, 11, 13, 17)), 1e-2),
+    ("3d-smooth", lambda: field3d((40, 40, 40), sigma=0.0), 1e-1),
+    ("3d-const", lambda: np.full((17, 19, 23), 3.25, np.float32), 1e-3),
+]
+
+
+@pytest.mark.parametrize("name,gen,eb", CASES, ids=[c[0] for c in CASES])
+def test_stages(name, gen, eb):
+    a = gen()
+    codes, pl, dec, st = _roundtrip_device(a, eb)
+    q, d, exp_codes, bad, dout = szh_ref.dualquant(a, eb)
+    # K1: codes bit-exact against the numpy model
+    assert np.array_equal(codes, exp_codes.reshape(-1)), "quantisation codes differ from the model"
+    h, o, sec = szh_ref.parse(pl)
+    assert h["magic"] == szh_ref.MAGIC and h["n"] == a.size and h["payload_bytes"] == len(pl)
+    assert h["n_vout"] == int(bad.sum()) and h["n_dout"] == int(dout.sum())
+    assert st["n_value_outliers"] == h["n_vout"] and st["payload_bytes"] == len(pl)
+    # K5: a complete prefix code over exactly the symbols that occur
+    present = np.unique(exp_codes)
+    lens = sec["lens"]
+    assert set(h["sym_min"] + np.nonzero(lens)[0]) == (set(present.tolist()) if len(present) > 1 else set())
+    if len(present) > 1:
+        assert abs(szh_ref.kraft(lens) - 1.0) < 1e-9 and lens.max() == h["max_len"] <= szh_ref.MAX_LEN
+        # optimality: total bits equal to an independent Huffman construction
+        freq = np.bincount(exp_codes.reshape(-1), minlength=65536)[h["sym_min"]:h["sym_min"] + h["sym_count"]]
+        import heapq
+        heap = [(int(f), i) for i, f in enumerate(freq) if f]
+        heapq.heapify(heap)
+        cost = 0
+        cnt = len(heap)
+        while len(heap) > 1:
+            f1, _ = heapq.heappop(heap)
+            f2, _ = heapq.heappop(heap)
+            cost += f1 + f2
+            cnt += 1
+            heapq.heappush(heap, (f1 + f2, cnt))
+        assert int((freq * lens.astype(np.int64)).sum()) == cost, "code is not optimal"
+    # K6: python decoder reads the bit-stream back to the same codes
+    if a.size <= 120000:
+        assert np.array_equal(szh_ref.huffman_decode(h, sec), exp_codes.reshape(-1))
+    # K8: GPU decode == model reconstruction, and the error bound holds strictly (in float64)
+    model = szh_ref.reconstruct(h, sec, exp_codes.reshape(-1)).reshape(a.shape)
+    assert np.array_equal(dec, model)
+    assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= eb
+
+
+def test_outliers_and_nonfinite():
+    a = field3d((24, 31, 40))
+    a[3, 4, 5] = np.nan
+    a[10, 2, 7] = np.inf
+    a[20, 20, 20] = 1e30
+    a[1, 1, 1] = -3e9
+    a[5, 6, 7] = 70000.0   # representable on the lattice but a huge Lorenzo delta -> delta outlier
+    eb = 1e-3
+    codes, pl, dec, st = _roundtrip_device(a, eb)
+    q, d, exp_codes, bad, dout = szh_ref.dualquant(a, eb)
+    assert np.array_equal(codes, exp_codes.reshape(-1))
+    assert st["n_value_outliers"] == int(bad.sum()) >= 4 and st["n_delta_outliers"] == int(dout.sum()) > 0
+    fin = np.isfinite(a)
+    assert np.array_equal(np.isnan(dec), np.isnan(a)) and np.array_equal(dec[~fin & ~np.isnan(a)], a[~fin & ~np.isnan(a)])
+    assert np.max(np.abs(dec[fin].astype(np.float64) - a[fin].astype(np.float64))) <= eb

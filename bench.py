@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — SZ3 hot path on MI355X: compression throughput (GB/s) + ratio at a fixed absolute error bound.
+
+Workload at N=1 (BASELINE.json configs[1], "C2"): 3-D float32 512x512x512 synthetic field, Lorenzo predictor,
+abs errBound 1e-3.  A "step" is one pass of the hot path over that volume with the input already resident in HBM:
+    stage1 (prequantise + integer Lorenzo + code emission + outlier capture + histogram)
+    [N>1: RCCL all-reduce(sum) of the 65536 x u64 code histogram — the path's only exchange, SURVEY.md 8e]
+    stage2 (canonical Huffman codebook, chunked bit-pack, payload assembly)  -> payload resident in HBM
+    finish (stream sync + payload size to the host)
+N>1 = weak scaling: every rank compresses its own 512^3 slab of an (N*512) x 512 x 512 volume (slabs are independent
+like the reference's SZ_compress_OMP slabs, api/impl/SZImplOMP.hpp:48-55), value = total bytes of all ranks / time.
+
+Printed JSON line (rank 0): the driver contract + "roofline" (dominant kernel, live HIP-event timing) +
+"cpu_baseline" (the reference itself from oracle/_ref when present, else the oracle port; rank 0, N=1 only) +
+informational extras (ratio, per-stage ms, host end-to-end incl. PCIe and zstd — never `value`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=512, help="edge of the cubic volume per GPU (512 = the metric's config)")
+    ap.add_argument("--eb", type=float, default=1e-3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-e2e", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import sz3_amd
+    from fields import field3d
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the hot path has no CPU implementation)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    S = args.size
+    shape = (S, S, S)
+    n = S * S * S
+    eb = args.eb
+    # every rank: its own slab of the same analytic field family (different noise seed per rank)
+    a = field3d(shape, np.float32, seed=20260928 + rank)
+    d_in = torch.from_numpy(a).to(dev)
+    conf = sz3_amd.Config(*shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.lorenzo, conf.lorenzo2, conf.regression = 1, 0, 0
+    conf.errorBoundMode = sz3_amd.EB_ABS
+    conf.absErrorBound = eb
+
+    dc = sz3_amd.DeviceCompressor(n, np.float32, device=local_rank)
+    cap = dc.payload_bound(n)
+    d_payload = torch.empty(cap, dtype=torch.uint8, device=dev)
+    hist = torch.zeros(65536, dtype=torch.int64, device=dev)  # caller-owned histogram so RCCL can reduce it in place
+    dc.set_histogram(hist.data_ptr())
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        dc.stage1(conf, d_in.data_ptr(), stream)
+        if world > 1:
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+        dc.stage2(d_payload.data_ptr(), cap, stream)
+        return dc.finish(stream)
+
+    for _ in range(args.warmup):
+        psize = step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        psize = step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+        ps = torch.tensor([psize], dtype=torch.int64, device=dev)
+        dist.all_reduce(ps, op=dist.ReduceOp.SUM)
+        total_payload = int(ps.item())
+    else:
+        total_payload = psize
+    barrier()
+
+    raw_bytes = n * 4
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * raw_bytes / (elapsed / args.steps) / 1e9
+    ratio = world * raw_bytes / float(total_payload)
+
+    # ---- per-stage kernel time, measured with HIP events on the launch stream (outside the timed loop) ----
+    dc.set_profiling(True)
+    acc = {}
+    reps = 10
+    for _ in range(reps):
+        step()
+        for k, v in dc.stage_times().items():
+            acc[k] = acc.get(k, 0.0) + v / reps
+    dc.set_profiling(False)
+    stats = dc.stats()
+
+    # ---- correctness gate (outside the timed region): decode on the GPU, strict bound in float64 ----
+    d_out = torch.empty_like(d_in)
+    dc.decompress(d_payload.data_ptr(), psize, d_out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    max_err = float((d_out.double() - d_in.double()).abs().max().item())
+
+    out = None
+    if rank == 0:
+        k1_ms = acc.get("lorenzo_quant_hist", float("nan"))
+        kernels_ms = sum(acc.get(k, 0.0) for k in ("lorenzo_quant_hist", "codebook", "encode", "assemble"))
+        # algorithmic bytes of the path per element: read sizeof(T) + write sizeof(T)/ratio; the
+        # dominant kernel (K1 lorenzo_quant_hist) is priced against the whole path's compulsory traffic.
+        algo_bytes = raw_bytes * (1.0 + 1.0 / (raw_bytes / float(psize)))
+        achieved = algo_bytes / (k1_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("lorenzo_quant_hist_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "compression throughput GB/s + ratio at fixed abs errBound, 512^3 f32",
+            "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: 3D float32 %dx%dx%d synthetic field per GPU, Lorenzo predictor, abs errBound=%g, "
+                                   "device-resident in -> device-resident Huffman payload" % (S, S, S, eb),
+                       "parallelism": "slab%d" % world, "algo": "HIP_LORENZO(16)", "eb": eb},
+            "ratio": round(ratio, 4), "max_abs_err": max_err, "err_bound_ok": bool(max_err <= eb),
+            "payload_bytes_rank0": int(psize),
+            "outliers": {"value": stats["n_value_outliers"], "delta": stats["n_delta_outliers"]},
+            "stage_ms": {k: round(v, 4) for k, v in acc.items()},
+            "kernels_ms": round(kernels_ms, 4),
+            "frac_read_peak_all_kernels": round(raw_bytes / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": {"bound": "hbm", "kernel": "k_lorenzo_quant (stage lorenzo_quant_hist)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(algo_bytes), "kernel_ms": round(k1_ms, 4)},
+        }
+
+    # ---- host end-to-end (PCIe + zstd inclusive; informational) ----
+    if rank == 0 and world == 1 and not args.no_host_e2e:
+        t0 = time.perf_counter()
+        blob, hratio = sz3_amd.compress(a, conf)
+        t1 = time.perf_counter()
+        dec, _ = sz3_amd.decompress(blob, np.float32, shape)
+        t2 = time.perf_counter()
+        out["host_e2e"] = {"compress_gbps": round(raw_bytes / (t1 - t0) / 1e9, 3), "ratio": round(hratio, 4),
+                           "decompress_gbps": round(raw_bytes / (t2 - t1) / 1e9, 3),
+                           "max_abs_err": float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))),
+                           "note": "host buffer in -> host SZ3 container out: H2D + kernels + D2H + zstd(threads)"}
+
+    # ---- CPU baseline on this box's host cores (rank 0, N=1 only; checker code, never the product) ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle_binding import have_ref, make_config, oracle_compress, ref_compress
+        oconf = make_config(shape, abs_eb=eb, lorenzo=True, regression=False)
+        # bounded sample: the full volume is ~8 s of single-thread reference work at 512^3; cap at 512^3
+        if have_ref():
+            blob, sec = ref_compress(a, oconf, timing=True)
+            kind = "reference"
+        else:
+            t0 = time.perf_counter()
+            blob = oracle_compress(a, oconf)
+            sec = time.perf_counter() - t0
+            kind = "port"
+        out["cpu_baseline"] = {"value": round(raw_bytes / sec / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
+                               "sample": "whole %dx%dx%d volume, SZ_compress<float> ALGO_LORENZO_REG (Lorenzo only) "
+                                         "abs 1e-3, single thread, %.2f s" % (S, S, S, sec),
+                               "ratio": round(raw_bytes / float(len(blob)), 4),
+                               "host_cpus": os.cpu_count()}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -115,6 +115,9 @@ int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf, const voi
  * all-reduces (sum) between stage1 and stage2 */
 void *sz3hip_histogram_ptr(sz3hip_ctx *ctx);
 size_t sz3hip_histogram_len(const sz3hip_ctx *ctx);
+/* let the caller own the histogram buffer (uint64_t[sz3hip_histogram_len()] in device memory), e.g. a tensor that its
+ * communication library can all-reduce in place; NULL restores the internal buffer */
+int sz3hip_ctx_set_histogram(sz3hip_ctx *ctx, void *d_hist);
 /* stage 2: canonical codebook from the histogram (K5), chunked Huffman bit-pack (K6), payload assembly into
  * d_payload (device, capacity cap bytes). Asynchronous on `stream`. */
 int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t cap, void *stream);
@@ -138,6 +141,8 @@ void sz3hip_set_profiling(sz3hip_ctx *ctx, int on);
 int sz3hip_get_stage_times(sz3hip_ctx *ctx, const char **names, float *ms, int max);
 /* test hooks: copy internal device arrays to host (quantisation codes as uint16, histogram as uint64) */
 int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, uint64_t n);
+/* test hook: non-zero routes every shape through the generic (any-shape) stage-1 kernel instead of the tuned one */
+void sz3hip_debug_force_generic(int on);
 
 #ifdef __cplusplus
 }

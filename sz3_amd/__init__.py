@@ -91,6 +91,8 @@ def lib():
     L.sz3hip_histogram_ptr.argtypes = [C.c_void_p]
     L.sz3hip_histogram_len.restype = C.c_size_t
     L.sz3hip_histogram_len.argtypes = [C.c_void_p]
+    L.sz3hip_ctx_set_histogram.restype = C.c_int
+    L.sz3hip_ctx_set_histogram.argtypes = [C.c_void_p, C.c_void_p]
     L.sz3hip_compress_stage2.restype = C.c_int
     L.sz3hip_compress_stage2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.sz3hip_compress_finish.restype = C.c_int
@@ -106,6 +108,7 @@ def lib():
     L.sz3hip_get_stage_times.argtypes = [C.c_void_p, P(C.c_char_p), P(C.c_float), C.c_int]
     L.sz3hip_debug_copy_codes.restype = C.c_int
     L.sz3hip_debug_copy_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.sz3hip_debug_force_generic.argtypes = [C.c_int]
     L.SZ_compress_args.restype = C.c_void_p
     L.SZ_compress_args.argtypes = [C.c_int, C.c_void_p, P(C.c_size_t), C.c_int, C.c_double, C.c_double, C.c_double,
                                    C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
@@ -262,6 +265,9 @@ class DeviceCompressor:
 
     def histogram_ptr(self):
         return int(lib().sz3hip_histogram_ptr(self._h)), int(lib().sz3hip_histogram_len(self._h))
+
+    def set_histogram(self, d_hist):
+        _check(lib().sz3hip_ctx_set_histogram(self._h, d_hist))
 
     def stage2(self, d_payload, cap, stream=0):
         _check(lib().sz3hip_compress_stage2(self._h, d_payload, int(cap), stream))

@@ -361,8 +361,10 @@ struct sz3hip_ctx {
     uint64_t max_n, out_cap, max_chunks;
     // device buffers
     uint16_t *d_codes;
-    uint64_t *d_hist;
+    uint64_t *d_hist;      // histogram in use (internal or caller-owned)
+    uint64_t *d_hist_own;  // internal allocation
     uint64_t *d_counters;  // [0]=n_vout [1]=n_dout [2]=total_words
+    uint32_t *d_hist_partial;
     uint64_t *d_vout_idx, *d_dout_idx;
     void *d_vout_val, *d_dout_val;
     uint32_t *d_enc;
@@ -390,7 +392,7 @@ struct sz3hip_ctx {
 
 static void ctx_free(sz3hip_ctx *c) {
     if (!c) return;
-    void *bufs[] = {c->d_codes, c->d_hist, c->d_counters, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
+    void *bufs[] = {c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_counters, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
                     c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_info,
                     c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax};
     for (void *b : bufs)
@@ -430,8 +432,10 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
         }
     };
     alloc((void **)&c->d_codes, (max_elems + 64) * 2);
-    alloc((void **)&c->d_hist, SZH_HIST_BINS * 8);
+    alloc((void **)&c->d_hist_own, SZH_HIST_BINS * 8);
+    c->d_hist = c->d_hist_own;
     alloc((void **)&c->d_counters, 64);
+    alloc((void **)&c->d_hist_partial, (size_t)SZK_K1_GRID * 1024 * 4);
     alloc((void **)&c->d_vout_idx, c->out_cap * 8);
     alloc((void **)&c->d_dout_idx, c->out_cap * 8);
     alloc(&c->d_vout_val, c->out_cap * 8);
@@ -474,6 +478,10 @@ static size_t payload_bound_n(uint64_t n, uint64_t out_cap) {
 extern "C" size_t sz3hip_payload_bound(const sz3hip_ctx *ctx, uint64_t n) { return payload_bound_n(n, ctx->out_cap); }
 extern "C" void *sz3hip_histogram_ptr(sz3hip_ctx *ctx) { return ctx->d_hist; }
 extern "C" size_t sz3hip_histogram_len(const sz3hip_ctx *) { return SZH_HIST_BINS; }
+extern "C" int sz3hip_ctx_set_histogram(sz3hip_ctx *ctx, void *d_hist) {
+    ctx->d_hist = d_hist ? (uint64_t *)d_hist : ctx->d_hist_own;
+    return 0;
+}
 extern "C" void sz3hip_set_profiling(sz3hip_ctx *ctx, int on) {
     ctx->profiling = on != 0;
     if (on)
@@ -538,12 +546,11 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     memset(&p, 0, sizeof(p));
     for (int i = 0; i < 4; i++) p.d[i] = 1;
     for (int i = 0; i < conf->N; i++) p.d[4 - conf->N + i] = conf->dims[i];
-    p.two_eb = 2.0 * eb;
-    p.recip = 1.0 / p.two_eb;
-    p.eb = eb;
+    p.lat = szk_make_lattice(eb);
     p.radius = (uint32_t)radius;
     p.out_cap = ctx->out_cap;
     p.hist = ctx->d_hist;
+    p.hist_partial = ctx->d_hist_partial;
     p.n_vout = ctx->d_counters + 0;
     p.n_dout = ctx->d_counters + 1;
     p.vout_idx = ctx->d_vout_idx;
@@ -672,6 +679,8 @@ extern "C" int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, ui
     HIPCHK(hipMemcpy(host_codes, ctx->d_codes, n * 2, hipMemcpyDeviceToHost));
     return 0;
 }
+
+extern "C" void sz3hip_debug_force_generic(int on) { szk_force_generic = on; }
 
 extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, size_t payload_size, void *d_out,
                                         void *stream) {

@@ -5,13 +5,33 @@
 #include <stdint.h>
 #include "sz3hip_format.h"
 
+// lattice constants derived from the absolute error bound (identical on the encode and the decode side)
+struct szk_lattice {
+    double recip, two_eb, eb;        // f64 data: 1/(2eb), 2eb, eb
+    float recip_f, two_eb_f, eb_lo_f;  // f32 data: (float)(1/(2eb)), (float)(2eb), largest float <= eb
+};
+static inline szk_lattice szk_make_lattice(double eb) {
+    szk_lattice l;
+    l.eb = eb;
+    l.two_eb = 2.0 * eb;
+    l.recip = 1.0 / l.two_eb;
+    l.recip_f = (float)l.recip;
+    l.two_eb_f = (float)l.two_eb;
+    float e = (float)eb;
+    if ((double)e > eb) e = __builtin_nextafterf(e, 0.0f);
+    l.eb_lo_f = e;
+    return l;
+}
+
+#define SZK_K1_GRID 1024u  // persistent stage-1 grid: 4 workgroups per CU on 256 CUs
+
 struct szk_k1_params {
     uint64_t d[4];  // extents slowest first, left-padded with 1: [w][z][y][x]
-    double recip;   // 1 / (2 eb)
-    double two_eb, eb;
+    szk_lattice lat;
     uint32_t radius;
     uint64_t out_cap;  // capacity of each outlier list
     uint64_t *hist;    // [SZH_HIST_BINS]
+    uint32_t *hist_partial;  // [SZK_K1_GRID][1024] private histogram rows of the persistent stage-1 workgroups
     uint64_t *n_vout, *n_dout;
     uint64_t *vout_idx, *dout_idx;
     void *vout_val, *dout_val;
@@ -72,7 +92,7 @@ int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, const 
 int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStream_t s);
 int szk_launch_layout_pre(const szk_layout_params *p, hipStream_t s);
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, int radius, uint16_t *chunk_words,
-                      uint64_t *chunk_off, uint64_t *total_words, const szk_state *state, uint8_t *payload, hipStream_t s);
+                      uint64_t *lb_state /*[n_chunks/4 + 2]*/, uint64_t *total_words, const szk_state *state, uint8_t *payload, hipStream_t s);
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, hipStream_t s);
 int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t *codes, uint64_t *chunk_off,
@@ -80,5 +100,6 @@ int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t 
 int szk_launch_reconstruct(const uint8_t *payload, const szh_header *h, const szh_offsets *o, const uint16_t *codes,
                            void *d_out, void *d_segtot, hipStream_t s);
 void szk_host_offsets(const szh_header *h, szh_offsets *o);
+extern int szk_force_generic;
 
 #endif

@@ -53,38 +53,53 @@ template <typename T> struct QTraits;
 template <> struct QTraits<float> {
     using Q = int32_t;
     using UQ = uint32_t;
-    static constexpr double QMAX = 1073741824.0;  // 2^30
 };
 template <> struct QTraits<double> {
     using Q = int64_t;
     using UQ = uint64_t;
-    static constexpr double QMAX = 4611686018427387904.0;  // 2^62
 };
 
-// prequantisation: q = rint(x * 1/(2eb)) in double; reconstruct (T)(q * 2eb); keep the raw value when the
-// reconstruction misses the bound (same acceptance test as quantizer/LinearQuantizer.hpp:57-60: |dec-data| in T,
-// compared with eb in double). Non-finite or huge values take q = 0 so that neighbours still predict sanely.
-template <typename T>
-__device__ __forceinline__ typename QTraits<T>::Q prequant(T x, double recip, double two_eb, double eb, bool &bad) {
-    using Q = typename QTraits<T>::Q;
-    double s = (double)x * recip;
-    Q q = 0;
-    bad = true;
-    if (fabs(s) < QTraits<T>::QMAX) {  // false for NaN
-        double r = rint(s);
-        q = (Q)r;
-        T dec = (T)(r * two_eb);
-        T diff = dec - x;
-        diff = diff < 0 ? -diff : diff;
-        bad = !((double)diff <= eb);
+// The quantisation lattice.  q = rint(x / 2eb); the reconstruction x^ = q * 2eb is verified against the bound
+// (same acceptance test as quantizer/LinearQuantizer.hpp:57-60: |dec - data| evaluated in T, compared with eb) and
+// the raw value is kept losslessly when the check fails.  Non-finite or huge values take q = 0 so that neighbours
+// still predict sanely.  The arithmetic type is the data type: f32 data use f32 multiplies (one rounding each, no
+// FMA contraction: built with -ffp-contract=off), f64 data f64 — the decoder applies the identical expression, so
+// the bound that the encoder verified is the bound the user gets.
+template <typename T> struct Lattice;
+template <> struct Lattice<float> {
+    float recip, two_eb, eb_lo;  // (float)(1/(2eb)), (float)(2eb), largest float <= eb
+    __device__ __forceinline__ explicit Lattice(const szk_lattice &l) : recip(l.recip_f), two_eb(l.two_eb_f), eb_lo(l.eb_lo_f) {}
+    __device__ __forceinline__ int32_t quant(float x, bool &bad) const {
+        float s = x * recip;
+        int32_t q = 0;
+        bad = true;
+        if (fabsf(s) < 8388608.0f) {  // 2^23: rintf(s) is an exact integer; false for NaN
+            float r = rintf(s);
+            q = (int32_t)r;
+            float dec = r * two_eb;
+            bad = !(fabsf(dec - x) <= eb_lo);
+        }
+        return q;
     }
-    return q;
-}
-
-template <typename T>
-__device__ __forceinline__ T dequant(typename QTraits<T>::Q q, double two_eb) {
-    return (T)((double)q * two_eb);
-}
+    __device__ __forceinline__ float dequant(int32_t q) const { return (float)q * two_eb; }
+};
+template <> struct Lattice<double> {
+    double recip, two_eb, eb;
+    __device__ __forceinline__ explicit Lattice(const szk_lattice &l) : recip(l.recip), two_eb(l.two_eb), eb(l.eb) {}
+    __device__ __forceinline__ int64_t quant(double x, bool &bad) const {
+        double s = x * recip;
+        int64_t q = 0;
+        bad = true;
+        if (fabs(s) < 4503599627370496.0) {  // 2^52
+            double r = rint(s);
+            q = (int64_t)r;
+            double dec = r * two_eb;
+            bad = !(fabs(dec - x) <= eb);
+        }
+        return q;
+    }
+    __device__ __forceinline__ double dequant(int64_t q) const { return (double)q * two_eb; }
+};
 
 // ------------------------------------------------------------------------------------------------------------
 // K0: min / max
@@ -171,6 +186,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant(const T *__restrict__ in,
     const int64_t x0 = (int64_t)(tx * TX), y0 = (int64_t)(ty * TY), z0 = (int64_t)(tz * TZ);
 
     for (int i = threadIdx.x; i < HIST_COPIES * HIST_WIN; i += 256) lh[i] = 0;
+    const Lattice<T> lat(p.lat);
 
     // ---- load + prequantise (tile + low-side halo) ----
     for (int c = threadIdx.x; c < CELLS; c += 256) {
@@ -186,7 +202,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant(const T *__restrict__ in,
             uint64_t gi = (((uint64_t)gw * d2 + (uint64_t)gz) * d1 + (uint64_t)gy) * d0 + (uint64_t)gx;
             T x = in[gi];
             bool bad;
-            q = prequant<T>(x, p.recip, p.two_eb, p.eb, bad);
+            q = lat.quant(x, bad);
             bool owned = (lx >= 1) && (ly >= HY) && (lz >= HZ) && (lw == 0);
             if (bad && owned) {
                 unsigned long long pos = atomicAdd((unsigned long long *)p.n_vout, 1ull);
@@ -262,6 +278,233 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant(const T *__restrict__ in,
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// K1 fast path (N = 3 or 4, x extent a multiple of 4, extents < 2^31): 64 x 8 x TZ tile; every thread owns TZ/2
+// "row quads" (4 consecutive x at one (y,z)) that it loads with one 16-byte (f32) / two 16-byte (f64) global loads,
+// prequantises, parks in LDS (row pitch 68: halo column at index 3, tile at 4..67 so that quads stay 16-byte
+// aligned) and keeps in registers for the stencil; the three neighbour rows come back from LDS as one b128 + one
+// b32 read each.  Codes leave as one 8-byte store per quad.  Index math is 32-bit inside the tile.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T> struct V4 { T v[4]; };
+__device__ __forceinline__ V4<float> ldg4(const float *p) {
+    float4 t = *reinterpret_cast<const float4 *>(p);
+    return {{t.x, t.y, t.z, t.w}};
+}
+__device__ __forceinline__ V4<double> ldg4(const double *p) {
+    double2 a = reinterpret_cast<const double2 *>(p)[0], b = reinterpret_cast<const double2 *>(p)[1];
+    return {{a.x, a.y, b.x, b.y}};
+}
+__device__ __forceinline__ void lds_st4(int32_t *p, const int32_t (&v)[4]) {
+    *reinterpret_cast<int4 *>(p) = make_int4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void lds_st4(int64_t *p, const int64_t (&v)[4]) {
+    reinterpret_cast<longlong2 *>(p)[0] = make_longlong2(v[0], v[1]);
+    reinterpret_cast<longlong2 *>(p)[1] = make_longlong2(v[2], v[3]);
+}
+__device__ __forceinline__ void lds_ld4(const int32_t *p, int32_t (&v)[4]) {
+    int4 t = *reinterpret_cast<const int4 *>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void lds_ld4(const int64_t *p, int64_t (&v)[4]) {
+    longlong2 a = reinterpret_cast<const longlong2 *>(p)[0], b = reinterpret_cast<const longlong2 *>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+
+// Persistent: the grid is a few workgroups per CU, each walks tiles blockIdx.x, +gridDim.x, ... so that the LDS
+// histogram is cleared and flushed once per workgroup; the flush goes to a private row of `hist_partial`
+// (no same-address global atomics: 32768 tiles hammering one 64-bit counter serialise at ~90 atomics/us) and
+// k_hist_reduce folds the rows into the 65536-bin histogram.
+template <typename T, int NDIM, int TZ>
+__global__ __launch_bounds__(256) void k_lorenzo_quant_v4(const T *__restrict__ in, uint16_t *__restrict__ codes,
+                                                          szk_k1_params p, uint32_t ntiles) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    constexpr int TX = 64, TY = 8, NW = NDIM == 4 ? 2 : 1;
+    constexpr int PX = TX + 4, PY = TY + 1, PZ = TZ + 1, SLAB = PZ * PY * PX;
+    constexpr int RPT = TZ / 2;  // row quads per thread
+    __shared__ __attribute__((aligned(16))) Q lq[NW * SLAB];
+    __shared__ uint32_t lh[HIST_COPIES * HIST_WIN + WAVE];  // + one private dummy bin per lane for the centre code
+
+    const uint32_t d0 = (uint32_t)p.d[3], d1 = (uint32_t)p.d[2], d2 = (uint32_t)p.d[1];
+    const uint32_t ntx = (d0 + TX - 1) / TX, nty = (d1 + TY - 1) / TY, ntz = (d2 + TZ - 1) / TZ;
+    const uint32_t plane = d1 * d0;  // < 2^31 / TZ guaranteed by the launcher
+    const uint64_t vol = (uint64_t)plane * d2;
+    const int t = threadIdx.x;
+    const int lx4 = t & 15, ly = (t >> 4) & 7, lzb = t >> 7;
+    const Lattice<T> lat(p.lat);
+    const int radius = (int)p.radius;
+    const int win_lo = radius - HIST_WIN / 2;
+    uint32_t *myh = lh + (t & (HIST_COPIES - 1)) * HIST_WIN;
+    const uint32_t dummy_bin = (uint32_t)(HIST_COPIES * HIST_WIN + lane_id()) - (uint32_t)((t & (HIST_COPIES - 1)) * HIST_WIN);
+    uint32_t center_count = 0;
+
+    for (int i = t; i < HIST_COPIES * HIST_WIN + WAVE; i += 256) lh[i] = 0;
+
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t b = tile;
+        const uint32_t tx = b % ntx;
+        b /= ntx;
+        const uint32_t ty = b % nty;
+        b /= nty;
+        const uint32_t tz = b % ntz;
+        const uint32_t w = b / ntz;
+        const int x0 = (int)(tx * TX), y0 = (int)(ty * TY), z0 = (int)(tz * TZ);
+        __syncthreads();  // previous tile's stencil reads are done before the slab is overwritten
+
+        Q qreg[RPT][4];
+        uint32_t badmask = 0;
+#pragma unroll
+        for (int lw = 0; lw < NW; lw++) {
+            const bool wok = (int)w - lw >= 0;
+            // tile origin (z0, y0, x0) of hyper-plane w - lw; offsets inside the tile are 32-bit
+            const T *src = in + (uint64_t)(wok ? w - lw : 0) * vol + ((uint64_t)z0 * plane + (uint64_t)y0 * d0 + x0);
+            Q *slab = lq + lw * SLAB;
+#pragma unroll
+            for (int k = 0; k < RPT; k++) {
+                const int lz = lzb + 2 * k;
+                const uint32_t gz = z0 + lz, gy = y0 + ly, gx = x0 + 4 * lx4;
+                Q q[4] = {0, 0, 0, 0};
+                if (wok && gz < d2 && gy < d1 && gx < d0) {
+                    V4<T> v = ldg4(src + ((uint32_t)lz * plane + (uint32_t)ly * d0 + 4u * lx4));
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        bool bad;
+                        q[i] = lat.quant(v.v[i], bad);
+                        if (lw == 0) badmask |= (uint32_t)bad << (4 * k + i);
+                    }
+                }
+                lds_st4(slab + ((lz + 1) * PY + (ly + 1)) * PX + 4 + 4 * lx4, q);
+                if (lw == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) qreg[k][i] = q[i];
+                }
+            }
+            // halo rows: y = y0-1 for lz = -1..TZ-1 (PZ rows), then z = z0-1 for ly = 0..TY-1 (TY rows)
+            for (int i = t; i < (PZ + TY) * 16; i += 256) {
+                const int r = i >> 4, xq = i & 15;
+                const int lz = r < PZ ? r - 1 : -1, hy = r < PZ ? -1 : r - PZ;
+                const int gz = z0 + lz, gy = y0 + hy;
+                const uint32_t gx = x0 + 4 * xq;
+                Q q[4] = {0, 0, 0, 0};
+                if (wok && gz >= 0 && gy >= 0 && (uint32_t)gz < d2 && (uint32_t)gy < d1 && gx < d0) {
+                    V4<T> v = ldg4(src + ((int64_t)lz * (int64_t)plane + (int64_t)hy * (int64_t)d0 + 4 * xq));
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        bool bad;
+                        q[j] = lat.quant(v.v[j], bad);
+                    }
+                }
+                lds_st4(slab + ((lz + 1) * PY + (hy + 1)) * PX + 4 + 4 * xq, q);
+            }
+            // halo column x = x0-1 of all PZ*PY rows
+            for (int i = t; i < PZ * PY; i += 256) {
+                const int lz = i / PY - 1, hy = i % PY - 1;
+                const int gz = z0 + lz, gy = y0 + hy;
+                Q q = 0;
+                if (wok && x0 > 0 && gz >= 0 && gy >= 0 && (uint32_t)gz < d2 && (uint32_t)gy < d1) {
+                    bool bad;
+                    q = lat.quant(src[(int64_t)lz * (int64_t)plane + (int64_t)hy * (int64_t)d0 - 1], bad);
+                }
+                slab[((lz + 1) * PY + (hy + 1)) * PX + 3] = q;
+            }
+        }
+        __syncthreads();
+
+        uint16_t *ctile = codes + (uint64_t)w * vol + ((uint64_t)z0 * plane + (uint64_t)y0 * d0 + x0);
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+            const int lz = lzb + 2 * k;
+            const uint32_t gz = z0 + lz, gy = y0 + ly, gx = x0 + 4 * lx4;
+            if (!(gz < d2 && gy < d1 && gx < d0)) continue;
+            const int c = ((lz + 1) * PY + (ly + 1)) * PX + 4 + 4 * lx4;
+            UQ delta[4];
+#pragma unroll
+            for (int lw = 0; lw < NW; lw++) {
+                const Q *L = lq + lw * SLAB;
+                Q cur[4], ra[4], rb[4], rd[4];
+                if (lw == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) cur[i] = qreg[k][i];
+                } else {
+                    lds_ld4(L + c, cur);
+                }
+                lds_ld4(L + c - PX, ra);
+                lds_ld4(L + c - PY * PX, rb);
+                lds_ld4(L + c - PY * PX - PX, rd);
+                UQ pc = (UQ)L[c - 1], pa = (UQ)L[c - PX - 1], pb = (UQ)L[c - PY * PX - 1], pd = (UQ)L[c - PY * PX - PX - 1];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    UQ s = ((UQ)cur[i] - pc) - ((UQ)ra[i] - pa) - ((UQ)rb[i] - pb) + ((UQ)rd[i] - pd);
+                    pc = (UQ)cur[i];
+                    pa = (UQ)ra[i];
+                    pb = (UQ)rb[i];
+                    pd = (UQ)rd[i];
+                    delta[i] = lw == 0 ? s : (UQ)(delta[i] - s);
+                }
+            }
+            // branch-free hot path: code, histogram bin (centre code -> private dummy bin + register count)
+            uint32_t code[4];
+            bool slow = ((badmask >> (4 * k)) & 15u) != 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const UQ shifted = delta[i] + (UQ)radius;               // in (0, 2r) when |delta| < r
+                const bool inr = (UQ)(shifted - 1) < (UQ)(2 * radius - 1);
+                code[i] = inr ? (uint32_t)shifted : 0u;
+                const uint32_t bin = code[i] - (uint32_t)win_lo;
+                const bool inwin = bin < (uint32_t)HIST_WIN;
+                const bool ctr = code[i] == (uint32_t)radius;
+                center_count += ctr;
+                slow |= !inr | !inwin;
+                atomicAdd(&myh[(ctr | !inwin) ? dummy_bin : bin], 1u);
+            }
+            const uint32_t off = (uint32_t)lz * plane + (uint32_t)ly * d0 + 4u * lx4;
+            uint2 pk;
+            pk.x = code[0] | (code[1] << 16);
+            pk.y = code[2] | (code[3] << 16);
+            *reinterpret_cast<uint2 *>(ctile + off) = pk;
+            if (slow) {  // rare: delta outliers, value outliers, codes outside the LDS histogram window
+                const uint64_t gi = (uint64_t)w * vol + (uint64_t)gz * plane + (uint64_t)gy * d0 + gx;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (code[i] == 0) {
+                        unsigned long long pos = atomicAdd((unsigned long long *)p.n_dout, 1ull);
+                        if (pos < p.out_cap) {
+                            p.dout_idx[pos] = gi + i;
+                            ((Q *)p.dout_val)[pos] = (Q)delta[i];
+                        }
+                    }
+                    if ((badmask >> (4 * k + i)) & 1u) {
+                        unsigned long long pos = atomicAdd((unsigned long long *)p.n_vout, 1ull);
+                        if (pos < p.out_cap) {
+                            p.vout_idx[pos] = gi + i;
+                            ((T *)p.vout_val)[pos] = in[gi + i];
+                        }
+                    }
+                    if (code[i] - (uint32_t)win_lo >= (uint32_t)HIST_WIN)
+                        atomicAdd((unsigned long long *)&p.hist[code[i]], 1ull);
+                }
+            }
+        }
+    }
+    // centre counts: one LDS add per thread, then the private row of hist_partial
+    atomicAdd(&lh[radius - win_lo], center_count);
+    __syncthreads();
+    uint32_t *row = p.hist_partial + (uint64_t)blockIdx.x * HIST_WIN;
+    for (int bnn = t; bnn < HIST_WIN; bnn += 256)
+        row[bnn] = lh[bnn] + lh[HIST_WIN + bnn] + lh[2 * HIST_WIN + bnn] + lh[3 * HIST_WIN + bnn];
+}
+
+// folds the per-workgroup histogram rows into hist[win_lo + bin] (bins inside the window are touched by nobody else)
+__global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict__ partial, uint32_t nrows, int win_lo,
+                                                     uint64_t *__restrict__ hist) {
+    const int bin = blockIdx.x * 256 + threadIdx.x;
+    if (bin >= HIST_WIN) return;
+    uint64_t s = 0;
+    for (uint32_t r = 0; r < nrows; r++) s += partial[(uint64_t)r * HIST_WIN + bin];
+    const int sym = win_lo + bin;
+    if (s && sym >= 0 && sym < (int)SZH_HIST_BINS) hist[sym] += s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // K5: canonical length-limited Huffman codebook, one 1024-thread workgroup.
 // ------------------------------------------------------------------------------------------------------------
 #define CB_THREADS 1024
@@ -286,58 +529,87 @@ __device__ void cb_bitonic_sort(uint64_t *keys, uint32_t npow2) {  // ascending;
     }
 }
 
-// keys[] (global scratch, >= 65536 + padding), work arrays in global scratch; small alphabets are staged in LDS.
+// Two-queue Huffman merge over leaves sorted by ascending frequency (keys = freq << 16 | sym). Serial (thread 0);
+// the two queue heads are kept in registers so that every merge costs two dependent memory reads.
+__device__ void cb_merge(const uint64_t *keys, uint64_t *ifreq, uint16_t *pleaf, uint16_t *pint, uint32_t m) {
+    const uint64_t INF = ~0ull;
+    uint32_t i = 0, j = 0;
+    uint64_t lf = keys[0] >> 16, nf = INF;
+    for (uint32_t k = 0; k + 1 < m; k++) {
+        uint64_t f = 0;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            if (lf <= nf) {  // ties prefer the leaf; INF marks an exhausted / empty queue
+                f += lf;
+                pleaf[i++] = (uint16_t)k;
+                lf = i < m ? keys[i] >> 16 : INF;
+            } else {
+                f += nf;
+                pint[j++] = (uint16_t)k;
+                nf = j < k ? ifreq[j] : INF;
+            }
+        }
+        ifreq[k] = f;
+        if (j == k) nf = f;  // the node just created becomes the head of the internal queue
+    }
+}
+
+// Kraft repair after clamping code lengths to SZH_MAX_LEN (serial, rare): lengthen the longest codes that are still
+// shorter than the limit until sum 2^-len <= 1.
+__device__ void cb_kraft_repair(uint16_t *len_sorted, uint32_t m, uint32_t *cnt) {
+    uint64_t kraft = 0;
+    for (uint32_t l = 1; l <= SZH_MAX_LEN; l++) kraft += (uint64_t)cnt[l] << (SZH_MAX_LEN - l);
+    const uint64_t budget = 1ull << SZH_MAX_LEN;
+    while (kraft > budget) {
+        int best = -1;
+        uint32_t bestl = 0;
+        for (uint32_t q = 0; q < m; q++) {  // leaves are sorted by ascending frequency: first hit = least frequent
+            uint32_t l = len_sorted[q];
+            if (l < SZH_MAX_LEN && l > bestl) {
+                bestl = l;
+                best = (int)q;
+            }
+        }
+        if (best < 0) break;
+        len_sorted[best] = (uint16_t)(bestl + 1);
+        cnt[bestl]--;
+        cnt[bestl + 1]++;
+        kraft -= 1ull << (SZH_MAX_LEN - bestl - 1);
+    }
+}
+
 __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restrict__ hist, szk_cb_params p) {
     __shared__ uint64_t s_keys[CB_LDS_SYMS];
     __shared__ uint64_t s_ifreq[CB_LDS_SYMS];
-    __shared__ uint16_t s_pleaf[CB_LDS_SYMS], s_pint[CB_LDS_SYMS];
-    __shared__ uint16_t s_depth[CB_LDS_SYMS];
-    __shared__ uint32_t s_scan[CB_THREADS];
-    __shared__ uint32_t s_m, s_symmin, s_symmax;
-    __shared__ uint32_t s_nextcode[SZH_MAX_LEN + 2], s_cnt[SZH_MAX_LEN + 2];
+    __shared__ uint16_t s_pleaf[CB_LDS_SYMS], s_pint[CB_LDS_SYMS], s_aux[CB_LDS_SYMS], s_syms[CB_LDS_SYMS];
+    __shared__ uint32_t s_wtot[CB_THREADS / WAVE];
+    __shared__ uint32_t s_lo, s_hi, s_over;
+    __shared__ uint32_t s_first[SZH_MAX_LEN + 2], s_cnt[SZH_MAX_LEN + 2];
+    const uint32_t t = threadIdx.x;
 
-    const uint32_t nbins = SZH_HIST_BINS;
-    const uint32_t per = nbins / CB_THREADS;  // 64 consecutive bins per thread
-    // clear encode table and lens
-    for (uint32_t i = threadIdx.x; i < nbins; i += CB_THREADS) {
-        p.enc[i] = 0;
-        p.lens[i] = 0;
+    // 0. range of the non-empty bins (coalesced sweep over the 65536 counters)
+    if (t == 0) {
+        s_lo = 0xFFFFFFFFu;
+        s_hi = 0;
+        s_over = 0;
     }
-    // 1. compaction of non-zero bins, in symbol order
-    uint32_t cnt = 0;
-    for (uint32_t i = 0; i < per; i++) cnt += hist[threadIdx.x * per + i] != 0;
-    s_scan[threadIdx.x] = cnt;
+    if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (uint32_t i = 0; i < CB_THREADS; i++) {
-            uint32_t c = s_scan[i];
-            s_scan[i] = run;
-            run += c;
-        }
-        s_m = run;
-        s_symmin = 0xFFFFFFFFu;
-        s_symmax = 0;
-    }
-    __syncthreads();
-    const uint32_t m = s_m;
     {
-        uint32_t pos = s_scan[threadIdx.x];
-        for (uint32_t i = 0; i < per; i++) {
-            uint32_t sym = threadIdx.x * per + i;
-            uint64_t f = hist[sym];
-            if (f) {
-                p.keys[pos] = (f << 16) | sym;  // freq < 2^48
-                p.syms[pos] = (uint16_t)sym;    // symbol order copy
-                pos++;
-                atomicMin(&s_symmin, sym);
-                atomicMax(&s_symmax, sym);
+        uint32_t lo = 0xFFFFFFFFu, hi = 0;
+        for (uint32_t i = t; i < SZH_HIST_BINS; i += CB_THREADS)
+            if (hist[i]) {
+                lo = lo < i ? lo : i;
+                hi = hi > i ? hi : i;
             }
+        if (lo != 0xFFFFFFFFu) {
+            atomicMin(&s_lo, lo);
+            atomicMax(&s_hi, hi);
         }
     }
     __syncthreads();
-    if (m == 0) {
-        if (threadIdx.x == 0) {
+    if (s_lo == 0xFFFFFFFFu) {
+        if (t == 0) {
             p.info->n_symbols = 0;
             p.info->max_len = 0;
             p.info->sym_min = 0;
@@ -345,113 +617,136 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
         }
         return;
     }
-    // 2. sort by (freq, sym)
-    uint32_t npow2 = 1;
-    while (npow2 < m) npow2 <<= 1;
+    const uint32_t lo = s_lo, range = s_hi - s_lo + 1;
+    const uint32_t per = (range + CB_THREADS - 1) / CB_THREADS;
+    for (uint32_t i = t; i < range; i += CB_THREADS) {  // only [lo, hi] is ever looked up / serialised
+        p.enc[lo + i] = 0;
+        p.lens[lo + i] = 0;
+    }
+    // 1. compaction of the non-zero bins in symbol order
+    uint32_t cnt = 0;
+    for (uint32_t i = t * per; i < range && i < (t + 1) * per; i++) cnt += hist[lo + i] != 0;
+    uint32_t incl = wave_incl_scan(cnt);
+    if (lane_id() == WAVE - 1) s_wtot[t / WAVE] = incl;
+    __syncthreads();
+    uint32_t pos = incl - cnt, m = 0;
+    for (uint32_t wv = 0; wv < CB_THREADS / WAVE; wv++) {
+        if (wv < t / WAVE) pos += s_wtot[wv];
+        m += s_wtot[wv];
+    }
     const bool small = m <= CB_LDS_SYMS;
     uint64_t *keys = small ? s_keys : p.keys;
-    __threadfence_block();
-    if (small) {
-        for (uint32_t i = threadIdx.x; i < npow2; i += CB_THREADS) s_keys[i] = i < m ? p.keys[i] : ~0ull;
-    } else {
-        for (uint32_t i = m + threadIdx.x; i < npow2; i += CB_THREADS) p.keys[i] = ~0ull;
-    }
-    __syncthreads();
-    cb_bitonic_sort(keys, npow2);
-
-    // 3. two-queue Huffman merge (thread 0), lengths, limit, canonical codes
     uint64_t *ifreq = small ? s_ifreq : p.ifreq;
     uint16_t *pleaf = small ? s_pleaf : p.pleaf;
     uint16_t *pint = small ? s_pint : p.pint;
-    uint16_t *depth = small ? s_depth : p.depth;
-    if (threadIdx.x == 0) {
-        uint32_t max_len = 0;
-        if (m == 1) {
-            // single symbol: zero-length code, empty bit-stream (as encoder/HuffmanEncoder.hpp:233-237)
-            p.lens[(uint32_t)(keys[0] & 0xFFFF)] = 0;
-        } else {
-            uint32_t i = 0, j = 0, k = 0;  // leaf cursor, internal cursor, internal count
-            for (; k < m - 1; k++) {
-                uint64_t f = 0;
-                for (int t = 0; t < 2; t++) {
-                    bool take_leaf;
-                    if (i >= m) take_leaf = false;
-                    else if (j >= k) take_leaf = true;
-                    else take_leaf = (keys[i] >> 16) <= ifreq[j];
-                    if (take_leaf) {
-                        f += keys[i] >> 16;
-                        pleaf[i++] = (uint16_t)k;
-                    } else {
-                        f += ifreq[j];
-                        pint[j++] = (uint16_t)k;
-                    }
-                }
-                ifreq[k] = f;
+    uint16_t *aux = small ? s_aux : p.depth;
+    uint16_t *syms = small ? s_syms : p.syms;
+    for (uint32_t i = t * per; i < range && i < (t + 1) * per; i++) {
+        uint64_t f = hist[lo + i];
+        if (f) {
+            keys[pos] = (f << 16) | (lo + i);  // freq < 2^48
+            syms[pos] = (uint16_t)(lo + i);
+            pos++;
+        }
+    }
+    uint32_t npow2 = 1;
+    while (npow2 < m) npow2 <<= 1;
+    __syncthreads();
+    for (uint32_t i = m + t; i < npow2; i += CB_THREADS) keys[i] = ~0ull;
+    __syncthreads();
+    // 2. sort by (freq, sym)
+    cb_bitonic_sort(keys, npow2);
+
+    uint32_t max_len = 0;
+    if (m == 1) {
+        // single symbol: zero-length code, empty bit-stream (as encoder/HuffmanEncoder.hpp:233-237)
+    } else {
+        // 3. merge (serial) ...
+        if (t == 0) cb_merge(keys, ifreq, pleaf, pint, m);
+        __syncthreads();
+        // 4. ... depth of every internal node: distance to the root (node m-2) by pointer doubling
+        //    aux[q] = distance so far, pint[q] = current ancestor pointer
+        for (uint32_t q = t; q + 1 < m; q += CB_THREADS) {
+            if (q == m - 2) pint[q] = (uint16_t)q;
+            aux[q] = q == m - 2 ? 0 : 1;
+        }
+        __syncthreads();
+        for (uint32_t span = 1; span < m; span <<= 1) {
+            // every thread handles q = t, t + 1024, ... ; two-phase (read, barrier, write) per round
+            uint16_t nd[(65536 + CB_THREADS - 1) / CB_THREADS], nj[(65536 + CB_THREADS - 1) / CB_THREADS];
+            int c = 0;
+            for (uint32_t q = t; q + 1 < m; q += CB_THREADS, c++) {
+                uint16_t j = pint[q];
+                nd[c] = (uint16_t)(aux[q] + aux[j]);
+                nj[c] = pint[j];
             }
-            // depths: root = internal m-2
-            depth[m - 2] = 0;
-            for (int32_t q = (int32_t)m - 3; q >= 0; q--) depth[q] = (uint16_t)(depth[pint[q]] + 1);  // depth <= m-2 < 65536
-            for (uint32_t q = 0; q < SZH_MAX_LEN + 2; q++) s_cnt[q] = 0;
-            bool over = false;
-            for (uint32_t q = 0; q < m; q++) {
-                uint32_t l = (uint32_t)depth[pleaf[q]] + 1;
-                if (l > SZH_MAX_LEN) {
-                    l = SZH_MAX_LEN;
-                    over = true;
-                }
-                // reuse pleaf[] as the per-leaf length store (sorted position q)
-                pleaf[q] = (uint16_t)l;
-                s_cnt[l]++;
+            __syncthreads();
+            c = 0;
+            for (uint32_t q = t; q + 1 < m; q += CB_THREADS, c++) {
+                aux[q] = nd[c];
+                pint[q] = nj[c];
             }
-            if (over) {
-                // Kraft repair: sum 2^(MAX-len) must be <= 2^MAX.  Lengthen the longest codes shorter than MAX
-                // (cheapest in expected bits: leaves are sorted by ascending frequency).
-                uint64_t kraft = 0;
-                for (uint32_t l = 1; l <= SZH_MAX_LEN; l++) kraft += (uint64_t)s_cnt[l] << (SZH_MAX_LEN - l);
-                const uint64_t budget = 1ull << SZH_MAX_LEN;
-                while (kraft > budget) {
-                    // pick the least frequent leaf with len < MAX and the largest such len
-                    int best = -1;
-                    uint32_t bestl = 0;
-                    for (uint32_t q = 0; q < m; q++) {
-                        uint32_t l = pleaf[q];
-                        if (l < SZH_MAX_LEN && l > bestl) {
-                            bestl = l;
-                            best = (int)q;
-                        }
-                    }
-                    if (best < 0) break;
-                    pleaf[best] = (uint16_t)(bestl + 1);
-                    s_cnt[bestl]--;
-                    s_cnt[bestl + 1]++;
-                    kraft -= 1ull << (SZH_MAX_LEN - bestl - 1);
-                }
+            __syncthreads();
+        }
+        // 5. leaf lengths (sorted position q), clamp to SZH_MAX_LEN, per-length counts
+        for (uint32_t q = t; q < m; q += CB_THREADS) {
+            uint32_t l = (uint32_t)aux[pleaf[q]] + 1;
+            if (l > SZH_MAX_LEN) {
+                l = SZH_MAX_LEN;
+                s_over = 1;
             }
-            for (uint32_t q = 0; q < m; q++) {
-                uint32_t sym = (uint32_t)(keys[q] & 0xFFFF);
-                uint32_t l = pleaf[q];
-                p.lens[sym] = (uint8_t)l;
-                if (l > max_len) max_len = l;
-            }
-            // canonical first codes
+            pleaf[q] = (uint16_t)l;
+            atomicAdd(&s_cnt[l], 1u);
+        }
+        __syncthreads();
+        if (s_over) {
+            if (t == 0) cb_kraft_repair(pleaf, m, s_cnt);
+            __syncthreads();
+        }
+        // 6. canonical first code per length
+        if (t == 0) {
             uint32_t code = 0;
             for (uint32_t l = 1; l <= SZH_MAX_LEN; l++) {
                 code = (code + (l > 1 ? s_cnt[l - 1] : 0)) << (l > 1 ? 1 : 0);
-                s_nextcode[l] = code;
-            }
-            __threadfence_block();
-            // assign in symbol order (syms[] is the compacted alphabet in increasing symbol order)
-            for (uint32_t q = 0; q < m; q++) {
-                uint32_t sym = p.syms[q];
-                uint32_t l = p.lens[sym];
-                uint32_t c = s_nextcode[l]++;
-                p.enc[sym] = (c << 5) | l;
+                s_first[l] = code;
             }
         }
+        // 7. scatter the lengths back to symbol order: aux[idx] = length of the idx-th symbol (syms[] is ascending)
+        __syncthreads();
+        for (uint32_t q = t; q < m; q += CB_THREADS) {
+            const uint32_t sym = (uint32_t)(keys[q] & 0xFFFF), l = pleaf[q];
+            uint32_t a = 0, bnd = m;  // lower_bound
+            while (a < bnd) {
+                uint32_t mid = (a + bnd) >> 1;
+                if (syms[mid] < sym) a = mid + 1;
+                else bnd = mid;
+            }
+            aux[a] = (uint16_t)l;
+            p.lens[sym] = (uint8_t)l;
+        }
+        __syncthreads();
+        // 8. codes in (len, symbol) order: rank among the earlier symbols of the same length
+        if (small) {
+            for (uint32_t q = t; q < m; q += CB_THREADS) {
+                const uint32_t l = aux[q];
+                uint32_t rank = 0;
+                for (uint32_t r = 0; r < q; r++) rank += aux[r] == l;
+                p.enc[syms[q]] = ((s_first[l] + rank) << 5) | l;
+            }
+        } else if (t == 0) {
+            for (uint32_t q = 0; q < m; q++) {
+                const uint32_t l = aux[q];
+                p.enc[syms[q]] = ((s_first[l]++) << 5) | l;
+            }
+        }
+        for (uint32_t l = 1; l <= SZH_MAX_LEN; l++)
+            if (s_cnt[l]) max_len = l;
+    }
+    if (t == 0) {
         p.info->n_symbols = m;
         p.info->max_len = max_len;
-        p.info->sym_min = s_symmin;
-        p.info->sym_count = s_symmax - s_symmin + 1;
+        p.info->sym_min = lo;
+        p.info->sym_count = range;
     }
 }
 
@@ -636,6 +931,156 @@ __global__ __launch_bounds__(256) void k_encode(const uint16_t *__restrict__ cod
     const uint32_t nwords = (total_bits + 31) >> 5;
     uint32_t *out = reinterpret_cast<uint32_t *>(payload + state->off.bitstream) + chunk_off[chunk];
     for (uint32_t i = lane_id(); i < nwords; i += WAVE) out[i] = stage[i];
+}
+
+// K6 fused: bit lengths, decoupled look-back for the output offset, bit-pack, write — one launch.
+// Persistent workgroups pull BATCHES of 32 chunks (32768 symbols) from a ticket counter: a workgroup therefore only
+// ever waits for batches that were taken earlier, i.e. by workgroups that are already running (no residency
+// assumption), and the single counter sees n/32768 atomics instead of one per tile (one address serialises at
+// ~90 atomics/us).  Per batch: pre-pass (code lengths -> words per chunk), publish the batch aggregate, look back,
+// then pack chunk by chunk (codes come from L2 the second time).  The look-back record is ONE 8-byte word
+// {flag:2, value:62} moved with relaxed agent-scope atomics — the data is the flag, no fence needed
+// (/opt/skills/guides/cdna_hip_programming.md G16 "R2").  flag 1 = batch word count, flag 2 = inclusive prefix.
+// Output placement is by batch index, hence deterministic.
+#define LB_AGG (1ull << 62)
+#define LB_INC (2ull << 62)
+#define LB_VAL ((1ull << 62) - 1)
+#define ENC_BATCH_CHUNKS 32
+__global__ __launch_bounds__(256) void k_encode_fused(const uint16_t *__restrict__ codes, uint64_t n,
+                                                      const uint32_t *__restrict__ g_enc, int radius,
+                                                      uint16_t *__restrict__ chunk_words, unsigned long long *lb_state,
+                                                      unsigned int *ticket, uint64_t *total_words,
+                                                      const szk_state *__restrict__ state, uint8_t *__restrict__ payload) {
+    constexpr int STAGE_WORDS = SZH_CHUNK_SYMS * SZH_MAX_LEN / 32;  // 768 words per chunk at most
+    __shared__ uint32_t s_enc[ENC_WIN];
+    __shared__ uint32_t s_stage[4][STAGE_WORDS];
+    __shared__ uint32_t s_words[ENC_BATCH_CHUNKS];
+    __shared__ uint32_t s_batch;
+    __shared__ unsigned long long s_excl;
+    const int win_lo = radius - ENC_WIN / 2;
+    for (int i = threadIdx.x; i < ENC_WIN; i += 256) {
+        int sym = win_lo + i;
+        s_enc[i] = (sym >= 0 && sym < (int)SZH_HIST_BINS) ? g_enc[sym] : 0;
+    }
+    const int wv = threadIdx.x / WAVE;
+    uint32_t *stage = s_stage[wv];
+    const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
+    const uint32_t n_batches = (uint32_t)((n_chunks + ENC_BATCH_CHUNKS - 1) / ENC_BATCH_CHUNKS);
+    uint32_t *out_base = reinterpret_cast<uint32_t *>(payload + state->off.bitstream);
+
+    for (;;) {
+        __syncthreads();  // s_words / s_batch / s_excl of the previous batch are no longer read
+        if (threadIdx.x == 0) s_batch = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const uint32_t bt = s_batch;
+        if (bt >= n_batches) break;
+        const uint64_t chunk0 = (uint64_t)bt * ENC_BATCH_CHUNKS;
+        // ---- pre-pass: words per chunk ----
+#pragma unroll 2
+        for (int g = 0; g < ENC_BATCH_CHUNKS / 4; g++) {
+            const uint64_t chunk = chunk0 + g * 4 + wv;
+            uint32_t bits = 0;
+            if (chunk < n_chunks) {
+                const uint64_t base = chunk * SZH_CHUNK_SYMS + (uint64_t)lane_id() * ENC_PER_LANE;
+                uint16_t c[ENC_PER_LANE];
+                load_codes16(codes, base, n, c);
+#pragma unroll
+                for (int i = 0; i < ENC_PER_LANE; i++)
+                    if (base + i < n) bits += enc_lookup(s_enc, g_enc, win_lo, c[i]) & 31u;
+            }
+            bits = wave_sum(bits);
+            if (lane_id() == 0) {
+                const uint32_t nw = (bits + 31) >> 5;
+                s_words[g * 4 + wv] = nw;
+                if (chunk < n_chunks) chunk_words[chunk] = (uint16_t)nw;
+            }
+        }
+        __syncthreads();
+        // ---- batch aggregate, look-back (wave 0) ----
+        if (wv == 0) {
+            uint32_t mine = lane_id() < ENC_BATCH_CHUNKS ? s_words[lane_id()] : 0u;
+            const uint32_t batch_words = wave_sum(mine);
+            if (lane_id() == 0)
+                __hip_atomic_store(&lb_state[bt], (bt == 0 ? LB_INC : LB_AGG) | (unsigned long long)batch_words,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long excl = 0;
+            if (bt > 0) {
+                int64_t idx = (int64_t)bt - 1;
+                for (;;) {
+                    const int64_t my = idx - lane_id();
+                    unsigned long long v;
+                    for (;;) {
+                        v = my >= 0 ? __hip_atomic_load(&lb_state[my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_INC;
+                        if (__all((v >> 62) != 0)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    const unsigned long long inc_mask = __ballot((v >> 62) == 2);
+                    unsigned long long contrib = v & LB_VAL;
+                    if (inc_mask) {
+                        const int first = __ffsll((long long)inc_mask) - 1;  // closest predecessor with an inclusive prefix
+                        if (lane_id() > first) contrib = 0;
+                        excl += wave_sum(contrib);
+                        break;
+                    }
+                    excl += wave_sum(contrib);
+                    idx -= WAVE;
+                }
+                if (lane_id() == 0)
+                    __hip_atomic_store(&lb_state[bt], LB_INC | (excl + batch_words), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane_id() == 0) {
+                s_excl = excl;
+                if (bt == n_batches - 1) *total_words = excl + batch_words;
+            }
+        }
+        __syncthreads();
+        const unsigned long long excl = s_excl;
+        // ---- pack pass ----
+        for (int g = 0; g < ENC_BATCH_CHUNKS / 4; g++) {
+            const uint64_t chunk = chunk0 + g * 4 + wv;
+            if (chunk >= n_chunks) break;
+            const int ci = g * 4 + wv;
+            uint32_t coff = 0;  // words of the earlier chunks of this batch
+            for (int i = lane_id(); i < ci; i += WAVE) coff += s_words[i];
+            coff = wave_sum(coff);
+            const uint32_t nwords = s_words[ci];
+            for (uint32_t i = lane_id(); i < nwords; i += WAVE) stage[i] = 0;
+            const uint64_t base = chunk * SZH_CHUNK_SYMS + (uint64_t)lane_id() * ENC_PER_LANE;
+            uint16_t c[ENC_PER_LANE];
+            load_codes16(codes, base, n, c);
+            uint32_t e[ENC_PER_LANE];
+            uint32_t bits = 0;
+#pragma unroll
+            for (int i = 0; i < ENC_PER_LANE; i++) {
+                e[i] = (base + i < n) ? enc_lookup(s_enc, g_enc, win_lo, c[i]) : 0u;
+                bits += e[i] & 31u;
+            }
+            const uint32_t incl = wave_incl_scan(bits);
+            uint32_t pos = incl - bits;
+            uint32_t word = pos >> 5;
+            uint32_t have = pos & 31;
+            uint64_t acc = 0;
+#pragma unroll
+            for (int i = 0; i < ENC_PER_LANE; i++) {
+                const uint32_t len = e[i] & 31u;
+                const uint64_t cw = e[i] >> 5;
+                acc |= len ? cw << (64 - have - len) : 0ull;
+                have += len;
+                if (have >= 32) {
+                    atomicOr(&stage[word], (uint32_t)(acc >> 32));
+                    word++;
+                    acc <<= 32;
+                    have -= 32;
+                }
+            }
+            if ((uint32_t)(acc >> 32) != 0) atomicOr(&stage[word], (uint32_t)(acc >> 32));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t *out = out_base + excl + coff;
+            for (uint32_t i = lane_id(); i < nwords; i += WAVE) out[i] = stage[i];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
 }
 
 // header + side sections (lens, chunk table, outliers) into the payload
@@ -873,13 +1318,14 @@ __global__ __launch_bounds__(256) void k_scan_strided(Q *__restrict__ q, uint64_
 
 // lattice index -> value, in place (Q and T have the same size)
 template <typename T>
-__global__ __launch_bounds__(256) void k_dequant(void *buf, uint64_t n, double two_eb) {
+__global__ __launch_bounds__(256) void k_dequant(void *buf, uint64_t n, szk_lattice l) {
     using Q = typename QTraits<T>::Q;
+    const Lattice<T> lat(l);
     Q *q = reinterpret_cast<Q *>(buf);
     T *o = reinterpret_cast<T *>(buf);
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         Q v = q[i];
-        o[i] = dequant<T>(v, two_eb);
+        o[i] = lat.dequant(v);
     }
 }
 template <typename T>
@@ -918,6 +1364,8 @@ int szk_launch_minmax(int dtype, const void *d_in, uint64_t n, double *d_partial
     return 0;
 }
 
+int szk_force_generic = 0;  // test hook: route every shape through the generic kernel
+
 template <typename T>
 static int launch_k1(int ndim, const void *d_in, uint16_t *codes, const szk_k1_params &p, hipStream_t s) {
     const uint64_t d0 = p.d[3], d1 = p.d[2], d2 = p.d[1], d3 = p.d[0];
@@ -925,6 +1373,10 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, const szk_k1_p
         return ((d0 + tx - 1) / tx) * ((d1 + ty - 1) / ty) * ((d2 + tz - 1) / tz) * d3;
     };
     uint64_t nb;
+    constexpr int FTZ = sizeof(T) == 4 ? 8 : 4;  // fast-path tile depth (LDS budget)
+    // tuned kernel: quads need x % 4 == 0; 32-bit in-tile offsets need (TZ+1) planes < 2^31 elements; tile count < 2^31
+    const bool fast = !szk_force_generic && (d0 % 4 == 0) && d0 < (1ull << 31) && d1 < (1ull << 31) && d2 < (1ull << 31) &&
+                      d0 * d1 < (1ull << 27) && tiles(64, 8, FTZ) < (1ull << 31);
     switch (ndim) {
         case 1:
             nb = tiles(4096, 1, 1);
@@ -937,11 +1389,25 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, const szk_k1_p
             hipLaunchKernelGGL((k_lorenzo_quant<T, 2, 128, 32, 1>), dim3((uint32_t)nb), dim3(256), 0, s, (const T *)d_in, codes, p);
             break;
         case 3:
+            if (fast) {
+                nb = tiles(64, 8, FTZ);
+                const uint32_t grid = (uint32_t)(nb < SZK_K1_GRID ? nb : SZK_K1_GRID);
+                hipLaunchKernelGGL((k_lorenzo_quant_v4<T, 3, FTZ>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
+                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+                break;
+            }
             nb = tiles(64, 8, 8);
             if (nb > 0x7FFFFFFFull) return -1;
             hipLaunchKernelGGL((k_lorenzo_quant<T, 3, 64, 8, 8>), dim3((uint32_t)nb), dim3(256), 0, s, (const T *)d_in, codes, p);
             break;
         default:
+            if (fast) {
+                nb = tiles(64, 8, FTZ);
+                const uint32_t grid = (uint32_t)(nb < SZK_K1_GRID ? nb : SZK_K1_GRID);
+                hipLaunchKernelGGL((k_lorenzo_quant_v4<T, 4, FTZ>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
+                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+                break;
+            }
             nb = tiles(64, 8, 4);
             if (nb > 0x7FFFFFFFull) return -1;
             hipLaunchKernelGGL((k_lorenzo_quant<T, 4, 64, 8, 4>), dim3((uint32_t)nb), dim3(256), 0, s, (const T *)d_in, codes, p);
@@ -965,14 +1431,17 @@ int szk_launch_layout_pre(const szk_layout_params *p, hipStream_t s) {
     return 0;
 }
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, int radius, uint16_t *chunk_words,
-                      uint64_t *chunk_off, uint64_t *total_words, const szk_state *state, uint8_t *payload,
+                      uint64_t *lb_state, uint64_t *total_words, const szk_state *state, uint8_t *payload,
                       hipStream_t s) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
-    const uint64_t nb = (n_chunks + 3) / 4;
-    if (nb > 0x7FFFFFFFull) return -1;
-    hipLaunchKernelGGL(k_chunk_bits, dim3((uint32_t)nb), dim3(256), 0, s, codes, n, d_enc, radius, chunk_words);
-    hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, chunk_words, n_chunks, chunk_off, total_words);
-    hipLaunchKernelGGL(k_encode, dim3((uint32_t)nb), dim3(256), 0, s, codes, n, d_enc, radius, chunk_off, state, payload);
+    const uint64_t n_batches = (n_chunks + ENC_BATCH_CHUNKS - 1) / ENC_BATCH_CHUNKS;
+    if (n_batches > 0x7FFFFFFFull) return -1;
+    // lb_state[0 .. n_batches) look-back records, lb_state[n_batches] the ticket counter: zeroed before every launch
+    hipError_t e = hipMemsetAsync(lb_state, 0, (n_batches + 1) * 8, s);
+    if (e != hipSuccess) return (int)e;
+    const uint32_t grid = (uint32_t)(n_batches < 1280 ? n_batches : 1280);  // any grid size is deadlock-free
+    hipLaunchKernelGGL(k_encode_fused, dim3(grid), dim3(256), 0, s, codes, n, d_enc, radius, chunk_words,
+                       (unsigned long long *)lb_state, (unsigned int *)(lb_state + n_batches), total_words, state, payload);
     SZK_CHECK_LAUNCH();
     return 0;
 }
@@ -1038,7 +1507,7 @@ static int launch_reconstruct(const uint8_t *payload, const szh_header &h, const
         }
         inner *= La;
     }
-    hipLaunchKernelGGL(k_dequant<T>, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, d_out, n, 2.0 * h.eb);
+    hipLaunchKernelGGL(k_dequant<T>, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, d_out, n, szk_make_lattice(h.eb));
     if (h.n_vout)
         hipLaunchKernelGGL(k_patch_vout<T>, dim3(grid_for(h.n_vout, 256, 4096)), dim3(256), 0, s, payload, o.vout_idx,
                            o.vout_val, h.n_vout, n, (T *)d_out);

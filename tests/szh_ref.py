@@ -15,18 +15,29 @@ def dualquant(a, eb, radius=32768):
     """Expected lattice indices, codes and outliers for array `a` (any ndim <= 4), exactly as K1 computes them."""
     a = np.ascontiguousarray(a)
     T = a.dtype
-    qt = np.int32 if T == np.float32 else np.int64
-    qmax = 2.0 ** 30 if T == np.float32 else 2.0 ** 62
-    two_eb = 2.0 * eb
-    recip = 1.0 / two_eb
+    # lattice arithmetic in the data type (sz3hip_kernels.hip, Lattice<T>): one rounding per multiply, no FMA
+    if T == np.float32:
+        qt = np.int32
+        recip = np.float32(1.0 / (2.0 * eb))
+        two_eb = np.float32(2.0 * eb)
+        eb_lo = np.float32(eb)
+        if float(eb_lo) > eb:
+            eb_lo = np.nextafter(eb_lo, np.float32(0))
+        lim = np.float32(8388608.0)
+    else:
+        qt = np.int64
+        recip = 1.0 / (2.0 * eb)
+        two_eb = 2.0 * eb
+        eb_lo = eb
+        lim = 4503599627370496.0
     with np.errstate(invalid="ignore", over="ignore"):
-        s = a.astype(np.float64) * recip
-        ok = np.abs(s) < qmax
-        r = np.rint(np.where(ok, s, 0.0))
+        s = a * recip
+        ok = np.abs(s) < lim
+        r = np.rint(np.where(ok, s, 0)).astype(T)
         q = r.astype(qt)
-        dec = (r * two_eb).astype(T)
-        diff = np.abs((dec - a).astype(T))
-        bad = ~ok | ~(diff.astype(np.float64) <= eb)
+        dec = r * two_eb
+        diff = np.abs(dec - a)
+        bad = ~ok | ~(diff <= eb_lo)
     # N-d Lorenzo = successive first differences with zero halo, wrap-around integer arithmetic
     d = q.copy()
     for ax in range(a.ndim):
@@ -157,7 +168,7 @@ def reconstruct(h, sec, codes):
     for ax in range(4):
         with np.errstate(over="ignore"):
             q = np.cumsum(q, axis=ax, dtype=Q)
-    x = (q.astype(np.float64) * (2.0 * h["eb"])).astype(T).reshape(-1)
+    x = (q.astype(T) * T(2.0 * h["eb"])).reshape(-1)
     x[sec["vout_idx"].astype(np.int64)] = sec["vout_val"]
     return x
 

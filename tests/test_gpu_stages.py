@@ -41,6 +41,11 @@ CASES = [
     ("3d", lambda: field3d((33, 47, 50)), 1e-3),
     ("3d-f64", lambda: field3d((20, 30, 37), np.float64, sigma=2e-6), 1e-6),
     ("4d", lambda: field4d((7, 11, 13, 17)), 1e-2),
+    ("3d-fast", lambda: field3d((33, 47, 52)), 1e-3),
+    ("3d-fast-exact-tiles", lambda: field3d((16, 24, 128)), 1e-4),
+    ("3d-fast-f64", lambda: field3d((21, 30, 36), np.float64, sigma=2e-6), 1e-6),
+    ("4d-fast", lambda: field4d((5, 11, 13, 16)), 1e-2),
+    ("4d-fast-f64", lambda: field4d((3, 6, 10, 68), np.float64), 1e-3),
     ("3d-smooth", lambda: field3d((40, 40, 40), sigma=0.0), 1e-1),
     ("3d-const", lambda: np.full((17, 19, 23), 3.25, np.float32), 1e-3),
 ]
@@ -92,7 +97,7 @@ def test_outliers_and_nonfinite():
     a[10, 2, 7] = np.inf
     a[20, 20, 20] = 1e30
     a[1, 1, 1] = -3e9
-    a[5, 6, 7] = 70000.0   # representable on the lattice but a huge Lorenzo delta -> delta outlier
+    a[5, 6, 7] = 3000.0   # representable on the lattice (|x/2eb| < 2^23) but a huge Lorenzo delta -> delta outlier
     eb = 1e-3
     codes, pl, dec, st = _roundtrip_device(a, eb)
     q, d, exp_codes, bad, dout = szh_ref.dualquant(a, eb)
@@ -101,3 +106,23 @@ def test_outliers_and_nonfinite():
     fin = np.isfinite(a)
     assert np.array_equal(np.isnan(dec), np.isnan(a)) and np.array_equal(dec[~fin & ~np.isnan(a)], a[~fin & ~np.isnan(a)])
     assert np.max(np.abs(dec[fin].astype(np.float64) - a[fin].astype(np.float64))) <= eb
+
+
+@pytest.mark.parametrize("shape,dtype", [((19, 26, 68), np.float32), ((9, 17, 64), np.float64), ((3, 9, 11, 72), np.float32)])
+def test_fast_kernel_equals_generic(shape, dtype):
+    """the tuned stage-1 kernel and the any-shape kernel must emit identical codes, outliers and payloads"""
+    a = (field3d(shape, dtype) if len(shape) == 3 else field4d(shape, dtype))
+    a[tuple(s // 2 for s in shape)] = np.nan
+    a[tuple(s // 3 for s in shape)] = 4e4
+    try:
+        sz3_amd.lib().sz3hip_debug_force_generic(1)
+        c0, p0, d0, s0 = _roundtrip_device(a, 1e-3)
+    finally:
+        sz3_amd.lib().sz3hip_debug_force_generic(0)
+    c1, p1, d1, s1 = _roundtrip_device(a, 1e-3)
+    assert np.array_equal(c0, c1)
+    assert s0["n_value_outliers"] == s1["n_value_outliers"] and s0["n_delta_outliers"] == s1["n_delta_outliers"]
+    h0, _, sec0 = szh_ref.parse(p0)
+    h1, _, sec1 = szh_ref.parse(p1)
+    assert np.array_equal(sec0["bitstream"], sec1["bitstream"]) and np.array_equal(sec0["lens"], sec1["lens"])
+    assert np.array_equal(d0, d1, equal_nan=True)

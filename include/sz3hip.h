@@ -143,6 +143,8 @@ int sz3hip_get_stage_times(sz3hip_ctx *ctx, const char **names, float *ms, int m
 int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, uint64_t n);
 /* test hook: non-zero routes every shape through the generic (any-shape) stage-1 kernel instead of the tuned one */
 void sz3hip_debug_force_generic(int on);
+/* ablation switches of the stage-1 kernel for tools/k1_lab.py (results are wrong when non-zero) */
+void sz3hip_debug_flags(int flags);
 
 #ifdef __cplusplus
 }

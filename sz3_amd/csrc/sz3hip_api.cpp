@@ -681,6 +681,7 @@ extern "C" int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, ui
 }
 
 extern "C" void sz3hip_debug_force_generic(int on) { szk_force_generic = on; }
+extern "C" void sz3hip_debug_flags(int flags) { szk_dbg_flags = flags; }
 
 extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, size_t payload_size, void *d_out,
                                         void *stream) {

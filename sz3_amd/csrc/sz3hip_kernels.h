@@ -23,12 +23,13 @@ static inline szk_lattice szk_make_lattice(double eb) {
     return l;
 }
 
-#define SZK_K1_GRID 1024u  // persistent stage-1 grid: 4 workgroups per CU on 256 CUs
+#define SZK_K1_GRID 2048u  // rows of hist_partial = upper bound of the persistent stage-1 grid
 
 struct szk_k1_params {
     uint64_t d[4];  // extents slowest first, left-padded with 1: [w][z][y][x]
     szk_lattice lat;
     uint32_t radius;
+    uint32_t dbg;      // ablation switches for tools/k1_lab.py (0 in production)
     uint64_t out_cap;  // capacity of each outlier list
     uint64_t *hist;    // [SZH_HIST_BINS]
     uint32_t *hist_partial;  // [SZK_K1_GRID][1024] private histogram rows of the persistent stage-1 workgroups
@@ -101,5 +102,6 @@ int szk_launch_reconstruct(const uint8_t *payload, const szh_header *h, const sz
                            void *d_out, void *d_segtot, hipStream_t s);
 void szk_host_offsets(const szh_header *h, szh_offsets *o);
 extern int szk_force_generic;
+extern int szk_dbg_flags;
 
 #endif

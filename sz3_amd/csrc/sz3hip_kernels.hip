@@ -313,64 +313,157 @@ __device__ __forceinline__ void lds_ld4(const int64_t *p, int64_t (&v)[4]) {
 // histogram is cleared and flushed once per workgroup; the flush goes to a private row of `hist_partial`
 // (no same-address global atomics: 32768 tiles hammering one 64-bit counter serialise at ~90 atomics/us) and
 // k_hist_reduce folds the rows into the 65536-bin histogram.
+// Software pipeline: the global loads of tile i+1 are issued into registers before the stencil of tile i runs, so
+// every workgroup keeps ~20 KB of HBM reads in flight all the time (4 workgroups per CU -> ~80 KB per CU).
+#define HIST_CSTRIDE (HIST_WIN + 8)  // copy k starts 8 banks further: one bin in different copies = different banks
+
+__device__ __forceinline__ int32_t dpp_shr1(int32_t old, int32_t src) {  // lane l <- lane l-1 inside rows of 16 lanes
+    return __builtin_amdgcn_update_dpp(old, src, 0x111, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int64_t dpp_shr1(int64_t old, int64_t src) {
+    int32_t lo = __builtin_amdgcn_update_dpp((int32_t)old, (int32_t)src, 0x111, 0xf, 0xf, false);
+    int32_t hi = __builtin_amdgcn_update_dpp((int32_t)(old >> 32), (int32_t)(src >> 32), 0x111, 0xf, 0xf, false);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+// four consecutive elements held in the native 16-byte vector registers a global load returns (no repacking, so
+// the compiler has no reason to wait for the load before the first real use)
+template <typename T> struct Quad;
+template <> struct Quad<float> {
+    float4 a;
+    __device__ __forceinline__ void load(const float *p) { a = *reinterpret_cast<const float4 *>(p); }
+    __device__ __forceinline__ float get(int i) const { return i == 0 ? a.x : i == 1 ? a.y : i == 2 ? a.z : a.w; }
+};
+template <> struct Quad<double> {
+    double2 a, b;
+    __device__ __forceinline__ void load(const double *p) {
+        a = reinterpret_cast<const double2 *>(p)[0];
+        b = reinterpret_cast<const double2 *>(p)[1];
+    }
+    __device__ __forceinline__ double get(int i) const { return i == 0 ? a.x : i == 1 ? a.y : i == 2 ? b.x : b.y; }
+};
+
+template <typename T, int NW, int RPT> struct K1Regs {
+    Quad<T> own[NW][RPT];  // this thread's row quads
+    Quad<T> h0[NW], h1[NW];  // halo-row quads (h1 only for threads 0..15)
+    T col[NW];               // halo-column element (threads 0..PZ*PY-1)
+    uint32_t valid;          // bit (lw*8 + k): own[lw][k]; bit (16 + lw*4 + {0,1,2}): h0, h1, col
+};
+
 template <typename T, int NDIM, int TZ>
-__global__ __launch_bounds__(256) void k_lorenzo_quant_v4(const T *__restrict__ in, uint16_t *__restrict__ codes,
+__global__ __launch_bounds__(256, (NDIM == 3 ? 3 : 2)) void k_lorenzo_quant_v4(const T *__restrict__ in, uint16_t *__restrict__ codes,
                                                           szk_k1_params p, uint32_t ntiles) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     constexpr int TX = 64, TY = 8, NW = NDIM == 4 ? 2 : 1;
     constexpr int PX = TX + 4, PY = TY + 1, PZ = TZ + 1, SLAB = PZ * PY * PX;
     constexpr int RPT = TZ / 2;  // row quads per thread
+    static_assert((PZ + TY) * 16 <= 256 + 16 && PZ * PY <= 256, "halo mapping assumes one/two quads per thread");
     __shared__ __attribute__((aligned(16))) Q lq[NW * SLAB];
-    __shared__ uint32_t lh[HIST_COPIES * HIST_WIN + WAVE];  // + one private dummy bin per lane for the centre code
+    __shared__ uint32_t lh[HIST_COPIES * HIST_CSTRIDE + WAVE];  // + one private dummy bin per lane for the centre code
 
     const uint32_t d0 = (uint32_t)p.d[3], d1 = (uint32_t)p.d[2], d2 = (uint32_t)p.d[1];
     const uint32_t ntx = (d0 + TX - 1) / TX, nty = (d1 + TY - 1) / TY, ntz = (d2 + TZ - 1) / TZ;
-    const uint32_t plane = d1 * d0;  // < 2^31 / TZ guaranteed by the launcher
+    const uint32_t plane = d1 * d0;  // (TZ+1) planes < 2^31 elements guaranteed by the launcher
     const uint64_t vol = (uint64_t)plane * d2;
     const int t = threadIdx.x;
     const int lx4 = t & 15, ly = (t >> 4) & 7, lzb = t >> 7;
     const Lattice<T> lat(p.lat);
     const int radius = (int)p.radius;
     const int win_lo = radius - HIST_WIN / 2;
-    uint32_t *myh = lh + (t & (HIST_COPIES - 1)) * HIST_WIN;
-    const uint32_t dummy_bin = (uint32_t)(HIST_COPIES * HIST_WIN + lane_id()) - (uint32_t)((t & (HIST_COPIES - 1)) * HIST_WIN);
+    uint32_t *myh = lh + (t & (HIST_COPIES - 1)) * HIST_CSTRIDE;
+    const uint32_t dummy_bin = (uint32_t)(HIST_COPIES * HIST_CSTRIDE + lane_id()) - (uint32_t)((t & (HIST_COPIES - 1)) * HIST_CSTRIDE);
     uint32_t center_count = 0;
+    // halo-row quads handled by this thread: index t (all threads) and 256 + t (threads 0..15 when needed)
+    const int hr0 = t >> 4, hx0 = t & 15;
+    const int h0_lz = hr0 < PZ ? hr0 - 1 : -1, h0_y = hr0 < PZ ? -1 : hr0 - PZ;
+    constexpr bool HAS_H1 = (PZ + TY) * 16 > 256;
+    const int hr1 = 16 + (t >> 4);  // only meaningful for t < 16
+    const int h1_lz = hr1 < PZ ? hr1 - 1 : -1, h1_y = hr1 < PZ ? -1 : hr1 - PZ;
+    const bool h0_on = hr0 < PZ + TY, h1_on = HAS_H1 && t < ((PZ + TY) * 16 - 256);
+    const int c_lz = t / PY - 1, c_y = t % PY - 1;
+    const bool col_on = t < PZ * PY;
 
-    for (int i = t; i < HIST_COPIES * HIST_WIN + WAVE; i += 256) lh[i] = 0;
+    for (int i = t; i < HIST_COPIES * HIST_CSTRIDE + WAVE; i += 256) lh[i] = 0;
 
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    auto decode = [&](uint32_t tile, int &x0, int &y0, int &z0, uint32_t &w) {
         uint32_t b = tile;
-        const uint32_t tx = b % ntx;
+        x0 = (int)((b % ntx) * TX);
         b /= ntx;
-        const uint32_t ty = b % nty;
+        y0 = (int)((b % nty) * TY);
         b /= nty;
-        const uint32_t tz = b % ntz;
-        const uint32_t w = b / ntz;
-        const int x0 = (int)(tx * TX), y0 = (int)(ty * TY), z0 = (int)(tz * TZ);
-        __syncthreads();  // previous tile's stencil reads are done before the slab is overwritten
-
-        Q qreg[RPT][4];
-        uint32_t badmask = 0;
+        z0 = (int)((b % ntz) * TZ);
+        w = b / ntz;
+    };
+    // issue the global loads of one tile: always a load (out-of-array quads read element 0 and are masked later), no
+    // branches, so that all of them go out back to back and stay in flight until the next iteration consumes them
+    auto fetch = [&](uint32_t tile, K1Regs<T, NW, RPT> &R) {
+        int x0, y0, z0;
+        uint32_t w;
+        decode(tile, x0, y0, z0, w);
+        uint32_t valid = 0;
 #pragma unroll
         for (int lw = 0; lw < NW; lw++) {
             const bool wok = (int)w - lw >= 0;
-            // tile origin (z0, y0, x0) of hyper-plane w - lw; offsets inside the tile are 32-bit
             const T *src = in + (uint64_t)(wok ? w - lw : 0) * vol + ((uint64_t)z0 * plane + (uint64_t)y0 * d0 + x0);
-            Q *slab = lq + lw * SLAB;
 #pragma unroll
             for (int k = 0; k < RPT; k++) {
                 const int lz = lzb + 2 * k;
                 const uint32_t gz = z0 + lz, gy = y0 + ly, gx = x0 + 4 * lx4;
-                Q q[4] = {0, 0, 0, 0};
-                if (wok && gz < d2 && gy < d1 && gx < d0) {
-                    V4<T> v = ldg4(src + ((uint32_t)lz * plane + (uint32_t)ly * d0 + 4u * lx4));
+                const bool ok = wok && gz < d2 && gy < d1 && gx < d0;
+                R.own[lw][k].load(ok ? src + ((uint32_t)lz * plane + (uint32_t)ly * d0 + 4u * lx4) : in);
+                valid |= (uint32_t)ok << (lw * 8 + k);
+            }
+            {
+                const int gz = z0 + h0_lz, gy = y0 + h0_y;
+                const bool ok = h0_on && wok && gz >= 0 && gy >= 0 && (uint32_t)gz < d2 && (uint32_t)gy < d1 && (uint32_t)(x0 + 4 * hx0) < d0;
+                R.h0[lw].load(ok ? src + ((int64_t)h0_lz * (int64_t)plane + (int64_t)h0_y * (int64_t)d0 + 4 * hx0) : in);
+                valid |= (uint32_t)ok << (16 + lw * 4);
+            }
+            if (HAS_H1) {
+                const int gz = z0 + h1_lz, gy = y0 + h1_y;
+                const bool ok = h1_on && wok && gz >= 0 && gy >= 0 && (uint32_t)gz < d2 && (uint32_t)gy < d1 && (uint32_t)(x0 + 4 * hx0) < d0;
+                R.h1[lw].load(ok ? src + ((int64_t)h1_lz * (int64_t)plane + (int64_t)h1_y * (int64_t)d0 + 4 * hx0) : in);
+                valid |= (uint32_t)ok << (17 + lw * 4);
+            }
+            {
+                const int gz = z0 + c_lz, gy = y0 + c_y;
+                const bool ok = col_on && wok && x0 > 0 && gz >= 0 && gy >= 0 && (uint32_t)gz < d2 && (uint32_t)gy < d1;
+                R.col[lw] = *(ok ? src + ((int64_t)c_lz * (int64_t)plane + (int64_t)c_y * (int64_t)d0 - 1) : in);
+                valid |= (uint32_t)ok << (18 + lw * 4);
+            }
+        }
+        R.valid = valid;
+    };
+
+    K1Regs<T, NW, RPT> R;
+    uint32_t tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile, R);
+    for (; tile < ntiles; tile += gridDim.x) {
+        int x0, y0, z0;
+        uint32_t w;
+        decode(tile, x0, y0, z0, w);
+        if ((p.dbg & 16) && tile != blockIdx.x) fetch(tile, R);
+        __syncthreads();  // previous tile's stencil reads are done before the slab is overwritten
+
+        // ---- prequantise the fetched registers into the LDS slab ----
+        Q qreg[RPT][4];
+        uint32_t badmask = 0;
+        const uint32_t valid = R.valid;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        bool bad;
-                        q[i] = lat.quant(v.v[i], bad);
-                        if (lw == 0) badmask |= (uint32_t)bad << (4 * k + i);
-                    }
+        for (int lw = 0; lw < NW; lw++) {
+            Q *slab = lq + lw * SLAB;
+#pragma unroll
+            for (int k = 0; k < RPT; k++) {
+                const int lz = lzb + 2 * k;
+                const bool ok = (valid >> (lw * 8 + k)) & 1u;
+                Q q[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    bool bad;
+                    const Q v = lat.quant(R.own[lw][k].get(i), bad);
+                    q[i] = ok ? v : (Q)0;
+                    if (lw == 0) badmask |= (uint32_t)(bad & ok) << (4 * k + i);
                 }
                 lds_st4(slab + ((lz + 1) * PY + (ly + 1)) * PX + 4 + 4 * lx4, q);
                 if (lw == 0) {
@@ -378,35 +471,37 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_v4(const T *__restrict__ 
                     for (int i = 0; i < 4; i++) qreg[k][i] = q[i];
                 }
             }
-            // halo rows: y = y0-1 for lz = -1..TZ-1 (PZ rows), then z = z0-1 for ly = 0..TY-1 (TY rows)
-            for (int i = t; i < (PZ + TY) * 16; i += 256) {
-                const int r = i >> 4, xq = i & 15;
-                const int lz = r < PZ ? r - 1 : -1, hy = r < PZ ? -1 : r - PZ;
-                const int gz = z0 + lz, gy = y0 + hy;
-                const uint32_t gx = x0 + 4 * xq;
-                Q q[4] = {0, 0, 0, 0};
-                if (wok && gz >= 0 && gy >= 0 && (uint32_t)gz < d2 && (uint32_t)gy < d1 && gx < d0) {
-                    V4<T> v = ldg4(src + ((int64_t)lz * (int64_t)plane + (int64_t)hy * (int64_t)d0 + 4 * xq));
+            if (h0_on) {
+                const bool ok = (valid >> (16 + lw * 4)) & 1u;
+                Q q[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        bool bad;
-                        q[j] = lat.quant(v.v[j], bad);
-                    }
-                }
-                lds_st4(slab + ((lz + 1) * PY + (hy + 1)) * PX + 4 + 4 * xq, q);
-            }
-            // halo column x = x0-1 of all PZ*PY rows
-            for (int i = t; i < PZ * PY; i += 256) {
-                const int lz = i / PY - 1, hy = i % PY - 1;
-                const int gz = z0 + lz, gy = y0 + hy;
-                Q q = 0;
-                if (wok && x0 > 0 && gz >= 0 && gy >= 0 && (uint32_t)gz < d2 && (uint32_t)gy < d1) {
+                for (int j = 0; j < 4; j++) {
                     bool bad;
-                    q = lat.quant(src[(int64_t)lz * (int64_t)plane + (int64_t)hy * (int64_t)d0 - 1], bad);
+                    const Q v = lat.quant(R.h0[lw].get(j), bad);
+                    q[j] = ok ? v : (Q)0;
                 }
-                slab[((lz + 1) * PY + (hy + 1)) * PX + 3] = q;
+                lds_st4(slab + ((h0_lz + 1) * PY + (h0_y + 1)) * PX + 4 + 4 * hx0, q);
+            }
+            if (HAS_H1 && h1_on) {
+                const bool ok = (valid >> (17 + lw * 4)) & 1u;
+                Q q[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    bool bad;
+                    const Q v = lat.quant(R.h1[lw].get(j), bad);
+                    q[j] = ok ? v : (Q)0;
+                }
+                lds_st4(slab + ((h1_lz + 1) * PY + (h1_y + 1)) * PX + 4 + 4 * hx0, q);
+            }
+            if (col_on) {
+                const bool ok = (valid >> (18 + lw * 4)) & 1u;
+                bool bad;
+                const Q v = lat.quant(R.col[lw], bad);
+                slab[((c_lz + 1) * PY + (c_y + 1)) * PX + 3] = ok ? v : (Q)0;
             }
         }
+        // ---- next tile's loads go out now and stay in flight across the barrier and the stencil ----
+        if (!(p.dbg & 16) && tile + gridDim.x < ntiles) fetch(tile + gridDim.x, R);
         __syncthreads();
 
         uint16_t *ctile = codes + (uint64_t)w * vol + ((uint64_t)z0 * plane + (uint64_t)y0 * d0 + x0);
@@ -427,10 +522,21 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_v4(const T *__restrict__ 
                 } else {
                     lds_ld4(L + c, cur);
                 }
-                lds_ld4(L + c - PX, ra);
-                lds_ld4(L + c - PY * PX, rb);
-                lds_ld4(L + c - PY * PX - PX, rd);
-                UQ pc = (UQ)L[c - 1], pa = (UQ)L[c - PX - 1], pb = (UQ)L[c - PY * PX - 1], pd = (UQ)L[c - PY * PX - PX - 1];
+                if (p.dbg & 4) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) ra[i] = rb[i] = rd[i] = cur[i];
+                } else {
+                    lds_ld4(L + c - PX, ra);
+                    lds_ld4(L + c - PY * PX, rb);
+                    lds_ld4(L + c - PY * PX - PX, rd);
+                }
+                // x-1 neighbours: the left lane's 4th element (DPP row_shr:1); the 16-lane row leader reads the halo
+                // column from LDS (the other lanes read one common word: broadcast, no bank conflict)
+                const bool lead = lx4 == 0;
+                const Q hc = L[lead ? c - 1 : 0], ha = L[lead ? c - PX - 1 : 0], hb = L[lead ? c - PY * PX - 1 : 0],
+                        hd = L[lead ? c - PY * PX - PX - 1 : 0];
+                UQ pc = (UQ)dpp_shr1(hc, cur[3]), pa = (UQ)dpp_shr1(ha, ra[3]), pb = (UQ)dpp_shr1(hb, rb[3]),
+                   pd = (UQ)dpp_shr1(hd, rd[3]);
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     UQ s = ((UQ)cur[i] - pc) - ((UQ)ra[i] - pa) - ((UQ)rb[i] - pb) + ((UQ)rd[i] - pd);
@@ -446,7 +552,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_v4(const T *__restrict__ 
             bool slow = ((badmask >> (4 * k)) & 15u) != 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const UQ shifted = delta[i] + (UQ)radius;               // in (0, 2r) when |delta| < r
+                const UQ shifted = delta[i] + (UQ)radius;  // in (0, 2r) when |delta| < r
                 const bool inr = (UQ)(shifted - 1) < (UQ)(2 * radius - 1);
                 code[i] = inr ? (uint32_t)shifted : 0u;
                 const uint32_t bin = code[i] - (uint32_t)win_lo;
@@ -454,13 +560,13 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_v4(const T *__restrict__ 
                 const bool ctr = code[i] == (uint32_t)radius;
                 center_count += ctr;
                 slow |= !inr | !inwin;
-                atomicAdd(&myh[(ctr | !inwin) ? dummy_bin : bin], 1u);
+                if (!(p.dbg & 1)) atomicAdd(&myh[(ctr | !inwin) ? dummy_bin : bin], 1u);
             }
             const uint32_t off = (uint32_t)lz * plane + (uint32_t)ly * d0 + 4u * lx4;
             uint2 pk;
             pk.x = code[0] | (code[1] << 16);
             pk.y = code[2] | (code[3] << 16);
-            *reinterpret_cast<uint2 *>(ctile + off) = pk;
+            if (!(p.dbg & 2)) *reinterpret_cast<uint2 *>(ctile + off) = pk;
             if (slow) {  // rare: delta outliers, value outliers, codes outside the LDS histogram window
                 const uint64_t gi = (uint64_t)w * vol + (uint64_t)gz * plane + (uint64_t)gy * d0 + gx;
 #pragma unroll
@@ -490,18 +596,198 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_v4(const T *__restrict__ 
     __syncthreads();
     uint32_t *row = p.hist_partial + (uint64_t)blockIdx.x * HIST_WIN;
     for (int bnn = t; bnn < HIST_WIN; bnn += 256)
-        row[bnn] = lh[bnn] + lh[HIST_WIN + bnn] + lh[2 * HIST_WIN + bnn] + lh[3 * HIST_WIN + bnn];
+        row[bnn] = lh[bnn] + lh[HIST_CSTRIDE + bnn] + lh[2 * HIST_CSTRIDE + bnn] + lh[3 * HIST_CSTRIDE + bnn];
 }
 
-// folds the per-workgroup histogram rows into hist[win_lo + bin] (bins inside the window are touched by nobody else)
+// ------------------------------------------------------------------------------------------------------------
+// K1 "march" (N = 3 or 4, x extent a multiple of 4 and >= 128): register-only stencil, no LDS tile, no barriers.
+// One wave owns a 256 (x) x TY (y) x TZ (z) brick: every lane holds 4 consecutive x, the wave walks the rows of a
+// plane and the planes of the brick keeping
+//     d1(x)   = q(x) - q(x-1)            left neighbour through DPP wave_shr:1 (lane 0: one extra 4-byte load)
+//     d2(x,y) = d1(y) - d1(y-1)          previous row in registers
+//     delta   = d2(z) - d2(z-1)          previous plane's TY rows in registers
+// (the N-d Lorenzo stencil is the product of first differences).  Row loads are 1 KiB contiguous per wave
+// (16 B per lane); a plane's TY+1 rows are requested together so ~5 KiB per wave are in flight, with 5-8 waves per
+// SIMD.  The low-side halo row / plane of a brick is re-read and re-quantised (L2 hits), never exchanged.
+// The histogram lives in LDS per workgroup ([bin][4 copies] interleaved), flushed to a private row of
+// hist_partial (see k_hist_reduce).
+// ------------------------------------------------------------------------------------------------------------
+#define MARCH_TX 256
+#define MARCH_TZ 16
+
+__device__ __forceinline__ int32_t dpp_wave_shr1(int32_t old, int32_t src) {  // lane l <- lane l-1 across the wave
+    return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int64_t dpp_wave_shr1(int64_t old, int64_t src) {
+    int32_t lo = __builtin_amdgcn_update_dpp((int32_t)old, (int32_t)src, 0x138, 0xf, 0xf, false);
+    int32_t hi = __builtin_amdgcn_update_dpp((int32_t)(old >> 32), (int32_t)(src >> 32), 0x138, 0xf, 0xf, false);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+template <typename T, int NDIM, int TY>
+__global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict__ in, uint16_t *__restrict__ codes,
+                                                             szk_k1_params p, uint32_t ntasks) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    constexpr int NW = NDIM == 4 ? 2 : 1;
+    __shared__ uint32_t lh[HIST_WIN * 4 + 4];  // [bin][copy]; bin HIST_WIN = overflow (never flushed)
+
+    const uint32_t d0 = (uint32_t)p.d[3], d1 = (uint32_t)p.d[2], d2 = (uint32_t)p.d[1];
+    const uint32_t ntx = (d0 + MARCH_TX - 1) / MARCH_TX, nty = (d1 + TY - 1) / TY, ntz = (d2 + MARCH_TZ - 1) / MARCH_TZ;
+    const uint64_t plane = (uint64_t)d1 * d0, vol = plane * d2;
+    const int lane = lane_id();
+    const Lattice<T> lat(p.lat);
+    const int radius = (int)p.radius;
+    const uint32_t win_lo = (uint32_t)(radius - HIST_WIN / 2);
+    const uint32_t copy = (uint32_t)lane & 3u;
+
+    for (int i = threadIdx.x; i < HIST_WIN * 4 + 4; i += 256) lh[i] = 0;
+    __syncthreads();
+
+    const uint32_t wave_gid = blockIdx.x * 4 + threadIdx.x / WAVE, nwaves = gridDim.x * 4;
+    for (uint32_t task = wave_gid; task < ntasks; task += nwaves) {
+        uint32_t b = task;
+        const uint32_t x0 = (b % ntx) * MARCH_TX;
+        b /= ntx;
+        const uint32_t y0 = (b % nty) * TY;
+        b /= nty;
+        const uint32_t z0 = (b % ntz) * MARCH_TZ;
+        const uint32_t w = b / ntz;
+        const uint32_t x = x0 + 4 * lane;
+        const bool xok = x < d0;            // quad granular (d0 % 4 == 0)
+        const bool has_left = x0 > 0;       // lane 0 needs element x0 - 1
+        const uint32_t ny = (d1 - y0 < (uint32_t)TY) ? d1 - y0 : (uint32_t)TY;
+
+        UQ pp[NW][TY][4];  // d2 of the previous plane
+#pragma unroll
+        for (int lw = 0; lw < NW; lw++)
+#pragma unroll
+            for (int yy = 0; yy < TY; yy++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) pp[lw][yy][i] = 0;
+
+        const int zstart = z0 > 0 ? -1 : 0;
+        for (int zz = zstart; zz < MARCH_TZ; zz++) {
+            const uint32_t gz = z0 + zz;
+            if (gz >= d2) break;
+            // ---- request the plane's rows: halo row y0-1 (slot 0) and rows y0 .. y0+TY-1 (slots 1..TY) ----
+            Quad<T> rq[NW][TY + 1];
+            T rl[NW][TY + 1];
+#pragma unroll
+            for (int lw = 0; lw < NW; lw++) {
+                const bool wok = (int)w - lw >= 0;
+                const T *src = in + (uint64_t)(wok ? w - lw : 0) * vol + (uint64_t)gz * plane;
+#pragma unroll
+                for (int r = 0; r <= TY; r++) {
+                    const int gy = (int)y0 + r - 1;
+                    const bool rok = wok && gy >= 0 && (uint32_t)gy < d1;
+                    const T *row = src + (uint64_t)(rok ? gy : 0) * d0;
+                    rq[lw][r].load((rok && xok) ? row + x : in);
+                    rl[lw][r] = *((rok && has_left && lane == 0) ? row + (x0 - 1) : in);
+                }
+            }
+            // ---- rows ----
+            UQ pd1[NW][4];  // d1 of the previous row
+            UQ delta[4];
+#pragma unroll
+            for (int r = 0; r <= TY; r++) {
+                const int gy = (int)y0 + r - 1;
+                uint32_t badmask = 0;
+#pragma unroll
+                for (int lw = 0; lw < NW; lw++) {
+                    const bool wok = (int)w - lw >= 0;
+                    const bool rok = wok && gy >= 0 && (uint32_t)gy < d1;
+                    const bool ok = rok && xok;
+                    Q q[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        bool bad;
+                        const Q v = lat.quant(rq[lw][r].get(i), bad);
+                        q[i] = ok ? v : (Q)0;
+                        if (lw == 0) badmask |= (uint32_t)(bad & ok) << i;
+                    }
+                    bool badl;
+                    const Q ql = lat.quant(rl[lw][r], badl);
+                    const Q left0 = (rok && has_left) ? ql : (Q)0;  // only lane 0's value is used
+                    UQ pv = (UQ)dpp_wave_shr1(left0, q[3]);
+                    UQ d1v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        d1v[i] = (UQ)q[i] - pv;
+                        pv = (UQ)q[i];
+                    }
+                    if (r > 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const UQ d2v = d1v[i] - pd1[lw][i];
+                            const UQ s = d2v - pp[lw][r - 1][i];
+                            pp[lw][r - 1][i] = d2v;
+                            delta[i] = lw == 0 ? s : (UQ)(delta[i] - s);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) pd1[lw][i] = d1v[i];
+                }
+                if (r == 0 || zz < 0) continue;                       // halo row / halo plane: state only
+                if ((uint32_t)(r - 1) >= ny || !xok) continue;         // beyond the array
+                // ---- codes, histogram, store ----
+                uint32_t code[4];
+                uint32_t mx = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const UQ shifted = delta[i] + (UQ)radius;  // in (0, 2r) when |delta| < r
+                    const bool inr = (UQ)(shifted - 1) < (UQ)(2 * radius - 1);
+                    code[i] = inr ? (uint32_t)shifted : 0u;
+                    uint32_t bin = code[i] - win_lo;           // wraps to a huge value below the window
+                    bin = bin < (uint32_t)HIST_WIN ? bin : (uint32_t)HIST_WIN;
+                    mx = mx > bin ? mx : bin;
+                    atomicAdd(&lh[bin * 4 + copy], 1u);
+                }
+                const uint64_t gi = (uint64_t)w * vol + (uint64_t)gz * plane + (uint64_t)gy * d0 + x;
+                uint2 pk;
+                pk.x = code[0] | (code[1] << 16);
+                pk.y = code[2] | (code[3] << 16);
+                *reinterpret_cast<uint2 *>(codes + gi) = pk;
+                if (mx >= (uint32_t)HIST_WIN || badmask) {  // rare: outliers, codes outside the LDS histogram window
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (code[i] == 0) {
+                            unsigned long long pos = atomicAdd((unsigned long long *)p.n_dout, 1ull);
+                            if (pos < p.out_cap) {
+                                p.dout_idx[pos] = gi + i;
+                                ((Q *)p.dout_val)[pos] = (Q)delta[i];
+                            }
+                        }
+                        if ((badmask >> i) & 1u) {
+                            unsigned long long pos = atomicAdd((unsigned long long *)p.n_vout, 1ull);
+                            if (pos < p.out_cap) {
+                                p.vout_idx[pos] = gi + i;
+                                ((T *)p.vout_val)[pos] = in[gi + i];
+                            }
+                        }
+                        if (code[i] - win_lo >= (uint32_t)HIST_WIN)
+                            atomicAdd((unsigned long long *)&p.hist[code[i]], 1ull);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *row = p.hist_partial + (uint64_t)blockIdx.x * HIST_WIN;
+    for (int bnn = threadIdx.x; bnn < HIST_WIN; bnn += 256)
+        row[bnn] = lh[bnn * 4] + lh[bnn * 4 + 1] + lh[bnn * 4 + 2] + lh[bnn * 4 + 3];
+}
+
+// folds the per-workgroup histogram rows into hist[win_lo + bin]: block (bx, by) sums rows by, by + gridDim.y, ... of
+// 256 bins and adds its partial sum with one 64-bit atomic per non-empty bin (at most gridDim.y atomics per address)
 __global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict__ partial, uint32_t nrows, int win_lo,
                                                      uint64_t *__restrict__ hist) {
     const int bin = blockIdx.x * 256 + threadIdx.x;
     if (bin >= HIST_WIN) return;
     uint64_t s = 0;
-    for (uint32_t r = 0; r < nrows; r++) s += partial[(uint64_t)r * HIST_WIN + bin];
+    for (uint32_t r = blockIdx.y; r < nrows; r += gridDim.y) s += partial[(uint64_t)r * HIST_WIN + bin];
     const int sym = win_lo + bin;
-    if (s && sym >= 0 && sym < (int)SZH_HIST_BINS) hist[sym] += s;
+    if (s && sym >= 0 && sym < (int)SZH_HIST_BINS) atomicAdd((unsigned long long *)&hist[sym], (unsigned long long)s);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1365,6 +1651,25 @@ int szk_launch_minmax(int dtype, const void *d_in, uint64_t n, double *d_partial
 }
 
 int szk_force_generic = 0;  // test hook: route every shape through the generic kernel
+int szk_dbg_flags = 0;     // ablation switches (tools/k1_lab.py)
+
+// persistent grid = resident workgroups of the kernel on this device (occupancy API x CU count), capped by the
+// number of hist_partial rows and by the tile count
+static uint32_t k1_grid(const void *kernel, uint64_t ntiles) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    uint64_t g = (uint64_t)per_cu * (uint64_t)n_cu;
+    if (g > SZK_K1_GRID) g = SZK_K1_GRID;
+    if (g > ntiles) g = ntiles;
+    return (uint32_t)(g ? g : 1);
+}
 
 template <typename T>
 static int launch_k1(int ndim, const void *d_in, uint16_t *codes, const szk_k1_params &p, hipStream_t s) {
@@ -1377,6 +1682,8 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, const szk_k1_p
     // tuned kernel: quads need x % 4 == 0; 32-bit in-tile offsets need (TZ+1) planes < 2^31 elements; tile count < 2^31
     const bool fast = !szk_force_generic && (d0 % 4 == 0) && d0 < (1ull << 31) && d1 < (1ull << 31) && d2 < (1ull << 31) &&
                       d0 * d1 < (1ull << 27) && tiles(64, 8, FTZ) < (1ull << 31);
+    constexpr int MTY = 4;
+    const bool march = fast && !(szk_dbg_flags & 32) && d0 >= 128 && tiles(MARCH_TX, MTY, MARCH_TZ) < (1ull << 31);
     switch (ndim) {
         case 1:
             nb = tiles(4096, 1, 1);
@@ -1389,11 +1696,18 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, const szk_k1_p
             hipLaunchKernelGGL((k_lorenzo_quant<T, 2, 128, 32, 1>), dim3((uint32_t)nb), dim3(256), 0, s, (const T *)d_in, codes, p);
             break;
         case 3:
+            if (march) {
+                nb = tiles(MARCH_TX, MTY, MARCH_TZ);  // wave tasks
+                uint32_t grid = k1_grid((const void *)k_lorenzo_quant_march<T, 3, MTY>, (nb + 3) / 4);
+                hipLaunchKernelGGL((k_lorenzo_quant_march<T, 3, MTY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
+                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+                break;
+            }
             if (fast) {
                 nb = tiles(64, 8, FTZ);
-                const uint32_t grid = (uint32_t)(nb < SZK_K1_GRID ? nb : SZK_K1_GRID);
+                const uint32_t grid = k1_grid((const void *)k_lorenzo_quant_v4<T, 3, FTZ>, nb);
                 hipLaunchKernelGGL((k_lorenzo_quant_v4<T, 3, FTZ>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
-                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
                 break;
             }
             nb = tiles(64, 8, 8);
@@ -1401,11 +1715,18 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, const szk_k1_p
             hipLaunchKernelGGL((k_lorenzo_quant<T, 3, 64, 8, 8>), dim3((uint32_t)nb), dim3(256), 0, s, (const T *)d_in, codes, p);
             break;
         default:
+            if (march) {
+                nb = tiles(MARCH_TX, MTY, MARCH_TZ);  // wave tasks
+                uint32_t grid = k1_grid((const void *)k_lorenzo_quant_march<T, 4, MTY>, (nb + 3) / 4);
+                hipLaunchKernelGGL((k_lorenzo_quant_march<T, 4, MTY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
+                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+                break;
+            }
             if (fast) {
                 nb = tiles(64, 8, FTZ);
-                const uint32_t grid = (uint32_t)(nb < SZK_K1_GRID ? nb : SZK_K1_GRID);
+                const uint32_t grid = k1_grid((const void *)k_lorenzo_quant_v4<T, 4, FTZ>, nb);
                 hipLaunchKernelGGL((k_lorenzo_quant_v4<T, 4, FTZ>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
-                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
                 break;
             }
             nb = tiles(64, 8, 4);
@@ -1417,7 +1738,9 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, const szk_k1_p
     return 0;
 }
 int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, const szk_k1_params *p, hipStream_t s) {
-    return dtype == 0 ? launch_k1<float>(ndim, d_in, codes, *p, s) : launch_k1<double>(ndim, d_in, codes, *p, s);
+    szk_k1_params pp = *p;
+    pp.dbg = (uint32_t)szk_dbg_flags;
+    return dtype == 0 ? launch_k1<float>(ndim, d_in, codes, pp, s) : launch_k1<double>(ndim, d_in, codes, pp, s);
 }
 
 int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStream_t s) {

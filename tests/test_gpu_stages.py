@@ -46,6 +46,11 @@ CASES = [
     ("3d-fast-f64", lambda: field3d((21, 30, 36), np.float64, sigma=2e-6), 1e-6),
     ("4d-fast", lambda: field4d((5, 11, 13, 16)), 1e-2),
     ("4d-fast-f64", lambda: field4d((3, 6, 10, 68), np.float64), 1e-3),
+    ("3d-march", lambda: field3d((19, 13, 132)), 1e-3),
+    ("3d-march-wide", lambda: field3d((35, 9, 520)), 1e-4),
+    ("3d-march-f64", lambda: field3d((18, 7, 260), np.float64, sigma=2e-6), 1e-6),
+    ("4d-march", lambda: field4d((3, 5, 7, 128)), 1e-2),
+    ("4d-march-f64", lambda: field4d((2, 18, 5, 264), np.float64), 1e-3),
     ("3d-smooth", lambda: field3d((40, 40, 40), sigma=0.0), 1e-1),
     ("3d-const", lambda: np.full((17, 19, 23), 3.25, np.float32), 1e-3),
 ]
@@ -108,7 +113,8 @@ def test_outliers_and_nonfinite():
     assert np.max(np.abs(dec[fin].astype(np.float64) - a[fin].astype(np.float64))) <= eb
 
 
-@pytest.mark.parametrize("shape,dtype", [((19, 26, 68), np.float32), ((9, 17, 64), np.float64), ((3, 9, 11, 72), np.float32)])
+@pytest.mark.parametrize("shape,dtype", [((19, 26, 68), np.float32), ((9, 17, 64), np.float64), ((3, 9, 11, 72), np.float32),
+                                         ((33, 10, 260), np.float32), ((2, 17, 6, 132), np.float64)])
 def test_fast_kernel_equals_generic(shape, dtype):
     """the tuned stage-1 kernel and the any-shape kernel must emit identical codes, outliers and payloads"""
     a = (field3d(shape, dtype) if len(shape) == 3 else field4d(shape, dtype))

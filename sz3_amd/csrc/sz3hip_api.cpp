@@ -370,7 +370,8 @@ struct sz3hip_ctx {
     uint32_t *d_enc;
     uint8_t *d_lens;
     uint64_t *d_keys, *d_ifreq;
-    uint16_t *d_syms, *d_pleaf, *d_pint, *d_depth;
+    uint16_t *d_syms, *d_pleaf, *d_pint, *d_depth, *d_aux2, *d_pint2;
+    uint32_t *d_range;
     szk_cb_info *d_info;
     uint16_t *d_chunk_words;
     uint64_t *d_chunk_off;
@@ -393,7 +394,7 @@ struct sz3hip_ctx {
 static void ctx_free(sz3hip_ctx *c) {
     if (!c) return;
     void *bufs[] = {c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_counters, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
-                    c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_info,
+                    c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_aux2, c->d_pint2, c->d_range, c->d_info,
                     c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -448,6 +449,9 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     alloc((void **)&c->d_pleaf, SZH_HIST_BINS * 2);
     alloc((void **)&c->d_pint, SZH_HIST_BINS * 2);
     alloc((void **)&c->d_depth, SZH_HIST_BINS * 2);
+    alloc((void **)&c->d_aux2, SZH_HIST_BINS * 2);
+    alloc((void **)&c->d_pint2, SZH_HIST_BINS * 2);
+    alloc((void **)&c->d_range, 16);
     alloc((void **)&c->d_info, sizeof(szk_cb_info));
     alloc((void **)&c->d_chunk_words, (c->max_chunks + 8) * 2);
     alloc((void **)&c->d_chunk_off, (c->max_chunks + 8) * 8);
@@ -596,6 +600,9 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     cb.pleaf = ctx->d_pleaf;
     cb.pint = ctx->d_pint;
     cb.depth = ctx->d_depth;
+    cb.aux2 = ctx->d_aux2;
+    cb.pint2 = ctx->d_pint2;
+    cb.range = ctx->d_range;
     cb.info = ctx->d_info;
     prof_begin(ctx, ST_CODEBOOK, s);
     int rc = szk_launch_codebook(ctx->d_hist, &cb, s);
@@ -611,7 +618,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     prof_end(ctx, ST_CODEBOOK, s);
     if (rc) return fail(SZ3HIP_EHIP, "layout kernel launch failed (%d)", rc);
     prof_begin(ctx, ST_ENCODE, s);
-    rc = szk_launch_encode(ctx->d_codes, n, ctx->d_enc, (int)ctx->proto.radius, ctx->d_chunk_words, ctx->d_chunk_off,
+    rc = szk_launch_encode(ctx->d_codes, n, ctx->d_enc, ctx->d_info, (int)ctx->proto.radius, ctx->d_chunk_words, ctx->d_chunk_off,
                            ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, s);
     prof_end(ctx, ST_ENCODE, s);
     if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
@@ -682,6 +689,15 @@ extern "C" int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, ui
 
 extern "C" void sz3hip_debug_force_generic(int on) { szk_force_generic = on; }
 extern "C" void sz3hip_debug_flags(int flags) { szk_dbg_flags = flags; }
+extern "C" int sz3hip_debug_codebook_info(sz3hip_ctx *ctx, uint64_t *out16) {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    szk_cb_info info;
+    HIPCHK(hipMemcpy(&info, ctx->d_info, sizeof(info), hipMemcpyDeviceToHost));
+    out16[0] = info.n_symbols; out16[1] = info.max_len; out16[2] = info.sym_min; out16[3] = info.sym_count;
+    for (int i = 0; i < 12; i++) out16[4 + i] = info.ts[i];
+    return 0;
+}
 
 extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, size_t payload_size, void *d_out,
                                         void *stream) {

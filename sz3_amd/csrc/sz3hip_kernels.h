@@ -40,6 +40,7 @@ struct szk_k1_params {
 
 struct szk_cb_info {
     uint32_t n_symbols, max_len, sym_min, sym_count;
+    uint64_t ts[12];  // phase timestamps (wall_clock64, 100 MHz) for tools/cb_lab.py
 };
 struct szk_cb_params {
     uint32_t *enc;   // [65536] (code << 5) | len
@@ -47,7 +48,8 @@ struct szk_cb_params {
     uint64_t *keys;  // [65536] scratch (freq << 16 | sym)
     uint16_t *syms;  // [65536] compacted alphabet in symbol order
     uint64_t *ifreq;
-    uint16_t *pleaf, *pint, *depth;  // [65536] scratch for alphabets > 2048 symbols
+    uint16_t *pleaf, *pint, *depth, *aux2, *pint2;  // [65536] scratch for alphabets > 2048 symbols
+    uint32_t *range;                 // [4] see k_hist_range
     szk_cb_info *info;
 };
 
@@ -92,8 +94,9 @@ int szk_launch_minmax(int dtype, const void *d_in, uint64_t n, double *d_partial
 int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, const szk_k1_params *p, hipStream_t s);
 int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStream_t s);
 int szk_launch_layout_pre(const szk_layout_params *p, hipStream_t s);
-int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, int radius, uint16_t *chunk_words,
-                      uint64_t *lb_state /*[n_chunks/4 + 2]*/, uint64_t *total_words, const szk_state *state, uint8_t *payload, hipStream_t s);
+int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
+                      uint16_t *chunk_words, uint64_t *group_off /*[n_chunks/32 + 1]*/, uint64_t *total_words,
+                      const szk_state *state, uint8_t *payload, hipStream_t s);
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, hipStream_t s);
 int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t *codes, uint64_t *chunk_off,

@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict_
 // ------------------------------------------------------------------------------------------------------------
 // K5: canonical length-limited Huffman codebook, one 1024-thread workgroup.
 // ------------------------------------------------------------------------------------------------------------
-#define CB_THREADS 1024
+#define CB_THREADS 256
 #define CB_LDS_SYMS 2048
 
 __device__ void cb_bitonic_sort(uint64_t *keys, uint32_t npow2) {  // ascending; keys in LDS or global
@@ -816,11 +816,13 @@ __device__ void cb_bitonic_sort(uint64_t *keys, uint32_t npow2) {  // ascending;
 }
 
 // Two-queue Huffman merge over leaves sorted by ascending frequency (keys = freq << 16 | sym). Serial (thread 0);
-// the two queue heads are kept in registers so that every merge costs two dependent memory reads.
+// both queue heads AND their successors are kept in registers, so the LDS latency of fetching the next element
+// overlaps the following merge step instead of stalling it.
 __device__ void cb_merge(const uint64_t *keys, uint64_t *ifreq, uint16_t *pleaf, uint16_t *pint, uint32_t m) {
     const uint64_t INF = ~0ull;
     uint32_t i = 0, j = 0;
-    uint64_t lf = keys[0] >> 16, nf = INF;
+    uint64_t lf = keys[0] >> 16, lf_next = m > 1 ? keys[1] >> 16 : INF;  // leaf queue: head, head + 1
+    uint64_t nf = INF, nf_next = INF;                                     // internal queue: head, head + 1
     for (uint32_t k = 0; k + 1 < m; k++) {
         uint64_t f = 0;
 #pragma unroll
@@ -828,39 +830,65 @@ __device__ void cb_merge(const uint64_t *keys, uint64_t *ifreq, uint16_t *pleaf,
             if (lf <= nf) {  // ties prefer the leaf; INF marks an exhausted / empty queue
                 f += lf;
                 pleaf[i++] = (uint16_t)k;
-                lf = i < m ? keys[i] >> 16 : INF;
+                lf = lf_next;
+                lf_next = i + 1 < m ? keys[i + 1] >> 16 : INF;
             } else {
                 f += nf;
                 pint[j++] = (uint16_t)k;
-                nf = j < k ? ifreq[j] : INF;
+                nf = nf_next;
+                nf_next = j + 1 < k ? ifreq[j + 1] : INF;  // nodes < k exist; node k is appended below
             }
         }
         ifreq[k] = f;
-        if (j == k) nf = f;  // the node just created becomes the head of the internal queue
+        // node k joins the tail of the internal queue: it is the head if the queue was empty, the successor if
+        // exactly one element was pending
+        if (j == k) nf = f;
+        else if (j + 1 == k) nf_next = f;
     }
 }
 
-// Kraft repair after clamping code lengths to SZH_MAX_LEN (serial, rare): lengthen the longest codes that are still
-// shorter than the limit until sum 2^-len <= 1.
+// Kraft repair after clamping code lengths to SZH_MAX_LEN (serial, O(m)): leaves are sorted by ascending frequency
+// and Huffman lengths never increase along that order, so the cheapest leaf to lengthen (least frequent among the
+// longest codes still below the limit) is always the first leaf whose length is below the limit.
 __device__ void cb_kraft_repair(uint16_t *len_sorted, uint32_t m, uint32_t *cnt) {
     uint64_t kraft = 0;
     for (uint32_t l = 1; l <= SZH_MAX_LEN; l++) kraft += (uint64_t)cnt[l] << (SZH_MAX_LEN - l);
     const uint64_t budget = 1ull << SZH_MAX_LEN;
+    uint32_t q0 = 0;
     while (kraft > budget) {
-        int best = -1;
-        uint32_t bestl = 0;
-        for (uint32_t q = 0; q < m; q++) {  // leaves are sorted by ascending frequency: first hit = least frequent
-            uint32_t l = len_sorted[q];
-            if (l < SZH_MAX_LEN && l > bestl) {
-                bestl = l;
-                best = (int)q;
-            }
-        }
-        if (best < 0) break;
-        len_sorted[best] = (uint16_t)(bestl + 1);
-        cnt[bestl]--;
-        cnt[bestl + 1]++;
-        kraft -= 1ull << (SZH_MAX_LEN - bestl - 1);
+        while (q0 < m && len_sorted[q0] >= SZH_MAX_LEN) q0++;
+        if (q0 == m) break;  // cannot happen for m <= 2^SZH_MAX_LEN
+        const uint32_t l = len_sorted[q0];
+        len_sorted[q0] = (uint16_t)(l + 1);
+        cnt[l]--;
+        cnt[l + 1]++;
+        kraft -= 1ull << (SZH_MAX_LEN - l - 1);
+    }
+    // give back what the last step freed beyond the need: shorten the most frequent codes of maximal length
+    uint32_t qe = m;
+    while (kraft < budget) {
+        while (qe > 0 && len_sorted[qe - 1] != SZH_MAX_LEN) qe--;
+        if (qe == 0) break;
+        len_sorted[qe - 1] = (uint16_t)(SZH_MAX_LEN - 1);  // costs one unit
+        cnt[SZH_MAX_LEN]--;
+        cnt[SZH_MAX_LEN - 1]++;
+        kraft += 1;
+        qe--;
+    }
+}
+
+// range of the non-empty histogram bins, many workgroups: range[0] = max(65535 - bin), range[1] = max(bin),
+// range[2] = count of non-empty bins (all three start at 0 and only grow)
+__global__ __launch_bounds__(256) void k_hist_range(const uint64_t *__restrict__ hist, uint32_t *range) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;  // 256 workgroups x 256 bins
+    const bool nz = hist[i] != 0;
+    const unsigned long long m = __ballot(nz);
+    if (m && lane_id() == 0) {
+        const uint32_t base = i;  // lane 0's bin
+        const uint32_t lo = base + (uint32_t)__ffsll((long long)m) - 1, hi = base + 63u - (uint32_t)__clzll((long long)m);
+        atomicMax(&range[0], 0xFFFFu - lo);
+        atomicMax(&range[1], hi);
+        atomicAdd(&range[2], (uint32_t)__popcll(m));
     }
 }
 
@@ -868,31 +896,22 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
     __shared__ uint64_t s_keys[CB_LDS_SYMS];
     __shared__ uint64_t s_ifreq[CB_LDS_SYMS];
     __shared__ uint16_t s_pleaf[CB_LDS_SYMS], s_pint[CB_LDS_SYMS], s_aux[CB_LDS_SYMS], s_syms[CB_LDS_SYMS];
+    __shared__ uint16_t s_aux2[CB_LDS_SYMS], s_pint2[CB_LDS_SYMS];
     __shared__ uint32_t s_wtot[CB_THREADS / WAVE];
     __shared__ uint32_t s_lo, s_hi, s_over;
     __shared__ uint32_t s_first[SZH_MAX_LEN + 2], s_cnt[SZH_MAX_LEN + 2];
     const uint32_t t = threadIdx.x;
 
-    // 0. range of the non-empty bins (coalesced sweep over the 65536 counters)
+    if (t == 0) p.info->ts[0] = wall_clock64();
+    if (t == 0) p.info->ts[0] = wall_clock64();
+    // 0. range of the non-empty bins: found by k_hist_range (256 workgroups) just before this launch
     if (t == 0) {
-        s_lo = 0xFFFFFFFFu;
-        s_hi = 0;
+        s_lo = 0xFFFFu - p.range[0];  // range[0] = max over bins of (65535 - bin), range[1] = max bin, both via atomicMax
+        s_hi = p.range[1];
         s_over = 0;
+        if (p.range[2] == 0) s_lo = 0xFFFFFFFFu;  // range[2] = number of non-empty bins seen (0 = empty histogram)
     }
     if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
-    __syncthreads();
-    {
-        uint32_t lo = 0xFFFFFFFFu, hi = 0;
-        for (uint32_t i = t; i < SZH_HIST_BINS; i += CB_THREADS)
-            if (hist[i]) {
-                lo = lo < i ? lo : i;
-                hi = hi > i ? hi : i;
-            }
-        if (lo != 0xFFFFFFFFu) {
-            atomicMin(&s_lo, lo);
-            atomicMax(&s_hi, hi);
-        }
-    }
     __syncthreads();
     if (s_lo == 0xFFFFFFFFu) {
         if (t == 0) {
@@ -927,6 +946,8 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
     uint16_t *pint = small ? s_pint : p.pint;
     uint16_t *aux = small ? s_aux : p.depth;
     uint16_t *syms = small ? s_syms : p.syms;
+    uint16_t *aux2 = small ? s_aux2 : p.aux2;
+    uint16_t *pint2 = small ? s_pint2 : p.pint2;
     for (uint32_t i = t * per; i < range && i < (t + 1) * per; i++) {
         uint64_t f = hist[lo + i];
         if (f) {
@@ -940,9 +961,29 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
     __syncthreads();
     for (uint32_t i = m + t; i < npow2; i += CB_THREADS) keys[i] = ~0ull;
     __syncthreads();
-    // 2. sort by (freq, sym)
-    cb_bitonic_sort(keys, npow2);
+    if (t == 0) p.info->ts[2] = wall_clock64();
+    // 2. sort by (freq, sym): rank sort for small alphabets (every thread counts the keys below its own; LDS
+    //    broadcast reads), bitonic otherwise
+    if (m <= 512) {
+        uint64_t mykey[2];
+        uint32_t myrank[2];
+        for (int c = 0; c < 2; c++) {
+            const uint32_t q = t + c * CB_THREADS;
+            mykey[c] = q < m ? keys[q] : ~0ull;
+            uint32_t r = 0;
+            if (q < m)
+                for (uint32_t o = 0; o < m; o++) r += keys[o] < mykey[c];  // keys are distinct (symbol in the low bits)
+            myrank[c] = r;
+        }
+        __syncthreads();
+        for (int c = 0; c < 2; c++)
+            if (t + c * CB_THREADS < m) keys[myrank[c]] = mykey[c];
+        __syncthreads();
+    } else {
+        cb_bitonic_sort(keys, npow2);
+    }
 
+    if (t == 0) p.info->ts[3] = wall_clock64();
     uint32_t max_len = 0;
     if (m == 1) {
         // single symbol: zero-length code, empty bit-stream (as encoder/HuffmanEncoder.hpp:233-237)
@@ -950,6 +991,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
         // 3. merge (serial) ...
         if (t == 0) cb_merge(keys, ifreq, pleaf, pint, m);
         __syncthreads();
+        if (t == 0) p.info->ts[4] = wall_clock64();
         // 4. ... depth of every internal node: distance to the root (node m-2) by pointer doubling
         //    aux[q] = distance so far, pint[q] = current ancestor pointer
         for (uint32_t q = t; q + 1 < m; q += CB_THREADS) {
@@ -957,23 +999,24 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
             aux[q] = q == m - 2 ? 0 : 1;
         }
         __syncthreads();
-        for (uint32_t span = 1; span < m; span <<= 1) {
+        // after r rounds aux[q] = min(depth, 2^r): 2^r >= SZH_MAX_LEN is all the clamp below needs
+        for (uint32_t span = 1; span < m && span < 2 * SZH_MAX_LEN; span <<= 1) {
             // every thread handles q = t, t + 1024, ... ; two-phase (read, barrier, write) per round
-            uint16_t nd[(65536 + CB_THREADS - 1) / CB_THREADS], nj[(65536 + CB_THREADS - 1) / CB_THREADS];
-            int c = 0;
-            for (uint32_t q = t; q + 1 < m; q += CB_THREADS, c++) {
-                uint16_t j = pint[q];
-                nd[c] = (uint16_t)(aux[q] + aux[j]);
-                nj[c] = pint[j];
+            // ping-pong between (aux, pint) and (aux2, pint2) instead of buffering in registers
+            for (uint32_t q = t; q + 1 < m; q += CB_THREADS) {
+                const uint16_t j = pint[q];
+                const uint32_t sum = (uint32_t)aux[q] + aux[j];
+                aux2[q] = (uint16_t)(sum > 0xFFFFu ? 0xFFFFu : sum);
+                pint2[q] = pint[j];
             }
             __syncthreads();
-            c = 0;
-            for (uint32_t q = t; q + 1 < m; q += CB_THREADS, c++) {
-                aux[q] = nd[c];
-                pint[q] = nj[c];
+            for (uint32_t q = t; q + 1 < m; q += CB_THREADS) {
+                aux[q] = aux2[q];
+                pint[q] = pint2[q];
             }
             __syncthreads();
         }
+        if (t == 0) p.info->ts[5] = wall_clock64();
         // 5. leaf lengths (sorted position q), clamp to SZH_MAX_LEN, per-length counts
         for (uint32_t q = t; q < m; q += CB_THREADS) {
             uint32_t l = (uint32_t)aux[pleaf[q]] + 1;
@@ -997,6 +1040,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
                 s_first[l] = code;
             }
         }
+        if (t == 0) p.info->ts[6] = wall_clock64();
         // 7. scatter the lengths back to symbol order: aux[idx] = length of the idx-th symbol (syms[] is ascending)
         __syncthreads();
         for (uint32_t q = t; q < m; q += CB_THREADS) {
@@ -1011,6 +1055,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
             p.lens[sym] = (uint8_t)l;
         }
         __syncthreads();
+        if (t == 0) p.info->ts[7] = wall_clock64();
         // 8. codes in (len, symbol) order: rank among the earlier symbols of the same length
         if (small) {
             for (uint32_t q = t; q < m; q += CB_THREADS) {
@@ -1029,6 +1074,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
             if (s_cnt[l]) max_len = l;
     }
     if (t == 0) {
+        p.info->ts[8] = wall_clock64();
         p.info->n_symbols = m;
         p.info->max_len = max_len;
         p.info->sym_min = lo;
@@ -1367,6 +1413,160 @@ __global__ __launch_bounds__(256) void k_encode_fused(const uint16_t *__restrict
             __builtin_amdgcn_wave_barrier();
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K6, split form (default): three plain streaming launches, no inter-workgroup dependency.
+//   k_chunk_bits2   words per 1024-symbol chunk                      (reads the codes once)
+//   k_scan_groups   exclusive word offset of every group of 32 chunks (one workgroup, 4 KiB of offsets per 4M symbols)
+//   k_pack          bit-pack: one wave per chunk, 16 symbols per lane; with code words <= 16 bit four of them always
+//                   fit one 64-bit register, so a lane emits 4 registers at its bit offset (wave prefix sum) with
+//                   three ds_or each into a zeroed LDS stage; the wave then streams the words out coalesced.
+// The code table is LDS-resident for alphabets up to ENC_WIN symbols (sym_min .. sym_min + sym_count), which is
+// every realistic case; wider alphabets take the per-symbol global lookup.
+// ------------------------------------------------------------------------------------------------------------
+#define PACK_GROUP 32  // chunks per offset group
+
+__device__ __forceinline__ uint32_t enc_lookup2(const uint32_t *s_enc, const uint32_t *__restrict__ g_enc,
+                                                uint32_t sym_min, bool all_lds, uint32_t sym) {
+    const uint32_t rel = sym - sym_min;
+    if (all_lds) return s_enc[rel & (ENC_WIN - 1)];
+    return rel < ENC_WIN ? s_enc[rel] : g_enc[sym];
+}
+__device__ __forceinline__ void enc_table_load(uint32_t *s_enc, const uint32_t *__restrict__ g_enc, uint32_t sym_min,
+                                               uint32_t sym_count) {
+    const uint32_t cnt = sym_count < ENC_WIN ? sym_count : ENC_WIN;
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) s_enc[i] = g_enc[sym_min + i];
+}
+
+__global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict__ codes, uint64_t n,
+                                                     const uint32_t *__restrict__ g_enc,
+                                                     const szk_cb_info *__restrict__ info,
+                                                     uint16_t *__restrict__ chunk_words) {
+    __shared__ uint32_t s_enc[ENC_WIN];
+    const uint32_t sym_min = info->sym_min, sym_count = info->sym_count;
+    const bool all_lds = sym_count <= ENC_WIN;
+    enc_table_load(s_enc, g_enc, sym_min, sym_count);
+    __syncthreads();
+    const uint64_t chunk = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE;
+    if (chunk * SZH_CHUNK_SYMS >= n) return;
+    const uint64_t base = chunk * SZH_CHUNK_SYMS + (uint64_t)lane_id() * ENC_PER_LANE;
+    uint16_t c[ENC_PER_LANE];
+    load_codes16(codes, base, n, c);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < ENC_PER_LANE; i++) {
+        const uint32_t e = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[i]);
+        bits += (base + i < n) ? (e & 31u) : 0u;
+    }
+    bits = wave_sum(bits);
+    if (lane_id() == 0) chunk_words[chunk] = (uint16_t)((bits + 31) >> 5);
+}
+
+__global__ __launch_bounds__(1024) void k_scan_groups(const uint16_t *__restrict__ chunk_words, uint64_t n_chunks,
+                                                      uint64_t *__restrict__ group_off, uint64_t *total_words) {
+    __shared__ uint64_t s_w[16];
+    __shared__ uint64_t s_carry;
+    const uint64_t n_groups = (n_chunks + PACK_GROUP - 1) / PACK_GROUP;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    // sweep: 1024 consecutive groups per round, one group (32 x u16 = four 16-byte loads) per thread
+    for (uint64_t g0 = 0; g0 < n_groups; g0 += 1024) {
+        const uint64_t g = g0 + threadIdx.x;
+        uint64_t sum = 0;
+        if (g < n_groups) {
+            const uint64_t c0 = g * PACK_GROUP;
+            if (c0 + PACK_GROUP <= n_chunks) {
+                const uint4 *v = reinterpret_cast<const uint4 *>(chunk_words + c0);
+                uint4 q[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    sum += (q[k].x & 0xFFFF) + (q[k].x >> 16) + (q[k].y & 0xFFFF) + (q[k].y >> 16) + (q[k].z & 0xFFFF) +
+                           (q[k].z >> 16) + (q[k].w & 0xFFFF) + (q[k].w >> 16);
+            } else {
+                for (uint64_t c = c0; c < n_chunks; c++) sum += chunk_words[c];
+            }
+        }
+        const uint64_t incl = wave_incl_scan(sum);
+        if (lane_id() == WAVE - 1) s_w[threadIdx.x / WAVE] = incl;
+        __syncthreads();
+        uint64_t run = s_carry + incl - sum, tot = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < (int)(threadIdx.x / WAVE)) run += s_w[w];
+            tot += s_w[w];
+        }
+        if (g < n_groups) group_off[g] = run;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_words = s_carry;
+}
+
+__global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes, uint64_t n,
+                                              const uint32_t *__restrict__ g_enc, const szk_cb_info *__restrict__ info,
+                                              const uint16_t *__restrict__ chunk_words,
+                                              const uint64_t *__restrict__ group_off,
+                                              const szk_state *__restrict__ state, uint8_t *__restrict__ payload) {
+    constexpr int STAGE_WORDS = SZH_CHUNK_SYMS * SZH_MAX_LEN / 32 + 4;  // + slack for the unconditional 3-word emit
+    __shared__ uint32_t s_enc[ENC_WIN];
+    __shared__ uint32_t s_stage[4][STAGE_WORDS];
+    const uint32_t sym_min = info->sym_min, sym_count = info->sym_count;
+    const bool all_lds = sym_count <= ENC_WIN;
+    enc_table_load(s_enc, g_enc, sym_min, sym_count);
+    const int wv = threadIdx.x / WAVE;
+    uint32_t *stage = s_stage[wv];
+    for (int i = lane_id(); i < STAGE_WORDS; i += WAVE) stage[i] = 0;
+    __syncthreads();
+    const uint64_t chunk = (uint64_t)blockIdx.x * 4 + wv;
+    if (chunk * SZH_CHUNK_SYMS >= n) return;
+    const uint64_t base = chunk * SZH_CHUNK_SYMS + (uint64_t)lane_id() * ENC_PER_LANE;
+    uint16_t c[ENC_PER_LANE];
+    load_codes16(codes, base, n, c);
+    // word offset of this chunk: group base + the chunks before it inside the group
+    const uint64_t grp = chunk / PACK_GROUP;
+    const uint32_t cin = (uint32_t)(chunk % PACK_GROUP);
+    uint32_t before = (uint32_t)lane_id() < cin ? chunk_words[grp * PACK_GROUP + lane_id()] : 0u;
+    before = wave_sum(before);
+    // 4 x (4 code words -> one 64-bit register)
+    uint64_t g[4];
+    uint32_t gl[4];
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint64_t acc = 0;
+        uint32_t len = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t e = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[4 * k + i]);
+            e = (base + 4 * k + i < n) ? e : 0u;
+            const uint32_t l = e & 31u;
+            acc = (acc << l) | (uint64_t)(e >> 5);
+            len += l;
+        }
+        g[k] = acc;
+        gl[k] = len;
+        bits += len;
+    }
+    const uint32_t incl = wave_incl_scan(bits);
+    const uint32_t total_bits = __shfl(incl, WAVE - 1, WAVE);
+    uint32_t pos = incl - bits;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint64_t v = gl[k] ? g[k] << (64 - gl[k]) : 0ull;  // left-aligned
+        const uint32_t word = pos >> 5, sh = pos & 31;
+        const uint64_t t = v >> sh;
+        const uint32_t w2 = (uint32_t)(((uint64_t)(uint32_t)v << 32) >> sh);
+        atomicOr(&stage[word], (uint32_t)(t >> 32));
+        atomicOr(&stage[word + 1], (uint32_t)t);
+        atomicOr(&stage[word + 2], w2);
+        pos += gl[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nwords = (total_bits + 31) >> 5;
+    uint32_t *out = reinterpret_cast<uint32_t *>(payload + state->off.bitstream) + group_off[grp] + before;
+    for (uint32_t i = lane_id(); i < nwords; i += WAVE) out[i] = stage[i];
 }
 
 // header + side sections (lens, chunk table, outliers) into the payload
@@ -1744,6 +1944,9 @@ int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, const 
 }
 
 int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(p->range, 0, 16, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256), dim3(256), 0, s, d_hist, p->range);
     hipLaunchKernelGGL(k_codebook, dim3(1), dim3(CB_THREADS), 0, s, d_hist, *p);
     SZK_CHECK_LAUNCH();
     return 0;
@@ -1753,18 +1956,16 @@ int szk_launch_layout_pre(const szk_layout_params *p, hipStream_t s) {
     SZK_CHECK_LAUNCH();
     return 0;
 }
-int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, int radius, uint16_t *chunk_words,
-                      uint64_t *lb_state, uint64_t *total_words, const szk_state *state, uint8_t *payload,
-                      hipStream_t s) {
+int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
+                      uint16_t *chunk_words, uint64_t *group_off, uint64_t *total_words, const szk_state *state,
+                      uint8_t *payload, hipStream_t s) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
-    const uint64_t n_batches = (n_chunks + ENC_BATCH_CHUNKS - 1) / ENC_BATCH_CHUNKS;
-    if (n_batches > 0x7FFFFFFFull) return -1;
-    // lb_state[0 .. n_batches) look-back records, lb_state[n_batches] the ticket counter: zeroed before every launch
-    hipError_t e = hipMemsetAsync(lb_state, 0, (n_batches + 1) * 8, s);
-    if (e != hipSuccess) return (int)e;
-    const uint32_t grid = (uint32_t)(n_batches < 1280 ? n_batches : 1280);  // any grid size is deadlock-free
-    hipLaunchKernelGGL(k_encode_fused, dim3(grid), dim3(256), 0, s, codes, n, d_enc, radius, chunk_words,
-                       (unsigned long long *)lb_state, (unsigned int *)(lb_state + n_batches), total_words, state, payload);
+    const uint64_t nb = (n_chunks + 3) / 4;
+    if (nb > 0x7FFFFFFFull) return -1;
+    (void)radius;
+    hipLaunchKernelGGL(k_chunk_bits2, dim3((uint32_t)nb), dim3(256), 0, s, codes, n, d_enc, info, chunk_words);
+    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, chunk_words, n_chunks, group_off, total_words);
+    hipLaunchKernelGGL(k_pack, dim3((uint32_t)nb), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, state, payload);
     SZK_CHECK_LAUNCH();
     return 0;
 }

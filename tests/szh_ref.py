@@ -8,7 +8,7 @@ import numpy as np
 
 MAGIC = 0x31485A53
 CHUNK = 1024
-MAX_LEN = 24
+MAX_LEN = 16
 
 
 def dualquant(a, eb, radius=32768):

@@ -73,20 +73,25 @@ def test_stages(name, gen, eb):
     assert set(h["sym_min"] + np.nonzero(lens)[0]) == (set(present.tolist()) if len(present) > 1 else set())
     if len(present) > 1:
         assert abs(szh_ref.kraft(lens) - 1.0) < 1e-9 and lens.max() == h["max_len"] <= szh_ref.MAX_LEN
-        # optimality: total bits equal to an independent Huffman construction
+        # optimality: total bits equal to an independent (unlimited) Huffman construction when that code respects the
+        # 16-bit limit, otherwise within 0.2 % of it (length-limited code)
         freq = np.bincount(exp_codes.reshape(-1), minlength=65536)[h["sym_min"]:h["sym_min"] + h["sym_count"]]
         import heapq
-        heap = [(int(f), i) for i, f in enumerate(freq) if f]
+        heap = [(int(f), i, 0) for i, f in enumerate(freq) if f]   # (freq, tiebreak, height)
         heapq.heapify(heap)
         cost = 0
-        cnt = len(heap)
+        cnt = len(freq)
         while len(heap) > 1:
-            f1, _ = heapq.heappop(heap)
-            f2, _ = heapq.heappop(heap)
+            f1, _, h1 = heapq.heappop(heap)
+            f2, _, h2 = heapq.heappop(heap)
             cost += f1 + f2
             cnt += 1
-            heapq.heappush(heap, (f1 + f2, cnt))
-        assert int((freq * lens.astype(np.int64)).sum()) == cost, "code is not optimal"
+            heapq.heappush(heap, (f1 + f2, cnt, max(h1, h2) + 1))
+        gpu_cost = int((freq * lens.astype(np.int64)).sum())
+        if heap[0][2] <= szh_ref.MAX_LEN:
+            assert gpu_cost == cost, "code is not optimal"
+        else:
+            assert cost <= gpu_cost <= cost * 1.002, "length-limited code too far from optimal"
     # K6: python decoder reads the bit-stream back to the same codes
     if a.size <= 120000:
         assert np.array_equal(szh_ref.huffman_decode(h, sec), exp_codes.reshape(-1))

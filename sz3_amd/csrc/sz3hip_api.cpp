@@ -358,7 +358,7 @@ static const char *const kStageNames[ST_COUNT] = {"lorenzo_quant_hist", "codeboo
 struct sz3hip_ctx {
     int device;
     int dtype;
-    uint64_t max_n, out_cap, max_chunks;
+    uint64_t max_n, out_cap, cur_out_cap, max_chunks;
     // device buffers
     uint16_t *d_codes;
     uint64_t *d_hist;      // histogram in use (internal or caller-owned)
@@ -552,7 +552,9 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     for (int i = 0; i < conf->N; i++) p.d[4 - conf->N + i] = conf->dims[i];
     p.lat = szk_make_lattice(eb);
     p.radius = (uint32_t)radius;
-    p.out_cap = ctx->out_cap;
+    // outlier lists larger than n/32 entries can never pay off (12-16 bytes each): overflow => lossless fallback
+    ctx->cur_out_cap = std::min<uint64_t>(ctx->out_cap, std::max<uint64_t>(1024, num / 32));
+    p.out_cap = ctx->cur_out_cap;
     p.hist = ctx->d_hist;
     p.hist_partial = ctx->d_hist_partial;
     p.n_vout = ctx->d_counters + 0;
@@ -611,7 +613,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     lp.proto = ctx->proto;
     lp.n_vout = ctx->d_counters + 0;
     lp.n_dout = ctx->d_counters + 1;
-    lp.out_cap = ctx->out_cap;
+    lp.out_cap = ctx->cur_out_cap;
     lp.info = ctx->d_info;
     lp.state = ctx->d_state;
     rc = szk_launch_layout_pre(&lp, s);
@@ -623,6 +625,10 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     prof_end(ctx, ST_ENCODE, s);
     if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
     szk_asm_params ap;
+    ap.n_vout = ctx->d_counters + 0;
+    ap.n_dout = ctx->d_counters + 1;
+    ap.out_cap = ctx->cur_out_cap;
+    ap.t_is_32bit = ap.q_is_32bit = ctx->dtype == SZ3HIP_FLOAT;
     ap.state = ctx->d_state;
     ap.payload = (uint8_t *)d_payload;
     ap.cap = cap;
@@ -660,7 +666,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     ctx->stats.n_symbols = 0;
     if (st.overflow)
         return fail(SZ3HIP_EOUTLIERS, "outlier capacity exceeded (%llu per list): data not compressible at this bound",
-                    (unsigned long long)ctx->out_cap);
+                    (unsigned long long)ctx->cur_out_cap);
     if (st.cap_exceeded) return fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
     if (payload_size) *payload_size = (size_t)st.hdr.payload_bytes;
     return 0;
@@ -860,6 +866,8 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
                 lossless = true;  // same policy as the reference's length_error fallback, SZDispatcher.hpp:44-59
             } else if (rc) {
                 return 0;
+            } else if (dsize + 64 >= raw_bytes) {
+                lossless = true;  // the GPU stream would not even beat the raw array (tiny or incompressible input)
             } else {
                 std::vector<uint8_t> host_payload(dsize);
                 if (hipMemcpy(host_payload.data(), g_dev_payload[dataType], dsize, hipMemcpyDeviceToHost) != hipSuccess) {

@@ -66,6 +66,9 @@ struct szk_layout_params {
     szk_state *state;
 };
 struct szk_asm_params {
+    const uint64_t *n_vout, *n_dout;
+    uint64_t out_cap;
+    int t_is_32bit, q_is_32bit;
     szk_state *state;
     uint8_t *payload;
     uint64_t cap;

@@ -1569,6 +1569,78 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     for (uint32_t i = lane_id(); i < nwords; i += WAVE) out[i] = stage[i];
 }
 
+// outlier lists are appended with atomics in arrival order; sorting them by element index makes the payload a pure
+// function of the input (the reference's CI compares stream digests across platforms, .github/workflows/cmake.yml:295-310).
+// One workgroup per list: LDS bitonic sort up to 2048 records, in-place global bitonic up to 65536; longer lists
+// (a sign that the bound is far too tight for the data) stay in arrival order.
+__global__ __launch_bounds__(1024) void k_sort_outliers(uint64_t *idx0, uint64_t *val0, const uint64_t *cnt0,
+                                                        uint64_t *idx1, uint64_t *val1, const uint64_t *cnt1,
+                                                        uint64_t cap, int val1_is_32bit, int val0_is_32bit) {
+    __shared__ uint64_t s_i[2048], s_v[2048];
+    uint64_t *idx = blockIdx.x == 0 ? idx0 : idx1;
+    uint8_t *valb = reinterpret_cast<uint8_t *>(blockIdx.x == 0 ? val0 : val1);
+    const bool v32 = blockIdx.x == 0 ? val0_is_32bit : val1_is_32bit;
+    uint64_t n = blockIdx.x == 0 ? *cnt0 : *cnt1;
+    if (n > cap) n = cap;
+    if (n < 2 || n > 65536) return;
+    auto ldv = [&](uint64_t i) -> uint64_t { return v32 ? (uint64_t) reinterpret_cast<uint32_t *>(valb)[i] : reinterpret_cast<uint64_t *>(valb)[i]; };
+    auto stv = [&](uint64_t i, uint64_t v) {
+        if (v32) reinterpret_cast<uint32_t *>(valb)[i] = (uint32_t)v;
+        else reinterpret_cast<uint64_t *>(valb)[i] = v;
+    };
+    uint32_t np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    if (n <= 2048) {
+        for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
+            s_i[i] = i < n ? idx[i] : ~0ull;
+            s_v[i] = i < n ? ldv(i) : 0;
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= np2; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
+                    const uint32_t ixj = i ^ j;
+                    if (ixj > i) {
+                        const uint64_t a = s_i[i], b = s_i[ixj];
+                        if ((a > b) == ((i & k) == 0)) {
+                            s_i[i] = b;
+                            s_i[ixj] = a;
+                            const uint64_t t = s_v[i];
+                            s_v[i] = s_v[ixj];
+                            s_v[ixj] = t;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+            idx[i] = s_i[i];
+            stv(i, s_v[i]);
+        }
+        return;
+    }
+    // global in-place bitonic; virtual padding: positions >= n compare as +infinity and are never written
+    for (uint32_t k = 2; k <= np2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
+                const uint32_t ixj = i ^ j;
+                if (ixj > i && i < n) {
+                    const uint64_t a = idx[i], b = ixj < n ? idx[ixj] : ~0ull;
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up && ixj < n) {
+                        idx[i] = b;
+                        idx[ixj] = a;
+                        const uint64_t t = ldv(i);
+                        stv(i, ldv(ixj));
+                        stv(ixj, t);
+                    }
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+}
+
 // header + side sections (lens, chunk table, outliers) into the payload
 __global__ __launch_bounds__(256) void k_assemble(szk_asm_params p) {
     const szh_header h0 = p.state->hdr;
@@ -1584,6 +1656,12 @@ __global__ __launch_bounds__(256) void k_assemble(szk_asm_params p) {
         p.state->hdr = h;
         p.state->off = oo;
         p.state->cap_exceeded = oo.end > p.cap;
+        // alignment gaps between the sections are part of the payload: zero them so that it is a pure function of the input
+        const uint64_t tsz0 = h.dtype == 0 ? 4 : 8;
+        for (uint64_t a = oo.lens + h.sym_count; a < oo.chunkwords; a++) p.payload[a] = 0;
+        for (uint64_t a = oo.chunkwords + 2 * h.n_chunks; a < oo.vout_idx; a++) p.payload[a] = 0;
+        for (uint64_t a = oo.vout_val + tsz0 * h.n_vout; a < oo.dout_idx; a++) p.payload[a] = 0;
+        for (uint64_t a = oo.dout_val + (uint64_t)h.qbytes * h.n_dout; a < oo.bitstream; a++) p.payload[a] = 0;
     }
     for (uint64_t i = tid; i < h0.sym_count; i += nth) p.payload[o.lens + i] = p.lens[h0.sym_min + i];
     uint16_t *cw = reinterpret_cast<uint16_t *>(p.payload + o.chunkwords);
@@ -1970,6 +2048,9 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
     return 0;
 }
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s) {
+    hipLaunchKernelGGL(k_sort_outliers, dim3(2), dim3(1024), 0, s, const_cast<uint64_t *>(p->vout_idx),
+                       (uint64_t *)const_cast<void *>(p->vout_val), p->n_vout, const_cast<uint64_t *>(p->dout_idx),
+                       (uint64_t *)const_cast<void *>(p->dout_val), p->n_dout, p->out_cap, p->q_is_32bit, p->t_is_32bit);
     hipLaunchKernelGGL(k_assemble, dim3(512), dim3(256), 0, s, *p);
     SZK_CHECK_LAUNCH();
     return 0;

@@ -1,0 +1,80 @@
+"""CPU tests (-m "not gpu") of the product's host side: libsz3hip.so loads, exports every symbol include/*.h declares,
+Config semantics / serialisation are byte-identical to the reference's (through the oracle), and every compute entry
+point FAILS LOUDLY without a HIP device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sz3_amd
+from oracle_binding import make_config, oracle, SzoConfig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sz3hip_[a-z0-9_]+|SZ_compress_args|SZ_decompress|free_buf)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = sz3_amd.lib()
+    names = _declared_symbols("sz3hip.h") + _declared_symbols("sz3c.h")
+    assert "sz3hip_compress_stage1" in names and "SZ_compress_args" in names and len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), "libsz3hip.so does not export " + n
+
+
+@pytest.mark.parametrize("dims", [(100,), (1, 500), (3, 1, 7, 1), (512, 512, 512), (100, 500, 500, 500), (1,), (2 ** 33, 3)])
+def test_config_matches_reference_semantics(dims):
+    c = sz3_amd.Config(*dims)
+    o = make_config(dims, algo=1, regression=True)  # defaults of SZ3::Config (Config.hpp:452-478)
+    assert c.N == o.N and c.dims == tuple(int(o.dims[i]) for i in range(o.N)) and c.num == o.num
+    assert (c.blockSize, c.quantbinCnt, c.cmprAlgo, c.lorenzo, c.regression, c.interpAnchorStride) == \
+           (o.blockSize, o.quantbinCnt, o.cmprAlgo, o.lorenzo, o.regression, o.interpAnchorStride)
+    buf = (C.c_ubyte * 256)()
+    n = oracle().szo_config_save(C.byref(o), buf)
+    assert c.save() == bytes(buf[:n]), "Config::save bytes differ from the reference layout"
+    for mode, kw in [(sz3_amd.EB_REL, dict(relErrorBound=1e-3)), (sz3_amd.EB_ABS_AND_REL, dict(absErrorBound=0.5, relErrorBound=1e-4)),
+                     (sz3_amd.EB_PSNR, dict(psnrErrorBound=80.0)), (sz3_amd.EB_L2NORM, dict(l2normErrorBound=2.5))]:
+        c.errorBoundMode = o.errorBoundMode = mode
+        for k, v in kw.items():
+            setattr(c, k, v)
+            setattr(o, k, v)
+        n = oracle().szo_config_save(C.byref(o), buf)
+        assert c.save() == bytes(buf[:n])
+        back = sz3_amd.Config.load(c.save())
+        assert back.dims == c.dims and back.errorBoundMode == mode and back.save() == c.save()
+
+
+def test_observed_trailer_bytes():
+    # 8x8x128 f32, Lorenzo only, eb 1e-3 -> 35-byte trailer "23 03 08 08 08 80 ..."
+    c = sz3_amd.Config(8, 8, 128)
+    c.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    c.regression = 0
+    raw = c.save()
+    assert len(raw) == 35 and raw[:6].hex() == "230308080880"
+
+
+def test_fails_loudly_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    a = np.zeros((8, 8, 8), np.float32)
+    with pytest.raises(sz3_amd.SZ3HipError):
+        sz3_amd.compress(a, sz3_amd.Config(8, 8, 8))
+    with pytest.raises(sz3_amd.SZ3HipError):
+        sz3_amd.DeviceCompressor(512, np.float32)
+    with pytest.raises(TypeError):
+        sz3_amd.compress(a.astype(np.int32), sz3_amd.Config(8, 8, 8))
+
+
+def test_peek_rejects_foreign_streams():
+    L = sz3_amd.lib()
+    junk = np.zeros(64, dtype=np.uint8)
+    conf = sz3_amd.Config(1)
+    assert L.sz3hip_peek_config(C.byref(conf._c), junk.ctypes.data, junk.size) == -3  # SZ3HIP_EFORMAT: bad magic
+    assert b"magic number mismatch" in L.sz3hip_last_error()

@@ -1,7 +1,12 @@
+#!/bin/bash
+# rocprofv3 passes for profiles/: (1) kernel stats of the bench command, (2)+(3) HBM traffic counters, each in its own
+# pass (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2 — MI355X_MICROARCH.md "rocprofv3 PMC slots"), (4) SQ counters.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/pmc1 -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-e2e > $R/gpurun_out/pmc1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d $R/gpurun_out/pmc2 -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-e2e > $R/gpurun_out/pmc2.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc3 -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-e2e > $R/gpurun_out/pmc3.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc4 -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-e2e > $R/gpurun_out/pmc4.log 2>&1
-ls $R/gpurun_out/pmc1 $R/gpurun_out/pmc3
+B="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-e2e"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o r -- $B > $R/gpurun_out/prof_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o p -- $B > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o p -- $B > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/pmc_sq -o p -- $B > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/pmc_lds -o p -- $B > /dev/null 2>&1
+grep metric $R/gpurun_out/prof_stats.log | cut -c1-300

@@ -159,6 +159,7 @@ def main():
             "ratio": round(ratio, 4), "max_abs_err": max_err, "err_bound_ok": bool(max_err <= eb),
             "payload_bytes_rank0": int(psize),
             "outliers": {"value": stats["n_value_outliers"], "delta": stats["n_delta_outliers"]},
+            "narrow_codes": stats.get("narrow_codes"),
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
             "kernels_ms": round(kernels_ms, 4),
             "frac_read_peak_all_kernels": round(raw_bytes / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

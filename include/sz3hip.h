@@ -133,6 +133,8 @@ int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, size_t payl
 typedef struct sz3hip_stats {
     uint64_t n, n_value_outliers, n_delta_outliers, n_chunks, bitstream_bytes, payload_bytes;
     uint32_t n_symbols, max_code_len;
+    uint32_t narrow_codes; /* 1 when stage 1 kept the intermediate codes as one byte each (internal, not a format property) */
+    uint32_t reserved;
 } sz3hip_stats;
 int sz3hip_get_stats(sz3hip_ctx *ctx, sz3hip_stats *st);
 /* per-stage kernel time of the last compress / decompress when profiling is on (hipEvents on `stream`):

@@ -47,7 +47,8 @@ class _CConfig(C.Structure):
 class _CStats(C.Structure):
     _fields_ = [("n", C.c_uint64), ("n_value_outliers", C.c_uint64), ("n_delta_outliers", C.c_uint64),
                 ("n_chunks", C.c_uint64), ("bitstream_bytes", C.c_uint64), ("payload_bytes", C.c_uint64),
-                ("n_symbols", C.c_uint32), ("max_code_len", C.c_uint32)]
+                ("n_symbols", C.c_uint32), ("max_code_len", C.c_uint32),
+                ("narrow_codes", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 _lib = None

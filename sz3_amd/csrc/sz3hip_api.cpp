@@ -380,6 +380,8 @@ struct sz3hip_ctx {
     void *d_segtot;
     double *d_minmax;
     szk_state *h_state;  // pinned
+    uint32_t *h_probe;   // pinned copy of the narrow-mode probe counter
+    szk_mode mode;       // of the pending / last compress
     double *h_minmax;    // pinned
     // pending compress
     szh_header proto;
@@ -400,6 +402,7 @@ static void ctx_free(sz3hip_ctx *c) {
         if (b) (void)hipFree(b);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
+    if (c->h_probe) (void)hipHostFree(c->h_probe);
     for (int i = 0; i < ST_COUNT; i++)
         for (int j = 0; j < 2; j++)
             if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
@@ -461,6 +464,7 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     alloc((void **)&c->d_minmax, (2 * 1024 + 2) * 8);
     if (ok && hipHostMalloc((void **)&c->h_state, sizeof(szk_state)) != hipSuccess) ok = false;
     if (ok && hipHostMalloc((void **)&c->h_minmax, 16) != hipSuccess) ok = false;
+    if (ok && hipHostMalloc((void **)&c->h_probe, 16) != hipSuccess) ok = false;
     (void)tsz;
     if (!ok) {
         if (!g_err[0]) fail(SZ3HIP_EHIP, "device allocation failed");
@@ -563,8 +567,13 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     p.dout_idx = ctx->d_dout_idx;
     p.vout_val = ctx->d_vout_val;
     p.dout_val = ctx->d_dout_val;
+    p.mode.probe_big = reinterpret_cast<uint32_t *>(ctx->d_counters + 4);  // zeroed with the counters above
+    p.mode.n_total = num;
+    p.mode.n_samples = (num / SZK_PROBE_STRIDE) * 64 + std::min<uint64_t>(64, num % SZK_PROBE_STRIDE);
+    p.mode.allow = radius >= 128;
     prof_begin(ctx, ST_K1, s);
     int rc = szk_launch_k1(ctx->dtype, conf->N, d_in, ctx->d_codes, &p, s);
+    ctx->mode = p.mode;
     prof_end(ctx, ST_K1, s);
     if (rc) return fail(SZ3HIP_EHIP, "lorenzo_quant kernel launch failed (%d)", rc);
 
@@ -620,7 +629,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     prof_end(ctx, ST_CODEBOOK, s);
     if (rc) return fail(SZ3HIP_EHIP, "layout kernel launch failed (%d)", rc);
     prof_begin(ctx, ST_ENCODE, s);
-    rc = szk_launch_encode(ctx->d_codes, n, ctx->d_enc, ctx->d_info, (int)ctx->proto.radius, ctx->d_chunk_words, ctx->d_chunk_off,
+    rc = szk_launch_encode(ctx->d_codes, n, ctx->d_enc, ctx->d_info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words, ctx->d_chunk_off,
                            ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, s);
     prof_end(ctx, ST_ENCODE, s);
     if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
@@ -644,6 +653,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     prof_end(ctx, ST_ASSEMBLE, s);
     if (rc) return fail(SZ3HIP_EHIP, "assemble kernel launch failed (%d)", rc);
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(szk_state), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ctx->h_probe, ctx->d_counters + 4, 4, hipMemcpyDeviceToHost, s));
     ctx->stage2_done = true;
     return 0;
 }
@@ -664,6 +674,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     ctx->stats.payload_bytes = st.hdr.payload_bytes;
     ctx->stats.max_code_len = st.hdr.max_len;
     ctx->stats.n_symbols = 0;
+    ctx->stats.narrow_codes = ctx->mode.allow && (uint64_t)(*ctx->h_probe) * 4096ull <= ctx->mode.n_samples;
     if (st.overflow)
         return fail(SZ3HIP_EOUTLIERS, "outlier capacity exceeded (%llu per list): data not compressible at this bound",
                     (unsigned long long)ctx->cur_out_cap);
@@ -689,7 +700,17 @@ extern "C" int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, ui
     HIPCHK(hipSetDevice(ctx->device));
     if (n > ctx->max_n) return fail(SZ3HIP_EINVAL, "n exceeds capacity");
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(host_codes, ctx->d_codes, n * 2, hipMemcpyDeviceToHost));
+    uint32_t big = 0;
+    HIPCHK(hipMemcpy(&big, ctx->d_counters + 4, 4, hipMemcpyDeviceToHost));
+    const bool narrow = ctx->mode.allow && (uint64_t)big * 4096ull <= ctx->mode.n_samples;
+    if (!narrow) {
+        HIPCHK(hipMemcpy(host_codes, ctx->d_codes, n * 2, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    std::vector<uint8_t> b(n);  // one-byte codes: delta + 128, 0 = outlier -> symbols
+    HIPCHK(hipMemcpy(b.data(), ctx->d_codes, n, hipMemcpyDeviceToHost));
+    const uint32_t add = ctx->h_state->hdr.radius ? ctx->h_state->hdr.radius - 128u : ctx->proto.radius - 128u;
+    for (uint64_t i = 0; i < n; i++) host_codes[i] = (uint16_t)(b[i] ? b[i] + add : 0u);
     return 0;
 }
 

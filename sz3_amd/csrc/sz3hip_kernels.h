@@ -25,11 +25,21 @@ static inline szk_lattice szk_make_lattice(double eb) {
 
 #define SZK_K1_GRID 2048u  // rows of hist_partial = upper bound of the persistent stage-1 grid
 
+#define SZK_PROBE_STRIDE 32768ull  // the probe looks at 64 consecutive elements of every 32768
+// narrow-code mode (see k_probe): a pure function of the probe counter, evaluated on the device by every kernel
+struct szk_mode {
+    uint32_t *probe_big;          // number of probed deltas outside [-127, 127]
+    uint64_t n_samples;           // number of probed elements
+    uint64_t n_total;             // elements of the array
+    uint32_t allow;               // 0: always two-byte codes
+};
+
 struct szk_k1_params {
     uint64_t d[4];  // extents slowest first, left-padded with 1: [w][z][y][x]
     szk_lattice lat;
     uint32_t radius;
     uint32_t dbg;      // ablation switches for tools/k1_lab.py (0 in production)
+    szk_mode mode;
     uint64_t out_cap;  // capacity of each outlier list
     uint64_t *hist;    // [SZH_HIST_BINS]
     uint32_t *hist_partial;  // [SZK_K1_GRID][1024] private histogram rows of the persistent stage-1 workgroups
@@ -94,11 +104,11 @@ struct szk_dec_params {
 };
 
 int szk_launch_minmax(int dtype, const void *d_in, uint64_t n, double *d_partial /*[2*1024]*/, double *d_out /*[2]*/, hipStream_t s);
-int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, const szk_k1_params *p, hipStream_t s);
+int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, szk_k1_params *p, hipStream_t s);
 int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStream_t s);
 int szk_launch_layout_pre(const szk_layout_params *p, hipStream_t s);
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
-                      uint16_t *chunk_words, uint64_t *group_off /*[n_chunks/32 + 1]*/, uint64_t *total_words,
+                      szk_mode mode, uint16_t *chunk_words, uint64_t *group_off /*[n_chunks/32 + 1]*/, uint64_t *total_words,
                       const szk_state *state, uint8_t *payload, hipStream_t s);
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, hipStream_t s);

@@ -600,6 +600,51 @@ __global__ __launch_bounds__(256, (NDIM == 3 ? 3 : 2)) void k_lorenzo_quant_v4(c
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// "Narrow" intermediate codes.  When a sparse probe of the Lorenzo deltas (64 consecutive elements of every 32768) finds fewer than one
+// in 4096 outside [-127, 127], stage 1 stores the codes as ONE byte (delta + 128, 0 = delta outlier) instead of two
+// and the packers read one byte — 0.4 GB less HBM traffic per 512^3 volume.  Symbols, histogram, code book and
+// payload are unchanged (symbol = delta + radius); the rare wider deltas join the delta-outlier list.  The decision
+// is a pure function of the probe counter, recomputed by every kernel (no host round trip).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool szk_is_narrow(const szk_mode &m) {
+    return m.allow && (unsigned long long)(*m.probe_big) * 4096ull <= m.n_samples;
+}
+
+template <typename T, int NDIM>
+__global__ __launch_bounds__(256) void k_probe(const T *__restrict__ in, szk_k1_params p, uint64_t n, uint32_t *probe_big) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    const Lattice<T> lat(p.lat);
+    const uint64_t d0 = p.d[3], d1 = p.d[2], d2 = p.d[1];
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t i = (s >> 6) * SZK_PROBE_STRIDE + (s & 63);  // runs of 64 consecutive elements, one run per stride
+    bool big = false;
+    if (i < n) {
+        uint64_t r = i;
+        const int64_t x = (int64_t)(r % d0);
+        r /= d0;
+        const int64_t y = (int64_t)(r % d1);
+        r /= d1;
+        const int64_t z = (int64_t)(r % d2);
+        const int64_t w = (int64_t)(r / d2);
+        UQ delta = 0;
+#pragma unroll
+        for (int c = 0; c < (1 << NDIM); c++) {
+            const int64_t xx = x - (c & 1), yy = y - ((c >> 1) & 1), zz = z - ((c >> 2) & 1), ww = w - ((c >> 3) & 1);
+            UQ q = 0;
+            if (xx >= 0 && yy >= 0 && zz >= 0 && ww >= 0) {
+                bool bad;
+                q = (UQ)lat.quant(in[(((uint64_t)ww * d2 + (uint64_t)zz) * d1 + (uint64_t)yy) * d0 + (uint64_t)xx], bad);
+            }
+            delta = (__popc(c) & 1) ? (UQ)(delta - q) : (UQ)(delta + q);
+        }
+        big = (UQ)(delta + 127) > (UQ)254;
+    }
+    const unsigned long long m = __ballot(big);
+    if (m && lane_id() == 0) atomicAdd(probe_big, (uint32_t)__popcll(m));
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // K1 "march" (N = 3 or 4, x extent a multiple of 4 and >= 128): register-only stencil, no LDS tile, no barriers.
 // One wave owns a 256 (x) x TY (y) x TZ (z) brick: every lane holds 4 consecutive x, the wave walks the rows of a
 // plane and the planes of the brick keeping
@@ -640,6 +685,8 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     const int radius = (int)p.radius;
     const uint32_t win_lo = (uint32_t)(radius - HIST_WIN / 2);
     const uint32_t copy = (uint32_t)lane & 3u;
+    const bool narrow = szk_is_narrow(p.mode);
+    uint8_t *codes8 = reinterpret_cast<uint8_t *>(codes);
 
     for (int i = threadIdx.x; i < HIST_WIN * 4 + 4; i += 256) lh[i] = 0;
     __syncthreads();
@@ -736,7 +783,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const UQ shifted = delta[i] + (UQ)radius;  // in (0, 2r) when |delta| < r
-                    const bool inr = (UQ)(shifted - 1) < (UQ)(2 * radius - 1);
+                    const bool inr = narrow ? (UQ)(delta[i] + 127) <= (UQ)254 : (UQ)(shifted - 1) < (UQ)(2 * radius - 1);
                     code[i] = inr ? (uint32_t)shifted : 0u;
                     uint32_t bin = code[i] - win_lo;           // wraps to a huge value below the window
                     bin = bin < (uint32_t)HIST_WIN ? bin : (uint32_t)HIST_WIN;
@@ -744,10 +791,18 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                     atomicAdd(&lh[bin * 4 + copy], 1u);
                 }
                 const uint64_t gi = (uint64_t)w * vol + (uint64_t)gz * plane + (uint64_t)gy * d0 + x;
-                uint2 pk;
-                pk.x = code[0] | (code[1] << 16);
-                pk.y = code[2] | (code[3] << 16);
-                *reinterpret_cast<uint2 *>(codes + gi) = pk;
+                if (narrow) {  // one byte per code: delta + 128, 0 = delta outlier
+                    const uint32_t off8 = (uint32_t)radius - 128u;
+                    uint32_t pk8 = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) pk8 |= (code[i] ? code[i] - off8 : 0u) << (8 * i);
+                    *reinterpret_cast<uint32_t *>(codes8 + gi) = pk8;
+                } else {
+                    uint2 pk;
+                    pk.x = code[0] | (code[1] << 16);
+                    pk.y = code[2] | (code[3] << 16);
+                    *reinterpret_cast<uint2 *>(codes + gi) = pk;
+                }
                 if (mx >= (uint32_t)HIST_WIN || badmask) {  // rare: outliers, codes outside the LDS histogram window
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
@@ -1136,8 +1191,27 @@ __device__ __forceinline__ uint32_t enc_lookup(const uint32_t *s_enc, const uint
     return (rel >= 0 && rel < ENC_WIN) ? s_enc[rel] : g_enc[sym];
 }
 
-__device__ __forceinline__ void load_codes16(const uint16_t *__restrict__ codes, uint64_t base, uint64_t n,
-                                             uint16_t (&c)[ENC_PER_LANE]) {
+__device__ __forceinline__ void load_codes16(const uint16_t *__restrict__ codes, uint64_t base, uint64_t n, bool narrow,
+                                             uint32_t sym_add, uint16_t (&c)[ENC_PER_LANE]) {
+    if (narrow) {  // one byte per code (delta + 128, 0 = outlier) -> symbol
+        const uint8_t *c8 = reinterpret_cast<const uint8_t *>(codes);
+        if (base + ENC_PER_LANE <= n) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(c8 + base);  // base is a multiple of 16
+            const uint32_t wds[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t b = (wds[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                c[i] = (uint16_t)(b ? b + sym_add : 0u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < ENC_PER_LANE; i++) {
+                const uint32_t b = (base + i < n) ? c8[base + i] : 0u;
+                c[i] = (uint16_t)(b ? b + sym_add : 0u);
+            }
+        }
+        return;
+    }
     if (base + ENC_PER_LANE <= n) {
         const uint4 *v = reinterpret_cast<const uint4 *>(codes + base);  // base is a multiple of 16 -> 32-byte aligned
         uint4 a = v[0], b = v[1];
@@ -1149,31 +1223,8 @@ __device__ __forceinline__ void load_codes16(const uint16_t *__restrict__ codes,
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < ENC_PER_LANE; i++) c[i] = (base + i < n) ? codes[base + i] : (uint16_t)0xFFFF;
+        for (int i = 0; i < ENC_PER_LANE; i++) c[i] = (base + i < n) ? codes[base + i] : (uint16_t)0;
     }
-}
-
-__global__ __launch_bounds__(256) void k_chunk_bits(const uint16_t *__restrict__ codes, uint64_t n,
-                                                    const uint32_t *__restrict__ g_enc, int radius,
-                                                    uint16_t *__restrict__ chunk_words) {
-    __shared__ uint32_t s_enc[ENC_WIN];
-    const int win_lo = radius - ENC_WIN / 2;
-    for (int i = threadIdx.x; i < ENC_WIN; i += 256) {
-        int sym = win_lo + i;
-        s_enc[i] = (sym >= 0 && sym < (int)SZH_HIST_BINS) ? g_enc[sym] : 0;
-    }
-    __syncthreads();
-    const uint64_t chunk = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE;
-    const uint64_t base = chunk * SZH_CHUNK_SYMS + (uint64_t)lane_id() * ENC_PER_LANE;
-    if (chunk * SZH_CHUNK_SYMS >= n) return;
-    uint16_t c[ENC_PER_LANE];
-    load_codes16(codes, base, n, c);
-    uint32_t bits = 0;
-#pragma unroll
-    for (int i = 0; i < ENC_PER_LANE; i++)
-        if (base + i < n) bits += enc_lookup(s_enc, g_enc, win_lo, c[i]) & 31u;
-    bits = wave_sum(bits);
-    if (lane_id() == 0) chunk_words[chunk] = (uint16_t)((bits + 31) >> 5);
 }
 
 // exclusive scan of the chunk word counts (one workgroup; n_chunks is n/1024)
@@ -1203,220 +1254,8 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(const uint16_t *__restrict
     }
 }
 
-// K6 pass 2: bit-pack. One wave per chunk; every lane packs its 16 code words at its bit offset inside the
-// chunk (wave prefix sum) into an LDS staging area with ds_or, then the wave streams the words out coalesced.
-__global__ __launch_bounds__(256) void k_encode(const uint16_t *__restrict__ codes, uint64_t n,
-                                                const uint32_t *__restrict__ g_enc, int radius,
-                                                const uint64_t *__restrict__ chunk_off,
-                                                const szk_state *__restrict__ state, uint8_t *__restrict__ payload) {
-    constexpr int STAGE_WORDS = SZH_CHUNK_SYMS * SZH_MAX_LEN / 32;  // 768 words per chunk at most
-    __shared__ uint32_t s_enc[ENC_WIN];
-    __shared__ uint32_t s_stage[4][STAGE_WORDS];
-    const int win_lo = radius - ENC_WIN / 2;
-    for (int i = threadIdx.x; i < ENC_WIN; i += 256) {
-        int sym = win_lo + i;
-        s_enc[i] = (sym >= 0 && sym < (int)SZH_HIST_BINS) ? g_enc[sym] : 0;
-    }
-    const int wv = threadIdx.x / WAVE;
-    uint32_t *stage = s_stage[wv];
-    for (int i = lane_id(); i < STAGE_WORDS; i += WAVE) stage[i] = 0;
-    __syncthreads();
-    const uint64_t chunk = (uint64_t)blockIdx.x * 4 + wv;
-    if (chunk * SZH_CHUNK_SYMS >= n) return;
-    const uint64_t base = chunk * SZH_CHUNK_SYMS + (uint64_t)lane_id() * ENC_PER_LANE;
-    uint16_t c[ENC_PER_LANE];
-    load_codes16(codes, base, n, c);
-    uint32_t e[ENC_PER_LANE];
-    uint32_t bits = 0;
-#pragma unroll
-    for (int i = 0; i < ENC_PER_LANE; i++) {
-        e[i] = (base + i < n) ? enc_lookup(s_enc, g_enc, win_lo, c[i]) : 0u;
-        bits += e[i] & 31u;
-    }
-    uint32_t incl = wave_incl_scan(bits);
-    uint32_t total_bits = __shfl(incl, WAVE - 1, WAVE);
-    uint32_t pos = incl - bits;  // bit offset of this lane inside the chunk
-    // pack: 64-bit accumulator, MSB-first within 32-bit words
-    uint32_t word = pos >> 5;
-    uint32_t fill = pos & 31;  // bits already occupied in the current word (by the previous lane)
-    uint64_t acc = 0;          // pending bits, left-aligned at bit (63 - fill)
-    uint32_t have = fill;      // number of valid bit positions consumed in acc (including the skipped prefix)
-#pragma unroll
-    for (int i = 0; i < ENC_PER_LANE; i++) {
-        uint32_t len = e[i] & 31u;
-        uint64_t cw = e[i] >> 5;
-        if (len) {
-            acc |= cw << (64 - have - len);
-            have += len;
-            if (have >= 32) {
-                atomicOr(&stage[word], (uint32_t)(acc >> 32));
-                word++;
-                acc <<= 32;
-                have -= 32;
-            }
-        }
-    }
-    if (have > 0 && (uint32_t)(acc >> 32) != 0) atomicOr(&stage[word], (uint32_t)(acc >> 32));
-    // (a lane whose bits end exactly on a word boundary has have == 0; a lane with no bits writes nothing)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t nwords = (total_bits + 31) >> 5;
-    uint32_t *out = reinterpret_cast<uint32_t *>(payload + state->off.bitstream) + chunk_off[chunk];
-    for (uint32_t i = lane_id(); i < nwords; i += WAVE) out[i] = stage[i];
-}
-
-// K6 fused: bit lengths, decoupled look-back for the output offset, bit-pack, write — one launch.
-// Persistent workgroups pull BATCHES of 32 chunks (32768 symbols) from a ticket counter: a workgroup therefore only
-// ever waits for batches that were taken earlier, i.e. by workgroups that are already running (no residency
-// assumption), and the single counter sees n/32768 atomics instead of one per tile (one address serialises at
-// ~90 atomics/us).  Per batch: pre-pass (code lengths -> words per chunk), publish the batch aggregate, look back,
-// then pack chunk by chunk (codes come from L2 the second time).  The look-back record is ONE 8-byte word
-// {flag:2, value:62} moved with relaxed agent-scope atomics — the data is the flag, no fence needed
-// (/opt/skills/guides/cdna_hip_programming.md G16 "R2").  flag 1 = batch word count, flag 2 = inclusive prefix.
-// Output placement is by batch index, hence deterministic.
-#define LB_AGG (1ull << 62)
-#define LB_INC (2ull << 62)
-#define LB_VAL ((1ull << 62) - 1)
-#define ENC_BATCH_CHUNKS 32
-__global__ __launch_bounds__(256) void k_encode_fused(const uint16_t *__restrict__ codes, uint64_t n,
-                                                      const uint32_t *__restrict__ g_enc, int radius,
-                                                      uint16_t *__restrict__ chunk_words, unsigned long long *lb_state,
-                                                      unsigned int *ticket, uint64_t *total_words,
-                                                      const szk_state *__restrict__ state, uint8_t *__restrict__ payload) {
-    constexpr int STAGE_WORDS = SZH_CHUNK_SYMS * SZH_MAX_LEN / 32;  // 768 words per chunk at most
-    __shared__ uint32_t s_enc[ENC_WIN];
-    __shared__ uint32_t s_stage[4][STAGE_WORDS];
-    __shared__ uint32_t s_words[ENC_BATCH_CHUNKS];
-    __shared__ uint32_t s_batch;
-    __shared__ unsigned long long s_excl;
-    const int win_lo = radius - ENC_WIN / 2;
-    for (int i = threadIdx.x; i < ENC_WIN; i += 256) {
-        int sym = win_lo + i;
-        s_enc[i] = (sym >= 0 && sym < (int)SZH_HIST_BINS) ? g_enc[sym] : 0;
-    }
-    const int wv = threadIdx.x / WAVE;
-    uint32_t *stage = s_stage[wv];
-    const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
-    const uint32_t n_batches = (uint32_t)((n_chunks + ENC_BATCH_CHUNKS - 1) / ENC_BATCH_CHUNKS);
-    uint32_t *out_base = reinterpret_cast<uint32_t *>(payload + state->off.bitstream);
-
-    for (;;) {
-        __syncthreads();  // s_words / s_batch / s_excl of the previous batch are no longer read
-        if (threadIdx.x == 0) s_batch = atomicAdd(ticket, 1u);
-        __syncthreads();
-        const uint32_t bt = s_batch;
-        if (bt >= n_batches) break;
-        const uint64_t chunk0 = (uint64_t)bt * ENC_BATCH_CHUNKS;
-        // ---- pre-pass: words per chunk ----
-#pragma unroll 2
-        for (int g = 0; g < ENC_BATCH_CHUNKS / 4; g++) {
-            const uint64_t chunk = chunk0 + g * 4 + wv;
-            uint32_t bits = 0;
-            if (chunk < n_chunks) {
-                const uint64_t base = chunk * SZH_CHUNK_SYMS + (uint64_t)lane_id() * ENC_PER_LANE;
-                uint16_t c[ENC_PER_LANE];
-                load_codes16(codes, base, n, c);
-#pragma unroll
-                for (int i = 0; i < ENC_PER_LANE; i++)
-                    if (base + i < n) bits += enc_lookup(s_enc, g_enc, win_lo, c[i]) & 31u;
-            }
-            bits = wave_sum(bits);
-            if (lane_id() == 0) {
-                const uint32_t nw = (bits + 31) >> 5;
-                s_words[g * 4 + wv] = nw;
-                if (chunk < n_chunks) chunk_words[chunk] = (uint16_t)nw;
-            }
-        }
-        __syncthreads();
-        // ---- batch aggregate, look-back (wave 0) ----
-        if (wv == 0) {
-            uint32_t mine = lane_id() < ENC_BATCH_CHUNKS ? s_words[lane_id()] : 0u;
-            const uint32_t batch_words = wave_sum(mine);
-            if (lane_id() == 0)
-                __hip_atomic_store(&lb_state[bt], (bt == 0 ? LB_INC : LB_AGG) | (unsigned long long)batch_words,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned long long excl = 0;
-            if (bt > 0) {
-                int64_t idx = (int64_t)bt - 1;
-                for (;;) {
-                    const int64_t my = idx - lane_id();
-                    unsigned long long v;
-                    for (;;) {
-                        v = my >= 0 ? __hip_atomic_load(&lb_state[my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_INC;
-                        if (__all((v >> 62) != 0)) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    const unsigned long long inc_mask = __ballot((v >> 62) == 2);
-                    unsigned long long contrib = v & LB_VAL;
-                    if (inc_mask) {
-                        const int first = __ffsll((long long)inc_mask) - 1;  // closest predecessor with an inclusive prefix
-                        if (lane_id() > first) contrib = 0;
-                        excl += wave_sum(contrib);
-                        break;
-                    }
-                    excl += wave_sum(contrib);
-                    idx -= WAVE;
-                }
-                if (lane_id() == 0)
-                    __hip_atomic_store(&lb_state[bt], LB_INC | (excl + batch_words), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (lane_id() == 0) {
-                s_excl = excl;
-                if (bt == n_batches - 1) *total_words = excl + batch_words;
-            }
-        }
-        __syncthreads();
-        const unsigned long long excl = s_excl;
-        // ---- pack pass ----
-        for (int g = 0; g < ENC_BATCH_CHUNKS / 4; g++) {
-            const uint64_t chunk = chunk0 + g * 4 + wv;
-            if (chunk >= n_chunks) break;
-            const int ci = g * 4 + wv;
-            uint32_t coff = 0;  // words of the earlier chunks of this batch
-            for (int i = lane_id(); i < ci; i += WAVE) coff += s_words[i];
-            coff = wave_sum(coff);
-            const uint32_t nwords = s_words[ci];
-            for (uint32_t i = lane_id(); i < nwords; i += WAVE) stage[i] = 0;
-            const uint64_t base = chunk * SZH_CHUNK_SYMS + (uint64_t)lane_id() * ENC_PER_LANE;
-            uint16_t c[ENC_PER_LANE];
-            load_codes16(codes, base, n, c);
-            uint32_t e[ENC_PER_LANE];
-            uint32_t bits = 0;
-#pragma unroll
-            for (int i = 0; i < ENC_PER_LANE; i++) {
-                e[i] = (base + i < n) ? enc_lookup(s_enc, g_enc, win_lo, c[i]) : 0u;
-                bits += e[i] & 31u;
-            }
-            const uint32_t incl = wave_incl_scan(bits);
-            uint32_t pos = incl - bits;
-            uint32_t word = pos >> 5;
-            uint32_t have = pos & 31;
-            uint64_t acc = 0;
-#pragma unroll
-            for (int i = 0; i < ENC_PER_LANE; i++) {
-                const uint32_t len = e[i] & 31u;
-                const uint64_t cw = e[i] >> 5;
-                acc |= len ? cw << (64 - have - len) : 0ull;
-                have += len;
-                if (have >= 32) {
-                    atomicOr(&stage[word], (uint32_t)(acc >> 32));
-                    word++;
-                    acc <<= 32;
-                    have -= 32;
-                }
-            }
-            if ((uint32_t)(acc >> 32) != 0) atomicOr(&stage[word], (uint32_t)(acc >> 32));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            uint32_t *out = out_base + excl + coff;
-            for (uint32_t i = lane_id(); i < nwords; i += WAVE) out[i] = stage[i];
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------
-// K6, split form (default): three plain streaming launches, no inter-workgroup dependency.
+// K6: three plain streaming launches, no inter-workgroup dependency.
 //   k_chunk_bits2   words per 1024-symbol chunk                      (reads the codes once)
 //   k_scan_groups   exclusive word offset of every group of 32 chunks (one workgroup, 4 KiB of offsets per 4M symbols)
 //   k_pack          bit-pack: one wave per chunk, 16 symbols per lane; with code words <= 16 bit four of them always
@@ -1439,28 +1278,81 @@ __device__ __forceinline__ void enc_table_load(uint32_t *s_enc, const uint32_t *
     for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) s_enc[i] = g_enc[sym_min + i];
 }
 
+// raw code registers of one lane (16 symbols: 32 bytes as two-byte codes, 16 bytes as one-byte codes) — loaded
+// unconditionally one chunk ahead so that the HBM latency hides behind the current chunk's work
+struct CodeRegs {
+    uint4 a, b;
+};
+__device__ __forceinline__ void fetch_codes(const uint16_t *__restrict__ codes, uint64_t base, bool narrow, CodeRegs &r) {
+    if (narrow) {
+        r.a = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(codes) + base);
+    } else {
+        const uint4 *v = reinterpret_cast<const uint4 *>(codes + base);
+        r.a = v[0];
+        r.b = v[1];
+    }
+}
+__device__ __forceinline__ void unpack_codes(const CodeRegs &r, bool narrow, uint32_t sym_add, uint16_t (&c)[ENC_PER_LANE]) {
+    if (narrow) {
+        const uint32_t wds[4] = {r.a.x, r.a.y, r.a.z, r.a.w};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t b = (wds[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            c[i] = (uint16_t)(b ? b + sym_add : 0u);
+        }
+    } else {
+        const uint32_t wds[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            c[2 * i] = (uint16_t)(wds[i] & 0xFFFF);
+            c[2 * i + 1] = (uint16_t)(wds[i] >> 16);
+        }
+    }
+}
+
+// persistent: every wave walks chunks wave_gid, +nwaves, ...; full chunks take the prefetching path, the ragged last
+// chunk (if any) the bounds-checked loader
 __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict__ codes, uint64_t n,
                                                      const uint32_t *__restrict__ g_enc,
-                                                     const szk_cb_info *__restrict__ info,
+                                                     const szk_cb_info *__restrict__ info, szk_mode mode, uint32_t sym_add,
                                                      uint16_t *__restrict__ chunk_words) {
     __shared__ uint32_t s_enc[ENC_WIN];
+    const bool narrow = szk_is_narrow(mode);
+    const uint64_t n_full = n / SZH_CHUNK_SYMS, n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
+    const uint64_t wave_gid = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE, nwaves = (uint64_t)gridDim.x * 4;
+    const uint64_t lane_off = (uint64_t)lane_id() * ENC_PER_LANE;
+    CodeRegs cur, nxt;
+    uint64_t chunk = wave_gid;
+    if (chunk < n_full) fetch_codes(codes, chunk * SZH_CHUNK_SYMS + lane_off, narrow, cur);  // in flight during the table load
     const uint32_t sym_min = info->sym_min, sym_count = info->sym_count;
     const bool all_lds = sym_count <= ENC_WIN;
     enc_table_load(s_enc, g_enc, sym_min, sym_count);
     __syncthreads();
-    const uint64_t chunk = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE;
-    if (chunk * SZH_CHUNK_SYMS >= n) return;
-    const uint64_t base = chunk * SZH_CHUNK_SYMS + (uint64_t)lane_id() * ENC_PER_LANE;
-    uint16_t c[ENC_PER_LANE];
-    load_codes16(codes, base, n, c);
-    uint32_t bits = 0;
+    for (; chunk < n_full; chunk += nwaves) {
+        const uint64_t nc = chunk + nwaves;
+        if (nc < n_full) fetch_codes(codes, nc * SZH_CHUNK_SYMS + lane_off, narrow, nxt);
+        uint16_t c[ENC_PER_LANE];
+        unpack_codes(cur, narrow, sym_add, c);
+        uint32_t bits = 0;
 #pragma unroll
-    for (int i = 0; i < ENC_PER_LANE; i++) {
-        const uint32_t e = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[i]);
-        bits += (base + i < n) ? (e & 31u) : 0u;
+        for (int i = 0; i < ENC_PER_LANE; i++) bits += enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[i]) & 31u;
+        bits = wave_sum(bits);
+        if (lane_id() == 0) chunk_words[chunk] = (uint16_t)((bits + 31) >> 5);
+        cur = nxt;
     }
-    bits = wave_sum(bits);
-    if (lane_id() == 0) chunk_words[chunk] = (uint16_t)((bits + 31) >> 5);
+    if (n_full < n_chunks && wave_gid == 0) {  // ragged tail
+        const uint64_t base = n_full * SZH_CHUNK_SYMS + lane_off;
+        uint16_t c[ENC_PER_LANE];
+        load_codes16(codes, base, n, narrow, sym_add, c);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int i = 0; i < ENC_PER_LANE; i++) {
+            const uint32_t e = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[i]);
+            bits += (base + i < n) ? (e & 31u) : 0u;
+        }
+        bits = wave_sum(bits);
+        if (lane_id() == 0) chunk_words[n_full] = (uint16_t)((bits + 31) >> 5);
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_scan_groups(const uint16_t *__restrict__ chunk_words, uint64_t n_chunks,
@@ -1503,50 +1395,32 @@ __global__ __launch_bounds__(1024) void k_scan_groups(const uint16_t *__restrict
     if (threadIdx.x == 0) *total_words = s_carry;
 }
 
-__global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes, uint64_t n,
-                                              const uint32_t *__restrict__ g_enc, const szk_cb_info *__restrict__ info,
-                                              const uint16_t *__restrict__ chunk_words,
-                                              const uint64_t *__restrict__ group_off,
-                                              const szk_state *__restrict__ state, uint8_t *__restrict__ payload) {
-    constexpr int STAGE_WORDS = SZH_CHUNK_SYMS * SZH_MAX_LEN / 32 + 4;  // + slack for the unconditional 3-word emit
-    __shared__ uint32_t s_enc[ENC_WIN];
-    __shared__ uint32_t s_stage[4][STAGE_WORDS];
-    const uint32_t sym_min = info->sym_min, sym_count = info->sym_count;
-    const bool all_lds = sym_count <= ENC_WIN;
-    enc_table_load(s_enc, g_enc, sym_min, sym_count);
-    const int wv = threadIdx.x / WAVE;
-    uint32_t *stage = s_stage[wv];
-    for (int i = lane_id(); i < STAGE_WORDS; i += WAVE) stage[i] = 0;
-    __syncthreads();
-    const uint64_t chunk = (uint64_t)blockIdx.x * 4 + wv;
-    if (chunk * SZH_CHUNK_SYMS >= n) return;
-    const uint64_t base = chunk * SZH_CHUNK_SYMS + (uint64_t)lane_id() * ENC_PER_LANE;
-    uint16_t c[ENC_PER_LANE];
-    load_codes16(codes, base, n, c);
-    // word offset of this chunk: group base + the chunks before it inside the group
-    const uint64_t grp = chunk / PACK_GROUP;
-    const uint32_t cin = (uint32_t)(chunk % PACK_GROUP);
-    uint32_t before = (uint32_t)lane_id() < cin ? chunk_words[grp * PACK_GROUP + lane_id()] : 0u;
-    before = wave_sum(before);
-    // 4 x (4 code words -> one 64-bit register)
+// pack 16 symbols of a lane into the wave's LDS stage at the lane's bit offset; returns the chunk's word count
+__device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE], uint64_t base, uint64_t n, bool check_n,
+                                               const uint32_t *s_enc, const uint32_t *__restrict__ g_enc,
+                                               uint32_t sym_min, bool all_lds, uint32_t *stage) {
     uint64_t g[4];
     uint32_t gl[4];
     uint32_t bits = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        uint64_t acc = 0;
-        uint32_t len = 0;
+        // two code words (<= 32 bits) are joined with 32-bit ops, two pairs (<= 64 bits) with one 64-bit shift
+        uint32_t pc[2], pl[2];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            uint32_t e = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[4 * k + i]);
-            e = (base + 4 * k + i < n) ? e : 0u;
-            const uint32_t l = e & 31u;
-            acc = (acc << l) | (uint64_t)(e >> 5);
-            len += l;
+        for (int h = 0; h < 2; h++) {
+            uint32_t e0 = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[4 * k + 2 * h]);
+            uint32_t e1 = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[4 * k + 2 * h + 1]);
+            if (check_n) {
+                e0 = (base + 4 * k + 2 * h < n) ? e0 : 0u;
+                e1 = (base + 4 * k + 2 * h + 1 < n) ? e1 : 0u;
+            }
+            const uint32_t l1 = e1 & 31u;
+            pc[h] = ((e0 >> 5) << l1) | (e1 >> 5);
+            pl[h] = (e0 & 31u) + l1;
         }
-        g[k] = acc;
-        gl[k] = len;
-        bits += len;
+        g[k] = ((uint64_t)pc[0] << pl[1]) | pc[1];
+        gl[k] = pl[0] + pl[1];
+        bits += gl[k];
     }
     const uint32_t incl = wave_incl_scan(bits);
     const uint32_t total_bits = __shfl(incl, WAVE - 1, WAVE);
@@ -1562,18 +1436,92 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         atomicOr(&stage[word + 2], w2);
         pos += gl[k];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t nwords = (total_bits + 31) >> 5;
-    uint32_t *out = reinterpret_cast<uint32_t *>(payload + state->off.bitstream) + group_off[grp] + before;
-    for (uint32_t i = lane_id(); i < nwords; i += WAVE) out[i] = stage[i];
+    return (total_bits + 31) >> 5;
+}
+
+// persistent like k_chunk_bits2: a wave owns a private LDS stage; per chunk it zeroes the words it will use, packs,
+// and streams them out; the next chunk's codes, word count and group offset are already in flight
+__global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes, uint64_t n,
+                                              const uint32_t *__restrict__ g_enc, const szk_cb_info *__restrict__ info,
+                                              const uint16_t *__restrict__ chunk_words,
+                                              const uint64_t *__restrict__ group_off, szk_mode mode, uint32_t sym_add,
+                                              const szk_state *__restrict__ state, uint8_t *__restrict__ payload) {
+    constexpr int STAGE_WORDS = SZH_CHUNK_SYMS * SZH_MAX_LEN / 32 + 4;  // + slack for the unconditional 3-word emit
+    __shared__ uint32_t s_enc[ENC_WIN];
+    __shared__ uint32_t s_stage[4][STAGE_WORDS];
+    const bool narrow = szk_is_narrow(mode);
+    const uint64_t n_full = n / SZH_CHUNK_SYMS, n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
+    const uint64_t wave_gid = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE, nwaves = (uint64_t)gridDim.x * 4;
+    const uint64_t lane_off = (uint64_t)lane_id() * ENC_PER_LANE;
+    const int lane = lane_id();
+    uint32_t *stage = s_stage[threadIdx.x / WAVE];
+    uint32_t *out_base = reinterpret_cast<uint32_t *>(payload + state->off.bitstream);
+
+    // side loads of a chunk: words of the chunks before it inside its group (one per lane) and the group offset
+    auto side = [&](uint64_t ch, uint32_t &before_part, uint64_t &goff) {
+        const uint64_t grp = ch / PACK_GROUP;
+        const uint32_t cin = (uint32_t)(ch % PACK_GROUP);
+        before_part = chunk_words[grp * PACK_GROUP + ((uint32_t)lane < cin ? lane : 0)];
+        before_part = (uint32_t)lane < cin ? before_part : 0u;
+        goff = group_off[grp];
+    };
+    CodeRegs cur, nxt;
+    uint32_t bp_cur = 0, bp_nxt = 0;
+    uint64_t go_cur = 0, go_nxt = 0;
+    uint64_t chunk = wave_gid;
+    if (chunk < n_full) {
+        fetch_codes(codes, chunk * SZH_CHUNK_SYMS + lane_off, narrow, cur);
+        side(chunk, bp_cur, go_cur);
+    }
+    const uint32_t sym_min = info->sym_min, sym_count = info->sym_count;
+    const bool all_lds = sym_count <= ENC_WIN;
+    enc_table_load(s_enc, g_enc, sym_min, sym_count);
+    for (int i = lane; i < STAGE_WORDS; i += WAVE) stage[i] = 0;
+    __syncthreads();
+    for (; chunk < n_full; chunk += nwaves) {
+        const uint64_t nc = chunk + nwaves;
+        if (nc < n_full) {
+            fetch_codes(codes, nc * SZH_CHUNK_SYMS + lane_off, narrow, nxt);
+            side(nc, bp_nxt, go_nxt);
+        }
+        uint16_t c[ENC_PER_LANE];
+        unpack_codes(cur, narrow, sym_add, c);
+        const uint32_t nwords = pack_chunk(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage);
+        const uint32_t before = wave_sum(bp_cur);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t *out = out_base + go_cur + before;
+        for (uint32_t i = lane; i < nwords + 2; i += WAVE) {  // copy out and re-zero the stage for the next chunk
+            const uint32_t wv = stage[i];
+            stage[i] = 0;
+            if (i < nwords) out[i] = wv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        cur = nxt;
+        bp_cur = bp_nxt;
+        go_cur = go_nxt;
+    }
+    if (n_full < n_chunks && wave_gid == 0) {  // ragged tail
+        const uint64_t base = n_full * SZH_CHUNK_SYMS + lane_off;
+        uint16_t c[ENC_PER_LANE];
+        load_codes16(codes, base, n, narrow, sym_add, c);
+        uint32_t bp;
+        uint64_t go;
+        side(n_full, bp, go);
+        const uint32_t nwords = pack_chunk(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage);
+        const uint32_t before = wave_sum(bp);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t *out = out_base + go + before;
+        for (uint32_t i = lane; i < nwords; i += WAVE) out[i] = stage[i];
+    }
 }
 
 // outlier lists are appended with atomics in arrival order; sorting them by element index makes the payload a pure
 // function of the input (the reference's CI compares stream digests across platforms, .github/workflows/cmake.yml:295-310).
 // One workgroup per list: LDS bitonic sort up to 2048 records, in-place global bitonic up to 65536; longer lists
 // (a sign that the bound is far too tight for the data) stay in arrival order.
-__global__ __launch_bounds__(1024) void k_sort_outliers(uint64_t *idx0, uint64_t *val0, const uint64_t *cnt0,
+__global__ __launch_bounds__(256) void k_sort_outliers(uint64_t *idx0, uint64_t *val0, const uint64_t *cnt0,
                                                         uint64_t *idx1, uint64_t *val1, const uint64_t *cnt1,
                                                         uint64_t cap, int val1_is_32bit, int val0_is_32bit) {
     __shared__ uint64_t s_i[2048], s_v[2048];
@@ -1590,15 +1538,15 @@ __global__ __launch_bounds__(1024) void k_sort_outliers(uint64_t *idx0, uint64_t
     };
     uint32_t np2 = 2;
     while (np2 < n) np2 <<= 1;
-    if (n <= 2048) {
-        for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
+    if (n <= 2048) {  // LDS bitonic; 4 waves keep the ~60 barriers cheap
+        for (uint32_t i = threadIdx.x; i < np2; i += 256) {
             s_i[i] = i < n ? idx[i] : ~0ull;
             s_v[i] = i < n ? ldv(i) : 0;
         }
         __syncthreads();
         for (uint32_t k = 2; k <= np2; k <<= 1)
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
+                for (uint32_t i = threadIdx.x; i < np2; i += 256) {
                     const uint32_t ixj = i ^ j;
                     if (ixj > i) {
                         const uint64_t a = s_i[i], b = s_i[ixj];
@@ -1613,7 +1561,7 @@ __global__ __launch_bounds__(1024) void k_sort_outliers(uint64_t *idx0, uint64_t
                 }
                 __syncthreads();
             }
-        for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
             idx[i] = s_i[i];
             stv(i, s_v[i]);
         }
@@ -1622,7 +1570,7 @@ __global__ __launch_bounds__(1024) void k_sort_outliers(uint64_t *idx0, uint64_t
     // global in-place bitonic; virtual padding: positions >= n compare as +infinity and are never written
     for (uint32_t k = 2; k <= np2; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < np2; i += 1024) {
+            for (uint32_t i = threadIdx.x; i < np2; i += 256) {
                 const uint32_t ixj = i ^ j;
                 if (ixj > i && i < n) {
                     const uint64_t a = idx[i], b = ixj < n ? idx[ixj] : ~0ull;
@@ -1950,7 +1898,7 @@ static uint32_t k1_grid(const void *kernel, uint64_t ntiles) {
 }
 
 template <typename T>
-static int launch_k1(int ndim, const void *d_in, uint16_t *codes, const szk_k1_params &p, hipStream_t s) {
+static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params &p, hipStream_t s) {
     const uint64_t d0 = p.d[3], d1 = p.d[2], d2 = p.d[1], d3 = p.d[0];
     auto tiles = [&](uint64_t tx, uint64_t ty, uint64_t tz) {
         return ((d0 + tx - 1) / tx) * ((d1 + ty - 1) / ty) * ((d2 + tz - 1) / tz) * d3;
@@ -1961,7 +1909,8 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, const szk_k1_p
     const bool fast = !szk_force_generic && (d0 % 4 == 0) && d0 < (1ull << 31) && d1 < (1ull << 31) && d2 < (1ull << 31) &&
                       d0 * d1 < (1ull << 27) && tiles(64, 8, FTZ) < (1ull << 31);
     constexpr int MTY = 4;
-    const bool march = fast && !(szk_dbg_flags & 32) && d0 >= 128 && tiles(MARCH_TX, MTY, MARCH_TZ) < (1ull << 31);
+    const bool march = fast && !(szk_dbg_flags & 32) && d0 >= 128 && tiles(MARCH_TX, MTY, MARCH_TZ) < (1ull << 31) && (ndim == 3 || ndim == 4);
+    if (!march) p.mode.allow = 0;
     switch (ndim) {
         case 1:
             nb = tiles(4096, 1, 1);
@@ -1975,6 +1924,10 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, const szk_k1_p
             break;
         case 3:
             if (march) {
+                if (p.mode.allow) {
+                    const uint64_t nsamp_threads = ((p.mode.n_total + SZK_PROBE_STRIDE - 1) / SZK_PROBE_STRIDE) * 64;
+                    hipLaunchKernelGGL((k_probe<T, 3>), dim3((uint32_t)((nsamp_threads + 255) / 256)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
+                }
                 nb = tiles(MARCH_TX, MTY, MARCH_TZ);  // wave tasks
                 uint32_t grid = k1_grid((const void *)k_lorenzo_quant_march<T, 3, MTY>, (nb + 3) / 4);
                 hipLaunchKernelGGL((k_lorenzo_quant_march<T, 3, MTY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
@@ -1994,6 +1947,10 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, const szk_k1_p
             break;
         default:
             if (march) {
+                if (p.mode.allow) {
+                    const uint64_t nsamp_threads = ((p.mode.n_total + SZK_PROBE_STRIDE - 1) / SZK_PROBE_STRIDE) * 64;
+                    hipLaunchKernelGGL((k_probe<T, 4>), dim3((uint32_t)((nsamp_threads + 255) / 256)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
+                }
                 nb = tiles(MARCH_TX, MTY, MARCH_TZ);  // wave tasks
                 uint32_t grid = k1_grid((const void *)k_lorenzo_quant_march<T, 4, MTY>, (nb + 3) / 4);
                 hipLaunchKernelGGL((k_lorenzo_quant_march<T, 4, MTY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
@@ -2015,9 +1972,10 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, const szk_k1_p
     SZK_CHECK_LAUNCH();
     return 0;
 }
-int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, const szk_k1_params *p, hipStream_t s) {
-    szk_k1_params pp = *p;
+int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, szk_k1_params *p, hipStream_t s) {
+    szk_k1_params &pp = *p;  // mode.allow is cleared when the chosen kernel has no one-byte store path
     pp.dbg = (uint32_t)szk_dbg_flags;
+    if (szk_dbg_flags & 64) pp.mode.allow = 0;
     return dtype == 0 ? launch_k1<float>(ndim, d_in, codes, pp, s) : launch_k1<double>(ndim, d_in, codes, pp, s);
 }
 
@@ -2035,20 +1993,21 @@ int szk_launch_layout_pre(const szk_layout_params *p, hipStream_t s) {
     return 0;
 }
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
-                      uint16_t *chunk_words, uint64_t *group_off, uint64_t *total_words, const szk_state *state,
-                      uint8_t *payload, hipStream_t s) {
+                      szk_mode mode, uint16_t *chunk_words, uint64_t *group_off, uint64_t *total_words,
+                      const szk_state *state, uint8_t *payload, hipStream_t s) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
     const uint64_t nb = (n_chunks + 3) / 4;
     if (nb > 0x7FFFFFFFull) return -1;
-    (void)radius;
-    hipLaunchKernelGGL(k_chunk_bits2, dim3((uint32_t)nb), dim3(256), 0, s, codes, n, d_enc, info, chunk_words);
+    const uint32_t sym_add = (uint32_t)radius - 128u;
+    const uint32_t pgrid = (uint32_t)(nb < 2048 ? nb : 2048);  // persistent: 8 workgroups per CU
+    hipLaunchKernelGGL(k_chunk_bits2, dim3(pgrid), dim3(256), 0, s, codes, n, d_enc, info, mode, sym_add, chunk_words);
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, chunk_words, n_chunks, group_off, total_words);
-    hipLaunchKernelGGL(k_pack, dim3((uint32_t)nb), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, state, payload);
+    hipLaunchKernelGGL(k_pack, dim3(pgrid < 1280 ? pgrid : 1280), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode, sym_add, state, payload);
     SZK_CHECK_LAUNCH();
     return 0;
 }
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s) {
-    hipLaunchKernelGGL(k_sort_outliers, dim3(2), dim3(1024), 0, s, const_cast<uint64_t *>(p->vout_idx),
+    hipLaunchKernelGGL(k_sort_outliers, dim3(2), dim3(256), 0, s, const_cast<uint64_t *>(p->vout_idx),
                        (uint64_t *)const_cast<void *>(p->vout_val), p->n_vout, const_cast<uint64_t *>(p->dout_idx),
                        (uint64_t *)const_cast<void *>(p->dout_val), p->n_dout, p->out_cap, p->q_is_32bit, p->t_is_32bit);
     hipLaunchKernelGGL(k_assemble, dim3(512), dim3(256), 0, s, *p);

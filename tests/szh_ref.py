@@ -11,8 +11,9 @@ CHUNK = 1024
 MAX_LEN = 16
 
 
-def dualquant(a, eb, radius=32768):
-    """Expected lattice indices, codes and outliers for array `a` (any ndim <= 4), exactly as K1 computes them."""
+def dualquant(a, eb, radius=32768, narrow=False):
+    """Expected lattice indices, codes and outliers for array `a` (any ndim <= 4), exactly as K1 computes them.
+    narrow: stage 1 kept one-byte codes, i.e. deltas outside [-127, 127] became delta outliers."""
     a = np.ascontiguousarray(a)
     T = a.dtype
     # lattice arithmetic in the data type (sz3hip_kernels.hip, Lattice<T>): one rounding per multiply, no FMA
@@ -51,7 +52,7 @@ def dualquant(a, eb, radius=32768):
             sl_lo[ax] = slice(0, -1)
             with np.errstate(over="ignore"):
                 d = (p[tuple(sl_hi)] - p[tuple(sl_lo)]).astype(qt)
-    inr = (d > -radius) & (d < radius)
+    inr = ((d >= -127) & (d <= 127)) if narrow else ((d > -radius) & (d < radius))
     codes = np.where(inr, d + radius, 0).astype(np.uint16)
     return q, d, codes, bad, ~inr
 

@@ -60,7 +60,7 @@ CASES = [
 def test_stages(name, gen, eb):
     a = gen()
     codes, pl, dec, st = _roundtrip_device(a, eb)
-    q, d, exp_codes, bad, dout = szh_ref.dualquant(a, eb)
+    q, d, exp_codes, bad, dout = szh_ref.dualquant(a, eb, narrow=bool(st["narrow_codes"]))
     # K1: codes bit-exact against the numpy model
     assert np.array_equal(codes, exp_codes.reshape(-1)), "quantisation codes differ from the model"
     h, o, sec = szh_ref.parse(pl)
@@ -110,7 +110,7 @@ def test_outliers_and_nonfinite():
     a[5, 6, 7] = 3000.0   # representable on the lattice (|x/2eb| < 2^23) but a huge Lorenzo delta -> delta outlier
     eb = 1e-3
     codes, pl, dec, st = _roundtrip_device(a, eb)
-    q, d, exp_codes, bad, dout = szh_ref.dualquant(a, eb)
+    q, d, exp_codes, bad, dout = szh_ref.dualquant(a, eb, narrow=bool(st["narrow_codes"]))
     assert np.array_equal(codes, exp_codes.reshape(-1))
     assert st["n_value_outliers"] == int(bad.sum()) >= 4 and st["n_delta_outliers"] == int(dout.sum()) > 0
     fin = np.isfinite(a)
@@ -126,14 +126,42 @@ def test_fast_kernel_equals_generic(shape, dtype):
     a[tuple(s // 2 for s in shape)] = np.nan
     a[tuple(s // 3 for s in shape)] = 4e4
     try:
+        sz3_amd.lib().sz3hip_debug_flags(64)          # two-byte codes on both sides (the narrow mode has its own test)
         sz3_amd.lib().sz3hip_debug_force_generic(1)
         c0, p0, d0, s0 = _roundtrip_device(a, 1e-3)
+        sz3_amd.lib().sz3hip_debug_force_generic(0)
+        c1, p1, d1, s1 = _roundtrip_device(a, 1e-3)
     finally:
         sz3_amd.lib().sz3hip_debug_force_generic(0)
-    c1, p1, d1, s1 = _roundtrip_device(a, 1e-3)
+        sz3_amd.lib().sz3hip_debug_flags(0)
     assert np.array_equal(c0, c1)
     assert s0["n_value_outliers"] == s1["n_value_outliers"] and s0["n_delta_outliers"] == s1["n_delta_outliers"]
     h0, _, sec0 = szh_ref.parse(p0)
     h1, _, sec1 = szh_ref.parse(p1)
     assert np.array_equal(sec0["bitstream"], sec1["bitstream"]) and np.array_equal(sec0["lens"], sec1["lens"])
     assert np.array_equal(d0, d1, equal_nan=True)
+
+
+def test_narrow_and_wide_code_paths_agree():
+    """one-byte intermediate codes (probe says the deltas are small) vs two-byte codes: same payload"""
+    a = field3d((24, 20, 256))
+    c1, p1, d1, s1 = _roundtrip_device(a, 1e-3)
+    assert s1["narrow_codes"] == 1
+    try:
+        sz3_amd.lib().sz3hip_debug_flags(64)   # forbid the narrow mode
+        c0, p0, d0, s0 = _roundtrip_device(a, 1e-3)
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(0)
+    assert s0["narrow_codes"] == 0
+    assert np.array_equal(c0, c1) and np.array_equal(p0, p1) and np.array_equal(d0, d1)
+    # rough data: the probe must refuse the narrow mode (deltas of a few hundred lattice steps)
+    b = field3d((24, 20, 256), sigma=0.2)
+    c2, p2, d2, s2 = _roundtrip_device(b, 1e-3)
+    assert s2["narrow_codes"] == 0
+    assert np.max(np.abs(d2.astype(np.float64) - b.astype(np.float64))) <= 1e-3
+    # moderately rough: narrow with a few delta outliers
+    e = field3d((24, 20, 256), sigma=0.012)
+    c3, p3, d3, s3 = _roundtrip_device(e, 1e-3)
+    q, dd, exp_codes, bad, dout = szh_ref.dualquant(e, 1e-3, narrow=bool(s3["narrow_codes"]))
+    assert np.array_equal(c3, exp_codes.reshape(-1)) and s3["n_delta_outliers"] == int(dout.sum())
+    assert np.max(np.abs(d3.astype(np.float64) - e.astype(np.float64))) <= 1e-3

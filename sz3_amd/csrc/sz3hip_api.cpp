@@ -614,6 +614,14 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     cb.aux2 = ctx->d_aux2;
     cb.pint2 = ctx->d_pint2;
     cb.range = ctx->d_range;
+    cb.vout_idx = ctx->d_vout_idx;
+    cb.dout_idx = ctx->d_dout_idx;
+    cb.vout_val = ctx->d_vout_val;
+    cb.dout_val = ctx->d_dout_val;
+    cb.n_vout = ctx->d_counters + 0;
+    cb.n_dout = ctx->d_counters + 1;
+    cb.out_cap = ctx->cur_out_cap;
+    cb.t_is_32bit = cb.q_is_32bit = ctx->dtype == SZ3HIP_FLOAT;
     cb.info = ctx->d_info;
     prof_begin(ctx, ST_CODEBOOK, s);
     int rc = szk_launch_codebook(ctx->d_hist, &cb, s);

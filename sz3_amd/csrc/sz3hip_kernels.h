@@ -60,6 +60,12 @@ struct szk_cb_params {
     uint64_t *ifreq;
     uint16_t *pleaf, *pint, *depth, *aux2, *pint2;  // [65536] scratch for alphabets > 2048 symbols
     uint32_t *range;                 // [4] see k_hist_range
+    // the two outlier lists, sorted by blocks 1 and 2 of the same launch
+    uint64_t *vout_idx, *dout_idx;
+    void *vout_val, *dout_val;
+    const uint64_t *n_vout, *n_dout;
+    uint64_t out_cap;
+    int t_is_32bit, q_is_32bit;
     szk_cb_info *info;
 };
 

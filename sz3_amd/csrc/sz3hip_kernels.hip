@@ -947,6 +947,73 @@ __global__ __launch_bounds__(256) void k_hist_range(const uint64_t *__restrict__
     }
 }
 
+// outlier lists are appended with atomics in arrival order; sorting them by element index makes the payload a pure
+// function of the input (the reference's CI compares stream digests across platforms, .github/workflows/cmake.yml:295-310).
+// One workgroup per list (blocks 1 and 2 of the k_codebook launch): LDS bitonic sort up to 2048 records, in-place global bitonic up to 65536; longer lists
+// (a sign that the bound is far too tight for the data) stay in arrival order.
+__device__ void sort_outlier_list(uint64_t *idx, void *val, uint64_t n, uint64_t cap, bool v32, uint64_t *s_i,
+                                  uint64_t *s_v) {
+    uint8_t *valb = reinterpret_cast<uint8_t *>(val);
+    if (n > cap) n = cap;
+    if (n < 2 || n > 65536) return;
+    auto ldv = [&](uint64_t i) -> uint64_t { return v32 ? (uint64_t) reinterpret_cast<uint32_t *>(valb)[i] : reinterpret_cast<uint64_t *>(valb)[i]; };
+    auto stv = [&](uint64_t i, uint64_t v) {
+        if (v32) reinterpret_cast<uint32_t *>(valb)[i] = (uint32_t)v;
+        else reinterpret_cast<uint64_t *>(valb)[i] = v;
+    };
+    uint32_t np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    if (n <= 2048) {  // LDS bitonic; 4 waves keep the ~60 barriers cheap
+        for (uint32_t i = threadIdx.x; i < np2; i += 256) {
+            s_i[i] = i < n ? idx[i] : ~0ull;
+            s_v[i] = i < n ? ldv(i) : 0;
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= np2; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = threadIdx.x; i < np2; i += 256) {
+                    const uint32_t ixj = i ^ j;
+                    if (ixj > i) {
+                        const uint64_t a = s_i[i], b = s_i[ixj];
+                        if ((a > b) == ((i & k) == 0)) {
+                            s_i[i] = b;
+                            s_i[ixj] = a;
+                            const uint64_t t = s_v[i];
+                            s_v[i] = s_v[ixj];
+                            s_v[ixj] = t;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            idx[i] = s_i[i];
+            stv(i, s_v[i]);
+        }
+        return;
+    }
+    // global in-place bitonic; virtual padding: positions >= n compare as +infinity and are never written
+    for (uint32_t k = 2; k <= np2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < np2; i += 256) {
+                const uint32_t ixj = i ^ j;
+                if (ixj > i && i < n) {
+                    const uint64_t a = idx[i], b = ixj < n ? idx[ixj] : ~0ull;
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up && ixj < n) {
+                        idx[i] = b;
+                        idx[ixj] = a;
+                        const uint64_t t = ldv(i);
+                        stv(i, ldv(ixj));
+                        stv(ixj, t);
+                    }
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+}
+
 __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restrict__ hist, szk_cb_params p) {
     __shared__ uint64_t s_keys[CB_LDS_SYMS];
     __shared__ uint64_t s_ifreq[CB_LDS_SYMS];
@@ -956,6 +1023,12 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
     __shared__ uint32_t s_lo, s_hi, s_over;
     __shared__ uint32_t s_first[SZH_MAX_LEN + 2], s_cnt[SZH_MAX_LEN + 2];
     const uint32_t t = threadIdx.x;
+    if (blockIdx.x > 0) {  // blocks 1 and 2: deterministic order of the two outlier lists (independent of the code book)
+        const bool d = blockIdx.x == 2;
+        sort_outlier_list(d ? p.dout_idx : p.vout_idx, d ? p.dout_val : p.vout_val, d ? *p.n_dout : *p.n_vout, p.out_cap,
+                          d ? p.q_is_32bit != 0 : p.t_is_32bit != 0, s_keys, s_ifreq);
+        return;
+    }
 
     if (t == 0) p.info->ts[0] = wall_clock64();
     if (t == 0) p.info->ts[0] = wall_clock64();
@@ -1083,8 +1156,56 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
             atomicAdd(&s_cnt[l], 1u);
         }
         __syncthreads();
-        if (s_over) {
+        if (s_over && !small) {
             if (t == 0) cb_kraft_repair(pleaf, m, s_cnt);
+            __syncthreads();
+        } else if (s_over) {
+            // Kraft repair in closed form (same policy as cb_kraft_repair): the clamped leaves are the first c in
+            // the sorted order; promoting leaf q >= c all the way to the limit frees 2^(L - len_q) - 1 units; take the
+            // shortest prefix of them that covers the excess E, then hand the surplus of the last one back by
+            // shortening the most frequent maximal-length codes by one bit each.
+            uint64_t kraft = 0;
+            for (uint32_t l = 1; l <= SZH_MAX_LEN; l++) kraft += (uint64_t)s_cnt[l] << (SZH_MAX_LEN - l);
+            const uint64_t E = kraft - (1ull << SZH_MAX_LEN);  // > 0 here
+            const uint32_t c = s_cnt[SZH_MAX_LEN];
+            constexpr uint32_t PER = CB_LDS_SYMS / CB_THREADS;  // 8 consecutive leaves per thread
+            uint64_t loc[PER], run = 0;
+            for (uint32_t e = 0; e < PER; e++) {
+                const uint32_t q = t * PER + e;
+                const uint32_t l = q < m ? pleaf[q] : SZH_MAX_LEN;
+                run += (q < m && q >= c) ? ((1ull << (SZH_MAX_LEN - l)) - 1) : 0ull;
+                loc[e] = run;
+            }
+            const uint64_t incl = wave_incl_scan(run);
+            __shared__ uint64_t s_wsum[CB_THREADS / WAVE];
+            __shared__ uint32_t s_kend, s_slack;
+            if (lane_id() == WAVE - 1) s_wsum[t / WAVE] = incl;
+            if (t == 0) {
+                s_kend = 0xFFFFFFFFu;
+                s_slack = 0;
+            }
+            __syncthreads();
+            uint64_t base = incl - run;
+            for (uint32_t wv = 0; wv < t / WAVE; wv++) base += s_wsum[wv];
+            for (uint32_t e = 0; e < PER; e++) {
+                const uint64_t hi = base + loc[e], lo = base + (e ? loc[e - 1] : 0ull);
+                if (lo < E && E <= hi) {  // exactly one (q) satisfies this
+                    s_kend = t * PER + e;
+                    s_slack = (uint32_t)(hi - E);
+                }
+            }
+            __syncthreads();
+            const uint32_t kend = s_kend;
+            if (kend != 0xFFFFFFFFu) {
+                const uint32_t n16 = kend + 1;  // leaves [0, kend] now sit at the limit
+                const uint32_t back = s_slack < n16 ? s_slack : n16;
+                for (uint32_t q = t; q <= kend; q += CB_THREADS)
+                    pleaf[q] = (uint16_t)((q + back > kend) ? SZH_MAX_LEN - 1 : SZH_MAX_LEN);
+            }
+            __syncthreads();
+            if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
+            __syncthreads();
+            for (uint32_t q = t; q < m; q += CB_THREADS) atomicAdd(&s_cnt[pleaf[q]], 1u);
             __syncthreads();
         }
         // 6. canonical first code per length
@@ -1517,78 +1638,6 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     }
 }
 
-// outlier lists are appended with atomics in arrival order; sorting them by element index makes the payload a pure
-// function of the input (the reference's CI compares stream digests across platforms, .github/workflows/cmake.yml:295-310).
-// One workgroup per list: LDS bitonic sort up to 2048 records, in-place global bitonic up to 65536; longer lists
-// (a sign that the bound is far too tight for the data) stay in arrival order.
-__global__ __launch_bounds__(256) void k_sort_outliers(uint64_t *idx0, uint64_t *val0, const uint64_t *cnt0,
-                                                        uint64_t *idx1, uint64_t *val1, const uint64_t *cnt1,
-                                                        uint64_t cap, int val1_is_32bit, int val0_is_32bit) {
-    __shared__ uint64_t s_i[2048], s_v[2048];
-    uint64_t *idx = blockIdx.x == 0 ? idx0 : idx1;
-    uint8_t *valb = reinterpret_cast<uint8_t *>(blockIdx.x == 0 ? val0 : val1);
-    const bool v32 = blockIdx.x == 0 ? val0_is_32bit : val1_is_32bit;
-    uint64_t n = blockIdx.x == 0 ? *cnt0 : *cnt1;
-    if (n > cap) n = cap;
-    if (n < 2 || n > 65536) return;
-    auto ldv = [&](uint64_t i) -> uint64_t { return v32 ? (uint64_t) reinterpret_cast<uint32_t *>(valb)[i] : reinterpret_cast<uint64_t *>(valb)[i]; };
-    auto stv = [&](uint64_t i, uint64_t v) {
-        if (v32) reinterpret_cast<uint32_t *>(valb)[i] = (uint32_t)v;
-        else reinterpret_cast<uint64_t *>(valb)[i] = v;
-    };
-    uint32_t np2 = 2;
-    while (np2 < n) np2 <<= 1;
-    if (n <= 2048) {  // LDS bitonic; 4 waves keep the ~60 barriers cheap
-        for (uint32_t i = threadIdx.x; i < np2; i += 256) {
-            s_i[i] = i < n ? idx[i] : ~0ull;
-            s_v[i] = i < n ? ldv(i) : 0;
-        }
-        __syncthreads();
-        for (uint32_t k = 2; k <= np2; k <<= 1)
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t i = threadIdx.x; i < np2; i += 256) {
-                    const uint32_t ixj = i ^ j;
-                    if (ixj > i) {
-                        const uint64_t a = s_i[i], b = s_i[ixj];
-                        if ((a > b) == ((i & k) == 0)) {
-                            s_i[i] = b;
-                            s_i[ixj] = a;
-                            const uint64_t t = s_v[i];
-                            s_v[i] = s_v[ixj];
-                            s_v[ixj] = t;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-        for (uint32_t i = threadIdx.x; i < n; i += 256) {
-            idx[i] = s_i[i];
-            stv(i, s_v[i]);
-        }
-        return;
-    }
-    // global in-place bitonic; virtual padding: positions >= n compare as +infinity and are never written
-    for (uint32_t k = 2; k <= np2; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < np2; i += 256) {
-                const uint32_t ixj = i ^ j;
-                if (ixj > i && i < n) {
-                    const uint64_t a = idx[i], b = ixj < n ? idx[ixj] : ~0ull;
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up && ixj < n) {
-                        idx[i] = b;
-                        idx[ixj] = a;
-                        const uint64_t t = ldv(i);
-                        stv(i, ldv(ixj));
-                        stv(ixj, t);
-                    }
-                }
-            }
-            __threadfence_block();
-            __syncthreads();
-        }
-}
-
 // header + side sections (lens, chunk table, outliers) into the payload
 __global__ __launch_bounds__(256) void k_assemble(szk_asm_params p) {
     const szh_header h0 = p.state->hdr;
@@ -1983,7 +2032,7 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
     hipError_t e = hipMemsetAsync(p->range, 0, 16, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256), dim3(256), 0, s, d_hist, p->range);
-    hipLaunchKernelGGL(k_codebook, dim3(1), dim3(CB_THREADS), 0, s, d_hist, *p);
+    hipLaunchKernelGGL(k_codebook, dim3(3), dim3(CB_THREADS), 0, s, d_hist, *p);
     SZK_CHECK_LAUNCH();
     return 0;
 }
@@ -2007,9 +2056,6 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
     return 0;
 }
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s) {
-    hipLaunchKernelGGL(k_sort_outliers, dim3(2), dim3(256), 0, s, const_cast<uint64_t *>(p->vout_idx),
-                       (uint64_t *)const_cast<void *>(p->vout_val), p->n_vout, const_cast<uint64_t *>(p->dout_idx),
-                       (uint64_t *)const_cast<void *>(p->dout_val), p->n_dout, p->out_cap, p->q_is_32bit, p->t_is_32bit);
     hipLaunchKernelGGL(k_assemble, dim3(512), dim3(256), 0, s, *p);
     SZK_CHECK_LAUNCH();
     return 0;

@@ -12,7 +12,8 @@
 
 namespace {
 SZ3::Config make_conf(int N, const size_t *dims_slowest_first, int algo, int eb_mode, double abs_eb, double rel_eb,
-                      int lorenzo, int lorenzo2, int regression, int openmp, int interp_algo, int block_size) {
+                      int lorenzo, int lorenzo2, int regression, int openmp, int interp_algo, int block_size,
+                      int interp_dir = -1, int anchor_stride = -2, double alpha = -2, double beta = -2) {
     std::vector<size_t> d(dims_slowest_first, dims_slowest_first + N);
     SZ3::Config conf;
     conf.setDims(d.begin(), d.end());
@@ -26,6 +27,10 @@ SZ3::Config make_conf(int N, const size_t *dims_slowest_first, int algo, int eb_
     conf.openmp = openmp != 0;
     if (interp_algo >= 0) conf.interpAlgo = static_cast<uint8_t>(interp_algo);
     if (block_size > 0) conf.blockSize = block_size;
+    if (interp_dir >= 0) conf.interpDirection = static_cast<uint8_t>(interp_dir);
+    if (anchor_stride > -2) conf.interpAnchorStride = anchor_stride;
+    if (alpha > -2) conf.interpAlpha = alpha;
+    if (beta > -2) conf.interpBeta = beta;
     return conf;
 }
 template <class T>
@@ -50,6 +55,20 @@ size_t ref_compress(int dtype, const void *data, int N, const size_t *dims, int 
         return do_compress<double>(static_cast<const double *>(data), out, cap, conf, seconds);
     } catch (std::exception &e) {
         fprintf(stderr, "ref_compress: %s\n", e.what());
+        return 0;
+    }
+}
+// same with the interpolation parameters of SZ3::Config (interpDirection, interpAnchorStride, interpAlpha, interpBeta)
+size_t ref_compress_ex(int dtype, const void *data, int N, const size_t *dims, int algo, int eb_mode, double abs_eb,
+                       double rel_eb, int lorenzo, int lorenzo2, int regression, int openmp, int interp_algo, int block_size,
+                       int interp_dir, int anchor_stride, double alpha, double beta, char *out, size_t cap, double *seconds) {
+    try {
+        SZ3::Config conf = make_conf(N, dims, algo, eb_mode, abs_eb, rel_eb, lorenzo, lorenzo2, regression, openmp,
+                                     interp_algo, block_size, interp_dir, anchor_stride, alpha, beta);
+        if (dtype == 0) return do_compress<float>(static_cast<const float *>(data), out, cap, conf, seconds);
+        return do_compress<double>(static_cast<const double *>(data), out, cap, conf, seconds);
+    } catch (std::exception &e) {
+        fprintf(stderr, "ref_compress_ex: %s\n", e.what());
         return 0;
     }
 }

@@ -746,3 +746,17 @@ size_t szo_decomposition_codes(const szo_config *config, int dtype, const void *
     }
     return (size_t)st.n_unpred;
 }
+
+size_t szo_interp_codes(const szo_config *config, int dtype, const void *data, int32_t *codes, uint64_t *order, void *recon) {
+    szo_config conf = *config;
+    if (conf.interpAnchorStride < 0) {
+        static const int def[4] = {4096, 128, 32, 16};
+        conf.interpAnchorStride = def[conf.N - 1];
+    }
+    if (dtype == SZO_FLOAT) {
+        if (cal_abs_eb_f32(&conf, (const float *)data)) return (size_t)-1;
+        return interp_codes_f32(&conf, (const float *)data, codes, order, (float *)recon);
+    }
+    if (cal_abs_eb_f64(&conf, (const double *)data)) return (size_t)-1;
+    return interp_codes_f64(&conf, (const double *)data, codes, order, (double *)recon);
+}

@@ -90,6 +90,11 @@ void szo_set_omp_slabs(int n);
  * data is NOT modified (internally copied). returns number of unpredictable values. */
 size_t szo_decomposition_codes(const szo_config *c, int dtype, const void *data, int32_t *codes);
 
+/* InterpolationDecomposition::compress only (ALGO_INTERP parameters from conf; interpAnchorStride must be >= 0):
+ * codes in the reference's emission order, the element index of every code (order, may be NULL) and the reconstructed
+ * array the encoder ends up with (recon, may be NULL).  returns the number of unpredictable values (incl. anchors) */
+size_t szo_interp_codes(const szo_config *c, int dtype, const void *data, int32_t *codes, uint64_t *order, void *recon);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,8 @@ def oracle():
         L.szo_decomposition_codes.restype = C.c_size_t
         L.szo_decomposition_codes.argtypes = [C.POINTER(SzoConfig), C.c_int, C.c_void_p, C.c_void_p]
         L.szo_set_omp_slabs.argtypes = [C.c_int]
+        L.szo_interp_codes.restype = C.c_size_t
+        L.szo_interp_codes.argtypes = [C.POINTER(SzoConfig), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _oracle = L
     return _oracle
 
@@ -153,6 +155,17 @@ def oracle_codes(a, conf):
     return codes, n
 
 
+def oracle_interp_codes(a, conf):
+    """(codes in emission order, element index of every code, reconstructed array, #unpredictable)"""
+    L = oracle()
+    a = np.ascontiguousarray(a)
+    codes = np.empty(a.size, dtype=np.int32)
+    order = np.empty(a.size, dtype=np.uint64)
+    recon = np.empty_like(a)
+    n = L.szo_interp_codes(C.byref(conf), _dtype_id(a), a.ctypes.data, codes.ctypes.data, order.ctypes.data, recon.ctypes.data)
+    return codes, order, recon, n
+
+
 # ---------------------------------------------------------------------------------------------------------
 _ref = None
 
@@ -169,6 +182,10 @@ def ref():
         L.ref_compress.argtypes = [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_double,
                                    C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_size_t, C.POINTER(C.c_double)]
+        L.ref_compress_ex.restype = C.c_size_t
+        L.ref_compress_ex.argtypes = [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_double,
+                                      C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_double, C.c_double, C.c_void_p, C.c_size_t, C.POINTER(C.c_double)]
         L.ref_compress_bound.restype = C.c_size_t
         L.ref_compress_bound.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_size_t)]
         L.ref_decompress.restype = C.c_size_t
@@ -186,9 +203,10 @@ def ref_compress(a, conf, timing=False):
     cap = L.ref_compress_bound(_dtype_id(a), len(shape), d)
     out = np.empty(cap, dtype=np.uint8)
     sec = C.c_double(0)
-    n = L.ref_compress(_dtype_id(a), a.ctypes.data, len(shape), d, conf.cmprAlgo, conf.errorBoundMode,
-                       conf.absErrorBound, conf.relErrorBound, conf.lorenzo, conf.lorenzo2, conf.regression,
-                       conf.openmp, conf.interpAlgo, conf.blockSize, out.ctypes.data, cap, C.byref(sec))
+    n = L.ref_compress_ex(_dtype_id(a), a.ctypes.data, len(shape), d, conf.cmprAlgo, conf.errorBoundMode,
+                          conf.absErrorBound, conf.relErrorBound, conf.lorenzo, conf.lorenzo2, conf.regression,
+                          conf.openmp, conf.interpAlgo, conf.blockSize, conf.interpDirection, conf.interpAnchorStride,
+                          conf.interpAlpha, conf.interpBeta, out.ctypes.data, cap, C.byref(sec))
     if n == 0:
         raise RuntimeError("reference compress failed")
     blob = out[:n].copy()

@@ -44,7 +44,8 @@ enum {
     SZ3HIP_ALGO_INTERP = 2,
     SZ3HIP_ALGO_NOPRED = 3,
     SZ3HIP_ALGO_LOSSLESS = 4,
-    SZ3HIP_ALGO_HIP_LORENZO = 16 /* dual-quantisation integer Lorenzo + chunked canonical Huffman (this library) */
+    SZ3HIP_ALGO_HIP_LORENZO = 16, /* dual-quantisation integer Lorenzo + chunked canonical Huffman (this library) */
+    SZ3HIP_ALGO_HIP_INTERP = 17   /* the reference's multilevel interpolation, pass-parallel, same codes bit for bit */
 };
 
 enum {

@@ -21,6 +21,8 @@ LIB_PATH = os.path.join(_HERE, "libsz3hip.so")
 EB_ABS, EB_REL, EB_PSNR, EB_L2NORM, EB_ABS_AND_REL, EB_ABS_OR_REL = range(6)
 ALGO_LORENZO_REG, ALGO_INTERP_LORENZO, ALGO_INTERP, ALGO_NOPRED, ALGO_LOSSLESS = range(5)
 ALGO_HIP_LORENZO = 16
+ALGO_HIP_INTERP = 17
+INTERP_ALGO_LINEAR, INTERP_ALGO_CUBIC = 0, 1
 SZ_FLOAT, SZ_DOUBLE = 0, 1
 
 

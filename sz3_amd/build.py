@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsz3hip.so")
-SOURCES = ["sz3hip_kernels.hip", "sz3hip_api.cpp"]
+SOURCES = ["sz3hip_kernels.hip", "sz3hip_interp.hip", "sz3hip_api.cpp"]
 HEADERS = ["sz3hip_kernels.h", "sz3hip_format.h", "../../include/sz3hip.h", "../../include/sz3c.h"]
 
 

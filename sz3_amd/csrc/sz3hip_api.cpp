@@ -365,6 +365,7 @@ struct sz3hip_ctx {
     uint64_t *d_hist_own;  // internal allocation
     uint64_t *d_counters;  // [0]=n_vout [1]=n_dout [2]=total_words
     uint32_t *d_hist_partial;
+    void *d_work;          // interpolation: the array being overwritten with reconstructed values (lazy)
     uint64_t *d_vout_idx, *d_dout_idx;
     void *d_vout_val, *d_dout_val;
     uint32_t *d_enc;
@@ -395,7 +396,7 @@ struct sz3hip_ctx {
 
 static void ctx_free(sz3hip_ctx *c) {
     if (!c) return;
-    void *bufs[] = {c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_counters, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
+    void *bufs[] = {c->d_work, c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_counters, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
                     c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_aux2, c->d_pint2, c->d_range, c->d_info,
                     c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax};
     for (void *b : bufs)
@@ -550,15 +551,69 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
 
     HIPCHK(hipMemsetAsync(ctx->d_hist, 0, SZH_HIST_BINS * 8, s));
     HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 64, s));
+    ctx->cur_out_cap = std::min<uint64_t>(ctx->out_cap, std::max<uint64_t>(1024, num / 32));
+    if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP || conf->cmprAlgo == SZ3HIP_ALGO_INTERP_LORENZO ||
+        conf->cmprAlgo == SZ3HIP_ALGO_HIP_INTERP) {
+        // multilevel interpolation with the Config's parameters (SZ_compress_Interp, api/impl/SZAlgoInterp.hpp:17-30).
+        // ALGO_INTERP_LORENZO's sampling auto-tuner (SZAlgoInterp.hpp:122-286) is not implemented: its defaults are used.
+        if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
+        szk_interp_params ip;
+        memset(&ip, 0, sizeof(ip));
+        ip.N = conf->N;
+        for (int i = 0; i < conf->N; i++) ip.dims[i] = conf->dims[i];
+        ip.interp_id = conf->interpAlgo ? 1 : 0;
+        ip.direction = conf->interpDirection;
+        static const int def_anchor[4] = {4096, 128, 32, 16};  // SZAlgoInterp.hpp:20-24
+        ip.anchor_stride = conf->interpAnchorStride < 0 ? (uint64_t)def_anchor[conf->N - 1] : (uint64_t)conf->interpAnchorStride;
+        if (ip.anchor_stride & (ip.anchor_stride - 1)) return fail(SZ3HIP_EINVAL, "Anchor stride should be 0 or 2's exponentials");
+        int nperm = 1;
+        for (int i = 2; i <= conf->N; i++) nperm *= i;
+        if (ip.direction < 0 || ip.direction >= nperm) return fail(SZ3HIP_EINVAL, "interpDirection out of range");
+        ip.alpha = conf->interpAlpha;
+        ip.beta = conf->interpBeta;
+        ip.eb = eb;
+        ip.radius = radius;
+        ip.n_vout = ctx->d_counters + 0;
+        ip.vout_idx = ctx->d_vout_idx;
+        ip.vout_val = ctx->d_vout_val;
+        ip.out_cap = ctx->cur_out_cap;
+        prof_begin(ctx, ST_K1, s);
+        int rci = szk_launch_interp_compress(ctx->dtype, &ip, d_in, ctx->d_work, ctx->d_codes, ctx->d_hist, s);
+        prof_end(ctx, ST_K1, s);
+        if (rci) return fail(SZ3HIP_EHIP, "interpolation kernel launch failed (%d)", rci);
+        memset(&ctx->mode, 0, sizeof(ctx->mode));
+        ctx->mode.probe_big = reinterpret_cast<uint32_t *>(ctx->d_counters + 4);
+        szh_header &hh = ctx->proto;
+        memset(&hh, 0, sizeof(hh));
+        hh.magic = SZH_MAGIC;
+        hh.version = SZH_VERSION;
+        hh.dtype = (uint8_t)ctx->dtype;
+        hh.ndim = (uint8_t)conf->N;
+        hh.qbytes = ctx->dtype == SZ3HIP_FLOAT ? 4 : 8;
+        hh.predictor = 1;
+        hh.radius = (uint32_t)radius;
+        for (int i = 0; i < 4; i++) hh.dims[i] = 1;
+        for (int i = 0; i < conf->N; i++) hh.dims[4 - conf->N + i] = conf->dims[i];
+        hh.eb = eb;
+        hh.n = num;
+        hh.chunk_syms = SZH_CHUNK_SYMS;
+        hh.n_chunks = (num + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
+        hh.interp_alpha = ip.alpha;
+        hh.interp_beta = ip.beta;
+        hh.interp_id = (uint32_t)ip.interp_id;
+        hh.interp_dir = (uint32_t)ip.direction;
+        hh.anchor_stride = ip.anchor_stride;
+        ctx->stage1_done = true;
+        ctx->stage2_done = false;
+        return 0;
+    }
     szk_k1_params p;
     memset(&p, 0, sizeof(p));
     for (int i = 0; i < 4; i++) p.d[i] = 1;
     for (int i = 0; i < conf->N; i++) p.d[4 - conf->N + i] = conf->dims[i];
     p.lat = szk_make_lattice(eb);
     p.radius = (uint32_t)radius;
-    // outlier lists larger than n/32 entries can never pay off (12-16 bytes each): overflow => lossless fallback
-    ctx->cur_out_cap = std::min<uint64_t>(ctx->out_cap, std::max<uint64_t>(1024, num / 32));
-    p.out_cap = ctx->cur_out_cap;
+    p.out_cap = ctx->cur_out_cap;  // lists larger than n/32 entries can never pay off: overflow => lossless fallback
     p.hist = ctx->d_hist;
     p.hist_partial = ctx->d_hist_partial;
     p.n_vout = ctx->d_counters + 0;
@@ -770,7 +825,23 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     prof_end(ctx, ST_DEC_HUFF, s);
     if (rc) return fail(SZ3HIP_EHIP, "decode kernel launch failed (%d)", rc);
     prof_begin(ctx, ST_DEC_RECON, s);
-    rc = szk_launch_reconstruct(pl, &h, &o, ctx->d_codes, d_out, ctx->d_segtot, s);
+    if (h.predictor == 1) {
+        szk_interp_params ip;
+        memset(&ip, 0, sizeof(ip));
+        ip.N = h.ndim;
+        if (ip.N < 1 || ip.N > 4) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header");
+        for (int i = 0; i < ip.N; i++) ip.dims[i] = h.dims[4 - ip.N + i];
+        ip.interp_id = (int)h.interp_id;
+        ip.direction = (int)h.interp_dir;
+        ip.anchor_stride = h.anchor_stride;
+        ip.alpha = h.interp_alpha;
+        ip.beta = h.interp_beta;
+        ip.eb = h.eb;
+        ip.radius = (int)h.radius;
+        rc = szk_launch_interp_decompress(ctx->dtype, &ip, pl, o.vout_idx, o.vout_val, h.n_vout, ctx->d_codes, d_out, s);
+    } else {
+        rc = szk_launch_reconstruct(pl, &h, &o, ctx->d_codes, d_out, ctx->d_segtot, s);
+    }
     prof_end(ctx, ST_DEC_RECON, s);
     if (rc) return fail(SZ3HIP_EHIP, "reconstruct kernel launch failed (%d)", rc);
     return 0;
@@ -888,7 +959,7 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
         if (cal_abs_eb(conf, ctx, g_dev_in[dataType])) return 0;
         if (conf.absErrorBound == 0) lossless = true;  // SZDispatcher.hpp:19-21
         if (!lossless) {
-            // every lossy algorithm id of the reference maps to the HIP Lorenzo stream in this release
+            // ALGO_LORENZO_REG / NOPRED -> HIP Lorenzo stream (16); ALGO_INTERP / ALGO_INTERP_LORENZO -> HIP interpolation (17)
             size_t dsize = 0;
             int rc = sz3hip_compress_device(ctx, &conf, g_dev_in[dataType], g_dev_payload[dataType], pb, &dsize, nullptr);
             if (rc == SZ3HIP_EOUTLIERS) {
@@ -905,7 +976,7 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
                 }
                 payload_size = zs::compress_frames(host_payload.data(), dsize, w.p, payload_cap);
                 if (!payload_size) return 0;
-                conf.cmprAlgo = SZ3HIP_ALGO_HIP_LORENZO;
+                conf.cmprAlgo = ctx->h_state->hdr.predictor == 1 ? SZ3HIP_ALGO_HIP_INTERP : SZ3HIP_ALGO_HIP_LORENZO;
                 if ((double)raw_bytes / (double)payload_size < 3) {  // SZDispatcher.hpp:62-74
                     std::vector<uint8_t> z(zs::bound_frames(raw_bytes) + 8);
                     size_t zsz = zs::compress_frames((const uint8_t *)data, raw_bytes, z.data(), z.size());
@@ -965,11 +1036,11 @@ extern "C" int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *
             return fail(SZ3HIP_EFORMAT, "Decompressed data size does not match the original data size");
         return zs::decompress_frames(p, payload, (uint8_t *)decData, raw_bytes) == raw_bytes ? 0 : SZ3HIP_EZSTD;
     }
-    if (conf->cmprAlgo != SZ3HIP_ALGO_HIP_LORENZO)
+    if (conf->cmprAlgo != SZ3HIP_ALGO_HIP_LORENZO && conf->cmprAlgo != SZ3HIP_ALGO_HIP_INTERP)
         return fail(SZ3HIP_EUNSUPPORTED,
-                    "stream uses cmprAlgo %d of the CPU reference; this library decodes only its own GPU streams (id %d) "
+                    "stream uses cmprAlgo %d of the CPU reference; this library decodes only its own GPU streams (ids %d, %d) "
                     "and ALGO_LOSSLESS",
-                    conf->cmprAlgo, SZ3HIP_ALGO_HIP_LORENZO);
+                    conf->cmprAlgo, SZ3HIP_ALGO_HIP_LORENZO, SZ3HIP_ALGO_HIP_INTERP);
     if (payload < 8) return fail(SZ3HIP_EFORMAT, "truncated payload");
     uint64_t raw_len;
     memcpy(&raw_len, p, 8);

@@ -1,0 +1,391 @@
+// sz3_amd/csrc/sz3hip_interp.hip — multilevel spline-interpolation predictor on gfx950.
+//
+// Reference: InterpolationDecomposition<T,N,LinearQuantizer<T>> (include/SZ3/decomposition/InterpolationDecomposition.hpp)
+// driven by SZ_compress_Interp (include/SZ3/api/impl/SZAlgoInterp.hpp:17-40), stencils of
+// include/SZ3/utils/Interpolators.hpp:12-39, quantiser include/SZ3/quantizer/LinearQuantizer.hpp:43-86.
+//
+// Unlike the Lorenzo path this predictor has NO loop-carried dependency inside a directional pass: the reference
+// walks level -> block (32*stride) -> direction, but every point predicted in pass k of a level reads only points of
+// coarser levels or of earlier passes of the same level, whichever block they belong to (blocks only decide where a
+// line is cut, i.e. which boundary stencil a point gets).  Re-ordering to level -> pass -> all points therefore
+// reproduces the reference's predictions, quantisation codes and reconstructed values BIT FOR BIT, with one launch
+// per (level, pass) and one thread per predicted point.  The single exception — the last point of an even-length line
+// in linear mode (N >= 3) extrapolates from a point of the same pass (InterpolationDecomposition.hpp:345-351) — runs
+// as a second, tiny launch of that pass.
+// The arithmetic is the reference's: predictions in T, operand order of Interpolators.hpp; quantiser in double
+// exactly as LinearQuantizer (no FMA contraction: -ffp-contract=off).  Codes are stored in element order (the
+// reference emits them in traversal order — same multiset, same histogram, same Huffman cost).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "sz3hip_format.h"
+#include "sz3hip_kernels.h"
+
+#define WAVE 64
+
+// ---- Interpolators.hpp:12-39 ---------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T ip_linear(T a, T b) { return (a + b) / 2; }
+template <typename T> __device__ __forceinline__ T ip_linear1(T a, T b) { return (T)(-0.5 * (double)a + 1.5 * (double)b); }
+template <typename T> __device__ __forceinline__ T ip_quad_1(T a, T b, T c) { return (3 * a + 6 * b - c) / 8; }
+template <typename T> __device__ __forceinline__ T ip_quad_2(T a, T b, T c) { return (-a + 6 * b + 3 * c) / 8; }
+template <typename T> __device__ __forceinline__ T ip_quad_3(T a, T b, T c) { return (3 * a - 10 * b + 15 * c) / 8; }
+template <typename T> __device__ __forceinline__ T ip_cubic(T a, T b, T c, T d) { return (-a + 9 * b + 9 * c - d) / 16; }
+
+// ---- LinearQuantizer<T>::quantize_and_overwrite / recover (LinearQuantizer.hpp:43-86) ---------------------------
+template <typename T>
+__device__ __forceinline__ int ref_quantize(T &data, T pred, double eb, double recip, int radius) {
+    const T diff = data - pred;
+    const double scaled = fabs((double)diff) * recip;
+    if (!(scaled < 9223372036854775808.0)) return 0;  // NaN / overflow of the reference's int64 cast: unpredictable
+    long long qi = (long long)scaled + 1;
+    if (qi < (long long)radius * 2) {
+        qi >>= 1;
+        const int half = (int)qi;
+        qi <<= 1;
+        int shifted;
+        if (diff < 0) {
+            qi = -qi;
+            shifted = radius - half;
+        } else {
+            shifted = radius + half;
+        }
+        const T dec = (T)((double)pred + (double)qi * eb);
+        const T ad = dec - data;
+        const double adiff = fabs((double)ad);
+        if (adiff <= eb) {
+            data = dec;
+            return shifted;
+        }
+    }
+    return 0;
+}
+template <typename T>
+__device__ __forceinline__ T ref_recover(T pred, int code, double eb, int radius) {
+    return (T)((double)pred + (double)(2 * (code - radius)) * eb);
+}
+
+// ---- one directional pass of one level: one thread per predicted point ----------------------------------------
+template <typename T, bool DEC>
+__global__ __launch_bounds__(256) void k_interp_pass(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.total) return;
+    uint64_t r = t, idx = 0, cd = 0;
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+        if (j >= p.N) continue;
+        const uint64_t q = r % p.cnt[j];
+        r /= p.cnt[j];
+        const uint64_t c = p.start[j] + q * p.step[j];
+        idx += c * p.off[j];
+        if (j == p.dir) cd = c;
+    }
+    const uint64_t D = p.dims[p.dir];
+    const uint64_t begin = (cd / p.bsz) * p.bsz;
+    uint64_t end = begin + p.bsz;
+    if (end > D - 1) end = D - 1;
+    const uint64_t n = (end - begin) / p.s + 1, i = (cd - begin) / p.s;  // i is odd, 1 <= i <= n-1
+    const int64_t st = (int64_t)(p.s * p.off[p.dir]);
+    T *d = w + idx;
+    bool deferred = false;
+    T pred;
+    if (p.old_api) {  // interpolation_1d, InterpolationDecomposition.hpp:248-293 (N <= 2)
+        if (p.interp_id == 0 || n < 5) {
+            if (i + 1 < n) pred = ip_linear<T>(d[-st], d[st]);
+            else pred = n < 4 ? d[-st] : ip_linear1<T>(d[-3 * st], d[-st]);
+        } else {
+            if (i == 1) pred = ip_quad_1<T>(d[-st], d[st], d[3 * st]);
+            else if (i + 3 < n) pred = ip_cubic<T>(d[-3 * st], d[-st], d[st], d[3 * st]);
+            else if (i + 1 < n) pred = ip_quad_2<T>(d[-3 * st], d[-st], d[st]);
+            else pred = ip_quad_3<T>(d[-5 * st], d[-3 * st], d[-st]);
+        }
+    } else if (p.interp_id == 0) {  // interpolation_1d_fastest_dim_first, linear branch :334-351
+        if (i + 1 < n) {
+            pred = ip_linear<T>(d[-st], d[st]);
+        } else if (n < 3) {
+            pred = d[-st];
+        } else {
+            deferred = true;  // reads d[-2*st]: a point of this same pass -> second launch
+            pred = p.subpass ? ip_linear1<T>(d[-2 * st], d[-st]) : (T)0;
+        }
+    } else {  // cubic branch :352-399
+        if (i >= 3) {
+            if (i + 3 < n) pred = ip_cubic<T>(d[-3 * st], d[-st], d[st], d[3 * st]);
+            else if (i + 1 < n) pred = ip_quad_2<T>(d[-3 * st], d[-st], d[st]);
+            else pred = ip_linear1<T>(d[-3 * st], d[-st]);
+        } else {
+            if (i + 3 < n) pred = ip_quad_1<T>(d[-st], d[st], d[3 * st]);
+            else if (i + 1 < n) pred = ip_linear<T>(d[-st], d[st]);
+            else pred = d[-st];
+        }
+    }
+    if ((p.subpass != 0) != deferred) return;
+    if (DEC) {
+        const int code = codes[idx];
+        if (code) *d = ref_recover<T>(pred, code, p.eb, p.radius);  // code 0: raw value already scattered in place
+    } else {
+        T v = *d;
+        const int code = ref_quantize<T>(v, pred, p.eb, p.eb_recip, p.radius);
+        codes[idx] = (uint16_t)code;
+        if (code) {
+            *d = v;
+        } else {  // unpredictable: keep the raw value (LinearQuantizer "unpred")
+            const unsigned long long pos = atomicAdd((unsigned long long *)p.n_vout, 1ull);
+            if (pos < p.out_cap) {
+                p.vout_idx[pos] = idx;
+                ((T *)p.vout_val)[pos] = v;
+            }
+        }
+    }
+}
+
+// anchor grid (build_anchor_grid :215-221): every anchor_stride-th point in each dimension is stored losslessly;
+// without anchors (anchor_stride == 0) the first element is quantised against 0 (:92-93)
+template <typename T>
+__global__ __launch_bounds__(256) void k_interp_anchors(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.total) return;
+    uint64_t r = t, idx = 0;
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+        if (j >= p.N) continue;
+        const uint64_t q = r % p.cnt[j];
+        r /= p.cnt[j];
+        idx += (p.start[j] + q * p.step[j]) * p.off[j];
+    }
+    T v = w[idx];
+    int code = 0;
+    if (p.subpass) {  // "no anchor" mode: one point, predicted by 0
+        code = ref_quantize<T>(v, (T)0, p.eb, p.eb_recip, p.radius);
+        if (code) w[idx] = v;
+    }
+    codes[idx] = (uint16_t)code;
+    if (!code) {
+        const unsigned long long pos = atomicAdd((unsigned long long *)p.n_vout, 1ull);
+        if (pos < p.out_cap) {
+            p.vout_idx[pos] = idx;
+            ((T *)p.vout_val)[pos] = v;
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_interp_first_dec(T *__restrict__ w, const uint16_t *__restrict__ codes, double eb, int radius) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && codes[0]) w[0] = ref_recover<T>((T)0, codes[0], eb, radius);
+}
+
+// histogram of u16 codes: persistent workgroups, LDS window [bin][4 copies] around the radius, flushed with one
+// 64-bit atomic per non-empty bin and workgroup
+#define IH_WIN 1024
+__global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__ codes, uint64_t n, int radius,
+                                                    uint64_t *__restrict__ hist) {
+    __shared__ uint32_t lh[IH_WIN * 4];
+    for (int i = threadIdx.x; i < IH_WIN * 4; i += 256) lh[i] = 0;
+    __syncthreads();
+    const uint32_t win_lo = (uint32_t)(radius - IH_WIN / 2), copy = threadIdx.x & 3u;
+    const uint64_t nth = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += nth * 8) {
+        uint16_t c[8];
+        if (i + 8 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(codes + i);
+            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                c[2 * k] = (uint16_t)(wv[k] & 0xFFFF);
+                c[2 * k + 1] = (uint16_t)(wv[k] >> 16);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) c[k] = (i + k < n) ? codes[i + k] : (uint16_t)0xFFFF;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (i + k >= n) break;
+            const uint32_t bin = (uint32_t)c[k] - win_lo;
+            if (bin < IH_WIN) atomicAdd(&lh[bin * 4 + copy], 1u);
+            else atomicAdd((unsigned long long *)&hist[c[k]], 1ull);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < IH_WIN; b += 256) {
+        const uint32_t s = lh[b * 4] + lh[b * 4 + 1] + lh[b * 4 + 2] + lh[b * 4 + 3];
+        const int sym = (int)win_lo + b;
+        if (s && sym >= 0 && sym < (int)SZH_HIST_BINS) atomicAdd((unsigned long long *)&hist[sym], (unsigned long long)s);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_scatter_raw(const uint8_t *__restrict__ payload, uint64_t idx_off, uint64_t val_off,
+                                                     uint64_t cnt, uint64_t n, T *__restrict__ out) {
+    const uint64_t *idx = reinterpret_cast<const uint64_t *>(payload + idx_off);
+    const T *val = reinterpret_cast<const T *>(payload + val_off);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t k = idx[i];
+        if (k < n) out[k] = val[i];
+    }
+}
+
+// ---- host side: the level / pass schedule (InterpolationDecomposition::init :176-213, compress :79-147) -----------
+static void nth_permutation(int N, int id, int *perm) {  // lexicographic order = std::next_permutation sequence
+    int p[4] = {0, 1, 2, 3};
+    for (int k = 0; k < id; k++) {
+        int i = N - 2;
+        while (i >= 0 && p[i] > p[i + 1]) i--;
+        if (i < 0) break;
+        int j = N - 1;
+        while (p[j] < p[i]) j--;
+        int t = p[i];
+        p[i] = p[j];
+        p[j] = t;
+        for (int a = i + 1, b = N - 1; a < b; a++, b--) {
+            t = p[a];
+            p[a] = p[b];
+            p[b] = t;
+        }
+    }
+    for (int i = 0; i < N; i++) perm[i] = p[i];
+}
+
+template <typename T, bool DEC>
+static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStream_t s) {
+    const int N = ip.N;
+    szk_interp_pass p;
+    memset(&p, 0, sizeof(p));
+    p.N = N;
+    uint64_t num = 1;
+    for (int i = 0; i < N; i++) {
+        p.dims[i] = ip.dims[i];
+        num *= ip.dims[i];
+    }
+    p.off[N - 1] = 1;
+    for (int i = N - 2; i >= 0; i--) p.off[i] = p.off[i + 1] * p.dims[i + 1];
+    p.radius = ip.radius;
+    p.interp_id = ip.interp_id;
+    p.old_api = N <= 2;
+    p.n_vout = ip.n_vout;
+    p.vout_idx = ip.vout_idx;
+    p.vout_val = ip.vout_val;
+    p.out_cap = ip.out_cap;
+    // init(): levels and whether anchors are used
+    uint64_t anchor = ip.anchor_stride;
+    int interp_level = -1;
+    bool use_anchor = false;
+    for (int i = 0; i < N; i++) {
+        const int lv = (int)ceil(log2((double)p.dims[i]));
+        if (interp_level < lv) interp_level = lv;
+        if (p.dims[i] > anchor) use_anchor = true;
+    }
+    if (!use_anchor) anchor = 0;
+    if (anchor > 0) {
+        const int maxl = (int)log2((double)anchor) + 1;
+        if (maxl <= interp_level) interp_level = maxl;
+    }
+    int perm[4], pos[4];
+    nth_permutation(N, ip.direction, perm);
+    for (int k = 0; k < N; k++) pos[perm[k]] = k;
+    // anchors / first point
+    if (anchor == 0) {
+        if (DEC) {
+            hipLaunchKernelGGL((k_interp_first_dec<T>), dim3(1), dim3(64), 0, s, w, codes, ip.eb, ip.radius);
+        } else {
+            p.total = 1;
+            for (int j = 0; j < N; j++) {
+                p.start[j] = 0;
+                p.step[j] = 1;
+                p.cnt[j] = 1;
+            }
+            p.subpass = 1;
+            p.eb = ip.eb;
+            p.eb_recip = 1.0 / ip.eb;
+            hipLaunchKernelGGL((k_interp_anchors<T>), dim3(1), dim3(256), 0, s, w, codes, p);
+        }
+    } else {
+        if (!DEC) {
+            p.total = 1;
+            for (int j = 0; j < N; j++) {
+                p.start[j] = 0;
+                p.step[j] = anchor;
+                p.cnt[j] = (p.dims[j] - 1) / anchor + 1;
+                p.total *= p.cnt[j];
+            }
+            p.subpass = 0;
+            p.eb = ip.eb;
+            p.eb_recip = 1.0 / ip.eb;
+            hipLaunchKernelGGL((k_interp_anchors<T>), dim3((uint32_t)((p.total + 255) / 256)), dim3(256), 0, s, w, codes, p);
+        }
+        interp_level--;
+    }
+    for (int level = interp_level; level > 0; level--) {
+        double cur_eb = ip.eb;  // per-level bound :103-117
+        if (ip.alpha < 0) {
+            cur_eb = level >= 3 ? ip.eb * 0.5 : ip.eb;
+        } else if (ip.alpha >= 1) {
+            double r = pow(ip.alpha, level - 1);
+            if (r > ip.beta) r = ip.beta;
+            cur_eb = ip.eb / r;
+        }
+        p.eb = cur_eb;
+        p.eb_recip = 1.0 / cur_eb;
+        p.s = 1ull << (level - 1);
+        p.bsz = 32ull * p.s;
+        for (int k = 0; k < N; k++) {
+            p.dir = perm[k];
+            p.total = 1;
+            for (int j = 0; j < N; j++) {
+                const uint64_t Dj = p.dims[j];
+                if (j == p.dir) {
+                    p.start[j] = p.s;
+                    p.step[j] = 2 * p.s;
+                    p.cnt[j] = ((Dj - 1) / p.s + 1) / 2;
+                } else if (pos[j] < k) {
+                    p.start[j] = 0;
+                    p.step[j] = p.s;
+                    p.cnt[j] = (Dj - 1) / p.s + 1;
+                } else {
+                    p.start[j] = 0;
+                    p.step[j] = 2 * p.s;
+                    p.cnt[j] = (Dj - 1) / (2 * p.s) + 1;
+                }
+                p.total *= p.cnt[j];
+            }
+            if (p.total == 0) continue;
+            const uint64_t nb = (p.total + 255) / 256;
+            if (nb > 0x7FFFFFFFull) return -1;
+            p.subpass = 0;
+            hipLaunchKernelGGL((k_interp_pass<T, DEC>), dim3((uint32_t)nb), dim3(256), 0, s, w, codes, p);
+            if (!p.old_api && p.interp_id == 0) {
+                p.subpass = 1;
+                hipLaunchKernelGGL((k_interp_pass<T, DEC>), dim3((uint32_t)nb), dim3(256), 0, s, w, codes, p);
+            }
+        }
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const void *d_in, void *d_work, uint16_t *codes,
+                               uint64_t *hist, hipStream_t s) {
+    uint64_t num = 1;
+    for (int i = 0; i < ip->N; i++) num *= ip->dims[i];
+    const size_t tsz = dtype == 0 ? 4 : 8;
+    hipError_t e = hipMemcpyAsync(d_work, d_in, num * tsz, hipMemcpyDeviceToDevice, s);  // the dispatcher's dataCopy
+    if (e != hipSuccess) return (int)e;
+    int rc = dtype == 0 ? run_interp<float, false>(*ip, (float *)d_work, codes, s)
+                        : run_interp<double, false>(*ip, (double *)d_work, codes, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_hist_codes, dim3(1024), dim3(256), 0, s, codes, num, ip->radius, hist);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int szk_launch_interp_decompress(int dtype, const szk_interp_params *ip, const uint8_t *payload, uint64_t vout_idx_off,
+                                 uint64_t vout_val_off, uint64_t n_vout, uint16_t *codes, void *d_out, hipStream_t s) {
+    uint64_t num = 1;
+    for (int i = 0; i < ip->N; i++) num *= ip->dims[i];
+    if (n_vout) {
+        const uint32_t g = (uint32_t)((n_vout + 255) / 256 < 4096 ? (n_vout + 255) / 256 : 4096);
+        if (dtype == 0) hipLaunchKernelGGL((k_scatter_raw<float>), dim3(g), dim3(256), 0, s, payload, vout_idx_off, vout_val_off, n_vout, num, (float *)d_out);
+        else hipLaunchKernelGGL((k_scatter_raw<double>), dim3(g), dim3(256), 0, s, payload, vout_idx_off, vout_val_off, n_vout, num, (double *)d_out);
+    }
+    return dtype == 0 ? run_interp<float, true>(*ip, (float *)d_out, codes, s) : run_interp<double, true>(*ip, (double *)d_out, codes, s);
+}

@@ -109,6 +109,32 @@ struct szk_dec_params {
     uint32_t single_sym;
 };
 
+// ---- interpolation predictor (sz3hip_interp.hip) ----
+struct szk_interp_params {  // what InterpolationDecomposition keeps (decomposition/InterpolationDecomposition.hpp:456-477)
+    int N;
+    uint64_t dims[4];  // slowest first, exactly N entries
+    int interp_id, direction;
+    uint64_t anchor_stride;
+    double alpha, beta, eb;
+    int radius;
+    uint64_t *n_vout, *vout_idx;
+    void *vout_val;
+    uint64_t out_cap;
+};
+struct szk_interp_pass {
+    int N, dir, interp_id, old_api, subpass, radius;
+    uint64_t dims[4], off[4], start[4], step[4], cnt[4];
+    uint64_t total, s, bsz;
+    double eb, eb_recip;
+    uint64_t *n_vout, *vout_idx;
+    void *vout_val;
+    uint64_t out_cap;
+};
+int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const void *d_in, void *d_work, uint16_t *codes,
+                               uint64_t *hist, hipStream_t s);
+int szk_launch_interp_decompress(int dtype, const szk_interp_params *ip, const uint8_t *payload, uint64_t vout_idx_off,
+                                 uint64_t vout_val_off, uint64_t n_vout, uint16_t *codes, void *d_out, hipStream_t s);
+
 int szk_launch_minmax(int dtype, const void *d_in, uint64_t n, double *d_partial /*[2*1024]*/, double *d_out /*[2]*/, hipStream_t s);
 int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, szk_k1_params *p, hipStream_t s);
 int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStream_t s);

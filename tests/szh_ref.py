@@ -59,16 +59,16 @@ def dualquant(a, eb, radius=32768, narrow=False):
 
 def parse(payload):
     b = bytes(payload)
-    (magic, version, dtype, ndim, qbytes, _r0, radius) = struct.unpack_from("<IIBBBBI", b, 0)
+    (magic, version, dtype, ndim, qbytes, predictor, radius) = struct.unpack_from("<IIBBBBI", b, 0)
     dims = struct.unpack_from("<4Q", b, 16)
     eb, n, chunk_syms, max_len, n_chunks, sym_min, sym_count, n_vout, n_dout, words, pbytes = struct.unpack_from(
         "<dQIIQIIQQQQ", b, 48)
     h = dict(magic=magic, version=version, dtype=dtype, ndim=ndim, qbytes=qbytes, radius=radius, dims=dims, eb=eb, n=n,
              chunk_syms=chunk_syms, max_len=max_len, n_chunks=n_chunks, sym_min=sym_min, sym_count=sym_count,
-             n_vout=n_vout, n_dout=n_dout, bitstream_words=words, payload_bytes=pbytes)
+             n_vout=n_vout, n_dout=n_dout, bitstream_words=words, payload_bytes=pbytes, predictor=predictor)
     a16 = lambda x: (x + 15) & ~15
     tsz = 4 if dtype == 0 else 8
-    off = 128
+    off = 160
     o = {}
     o["lens"] = off
     off = a16(off + sym_count)

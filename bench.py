@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512, help="edge of the cubic volume per GPU (512 = the metric's config)")
     ap.add_argument("--eb", type=float, default=1e-3)
+    ap.add_argument("--algo", choices=["lorenzo", "interp"], default="lorenzo",
+                    help="lorenzo = the metric's config C2 (default); interp = C3 (ALGO_INTERP, cubic, abs 1e-4 unless --eb)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-e2e", action="store_true")
     args = ap.parse_args()
@@ -66,7 +68,7 @@ def main():
     a = field3d(shape, np.float32, seed=20260928 + rank)
     d_in = torch.from_numpy(a).to(dev)
     conf = sz3_amd.Config(*shape)
-    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG if args.algo == "lorenzo" else sz3_amd.ALGO_INTERP
     conf.lorenzo, conf.lorenzo2, conf.regression = 1, 0, 0
     conf.errorBoundMode = sz3_amd.EB_ABS
     conf.absErrorBound = eb
@@ -153,9 +155,10 @@ def main():
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: 3D float32 %dx%dx%d synthetic field per GPU, Lorenzo predictor, abs errBound=%g, "
-                                   "device-resident in -> device-resident Huffman payload" % (S, S, S, eb),
-                       "parallelism": "slab%d" % world, "algo": "HIP_LORENZO(16)", "eb": eb},
+            "config": {"workload": "%s: 3D float32 %dx%dx%d synthetic field per GPU, %s predictor, abs errBound=%g, "
+                                   "device-resident in -> device-resident Huffman payload"
+                                   % ("C2" if args.algo == "lorenzo" else "C3", S, S, S, "Lorenzo" if args.algo == "lorenzo" else "interpolation", eb),
+                       "parallelism": "slab%d" % world, "algo": "HIP_LORENZO(16)" if args.algo == "lorenzo" else "HIP_INTERP(17)", "eb": eb},
             "ratio": round(ratio, 4), "max_abs_err": max_err, "err_bound_ok": bool(max_err <= eb),
             "payload_bytes_rank0": int(psize),
             "outliers": {"value": stats["n_value_outliers"], "delta": stats["n_delta_outliers"]},
@@ -184,7 +187,8 @@ def main():
     # ---- CPU baseline on this box's host cores (rank 0, N=1 only; checker code, never the product) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle_binding import have_ref, make_config, oracle_compress, ref_compress
-        oconf = make_config(shape, abs_eb=eb, lorenzo=True, regression=False)
+        from oracle_binding import ALGO_INTERP as O_INTERP
+        oconf = make_config(shape, abs_eb=eb, lorenzo=True, regression=False) if args.algo == "lorenzo" else make_config(shape, algo=O_INTERP, abs_eb=eb)
         # bounded sample: the full volume is ~8 s of single-thread reference work at 512^3; cap at 512^3
         if have_ref():
             blob, sec = ref_compress(a, oconf, timing=True)
@@ -195,8 +199,8 @@ def main():
             sec = time.perf_counter() - t0
             kind = "port"
         out["cpu_baseline"] = {"value": round(raw_bytes / sec / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
-                               "sample": "whole %dx%dx%d volume, SZ_compress<float> ALGO_LORENZO_REG (Lorenzo only) "
-                                         "abs 1e-3, single thread, %.2f s" % (S, S, S, sec),
+                               "sample": "whole %dx%dx%d volume, SZ_compress<float> %s abs %g, single thread, %.2f s"
+                                         % (S, S, S, "ALGO_LORENZO_REG (Lorenzo only)" if args.algo == "lorenzo" else "ALGO_INTERP (cubic)", eb, sec),
                                "ratio": round(raw_bytes / float(len(blob)), 4),
                                "host_cpus": os.cpu_count()}
     if rank == 0:

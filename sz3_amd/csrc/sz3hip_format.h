@@ -19,7 +19,7 @@
 #define SZH_MAGIC 0x31485A53u /* "SZH1" */
 #define SZH_VERSION 2u
 #define SZH_CHUNK_SYMS 1024u
-#define SZH_MAX_LEN 16u /* longest code word: 4 code words always fit one 64-bit register in the packer */
+#define SZH_MAX_LEN 24u /* longest code word; alphabets <= 512 symbols are limited to 16 (4 words per 64-bit register in the packer) */
 #define SZH_HIST_BINS 65536u
 
 typedef struct szh_header {

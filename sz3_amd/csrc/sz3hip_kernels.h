@@ -50,6 +50,7 @@ struct szk_k1_params {
 
 struct szk_cb_info {
     uint32_t n_symbols, max_len, sym_min, sym_count;
+    uint32_t win_lo, reserved;  // first symbol of the packers' LDS window of the encode table
     uint64_t ts[12];  // phase timestamps (wall_clock64, 100 MHz) for tools/cb_lab.py
 };
 struct szk_cb_params {

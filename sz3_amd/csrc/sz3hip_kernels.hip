@@ -846,10 +846,21 @@ __global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K5: canonical length-limited Huffman codebook, one 1024-thread workgroup.
+// K5: canonical length-limited Huffman code book. One launch of 3 workgroups x 1024 threads:
+//   block 0   code book.  Alphabets up to CB_LDS_SYMS symbols (every smooth field) run on 256 threads entirely in
+//             LDS with the two-queue merge executed by one wave out of registers; wider alphabets (tight bounds, the
+//             interpolation predictor's coarse levels) use all 1024 threads: tile bitonic sort, a round-parallel
+//             merge (every round pairs ALL items below the smallest possible new node), chunked code assignment.
+//   block 1/2 deterministic order of the two outlier lists.
+// Code lengths are limited to 16 bits for alphabets up to 512 symbols (the packer then joins four code words per
+// 64-bit register; the loss is < 0.01 bit/symbol) and to SZH_MAX_LEN = 24 bits otherwise (two per register).
 // ------------------------------------------------------------------------------------------------------------
-#define CB_THREADS 256
-#define CB_LDS_SYMS 2048
+#define CB_THREADS 256       // threads of the small-alphabet path
+#define CB_LAUNCH 1024       // threads per workgroup of the launch
+#define CB_LDS_SYMS 2048     // small-alphabet path: everything LDS-resident
+#define CB_POOL_BYTES 131072 // LDS pool, carved per phase
+#define CB_SHORT_SYMS 512    // alphabets up to this size are limited to 16-bit code words
+#define ENC_WIN 4096         // symbols of the encode table the packers cache in LDS (window around the most frequent symbol)
 
 __device__ void cb_bitonic_sort(uint64_t *keys, uint32_t npow2) {  // ascending; keys in LDS or global
     for (uint32_t k = 2; k <= npow2; k <<= 1) {
@@ -870,9 +881,118 @@ __device__ void cb_bitonic_sort(uint64_t *keys, uint32_t npow2) {  // ascending;
     }
 }
 
-// Two-queue Huffman merge over leaves sorted by ascending frequency (keys = freq << 16 | sym). Serial (thread 0);
-// both queue heads AND their successors are kept in registers, so the LDS latency of fetching the next element
-// overlaps the following merge step instead of stalling it.
+// ---- record sort: keys (u64, ascending) + optional value, global memory, LDS tiles ----------------------------
+// Bitonic network in its "flip" form: every compare-exchange is ascending (min to the lower index), so virtual
+// padding with +infinity at positions >= n never moves and is never stored.
+struct RecView {
+    uint64_t *k;
+    uint8_t *v;
+    bool has_val, v32;
+};
+__device__ __forceinline__ uint64_t rec_ldv(const RecView &r, uint64_t i) {
+    return r.v32 ? (uint64_t) reinterpret_cast<const uint32_t *>(r.v)[i] : reinterpret_cast<const uint64_t *>(r.v)[i];
+}
+__device__ __forceinline__ void rec_stv(const RecView &r, uint64_t i, uint64_t x) {
+    if (r.v32) reinterpret_cast<uint32_t *>(r.v)[i] = (uint32_t)x;
+    else reinterpret_cast<uint64_t *>(r.v)[i] = x;
+}
+// one global compare-exchange step over all pairs; flip: partner mirrors inside the block of size k, else i + j
+__device__ void rec_global_step(const RecView &r, uint32_t n, uint32_t np2, uint32_t k, uint32_t j, bool flip) {
+    const uint32_t half = flip ? k >> 1 : j;
+    for (uint32_t pr = threadIdx.x; pr < np2 / 2; pr += blockDim.x) {
+        const uint32_t blk = pr / half, off = pr % half;
+        const uint32_t i = blk * 2 * half + off;
+        const uint32_t x = flip ? blk * 2 * half + 2 * half - 1 - off : i + half;
+        if (x < n) {  // i < x; a partner in the padding never swaps
+            const uint64_t a = r.k[i], b = r.k[x];
+            if (a > b) {
+                r.k[i] = b;
+                r.k[x] = a;
+                if (r.has_val) {
+                    const uint64_t va = rec_ldv(r, i), vb = rec_ldv(r, x);
+                    rec_stv(r, i, vb);
+                    rec_stv(r, x, va);
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+// stages k_lo .. k_hi inside the LDS tile [base, base + T); if clean_from != 0 only the half-cleaners
+// j = clean_from .. 1 of one stage are run (the tail of a stage whose wide steps ran in global memory)
+__device__ void rec_tile_pass(const RecView &r, uint32_t n, uint32_t base, uint32_t T, uint32_t k_lo, uint32_t k_hi,
+                              uint32_t clean_from, uint64_t *sk, uint64_t *sv) {
+    for (uint32_t i = threadIdx.x; i < T; i += blockDim.x) {
+        const uint32_t g = base + i;
+        sk[i] = g < n ? r.k[g] : ~0ull;
+        if (r.has_val) sv[i] = g < n ? rec_ldv(r, g) : 0ull;
+    }
+    __syncthreads();
+    auto step = [&](uint32_t half, bool flip) {
+        for (uint32_t pr = threadIdx.x; pr < T / 2; pr += blockDim.x) {
+            const uint32_t blk = pr / half, off = pr % half;
+            const uint32_t i = blk * 2 * half + off;
+            const uint32_t x = flip ? blk * 2 * half + 2 * half - 1 - off : i + half;
+            const uint64_t a = sk[i], b = sk[x];
+            if (a > b) {
+                sk[i] = b;
+                sk[x] = a;
+                if (r.has_val) {
+                    const uint64_t va = sv[i];
+                    sv[i] = sv[x];
+                    sv[x] = va;
+                }
+            }
+        }
+        __syncthreads();
+    };
+    if (clean_from) {
+        for (uint32_t j = clean_from; j > 0; j >>= 1) step(j, false);
+    } else {
+        for (uint32_t k = k_lo; k <= k_hi; k <<= 1) {
+            step(k >> 1, true);
+            for (uint32_t j = k >> 2; j > 0; j >>= 1) step(j, false);
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < T; i += blockDim.x) {
+        const uint32_t g = base + i;
+        if (g < n) {
+            r.k[g] = sk[i];
+            if (r.has_val) rec_stv(r, g, sv[i]);
+        }
+    }
+    __syncthreads();
+}
+__device__ void rec_sort(const RecView &r, uint32_t n, uint8_t *pool) {
+    if (n < 2) return;
+    uint32_t np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    uint32_t T = CB_POOL_BYTES / (r.has_val ? 16 : 8);  // power of two
+    if (T > np2) T = np2;
+    uint64_t *sk = reinterpret_cast<uint64_t *>(pool), *sv = sk + T;
+    for (uint32_t base = 0; base < n; base += T) rec_tile_pass(r, n, base, T, 2, T, 0, sk, sv);
+    for (uint32_t k = 2 * T; k <= np2; k <<= 1) {
+        rec_global_step(r, n, np2, k, 0, true);
+        uint32_t j = k >> 2;
+        for (; j >= T; j >>= 1) rec_global_step(r, n, np2, k, j, false);
+        for (uint32_t base = 0; base < n; base += T) rec_tile_pass(r, n, base, T, 0, 0, T >> 1, sk, sv);
+    }
+}
+
+// outlier lists are appended with atomics in arrival order; sorting them by element index makes the payload a pure
+// function of the input (the reference's CI compares stream digests across platforms, .github/workflows/cmake.yml:295-310).
+// Lists beyond 2^20 records (a sign that the bound is far too tight for the data) stay in arrival order.
+__device__ void sort_outlier_list(uint64_t *idx, void *val, uint64_t n, uint64_t cap, bool v32, uint8_t *pool) {
+    if (n > cap) n = cap;
+    if (n < 2 || n > (1u << 20)) return;
+    RecView r{idx, reinterpret_cast<uint8_t *>(val), true, v32};
+    rec_sort(r, (uint32_t)n, pool);
+}
+
+// ---- two-queue Huffman merge, serial forms ---------------------------------------------------------------------
+// Leaves sorted by ascending frequency (keys = freq << 16 | sym); internal node k is created at step k, so the
+// internal queue is ifreq[j .. k). pleaf[i] / pint[j] = parent (internal node index).
+// Generic serial form (thread 0, 64-bit frequencies): heads and their successors are kept in registers.
 __device__ void cb_merge(const uint64_t *keys, uint64_t *ifreq, uint16_t *pleaf, uint16_t *pint, uint32_t m) {
     const uint64_t INF = ~0ull;
     uint32_t i = 0, j = 0;
@@ -895,41 +1015,188 @@ __device__ void cb_merge(const uint64_t *keys, uint64_t *ifreq, uint16_t *pleaf,
             }
         }
         ifreq[k] = f;
-        // node k joins the tail of the internal queue: it is the head if the queue was empty, the successor if
-        // exactly one element was pending
         if (j == k) nf = f;
         else if (j + 1 == k) nf_next = f;
     }
 }
+// Wave form (all 64 lanes of one wave, frequencies < 2^32 - 1): each queue has a 64-entry register window, one
+// entry per lane, read with v_readlane at a scalar index; the parents of the window's entries are collected in a
+// second register per queue and written to LDS when the window moves on. No LDS access on the critical path except
+// for nodes created beyond the internal window (near-uniform distributions). nfq: 32-bit internal frequencies (LDS).
+__device__ void cb_merge_wave32(const uint64_t *keys, uint32_t *nfq, uint16_t *pleaf, uint16_t *pint, uint32_t m) {
+    const uint32_t lane = lane_id();
+    const uint32_t INF = 0xFFFFFFFFu;
+    uint32_t i = 0, j = 0, ibase = 0, jbase = 0;
+    uint32_t lreg = lane < m ? (uint32_t)(keys[lane] >> 16) : INF;
+    uint32_t nreg = INF;
+    uint32_t lpar = 0, npar = 0;  // parents of the window entries
+    for (uint32_t k = 0; k + 1 < m; k++) {
+        uint32_t f = 0;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const uint32_t lf = (uint32_t)__builtin_amdgcn_readlane((int)lreg, (int)(i - ibase));
+            const uint32_t nf = (uint32_t)__builtin_amdgcn_readlane((int)nreg, (int)(j - jbase));
+            if (lf <= nf) {
+                f += lf;
+                lpar = lane == i - ibase ? k : lpar;
+                i++;
+                if (i - ibase == WAVE) {
+                    pleaf[ibase + lane] = (uint16_t)lpar;
+                    ibase = i;
+                    lreg = ibase + lane < m ? (uint32_t)(keys[ibase + lane] >> 16) : INF;
+                }
+            } else {
+                f += nf;
+                npar = lane == j - jbase ? k : npar;
+                j++;
+                if (j - jbase == WAVE) {
+                    pint[jbase + lane] = (uint16_t)npar;
+                    jbase = j;
+                    nreg = jbase + lane < k ? nfq[jbase + lane] : INF;
+                }
+            }
+        }
+        if (k - jbase < WAVE) nreg = (lane == k - jbase) ? f : nreg;
+        else if (lane == 0) nfq[k] = f;
+    }
+    if (ibase + lane < i) pleaf[ibase + lane] = (uint16_t)lpar;
+    if (jbase + lane < j) pint[jbase + lane] = (uint16_t)npar;
+}
 
-// Kraft repair after clamping code lengths to SZH_MAX_LEN (serial, O(m)): leaves are sorted by ascending frequency
-// and Huffman lengths never increase along that order, so the cheapest leaf to lengthen (least frequent among the
-// longest codes still below the limit) is always the first leaf whose length is below the limit.
-__device__ void cb_kraft_repair(uint16_t *len_sorted, uint32_t m, uint32_t *cnt) {
+// ---- round-parallel merge (wide alphabets, whole workgroup) -----------------------------------------------------
+// Invariant of the two-queue merge: every pending internal node is <= c, the sum of the two smallest pending items,
+// and every node created from now on is >= c. So ALL pending items below c (set A) get paired among themselves, in
+// merged sorted order (ties: leaf first), before any new node is touched: one round creates |A|/2 nodes at once —
+// a co-rank search per pair. c at least doubles the smallest pending item per round: O(log(total)) rounds.
+// INLDS: 32-bit frequencies in LDS (lf32 leaves, nf32 internals); else 64-bit in global memory (keys, ifreq).
+template <bool INLDS>
+__device__ void cb_merge_rounds(const uint64_t *keys, uint64_t *ifreq, const uint32_t *lf32, uint32_t *nf32,
+                                uint16_t *pleaf, uint16_t *pint, uint32_t m, uint32_t *s_red /* [4], zeroed */) {
+    const uint32_t t = threadIdx.x, NT = blockDim.x, lane = lane_id();
+    const uint64_t INF = ~0ull;
+    auto LF = [&](uint32_t x) -> uint64_t { return INLDS ? (uint64_t)lf32[x] : keys[x] >> 16; };
+    auto NF = [&](uint32_t x) -> uint64_t { return INLDS ? (uint64_t)nf32[x] : ifreq[x]; };
+    uint32_t i = 0, j = 0, k = 0, round = 0;
+    while (k + 1 < m) {
+        uint32_t *red = s_red + 2 * (round & 1), *red_next = s_red + 2 * ((round + 1) & 1);
+        const uint64_t l0 = i < m ? LF(i) : INF, l1 = i + 1 < m ? LF(i + 1) : INF;
+        const uint64_t n0 = j < k ? NF(j) : INF, n1 = j + 1 < k ? NF(j + 1) : INF;
+        uint64_t c;
+        if (l0 <= n0) c = l0 + (l1 <= n0 ? l1 : n0);
+        else c = n0 + (l0 <= n1 ? l0 : n1);
+        // items below c in each queue: NT-ary probe (one barrier), then a 64-ary probe inside the hit segment
+        const uint32_t RL = m - i, RN = k - j;
+        const uint32_t SL = (RL + NT - 1) / NT, SN = (RN + NT - 1) / NT;  // <= 64 (m <= 65536, NT = 1024)
+        bool pl = false, pn = false;
+        if (RL && t * SL < RL) {
+            const uint32_t e = (t + 1) * SL < RL ? (t + 1) * SL : RL;
+            pl = LF(i + e - 1) < c;
+        }
+        if (RN && t * SN < RN) {
+            const uint32_t e = (t + 1) * SN < RN ? (t + 1) * SN : RN;
+            pn = NF(j + e - 1) < c;
+        }
+        const uint32_t cl = (uint32_t)__popcll(__ballot(pl)), cn = (uint32_t)__popcll(__ballot(pn));
+        if (lane == 0) {
+            if (cl) atomicAdd(&red[0], cl);
+            if (cn) atomicAdd(&red[1], cn);
+        }
+        if (t == 0) red_next[0] = red_next[1] = 0;
+        __syncthreads();
+        uint32_t nl = red[0] * SL, nn = red[1] * SN;  // full segments below c
+        if (nl < RL) {
+            const uint32_t x = nl + lane;
+            const bool b = lane < SL && x < RL && LF(i + x) < c;
+            nl += (uint32_t)__popcll(__ballot(b));
+        } else nl = RL;
+        if (nn < RN) {
+            const uint32_t x = nn + lane;
+            const bool b = lane < SN && x < RN && NF(j + x) < c;
+            nn += (uint32_t)__popcll(__ballot(b));
+        } else nn = RN;
+        const uint32_t tot = nl + nn, P = tot >> 1;  // tot >= 2
+        // the unpaired last item of an odd A stays pending: it is the larger of the two tails (tie: the internal)
+        bool leaf_last = false;
+        if (tot & 1) leaf_last = nl > 0 && (nn == 0 || LF(i + nl - 1) > NF(j + nn - 1));
+        for (uint32_t q = t; q < P; q += NT) {
+            const uint32_t d = 2 * q;
+            uint32_t lo = d > nn ? d - nn : 0, hi = d < nl ? d : nl;
+            while (lo < hi) {  // co-rank: smallest a such that leaf[a] does not precede internal[d - a - 1]
+                const uint32_t a = (lo + hi) >> 1;
+                if (LF(i + a) <= NF(j + d - a - 1)) lo = a + 1;
+                else hi = a;
+            }
+            uint32_t a = lo, b = d - lo;
+            uint64_t sum = 0;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const uint64_t fl = a < nl ? LF(i + a) : INF, fn = b < nn ? NF(j + b) : INF;
+                if (fl <= fn) {
+                    sum += fl;
+                    pleaf[i + a] = (uint16_t)(k + q);
+                    a++;
+                } else {
+                    sum += fn;
+                    pint[j + b] = (uint16_t)(k + q);
+                    b++;
+                }
+            }
+            if (INLDS) nf32[k + q] = (uint32_t)sum;
+            else ifreq[k + q] = sum;
+        }
+        i += nl - ((tot & 1) && leaf_last ? 1 : 0);
+        j += nn - ((tot & 1) && !leaf_last ? 1 : 0);
+        k += P;
+        round++;
+        __syncthreads();
+    }
+}
+
+// Kraft repair after clamping code lengths to L. Leaves are sorted by ascending frequency and Huffman lengths never
+// increase along that order, so the cheapest leaves to lengthen are the first ones below the limit. Closed form:
+// the c clamped leaves come first; promoting leaf q >= c all the way to the limit frees 2^(L - len_q) - 1 units;
+// take the shortest prefix of them that covers the excess E, then hand the surplus of the last one back by shortening
+// the most frequent maximal-length codes by one bit each. NT live threads, contiguous runs of leaves per thread;
+// s_cnt is rebuilt. s_ws: [NT / 64 + 2] u64 scratch in LDS.
+__device__ void cb_kraft_repair(uint16_t *pleaf, uint32_t m, uint32_t *s_cnt, uint32_t L, uint32_t NT, uint64_t *s_ws) {
+    const uint32_t t = threadIdx.x;
     uint64_t kraft = 0;
-    for (uint32_t l = 1; l <= SZH_MAX_LEN; l++) kraft += (uint64_t)cnt[l] << (SZH_MAX_LEN - l);
-    const uint64_t budget = 1ull << SZH_MAX_LEN;
-    uint32_t q0 = 0;
-    while (kraft > budget) {
-        while (q0 < m && len_sorted[q0] >= SZH_MAX_LEN) q0++;
-        if (q0 == m) break;  // cannot happen for m <= 2^SZH_MAX_LEN
-        const uint32_t l = len_sorted[q0];
-        len_sorted[q0] = (uint16_t)(l + 1);
-        cnt[l]--;
-        cnt[l + 1]++;
-        kraft -= 1ull << (SZH_MAX_LEN - l - 1);
+    for (uint32_t l = 1; l <= L; l++) kraft += (uint64_t)s_cnt[l] << (L - l);
+    const uint64_t E = kraft - (1ull << L);  // > 0: the caller saw a clamp
+    const uint32_t c = s_cnt[L];
+    const uint32_t per = (m + NT - 1) / NT;
+    const uint32_t q0 = t * per < m ? t * per : m, q1 = q0 + per < m ? q0 + per : m;
+    uint64_t run = 0;
+    for (uint32_t q = q0; q < q1; q++) run += q >= c ? ((1ull << (L - pleaf[q])) - 1) : 0ull;
+    const uint64_t incl = wave_incl_scan(run);
+    uint32_t *s_k = reinterpret_cast<uint32_t *>(s_ws + NT / WAVE);  // [0] = kend, [1] = slack
+    if (lane_id() == WAVE - 1) s_ws[t / WAVE] = incl;
+    if (t == 0) {
+        s_k[0] = 0xFFFFFFFFu;
+        s_k[1] = 0;
     }
-    // give back what the last step freed beyond the need: shorten the most frequent codes of maximal length
-    uint32_t qe = m;
-    while (kraft < budget) {
-        while (qe > 0 && len_sorted[qe - 1] != SZH_MAX_LEN) qe--;
-        if (qe == 0) break;
-        len_sorted[qe - 1] = (uint16_t)(SZH_MAX_LEN - 1);  // costs one unit
-        cnt[SZH_MAX_LEN]--;
-        cnt[SZH_MAX_LEN - 1]++;
-        kraft += 1;
-        qe--;
+    __syncthreads();
+    uint64_t acc = incl - run;
+    for (uint32_t wv = 0; wv < t / WAVE; wv++) acc += s_ws[wv];
+    for (uint32_t q = q0; q < q1; q++) {
+        const uint64_t lo = acc;
+        acc += q >= c ? ((1ull << (L - pleaf[q])) - 1) : 0ull;
+        if (lo < E && E <= acc) {  // exactly one q satisfies this
+            s_k[0] = q;
+            s_k[1] = (uint32_t)(acc - E < 0xFFFFFFFFull ? acc - E : 0xFFFFFFFFull);
+        }
     }
+    __syncthreads();
+    const uint32_t kend = s_k[0];
+    if (kend != 0xFFFFFFFFu) {
+        const uint32_t nlim = kend + 1;  // leaves [0, kend] now sit at the limit
+        const uint32_t back = s_k[1] < nlim ? s_k[1] : nlim;
+        for (uint32_t q = t; q <= kend; q += NT) pleaf[q] = (uint16_t)((q + back > kend) ? L - 1 : L);
+    }
+    if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t q = t; q < m; q += NT) atomicAdd(&s_cnt[pleaf[q]], 1u);
+    __syncthreads();
 }
 
 // range of the non-empty histogram bins, many workgroups: range[0] = max(65535 - bin), range[1] = max(bin),
@@ -947,135 +1214,244 @@ __global__ __launch_bounds__(256) void k_hist_range(const uint64_t *__restrict__
     }
 }
 
-// outlier lists are appended with atomics in arrival order; sorting them by element index makes the payload a pure
-// function of the input (the reference's CI compares stream digests across platforms, .github/workflows/cmake.yml:295-310).
-// One workgroup per list (blocks 1 and 2 of the k_codebook launch): LDS bitonic sort up to 2048 records, in-place global bitonic up to 65536; longer lists
-// (a sign that the bound is far too tight for the data) stay in arrival order.
-__device__ void sort_outlier_list(uint64_t *idx, void *val, uint64_t n, uint64_t cap, bool v32, uint64_t *s_i,
-                                  uint64_t *s_v) {
-    uint8_t *valb = reinterpret_cast<uint8_t *>(val);
-    if (n > cap) n = cap;
-    if (n < 2 || n > 65536) return;
-    auto ldv = [&](uint64_t i) -> uint64_t { return v32 ? (uint64_t) reinterpret_cast<uint32_t *>(valb)[i] : reinterpret_cast<uint64_t *>(valb)[i]; };
-    auto stv = [&](uint64_t i, uint64_t v) {
-        if (v32) reinterpret_cast<uint32_t *>(valb)[i] = (uint32_t)v;
-        else reinterpret_cast<uint64_t *>(valb)[i] = v;
-    };
-    uint32_t np2 = 2;
-    while (np2 < n) np2 <<= 1;
-    if (n <= 2048) {  // LDS bitonic; 4 waves keep the ~60 barriers cheap
-        for (uint32_t i = threadIdx.x; i < np2; i += 256) {
-            s_i[i] = i < n ? idx[i] : ~0ull;
-            s_v[i] = i < n ? ldv(i) : 0;
+// canonical codes in (length, symbol) order for the compacted alphabet (syms ascending, len_of[q] = length of the
+// q-th symbol): every thread owns a contiguous run of symbols; per-(length, thread) counts are scanned along the
+// threads by one wave per length. cnt_tbl: u16 [(SZH_MAX_LEN + 1) * NT] in LDS.
+__device__ void cb_assign_codes(const uint16_t *len_of, const uint16_t *syms, uint32_t m, const uint32_t *s_first,
+                                uint16_t *cnt_tbl, uint32_t *enc, uint32_t NT /* live threads */) {
+    const uint32_t t = threadIdx.x, lane = lane_id();
+    const uint32_t per = (m + NT - 1) / NT;
+    const uint32_t q0 = t * per < m ? t * per : m, q1 = q0 + per < m ? q0 + per : m;
+    for (uint32_t l = 0; l <= SZH_MAX_LEN; l++) cnt_tbl[l * NT + t] = 0;
+    for (uint32_t q = q0; q < q1; q++) cnt_tbl[(uint32_t)len_of[q] * NT + t]++;
+    __syncthreads();
+    for (uint32_t l = 1 + t / WAVE; l <= SZH_MAX_LEN; l += NT / WAVE) {
+        uint32_t carry = 0;
+        for (uint32_t c0 = 0; c0 < NT; c0 += WAVE) {
+            const uint32_t v = cnt_tbl[l * NT + c0 + lane];
+            const uint32_t incl = wave_incl_scan(v);
+            cnt_tbl[l * NT + c0 + lane] = (uint16_t)(carry + incl - v);
+            carry += __shfl(incl, WAVE - 1, WAVE);
         }
-        __syncthreads();
-        for (uint32_t k = 2; k <= np2; k <<= 1)
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t i = threadIdx.x; i < np2; i += 256) {
-                    const uint32_t ixj = i ^ j;
-                    if (ixj > i) {
-                        const uint64_t a = s_i[i], b = s_i[ixj];
-                        if ((a > b) == ((i & k) == 0)) {
-                            s_i[i] = b;
-                            s_i[ixj] = a;
-                            const uint64_t t = s_v[i];
-                            s_v[i] = s_v[ixj];
-                            s_v[ixj] = t;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-        for (uint32_t i = threadIdx.x; i < n; i += 256) {
-            idx[i] = s_i[i];
-            stv(i, s_v[i]);
-        }
-        return;
     }
-    // global in-place bitonic; virtual padding: positions >= n compare as +infinity and are never written
-    for (uint32_t k = 2; k <= np2; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < np2; i += 256) {
-                const uint32_t ixj = i ^ j;
-                if (ixj > i && i < n) {
-                    const uint64_t a = idx[i], b = ixj < n ? idx[ixj] : ~0ull;
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up && ixj < n) {
-                        idx[i] = b;
-                        idx[ixj] = a;
-                        const uint64_t t = ldv(i);
-                        stv(i, ldv(ixj));
-                        stv(ixj, t);
-                    }
-                }
-            }
-            __threadfence_block();
-            __syncthreads();
-        }
+    __syncthreads();
+    for (uint32_t q = q0; q < q1; q++) {
+        const uint32_t l = len_of[q];
+        const uint32_t rank = cnt_tbl[l * NT + t]++;
+        enc[syms[q]] = ((s_first[l] + rank) << 5) | l;
+    }
 }
 
-__global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restrict__ hist, szk_cb_params p) {
-    __shared__ uint64_t s_keys[CB_LDS_SYMS];
-    __shared__ uint64_t s_ifreq[CB_LDS_SYMS];
-    __shared__ uint16_t s_pleaf[CB_LDS_SYMS], s_pint[CB_LDS_SYMS], s_aux[CB_LDS_SYMS], s_syms[CB_LDS_SYMS];
-    __shared__ uint16_t s_aux2[CB_LDS_SYMS], s_pint2[CB_LDS_SYMS];
+// wide alphabets (m > CB_LDS_SYMS): all CB_LAUNCH threads, scratch arrays in global memory (L2-resident), LDS pool
+// for the sort tiles, the 32-bit frequency queues and the code assignment table
+__device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_params &p, uint8_t *pool, uint32_t lo,
+                              uint32_t range, uint32_t *s_cnt, uint32_t *s_first, uint32_t *s_misc) {
+    const uint32_t t = threadIdx.x, NT = blockDim.x;
+    __shared__ uint32_t s_wt[CB_LAUNCH / WAVE];
+    __shared__ unsigned long long s_total;
+    // 1. compaction of the non-zero bins in symbol order + total count: every wave owns a contiguous slice of the
+    //    range and walks it 64 bins at a time (coalesced); positions come from ballot prefix counts
+    const uint32_t lane = lane_id(), wv_id = t / WAVE, n_wv = NT / WAVE;
+    const uint32_t seg = ((range + n_wv - 1) / n_wv + WAVE - 1) / WAVE * WAVE;  // bins per wave, multiple of 64
+    const uint32_t b0 = wv_id * seg < range ? wv_id * seg : range, b1 = b0 + seg < range ? b0 + seg : range;
+    uint32_t cnt = 0;
+    uint64_t fsum = 0;
+    for (uint32_t i = b0 + lane; i < b1; i += WAVE) {  // (b1 - b0 need not be a multiple of 64: ballot sees inactive lanes as 0)
+        const uint64_t f = hist[lo + i];
+        cnt += (uint32_t)__popcll(__ballot(f != 0));
+        fsum += f;
+    }
+    // lanes that left the loop early have a smaller cnt: take the wave maximum (= the true count)
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t o = __shfl_xor(cnt, off, WAVE);
+        cnt = o > cnt ? o : cnt;
+    }
+    if (t == 0) s_total = 0;
+    if (t < 8) s_misc[t] = 0;
+    if (lane == 0) s_wt[wv_id] = cnt;
+    __syncthreads();
+    fsum = wave_sum(fsum);
+    if (lane == 0 && fsum) atomicAdd(&s_total, (unsigned long long)fsum);
+    uint32_t pos = 0, m = 0;
+    for (uint32_t wv = 0; wv < n_wv; wv++) {
+        if (wv < wv_id) pos += s_wt[wv];
+        m += s_wt[wv];
+    }
+    for (uint32_t i0 = b0; i0 < b1; i0 += WAVE) {
+        const uint32_t i = i0 + lane;
+        const uint64_t f = i < b1 ? hist[lo + i] : 0ull;
+        const unsigned long long bal = __ballot(f != 0);
+        if (f) {
+            const uint32_t at = pos + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            p.keys[at] = (f << 16) | (lo + i);
+            p.syms[at] = (uint16_t)(lo + i);
+        }
+        pos += (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    const uint64_t total = s_total;
+    if (t == 0) p.info->ts[2] = wall_clock64();
+    // 2. sort by (freq, sym)
+    RecView rv{p.keys, nullptr, false, false};
+    rec_sort(rv, m, pool);
+    if (t == 0) p.info->ts[3] = wall_clock64();
+    // 3. merge
+    uint16_t *pleaf = p.pleaf, *pint = p.pint, *aux = p.depth, *aux2 = p.aux2, *pint2 = p.pint2;
+    constexpr uint32_t LDSQ = CB_POOL_BYTES / 8;  // symbols whose two 32-bit queues fit the pool
+    if (m <= LDSQ && total < 0xFFFFFFFFull) {
+        uint32_t *lf32 = reinterpret_cast<uint32_t *>(pool), *nf32 = lf32 + LDSQ;
+        for (uint32_t q = t; q < m; q += NT) lf32[q] = (uint32_t)(p.keys[q] >> 16);
+        __syncthreads();
+        cb_merge_rounds<true>(p.keys, p.ifreq, lf32, nf32, pleaf, pint, m, s_misc);
+    } else {
+        cb_merge_rounds<false>(p.keys, p.ifreq, nullptr, nullptr, pleaf, pint, m, s_misc);
+    }
+    if (t == 0) p.info->ts[4] = wall_clock64();
+    // 4. depth of every internal node by pointer doubling (min(depth, 2^rounds) is all the clamp needs); the four
+    //    u16 arrays ping-pong in the LDS pool when they fit (m <= 16384), else in global memory
+    const uint32_t L = SZH_MAX_LEN;
+    {
+        const bool in_lds = m <= CB_POOL_BYTES / 8;
+        uint16_t *dA = in_lds ? reinterpret_cast<uint16_t *>(pool) : aux, *pA = in_lds ? dA + CB_POOL_BYTES / 8 : pint;
+        uint16_t *dB = in_lds ? pA + CB_POOL_BYTES / 8 : aux2, *pB = in_lds ? dB + CB_POOL_BYTES / 8 : pint2;
+        __syncthreads();  // (the merge's LDS queues are dead from here on)
+        for (uint32_t q = t; q + 1 < m; q += NT) {
+            pA[q] = q == m - 2 ? (uint16_t)q : pint[q];
+            dA[q] = q == m - 2 ? 0 : 1;
+        }
+        __syncthreads();
+        for (uint32_t span = 1; span < m && span < 2 * L; span <<= 1) {
+            for (uint32_t q = t; q + 1 < m; q += NT) {
+                const uint16_t jn = pA[q];
+                const uint32_t sum = (uint32_t)dA[q] + dA[jn];
+                dB[q] = (uint16_t)(sum > 0xFFFFu ? 0xFFFFu : sum);
+                pB[q] = pA[jn];
+            }
+            __syncthreads();
+            uint16_t *sw = dA;
+            dA = dB;
+            dB = sw;
+            sw = pA;
+            pA = pB;
+            pB = sw;
+        }
+        // leaf lengths in sorted order, clamped
+        for (uint32_t q = t; q < m; q += NT) {
+            uint32_t l = (uint32_t)dA[pleaf[q]] + 1;
+            if (l > L) {
+                l = L;
+                s_misc[4] = 1;
+            }
+            pleaf[q] = (uint16_t)l;
+            atomicAdd(&s_cnt[l], 1u);
+        }
+        __syncthreads();
+    }
+    if (t == 0) p.info->ts[5] = wall_clock64();
+    // 5. Kraft repair when a natural depth exceeded the limit
+    if (s_misc[4]) cb_kraft_repair(pleaf, m, s_cnt, L, NT, reinterpret_cast<uint64_t *>(pool));
+    if (t == 0) {
+        uint32_t code = 0;
+        for (uint32_t l = 1; l <= L; l++) {
+            code = (code + (l > 1 ? s_cnt[l - 1] : 0)) << (l > 1 ? 1 : 0);
+            s_first[l] = code;
+        }
+        p.info->ts[6] = wall_clock64();
+    }
+    // 6. lengths to symbol order (through the serialised lens[] table), then canonical codes
+    for (uint32_t q = t; q < m; q += NT) p.lens[(uint32_t)(p.keys[q] & 0xFFFF)] = (uint8_t)pleaf[q];
+    __syncthreads();
+    for (uint32_t q = t; q < m; q += NT) aux[q] = p.lens[p.syms[q]];
+    __syncthreads();
+    if (t == 0) p.info->ts[7] = wall_clock64();
+    cb_assign_codes(aux, p.syms, m, s_first, reinterpret_cast<uint16_t *>(pool), p.enc, NT);
+    uint32_t max_len = 0;
+    for (uint32_t l = 1; l <= L; l++)
+        if (s_cnt[l]) max_len = l;
+    if (t == 0) {
+        const uint32_t peak = (uint32_t)(p.keys[m - 1] & 0xFFFF);  // most frequent symbol: centre of the packers' LDS window
+        uint32_t wl = peak > lo + ENC_WIN / 2 ? peak - ENC_WIN / 2 : lo;
+        if (range > ENC_WIN && wl > lo + range - ENC_WIN) wl = lo + range - ENC_WIN;
+        if (range <= ENC_WIN) wl = lo;
+        p.info->ts[8] = wall_clock64();
+        p.info->n_symbols = m;
+        p.info->max_len = max_len;
+        p.info->sym_min = lo;
+        p.info->sym_count = range;
+        p.info->win_lo = wl;
+    }
+}
+
+__global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restrict__ hist, szk_cb_params p) {
+    __shared__ __align__(16) uint8_t s_pool[CB_POOL_BYTES];
     __shared__ uint32_t s_wtot[CB_THREADS / WAVE];
     __shared__ uint32_t s_lo, s_hi, s_over;
     __shared__ uint32_t s_first[SZH_MAX_LEN + 2], s_cnt[SZH_MAX_LEN + 2];
+    __shared__ uint32_t s_misc[8];
+    __shared__ unsigned long long s_total;
     const uint32_t t = threadIdx.x;
     if (blockIdx.x > 0) {  // blocks 1 and 2: deterministic order of the two outlier lists (independent of the code book)
         const bool d = blockIdx.x == 2;
         sort_outlier_list(d ? p.dout_idx : p.vout_idx, d ? p.dout_val : p.vout_val, d ? *p.n_dout : *p.n_vout, p.out_cap,
-                          d ? p.q_is_32bit != 0 : p.t_is_32bit != 0, s_keys, s_ifreq);
+                          d ? p.q_is_32bit != 0 : p.t_is_32bit != 0, s_pool);
         return;
     }
-
-    if (t == 0) p.info->ts[0] = wall_clock64();
-    if (t == 0) p.info->ts[0] = wall_clock64();
-    // 0. range of the non-empty bins: found by k_hist_range (256 workgroups) just before this launch
-    if (t == 0) {
-        s_lo = 0xFFFFu - p.range[0];  // range[0] = max over bins of (65535 - bin), range[1] = max bin, both via atomicMax
-        s_hi = p.range[1];
-        s_over = 0;
-        if (p.range[2] == 0) s_lo = 0xFFFFFFFFu;  // range[2] = number of non-empty bins seen (0 = empty histogram)
-    }
-    if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
-    __syncthreads();
-    if (s_lo == 0xFFFFFFFFu) {
+    // range and number of the non-empty bins: found by k_hist_range (256 workgroups) just before this launch
+    const uint32_t n_nonzero = p.range[2];
+    if (n_nonzero == 0) {
         if (t == 0) {
             p.info->n_symbols = 0;
             p.info->max_len = 0;
             p.info->sym_min = 0;
             p.info->sym_count = 0;
+            p.info->win_lo = 0;
         }
         return;
     }
-    const uint32_t lo = s_lo, range = s_hi - s_lo + 1;
-    const uint32_t per = (range + CB_THREADS - 1) / CB_THREADS;
-    for (uint32_t i = t; i < range; i += CB_THREADS) {  // only [lo, hi] is ever looked up / serialised
+    const uint32_t lo = 0xFFFFu - p.range[0], range = p.range[1] - lo + 1;  // range[0] = max(65535 - bin), range[1] = max bin
+    const bool small = n_nonzero <= CB_LDS_SYMS;
+    if (small && t >= CB_THREADS) return;  // the small path runs on 4 waves (cheap barriers)
+    if (t == 0) p.info->ts[0] = wall_clock64();
+    if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
+    if (t == 0) {
+        s_over = 0;
+        s_total = 0;
+    }
+    for (uint32_t i = t; i < range; i += small ? CB_THREADS : CB_LAUNCH) {  // only [lo, hi] is ever looked up / serialised
         p.enc[lo + i] = 0;
         p.lens[lo + i] = 0;
     }
+    __syncthreads();
+    if (!small) {
+        codebook_wide(hist, p, s_pool, lo, range, s_cnt, s_first, s_misc);
+        return;
+    }
+    // ---------------- small alphabets: LDS-resident, 256 threads ----------------
+    uint64_t *keys = reinterpret_cast<uint64_t *>(s_pool);                          // [2048]
+    uint64_t *ifreq = keys + CB_LDS_SYMS;                                            // [2048] (u32 view in the wave merge)
+    uint16_t *pleaf = reinterpret_cast<uint16_t *>(ifreq + CB_LDS_SYMS);             // 6 x u16 [2048]
+    uint16_t *pint = pleaf + CB_LDS_SYMS, *aux = pint + CB_LDS_SYMS, *syms = aux + CB_LDS_SYMS;
+    uint16_t *aux2 = syms + CB_LDS_SYMS, *pint2 = aux2 + CB_LDS_SYMS;
+    uint16_t *cnt_tbl = pint2 + CB_LDS_SYMS;                                         // (SZH_MAX_LEN + 1) * 256 u16
+    const uint32_t per = (range + CB_THREADS - 1) / CB_THREADS;
     // 1. compaction of the non-zero bins in symbol order
     uint32_t cnt = 0;
-    for (uint32_t i = t * per; i < range && i < (t + 1) * per; i++) cnt += hist[lo + i] != 0;
+    uint64_t fsum = 0;
+    for (uint32_t i = t * per; i < range && i < (t + 1) * per; i++) {
+        const uint64_t f = hist[lo + i];
+        cnt += f != 0;
+        fsum += f;
+    }
     uint32_t incl = wave_incl_scan(cnt);
     if (lane_id() == WAVE - 1) s_wtot[t / WAVE] = incl;
+    fsum = wave_sum(fsum);
+    if (lane_id() == 0 && fsum) atomicAdd(&s_total, (unsigned long long)fsum);
     __syncthreads();
     uint32_t pos = incl - cnt, m = 0;
     for (uint32_t wv = 0; wv < CB_THREADS / WAVE; wv++) {
         if (wv < t / WAVE) pos += s_wtot[wv];
         m += s_wtot[wv];
     }
-    const bool small = m <= CB_LDS_SYMS;
-    uint64_t *keys = small ? s_keys : p.keys;
-    uint64_t *ifreq = small ? s_ifreq : p.ifreq;
-    uint16_t *pleaf = small ? s_pleaf : p.pleaf;
-    uint16_t *pint = small ? s_pint : p.pint;
-    uint16_t *aux = small ? s_aux : p.depth;
-    uint16_t *syms = small ? s_syms : p.syms;
-    uint16_t *aux2 = small ? s_aux2 : p.aux2;
-    uint16_t *pint2 = small ? s_pint2 : p.pint2;
     for (uint32_t i = t * per; i < range && i < (t + 1) * per; i++) {
         uint64_t f = hist[lo + i];
         if (f) {
@@ -1112,12 +1488,17 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
     }
 
     if (t == 0) p.info->ts[3] = wall_clock64();
+    const uint32_t L = m <= CB_SHORT_SYMS ? 16u : SZH_MAX_LEN;
     uint32_t max_len = 0;
     if (m == 1) {
         // single symbol: zero-length code, empty bit-stream (as encoder/HuffmanEncoder.hpp:233-237)
     } else {
-        // 3. merge (serial) ...
-        if (t == 0) cb_merge(keys, ifreq, pleaf, pint, m);
+        // 3. merge: one wave out of registers (32-bit counts), or thread 0 (64-bit counts)
+        if (s_total < 0xFFFFFFFFull) {
+            if (t < WAVE) cb_merge_wave32(keys, reinterpret_cast<uint32_t *>(ifreq), pleaf, pint, m);
+        } else if (t == 0) {
+            cb_merge(keys, ifreq, pleaf, pint, m);
+        }
         __syncthreads();
         if (t == 0) p.info->ts[4] = wall_clock64();
         // 4. ... depth of every internal node: distance to the root (node m-2) by pointer doubling
@@ -1127,10 +1508,8 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
             aux[q] = q == m - 2 ? 0 : 1;
         }
         __syncthreads();
-        // after r rounds aux[q] = min(depth, 2^r): 2^r >= SZH_MAX_LEN is all the clamp below needs
-        for (uint32_t span = 1; span < m && span < 2 * SZH_MAX_LEN; span <<= 1) {
-            // every thread handles q = t, t + 1024, ... ; two-phase (read, barrier, write) per round
-            // ping-pong between (aux, pint) and (aux2, pint2) instead of buffering in registers
+        // after r rounds aux[q] = min(depth, 2^r): 2^r >= L is all the clamp below needs
+        for (uint32_t span = 1; span < m && span < 2 * L; span <<= 1) {
             for (uint32_t q = t; q + 1 < m; q += CB_THREADS) {
                 const uint16_t j = pint[q];
                 const uint32_t sum = (uint32_t)aux[q] + aux[j];
@@ -1145,69 +1524,18 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
             __syncthreads();
         }
         if (t == 0) p.info->ts[5] = wall_clock64();
-        // 5. leaf lengths (sorted position q), clamp to SZH_MAX_LEN, per-length counts
+        // 5. leaf lengths (sorted position q), clamp to L, per-length counts
         for (uint32_t q = t; q < m; q += CB_THREADS) {
             uint32_t l = (uint32_t)aux[pleaf[q]] + 1;
-            if (l > SZH_MAX_LEN) {
-                l = SZH_MAX_LEN;
+            if (l > L) {
+                l = L;
                 s_over = 1;
             }
             pleaf[q] = (uint16_t)l;
             atomicAdd(&s_cnt[l], 1u);
         }
         __syncthreads();
-        if (s_over && !small) {
-            if (t == 0) cb_kraft_repair(pleaf, m, s_cnt);
-            __syncthreads();
-        } else if (s_over) {
-            // Kraft repair in closed form (same policy as cb_kraft_repair): the clamped leaves are the first c in
-            // the sorted order; promoting leaf q >= c all the way to the limit frees 2^(L - len_q) - 1 units; take the
-            // shortest prefix of them that covers the excess E, then hand the surplus of the last one back by
-            // shortening the most frequent maximal-length codes by one bit each.
-            uint64_t kraft = 0;
-            for (uint32_t l = 1; l <= SZH_MAX_LEN; l++) kraft += (uint64_t)s_cnt[l] << (SZH_MAX_LEN - l);
-            const uint64_t E = kraft - (1ull << SZH_MAX_LEN);  // > 0 here
-            const uint32_t c = s_cnt[SZH_MAX_LEN];
-            constexpr uint32_t PER = CB_LDS_SYMS / CB_THREADS;  // 8 consecutive leaves per thread
-            uint64_t loc[PER], run = 0;
-            for (uint32_t e = 0; e < PER; e++) {
-                const uint32_t q = t * PER + e;
-                const uint32_t l = q < m ? pleaf[q] : SZH_MAX_LEN;
-                run += (q < m && q >= c) ? ((1ull << (SZH_MAX_LEN - l)) - 1) : 0ull;
-                loc[e] = run;
-            }
-            const uint64_t incl = wave_incl_scan(run);
-            __shared__ uint64_t s_wsum[CB_THREADS / WAVE];
-            __shared__ uint32_t s_kend, s_slack;
-            if (lane_id() == WAVE - 1) s_wsum[t / WAVE] = incl;
-            if (t == 0) {
-                s_kend = 0xFFFFFFFFu;
-                s_slack = 0;
-            }
-            __syncthreads();
-            uint64_t base = incl - run;
-            for (uint32_t wv = 0; wv < t / WAVE; wv++) base += s_wsum[wv];
-            for (uint32_t e = 0; e < PER; e++) {
-                const uint64_t hi = base + loc[e], lo = base + (e ? loc[e - 1] : 0ull);
-                if (lo < E && E <= hi) {  // exactly one (q) satisfies this
-                    s_kend = t * PER + e;
-                    s_slack = (uint32_t)(hi - E);
-                }
-            }
-            __syncthreads();
-            const uint32_t kend = s_kend;
-            if (kend != 0xFFFFFFFFu) {
-                const uint32_t n16 = kend + 1;  // leaves [0, kend] now sit at the limit
-                const uint32_t back = s_slack < n16 ? s_slack : n16;
-                for (uint32_t q = t; q <= kend; q += CB_THREADS)
-                    pleaf[q] = (uint16_t)((q + back > kend) ? SZH_MAX_LEN - 1 : SZH_MAX_LEN);
-            }
-            __syncthreads();
-            if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
-            __syncthreads();
-            for (uint32_t q = t; q < m; q += CB_THREADS) atomicAdd(&s_cnt[pleaf[q]], 1u);
-            __syncthreads();
-        }
+        if (s_over) cb_kraft_repair(pleaf, m, s_cnt, L, CB_THREADS, reinterpret_cast<uint64_t *>(cnt_tbl));
         // 6. canonical first code per length
         if (t == 0) {
             uint32_t code = 0;
@@ -1233,28 +1561,30 @@ __global__ __launch_bounds__(CB_THREADS) void k_codebook(const uint64_t *__restr
         __syncthreads();
         if (t == 0) p.info->ts[7] = wall_clock64();
         // 8. codes in (len, symbol) order: rank among the earlier symbols of the same length
-        if (small) {
+        if (m <= 512) {
             for (uint32_t q = t; q < m; q += CB_THREADS) {
                 const uint32_t l = aux[q];
                 uint32_t rank = 0;
                 for (uint32_t r = 0; r < q; r++) rank += aux[r] == l;
                 p.enc[syms[q]] = ((s_first[l] + rank) << 5) | l;
             }
-        } else if (t == 0) {
-            for (uint32_t q = 0; q < m; q++) {
-                const uint32_t l = aux[q];
-                p.enc[syms[q]] = ((s_first[l]++) << 5) | l;
-            }
+        } else {
+            cb_assign_codes(aux, syms, m, s_first, cnt_tbl, p.enc, CB_THREADS);
         }
         for (uint32_t l = 1; l <= SZH_MAX_LEN; l++)
             if (s_cnt[l]) max_len = l;
     }
     if (t == 0) {
+        const uint32_t peak = (uint32_t)(keys[m - 1] & 0xFFFF);
+        uint32_t wl = peak > lo + ENC_WIN / 2 ? peak - ENC_WIN / 2 : lo;
+        if (range > ENC_WIN && wl > lo + range - ENC_WIN) wl = lo + range - ENC_WIN;
+        if (range <= ENC_WIN) wl = lo;
         p.info->ts[8] = wall_clock64();
         p.info->n_symbols = m;
         p.info->max_len = max_len;
         p.info->sym_min = lo;
         p.info->sym_count = range;
+        p.info->win_lo = wl;
     }
 }
 
@@ -1304,7 +1634,6 @@ __global__ void k_layout_pre(szk_layout_params p) {  // after K1 + K5, before th
 // K6 pass 1: 32-bit words needed by every chunk of SZH_CHUNK_SYMS symbols (one wave per chunk, 16 symbols/lane)
 // ------------------------------------------------------------------------------------------------------------
 #define ENC_PER_LANE 16
-#define ENC_WIN 4096  // LDS-cached slice of the encode table around the radius
 
 __device__ __forceinline__ uint32_t enc_lookup(const uint32_t *s_enc, const uint32_t *__restrict__ g_enc, int win_lo,
                                                uint32_t sym) {
@@ -1388,15 +1717,15 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(const uint16_t *__restrict
 #define PACK_GROUP 32  // chunks per offset group
 
 __device__ __forceinline__ uint32_t enc_lookup2(const uint32_t *s_enc, const uint32_t *__restrict__ g_enc,
-                                                uint32_t sym_min, bool all_lds, uint32_t sym) {
-    const uint32_t rel = sym - sym_min;
+                                                uint32_t win_lo, bool all_lds, uint32_t sym) {
+    const uint32_t rel = sym - win_lo;
     if (all_lds) return s_enc[rel & (ENC_WIN - 1)];
     return rel < ENC_WIN ? s_enc[rel] : g_enc[sym];
 }
-__device__ __forceinline__ void enc_table_load(uint32_t *s_enc, const uint32_t *__restrict__ g_enc, uint32_t sym_min,
+__device__ __forceinline__ void enc_table_load(uint32_t *s_enc, const uint32_t *__restrict__ g_enc, uint32_t win_lo,
                                                uint32_t sym_count) {
     const uint32_t cnt = sym_count < ENC_WIN ? sym_count : ENC_WIN;
-    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) s_enc[i] = g_enc[sym_min + i];
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) s_enc[i] = g_enc[win_lo + i];
 }
 
 // raw code registers of one lane (16 symbols: 32 bytes as two-byte codes, 16 bytes as one-byte codes) — loaded
@@ -1445,7 +1774,7 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
     CodeRegs cur, nxt;
     uint64_t chunk = wave_gid;
     if (chunk < n_full) fetch_codes(codes, chunk * SZH_CHUNK_SYMS + lane_off, narrow, cur);  // in flight during the table load
-    const uint32_t sym_min = info->sym_min, sym_count = info->sym_count;
+    const uint32_t sym_min = info->win_lo, sym_count = info->sym_count;  // sym_min: start of the LDS window
     const bool all_lds = sym_count <= ENC_WIN;
     enc_table_load(s_enc, g_enc, sym_min, sym_count);
     __syncthreads();
@@ -1516,45 +1845,56 @@ __global__ __launch_bounds__(1024) void k_scan_groups(const uint16_t *__restrict
     if (threadIdx.x == 0) *total_words = s_carry;
 }
 
-// pack 16 symbols of a lane into the wave's LDS stage at the lane's bit offset; returns the chunk's word count
+// pack 16 symbols of a lane into the wave's LDS stage at the lane's bit offset; returns the chunk's word count.
+// G code words are joined per 64-bit register: G = 4 when the code book's longest word is <= 16 bits, else G = 2
+// (<= 24 bits each); every register is emitted left-aligned at its bit offset with three ds_or.
+template <int G>
 __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE], uint64_t base, uint64_t n, bool check_n,
                                                const uint32_t *s_enc, const uint32_t *__restrict__ g_enc,
                                                uint32_t sym_min, bool all_lds, uint32_t *stage) {
-    uint64_t g[4];
-    uint32_t gl[4];
+    constexpr int NG = ENC_PER_LANE / G;
+    uint64_t g[NG];
+    uint32_t gl[NG];
     uint32_t bits = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        // two code words (<= 32 bits) are joined with 32-bit ops, two pairs (<= 64 bits) with one 64-bit shift
-        uint32_t pc[2], pl[2];
+    for (int k = 0; k < NG; k++) {
+        // two code words are joined with 32-bit ops when they are <= 16 bits each, two pairs with one 64-bit shift
+        uint64_t pc[G / 2];
+        uint32_t pl[G / 2];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            uint32_t e0 = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[4 * k + 2 * h]);
-            uint32_t e1 = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[4 * k + 2 * h + 1]);
+        for (int h = 0; h < G / 2; h++) {
+            uint32_t e0 = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h]);
+            uint32_t e1 = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h + 1]);
             if (check_n) {
-                e0 = (base + 4 * k + 2 * h < n) ? e0 : 0u;
-                e1 = (base + 4 * k + 2 * h + 1 < n) ? e1 : 0u;
+                e0 = (base + G * k + 2 * h < n) ? e0 : 0u;
+                e1 = (base + G * k + 2 * h + 1 < n) ? e1 : 0u;
             }
             const uint32_t l1 = e1 & 31u;
-            pc[h] = ((e0 >> 5) << l1) | (e1 >> 5);
+            if (G == 4) pc[h] = ((e0 >> 5) << l1) | (e1 >> 5);
+            else pc[h] = ((uint64_t)(e0 >> 5) << l1) | (e1 >> 5);
             pl[h] = (e0 & 31u) + l1;
         }
-        g[k] = ((uint64_t)pc[0] << pl[1]) | pc[1];
-        gl[k] = pl[0] + pl[1];
+        if (G == 4) {
+            g[k] = (pc[0] << pl[G / 2 - 1]) | pc[G / 2 - 1];
+            gl[k] = pl[0] + pl[G / 2 - 1];
+        } else {
+            g[k] = pc[0];
+            gl[k] = pl[0];
+        }
         bits += gl[k];
     }
     const uint32_t incl = wave_incl_scan(bits);
     const uint32_t total_bits = __shfl(incl, WAVE - 1, WAVE);
     uint32_t pos = incl - bits;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NG; k++) {
         const uint64_t v = gl[k] ? g[k] << (64 - gl[k]) : 0ull;  // left-aligned
         const uint32_t word = pos >> 5, sh = pos & 31;
         const uint64_t t = v >> sh;
         const uint32_t w2 = (uint32_t)(((uint64_t)(uint32_t)v << 32) >> sh);
         atomicOr(&stage[word], (uint32_t)(t >> 32));
         atomicOr(&stage[word + 1], (uint32_t)t);
-        atomicOr(&stage[word + 2], w2);
+        if (G == 4 || gl[k] + sh > 64) atomicOr(&stage[word + 2], w2);
         pos += gl[k];
     }
     return (total_bits + 31) >> 5;
@@ -1594,8 +1934,9 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         fetch_codes(codes, chunk * SZH_CHUNK_SYMS + lane_off, narrow, cur);
         side(chunk, bp_cur, go_cur);
     }
-    const uint32_t sym_min = info->sym_min, sym_count = info->sym_count;
+    const uint32_t sym_min = info->win_lo, sym_count = info->sym_count;  // sym_min: start of the LDS window
     const bool all_lds = sym_count <= ENC_WIN;
+    const bool wide = info->max_len > 16;  // two instead of four code words per 64-bit register
     enc_table_load(s_enc, g_enc, sym_min, sym_count);
     for (int i = lane; i < STAGE_WORDS; i += WAVE) stage[i] = 0;
     __syncthreads();
@@ -1607,7 +1948,8 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         }
         uint16_t c[ENC_PER_LANE];
         unpack_codes(cur, narrow, sym_add, c);
-        const uint32_t nwords = pack_chunk(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage);
+        const uint32_t nwords = wide ? pack_chunk<2>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage)
+                                     : pack_chunk<4>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage);
         const uint32_t before = wave_sum(bp_cur);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -1629,7 +1971,8 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         uint32_t bp;
         uint64_t go;
         side(n_full, bp, go);
-        const uint32_t nwords = pack_chunk(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage);
+        const uint32_t nwords = wide ? pack_chunk<2>(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage)
+                                     : pack_chunk<4>(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage);
         const uint32_t before = wave_sum(bp);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -2032,7 +2375,7 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
     hipError_t e = hipMemsetAsync(p->range, 0, 16, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256), dim3(256), 0, s, d_hist, p->range);
-    hipLaunchKernelGGL(k_codebook, dim3(3), dim3(CB_THREADS), 0, s, d_hist, *p);
+    hipLaunchKernelGGL(k_codebook, dim3(3), dim3(CB_LAUNCH), 0, s, d_hist, *p);
     SZK_CHECK_LAUNCH();
     return 0;
 }

@@ -8,7 +8,8 @@ import numpy as np
 
 MAGIC = 0x31485A53
 CHUNK = 1024
-MAX_LEN = 16
+MAX_LEN = 24        # format limit; code books of <= SHORT_SYMS symbols are limited to SHORT_LEN
+SHORT_SYMS, SHORT_LEN = 512, 16
 
 
 def dualquant(a, eb, radius=32768, narrow=False):

@@ -13,6 +13,7 @@ torch = pytest.importorskip("torch")
 
 def _conf(shape, eb):
     c = sz3_amd.Config(*shape)
+    c.cmprAlgo = sz3_amd.ALGO_LORENZO_REG   # the Lorenzo path (the default ALGO_INTERP_LORENZO takes interpolation)
     c.errorBoundMode = sz3_amd.EB_ABS
     c.absErrorBound = eb
     return c
@@ -53,7 +54,17 @@ CASES = [
     ("4d-march-f64", lambda: field4d((2, 18, 5, 264), np.float64), 1e-3),
     ("3d-smooth", lambda: field3d((40, 40, 40), sigma=0.0), 1e-1),
     ("3d-const", lambda: np.full((17, 19, 23), 3.25, np.float32), 1e-3),
+    # wide alphabets: ~1.5k symbols (LDS code book, 24-bit limit), ~6k (round-parallel merge, LDS queues),
+    # ~40k symbols with deltas beyond the radius (global-memory queues, delta outliers)
+    ("3d-rough-1k", lambda: _rough((40, 64, 64), 0.12), 1e-3),
+    ("3d-rough-6k", lambda: _rough((48, 64, 64), 0.6), 1e-3),
+    ("3d-rough-40k", lambda: _rough((48, 64, 128), 6.0), 1e-3),
 ]
+
+
+def _rough(shape, sigma):
+    rng = np.random.default_rng(7)
+    return (field3d(shape) + rng.normal(0.0, sigma, shape)).astype(np.float32)
 
 
 @pytest.mark.parametrize("name,gen,eb", CASES, ids=[c[0] for c in CASES])
@@ -72,9 +83,10 @@ def test_stages(name, gen, eb):
     lens = sec["lens"]
     assert set(h["sym_min"] + np.nonzero(lens)[0]) == (set(present.tolist()) if len(present) > 1 else set())
     if len(present) > 1:
-        assert abs(szh_ref.kraft(lens) - 1.0) < 1e-9 and lens.max() == h["max_len"] <= szh_ref.MAX_LEN
+        limit = szh_ref.SHORT_LEN if len(present) <= szh_ref.SHORT_SYMS else szh_ref.MAX_LEN
+        assert abs(szh_ref.kraft(lens) - 1.0) < 1e-9 and lens.max() == h["max_len"] <= limit
         # optimality: total bits equal to an independent (unlimited) Huffman construction when that code respects the
-        # 16-bit limit, otherwise within 0.2 % of it (length-limited code)
+        # length limit (16 bits up to 512 symbols, else 24), otherwise within 0.2 % of it (length-limited code)
         freq = np.bincount(exp_codes.reshape(-1), minlength=65536)[h["sym_min"]:h["sym_min"] + h["sym_count"]]
         import heapq
         heap = [(int(f), i, 0) for i, f in enumerate(freq) if f]   # (freq, tiebreak, height)
@@ -88,7 +100,7 @@ def test_stages(name, gen, eb):
             cnt += 1
             heapq.heappush(heap, (f1 + f2, cnt, max(h1, h2) + 1))
         gpu_cost = int((freq * lens.astype(np.int64)).sum())
-        if heap[0][2] <= szh_ref.MAX_LEN:
+        if heap[0][2] <= limit:
             assert gpu_cost == cost, "code is not optimal"
         else:
             assert cost <= gpu_cost <= cost * 1.002, "length-limited code too far from optimal"

@@ -8,13 +8,14 @@ from fields import field3d
 S = int(os.environ.get("LAB_SIZE", "256"))
 a = field3d((S, S, S)); dev = torch.device("cuda:0")
 d_in = torch.from_numpy(a).to(dev)
-conf = sz3_amd.Config(S, S, S); conf.absErrorBound = float(os.environ.get("LAB_EB", "1e-3"))
+conf = sz3_amd.Config(S, S, S); conf.cmprAlgo = sz3_amd.ALGO_INTERP if os.environ.get('LAB_ALGO') == 'interp' else sz3_amd.ALGO_LORENZO_REG; conf.absErrorBound = float(os.environ.get("LAB_EB", "1e-3"))
 dc = sz3_amd.DeviceCompressor(a.size, np.float32)
 cap = dc.payload_bound(a.size); pl = torch.empty(cap, dtype=torch.uint8, device=dev)
 for _ in range(3): dc.compress(conf, d_in.data_ptr(), pl.data_ptr(), cap, 0)
 L = sz3_amd.lib(); L.sz3hip_debug_codebook_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 out = (C.c_uint64 * 16)(); L.sz3hip_debug_codebook_info(dc._h, out)
 ts = [out[4 + i] for i in range(9)]
+ts[1] = ts[0]  # (no separate sweep phase any more)
 print("n_symbols %d max_len %d sym_min %d sym_count %d" % tuple(out[:4]))
 names = ["sweep", "compact", "sort", "merge", "depth", "lengths", "scatter", "assign"]
 for i, n in enumerate(names): print("  %-8s %7.2f us" % (n, (ts[i + 1] - ts[i]) / 100.0))

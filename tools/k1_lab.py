@@ -8,7 +8,7 @@ from fields import field3d
 S = int(os.environ.get("LAB_SIZE", "512"))
 a = field3d((S, S, S)); dev = torch.device("cuda:0")
 d_in = torch.from_numpy(a).to(dev)
-conf = sz3_amd.Config(S, S, S); conf.absErrorBound = 1e-3
+conf = sz3_amd.Config(S, S, S); conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG; conf.absErrorBound = 1e-3
 dc = sz3_amd.DeviceCompressor(a.size, np.float32)
 stream = torch.cuda.current_stream().cuda_stream
 L = sz3_amd.lib(); L.sz3hip_debug_flags.argtypes = [__import__("ctypes").c_int]

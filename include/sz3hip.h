@@ -76,6 +76,7 @@ typedef struct sz3hip_config {
 } sz3hip_config;
 
 const char *sz3hip_last_error(void);
+int sz3hip_last_error_code(void); /* SZ3HIP_E* of the last failure on this thread (for wrappers that map codes to exceptions) */
 const char *sz3hip_version(void);
 
 /* ---- (2) Config + host-buffer API ------------------------------------------------------------------------ */

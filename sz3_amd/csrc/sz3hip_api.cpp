@@ -33,15 +33,18 @@
 
 // ------------------------------------------------------------------------------------------------------------
 static thread_local char g_err[512];
+static thread_local int g_err_code = 0;
 static int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 static int fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+    g_err_code = code;
     return code;
 }
 extern "C" const char *sz3hip_last_error(void) { return g_err; }
+extern "C" int sz3hip_last_error_code(void) { return g_err_code; }
 extern "C" const char *sz3hip_version(void) { return "sz3hip 0.1 (gfx950; data format SZ3 3.3.2 container, payload SZH1)"; }
 
 #define HIPCHK(call)                                                                              \

@@ -236,3 +236,30 @@ def test_histogram_split_path_equals_single_call():
     dc.decompress(p2.data_ptr(), n3, out.data_ptr(), s)
     torch.cuda.synchronize()
     assert float((out.double() - t.double()).abs().max()) <= 1e-3
+
+
+def test_unmodified_reference_cli_runs_on_the_gpu_path(tmp_path):
+    """oracle/_ref/sz3_hip: the reference's CLI source (tools/sz3/sz3.cpp, unmodified, compiled where it lies) built
+    against include/SZ3/api/sz.hpp + libsz3hip.so. Its own round-trip report must show the bound, and the stream
+    it wrote must decode through the Python binding too (tools/sz3/sz3.cpp:130-190)."""
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "sz3_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/sz3_hip not built (needs /root/reference at build time)")
+    a = field3d((40, 50, 60))
+    src, cmp_, dec = tmp_path / "a.f32", tmp_path / "a.sz", tmp_path / "a.out"
+    a.tofile(src)
+    for algo_ini, want in (("ALGO_LORENZO_REG", sz3_amd.ALGO_HIP_LORENZO), ("ALGO_INTERP", sz3_amd.ALGO_HIP_INTERP)):
+        ini = tmp_path / "c.ini"
+        ini.write_text("[GlobalSettings]\nCmprAlgo = %s\n" % algo_ini)
+        r = subprocess.run([exe, "-f", "-i", str(src), "-z", str(cmp_), "-o", str(dec), "-3", "60", "50", "40", "-c", str(ini),
+                            "-M", "ABS", "1e-3", "-a"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        m = re.search(r"Max absolute error = ([0-9.eE+-]+)", r.stdout)
+        assert m and float(m.group(1)) <= 1e-3, r.stdout
+        out = np.fromfile(dec, dtype=np.float32).reshape(a.shape)
+        assert np.max(np.abs(out.astype(np.float64) - a.astype(np.float64))) <= 1e-3
+        blob = np.fromfile(cmp_, dtype=np.uint8)
+        d2, c2 = sz3_amd.decompress(blob, np.float32, a.shape)
+        assert c2.cmprAlgo == want and np.array_equal(d2, out)

@@ -36,8 +36,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512, help="edge of the cubic volume per GPU (512 = the metric's config)")
     ap.add_argument("--eb", type=float, default=1e-3)
-    ap.add_argument("--algo", choices=["lorenzo", "interp"], default="lorenzo",
-                    help="lorenzo = the metric's config C2 (default); interp = C3 (ALGO_INTERP, cubic, abs 1e-4 unless --eb)")
+    ap.add_argument("--algo", choices=["lorenzo", "interp", "interp-notune"], default="lorenzo",
+                    help="lorenzo = the metric's config C2 (default); interp = C3 (ALGO_INTERP_LORENZO: sampling auto-tuner + "
+                         "interpolation; use --eb 1e-4); interp-notune = ALGO_INTERP with the default cubic parameters")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-e2e", action="store_true")
     args = ap.parse_args()
@@ -68,7 +69,8 @@ def main():
     a = field3d(shape, np.float32, seed=20260928 + rank)
     d_in = torch.from_numpy(a).to(dev)
     conf = sz3_amd.Config(*shape)
-    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG if args.algo == "lorenzo" else sz3_amd.ALGO_INTERP
+    conf.cmprAlgo = {"lorenzo": sz3_amd.ALGO_LORENZO_REG, "interp": sz3_amd.ALGO_INTERP_LORENZO,
+                     "interp-notune": sz3_amd.ALGO_INTERP}[args.algo]
     conf.lorenzo, conf.lorenzo2, conf.regression = 1, 0, 0
     conf.errorBoundMode = sz3_amd.EB_ABS
     conf.absErrorBound = eb
@@ -157,13 +159,16 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: 3D float32 %dx%dx%d synthetic field per GPU, %s predictor, abs errBound=%g, "
                                    "device-resident in -> device-resident Huffman payload"
-                                   % ("C2" if args.algo == "lorenzo" else "C3", S, S, S, "Lorenzo" if args.algo == "lorenzo" else "interpolation", eb),
+                                   % ("C2" if args.algo == "lorenzo" else "C3", S, S, S,
+                                      {"lorenzo": "Lorenzo", "interp": "ALGO_INTERP_LORENZO (auto-tuned interpolation)",
+                                       "interp-notune": "interpolation (ALGO_INTERP)"}[args.algo], eb),
                        "parallelism": "slab%d" % world, "algo": "HIP_LORENZO(16)" if args.algo == "lorenzo" else "HIP_INTERP(17)", "eb": eb},
             "ratio": round(ratio, 4), "max_abs_err": max_err, "err_bound_ok": bool(max_err <= eb),
             "payload_bytes_rank0": int(psize),
             "outliers": {"value": stats["n_value_outliers"], "delta": stats["n_delta_outliers"]},
             "narrow_codes": stats.get("narrow_codes"),
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
+            "tuner": dc.tuner_report() if args.algo == "interp" else None,
             "kernels_ms": round(kernels_ms, 4),
             "frac_read_peak_all_kernels": round(raw_bytes / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": "k_lorenzo_quant (stage lorenzo_quant_hist)",
@@ -188,7 +193,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle_binding import have_ref, make_config, oracle_compress, ref_compress
         from oracle_binding import ALGO_INTERP as O_INTERP
-        oconf = make_config(shape, abs_eb=eb, lorenzo=True, regression=False) if args.algo == "lorenzo" else make_config(shape, algo=O_INTERP, abs_eb=eb)
+        from oracle_binding import ALGO_INTERP_LORENZO as O_TUNED
+        oconf = (make_config(shape, abs_eb=eb, lorenzo=True, regression=False) if args.algo == "lorenzo" else
+                 make_config(shape, algo=O_TUNED if args.algo == "interp" else O_INTERP, abs_eb=eb, regression=True))
         # bounded sample: the full volume is ~8 s of single-thread reference work at 512^3; cap at 512^3
         if have_ref():
             blob, sec = ref_compress(a, oconf, timing=True)
@@ -200,7 +207,8 @@ def main():
             kind = "port"
         out["cpu_baseline"] = {"value": round(raw_bytes / sec / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
                                "sample": "whole %dx%dx%d volume, SZ_compress<float> %s abs %g, single thread, %.2f s"
-                                         % (S, S, S, "ALGO_LORENZO_REG (Lorenzo only)" if args.algo == "lorenzo" else "ALGO_INTERP (cubic)", eb, sec),
+                                         % (S, S, S, {"lorenzo": "ALGO_LORENZO_REG (Lorenzo only)", "interp": "ALGO_INTERP_LORENZO (default)",
+                                                       "interp-notune": "ALGO_INTERP (cubic)"}[args.algo], eb, sec),
                                "ratio": round(raw_bytes / float(len(blob)), 4),
                                "host_cpus": os.cpu_count()}
     if rank == 0:

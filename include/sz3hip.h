@@ -139,6 +139,20 @@ typedef struct sz3hip_stats {
     uint32_t reserved;
 } sz3hip_stats;
 int sz3hip_get_stats(sz3hip_ctx *ctx, sz3hip_stats *st);
+
+/* what the ALGO_INTERP_LORENZO sampling auto-tuner (SZ_compress_Interp_lorenzo, api/impl/SZAlgoInterp.hpp:122-286) saw and
+ * decided in the last sz3hip_compress_stage1 / sz3hip_compress_device call of this context */
+typedef struct sz3hip_tuner_report {
+    int32_t ran;        /* 1: the sampling trials ran; 0: skipped like the reference (:149-162, :176-179) or another cmprAlgo */
+    int32_t use_interp; /* 1: interpolation chosen; 0: Lorenzo (possible in 1-D only, :232-250) */
+    uint64_t sample_block_size, n_filtered, n_blocks;
+    int32_t profiling;
+    int32_t interpAlgo, interpDirection, reserved;
+    double interpAlpha, interpBeta;
+    double est_bytes[8]; /* priced size of the trials: linear, cubic, reversed direction, 3 x (alpha, beta), [6] Lorenzo (1-D) */
+} sz3hip_tuner_report;
+int sz3hip_get_tuner_report(sz3hip_ctx *ctx, sz3hip_tuner_report *rep);
+
 /* per-stage kernel time of the last compress / decompress when profiling is on (hipEvents on `stream`):
  * names[i] / ms[i] for i < returned count; count 0 if profiling is off */
 void sz3hip_set_profiling(sz3hip_ctx *ctx, int on);

@@ -747,6 +747,16 @@ size_t szo_decomposition_codes(const szo_config *config, int dtype, const void *
     return (size_t)st.n_unpred;
 }
 
+int szo_tune_interp_lorenzo(szo_config *conf, int dtype, const void *data, szo_tuner_report *rep) {
+    if (conf->cmprAlgo != SZO_ALGO_INTERP_LORENZO) return -1;
+    if (dtype == SZO_FLOAT) {
+        if (cal_abs_eb_f32(conf, (const float *)data)) return -1;
+        return tune_interp_lorenzo_f32(conf, (const float *)data, rep);
+    }
+    if (cal_abs_eb_f64(conf, (const double *)data)) return -1;
+    return tune_interp_lorenzo_f64(conf, (const double *)data, rep);
+}
+
 size_t szo_interp_codes(const szo_config *config, int dtype, const void *data, int32_t *codes, uint64_t *order, void *recon) {
     szo_config conf = *config;
     if (conf.interpAnchorStride < 0) {

@@ -51,6 +51,15 @@ typedef struct szo_stats {
     double t_decomp, t_hist_tree, t_encode, t_zstd; /* seconds */
 } szo_stats;
 
+/* what the ALGO_INTERP_LORENZO tuner saw and decided (diagnostics for the parity tests) */
+typedef struct szo_tuner_report {
+    uint64_t sample_block_size, n_filtered, n_blocks;
+    int32_t profiling, reserved;
+    double ratios[8]; /* trial ratios in the reference's order: linear, cubic, reversed direction, 3 x (alpha, beta) */
+    double best_interp, best_lorenzo;
+    uint64_t raw_bytes[8], huff_bytes[8], node_count[8], n_unpred[8]; /* per interpolation trial (pre-zstd size, ...) */
+} szo_tuner_report;
+
 /* Config ctor semantics: setDims drops dims==1, sets N/num/predDim/blockSize defaults (Config.hpp:161-177, 452-478) */
 void szo_config_init(szo_config *c, int ndims, const uint64_t *dims_slowest_first);
 size_t szo_config_save(const szo_config *c, uint8_t *out);                     /* Config.hpp:312-354 */
@@ -94,6 +103,13 @@ size_t szo_decomposition_codes(const szo_config *c, int dtype, const void *data,
  * codes in the reference's emission order, the element index of every code (order, may be NULL) and the reconstructed
  * array the encoder ends up with (recon, may be NULL).  returns the number of unpredictable values (incl. anchors) */
 size_t szo_interp_codes(const szo_config *c, int dtype, const void *data, int32_t *codes, uint64_t *order, void *recon);
+
+
+/* SZ_compress_Interp_lorenzo's decisions only (api/impl/SZAlgoInterp.hpp:122-262): conf (cmprAlgo must be
+ * ALGO_INTERP_LORENZO) is updated exactly as the reference updates it before the final compress call — cmprAlgo becomes
+ * ALGO_INTERP (interpAlgo / interpDirection / interpAlpha / interpBeta tuned) or ALGO_LORENZO_REG (1-D only).
+ * returns 1 if the sampling trials ran, 0 if the tuner was skipped, -1 on error */
+int szo_tune_interp_lorenzo(szo_config *conf, int dtype, const void *data, szo_tuner_report *rep);
 
 #ifdef __cplusplus
 }

@@ -759,6 +759,8 @@ static int SUF(cal_abs_eb)(szo_config *conf, const T *data) {
     return 0;
 }
 
+#include "sz3_oracle_tuner.h"
+
 /* SZ_compress_dispatcher, api/impl/SZDispatcher.hpp:13-76 (serial path; conf is modified like the reference's copy) */
 static size_t SUF(compress_dispatch)(szo_config *conf, const T *data, uint8_t *out, size_t cap, szo_stats *st) {
     if (SUF(cal_abs_eb)(conf, data)) return 0;

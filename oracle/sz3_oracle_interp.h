@@ -430,10 +430,3 @@ static int SUF(decompress_interp)(const szo_config *conf, const uint8_t *cmp, si
     free(raw);
     return rc;
 }
-
-/* SZ_compress_Interp_lorenzo (SZAlgoInterp.hpp:122-286): the sampling auto-tuner is not restated yet */
-static size_t SUF(compress_interp_lorenzo)(szo_config *conf, const T *data, uint8_t *out, size_t cap, szo_stats *st) {
-    (void)conf; (void)data; (void)out; (void)cap; (void)st;
-    set_err("oracle: ALGO_INTERP_LORENZO auto-tuner not restated yet (use ALGO_INTERP with explicit parameters)");
-    return 0;
-}

@@ -46,6 +46,12 @@ class _CConfig(C.Structure):
     ]
 
 
+class _CTunerReport(C.Structure):
+    _fields_ = [("ran", C.c_int32), ("use_interp", C.c_int32), ("sample_block_size", C.c_uint64), ("n_filtered", C.c_uint64),
+                ("n_blocks", C.c_uint64), ("profiling", C.c_int32), ("interpAlgo", C.c_int32), ("interpDirection", C.c_int32),
+                ("reserved", C.c_int32), ("interpAlpha", C.c_double), ("interpBeta", C.c_double), ("est_bytes", C.c_double * 8)]
+
+
 class _CStats(C.Structure):
     _fields_ = [("n", C.c_uint64), ("n_value_outliers", C.c_uint64), ("n_delta_outliers", C.c_uint64),
                 ("n_chunks", C.c_uint64), ("bitstream_bytes", C.c_uint64), ("payload_bytes", C.c_uint64),
@@ -106,6 +112,8 @@ def lib():
     L.sz3hip_decompress_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.sz3hip_get_stats.restype = C.c_int
     L.sz3hip_get_stats.argtypes = [C.c_void_p, P(_CStats)]
+    L.sz3hip_get_tuner_report.restype = C.c_int
+    L.sz3hip_get_tuner_report.argtypes = [C.c_void_p, P(_CTunerReport)]
     L.sz3hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.sz3hip_get_stage_times.restype = C.c_int
     L.sz3hip_get_stage_times.argtypes = [C.c_void_p, P(C.c_char_p), P(C.c_float), C.c_int]
@@ -292,6 +300,14 @@ class DeviceCompressor:
         st = _CStats()
         lib().sz3hip_get_stats(self._h, C.byref(st))
         return {k: int(getattr(st, k)) for k, _ in _CStats._fields_}
+
+    def tuner_report(self):
+        """what the ALGO_INTERP_LORENZO auto-tuner decided in the last stage1 / compress call (sz3hip_get_tuner_report)"""
+        r = _CTunerReport()
+        lib().sz3hip_get_tuner_report(self._h, C.byref(r))
+        out = {k: getattr(r, k) for k, _ in _CTunerReport._fields_ if k not in ("est_bytes", "reserved")}
+        out["est_bytes"] = [float(x) for x in r.est_bytes]
+        return out
 
     def set_profiling(self, on=True):
         lib().sz3hip_set_profiling(self._h, int(on))

@@ -354,9 +354,9 @@ extern "C" size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in) 
 // ------------------------------------------------------------------------------------------------------------
 // device context
 // ------------------------------------------------------------------------------------------------------------
-enum { ST_K1 = 0, ST_CODEBOOK, ST_ENCODE, ST_ASSEMBLE, ST_DEC_HUFF, ST_DEC_RECON, ST_COUNT };
+enum { ST_K1 = 0, ST_CODEBOOK, ST_ENCODE, ST_ASSEMBLE, ST_DEC_HUFF, ST_DEC_RECON, ST_TUNER, ST_COUNT };
 static const char *const kStageNames[ST_COUNT] = {"lorenzo_quant_hist", "codebook", "encode", "assemble",
-                                                  "huffman_decode",     "reconstruct"};
+                                                  "huffman_decode",     "reconstruct", "tuner"};
 
 struct sz3hip_ctx {
     int device;
@@ -391,6 +391,16 @@ struct sz3hip_ctx {
     szh_header proto;
     bool stage1_done, stage2_done;
     sz3hip_stats stats;
+    // ALGO_INTERP_LORENZO tuner scratch (lazy)
+    uint8_t *d_flags;
+    size_t flags_cap;
+    uint64_t *d_starts;
+    size_t starts_cap;
+    void *d_samples;
+    size_t samples_cap;
+    uint64_t *d_trial;  // [8][4]: bits, symbols, unpredictables, delta outliers
+    uint64_t *h_trial;  // pinned
+    sz3hip_tuner_report tuner;
     // profiling
     bool profiling;
     hipEvent_t ev[ST_COUNT][2];
@@ -401,12 +411,14 @@ static void ctx_free(sz3hip_ctx *c) {
     if (!c) return;
     void *bufs[] = {c->d_work, c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_counters, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
                     c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_aux2, c->d_pint2, c->d_range, c->d_info,
-                    c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax};
+                    c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_flags, c->d_starts, c->d_samples,
+                    c->d_trial};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
     if (c->h_probe) (void)hipHostFree(c->h_probe);
+    if (c->h_trial) (void)hipHostFree(c->h_trial);
     for (int i = 0; i < ST_COUNT; i++)
         for (int j = 0; j < 2; j++)
             if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
@@ -537,86 +549,97 @@ extern "C" int sz3hip_minmax_device(sz3hip_ctx *ctx, const void *d_in, uint64_t 
     return 0;
 }
 
-extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, void *stream) {
-    hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipSetDevice(ctx->device));
-    if (conf->N < 1 || conf->N > 4) return fail(SZ3HIP_EINVAL, "Data dimension higher than 4 is not supported.");
-    uint64_t num = 1;
-    for (int i = 0; i < conf->N; i++) num *= conf->dims[i];
-    if (num != conf->num || num == 0) return fail(SZ3HIP_EINVAL, "conf.num does not match conf.dims");
-    if (num > ctx->max_n) return fail(SZ3HIP_EINVAL, "array of %llu elements exceeds the context capacity %llu",
-                                      (unsigned long long)num, (unsigned long long)ctx->max_n);
-    if (conf->errorBoundMode != SZ3HIP_EB_ABS) return fail(SZ3HIP_EINVAL, "stage1 needs an absolute error bound");
-    const double eb = conf->absErrorBound;
-    if (!(eb > 0) || !isfinite(eb)) return fail(SZ3HIP_EINVAL, "absErrorBound must be positive and finite");
-    const int radius = conf->quantbinCnt / 2;  // api/impl/SZAlgoLorenzoReg.hpp:72
-    if (radius < 2 || radius > 32768) return fail(SZ3HIP_EINVAL, "quantbinCnt must be in [4, 65536]");
+// ---- stage 1, interpolation predictor with explicit parameters (SZ_compress_Interp, api/impl/SZAlgoInterp.hpp:17-30) ----
+static int interp_params_from(const sz3hip_config *conf, double eb, int radius, szk_interp_params &ip) {
+    memset(&ip, 0, sizeof(ip));
+    ip.N = conf->N;
+    for (int i = 0; i < conf->N; i++) ip.dims[i] = conf->dims[i];
+    ip.interp_id = conf->interpAlgo ? 1 : 0;
+    ip.direction = conf->interpDirection;
+    static const int def_anchor[4] = {4096, 128, 32, 16};  // SZAlgoInterp.hpp:20-24
+    ip.anchor_stride = conf->interpAnchorStride < 0 ? (uint64_t)def_anchor[conf->N - 1] : (uint64_t)conf->interpAnchorStride;
+    if (ip.anchor_stride & (ip.anchor_stride - 1)) return fail(SZ3HIP_EINVAL, "Anchor stride should be 0 or 2's exponentials");
+    int nperm = 1;
+    for (int i = 2; i <= conf->N; i++) nperm *= i;
+    if (ip.direction < 0 || ip.direction >= nperm) return fail(SZ3HIP_EINVAL, "interpDirection out of range");
+    ip.alpha = conf->interpAlpha;
+    ip.beta = conf->interpBeta;
+    ip.eb = eb;
+    ip.radius = radius;
+    return 0;
+}
+static void cb_params_from(sz3hip_ctx *ctx, szk_cb_params &cb, uint64_t out_cap) {
+    cb.enc = ctx->d_enc;
+    cb.lens = ctx->d_lens;
+    cb.keys = ctx->d_keys;
+    cb.syms = ctx->d_syms;
+    cb.ifreq = ctx->d_ifreq;
+    cb.pleaf = ctx->d_pleaf;
+    cb.pint = ctx->d_pint;
+    cb.depth = ctx->d_depth;
+    cb.aux2 = ctx->d_aux2;
+    cb.pint2 = ctx->d_pint2;
+    cb.range = ctx->d_range;
+    cb.vout_idx = ctx->d_vout_idx;
+    cb.dout_idx = ctx->d_dout_idx;
+    cb.vout_val = ctx->d_vout_val;
+    cb.dout_val = ctx->d_dout_val;
+    cb.n_vout = ctx->d_counters + 0;
+    cb.n_dout = ctx->d_counters + 1;
+    cb.out_cap = out_cap;
+    cb.t_is_32bit = cb.q_is_32bit = ctx->dtype == SZ3HIP_FLOAT;
+    cb.info = ctx->d_info;
+}
 
-    HIPCHK(hipMemsetAsync(ctx->d_hist, 0, SZH_HIST_BINS * 8, s));
-    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 64, s));
-    ctx->cur_out_cap = std::min<uint64_t>(ctx->out_cap, std::max<uint64_t>(1024, num / 32));
-    if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP || conf->cmprAlgo == SZ3HIP_ALGO_INTERP_LORENZO ||
-        conf->cmprAlgo == SZ3HIP_ALGO_HIP_INTERP) {
-        // multilevel interpolation with the Config's parameters (SZ_compress_Interp, api/impl/SZAlgoInterp.hpp:17-30).
-        // ALGO_INTERP_LORENZO's sampling auto-tuner (SZAlgoInterp.hpp:122-286) is not implemented: its defaults are used.
-        if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
-        szk_interp_params ip;
-        memset(&ip, 0, sizeof(ip));
-        ip.N = conf->N;
-        for (int i = 0; i < conf->N; i++) ip.dims[i] = conf->dims[i];
-        ip.interp_id = conf->interpAlgo ? 1 : 0;
-        ip.direction = conf->interpDirection;
-        static const int def_anchor[4] = {4096, 128, 32, 16};  // SZAlgoInterp.hpp:20-24
-        ip.anchor_stride = conf->interpAnchorStride < 0 ? (uint64_t)def_anchor[conf->N - 1] : (uint64_t)conf->interpAnchorStride;
-        if (ip.anchor_stride & (ip.anchor_stride - 1)) return fail(SZ3HIP_EINVAL, "Anchor stride should be 0 or 2's exponentials");
-        int nperm = 1;
-        for (int i = 2; i <= conf->N; i++) nperm *= i;
-        if (ip.direction < 0 || ip.direction >= nperm) return fail(SZ3HIP_EINVAL, "interpDirection out of range");
-        ip.alpha = conf->interpAlpha;
-        ip.beta = conf->interpBeta;
-        ip.eb = eb;
-        ip.radius = radius;
-        ip.n_vout = ctx->d_counters + 0;
-        ip.vout_idx = ctx->d_vout_idx;
-        ip.vout_val = ctx->d_vout_val;
-        ip.out_cap = ctx->cur_out_cap;
-        prof_begin(ctx, ST_K1, s);
-        int rci = szk_launch_interp_compress(ctx->dtype, &ip, d_in, ctx->d_work, ctx->d_codes, ctx->d_hist, s);
-        prof_end(ctx, ST_K1, s);
-        if (rci) return fail(SZ3HIP_EHIP, "interpolation kernel launch failed (%d)", rci);
-        memset(&ctx->mode, 0, sizeof(ctx->mode));
-        ctx->mode.probe_big = reinterpret_cast<uint32_t *>(ctx->d_counters + 4);
-        szh_header &hh = ctx->proto;
-        memset(&hh, 0, sizeof(hh));
-        hh.magic = SZH_MAGIC;
-        hh.version = SZH_VERSION;
-        hh.dtype = (uint8_t)ctx->dtype;
-        hh.ndim = (uint8_t)conf->N;
-        hh.qbytes = ctx->dtype == SZ3HIP_FLOAT ? 4 : 8;
-        hh.predictor = 1;
-        hh.radius = (uint32_t)radius;
-        for (int i = 0; i < 4; i++) hh.dims[i] = 1;
-        for (int i = 0; i < conf->N; i++) hh.dims[4 - conf->N + i] = conf->dims[i];
-        hh.eb = eb;
-        hh.n = num;
-        hh.chunk_syms = SZH_CHUNK_SYMS;
-        hh.n_chunks = (num + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
-        hh.interp_alpha = ip.alpha;
-        hh.interp_beta = ip.beta;
-        hh.interp_id = (uint32_t)ip.interp_id;
-        hh.interp_dir = (uint32_t)ip.direction;
-        hh.anchor_stride = ip.anchor_stride;
-        ctx->stage1_done = true;
-        ctx->stage2_done = false;
-        return 0;
-    }
-    szk_k1_params p;
+static int stage1_interp(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint64_t num, hipStream_t s) {
+    if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
+    szk_interp_params ip;
+    int rcp = interp_params_from(conf, eb, radius, ip);
+    if (rcp) return rcp;
+    ip.n_vout = ctx->d_counters + 0;
+    ip.vout_idx = ctx->d_vout_idx;
+    ip.vout_val = ctx->d_vout_val;
+    ip.out_cap = ctx->cur_out_cap;
+    prof_begin(ctx, ST_K1, s);
+    int rci = szk_launch_interp_compress(ctx->dtype, &ip, d_in, ctx->d_work, ctx->d_codes, ctx->d_hist, s);
+    prof_end(ctx, ST_K1, s);
+    if (rci) return fail(SZ3HIP_EHIP, "interpolation kernel launch failed (%d)", rci);
+    memset(&ctx->mode, 0, sizeof(ctx->mode));
+    ctx->mode.probe_big = reinterpret_cast<uint32_t *>(ctx->d_counters + 4);
+    szh_header &hh = ctx->proto;
+    memset(&hh, 0, sizeof(hh));
+    hh.magic = SZH_MAGIC;
+    hh.version = SZH_VERSION;
+    hh.dtype = (uint8_t)ctx->dtype;
+    hh.ndim = (uint8_t)conf->N;
+    hh.qbytes = ctx->dtype == SZ3HIP_FLOAT ? 4 : 8;
+    hh.predictor = 1;
+    hh.radius = (uint32_t)radius;
+    for (int i = 0; i < 4; i++) hh.dims[i] = 1;
+    for (int i = 0; i < conf->N; i++) hh.dims[4 - conf->N + i] = conf->dims[i];
+    hh.eb = eb;
+    hh.n = num;
+    hh.chunk_syms = SZH_CHUNK_SYMS;
+    hh.n_chunks = (num + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
+    hh.interp_alpha = ip.alpha;
+    hh.interp_beta = ip.beta;
+    hh.interp_id = (uint32_t)ip.interp_id;
+    hh.interp_dir = (uint32_t)ip.direction;
+    hh.anchor_stride = ip.anchor_stride;
+    ctx->stage1_done = true;
+    ctx->stage2_done = false;
+    return 0;
+}
+
+// ---- stage 1, integer Lorenzo on the prequantised lattice ----
+static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *d_in, double eb, int radius, uint64_t num,
+                      uint64_t out_cap, bool allow_narrow, szk_k1_params &p, hipStream_t s) {
     memset(&p, 0, sizeof(p));
     for (int i = 0; i < 4; i++) p.d[i] = 1;
-    for (int i = 0; i < conf->N; i++) p.d[4 - conf->N + i] = conf->dims[i];
+    for (int i = 0; i < N; i++) p.d[4 - N + i] = dims[i];
     p.lat = szk_make_lattice(eb);
     p.radius = (uint32_t)radius;
-    p.out_cap = ctx->cur_out_cap;  // lists larger than n/32 entries can never pay off: overflow => lossless fallback
+    p.out_cap = out_cap;  // lists larger than n/32 entries can never pay off: overflow => lossless fallback
     p.hist = ctx->d_hist;
     p.hist_partial = ctx->d_hist_partial;
     p.n_vout = ctx->d_counters + 0;
@@ -625,16 +648,19 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     p.dout_idx = ctx->d_dout_idx;
     p.vout_val = ctx->d_vout_val;
     p.dout_val = ctx->d_dout_val;
-    p.mode.probe_big = reinterpret_cast<uint32_t *>(ctx->d_counters + 4);  // zeroed with the counters above
+    p.mode.probe_big = reinterpret_cast<uint32_t *>(ctx->d_counters + 4);  // zeroed with the counters
     p.mode.n_total = num;
     p.mode.n_samples = (num / SZK_PROBE_STRIDE) * 64 + std::min<uint64_t>(64, num % SZK_PROBE_STRIDE);
-    p.mode.allow = radius >= 128;
+    p.mode.allow = allow_narrow && radius >= 128;
+    return szk_launch_k1(ctx->dtype, N, d_in, ctx->d_codes, &p, s);
+}
+static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint64_t num, hipStream_t s) {
+    szk_k1_params p;
     prof_begin(ctx, ST_K1, s);
-    int rc = szk_launch_k1(ctx->dtype, conf->N, d_in, ctx->d_codes, &p, s);
+    int rc = lorenzo_k1(ctx, conf->N, conf->dims, d_in, eb, radius, num, ctx->cur_out_cap, true, p, s);
     ctx->mode = p.mode;
     prof_end(ctx, ST_K1, s);
     if (rc) return fail(SZ3HIP_EHIP, "lorenzo_quant kernel launch failed (%d)", rc);
-
     szh_header &h = ctx->proto;
     memset(&h, 0, sizeof(h));
     h.magic = SZH_MAGIC;
@@ -653,6 +679,286 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     return 0;
 }
 
+// ---- ALGO_INTERP_LORENZO: the sampling auto-tuner (SZ_compress_Interp_lorenzo, api/impl/SZAlgoInterp.hpp:122-286) ----
+// Same sampling geometry, trial list and decision rules as the reference. The six interpolation trials (and, in 1-D,
+// the Lorenzo trial) run on the GPU over the batch of sampled blocks. What differs is the size estimate of a trial:
+// the reference Huffman-codes and zstd-compresses every trial on the CPU; here a trial's size is priced on the device
+// as   optimal-Huffman bits / 8  +  0.45 x serialised tree bytes  +  unpredictable values  +  80
+// (0.45 = measured zstd gain on the reference's tree bytes; the bit stream itself is taken as incompressible).
+// Decisions agree with the reference in most cases and can differ near its 2 % thresholds or at ratios > 30 where
+// zstd matters; any decision yields a valid stream.
+static int tuner_reserve(sz3hip_ctx *ctx, size_t flags, size_t starts, size_t samples) {
+    if (ctx->flags_cap < flags) {
+        if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+        ctx->d_flags = nullptr;
+        HIPCHK(hipMalloc(&ctx->d_flags, flags));
+        ctx->flags_cap = flags;
+    }
+    if (ctx->starts_cap < starts) {
+        if (ctx->d_starts) (void)hipFree(ctx->d_starts);
+        ctx->d_starts = nullptr;
+        HIPCHK(hipMalloc(&ctx->d_starts, starts));
+        ctx->starts_cap = starts;
+    }
+    if (ctx->samples_cap < samples) {
+        if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+        ctx->d_samples = nullptr;
+        HIPCHK(hipMalloc(&ctx->d_samples, samples));
+        ctx->samples_cap = samples;
+    }
+    if (!ctx->d_trial) HIPCHK(hipMalloc(&ctx->d_trial, 8 * 4 * 8));
+    if (!ctx->h_trial) HIPCHK(hipHostMalloc((void **)&ctx->h_trial, 8 * 4 * 8));
+    if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
+    return 0;
+}
+static double trial_bytes(const uint64_t *r, size_t tsz) {  // r: bits, symbols, unpredictables, delta outliers
+    const double nc = r[1] ? 2.0 * (double)r[1] - 1.0 : 0.0;
+    const double w = nc <= 256 ? 1 : (nc <= 65536 ? 2 : 4);
+    const double tree = 13.0 + nc * (2 * w + 5);  // HuffmanEncoder::save: [i32][i32][i32][u8] L R C t (HuffmanEncoder.hpp:108-125)
+    return std::ceil((double)r[0] / 8.0) + 0.45 * tree + (double)r[2] * (double)tsz + (double)r[3] * 12.0 + 80.0;
+}
+static int tuner_interp_trial(sz3hip_ctx *ctx, const sz3hip_config &tc, double eb, int radius, uint32_t nb, int slot, hipStream_t s) {
+    HIPCHK(hipMemsetAsync(ctx->d_hist, 0, SZH_HIST_BINS * 8, s));
+    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 64, s));
+    HIPCHK(hipMemsetAsync(ctx->d_trial + 4 * slot, 0, 32, s));
+    szk_interp_params ip;
+    int rc = interp_params_from(&tc, eb, radius, ip);
+    if (rc) return rc;
+    ip.n_vout = ctx->d_counters + 0;
+    ip.vout_idx = ctx->d_vout_idx;
+    ip.vout_val = ctx->d_vout_val;
+    ip.out_cap = 0;  // count only
+    rc = szk_launch_interp_trial(ctx->dtype, &ip, ctx->d_samples, ctx->d_work, ctx->d_codes, nb, ctx->d_hist, s);
+    if (rc) return fail(SZ3HIP_EHIP, "tuner: interpolation trial launch failed (%d)", rc);
+    szk_cb_params cb;
+    cb_params_from(ctx, cb, 0);
+    rc = szk_launch_codebook(ctx->d_hist, &cb, s);
+    if (rc) return fail(SZ3HIP_EHIP, "tuner: codebook launch failed (%d)", rc);
+    rc = szk_launch_code_cost(ctx->d_hist, ctx->d_lens, ctx->d_info, ctx->d_counters, ctx->d_trial + 4 * slot, s);
+    if (rc) return fail(SZ3HIP_EHIP, "tuner: cost kernel launch failed (%d)", rc);
+    return 0;
+}
+static int tuner_fetch(sz3hip_ctx *ctx, hipStream_t s) {
+    HIPCHK(hipMemcpyAsync(ctx->h_trial, ctx->d_trial, 8 * 4 * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+// fills `conf` like the reference does before its final compress call: cmprAlgo becomes ALGO_INTERP (interpAlgo,
+// interpDirection, interpAlpha, interpBeta tuned) or ALGO_LORENZO_REG (1-D only)
+static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void *d_in, double eb, int radius, hipStream_t s) {
+    const int N = conf.N;
+    const size_t tsz = ctx->dtype == SZ3HIP_FLOAT ? 4 : 8;
+    sz3hip_tuner_report &rep = ctx->tuner;
+    memset(&rep, 0, sizeof(rep));
+    rep.use_interp = 1;
+    static const int def_anchor[4] = {4096, 128, 32, 16};
+    if (conf.interpAnchorStride < 0) conf.interpAnchorStride = def_anchor[N - 1];
+    const double rate = 0.005;                               // SZAlgoInterp.hpp:133-135
+    uint64_t sbs = (uint64_t)def_anchor[N - 1];              // sampleBlock_Sizes :136-138
+    uint64_t shortest = conf.dims[0];
+    for (int i = 0; i < N; i++) shortest = std::min<uint64_t>(shortest, conf.dims[i]);
+    while (sbs >= shortest) sbs /= 2;                        // :144-147
+    while (sbs >= 16 && (std::pow((double)(sbs + 1), N) / (double)conf.num) > 1.5 * rate) sbs /= 2;
+    if (sbs < 8) sbs = 8;
+    bool to_tune = std::pow((double)(sbs + 1), N) <= 0.05 * (double)conf.num;
+    for (int i = 0; i < N; i++)
+        if (conf.dims[i] < sbs) to_tune = false;
+    rep.sample_block_size = sbs;
+    auto fall_back = [&]() {
+        conf.cmprAlgo = SZ3HIP_ALGO_INTERP;
+        rep.interpAlgo = conf.interpAlgo;
+        rep.interpDirection = conf.interpDirection;
+        rep.interpAlpha = conf.interpAlpha;
+        rep.interpBeta = conf.interpBeta;
+        return 0;
+    };
+    if (!to_tune) return fall_back();
+    const uint64_t per = (uint64_t)std::pow((double)(sbs + 1), N);
+    // profiling_block: candidate origins whose strided samples are not constant within eb
+    uint64_t cand = 1;
+    for (int i = 0; i < N; i++) cand *= (conf.dims[i] - sbs + sbs - 1) / sbs;
+    int rc = tuner_reserve(ctx, std::max<uint64_t>(cand, 1), 4096 * 32, 0);
+    if (rc) return rc;
+    uint64_t total = 0;
+    rc = szk_launch_profile_blocks(ctx->dtype, d_in, N, conf.dims, sbs, sbs / 4, eb, ctx->d_flags, &total, s);
+    if (rc) return fail(SZ3HIP_EHIP, "tuner: profiling launch failed (%d)", rc);
+    std::vector<uint8_t> flags(total);
+    if (total) {
+        HIPCHK(hipMemcpyAsync(flags.data(), ctx->d_flags, total, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    uint64_t cnt[4] = {1, 1, 1, 1};
+    for (int i = 0; i < N; i++) cnt[i] = (conf.dims[i] - sbs + sbs - 1) / sbs;
+    std::vector<uint64_t> filtered;  // linear candidate indices, lexicographic
+    for (uint64_t t = 0; t < total; t++)
+        if (flags[t]) filtered.push_back(t);
+    const uint64_t nf = filtered.size();
+    const bool profiling = (double)(nf * per) >= 0.5 * rate * (double)conf.num;  // :169
+    // sampleBlocks (utils/Sample.hpp:221-289)
+    uint64_t totalblock = 1;
+    for (int i = 0; i < N; i++) totalblock *= (uint64_t)(int)((conf.dims[i] - 1) / sbs);
+    std::vector<uint64_t> chosen;
+    if (profiling) {
+        uint64_t stride = (uint64_t)((double)nf / ((double)totalblock * rate));
+        if (stride == 0) stride = 1;
+        for (uint64_t i = 0; i < nf; i += stride) chosen.push_back(filtered[i]);
+    } else {
+        uint64_t stride = (uint64_t)(1.0 / rate);
+        if (stride == 0) stride = 1;
+        for (uint64_t idx = 0; idx < total; idx += stride) chosen.push_back(idx);
+    }
+    const uint64_t nb = chosen.size();
+    rep.n_filtered = nf;
+    rep.profiling = profiling;
+    rep.n_blocks = nb;
+    const uint64_t sampling_num = nb * per;
+    if (sampling_num == 0 || (double)sampling_num >= (double)conf.num * 0.2) return fall_back();  // :176-179
+    if (nb > 0x7FFFFFFFull) return fall_back();
+    std::vector<uint64_t> starts(nb * 4, 0);
+    for (uint64_t b = 0; b < nb; b++) {
+        uint64_t r = chosen[b];
+        for (int j = N - 1; j >= 0; j--) {
+            starts[b * 4 + j] = (r % cnt[j]) * sbs;
+            r /= cnt[j];
+        }
+    }
+    rc = tuner_reserve(ctx, 0, nb * 32, sampling_num * tsz);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->d_starts, starts.data(), nb * 32, hipMemcpyHostToDevice, s));
+    rc = szk_launch_gather_blocks(ctx->dtype, d_in, N, conf.dims, sbs + 1, ctx->d_starts, (uint32_t)nb, ctx->d_samples, s);
+    if (rc) return fail(SZ3HIP_EHIP, "tuner: gather launch failed (%d)", rc);
+    HIPCHK(hipStreamSynchronize(s));  // `starts` must outlive the copy
+
+    const double raw = (double)sampling_num * (double)tsz;
+    double best_interp = 0, best_lorenzo = 0;
+    sz3hip_config lorenzo_config = conf;
+    conf.interpDirection = 0;  // :186-189
+    conf.interpAlpha = 1.25;
+    conf.interpBeta = 2.0;
+    sz3hip_config tc = conf;
+    tc.N = N;
+    for (int i = 0; i < N; i++) tc.dims[i] = sbs + 1;
+    tc.num = per;
+    // linear and cubic
+    for (int op = 0; op < 2; op++) {
+        tc.interpAlgo = (uint8_t)op;
+        rc = tuner_interp_trial(ctx, tc, eb, radius, (uint32_t)nb, op, s);
+        if (rc) return rc;
+    }
+    rc = tuner_fetch(ctx, s);
+    if (rc) return rc;
+    for (int op = 0; op < 2; op++) {
+        rep.est_bytes[op] = trial_bytes(ctx->h_trial + 4 * op, tsz);
+        const double ratio = raw / rep.est_bytes[op];
+        if (ratio > best_interp) {
+            best_interp = ratio;
+            conf.interpAlgo = (uint8_t)op;
+        }
+    }
+    // reversed dimension order
+    tc.interpAlgo = conf.interpAlgo;
+    int fact = 1;
+    for (int i = 2; i <= N; i++) fact *= i;
+    tc.interpDirection = (uint8_t)(fact - 1);
+    rc = tuner_interp_trial(ctx, tc, eb, radius, (uint32_t)nb, 2, s);
+    if (rc) return rc;
+    rc = tuner_fetch(ctx, s);
+    if (rc) return rc;
+    rep.est_bytes[2] = trial_bytes(ctx->h_trial + 8, tsz);
+    if (raw / rep.est_bytes[2] > best_interp * 1.02) {
+        best_interp = raw / rep.est_bytes[2];
+        conf.interpDirection = tc.interpDirection;
+    }
+    tc.interpDirection = conf.interpDirection;
+    // (alpha, beta) pairs
+    static const double alphas[3] = {1.0, 1.5, 2.0}, betas[3] = {1.0, 2.5, 3.0};
+    for (int i = 0; i < 3; i++) {
+        tc.interpAlpha = alphas[i];
+        tc.interpBeta = betas[i];
+        rc = tuner_interp_trial(ctx, tc, eb, radius, (uint32_t)nb, 3 + i, s);
+        if (rc) return rc;
+    }
+    rc = tuner_fetch(ctx, s);
+    if (rc) return rc;
+    for (int i = 0; i < 3; i++) {
+        rep.est_bytes[3 + i] = trial_bytes(ctx->h_trial + 4 * (3 + i), tsz);
+        const double ratio = raw / rep.est_bytes[3 + i];
+        if (ratio > best_interp * 1.02) {
+            best_interp = ratio;
+            conf.interpAlpha = alphas[i];
+            conf.interpBeta = betas[i];
+        }
+    }
+    if (N == 1 && best_interp < 50) {  // :232-247 — here: this library's own Lorenzo coder over the concatenated samples
+        HIPCHK(hipMemsetAsync(ctx->d_hist, 0, SZH_HIST_BINS * 8, s));
+        HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 64, s));
+        HIPCHK(hipMemsetAsync(ctx->d_trial + 24, 0, 32, s));
+        szk_k1_params p;
+        const uint64_t d1[1] = {sampling_num};
+        rc = lorenzo_k1(ctx, 1, d1, ctx->d_samples, eb, radius, sampling_num, 0, false, p, s);
+        if (rc) return fail(SZ3HIP_EHIP, "tuner: Lorenzo trial launch failed (%d)", rc);
+        szk_cb_params cb;
+        cb_params_from(ctx, cb, 0);
+        rc = szk_launch_codebook(ctx->d_hist, &cb, s);
+        if (rc) return fail(SZ3HIP_EHIP, "tuner: codebook launch failed (%d)", rc);
+        rc = szk_launch_code_cost(ctx->d_hist, ctx->d_lens, ctx->d_info, ctx->d_counters, ctx->d_trial + 24, s);
+        if (rc) return fail(SZ3HIP_EHIP, "tuner: cost kernel launch failed (%d)", rc);
+        rc = tuner_fetch(ctx, s);
+        if (rc) return rc;
+        rep.est_bytes[6] = trial_bytes(ctx->h_trial + 24, tsz);
+        best_lorenzo = raw / rep.est_bytes[6];
+    }
+    rep.ran = 1;
+    const bool use_interp = !(best_lorenzo >= best_interp * 1.1 && best_lorenzo < 50 && best_interp < 50);  // :249-250
+    rep.use_interp = use_interp;
+    if (use_interp) {
+        conf.cmprAlgo = SZ3HIP_ALGO_INTERP;
+    } else {
+        lorenzo_config.cmprAlgo = SZ3HIP_ALGO_LORENZO_REG;
+        conf = lorenzo_config;
+    }
+    rep.interpAlgo = conf.interpAlgo;
+    rep.interpDirection = conf.interpDirection;
+    rep.interpAlpha = conf.interpAlpha;
+    rep.interpBeta = conf.interpBeta;
+    return 0;
+}
+extern "C" int sz3hip_get_tuner_report(sz3hip_ctx *ctx, sz3hip_tuner_report *rep) {
+    *rep = ctx->tuner;
+    return 0;
+}
+
+extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf_in, const void *d_in, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    sz3hip_config conf_copy = *conf_in;
+    sz3hip_config *conf = &conf_copy;
+    if (conf->N < 1 || conf->N > 4) return fail(SZ3HIP_EINVAL, "Data dimension higher than 4 is not supported.");
+    uint64_t num = 1;
+    for (int i = 0; i < conf->N; i++) num *= conf->dims[i];
+    if (num != conf->num || num == 0) return fail(SZ3HIP_EINVAL, "conf.num does not match conf.dims");
+    if (num > ctx->max_n) return fail(SZ3HIP_EINVAL, "array of %llu elements exceeds the context capacity %llu",
+                                      (unsigned long long)num, (unsigned long long)ctx->max_n);
+    if (conf->errorBoundMode != SZ3HIP_EB_ABS) return fail(SZ3HIP_EINVAL, "stage1 needs an absolute error bound");
+    const double eb = conf->absErrorBound;
+    if (!(eb > 0) || !isfinite(eb)) return fail(SZ3HIP_EINVAL, "absErrorBound must be positive and finite");
+    const int radius = conf->quantbinCnt / 2;  // api/impl/SZAlgoLorenzoReg.hpp:72
+    if (radius < 2 || radius > 32768) return fail(SZ3HIP_EINVAL, "quantbinCnt must be in [4, 65536]");
+    ctx->cur_out_cap = std::min<uint64_t>(ctx->out_cap, std::max<uint64_t>(1024, num / 32));
+    memset(&ctx->tuner, 0, sizeof(ctx->tuner));
+    if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP_LORENZO) {  // the reference's default: sampling auto-tuner, then one of the two paths
+        prof_begin(ctx, ST_TUNER, s);
+        int rct = tune_interp_lorenzo(ctx, *conf, d_in, eb, radius, s);
+        prof_end(ctx, ST_TUNER, s);
+        if (rct) return rct;
+    }
+    HIPCHK(hipMemsetAsync(ctx->d_hist, 0, SZH_HIST_BINS * 8, s));
+    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 64, s));
+    if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP || conf->cmprAlgo == SZ3HIP_ALGO_HIP_INTERP)
+        return stage1_interp(ctx, conf, d_in, eb, radius, num, s);
+    return stage1_lorenzo(ctx, conf, d_in, eb, radius, num, s);
+}
+
 extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t cap, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
@@ -661,26 +967,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     if (cap < payload_bound_n(n, ctx->out_cap))
         return fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
     szk_cb_params cb;
-    cb.enc = ctx->d_enc;
-    cb.lens = ctx->d_lens;
-    cb.keys = ctx->d_keys;
-    cb.syms = ctx->d_syms;
-    cb.ifreq = ctx->d_ifreq;
-    cb.pleaf = ctx->d_pleaf;
-    cb.pint = ctx->d_pint;
-    cb.depth = ctx->d_depth;
-    cb.aux2 = ctx->d_aux2;
-    cb.pint2 = ctx->d_pint2;
-    cb.range = ctx->d_range;
-    cb.vout_idx = ctx->d_vout_idx;
-    cb.dout_idx = ctx->d_dout_idx;
-    cb.vout_val = ctx->d_vout_val;
-    cb.dout_val = ctx->d_dout_val;
-    cb.n_vout = ctx->d_counters + 0;
-    cb.n_dout = ctx->d_counters + 1;
-    cb.out_cap = ctx->cur_out_cap;
-    cb.t_is_32bit = cb.q_is_32bit = ctx->dtype == SZ3HIP_FLOAT;
-    cb.info = ctx->d_info;
+    cb_params_from(ctx, cb, ctx->cur_out_cap);
     prof_begin(ctx, ST_CODEBOOK, s);
     int rc = szk_launch_codebook(ctx->d_hist, &cb, s);
     if (rc) return fail(SZ3HIP_EHIP, "codebook kernel launch failed (%d)", rc);

@@ -71,6 +71,9 @@ template <typename T, bool DEC>
 __global__ __launch_bounds__(256) void k_interp_pass(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= p.total) return;
+    const uint64_t boff = (uint64_t)blockIdx.y * p.batch_stride;  // independent arrays of one batch (the tuner's sample blocks)
+    w += boff;
+    codes += boff;
     uint64_t r = t, idx = 0, cd = 0;
 #pragma unroll
     for (int j = 3; j >= 0; j--) {
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void k_interp_pass(T *__restrict__ w, uint16_t
         } else {  // unpredictable: keep the raw value (LinearQuantizer "unpred")
             const unsigned long long pos = atomicAdd((unsigned long long *)p.n_vout, 1ull);
             if (pos < p.out_cap) {
-                p.vout_idx[pos] = idx;
+                p.vout_idx[pos] = idx + boff;
                 ((T *)p.vout_val)[pos] = v;
             }
         }
@@ -146,6 +149,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_interp_anchors(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= p.total) return;
+    const uint64_t boff = (uint64_t)blockIdx.y * p.batch_stride;
+    w += boff;
+    codes += boff;
     uint64_t r = t, idx = 0;
 #pragma unroll
     for (int j = 3; j >= 0; j--) {
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(256) void k_interp_anchors(T *__restrict__ w, uint1
     if (!code) {
         const unsigned long long pos = atomicAdd((unsigned long long *)p.n_vout, 1ull);
         if (pos < p.out_cap) {
-            p.vout_idx[pos] = idx;
+            p.vout_idx[pos] = idx + boff;
             ((T *)p.vout_val)[pos] = v;
         }
     }
@@ -247,7 +253,7 @@ static void nth_permutation(int N, int id, int *perm) {  // lexicographic order 
 }
 
 template <typename T, bool DEC>
-static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStream_t s) {
+static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStream_t s, uint32_t nbatch = 1) {
     const int N = ip.N;
     szk_interp_pass p;
     memset(&p, 0, sizeof(p));
@@ -259,6 +265,7 @@ static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStr
     }
     p.off[N - 1] = 1;
     for (int i = N - 2; i >= 0; i--) p.off[i] = p.off[i + 1] * p.dims[i + 1];
+    p.batch_stride = nbatch > 1 ? num : 0;
     p.radius = ip.radius;
     p.interp_id = ip.interp_id;
     p.old_api = N <= 2;
@@ -297,7 +304,7 @@ static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStr
             p.subpass = 1;
             p.eb = ip.eb;
             p.eb_recip = 1.0 / ip.eb;
-            hipLaunchKernelGGL((k_interp_anchors<T>), dim3(1), dim3(256), 0, s, w, codes, p);
+            hipLaunchKernelGGL((k_interp_anchors<T>), dim3(1, nbatch), dim3(256), 0, s, w, codes, p);
         }
     } else {
         if (!DEC) {
@@ -311,7 +318,7 @@ static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStr
             p.subpass = 0;
             p.eb = ip.eb;
             p.eb_recip = 1.0 / ip.eb;
-            hipLaunchKernelGGL((k_interp_anchors<T>), dim3((uint32_t)((p.total + 255) / 256)), dim3(256), 0, s, w, codes, p);
+            hipLaunchKernelGGL((k_interp_anchors<T>), dim3((uint32_t)((p.total + 255) / 256), nbatch), dim3(256), 0, s, w, codes, p);
         }
         interp_level--;
     }
@@ -352,10 +359,10 @@ static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStr
             const uint64_t nb = (p.total + 255) / 256;
             if (nb > 0x7FFFFFFFull) return -1;
             p.subpass = 0;
-            hipLaunchKernelGGL((k_interp_pass<T, DEC>), dim3((uint32_t)nb), dim3(256), 0, s, w, codes, p);
+            hipLaunchKernelGGL((k_interp_pass<T, DEC>), dim3((uint32_t)nb, nbatch), dim3(256), 0, s, w, codes, p);
             if (!p.old_api && p.interp_id == 0) {
                 p.subpass = 1;
-                hipLaunchKernelGGL((k_interp_pass<T, DEC>), dim3((uint32_t)nb), dim3(256), 0, s, w, codes, p);
+                hipLaunchKernelGGL((k_interp_pass<T, DEC>), dim3((uint32_t)nb, nbatch), dim3(256), 0, s, w, codes, p);
             }
         }
     }
@@ -388,4 +395,134 @@ int szk_launch_interp_decompress(int dtype, const szk_interp_params *ip, const u
         else hipLaunchKernelGGL((k_scatter_raw<double>), dim3(g), dim3(256), 0, s, payload, vout_idx_off, vout_val_off, n_vout, num, (double *)d_out);
     }
     return dtype == 0 ? run_interp<float, true>(*ip, (float *)d_out, codes, s) : run_interp<double, true>(*ip, (double *)d_out, codes, s);
+}
+
+// ---- ALGO_INTERP_LORENZO tuner: device side (SZ_compress_Interp_lorenzo, api/impl/SZAlgoInterp.hpp:122-286) ---------
+// profiling_block (utils/Sample.hpp:9-136): one thread per candidate block origin (multiples of bs below dim - bs);
+// flags the blocks whose strided samples span more than abseb (same min / else-if-max walk as the reference)
+struct szk_prof_params {
+    int N;
+    uint64_t off[4], cnt[4], total, bs, stride;
+    double abseb;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_profile_blocks(const T *__restrict__ data, szk_prof_params p, uint8_t *__restrict__ flags) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.total) return;
+    uint64_t r = t, start = 0;
+    for (int j = p.N - 1; j >= 0; j--) {
+        start += (r % p.cnt[j]) * p.bs * p.off[j];
+        r /= p.cnt[j];
+    }
+    T mn = data[start], mx = mn;
+    uint64_t k[4] = {0, 0, 0, 0};
+    for (;;) {
+        uint64_t idx = start;
+        for (int j = 0; j < p.N; j++) idx += k[j] * p.off[j];
+        const T v = data[idx];
+        if (v < mn) mn = v;
+        else if (v > mx) mx = v;
+        int j = p.N - 1;
+        for (; j >= 0; j--) {
+            k[j] += p.stride;
+            if (k[j] <= p.bs) break;
+            k[j] = 0;
+        }
+        if (j < 0) break;
+    }
+    flags[t] = (mx - mn > p.abseb) ? 1 : 0;
+}
+// sample_blocks (utils/Sample.hpp:138-219): copy the edge^N block at starts[b] into the b-th slot of the batch
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_blocks(const T *__restrict__ data, szk_prof_params p, uint64_t edge, uint64_t per,
+                                                       const uint64_t *__restrict__ starts, T *__restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= per) return;
+    const uint64_t *st = starts + (uint64_t)blockIdx.y * 4;
+    uint64_t r = t, idx = 0;
+    for (int j = p.N - 1; j >= 0; j--) {
+        idx += (st[j] + r % edge) * p.off[j];
+        r /= edge;
+    }
+    out[(uint64_t)blockIdx.y * per + t] = data[idx];
+}
+// sum over the alphabet of hist[s] * len[s] (bits of the Huffman-coded trial) -> res[0]
+__global__ __launch_bounds__(256) void k_code_cost(const uint64_t *__restrict__ hist, const uint8_t *__restrict__ lens,
+                                                   const szk_cb_info *__restrict__ info, const uint64_t *__restrict__ counters,
+                                                   unsigned long long *res) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {  // res[1] = symbols of the alphabet, res[2] = unpredictable values, res[3] = delta outliers
+        res[1] = info->n_symbols;
+        res[2] = counters[0];
+        res[3] = counters[1];
+    }
+    unsigned long long v = hist[i] * (unsigned long long)lens[i];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(res, v);
+}
+
+int szk_launch_profile_blocks(int dtype, const void *d_in, int N, const uint64_t *dims, uint64_t bs, uint64_t stride, double abseb,
+                              uint8_t *d_flags, uint64_t *total_out, hipStream_t s) {
+    szk_prof_params p;
+    memset(&p, 0, sizeof(p));
+    p.N = N;
+    p.off[N - 1] = 1;
+    for (int i = N - 2; i >= 0; i--) p.off[i] = p.off[i + 1] * dims[i + 1];
+    p.total = 1;
+    for (int i = 0; i < N; i++) {
+        if (dims[i] < bs) {
+            *total_out = 0;
+            return 0;
+        }
+        p.cnt[i] = (dims[i] - bs + bs - 1) / bs;  // origins 0, bs, 2 bs, ... strictly below dim - bs
+        p.total *= p.cnt[i];
+    }
+    p.bs = bs;
+    p.stride = stride ? stride : bs;
+    p.abseb = abseb;
+    *total_out = p.total;
+    if (p.total == 0) return 0;
+    const uint32_t g = (uint32_t)((p.total + 255) / 256);
+    if (dtype == 0) hipLaunchKernelGGL((k_profile_blocks<float>), dim3(g), dim3(256), 0, s, (const float *)d_in, p, d_flags);
+    else hipLaunchKernelGGL((k_profile_blocks<double>), dim3(g), dim3(256), 0, s, (const double *)d_in, p, d_flags);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+int szk_launch_gather_blocks(int dtype, const void *d_in, int N, const uint64_t *dims, uint64_t edge, const uint64_t *d_starts,
+                             uint32_t nblocks, void *d_out, hipStream_t s) {
+    szk_prof_params p;
+    memset(&p, 0, sizeof(p));
+    p.N = N;
+    p.off[N - 1] = 1;
+    for (int i = N - 2; i >= 0; i--) p.off[i] = p.off[i + 1] * dims[i + 1];
+    uint64_t per = 1;
+    for (int i = 0; i < N; i++) per *= edge;
+    const dim3 g((uint32_t)((per + 255) / 256), nblocks);
+    if (dtype == 0) hipLaunchKernelGGL((k_gather_blocks<float>), g, dim3(256), 0, s, (const float *)d_in, p, edge, per, d_starts, (float *)d_out);
+    else hipLaunchKernelGGL((k_gather_blocks<double>), g, dim3(256), 0, s, (const double *)d_in, p, edge, per, d_starts, (double *)d_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+// one tuner trial (interp_compress_test, SZAlgoInterp.hpp:42-78, decomposition part): nblocks independent arrays of
+// ip->dims each, interpolated in place in d_work (a copy of the samples), codes + histogram out; unpredictables are
+// only counted (ip->out_cap = 0)
+int szk_launch_interp_trial(int dtype, const szk_interp_params *ip, const void *d_samples, void *d_work, uint16_t *codes,
+                            uint32_t nblocks, uint64_t *hist, hipStream_t s) {
+    uint64_t per = 1;
+    for (int i = 0; i < ip->N; i++) per *= ip->dims[i];
+    const size_t tsz = dtype == 0 ? 4 : 8;
+    hipError_t e = hipMemcpyAsync(d_work, d_samples, per * nblocks * tsz, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    int rc = dtype == 0 ? run_interp<float, false>(*ip, (float *)d_work, codes, s, nblocks)
+                        : run_interp<double, false>(*ip, (double *)d_work, codes, s, nblocks);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_hist_codes, dim3(64), dim3(256), 0, s, codes, per * nblocks, ip->radius, hist);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+int szk_launch_code_cost(const uint64_t *hist, const uint8_t *lens, const szk_cb_info *info, const uint64_t *counters, uint64_t *d_res,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(k_code_cost, dim3(SZH_HIST_BINS / 256), dim3(256), 0, s, hist, lens, info, counters, (unsigned long long *)d_res);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
 }

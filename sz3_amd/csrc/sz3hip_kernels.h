@@ -126,6 +126,7 @@ struct szk_interp_pass {
     int N, dir, interp_id, old_api, subpass, radius;
     uint64_t dims[4], off[4], start[4], step[4], cnt[4];
     uint64_t total, s, bsz;
+    uint64_t batch_stride;  // elements between the independent arrays of a batch (grid.y), 0 = one array
     double eb, eb_recip;
     uint64_t *n_vout, *vout_idx;
     void *vout_val;
@@ -135,6 +136,15 @@ int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const voi
                                uint64_t *hist, hipStream_t s);
 int szk_launch_interp_decompress(int dtype, const szk_interp_params *ip, const uint8_t *payload, uint64_t vout_idx_off,
                                  uint64_t vout_val_off, uint64_t n_vout, uint16_t *codes, void *d_out, hipStream_t s);
+
+int szk_launch_profile_blocks(int dtype, const void *d_in, int N, const uint64_t *dims, uint64_t bs, uint64_t stride, double abseb,
+                              uint8_t *d_flags, uint64_t *total_out, hipStream_t s);
+int szk_launch_gather_blocks(int dtype, const void *d_in, int N, const uint64_t *dims, uint64_t edge, const uint64_t *d_starts,
+                             uint32_t nblocks, void *d_out, hipStream_t s);
+int szk_launch_interp_trial(int dtype, const szk_interp_params *ip, const void *d_samples, void *d_work, uint16_t *codes,
+                            uint32_t nblocks, uint64_t *hist, hipStream_t s);
+int szk_launch_code_cost(const uint64_t *hist, const uint8_t *lens, const szk_cb_info *info, const uint64_t *counters, uint64_t *d_res,
+                         hipStream_t s);
 
 int szk_launch_minmax(int dtype, const void *d_in, uint64_t n, double *d_partial /*[2*1024]*/, double *d_out /*[2]*/, hipStream_t s);
 int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, szk_k1_params *p, hipStream_t s);

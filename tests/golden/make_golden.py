@@ -31,7 +31,26 @@ CASES = [
     ("f32_4d_12x20x20x20_rel_1e-3", lambda: field4d((12, 20, 20, 20)), dict(eb_mode=EB_REL, rel_eb=1e-3, regression=True)),
     ("f32_1d_65536_lorenzo_reg_1e-3", lambda: field1d(65536), dict(abs_eb=1e-3, regression=True)),
     ("f32_2d_100x100_lorenzo_1e-2", lambda: field2d((100, 100)), dict(abs_eb=1e-2)),
+    # interpolation predictor with explicit parameters (ALGO_INTERP) ...
+    ("f32_3d_33x47x50_interp_cubic_1e-3", lambda: field3d((33, 47, 50)), dict(algo=ALGO_INTERP, abs_eb=1e-3, interp_algo=1)),
+    ("f32_3d_34x66x36_interp_linear_dir5_1e-2", lambda: field3d((34, 66, 36)), dict(algo=ALGO_INTERP, abs_eb=1e-2, interp_algo=0, interpDirection=5)),
+    ("f64_3d_20x30x37_interp_cubic_1e-6", lambda: field3d((20, 30, 37), np.float64, sigma=2e-6), dict(algo=ALGO_INTERP, abs_eb=1e-6, interp_algo=1)),
+    ("f32_2d_123x257_interp_cubic_a1.5b3", lambda: field2d((123, 257)), dict(algo=ALGO_INTERP, abs_eb=1e-3, interp_algo=1, interpAlpha=1.5, interpBeta=3.0)),
+    ("f32_1d_70001_interp_cubic_1e-3", lambda: field1d(70001), dict(algo=ALGO_INTERP, abs_eb=1e-3, interp_algo=1)),
+    # ... and the default algorithm with its sampling auto-tuner (ALGO_INTERP_LORENZO)
+    ("f32_3d_96c_tuned_1e-3", lambda: field3d((96, 96, 96)), dict(algo=ALGO_INTERP_LORENZO, abs_eb=1e-3, regression=True)),
+    ("f32_3d_70x101x130_tuned_1e-2", lambda: field3d((70, 101, 130)), dict(algo=ALGO_INTERP_LORENZO, abs_eb=1e-2, regression=True)),
+    ("f64_3d_80x90x100_tuned_1e-6", lambda: field3d((80, 90, 100), np.float64, sigma=2e-6), dict(algo=ALGO_INTERP_LORENZO, abs_eb=1e-6, regression=True)),
+    ("f32_2d_600x700_tuned_1e-3", lambda: field2d((600, 700)), dict(algo=ALGO_INTERP_LORENZO, abs_eb=1e-3, regression=True)),
+    ("f32_1d_2^20_tuned_1e-3", lambda: field1d(1 << 20), dict(algo=ALGO_INTERP_LORENZO, abs_eb=1e-3, regression=True)),
+    ("f32_4d_12x40x40x40_tuned_1e-3", lambda: field4d((12, 40, 40, 40)), dict(algo=ALGO_INTERP_LORENZO, abs_eb=1e-3, regression=True)),
+    ("f32_3d_20x21x22_tuner_skipped_1e-3", lambda: field3d((20, 21, 22)), dict(algo=ALGO_INTERP_LORENZO, abs_eb=1e-3, regression=True)),
 ]
+
+
+def case_config(shape, kw):
+    kw = dict(kw)
+    return make_config(shape, algo=kw.pop("algo", ALGO_LORENZO_REG), **kw)
 
 
 def payload_sha(blob):
@@ -51,7 +70,7 @@ def main():
     out = {}
     for name, gen, kw in CASES:
         a = gen()
-        conf = make_config(a.shape, algo=ALGO_LORENZO_REG, **kw)
+        conf = case_config(a.shape, kw)
         blob = ref_compress(a, conf)
         dec = ref_decompress(blob, a.dtype, a.shape)
         raw_sha, trailer_hex = payload_sha(blob)

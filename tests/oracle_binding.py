@@ -42,6 +42,13 @@ class SzoStats(C.Structure):
     ]
 
 
+class SzoTunerReport(C.Structure):
+    _fields_ = [("sample_block_size", C.c_uint64), ("n_filtered", C.c_uint64), ("n_blocks", C.c_uint64),
+                ("profiling", C.c_int32), ("reserved", C.c_int32), ("ratios", C.c_double * 8),
+                ("best_interp", C.c_double), ("best_lorenzo", C.c_double), ("raw_bytes", C.c_uint64 * 8), ("huff_bytes", C.c_uint64 * 8),
+                ("node_count", C.c_uint64 * 8), ("n_unpred", C.c_uint64 * 8)]
+
+
 def _dtype_id(a):
     if a.dtype == np.float32:
         return 0
@@ -95,6 +102,8 @@ def oracle():
         L.szo_set_omp_slabs.argtypes = [C.c_int]
         L.szo_interp_codes.restype = C.c_size_t
         L.szo_interp_codes.argtypes = [C.POINTER(SzoConfig), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.szo_tune_interp_lorenzo.restype = C.c_int
+        L.szo_tune_interp_lorenzo.argtypes = [C.POINTER(SzoConfig), C.c_int, C.c_void_p, C.POINTER(SzoTunerReport)]
         _oracle = L
     return _oracle
 
@@ -164,6 +173,21 @@ def oracle_interp_codes(a, conf):
     recon = np.empty_like(a)
     n = L.szo_interp_codes(C.byref(conf), _dtype_id(a), a.ctypes.data, codes.ctypes.data, order.ctypes.data, recon.ctypes.data)
     return codes, order, recon, n
+
+
+def oracle_tune(a, conf):
+    """SZ_compress_Interp_lorenzo's decisions (api/impl/SZAlgoInterp.hpp:122-262) on array a: returns (tuned config copy,
+    report, ran) — tuned.cmprAlgo is ALGO_INTERP (interpAlgo / interpDirection / interpAlpha / interpBeta chosen) or
+    ALGO_LORENZO_REG (1-D only)."""
+    L = oracle()
+    a = np.ascontiguousarray(a)
+    c = SzoConfig.from_buffer_copy(conf)
+    c.cmprAlgo = ALGO_INTERP_LORENZO
+    rep = SzoTunerReport()
+    ran = L.szo_tune_interp_lorenzo(C.byref(c), _dtype_id(a), a.ctypes.data, C.byref(rep))
+    if ran < 0:
+        raise RuntimeError(L.szo_last_error().decode())
+    return c, rep, bool(ran)
 
 
 # ---------------------------------------------------------------------------------------------------------

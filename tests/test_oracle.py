@@ -40,7 +40,7 @@ def _prezstd_sha(blob):
 @pytest.mark.parametrize("name,gen,kw", make_golden.CASES, ids=[c[0] for c in make_golden.CASES])
 def test_oracle_matches_reference_goldens(name, gen, kw):
     a = gen()
-    conf = make_config(a.shape, algo=ALGO_LORENZO_REG, **kw)
+    conf = make_golden.case_config(a.shape, kw)
     blob = oracle_compress(a, conf)
     sha, trailer = _prezstd_sha(blob)
     assert sha == str(GOLD[name + "/sha256_prezstd"]), "pre-zstd buffer differs from the reference's"

@@ -160,8 +160,9 @@ def test_sz3c_abi_roundtrip():
     assert np.max(np.abs(dec - b)) <= 1e-4 * (b.max() - b.min())
 
 
-@pytest.mark.parametrize("shape,dtype,eb", [((512, 512, 512), np.float32, 1e-3), ((256, 256, 256), np.float64, 1e-6)],
-                         ids=["C2-512c-f32", "C4-slab-256c-f64"])
+@pytest.mark.parametrize("shape,dtype,eb", [((512, 512, 512), np.float32, 1e-3), ((256, 256, 256), np.float64, 1e-6),
+                                            ((128, 1024, 1024), np.float64, 1e-6)],
+                         ids=["C2-512c-f32", "C4-256c-f64", "C4-slab-128x1024x1024-f64"])
 def test_full_size_properties(shape, dtype, eb):
     """size-independent properties at the benchmark size (no oracle: it would take minutes): strict bound after a
     device round trip, idempotence (re-compressing the decompressed field reproduces it bit for bit — the lattice is a
@@ -263,3 +264,52 @@ def test_unmodified_reference_cli_runs_on_the_gpu_path(tmp_path):
         blob = np.fromfile(cmp_, dtype=np.uint8)
         d2, c2 = sz3_amd.decompress(blob, np.float32, a.shape)
         assert c2.cmprAlgo == want and np.array_equal(d2, out)
+
+
+def test_full_size_interpolation_properties():
+    """C3 at its full size (512^3 f32, ALGO_INTERP_LORENZO = tuner + interpolation, abs 1e-4): strict bound after a device
+    round trip, payload determinism, and the tuner's report is the same on every run."""
+    dev = torch.device("cuda:0")
+    shape = (512, 512, 512)
+    g = torch.Generator(device=dev).manual_seed(99)
+    z, y, x = torch.meshgrid(*[torch.arange(s, device=dev, dtype=torch.float32) for s in shape], indexing="ij")
+    f = torch.sin(2 * np.pi * x / 64) * torch.cos(2 * np.pi * y / 96) * torch.sin(2 * np.pi * z / 128) + \
+        0.25 * torch.sin(2 * np.pi * (x + 2 * y + 3 * z) / 37)
+    del x, y, z
+    f = f + 2e-3 * torch.randn(shape, device=dev, dtype=torch.float32, generator=g)
+    n = f.numel()
+    dc = sz3_amd.DeviceCompressor(n, np.float32)
+    cap = dc.payload_bound(n)
+    pl1 = torch.empty(cap, dtype=torch.uint8, device=dev)
+    pl2 = torch.empty(cap, dtype=torch.uint8, device=dev)
+    conf = sz3_amd.Config(*shape)
+    conf.absErrorBound = 1e-4
+    s = torch.cuda.current_stream().cuda_stream
+    sz1 = dc.compress(conf, f.data_ptr(), pl1.data_ptr(), cap, s)
+    rep1 = dc.tuner_report()
+    assert rep1["ran"] == 1 and rep1["use_interp"] == 1 and rep1["sample_block_size"] == 32 and rep1["n_blocks"] == 17
+    out = torch.empty_like(f)
+    dc.decompress(pl1.data_ptr(), sz1, out.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert float((out.double() - f.double()).abs().max()) <= 1e-4
+    assert 4.0 * n / sz1 > 3
+    sz2 = dc.compress(conf, f.data_ptr(), pl2.data_ptr(), cap, s)
+    torch.cuda.synchronize()
+    assert dc.tuner_report() == rep1
+    assert sz2 == sz1 and torch.equal(pl1[:sz1], pl2[:sz1]), "payload is not deterministic"
+
+
+@pytest.mark.parametrize("algo", ["lorenzo", "default"])
+def test_c5_shaped_4d_rel_roundtrip(algo):
+    """C5's shape family (time x 3-D volume, REL 1e-3) through the host API at 12 x 128^3 (one rank's slab thickness)"""
+    a = field4d((12, 128, 128, 128))
+    conf = sz3_amd.Config(*a.shape)
+    if algo == "lorenzo":
+        conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.errorBoundMode = sz3_amd.EB_REL
+    conf.relErrorBound = 1e-3
+    blob, ratio = sz3_amd.compress(a, conf)
+    dec, c2 = sz3_amd.decompress(blob, np.float32, a.shape)
+    eb = 1e-3 * (float(a.max()) - float(a.min()))
+    assert c2.absErrorBound == pytest.approx(eb, rel=1e-6)
+    assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= c2.absErrorBound and ratio > 4

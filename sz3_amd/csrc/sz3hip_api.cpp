@@ -1108,7 +1108,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     dp.n_chunks = h.n_chunks;
     dp.bitstream_off = o.bitstream;
     dp.chunk_words = (const uint16_t *)(pl + o.chunkwords);
-    dp.chunk_off = ctx->d_chunk_off;
+    dp.group_off = ctx->d_chunk_off;
     dp.tables = ctx->d_tables;
     dp.single_sym = h.sym_min;
     rc = szk_launch_decode(pl, &dp, ctx->d_codes, ctx->d_chunk_off, ctx->d_counters + 3, s);

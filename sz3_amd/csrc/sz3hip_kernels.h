@@ -96,16 +96,18 @@ struct szk_asm_params {
     const void *vout_val, *dout_val;
 };
 
+#define DEC_LUT_BITS 12u
 struct szk_dec_tables {
     uint32_t first_code[SZH_MAX_LEN + 2], first_rank[SZH_MAX_LEN + 2], count[SZH_MAX_LEN + 2];
-    uint32_t max_len, n_coded;
+    uint32_t max_len, n_coded, lut_bits, reserved;
     uint16_t sorted_syms[65536];
+    uint32_t lut[1u << DEC_LUT_BITS];  // next lut_bits bits -> (symbol << 8) | length, 0 = longer code word
 };
 struct szk_dec_params {
     uint64_t n, n_chunks;
     uint64_t bitstream_off;
     const uint16_t *chunk_words;  // inside the payload
-    const uint64_t *chunk_off;
+    const uint64_t *group_off;    // word offset of every group of 32 chunks (k_scan_groups)
     const szk_dec_tables *tables;
     uint32_t single_sym;
 };

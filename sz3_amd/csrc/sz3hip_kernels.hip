@@ -2018,68 +2018,111 @@ __global__ __launch_bounds__(256) void k_assemble(szk_asm_params p) {
 // ------------------------------------------------------------------------------------------------------------
 // K8: decode side
 // ------------------------------------------------------------------------------------------------------------
-// canonical decode tables from the code lengths: first code / first rank per length and the symbols sorted by
-// (len, sym).  One workgroup; the alphabet is at most 65536 symbols.
+// canonical decode tables from the code lengths: first code / first rank per length, the symbols sorted by
+// (len, sym), and a direct lookup table over the next DEC_LUT_BITS bits of the stream: (symbol << 8) | length for every
+// code word of at most DEC_LUT_BITS bits (0 = longer code: length search). One workgroup; <= 65536 symbols.
 __global__ __launch_bounds__(1024) void k_dec_tables(const uint8_t *__restrict__ lens, uint32_t sym_min,
                                                      uint32_t sym_count, szk_dec_tables *t) {
-    __shared__ uint32_t s_cnt[SZH_MAX_LEN + 2];
-    __shared__ uint32_t s_first_rank[SZH_MAX_LEN + 2];
-    if (threadIdx.x < SZH_MAX_LEN + 2) s_cnt[threadIdx.x] = 0;
+    __shared__ uint32_t s_cnt[SZH_MAX_LEN + 2], s_first_code[SZH_MAX_LEN + 2], s_first_rank[SZH_MAX_LEN + 2];
+    __shared__ uint16_t s_tbl[(SZH_MAX_LEN + 1) * 1024];  // per-(length, thread) counts -> exclusive ranks
+    const uint32_t tid = threadIdx.x, lane = lane_id();
+    if (tid < SZH_MAX_LEN + 2) s_cnt[tid] = 0;
+    // every thread owns a contiguous run of symbols (keeps (len, sym) order without a sort)
+    const uint32_t per = (sym_count + 1023) / 1024;
+    const uint32_t q0 = tid * per < sym_count ? tid * per : sym_count, q1 = q0 + per < sym_count ? q0 + per : sym_count;
+    for (uint32_t l = 0; l <= SZH_MAX_LEN; l++) s_tbl[l * 1024 + tid] = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < sym_count; i += 1024) {
-        uint32_t l = lens[i];
-        if (l) atomicAdd(&s_cnt[l], 1u);
+    for (uint32_t i = q0; i < q1; i++) {
+        const uint32_t l = lens[i];
+        if (l && l <= SZH_MAX_LEN) s_tbl[l * 1024 + tid]++;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t code = 0, rank = 0, maxl = 0, single = 0xFFFFFFFFu;
+    for (uint32_t l = 1 + tid / WAVE; l <= SZH_MAX_LEN; l += 1024 / WAVE) {  // one wave per length: scan along the threads
+        uint32_t carry = 0;
+        for (uint32_t c0 = 0; c0 < 1024; c0 += WAVE) {
+            const uint32_t v = s_tbl[l * 1024 + c0 + lane];
+            const uint32_t incl = wave_incl_scan(v);
+            s_tbl[l * 1024 + c0 + lane] = (uint16_t)(carry + incl - v);
+            carry += __shfl(incl, WAVE - 1, WAVE);
+        }
+        if (lane == 0) s_cnt[l] = carry;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t code = 0, rank = 0, maxl = 0;
         for (uint32_t l = 1; l <= SZH_MAX_LEN; l++) {
             code = (code + (l > 1 ? s_cnt[l - 1] : 0)) << (l > 1 ? 1 : 0);
             t->first_code[l] = code;
             t->first_rank[l] = rank;
             t->count[l] = s_cnt[l];
+            s_first_code[l] = code;
             s_first_rank[l] = rank;
             rank += s_cnt[l];
             if (s_cnt[l]) maxl = l;
         }
         t->max_len = maxl;
         t->n_coded = rank;
-        // serial placement keeps (len, sym) order; alphabets are small in practice
-        for (uint32_t i = 0; i < sym_count; i++) {
-            uint32_t l = lens[i];
-            if (l) t->sorted_syms[s_first_rank[l]++] = (uint16_t)(sym_min + i);
+        t->lut_bits = maxl < DEC_LUT_BITS ? maxl : DEC_LUT_BITS;
+    }
+    __syncthreads();
+    for (uint32_t i = q0; i < q1; i++) {
+        const uint32_t l = lens[i];
+        if (l && l <= SZH_MAX_LEN) t->sorted_syms[s_first_rank[l] + s_tbl[l * 1024 + tid]++] = (uint16_t)(sym_min + i);
+    }
+    __threadfence();
+    __syncthreads();
+    uint32_t maxl = 0;
+    for (uint32_t l = 1; l <= SZH_MAX_LEN; l++)
+        if (s_cnt[l]) maxl = l;
+    const uint32_t K = maxl < DEC_LUT_BITS ? maxl : DEC_LUT_BITS;
+    for (uint32_t e = tid; e < (1u << K); e += 1024) {
+        uint32_t ent = 0;
+        for (uint32_t l = 1; l <= K; l++) {
+            const uint32_t rel = (e >> (K - l)) - s_first_code[l];
+            if (rel < s_cnt[l]) {
+                ent = ((uint32_t)t->sorted_syms[s_first_rank[l] + rel] << 8) | l;
+                break;
+            }
         }
-        (void)single;
+        t->lut[e] = ent;
     }
 }
 
-// one thread per chunk: canonical decode by length search on a 64-bit MSB-aligned window
+// one thread per chunk: table lookup on the next lut_bits bits of a 64-bit MSB-aligned window, canonical length search
+// for the (rare) longer code words; the next stream word is always in flight
 __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payload, szk_dec_params p,
                                                 uint16_t *__restrict__ codes) {
     __shared__ uint32_t s_first_code[SZH_MAX_LEN + 2], s_first_rank[SZH_MAX_LEN + 2], s_count[SZH_MAX_LEN + 2];
+    __shared__ uint32_t s_lut[1u << DEC_LUT_BITS];
     if (threadIdx.x <= SZH_MAX_LEN) {
         s_first_code[threadIdx.x] = threadIdx.x ? p.tables->first_code[threadIdx.x] : 0;
         s_first_rank[threadIdx.x] = threadIdx.x ? p.tables->first_rank[threadIdx.x] : 0;
         s_count[threadIdx.x] = threadIdx.x ? p.tables->count[threadIdx.x] : 0;
     }
+    const uint32_t max_len = p.tables->max_len, K = p.tables->lut_bits;
+    for (uint32_t e = threadIdx.x; e < (1u << K); e += 256) s_lut[e] = p.tables->lut[e];
     __syncthreads();
     const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (chunk >= p.n_chunks) return;
     const uint64_t s0 = chunk * SZH_CHUNK_SYMS;
     const uint32_t nsym = (uint32_t)((p.n - s0 < SZH_CHUNK_SYMS) ? (p.n - s0) : SZH_CHUNK_SYMS);
     uint16_t *out = codes + s0;
-    const uint32_t max_len = p.tables->max_len;
     if (max_len == 0) {  // single-symbol alphabet: zero-length code
         uint16_t sym = (uint16_t)p.single_sym;
         for (uint32_t i = 0; i < nsym; i++) out[i] = sym;
         return;
     }
-    const uint32_t *in = reinterpret_cast<const uint32_t *>(payload + p.bitstream_off) + p.chunk_off[chunk];
+    // word offset of the chunk: group offset + the chunks before it inside its group
+    const uint64_t grp = chunk / PACK_GROUP;
+    uint64_t woff = p.group_off[grp];
+    for (uint64_t c = grp * PACK_GROUP; c < chunk; c++) woff += p.chunk_words[c];
+    const uint32_t *in = reinterpret_cast<const uint32_t *>(payload + p.bitstream_off) + woff;
     const uint16_t *sorted = p.tables->sorted_syms;
+    const uint32_t nwords = p.chunk_words[chunk];
     uint64_t buf = 0;  // next bits at the MSB end
     int have = 0;
     uint32_t wi = 0;
-    const uint32_t nwords = p.chunk_words[chunk];
+    uint32_t wnext = nwords ? in[0] : 0u;  // one word ahead
     for (uint32_t i0 = 0; i0 < nsym; i0 += 16) {
         uint32_t packed[8];
 #pragma unroll
@@ -2087,18 +2130,22 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
             uint32_t sym = 0;
             if (i0 + k < nsym) {
                 if (have <= 32) {
-                    uint32_t wd = wi < nwords ? in[wi] : 0u;
-                    wi++;
-                    buf |= (uint64_t)wd << (32 - have);
+                    buf |= (uint64_t)wnext << (32 - have);
                     have += 32;
+                    wi++;
+                    wnext = wi < nwords ? in[wi] : 0u;
                 }
-                uint32_t l;
-                for (l = 1; l <= max_len; l++) {
-                    uint32_t v = (uint32_t)(buf >> (64 - l));
-                    uint32_t rel = v - s_first_code[l];
-                    if (rel < s_count[l]) {  // unsigned compare also rejects v < first_code
-                        sym = sorted[s_first_rank[l] + rel];
-                        break;
+                const uint32_t ent = s_lut[(uint32_t)(buf >> (64 - K))];
+                uint32_t l = ent & 0xFFu;
+                sym = ent >> 8;
+                if (ent == 0) {  // longer than the table: canonical length search
+                    for (l = K + 1; l <= max_len; l++) {
+                        const uint32_t v = (uint32_t)(buf >> (64 - l));
+                        const uint32_t rel = v - s_first_code[l];
+                        if (rel < s_count[l]) {
+                            sym = sorted[s_first_rank[l] + rel];
+                            break;
+                        }
                     }
                 }
                 buf <<= l;
@@ -2411,7 +2458,7 @@ int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_
 }
 int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t *codes, uint64_t *chunk_off,
                       uint64_t *total_words, hipStream_t s) {
-    hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, p->chunk_words, p->n_chunks, chunk_off, total_words);
+    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, p->chunk_words, p->n_chunks, chunk_off, total_words);  // chunk_off = p->group_off
     const uint64_t nb = (p->n_chunks + 255) / 256;
     if (nb > 0x7FFFFFFFull) return -1;
     hipLaunchKernelGGL(k_decode, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);

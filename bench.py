@@ -136,6 +136,12 @@ def main():
     dc.decompress(d_payload.data_ptr(), psize, d_out.data_ptr(), stream)
     torch.cuda.synchronize()
     max_err = float((d_out.double() - d_in.double()).abs().max().item())
+    # device-resident decompression rate (informational)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        dc.decompress(d_payload.data_ptr(), psize, d_out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    dec_ms = (time.perf_counter() - t0) / 5 * 1e3
 
     out = None
     if rank == 0:
@@ -165,6 +171,7 @@ def main():
                        "parallelism": "slab%d" % world, "algo": "HIP_LORENZO(16)" if args.algo == "lorenzo" else "HIP_INTERP(17)", "eb": eb},
             "ratio": round(ratio, 4), "max_abs_err": max_err, "err_bound_ok": bool(max_err <= eb),
             "payload_bytes_rank0": int(psize),
+            "decompress_device": {"ms": round(dec_ms, 4), "gbps": round(raw_bytes / (dec_ms * 1e-3) / 1e9, 2)},
             "outliers": {"value": stats["n_value_outliers"], "delta": stats["n_delta_outliers"]},
             "narrow_codes": stats.get("narrow_codes"),
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},

@@ -2237,6 +2237,52 @@ __global__ __launch_bounds__(256) void k_scan_x_fix(Q *__restrict__ q, uint64_t 
     for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) r[i] = (Q)((UQ)r[i] + off);
 }
 
+// inclusive scan along the contiguous axis for rows of up to SCANX_SEG elements: one wave per row, 4 elements per lane
+// and step, no barrier; FROM_CODES reads the decoded u16 codes directly (code c -> delta c - radius, 0 -> 0) instead
+// of a previously expanded delta array.
+template <typename Q, bool FROM_CODES>
+__global__ __launch_bounds__(256) void k_scan_x_wave(Q *__restrict__ q, const uint16_t *__restrict__ codes, int radius,
+                                                     uint64_t L, uint64_t nrows) {
+    using UQ = typename std::make_unsigned<Q>::type;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE, nwaves = (uint64_t)gridDim.x * 4;
+    const int lane = lane_id();
+    for (uint64_t row = wave0; row < nrows; row += nwaves) {
+        Q *r = q + row * L;
+        const uint16_t *c = codes + row * L;
+        UQ carry = 0;
+        for (uint64_t b = 0; b < L; b += 256) {
+            const uint64_t i0 = b + (uint64_t)lane * 4;
+            UQ v[4];
+            if (FROM_CODES) {
+                if (i0 + 4 <= L && (((row * L + i0) & 3) == 0)) {
+                    const uint2 w = *reinterpret_cast<const uint2 *>(c + i0);
+                    const uint32_t cc[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[k] = cc[k] ? (UQ)(Q)((int)cc[k] - radius) : (UQ)0;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int cc = (i0 + k < L) ? (int)c[i0 + k] : 0;
+                        v[k] = cc ? (UQ)(Q)(cc - radius) : (UQ)0;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = (i0 + k < L) ? (UQ)r[i0 + k] : (UQ)0;
+            }
+            v[1] += v[0];
+            v[2] += v[1];
+            v[3] += v[2];
+            const UQ incl = wave_incl_scan(v[3]);
+            const UQ off = carry + (incl - v[3]);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (i0 + k < L) r[i0 + k] = (Q)(v[k] + off);
+            carry += __shfl(incl, WAVE - 1, WAVE);
+        }
+    }
+}
+
 // inclusive scan along a strided axis: one thread per line, lanes adjacent along the contiguous axis.
 // element index = outer * (L * inner) + a * inner + in,  a = 0..L-1 ; inner = product of faster dims
 template <typename Q>
@@ -2264,6 +2310,39 @@ __global__ __launch_bounds__(256) void k_scan_strided(Q *__restrict__ q, uint64_
     for (; a < L; a++) {
         run += (UQ)pp[a * inner];
         pp[a * inner] = (Q)run;
+    }
+}
+
+// the last strided scan of the reconstruction also turns the lattice index into the value (same buffer, Q and T
+// have the same size)
+template <typename T>
+__global__ __launch_bounds__(256) void k_scan_strided_dequant(void *buf, uint64_t L, uint64_t inner, uint64_t nlines, szk_lattice l) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename std::make_unsigned<Q>::type;
+    const Lattice<T> lat(l);
+    const uint64_t line = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (line >= nlines) return;
+    const uint64_t outer = line / inner, in = line % inner;
+    Q *pp = reinterpret_cast<Q *>(buf) + outer * L * inner + in;
+    T *po = reinterpret_cast<T *>(buf) + outer * L * inner + in;
+    UQ run = 0;
+    uint64_t a = 0;
+    for (; a + 4 <= L; a += 4) {
+        UQ v0 = (UQ)pp[(a + 0) * inner], v1 = (UQ)pp[(a + 1) * inner], v2 = (UQ)pp[(a + 2) * inner],
+           v3 = (UQ)pp[(a + 3) * inner];
+        v0 += run;
+        v1 += v0;
+        v2 += v1;
+        v3 += v2;
+        po[(a + 0) * inner] = lat.dequant((Q)v0);
+        po[(a + 1) * inner] = lat.dequant((Q)v1);
+        po[(a + 2) * inner] = lat.dequant((Q)v2);
+        po[(a + 3) * inner] = lat.dequant((Q)v3);
+        run = v3;
+    }
+    for (; a < L; a++) {
+        run += (UQ)pp[a * inner];
+        po[a * inner] = lat.dequant((Q)run);
     }
 }
 
@@ -2487,27 +2566,43 @@ static int launch_reconstruct(const uint8_t *payload, const szh_header &h, const
     using Q = typename QTraits<T>::Q;
     Q *q = reinterpret_cast<Q *>(d_out);
     const uint64_t n = h.n;
-    hipLaunchKernelGGL(k_expand_codes<Q>, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, codes, n, (int)h.radius, q);
-    if (h.n_dout)
-        hipLaunchKernelGGL(k_scatter_dout<Q>, dim3(grid_for(h.n_dout, 256, 4096)), dim3(256), 0, s, payload, o.dout_idx,
-                           o.dout_val, h.n_dout, n, q);
-    // axis x (contiguous)
     const uint64_t L = h.dims[3], nrows = n / L;
-    {
-        int rc = scan_rows<Q>(q, L, nrows, (Q *)d_segtot, s);
-        if (rc) return rc;
+    const bool wave_rows = L <= SCANX_SEG;  // one wave per row, no segment totals
+    const uint32_t wgrid = grid_for(nrows, 4, 16384);
+    if (wave_rows && h.n_dout == 0) {
+        // codes -> deltas -> x-scan in one pass
+        hipLaunchKernelGGL((k_scan_x_wave<Q, true>), dim3(wgrid), dim3(256), 0, s, q, codes, (int)h.radius, L, nrows);
+    } else {
+        hipLaunchKernelGGL(k_expand_codes<Q>, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, codes, n, (int)h.radius, q);
+        if (h.n_dout)
+            hipLaunchKernelGGL(k_scatter_dout<Q>, dim3(grid_for(h.n_dout, 256, 4096)), dim3(256), 0, s, payload, o.dout_idx,
+                               o.dout_val, h.n_dout, n, q);
+        if (wave_rows) {
+            hipLaunchKernelGGL((k_scan_x_wave<Q, false>), dim3(wgrid), dim3(256), 0, s, q, codes, (int)h.radius, L, nrows);
+        } else {
+            int rc = scan_rows<Q>(q, L, nrows, (Q *)d_segtot, s);
+            if (rc) return rc;
+        }
     }
-    // strided axes y, z, w
+    // strided axes y, z, w; the last one that exists also dequantises
+    int last_ax = -1;
+    for (int ax = 2; ax >= 0; ax--)
+        if (h.dims[ax] > 1) last_ax = ax;
     uint64_t inner = L;
     for (int ax = 2; ax >= 0; ax--) {
         const uint64_t La = h.dims[ax];
         if (La > 1) {
             const uint64_t nlines = n / La;
-            hipLaunchKernelGGL(k_scan_strided<Q>, dim3(grid_for(nlines, 256, 0x7FFFFFFF)), dim3(256), 0, s, q, La, inner, nlines);
+            if (ax == last_ax)
+                hipLaunchKernelGGL(k_scan_strided_dequant<T>, dim3(grid_for(nlines, 256, 0x7FFFFFFF)), dim3(256), 0, s, d_out, La, inner,
+                                   nlines, szk_make_lattice(h.eb));
+            else
+                hipLaunchKernelGGL(k_scan_strided<Q>, dim3(grid_for(nlines, 256, 0x7FFFFFFF)), dim3(256), 0, s, q, La, inner, nlines);
         }
         inner *= La;
     }
-    hipLaunchKernelGGL(k_dequant<T>, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, d_out, n, szk_make_lattice(h.eb));
+    if (last_ax < 0)
+        hipLaunchKernelGGL(k_dequant<T>, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, d_out, n, szk_make_lattice(h.eb));
     if (h.n_vout)
         hipLaunchKernelGGL(k_patch_vout<T>, dim3(grid_for(h.n_vout, 256, 4096)), dim3(256), 0, s, payload, o.vout_idx,
                            o.vout_val, h.n_vout, n, (T *)d_out);

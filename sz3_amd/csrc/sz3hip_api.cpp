@@ -946,6 +946,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     if (radius < 2 || radius > 32768) return fail(SZ3HIP_EINVAL, "quantbinCnt must be in [4, 65536]");
     ctx->cur_out_cap = std::min<uint64_t>(ctx->out_cap, std::max<uint64_t>(1024, num / 32));
     memset(&ctx->tuner, 0, sizeof(ctx->tuner));
+    for (int i = 0; i < ST_COUNT; i++) ctx->ev_used[i] = false;  // stage times describe this call only
     if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP_LORENZO) {  // the reference's default: sampling auto-tuner, then one of the two paths
         prof_begin(ctx, ST_TUNER, s);
         int rct = tune_interp_lorenzo(ctx, *conf, d_in, eb, radius, s);

@@ -10,3 +10,6 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/pmc_sq -o p -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/pmc_lds -o p -- $B > /dev/null 2>&1
 grep metric $R/gpurun_out/prof_stats.log | cut -c1-300
+# summaries for profiles/ (copied there by hand after a look)
+python $R/tools/pmc_summary.py $R/gpurun_out/pmc_fetch/*counter_collection.csv $R/gpurun_out/pmc_write/*counter_collection.csv $R/gpurun_out/pmc_sq/*counter_collection.csv $R/gpurun_out/pmc_lds/*counter_collection.csv > $R/gpurun_out/pmc_summary.txt 2>&1
+cp $R/gpurun_out/prof_stats/*kernel_stats.csv $R/gpurun_out/kernel_stats.csv 2>/dev/null

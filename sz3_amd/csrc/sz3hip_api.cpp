@@ -400,6 +400,10 @@ struct sz3hip_ctx {
     size_t samples_cap;
     uint64_t *d_trial;  // [8][4]: bits, symbols, unpredictables, delta outliers
     uint64_t *h_trial;  // pinned
+    uint64_t *d_trial_hist;      // [SZK_MAX_BOOKS][65536] histograms of the trials of one group
+    uint64_t *d_trial_counters;  // [SZK_MAX_BOOKS][8]
+    szk_interp_pass *d_passes, *h_passes;  // [SZK_MAX_BOOKS][SZK_TRIAL_MAX_PASSES] pass schedules (h: pinned)
+    uint32_t *d_np, *h_np;
     sz3hip_tuner_report tuner;
     // profiling
     bool profiling;
@@ -412,13 +416,15 @@ static void ctx_free(sz3hip_ctx *c) {
     void *bufs[] = {c->d_work, c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_counters, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
                     c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_aux2, c->d_pint2, c->d_range, c->d_info,
                     c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_flags, c->d_starts, c->d_samples,
-                    c->d_trial};
+                    c->d_trial, c->d_trial_hist, c->d_trial_counters, c->d_passes, c->d_np};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
     if (c->h_probe) (void)hipHostFree(c->h_probe);
     if (c->h_trial) (void)hipHostFree(c->h_trial);
+    if (c->h_passes) (void)hipHostFree(c->h_passes);
+    if (c->h_np) (void)hipHostFree(c->h_np);
     for (int i = 0; i < ST_COUNT; i++)
         for (int j = 0; j < 2; j++)
             if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
@@ -460,18 +466,18 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     alloc((void **)&c->d_dout_idx, c->out_cap * 8);
     alloc(&c->d_vout_val, c->out_cap * 8);
     alloc(&c->d_dout_val, c->out_cap * 8);
-    alloc((void **)&c->d_enc, SZH_HIST_BINS * 4);
-    alloc((void **)&c->d_lens, SZH_HIST_BINS);
-    alloc((void **)&c->d_keys, SZH_HIST_BINS * 8);
-    alloc((void **)&c->d_ifreq, SZH_HIST_BINS * 8);
-    alloc((void **)&c->d_syms, SZH_HIST_BINS * 2);
-    alloc((void **)&c->d_pleaf, SZH_HIST_BINS * 2);
-    alloc((void **)&c->d_pint, SZH_HIST_BINS * 2);
-    alloc((void **)&c->d_depth, SZH_HIST_BINS * 2);
-    alloc((void **)&c->d_aux2, SZH_HIST_BINS * 2);
-    alloc((void **)&c->d_pint2, SZH_HIST_BINS * 2);
-    alloc((void **)&c->d_range, 16);
-    alloc((void **)&c->d_info, sizeof(szk_cb_info));
+    alloc((void **)&c->d_enc, SZK_MAX_BOOKS * SZH_HIST_BINS * 4);
+    alloc((void **)&c->d_lens, SZK_MAX_BOOKS * SZH_HIST_BINS);
+    alloc((void **)&c->d_keys, SZK_MAX_BOOKS * SZH_HIST_BINS * 8);
+    alloc((void **)&c->d_ifreq, SZK_MAX_BOOKS * SZH_HIST_BINS * 8);
+    alloc((void **)&c->d_syms, SZK_MAX_BOOKS * SZH_HIST_BINS * 2);
+    alloc((void **)&c->d_pleaf, SZK_MAX_BOOKS * SZH_HIST_BINS * 2);
+    alloc((void **)&c->d_pint, SZK_MAX_BOOKS * SZH_HIST_BINS * 2);
+    alloc((void **)&c->d_depth, SZK_MAX_BOOKS * SZH_HIST_BINS * 2);
+    alloc((void **)&c->d_aux2, SZK_MAX_BOOKS * SZH_HIST_BINS * 2);
+    alloc((void **)&c->d_pint2, SZK_MAX_BOOKS * SZH_HIST_BINS * 2);
+    alloc((void **)&c->d_range, SZK_MAX_BOOKS * 16);
+    alloc((void **)&c->d_info, SZK_MAX_BOOKS * sizeof(szk_cb_info));
     alloc((void **)&c->d_chunk_words, (c->max_chunks + 8) * 2);
     alloc((void **)&c->d_chunk_off, (c->max_chunks + 8) * 8);
     alloc((void **)&c->d_state, sizeof(szk_state));
@@ -589,6 +595,7 @@ static void cb_params_from(sz3hip_ctx *ctx, szk_cb_params &cb, uint64_t out_cap)
     cb.out_cap = out_cap;
     cb.t_is_32bit = cb.q_is_32bit = ctx->dtype == SZ3HIP_FLOAT;
     cb.info = ctx->d_info;
+    cb.n_books = 1;
 }
 
 static int stage1_interp(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint64_t num, hipStream_t s) {
@@ -708,6 +715,13 @@ static int tuner_reserve(sz3hip_ctx *ctx, size_t flags, size_t starts, size_t sa
     }
     if (!ctx->d_trial) HIPCHK(hipMalloc(&ctx->d_trial, 8 * 4 * 8));
     if (!ctx->h_trial) HIPCHK(hipHostMalloc((void **)&ctx->h_trial, 8 * 4 * 8));
+    if (!ctx->d_trial_hist) HIPCHK(hipMalloc(&ctx->d_trial_hist, SZK_MAX_BOOKS * SZH_HIST_BINS * 8));
+    if (!ctx->d_trial_counters) HIPCHK(hipMalloc(&ctx->d_trial_counters, SZK_MAX_BOOKS * 64));
+    const size_t pbytes = SZK_MAX_BOOKS * SZK_TRIAL_MAX_PASSES * sizeof(szk_interp_pass);
+    if (!ctx->d_passes) HIPCHK(hipMalloc(&ctx->d_passes, pbytes));
+    if (!ctx->h_passes) HIPCHK(hipHostMalloc((void **)&ctx->h_passes, pbytes));
+    if (!ctx->d_np) HIPCHK(hipMalloc(&ctx->d_np, 4 * SZK_MAX_BOOKS));
+    if (!ctx->h_np) HIPCHK(hipHostMalloc((void **)&ctx->h_np, 4 * SZK_MAX_BOOKS));
     if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
     return 0;
 }
@@ -717,24 +731,31 @@ static double trial_bytes(const uint64_t *r, size_t tsz) {  // r: bits, symbols,
     const double tree = 13.0 + nc * (2 * w + 5);  // HuffmanEncoder::save: [i32][i32][i32][u8] L R C t (HuffmanEncoder.hpp:108-125)
     return std::ceil((double)r[0] / 8.0) + 0.45 * tree + (double)r[2] * (double)tsz + (double)r[3] * 12.0 + 80.0;
 }
-static int tuner_interp_trial(sz3hip_ctx *ctx, const sz3hip_config &tc, double eb, int radius, uint32_t nb, int slot, hipStream_t s) {
-    HIPCHK(hipMemsetAsync(ctx->d_hist, 0, SZH_HIST_BINS * 8, s));
-    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 64, s));
-    HIPCHK(hipMemsetAsync(ctx->d_trial + 4 * slot, 0, 32, s));
-    szk_interp_params ip;
-    int rc = interp_params_from(&tc, eb, radius, ip);
-    if (rc) return rc;
-    ip.n_vout = ctx->d_counters + 0;
-    ip.vout_idx = ctx->d_vout_idx;
-    ip.vout_val = ctx->d_vout_val;
-    ip.out_cap = 0;  // count only
-    rc = szk_launch_interp_trial(ctx->dtype, &ip, ctx->d_samples, ctx->d_work, ctx->d_codes, nb, ctx->d_hist, s);
+// one group of up to SZK_MAX_BOOKS independent trials: one interpolation launch for all of them, one batched code-book launch
+// over their histograms, one cost launch; trial j's priced size lands in result slot slot0 + j
+static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr, double eb, int radius, uint32_t nb, int slot0,
+                              hipStream_t s) {
+    HIPCHK(hipMemsetAsync(ctx->d_trial_hist, 0, (size_t)ntr * SZH_HIST_BINS * 8, s));
+    HIPCHK(hipMemsetAsync(ctx->d_trial_counters, 0, SZK_MAX_BOOKS * 64, s));
+    HIPCHK(hipMemsetAsync(ctx->d_trial + 4 * slot0, 0, 32 * ntr, s));
+    szk_interp_params ips[SZK_MAX_BOOKS];
+    for (int j = 0; j < ntr; j++) {
+        int rc = interp_params_from(&tcs[j], eb, radius, ips[j]);
+        if (rc) return rc;
+        ips[j].n_vout = ctx->d_trial_counters + 8 * j;
+        ips[j].vout_idx = ctx->d_vout_idx;
+        ips[j].vout_val = ctx->d_vout_val;
+        ips[j].out_cap = 0;  // count only
+    }
+    int rc = szk_launch_interp_trials(ctx->dtype, ips, (uint32_t)ntr, ctx->d_samples, ctx->d_work, ctx->d_codes, nb, ctx->d_trial_hist,
+                                      ctx->h_passes, ctx->d_passes, ctx->h_np, ctx->d_np, s);
     if (rc) return fail(SZ3HIP_EHIP, "tuner: interpolation trial launch failed (%d)", rc);
     szk_cb_params cb;
     cb_params_from(ctx, cb, 0);
-    rc = szk_launch_codebook(ctx->d_hist, &cb, s);
+    cb.n_books = (uint32_t)ntr;
+    rc = szk_launch_codebook(ctx->d_trial_hist, &cb, s);
     if (rc) return fail(SZ3HIP_EHIP, "tuner: codebook launch failed (%d)", rc);
-    rc = szk_launch_code_cost(ctx->d_hist, ctx->d_lens, ctx->d_info, ctx->d_counters, ctx->d_trial + 4 * slot, s);
+    rc = szk_launch_code_cost(ctx->d_trial_hist, ctx->d_lens, ctx->d_info, ctx->d_trial_counters, ctx->d_trial + 4 * slot0, (uint32_t)ntr, s);
     if (rc) return fail(SZ3HIP_EHIP, "tuner: cost kernel launch failed (%d)", rc);
     return 0;
 }
@@ -839,43 +860,47 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
     tc.N = N;
     for (int i = 0; i < N; i++) tc.dims[i] = sbs + 1;
     tc.num = per;
-    // linear and cubic
-    for (int op = 0; op < 2; op++) {
-        tc.interpAlgo = (uint8_t)op;
-        rc = tuner_interp_trial(ctx, tc, eb, radius, (uint32_t)nb, op, s);
+    // linear and cubic, each with the identity and with the reversed dimension order, in one batch (the reference runs the
+    // reversed-order trial only for the better formula: slots 2 / 3 hold that trial for linear / cubic)
+    int fact = 1;
+    for (int i = 2; i <= N; i++) fact *= i;
+    {
+        sz3hip_config g[4] = {tc, tc, tc, tc};
+        for (int k = 0; k < 4; k++) {
+            g[k].interpAlgo = (uint8_t)(k & 1);
+            g[k].interpDirection = (uint8_t)(k < 2 ? 0 : fact - 1);
+        }
+        rc = tuner_interp_group(ctx, g, 4, eb, radius, (uint32_t)nb, 0, s);
         if (rc) return rc;
     }
     rc = tuner_fetch(ctx, s);
     if (rc) return rc;
+    double dir_bytes[2];
     for (int op = 0; op < 2; op++) {
         rep.est_bytes[op] = trial_bytes(ctx->h_trial + 4 * op, tsz);
+        dir_bytes[op] = trial_bytes(ctx->h_trial + 4 * (2 + op), tsz);
         const double ratio = raw / rep.est_bytes[op];
         if (ratio > best_interp) {
             best_interp = ratio;
             conf.interpAlgo = (uint8_t)op;
         }
     }
-    // reversed dimension order
     tc.interpAlgo = conf.interpAlgo;
-    int fact = 1;
-    for (int i = 2; i <= N; i++) fact *= i;
-    tc.interpDirection = (uint8_t)(fact - 1);
-    rc = tuner_interp_trial(ctx, tc, eb, radius, (uint32_t)nb, 2, s);
-    if (rc) return rc;
-    rc = tuner_fetch(ctx, s);
-    if (rc) return rc;
-    rep.est_bytes[2] = trial_bytes(ctx->h_trial + 8, tsz);
+    rep.est_bytes[2] = dir_bytes[conf.interpAlgo ? 1 : 0];
     if (raw / rep.est_bytes[2] > best_interp * 1.02) {
         best_interp = raw / rep.est_bytes[2];
-        conf.interpDirection = tc.interpDirection;
+        conf.interpDirection = (uint8_t)(fact - 1);
     }
     tc.interpDirection = conf.interpDirection;
     // (alpha, beta) pairs
     static const double alphas[3] = {1.0, 1.5, 2.0}, betas[3] = {1.0, 2.5, 3.0};
-    for (int i = 0; i < 3; i++) {
-        tc.interpAlpha = alphas[i];
-        tc.interpBeta = betas[i];
-        rc = tuner_interp_trial(ctx, tc, eb, radius, (uint32_t)nb, 3 + i, s);
+    {
+        sz3hip_config g[3] = {tc, tc, tc};
+        for (int i = 0; i < 3; i++) {
+            g[i].interpAlpha = alphas[i];
+            g[i].interpBeta = betas[i];
+        }
+        rc = tuner_interp_group(ctx, g, 3, eb, radius, (uint32_t)nb, 3, s);
         if (rc) return rc;
     }
     rc = tuner_fetch(ctx, s);
@@ -901,7 +926,7 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
         cb_params_from(ctx, cb, 0);
         rc = szk_launch_codebook(ctx->d_hist, &cb, s);
         if (rc) return fail(SZ3HIP_EHIP, "tuner: codebook launch failed (%d)", rc);
-        rc = szk_launch_code_cost(ctx->d_hist, ctx->d_lens, ctx->d_info, ctx->d_counters, ctx->d_trial + 24, s);
+        rc = szk_launch_code_cost(ctx->d_hist, ctx->d_lens, ctx->d_info, ctx->d_counters, ctx->d_trial + 24, 1, s);
         if (rc) return fail(SZ3HIP_EHIP, "tuner: cost kernel launch failed (%d)", rc);
         rc = tuner_fetch(ctx, s);
         if (rc) return rc;

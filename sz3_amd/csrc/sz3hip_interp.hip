@@ -19,9 +19,12 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#include <vector>
 
 #include "sz3hip_format.h"
 #include "sz3hip_kernels.h"
+
+#define IH_WIN 1024  // LDS histogram window (bins) around the radius
 
 #define WAVE 64
 
@@ -68,12 +71,8 @@ __device__ __forceinline__ T ref_recover(T pred, int code, double eb, int radius
 
 // ---- one directional pass of one level: one thread per predicted point ----------------------------------------
 template <typename T, bool DEC>
-__global__ __launch_bounds__(256) void k_interp_pass(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= p.total) return;
-    const uint64_t boff = (uint64_t)blockIdx.y * p.batch_stride;  // independent arrays of one batch (the tuner's sample blocks)
-    w += boff;
-    codes += boff;
+__device__ __forceinline__ void interp_point(T *__restrict__ w, uint16_t *__restrict__ codes, const szk_interp_pass &p, uint64_t t,
+                                             uint64_t boff) {
     uint64_t r = t, idx = 0, cd = 0;
 #pragma unroll
     for (int j = 3; j >= 0; j--) {
@@ -142,16 +141,19 @@ __global__ __launch_bounds__(256) void k_interp_pass(T *__restrict__ w, uint16_t
         }
     }
 }
+template <typename T, bool DEC>
+__global__ __launch_bounds__(256) void k_interp_pass(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.total) return;
+    const uint64_t boff = (uint64_t)blockIdx.y * p.batch_stride;  // independent arrays of one batch
+    interp_point<T, DEC>(w + boff, codes + boff, p, t, boff);
+}
 
 // anchor grid (build_anchor_grid :215-221): every anchor_stride-th point in each dimension is stored losslessly;
 // without anchors (anchor_stride == 0) the first element is quantised against 0 (:92-93)
 template <typename T>
-__global__ __launch_bounds__(256) void k_interp_anchors(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= p.total) return;
-    const uint64_t boff = (uint64_t)blockIdx.y * p.batch_stride;
-    w += boff;
-    codes += boff;
+__device__ __forceinline__ void anchor_point(T *__restrict__ w, uint16_t *__restrict__ codes, const szk_interp_pass &p, uint64_t t,
+                                             uint64_t boff) {
     uint64_t r = t, idx = 0;
 #pragma unroll
     for (int j = 3; j >= 0; j--) {
@@ -176,13 +178,19 @@ __global__ __launch_bounds__(256) void k_interp_anchors(T *__restrict__ w, uint1
     }
 }
 template <typename T>
+__global__ __launch_bounds__(256) void k_interp_anchors(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.total) return;
+    const uint64_t boff = (uint64_t)blockIdx.y * p.batch_stride;
+    anchor_point<T>(w + boff, codes + boff, p, t, boff);
+}
+template <typename T>
 __global__ __launch_bounds__(256) void k_interp_first_dec(T *__restrict__ w, const uint16_t *__restrict__ codes, double eb, int radius) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && codes[0]) w[0] = ref_recover<T>((T)0, codes[0], eb, radius);
 }
 
 // histogram of u16 codes: persistent workgroups, LDS window [bin][4 copies] around the radius, flushed with one
 // 64-bit atomic per non-empty bin and workgroup
-#define IH_WIN 1024
 __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__ codes, uint64_t n, int radius,
                                                     uint64_t *__restrict__ hist) {
     __shared__ uint32_t lh[IH_WIN * 4];
@@ -252,8 +260,8 @@ static void nth_permutation(int N, int id, int *perm) {  // lexicographic order 
     for (int i = 0; i < N; i++) perm[i] = p[i];
 }
 
-template <typename T, bool DEC>
-static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStream_t s, uint32_t nbatch = 1) {
+// the level / pass schedule as a list (kind 0: anchor grid, 1: first point without anchors, 2: directional pass)
+static int build_schedule(const szk_interp_params &ip, bool dec, uint32_t nbatch, std::vector<szk_interp_pass> &out) {
     const int N = ip.N;
     szk_interp_pass p;
     memset(&p, 0, sizeof(p));
@@ -290,24 +298,21 @@ static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStr
     int perm[4], pos[4];
     nth_permutation(N, ip.direction, perm);
     for (int k = 0; k < N; k++) pos[perm[k]] = k;
-    // anchors / first point
-    if (anchor == 0) {
-        if (DEC) {
-            hipLaunchKernelGGL((k_interp_first_dec<T>), dim3(1), dim3(64), 0, s, w, codes, ip.eb, ip.radius);
-        } else {
-            p.total = 1;
-            for (int j = 0; j < N; j++) {
-                p.start[j] = 0;
-                p.step[j] = 1;
-                p.cnt[j] = 1;
-            }
-            p.subpass = 1;
-            p.eb = ip.eb;
-            p.eb_recip = 1.0 / ip.eb;
-            hipLaunchKernelGGL((k_interp_anchors<T>), dim3(1, nbatch), dim3(256), 0, s, w, codes, p);
+    p.eb = ip.eb;
+    p.eb_recip = 1.0 / ip.eb;
+    if (anchor == 0) {  // first point, predicted by 0
+        p.kind = 1;
+        p.total = 1;
+        for (int j = 0; j < N; j++) {
+            p.start[j] = 0;
+            p.step[j] = 1;
+            p.cnt[j] = 1;
         }
+        p.subpass = 1;
+        out.push_back(p);
     } else {
-        if (!DEC) {
+        if (!dec) {  // anchors are lossless: the decoder finds them among the scattered raw values
+            p.kind = 0;
             p.total = 1;
             for (int j = 0; j < N; j++) {
                 p.start[j] = 0;
@@ -316,12 +321,11 @@ static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStr
                 p.total *= p.cnt[j];
             }
             p.subpass = 0;
-            p.eb = ip.eb;
-            p.eb_recip = 1.0 / ip.eb;
-            hipLaunchKernelGGL((k_interp_anchors<T>), dim3((uint32_t)((p.total + 255) / 256), nbatch), dim3(256), 0, s, w, codes, p);
+            out.push_back(p);
         }
         interp_level--;
     }
+    p.kind = 2;
     for (int level = interp_level; level > 0; level--) {
         double cur_eb = ip.eb;  // per-level bound :103-117
         if (ip.alpha < 0) {
@@ -356,14 +360,30 @@ static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStr
                 p.total *= p.cnt[j];
             }
             if (p.total == 0) continue;
-            const uint64_t nb = (p.total + 255) / 256;
-            if (nb > 0x7FFFFFFFull) return -1;
+            if ((p.total + 255) / 256 > 0x7FFFFFFFull) return -1;
             p.subpass = 0;
-            hipLaunchKernelGGL((k_interp_pass<T, DEC>), dim3((uint32_t)nb, nbatch), dim3(256), 0, s, w, codes, p);
-            if (!p.old_api && p.interp_id == 0) {
+            out.push_back(p);
+            if (!p.old_api && p.interp_id == 0) {  // the deferred last point of even-length lines (linear, fastest-dim-first rule)
                 p.subpass = 1;
-                hipLaunchKernelGGL((k_interp_pass<T, DEC>), dim3((uint32_t)nb, nbatch), dim3(256), 0, s, w, codes, p);
+                out.push_back(p);
             }
+        }
+    }
+    return 0;
+}
+
+template <typename T, bool DEC>
+static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStream_t s, uint32_t nbatch = 1) {
+    std::vector<szk_interp_pass> sched;
+    if (build_schedule(ip, DEC, nbatch, sched)) return -1;
+    for (const szk_interp_pass &p : sched) {
+        const uint32_t nb = (uint32_t)((p.total + 255) / 256);
+        if (p.kind == 2) {
+            hipLaunchKernelGGL((k_interp_pass<T, DEC>), dim3(nb, nbatch), dim3(256), 0, s, w, codes, p);
+        } else if (DEC) {
+            hipLaunchKernelGGL((k_interp_first_dec<T>), dim3(1), dim3(64), 0, s, w, codes, ip.eb, ip.radius);
+        } else {
+            hipLaunchKernelGGL((k_interp_anchors<T>), dim3(nb, nbatch), dim3(256), 0, s, w, codes, p);
         }
     }
     hipError_t e = hipGetLastError();
@@ -407,30 +427,38 @@ struct szk_prof_params {
 };
 template <typename T>
 __global__ __launch_bounds__(256) void k_profile_blocks(const T *__restrict__ data, szk_prof_params p, uint8_t *__restrict__ flags) {
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    // one wave per candidate block; lanes share the strided sample points. The reference's sequential
+    // "if (v < min) min = v; else if (v > max) max = v" walk equals the plain min / max of the samples (NaN samples never
+    // update either, in both forms)
+    const uint64_t t = (uint64_t)blockIdx.x * 4 + threadIdx.x / 64;
     if (t >= p.total) return;
+    const int lane = threadIdx.x & 63;
     uint64_t r = t, start = 0;
     for (int j = p.N - 1; j >= 0; j--) {
         start += (r % p.cnt[j]) * p.bs * p.off[j];
         r /= p.cnt[j];
     }
-    T mn = data[start], mx = mn;
-    uint64_t k[4] = {0, 0, 0, 0};
-    for (;;) {
-        uint64_t idx = start;
-        for (int j = 0; j < p.N; j++) idx += k[j] * p.off[j];
+    const uint64_t m = p.bs / p.stride + 1;  // sample points per dimension: 0, stride, ..., <= bs
+    uint64_t npts = 1;
+    for (int j = 0; j < p.N; j++) npts *= m;
+    const T first = data[start];
+    T mn = first, mx = first;
+    for (uint64_t q = lane; q < npts; q += 64) {
+        uint64_t rr = q, idx = start;
+        for (int j = p.N - 1; j >= 0; j--) {
+            idx += (rr % m) * p.stride * p.off[j];
+            rr /= m;
+        }
         const T v = data[idx];
         if (v < mn) mn = v;
-        else if (v > mx) mx = v;
-        int j = p.N - 1;
-        for (; j >= 0; j--) {
-            k[j] += p.stride;
-            if (k[j] <= p.bs) break;
-            k[j] = 0;
-        }
-        if (j < 0) break;
+        if (v > mx) mx = v;
     }
-    flags[t] = (mx - mn > p.abseb) ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) {
+        const T a = __shfl_xor(mn, off, 64), b = __shfl_xor(mx, off, 64);
+        if (a < mn) mn = a;
+        if (b > mx) mx = b;
+    }
+    if (lane == 0) flags[t] = (mx - mn > p.abseb) ? 1 : 0;
 }
 // sample_blocks (utils/Sample.hpp:138-219): copy the edge^N block at starts[b] into the b-th slot of the batch
 template <typename T>
@@ -450,6 +478,12 @@ __global__ __launch_bounds__(256) void k_gather_blocks(const T *__restrict__ dat
 __global__ __launch_bounds__(256) void k_code_cost(const uint64_t *__restrict__ hist, const uint8_t *__restrict__ lens,
                                                    const szk_cb_info *__restrict__ info, const uint64_t *__restrict__ counters,
                                                    unsigned long long *res) {
+    const size_t book = blockIdx.y;  // batch of code books: tables sliced per book, results 4 words apart, counters 8 apart
+    hist += book * SZH_HIST_BINS;
+    lens += book * SZH_HIST_BINS;
+    info += book;
+    counters += book * 8;
+    res += book * 4;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) {  // res[1] = symbols of the alphabet, res[2] = unpredictable values, res[3] = delta outliers
         res[1] = info->n_symbols;
@@ -482,7 +516,7 @@ int szk_launch_profile_blocks(int dtype, const void *d_in, int N, const uint64_t
     p.abseb = abseb;
     *total_out = p.total;
     if (p.total == 0) return 0;
-    const uint32_t g = (uint32_t)((p.total + 255) / 256);
+    const uint32_t g = (uint32_t)((p.total + 3) / 4);
     if (dtype == 0) hipLaunchKernelGGL((k_profile_blocks<float>), dim3(g), dim3(256), 0, s, (const float *)d_in, p, d_flags);
     else hipLaunchKernelGGL((k_profile_blocks<double>), dim3(g), dim3(256), 0, s, (const double *)d_in, p, d_flags);
     hipError_t e = hipGetLastError();
@@ -503,26 +537,84 @@ int szk_launch_gather_blocks(int dtype, const void *d_in, int N, const uint64_t 
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
-// one tuner trial (interp_compress_test, SZAlgoInterp.hpp:42-78, decomposition part): nblocks independent arrays of
-// ip->dims each, interpolated in place in d_work (a copy of the samples), codes + histogram out; unpredictables are
-// only counted (ip->out_cap = 0)
-int szk_launch_interp_trial(int dtype, const szk_interp_params *ip, const void *d_samples, void *d_work, uint16_t *codes,
-                            uint32_t nblocks, uint64_t *hist, hipStream_t s) {
+// Tuner trials (interp_compress_test, SZAlgoInterp.hpp:42-78, decomposition part) in ONE launch: workgroup (b, j) runs the
+// whole pass schedule of trial j over sample block b (a private copy of the block in `work`; the passes of a block only
+// need workgroup-level ordering), then adds its codes to trial j's histogram through an LDS window. Unpredictables are
+// only counted (out_cap = 0 in the schedules).
+#define TRIAL_MAX_PASSES 64
+template <typename T>
+__global__ __launch_bounds__(1024) void k_interp_trials(const T *__restrict__ samples, T *__restrict__ work, uint16_t *__restrict__ codes,
+                                                        const szk_interp_pass *__restrict__ passes, const uint32_t *__restrict__ npasses,
+                                                        uint64_t per, uint64_t *__restrict__ hists) {
+    __shared__ szk_interp_pass sp;
+    __shared__ uint32_t lh[IH_WIN];
+    const uint32_t b = blockIdx.x, j = blockIdx.y, nb = gridDim.x, tid = threadIdx.x;
+    const uint64_t base = ((uint64_t)j * nb + b) * per;
+    T *w = work + base;
+    uint16_t *c = codes + base;
+    const T *in = samples + (uint64_t)b * per;
+    for (uint64_t i = tid; i < per; i += 1024) w[i] = in[i];
+    for (uint32_t i = tid; i < IH_WIN; i += 1024) lh[i] = 0;
+    const uint32_t np = npasses[j];
+    for (uint32_t k = 0; k < np; k++) {
+        __syncthreads();  // previous pass complete (and its sp no longer read)
+        if (tid < sizeof(szk_interp_pass) / 4)
+            reinterpret_cast<uint32_t *>(&sp)[tid] = reinterpret_cast<const uint32_t *>(&passes[(size_t)j * TRIAL_MAX_PASSES + k])[tid];
+        __syncthreads();
+        if (sp.kind == 2) {
+            for (uint64_t t = tid; t < sp.total; t += 1024) interp_point<T, false>(w, c, sp, t, base);
+        } else {
+            for (uint64_t t = tid; t < sp.total; t += 1024) anchor_point<T>(w, c, sp, t, base);
+        }
+    }
+    __syncthreads();
+    uint64_t *hist = hists + (size_t)j * SZH_HIST_BINS;
+    const uint32_t win_lo = (uint32_t)(sp.radius - IH_WIN / 2);
+    for (uint64_t i = tid; i < per; i += 1024) {
+        const uint32_t code = c[i];
+        const uint32_t bin = code - win_lo;
+        if (bin < IH_WIN) atomicAdd(&lh[bin], 1u);
+        else atomicAdd((unsigned long long *)&hist[code], 1ull);
+    }
+    __syncthreads();
+    for (uint32_t bb = tid; bb < IH_WIN; bb += 1024) {
+        const uint32_t v = lh[bb];
+        const uint32_t sym = win_lo + bb;
+        if (v && sym < SZH_HIST_BINS) atomicAdd((unsigned long long *)&hist[sym], (unsigned long long)v);
+    }
+}
+
+// ips[j]: parameters of trial j (dims = the sample block's, n_vout = that trial's counter, out_cap = 0); the schedules are
+// built on the host into h_passes (pinned) and copied to d_passes
+int szk_launch_interp_trials(int dtype, const szk_interp_params *ips, uint32_t ntrials, const void *d_samples, void *d_work,
+                             uint16_t *codes, uint32_t nblocks, uint64_t *d_hists, szk_interp_pass *h_passes, szk_interp_pass *d_passes,
+                             uint32_t *h_np, uint32_t *d_np, hipStream_t s) {
     uint64_t per = 1;
-    for (int i = 0; i < ip->N; i++) per *= ip->dims[i];
-    const size_t tsz = dtype == 0 ? 4 : 8;
-    hipError_t e = hipMemcpyAsync(d_work, d_samples, per * nblocks * tsz, hipMemcpyDeviceToDevice, s);
+    for (int i = 0; i < ips[0].N; i++) per *= ips[0].dims[i];
+    for (uint32_t j = 0; j < ntrials; j++) {
+        std::vector<szk_interp_pass> sched;
+        if (build_schedule(ips[j], false, 1, sched)) return -1;
+        if (sched.size() > TRIAL_MAX_PASSES) return -2;
+        h_np[j] = (uint32_t)sched.size();
+        memcpy(h_passes + (size_t)j * TRIAL_MAX_PASSES, sched.data(), sched.size() * sizeof(szk_interp_pass));
+    }
+    hipError_t e = hipMemcpyAsync(d_passes, h_passes, (size_t)ntrials * TRIAL_MAX_PASSES * sizeof(szk_interp_pass), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return (int)e;
-    int rc = dtype == 0 ? run_interp<float, false>(*ip, (float *)d_work, codes, s, nblocks)
-                        : run_interp<double, false>(*ip, (double *)d_work, codes, s, nblocks);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_hist_codes, dim3(64), dim3(256), 0, s, codes, per * nblocks, ip->radius, hist);
+    e = hipMemcpyAsync(d_np, h_np, ntrials * 4, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    if (dtype == 0)
+        hipLaunchKernelGGL((k_interp_trials<float>), dim3(nblocks, ntrials), dim3(1024), 0, s, (const float *)d_samples, (float *)d_work, codes,
+                           d_passes, d_np, per, d_hists);
+    else
+        hipLaunchKernelGGL((k_interp_trials<double>), dim3(nblocks, ntrials), dim3(1024), 0, s, (const double *)d_samples, (double *)d_work, codes,
+                           d_passes, d_np, per, d_hists);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
 int szk_launch_code_cost(const uint64_t *hist, const uint8_t *lens, const szk_cb_info *info, const uint64_t *counters, uint64_t *d_res,
-                         hipStream_t s) {
-    hipLaunchKernelGGL(k_code_cost, dim3(SZH_HIST_BINS / 256), dim3(256), 0, s, hist, lens, info, counters, (unsigned long long *)d_res);
+                         uint32_t n_books, hipStream_t s) {
+    hipLaunchKernelGGL(k_code_cost, dim3(SZH_HIST_BINS / 256, n_books), dim3(256), 0, s, hist, lens, info, counters,
+                       (unsigned long long *)d_res);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -68,7 +68,9 @@ struct szk_cb_params {
     uint64_t out_cap;
     int t_is_32bit, q_is_32bit;
     szk_cb_info *info;
+    uint32_t n_books;  // 0/1: one code book (+ the outlier sorts); 2..SZK_MAX_BOOKS: a batch, tables sliced per book
 };
+#define SZK_MAX_BOOKS 4
 
 struct szk_state {
     szh_header hdr;
@@ -126,6 +128,7 @@ struct szk_interp_params {  // what InterpolationDecomposition keeps (decomposit
 };
 struct szk_interp_pass {
     int N, dir, interp_id, old_api, subpass, radius;
+    int kind, reserved;  // 0: anchor grid, 1: first point (no anchors), 2: directional pass
     uint64_t dims[4], off[4], start[4], step[4], cnt[4];
     uint64_t total, s, bsz;
     uint64_t batch_stride;  // elements between the independent arrays of a batch (grid.y), 0 = one array
@@ -143,10 +146,12 @@ int szk_launch_profile_blocks(int dtype, const void *d_in, int N, const uint64_t
                               uint8_t *d_flags, uint64_t *total_out, hipStream_t s);
 int szk_launch_gather_blocks(int dtype, const void *d_in, int N, const uint64_t *dims, uint64_t edge, const uint64_t *d_starts,
                              uint32_t nblocks, void *d_out, hipStream_t s);
-int szk_launch_interp_trial(int dtype, const szk_interp_params *ip, const void *d_samples, void *d_work, uint16_t *codes,
-                            uint32_t nblocks, uint64_t *hist, hipStream_t s);
+#define SZK_TRIAL_MAX_PASSES 64
+int szk_launch_interp_trials(int dtype, const szk_interp_params *ips, uint32_t ntrials, const void *d_samples, void *d_work,
+                             uint16_t *codes, uint32_t nblocks, uint64_t *d_hists, szk_interp_pass *h_passes, szk_interp_pass *d_passes,
+                             uint32_t *h_np, uint32_t *d_np, hipStream_t s);
 int szk_launch_code_cost(const uint64_t *hist, const uint8_t *lens, const szk_cb_info *info, const uint64_t *counters, uint64_t *d_res,
-                         hipStream_t s);
+                         uint32_t n_books, hipStream_t s);
 
 int szk_launch_minmax(int dtype, const void *d_in, uint64_t n, double *d_partial /*[2*1024]*/, double *d_out /*[2]*/, hipStream_t s);
 int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, szk_k1_params *p, hipStream_t s);

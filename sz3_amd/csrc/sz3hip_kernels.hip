@@ -8,9 +8,9 @@
 //                            encoder/HuffmanEncoder.hpp:520-524)
 //   K5  k_codebook          canonical, length-limited Huffman code from the histogram, one workgroup
 //                           (reference: encoder/HuffmanEncoder.hpp:516-561, 478-508)
-//   K6  k_chunk_bits / k_scan_chunks / k_encode   two-pass chunked bit-pack  (reference: HuffmanEncoder.hpp:140-218)
-//   K8  k_dec_tables / k_decode / k_expand_codes / k_scatter_dout / k_scan_x* / k_scan_strided /
-//       k_dequant / k_patch_vout      chunk-parallel Huffman decode, Lorenzo inverse = N-d inclusive prefix sums
+//   K6  k_chunk_bits2 / k_scan_groups / k_pack    two-pass chunked bit-pack  (reference: HuffmanEncoder.hpp:140-218)
+//   K8  k_dec_tables / k_decode / k_scan_x_wave (k_expand_codes, k_scatter_dout, k_scan_x*) / k_scan_strided /
+//       k_scan_strided_dequant / k_patch_vout   chunk-parallel Huffman decode, Lorenzo inverse = N-d inclusive prefix sums
 //                           (reference: HuffmanEncoder.hpp:225-255, BlockwiseDecomposition.hpp:48-67)
 //
 // The reference predicts from already *reconstructed* neighbours (a loop-carried dependency through the whole
@@ -1202,6 +1202,8 @@ __device__ void cb_kraft_repair(uint16_t *pleaf, uint32_t m, uint32_t *s_cnt, ui
 // range of the non-empty histogram bins, many workgroups: range[0] = max(65535 - bin), range[1] = max(bin),
 // range[2] = count of non-empty bins (all three start at 0 and only grow)
 __global__ __launch_bounds__(256) void k_hist_range(const uint64_t *__restrict__ hist, uint32_t *range) {
+    hist += (size_t)blockIdx.y * SZH_HIST_BINS;  // grid.y = code book of a batch
+    range += blockIdx.y * 4;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;  // 256 workgroups x 256 bins
     const bool nz = hist[i] != 0;
     const unsigned long long m = __ballot(nz);
@@ -1390,11 +1392,27 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     __shared__ uint32_t s_misc[8];
     __shared__ unsigned long long s_total;
     const uint32_t t = threadIdx.x;
-    if (blockIdx.x > 0) {  // blocks 1 and 2: deterministic order of the two outlier lists (independent of the code book)
-        const bool d = blockIdx.x == 2;
+    if (blockIdx.x >= p.n_books) {  // the two blocks after the code books: deterministic order of the two outlier lists
+        const bool d = blockIdx.x == p.n_books + 1;
         sort_outlier_list(d ? p.dout_idx : p.vout_idx, d ? p.dout_val : p.vout_val, d ? *p.n_dout : *p.n_vout, p.out_cap,
                           d ? p.q_is_32bit != 0 : p.t_is_32bit != 0, s_pool);
         return;
+    }
+    {  // book b of a batch (the tuner's trials) uses the b-th slice of every table
+        const size_t b = blockIdx.x;
+        hist += b * SZH_HIST_BINS;
+        p.enc += b * SZH_HIST_BINS;
+        p.lens += b * SZH_HIST_BINS;
+        p.keys += b * SZH_HIST_BINS;
+        p.syms += b * SZH_HIST_BINS;
+        p.ifreq += b * SZH_HIST_BINS;
+        p.pleaf += b * SZH_HIST_BINS;
+        p.pint += b * SZH_HIST_BINS;
+        p.depth += b * SZH_HIST_BINS;
+        p.aux2 += b * SZH_HIST_BINS;
+        p.pint2 += b * SZH_HIST_BINS;
+        p.range += b * 4;
+        p.info += b;
     }
     // range and number of the non-empty bins: found by k_hist_range (256 workgroups) just before this launch
     const uint32_t n_nonzero = p.range[2];
@@ -1674,33 +1692,6 @@ __device__ __forceinline__ void load_codes16(const uint16_t *__restrict__ codes,
     } else {
 #pragma unroll
         for (int i = 0; i < ENC_PER_LANE; i++) c[i] = (base + i < n) ? codes[base + i] : (uint16_t)0;
-    }
-}
-
-// exclusive scan of the chunk word counts (one workgroup; n_chunks is n/1024)
-__global__ __launch_bounds__(1024) void k_scan_chunks(const uint16_t *__restrict__ chunk_words, uint64_t n_chunks,
-                                                      uint64_t *__restrict__ chunk_off, uint64_t *total_words) {
-    __shared__ uint64_t s_part[1024];
-    const uint64_t per = (n_chunks + 1023) / 1024;
-    const uint64_t lo = (uint64_t)threadIdx.x * per, hi = (lo + per < n_chunks) ? lo + per : n_chunks;
-    uint64_t s = 0;
-    for (uint64_t i = lo; i < hi; i++) s += chunk_words[i];
-    s_part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t run = 0;
-        for (int i = 0; i < 1024; i++) {
-            uint64_t v = s_part[i];
-            s_part[i] = run;
-            run += v;
-        }
-        *total_words = run;
-    }
-    __syncthreads();
-    uint64_t run = s_part[threadIdx.x];
-    for (uint64_t i = lo; i < hi; i++) {
-        chunk_off[i] = run;
-        run += chunk_words[i];
     }
 }
 
@@ -2498,10 +2489,13 @@ int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, szk_k1
 }
 
 int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(p->range, 0, 16, s);
+    const uint32_t nb = p->n_books ? p->n_books : 1;  // > 1: batch of independent code books (tuner trials), no outlier sort
+    szk_cb_params q = *p;
+    q.n_books = nb;
+    hipError_t e = hipMemsetAsync(q.range, 0, 16 * nb, s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256), dim3(256), 0, s, d_hist, p->range);
-    hipLaunchKernelGGL(k_codebook, dim3(3), dim3(CB_LAUNCH), 0, s, d_hist, *p);
+    hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256, nb), dim3(256), 0, s, d_hist, q.range);
+    hipLaunchKernelGGL(k_codebook, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
     SZK_CHECK_LAUNCH();
     return 0;
 }

@@ -1094,7 +1094,10 @@ extern "C" int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, ui
 }
 
 extern "C" void sz3hip_debug_force_generic(int on) { szk_force_generic = on; }
-extern "C" void sz3hip_debug_flags(int flags) { szk_dbg_flags = flags; }
+extern "C" void sz3hip_debug_flags(int flags) {
+    szk_dbg_flags = flags;
+    szk_interp_novec = (flags & 128) != 0;  // 128: interpolation without the 8-wide level-1 kernels
+}
 extern "C" int sz3hip_debug_codebook_info(sz3hip_ctx *ctx, uint64_t *out16) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipDeviceSynchronize());

@@ -149,6 +149,166 @@ __global__ __launch_bounds__(256) void k_interp_pass(T *__restrict__ w, uint16_t
     interp_point<T, DEC>(w + boff, codes + boff, p, t, boff);
 }
 
+// ---- level 1 (stride 1), cubic, N >= 3, row length a multiple of 8: 8 consecutive x per thread --------------------------
+// The finest level holds 7/8 of all points. One thread owns 8 consecutive elements of a row (two 16-byte accesses per
+// array row it touches) instead of one 4-byte access per neighbour; operands, formulas and their order are exactly those
+// of interp_point, so codes and reconstruction stay bit-identical.
+//   XDIR = false: the pass runs along a slower dimension: the four neighbour rows are loaded as vectors, the case
+//                 (cubic / quad / linear at the line ends) is uniform for the thread; only every xstep-th x is a point.
+//   XDIR = true:  the pass runs along x: a 16-element window [x0 - 4, x0 + 12) supplies the even neighbours of the four odd
+//                 points; the case is chosen per point.
+template <typename T>
+struct Vec8 {
+    T v[8];
+};
+template <typename T>
+__device__ __forceinline__ void ld8(const T *p, T (&o)[8]) {
+    if (sizeof(T) == 4) {
+        const float4 a = reinterpret_cast<const float4 *>(p)[0], b = reinterpret_cast<const float4 *>(p)[1];
+        o[0] = (T)a.x; o[1] = (T)a.y; o[2] = (T)a.z; o[3] = (T)a.w; o[4] = (T)b.x; o[5] = (T)b.y; o[6] = (T)b.z; o[7] = (T)b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double2 a = reinterpret_cast<const double2 *>(p)[k];
+            o[2 * k] = (T)a.x;
+            o[2 * k + 1] = (T)a.y;
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void st8(T *p, const T (&o)[8]) {
+    if (sizeof(T) == 4) {
+        reinterpret_cast<float4 *>(p)[0] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+        reinterpret_cast<float4 *>(p)[1] = make_float4((float)o[4], (float)o[5], (float)o[6], (float)o[7]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) reinterpret_cast<double2 *>(p)[k] = make_double2((double)o[2 * k], (double)o[2 * k + 1]);
+    }
+}
+template <typename T, bool DEC, bool XDIR>
+__global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
+    const int N = p.N;
+    const uint64_t dx = p.dims[N - 1], xg = dx / 8;
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.total) return;  // total = rows * xg here
+    const uint64_t tx = t % xg;
+    uint64_t r = t / xg, idx = 0, cd = 0;
+#pragma unroll
+    for (int j = 2; j >= 0; j--) {
+        if (j >= N - 1) continue;
+        const uint64_t q = r % p.cnt[j];
+        r /= p.cnt[j];
+        const uint64_t c = p.start[j] + q * p.step[j];
+        idx += c * p.off[j];
+        if (j == p.dir) cd = c;
+    }
+    const uint64_t x0 = tx * 8;
+    idx += x0;
+    T o[8];
+    ld8<T>(w + idx, o);
+    uint32_t cw[4];
+    {
+        const uint4 cv = *reinterpret_cast<const uint4 *>(codes + idx);
+        cw[0] = cv.x; cw[1] = cv.y; cw[2] = cv.z; cw[3] = cv.w;
+    }
+    auto get_code = [&](int e) -> int { return (int)((cw[e >> 1] >> (16 * (e & 1))) & 0xFFFFu); };
+    auto set_code = [&](int e, int c) { cw[e >> 1] = (cw[e >> 1] & ~(0xFFFFu << (16 * (e & 1)))) | ((uint32_t)c << (16 * (e & 1))); };
+    auto finish = [&](int e, T pred) {
+        if (DEC) {
+            const int code = get_code(e);
+            if (code) o[e] = ref_recover<T>(pred, code, p.eb, p.radius);
+        } else {
+            T v = o[e];
+            const int code = ref_quantize<T>(v, pred, p.eb, p.eb_recip, p.radius);
+            set_code(e, code);
+            if (code) {
+                o[e] = v;
+            } else {
+                const unsigned long long pos = atomicAdd((unsigned long long *)p.n_vout, 1ull);
+                if (pos < p.out_cap) {
+                    p.vout_idx[pos] = idx + e;
+                    ((T *)p.vout_val)[pos] = v;
+                }
+            }
+        }
+    };
+    if (!XDIR) {
+        const uint64_t D = p.dims[p.dir];
+        const uint64_t begin = (cd / 32) * 32;
+        uint64_t end = begin + 32;
+        if (end > D - 1) end = D - 1;
+        const uint64_t n = end - begin + 1, i = cd - begin;
+        const int64_t st = (int64_t)p.off[p.dir];
+        const int xstep = (int)p.step[N - 1];
+        T a[8], b[8], c[8], d[8];
+        const T *base = w + idx;
+        if (i >= 3) {
+            ld8<T>(base - 3 * st, a);
+            ld8<T>(base - st, b);
+            if (i + 1 < n) ld8<T>(base + st, c);
+            if (i + 3 < n) ld8<T>(base + 3 * st, d);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (e % xstep) continue;
+                T pred;
+                if (i + 3 < n) pred = ip_cubic<T>(a[e], b[e], c[e], d[e]);
+                else if (i + 1 < n) pred = ip_quad_2<T>(a[e], b[e], c[e]);
+                else pred = ip_linear1<T>(a[e], b[e]);
+                finish(e, pred);
+            }
+        } else {
+            ld8<T>(base - st, b);
+            if (i + 1 < n) ld8<T>(base + st, c);
+            if (i + 3 < n) ld8<T>(base + 3 * st, d);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (e % xstep) continue;
+                T pred;
+                if (i + 3 < n) pred = ip_quad_1<T>(b[e], c[e], d[e]);
+                else if (i + 1 < n) pred = ip_linear<T>(b[e], c[e]);
+                else pred = b[e];
+                finish(e, pred);
+            }
+        }
+    } else {
+        // window win[k] = row[x0 - 4 + k], k = 0..15 (outside the row: never used by the case rules below)
+        T win[16];
+        T lo4[8], hi4[8];
+        const T *row = w + idx;  // row + x0
+        if (x0 >= 8) ld8<T>(row - 8, lo4);
+        if (x0 + 8 < dx) ld8<T>(row + 8, hi4);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            win[k] = x0 >= 8 ? lo4[4 + k] : (T)0;
+            win[12 + k] = x0 + 8 < dx ? hi4[k] : (T)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) win[4 + k] = o[k];
+#pragma unroll
+        for (int e = 1; e < 8; e += 2) {
+            const uint64_t cx = x0 + e;
+            const uint64_t begin = (cx / 32) * 32;
+            uint64_t end = begin + 32;
+            if (end > dx - 1) end = dx - 1;
+            const uint64_t n = end - begin + 1, i = cx - begin;
+            const T m3 = win[4 + e - 3], m1 = win[4 + e - 1], p1 = win[4 + e + 1], p3 = win[4 + e + 3];
+            T pred;
+            if (i >= 3) {
+                if (i + 3 < n) pred = ip_cubic<T>(m3, m1, p1, p3);
+                else if (i + 1 < n) pred = ip_quad_2<T>(m3, m1, p1);
+                else pred = ip_linear1<T>(m3, m1);
+            } else {
+                if (i + 3 < n) pred = ip_quad_1<T>(m1, p1, p3);
+                else if (i + 1 < n) pred = ip_linear<T>(m1, p1);
+                else pred = m1;
+            }
+            finish(e, pred);
+        }
+    }
+    st8<T>(w + idx, o);
+    if (!DEC) *reinterpret_cast<uint4 *>(codes + idx) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+}
+
 // anchor grid (build_anchor_grid :215-221): every anchor_stride-th point in each dimension is stored losslessly;
 // without anchors (anchor_stride == 0) the first element is quantised against 0 (:92-93)
 template <typename T>
@@ -259,6 +419,8 @@ static void nth_permutation(int N, int id, int *perm) {  // lexicographic order 
     }
     for (int i = 0; i < N; i++) perm[i] = p[i];
 }
+
+int szk_interp_novec = 0;  // test hook: force the one-point-per-thread kernels
 
 // the level / pass schedule as a list (kind 0: anchor grid, 1: first point without anchors, 2: directional pass)
 static int build_schedule(const szk_interp_params &ip, bool dec, uint32_t nbatch, std::vector<szk_interp_pass> &out) {
@@ -378,7 +540,19 @@ static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStr
     if (build_schedule(ip, DEC, nbatch, sched)) return -1;
     for (const szk_interp_pass &p : sched) {
         const uint32_t nb = (uint32_t)((p.total + 255) / 256);
-        if (p.kind == 2) {
+        const uint64_t dxl = p.dims[p.N - 1];
+        const bool vec = p.kind == 2 && nbatch == 1 && !p.old_api && p.interp_id == 1 && p.s == 1 && dxl % 8 == 0 && dxl >= 16 &&
+                         (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (reinterpret_cast<uintptr_t>(codes) & 15) == 0 && !szk_interp_novec;
+        if (vec) {
+            szk_interp_pass q = p;
+            uint64_t rows = 1;
+            for (int j = 0; j < p.N - 1; j++) rows *= p.cnt[j];
+            q.total = rows * (dxl / 8);
+            const uint64_t vb = (q.total + 255) / 256;
+            if (vb > 0x7FFFFFFFull) return -1;
+            if (p.dir == p.N - 1) hipLaunchKernelGGL((k_interp_vec<T, DEC, true>), dim3((uint32_t)vb), dim3(256), 0, s, w, codes, q);
+            else hipLaunchKernelGGL((k_interp_vec<T, DEC, false>), dim3((uint32_t)vb), dim3(256), 0, s, w, codes, q);
+        } else if (p.kind == 2) {
             hipLaunchKernelGGL((k_interp_pass<T, DEC>), dim3(nb, nbatch), dim3(256), 0, s, w, codes, p);
         } else if (DEC) {
             hipLaunchKernelGGL((k_interp_first_dec<T>), dim3(1), dim3(64), 0, s, w, codes, ip.eb, ip.radius);

@@ -26,6 +26,14 @@ CASES = [
     ("4d-cubic", lambda: field4d((7, 11, 13, 17)), 1e-2, dict(interpAlgo=1)),
     ("4d-linear-dir23", lambda: field4d((5, 20, 33, 40)), 1e-3, dict(interpAlgo=0, interpDirection=23)),
     ("3d-nan", None, 1e-3, dict(interpAlgo=1)),
+    # row lengths that are multiples of 8: the 8-wide level-1 kernels (every direction order puts x at a different place)
+    ("3d-vec-cubic", lambda: field3d((37, 41, 64)), 1e-3, dict(interpAlgo=1)),
+    ("3d-vec-cubic-dir5", lambda: field3d((33, 40, 48)), 1e-4, dict(interpAlgo=1, interpDirection=5)),
+    ("3d-vec-cubic-dir2", lambda: field3d((70, 35, 104)), 1e-3, dict(interpAlgo=1, interpDirection=2, interpAlpha=1.5, interpBeta=3.0)),
+    ("3d-vec-f64", lambda: field3d((20, 30, 40), np.float64, sigma=2e-6), 1e-6, dict(interpAlgo=1)),
+    ("4d-vec-cubic", lambda: field4d((5, 9, 16, 24)), 1e-2, dict(interpAlgo=1)),
+    ("4d-vec-cubic-dir17", lambda: field4d((6, 7, 34, 16)), 1e-3, dict(interpAlgo=1, interpDirection=17)),
+    ("3d-vec-nan", "nan64", 1e-3, dict(interpAlgo=1)),
 ]
 
 
@@ -51,8 +59,8 @@ def _device_roundtrip(a, eb, kw):
 
 @pytest.mark.parametrize("name,gen,eb,kw", CASES, ids=[c[0] for c in CASES])
 def test_interp_bit_exact_with_oracle(name, gen, eb, kw):
-    if gen is None:
-        a = field3d((24, 31, 40))
+    if gen is None or gen == "nan64":
+        a = field3d((24, 31, 40) if gen is None else (24, 31, 64))
         a[3, 4, 5] = np.nan
         a[10, 2, 7] = np.inf
         a[20, 20, 20] = 1e30
@@ -93,3 +101,30 @@ def test_interp_host_api_and_ratio():
     blob, ratio = sz3_amd.compress(a, conf)
     dec, c2 = sz3_amd.decompress(blob, np.float32, a.shape)
     assert c2.cmprAlgo == sz3_amd.ALGO_HIP_INTERP and np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= 1e-3
+
+
+def test_vector_and_scalar_level1_kernels_agree():
+    """debug flag 128 forces the one-point-per-thread kernels: same payload, byte for byte"""
+    a = field3d((48, 56, 128))
+    a[7, 7, 7] = np.nan
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    cap = dc.payload_bound(a.size)
+    pl = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)]
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_INTERP
+    conf.absErrorBound = 1e-3
+    sizes, outs = [], []
+    try:
+        for k, flag in enumerate((0, 128)):
+            sz3_amd.lib().sz3hip_debug_flags(flag)
+            sizes.append(dc.compress(conf, t.data_ptr(), pl[k].data_ptr(), cap, 0))
+            o = torch.empty_like(t)
+            dc.decompress(pl[k].data_ptr(), sizes[-1], o.data_ptr(), 0)
+            torch.cuda.synchronize()
+            outs.append(o)
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(0)
+    assert sizes[0] == sizes[1] and torch.equal(pl[0][:sizes[0]], pl[1][:sizes[1]])
+    assert torch.equal(outs[0], outs[1], ) or bool(((outs[0] == outs[1]) | (outs[0].isnan() & outs[1].isnan())).all())

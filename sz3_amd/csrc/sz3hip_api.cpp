@@ -1136,6 +1136,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     dp.n = h.n;
     dp.n_chunks = h.n_chunks;
     dp.bitstream_off = o.bitstream;
+    dp.total_words = h.bitstream_words;
     dp.chunk_words = (const uint16_t *)(pl + o.chunkwords);
     dp.group_off = ctx->d_chunk_off;
     dp.tables = ctx->d_tables;

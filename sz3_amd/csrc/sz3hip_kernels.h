@@ -107,7 +107,7 @@ struct szk_dec_tables {
 };
 struct szk_dec_params {
     uint64_t n, n_chunks;
-    uint64_t bitstream_off;
+    uint64_t bitstream_off, total_words;  // the bit-stream section of the payload and its length in 32-bit words
     const uint16_t *chunk_words;  // inside the payload
     const uint64_t *group_off;    // word offset of every group of 32 chunks (k_scan_groups)
     const szk_dec_tables *tables;

@@ -2107,24 +2107,42 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     const uint64_t grp = chunk / PACK_GROUP;
     uint64_t woff = p.group_off[grp];
     for (uint64_t c = grp * PACK_GROUP; c < chunk; c++) woff += p.chunk_words[c];
-    const uint32_t *in = reinterpret_cast<const uint32_t *>(payload + p.bitstream_off) + woff;
+    const uint32_t *bs = reinterpret_cast<const uint32_t *>(payload + p.bitstream_off);
     const uint16_t *sorted = p.tables->sorted_syms;
     const uint32_t nwords = p.chunk_words[chunk];
+    const uint64_t wlast = p.total_words ? p.total_words - 1 : 0;  // loads are clamped to the section, never conditional
     uint64_t buf = 0;  // next bits at the MSB end
     int have = 0;
     uint32_t wi = 0;
-    uint32_t wnext = nwords ? in[0] : 0u;  // one word ahead
     for (uint32_t i0 = 0; i0 < nsym; i0 += 16) {
+        // the next four stream words of this lane, fetched once per 16 symbols with one wait (a load issued inside the
+        // divergent refill branch would be waited for at every symbol); typical groups consume 2-3 words, longer ones
+        // fall back to single loads
+        uint32_t qw[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t a = woff + wi + k;
+            qw[k] = bs[a < wlast ? a : wlast];
+        }
+        uint32_t qn = 0;
         uint32_t packed[8];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             uint32_t sym = 0;
             if (i0 + k < nsym) {
                 if (have <= 32) {
-                    buf |= (uint64_t)wnext << (32 - have);
+                    uint32_t wd;
+                    if (qn < 4) {
+                        wd = qn == 0 ? qw[0] : (qn == 1 ? qw[1] : (qn == 2 ? qw[2] : qw[3]));
+                    } else {
+                        const uint64_t a = woff + wi;
+                        wd = bs[a < wlast ? a : wlast];
+                    }
+                    wd = wi < nwords ? wd : 0u;
+                    qn++;
+                    buf |= (uint64_t)wd << (32 - have);
                     have += 32;
                     wi++;
-                    wnext = wi < nwords ? in[wi] : 0u;
                 }
                 const uint32_t ent = s_lut[(uint32_t)(buf >> (64 - K))];
                 uint32_t l = ent & 0xFFu;

@@ -432,7 +432,9 @@ template <class T>
 inline int dtype_of() {
     if (std::is_same<T, float>::value) return SZ3HIP_FLOAT;
     if (std::is_same<T, double>::value) return SZ3HIP_DOUBLE;
-    throw std::invalid_argument("SZ3 (HIP path): only float and double arrays are accelerated; integer types are not supported by libsz3hip");
+    if (std::is_same<T, int32_t>::value) return SZ3HIP_INT32;
+    if (std::is_same<T, int64_t>::value || (std::is_integral<T>::value && std::is_signed<T>::value && sizeof(T) == 8)) return SZ3HIP_INT64;
+    throw std::invalid_argument("SZ3 (HIP path): float, double, int32 and int64 arrays are supported by libsz3hip");
 }
 [[noreturn]] inline void raise_last(int code) {
     const std::string msg = sz3hip_last_error();

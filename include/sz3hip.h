@@ -33,6 +33,8 @@ extern "C" {
 /* data types: include/SZ3/utils/Config.hpp:27-36 */
 #define SZ3HIP_FLOAT 0
 #define SZ3HIP_DOUBLE 1
+#define SZ3HIP_INT32 7 /* host-buffer API only: integers ride the f64 pipeline (exact; int64 beyond 2^53 -> lossless) */
+#define SZ3HIP_INT64 9
 
 /* error-bound modes: include/SZ3/utils/Config.hpp:66 (enum EB) */
 enum { SZ3HIP_EB_ABS = 0, SZ3HIP_EB_REL, SZ3HIP_EB_PSNR, SZ3HIP_EB_L2NORM, SZ3HIP_EB_ABS_AND_REL, SZ3HIP_EB_ABS_OR_REL };

@@ -138,10 +138,14 @@ def _check(rc):
 def _dtype_id(dt):
     dt = np.dtype(dt)
     if dt == np.float32:
-        return SZ_FLOAT
+        return 0
     if dt == np.float64:
-        return SZ_DOUBLE
-    raise TypeError("sz3_amd supports float32 / float64 (got %s)" % dt)
+        return 1
+    if dt == np.int32:   # host-buffer API only (compress / decompress): integers ride the f64 pipeline
+        return 7
+    if dt == np.int64:
+        return 9
+    raise TypeError("sz3_amd supports float32 / float64 / int32 / int64 (got %s)" % dt)
 
 
 class Config:

@@ -1173,10 +1173,15 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
 static const uint32_t kMagic = 0xF342F310u;                          // include/SZ3/version.hpp.in:10
 static const uint32_t kDataVer = (3u << 24) | (3u << 16) | (2u << 8);  // SZ3_DATA_VERSION 3.3.2 (CMakeLists.txt:7)
 
+static inline bool dtype_ok(int dt) { return dt == SZ3HIP_FLOAT || dt == SZ3HIP_DOUBLE || dt == SZ3HIP_INT32 || dt == SZ3HIP_INT64; }
+static inline bool dtype_is_int(int dt) { return dt == SZ3HIP_INT32 || dt == SZ3HIP_INT64; }
+static inline size_t dtype_size(int dt) { return (dt == SZ3HIP_FLOAT || dt == SZ3HIP_INT32) ? 4 : 8; }
+static inline int dtype_compute(int dt) { return dtype_is_int(dt) ? SZ3HIP_DOUBLE : dt; }  // integers ride the f64 pipeline
+
 extern "C" size_t sz3hip_compress_bound(const sz3hip_config *c, int dataType) {  // api/impl/SZImpl.hpp:34-44
     if (zs::load()) return 0;
     unsigned char tmp[160];
-    const size_t es = dataType == SZ3HIP_FLOAT ? 4 : 8;
+    const size_t es = dtype_size(dataType);
     return 4096 + sz3hip_config_save(c, tmp) + zs::bound_frames((size_t)c->num * es);
 }
 
@@ -1238,10 +1243,12 @@ static int cal_abs_eb(sz3hip_config &conf, sz3hip_ctx *ctx, const void *d_in) {
 
 extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, const void *data, char *cmpData,
                                   size_t cmpCap) {
-    if (dataType != SZ3HIP_FLOAT && dataType != SZ3HIP_DOUBLE) {
-        fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float / double only)", dataType);
+    if (!dtype_ok(dataType)) {
+        fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
         return 0;
     }
+    const bool is_int = dtype_is_int(dataType);
+    const int cdt = dtype_compute(dataType);  // the type the kernels compute in
     sz3hip_config conf = *config;  // sz.hpp:45
     if (conf.N < 1 || conf.N > 4) {
         fail(SZ3HIP_EINVAL, "Data dimension higher than 4 is not supported.");
@@ -1252,7 +1259,7 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
         fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
         return 0;
     }
-    const size_t es = dataType == SZ3HIP_FLOAT ? 4 : 8;
+    const size_t es = dtype_size(dataType);
     const size_t raw_bytes = (size_t)conf.num * es;
     unsigned char *out = reinterpret_cast<unsigned char *>(cmpData);
     Writer w{out};
@@ -1267,21 +1274,47 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
     std::lock_guard<std::mutex> lock(g_ctx_mu);
     bool lossless = conf.cmprAlgo == SZ3HIP_ALGO_LOSSLESS;
     if (!lossless) {
-        sz3hip_ctx *ctx = get_ctx(dataType, conf.num);
+        sz3hip_ctx *ctx = get_ctx(cdt, conf.num);
         if (!ctx) return 0;
-        if (ensure_dev(&g_dev_in[dataType], &g_dev_in_bytes[dataType], raw_bytes)) return 0;
+        if (ensure_dev(&g_dev_in[cdt], &g_dev_in_bytes[cdt], (size_t)conf.num * (cdt == SZ3HIP_FLOAT ? 4 : 8))) return 0;
         const size_t pb = sz3hip_payload_bound(ctx, conf.num);
-        if (ensure_dev(&g_dev_payload[dataType], &g_dev_payload_bytes[dataType], pb)) return 0;
-        if (hipMemcpy(g_dev_in[dataType], data, raw_bytes, hipMemcpyHostToDevice) != hipSuccess) {
-            fail(SZ3HIP_EHIP, "host->device copy failed");
-            return 0;
+        if (ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], pb)) return 0;
+        if (!is_int) {
+            if (hipMemcpy(g_dev_in[cdt], data, raw_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+                fail(SZ3HIP_EHIP, "host->device copy failed");
+                return 0;
+            }
+        } else {
+            // integers: staged in the (still unused) payload buffer, widened to f64 on the device
+            if (pb < raw_bytes + 16 && ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], raw_bytes + 16)) return 0;
+            if (hipMemcpy(g_dev_payload[cdt], data, raw_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemsetAsync(ctx->d_counters + 5, 0, 8, nullptr) != hipSuccess) {
+                fail(SZ3HIP_EHIP, "host->device copy failed");
+                return 0;
+            }
+            if (szk_launch_int_to_f64(dataType == SZ3HIP_INT64, g_dev_payload[cdt], conf.num, (double *)g_dev_in[cdt],
+                                      reinterpret_cast<uint32_t *>(ctx->d_counters + 5), nullptr)) {
+                fail(SZ3HIP_EHIP, "integer widening kernel failed");
+                return 0;
+            }
+            uint32_t big = 0;
+            if (hipMemcpy(&big, ctx->d_counters + 5, 4, hipMemcpyDeviceToHost) != hipSuccess) {
+                fail(SZ3HIP_EHIP, "device->host copy failed");
+                return 0;
+            }
+            if (big) lossless = true;  // |x| > 2^53 is not exact in f64: keep such arrays lossless
         }
-        if (cal_abs_eb(conf, ctx, g_dev_in[dataType])) return 0;
+        if (!lossless && cal_abs_eb(conf, ctx, g_dev_in[cdt])) return 0;
+        if (is_int) {
+            // |x - x^| <= eb between integers means <= floor(eb); the lattice 2*floor(eb) keeps every reconstruction integral
+            conf.absErrorBound = std::floor(conf.absErrorBound);
+            conf.errorBoundMode = SZ3HIP_EB_ABS;
+        }
         if (conf.absErrorBound == 0) lossless = true;  // SZDispatcher.hpp:19-21
         if (!lossless) {
             // ALGO_LORENZO_REG / NOPRED -> HIP Lorenzo stream (16); ALGO_INTERP / ALGO_INTERP_LORENZO -> HIP interpolation (17)
             size_t dsize = 0;
-            int rc = sz3hip_compress_device(ctx, &conf, g_dev_in[dataType], g_dev_payload[dataType], pb, &dsize, nullptr);
+            int rc = sz3hip_compress_device(ctx, &conf, g_dev_in[cdt], g_dev_payload[cdt], g_dev_payload_bytes[cdt], &dsize, nullptr);
             if (rc == SZ3HIP_EOUTLIERS) {
                 lossless = true;  // same policy as the reference's length_error fallback, SZDispatcher.hpp:44-59
             } else if (rc) {
@@ -1290,7 +1323,7 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
                 lossless = true;  // the GPU stream would not even beat the raw array (tiny or incompressible input)
             } else {
                 std::vector<uint8_t> host_payload(dsize);
-                if (hipMemcpy(host_payload.data(), g_dev_payload[dataType], dsize, hipMemcpyDeviceToHost) != hipSuccess) {
+                if (hipMemcpy(host_payload.data(), g_dev_payload[cdt], dsize, hipMemcpyDeviceToHost) != hipSuccess) {
                     fail(SZ3HIP_EHIP, "device->host copy failed");
                     return 0;
                 }
@@ -1318,6 +1351,7 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
     memcpy(size_pos, &ps, 8);
     w.p += payload_size;
     conf.openmp = 0;
+    conf.dataType = (uint8_t)dataType;  // lets the decoder refuse a request for another element type
     w.p += sz3hip_config_save(&conf, w.p);
     return (size_t)(w.p - out);
 }
@@ -1338,16 +1372,21 @@ extern "C" int sz3hip_peek_config(sz3hip_config *conf, const char *cmpData, size
 }
 
 extern "C" int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *cmpData, size_t cmpSize, void *decData) {
-    if (dataType != SZ3HIP_FLOAT && dataType != SZ3HIP_DOUBLE)
-        return fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float / double only)", dataType);
+    if (!dtype_ok(dataType))
+        return fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
     int rc = sz3hip_peek_config(conf, cmpData, cmpSize);
     if (rc) return rc;
+    const bool is_int = dtype_is_int(dataType);
+    const int cdt = dtype_compute(dataType);
+    if (dtype_is_int(conf->dataType) != is_int)
+        return fail(SZ3HIP_EINVAL, "the stream holds %s data but %s output was requested", dtype_is_int(conf->dataType) ? "integer" : "floating-point",
+                    is_int ? "integer" : "floating-point");
     if (zs::load()) return SZ3HIP_EZSTD;
     const unsigned char *p = reinterpret_cast<const unsigned char *>(cmpData) + 8;
     uint64_t payload;
     memcpy(&payload, p, 8);
     p += 8;
-    const size_t es = dataType == SZ3HIP_FLOAT ? 4 : 8;
+    const size_t es = dtype_size(dataType);
     const size_t raw_bytes = (size_t)conf->num * es;
     if (conf->cmprAlgo == SZ3HIP_ALGO_LOSSLESS) {  // SZDispatcher.hpp:81-88
         uint64_t len = 0;
@@ -1367,16 +1406,24 @@ extern "C" int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *
     std::vector<uint8_t> host_payload(raw_len);
     if (zs::decompress_frames(p, payload, host_payload.data(), raw_len) != raw_len) return SZ3HIP_EZSTD;
     std::lock_guard<std::mutex> lock(g_ctx_mu);
-    sz3hip_ctx *ctx = get_ctx(dataType, conf->num);
+    sz3hip_ctx *ctx = get_ctx(cdt, conf->num);
     if (!ctx) return SZ3HIP_EHIP;
-    if ((rc = ensure_dev(&g_dev_in[dataType], &g_dev_in_bytes[dataType], raw_bytes))) return rc;
-    if ((rc = ensure_dev(&g_dev_payload[dataType], &g_dev_payload_bytes[dataType], raw_len + 64))) return rc;
-    HIPCHK(hipMemcpy(g_dev_payload[dataType], host_payload.data(), raw_len, hipMemcpyHostToDevice));
-    rc = sz3hip_decompress_device(ctx, g_dev_payload[dataType], raw_len, g_dev_in[dataType], nullptr);
+    const size_t cbytes = (size_t)conf->num * (cdt == SZ3HIP_FLOAT ? 4 : 8);
+    if ((rc = ensure_dev(&g_dev_in[cdt], &g_dev_in_bytes[cdt], cbytes))) return rc;
+    if ((rc = ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], std::max<size_t>(raw_len + 64, is_int ? raw_bytes : 0)))) return rc;
+    HIPCHK(hipMemcpy(g_dev_payload[cdt], host_payload.data(), raw_len, hipMemcpyHostToDevice));
+    rc = sz3hip_decompress_device(ctx, g_dev_payload[cdt], raw_len, g_dev_in[cdt], nullptr);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(nullptr));
     if (ctx->h_state->hdr.n != conf->num) return fail(SZ3HIP_EFORMAT, "payload element count does not match the trailer");
-    HIPCHK(hipMemcpy(decData, g_dev_in[dataType], raw_bytes, hipMemcpyDeviceToHost));
+    if (ctx->h_state->hdr.dtype != (uint8_t)cdt) return fail(SZ3HIP_EINVAL, "the stream's element type does not match the requested one");
+    if (!is_int) {
+        HIPCHK(hipMemcpy(decData, g_dev_in[cdt], raw_bytes, hipMemcpyDeviceToHost));
+    } else {
+        rc = szk_launch_f64_to_int(dataType == SZ3HIP_INT64, (const double *)g_dev_in[cdt], conf->num, g_dev_payload[cdt], nullptr);
+        if (rc) return fail(SZ3HIP_EHIP, "integer narrowing kernel failed");
+        HIPCHK(hipMemcpy(decData, g_dev_payload[cdt], raw_bytes, hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 

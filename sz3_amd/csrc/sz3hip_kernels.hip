@@ -2394,6 +2394,42 @@ static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap) {
     return (uint32_t)g;
 }
 
+// ---- integer inputs ride the f64 pipeline (int32 exactly; int64 exactly up to 2^53 in magnitude) --------------------
+template <typename I>
+__global__ __launch_bounds__(256) void k_int_to_f64(const I *__restrict__ in, uint64_t n, double *__restrict__ out, uint32_t *too_big) {
+    bool big = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const I v = in[i];
+        if (sizeof(I) == 8) {
+            const long long a = (long long)v;
+            big |= a > (1ll << 53) || a < -(1ll << 53);
+        }
+        out[i] = (double)v;
+    }
+    if (__ballot(big) && (threadIdx.x & 63) == 0) atomicOr(too_big, 1u);
+}
+template <typename I>
+__global__ __launch_bounds__(256) void k_f64_to_int(const double *__restrict__ in, uint64_t n, I *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const double v = rint(in[i]);
+        out[i] = sizeof(I) == 4 ? (I)(long long)fmin(fmax(v, -2147483648.0), 2147483647.0) : (I)(long long)v;
+    }
+}
+int szk_launch_int_to_f64(int is64, const void *d_in, uint64_t n, double *d_out, uint32_t *d_flag, hipStream_t s) {
+    const uint32_t g = grid_for(n, 256, 65536);
+    if (is64) hipLaunchKernelGGL((k_int_to_f64<int64_t>), dim3(g), dim3(256), 0, s, (const int64_t *)d_in, n, d_out, d_flag);
+    else hipLaunchKernelGGL((k_int_to_f64<int32_t>), dim3(g), dim3(256), 0, s, (const int32_t *)d_in, n, d_out, d_flag);
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
+int szk_launch_f64_to_int(int is64, const double *d_in, uint64_t n, void *d_out, hipStream_t s) {
+    const uint32_t g = grid_for(n, 256, 65536);
+    if (is64) hipLaunchKernelGGL((k_f64_to_int<int64_t>), dim3(g), dim3(256), 0, s, d_in, n, (int64_t *)d_out);
+    else hipLaunchKernelGGL((k_f64_to_int<int32_t>), dim3(g), dim3(256), 0, s, d_in, n, (int32_t *)d_out);
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
+
 int szk_launch_minmax(int dtype, const void *d_in, uint64_t n, double *d_partial, double *d_out, hipStream_t s) {
     const int nb = 1024;
     if (dtype == 0) hipLaunchKernelGGL(k_minmax<float>, dim3(nb), dim3(256), 0, s, (const float *)d_in, n, d_partial);

@@ -71,7 +71,7 @@ def test_fails_loudly_without_device():
     with pytest.raises(sz3_amd.SZ3HipError):
         sz3_amd.DeviceCompressor(512, np.float32)
     with pytest.raises(TypeError):
-        sz3_amd.compress(a.astype(np.int32), sz3_amd.Config(8, 8, 8))
+        sz3_amd.compress(a.astype(np.uint8), sz3_amd.Config(8, 8, 8))
 
 
 def test_peek_rejects_foreign_streams():

@@ -313,3 +313,35 @@ def test_c5_shaped_4d_rel_roundtrip(algo):
     eb = 1e-3 * (float(a.max()) - float(a.min()))
     assert c2.absErrorBound == pytest.approx(eb, rel=1e-6)
     assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= c2.absErrorBound and ratio > 4
+
+
+def test_integer_inputs_ride_the_f64_pipeline():
+    """int32 / int64 arrays (tools/sz3/sz3.cpp:458-461 instantiates SZ_compress<int32_t/int64_t>): |x - x^| <= floor(eb)
+    between integers; a bound below 1 and int64 magnitudes beyond 2^53 fall back to the lossless stream"""
+    rng = np.random.default_rng(3)
+    base = (1000 * field3d((40, 48, 56))).astype(np.int64) + rng.integers(-3, 4, (40, 48, 56))
+    for dt in (np.int32, np.int64):
+        a = base.astype(dt)
+        for algo in (sz3_amd.ALGO_LORENZO_REG, sz3_amd.ALGO_INTERP):
+            conf = sz3_amd.Config(*a.shape)
+            conf.cmprAlgo = algo
+            conf.absErrorBound = 4.7
+            blob, ratio = sz3_amd.compress(a, conf)
+            dec, c2 = sz3_amd.decompress(blob, dt, a.shape)
+            assert dec.dtype == dt and c2.absErrorBound == 4.0 and c2.cmprAlgo in (sz3_amd.ALGO_HIP_LORENZO, sz3_amd.ALGO_HIP_INTERP)
+            assert np.max(np.abs(dec.astype(np.int64) - a.astype(np.int64))) <= 4 and ratio > 2
+        conf = sz3_amd.Config(*a.shape)
+        conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+        conf.absErrorBound = 0.5                      # floor -> 0 -> lossless (SZDispatcher.hpp:19-21)
+        blob, _ = sz3_amd.compress(a, conf)
+        dec, c2 = sz3_amd.decompress(blob, dt, a.shape)
+        assert c2.cmprAlgo == sz3_amd.ALGO_LOSSLESS and np.array_equal(dec, a)
+        with pytest.raises(sz3_amd.SZ3HipError):
+            sz3_amd.decompress(sz3_amd.compress(a, sz3_amd.Config(*a.shape))[0], np.float64, a.shape)
+    big = base.copy()
+    big[1, 2, 3] = (1 << 60) + 12345
+    conf = sz3_amd.Config(*big.shape)
+    conf.absErrorBound = 2.0
+    blob, _ = sz3_amd.compress(big, conf)
+    dec, c2 = sz3_amd.decompress(blob, np.int64, big.shape)
+    assert c2.cmprAlgo == sz3_amd.ALGO_LOSSLESS and np.array_equal(dec, big)

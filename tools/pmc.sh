@@ -13,3 +13,7 @@ grep metric $R/gpurun_out/prof_stats.log | cut -c1-300
 # summaries for profiles/ (copied there by hand after a look)
 python $R/tools/pmc_summary.py $R/gpurun_out/pmc_fetch/*counter_collection.csv $R/gpurun_out/pmc_write/*counter_collection.csv $R/gpurun_out/pmc_sq/*counter_collection.csv $R/gpurun_out/pmc_lds/*counter_collection.csv > $R/gpurun_out/pmc_summary.txt 2>&1
 cp $R/gpurun_out/prof_stats/*kernel_stats.csv $R/gpurun_out/kernel_stats.csv 2>/dev/null
+# C3 (ALGO_INTERP_LORENZO) kernel stats
+B3="python $R/bench.py --algo interp --eb 1e-4 --steps 10 --warmup 2 --no-cpu-baseline --no-host-e2e"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats_c3 -o r -- $B3 > $R/gpurun_out/prof_stats_c3.log 2>&1
+cp $R/gpurun_out/prof_stats_c3/*kernel_stats.csv $R/gpurun_out/kernel_stats_c3.csv 2>/dev/null

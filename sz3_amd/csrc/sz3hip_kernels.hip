@@ -857,7 +857,9 @@ __global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict_
 // ------------------------------------------------------------------------------------------------------------
 #define CB_THREADS 256       // threads of the small-alphabet path
 #define CB_LAUNCH 1024       // threads per workgroup of the launch
-#define CB_LDS_SYMS 2048     // small-alphabet path: everything LDS-resident
+#define CB_LDS_SYMS 2048     // capacity of the small-alphabet path's LDS arrays
+#define CB_SMALL_SYMS 256    // alphabets up to this size take the small path (serial wave merge: ~0.1 us per symbol);
+                             // beyond it the round-parallel merge of the wide path wins (37 us for 2000 symbols)
 #define CB_POOL_BYTES 131072 // LDS pool, carved per phase
 #define CB_SHORT_SYMS 512    // alphabets up to this size are limited to 16-bit code words
 #define ENC_WIN 4096         // symbols of the encode table the packers cache in LDS (window around the most frequent symbol)
@@ -1311,7 +1313,7 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
     if (t == 0) p.info->ts[4] = wall_clock64();
     // 4. depth of every internal node by pointer doubling (min(depth, 2^rounds) is all the clamp needs); the four
     //    u16 arrays ping-pong in the LDS pool when they fit (m <= 16384), else in global memory
-    const uint32_t L = SZH_MAX_LEN;
+    const uint32_t L = m <= CB_SHORT_SYMS ? 16u : SZH_MAX_LEN;
     {
         const bool in_lds = m <= CB_POOL_BYTES / 8;
         uint16_t *dA = in_lds ? reinterpret_cast<uint16_t *>(pool) : aux, *pA = in_lds ? dA + CB_POOL_BYTES / 8 : pint;
@@ -1427,7 +1429,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
         return;
     }
     const uint32_t lo = 0xFFFFu - p.range[0], range = p.range[1] - lo + 1;  // range[0] = max(65535 - bin), range[1] = max bin
-    const bool small = n_nonzero <= CB_LDS_SYMS;
+    const bool small = n_nonzero <= CB_SMALL_SYMS;
     if (small && t >= CB_THREADS) return;  // the small path runs on 4 waves (cheap barriers)
     if (t == 0) p.info->ts[0] = wall_clock64();
     if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;

@@ -686,6 +686,8 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     const uint32_t win_lo = (uint32_t)(radius - HIST_WIN / 2);
     const uint32_t copy = (uint32_t)lane & 3u;
     const bool narrow = szk_is_narrow(p.mode);
+    // in-range test of a delta, one form for both code widths: (delta + rng_lo) <= rng_span (unsigned)
+    const UQ rng_lo = narrow ? (UQ)127 : (UQ)(radius - 1), rng_span = narrow ? (UQ)254 : (UQ)(2 * radius - 2);
     uint8_t *codes8 = reinterpret_cast<uint8_t *>(codes);
 
     for (int i = threadIdx.x; i < HIST_WIN * 4 + 4; i += 256) lh[i] = 0;
@@ -704,6 +706,9 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
         const bool xok = x < d0;            // quad granular (d0 % 4 == 0)
         const bool has_left = x0 > 0;       // lane 0 needs element x0 - 1
         const uint32_t ny = (d1 - y0 < (uint32_t)TY) ? d1 - y0 : (uint32_t)TY;
+        // per-lane element offsets inside a row, fixed for the task: own quad, and the element left of it (lane 0 of a tile
+        // that has a left neighbour reads x0 - 1; the other lanes' values are never used)
+        const uint32_t lane_off = xok ? x : 0u, left_off = (xok && x > 0) ? x - 1 : 0u;
 
         UQ pp[NW][TY][4];  // d2 of the previous plane
 #pragma unroll
@@ -723,14 +728,16 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
 #pragma unroll
             for (int lw = 0; lw < NW; lw++) {
                 const bool wok = (int)w - lw >= 0;
-                const T *src = in + (uint64_t)(wok ? w - lw : 0) * vol + (uint64_t)gz * plane;
+                const T *src = in + (uint64_t)(wok ? w - lw : 0) * vol + (uint64_t)gz * plane;  // wave-uniform
 #pragma unroll
                 for (int r = 0; r <= TY; r++) {
                     const int gy = (int)y0 + r - 1;
                     const bool rok = wok && gy >= 0 && (uint32_t)gy < d1;
-                    const T *row = src + (uint64_t)(rok ? gy : 0) * d0;
-                    rq[lw][r].load((rok && xok) ? row + x : in);
-                    rl[lw][r] = *((rok && has_left && lane == 0) ? row + (x0 - 1) : in);
+                    // rows outside the array are read from row 0 of the plane (valid memory) and masked below:
+                    // the row offset is wave-uniform (scalar unit), only the lane offset is per-lane
+                    const T *row = src + (uint64_t)(rok ? (uint32_t)gy : 0u) * d0;
+                    rq[lw][r].load(row + lane_off);
+                    rl[lw][r] = row[left_off];
                 }
             }
             // ---- rows ----
@@ -783,7 +790,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const UQ shifted = delta[i] + (UQ)radius;  // in (0, 2r) when |delta| < r
-                    const bool inr = narrow ? (UQ)(delta[i] + 127) <= (UQ)254 : (UQ)(shifted - 1) < (UQ)(2 * radius - 1);
+                    const bool inr = (UQ)(delta[i] + rng_lo) <= rng_span;
                     code[i] = inr ? (uint32_t)shifted : 0u;
                     uint32_t bin = code[i] - win_lo;           // wraps to a huge value below the window
                     bin = bin < (uint32_t)HIST_WIN ? bin : (uint32_t)HIST_WIN;

@@ -1767,6 +1767,7 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
                                                      const szk_cb_info *__restrict__ info, szk_mode mode, uint32_t sym_add,
                                                      uint16_t *__restrict__ chunk_words) {
     __shared__ uint32_t s_enc[ENC_WIN];
+    __shared__ uint8_t s_len8[256];  // one-byte codes: code length by byte value (no symbol arithmetic per element)
     const bool narrow = szk_is_narrow(mode);
     const uint64_t n_full = n / SZH_CHUNK_SYMS, n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
     const uint64_t wave_gid = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE, nwaves = (uint64_t)gridDim.x * 4;
@@ -1777,18 +1778,34 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
     const uint32_t sym_min = info->win_lo, sym_count = info->sym_count;  // sym_min: start of the LDS window
     const bool all_lds = sym_count <= ENC_WIN;
     enc_table_load(s_enc, g_enc, sym_min, sym_count);
+    if (narrow) s_len8[threadIdx.x] = (uint8_t)(g_enc[threadIdx.x ? threadIdx.x + sym_add : 0u] & 31u);
     __syncthreads();
-    for (; chunk < n_full; chunk += nwaves) {
-        const uint64_t nc = chunk + nwaves;
-        if (nc < n_full) fetch_codes(codes, nc * SZH_CHUNK_SYMS + lane_off, narrow, nxt);
-        uint16_t c[ENC_PER_LANE];
-        unpack_codes(cur, narrow, sym_add, c);
-        uint32_t bits = 0;
+    if (narrow) {
+        for (; chunk < n_full; chunk += nwaves) {
+            const uint64_t nc = chunk + nwaves;
+            if (nc < n_full) fetch_codes(codes, nc * SZH_CHUNK_SYMS + lane_off, narrow, nxt);
+            const uint32_t wds[4] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w};
+            uint32_t bits = 0;
 #pragma unroll
-        for (int i = 0; i < ENC_PER_LANE; i++) bits += enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[i]) & 31u;
-        bits = wave_sum(bits);
-        if (lane_id() == 0) chunk_words[chunk] = (uint16_t)((bits + 31) >> 5);
-        cur = nxt;
+            for (int k = 0; k < 4; k++)
+                bits += (uint32_t)s_len8[wds[k] & 0xFFu] + s_len8[(wds[k] >> 8) & 0xFFu] + s_len8[(wds[k] >> 16) & 0xFFu] + s_len8[wds[k] >> 24];
+            bits = wave_sum(bits);
+            if (lane_id() == 0) chunk_words[chunk] = (uint16_t)((bits + 31) >> 5);
+            cur = nxt;
+        }
+    } else {
+        for (; chunk < n_full; chunk += nwaves) {
+            const uint64_t nc = chunk + nwaves;
+            if (nc < n_full) fetch_codes(codes, nc * SZH_CHUNK_SYMS + lane_off, narrow, nxt);
+            uint16_t c[ENC_PER_LANE];
+            unpack_codes(cur, narrow, sym_add, c);
+            uint32_t bits = 0;
+#pragma unroll
+            for (int i = 0; i < ENC_PER_LANE; i++) bits += enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[i]) & 31u;
+            bits = wave_sum(bits);
+            if (lane_id() == 0) chunk_words[chunk] = (uint16_t)((bits + 31) >> 5);
+            cur = nxt;
+        }
     }
     if (n_full < n_chunks && wave_gid == 0) {  // ragged tail
         const uint64_t base = n_full * SZH_CHUNK_SYMS + lane_off;

@@ -1865,7 +1865,7 @@ __global__ __launch_bounds__(1024) void k_scan_groups(const uint16_t *__restrict
 // pack 16 symbols of a lane into the wave's LDS stage at the lane's bit offset; returns the chunk's word count.
 // G code words are joined per 64-bit register: G = 4 when the code book's longest word is <= 16 bits, else G = 2
 // (<= 24 bits each); every register is emitted left-aligned at its bit offset with three ds_or.
-template <int G>
+template <int G, bool BYTE = false>  // BYTE: c[] are one-byte codes and s_enc is the 256-entry table indexed by them
 __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE], uint64_t base, uint64_t n, bool check_n,
                                                const uint32_t *s_enc, const uint32_t *__restrict__ g_enc,
                                                uint32_t sym_min, bool all_lds, uint32_t *stage) {
@@ -1880,8 +1880,8 @@ __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE]
         uint32_t pl[G / 2];
 #pragma unroll
         for (int h = 0; h < G / 2; h++) {
-            uint32_t e0 = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h]);
-            uint32_t e1 = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h + 1]);
+            uint32_t e0 = BYTE ? s_enc[c[G * k + 2 * h]] : enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h]);
+            uint32_t e1 = BYTE ? s_enc[c[G * k + 2 * h + 1]] : enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h + 1]);
             if (check_n) {
                 e0 = (base + G * k + 2 * h < n) ? e0 : 0u;
                 e1 = (base + G * k + 2 * h + 1 < n) ? e1 : 0u;
@@ -1926,6 +1926,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
                                               const szk_state *__restrict__ state, uint8_t *__restrict__ payload) {
     constexpr int STAGE_WORDS = SZH_CHUNK_SYMS * SZH_MAX_LEN / 32 + 4;  // + slack for the unconditional 3-word emit
     __shared__ uint32_t s_enc[ENC_WIN];
+    __shared__ uint32_t s_enc8[256];  // one-byte codes: encode entry by byte value
     __shared__ uint32_t s_stage[4][STAGE_WORDS];
     const bool narrow = szk_is_narrow(mode);
     const uint64_t n_full = n / SZH_CHUNK_SYMS, n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
@@ -1955,6 +1956,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     const bool all_lds = sym_count <= ENC_WIN;
     const bool wide = info->max_len > 16;  // two instead of four code words per 64-bit register
     enc_table_load(s_enc, g_enc, sym_min, sym_count);
+    if (narrow) s_enc8[threadIdx.x] = g_enc[threadIdx.x ? threadIdx.x + sym_add : 0u];
     for (int i = lane; i < STAGE_WORDS; i += WAVE) stage[i] = 0;
     __syncthreads();
     for (; chunk < n_full; chunk += nwaves) {
@@ -1964,9 +1966,17 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
             side(nc, bp_nxt, go_nxt);
         }
         uint16_t c[ENC_PER_LANE];
-        unpack_codes(cur, narrow, sym_add, c);
-        const uint32_t nwords = wide ? pack_chunk<2>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage)
-                                     : pack_chunk<4>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage);
+        uint32_t nwords;
+        if (narrow) {  // alphabets of one-byte codes have at most 256 symbols: code words <= 16 bits
+            const uint32_t wds[4] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w};
+#pragma unroll
+            for (int i = 0; i < 16; i++) c[i] = (uint16_t)((wds[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+            nwords = pack_chunk<4, true>(c, 0, 0, false, s_enc8, g_enc, sym_min, all_lds, stage);
+        } else {
+            unpack_codes(cur, narrow, sym_add, c);
+            nwords = wide ? pack_chunk<2>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage)
+                          : pack_chunk<4>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage);
+        }
         const uint32_t before = wave_sum(bp_cur);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();

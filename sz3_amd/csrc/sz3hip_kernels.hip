@@ -33,20 +33,39 @@
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
-template <typename V>
-__device__ __forceinline__ V wave_incl_scan(V v) {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        V t = __shfl_up(v, d, WAVE);
-        if (lane_id() >= d) v += t;
-    }
-    return v;
+// Wave-wide inclusive scan / sum with DPP lane moves (no LDS round trip; __shfl_up lowers to ds_bpermute, ~100 cycles
+// per step): Kogge-Stone inside the rows of 16 lanes (row_shr 1, 2, 4, 8), then row_bcast:15 carries the row totals into
+// rows 1 and 3 and row_bcast:31 the half-wave total into rows 2 and 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov0(uint32_t v) {  // lanes without a source (or outside ROW_MASK) read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_mov0(uint64_t v) {
+    const uint32_t lo = dpp_mov0<CTRL, ROW_MASK>((uint32_t)v), hi = dpp_mov0<CTRL, ROW_MASK>((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
 }
 template <typename V>
-__device__ __forceinline__ V wave_sum(V v) {
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
-    return v;
+__device__ __forceinline__ V wave_incl_scan(V v) {
+    using U = typename std::conditional<sizeof(V) == 8, uint64_t, uint32_t>::type;
+    U u = (U)v;
+    u += dpp_mov0<0x111, 0xf>(u);  // row_shr:1
+    u += dpp_mov0<0x112, 0xf>(u);  // row_shr:2
+    u += dpp_mov0<0x114, 0xf>(u);  // row_shr:4
+    u += dpp_mov0<0x118, 0xf>(u);  // row_shr:8
+    u += dpp_mov0<0x142, 0xa>(u);  // row_bcast:15 -> rows 1, 3
+    u += dpp_mov0<0x143, 0xc>(u);  // row_bcast:31 -> rows 2, 3
+    return (V)u;
+}
+template <typename V>
+__device__ __forceinline__ V wave_sum(V v) {  // total in every lane
+    const V incl = wave_incl_scan(v);
+    if (sizeof(V) == 8) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)incl, WAVE - 1);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)incl >> 32), WAVE - 1);
+        return (V)(((uint64_t)hi << 32) | lo);
+    }
+    return (V)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)incl, WAVE - 1);
 }
 
 template <typename T> struct QTraits;

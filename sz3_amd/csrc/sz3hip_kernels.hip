@@ -805,31 +805,39 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                 if ((uint32_t)(r - 1) >= ny || !xok) continue;         // beyond the array
                 // ---- codes, histogram, store ----
                 uint32_t code[4];
-                uint32_t mx = 0;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const UQ shifted = delta[i] + (UQ)radius;  // in (0, 2r) when |delta| < r
-                    const bool inr = (UQ)(delta[i] + rng_lo) <= rng_span;
-                    code[i] = inr ? (uint32_t)shifted : 0u;
-                    uint32_t bin = code[i] - win_lo;           // wraps to a huge value below the window
-                    bin = bin < (uint32_t)HIST_WIN ? bin : (uint32_t)HIST_WIN;
-                    mx = mx > bin ? mx : bin;
-                    atomicAdd(&lh[bin * 4 + copy], 1u);
-                }
+                bool rare = badmask != 0;
                 const uint64_t gi = (uint64_t)w * vol + (uint64_t)gz * plane + (uint64_t)gy * d0 + x;
-                if (narrow) {  // one byte per code: delta + 128, 0 = delta outlier
-                    const uint32_t off8 = (uint32_t)radius - 128u;
+                if (narrow) {  // one byte per code: delta + 128, 0 = delta outlier; every in-range code lies inside the window
                     uint32_t pk8 = 0;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) pk8 |= (code[i] ? code[i] - off8 : 0u) << (8 * i);
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t t = (uint32_t)delta[i] + 127u;
+                        const bool inr = (UQ)(delta[i] + (UQ)127) <= (UQ)254;
+                        const uint32_t byte = inr ? t + 1u : 0u;
+                        const uint32_t bin = inr ? t + (uint32_t)(HIST_WIN / 2 - 127) : (uint32_t)HIST_WIN;  // delta + radius - win_lo
+                        rare |= !inr;
+                        pk8 |= byte << (8 * i);
+                        code[i] = inr ? (uint32_t)delta[i] + (uint32_t)radius : 0u;  // only read on the rare path
+                        atomicAdd(&lh[bin * 4 + copy], 1u);
+                    }
                     *reinterpret_cast<uint32_t *>(codes8 + gi) = pk8;
                 } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const UQ shifted = delta[i] + (UQ)radius;  // in (0, 2r) when |delta| < r
+                        const bool inr = (UQ)(delta[i] + rng_lo) <= rng_span;
+                        code[i] = inr ? (uint32_t)shifted : 0u;
+                        uint32_t bin = code[i] - win_lo;           // wraps to a huge value below the window
+                        rare |= bin >= (uint32_t)HIST_WIN;
+                        bin = bin < (uint32_t)HIST_WIN ? bin : (uint32_t)HIST_WIN;
+                        atomicAdd(&lh[bin * 4 + copy], 1u);
+                    }
                     uint2 pk;
                     pk.x = code[0] | (code[1] << 16);
                     pk.y = code[2] | (code[3] << 16);
                     *reinterpret_cast<uint2 *>(codes + gi) = pk;
                 }
-                if (mx >= (uint32_t)HIST_WIN || badmask) {  // rare: outliers, codes outside the LDS histogram window
+                if (rare) {  // outliers, codes outside the LDS histogram window
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         if (code[i] == 0) {

@@ -1892,10 +1892,10 @@ __global__ __launch_bounds__(1024) void k_scan_groups(const uint16_t *__restrict
 // pack 16 symbols of a lane into the wave's LDS stage at the lane's bit offset; returns the chunk's word count.
 // G code words are joined per 64-bit register: G = 4 when the code book's longest word is <= 16 bits, else G = 2
 // (<= 24 bits each); every register is emitted left-aligned at its bit offset with three ds_or.
-template <int G, bool BYTE = false>  // BYTE: c[] are one-byte codes and s_enc is the 256-entry table indexed by them
+template <int G, bool BYTE = false>  // BYTE: c[] are one-byte codes; s_enc[0..255] = code word, s_len8 = its length, by byte value
 __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE], uint64_t base, uint64_t n, bool check_n,
                                                const uint32_t *s_enc, const uint32_t *__restrict__ g_enc,
-                                               uint32_t sym_min, bool all_lds, uint32_t *stage) {
+                                               uint32_t sym_min, bool all_lds, uint32_t *stage, const uint8_t *s_len8 = nullptr) {
     constexpr int NG = ENC_PER_LANE / G;
     uint64_t g[NG];
     uint32_t gl[NG];
@@ -1907,8 +1907,15 @@ __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE]
         uint32_t pl[G / 2];
 #pragma unroll
         for (int h = 0; h < G / 2; h++) {
-            uint32_t e0 = BYTE ? s_enc[c[G * k + 2 * h]] : enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h]);
-            uint32_t e1 = BYTE ? s_enc[c[G * k + 2 * h + 1]] : enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h + 1]);
+            if (BYTE) {  // code word and length come from separate tables: no shift / mask per symbol
+                const uint32_t b0 = c[G * k + 2 * h], b1 = c[G * k + 2 * h + 1];
+                const uint32_t l1 = s_len8[b1];
+                pc[h] = (s_enc[b0] << l1) | s_enc[b1];
+                pl[h] = (uint32_t)s_len8[b0] + l1;
+                continue;
+            }
+            uint32_t e0 = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h]);
+            uint32_t e1 = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h + 1]);
             if (check_n) {
                 e0 = (base + G * k + 2 * h < n) ? e0 : 0u;
                 e1 = (base + G * k + 2 * h + 1 < n) ? e1 : 0u;
@@ -1953,7 +1960,8 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
                                               const szk_state *__restrict__ state, uint8_t *__restrict__ payload) {
     constexpr int STAGE_WORDS = SZH_CHUNK_SYMS * SZH_MAX_LEN / 32 + 4;  // + slack for the unconditional 3-word emit
     __shared__ uint32_t s_enc[ENC_WIN];
-    __shared__ uint32_t s_enc8[256];  // one-byte codes: encode entry by byte value
+    __shared__ uint32_t s_enc8[256];  // one-byte codes: code word by byte value ...
+    __shared__ uint8_t s_plen8[256];  // ... and its length
     __shared__ uint32_t s_stage[4][STAGE_WORDS];
     const bool narrow = szk_is_narrow(mode);
     const uint64_t n_full = n / SZH_CHUNK_SYMS, n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
@@ -1983,7 +1991,11 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     const bool all_lds = sym_count <= ENC_WIN;
     const bool wide = info->max_len > 16;  // two instead of four code words per 64-bit register
     enc_table_load(s_enc, g_enc, sym_min, sym_count);
-    if (narrow) s_enc8[threadIdx.x] = g_enc[threadIdx.x ? threadIdx.x + sym_add : 0u];
+    if (narrow) {
+        const uint32_t e = g_enc[threadIdx.x ? threadIdx.x + sym_add : 0u];
+        s_enc8[threadIdx.x] = e >> 5;
+        s_plen8[threadIdx.x] = (uint8_t)(e & 31u);
+    }
     for (int i = lane; i < STAGE_WORDS; i += WAVE) stage[i] = 0;
     __syncthreads();
     for (; chunk < n_full; chunk += nwaves) {
@@ -1998,7 +2010,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
             const uint32_t wds[4] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w};
 #pragma unroll
             for (int i = 0; i < 16; i++) c[i] = (uint16_t)((wds[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-            nwords = pack_chunk<4, true>(c, 0, 0, false, s_enc8, g_enc, sym_min, all_lds, stage);
+            nwords = pack_chunk<4, true>(c, 0, 0, false, s_enc8, g_enc, sym_min, all_lds, stage, s_plen8);
         } else {
             unpack_codes(cur, narrow, sym_add, c);
             nwords = wide ? pack_chunk<2>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage)

@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--algo", choices=["lorenzo", "interp", "interp-notune"], default="lorenzo",
                     help="lorenzo = the metric's config C2 (default); interp = C3 (ALGO_INTERP_LORENZO: sampling auto-tuner + "
                          "interpolation; use --eb 1e-4); interp-notune = ALGO_INTERP with the default cubic parameters")
+    ap.add_argument("--shape", default=None, help="z,y,x of the per-GPU volume instead of --size^3 (e.g. 128,1024,1024 = one C4 slab)")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="f64 + --shape 128,1024,1024 --eb 1e-6 = C4's per-GPU slab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-e2e", action="store_true")
     args = ap.parse_args()
@@ -62,11 +64,13 @@ def main():
         print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
     S = args.size
-    shape = (S, S, S)
-    n = S * S * S
+    shape = tuple(int(v) for v in args.shape.split(",")) if args.shape else (S, S, S)
+    n = int(np.prod(shape))
     eb = args.eb
+    npdt = np.float32 if args.dtype == "f32" else np.float64
+    esz = 4 if args.dtype == "f32" else 8
     # every rank: its own slab of the same analytic field family (different noise seed per rank)
-    a = field3d(shape, np.float32, seed=20260928 + rank)
+    a = field3d(shape, npdt, seed=20260928 + rank) if args.dtype == "f32" else field3d(shape, npdt, seed=20260928 + rank, sigma=2e-6)
     d_in = torch.from_numpy(a).to(dev)
     conf = sz3_amd.Config(*shape)
     conf.cmprAlgo = {"lorenzo": sz3_amd.ALGO_LORENZO_REG, "interp": sz3_amd.ALGO_INTERP_LORENZO,
@@ -75,7 +79,7 @@ def main():
     conf.errorBoundMode = sz3_amd.EB_ABS
     conf.absErrorBound = eb
 
-    dc = sz3_amd.DeviceCompressor(n, np.float32, device=local_rank)
+    dc = sz3_amd.DeviceCompressor(n, npdt, device=local_rank)
     cap = dc.payload_bound(n)
     d_payload = torch.empty(cap, dtype=torch.uint8, device=dev)
     hist = torch.zeros(65536, dtype=torch.int64, device=dev)  # caller-owned histogram so RCCL can reduce it in place
@@ -115,7 +119,7 @@ def main():
         total_payload = psize
     barrier()
 
-    raw_bytes = n * 4
+    raw_bytes = n * esz
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * raw_bytes / (elapsed / args.steps) / 1e9
     ratio = world * raw_bytes / float(total_payload)
@@ -162,10 +166,11 @@ def main():
             "metric": "compression throughput GB/s + ratio at fixed abs errBound, 512^3 f32",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: 3D float32 %dx%dx%d synthetic field per GPU, %s predictor, abs errBound=%g, "
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%s: 3D %s %dx%dx%d synthetic field per GPU, %s predictor, abs errBound=%g, "
                                    "device-resident in -> device-resident Huffman payload"
-                                   % ("C2" if args.algo == "lorenzo" else "C3", S, S, S,
+                                   % (("C2" if args.algo == "lorenzo" else "C3") if args.dtype == "f32" and not args.shape else "custom",
+                                      "float32" if args.dtype == "f32" else "float64", shape[0], shape[1], shape[2],
                                       {"lorenzo": "Lorenzo", "interp": "ALGO_INTERP_LORENZO (auto-tuned interpolation)",
                                        "interp-notune": "interpolation (ALGO_INTERP)"}[args.algo], eb),
                        "parallelism": "slab%d" % world, "algo": "HIP_LORENZO(16)" if args.algo == "lorenzo" else "HIP_INTERP(17)", "eb": eb},
@@ -189,7 +194,7 @@ def main():
         t0 = time.perf_counter()
         blob, hratio = sz3_amd.compress(a, conf)
         t1 = time.perf_counter()
-        dec, _ = sz3_amd.decompress(blob, np.float32, shape)
+        dec, _ = sz3_amd.decompress(blob, npdt, shape)
         t2 = time.perf_counter()
         out["host_e2e"] = {"compress_gbps": round(raw_bytes / (t1 - t0) / 1e9, 3), "ratio": round(hratio, 4),
                            "decompress_gbps": round(raw_bytes / (t2 - t1) / 1e9, 3),
@@ -213,8 +218,8 @@ def main():
             sec = time.perf_counter() - t0
             kind = "port"
         out["cpu_baseline"] = {"value": round(raw_bytes / sec / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
-                               "sample": "whole %dx%dx%d volume, SZ_compress<float> %s abs %g, single thread, %.2f s"
-                                         % (S, S, S, {"lorenzo": "ALGO_LORENZO_REG (Lorenzo only)", "interp": "ALGO_INTERP_LORENZO (default)",
+                               "sample": "whole %dx%dx%d volume, SZ_compress<T> %s abs %g, single thread, %.2f s"
+                                         % (shape[0], shape[1], shape[2], {"lorenzo": "ALGO_LORENZO_REG (Lorenzo only)", "interp": "ALGO_INTERP_LORENZO (default)",
                                                        "interp-notune": "ALGO_INTERP (cubic)"}[args.algo], eb, sec),
                                "ratio": round(raw_bytes / float(len(blob)), 4),
                                "host_cpus": os.cpu_count()}

@@ -688,13 +688,17 @@ __device__ __forceinline__ int64_t dpp_wave_shr1(int64_t old, int64_t src) {
     return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
+#define MARCH_WIDE_WIN 8192  // LDS histogram bins of the march kernel when the codes are two bytes wide
 template <typename T, int NDIM, int TY>
 __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict__ in, uint16_t *__restrict__ codes,
                                                              szk_k1_params p, uint32_t ntasks) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     constexpr int NW = NDIM == 4 ? 2 : 1;
-    __shared__ uint32_t lh[HIST_WIN * 4 + 4];  // [bin][copy]; bin HIST_WIN = overflow (never flushed)
+    // LDS histogram. One-byte codes (narrow deltas): 1024 bins x 4 copies around the radius; two-byte codes (deltas of
+    // hundreds or thousands of lattice steps, e.g. C4's 1e-6 on f64): MARCH_WIDE_WIN bins x 1 copy — with the narrow window
+    // nearly every element of such a field would fall through to a global atomic. Last word = overflow bin (never flushed).
+    __shared__ uint32_t lh[MARCH_WIDE_WIN + 4];
 
     const uint32_t d0 = (uint32_t)p.d[3], d1 = (uint32_t)p.d[2], d2 = (uint32_t)p.d[1];
     const uint32_t ntx = (d0 + MARCH_TX - 1) / MARCH_TX, nty = (d1 + TY - 1) / TY, ntz = (d2 + MARCH_TZ - 1) / MARCH_TZ;
@@ -702,14 +706,15 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     const int lane = lane_id();
     const Lattice<T> lat(p.lat);
     const int radius = (int)p.radius;
-    const uint32_t win_lo = (uint32_t)(radius - HIST_WIN / 2);
     const uint32_t copy = (uint32_t)lane & 3u;
     const bool narrow = szk_is_narrow(p.mode);
+    const uint32_t win_bins = narrow ? (uint32_t)HIST_WIN : (uint32_t)MARCH_WIDE_WIN;
+    const uint32_t win_lo = (uint32_t)radius - win_bins / 2;
     // in-range test of a delta, one form for both code widths: (delta + rng_lo) <= rng_span (unsigned)
     const UQ rng_lo = narrow ? (UQ)127 : (UQ)(radius - 1), rng_span = narrow ? (UQ)254 : (UQ)(2 * radius - 2);
     uint8_t *codes8 = reinterpret_cast<uint8_t *>(codes);
 
-    for (int i = threadIdx.x; i < HIST_WIN * 4 + 4; i += 256) lh[i] = 0;
+    for (int i = threadIdx.x; i < MARCH_WIDE_WIN + 4; i += 256) lh[i] = 0;
     __syncthreads();
 
     const uint32_t wave_gid = blockIdx.x * 4 + threadIdx.x / WAVE, nwaves = gridDim.x * 4;
@@ -828,9 +833,9 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                         const bool inr = (UQ)(delta[i] + rng_lo) <= rng_span;
                         code[i] = inr ? (uint32_t)shifted : 0u;
                         uint32_t bin = code[i] - win_lo;           // wraps to a huge value below the window
-                        rare |= bin >= (uint32_t)HIST_WIN;
-                        bin = bin < (uint32_t)HIST_WIN ? bin : (uint32_t)HIST_WIN;
-                        atomicAdd(&lh[bin * 4 + copy], 1u);
+                        rare |= bin >= (uint32_t)MARCH_WIDE_WIN;
+                        bin = bin < (uint32_t)MARCH_WIDE_WIN ? bin : (uint32_t)MARCH_WIDE_WIN;
+                        atomicAdd(&lh[bin], 1u);
                     }
                     uint2 pk;
                     pk.x = code[0] | (code[1] << 16);
@@ -854,7 +859,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                                 ((T *)p.vout_val)[pos] = in[gi + i];
                             }
                         }
-                        if (code[i] - win_lo >= (uint32_t)HIST_WIN)
+                        if (code[i] - win_lo >= win_bins)
                             atomicAdd((unsigned long long *)&p.hist[code[i]], 1ull);
                     }
                 }
@@ -863,8 +868,17 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     }
     __syncthreads();
     uint32_t *row = p.hist_partial + (uint64_t)blockIdx.x * HIST_WIN;
-    for (int bnn = threadIdx.x; bnn < HIST_WIN; bnn += 256)
-        row[bnn] = lh[bnn * 4] + lh[bnn * 4 + 1] + lh[bnn * 4 + 2] + lh[bnn * 4 + 3];
+    if (narrow) {
+        for (int bnn = threadIdx.x; bnn < HIST_WIN; bnn += 256)
+            row[bnn] = lh[bnn * 4] + lh[bnn * 4 + 1] + lh[bnn * 4 + 2] + lh[bnn * 4 + 3];
+    } else {  // wide window: straight into the global histogram (the bins are spread, no hot address), empty row for the fold
+        for (int bnn = threadIdx.x; bnn < HIST_WIN; bnn += 256) row[bnn] = 0;
+        for (int bnn = threadIdx.x; bnn < MARCH_WIDE_WIN; bnn += 256) {
+            const uint32_t v = lh[bnn];
+            const uint32_t sym = win_lo + (uint32_t)bnn;
+            if (v && sym < SZH_HIST_BINS) atomicAdd((unsigned long long *)&p.hist[sym], (unsigned long long)v);
+        }
+    }
 }
 
 // folds the per-workgroup histogram rows into hist[win_lo + bin]: block (bx, by) sums rows by, by + gridDim.y, ... of

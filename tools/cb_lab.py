@@ -6,10 +6,12 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, sz3_amd
 from fields import field3d
 S = int(os.environ.get("LAB_SIZE", "256"))
-a = field3d((S, S, S)); dev = torch.device("cuda:0")
+shape = tuple(int(v) for v in os.environ['LAB_SHAPE'].split(',')) if os.environ.get('LAB_SHAPE') else (S, S, S)
+dt = np.float64 if os.environ.get('LAB_DTYPE') == 'f64' else np.float32
+a = field3d(shape, dt, sigma=2e-6) if dt == np.float64 else field3d(shape); dev = torch.device("cuda:0")
 d_in = torch.from_numpy(a).to(dev)
-conf = sz3_amd.Config(S, S, S); conf.cmprAlgo = sz3_amd.ALGO_INTERP if os.environ.get('LAB_ALGO') == 'interp' else sz3_amd.ALGO_LORENZO_REG; conf.absErrorBound = float(os.environ.get("LAB_EB", "1e-3"))
-dc = sz3_amd.DeviceCompressor(a.size, np.float32)
+conf = sz3_amd.Config(*shape); conf.cmprAlgo = sz3_amd.ALGO_INTERP if os.environ.get('LAB_ALGO') == 'interp' else sz3_amd.ALGO_LORENZO_REG; conf.absErrorBound = float(os.environ.get("LAB_EB", "1e-3"))
+dc = sz3_amd.DeviceCompressor(a.size, dt)
 cap = dc.payload_bound(a.size); pl = torch.empty(cap, dtype=torch.uint8, device=dev)
 for _ in range(3): dc.compress(conf, d_in.data_ptr(), pl.data_ptr(), cap, 0)
 L = sz3_amd.lib(); L.sz3hip_debug_codebook_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]

@@ -2562,14 +2562,39 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
                       d0 * d1 < (1ull << 27) && tiles(64, 8, FTZ) < (1ull << 31);
     constexpr int MTY = 4;
     const bool march = fast && !(szk_dbg_flags & 32) && d0 >= 128 && tiles(MARCH_TX, MTY, MARCH_TZ) < (1ull << 31) && (ndim == 3 || ndim == 4);
-    if (!march) p.mode.allow = 0;
+    // 1-D and 2-D arrays are 3-D arrays with d2 = 1 (and d1 = 1): the register-marching kernel needs no plane-size limit
+    const bool march12 = !szk_force_generic && !(szk_dbg_flags & 32) && (ndim == 1 || ndim == 2) && d0 % 4 == 0 && d0 >= 128 &&
+                         d0 < (1ull << 31) && d1 < (1ull << 31) && tiles(MARCH_TX, ndim == 1 ? 1 : MTY, MARCH_TZ) < (1ull << 31);
+    if (!march && !march12) p.mode.allow = 0;
     switch (ndim) {
         case 1:
+            if (march12) {
+                if (p.mode.allow) {
+                    const uint64_t nsamp_threads = ((p.mode.n_total + SZK_PROBE_STRIDE - 1) / SZK_PROBE_STRIDE) * 64;
+                    hipLaunchKernelGGL((k_probe<T, 3>), dim3((uint32_t)((nsamp_threads + 255) / 256)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
+                }
+                nb = tiles(MARCH_TX, 1, MARCH_TZ);
+                uint32_t grid = k1_grid((const void *)k_lorenzo_quant_march<T, 3, 1>, (nb + 3) / 4);
+                hipLaunchKernelGGL((k_lorenzo_quant_march<T, 3, 1>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
+                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+                break;
+            }
             nb = tiles(4096, 1, 1);
             if (nb > 0x7FFFFFFFull) return -1;
             hipLaunchKernelGGL((k_lorenzo_quant<T, 1, 4096, 1, 1>), dim3((uint32_t)nb), dim3(256), 0, s, (const T *)d_in, codes, p);
             break;
         case 2:
+            if (march12) {
+                if (p.mode.allow) {
+                    const uint64_t nsamp_threads = ((p.mode.n_total + SZK_PROBE_STRIDE - 1) / SZK_PROBE_STRIDE) * 64;
+                    hipLaunchKernelGGL((k_probe<T, 3>), dim3((uint32_t)((nsamp_threads + 255) / 256)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
+                }
+                nb = tiles(MARCH_TX, MTY, MARCH_TZ);
+                uint32_t grid = k1_grid((const void *)k_lorenzo_quant_march<T, 3, MTY>, (nb + 3) / 4);
+                hipLaunchKernelGGL((k_lorenzo_quant_march<T, 3, MTY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
+                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+                break;
+            }
             nb = tiles(128, 32, 1);
             if (nb > 0x7FFFFFFFull) return -1;
             hipLaunchKernelGGL((k_lorenzo_quant<T, 2, 128, 32, 1>), dim3((uint32_t)nb), dim3(256), 0, s, (const T *)d_in, codes, p);

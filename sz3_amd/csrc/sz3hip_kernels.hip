@@ -2381,67 +2381,77 @@ __global__ __launch_bounds__(256) void k_scan_x_wave(Q *__restrict__ q, const ui
     }
 }
 
-// inclusive scan along a strided axis: one thread per line, lanes adjacent along the contiguous axis.
-// element index = outer * (L * inner) + a * inner + in,  a = 0..L-1 ; inner = product of faster dims
+// inclusive scan along a strided axis: one thread per (line, segment), lanes adjacent along the contiguous axis.
+// element index = outer * (L * inner) + a * inner + in,  a = 0..L-1 ; inner = product of faster dims.
+// Arrays with few lines (2-D, or a short slow axis product) cut every line into S segments so that the launch still fills
+// the chip: k_strided_totals sums the segments first (one extra read), the scan adds the totals of the preceding segments.
+// The last strided scan of the reconstruction also turns the lattice index into the value (same buffer, Q and T have the
+// same size).
 template <typename Q>
-__global__ __launch_bounds__(256) void k_scan_strided(Q *__restrict__ q, uint64_t L, uint64_t inner, uint64_t nlines) {
+__global__ __launch_bounds__(256) void k_strided_totals(const Q *__restrict__ q, uint64_t L, uint64_t inner, uint64_t nlines, uint32_t S,
+                                                        uint64_t Lseg, Q *__restrict__ totals) {
     using UQ = typename std::make_unsigned<Q>::type;
-    const uint64_t line = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (line >= nlines) return;
+    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nlines * S) return;
+    const uint64_t seg = id / nlines, line = id % nlines;
     const uint64_t outer = line / inner, in = line % inner;
-    Q *pp = q + outer * L * inner + in;
+    const Q *pp = q + outer * L * inner + in;
+    const uint64_t a0 = seg * Lseg, a1 = (a0 + Lseg < L) ? a0 + Lseg : L;
     UQ run = 0;
-    uint64_t a = 0;
-    for (; a + 4 <= L; a += 4) {
-        UQ v0 = (UQ)pp[(a + 0) * inner], v1 = (UQ)pp[(a + 1) * inner], v2 = (UQ)pp[(a + 2) * inner],
-           v3 = (UQ)pp[(a + 3) * inner];
-        v0 += run;
-        v1 += v0;
-        v2 += v1;
-        v3 += v2;
-        pp[(a + 0) * inner] = (Q)v0;
-        pp[(a + 1) * inner] = (Q)v1;
-        pp[(a + 2) * inner] = (Q)v2;
-        pp[(a + 3) * inner] = (Q)v3;
-        run = v3;
-    }
-    for (; a < L; a++) {
-        run += (UQ)pp[a * inner];
-        pp[a * inner] = (Q)run;
-    }
+    for (uint64_t a = a0; a < a1; a++) run += (UQ)pp[a * inner];
+    totals[id] = (Q)run;
 }
-
-// the last strided scan of the reconstruction also turns the lattice index into the value (same buffer, Q and T
-// have the same size)
-template <typename T>
-__global__ __launch_bounds__(256) void k_scan_strided_dequant(void *buf, uint64_t L, uint64_t inner, uint64_t nlines, szk_lattice l) {
-    using Q = typename QTraits<T>::Q;
+template <typename Q, typename T, bool DEQUANT>
+__device__ __forceinline__ void scan_strided_body(void *buf, uint64_t L, uint64_t inner, uint64_t nlines, uint32_t S, uint64_t Lseg,
+                                                  const Q *__restrict__ totals, szk_lattice l) {
     using UQ = typename std::make_unsigned<Q>::type;
     const Lattice<T> lat(l);
-    const uint64_t line = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (line >= nlines) return;
+    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nlines * S) return;
+    const uint64_t seg = id / nlines, line = id % nlines;
     const uint64_t outer = line / inner, in = line % inner;
     Q *pp = reinterpret_cast<Q *>(buf) + outer * L * inner + in;
     T *po = reinterpret_cast<T *>(buf) + outer * L * inner + in;
+    const uint64_t a1 = (seg * Lseg + Lseg < L) ? seg * Lseg + Lseg : L;
     UQ run = 0;
-    uint64_t a = 0;
-    for (; a + 4 <= L; a += 4) {
+    for (uint32_t k = 0; k < seg; k++) run += (UQ)totals[(uint64_t)k * nlines + line];
+    uint64_t a = seg * Lseg;
+    for (; a + 4 <= a1; a += 4) {
         UQ v0 = (UQ)pp[(a + 0) * inner], v1 = (UQ)pp[(a + 1) * inner], v2 = (UQ)pp[(a + 2) * inner],
            v3 = (UQ)pp[(a + 3) * inner];
         v0 += run;
         v1 += v0;
         v2 += v1;
         v3 += v2;
-        po[(a + 0) * inner] = lat.dequant((Q)v0);
-        po[(a + 1) * inner] = lat.dequant((Q)v1);
-        po[(a + 2) * inner] = lat.dequant((Q)v2);
-        po[(a + 3) * inner] = lat.dequant((Q)v3);
+        if (DEQUANT) {
+            po[(a + 0) * inner] = lat.dequant((Q)v0);
+            po[(a + 1) * inner] = lat.dequant((Q)v1);
+            po[(a + 2) * inner] = lat.dequant((Q)v2);
+            po[(a + 3) * inner] = lat.dequant((Q)v3);
+        } else {
+            pp[(a + 0) * inner] = (Q)v0;
+            pp[(a + 1) * inner] = (Q)v1;
+            pp[(a + 2) * inner] = (Q)v2;
+            pp[(a + 3) * inner] = (Q)v3;
+        }
         run = v3;
     }
-    for (; a < L; a++) {
+    for (; a < a1; a++) {
         run += (UQ)pp[a * inner];
-        po[a * inner] = lat.dequant((Q)run);
+        if (DEQUANT) po[a * inner] = lat.dequant((Q)run);
+        else pp[a * inner] = (Q)run;
     }
+}
+template <typename Q>
+__global__ __launch_bounds__(256) void k_scan_strided(Q *__restrict__ q, uint64_t L, uint64_t inner, uint64_t nlines, uint32_t S,
+                                                      uint64_t Lseg, const Q *__restrict__ totals) {
+    using T = typename std::conditional<sizeof(Q) == 4, float, double>::type;
+    scan_strided_body<Q, T, false>(q, L, inner, nlines, S, Lseg, totals, szk_lattice{});
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_scan_strided_dequant(void *buf, uint64_t L, uint64_t inner, uint64_t nlines, uint32_t S, uint64_t Lseg,
+                                                              const typename QTraits<T>::Q *__restrict__ totals, szk_lattice l) {
+    scan_strided_body<typename QTraits<T>::Q, T, true>(buf, L, inner, nlines, S, Lseg, totals, l);
 }
 
 // lattice index -> value, in place (Q and T have the same size)
@@ -2755,11 +2765,24 @@ static int launch_reconstruct(const uint8_t *payload, const szh_header &h, const
         const uint64_t La = h.dims[ax];
         if (La > 1) {
             const uint64_t nlines = n / La;
+            // few lines: cut them into segments (totals first) so that ~64K threads run
+            uint32_t S = 1;
+            if (nlines < 32768 && La >= 64) {
+                S = (uint32_t)(65536 / nlines);
+                if (S > La / 16) S = (uint32_t)(La / 16);
+                if (S < 1) S = 1;
+            }
+            const uint64_t Lseg = (La + S - 1) / S;
+            Q *totals = (Q *)d_segtot;
+            if (S > 1)
+                hipLaunchKernelGGL(k_strided_totals<Q>, dim3(grid_for(nlines * S, 256, 0x7FFFFFFF)), dim3(256), 0, s, (const Q *)q, La, inner, nlines, S,
+                                   Lseg, totals);
             if (ax == last_ax)
-                hipLaunchKernelGGL(k_scan_strided_dequant<T>, dim3(grid_for(nlines, 256, 0x7FFFFFFF)), dim3(256), 0, s, d_out, La, inner,
-                                   nlines, szk_make_lattice(h.eb));
+                hipLaunchKernelGGL(k_scan_strided_dequant<T>, dim3(grid_for(nlines * S, 256, 0x7FFFFFFF)), dim3(256), 0, s, d_out, La, inner,
+                                   nlines, S, Lseg, (const Q *)totals, szk_make_lattice(h.eb));
             else
-                hipLaunchKernelGGL(k_scan_strided<Q>, dim3(grid_for(nlines, 256, 0x7FFFFFFF)), dim3(256), 0, s, q, La, inner, nlines);
+                hipLaunchKernelGGL(k_scan_strided<Q>, dim3(grid_for(nlines * S, 256, 0x7FFFFFFF)), dim3(256), 0, s, q, La, inner, nlines, S, Lseg,
+                                   (const Q *)totals);
         }
         inner *= La;
     }

@@ -69,6 +69,27 @@ __device__ __forceinline__ T ref_recover(T pred, int code, double eb, int radius
     return (T)((double)pred + (double)(2 * (code - radius)) * eb);
 }
 
+// append an unpredictable value to the list: ONE atomic per wave (a field whose coarse levels miss the code range makes
+// hundreds of thousands of them; same-address atomics run at ~90/us). Works for any set of active lanes.
+template <typename T>
+__device__ __forceinline__ void append_unpred(bool unp, const szk_interp_pass &p, uint64_t idx, T v) {
+    const unsigned long long m = __ballot(unp);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd((unsigned long long *)p.n_vout, (unsigned long long)__popcll(m));
+    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader);
+    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), leader);
+    if (unp) {
+        const unsigned long long pos = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < p.out_cap) {
+            p.vout_idx[pos] = idx;
+            ((T *)p.vout_val)[pos] = v;
+        }
+    }
+}
+
 // ---- one directional pass of one level: one thread per predicted point ----------------------------------------
 template <typename T, bool DEC>
 __device__ __forceinline__ void interp_point(T *__restrict__ w, uint16_t *__restrict__ codes, const szk_interp_pass &p, uint64_t t,
@@ -133,11 +154,7 @@ __device__ __forceinline__ void interp_point(T *__restrict__ w, uint16_t *__rest
         if (code) {
             *d = v;
         } else {  // unpredictable: keep the raw value (LinearQuantizer "unpred")
-            const unsigned long long pos = atomicAdd((unsigned long long *)p.n_vout, 1ull);
-            if (pos < p.out_cap) {
-                p.vout_idx[pos] = idx + boff;
-                ((T *)p.vout_val)[pos] = v;
-            }
+            append_unpred<T>(true, p, idx + boff, v);
         }
     }
 }
@@ -224,11 +241,7 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
             if (code) {
                 o[e] = v;
             } else {
-                const unsigned long long pos = atomicAdd((unsigned long long *)p.n_vout, 1ull);
-                if (pos < p.out_cap) {
-                    p.vout_idx[pos] = idx + e;
-                    ((T *)p.vout_val)[pos] = v;
-                }
+                append_unpred<T>(true, p, idx + e, v);
             }
         }
     };
@@ -329,13 +342,7 @@ __device__ __forceinline__ void anchor_point(T *__restrict__ w, uint16_t *__rest
         if (code) w[idx] = v;
     }
     codes[idx] = (uint16_t)code;
-    if (!code) {
-        const unsigned long long pos = atomicAdd((unsigned long long *)p.n_vout, 1ull);
-        if (pos < p.out_cap) {
-            p.vout_idx[pos] = idx + boff;
-            ((T *)p.vout_val)[pos] = v;
-        }
-    }
+    if (!code) append_unpred<T>(true, p, idx + boff, v);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_interp_anchors(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
@@ -354,7 +361,9 @@ __global__ __launch_bounds__(256) void k_interp_first_dec(T *__restrict__ w, con
 __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__ codes, uint64_t n, int radius,
                                                     uint64_t *__restrict__ hist) {
     __shared__ uint32_t lh[IH_WIN * 4];
+    __shared__ uint32_t l_zero[4];  // code 0 (unpredictable): far from the window and ONE address for all of them
     for (int i = threadIdx.x; i < IH_WIN * 4; i += 256) lh[i] = 0;
+    if (threadIdx.x < 4) l_zero[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t win_lo = (uint32_t)(radius - IH_WIN / 2), copy = threadIdx.x & 3u;
     const uint64_t nth = (uint64_t)gridDim.x * 256;
@@ -377,10 +386,15 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
             if (i + k >= n) break;
             const uint32_t bin = (uint32_t)c[k] - win_lo;
             if (bin < IH_WIN) atomicAdd(&lh[bin * 4 + copy], 1u);
+            else if (c[k] == 0) atomicAdd(&l_zero[copy], 1u);
             else atomicAdd((unsigned long long *)&hist[c[k]], 1ull);
         }
     }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t z = l_zero[0] + l_zero[1] + l_zero[2] + l_zero[3];
+        if (z) atomicAdd((unsigned long long *)&hist[0], (unsigned long long)z);
+    }
     for (int b = threadIdx.x; b < IH_WIN; b += 256) {
         const uint32_t s = lh[b * 4] + lh[b * 4 + 1] + lh[b * 4 + 2] + lh[b * 4 + 3];
         const int sym = (int)win_lo + b;

@@ -1031,10 +1031,11 @@ __device__ void rec_sort(const RecView &r, uint32_t n, uint8_t *pool) {
 
 // outlier lists are appended with atomics in arrival order; sorting them by element index makes the payload a pure
 // function of the input (the reference's CI compares stream digests across platforms, .github/workflows/cmake.yml:295-310).
-// Lists beyond 2^20 records (a sign that the bound is far too tight for the data) stay in arrival order.
+// Lists beyond 32768 records (a sign that the bound is too tight for the data; sorting them would take longer than the
+// rest of stage 2) stay in arrival order.
 __device__ void sort_outlier_list(uint64_t *idx, void *val, uint64_t n, uint64_t cap, bool v32, uint8_t *pool) {
     if (n > cap) n = cap;
-    if (n < 2 || n > (1u << 20)) return;
+    if (n < 2 || n > 32768) return;
     RecView r{idx, reinterpret_cast<uint8_t *>(val), true, v32};
     rec_sort(r, (uint32_t)n, pool);
 }

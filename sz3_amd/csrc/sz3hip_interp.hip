@@ -358,14 +358,17 @@ __global__ __launch_bounds__(256) void k_interp_first_dec(T *__restrict__ w, con
 
 // histogram of u16 codes: persistent workgroups, LDS window [bin][4 copies] around the radius, flushed with one
 // 64-bit atomic per non-empty bin and workgroup
+#define IHW_WIN 8192
 __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__ codes, uint64_t n, int radius,
                                                     uint64_t *__restrict__ hist) {
     __shared__ uint32_t lh[IH_WIN * 4];
     __shared__ uint32_t l_zero[4];  // code 0 (unpredictable): far from the window and ONE address for all of them
+    __shared__ uint32_t lw[IHW_WIN];  // second tier, one copy: the tails (tight bounds spread the codes over thousands of bins)
     for (int i = threadIdx.x; i < IH_WIN * 4; i += 256) lh[i] = 0;
+    for (int i = threadIdx.x; i < IHW_WIN; i += 256) lw[i] = 0;
     if (threadIdx.x < 4) l_zero[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t win_lo = (uint32_t)(radius - IH_WIN / 2), copy = threadIdx.x & 3u;
+    const uint32_t win_lo = (uint32_t)(radius - IH_WIN / 2), wide_lo = (uint32_t)radius - IHW_WIN / 2, copy = threadIdx.x & 3u;
     const uint64_t nth = (uint64_t)gridDim.x * 256;
     for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += nth * 8) {
         uint16_t c[8];
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
             const uint32_t bin = (uint32_t)c[k] - win_lo;
             if (bin < IH_WIN) atomicAdd(&lh[bin * 4 + copy], 1u);
             else if (c[k] == 0) atomicAdd(&l_zero[copy], 1u);
+            else if ((uint32_t)c[k] - wide_lo < IHW_WIN) atomicAdd(&lw[(uint32_t)c[k] - wide_lo], 1u);
             else atomicAdd((unsigned long long *)&hist[c[k]], 1ull);
         }
     }
@@ -394,6 +398,11 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
     if (threadIdx.x == 0) {
         const uint32_t z = l_zero[0] + l_zero[1] + l_zero[2] + l_zero[3];
         if (z) atomicAdd((unsigned long long *)&hist[0], (unsigned long long)z);
+    }
+    for (int b = threadIdx.x; b < IHW_WIN; b += 256) {
+        const uint32_t v = lw[b];
+        const uint32_t sym = wide_lo + (uint32_t)b;
+        if (v && sym < SZH_HIST_BINS) atomicAdd((unsigned long long *)&hist[sym], (unsigned long long)v);
     }
     for (int b = threadIdx.x; b < IH_WIN; b += 256) {
         const uint32_t s = lh[b * 4] + lh[b * 4 + 1] + lh[b * 4 + 2] + lh[b * 4 + 3];

@@ -68,6 +68,21 @@ __device__ __forceinline__ V wave_sum(V v) {  // total in every lane
     return (V)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)incl, WAVE - 1);
 }
 
+// reserve one slot of an append-only list for every active lane with want == true: ONE atomic per wave (same-address
+// global atomics run at ~90/us: a field with a third of NaNs would otherwise spend half a second here). Any set of active
+// lanes may call it together. Returns the lane's slot (meaningful only where want).
+__device__ __forceinline__ unsigned long long wave_append_slot(bool want, uint64_t *counter) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return ~0ull;
+    const int lane = lane_id();
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd((unsigned long long *)counter, (unsigned long long)__popcll(m));
+    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader);
+    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), leader);
+    return (((unsigned long long)bhi << 32) | blo) + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+}
+
 template <typename T> struct QTraits;
 template <> struct QTraits<float> {
     using Q = int32_t;
@@ -689,6 +704,7 @@ __device__ __forceinline__ int64_t dpp_wave_shr1(int64_t old, int64_t src) {
 }
 
 #define MARCH_WIDE_WIN 8192  // LDS histogram bins of the march kernel when the codes are two bytes wide
+#define MARCH_OQ 256  // records per wave in the LDS outlier staging queue
 template <typename T, int NDIM, int TY>
 __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict__ in, uint16_t *__restrict__ codes,
                                                              szk_k1_params p, uint32_t ntasks) {
@@ -699,6 +715,10 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     // hundreds or thousands of lattice steps, e.g. C4's 1e-6 on f64): MARCH_WIDE_WIN bins x 1 copy — with the narrow window
     // nearly every element of such a field would fall through to a global atomic. Last word = overflow bin (never flushed).
     __shared__ uint32_t lh[MARCH_WIDE_WIN + 4];
+    // per-wave staging of value outliers (NaN / Inf / fill values can be percents of a field): records collect in LDS and go
+    // to the global list in batches, one global atomic per batch instead of one per wave instruction
+    __shared__ uint64_t s_oq_idx[4][MARCH_OQ];
+    __shared__ uint64_t s_oq_val[4][MARCH_OQ];
 
     const uint32_t d0 = (uint32_t)p.d[3], d1 = (uint32_t)p.d[2], d2 = (uint32_t)p.d[1];
     const uint32_t ntx = (d0 + MARCH_TX - 1) / MARCH_TX, nty = (d1 + TY - 1) / TY, ntz = (d2 + MARCH_TZ - 1) / MARCH_TZ;
@@ -717,6 +737,26 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     for (int i = threadIdx.x; i < MARCH_WIDE_WIN + 4; i += 256) lh[i] = 0;
     __syncthreads();
 
+    uint64_t *oq_idx = s_oq_idx[threadIdx.x / WAVE], *oq_val = s_oq_val[threadIdx.x / WAVE];
+    uint32_t oq_n = 0;  // fill level; lane 0 takes part in every update, the other lanes re-read its copy before use
+    auto oq_flush = [&]() {
+        oq_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)oq_n);
+        if (oq_n == 0) return;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd((unsigned long long *)p.n_vout, (unsigned long long)oq_n);
+        const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+        const unsigned long long b0 = ((unsigned long long)bhi << 32) | blo;
+        for (uint32_t k = lane; k < oq_n; k += WAVE) {
+            const unsigned long long pos = b0 + k;
+            if (pos < p.out_cap) {
+                p.vout_idx[pos] = oq_idx[k];
+                if (sizeof(T) == 4) reinterpret_cast<uint32_t *>(p.vout_val)[pos] = (uint32_t)oq_val[k];
+                else reinterpret_cast<uint64_t *>(p.vout_val)[pos] = oq_val[k];
+            }
+        }
+        oq_n = 0;
+    };
     const uint32_t wave_gid = blockIdx.x * 4 + threadIdx.x / WAVE, nwaves = gridDim.x * 4;
     for (uint32_t task = wave_gid; task < ntasks; task += nwaves) {
         uint32_t b = task;
@@ -842,30 +882,41 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                     pk.y = code[2] | (code[3] << 16);
                     *reinterpret_cast<uint2 *>(codes + gi) = pk;
                 }
-                if (rare) {  // outliers, codes outside the LDS histogram window
+                if (__ballot(rare)) {  // some lane has outliers or codes outside the LDS histogram window
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        if (code[i] == 0) {
-                            unsigned long long pos = atomicAdd((unsigned long long *)p.n_dout, 1ull);
-                            if (pos < p.out_cap) {
-                                p.dout_idx[pos] = gi + i;
-                                ((Q *)p.dout_val)[pos] = (Q)delta[i];
-                            }
+                        const bool is_dout = rare && code[i] == 0, is_vout = rare && ((badmask >> i) & 1u);
+                        const unsigned long long pd = wave_append_slot(is_dout, p.n_dout);
+                        if (is_dout && pd < p.out_cap) {
+                            p.dout_idx[pd] = gi + i;
+                            ((Q *)p.dout_val)[pd] = (Q)delta[i];
                         }
-                        if ((badmask >> i) & 1u) {
-                            unsigned long long pos = atomicAdd((unsigned long long *)p.n_vout, 1ull);
-                            if (pos < p.out_cap) {
-                                p.vout_idx[pos] = gi + i;
-                                ((T *)p.vout_val)[pos] = in[gi + i];
+                        const unsigned long long vm = __ballot(is_vout);
+                        if (vm) {
+                            oq_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)oq_n);
+                            if (oq_n + WAVE > MARCH_OQ) oq_flush();
+                            if (is_vout) {
+                                const uint32_t slot = oq_n + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull));
+                                oq_idx[slot] = gi + i;
+                                const T raw = in[gi + i];
+                                uint64_t bits = 0;
+                                memcpy(&bits, &raw, sizeof(T));
+                                oq_val[slot] = bits;
                             }
+                            oq_n += (uint32_t)__popcll(vm);
                         }
-                        if (code[i] - win_lo >= win_bins)
-                            atomicAdd((unsigned long long *)&p.hist[code[i]], 1ull);
+                        if (rare && code[i] - win_lo >= win_bins) {
+                            // code 0 (delta outliers) is one address for the whole grid: one atomic per wave
+                            const unsigned long long zm = __ballot(code[i] == 0);
+                            if (code[i] != 0) atomicAdd((unsigned long long *)&p.hist[code[i]], 1ull);
+                            else if (lane == __ffsll((long long)zm) - 1) atomicAdd((unsigned long long *)&p.hist[0], (unsigned long long)__popcll(zm));
+                        }
                     }
                 }
             }
         }
     }
+    oq_flush();
     __syncthreads();
     uint32_t *row = p.hist_partial + (uint64_t)blockIdx.x * HIST_WIN;
     if (narrow) {

@@ -206,8 +206,10 @@ template <typename T, bool DEC, bool XDIR>
 __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
     const int N = p.N;
     const uint64_t dx = p.dims[N - 1], xg = dx / 8;
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= p.total) return;  // total = rows * xg here
+    const uint64_t t0 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = t0 < p.total;  // total = rows * xg here; no early return: the workgroup appends its outliers together
+    const uint64_t t = valid ? t0 : 0;
+    uint32_t unp_mask = 0;  // elements of this thread that turned out unpredictable
     const uint64_t tx = t % xg;
     uint64_t r = t / xg, idx = 0, cd = 0;
 #pragma unroll
@@ -238,11 +240,8 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
             T v = o[e];
             const int code = ref_quantize<T>(v, pred, p.eb, p.eb_recip, p.radius);
             set_code(e, code);
-            if (code) {
-                o[e] = v;
-            } else {
-                append_unpred<T>(true, p, idx + e, v);
-            }
+            if (code) o[e] = v;
+            else unp_mask |= 1u << e;  // the raw value stays in o[e]; appended below, one atomic per workgroup
         }
     };
     if (!XDIR) {
@@ -318,8 +317,45 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
             finish(e, pred);
         }
     }
-    st8<T>(w + idx, o);
-    if (!DEC) *reinterpret_cast<uint4 *>(codes + idx) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+    if (valid) {
+        st8<T>(w + idx, o);
+        if (!DEC) *reinterpret_cast<uint4 *>(codes + idx) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+    }
+    if (!DEC) {
+        // unpredictable values of the whole workgroup (up to 2048 points) take ONE global atomic: NaN / fill-value masks make
+        // percents of a field unpredictable, and same-address atomics run at ~90/us
+        __shared__ uint32_t s_cnt[4];
+        __shared__ unsigned long long s_base;
+        const uint32_t cnt = valid ? (uint32_t)__popc(unp_mask) : 0u;
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const uint32_t up = __shfl_up(incl, dlt, 64);
+            if ((int)(threadIdx.x & 63) >= dlt) incl += up;
+        }
+        if ((threadIdx.x & 63) == 63) s_cnt[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t off = incl - cnt, tot = 0;
+        for (int wv = 0; wv < 4; wv++) {
+            if (wv < (int)(threadIdx.x >> 6)) off += s_cnt[wv];
+            tot += s_cnt[wv];
+        }
+        if (tot) {  // uniform for the workgroup
+            if (threadIdx.x == 0) s_base = atomicAdd((unsigned long long *)p.n_vout, (unsigned long long)tot);
+            __syncthreads();
+            unsigned long long pos = s_base + off;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if ((unp_mask >> e) & 1u) {
+                    if (pos < p.out_cap) {
+                        p.vout_idx[pos] = idx + e;
+                        ((T *)p.vout_val)[pos] = o[e];
+                    }
+                    pos++;
+                }
+            }
+        }
+    }
 }
 
 // anchor grid (build_anchor_grid :215-221): every anchor_stride-th point in each dimension is stored losslessly;

@@ -264,6 +264,15 @@ def test_unmodified_reference_cli_runs_on_the_gpu_path(tmp_path):
         blob = np.fromfile(cmp_, dtype=np.uint8)
         d2, c2 = sz3_amd.decompress(blob, np.float32, a.shape)
         assert c2.cmprAlgo == want and np.array_equal(d2, out)
+    # integer input through the CLI's -I 32 (SZ_compress<int32_t>)
+    ai = (1000 * a).astype(np.int32)
+    isrc, icmp, idec = tmp_path / "a.i32", tmp_path / "ai.sz", tmp_path / "ai.out"
+    ai.tofile(isrc)
+    r = subprocess.run([exe, "-I", "32", "-i", str(isrc), "-z", str(icmp), "-o", str(idec), "-3", "60", "50", "40", "-M", "ABS", "3", "-a"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    outi = np.fromfile(idec, dtype=np.int32).reshape(a.shape)
+    assert np.max(np.abs(outi.astype(np.int64) - ai.astype(np.int64))) <= 3
 
 
 def test_full_size_interpolation_properties():

@@ -58,6 +58,7 @@ typedef struct szo_tuner_report {
     double ratios[8]; /* trial ratios in the reference's order: linear, cubic, reversed direction, 3 x (alpha, beta) */
     double best_interp, best_lorenzo;
     uint64_t raw_bytes[8], huff_bytes[8], node_count[8], n_unpred[8]; /* per interpolation trial (pre-zstd size, ...) */
+    double entropy_bits[8]; /* Shannon entropy of the trial's quantisation codes, in bits (estimator studies, tools/) */
 } szo_tuner_report;
 
 /* Config ctor semantics: setDims drops dims==1, sets N/num/predDim/blockSize defaults (Config.hpp:161-177, 452-478) */

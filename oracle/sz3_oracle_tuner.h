@@ -122,7 +122,8 @@ static size_t SUF(tn_sample)(const T *data, int N, const uint64_t *dims, size_t 
 /* interp_compress_test: one decomposition object (its quantizer keeps the unpredictables of all blocks), codes of all
  * blocks concatenated, one Huffman tree, zstd; ratio = raw bytes of the samples / compressed bytes */
 static double SUF(tn_interp_test)(const szo_config *tc, T **blocks, size_t nb, size_t per, uint64_t *raw_bytes) {
-    /* raw_bytes (optional): [0] pre-zstd size, [8] Huffman bit-stream bytes, [16] node count, [24] unpredictables */
+    /* raw_bytes (optional): [0] pre-zstd size, [8] Huffman bit-stream bytes, [16] node count, [24] unpredictables,
+     * [32] (as double) Shannon entropy of the codes in bits */
     SUF(interp) c;
     memset(&c, 0, sizeof(c));
     c.N = tc->N;
@@ -153,6 +154,13 @@ static double SUF(tn_interp_test)(const szo_config *tc, T **blocks, size_t nb, s
         raw_bytes[8] = enc_bytes;
         raw_bytes[16] = node_count;
         raw_bytes[24] = c.q.n_unpred;
+        uint64_t *hh = (uint64_t *)calloc(65536 * 2, sizeof(uint64_t));
+        for (size_t i = 0; i < n; i++) hh[(uint32_t)codes[i] & 0x1FFFF]++;
+        double H = 0;
+        for (size_t i = 0; i < 65536 * 2; i++)
+            if (hh[i]) H += (double)hh[i] * log2((double)n / (double)hh[i]);
+        free(hh);
+        memcpy(&raw_bytes[32], &H, 8);
     }
     size_t zcap = szo_zstd_bound((size_t)(p - buf)) + 8;
     uint8_t *z = (uint8_t *)malloc(zcap);

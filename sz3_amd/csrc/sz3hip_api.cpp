@@ -415,10 +415,12 @@ static void ctx_free(sz3hip_ctx *c) {
     if (!c) return;
     void *bufs[] = {c->d_work, c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_counters, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
                     c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_aux2, c->d_pint2, c->d_range, c->d_info,
-                    c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_flags, c->d_starts, c->d_samples,
-                    c->d_trial, c->d_trial_hist, c->d_trial_counters, c->d_passes, c->d_np};
+                    c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples,
+                    c->d_trial, c->d_passes, c->d_np};  // (d_trial_counters / d_trial_hist live inside d_trial's block)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    if (c->d_flags) (void)hipHostFree(c->d_flags);
+    if (c->d_starts) (void)hipHostFree(c->d_starts);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
     if (c->h_probe) (void)hipHostFree(c->h_probe);
@@ -696,15 +698,17 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
 // zstd matters; any decision yields a valid stream.
 static int tuner_reserve(sz3hip_ctx *ctx, size_t flags, size_t starts, size_t samples) {
     if (ctx->flags_cap < flags) {
-        if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+        // flags and block origins live in pinned host memory the kernels access directly: a few KB each way, and the
+        // tuner saves two staged copies and one synchronisation
+        if (ctx->d_flags) (void)hipHostFree(ctx->d_flags);
         ctx->d_flags = nullptr;
-        HIPCHK(hipMalloc(&ctx->d_flags, flags));
+        HIPCHK(hipHostMalloc((void **)&ctx->d_flags, flags));
         ctx->flags_cap = flags;
     }
     if (ctx->starts_cap < starts) {
-        if (ctx->d_starts) (void)hipFree(ctx->d_starts);
+        if (ctx->d_starts) (void)hipHostFree(ctx->d_starts);
         ctx->d_starts = nullptr;
-        HIPCHK(hipMalloc(&ctx->d_starts, starts));
+        HIPCHK(hipHostMalloc((void **)&ctx->d_starts, starts));
         ctx->starts_cap = starts;
     }
     if (ctx->samples_cap < samples) {
@@ -713,10 +717,12 @@ static int tuner_reserve(sz3hip_ctx *ctx, size_t flags, size_t starts, size_t sa
         HIPCHK(hipMalloc(&ctx->d_samples, samples));
         ctx->samples_cap = samples;
     }
-    if (!ctx->d_trial) HIPCHK(hipMalloc(&ctx->d_trial, 8 * 4 * 8));
+    if (!ctx->d_trial) {  // one block [results 256 B][counters 256 B][histograms]: a group zeroes it with one memset
+        HIPCHK(hipMalloc(&ctx->d_trial, 512 + SZK_MAX_BOOKS * SZH_HIST_BINS * 8));
+        ctx->d_trial_counters = ctx->d_trial + 32;
+        ctx->d_trial_hist = ctx->d_trial + 64;
+    }
     if (!ctx->h_trial) HIPCHK(hipHostMalloc((void **)&ctx->h_trial, 8 * 4 * 8));
-    if (!ctx->d_trial_hist) HIPCHK(hipMalloc(&ctx->d_trial_hist, SZK_MAX_BOOKS * SZH_HIST_BINS * 8));
-    if (!ctx->d_trial_counters) HIPCHK(hipMalloc(&ctx->d_trial_counters, SZK_MAX_BOOKS * 64));
     const size_t pbytes = SZK_MAX_BOOKS * SZK_TRIAL_MAX_PASSES * sizeof(szk_interp_pass);
     if (!ctx->d_passes) HIPCHK(hipMalloc(&ctx->d_passes, pbytes));
     if (!ctx->h_passes) HIPCHK(hipHostMalloc((void **)&ctx->h_passes, pbytes));
@@ -725,19 +731,19 @@ static int tuner_reserve(sz3hip_ctx *ctx, size_t flags, size_t starts, size_t sa
     if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
     return 0;
 }
-static double trial_bytes(const uint64_t *r, size_t tsz) {  // r: bits, symbols, unpredictables, delta outliers
+// Priced size of one trial. r: entropy of the codes in 1/256 bit, symbols in use, unpredictables, delta outliers. The code
+// stream is priced at its entropy (a Huffman code spends at most a few per cent more; no code book is built for a trial).
+static double trial_bytes(const uint64_t *r, size_t tsz) {
     const double nc = r[1] ? 2.0 * (double)r[1] - 1.0 : 0.0;
     const double w = nc <= 256 ? 1 : (nc <= 65536 ? 2 : 4);
     const double tree = 13.0 + nc * (2 * w + 5);  // HuffmanEncoder::save: [i32][i32][i32][u8] L R C t (HuffmanEncoder.hpp:108-125)
-    return std::ceil((double)r[0] / 8.0) + 0.45 * tree + (double)r[2] * (double)tsz + (double)r[3] * 12.0 + 80.0;
+    return std::ceil((double)r[0] / 2048.0) + 0.45 * tree + (double)r[2] * (double)tsz + (double)r[3] * 12.0 + 80.0;
 }
-// one group of up to SZK_MAX_BOOKS independent trials: one interpolation launch for all of them, one batched code-book launch
-// over their histograms, one cost launch; trial j's priced size lands in result slot slot0 + j
+// one group of up to SZK_MAX_BOOKS independent trials: one interpolation launch for all of them, one cost launch over their
+// histograms; trial j's priced size lands in result slot slot0 + j
 static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr, double eb, int radius, uint32_t nb, int slot0,
                               hipStream_t s) {
-    HIPCHK(hipMemsetAsync(ctx->d_trial_hist, 0, (size_t)ntr * SZH_HIST_BINS * 8, s));
-    HIPCHK(hipMemsetAsync(ctx->d_trial_counters, 0, SZK_MAX_BOOKS * 64, s));
-    HIPCHK(hipMemsetAsync(ctx->d_trial + 4 * slot0, 0, 32 * ntr, s));
+    HIPCHK(hipMemsetAsync(ctx->d_trial, 0, 512 + (size_t)ntr * SZH_HIST_BINS * 8, s));  // (earlier groups' results were fetched)
     szk_interp_params ips[SZK_MAX_BOOKS];
     for (int j = 0; j < ntr; j++) {
         int rc = interp_params_from(&tcs[j], eb, radius, ips[j]);
@@ -750,12 +756,7 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
     int rc = szk_launch_interp_trials(ctx->dtype, ips, (uint32_t)ntr, ctx->d_samples, ctx->d_work, ctx->d_codes, nb, ctx->d_trial_hist,
                                       ctx->h_passes, ctx->d_passes, ctx->h_np, ctx->d_np, s);
     if (rc) return fail(SZ3HIP_EHIP, "tuner: interpolation trial launch failed (%d)", rc);
-    szk_cb_params cb;
-    cb_params_from(ctx, cb, 0);
-    cb.n_books = (uint32_t)ntr;
-    rc = szk_launch_codebook(ctx->d_trial_hist, &cb, s);
-    if (rc) return fail(SZ3HIP_EHIP, "tuner: codebook launch failed (%d)", rc);
-    rc = szk_launch_code_cost(ctx->d_trial_hist, ctx->d_lens, ctx->d_info, ctx->d_trial_counters, ctx->d_trial + 4 * slot0, (uint32_t)ntr, s);
+    rc = szk_launch_code_cost(ctx->d_trial_hist, ctx->d_trial_counters, ctx->d_trial + 4 * slot0, (uint32_t)ntr, tcs[0].num * nb, s);
     if (rc) return fail(SZ3HIP_EHIP, "tuner: cost kernel launch failed (%d)", rc);
     return 0;
 }
@@ -803,11 +804,8 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
     uint64_t total = 0;
     rc = szk_launch_profile_blocks(ctx->dtype, d_in, N, conf.dims, sbs, sbs / 4, eb, ctx->d_flags, &total, s);
     if (rc) return fail(SZ3HIP_EHIP, "tuner: profiling launch failed (%d)", rc);
-    std::vector<uint8_t> flags(total);
-    if (total) {
-        HIPCHK(hipMemcpyAsync(flags.data(), ctx->d_flags, total, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-    }
+    if (total) HIPCHK(hipStreamSynchronize(s));
+    const uint8_t *flags = ctx->d_flags;
     uint64_t cnt[4] = {1, 1, 1, 1};
     for (int i = 0; i < N; i++) cnt[i] = (conf.dims[i] - sbs + sbs - 1) / sbs;
     std::vector<uint64_t> filtered;  // linear candidate indices, lexicographic
@@ -835,7 +833,10 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
     const uint64_t sampling_num = nb * per;
     if (sampling_num == 0 || (double)sampling_num >= (double)conf.num * 0.2) return fall_back();  // :176-179
     if (nb > 0x7FFFFFFFull) return fall_back();
-    std::vector<uint64_t> starts(nb * 4, 0);
+    rc = tuner_reserve(ctx, 0, nb * 32, sampling_num * tsz);
+    if (rc) return rc;
+    uint64_t *starts = ctx->d_starts;  // (the previous call's gather finished before this call's profiling synchronised)
+    memset(starts, 0, nb * 32);
     for (uint64_t b = 0; b < nb; b++) {
         uint64_t r = chosen[b];
         for (int j = N - 1; j >= 0; j--) {
@@ -843,12 +844,8 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
             r /= cnt[j];
         }
     }
-    rc = tuner_reserve(ctx, 0, nb * 32, sampling_num * tsz);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->d_starts, starts.data(), nb * 32, hipMemcpyHostToDevice, s));
     rc = szk_launch_gather_blocks(ctx->dtype, d_in, N, conf.dims, sbs + 1, ctx->d_starts, (uint32_t)nb, ctx->d_samples, s);
     if (rc) return fail(SZ3HIP_EHIP, "tuner: gather launch failed (%d)", rc);
-    HIPCHK(hipStreamSynchronize(s));  // `starts` must outlive the copy
 
     const double raw = (double)sampling_num * (double)tsz;
     double best_interp = 0, best_lorenzo = 0;
@@ -922,11 +919,7 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
         const uint64_t d1[1] = {sampling_num};
         rc = lorenzo_k1(ctx, 1, d1, ctx->d_samples, eb, radius, sampling_num, 0, false, p, s);
         if (rc) return fail(SZ3HIP_EHIP, "tuner: Lorenzo trial launch failed (%d)", rc);
-        szk_cb_params cb;
-        cb_params_from(ctx, cb, 0);
-        rc = szk_launch_codebook(ctx->d_hist, &cb, s);
-        if (rc) return fail(SZ3HIP_EHIP, "tuner: codebook launch failed (%d)", rc);
-        rc = szk_launch_code_cost(ctx->d_hist, ctx->d_lens, ctx->d_info, ctx->d_counters, ctx->d_trial + 24, 1, s);
+        rc = szk_launch_code_cost(ctx->d_hist, ctx->d_counters, ctx->d_trial + 24, 1, sampling_num, s);
         if (rc) return fail(SZ3HIP_EHIP, "tuner: cost kernel launch failed (%d)", rc);
         rc = tuner_fetch(ctx, s);
         if (rc) return rc;

@@ -46,7 +46,7 @@ class SzoTunerReport(C.Structure):
     _fields_ = [("sample_block_size", C.c_uint64), ("n_filtered", C.c_uint64), ("n_blocks", C.c_uint64),
                 ("profiling", C.c_int32), ("reserved", C.c_int32), ("ratios", C.c_double * 8),
                 ("best_interp", C.c_double), ("best_lorenzo", C.c_double), ("raw_bytes", C.c_uint64 * 8), ("huff_bytes", C.c_uint64 * 8),
-                ("node_count", C.c_uint64 * 8), ("n_unpred", C.c_uint64 * 8)]
+                ("node_count", C.c_uint64 * 8), ("n_unpred", C.c_uint64 * 8), ("entropy_bits", C.c_double * 8)]
 
 
 def _dtype_id(a):

@@ -183,7 +183,8 @@ def main():
             "tuner": dc.tuner_report() if args.algo == "interp" else None,
             "kernels_ms": round(kernels_ms, 4),
             "frac_read_peak_all_kernels": round(raw_bytes / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "roofline": {"bound": "hbm", "kernel": "k_lorenzo_quant (stage lorenzo_quant_hist)",
+            "roofline": {"bound": "hbm", "kernel": "k_lorenzo_quant (stage lorenzo_quant_hist)" if args.algo == "lorenzo" else
+                         "stage 1 = copy + interpolation passes + code histogram (a multi-kernel stage: see profiles/)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(algo_bytes), "kernel_ms": round(k1_ms, 4)},

@@ -152,7 +152,7 @@ __device__ __forceinline__ void interp_point(T *__restrict__ w, uint16_t *__rest
         const int code = ref_quantize<T>(v, pred, p.eb, p.eb_recip, p.radius);
         codes[idx] = (uint16_t)code;
         if (code) {
-            *d = v;
+            if (!p.no_store) *d = v;
         } else {  // unpredictable: keep the raw value (LinearQuantizer "unpred")
             append_unpred<T>(true, p, idx + boff, v);
         }
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
         }
     }
     if (valid) {
-        st8<T>(w + idx, o);
+        if (DEC || !p.no_store) st8<T>(w + idx, o);
         if (!DEC) *reinterpret_cast<uint4 *>(codes + idx) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
     }
     if (!DEC) {
@@ -590,6 +590,7 @@ static int build_schedule(const szk_interp_params &ip, bool dec, uint32_t nbatch
             }
         }
     }
+    if (!dec && !out.empty() && out.back().kind == 2) out.back().no_store = 1;  // (a deferred sub-pass, if any, is that last entry)
     return 0;
 }
 

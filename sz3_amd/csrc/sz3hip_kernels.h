@@ -128,7 +128,8 @@ struct szk_interp_params {  // what InterpolationDecomposition keeps (decomposit
 };
 struct szk_interp_pass {
     int N, dir, interp_id, old_api, subpass, radius;
-    int kind, reserved;  // 0: anchor grid, 1: first point (no anchors), 2: directional pass
+    int kind;     // 0: anchor grid, 1: first point (no anchors), 2: directional pass
+    int no_store; // compression, final pass of the schedule: nothing reads its reconstruction, so it is not written
     uint64_t dims[4], off[4], start[4], step[4], cnt[4];
     uint64_t total, s, bsz;
     uint64_t batch_stride;  // elements between the independent arrays of a batch (grid.y), 0 = one array

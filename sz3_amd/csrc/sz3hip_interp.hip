@@ -634,7 +634,7 @@ int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const voi
     int rc = dtype == 0 ? run_interp<float, false>(*ip, (float *)d_work, codes, s)
                         : run_interp<double, false>(*ip, (double *)d_work, codes, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_hist_codes, dim3(1024), dim3(256), 0, s, codes, num, ip->radius, hist);
+    hipLaunchKernelGGL(k_hist_codes, dim3(768), dim3(256), 0, s, codes, num, ip->radius, hist);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -1001,9 +1001,9 @@ __device__ __forceinline__ void rec_stv(const RecView &r, uint64_t i, uint64_t x
 __device__ void rec_global_step(const RecView &r, uint32_t n, uint32_t np2, uint32_t k, uint32_t j, bool flip) {
     const uint32_t half = flip ? k >> 1 : j;
     for (uint32_t pr = threadIdx.x; pr < np2 / 2; pr += blockDim.x) {
-        const uint32_t blk = pr / half, off = pr % half;
-        const uint32_t i = blk * 2 * half + off;
-        const uint32_t x = flip ? blk * 2 * half + 2 * half - 1 - off : i + half;
+        const uint32_t off = pr & (half - 1u);  // half is a power of two
+        const uint32_t i = ((pr - off) << 1) + off;
+        const uint32_t x = flip ? i + 2 * half - 1 - 2 * off : i + half;
         if (x < n) {  // i < x; a partner in the padding never swaps
             const uint64_t a = r.k[i], b = r.k[x];
             if (a > b) {
@@ -1031,9 +1031,9 @@ __device__ void rec_tile_pass(const RecView &r, uint32_t n, uint32_t base, uint3
     __syncthreads();
     auto step = [&](uint32_t half, bool flip) {
         for (uint32_t pr = threadIdx.x; pr < T / 2; pr += blockDim.x) {
-            const uint32_t blk = pr / half, off = pr % half;
-            const uint32_t i = blk * 2 * half + off;
-            const uint32_t x = flip ? blk * 2 * half + 2 * half - 1 - off : i + half;
+            const uint32_t off = pr & (half - 1u);  // half is a power of two
+            const uint32_t i = ((pr - off) << 1) + off;
+            const uint32_t x = flip ? i + 2 * half - 1 - 2 * off : i + half;
             const uint64_t a = sk[i], b = sk[x];
             if (a > b) {
                 sk[i] = b;
@@ -1064,6 +1064,91 @@ __device__ void rec_tile_pass(const RecView &r, uint32_t n, uint32_t base, uint3
     }
     __syncthreads();
 }
+// Full ascending sort of one LDS tile, register-blocked: every thread holds 16 elements whose indices differ in a 4-bit
+// window [lo, lo + 4) of the index, so up to four compare-exchange distances are done per LDS round trip (29 round trips for
+// 16384 keys instead of 105 steps: 143 us -> ~25 us). Standard bitonic network (direction = bit `stage` of the index; the
+// tile is padded with +infinity keys in LDS). Indices are XOR-swizzled (bits 4..7 into bits 0..3): conflict-free for every window.
+__device__ __forceinline__ uint32_t tile_sw(uint32_t i) { return i ^ ((i >> 4) & 15u); }
+template <bool HAS_VAL, uint32_t LOGE>  // (records with values: 8 per thread, to stay within 128 VGPRs at 1024 threads)
+__device__ void rec_tile_sort_fast(const RecView &r, uint32_t n, uint32_t base, uint32_t T, uint64_t *sk, uint64_t *sv) {
+    constexpr uint32_t E = 1u << LOGE;
+    const uint32_t tid = threadIdx.x, NA = T >> LOGE, logT = 31u - (uint32_t)__clz((int)T);
+    uint64_t kv[E], vv[HAS_VAL ? E : 1];
+    // (clamped unconditional loads, all in flight at once: a load under a condition makes hipcc wait for each one)
+#pragma unroll
+    for (uint32_t c = 0; c < E; c++) {
+        const uint32_t g = base + tid + c * blockDim.x, gc = g < n ? g : n - 1;
+        kv[c] = r.k[gc];
+        if (HAS_VAL) vv[c] = rec_ldv(r, gc);
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < E; c++) {
+        const uint32_t i = tid + c * blockDim.x;
+        if (i < T) {
+            sk[tile_sw(i)] = base + i < n ? kv[c] : ~0ull;
+            if (HAS_VAL) sv[tile_sw(i)] = vv[c];
+        }
+    }
+    __syncthreads();
+    // one round: window lo, stages s0..s1 (s1 > s0 only for the first round, lo = 0); bits hi-1 .. lo of stage s
+    auto round = [&](uint32_t lo, uint32_t s0, uint32_t s1, uint32_t hi) {
+        if (tid < NA) {
+            const uint32_t b0 = ((tid >> lo) << (lo + LOGE)) | (tid & ((1u << lo) - 1u));
+#pragma unroll
+            for (uint32_t c = 0; c < E; c++) {
+                kv[c] = sk[tile_sw(b0 | (c << lo))];
+                if (HAS_VAL) vv[c] = sv[tile_sw(b0 | (c << lo))];
+            }
+            for (uint32_t st = s0; st <= s1; st++) {
+                const uint32_t top = s0 == s1 ? hi : st;  // first round: stage st runs bits st-1 .. 0
+                const bool up_t = st < LOGE || ((tid >> (st - LOGE)) & 1u) == 0;  // (used when st >= lo + 4)
+#pragma unroll
+                for (int d = (int)LOGE - 1; d >= 0; d--) {
+                    if (lo + (uint32_t)d >= top) continue;
+#pragma unroll
+                    for (uint32_t c = 0; c < E; c++) {
+                        if (c & (1u << d)) continue;
+                        const uint32_t c2 = c | (1u << d);
+                        const bool up = st >= lo + LOGE ? up_t : ((c >> (st - lo)) & 1u) == 0;
+                        const uint64_t a = kv[c], b = kv[c2];
+                        if ((a > b) == up) {
+                            kv[c] = b;
+                            kv[c2] = a;
+                            if (HAS_VAL) {
+                                const uint64_t va = vv[c];
+                                vv[c] = vv[c2];
+                                vv[c2] = va;
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < E; c++) {
+                sk[tile_sw(b0 | (c << lo))] = kv[c];
+                if (HAS_VAL) sv[tile_sw(b0 | (c << lo))] = vv[c];
+            }
+        }
+        __syncthreads();
+    };
+    round(0, 1, LOGE, 0);
+    for (uint32_t st = LOGE + 1; st <= logT; st++) {
+        uint32_t hi = st;
+        while (hi > 0) {
+            const uint32_t lo = hi > LOGE ? hi - LOGE : 0;
+            round(lo, st, st, hi);
+            hi = lo;
+        }
+    }
+    for (uint32_t i = tid; i < T; i += blockDim.x) {
+        const uint32_t g = base + i;
+        if (g < n) {
+            r.k[g] = sk[tile_sw(i)];
+            if (HAS_VAL) rec_stv(r, g, sv[tile_sw(i)]);
+        }
+    }
+    __syncthreads();
+}
 __device__ void rec_sort(const RecView &r, uint32_t n, uint8_t *pool) {
     if (n < 2) return;
     uint32_t np2 = 2;
@@ -1071,7 +1156,14 @@ __device__ void rec_sort(const RecView &r, uint32_t n, uint8_t *pool) {
     uint32_t T = CB_POOL_BYTES / (r.has_val ? 16 : 8);  // power of two
     if (T > np2) T = np2;
     uint64_t *sk = reinterpret_cast<uint64_t *>(pool), *sv = sk + T;
-    for (uint32_t base = 0; base < n; base += T) rec_tile_pass(r, n, base, T, 2, T, 0, sk, sv);
+    for (uint32_t base = 0; base < n; base += T) {
+        if (T >= 1024 && blockDim.x * (r.has_val ? 8 : 16) >= T) {  // (every caller runs CB_LAUNCH = 1024 threads)
+            if (r.has_val) rec_tile_sort_fast<true, 3>(r, n, base, T, sk, sv);
+            else rec_tile_sort_fast<false, 4>(r, n, base, T, sk, sv);
+        } else {
+            rec_tile_pass(r, n, base, T, 2, T, 0, sk, sv);
+        }
+    }
     for (uint32_t k = 2 * T; k <= np2; k <<= 1) {
         rec_global_step(r, n, np2, k, 0, true);
         uint32_t j = k >> 2;

@@ -91,24 +91,29 @@ __device__ __forceinline__ void append_unpred(bool unp, const szk_interp_pass &p
 }
 
 // ---- one directional pass of one level: one thread per predicted point ----------------------------------------
-template <typename T, bool DEC>
+// IT: type of the point counter arithmetic (u32 when the pass has fewer than 2^32 points: 64-bit divisions cost ~100
+// instructions each, and a tuner trial block is worked by ONE compute unit)
+template <typename T, bool DEC, typename IT = uint64_t>
 __device__ __forceinline__ void interp_point(T *__restrict__ w, uint16_t *__restrict__ codes, const szk_interp_pass &p, uint64_t t,
                                              uint64_t boff) {
-    uint64_t r = t, idx = 0, cd = 0;
+    IT r = (IT)t;
+    uint64_t idx = 0, cd = 0;
 #pragma unroll
     for (int j = 3; j >= 0; j--) {
         if (j >= p.N) continue;
-        const uint64_t q = r % p.cnt[j];
-        r /= p.cnt[j];
-        const uint64_t c = p.start[j] + q * p.step[j];
+        const IT cj = (IT)p.cnt[j];
+        const IT q = r % cj;
+        r /= cj;
+        const uint64_t c = p.start[j] + (uint64_t)q * p.step[j];
         idx += c * p.off[j];
         if (j == p.dir) cd = c;
     }
     const uint64_t D = p.dims[p.dir];
-    const uint64_t begin = (cd / p.bsz) * p.bsz;
+    const int ls = __ffsll((long long)p.s) - 1;  // s and bsz = 32 s are powers of two
+    const uint64_t begin = cd & ~(p.bsz - 1);
     uint64_t end = begin + p.bsz;
     if (end > D - 1) end = D - 1;
-    const uint64_t n = (end - begin) / p.s + 1, i = (cd - begin) / p.s;  // i is odd, 1 <= i <= n-1
+    const uint64_t n = ((end - begin) >> ls) + 1, i = (cd - begin) >> ls;  // i is odd, 1 <= i <= n-1
     const int64_t st = (int64_t)(p.s * p.off[p.dir]);
     T *d = w + idx;
     bool deferred = false;
@@ -163,7 +168,8 @@ __global__ __launch_bounds__(256) void k_interp_pass(T *__restrict__ w, uint16_t
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= p.total) return;
     const uint64_t boff = (uint64_t)blockIdx.y * p.batch_stride;  // independent arrays of one batch
-    interp_point<T, DEC>(w + boff, codes + boff, p, t, boff);
+    if (p.total <= 0xFFFFFFFFull) interp_point<T, DEC, uint32_t>(w + boff, codes + boff, p, t, boff);  // (uniform branch)
+    else interp_point<T, DEC, uint64_t>(w + boff, codes + boff, p, t, boff);
 }
 
 // ---- level 1 (stride 1), cubic, N >= 3, row length a multiple of 8: 8 consecutive x per thread --------------------------
@@ -360,16 +366,18 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
 
 // anchor grid (build_anchor_grid :215-221): every anchor_stride-th point in each dimension is stored losslessly;
 // without anchors (anchor_stride == 0) the first element is quantised against 0 (:92-93)
-template <typename T>
+template <typename T, typename IT = uint64_t>
 __device__ __forceinline__ void anchor_point(T *__restrict__ w, uint16_t *__restrict__ codes, const szk_interp_pass &p, uint64_t t,
                                              uint64_t boff) {
-    uint64_t r = t, idx = 0;
+    IT r = (IT)t;
+    uint64_t idx = 0;
 #pragma unroll
     for (int j = 3; j >= 0; j--) {
         if (j >= p.N) continue;
-        const uint64_t q = r % p.cnt[j];
-        r /= p.cnt[j];
-        idx += (p.start[j] + q * p.step[j]) * p.off[j];
+        const IT cj = (IT)p.cnt[j];
+        const IT q = r % cj;
+        r /= cj;
+        idx += (p.start[j] + (uint64_t)q * p.step[j]) * p.off[j];
     }
     T v = w[idx];
     int code = 0;
@@ -803,9 +811,9 @@ __global__ __launch_bounds__(1024) void k_interp_trials(const T *__restrict__ sa
             reinterpret_cast<uint32_t *>(&sp)[tid] = reinterpret_cast<const uint32_t *>(&passes[(size_t)j * TRIAL_MAX_PASSES + k])[tid];
         __syncthreads();
         if (sp.kind == 2) {
-            for (uint64_t t = tid; t < sp.total; t += 1024) interp_point<T, false>(w, c, sp, t, base);
+            for (uint64_t t = tid; t < sp.total; t += 1024) interp_point<T, false, uint32_t>(w, c, sp, t, base);  // (a block has < 2^32 points)
         } else {
-            for (uint64_t t = tid; t < sp.total; t += 1024) anchor_point<T>(w, c, sp, t, base);
+            for (uint64_t t = tid; t < sp.total; t += 1024) anchor_point<T, uint32_t>(w, c, sp, t, base);
         }
     }
     __syncthreads();

@@ -91,11 +91,22 @@ __device__ __forceinline__ void append_unpred(bool unp, const szk_interp_pass &p
 }
 
 // ---- one directional pass of one level: one thread per predicted point ----------------------------------------
+// tuner trials in LDS: the code of a point goes straight into the trial's histogram (LDS window, global tail)
+struct TrialSink {
+    uint32_t *lh;
+    unsigned long long *hist;
+    uint32_t win_lo;
+};
+__device__ __forceinline__ void sink_code(const TrialSink *sk, uint32_t code) {
+    const uint32_t bin = code - sk->win_lo;
+    if (bin < IH_WIN) atomicAdd(&sk->lh[bin], 1u);
+    else atomicAdd(&sk->hist[code], 1ull);
+}
 // IT: type of the point counter arithmetic (u32 when the pass has fewer than 2^32 points: 64-bit divisions cost ~100
 // instructions each, and a tuner trial block is worked by ONE compute unit)
-template <typename T, bool DEC, typename IT = uint64_t>
+template <typename T, bool DEC, typename IT = uint64_t, bool SINK = false>
 __device__ __forceinline__ void interp_point(T *__restrict__ w, uint16_t *__restrict__ codes, const szk_interp_pass &p, uint64_t t,
-                                             uint64_t boff) {
+                                             uint64_t boff, const TrialSink *sink = nullptr) {
     IT r = (IT)t;
     uint64_t idx = 0, cd = 0;
 #pragma unroll
@@ -155,7 +166,8 @@ __device__ __forceinline__ void interp_point(T *__restrict__ w, uint16_t *__rest
     } else {
         T v = *d;
         const int code = ref_quantize<T>(v, pred, p.eb, p.eb_recip, p.radius);
-        codes[idx] = (uint16_t)code;
+        if (SINK) sink_code(sink, (uint32_t)code);
+        else codes[idx] = (uint16_t)code;
         if (code) {
             if (!p.no_store) *d = v;
         } else {  // unpredictable: keep the raw value (LinearQuantizer "unpred")
@@ -366,9 +378,9 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
 
 // anchor grid (build_anchor_grid :215-221): every anchor_stride-th point in each dimension is stored losslessly;
 // without anchors (anchor_stride == 0) the first element is quantised against 0 (:92-93)
-template <typename T, typename IT = uint64_t>
+template <typename T, typename IT = uint64_t, bool SINK = false>
 __device__ __forceinline__ void anchor_point(T *__restrict__ w, uint16_t *__restrict__ codes, const szk_interp_pass &p, uint64_t t,
-                                             uint64_t boff) {
+                                             uint64_t boff, const TrialSink *sink = nullptr) {
     IT r = (IT)t;
     uint64_t idx = 0;
 #pragma unroll
@@ -385,7 +397,8 @@ __device__ __forceinline__ void anchor_point(T *__restrict__ w, uint16_t *__rest
         code = ref_quantize<T>(v, (T)0, p.eb, p.eb_recip, p.radius);
         if (code) w[idx] = v;
     }
-    codes[idx] = (uint16_t)code;
+    if (SINK) sink_code(sink, (uint32_t)code);
+    else codes[idx] = (uint16_t)code;
     if (!code) append_unpred<T>(true, p, idx + boff, v);
 }
 template <typename T>
@@ -791,34 +804,44 @@ int szk_launch_gather_blocks(int dtype, const void *d_in, int N, const uint64_t 
 // need workgroup-level ordering), then adds its codes to trial j's histogram through an LDS window. Unpredictables are
 // only counted (out_cap = 0 in the schedules).
 #define TRIAL_MAX_PASSES 64
+__device__ unsigned long long g_trial_ts[TRIAL_MAX_PASSES + 8];  // development: per-pass time stamps of workgroup (0, 1)
+extern "C" int szk_debug_trial_ts(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trial_ts), sizeof(g_trial_ts));
+}
 template <typename T>
 __global__ __launch_bounds__(1024) void k_interp_trials(const T *__restrict__ samples, T *__restrict__ work, uint16_t *__restrict__ codes,
                                                         const szk_interp_pass *__restrict__ passes, const uint32_t *__restrict__ npasses,
                                                         uint64_t per, uint64_t *__restrict__ hists) {
-    __shared__ szk_interp_pass sp;
+    __shared__ szk_interp_pass sps[TRIAL_MAX_PASSES];  // the whole schedule of this trial (one fetch, not one per pass)
     __shared__ uint32_t lh[IH_WIN];
     const uint32_t b = blockIdx.x, j = blockIdx.y, nb = gridDim.x, tid = threadIdx.x;
     const uint64_t base = ((uint64_t)j * nb + b) * per;
     T *w = work + base;
     uint16_t *c = codes + base;
     const T *in = samples + (uint64_t)b * per;
+    const uint32_t np = npasses[j];
+    {
+        const uint32_t words = np * (uint32_t)(sizeof(szk_interp_pass) / 4);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(passes + (size_t)j * TRIAL_MAX_PASSES);
+        for (uint32_t i = tid; i < words; i += 1024) reinterpret_cast<uint32_t *>(sps)[i] = src[i];
+    }
     for (uint64_t i = tid; i < per; i += 1024) w[i] = in[i];
     for (uint32_t i = tid; i < IH_WIN; i += 1024) lh[i] = 0;
-    const uint32_t np = npasses[j];
     for (uint32_t k = 0; k < np; k++) {
-        __syncthreads();  // previous pass complete (and its sp no longer read)
-        if (tid < sizeof(szk_interp_pass) / 4)
-            reinterpret_cast<uint32_t *>(&sp)[tid] = reinterpret_cast<const uint32_t *>(&passes[(size_t)j * TRIAL_MAX_PASSES + k])[tid];
-        __syncthreads();
+        __syncthreads();  // previous pass complete
+        if (tid == 0 && b == 0 && j == 1) g_trial_ts[k] = wall_clock64();
+        const szk_interp_pass &sp = sps[k];
         if (sp.kind == 2) {
             for (uint64_t t = tid; t < sp.total; t += 1024) interp_point<T, false, uint32_t>(w, c, sp, t, base);  // (a block has < 2^32 points)
         } else {
             for (uint64_t t = tid; t < sp.total; t += 1024) anchor_point<T, uint32_t>(w, c, sp, t, base);
         }
     }
+    const int radius = sps[0].radius;
     __syncthreads();
+    if (tid == 0 && b == 0 && j == 1) g_trial_ts[np] = wall_clock64();
     uint64_t *hist = hists + (size_t)j * SZH_HIST_BINS;
-    const uint32_t win_lo = (uint32_t)(sp.radius - IH_WIN / 2);
+    const uint32_t win_lo = (uint32_t)(radius - IH_WIN / 2);
     for (uint64_t i = tid; i < per; i += 1024) {
         const uint32_t code = c[i];
         const uint32_t bin = code - win_lo;
@@ -830,6 +853,54 @@ __global__ __launch_bounds__(1024) void k_interp_trials(const T *__restrict__ sa
         const uint32_t v = lh[bb];
         const uint32_t sym = win_lo + bb;
         if (v && sym < SZH_HIST_BINS) atomicAdd((unsigned long long *)&hist[sym], (unsigned long long)v);
+    }
+    if (tid == 0 && b == 0 && j == 1) {
+        g_trial_ts[np + 1] = wall_clock64();
+        g_trial_ts[TRIAL_MAX_PASSES + 7] = np;
+    }
+}
+
+// The same trials with the sample block resident in LDS (blocks up to 140 KB: 33^3 f32, 129^2 f32 / f64, 1-D): neighbour reads
+// cost LDS latency instead of an L2 round trip per point (the passes of a block are latency-bound: 17 points per thread in
+// the last pass), and codes go straight into the histogram window instead of through a code array.
+#define TRIAL_LDS_BYTES 143752
+#define TRIAL_LDS_PASSES 48
+template <typename T>
+__global__ __launch_bounds__(1024) void k_interp_trials_lds(const T *__restrict__ samples, const szk_interp_pass *__restrict__ passes,
+                                                            const uint32_t *__restrict__ npasses, uint32_t per,
+                                                            uint64_t *__restrict__ hists) {
+    __shared__ __align__(16) T w[TRIAL_LDS_BYTES / sizeof(T)];
+    __shared__ szk_interp_pass sps[TRIAL_LDS_PASSES];
+    __shared__ uint32_t lh[IH_WIN];
+    const uint32_t b = blockIdx.x, j = blockIdx.y, nb = gridDim.x, tid = threadIdx.x;
+    const uint64_t base = ((uint64_t)j * nb + b) * per;  // (only offsets the indices of counted unpredictables)
+    const T *in = samples + (uint64_t)b * per;
+    const uint32_t np = npasses[j];
+    {
+        const uint32_t words = np * (uint32_t)(sizeof(szk_interp_pass) / 4);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(passes + (size_t)j * TRIAL_MAX_PASSES);
+        for (uint32_t i = tid; i < words; i += 1024) reinterpret_cast<uint32_t *>(sps)[i] = src[i];
+    }
+    for (uint32_t i = tid; i < per; i += 1024) w[i] = in[i];
+    for (uint32_t i = tid; i < IH_WIN; i += 1024) lh[i] = 0;
+    __syncthreads();
+    TrialSink sink;
+    sink.lh = lh;
+    sink.hist = reinterpret_cast<unsigned long long *>(hists + (size_t)j * SZH_HIST_BINS);
+    sink.win_lo = (uint32_t)(sps[0].radius - IH_WIN / 2);
+    for (uint32_t k = 0; k < np; k++) {
+        const szk_interp_pass &sp = sps[k];
+        if (sp.kind == 2) {
+            for (uint32_t t = tid; t < (uint32_t)sp.total; t += 1024) interp_point<T, false, uint32_t, true>(w, nullptr, sp, t, base, &sink);
+        } else {
+            for (uint32_t t = tid; t < (uint32_t)sp.total; t += 1024) anchor_point<T, uint32_t, true>(w, nullptr, sp, t, base, &sink);
+        }
+        __syncthreads();
+    }
+    for (uint32_t bb = tid; bb < IH_WIN; bb += 1024) {
+        const uint32_t v = lh[bb];
+        const uint32_t sym = sink.win_lo + bb;
+        if (v && sym < SZH_HIST_BINS) atomicAdd(&sink.hist[sym], (unsigned long long)v);
     }
 }
 
@@ -851,7 +922,16 @@ int szk_launch_interp_trials(int dtype, const szk_interp_params *ips, uint32_t n
     if (e != hipSuccess) return (int)e;
     e = hipMemcpyAsync(d_np, h_np, ntrials * 4, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return (int)e;
-    if (dtype == 0)
+    const size_t tsz = dtype == 0 ? 4 : 8;
+    bool lds = per * tsz <= TRIAL_LDS_BYTES;
+    for (uint32_t j = 0; j < ntrials; j++) lds = lds && h_np[j] <= TRIAL_LDS_PASSES;
+    if (lds && dtype == 0)
+        hipLaunchKernelGGL((k_interp_trials_lds<float>), dim3(nblocks, ntrials), dim3(1024), 0, s, (const float *)d_samples, d_passes, d_np,
+                           (uint32_t)per, d_hists);
+    else if (lds)
+        hipLaunchKernelGGL((k_interp_trials_lds<double>), dim3(nblocks, ntrials), dim3(1024), 0, s, (const double *)d_samples, d_passes, d_np,
+                           (uint32_t)per, d_hists);
+    else if (dtype == 0)
         hipLaunchKernelGGL((k_interp_trials<float>), dim3(nblocks, ntrials), dim3(1024), 0, s, (const float *)d_samples, (float *)d_work, codes,
                            d_passes, d_np, per, d_hists);
     else

@@ -400,9 +400,9 @@ struct sz3hip_ctx {
     size_t samples_cap;
     uint64_t *d_trial;  // [8][4]: bits, symbols, unpredictables, delta outliers
     uint64_t *h_trial;  // pinned
-    uint64_t *d_trial_hist;      // [SZK_MAX_BOOKS][65536] histograms of the trials of one group
-    uint64_t *d_trial_counters;  // [SZK_MAX_BOOKS][8]
-    szk_interp_pass *d_passes, *h_passes;  // [SZK_MAX_BOOKS][SZK_TRIAL_MAX_PASSES] pass schedules (h: pinned)
+    uint64_t *d_trial_hist;      // [SZK_MAX_TRIALS][65536] histograms of the trials of one group
+    uint64_t *d_trial_counters;  // [SZK_MAX_TRIALS][8]
+    szk_interp_pass *d_passes, *h_passes;  // [SZK_MAX_TRIALS][SZK_TRIAL_MAX_PASSES] pass schedules (h: pinned)
     uint32_t *d_np, *h_np;
     sz3hip_tuner_report tuner;
     // profiling
@@ -717,17 +717,17 @@ static int tuner_reserve(sz3hip_ctx *ctx, size_t flags, size_t starts, size_t sa
         HIPCHK(hipMalloc(&ctx->d_samples, samples));
         ctx->samples_cap = samples;
     }
-    if (!ctx->d_trial) {  // one block [results 256 B][counters 256 B][histograms]: a group zeroes it with one memset
-        HIPCHK(hipMalloc(&ctx->d_trial, 512 + SZK_MAX_BOOKS * SZH_HIST_BINS * 8));
+    if (!ctx->d_trial) {  // one block [results 256 B][counters 512 B][pad][histograms]: a group zeroes it with one memset
+        HIPCHK(hipMalloc(&ctx->d_trial, 1024 + SZK_MAX_TRIALS * SZH_HIST_BINS * 8));
         ctx->d_trial_counters = ctx->d_trial + 32;
-        ctx->d_trial_hist = ctx->d_trial + 64;
+        ctx->d_trial_hist = ctx->d_trial + 128;
     }
     if (!ctx->h_trial) HIPCHK(hipHostMalloc((void **)&ctx->h_trial, 8 * 4 * 8));
-    const size_t pbytes = SZK_MAX_BOOKS * SZK_TRIAL_MAX_PASSES * sizeof(szk_interp_pass);
+    const size_t pbytes = SZK_MAX_TRIALS * SZK_TRIAL_MAX_PASSES * sizeof(szk_interp_pass);
     if (!ctx->d_passes) HIPCHK(hipMalloc(&ctx->d_passes, pbytes));
     if (!ctx->h_passes) HIPCHK(hipHostMalloc((void **)&ctx->h_passes, pbytes));
-    if (!ctx->d_np) HIPCHK(hipMalloc(&ctx->d_np, 4 * SZK_MAX_BOOKS));
-    if (!ctx->h_np) HIPCHK(hipHostMalloc((void **)&ctx->h_np, 4 * SZK_MAX_BOOKS));
+    if (!ctx->d_np) HIPCHK(hipMalloc(&ctx->d_np, 4 * SZK_MAX_TRIALS));
+    if (!ctx->h_np) HIPCHK(hipHostMalloc((void **)&ctx->h_np, 4 * SZK_MAX_TRIALS));
     if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
     return 0;
 }
@@ -739,12 +739,12 @@ static double trial_bytes(const uint64_t *r, size_t tsz) {
     const double tree = 13.0 + nc * (2 * w + 5);  // HuffmanEncoder::save: [i32][i32][i32][u8] L R C t (HuffmanEncoder.hpp:108-125)
     return std::ceil((double)r[0] / 2048.0) + 0.45 * tree + (double)r[2] * (double)tsz + (double)r[3] * 12.0 + 80.0;
 }
-// one group of up to SZK_MAX_BOOKS independent trials: one interpolation launch for all of them, one cost launch over their
+// one group of up to SZK_MAX_TRIALS independent trials: one interpolation launch for all of them, one cost launch over their
 // histograms; trial j's priced size lands in result slot slot0 + j
 static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr, double eb, int radius, uint32_t nb, int slot0,
                               hipStream_t s) {
-    HIPCHK(hipMemsetAsync(ctx->d_trial, 0, 512 + (size_t)ntr * SZH_HIST_BINS * 8, s));  // (earlier groups' results were fetched)
-    szk_interp_params ips[SZK_MAX_BOOKS];
+    HIPCHK(hipMemsetAsync(ctx->d_trial, 0, 1024 + (size_t)ntr * SZH_HIST_BINS * 8, s));  // (earlier groups' results were fetched)
+    szk_interp_params ips[SZK_MAX_TRIALS];
     for (int j = 0; j < ntr; j++) {
         int rc = interp_params_from(&tcs[j], eb, radius, ips[j]);
         if (rc) return rc;
@@ -861,13 +861,24 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
     // reversed-order trial only for the better formula: slots 2 / 3 hold that trial for linear / cubic)
     int fact = 1;
     for (int i = 2; i <= N; i++) fact *= i;
+    // The (alpha, beta) trials of the most common outcome (cubic, identity order) ride along speculatively in slots 4..6 when
+    // all trial workgroups of the launch still fit the chip at once (one workgroup per compute unit): the launch takes no
+    // longer, and the second round trip (launch + fetch) is saved whenever the first group confirms that outcome.
+    static const double alphas[3] = {1.0, 1.5, 2.0}, betas[3] = {1.0, 2.5, 3.0};
+    const bool speculate = nb * 7 <= 256;
     {
-        sz3hip_config g[4] = {tc, tc, tc, tc};
+        sz3hip_config g[7] = {tc, tc, tc, tc, tc, tc, tc};
         for (int k = 0; k < 4; k++) {
             g[k].interpAlgo = (uint8_t)(k & 1);
             g[k].interpDirection = (uint8_t)(k < 2 ? 0 : fact - 1);
         }
-        rc = tuner_interp_group(ctx, g, 4, eb, radius, (uint32_t)nb, 0, s);
+        for (int i = 0; i < 3; i++) {
+            g[4 + i].interpAlgo = 1;
+            g[4 + i].interpDirection = 0;
+            g[4 + i].interpAlpha = alphas[i];
+            g[4 + i].interpBeta = betas[i];
+        }
+        rc = tuner_interp_group(ctx, g, speculate ? 7 : 4, eb, radius, (uint32_t)nb, 0, s);
         if (rc) return rc;
     }
     rc = tuner_fetch(ctx, s);
@@ -890,8 +901,8 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
     }
     tc.interpDirection = conf.interpDirection;
     // (alpha, beta) pairs
-    static const double alphas[3] = {1.0, 1.5, 2.0}, betas[3] = {1.0, 2.5, 3.0};
-    {
+    int ab_slot = 4;
+    if (!(speculate && conf.interpAlgo == 1 && conf.interpDirection == 0)) {
         sz3hip_config g[3] = {tc, tc, tc};
         for (int i = 0; i < 3; i++) {
             g[i].interpAlpha = alphas[i];
@@ -899,11 +910,12 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
         }
         rc = tuner_interp_group(ctx, g, 3, eb, radius, (uint32_t)nb, 3, s);
         if (rc) return rc;
+        rc = tuner_fetch(ctx, s);
+        if (rc) return rc;
+        ab_slot = 3;
     }
-    rc = tuner_fetch(ctx, s);
-    if (rc) return rc;
     for (int i = 0; i < 3; i++) {
-        rep.est_bytes[3 + i] = trial_bytes(ctx->h_trial + 4 * (3 + i), tsz);
+        rep.est_bytes[3 + i] = trial_bytes(ctx->h_trial + 4 * (ab_slot + i), tsz);
         const double ratio = raw / rep.est_bytes[3 + i];
         if (ratio > best_interp * 1.02) {
             best_interp = ratio;

@@ -71,6 +71,7 @@ struct szk_cb_params {
     uint32_t n_books;  // 0/1: one code book (+ the outlier sorts); 2..SZK_MAX_BOOKS: a batch, tables sliced per book
 };
 #define SZK_MAX_BOOKS 4
+#define SZK_MAX_TRIALS 8  // tuner trials of one launch group
 
 struct szk_state {
     szh_header hdr;

@@ -398,6 +398,11 @@ struct sz3hip_ctx {
     size_t starts_cap;
     void *d_samples;
     size_t samples_cap;
+    void *d_trial_work;  // scratch of the trial kernel's global-memory variant (blocks too large for LDS)
+    size_t trial_work_cap;
+    hipStream_t side;    // the working copy of the input is made here while the tuner runs on the caller's stream
+    hipEvent_t ev_fork, ev_join;
+    bool copy_ahead;     // d_work already holds this call's input (joined into the caller's stream)
     uint64_t *d_trial;  // [8][4]: bits, symbols, unpredictables, delta outliers
     uint64_t *h_trial;  // pinned
     uint64_t *d_trial_hist;      // [SZK_MAX_TRIALS][65536] histograms of the trials of one group
@@ -415,10 +420,16 @@ static void ctx_free(sz3hip_ctx *c) {
     if (!c) return;
     void *bufs[] = {c->d_work, c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_counters, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
                     c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_aux2, c->d_pint2, c->d_range, c->d_info,
-                    c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples,
+                    c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples, c->d_trial_work,
                     c->d_trial, c->d_passes, c->d_np};  // (d_trial_counters / d_trial_hist live inside d_trial's block)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->d_flags) (void)hipHostFree(c->d_flags);
     if (c->d_starts) (void)hipHostFree(c->d_starts);
     if (c->h_state) (void)hipHostFree(c->h_state);
@@ -610,7 +621,8 @@ static int stage1_interp(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
     ip.vout_val = ctx->d_vout_val;
     ip.out_cap = ctx->cur_out_cap;
     prof_begin(ctx, ST_K1, s);
-    int rci = szk_launch_interp_compress(ctx->dtype, &ip, d_in, ctx->d_work, ctx->d_codes, ctx->d_hist, s);
+    int rci = szk_launch_interp_compress(ctx->dtype, &ip, ctx->copy_ahead ? nullptr : d_in, ctx->d_work, ctx->d_codes, ctx->d_hist, s);
+    ctx->copy_ahead = false;
     prof_end(ctx, ST_K1, s);
     if (rci) return fail(SZ3HIP_EHIP, "interpolation kernel launch failed (%d)", rci);
     memset(&ctx->mode, 0, sizeof(ctx->mode));
@@ -717,6 +729,12 @@ static int tuner_reserve(sz3hip_ctx *ctx, size_t flags, size_t starts, size_t sa
         HIPCHK(hipMalloc(&ctx->d_samples, samples));
         ctx->samples_cap = samples;
     }
+    if (ctx->trial_work_cap < samples * SZK_MAX_TRIALS) {  // (d_work itself is being filled on the side stream)
+        if (ctx->d_trial_work) (void)hipFree(ctx->d_trial_work);
+        ctx->d_trial_work = nullptr;
+        HIPCHK(hipMalloc(&ctx->d_trial_work, samples * SZK_MAX_TRIALS));
+        ctx->trial_work_cap = samples * SZK_MAX_TRIALS;
+    }
     if (!ctx->d_trial) {  // one block [results 256 B][counters 512 B][pad][histograms]: a group zeroes it with one memset
         HIPCHK(hipMalloc(&ctx->d_trial, 1024 + SZK_MAX_TRIALS * SZH_HIST_BINS * 8));
         ctx->d_trial_counters = ctx->d_trial + 32;
@@ -753,7 +771,7 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
         ips[j].vout_val = ctx->d_vout_val;
         ips[j].out_cap = 0;  // count only
     }
-    int rc = szk_launch_interp_trials(ctx->dtype, ips, (uint32_t)ntr, ctx->d_samples, ctx->d_work, ctx->d_codes, nb, ctx->d_trial_hist,
+    int rc = szk_launch_interp_trials(ctx->dtype, ips, (uint32_t)ntr, ctx->d_samples, ctx->d_trial_work, ctx->d_codes, nb, ctx->d_trial_hist,
                                       ctx->h_passes, ctx->d_passes, ctx->h_np, ctx->d_np, s);
     if (rc) return fail(SZ3HIP_EHIP, "tuner: interpolation trial launch failed (%d)", rc);
     rc = szk_launch_code_cost(ctx->d_trial_hist, ctx->d_trial_counters, ctx->d_trial + 4 * slot0, (uint32_t)ntr, tcs[0].num * nb, s);
@@ -977,11 +995,30 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     ctx->cur_out_cap = std::min<uint64_t>(ctx->out_cap, std::max<uint64_t>(1024, num / 32));
     memset(&ctx->tuner, 0, sizeof(ctx->tuner));
     for (int i = 0; i < ST_COUNT; i++) ctx->ev_used[i] = false;  // stage times describe this call only
+    ctx->copy_ahead = false;
     if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP_LORENZO) {  // the reference's default: sampling auto-tuner, then one of the two paths
+        // The tuner is a chain of small launches and host round trips (the chip is mostly idle), and its outcome is almost
+        // always interpolation, which starts from a working copy of the input: make that copy meanwhile on a side stream.
+        if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
+        if (!ctx->side) {
+            HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(ctx->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        HIPCHK(hipMemcpyAsync(ctx->d_work, d_in, num * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8), hipMemcpyDeviceToDevice, ctx->side));
+        HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
         prof_begin(ctx, ST_TUNER, s);
         int rct = tune_interp_lorenzo(ctx, *conf, d_in, eb, radius, s);
         prof_end(ctx, ST_TUNER, s);
+        hipError_t ej = hipStreamWaitEvent(s, ctx->ev_join, 0);  // whatever the outcome: the caller's stream owns d_in again
+        if (ej != hipSuccess) {
+            (void)hipStreamSynchronize(ctx->side);
+            return fail(SZ3HIP_EHIP, "joining the side stream failed: %s", hipGetErrorString(ej));
+        }
         if (rct) return rct;
+        ctx->copy_ahead = true;
     }
     HIPCHK(hipMemsetAsync(ctx->d_hist, 0, SZH_HIST_BINS * 8, s));
     HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 64, s));

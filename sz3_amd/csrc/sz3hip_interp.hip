@@ -650,7 +650,8 @@ int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const voi
     uint64_t num = 1;
     for (int i = 0; i < ip->N; i++) num *= ip->dims[i];
     const size_t tsz = dtype == 0 ? 4 : 8;
-    hipError_t e = hipMemcpyAsync(d_work, d_in, num * tsz, hipMemcpyDeviceToDevice, s);  // the dispatcher's dataCopy
+    hipError_t e = hipSuccess;
+    if (d_in) e = hipMemcpyAsync(d_work, d_in, num * tsz, hipMemcpyDeviceToDevice, s);  // the dispatcher's dataCopy
     if (e != hipSuccess) return (int)e;
     int rc = dtype == 0 ? run_interp<float, false>(*ip, (float *)d_work, codes, s)
                         : run_interp<double, false>(*ip, (double *)d_work, codes, s);

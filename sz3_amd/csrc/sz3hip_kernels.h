@@ -140,6 +140,7 @@ struct szk_interp_pass {
     uint64_t out_cap;
 };
 extern int szk_interp_novec;
+// d_in == nullptr: d_work already holds the copy of the input (made on a side stream while the tuner ran)
 int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const void *d_in, void *d_work, uint16_t *codes,
                                uint64_t *hist, hipStream_t s);
 int szk_launch_interp_decompress(int dtype, const szk_interp_params *ip, const uint8_t *payload, uint64_t vout_idx_off,

@@ -243,8 +243,11 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
     idx += x0;
     T o[8];
     ld8<T>(w + idx, o);
-    uint32_t cw[4];
-    {
+    // Codes of the 8 elements. Decompression reads them. A compression pass along x keeps the even-x codes of earlier
+    // passes; a pass along a slower dimension owns every slot it writes (with xstep = 2 the odd-x slots belong to the
+    // later pass along x, which overwrites them), so it does not read the old words at all.
+    uint32_t cw[4] = {0u, 0u, 0u, 0u};
+    if (DEC || XDIR) {
         const uint4 cv = *reinterpret_cast<const uint4 *>(codes + idx);
         cw[0] = cv.x; cw[1] = cv.y; cw[2] = cv.z; cw[3] = cv.w;
     }

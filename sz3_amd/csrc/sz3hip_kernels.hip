@@ -2312,19 +2312,30 @@ __global__ __launch_bounds__(1024) void k_dec_tables(const uint8_t *__restrict__
     }
 }
 
-// one thread per chunk: table lookup on the next lut_bits bits of a 64-bit MSB-aligned window, canonical length search
-// for the (rare) longer code words; the next stream word is always in flight
+// one thread per chunk: table lookup on the next lut_bits bits of a 64-bit MSB-aligned window. Code words longer than the
+// table (interpolation streams at tight bounds keep ~3 % of their symbols there: every step of a wave meets one) are
+// decoded without a loop or a global access: the length is K + 1 + the number of lengths l whose left-aligned upper code
+// bound is <= the window (canonical codes grow with the length), and the symbols of the long codes sit in LDS.
+#define DEC_SORTED_LDS 16384u  // symbols of the codes longer than the table kept in LDS (further ranks: global)
 __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payload, szk_dec_params p,
                                                 uint16_t *__restrict__ codes) {
-    __shared__ uint32_t s_first_code[SZH_MAX_LEN + 2], s_first_rank[SZH_MAX_LEN + 2], s_count[SZH_MAX_LEN + 2];
+    __shared__ uint32_t s_first_code[SZH_MAX_LEN + 2], s_first_rank[SZH_MAX_LEN + 2], s_upper[SZH_MAX_LEN + 2];
     __shared__ uint32_t s_lut[1u << DEC_LUT_BITS];
-    if (threadIdx.x <= SZH_MAX_LEN) {
-        s_first_code[threadIdx.x] = threadIdx.x ? p.tables->first_code[threadIdx.x] : 0;
-        s_first_rank[threadIdx.x] = threadIdx.x ? p.tables->first_rank[threadIdx.x] : 0;
-        s_count[threadIdx.x] = threadIdx.x ? p.tables->count[threadIdx.x] : 0;
+    __shared__ uint16_t s_sorted[DEC_SORTED_LDS];
+    const uint32_t max_len = p.tables->max_len, K = p.tables->lut_bits, n_coded = p.tables->n_coded;
+    if (threadIdx.x <= SZH_MAX_LEN + 1) {
+        const uint32_t l = threadIdx.x;
+        const bool in = l >= 1 && l <= SZH_MAX_LEN;
+        const uint32_t fc = in ? p.tables->first_code[l] : 0, cnt = in ? p.tables->count[l] : 0;
+        s_first_code[l] = fc;
+        s_first_rank[l] = in ? p.tables->first_rank[l] : 0;
+        // exclusive upper bound of the length-l code words, left-aligned to 32 bits (lengths >= max_len never count)
+        s_upper[l] = in && l < max_len ? (fc + cnt) << (32 - l) : 0xFFFFFFFFu;
     }
-    const uint32_t max_len = p.tables->max_len, K = p.tables->lut_bits;
     for (uint32_t e = threadIdx.x; e < (1u << K); e += 256) s_lut[e] = p.tables->lut[e];
+    const uint16_t *sorted = p.tables->sorted_syms;
+    const uint32_t base_rank = K < max_len ? p.tables->first_rank[K + 1] : n_coded;
+    for (uint32_t e = threadIdx.x; e < DEC_SORTED_LDS && base_rank + e < n_coded; e += 256) s_sorted[e] = sorted[base_rank + e];
     __syncthreads();
     const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (chunk >= p.n_chunks) return;
@@ -2341,7 +2352,6 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     uint64_t woff = p.group_off[grp];
     for (uint64_t c = grp * PACK_GROUP; c < chunk; c++) woff += p.chunk_words[c];
     const uint32_t *bs = reinterpret_cast<const uint32_t *>(payload + p.bitstream_off);
-    const uint16_t *sorted = p.tables->sorted_syms;
     const uint32_t nwords = p.chunk_words[chunk];
     const uint64_t wlast = p.total_words ? p.total_words - 1 : 0;  // loads are clamped to the section, never conditional
     uint64_t buf = 0;  // next bits at the MSB end
@@ -2380,15 +2390,19 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                 const uint32_t ent = s_lut[(uint32_t)(buf >> (64 - K))];
                 uint32_t l = ent & 0xFFu;
                 sym = ent >> 8;
-                if (ent == 0) {  // longer than the table: canonical length search
-                    for (l = K + 1; l <= max_len; l++) {
-                        const uint32_t v = (uint32_t)(buf >> (64 - l));
-                        const uint32_t rel = v - s_first_code[l];
-                        if (rel < s_count[l]) {
-                            sym = sorted[s_first_rank[l] + rel];
-                            break;
-                        }
+                if (ent == 0) {  // longer than the table
+                    const uint32_t v = (uint32_t)(buf >> 32);
+                    l = K + 1;
+#pragma unroll
+                    for (uint32_t q = DEC_LUT_BITS + 1; q < SZH_MAX_LEN; q++) l += (q > K && v >= s_upper[q]) ? 1u : 0u;
+                    if (K < DEC_LUT_BITS) {  // (short tables only exist when max_len <= K: never here; keeps the rule general)
+                        for (uint32_t q = K + 1; q <= DEC_LUT_BITS && q < SZH_MAX_LEN; q++) l += v >= s_upper[q] ? 1u : 0u;
                     }
+                    l = l > max_len ? max_len : l;
+                    uint32_t rank = s_first_rank[l] + ((v >> (32 - l)) - s_first_code[l]);
+                    rank = rank < n_coded ? rank : n_coded - 1;  // (corrupt streams must not read out of bounds)
+                    const uint32_t rr = rank - base_rank;
+                    sym = rr < DEC_SORTED_LDS ? (uint32_t)s_sorted[rr] : (uint32_t)sorted[rank];
                 }
                 buf <<= l;
                 have -= (int)l;

@@ -106,8 +106,13 @@ typedef struct sz3hip_ctx sz3hip_ctx;
  * allocated here, nothing is allocated inside the compress/decompress calls) */
 sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dataType);
 void sz3hip_ctx_destroy(sz3hip_ctx *ctx);
-/* upper bound of the device payload for n elements */
+/* upper bound of the device payload for n elements (outlier lists of up to n / 32 entries: a compress call that needs more
+ * returns SZ3HIP_EOUTLIERS when the buffer is this size) */
 size_t sz3hip_payload_bound(const sz3hip_ctx *ctx, uint64_t n);
+/* the bound with the largest outlier lists the library will build (n / 8 entries: rough fields at tight bounds, small
+ * quantbinCnt). With a buffer this large sz3hip_compress_device grows its lists on demand and retries instead of
+ * returning SZ3HIP_EOUTLIERS (the reference keeps any number of unpredictable values, LinearQuantizer.hpp:43-66). */
+size_t sz3hip_payload_bound_max(const sz3hip_ctx *ctx, uint64_t n);
 
 /* global min/max of a device array (K0: utils/Statistic.hpp:12-21); result written to host doubles (synchronises) */
 int sz3hip_minmax_device(sz3hip_ctx *ctx, const void *d_in, uint64_t n, double *min_out, double *max_out, void *stream);

@@ -92,6 +92,8 @@ def lib():
     L.sz3hip_ctx_destroy.argtypes = [C.c_void_p]
     L.sz3hip_payload_bound.restype = C.c_size_t
     L.sz3hip_payload_bound.argtypes = [C.c_void_p, C.c_uint64]
+    L.sz3hip_payload_bound_max.restype = C.c_size_t
+    L.sz3hip_payload_bound_max.argtypes = [C.c_void_p, C.c_uint64]
     L.sz3hip_minmax_device.restype = C.c_int
     L.sz3hip_minmax_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_double), P(C.c_double), C.c_void_p]
     L.sz3hip_compress_stage1.restype = C.c_int
@@ -267,7 +269,11 @@ class DeviceCompressor:
         except Exception:
             pass
 
-    def payload_bound(self, n):
+    def payload_bound(self, n, worst_case=False):
+        """device payload bound; worst_case=True leaves room for outlier lists of n / 8 entries (compress then grows
+        its lists on demand instead of raising SZ3HIP_EOUTLIERS)"""
+        if worst_case:
+            return int(lib().sz3hip_payload_bound_max(self._h, int(n)))
         return int(lib().sz3hip_payload_bound(self._h, int(n)))
 
     def minmax(self, d_in, n, stream=0):

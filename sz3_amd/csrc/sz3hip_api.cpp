@@ -362,6 +362,8 @@ struct sz3hip_ctx {
     int device;
     int dtype;
     uint64_t max_n, out_cap, cur_out_cap, max_chunks;
+    uint64_t out_alloc;      // entries the four outlier arrays hold (>= out_cap; grown on demand)
+    uint64_t force_out_cap;  // != 0: list capacity of the retry after an overflow
     // device buffers
     uint16_t *d_codes;
     uint64_t *d_hist;      // histogram in use (internal or caller-owned)
@@ -460,6 +462,7 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     c->dtype = dataType;
     c->max_n = max_elems;
     c->out_cap = std::max<uint64_t>(4096, max_elems / 32);
+    c->out_alloc = c->out_cap;
     c->max_chunks = (max_elems + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
     const size_t tsz = dataType == SZ3HIP_FLOAT ? 4 : 8;
     bool ok = true;
@@ -519,6 +522,11 @@ static size_t payload_bound_n(uint64_t n, uint64_t out_cap) {
                     4 * n_chunks * (SZH_CHUNK_SYMS * SZH_MAX_LEN / 32) + 64);
 }
 extern "C" size_t sz3hip_payload_bound(const sz3hip_ctx *ctx, uint64_t n) { return payload_bound_n(n, ctx->out_cap); }
+// lists of up to n / 8 entries: beyond that the stream cannot beat the lossless fallback any more
+static uint64_t out_cap_limit(uint64_t n) { return std::max<uint64_t>(1024, n / 8); }
+extern "C" size_t sz3hip_payload_bound_max(const sz3hip_ctx *ctx, uint64_t n) {
+    return payload_bound_n(n, std::max<uint64_t>(ctx->out_cap, out_cap_limit(n)));
+}
 extern "C" void *sz3hip_histogram_ptr(sz3hip_ctx *ctx) { return ctx->d_hist; }
 extern "C" size_t sz3hip_histogram_len(const sz3hip_ctx *) { return SZH_HIST_BINS; }
 extern "C" int sz3hip_ctx_set_histogram(sz3hip_ctx *ctx, void *d_hist) {
@@ -992,7 +1000,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     if (!(eb > 0) || !isfinite(eb)) return fail(SZ3HIP_EINVAL, "absErrorBound must be positive and finite");
     const int radius = conf->quantbinCnt / 2;  // api/impl/SZAlgoLorenzoReg.hpp:72
     if (radius < 2 || radius > 32768) return fail(SZ3HIP_EINVAL, "quantbinCnt must be in [4, 65536]");
-    ctx->cur_out_cap = std::min<uint64_t>(ctx->out_cap, std::max<uint64_t>(1024, num / 32));
+    ctx->cur_out_cap = ctx->force_out_cap ? ctx->force_out_cap : std::min<uint64_t>(ctx->out_cap, std::max<uint64_t>(1024, num / 32));
     memset(&ctx->tuner, 0, sizeof(ctx->tuner));
     for (int i = 0; i < ST_COUNT; i++) ctx->ev_used[i] = false;  // stage times describe this call only
     ctx->copy_ahead = false;
@@ -1032,7 +1040,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     HIPCHK(hipSetDevice(ctx->device));
     if (!ctx->stage1_done) return fail(SZ3HIP_EINVAL, "stage2 called before stage1");
     const uint64_t n = ctx->proto.n;
-    if (cap < payload_bound_n(n, ctx->out_cap))
+    if (cap < payload_bound_n(n, std::max<uint64_t>(ctx->out_cap, ctx->cur_out_cap)))
         return fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
     szk_cb_params cb;
     cb_params_from(ctx, cb, ctx->cur_out_cap);
@@ -1107,6 +1115,42 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
 extern "C" int sz3hip_compress_device(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, void *d_payload,
                                       size_t cap, size_t *payload_size, void *stream) {
     int rc = sz3hip_compress_stage1(ctx, conf, d_in, stream);
+    if (rc) return rc;
+    rc = sz3hip_compress_stage2(ctx, d_payload, cap, stream);
+    if (rc) return rc;
+    rc = sz3hip_compress_finish(ctx, payload_size, stream);
+    if (rc != SZ3HIP_EOUTLIERS) return rc;
+    // More unpredictable values than the default lists hold (n / 32): a rough field at a tight bound, or a small
+    // quantbinCnt. The reference keeps any number of them; here the lists grow to what this input needs (up to n / 8,
+    // where the stream stops beating the lossless fallback) when the caller's buffer allows it
+    // (sz3hip_payload_bound_max), and the call runs once more.
+    const uint64_t n = ctx->proto.n;
+    uint64_t cnt[2] = {0, 0};
+    HIPCHK(hipMemcpy(cnt, ctx->d_counters, 16, hipMemcpyDeviceToHost));
+    const uint64_t need = std::max(cnt[0], cnt[1]);
+    if (need > out_cap_limit(n)) return rc;
+    const uint64_t want = std::min<uint64_t>(out_cap_limit(n), need + need / 16 + 1024);
+    if (cap < payload_bound_n(n, std::max<uint64_t>(ctx->out_cap, want))) return rc;
+    if (want > ctx->out_alloc) {  // (finish() synchronised the stream: nothing uses the old arrays)
+        void **arr[4] = {(void **)&ctx->d_vout_idx, (void **)&ctx->d_dout_idx, &ctx->d_vout_val, &ctx->d_dout_val};
+        void *fresh[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool ok = true;
+        for (int i = 0; i < 4 && ok; i++) ok = hipMalloc(&fresh[i], want * 8) == hipSuccess;
+        if (!ok) {
+            for (void *f : fresh)
+                if (f) (void)hipFree(f);
+            (void)hipGetLastError();
+            return rc;  // no memory for larger lists: the caller falls back to lossless
+        }
+        for (int i = 0; i < 4; i++) {
+            (void)hipFree(*arr[i]);
+            *arr[i] = fresh[i];
+        }
+        ctx->out_alloc = want;
+    }
+    ctx->force_out_cap = want;
+    rc = sz3hip_compress_stage1(ctx, conf, d_in, stream);
+    ctx->force_out_cap = 0;
     if (rc) return rc;
     rc = sz3hip_compress_stage2(ctx, d_payload, cap, stream);
     if (rc) return rc;
@@ -1357,6 +1401,11 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
             // ALGO_LORENZO_REG / NOPRED -> HIP Lorenzo stream (16); ALGO_INTERP / ALGO_INTERP_LORENZO -> HIP interpolation (17)
             size_t dsize = 0;
             int rc = sz3hip_compress_device(ctx, &conf, g_dev_in[cdt], g_dev_payload[cdt], g_dev_payload_bytes[cdt], &dsize, nullptr);
+            if (rc == SZ3HIP_EOUTLIERS && g_dev_payload_bytes[cdt] < sz3hip_payload_bound_max(ctx, conf.num)) {
+                // room for the largest lists, then once more (the device call grows them to what the input needs)
+                if (ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], sz3hip_payload_bound_max(ctx, conf.num))) return 0;
+                rc = sz3hip_compress_device(ctx, &conf, g_dev_in[cdt], g_dev_payload[cdt], g_dev_payload_bytes[cdt], &dsize, nullptr);
+            }
             if (rc == SZ3HIP_EOUTLIERS) {
                 lossless = true;  // same policy as the reference's length_error fallback, SZDispatcher.hpp:44-59
             } else if (rc) {

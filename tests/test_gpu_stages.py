@@ -177,3 +177,47 @@ def test_narrow_and_wide_code_paths_agree():
     q, dd, exp_codes, bad, dout = szh_ref.dualquant(e, 1e-3, narrow=bool(s3["narrow_codes"]))
     assert np.array_equal(c3, exp_codes.reshape(-1)) and s3["n_delta_outliers"] == int(dout.sum())
     assert np.max(np.abs(d3.astype(np.float64) - e.astype(np.float64))) <= 1e-3
+
+
+@pytest.mark.parametrize("algo", ["lorenzo", "interp"])
+def test_many_unpredictables_grow_the_lists(algo):
+    """More unpredictable values than the default lists hold (n / 32): with a default-sized buffer the device call
+    reports SZ3HIP_EOUTLIERS; with sz3hip_payload_bound_max it grows its lists and succeeds, and the host API keeps
+    the GPU stream instead of falling back to lossless (the reference keeps any number of unpredictables)."""
+    rng = np.random.default_rng(11)
+    shape = (64, 64, 64)
+    a = field3d(shape)
+    mask = rng.random(shape) < 0.01          # 1 % spikes far outside a 64-bin quantiser: each one spoils its neighbours' predictions
+    a[mask] += rng.choice([-1.0, 1.0], size=int(mask.sum())).astype(np.float32) * 50.0
+    eb = 1e-3
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    conf = sz3_amd.Config(*shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG if algo == "lorenzo" else sz3_amd.ALGO_INTERP
+    conf.absErrorBound = eb
+    conf.quantbinCnt = 64
+    cap = dc.payload_bound(a.size)
+    pl = torch.empty(dc.payload_bound(a.size, worst_case=True), dtype=torch.uint8, device=dev)
+    with pytest.raises(sz3_amd.SZ3HipError):
+        dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+    size = dc.compress(conf, t.data_ptr(), pl.data_ptr(), pl.numel(), 0)
+    st = dc.stats()
+    assert max(st["n_value_outliers"], st["n_delta_outliers"]) > a.size // 32
+    out = torch.empty_like(t)
+    dc.decompress(pl.data_ptr(), size, out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    dec = out.cpu().numpy()
+    assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= eb
+    # an easy input afterwards still fits the default bound (the grown lists do not change sz3hip_payload_bound)
+    b = field3d(shape)
+    tb = torch.from_numpy(b).to(dev)
+    conf.quantbinCnt = 65536
+    size_b = dc.compress(conf, tb.data_ptr(), pl.data_ptr(), cap, 0)
+    assert 0 < size_b < b.nbytes // 4
+    # host API: GPU stream, not the lossless fallback
+    conf.quantbinCnt = 64
+    blob, ratio = sz3_amd.compress(a, conf)
+    back, got_conf = sz3_amd.decompress(blob, a.dtype, shape)
+    assert np.max(np.abs(back.astype(np.float64) - a.astype(np.float64))) <= eb
+    assert ratio > 2 and got_conf.cmprAlgo in (16, 17)

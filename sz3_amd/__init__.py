@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsz3hip.so")
+LIB_PATH = os.environ.get("SZ3HIP_LIB") or os.path.join(_HERE, "libsz3hip.so")  # (SZ3HIP_LIB: A/B runs of two builds)
 
 # include/SZ3/utils/Config.hpp:66,80,93 (enum EB / ALGO / INTERP_ALGO) + the GPU stream id (include/sz3hip.h)
 EB_ABS, EB_REL, EB_PSNR, EB_L2NORM, EB_ABS_AND_REL, EB_ABS_OR_REL = range(6)

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1289,6 +1290,19 @@ sz3hip_ctx *get_ctx(int dtype, uint64_t n) {
     c = sz3hip_ctx_create(host_device(), n, dtype);
     return c;
 }
+// pinned host staging for the payload (the device <-> host hop of the host API): DMA at link speed, no page faults
+void *g_pin;
+size_t g_pin_bytes;
+int ensure_pin(size_t want) {
+    if (g_pin_bytes >= want) return 0;
+    if (g_pin) (void)hipHostFree(g_pin);
+    g_pin = nullptr;
+    g_pin_bytes = 0;
+    want += want / 4;  // (payload sizes vary from call to call)
+    HIPCHK(hipHostMalloc(&g_pin, want));
+    g_pin_bytes = want;
+    return 0;
+}
 int ensure_dev(void **p, size_t *have, size_t want) {
     if (*have >= want) return 0;
     if (*p) (void)hipFree(*p);
@@ -1327,8 +1341,21 @@ static int cal_abs_eb(sz3hip_config &conf, sz3hip_ctx *ctx, const void *d_in) {
     return 0;
 }
 
+// SZ3HIP_TIMING=1: wall-clock breakdown of the host API on stderr (development aid)
+struct HostTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    HostTimer() : on(getenv("SZ3HIP_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void lap(const char *what) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sz3hip] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, const void *data, char *cmpData,
                                   size_t cmpCap) {
+    HostTimer tm;
     if (!dtype_ok(dataType)) {
         fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
         return 0;
@@ -1365,11 +1392,13 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
         if (ensure_dev(&g_dev_in[cdt], &g_dev_in_bytes[cdt], (size_t)conf.num * (cdt == SZ3HIP_FLOAT ? 4 : 8))) return 0;
         const size_t pb = sz3hip_payload_bound(ctx, conf.num);
         if (ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], pb)) return 0;
+        tm.lap("setup");
         if (!is_int) {
             if (hipMemcpy(g_dev_in[cdt], data, raw_bytes, hipMemcpyHostToDevice) != hipSuccess) {
                 fail(SZ3HIP_EHIP, "host->device copy failed");
                 return 0;
             }
+            tm.lap("host->device");
         } else {
             // integers: staged in the (still unused) payload buffer, widened to f64 on the device
             if (pb < raw_bytes + 16 && ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], raw_bytes + 16)) return 0;
@@ -1401,6 +1430,7 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
             // ALGO_LORENZO_REG / NOPRED -> HIP Lorenzo stream (16); ALGO_INTERP / ALGO_INTERP_LORENZO -> HIP interpolation (17)
             size_t dsize = 0;
             int rc = sz3hip_compress_device(ctx, &conf, g_dev_in[cdt], g_dev_payload[cdt], g_dev_payload_bytes[cdt], &dsize, nullptr);
+            tm.lap("device compress");
             if (rc == SZ3HIP_EOUTLIERS && g_dev_payload_bytes[cdt] < sz3hip_payload_bound_max(ctx, conf.num)) {
                 // room for the largest lists, then once more (the device call grows them to what the input needs)
                 if (ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], sz3hip_payload_bound_max(ctx, conf.num))) return 0;
@@ -1413,13 +1443,15 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
             } else if (dsize + 64 >= raw_bytes) {
                 lossless = true;  // the GPU stream would not even beat the raw array (tiny or incompressible input)
             } else {
-                std::vector<uint8_t> host_payload(dsize);
-                if (hipMemcpy(host_payload.data(), g_dev_payload[cdt], dsize, hipMemcpyDeviceToHost) != hipSuccess) {
+                if (ensure_pin(dsize)) return 0;
+                if (hipMemcpy(g_pin, g_dev_payload[cdt], dsize, hipMemcpyDeviceToHost) != hipSuccess) {
                     fail(SZ3HIP_EHIP, "device->host copy failed");
                     return 0;
                 }
-                payload_size = zs::compress_frames(host_payload.data(), dsize, w.p, payload_cap);
+                tm.lap("device->host");
+                payload_size = zs::compress_frames((const uint8_t *)g_pin, dsize, w.p, payload_cap);
                 if (!payload_size) return 0;
+                tm.lap("zstd");
                 conf.cmprAlgo = ctx->h_state->hdr.predictor == 1 ? SZ3HIP_ALGO_HIP_INTERP : SZ3HIP_ALGO_HIP_LORENZO;
                 if ((double)raw_bytes / (double)payload_size < 3) {  // SZDispatcher.hpp:62-74
                     std::vector<uint8_t> z(zs::bound_frames(raw_bytes) + 8);
@@ -1494,22 +1526,23 @@ extern "C" int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *
     if (payload < 8) return fail(SZ3HIP_EFORMAT, "truncated payload");
     uint64_t raw_len;
     memcpy(&raw_len, p, 8);
-    std::vector<uint8_t> host_payload(raw_len);
-    if (zs::decompress_frames(p, payload, host_payload.data(), raw_len) != raw_len) return SZ3HIP_EZSTD;
     std::lock_guard<std::mutex> lock(g_ctx_mu);
+    if ((rc = ensure_pin(raw_len))) return rc;
+    if (zs::decompress_frames(p, payload, (uint8_t *)g_pin, raw_len) != raw_len) return SZ3HIP_EZSTD;
     sz3hip_ctx *ctx = get_ctx(cdt, conf->num);
     if (!ctx) return SZ3HIP_EHIP;
     const size_t cbytes = (size_t)conf->num * (cdt == SZ3HIP_FLOAT ? 4 : 8);
     if ((rc = ensure_dev(&g_dev_in[cdt], &g_dev_in_bytes[cdt], cbytes))) return rc;
     if ((rc = ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], std::max<size_t>(raw_len + 64, is_int ? raw_bytes : 0)))) return rc;
-    HIPCHK(hipMemcpy(g_dev_payload[cdt], host_payload.data(), raw_len, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g_dev_payload[cdt], g_pin, raw_len, hipMemcpyHostToDevice));
     rc = sz3hip_decompress_device(ctx, g_dev_payload[cdt], raw_len, g_dev_in[cdt], nullptr);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(nullptr));
     if (ctx->h_state->hdr.n != conf->num) return fail(SZ3HIP_EFORMAT, "payload element count does not match the trailer");
     if (ctx->h_state->hdr.dtype != (uint8_t)cdt) return fail(SZ3HIP_EINVAL, "the stream's element type does not match the requested one");
     if (!is_int) {
-        HIPCHK(hipMemcpy(decData, g_dev_in[cdt], raw_bytes, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(decData, g_dev_in[cdt], raw_bytes, hipMemcpyDeviceToHost));  // (the runtime pins large pageable buffers
+                                                                                       // itself: a hand-made pinned pipeline was slower)
     } else {
         rc = szk_launch_f64_to_int(dataType == SZ3HIP_INT64, (const double *)g_dev_in[cdt], conf->num, g_dev_payload[cdt], nullptr);
         if (rc) return fail(SZ3HIP_EHIP, "integer narrowing kernel failed");

@@ -219,7 +219,7 @@ def compress(data, conf):
     n = lib().sz3hip_compress(C.byref(conf._c), dt, a.ctypes.data, out.ctypes.data, cap)
     if n == 0:
         raise SZ3HipError(-1, lib().sz3hip_last_error().decode())
-    blob = out[:n].copy()
+    blob = out[:n]  # a view, like pysz (sz.pyx:230-272): the untouched rest of the bound-sized buffer is never resident
     return blob, a.nbytes / float(n)
 
 

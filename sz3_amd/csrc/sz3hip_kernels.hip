@@ -705,20 +705,27 @@ __device__ __forceinline__ int64_t dpp_wave_shr1(int64_t old, int64_t src) {
 
 #define MARCH_WIDE_WIN 8192  // LDS histogram bins of the march kernel when the codes are two bytes wide
 #define MARCH_OQ 256  // records per wave in the LDS outlier staging queue
-template <typename T, int NDIM, int TY>
+// MODE 0: the code width (one or two bytes, decided on the device by k_probe) is a run-time branch. MODE 1 / 2: the kernel
+// is specialised for one-byte / two-byte codes and returns at once when the probe chose the other width; the host launches
+// both. The one-byte specialisation needs a third of the LDS (16 KB histogram, 8 KB outlier queue): 4 waves per SIMD
+// instead of 3.
+template <typename T, int NDIM, int TY, int MODE = 0>
 __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict__ in, uint16_t *__restrict__ codes,
                                                              szk_k1_params p, uint32_t ntasks) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     constexpr int NW = NDIM == 4 ? 2 : 1;
+    constexpr int LH_WORDS = MODE == 1 ? HIST_WIN * 4 : MARCH_WIDE_WIN;
+    constexpr int OQ = MODE == 1 ? 128 : MARCH_OQ;
+    if (MODE != 0 && szk_is_narrow(p.mode) != (MODE == 1)) return;
     // LDS histogram. One-byte codes (narrow deltas): 1024 bins x 4 copies around the radius; two-byte codes (deltas of
     // hundreds or thousands of lattice steps, e.g. C4's 1e-6 on f64): MARCH_WIDE_WIN bins x 1 copy — with the narrow window
     // nearly every element of such a field would fall through to a global atomic. Last word = overflow bin (never flushed).
-    __shared__ uint32_t lh[MARCH_WIDE_WIN + 4];
+    __shared__ uint32_t lh[LH_WORDS + 4];
     // per-wave staging of value outliers (NaN / Inf / fill values can be percents of a field): records collect in LDS and go
     // to the global list in batches, one global atomic per batch instead of one per wave instruction
-    __shared__ uint64_t s_oq_idx[4][MARCH_OQ];
-    __shared__ uint64_t s_oq_val[4][MARCH_OQ];
+    __shared__ uint64_t s_oq_idx[4][OQ];
+    __shared__ uint64_t s_oq_val[4][OQ];
 
     const uint32_t d0 = (uint32_t)p.d[3], d1 = (uint32_t)p.d[2], d2 = (uint32_t)p.d[1];
     const uint32_t ntx = (d0 + MARCH_TX - 1) / MARCH_TX, nty = (d1 + TY - 1) / TY, ntz = (d2 + MARCH_TZ - 1) / MARCH_TZ;
@@ -727,14 +734,14 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     const Lattice<T> lat(p.lat);
     const int radius = (int)p.radius;
     const uint32_t copy = (uint32_t)lane & 3u;
-    const bool narrow = szk_is_narrow(p.mode);
+    const bool narrow = MODE == 1 ? true : (MODE == 2 ? false : szk_is_narrow(p.mode));
     const uint32_t win_bins = narrow ? (uint32_t)HIST_WIN : (uint32_t)MARCH_WIDE_WIN;
     const uint32_t win_lo = (uint32_t)radius - win_bins / 2;
     // in-range test of a delta, one form for both code widths: (delta + rng_lo) <= rng_span (unsigned)
     const UQ rng_lo = narrow ? (UQ)127 : (UQ)(radius - 1), rng_span = narrow ? (UQ)254 : (UQ)(2 * radius - 2);
     uint8_t *codes8 = reinterpret_cast<uint8_t *>(codes);
 
-    for (int i = threadIdx.x; i < MARCH_WIDE_WIN + 4; i += 256) lh[i] = 0;
+    for (int i = threadIdx.x; i < LH_WORDS + 4; i += 256) lh[i] = 0;
     __syncthreads();
 
     uint64_t *oq_idx = s_oq_idx[threadIdx.x / WAVE], *oq_val = s_oq_val[threadIdx.x / WAVE];
@@ -894,7 +901,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                         const unsigned long long vm = __ballot(is_vout);
                         if (vm) {
                             oq_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)oq_n);
-                            if (oq_n + WAVE > MARCH_OQ) oq_flush();
+                            if (oq_n + WAVE > (uint32_t)OQ) oq_flush();
                             if (is_vout) {
                                 const uint32_t slot = oq_n + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull));
                                 oq_idx[slot] = gi + i;
@@ -2717,6 +2724,22 @@ static uint32_t k1_grid(const void *kernel, uint64_t ntiles) {
     return (uint32_t)(g ? g : 1);
 }
 
+// the marching kernel + histogram fold. When one-byte codes are possible both specialisations are launched with the same
+// grid (= rows of the fold); the one the probe did not choose returns at once.
+template <typename T, int NDIM, int TY>
+static void launch_march(const void *d_in, uint16_t *codes, const szk_k1_params &p, uint64_t nb, hipStream_t s) {
+    uint32_t grid;
+    if (p.mode.allow && !(szk_dbg_flags & 256)) {
+        grid = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 1>, (nb + 3) / 4);
+        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 1>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
+        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 2>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
+    } else {
+        grid = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY>, (nb + 3) / 4);
+        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
+    }
+    hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+}
+
 template <typename T>
 static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params &p, hipStream_t s) {
     const uint64_t d0 = p.d[3], d1 = p.d[2], d2 = p.d[1], d3 = p.d[0];
@@ -2742,9 +2765,7 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
                     hipLaunchKernelGGL((k_probe<T, 3>), dim3((uint32_t)((nsamp_threads + 255) / 256)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
                 }
                 nb = tiles(MARCH_TX, 1, MARCH_TZ);
-                uint32_t grid = k1_grid((const void *)k_lorenzo_quant_march<T, 3, 1>, (nb + 3) / 4);
-                hipLaunchKernelGGL((k_lorenzo_quant_march<T, 3, 1>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
-                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+                launch_march<T, 3, 1>(d_in, codes, p, nb, s);
                 break;
             }
             nb = tiles(4096, 1, 1);
@@ -2758,9 +2779,7 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
                     hipLaunchKernelGGL((k_probe<T, 3>), dim3((uint32_t)((nsamp_threads + 255) / 256)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
                 }
                 nb = tiles(MARCH_TX, MTY, MARCH_TZ);
-                uint32_t grid = k1_grid((const void *)k_lorenzo_quant_march<T, 3, MTY>, (nb + 3) / 4);
-                hipLaunchKernelGGL((k_lorenzo_quant_march<T, 3, MTY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
-                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+                launch_march<T, 3, MTY>(d_in, codes, p, nb, s);
                 break;
             }
             nb = tiles(128, 32, 1);
@@ -2774,9 +2793,7 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
                     hipLaunchKernelGGL((k_probe<T, 3>), dim3((uint32_t)((nsamp_threads + 255) / 256)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
                 }
                 nb = tiles(MARCH_TX, MTY, MARCH_TZ);  // wave tasks
-                uint32_t grid = k1_grid((const void *)k_lorenzo_quant_march<T, 3, MTY>, (nb + 3) / 4);
-                hipLaunchKernelGGL((k_lorenzo_quant_march<T, 3, MTY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
-                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+                launch_march<T, 3, MTY>(d_in, codes, p, nb, s);
                 break;
             }
             if (fast) {
@@ -2797,9 +2814,7 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
                     hipLaunchKernelGGL((k_probe<T, 4>), dim3((uint32_t)((nsamp_threads + 255) / 256)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
                 }
                 nb = tiles(MARCH_TX, MTY, MARCH_TZ);  // wave tasks
-                uint32_t grid = k1_grid((const void *)k_lorenzo_quant_march<T, 4, MTY>, (nb + 3) / 4);
-                hipLaunchKernelGGL((k_lorenzo_quant_march<T, 4, MTY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
-                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+                launch_march<T, 4, MTY>(d_in, codes, p, nb, s);
                 break;
             }
             if (fast) {

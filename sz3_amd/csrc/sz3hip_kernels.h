@@ -113,6 +113,10 @@ struct szk_dec_params {
     const uint64_t *group_off;    // word offset of every group of 32 chunks (k_scan_groups)
     const szk_dec_tables *tables;
     uint32_t single_sym;
+    // Lorenzo streams whose rows start on chunk boundaries (row length divides the chunk, no delta outliers): the decoder
+    // turns the codes into deltas and prefix-sums them along x itself (scan_row = row length, 0 = plain code output)
+    uint32_t scan_row, radius, q_bytes, reserved;  // q_bytes: 4 = int32 lattice (f32 data), 8 = int64 (f64 data)
+    void *q_out;  // lattice deltas summed along x: int32 (f32 data) / int64 (f64 data), n elements
 };
 
 // ---- interpolation predictor (sz3hip_interp.hip) ----
@@ -171,7 +175,8 @@ int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, hipStream_t s);
 int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t *codes, uint64_t *chunk_off,
                       uint64_t *total_words, hipStream_t s);
-int szk_launch_reconstruct(const uint8_t *payload, const szh_header *h, const szh_offsets *o, const uint16_t *codes,
+// x_done: the decoder already produced the x-scanned lattice values in d_out (szk_dec_params::scan_row)
+int szk_launch_reconstruct(int x_done, const uint8_t *payload, const szh_header *h, const szh_offsets *o, const uint16_t *codes,
                            void *d_out, void *d_segtot, hipStream_t s);
 void szk_host_offsets(const szh_header *h, szh_offsets *o);
 extern int szk_force_generic;

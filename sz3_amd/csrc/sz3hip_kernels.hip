@@ -2324,8 +2324,11 @@ __global__ __launch_bounds__(1024) void k_dec_tables(const uint8_t *__restrict__
 // decoded without a loop or a global access: the length is K + 1 + the number of lengths l whose left-aligned upper code
 // bound is <= the window (canonical codes grow with the length), and the symbols of the long codes sit in LDS.
 #define DEC_SORTED_LDS 16384u  // symbols of the codes longer than the table kept in LDS (further ranks: global)
+// QB: 0 = u16 codes out; 4 / 8 = fused Lorenzo x-scan, int32 / int64 lattice values out (see szk_dec_params::scan_row)
+template <int QB>
 __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payload, szk_dec_params p,
                                                 uint16_t *__restrict__ codes) {
+    using QO = typename std::conditional<QB == 8, int64_t, int32_t>::type;
     __shared__ uint32_t s_first_code[SZH_MAX_LEN + 2], s_first_rank[SZH_MAX_LEN + 2], s_upper[SZH_MAX_LEN + 2];
     __shared__ uint32_t s_lut[1u << DEC_LUT_BITS];
     __shared__ uint16_t s_sorted[DEC_SORTED_LDS];
@@ -2349,9 +2352,20 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     const uint64_t s0 = chunk * SZH_CHUNK_SYMS;
     const uint32_t nsym = (uint32_t)((p.n - s0 < SZH_CHUNK_SYMS) ? (p.n - s0) : SZH_CHUNK_SYMS);
     uint16_t *out = codes + s0;
+    QO *qout = QB ? reinterpret_cast<QO *>(p.q_out) + s0 : nullptr;
+    const uint32_t row_mask = QB ? p.scan_row - 1u : 0u;  // (scan_row is a power of two dividing the chunk)
+    QO acc = 0;
     if (max_len == 0) {  // single-symbol alphabet: zero-length code
         uint16_t sym = (uint16_t)p.single_sym;
-        for (uint32_t i = 0; i < nsym; i++) out[i] = sym;
+        if (QB) {
+            const QO d = sym ? (QO)((int)sym - (int)p.radius) : (QO)0;
+            for (uint32_t i = 0; i < nsym; i++) {
+                acc = (i & row_mask) ? (QO)(acc + d) : d;
+                qout[i] = acc;
+            }
+        } else {
+            for (uint32_t i = 0; i < nsym; i++) out[i] = sym;
+        }
         return;
     }
     // word offset of the chunk: group offset + the chunks before it inside its group
@@ -2417,7 +2431,32 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
             if (k & 1) packed[k >> 1] |= sym << 16;
             else packed[k >> 1] = sym;
         }
-        if (i0 + 16 <= nsym) {
+        if (QB) {  // codes -> deltas (0 = delta outlier: none in a fused stream) -> running sum, restarted at every row start
+            QO qv[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t sym = (k & 1) ? (packed[k >> 1] >> 16) : (packed[k >> 1] & 0xFFFFu);
+                const QO d = sym ? (QO)((int)sym - (int)p.radius) : (QO)0;
+                acc = ((i0 + k) & row_mask) ? (QO)(acc + d) : d;  // (wave-uniform condition)
+                qv[k] = acc;
+            }
+            if (i0 + 16 <= nsym) {
+                if (QB == 4) {
+                    uint4 *o4 = reinterpret_cast<uint4 *>(qout + i0);
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        o4[k] = make_uint4((uint32_t)qv[4 * k], (uint32_t)qv[4 * k + 1], (uint32_t)qv[4 * k + 2], (uint32_t)qv[4 * k + 3]);
+                } else {
+                    ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(qout + i0);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) o2[k] = make_ulonglong2((unsigned long long)qv[2 * k], (unsigned long long)qv[2 * k + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    if (i0 + k < nsym) qout[i0 + k] = qv[k];
+            }
+        } else if (i0 + 16 <= nsym) {
             uint4 *o4 = reinterpret_cast<uint4 *>(out + i0);
             o4[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
             o4[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
@@ -2885,7 +2924,9 @@ int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t 
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, p->chunk_words, p->n_chunks, chunk_off, total_words);  // chunk_off = p->group_off
     const uint64_t nb = (p->n_chunks + 255) / 256;
     if (nb > 0x7FFFFFFFull) return -1;
-    hipLaunchKernelGGL(k_decode, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
+    if (!p->scan_row) hipLaunchKernelGGL(k_decode<0>, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
+    else if (p->q_bytes == 8) hipLaunchKernelGGL(k_decode<8>, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
+    else hipLaunchKernelGGL(k_decode<4>, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
     SZK_CHECK_LAUNCH();
     return 0;
 }
@@ -2906,7 +2947,7 @@ static int scan_rows(Q *q, uint64_t L, uint64_t nrows, Q *scratch, hipStream_t s
 }
 
 template <typename T>
-static int launch_reconstruct(const uint8_t *payload, const szh_header &h, const szh_offsets &o, const uint16_t *codes,
+static int launch_reconstruct(bool x_done, const uint8_t *payload, const szh_header &h, const szh_offsets &o, const uint16_t *codes,
                               void *d_out, void *d_segtot, hipStream_t s) {
     using Q = typename QTraits<T>::Q;
     Q *q = reinterpret_cast<Q *>(d_out);
@@ -2914,7 +2955,9 @@ static int launch_reconstruct(const uint8_t *payload, const szh_header &h, const
     const uint64_t L = h.dims[3], nrows = n / L;
     const bool wave_rows = L <= SCANX_SEG;  // one wave per row, no segment totals
     const uint32_t wgrid = grid_for(nrows, 4, 16384);
-    if (wave_rows && h.n_dout == 0) {
+    if (x_done) {
+        // the decoder wrote the x-scanned lattice values itself
+    } else if (wave_rows && h.n_dout == 0) {
         // codes -> deltas -> x-scan in one pass
         hipLaunchKernelGGL((k_scan_x_wave<Q, true>), dim3(wgrid), dim3(256), 0, s, q, codes, (int)h.radius, L, nrows);
     } else {
@@ -2967,10 +3010,10 @@ static int launch_reconstruct(const uint8_t *payload, const szh_header &h, const
     SZK_CHECK_LAUNCH();
     return 0;
 }
-int szk_launch_reconstruct(const uint8_t *payload, const szh_header *h, const szh_offsets *o, const uint16_t *codes,
+int szk_launch_reconstruct(int x_done, const uint8_t *payload, const szh_header *h, const szh_offsets *o, const uint16_t *codes,
                            void *d_out, void *d_segtot, hipStream_t s) {
-    return h->dtype == 0 ? launch_reconstruct<float>(payload, *h, *o, codes, d_out, d_segtot, s)
-                         : launch_reconstruct<double>(payload, *h, *o, codes, d_out, d_segtot, s);
+    return h->dtype == 0 ? launch_reconstruct<float>(x_done != 0, payload, *h, *o, codes, d_out, d_segtot, s)
+                         : launch_reconstruct<double>(x_done != 0, payload, *h, *o, codes, d_out, d_segtot, s);
 }
 
 void szk_host_offsets(const szh_header *h, szh_offsets *o) { szh_compute_offsets(*h, *o); }

@@ -113,10 +113,13 @@ struct szk_dec_params {
     const uint64_t *group_off;    // word offset of every group of 32 chunks (k_scan_groups)
     const szk_dec_tables *tables;
     uint32_t single_sym;
-    // Lorenzo streams whose rows start on chunk boundaries (row length divides the chunk, no delta outliers): the decoder
-    // turns the codes into deltas and prefix-sums them along x itself (scan_row = row length, 0 = plain code output)
+    // Lorenzo streams with rows of at most one chunk and no delta outliers: the decoder turns the codes into deltas and
+    // prefix-sums them along x itself (scan_row = row length, 0 = plain code output). A row that starts in the previous
+    // chunk misses that chunk's running sum: every chunk leaves it in carry[] and k_scan_carry adds it afterwards (not
+    // needed when the row length divides the chunk).
     uint32_t scan_row, radius, q_bytes, reserved;  // q_bytes: 4 = int32 lattice (f32 data), 8 = int64 (f64 data)
     void *q_out;  // lattice deltas summed along x: int32 (f32 data) / int64 (f64 data), n elements
+    void *carry;  // [n_chunks] running sum at the end of every chunk (same type), nullptr when rows start on chunk boundaries
 };
 
 // ---- interpolation predictor (sz3hip_interp.hip) ----

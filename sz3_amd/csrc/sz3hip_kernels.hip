@@ -2353,16 +2353,22 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     const uint32_t nsym = (uint32_t)((p.n - s0 < SZH_CHUNK_SYMS) ? (p.n - s0) : SZH_CHUNK_SYMS);
     uint16_t *out = codes + s0;
     QO *qout = QB ? reinterpret_cast<QO *>(p.q_out) + s0 : nullptr;
-    const uint32_t row_mask = QB ? p.scan_row - 1u : 0u;  // (scan_row is a power of two dividing the chunk)
+    // symbols left in the current row (the chunk may start inside a row); the running sum restarts at every row start
+    uint32_t left = QB ? p.scan_row - (uint32_t)(s0 % p.scan_row) : 0u;
     QO acc = 0;
     if (max_len == 0) {  // single-symbol alphabet: zero-length code
         uint16_t sym = (uint16_t)p.single_sym;
         if (QB) {
             const QO d = sym ? (QO)((int)sym - (int)p.radius) : (QO)0;
             for (uint32_t i = 0; i < nsym; i++) {
-                acc = (i & row_mask) ? (QO)(acc + d) : d;
+                acc += d;
                 qout[i] = acc;
+                if (--left == 0) {
+                    acc = 0;
+                    left = p.scan_row;
+                }
             }
+            if (p.carry) reinterpret_cast<QO *>(p.carry)[chunk] = acc;
         } else {
             for (uint32_t i = 0; i < nsym; i++) out[i] = sym;
         }
@@ -2437,8 +2443,12 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
             for (int k = 0; k < 16; k++) {
                 const uint32_t sym = (k & 1) ? (packed[k >> 1] >> 16) : (packed[k >> 1] & 0xFFFFu);
                 const QO d = sym ? (QO)((int)sym - (int)p.radius) : (QO)0;
-                acc = ((i0 + k) & row_mask) ? (QO)(acc + d) : d;  // (wave-uniform condition)
+                acc += d;
                 qv[k] = acc;
+                if (--left == 0) {
+                    acc = 0;
+                    left = p.scan_row;
+                }
             }
             if (i0 + 16 <= nsym) {
                 if (QB == 4) {
@@ -2466,6 +2476,25 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                 if (i0 + k < nsym) out[i0 + k] = (uint16_t)((k & 1) ? (packed[k >> 1] >> 16) : (packed[k >> 1] & 0xFFFF));
         }
     }
+    if (QB && p.carry) reinterpret_cast<QO *>(p.carry)[chunk] = acc;
+}
+
+// adds the running sum the previous chunk ended with to the head of every chunk that starts inside a row (rows of at most
+// one chunk: the row's start lies in the previous chunk). One wave per chunk.
+template <typename QO>
+__global__ __launch_bounds__(256) void k_scan_carry(QO *__restrict__ q, const QO *__restrict__ carry, uint64_t n, uint64_t n_chunks,
+                                                    uint32_t L) {
+    const uint64_t c = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE;
+    if (c == 0 || c >= n_chunks) return;
+    const uint64_t s0 = c * SZH_CHUNK_SYMS;
+    const uint32_t x0 = (uint32_t)(s0 % L);
+    if (x0 == 0) return;
+    uint64_t seg = L - x0;
+    if (seg > SZH_CHUNK_SYMS) seg = SZH_CHUNK_SYMS;
+    if (seg > n - s0) seg = n - s0;
+    const QO cin = carry[c - 1];
+    if (cin == 0) return;
+    for (uint32_t i = lane_id(); i < seg; i += WAVE) q[s0 + i] += cin;
 }
 
 // codes -> integer deltas (code 0 -> 0, patched by k_scatter_dout)
@@ -2927,6 +2956,15 @@ int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t 
     if (!p->scan_row) hipLaunchKernelGGL(k_decode<0>, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
     else if (p->q_bytes == 8) hipLaunchKernelGGL(k_decode<8>, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
     else hipLaunchKernelGGL(k_decode<4>, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
+    if (p->scan_row && p->carry) {
+        const uint64_t cb = (p->n_chunks + 3) / 4;
+        if (p->q_bytes == 8)
+            hipLaunchKernelGGL(k_scan_carry<int64_t>, dim3((uint32_t)cb), dim3(256), 0, s, (int64_t *)p->q_out, (const int64_t *)p->carry, p->n,
+                               p->n_chunks, p->scan_row);
+        else
+            hipLaunchKernelGGL(k_scan_carry<int32_t>, dim3((uint32_t)cb), dim3(256), 0, s, (int32_t *)p->q_out, (const int32_t *)p->carry, p->n,
+                               p->n_chunks, p->scan_row);
+    }
     SZK_CHECK_LAUNCH();
     return 0;
 }

@@ -2399,41 +2399,40 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             uint32_t sym = 0;
-            if (i0 + k < nsym) {
-                if (have <= 32) {
-                    uint32_t wd;
-                    if (qn < 4) {
-                        wd = qn == 0 ? qw[0] : (qn == 1 ? qw[1] : (qn == 2 ? qw[2] : qw[3]));
-                    } else {
-                        const uint64_t a = woff + wi;
-                        wd = bs[a < wlast ? a : wlast];
-                    }
-                    wd = wi < nwords ? wd : 0u;
-                    qn++;
-                    buf |= (uint64_t)wd << (32 - have);
-                    have += 32;
-                    wi++;
+            // (symbols past the end of the last chunk decode zero padding: harmless, only the stores are guarded)
+            if (have <= 32) {
+                uint32_t wd;
+                if (qn < 4) {
+                    wd = qn == 0 ? qw[0] : (qn == 1 ? qw[1] : (qn == 2 ? qw[2] : qw[3]));
+                } else {
+                    const uint64_t a = woff + wi;
+                    wd = bs[a < wlast ? a : wlast];
                 }
-                const uint32_t ent = s_lut[(uint32_t)(buf >> (64 - K))];
-                uint32_t l = ent & 0xFFu;
-                sym = ent >> 8;
-                if (ent == 0) {  // longer than the table
-                    const uint32_t v = (uint32_t)(buf >> 32);
-                    l = K + 1;
-#pragma unroll
-                    for (uint32_t q = DEC_LUT_BITS + 1; q < SZH_MAX_LEN; q++) l += (q > K && v >= s_upper[q]) ? 1u : 0u;
-                    if (K < DEC_LUT_BITS) {  // (short tables only exist when max_len <= K: never here; keeps the rule general)
-                        for (uint32_t q = K + 1; q <= DEC_LUT_BITS && q < SZH_MAX_LEN; q++) l += v >= s_upper[q] ? 1u : 0u;
-                    }
-                    l = l > max_len ? max_len : l;
-                    uint32_t rank = s_first_rank[l] + ((v >> (32 - l)) - s_first_code[l]);
-                    rank = rank < n_coded ? rank : n_coded - 1;  // (corrupt streams must not read out of bounds)
-                    const uint32_t rr = rank - base_rank;
-                    sym = rr < DEC_SORTED_LDS ? (uint32_t)s_sorted[rr] : (uint32_t)sorted[rank];
-                }
-                buf <<= l;
-                have -= (int)l;
+                wd = wi < nwords ? wd : 0u;
+                qn++;
+                buf |= (uint64_t)wd << (32 - have);
+                have += 32;
+                wi++;
             }
+            const uint32_t ent = s_lut[(uint32_t)(buf >> (64 - K))];
+            uint32_t l = ent & 0xFFu;
+            sym = ent >> 8;
+            if (ent == 0) {  // longer than the table
+                const uint32_t v = (uint32_t)(buf >> 32);
+                l = K + 1;
+#pragma unroll
+                for (uint32_t q = DEC_LUT_BITS + 1; q < SZH_MAX_LEN; q++) l += (q > K && v >= s_upper[q]) ? 1u : 0u;
+                if (K < DEC_LUT_BITS) {  // (short tables only exist when max_len <= K: never here; keeps the rule general)
+                    for (uint32_t q = K + 1; q <= DEC_LUT_BITS && q < SZH_MAX_LEN; q++) l += v >= s_upper[q] ? 1u : 0u;
+                }
+                l = l > max_len ? max_len : l;
+                uint32_t rank = s_first_rank[l] + ((v >> (32 - l)) - s_first_code[l]);
+                rank = rank < n_coded ? rank : n_coded - 1;  // (corrupt streams must not read out of bounds)
+                const uint32_t rr = rank - base_rank;
+                sym = rr < DEC_SORTED_LDS ? (uint32_t)s_sorted[rr] : (uint32_t)sorted[rank];
+            }
+            buf <<= l;
+            have -= (int)l;
             if (k & 1) packed[k >> 1] |= sym << 16;
             else packed[k >> 1] = sym;
         }

@@ -355,9 +355,9 @@ extern "C" size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in) 
 // ------------------------------------------------------------------------------------------------------------
 // device context
 // ------------------------------------------------------------------------------------------------------------
-enum { ST_K1 = 0, ST_CODEBOOK, ST_ENCODE, ST_ASSEMBLE, ST_DEC_HUFF, ST_DEC_RECON, ST_TUNER, ST_COUNT };
+enum { ST_K1 = 0, ST_CODEBOOK, ST_ENCODE, ST_ASSEMBLE, ST_DEC_HUFF, ST_DEC_RECON, ST_TUNER, ST_K1_KERNEL, ST_COUNT };
 static const char *const kStageNames[ST_COUNT] = {"lorenzo_quant_hist", "codebook", "encode", "assemble",
-                                                  "huffman_decode",     "reconstruct", "tuner"};
+                                                  "huffman_decode",     "reconstruct", "tuner", "k1_kernel"};
 
 struct sz3hip_ctx {
     int device;
@@ -682,6 +682,12 @@ static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *
     p.mode.n_total = num;
     p.mode.n_samples = (num / SZK_PROBE_STRIDE) * 64 + std::min<uint64_t>(64, num % SZK_PROBE_STRIDE);
     p.mode.allow = allow_narrow && radius >= 128;
+    p.prof_ev0 = p.prof_ev1 = nullptr;
+    if (ctx->profiling && allow_narrow) {  // (the production call, not the tuner's trial): events around the kernel itself
+        p.prof_ev0 = ctx->ev[ST_K1_KERNEL][0];
+        p.prof_ev1 = ctx->ev[ST_K1_KERNEL][1];
+        ctx->ev_used[ST_K1_KERNEL] = true;
+    }
     return szk_launch_k1(ctx->dtype, N, d_in, ctx->d_codes, &p, s);
 }
 static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint64_t num, hipStream_t s) {

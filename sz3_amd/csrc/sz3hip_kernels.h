@@ -46,6 +46,9 @@ struct szk_k1_params {
     uint64_t *n_vout, *n_dout;
     uint64_t *vout_idx, *dout_idx;
     void *vout_val, *dout_val;
+    // host side only (profiling): HIP events recorded right before / after the predictor kernel itself, so that its own
+    // duration can be set against the per-kernel average of a rocprofv3 trace
+    void *prof_ev0, *prof_ev1;
 };
 
 struct szk_cb_info {

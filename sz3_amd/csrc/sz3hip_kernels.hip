@@ -2796,6 +2796,7 @@ static uint32_t k1_grid(const void *kernel, uint64_t ntiles) {
 template <typename T, int NDIM, int TY>
 static void launch_march(const void *d_in, uint16_t *codes, const szk_k1_params &p, uint64_t nb, hipStream_t s) {
     uint32_t grid;
+    if (p.prof_ev0) (void)hipEventRecord((hipEvent_t)p.prof_ev0, s);
     if (p.mode.allow && !(szk_dbg_flags & 256)) {
         grid = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 1>, (nb + 3) / 4);
         hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 1>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
@@ -2804,6 +2805,7 @@ static void launch_march(const void *d_in, uint16_t *codes, const szk_k1_params 
         grid = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY>, (nb + 3) / 4);
         hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
     }
+    if (p.prof_ev1) (void)hipEventRecord((hipEvent_t)p.prof_ev1, s);
     hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
 }
 

@@ -789,7 +789,7 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
     int rc = szk_launch_interp_trials(ctx->dtype, ips, (uint32_t)ntr, ctx->d_samples, ctx->d_trial_work, ctx->d_codes, nb, ctx->d_trial_hist,
                                       ctx->h_passes, ctx->d_passes, ctx->h_np, ctx->d_np, s);
     if (rc) return fail(SZ3HIP_EHIP, "tuner: interpolation trial launch failed (%d)", rc);
-    rc = szk_launch_code_cost(ctx->d_trial_hist, ctx->d_trial_counters, ctx->d_trial + 4 * slot0, (uint32_t)ntr, tcs[0].num * nb, s);
+    rc = szk_launch_code_cost(ctx->d_trial_hist, ctx->d_trial_counters, ctx->d_trial + 4 * slot0, (uint32_t)ntr, tcs[0].num * nb, 1, s);
     if (rc) return fail(SZ3HIP_EHIP, "tuner: cost kernel launch failed (%d)", rc);
     return 0;
 }
@@ -964,7 +964,7 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
         const uint64_t d1[1] = {sampling_num};
         rc = lorenzo_k1(ctx, 1, d1, ctx->d_samples, eb, radius, sampling_num, 0, false, p, s);
         if (rc) return fail(SZ3HIP_EHIP, "tuner: Lorenzo trial launch failed (%d)", rc);
-        rc = szk_launch_code_cost(ctx->d_hist, ctx->d_counters, ctx->d_trial + 24, 1, sampling_num, s);
+        rc = szk_launch_code_cost(ctx->d_hist, ctx->d_counters, ctx->d_trial + 24, 1, sampling_num, 0, s);
         if (rc) return fail(SZ3HIP_EHIP, "tuner: cost kernel launch failed (%d)", rc);
         rc = tuner_fetch(ctx, s);
         if (rc) return rc;

@@ -69,27 +69,9 @@ __device__ __forceinline__ T ref_recover(T pred, int code, double eb, int radius
     return (T)((double)pred + (double)(2 * (code - radius)) * eb);
 }
 
-// append an unpredictable value to the list: ONE atomic per wave (a field whose coarse levels miss the code range makes
-// hundreds of thousands of them; same-address atomics run at ~90/us). Works for any set of active lanes.
-template <typename T>
-__device__ __forceinline__ void append_unpred(bool unp, const szk_interp_pass &p, uint64_t idx, T v) {
-    const unsigned long long m = __ballot(unp);
-    if (m == 0) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd((unsigned long long *)p.n_vout, (unsigned long long)__popcll(m));
-    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader);
-    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), leader);
-    if (unp) {
-        const unsigned long long pos = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-        if (pos < p.out_cap) {
-            p.vout_idx[pos] = idx;
-            ((T *)p.vout_val)[pos] = v;
-        }
-    }
-}
-
+// Unpredictable values (code 0: the raw value stays in the array) are NOT appended by the pass kernels: the histogram pass
+// that reads every code anyway (k_hist_codes) collects their indices and values into the list, through per-wave LDS queues
+// (a field with NaN / fill-value masks makes millions of them, and same-address global atomics run at ~90/us).
 // ---- one directional pass of one level: one thread per predicted point ----------------------------------------
 // tuner trials in LDS: the code of a point goes straight into the trial's histogram (LDS window, global tail)
 struct TrialSink {
@@ -168,11 +150,7 @@ __device__ __forceinline__ void interp_point(T *__restrict__ w, uint16_t *__rest
         const int code = ref_quantize<T>(v, pred, p.eb, p.eb_recip, p.radius);
         if (SINK) sink_code(sink, (uint32_t)code);
         else codes[idx] = (uint16_t)code;
-        if (code) {
-            if (!p.no_store) *d = v;
-        } else {  // unpredictable: keep the raw value (LinearQuantizer "unpred")
-            append_unpred<T>(true, p, idx + boff, v);
-        }
+        if (code && !p.no_store) *d = v;  // (unpredictable, code 0: the raw value stays; LinearQuantizer "unpred")
     }
 }
 template <typename T, bool DEC>
@@ -225,9 +203,8 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
     const int N = p.N;
     const uint64_t dx = p.dims[N - 1], xg = dx / 8;
     const uint64_t t0 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = t0 < p.total;  // total = rows * xg here; no early return: the workgroup appends its outliers together
+    const bool valid = t0 < p.total;  // total = rows * xg here
     const uint64_t t = valid ? t0 : 0;
-    uint32_t unp_mask = 0;  // elements of this thread that turned out unpredictable
     const uint64_t tx = t % xg;
     uint64_t r = t / xg, idx = 0, cd = 0;
 #pragma unroll
@@ -261,8 +238,7 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
             T v = o[e];
             const int code = ref_quantize<T>(v, pred, p.eb, p.eb_recip, p.radius);
             set_code(e, code);
-            if (code) o[e] = v;
-            else unp_mask |= 1u << e;  // the raw value stays in o[e]; appended below, one atomic per workgroup
+            if (code) o[e] = v;  // (code 0: the raw value stays in o[e])
         }
     };
     if (!XDIR) {
@@ -342,41 +318,6 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
         if (DEC || !p.no_store) st8<T>(w + idx, o);
         if (!DEC) *reinterpret_cast<uint4 *>(codes + idx) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
     }
-    if (!DEC) {
-        // unpredictable values of the whole workgroup (up to 2048 points) take ONE global atomic: NaN / fill-value masks make
-        // percents of a field unpredictable, and same-address atomics run at ~90/us
-        __shared__ uint32_t s_cnt[4];
-        __shared__ unsigned long long s_base;
-        const uint32_t cnt = valid ? (uint32_t)__popc(unp_mask) : 0u;
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const uint32_t up = __shfl_up(incl, dlt, 64);
-            if ((int)(threadIdx.x & 63) >= dlt) incl += up;
-        }
-        if ((threadIdx.x & 63) == 63) s_cnt[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        uint32_t off = incl - cnt, tot = 0;
-        for (int wv = 0; wv < 4; wv++) {
-            if (wv < (int)(threadIdx.x >> 6)) off += s_cnt[wv];
-            tot += s_cnt[wv];
-        }
-        if (tot) {  // uniform for the workgroup
-            if (threadIdx.x == 0) s_base = atomicAdd((unsigned long long *)p.n_vout, (unsigned long long)tot);
-            __syncthreads();
-            unsigned long long pos = s_base + off;
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                if ((unp_mask >> e) & 1u) {
-                    if (pos < p.out_cap) {
-                        p.vout_idx[pos] = idx + e;
-                        ((T *)p.vout_val)[pos] = o[e];
-                    }
-                    pos++;
-                }
-            }
-        }
-    }
 }
 
 // anchor grid (build_anchor_grid :215-221): every anchor_stride-th point in each dimension is stored losslessly;
@@ -402,7 +343,6 @@ __device__ __forceinline__ void anchor_point(T *__restrict__ w, uint16_t *__rest
     }
     if (SINK) sink_code(sink, (uint32_t)code);
     else codes[idx] = (uint16_t)code;
-    if (!code) append_unpred<T>(true, p, idx + boff, v);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_interp_anchors(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
@@ -417,20 +357,49 @@ __global__ __launch_bounds__(256) void k_interp_first_dec(T *__restrict__ w, con
 }
 
 // histogram of u16 codes: persistent workgroups, LDS window [bin][4 copies] around the radius, flushed with one
-// 64-bit atomic per non-empty bin and workgroup
+// 64-bit atomic per non-empty bin and workgroup. The same pass builds the list of unpredictable values (code 0): their
+// indices collect in a per-wave LDS queue and go to the global list in batches (one global atomic per batch), the values are
+// gathered from the work array, where an unpredictable point keeps its raw value.
 #define IHW_WIN 8192
+#define IH_OQ 128  // indices per wave in the staging queue
+template <typename T>
 __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__ codes, uint64_t n, int radius,
-                                                    uint64_t *__restrict__ hist) {
+                                                    uint64_t *__restrict__ hist, const T *__restrict__ work,
+                                                    uint64_t *__restrict__ n_vout, uint64_t *__restrict__ vout_idx,
+                                                    T *__restrict__ vout_val, uint64_t out_cap) {
     __shared__ uint32_t lh[IH_WIN * 4];
     __shared__ uint32_t l_zero[4];  // code 0 (unpredictable): far from the window and ONE address for all of them
     __shared__ uint32_t lw[IHW_WIN];  // second tier, one copy: the tails (tight bounds spread the codes over thousands of bins)
+    __shared__ uint64_t s_oq[4][IH_OQ];
     for (int i = threadIdx.x; i < IH_WIN * 4; i += 256) lh[i] = 0;
     for (int i = threadIdx.x; i < IHW_WIN; i += 256) lw[i] = 0;
     if (threadIdx.x < 4) l_zero[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t win_lo = (uint32_t)(radius - IH_WIN / 2), wide_lo = (uint32_t)radius - IHW_WIN / 2, copy = threadIdx.x & 3u;
+    const int lane = threadIdx.x & 63;
+    uint64_t *oq = s_oq[threadIdx.x >> 6];
+    uint32_t oq_n = 0;  // wave-uniform fill level
+    auto oq_flush = [&]() {
+        if (oq_n == 0) return;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd((unsigned long long *)n_vout, (unsigned long long)oq_n);
+        const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+        const unsigned long long b0 = ((unsigned long long)bhi << 32) | blo;
+        for (uint32_t k = lane; k < oq_n; k += 64) {
+            const unsigned long long pos = b0 + k;
+            if (pos < out_cap) {
+                const uint64_t id = oq[k];
+                vout_idx[pos] = id;
+                vout_val[pos] = work[id];
+            }
+        }
+        oq_n = 0;
+    };
     const uint64_t nth = (uint64_t)gridDim.x * 256;
-    for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += nth * 8) {
+    // (every lane of a wave runs the same number of iterations: the loop bound is rounded up to whole waves below)
+    for (uint64_t i0 = ((uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u)) * 8; i0 < n; i0 += nth * 8) {
+        const uint64_t i = i0 + (uint64_t)lane * 8;
         uint16_t c[8];
         if (i + 8 <= n) {
             const uint4 v = *reinterpret_cast<const uint4 *>(codes + i);
@@ -444,16 +413,33 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
 #pragma unroll
             for (int k = 0; k < 8; k++) c[k] = (i + k < n) ? codes[i + k] : (uint16_t)0xFFFF;
         }
+        uint32_t zmask = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             if (i + k >= n) break;
             const uint32_t bin = (uint32_t)c[k] - win_lo;
-            if (bin < IH_WIN) atomicAdd(&lh[bin * 4 + copy], 1u);
-            else if (c[k] == 0) atomicAdd(&l_zero[copy], 1u);
-            else if ((uint32_t)c[k] - wide_lo < IHW_WIN) atomicAdd(&lw[(uint32_t)c[k] - wide_lo], 1u);
+            // (code 0 never counts in the window: with a small quantbinCnt it would lie inside it)
+            if (bin < IH_WIN && c[k] != 0) atomicAdd(&lh[bin * 4 + copy], 1u);
+            else if (c[k] == 0) {
+                atomicAdd(&l_zero[copy], 1u);
+                zmask |= 1u << k;
+            } else if ((uint32_t)c[k] - wide_lo < IHW_WIN) atomicAdd(&lw[(uint32_t)c[k] - wide_lo], 1u);
             else atomicAdd((unsigned long long *)&hist[c[k]], 1ull);
         }
+        if (__ballot(zmask != 0)) {  // some lane met unpredictable points: queue their indices
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool z = (zmask >> k) & 1u;
+                const unsigned long long m = __ballot(z);
+                if (m) {
+                    if (oq_n + 64 > IH_OQ) oq_flush();
+                    if (z) oq[oq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i + k;
+                    oq_n += (uint32_t)__popcll(m);
+                }
+            }
+        }
     }
+    oq_flush();
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t z = l_zero[0] + l_zero[1] + l_zero[2] + l_zero[3];
@@ -659,7 +645,12 @@ int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const voi
     int rc = dtype == 0 ? run_interp<float, false>(*ip, (float *)d_work, codes, s)
                         : run_interp<double, false>(*ip, (double *)d_work, codes, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_hist_codes, dim3(768), dim3(256), 0, s, codes, num, ip->radius, hist);
+    if (dtype == 0)
+        hipLaunchKernelGGL((k_hist_codes<float>), dim3(768), dim3(256), 0, s, codes, num, ip->radius, hist, (const float *)d_work, ip->n_vout,
+                           ip->vout_idx, (float *)ip->vout_val, ip->out_cap);
+    else
+        hipLaunchKernelGGL((k_hist_codes<double>), dim3(768), dim3(256), 0, s, codes, num, ip->radius, hist, (const double *)d_work, ip->n_vout,
+                           ip->vout_idx, (double *)ip->vout_val, ip->out_cap);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -738,14 +729,14 @@ __global__ __launch_bounds__(256) void k_gather_blocks(const T *__restrict__ dat
 // entropy tracks the Huffman-coded size closely enough for the tuner's ratio comparisons (tools/estimator_study.py:
 // 29 vs 30 of 41 decisions equal to the reference's) and needs no code book.
 __global__ __launch_bounds__(256) void k_code_cost(const uint64_t *__restrict__ hist, const uint64_t *__restrict__ counters,
-                                                   unsigned long long *res, double total) {
+                                                   unsigned long long *res, double total, int unpred_is_code0) {
     const size_t book = blockIdx.y;  // batch of trials: histograms sliced per book, results 4 words apart, counters 8 apart
     hist += book * SZH_HIST_BINS;
     counters += book * 8;
     res += book * 4;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) {  // res[2] = unpredictable values, res[3] = delta outliers
-        res[2] = counters[0];
+    if (i == 0) {  // res[2] = unpredictable values (interpolation: the points coded 0), res[3] = delta outliers
+        res[2] = unpred_is_code0 ? hist[0] : counters[0];
         res[3] = counters[1];
     }
     const uint64_t f = hist[i];
@@ -945,9 +936,9 @@ int szk_launch_interp_trials(int dtype, const szk_interp_params *ips, uint32_t n
     return e == hipSuccess ? 0 : (int)e;
 }
 int szk_launch_code_cost(const uint64_t *hist, const uint64_t *counters, uint64_t *d_res, uint32_t n_books, uint64_t total,
-                         hipStream_t s) {
+                         int unpred_is_code0, hipStream_t s) {
     hipLaunchKernelGGL(k_code_cost, dim3(SZH_HIST_BINS / 256, n_books), dim3(256), 0, s, hist, counters, (unsigned long long *)d_res,
-                       (double)total);
+                       (double)total, unpred_is_code0);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

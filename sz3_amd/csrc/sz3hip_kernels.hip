@@ -764,7 +764,12 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
         }
         oq_n = 0;
     };
-    const uint32_t wave_gid = blockIdx.x * 4 + threadIdx.x / WAVE, nwaves = gridDim.x * 4;
+    // XCD-aware task order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the workgroups of one
+    // XCD take a contiguous range of tasks: tiles that share halo rows / planes then share an L2 instead of each pulling
+    // the shared lines from HBM
+    const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
+    const uint32_t wg_seq = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+    const uint32_t wave_gid = wg_seq * 4 + threadIdx.x / WAVE, nwaves = per_xcd * 8u * 4u;
     for (uint32_t task = wave_gid; task < ntasks; task += nwaves) {
         uint32_t b = task;
         const uint32_t x0 = (b % ntx) * MARCH_TX;

@@ -767,9 +767,10 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     // XCD-aware task order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the workgroups of one
     // XCD take a contiguous range of tasks: tiles that share halo rows / planes then share an L2 instead of each pulling
     // the shared lines from HBM
-    const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
-    const uint32_t wg_seq = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
-    const uint32_t wave_gid = wg_seq * 4 + threadIdx.x / WAVE, nwaves = per_xcd * 8u * 4u;
+    // (grids that are not a multiple of 8 keep the plain order: the remapped sequence would have holes)
+    const uint32_t per_xcd = gridDim.x / 8u;
+    const uint32_t wg_seq = gridDim.x % 8u == 0 ? (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : blockIdx.x;
+    const uint32_t wave_gid = wg_seq * 4 + threadIdx.x / WAVE, nwaves = gridDim.x * 4u;
     for (uint32_t task = wave_gid; task < ntasks; task += nwaves) {
         uint32_t b = task;
         const uint32_t x0 = (b % ntx) * MARCH_TX;

@@ -72,6 +72,13 @@ __device__ __forceinline__ T ref_recover(T pred, int code, double eb, int radius
 // Unpredictable values (code 0: the raw value stays in the array) are NOT appended by the pass kernels: the histogram pass
 // that reads every code anyway (k_hist_codes) collects their indices and values into the list, through per-wave LDS queues
 // (a field with NaN / fill-value masks makes millions of them, and same-address global atomics run at ~90/us).
+// XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); giving every XCD a contiguous
+// range of logical blocks keeps neighbouring rows / planes (read by several blocks) inside one L2
+__device__ __forceinline__ uint32_t xcd_block() {
+    const uint32_t g = gridDim.x;
+    return g % 8u == 0 ? (blockIdx.x % 8u) * (g / 8u) + blockIdx.x / 8u : blockIdx.x;
+}
+
 // ---- one directional pass of one level: one thread per predicted point ----------------------------------------
 // tuner trials in LDS: the code of a point goes straight into the trial's histogram (LDS window, global tail)
 struct TrialSink {
@@ -155,7 +162,7 @@ __device__ __forceinline__ void interp_point(T *__restrict__ w, uint16_t *__rest
 }
 template <typename T, bool DEC>
 __global__ __launch_bounds__(256) void k_interp_pass(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t t = (uint64_t)xcd_block() * 256 + threadIdx.x;
     if (t >= p.total) return;
     const uint64_t boff = (uint64_t)blockIdx.y * p.batch_stride;  // independent arrays of one batch
     if (p.total <= 0xFFFFFFFFull) interp_point<T, DEC, uint32_t>(w + boff, codes + boff, p, t, boff);  // (uniform branch)
@@ -202,7 +209,7 @@ template <typename T, bool DEC, bool XDIR>
 __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
     const int N = p.N;
     const uint64_t dx = p.dims[N - 1], xg = dx / 8;
-    const uint64_t t0 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t t0 = (uint64_t)xcd_block() * 256 + threadIdx.x;
     const bool valid = t0 < p.total;  // total = rows * xg here
     const uint64_t t = valid ? t0 : 0;
     const uint64_t tx = t % xg;

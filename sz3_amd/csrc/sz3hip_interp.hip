@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void k_interp_first_dec(T *__restrict__ w, con
 // gathered from the work array, where an unpredictable point keeps its raw value.
 #define IHW_WIN 8192
 #define IH_OQ 128  // indices per wave in the staging queue
-template <typename T>
+template <typename T, bool SMALLR>  // SMALLR: radius <= IH_WIN / 2, code 0 would fall inside the window
 __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__ codes, uint64_t n, int radius,
                                                     uint64_t *__restrict__ hist, const T *__restrict__ work,
                                                     uint64_t *__restrict__ n_vout, uint64_t *__restrict__ vout_idx,
@@ -386,14 +386,18 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
     const int lane = threadIdx.x & 63;
     uint64_t *oq = s_oq[threadIdx.x >> 6];
     uint32_t oq_n = 0;  // wave-uniform fill level
-    auto oq_flush = [&]() {
+    auto oq_flush = [&]() {  // (called by whatever lanes are active)
+        oq_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)oq_n);
         if (oq_n == 0) return;
+        // lane 0 has the smallest index of its wave, so it is active whenever any lane is (and its oq_n is current)
+        const unsigned long long act = __ballot(1);
+        const uint32_t nact = (uint32_t)__popcll(act), rank = (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd((unsigned long long *)n_vout, (unsigned long long)oq_n);
         const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
         const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
         const unsigned long long b0 = ((unsigned long long)bhi << 32) | blo;
-        for (uint32_t k = lane; k < oq_n; k += 64) {
+        for (uint32_t k = rank; k < oq_n; k += nact) {
             const unsigned long long pos = b0 + k;
             if (pos < out_cap) {
                 const uint64_t id = oq[k];
@@ -404,12 +408,20 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
         oq_n = 0;
     };
     const uint64_t nth = (uint64_t)gridDim.x * 256;
-    // (every lane of a wave runs the same number of iterations: the loop bound is rounded up to whole waves below)
-    for (uint64_t i0 = ((uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u)) * 8; i0 < n; i0 += nth * 8) {
-        const uint64_t i = i0 + (uint64_t)lane * 8;
+    // (lanes may leave the loop one iteration apart: the queue level is re-read from the first active lane before use)
+    // the next iteration's 8 codes are requested before this iteration's are counted (clamped address, never conditional)
+    const uint64_t i_first = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    const uint64_t last8 = n >= 8 ? n - 8 : 0;
+    uint4 nxt = make_uint4(0, 0, 0, 0);
+    if (n >= 8) nxt = *reinterpret_cast<const uint4 *>(codes + (i_first < last8 ? i_first : last8));
+    for (uint64_t i = i_first; i < n; i += nth * 8) {
         uint16_t c[8];
+        const uint4 v = nxt;
+        {
+            const uint64_t in = i + nth * 8;
+            if (n >= 8) nxt = *reinterpret_cast<const uint4 *>(codes + (in < last8 ? in : last8));
+        }
         if (i + 8 <= n) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(codes + i);
             const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
             if (i + k >= n) break;
             const uint32_t bin = (uint32_t)c[k] - win_lo;
             // (code 0 never counts in the window: with a small quantbinCnt it would lie inside it)
-            if (bin < IH_WIN && c[k] != 0) atomicAdd(&lh[bin * 4 + copy], 1u);
+            if (bin < IH_WIN && (!SMALLR || c[k] != 0)) atomicAdd(&lh[bin * 4 + copy], 1u);
             else if (c[k] == 0) {
                 atomicAdd(&l_zero[copy], 1u);
                 zmask |= 1u << k;
@@ -439,6 +451,7 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
                 const bool z = (zmask >> k) & 1u;
                 const unsigned long long m = __ballot(z);
                 if (m) {
+                    oq_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)oq_n);
                     if (oq_n + 64 > IH_OQ) oq_flush();
                     if (z) oq[oq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i + k;
                     oq_n += (uint32_t)__popcll(m);
@@ -652,12 +665,18 @@ int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const voi
     int rc = dtype == 0 ? run_interp<float, false>(*ip, (float *)d_work, codes, s)
                         : run_interp<double, false>(*ip, (double *)d_work, codes, s);
     if (rc) return rc;
-    if (dtype == 0)
-        hipLaunchKernelGGL((k_hist_codes<float>), dim3(768), dim3(256), 0, s, codes, num, ip->radius, hist, (const float *)d_work, ip->n_vout,
-                           ip->vout_idx, (float *)ip->vout_val, ip->out_cap);
-    else
-        hipLaunchKernelGGL((k_hist_codes<double>), dim3(768), dim3(256), 0, s, codes, num, ip->radius, hist, (const double *)d_work, ip->n_vout,
-                           ip->vout_idx, (double *)ip->vout_val, ip->out_cap);
+    const bool smallr = ip->radius <= IH_WIN / 2;  // window start <= 0: code 0 lies inside it
+#define SZK_HIST_LAUNCH(T, SR)                                                                                                          \
+    hipLaunchKernelGGL((k_hist_codes<T, SR>), dim3(768), dim3(256), 0, s, codes, num, ip->radius, hist, (const T *)d_work, ip->n_vout, \
+                       ip->vout_idx, (T *)ip->vout_val, ip->out_cap)
+    if (dtype == 0) {
+        if (smallr) SZK_HIST_LAUNCH(float, true);
+        else SZK_HIST_LAUNCH(float, false);
+    } else {
+        if (smallr) SZK_HIST_LAUNCH(double, true);
+        else SZK_HIST_LAUNCH(double, false);
+    }
+#undef SZK_HIST_LAUNCH
     e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

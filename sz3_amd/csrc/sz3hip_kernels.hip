@@ -886,7 +886,8 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                         const bool inr = (UQ)(delta[i] + rng_lo) <= rng_span;
                         code[i] = inr ? (uint32_t)shifted : 0u;
                         uint32_t bin = code[i] - win_lo;           // wraps to a huge value below the window
-                        rare |= bin >= (uint32_t)MARCH_WIDE_WIN;
+                        // (a delta outlier is rare whatever its bin: with a small radius code 0 lies inside the window)
+                        rare |= !inr || bin >= (uint32_t)MARCH_WIDE_WIN;
                         bin = bin < (uint32_t)MARCH_WIDE_WIN ? bin : (uint32_t)MARCH_WIDE_WIN;
                         atomicAdd(&lh[bin], 1u);
                     }
@@ -918,7 +919,10 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                             }
                             oq_n += (uint32_t)__popcll(vm);
                         }
-                        if (rare && code[i] - win_lo >= win_bins) {
+                        // what the LDS window did not count goes to the global histogram: one-byte mode keeps its delta
+                        // outliers (code 0) out of the window (overflow bin) even when a small radius puts bin 0 inside it
+                        const bool in_lds = narrow ? code[i] != 0 : code[i] - win_lo < win_bins;
+                        if (rare && !in_lds) {
                             // code 0 (delta outliers) is one address for the whole grid: one atomic per wave
                             const unsigned long long zm = __ballot(code[i] == 0);
                             if (code[i] != 0) atomicAdd((unsigned long long *)&p.hist[code[i]], 1ull);

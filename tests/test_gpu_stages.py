@@ -221,3 +221,46 @@ def test_many_unpredictables_grow_the_lists(algo):
     back, got_conf = sz3_amd.decompress(blob, a.dtype, shape)
     assert np.max(np.abs(back.astype(np.float64) - a.astype(np.float64))) <= eb
     assert ratio > 2 and got_conf.cmprAlgo in (16, 17)
+
+
+@pytest.mark.parametrize("shape,dtype,qb,eb,sigma,nan", [
+    ((17, 260), np.float32, 256, 1e-3, 2e-3, False),       # two-byte codes, radius 128: code 0 lies inside the LDS window
+    ((64, 65, 128), np.float64, 256, 1e-2, 5e-2, True),    # one-byte codes, radius 128: delta outliers must reach the histogram
+    ((40, 128), np.float32, 256, 1e-3, 2e-3, True),
+    ((128, 32, 128), np.float64, 1024, 1e-3, 2e-3, False),
+    ((8, 3, 100, 260), np.float64, 4096, 1e-3, 5e-2, True),
+    ((256, 256), np.float32, 64, 1e-2, 1e-4, False),
+])
+def test_small_quantiser_lorenzo(shape, dtype, qb, eb, sigma, nan):
+    """quantbinCnt far below the default: the code range is narrower than the kernels' LDS histogram windows, so code 0
+    (delta outlier) falls inside / next to them. Found by tools/lorenzo_sweep.py; checked against the numpy model of K1."""
+    rng = np.random.default_rng(2)
+    grids = np.meshgrid(*[np.arange(s, dtype=np.float64) for s in shape], indexing="ij")
+    a = (sum(np.sin(2 * np.pi * g / (11.0 + 5 * i)) for i, g in enumerate(grids)) + sigma * rng.standard_normal(shape)).astype(dtype)
+    if nan:
+        a.reshape(-1)[rng.integers(0, a.size, size=max(1, a.size // 500))] = np.nan
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    cap = dc.payload_bound(a.size, worst_case=True)
+    pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+    conf = sz3_amd.Config(*shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.absErrorBound = eb
+    conf.quantbinCnt = qb
+    size = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+    st = dc.stats()
+    codes = dc.debug_codes(a.size)
+    out = torch.empty_like(t)
+    dc.decompress(pl.data_ptr(), size, out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    dec = out.cpu().numpy()
+    q, d, exp_codes, bad, dout = szh_ref.dualquant(a, eb, radius=qb // 2, narrow=bool(st["narrow_codes"]))
+    assert np.array_equal(codes, exp_codes.reshape(-1))
+    assert (st["n_value_outliers"], st["n_delta_outliers"]) == (int(bad.sum()), int(dout.sum()))
+    h, o, sec = szh_ref.parse(pl[:size].cpu().numpy().tobytes())
+    model = szh_ref.reconstruct(h, sec, exp_codes.reshape(-1)).reshape(a.shape)
+    assert np.array_equal(dec, model, equal_nan=True)
+    fin = np.isfinite(a)
+    assert np.max(np.abs(dec[fin].astype(np.float64) - a[fin].astype(np.float64))) <= eb
+    assert np.array_equal(np.isnan(dec), np.isnan(a))

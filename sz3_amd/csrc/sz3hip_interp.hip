@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void k_gather_blocks(const T *__restrict__ dat
 }
 // Priced size of a trial's code stream from its histogram alone: res[0] = sum over the alphabet of f * log2(total / f) in
 // 1/256-bit fixed point (integer atomics: the sum does not depend on arrival order), res[1] = symbols in use. The
-// entropy tracks the Huffman-coded size closely enough for the tuner's ratio comparisons (tools/estimator_study.py:
+// entropy tracks the Huffman-coded size closely enough for the tuner's ratio comparisons (tests/checks/estimator_study.py:
 // 29 vs 30 of 41 decisions equal to the reference's) and needs no code book.
 __global__ __launch_bounds__(256) void k_code_cost(const uint64_t *__restrict__ hist, const uint64_t *__restrict__ counters,
                                                    unsigned long long *res, double total, int unpred_is_code0) {

@@ -3,7 +3,7 @@
 The oracle runs the reference's trials exactly (zstd and all) and reports, per trial, Huffman bytes, tree nodes,
 unpredictables and the entropy of the codes; the candidate estimators are evaluated from those on the same trials."""
 import os, sys, math
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from fields import field1d, field2d, field3d, field4d

@@ -2,7 +2,7 @@
 """random sweep of the host API (sz3hip_compress / sz3hip_decompress): shapes, dtypes (f32, f64, i32, i64), every error-bound
 mode, every cmprAlgo, quantbinCnt; checks the user-visible guarantee of each mode on the decompressed array"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, sz3_amd
 rng = np.random.default_rng(int(os.environ.get("SEED", "1")))

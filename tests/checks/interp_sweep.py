@@ -2,7 +2,7 @@
 """random sweep: GPU interpolation codes / reconstruction vs the oracle (bit-exact) over shapes, directions, anchors, alpha/beta,
 quantisation radii, linear/cubic, f32/f64 — a development check beyond tests/test_gpu_interp.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, sz3_amd, math
 from oracle_binding import ALGO_INTERP, make_config, oracle_interp_codes

@@ -2,7 +2,7 @@
 """random sweep of the Lorenzo path: GPU codes vs the numpy model of K1 (tests/szh_ref.py), payload decode vs the model,
 error bound; shapes, dtypes, quantisation radii (small radii put code 0 inside the histogram windows), bounds, NaNs"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, sz3_amd, szh_ref
 rng = np.random.default_rng(int(os.environ.get("SEED", "1")))

@@ -233,7 +233,7 @@ def test_many_unpredictables_grow_the_lists(algo):
 ])
 def test_small_quantiser_lorenzo(shape, dtype, qb, eb, sigma, nan):
     """quantbinCnt far below the default: the code range is narrower than the kernels' LDS histogram windows, so code 0
-    (delta outlier) falls inside / next to them. Found by tools/lorenzo_sweep.py; checked against the numpy model of K1."""
+    (delta outlier) falls inside / next to them. Found by tests/checks/lorenzo_sweep.py; checked against the numpy model of K1."""
     rng = np.random.default_rng(2)
     grids = np.meshgrid(*[np.arange(s, dtype=np.float64) for s in shape], indexing="ij")
     a = (sum(np.sin(2 * np.pi * g / (11.0 + 5 * i)) for i, g in enumerate(grids)) + sigma * rng.standard_normal(shape)).astype(dtype)

@@ -1,7 +1,7 @@
-"""GPU tests (-m gpu): the randomised sweeps of tools/ as part of the suite (fixed seeds, a few seconds each).
-tools/lorenzo_sweep.py  - K1 codes / outlier counts / payload decode against the numpy model of the format (tests/szh_ref.py)
-tools/interp_sweep.py   - interpolation codes and reconstruction against the oracle, bit for bit
-tools/host_sweep.py     - the host API over dtypes, error-bound modes and algorithms: the user-visible guarantee of each mode
+"""GPU tests (-m gpu): the randomised sweeps of tests/checks/ as part of the suite (fixed seeds, a few seconds each).
+tests/checks/lorenzo_sweep.py  - K1 codes / outlier counts / payload decode against the numpy model of the format (tests/szh_ref.py)
+tests/checks/interp_sweep.py   - interpolation codes and reconstruction against the oracle, bit for bit
+tests/checks/host_sweep.py     - the host API over dtypes, error-bound modes and algorithms: the user-visible guarantee of each mode
 They found the small-quantbinCnt bugs fixed in round 1 (code 0 inside the kernels' LDS histogram windows)."""
 import os
 import subprocess
@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(tool, seed, n):
     env = dict(os.environ, SEED=str(seed), N=str(n))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)], env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", tool)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
 

@@ -556,7 +556,10 @@ extern "C" int sz3hip_get_stage_times(sz3hip_ctx *ctx, const char **names, float
     for (int i = 0; i < ST_COUNT && k < max; i++) {
         if (!ctx->ev_used[i]) continue;
         float t = 0;
-        if (hipEventElapsedTime(&t, ctx->ev[i][0], ctx->ev[i][1]) != hipSuccess) continue;
+        if (hipEventElapsedTime(&t, ctx->ev[i][0], ctx->ev[i][1]) != hipSuccess) {
+            (void)hipGetLastError();  // (e.g. the kernel-level pair when another predictor kernel ran: never recorded)
+            continue;
+        }
         names[k] = kStageNames[i];
         ms[k] = t;
         k++;

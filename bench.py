@@ -54,12 +54,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the hot path has no CPU implementation)")
+    # SZ3_BENCH_ONE_GPU=1 (testing the multi-rank code path on a 1-GPU box): every rank uses cuda:0 and gloo instead of RCCL
+    one_gpu = os.environ.get("SZ3_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 

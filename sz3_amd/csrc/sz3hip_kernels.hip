@@ -1457,6 +1457,16 @@ __device__ void cb_assign_codes(const uint16_t *len_of, const uint16_t *syms, ui
 
 // wide alphabets (m > CB_LDS_SYMS): all CB_LAUNCH threads, scratch arrays in global memory (L2-resident), LDS pool
 // for the sort tiles, the 32-bit frequency queues and the code assignment table
+// Very wide alphabets (m > CB_CLASS_MIN: tight bounds on rough data) are coded in two classes: the CB_CLASS_KEEP or fewer
+// most frequent symbols take part in the Huffman construction one by one, all rarer symbols together as ONE pseudo-symbol
+// of their summed weight; a rare symbol's code is the pseudo-symbol's code word followed by a fixed-length index
+// (length = len(pseudo) + ceil(log2(number of rare symbols))). The format only stores code lengths, so the decoder does
+// not know about classes. The construction then runs on <= CB_CLASS_KEEP + 1 keys, inside LDS, instead of on up to 65536
+// keys through global memory (C4's 25 887 symbols: 0.63 -> ~0.25 ms); the rare symbols carry ~1 % of the occurrences, so
+// the coded size grows by well under 0.1 %.
+#define CB_CLASS_MIN 16384u
+#define CB_CLASS_KEEP 12288u
+template <bool ALLOW_CLS>
 __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_params &p, uint8_t *pool, uint32_t lo,
                               uint32_t range, uint32_t *s_cnt, uint32_t *s_first, uint32_t *s_misc) {
     const uint32_t t = threadIdx.x, NT = blockDim.x;
@@ -1502,39 +1512,122 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
         pos += (uint32_t)__popcll(bal);
     }
     __syncthreads();
-    const uint64_t total = s_total;
+    uint64_t total = s_total;
+    const uint32_t L = m <= CB_SHORT_SYMS ? 16u : SZH_MAX_LEN;
+    // 1b. two-class mode: keep the frequent symbols, fold the rare ones into one pseudo-symbol
+    const bool cls = ALLOW_CLS && m > CB_CLASS_MIN;
+    uint32_t mk = m, n_rare = 0, rare_bits = 0, pseudo_sym = 0;
+    uint64_t rare_max = 0;  // a symbol is rare when its count is <= rare_max
+    if (cls) {
+        __shared__ uint32_t s_cls[48];
+        __shared__ unsigned long long s_fsum;
+        if (t < 48) s_cls[t] = 0;
+        if (t == 0) s_fsum = 0;
+        __syncthreads();
+        for (uint32_t q = t; q < m; q += NT) atomicAdd(&s_cls[63 - __clzll((long long)(p.keys[q] >> 16))], 1u);
+        __syncthreads();
+        if (t == 0) {  // smallest k with (symbols of count >= 2^(k+1)) <= CB_CLASS_KEEP
+            uint32_t above = 0;
+            int k = 47;
+            while (k >= 0 && above + s_cls[k] <= CB_CLASS_KEEP) above += s_cls[k--];
+            unsigned long long mass = 0;  // occurrences the rare class would hold, estimated from the counts per octave
+            for (int j = 0; j <= k; j++) mass += (unsigned long long)s_cls[j] * (3ull << j) / 2ull;
+            // a flat code only suits a class that carries little: beyond 1/64 of the occurrences (a near-uniform spread
+            // over tens of thousands of bins, ratio ~2) the one-by-one construction is kept
+            s_misc[5] = mass * 64ull <= total ? (uint32_t)k : 0xFFFFFFFFu;
+            s_misc[6] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        if (s_misc[5] == 0xFFFFFFFFu) {
+            __syncthreads();
+            if (ALLOW_CLS) codebook_wide<false>(hist, p, pool, lo, range, s_cnt, s_first, s_misc);
+            return;
+        }
+        rare_max = (2ull << s_misc[5]) - 1ull;
+        // compaction of the frequent keys (symbol order kept) into ifreq[], as in step 1
+        const uint32_t segk = ((m + n_wv - 1) / n_wv + WAVE - 1) / WAVE * WAVE;
+        const uint32_t k0 = wv_id * segk < m ? wv_id * segk : m, k1 = k0 + segk < m ? k0 + segk : m;
+        uint32_t c2 = 0;
+        for (uint32_t i0 = k0; i0 < k1; i0 += WAVE) {
+            const uint32_t i = i0 + lane;
+            const uint64_t f = i < k1 ? p.keys[i] >> 16 : 0ull;
+            c2 += (uint32_t)__popcll(__ballot(f > rare_max));
+        }
+        __syncthreads();  // (s_wt of step 1 no longer read)
+        if (lane == 0) s_wt[wv_id] = c2;
+        __syncthreads();
+        uint32_t pos2 = 0, n_freq = 0;
+        for (uint32_t wv = 0; wv < n_wv; wv++) {
+            if (wv < wv_id) pos2 += s_wt[wv];
+            n_freq += s_wt[wv];
+        }
+        uint64_t fs = 0;
+        uint32_t rare_sym = 0xFFFFFFFFu;
+        for (uint32_t i0 = k0; i0 < k1; i0 += WAVE) {
+            const uint32_t i = i0 + lane;
+            const uint64_t key = i < k1 ? p.keys[i] : 0ull;
+            const uint64_t f = key >> 16;
+            const bool fr = f > rare_max;
+            const unsigned long long bal = __ballot(fr);
+            if (fr) {
+                p.ifreq[pos2 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = key;
+                fs += f;
+            } else if (f) {
+                const uint32_t sy = (uint32_t)(key & 0xFFFF);
+                rare_sym = sy < rare_sym ? sy : rare_sym;
+            }
+            pos2 += (uint32_t)__popcll(bal);
+        }
+        fs = wave_sum(fs);
+        if (lane == 0 && fs) atomicAdd(&s_fsum, (unsigned long long)fs);
+        if (rare_sym != 0xFFFFFFFFu) atomicMin(&s_misc[6], rare_sym);
+        __syncthreads();
+        n_rare = m - n_freq;
+        rare_bits = n_rare > 1 ? 32u - (uint32_t)__clz((int)(n_rare - 1)) : 0u;
+        pseudo_sym = s_misc[6];  // a rare symbol's id stands for the class (no frequent key carries it)
+        // weight of the class: the rare occurrences, but at least enough for a code word short enough to leave room for
+        // the index below it (Huffman gives a weight w of W a length of about log2(W / w), +-1)
+        uint64_t w_rare = total - s_fsum;
+        const uint32_t room = L > rare_bits + 3 ? L - rare_bits - 3 : 1;
+        const uint64_t w_min = (total >> room) + 1;
+        if (w_rare < w_min) w_rare = w_min;
+        total = s_fsum + w_rare;
+        for (uint32_t q = t; q < n_freq; q += NT) p.keys[q] = p.ifreq[q];
+        if (t == 0) p.keys[n_freq] = (w_rare << 16) | pseudo_sym;
+        mk = n_freq + 1;
+        __syncthreads();
+    }
     if (t == 0) p.info->ts[2] = wall_clock64();
     // 2. sort by (freq, sym)
     RecView rv{p.keys, nullptr, false, false};
-    rec_sort(rv, m, pool);
+    rec_sort(rv, mk, pool);
     if (t == 0) p.info->ts[3] = wall_clock64();
     // 3. merge
     uint16_t *pleaf = p.pleaf, *pint = p.pint, *aux = p.depth, *aux2 = p.aux2, *pint2 = p.pint2;
     constexpr uint32_t LDSQ = CB_POOL_BYTES / 8;  // symbols whose two 32-bit queues fit the pool
-    if (m <= LDSQ && total < 0xFFFFFFFFull) {
+    if (mk <= LDSQ && total < 0xFFFFFFFFull) {
         uint32_t *lf32 = reinterpret_cast<uint32_t *>(pool), *nf32 = lf32 + LDSQ;
-        for (uint32_t q = t; q < m; q += NT) lf32[q] = (uint32_t)(p.keys[q] >> 16);
+        for (uint32_t q = t; q < mk; q += NT) lf32[q] = (uint32_t)(p.keys[q] >> 16);
         __syncthreads();
-        cb_merge_rounds<true>(p.keys, p.ifreq, lf32, nf32, pleaf, pint, m, s_misc);
+        cb_merge_rounds<true>(p.keys, p.ifreq, lf32, nf32, pleaf, pint, mk, s_misc);
     } else {
-        cb_merge_rounds<false>(p.keys, p.ifreq, nullptr, nullptr, pleaf, pint, m, s_misc);
+        cb_merge_rounds<false>(p.keys, p.ifreq, nullptr, nullptr, pleaf, pint, mk, s_misc);
     }
     if (t == 0) p.info->ts[4] = wall_clock64();
     // 4. depth of every internal node by pointer doubling (min(depth, 2^rounds) is all the clamp needs); the four
     //    u16 arrays ping-pong in the LDS pool when they fit (m <= 16384), else in global memory
-    const uint32_t L = m <= CB_SHORT_SYMS ? 16u : SZH_MAX_LEN;
     {
-        const bool in_lds = m <= CB_POOL_BYTES / 8;
+        const bool in_lds = mk <= CB_POOL_BYTES / 8;
         uint16_t *dA = in_lds ? reinterpret_cast<uint16_t *>(pool) : aux, *pA = in_lds ? dA + CB_POOL_BYTES / 8 : pint;
         uint16_t *dB = in_lds ? pA + CB_POOL_BYTES / 8 : aux2, *pB = in_lds ? dB + CB_POOL_BYTES / 8 : pint2;
         __syncthreads();  // (the merge's LDS queues are dead from here on)
-        for (uint32_t q = t; q + 1 < m; q += NT) {
-            pA[q] = q == m - 2 ? (uint16_t)q : pint[q];
-            dA[q] = q == m - 2 ? 0 : 1;
+        for (uint32_t q = t; q + 1 < mk; q += NT) {
+            pA[q] = q == mk - 2 ? (uint16_t)q : pint[q];
+            dA[q] = q == mk - 2 ? 0 : 1;
         }
         __syncthreads();
-        for (uint32_t span = 1; span < m && span < 2 * L; span <<= 1) {
-            for (uint32_t q = t; q + 1 < m; q += NT) {
+        for (uint32_t span = 1; span < mk && span < 2 * L; span <<= 1) {
+            for (uint32_t q = t; q + 1 < mk; q += NT) {
                 const uint16_t jn = pA[q];
                 const uint32_t sum = (uint32_t)dA[q] + dA[jn];
                 dB[q] = (uint16_t)(sum > 0xFFFFu ? 0xFFFFu : sum);
@@ -1549,7 +1642,7 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
             pB = sw;
         }
         // leaf lengths in sorted order, clamped
-        for (uint32_t q = t; q < m; q += NT) {
+        for (uint32_t q = t; q < mk; q += NT) {
             uint32_t l = (uint32_t)dA[pleaf[q]] + 1;
             if (l > L) {
                 l = L;
@@ -1562,7 +1655,32 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
     }
     if (t == 0) p.info->ts[5] = wall_clock64();
     // 5. Kraft repair when a natural depth exceeded the limit
-    if (s_misc[4]) cb_kraft_repair(pleaf, m, s_cnt, L, NT, reinterpret_cast<uint64_t *>(pool));
+    if (s_misc[4]) cb_kraft_repair(pleaf, mk, s_cnt, L, NT, reinterpret_cast<uint64_t *>(pool));
+    // 6. lengths to symbol order (through the serialised lens[] table), then canonical codes
+    __syncthreads();
+    for (uint32_t q = t; q < mk; q += NT) p.lens[(uint32_t)(p.keys[q] & 0xFFFF)] = (uint8_t)pleaf[q];
+    __syncthreads();
+    if (cls) {  // every rare symbol: the class's code word + a fixed-length index
+        const uint32_t len_cls = p.lens[pseudo_sym], len_rare = len_cls + rare_bits;
+        if (len_rare > L) {  // (the weight floor above makes this all but impossible) one-class construction instead
+            __syncthreads();
+            if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
+            for (uint32_t q = t; q < range; q += NT) p.lens[lo + q] = 0;
+            __syncthreads();
+            if (ALLOW_CLS) codebook_wide<false>(hist, p, pool, lo, range, s_cnt, s_first, s_misc);
+            return;
+        }
+        __syncthreads();
+        for (uint32_t q = t; q < m; q += NT) {
+            const uint32_t sy = p.syms[q];
+            if (hist[sy] <= rare_max) p.lens[sy] = (uint8_t)len_rare;
+        }
+        if (t == 0) {
+            s_cnt[len_cls] -= 1;
+            s_cnt[len_rare] += n_rare;
+        }
+        __syncthreads();
+    }
     if (t == 0) {
         uint32_t code = 0;
         for (uint32_t l = 1; l <= L; l++) {
@@ -1571,9 +1689,6 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
         }
         p.info->ts[6] = wall_clock64();
     }
-    // 6. lengths to symbol order (through the serialised lens[] table), then canonical codes
-    for (uint32_t q = t; q < m; q += NT) p.lens[(uint32_t)(p.keys[q] & 0xFFFF)] = (uint8_t)pleaf[q];
-    __syncthreads();
     for (uint32_t q = t; q < m; q += NT) aux[q] = p.lens[p.syms[q]];
     __syncthreads();
     if (t == 0) p.info->ts[7] = wall_clock64();
@@ -1582,7 +1697,8 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
     for (uint32_t l = 1; l <= L; l++)
         if (s_cnt[l]) max_len = l;
     if (t == 0) {
-        const uint32_t peak = (uint32_t)(p.keys[m - 1] & 0xFFFF);  // most frequent symbol: centre of the packers' LDS window
+        uint32_t peak = (uint32_t)(p.keys[mk - 1] & 0xFFFF);  // most frequent symbol: centre of the packers' LDS window
+        if (cls && peak == pseudo_sym && mk > 1) peak = (uint32_t)(p.keys[mk - 2] & 0xFFFF);  // (not the rare class)
         uint32_t wl = peak > lo + ENC_WIN / 2 ? peak - ENC_WIN / 2 : lo;
         if (range > ENC_WIN && wl > lo + range - ENC_WIN) wl = lo + range - ENC_WIN;
         if (range <= ENC_WIN) wl = lo;
@@ -1652,7 +1768,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     }
     __syncthreads();
     if (!small) {
-        codebook_wide(hist, p, s_pool, lo, range, s_cnt, s_first, s_misc);
+        codebook_wide<true>(hist, p, s_pool, lo, range, s_cnt, s_first, s_misc);
         return;
     }
     // ---------------- small alphabets: LDS-resident, 256 threads ----------------

@@ -1457,15 +1457,17 @@ __device__ void cb_assign_codes(const uint16_t *len_of, const uint16_t *syms, ui
 
 // wide alphabets (m > CB_LDS_SYMS): all CB_LAUNCH threads, scratch arrays in global memory (L2-resident), LDS pool
 // for the sort tiles, the 32-bit frequency queues and the code assignment table
-// Very wide alphabets (m > CB_CLASS_MIN: tight bounds on rough data) are coded in two classes: the CB_CLASS_KEEP or fewer
-// most frequent symbols take part in the Huffman construction one by one, all rarer symbols together as ONE pseudo-symbol
-// of their summed weight; a rare symbol's code is the pseudo-symbol's code word followed by a fixed-length index
-// (length = len(pseudo) + ceil(log2(number of rare symbols))). The format only stores code lengths, so the decoder does
-// not know about classes. The construction then runs on <= CB_CLASS_KEEP + 1 keys, inside LDS, instead of on up to 65536
-// keys through global memory (C4's 25 887 symbols: 0.63 -> ~0.25 ms); the rare symbols carry ~1 % of the occurrences, so
-// the coded size grows by well under 0.1 %.
-#define CB_CLASS_MIN 16384u
-#define CB_CLASS_KEEP 12288u
+// Wide alphabets (m > CB_CLASS_MIN: the interpolation predictor's coarse levels, tight bounds on rough data) are coded in
+// two classes: the most frequent symbols (at most CB_CLASS_KEEP, else CB_CLASS_KEEP2 of them) take part in the Huffman
+// construction one by one, all rarer symbols together as ONE pseudo-symbol of their summed weight; a rare symbol's code is
+// the pseudo-symbol's code word followed by a fixed-length index (length = len(pseudo) + ceil(log2(number of rare
+// symbols))). The format only stores code lengths, so the decoder does not know about classes. The construction then
+// runs on a few thousand keys inside LDS instead of on up to 65536 keys through global memory (C3's 16 365 symbols: 0.25 ->
+// 0.20 ms; C4's 25 887: 0.63 -> 0.40 ms). A tier is taken only when its rare class would hold at most 1/64 of the
+// occurrences: the coded size then grows by 0.05-0.3 %.
+#define CB_CLASS_MIN 4096u
+#define CB_CLASS_KEEP 3072u    // first choice: everything after it runs on one 4096-key LDS tile
+#define CB_CLASS_KEEP2 12288u  // second choice when the first would put too many occurrences into the rare class
 template <bool ALLOW_CLS>
 __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_params &p, uint8_t *pool, uint32_t lo,
                               uint32_t range, uint32_t *s_cnt, uint32_t *s_first, uint32_t *s_misc) {
@@ -1526,15 +1528,22 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
         __syncthreads();
         for (uint32_t q = t; q < m; q += NT) atomicAdd(&s_cls[63 - __clzll((long long)(p.keys[q] >> 16))], 1u);
         __syncthreads();
-        if (t == 0) {  // smallest k with (symbols of count >= 2^(k+1)) <= CB_CLASS_KEEP
-            uint32_t above = 0;
-            int k = 47;
-            while (k >= 0 && above + s_cls[k] <= CB_CLASS_KEEP) above += s_cls[k--];
-            unsigned long long mass = 0;  // occurrences the rare class would hold, estimated from the counts per octave
-            for (int j = 0; j <= k; j++) mass += (unsigned long long)s_cls[j] * (3ull << j) / 2ull;
-            // a flat code only suits a class that carries little: beyond 1/64 of the occurrences (a near-uniform spread
-            // over tens of thousands of bins, ratio ~2) the one-by-one construction is kept
-            s_misc[5] = mass * 64ull <= total ? (uint32_t)k : 0xFFFFFFFFu;
+        if (t == 0) {
+            // a flat code only suits a class that carries little: the rare class may hold at most 1/64 of the occurrences
+            // (estimated from the counts per octave); a near-uniform spread over tens of thousands of bins (ratio ~2)
+            // keeps the one-by-one construction
+            uint32_t choice = 0xFFFFFFFFu;
+            const uint32_t keep[2] = {CB_CLASS_KEEP, CB_CLASS_KEEP2};
+            for (int tier = 0; tier < 2 && choice == 0xFFFFFFFFu; tier++) {
+                if (m <= keep[tier] + keep[tier] / 4) continue;  // (nothing to gain)
+                uint32_t above = 0;  // smallest k with (symbols of count >= 2^(k+1)) <= keep
+                int k = 47;
+                while (k >= 0 && above + s_cls[k] <= keep[tier]) above += s_cls[k--];
+                unsigned long long mass = 0;
+                for (int j = 0; j <= k; j++) mass += (unsigned long long)s_cls[j] * (3ull << j) / 2ull;
+                if (k >= 0 && mass * 64ull <= total) choice = (uint32_t)k;
+            }
+            s_misc[5] = choice;
             s_misc[6] = 0xFFFFFFFFu;
         }
         __syncthreads();

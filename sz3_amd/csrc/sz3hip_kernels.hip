@@ -1720,6 +1720,10 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
     }
 }
 
+// PART 0: alphabets up to CB_SMALL_SYMS symbols + the outlier-list sorts; PART 1: wider alphabets. Which one applies is
+// known only on the device (k_hist_range), so both are launched and the other returns at once: the small path keeps its
+// own register allocation and instruction footprint (sharing one kernel with the wide path cost it 10 us of its 40).
+template <int PART>
 __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restrict__ hist, szk_cb_params p) {
     __shared__ __align__(16) uint8_t s_pool[CB_POOL_BYTES];
     __shared__ uint32_t s_wtot[CB_THREADS / WAVE];
@@ -1729,6 +1733,8 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     __shared__ unsigned long long s_total;
     const uint32_t t = threadIdx.x;
     if (blockIdx.x >= p.n_books) {  // the two blocks after the code books: deterministic order of the two outlier lists
+        // (in the launch whose code-book path is the active one, so that they run beside it)
+        if ((PART == 1) != (p.range[2] > CB_SMALL_SYMS)) return;
         const bool d = blockIdx.x == p.n_books + 1;
         sort_outlier_list(d ? p.dout_idx : p.vout_idx, d ? p.dout_val : p.vout_val, d ? *p.n_dout : *p.n_vout, p.out_cap,
                           d ? p.q_is_32bit != 0 : p.t_is_32bit != 0, s_pool);
@@ -1752,6 +1758,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     }
     // range and number of the non-empty bins: found by k_hist_range (256 workgroups) just before this launch
     const uint32_t n_nonzero = p.range[2];
+    if ((PART == 1) != (n_nonzero > CB_SMALL_SYMS)) return;  // the other launch's case
     if (n_nonzero == 0) {
         if (t == 0) {
             p.info->n_symbols = 0;
@@ -1776,7 +1783,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
         p.lens[lo + i] = 0;
     }
     __syncthreads();
-    if (!small) {
+    if (PART == 1) {
         codebook_wide<true>(hist, p, s_pool, lo, range, s_cnt, s_first, s_misc);
         return;
     }
@@ -3050,7 +3057,8 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
     hipError_t e = hipMemsetAsync(q.range, 0, 16 * nb, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256, nb), dim3(256), 0, s, d_hist, q.range);
-    hipLaunchKernelGGL(k_codebook, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
+    hipLaunchKernelGGL(k_codebook<0>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
+    hipLaunchKernelGGL(k_codebook<1>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
     SZK_CHECK_LAUNCH();
     return 0;
 }

@@ -202,15 +202,19 @@ def main():
 
     # ---- host end-to-end (PCIe + zstd inclusive; informational) ----
     if rank == 0 and world == 1 and not args.no_host_e2e:
-        t0 = time.perf_counter()
-        blob, hratio = sz3_amd.compress(a, conf)
-        t1 = time.perf_counter()
-        dec, _ = sz3_amd.decompress(blob, npdt, shape)
-        t2 = time.perf_counter()
-        out["host_e2e"] = {"compress_gbps": round(raw_bytes / (t1 - t0) / 1e9, 3), "ratio": round(hratio, 4),
-                           "decompress_gbps": round(raw_bytes / (t2 - t1) / 1e9, 3),
+        best_c = best_d = 0.0
+        for _ in range(3):  # the first call creates the host API's cached context and pinned staging buffer
+            t0 = time.perf_counter()
+            blob, hratio = sz3_amd.compress(a, conf)
+            t1 = time.perf_counter()
+            dec, _ = sz3_amd.decompress(blob, npdt, shape)
+            t2 = time.perf_counter()
+            best_c = max(best_c, raw_bytes / (t1 - t0) / 1e9)
+            best_d = max(best_d, raw_bytes / (t2 - t1) / 1e9)
+        out["host_e2e"] = {"compress_gbps": round(best_c, 3), "ratio": round(hratio, 4),
+                           "decompress_gbps": round(best_d, 3),
                            "max_abs_err": float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))),
-                           "note": "host buffer in -> host SZ3 container out: H2D + kernels + D2H + zstd(threads)"}
+                           "note": "host buffer in -> host SZ3 container out: H2D + kernels + D2H + zstd(threads); best of 3 calls"}
 
     # ---- CPU baseline on this box's host cores (rank 0, N=1 only; checker code, never the product) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1193,9 +1193,31 @@ __device__ void rec_sort(const RecView &r, uint32_t n, uint8_t *pool) {
 // function of the input (the reference's CI compares stream digests across platforms, .github/workflows/cmake.yml:295-310).
 // Lists beyond 32768 records (a sign that the bound is too tight for the data; sorting them would take longer than the
 // rest of stage 2) stay in arrival order.
-__device__ void sort_outlier_list(uint64_t *idx, void *val, uint64_t n, uint64_t cap, bool v32, uint8_t *pool) {
+// With a 512 KB scratch area the sort runs on keys alone — (index << 16) | arrival position — which fit one 16384-key
+// LDS tile up to 16384 records (records with their values take 16 bytes: 8192 per tile); the values follow by position.
+__device__ void sort_outlier_list(uint64_t *idx, void *val, uint64_t n, uint64_t cap, bool v32, uint8_t *pool, uint64_t *scratch) {
     if (n > cap) n = cap;
     if (n < 2 || n > 32768) return;
+    if (scratch) {  // [32768] keys, then [32768] saved values (indices are element offsets: far below 2^48)
+        uint64_t *sk = scratch, *sv = scratch + 32768;
+        const uint32_t m = (uint32_t)n;
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+            sk[i] = (idx[i] << 16) | i;
+            sv[i] = v32 ? (uint64_t) reinterpret_cast<const uint32_t *>(val)[i] : reinterpret_cast<const uint64_t *>(val)[i];
+        }
+        __syncthreads();
+        RecView r{sk, nullptr, false, false};
+        rec_sort(r, m, pool);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+            const uint64_t k = sk[i];
+            idx[i] = k >> 16;
+            const uint64_t v = sv[(uint32_t)(k & 0xFFFFu)];
+            if (v32) reinterpret_cast<uint32_t *>(val)[i] = (uint32_t)v;
+            else reinterpret_cast<uint64_t *>(val)[i] = v;
+        }
+        return;
+    }
     RecView r{idx, reinterpret_cast<uint8_t *>(val), true, v32};
     rec_sort(r, (uint32_t)n, pool);
 }
@@ -1736,8 +1758,10 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
         // (in the launch whose code-book path is the active one, so that they run beside it)
         if ((PART == 1) != (p.range[2] > CB_SMALL_SYMS)) return;
         const bool d = blockIdx.x == p.n_books + 1;
+        // scratch: the key tables of the batch slots 1 and 2, idle when a single code book is built (n_books <= 1)
+        uint64_t *scratch = p.n_books <= 1 ? p.keys + (size_t)(d ? 2 : 1) * SZH_HIST_BINS : nullptr;
         sort_outlier_list(d ? p.dout_idx : p.vout_idx, d ? p.dout_val : p.vout_val, d ? *p.n_dout : *p.n_vout, p.out_cap,
-                          d ? p.q_is_32bit != 0 : p.t_is_32bit != 0, s_pool);
+                          d ? p.q_is_32bit != 0 : p.t_is_32bit != 0, s_pool, scratch);
         return;
     }
     {  // book b of a batch (the tuner's trials) uses the b-th slice of every table

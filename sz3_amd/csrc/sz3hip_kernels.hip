@@ -869,10 +869,13 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                     uint32_t pk8 = 0;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const uint32_t t = (uint32_t)delta[i] + 127u;
-                        const bool inr = (UQ)(delta[i] + (UQ)127) <= (UQ)254;
-                        const uint32_t byte = inr ? t + 1u : 0u;
-                        const uint32_t bin = inr ? t + (uint32_t)(HIST_WIN / 2 - 127) : (uint32_t)HIST_WIN;  // delta + radius - win_lo
+                        // t = delta + 127 as an unsigned number: in range <=> t <= 254; clamping it to 255 sends every
+                        // out-of-range delta to the spare bin next to the window's last used one and to byte (255 + 1) & 255 = 0
+                        const UQ tq = delta[i] + (UQ)127;
+                        const bool inr = tq <= (UQ)254;
+                        const uint32_t tc = inr ? (uint32_t)tq : 255u;
+                        const uint32_t byte = (tc + 1u) & 255u;
+                        const uint32_t bin = tc + (uint32_t)(HIST_WIN / 2 - 127);  // delta + radius - win_lo; 255 + 385 = spare bin, skipped by the flush
                         rare |= !inr;
                         pk8 |= byte << (8 * i);
                         code[i] = inr ? (uint32_t)delta[i] + (uint32_t)radius : 0u;  // only read on the rare path
@@ -937,8 +940,8 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     __syncthreads();
     uint32_t *row = p.hist_partial + (uint64_t)blockIdx.x * HIST_WIN;
     if (narrow) {
-        for (int bnn = threadIdx.x; bnn < HIST_WIN; bnn += 256)
-            row[bnn] = lh[bnn * 4] + lh[bnn * 4 + 1] + lh[bnn * 4 + 2] + lh[bnn * 4 + 3];
+        for (int bnn = threadIdx.x; bnn < HIST_WIN; bnn += 256)  // (bin 255 + 385 collected the out-of-range deltas: not a symbol)
+            row[bnn] = bnn == 255 + HIST_WIN / 2 - 127 ? 0u : lh[bnn * 4] + lh[bnn * 4 + 1] + lh[bnn * 4 + 2] + lh[bnn * 4 + 3];
     } else {  // wide window: straight into the global histogram (the bins are spread, no hot address), empty row for the fold
         for (int bnn = threadIdx.x; bnn < HIST_WIN; bnn += 256) row[bnn] = 0;
         for (int bnn = threadIdx.x; bnn < MARCH_WIDE_WIN; bnn += 256) {

@@ -814,7 +814,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                     // the row offset is wave-uniform (scalar unit), only the lane offset is per-lane
                     const T *row = src + (uint64_t)(rok ? (uint32_t)gy : 0u) * d0;
                     rq[lw][r].load(row + lane_off);
-                    rl[lw][r] = row[left_off];
+                    rl[lw][r] = has_left ? row[left_off] : (T)0;  // (wave-uniform: tiles at x = 0 have no left neighbour)
                 }
             }
             // ---- rows ----
@@ -837,9 +837,12 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                         q[i] = ok ? v : (Q)0;
                         if (lw == 0) badmask |= (uint32_t)(bad & ok) << i;
                     }
-                    bool badl;
-                    const Q ql = lat.quant(rl[lw][r], badl);
-                    const Q left0 = (rok && has_left) ? ql : (Q)0;  // only lane 0's value is used
+                    Q left0 = (Q)0;  // only lane 0's value is used
+                    if (has_left) {  // wave-uniform
+                        bool badl;
+                        const Q ql = lat.quant(rl[lw][r], badl);
+                        left0 = rok ? ql : (Q)0;
+                    }
                     UQ pv = (UQ)dpp_wave_shr1(left0, q[3]);
                     UQ d1v[4];
 #pragma unroll

@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
         const uint32_t ny = (d1 - y0 < (uint32_t)TY) ? d1 - y0 : (uint32_t)TY;
         // per-lane element offsets inside a row, fixed for the task: own quad, and the element left of it (lane 0 of a tile
         // that has a left neighbour reads x0 - 1; the other lanes' values are never used)
-        const uint32_t lane_off = xok ? x : 0u, left_off = (xok && x > 0) ? x - 1 : 0u;
+        const uint32_t lane_off = xok ? x : 0u;
 
         UQ pp[NW][TY][4];  // d2 of the previous plane
 #pragma unroll
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                     // the row offset is wave-uniform (scalar unit), only the lane offset is per-lane
                     const T *row = src + (uint64_t)(rok ? (uint32_t)gy : 0u) * d0;
                     rq[lw][r].load(row + lane_off);
-                    rl[lw][r] = has_left ? row[left_off] : (T)0;  // (wave-uniform: tiles at x = 0 have no left neighbour)
+                    rl[lw][r] = has_left ? row[x0 - 1] : (T)0;  // wave-uniform address (element left of the tile): a scalar load
                 }
             }
             // ---- rows ----

@@ -72,6 +72,7 @@ struct szk_cb_params {
     int t_is_32bit, q_is_32bit;
     szk_cb_info *info;
     uint32_t n_books;  // 0/1: one code book (+ the outlier sorts); 2..SZK_MAX_BOOKS: a batch, tables sliced per book
+    uint32_t dbg;      // development switches, filled by the launcher from the debug flags (1: force the one-class fallback)
 };
 #define SZK_MAX_BOOKS 4
 #define SZK_MAX_TRIALS 8  // tuner trials of one launch group

@@ -1699,7 +1699,7 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
     __syncthreads();
     if (cls) {  // every rare symbol: the class's code word + a fixed-length index
         const uint32_t len_cls = p.lens[pseudo_sym], len_rare = len_cls + rare_bits;
-        if (len_rare > L) {  // (the weight floor above makes this all but impossible) one-class construction instead
+        if (len_rare > L || (p.dbg & 1u)) {  // (the weight floor above makes this all but impossible) one-class construction instead
             __syncthreads();
             if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
             for (uint32_t q = t; q < range; q += NT) p.lens[lo + q] = 0;
@@ -3084,6 +3084,7 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
     const uint32_t nb = p->n_books ? p->n_books : 1;  // > 1: batch of independent code books (tuner trials), no outlier sort
     szk_cb_params q = *p;
     q.n_books = nb;
+    q.dbg = (szk_dbg_flags & 1024) ? 1u : 0u;
     hipError_t e = hipMemsetAsync(q.range, 0, 16 * nb, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256, nb), dim3(256), 0, s, d_hist, q.range);

@@ -264,3 +264,35 @@ def test_small_quantiser_lorenzo(shape, dtype, qb, eb, sigma, nan):
     fin = np.isfinite(a)
     assert np.max(np.abs(dec[fin].astype(np.float64) - a[fin].astype(np.float64))) <= eb
     assert np.array_equal(np.isnan(dec), np.isnan(a))
+
+
+def test_two_class_code_book_and_its_fallback():
+    """wide alphabet (> 4096 symbols): the two-class code book (frequent symbols one by one + one rare class) and, forced by
+    debug flag 1024, the one-class construction it falls back to both give a decodable stream within the bound; the class
+    form may cost at most 0.5 % of the size"""
+    a = field3d((128, 160, 192))
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    cap = dc.payload_bound(a.size)
+    out = torch.empty_like(t)
+    sizes, lens = [], []
+    try:
+        for flag in (0, 1024):
+            sz3_amd.lib().sz3hip_debug_flags(flag)
+            pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+            conf = sz3_amd.Config(*a.shape)
+            conf.cmprAlgo = sz3_amd.ALGO_INTERP
+            conf.absErrorBound = 1e-5
+            n = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+            dc.decompress(pl.data_ptr(), n, out.data_ptr(), 0)
+            torch.cuda.synchronize()
+            assert float((out.double() - t.double()).abs().max()) <= 1e-5
+            h, o, sec = szh_ref.parse(pl[:n].cpu().numpy().tobytes())
+            assert h["sym_count"] > 4096 and szh_ref.kraft(sec["lens"]) <= 1.0
+            sizes.append(n)
+            lens.append(sec["lens"])
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(0)
+    assert not np.array_equal(lens[0], lens[1])          # the two constructions really differ ...
+    assert sizes[1] <= sizes[0] <= 1.005 * sizes[1]       # ... and the class form costs next to nothing

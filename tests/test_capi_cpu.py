@@ -136,3 +136,18 @@ def test_reference_cli_builds_against_our_headers():
         pytest.skip("oracle/_ref/sz3_hip not built (needs /root/reference)")
     out = subprocess.run([exe, "-v"], capture_output=True, text=True).stdout
     assert "SZ3 Version: 3.3.2" in out
+
+
+def test_c_headers_are_plain_c(tmp_path):
+    """include/sz3hip.h and include/sz3c.h are the FFI boundary: they must compile as C99 (cgo / JNI / ctypes generators
+    read them as C), not only as C++"""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "sz3hip.h"\n#include "sz3c.h"\nint main(void) { return 0; }\n')
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

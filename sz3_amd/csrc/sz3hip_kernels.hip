@@ -711,7 +711,7 @@ __device__ __forceinline__ int64_t dpp_wave_shr1(int64_t old, int64_t src) {
 // instead of 3.
 template <typename T, int NDIM, int TY, int MODE = 0>
 __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict__ in, uint16_t *__restrict__ codes,
-                                                             szk_k1_params p, uint32_t ntasks) {
+                                                             szk_k1_params p, uint32_t ntasks, uint32_t nrows) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     constexpr int NW = NDIM == 4 ? 2 : 1;
@@ -945,8 +945,10 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     if (narrow) {
         for (int bnn = threadIdx.x; bnn < HIST_WIN; bnn += 256)  // (bin 255 + 385 collected the out-of-range deltas: not a symbol)
             row[bnn] = bnn == 255 + HIST_WIN / 2 - 127 ? 0u : lh[bnn * 4] + lh[bnn * 4 + 1] + lh[bnn * 4 + 2] + lh[bnn * 4 + 3];
-    } else {  // wide window: straight into the global histogram (the bins are spread, no hot address), empty row for the fold
-        for (int bnn = threadIdx.x; bnn < HIST_WIN; bnn += 256) row[bnn] = 0;
+    } else {  // wide window: straight into the global histogram (the bins are spread, no hot address), empty rows for the fold
+        // (nrows = rows the fold reads: the larger grid of the two specialisations)
+        for (uint32_t r = blockIdx.x; r < nrows; r += gridDim.x)
+            for (int bnn = threadIdx.x; bnn < HIST_WIN; bnn += 256) p.hist_partial[(uint64_t)r * HIST_WIN + bnn] = 0;
         for (int bnn = threadIdx.x; bnn < MARCH_WIDE_WIN; bnn += 256) {
             const uint32_t v = lh[bnn];
             const uint32_t sym = win_lo + (uint32_t)bnn;
@@ -2970,12 +2972,17 @@ static void launch_march(const void *d_in, uint16_t *codes, const szk_k1_params 
     uint32_t grid;
     if (p.prof_ev0) (void)hipEventRecord((hipEvent_t)p.prof_ev0, s);
     if (p.mode.allow && !(szk_dbg_flags & 256)) {
-        grid = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 1>, (nb + 3) / 4);
-        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 1>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
-        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 2>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
+        // each specialisation gets the grid its own occupancy allows (all workgroups resident: the tasks are dealt by stride;
+        // the two-byte kernel holds 48 KB of LDS, 3 workgroups per CU against 4); the fold reads the larger number of rows,
+        // the two-byte kernel leaves them all empty
+        const uint32_t g1 = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 1>, (nb + 3) / 4);
+        const uint32_t g2 = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 2>, (nb + 3) / 4);
+        grid = g1 > g2 ? g1 : g2;
+        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 1>), dim3(g1), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
+        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 2>), dim3(g2), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
     } else {
         grid = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY>, (nb + 3) / 4);
-        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
+        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
     }
     if (p.prof_ev1) (void)hipEventRecord((hipEvent_t)p.prof_ev1, s);
     hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);

@@ -704,7 +704,7 @@ __device__ __forceinline__ int64_t dpp_wave_shr1(int64_t old, int64_t src) {
 }
 
 #define MARCH_WIDE_WIN 8192  // LDS histogram bins of the march kernel when the codes are two bytes wide
-#define MARCH_OQ 256  // records per wave in the LDS outlier staging queue
+#define MARCH_OQ 128  // records per wave in the LDS outlier staging queue (f32, two-byte kernel: 32 KB window + 6 KB queues = 4 workgroups per CU)
 // MODE 0: the code width (one or two bytes, decided on the device by k_probe) is a run-time branch. MODE 1 / 2: the kernel
 // is specialised for one-byte / two-byte codes and returns at once when the probe chose the other width; the host launches
 // both. The one-byte specialisation needs a third of the LDS (16 KB histogram, 8 KB outlier queue): 4 waves per SIMD
@@ -724,8 +724,9 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     __shared__ uint32_t lh[LH_WORDS + 4];
     // per-wave staging of value outliers (NaN / Inf / fill values can be percents of a field): records collect in LDS and go
     // to the global list in batches, one global atomic per batch instead of one per wave instruction
+    using OQV = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;  // raw bits of a value
     __shared__ uint64_t s_oq_idx[4][OQ];
-    __shared__ uint64_t s_oq_val[4][OQ];
+    __shared__ OQV s_oq_val[4][OQ];
 
     const uint32_t d0 = (uint32_t)p.d[3], d1 = (uint32_t)p.d[2], d2 = (uint32_t)p.d[1];
     const uint32_t ntx = (d0 + MARCH_TX - 1) / MARCH_TX, nty = (d1 + TY - 1) / TY, ntz = (d2 + MARCH_TZ - 1) / MARCH_TZ;
@@ -744,7 +745,8 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     for (int i = threadIdx.x; i < LH_WORDS + 4; i += 256) lh[i] = 0;
     __syncthreads();
 
-    uint64_t *oq_idx = s_oq_idx[threadIdx.x / WAVE], *oq_val = s_oq_val[threadIdx.x / WAVE];
+    uint64_t *oq_idx = s_oq_idx[threadIdx.x / WAVE];
+    OQV *oq_val = s_oq_val[threadIdx.x / WAVE];
     uint32_t oq_n = 0;  // fill level; lane 0 takes part in every update, the other lanes re-read its copy before use
     auto oq_flush = [&]() {
         oq_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)oq_n);
@@ -919,7 +921,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                                 const uint32_t slot = oq_n + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull));
                                 oq_idx[slot] = gi + i;
                                 const T raw = in[gi + i];
-                                uint64_t bits = 0;
+                                OQV bits = 0;
                                 memcpy(&bits, &raw, sizeof(T));
                                 oq_val[slot] = bits;
                             }

@@ -49,6 +49,10 @@ struct szk_k1_params {
     // host side only (profiling): HIP events recorded right before / after the predictor kernel itself, so that its own
     // duration can be set against the per-kernel average of a rocprofv3 trace
     void *prof_ev0, *prof_ev1;
+    // two-byte marching kernel: 16384-bin LDS histogram window instead of 8192 (64 KB: 2 workgroups per CU). Codes outside the
+    // window cost a global atomic each; when the previous call of the context saw an alphabet wider than the small window the
+    // large one pays (C4's f64 slab: 0.6 % of the deltas beyond +-4096, stage 1 0.57 -> 0.36 ms)
+    uint32_t wide16;
 };
 
 struct szk_cb_info {

@@ -640,6 +640,7 @@ __global__ __launch_bounds__(256, (NDIM == 3 ? 3 : 2)) void k_lorenzo_quant_v4(c
 // payload are unchanged (symbol = delta + radius); the rare wider deltas join the delta-outlier list.  The decision
 // is a pure function of the probe counter, recomputed by every kernel (no host round trip).
 // ------------------------------------------------------------------------------------------------------------
+#define MARCH_WIDE_WIN 8192  // LDS histogram bins of the march kernel when the codes are two bytes wide (x2 on request)
 __device__ __forceinline__ bool szk_is_narrow(const szk_mode &m) {
     return m.allow && (unsigned long long)(*m.probe_big) * 4096ull <= m.n_samples;
 }
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(256) void k_probe(const T *__restrict__ in, szk_k1_
     const uint64_t d0 = p.d[3], d1 = p.d[2], d2 = p.d[1];
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t i = (s >> 6) * SZK_PROBE_STRIDE + (s & 63);  // runs of 64 consecutive elements, one run per stride
-    bool big = false;
+    bool big = false, far = false;  // far: beyond the 8192-bin stage-1 window of the two-byte kernel, inside the 16384-bin one
     if (i < n) {
         uint64_t r = i;
         const int64_t x = (int64_t)(r % d0);
@@ -673,9 +674,12 @@ __global__ __launch_bounds__(256) void k_probe(const T *__restrict__ in, szk_k1_
             delta = (__popc(c) & 1) ? (UQ)(delta - q) : (UQ)(delta + q);
         }
         big = (UQ)(delta + 127) > (UQ)254;
+        // codes the doubled window would catch and the plain one would not (what lies beyond both costs the same either way)
+        far = (UQ)(delta + (UQ)(MARCH_WIDE_WIN / 2)) >= (UQ)MARCH_WIDE_WIN && (UQ)(delta + (UQ)MARCH_WIDE_WIN) < (UQ)(2 * MARCH_WIDE_WIN);
     }
-    const unsigned long long m = __ballot(big);
+    const unsigned long long m = __ballot(big), mf = __ballot(far);
     if (m && lane_id() == 0) atomicAdd(probe_big, (uint32_t)__popcll(m));
+    if (mf && lane_id() == 0) atomicAdd(probe_big + 1, (uint32_t)__popcll(mf));  // (second word: read by the host after the call)
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -703,19 +707,19 @@ __device__ __forceinline__ int64_t dpp_wave_shr1(int64_t old, int64_t src) {
     return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
-#define MARCH_WIDE_WIN 8192  // LDS histogram bins of the march kernel when the codes are two bytes wide
 #define MARCH_OQ 128  // records per wave in the LDS outlier staging queue (f32, two-byte kernel: 32 KB window + 6 KB queues = 4 workgroups per CU)
 // MODE 0: the code width (one or two bytes, decided on the device by k_probe) is a run-time branch. MODE 1 / 2: the kernel
 // is specialised for one-byte / two-byte codes and returns at once when the probe chose the other width; the host launches
 // both. The one-byte specialisation needs a third of the LDS (16 KB histogram, 8 KB outlier queue): 4 waves per SIMD
 // instead of 3.
-template <typename T, int NDIM, int TY, int MODE = 0>
+template <typename T, int NDIM, int TY, int MODE = 0, bool WIN16 = false>
 __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict__ in, uint16_t *__restrict__ codes,
                                                              szk_k1_params p, uint32_t ntasks, uint32_t nrows) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     constexpr int NW = NDIM == 4 ? 2 : 1;
-    constexpr int LH_WORDS = MODE == 1 ? HIST_WIN * 4 : MARCH_WIDE_WIN;
+    constexpr int WIDE_WIN = WIN16 ? 2 * MARCH_WIDE_WIN : MARCH_WIDE_WIN;
+    constexpr int LH_WORDS = MODE == 1 ? HIST_WIN * 4 : WIDE_WIN;
     constexpr int OQ = MODE == 1 ? 128 : MARCH_OQ;
     if (MODE != 0 && szk_is_narrow(p.mode) != (MODE == 1)) return;
     // LDS histogram. One-byte codes (narrow deltas): 1024 bins x 4 copies around the radius; two-byte codes (deltas of
@@ -736,7 +740,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     const int radius = (int)p.radius;
     const uint32_t copy = (uint32_t)lane & 3u;
     const bool narrow = MODE == 1 ? true : (MODE == 2 ? false : szk_is_narrow(p.mode));
-    const uint32_t win_bins = narrow ? (uint32_t)HIST_WIN : (uint32_t)MARCH_WIDE_WIN;
+    const uint32_t win_bins = narrow ? (uint32_t)HIST_WIN : (uint32_t)WIDE_WIN;
     const uint32_t win_lo = (uint32_t)radius - win_bins / 2;
     // in-range test of a delta, one form for both code widths: (delta + rng_lo) <= rng_span (unsigned)
     const UQ rng_lo = narrow ? (UQ)127 : (UQ)(radius - 1), rng_span = narrow ? (UQ)254 : (UQ)(2 * radius - 2);
@@ -895,8 +899,8 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                         code[i] = inr ? (uint32_t)shifted : 0u;
                         uint32_t bin = code[i] - win_lo;           // wraps to a huge value below the window
                         // (a delta outlier is rare whatever its bin: with a small radius code 0 lies inside the window)
-                        rare |= !inr || bin >= (uint32_t)MARCH_WIDE_WIN;
-                        bin = bin < (uint32_t)MARCH_WIDE_WIN ? bin : (uint32_t)MARCH_WIDE_WIN;
+                        rare |= !inr || bin >= (uint32_t)WIDE_WIN;
+                        bin = bin < (uint32_t)WIDE_WIN ? bin : (uint32_t)WIDE_WIN;
                         atomicAdd(&lh[bin], 1u);
                     }
                     uint2 pk;
@@ -951,7 +955,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
         // (nrows = rows the fold reads: the larger grid of the two specialisations)
         for (uint32_t r = blockIdx.x; r < nrows; r += gridDim.x)
             for (int bnn = threadIdx.x; bnn < HIST_WIN; bnn += 256) p.hist_partial[(uint64_t)r * HIST_WIN + bnn] = 0;
-        for (int bnn = threadIdx.x; bnn < MARCH_WIDE_WIN; bnn += 256) {
+        for (int bnn = threadIdx.x; bnn < WIDE_WIN; bnn += 256) {
             const uint32_t v = lh[bnn];
             const uint32_t sym = win_lo + (uint32_t)bnn;
             if (v && sym < SZH_HIST_BINS) atomicAdd((unsigned long long *)&p.hist[sym], (unsigned long long)v);
@@ -2969,25 +2973,32 @@ static uint32_t k1_grid(const void *kernel, uint64_t ntiles) {
 
 // the marching kernel + histogram fold. When one-byte codes are possible both specialisations are launched with the same
 // grid (= rows of the fold); the one the probe did not choose returns at once.
-template <typename T, int NDIM, int TY>
-static void launch_march(const void *d_in, uint16_t *codes, const szk_k1_params &p, uint64_t nb, hipStream_t s) {
+template <typename T, int NDIM, int TY, bool WIN16>
+static void launch_march_w(const void *d_in, uint16_t *codes, const szk_k1_params &p, uint64_t nb, hipStream_t s) {
     uint32_t grid;
     if (p.prof_ev0) (void)hipEventRecord((hipEvent_t)p.prof_ev0, s);
     if (p.mode.allow && !(szk_dbg_flags & 256)) {
         // each specialisation gets the grid its own occupancy allows (all workgroups resident: the tasks are dealt by stride;
-        // the two-byte kernel holds 48 KB of LDS, 3 workgroups per CU against 4); the fold reads the larger number of rows,
-        // the two-byte kernel leaves them all empty
-        const uint32_t g1 = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 1>, (nb + 3) / 4);
-        const uint32_t g2 = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 2>, (nb + 3) / 4);
+        // the two-byte kernel holds 38-72 KB of LDS); the fold reads the larger number of rows, the two-byte kernel leaves
+        // them all empty
+        const uint32_t g1 = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 1, false>, (nb + 3) / 4);
+        const uint32_t g2 = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 2, WIN16>, (nb + 3) / 4);
         grid = g1 > g2 ? g1 : g2;
-        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 1>), dim3(g1), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
-        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 2>), dim3(g2), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
+        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 1, false>), dim3(g1), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
+        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 2, WIN16>), dim3(g2), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
     } else {
-        grid = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY>, (nb + 3) / 4);
-        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
+        grid = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 0, WIN16>, (nb + 3) / 4);
+        hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 0, WIN16>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
     }
     if (p.prof_ev1) (void)hipEventRecord((hipEvent_t)p.prof_ev1, s);
     hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+}
+// the marching kernel + histogram fold. When one-byte codes are possible both specialisations are launched (the one the
+// probe did not choose returns at once); the two-byte one with the LDS window the context asks for (szk_k1_params::wide16)
+template <typename T, int NDIM, int TY>
+static void launch_march(const void *d_in, uint16_t *codes, const szk_k1_params &p, uint64_t nb, hipStream_t s) {
+    if (p.wide16) launch_march_w<T, NDIM, TY, true>(d_in, codes, p, nb, s);
+    else launch_march_w<T, NDIM, TY, false>(d_in, codes, p, nb, s);
 }
 
 template <typename T>

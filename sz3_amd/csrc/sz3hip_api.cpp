@@ -1248,14 +1248,17 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     dp.group_off = ctx->d_chunk_off;
     dp.tables = ctx->d_tables;
     dp.single_sym = h.sym_min;
-    // Lorenzo stream, no delta outliers, rows of at most one chunk: the decoder also does the x prefix sum
+    // Lorenzo stream, rows of at most one chunk, a sorted delta-outlier list: the decoder also does the x prefix sum
     const uint64_t row = h.dims[3];
-    const bool fuse_x = h.predictor == 0 && h.n_dout == 0 && row >= 1 && row <= SZH_CHUNK_SYMS && !(szk_dbg_flags & 512);
+    const bool fuse_x = h.predictor == 0 && h.n_dout <= 32768 && row >= 1 && row <= SZH_CHUNK_SYMS && !(szk_dbg_flags & 512);  // (lists that long are sorted)
     dp.scan_row = fuse_x ? (uint32_t)row : 0u;
     dp.radius = h.radius;
     dp.q_bytes = h.qbytes;
     dp.reserved = 0;
     dp.q_out = d_out;
+    dp.dout_idx = reinterpret_cast<const uint64_t *>(pl + o.dout_idx);
+    dp.dout_val = pl + o.dout_val;
+    dp.n_dout = h.n_dout;
     dp.carry = fuse_x && (SZH_CHUNK_SYMS % row) != 0 ? (void *)ctx->d_codes : nullptr;  // (the code array is idle in this mode)
     rc = szk_launch_decode(pl, &dp, ctx->d_codes, ctx->d_chunk_off, ctx->d_counters + 3, s);
     prof_end(ctx, ST_DEC_HUFF, s);

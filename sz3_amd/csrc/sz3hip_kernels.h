@@ -121,13 +121,17 @@ struct szk_dec_params {
     const uint64_t *group_off;    // word offset of every group of 32 chunks (k_scan_groups)
     const szk_dec_tables *tables;
     uint32_t single_sym;
-    // Lorenzo streams with rows of at most one chunk and no delta outliers: the decoder turns the codes into deltas and
+    // Lorenzo streams with rows of at most one chunk and a sorted delta-outlier list (<= 32768 records): the decoder turns the codes into deltas and
     // prefix-sums them along x itself (scan_row = row length, 0 = plain code output). A row that starts in the previous
     // chunk misses that chunk's running sum: every chunk leaves it in carry[] and k_scan_carry adds it afterwards (not
     // needed when the row length divides the chunk).
     uint32_t scan_row, radius, q_bytes, reserved;  // q_bytes: 4 = int32 lattice (f32 data), 8 = int64 (f64 data)
     void *q_out;  // lattice deltas summed along x: int32 (f32 data) / int64 (f64 data), n elements
     void *carry;  // [n_chunks] running sum at the end of every chunk (same type), nullptr when rows start on chunk boundaries
+    // delta outliers of a fused stream (code 0): the sorted (index, delta) lists inside the payload, searched by index
+    const uint64_t *dout_idx;
+    const void *dout_val;  // int32 / int64 like q_out
+    uint64_t n_dout;
 };
 
 // ---- interpolation predictor (sz3hip_interp.hip) ----

@@ -2504,6 +2504,18 @@ __global__ __launch_bounds__(1024) void k_dec_tables(const uint8_t *__restrict__
 // decoded without a loop or a global access: the length is K + 1 + the number of lengths l whose left-aligned upper code
 // bound is <= the window (canonical codes grow with the length), and the symbols of the long codes sit in LDS.
 #define DEC_SORTED_LDS 16384u  // symbols of the codes longer than the table kept in LDS (further ranks: global)
+// delta of a delta outlier (code 0) by binary search in the sorted index list; 0 when the element is not listed (a corrupt
+// stream must not crash the decoder)
+template <typename QO>
+__device__ __forceinline__ QO dec_dout(const szk_dec_params &p, uint64_t elem) {
+    uint64_t lo = 0, hi = p.n_dout;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (p.dout_idx[mid] < elem) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < p.n_dout && p.dout_idx[lo] == elem ? reinterpret_cast<const QO *>(p.dout_val)[lo] : (QO)0;
+}
 // QB: 0 = u16 codes out; 4 / 8 = fused Lorenzo x-scan, int32 / int64 lattice values out (see szk_dec_params::scan_row)
 template <int QB>
 __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payload, szk_dec_params p,
@@ -2539,8 +2551,8 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     if (max_len == 0) {  // single-symbol alphabet: zero-length code
         uint16_t sym = (uint16_t)p.single_sym;
         if (QB) {
-            const QO d = sym ? (QO)((int)sym - (int)p.radius) : (QO)0;
             for (uint32_t i = 0; i < nsym; i++) {
+                const QO d = sym ? (QO)((int)sym - (int)p.radius) : dec_dout<QO>(p, s0 + i);
                 acc += d;
                 qout[i] = acc;
                 if (--left == 0) {
@@ -2616,12 +2628,13 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
             if (k & 1) packed[k >> 1] |= sym << 16;
             else packed[k >> 1] = sym;
         }
-        if (QB) {  // codes -> deltas (0 = delta outlier: none in a fused stream) -> running sum, restarted at every row start
+        if (QB) {  // codes -> deltas (0 = delta outlier: looked up) -> running sum, restarted at every row start
             QO qv[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint32_t sym = (k & 1) ? (packed[k >> 1] >> 16) : (packed[k >> 1] & 0xFFFFu);
-                const QO d = sym ? (QO)((int)sym - (int)p.radius) : (QO)0;
+                QO d = (QO)((int)sym - (int)p.radius);
+                if (sym == 0) d = i0 + k < nsym ? dec_dout<QO>(p, s0 + i0 + k) : (QO)0;  // delta outlier (rare)
                 acc += d;
                 qv[k] = acc;
                 if (--left == 0) {

@@ -2138,7 +2138,10 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
                                                      const uint32_t *__restrict__ g_enc,
                                                      const szk_cb_info *__restrict__ info, szk_mode mode, uint32_t sym_add,
                                                      uint16_t *__restrict__ chunk_words) {
-    __shared__ uint32_t s_enc[ENC_WIN];
+    // code lengths only: one byte per symbol, so the LDS table covers 16384 symbols around the most frequent one (the
+    // packers' 4-byte entries cover 4096): C4's deltas (std 2600 lattice steps) miss a 4096-symbol window 44 % of the time
+    constexpr uint32_t LEN_WIN = 4 * ENC_WIN;
+    __shared__ uint8_t s_lenw[LEN_WIN];
     __shared__ uint8_t s_len8[256];  // one-byte codes: code length by byte value (no symbol arithmetic per element)
     const bool narrow = szk_is_narrow(mode);
     const uint64_t n_full = n / SZH_CHUNK_SYMS, n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
@@ -2147,11 +2150,18 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
     CodeRegs cur, nxt;
     uint64_t chunk = wave_gid;
     if (chunk < n_full) fetch_codes(codes, chunk * SZH_CHUNK_SYMS + lane_off, narrow, cur);  // in flight during the table load
-    const uint32_t sym_min = info->win_lo, sym_count = info->sym_count;  // sym_min: start of the LDS window
-    const bool all_lds = sym_count <= ENC_WIN;
-    enc_table_load(s_enc, g_enc, sym_min, sym_count);
+    // window start: the packers' window is centred on the most frequent symbol; widen it symmetrically, inside [0, 65536)
+    const uint32_t centre = info->win_lo + ENC_WIN / 2;
+    uint32_t lw_lo = centre > LEN_WIN / 2 ? centre - LEN_WIN / 2 : 0u;
+    if (lw_lo > SZH_HIST_BINS - LEN_WIN) lw_lo = SZH_HIST_BINS - LEN_WIN;
+    if (!narrow || n_full < n_chunks)  // (the ragged last chunk goes through the symbol table in both modes)
+        for (uint32_t i = threadIdx.x; i < LEN_WIN; i += 256) s_lenw[i] = (uint8_t)(g_enc[lw_lo + i] & 31u);
     if (narrow) s_len8[threadIdx.x] = (uint8_t)(g_enc[threadIdx.x ? threadIdx.x + sym_add : 0u] & 31u);
     __syncthreads();
+    auto len_of = [&](uint32_t sym) -> uint32_t {
+        const uint32_t rel = sym - lw_lo;
+        return rel < LEN_WIN ? (uint32_t)s_lenw[rel] : (g_enc[sym] & 31u);
+    };
     if (narrow) {
         for (; chunk < n_full; chunk += nwaves) {
             const uint64_t nc = chunk + nwaves;
@@ -2173,7 +2183,7 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
             unpack_codes(cur, narrow, sym_add, c);
             uint32_t bits = 0;
 #pragma unroll
-            for (int i = 0; i < ENC_PER_LANE; i++) bits += enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[i]) & 31u;
+            for (int i = 0; i < ENC_PER_LANE; i++) bits += len_of(c[i]);
             bits = wave_sum(bits);
             if (lane_id() == 0) chunk_words[chunk] = (uint16_t)((bits + 31) >> 5);
             cur = nxt;
@@ -2186,8 +2196,8 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
         uint32_t bits = 0;
 #pragma unroll
         for (int i = 0; i < ENC_PER_LANE; i++) {
-            const uint32_t e = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[i]);
-            bits += (base + i < n) ? (e & 31u) : 0u;
+            const uint32_t e = len_of(c[i]);
+            bits += (base + i < n) ? e : 0u;
         }
         bits = wave_sum(bits);
         if (lane_id() == 0) chunk_words[n_full] = (uint16_t)((bits + 31) >> 5);

@@ -406,6 +406,7 @@ struct sz3hip_ctx {
     hipStream_t side;    // the working copy of the input is made here while the tuner runs on the caller's stream
     hipEvent_t ev_fork, ev_join;
     bool copy_ahead;     // d_work already holds this call's input (joined into the caller's stream)
+    int pack_wide;       // the packer's LDS table window: 8192 instead of 4096 entries (from the previous call's probe)
     int wide16;          // -1: not decided yet (f64 starts with the 16384-bin stage-1 window, f32 with 8192); else 0 / 1,
                          // adapted after every Lorenzo call from the width of the alphabet it saw
     uint64_t *d_trial;  // [8][4]: bits, symbols, unpredictables, delta outliers
@@ -688,6 +689,7 @@ static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *
     p.mode.n_total = num;
     p.mode.n_samples = (num / SZK_PROBE_STRIDE) * 64 + std::min<uint64_t>(64, num % SZK_PROBE_STRIDE);
     p.mode.allow = allow_narrow && radius >= 128;
+    p.mode.pack_wide = allow_narrow ? (uint32_t)ctx->pack_wide : 0u;
     p.wide16 = ctx->wide16 < 0 ? (ctx->dtype == SZ3HIP_DOUBLE ? 1u : 0u) : (uint32_t)ctx->wide16;
     p.prof_ev0 = p.prof_ev1 = nullptr;
     if (ctx->profiling && allow_narrow) {  // (the production call, not the tuner's trial): events around the kernel itself
@@ -1096,7 +1098,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     prof_end(ctx, ST_ASSEMBLE, s);
     if (rc) return fail(SZ3HIP_EHIP, "assemble kernel launch failed (%d)", rc);
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(szk_state), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(ctx->h_probe, ctx->d_counters + 4, 8, hipMemcpyDeviceToHost, s));  // probe counters: |delta| > 127, >= 4096
+    HIPCHK(hipMemcpyAsync(ctx->h_probe, ctx->d_counters + 4, 12, hipMemcpyDeviceToHost, s));  // probe counters: |delta| > 127, in [4096, 8192), in [2048, 4096)
     ctx->stage2_done = true;
     return 0;
 }
@@ -1124,6 +1126,8 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
         // the deltas between the two windows (each costs a global atomic with the small one; measured break-even ~0.2 %:
         // 0.1 % -> 0.20 vs 0.28 ms in favour of the small window, 0.5 % -> 0.57 vs 0.36 ms in favour of the large one)
         ctx->wide16 = (uint64_t)ctx->h_probe[1] * 300ull > ctx->mode.n_samples ? 1 : 0;
+        // the packers' table window likewise: doubled (3 instead of 5 workgroups per CU) when > 2 % of the symbols lie between
+        ctx->pack_wide = (uint64_t)ctx->h_probe[2] * 50ull > ctx->mode.n_samples ? 1 : 0;
     }
     if (st.overflow)
         return fail(SZ3HIP_EOUTLIERS, "outlier capacity exceeded (%llu per list): data not compressible at this bound",

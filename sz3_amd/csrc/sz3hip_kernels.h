@@ -29,6 +29,7 @@ static inline szk_lattice szk_make_lattice(double eb) {
 // narrow-code mode (see k_probe): a pure function of the probe counter, evaluated on the device by every kernel
 struct szk_mode {
     uint32_t *probe_big;          // number of probed deltas outside [-127, 127]
+    uint32_t pack_wide;           // host-side choice: the packer caches 8192 instead of 4096 encode-table entries in LDS
     uint64_t n_samples;           // number of probed elements
     uint64_t n_total;             // elements of the array
     uint32_t allow;               // 0: always two-byte codes

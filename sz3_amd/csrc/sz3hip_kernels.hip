@@ -651,9 +651,14 @@ __global__ __launch_bounds__(256) void k_probe(const T *__restrict__ in, szk_k1_
     using UQ = typename QTraits<T>::UQ;
     const Lattice<T> lat(p.lat);
     const uint64_t d0 = p.d[3], d1 = p.d[2], d2 = p.d[1];
-    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    // counts per thread over a grid-stride loop, then one atomic per counter and WORKGROUP (on rough data every wave finds
+    // some: 4096 waves x same-address atomics at ~90/us were 45 us of a 56 us kernel)
+    uint32_t n_big = 0, n_far = 0, n_pfar = 0;
+    const uint64_t n_runs = (n + SZK_PROBE_STRIDE - 1) / SZK_PROBE_STRIDE;
+    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; (s >> 6) < n_runs; s += (uint64_t)gridDim.x * 256) {
     const uint64_t i = (s >> 6) * SZK_PROBE_STRIDE + (s & 63);  // runs of 64 consecutive elements, one run per stride
-    bool big = false, far = false;  // far: beyond the 8192-bin stage-1 window of the two-byte kernel, inside the 16384-bin one
+    bool big = false, far = false, pfar = false;  // far: beyond the 8192-bin stage-1 window of the two-byte kernel, inside the 16384-bin one
+                                                  // pfar: beyond the packers' 4096-entry table window, inside the doubled one
     if (i < n) {
         uint64_t r = i;
         const int64_t x = (int64_t)(r % d0);
@@ -676,10 +681,25 @@ __global__ __launch_bounds__(256) void k_probe(const T *__restrict__ in, szk_k1_
         big = (UQ)(delta + 127) > (UQ)254;
         // codes the doubled window would catch and the plain one would not (what lies beyond both costs the same either way)
         far = (UQ)(delta + (UQ)(MARCH_WIDE_WIN / 2)) >= (UQ)MARCH_WIDE_WIN && (UQ)(delta + (UQ)MARCH_WIDE_WIN) < (UQ)(2 * MARCH_WIDE_WIN);
+        pfar = (UQ)(delta + (UQ)2048) >= (UQ)4096 && (UQ)(delta + (UQ)4096) < (UQ)8192;
     }
-    const unsigned long long m = __ballot(big), mf = __ballot(far);
-    if (m && lane_id() == 0) atomicAdd(probe_big, (uint32_t)__popcll(m));
-    if (mf && lane_id() == 0) atomicAdd(probe_big + 1, (uint32_t)__popcll(mf));  // (second word: read by the host after the call)
+    n_big += big;
+    n_far += far;
+    n_pfar += pfar;
+    }
+    __shared__ uint32_t s_p[3];
+    if (threadIdx.x < 3) s_p[threadIdx.x] = 0;
+    __syncthreads();
+    n_big = wave_sum(n_big);
+    n_far = wave_sum(n_far);
+    n_pfar = wave_sum(n_pfar);
+    if (lane_id() == 0) {
+        if (n_big) atomicAdd(&s_p[0], n_big);
+        if (n_far) atomicAdd(&s_p[1], n_far);
+        if (n_pfar) atomicAdd(&s_p[2], n_pfar);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && s_p[threadIdx.x]) atomicAdd(probe_big + threadIdx.x, s_p[threadIdx.x]);  // ([1], [2]: read by the host after the call)
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2088,11 +2108,12 @@ __device__ __forceinline__ void load_codes16(const uint16_t *__restrict__ codes,
 // ------------------------------------------------------------------------------------------------------------
 #define PACK_GROUP 32  // chunks per offset group
 
+template <uint32_t WIN = ENC_WIN>
 __device__ __forceinline__ uint32_t enc_lookup2(const uint32_t *s_enc, const uint32_t *__restrict__ g_enc,
                                                 uint32_t win_lo, bool all_lds, uint32_t sym) {
     const uint32_t rel = sym - win_lo;
     if (all_lds) return s_enc[rel & (ENC_WIN - 1)];
-    return rel < ENC_WIN ? s_enc[rel] : g_enc[sym];
+    return rel < WIN ? s_enc[rel] : g_enc[sym];
 }
 __device__ __forceinline__ void enc_table_load(uint32_t *s_enc, const uint32_t *__restrict__ g_enc, uint32_t win_lo,
                                                uint32_t sym_count) {
@@ -2247,7 +2268,7 @@ __global__ __launch_bounds__(1024) void k_scan_groups(const uint16_t *__restrict
 // pack 16 symbols of a lane into the wave's LDS stage at the lane's bit offset; returns the chunk's word count.
 // G code words are joined per 64-bit register: G = 4 when the code book's longest word is <= 16 bits, else G = 2
 // (<= 24 bits each); every register is emitted left-aligned at its bit offset with three ds_or.
-template <int G, bool BYTE = false>  // BYTE: c[] are one-byte codes; s_enc[0..255] = code word, s_len8 = its length, by byte value
+template <int G, bool BYTE = false, uint32_t WIN = ENC_WIN>  // BYTE: c[] are one-byte codes; s_enc[0..255] = code word, s_len8 = its length, by byte value
 __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE], uint64_t base, uint64_t n, bool check_n,
                                                const uint32_t *s_enc, const uint32_t *__restrict__ g_enc,
                                                uint32_t sym_min, bool all_lds, uint32_t *stage, const uint8_t *s_len8 = nullptr) {
@@ -2269,8 +2290,8 @@ __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE]
                 pl[h] = (uint32_t)s_len8[b0] + l1;
                 continue;
             }
-            uint32_t e0 = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h]);
-            uint32_t e1 = enc_lookup2(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h + 1]);
+            uint32_t e0 = enc_lookup2<WIN>(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h]);
+            uint32_t e1 = enc_lookup2<WIN>(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h + 1]);
             if (check_n) {
                 e0 = (base + G * k + 2 * h < n) ? e0 : 0u;
                 e1 = (base + G * k + 2 * h + 1 < n) ? e1 : 0u;
@@ -2308,13 +2329,16 @@ __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE]
 
 // persistent like k_chunk_bits2: a wave owns a private LDS stage; per chunk it zeroes the words it will use, packs,
 // and streams them out; the next chunk's codes, word count and group offset are already in flight
+// WIN: symbols of the encode table cached in LDS around the most frequent one: ENC_WIN (30 KB of LDS, 5 workgroups per CU)
+// or 2 * ENC_WIN (46 KB, 3 per CU) for alphabets that spread wider (chosen per context from the previous call's alphabet)
+template <uint32_t WIN>
 __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes, uint64_t n,
                                               const uint32_t *__restrict__ g_enc, const szk_cb_info *__restrict__ info,
                                               const uint16_t *__restrict__ chunk_words,
                                               const uint64_t *__restrict__ group_off, szk_mode mode, uint32_t sym_add,
                                               const szk_state *__restrict__ state, uint8_t *__restrict__ payload) {
     constexpr int STAGE_WORDS = SZH_CHUNK_SYMS * SZH_MAX_LEN / 32 + 4;  // + slack for the unconditional 3-word emit
-    __shared__ uint32_t s_enc[ENC_WIN];
+    __shared__ uint32_t s_enc[WIN];
     __shared__ uint32_t s_enc8[256];  // one-byte codes: code word by byte value ...
     __shared__ uint8_t s_plen8[256];  // ... and its length
     __shared__ uint32_t s_stage[4][STAGE_WORDS];
@@ -2342,10 +2366,18 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         fetch_codes(codes, chunk * SZH_CHUNK_SYMS + lane_off, narrow, cur);
         side(chunk, bp_cur, go_cur);
     }
-    const uint32_t sym_min = info->win_lo, sym_count = info->sym_count;  // sym_min: start of the LDS window
-    const bool all_lds = sym_count <= ENC_WIN;
+    uint32_t sym_min = info->win_lo;  // start of the LDS window
+    const uint32_t sym_count = info->sym_count;
+    const bool all_lds = WIN == ENC_WIN && sym_count <= ENC_WIN;
     const bool wide = info->max_len > 16;  // two instead of four code words per 64-bit register
-    enc_table_load(s_enc, g_enc, sym_min, sym_count);
+    if (WIN == ENC_WIN) {
+        enc_table_load(s_enc, g_enc, sym_min, sym_count);
+    } else {  // the doubled window: same centre, inside [0, 65536)
+        const uint32_t centre = sym_min + ENC_WIN / 2;
+        sym_min = centre > WIN / 2 ? centre - WIN / 2 : 0u;
+        if (sym_min > SZH_HIST_BINS - WIN) sym_min = SZH_HIST_BINS - WIN;
+        for (uint32_t i = threadIdx.x; i < WIN; i += 256) s_enc[i] = g_enc[sym_min + i];
+    }
     if (narrow) {
         const uint32_t e = g_enc[threadIdx.x ? threadIdx.x + sym_add : 0u];
         s_enc8[threadIdx.x] = e >> 5;
@@ -2368,8 +2400,8 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
             nwords = pack_chunk<4, true>(c, 0, 0, false, s_enc8, g_enc, sym_min, all_lds, stage, s_plen8);
         } else {
             unpack_codes(cur, narrow, sym_add, c);
-            nwords = wide ? pack_chunk<2>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage)
-                          : pack_chunk<4>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage);
+            nwords = wide ? pack_chunk<2, false, WIN>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage)
+                          : pack_chunk<4, false, WIN>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage);
         }
         const uint32_t before = wave_sum(bp_cur);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2392,8 +2424,8 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         uint32_t bp;
         uint64_t go;
         side(n_full, bp, go);
-        const uint32_t nwords = wide ? pack_chunk<2>(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage)
-                                     : pack_chunk<4>(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage);
+        const uint32_t nwords = wide ? pack_chunk<2, false, WIN>(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage)
+                                     : pack_chunk<4, false, WIN>(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage);
         const uint32_t before = wave_sum(bp);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -3046,7 +3078,7 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
             if (march12) {
                 if (p.mode.allow) {
                     const uint64_t nsamp_threads = ((p.mode.n_total + SZK_PROBE_STRIDE - 1) / SZK_PROBE_STRIDE) * 64;
-                    hipLaunchKernelGGL((k_probe<T, 3>), dim3((uint32_t)((nsamp_threads + 255) / 256)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
+                    hipLaunchKernelGGL((k_probe<T, 3>), dim3((uint32_t)std::min<uint64_t>((nsamp_threads + 255) / 256, 1024)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
                 }
                 nb = tiles(MARCH_TX, 1, MARCH_TZ);
                 launch_march<T, 3, 1>(d_in, codes, p, nb, s);
@@ -3060,7 +3092,7 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
             if (march12) {
                 if (p.mode.allow) {
                     const uint64_t nsamp_threads = ((p.mode.n_total + SZK_PROBE_STRIDE - 1) / SZK_PROBE_STRIDE) * 64;
-                    hipLaunchKernelGGL((k_probe<T, 3>), dim3((uint32_t)((nsamp_threads + 255) / 256)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
+                    hipLaunchKernelGGL((k_probe<T, 3>), dim3((uint32_t)std::min<uint64_t>((nsamp_threads + 255) / 256, 1024)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
                 }
                 nb = tiles(MARCH_TX, MTY, MARCH_TZ);
                 launch_march<T, 3, MTY>(d_in, codes, p, nb, s);
@@ -3074,7 +3106,7 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
             if (march) {
                 if (p.mode.allow) {
                     const uint64_t nsamp_threads = ((p.mode.n_total + SZK_PROBE_STRIDE - 1) / SZK_PROBE_STRIDE) * 64;
-                    hipLaunchKernelGGL((k_probe<T, 3>), dim3((uint32_t)((nsamp_threads + 255) / 256)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
+                    hipLaunchKernelGGL((k_probe<T, 3>), dim3((uint32_t)std::min<uint64_t>((nsamp_threads + 255) / 256, 1024)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
                 }
                 nb = tiles(MARCH_TX, MTY, MARCH_TZ);  // wave tasks
                 launch_march<T, 3, MTY>(d_in, codes, p, nb, s);
@@ -3095,7 +3127,7 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
             if (march) {
                 if (p.mode.allow) {
                     const uint64_t nsamp_threads = ((p.mode.n_total + SZK_PROBE_STRIDE - 1) / SZK_PROBE_STRIDE) * 64;
-                    hipLaunchKernelGGL((k_probe<T, 4>), dim3((uint32_t)((nsamp_threads + 255) / 256)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
+                    hipLaunchKernelGGL((k_probe<T, 4>), dim3((uint32_t)std::min<uint64_t>((nsamp_threads + 255) / 256, 1024)), dim3(256), 0, s, (const T *)d_in, p, p.mode.n_total, p.mode.probe_big);
                 }
                 nb = tiles(MARCH_TX, MTY, MARCH_TZ);  // wave tasks
                 launch_march<T, 4, MTY>(d_in, codes, p, nb, s);
@@ -3151,7 +3183,12 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
     const uint32_t pgrid = (uint32_t)(nb < 2048 ? nb : 2048);  // persistent: 8 workgroups per CU
     hipLaunchKernelGGL(k_chunk_bits2, dim3(pgrid), dim3(256), 0, s, codes, n, d_enc, info, mode, sym_add, chunk_words);
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, chunk_words, n_chunks, group_off, total_words);
-    hipLaunchKernelGGL(k_pack, dim3(pgrid < 1280 ? pgrid : 1280), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode, sym_add, state, payload);
+    if (mode.pack_wide)
+        hipLaunchKernelGGL((k_pack<2 * ENC_WIN>), dim3(pgrid < 768 ? pgrid : 768), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
+                           sym_add, state, payload);
+    else
+        hipLaunchKernelGGL((k_pack<ENC_WIN>), dim3(pgrid < 1280 ? pgrid : 1280), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
+                           sym_add, state, payload);
     SZK_CHECK_LAUNCH();
     return 0;
 }

@@ -296,3 +296,38 @@ def test_two_class_code_book_and_its_fallback():
         sz3_amd.lib().sz3hip_debug_flags(0)
     assert not np.array_equal(lens[0], lens[1])          # the two constructions really differ ...
     assert sizes[1] <= sizes[0] <= 1.005 * sizes[1]       # ... and the class form costs next to nothing
+
+
+def test_payload_does_not_depend_on_the_context_history():
+    """window sizes of stage 1 / the packer are per-context choices taken from the previous call's probe: a context that
+    has just seen a rough field (wide windows selected) must produce the same bytes as a fresh one"""
+    shape = (96, 128, 256)
+    rng = np.random.default_rng(4)
+    rough = (field3d(shape).astype(np.float64) + 0.05 * rng.standard_normal(shape)).astype(np.float32)
+    smooth = field3d(shape)
+    dev = torch.device("cuda:0")
+
+    def run(dc, a, eb):
+        t = torch.from_numpy(a).to(dev)
+        cap = dc.payload_bound(a.size, worst_case=True)
+        pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+        conf = sz3_amd.Config(*a.shape)
+        conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+        conf.absErrorBound = eb
+        n = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+        out = torch.empty_like(t)
+        dc.decompress(pl.data_ptr(), n, out.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert float((out.double() - t.double()).abs().max()) <= eb
+        return pl[:n].cpu().numpy().tobytes()
+
+    used = sz3_amd.DeviceCompressor(smooth.size, smooth.dtype)
+    p_rough_1 = run(used, rough, 1e-5)       # deltas of thousands of lattice steps: the wide windows get selected ...
+    p_rough_2 = run(used, rough, 1e-5)       # ... and used
+    p_smooth_used = run(used, smooth, 1e-3)  # first smooth call still runs with the wide windows
+    p_smooth_used2 = run(used, smooth, 1e-3)
+    fresh = sz3_amd.DeviceCompressor(smooth.size, smooth.dtype)
+    p_smooth_fresh = run(fresh, smooth, 1e-3)
+    p_rough_fresh = run(sz3_amd.DeviceCompressor(smooth.size, smooth.dtype), rough, 1e-5)
+    assert p_rough_1 == p_rough_2 == p_rough_fresh
+    assert p_smooth_used == p_smooth_used2 == p_smooth_fresh

@@ -406,6 +406,7 @@ struct sz3hip_ctx {
     hipStream_t side;    // the working copy of the input is made here while the tuner runs on the caller's stream
     hipEvent_t ev_fork, ev_join;
     bool copy_ahead;     // d_work already holds this call's input (joined into the caller's stream)
+    int hist_big;        // interpolation histogram pass with the 16384-bin second tier (from the previous call's far count)
     int pack_wide;       // the packer's LDS table window: 8192 instead of 4096 entries (from the previous call's probe)
     int wide16;          // -1: not decided yet (f64 starts with the 16384-bin stage-1 window, f32 with 8192); else 0 / 1,
                          // adapted after every Lorenzo call from the width of the alphabet it saw
@@ -507,7 +508,7 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     alloc((void **)&c->d_minmax, (2 * 1024 + 2) * 8);
     if (ok && hipHostMalloc((void **)&c->h_state, sizeof(szk_state)) != hipSuccess) ok = false;
     if (ok && hipHostMalloc((void **)&c->h_minmax, 16) != hipSuccess) ok = false;
-    if (ok && hipHostMalloc((void **)&c->h_probe, 16) != hipSuccess) ok = false;
+    if (ok && hipHostMalloc((void **)&c->h_probe, 32) != hipSuccess) ok = false;
     (void)tsz;
     if (!ok) {
         if (!g_err[0]) fail(SZ3HIP_EHIP, "device allocation failed");
@@ -636,6 +637,8 @@ static int stage1_interp(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
     ip.vout_idx = ctx->d_vout_idx;
     ip.vout_val = ctx->d_vout_val;
     ip.out_cap = ctx->cur_out_cap;
+    ip.hist_big = (uint32_t)ctx->hist_big;
+    ip.far_cnt = reinterpret_cast<uint32_t *>(ctx->d_counters + 6);  // (zeroed with the counters, fetched with the probe words)
     prof_begin(ctx, ST_K1, s);
     int rci = szk_launch_interp_compress(ctx->dtype, &ip, ctx->copy_ahead ? nullptr : d_in, ctx->d_work, ctx->d_codes, ctx->d_hist, s);
     ctx->copy_ahead = false;
@@ -1098,7 +1101,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     prof_end(ctx, ST_ASSEMBLE, s);
     if (rc) return fail(SZ3HIP_EHIP, "assemble kernel launch failed (%d)", rc);
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(szk_state), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(ctx->h_probe, ctx->d_counters + 4, 12, hipMemcpyDeviceToHost, s));  // probe counters: |delta| > 127, in [4096, 8192), in [2048, 4096)
+    HIPCHK(hipMemcpyAsync(ctx->h_probe, ctx->d_counters + 4, 24, hipMemcpyDeviceToHost, s));  // probe counters: |delta| > 127, in [4096, 8192), in [2048, 4096); [4] = interpolation codes beyond +-4096
     ctx->stage2_done = true;
     return 0;
 }
@@ -1121,6 +1124,8 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     ctx->stats.n_symbols = 0;
     ctx->stats.narrow_codes = ctx->mode.allow && (uint64_t)(*ctx->h_probe) * 4096ull <= ctx->mode.n_samples;
     ctx->stats.reserved = (ctx->wide16 > 0 ? 1u : 0u) | (ctx->h_probe[1] << 1);  // (development: window used, far-delta count)
+    if (st.hdr.predictor == 1)  // interpolation: second histogram tier of the next call (one workgroup per CU against three)
+        ctx->hist_big = (uint64_t)ctx->h_probe[4] * 100ull > st.hdr.n ? 1 : 0;  // (> 1 %: below, the lost occupancy costs more)
     if (st.hdr.predictor == 0 && ctx->mode.allow && ctx->mode.n_samples) {
         // stage-1 window of the next Lorenzo call: the large one (half the occupancy) when the probe saw more than 1/300 of
         // the deltas between the two windows (each costs a global atomic with the small one; measured break-even ~0.2 %:

@@ -72,6 +72,11 @@ __device__ __forceinline__ T ref_recover(T pred, int code, double eb, int radius
 // Unpredictable values (code 0: the raw value stays in the array) are NOT appended by the pass kernels: the histogram pass
 // that reads every code anyway (k_hist_codes) collects their indices and values into the list, through per-wave LDS queues
 // (a field with NaN / fill-value masks makes millions of them, and same-address global atomics run at ~90/us).
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); giving every XCD a contiguous
 // range of logical blocks keeps neighbouring rows / planes (read by several blocks) inside one L2
 __device__ __forceinline__ uint32_t xcd_block() {
@@ -369,20 +374,27 @@ __global__ __launch_bounds__(256) void k_interp_first_dec(T *__restrict__ w, con
 // gathered from the work array, where an unpredictable point keeps its raw value.
 #define IHW_WIN 8192
 #define IH_OQ 128  // indices per wave in the staging queue
-template <typename T, bool SMALLR>  // SMALLR: radius <= IH_WIN / 2, code 0 would fall inside the window
+// BIGW: second tier of 16384 instead of 8192 bins (84 KB of LDS: one workgroup per CU) for alphabets that spread wider
+// (every code outside the tier is a global atomic); *far_cnt receives the number of codes outside +-4096 in either form, from
+// which the host picks the form of the context's next call
+template <typename T, bool SMALLR, bool BIGW>  // SMALLR: radius <= IH_WIN / 2, code 0 would fall inside the window
 __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__ codes, uint64_t n, int radius,
                                                     uint64_t *__restrict__ hist, const T *__restrict__ work,
                                                     uint64_t *__restrict__ n_vout, uint64_t *__restrict__ vout_idx,
-                                                    T *__restrict__ vout_val, uint64_t out_cap) {
+                                                    T *__restrict__ vout_val, uint64_t out_cap, uint32_t *__restrict__ far_cnt) {
+    constexpr uint32_t WWIN = BIGW ? 2 * IHW_WIN : IHW_WIN;
     __shared__ uint32_t lh[IH_WIN * 4];
     __shared__ uint32_t l_zero[4];  // code 0 (unpredictable): far from the window and ONE address for all of them
-    __shared__ uint32_t lw[IHW_WIN];  // second tier, one copy: the tails (tight bounds spread the codes over thousands of bins)
+    __shared__ uint32_t lw[WWIN];  // second tier, one copy: the tails (tight bounds spread the codes over thousands of bins)
+    __shared__ uint32_t s_far;
+    uint32_t my_far = 0;  // codes beyond the plain tier (global atomics)
     __shared__ uint64_t s_oq[4][IH_OQ];
     for (int i = threadIdx.x; i < IH_WIN * 4; i += 256) lh[i] = 0;
-    for (int i = threadIdx.x; i < IHW_WIN; i += 256) lw[i] = 0;
+    for (uint32_t i = threadIdx.x; i < WWIN; i += 256) lw[i] = 0;
     if (threadIdx.x < 4) l_zero[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_far = 0;
     __syncthreads();
-    const uint32_t win_lo = (uint32_t)(radius - IH_WIN / 2), wide_lo = (uint32_t)radius - IHW_WIN / 2, copy = threadIdx.x & 3u;
+    const uint32_t win_lo = (uint32_t)(radius - IH_WIN / 2), wide_lo = (uint32_t)radius - WWIN / 2, copy = threadIdx.x & 3u;
     const int lane = threadIdx.x & 63;
     uint64_t *oq = s_oq[threadIdx.x >> 6];
     uint32_t oq_n = 0;  // wave-uniform fill level
@@ -442,8 +454,11 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
             else if (c[k] == 0) {
                 atomicAdd(&l_zero[copy], 1u);
                 zmask |= 1u << k;
-            } else if ((uint32_t)c[k] - wide_lo < IHW_WIN) atomicAdd(&lw[(uint32_t)c[k] - wide_lo], 1u);
-            else atomicAdd((unsigned long long *)&hist[c[k]], 1ull);
+            } else if ((uint32_t)c[k] - wide_lo < WWIN) atomicAdd(&lw[(uint32_t)c[k] - wide_lo], 1u);
+            else {
+                atomicAdd((unsigned long long *)&hist[c[k]], 1ull);
+                my_far++;
+            }
         }
         if (__ballot(zmask != 0)) {  // some lane met unpredictable points: queue their indices
 #pragma unroll
@@ -465,11 +480,16 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
         const uint32_t z = l_zero[0] + l_zero[1] + l_zero[2] + l_zero[3];
         if (z) atomicAdd((unsigned long long *)&hist[0], (unsigned long long)z);
     }
-    for (int b = threadIdx.x; b < IHW_WIN; b += 256) {
+    for (uint32_t b = threadIdx.x; b < WWIN; b += 256) {
         const uint32_t v = lw[b];
-        const uint32_t sym = wide_lo + (uint32_t)b;
+        const uint32_t sym = wide_lo + b;
         if (v && sym < SZH_HIST_BINS) atomicAdd((unsigned long long *)&hist[sym], (unsigned long long)v);
+        if (BIGW && (b < IHW_WIN / 2 || b >= WWIN - IHW_WIN / 2)) my_far += v;  // what the plain tier would have missed
     }
+    my_far = wave_sum32(my_far);
+    if ((threadIdx.x & 63) == 0 && my_far) atomicAdd(&s_far, my_far);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_far) atomicAdd(far_cnt, s_far);
     for (int b = threadIdx.x; b < IH_WIN; b += 256) {
         const uint32_t s = lh[b * 4] + lh[b * 4 + 1] + lh[b * 4 + 2] + lh[b * 4 + 3];
         const int sym = (int)win_lo + b;
@@ -666,9 +686,15 @@ int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const voi
                         : run_interp<double, false>(*ip, (double *)d_work, codes, s);
     if (rc) return rc;
     const bool smallr = ip->radius <= IH_WIN / 2;  // window start <= 0: code 0 lies inside it
-#define SZK_HIST_LAUNCH(T, SR)                                                                                                          \
-    hipLaunchKernelGGL((k_hist_codes<T, SR>), dim3(768), dim3(256), 0, s, codes, num, ip->radius, hist, (const T *)d_work, ip->n_vout, \
-                       ip->vout_idx, (T *)ip->vout_val, ip->out_cap)
+#define SZK_HIST_LAUNCH(T, SR)                                                                                                    \
+    do {                                                                                                                          \
+        if (ip->hist_big)                                                                                                         \
+            hipLaunchKernelGGL((k_hist_codes<T, SR, true>), dim3(256), dim3(256), 0, s, codes, num, ip->radius, hist, (const T *)d_work, \
+                               ip->n_vout, ip->vout_idx, (T *)ip->vout_val, ip->out_cap, ip->far_cnt);                            \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((k_hist_codes<T, SR, false>), dim3(768), dim3(256), 0, s, codes, num, ip->radius, hist, (const T *)d_work, \
+                               ip->n_vout, ip->vout_idx, (T *)ip->vout_val, ip->out_cap, ip->far_cnt);                            \
+    } while (0)
     if (dtype == 0) {
         if (smallr) SZK_HIST_LAUNCH(float, true);
         else SZK_HIST_LAUNCH(float, false);

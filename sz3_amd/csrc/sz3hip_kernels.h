@@ -146,6 +146,8 @@ struct szk_interp_params {  // what InterpolationDecomposition keeps (decomposit
     uint64_t *n_vout, *vout_idx;
     void *vout_val;
     uint64_t out_cap;
+    uint32_t hist_big;   // histogram pass with the 16384-bin second tier (host choice, from the previous call's far count)
+    uint32_t *far_cnt;   // receives the number of codes outside +-4096 of the radius
 };
 struct szk_interp_pass {
     int N, dir, interp_id, old_api, subpass, radius;

@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     // the shared lines from HBM
     // (grids that are not a multiple of 8 keep the plain order: the remapped sequence would have holes)
     const uint32_t per_xcd = gridDim.x / 8u;
-    const uint32_t wg_seq = gridDim.x % 8u == 0 ? (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : blockIdx.x;
+    const uint32_t wg_seq = gridDim.x % 8u == 0 && !(p.dbg & 4096u) ? (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : blockIdx.x;
     const uint32_t wave_gid = wg_seq * 4 + threadIdx.x / WAVE, nwaves = gridDim.x * 4u;
     for (uint32_t task = wave_gid; task < ntasks; task += nwaves) {
         uint32_t b = task;
@@ -840,7 +840,9 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                     // the row offset is wave-uniform (scalar unit), only the lane offset is per-lane
                     const T *row = src + (uint64_t)(rok ? (uint32_t)gy : 0u) * d0;
                     rq[lw][r].load(row + lane_off);
-                    rl[lw][r] = has_left ? row[x0 - 1] : (T)0;  // wave-uniform address (element left of the tile): a scalar load
+                    // wave-uniform address (element left of the tile). 3-D: tiles at x = 0 skip it; the 4-D kernel (two time
+                    // slabs in flight) is 20 % slower with that branch in its row loop and keeps the unconditional form
+                    rl[lw][r] = (NW == 2 || has_left) ? row[x0 > 0 ? x0 - 1 : 0] : (T)0;
                 }
             }
             // ---- rows ----
@@ -864,10 +866,10 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                         if (lw == 0) badmask |= (uint32_t)(bad & ok) << i;
                     }
                     Q left0 = (Q)0;  // only lane 0's value is used
-                    if (has_left) {  // wave-uniform
+                    if (NW == 2 || has_left) {  // wave-uniform (compile-time true for 4-D)
                         bool badl;
                         const Q ql = lat.quant(rl[lw][r], badl);
-                        left0 = rok ? ql : (Q)0;
+                        left0 = (rok && has_left) ? ql : (Q)0;
                     }
                     UQ pv = (UQ)dpp_wave_shr1(left0, q[3]);
                     UQ d1v[4];

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_interp_pass(T *__restrict__ w, uint16_t
     else interp_point<T, DEC, uint64_t>(w + boff, codes + boff, p, t, boff);
 }
 
-// ---- level 1 (stride 1), cubic, N >= 3, row length a multiple of 8: 8 consecutive x per thread --------------------------
+// ---- level 1 (stride 1), cubic, N >= 3, row length a multiple of 4: 8 consecutive x per thread (a row may end in a half group) ----
 // The finest level holds 7/8 of all points. One thread owns 8 consecutive elements of a row (two 16-byte accesses per
 // array row it touches) instead of one 4-byte access per neighbour; operands, formulas and their order are exactly those
 // of interp_point, so codes and reconstruction stay bit-identical.
@@ -200,6 +200,46 @@ __device__ __forceinline__ void ld8(const T *p, T (&o)[8]) {
         }
     }
 }
+// rows whose length is a multiple of 4 but not of 8 end in a half group (4 valid elements): its upper half is read from the
+// lower half's address again (never past the row, never conditional) and not written
+template <typename T>
+__device__ __forceinline__ void ld8m(const T *p, T (&o)[8], bool full) {
+    const T *q = p + (full ? 4 : 0);
+    if (sizeof(T) == 4) {
+        const float4 a = reinterpret_cast<const float4 *>(p)[0], b = reinterpret_cast<const float4 *>(q)[0];
+        o[0] = (T)a.x; o[1] = (T)a.y; o[2] = (T)a.z; o[3] = (T)a.w; o[4] = (T)b.x; o[5] = (T)b.y; o[6] = (T)b.z; o[7] = (T)b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const double2 a = reinterpret_cast<const double2 *>(p)[k], b = reinterpret_cast<const double2 *>(q)[k];
+            o[2 * k] = (T)a.x;
+            o[2 * k + 1] = (T)a.y;
+            o[4 + 2 * k] = (T)b.x;
+            o[4 + 2 * k + 1] = (T)b.y;
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void ld4(const T *p, T (&o)[4]) {
+    if (sizeof(T) == 4) {
+        const float4 a = reinterpret_cast<const float4 *>(p)[0];
+        o[0] = (T)a.x; o[1] = (T)a.y; o[2] = (T)a.z; o[3] = (T)a.w;
+    } else {
+        const double2 a = reinterpret_cast<const double2 *>(p)[0], b = reinterpret_cast<const double2 *>(p)[1];
+        o[0] = (T)a.x; o[1] = (T)a.y; o[2] = (T)b.x; o[3] = (T)b.y;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void st8m(T *p, const T (&o)[8], bool full) {
+    if (sizeof(T) == 4) {
+        reinterpret_cast<float4 *>(p)[0] = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+        if (full) reinterpret_cast<float4 *>(p)[1] = make_float4((float)o[4], (float)o[5], (float)o[6], (float)o[7]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k < 2 || full) reinterpret_cast<double2 *>(p)[k] = make_double2((double)o[2 * k], (double)o[2 * k + 1]);
+    }
+}
 template <typename T>
 __device__ __forceinline__ void st8(T *p, const T (&o)[8]) {
     if (sizeof(T) == 4) {
@@ -213,7 +253,7 @@ __device__ __forceinline__ void st8(T *p, const T (&o)[8]) {
 template <typename T, bool DEC, bool XDIR>
 __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
     const int N = p.N;
-    const uint64_t dx = p.dims[N - 1], xg = dx / 8;
+    const uint64_t dx = p.dims[N - 1], xg = (dx + 7) / 8;  // dx is a multiple of 4: the last group of a row may hold 4 elements
     const uint64_t t0 = (uint64_t)xcd_block() * 256 + threadIdx.x;
     const bool valid = t0 < p.total;  // total = rows * xg here
     const uint64_t t = valid ? t0 : 0;
@@ -229,16 +269,17 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
         if (j == p.dir) cd = c;
     }
     const uint64_t x0 = tx * 8;
+    const bool full = x0 + 8 <= dx;  // else 4 valid elements: the upper halves below are dummies, never stored
     idx += x0;
     T o[8];
-    ld8<T>(w + idx, o);
+    ld8m<T>(w + idx, o, full);
     // Codes of the 8 elements. Decompression reads them. A compression pass along x keeps the even-x codes of earlier
     // passes; a pass along a slower dimension owns every slot it writes (with xstep = 2 the odd-x slots belong to the
     // later pass along x, which overwrites them), so it does not read the old words at all.
     uint32_t cw[4] = {0u, 0u, 0u, 0u};
     if (DEC || XDIR) {
-        const uint4 cv = *reinterpret_cast<const uint4 *>(codes + idx);
-        cw[0] = cv.x; cw[1] = cv.y; cw[2] = cv.z; cw[3] = cv.w;
+        const uint2 c0 = *reinterpret_cast<const uint2 *>(codes + idx), c1 = *reinterpret_cast<const uint2 *>(codes + idx + (full ? 4 : 0));
+        cw[0] = c0.x; cw[1] = c0.y; cw[2] = c1.x; cw[3] = c1.y;
     }
     auto get_code = [&](int e) -> int { return (int)((cw[e >> 1] >> (16 * (e & 1))) & 0xFFFFu); };
     auto set_code = [&](int e, int c) { cw[e >> 1] = (cw[e >> 1] & ~(0xFFFFu << (16 * (e & 1)))) | ((uint32_t)c << (16 * (e & 1))); };
@@ -264,13 +305,13 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
         T a[8], b[8], c[8], d[8];
         const T *base = w + idx;
         if (i >= 3) {
-            ld8<T>(base - 3 * st, a);
-            ld8<T>(base - st, b);
-            if (i + 1 < n) ld8<T>(base + st, c);
-            if (i + 3 < n) ld8<T>(base + 3 * st, d);
+            ld8m<T>(base - 3 * st, a, full);
+            ld8m<T>(base - st, b, full);
+            if (i + 1 < n) ld8m<T>(base + st, c, full);
+            if (i + 3 < n) ld8m<T>(base + 3 * st, d, full);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                if (e % xstep) continue;
+                if (e % xstep || (!full && e >= 4)) continue;
                 T pred;
                 if (i + 3 < n) pred = ip_cubic<T>(a[e], b[e], c[e], d[e]);
                 else if (i + 1 < n) pred = ip_quad_2<T>(a[e], b[e], c[e]);
@@ -278,12 +319,12 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
                 finish(e, pred);
             }
         } else {
-            ld8<T>(base - st, b);
-            if (i + 1 < n) ld8<T>(base + st, c);
-            if (i + 3 < n) ld8<T>(base + 3 * st, d);
+            ld8m<T>(base - st, b, full);
+            if (i + 1 < n) ld8m<T>(base + st, c, full);
+            if (i + 3 < n) ld8m<T>(base + 3 * st, d, full);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                if (e % xstep) continue;
+                if (e % xstep || (!full && e >= 4)) continue;
                 T pred;
                 if (i + 3 < n) pred = ip_quad_1<T>(b[e], c[e], d[e]);
                 else if (i + 1 < n) pred = ip_linear<T>(b[e], c[e]);
@@ -294,19 +335,20 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
     } else {
         // window win[k] = row[x0 - 4 + k], k = 0..15 (outside the row: never used by the case rules below)
         T win[16];
-        T lo4[8], hi4[8];
+        T lo4[4], hi4[4];
         const T *row = w + idx;  // row + x0
-        if (x0 >= 8) ld8<T>(row - 8, lo4);
-        if (x0 + 8 < dx) ld8<T>(row + 8, hi4);
+        if (x0 >= 8) ld4<T>(row - 4, lo4);
+        if (x0 + 8 < dx) ld4<T>(row + 8, hi4);  // (dx % 4 == 0: these four lie inside the row)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            win[k] = x0 >= 8 ? lo4[4 + k] : (T)0;
+            win[k] = x0 >= 8 ? lo4[k] : (T)0;
             win[12 + k] = x0 + 8 < dx ? hi4[k] : (T)0;
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) win[4 + k] = o[k];
 #pragma unroll
         for (int e = 1; e < 8; e += 2) {
+            if (!full && e >= 4) continue;
             const uint64_t cx = x0 + e;
             const uint64_t begin = (cx / 32) * 32;
             uint64_t end = begin + 32;
@@ -327,8 +369,11 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
         }
     }
     if (valid) {
-        if (DEC || !p.no_store) st8<T>(w + idx, o);
-        if (!DEC) *reinterpret_cast<uint4 *>(codes + idx) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+        if (DEC || !p.no_store) st8m<T>(w + idx, o, full);
+        if (!DEC) {
+            *reinterpret_cast<uint2 *>(codes + idx) = make_uint2(cw[0], cw[1]);
+            if (full) *reinterpret_cast<uint2 *>(codes + idx + 4) = make_uint2(cw[2], cw[3]);
+        }
     }
 }
 
@@ -651,13 +696,13 @@ static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStr
     for (const szk_interp_pass &p : sched) {
         const uint32_t nb = (uint32_t)((p.total + 255) / 256);
         const uint64_t dxl = p.dims[p.N - 1];
-        const bool vec = p.kind == 2 && nbatch == 1 && !p.old_api && p.interp_id == 1 && p.s == 1 && dxl % 8 == 0 && dxl >= 16 &&
+        const bool vec = p.kind == 2 && nbatch == 1 && !p.old_api && p.interp_id == 1 && p.s == 1 && dxl % 4 == 0 && dxl >= 16 &&
                          (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (reinterpret_cast<uintptr_t>(codes) & 15) == 0 && !szk_interp_novec;
         if (vec) {
             szk_interp_pass q = p;
             uint64_t rows = 1;
             for (int j = 0; j < p.N - 1; j++) rows *= p.cnt[j];
-            q.total = rows * (dxl / 8);
+            q.total = rows * ((dxl + 7) / 8);
             const uint64_t vb = (q.total + 255) / 256;
             if (vb > 0x7FFFFFFFull) return -1;
             if (p.dir == p.N - 1) hipLaunchKernelGGL((k_interp_vec<T, DEC, true>), dim3((uint32_t)vb), dim3(256), 0, s, w, codes, q);

@@ -34,6 +34,12 @@ CASES = [
     ("4d-vec-cubic", lambda: field4d((5, 9, 16, 24)), 1e-2, dict(interpAlgo=1)),
     ("4d-vec-cubic-dir17", lambda: field4d((6, 7, 34, 16)), 1e-3, dict(interpAlgo=1, interpDirection=17)),
     ("3d-vec-nan", "nan64", 1e-3, dict(interpAlgo=1)),
+    # rows of a multiple of 4 but not of 8 elements: the 8-wide level-1 kernels end every row in a half group
+    ("3d-vec-half-100", lambda: field3d((33, 40, 100)), 1e-3, dict(interpAlgo=1)),
+    ("3d-vec-half-20-dir5", lambda: field3d((40, 36, 20)), 1e-4, dict(interpAlgo=1, interpDirection=5)),
+    ("3d-vec-half-f64-dir2", lambda: field3d((18, 35, 68), np.float64, sigma=2e-6), 1e-6, dict(interpAlgo=1, interpDirection=2)),
+    ("4d-vec-half-36", lambda: field4d((5, 9, 17, 36)), 1e-3, dict(interpAlgo=1, interpDirection=11)),
+    ("3d-vec-half-500", lambda: field3d((9, 20, 500)), 1e-3, dict(interpAlgo=1, interpAlpha=1.0, interpBeta=1.0)),
     # small quantisers: code 0 (unpredictable) lies inside / at the edge of the histogram window around the radius
     ("3d-qbin1024", lambda: field3d((33, 40, 48)), 1e-3, dict(interpAlgo=1, quantbinCnt=1024)),
     ("3d-qbin256", lambda: field3d((33, 40, 48)), 1e-2, dict(interpAlgo=1, quantbinCnt=256)),
@@ -109,9 +115,10 @@ def test_interp_host_api_and_ratio():
     assert c2.cmprAlgo == sz3_amd.ALGO_HIP_INTERP and np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= 1e-3
 
 
-def test_vector_and_scalar_level1_kernels_agree():
+@pytest.mark.parametrize("VEC_SHAPE", [(48, 56, 128), (40, 33, 100), (17, 24, 36)])
+def test_vector_and_scalar_level1_kernels_agree(VEC_SHAPE):
     """debug flag 128 forces the one-point-per-thread kernels: same payload, byte for byte"""
-    a = field3d((48, 56, 128))
+    a = field3d(VEC_SHAPE)
     a[7, 7, 7] = np.nan
     dev = torch.device("cuda:0")
     t = torch.from_numpy(a).to(dev)

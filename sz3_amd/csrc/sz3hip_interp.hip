@@ -250,7 +250,20 @@ __device__ __forceinline__ void st8(T *p, const T (&o)[8]) {
         for (int k = 0; k < 4; k++) reinterpret_cast<double2 *>(p)[k] = make_double2((double)o[2 * k], (double)o[2 * k + 1]);
     }
 }
-template <typename T, bool DEC, bool XDIR>
+// the 1-D / 2-D rules (interpolation_1d, InterpolationDecomposition.hpp:248-293) on gathered neighbours
+template <typename T>
+__device__ __forceinline__ T old_rule(uint64_t i, uint64_t n, T m5, T m3, T m1, T p1, T p3) {
+    if (n < 5) {
+        if (i + 1 < n) return ip_linear<T>(m1, p1);
+        return n < 4 ? m1 : ip_linear1<T>(m3, m1);
+    }
+    if (i == 1) return ip_quad_1<T>(m1, p1, p3);
+    if (i + 3 < n) return ip_cubic<T>(m3, m1, p1, p3);
+    if (i + 1 < n) return ip_quad_2<T>(m3, m1, p1);
+    return ip_quad_3<T>(m5, m3, m1);
+}
+// OLD: the case rules of the 1-D / 2-D interface (same block structure, different boundary formulas)
+template <typename T, bool DEC, bool XDIR, bool OLD = false>
 __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
     const int N = p.N;
     const uint64_t dx = p.dims[N - 1], xg = (dx + 7) / 8;  // dx is a multiple of 4: the last group of a row may hold 4 elements
@@ -304,7 +317,19 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
         const int xstep = (int)p.step[N - 1];
         T a[8], b[8], c[8], d[8];
         const T *base = w + idx;
-        if (i >= 3) {
+        if (OLD) {
+            T a5[8];
+            if (i >= 3) ld8m<T>(base - 3 * st, a, full);
+            ld8m<T>(base - st, b, full);
+            if (i + 1 < n) ld8m<T>(base + st, c, full);
+            if (i + 3 < n) ld8m<T>(base + 3 * st, d, full);
+            if (i + 1 >= n && n >= 5) ld8m<T>(base - 5 * st, a5, full);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (e % xstep || (!full && e >= 4)) continue;
+                finish(e, old_rule<T>(i, n, a5[e], a[e], b[e], c[e], d[e]));
+            }
+        } else if (i >= 3) {
             ld8m<T>(base - 3 * st, a, full);
             ld8m<T>(base - st, b, full);
             if (i + 1 < n) ld8m<T>(base + st, c, full);
@@ -356,7 +381,9 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
             const uint64_t n = end - begin + 1, i = cx - begin;
             const T m3 = win[4 + e - 3], m1 = win[4 + e - 1], p1 = win[4 + e + 1], p3 = win[4 + e + 3];
             T pred;
-            if (i >= 3) {
+            if (OLD) {
+                pred = old_rule<T>(i, n, win[4 + e - 5], m3, m1, p1, p3);
+            } else if (i >= 3) {
                 if (i + 3 < n) pred = ip_cubic<T>(m3, m1, p1, p3);
                 else if (i + 1 < n) pred = ip_quad_2<T>(m3, m1, p1);
                 else pred = ip_linear1<T>(m3, m1);
@@ -696,7 +723,7 @@ static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStr
     for (const szk_interp_pass &p : sched) {
         const uint32_t nb = (uint32_t)((p.total + 255) / 256);
         const uint64_t dxl = p.dims[p.N - 1];
-        const bool vec = p.kind == 2 && nbatch == 1 && !p.old_api && p.interp_id == 1 && p.s == 1 && dxl % 4 == 0 && dxl >= 16 &&
+        const bool vec = p.kind == 2 && nbatch == 1 && p.interp_id == 1 && p.s == 1 && dxl % 4 == 0 && dxl >= 16 &&
                          (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (reinterpret_cast<uintptr_t>(codes) & 15) == 0 && !szk_interp_novec;
         if (vec) {
             szk_interp_pass q = p;
@@ -705,8 +732,12 @@ static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStr
             q.total = rows * ((dxl + 7) / 8);
             const uint64_t vb = (q.total + 255) / 256;
             if (vb > 0x7FFFFFFFull) return -1;
-            if (p.dir == p.N - 1) hipLaunchKernelGGL((k_interp_vec<T, DEC, true>), dim3((uint32_t)vb), dim3(256), 0, s, w, codes, q);
-            else hipLaunchKernelGGL((k_interp_vec<T, DEC, false>), dim3((uint32_t)vb), dim3(256), 0, s, w, codes, q);
+            const dim3 g((uint32_t)vb), b(256);
+            if (p.old_api) {
+                if (p.dir == p.N - 1) hipLaunchKernelGGL((k_interp_vec<T, DEC, true, true>), g, b, 0, s, w, codes, q);
+                else hipLaunchKernelGGL((k_interp_vec<T, DEC, false, true>), g, b, 0, s, w, codes, q);
+            } else if (p.dir == p.N - 1) hipLaunchKernelGGL((k_interp_vec<T, DEC, true>), g, b, 0, s, w, codes, q);
+            else hipLaunchKernelGGL((k_interp_vec<T, DEC, false>), g, b, 0, s, w, codes, q);
         } else if (p.kind == 2) {
             hipLaunchKernelGGL((k_interp_pass<T, DEC>), dim3(nb, nbatch), dim3(256), 0, s, w, codes, p);
         } else if (DEC) {

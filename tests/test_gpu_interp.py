@@ -40,6 +40,15 @@ CASES = [
     ("3d-vec-half-f64-dir2", lambda: field3d((18, 35, 68), np.float64, sigma=2e-6), 1e-6, dict(interpAlgo=1, interpDirection=2)),
     ("4d-vec-half-36", lambda: field4d((5, 9, 17, 36)), 1e-3, dict(interpAlgo=1, interpDirection=11)),
     ("3d-vec-half-500", lambda: field3d((9, 20, 500)), 1e-3, dict(interpAlgo=1, interpAlpha=1.0, interpBeta=1.0)),
+    # 1-D / 2-D fields: the 8-wide level-1 kernels with the 1-D / 2-D interface's boundary rules (tails of 2..4 points too)
+    ("2d-vec-cubic", lambda: field2d((123, 256)), 1e-3, dict(interpAlgo=1)),
+    ("2d-vec-cubic-dir1-half", lambda: field2d((130, 260)), 1e-4, dict(interpAlgo=1, interpDirection=1)),
+    ("2d-vec-tails-34x36", lambda: field2d((34, 36)), 1e-3, dict(interpAlgo=1)),
+    ("2d-vec-tails-35x68-dir1", lambda: field2d((35, 68)), 1e-3, dict(interpAlgo=1, interpDirection=1)),
+    ("2d-vec-tails-37x100", lambda: field2d((37, 100)), 1e-3, dict(interpAlgo=1, interpAlpha=1.5, interpBeta=2.0)),
+    ("2d-vec-f64", lambda: field2d((96, 72), np.float64, sigma=2e-6), 1e-6, dict(interpAlgo=1)),
+    ("1d-vec-cubic", lambda: field1d(70004), 1e-3, dict(interpAlgo=1)),
+    ("1d-vec-cubic-tail3", lambda: field1d(32 * 100 + 3 + 1), 1e-3, dict(interpAlgo=1)),
     # small quantisers: code 0 (unpredictable) lies inside / at the edge of the histogram window around the radius
     ("3d-qbin1024", lambda: field3d((33, 40, 48)), 1e-3, dict(interpAlgo=1, quantbinCnt=1024)),
     ("3d-qbin256", lambda: field3d((33, 40, 48)), 1e-2, dict(interpAlgo=1, quantbinCnt=256)),
@@ -115,11 +124,11 @@ def test_interp_host_api_and_ratio():
     assert c2.cmprAlgo == sz3_amd.ALGO_HIP_INTERP and np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= 1e-3
 
 
-@pytest.mark.parametrize("VEC_SHAPE", [(48, 56, 128), (40, 33, 100), (17, 24, 36)])
+@pytest.mark.parametrize("VEC_SHAPE", [(48, 56, 128), (40, 33, 100), (17, 24, 36), (200, 136), (67, 36), (40004,)])
 def test_vector_and_scalar_level1_kernels_agree(VEC_SHAPE):
     """debug flag 128 forces the one-point-per-thread kernels: same payload, byte for byte"""
-    a = field3d(VEC_SHAPE)
-    a[7, 7, 7] = np.nan
+    a = {1: field1d, 2: field2d, 3: field3d}[len(VEC_SHAPE)](VEC_SHAPE if len(VEC_SHAPE) > 1 else VEC_SHAPE[0])
+    a.flat[a.size // 3 + 7] = np.nan
     dev = torch.device("cuda:0")
     t = torch.from_numpy(a).to(dev)
     dc = sz3_amd.DeviceCompressor(a.size, a.dtype)

@@ -9,6 +9,7 @@ dt = np.float64 if os.environ.get("LAB_DTYPE") == "f64" else np.float32
 eb = float(os.environ.get("LAB_EB", "3e-3"))
 algo = {"interp": sz3_amd.ALGO_INTERP, "lorenzo": sz3_amd.ALGO_LORENZO_REG, "default": sz3_amd.ALGO_INTERP_LORENZO}[os.environ.get("LAB_ALGO", "lorenzo")]
 dev = torch.device("cuda:0")
+if os.environ.get("LAB_DBG"): sz3_amd.lib().sz3hip_debug_flags(int(os.environ["LAB_DBG"]))  # e.g. 128: one-point-per-thread kernels
 g = torch.Generator(device=dev).manual_seed(5)
 grids = torch.meshgrid(*[torch.arange(s, device=dev, dtype=torch.float32) for s in shape], indexing="ij")
 f = sum(torch.sin(2 * np.pi * gr / (29.0 + 17 * i)) for i, gr in enumerate(grids))

@@ -41,26 +41,26 @@ template <typename T>
 __device__ __forceinline__ int ref_quantize(T &data, T pred, double eb, double recip, int radius) {
     const T diff = data - pred;
     const double scaled = fabs((double)diff) * recip;
-    if (!(scaled < 9223372036854775808.0)) return 0;  // NaN / overflow of the reference's int64 cast: unpredictable
-    long long qi = (long long)scaled + 1;
-    if (qi < (long long)radius * 2) {
-        qi >>= 1;
-        const int half = (int)qi;
-        qi <<= 1;
-        int shifted;
-        if (diff < 0) {
-            qi = -qi;
-            shifted = radius - half;
-        } else {
-            shifted = radius + half;
-        }
-        const T dec = (T)((double)pred + (double)qi * eb);
-        const T ad = dec - data;
-        const double adiff = fabs((double)ad);
-        if (adiff <= eb) {
-            data = dec;
-            return shifted;
-        }
+    // the reference casts to int64, adds 1 and asks "< 2 * radius": true exactly when scaled < 2 * radius - 1 (a NaN or an
+    // overflowing quotient fails it: unpredictable). Inside that range the quotient fits 32 bits, where the conversions
+    // are single instructions (the 64-bit ones are emulated: they were a third of the pass kernels' time).
+    if (!(scaled < (double)(2 * radius - 1))) return 0;
+    int qi = (int)scaled + 1;
+    const int half = qi >> 1;
+    qi = half << 1;
+    int shifted;
+    if (diff < 0) {
+        qi = -qi;
+        shifted = radius - half;
+    } else {
+        shifted = radius + half;
+    }
+    const T dec = (T)((double)pred + (double)qi * eb);
+    const T ad = dec - data;
+    const double adiff = fabs((double)ad);
+    if (adiff <= eb) {
+        data = dec;
+        return shifted;
     }
     return 0;
 }

@@ -387,7 +387,6 @@ struct sz3hip_ctx {
     void *d_segtot;
     double *d_minmax;
     szk_state *h_state;  // pinned
-    uint32_t *h_probe;   // pinned copy of the narrow-mode probe counter
     szk_mode mode;       // of the pending / last compress
     double *h_minmax;    // pinned
     // pending compress
@@ -441,7 +440,6 @@ static void ctx_free(sz3hip_ctx *c) {
     if (c->d_starts) (void)hipHostFree(c->d_starts);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
-    if (c->h_probe) (void)hipHostFree(c->h_probe);
     if (c->h_trial) (void)hipHostFree(c->h_trial);
     if (c->h_passes) (void)hipHostFree(c->h_passes);
     if (c->h_np) (void)hipHostFree(c->h_np);
@@ -508,7 +506,6 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     alloc((void **)&c->d_minmax, (2 * 1024 + 2) * 8);
     if (ok && hipHostMalloc((void **)&c->h_state, sizeof(szk_state)) != hipSuccess) ok = false;
     if (ok && hipHostMalloc((void **)&c->h_minmax, 16) != hipSuccess) ok = false;
-    if (ok && hipHostMalloc((void **)&c->h_probe, 32) != hipSuccess) ok = false;
     (void)tsz;
     if (!ok) {
         if (!g_err[0]) fail(SZ3HIP_EHIP, "device allocation failed");
@@ -1101,7 +1098,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     prof_end(ctx, ST_ASSEMBLE, s);
     if (rc) return fail(SZ3HIP_EHIP, "assemble kernel launch failed (%d)", rc);
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(szk_state), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(ctx->h_probe, ctx->d_counters + 4, 24, hipMemcpyDeviceToHost, s));  // probe counters: |delta| > 127, in [4096, 8192), in [2048, 4096); [4] = interpolation codes beyond +-4096
+    // (h_state->probe = the probe counters: |delta| > 127, in [4096, 8192), in [2048, 4096); [4] = interpolation codes beyond +-4096)
     ctx->stage2_done = true;
     return 0;
 }
@@ -1122,17 +1119,17 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     ctx->stats.payload_bytes = st.hdr.payload_bytes;
     ctx->stats.max_code_len = st.hdr.max_len;
     ctx->stats.n_symbols = 0;
-    ctx->stats.narrow_codes = ctx->mode.allow && (uint64_t)(*ctx->h_probe) * 4096ull <= ctx->mode.n_samples;
-    ctx->stats.reserved = (ctx->wide16 > 0 ? 1u : 0u) | (ctx->h_probe[1] << 1);  // (development: window used, far-delta count)
+    ctx->stats.narrow_codes = ctx->mode.allow && (uint64_t)st.probe[0] * 4096ull <= ctx->mode.n_samples;
+    ctx->stats.reserved = (ctx->wide16 > 0 ? 1u : 0u) | (st.probe[1] << 1);  // (development: window used, far-delta count)
     if (st.hdr.predictor == 1)  // interpolation: second histogram tier of the next call (one workgroup per CU against three)
-        ctx->hist_big = (uint64_t)ctx->h_probe[4] * 100ull > st.hdr.n ? 1 : 0;  // (> 1 %: below, the lost occupancy costs more)
+        ctx->hist_big = (uint64_t)st.probe[4] * 100ull > st.hdr.n ? 1 : 0;  // (> 1 %: below, the lost occupancy costs more)
     if (st.hdr.predictor == 0 && ctx->mode.allow && ctx->mode.n_samples) {
         // stage-1 window of the next Lorenzo call: the large one (half the occupancy) when the probe saw more than 1/300 of
         // the deltas between the two windows (each costs a global atomic with the small one; measured break-even ~0.2 %:
         // 0.1 % -> 0.20 vs 0.28 ms in favour of the small window, 0.5 % -> 0.57 vs 0.36 ms in favour of the large one)
-        ctx->wide16 = (uint64_t)ctx->h_probe[1] * 300ull > ctx->mode.n_samples ? 1 : 0;
+        ctx->wide16 = (uint64_t)st.probe[1] * 300ull > ctx->mode.n_samples ? 1 : 0;
         // the packers' table window likewise: doubled (3 instead of 5 workgroups per CU) when > 2 % of the symbols lie between
-        ctx->pack_wide = (uint64_t)ctx->h_probe[2] * 50ull > ctx->mode.n_samples ? 1 : 0;
+        ctx->pack_wide = (uint64_t)st.probe[2] * 50ull > ctx->mode.n_samples ? 1 : 0;
     }
     if (st.overflow)
         return fail(SZ3HIP_EOUTLIERS, "outlier capacity exceeded (%llu per list): data not compressible at this bound",

@@ -86,6 +86,7 @@ struct szk_state {
     szh_header hdr;
     szh_offsets off;
     uint32_t overflow, cap_exceeded;
+    uint32_t probe[6];  // copy of the probe counters (d_counters + 4): one device-to-host copy brings everything the host reads
 };
 struct szk_layout_params {
     szh_header proto;

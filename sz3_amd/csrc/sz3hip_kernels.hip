@@ -2451,6 +2451,7 @@ __global__ __launch_bounds__(256) void k_assemble(szk_asm_params p) {
         p.state->hdr = h;
         p.state->off = oo;
         p.state->cap_exceeded = oo.end > p.cap;
+        for (int i = 0; i < 6; i++) p.state->probe[i] = reinterpret_cast<const uint32_t *>(p.n_vout + 4)[i];
         // alignment gaps between the sections are part of the payload: zero them so that it is a pure function of the input
         const uint64_t tsz0 = h.dtype == 0 ? 4 : 8;
         for (uint64_t a = oo.lens + h.sym_count; a < oo.chunkwords; a++) p.payload[a] = 0;

@@ -369,7 +369,7 @@ struct sz3hip_ctx {
     uint16_t *d_codes;
     uint64_t *d_hist;      // histogram in use (internal or caller-owned)
     uint64_t *d_hist_own;  // internal allocation
-    uint64_t *d_counters;  // [0]=n_vout [1]=n_dout [2]=total_words
+    uint64_t *d_counters;  // [0]=n_vout [1]=n_dout [2]=total_words [3]=decoder [4..6]=probe words [8..9]=code book's symbol range (inside d_hist_own's block)
     uint32_t *d_hist_partial;
     void *d_work;          // interpolation: the array being overwritten with reconstructed values (lazy)
     uint64_t *d_vout_idx, *d_dout_idx;
@@ -422,9 +422,16 @@ struct sz3hip_ctx {
     bool ev_used[ST_COUNT];
 };
 
+#define SZ_COUNTER_BYTES 128
+// histogram and counters of a call start at zero; the internal histogram and the counters share one block (one fill launch)
+static hipError_t clear_hist_counters(sz3hip_ctx *c, hipStream_t s) {
+    if (c->d_hist == c->d_hist_own) return hipMemsetAsync(c->d_hist, 0, SZH_HIST_BINS * 8 + SZ_COUNTER_BYTES, s);
+    hipError_t e = hipMemsetAsync(c->d_hist, 0, SZH_HIST_BINS * 8, s);  // caller-owned histogram (multi-GPU all-reduce buffer)
+    return e != hipSuccess ? e : hipMemsetAsync(c->d_counters, 0, SZ_COUNTER_BYTES, s);
+}
 static void ctx_free(sz3hip_ctx *c) {
     if (!c) return;
-    void *bufs[] = {c->d_work, c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_counters, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
+    void *bufs[] = {c->d_work, c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
                     c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_aux2, c->d_pint2, c->d_range, c->d_info,
                     c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples, c->d_trial_work,
                     c->d_trial, c->d_passes, c->d_np};  // (d_trial_counters / d_trial_hist live inside d_trial's block)
@@ -478,9 +485,9 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
         }
     };
     alloc((void **)&c->d_codes, (max_elems + 64) * 2);
-    alloc((void **)&c->d_hist_own, SZH_HIST_BINS * 8);
+    alloc((void **)&c->d_hist_own, SZH_HIST_BINS * 8 + SZ_COUNTER_BYTES);  // the counters follow the histogram: one memset per call
     c->d_hist = c->d_hist_own;
-    alloc((void **)&c->d_counters, 64);
+    c->d_counters = c->d_hist_own ? c->d_hist_own + SZH_HIST_BINS : nullptr;
     alloc((void **)&c->d_hist_partial, (size_t)SZK_K1_GRID * 1024 * 4);
     alloc((void **)&c->d_vout_idx, c->out_cap * 8);
     alloc((void **)&c->d_dout_idx, c->out_cap * 8);
@@ -612,7 +619,7 @@ static void cb_params_from(sz3hip_ctx *ctx, szk_cb_params &cb, uint64_t out_cap)
     cb.depth = ctx->d_depth;
     cb.aux2 = ctx->d_aux2;
     cb.pint2 = ctx->d_pint2;
-    cb.range = ctx->d_range;
+    cb.range = reinterpret_cast<uint32_t *>(ctx->d_counters + 8);  // (zeroed with the counters)
     cb.vout_idx = ctx->d_vout_idx;
     cb.dout_idx = ctx->d_dout_idx;
     cb.vout_val = ctx->d_vout_val;
@@ -966,8 +973,7 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
         }
     }
     if (N == 1 && best_interp < 50) {  // :232-247 — here: this library's own Lorenzo coder over the concatenated samples
-        HIPCHK(hipMemsetAsync(ctx->d_hist, 0, SZH_HIST_BINS * 8, s));
-        HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 64, s));
+        HIPCHK(clear_hist_counters(ctx, s));
         HIPCHK(hipMemsetAsync(ctx->d_trial + 24, 0, 32, s));
         szk_k1_params p;
         const uint64_t d1[1] = {sampling_num};
@@ -1044,8 +1050,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
         if (rct) return rct;
         ctx->copy_ahead = true;
     }
-    HIPCHK(hipMemsetAsync(ctx->d_hist, 0, SZH_HIST_BINS * 8, s));
-    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 64, s));
+    HIPCHK(clear_hist_counters(ctx, s));
     if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP || conf->cmprAlgo == SZ3HIP_ALGO_HIP_INTERP)
         return stage1_interp(ctx, conf, d_in, eb, radius, num, s);
     return stage1_lorenzo(ctx, conf, d_in, eb, radius, num, s);

@@ -3163,8 +3163,10 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
     szk_cb_params q = *p;
     q.n_books = nb;
     q.dbg = (szk_dbg_flags & 1024) ? 1u : 0u;
-    hipError_t e = hipMemsetAsync(q.range, 0, 16 * nb, s);
-    if (e != hipSuccess) return (int)e;
+    if (nb > 1) {  // (a single book's range words are zeroed by the caller together with its counters)
+        hipError_t e = hipMemsetAsync(q.range, 0, 16 * nb, s);
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256, nb), dim3(256), 0, s, d_hist, q.range);
     hipLaunchKernelGGL(k_codebook<0>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
     hipLaunchKernelGGL(k_codebook<1>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);

@@ -1075,12 +1075,10 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     lp.out_cap = ctx->cur_out_cap;
     lp.info = ctx->d_info;
     lp.state = ctx->d_state;
-    rc = szk_launch_layout_pre(&lp, s);
     prof_end(ctx, ST_CODEBOOK, s);
-    if (rc) return fail(SZ3HIP_EHIP, "layout kernel launch failed (%d)", rc);
-    prof_begin(ctx, ST_ENCODE, s);
+    prof_begin(ctx, ST_ENCODE, s);  // (the payload layout is computed inside the encoder's scan launch)
     rc = szk_launch_encode(ctx->d_codes, n, ctx->d_enc, ctx->d_info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words, ctx->d_chunk_off,
-                           ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, s);
+                           ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, &lp, s);
     prof_end(ctx, ST_ENCODE, s);
     if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
     szk_asm_params ap;

@@ -187,10 +187,9 @@ int szk_launch_f64_to_int(int is64, const double *d_in, uint64_t n, void *d_out,
 int szk_launch_minmax(int dtype, const void *d_in, uint64_t n, double *d_partial /*[2*1024]*/, double *d_out /*[2]*/, hipStream_t s);
 int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, szk_k1_params *p, hipStream_t s);
 int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStream_t s);
-int szk_launch_layout_pre(const szk_layout_params *p, hipStream_t s);
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
                       szk_mode mode, uint16_t *chunk_words, uint64_t *group_off /*[n_chunks/32 + 1]*/, uint64_t *total_words,
-                      const szk_state *state, uint8_t *payload, hipStream_t s);
+                      const szk_state *state, uint8_t *payload, const szk_layout_params *layout, hipStream_t s);
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, hipStream_t s);
 int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t *codes, uint64_t *chunk_off,

@@ -2032,8 +2032,7 @@ __device__ __host__ inline void szh_compute_offsets(const szh_header &h, szh_off
     o.end = off + 4 * h.bitstream_words;
 }
 
-__global__ void k_layout_pre(szk_layout_params p) {  // after K1 + K5, before the encoder
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void layout_pre(const szk_layout_params &p) {  // after K1 + K5, before the packer (one thread)
     szh_header h = p.proto;  // dtype, ndim, dims, eb, radius, n, chunk geometry filled by the host
     uint64_t nv = *p.n_vout, nd = *p.n_dout;
     p.state->overflow = (nv > p.out_cap) || (nd > p.out_cap);
@@ -2227,39 +2226,56 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
     }
 }
 
+// offsets of the 32-chunk groups (exclusive scan of the groups' word counts) and the total; one workgroup, four
+// consecutive groups per thread and round. The encoder's call also lays the payload out (k_layout_pre's work: the
+// sections' offsets depend on the outlier counts and the alphabet, known since the code book kernel) — one launch less.
+#define SCAN_GPT 4
 __global__ __launch_bounds__(1024) void k_scan_groups(const uint16_t *__restrict__ chunk_words, uint64_t n_chunks,
-                                                      uint64_t *__restrict__ group_off, uint64_t *total_words) {
+                                                      uint64_t *__restrict__ group_off, uint64_t *total_words,
+                                                      szk_layout_params lp, int do_layout) {
     __shared__ uint64_t s_w[16];
     __shared__ uint64_t s_carry;
+    if (do_layout && threadIdx.x == 1023) layout_pre(lp);
     const uint64_t n_groups = (n_chunks + PACK_GROUP - 1) / PACK_GROUP;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    // sweep: 1024 consecutive groups per round, one group (32 x u16 = four 16-byte loads) per thread
-    for (uint64_t g0 = 0; g0 < n_groups; g0 += 1024) {
-        const uint64_t g = g0 + threadIdx.x;
-        uint64_t sum = 0;
-        if (g < n_groups) {
-            const uint64_t c0 = g * PACK_GROUP;
-            if (c0 + PACK_GROUP <= n_chunks) {
-                const uint4 *v = reinterpret_cast<const uint4 *>(chunk_words + c0);
-                uint4 q[4] = {v[0], v[1], v[2], v[3]};
+    for (uint64_t g0 = 0; g0 < n_groups; g0 += 1024 * SCAN_GPT) {
+        const uint64_t gt = g0 + (uint64_t)threadIdx.x * SCAN_GPT;
+        uint64_t sum[SCAN_GPT];
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    sum += (q[k].x & 0xFFFF) + (q[k].x >> 16) + (q[k].y & 0xFFFF) + (q[k].y >> 16) + (q[k].z & 0xFFFF) +
-                           (q[k].z >> 16) + (q[k].w & 0xFFFF) + (q[k].w >> 16);
-            } else {
-                for (uint64_t c = c0; c < n_chunks; c++) sum += chunk_words[c];
+        for (int j = 0; j < SCAN_GPT; j++) {
+            const uint64_t g = gt + j;
+            sum[j] = 0;
+            if (g < n_groups) {
+                const uint64_t c0 = g * PACK_GROUP;
+                if (c0 + PACK_GROUP <= n_chunks) {  // 32 x u16 = four 16-byte loads
+                    const uint4 *v = reinterpret_cast<const uint4 *>(chunk_words + c0);
+                    uint4 q[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        sum[j] += (q[k].x & 0xFFFF) + (q[k].x >> 16) + (q[k].y & 0xFFFF) + (q[k].y >> 16) + (q[k].z & 0xFFFF) +
+                                  (q[k].z >> 16) + (q[k].w & 0xFFFF) + (q[k].w >> 16);
+                } else {
+                    for (uint64_t c = c0; c < n_chunks; c++) sum[j] += chunk_words[c];
+                }
             }
         }
-        const uint64_t incl = wave_incl_scan(sum);
+        uint64_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < SCAN_GPT; j++) mine += sum[j];
+        const uint64_t incl = wave_incl_scan(mine);
         if (lane_id() == WAVE - 1) s_w[threadIdx.x / WAVE] = incl;
         __syncthreads();
-        uint64_t run = s_carry + incl - sum, tot = 0;
+        uint64_t run = s_carry + incl - mine, tot = 0;
         for (int w = 0; w < 16; w++) {
             if (w < (int)(threadIdx.x / WAVE)) run += s_w[w];
             tot += s_w[w];
         }
-        if (g < n_groups) group_off[g] = run;
+#pragma unroll
+        for (int j = 0; j < SCAN_GPT; j++) {
+            if (gt + j < n_groups) group_off[gt + j] = run;
+            run += sum[j];
+        }
         __syncthreads();
         if (threadIdx.x == 0) s_carry += tot;
         __syncthreads();
@@ -3173,21 +3189,16 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
     SZK_CHECK_LAUNCH();
     return 0;
 }
-int szk_launch_layout_pre(const szk_layout_params *p, hipStream_t s) {
-    hipLaunchKernelGGL(k_layout_pre, dim3(1), dim3(64), 0, s, *p);
-    SZK_CHECK_LAUNCH();
-    return 0;
-}
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
                       szk_mode mode, uint16_t *chunk_words, uint64_t *group_off, uint64_t *total_words,
-                      const szk_state *state, uint8_t *payload, hipStream_t s) {
+                      const szk_state *state, uint8_t *payload, const szk_layout_params *layout, hipStream_t s) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
     const uint64_t nb = (n_chunks + 3) / 4;
     if (nb > 0x7FFFFFFFull) return -1;
     const uint32_t sym_add = (uint32_t)radius - 128u;
     const uint32_t pgrid = (uint32_t)(nb < 2048 ? nb : 2048);  // persistent: 8 workgroups per CU
     hipLaunchKernelGGL(k_chunk_bits2, dim3(pgrid), dim3(256), 0, s, codes, n, d_enc, info, mode, sym_add, chunk_words);
-    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, chunk_words, n_chunks, group_off, total_words);
+    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, chunk_words, n_chunks, group_off, total_words, *layout, 1);
     if (mode.pack_wide)
         hipLaunchKernelGGL((k_pack<2 * ENC_WIN>), dim3(pgrid < 768 ? pgrid : 768), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
                            sym_add, state, payload);
@@ -3210,7 +3221,8 @@ int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_
 }
 int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t *codes, uint64_t *chunk_off,
                       uint64_t *total_words, hipStream_t s) {
-    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, p->chunk_words, p->n_chunks, chunk_off, total_words);  // chunk_off = p->group_off
+    szk_layout_params no_layout{};
+    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, p->chunk_words, p->n_chunks, chunk_off, total_words, no_layout, 0);  // chunk_off = p->group_off
     const uint64_t nb = (p->n_chunks + 255) / 256;
     if (nb > 0x7FFFFFFFull) return -1;
     if (!p->scan_row) hipLaunchKernelGGL(k_decode<0>, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);

@@ -151,3 +151,13 @@ def test_c_headers_are_plain_c(tmp_path):
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_committed_traffic_file_has_the_key_the_bench_reads():
+    """bench.py takes roofline.traffic from profiles/pmc_traffic.json (written by tools/pmc_traffic.py from the PMC passes);
+    a renamed kernel must not silently turn it into null"""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    d = json.load(open(path))
+    t = d.get("lorenzo_quant_hist_hbm_bytes_per_launch")
+    assert isinstance(t, int) and 537_000_000 + 134_000_000 <= t < 2 * 671_000_000  # at least the compulsory read + write

@@ -2227,7 +2227,7 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
 }
 
 // offsets of the 32-chunk groups (exclusive scan of the groups' word counts) and the total; one workgroup, four
-// consecutive groups per thread and round. The encoder's call also lays the payload out (k_layout_pre's work: the
+// consecutive groups per thread and round. The encoder's call also lays the payload out (layout_pre: the
 // sections' offsets depend on the outlier counts and the alphabet, known since the code book kernel) — one launch less.
 #define SCAN_GPT 4
 __global__ __launch_bounds__(1024) void k_scan_groups(const uint16_t *__restrict__ chunk_words, uint64_t n_chunks,

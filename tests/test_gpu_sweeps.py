@@ -37,17 +37,37 @@ def test_host_api_sweep():
     assert "failures: 0" in out, out[-3000:]
 
 
+BIG = [  # (id, algorithm, shape, dtype, abs bound, noise, GiB of free HBM needed)
+    ("4.4e9-f32-lorenzo", "lorenzo", "1100,2000,2000", "f32", "1e-3", "2e-3", 120),
+    ("4.4e9-f32-interp", "interp", "1100,2000,2000", "f32", "1e-3", "2e-3", 120),
+    ("C5-whole-lorenzo", "lorenzo", "100,500,500,500", "f32", "2.4e-3", "2e-3", 225),
+    ("C5-whole-default", "default", "100,500,500,500", "f32", "2.4e-3", "2e-3", 225),
+    ("C4-whole-lorenzo", "lorenzo", "1024,1024,1024", "f64", "1e-6", "2e-6", 60),
+    ("C4-whole-default", "default", "1024,1024,1024", "f64", "1e-6", "2e-6", 60),
+]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("algo", ["lorenzo", "interp"])
-def test_round_trip_beyond_2_pow_32_elements(algo):
-    """1100 x 2000 x 2000 f32 = 4.4e9 elements (17.6 GB): every index, chunk and list position beyond 32 bits; the field is
-    generated and the bound checked slab by slab on the device (tests/checks/big_roundtrip.py, own process: ~70 GB of HBM for seconds)"""
+@pytest.mark.parametrize("case", BIG, ids=[c[0] for c in BIG])
+def test_round_trip_at_full_benchmark_sizes_and_beyond_2_pow_32_elements(case):
+    """BASELINE.json's largest configurations whole on ONE GPU - C5 100 x 500^3 f32 (1.25e10 elements, 50 GB) and C4 1024^3 f64
+    (8 GiB) - and 1100 x 2000 x 2000 f32 (4.4e9 elements): every index, chunk and list position beyond 32 bits. The field is
+    generated and the error bound checked slab by slab on the device (tests/checks/big_roundtrip.py, a process of its own)"""
     import torch
-    free, _ = torch.cuda.mem_get_info(0)
-    if free < 120 * 2 ** 30:
-        pytest.skip("needs ~70 GB of free HBM")
-    env = dict(os.environ, LAB_ALGO=algo, LAB_SHAPE="1100,2000,2000", LAB_EB="1e-3")
+    _, algo, shape, dtype, eb, sigma, need = case
+    import time
+    for _ in range(30):  # (the previous case's process has exited, the driver may still be handing its memory back)
+        free, _ = torch.cuda.mem_get_info(0)
+        if free >= need * 2 ** 30:
+            break
+        time.sleep(1.0)
+    if free < need * 2 ** 30:
+        pytest.skip("needs %d GiB of free HBM, %.0f free" % (need, free / 2 ** 30))
+    n = 1
+    for d in shape.split(","):
+        n *= int(d)
+    env = dict(os.environ, LAB_ALGO=algo, LAB_SHAPE=shape, LAB_EB=eb, LAB_DTYPE=dtype, LAB_SIGMA=sigma)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "big_roundtrip.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
-    assert " OK " in last and "4400000000" in r.stdout, last
+    assert " OK " in last and str(n) in r.stdout, last

@@ -405,6 +405,7 @@ struct sz3hip_ctx {
     hipStream_t side;    // the working copy of the input is made here while the tuner runs on the caller's stream
     hipEvent_t ev_fork, ev_join;
     bool copy_ahead;     // d_work already holds this call's input (joined into the caller's stream)
+    int hist_tail;       // with hist_big: codes beyond the large tier counted by windowed passes (from the previous call's count)
     int hist_big;        // interpolation histogram pass with the 16384-bin second tier (from the previous call's far count)
     int pack_wide;       // the packer's LDS table window: 8192 instead of 4096 entries (from the previous call's probe)
     int wide16;          // -1: not decided yet (f64 starts with the 16384-bin stage-1 window, f32 with 8192); else 0 / 1,
@@ -642,6 +643,8 @@ static int stage1_interp(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
     ip.vout_val = ctx->d_vout_val;
     ip.out_cap = ctx->cur_out_cap;
     ip.hist_big = (uint32_t)ctx->hist_big;
+    ip.hist_tail = ctx->hist_tail > 0 || (szk_dbg_flags & 4096) ? 1u : 0u;
+    if (szk_dbg_flags & 4096) ip.hist_big = 1;  // (test hook: large tier + tail passes whatever the history)
     ip.far_cnt = reinterpret_cast<uint32_t *>(ctx->d_counters + 6);  // (zeroed with the counters, fetched with the probe words)
     prof_begin(ctx, ST_K1, s);
     int rci = szk_launch_interp_compress(ctx->dtype, &ip, ctx->copy_ahead ? nullptr : d_in, ctx->d_work, ctx->d_codes, ctx->d_hist, s);
@@ -1125,7 +1128,13 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     ctx->stats.narrow_codes = ctx->mode.allow && (uint64_t)st.probe[0] * 4096ull <= ctx->mode.n_samples;
     ctx->stats.reserved = (ctx->wide16 > 0 ? 1u : 0u) | (st.probe[1] << 1);  // (development: window used, far-delta count)
     if (st.hdr.predictor == 1)  // interpolation: second histogram tier of the next call (one workgroup per CU against three)
+    {
+        const bool was_big = ctx->hist_big > 0;
         ctx->hist_big = (uint64_t)st.probe[4] * 100ull > st.hdr.n ? 1 : 0;  // (> 1 %: below, the lost occupancy costs more)
+        // beyond +-8192 every code is a global atomic (~1.2 G/s for the chip): from 2^18 of them on, three more passes over
+        // the codes with LDS windows are cheaper (measured: 1.5 M of them cost 1.15 ms, the passes 0.2 ms)
+        ctx->hist_tail = was_big && ctx->hist_big && st.probe[5] > (1u << 18) ? 1 : (was_big ? 0 : ctx->hist_tail);
+    }
     if (st.hdr.predictor == 0 && ctx->mode.allow && ctx->mode.n_samples) {
         // stage-1 window of the next Lorenzo call: the large one (half the occupancy) when the probe saw more than 1/300 of
         // the deltas between the two windows (each costs a global atomic with the small one; measured break-even ~0.2 %:

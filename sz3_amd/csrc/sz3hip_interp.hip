@@ -453,18 +453,22 @@ template <typename T, bool SMALLR, bool BIGW>  // SMALLR: radius <= IH_WIN / 2, 
 __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__ codes, uint64_t n, int radius,
                                                     uint64_t *__restrict__ hist, const T *__restrict__ work,
                                                     uint64_t *__restrict__ n_vout, uint64_t *__restrict__ vout_idx,
-                                                    T *__restrict__ vout_val, uint64_t out_cap, uint32_t *__restrict__ far_cnt) {
+                                                    T *__restrict__ vout_val, uint64_t out_cap, uint32_t *__restrict__ far_cnt,
+                                                    uint32_t drop_far) {
+    // drop_far (BIGW only): codes beyond the second tier are not counted here (every one a global atomic, ~1.2 G/s for the
+    // whole chip): k_hist_tail counts them, window by window; far_cnt[1] receives their number either way
     constexpr uint32_t WWIN = BIGW ? 2 * IHW_WIN : IHW_WIN;
     __shared__ uint32_t lh[IH_WIN * 4];
     __shared__ uint32_t l_zero[4];  // code 0 (unpredictable): far from the window and ONE address for all of them
     __shared__ uint32_t lw[WWIN];  // second tier, one copy: the tails (tight bounds spread the codes over thousands of bins)
-    __shared__ uint32_t s_far;
+    __shared__ uint32_t s_far, s_far2;
     uint32_t my_far = 0;  // codes beyond the plain tier (global atomics)
+    uint32_t my_far2 = 0; // codes beyond this form's second tier
     __shared__ uint64_t s_oq[4][IH_OQ];
     for (int i = threadIdx.x; i < IH_WIN * 4; i += 256) lh[i] = 0;
     for (uint32_t i = threadIdx.x; i < WWIN; i += 256) lw[i] = 0;
     if (threadIdx.x < 4) l_zero[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_far = 0;
+    if (threadIdx.x == 0) s_far = s_far2 = 0;
     __syncthreads();
     const uint32_t win_lo = (uint32_t)(radius - IH_WIN / 2), wide_lo = (uint32_t)radius - WWIN / 2, copy = threadIdx.x & 3u;
     const int lane = threadIdx.x & 63;
@@ -528,8 +532,9 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
                 zmask |= 1u << k;
             } else if ((uint32_t)c[k] - wide_lo < WWIN) atomicAdd(&lw[(uint32_t)c[k] - wide_lo], 1u);
             else {
-                atomicAdd((unsigned long long *)&hist[c[k]], 1ull);
+                if (!(BIGW && drop_far)) atomicAdd((unsigned long long *)&hist[c[k]], 1ull);
                 my_far++;
+                my_far2++;
             }
         }
         if (__ballot(zmask != 0)) {  // some lane met unpredictable points: queue their indices
@@ -559,13 +564,61 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
         if (BIGW && (b < IHW_WIN / 2 || b >= WWIN - IHW_WIN / 2)) my_far += v;  // what the plain tier would have missed
     }
     my_far = wave_sum32(my_far);
+    my_far2 = wave_sum32(my_far2);
     if ((threadIdx.x & 63) == 0 && my_far) atomicAdd(&s_far, my_far);
+    if ((threadIdx.x & 63) == 0 && my_far2) atomicAdd(&s_far2, my_far2);
     __syncthreads();
     if (threadIdx.x == 0 && s_far) atomicAdd(far_cnt, s_far);
+    if (threadIdx.x == 0 && BIGW && s_far2) atomicAdd(far_cnt + 1, s_far2);
     for (int b = threadIdx.x; b < IH_WIN; b += 256) {
         const uint32_t s = lh[b * 4] + lh[b * 4 + 1] + lh[b * 4 + 2] + lh[b * 4 + 3];
         const int sym = (int)win_lo + b;
         if (s && sym >= 0 && sym < (int)SZH_HIST_BINS) atomicAdd((unsigned long long *)&hist[sym], (unsigned long long)s);
+    }
+}
+
+// the codes beyond k_hist_codes' 16384-bin tier, counted in LDS: blockIdx.y picks one of the three 16384-bin windows that
+// cover the rest of the 65536 symbols (cyclically, starting at radius + 8192); every workgroup reads all codes and counts
+// the ones of its window. Code 0 (unpredictable) is k_hist_codes' business.
+#define IHT_WIN 16384
+__global__ __launch_bounds__(256) void k_hist_tail(const uint16_t *__restrict__ codes, uint64_t n, int radius, uint64_t *__restrict__ hist) {
+    __shared__ uint32_t lw[IHT_WIN];
+    for (uint32_t i = threadIdx.x; i < IHT_WIN; i += 256) lw[i] = 0;
+    __syncthreads();
+    const uint32_t lo = ((uint32_t)radius + IHT_WIN / 2 + blockIdx.y * IHT_WIN) & 0xFFFFu;
+    const uint64_t nth = (uint64_t)gridDim.x * 256;
+    const uint64_t i_first = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    const uint64_t last8 = n >= 8 ? n - 8 : 0;
+    uint4 nxt = make_uint4(0, 0, 0, 0);
+    if (n >= 8) nxt = *reinterpret_cast<const uint4 *>(codes + (i_first < last8 ? i_first : last8));
+    for (uint64_t i = i_first; i < n; i += nth * 8) {
+        const uint4 v = nxt;
+        {
+            const uint64_t in = i + nth * 8;
+            if (n >= 8) nxt = *reinterpret_cast<const uint4 *>(codes + (in < last8 ? in : last8));
+        }
+        uint32_t c[8];
+        if (i + 8 <= n) {
+            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                c[2 * k] = wv[k] & 0xFFFFu;
+                c[2 * k + 1] = wv[k] >> 16;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) c[k] = (i + k < n) ? codes[i + k] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t b = (c[k] - lo) & 0xFFFFu;
+            if (b < IHT_WIN && c[k] != 0) atomicAdd(&lw[b], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < IHT_WIN; b += 256) {
+        const uint32_t v = lw[b];
+        if (v) atomicAdd((unsigned long long *)&hist[(lo + b) & 0xFFFFu], (unsigned long long)v);
     }
 }
 
@@ -762,14 +815,16 @@ int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const voi
                         : run_interp<double, false>(*ip, (double *)d_work, codes, s);
     if (rc) return rc;
     const bool smallr = ip->radius <= IH_WIN / 2;  // window start <= 0: code 0 lies inside it
+    // tail passes: only with the large second tier (which covers radius +- 8192) and an alphabet that reaches beyond it
+    const bool tails = ip->hist_big && ip->hist_tail && ip->radius > IHW_WIN && SZH_HIST_BINS == 65536;
 #define SZK_HIST_LAUNCH(T, SR)                                                                                                    \
     do {                                                                                                                          \
         if (ip->hist_big)                                                                                                         \
             hipLaunchKernelGGL((k_hist_codes<T, SR, true>), dim3(256), dim3(256), 0, s, codes, num, ip->radius, hist, (const T *)d_work, \
-                               ip->n_vout, ip->vout_idx, (T *)ip->vout_val, ip->out_cap, ip->far_cnt);                            \
+                               ip->n_vout, ip->vout_idx, (T *)ip->vout_val, ip->out_cap, ip->far_cnt, tails ? 1u : 0u);           \
         else                                                                                                                      \
             hipLaunchKernelGGL((k_hist_codes<T, SR, false>), dim3(768), dim3(256), 0, s, codes, num, ip->radius, hist, (const T *)d_work, \
-                               ip->n_vout, ip->vout_idx, (T *)ip->vout_val, ip->out_cap, ip->far_cnt);                            \
+                               ip->n_vout, ip->vout_idx, (T *)ip->vout_val, ip->out_cap, ip->far_cnt, 0u);                        \
     } while (0)
     if (dtype == 0) {
         if (smallr) SZK_HIST_LAUNCH(float, true);
@@ -779,6 +834,7 @@ int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const voi
         else SZK_HIST_LAUNCH(double, false);
     }
 #undef SZK_HIST_LAUNCH
+    if (tails) hipLaunchKernelGGL(k_hist_tail, dim3(170, 3), dim3(256), 0, s, codes, num, ip->radius, hist);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -148,7 +148,8 @@ struct szk_interp_params {  // what InterpolationDecomposition keeps (decomposit
     void *vout_val;
     uint64_t out_cap;
     uint32_t hist_big;   // histogram pass with the 16384-bin second tier (host choice, from the previous call's far count)
-    uint32_t *far_cnt;   // receives the number of codes outside +-4096 of the radius
+    uint32_t hist_tail;  // with hist_big: the codes beyond +-8192 are counted by three windowed passes in LDS (k_hist_tail)
+    uint32_t *far_cnt;   // [0] receives the number of codes outside +-4096 of the radius, [1] (hist_big form) outside +-8192
 };
 struct szk_interp_pass {
     int N, dir, interp_id, old_api, subpass, radius;

@@ -151,3 +151,32 @@ def test_vector_and_scalar_level1_kernels_agree(VEC_SHAPE):
     for k in (1,):
         assert sizes[0] == sizes[k] and torch.equal(pl[0][:sizes[0]], pl[k][:sizes[k]])
         assert bool(((outs[0] == outs[k]) | (outs[0].isnan() & outs[k].isnan())).all())
+
+
+@pytest.mark.parametrize("dtype,eb", [(np.float32, 1e-6), (np.float64, 1e-6)])
+def test_histogram_tail_passes_change_nothing(dtype, eb):
+    """tight bound: the interpolation codes spread over the whole alphabet. Debug flag 4096 forces the histogram pass with
+    the 16384-bin tier plus the three windowed tail passes (normally a per-context choice from the previous call's counts):
+    the payload must be the same bytes as with the plain pass. (Noise of 5000 quantisation steps: a tenth of the codes lie
+    beyond +-8192, none beyond the quantiser's range - lists of more than 32768 unpredictable values are not sorted.)"""
+    a = field3d((96, 80, 128), dtype, sigma=5e-3)
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_INTERP
+    conf.absErrorBound = eb
+    res = []
+    try:
+        for flag in (0, 4096):
+            sz3_amd.lib().sz3hip_debug_flags(flag)
+            dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+            cap = dc.payload_bound(a.size, worst_case=True)
+            pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+            size = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+            torch.cuda.synchronize()
+            res.append(pl[:size].clone())
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(0)
+    assert res[0].numel() == res[1].numel() and torch.equal(res[0], res[1])
+    st = dc.stats()
+    assert st["n_value_outliers"] < 32768 and st["max_code_len"] > 12  # (the spread is real: thousands of distinct symbols)

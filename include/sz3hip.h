@@ -168,7 +168,12 @@ int sz3hip_get_stage_times(sz3hip_ctx *ctx, const char **names, float *ms, int m
 int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, uint64_t n);
 /* test hook: non-zero routes every shape through the generic (any-shape) stage-1 kernel instead of the tuned one */
 void sz3hip_debug_force_generic(int on);
-/* ablation switches of the stage-1 kernel for tools/k1_lab.py (results are wrong when non-zero) */
+/* development switches (bit mask, process-wide; 0 = product behaviour). Bits 1..16: ablations of the stage-1 kernel for
+ * tools/k1_lab.py - results are WRONG. The others force one of two equivalent paths, results unchanged (tests compare them):
+ * 32 no marching kernel, 64 no one-byte codes, 128 interpolation without the 8-wide level-1 kernels, 256 no stage-1
+ * specialisation by code width, 512 decoder without the fused x prefix sum, 1024 code book without the two-class
+ * construction, 4096 stage 1 without the XCD-aware task order, 8192 interpolation histogram with the large tier and the
+ * windowed tail passes */
 void sz3hip_debug_flags(int flags);
 
 #ifdef __cplusplus

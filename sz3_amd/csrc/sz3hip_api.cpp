@@ -643,8 +643,8 @@ static int stage1_interp(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
     ip.vout_val = ctx->d_vout_val;
     ip.out_cap = ctx->cur_out_cap;
     ip.hist_big = (uint32_t)ctx->hist_big;
-    ip.hist_tail = ctx->hist_tail > 0 || (szk_dbg_flags & 4096) ? 1u : 0u;
-    if (szk_dbg_flags & 4096) ip.hist_big = 1;  // (test hook: large tier + tail passes whatever the history)
+    ip.hist_tail = ctx->hist_tail > 0 || (szk_dbg_flags & 8192) ? 1u : 0u;
+    if (szk_dbg_flags & 8192) ip.hist_big = 1;  // (test hook: large tier + tail passes whatever the history)
     ip.far_cnt = reinterpret_cast<uint32_t *>(ctx->d_counters + 6);  // (zeroed with the counters, fetched with the probe words)
     prof_begin(ctx, ST_K1, s);
     int rci = szk_launch_interp_compress(ctx->dtype, &ip, ctx->copy_ahead ? nullptr : d_in, ctx->d_work, ctx->d_codes, ctx->d_hist, s);

@@ -155,7 +155,7 @@ def test_vector_and_scalar_level1_kernels_agree(VEC_SHAPE):
 
 @pytest.mark.parametrize("dtype,eb", [(np.float32, 1e-6), (np.float64, 1e-6)])
 def test_histogram_tail_passes_change_nothing(dtype, eb):
-    """tight bound: the interpolation codes spread over the whole alphabet. Debug flag 4096 forces the histogram pass with
+    """tight bound: the interpolation codes spread over the whole alphabet. Debug flag 8192 forces the histogram pass with
     the 16384-bin tier plus the three windowed tail passes (normally a per-context choice from the previous call's counts):
     the payload must be the same bytes as with the plain pass. (Noise of 5000 quantisation steps: a tenth of the codes lie
     beyond +-8192, none beyond the quantiser's range - lists of more than 32768 unpredictable values are not sorted.)"""
@@ -167,7 +167,7 @@ def test_histogram_tail_passes_change_nothing(dtype, eb):
     conf.absErrorBound = eb
     res = []
     try:
-        for flag in (0, 4096):
+        for flag in (0, 8192):
             sz3_amd.lib().sz3hip_debug_flags(flag)
             dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
             cap = dc.payload_bound(a.size, worst_case=True)

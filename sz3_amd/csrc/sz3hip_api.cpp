@@ -1063,6 +1063,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
     if (!ctx->stage1_done) return fail(SZ3HIP_EINVAL, "stage2 called before stage1");
+    if (ctx->stage2_done) return fail(SZ3HIP_EINVAL, "stage2 called twice for one stage1 (finish the call first)");
     const uint64_t n = ctx->proto.n;
     if (cap < payload_bound_n(n, std::max<uint64_t>(ctx->out_cap, ctx->cur_out_cap)))
         return fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");

@@ -331,3 +331,25 @@ def test_payload_does_not_depend_on_the_context_history():
     p_rough_fresh = run(sz3_amd.DeviceCompressor(smooth.size, smooth.dtype), rough, 1e-5)
     assert p_rough_1 == p_rough_2 == p_rough_fresh
     assert p_smooth_used == p_smooth_used2 == p_smooth_fresh
+
+
+def test_stage_calls_out_of_order_are_refused():
+    """stage2 needs a stage1, and only one stage2 per stage1 (the code book's range words are accumulated by atomics)"""
+    a = field3d((32, 32, 64))
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    cap = dc.payload_bound(a.size)
+    pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.absErrorBound = 1e-3
+    with pytest.raises(sz3_amd.SZ3HipError):
+        dc.stage2(pl.data_ptr(), cap, 0)
+    dc.stage1(conf, t.data_ptr(), 0)
+    dc.stage2(pl.data_ptr(), cap, 0)
+    with pytest.raises(sz3_amd.SZ3HipError):
+        dc.stage2(pl.data_ptr(), cap, 0)
+    size = dc.finish(0)
+    ref = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)  # the whole call again: same payload size
+    assert size == ref

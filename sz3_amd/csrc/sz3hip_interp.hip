@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void k_interp_first_dec(T *__restrict__ w, con
 // (every code outside the tier is a global atomic); *far_cnt receives the number of codes outside +-4096 in either form, from
 // which the host picks the form of the context's next call
 template <typename T, bool SMALLR, bool BIGW>  // SMALLR: radius <= IH_WIN / 2, code 0 would fall inside the window
-__global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__ codes, uint64_t n, int radius,
+__global__ __launch_bounds__(BIGW ? 1024 : 256) void k_hist_codes(const uint16_t *__restrict__ codes, uint64_t n, int radius,
                                                     uint64_t *__restrict__ hist, const T *__restrict__ work,
                                                     uint64_t *__restrict__ n_vout, uint64_t *__restrict__ vout_idx,
                                                     T *__restrict__ vout_val, uint64_t out_cap, uint32_t *__restrict__ far_cnt,
@@ -464,9 +464,10 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
     __shared__ uint32_t s_far, s_far2;
     uint32_t my_far = 0;  // codes beyond the plain tier (global atomics)
     uint32_t my_far2 = 0; // codes beyond this form's second tier
-    __shared__ uint64_t s_oq[4][IH_OQ];
-    for (int i = threadIdx.x; i < IH_WIN * 4; i += 256) lh[i] = 0;
-    for (uint32_t i = threadIdx.x; i < WWIN; i += 256) lw[i] = 0;
+    constexpr uint32_t NT = BIGW ? 1024 : 256;  // the large tier leaves room for one workgroup per CU: a big one
+    __shared__ uint64_t s_oq[NT / 64][IH_OQ];
+    for (int i = threadIdx.x; i < IH_WIN * 4; i += NT) lh[i] = 0;
+    for (uint32_t i = threadIdx.x; i < WWIN; i += NT) lw[i] = 0;
     if (threadIdx.x < 4) l_zero[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_far = s_far2 = 0;
     __syncthreads();
@@ -495,10 +496,10 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
         }
         oq_n = 0;
     };
-    const uint64_t nth = (uint64_t)gridDim.x * 256;
+    const uint64_t nth = (uint64_t)gridDim.x * NT;
     // (lanes may leave the loop one iteration apart: the queue level is re-read from the first active lane before use)
     // the next iteration's 8 codes are requested before this iteration's are counted (clamped address, never conditional)
-    const uint64_t i_first = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    const uint64_t i_first = ((uint64_t)blockIdx.x * NT + threadIdx.x) * 8;
     const uint64_t last8 = n >= 8 ? n - 8 : 0;
     uint4 nxt = make_uint4(0, 0, 0, 0);
     if (n >= 8) nxt = *reinterpret_cast<const uint4 *>(codes + (i_first < last8 ? i_first : last8));
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
         const uint32_t z = l_zero[0] + l_zero[1] + l_zero[2] + l_zero[3];
         if (z) atomicAdd((unsigned long long *)&hist[0], (unsigned long long)z);
     }
-    for (uint32_t b = threadIdx.x; b < WWIN; b += 256) {
+    for (uint32_t b = threadIdx.x; b < WWIN; b += NT) {
         const uint32_t v = lw[b];
         const uint32_t sym = wide_lo + b;
         if (v && sym < SZH_HIST_BINS) atomicAdd((unsigned long long *)&hist[sym], (unsigned long long)v);
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(256) void k_hist_codes(const uint16_t *__restrict__
     __syncthreads();
     if (threadIdx.x == 0 && s_far) atomicAdd(far_cnt, s_far);
     if (threadIdx.x == 0 && BIGW && s_far2) atomicAdd(far_cnt + 1, s_far2);
-    for (int b = threadIdx.x; b < IH_WIN; b += 256) {
+    for (int b = threadIdx.x; b < IH_WIN; b += NT) {
         const uint32_t s = lh[b * 4] + lh[b * 4 + 1] + lh[b * 4 + 2] + lh[b * 4 + 3];
         const int sym = (int)win_lo + b;
         if (s && sym >= 0 && sym < (int)SZH_HIST_BINS) atomicAdd((unsigned long long *)&hist[sym], (unsigned long long)s);
@@ -820,7 +821,7 @@ int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const voi
 #define SZK_HIST_LAUNCH(T, SR)                                                                                                    \
     do {                                                                                                                          \
         if (ip->hist_big)                                                                                                         \
-            hipLaunchKernelGGL((k_hist_codes<T, SR, true>), dim3(256), dim3(256), 0, s, codes, num, ip->radius, hist, (const T *)d_work, \
+            hipLaunchKernelGGL((k_hist_codes<T, SR, true>), dim3(256), dim3(1024), 0, s, codes, num, ip->radius, hist, (const T *)d_work, \
                                ip->n_vout, ip->vout_idx, (T *)ip->vout_val, ip->out_cap, ip->far_cnt, tails ? 1u : 0u);           \
         else                                                                                                                      \
             hipLaunchKernelGGL((k_hist_codes<T, SR, false>), dim3(768), dim3(256), 0, s, codes, num, ip->radius, hist, (const T *)d_work, \

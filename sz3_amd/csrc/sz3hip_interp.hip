@@ -263,25 +263,30 @@ __device__ __forceinline__ T old_rule(uint64_t i, uint64_t n, T m5, T m3, T m1, 
     return ip_quad_3<T>(m5, m3, m1);
 }
 // OLD: the case rules of the 1-D / 2-D interface (same block structure, different boundary formulas)
-template <typename T, bool DEC, bool XDIR, bool OLD = false>
+// IT: type of the thread-index arithmetic (u32 when the pass has fewer than 2^32 groups: a 64-bit division costs ~100
+// instructions, and the three of them were most of the pass along x's instruction count)
+template <typename T, bool DEC, bool XDIR, bool OLD = false, typename IT = uint64_t>
 __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
     const int N = p.N;
-    const uint64_t dx = p.dims[N - 1], xg = (dx + 7) / 8;  // dx is a multiple of 4: the last group of a row may hold 4 elements
+    const uint64_t dx = p.dims[N - 1];  // dx is a multiple of 4: the last group of a row may hold 4 elements
+    const IT xg = (IT)((dx + 7) / 8);
     const uint64_t t0 = (uint64_t)xcd_block() * 256 + threadIdx.x;
     const bool valid = t0 < p.total;  // total = rows * xg here
-    const uint64_t t = valid ? t0 : 0;
-    const uint64_t tx = t % xg;
-    uint64_t r = t / xg, idx = 0, cd = 0;
+    const IT t = valid ? (IT)t0 : (IT)0;
+    const IT tx = t % xg;
+    IT r = t / xg;
+    uint64_t idx = 0, cd = 0;
 #pragma unroll
     for (int j = 2; j >= 0; j--) {
         if (j >= N - 1) continue;
-        const uint64_t q = r % p.cnt[j];
-        r /= p.cnt[j];
-        const uint64_t c = p.start[j] + q * p.step[j];
+        const IT cj = (IT)p.cnt[j];
+        const IT q = r % cj;
+        r /= cj;
+        const uint64_t c = p.start[j] + (uint64_t)q * p.step[j];
         idx += c * p.off[j];
         if (j == p.dir) cd = c;
     }
-    const uint64_t x0 = tx * 8;
+    const uint64_t x0 = (uint64_t)tx * 8;
     const bool full = x0 + 8 <= dx;  // else 4 valid elements: the upper halves below are dummies, never stored
     idx += x0;
     T o[8];
@@ -371,14 +376,15 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) win[4 + k] = o[k];
+        // the 8 elements lie in one block of 32 (x0 is a multiple of 8): its bounds once, in 32 bits (dx < 2^31 here)
+        const uint32_t xb = (uint32_t)x0 & ~31u;
+        uint32_t xe = xb + 32;
+        if (xe > (uint32_t)dx - 1) xe = (uint32_t)dx - 1;
+        const uint32_t n = xe - xb + 1, i0 = (uint32_t)x0 - xb;
 #pragma unroll
         for (int e = 1; e < 8; e += 2) {
             if (!full && e >= 4) continue;
-            const uint64_t cx = x0 + e;
-            const uint64_t begin = (cx / 32) * 32;
-            uint64_t end = begin + 32;
-            if (end > dx - 1) end = dx - 1;
-            const uint64_t n = end - begin + 1, i = cx - begin;
+            const uint32_t i = i0 + e;
             const T m3 = win[4 + e - 3], m1 = win[4 + e - 1], p1 = win[4 + e + 1], p3 = win[4 + e + 3];
             T pred;
             if (OLD) {
@@ -777,7 +783,7 @@ static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStr
     for (const szk_interp_pass &p : sched) {
         const uint32_t nb = (uint32_t)((p.total + 255) / 256);
         const uint64_t dxl = p.dims[p.N - 1];
-        const bool vec = p.kind == 2 && nbatch == 1 && p.interp_id == 1 && p.s == 1 && dxl % 4 == 0 && dxl >= 16 &&
+        const bool vec = p.kind == 2 && nbatch == 1 && p.interp_id == 1 && p.s == 1 && dxl % 4 == 0 && dxl >= 16 && dxl < (1ull << 31) &&
                          (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (reinterpret_cast<uintptr_t>(codes) & 15) == 0 && !szk_interp_novec;
         if (vec) {
             szk_interp_pass q = p;
@@ -787,11 +793,18 @@ static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStr
             const uint64_t vb = (q.total + 255) / 256;
             if (vb > 0x7FFFFFFFull) return -1;
             const dim3 g((uint32_t)vb), b(256);
+            const bool small = q.total <= 0xFFFFFFFFull;  // (then every count of the decomposition fits 32 bits too)
+#define SZK_VEC_LAUNCH(XD, OL)                                                                                             \
+    do {                                                                                                                   \
+        if (small) hipLaunchKernelGGL((k_interp_vec<T, DEC, XD, OL, uint32_t>), g, b, 0, s, w, codes, q);                   \
+        else hipLaunchKernelGGL((k_interp_vec<T, DEC, XD, OL, uint64_t>), g, b, 0, s, w, codes, q);                         \
+    } while (0)
             if (p.old_api) {
-                if (p.dir == p.N - 1) hipLaunchKernelGGL((k_interp_vec<T, DEC, true, true>), g, b, 0, s, w, codes, q);
-                else hipLaunchKernelGGL((k_interp_vec<T, DEC, false, true>), g, b, 0, s, w, codes, q);
-            } else if (p.dir == p.N - 1) hipLaunchKernelGGL((k_interp_vec<T, DEC, true>), g, b, 0, s, w, codes, q);
-            else hipLaunchKernelGGL((k_interp_vec<T, DEC, false>), g, b, 0, s, w, codes, q);
+                if (p.dir == p.N - 1) SZK_VEC_LAUNCH(true, true);
+                else SZK_VEC_LAUNCH(false, true);
+            } else if (p.dir == p.N - 1) SZK_VEC_LAUNCH(true, false);
+            else SZK_VEC_LAUNCH(false, false);
+#undef SZK_VEC_LAUNCH
         } else if (p.kind == 2) {
             hipLaunchKernelGGL((k_interp_pass<T, DEC>), dim3(nb, nbatch), dim3(256), 0, s, w, codes, p);
         } else if (DEC) {

@@ -166,7 +166,8 @@ def main():
         achieved = algo_bytes / (k1_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and args.algo == "lorenzo":
+        # (the committed PMC passes are of the default workload only: C2, f32 512^3, Lorenzo, 1e-3)
+        if os.path.exists(tpath) and args.algo == "lorenzo" and args.dtype == "f32" and tuple(shape) == (512, 512, 512) and eb == 1e-3:
             try:
                 traffic = json.load(open(tpath)).get("lorenzo_quant_hist_hbm_bytes_per_launch")
             except Exception:

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void k_interp_first_dec(T *__restrict__ w, con
 // (every code outside the tier is a global atomic); *far_cnt receives the number of codes outside +-4096 in either form, from
 // which the host picks the form of the context's next call
 template <typename T, bool SMALLR, bool BIGW>  // SMALLR: radius <= IH_WIN / 2, code 0 would fall inside the window
-__global__ __launch_bounds__(BIGW ? 1024 : 256) void k_hist_codes(const uint16_t *__restrict__ codes, uint64_t n, int radius,
+__global__ __launch_bounds__(BIGW ? 1024 : 512) void k_hist_codes(const uint16_t *__restrict__ codes, uint64_t n, int radius,
                                                     uint64_t *__restrict__ hist, const T *__restrict__ work,
                                                     uint64_t *__restrict__ n_vout, uint64_t *__restrict__ vout_idx,
                                                     T *__restrict__ vout_val, uint64_t out_cap, uint32_t *__restrict__ far_cnt,
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(BIGW ? 1024 : 256) void k_hist_codes(const uint16_t
     __shared__ uint32_t s_far, s_far2;
     uint32_t my_far = 0;  // codes beyond the plain tier (global atomics)
     uint32_t my_far2 = 0; // codes beyond this form's second tier
-    constexpr uint32_t NT = BIGW ? 1024 : 256;  // the large tier leaves room for one workgroup per CU: a big one
+    constexpr uint32_t NT = BIGW ? 1024 : 512;  // the large tier leaves room for one workgroup per CU (a big one), the plain one for two
     __shared__ uint64_t s_oq[NT / 64][IH_OQ];
     for (int i = threadIdx.x; i < IH_WIN * 4; i += NT) lh[i] = 0;
     for (uint32_t i = threadIdx.x; i < WWIN; i += NT) lw[i] = 0;
@@ -837,7 +837,7 @@ int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const voi
             hipLaunchKernelGGL((k_hist_codes<T, SR, true>), dim3(256), dim3(1024), 0, s, codes, num, ip->radius, hist, (const T *)d_work, \
                                ip->n_vout, ip->vout_idx, (T *)ip->vout_val, ip->out_cap, ip->far_cnt, tails ? 1u : 0u);           \
         else                                                                                                                      \
-            hipLaunchKernelGGL((k_hist_codes<T, SR, false>), dim3(768), dim3(256), 0, s, codes, num, ip->radius, hist, (const T *)d_work, \
+            hipLaunchKernelGGL((k_hist_codes<T, SR, false>), dim3(512), dim3(512), 0, s, codes, num, ip->radius, hist, (const T *)d_work, \
                                ip->n_vout, ip->vout_idx, (T *)ip->vout_val, ip->out_cap, ip->far_cnt, 0u);                        \
     } while (0)
     if (dtype == 0) {

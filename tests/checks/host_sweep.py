@@ -52,7 +52,10 @@ for k in range(int(os.environ.get("N", "40"))):
         ok = ok and err <= bound * tol
     elif mode == sz3_amd.EB_PSNR:
         mse = float(np.mean((df[fin] - af[fin]) ** 2)); psnr = 20 * np.log10(rngv) - 10 * np.log10(mse) if mse > 0 and rngv > 0 else np.inf
-        ok = ok and psnr >= conf.psnrErrorBound - 0.5
+        # the reference turns the PSNR target into abs eb = sqrt(3) * range * 10^(-psnr/20) (uniform-error assumption,
+        # utils/Statistic.hpp): what |err| <= eb guarantees is psnr >= target - 20 log10(sqrt 3) = target - 4.77 dB (all errors
+        # at the bound); coarse quantisation of a small smooth field gets close to that (seed 32, case 33: -1.x dB)
+        ok = ok and psnr >= conf.psnrErrorBound - 4.8
     else:
         l2 = float(np.sqrt(np.sum((df[fin] - af[fin]) ** 2)))
         ok = ok and l2 <= conf.l2normErrorBound * 1.1  # (the reference's bound sqrt(3/n) * l2 holds in expectation: uniform errors)

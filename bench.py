@@ -4,19 +4,28 @@
 Workload at N=1 (BASELINE.json configs[1], "C2"): 3-D float32 512x512x512 synthetic field, Lorenzo predictor,
 abs errBound 1e-3.  A "step" is one pass of the hot path over that volume with the input already resident in HBM:
     stage1 (prequantise + integer Lorenzo + code emission + outlier capture + histogram)
-    [N>1: RCCL all-reduce(sum) of the 65536 x u64 code histogram — the path's only exchange, SURVEY.md 8e]
+    [N>1: RCCL all-reduce(sum) of the 65536 x u64 code histogram, issued by the library itself
+          (sz3hip_comm_allreduce_histogram, csrc/sz3hip_comm.cpp) on the compress stream — the path's only exchange]
     stage2 (canonical Huffman codebook, chunked bit-pack, payload assembly)  -> payload resident in HBM
     finish (stream sync + payload size to the host)
 N>1 = weak scaling: every rank compresses its own 512^3 slab of an (N*512) x 512 x 512 volume (slabs are independent
 like the reference's SZ_compress_OMP slabs, api/impl/SZImplOMP.hpp:48-55), value = total bytes of all ranks / time.
+One process per GPU: under a launcher (torchrun sets WORLD_SIZE) this process is one rank; started plainly with
+--gpus N > 1 it re-launches itself as N ranks (python -m torch.distributed.run, 127.0.0.1). The ranks' RCCL
+communicator lives in the library (ncclCommInitRank with rank 0's id shipped over the launcher's process group) and the
+bench asserts that RCCL reports N ranks.
 
-Printed JSON line (rank 0): the driver contract + "roofline" (dominant kernel, live HIP-event timing) +
-"cpu_baseline" (the reference itself from oracle/_ref when present, else the oracle port; rank 0, N=1 only) +
-informational extras (ratio, per-stage ms, host end-to-end incl. PCIe and zstd — never `value`).
+Printed JSON line (rank 0): the driver contract + "roofline" (dominant kernel against ITS compulsory bytes, live
+HIP-event timing; "roofline_path" = the whole path's algorithmic bytes over the whole step) + "cpu_baseline" (the
+reference itself from oracle/_ref when present, else the oracle port; one thread AND all host cores through the
+reference's OpenMP slab path; rank 0, N=1 only) + "extra_configs" (C3 = ALGO_INTERP_LORENZO at 1e-4, same protocol,
+fewer steps) + informational extras (ratio, per-stage ms, host end-to-end incl. PCIe and zstd — never `value`).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,7 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -43,135 +52,256 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="f64 + --shape 128,1024,1024 --eb 1e-6 = C4's per-GPU slab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-e2e", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs (C3) leg")
+    return ap.parse_args()
+
+
+def relaunch_as_ranks(n):
+    """no launcher around us and --gpus N > 1: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+class Workload:
+    """one configuration, device resident: input tensor, context, payload buffer; step() = one pass of the hot path"""
+
+    def __init__(self, torch, sz3_amd, dev, local_rank, rank, shape, dtype, algo, eb, comm=None, dist=None):
+        from fields import field3d
+        self.torch, self.sz = torch, sz3_amd
+        self.shape, self.algo, self.eb, self.dtype = shape, algo, eb, dtype
+        self.npdt = np.float32 if dtype == "f32" else np.float64
+        self.esz = 4 if dtype == "f32" else 8
+        self.n = int(np.prod(shape))
+        # every rank: its own slab of the same analytic field family (different noise seed per rank)
+        self.a = field3d(shape, self.npdt, seed=20260928 + rank) if dtype == "f32" else field3d(shape, self.npdt, seed=20260928 + rank, sigma=2e-6)
+        self.d_in = torch.from_numpy(self.a).to(dev)
+        conf = sz3_amd.Config(*shape)
+        conf.cmprAlgo = {"lorenzo": sz3_amd.ALGO_LORENZO_REG, "interp": sz3_amd.ALGO_INTERP_LORENZO, "interp-notune": sz3_amd.ALGO_INTERP}[algo]
+        conf.lorenzo, conf.lorenzo2, conf.regression = 1, 0, 0
+        conf.errorBoundMode = sz3_amd.EB_ABS
+        conf.absErrorBound = eb
+        self.conf = conf
+        self.dc = sz3_amd.DeviceCompressor(self.n, self.npdt, device=local_rank)
+        self.cap = self.dc.payload_bound(self.n)
+        self.d_payload = torch.empty(self.cap, dtype=torch.uint8, device=dev)
+        self.comm, self.dist = comm, dist
+        self.hist = None
+        if comm is None and dist is not None:  # ranks sharing one GPU (SZ3_BENCH_ONE_GPU): gloo reduces a caller-owned histogram
+            self.hist = torch.zeros(65536, dtype=torch.int64, device=dev)
+            self.dc.set_histogram(self.hist.data_ptr())
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def step(self):
+        dc = self.dc
+        dc.stage1(self.conf, self.d_in.data_ptr(), self.stream)
+        if self.comm is not None:
+            self.comm.allreduce_histogram([dc], [self.stream])
+        elif self.hist is not None:
+            self.dist.all_reduce(self.hist, op=self.dist.ReduceOp.SUM)
+        dc.stage2(self.d_payload.data_ptr(), self.cap, self.stream)
+        return dc.finish(self.stream)
+
+    def stage_profile(self, reps=10):
+        """per-stage kernel time, HIP events on the launch stream (outside the timed loop)"""
+        self.dc.set_profiling(True)
+        acc = {}
+        for _ in range(reps):
+            self.step()
+            for k, v in self.dc.stage_times().items():
+                acc[k] = acc.get(k, 0.0) + v / reps
+        self.dc.set_profiling(False)
+        return acc
+
+    def verify_and_time_decode(self, psize):
+        torch = self.torch
+        d_out = torch.empty_like(self.d_in)
+        self.dc.decompress(self.d_payload.data_ptr(), psize, d_out.data_ptr(), self.stream)
+        torch.cuda.synchronize()
+        max_err = float((d_out.double() - self.d_in.double()).abs().max().item())
+        t0 = time.perf_counter()
+        for _ in range(5):
+            self.dc.decompress(self.d_payload.data_ptr(), psize, d_out.data_ptr(), self.stream)
+        torch.cuda.synchronize()
+        return max_err, (time.perf_counter() - t0) / 5 * 1e3
+
+
+def rooflines(w, acc, psize, ms_per_step, traffic_key):
+    """the dominant kernel against ITS compulsory bytes; the whole path's algorithmic bytes over the whole step"""
+    raw = w.n * w.esz
+    out = {}
+    k1_ms = acc.get("k1_kernel", acc.get("lorenzo_quant_hist", float("nan")))
+    kernels_ms = sum(acc.get(k, 0.0) for k in ("tuner", "lorenzo_quant_hist", "codebook", "encode", "assemble"))
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if traffic_key and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(traffic_key)
+        except Exception:
+            traffic = None
+    if w.algo == "lorenzo":
+        stats = w.dc.stats()
+        code_bytes = 1 if stats.get("narrow_codes") else 2
+        k_bytes = w.n * (w.esz + code_bytes)  # the predictor kernel reads the array once and writes one code per element
+        kname = ("k_lorenzo_quant_march (HIP events around its launch)" if "k1_kernel" in acc else "k_lorenzo_quant (stage lorenzo_quant_hist)")
+        note = "read sizeof(T) + write %d B of codes per element" % code_bytes
+    else:
+        k_bytes = w.n * (2 * w.esz + 2)  # working copy in + reconstruction out + one 2-byte code per point, each once
+        kname = "stage 1 = copy + interpolation passes + code histogram (a multi-kernel stage: see profiles/)"
+        note = "read sizeof(T) + write sizeof(T) of reconstruction + 2 B of codes per element, each once"
+    ach = k_bytes / (k1_ms * 1e-3) / 1e9
+    out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "compulsory_bytes_per_launch": int(k_bytes),
+                       "bytes_note": note, "kernel_ms": round(k1_ms, 4)}
+    algo_bytes = raw + psize  # SURVEY.md 8d: read sizeof(T) + write sizeof(T)/ratio per element
+    pach = algo_bytes / (ms_per_step * 1e-3) / 1e9
+    out["roofline_path"] = {"bound": "hbm", "what": "whole step (all kernels + launch gaps + the final sync), algorithmic bytes = input + payload",
+                            "achieved": round(pach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pach / HBM_PEAK_GBS, 4),
+                            "algorithmic_bytes_per_step": int(algo_bytes)}
+    out["kernels_ms"] = round(kernels_ms, 4)
+    out["frac_read_peak_all_kernels"] = round(raw / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return out
+
+
+def cpu_baseline(w):
+    """the reference's CPU path on this box's host cores (checker code, never the product): one thread, and all cores
+    through its OpenMP slab path (SZ_compress_OMP, api/impl/SZImplOMP.hpp:16-117) in a child process so that
+    OMP_NUM_THREADS takes effect"""
+    from oracle_binding import have_ref, make_config, oracle_compress, ref_compress
+    from oracle_binding import ALGO_INTERP as O_INTERP
+    from oracle_binding import ALGO_INTERP_LORENZO as O_TUNED
+    shape, eb, algo = w.shape, w.eb, w.algo
+    raw = w.n * w.esz
+
+    def oconf(openmp):
+        return (make_config(shape, abs_eb=eb, lorenzo=True, regression=False, openmp=openmp) if algo == "lorenzo" else
+                make_config(shape, algo=O_TUNED if algo == "interp" else O_INTERP, abs_eb=eb, regression=True, openmp=openmp))
+    if have_ref():
+        blob, sec = ref_compress(w.a, oconf(False), timing=True)
+        kind = "reference"
+    else:
+        t0 = time.perf_counter()
+        blob = oracle_compress(w.a, oconf(False))
+        sec = time.perf_counter() - t0
+        kind = "port"
+    what = {"lorenzo": "ALGO_LORENZO_REG (Lorenzo only)", "interp": "ALGO_INTERP_LORENZO (default)", "interp-notune": "ALGO_INTERP (cubic)"}[algo]
+    out = {"value": round(raw / sec / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
+           "sample": "whole %dx%dx%d volume, SZ_compress<T> %s abs %g, single thread, %.2f s" % (shape[0], shape[1], shape[2], what, eb, sec),
+           "ratio": round(raw / float(len(blob)), 4), "host_cpus": os.cpu_count()}
+    if have_ref():
+        try:
+            import psutil
+            phys = psutil.cpu_count(logical=False) or os.cpu_count()
+        except Exception:
+            phys = os.cpu_count()
+        threads = int(min(phys, shape[0]))
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="spread")
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "ref_all_cores.py"), ",".join(str(v) for v in shape),
+                                w.dtype, algo, repr(eb)], env=env, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            m = json.loads(line)
+            out["all_cores"] = {"value": round(raw / m["sec"] / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "reference",
+                                "sample": "same volume, conf.openmp = true (SZ_compress_OMP: %d slabs, one per thread), OMP_NUM_THREADS=%d "
+                                          "(physical cores, capped at dims[0]), best of 2, %.3f s" % (threads, threads, m["sec"]),
+                                "ratio": round(raw / float(m["bytes"]), 4)}
+        except Exception as e:  # noqa: BLE001 - a missing all-cores leg must not lose the bench line
+            out["all_cores"] = {"error": repr(e)[:200]}
+    return out
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        relaunch_as_ranks(args.gpus)
 
     import torch
     import sz3_amd
-    from fields import field3d
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the hot path has no CPU implementation)")
-    # SZ3_BENCH_ONE_GPU=1 (testing the multi-rank code path on a 1-GPU box): every rank uses cuda:0 and gloo instead of RCCL
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE); refusing to print a line for "
+                         "another GPU count than asked" % (args.gpus, world))
+    # SZ3_BENCH_ONE_GPU=1 (testing the multi-rank code path on a 1-GPU box): every rank uses cuda:0; RCCL cannot put two
+    # ranks on one device, so the histogram goes through gloo there (the line says so)
     one_gpu = os.environ.get("SZ3_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
+    elif world > torch.cuda.device_count():
+        raise SystemExit("bench.py: %d ranks but %d visible GPUs" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    comm = None
+    exchange = "none (one rank)"
     if world > 1:
         import torch.distributed as dist
+        from sz3_amd import distributed as D
         if one_gpu:
             dist.init_process_group(backend="gloo")
+            exchange = "gloo all_reduce (SZ3_BENCH_ONE_GPU: ranks share one GPU, RCCL needs one GPU per rank)"
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-    if args.gpus != world and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+            dist.init_process_group(backend="nccl", device_id=dev)  # the launcher's own group: barrier + max-over-ranks timing
+            comm = D.init_comm(dist, local_rank)
+            seen = comm.size
+            if seen != world:
+                raise SystemExit("bench.py: RCCL reports %d ranks, expected %d" % (seen, world))
+            exchange = "RCCL ncclAllReduce(u64[65536], sum) inside libsz3hip.so, %d ranks" % seen
 
     S = args.size
     shape = tuple(int(v) for v in args.shape.split(",")) if args.shape else (S, S, S)
-    n = int(np.prod(shape))
-    eb = args.eb
-    npdt = np.float32 if args.dtype == "f32" else np.float64
-    esz = 4 if args.dtype == "f32" else 8
-    # every rank: its own slab of the same analytic field family (different noise seed per rank)
-    a = field3d(shape, npdt, seed=20260928 + rank) if args.dtype == "f32" else field3d(shape, npdt, seed=20260928 + rank, sigma=2e-6)
-    d_in = torch.from_numpy(a).to(dev)
-    conf = sz3_amd.Config(*shape)
-    conf.cmprAlgo = {"lorenzo": sz3_amd.ALGO_LORENZO_REG, "interp": sz3_amd.ALGO_INTERP_LORENZO,
-                     "interp-notune": sz3_amd.ALGO_INTERP}[args.algo]
-    conf.lorenzo, conf.lorenzo2, conf.regression = 1, 0, 0
-    conf.errorBoundMode = sz3_amd.EB_ABS
-    conf.absErrorBound = eb
-
-    dc = sz3_amd.DeviceCompressor(n, npdt, device=local_rank)
-    cap = dc.payload_bound(n)
-    d_payload = torch.empty(cap, dtype=torch.uint8, device=dev)
-    hist = torch.zeros(65536, dtype=torch.int64, device=dev)  # caller-owned histogram so RCCL can reduce it in place
-    dc.set_histogram(hist.data_ptr())
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        dc.stage1(conf, d_in.data_ptr(), stream)
-        if world > 1:
-            dist.all_reduce(hist, op=dist.ReduceOp.SUM)
-        dc.stage2(d_payload.data_ptr(), cap, stream)
-        return dc.finish(stream)
-
-    for _ in range(args.warmup):
-        psize = step()
+    w = Workload(torch, sz3_amd, dev, local_rank, rank, shape, args.dtype, args.algo, args.eb, comm=comm, dist=dist if world > 1 else None)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        psize = step()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    def timed(wl, steps, warmup):
+        for _ in range(warmup):
+            ps = wl.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ps = wl.step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return el, ps
+
+    elapsed, psize = timed(w, args.steps, args.warmup)
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev if not one_gpu else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
-        ps = torch.tensor([psize], dtype=torch.int64, device=dev)
+        ps = torch.tensor([psize], dtype=torch.int64, device=dev if not one_gpu else "cpu")
         dist.all_reduce(ps, op=dist.ReduceOp.SUM)
         total_payload = int(ps.item())
     else:
         total_payload = psize
     barrier()
 
-    raw_bytes = n * esz
+    raw_bytes = w.n * w.esz
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * raw_bytes / (elapsed / args.steps) / 1e9
     ratio = world * raw_bytes / float(total_payload)
-
-    # ---- per-stage kernel time, measured with HIP events on the launch stream (outside the timed loop) ----
-    dc.set_profiling(True)
-    acc = {}
-    reps = 10
-    for _ in range(reps):
-        step()
-        for k, v in dc.stage_times().items():
-            acc[k] = acc.get(k, 0.0) + v / reps
-    dc.set_profiling(False)
-    stats = dc.stats()
-
-    # ---- correctness gate (outside the timed region): decode on the GPU, strict bound in float64 ----
-    d_out = torch.empty_like(d_in)
-    dc.decompress(d_payload.data_ptr(), psize, d_out.data_ptr(), stream)
-    torch.cuda.synchronize()
-    max_err = float((d_out.double() - d_in.double()).abs().max().item())
-    # device-resident decompression rate (informational)
-    t0 = time.perf_counter()
-    for _ in range(5):
-        dc.decompress(d_payload.data_ptr(), psize, d_out.data_ptr(), stream)
-    torch.cuda.synchronize()
-    dec_ms = (time.perf_counter() - t0) / 5 * 1e3
+    acc = w.stage_profile()
+    stats = w.dc.stats()
+    max_err, dec_ms = w.verify_and_time_decode(psize)
 
     out = None
     if rank == 0:
-        # the dominant kernel by itself (HIP events right around its launch: comparable with the per-kernel average of a
-        # rocprofv3 trace, profiles/r01_kernel_stats.csv); the stage time also holds the probe and the histogram fold
-        k1_ms = acc.get("k1_kernel", acc.get("lorenzo_quant_hist", float("nan")))
-        kernels_ms = sum(acc.get(k, 0.0) for k in ("lorenzo_quant_hist", "codebook", "encode", "assemble"))
-        # algorithmic bytes of the path per element: read sizeof(T) + write sizeof(T)/ratio; the
-        # dominant kernel (K1 lorenzo_quant_hist) is priced against the whole path's compulsory traffic.
-        algo_bytes = raw_bytes * (1.0 + 1.0 / (raw_bytes / float(psize)))
-        achieved = algo_bytes / (k1_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        # (the committed PMC passes are of the default workload only: C2, f32 512^3, Lorenzo, 1e-3)
-        if os.path.exists(tpath) and args.algo == "lorenzo" and args.dtype == "f32" and tuple(shape) == (512, 512, 512) and eb == 1e-3:
-            try:
-                traffic = json.load(open(tpath)).get("lorenzo_quant_hist_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        is_c2 = args.algo == "lorenzo" and args.dtype == "f32" and tuple(shape) == (512, 512, 512) and args.eb == 1e-3
+        is_c3 = args.algo == "interp" and args.dtype == "f32" and tuple(shape) == (512, 512, 512) and args.eb == 1e-4
         out = {
             "metric": "compression throughput GB/s + ratio at fixed abs errBound, 512^3 f32",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -179,68 +309,66 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s: 3D %s %dx%dx%d synthetic field per GPU, %s predictor, abs errBound=%g, "
                                    "device-resident in -> device-resident Huffman payload"
-                                   % (("C2" if args.algo == "lorenzo" else "C3") if args.dtype == "f32" and not args.shape else "custom",
+                                   % ("C2" if is_c2 else "C3" if is_c3 else "custom",
                                       "float32" if args.dtype == "f32" else "float64", shape[0], shape[1], shape[2],
                                       {"lorenzo": "Lorenzo", "interp": "ALGO_INTERP_LORENZO (auto-tuned interpolation)",
-                                       "interp-notune": "interpolation (ALGO_INTERP)"}[args.algo], eb),
-                       "parallelism": "slab%d" % world, "algo": "HIP_LORENZO(16)" if args.algo == "lorenzo" else "HIP_INTERP(17)", "eb": eb},
-            "ratio": round(ratio, 4), "max_abs_err": max_err, "err_bound_ok": bool(max_err <= eb),
+                                       "interp-notune": "interpolation (ALGO_INTERP)"}[args.algo], args.eb),
+                       "parallelism": "slab%d" % world, "algo": "HIP_LORENZO(16)" if args.algo == "lorenzo" else "HIP_INTERP(17)", "eb": args.eb,
+                       "exchange": exchange},
+            "ratio": round(ratio, 4), "max_abs_err": max_err, "err_bound_ok": bool(max_err <= args.eb),
             "payload_bytes_rank0": int(psize),
             "decompress_device": {"ms": round(dec_ms, 4), "gbps": round(raw_bytes / (dec_ms * 1e-3) / 1e9, 2)},
             "outliers": {"value": stats["n_value_outliers"], "delta": stats["n_delta_outliers"]},
             "narrow_codes": stats.get("narrow_codes"),
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
-            "tuner": dc.tuner_report() if args.algo == "interp" else None,
-            "kernels_ms": round(kernels_ms, 4),
-            "frac_read_peak_all_kernels": round(raw_bytes / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "roofline": {"bound": "hbm", "kernel": "k_lorenzo_quant_march (HIP events around its launch)" if "k1_kernel" in acc else
-                         "k_lorenzo_quant (stage lorenzo_quant_hist)" if args.algo == "lorenzo" else
-                         "stage 1 = copy + interpolation passes + code histogram (a multi-kernel stage: see profiles/)",
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(algo_bytes), "kernel_ms": round(k1_ms, 4)},
+            "tuner": w.dc.tuner_report() if args.algo == "interp" else None,
         }
+        out.update(rooflines(w, acc, psize, ms_per_step,
+                             "lorenzo_quant_hist_hbm_bytes_per_launch" if is_c2 else "c3_stage1_hbm_bytes_per_step" if is_c3 else None))
 
     # ---- host end-to-end (PCIe + zstd inclusive; informational) ----
     if rank == 0 and world == 1 and not args.no_host_e2e:
         best_c = best_d = 0.0
         for _ in range(3):  # the first call creates the host API's cached context and pinned staging buffer
             t0 = time.perf_counter()
-            blob, hratio = sz3_amd.compress(a, conf)
+            blob, hratio = sz3_amd.compress(w.a, w.conf)
             t1 = time.perf_counter()
-            dec, _ = sz3_amd.decompress(blob, npdt, shape)
+            dec, _ = sz3_amd.decompress(blob, w.npdt, shape)
             t2 = time.perf_counter()
             best_c = max(best_c, raw_bytes / (t1 - t0) / 1e9)
             best_d = max(best_d, raw_bytes / (t2 - t1) / 1e9)
         out["host_e2e"] = {"compress_gbps": round(best_c, 3), "ratio": round(hratio, 4),
                            "decompress_gbps": round(best_d, 3),
-                           "max_abs_err": float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))),
+                           "max_abs_err": float(np.max(np.abs(dec.astype(np.float64) - w.a.astype(np.float64)))),
                            "note": "host buffer in -> host SZ3 container out: H2D + kernels + D2H + zstd(threads); best of 3 calls"}
+
+    # ---- the other single-GPU configuration of BASELINE.json, same protocol, as an extra object of the same line ----
+    if rank == 0 and world == 1 and not args.no_extra and args.algo == "lorenzo" and args.dtype == "f32" and tuple(shape) == (512, 512, 512):
+        try:
+            w3 = Workload(torch, sz3_amd, dev, local_rank, rank, shape, "f32", "interp", 1e-4)
+            st3 = max(5, args.steps // 2)
+            el3, ps3 = timed(w3, st3, 2)
+            acc3 = w3.stage_profile(5)
+            err3, dec3 = w3.verify_and_time_decode(ps3)
+            ms3 = 1e3 * el3 / st3
+            c3 = {"config": "C3: 3D float32 512x512x512, ALGO_INTERP_LORENZO (sampling tuner + interpolation), abs errBound=1e-4, 1 GPU",
+                  "value": round(raw_bytes / (el3 / st3) / 1e9, 3), "unit": "GB/s", "steps": st3, "ms_per_step": round(ms3, 4),
+                  "ratio": round(raw_bytes / float(ps3), 4), "max_abs_err": err3, "err_bound_ok": bool(err3 <= 1e-4),
+                  "decompress_device": {"ms": round(dec3, 4), "gbps": round(raw_bytes / (dec3 * 1e-3) / 1e9, 2)},
+                  "stage_ms": {k: round(v, 4) for k, v in acc3.items()}, "tuner": w3.dc.tuner_report()}
+            c3.update(rooflines(w3, acc3, ps3, ms3, "c3_stage1_hbm_bytes_per_step"))
+            out["extra_configs"] = {"C3": c3}
+            del w3
+        except Exception as e:  # noqa: BLE001 - the headline line must survive a failing extra
+            out["extra_configs"] = {"C3": {"error": repr(e)[:300]}}
 
     # ---- CPU baseline on this box's host cores (rank 0, N=1 only; checker code, never the product) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle_binding import have_ref, make_config, oracle_compress, ref_compress
-        from oracle_binding import ALGO_INTERP as O_INTERP
-        from oracle_binding import ALGO_INTERP_LORENZO as O_TUNED
-        oconf = (make_config(shape, abs_eb=eb, lorenzo=True, regression=False) if args.algo == "lorenzo" else
-                 make_config(shape, algo=O_TUNED if args.algo == "interp" else O_INTERP, abs_eb=eb, regression=True))
-        # bounded sample: the full volume is ~8 s of single-thread reference work at 512^3; cap at 512^3
-        if have_ref():
-            blob, sec = ref_compress(a, oconf, timing=True)
-            kind = "reference"
-        else:
-            t0 = time.perf_counter()
-            blob = oracle_compress(a, oconf)
-            sec = time.perf_counter() - t0
-            kind = "port"
-        out["cpu_baseline"] = {"value": round(raw_bytes / sec / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
-                               "sample": "whole %dx%dx%d volume, SZ_compress<T> %s abs %g, single thread, %.2f s"
-                                         % (shape[0], shape[1], shape[2], {"lorenzo": "ALGO_LORENZO_REG (Lorenzo only)", "interp": "ALGO_INTERP_LORENZO (default)",
-                                                       "interp-notune": "ALGO_INTERP (cubic)"}[args.algo], eb, sec),
-                               "ratio": round(raw_bytes / float(len(blob)), 4),
-                               "host_cpus": os.cpu_count()}
+        out["cpu_baseline"] = cpu_baseline(w)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -17,6 +17,10 @@
  *  (3) the device-resident API (sz3hip_ctx_*, sz3hip_*_device): input already in HBM, payload left in HBM,
  *      split into stage1 (predict+quantize+histogram) and stage2 (codebook+encode) so that a multi-GPU caller
  *      can all-reduce the histogram between them.
+ *  (4) the multi-GPU exchange (sz3hip_comm_*): an RCCL communicator over xGMI — one process driving all its GPUs
+ *      (what sz3hip_compress does by itself when conf.openmp is set: slabs along dims[0] like SZ_compress_OMP,
+ *      api/impl/SZImplOMP.hpp:16-117) or one process per GPU — with the sum all-reduce of the code histogram and the
+ *      min/max all-reduce of the value range as its two collectives.
  *
  * Error handling: functions returning int return 0 on success, a negative SZ3HIP_E* code otherwise;
  * functions returning size_t return 0 on error. sz3hip_last_error() gives the message (thread-local).
@@ -68,7 +72,8 @@ typedef struct sz3hip_config {
     uint64_t num;
     uint8_t cmprAlgo, errorBoundMode;
     double absErrorBound, relErrorBound, psnrErrorBound, l2normErrorBound;
-    uint8_t openmp; /* here: "slab container" flag — set when the payload holds several independent slabs */
+    uint8_t openmp; /* compress: split dims[0] into one slab per visible GPU (SZ_compress_OMP's slabs, SZImplOMP.hpp:48-55)
+                     * and write the multi-slab container; trailer bit: the payload is that container */
     int32_t quantbinCnt, blockSize;
     uint8_t predDim, dataType;
     uint8_t lorenzo, lorenzo2, regression, regression2;
@@ -87,14 +92,21 @@ void sz3hip_config_init(sz3hip_config *c, int ndims, const uint64_t *dims_slowes
 /* Config::save / Config::load (Config.hpp:312-413); return bytes written / consumed */
 size_t sz3hip_config_save(const sz3hip_config *c, unsigned char *out);
 size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in);
+/* the same over at most `avail` readable bytes: 0 when the serialised Config does not fit in them (truncated stream) */
+size_t sz3hip_config_load_n(sz3hip_config *c, const unsigned char *in, size_t avail);
 /* SZ_compress_size_bound<T> (api/impl/SZImpl.hpp:34-44) */
 size_t sz3hip_compress_bound(const sz3hip_config *c, int dataType);
 /* SZ_compress<T>(conf, data, cmpData, cmpCap) -> size (api/sz.hpp:43); `conf` is not modified (copied, sz.hpp:45).
- * nslabs >= 1 splits dims[0] into independent slabs exactly like SZ_compress_OMP (api/impl/SZImplOMP.hpp:48-55)
- * and stores them in the reference's multi-slab container (SZImplOMP.hpp:100-107). */
+ * conf->openmp (SZ_compress_impl, api/impl/SZImpl.hpp:10-20): dims[0] is split into independent slabs exactly like
+ * SZ_compress_OMP (api/impl/SZImplOMP.hpp:48-55), one per visible GPU (SZ3HIP_GPUS caps the GPUs, SZ3HIP_SLABS sets
+ * another slab count; never more slabs than dims[0]); range-based bounds use the global value range (:57-69); the code
+ * histograms of all slabs are summed (RCCL all-reduce across GPUs) so that every slab is coded with the same code book;
+ * the slabs are stored in the reference's multi-slab container [i32 G][Config x G][u64 size x G][blob x G] (:100-107),
+ * every blob what a single-slab call would have produced. */
 size_t sz3hip_compress(const sz3hip_config *conf, int dataType, const void *data, char *cmpData, size_t cmpCap);
 /* SZ_decompress<T>(conf, cmpData, cmpSize, decData) (api/sz.hpp:117): conf is overwritten from the trailer;
- * decData must hold conf.num elements (query with sz3hip_peek_config first). Also decodes ALGO_LOSSLESS streams. */
+ * decData must hold conf.num elements (query with sz3hip_peek_config first). Also decodes ALGO_LOSSLESS streams and
+ * multi-slab containers (trailer bit openmp; SZ_decompress_OMP, SZImplOMP.hpp:120-186), slab g on GPU g % visible GPUs. */
 int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *cmpData, size_t cmpSize, void *decData);
 /* reads only header + trailer (what SZ_decompress does before dispatching, sz.hpp:119-141) */
 int sz3hip_peek_config(sz3hip_config *conf, const char *cmpData, size_t cmpSize);
@@ -135,7 +147,7 @@ int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, void *stream);
 /* stage1 + stage2 + finish */
 int sz3hip_compress_device(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, void *d_payload, size_t cap,
                            size_t *payload_size, void *stream);
-/* inverse: payload (device) -> d_out (device, n elements). Synchronises once to read the 128-byte header. */
+/* inverse: payload (device) -> d_out (device, n elements). Synchronises once to read the 160-byte header. */
 int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, size_t payload_size, void *d_out, void *stream);
 
 /* diagnostics of the last compress on this ctx (valid after sz3hip_compress_finish) */
@@ -175,6 +187,45 @@ void sz3hip_debug_force_generic(int on);
  * construction, 4096 stage 1 without the XCD-aware task order, 8192 interpolation histogram with the large tier and the
  * windowed tail passes */
 void sz3hip_debug_flags(int flags);
+
+/* ---- (4) multi-GPU exchange over RCCL / xGMI ------------------------------------------------------------------- */
+typedef struct sz3hip_comm sz3hip_comm;
+#define SZ3HIP_COMM_ID_BYTES 128
+/* one process, `ndev` GPUs (devices[i], or 0..ndev-1 when NULL; ndev <= 0: all visible): ncclCommInitAll. The
+ * communicator has ndev members, all local. */
+sz3hip_comm *sz3hip_comm_create_local(int ndev, const int *devices);
+/* one process per GPU: rank 0 makes the id (ncclGetUniqueId), the launcher ships its SZ3HIP_COMM_ID_BYTES bytes to
+ * every rank, each rank joins with its device (ncclCommInitRank). The communicator has one local member. */
+int sz3hip_comm_unique_id(unsigned char *id128);
+sz3hip_comm *sz3hip_comm_create_rank(int nranks, int rank, int device, const unsigned char *id128);
+void sz3hip_comm_destroy(sz3hip_comm *comm);
+int sz3hip_comm_size(const sz3hip_comm *comm);       /* ranks RCCL reports for the communicator */
+int sz3hip_comm_rank(const sz3hip_comm *comm);       /* rank of this process's first member (0 for a local communicator) */
+int sz3hip_comm_local_size(const sz3hip_comm *comm); /* members this process drives */
+int sz3hip_comm_device(const sz3hip_comm *comm, int member);
+/* Between stage1 and stage2: in-place sum all-reduce of the code histogram of ctxs[m] (one context per local member, on
+ * that member's device), enqueued on streams[m] — stage2 on the same stream sees the global histogram, and every member
+ * builds the same code book. Asynchronous. */
+int sz3hip_comm_allreduce_histogram(sz3hip_comm *comm, sz3hip_ctx *const *ctxs, void *const *streams);
+/* the same for any uint64 device buffers (d_bufs[m] on member m's device) */
+int sz3hip_comm_allreduce_u64(sz3hip_comm *comm, void *const *d_bufs, size_t count, void *const *streams);
+/* global value range for REL / PSNR / ABS_AND_REL / ABS_OR_REL bounds (api/impl/SZImplOMP.hpp:57-69): mins[m] / maxs[m]
+ * hold member m's local pair on entry and the global pair on return (synchronises the streams) */
+int sz3hip_comm_allreduce_minmax(sz3hip_comm *comm, double *mins, double *maxs, void *const *streams);
+
+
+/* One process per GPU (communicator from sz3hip_comm_create_rank): this rank's share of SZ_compress_OMP. `global_conf`
+ * describes the WHOLE array; rank r of G owns the slab [r*dims[0]/G, (r+1)*dims[0]/G) (SZImplOMP.hpp:48-50) and passes
+ * a host pointer to that slab. Collective: every rank of the communicator must call it (value range for range-based
+ * bounds, a status word, the code histogram). Writes this slab's blob — what the container stores for it — to `blob`
+ * (capacity >= sz3hip_compress_bound of the slab's Config) and the slab's Config to *slab_conf; returns the blob size,
+ * 0 on error (then on every rank). The launcher gathers blobs + Configs and rank 0 calls sz3hip_assemble_container. */
+size_t sz3hip_compress_rank(sz3hip_comm *comm, const sz3hip_config *global_conf, int dataType, const void *slab_data,
+                            char *blob, size_t cap, sz3hip_config *slab_conf);
+/* [magic][version][u64 body][ i32 G | Config x G | u64 size x G | blob x G ][outer Config, openmp = 1] (api/sz.hpp:53-81
+ * around SZImplOMP.hpp:100-107): the stream sz3hip_decompress / SZ_decompress<T> read back. Returns its size, 0 on error. */
+size_t sz3hip_assemble_container(const sz3hip_config *global_conf, int dataType, int G, const sz3hip_config *slab_confs,
+                                 const char *const *blobs, const size_t *blob_sizes, char *out, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -122,6 +122,30 @@ def lib():
     L.sz3hip_debug_copy_codes.restype = C.c_int
     L.sz3hip_debug_copy_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.sz3hip_debug_force_generic.argtypes = [C.c_int]
+    L.sz3hip_config_load_n.restype = C.c_size_t
+    L.sz3hip_config_load_n.argtypes = [P(_CConfig), C.c_void_p, C.c_size_t]
+    L.sz3hip_comm_create_local.restype = C.c_void_p
+    L.sz3hip_comm_create_local.argtypes = [C.c_int, P(C.c_int)]
+    L.sz3hip_comm_unique_id.restype = C.c_int
+    L.sz3hip_comm_unique_id.argtypes = [C.c_void_p]
+    L.sz3hip_comm_create_rank.restype = C.c_void_p
+    L.sz3hip_comm_create_rank.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.sz3hip_comm_destroy.argtypes = [C.c_void_p]
+    for f in ("size", "rank", "local_size"):
+        getattr(L, "sz3hip_comm_" + f).restype = C.c_int
+        getattr(L, "sz3hip_comm_" + f).argtypes = [C.c_void_p]
+    L.sz3hip_comm_device.restype = C.c_int
+    L.sz3hip_comm_device.argtypes = [C.c_void_p, C.c_int]
+    L.sz3hip_comm_allreduce_histogram.restype = C.c_int
+    L.sz3hip_comm_allreduce_histogram.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_void_p)]
+    L.sz3hip_comm_allreduce_u64.restype = C.c_int
+    L.sz3hip_comm_allreduce_u64.argtypes = [C.c_void_p, P(C.c_void_p), C.c_size_t, P(C.c_void_p)]
+    L.sz3hip_comm_allreduce_minmax.restype = C.c_int
+    L.sz3hip_comm_allreduce_minmax.argtypes = [C.c_void_p, P(C.c_double), P(C.c_double), P(C.c_void_p)]
+    L.sz3hip_compress_rank.restype = C.c_size_t
+    L.sz3hip_compress_rank.argtypes = [C.c_void_p, P(_CConfig), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, P(_CConfig)]
+    L.sz3hip_assemble_container.restype = C.c_size_t
+    L.sz3hip_assemble_container.argtypes = [P(_CConfig), C.c_int, C.c_int, P(_CConfig), P(C.c_void_p), P(C.c_size_t), C.c_void_p, C.c_size_t]
     L.SZ_compress_args.restype = C.c_void_p
     L.SZ_compress_args.argtypes = [C.c_int, C.c_void_p, P(C.c_size_t), C.c_int, C.c_double, C.c_double, C.c_double,
                                    C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
@@ -199,7 +223,13 @@ class Config:
     def load(cls, raw):
         c = cls(1)
         b = (C.c_ubyte * len(raw)).from_buffer_copy(raw)
-        lib().sz3hip_config_load(C.byref(c._c), b)
+        if lib().sz3hip_config_load_n(C.byref(c._c), b, len(raw)) == 0:
+            raise ValueError("truncated serialised Config")
+        return c
+
+    def copy(self):
+        c = Config(1)
+        C.memmove(C.byref(c._c), C.byref(self._c), C.sizeof(_CConfig))
         return c
 
 
@@ -332,3 +362,104 @@ class DeviceCompressor:
         out = np.empty(int(n), dtype=np.uint16)
         _check(lib().sz3hip_debug_copy_codes(self._h, out.ctypes.data, int(n)))
         return out
+
+
+# ---- multi-GPU exchange (RCCL over xGMI, in the library) --------------------------------------------------------
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """sz3hip_comm: the RCCL communicator of the slab-parallel path. ``Comm.local(ndev)`` = one process drives ndev GPUs;
+    ``Comm.rank(nranks, rank, device, id)`` = one process per GPU, ``id`` being ``Comm.unique_id()`` of rank 0 shipped by
+    the launcher (sz3_amd.distributed.init_comm does that over torch.distributed)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise SZ3HipError(lib().sz3hip_last_error_code(), lib().sz3hip_last_error().decode())
+        self._h = handle
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * COMM_ID_BYTES)()
+        _check(lib().sz3hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def local(cls, ndev=0, devices=None):
+        arr = (C.c_int * len(devices))(*devices) if devices else None
+        return cls(lib().sz3hip_comm_create_local(int(ndev if not devices else len(devices)), arr))
+
+    @classmethod
+    def rank(cls, nranks, rank, device, id_bytes):
+        b = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes))
+        return cls(lib().sz3hip_comm_create_rank(int(nranks), int(rank), int(device), b))
+
+    def close(self):
+        if self._h:
+            lib().sz3hip_comm_destroy(self._h)
+            self._h = None
+
+    @property
+    def size(self):
+        return int(lib().sz3hip_comm_size(self._h))
+
+    @property
+    def my_rank(self):
+        return int(lib().sz3hip_comm_rank(self._h))
+
+    @property
+    def local_size(self):
+        return int(lib().sz3hip_comm_local_size(self._h))
+
+    def device(self, member=0):
+        return int(lib().sz3hip_comm_device(self._h, member))
+
+    def allreduce_histogram(self, compressors, streams):
+        """in-place sum of the code histograms of the local members' DeviceCompressors, enqueued on their streams"""
+        m = len(compressors)
+        ctxs = (C.c_void_p * m)(*[dc._h for dc in compressors])
+        st = (C.c_void_p * m)(*[int(x) if x else None for x in streams])
+        _check(lib().sz3hip_comm_allreduce_histogram(self._h, ctxs, st))
+
+    def allreduce_u64(self, ptrs, count, streams):
+        m = len(ptrs)
+        bufs = (C.c_void_p * m)(*[int(p) for p in ptrs])
+        st = (C.c_void_p * m)(*[int(x) if x else None for x in streams])
+        _check(lib().sz3hip_comm_allreduce_u64(self._h, bufs, int(count), st))
+
+    def allreduce_minmax(self, mins, maxs, streams):
+        m = len(mins)
+        a = (C.c_double * m)(*mins)
+        b = (C.c_double * m)(*maxs)
+        st = (C.c_void_p * m)(*[int(x) if x else None for x in streams])
+        _check(lib().sz3hip_comm_allreduce_minmax(self._h, a, b, st))
+        return list(a), list(b)
+
+
+def compress_rank(comm, slab, global_conf):
+    """this rank's slab of a slab-parallel compress (sz3hip_compress_rank; collective): returns (blob, slab Config)"""
+    a = np.ascontiguousarray(slab)
+    sc = Config(1)
+    cap = int(lib().sz3hip_compress_bound(C.byref(global_conf._c), _dtype_id(a.dtype)))  # (>= the slab's own bound)
+    out = np.empty(cap, dtype=np.uint8)
+    n = lib().sz3hip_compress_rank(comm._h, C.byref(global_conf._c), _dtype_id(a.dtype), a.ctypes.data, out.ctypes.data, cap, C.byref(sc._c))
+    if n == 0:
+        raise SZ3HipError(lib().sz3hip_last_error_code(), lib().sz3hip_last_error().decode())
+    return out[:n].copy(), sc
+
+
+def assemble_container(global_conf, dtype, slab_confs, blobs):
+    """sz3hip_assemble_container: the multi-slab SZ3 stream from the ranks' blobs and Configs (rank order)"""
+    G = len(blobs)
+    arrs = [np.ascontiguousarray(np.frombuffer(b, dtype=np.uint8) if isinstance(b, (bytes, bytearray)) else b) for b in blobs]
+    confs = (_CConfig * G)()
+    for i, c in enumerate(slab_confs):
+        C.memmove(C.byref(confs[i]), C.byref(c._c), C.sizeof(_CConfig))
+    ptrs = (C.c_void_p * G)(*[a.ctypes.data for a in arrs])
+    sizes = (C.c_size_t * G)(*[a.size for a in arrs])
+    cap = 16 + 4 + G * (8 + 160) + 160 + sum(a.size for a in arrs)
+    out = np.empty(cap, dtype=np.uint8)
+    n = lib().sz3hip_assemble_container(C.byref(global_conf._c), _dtype_id(dtype), G, confs, ptrs, sizes, out.ctypes.data, cap)
+    if n == 0:
+        raise SZ3HipError(lib().sz3hip_last_error_code(), lib().sz3hip_last_error().decode())
+    return out[:n]

@@ -1,31 +1,51 @@
-"""Builds sz3_amd/libsz3hip.so (hipcc, gfx950 only) in-tree.  `python -m sz3_amd.build [--force]`."""
+"""Builds sz3_amd/libsz3hip.so (hipcc, gfx950 only) in-tree.  `python -m sz3_amd.build [--force]`.
+
+Every source is compiled to its own object (in parallel, only when it or a header changed), then linked."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libsz3hip.so")
-SOURCES = ["sz3hip_kernels.hip", "sz3hip_interp.hip", "sz3hip_api.cpp"]
-HEADERS = ["sz3hip_kernels.h", "sz3hip_format.h", "../../include/sz3hip.h", "../../include/sz3c.h"]
+SOURCES = ["sz3hip_kernels.hip", "sz3hip_interp.hip", "sz3hip_regress.hip", "sz3hip_api.cpp", "sz3hip_host.cpp", "sz3hip_comm.cpp"]
+HEADERS = ["sz3hip_kernels.h", "sz3hip_format.h", "sz3hip_internal.h", "../../include/sz3hip.h", "../../include/sz3c.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+def _sources():
+    return [f for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+
+
+def _newest_header():
+    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
 
 
 def build(force=False, verbose=True):
-    if not force and not _stale():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           *[os.path.join(CSRC, f) for f in SOURCES], "-o", LIB, "-ldl", "-lpthread"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    th = _newest_header()
+    jobs = []
+    objs = []
+    for f in _sources():
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJ, f + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), th):
+            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB, "-ldl", "-lpthread"])
     return LIB
 
 

@@ -1,15 +1,12 @@
-// sz3_amd/csrc/sz3hip_api.cpp — host side of libsz3hip.so: the C ABI declared in include/sz3hip.h and include/sz3c.h.
+// sz3_amd/csrc/sz3hip_api.cpp — Config and the device-resident API of libsz3hip.so (include/sz3hip.h groups 2 and 3).
 //
 // Mirrors, for the GPU path, what these reference pieces do on the CPU (paths relative to /root/reference):
-//   include/SZ3/api/sz.hpp:43-82,117-157        container: 16-byte header + payload + Config trailer
-//   include/SZ3/utils/Config.hpp:161-177,312-413 Config::setDims / save / load
-//   include/SZ3/api/impl/SZDispatcher.hpp:13-100 eb-mode conversion, eb==0 => lossless, lossless fallback,
-//                                                "ratio < 3 => also try zstd alone"
-//   include/SZ3/lossless/Lossless_zstd.hpp:29-45 [u64 rawLen][zstd frames]  (we emit several concatenated frames,
-//                                                compressed by a thread pool; any zstd decoder reads them)
-//   tools/sz3c/src/sz3c.cpp:11-94                SZ_compress_args / SZ_decompress / free_buf
-// There is NO CPU implementation of the predictor/quantizer/Huffman stages in this library: if the HIP device
-// or kernels are unavailable every entry point fails loudly.
+//   include/SZ3/utils/Config.hpp:161-177,312-413     Config::setDims / save / load
+//   include/SZ3/compressor/SZGenericCompressor.hpp:38-84  stage glue: decomposition -> encoder (-> lossless on the host)
+//   include/SZ3/api/impl/SZAlgoInterp.hpp:122-286    the ALGO_INTERP_LORENZO sampling tuner
+// The host-buffer API (container, dispatcher policies, slab-parallel path, sz3c.h) is sz3hip_host.cpp, the RCCL
+// communicator sz3hip_comm.cpp. There is NO CPU implementation of the predictor/quantizer/Huffman stages in this
+// library: if the HIP device or kernels are unavailable every entry point fails loudly.
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -30,13 +27,13 @@
 #include "../../include/sz3c.h"
 #include "../../include/sz3hip.h"
 #include "sz3hip_format.h"
+#include "sz3hip_internal.h"
 #include "sz3hip_kernels.h"
 
 // ------------------------------------------------------------------------------------------------------------
 static thread_local char g_err[512];
 static thread_local int g_err_code = 0;
-static int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
-static int fail(int code, const char *fmt, ...) {
+int szi_fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -44,6 +41,7 @@ static int fail(int code, const char *fmt, ...) {
     g_err_code = code;
     return code;
 }
+#define fail szi_fail
 extern "C" const char *sz3hip_last_error(void) { return g_err; }
 extern "C" int sz3hip_last_error_code(void) { return g_err_code; }
 extern "C" const char *sz3hip_version(void) { return "sz3hip 0.1 (gfx950; data format SZ3 3.3.2 container, payload SZH1)"; }
@@ -54,166 +52,6 @@ extern "C" const char *sz3hip_version(void) { return "sz3hip 0.1 (gfx950; data f
         if (e_ != hipSuccess) return fail(SZ3HIP_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
-// ------------------------------------------------------------------------------------------------------------
-// libzstd (third-party, the reference's lossless stage; not vendored there either — CMakeLists.txt:69-75).
-// zstd.h is not installed in /usr/include of this image, so the five prototypes are declared here and the
-// library is dlopen'ed; a missing library is a hard error.
-// ------------------------------------------------------------------------------------------------------------
-namespace zs {
-typedef size_t (*compress_fn)(void *, size_t, const void *, size_t, int);
-typedef size_t (*decompress_fn)(void *, size_t, const void *, size_t);
-typedef size_t (*bound_fn)(size_t);
-typedef unsigned (*iserr_fn)(size_t);
-typedef size_t (*framesize_fn)(const void *, size_t);
-typedef unsigned long long (*contentsize_fn)(const void *, size_t);
-static void *h;
-static compress_fn compress;
-static decompress_fn decompress;
-static bound_fn bound;
-static iserr_fn is_error;
-static framesize_fn frame_csize;
-static contentsize_fn frame_content;
-static std::once_flag once;
-static bool ok;
-static void load_once() {
-    const char *names[] = {"libzstd.so.1", "libzstd.so", "/usr/lib/x86_64-linux-gnu/libzstd.so.1", nullptr};
-    for (int i = 0; names[i] && !h; i++) h = dlopen(names[i], RTLD_NOW);
-    if (!h) return;
-    compress = (compress_fn)dlsym(h, "ZSTD_compress");
-    decompress = (decompress_fn)dlsym(h, "ZSTD_decompress");
-    bound = (bound_fn)dlsym(h, "ZSTD_compressBound");
-    is_error = (iserr_fn)dlsym(h, "ZSTD_isError");
-    frame_csize = (framesize_fn)dlsym(h, "ZSTD_findFrameCompressedSize");
-    frame_content = (contentsize_fn)dlsym(h, "ZSTD_getFrameContentSize");
-    ok = compress && decompress && bound && is_error;
-}
-static int load() {
-    std::call_once(once, load_once);
-    return ok ? 0 : fail(SZ3HIP_EZSTD, "libzstd.so.1 not found or incomplete");
-}
-static const size_t FRAME = 4u << 20;  // bytes of input per zstd frame
-static unsigned nthreads() {
-    const char *e = getenv("SZ3HIP_ZSTD_THREADS");
-    unsigned n = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
-    if (n < 1) n = 1;
-    if (n > 64) n = 64;
-    return n;
-}
-static size_t bound_frames(size_t n) {
-    size_t nf = (n + FRAME - 1) / FRAME;
-    if (nf == 0) nf = 1;
-    return nf * bound(std::min(n, FRAME)) + 8;
-}
-// [u64 srcLen][frame]...  level 3 (lossless/Lossless_zstd.hpp:48); returns 0 on error
-static size_t compress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {
-    if (load()) return 0;
-    if (cap < 8) {
-        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
-        return 0;
-    }
-    uint64_t len = n;
-    memcpy(dst, &len, 8);
-    const size_t nf = std::max<size_t>(1, (n + FRAME - 1) / FRAME);
-    const size_t fb = bound(std::min(n, FRAME));
-    std::vector<std::vector<uint8_t>> out(nf);
-    std::vector<size_t> sz(nf, 0);
-    std::atomic<size_t> next(0);
-    std::atomic<int> bad(0);
-    auto work = [&]() {
-        for (;;) {
-            size_t f = next.fetch_add(1);
-            if (f >= nf) break;
-            size_t lo = f * FRAME, l = std::min(FRAME, n - lo);
-            out[f].resize(fb);
-            size_t r = compress(out[f].data(), fb, src + lo, l, 3);
-            if (is_error(r)) bad = 1;
-            sz[f] = r;
-        }
-    };
-    unsigned nt = (unsigned)std::min<size_t>(nthreads(), nf);
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
-    work();
-    for (auto &t : th) t.join();
-    if (bad) {
-        fail(SZ3HIP_EZSTD, "ZSTD_compress failed");
-        return 0;
-    }
-    size_t total = 8;
-    for (size_t f = 0; f < nf; f++) total += sz[f];
-    if (total > cap) {
-        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
-        return 0;
-    }
-    uint8_t *p = dst + 8;
-    for (size_t f = 0; f < nf; f++) {
-        memcpy(p, out[f].data(), sz[f]);
-        p += sz[f];
-    }
-    return total;
-}
-// inverse; frames are located with ZSTD_findFrameCompressedSize and decoded in parallel. returns bytes produced
-static size_t decompress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {
-    if (load()) return 0;
-    if (n < 8) {
-        fail(SZ3HIP_EFORMAT, "truncated lossless block");
-        return 0;
-    }
-    uint64_t len;
-    memcpy(&len, src, 8);
-    if (len > cap) {
-        fail(SZ3HIP_ECAPACITY, "lossless block larger than the destination");
-        return 0;
-    }
-    const uint8_t *p = src + 8;
-    size_t rem = n - 8;
-    struct Fr { const uint8_t *p; size_t c, off, d; };
-    std::vector<Fr> frames;
-    bool split = frame_csize && frame_content;
-    if (split) {
-        size_t off = 0;
-        while (rem > 0) {
-            size_t c = frame_csize(p, rem);
-            if (is_error(c)) { split = false; break; }
-            unsigned long long d = frame_content(p, c);
-            if (d == (unsigned long long)-1 || d == (unsigned long long)-2) { split = false; break; }
-            frames.push_back({p, c, off, (size_t)d});
-            off += (size_t)d;
-            p += c;
-            rem -= c;
-        }
-        if (split && off != len) split = false;
-    }
-    if (!split || frames.size() <= 1) {
-        size_t r = decompress(dst, (size_t)len, src + 8, n - 8);
-        if (is_error(r) || r != len) {
-            fail(SZ3HIP_EZSTD, "ZSTD_decompress failed");
-            return 0;
-        }
-        return r;
-    }
-    std::atomic<size_t> next(0);
-    std::atomic<int> bad(0);
-    auto work = [&]() {
-        for (;;) {
-            size_t f = next.fetch_add(1);
-            if (f >= frames.size()) break;
-            size_t r = decompress(dst + frames[f].off, frames[f].d, frames[f].p, frames[f].c);
-            if (is_error(r) || r != frames[f].d) bad = 1;
-        }
-    };
-    unsigned nt = (unsigned)std::min<size_t>(nthreads(), frames.size());
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
-    work();
-    for (auto &t : th) t.join();
-    if (bad) {
-        fail(SZ3HIP_EZSTD, "ZSTD_decompress failed");
-        return 0;
-    }
-    return (size_t)len;
-}
-}  // namespace zs
 
 // ------------------------------------------------------------------------------------------------------------
 // Config (include/SZ3/utils/Config.hpp)
@@ -242,24 +80,6 @@ extern "C" void sz3hip_config_init(sz3hip_config *c, int ndims, const uint64_t *
     c->interpBeta = 2.0;
 }
 
-namespace {
-struct Writer {
-    unsigned char *p;
-    template <class V> void put(V v) {
-        memcpy(p, &v, sizeof(V));
-        p += sizeof(V);
-    }
-};
-struct Reader {
-    const unsigned char *p;
-    template <class V> V get() {
-        V v;
-        memcpy(&v, p, sizeof(V));
-        p += sizeof(V);
-        return v;
-    }
-};
-}  // namespace
 
 extern "C" size_t sz3hip_config_save(const sz3hip_config *c, unsigned char *out) {  // Config.hpp:312-354
     Writer w{out + 1};
@@ -303,16 +123,23 @@ extern "C" size_t sz3hip_config_save(const sz3hip_config *c, unsigned char *out)
     return (size_t)(w.p - out);
 }
 
-extern "C" size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in) {  // Config.hpp:361-413
-    Reader r{in};
-    const uint8_t conf_size = r.get<uint8_t>();
-    const unsigned char *end = r.p + conf_size;
+// Config::load (Config.hpp:361-413) over at most `avail` bytes: 0 when the leading size byte or any field runs past them
+extern "C" size_t sz3hip_config_load_n(sz3hip_config *c, const unsigned char *in, size_t avail) {
     uint64_t one = 1;
     sz3hip_config_init(c, 1, &one);
+    if (avail < 1) return 0;
+    Reader r{in};
+    const uint8_t conf_size = r.get<uint8_t>();
+    // (the stored size counts its own byte: Config::save writes `pos - start` over the first byte, Config.hpp:351-353)
+    if (conf_size < 1 || conf_size > avail) return 0;
+    const unsigned char *end = in + conf_size;
+    auto room = [&](size_t k) { return (size_t)(end - r.p) >= k; };
+    if (!room(2)) return 0;
     c->N = r.get<int8_t>();
     if (c->N < 0 || c->N > 4) c->N = 0;
     const uint8_t bw = r.get<uint8_t>();
     const size_t nbytes = ((size_t)bw * (size_t)c->N + 7) / 8;
+    if (!room(nbytes)) return 0;
     for (int i = 0; i < c->N; i++) {  // bytes2vector, ByteUtil.hpp:240-264
         uint64_t v = 0;
         for (int j = 0; j < bw && j < 64; j++) {
@@ -322,22 +149,24 @@ extern "C" size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in) 
         c->dims[i] = v;
     }
     r.p += nbytes;
+    if (!room(10)) return 0;
     c->num = r.get<uint64_t>();
     c->cmprAlgo = r.get<uint8_t>();
     c->errorBoundMode = r.get<uint8_t>();
     switch (c->errorBoundMode) {
-        case SZ3HIP_EB_ABS: c->absErrorBound = r.get<double>(); break;
-        case SZ3HIP_EB_REL: c->relErrorBound = r.get<double>(); break;
-        case SZ3HIP_EB_PSNR: c->psnrErrorBound = r.get<double>(); break;
-        case SZ3HIP_EB_L2NORM: c->l2normErrorBound = r.get<double>(); break;
+        case SZ3HIP_EB_ABS: if (!room(8)) return 0; c->absErrorBound = r.get<double>(); break;
+        case SZ3HIP_EB_REL: if (!room(8)) return 0; c->relErrorBound = r.get<double>(); break;
+        case SZ3HIP_EB_PSNR: if (!room(8)) return 0; c->psnrErrorBound = r.get<double>(); break;
+        case SZ3HIP_EB_L2NORM: if (!room(8)) return 0; c->l2normErrorBound = r.get<double>(); break;
         case SZ3HIP_EB_ABS_AND_REL:
         case SZ3HIP_EB_ABS_OR_REL:
+            if (!room(16)) return 0;
             c->absErrorBound = r.get<double>();
             c->relErrorBound = r.get<double>();
             break;
         default: break;
     }
-    if (r.p < end) {
+    if (room(1)) {
         uint8_t b = r.get<uint8_t>();
         c->lorenzo = (b >> 7) & 1;
         c->lorenzo2 = (b >> 6) & 1;
@@ -345,83 +174,21 @@ extern "C" size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in) 
         c->regression2 = (b >> 4) & 1;
         c->openmp = (b >> 3) & 1;
     }
-    if (r.p < end) c->dataType = r.get<uint8_t>();
-    if (r.p < end) c->quantbinCnt = r.get<int32_t>();
-    if (r.p < end) c->blockSize = r.get<int32_t>();
-    if (r.p < end) c->predDim = r.get<uint8_t>();
-    return (size_t)(r.p - in);
+    if (room(1)) c->dataType = r.get<uint8_t>();
+    if (room(4)) c->quantbinCnt = r.get<int32_t>();
+    if (room(4)) c->blockSize = r.get<int32_t>();
+    if (room(1)) c->predDim = r.get<uint8_t>();
+    return (size_t)conf_size;
+}
+extern "C" size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in) {  // the caller vouches for in[0] readable bytes
+    return sz3hip_config_load_n(c, in, in[0]);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // device context
 // ------------------------------------------------------------------------------------------------------------
-enum { ST_K1 = 0, ST_CODEBOOK, ST_ENCODE, ST_ASSEMBLE, ST_DEC_HUFF, ST_DEC_RECON, ST_TUNER, ST_K1_KERNEL, ST_COUNT };
 static const char *const kStageNames[ST_COUNT] = {"lorenzo_quant_hist", "codebook", "encode", "assemble",
                                                   "huffman_decode",     "reconstruct", "tuner", "k1_kernel"};
-
-struct sz3hip_ctx {
-    int device;
-    int dtype;
-    uint64_t max_n, out_cap, cur_out_cap, max_chunks;
-    uint64_t out_alloc;      // entries the four outlier arrays hold (>= out_cap; grown on demand)
-    uint64_t force_out_cap;  // != 0: list capacity of the retry after an overflow
-    // device buffers
-    uint16_t *d_codes;
-    uint64_t *d_hist;      // histogram in use (internal or caller-owned)
-    uint64_t *d_hist_own;  // internal allocation
-    uint64_t *d_counters;  // [0]=n_vout [1]=n_dout [2]=total_words [3]=decoder [4..6]=probe words [8..9]=code book's symbol range (inside d_hist_own's block)
-    uint32_t *d_hist_partial;
-    void *d_work;          // interpolation: the array being overwritten with reconstructed values (lazy)
-    uint64_t *d_vout_idx, *d_dout_idx;
-    void *d_vout_val, *d_dout_val;
-    uint32_t *d_enc;
-    uint8_t *d_lens;
-    uint64_t *d_keys, *d_ifreq;
-    uint16_t *d_syms, *d_pleaf, *d_pint, *d_depth, *d_aux2, *d_pint2;
-    uint32_t *d_range;
-    szk_cb_info *d_info;
-    uint16_t *d_chunk_words;
-    uint64_t *d_chunk_off;
-    szk_state *d_state;
-    szk_dec_tables *d_tables;
-    void *d_segtot;
-    double *d_minmax;
-    szk_state *h_state;  // pinned
-    szk_mode mode;       // of the pending / last compress
-    double *h_minmax;    // pinned
-    // pending compress
-    szh_header proto;
-    bool stage1_done, stage2_done;
-    sz3hip_stats stats;
-    // ALGO_INTERP_LORENZO tuner scratch (lazy)
-    uint8_t *d_flags;
-    size_t flags_cap;
-    uint64_t *d_starts;
-    size_t starts_cap;
-    void *d_samples;
-    size_t samples_cap;
-    void *d_trial_work;  // scratch of the trial kernel's global-memory variant (blocks too large for LDS)
-    size_t trial_work_cap;
-    hipStream_t side;    // the working copy of the input is made here while the tuner runs on the caller's stream
-    hipEvent_t ev_fork, ev_join;
-    bool copy_ahead;     // d_work already holds this call's input (joined into the caller's stream)
-    int hist_tail;       // with hist_big: codes beyond the large tier counted by windowed passes (from the previous call's count)
-    int hist_big;        // interpolation histogram pass with the 16384-bin second tier (from the previous call's far count)
-    int pack_wide;       // the packer's LDS table window: 8192 instead of 4096 entries (from the previous call's probe)
-    int wide16;          // -1: not decided yet (f64 starts with the 16384-bin stage-1 window, f32 with 8192); else 0 / 1,
-                         // adapted after every Lorenzo call from the width of the alphabet it saw
-    uint64_t *d_trial;  // [8][4]: bits, symbols, unpredictables, delta outliers
-    uint64_t *h_trial;  // pinned
-    uint64_t *d_trial_hist;      // [SZK_MAX_TRIALS][65536] histograms of the trials of one group
-    uint64_t *d_trial_counters;  // [SZK_MAX_TRIALS][8]
-    szk_interp_pass *d_passes, *h_passes;  // [SZK_MAX_TRIALS][SZK_TRIAL_MAX_PASSES] pass schedules (h: pinned)
-    uint32_t *d_np, *h_np;
-    sz3hip_tuner_report tuner;
-    // profiling
-    bool profiling;
-    hipEvent_t ev[ST_COUNT][2];
-    bool ev_used[ST_COUNT];
-};
 
 #define SZ_COUNTER_BYTES 128
 // histogram and counters of a call start at zero; the internal histogram and the counters share one block (one fill launch)
@@ -1251,7 +1018,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     if (h.dims[0] * h.dims[1] * h.dims[2] * h.dims[3] != h.n || h.chunk_syms != SZH_CHUNK_SYMS ||
         h.n_chunks != (h.n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS || h.sym_count > SZH_HIST_BINS ||
         h.sym_min + h.sym_count > SZH_HIST_BINS || h.max_len > SZH_MAX_LEN || h.radius < 2 || h.radius > 32768 ||
-        h.qbytes != (h.dtype == 0 ? 4 : 8))
+        h.qbytes != (h.dtype == 0 ? 4 : 8) || h.n_vout > h.n || h.n_dout > h.n || h.bitstream_words > payload_size / 4)
         return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header");
     szh_offsets o;
     szk_host_offsets(&h, &o);
@@ -1307,374 +1074,3 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// host-buffer API: SZ_compress<T> / SZ_decompress<T> equivalents
-// ------------------------------------------------------------------------------------------------------------
-static const uint32_t kMagic = 0xF342F310u;                          // include/SZ3/version.hpp.in:10
-static const uint32_t kDataVer = (3u << 24) | (3u << 16) | (2u << 8);  // SZ3_DATA_VERSION 3.3.2 (CMakeLists.txt:7)
-
-static inline bool dtype_ok(int dt) { return dt == SZ3HIP_FLOAT || dt == SZ3HIP_DOUBLE || dt == SZ3HIP_INT32 || dt == SZ3HIP_INT64; }
-static inline bool dtype_is_int(int dt) { return dt == SZ3HIP_INT32 || dt == SZ3HIP_INT64; }
-static inline size_t dtype_size(int dt) { return (dt == SZ3HIP_FLOAT || dt == SZ3HIP_INT32) ? 4 : 8; }
-static inline int dtype_compute(int dt) { return dtype_is_int(dt) ? SZ3HIP_DOUBLE : dt; }  // integers ride the f64 pipeline
-
-extern "C" size_t sz3hip_compress_bound(const sz3hip_config *c, int dataType) {  // api/impl/SZImpl.hpp:34-44
-    if (zs::load()) return 0;
-    unsigned char tmp[160];
-    const size_t es = dtype_size(dataType);
-    return 4096 + sz3hip_config_save(c, tmp) + zs::bound_frames((size_t)c->num * es);
-}
-
-namespace {
-// one cached context per (device, dtype); grown on demand. The host API is serialised per process.
-std::mutex g_ctx_mu;
-sz3hip_ctx *g_ctx[2];
-void *g_dev_in[2], *g_dev_payload[2];
-size_t g_dev_in_bytes[2], g_dev_payload_bytes[2];
-
-int host_device() {
-    const char *e = getenv("SZ3HIP_DEVICE");
-    return e ? atoi(e) : 0;
-}
-sz3hip_ctx *get_ctx(int dtype, uint64_t n) {
-    sz3hip_ctx *&c = g_ctx[dtype];
-    if (c && c->max_n >= n) return c;
-    if (c) sz3hip_ctx_destroy(c);
-    c = sz3hip_ctx_create(host_device(), n, dtype);
-    return c;
-}
-// pinned host staging for the payload (the device <-> host hop of the host API): DMA at link speed, no page faults
-void *g_pin;
-size_t g_pin_bytes;
-int ensure_pin(size_t want) {
-    if (g_pin_bytes >= want) return 0;
-    if (g_pin) (void)hipHostFree(g_pin);
-    g_pin = nullptr;
-    g_pin_bytes = 0;
-    want += want / 4;  // (payload sizes vary from call to call)
-    HIPCHK(hipHostMalloc(&g_pin, want));
-    g_pin_bytes = want;
-    return 0;
-}
-int ensure_dev(void **p, size_t *have, size_t want) {
-    if (*have >= want) return 0;
-    if (*p) (void)hipFree(*p);
-    *p = nullptr;
-    *have = 0;
-    HIPCHK(hipMalloc(p, want));
-    *have = want;
-    return 0;
-}
-}  // namespace
-
-// utils/Statistic.hpp:32-56 with the range taken from the device min/max kernel
-static int cal_abs_eb(sz3hip_config &conf, sz3hip_ctx *ctx, const void *d_in) {
-    if (conf.errorBoundMode == SZ3HIP_EB_ABS) return 0;
-    double range = 0;
-    if (conf.errorBoundMode != SZ3HIP_EB_L2NORM) {
-        double mn, mx;
-        int rc = sz3hip_minmax_device(ctx, d_in, conf.num, &mn, &mx, nullptr);
-        if (rc) return rc;
-        // data_range computes max - min in T (Statistic.hpp:12-21)
-        range = ctx->dtype == SZ3HIP_FLOAT ? (double)((float)mx - (float)mn) : mx - mn;
-    }
-    switch (conf.errorBoundMode) {
-        case SZ3HIP_EB_REL: conf.absErrorBound = conf.relErrorBound * range; break;
-        case SZ3HIP_EB_PSNR: {  // computeABSErrBoundFromPSNR, Statistic.hpp:25-30, threshold 0.99
-            double v1 = conf.psnrErrorBound + 10 * log10(1 - 2.0 / 3.0 * 0.99);
-            conf.absErrorBound = range * pow(10, v1 / (-20));
-            break;
-        }
-        case SZ3HIP_EB_L2NORM: conf.absErrorBound = sqrt(3.0 / (double)conf.num) * conf.l2normErrorBound; break;
-        case SZ3HIP_EB_ABS_AND_REL: conf.absErrorBound = std::min(conf.absErrorBound, conf.relErrorBound * range); break;
-        case SZ3HIP_EB_ABS_OR_REL: conf.absErrorBound = std::max(conf.absErrorBound, conf.relErrorBound * range); break;
-        default: return fail(SZ3HIP_EINVAL, "Error bound mode not supported");
-    }
-    conf.errorBoundMode = SZ3HIP_EB_ABS;
-    return 0;
-}
-
-// SZ3HIP_TIMING=1: wall-clock breakdown of the host API on stderr (development aid)
-struct HostTimer {
-    bool on;
-    std::chrono::steady_clock::time_point t0;
-    HostTimer() : on(getenv("SZ3HIP_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
-    void lap(const char *what) {
-        if (!on) return;
-        auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[sz3hip] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    }
-};
-extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, const void *data, char *cmpData,
-                                  size_t cmpCap) {
-    HostTimer tm;
-    if (!dtype_ok(dataType)) {
-        fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
-        return 0;
-    }
-    const bool is_int = dtype_is_int(dataType);
-    const int cdt = dtype_compute(dataType);  // the type the kernels compute in
-    sz3hip_config conf = *config;  // sz.hpp:45
-    if (conf.N < 1 || conf.N > 4) {
-        fail(SZ3HIP_EINVAL, "Data dimension higher than 4 is not supported.");
-        return 0;
-    }
-    if (zs::load()) return 0;
-    if (cmpCap < sz3hip_compress_bound(&conf, dataType)) {  // sz.hpp:47-49
-        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
-        return 0;
-    }
-    const size_t es = dtype_size(dataType);
-    const size_t raw_bytes = (size_t)conf.num * es;
-    unsigned char *out = reinterpret_cast<unsigned char *>(cmpData);
-    Writer w{out};
-    w.put<uint32_t>(kMagic);
-    w.put<uint32_t>(kDataVer);
-    unsigned char *size_pos = w.p;
-    w.p += 8;
-    unsigned char tmp[160];
-    const size_t payload_cap = cmpCap - 16 - 2 * sz3hip_config_save(&conf, tmp);
-    size_t payload_size = 0;
-
-    std::lock_guard<std::mutex> lock(g_ctx_mu);
-    bool lossless = conf.cmprAlgo == SZ3HIP_ALGO_LOSSLESS;
-    if (!lossless) {
-        sz3hip_ctx *ctx = get_ctx(cdt, conf.num);
-        if (!ctx) return 0;
-        if (ensure_dev(&g_dev_in[cdt], &g_dev_in_bytes[cdt], (size_t)conf.num * (cdt == SZ3HIP_FLOAT ? 4 : 8))) return 0;
-        const size_t pb = sz3hip_payload_bound(ctx, conf.num);
-        if (ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], pb)) return 0;
-        tm.lap("setup");
-        if (!is_int) {
-            if (hipMemcpy(g_dev_in[cdt], data, raw_bytes, hipMemcpyHostToDevice) != hipSuccess) {
-                fail(SZ3HIP_EHIP, "host->device copy failed");
-                return 0;
-            }
-            tm.lap("host->device");
-        } else {
-            // integers: staged in the (still unused) payload buffer, widened to f64 on the device
-            if (pb < raw_bytes + 16 && ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], raw_bytes + 16)) return 0;
-            if (hipMemcpy(g_dev_payload[cdt], data, raw_bytes, hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemsetAsync(ctx->d_counters + 5, 0, 8, nullptr) != hipSuccess) {
-                fail(SZ3HIP_EHIP, "host->device copy failed");
-                return 0;
-            }
-            if (szk_launch_int_to_f64(dataType == SZ3HIP_INT64, g_dev_payload[cdt], conf.num, (double *)g_dev_in[cdt],
-                                      reinterpret_cast<uint32_t *>(ctx->d_counters + 5), nullptr)) {
-                fail(SZ3HIP_EHIP, "integer widening kernel failed");
-                return 0;
-            }
-            uint32_t big = 0;
-            if (hipMemcpy(&big, ctx->d_counters + 5, 4, hipMemcpyDeviceToHost) != hipSuccess) {
-                fail(SZ3HIP_EHIP, "device->host copy failed");
-                return 0;
-            }
-            if (big) lossless = true;  // |x| > 2^53 is not exact in f64: keep such arrays lossless
-        }
-        if (!lossless && cal_abs_eb(conf, ctx, g_dev_in[cdt])) return 0;
-        if (is_int) {
-            // |x - x^| <= eb between integers means <= floor(eb); the lattice 2*floor(eb) keeps every reconstruction integral
-            conf.absErrorBound = std::floor(conf.absErrorBound);
-            conf.errorBoundMode = SZ3HIP_EB_ABS;
-        }
-        if (conf.absErrorBound == 0) lossless = true;  // SZDispatcher.hpp:19-21
-        if (!lossless) {
-            // ALGO_LORENZO_REG / NOPRED -> HIP Lorenzo stream (16); ALGO_INTERP / ALGO_INTERP_LORENZO -> HIP interpolation (17)
-            size_t dsize = 0;
-            int rc = sz3hip_compress_device(ctx, &conf, g_dev_in[cdt], g_dev_payload[cdt], g_dev_payload_bytes[cdt], &dsize, nullptr);
-            tm.lap("device compress");
-            if (rc == SZ3HIP_EOUTLIERS && g_dev_payload_bytes[cdt] < sz3hip_payload_bound_max(ctx, conf.num)) {
-                // room for the largest lists, then once more (the device call grows them to what the input needs)
-                if (ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], sz3hip_payload_bound_max(ctx, conf.num))) return 0;
-                rc = sz3hip_compress_device(ctx, &conf, g_dev_in[cdt], g_dev_payload[cdt], g_dev_payload_bytes[cdt], &dsize, nullptr);
-            }
-            if (rc == SZ3HIP_EOUTLIERS) {
-                lossless = true;  // same policy as the reference's length_error fallback, SZDispatcher.hpp:44-59
-            } else if (rc) {
-                return 0;
-            } else if (dsize + 64 >= raw_bytes) {
-                lossless = true;  // the GPU stream would not even beat the raw array (tiny or incompressible input)
-            } else {
-                if (ensure_pin(dsize)) return 0;
-                if (hipMemcpy(g_pin, g_dev_payload[cdt], dsize, hipMemcpyDeviceToHost) != hipSuccess) {
-                    fail(SZ3HIP_EHIP, "device->host copy failed");
-                    return 0;
-                }
-                tm.lap("device->host");
-                payload_size = zs::compress_frames((const uint8_t *)g_pin, dsize, w.p, payload_cap);
-                if (!payload_size) return 0;
-                tm.lap("zstd");
-                conf.cmprAlgo = ctx->h_state->hdr.predictor == 1 ? SZ3HIP_ALGO_HIP_INTERP : SZ3HIP_ALGO_HIP_LORENZO;
-                if ((double)raw_bytes / (double)payload_size < 3) {  // SZDispatcher.hpp:62-74
-                    std::vector<uint8_t> z(zs::bound_frames(raw_bytes) + 8);
-                    size_t zsz = zs::compress_frames((const uint8_t *)data, raw_bytes, z.data(), z.size());
-                    if (zsz && zsz < payload_size && zsz <= payload_cap) {
-                        memcpy(w.p, z.data(), zsz);
-                        payload_size = zsz;
-                        conf.cmprAlgo = SZ3HIP_ALGO_LOSSLESS;
-                    }
-                }
-            }
-        }
-    }
-    if (lossless) {
-        conf.cmprAlgo = SZ3HIP_ALGO_LOSSLESS;
-        payload_size = zs::compress_frames((const uint8_t *)data, raw_bytes, w.p, payload_cap);
-        if (!payload_size) return 0;
-    }
-    uint64_t ps = payload_size;
-    memcpy(size_pos, &ps, 8);
-    w.p += payload_size;
-    conf.openmp = 0;
-    conf.dataType = (uint8_t)dataType;  // lets the decoder refuse a request for another element type
-    w.p += sz3hip_config_save(&conf, w.p);
-    return (size_t)(w.p - out);
-}
-
-extern "C" int sz3hip_peek_config(sz3hip_config *conf, const char *cmpData, size_t cmpSize) {
-    if (cmpSize < 16 + 8) return fail(SZ3HIP_EFORMAT, "compressed buffer too small");
-    Reader r{reinterpret_cast<const unsigned char *>(cmpData)};
-    if (r.get<uint32_t>() != kMagic)  // sz.hpp:122-125
-        return fail(SZ3HIP_EFORMAT, "magic number mismatch, the input data is not compressed by SZ3");
-    const uint32_t ver = r.get<uint32_t>();
-    if ((ver >> 8) != (kDataVer >> 8))  // sz.hpp:127-135 compares major.minor.patch
-        return fail(SZ3HIP_EFORMAT, "Please use SZ3 v%u.%u.%u to decompress the data", ver >> 24, (ver >> 16) & 255,
-                    (ver >> 8) & 255);
-    const uint64_t payload = r.get<uint64_t>();
-    if (payload > cmpSize - 16) return fail(SZ3HIP_EFORMAT, "payload size exceeds the buffer");
-    sz3hip_config_load(conf, r.p + payload);
-    return 0;
-}
-
-extern "C" int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *cmpData, size_t cmpSize, void *decData) {
-    if (!dtype_ok(dataType))
-        return fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
-    int rc = sz3hip_peek_config(conf, cmpData, cmpSize);
-    if (rc) return rc;
-    const bool is_int = dtype_is_int(dataType);
-    const int cdt = dtype_compute(dataType);
-    if (dtype_is_int(conf->dataType) != is_int)
-        return fail(SZ3HIP_EINVAL, "the stream holds %s data but %s output was requested", dtype_is_int(conf->dataType) ? "integer" : "floating-point",
-                    is_int ? "integer" : "floating-point");
-    if (zs::load()) return SZ3HIP_EZSTD;
-    const unsigned char *p = reinterpret_cast<const unsigned char *>(cmpData) + 8;
-    uint64_t payload;
-    memcpy(&payload, p, 8);
-    p += 8;
-    const size_t es = dtype_size(dataType);
-    const size_t raw_bytes = (size_t)conf->num * es;
-    if (conf->cmprAlgo == SZ3HIP_ALGO_LOSSLESS) {  // SZDispatcher.hpp:81-88
-        uint64_t len = 0;
-        if (payload >= 8) memcpy(&len, p, 8);
-        if (len != raw_bytes)
-            return fail(SZ3HIP_EFORMAT, "Decompressed data size does not match the original data size");
-        return zs::decompress_frames(p, payload, (uint8_t *)decData, raw_bytes) == raw_bytes ? 0 : SZ3HIP_EZSTD;
-    }
-    if (conf->cmprAlgo != SZ3HIP_ALGO_HIP_LORENZO && conf->cmprAlgo != SZ3HIP_ALGO_HIP_INTERP)
-        return fail(SZ3HIP_EUNSUPPORTED,
-                    "stream uses cmprAlgo %d of the CPU reference; this library decodes only its own GPU streams (ids %d, %d) "
-                    "and ALGO_LOSSLESS",
-                    conf->cmprAlgo, SZ3HIP_ALGO_HIP_LORENZO, SZ3HIP_ALGO_HIP_INTERP);
-    if (payload < 8) return fail(SZ3HIP_EFORMAT, "truncated payload");
-    uint64_t raw_len;
-    memcpy(&raw_len, p, 8);
-    std::lock_guard<std::mutex> lock(g_ctx_mu);
-    if ((rc = ensure_pin(raw_len))) return rc;
-    if (zs::decompress_frames(p, payload, (uint8_t *)g_pin, raw_len) != raw_len) return SZ3HIP_EZSTD;
-    sz3hip_ctx *ctx = get_ctx(cdt, conf->num);
-    if (!ctx) return SZ3HIP_EHIP;
-    const size_t cbytes = (size_t)conf->num * (cdt == SZ3HIP_FLOAT ? 4 : 8);
-    if ((rc = ensure_dev(&g_dev_in[cdt], &g_dev_in_bytes[cdt], cbytes))) return rc;
-    if ((rc = ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], std::max<size_t>(raw_len + 64, is_int ? raw_bytes : 0)))) return rc;
-    HIPCHK(hipMemcpy(g_dev_payload[cdt], g_pin, raw_len, hipMemcpyHostToDevice));
-    rc = sz3hip_decompress_device(ctx, g_dev_payload[cdt], raw_len, g_dev_in[cdt], nullptr);
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(nullptr));
-    if (ctx->h_state->hdr.n != conf->num) return fail(SZ3HIP_EFORMAT, "payload element count does not match the trailer");
-    if (ctx->h_state->hdr.dtype != (uint8_t)cdt) return fail(SZ3HIP_EINVAL, "the stream's element type does not match the requested one");
-    if (!is_int) {
-        HIPCHK(hipMemcpy(decData, g_dev_in[cdt], raw_bytes, hipMemcpyDeviceToHost));  // (the runtime pins large pageable buffers
-                                                                                       // itself: a hand-made pinned pipeline was slower)
-    } else {
-        rc = szk_launch_f64_to_int(dataType == SZ3HIP_INT64, (const double *)g_dev_in[cdt], conf->num, g_dev_payload[cdt], nullptr);
-        if (rc) return fail(SZ3HIP_EHIP, "integer narrowing kernel failed");
-        HIPCHK(hipMemcpy(decData, g_dev_payload[cdt], raw_bytes, hipMemcpyDeviceToHost));
-    }
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// the reference's C ABI (tools/sz3c/include/sz3c.h:52-59, tools/sz3c/src/sz3c.cpp:11-94)
-// ------------------------------------------------------------------------------------------------------------
-extern "C" unsigned char *SZ_compress_args(int dataType, void *data, size_t *outSize, int errBoundMode,
-                                           double absErrBound, double relBoundRatio, double pwrBoundRatio, size_t r5,
-                                           size_t r4, size_t r3, size_t r2, size_t r1) {
-    (void)pwrBoundRatio;  // sz3c.cpp:29 ignores it too
-    uint64_t d[4];
-    int nd;
-    if (r2 == 0) { nd = 1; d[0] = r1; }
-    else if (r3 == 0) { nd = 2; d[0] = r2; d[1] = r1; }
-    else if (r4 == 0) { nd = 3; d[0] = r3; d[1] = r2; d[2] = r1; }
-    else if (r5 == 0) { nd = 4; d[0] = r4; d[1] = r3; d[2] = r2; d[3] = r1; }
-    else { nd = 4; d[0] = r5 * r4; d[1] = r3; d[2] = r2; d[3] = r1; }  // sz3c.cpp:24
-    sz3hip_config conf;
-    sz3hip_config_init(&conf, nd, d);
-    conf.absErrorBound = absErrBound;
-    conf.relErrorBound = relBoundRatio;
-    if (errBoundMode == ABS) conf.errorBoundMode = SZ3HIP_EB_ABS;
-    else if (errBoundMode == REL) conf.errorBoundMode = SZ3HIP_EB_REL;
-    else if (errBoundMode == ABS_AND_REL) conf.errorBoundMode = SZ3HIP_EB_ABS_AND_REL;
-    else if (errBoundMode == ABS_OR_REL) conf.errorBoundMode = SZ3HIP_EB_ABS_OR_REL;
-    else {
-        printf("errBoundMode %d not support\n ", errBoundMode);  // sz3c.cpp:39-40
-        exit(0);
-    }
-    if (dataType != SZ_FLOAT && dataType != SZ_DOUBLE) {
-        printf("dataType %d not support\n", dataType);  // sz3c.cpp:51-52
-        exit(0);
-    }
-    const size_t cap = sz3hip_compress_bound(&conf, dataType);
-    unsigned char *buf = static_cast<unsigned char *>(malloc(cap));  // C memory, released by free_buf (sz3c.cpp:56-58)
-    if (!buf) return nullptr;
-    const size_t n = sz3hip_compress(&conf, dataType, data, reinterpret_cast<char *>(buf), cap);
-    if (n == 0) {
-        fprintf(stderr, "SZ_compress_args: %s\n", sz3hip_last_error());
-        free(buf);
-        *outSize = 0;
-        return nullptr;
-    }
-    *outSize = n;
-    unsigned char *shrunk = static_cast<unsigned char *>(realloc(buf, n));
-    return shrunk ? shrunk : buf;
-}
-
-extern "C" void *SZ_decompress(int dataType, unsigned char *bytes, size_t byteLength, size_t r5, size_t r4, size_t r3,
-                               size_t r2, size_t r1) {
-    size_t n;  // sz3c.cpp:66-77
-    if (r2 == 0) n = r1;
-    else if (r3 == 0) n = r1 * r2;
-    else if (r4 == 0) n = r1 * r2 * r3;
-    else if (r5 == 0) n = r1 * r2 * r3 * r4;
-    else n = r1 * r2 * r3 * r4 * r5;
-    if (dataType != SZ_FLOAT && dataType != SZ_DOUBLE) {
-        printf("dataType %d not support\n", dataType);  // sz3c.cpp:90-91
-        exit(0);
-    }
-    sz3hip_config conf;
-    if (sz3hip_peek_config(&conf, reinterpret_cast<const char *>(bytes), byteLength)) {
-        fprintf(stderr, "SZ_decompress: %s\n", sz3hip_last_error());
-        return nullptr;
-    }
-    if (conf.num > n) n = (size_t)conf.num;
-    void *dec = malloc(n * (dataType == SZ_FLOAT ? 4 : 8));
-    if (!dec) return nullptr;
-    if (sz3hip_decompress(&conf, dataType, reinterpret_cast<const char *>(bytes), byteLength, dec)) {
-        fprintf(stderr, "SZ_decompress: %s\n", sz3hip_last_error());
-        free(dec);
-        return nullptr;
-    }
-    return dec;
-}
-
-extern "C" void free_buf(void *p) { free(p); }  // sz3c.cpp:94

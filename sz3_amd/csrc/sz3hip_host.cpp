@@ -1,0 +1,1162 @@
+// sz3_amd/csrc/sz3hip_host.cpp — the host-buffer side of libsz3hip.so: what SZ_compress<T> / SZ_decompress<T> do around the
+// GPU path (paths relative to /root/reference):
+//   include/SZ3/api/sz.hpp:43-82,117-157         container: 16-byte header + payload + Config trailer
+//   include/SZ3/api/impl/SZImpl.hpp:10-44        openmp ? SZ_compress_OMP : SZ_compress_dispatcher, size bound
+//   include/SZ3/api/impl/SZDispatcher.hpp:13-100 eb-mode conversion, eb==0 => lossless, lossless fallback,
+//                                                "ratio < 3 => also try zstd alone"
+//   include/SZ3/api/impl/SZImplOMP.hpp:16-186    slabs along dims[0], global value range, the multi-slab container
+//                                                [i32 G][Config x G][u64 size x G][blob x G] and its decoder —
+//                                                here: slabs dealt to the visible GPUs, one host thread per GPU, one
+//                                                RCCL all-reduce of the code histogram between stage 1 and stage 2
+//   include/SZ3/lossless/Lossless_zstd.hpp:29-45 [u64 rawLen][zstd frames]  (several concatenated frames, compressed by
+//                                                a thread pool; any zstd decoder reads them)
+//   tools/sz3c/src/sz3c.cpp:11-94                SZ_compress_args / SZ_decompress / free_buf
+// There is NO CPU implementation of the predictor/quantizer/Huffman stages in this library: without a HIP device every
+// entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/sz3c.h"
+#include "../../include/sz3hip.h"
+#include "sz3hip_internal.h"
+
+#define fail szi_fail
+#define HIPCHK(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return fail(SZ3HIP_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------------------
+// libzstd (third-party, the reference's lossless stage; not vendored there either — CMakeLists.txt:69-75).
+// zstd.h is not installed in /usr/include of this image, so the five prototypes are declared here and the
+// library is dlopen'ed; a missing library is a hard error.
+// ------------------------------------------------------------------------------------------------------------
+namespace zs {
+typedef size_t (*compress_fn)(void *, size_t, const void *, size_t, int);
+typedef size_t (*decompress_fn)(void *, size_t, const void *, size_t);
+typedef size_t (*bound_fn)(size_t);
+typedef unsigned (*iserr_fn)(size_t);
+typedef size_t (*framesize_fn)(const void *, size_t);
+typedef unsigned long long (*contentsize_fn)(const void *, size_t);
+static void *h;
+static compress_fn compress;
+static decompress_fn decompress;
+static bound_fn bound;
+static iserr_fn is_error;
+static framesize_fn frame_csize;
+static contentsize_fn frame_content;
+static std::once_flag once;
+static bool ok;
+static void load_once() {
+    const char *names[] = {"libzstd.so.1", "libzstd.so", "/usr/lib/x86_64-linux-gnu/libzstd.so.1", nullptr};
+    for (int i = 0; names[i] && !h; i++) h = dlopen(names[i], RTLD_NOW);
+    if (!h) return;
+    compress = (compress_fn)dlsym(h, "ZSTD_compress");
+    decompress = (decompress_fn)dlsym(h, "ZSTD_decompress");
+    bound = (bound_fn)dlsym(h, "ZSTD_compressBound");
+    is_error = (iserr_fn)dlsym(h, "ZSTD_isError");
+    frame_csize = (framesize_fn)dlsym(h, "ZSTD_findFrameCompressedSize");
+    frame_content = (contentsize_fn)dlsym(h, "ZSTD_getFrameContentSize");
+    ok = compress && decompress && bound && is_error;
+}
+static int load() {
+    std::call_once(once, load_once);
+    return ok ? 0 : fail(SZ3HIP_EZSTD, "libzstd.so.1 not found or incomplete");
+}
+static const size_t FRAME = 4u << 20;  // bytes of input per zstd frame
+static unsigned nthreads() {
+    const char *e = getenv("SZ3HIP_ZSTD_THREADS");
+    unsigned n = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    return n;
+}
+static size_t bound_frames(size_t n) {
+    size_t nf = (n + FRAME - 1) / FRAME;
+    if (nf == 0) nf = 1;
+    return nf * bound(std::min(n, FRAME)) + 8;
+}
+// [u64 srcLen][frame]...  level 3 (lossless/Lossless_zstd.hpp:48); returns 0 on error
+static size_t compress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {
+    if (load()) return 0;
+    if (cap < 8) {
+        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+        return 0;
+    }
+    uint64_t len = n;
+    memcpy(dst, &len, 8);
+    const size_t nf = std::max<size_t>(1, (n + FRAME - 1) / FRAME);
+    const size_t fb = bound(std::min(n, FRAME));
+    std::vector<std::vector<uint8_t>> out(nf);
+    std::vector<size_t> sz(nf, 0);
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    auto work = [&]() {
+        for (;;) {
+            size_t f = next.fetch_add(1);
+            if (f >= nf) break;
+            size_t lo = f * FRAME, l = std::min(FRAME, n - lo);
+            out[f].resize(fb);
+            size_t r = compress(out[f].data(), fb, src + lo, l, 3);
+            if (is_error(r)) bad = 1;
+            sz[f] = r;
+        }
+    };
+    unsigned nt = (unsigned)std::min<size_t>(nthreads(), nf);
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (bad) {
+        fail(SZ3HIP_EZSTD, "ZSTD_compress failed");
+        return 0;
+    }
+    size_t total = 8;
+    for (size_t f = 0; f < nf; f++) total += sz[f];
+    if (total > cap) {
+        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+        return 0;
+    }
+    uint8_t *p = dst + 8;
+    for (size_t f = 0; f < nf; f++) {
+        memcpy(p, out[f].data(), sz[f]);
+        p += sz[f];
+    }
+    return total;
+}
+// inverse; frames are located with ZSTD_findFrameCompressedSize and decoded in parallel. returns bytes produced
+static size_t decompress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {
+    if (load()) return 0;
+    if (n < 8) {
+        fail(SZ3HIP_EFORMAT, "truncated lossless block");
+        return 0;
+    }
+    uint64_t len;
+    memcpy(&len, src, 8);
+    if (len > cap) {
+        fail(SZ3HIP_ECAPACITY, "lossless block larger than the destination");
+        return 0;
+    }
+    const uint8_t *p = src + 8;
+    size_t rem = n - 8;
+    struct Fr { const uint8_t *p; size_t c, off, d; };
+    std::vector<Fr> frames;
+    bool split = frame_csize && frame_content;
+    if (split) {
+        size_t off = 0;
+        while (rem > 0) {
+            size_t c = frame_csize(p, rem);
+            if (is_error(c)) { split = false; break; }
+            unsigned long long d = frame_content(p, c);
+            if (d == (unsigned long long)-1 || d == (unsigned long long)-2) { split = false; break; }
+            frames.push_back({p, c, off, (size_t)d});
+            off += (size_t)d;
+            p += c;
+            rem -= c;
+        }
+        if (split && off != len) split = false;
+    }
+    if (!split || frames.size() <= 1) {
+        size_t r = decompress(dst, (size_t)len, src + 8, n - 8);
+        if (is_error(r) || r != len) {
+            fail(SZ3HIP_EZSTD, "ZSTD_decompress failed");
+            return 0;
+        }
+        return r;
+    }
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    auto work = [&]() {
+        for (;;) {
+            size_t f = next.fetch_add(1);
+            if (f >= frames.size()) break;
+            size_t r = decompress(dst + frames[f].off, frames[f].d, frames[f].p, frames[f].c);
+            if (is_error(r) || r != frames[f].d) bad = 1;
+        }
+    };
+    unsigned nt = (unsigned)std::min<size_t>(nthreads(), frames.size());
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (bad) {
+        fail(SZ3HIP_EZSTD, "ZSTD_decompress failed");
+        return 0;
+    }
+    return (size_t)len;
+}
+}  // namespace zs
+
+// ------------------------------------------------------------------------------------------------------------
+// host-buffer API: SZ_compress<T> / SZ_decompress<T> equivalents
+// ------------------------------------------------------------------------------------------------------------
+static const uint32_t kMagic = 0xF342F310u;                          // include/SZ3/version.hpp.in:10
+static const uint32_t kDataVer = (3u << 24) | (3u << 16) | (2u << 8);  // SZ3_DATA_VERSION 3.3.2 (CMakeLists.txt:7)
+
+static inline bool dtype_ok(int dt) { return dt == SZ3HIP_FLOAT || dt == SZ3HIP_DOUBLE || dt == SZ3HIP_INT32 || dt == SZ3HIP_INT64; }
+static inline bool dtype_is_int(int dt) { return dt == SZ3HIP_INT32 || dt == SZ3HIP_INT64; }
+static inline size_t dtype_size(int dt) { return (dt == SZ3HIP_FLOAT || dt == SZ3HIP_INT32) ? 4 : 8; }
+static inline int dtype_compute(int dt) { return dtype_is_int(dt) ? SZ3HIP_DOUBLE : dt; }  // integers ride the f64 pipeline
+
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+static int host_device() { return env_int("SZ3HIP_DEVICE", 0); }
+// GPUs a conf.openmp call spreads its slabs over: all visible ones (SZ3HIP_GPUS caps the number)
+static int multi_devices() {
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess) {
+        (void)hipGetLastError();
+        have = 0;
+    }
+    int want = env_int("SZ3HIP_GPUS", have);
+    return std::max(1, std::min(want, std::max(have, 1)));
+}
+// slabs of a conf.openmp call: one per GPU, as the reference makes one per OpenMP thread, never more than dims[0]
+// (api/impl/SZImplOMP.hpp:33-36); SZ3HIP_SLABS asks for another count (several slabs per GPU run one after the other)
+static int multi_slabs(const sz3hip_config &c) {
+    int g = env_int("SZ3HIP_SLABS", multi_devices());
+    g = std::max(1, std::min(g, 4096));
+    if (c.N >= 1 && (uint64_t)g > c.dims[0]) g = (int)std::max<uint64_t>(1, c.dims[0]);
+    return g;
+}
+static void slab_range(const sz3hip_config &c, int G, int g, uint64_t *lo, uint64_t *hi) {  // SZImplOMP.hpp:48-50
+    *lo = (uint64_t)g * c.dims[0] / (uint64_t)G;
+    *hi = (uint64_t)(g + 1) * c.dims[0] / (uint64_t)G;
+}
+
+extern "C" size_t sz3hip_compress_bound(const sz3hip_config *c, int dataType) {  // api/impl/SZImpl.hpp:34-44
+    if (zs::load()) return 0;
+    unsigned char tmp[160];
+    const size_t es = dtype_size(dataType);
+    size_t b = 4096 + sz3hip_config_save(c, tmp) + zs::bound_frames((size_t)c->num * es);
+    if (c->openmp && c->N >= 1 && c->dims[0] > 0) {  // SZ_compress_size_bound_omp, SZImplOMP.hpp:188-206
+        const size_t G = (size_t)multi_slabs(*c);
+        const size_t slab = (size_t)((c->dims[0] + G - 1) / G) * (size_t)(c->num / c->dims[0]) * es;
+        b += 4 + G * (160 + 8 + 8 + zs::bound(std::min(slab, zs::FRAME)));
+    }
+    return b;
+}
+
+namespace {
+// Everything one slab of a host-API call needs on one GPU: context, staging buffers, stream. Cached per (device, computing
+// type, index); grown on demand. The host API is serialised per process (g_host_mu); inside a multi-slab call the slots of
+// one device are worked by that device's host thread only.
+struct HostSlot {
+    int device = 0, dtype = 0, index = 0;
+    sz3hip_ctx *ctx = nullptr;
+    hipStream_t stream = nullptr;
+    void *dev_in = nullptr, *dev_payload = nullptr, *pin = nullptr;
+    size_t dev_in_bytes = 0, dev_payload_bytes = 0, pin_bytes = 0;
+};
+std::mutex g_host_mu;
+std::vector<std::unique_ptr<HostSlot>> g_slots;
+sz3hip_comm *g_comm;
+int g_comm_ndev;
+
+HostSlot *get_slot(int device, int dtype, int index) {
+    for (auto &s : g_slots)
+        if (s->device == device && s->dtype == dtype && s->index == index) return s.get();
+    g_slots.emplace_back(new HostSlot());
+    HostSlot *s = g_slots.back().get();
+    s->device = device;
+    s->dtype = dtype;
+    s->index = index;
+    return s;
+}
+// (the calling thread's current device is the slot's)
+int slot_ctx(HostSlot *s, uint64_t n) {
+    if (!s->stream) HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    if (s->ctx && s->ctx->max_n >= n) return 0;
+    if (s->ctx) sz3hip_ctx_destroy(s->ctx);
+    s->ctx = sz3hip_ctx_create(s->device, n, s->dtype);
+    return s->ctx ? 0 : sz3hip_last_error_code();
+}
+int ensure_dev(void **p, size_t *have, size_t want) {
+    if (*have >= want) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    HIPCHK(hipMalloc(p, want));
+    *have = want;
+    return 0;
+}
+// pinned host staging for the payload (the device <-> host hop of the host API): DMA at link speed, no page faults
+int ensure_pin(HostSlot *s, size_t want) {
+    if (s->pin_bytes >= want) return 0;
+    if (s->pin) (void)hipHostFree(s->pin);
+    s->pin = nullptr;
+    s->pin_bytes = 0;
+    want += want / 4;  // (payload sizes vary from call to call)
+    HIPCHK(hipHostMalloc(&s->pin, want));
+    s->pin_bytes = want;
+    return 0;
+}
+
+// the caller's current device is left as it was found (the library binds its own per slot)
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() {
+        if (hipGetDevice(&prev) != hipSuccess) {
+            (void)hipGetLastError();
+            prev = -1;
+        }
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// SZ3HIP_TIMING=1: wall-clock breakdown of the host API on stderr (development aid)
+struct HostTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    HostTimer() : on(getenv("SZ3HIP_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void lap(const char *what) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sz3hip] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
+struct Barrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int n, count = 0, gen = 0;
+    explicit Barrier(int n_) : n(n_) {}
+    void wait() {
+        std::unique_lock<std::mutex> l(m);
+        const int g = gen;
+        if (++count == n) {
+            count = 0;
+            gen++;
+            cv.notify_all();
+        } else {
+            cv.wait(l, [&] { return g != gen; });
+        }
+    }
+};
+
+// One slab's trip through SZ_compress_dispatcher (api/impl/SZDispatcher.hpp:13-76), cut where the slab-parallel path
+// needs all slabs to meet: [upload, value range] | global range -> eb | [stage 1] | histogram exchange | [stage 2, D2H, zstd]
+struct SlabJob {
+    int index = 0, dataType = 0, cdt = 0;
+    bool is_int = false;
+    size_t es = 0, raw_bytes = 0;
+    sz3hip_config conf;          // this slab's Config; cmprAlgo becomes the id of the stream that was written
+    const void *data = nullptr;  // host pointer of the slab
+    HostSlot *slot = nullptr;
+    unsigned char *out = nullptr;  // receives the dispatcher's output ([u64 rawLen][zstd frames])
+    size_t out_cap = 0, out_size = 0;
+    std::vector<unsigned char> own_out;  // multi-slab: the blob is staged here, then copied into the container
+    bool lossless = false, staged = false;
+    double mn = 0, mx = 0;
+    int rc = 0;
+    std::string err;
+    HostTimer *tm = nullptr;
+    int failed(int code) {  // keeps the failing thread's message for the thread that reports
+        rc = code ? code : SZ3HIP_EHIP;
+        err = sz3hip_last_error();
+        return rc;
+    }
+};
+
+// utils/Statistic.hpp:32-56 with the range from the device min/max kernel; data_range computes max - min in T (:12-21)
+int abs_eb_from_range(sz3hip_config &conf, int cdt, double mn, double mx) {
+    if (conf.errorBoundMode == SZ3HIP_EB_ABS) return 0;
+    const double range = cdt == SZ3HIP_FLOAT ? (double)((float)mx - (float)mn) : mx - mn;
+    switch (conf.errorBoundMode) {
+        case SZ3HIP_EB_REL: conf.absErrorBound = conf.relErrorBound * range; break;
+        case SZ3HIP_EB_PSNR: {  // computeABSErrBoundFromPSNR, Statistic.hpp:25-30, threshold 0.99
+            double v1 = conf.psnrErrorBound + 10 * log10(1 - 2.0 / 3.0 * 0.99);
+            conf.absErrorBound = range * pow(10, v1 / (-20));
+            break;
+        }
+        case SZ3HIP_EB_L2NORM: conf.absErrorBound = sqrt(3.0 / (double)conf.num) * conf.l2normErrorBound; break;
+        case SZ3HIP_EB_ABS_AND_REL: conf.absErrorBound = std::min(conf.absErrorBound, conf.relErrorBound * range); break;
+        case SZ3HIP_EB_ABS_OR_REL: conf.absErrorBound = std::max(conf.absErrorBound, conf.relErrorBound * range); break;
+        default: return fail(SZ3HIP_EINVAL, "Error bound mode not supported");
+    }
+    conf.errorBoundMode = SZ3HIP_EB_ABS;
+    return 0;
+}
+
+// phase 1: input into HBM (SZDispatcher.hpp:27 makes a copy too), local value range when the bound needs it
+int job_upload(SlabJob &j) {
+    if (j.conf.cmprAlgo == SZ3HIP_ALGO_LOSSLESS) {
+        j.lossless = true;
+        return 0;
+    }
+    HostSlot *s = j.slot;
+    if (hipSetDevice(s->device) != hipSuccess) {
+        fail(SZ3HIP_EHIP, "hipSetDevice(%d) failed — no usable HIP device; this library has no CPU path", s->device);
+        return j.failed(SZ3HIP_EHIP);
+    }
+    if (slot_ctx(s, j.conf.num)) return j.failed(sz3hip_last_error_code());
+    sz3hip_ctx *ctx = s->ctx;
+    const size_t cbytes = (size_t)j.conf.num * (j.cdt == SZ3HIP_FLOAT ? 4 : 8);
+    if (ensure_dev(&s->dev_in, &s->dev_in_bytes, cbytes)) return j.failed(SZ3HIP_EHIP);
+    const size_t pb = sz3hip_payload_bound(ctx, j.conf.num);
+    if (ensure_dev(&s->dev_payload, &s->dev_payload_bytes, pb)) return j.failed(SZ3HIP_EHIP);
+    if (j.tm) j.tm->lap("setup");
+    if (!j.is_int) {
+        if (hipMemcpy(s->dev_in, j.data, j.raw_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            fail(SZ3HIP_EHIP, "host->device copy failed");
+            return j.failed(SZ3HIP_EHIP);
+        }
+        if (j.tm) j.tm->lap("host->device");
+    } else {
+        // integers: staged in the (still unused) payload buffer, widened to f64 on the device
+        if (pb < j.raw_bytes + 16 && ensure_dev(&s->dev_payload, &s->dev_payload_bytes, j.raw_bytes + 16)) return j.failed(SZ3HIP_EHIP);
+        if (hipMemcpy(s->dev_payload, j.data, j.raw_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemsetAsync(ctx->d_counters + 5, 0, 8, s->stream) != hipSuccess) {
+            fail(SZ3HIP_EHIP, "host->device copy failed");
+            return j.failed(SZ3HIP_EHIP);
+        }
+        if (szk_launch_int_to_f64(j.dataType == SZ3HIP_INT64, s->dev_payload, j.conf.num, (double *)s->dev_in,
+                                  reinterpret_cast<uint32_t *>(ctx->d_counters + 5), s->stream)) {
+            fail(SZ3HIP_EHIP, "integer widening kernel failed");
+            return j.failed(SZ3HIP_EHIP);
+        }
+        uint32_t big = 0;
+        if (hipMemcpyAsync(&big, ctx->d_counters + 5, 4, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+            hipStreamSynchronize(s->stream) != hipSuccess) {
+            fail(SZ3HIP_EHIP, "device->host copy failed");
+            return j.failed(SZ3HIP_EHIP);
+        }
+        if (big) j.lossless = true;  // |x| > 2^53 is not exact in f64: keep such arrays lossless
+    }
+    if (!j.lossless && j.conf.errorBoundMode != SZ3HIP_EB_ABS && j.conf.errorBoundMode != SZ3HIP_EB_L2NORM)
+        if (sz3hip_minmax_device(ctx, s->dev_in, j.conf.num, &j.mn, &j.mx, s->stream)) return j.failed(sz3hip_last_error_code());
+    return 0;
+}
+
+// phase 2: predictor + quantizer + histogram (asynchronous on the slot's stream); conf carries the absolute bound
+int job_stage1(SlabJob &j) {
+    if (j.rc || j.lossless) return j.rc;
+    HostSlot *s = j.slot;
+    (void)hipSetDevice(s->device);
+    if (j.is_int) {
+        // |x - x^| <= eb between integers means <= floor(eb); the lattice 2*floor(eb) keeps every reconstruction integral
+        j.conf.absErrorBound = std::floor(j.conf.absErrorBound);
+        j.conf.errorBoundMode = SZ3HIP_EB_ABS;
+    }
+    if (j.conf.absErrorBound == 0) {  // SZDispatcher.hpp:19-21
+        j.lossless = true;
+        return 0;
+    }
+    // ALGO_LORENZO_REG / NOPRED -> HIP Lorenzo stream (16); ALGO_INTERP / ALGO_INTERP_LORENZO -> HIP interpolation (17)
+    if (sz3hip_compress_stage1(s->ctx, &j.conf, s->dev_in, s->stream)) return j.failed(sz3hip_last_error_code());
+    j.staged = true;
+    return 0;
+}
+
+// phase 3: code book + encode on the device, payload to the host, lossless stage, the dispatcher's fallbacks
+int job_encode(SlabJob &j) {
+    if (j.rc) return j.rc;
+    HostSlot *s = j.slot;
+    if (!j.lossless) {
+        (void)hipSetDevice(s->device);
+        sz3hip_ctx *ctx = s->ctx;
+        size_t dsize = 0;
+        int rc = sz3hip_compress_stage2(ctx, s->dev_payload, s->dev_payload_bytes, s->stream);
+        if (!rc) rc = sz3hip_compress_finish(ctx, &dsize, s->stream);
+        if (j.tm) j.tm->lap("device compress");
+        if (rc == SZ3HIP_EOUTLIERS) {
+            // more unpredictable values than the default lists hold: room for the largest lists, then the slab once more by
+            // itself (the device call grows the lists to what the input needs; a slab that took this turn is coded with its
+            // own code book — every blob carries its code lengths, so the container does not care)
+            if (ensure_dev(&s->dev_payload, &s->dev_payload_bytes, sz3hip_payload_bound_max(ctx, j.conf.num))) return j.failed(SZ3HIP_EHIP);
+            rc = sz3hip_compress_device(ctx, &j.conf, s->dev_in, s->dev_payload, s->dev_payload_bytes, &dsize, s->stream);
+        }
+        if (rc == SZ3HIP_EOUTLIERS) {
+            j.lossless = true;  // same policy as the reference's length_error fallback, SZDispatcher.hpp:44-59
+        } else if (rc) {
+            return j.failed(rc);
+        } else if (dsize + 64 >= j.raw_bytes) {
+            j.lossless = true;  // the GPU stream would not even beat the raw array (tiny or incompressible input)
+        } else {
+            if (ensure_pin(s, dsize)) return j.failed(SZ3HIP_EHIP);
+            if (hipMemcpy(s->pin, s->dev_payload, dsize, hipMemcpyDeviceToHost) != hipSuccess) {
+                fail(SZ3HIP_EHIP, "device->host copy failed");
+                return j.failed(SZ3HIP_EHIP);
+            }
+            if (j.tm) j.tm->lap("device->host");
+            j.out_size = zs::compress_frames((const uint8_t *)s->pin, dsize, j.out, j.out_cap);
+            if (!j.out_size) return j.failed(sz3hip_last_error_code());
+            if (j.tm) j.tm->lap("zstd");
+            j.conf.cmprAlgo = ctx->h_state->hdr.predictor == 1 ? SZ3HIP_ALGO_HIP_INTERP : SZ3HIP_ALGO_HIP_LORENZO;
+            if ((double)j.raw_bytes / (double)j.out_size < 3) {  // SZDispatcher.hpp:62-74
+                std::vector<uint8_t> z(zs::bound_frames(j.raw_bytes) + 8);
+                size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size());
+                if (zsz && zsz < j.out_size && zsz <= j.out_cap) {
+                    memcpy(j.out, z.data(), zsz);
+                    j.out_size = zsz;
+                    j.conf.cmprAlgo = SZ3HIP_ALGO_LOSSLESS;
+                }
+            }
+        }
+    }
+    if (j.lossless) {
+        j.conf.cmprAlgo = SZ3HIP_ALGO_LOSSLESS;
+        j.out_size = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, j.out, j.out_cap);
+        if (!j.out_size) return j.failed(sz3hip_last_error_code());
+    }
+    return 0;
+}
+
+void job_init(SlabJob &j, const sz3hip_config &conf, int dataType, const void *data, int index) {
+    j.index = index;
+    j.dataType = dataType;
+    j.cdt = dtype_compute(dataType);
+    j.is_int = dtype_is_int(dataType);
+    j.es = dtype_size(dataType);
+    j.conf = conf;
+    j.conf.dataType = (uint8_t)dataType;  // lets the decoder refuse a request for another element type
+    j.raw_bytes = (size_t)conf.num * j.es;
+    j.data = data;
+}
+
+// The histogram exchange of a multi-slab call (the calling thread drives every GPU, as a single-process RCCL program
+// does): per GPU the histograms of its slabs are summed into the first one's, the per-GPU sums are all-reduced over
+// xGMI, the result is handed back to every slab's context. Slabs that never reached stage 1 (lossless) take no part.
+int exchange_histograms(std::vector<SlabJob> &jobs, const std::vector<int> &devices) {
+    const size_t nd = devices.size();
+    std::vector<std::vector<SlabJob *>> per(nd);
+    for (auto &j : jobs)
+        if (j.staged && !j.rc)
+            for (size_t d = 0; d < nd; d++)
+                if (j.slot->device == devices[d]) per[d].push_back(&j);
+    size_t total = 0;
+    for (auto &p : per) total += p.size();
+    if (total <= 1 && !g_comm) return 0;
+    std::vector<sz3hip_ctx *> lead(nd, nullptr);
+    std::vector<void *> bufs(nd, nullptr), streams(nd, nullptr);
+    static std::vector<std::pair<int, void *>> zero_hist;  // per device: what a GPU without a coded slab contributes
+    for (size_t d = 0; d < nd; d++) {
+        HIPCHK(hipSetDevice(devices[d]));
+        if (per[d].empty()) {
+            if (!g_comm) continue;
+            void *z = nullptr;
+            for (auto &zh : zero_hist)
+                if (zh.first == devices[d]) z = zh.second;
+            if (!z) {
+                HIPCHK(hipMalloc(&z, SZH_HIST_BINS * 8));
+                zero_hist.emplace_back(devices[d], z);
+            }
+            HIPCHK(hipMemsetAsync(z, 0, SZH_HIST_BINS * 8, nullptr));
+            bufs[d] = z;
+            streams[d] = nullptr;
+            continue;
+        }
+        SlabJob *l = per[d][0];
+        bufs[d] = sz3hip_histogram_ptr(l->slot->ctx);
+        streams[d] = l->slot->stream;
+        for (size_t k = 1; k < per[d].size(); k++) {
+            HIPCHK(hipStreamSynchronize(per[d][k]->slot->stream));  // (its stage 1 wrote the histogram being added)
+            if (szk_launch_hist_add((uint64_t *)bufs[d], (const uint64_t *)sz3hip_histogram_ptr(per[d][k]->slot->ctx), SZH_HIST_BINS,
+                                    (hipStream_t)streams[d]))
+                return fail(SZ3HIP_EHIP, "histogram add kernel failed");
+        }
+    }
+    if (g_comm) {
+        int rc = sz3hip_comm_allreduce_u64(g_comm, bufs.data(), SZH_HIST_BINS, streams.data());
+        if (rc) return rc;
+    }
+    for (size_t d = 0; d < nd; d++) {
+        if (per[d].empty()) {
+            if (g_comm) {
+                HIPCHK(hipSetDevice(devices[d]));
+                HIPCHK(hipStreamSynchronize(nullptr));
+            }
+            continue;
+        }
+        HIPCHK(hipSetDevice(devices[d]));
+        for (size_t k = 1; k < per[d].size(); k++)
+            HIPCHK(hipMemcpyAsync(sz3hip_histogram_ptr(per[d][k]->slot->ctx), bufs[d], SZH_HIST_BINS * 8, hipMemcpyDeviceToDevice,
+                                  (hipStream_t)streams[d]));
+        HIPCHK(hipStreamSynchronize((hipStream_t)streams[d]));
+    }
+    return 0;
+}
+
+// SZ_compress_OMP (api/impl/SZImplOMP.hpp:16-117) over GPUs: returns the size of the container body written at `out`
+size_t compress_slabs(sz3hip_config &conf, int dataType, const void *data, unsigned char *out, size_t cap) {
+    const int ndev = multi_devices();
+    const int G = multi_slabs(conf);
+    const int cdt = dtype_compute(dataType);
+    const size_t es = dtype_size(dataType);
+    if (conf.cmprAlgo != SZ3HIP_ALGO_LOSSLESS) {
+        int have = 0;
+        if (hipGetDeviceCount(&have) != hipSuccess || have < 1) {
+            (void)hipGetLastError();
+            fail(SZ3HIP_EHIP, "no usable HIP device; this library has no CPU path");
+            return 0;
+        }
+        // several GPUs need the exchange; one GPU sums its slabs' histograms by itself (SZ3HIP_RCCL_SINGLE=1 sends that sum
+        // through a one-rank communicator all the same: the RCCL path on a one-GPU box)
+        const bool want_comm = ndev > 1 || env_int("SZ3HIP_RCCL_SINGLE", 0) == 1;
+        if (g_comm && (!want_comm || g_comm_ndev != ndev)) {
+            sz3hip_comm_destroy(g_comm);
+            g_comm = nullptr;
+        }
+        if (want_comm && !g_comm) {
+            g_comm = sz3hip_comm_create_local(ndev, nullptr);
+            g_comm_ndev = ndev;
+            if (!g_comm) return 0;
+        }
+    }
+    std::vector<int> devices;
+    for (int d = 0; d < ndev; d++) devices.push_back(ndev == 1 ? host_device() : d);
+    const uint64_t base = conf.num / conf.dims[0];
+    std::vector<SlabJob> jobs(G);
+    for (int g = 0; g < G; g++) {
+        uint64_t lo, hi;
+        slab_range(conf, G, g, &lo, &hi);
+        sz3hip_config ct = conf;  // conf_t[tid] = conf; setDims(slab) (SZImplOMP.hpp:71-72)
+        uint64_t d[4];
+        for (int i = 0; i < conf.N; i++) d[i] = conf.dims[i];
+        d[0] = hi - lo;
+        sz3hip_config geo;
+        sz3hip_config_init(&geo, conf.N, d);
+        ct.N = geo.N;
+        memcpy(ct.dims, geo.dims, sizeof(ct.dims));
+        ct.num = geo.num;
+        ct.predDim = geo.predDim;
+        ct.blockSize = geo.blockSize;
+        job_init(jobs[g], ct, dataType, (const unsigned char *)data + lo * base * es, g);
+        jobs[g].slot = get_slot(devices[g % ndev], cdt, g / ndev);
+        jobs[g].own_out.resize(zs::bound_frames(jobs[g].raw_bytes) + 64);
+        jobs[g].out = jobs[g].own_out.data();
+        jobs[g].out_cap = jobs[g].own_out.size();
+    }
+    Barrier bar(ndev);
+    int shared_rc = 0;
+    std::string shared_err;
+    auto worker = [&](int t) {
+        for (int g = t; g < G; g += ndev) job_upload(jobs[g]);
+        bar.wait();
+        if (t == 0) {  // global value range -> the absolute bound every slab uses (SZImplOMP.hpp:57-69)
+            if (conf.errorBoundMode != SZ3HIP_EB_ABS) {
+                double mn = INFINITY, mx = -INFINITY;
+                bool any = false;
+                for (auto &j : jobs)
+                    if (!j.rc && !j.lossless) {
+                        mn = std::min(mn, j.mn);
+                        mx = std::max(mx, j.mx);
+                        any = true;
+                    }
+                if (any && abs_eb_from_range(conf, cdt, mn, mx)) {
+                    shared_rc = sz3hip_last_error_code();
+                    shared_err = sz3hip_last_error();
+                }
+            }
+            for (auto &j : jobs) {
+                j.conf.errorBoundMode = conf.errorBoundMode;
+                j.conf.absErrorBound = conf.absErrorBound;
+            }
+        }
+        bar.wait();
+        if (!shared_rc)
+            for (int g = t; g < G; g += ndev) job_stage1(jobs[g]);
+        bar.wait();
+        if (t == 0 && !shared_rc && exchange_histograms(jobs, devices)) {
+            shared_rc = sz3hip_last_error_code();
+            shared_err = sz3hip_last_error();
+        }
+        bar.wait();
+        if (!shared_rc)
+            for (int g = t; g < G; g += ndev) job_encode(jobs[g]);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < ndev; t++) th.emplace_back(worker, t);
+    worker(0);
+    for (auto &t : th) t.join();
+    if (shared_rc) {
+        fail(shared_rc, "%s", shared_err.c_str());
+        return 0;
+    }
+    for (auto &j : jobs)
+        if (j.rc) {
+            fail(j.rc, "slab %d: %s", j.index, j.err.c_str());
+            return 0;
+        }
+    // [i32 G][Config x G][u64 size x G][blob x G]  (SZImplOMP.hpp:100-110)
+    unsigned char tmp[160];
+    size_t need = 4 + 8 * (size_t)G;
+    for (auto &j : jobs) need += sz3hip_config_save(&j.conf, tmp) + j.out_size;
+    if (need > cap) {
+        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+        return 0;
+    }
+    Writer w{out};
+    w.put<int32_t>(G);
+    for (auto &j : jobs) w.p += sz3hip_config_save(&j.conf, w.p);
+    for (auto &j : jobs) w.put<uint64_t>((uint64_t)j.out_size);
+    for (auto &j : jobs) {
+        memcpy(w.p, j.out, j.out_size);
+        w.p += j.out_size;
+    }
+    return (size_t)(w.p - out);
+}
+}  // namespace
+
+extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, const void *data, char *cmpData,
+                                  size_t cmpCap) {
+    HostTimer tm;
+    if (!dtype_ok(dataType)) {
+        fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
+        return 0;
+    }
+    sz3hip_config conf = *config;  // sz.hpp:45
+    if (conf.N < 1 || conf.N > 4) {
+        fail(SZ3HIP_EINVAL, "Data dimension higher than 4 is not supported.");
+        return 0;
+    }
+    uint64_t num = 1;
+    for (int i = 0; i < conf.N; i++) num *= conf.dims[i];
+    if (num != conf.num || num == 0) {
+        fail(SZ3HIP_EINVAL, "conf.num does not match conf.dims");
+        return 0;
+    }
+    if (zs::load()) return 0;
+    if (cmpCap < sz3hip_compress_bound(&conf, dataType)) {  // sz.hpp:47-49
+        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+        return 0;
+    }
+    unsigned char *out = reinterpret_cast<unsigned char *>(cmpData);
+    Writer w{out};
+    w.put<uint32_t>(kMagic);
+    w.put<uint32_t>(kDataVer);
+    unsigned char *size_pos = w.p;
+    w.p += 8;
+    unsigned char tmp[160];
+    const size_t payload_cap = cmpCap - 16 - 2 * sz3hip_config_save(&conf, tmp);
+    size_t payload_size = 0;
+
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    DeviceGuard guard;
+    if (conf.openmp) {  // SZ_compress_impl, api/impl/SZImpl.hpp:10-20
+        payload_size = compress_slabs(conf, dataType, data, w.p, payload_cap);
+        if (!payload_size) return 0;
+    } else {
+        SlabJob j;
+        job_init(j, conf, dataType, data, 0);
+        j.slot = get_slot(host_device(), j.cdt, 0);
+        j.out = w.p;
+        j.out_cap = payload_cap;
+        j.tm = &tm;
+        if (job_upload(j)) return 0;  // (same thread: sz3hip_last_error() already holds the message)
+        if (!j.lossless && abs_eb_from_range(j.conf, j.cdt, j.mn, j.mx)) return 0;
+        if (job_stage1(j) || job_encode(j)) return 0;
+        payload_size = j.out_size;
+        conf = j.conf;
+    }
+    uint64_t ps = payload_size;
+    memcpy(size_pos, &ps, 8);
+    w.p += payload_size;
+    conf.dataType = (uint8_t)dataType;  // lets the decoder refuse a request for another element type
+    w.p += sz3hip_config_save(&conf, w.p);
+    return (size_t)(w.p - out);
+}
+
+// one process per GPU: this rank's slab of SZ_compress_OMP, the exchanges through the rank communicator
+extern "C" size_t sz3hip_compress_rank(sz3hip_comm *comm, const sz3hip_config *global_conf, int dataType, const void *slab_data,
+                                       char *blob, size_t cap, sz3hip_config *slab_conf) {
+    if (!comm || sz3hip_comm_local_size(comm) != 1) {
+        fail(SZ3HIP_EINVAL, "sz3hip_compress_rank needs a communicator made by sz3hip_comm_create_rank");
+        return 0;
+    }
+    if (!dtype_ok(dataType)) {
+        fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
+        return 0;
+    }
+    sz3hip_config conf = *global_conf;
+    const int G = sz3hip_comm_size(comm), g = sz3hip_comm_rank(comm);
+    if (conf.N < 1 || conf.N > 4 || (uint64_t)G > conf.dims[0]) {
+        fail(SZ3HIP_EINVAL, "%d ranks for an array of %llu slices along dims[0]", G, (unsigned long long)(conf.N >= 1 ? conf.dims[0] : 0));
+        return 0;
+    }
+    if (zs::load()) return 0;
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    DeviceGuard guard;
+    const int cdt = dtype_compute(dataType);
+    uint64_t lo, hi;
+    slab_range(conf, G, g, &lo, &hi);
+    sz3hip_config ct = conf;
+    uint64_t d[4];
+    for (int i = 0; i < conf.N; i++) d[i] = conf.dims[i];
+    d[0] = hi - lo;
+    sz3hip_config geo;
+    sz3hip_config_init(&geo, conf.N, d);
+    ct.N = geo.N;
+    memcpy(ct.dims, geo.dims, sizeof(ct.dims));
+    ct.num = geo.num;
+    ct.predDim = geo.predDim;
+    ct.blockSize = geo.blockSize;
+    ct.openmp = 1;
+    SlabJob j;
+    job_init(j, ct, dataType, slab_data, g);
+    j.slot = get_slot(sz3hip_comm_device(comm, 0), cdt, 0);
+    j.out = reinterpret_cast<unsigned char *>(blob);
+    j.out_cap = cap;
+    if (cap < zs::bound_frames(j.raw_bytes) + 8) {
+        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+        j.failed(SZ3HIP_ECAPACITY);  // (still joins the collectives below: the other ranks are waiting in them)
+    }
+    if (!j.rc) job_upload(j);
+    const bool exchanges = conf.cmprAlgo != SZ3HIP_ALGO_LOSSLESS;  // (the same on every rank)
+    void *stream = j.slot->stream;
+    if (exchanges && !j.slot->stream) {  // upload failed before the slot had a stream: the collectives still need the device
+        (void)hipSetDevice(j.slot->device);
+        if (hipStreamCreateWithFlags(&j.slot->stream, hipStreamNonBlocking) == hipSuccess) stream = j.slot->stream;
+    }
+    stream = j.slot->stream;
+    if (exchanges && conf.errorBoundMode != SZ3HIP_EB_ABS) {  // SZImplOMP.hpp:57-69
+        double mn = INFINITY, mx = -INFINITY;
+        if (!j.rc && !j.lossless && conf.errorBoundMode != SZ3HIP_EB_L2NORM) {
+            mn = j.mn;
+            mx = j.mx;
+        }
+        if (sz3hip_comm_allreduce_minmax(comm, &mn, &mx, &stream)) return 0;
+        if (abs_eb_from_range(conf, cdt, mn, mx)) j.failed(sz3hip_last_error_code());
+        j.conf.errorBoundMode = conf.errorBoundMode;
+        j.conf.absErrorBound = conf.absErrorBound;
+    }
+    job_stage1(j);
+    if (exchanges) {
+        // a status word first, so that all ranks give up together instead of one of them waiting in the exchange for ever
+        static std::vector<std::pair<int, uint64_t *>> scratch;  // per device: [status][pad...][zero histogram]
+        uint64_t *sc = nullptr;
+        (void)hipSetDevice(j.slot->device);
+        for (auto &e : scratch)
+            if (e.first == j.slot->device) sc = e.second;
+        if (!sc) {
+            if (hipMalloc((void **)&sc, (16 + SZH_HIST_BINS) * 8) != hipSuccess) {
+                fail(SZ3HIP_EHIP, "hipMalloc of the exchange scratch failed");
+                return 0;
+            }
+            scratch.emplace_back(j.slot->device, sc);
+        }
+        const uint64_t bad = j.rc ? 1 : 0;
+        uint64_t *h_bad = nullptr;
+        if (hipHostMalloc((void **)&h_bad, 8) != hipSuccess) {
+            fail(SZ3HIP_EHIP, "hipHostMalloc failed");
+            return 0;
+        }
+        *h_bad = bad;
+        void *sb = sc;
+        bool okx = hipMemcpyAsync(sc, h_bad, 8, hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess &&
+                   sz3hip_comm_allreduce_u64(comm, &sb, 1, &stream) == 0 &&
+                   hipMemcpyAsync(h_bad, sc, 8, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess &&
+                   hipStreamSynchronize((hipStream_t)stream) == hipSuccess;
+        const uint64_t nbad = *h_bad;
+        (void)hipHostFree(h_bad);
+        if (!okx) {
+            if (!sz3hip_last_error_code()) fail(SZ3HIP_EHIP, "status exchange failed");
+            return 0;
+        }
+        if (nbad) {
+            if (j.rc) fail(j.rc, "slab %d: %s", g, j.err.c_str());
+            else fail(SZ3HIP_EHIP, "%llu other rank(s) failed before the histogram exchange", (unsigned long long)nbad);
+            return 0;
+        }
+        void *hb = sc + 16;
+        if (j.staged) {
+            hb = sz3hip_histogram_ptr(j.slot->ctx);
+        } else if (hipMemsetAsync(hb, 0, SZH_HIST_BINS * 8, (hipStream_t)stream) != hipSuccess) {
+            fail(SZ3HIP_EHIP, "hipMemsetAsync failed");
+            return 0;
+        }
+        if (sz3hip_comm_allreduce_u64(comm, &hb, SZH_HIST_BINS, &stream)) return 0;
+    }
+    if (job_encode(j)) {
+        fail(j.rc, "slab %d: %s", g, j.err.c_str());
+        return 0;
+    }
+    *slab_conf = j.conf;
+    return j.out_size;
+}
+
+extern "C" size_t sz3hip_assemble_container(const sz3hip_config *global_conf, int dataType, int G, const sz3hip_config *slab_confs,
+                                            const char *const *blobs, const size_t *blob_sizes, char *outp, size_t cap) {
+    unsigned char tmp[160];
+    size_t need = 16 + 4 + 8 * (size_t)G + sz3hip_config_save(global_conf, tmp);
+    for (int g = 0; g < G; g++) need += sz3hip_config_save(&slab_confs[g], tmp) + blob_sizes[g];
+    if (G < 1 || need > cap) {
+        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+        return 0;
+    }
+    unsigned char *out = reinterpret_cast<unsigned char *>(outp);
+    Writer w{out};
+    w.put<uint32_t>(kMagic);
+    w.put<uint32_t>(kDataVer);
+    unsigned char *size_pos = w.p;
+    w.p += 8;
+    unsigned char *body = w.p;
+    w.put<int32_t>(G);
+    for (int g = 0; g < G; g++) w.p += sz3hip_config_save(&slab_confs[g], w.p);
+    for (int g = 0; g < G; g++) w.put<uint64_t>((uint64_t)blob_sizes[g]);
+    for (int g = 0; g < G; g++) {
+        memcpy(w.p, blobs[g], blob_sizes[g]);
+        w.p += blob_sizes[g];
+    }
+    const uint64_t ps = (uint64_t)(w.p - body);
+    memcpy(size_pos, &ps, 8);
+    sz3hip_config outer = *global_conf;
+    outer.openmp = 1;
+    outer.dataType = (uint8_t)dataType;
+    // the reference's calAbsErrorBound rewrites the global Config to the absolute bound it derived (SZImplOMP.hpp:64); the
+    // slabs carry that bound, the outer trailer keeps what the caller passed unless the slabs agree on an absolute one
+    if (slab_confs[0].errorBoundMode == SZ3HIP_EB_ABS) {
+        outer.errorBoundMode = SZ3HIP_EB_ABS;
+        outer.absErrorBound = slab_confs[0].absErrorBound;
+    }
+    w.p += sz3hip_config_save(&outer, w.p);
+    return (size_t)(w.p - out);
+}
+
+extern "C" int sz3hip_peek_config(sz3hip_config *conf, const char *cmpData, size_t cmpSize) {
+    if (cmpSize < 16 + 8) return fail(SZ3HIP_EFORMAT, "compressed buffer too small");
+    Reader r{reinterpret_cast<const unsigned char *>(cmpData)};
+    if (r.get<uint32_t>() != kMagic)  // sz.hpp:122-125
+        return fail(SZ3HIP_EFORMAT, "magic number mismatch, the input data is not compressed by SZ3");
+    const uint32_t ver = r.get<uint32_t>();
+    if ((ver >> 8) != (kDataVer >> 8))  // sz.hpp:127-135 compares major.minor.patch
+        return fail(SZ3HIP_EFORMAT, "Please use SZ3 v%u.%u.%u to decompress the data", ver >> 24, (ver >> 16) & 255,
+                    (ver >> 8) & 255);
+    const uint64_t payload = r.get<uint64_t>();
+    if (payload > cmpSize - 16) return fail(SZ3HIP_EFORMAT, "payload size exceeds the buffer");
+    if (!sz3hip_config_load_n(conf, r.p + payload, (size_t)(cmpSize - 16 - payload)))
+        return fail(SZ3HIP_EFORMAT, "truncated or corrupt Config trailer");
+    uint64_t num = 1;
+    for (int i = 0; i < conf->N; i++) num *= conf->dims[i];
+    if (conf->N < 1 || num != conf->num) return fail(SZ3HIP_EFORMAT, "corrupt Config trailer (dims do not match num)");
+    return 0;
+}
+
+namespace {
+// SZ_decompress_dispatcher (api/impl/SZDispatcher.hpp:79-100) for one blob: `payload` bytes at p, conf = the Config that
+// describes it, decData receives conf->num elements of dataType
+int decompress_blob(HostSlot *s, const sz3hip_config *conf, int dataType, const unsigned char *p, size_t payload, void *decData) {
+    const bool is_int = dtype_is_int(dataType);
+    const int cdt = dtype_compute(dataType);
+    const size_t es = dtype_size(dataType);
+    const size_t raw_bytes = (size_t)conf->num * es;
+    if (conf->cmprAlgo == SZ3HIP_ALGO_LOSSLESS) {  // SZDispatcher.hpp:81-88 (no look at conf->dataType: the reference never sets it)
+        uint64_t len = 0;
+        if (payload >= 8) memcpy(&len, p, 8);
+        if (len != raw_bytes) return fail(SZ3HIP_EFORMAT, "Decompressed data size does not match the original data size");
+        return zs::decompress_frames(p, payload, (uint8_t *)decData, raw_bytes) == raw_bytes ? 0 : SZ3HIP_EZSTD;
+    }
+    if (conf->cmprAlgo != SZ3HIP_ALGO_HIP_LORENZO && conf->cmprAlgo != SZ3HIP_ALGO_HIP_INTERP)
+        return fail(SZ3HIP_EUNSUPPORTED,
+                    "stream uses cmprAlgo %d of the CPU reference; this library decodes only its own GPU streams (ids %d, %d) "
+                    "and ALGO_LOSSLESS",
+                    conf->cmprAlgo, SZ3HIP_ALGO_HIP_LORENZO, SZ3HIP_ALGO_HIP_INTERP);
+    if (payload < 8) return fail(SZ3HIP_EFORMAT, "truncated payload");
+    uint64_t raw_len;
+    memcpy(&raw_len, p, 8);
+    if (raw_len < sizeof(szh_header) || raw_len > (uint64_t)conf->num * 16 + (1u << 20))
+        return fail(SZ3HIP_EFORMAT, "implausible payload length in the lossless block");
+    HIPCHK(hipSetDevice(s->device));
+    int rc;
+    if ((rc = ensure_pin(s, raw_len))) return rc;
+    if (zs::decompress_frames(p, payload, (uint8_t *)s->pin, raw_len) != raw_len) return SZ3HIP_EZSTD;
+    // the SZH1 header is authoritative for the GPU streams: element count and type are checked before anything is launched
+    szh_header hdr;
+    memcpy(&hdr, s->pin, sizeof(hdr));
+    if (hdr.magic != SZH_MAGIC) return fail(SZ3HIP_EFORMAT, "not an SZH1 payload");
+    if (hdr.n != conf->num) return fail(SZ3HIP_EFORMAT, "payload element count does not match the Config");
+    if (hdr.dtype != (uint8_t)cdt)
+        return fail(SZ3HIP_EINVAL, "the stream holds %s data but %s output was requested", hdr.dtype == SZ3HIP_FLOAT ? "float32" : "float64 / integer",
+                    cdt == SZ3HIP_FLOAT ? "float32" : "float64 / integer");
+    if (dtype_is_int(conf->dataType) != is_int)
+        return fail(SZ3HIP_EINVAL, "the stream holds %s data but %s output was requested", dtype_is_int(conf->dataType) ? "integer" : "floating-point",
+                    is_int ? "integer" : "floating-point");
+    if ((rc = slot_ctx(s, conf->num))) return rc;
+    const size_t cbytes = (size_t)conf->num * (cdt == SZ3HIP_FLOAT ? 4 : 8);
+    if ((rc = ensure_dev(&s->dev_in, &s->dev_in_bytes, cbytes))) return rc;
+    if ((rc = ensure_dev(&s->dev_payload, &s->dev_payload_bytes, std::max<size_t>(raw_len + 64, is_int ? raw_bytes : 0)))) return rc;
+    HIPCHK(hipMemcpy(s->dev_payload, s->pin, raw_len, hipMemcpyHostToDevice));
+    rc = sz3hip_decompress_device(s->ctx, s->dev_payload, raw_len, s->dev_in, s->stream);
+    if (rc) return rc;
+    if (!is_int) {
+        HIPCHK(hipStreamSynchronize(s->stream));
+        HIPCHK(hipMemcpy(decData, s->dev_in, raw_bytes, hipMemcpyDeviceToHost));  // (the runtime pins large pageable buffers
+                                                                                  // itself: a hand-made pinned pipeline was slower)
+    } else {
+        rc = szk_launch_f64_to_int(dataType == SZ3HIP_INT64, (const double *)s->dev_in, conf->num, s->dev_payload, s->stream);
+        if (rc) return fail(SZ3HIP_EHIP, "integer narrowing kernel failed");
+        HIPCHK(hipStreamSynchronize(s->stream));
+        HIPCHK(hipMemcpy(decData, s->dev_payload, raw_bytes, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+// SZ_decompress_OMP (api/impl/SZImplOMP.hpp:120-186): [i32 G][Config x G][u64 size x G][blob x G], slab g of the array
+// described by the outer Config goes to GPU g % (visible GPUs), one host thread per GPU
+int decompress_slabs(const sz3hip_config *conf, int dataType, const unsigned char *p, size_t payload, void *decData) {
+    const unsigned char *end = p + payload;
+    if (payload < 4) return fail(SZ3HIP_EFORMAT, "truncated multi-slab container");
+    Reader r{p};
+    const int32_t G = r.get<int32_t>();
+    if (G < 1 || (uint64_t)G > conf->dims[0] || G > 65536) return fail(SZ3HIP_EFORMAT, "corrupt multi-slab container (%d slabs)", G);
+    std::vector<sz3hip_config> ct(G);
+    for (int g = 0; g < G; g++) {
+        size_t k = sz3hip_config_load_n(&ct[g], r.p, (size_t)(end - r.p));
+        if (!k) return fail(SZ3HIP_EFORMAT, "truncated multi-slab container (Config of slab %d)", g);
+        r.p += k;
+    }
+    if ((size_t)(end - r.p) < 8 * (size_t)G) return fail(SZ3HIP_EFORMAT, "truncated multi-slab container (size table)");
+    std::vector<uint64_t> size(G), start(G + 1, 0);
+    for (int g = 0; g < G; g++) {
+        size[g] = r.get<uint64_t>();
+        if (size[g] > payload) return fail(SZ3HIP_EFORMAT, "corrupt multi-slab container (size of slab %d)", g);
+        start[g + 1] = start[g] + size[g];
+    }
+    if (start[G] > (uint64_t)(end - r.p)) return fail(SZ3HIP_EFORMAT, "truncated multi-slab container (blobs)");
+    const unsigned char *blobs = r.p;
+    const uint64_t base = conf->num / conf->dims[0];
+    const size_t es = dtype_size(dataType);
+    bool need_gpu = false;
+    for (int g = 0; g < G; g++) {
+        uint64_t lo, hi;
+        slab_range(*conf, G, g, &lo, &hi);
+        if (ct[g].num != (hi - lo) * base) return fail(SZ3HIP_EFORMAT, "slab %d does not have the extent the outer Config implies", g);
+        if (ct[g].cmprAlgo != SZ3HIP_ALGO_LOSSLESS) need_gpu = true;
+    }
+    const int ndev = need_gpu ? multi_devices() : 1;
+    const int cdt = dtype_compute(dataType);
+    std::vector<HostSlot *> slots(G);
+    for (int g = 0; g < G; g++) slots[g] = get_slot(ndev == 1 ? host_device() : g % ndev, cdt, g / ndev);
+    std::vector<int> rcs(G, 0);
+    std::vector<std::string> errs(G);
+    auto worker = [&](int t) {
+        for (int g = t; g < G; g += ndev) {
+            uint64_t lo, hi;
+            slab_range(*conf, G, g, &lo, &hi);
+            rcs[g] = decompress_blob(slots[g], &ct[g], dataType, blobs + start[g], (size_t)size[g], (unsigned char *)decData + lo * base * es);
+            if (rcs[g]) errs[g] = sz3hip_last_error();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < ndev; t++) th.emplace_back(worker, t);
+    worker(0);
+    for (auto &t : th) t.join();
+    for (int g = 0; g < G; g++)
+        if (rcs[g]) return fail(rcs[g], "slab %d: %s", g, errs[g].c_str());
+    return 0;
+}
+}  // namespace
+
+extern "C" int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *cmpData, size_t cmpSize, void *decData) {
+    if (!dtype_ok(dataType))
+        return fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
+    int rc = sz3hip_peek_config(conf, cmpData, cmpSize);
+    if (rc) return rc;
+    if (zs::load()) return SZ3HIP_EZSTD;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(cmpData) + 8;
+    uint64_t payload;
+    memcpy(&payload, p, 8);
+    p += 8;
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    DeviceGuard guard;
+    if (conf->openmp) return decompress_slabs(conf, dataType, p, (size_t)payload, decData);  // SZ_decompress_impl, SZImpl.hpp:22-32
+    HostSlot *s = get_slot(host_device(), dtype_compute(dataType), 0);
+    return decompress_blob(s, conf, dataType, p, (size_t)payload, decData);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// the reference's C ABI (tools/sz3c/include/sz3c.h:52-59, tools/sz3c/src/sz3c.cpp:11-94)
+// ------------------------------------------------------------------------------------------------------------
+extern "C" unsigned char *SZ_compress_args(int dataType, void *data, size_t *outSize, int errBoundMode,
+                                           double absErrBound, double relBoundRatio, double pwrBoundRatio, size_t r5,
+                                           size_t r4, size_t r3, size_t r2, size_t r1) {
+    (void)pwrBoundRatio;  // sz3c.cpp:29 ignores it too
+    uint64_t d[4];
+    int nd;
+    if (r2 == 0) { nd = 1; d[0] = r1; }
+    else if (r3 == 0) { nd = 2; d[0] = r2; d[1] = r1; }
+    else if (r4 == 0) { nd = 3; d[0] = r3; d[1] = r2; d[2] = r1; }
+    else if (r5 == 0) { nd = 4; d[0] = r4; d[1] = r3; d[2] = r2; d[3] = r1; }
+    else { nd = 4; d[0] = r5 * r4; d[1] = r3; d[2] = r2; d[3] = r1; }  // sz3c.cpp:24
+    sz3hip_config conf;
+    sz3hip_config_init(&conf, nd, d);
+    conf.absErrorBound = absErrBound;
+    conf.relErrorBound = relBoundRatio;
+    if (errBoundMode == ABS) conf.errorBoundMode = SZ3HIP_EB_ABS;
+    else if (errBoundMode == REL) conf.errorBoundMode = SZ3HIP_EB_REL;
+    else if (errBoundMode == ABS_AND_REL) conf.errorBoundMode = SZ3HIP_EB_ABS_AND_REL;
+    else if (errBoundMode == ABS_OR_REL) conf.errorBoundMode = SZ3HIP_EB_ABS_OR_REL;
+    else {
+        printf("errBoundMode %d not support\n ", errBoundMode);  // sz3c.cpp:39-40
+        exit(0);
+    }
+    if (dataType != SZ_FLOAT && dataType != SZ_DOUBLE) {
+        printf("dataType %d not support\n", dataType);  // sz3c.cpp:51-52
+        exit(0);
+    }
+    const size_t cap = sz3hip_compress_bound(&conf, dataType);
+    unsigned char *buf = static_cast<unsigned char *>(malloc(cap));  // C memory, released by free_buf (sz3c.cpp:56-58)
+    if (!buf) return nullptr;
+    const size_t n = sz3hip_compress(&conf, dataType, data, reinterpret_cast<char *>(buf), cap);
+    if (n == 0) {
+        fprintf(stderr, "SZ_compress_args: %s\n", sz3hip_last_error());
+        free(buf);
+        *outSize = 0;
+        return nullptr;
+    }
+    *outSize = n;
+    unsigned char *shrunk = static_cast<unsigned char *>(realloc(buf, n));
+    return shrunk ? shrunk : buf;
+}
+
+extern "C" void *SZ_decompress(int dataType, unsigned char *bytes, size_t byteLength, size_t r5, size_t r4, size_t r3,
+                               size_t r2, size_t r1) {
+    size_t n;  // sz3c.cpp:66-77
+    if (r2 == 0) n = r1;
+    else if (r3 == 0) n = r1 * r2;
+    else if (r4 == 0) n = r1 * r2 * r3;
+    else if (r5 == 0) n = r1 * r2 * r3 * r4;
+    else n = r1 * r2 * r3 * r4 * r5;
+    if (dataType != SZ_FLOAT && dataType != SZ_DOUBLE) {
+        printf("dataType %d not support\n", dataType);  // sz3c.cpp:90-91
+        exit(0);
+    }
+    sz3hip_config conf;
+    if (sz3hip_peek_config(&conf, reinterpret_cast<const char *>(bytes), byteLength)) {
+        fprintf(stderr, "SZ_decompress: %s\n", sz3hip_last_error());
+        return nullptr;
+    }
+    if (conf.num > n) n = (size_t)conf.num;
+    void *dec = malloc(n * (dataType == SZ_FLOAT ? 4 : 8));
+    if (!dec) return nullptr;
+    if (sz3hip_decompress(&conf, dataType, reinterpret_cast<const char *>(bytes), byteLength, dec)) {
+        fprintf(stderr, "SZ_decompress: %s\n", sz3hip_last_error());
+        free(dec);
+        return nullptr;
+    }
+    return dec;
+}
+
+extern "C" void free_buf(void *p) { free(p); }  // sz3c.cpp:94

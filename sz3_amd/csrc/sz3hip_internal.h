@@ -1,0 +1,100 @@
+// sz3_amd/csrc/sz3hip_internal.h — shared between the host-side translation units of libsz3hip.so (not installed):
+//   sz3hip_api.cpp   Config, the device-resident API (contexts, stage 1 / 2, decode)
+//   sz3hip_host.cpp  libzstd, the SZ3 container, the host-buffer API incl. the slab-parallel (multi-GPU) path, sz3c.h
+//   sz3hip_comm.cpp  the RCCL communicator
+#ifndef SZ3HIP_INTERNAL_H
+#define SZ3HIP_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "../../include/sz3hip.h"
+#include "sz3hip_format.h"
+#include "sz3hip_kernels.h"
+
+// records code + message for sz3hip_last_error() (thread-local) and returns code
+int szi_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+struct Writer {
+    unsigned char *p;
+    template <class V> void put(V v) {
+        memcpy(p, &v, sizeof(V));
+        p += sizeof(V);
+    }
+};
+struct Reader {
+    const unsigned char *p;
+    template <class V> V get() {
+        V v;
+        memcpy(&v, p, sizeof(V));
+        p += sizeof(V);
+        return v;
+    }
+};
+
+enum { ST_K1 = 0, ST_CODEBOOK, ST_ENCODE, ST_ASSEMBLE, ST_DEC_HUFF, ST_DEC_RECON, ST_TUNER, ST_K1_KERNEL, ST_COUNT };
+
+struct sz3hip_ctx {
+    int device;
+    int dtype;
+    uint64_t max_n, out_cap, cur_out_cap, max_chunks;
+    uint64_t out_alloc;      // entries the four outlier arrays hold (>= out_cap; grown on demand)
+    uint64_t force_out_cap;  // != 0: list capacity of the retry after an overflow
+    // device buffers
+    uint16_t *d_codes;
+    uint64_t *d_hist;      // histogram in use (internal or caller-owned)
+    uint64_t *d_hist_own;  // internal allocation
+    uint64_t *d_counters;  // [0]=n_vout [1]=n_dout [2]=total_words [3]=decoder [4..6]=probe words [8..9]=code book's symbol range (inside d_hist_own's block)
+    uint32_t *d_hist_partial;
+    void *d_work;          // interpolation: the array being overwritten with reconstructed values (lazy)
+    uint64_t *d_vout_idx, *d_dout_idx;
+    void *d_vout_val, *d_dout_val;
+    uint32_t *d_enc;
+    uint8_t *d_lens;
+    uint64_t *d_keys, *d_ifreq;
+    uint16_t *d_syms, *d_pleaf, *d_pint, *d_depth, *d_aux2, *d_pint2;
+    uint32_t *d_range;
+    szk_cb_info *d_info;
+    uint16_t *d_chunk_words;
+    uint64_t *d_chunk_off;
+    szk_state *d_state;
+    szk_dec_tables *d_tables;
+    void *d_segtot;
+    double *d_minmax;
+    szk_state *h_state;  // pinned
+    szk_mode mode;       // of the pending / last compress
+    double *h_minmax;    // pinned
+    // pending compress
+    szh_header proto;
+    bool stage1_done, stage2_done;
+    sz3hip_stats stats;
+    // ALGO_INTERP_LORENZO tuner scratch (lazy)
+    uint8_t *d_flags;
+    size_t flags_cap;
+    uint64_t *d_starts;
+    size_t starts_cap;
+    void *d_samples;
+    size_t samples_cap;
+    void *d_trial_work;  // scratch of the trial kernel's global-memory variant (blocks too large for LDS)
+    size_t trial_work_cap;
+    hipStream_t side;    // the working copy of the input is made here while the tuner runs on the caller's stream
+    hipEvent_t ev_fork, ev_join;
+    bool copy_ahead;     // d_work already holds this call's input (joined into the caller's stream)
+    int hist_tail;       // with hist_big: codes beyond the large tier counted by windowed passes (from the previous call's count)
+    int hist_big;        // interpolation histogram pass with the 16384-bin second tier (from the previous call's far count)
+    int pack_wide;       // the packer's LDS table window: 8192 instead of 4096 entries (from the previous call's probe)
+    int wide16;          // -1: not decided yet (f64 starts with the 16384-bin stage-1 window, f32 with 8192); else 0 / 1,
+                         // adapted after every Lorenzo call from the width of the alphabet it saw
+    uint64_t *d_trial;  // [8][4]: bits, symbols, unpredictables, delta outliers
+    uint64_t *h_trial;  // pinned
+    uint64_t *d_trial_hist;      // [SZK_MAX_TRIALS][65536] histograms of the trials of one group
+    uint64_t *d_trial_counters;  // [SZK_MAX_TRIALS][8]
+    szk_interp_pass *d_passes, *h_passes;  // [SZK_MAX_TRIALS][SZK_TRIAL_MAX_PASSES] pass schedules (h: pinned)
+    uint32_t *d_np, *h_np;
+    sz3hip_tuner_report tuner;
+    // profiling
+    bool profiling;
+    hipEvent_t ev[ST_COUNT][2];
+    bool ev_used[ST_COUNT];
+};
+
+#endif

@@ -3015,6 +3015,17 @@ int szk_launch_f64_to_int(int is64, const double *d_in, uint64_t n, void *d_out,
     return 0;
 }
 
+// ---- several slabs on one GPU: their code histograms are summed before / instead of the RCCL exchange ------------------
+__global__ __launch_bounds__(256) void k_hist_add(uint64_t *__restrict__ dst, const uint64_t *__restrict__ src, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+int szk_launch_hist_add(uint64_t *d_dst, const uint64_t *d_src, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_hist_add, dim3((n + 255) / 256), dim3(256), 0, s, d_dst, d_src, n);
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
+
 int szk_launch_minmax(int dtype, const void *d_in, uint64_t n, double *d_partial, double *d_out, hipStream_t s) {
     const int nb = 1024;
     if (dtype == 0) hipLaunchKernelGGL(k_minmax<float>, dim3(nb), dim3(256), 0, s, (const float *)d_in, n, d_partial);

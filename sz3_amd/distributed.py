@@ -1,5 +1,10 @@
-"""Slab-parallel (multi-GPU) driver of the hot path — one process per GPU, torch.distributed (backend "nccl" = RCCL
-over xGMI on ROCm, "gloo" on CPU for the tests).
+"""Launcher glue of the slab-parallel (multi-GPU) path for one process per GPU.
+
+The path itself is C++ in libsz3hip.so: the RCCL communicator (csrc/sz3hip_comm.cpp), this rank's slab
+(sz3hip_compress_rank), the multi-slab container and its decoder (csrc/sz3hip_host.cpp; a single process that sees
+several GPUs needs none of this file: conf.openmp = 1 makes sz3hip_compress do it all). What is left for the launcher
+(torchrun + torch.distributed here, MPI elsewhere) is shipping rank 0's communicator id, gathering the blobs and the
+world_size / barrier / timing plumbing — that, and the format helpers the CPU tests use, is this file.
 
 Mirrors the reference's only parallel strategy, SZ_compress_OMP (include/SZ3/api/impl/SZImplOMP.hpp:16-117):
   * slabs along dims[0]:  lo = r*dims[0]/G, hi = (r+1)*dims[0]/G                      (SZImplOMP.hpp:48-50)
@@ -90,18 +95,83 @@ def split_container(blob):
     return outer, confs, blobs
 
 
-class SlabCompressor:
-    """One rank's share of a slab-parallel compress: stage1 -> histogram all-reduce -> stage2 (device resident)."""
+def init_comm(dist, device):
+    """the library's RCCL communicator for this process group: rank 0 draws the id (ncclGetUniqueId), the launcher's
+    process group ships its 128 bytes, every rank joins with its GPU (ncclCommInitRank)"""
+    import sz3_amd
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [sz3_amd.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return sz3_amd.Comm.rank(world, rank, device, box[0])
 
-    def __init__(self, dist, device_compressor, hist_tensor):
+
+class SlabCompressor:
+    """One rank's share of a slab-parallel compress, device resident: stage1 -> histogram all-reduce -> stage2.
+
+    comm: sz3_amd.Comm (RCCL inside the library, enqueued on the compress stream) — the product path. Without one
+    (comm=None, dist given: the gloo tests, several ranks sharing one GPU) the histogram is reduced by torch.distributed
+    on `hist_tensor`, with the stream handed to torch so that stage 1, the reduction and stage 2 stay ordered."""
+
+    def __init__(self, dist, device_compressor, hist_tensor=None, comm=None):
         self.dist = dist
         self.dc = device_compressor
+        self.comm = comm
         self.hist = hist_tensor
-        self.dc.set_histogram(hist_tensor.data_ptr())
+        if comm is None and hist_tensor is not None:
+            self.dc.set_histogram(hist_tensor.data_ptr())
 
     def compress(self, conf, d_in_ptr, d_payload_ptr, cap, stream=0):
-        self.dc.stage1(conf, d_in_ptr, stream)
-        if self.dist is not None and self.dist.get_world_size() > 1:
-            allreduce_histogram(self.hist, self.dist)
-        self.dc.stage2(d_payload_ptr, cap, stream)
-        return self.dc.finish(stream)
+        world = self.comm.size if self.comm is not None else (self.dist.get_world_size() if self.dist is not None else 1)
+        if self.comm is not None:
+            self.dc.stage1(conf, d_in_ptr, stream)
+            self.comm.allreduce_histogram([self.dc], [stream])
+            self.dc.stage2(d_payload_ptr, cap, stream)
+            return self.dc.finish(stream)
+        import torch
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream)) if stream else _null()
+        with ctx:
+            # every rank reaches the reduction even when its stage 1 failed: a status word travels with it
+            err = None
+            try:
+                self.dc.stage1(conf, d_in_ptr, stream)
+            except Exception as e:  # noqa: BLE001 - re-raised below, after the collective
+                err = e
+            if world > 1:
+                bad = torch.tensor([1 if err else 0], dtype=torch.int64, device=self.hist.device)
+                self.dist.all_reduce(bad, op=self.dist.ReduceOp.SUM)
+                if int(bad.item()):
+                    raise err if err else RuntimeError("another rank failed in stage 1")
+                allreduce_histogram(self.hist, self.dist)
+            elif err:
+                raise err
+            self.dc.stage2(d_payload_ptr, cap, stream)
+            return self.dc.finish(stream)
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def compress_distributed(dist, comm, slab, global_conf):
+    """Slab-parallel compress of an array distributed along dims[0] (one process per GPU): every rank passes ITS slab
+    (numpy, host) and the Config of the WHOLE array; rank 0 returns the SZ3 stream (multi-slab container), the others
+    None. Collective. The stream decodes with sz3_amd.decompress / SZ_decompress<T> on any number of GPUs."""
+    import sz3_amd
+    blob, sconf = sz3_amd.compress_rank(comm, slab, global_conf)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object((sconf.save(), blob.tobytes()), gathered, dst=0)
+    if rank != 0:
+        return None
+    confs = [sz3_amd.Config.load(c) for c, _ in gathered]
+    return sz3_amd.assemble_container(global_conf, slab.dtype, confs, [b for _, b in gathered])
+
+
+def decompress_container(blob, dtype, shape=None):
+    """any multi-slab stream (this module's, sz3hip_compress with conf.openmp) -> array: the library's decoder"""
+    import sz3_amd
+    return sz3_amd.decompress(blob, dtype, shape)

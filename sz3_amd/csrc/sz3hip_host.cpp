@@ -961,7 +961,12 @@ int decompress_blob(HostSlot *s, const sz3hip_config *conf, int dataType, const 
     const int cdt = dtype_compute(dataType);
     const size_t es = dtype_size(dataType);
     const size_t raw_bytes = (size_t)conf->num * es;
-    if (conf->cmprAlgo == SZ3HIP_ALGO_LOSSLESS) {  // SZDispatcher.hpp:81-88 (no look at conf->dataType: the reference never sets it)
+    if (conf->cmprAlgo == SZ3HIP_ALGO_LOSSLESS) {  // SZDispatcher.hpp:81-88
+        // The reference never sets Config::dataType (api/sz.hpp:43-82): stock streams say SZ_FLOAT whatever they hold, and
+        // only the length check below guards them. This library records the type: a stream that names an integer type
+        // is not handed out as floating point.
+        if (dtype_is_int(conf->dataType) && !is_int)
+            return fail(SZ3HIP_EINVAL, "the stream holds integer data but floating-point output was requested");
         uint64_t len = 0;
         if (payload >= 8) memcpy(&len, p, 8);
         if (len != raw_bytes) return fail(SZ3HIP_EFORMAT, "Decompressed data size does not match the original data size");

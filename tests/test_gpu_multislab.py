@@ -142,19 +142,22 @@ def test_range_based_bound_uses_the_global_range(rccl, monkeypatch):
 
 def test_slabs_that_fall_back_to_lossless_and_integer_input(rccl, monkeypatch):
     monkeypatch.setenv("SZ3HIP_SLABS", "3")
-    shape = (9, 40, 64)
+    shape = (12, 96, 128)
     a = field3d(shape)
-    a[3:6] = np.random.default_rng(0).normal(size=a[3:6].shape).astype(np.float32) * 1e3  # incompressible at this bound
+    mask = np.random.default_rng(0).random(a[4:8].shape) < 0.3
+    a[4:8][mask] = np.nan  # 30 % unpredictable values: beyond the n/8 the outlier lists grow to -> this slab goes lossless
     conf = sz3_amd.Config(*shape)
     conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
-    conf.absErrorBound = 1e-6
+    conf.absErrorBound = 1e-3
     conf.openmp = 1
     blob, _ = sz3_amd.compress(a, conf)
     _, confs, _ = D.split_container(blob.tobytes())
     algos = [sz3_amd.Config.load(c).cmprAlgo for c in confs]
-    assert algos[1] == sz3_amd.ALGO_LOSSLESS and algos[0] != sz3_amd.ALGO_LOSSLESS, algos
+    assert algos[1] == sz3_amd.ALGO_LOSSLESS and algos[0] == algos[2] == sz3_amd.ALGO_HIP_LORENZO, algos
     dec, _ = sz3_amd.decompress(blob, np.float32, shape)
-    assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= 1e-6
+    ok = ~np.isnan(a)
+    assert np.array_equal(np.isnan(dec), np.isnan(a))
+    assert float(np.max(np.abs(dec[ok].astype(np.float64) - a[ok].astype(np.float64)))) <= 1e-3
     ai = (field3d(shape) * 1000).astype(np.int32)
     ci = sz3_amd.Config(*shape)
     ci.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
@@ -210,7 +213,7 @@ def test_cxx_face_smoke_test_with_openmp(args, tmp_path, rccl, monkeypatch):
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(HERE, "cxx", "multislab_roundtrip.cpp"),
                            "-o", exe, "-L" + os.path.join(ROOT, "sz3_amd"), "-lsz3hip", "-Wl,-rpath," + os.path.join(ROOT, "sz3_amd")])
     out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and out.stdout.startswith("ok"), (out.stdout, out.stderr)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("ok"), (out.stdout, out.stderr)  # (RCCL prints a banner)
 
 
 def test_the_callers_device_is_left_alone():

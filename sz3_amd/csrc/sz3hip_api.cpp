@@ -202,7 +202,8 @@ static void ctx_free(sz3hip_ctx *c) {
     void *bufs[] = {c->d_work, c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
                     c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_aux2, c->d_pint2, c->d_range, c->d_info,
                     c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples, c->d_trial_work,
-                    c->d_trial, c->d_passes, c->d_np};  // (d_trial_counters / d_trial_hist live inside d_trial's block)
+                    c->d_trial, c->d_passes, c->d_np,  // (d_trial_counters / d_trial_hist live inside d_trial's block)
+                    c->d_blk_sel, c->d_blk_coef, c->d_blk_rank, c->d_blk_comp, c->d_blk_side, c->d_blk_counters};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->side) {
@@ -218,6 +219,7 @@ static void ctx_free(sz3hip_ctx *c) {
     if (c->h_trial) (void)hipHostFree(c->h_trial);
     if (c->h_passes) (void)hipHostFree(c->h_passes);
     if (c->h_np) (void)hipHostFree(c->h_np);
+    if (c->h_blk_side_hdr) (void)hipHostFree(c->h_blk_side_hdr);
     for (int i = 0; i < ST_COUNT; i++)
         for (int j = 0; j < 2; j++)
             if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
@@ -296,8 +298,9 @@ extern "C" void sz3hip_ctx_destroy(sz3hip_ctx *ctx) {
 
 static size_t payload_bound_n(uint64_t n, uint64_t out_cap) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
+    // (+ the side section of the block-composed predictor: blocks of at least 4^3 elements)
     return (size_t)(sizeof(szh_header) + SZH_HIST_BINS + 16 + 2 * n_chunks + 16 + 2 * (out_cap * 16 + 16) +
-                    4 * n_chunks * (SZH_CHUNK_SYMS * SZH_MAX_LEN / 32) + 64);
+                    4 * n_chunks * (SZH_CHUNK_SYMS * SZH_MAX_LEN / 32) + 64 + szk_blk_side_bound(n / 64 + 64));
 }
 extern "C" size_t sz3hip_payload_bound(const sz3hip_ctx *ctx, uint64_t n) { return payload_bound_n(n, ctx->out_cap); }
 // lists of up to n / 8 entries: beyond that the stream cannot beat the lossless fallback any more
@@ -496,6 +499,97 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
     h.n = num;
     h.chunk_syms = SZH_CHUNK_SYMS;
     h.n_chunks = (num + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
+    ctx->stage1_done = true;
+    ctx->stage2_done = false;
+    return 0;
+}
+
+// ---- stage 1, block-composed predictor: Lorenzo-1 / Lorenzo-2 / regression chosen per block
+// (make_compressor_lorenzo_regression, api/impl/SZAlgoLorenzoReg.hpp:22-64) ----
+static int blk_reserve(sz3hip_ctx *ctx, uint64_t nblocks) {
+    if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
+    if (!ctx->d_blk_counters) HIPCHK(hipMalloc((void **)&ctx->d_blk_counters, 64));
+    if (!ctx->h_blk_side_hdr) HIPCHK(hipHostMalloc((void **)&ctx->h_blk_side_hdr, 32));
+    if (ctx->blk_cap >= nblocks) return 0;
+    void **arr[5] = {(void **)&ctx->d_blk_sel, (void **)&ctx->d_blk_coef, (void **)&ctx->d_blk_rank, (void **)&ctx->d_blk_comp, (void **)&ctx->d_blk_side};
+    for (void **a : arr) {
+        if (*a) (void)hipFree(*a);
+        *a = nullptr;
+    }
+    ctx->blk_cap = 0;
+    HIPCHK(hipMalloc((void **)&ctx->d_blk_sel, nblocks));
+    HIPCHK(hipMalloc((void **)&ctx->d_blk_coef, nblocks * 32));
+    HIPCHK(hipMalloc((void **)&ctx->d_blk_rank, nblocks * 4));
+    HIPCHK(hipMalloc((void **)&ctx->d_blk_comp, nblocks * 4));
+    HIPCHK(hipMalloc((void **)&ctx->d_blk_side, szk_blk_side_bound(nblocks)));
+    ctx->blk_cap = nblocks;
+    return 0;
+}
+static void blk_params_from(sz3hip_ctx *ctx, const uint64_t *dims3, uint32_t B, uint32_t mask, double eb, int radius, uint64_t out_cap,
+                            szk_blk_params &bp, szk_blk_scratch &sc) {
+    memset(&bp, 0, sizeof(bp));
+    memset(&sc, 0, sizeof(sc));
+    for (int i = 0; i < 3; i++) {
+        bp.d[i] = dims3[i];
+        bp.nb[i] = (uint32_t)((dims3[i] + B - 1) / B);
+    }
+    bp.B = B;
+    bp.mask = mask;
+    bp.lat = szk_make_lattice(eb);
+    bp.eb = eb;
+    bp.radius = (uint32_t)radius;
+    bp.out_cap = out_cap;
+    bp.hist = ctx->d_hist;
+    bp.n_vout = ctx->d_counters + 0;
+    bp.n_dout = ctx->d_counters + 1;
+    bp.vout_idx = ctx->d_vout_idx;
+    bp.dout_idx = ctx->d_dout_idx;
+    bp.vout_val = ctx->d_vout_val;
+    bp.dout_val = ctx->d_dout_val;
+    bp.sel = ctx->d_blk_sel;
+    bp.coef = ctx->d_blk_coef;
+    bp.qwork = ctx->d_work;
+    bp.n_reg = ctx->d_blk_counters + 3;
+    sc.rank = ctx->d_blk_rank;
+    sc.comp = ctx->d_blk_comp;
+    sc.counters = ctx->d_blk_counters;
+    sc.side = ctx->d_blk_side;
+}
+static bool blk_shape_ok(const sz3hip_config *conf) { return conf->N == 3 && conf->blockSize >= 4 && conf->blockSize <= 8; }
+static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint64_t num, uint32_t mask, hipStream_t s) {
+    const uint32_t B = (uint32_t)conf->blockSize;
+    uint64_t nblocks = 1;
+    for (int i = 0; i < 3; i++) nblocks *= (conf->dims[i] + B - 1) / B;
+    if (nblocks > 0x7FFFFFF0ull) return fail(SZ3HIP_EUNSUPPORTED, "too many blocks for the block-composed predictor");
+    int rc = blk_reserve(ctx, nblocks);
+    if (rc) return rc;
+    szk_blk_params bp;
+    szk_blk_scratch sc;
+    blk_params_from(ctx, conf->dims, B, mask, eb, radius, ctx->cur_out_cap, bp, sc);
+    HIPCHK(hipMemsetAsync(ctx->d_blk_counters, 0, 64, s));
+    prof_begin(ctx, ST_K1, s);
+    rc = szk_launch_blk_compress(ctx->dtype, d_in, ctx->d_codes, &bp, &sc, s);
+    prof_end(ctx, ST_K1, s);
+    if (rc) return fail(SZ3HIP_EHIP, "block predictor kernel launch failed (%d)", rc);
+    memset(&ctx->mode, 0, sizeof(ctx->mode));
+    ctx->mode.probe_big = reinterpret_cast<uint32_t *>(ctx->d_counters + 4);
+    szh_header &h = ctx->proto;
+    memset(&h, 0, sizeof(h));
+    h.magic = SZH_MAGIC;
+    h.version = SZH_VERSION;
+    h.dtype = (uint8_t)ctx->dtype;
+    h.ndim = 3;
+    h.qbytes = ctx->dtype == SZ3HIP_FLOAT ? 4 : 8;
+    h.predictor = 2;
+    h.radius = (uint32_t)radius;
+    h.dims[0] = 1;
+    for (int i = 0; i < 3; i++) h.dims[1 + i] = conf->dims[i];
+    h.eb = eb;
+    h.n = num;
+    h.chunk_syms = SZH_CHUNK_SYMS;
+    h.n_chunks = (num + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
+    h.interp_id = B;
+    h.interp_dir = mask;
     ctx->stage1_done = true;
     ctx->stage2_done = false;
     return 0;
@@ -823,6 +917,20 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     HIPCHK(clear_hist_counters(ctx, s));
     if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP || conf->cmprAlgo == SZ3HIP_ALGO_HIP_INTERP)
         return stage1_interp(ctx, conf, d_in, eb, radius, num, s);
+    if (conf->cmprAlgo == SZ3HIP_ALGO_LORENZO_REG) {
+        // the predictor set of make_compressor_lorenzo_regression (api/impl/SZAlgoLorenzoReg.hpp:28-64). Lorenzo-1 alone is
+        // the plain stream; anything with Lorenzo-2 or regression is the block-composed one, built for 3-D arrays with
+        // block edges 4..8. Elsewhere the set falls back to its Lorenzo-1 member (the stream's header says which predictor
+        // coded it, the host API clears the flags it did not honour in the trailer) and is refused when it has none.
+        const uint32_t mask = (conf->lorenzo ? 1u : 0u) | (conf->lorenzo2 ? 2u : 0u) | (conf->regression ? 4u : 0u);
+        if (mask == 0) return fail(SZ3HIP_EINVAL, "All lorenzo and regression methods are disabled.");
+        if (mask != 1u) {
+            if (blk_shape_ok(conf) && !(szk_dbg_flags & 16384)) return stage1_blocks(ctx, conf, d_in, eb, radius, num, mask, s);
+            if (!(mask & 1u))
+                return fail(SZ3HIP_EUNSUPPORTED, "2nd-order Lorenzo / regression without Lorenzo are built for 3-D arrays with blockSize 4..8 "
+                                                 "(got N = %d, blockSize = %d)", conf->N, conf->blockSize);
+        }
+    }
     return stage1_lorenzo(ctx, conf, d_in, eb, radius, num, s);
 }
 
@@ -846,6 +954,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     lp.out_cap = ctx->cur_out_cap;
     lp.info = ctx->d_info;
     lp.state = ctx->d_state;
+    lp.side_bytes = ctx->proto.predictor == 2 ? ctx->d_blk_counters + 2 : nullptr;
     prof_end(ctx, ST_CODEBOOK, s);
     prof_begin(ctx, ST_ENCODE, s);  // (the payload layout is computed inside the encoder's scan launch)
     rc = szk_launch_encode(ctx->d_codes, n, ctx->d_enc, ctx->d_info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words, ctx->d_chunk_off,
@@ -867,6 +976,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     ap.dout_idx = ctx->d_dout_idx;
     ap.vout_val = ctx->d_vout_val;
     ap.dout_val = ctx->d_dout_val;
+    ap.side = ctx->proto.predictor == 2 ? ctx->d_blk_side : nullptr;
     prof_begin(ctx, ST_ASSEMBLE, s);
     rc = szk_launch_assemble(&ap, s);
     prof_end(ctx, ST_ASSEMBLE, s);
@@ -1013,6 +1123,9 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     HIPCHK(hipStreamSynchronize(s));
     h = ctx->h_state->hdr;
     if (h.magic != SZH_MAGIC || h.version != SZH_VERSION) return fail(SZ3HIP_EFORMAT, "not an SZH1 payload");
+    if (h.predictor > 2) return fail(SZ3HIP_EFORMAT, "unknown predictor id %d in the SZH1 header", h.predictor);
+    if (h.predictor != 2 && h.side_bytes) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (side section)");
+    if (h.side_bytes > payload_size) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (side section)");
     if (h.dtype != ctx->dtype) return fail(SZ3HIP_EINVAL, "payload data type does not match the context");
     if (h.n == 0 || h.n > ctx->max_n) return fail(SZ3HIP_EINVAL, "payload element count exceeds the context capacity");
     if (h.dims[0] * h.dims[1] * h.dims[2] * h.dims[3] != h.n || h.chunk_syms != SZH_CHUNK_SYMS ||
@@ -1066,6 +1179,36 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         ip.eb = h.eb;
         ip.radius = (int)h.radius;
         rc = szk_launch_interp_decompress(ctx->dtype, &ip, pl, o.vout_idx, o.vout_val, h.n_vout, ctx->d_codes, d_out, s);
+    } else if (h.predictor == 2) {
+        // block-composed stream: selection + coefficients from the side section, then the blocks in anti-diagonal fronts
+        const uint32_t B = h.interp_id, mask = h.interp_dir;
+        if (h.ndim != 3 || B < 4 || B > 8 || mask == 0 || mask > 7 || h.side_bytes < 24 || h.n_dout > h.n)
+            return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block predictor fields)");
+        uint64_t nblocks = 1;
+        for (int i = 0; i < 3; i++) nblocks *= (h.dims[1 + i] + B - 1) / B;
+        if (nblocks > 0x7FFFFFF0ull) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block count)");
+        int rb = blk_reserve(ctx, nblocks);
+        if (rb) return rb;
+        HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr, pl + o.side, 24, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        uint32_t coding, sel_bits;
+        uint64_t nb_side, nr;
+        memcpy(&coding, ctx->h_blk_side_hdr, 4);
+        memcpy(&sel_bits, ctx->h_blk_side_hdr + 4, 4);
+        memcpy(&nb_side, ctx->h_blk_side_hdr + 8, 8);
+        memcpy(&nr, ctx->h_blk_side_hdr + 16, 8);
+        const uint64_t sel_bytes = ((nblocks + 3) / 4 + 7) & ~7ull;
+        const uint64_t ngroups = (nr + 63) / 64;
+        const uint64_t fixed = 24 + sel_bytes + 8 + 4 * ngroups;  // header, selection, Rice parameters, group offsets
+        if (coding != 1 || sel_bits != 2 || nb_side != nblocks || nr > nblocks || h.side_bytes < fixed || (h.side_bytes - fixed) % 4)
+            return fail(SZ3HIP_EFORMAT, "corrupt side section of a block-predictor stream");
+        const uint64_t bit_words = (h.side_bytes - fixed) / 4;
+        szk_blk_params bp;
+        szk_blk_scratch sc;
+        blk_params_from(ctx, h.dims + 1, B, mask, h.eb, (int)h.radius, 0, bp, sc);
+        memcpy(sc.side_hdr, ctx->h_blk_side_hdr, 24);
+        memcpy(sc.side_hdr + 24, &bit_words, 8);
+        rc = szk_launch_blk_decompress(ctx->dtype, ctx->d_codes, d_out, &bp, &sc, pl, &h, &o, ctx->d_blk_coef, s);
     } else {
         rc = szk_launch_reconstruct(fuse_x ? 1 : 0, pl, &h, &o, ctx->d_codes, d_out, ctx->d_segtot, s);
     }

@@ -504,6 +504,10 @@ int job_encode(SlabJob &j) {
             if (!j.out_size) return j.failed(sz3hip_last_error_code());
             if (j.tm) j.tm->lap("zstd");
             j.conf.cmprAlgo = ctx->h_state->hdr.predictor == 1 ? SZ3HIP_ALGO_HIP_INTERP : SZ3HIP_ALGO_HIP_LORENZO;
+            if (ctx->h_state->hdr.predictor == 0) {  // the plain Lorenzo stream: the trailer names the predictor set that coded it
+                j.conf.lorenzo = 1;
+                j.conf.lorenzo2 = j.conf.regression = j.conf.regression2 = 0;
+            }
             if ((double)j.raw_bytes / (double)j.out_size < 3) {  // SZDispatcher.hpp:62-74
                 std::vector<uint8_t> z(zs::bound_frames(j.raw_bytes) + 8);
                 size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size());

@@ -45,7 +45,16 @@ struct sz3hip_ctx {
     uint64_t *d_hist_own;  // internal allocation
     uint64_t *d_counters;  // [0]=n_vout [1]=n_dout [2]=total_words [3]=decoder [4..6]=probe words [8..9]=code book's symbol range (inside d_hist_own's block)
     uint32_t *d_hist_partial;
-    void *d_work;          // interpolation: the array being overwritten with reconstructed values (lazy)
+    void *d_work;          // interpolation: the array being overwritten with reconstructed values (lazy);
+                           // block-composed predictor: the lattice values q~ the Lorenzo stencils run on
+    // block-composed predictor (sz3hip_regress.hip), allocated on first use for the call's block count
+    uint64_t blk_cap;       // blocks the arrays below hold
+    uint8_t *d_blk_sel;     // [blk_cap]
+    int64_t *d_blk_coef;    // [blk_cap][4] (encode: per block; decode: per regression rank)
+    uint32_t *d_blk_rank, *d_blk_comp;
+    uint8_t *d_blk_side;    // szk_blk_side_bound(blk_cap) bytes
+    uint64_t *d_blk_counters;  // [8]
+    uint8_t *h_blk_side_hdr;   // pinned, 32 bytes
     uint64_t *d_vout_idx, *d_dout_idx;
     void *d_vout_val, *d_dout_val;
     uint32_t *d_enc;

@@ -23,10 +23,10 @@
 
 #include "sz3hip_format.h"
 #include "sz3hip_kernels.h"
+#include "sz3hip_devutil.h"
 
 #define IH_WIN 1024  // LDS histogram window (bins) around the radius
 
-#define WAVE 64
 
 // ---- Interpolators.hpp:12-39 ---------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ T ip_linear(T a, T b) { return (a + b) / 2; }
@@ -35,39 +35,6 @@ template <typename T> __device__ __forceinline__ T ip_quad_1(T a, T b, T c) { re
 template <typename T> __device__ __forceinline__ T ip_quad_2(T a, T b, T c) { return (-a + 6 * b + 3 * c) / 8; }
 template <typename T> __device__ __forceinline__ T ip_quad_3(T a, T b, T c) { return (3 * a - 10 * b + 15 * c) / 8; }
 template <typename T> __device__ __forceinline__ T ip_cubic(T a, T b, T c, T d) { return (-a + 9 * b + 9 * c - d) / 16; }
-
-// ---- LinearQuantizer<T>::quantize_and_overwrite / recover (LinearQuantizer.hpp:43-86) ---------------------------
-template <typename T>
-__device__ __forceinline__ int ref_quantize(T &data, T pred, double eb, double recip, int radius) {
-    const T diff = data - pred;
-    const double scaled = fabs((double)diff) * recip;
-    // the reference casts to int64, adds 1 and asks "< 2 * radius": true exactly when scaled < 2 * radius - 1 (a NaN or an
-    // overflowing quotient fails it: unpredictable). Inside that range the quotient fits 32 bits, where the conversions
-    // are single instructions (the 64-bit ones are emulated: they were a third of the pass kernels' time).
-    if (!(scaled < (double)(2 * radius - 1))) return 0;
-    int qi = (int)scaled + 1;
-    const int half = qi >> 1;
-    qi = half << 1;
-    int shifted;
-    if (diff < 0) {
-        qi = -qi;
-        shifted = radius - half;
-    } else {
-        shifted = radius + half;
-    }
-    const T dec = (T)((double)pred + (double)qi * eb);
-    const T ad = dec - data;
-    const double adiff = fabs((double)ad);
-    if (adiff <= eb) {
-        data = dec;
-        return shifted;
-    }
-    return 0;
-}
-template <typename T>
-__device__ __forceinline__ T ref_recover(T pred, int code, double eb, int radius) {
-    return (T)((double)pred + (double)(2 * (code - radius)) * eb);
-}
 
 // Unpredictable values (code 0: the raw value stays in the array) are NOT appended by the pass kernels: the histogram pass
 // that reads every code anyway (k_hist_codes) collects their indices and values into the list, through per-wave LDS queues

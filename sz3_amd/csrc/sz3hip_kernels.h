@@ -94,6 +94,7 @@ struct szk_layout_params {
     uint64_t out_cap;
     const szk_cb_info *info;
     szk_state *state;
+    const uint64_t *side_bytes;  // predictor 2: device word holding the length of the side section (else nullptr)
 };
 struct szk_asm_params {
     const uint64_t *n_vout, *n_dout;
@@ -107,6 +108,7 @@ struct szk_asm_params {
     const uint16_t *chunk_words;
     const uint64_t *vout_idx, *dout_idx;
     const void *vout_val, *dout_val;
+    const uint8_t *side;  // predictor 2: the side section as the block kernels left it (else nullptr)
 };
 
 #define DEC_LUT_BITS 12u
@@ -135,6 +137,39 @@ struct szk_dec_params {
     const void *dout_val;  // int32 / int64 like q_out
     uint64_t n_dout;
 };
+
+// ---- block-composed predictor: Lorenzo-1 / Lorenzo-2 / regression per block (sz3hip_regress.hip) ----
+struct szk_blk_params {
+    uint64_t d[3];   // z, y, x extents
+    uint32_t nb[3];  // blocks per dimension
+    uint32_t B;      // block edge, 4..8
+    uint32_t mask;   // enabled predictors: 1 Lorenzo-1 | 2 Lorenzo-2 | 4 regression
+    szk_lattice lat;
+    double eb;
+    uint32_t radius;
+    uint64_t out_cap;
+    uint64_t *hist;
+    uint64_t *n_vout, *n_dout;
+    uint64_t *vout_idx, *dout_idx;
+    void *vout_val, *dout_val;
+    uint8_t *sel;    // [blocks] chosen predictor: 0 Lorenzo-1, 1 Lorenzo-2, 2 regression
+    int64_t *coef;   // [blocks][4] coefficient lattice values of the regression blocks
+    void *qwork;     // [n] lattice values q~ (int32 / int64) the Lorenzo stencils run on
+    uint64_t *n_reg; // number of regression blocks (counted by the fit pass; the rank pass writes the same number)
+};
+struct szk_blk_scratch {
+    uint32_t *rank, *comp;  // [blocks] rank among the regression blocks, compacted list of their ids
+    uint64_t *counters;     // [8]: [0] regression blocks, [2] side bytes, [3] fit pass's count, [4..7] Rice statistics
+    uint8_t *side;          // the side section being built
+    uint8_t side_hdr[32];   // decode: host copy of the side section's header + [24..31] words of its bit section (validated by the caller)
+};
+int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s);
+int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, const szk_blk_params *p, const szk_blk_scratch *sc,
+                              const uint8_t *payload, const szh_header *h, const szh_offsets *o, int64_t *coef_by_rank, hipStream_t s);
+size_t szk_blk_side_bound(uint64_t nblocks);
+// codes -> lattice deltas (code - radius) in d_out, the delta outliers scattered over them (Lorenzo and block streams)
+int szk_launch_expand_deltas(int dtype, const uint16_t *codes, uint64_t n, int radius, const uint8_t *payload, const szh_offsets *o,
+                             uint64_t n_dout, void *d_out, hipStream_t s);
 
 // ---- interpolation predictor (sz3hip_interp.hip) ----
 struct szk_interp_params {  // what InterpolationDecomposition keeps (decomposition/InterpolationDecomposition.hpp:456-477)

@@ -26,114 +26,7 @@
 #include "sz3hip_format.h"
 #include "sz3hip_kernels.h"
 
-#define WAVE 64
-
-// ------------------------------------------------------------------------------------------------------------
-// small helpers
-// ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
-
-// Wave-wide inclusive scan / sum with DPP lane moves (no LDS round trip; __shfl_up lowers to ds_bpermute, ~100 cycles
-// per step): Kogge-Stone inside the rows of 16 lanes (row_shr 1, 2, 4, 8), then row_bcast:15 carries the row totals into
-// rows 1 and 3 and row_bcast:31 the half-wave total into rows 2 and 3.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_mov0(uint32_t v) {  // lanes without a source (or outside ROW_MASK) read 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint64_t dpp_mov0(uint64_t v) {
-    const uint32_t lo = dpp_mov0<CTRL, ROW_MASK>((uint32_t)v), hi = dpp_mov0<CTRL, ROW_MASK>((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-template <typename V>
-__device__ __forceinline__ V wave_incl_scan(V v) {
-    using U = typename std::conditional<sizeof(V) == 8, uint64_t, uint32_t>::type;
-    U u = (U)v;
-    u += dpp_mov0<0x111, 0xf>(u);  // row_shr:1
-    u += dpp_mov0<0x112, 0xf>(u);  // row_shr:2
-    u += dpp_mov0<0x114, 0xf>(u);  // row_shr:4
-    u += dpp_mov0<0x118, 0xf>(u);  // row_shr:8
-    u += dpp_mov0<0x142, 0xa>(u);  // row_bcast:15 -> rows 1, 3
-    u += dpp_mov0<0x143, 0xc>(u);  // row_bcast:31 -> rows 2, 3
-    return (V)u;
-}
-template <typename V>
-__device__ __forceinline__ V wave_sum(V v) {  // total in every lane
-    const V incl = wave_incl_scan(v);
-    if (sizeof(V) == 8) {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)incl, WAVE - 1);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)incl >> 32), WAVE - 1);
-        return (V)(((uint64_t)hi << 32) | lo);
-    }
-    return (V)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)incl, WAVE - 1);
-}
-
-// reserve one slot of an append-only list for every active lane with want == true: ONE atomic per wave (same-address
-// global atomics run at ~90/us: a field with a third of NaNs would otherwise spend half a second here). Any set of active
-// lanes may call it together. Returns the lane's slot (meaningful only where want).
-__device__ __forceinline__ unsigned long long wave_append_slot(bool want, uint64_t *counter) {
-    const unsigned long long m = __ballot(want);
-    if (m == 0) return ~0ull;
-    const int lane = lane_id();
-    const int leader = __ffsll((long long)m) - 1;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd((unsigned long long *)counter, (unsigned long long)__popcll(m));
-    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader);
-    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), leader);
-    return (((unsigned long long)bhi << 32) | blo) + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-}
-
-template <typename T> struct QTraits;
-template <> struct QTraits<float> {
-    using Q = int32_t;
-    using UQ = uint32_t;
-};
-template <> struct QTraits<double> {
-    using Q = int64_t;
-    using UQ = uint64_t;
-};
-
-// The quantisation lattice.  q = rint(x / 2eb); the reconstruction x^ = q * 2eb is verified against the bound
-// (same acceptance test as quantizer/LinearQuantizer.hpp:57-60: |dec - data| evaluated in T, compared with eb) and
-// the raw value is kept losslessly when the check fails.  Non-finite or huge values take q = 0 so that neighbours
-// still predict sanely.  The arithmetic type is the data type: f32 data use f32 multiplies (one rounding each, no
-// FMA contraction: built with -ffp-contract=off), f64 data f64 — the decoder applies the identical expression, so
-// the bound that the encoder verified is the bound the user gets.
-template <typename T> struct Lattice;
-template <> struct Lattice<float> {
-    float recip, two_eb, eb_lo;  // (float)(1/(2eb)), (float)(2eb), largest float <= eb
-    __device__ __forceinline__ explicit Lattice(const szk_lattice &l) : recip(l.recip_f), two_eb(l.two_eb_f), eb_lo(l.eb_lo_f) {}
-    __device__ __forceinline__ int32_t quant(float x, bool &bad) const {
-        float s = x * recip;
-        int32_t q = 0;
-        bad = true;
-        if (fabsf(s) < 8388608.0f) {  // 2^23: rintf(s) is an exact integer; false for NaN
-            float r = rintf(s);
-            q = (int32_t)r;
-            float dec = r * two_eb;
-            bad = !(fabsf(dec - x) <= eb_lo);
-        }
-        return q;
-    }
-    __device__ __forceinline__ float dequant(int32_t q) const { return (float)q * two_eb; }
-};
-template <> struct Lattice<double> {
-    double recip, two_eb, eb;
-    __device__ __forceinline__ explicit Lattice(const szk_lattice &l) : recip(l.recip), two_eb(l.two_eb), eb(l.eb) {}
-    __device__ __forceinline__ int64_t quant(double x, bool &bad) const {
-        double s = x * recip;
-        int64_t q = 0;
-        bad = true;
-        if (fabs(s) < 4503599627370496.0) {  // 2^52
-            double r = rint(s);
-            q = (int64_t)r;
-            double dec = r * two_eb;
-            bad = !(fabs(dec - x) <= eb);
-        }
-        return q;
-    }
-    __device__ __forceinline__ double dequant(int64_t q) const { return (double)q * two_eb; }
-};
+#include "sz3hip_devutil.h"
 
 // ------------------------------------------------------------------------------------------------------------
 // K0: min / max
@@ -2028,6 +1921,8 @@ __device__ __host__ inline void szh_compute_offsets(const szh_header &h, szh_off
     off += 8 * h.n_dout;
     o.dout_val = off;
     off = szh_align16(off + (uint64_t)h.qbytes * h.n_dout);
+    o.side = off;
+    off = szh_align16(off + (h.predictor == 2 ? h.side_bytes : 0));
     o.bitstream = off;
     o.end = off + 4 * h.bitstream_words;
 }
@@ -2043,6 +1938,7 @@ __device__ void layout_pre(const szk_layout_params &p) {  // after K1 + K5, befo
     h.sym_min = p.info->sym_min;
     h.sym_count = p.info->sym_count;
     h.max_len = p.info->max_len;
+    h.side_bytes = p.side_bytes ? *p.side_bytes : 0;
     h.bitstream_words = 0;
     szh_offsets o;
     szh_compute_offsets(h, o);
@@ -2428,7 +2324,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         for (uint32_t i = lane; i < nwords + 2; i += WAVE) {  // copy out and re-zero the stage for the next chunk
             const uint32_t wv = stage[i];
             stage[i] = 0;
-            if (i < nwords) out[i] = wv;
+            if (i < nwords) out[i] = __builtin_bswap32(wv);  // bytes in stream order (see sz3hip_format.h)
         }
         __builtin_amdgcn_wave_barrier();
         cur = nxt;
@@ -2448,7 +2344,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         uint32_t *out = out_base + go + before;
-        for (uint32_t i = lane; i < nwords; i += WAVE) out[i] = stage[i];
+        for (uint32_t i = lane; i < nwords; i += WAVE) out[i] = __builtin_bswap32(stage[i]);
     }
 }
 
@@ -2473,7 +2369,8 @@ __global__ __launch_bounds__(256) void k_assemble(szk_asm_params p) {
         for (uint64_t a = oo.lens + h.sym_count; a < oo.chunkwords; a++) p.payload[a] = 0;
         for (uint64_t a = oo.chunkwords + 2 * h.n_chunks; a < oo.vout_idx; a++) p.payload[a] = 0;
         for (uint64_t a = oo.vout_val + tsz0 * h.n_vout; a < oo.dout_idx; a++) p.payload[a] = 0;
-        for (uint64_t a = oo.dout_val + (uint64_t)h.qbytes * h.n_dout; a < oo.bitstream; a++) p.payload[a] = 0;
+        for (uint64_t a = oo.dout_val + (uint64_t)h.qbytes * h.n_dout; a < oo.side; a++) p.payload[a] = 0;
+        for (uint64_t a = oo.side + (h.predictor == 2 ? h.side_bytes : 0); a < oo.bitstream; a++) p.payload[a] = 0;
     }
     for (uint64_t i = tid; i < h0.sym_count; i += nth) p.payload[o.lens + i] = p.lens[h0.sym_min + i];
     uint16_t *cw = reinterpret_cast<uint16_t *>(p.payload + o.chunkwords);
@@ -2485,6 +2382,8 @@ __global__ __launch_bounds__(256) void k_assemble(szk_asm_params p) {
     const uint64_t tsz = h0.dtype == 0 ? 4 : 8, qsz = h0.qbytes;
     for (uint64_t i = tid; i < h0.n_vout * tsz; i += nth) p.payload[o.vout_val + i] = ((const uint8_t *)p.vout_val)[i];
     for (uint64_t i = tid; i < h0.n_dout * qsz; i += nth) p.payload[o.dout_val + i] = ((const uint8_t *)p.dout_val)[i];
+    if (h0.predictor == 2 && p.side)
+        for (uint64_t i = tid; i < h0.side_bytes; i += nth) p.payload[o.side + i] = p.side[i];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2645,7 +2544,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint64_t a = woff + wi + k;
-            qw[k] = bs[a < wlast ? a : wlast];
+            qw[k] = __builtin_bswap32(bs[a < wlast ? a : wlast]);
         }
         uint32_t qn = 0;
         uint32_t packed[8];
@@ -2659,7 +2558,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                     wd = qn == 0 ? qw[0] : (qn == 1 ? qw[1] : (qn == 2 ? qw[2] : qw[3]));
                 } else {
                     const uint64_t a = woff + wi;
-                    wd = bs[a < wlast ? a : wlast];
+                    wd = __builtin_bswap32(bs[a < wlast ? a : wlast]);
                 }
                 wd = wi < nwords ? wd : 0u;
                 qn++;
@@ -3328,6 +3227,22 @@ static int launch_reconstruct(bool x_done, const uint8_t *payload, const szh_hea
     if (h.n_vout)
         hipLaunchKernelGGL(k_patch_vout<T>, dim3(grid_for(h.n_vout, 256, 4096)), dim3(256), 0, s, payload, o.vout_idx,
                            o.vout_val, h.n_vout, n, (T *)d_out);
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
+int szk_launch_expand_deltas(int dtype, const uint16_t *codes, uint64_t n, int radius, const uint8_t *payload, const szh_offsets *o,
+                             uint64_t n_dout, void *d_out, hipStream_t s) {
+    if (dtype == 0) {
+        hipLaunchKernelGGL(k_expand_codes<int32_t>, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, codes, n, radius, (int32_t *)d_out);
+        if (n_dout)
+            hipLaunchKernelGGL(k_scatter_dout<int32_t>, dim3(grid_for(n_dout, 256, 4096)), dim3(256), 0, s, payload, o->dout_idx, o->dout_val, n_dout, n,
+                               (int32_t *)d_out);
+    } else {
+        hipLaunchKernelGGL(k_expand_codes<int64_t>, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, codes, n, radius, (int64_t *)d_out);
+        if (n_dout)
+            hipLaunchKernelGGL(k_scatter_dout<int64_t>, dim3(grid_for(n_dout, 256, 4096)), dim3(256), 0, s, payload, o->dout_idx, o->dout_val, n_dout, n,
+                               (int64_t *)d_out);
+    }
     SZK_CHECK_LAUNCH();
     return 0;
 }

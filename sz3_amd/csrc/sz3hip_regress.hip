@@ -1,0 +1,892 @@
+// sz3_amd/csrc/sz3hip_regress.hip — the block-composed predictor path on gfx950: per-block choice among first-order
+// Lorenzo, second-order Lorenzo and linear regression (SZH1 payload, predictor id 2; 3-D arrays, block edge 4..8).
+//
+// Reference (paths relative to /root/reference/include/SZ3):
+//   predictor/RegressionPredictor.hpp:28-55    per-block fit: sum[i] = S idx_i*v, sum[N] = S v (double), coefficients in T
+//   predictor/RegressionPredictor.hpp:77-92    predict = c0*i0 + c1*i1 + c2*i2 + c3 with block-local indices
+//   predictor/RegressionPredictor.hpp:22-26    coefficient precision: linear terms eb/(N+1)/blockSize, constant eb/(N+1)
+//   predictor/LorenzoPredictor.hpp:17-38,56-95 Lorenzo stencils (L = 1, 2) and the noise term of their error estimate
+//   predictor/ComposedPredictor.hpp:25-40      selection: sampled S estimate_error per predictor, first minimum wins
+//   utils/BlockwiseIterator.hpp:151-184        the sample points: the four diagonals (i,i,i) (i,i,j) (i,j,i) (i,j,j)
+//   decomposition/BlockwiseDecomposition.hpp:28-67  block walk, fallback to Lorenzo-1 when the choice is not valid
+//   quantizer/LinearQuantizer.hpp:43-86        quantize_and_overwrite / recover (regression residuals: used as is)
+//
+// What is re-designed. The reference walks the blocks one after the other and predicts from reconstructed values. Here
+//   * Lorenzo blocks live on the lattice q = rint(x / 2eb) like the plain Lorenzo stream (sz3hip_kernels.hip): the code
+//     is an exact integer stencil over q~, where q~ = q for Lorenzo elements and rint(x^ / 2eb) for the elements of
+//     regression blocks (x^ = their reconstruction) — known to the encoder before any Lorenzo delta is formed, so the
+//     whole encoder is two embarrassingly parallel block passes (k_blk_fit, k_blk_lorenzo), one wave per block, the block
+//     and its low halo staged in LDS, the fit's four sums reduced across the wave in double.
+//   * Regression blocks use the reference's own quantizer on x - pred (the point of regression — no differencing of the
+//     noise — would be lost on the lattice); coefficients are snapped to their own lattice (dual quantisation again) and
+//     delta-coded between consecutive regression blocks by a scan instead of the reference's running prev_coeffs.
+//   * The decoder cannot be a global prefix sum any more (a regression block supplies values, not deltas): blocks are
+//     solved in anti-diagonal wavefronts (bz + by + bx = const, one launch per front, one wave per block), every
+//     Lorenzo block inverting its stencil from its low halo by three (six for L = 2) passes of line scans in LDS.
+// Selection uses the reference's estimator with the reference's inputs: original values inside the block, reconstructed
+// ones (here: the lattice reconstruction) outside it; the share of regression blocks is asserted against the oracle's.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "sz3hip_devutil.h"
+#include "sz3hip_format.h"
+#include "sz3hip_kernels.h"
+
+#define BLK_MAXE 10                               // tile edge: block edge (<= 8) + 2 halo layers
+#define BLK_TILE (BLK_MAXE * BLK_MAXE * BLK_MAXE)  // elements of a wave's tile
+#define BLK_HWIN 4096                             // LDS histogram window (bins around the radius) of a workgroup
+#define BLK_GRID 2048u
+
+#define SZK_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return -1;      \
+    } while (0)
+
+namespace {
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+struct BlkGeom {
+    uint32_t bz, by, bx;
+    uint32_t oz, oy, ox;  // origin of the block in the array
+    uint32_t ez, ey, ex;  // extents (ragged at the high end)
+    uint64_t coff;        // position of the block's first code: the codes are stored block by block (block raster order, elements in
+                          // raster order inside the block) like the reference emits them (BlockwiseDecomposition.hpp:33-44) — a
+                          // block's codes are one contiguous run, and the lossless stage finds 15 % more in that order
+                          // (C2 field at 5e-2, regression: zstd of the Huffman stream 138 -> 118 KB)
+};
+__device__ __forceinline__ BlkGeom blk_geom(const szk_blk_params &p, uint32_t task) {
+    BlkGeom g;
+    g.bx = task % p.nb[2];
+    const uint32_t r = task / p.nb[2];
+    g.by = r % p.nb[1];
+    g.bz = r / p.nb[1];
+    g.oz = g.bz * p.B;
+    g.oy = g.by * p.B;
+    g.ox = g.bx * p.B;
+    g.ez = min(p.B, (uint32_t)p.d[0] - g.oz);
+    g.ey = min(p.B, (uint32_t)p.d[1] - g.oy);
+    g.ex = min(p.B, (uint32_t)p.d[2] - g.ox);
+    // whole slabs of blocks below, whole rows of blocks in this slab, the blocks left of this one
+    g.coff = (uint64_t)g.oz * p.d[1] * p.d[2] + (uint64_t)g.ez * ((uint64_t)g.oy * p.d[2] + (uint64_t)g.ey * g.ox);
+    return g;
+}
+// tile coordinate t (E^3, E = B + 2, two halo layers on the low side) <-> array element
+__device__ __forceinline__ uint32_t tile_at(uint32_t E, uint32_t tz, uint32_t ty, uint32_t tx) { return (tz * E + ty) * E + tx; }
+
+// LDS histogram of a workgroup: BLK_HWIN bins around the radius, the rest straight to the global histogram; code 0
+// (one address for the whole grid) is counted per wave
+__device__ __forceinline__ void blk_count(uint32_t *lh, const szk_blk_params &p, uint32_t code, bool active) {
+    const unsigned long long zm = __ballot(active && code == 0);
+    if (zm && lane_id() == __ffsll((long long)zm) - 1) atomicAdd((unsigned long long *)&p.hist[0], (unsigned long long)__popcll(zm));
+    if (!active || code == 0) return;
+    const uint32_t bin = code - (p.radius - BLK_HWIN / 2);
+    if (bin < BLK_HWIN) atomicAdd(&lh[bin], 1u);
+    else atomicAdd((unsigned long long *)&p.hist[code], 1ull);
+}
+__device__ __forceinline__ void blk_flush(const uint32_t *lh, const szk_blk_params &p) {
+    for (uint32_t b = threadIdx.x; b < BLK_HWIN; b += blockDim.x) {
+        const uint32_t v = lh[b];
+        const uint32_t sym = p.radius - BLK_HWIN / 2 + b;
+        if (v && sym < SZH_HIST_BINS) atomicAdd((unsigned long long *)&p.hist[sym], (unsigned long long)v);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void blk_vout(const szk_blk_params &p, bool want, uint64_t gi, T raw) {
+    const unsigned long long pos = wave_append_slot(want, p.n_vout);
+    if (want && pos < p.out_cap) {
+        p.vout_idx[pos] = gi;
+        reinterpret_cast<T *>(p.vout_val)[pos] = raw;
+    }
+}
+
+// Lorenzo stencil weights along one dimension: L = 1 -> (1, -1), L = 2 -> (1, -2, 1)
+__device__ __forceinline__ int lz_w(int order, int j) { return order == 1 ? (j == 0 ? 1 : -1) : (j == 1 ? -2 : 1); }
+
+// the reference's prediction from the ORIGINAL values of the tile (T arithmetic, the reference's term order):
+// LorenzoPredictor.hpp:66-68 (L = 1) and :75-91 (L = 2, terms in lexicographic (k, j, i) order, coefficient -w(k)w(j)w(i))
+template <typename T>
+__device__ __forceinline__ T lorenzo_pred_orig(const T *sx, uint32_t E, uint32_t tz, uint32_t ty, uint32_t tx, int order) {
+    if (order == 1) {
+        return sx[tile_at(E, tz, ty, tx - 1)] + sx[tile_at(E, tz, ty - 1, tx)] + sx[tile_at(E, tz - 1, ty, tx)] - sx[tile_at(E, tz, ty - 1, tx - 1)] -
+               sx[tile_at(E, tz - 1, ty, tx - 1)] - sx[tile_at(E, tz - 1, ty - 1, tx)] + sx[tile_at(E, tz - 1, ty - 1, tx - 1)];
+    }
+    T acc = 0;
+    bool first = true;
+    for (int k = 0; k <= 2; k++)
+        for (int j = 0; j <= 2; j++)
+            for (int i = 0; i <= 2; i++) {
+                if ((k | j | i) == 0) continue;
+                const int c = -(lz_w(2, k) * lz_w(2, j) * lz_w(2, i));
+                const T term = (T)c * sx[tile_at(E, tz - k, ty - j, tx - i)];
+                acc = first ? term : acc + term;
+                first = false;
+            }
+    return acc;
+}
+
+// coefficient lattices (RegressionPredictor.hpp:22-26: quantizer_liner eb/(N+1)/block_size, quantizer_independent eb/(N+1))
+struct CoefLat {
+    double step_lin, step_ind;  // 2 * eb of the two quantizers
+};
+__device__ __host__ __forceinline__ CoefLat coef_lat(double eb, uint32_t B) {
+    CoefLat c;
+    c.step_ind = 2.0 * (eb / 4.0);
+    c.step_lin = 2.0 * (eb / 4.0 / (double)B);
+    return c;
+}
+template <typename T>
+__device__ __forceinline__ void coef_recover(const int64_t *lc, const CoefLat &cl, T (&rc)[4]) {
+    for (int i = 0; i < 3; i++) rc[i] = (T)((double)lc[i] * cl.step_lin);
+    rc[3] = (T)((double)lc[3] * cl.step_ind);
+}
+template <typename T>
+__device__ __forceinline__ T reg_predict(const T (&c)[4], uint32_t i0, uint32_t i1, uint32_t i2) {  // RegressionPredictor.hpp:82-84
+    return c[0] * (T)i0 + c[1] * (T)i1 + c[2] * (T)i2 + c[3];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// encoder pass 1: fit, select, regression blocks coded; q~ of every element written to qwork
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_blk_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
+    using Q = typename QTraits<T>::Q;
+    __shared__ T s_x[4][BLK_TILE];
+    __shared__ uint32_t lh[BLK_HWIN];
+    for (uint32_t b = threadIdx.x; b < BLK_HWIN; b += 256) lh[b] = 0;
+    __syncthreads();
+    const Lattice<T> lat(p.lat);
+    const int lane = lane_id();
+    const uint32_t wv = threadIdx.x / WAVE;
+    T *sx = s_x[wv];
+    const uint32_t E = p.B + 2;
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    Q *qwork = reinterpret_cast<Q *>(p.qwork);
+    const CoefLat cl = coef_lat(p.eb, p.B);
+    const double eb_recip = 1.0 / p.eb;
+    const bool has_l1 = p.mask & 1u, has_l2 = p.mask & 2u, has_r = p.mask & 4u;
+    for (uint32_t task = blockIdx.x * 4 + wv; task < nblocks; task += gridDim.x * 4) {
+        const BlkGeom g = blk_geom(p, task);
+        // ---- originals of the block and two low halo layers (zero outside the array, like the reference's padding) ----
+        for (uint32_t t = lane; t < E * E * E; t += WAVE) {
+            const uint32_t tx = t % E, ty = (t / E) % E, tz = t / (E * E);
+            const int64_t z = (int64_t)g.oz + tz - 2, y = (int64_t)g.oy + ty - 2, x = (int64_t)g.ox + tx - 2;
+            T v = 0;
+            if (z >= 0 && y >= 0 && x >= 0 && z < (int64_t)p.d[0] && y < (int64_t)d1 && x < (int64_t)d2) v = in[((uint64_t)z * d1 + (uint64_t)y) * d2 + (uint64_t)x];
+            // The selection's error estimates see what the reference's see (ComposedPredictor.hpp:29-33 on a block whose
+            // predecessors are already compressed): ORIGINAL values inside the block, RECONSTRUCTED ones outside it — here the
+            // lattice reconstruction the decoder will hold for a Lorenzo neighbour.
+            if (tz < 2 || ty < 2 || tx < 2) {
+                bool bad;
+                const Q qh = lat.quant(v, bad);
+                if (!bad) v = lat.dequant(qh);
+            }
+            sx[t] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's LDS writes are visible to its own reads
+        const uint32_t nown = g.ez * g.ey * g.ex;
+        // ---- regression fit (RegressionPredictor.hpp:28-55) ----
+        bool r_valid = has_r && g.ez > 1 && g.ey > 1 && g.ex > 1;
+        T cf[4] = {0, 0, 0, 0};
+        if (r_valid) {
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            for (uint32_t t = lane; t < nown; t += WAVE) {
+                const uint32_t i2 = t % g.ex, i1 = (t / g.ex) % g.ey, i0 = t / (g.ex * g.ey);
+                const T v = sx[tile_at(E, i0 + 2, i1 + 2, i2 + 2)];
+                s0 += (double)((T)i0 * v);  // sum[i] += index[i] * (*c): size_t * T is evaluated in T, accumulated in double
+                s1 += (double)((T)i1 * v);
+                s2 += (double)((T)i2 * v);
+                s3 += (double)v;
+            }
+            s0 = wave_sum_f64(s0);
+            s1 = wave_sum_f64(s1);
+            s2 = wave_sum_f64(s2);
+            s3 = wave_sum_f64(s3);
+            const double dz = g.ez, dy = g.ey, dx = g.ex, num = dz * dy * dx;
+            cf[3] = (T)(s3 / num);
+            cf[0] = (T)((2 * s0 / (dz - 1) - s3) * 6 / num / (dz + 1));
+            cf[3] = (T)((double)cf[3] - (dz - 1) * (double)cf[0] / 2);
+            cf[1] = (T)((2 * s1 / (dy - 1) - s3) * 6 / num / (dy + 1));
+            cf[3] = (T)((double)cf[3] - (dy - 1) * (double)cf[1] / 2);
+            cf[2] = (T)((2 * s2 / (dx - 1) - s3) * 6 / num / (dx + 1));
+            cf[3] = (T)((double)cf[3] - (dx - 1) * (double)cf[2] / 2);
+        }
+        // ---- selection (ComposedPredictor.hpp:25-40 over foreach_sampling) ----
+        int sid = has_l1 ? 0 : (has_l2 ? 1 : 2);
+        const int npred = (int)has_l1 + (int)has_l2 + (int)has_r;
+        if (npred > 1) {
+            const uint32_t m = min(g.ez, min(g.ey, g.ex));
+            double e1 = 0, e2 = 0, er = 0;
+            if ((uint32_t)lane < 4 * m) {
+                const uint32_t i = (uint32_t)lane / 4, kind = (uint32_t)lane % 4, j = m - 1 - i;
+                const uint32_t i0 = i, i1 = (kind & 2) ? j : i, i2 = (kind & 1) ? j : i;
+                const uint32_t tz = i0 + 2, ty = i1 + 2, tx = i2 + 2;
+                const T v = sx[tile_at(E, tz, ty, tx)];
+                if (has_l1) e1 = (double)(T)(fabs((double)(T)(v - lorenzo_pred_orig(sx, E, tz, ty, tx, 1))) + (T)(1.22 * p.eb));
+                if (has_l2) e2 = (double)(T)(fabs((double)(T)(v - lorenzo_pred_orig(sx, E, tz, ty, tx, 2))) + (T)(6.8 * p.eb));
+                if (r_valid) er = (double)(T)fabs((double)(T)(v - reg_predict(cf, i0, i1, i2)));
+            }
+            e1 = wave_sum_f64(e1);
+            e2 = wave_sum_f64(e2);
+            er = wave_sum_f64(er);
+            double best = 1.7976931348623157e308;
+            sid = -1;
+            if (has_l1) { best = e1; sid = 0; }
+            if (has_l2 && (sid < 0 || e2 < best)) { best = e2; sid = 1; }
+            if (has_r && r_valid && (sid < 0 || er < best)) { best = er; sid = 2; }
+            if (sid < 0) sid = 0;  // (regression the only candidate and not valid: the fallback predictor, Lorenzo-1)
+        } else if (sid == 2 && !r_valid) {
+            sid = 0;  // BlockwiseDecomposition.hpp:35-37
+        }
+        // ---- regression: coefficients onto their lattices; a coefficient the lattice cannot hold -> Lorenzo-1 ----
+        int64_t lc[4] = {0, 0, 0, 0};
+        if (sid == 2) {
+            bool ok = true;
+            for (int i = 0; i < 4; i++) {
+                const double s = (double)cf[i] / (i < 3 ? cl.step_lin : cl.step_ind);
+                if (!(fabs(s) < 4503599627370496.0)) ok = false;
+                else lc[i] = (int64_t)rint(s);
+            }
+            if (!ok) sid = 0;
+        }
+        if (sid == 2) {
+            T rc[4];
+            coef_recover(lc, cl, rc);
+            for (uint32_t t0 = 0; t0 < nown; t0 += WAVE) {
+                const uint32_t t = t0 + lane;
+                const bool act = t < nown;
+                const uint32_t tt = act ? t : 0;
+                const uint32_t i2 = tt % g.ex, i1 = (tt / g.ex) % g.ey, i0 = tt / (g.ex * g.ey);
+                const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
+                const T raw = sx[tile_at(E, i0 + 2, i1 + 2, i2 + 2)];
+                T v = raw;
+                const int code = act ? ref_quantize(v, reg_predict(rc, i0, i1, i2), p.eb, eb_recip, (int)p.radius) : 1;
+                Q qt = 0;
+                if (code != 0) {
+                    bool bad;
+                    qt = lat.quant(v, bad);
+                    if (bad) qt = 0;
+                }
+                if (act) {
+                    codes[g.coff + t] = (uint16_t)code;
+                    qwork[gi] = qt;
+                }
+                blk_count(lh, p, (uint32_t)code, act);
+                blk_vout<T>(p, act && code == 0, gi, raw);  // unpredictable: the raw value, LinearQuantizer.hpp:66-69
+            }
+            if (lane == 0) {
+                for (int i = 0; i < 4; i++) p.coef[(uint64_t)task * 4 + i] = lc[i];
+                atomicAdd((unsigned long long *)p.n_reg, 1ull);
+            }
+        } else {
+            for (uint32_t t0 = 0; t0 < nown; t0 += WAVE) {
+                const uint32_t t = t0 + lane;
+                const bool act = t < nown;
+                const uint32_t tt = act ? t : 0;
+                const uint32_t i2 = tt % g.ex, i1 = (tt / g.ex) % g.ey, i0 = tt / (g.ex * g.ey);
+                const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
+                const T raw = sx[tile_at(E, i0 + 2, i1 + 2, i2 + 2)];
+                bool bad;
+                Q q = lat.quant(raw, bad);
+                if (bad) q = 0;
+                if (act) qwork[gi] = q;
+                blk_vout<T>(p, act && bad, gi, raw);
+            }
+        }
+        if (lane == 0) p.sel[task] = (uint8_t)sid;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    blk_flush(lh, p);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// encoder pass 2: Lorenzo blocks — integer stencil over q~ (block + two low halo layers in LDS)
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_blk_lorenzo(uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    __shared__ Q s_q[4][BLK_TILE];
+    __shared__ uint32_t lh[BLK_HWIN];
+    for (uint32_t b = threadIdx.x; b < BLK_HWIN; b += 256) lh[b] = 0;
+    __syncthreads();
+    const int lane = lane_id();
+    const uint32_t wv = threadIdx.x / WAVE;
+    Q *sq = s_q[wv];
+    const uint32_t E = p.B + 2;
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    const Q *qwork = reinterpret_cast<const Q *>(p.qwork);
+    for (uint32_t task = blockIdx.x * 4 + wv; task < nblocks; task += gridDim.x * 4) {
+        const int sid = p.sel[task];
+        if (sid == 2) continue;
+        const int order = sid == 1 ? 2 : 1;
+        const BlkGeom g = blk_geom(p, task);
+        for (uint32_t t = lane; t < E * E * E; t += WAVE) {
+            const uint32_t tx = t % E, ty = (t / E) % E, tz = t / (E * E);
+            const int64_t z = (int64_t)g.oz + tz - 2, y = (int64_t)g.oy + ty - 2, x = (int64_t)g.ox + tx - 2;
+            Q v = 0;
+            if (z >= 0 && y >= 0 && x >= 0 && z < (int64_t)p.d[0] && y < (int64_t)d1 && x < (int64_t)d2) v = qwork[((uint64_t)z * d1 + (uint64_t)y) * d2 + (uint64_t)x];
+            sq[t] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const uint32_t nown = g.ez * g.ey * g.ex;
+        for (uint32_t t0 = 0; t0 < nown; t0 += WAVE) {
+            const uint32_t t = t0 + lane;
+            const bool act = t < nown;
+            const uint32_t tt = act ? t : 0;
+            const uint32_t i2 = tt % g.ex, i1 = (tt / g.ex) % g.ey, i0 = tt / (g.ex * g.ey);
+            const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
+            UQ delta = 0;  // wrap-around arithmetic like the plain Lorenzo stream
+            for (int k = 0; k <= order; k++)
+                for (int j = 0; j <= order; j++)
+                    for (int i = 0; i <= order; i++) {
+                        const int w = lz_w(order, k) * lz_w(order, j) * lz_w(order, i);
+                        delta += (UQ)((Q)w * sq[tile_at(E, i0 + 2 - k, i1 + 2 - j, i2 + 2 - i)]);
+                    }
+            const bool inr = (UQ)(delta + (UQ)(p.radius - 1)) <= (UQ)(2 * p.radius - 2);
+            const uint32_t code = inr ? (uint32_t)(delta + (UQ)p.radius) : 0u;
+            if (act) codes[g.coff + t] = (uint16_t)code;
+            blk_count(lh, p, code, act);
+            const unsigned long long pd = wave_append_slot(act && !inr, p.n_dout);
+            if (act && !inr && pd < p.out_cap) {
+                p.dout_idx[pd] = g.coff + t;  // (position of the code, not of the element: the decoder expands the codes in place)
+                reinterpret_cast<Q *>(p.dout_val)[pd] = (Q)delta;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    blk_flush(lh, p);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// side information of a block stream:
+//   [u32 coding = 1][u32 sel_bits = 2][u64 n_blocks][u64 n_reg]
+//   [selection: 2 bits per block, padded to 8 bytes]
+//   [u8 k[4]][u32 n_groups]                      Rice parameters of the four coefficients, groups of 64 regression blocks
+//   [u32 bit offset of every group][bits: u32 words, MSB first]
+// A regression block's four coefficient lattice values are coded as differences to the previous regression block's (block
+// raster order — the chain the reference's prev_coeffs follows, RegressionPredictor.hpp:148-156, but made of lattice
+// integers so that it is a scan): zigzag, then Rice with the coefficient's own parameter; quotients >= 24 escape to the
+// 64 raw bits. Groups of 64 blocks start at recorded bit offsets: the decoder parses the groups in parallel.
+// (The reference Huffman-codes these values with a tree of their own, RegressionPredictor.hpp:94-107; raw 16-bit
+// differences were 8 bytes per block = 2.4 % of the C4a stream, Rice codes are ~3.)
+// ------------------------------------------------------------------------------------------------------------
+#define SIDE_HDR 24u
+#define RICE_ESC 24u
+#define RICE_GROUP 64u
+__device__ __forceinline__ uint64_t side_sel_bytes(uint64_t nblocks) { return ((nblocks + 3) / 4 + 7) & ~7ull; }
+__device__ __forceinline__ uint64_t zigzag(int64_t v) { return ((uint64_t)v << 1) ^ (uint64_t)(v >> 63); }
+__device__ __forceinline__ int64_t unzigzag(uint64_t u) { return (int64_t)(u >> 1) ^ -(int64_t)(u & 1); }
+__device__ __forceinline__ uint32_t rice_len(uint64_t u, uint32_t k) {
+    const uint64_t q = u >> k;
+    return q < RICE_ESC ? (uint32_t)q + 1u + k : RICE_ESC + 64u;
+}
+// rank of every block among the regression blocks (exclusive), the compacted list, the count: one workgroup walks the
+// block list (a few hundred thousand flags: tens of microseconds)
+__global__ __launch_bounds__(1024) void k_blk_rank(const uint8_t *__restrict__ sel, uint32_t nblocks, uint32_t *__restrict__ rank,
+                                                   uint32_t *__restrict__ comp, uint64_t *n_reg_out) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    constexpr uint32_t PER = 8;
+    for (uint32_t base = 0; base < nblocks; base += 1024 * PER) {
+        const uint32_t b0 = base + threadIdx.x * PER;
+        uint32_t f[PER], mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            f[k] = (b0 + k < nblocks && sel[b0 + k] == 2) ? 1u : 0u;
+            mine += f[k];
+        }
+        const uint32_t incl = wave_incl_scan(mine);
+        if (lane_id() == WAVE - 1) s_w[threadIdx.x / WAVE] = incl;
+        __syncthreads();
+        uint32_t run = s_carry + incl - mine, tot = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            if (w < threadIdx.x / WAVE) run += s_w[w];
+            tot += s_w[w];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            if (b0 + k < nblocks) {
+                rank[b0 + k] = run;
+                if (f[k] && comp) comp[run] = b0 + k;
+            }
+            run += f[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_reg_out = s_carry;
+}
+__device__ __forceinline__ void coef_delta(const int64_t *__restrict__ coef, const uint32_t *__restrict__ comp, uint64_t r, uint64_t (&u)[4]) {
+    const int64_t *cur = coef + (uint64_t)comp[r] * 4;
+    const int64_t *prv = r ? coef + (uint64_t)comp[r - 1] * 4 : nullptr;
+    for (int i = 0; i < 4; i++) u[i] = zigzag(cur[i] - (prv ? prv[i] : 0));
+}
+// sum of the zigzagged differences per coefficient -> its Rice parameter (stats[0..3]; doubles: no overflow worries)
+__global__ __launch_bounds__(256) void k_blk_coef_stats(const int64_t *__restrict__ coef, const uint32_t *__restrict__ comp, const uint64_t *n_reg,
+                                                        double *stats) {
+    const uint64_t nr = *n_reg;
+    double s[4] = {0, 0, 0, 0};
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < nr; r += (uint64_t)gridDim.x * 256) {
+        uint64_t u[4];
+        coef_delta(coef, comp, r, u);
+        for (int i = 0; i < 4; i++) s[i] += (double)u[i];
+    }
+    for (int i = 0; i < 4; i++) {
+        s[i] = wave_sum_f64(s[i]);
+        if (lane_id() == 0 && s[i] != 0) atomicAdd(&stats[i], s[i]);
+    }
+}
+__device__ __forceinline__ uint32_t rice_param(double sum, uint64_t n) {
+    const double mean = n ? sum / (double)n : 0.0;
+    uint32_t k = 0;
+    while (k < 40 && (double)(1ull << (k + 1)) <= mean + 1.0) k++;  // 2^k ~ mean: within a fraction of a bit of the best choice
+    return k;
+}
+// bits of every group of 64 regression blocks (one wave per group)
+__global__ __launch_bounds__(256) void k_blk_coef_len(const int64_t *__restrict__ coef, const uint32_t *__restrict__ comp, const uint64_t *n_reg,
+                                                      const double *__restrict__ stats, uint32_t *__restrict__ group_bits) {
+    const uint64_t nr = *n_reg;
+    const uint64_t ngroups = (nr + RICE_GROUP - 1) / RICE_GROUP;
+    uint32_t k[4];
+    for (int i = 0; i < 4; i++) k[i] = rice_param(stats[i], nr);
+    for (uint64_t g = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE; g < ngroups; g += (uint64_t)gridDim.x * 4) {
+        const uint64_t r = g * RICE_GROUP + lane_id();
+        uint32_t bits = 0;
+        if (r < nr) {
+            uint64_t u[4];
+            coef_delta(coef, comp, r, u);
+            for (int i = 0; i < 4; i++) bits += rice_len(u[i], k[i]);
+        }
+        bits = wave_sum(bits);
+        if (lane_id() == 0) group_bits[g] = bits;
+    }
+}
+__device__ __forceinline__ void put_bits(uint32_t *words, uint64_t pos, uint64_t v, uint32_t nb) {  // nb <= 64, MSB first
+    while (nb) {
+        const uint32_t room = 32u - (uint32_t)(pos & 31);
+        const uint32_t take = nb < room ? nb : room;
+        const uint32_t chunk = (uint32_t)((v >> (nb - take)) & (take == 32 ? 0xFFFFFFFFull : ((1ull << take) - 1ull)));
+        atomicOr(&words[pos >> 5], chunk << (room - take));
+        pos += take;
+        nb -= take;
+    }
+}
+// header, selection bits, Rice parameters, group offsets (one workgroup scans the group sizes), then the bits
+__global__ __launch_bounds__(1024) void k_blk_side_layout(const uint8_t *__restrict__ sel, uint32_t nblocks, const uint64_t *n_reg,
+                                                          const double *__restrict__ stats, const uint32_t *__restrict__ group_bits,
+                                                          uint8_t *__restrict__ side, uint64_t *side_bytes) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const uint64_t nr = *n_reg;
+    const uint64_t sel_bytes = side_sel_bytes(nblocks);
+    const uint32_t ngroups = (uint32_t)((nr + RICE_GROUP - 1) / RICE_GROUP);
+    uint8_t *kp = side + SIDE_HDR + sel_bytes;
+    uint32_t *goff = reinterpret_cast<uint32_t *>(kp + 8);
+    if (threadIdx.x == 0) {
+        const uint32_t h0[2] = {1u, 2u};
+        const uint64_t h1[2] = {nblocks, nr};
+        memcpy(side, h0, 8);
+        memcpy(side + 8, h1, 16);
+        for (int i = 0; i < 4; i++) kp[i] = (uint8_t)rice_param(stats[i], nr);
+        memcpy(kp + 4, &ngroups, 4);
+        s_carry = 0;
+    }
+    for (uint64_t b = threadIdx.x; b < sel_bytes; b += 1024) {
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint64_t blk = b * 4 + k;
+            if (blk < nblocks) v |= (uint32_t)(sel[blk] & 3u) << (2 * k);
+        }
+        side[SIDE_HDR + b] = (uint8_t)v;
+    }
+    __syncthreads();
+    for (uint32_t base = 0; base < ngroups; base += 1024) {
+        const uint32_t g = base + threadIdx.x;
+        const uint32_t mine = g < ngroups ? group_bits[g] : 0u;
+        const uint32_t incl = wave_incl_scan(mine);
+        if (lane_id() == WAVE - 1) s_w[threadIdx.x / WAVE] = incl;
+        __syncthreads();
+        uint32_t run = s_carry + incl - mine, tot = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            if (w < threadIdx.x / WAVE) run += s_w[w];
+            tot += s_w[w];
+        }
+        if (g < ngroups) goff[g] = run;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    const uint64_t words = ((uint64_t)s_carry + 31) / 32;
+    uint32_t *bits = goff + ngroups;
+    for (uint64_t i = threadIdx.x; i < words; i += 1024) bits[i] = 0;
+    if (threadIdx.x == 0) *side_bytes = SIDE_HDR + sel_bytes + 8 + 4ull * ngroups + 4 * words;
+}
+__global__ __launch_bounds__(256) void k_blk_coef_write(const int64_t *__restrict__ coef, const uint32_t *__restrict__ comp, const uint64_t *n_reg,
+                                                        uint32_t nblocks, uint8_t *__restrict__ side) {
+    const uint64_t nr = *n_reg;
+    const uint64_t ngroups = (nr + RICE_GROUP - 1) / RICE_GROUP;
+    const uint8_t *kp = side + SIDE_HDR + side_sel_bytes(nblocks);
+    const uint32_t k[4] = {kp[0], kp[1], kp[2], kp[3]};
+    const uint32_t *goff = reinterpret_cast<const uint32_t *>(kp + 8);
+    uint32_t *bits = const_cast<uint32_t *>(goff) + ngroups;
+    for (uint64_t g = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE; g < ngroups; g += (uint64_t)gridDim.x * 4) {
+        const uint64_t r = g * RICE_GROUP + lane_id();
+        uint64_t u[4] = {0, 0, 0, 0};
+        uint32_t len = 0;
+        if (r < nr) {
+            coef_delta(coef, comp, r, u);
+            for (int i = 0; i < 4; i++) len += rice_len(u[i], k[i]);
+        }
+        uint64_t pos = (uint64_t)goff[g] + (wave_incl_scan(len) - len);
+        if (r < nr)
+            for (int i = 0; i < 4; i++) {
+                const uint64_t q = u[i] >> k[i];
+                if (q < RICE_ESC) {
+                    put_bits(bits, pos, ((1ull << q) - 1ull) << 1, (uint32_t)q + 1u);  // q ones, a zero
+                    pos += q + 1;
+                    if (k[i]) put_bits(bits, pos, u[i] & ((1ull << k[i]) - 1ull), k[i]);
+                    pos += k[i];
+                } else {
+                    put_bits(bits, pos, (1ull << RICE_ESC) - 1ull, RICE_ESC);
+                    pos += RICE_ESC;
+                    put_bits(bits, pos, u[i], 64);
+                    pos += 64;
+                }
+            }
+    }
+}
+
+// ---- decoder side: selection bits out, coefficient differences parsed (one thread per group) and summed up ----
+__global__ __launch_bounds__(256) void k_blk_side_sel(const uint8_t *__restrict__ side, uint32_t nblocks, uint8_t *__restrict__ sel) {
+    for (uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x; b < nblocks; b += (uint64_t)gridDim.x * 256)
+        sel[b] = (side[SIDE_HDR + b / 4] >> (2 * (b & 3))) & 3u;
+}
+__device__ __forceinline__ uint32_t get_bit(const uint32_t *words, uint64_t pos) { return (words[pos >> 5] >> (31u - (uint32_t)(pos & 31))) & 1u; }
+__device__ __forceinline__ uint64_t get_bits(const uint32_t *words, uint64_t pos, uint32_t nb) {
+    uint64_t v = 0;
+    while (nb) {
+        const uint32_t room = 32u - (uint32_t)(pos & 31);
+        const uint32_t take = nb < room ? nb : room;
+        const uint32_t w = words[pos >> 5];
+        const uint32_t chunk = (w >> (room - take)) & (take == 32 ? 0xFFFFFFFFu : ((1u << take) - 1u));
+        v = take == 64 ? chunk : ((v << take) | chunk);
+        pos += take;
+        nb -= take;
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void k_blk_coef_parse(const uint8_t *__restrict__ side, uint32_t nblocks, uint64_t nr, uint64_t bit_words,
+                                                        int64_t *__restrict__ delta_by_rank) {
+    const uint64_t ngroups = (nr + RICE_GROUP - 1) / RICE_GROUP;
+    const uint8_t *kp = side + SIDE_HDR + side_sel_bytes(nblocks);
+    const uint32_t k[4] = {kp[0], kp[1], kp[2], kp[3]};
+    const uint32_t *goff = reinterpret_cast<const uint32_t *>(kp + 8);
+    const uint32_t *bits = goff + ngroups;
+    const uint64_t total_bits = bit_words * 32;
+    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * 256) {
+        uint64_t pos = goff[g];
+        const uint64_t r1 = (g + 1) * RICE_GROUP < nr ? (g + 1) * RICE_GROUP : nr;
+        for (uint64_t r = g * RICE_GROUP; r < r1; r++)
+            for (int i = 0; i < 4; i++) {
+                uint64_t q = 0, u = 0;
+                while (q < RICE_ESC && pos < total_bits && get_bit(bits, pos)) {
+                    q++;
+                    pos++;
+                }
+                if (q < RICE_ESC) {
+                    pos++;  // the terminating zero
+                    const uint64_t low = k[i] && pos + k[i] <= total_bits ? get_bits(bits, pos, k[i]) : 0;
+                    pos += k[i];
+                    u = (q << k[i]) | low;
+                } else {
+                    u = pos + 64 <= total_bits ? get_bits(bits, pos, 64) : 0;
+                    pos += 64;
+                }
+                delta_by_rank[r * 4 + i] = unzigzag(u);
+            }
+    }
+}
+// inclusive prefix sums of the four difference sequences, in place: coef_by_rank[r][i] (one workgroup, 1024 ranks per round)
+__global__ __launch_bounds__(1024) void k_blk_coef_scan(uint64_t nr, int64_t *__restrict__ coef_by_rank) {
+    __shared__ int64_t s_w[4][16];
+    __shared__ int64_t s_carry[4];
+    if (threadIdx.x < 4) s_carry[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < nr; base += 1024) {
+        const uint64_t r = base + threadIdx.x;
+        int64_t d[4] = {0, 0, 0, 0}, incl[4];
+        if (r < nr)
+            for (int i = 0; i < 4; i++) d[i] = coef_by_rank[r * 4 + i];
+        for (int i = 0; i < 4; i++) {
+            incl[i] = (int64_t)wave_incl_scan((uint64_t)d[i]);
+            if (lane_id() == WAVE - 1) s_w[i][threadIdx.x / WAVE] = incl[i];
+        }
+        __syncthreads();
+        for (int i = 0; i < 4; i++) {
+            int64_t run = s_carry[i] + incl[i];
+            for (uint32_t k = 0; k < threadIdx.x / WAVE; k++) run += s_w[i][k];
+            if (r < nr) coef_by_rank[r * 4 + i] = run;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            int64_t tot = 0;
+            for (int k = 0; k < 16; k++) tot += s_w[threadIdx.x][k];
+            s_carry[threadIdx.x] += tot;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// decoder: one anti-diagonal front of blocks per launch, one wave per block. d_out holds lattice values q~ (Q) until the
+// final pass turns them into T.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_blk_decode(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t diag, uint32_t bz_lo,
+                                                    uint32_t npairs, const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    __shared__ Q s_q[4][BLK_TILE];
+    __shared__ Q s_a[4][BLK_TILE];
+    const Lattice<T> lat(p.lat);
+    const int lane = lane_id();
+    const uint32_t wv = threadIdx.x / WAVE;
+    Q *sq = s_q[wv], *sa = s_a[wv];
+    const uint32_t E = p.B + 2;
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    Q *qout = reinterpret_cast<Q *>(d_out);
+    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    const uint32_t pair = blockIdx.x * 4 + wv;
+    bool live = pair < npairs;
+    uint32_t bz = 0, by = 0, bx = 0;
+    if (live) {
+        bz = bz_lo + pair / p.nb[1];
+        by = pair % p.nb[1];
+        live = bz + by <= diag && diag - bz - by < p.nb[2] && bz < p.nb[0];
+        bx = live ? diag - bz - by : 0;
+    }
+    const uint32_t task = (bz * p.nb[1] + by) * p.nb[2] + bx;
+    const int sid = live ? (int)p.sel[task] : 0;
+    const BlkGeom g = blk_geom(p, live ? task : 0);
+    const uint32_t nown = live ? g.ez * g.ey * g.ex : 0;
+    if (live && sid == 2) {  // regression: values, no dependency
+        const CoefLat cl = coef_lat(p.eb, p.B);
+        T rc[4];
+        coef_recover(coef_by_rank + (uint64_t)rank[task] * 4, cl, rc);
+        for (uint32_t t = lane; t < nown; t += WAVE) {
+            const uint32_t i2 = t % g.ex, i1 = (t / g.ex) % g.ey, i0 = t / (g.ex * g.ey);
+            const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
+            const uint32_t code = codes[g.coff + t];
+            Q qt = 0;
+            if (code) {
+                bool bad;
+                qt = lat.quant(ref_recover(reg_predict(rc, i0, i1, i2), (int)code, p.eb, (int)p.radius), bad);
+                if (bad) qt = 0;
+            }
+            qout[gi] = qt;
+        }
+        live = false;  // (still walks through the barriers below)
+    }
+    const int order = sid == 1 ? 2 : 1;
+    // ---- tile: halo = finished q~ of the lower neighbours (d_out, element order), own region = this block's deltas (the
+    // codes expanded in their own order, block by block: szk_launch_expand_deltas into `deltas`) ----
+    if (live) {
+        for (uint32_t t = lane; t < E * E * E; t += WAVE) {
+            const uint32_t tx = t % E, ty = (t / E) % E, tz = t / (E * E);
+            const int64_t z = (int64_t)g.oz + tz - 2, y = (int64_t)g.oy + ty - 2, x = (int64_t)g.ox + tx - 2;
+            Q v = 0;
+            if (tz >= 2 && ty >= 2 && tx >= 2) {
+                if (tz - 2 < g.ez && ty - 2 < g.ey && tx - 2 < g.ex) v = deltas[g.coff + ((uint64_t)(tz - 2) * g.ey + (ty - 2)) * g.ex + (tx - 2)];
+            } else if (z >= 0 && y >= 0 && x >= 0 && z < (int64_t)p.d[0] && y < (int64_t)d1 && x < (int64_t)d2) {
+                v = qout[((uint64_t)z * d1 + (uint64_t)y) * d2 + (uint64_t)x];
+            }
+            sq[t] = v;
+        }
+    }
+    __syncthreads();
+    // ---- pass along x: a = Dy^m Dz^m q on the two halo columns, then the recurrence over the own columns ----
+    if (live) {
+        for (uint32_t l = lane; l < g.ez * g.ey; l += WAVE) {
+            const uint32_t tz = l / g.ey + 2, ty = l % g.ey + 2;
+            UQ a[2];
+            for (uint32_t tx = 0; tx < 2; tx++) {
+                UQ s = 0;
+                for (int k = 0; k <= order; k++)
+                    for (int j = 0; j <= order; j++) s += (UQ)((Q)(lz_w(order, k) * lz_w(order, j)) * sq[tile_at(E, tz - k, ty - j, tx)]);
+                a[tx] = s;
+            }
+            UQ p2 = a[0], p1 = a[1];
+            for (uint32_t tx = 2; tx < 2 + g.ex; tx++) {
+                const UQ in = (UQ)sq[tile_at(E, tz, ty, tx)];
+                const UQ v = order == 1 ? p1 + in : (UQ)(2 * p1 - p2 + in);
+                sa[tile_at(E, tz, ty, tx)] = (Q)v;
+                p2 = p1;
+                p1 = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pass along y: b = Dz^m q on the two halo rows (own columns), recurrence over the own rows ----
+    if (live) {
+        for (uint32_t l = lane; l < g.ez * g.ex; l += WAVE) {
+            const uint32_t tz = l / g.ex + 2, tx = l % g.ex + 2;
+            UQ b[2];
+            for (uint32_t ty = 0; ty < 2; ty++) {
+                UQ s = 0;
+                for (int k = 0; k <= order; k++) s += (UQ)((Q)lz_w(order, k) * sq[tile_at(E, tz - k, ty, tx)]);
+                b[ty] = s;
+            }
+            UQ p2 = b[0], p1 = b[1];
+            for (uint32_t ty = 2; ty < 2 + g.ey; ty++) {
+                const UQ in = (UQ)sa[tile_at(E, tz, ty, tx)];
+                const UQ v = order == 1 ? p1 + in : (UQ)(2 * p1 - p2 + in);
+                sa[tile_at(E, tz, ty, tx)] = (Q)v;
+                p2 = p1;
+                p1 = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pass along z: inflow = q~ of the two halo planes; the result is q ----
+    if (live) {
+        for (uint32_t l = lane; l < g.ey * g.ex; l += WAVE) {
+            const uint32_t ty = l / g.ex + 2, tx = l % g.ex + 2;
+            UQ p2 = (UQ)sq[tile_at(E, 0, ty, tx)], p1 = (UQ)sq[tile_at(E, 1, ty, tx)];
+            for (uint32_t tz = 2; tz < 2 + g.ez; tz++) {
+                const UQ in = (UQ)sa[tile_at(E, tz, ty, tx)];
+                const UQ v = order == 1 ? p1 + in : (UQ)(2 * p1 - p2 + in);
+                qout[((uint64_t)(g.oz + tz - 2) * d1 + (g.oy + ty - 2)) * d2 + (g.ox + tx - 2)] = (Q)v;
+                p2 = p1;
+                p1 = v;
+            }
+        }
+    }
+}
+
+// final pass: lattice value -> T for Lorenzo blocks; regression blocks are recomputed from their codes (their value is
+// pred + 2*code*eb, not a lattice point)
+template <typename T>
+__global__ __launch_bounds__(256) void k_blk_final(const uint16_t *__restrict__ codes, void *d_out, szk_blk_params p, uint32_t nblocks,
+                                                   const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
+    using Q = typename QTraits<T>::Q;
+    const Lattice<T> lat(p.lat);
+    const int lane = lane_id();
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    Q *qv = reinterpret_cast<Q *>(d_out);
+    T *ov = reinterpret_cast<T *>(d_out);
+    const CoefLat cl = coef_lat(p.eb, p.B);
+    for (uint32_t task = blockIdx.x * 4 + threadIdx.x / WAVE; task < nblocks; task += gridDim.x * 4) {
+        const BlkGeom g = blk_geom(p, task);
+        const uint32_t nown = g.ez * g.ey * g.ex;
+        const bool reg = p.sel[task] == 2;
+        T rc[4] = {0, 0, 0, 0};
+        if (reg) coef_recover(coef_by_rank + (uint64_t)rank[task] * 4, cl, rc);
+        for (uint32_t t = lane; t < nown; t += WAVE) {
+            const uint32_t i2 = t % g.ex, i1 = (t / g.ex) % g.ey, i0 = t / (g.ex * g.ey);
+            const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
+            if (reg) {
+                const uint32_t code = codes[g.coff + t];
+                ov[gi] = code ? ref_recover(reg_predict(rc, i0, i1, i2), (int)code, p.eb, (int)p.radius) : (T)0;  // (code 0: patched from the list)
+            } else {
+                const Q q = qv[gi];
+                ov[gi] = lat.dequant(q);
+            }
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_blk_patch(const uint8_t *__restrict__ payload, uint64_t idx_off, uint64_t val_off, uint64_t cnt, uint64_t n,
+                                                   T *__restrict__ out) {
+    const uint64_t *idx = reinterpret_cast<const uint64_t *>(payload + idx_off);
+    const T *val = reinterpret_cast<const T *>(payload + val_off);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t k = idx[i];
+        if (k < n) out[k] = val[i];
+    }
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------------
+static uint32_t blk_count_blocks(const szk_blk_params *p) { return p->nb[0] * p->nb[1] * p->nb[2]; }
+
+int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s) {
+    const uint32_t nblocks = blk_count_blocks(p);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
+    if (dtype == 0) {
+        hipLaunchKernelGGL(k_blk_fit<float>, dim3(grid), dim3(256), 0, s, (const float *)d_in, codes, *p, nblocks);
+        hipLaunchKernelGGL(k_blk_lorenzo<float>, dim3(grid), dim3(256), 0, s, codes, *p, nblocks);
+    } else {
+        hipLaunchKernelGGL(k_blk_fit<double>, dim3(grid), dim3(256), 0, s, (const double *)d_in, codes, *p, nblocks);
+        hipLaunchKernelGGL(k_blk_lorenzo<double>, dim3(grid), dim3(256), 0, s, codes, *p, nblocks);
+    }
+    hipLaunchKernelGGL(k_blk_rank, dim3(1), dim3(1024), 0, s, p->sel, nblocks, sc->rank, sc->comp, sc->counters + 0);
+    // (counters: [0] regression blocks, [2] side bytes, [4..7] as doubles: sum of the zigzagged differences per coefficient;
+    // the group sizes are staged in the rank array, which the encoder needs no more once comp is written)
+    double *stats = reinterpret_cast<double *>(sc->counters + 4);
+    uint32_t *group_bits = sc->rank;
+    hipLaunchKernelGGL(k_blk_coef_stats, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, stats);
+    hipLaunchKernelGGL(k_blk_coef_len, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, stats, group_bits);
+    hipLaunchKernelGGL(k_blk_side_layout, dim3(1), dim3(1024), 0, s, p->sel, nblocks, sc->counters + 0, stats, group_bits, sc->side, sc->counters + 2);
+    hipLaunchKernelGGL(k_blk_coef_write, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, nblocks, sc->side);
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
+
+// worst case: every block a regression block, every coefficient escaped (4 x 88 bits)
+size_t szk_blk_side_bound(uint64_t nblocks) { return SIDE_HDR + ((nblocks + 3) / 4 + 16) + 8 + 4 * (nblocks / RICE_GROUP + 1) + nblocks * 44 + 64; }
+
+int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, const szk_blk_params *p, const szk_blk_scratch *sc,
+                              const uint8_t *payload, const szh_header *h, const szh_offsets *o, int64_t *coef_by_rank, hipStream_t s) {
+    const uint32_t nblocks = blk_count_blocks(p);
+    const uint8_t *side = payload + o->side;
+    // the side header was validated by the host (coding, counts, lengths)
+    uint64_t nr, bit_words;
+    memcpy(&nr, &sc->side_hdr[16], 8);
+    memcpy(&bit_words, &sc->side_hdr[24], 8);
+    hipLaunchKernelGGL(k_blk_side_sel, dim3((nblocks + 255) / 256 < 1024 ? (nblocks + 255) / 256 : 1024), dim3(256), 0, s, side, nblocks, p->sel);
+    hipLaunchKernelGGL(k_blk_rank, dim3(1), dim3(1024), 0, s, p->sel, nblocks, sc->rank, (uint32_t *)nullptr, sc->counters + 0);
+    if (nr) {
+        const uint64_t ngroups = (nr + RICE_GROUP - 1) / RICE_GROUP;
+        hipLaunchKernelGGL(k_blk_coef_parse, dim3((uint32_t)((ngroups + 255) / 256 < 1024 ? (ngroups + 255) / 256 : 1024)), dim3(256), 0, s, side, nblocks, nr,
+                           bit_words, coef_by_rank);
+        hipLaunchKernelGGL(k_blk_coef_scan, dim3(1), dim3(1024), 0, s, nr, coef_by_rank);
+    }
+    if (szk_launch_expand_deltas(dtype, codes, h->n, (int)h->radius, payload, o, h->n_dout, p->qwork, s)) return -1;
+    const uint32_t ndiag = p->nb[0] + p->nb[1] + p->nb[2] - 2;
+    for (uint32_t d = 0; d < ndiag; d++) {
+        // blocks of the front: bz + by + bx = d; only the bz that can have a partner (by, bx) are enumerated
+        const uint32_t rest = (p->nb[1] - 1) + (p->nb[2] - 1);
+        const uint32_t bz_lo = d > rest ? d - rest : 0, bz_hi = d < p->nb[0] - 1 ? d : p->nb[0] - 1;
+        if (bz_lo > bz_hi) continue;
+        const uint32_t npairs = (bz_hi - bz_lo + 1) * p->nb[1];
+        if (dtype == 0)
+            hipLaunchKernelGGL(k_blk_decode<float>, dim3((npairs + 3) / 4), dim3(256), 0, s, codes, p->qwork, d_out, *p, d, bz_lo, npairs, sc->rank, coef_by_rank);
+        else
+            hipLaunchKernelGGL(k_blk_decode<double>, dim3((npairs + 3) / 4), dim3(256), 0, s, codes, p->qwork, d_out, *p, d, bz_lo, npairs, sc->rank, coef_by_rank);
+    }
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
+    if (dtype == 0) {
+        hipLaunchKernelGGL(k_blk_final<float>, dim3(grid), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);
+        if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<float>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (float *)d_out);
+    } else {
+        hipLaunchKernelGGL(k_blk_final<double>, dim3(grid), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);
+        if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<double>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (double *)d_out);
+    }
+    SZK_CHECK_LAUNCH();
+    return 0;
+}

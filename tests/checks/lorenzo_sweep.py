@@ -21,7 +21,7 @@ for k in range(int(os.environ.get("N", "40"))):
     qb = int(rng.choice([64, 256, 1024, 4096, 65536])); eb = float(10.0 ** rng.integers(-4, -1))
     dev = torch.device("cuda:0"); t = torch.from_numpy(a).to(dev)
     dc = sz3_amd.DeviceCompressor(a.size, a.dtype); cap = dc.payload_bound(a.size, worst_case=True); pl = torch.empty(cap, dtype=torch.uint8, device=dev)
-    conf = sz3_amd.Config(*shape); conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG; conf.absErrorBound = eb; conf.quantbinCnt = qb
+    conf = sz3_amd.Config(*shape); conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG; conf.regression = 0; conf.absErrorBound = eb; conf.quantbinCnt = qb
     try:
         size = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
     except sz3_amd.SZ3HipError as e:

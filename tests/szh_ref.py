@@ -62,11 +62,13 @@ def parse(payload):
     b = bytes(payload)
     (magic, version, dtype, ndim, qbytes, predictor, radius) = struct.unpack_from("<IIBBBBI", b, 0)
     dims = struct.unpack_from("<4Q", b, 16)
-    eb, n, chunk_syms, max_len, n_chunks, sym_min, sym_count, n_vout, n_dout, words, pbytes = struct.unpack_from(
-        "<dQIIQIIQQQQ", b, 48)
+    eb, n, chunk_syms, max_len, n_chunks, sym_min, sym_count, n_vout, n_dout, words, pbytes, side_bytes = struct.unpack_from(
+        "<dQIIQIIQQQQQ", b, 48)
+    blk_edge, blk_mask = struct.unpack_from("<II", b, 144)  # (interp_id, interp_dir: block edge / predictor mask when predictor == 2)
     h = dict(magic=magic, version=version, dtype=dtype, ndim=ndim, qbytes=qbytes, radius=radius, dims=dims, eb=eb, n=n,
              chunk_syms=chunk_syms, max_len=max_len, n_chunks=n_chunks, sym_min=sym_min, sym_count=sym_count,
-             n_vout=n_vout, n_dout=n_dout, bitstream_words=words, payload_bytes=pbytes, predictor=predictor)
+             n_vout=n_vout, n_dout=n_dout, bitstream_words=words, payload_bytes=pbytes, predictor=predictor,
+             side_bytes=side_bytes if predictor == 2 else 0, blk_edge=blk_edge, blk_mask=blk_mask)
     a16 = lambda x: (x + 15) & ~15
     tsz = 4 if dtype == 0 else 8
     off = 160
@@ -83,6 +85,8 @@ def parse(payload):
     off += 8 * n_dout
     o["dout_val"] = off
     off = a16(off + qbytes * n_dout)
+    o["side"] = off
+    off = a16(off + h["side_bytes"])
     o["bitstream"] = off
     o["end"] = off + 4 * words
     T = np.float32 if dtype == 0 else np.float64
@@ -96,6 +100,7 @@ def parse(payload):
         dout_idx=np.frombuffer(b, dtype=np.uint64, count=n_dout, offset=o["dout_idx"]).copy(),
         dout_val=np.frombuffer(b, dtype=Q, count=n_dout, offset=o["dout_val"]).copy(),
         bitstream=np.frombuffer(b, dtype=np.uint32, count=words, offset=o["bitstream"]).copy(),
+        side=buf[o["side"]:o["side"] + h["side_bytes"]].copy(),
     )
     return h, o, sec
 
@@ -141,7 +146,7 @@ def huffman_decode(h, sec):
     bs = sec["bitstream"]
     for c in range(h["n_chunks"]):
         words = bs[offs[c]:offs[c + 1]]
-        bits = np.unpackbits(words.astype(">u4").view(np.uint8)) if len(words) else np.zeros(0, np.uint8)
+        bits = np.unpackbits(words.view(np.uint8)) if len(words) else np.zeros(0, np.uint8)  # bytes are in stream order
         s0 = c * CHUNK
         ns = min(CHUNK, n - s0)
         pos = 0
@@ -179,3 +184,121 @@ def decode_payload(payload):
     h, o, sec = parse(payload)
     codes = huffman_decode(h, sec)
     return reconstruct(h, sec, codes), h
+
+
+# ---- block-composed predictor (predictor id 2, sz3hip_regress.hip): side section and a slow block-by-block decoder ----
+def parse_side(h, sec):
+    """-> (selection per block uint8 [nbz, nby, nbx], coefficient lattice values int64 [n_reg, 4] in block raster order)"""
+    side = sec["side"].tobytes()
+    coding, sel_bits, nblocks, nreg = struct.unpack_from("<IIQQ", side, 0)
+    B = h["blk_edge"]
+    nb = [(d + B - 1) // B for d in h["dims"][1:]]
+    assert coding == 1 and sel_bits == 2 and nblocks == nb[0] * nb[1] * nb[2]
+    sel_bytes = ((nblocks + 3) // 4 + 7) & ~7
+    packed = np.frombuffer(side, dtype=np.uint8, count=sel_bytes, offset=24)
+    sel = ((packed[:, None] >> (2 * np.arange(4))) & 3).reshape(-1)[:nblocks].astype(np.uint8)
+    # Rice-coded differences: [u8 k[4]][u32 groups][u32 bit offset per group of 64 blocks][u32 words, MSB first]
+    p0 = 24 + sel_bytes
+    ks = list(side[p0:p0 + 4])
+    ngroups, = struct.unpack_from("<I", side, p0 + 4)
+    assert ngroups == (nreg + 63) // 64
+    goff = np.frombuffer(side, dtype=np.uint32, count=ngroups, offset=p0 + 8)
+    words = np.frombuffer(side, dtype=np.uint32, offset=p0 + 8 + 4 * ngroups)
+    bits = np.unpackbits(words.astype(">u4").view(np.uint8))
+    deltas = np.zeros((nreg, 4), dtype=np.int64)
+    for g in range(ngroups):
+        pos = int(goff[g])
+        for r in range(g * 64, min(nreg, (g + 1) * 64)):
+            for i in range(4):
+                q = 0
+                while q < 24 and bits[pos]:
+                    q += 1
+                    pos += 1
+                if q < 24:
+                    pos += 1
+                    low = 0
+                    for _ in range(ks[i]):
+                        low = (low << 1) | int(bits[pos])
+                        pos += 1
+                    u = (q << ks[i]) | low
+                else:
+                    u = 0
+                    for _ in range(64):
+                        u = (u << 1) | int(bits[pos])
+                        pos += 1
+                deltas[r, i] = (u >> 1) ^ -(u & 1)
+    coef = np.cumsum(deltas, axis=0)
+    assert int((sel == 2).sum()) == nreg
+    return sel.reshape(nb), coef
+
+
+def reconstruct_blocks(h, sec, codes):
+    """numpy model of the block decoder: blocks in raster order (any order that respects the low-side dependencies works),
+    Lorenzo blocks invert their integer stencil element by element, regression blocks are pred + 2*(code - radius)*eb"""
+    T = np.float32 if h["dtype"] == 0 else np.float64
+    Q = np.int32 if h["dtype"] == 0 else np.int64
+    dz, dy, dx = h["dims"][1:]
+    B, eb, radius = h["blk_edge"], h["eb"], h["radius"]
+    sel, coef = parse_side(h, sec)
+    dflat = np.where(codes == 0, 0, codes.astype(np.int64) - radius).astype(np.int64)
+    dflat[sec["dout_idx"].astype(np.int64)] = sec["dout_val"]  # (outlier indices are code positions)
+    # the codes are stored block by block (block raster order, raster order inside a block): back to element order
+    d = np.zeros((dz, dy, dx), dtype=np.int64)
+    c3 = np.zeros((dz, dy, dx), dtype=np.int64)
+    pos = 0
+    for z0 in range(0, dz, B):
+        for y0 in range(0, dy, B):
+            for x0 in range(0, dx, B):
+                ez, ey, ex = min(B, dz - z0), min(B, dy - y0), min(B, dx - x0)
+                m = ez * ey * ex
+                d[z0:z0 + ez, y0:y0 + ey, x0:x0 + ex] = dflat[pos:pos + m].reshape(ez, ey, ex)
+                c3[z0:z0 + ez, y0:y0 + ey, x0:x0 + ex] = codes[pos:pos + m].reshape(ez, ey, ex)
+                pos += m
+    q = np.zeros((dz + 2, dy + 2, dx + 2), dtype=np.int64)  # two zero halo layers on the low side
+    out = np.zeros((dz, dy, dx), dtype=T)
+    recip = T(1.0 / (2.0 * eb)) if T == np.float32 else 1.0 / (2.0 * eb)
+    lim = T(8388608.0) if T == np.float32 else 4503599627370496.0
+    step_ind, step_lin = 2.0 * (eb / 4.0), 2.0 * (eb / 4.0 / B)
+    w1, w2 = np.array([1, -1]), np.array([1, -2, 1])
+    r = 0
+    for bz in range(sel.shape[0]):
+        for by in range(sel.shape[1]):
+            for bx in range(sel.shape[2]):
+                z0, y0, x0 = bz * B, by * B, bx * B
+                ez, ey, ex = min(B, dz - z0), min(B, dy - y0), min(B, dx - x0)
+                s = int(sel[bz, by, bx])
+                if s == 2:
+                    lc = coef[r]
+                    r += 1
+                    rc = [T(float(lc[i]) * step_lin) for i in range(3)] + [T(float(lc[3]) * step_ind)]
+                    i0, i1, i2 = np.meshgrid(np.arange(ez), np.arange(ey), np.arange(ex), indexing="ij")
+                    pred = (rc[0] * i0.astype(T) + rc[1] * i1.astype(T) + rc[2] * i2.astype(T) + rc[3]).astype(T)
+                    cc = c3[z0:z0 + ez, y0:y0 + ey, x0:x0 + ex].astype(np.int64)
+                    val = (pred.astype(np.float64) + (2 * (cc - radius)).astype(np.float64) * eb).astype(T)
+                    with np.errstate(invalid="ignore", over="ignore"):
+                        sc = val * recip
+                        ok = np.abs(sc) < lim
+                        rr = np.rint(np.where(ok, sc, 0)).astype(T)
+                        bad = ~ok | ~(np.abs(rr * T(2.0 * eb) - val) <= (T(eb) if float(T(eb)) <= eb else np.nextafter(T(eb), T(0))))
+                    qt = np.where((cc == 0) | bad, 0, rr.astype(np.int64))
+                    q[z0 + 2:z0 + 2 + ez, y0 + 2:y0 + 2 + ey, x0 + 2:x0 + 2 + ex] = qt
+                    out[z0:z0 + ez, y0:y0 + ey, x0:x0 + ex] = np.where(cc == 0, 0, val)
+                else:
+                    w = w1 if s == 0 else w2
+                    m = len(w) - 1
+                    for k in range(ez):
+                        for j in range(ey):
+                            for i in range(ex):
+                                z, y, x = z0 + k + 2, y0 + j + 2, x0 + i + 2
+                                acc = int(d[z0 + k, y0 + j, x0 + i])
+                                for a in range(m + 1):
+                                    for b_ in range(m + 1):
+                                        for c_ in range(m + 1):
+                                            if a or b_ or c_:
+                                                acc -= int(w[a] * w[b_] * w[c_]) * int(q[z - a, y - b_, x - c_])
+                                q[z, y, x] = acc
+                    blk = q[z0 + 2:z0 + 2 + ez, y0 + 2:y0 + 2 + ey, x0 + 2:x0 + 2 + ex]
+                    out[z0:z0 + ez, y0:y0 + ey, x0:x0 + ex] = blk.astype(T) * T(2.0 * eb)
+    x = out.reshape(-1)
+    x[sec["vout_idx"].astype(np.int64)] = sec["vout_val"]
+    return x, sel

@@ -25,6 +25,7 @@ GOLD = np.load(os.path.join(HERE, "golden", "golden.npz"))
 def _gpu_roundtrip(a, **kw):
     conf = sz3_amd.Config(*a.shape)
     conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.regression = 0  # Lorenzo-1 alone = the plain stream; tests/test_gpu_regression.py covers the block-composed predictor
     for k, v in kw.items():
         setattr(conf, k, v)
     blob, ratio = sz3_amd.compress(a, conf)
@@ -182,6 +183,7 @@ def test_full_size_properties(shape, dtype, eb):
     pl2 = torch.empty(cap, dtype=torch.uint8, device=dev)
     conf = sz3_amd.Config(*shape)
     conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.regression = 0  # (idempotence is a property of the lattice: regression blocks reconstruct off it)
     conf.absErrorBound = eb
     s = torch.cuda.current_stream().cuda_stream
     sz1 = dc.compress(conf, f.data_ptr(), pl1.data_ptr(), cap, s)
@@ -213,6 +215,7 @@ def test_histogram_split_path_equals_single_call():
     p2 = torch.empty(cap, dtype=torch.uint8, device=dev)
     conf = sz3_amd.Config(*a.shape)
     conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.regression = 0
     conf.absErrorBound = 1e-3
     s = torch.cuda.current_stream().cuda_stream
     n1 = dc.compress(conf, t.data_ptr(), p1.data_ptr(), cap, s)

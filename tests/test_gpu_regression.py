@@ -1,0 +1,139 @@
+"""GPU tests (-m gpu) of the block-composed predictor (sz3hip_regress.hip): per-block choice of Lorenzo-1 / Lorenzo-2 /
+linear regression — RegressionPredictor.hpp:28-164, ComposedPredictor.hpp:25-64, LorenzoPredictor.hpp:75-91,
+make_compressor_lorenzo_regression (api/impl/SZAlgoLorenzoReg.hpp:22-64).
+
+Parity bar: the strict error bound of the reference's own tests; the stream read back by an independent
+numpy model of the block decoder (tests/szh_ref.py) bit for bit; the ratio and the share of regression blocks against the
+oracle (the CPU restatement, pinned to the reference) on SURVEY.md 8(d)'s C4a field, where both predictors are exercised."""
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import sz3_amd  # noqa: E402
+import szh_ref  # noqa: E402
+from fields import field3d, field_c4a  # noqa: E402
+from oracle_binding import make_config, oracle, oracle_compress  # noqa: E402
+
+
+def _payload_of(stream):
+    b = stream.tobytes()
+    plen, = struct.unpack_from("<Q", b, 8)
+    blob = np.frombuffer(b[16:16 + plen], dtype=np.uint8).copy()
+    rawlen, = struct.unpack_from("<Q", blob.tobytes(), 0)
+    out = np.empty(rawlen, dtype=np.uint8)
+    assert oracle().szo_zstd_decompress(blob.ctypes.data, blob.size, out.ctypes.data, rawlen) == rawlen
+    return out.tobytes()
+
+
+def _conf(shape, eb, lorenzo, lorenzo2, regression, block=None):
+    c = sz3_amd.Config(*shape)
+    c.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    c.lorenzo, c.lorenzo2, c.regression = int(lorenzo), int(lorenzo2), int(regression)
+    c.absErrorBound = eb
+    if block:
+        c.blockSize = block
+    return c
+
+
+MASKS = {"R": (0, 0, 1), "L2": (0, 1, 0), "L1+R": (1, 0, 1), "L1+L2": (1, 1, 0), "L1+L2+R": (1, 1, 1), "L2+R": (0, 1, 1)}
+
+
+@pytest.mark.parametrize("mask", list(MASKS))
+@pytest.mark.parametrize("dtype,shape,eb,block", [(np.float32, (20, 31, 45), 1e-2, None), (np.float64, (13, 24, 38), 2e-2, 4),
+                                                 (np.float32, (16, 16, 16), 5e-2, 8), (np.float32, (7, 9, 11), 1e-3, 5)])
+def test_block_stream_against_the_numpy_model(mask, dtype, shape, eb, block):
+    """small fields (ragged blocks at every high face): bound, header, and the numpy block decoder reproduces the GPU's
+    reconstruction bit for bit from the stream — selection bits, coefficient deltas, codes, outlier lists"""
+    a = field3d(shape, dtype, sigma=2e-3)
+    conf = _conf(shape, eb, *MASKS[mask], block=block)
+    blob, ratio = sz3_amd.compress(a, conf)
+    dec, c2 = sz3_amd.decompress(blob, dtype, shape)
+    assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= eb
+    if c2.cmprAlgo == sz3_amd.ALGO_LOSSLESS:
+        pytest.skip("tiny field went lossless")
+    h, o, sec = szh_ref.parse(_payload_of(blob))
+    assert h["predictor"] == 2 and h["blk_edge"] == (block or 6) and h["blk_mask"] == sum(b << i for i, b in enumerate(MASKS[mask]))
+    assert (c2.lorenzo, c2.lorenzo2, c2.regression) == MASKS[mask]
+    codes = szh_ref.huffman_decode(h, sec)
+    model, sel = szh_ref.reconstruct_blocks(h, sec, codes)
+    assert np.array_equal(model.reshape(shape), dec), "numpy model of the block decoder and the GPU decoder disagree"
+    allowed = [i for i, b in enumerate(MASKS[mask]) if b]
+    assert set(np.unique(sel)) <= set(allowed) | {0}  # (0 = the Lorenzo-1 fallback of blocks regression cannot take)
+
+
+def test_unpredictable_values_and_wide_deltas_in_block_streams():
+    a = field3d((24, 30, 36), np.float32)
+    a[3, 4, 5] = np.nan
+    a[10, 11, 12] = np.inf
+    a[20:23, 20:25, 20:30] += 500.0  # a step: Lorenzo deltas beyond the radius next to it, regression residuals unpredictable
+    for mask in ("L1+R", "R", "L1+L2+R"):
+        conf = _conf(a.shape, 1e-3, *MASKS[mask])
+        conf.quantbinCnt = 1024
+        blob, _ = sz3_amd.compress(a, conf)
+        dec, _ = sz3_amd.decompress(blob, np.float32, a.shape)
+        ok = np.isfinite(a)
+        assert np.array_equal(dec[~ok].view(np.uint32), a[~ok].view(np.uint32))
+        assert float(np.max(np.abs(dec[ok].astype(np.float64) - a[ok].astype(np.float64)))) <= 1e-3
+        h, o, sec = szh_ref.parse(_payload_of(blob))
+        model, _ = szh_ref.reconstruct_blocks(h, sec, szh_ref.huffman_decode(h, sec))
+        assert np.array_equal(model.view(np.uint32), dec.reshape(-1).view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [96, 160])
+def test_c4a_ratio_and_selection_share_against_the_oracle(n):
+    """3.3e-5 x the C2 formula in f64, abs 1e-6 — eb is ~3 % of the amplitude and both predictors are
+    chosen. Bound strict; ratio >= 0.97 x the oracle's Lorenzo+regression ratio; share of regression blocks within
+    +-40 % (relative) of the oracle's (the estimator is the reference's, fed with original instead of reconstructed
+    neighbours outside the block)."""
+    a = field_c4a((n, n, n))
+    eb = 1e-6
+    ob, st = oracle_compress(a, make_config(a.shape, abs_eb=eb, lorenzo=True, regression=True), stats=True)
+    o_ratio = a.nbytes / len(ob)
+    o_share = st.n_regression_blocks / st.n_blocks
+    blob, ratio = sz3_amd.compress(a, _conf(a.shape, eb, 1, 0, 1))
+    dec, _ = sz3_amd.decompress(blob, np.float64, a.shape)
+    assert float(np.max(np.abs(dec - a))) <= eb
+    h, o, sec = szh_ref.parse(_payload_of(blob))
+    sel, coef = szh_ref.parse_side(h, sec)
+    share = float((sel == 2).mean())
+    print("C4a %d^3: ratio %.2f (oracle %.2f), regression share %.3f (oracle %.3f)" % (n, ratio, o_ratio, share, o_share))
+    assert ratio >= 0.97 * o_ratio
+    assert 0.6 * o_share <= share <= 1.4 * o_share
+
+
+def test_regression_only_beats_lorenzo_where_the_reference_says_so():
+    """C2 field at eb 5e-2 (regression wins from ~3e-2 on): oracle regression-only 28.8 vs Lorenzo 18.5 at 128^3"""
+    a = field3d((96, 96, 96), np.float32)
+    eb = 5e-2
+    r = {}
+    for mask in ("L1+R", "R"):
+        blob, r[mask] = sz3_amd.compress(a, _conf(a.shape, eb, *MASKS[mask]))
+        dec, _ = sz3_amd.decompress(blob, np.float32, a.shape)
+        assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= eb
+    plain = _conf(a.shape, eb, 1, 0, 0)
+    _, r["L1"] = sz3_amd.compress(a, plain)
+    orc = {k: a.nbytes / len(oracle_compress(a, make_config(a.shape, abs_eb=eb, lorenzo=l, regression=g)))
+           for k, (l, g) in {"L1": (True, False), "L1+R": (True, True), "R": (False, True)}.items()}
+    print("C2 96^3 @5e-2: gpu", {k: round(v, 2) for k, v in r.items()}, "oracle", {k: round(v, 2) for k, v in orc.items()})
+    # (measured: regression-only 27.0 vs the oracle's 27.1; composed 19.0 vs 20.0 — the Lorenzo blocks of the composed stream
+    # carry the lattice's extra rounding noise, code entropy 1.80 vs 1.72 bit)
+    assert r["R"] > 1.2 * r["L1"] and r["R"] >= 0.97 * orc["R"] and r["L1+R"] >= 0.93 * orc["L1+R"]
+
+
+def test_predictor_sets_outside_the_block_path():
+    a2 = np.random.default_rng(0).normal(size=(64, 64)).astype(np.float32).cumsum(axis=1)
+    c = sz3_amd.Config(64, 64)
+    c.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    c.absErrorBound = 1e-2
+    blob, _ = sz3_amd.compress(a2, c)  # defaults: lorenzo + regression, 2-D -> the Lorenzo-1 member, recorded in the trailer
+    dec, c2 = sz3_amd.decompress(blob, np.float32, a2.shape)
+    assert (c2.lorenzo, c2.lorenzo2, c2.regression) == (1, 0, 0) and float(np.max(np.abs(dec - a2))) <= 1e-2
+    c.lorenzo = 0  # regression only, 2-D: not built -> refused, never silently replaced
+    with pytest.raises(sz3_amd.SZ3HipError, match="3-D"):
+        sz3_amd.compress(a2, c)
+    c.regression = 0
+    with pytest.raises(sz3_amd.SZ3HipError, match="disabled"):
+        sz3_amd.compress(a2, c)

@@ -14,6 +14,7 @@ torch = pytest.importorskip("torch")
 def _conf(shape, eb):
     c = sz3_amd.Config(*shape)
     c.cmprAlgo = sz3_amd.ALGO_LORENZO_REG   # the Lorenzo path (the default ALGO_INTERP_LORENZO takes interpolation)
+    c.regression = 0  # Lorenzo-1 alone: the plain stream (with regression the block-composed predictor takes over)
     c.errorBoundMode = sz3_amd.EB_ABS
     c.absErrorBound = eb
     return c
@@ -195,6 +196,7 @@ def test_many_unpredictables_grow_the_lists(algo):
     dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
     conf = sz3_amd.Config(*shape)
     conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG if algo == "lorenzo" else sz3_amd.ALGO_INTERP
+    conf.regression = 0
     conf.absErrorBound = eb
     conf.quantbinCnt = 64
     cap = dc.payload_bound(a.size)
@@ -246,6 +248,7 @@ def test_small_quantiser_lorenzo(shape, dtype, qb, eb, sigma, nan):
     pl = torch.empty(cap, dtype=torch.uint8, device=dev)
     conf = sz3_amd.Config(*shape)
     conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.regression = 0  # Lorenzo-1 alone: the plain stream (with regression the block-composed predictor takes over)
     conf.absErrorBound = eb
     conf.quantbinCnt = qb
     size = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
@@ -313,6 +316,7 @@ def test_payload_does_not_depend_on_the_context_history():
         pl = torch.empty(cap, dtype=torch.uint8, device=dev)
         conf = sz3_amd.Config(*a.shape)
         conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+        conf.regression = 0  # Lorenzo-1 alone: the plain stream (with regression the block-composed predictor takes over)
         conf.absErrorBound = eb
         n = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
         out = torch.empty_like(t)
@@ -343,6 +347,7 @@ def test_stage_calls_out_of_order_are_refused():
     pl = torch.empty(cap, dtype=torch.uint8, device=dev)
     conf = sz3_amd.Config(*a.shape)
     conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.regression = 0  # Lorenzo-1 alone: the plain stream (with regression the block-composed predictor takes over)
     conf.absErrorBound = 1e-3
     with pytest.raises(sz3_amd.SZ3HipError):
         dc.stage2(pl.data_ptr(), cap, 0)

@@ -45,9 +45,11 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512, help="edge of the cubic volume per GPU (512 = the metric's config)")
     ap.add_argument("--eb", type=float, default=1e-3)
-    ap.add_argument("--algo", choices=["lorenzo", "interp", "interp-notune"], default="lorenzo",
+    ap.add_argument("--algo", choices=["lorenzo", "interp", "interp-notune", "composed"], default="lorenzo",
                     help="lorenzo = the metric's config C2 (default); interp = C3 (ALGO_INTERP_LORENZO: sampling auto-tuner + "
-                         "interpolation; use --eb 1e-4); interp-notune = ALGO_INTERP with the default cubic parameters")
+                         "interpolation; use --eb 1e-4); interp-notune = ALGO_INTERP with the default cubic parameters; composed = "
+                         "ALGO_LORENZO_REG with Lorenzo + regression chosen per block (C4's predictor set: --dtype f64 --shape 128,1024,1024 --eb 1e-6)")
+    ap.add_argument("--field", choices=["default", "c4a"], default="default", help="c4a: SURVEY.md 8(d)'s C4a field (f64, scale 3.3e-5) where both predictors are chosen")
     ap.add_argument("--shape", default=None, help="z,y,x of the per-GPU volume instead of --size^3 (e.g. 128,1024,1024 = one C4 slab)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="f64 + --shape 128,1024,1024 --eb 1e-6 = C4's per-GPU slab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -72,19 +74,23 @@ def relaunch_as_ranks(n):
 class Workload:
     """one configuration, device resident: input tensor, context, payload buffer; step() = one pass of the hot path"""
 
-    def __init__(self, torch, sz3_amd, dev, local_rank, rank, shape, dtype, algo, eb, comm=None, dist=None):
-        from fields import field3d
+    def __init__(self, torch, sz3_amd, dev, local_rank, rank, shape, dtype, algo, eb, comm=None, dist=None, field="default"):
+        from fields import field3d, field_c4a
         self.torch, self.sz = torch, sz3_amd
         self.shape, self.algo, self.eb, self.dtype = shape, algo, eb, dtype
         self.npdt = np.float32 if dtype == "f32" else np.float64
         self.esz = 4 if dtype == "f32" else 8
         self.n = int(np.prod(shape))
         # every rank: its own slab of the same analytic field family (different noise seed per rank)
-        self.a = field3d(shape, self.npdt, seed=20260928 + rank) if dtype == "f32" else field3d(shape, self.npdt, seed=20260928 + rank, sigma=2e-6)
+        if field == "c4a":
+            self.a = field_c4a(shape, seed=20260928 + rank).astype(self.npdt)
+        else:
+            self.a = field3d(shape, self.npdt, seed=20260928 + rank) if dtype == "f32" else field3d(shape, self.npdt, seed=20260928 + rank, sigma=2e-6)
         self.d_in = torch.from_numpy(self.a).to(dev)
         conf = sz3_amd.Config(*shape)
-        conf.cmprAlgo = {"lorenzo": sz3_amd.ALGO_LORENZO_REG, "interp": sz3_amd.ALGO_INTERP_LORENZO, "interp-notune": sz3_amd.ALGO_INTERP}[algo]
-        conf.lorenzo, conf.lorenzo2, conf.regression = 1, 0, 0
+        conf.cmprAlgo = {"lorenzo": sz3_amd.ALGO_LORENZO_REG, "interp": sz3_amd.ALGO_INTERP_LORENZO, "interp-notune": sz3_amd.ALGO_INTERP,
+                         "composed": sz3_amd.ALGO_LORENZO_REG}[algo]
+        conf.lorenzo, conf.lorenzo2, conf.regression = 1, 0, int(algo == "composed")
         conf.errorBoundMode = sz3_amd.EB_ABS
         conf.absErrorBound = eb
         self.conf = conf
@@ -145,7 +151,11 @@ def rooflines(w, acc, psize, ms_per_step, traffic_key):
             traffic = json.load(open(tpath)).get(traffic_key)
         except Exception:
             traffic = None
-    if w.algo == "lorenzo":
+    if w.algo == "composed":
+        k_bytes = w.n * (3 * w.esz + 2)  # input in, lattice values out and in again (the two block passes), one 2-byte code per element
+        kname = "stage 1 = k_blk_fit + k_blk_lorenzo + side information (block-composed predictor, sz3hip_regress.hip)"
+        note = "read sizeof(T), write + read sizeof(T) of lattice values, write 2 B of codes per element"
+    elif w.algo == "lorenzo":
         stats = w.dc.stats()
         code_bytes = 1 if stats.get("narrow_codes") else 2
         k_bytes = w.n * (w.esz + code_bytes)  # the predictor kernel reads the array once and writes one code per element
@@ -180,8 +190,9 @@ def cpu_baseline(w):
     raw = w.n * w.esz
 
     def oconf(openmp):
-        return (make_config(shape, abs_eb=eb, lorenzo=True, regression=False, openmp=openmp) if algo == "lorenzo" else
-                make_config(shape, algo=O_TUNED if algo == "interp" else O_INTERP, abs_eb=eb, regression=True, openmp=openmp))
+        if algo in ("lorenzo", "composed"):
+            return make_config(shape, abs_eb=eb, lorenzo=True, regression=algo == "composed", openmp=openmp)
+        return make_config(shape, algo=O_TUNED if algo == "interp" else O_INTERP, abs_eb=eb, regression=True, openmp=openmp)
     if have_ref():
         blob, sec = ref_compress(w.a, oconf(False), timing=True)
         kind = "reference"
@@ -190,7 +201,8 @@ def cpu_baseline(w):
         blob = oracle_compress(w.a, oconf(False))
         sec = time.perf_counter() - t0
         kind = "port"
-    what = {"lorenzo": "ALGO_LORENZO_REG (Lorenzo only)", "interp": "ALGO_INTERP_LORENZO (default)", "interp-notune": "ALGO_INTERP (cubic)"}[algo]
+    what = {"lorenzo": "ALGO_LORENZO_REG (Lorenzo only)", "interp": "ALGO_INTERP_LORENZO (default)", "interp-notune": "ALGO_INTERP (cubic)",
+            "composed": "ALGO_LORENZO_REG (Lorenzo + regression)"}[algo]
     out = {"value": round(raw / sec / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
            "sample": "whole %dx%dx%d volume, SZ_compress<T> %s abs %g, single thread, %.2f s" % (shape[0], shape[1], shape[2], what, eb, sec),
            "ratio": round(raw / float(len(blob)), 4), "host_cpus": os.cpu_count()}
@@ -260,7 +272,8 @@ def main():
 
     S = args.size
     shape = tuple(int(v) for v in args.shape.split(",")) if args.shape else (S, S, S)
-    w = Workload(torch, sz3_amd, dev, local_rank, rank, shape, args.dtype, args.algo, args.eb, comm=comm, dist=dist if world > 1 else None)
+    w = Workload(torch, sz3_amd, dev, local_rank, rank, shape, args.dtype, args.algo, args.eb, comm=comm, dist=dist if world > 1 else None,
+                 field=args.field)
 
     def barrier():
         if world > 1:
@@ -312,8 +325,8 @@ def main():
                                    % ("C2" if is_c2 else "C3" if is_c3 else "custom",
                                       "float32" if args.dtype == "f32" else "float64", shape[0], shape[1], shape[2],
                                       {"lorenzo": "Lorenzo", "interp": "ALGO_INTERP_LORENZO (auto-tuned interpolation)",
-                                       "interp-notune": "interpolation (ALGO_INTERP)"}[args.algo], args.eb),
-                       "parallelism": "slab%d" % world, "algo": "HIP_LORENZO(16)" if args.algo == "lorenzo" else "HIP_INTERP(17)", "eb": args.eb,
+                                       "interp-notune": "interpolation (ALGO_INTERP)", "composed": "Lorenzo + regression per block"}[args.algo], args.eb),
+                       "parallelism": "slab%d" % world, "algo": "HIP_LORENZO(16)" if args.algo in ("lorenzo", "composed") else "HIP_INTERP(17)", "eb": args.eb,
                        "exchange": exchange},
             "ratio": round(ratio, 4), "max_abs_err": max_err, "err_bound_ok": bool(max_err <= args.eb),
             "payload_bytes_rank0": int(psize),

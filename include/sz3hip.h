@@ -108,6 +108,13 @@ size_t sz3hip_compress(const sz3hip_config *conf, int dataType, const void *data
  * decData must hold conf.num elements (query with sz3hip_peek_config first). Also decodes ALGO_LOSSLESS streams and
  * multi-slab containers (trailer bit openmp; SZ_decompress_OMP, SZImplOMP.hpp:120-186), slab g on GPU g % visible GPUs. */
 int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *cmpData, size_t cmpSize, void *decData);
+/* One algorithm of the reference's dispatcher (SZ_compress_LorenzoReg / SZ_compress_Interp / ..., SZDispatcher.hpp:28-42 and
+ * their SZ_decompress_* counterparts :89-99): only the bytes between the container's 16-byte header and its Config trailer.
+ * compress: returns their number (0 on error); *conf is updated like the reference updates it (absolute bound resolved,
+ * cmprAlgo = id of the stream written: SZ3HIP_ALGO_HIP_LORENZO / _HIP_INTERP, or ALGO_LOSSLESS after a fallback).
+ * These are what include/SZ3/api/impl/SZAlgoHip.hpp binds inside the reference's own header tree. */
+size_t sz3hip_compress_blob(sz3hip_config *conf, int dataType, const void *data, char *blob, size_t cap);
+int sz3hip_decompress_blob(const sz3hip_config *conf, int dataType, const char *blob, size_t size, void *decData);
 /* reads only header + trailer (what SZ_decompress does before dispatching, sz.hpp:119-141) */
 int sz3hip_peek_config(sz3hip_config *conf, const char *cmpData, size_t cmpSize);
 

@@ -782,6 +782,46 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
     return (size_t)(w.p - out);
 }
 
+namespace {
+int decompress_blob(HostSlot *s, const sz3hip_config *conf, int dataType, const unsigned char *p, size_t payload, void *decData);
+}
+// What ONE algorithm of the reference's dispatcher does (SZ_compress_LorenzoReg / SZ_compress_Interp ... and their
+// SZ_decompress_* counterparts, api/impl/SZDispatcher.hpp:28-42, 89-99): the bytes between the 16-byte header and the
+// Config trailer, nothing around them — the entry points include/SZ3/api/impl/SZAlgoHip.hpp binds when the GPU path is
+// added to the reference's own header tree as one more ALGO (tools/sz3/sz3_customized_demo.cpp:8-14).
+extern "C" size_t sz3hip_compress_blob(sz3hip_config *conf, int dataType, const void *data, char *blob, size_t cap) {
+    if (!dtype_ok(dataType)) {
+        fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
+        return 0;
+    }
+    if (conf->N < 1 || conf->N > 4) {
+        fail(SZ3HIP_EINVAL, "Data dimension higher than 4 is not supported.");
+        return 0;
+    }
+    if (zs::load()) return 0;
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    DeviceGuard guard;
+    SlabJob j;
+    job_init(j, *conf, dataType, data, 0);
+    j.slot = get_slot(host_device(), j.cdt, 0);
+    j.out = reinterpret_cast<unsigned char *>(blob);
+    j.out_cap = cap;
+    if (job_upload(j)) return 0;
+    if (!j.lossless && abs_eb_from_range(j.conf, j.cdt, j.mn, j.mx)) return 0;
+    if (job_stage1(j) || job_encode(j)) return 0;
+    *conf = j.conf;  // cmprAlgo = the id of the stream that was written, the bound as resolved (calAbsErrorBound rewrites conf too)
+    return j.out_size;
+}
+extern "C" int sz3hip_decompress_blob(const sz3hip_config *conf, int dataType, const char *blob, size_t size, void *decData) {
+    if (!dtype_ok(dataType))
+        return fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
+    if (zs::load()) return SZ3HIP_EZSTD;
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    DeviceGuard guard;
+    HostSlot *s = get_slot(host_device(), dtype_compute(dataType), 0);
+    return decompress_blob(s, conf, dataType, reinterpret_cast<const unsigned char *>(blob), size, decData);
+}
+
 // one process per GPU: this rank's slab of SZ_compress_OMP, the exchanges through the rank communicator
 extern "C" size_t sz3hip_compress_rank(sz3hip_comm *comm, const sz3hip_config *global_conf, int dataType, const void *slab_data,
                                        char *blob, size_t cap, sz3hip_config *slab_conf) {

@@ -16,7 +16,7 @@ from oracle_binding import ALGO_INTERP, ALGO_INTERP_LORENZO, make_config, ref_co
 shape = tuple(int(v) for v in sys.argv[1].split(","))
 dtype, algo, eb = sys.argv[2], sys.argv[3], float(sys.argv[4])
 a = field3d(shape, np.float32) if dtype == "f32" else field3d(shape, np.float64, sigma=2e-6)
-conf = (make_config(shape, abs_eb=eb, lorenzo=True, regression=False, openmp=True) if algo == "lorenzo" else
+conf = (make_config(shape, abs_eb=eb, lorenzo=True, regression=algo == "composed", openmp=True) if algo in ("lorenzo", "composed") else
         make_config(shape, algo=ALGO_INTERP_LORENZO if algo == "interp" else ALGO_INTERP, abs_eb=eb, regression=True, openmp=True))
 best = 1e30
 for _ in range(2):

@@ -138,6 +138,28 @@ def test_reference_cli_builds_against_our_headers():
     assert "SZ3 Version: 3.3.2" in out
 
 
+def test_extension_recipe_header_builds_inside_the_reference_tree(tmp_path):
+    """include/SZ3/api/impl/SZAlgoHip.hpp is for the REFERENCE's header tree (its own recipe for a new ALGO,
+    tools/sz3/sz3_customized_demo.cpp:8-14): `make -C oracle algohip` applies the three documented edits to scratch copies
+    of the reference's Config.hpp / SZDispatcher.hpp and builds the reference CLI with them -> oracle/_ref/sz3_algohip.
+    Here (no GPU): the binary exists, knows the new algorithm names, and the library under it refuses loudly."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "sz3_algohip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/sz3_algohip not built (needs /root/reference)")
+    assert "SZ3 Version: 3.3.2" in subprocess.run([exe, "-v"], capture_output=True, text=True).stdout
+    a = (np.arange(32 * 32 * 64, dtype=np.float32) * 0.01).reshape(32, 32, 64)  # (the CLI's buffer is 2 x raw: enough only from ~10^4 values on)
+    src = tmp_path / "a.f32"
+    a.tofile(src)
+    ini = tmp_path / "c.ini"
+    ini.write_text("[GlobalSettings]\nCmprAlgo = ALGO_HIP_LORENZO\n")
+    r = subprocess.run([exe, "-f", "-i", str(src), "-z", str(tmp_path / "a.sz"), "-3", "64", "32", "32", "-c", str(ini), "-M", "ABS", "1e-3"],
+                       capture_output=True, text=True, timeout=120)
+    from conftest import gpu_available
+    if not gpu_available():
+        assert r.returncode != 0 and "HIP" in (r.stderr + r.stdout), (r.stdout, r.stderr)  # reached SZ_compress_Hip -> libsz3hip -> no device
+
+
 def test_c_headers_are_plain_c(tmp_path):
     """include/sz3hip.h and include/sz3c.h are the FFI boundary: they must compile as C99 (cgo / JNI / ctypes generators
     read them as C), not only as C++"""

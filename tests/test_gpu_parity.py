@@ -278,6 +278,74 @@ def test_unmodified_reference_cli_runs_on_the_gpu_path(tmp_path):
     assert np.max(np.abs(outi.astype(np.int64) - ai.astype(np.int64))) <= 3
 
 
+def test_reference_tree_with_the_hip_algorithm_added(tmp_path):
+    """oracle/_ref/sz3_algohip: the reference's CLI over the reference's OWN headers with the GPU path added as one more
+    ALGO by the reference's documented recipe (include/SZ3/api/impl/SZAlgoHip.hpp + three edits, oracle/algohip_patch.py).
+    Round trip through the CLI, and the file opens through this repository's faces too (same container, same ids)."""
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "sz3_algohip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/sz3_algohip not built (needs /root/reference at build time)")
+    a = field3d((40, 50, 60))
+    src, cmp_, dec = tmp_path / "a.f32", tmp_path / "a.sz", tmp_path / "a.out"
+    a.tofile(src)
+    for algo_ini, want in (("ALGO_HIP_LORENZO", sz3_amd.ALGO_HIP_LORENZO), ("ALGO_HIP_INTERP", sz3_amd.ALGO_HIP_INTERP)):
+        ini = tmp_path / "c.ini"
+        ini.write_text("[GlobalSettings]\nCmprAlgo = %s\n" % algo_ini)
+        r = subprocess.run([exe, "-f", "-i", str(src), "-z", str(cmp_), "-o", str(dec), "-3", "60", "50", "40", "-c", str(ini),
+                            "-M", "ABS", "1e-3", "-a"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        m = re.search(r"Max absolute error = ([0-9.eE+-]+)", r.stdout)
+        assert m and float(m.group(1)) <= 1e-3, r.stdout
+        out = np.fromfile(dec, dtype=np.float32).reshape(a.shape)
+        assert np.max(np.abs(out.astype(np.float64) - a.astype(np.float64))) <= 1e-3
+        d2, c2 = sz3_amd.decompress(np.fromfile(cmp_, dtype=np.uint8), np.float32, a.shape)
+        assert c2.cmprAlgo == want and np.array_equal(d2, out)
+    # an algorithm of the reference itself still runs on its CPU path in the same binary (the recipe adds, it does not replace)
+    ini.write_text("[GlobalSettings]\nCmprAlgo = ALGO_LORENZO_REG\n")
+    r = subprocess.run([exe, "-f", "-i", str(src), "-z", str(cmp_), "-o", str(dec), "-3", "60", "50", "40", "-c", str(ini), "-M", "ABS", "1e-3", "-a"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and float(re.search(r"Max absolute error = ([0-9.eE+-]+)", r.stdout).group(1)) <= 1e-3
+
+
+def test_c1_through_the_cli_boundary(tmp_path):
+    """BASELINE.json configs[0] (C1): 1-D float32, 2^20 values (the first 2^20 of the C2 field), ALGO_LORENZO_REG, abs 1e-3,
+    "via tools/sz3 CLI". The configuration is about the CLI boundary, so it goes through it three ways:
+      sz3_hip       the unmodified CLI source over THIS repository's headers          -> GPU Lorenzo stream
+      sz3_algohip   the CLI over the reference's tree + SZAlgoHip.hpp, ALGO_HIP_LORENZO -> the same GPU path
+      sz3_algohip   ... with the reference's own ALGO_LORENZO_REG                      -> the reference's CPU path (stock stream)
+    Every reconstruction within the bound, GPU and CPU reconstructions within 2 eb of each other, ratios comparable. (Stock
+    CPU streams are opened by stock SZ3 — or by this very binary; the GPU library has no CPU decoder, by design.)"""
+    import re
+    import subprocess
+    from fields import field1d
+    ref_dir = os.path.join(os.path.dirname(HERE), "oracle", "_ref")
+    exes = {k: os.path.join(ref_dir, k) for k in ("sz3_hip", "sz3_algohip")}
+    if not all(os.path.exists(e) for e in exes.values()):
+        pytest.skip("oracle/_ref CLIs not built (need /root/reference at build time)")
+    a = field1d(1 << 20)
+    src = tmp_path / "c1.f32"
+    a.tofile(src)
+    runs = {}
+    for name, exe, algo in (("ours", "sz3_hip", "ALGO_LORENZO_REG"), ("recipe-gpu", "sz3_algohip", "ALGO_HIP_LORENZO"), ("recipe-cpu", "sz3_algohip", "ALGO_LORENZO_REG")):
+        ini = tmp_path / (name + ".ini")
+        ini.write_text("[GlobalSettings]\nCmprAlgo = %s\n" % algo)
+        cmp_, dec = tmp_path / (name + ".sz"), tmp_path / (name + ".out")
+        r = subprocess.run([exes[exe], "-f", "-i", str(src), "-z", str(cmp_), "-o", str(dec), "-1", str(1 << 20), "-c", str(ini), "-M", "ABS", "1e-3", "-a"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (name, r.stdout, r.stderr)
+        assert float(re.search(r"Max absolute error = ([0-9.eE+-]+)", r.stdout).group(1)) <= 1e-3
+        out = np.fromfile(dec, dtype=np.float32)
+        assert np.max(np.abs(out.astype(np.float64) - a.astype(np.float64))) <= 1e-3
+        runs[name] = (out, a.nbytes / os.path.getsize(cmp_))
+    assert np.array_equal(runs["ours"][0], runs["recipe-gpu"][0])  # the same library under both faces
+    assert np.max(np.abs(runs["ours"][0].astype(np.float64) - runs["recipe-cpu"][0].astype(np.float64))) <= 2e-3
+    assert runs["ours"][1] >= 0.9 * runs["recipe-cpu"][1], {k: v[1] for k, v in runs.items()}
+    with pytest.raises(sz3_amd.SZ3HipError, match="CPU reference"):  # a stock stream is refused by name, not mis-decoded
+        sz3_amd.decompress(np.fromfile(tmp_path / "recipe-cpu.sz", dtype=np.uint8), np.float32, a.shape)
+
+
 def test_full_size_interpolation_properties():
     """C3 at its full size (512^3 f32, ALGO_INTERP_LORENZO = tuner + interpolation, abs 1e-4): strict bound after a device
     round trip, payload determinism, and the tuner's report is the same on every run."""

@@ -239,6 +239,7 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     sz3hip_ctx *c = new sz3hip_ctx();
     memset(c, 0, sizeof(*c));
     c->wide16 = -1;
+    c->narrow_hint = c->cb_hint = -1;
     c->device = device;
     c->dtype = dataType;
     c->max_n = max_elems;
@@ -308,10 +309,14 @@ static uint64_t out_cap_limit(uint64_t n) { return std::max<uint64_t>(1024, n / 
 extern "C" size_t sz3hip_payload_bound_max(const sz3hip_ctx *ctx, uint64_t n) {
     return payload_bound_n(n, std::max<uint64_t>(ctx->out_cap, out_cap_limit(n)));
 }
-extern "C" void *sz3hip_histogram_ptr(sz3hip_ctx *ctx) { return ctx->d_hist; }
+extern "C" void *sz3hip_histogram_ptr(sz3hip_ctx *ctx) {
+    ctx->hist_exposed = true;  // (whoever holds the pointer may change the histogram between the stages)
+    return ctx->d_hist;
+}
 extern "C" size_t sz3hip_histogram_len(const sz3hip_ctx *) { return SZH_HIST_BINS; }
 extern "C" int sz3hip_ctx_set_histogram(sz3hip_ctx *ctx, void *d_hist) {
     ctx->d_hist = d_hist ? (uint64_t *)d_hist : ctx->d_hist_own;
+    ctx->hist_exposed = d_hist != nullptr;
     return 0;
 }
 extern "C" void sz3hip_set_profiling(sz3hip_ctx *ctx, int on) {
@@ -401,6 +406,9 @@ static void cb_params_from(sz3hip_ctx *ctx, szk_cb_params &cb, uint64_t out_cap)
     cb.t_is_32bit = cb.q_is_32bit = ctx->dtype == SZ3HIP_FLOAT;
     cb.info = ctx->d_info;
     cb.n_books = 1;
+    cb.range_ready = ctx->range_ready && !ctx->hist_exposed;
+    cb.part_hint = (szk_dbg_flags & 131072) ? -1 : ctx->cb_hint;
+    cb.mispredict = reinterpret_cast<uint32_t *>(ctx->d_counters + 7);  // (zeroed with the counters)
 }
 
 static int stage1_interp(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint64_t num, hipStream_t s) {
@@ -471,6 +479,8 @@ static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *
     p.mode.allow = allow_narrow && radius >= 128;
     p.mode.pack_wide = allow_narrow ? (uint32_t)ctx->pack_wide : 0u;
     p.wide16 = ctx->wide16 < 0 ? (ctx->dtype == SZ3HIP_DOUBLE ? 1u : 0u) : (uint32_t)ctx->wide16;
+    p.range = reinterpret_cast<uint32_t *>(ctx->d_counters + 8);
+    p.hint_narrow = allow_narrow ? ctx->narrow_hint : -1;
     p.prof_ev0 = p.prof_ev1 = nullptr;
     if (ctx->profiling && allow_narrow) {  // (the production call, not the tuner's trial): events around the kernel itself
         p.prof_ev0 = ctx->ev[ST_K1_KERNEL][0];
@@ -484,6 +494,7 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
     prof_begin(ctx, ST_K1, s);
     int rc = lorenzo_k1(ctx, conf->N, conf->dims, d_in, eb, radius, num, ctx->cur_out_cap, true, p, s);
     ctx->mode = p.mode;
+    ctx->range_ready = p.range_kept != 0;
     prof_end(ctx, ST_K1, s);
     if (rc) return fail(SZ3HIP_EHIP, "lorenzo_quant kernel launch failed (%d)", rc);
     szh_header &h = ctx->proto;
@@ -890,6 +901,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     memset(&ctx->tuner, 0, sizeof(ctx->tuner));
     for (int i = 0; i < ST_COUNT; i++) ctx->ev_used[i] = false;  // stage times describe this call only
     ctx->copy_ahead = false;
+    ctx->range_ready = false;
     if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP_LORENZO) {  // the reference's default: sampling auto-tuner, then one of the two paths
         // The tuner is a chain of small launches and host round trips (the chip is mostly idle), and its outcome is almost
         // always interpolation, which starts from a working copy of the input: make that copy meanwhile on a side stream.
@@ -934,6 +946,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     return stage1_lorenzo(ctx, conf, d_in, eb, radius, num, s);
 }
 
+static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream_t s);
 extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t cap, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
@@ -942,6 +955,15 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     const uint64_t n = ctx->proto.n;
     if (cap < payload_bound_n(n, std::max<uint64_t>(ctx->out_cap, ctx->cur_out_cap)))
         return fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+    ctx->s2_payload = d_payload;
+    ctx->s2_cap = cap;
+    int rc = stage2_launch(ctx, d_payload, cap, s);
+    if (rc) return rc;
+    ctx->stage2_done = true;
+    return 0;
+}
+static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream_t s) {
+    const uint64_t n = ctx->proto.n;
     szk_cb_params cb;
     cb_params_from(ctx, cb, ctx->cur_out_cap);
     prof_begin(ctx, ST_CODEBOOK, s);
@@ -956,11 +978,6 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     lp.state = ctx->d_state;
     lp.side_bytes = ctx->proto.predictor == 2 ? ctx->d_blk_counters + 2 : nullptr;
     prof_end(ctx, ST_CODEBOOK, s);
-    prof_begin(ctx, ST_ENCODE, s);  // (the payload layout is computed inside the encoder's scan launch)
-    rc = szk_launch_encode(ctx->d_codes, n, ctx->d_enc, ctx->d_info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words, ctx->d_chunk_off,
-                           ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, &lp, s);
-    prof_end(ctx, ST_ENCODE, s);
-    if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
     szk_asm_params ap;
     ap.n_vout = ctx->d_counters + 0;
     ap.n_dout = ctx->d_counters + 1;
@@ -977,13 +994,13 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     ap.vout_val = ctx->d_vout_val;
     ap.dout_val = ctx->d_dout_val;
     ap.side = ctx->proto.predictor == 2 ? ctx->d_blk_side : nullptr;
-    prof_begin(ctx, ST_ASSEMBLE, s);
-    rc = szk_launch_assemble(&ap, s);
-    prof_end(ctx, ST_ASSEMBLE, s);
-    if (rc) return fail(SZ3HIP_EHIP, "assemble kernel launch failed (%d)", rc);
+    prof_begin(ctx, ST_ENCODE, s);  // (the payload layout is computed inside the encoder's scan launch, the sections are assembled by the packer's)
+    rc = szk_launch_encode(ctx->d_codes, n, ctx->d_enc, ctx->d_info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words, ctx->d_chunk_off,
+                           ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, &lp, &ap, s);
+    prof_end(ctx, ST_ENCODE, s);
+    if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(szk_state), hipMemcpyDeviceToHost, s));
     // (h_state->probe = the probe counters: |delta| > 127, in [4096, 8192), in [2048, 4096); [4] = interpolation codes beyond +-4096)
-    ctx->stage2_done = true;
     return 0;
 }
 
@@ -992,9 +1009,20 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     HIPCHK(hipSetDevice(ctx->device));
     if (!ctx->stage2_done) return fail(SZ3HIP_EINVAL, "finish called before stage2");
     HIPCHK(hipStreamSynchronize(s));
+    if (ctx->h_state->mispredict) {
+        // the code-book form launched alone met the other form's alphabet (the data changed character since the previous
+        // call): stage 2 once more with both forms; histogram, range words and outlier lists are as stage 1 left them
+        ctx->cb_hint = -1;
+        HIPCHK(hipMemsetAsync(ctx->d_counters + 7, 0, 8, s));
+        int rc2 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s);
+        if (rc2) return rc2;
+        HIPCHK(hipStreamSynchronize(s));
+        if (ctx->h_state->mispredict) return fail(SZ3HIP_EHIP, "code book was not built (both forms declined)");
+    }
     ctx->stage1_done = ctx->stage2_done = false;
     const szk_state &st = *ctx->h_state;
     if (st.hdr.magic != SZH_MAGIC) return fail(SZ3HIP_EHIP, "device did not produce a payload header (kernel fault?)");
+    ctx->cb_hint = st.n_symbols > SZK_CB_SMALL_SYMS ? 1 : 0;
     ctx->stats.n = st.hdr.n;
     ctx->stats.n_value_outliers = st.hdr.n_vout;
     ctx->stats.n_delta_outliers = st.hdr.n_dout;
@@ -1004,6 +1032,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     ctx->stats.max_code_len = st.hdr.max_len;
     ctx->stats.n_symbols = 0;
     ctx->stats.narrow_codes = ctx->mode.allow && (uint64_t)st.probe[0] * 4096ull <= ctx->mode.n_samples;
+    if (st.hdr.predictor == 0 && ctx->mode.allow) ctx->narrow_hint = ctx->stats.narrow_codes ? 1 : 0;
     ctx->stats.reserved = (ctx->wide16 > 0 ? 1u : 0u) | (st.probe[1] << 1);  // (development: window used, far-delta count)
     if (st.hdr.predictor == 1)  // interpolation: second histogram tier of the next call (one workgroup per CU against three)
     {

@@ -48,6 +48,13 @@ struct sz3hip_ctx {
     void *d_work;          // interpolation: the array being overwritten with reconstructed values (lazy);
                            // block-composed predictor: the lattice values q~ the Lorenzo stencils run on
     // block-composed predictor (sz3hip_regress.hip), allocated on first use for the call's block count
+    // what the previous call of this context found, so that this call launches one form of a kernel instead of two
+    int narrow_hint;   // Lorenzo code width: 1 one byte, 0 two bytes, -1 unknown
+    int cb_hint;       // code book form: 0 small alphabets, 1 wide, -1 unknown
+    bool range_ready;  // stage 1 of the pending call kept the alphabet's range words itself
+    bool hist_exposed; // the caller holds a pointer to the histogram (multi-GPU exchange): its range is recomputed in stage 2
+    void *s2_payload;  // stage 2's arguments, kept for the repeat after a mispredicted code-book form
+    size_t s2_cap;
     uint64_t blk_cap;       // blocks the arrays below hold
     uint8_t *d_blk_sel;     // [blk_cap]
     int64_t *d_blk_coef;    // [blk_cap][4] (encode: per block; decode: per regression rank)

@@ -54,6 +54,9 @@ struct szk_k1_params {
     // window cost a global atomic each; when the previous call of the context saw an alphabet wider than the small window the
     // large one pays (C4's f64 slab: 0.6 % of the deltas beyond +-4096, stage 1 0.57 -> 0.36 ms)
     uint32_t wide16;
+    uint32_t *range;   // the alphabet's range words (see hist_add_ranged), updated with the histogram; nullptr: left to k_hist_range
+    int hint_narrow;   // code width of the context's previous call: 1 one byte, 0 two bytes, -1 unknown (both forms are launched)
+    int range_kept;    // out: the launched kernels keep the range words (the register-marching forms do)
 };
 
 struct szk_cb_info {
@@ -78,7 +81,11 @@ struct szk_cb_params {
     szk_cb_info *info;
     uint32_t n_books;  // 0/1: one code book (+ the outlier sorts); 2..SZK_MAX_BOOKS: a batch, tables sliced per book
     uint32_t dbg;      // development switches, filled by the launcher from the debug flags (1: force the one-class fallback)
+    int range_ready;   // the range words are already filled (stage 1 kept them with the histogram): no k_hist_range launch
+    int part_hint;     // -1: both forms of k_codebook are launched; 0 / 1: only that form (small / wide alphabets), see mispredict
+    uint32_t *mispredict;  // set to 1 by a form launched alone that meets the other form's alphabet
 };
+#define SZK_CB_SMALL_SYMS 256  // alphabets up to this size take k_codebook<0>, wider ones <1>
 #define SZK_MAX_BOOKS 4
 #define SZK_MAX_TRIALS 8  // tuner trials of one launch group
 
@@ -86,6 +93,7 @@ struct szk_state {
     szh_header hdr;
     szh_offsets off;
     uint32_t overflow, cap_exceeded;
+    uint32_t mispredict, n_symbols;  // code book: wrong form launched alone (stage 2 is repeated); size of the alphabet
     uint32_t probe[6];  // copy of the probe counters (d_counters + 4): one device-to-host copy brings everything the host reads
 };
 struct szk_layout_params {
@@ -226,7 +234,8 @@ int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, szk_k1
 int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStream_t s);
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
                       szk_mode mode, uint16_t *chunk_words, uint64_t *group_off /*[n_chunks/32 + 1]*/, uint64_t *total_words,
-                      const szk_state *state, uint8_t *payload, const szk_layout_params *layout, hipStream_t s);
+                      const szk_state *state, uint8_t *payload, const szk_layout_params *layout,
+                      const szk_asm_params *asmp /* non-null: the packer's launch also assembles the payload (no szk_launch_assemble) */, hipStream_t s);
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, hipStream_t s);
 int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t *codes, uint64_t *chunk_off,

@@ -538,6 +538,18 @@ __device__ __forceinline__ bool szk_is_narrow(const szk_mode &m) {
     return m.allow && (unsigned long long)(*m.probe_big) * 4096ull <= m.n_samples;
 }
 
+// adds `cnt` to a bin of the global histogram; whoever finds the bin empty also enters it into the alphabet's range words
+// (range[0] = max(65535 - bin), [1] = max bin, [2] = number of non-empty bins): the code book then needs no pass of its own
+// over the 65536 bins (k_hist_range) as long as nobody else touched the histogram
+__device__ __forceinline__ void hist_add_ranged(uint64_t *hist, uint32_t *range, uint32_t sym, unsigned long long cnt) {
+    const unsigned long long old = atomicAdd((unsigned long long *)&hist[sym], cnt);
+    if (old == 0 && range) {
+        atomicMax(&range[0], 0xFFFFu - sym);
+        atomicMax(&range[1], sym);
+        atomicAdd(&range[2], 1u);
+    }
+}
+
 template <typename T, int NDIM>
 __global__ __launch_bounds__(256) void k_probe(const T *__restrict__ in, szk_k1_params p, uint64_t n, uint32_t *probe_big) {
     using Q = typename QTraits<T>::Q;
@@ -625,25 +637,25 @@ __device__ __forceinline__ int64_t dpp_wave_shr1(int64_t old, int64_t src) {
 // is specialised for one-byte / two-byte codes and returns at once when the probe chose the other width; the host launches
 // both. The one-byte specialisation needs a third of the LDS (16 KB histogram, 8 KB outlier queue): 4 waves per SIMD
 // instead of 3.
-template <typename T, int NDIM, int TY, int MODE = 0, bool WIN16 = false>
-__global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict__ in, uint16_t *__restrict__ codes,
-                                                             szk_k1_params p, uint32_t ntasks, uint32_t nrows) {
+// geometry of a form's LDS (shared by the kernel, which declares the arrays, and the body, which indexes them)
+template <int MODE, bool WIN16> struct MarchLds {
+    // MODE 1 (one-byte codes) / MODE 4 (two-byte fallback inside the one-byte launch): HIST_WIN x 4 words, short outlier queues
+    static constexpr int WIDE_WIN = MODE == 4 ? HIST_WIN * 4 : (WIN16 ? 2 * MARCH_WIDE_WIN : MARCH_WIDE_WIN);
+    static constexpr int LH_WORDS = (MODE == 1 || MODE == 4) ? HIST_WIN * 4 : WIDE_WIN;
+    static constexpr int OQ = (MODE == 1 || MODE == 4) ? 128 : MARCH_OQ;
+};
+// MODE 0: code width decided at run time; 1 / 2: one-byte / two-byte specialisation of the two-launch form (returns at once
+// when the probe chose the other width); 4: two-byte codes inside the one-byte form's LDS budget (see k_lorenzo_quant_march3)
+template <typename T, int NDIM, int TY, int MODE, bool WIN16>
+__device__ __forceinline__ void march_body(const T *__restrict__ in, uint16_t *__restrict__ codes, const szk_k1_params &p, uint32_t ntasks,
+                                           uint32_t nrows, uint32_t *lh, uint64_t (*s_oq_idx)[MarchLds<MODE, WIN16>::OQ],
+                                           typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type (*s_oq_val)[MarchLds<MODE, WIN16>::OQ]) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     constexpr int NW = NDIM == 4 ? 2 : 1;
-    constexpr int WIDE_WIN = WIN16 ? 2 * MARCH_WIDE_WIN : MARCH_WIDE_WIN;
-    constexpr int LH_WORDS = MODE == 1 ? HIST_WIN * 4 : WIDE_WIN;
-    constexpr int OQ = MODE == 1 ? 128 : MARCH_OQ;
-    if (MODE != 0 && szk_is_narrow(p.mode) != (MODE == 1)) return;
-    // LDS histogram. One-byte codes (narrow deltas): 1024 bins x 4 copies around the radius; two-byte codes (deltas of
-    // hundreds or thousands of lattice steps, e.g. C4's 1e-6 on f64): MARCH_WIDE_WIN bins x 1 copy — with the narrow window
-    // nearly every element of such a field would fall through to a global atomic. Last word = overflow bin (never flushed).
-    __shared__ uint32_t lh[LH_WORDS + 4];
-    // per-wave staging of value outliers (NaN / Inf / fill values can be percents of a field): records collect in LDS and go
-    // to the global list in batches, one global atomic per batch instead of one per wave instruction
+    constexpr int WIDE_WIN = MarchLds<MODE, WIN16>::WIDE_WIN, LH_WORDS = MarchLds<MODE, WIN16>::LH_WORDS, OQ = MarchLds<MODE, WIN16>::OQ;
+    if ((MODE == 1 || MODE == 2) && szk_is_narrow(p.mode) != (MODE == 1)) return;
     using OQV = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;  // raw bits of a value
-    __shared__ uint64_t s_oq_idx[4][OQ];
-    __shared__ OQV s_oq_val[4][OQ];
 
     const uint32_t d0 = (uint32_t)p.d[3], d1 = (uint32_t)p.d[2], d2 = (uint32_t)p.d[1];
     const uint32_t ntx = (d0 + MARCH_TX - 1) / MARCH_TX, nty = (d1 + TY - 1) / TY, ntz = (d2 + MARCH_TZ - 1) / MARCH_TZ;
@@ -652,7 +664,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     const Lattice<T> lat(p.lat);
     const int radius = (int)p.radius;
     const uint32_t copy = (uint32_t)lane & 3u;
-    const bool narrow = MODE == 1 ? true : (MODE == 2 ? false : szk_is_narrow(p.mode));
+    const bool narrow = MODE == 1 ? true : ((MODE == 2 || MODE == 4) ? false : szk_is_narrow(p.mode));
     const uint32_t win_bins = narrow ? (uint32_t)HIST_WIN : (uint32_t)WIDE_WIN;
     const uint32_t win_lo = (uint32_t)radius - win_bins / 2;
     // in-range test of a delta, one form for both code widths: (delta + rng_lo) <= rng_span (unsigned)
@@ -852,8 +864,8 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
                         if (rare && !in_lds) {
                             // code 0 (delta outliers) is one address for the whole grid: one atomic per wave
                             const unsigned long long zm = __ballot(code[i] == 0);
-                            if (code[i] != 0) atomicAdd((unsigned long long *)&p.hist[code[i]], 1ull);
-                            else if (lane == __ffsll((long long)zm) - 1) atomicAdd((unsigned long long *)&p.hist[0], (unsigned long long)__popcll(zm));
+                            if (code[i] != 0) hist_add_ranged(p.hist, p.range, code[i], 1ull);
+                            else if (lane == __ffsll((long long)zm) - 1) hist_add_ranged(p.hist, p.range, 0u, (unsigned long long)__popcll(zm));
                         }
                     }
                 }
@@ -873,21 +885,53 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
         for (int bnn = threadIdx.x; bnn < WIDE_WIN; bnn += 256) {
             const uint32_t v = lh[bnn];
             const uint32_t sym = win_lo + (uint32_t)bnn;
-            if (v && sym < SZH_HIST_BINS) atomicAdd((unsigned long long *)&p.hist[sym], (unsigned long long)v);
+            if (v && sym < SZH_HIST_BINS) hist_add_ranged(p.hist, p.range, sym, (unsigned long long)v);
         }
     }
+}
+
+// LDS histogram. One-byte codes (narrow deltas): 1024 bins x 4 copies around the radius; two-byte codes (deltas of
+// hundreds or thousands of lattice steps, e.g. C4's 1e-6 on f64): MARCH_WIDE_WIN bins x 1 copy — with the narrow window
+// nearly every element of such a field would fall through to a global atomic. Last word = overflow bin (never flushed).
+// Per-wave staging of value outliers (NaN / Inf / fill values can be percents of a field): records collect in LDS and go
+// to the global list in batches, one global atomic per batch instead of one per wave instruction.
+template <typename T, int NDIM, int TY, int MODE = 0, bool WIN16 = false>
+__global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict__ in, uint16_t *__restrict__ codes,
+                                                             szk_k1_params p, uint32_t ntasks, uint32_t nrows) {
+    using L = MarchLds<MODE, WIN16>;
+    using OQV = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;
+    __shared__ uint32_t lh[L::LH_WORDS + 4];
+    __shared__ uint64_t s_oq_idx[4][L::OQ];
+    __shared__ OQV s_oq_val[4][L::OQ];
+    march_body<T, NDIM, TY, MODE, WIN16>(in, codes, p, ntasks, nrows, lh, s_oq_idx, s_oq_val);
+}
+// Launched ALONE when the context's previous call chose one-byte codes: the one-byte form's LDS budget (4 waves per SIMD) and
+// its specialised code; the width is still decided by THIS call's probe — should it say two bytes after all, the same LDS
+// serves a 4096-bin window (correct, slower: more codes fall through to global atomics) and the next call is launched in
+// the other form. (One kernel with the width as a run-time flag in the inner loop was 14 % slower: 172 vs 151 us at C2.)
+template <typename T, int NDIM, int TY>
+__global__ __launch_bounds__(256) void k_lorenzo_quant_march3(const T *__restrict__ in, uint16_t *__restrict__ codes,
+                                                              szk_k1_params p, uint32_t ntasks, uint32_t nrows) {
+    using L = MarchLds<1, false>;
+    static_assert(L::LH_WORDS == MarchLds<4, false>::LH_WORDS && L::OQ == MarchLds<4, false>::OQ, "both bodies share the arrays");
+    using OQV = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;
+    __shared__ uint32_t lh[L::LH_WORDS + 4];
+    __shared__ uint64_t s_oq_idx[4][L::OQ];
+    __shared__ OQV s_oq_val[4][L::OQ];
+    if (szk_is_narrow(p.mode)) march_body<T, NDIM, TY, 1, false>(in, codes, p, ntasks, nrows, lh, s_oq_idx, s_oq_val);
+    else march_body<T, NDIM, TY, 4, false>(in, codes, p, ntasks, nrows, lh, s_oq_idx, s_oq_val);
 }
 
 // folds the per-workgroup histogram rows into hist[win_lo + bin]: block (bx, by) sums rows by, by + gridDim.y, ... of
 // 256 bins and adds its partial sum with one 64-bit atomic per non-empty bin (at most gridDim.y atomics per address)
 __global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict__ partial, uint32_t nrows, int win_lo,
-                                                     uint64_t *__restrict__ hist) {
+                                                     uint64_t *__restrict__ hist, uint32_t *range) {
     const int bin = blockIdx.x * 256 + threadIdx.x;
     if (bin >= HIST_WIN) return;
     uint64_t s = 0;
     for (uint32_t r = blockIdx.y; r < nrows; r += gridDim.y) s += partial[(uint64_t)r * HIST_WIN + bin];
     const int sym = win_lo + bin;
-    if (s && sym >= 0 && sym < (int)SZH_HIST_BINS) atomicAdd((unsigned long long *)&hist[sym], (unsigned long long)s);
+    if (s && sym >= 0 && sym < (int)SZH_HIST_BINS) hist_add_ranged(hist, range, (uint32_t)sym, (unsigned long long)s);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -903,7 +947,7 @@ __global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict_
 #define CB_THREADS 256       // threads of the small-alphabet path
 #define CB_LAUNCH 1024       // threads per workgroup of the launch
 #define CB_LDS_SYMS 2048     // capacity of the small-alphabet path's LDS arrays
-#define CB_SMALL_SYMS 256    // alphabets up to this size take the small path (serial wave merge: ~0.1 us per symbol);
+#define CB_SMALL_SYMS SZK_CB_SMALL_SYMS    // alphabets up to this size take the small path (serial wave merge: ~0.1 us per symbol);
                              // beyond it the round-parallel merge of the wide path wins (37 us for 2000 symbols)
 #define CB_POOL_BYTES 131072 // LDS pool, carved per phase
 #define CB_SHORT_SYMS 512    // alphabets up to this size are limited to 16-bit code words
@@ -1685,7 +1729,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     const uint32_t t = threadIdx.x;
     if (blockIdx.x >= p.n_books) {  // the two blocks after the code books: deterministic order of the two outlier lists
         // (in the launch whose code-book path is the active one, so that they run beside it)
-        if ((PART == 1) != (p.range[2] > CB_SMALL_SYMS)) return;
+        if ((PART == 1) != (p.range[2] > CB_SMALL_SYMS) && p.part_hint < 0) return;  // (launched alone: sorts whatever the alphabet)
         const bool d = blockIdx.x == p.n_books + 1;
         // scratch: the key tables of the batch slots 1 and 2, idle when a single code book is built (n_books <= 1)
         uint64_t *scratch = p.n_books <= 1 ? p.keys + (size_t)(d ? 2 : 1) * SZH_HIST_BINS : nullptr;
@@ -1711,7 +1755,10 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     }
     // range and number of the non-empty bins: found by k_hist_range (256 workgroups) just before this launch
     const uint32_t n_nonzero = p.range[2];
-    if ((PART == 1) != (n_nonzero > CB_SMALL_SYMS)) return;  // the other launch's case
+    if ((PART == 1) != (n_nonzero > CB_SMALL_SYMS)) {  // the other form's case
+        if (p.part_hint >= 0 && p.mispredict && threadIdx.x == 0) *p.mispredict = 1u;  // launched alone: the host repeats stage 2 with both
+        return;
+    }
     if (n_nonzero == 0) {
         if (t == 0) {
             p.info->n_symbols = 0;
@@ -2241,6 +2288,50 @@ __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE]
     return (total_bits + 31) >> 5;
 }
 
+// header + side sections (lens, chunk table, outliers) into the payload. Everything it reads is final before the packer
+// starts (outlier counts and alphabet since the code book, chunk table and total since the offset scan), so it runs as a few
+// extra workgroups of the packer's launch instead of a launch of its own.
+__device__ void assemble_body(const szk_asm_params &p, uint64_t tid, uint64_t nth) {
+    const szh_header h0 = p.state->hdr;
+    const szh_offsets o = p.state->off;
+    if (tid == 0) {
+        szh_header h = h0;
+        h.bitstream_words = *p.total_words;
+        szh_offsets oo;
+        szh_compute_offsets(h, oo);
+        h.payload_bytes = oo.end;
+        *reinterpret_cast<szh_header *>(p.payload) = h;
+        p.state->hdr = h;
+        p.state->off = oo;
+        p.state->cap_exceeded = oo.end > p.cap;
+        for (int i = 0; i < 6; i++) p.state->probe[i] = reinterpret_cast<const uint32_t *>(p.n_vout + 4)[i];
+        p.state->mispredict = (uint32_t)p.n_vout[7];                                  // (d_counters[7]: raised by a code-book form launched alone)
+        p.state->n_symbols = reinterpret_cast<const uint32_t *>(p.n_vout + 8)[2];   // (the range words: number of non-empty bins)
+        // alignment gaps between the sections are part of the payload: zero them so that it is a pure function of the input
+        const uint64_t tsz0 = h.dtype == 0 ? 4 : 8;
+        for (uint64_t a = oo.lens + h.sym_count; a < oo.chunkwords; a++) p.payload[a] = 0;
+        for (uint64_t a = oo.chunkwords + 2 * h.n_chunks; a < oo.vout_idx; a++) p.payload[a] = 0;
+        for (uint64_t a = oo.vout_val + tsz0 * h.n_vout; a < oo.dout_idx; a++) p.payload[a] = 0;
+        for (uint64_t a = oo.dout_val + (uint64_t)h.qbytes * h.n_dout; a < oo.side; a++) p.payload[a] = 0;
+        for (uint64_t a = oo.side + (h.predictor == 2 ? h.side_bytes : 0); a < oo.bitstream; a++) p.payload[a] = 0;
+    }
+    for (uint64_t i = tid; i < h0.sym_count; i += nth) p.payload[o.lens + i] = p.lens[h0.sym_min + i];
+    uint16_t *cw = reinterpret_cast<uint16_t *>(p.payload + o.chunkwords);
+    for (uint64_t i = tid; i < h0.n_chunks; i += nth) cw[i] = p.chunk_words[i];
+    uint64_t *vi = reinterpret_cast<uint64_t *>(p.payload + o.vout_idx);
+    uint64_t *di = reinterpret_cast<uint64_t *>(p.payload + o.dout_idx);
+    for (uint64_t i = tid; i < h0.n_vout; i += nth) vi[i] = p.vout_idx[i];
+    for (uint64_t i = tid; i < h0.n_dout; i += nth) di[i] = p.dout_idx[i];
+    const uint64_t tsz = h0.dtype == 0 ? 4 : 8, qsz = h0.qbytes;
+    for (uint64_t i = tid; i < h0.n_vout * tsz; i += nth) p.payload[o.vout_val + i] = ((const uint8_t *)p.vout_val)[i];
+    for (uint64_t i = tid; i < h0.n_dout * qsz; i += nth) p.payload[o.dout_val + i] = ((const uint8_t *)p.dout_val)[i];
+    if (h0.predictor == 2 && p.side)
+        for (uint64_t i = tid; i < h0.side_bytes; i += nth) p.payload[o.side + i] = p.side[i];
+}
+__global__ __launch_bounds__(256) void k_assemble(szk_asm_params p) {
+    assemble_body(p, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+}
+
 // persistent like k_chunk_bits2: a wave owns a private LDS stage; per chunk it zeroes the words it will use, packs,
 // and streams them out; the next chunk's codes, word count and group offset are already in flight
 // WIN: symbols of the encode table cached in LDS around the most frequent one: ENC_WIN (30 KB of LDS, 5 workgroups per CU)
@@ -2250,7 +2341,12 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
                                               const uint32_t *__restrict__ g_enc, const szk_cb_info *__restrict__ info,
                                               const uint16_t *__restrict__ chunk_words,
                                               const uint64_t *__restrict__ group_off, szk_mode mode, uint32_t sym_add,
-                                              const szk_state *__restrict__ state, uint8_t *__restrict__ payload) {
+                                              const szk_state *__restrict__ state, uint8_t *__restrict__ payload, szk_asm_params ap,
+                                              uint32_t pack_blocks) {
+    if (blockIdx.x >= pack_blocks) {  // the launch's last workgroups assemble the payload's other sections meanwhile
+        assemble_body(ap, (uint64_t)(blockIdx.x - pack_blocks) * 256 + threadIdx.x, (uint64_t)(gridDim.x - pack_blocks) * 256);
+        return;
+    }
     constexpr int STAGE_WORDS = SZH_CHUNK_SYMS * SZH_MAX_LEN / 32 + 4;  // + slack for the unconditional 3-word emit
     __shared__ uint32_t s_enc[WIN];
     __shared__ uint32_t s_enc8[256];  // one-byte codes: code word by byte value ...
@@ -2258,7 +2354,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     __shared__ uint32_t s_stage[4][STAGE_WORDS];
     const bool narrow = szk_is_narrow(mode);
     const uint64_t n_full = n / SZH_CHUNK_SYMS, n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
-    const uint64_t wave_gid = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE, nwaves = (uint64_t)gridDim.x * 4;
+    const uint64_t wave_gid = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE, nwaves = (uint64_t)pack_blocks * 4;
     const uint64_t lane_off = (uint64_t)lane_id() * ENC_PER_LANE;
     const int lane = lane_id();
     uint32_t *stage = s_stage[threadIdx.x / WAVE];
@@ -2346,44 +2442,6 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         uint32_t *out = out_base + go + before;
         for (uint32_t i = lane; i < nwords; i += WAVE) out[i] = __builtin_bswap32(stage[i]);
     }
-}
-
-// header + side sections (lens, chunk table, outliers) into the payload
-__global__ __launch_bounds__(256) void k_assemble(szk_asm_params p) {
-    const szh_header h0 = p.state->hdr;
-    const szh_offsets o = p.state->off;
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
-    if (tid == 0) {
-        szh_header h = h0;
-        h.bitstream_words = *p.total_words;
-        szh_offsets oo;
-        szh_compute_offsets(h, oo);
-        h.payload_bytes = oo.end;
-        *reinterpret_cast<szh_header *>(p.payload) = h;
-        p.state->hdr = h;
-        p.state->off = oo;
-        p.state->cap_exceeded = oo.end > p.cap;
-        for (int i = 0; i < 6; i++) p.state->probe[i] = reinterpret_cast<const uint32_t *>(p.n_vout + 4)[i];
-        // alignment gaps between the sections are part of the payload: zero them so that it is a pure function of the input
-        const uint64_t tsz0 = h.dtype == 0 ? 4 : 8;
-        for (uint64_t a = oo.lens + h.sym_count; a < oo.chunkwords; a++) p.payload[a] = 0;
-        for (uint64_t a = oo.chunkwords + 2 * h.n_chunks; a < oo.vout_idx; a++) p.payload[a] = 0;
-        for (uint64_t a = oo.vout_val + tsz0 * h.n_vout; a < oo.dout_idx; a++) p.payload[a] = 0;
-        for (uint64_t a = oo.dout_val + (uint64_t)h.qbytes * h.n_dout; a < oo.side; a++) p.payload[a] = 0;
-        for (uint64_t a = oo.side + (h.predictor == 2 ? h.side_bytes : 0); a < oo.bitstream; a++) p.payload[a] = 0;
-    }
-    for (uint64_t i = tid; i < h0.sym_count; i += nth) p.payload[o.lens + i] = p.lens[h0.sym_min + i];
-    uint16_t *cw = reinterpret_cast<uint16_t *>(p.payload + o.chunkwords);
-    for (uint64_t i = tid; i < h0.n_chunks; i += nth) cw[i] = p.chunk_words[i];
-    uint64_t *vi = reinterpret_cast<uint64_t *>(p.payload + o.vout_idx);
-    uint64_t *di = reinterpret_cast<uint64_t *>(p.payload + o.dout_idx);
-    for (uint64_t i = tid; i < h0.n_vout; i += nth) vi[i] = p.vout_idx[i];
-    for (uint64_t i = tid; i < h0.n_dout; i += nth) di[i] = p.dout_idx[i];
-    const uint64_t tsz = h0.dtype == 0 ? 4 : 8, qsz = h0.qbytes;
-    for (uint64_t i = tid; i < h0.n_vout * tsz; i += nth) p.payload[o.vout_val + i] = ((const uint8_t *)p.vout_val)[i];
-    for (uint64_t i = tid; i < h0.n_dout * qsz; i += nth) p.payload[o.dout_val + i] = ((const uint8_t *)p.dout_val)[i];
-    if (h0.predictor == 2 && p.side)
-        for (uint64_t i = tid; i < h0.side_bytes; i += nth) p.payload[o.side + i] = p.side[i];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2477,13 +2535,24 @@ __device__ __forceinline__ QO dec_dout(const szk_dec_params &p, uint64_t elem) {
     return lo < p.n_dout && p.dout_idx[lo] == elem ? reinterpret_cast<const QO *>(p.dout_val)[lo] : (QO)0;
 }
 // QB: 0 = u16 codes out; 4 / 8 = fused Lorenzo x-scan, int32 / int64 lattice values out (see szk_dec_params::scan_row)
-template <int QB>
+// RING: the lanes' stream words come through LDS. A lane decodes its own chunk, so a wave's loads touch 64 different cache
+// lines per instruction, eight times per line (16 bytes a round): 0.25 of the 0.42 ms of the plain form at C2. Here eight
+// lanes fetch one 128-byte line together for the lane that runs low (its rank among the needy lanes picks the group; the
+// line's address travels through a small LDS mailbox), into that lane's private two-line ring; a line is touched once.
+// RING = words per line of the ring (0: off; 32: whole 128-byte lines, 8 lanes per line, 70 KB of LDS; 16: half lines, 4 lanes
+// per line, 37 KB: two workgroups per CU).
+template <int QB, int RING = 0>
 __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payload, szk_dec_params p,
                                                 uint16_t *__restrict__ codes) {
     using QO = typename std::conditional<QB == 8, int64_t, int32_t>::type;
+    constexpr uint32_t SORTED_LDS = RING ? 2048u : DEC_SORTED_LDS;
+    constexpr uint32_t RL = RING ? RING : 32, RSTRIDE = 2 * RL + 4;  // words per lane: two lines + padding (16-byte aligned rows)
+    constexpr uint32_t LPL = RL / 4;                                   // lanes that fetch one line together (16 bytes each)
     __shared__ uint32_t s_first_code[SZH_MAX_LEN + 2], s_first_rank[SZH_MAX_LEN + 2], s_upper[SZH_MAX_LEN + 2];
     __shared__ uint32_t s_lut[1u << DEC_LUT_BITS];
-    __shared__ uint16_t s_sorted[DEC_SORTED_LDS];
+    __shared__ uint16_t s_sorted[SORTED_LDS];
+    __shared__ __align__(16) uint32_t s_ring[RING ? 256 * RSTRIDE : 4];
+    __shared__ uint32_t s_mail[RING ? 4 * 16 * 2 : 2];
     const uint32_t max_len = p.tables->max_len, K = p.tables->lut_bits, n_coded = p.tables->n_coded;
     if (threadIdx.x <= SZH_MAX_LEN + 1) {
         const uint32_t l = threadIdx.x;
@@ -2497,12 +2566,16 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     for (uint32_t e = threadIdx.x; e < (1u << K); e += 256) s_lut[e] = p.tables->lut[e];
     const uint16_t *sorted = p.tables->sorted_syms;
     const uint32_t base_rank = K < max_len ? p.tables->first_rank[K + 1] : n_coded;
-    for (uint32_t e = threadIdx.x; e < DEC_SORTED_LDS && base_rank + e < n_coded; e += 256) s_sorted[e] = sorted[base_rank + e];
+    for (uint32_t e = threadIdx.x; e < SORTED_LDS && base_rank + e < n_coded; e += 256) s_sorted[e] = sorted[base_rank + e];
     __syncthreads();
-    const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (chunk >= p.n_chunks) return;
+    uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool chunk_live = chunk < p.n_chunks;
+    if (!chunk_live) {
+        if (!RING || max_len == 0) return;
+        chunk = p.n_chunks - 1;  // (stays for the wave's cooperative loads; decodes the last chunk again, stores nothing)
+    }
     const uint64_t s0 = chunk * SZH_CHUNK_SYMS;
-    const uint32_t nsym = (uint32_t)((p.n - s0 < SZH_CHUNK_SYMS) ? (p.n - s0) : SZH_CHUNK_SYMS);
+    const uint32_t nsym = !chunk_live ? 0u : (uint32_t)((p.n - s0 < SZH_CHUNK_SYMS) ? (p.n - s0) : SZH_CHUNK_SYMS);
     uint16_t *out = codes + s0;
     QO *qout = QB ? reinterpret_cast<QO *>(p.q_out) + s0 : nullptr;
     // symbols left in the current row (the chunk may start inside a row); the running sum restarts at every row start
@@ -2536,7 +2609,50 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     uint64_t buf = 0;  // next bits at the MSB end
     int have = 0;
     uint32_t wi = 0;
-    for (uint32_t i0 = 0; i0 < nsym; i0 += 16) {
+    // ring state: lines [.., buf_line) of the stream section are in this lane's ring (line = RL words, slot = line & 1)
+    uint64_t buf_line = woff / RL;
+    uint32_t *ring = s_ring + (RING ? threadIdx.x * RSTRIDE : 0);
+    uint32_t *mail = s_mail + (RING ? (threadIdx.x / WAVE) * 32 : 0);
+    constexpr uint32_t BATCH = WAVE / LPL;  // lines one cooperative load instruction brings in
+    const uint32_t nrounds = RING ? (SZH_CHUNK_SYMS / 16) : (nsym + 15) / 16;  // (RING: every lane of the wave walks all rounds)
+    for (uint32_t rnd = 0; rnd < nrounds; rnd++) {
+        const uint32_t i0 = rnd * 16;
+        if (RING) {
+            // a round consumes at most 16 x 24 bits = 12 words: whoever has fewer than 13 buffered ahead gets its next line
+            // (then the line two back, whose slot is overwritten, is behind the lane: 13 <= RL)
+            bool need = i0 < nsym && (int64_t)(buf_line * RL) - (int64_t)(woff + wi) < 13;
+            unsigned long long m = __ballot(need);
+            while (m) {
+                const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+                if (need && rank < BATCH) {
+                    mail[rank * 2] = (uint32_t)lane_id();
+                    mail[rank * 2 + 1] = (uint32_t)buf_line;  // (sections of < 2^37 bytes)
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                const uint32_t cnt = (uint32_t)__popcll(m);
+                const uint32_t grp = (uint32_t)lane_id() / LPL, sub = (uint32_t)lane_id() % LPL;
+                if (grp < (cnt < BATCH ? cnt : BATCH)) {
+                    const uint32_t tgt = mail[grp * 2], line = mail[grp * 2 + 1];
+                    uint64_t a = (uint64_t)line * RL + sub * 4;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (a + 3 <= wlast) v = *reinterpret_cast<const uint4 *>(bs + a);  // (the section is 16-byte aligned)
+                    else {
+                        uint32_t t[4];
+                        for (int k = 0; k < 4; k++) t[k] = a + k <= wlast ? bs[a + k] : 0u;
+                        v = make_uint4(t[0], t[1], t[2], t[3]);
+                    }
+                    *reinterpret_cast<uint4 *>(s_ring + ((threadIdx.x & ~63u) + tgt) * RSTRIDE + (line & 1u) * RL + sub * 4) = v;
+                }
+                if (need && rank < BATCH) {
+                    buf_line++;
+                    need = (int64_t)(buf_line * RL) - (int64_t)(woff + wi) < 13;  // (the first fill takes two lines)
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                m = __ballot(need);
+            }
+        }
         // the next four stream words of this lane, fetched once per 16 symbols with one wait (a load issued inside the
         // divergent refill branch would be waited for at every symbol); typical groups consume 2-3 words, longer ones
         // fall back to single loads
@@ -2544,7 +2660,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint64_t a = woff + wi + k;
-            qw[k] = __builtin_bswap32(bs[a < wlast ? a : wlast]);
+            qw[k] = RING ? __builtin_bswap32(ring[(uint32_t)(a & (2 * RL - 1))]) : __builtin_bswap32(bs[a < wlast ? a : wlast]);
         }
         uint32_t qn = 0;
         uint32_t packed[8];
@@ -2558,7 +2674,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                     wd = qn == 0 ? qw[0] : (qn == 1 ? qw[1] : (qn == 2 ? qw[2] : qw[3]));
                 } else {
                     const uint64_t a = woff + wi;
-                    wd = __builtin_bswap32(bs[a < wlast ? a : wlast]);
+                    wd = RING ? __builtin_bswap32(ring[(uint32_t)(a & (2 * RL - 1))]) : __builtin_bswap32(bs[a < wlast ? a : wlast]);
                 }
                 wd = wi < nwords ? wd : 0u;
                 qn++;
@@ -2581,7 +2697,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                 uint32_t rank = s_first_rank[l] + ((v >> (32 - l)) - s_first_code[l]);
                 rank = rank < n_coded ? rank : n_coded - 1;  // (corrupt streams must not read out of bounds)
                 const uint32_t rr = rank - base_rank;
-                sym = rr < DEC_SORTED_LDS ? (uint32_t)s_sorted[rr] : (uint32_t)sorted[rank];
+                sym = rr < SORTED_LDS ? (uint32_t)s_sorted[rr] : (uint32_t)sorted[rank];
             }
             buf <<= l;
             have -= (int)l;
@@ -2628,7 +2744,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                 if (i0 + k < nsym) out[i0 + k] = (uint16_t)((k & 1) ? (packed[k >> 1] >> 16) : (packed[k >> 1] & 0xFFFF));
         }
     }
-    if (QB && p.carry) reinterpret_cast<QO *>(p.carry)[chunk] = acc;
+    if (QB && p.carry && chunk_live) reinterpret_cast<QO *>(p.carry)[chunk] = acc;
 }
 
 // adds the running sum the previous chunk ended with to the head of every chunk that starts inside a row (rows of at most
@@ -2961,8 +3077,18 @@ template <typename T, int NDIM, int TY, bool WIN16>
 static void launch_march_w(const void *d_in, uint16_t *codes, const szk_k1_params &p, uint64_t nb, hipStream_t s) {
     uint32_t grid;
     if (p.prof_ev0) (void)hipEventRecord((hipEvent_t)p.prof_ev0, s);
-    if (p.mode.allow && !(szk_dbg_flags & 256)) {
-        // each specialisation gets the grid its own occupancy allows (all workgroups resident: the tasks are dealt by stride;
+    if (p.mode.allow && !(szk_dbg_flags & 256) && p.hint_narrow >= 0 && !(szk_dbg_flags & 131072)) {
+        // the context knows which code width its previous call took: one launch in the form that suits it (both forms decide
+        // the width from THIS call's probe and handle either)
+        if (p.hint_narrow) {
+            grid = k1_grid((const void *)k_lorenzo_quant_march3<T, NDIM, TY>, (nb + 3) / 4);
+            hipLaunchKernelGGL((k_lorenzo_quant_march3<T, NDIM, TY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
+        } else {
+            grid = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 0, WIN16>, (nb + 3) / 4);
+            hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 0, WIN16>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
+        }
+    } else if (p.mode.allow && !(szk_dbg_flags & 256)) {
+        // (first call of a context) each specialisation gets the grid its own occupancy allows (all workgroups resident: the tasks are dealt by stride;
         // the two-byte kernel holds 38-72 KB of LDS); the fold reads the larger number of rows, the two-byte kernel leaves
         // them all empty
         const uint32_t g1 = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 1, false>, (nb + 3) / 4);
@@ -2975,7 +3101,7 @@ static void launch_march_w(const void *d_in, uint16_t *codes, const szk_k1_param
         hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 0, WIN16>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
     }
     if (p.prof_ev1) (void)hipEventRecord((hipEvent_t)p.prof_ev1, s);
-    hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+    hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist, p.range);
 }
 // the marching kernel + histogram fold. When one-byte codes are possible both specialisations are launched (the one the
 // probe did not choose returns at once); the two-byte one with the LDS window the context asks for (szk_k1_params::wide16)
@@ -3002,6 +3128,8 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
     const bool march12 = !szk_force_generic && !(szk_dbg_flags & 32) && (ndim == 1 || ndim == 2) && d0 % 4 == 0 && d0 >= 128 &&
                          d0 < (1ull << 31) && d1 < (1ull << 31) && tiles(MARCH_TX, ndim == 1 ? 1 : MTY, MARCH_TZ) < (1ull << 31);
     if (!march && !march12) p.mode.allow = 0;
+    p.range_kept = (march || march12) && p.range ? 1 : 0;
+    if (!p.range_kept) p.range = nullptr;
     switch (ndim) {
         case 1:
             if (march12) {
@@ -3045,7 +3173,7 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
                 nb = tiles(64, 8, FTZ);
                 const uint32_t grid = k1_grid((const void *)k_lorenzo_quant_v4<T, 3, FTZ>, nb);
                 hipLaunchKernelGGL((k_lorenzo_quant_v4<T, 3, FTZ>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
-                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist, (uint32_t *)nullptr);
                 break;
             }
             nb = tiles(64, 8, 8);
@@ -3066,7 +3194,7 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
                 nb = tiles(64, 8, FTZ);
                 const uint32_t grid = k1_grid((const void *)k_lorenzo_quant_v4<T, 4, FTZ>, nb);
                 hipLaunchKernelGGL((k_lorenzo_quant_v4<T, 4, FTZ>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
-                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
+                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist, (uint32_t *)nullptr);
                 break;
             }
             nb = tiles(64, 8, 4);
@@ -3093,15 +3221,17 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
         hipError_t e = hipMemsetAsync(q.range, 0, 16 * nb, s);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256, nb), dim3(256), 0, s, d_hist, q.range);
-    hipLaunchKernelGGL(k_codebook<0>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
-    hipLaunchKernelGGL(k_codebook<1>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
+    if (!p->range_ready) hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256, nb), dim3(256), 0, s, d_hist, q.range);
+    // which of the two forms applies is known on the device only; a context that remembers the previous call's alphabet
+    // launches that form alone (solo): the kernel raises `mispredict` when it is the wrong one and the host repeats stage 2
+    if (p->part_hint != 1) hipLaunchKernelGGL(k_codebook<0>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
+    if (p->part_hint != 0) hipLaunchKernelGGL(k_codebook<1>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
     SZK_CHECK_LAUNCH();
     return 0;
 }
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
                       szk_mode mode, uint16_t *chunk_words, uint64_t *group_off, uint64_t *total_words,
-                      const szk_state *state, uint8_t *payload, const szk_layout_params *layout, hipStream_t s) {
+                      const szk_state *state, uint8_t *payload, const szk_layout_params *layout, const szk_asm_params *asmp, hipStream_t s) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
     const uint64_t nb = (n_chunks + 3) / 4;
     if (nb > 0x7FFFFFFFull) return -1;
@@ -3109,12 +3239,16 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
     const uint32_t pgrid = (uint32_t)(nb < 2048 ? nb : 2048);  // persistent: 8 workgroups per CU
     hipLaunchKernelGGL(k_chunk_bits2, dim3(pgrid), dim3(256), 0, s, codes, n, d_enc, info, mode, sym_add, chunk_words);
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, chunk_words, n_chunks, group_off, total_words, *layout, 1);
-    if (mode.pack_wide)
-        hipLaunchKernelGGL((k_pack<2 * ENC_WIN>), dim3(pgrid < 768 ? pgrid : 768), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
-                           sym_add, state, payload);
-    else
-        hipLaunchKernelGGL((k_pack<ENC_WIN>), dim3(pgrid < 1280 ? pgrid : 1280), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
-                           sym_add, state, payload);
+    constexpr uint32_t ASM_BLOCKS = 32;
+    if (mode.pack_wide) {
+        const uint32_t pb = pgrid < 768 ? pgrid : 768;
+        hipLaunchKernelGGL((k_pack<2 * ENC_WIN>), dim3(pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
+                           sym_add, state, payload, asmp ? *asmp : szk_asm_params{}, pb);
+    } else {
+        const uint32_t pb = pgrid < 1280 ? pgrid : 1280;
+        hipLaunchKernelGGL((k_pack<ENC_WIN>), dim3(pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
+                           sym_add, state, payload, asmp ? *asmp : szk_asm_params{}, pb);
+    }
     SZK_CHECK_LAUNCH();
     return 0;
 }
@@ -3135,9 +3269,18 @@ int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t 
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, p->chunk_words, p->n_chunks, chunk_off, total_words, no_layout, 0);  // chunk_off = p->group_off
     const uint64_t nb = (p->n_chunks + 255) / 256;
     if (nb > 0x7FFFFFFFull) return -1;
-    if (!p->scan_row) hipLaunchKernelGGL(k_decode<0>, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
-    else if (p->q_bytes == 8) hipLaunchKernelGGL(k_decode<8>, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
-    else hipLaunchKernelGGL(k_decode<4>, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
+    // (development switches 32768 / 65536: stream words through the LDS ring with 32- / 16-word lines)
+    const int ring = (szk_dbg_flags & 32768) ? 32 : ((szk_dbg_flags & 65536) ? 16 : 0);
+#define SZK_DEC(QB)                                                                                                          \
+    do {                                                                                                                     \
+        if (ring == 32) hipLaunchKernelGGL((k_decode<QB, 32>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);      \
+        else if (ring == 16) hipLaunchKernelGGL((k_decode<QB, 16>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes); \
+        else hipLaunchKernelGGL((k_decode<QB, 0>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);                  \
+    } while (0)
+    if (!p->scan_row) SZK_DEC(0);
+    else if (p->q_bytes == 8) SZK_DEC(8);
+    else SZK_DEC(4);
+#undef SZK_DEC
     if (p->scan_row && p->carry) {
         const uint64_t cb = (p->n_chunks + 3) / 4;
         if (p->q_bytes == 8)

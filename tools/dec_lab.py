@@ -8,7 +8,9 @@ from fields import field3d
 S = int(os.environ.get("LAB_SIZE", "512")); eb = float(os.environ.get("LAB_EB", "1e-3"))
 algo = {"interp": sz3_amd.ALGO_INTERP, "lorenzo": sz3_amd.ALGO_LORENZO_REG}[os.environ.get("LAB_ALGO", "lorenzo")]
 a = field3d((S, S, S)); dev = torch.device("cuda:0"); d_in = torch.from_numpy(a).to(dev)
-conf = sz3_amd.Config(S, S, S); conf.cmprAlgo = algo; conf.absErrorBound = eb
+conf = sz3_amd.Config(S, S, S); conf.cmprAlgo = algo; conf.absErrorBound = eb; conf.regression = 0
+if os.environ.get("LAB_FLAGS"):
+    sz3_amd.lib().sz3hip_debug_flags(int(os.environ["LAB_FLAGS"]))
 dc = sz3_amd.DeviceCompressor(a.size, np.float32); cap = dc.payload_bound(a.size)
 pl = torch.empty(cap, dtype=torch.uint8, device=dev); out = torch.empty_like(d_in)
 n = dc.compress(conf, d_in.data_ptr(), pl.data_ptr(), cap, 0)

@@ -1236,12 +1236,13 @@ __device__ void cb_merge_wave32(const uint64_t *keys, uint32_t *nfq, uint16_t *p
     uint32_t lreg = lane < m ? (uint32_t)(keys[lane] >> 16) : INF;
     uint32_t nreg = INF;
     uint32_t lpar = 0, npar = 0;  // parents of the window entries
+    // the two queue heads live in scalar registers: a pick compares them there and re-reads only the queue it consumed
+    // (one v_readlane per pick instead of two, no vector compare on the critical path)
+    uint32_t lf = (uint32_t)__builtin_amdgcn_readlane((int)lreg, 0), nf = INF;
     for (uint32_t k = 0; k + 1 < m; k++) {
         uint32_t f = 0;
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            const uint32_t lf = (uint32_t)__builtin_amdgcn_readlane((int)lreg, (int)(i - ibase));
-            const uint32_t nf = (uint32_t)__builtin_amdgcn_readlane((int)nreg, (int)(j - jbase));
             if (lf <= nf) {
                 f += lf;
                 lpar = lane == i - ibase ? k : lpar;
@@ -1251,6 +1252,7 @@ __device__ void cb_merge_wave32(const uint64_t *keys, uint32_t *nfq, uint16_t *p
                     ibase = i;
                     lreg = ibase + lane < m ? (uint32_t)(keys[ibase + lane] >> 16) : INF;
                 }
+                lf = (uint32_t)__builtin_amdgcn_readlane((int)lreg, (int)(i - ibase));
             } else {
                 f += nf;
                 npar = lane == j - jbase ? k : npar;
@@ -1260,10 +1262,12 @@ __device__ void cb_merge_wave32(const uint64_t *keys, uint32_t *nfq, uint16_t *p
                     jbase = j;
                     nreg = jbase + lane < k ? nfq[jbase + lane] : INF;
                 }
+                nf = (uint32_t)__builtin_amdgcn_readlane((int)nreg, (int)(j - jbase));  // (INF when the queue ran empty: j == k)
             }
         }
         if (k - jbase < WAVE) nreg = (lane == k - jbase) ? f : nreg;
         else if (lane == 0) nfq[k] = f;
+        if (j == k) nf = f;  // the queue was empty: the new node is its head
     }
     if (ibase + lane < i) pleaf[ibase + lane] = (uint16_t)lpar;
     if (jbase + lane < j) pint[jbase + lane] = (uint16_t)npar;
@@ -1277,8 +1281,8 @@ __device__ void cb_merge_wave32(const uint64_t *keys, uint32_t *nfq, uint16_t *p
 // INLDS: 32-bit frequencies in LDS (lf32 leaves, nf32 internals); else 64-bit in global memory (keys, ifreq).
 template <bool INLDS>
 __device__ void cb_merge_rounds(const uint64_t *keys, uint64_t *ifreq, const uint32_t *lf32, uint32_t *nf32,
-                                uint16_t *pleaf, uint16_t *pint, uint32_t m, uint32_t *s_red /* [4], zeroed */) {
-    const uint32_t t = threadIdx.x, NT = blockDim.x, lane = lane_id();
+                                uint16_t *pleaf, uint16_t *pint, uint32_t m, uint32_t *s_red /* [4], zeroed */, uint32_t NT /* live threads */) {
+    const uint32_t t = threadIdx.x, lane = lane_id();
     const uint64_t INF = ~0ull;
     auto LF = [&](uint32_t x) -> uint64_t { return INLDS ? (uint64_t)lf32[x] : keys[x] >> 16; };
     auto NF = [&](uint32_t x) -> uint64_t { return INLDS ? (uint64_t)nf32[x] : ifreq[x]; };
@@ -1613,9 +1617,9 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
         uint32_t *lf32 = reinterpret_cast<uint32_t *>(pool), *nf32 = lf32 + LDSQ;
         for (uint32_t q = t; q < mk; q += NT) lf32[q] = (uint32_t)(p.keys[q] >> 16);
         __syncthreads();
-        cb_merge_rounds<true>(p.keys, p.ifreq, lf32, nf32, pleaf, pint, mk, s_misc);
+        cb_merge_rounds<true>(p.keys, p.ifreq, lf32, nf32, pleaf, pint, mk, s_misc, blockDim.x);
     } else {
-        cb_merge_rounds<false>(p.keys, p.ifreq, nullptr, nullptr, pleaf, pint, mk, s_misc);
+        cb_merge_rounds<false>(p.keys, p.ifreq, nullptr, nullptr, pleaf, pint, mk, s_misc, blockDim.x);
     }
     if (t == 0) p.info->ts[4] = wall_clock64();
     // 4. depth of every internal node by pointer doubling (min(depth, 2^rounds) is all the clamp needs); the four
@@ -1855,7 +1859,16 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
         // single symbol: zero-length code, empty bit-stream (as encoder/HuffmanEncoder.hpp:233-237)
     } else {
         // 3. merge: one wave out of registers (32-bit counts), or thread 0 (64-bit counts)
-        if (s_total < 0xFFFFFFFFull) {
+        if (s_total < 0xFFFFFFFFull && (p.dbg & 2u)) {  // (development switch: measured slower, 35 vs 28 us at C2)
+            // round-parallel merge on the 256 live threads (every round pairs ALL pending items below the smallest possible
+            // new node, cb_merge_rounds): ~a dozen rounds for a smooth field's 128 symbols instead of 127 dependent picks of
+            // one wave (28 us of the kernel's 38 at C2)
+            uint32_t *nf32 = reinterpret_cast<uint32_t *>(ifreq), *lf32 = nf32 + CB_LDS_SYMS;
+            for (uint32_t q = t; q < m; q += CB_THREADS) lf32[q] = (uint32_t)(keys[q] >> 16);
+            if (t < 4) s_misc[t] = 0;
+            __syncthreads();
+            cb_merge_rounds<true>(keys, ifreq, lf32, nf32, pleaf, pint, m, s_misc, CB_THREADS);
+        } else if (s_total < 0xFFFFFFFFull) {
             if (t < WAVE) cb_merge_wave32(keys, reinterpret_cast<uint32_t *>(ifreq), pleaf, pint, m);
         } else if (t == 0) {
             cb_merge(keys, ifreq, pleaf, pint, m);
@@ -3216,7 +3229,7 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
     const uint32_t nb = p->n_books ? p->n_books : 1;  // > 1: batch of independent code books (tuner trials), no outlier sort
     szk_cb_params q = *p;
     q.n_books = nb;
-    q.dbg = (szk_dbg_flags & 1024) ? 1u : 0u;
+    q.dbg = ((szk_dbg_flags & 1024) ? 1u : 0u) | ((szk_dbg_flags & 262144) ? 2u : 0u);  // (262144: the small path with the round-parallel merge)
     if (nb > 1) {  // (a single book's range words are zeroed by the caller together with its counters)
         hipError_t e = hipMemsetAsync(q.range, 0, 16 * nb, s);
         if (e != hipSuccess) return (int)e;

@@ -10,7 +10,7 @@ shape = tuple(int(v) for v in os.environ['LAB_SHAPE'].split(',')) if os.environ.
 dt = np.float64 if os.environ.get('LAB_DTYPE') == 'f64' else np.float32
 a = field3d(shape, dt, sigma=2e-6) if dt == np.float64 else field3d(shape); dev = torch.device("cuda:0")
 d_in = torch.from_numpy(a).to(dev)
-conf = sz3_amd.Config(*shape); conf.cmprAlgo = sz3_amd.ALGO_INTERP if os.environ.get('LAB_ALGO') == 'interp' else sz3_amd.ALGO_LORENZO_REG; conf.absErrorBound = float(os.environ.get("LAB_EB", "1e-3"))
+conf = sz3_amd.Config(*shape); conf.cmprAlgo = sz3_amd.ALGO_INTERP if os.environ.get('LAB_ALGO') == 'interp' else sz3_amd.ALGO_LORENZO_REG; conf.absErrorBound = float(os.environ.get("LAB_EB", "1e-3")); conf.regression = 0
 dc = sz3_amd.DeviceCompressor(a.size, dt)
 cap = dc.payload_bound(a.size); pl = torch.empty(cap, dtype=torch.uint8, device=dev)
 for _ in range(3): dc.compress(conf, d_in.data_ptr(), pl.data_ptr(), cap, 0)

@@ -220,6 +220,7 @@ static void ctx_free(sz3hip_ctx *c) {
     if (c->h_passes) (void)hipHostFree(c->h_passes);
     if (c->h_np) (void)hipHostFree(c->h_np);
     if (c->h_blk_side_hdr) (void)hipHostFree(c->h_blk_side_hdr);
+    if (c->h_ovf) (void)hipHostFree(c->h_ovf);
     for (int i = 0; i < ST_COUNT; i++)
         for (int j = 0; j < 2; j++)
             if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
@@ -1148,8 +1149,17 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     HIPCHK(hipSetDevice(ctx->device));
     if (payload_size < sizeof(szh_header)) return fail(SZ3HIP_EFORMAT, "payload shorter than its header");
     szh_header h;
+    uint32_t *ovf = reinterpret_cast<uint32_t *>(ctx->d_counters + 12);  // overflow flag of the half-width chain (see below)
+    if (!ctx->h_ovf) {
+        HIPCHK(hipHostMalloc((void **)&ctx->h_ovf, 8));
+        *ctx->h_ovf = 0;
+        HIPCHK(hipMemsetAsync(ovf, 0, 4, s));
+    }
     HIPCHK(hipMemcpyAsync(&ctx->h_state->hdr, d_payload, sizeof(szh_header), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ctx->h_ovf, ovf, 4, hipMemcpyDeviceToHost, s));  // (the previous call's: rides with the header's round trip)
     HIPCHK(hipStreamSynchronize(s));
+    if (*ctx->h_ovf) ctx->half_skip = 8;  // that stream's values did not fit: the next calls go straight to full width
+    else if (ctx->half_skip > 0) ctx->half_skip--;
     h = ctx->h_state->hdr;
     if (h.magic != SZH_MAGIC || h.version != SZH_VERSION) return fail(SZ3HIP_EFORMAT, "not an SZH1 payload");
     if (h.predictor > 2) return fail(SZ3HIP_EFORMAT, "unknown predictor id %d in the SZH1 header", h.predictor);
@@ -1167,7 +1177,8 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     if (o.end > payload_size || h.payload_bytes != o.end) return fail(SZ3HIP_EFORMAT, "truncated SZH1 payload");
     const uint8_t *pl = (const uint8_t *)d_payload;
     prof_begin(ctx, ST_DEC_HUFF, s);
-    int rc = szk_launch_dec_tables(pl + o.lens, h.sym_min, h.sym_count, ctx->d_tables, s);
+    int rc = szk_launch_dec_tables(pl + o.lens, h.sym_min, h.sym_count, ctx->d_tables, ovf, (const uint16_t *)(pl + o.chunkwords), h.n_chunks,
+                                   ctx->d_chunk_off, ctx->d_counters + 3, s);
     if (rc) return fail(SZ3HIP_EHIP, "dec_tables kernel launch failed (%d)", rc);
     szk_dec_params dp;
     dp.n = h.n;
@@ -1184,13 +1195,34 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     dp.scan_row = fuse_x ? (uint32_t)row : 0u;
     dp.radius = h.radius;
     dp.q_bytes = h.qbytes;
-    dp.reserved = 0;
+    dp.reserved = ((szk_dbg_flags & 524288) ? 1u : 0u) | ((szk_dbg_flags & 1048576) ? 2u : 0u);  // (experiments: no stores / direct stores)
     dp.q_out = d_out;
     dp.dout_idx = reinterpret_cast<const uint64_t *>(pl + o.dout_idx);
     dp.dout_val = pl + o.dout_val;
     dp.n_dout = h.n_dout;
     dp.carry = fuse_x && (SZH_CHUNK_SYMS % row) != 0 ? (void *)ctx->d_codes : nullptr;  // (the code array is idle in this mode)
+    dp.half = 0;
+    dp.ovf = nullptr;
+    dp.gate = nullptr;
+    // Half-width intermediates: the x-scanned lattice differences of a smooth f32 field fit int16, and the strided scans that
+    // follow then move half the bytes (the code array, idle in the fused mode, holds them). The decoder and the scans raise a
+    // flag on a value that does not fit; the full-width chain is enqueued right behind with that flag as its gate (its kernels
+    // return at once while it is clear), so the call stays asynchronous and correct either way.
+    const bool half = fuse_x && !dp.carry && szk_half_scans_ok(&h) && ctx->half_skip == 0 && !(szk_dbg_flags & 2097152);
+    if (half) {
+        dp.half = 1;
+        dp.ovf = ovf;
+        dp.q_out = ctx->d_codes;
+    }
     rc = szk_launch_decode(pl, &dp, ctx->d_codes, ctx->d_chunk_off, ctx->d_counters + 3, s);
+    if (!rc && half) {
+        rc = szk_launch_reconstruct_half(pl, &h, &o, reinterpret_cast<int16_t *>(ctx->d_codes), d_out, ovf, s);
+        dp.half = 0;
+        dp.ovf = nullptr;
+        dp.gate = ovf;
+        dp.q_out = d_out;
+        if (!rc) rc = szk_launch_decode(pl, &dp, ctx->d_codes, ctx->d_chunk_off, ctx->d_counters + 3, s);
+    }
     prof_end(ctx, ST_DEC_HUFF, s);
     if (rc) return fail(SZ3HIP_EHIP, "decode kernel launch failed (%d)", rc);
     prof_begin(ctx, ST_DEC_RECON, s);
@@ -1239,7 +1271,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         memcpy(sc.side_hdr + 24, &bit_words, 8);
         rc = szk_launch_blk_decompress(ctx->dtype, ctx->d_codes, d_out, &bp, &sc, pl, &h, &o, ctx->d_blk_coef, s);
     } else {
-        rc = szk_launch_reconstruct(fuse_x ? 1 : 0, pl, &h, &o, ctx->d_codes, d_out, ctx->d_segtot, s);
+        rc = szk_launch_reconstruct(fuse_x ? 1 : 0, pl, &h, &o, ctx->d_codes, d_out, ctx->d_segtot, s, half ? ovf : nullptr);
     }
     prof_end(ctx, ST_DEC_RECON, s);
     if (rc) return fail(SZ3HIP_EHIP, "reconstruct kernel launch failed (%d)", rc);

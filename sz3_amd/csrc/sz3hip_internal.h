@@ -53,6 +53,8 @@ struct sz3hip_ctx {
     int cb_hint;       // code book form: 0 small alphabets, 1 wide, -1 unknown
     bool range_ready;  // stage 1 of the pending call kept the alphabet's range words itself
     bool hist_exposed; // the caller holds a pointer to the histogram (multi-GPU exchange): its range is recomputed in stage 2
+    int half_skip;     // decoder: calls left before half-width intermediates are tried again (after a call whose values overflowed)
+    uint32_t *h_ovf;   // pinned: the previous decode's overflow flag, fetched with this call's header
     void *s2_payload;  // stage 2's arguments, kept for the repeat after a mispredicted code-book form
     size_t s2_cap;
     uint64_t blk_cap;       // blocks the arrays below hold

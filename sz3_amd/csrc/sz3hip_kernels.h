@@ -144,6 +144,12 @@ struct szk_dec_params {
     const uint64_t *dout_idx;
     const void *dout_val;  // int32 / int64 like q_out
     uint64_t n_dout;
+    // Half-width intermediates (f32 data: q_out is int16, half = 1): the x-scanned lattice differences of smooth fields are
+    // small, and the two strided scans that follow move half the bytes. A value that does not fit raises *ovf; the full-width
+    // chain is enqueued behind the half-width one with gate = ovf: its kernels return at once while the flag is clear.
+    uint32_t half;
+    uint32_t *ovf;         // half: raised on a value outside int16
+    const uint32_t *gate;  // non-null: the kernel runs only when *gate != 0
 };
 
 // ---- block-composed predictor: Lorenzo-1 / Lorenzo-2 / regression per block (sz3hip_regress.hip) ----
@@ -237,12 +243,20 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
                       const szk_state *state, uint8_t *payload, const szk_layout_params *layout,
                       const szk_asm_params *asmp /* non-null: the packer's launch also assembles the payload (no szk_launch_assemble) */, hipStream_t s);
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
-int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, hipStream_t s);
+int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t,
+                          uint32_t *zero_word /* a device word this launch clears (nullptr: none) */,
+                          const uint16_t *chunk_words, uint64_t n_chunks, uint64_t *group_off, uint64_t *total_words /* the decoder's group
+                          offsets, made by a second workgroup of the same launch (chunk_words == nullptr: not made) */, hipStream_t s);
 int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t *codes, uint64_t *chunk_off,
                       uint64_t *total_words, hipStream_t s);
 // x_done: the decoder already produced the x-scanned lattice values in d_out (szk_dec_params::scan_row)
 int szk_launch_reconstruct(int x_done, const uint8_t *payload, const szh_header *h, const szh_offsets *o, const uint16_t *codes,
-                           void *d_out, void *d_segtot, hipStream_t s);
+                           void *d_out, void *d_segtot, hipStream_t s, const uint32_t *gate = nullptr);
+// the strided scans of a Lorenzo stream whose decoder left int16 x-scanned values in d_half (see szk_dec_params::half);
+// szk_half_scans_ok says whether the shape qualifies (f32, even x extent, enough lines for one thread pair per line)
+int szk_half_scans_ok(const szh_header *h);
+int szk_launch_reconstruct_half(const uint8_t *payload, const szh_header *h, const szh_offsets *o, int16_t *d_half, void *d_out, uint32_t *ovf,
+                                hipStream_t s);
 void szk_host_offsets(const szh_header *h, szh_offsets *o);
 extern int szk_force_generic;
 extern int szk_dbg_flags;

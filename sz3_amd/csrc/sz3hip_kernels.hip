@@ -2186,12 +2186,18 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
 // consecutive groups per thread and round. The encoder's call also lays the payload out (layout_pre: the
 // sections' offsets depend on the outlier counts and the alphabet, known since the code book kernel) — one launch less.
 #define SCAN_GPT 4
+__device__ void scan_groups_body(const uint16_t *__restrict__ chunk_words, uint64_t n_chunks, uint64_t *__restrict__ group_off,
+                                 uint64_t *total_words);
 __global__ __launch_bounds__(1024) void k_scan_groups(const uint16_t *__restrict__ chunk_words, uint64_t n_chunks,
                                                       uint64_t *__restrict__ group_off, uint64_t *total_words,
                                                       szk_layout_params lp, int do_layout) {
+    if (do_layout && threadIdx.x == 1023) layout_pre(lp);
+    scan_groups_body(chunk_words, n_chunks, group_off, total_words);
+}
+__device__ void scan_groups_body(const uint16_t *__restrict__ chunk_words, uint64_t n_chunks, uint64_t *__restrict__ group_off,
+                                 uint64_t *total_words) {
     __shared__ uint64_t s_w[16];
     __shared__ uint64_t s_carry;
-    if (do_layout && threadIdx.x == 1023) layout_pre(lp);
     const uint64_t n_groups = (n_chunks + PACK_GROUP - 1) / PACK_GROUP;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
@@ -2464,7 +2470,14 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
 // (len, sym), and a direct lookup table over the next DEC_LUT_BITS bits of the stream: (symbol << 8) | length for every
 // code word of at most DEC_LUT_BITS bits (0 = longer code: length search). One workgroup; <= 65536 symbols.
 __global__ __launch_bounds__(1024) void k_dec_tables(const uint8_t *__restrict__ lens, uint32_t sym_min,
-                                                     uint32_t sym_count, szk_dec_tables *t) {
+                                                     uint32_t sym_count, szk_dec_tables *t, uint32_t *zero_word,
+                                                     const uint16_t *__restrict__ chunk_words, uint64_t n_chunks, uint64_t *group_off,
+                                                     uint64_t *total_words) {
+    if (blockIdx.x == 1) {  // the decoder's other preparation, beside the tables: word offsets of the chunk groups
+        scan_groups_body(chunk_words, n_chunks, group_off, total_words);
+        return;
+    }
+    if (zero_word && threadIdx.x == 0) *zero_word = 0;  // (the decoder's overflow flag of a half-width chain)
     __shared__ uint32_t s_cnt[SZH_MAX_LEN + 2], s_first_code[SZH_MAX_LEN + 2], s_first_rank[SZH_MAX_LEN + 2];
     __shared__ uint16_t s_tbl[(SZH_MAX_LEN + 1) * 1024];  // per-(length, thread) counts -> exclusive ranks
     const uint32_t tid = threadIdx.x, lane = lane_id();
@@ -2554,11 +2567,19 @@ __device__ __forceinline__ QO dec_dout(const szk_dec_params &p, uint64_t elem) {
 // line's address travels through a small LDS mailbox), into that lane's private two-line ring; a line is touched once.
 // RING = words per line of the ring (0: off; 32: whole 128-byte lines, 8 lanes per line, 70 KB of LDS; 16: half lines, 4 lanes
 // per line, 37 KB: two workgroups per CU).
-template <int QB, int RING = 0>
+template <int QB, int RING = 0, bool HALF = false>
 __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payload, szk_dec_params p,
                                                 uint16_t *__restrict__ codes) {
     using QO = typename std::conditional<QB == 8, int64_t, int32_t>::type;
-    constexpr uint32_t SORTED_LDS = RING ? 2048u : DEC_SORTED_LDS;
+    if (p.gate && *p.gate == 0) return;  // (the full-width chain behind a half-width one that did not overflow)
+    constexpr uint32_t SORTED_LDS = RING ? 2048u : DEC_SORTED_LDS / 2;
+    // Output through LDS: a lane's 16 values of a round are one 32- / 64- / 128-byte run of ITS chunk, 4 KB from its
+    // neighbour's — stored directly, every store instruction touches 64 cache lines with 16 bytes each (0.23 of the kernel's
+    // 0.5 ms at C2: measured by switching the stores off). Staged in LDS and read back piece-major, NP consecutive lanes
+    // write one chunk's run: 64 / NP whole runs per instruction.
+    constexpr uint32_t NP = QB == 8 ? 8 : ((QB == 4 && !HALF) ? 4 : 2);  // 16-byte pieces per lane and round
+    constexpr uint32_t NR = 8 / NP;                             // rounds collected before a store: one whole 128-byte line per chunk
+    __shared__ uint4 s_out[4][64 * (NP * NR + 1)];
     constexpr uint32_t RL = RING ? RING : 32, RSTRIDE = 2 * RL + 4;  // words per lane: two lines + padding (16-byte aligned rows)
     constexpr uint32_t LPL = RL / 4;                                   // lanes that fetch one line together (16 bytes each)
     __shared__ uint32_t s_first_code[SZH_MAX_LEN + 2], s_first_rank[SZH_MAX_LEN + 2], s_upper[SZH_MAX_LEN + 2];
@@ -2591,6 +2612,29 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     const uint32_t nsym = !chunk_live ? 0u : (uint32_t)((p.n - s0 < SZH_CHUNK_SYMS) ? (p.n - s0) : SZH_CHUNK_SYMS);
     uint16_t *out = codes + s0;
     QO *qout = QB ? reinterpret_cast<QO *>(p.q_out) + s0 : nullptr;
+    // (wave-uniform: all 64 lanes decode full chunks — everywhere but in the array's last wave)
+    const bool coop = !(p.reserved & 2u) && __ballot(chunk_live && nsym == SZH_CHUNK_SYMS) == ~0ull;
+    uint4 *stage = s_out[threadIdx.x / WAVE];
+    constexpr uint32_t ELT = QB ? (HALF ? QB / 2 : QB) : 2;  // bytes per output element
+    uint8_t *wave_out = QB ? reinterpret_cast<uint8_t *>(p.q_out) + (s0 - (uint64_t)lane_id() * SZH_CHUNK_SYMS) * ELT
+                           : reinterpret_cast<uint8_t *>(codes + (s0 - (uint64_t)lane_id() * SZH_CHUNK_SYMS));
+    uint32_t ovf_seen = 0;
+    auto coop_store = [&](const uint4 (&pc)[NP], uint32_t rnd) {  // (a chunk is 64 rounds: a multiple of NR)
+        const uint32_t sub = rnd % NR;
+#pragma unroll
+        for (uint32_t j = 0; j < NP; j++) stage[(uint32_t)lane_id() * (NP * NR + 1) + sub * NP + j] = pc[j];
+        if (sub != NR - 1) return;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const uint32_t i0 = (rnd - sub) * 16;
+#pragma unroll
+        for (uint32_t it = 0; it < NP * NR; it++) {
+            const uint32_t idx = it * 64 + (uint32_t)lane_id(), c = idx / (NP * NR), j = idx % (NP * NR);
+            const uint4 v = stage[c * (NP * NR + 1) + j];
+            *reinterpret_cast<uint4 *>(wave_out + ((uint64_t)c * SZH_CHUNK_SYMS + i0) * ELT + j * 16) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
     // symbols left in the current row (the chunk may start inside a row); the running sum restarts at every row start
     uint32_t left = QB ? p.scan_row - (uint32_t)(s0 % p.scan_row) : 0u;
     QO acc = 0;
@@ -2676,12 +2720,15 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
             qw[k] = RING ? __builtin_bswap32(ring[(uint32_t)(a & (2 * RL - 1))]) : __builtin_bswap32(bs[a < wlast ? a : wlast]);
         }
         uint32_t qn = 0;
-        uint32_t packed[8];
+        uint32_t syms[16];
+        // code books of at most 16-bit words (every alphabet up to 512 symbols): two symbols never need more than the 32 bits
+        // a refill guarantees, so the buffer is looked at before every second symbol only
+        const bool short_words = max_len <= 16;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             uint32_t sym = 0;
             // (symbols past the end of the last chunk decode zero padding: harmless, only the stores are guarded)
-            if (have <= 32) {
+            if (((k & 1) == 0 || !short_words) && have <= 32) {
                 uint32_t wd;
                 if (qn < 4) {
                     wd = qn == 0 ? qw[0] : (qn == 1 ? qw[1] : (qn == 2 ? qw[2] : qw[3]));
@@ -2695,7 +2742,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                 have += 32;
                 wi++;
             }
-            const uint32_t ent = s_lut[(uint32_t)(buf >> (64 - K))];
+            const uint32_t ent = s_lut[(uint32_t)(buf >> 32) >> (32 - K)];
             uint32_t l = ent & 0xFFu;
             sym = ent >> 8;
             if (ent == 0) {  // longer than the table
@@ -2714,24 +2761,78 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
             }
             buf <<= l;
             have -= (int)l;
-            if (k & 1) packed[k >> 1] |= sym << 16;
-            else packed[k >> 1] = sym;
+            syms[k] = sym;
         }
         if (QB) {  // codes -> deltas (0 = delta outlier: looked up) -> running sum, restarted at every row start
             QO qv[16];
+            uint32_t zero_any = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t sym = (k & 1) ? (packed[k >> 1] >> 16) : (packed[k >> 1] & 0xFFFFu);
-                QO d = (QO)((int)sym - (int)p.radius);
-                if (sym == 0) d = i0 + k < nsym ? dec_dout<QO>(p, s0 + i0 + k) : (QO)0;  // delta outlier (rare)
-                acc += d;
-                qv[k] = acc;
-                if (--left == 0) {
+            for (int k = 0; k < 16; k++) zero_any |= syms[k] == 0 ? 1u : 0u;
+            if (!zero_any && left >= 16 && i0 + 16 <= nsym) {
+                // the usual round: no delta outlier among the 16 symbols, no row start inside them
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    acc += (QO)((int)syms[k] - (int)p.radius);
+                    qv[k] = acc;
+                }
+                left -= 16;
+                if (left == 0) {
                     acc = 0;
                     left = p.scan_row;
                 }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t sym = syms[k];
+                    QO d = (QO)((int)sym - (int)p.radius);
+                    if (sym == 0) d = i0 + k < nsym ? dec_dout<QO>(p, s0 + i0 + k) : (QO)0;  // delta outlier (rare)
+                    acc += d;
+                    qv[k] = acc;
+                    if (--left == 0) {
+                        acc = 0;
+                        left = p.scan_row;
+                    }
+                }
             }
-            if (i0 + 16 <= nsym) {
+            if (p.reserved & 1u) {  // (experiment: no output traffic; the sum keeps the work alive)
+                QO sx = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) sx += qv[k];
+                if (sx == (QO)0x7FFFFFF1) qout[i0] = sx;
+            } else if (HALF) {
+                // int16 out: 32 bytes per lane and round; a value that does not fit raises the flag (the full-width chain follows)
+                uint32_t hw[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int32_t a = (int32_t)qv[2 * k], b = (int32_t)qv[2 * k + 1];
+                    ovf_seen |= (uint32_t)(a != (int32_t)(int16_t)a) | (uint32_t)(b != (int32_t)(int16_t)b);
+                    hw[k] = ((uint32_t)a & 0xFFFFu) | ((uint32_t)b << 16);
+                }
+                if (coop) {
+                    uint4 pc[NP];
+                    pc[0] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                    pc[NP > 1 ? 1 : 0] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
+                    coop_store(pc, rnd);
+                } else {
+                    int16_t *ho = reinterpret_cast<int16_t *>(p.q_out) + s0;
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        if (i0 + k < nsym) ho[i0 + k] = (int16_t)qv[k];
+                }
+            } else if (coop) {
+                uint4 pc[NP];
+                if (QB == 4) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pc[k] = make_uint4((uint32_t)qv[4 * k], (uint32_t)qv[4 * k + 1], (uint32_t)qv[4 * k + 2], (uint32_t)qv[4 * k + 3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < (int)NP; k++) {
+                        const unsigned long long a = (unsigned long long)qv[(2 * k) & 15], b = (unsigned long long)qv[(2 * k + 1) & 15];
+                        pc[k] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+                    }
+                }
+                coop_store(pc, rnd);
+            } else if (i0 + 16 <= nsym) {
                 if (QB == 4) {
                     uint4 *o4 = reinterpret_cast<uint4 *>(qout + i0);
 #pragma unroll
@@ -2747,17 +2848,29 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                 for (int k = 0; k < 16; k++)
                     if (i0 + k < nsym) qout[i0 + k] = qv[k];
             }
+        } else if (coop) {
+            uint32_t packed[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) packed[k] = syms[2 * k] | (syms[2 * k + 1] << 16);
+            uint4 pc[NP];
+            pc[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+            pc[NP > 1 ? 1 : 0] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+            coop_store(pc, rnd);
         } else if (i0 + 16 <= nsym) {
+            uint32_t packed[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) packed[k] = syms[2 * k] | (syms[2 * k + 1] << 16);
             uint4 *o4 = reinterpret_cast<uint4 *>(out + i0);
             o4[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
             o4[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                if (i0 + k < nsym) out[i0 + k] = (uint16_t)((k & 1) ? (packed[k >> 1] >> 16) : (packed[k >> 1] & 0xFFFF));
+                if (i0 + k < nsym) out[i0 + k] = (uint16_t)syms[k];
         }
     }
     if (QB && p.carry && chunk_live) reinterpret_cast<QO *>(p.carry)[chunk] = acc;
+    if (HALF && __ballot(ovf_seen != 0) && lane_id() == 0) atomicOr(p.ovf, 1u);
 }
 
 // adds the running sum the previous chunk ended with to the head of every chunk that starts inside a row (rows of at most
@@ -2958,20 +3071,63 @@ __device__ __forceinline__ void scan_strided_body(void *buf, uint64_t L, uint64_
 }
 template <typename Q>
 __global__ __launch_bounds__(256) void k_scan_strided(Q *__restrict__ q, uint64_t L, uint64_t inner, uint64_t nlines, uint32_t S,
-                                                      uint64_t Lseg, const Q *__restrict__ totals) {
+                                                      uint64_t Lseg, const Q *__restrict__ totals, const uint32_t *gate) {
     using T = typename std::conditional<sizeof(Q) == 4, float, double>::type;
+    if (gate && *gate == 0) return;
     scan_strided_body<Q, T, false>(q, L, inner, nlines, S, Lseg, totals, szk_lattice{});
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_scan_strided_dequant(void *buf, uint64_t L, uint64_t inner, uint64_t nlines, uint32_t S, uint64_t Lseg,
-                                                              const typename QTraits<T>::Q *__restrict__ totals, szk_lattice l) {
+                                                              const typename QTraits<T>::Q *__restrict__ totals, szk_lattice l, const uint32_t *gate) {
+    if (gate && *gate == 0) return;
     scan_strided_body<typename QTraits<T>::Q, T, true>(buf, L, inner, nlines, S, Lseg, totals, l);
+}
+// Half-width strided scans (f32 data, int16 storage, see szk_dec_params::half): one thread per PAIR of adjacent lines (two
+// neighbouring x), marching along the axis; sums in int32. DEQ = false: in place, a sum outside int16 raises the flag;
+// DEQ = true (the last axis): int16 in, dequantised float out.
+template <bool DEQ>
+__global__ __launch_bounds__(256) void k_scan_strided_half(const int16_t *__restrict__ in, void *__restrict__ outp, uint64_t L, uint64_t inner,
+                                                           uint64_t nlines, szk_lattice l, uint32_t *ovf) {
+    const Lattice<float> lat(l);
+    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index
+    if (id * 2 >= nlines) return;
+    const uint64_t line = id * 2, outer = line / inner, inn = line % inner;
+    const uint64_t base = outer * L * inner + inn;
+    const uint32_t *pin = reinterpret_cast<const uint32_t *>(in + base);  // (inner is even: a pair is one aligned word)
+    const uint64_t step = inner / 2;                                       // words between consecutive elements of a line
+    int32_t r0 = 0, r1 = 0;
+    uint32_t bad = 0;
+    constexpr int DEPTH = 16;  // loads in flight per thread (half as many threads as the full-width scans: twice their depth)
+    for (uint64_t a = 0; a < L; a += DEPTH) {
+        uint32_t w[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) w[k] = a + k < L ? pin[(a + k) * step] : 0u;
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) {
+            if (a + k >= L) break;
+            r0 += (int32_t)(int16_t)(w[k] & 0xFFFFu);
+            r1 += (int32_t)(int16_t)(w[k] >> 16);
+            if (DEQ) {
+                float2 v = make_float2(lat.dequant(r0), lat.dequant(r1));
+                *reinterpret_cast<float2 *>(reinterpret_cast<float *>(outp) + base + (a + k) * inner) = v;
+            } else {
+                bad |= (uint32_t)(r0 != (int32_t)(int16_t)r0) | (uint32_t)(r1 != (int32_t)(int16_t)r1);
+                reinterpret_cast<uint32_t *>(reinterpret_cast<int16_t *>(outp) + base)[(a + k) * step] = ((uint32_t)r0 & 0xFFFFu) | ((uint32_t)r1 << 16);
+            }
+        }
+    }
+    if (!DEQ && __ballot(bad != 0) && lane_id() == 0) atomicOr(ovf, 1u);
+}
+__global__ __launch_bounds__(256) void k_dequant_half(const int16_t *__restrict__ in, float *__restrict__ out, uint64_t n, szk_lattice l) {
+    const Lattice<float> lat(l);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = lat.dequant((int32_t)in[i]);
 }
 
 // lattice index -> value, in place (Q and T have the same size)
 template <typename T>
-__global__ __launch_bounds__(256) void k_dequant(void *buf, uint64_t n, szk_lattice l) {
+__global__ __launch_bounds__(256) void k_dequant(void *buf, uint64_t n, szk_lattice l, const uint32_t *gate) {
     using Q = typename QTraits<T>::Q;
+    if (gate && *gate == 0) return;
     const Lattice<T> lat(l);
     Q *q = reinterpret_cast<Q *>(buf);
     T *o = reinterpret_cast<T *>(buf);
@@ -3271,15 +3427,19 @@ int szk_launch_assemble(const szk_asm_params *p, hipStream_t s) {
     return 0;
 }
 
-int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, hipStream_t s) {
-    hipLaunchKernelGGL(k_dec_tables, dim3(1), dim3(1024), 0, s, d_lens, sym_min, sym_count, t);
+int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, uint32_t *zero_word,
+                          const uint16_t *chunk_words, uint64_t n_chunks, uint64_t *group_off, uint64_t *total_words, hipStream_t s) {
+    hipLaunchKernelGGL(k_dec_tables, dim3(chunk_words ? 2 : 1), dim3(1024), 0, s, d_lens, sym_min, sym_count, t, zero_word, chunk_words, n_chunks, group_off,
+                       total_words);
     SZK_CHECK_LAUNCH();
     return 0;
 }
 int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t *codes, uint64_t *chunk_off,
                       uint64_t *total_words, hipStream_t s) {
     szk_layout_params no_layout{};
-    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, p->chunk_words, p->n_chunks, chunk_off, total_words, no_layout, 0);  // chunk_off = p->group_off
+    (void)no_layout;  // (the group offsets are made by the second workgroup of the tables' launch: szk_launch_dec_tables)
+    (void)chunk_off;
+    (void)total_words;
     const uint64_t nb = (p->n_chunks + 255) / 256;
     if (nb > 0x7FFFFFFFull) return -1;
     // (development switches 32768 / 65536: stream words through the LDS ring with 32- / 16-word lines)
@@ -3292,6 +3452,7 @@ int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t 
     } while (0)
     if (!p->scan_row) SZK_DEC(0);
     else if (p->q_bytes == 8) SZK_DEC(8);
+    else if (p->half) hipLaunchKernelGGL((k_decode<4, 0, true>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
     else SZK_DEC(4);
 #undef SZK_DEC
     if (p->scan_row && p->carry) {
@@ -3324,7 +3485,7 @@ static int scan_rows(Q *q, uint64_t L, uint64_t nrows, Q *scratch, hipStream_t s
 
 template <typename T>
 static int launch_reconstruct(bool x_done, const uint8_t *payload, const szh_header &h, const szh_offsets &o, const uint16_t *codes,
-                              void *d_out, void *d_segtot, hipStream_t s) {
+                              void *d_out, void *d_segtot, hipStream_t s, const uint32_t *gate) {
     using Q = typename QTraits<T>::Q;
     Q *q = reinterpret_cast<Q *>(d_out);
     const uint64_t n = h.n;
@@ -3371,15 +3532,15 @@ static int launch_reconstruct(bool x_done, const uint8_t *payload, const szh_hea
                                    Lseg, totals);
             if (ax == last_ax)
                 hipLaunchKernelGGL(k_scan_strided_dequant<T>, dim3(grid_for(nlines * S, 256, 0x7FFFFFFF)), dim3(256), 0, s, d_out, La, inner,
-                                   nlines, S, Lseg, (const Q *)totals, szk_make_lattice(h.eb));
+                                   nlines, S, Lseg, (const Q *)totals, szk_make_lattice(h.eb), gate);
             else
                 hipLaunchKernelGGL(k_scan_strided<Q>, dim3(grid_for(nlines * S, 256, 0x7FFFFFFF)), dim3(256), 0, s, q, La, inner, nlines, S, Lseg,
-                                   (const Q *)totals);
+                                   (const Q *)totals, gate);
         }
         inner *= La;
     }
     if (last_ax < 0)
-        hipLaunchKernelGGL(k_dequant<T>, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, d_out, n, szk_make_lattice(h.eb));
+        hipLaunchKernelGGL(k_dequant<T>, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, d_out, n, szk_make_lattice(h.eb), gate);
     if (h.n_vout)
         hipLaunchKernelGGL(k_patch_vout<T>, dim3(grid_for(h.n_vout, 256, 4096)), dim3(256), 0, s, payload, o.vout_idx,
                            o.vout_val, h.n_vout, n, (T *)d_out);
@@ -3403,9 +3564,42 @@ int szk_launch_expand_deltas(int dtype, const uint16_t *codes, uint64_t n, int r
     return 0;
 }
 int szk_launch_reconstruct(int x_done, const uint8_t *payload, const szh_header *h, const szh_offsets *o, const uint16_t *codes,
-                           void *d_out, void *d_segtot, hipStream_t s) {
-    return h->dtype == 0 ? launch_reconstruct<float>(x_done != 0, payload, *h, *o, codes, d_out, d_segtot, s)
-                         : launch_reconstruct<double>(x_done != 0, payload, *h, *o, codes, d_out, d_segtot, s);
+                           void *d_out, void *d_segtot, hipStream_t s, const uint32_t *gate) {
+    return h->dtype == 0 ? launch_reconstruct<float>(x_done != 0, payload, *h, *o, codes, d_out, d_segtot, s, gate)
+                         : launch_reconstruct<double>(x_done != 0, payload, *h, *o, codes, d_out, d_segtot, s, gate);
+}
+// the shape gives every strided axis enough lines for one thread per line pair (no segment totals) and an even x extent
+int szk_half_scans_ok(const szh_header *h) {
+    if (h->dtype != 0 || h->dims[3] % 2) return 0;
+    for (int ax = 2; ax >= 0; ax--)
+        if (h->dims[ax] > 1 && h->n / h->dims[ax] < 32768) return 0;
+    return 1;
+}
+int szk_launch_reconstruct_half(const uint8_t *payload, const szh_header *h, const szh_offsets *o, int16_t *d_half, void *d_out, uint32_t *ovf,
+                                hipStream_t s) {
+    const uint64_t n = h->n;
+    int last_ax = -1;
+    for (int ax = 2; ax >= 0; ax--)
+        if (h->dims[ax] > 1) last_ax = ax;
+    uint64_t inner = h->dims[3];
+    const szk_lattice lat = szk_make_lattice(h->eb);
+    for (int ax = 2; ax >= 0; ax--) {
+        const uint64_t La = h->dims[ax];
+        if (La > 1) {
+            const uint64_t npairs = n / La / 2;
+            if (ax == last_ax)
+                hipLaunchKernelGGL(k_scan_strided_half<true>, dim3(grid_for(npairs, 256, 0x7FFFFFFF)), dim3(256), 0, s, d_half, d_out, La, inner, n / La, lat, ovf);
+            else
+                hipLaunchKernelGGL(k_scan_strided_half<false>, dim3(grid_for(npairs, 256, 0x7FFFFFFF)), dim3(256), 0, s, d_half, (void *)d_half, La, inner,
+                                   n / La, lat, ovf);
+        }
+        inner *= La;
+    }
+    if (last_ax < 0) hipLaunchKernelGGL(k_dequant_half, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, d_half, (float *)d_out, n, lat);
+    (void)payload;
+    (void)o;
+    SZK_CHECK_LAUNCH();
+    return 0;
 }
 
 void szk_host_offsets(const szh_header *h, szh_offsets *o) { szh_compute_offsets(*h, *o); }

@@ -346,6 +346,46 @@ def test_c1_through_the_cli_boundary(tmp_path):
         sz3_amd.decompress(np.fromfile(tmp_path / "recipe-cpu.sz", dtype=np.uint8), np.float32, a.shape)
 
 
+def test_half_width_decoder_intermediates_and_their_overflow_path():
+    """The Lorenzo decoder keeps its x-scanned values and the y-prefixed ones as int16 when they fit (smooth f32 fields) and
+    repeats the chain at full width behind a device-side gate when one does not. A step of 2000 between two planes makes
+    D_z q = 10^6 lattice steps: the first call overflows and takes the gated chain, the following ones go to full width
+    directly (the context fetched the flag with the next header); a smooth field stays on the half-width chain. All exact
+    against each other and within the bound."""
+    dev = torch.device("cuda:0")
+    shape = (64, 128, 256)
+    eb = 1e-3
+    smooth = field3d(shape)
+    step = smooth.copy()
+    step[32:] += 2000.0
+    for a in (smooth, step):
+        t = torch.from_numpy(a).to(dev)
+        dc = sz3_amd.DeviceCompressor(a.size, np.float32)
+        cap = dc.payload_bound(a.size, worst_case=True)
+        pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+        conf = sz3_amd.Config(*shape)
+        conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+        conf.regression = 0
+        conf.absErrorBound = eb
+        n = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+        outs = []
+        for _ in range(3):
+            out = torch.empty_like(t)
+            dc.decompress(pl.data_ptr(), n, out.data_ptr(), 0)
+            torch.cuda.synchronize()
+            outs.append(out.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+        assert float(np.max(np.abs(outs[0].astype(np.float64) - a.astype(np.float64)))) <= eb
+        sz3_amd.lib().sz3hip_debug_flags(2097152)  # full-width chain only
+        try:
+            ref = torch.empty_like(t)
+            dc.decompress(pl.data_ptr(), n, ref.data_ptr(), 0)
+            torch.cuda.synchronize()
+        finally:
+            sz3_amd.lib().sz3hip_debug_flags(0)
+        assert np.array_equal(ref.cpu().numpy(), outs[0])
+
+
 def test_full_size_interpolation_properties():
     """C3 at its full size (512^3 f32, ALGO_INTERP_LORENZO = tuner + interpolation, abs 1e-4): strict bound after a device
     round trip, payload determinism, and the tuner's report is the same on every run."""

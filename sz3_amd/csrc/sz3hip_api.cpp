@@ -520,7 +520,7 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
 // (make_compressor_lorenzo_regression, api/impl/SZAlgoLorenzoReg.hpp:22-64) ----
 static int blk_reserve(sz3hip_ctx *ctx, uint64_t nblocks) {
     if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
-    if (!ctx->d_blk_counters) HIPCHK(hipMalloc((void **)&ctx->d_blk_counters, 64));
+    if (!ctx->d_blk_counters) HIPCHK(hipMalloc((void **)&ctx->d_blk_counters, 64 + 4 * (0x7FFFFFF0ull / 8192 + 2)));
     if (!ctx->h_blk_side_hdr) HIPCHK(hipHostMalloc((void **)&ctx->h_blk_side_hdr, 32));
     if (ctx->blk_cap >= nblocks) return 0;
     void **arr[5] = {(void **)&ctx->d_blk_sel, (void **)&ctx->d_blk_coef, (void **)&ctx->d_blk_rank, (void **)&ctx->d_blk_comp, (void **)&ctx->d_blk_side};
@@ -566,6 +566,7 @@ static void blk_params_from(sz3hip_ctx *ctx, const uint64_t *dims3, uint32_t B, 
     sc.comp = ctx->d_blk_comp;
     sc.counters = ctx->d_blk_counters;
     sc.side = ctx->d_blk_side;
+    sc.run_scratch = reinterpret_cast<uint32_t *>(ctx->d_blk_counters + 8);  // (the counter block holds 8 words + a run table)
 }
 static bool blk_shape_ok(const sz3hip_config *conf) { return conf->N == 3 && conf->blockSize >= 4 && conf->blockSize <= 8; }
 static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint64_t num, uint32_t mask, hipStream_t s) {
@@ -578,6 +579,7 @@ static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
     szk_blk_params bp;
     szk_blk_scratch sc;
     blk_params_from(ctx, conf->dims, B, mask, eb, radius, ctx->cur_out_cap, bp, sc);
+    sc.wide_hist = ctx->blk_wide;
     HIPCHK(hipMemsetAsync(ctx->d_blk_counters, 0, 64, s));
     prof_begin(ctx, ST_K1, s);
     rc = szk_launch_blk_compress(ctx->dtype, d_in, ctx->d_codes, &bp, &sc, s);
@@ -1024,6 +1026,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     const szk_state &st = *ctx->h_state;
     if (st.hdr.magic != SZH_MAGIC) return fail(SZ3HIP_EHIP, "device did not produce a payload header (kernel fault?)");
     ctx->cb_hint = st.n_symbols > SZK_CB_SMALL_SYMS ? 1 : 0;
+    if (st.hdr.predictor == 2) ctx->blk_wide = st.hdr.sym_count > 3000 ? 1 : 0;  // the block kernels' LDS histogram window of the next call
     ctx->stats.n = st.hdr.n;
     ctx->stats.n_value_outliers = st.hdr.n_vout;
     ctx->stats.n_delta_outliers = st.hdr.n_dout;

@@ -57,6 +57,7 @@ struct sz3hip_ctx {
     uint32_t *h_ovf;   // pinned: the previous decode's overflow flag, fetched with this call's header
     void *s2_payload;  // stage 2's arguments, kept for the repeat after a mispredicted code-book form
     size_t s2_cap;
+    int blk_wide;           // block predictor: wide LDS histogram window (from the previous call's alphabet)
     uint64_t blk_cap;       // blocks the arrays below hold
     uint8_t *d_blk_sel;     // [blk_cap]
     int64_t *d_blk_coef;    // [blk_cap][4] (encode: per block; decode: per regression rank)

@@ -173,8 +173,10 @@ struct szk_blk_params {
 };
 struct szk_blk_scratch {
     uint32_t *rank, *comp;  // [blocks] rank among the regression blocks, compacted list of their ids
+    uint32_t *run_scratch;  // [blocks / 8192 + 1] regression blocks per run of 8192 blocks, then the runs' offsets
     uint64_t *counters;     // [8]: [0] regression blocks, [2] side bytes, [3] fit pass's count, [4..7] Rice statistics
     uint8_t *side;          // the side section being built
+    int wide_hist;          // encode: 16384-bin LDS histogram window instead of 4096 (the context's previous alphabet was wide)
     uint8_t side_hdr[32];   // decode: host copy of the side section's header + [24..31] words of its bit section (validated by the caller)
 };
 int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s);

@@ -36,7 +36,8 @@
 
 #define BLK_MAXE 10                               // tile edge: block edge (<= 8) + 2 halo layers
 #define BLK_TILE (BLK_MAXE * BLK_MAXE * BLK_MAXE)  // elements of a wave's tile
-#define BLK_HWIN 4096                             // LDS histogram window (bins around the radius) of a workgroup
+#define BLK_HWIN 4096   // LDS histogram window (bins around the radius) of a workgroup; BLK_HWIN_WIDE when the previous call of the
+#define BLK_HWIN_WIDE 16384  // context saw an alphabet wider than the small one (C4-like fields: deltas of thousands of lattice steps)
 #define BLK_GRID 2048u
 
 #define SZK_CHECK_LAUNCH()                                   \
@@ -76,23 +77,40 @@ __device__ __forceinline__ BlkGeom blk_geom(const szk_blk_params &p, uint32_t ta
     g.coff = (uint64_t)g.oz * p.d[1] * p.d[2] + (uint64_t)g.ez * ((uint64_t)g.oy * p.d[2] + (uint64_t)g.ey * g.ox);
     return g;
 }
+// t-th element of a block in raster order -> (i0, i1, i2). CB != 0: the kernel is compiled for that block edge — whole
+// blocks (all but the array's high faces) then divide by constants (the run-time divisions were most of the block passes'
+// instructions)
+template <int CB>
+__device__ __forceinline__ void own_index(const BlkGeom &g, uint32_t t, uint32_t &i0, uint32_t &i1, uint32_t &i2) {
+    if (CB && g.ex == CB && g.ey == CB) {
+        i2 = t % CB;
+        i1 = (t / CB) % CB;
+        i0 = t / (CB * CB);
+    } else {
+        i2 = t % g.ex;
+        i1 = (t / g.ex) % g.ey;
+        i0 = t / (g.ex * g.ey);
+    }
+}
 // tile coordinate t (E^3, E = B + 2, two halo layers on the low side) <-> array element
 __device__ __forceinline__ uint32_t tile_at(uint32_t E, uint32_t tz, uint32_t ty, uint32_t tx) { return (tz * E + ty) * E + tx; }
 
 // LDS histogram of a workgroup: BLK_HWIN bins around the radius, the rest straight to the global histogram; code 0
 // (one address for the whole grid) is counted per wave
+template <uint32_t HW>
 __device__ __forceinline__ void blk_count(uint32_t *lh, const szk_blk_params &p, uint32_t code, bool active) {
     const unsigned long long zm = __ballot(active && code == 0);
     if (zm && lane_id() == __ffsll((long long)zm) - 1) atomicAdd((unsigned long long *)&p.hist[0], (unsigned long long)__popcll(zm));
     if (!active || code == 0) return;
-    const uint32_t bin = code - (p.radius - BLK_HWIN / 2);
-    if (bin < BLK_HWIN) atomicAdd(&lh[bin], 1u);
+    const uint32_t bin = code - (p.radius - HW / 2);
+    if (bin < HW) atomicAdd(&lh[bin], 1u);
     else atomicAdd((unsigned long long *)&p.hist[code], 1ull);
 }
+template <uint32_t HW>
 __device__ __forceinline__ void blk_flush(const uint32_t *lh, const szk_blk_params &p) {
-    for (uint32_t b = threadIdx.x; b < BLK_HWIN; b += blockDim.x) {
+    for (uint32_t b = threadIdx.x; b < HW; b += blockDim.x) {
         const uint32_t v = lh[b];
-        const uint32_t sym = p.radius - BLK_HWIN / 2 + b;
+        const uint32_t sym = p.radius - HW / 2 + b;
         if (v && sym < SZH_HIST_BINS) atomicAdd((unsigned long long *)&p.hist[sym], (unsigned long long)v);
     }
 }
@@ -153,18 +171,18 @@ __device__ __forceinline__ T reg_predict(const T (&c)[4], uint32_t i0, uint32_t 
 // ------------------------------------------------------------------------------------------------------------
 // encoder pass 1: fit, select, regression blocks coded; q~ of every element written to qwork
 // ------------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, uint32_t HW, int CB>
 __global__ __launch_bounds__(256) void k_blk_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;
-    __shared__ T s_x[4][BLK_TILE];
-    __shared__ uint32_t lh[BLK_HWIN];
-    for (uint32_t b = threadIdx.x; b < BLK_HWIN; b += 256) lh[b] = 0;
+    __shared__ T s_x[4][CB ? (CB + 2) * (CB + 2) * (CB + 2) : BLK_TILE];
+    __shared__ uint32_t lh[HW];
+    for (uint32_t b = threadIdx.x; b < HW; b += 256) lh[b] = 0;
     __syncthreads();
     const Lattice<T> lat(p.lat);
     const int lane = lane_id();
     const uint32_t wv = threadIdx.x / WAVE;
     T *sx = s_x[wv];
-    const uint32_t E = p.B + 2;
+    const uint32_t B = CB ? (uint32_t)CB : p.B, E = B + 2;
     const uint64_t d1 = p.d[1], d2 = p.d[2];
     Q *qwork = reinterpret_cast<Q *>(p.qwork);
     const CoefLat cl = coef_lat(p.eb, p.B);
@@ -197,7 +215,8 @@ __global__ __launch_bounds__(256) void k_blk_fit(const T *__restrict__ in, uint1
         if (r_valid) {
             double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
             for (uint32_t t = lane; t < nown; t += WAVE) {
-                const uint32_t i2 = t % g.ex, i1 = (t / g.ex) % g.ey, i0 = t / (g.ex * g.ey);
+                uint32_t i0, i1, i2;
+            own_index<CB>(g, t, i0, i1, i2);
                 const T v = sx[tile_at(E, i0 + 2, i1 + 2, i2 + 2)];
                 s0 += (double)((T)i0 * v);  // sum[i] += index[i] * (*c): size_t * T is evaluated in T, accumulated in double
                 s1 += (double)((T)i1 * v);
@@ -262,7 +281,8 @@ __global__ __launch_bounds__(256) void k_blk_fit(const T *__restrict__ in, uint1
                 const uint32_t t = t0 + lane;
                 const bool act = t < nown;
                 const uint32_t tt = act ? t : 0;
-                const uint32_t i2 = tt % g.ex, i1 = (tt / g.ex) % g.ey, i0 = tt / (g.ex * g.ey);
+                uint32_t i0, i1, i2;
+            own_index<CB>(g, tt, i0, i1, i2);
                 const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
                 const T raw = sx[tile_at(E, i0 + 2, i1 + 2, i2 + 2)];
                 T v = raw;
@@ -277,7 +297,7 @@ __global__ __launch_bounds__(256) void k_blk_fit(const T *__restrict__ in, uint1
                     codes[g.coff + t] = (uint16_t)code;
                     qwork[gi] = qt;
                 }
-                blk_count(lh, p, (uint32_t)code, act);
+                blk_count<HW>(lh, p, (uint32_t)code, act);
                 blk_vout<T>(p, act && code == 0, gi, raw);  // unpredictable: the raw value, LinearQuantizer.hpp:66-69
             }
             if (lane == 0) {
@@ -289,7 +309,8 @@ __global__ __launch_bounds__(256) void k_blk_fit(const T *__restrict__ in, uint1
                 const uint32_t t = t0 + lane;
                 const bool act = t < nown;
                 const uint32_t tt = act ? t : 0;
-                const uint32_t i2 = tt % g.ex, i1 = (tt / g.ex) % g.ey, i0 = tt / (g.ex * g.ey);
+                uint32_t i0, i1, i2;
+            own_index<CB>(g, tt, i0, i1, i2);
                 const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
                 const T raw = sx[tile_at(E, i0 + 2, i1 + 2, i2 + 2)];
                 bool bad;
@@ -303,24 +324,24 @@ __global__ __launch_bounds__(256) void k_blk_fit(const T *__restrict__ in, uint1
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    blk_flush(lh, p);
+    blk_flush<HW>(lh, p);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // encoder pass 2: Lorenzo blocks — integer stencil over q~ (block + two low halo layers in LDS)
 // ------------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, uint32_t HW, int CB>
 __global__ __launch_bounds__(256) void k_blk_lorenzo(uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
-    __shared__ Q s_q[4][BLK_TILE];
-    __shared__ uint32_t lh[BLK_HWIN];
-    for (uint32_t b = threadIdx.x; b < BLK_HWIN; b += 256) lh[b] = 0;
+    __shared__ Q s_q[4][CB ? (CB + 2) * (CB + 2) * (CB + 2) : BLK_TILE];
+    __shared__ uint32_t lh[HW];
+    for (uint32_t b = threadIdx.x; b < HW; b += 256) lh[b] = 0;
     __syncthreads();
     const int lane = lane_id();
     const uint32_t wv = threadIdx.x / WAVE;
     Q *sq = s_q[wv];
-    const uint32_t E = p.B + 2;
+    const uint32_t B = CB ? (uint32_t)CB : p.B, E = B + 2;
     const uint64_t d1 = p.d[1], d2 = p.d[2];
     const Q *qwork = reinterpret_cast<const Q *>(p.qwork);
     for (uint32_t task = blockIdx.x * 4 + wv; task < nblocks; task += gridDim.x * 4) {
@@ -342,7 +363,8 @@ __global__ __launch_bounds__(256) void k_blk_lorenzo(uint16_t *__restrict__ code
             const uint32_t t = t0 + lane;
             const bool act = t < nown;
             const uint32_t tt = act ? t : 0;
-            const uint32_t i2 = tt % g.ex, i1 = (tt / g.ex) % g.ey, i0 = tt / (g.ex * g.ey);
+            uint32_t i0, i1, i2;
+            own_index<CB>(g, tt, i0, i1, i2);
             const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
             UQ delta = 0;  // wrap-around arithmetic like the plain Lorenzo stream
             for (int k = 0; k <= order; k++)
@@ -354,7 +376,7 @@ __global__ __launch_bounds__(256) void k_blk_lorenzo(uint16_t *__restrict__ code
             const bool inr = (UQ)(delta + (UQ)(p.radius - 1)) <= (UQ)(2 * p.radius - 2);
             const uint32_t code = inr ? (uint32_t)(delta + (UQ)p.radius) : 0u;
             if (act) codes[g.coff + t] = (uint16_t)code;
-            blk_count(lh, p, code, act);
+            blk_count<HW>(lh, p, code, act);
             const unsigned long long pd = wave_append_slot(act && !inr, p.n_dout);
             if (act && !inr && pd < p.out_cap) {
                 p.dout_idx[pd] = g.coff + t;  // (position of the code, not of the element: the decoder expands the codes in place)
@@ -364,7 +386,7 @@ __global__ __launch_bounds__(256) void k_blk_lorenzo(uint16_t *__restrict__ code
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    blk_flush(lh, p);
+    blk_flush<HW>(lh, p);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -390,16 +412,54 @@ __device__ __forceinline__ uint32_t rice_len(uint64_t u, uint32_t k) {
     const uint64_t q = u >> k;
     return q < RICE_ESC ? (uint32_t)q + 1u + k : RICE_ESC + 64u;
 }
-// rank of every block among the regression blocks (exclusive), the compacted list, the count: one workgroup walks the
-// block list (a few hundred thousand flags: tens of microseconds)
-__global__ __launch_bounds__(1024) void k_blk_rank(const uint8_t *__restrict__ sel, uint32_t nblocks, uint32_t *__restrict__ rank,
-                                                   uint32_t *__restrict__ comp, uint64_t *n_reg_out) {
+// rank of every block among the regression blocks (exclusive), the compacted list, the count — three small launches: the
+// regression blocks of every run of 8192 blocks are counted, one workgroup turns the counts into offsets, every run is walked
+// again with its offset (one workgroup over all flags took 0.38 ms for C4's 643 302 blocks)
+#define RANK_RUN 8192u
+__global__ __launch_bounds__(256) void k_blk_rank_count(const uint8_t *__restrict__ sel, uint32_t nblocks, uint32_t *__restrict__ run_cnt) {
+    __shared__ uint32_t s_c;
+    if (threadIdx.x == 0) s_c = 0;
+    __syncthreads();
+    const uint32_t b0 = blockIdx.x * RANK_RUN;
+    uint32_t c = 0;
+    for (uint32_t b = b0 + threadIdx.x; b < b0 + RANK_RUN && b < nblocks; b += 256) c += sel[b] == 2;
+    c = wave_sum(c);
+    if (lane_id() == 0 && c) atomicAdd(&s_c, c);
+    __syncthreads();
+    if (threadIdx.x == 0) run_cnt[blockIdx.x] = s_c;
+}
+__global__ __launch_bounds__(1024) void k_blk_rank_offsets(uint32_t *__restrict__ run_cnt, uint32_t nruns, uint64_t *n_reg_out) {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
+    for (uint32_t base = 0; base < nruns; base += 1024) {
+        const uint32_t r = base + threadIdx.x;
+        const uint32_t mine = r < nruns ? run_cnt[r] : 0u;
+        const uint32_t incl = wave_incl_scan(mine);
+        if (lane_id() == WAVE - 1) s_w[threadIdx.x / WAVE] = incl;
+        __syncthreads();
+        uint32_t run = s_carry + incl - mine, tot = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            if (w < threadIdx.x / WAVE) run += s_w[w];
+            tot += s_w[w];
+        }
+        if (r < nruns) run_cnt[r] = run;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_reg_out = s_carry;
+}
+__global__ __launch_bounds__(256) void k_blk_rank_write(const uint8_t *__restrict__ sel, uint32_t nblocks, const uint32_t *__restrict__ run_off,
+                                                        uint32_t *__restrict__ rank, uint32_t *__restrict__ comp) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = run_off[blockIdx.x];
+    __syncthreads();
     constexpr uint32_t PER = 8;
-    for (uint32_t base = 0; base < nblocks; base += 1024 * PER) {
+    const uint32_t r0 = blockIdx.x * RANK_RUN;
+    for (uint32_t base = r0; base < r0 + RANK_RUN && base < nblocks; base += 256 * PER) {
         const uint32_t b0 = base + threadIdx.x * PER;
         uint32_t f[PER], mine = 0;
 #pragma unroll
@@ -411,7 +471,7 @@ __global__ __launch_bounds__(1024) void k_blk_rank(const uint8_t *__restrict__ s
         if (lane_id() == WAVE - 1) s_w[threadIdx.x / WAVE] = incl;
         __syncthreads();
         uint32_t run = s_carry + incl - mine, tot = 0;
-        for (uint32_t w = 0; w < 16; w++) {
+        for (uint32_t w = 0; w < 4; w++) {
             if (w < threadIdx.x / WAVE) run += s_w[w];
             tot += s_w[w];
         }
@@ -427,7 +487,12 @@ __global__ __launch_bounds__(1024) void k_blk_rank(const uint8_t *__restrict__ s
         if (threadIdx.x == 0) s_carry += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *n_reg_out = s_carry;
+}
+static void launch_blk_rank(const uint8_t *sel, uint32_t nblocks, uint32_t *rank, uint32_t *comp, uint32_t *run_scratch, uint64_t *n_reg, hipStream_t s) {
+    const uint32_t nruns = (nblocks + RANK_RUN - 1) / RANK_RUN;
+    hipLaunchKernelGGL(k_blk_rank_count, dim3(nruns), dim3(256), 0, s, sel, nblocks, run_scratch);
+    hipLaunchKernelGGL(k_blk_rank_offsets, dim3(1), dim3(1024), 0, s, run_scratch, nruns, n_reg);
+    hipLaunchKernelGGL(k_blk_rank_write, dim3(nruns), dim3(256), 0, s, sel, nblocks, (const uint32_t *)run_scratch, rank, comp);
 }
 __device__ __forceinline__ void coef_delta(const int64_t *__restrict__ coef, const uint32_t *__restrict__ comp, uint64_t r, uint64_t (&u)[4]) {
     const int64_t *cur = coef + (uint64_t)comp[r] * 4;
@@ -654,18 +719,18 @@ __global__ __launch_bounds__(1024) void k_blk_coef_scan(uint64_t nr, int64_t *__
 // decoder: one anti-diagonal front of blocks per launch, one wave per block. d_out holds lattice values q~ (Q) until the
 // final pass turns them into T.
 // ------------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int CB>
 __global__ __launch_bounds__(256) void k_blk_decode(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t diag, uint32_t bz_lo,
                                                     uint32_t npairs, const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
-    __shared__ Q s_q[4][BLK_TILE];
-    __shared__ Q s_a[4][BLK_TILE];
+    __shared__ Q s_q[4][CB ? (CB + 2) * (CB + 2) * (CB + 2) : BLK_TILE];
+    __shared__ Q s_a[4][CB ? (CB + 2) * (CB + 2) * (CB + 2) : BLK_TILE];
     const Lattice<T> lat(p.lat);
     const int lane = lane_id();
     const uint32_t wv = threadIdx.x / WAVE;
     Q *sq = s_q[wv], *sa = s_a[wv];
-    const uint32_t E = p.B + 2;
+    const uint32_t B = CB ? (uint32_t)CB : p.B, E = B + 2;
     const uint64_t d1 = p.d[1], d2 = p.d[2];
     Q *qout = reinterpret_cast<Q *>(d_out);
     const Q *deltas = reinterpret_cast<const Q *>(deltas_);
@@ -687,7 +752,8 @@ __global__ __launch_bounds__(256) void k_blk_decode(const uint16_t *__restrict__
         T rc[4];
         coef_recover(coef_by_rank + (uint64_t)rank[task] * 4, cl, rc);
         for (uint32_t t = lane; t < nown; t += WAVE) {
-            const uint32_t i2 = t % g.ex, i1 = (t / g.ex) % g.ey, i0 = t / (g.ex * g.ey);
+            uint32_t i0, i1, i2;
+            own_index<CB>(g, t, i0, i1, i2);
             const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
             const uint32_t code = codes[g.coff + t];
             Q qt = 0;
@@ -778,7 +844,7 @@ __global__ __launch_bounds__(256) void k_blk_decode(const uint16_t *__restrict__
 
 // final pass: lattice value -> T for Lorenzo blocks; regression blocks are recomputed from their codes (their value is
 // pred + 2*code*eb, not a lattice point)
-template <typename T>
+template <typename T, int CB>
 __global__ __launch_bounds__(256) void k_blk_final(const uint16_t *__restrict__ codes, void *d_out, szk_blk_params p, uint32_t nblocks,
                                                    const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
     using Q = typename QTraits<T>::Q;
@@ -795,7 +861,8 @@ __global__ __launch_bounds__(256) void k_blk_final(const uint16_t *__restrict__ 
         T rc[4] = {0, 0, 0, 0};
         if (reg) coef_recover(coef_by_rank + (uint64_t)rank[task] * 4, cl, rc);
         for (uint32_t t = lane; t < nown; t += WAVE) {
-            const uint32_t i2 = t % g.ex, i1 = (t / g.ex) % g.ey, i0 = t / (g.ex * g.ey);
+            uint32_t i0, i1, i2;
+            own_index<CB>(g, t, i0, i1, i2);
             const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
             if (reg) {
                 const uint32_t code = codes[g.coff + t];
@@ -827,14 +894,25 @@ static uint32_t blk_count_blocks(const szk_blk_params *p) { return p->nb[0] * p-
 int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s) {
     const uint32_t nblocks = blk_count_blocks(p);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
+#define BLK_ENC(T, HW)                                                                                                   \
+    do {                                                                                                                 \
+        if (p->B == 6) {                                                                                                  \
+            hipLaunchKernelGGL((k_blk_fit<T, HW, 6>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, *p, nblocks); \
+            hipLaunchKernelGGL((k_blk_lorenzo<T, HW, 6>), dim3(grid), dim3(256), 0, s, codes, *p, nblocks);             \
+        } else {                                                                                                         \
+            hipLaunchKernelGGL((k_blk_fit<T, HW, 0>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, *p, nblocks); \
+            hipLaunchKernelGGL((k_blk_lorenzo<T, HW, 0>), dim3(grid), dim3(256), 0, s, codes, *p, nblocks);             \
+        }                                                                                                                \
+    } while (0)
     if (dtype == 0) {
-        hipLaunchKernelGGL(k_blk_fit<float>, dim3(grid), dim3(256), 0, s, (const float *)d_in, codes, *p, nblocks);
-        hipLaunchKernelGGL(k_blk_lorenzo<float>, dim3(grid), dim3(256), 0, s, codes, *p, nblocks);
+        if (sc->wide_hist) BLK_ENC(float, BLK_HWIN_WIDE);
+        else BLK_ENC(float, BLK_HWIN);
     } else {
-        hipLaunchKernelGGL(k_blk_fit<double>, dim3(grid), dim3(256), 0, s, (const double *)d_in, codes, *p, nblocks);
-        hipLaunchKernelGGL(k_blk_lorenzo<double>, dim3(grid), dim3(256), 0, s, codes, *p, nblocks);
+        if (sc->wide_hist) BLK_ENC(double, BLK_HWIN_WIDE);
+        else BLK_ENC(double, BLK_HWIN);
     }
-    hipLaunchKernelGGL(k_blk_rank, dim3(1), dim3(1024), 0, s, p->sel, nblocks, sc->rank, sc->comp, sc->counters + 0);
+#undef BLK_ENC
+    launch_blk_rank(p->sel, nblocks, sc->rank, sc->comp, sc->run_scratch, sc->counters + 0, s);
     // (counters: [0] regression blocks, [2] side bytes, [4..7] as doubles: sum of the zigzagged differences per coefficient;
     // the group sizes are staged in the rank array, which the encoder needs no more once comp is written)
     double *stats = reinterpret_cast<double *>(sc->counters + 4);
@@ -859,7 +937,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
     memcpy(&nr, &sc->side_hdr[16], 8);
     memcpy(&bit_words, &sc->side_hdr[24], 8);
     hipLaunchKernelGGL(k_blk_side_sel, dim3((nblocks + 255) / 256 < 1024 ? (nblocks + 255) / 256 : 1024), dim3(256), 0, s, side, nblocks, p->sel);
-    hipLaunchKernelGGL(k_blk_rank, dim3(1), dim3(1024), 0, s, p->sel, nblocks, sc->rank, (uint32_t *)nullptr, sc->counters + 0);
+    launch_blk_rank(p->sel, nblocks, sc->rank, (uint32_t *)nullptr, sc->run_scratch, sc->counters + 0, s);
     if (nr) {
         const uint64_t ngroups = (nr + RICE_GROUP - 1) / RICE_GROUP;
         hipLaunchKernelGGL(k_blk_coef_parse, dim3((uint32_t)((ngroups + 255) / 256 < 1024 ? (ngroups + 255) / 256 : 1024)), dim3(256), 0, s, side, nblocks, nr,
@@ -874,17 +952,24 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         const uint32_t bz_lo = d > rest ? d - rest : 0, bz_hi = d < p->nb[0] - 1 ? d : p->nb[0] - 1;
         if (bz_lo > bz_hi) continue;
         const uint32_t npairs = (bz_hi - bz_lo + 1) * p->nb[1];
-        if (dtype == 0)
-            hipLaunchKernelGGL(k_blk_decode<float>, dim3((npairs + 3) / 4), dim3(256), 0, s, codes, p->qwork, d_out, *p, d, bz_lo, npairs, sc->rank, coef_by_rank);
-        else
-            hipLaunchKernelGGL(k_blk_decode<double>, dim3((npairs + 3) / 4), dim3(256), 0, s, codes, p->qwork, d_out, *p, d, bz_lo, npairs, sc->rank, coef_by_rank);
+#define BLK_DEC(T, CBV) hipLaunchKernelGGL((k_blk_decode<T, CBV>), dim3((npairs + 3) / 4), dim3(256), 0, s, codes, p->qwork, d_out, *p, d, bz_lo, npairs, sc->rank, coef_by_rank)
+        if (dtype == 0) {
+            if (p->B == 6) BLK_DEC(float, 6);
+            else BLK_DEC(float, 0);
+        } else {
+            if (p->B == 6) BLK_DEC(double, 6);
+            else BLK_DEC(double, 0);
+        }
+#undef BLK_DEC
     }
     const uint32_t grid = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
     if (dtype == 0) {
-        hipLaunchKernelGGL(k_blk_final<float>, dim3(grid), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);
+        if (p->B == 6) hipLaunchKernelGGL((k_blk_final<float, 6>), dim3(grid), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);
+        else hipLaunchKernelGGL((k_blk_final<float, 0>), dim3(grid), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);
         if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<float>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (float *)d_out);
     } else {
-        hipLaunchKernelGGL(k_blk_final<double>, dim3(grid), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);
+        if (p->B == 6) hipLaunchKernelGGL((k_blk_final<double, 6>), dim3(grid), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);
+        else hipLaunchKernelGGL((k_blk_final<double, 0>), dim3(grid), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);
         if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<double>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (double *)d_out);
     }
     SZK_CHECK_LAUNCH();

@@ -3,7 +3,7 @@
 # pass (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2 — MI355X_MICROARCH.md "rocprofv3 PMC slots"), (4) SQ counters.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-B="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-e2e"
+B="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-e2e --no-extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o r -- $B > $R/gpurun_out/prof_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o p -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o p -- $B > /dev/null 2>&1

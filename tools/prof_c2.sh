@@ -11,8 +11,8 @@ import csv,glob
 f=glob.glob("$R/gpurun_out/prof_c2/raw/*kernel_trace.csv")[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-# last full step: find last k_assemble, walk back to previous k_assemble
-idx=[i for i,r in enumerate(rows) if r["Kernel_Name"].startswith("k_assemble")]
+# one step of the timed loop: from the packer's launch of one step (the step's last kernel) to the next one
+idx=[i for i,r in enumerate(rows) if "k_pack<" in r["Kernel_Name"]]
 a,b=idx[-6],idx[-5]
 t0=int(rows[a+1]["Start_Timestamp"])
 prev_end=None

@@ -256,7 +256,8 @@ def main():
     dist = None
     comm = None
     exchange = "none (one rank)"
-    if world > 1:
+    force_comm = os.environ.get("SZ3_BENCH_FORCE_COMM") == "1" and "RANK" in os.environ  # (one rank under a launcher: the RCCL path end to end)
+    if world > 1 or force_comm:
         import torch.distributed as dist
         from sz3_amd import distributed as D
         if one_gpu:
@@ -272,11 +273,11 @@ def main():
 
     S = args.size
     shape = tuple(int(v) for v in args.shape.split(",")) if args.shape else (S, S, S)
-    w = Workload(torch, sz3_amd, dev, local_rank, rank, shape, args.dtype, args.algo, args.eb, comm=comm, dist=dist if world > 1 else None,
+    w = Workload(torch, sz3_amd, dev, local_rank, rank, shape, args.dtype, args.algo, args.eb, comm=comm, dist=dist if (world > 1 and comm is None) else None,
                  field=args.field)
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -382,7 +383,7 @@ def main():
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

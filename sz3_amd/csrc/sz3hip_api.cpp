@@ -969,6 +969,8 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     const uint64_t n = ctx->proto.n;
     szk_cb_params cb;
     cb_params_from(ctx, cb, ctx->cur_out_cap);
+    if (ctx->range_ready && !cb.range_ready)  // stage 1 kept the range of the LOCAL histogram, the caller then changed it (all-reduce):
+        HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, 16, s));  // k_hist_range starts from zero
     prof_begin(ctx, ST_CODEBOOK, s);
     int rc = szk_launch_codebook(ctx->d_hist, &cb, s);
     if (rc) return fail(SZ3HIP_EHIP, "codebook kernel launch failed (%d)", rc);

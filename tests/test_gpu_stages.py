@@ -358,3 +358,33 @@ def test_stage_calls_out_of_order_are_refused():
     size = dc.finish(0)
     ref = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)  # the whole call again: same payload size
     assert size == ref
+
+
+
+def test_context_hints_survive_a_change_of_regime():
+    """A context launches ONE form of the stage-1 kernel and ONE form of the code-book kernel, chosen from what its previous
+    call found (code width, alphabet size). Data that changes character between calls must still come out right: the
+    one-byte form of stage 1 falls back to two-byte codes inside its own LDS budget when this call's probe says so, and a
+    code-book form that meets the other form's alphabet makes `finish` repeat stage 2. Alternating a smooth field at a loose
+    bound (128 symbols, one-byte codes) with the same field at a tight bound (thousands of symbols, two-byte codes), every
+    call against a fresh context's result."""
+    import torch
+    dev = torch.device("cuda:0")
+    shape = (48, 64, 256)
+    a = field3d(shape)
+    t = torch.from_numpy(a).to(dev)
+    n = a.size
+    shared = sz3_amd.DeviceCompressor(n, np.float32)
+    cap = shared.payload_bound(n, worst_case=True)
+    for eb in (1e-3, 1e-6, 1e-3, 1e-3, 2e-6, 1e-6, 1e-2):
+        conf = _conf(shape, eb)
+        out = {}
+        for name, dc in (("shared", shared), ("fresh", sz3_amd.DeviceCompressor(n, np.float32))):
+            pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+            size = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+            dec = torch.empty_like(t)
+            dc.decompress(pl.data_ptr(), size, dec.data_ptr(), 0)
+            torch.cuda.synchronize()
+            out[name] = (pl[:size].cpu().numpy().tobytes(), dec.cpu().numpy())
+        assert out["shared"][0] == out["fresh"][0], "payload depends on the context's history (eb %g)" % eb
+        assert float(np.max(np.abs(out["shared"][1].astype(np.float64) - a.astype(np.float64)))) <= eb

@@ -908,26 +908,36 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP_LORENZO) {  // the reference's default: sampling auto-tuner, then one of the two paths
         // The tuner is a chain of small launches and host round trips (the chip is mostly idle), and its outcome is almost
         // always interpolation, which starts from a working copy of the input: make that copy meanwhile on a side stream.
+        // (3-D arrays run through the level kernels, which read the input where it lies: no copy)
+        szk_interp_params shape;
+        memset(&shape, 0, sizeof(shape));
+        shape.N = conf->N;
+        for (int i = 0; i < conf->N && i < 4; i++) shape.dims[i] = conf->dims[i];
+        const bool ahead = !szk_interp_levels_ok(&shape);
         if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
-        if (!ctx->side) {
-            HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        if (ahead) {
+            if (!ctx->side) {
+                HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+            }
+            HIPCHK(hipEventRecord(ctx->ev_fork, s));
+            HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+            HIPCHK(hipMemcpyAsync(ctx->d_work, d_in, num * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8), hipMemcpyDeviceToDevice, ctx->side));
+            HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
         }
-        HIPCHK(hipEventRecord(ctx->ev_fork, s));
-        HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-        HIPCHK(hipMemcpyAsync(ctx->d_work, d_in, num * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8), hipMemcpyDeviceToDevice, ctx->side));
-        HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
         prof_begin(ctx, ST_TUNER, s);
         int rct = tune_interp_lorenzo(ctx, *conf, d_in, eb, radius, s);
         prof_end(ctx, ST_TUNER, s);
-        hipError_t ej = hipStreamWaitEvent(s, ctx->ev_join, 0);  // whatever the outcome: the caller's stream owns d_in again
-        if (ej != hipSuccess) {
-            (void)hipStreamSynchronize(ctx->side);
-            return fail(SZ3HIP_EHIP, "joining the side stream failed: %s", hipGetErrorString(ej));
+        if (ahead) {
+            hipError_t ej = hipStreamWaitEvent(s, ctx->ev_join, 0);  // whatever the outcome: the caller's stream owns d_in again
+            if (ej != hipSuccess) {
+                (void)hipStreamSynchronize(ctx->side);
+                return fail(SZ3HIP_EHIP, "joining the side stream failed: %s", hipGetErrorString(ej));
+            }
         }
         if (rct) return rct;
-        ctx->copy_ahead = true;
+        ctx->copy_ahead = ahead;
     }
     HIPCHK(clear_hist_counters(ctx, s));
     if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP || conf->cmprAlgo == SZ3HIP_ALGO_HIP_INTERP)

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -67,7 +68,7 @@ __device__ __forceinline__ void sink_code(const TrialSink *sk, uint32_t code) {
 // instructions each, and a tuner trial block is worked by ONE compute unit)
 template <typename T, bool DEC, typename IT = uint64_t, bool SINK = false>
 __device__ __forceinline__ void interp_point(T *__restrict__ w, uint16_t *__restrict__ codes, const szk_interp_pass &p, uint64_t t,
-                                             uint64_t boff, const TrialSink *sink = nullptr) {
+                                             uint64_t boff, const TrialSink *sink = nullptr, const T *__restrict__ orig = nullptr) {
     IT r = (IT)t;
     uint64_t idx = 0, cd = 0;
 #pragma unroll
@@ -125,20 +126,22 @@ __device__ __forceinline__ void interp_point(T *__restrict__ w, uint16_t *__rest
         const int code = codes[idx];
         if (code) *d = ref_recover<T>(pred, code, p.eb, p.radius);  // code 0: raw value already scattered in place
     } else {
-        T v = *d;
+        // orig: the work array holds reconstructions only (no working copy of the input was made), the original comes from
+        // the caller's array and an unpredictable point's raw value is stored like a reconstruction
+        T v = orig ? orig[idx] : *d;
         const int code = ref_quantize<T>(v, pred, p.eb, p.eb_recip, p.radius);
         if (SINK) sink_code(sink, (uint32_t)code);
         else codes[idx] = (uint16_t)code;
-        if (code && !p.no_store) *d = v;  // (unpredictable, code 0: the raw value stays; LinearQuantizer "unpred")
+        if ((code || orig) && !p.no_store) *d = v;  // (unpredictable, code 0: the raw value stays; LinearQuantizer "unpred")
     }
 }
 template <typename T, bool DEC>
-__global__ __launch_bounds__(256) void k_interp_pass(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
+__global__ __launch_bounds__(256) void k_interp_pass(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p, const T *__restrict__ orig) {
     const uint64_t t = (uint64_t)xcd_block() * 256 + threadIdx.x;
     if (t >= p.total) return;
     const uint64_t boff = (uint64_t)blockIdx.y * p.batch_stride;  // independent arrays of one batch
-    if (p.total <= 0xFFFFFFFFull) interp_point<T, DEC, uint32_t>(w + boff, codes + boff, p, t, boff);  // (uniform branch)
-    else interp_point<T, DEC, uint64_t>(w + boff, codes + boff, p, t, boff);
+    if (p.total <= 0xFFFFFFFFull) interp_point<T, DEC, uint32_t>(w + boff, codes + boff, p, t, boff, nullptr, orig);  // (uniform branch)
+    else interp_point<T, DEC, uint64_t>(w + boff, codes + boff, p, t, boff, nullptr, orig);
 }
 
 // ---- level 1 (stride 1), cubic, N >= 3, row length a multiple of 4: 8 consecutive x per thread (a row may end in a half group) ----
@@ -377,11 +380,296 @@ __global__ __launch_bounds__(256) void k_interp_vec(T *__restrict__ w, uint16_t 
     }
 }
 
+// ---- one LEVEL per launch (N == 3): the three directional passes of a tile of 32^3 grid intervals, in LDS ----------------
+// The per-pass kernels above move every level's rows through HBM three times (once per direction). Here a workgroup owns one
+// block of the reference's decomposition — 32 grid intervals of the level's stride in each dimension, 33^3 grid points with its
+// faces, exactly the range [begin, end] inside which the reference cuts its stencils (InterpolationDecomposition.hpp:121-135) —
+// and runs the three passes on it in LDS. What a pass reads is either coarser (final when the launch starts) or an earlier
+// pass's point of the same block range along the pass axis: so the closed block is self-contained. The points on a face belong
+// to two blocks (four on an edge, eight at a corner); all of them compute it — same inputs, same arithmetic, same bits — and
+// one writes it: the block in which every coordinate of the point lies below the block's end (or the block is the axis' last).
+//   LDS: the points with an even coordinate along the LAST pass's axis (the odd ones are that pass's own points: nobody reads
+//        them) — 33 x 33 x 17 values, 74 KB for f32 (two workgroups per CU), 148 KB for f64.
+//   in:  the originals are read from the caller's array (never written: a neighbour block may already have replaced a face
+//        point's original in the work array by its reconstruction), coarser points from the work array w; nothing else of w is
+//        read, so the working copy of the input the per-pass path starts from is not needed at all.
+struct szk_interp_level {
+    uint32_t off[2];   // element strides of the two slower dimensions (the fastest has stride 1)
+    uint32_t s;        // level stride
+    uint32_t g[3];     // grid points per dimension at this level: (D - 1) / s + 1
+    uint32_t nt[3];    // blocks per dimension
+    int perm[3];       // pass k runs along dimension perm[k]
+    int interp_id, radius, no_store;
+    int dbg;
+    double eb, eb_recip;
+};
+#define LV_MAIN (33 * 33 * 17)
+#define LV_SIDE (33 * 33)
+#define LV_NT 512
+struct LvMagic {
+    uint32_t m[40];
+};
+__device__ __forceinline__ uint32_t lv_div(uint32_t t, uint32_t d, uint32_t magic) { return d <= 1 ? t : __umulhi(t, magic); }
+static LvMagic lv_magic_host() {
+    LvMagic g;
+    g.m[0] = g.m[1] = 0;
+    for (uint32_t d = 2; d < 40; d++) g.m[d] = 0xFFFFFFFFu / d + 1;  // exact quotients for t * d < 2^32
+    return g;
+}
+__device__ __forceinline__ uint32_t sel3(int i, uint32_t a, uint32_t b, uint32_t c) { return i == 0 ? a : (i == 1 ? b : c); }
+
+// the stencil rules of interpolation_1d_fastest_dim_first (:334-399) on gathered neighbours (unused ones hold anything);
+// linear mode's extrapolated last point of an even-length line (reads the previous point of its own pass) is the caller's
+template <typename T>
+__device__ __forceinline__ T lv_rule(uint32_t i, uint32_t n, T m3, T m1, T p1, T p3, int interp_id) {
+    if (interp_id == 0) return i + 1 < n ? ip_linear<T>(m1, p1) : m1;
+    if (i >= 3) {
+        if (i + 3 < n) return ip_cubic<T>(m3, m1, p1, p3);
+        if (i + 1 < n) return ip_quad_2<T>(m3, m1, p1);
+        return ip_linear1<T>(m3, m1);
+    }
+    if (i + 3 < n) return ip_quad_1<T>(m1, p1, p3);
+    if (i + 1 < n) return ip_linear<T>(m1, p1);
+    return m1;
+}
+
+// cubic mode without per-point branches: the three stencils a full block meets are computed and selected; the others (ragged
+// blocks' line ends) take the branch
+template <typename T>
+__device__ __forceinline__ T lv_cubic_sel(uint32_t i, uint32_t n, T m3, T m1, T p1, T p3) {
+    const T c = ip_cubic<T>(m3, m1, p1, p3), q1 = ip_quad_1<T>(m1, p1, p3), q2 = ip_quad_2<T>(m3, m1, p1);
+    const bool lo = i < 3, hi3 = i + 3 >= n;
+    T r = lo ? q1 : c;
+    r = (!lo && hi3) ? q2 : r;
+    if (i + 1 >= n || (lo && hi3)) r = lv_rule<T>(i, n, m3, m1, p1, p3, 1);
+    return r;
+}
+// ref_quantize with selects instead of its early returns (same arithmetic, same results)
+template <typename T>
+__device__ __forceinline__ int lv_quantize(T &data, T pred, double eb, double recip, int radius) {
+    const T diff = data - pred;
+    const double scaled = fabs((double)diff) * recip;
+    const bool inr = scaled < (double)(2 * radius - 1);  // (false for NaN)
+    int qi = (int)(inr ? scaled : 0.0) + 1;
+    const int half = qi >> 1;
+    qi = half << 1;
+    const bool neg = diff < 0;
+    const int sq = neg ? -qi : qi;
+    const int shifted = neg ? radius - half : radius + half;
+    const T dec = (T)((double)pred + (double)sq * eb);
+    const T ad = dec - data;
+    const bool ok = inr && fabs((double)ad) <= eb;
+    data = ok ? dec : data;
+    return ok ? shifted : 0;
+}
+
+// Work of a pass: ITEMS = (index along x) x (index along the other non-walk axis) x (segment of the walk); a thread takes an
+// item and walks along z or y — never along x, so that the lanes of a wave lie along x (coalesced global accesses, LDS rows
+// without bank conflicts), all per-item index arithmetic is paid once per walk, and a pass along the walk axis slides its
+// four-point stencil (one LDS read per point instead of four). The walk's originals (codes, when decoding) are requested four
+// points ahead of their use.
+template <typename T, bool DEC>
+__global__ __launch_bounds__(LV_NT) void k_interp_level(const T *__restrict__ in, T *w, uint16_t *codes, szk_interp_level p, LvMagic mg) {
+    extern __shared__ __align__(16) unsigned char lv_smem[];
+    T *L = reinterpret_cast<T *>(lv_smem);
+    T *Ls = L + LV_MAIN;  // linear mode, last pass along x: the points the extrapolated last point of a row reads
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b = xcd_block();
+    const uint32_t tq = b / p.nt[2];
+    const uint32_t t2 = b - tq * p.nt[2];
+    const uint32_t t0 = tq / p.nt[1], t1 = tq - t0 * p.nt[1];
+    const int aL = p.perm[2];
+    // block geometry (all wave-uniform)
+    const uint32_t r0 = p.g[0] - 1 - t0 * 32, r1 = p.g[1] - 1 - t1 * 32, r2 = p.g[2] - 1 - t2 * 32;
+    const uint32_t n0 = (r0 < 32 ? r0 : 32) + 1, n1 = (r1 < 32 ? r1 : 32) + 1, n2 = (r2 < 32 ? r2 : 32) + 1;
+    const bool last0 = t0 == p.nt[0] - 1, last1 = t1 == p.nt[1] - 1, last2 = t2 == p.nt[2] - 1;
+    const uint32_t m1 = aL == 1 ? (n1 + 1) >> 1 : n1, m2 = aL == 2 ? (n2 + 1) >> 1 : n2;
+    const uint32_t str0 = m1 * m2, str1 = m2;  // LDS strides (the fastest dimension has 1)
+    const uint64_t gs0 = (uint64_t)p.s * p.off[0], gs1 = (uint64_t)p.s * p.off[1];
+    const uint64_t gbase = (uint64_t)(t0 * 32) * gs0 + (uint64_t)(t1 * 32) * gs1 + (uint64_t)(t2 * 32) * p.s;
+    // ---- load: the coarse points (every coordinate even) from w ----
+    if (!(p.dbg & 32)) {
+        const uint32_t e0 = (n0 + 1) >> 1, e1 = (n1 + 1) >> 1, e2 = (n2 + 1) >> 1;
+        const uint32_t total = e0 * e1 * e2;
+        const uint32_t k0 = (aL == 0 ? 1u : 2u) * str0, k1 = (aL == 1 ? 1u : 2u) * str1, k2 = aL == 2 ? 1u : 2u;
+        const uint32_t mg_e2 = mg.m[e2], mg_e1 = mg.m[e1];
+        for (uint32_t base = tid; base < total; base += 4 * LV_NT) {
+            T v[4];
+            int ad[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t t = base + u * LV_NT;
+                ad[u] = -1;
+                if (t < total) {
+                    const uint32_t q2 = lv_div(t, e2, mg_e2), l2 = t - q2 * e2;
+                    const uint32_t l0 = lv_div(q2, e1, mg_e1), l1 = q2 - l0 * e1;
+                    v[u] = w[gbase + (uint64_t)(2 * l0) * gs0 + (uint64_t)(2 * l1) * gs1 + (uint64_t)(2 * l2 * p.s)];
+                    ad[u] = (int)(l0 * k0 + l1 * k1 + l2 * k2);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (ad[u] >= 0) L[ad[u]] = v[u];
+        }
+    }
+    for (int k = 0; k < 3; k++) {
+        __syncthreads();
+        const int a = p.perm[k];
+        const uint32_t na = sel3(a, n0, n1, n2);
+        if (na < 2) continue;
+        if ((p.dbg & 4) && k == 2) continue;
+        if ((p.dbg & 8) && k < 2) continue;
+        const bool defer = p.interp_id == 0 && na >= 3 && !(na & 1u);
+        // point set of the pass: odd along a, every index along the axes of earlier passes, even ones along later axes;
+        // the last pass computes owned points only (nobody reads the others)
+        uint32_t st0, st1, st2, sp0, sp1, sp2, c0, c1, c2;
+        auto axis = [&](int j, uint32_t n, bool last, uint32_t &st, uint32_t &sp, uint32_t &c) {
+            if (j == a) {
+                st = 1; sp = 2; c = n >> 1;
+            } else if (k == 2) {
+                st = 0; sp = 1; c = last ? n : n - 1;
+            } else if (k == 1 && j == p.perm[0]) {
+                st = 0; sp = 1; c = n;
+            } else {
+                st = 0; sp = 2; c = (n + 1) >> 1;
+            }
+        };
+        axis(0, n0, last0, st0, sp0, c0);
+        axis(1, n1, last1, st1, sp1, c1);
+        axis(2, n2, last2, st2, sp2, c2);
+        const int W = a == 2 ? 0 : a, U = 1 - W;   // walk axis, the other slow axis
+        const bool slide = W == a;                  // the walk runs along the pass axis: sliding stencil
+        const uint32_t nW = W == 0 ? n0 : n1, nU = U == 0 ? n0 : n1;
+        const bool lastW = W == 0 ? last0 : last1, lastU = U == 0 ? last0 : last1;
+        const uint32_t stW = W == 0 ? st0 : st1, spW = W == 0 ? sp0 : sp1, cW = W == 0 ? c0 : c1;
+        const uint32_t stU = U == 0 ? st0 : st1, spU = U == 0 ? sp0 : sp1, cU = U == 0 ? c0 : c1;
+        const uint32_t strW = W == 0 ? str0 : str1, strU = U == 0 ? str0 : str1;
+        const uint64_t gsW = W == 0 ? gs0 : gs1, gsU = U == 0 ? gs0 : gs1;
+        // LDS: coordinates along the last pass's axis are halved
+        const uint32_t dW = (aL == W ? spW >> 1 : spW) * strW;  // address step of one walk step (spW = 2 whenever aL == W)
+        const int sa = (int)sel3(a, str0, str1, 1u);
+        const int o_m3 = k < 2 ? -3 * sa : -sa, o_m1 = k < 2 ? -sa : 0, o_p1 = sa, o_p3 = k < 2 ? 3 * sa : 2 * sa;
+        const uint64_t gstep = (uint64_t)spW * gsW;
+        // segment length of the walk: what keeps the workgroup's threads busiest (a deferred point needs its predecessor in
+        // the same walk)
+        uint32_t seglen = 32;
+        if (!(defer && slide)) {
+            uint32_t best = 0xFFFFFFFFu;
+            for (uint32_t sl = 32; sl >= 4; sl >>= 1) {
+                const uint32_t items = c2 * cU * ((cW + sl - 1) / sl);
+                const uint32_t cost = ((items + LV_NT - 1) / LV_NT) * (sl + 2);
+                if (cost < best) {
+                    best = cost;
+                    seglen = sl;
+                }
+            }
+        }
+        const uint32_t nseg = (cW + seglen - 1) / seglen;
+        const uint32_t items = c2 * cU * nseg;
+        const uint32_t mg_c2 = mg.m[c2], mg_cU = mg.m[cU];
+        for (int sub = 0; sub < (defer && !slide ? 2 : 1); sub++) {
+            if (sub) __syncthreads();
+            for (uint32_t it = tid; it < items; it += LV_NT) {
+                const uint32_t q2 = lv_div(it, c2, mg_c2), xi = it - q2 * c2;
+                const uint32_t sg = lv_div(q2, cU, mg_cU), ui = q2 - sg * cU;
+                const uint32_t iX = st2 + xi * sp2, iU = stU + ui * spU;
+                const uint32_t lw0 = sg * seglen;
+                const uint32_t cnt = cW - lw0 < seglen ? cW - lw0 : seglen;
+                uint32_t iW = stW + lw0 * spW;
+                if (!slide && (defer && iX + 1 == na) != (sub != 0)) continue;  // (pass along x: a row's deferred point is an item's)
+                const uint32_t xX = aL == 2 ? iX >> 1 : iX, xU = aL == U ? iU >> 1 : iU, xW = aL == W ? iW >> 1 : iW;
+                int addr = (int)(xW * strW + xU * strU + xX);  // the point itself (passes 0, 1) or its lower neighbour (last pass)
+                uint64_t g = gbase + (uint64_t)iW * gsW + (uint64_t)iU * gsU + (uint64_t)(iX * p.s);
+                const bool own_item = k == 2 || ((iU + 1 < nU || lastU) && (iX + 1 < n2 || last2));
+                // sliding stencil along the walk (slide), else the fixed position of the item along x
+                T wm3 = (T)0, wm1 = (T)0, wp1 = (T)0, prev = (T)0;
+                if (slide) {  // (addresses outside the line fall back to a valid one: the rules do not use what they return)
+                    wm3 = L[addr + (iW >= 3 ? o_m3 : o_m1)];
+                    wm1 = L[addr + o_m1];
+                    wp1 = L[addr + (iW + 1 < na ? o_p1 : o_m1)];
+                }
+                // pass along x: the item's position along the line is fixed, and so is what may be read
+                const int e_m3 = iX >= 3 ? o_m3 : o_m1, e_p1 = iX + 1 < na ? o_p1 : o_m1, e_p3 = iX + 3 < na ? o_p3 : o_m1;
+                // originals (codes) of the walk, four points ahead
+                T ov[4];
+                int cv[4];
+                uint64_t gf = g;  // where the next fetch starts
+                auto fetch = [&](uint32_t from) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (from + u < cnt) {
+                            if (DEC) cv[u] = codes[gf];
+                            else ov[u] = (p.dbg & 2) ? (T)u : in[gf];
+                        }
+                        gf += gstep;
+                    }
+                };
+                fetch(0);
+                for (uint32_t cb = 0; cb < cnt; cb += 4) {
+                    T cur[4];
+                    int ccur[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        cur[u] = ov[u];
+                        ccur[u] = cv[u];
+                    }
+                    if (cb + 4 < cnt) fetch(cb + 4);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (cb + u >= cnt) break;
+                        const uint32_t ia = slide ? iW : iX;
+                        T pred;
+                        if (slide) {
+                            const T wp3 = L[addr + (iW + 3 < na ? o_p3 : o_m1)];
+                            if (p.interp_id == 0) {
+                                if (defer && iW + 1 == na) pred = ip_linear1<T>(prev, wm1);
+                                else pred = lv_rule<T>(iW, na, wm3, wm1, wp1, wp3, 0);
+                            } else {
+                                pred = lv_cubic_sel<T>(iW, na, wm3, wm1, wp1, wp3);
+                            }
+                            wm3 = wm1;
+                            wm1 = wp1;
+                            wp1 = wp3;
+                        } else if (sub) {
+                            pred = ip_linear1<T>(k < 2 ? L[addr - 2] : Ls[iW * 33u + iU], L[addr + o_m1]);
+                        } else {
+                            const T xm3 = L[addr + e_m3], xm1 = L[addr + o_m1], xp1 = L[addr + e_p1], xp3 = L[addr + e_p3];
+                            if (p.interp_id == 0) pred = lv_rule<T>(iX, na, xm3, xm1, xp1, xp3, 0);
+                            else pred = lv_cubic_sel<T>(iX, na, xm3, xm1, xp1, xp3);
+                        }
+                        const bool owned = own_item && (k == 2 || iW + 1 < nW || lastW);
+                        const uint64_t gp = g;
+                        g += gstep;
+                        T v;
+                        if (DEC) {
+                            const int code = ccur[u];
+                            v = code ? ref_recover<T>(pred, code, p.eb, p.radius) : w[gp];  // code 0: the raw value, scattered in place before
+                            if (owned && code) w[gp] = v;
+                        } else {
+                            v = cur[u];
+                            const int code = (p.dbg & 16) ? (int)pred : lv_quantize<T>(v, pred, p.eb, p.eb_recip, p.radius);
+                            if (owned && !((p.dbg & 1) && code != 77)) {
+                                codes[gp] = (uint16_t)code;
+                                if (!p.no_store) w[gp] = v;
+                            }
+                        }
+                        if (k < 2) L[addr] = v;
+                        else if (!slide && defer && ia + 3 == na) Ls[iW * 33u + iU] = v;
+                        prev = v;
+                        iW += spW;
+                        addr += (int)dW;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // anchor grid (build_anchor_grid :215-221): every anchor_stride-th point in each dimension is stored losslessly;
 // without anchors (anchor_stride == 0) the first element is quantised against 0 (:92-93)
 template <typename T, typename IT = uint64_t, bool SINK = false>
 __device__ __forceinline__ void anchor_point(T *__restrict__ w, uint16_t *__restrict__ codes, const szk_interp_pass &p, uint64_t t,
-                                             uint64_t boff, const TrialSink *sink = nullptr) {
+                                             uint64_t boff, const TrialSink *sink = nullptr, const T *orig = nullptr) {
     IT r = (IT)t;
     uint64_t idx = 0;
 #pragma unroll
@@ -392,21 +680,22 @@ __device__ __forceinline__ void anchor_point(T *__restrict__ w, uint16_t *__rest
         r /= cj;
         idx += (p.start[j] + (uint64_t)q * p.step[j]) * p.off[j];
     }
-    T v = w[idx];
+    T v = orig ? orig[idx] : w[idx];
     int code = 0;
     if (p.subpass) {  // "no anchor" mode: one point, predicted by 0
         code = ref_quantize<T>(v, (T)0, p.eb, p.eb_recip, p.radius);
         if (code) w[idx] = v;
     }
+    if (orig && !code) w[idx] = v;  // (level kernels: the work array holds nothing but what the launches put there)
     if (SINK) sink_code(sink, (uint32_t)code);
     else codes[idx] = (uint16_t)code;
 }
 template <typename T>
-__global__ __launch_bounds__(256) void k_interp_anchors(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p) {
+__global__ __launch_bounds__(256) void k_interp_anchors(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p, const T *orig) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= p.total) return;
     const uint64_t boff = (uint64_t)blockIdx.y * p.batch_stride;
-    anchor_point<T>(w + boff, codes + boff, p, t, boff);
+    anchor_point<T>(w + boff, codes + boff, p, t, boff, nullptr, orig);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_interp_first_dec(T *__restrict__ w, const uint16_t *__restrict__ codes, double eb, int radius) {
@@ -743,12 +1032,77 @@ static int build_schedule(const szk_interp_params &ip, bool dec, uint32_t nbatch
     return 0;
 }
 
+// the level kernels apply to 3-D arrays whose index arithmetic fits their 32-bit fields and whose finest level has enough
+// blocks to fill the chip (smaller arrays: the per-pass kernels on a working copy)
+#define LV_MIN_BLOCKS 256
+int szk_interp_levels_ok(const szk_interp_params *ip) {
+    if (ip->N != 3 || szk_interp_novec) return 0;
+    uint64_t blocks = 1;
+    for (int j = 0; j < 3; j++) {
+        if (ip->dims[j] >= (1ull << 26)) return 0;
+        blocks *= ip->dims[j] > 1 ? (ip->dims[j] - 1 + 31) / 32 : 1;
+    }
+    if (ip->dims[1] * ip->dims[2] >= (1ull << 32)) return 0;
+    return blocks >= LV_MIN_BLOCKS;
+}
+// a level with few blocks leaves most of the chip idle in the level kernel (one workgroup per block, ~60 us each whatever
+// their number): such levels run pass by pass, one thread per point
+static uint64_t level_blocks(const szk_interp_pass &p) {
+    uint64_t tiles = 1;
+    for (int j = 0; j < 3; j++) {
+        const uint64_t g = (p.dims[j] - 1) / p.s + 1;
+        tiles *= g > 1 ? (g - 1 + 31) / 32 : 1;
+    }
+    return tiles;
+}
 template <typename T, bool DEC>
-static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStream_t s, uint32_t nbatch = 1) {
+static int launch_level(const szk_interp_pass &p, const int *perm, const T *in, T *w, uint16_t *codes, hipStream_t s) {
+    static const LvMagic mg = lv_magic_host();
+    szk_interp_level L;
+    memset(&L, 0, sizeof(L));
+    L.off[0] = (uint32_t)p.off[0];
+    L.off[1] = (uint32_t)p.off[1];
+    L.s = (uint32_t)p.s;
+    uint64_t tiles = 1;
+    for (int j = 0; j < 3; j++) {
+        L.g[j] = (uint32_t)((p.dims[j] - 1) / p.s + 1);
+        L.nt[j] = L.g[j] > 1 ? (L.g[j] - 1 + 31) / 32 : 1;
+        L.perm[j] = perm[j];
+        tiles *= L.nt[j];
+    }
+    if (tiles > 0x7FFFFFFFull) return -1;
+    L.interp_id = p.interp_id;
+    L.radius = p.radius;
+    L.no_store = !DEC && p.s == 1;  // the finest level's reconstruction is read by nobody
+    L.eb = p.eb;
+    L.eb_recip = p.eb_recip;
+    { const char *e = getenv("SZ3HIP_LVDBG"); L.dbg = e ? atoi(e) : 0; }
+    const size_t lds = (size_t)(LV_MAIN + LV_SIDE) * sizeof(T);
+    // (per device, and a context may sit on any of them: asked for at every launch, a host-side table lookup)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_interp_level<T, DEC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return -2;
+    hipLaunchKernelGGL((k_interp_level<T, DEC>), dim3((uint32_t)tiles), dim3(LV_NT), lds, s, in, w, codes, L, mg);
+    return 0;
+}
+
+// in: the originals (compression with the level kernels: never written; nullptr = w holds a working copy of them)
+template <typename T, bool DEC>
+static int run_interp(const szk_interp_params &ip, const T *in, T *w, uint16_t *codes, hipStream_t s, uint32_t nbatch = 1) {
     std::vector<szk_interp_pass> sched;
     if (build_schedule(ip, DEC, nbatch, sched)) return -1;
+    const bool levels = nbatch == 1 && szk_interp_levels_ok(&ip) && (DEC || in != nullptr);
+    int perm[4];
+    nth_permutation(ip.N, ip.direction, perm);
+    uint64_t level_done = 0;  // stride of the level the last level launch covered
     for (const szk_interp_pass &p : sched) {
         const uint32_t nb = (uint32_t)((p.total + 255) / 256);
+        if (levels && p.kind == 2 && level_blocks(p) >= LV_MIN_BLOCKS) {
+            if (p.s == level_done) continue;  // the other passes of a level already launched
+            level_done = p.s;
+            const int rc = launch_level<T, DEC>(p, perm, in, w, codes, s);
+            if (rc) return rc;
+            continue;
+        }
         const uint64_t dxl = p.dims[p.N - 1];
         const bool vec = p.kind == 2 && nbatch == 1 && p.interp_id == 1 && p.s == 1 && dxl % 4 == 0 && dxl >= 16 && dxl < (1ull << 31) &&
                          (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (reinterpret_cast<uintptr_t>(codes) & 15) == 0 && !szk_interp_novec;
@@ -773,11 +1127,11 @@ static int run_interp(const szk_interp_params &ip, T *w, uint16_t *codes, hipStr
             else SZK_VEC_LAUNCH(false, false);
 #undef SZK_VEC_LAUNCH
         } else if (p.kind == 2) {
-            hipLaunchKernelGGL((k_interp_pass<T, DEC>), dim3(nb, nbatch), dim3(256), 0, s, w, codes, p);
+            hipLaunchKernelGGL((k_interp_pass<T, DEC>), dim3(nb, nbatch), dim3(256), 0, s, w, codes, p, levels ? in : (const T *)nullptr);
         } else if (DEC) {
             hipLaunchKernelGGL((k_interp_first_dec<T>), dim3(1), dim3(64), 0, s, w, codes, ip.eb, ip.radius);
         } else {
-            hipLaunchKernelGGL((k_interp_anchors<T>), dim3(nb, nbatch), dim3(256), 0, s, w, codes, p);
+            hipLaunchKernelGGL((k_interp_anchors<T>), dim3(nb, nbatch), dim3(256), 0, s, w, codes, p, levels ? in : (const T *)nullptr);
         }
     }
     hipError_t e = hipGetLastError();
@@ -790,21 +1144,24 @@ int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const voi
     for (int i = 0; i < ip->N; i++) num *= ip->dims[i];
     const size_t tsz = dtype == 0 ? 4 : 8;
     hipError_t e = hipSuccess;
-    if (d_in) e = hipMemcpyAsync(d_work, d_in, num * tsz, hipMemcpyDeviceToDevice, s);  // the dispatcher's dataCopy
+    const bool levels = d_in && szk_interp_levels_ok(ip);  // level kernels: no working copy, the originals stay where they are
+    if (d_in && !levels) e = hipMemcpyAsync(d_work, d_in, num * tsz, hipMemcpyDeviceToDevice, s);  // the dispatcher's dataCopy
     if (e != hipSuccess) return (int)e;
-    int rc = dtype == 0 ? run_interp<float, false>(*ip, (float *)d_work, codes, s)
-                        : run_interp<double, false>(*ip, (double *)d_work, codes, s);
+    const void *orig = levels ? d_in : nullptr;
+    int rc = dtype == 0 ? run_interp<float, false>(*ip, (const float *)orig, (float *)d_work, codes, s)
+                        : run_interp<double, false>(*ip, (const double *)orig, (double *)d_work, codes, s);
     if (rc) return rc;
+    const void *raw_src = levels ? d_in : d_work;  // an unpredictable point's value: the original (kept in place by the passes)
     const bool smallr = ip->radius <= IH_WIN / 2;  // window start <= 0: code 0 lies inside it
     // tail passes: only with the large second tier (which covers radius +- 8192) and an alphabet that reaches beyond it
     const bool tails = ip->hist_big && ip->hist_tail && ip->radius > IHW_WIN && SZH_HIST_BINS == 65536;
 #define SZK_HIST_LAUNCH(T, SR)                                                                                                    \
     do {                                                                                                                          \
         if (ip->hist_big)                                                                                                         \
-            hipLaunchKernelGGL((k_hist_codes<T, SR, true>), dim3(256), dim3(1024), 0, s, codes, num, ip->radius, hist, (const T *)d_work, \
+            hipLaunchKernelGGL((k_hist_codes<T, SR, true>), dim3(256), dim3(1024), 0, s, codes, num, ip->radius, hist, (const T *)raw_src, \
                                ip->n_vout, ip->vout_idx, (T *)ip->vout_val, ip->out_cap, ip->far_cnt, tails ? 1u : 0u);           \
         else                                                                                                                      \
-            hipLaunchKernelGGL((k_hist_codes<T, SR, false>), dim3(512), dim3(512), 0, s, codes, num, ip->radius, hist, (const T *)d_work, \
+            hipLaunchKernelGGL((k_hist_codes<T, SR, false>), dim3(512), dim3(512), 0, s, codes, num, ip->radius, hist, (const T *)raw_src, \
                                ip->n_vout, ip->vout_idx, (T *)ip->vout_val, ip->out_cap, ip->far_cnt, 0u);                        \
     } while (0)
     if (dtype == 0) {
@@ -829,7 +1186,8 @@ int szk_launch_interp_decompress(int dtype, const szk_interp_params *ip, const u
         if (dtype == 0) hipLaunchKernelGGL((k_scatter_raw<float>), dim3(g), dim3(256), 0, s, payload, vout_idx_off, vout_val_off, n_vout, num, (float *)d_out);
         else hipLaunchKernelGGL((k_scatter_raw<double>), dim3(g), dim3(256), 0, s, payload, vout_idx_off, vout_val_off, n_vout, num, (double *)d_out);
     }
-    return dtype == 0 ? run_interp<float, true>(*ip, (float *)d_out, codes, s) : run_interp<double, true>(*ip, (double *)d_out, codes, s);
+    return dtype == 0 ? run_interp<float, true>(*ip, (const float *)nullptr, (float *)d_out, codes, s)
+                      : run_interp<double, true>(*ip, (const double *)nullptr, (double *)d_out, codes, s);
 }
 
 // ---- ALGO_INTERP_LORENZO tuner: device side (SZ_compress_Interp_lorenzo, api/impl/SZAlgoInterp.hpp:122-286) ---------

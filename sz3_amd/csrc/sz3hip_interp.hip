@@ -400,12 +400,11 @@ struct szk_interp_level {
     uint32_t nt[3];    // blocks per dimension
     int perm[3];       // pass k runs along dimension perm[k]
     int interp_id, radius, no_store;
-    int dbg;
     double eb, eb_recip;
 };
 #define LV_MAIN (33 * 33 * 17)
 #define LV_SIDE (33 * 33)
-#define LV_NT 512
+#define LV_NT 768
 struct LvMagic {
     uint32_t m[40];
 };
@@ -435,13 +434,14 @@ __device__ __forceinline__ T lv_rule(uint32_t i, uint32_t n, T m3, T m1, T p1, T
 
 // cubic mode without per-point branches: the three stencils a full block meets are computed and selected; the others (ragged
 // blocks' line ends) take the branch
-template <typename T>
+// FULL: the line has 33 points (every block but an axis' last one): the three stencils are all there is
+template <typename T, bool FULL>
 __device__ __forceinline__ T lv_cubic_sel(uint32_t i, uint32_t n, T m3, T m1, T p1, T p3) {
     const T c = ip_cubic<T>(m3, m1, p1, p3), q1 = ip_quad_1<T>(m1, p1, p3), q2 = ip_quad_2<T>(m3, m1, p1);
     const bool lo = i < 3, hi3 = i + 3 >= n;
     T r = lo ? q1 : c;
     r = (!lo && hi3) ? q2 : r;
-    if (i + 1 >= n || (lo && hi3)) r = lv_rule<T>(i, n, m3, m1, p1, p3, 1);
+    if (!FULL && (i + 1 >= n || (lo && hi3))) r = lv_rule<T>(i, n, m3, m1, p1, p3, 1);
     return r;
 }
 // ref_quantize with selects instead of its early returns (same arithmetic, same results)
@@ -461,6 +461,122 @@ __device__ __forceinline__ int lv_quantize(T &data, T pred, double eb, double re
     const bool ok = inr && fabs((double)ad) <= eb;
     data = ok ? dec : data;
     return ok ? shifted : 0;
+}
+
+// what a pass's item loop needs (all wave-uniform)
+template <typename T>
+struct LvPass {
+    const T *inb;       // originals, at the block's origin
+    T *wb;              // work array, at the block's origin
+    uint16_t *cb;       // codes, at the block's origin
+    T *L, *Ls;
+    uint32_t na, nW, c2, cU, cW, seglen, items, mg_c2, mg_cU;
+    uint32_t st2, sp2, stU, spU, stW, spW;
+    uint32_t strW, strU, dW;
+    uint32_t hX, hU, hW;   // 1: the LDS coordinate along that axis is half the index
+    int o_m3, o_m1, o_p1, o_p3;
+    uint32_t gX, gU, gW, gstep;  // element strides inside the block (32 bits: the host checked the block's span)
+    uint32_t ownU_lim, ownX_lim, ownW_lim;  // an index below the limit is owned (limit = n - 1, or n in the axis' last block)
+    int defer, no_store, radius;
+    double eb, eb_recip;
+};
+
+// SLIDE: the walk runs along the pass axis (sliding stencil); CUBIC: interp_id 1; LASTP: last pass of the level (its points
+// are not kept in LDS, only owned ones are computed)
+template <typename T, bool DEC, bool SLIDE, bool CUBIC, bool LASTP, bool FULL = false>
+__device__ __forceinline__ void lv_items(const LvPass<T> &q, uint32_t tid, int sub) {
+    T *__restrict__ L = q.L;
+    for (uint32_t it = tid; it < q.items; it += LV_NT) {
+        const uint32_t q2 = lv_div(it, q.c2, q.mg_c2), xi = it - q2 * q.c2;
+        const uint32_t sg = lv_div(q2, q.cU, q.mg_cU), ui = q2 - sg * q.cU;
+        const uint32_t iX = q.st2 + xi * q.sp2, iU = q.stU + ui * q.spU;
+        const uint32_t lw0 = sg * q.seglen;
+        const uint32_t cnt = q.cW - lw0 < q.seglen ? q.cW - lw0 : q.seglen;
+        uint32_t iW = q.stW + lw0 * q.spW;
+        if (!SLIDE && !CUBIC && (q.defer && iX + 1 == q.na) != (sub != 0)) continue;  // (pass along x: a row's deferred point is an item's)
+        int addr = (int)((iW >> q.hW) * q.strW + (iU >> q.hU) * q.strU + (iX >> q.hX));  // the point (passes 0, 1) or its lower neighbour
+        uint32_t go = iW * q.gW + iU * q.gU + iX * q.gX;
+        const bool own_item = LASTP || (iU < q.ownU_lim && iX < q.ownX_lim);
+        T wm3 = (T)0, wm1 = (T)0, wp1 = (T)0, prev = (T)0;
+        if (SLIDE) {  // (addresses outside the line fall back to a valid one: the rules do not use what they return)
+            wm3 = L[addr + (iW >= 3 ? q.o_m3 : q.o_m1)];
+            wm1 = L[addr + q.o_m1];
+            wp1 = L[addr + (iW + 1 < q.na ? q.o_p1 : q.o_m1)];
+        }
+        // pass along x: the item's position along the line is fixed, and so is what may be read
+        const int e_m3 = iX >= 3 ? q.o_m3 : q.o_m1, e_p1 = iX + 1 < q.na ? q.o_p1 : q.o_m1, e_p3 = iX + 3 < q.na ? q.o_p3 : q.o_m1;
+        // originals (codes) of the walk, four points ahead; beyond the walk's end the last point is read again
+        T ov[4];
+        int cv[4];
+        const uint32_t go_last = go + (cnt - 1) * q.gstep;
+        uint32_t gf = go;
+        auto fetch = [&]() {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t ga = gf < go_last ? gf : go_last;
+                if (DEC) cv[u] = q.cb[ga];
+                else ov[u] = q.inb[ga];
+                gf += q.gstep;
+            }
+        };
+        auto point = [&](T orig, int code_in) {
+            T pred;
+            if (SLIDE) {
+                const T wp3 = L[addr + (iW + 3 < q.na ? q.o_p3 : q.o_m1)];
+                if (CUBIC) pred = lv_cubic_sel<T, FULL>(iW, FULL ? 33u : q.na, wm3, wm1, wp1, wp3);
+                else if (q.defer && iW + 1 == q.na) pred = ip_linear1<T>(prev, wm1);
+                else pred = lv_rule<T>(iW, q.na, wm3, wm1, wp1, wp3, 0);
+                wm3 = wm1;
+                wm1 = wp1;
+                wp1 = wp3;
+            } else if (!CUBIC && sub) {
+                pred = ip_linear1<T>(LASTP ? q.Ls[iW * 33u + iU] : L[addr - 2], L[addr + q.o_m1]);
+            } else {
+                const T xm3 = L[addr + e_m3], xm1 = L[addr + q.o_m1], xp1 = L[addr + e_p1], xp3 = L[addr + e_p3];
+                if (CUBIC) pred = lv_cubic_sel<T, FULL>(iX, FULL ? 33u : q.na, xm3, xm1, xp1, xp3);
+                else pred = lv_rule<T>(iX, q.na, xm3, xm1, xp1, xp3, 0);
+            }
+            // (SLIDE: the walk's indices are odd, the last one of an axis lies in its last block: owned whenever the item is)
+            const bool owned = own_item && (SLIDE || LASTP || iW < q.ownW_lim);
+            T v;
+            if (DEC) {
+                v = code_in ? ref_recover<T>(pred, code_in, q.eb, q.radius) : q.wb[go];  // code 0: the raw value, scattered in place before
+                if (owned && code_in) q.wb[go] = v;
+            } else {
+                v = orig;
+                const int code = lv_quantize<T>(v, pred, q.eb, q.eb_recip, q.radius);
+                if (owned) {
+                    q.cb[go] = (uint16_t)code;
+                    if (!q.no_store) q.wb[go] = v;
+                }
+            }
+            if (!LASTP) L[addr] = v;
+            else if (!SLIDE && !CUBIC && q.defer && iX + 3 == q.na) q.Ls[iW * 33u + iU] = v;
+            prev = v;
+            iW += q.spW;
+            addr += (int)q.dW;
+            go += q.gstep;
+        };
+        fetch();
+        uint32_t c = 0;
+        for (; c + 4 <= cnt; c += 4) {
+            T cur[4];
+            int ccur[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                cur[u] = ov[u];
+                ccur[u] = cv[u];
+            }
+            fetch();
+#pragma unroll
+            for (int u = 0; u < 4; u++) point(cur[u], ccur[u]);
+        }
+        if (c < cnt) {  // (the last fetch holds the tail's points)
+            point(ov[0], cv[0]);
+            if (c + 1 < cnt) point(ov[1], cv[1]);
+            if (c + 2 < cnt) point(ov[2], cv[2]);
+        }
+    }
 }
 
 // Work of a pass: ITEMS = (index along x) x (index along the other non-walk axis) x (segment of the walk); a thread takes an
@@ -488,7 +604,7 @@ __global__ __launch_bounds__(LV_NT) void k_interp_level(const T *__restrict__ in
     const uint64_t gs0 = (uint64_t)p.s * p.off[0], gs1 = (uint64_t)p.s * p.off[1];
     const uint64_t gbase = (uint64_t)(t0 * 32) * gs0 + (uint64_t)(t1 * 32) * gs1 + (uint64_t)(t2 * 32) * p.s;
     // ---- load: the coarse points (every coordinate even) from w ----
-    if (!(p.dbg & 32)) {
+    {
         const uint32_t e0 = (n0 + 1) >> 1, e1 = (n1 + 1) >> 1, e2 = (n2 + 1) >> 1;
         const uint32_t total = e0 * e1 * e2;
         const uint32_t k0 = (aL == 0 ? 1u : 2u) * str0, k1 = (aL == 1 ? 1u : 2u) * str1, k2 = aL == 2 ? 1u : 2u;
@@ -517,8 +633,6 @@ __global__ __launch_bounds__(LV_NT) void k_interp_level(const T *__restrict__ in
         const int a = p.perm[k];
         const uint32_t na = sel3(a, n0, n1, n2);
         if (na < 2) continue;
-        if ((p.dbg & 4) && k == 2) continue;
-        if ((p.dbg & 8) && k < 2) continue;
         const bool defer = p.interp_id == 0 && na >= 3 && !(na & 1u);
         // point set of the pass: odd along a, every index along the axes of earlier passes, even ones along later axes;
         // the last pass computes owned points only (nobody reads the others)
@@ -565,100 +679,54 @@ __global__ __launch_bounds__(LV_NT) void k_interp_level(const T *__restrict__ in
             }
         }
         const uint32_t nseg = (cW + seglen - 1) / seglen;
-        const uint32_t items = c2 * cU * nseg;
-        const uint32_t mg_c2 = mg.m[c2], mg_cU = mg.m[cU];
-        for (int sub = 0; sub < (defer && !slide ? 2 : 1); sub++) {
-            if (sub) __syncthreads();
-            for (uint32_t it = tid; it < items; it += LV_NT) {
-                const uint32_t q2 = lv_div(it, c2, mg_c2), xi = it - q2 * c2;
-                const uint32_t sg = lv_div(q2, cU, mg_cU), ui = q2 - sg * cU;
-                const uint32_t iX = st2 + xi * sp2, iU = stU + ui * spU;
-                const uint32_t lw0 = sg * seglen;
-                const uint32_t cnt = cW - lw0 < seglen ? cW - lw0 : seglen;
-                uint32_t iW = stW + lw0 * spW;
-                if (!slide && (defer && iX + 1 == na) != (sub != 0)) continue;  // (pass along x: a row's deferred point is an item's)
-                const uint32_t xX = aL == 2 ? iX >> 1 : iX, xU = aL == U ? iU >> 1 : iU, xW = aL == W ? iW >> 1 : iW;
-                int addr = (int)(xW * strW + xU * strU + xX);  // the point itself (passes 0, 1) or its lower neighbour (last pass)
-                uint64_t g = gbase + (uint64_t)iW * gsW + (uint64_t)iU * gsU + (uint64_t)(iX * p.s);
-                const bool own_item = k == 2 || ((iU + 1 < nU || lastU) && (iX + 1 < n2 || last2));
-                // sliding stencil along the walk (slide), else the fixed position of the item along x
-                T wm3 = (T)0, wm1 = (T)0, wp1 = (T)0, prev = (T)0;
-                if (slide) {  // (addresses outside the line fall back to a valid one: the rules do not use what they return)
-                    wm3 = L[addr + (iW >= 3 ? o_m3 : o_m1)];
-                    wm1 = L[addr + o_m1];
-                    wp1 = L[addr + (iW + 1 < na ? o_p1 : o_m1)];
-                }
-                // pass along x: the item's position along the line is fixed, and so is what may be read
-                const int e_m3 = iX >= 3 ? o_m3 : o_m1, e_p1 = iX + 1 < na ? o_p1 : o_m1, e_p3 = iX + 3 < na ? o_p3 : o_m1;
-                // originals (codes) of the walk, four points ahead
-                T ov[4];
-                int cv[4];
-                uint64_t gf = g;  // where the next fetch starts
-                auto fetch = [&](uint32_t from) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (from + u < cnt) {
-                            if (DEC) cv[u] = codes[gf];
-                            else ov[u] = (p.dbg & 2) ? (T)u : in[gf];
-                        }
-                        gf += gstep;
-                    }
-                };
-                fetch(0);
-                for (uint32_t cb = 0; cb < cnt; cb += 4) {
-                    T cur[4];
-                    int ccur[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        cur[u] = ov[u];
-                        ccur[u] = cv[u];
-                    }
-                    if (cb + 4 < cnt) fetch(cb + 4);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (cb + u >= cnt) break;
-                        const uint32_t ia = slide ? iW : iX;
-                        T pred;
-                        if (slide) {
-                            const T wp3 = L[addr + (iW + 3 < na ? o_p3 : o_m1)];
-                            if (p.interp_id == 0) {
-                                if (defer && iW + 1 == na) pred = ip_linear1<T>(prev, wm1);
-                                else pred = lv_rule<T>(iW, na, wm3, wm1, wp1, wp3, 0);
-                            } else {
-                                pred = lv_cubic_sel<T>(iW, na, wm3, wm1, wp1, wp3);
-                            }
-                            wm3 = wm1;
-                            wm1 = wp1;
-                            wp1 = wp3;
-                        } else if (sub) {
-                            pred = ip_linear1<T>(k < 2 ? L[addr - 2] : Ls[iW * 33u + iU], L[addr + o_m1]);
-                        } else {
-                            const T xm3 = L[addr + e_m3], xm1 = L[addr + o_m1], xp1 = L[addr + e_p1], xp3 = L[addr + e_p3];
-                            if (p.interp_id == 0) pred = lv_rule<T>(iX, na, xm3, xm1, xp1, xp3, 0);
-                            else pred = lv_cubic_sel<T>(iX, na, xm3, xm1, xp1, xp3);
-                        }
-                        const bool owned = own_item && (k == 2 || iW + 1 < nW || lastW);
-                        const uint64_t gp = g;
-                        g += gstep;
-                        T v;
-                        if (DEC) {
-                            const int code = ccur[u];
-                            v = code ? ref_recover<T>(pred, code, p.eb, p.radius) : w[gp];  // code 0: the raw value, scattered in place before
-                            if (owned && code) w[gp] = v;
-                        } else {
-                            v = cur[u];
-                            const int code = (p.dbg & 16) ? (int)pred : lv_quantize<T>(v, pred, p.eb, p.eb_recip, p.radius);
-                            if (owned && !((p.dbg & 1) && code != 77)) {
-                                codes[gp] = (uint16_t)code;
-                                if (!p.no_store) w[gp] = v;
-                            }
-                        }
-                        if (k < 2) L[addr] = v;
-                        else if (!slide && defer && ia + 3 == na) Ls[iW * 33u + iU] = v;
-                        prev = v;
-                        iW += spW;
-                        addr += (int)dW;
-                    }
+        LvPass<T> q;
+        q.inb = in + gbase;
+        q.wb = w + gbase;
+        q.cb = codes + gbase;
+        q.L = L;
+        q.Ls = Ls;
+        q.na = na;
+        q.nW = nW;
+        q.c2 = c2;
+        q.cU = cU;
+        q.cW = cW;
+        q.seglen = seglen;
+        q.items = c2 * cU * nseg;
+        q.mg_c2 = mg.m[c2];
+        q.mg_cU = mg.m[cU];
+        q.st2 = st2; q.sp2 = sp2; q.stU = stU; q.spU = spU; q.stW = stW; q.spW = spW;
+        q.strW = strW; q.strU = strU; q.dW = dW;
+        q.hX = aL == 2; q.hU = aL == U; q.hW = aL == W;
+        q.o_m3 = o_m3; q.o_m1 = o_m1; q.o_p1 = o_p1; q.o_p3 = o_p3;
+        q.gX = p.s; q.gU = (uint32_t)gsU; q.gW = (uint32_t)gsW; q.gstep = (uint32_t)gstep;
+        q.ownU_lim = lastU ? nU : nU - 1;
+        q.ownX_lim = last2 ? n2 : n2 - 1;
+        q.ownW_lim = lastW ? nW : nW - 1;
+        q.defer = defer; q.no_store = p.no_store; q.radius = p.radius;
+        q.eb = p.eb; q.eb_recip = p.eb_recip;
+        const bool cubic = p.interp_id != 0;
+        const bool full = cubic && na == 33;
+        if (slide) {
+            if (k == 2) {
+                if (full) lv_items<T, DEC, true, true, true, true>(q, tid, 0);
+                else if (cubic) lv_items<T, DEC, true, true, true>(q, tid, 0);
+                else lv_items<T, DEC, true, false, true>(q, tid, 0);
+            } else {
+                if (full) lv_items<T, DEC, true, true, false, true>(q, tid, 0);
+                else if (cubic) lv_items<T, DEC, true, true, false>(q, tid, 0);
+                else lv_items<T, DEC, true, false, false>(q, tid, 0);
+            }
+        } else {
+            for (int sub = 0; sub < (defer ? 2 : 1); sub++) {
+                if (sub) __syncthreads();
+                if (k == 2) {
+                    if (full) lv_items<T, DEC, false, true, true, true>(q, tid, sub);
+                    else if (cubic) lv_items<T, DEC, false, true, true>(q, tid, sub);
+                    else lv_items<T, DEC, false, false, true>(q, tid, sub);
+                } else {
+                    if (full) lv_items<T, DEC, false, true, false, true>(q, tid, sub);
+                    else if (cubic) lv_items<T, DEC, false, true, false>(q, tid, sub);
+                    else lv_items<T, DEC, false, false, false>(q, tid, sub);
                 }
             }
         }
@@ -1053,6 +1121,8 @@ static uint64_t level_blocks(const szk_interp_pass &p) {
         const uint64_t g = (p.dims[j] - 1) / p.s + 1;
         tiles *= g > 1 ? (g - 1 + 31) / 32 : 1;
     }
+    // (the kernel addresses a block's elements with 32-bit offsets from the block's origin)
+    if (33 * p.s * (p.off[0] + p.off[1] + 1) >= (1ull << 31)) return 0;
     return tiles;
 }
 template <typename T, bool DEC>
@@ -1076,7 +1146,6 @@ static int launch_level(const szk_interp_pass &p, const int *perm, const T *in, 
     L.no_store = !DEC && p.s == 1;  // the finest level's reconstruction is read by nobody
     L.eb = p.eb;
     L.eb_recip = p.eb_recip;
-    { const char *e = getenv("SZ3HIP_LVDBG"); L.dbg = e ? atoi(e) : 0; }
     const size_t lds = (size_t)(LV_MAIN + LV_SIDE) * sizeof(T);
     // (per device, and a context may sit on any of them: asked for at every launch, a host-side table lookup)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_interp_level<T, DEC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -171,12 +171,14 @@ __device__ __forceinline__ T reg_predict(const T (&c)[4], uint32_t i0, uint32_t 
 // ------------------------------------------------------------------------------------------------------------
 // encoder pass 1: fit, select, regression blocks coded; q~ of every element written to qwork
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, uint32_t HW, int CB>
-__global__ __launch_bounds__(256) void k_blk_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
+// NW: waves (= blocks in flight) per workgroup; they share the LDS histogram, so the wide form (64 KB of bins) takes 16 of them to
+// keep four waves per SIMD busy (with 4 the two passes ran at two waves per SIMD, bound by the latency of their tile loads)
+template <typename T, uint32_t HW, int CB, int NW>
+__global__ __launch_bounds__(NW * 64) void k_blk_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;
-    __shared__ T s_x[4][CB ? (CB + 2) * (CB + 2) * (CB + 2) : BLK_TILE];
+    __shared__ T s_x[NW][CB ? (CB + 2) * (CB + 2) * (CB + 2) : BLK_TILE];
     __shared__ uint32_t lh[HW];
-    for (uint32_t b = threadIdx.x; b < HW; b += 256) lh[b] = 0;
+    for (uint32_t b = threadIdx.x; b < HW; b += NW * 64) lh[b] = 0;
     __syncthreads();
     const Lattice<T> lat(p.lat);
     const int lane = lane_id();
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void k_blk_fit(const T *__restrict__ in, uint1
     const CoefLat cl = coef_lat(p.eb, p.B);
     const double eb_recip = 1.0 / p.eb;
     const bool has_l1 = p.mask & 1u, has_l2 = p.mask & 2u, has_r = p.mask & 4u;
-    for (uint32_t task = blockIdx.x * 4 + wv; task < nblocks; task += gridDim.x * 4) {
+    for (uint32_t task = blockIdx.x * NW + wv; task < nblocks; task += gridDim.x * NW) {
         const BlkGeom g = blk_geom(p, task);
         // ---- originals of the block and two low halo layers (zero outside the array, like the reference's padding) ----
         for (uint32_t t = lane; t < E * E * E; t += WAVE) {
@@ -227,13 +229,17 @@ __global__ __launch_bounds__(256) void k_blk_fit(const T *__restrict__ in, uint1
             s1 = wave_sum_f64(s1);
             s2 = wave_sum_f64(s2);
             s3 = wave_sum_f64(s3);
+            // the three slopes have the same expression (RegressionPredictor.hpp:43-52): lanes 0..2 evaluate one each (a double
+            // division is ~40 instructions, ten of them were a fifth of the pass), then everybody takes the results
             const double dz = g.ez, dy = g.ey, dx = g.ex, num = dz * dy * dx;
+            const double sk = lane == 0 ? s0 : (lane == 1 ? s1 : s2), dk = lane == 0 ? dz : (lane == 1 ? dy : dx);
+            const T ck = (T)((2 * sk / (dk - 1) - s3) * 6 / num / (dk + 1));
+            cf[0] = __shfl(ck, 0, WAVE);
+            cf[1] = __shfl(ck, 1, WAVE);
+            cf[2] = __shfl(ck, 2, WAVE);
             cf[3] = (T)(s3 / num);
-            cf[0] = (T)((2 * s0 / (dz - 1) - s3) * 6 / num / (dz + 1));
             cf[3] = (T)((double)cf[3] - (dz - 1) * (double)cf[0] / 2);
-            cf[1] = (T)((2 * s1 / (dy - 1) - s3) * 6 / num / (dy + 1));
             cf[3] = (T)((double)cf[3] - (dy - 1) * (double)cf[1] / 2);
-            cf[2] = (T)((2 * s2 / (dx - 1) - s3) * 6 / num / (dx + 1));
             cf[3] = (T)((double)cf[3] - (dx - 1) * (double)cf[2] / 2);
         }
         // ---- selection (ComposedPredictor.hpp:25-40 over foreach_sampling) ----
@@ -330,13 +336,13 @@ __global__ __launch_bounds__(256) void k_blk_fit(const T *__restrict__ in, uint1
 // ------------------------------------------------------------------------------------------------------------
 // encoder pass 2: Lorenzo blocks — integer stencil over q~ (block + two low halo layers in LDS)
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, uint32_t HW, int CB>
-__global__ __launch_bounds__(256) void k_blk_lorenzo(uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
+template <typename T, uint32_t HW, int CB, int NW>
+__global__ __launch_bounds__(NW * 64) void k_blk_lorenzo(uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
-    __shared__ Q s_q[4][CB ? (CB + 2) * (CB + 2) * (CB + 2) : BLK_TILE];
+    __shared__ Q s_q[NW][CB ? (CB + 2) * (CB + 2) * (CB + 2) : BLK_TILE];
     __shared__ uint32_t lh[HW];
-    for (uint32_t b = threadIdx.x; b < HW; b += 256) lh[b] = 0;
+    for (uint32_t b = threadIdx.x; b < HW; b += NW * 64) lh[b] = 0;
     __syncthreads();
     const int lane = lane_id();
     const uint32_t wv = threadIdx.x / WAVE;
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(256) void k_blk_lorenzo(uint16_t *__restrict__ code
     const uint32_t B = CB ? (uint32_t)CB : p.B, E = B + 2;
     const uint64_t d1 = p.d[1], d2 = p.d[2];
     const Q *qwork = reinterpret_cast<const Q *>(p.qwork);
-    for (uint32_t task = blockIdx.x * 4 + wv; task < nblocks; task += gridDim.x * 4) {
+    for (uint32_t task = blockIdx.x * NW + wv; task < nblocks; task += gridDim.x * NW) {
         const int sid = p.sel[task];
         if (sid == 2) continue;
         const int order = sid == 1 ? 2 : 1;
@@ -367,12 +373,27 @@ __global__ __launch_bounds__(256) void k_blk_lorenzo(uint16_t *__restrict__ code
             own_index<CB>(g, tt, i0, i1, i2);
             const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
             UQ delta = 0;  // wrap-around arithmetic like the plain Lorenzo stream
-            for (int k = 0; k <= order; k++)
-                for (int j = 0; j <= order; j++)
-                    for (int i = 0; i <= order; i++) {
-                        const int w = lz_w(order, k) * lz_w(order, j) * lz_w(order, i);
-                        delta += (UQ)((Q)w * sq[tile_at(E, i0 + 2 - k, i1 + 2 - j, i2 + 2 - i)]);
-                    }
+            if (order == 1) {  // (wave-uniform; the stencils unrolled with their constant weights)
+#pragma unroll
+                for (int k = 0; k <= 1; k++)
+#pragma unroll
+                    for (int j = 0; j <= 1; j++)
+#pragma unroll
+                        for (int i = 0; i <= 1; i++) {
+                            const UQ v = (UQ)sq[tile_at(E, i0 + 2 - k, i1 + 2 - j, i2 + 2 - i)];
+                            delta = ((k + j + i) & 1) ? delta - v : delta + v;
+                        }
+            } else {
+#pragma unroll
+                for (int k = 0; k <= 2; k++)
+#pragma unroll
+                    for (int j = 0; j <= 2; j++)
+#pragma unroll
+                        for (int i = 0; i <= 2; i++) {
+                            const int w = lz_w(2, k) * lz_w(2, j) * lz_w(2, i);
+                            delta += (UQ)((Q)w * sq[tile_at(E, i0 + 2 - k, i1 + 2 - j, i2 + 2 - i)]);
+                        }
+            }
             const bool inr = (UQ)(delta + (UQ)(p.radius - 1)) <= (UQ)(2 * p.radius - 2);
             const uint32_t code = inr ? (uint32_t)(delta + (UQ)p.radius) : 0u;
             if (act) codes[g.coff + t] = (uint16_t)code;
@@ -893,25 +914,27 @@ static uint32_t blk_count_blocks(const szk_blk_params *p) { return p->nb[0] * p-
 
 int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s) {
     const uint32_t nblocks = blk_count_blocks(p);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
-#define BLK_ENC(T, HW)                                                                                                   \
-    do {                                                                                                                 \
-        if (p->B == 6) {                                                                                                  \
-            hipLaunchKernelGGL((k_blk_fit<T, HW, 6>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, *p, nblocks); \
-            hipLaunchKernelGGL((k_blk_lorenzo<T, HW, 6>), dim3(grid), dim3(256), 0, s, codes, *p, nblocks);             \
-        } else {                                                                                                         \
-            hipLaunchKernelGGL((k_blk_fit<T, HW, 0>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, *p, nblocks); \
-            hipLaunchKernelGGL((k_blk_lorenzo<T, HW, 0>), dim3(grid), dim3(256), 0, s, codes, *p, nblocks);             \
-        }                                                                                                                \
+#define BLK_ENC1(T, HW, CBV, NW)                                                                                                       \
+    do {                                                                                                                               \
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                        \
+        hipLaunchKernelGGL((k_blk_fit<T, HW, CBV, NW>), dim3(grid), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks);          \
+        hipLaunchKernelGGL((k_blk_lorenzo<T, HW, CBV, NW>), dim3(grid), dim3(NW * 64), 0, s, codes, *p, nblocks);                       \
+    } while (0)
+    // (LDS: NW tiles of (B + 2)^3 values + the histogram window; the generic-edge form's tiles hold 1000 values)
+#define BLK_ENC(T, HW, NW6, NW0)                  \
+    do {                                          \
+        if (p->B == 6) BLK_ENC1(T, HW, 6, NW6);   \
+        else BLK_ENC1(T, HW, 0, NW0);             \
     } while (0)
     if (dtype == 0) {
-        if (sc->wide_hist) BLK_ENC(float, BLK_HWIN_WIDE);
-        else BLK_ENC(float, BLK_HWIN);
+        if (sc->wide_hist) BLK_ENC(float, BLK_HWIN_WIDE, 16, 16);
+        else BLK_ENC(float, BLK_HWIN, 4, 4);
     } else {
-        if (sc->wide_hist) BLK_ENC(double, BLK_HWIN_WIDE);
-        else BLK_ENC(double, BLK_HWIN);
+        if (sc->wide_hist) BLK_ENC(double, BLK_HWIN_WIDE, 16, 8);
+        else BLK_ENC(double, BLK_HWIN, 4, 4);
     }
 #undef BLK_ENC
+#undef BLK_ENC1
     launch_blk_rank(p->sel, nblocks, sc->rank, sc->comp, sc->run_scratch, sc->counters + 0, s);
     // (counters: [0] regression blocks, [2] side bytes, [4..7] as doubles: sum of the zigzagged differences per coefficient;
     // the group sizes are staged in the rank array, which the encoder needs no more once comp is written)

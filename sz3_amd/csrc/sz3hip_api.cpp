@@ -1146,7 +1146,8 @@ extern "C" int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, ui
 extern "C" void sz3hip_debug_force_generic(int on) { szk_force_generic = on; }
 extern "C" void sz3hip_debug_flags(int flags) {
     szk_dbg_flags = flags;
-    szk_interp_novec = (flags & 128) != 0;  // 128: interpolation without the 8-wide level-1 kernels
+    szk_interp_novec = (flags & 128) != 0;  // 128: interpolation without the 8-wide level-1 kernels and without the level kernels
+    szk_interp_min_blocks = (flags & 4194304) ? 1 : 256;  // 4194304: level kernels whatever the array's size
 }
 extern "C" int sz3hip_debug_codebook_info(sz3hip_ctx *ctx, uint64_t *out16) {
     HIPCHK(hipSetDevice(ctx->device));

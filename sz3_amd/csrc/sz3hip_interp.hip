@@ -1103,6 +1103,7 @@ static int build_schedule(const szk_interp_params &ip, bool dec, uint32_t nbatch
 // the level kernels apply to 3-D arrays whose index arithmetic fits their 32-bit fields and whose finest level has enough
 // blocks to fill the chip (smaller arrays: the per-pass kernels on a working copy)
 #define LV_MIN_BLOCKS 256
+int szk_interp_min_blocks = LV_MIN_BLOCKS;  // test hook: 1 sends every level of every 3-D array through the level kernel
 int szk_interp_levels_ok(const szk_interp_params *ip) {
     if (ip->N != 3 || szk_interp_novec) return 0;
     uint64_t blocks = 1;
@@ -1111,7 +1112,7 @@ int szk_interp_levels_ok(const szk_interp_params *ip) {
         blocks *= ip->dims[j] > 1 ? (ip->dims[j] - 1 + 31) / 32 : 1;
     }
     if (ip->dims[1] * ip->dims[2] >= (1ull << 32)) return 0;
-    return blocks >= LV_MIN_BLOCKS;
+    return blocks >= (uint64_t)szk_interp_min_blocks;
 }
 // a level with few blocks leaves most of the chip idle in the level kernel (one workgroup per block, ~60 us each whatever
 // their number): such levels run pass by pass, one thread per point
@@ -1165,7 +1166,7 @@ static int run_interp(const szk_interp_params &ip, const T *in, T *w, uint16_t *
     uint64_t level_done = 0;  // stride of the level the last level launch covered
     for (const szk_interp_pass &p : sched) {
         const uint32_t nb = (uint32_t)((p.total + 255) / 256);
-        if (levels && p.kind == 2 && level_blocks(p) >= LV_MIN_BLOCKS) {
+        if (levels && p.kind == 2 && level_blocks(p) >= (uint64_t)szk_interp_min_blocks) {
             if (p.s == level_done) continue;  // the other passes of a level already launched
             level_done = p.s;
             const int rc = launch_level<T, DEC>(p, perm, in, w, codes, s);

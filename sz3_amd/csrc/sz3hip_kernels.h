@@ -215,6 +215,7 @@ struct szk_interp_pass {
     uint64_t out_cap;
 };
 extern int szk_interp_novec;
+extern int szk_interp_min_blocks;
 // 1: the array runs through the level kernels (one launch per level, no working copy of the input)
 int szk_interp_levels_ok(const szk_interp_params *ip);
 // d_in == nullptr: d_work already holds the copy of the input (made on a side stream while the tuner ran)

@@ -103,6 +103,70 @@ def test_interp_bit_exact_with_oracle(name, gen, eb, kw):
     assert np.max(np.abs(dec[m].astype(np.float64) - a[m].astype(np.float64))) <= eb
 
 
+LEVEL_CASES = [c for c in CASES if c[0].startswith("3d")] + [
+    # shapes chosen for the level kernels: several blocks per axis with ragged last blocks (line lengths 33, 32, even, 2, 1),
+    # every direction order, linear mode's extrapolated line ends, anchors on and off, f64
+    ("lv-cubic-97x66x130", lambda: field3d((97, 66, 130)), 1e-3, dict(interpAlgo=1)),
+    ("lv-cubic-dir5-65x64x96", lambda: field3d((65, 64, 96)), 1e-4, dict(interpAlgo=1, interpDirection=5)),
+    ("lv-cubic-dir1-70x99x34", lambda: field3d((70, 99, 34)), 1e-3, dict(interpAlgo=1, interpDirection=1)),
+    ("lv-cubic-dir2-34x67x100", lambda: field3d((34, 67, 100)), 1e-3, dict(interpAlgo=1, interpDirection=2, interpAlpha=1.5, interpBeta=3.0)),
+    ("lv-cubic-dir3-66x35x68", lambda: field3d((66, 35, 68)), 1e-3, dict(interpAlgo=1, interpDirection=3)),
+    ("lv-cubic-dir4-36x98x67", lambda: field3d((36, 98, 67)), 1e-3, dict(interpAlgo=1, interpDirection=4)),
+    ("lv-linear-68x66x100", lambda: field3d((68, 66, 100)), 1e-3, dict(interpAlgo=0)),
+    ("lv-linear-dir5-36x70x98", lambda: field3d((36, 70, 98)), 1e-2, dict(interpAlgo=0, interpDirection=5)),
+    ("lv-linear-dir2-100x34x36", lambda: field3d((100, 34, 36)), 1e-3, dict(interpAlgo=0, interpDirection=2)),
+    ("lv-linear-dir1-noanchor-38x40x70", lambda: field3d((38, 40, 70)), 1e-3, dict(interpAlgo=0, interpDirection=1, interpAnchorStride=0)),
+    ("lv-noanchor-67x65x66", lambda: field3d((67, 65, 66)), 1e-3, dict(interpAlgo=1, interpAnchorStride=0, interpAlpha=-1.0)),
+    ("lv-anchor8-40x73x61", lambda: field3d((40, 73, 61)), 1e-2, dict(interpAlgo=1, interpAnchorStride=8)),
+    ("lv-f64-dir5-66x40x97", lambda: field3d((66, 40, 97), np.float64, sigma=2e-6), 1e-6, dict(interpAlgo=1, interpDirection=5)),
+    ("lv-f64-linear-35x66x70", lambda: field3d((35, 66, 70), np.float64, sigma=2e-6), 1e-6, dict(interpAlgo=0)),
+    ("lv-thin-3x130x131", lambda: field3d((3, 130, 131)), 1e-3, dict(interpAlgo=1)),
+    ("lv-thin-dir5-130x2x131", lambda: field3d((130, 2, 131)), 1e-3, dict(interpAlgo=1, interpDirection=5)),
+    ("lv-qbin256-66x40x70", lambda: field3d((66, 40, 70)), 1e-2, dict(interpAlgo=1, quantbinCnt=256)),
+]
+
+
+@pytest.mark.parametrize("name,gen,eb,kw", LEVEL_CASES, ids=[c[0] for c in LEVEL_CASES])
+def test_level_kernels_bit_exact_with_oracle(name, gen, eb, kw):
+    """debug flag 4194304 sends every level of every 3-D array through the level kernels (one launch per level, a block's three
+    passes in LDS; normally taken from 256 blocks up): codes, unpredictable set and reconstruction against the oracle."""
+    try:
+        sz3_amd.lib().sz3hip_debug_flags(4194304)
+        test_interp_bit_exact_with_oracle(name, gen, eb, kw)
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(0)
+
+
+@pytest.mark.parametrize("kw", [dict(interpAlgo=1), dict(interpAlgo=1, interpDirection=5), dict(interpAlgo=0)], ids=["cubic", "cubic-dir5", "linear"])
+def test_level_kernels_at_their_natural_size(kw):
+    """231 x 200 x 193: 8 x 7 x 7 blocks at the finest level (the level kernels' own routing: fine levels in the level kernel, coarse
+    ones pass by pass on the same work array), against the oracle; and the same bytes as the per-pass path (flag 128)"""
+    a = field3d((231, 200, 193))
+    a[100, 50, 60] = np.nan
+    a[7, 199, 192] = 1e30
+    test_interp_bit_exact_with_oracle("3d-natural", lambda: a.copy(), 1e-3, kw)
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    cap = dc.payload_bound(a.size)
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_INTERP
+    conf.absErrorBound = 1e-3
+    for k, v in kw.items():
+        setattr(conf, k, v)
+    res = []
+    try:
+        for flag in (0, 128):
+            sz3_amd.lib().sz3hip_debug_flags(flag)
+            pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+            n = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+            torch.cuda.synchronize()
+            res.append(pl[:n].clone())
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(0)
+    assert res[0].numel() == res[1].numel() and torch.equal(res[0], res[1])
+
+
 def test_interp_host_api_and_ratio():
     a = field3d((96, 96, 96))
     conf = sz3_amd.Config(*a.shape)

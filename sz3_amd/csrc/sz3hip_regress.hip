@@ -740,6 +740,76 @@ __global__ __launch_bounds__(1024) void k_blk_coef_scan(uint64_t nr, int64_t *__
 // decoder: one anti-diagonal front of blocks per launch, one wave per block. d_out holds lattice values q~ (Q) until the
 // final pass turns them into T.
 // ------------------------------------------------------------------------------------------------------------
+// the three line-scan passes that invert a block's stencil from its low halo, the stencil order a compile-time constant
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+}
+template <typename T, int CB, int ORDER>
+__device__ __forceinline__ void blk_invert(typename QTraits<T>::Q *sq, typename QTraits<T>::Q *sa, typename QTraits<T>::Q *qout, const BlkGeom &g,
+                                           uint32_t E, uint64_t d1, uint64_t d2, int lane) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    wave_lds_fence();
+    // ---- pass along x: a = Dy^m Dz^m q on the two halo columns, then the recurrence over the own columns ----
+    for (uint32_t l = lane; l < g.ez * g.ey; l += WAVE) {
+        const uint32_t tz = l / g.ey + 2, ty = l % g.ey + 2;
+        UQ a[2];
+#pragma unroll
+        for (uint32_t tx = 0; tx < 2; tx++) {
+            UQ s = 0;
+#pragma unroll
+            for (int k = 0; k <= ORDER; k++)
+#pragma unroll
+                for (int j = 0; j <= ORDER; j++) s += (UQ)((Q)(lz_w(ORDER, k) * lz_w(ORDER, j)) * sq[tile_at(E, tz - k, ty - j, tx)]);
+            a[tx] = s;
+        }
+        UQ p2 = a[0], p1 = a[1];
+        for (uint32_t tx = 2; tx < 2 + g.ex; tx++) {
+            const UQ in = (UQ)sq[tile_at(E, tz, ty, tx)];
+            const UQ v = ORDER == 1 ? p1 + in : (UQ)(2 * p1 - p2 + in);
+            sa[tile_at(E, tz, ty, tx)] = (Q)v;
+            p2 = p1;
+            p1 = v;
+        }
+    }
+    wave_lds_fence();
+    // ---- pass along y: b = Dz^m q on the two halo rows (own columns), recurrence over the own rows ----
+    for (uint32_t l = lane; l < g.ez * g.ex; l += WAVE) {
+        const uint32_t tz = l / g.ex + 2, tx = l % g.ex + 2;
+        UQ b[2];
+#pragma unroll
+        for (uint32_t ty = 0; ty < 2; ty++) {
+            UQ s = 0;
+#pragma unroll
+            for (int k = 0; k <= ORDER; k++) s += (UQ)((Q)lz_w(ORDER, k) * sq[tile_at(E, tz - k, ty, tx)]);
+            b[ty] = s;
+        }
+        UQ p2 = b[0], p1 = b[1];
+        for (uint32_t ty = 2; ty < 2 + g.ey; ty++) {
+            const UQ in = (UQ)sa[tile_at(E, tz, ty, tx)];
+            const UQ v = ORDER == 1 ? p1 + in : (UQ)(2 * p1 - p2 + in);
+            sa[tile_at(E, tz, ty, tx)] = (Q)v;
+            p2 = p1;
+            p1 = v;
+        }
+    }
+    wave_lds_fence();
+    // ---- pass along z: inflow = q~ of the two halo planes; the result is q ----
+    for (uint32_t l = lane; l < g.ey * g.ex; l += WAVE) {
+        const uint32_t ty = l / g.ex + 2, tx = l % g.ex + 2;
+        UQ p2 = (UQ)sq[tile_at(E, 0, ty, tx)], p1 = (UQ)sq[tile_at(E, 1, ty, tx)];
+        for (uint32_t tz = 2; tz < 2 + g.ez; tz++) {
+            const UQ in = (UQ)sa[tile_at(E, tz, ty, tx)];
+            const UQ v = ORDER == 1 ? p1 + in : (UQ)(2 * p1 - p2 + in);
+            qout[((uint64_t)(g.oz + tz - 2) * d1 + (g.oy + ty - 2)) * d2 + (g.ox + tx - 2)] = (Q)v;
+            p2 = p1;
+            p1 = v;
+        }
+    }
+}
+
 template <typename T, int CB>
 __global__ __launch_bounds__(256) void k_blk_decode(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t diag, uint32_t bz_lo,
                                                     uint32_t npairs, const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
@@ -803,63 +873,10 @@ __global__ __launch_bounds__(256) void k_blk_decode(const uint16_t *__restrict__
             sq[t] = v;
         }
     }
-    __syncthreads();
-    // ---- pass along x: a = Dy^m Dz^m q on the two halo columns, then the recurrence over the own columns ----
+    // (the tile is the wave's own: its LDS writes only need to be visible to itself)
     if (live) {
-        for (uint32_t l = lane; l < g.ez * g.ey; l += WAVE) {
-            const uint32_t tz = l / g.ey + 2, ty = l % g.ey + 2;
-            UQ a[2];
-            for (uint32_t tx = 0; tx < 2; tx++) {
-                UQ s = 0;
-                for (int k = 0; k <= order; k++)
-                    for (int j = 0; j <= order; j++) s += (UQ)((Q)(lz_w(order, k) * lz_w(order, j)) * sq[tile_at(E, tz - k, ty - j, tx)]);
-                a[tx] = s;
-            }
-            UQ p2 = a[0], p1 = a[1];
-            for (uint32_t tx = 2; tx < 2 + g.ex; tx++) {
-                const UQ in = (UQ)sq[tile_at(E, tz, ty, tx)];
-                const UQ v = order == 1 ? p1 + in : (UQ)(2 * p1 - p2 + in);
-                sa[tile_at(E, tz, ty, tx)] = (Q)v;
-                p2 = p1;
-                p1 = v;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- pass along y: b = Dz^m q on the two halo rows (own columns), recurrence over the own rows ----
-    if (live) {
-        for (uint32_t l = lane; l < g.ez * g.ex; l += WAVE) {
-            const uint32_t tz = l / g.ex + 2, tx = l % g.ex + 2;
-            UQ b[2];
-            for (uint32_t ty = 0; ty < 2; ty++) {
-                UQ s = 0;
-                for (int k = 0; k <= order; k++) s += (UQ)((Q)lz_w(order, k) * sq[tile_at(E, tz - k, ty, tx)]);
-                b[ty] = s;
-            }
-            UQ p2 = b[0], p1 = b[1];
-            for (uint32_t ty = 2; ty < 2 + g.ey; ty++) {
-                const UQ in = (UQ)sa[tile_at(E, tz, ty, tx)];
-                const UQ v = order == 1 ? p1 + in : (UQ)(2 * p1 - p2 + in);
-                sa[tile_at(E, tz, ty, tx)] = (Q)v;
-                p2 = p1;
-                p1 = v;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- pass along z: inflow = q~ of the two halo planes; the result is q ----
-    if (live) {
-        for (uint32_t l = lane; l < g.ey * g.ex; l += WAVE) {
-            const uint32_t ty = l / g.ex + 2, tx = l % g.ex + 2;
-            UQ p2 = (UQ)sq[tile_at(E, 0, ty, tx)], p1 = (UQ)sq[tile_at(E, 1, ty, tx)];
-            for (uint32_t tz = 2; tz < 2 + g.ez; tz++) {
-                const UQ in = (UQ)sa[tile_at(E, tz, ty, tx)];
-                const UQ v = order == 1 ? p1 + in : (UQ)(2 * p1 - p2 + in);
-                qout[((uint64_t)(g.oz + tz - 2) * d1 + (g.oy + ty - 2)) * d2 + (g.ox + tx - 2)] = (Q)v;
-                p2 = p1;
-                p1 = v;
-            }
-        }
+        if (order == 1) blk_invert<T, CB, 1>(sq, sa, qout, g, E, d1, d2, lane);
+        else blk_invert<T, CB, 2>(sq, sa, qout, g, E, d1, d2, lane);
     }
 }
 

@@ -1,0 +1,334 @@
+"""sz3_amd — host-side mirror of the SZ3 API for the MI355X (gfx950) hot path.
+
+The product is the C-ABI shared library ``sz3_amd/libsz3hip.so`` (include/sz3hip.h, include/sz3c.h): predictor ->
+quantizer -> Huffman as hand-written HIP kernels.  This module is a thin ctypes binding that mirrors the reference's
+Python face ``pysz`` (tools/pysz/src/pysz/sz.pyx:185-405: ``sz.compress(ndarray, szConfig) -> (uint8 ndarray, ratio)``,
+``sz.decompress(bytes, dtype, shape) -> (ndarray, szConfig)``, ``sz.verify -> (max_diff, psnr, nrmse)``) plus the
+device-resident entry points used by bench.py and the multi-GPU driver.
+
+There is no CPU implementation here: importing works anywhere, but every call needs the built library and a HIP
+device and raises otherwise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("SZ3HIP_LIB") or os.path.join(_HERE, "libsz3hip.so")  # (SZ3HIP_LIB: A/B runs of two builds)
+
+# include/SZ3/utils/Config.hpp:66,80,93 (enum EB / ALGO / INTERP_ALGO) + the GPU stream id (include/sz3hip.h)
+EB_ABS, EB_REL, EB_PSNR, EB_L2NORM, EB_ABS_AND_REL, EB_ABS_OR_REL = range(6)
+ALGO_LORENZO_REG, ALGO_INTERP_LORENZO, ALGO_INTERP, ALGO_NOPRED, ALGO_LOSSLESS = range(5)
+ALGO_HIP_LORENZO = 16
+ALGO_HIP_INTERP = 17
+INTERP_ALGO_LINEAR, INTERP_ALGO_CUBIC = 0, 1
+SZ_FLOAT, SZ_DOUBLE = 0, 1
+
+
+class SZ3HipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sz3hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _CConfig(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("dims", C.c_uint64 * 4), ("num", C.c_uint64),
+        ("cmprAlgo", C.c_uint8), ("errorBoundMode", C.c_uint8),
+        ("absErrorBound", C.c_double), ("relErrorBound", C.c_double),
+        ("psnrErrorBound", C.c_double), ("l2normErrorBound", C.c_double),
+        ("openmp", C.c_uint8), ("quantbinCnt", C.c_int32), ("blockSize", C.c_int32),
+        ("predDim", C.c_uint8), ("dataType", C.c_uint8),
+        ("lorenzo", C.c_uint8), ("lorenzo2", C.c_uint8), ("regression", C.c_uint8), ("regression2", C.c_uint8),
+        ("interpAlgo", C.c_uint8), ("interpDirection", C.c_uint8),
+        ("interpAnchorStride", C.c_int32), ("interpAlpha", C.c_double), ("interpBeta", C.c_double),
+    ]
+
+
+class _CTunerReport(C.Structure):
+    _fields_ = [("ran", C.c_int32), ("use_interp", C.c_int32), ("sample_block_size", C.c_uint64), ("n_filtered", C.c_uint64),
+                ("n_blocks", C.c_uint64), ("profiling", C.c_int32), ("interpAlgo", C.c_int32), ("interpDirection", C.c_int32),
+                ("reserved", C.c_int32), ("interpAlpha", C.c_double), ("interpBeta", C.c_double), ("est_bytes", C.c_double * 8)]
+
+
+class _CStats(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("n_value_outliers", C.c_uint64), ("n_delta_outliers", C.c_uint64),
+                ("n_chunks", C.c_uint64), ("bitstream_bytes", C.c_uint64), ("payload_bytes", C.c_uint64),
+                ("n_symbols", C.c_uint32), ("max_code_len", C.c_uint32),
+                ("narrow_codes", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libsz3hip.so; fails loudly when it has not been built (python -m sz3_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("sz3_amd/libsz3hip.so is missing — build it with `python -m sz3_amd.build` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    L.sz3hip_last_error.restype = C.c_char_p
+    L.sz3hip_version.restype = C.c_char_p
+    L.sz3hip_config_init.argtypes = [P(_CConfig), C.c_int, P(C.c_uint64)]
+    L.sz3hip_config_save.restype = C.c_size_t
+    L.sz3hip_config_save.argtypes = [P(_CConfig), C.c_void_p]
+    L.sz3hip_config_load.restype = C.c_size_t
+    L.sz3hip_config_load.argtypes = [P(_CConfig), C.c_void_p]
+    L.sz3hip_compress_bound.restype = C.c_size_t
+    L.sz3hip_compress_bound.argtypes = [P(_CConfig), C.c_int]
+    L.sz3hip_compress.restype = C.c_size_t
+    L.sz3hip_compress.argtypes = [P(_CConfig), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.sz3hip_decompress.restype = C.c_int
+    L.sz3hip_decompress.argtypes = [P(_CConfig), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.sz3hip_peek_config.restype = C.c_int
+    L.sz3hip_peek_config.argtypes = [P(_CConfig), C.c_void_p, C.c_size_t]
+    L.sz3hip_ctx_create.restype = C.c_void_p
+    L.sz3hip_ctx_create.argtypes = [C.c_int, C.c_uint64, C.c_int]
+    L.sz3hip_ctx_destroy.argtypes = [C.c_void_p]
+    L.sz3hip_payload_bound.restype = C.c_size_t
+    L.sz3hip_payload_bound.argtypes = [C.c_void_p, C.c_uint64]
+    L.sz3hip_payload_bound_max.restype = C.c_size_t
+    L.sz3hip_payload_bound_max.argtypes = [C.c_void_p, C.c_uint64]
+    L.sz3hip_minmax_device.restype = C.c_int
+    L.sz3hip_minmax_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, P(C.c_double), P(C.c_double), C.c_void_p]
+    L.sz3hip_compress_stage1.restype = C.c_int
+    L.sz3hip_compress_stage1.argtypes = [C.c_void_p, P(_CConfig), C.c_void_p, C.c_void_p]
+    L.sz3hip_histogram_ptr.restype = C.c_void_p
+    L.sz3hip_histogram_ptr.argtypes = [C.c_void_p]
+    L.sz3hip_histogram_len.restype = C.c_size_t
+    L.sz3hip_histogram_len.argtypes = [C.c_void_p]
+    L.sz3hip_ctx_set_histogram.restype = C.c_int
+    L.sz3hip_ctx_set_histogram.argtypes = [C.c_void_p, C.c_void_p]
+    L.sz3hip_compress_stage2.restype = C.c_int
+    L.sz3hip_compress_stage2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.sz3hip_compress_finish.restype = C.c_int
+    L.sz3hip_compress_finish.argtypes = [C.c_void_p, P(C.c_size_t), C.c_void_p]
+    L.sz3hip_compress_device.restype = C.c_int
+    L.sz3hip_compress_device.argtypes = [C.c_void_p, P(_CConfig), C.c_void_p, C.c_void_p, C.c_size_t, P(C.c_size_t), C.c_void_p]
+    L.sz3hip_decompress_device.restype = C.c_int
+    L.sz3hip_decompress_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.sz3hip_get_stats.restype = C.c_int
+    L.sz3hip_get_stats.argtypes = [C.c_void_p, P(_CStats)]
+    L.sz3hip_get_tuner_report.restype = C.c_int
+    L.sz3hip_get_tuner_report.argtypes = [C.c_void_p, P(_CTunerReport)]
+    L.sz3hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.sz3hip_get_stage_times.restype = C.c_int
+    L.sz3hip_get_stage_times.argtypes = [C.c_void_p, P(C.c_char_p), P(C.c_float), C.c_int]
+    L.sz3hip_debug_copy_codes.restype = C.c_int
+    L.sz3hip_debug_copy_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.sz3hip_debug_force_generic.argtypes = [C.c_int]
+    L.SZ_compress_args.restype = C.c_void_p
+    L.SZ_compress_args.argtypes = [C.c_int, C.c_void_p, P(C.c_size_t), C.c_int, C.c_double, C.c_double, C.c_double,
+                                   C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+    L.SZ_decompress.restype = C.c_void_p
+    L.SZ_decompress.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+    L.free_buf.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise SZ3HipError(rc, lib().sz3hip_last_error().decode())
+
+
+def _dtype_id(dt):
+    dt = np.dtype(dt)
+    if dt == np.float32:
+        return 0
+    if dt == np.float64:
+        return 1
+    if dt == np.int32:   # host-buffer API only (compress / decompress): integers ride the f64 pipeline
+        return 7
+    if dt == np.int64:
+        return 9
+    raise TypeError("sz3_amd supports float32 / float64 / int32 / int64 (got %s)" % dt)
+
+
+class Config:
+    """Mirror of SZ3::Config (include/SZ3/utils/Config.hpp:138-479): ``Config(d0, d1, ...)`` with dims slowest first,
+    size-1 dims dropped; public fields with the reference's names and defaults."""
+
+    _FIELDS = [f[0] for f in _CConfig._fields_ if f[0] not in ("dims",)]
+
+    def __init__(self, *dims):
+        if len(dims) == 1 and isinstance(dims[0], (tuple, list)):
+            dims = tuple(dims[0])
+        if not dims:
+            dims = (1,)
+        self._c = _CConfig()
+        self.setDims(dims)
+
+    def setDims(self, dims):
+        dims = [int(d) for d in dims]
+        saved = {k: getattr(self._c, k) for k in self._FIELDS} if getattr(self._c, "num", 0) else None
+        arr = (C.c_uint64 * len(dims))(*dims)
+        lib().sz3hip_config_init(C.byref(self._c), len(dims), arr)
+        if saved:  # setDims only touches dims/N/num/predDim/blockSize (Config.hpp:161-177)
+            for k, v in saved.items():
+                if k not in ("N", "num", "predDim", "blockSize"):
+                    setattr(self._c, k, v)
+        return int(self._c.num)
+
+    @property
+    def dims(self):
+        return tuple(int(self._c.dims[i]) for i in range(self._c.N))
+
+    def __getattr__(self, k):
+        if k != "_c" and k in Config._FIELDS:
+            return getattr(self._c, k)
+        raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        if k != "_c" and k in Config._FIELDS:
+            setattr(self._c, k, v)
+        else:
+            object.__setattr__(self, k, v)
+
+    def save(self):
+        buf = (C.c_ubyte * 256)()
+        n = lib().sz3hip_config_save(C.byref(self._c), buf)
+        return bytes(buf[:n])
+
+    @classmethod
+    def load(cls, raw):
+        c = cls(1)
+        b = (C.c_ubyte * len(raw)).from_buffer_copy(raw)
+        lib().sz3hip_config_load(C.byref(c._c), b)
+        return c
+
+
+# ---- pysz-like host API (tools/pysz/src/pysz/sz.pyx) -----------------------------------------------------------
+def compress_bound(conf, dtype):
+    return int(lib().sz3hip_compress_bound(C.byref(conf._c), _dtype_id(dtype)))
+
+
+def compress(data, conf):
+    """sz.compress (sz.pyx:185-272): returns (uint8 ndarray, ratio)."""
+    a = np.ascontiguousarray(data)
+    dt = _dtype_id(a.dtype)
+    if int(conf.num) != a.size:
+        raise ValueError("config dims do not match the array")
+    cap = compress_bound(conf, a.dtype)
+    out = np.empty(cap, dtype=np.uint8)
+    n = lib().sz3hip_compress(C.byref(conf._c), dt, a.ctypes.data, out.ctypes.data, cap)
+    if n == 0:
+        raise SZ3HipError(-1, lib().sz3hip_last_error().decode())
+    blob = out[:n]  # a view, like pysz (sz.pyx:230-272): the untouched rest of the bound-sized buffer is never resident
+    return blob, a.nbytes / float(n)
+
+
+def decompress(blob, dtype, shape=None):
+    """sz.decompress (sz.pyx:276-365): returns (ndarray, Config)."""
+    blob = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8) if isinstance(blob, (bytes, bytearray)) else blob)
+    conf = Config(1)
+    _check(lib().sz3hip_peek_config(C.byref(conf._c), blob.ctypes.data, blob.size))
+    dec = np.empty(int(conf.num), dtype=dtype)
+    _check(lib().sz3hip_decompress(C.byref(conf._c), _dtype_id(dtype), blob.ctypes.data, blob.size, dec.ctypes.data))
+    if shape is None:
+        shape = conf.dims
+    return dec.reshape(shape), conf
+
+
+def verify(ori, dec):
+    """sz.verify (sz.pyx:368-405, utils/Statistic.hpp:80-137): (max_diff, psnr, nrmse) in float64."""
+    o = np.asarray(ori, dtype=np.float64).ravel()
+    d = np.asarray(dec, dtype=np.float64).ravel()
+    err = np.abs(d - o)
+    rng = o.max() - o.min()
+    mse = float(np.mean(err * err))
+    psnr = 20 * np.log10(rng) - 10 * np.log10(mse) if mse > 0 and rng > 0 else float("inf")
+    nrmse = np.sqrt(mse) / rng if rng > 0 else 0.0
+    return float(err.max()), float(psnr), float(nrmse)
+
+
+# ---- device-resident API ---------------------------------------------------------------------------------------
+class DeviceCompressor:
+    """Workspace + entry points for arrays that already live in HBM (pointers are plain ints, e.g. tensor.data_ptr())."""
+
+    def __init__(self, max_elems, dtype, device=0):
+        self.dtype = np.dtype(dtype)
+        self._h = lib().sz3hip_ctx_create(int(device), int(max_elems), _dtype_id(dtype))
+        if not self._h:
+            raise SZ3HipError(-4, lib().sz3hip_last_error().decode())
+        self.max_elems = int(max_elems)
+
+    def close(self):
+        if self._h:
+            lib().sz3hip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def payload_bound(self, n, worst_case=False):
+        """device payload bound; worst_case=True leaves room for outlier lists of n / 8 entries (compress then grows
+        its lists on demand instead of raising SZ3HIP_EOUTLIERS)"""
+        if worst_case:
+            return int(lib().sz3hip_payload_bound_max(self._h, int(n)))
+        return int(lib().sz3hip_payload_bound(self._h, int(n)))
+
+    def minmax(self, d_in, n, stream=0):
+        mn, mx = C.c_double(), C.c_double()
+        _check(lib().sz3hip_minmax_device(self._h, d_in, int(n), C.byref(mn), C.byref(mx), stream))
+        return mn.value, mx.value
+
+    def stage1(self, conf, d_in, stream=0):
+        _check(lib().sz3hip_compress_stage1(self._h, C.byref(conf._c), d_in, stream))
+
+    def histogram_ptr(self):
+        return int(lib().sz3hip_histogram_ptr(self._h)), int(lib().sz3hip_histogram_len(self._h))
+
+    def set_histogram(self, d_hist):
+        _check(lib().sz3hip_ctx_set_histogram(self._h, d_hist))
+
+    def stage2(self, d_payload, cap, stream=0):
+        _check(lib().sz3hip_compress_stage2(self._h, d_payload, int(cap), stream))
+
+    def finish(self, stream=0):
+        sz = C.c_size_t()
+        _check(lib().sz3hip_compress_finish(self._h, C.byref(sz), stream))
+        return int(sz.value)
+
+    def compress(self, conf, d_in, d_payload, cap, stream=0):
+        sz = C.c_size_t()
+        _check(lib().sz3hip_compress_device(self._h, C.byref(conf._c), d_in, d_payload, int(cap), C.byref(sz), stream))
+        return int(sz.value)
+
+    def decompress(self, d_payload, size, d_out, stream=0):
+        _check(lib().sz3hip_decompress_device(self._h, d_payload, int(size), d_out, stream))
+
+    def stats(self):
+        st = _CStats()
+        lib().sz3hip_get_stats(self._h, C.byref(st))
+        return {k: int(getattr(st, k)) for k, _ in _CStats._fields_}
+
+    def tuner_report(self):
+        """what the ALGO_INTERP_LORENZO auto-tuner decided in the last stage1 / compress call (sz3hip_get_tuner_report)"""
+        r = _CTunerReport()
+        lib().sz3hip_get_tuner_report(self._h, C.byref(r))
+        out = {k: getattr(r, k) for k, _ in _CTunerReport._fields_ if k not in ("est_bytes", "reserved")}
+        out["est_bytes"] = [float(x) for x in r.est_bytes]
+        return out
+
+    def set_profiling(self, on=True):
+        lib().sz3hip_set_profiling(self._h, int(on))
+
+    def stage_times(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        k = lib().sz3hip_get_stage_times(self._h, names, ms, 16)
+        return {names[i].decode(): float(ms[i]) for i in range(k)}
+
+    def debug_codes(self, n):
+        out = np.empty(int(n), dtype=np.uint16)
+        _check(lib().sz3hip_debug_copy_codes(self._h, out.ctypes.data, int(n)))
+        return out

@@ -1,12 +1,15 @@
-// sz3_amd/csrc/sz3hip_api.cpp — Config and the device-resident API of libsz3hip.so (include/sz3hip.h groups 2 and 3).
+// sz3_amd/csrc/sz3hip_api.cpp — host side of libsz3hip.so: the C ABI declared in include/sz3hip.h and include/sz3c.h.
 //
 // Mirrors, for the GPU path, what these reference pieces do on the CPU (paths relative to /root/reference):
-//   include/SZ3/utils/Config.hpp:161-177,312-413     Config::setDims / save / load
-//   include/SZ3/compressor/SZGenericCompressor.hpp:38-84  stage glue: decomposition -> encoder (-> lossless on the host)
-//   include/SZ3/api/impl/SZAlgoInterp.hpp:122-286    the ALGO_INTERP_LORENZO sampling tuner
-// The host-buffer API (container, dispatcher policies, slab-parallel path, sz3c.h) is sz3hip_host.cpp, the RCCL
-// communicator sz3hip_comm.cpp. There is NO CPU implementation of the predictor/quantizer/Huffman stages in this
-// library: if the HIP device or kernels are unavailable every entry point fails loudly.
+//   include/SZ3/api/sz.hpp:43-82,117-157        container: 16-byte header + payload + Config trailer
+//   include/SZ3/utils/Config.hpp:161-177,312-413 Config::setDims / save / load
+//   include/SZ3/api/impl/SZDispatcher.hpp:13-100 eb-mode conversion, eb==0 => lossless, lossless fallback,
+//                                                "ratio < 3 => also try zstd alone"
+//   include/SZ3/lossless/Lossless_zstd.hpp:29-45 [u64 rawLen][zstd frames]  (we emit several concatenated frames,
+//                                                compressed by a thread pool; any zstd decoder reads them)
+//   tools/sz3c/src/sz3c.cpp:11-94                SZ_compress_args / SZ_decompress / free_buf
+// There is NO CPU implementation of the predictor/quantizer/Huffman stages in this library: if the HIP device
+// or kernels are unavailable every entry point fails loudly.
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -27,13 +30,13 @@
 #include "../../include/sz3c.h"
 #include "../../include/sz3hip.h"
 #include "sz3hip_format.h"
-#include "sz3hip_internal.h"
 #include "sz3hip_kernels.h"
 
 // ------------------------------------------------------------------------------------------------------------
 static thread_local char g_err[512];
 static thread_local int g_err_code = 0;
-int szi_fail(int code, const char *fmt, ...) {
+static int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+static int fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -41,7 +44,6 @@ int szi_fail(int code, const char *fmt, ...) {
     g_err_code = code;
     return code;
 }
-#define fail szi_fail
 extern "C" const char *sz3hip_last_error(void) { return g_err; }
 extern "C" int sz3hip_last_error_code(void) { return g_err_code; }
 extern "C" const char *sz3hip_version(void) { return "sz3hip 0.1 (gfx950; data format SZ3 3.3.2 container, payload SZH1)"; }
@@ -52,6 +54,166 @@ extern "C" const char *sz3hip_version(void) { return "sz3hip 0.1 (gfx950; data f
         if (e_ != hipSuccess) return fail(SZ3HIP_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// ------------------------------------------------------------------------------------------------------------
+// libzstd (third-party, the reference's lossless stage; not vendored there either — CMakeLists.txt:69-75).
+// zstd.h is not installed in /usr/include of this image, so the five prototypes are declared here and the
+// library is dlopen'ed; a missing library is a hard error.
+// ------------------------------------------------------------------------------------------------------------
+namespace zs {
+typedef size_t (*compress_fn)(void *, size_t, const void *, size_t, int);
+typedef size_t (*decompress_fn)(void *, size_t, const void *, size_t);
+typedef size_t (*bound_fn)(size_t);
+typedef unsigned (*iserr_fn)(size_t);
+typedef size_t (*framesize_fn)(const void *, size_t);
+typedef unsigned long long (*contentsize_fn)(const void *, size_t);
+static void *h;
+static compress_fn compress;
+static decompress_fn decompress;
+static bound_fn bound;
+static iserr_fn is_error;
+static framesize_fn frame_csize;
+static contentsize_fn frame_content;
+static std::once_flag once;
+static bool ok;
+static void load_once() {
+    const char *names[] = {"libzstd.so.1", "libzstd.so", "/usr/lib/x86_64-linux-gnu/libzstd.so.1", nullptr};
+    for (int i = 0; names[i] && !h; i++) h = dlopen(names[i], RTLD_NOW);
+    if (!h) return;
+    compress = (compress_fn)dlsym(h, "ZSTD_compress");
+    decompress = (decompress_fn)dlsym(h, "ZSTD_decompress");
+    bound = (bound_fn)dlsym(h, "ZSTD_compressBound");
+    is_error = (iserr_fn)dlsym(h, "ZSTD_isError");
+    frame_csize = (framesize_fn)dlsym(h, "ZSTD_findFrameCompressedSize");
+    frame_content = (contentsize_fn)dlsym(h, "ZSTD_getFrameContentSize");
+    ok = compress && decompress && bound && is_error;
+}
+static int load() {
+    std::call_once(once, load_once);
+    return ok ? 0 : fail(SZ3HIP_EZSTD, "libzstd.so.1 not found or incomplete");
+}
+static const size_t FRAME = 4u << 20;  // bytes of input per zstd frame
+static unsigned nthreads() {
+    const char *e = getenv("SZ3HIP_ZSTD_THREADS");
+    unsigned n = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    return n;
+}
+static size_t bound_frames(size_t n) {
+    size_t nf = (n + FRAME - 1) / FRAME;
+    if (nf == 0) nf = 1;
+    return nf * bound(std::min(n, FRAME)) + 8;
+}
+// [u64 srcLen][frame]...  level 3 (lossless/Lossless_zstd.hpp:48); returns 0 on error
+static size_t compress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {
+    if (load()) return 0;
+    if (cap < 8) {
+        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+        return 0;
+    }
+    uint64_t len = n;
+    memcpy(dst, &len, 8);
+    const size_t nf = std::max<size_t>(1, (n + FRAME - 1) / FRAME);
+    const size_t fb = bound(std::min(n, FRAME));
+    std::vector<std::vector<uint8_t>> out(nf);
+    std::vector<size_t> sz(nf, 0);
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    auto work = [&]() {
+        for (;;) {
+            size_t f = next.fetch_add(1);
+            if (f >= nf) break;
+            size_t lo = f * FRAME, l = std::min(FRAME, n - lo);
+            out[f].resize(fb);
+            size_t r = compress(out[f].data(), fb, src + lo, l, 3);
+            if (is_error(r)) bad = 1;
+            sz[f] = r;
+        }
+    };
+    unsigned nt = (unsigned)std::min<size_t>(nthreads(), nf);
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (bad) {
+        fail(SZ3HIP_EZSTD, "ZSTD_compress failed");
+        return 0;
+    }
+    size_t total = 8;
+    for (size_t f = 0; f < nf; f++) total += sz[f];
+    if (total > cap) {
+        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+        return 0;
+    }
+    uint8_t *p = dst + 8;
+    for (size_t f = 0; f < nf; f++) {
+        memcpy(p, out[f].data(), sz[f]);
+        p += sz[f];
+    }
+    return total;
+}
+// inverse; frames are located with ZSTD_findFrameCompressedSize and decoded in parallel. returns bytes produced
+static size_t decompress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {
+    if (load()) return 0;
+    if (n < 8) {
+        fail(SZ3HIP_EFORMAT, "truncated lossless block");
+        return 0;
+    }
+    uint64_t len;
+    memcpy(&len, src, 8);
+    if (len > cap) {
+        fail(SZ3HIP_ECAPACITY, "lossless block larger than the destination");
+        return 0;
+    }
+    const uint8_t *p = src + 8;
+    size_t rem = n - 8;
+    struct Fr { const uint8_t *p; size_t c, off, d; };
+    std::vector<Fr> frames;
+    bool split = frame_csize && frame_content;
+    if (split) {
+        size_t off = 0;
+        while (rem > 0) {
+            size_t c = frame_csize(p, rem);
+            if (is_error(c)) { split = false; break; }
+            unsigned long long d = frame_content(p, c);
+            if (d == (unsigned long long)-1 || d == (unsigned long long)-2) { split = false; break; }
+            frames.push_back({p, c, off, (size_t)d});
+            off += (size_t)d;
+            p += c;
+            rem -= c;
+        }
+        if (split && off != len) split = false;
+    }
+    if (!split || frames.size() <= 1) {
+        size_t r = decompress(dst, (size_t)len, src + 8, n - 8);
+        if (is_error(r) || r != len) {
+            fail(SZ3HIP_EZSTD, "ZSTD_decompress failed");
+            return 0;
+        }
+        return r;
+    }
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    auto work = [&]() {
+        for (;;) {
+            size_t f = next.fetch_add(1);
+            if (f >= frames.size()) break;
+            size_t r = decompress(dst + frames[f].off, frames[f].d, frames[f].p, frames[f].c);
+            if (is_error(r) || r != frames[f].d) bad = 1;
+        }
+    };
+    unsigned nt = (unsigned)std::min<size_t>(nthreads(), frames.size());
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (bad) {
+        fail(SZ3HIP_EZSTD, "ZSTD_decompress failed");
+        return 0;
+    }
+    return (size_t)len;
+}
+}  // namespace zs
 
 // ------------------------------------------------------------------------------------------------------------
 // Config (include/SZ3/utils/Config.hpp)
@@ -80,6 +242,24 @@ extern "C" void sz3hip_config_init(sz3hip_config *c, int ndims, const uint64_t *
     c->interpBeta = 2.0;
 }
 
+namespace {
+struct Writer {
+    unsigned char *p;
+    template <class V> void put(V v) {
+        memcpy(p, &v, sizeof(V));
+        p += sizeof(V);
+    }
+};
+struct Reader {
+    const unsigned char *p;
+    template <class V> V get() {
+        V v;
+        memcpy(&v, p, sizeof(V));
+        p += sizeof(V);
+        return v;
+    }
+};
+}  // namespace
 
 extern "C" size_t sz3hip_config_save(const sz3hip_config *c, unsigned char *out) {  // Config.hpp:312-354
     Writer w{out + 1};
@@ -123,23 +303,16 @@ extern "C" size_t sz3hip_config_save(const sz3hip_config *c, unsigned char *out)
     return (size_t)(w.p - out);
 }
 
-// Config::load (Config.hpp:361-413) over at most `avail` bytes: 0 when the leading size byte or any field runs past them
-extern "C" size_t sz3hip_config_load_n(sz3hip_config *c, const unsigned char *in, size_t avail) {
-    uint64_t one = 1;
-    sz3hip_config_init(c, 1, &one);
-    if (avail < 1) return 0;
+extern "C" size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in) {  // Config.hpp:361-413
     Reader r{in};
     const uint8_t conf_size = r.get<uint8_t>();
-    // (the stored size counts its own byte: Config::save writes `pos - start` over the first byte, Config.hpp:351-353)
-    if (conf_size < 1 || conf_size > avail) return 0;
-    const unsigned char *end = in + conf_size;
-    auto room = [&](size_t k) { return (size_t)(end - r.p) >= k; };
-    if (!room(2)) return 0;
+    const unsigned char *end = r.p + conf_size;
+    uint64_t one = 1;
+    sz3hip_config_init(c, 1, &one);
     c->N = r.get<int8_t>();
     if (c->N < 0 || c->N > 4) c->N = 0;
     const uint8_t bw = r.get<uint8_t>();
     const size_t nbytes = ((size_t)bw * (size_t)c->N + 7) / 8;
-    if (!room(nbytes)) return 0;
     for (int i = 0; i < c->N; i++) {  // bytes2vector, ByteUtil.hpp:240-264
         uint64_t v = 0;
         for (int j = 0; j < bw && j < 64; j++) {
@@ -149,24 +322,22 @@ extern "C" size_t sz3hip_config_load_n(sz3hip_config *c, const unsigned char *in
         c->dims[i] = v;
     }
     r.p += nbytes;
-    if (!room(10)) return 0;
     c->num = r.get<uint64_t>();
     c->cmprAlgo = r.get<uint8_t>();
     c->errorBoundMode = r.get<uint8_t>();
     switch (c->errorBoundMode) {
-        case SZ3HIP_EB_ABS: if (!room(8)) return 0; c->absErrorBound = r.get<double>(); break;
-        case SZ3HIP_EB_REL: if (!room(8)) return 0; c->relErrorBound = r.get<double>(); break;
-        case SZ3HIP_EB_PSNR: if (!room(8)) return 0; c->psnrErrorBound = r.get<double>(); break;
-        case SZ3HIP_EB_L2NORM: if (!room(8)) return 0; c->l2normErrorBound = r.get<double>(); break;
+        case SZ3HIP_EB_ABS: c->absErrorBound = r.get<double>(); break;
+        case SZ3HIP_EB_REL: c->relErrorBound = r.get<double>(); break;
+        case SZ3HIP_EB_PSNR: c->psnrErrorBound = r.get<double>(); break;
+        case SZ3HIP_EB_L2NORM: c->l2normErrorBound = r.get<double>(); break;
         case SZ3HIP_EB_ABS_AND_REL:
         case SZ3HIP_EB_ABS_OR_REL:
-            if (!room(16)) return 0;
             c->absErrorBound = r.get<double>();
             c->relErrorBound = r.get<double>();
             break;
         default: break;
     }
-    if (room(1)) {
+    if (r.p < end) {
         uint8_t b = r.get<uint8_t>();
         c->lorenzo = (b >> 7) & 1;
         c->lorenzo2 = (b >> 6) & 1;
@@ -174,21 +345,83 @@ extern "C" size_t sz3hip_config_load_n(sz3hip_config *c, const unsigned char *in
         c->regression2 = (b >> 4) & 1;
         c->openmp = (b >> 3) & 1;
     }
-    if (room(1)) c->dataType = r.get<uint8_t>();
-    if (room(4)) c->quantbinCnt = r.get<int32_t>();
-    if (room(4)) c->blockSize = r.get<int32_t>();
-    if (room(1)) c->predDim = r.get<uint8_t>();
-    return (size_t)conf_size;
-}
-extern "C" size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in) {  // the caller vouches for in[0] readable bytes
-    return sz3hip_config_load_n(c, in, in[0]);
+    if (r.p < end) c->dataType = r.get<uint8_t>();
+    if (r.p < end) c->quantbinCnt = r.get<int32_t>();
+    if (r.p < end) c->blockSize = r.get<int32_t>();
+    if (r.p < end) c->predDim = r.get<uint8_t>();
+    return (size_t)(r.p - in);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // device context
 // ------------------------------------------------------------------------------------------------------------
+enum { ST_K1 = 0, ST_CODEBOOK, ST_ENCODE, ST_ASSEMBLE, ST_DEC_HUFF, ST_DEC_RECON, ST_TUNER, ST_K1_KERNEL, ST_COUNT };
 static const char *const kStageNames[ST_COUNT] = {"lorenzo_quant_hist", "codebook", "encode", "assemble",
                                                   "huffman_decode",     "reconstruct", "tuner", "k1_kernel"};
+
+struct sz3hip_ctx {
+    int device;
+    int dtype;
+    uint64_t max_n, out_cap, cur_out_cap, max_chunks;
+    uint64_t out_alloc;      // entries the four outlier arrays hold (>= out_cap; grown on demand)
+    uint64_t force_out_cap;  // != 0: list capacity of the retry after an overflow
+    // device buffers
+    uint16_t *d_codes;
+    uint64_t *d_hist;      // histogram in use (internal or caller-owned)
+    uint64_t *d_hist_own;  // internal allocation
+    uint64_t *d_counters;  // [0]=n_vout [1]=n_dout [2]=total_words [3]=decoder [4..6]=probe words [8..9]=code book's symbol range (inside d_hist_own's block)
+    uint32_t *d_hist_partial;
+    void *d_work;          // interpolation: the array being overwritten with reconstructed values (lazy)
+    uint64_t *d_vout_idx, *d_dout_idx;
+    void *d_vout_val, *d_dout_val;
+    uint32_t *d_enc;
+    uint8_t *d_lens;
+    uint64_t *d_keys, *d_ifreq;
+    uint16_t *d_syms, *d_pleaf, *d_pint, *d_depth, *d_aux2, *d_pint2;
+    uint32_t *d_range;
+    szk_cb_info *d_info;
+    uint16_t *d_chunk_words;
+    uint64_t *d_chunk_off;
+    szk_state *d_state;
+    szk_dec_tables *d_tables;
+    void *d_segtot;
+    double *d_minmax;
+    szk_state *h_state;  // pinned
+    szk_mode mode;       // of the pending / last compress
+    double *h_minmax;    // pinned
+    // pending compress
+    szh_header proto;
+    bool stage1_done, stage2_done;
+    sz3hip_stats stats;
+    // ALGO_INTERP_LORENZO tuner scratch (lazy)
+    uint8_t *d_flags;
+    size_t flags_cap;
+    uint64_t *d_starts;
+    size_t starts_cap;
+    void *d_samples;
+    size_t samples_cap;
+    void *d_trial_work;  // scratch of the trial kernel's global-memory variant (blocks too large for LDS)
+    size_t trial_work_cap;
+    hipStream_t side;    // the working copy of the input is made here while the tuner runs on the caller's stream
+    hipEvent_t ev_fork, ev_join;
+    bool copy_ahead;     // d_work already holds this call's input (joined into the caller's stream)
+    int hist_tail;       // with hist_big: codes beyond the large tier counted by windowed passes (from the previous call's count)
+    int hist_big;        // interpolation histogram pass with the 16384-bin second tier (from the previous call's far count)
+    int pack_wide;       // the packer's LDS table window: 8192 instead of 4096 entries (from the previous call's probe)
+    int wide16;          // -1: not decided yet (f64 starts with the 16384-bin stage-1 window, f32 with 8192); else 0 / 1,
+                         // adapted after every Lorenzo call from the width of the alphabet it saw
+    uint64_t *d_trial;  // [8][4]: bits, symbols, unpredictables, delta outliers
+    uint64_t *h_trial;  // pinned
+    uint64_t *d_trial_hist;      // [SZK_MAX_TRIALS][65536] histograms of the trials of one group
+    uint64_t *d_trial_counters;  // [SZK_MAX_TRIALS][8]
+    szk_interp_pass *d_passes, *h_passes;  // [SZK_MAX_TRIALS][SZK_TRIAL_MAX_PASSES] pass schedules (h: pinned)
+    uint32_t *d_np, *h_np;
+    sz3hip_tuner_report tuner;
+    // profiling
+    bool profiling;
+    hipEvent_t ev[ST_COUNT][2];
+    bool ev_used[ST_COUNT];
+};
 
 #define SZ_COUNTER_BYTES 128
 // histogram and counters of a call start at zero; the internal histogram and the counters share one block (one fill launch)
@@ -202,8 +435,7 @@ static void ctx_free(sz3hip_ctx *c) {
     void *bufs[] = {c->d_work, c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
                     c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_aux2, c->d_pint2, c->d_range, c->d_info,
                     c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples, c->d_trial_work,
-                    c->d_trial, c->d_passes, c->d_np,  // (d_trial_counters / d_trial_hist live inside d_trial's block)
-                    c->d_blk_sel, c->d_blk_coef, c->d_blk_rank, c->d_blk_comp, c->d_blk_side, c->d_blk_counters};
+                    c->d_trial, c->d_passes, c->d_np};  // (d_trial_counters / d_trial_hist live inside d_trial's block)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->side) {
@@ -219,8 +451,6 @@ static void ctx_free(sz3hip_ctx *c) {
     if (c->h_trial) (void)hipHostFree(c->h_trial);
     if (c->h_passes) (void)hipHostFree(c->h_passes);
     if (c->h_np) (void)hipHostFree(c->h_np);
-    if (c->h_blk_side_hdr) (void)hipHostFree(c->h_blk_side_hdr);
-    if (c->h_ovf) (void)hipHostFree(c->h_ovf);
     for (int i = 0; i < ST_COUNT; i++)
         for (int j = 0; j < 2; j++)
             if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
@@ -240,7 +470,6 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     sz3hip_ctx *c = new sz3hip_ctx();
     memset(c, 0, sizeof(*c));
     c->wide16 = -1;
-    c->narrow_hint = c->cb_hint = -1;
     c->device = device;
     c->dtype = dataType;
     c->max_n = max_elems;
@@ -300,9 +529,8 @@ extern "C" void sz3hip_ctx_destroy(sz3hip_ctx *ctx) {
 
 static size_t payload_bound_n(uint64_t n, uint64_t out_cap) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
-    // (+ the side section of the block-composed predictor: blocks of at least 4^3 elements)
     return (size_t)(sizeof(szh_header) + SZH_HIST_BINS + 16 + 2 * n_chunks + 16 + 2 * (out_cap * 16 + 16) +
-                    4 * n_chunks * (SZH_CHUNK_SYMS * SZH_MAX_LEN / 32) + 64 + szk_blk_side_bound(n / 64 + 64));
+                    4 * n_chunks * (SZH_CHUNK_SYMS * SZH_MAX_LEN / 32) + 64);
 }
 extern "C" size_t sz3hip_payload_bound(const sz3hip_ctx *ctx, uint64_t n) { return payload_bound_n(n, ctx->out_cap); }
 // lists of up to n / 8 entries: beyond that the stream cannot beat the lossless fallback any more
@@ -310,14 +538,10 @@ static uint64_t out_cap_limit(uint64_t n) { return std::max<uint64_t>(1024, n / 
 extern "C" size_t sz3hip_payload_bound_max(const sz3hip_ctx *ctx, uint64_t n) {
     return payload_bound_n(n, std::max<uint64_t>(ctx->out_cap, out_cap_limit(n)));
 }
-extern "C" void *sz3hip_histogram_ptr(sz3hip_ctx *ctx) {
-    ctx->hist_exposed = true;  // (whoever holds the pointer may change the histogram between the stages)
-    return ctx->d_hist;
-}
+extern "C" void *sz3hip_histogram_ptr(sz3hip_ctx *ctx) { return ctx->d_hist; }
 extern "C" size_t sz3hip_histogram_len(const sz3hip_ctx *) { return SZH_HIST_BINS; }
 extern "C" int sz3hip_ctx_set_histogram(sz3hip_ctx *ctx, void *d_hist) {
     ctx->d_hist = d_hist ? (uint64_t *)d_hist : ctx->d_hist_own;
-    ctx->hist_exposed = d_hist != nullptr;
     return 0;
 }
 extern "C" void sz3hip_set_profiling(sz3hip_ctx *ctx, int on) {
@@ -407,9 +631,6 @@ static void cb_params_from(sz3hip_ctx *ctx, szk_cb_params &cb, uint64_t out_cap)
     cb.t_is_32bit = cb.q_is_32bit = ctx->dtype == SZ3HIP_FLOAT;
     cb.info = ctx->d_info;
     cb.n_books = 1;
-    cb.range_ready = ctx->range_ready && !ctx->hist_exposed;
-    cb.part_hint = (szk_dbg_flags & 131072) ? -1 : ctx->cb_hint;
-    cb.mispredict = reinterpret_cast<uint32_t *>(ctx->d_counters + 7);  // (zeroed with the counters)
 }
 
 static int stage1_interp(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint64_t num, hipStream_t s) {
@@ -480,11 +701,6 @@ static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *
     p.mode.allow = allow_narrow && radius >= 128;
     p.mode.pack_wide = allow_narrow ? (uint32_t)ctx->pack_wide : 0u;
     p.wide16 = ctx->wide16 < 0 ? (ctx->dtype == SZ3HIP_DOUBLE ? 1u : 0u) : (uint32_t)ctx->wide16;
-    // range words of the alphabet kept by stage 1 itself (whoever finds a bin empty enters it): the one-launch form a context takes
-    // after a one-byte call does (few bins); the two-byte forms flush thousands of bins per workgroup, where the returning atomic
-    // that takes costs more than the k_hist_range launch it saves (szk_launch_k1 reports through range_kept what was done)
-    p.range = reinterpret_cast<uint32_t *>(ctx->d_counters + 8);
-    p.hint_narrow = allow_narrow ? ctx->narrow_hint : -1;
     p.prof_ev0 = p.prof_ev1 = nullptr;
     if (ctx->profiling && allow_narrow) {  // (the production call, not the tuner's trial): events around the kernel itself
         p.prof_ev0 = ctx->ev[ST_K1_KERNEL][0];
@@ -498,7 +714,6 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
     prof_begin(ctx, ST_K1, s);
     int rc = lorenzo_k1(ctx, conf->N, conf->dims, d_in, eb, radius, num, ctx->cur_out_cap, true, p, s);
     ctx->mode = p.mode;
-    ctx->range_ready = p.range_kept != 0;
     prof_end(ctx, ST_K1, s);
     if (rc) return fail(SZ3HIP_EHIP, "lorenzo_quant kernel launch failed (%d)", rc);
     szh_header &h = ctx->proto;
@@ -514,99 +729,6 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
     h.n = num;
     h.chunk_syms = SZH_CHUNK_SYMS;
     h.n_chunks = (num + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
-    ctx->stage1_done = true;
-    ctx->stage2_done = false;
-    return 0;
-}
-
-// ---- stage 1, block-composed predictor: Lorenzo-1 / Lorenzo-2 / regression chosen per block
-// (make_compressor_lorenzo_regression, api/impl/SZAlgoLorenzoReg.hpp:22-64) ----
-static int blk_reserve(sz3hip_ctx *ctx, uint64_t nblocks) {
-    if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
-    if (!ctx->d_blk_counters) HIPCHK(hipMalloc((void **)&ctx->d_blk_counters, 64 + 4 * (0x7FFFFFF0ull / 8192 + 2)));
-    if (!ctx->h_blk_side_hdr) HIPCHK(hipHostMalloc((void **)&ctx->h_blk_side_hdr, 32));
-    if (ctx->blk_cap >= nblocks) return 0;
-    void **arr[5] = {(void **)&ctx->d_blk_sel, (void **)&ctx->d_blk_coef, (void **)&ctx->d_blk_rank, (void **)&ctx->d_blk_comp, (void **)&ctx->d_blk_side};
-    for (void **a : arr) {
-        if (*a) (void)hipFree(*a);
-        *a = nullptr;
-    }
-    ctx->blk_cap = 0;
-    HIPCHK(hipMalloc((void **)&ctx->d_blk_sel, nblocks));
-    HIPCHK(hipMalloc((void **)&ctx->d_blk_coef, nblocks * 32));
-    HIPCHK(hipMalloc((void **)&ctx->d_blk_rank, nblocks * 4));
-    HIPCHK(hipMalloc((void **)&ctx->d_blk_comp, nblocks * 4));
-    HIPCHK(hipMalloc((void **)&ctx->d_blk_side, szk_blk_side_bound(nblocks)));
-    ctx->blk_cap = nblocks;
-    return 0;
-}
-static void blk_params_from(sz3hip_ctx *ctx, const uint64_t *dims3, uint32_t B, uint32_t mask, double eb, int radius, uint64_t out_cap,
-                            szk_blk_params &bp, szk_blk_scratch &sc) {
-    memset(&bp, 0, sizeof(bp));
-    memset(&sc, 0, sizeof(sc));
-    for (int i = 0; i < 3; i++) {
-        bp.d[i] = dims3[i];
-        bp.nb[i] = (uint32_t)((dims3[i] + B - 1) / B);
-    }
-    bp.B = B;
-    bp.mask = mask;
-    bp.lat = szk_make_lattice(eb);
-    bp.eb = eb;
-    bp.radius = (uint32_t)radius;
-    bp.out_cap = out_cap;
-    bp.hist = ctx->d_hist;
-    bp.n_vout = ctx->d_counters + 0;
-    bp.n_dout = ctx->d_counters + 1;
-    bp.vout_idx = ctx->d_vout_idx;
-    bp.dout_idx = ctx->d_dout_idx;
-    bp.vout_val = ctx->d_vout_val;
-    bp.dout_val = ctx->d_dout_val;
-    bp.sel = ctx->d_blk_sel;
-    bp.coef = ctx->d_blk_coef;
-    bp.qwork = ctx->d_work;
-    bp.n_reg = ctx->d_blk_counters + 3;
-    sc.rank = ctx->d_blk_rank;
-    sc.comp = ctx->d_blk_comp;
-    sc.counters = ctx->d_blk_counters;
-    sc.side = ctx->d_blk_side;
-    sc.run_scratch = reinterpret_cast<uint32_t *>(ctx->d_blk_counters + 8);  // (the counter block holds 8 words + a run table)
-}
-static bool blk_shape_ok(const sz3hip_config *conf) { return conf->N == 3 && conf->blockSize >= 4 && conf->blockSize <= 8; }
-static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint64_t num, uint32_t mask, hipStream_t s) {
-    const uint32_t B = (uint32_t)conf->blockSize;
-    uint64_t nblocks = 1;
-    for (int i = 0; i < 3; i++) nblocks *= (conf->dims[i] + B - 1) / B;
-    if (nblocks > 0x7FFFFFF0ull) return fail(SZ3HIP_EUNSUPPORTED, "too many blocks for the block-composed predictor");
-    int rc = blk_reserve(ctx, nblocks);
-    if (rc) return rc;
-    szk_blk_params bp;
-    szk_blk_scratch sc;
-    blk_params_from(ctx, conf->dims, B, mask, eb, radius, ctx->cur_out_cap, bp, sc);
-    sc.wide_hist = ctx->blk_wide;
-    HIPCHK(hipMemsetAsync(ctx->d_blk_counters, 0, 64, s));
-    prof_begin(ctx, ST_K1, s);
-    rc = szk_launch_blk_compress(ctx->dtype, d_in, ctx->d_codes, &bp, &sc, s);
-    prof_end(ctx, ST_K1, s);
-    if (rc) return fail(SZ3HIP_EHIP, "block predictor kernel launch failed (%d)", rc);
-    memset(&ctx->mode, 0, sizeof(ctx->mode));
-    ctx->mode.probe_big = reinterpret_cast<uint32_t *>(ctx->d_counters + 4);
-    szh_header &h = ctx->proto;
-    memset(&h, 0, sizeof(h));
-    h.magic = SZH_MAGIC;
-    h.version = SZH_VERSION;
-    h.dtype = (uint8_t)ctx->dtype;
-    h.ndim = 3;
-    h.qbytes = ctx->dtype == SZ3HIP_FLOAT ? 4 : 8;
-    h.predictor = 2;
-    h.radius = (uint32_t)radius;
-    h.dims[0] = 1;
-    for (int i = 0; i < 3; i++) h.dims[1 + i] = conf->dims[i];
-    h.eb = eb;
-    h.n = num;
-    h.chunk_syms = SZH_CHUNK_SYMS;
-    h.n_chunks = (num + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
-    h.interp_id = B;
-    h.interp_dir = mask;
     ctx->stage1_done = true;
     ctx->stage2_done = false;
     return 0;
@@ -907,62 +1029,36 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     memset(&ctx->tuner, 0, sizeof(ctx->tuner));
     for (int i = 0; i < ST_COUNT; i++) ctx->ev_used[i] = false;  // stage times describe this call only
     ctx->copy_ahead = false;
-    ctx->range_ready = false;
     if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP_LORENZO) {  // the reference's default: sampling auto-tuner, then one of the two paths
         // The tuner is a chain of small launches and host round trips (the chip is mostly idle), and its outcome is almost
         // always interpolation, which starts from a working copy of the input: make that copy meanwhile on a side stream.
-        // (3-D arrays run through the level kernels, which read the input where it lies: no copy)
-        szk_interp_params shape;
-        memset(&shape, 0, sizeof(shape));
-        shape.N = conf->N;
-        for (int i = 0; i < conf->N && i < 4; i++) shape.dims[i] = conf->dims[i];
-        const bool ahead = !szk_interp_levels_ok(&shape);
         if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
-        if (ahead) {
-            if (!ctx->side) {
-                HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-                HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-            }
-            HIPCHK(hipEventRecord(ctx->ev_fork, s));
-            HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-            HIPCHK(hipMemcpyAsync(ctx->d_work, d_in, num * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8), hipMemcpyDeviceToDevice, ctx->side));
-            HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
+        if (!ctx->side) {
+            HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         }
+        HIPCHK(hipEventRecord(ctx->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        HIPCHK(hipMemcpyAsync(ctx->d_work, d_in, num * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8), hipMemcpyDeviceToDevice, ctx->side));
+        HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
         prof_begin(ctx, ST_TUNER, s);
         int rct = tune_interp_lorenzo(ctx, *conf, d_in, eb, radius, s);
         prof_end(ctx, ST_TUNER, s);
-        if (ahead) {
-            hipError_t ej = hipStreamWaitEvent(s, ctx->ev_join, 0);  // whatever the outcome: the caller's stream owns d_in again
-            if (ej != hipSuccess) {
-                (void)hipStreamSynchronize(ctx->side);
-                return fail(SZ3HIP_EHIP, "joining the side stream failed: %s", hipGetErrorString(ej));
-            }
+        hipError_t ej = hipStreamWaitEvent(s, ctx->ev_join, 0);  // whatever the outcome: the caller's stream owns d_in again
+        if (ej != hipSuccess) {
+            (void)hipStreamSynchronize(ctx->side);
+            return fail(SZ3HIP_EHIP, "joining the side stream failed: %s", hipGetErrorString(ej));
         }
         if (rct) return rct;
-        ctx->copy_ahead = ahead;
+        ctx->copy_ahead = true;
     }
     HIPCHK(clear_hist_counters(ctx, s));
     if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP || conf->cmprAlgo == SZ3HIP_ALGO_HIP_INTERP)
         return stage1_interp(ctx, conf, d_in, eb, radius, num, s);
-    if (conf->cmprAlgo == SZ3HIP_ALGO_LORENZO_REG) {
-        // the predictor set of make_compressor_lorenzo_regression (api/impl/SZAlgoLorenzoReg.hpp:28-64). Lorenzo-1 alone is
-        // the plain stream; anything with Lorenzo-2 or regression is the block-composed one, built for 3-D arrays with
-        // block edges 4..8. Elsewhere the set falls back to its Lorenzo-1 member (the stream's header says which predictor
-        // coded it, the host API clears the flags it did not honour in the trailer) and is refused when it has none.
-        const uint32_t mask = (conf->lorenzo ? 1u : 0u) | (conf->lorenzo2 ? 2u : 0u) | (conf->regression ? 4u : 0u);
-        if (mask == 0) return fail(SZ3HIP_EINVAL, "All lorenzo and regression methods are disabled.");
-        if (mask != 1u) {
-            if (blk_shape_ok(conf) && !(szk_dbg_flags & 16384)) return stage1_blocks(ctx, conf, d_in, eb, radius, num, mask, s);
-            if (!(mask & 1u))
-                return fail(SZ3HIP_EUNSUPPORTED, "2nd-order Lorenzo / regression without Lorenzo are built for 3-D arrays with blockSize 4..8 "
-                                                 "(got N = %d, blockSize = %d)", conf->N, conf->blockSize);
-        }
-    }
     return stage1_lorenzo(ctx, conf, d_in, eb, radius, num, s);
 }
 
-static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream_t s);
 extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t cap, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
@@ -971,19 +1067,8 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     const uint64_t n = ctx->proto.n;
     if (cap < payload_bound_n(n, std::max<uint64_t>(ctx->out_cap, ctx->cur_out_cap)))
         return fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
-    ctx->s2_payload = d_payload;
-    ctx->s2_cap = cap;
-    int rc = stage2_launch(ctx, d_payload, cap, s);
-    if (rc) return rc;
-    ctx->stage2_done = true;
-    return 0;
-}
-static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream_t s) {
-    const uint64_t n = ctx->proto.n;
     szk_cb_params cb;
     cb_params_from(ctx, cb, ctx->cur_out_cap);
-    if (ctx->range_ready && !cb.range_ready)  // stage 1 kept the range of the LOCAL histogram, the caller then changed it (all-reduce):
-        HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, 16, s));  // k_hist_range starts from zero
     prof_begin(ctx, ST_CODEBOOK, s);
     int rc = szk_launch_codebook(ctx->d_hist, &cb, s);
     if (rc) return fail(SZ3HIP_EHIP, "codebook kernel launch failed (%d)", rc);
@@ -994,8 +1079,12 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     lp.out_cap = ctx->cur_out_cap;
     lp.info = ctx->d_info;
     lp.state = ctx->d_state;
-    lp.side_bytes = ctx->proto.predictor == 2 ? ctx->d_blk_counters + 2 : nullptr;
     prof_end(ctx, ST_CODEBOOK, s);
+    prof_begin(ctx, ST_ENCODE, s);  // (the payload layout is computed inside the encoder's scan launch)
+    rc = szk_launch_encode(ctx->d_codes, n, ctx->d_enc, ctx->d_info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words, ctx->d_chunk_off,
+                           ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, &lp, s);
+    prof_end(ctx, ST_ENCODE, s);
+    if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
     szk_asm_params ap;
     ap.n_vout = ctx->d_counters + 0;
     ap.n_dout = ctx->d_counters + 1;
@@ -1011,14 +1100,13 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     ap.dout_idx = ctx->d_dout_idx;
     ap.vout_val = ctx->d_vout_val;
     ap.dout_val = ctx->d_dout_val;
-    ap.side = ctx->proto.predictor == 2 ? ctx->d_blk_side : nullptr;
-    prof_begin(ctx, ST_ENCODE, s);  // (the payload layout is computed inside the encoder's scan launch, the sections are assembled by the packer's)
-    rc = szk_launch_encode(ctx->d_codes, n, ctx->d_enc, ctx->d_info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words, ctx->d_chunk_off,
-                           ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, &lp, &ap, s);
-    prof_end(ctx, ST_ENCODE, s);
-    if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
+    prof_begin(ctx, ST_ASSEMBLE, s);
+    rc = szk_launch_assemble(&ap, s);
+    prof_end(ctx, ST_ASSEMBLE, s);
+    if (rc) return fail(SZ3HIP_EHIP, "assemble kernel launch failed (%d)", rc);
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(szk_state), hipMemcpyDeviceToHost, s));
     // (h_state->probe = the probe counters: |delta| > 127, in [4096, 8192), in [2048, 4096); [4] = interpolation codes beyond +-4096)
+    ctx->stage2_done = true;
     return 0;
 }
 
@@ -1027,21 +1115,9 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     HIPCHK(hipSetDevice(ctx->device));
     if (!ctx->stage2_done) return fail(SZ3HIP_EINVAL, "finish called before stage2");
     HIPCHK(hipStreamSynchronize(s));
-    if (ctx->h_state->mispredict) {
-        // the code-book form launched alone met the other form's alphabet (the data changed character since the previous
-        // call): stage 2 once more with both forms; histogram, range words and outlier lists are as stage 1 left them
-        ctx->cb_hint = -1;
-        HIPCHK(hipMemsetAsync(ctx->d_counters + 7, 0, 8, s));
-        int rc2 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s);
-        if (rc2) return rc2;
-        HIPCHK(hipStreamSynchronize(s));
-        if (ctx->h_state->mispredict) return fail(SZ3HIP_EHIP, "code book was not built (both forms declined)");
-    }
     ctx->stage1_done = ctx->stage2_done = false;
     const szk_state &st = *ctx->h_state;
     if (st.hdr.magic != SZH_MAGIC) return fail(SZ3HIP_EHIP, "device did not produce a payload header (kernel fault?)");
-    ctx->cb_hint = st.n_symbols > SZK_CB_SMALL_SYMS ? 1 : 0;
-    if (st.hdr.predictor == 2) ctx->blk_wide = st.hdr.sym_count > 3000 ? 1 : 0;  // the block kernels' LDS histogram window of the next call
     ctx->stats.n = st.hdr.n;
     ctx->stats.n_value_outliers = st.hdr.n_vout;
     ctx->stats.n_delta_outliers = st.hdr.n_dout;
@@ -1051,7 +1127,6 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     ctx->stats.max_code_len = st.hdr.max_len;
     ctx->stats.n_symbols = 0;
     ctx->stats.narrow_codes = ctx->mode.allow && (uint64_t)st.probe[0] * 4096ull <= ctx->mode.n_samples;
-    if (st.hdr.predictor == 0 && ctx->mode.allow) ctx->narrow_hint = ctx->stats.narrow_codes ? 1 : 0;
     ctx->stats.reserved = (ctx->wide16 > 0 ? 1u : 0u) | (st.probe[1] << 1);  // (development: window used, far-delta count)
     if (st.hdr.predictor == 1)  // interpolation: second histogram tier of the next call (one workgroup per CU against three)
     {
@@ -1149,8 +1224,7 @@ extern "C" int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, ui
 extern "C" void sz3hip_debug_force_generic(int on) { szk_force_generic = on; }
 extern "C" void sz3hip_debug_flags(int flags) {
     szk_dbg_flags = flags;
-    szk_interp_novec = (flags & 128) != 0;  // 128: interpolation without the 8-wide level-1 kernels and without the level kernels
-    szk_interp_min_blocks = (flags & 4194304) ? 1 : 256;  // 4194304: level kernels whatever the array's size
+    szk_interp_novec = (flags & 128) != 0;  // 128: interpolation without the 8-wide level-1 kernels
 }
 extern "C" int sz3hip_debug_codebook_info(sz3hip_ctx *ctx, uint64_t *out16) {
     HIPCHK(hipSetDevice(ctx->device));
@@ -1168,36 +1242,23 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     HIPCHK(hipSetDevice(ctx->device));
     if (payload_size < sizeof(szh_header)) return fail(SZ3HIP_EFORMAT, "payload shorter than its header");
     szh_header h;
-    uint32_t *ovf = reinterpret_cast<uint32_t *>(ctx->d_counters + 12);  // overflow flag of the half-width chain (see below)
-    if (!ctx->h_ovf) {
-        HIPCHK(hipHostMalloc((void **)&ctx->h_ovf, 8));
-        *ctx->h_ovf = 0;
-        HIPCHK(hipMemsetAsync(ovf, 0, 4, s));
-    }
     HIPCHK(hipMemcpyAsync(&ctx->h_state->hdr, d_payload, sizeof(szh_header), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(ctx->h_ovf, ovf, 4, hipMemcpyDeviceToHost, s));  // (the previous call's: rides with the header's round trip)
     HIPCHK(hipStreamSynchronize(s));
-    if (*ctx->h_ovf) ctx->half_skip = 8;  // that stream's values did not fit: the next calls go straight to full width
-    else if (ctx->half_skip > 0) ctx->half_skip--;
     h = ctx->h_state->hdr;
     if (h.magic != SZH_MAGIC || h.version != SZH_VERSION) return fail(SZ3HIP_EFORMAT, "not an SZH1 payload");
-    if (h.predictor > 2) return fail(SZ3HIP_EFORMAT, "unknown predictor id %d in the SZH1 header", h.predictor);
-    if (h.predictor != 2 && h.side_bytes) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (side section)");
-    if (h.side_bytes > payload_size) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (side section)");
     if (h.dtype != ctx->dtype) return fail(SZ3HIP_EINVAL, "payload data type does not match the context");
     if (h.n == 0 || h.n > ctx->max_n) return fail(SZ3HIP_EINVAL, "payload element count exceeds the context capacity");
     if (h.dims[0] * h.dims[1] * h.dims[2] * h.dims[3] != h.n || h.chunk_syms != SZH_CHUNK_SYMS ||
         h.n_chunks != (h.n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS || h.sym_count > SZH_HIST_BINS ||
         h.sym_min + h.sym_count > SZH_HIST_BINS || h.max_len > SZH_MAX_LEN || h.radius < 2 || h.radius > 32768 ||
-        h.qbytes != (h.dtype == 0 ? 4 : 8) || h.n_vout > h.n || h.n_dout > h.n || h.bitstream_words > payload_size / 4)
+        h.qbytes != (h.dtype == 0 ? 4 : 8))
         return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header");
     szh_offsets o;
     szk_host_offsets(&h, &o);
     if (o.end > payload_size || h.payload_bytes != o.end) return fail(SZ3HIP_EFORMAT, "truncated SZH1 payload");
     const uint8_t *pl = (const uint8_t *)d_payload;
     prof_begin(ctx, ST_DEC_HUFF, s);
-    int rc = szk_launch_dec_tables(pl + o.lens, h.sym_min, h.sym_count, ctx->d_tables, ovf, (const uint16_t *)(pl + o.chunkwords), h.n_chunks,
-                                   ctx->d_chunk_off, ctx->d_counters + 3, s);
+    int rc = szk_launch_dec_tables(pl + o.lens, h.sym_min, h.sym_count, ctx->d_tables, s);
     if (rc) return fail(SZ3HIP_EHIP, "dec_tables kernel launch failed (%d)", rc);
     szk_dec_params dp;
     dp.n = h.n;
@@ -1214,34 +1275,13 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     dp.scan_row = fuse_x ? (uint32_t)row : 0u;
     dp.radius = h.radius;
     dp.q_bytes = h.qbytes;
-    dp.reserved = ((szk_dbg_flags & 524288) ? 1u : 0u) | ((szk_dbg_flags & 1048576) ? 2u : 0u);  // (experiments: no stores / direct stores)
+    dp.reserved = 0;
     dp.q_out = d_out;
     dp.dout_idx = reinterpret_cast<const uint64_t *>(pl + o.dout_idx);
     dp.dout_val = pl + o.dout_val;
     dp.n_dout = h.n_dout;
     dp.carry = fuse_x && (SZH_CHUNK_SYMS % row) != 0 ? (void *)ctx->d_codes : nullptr;  // (the code array is idle in this mode)
-    dp.half = 0;
-    dp.ovf = nullptr;
-    dp.gate = nullptr;
-    // Half-width intermediates: the x-scanned lattice differences of a smooth f32 field fit int16, and the strided scans that
-    // follow then move half the bytes (the code array, idle in the fused mode, holds them). The decoder and the scans raise a
-    // flag on a value that does not fit; the full-width chain is enqueued right behind with that flag as its gate (its kernels
-    // return at once while it is clear), so the call stays asynchronous and correct either way.
-    const bool half = fuse_x && !dp.carry && szk_half_scans_ok(&h) && ctx->half_skip == 0 && !(szk_dbg_flags & 2097152);
-    if (half) {
-        dp.half = 1;
-        dp.ovf = ovf;
-        dp.q_out = ctx->d_codes;
-    }
     rc = szk_launch_decode(pl, &dp, ctx->d_codes, ctx->d_chunk_off, ctx->d_counters + 3, s);
-    if (!rc && half) {
-        rc = szk_launch_reconstruct_half(pl, &h, &o, reinterpret_cast<int16_t *>(ctx->d_codes), d_out, ovf, s);
-        dp.half = 0;
-        dp.ovf = nullptr;
-        dp.gate = ovf;
-        dp.q_out = d_out;
-        if (!rc) rc = szk_launch_decode(pl, &dp, ctx->d_codes, ctx->d_chunk_off, ctx->d_counters + 3, s);
-    }
     prof_end(ctx, ST_DEC_HUFF, s);
     if (rc) return fail(SZ3HIP_EHIP, "decode kernel launch failed (%d)", rc);
     prof_begin(ctx, ST_DEC_RECON, s);
@@ -1259,41 +1299,382 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         ip.eb = h.eb;
         ip.radius = (int)h.radius;
         rc = szk_launch_interp_decompress(ctx->dtype, &ip, pl, o.vout_idx, o.vout_val, h.n_vout, ctx->d_codes, d_out, s);
-    } else if (h.predictor == 2) {
-        // block-composed stream: selection + coefficients from the side section, then the blocks in anti-diagonal fronts
-        const uint32_t B = h.interp_id, mask = h.interp_dir;
-        if (h.ndim != 3 || B < 4 || B > 8 || mask == 0 || mask > 7 || h.side_bytes < 24 || h.n_dout > h.n)
-            return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block predictor fields)");
-        uint64_t nblocks = 1;
-        for (int i = 0; i < 3; i++) nblocks *= (h.dims[1 + i] + B - 1) / B;
-        if (nblocks > 0x7FFFFFF0ull) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block count)");
-        int rb = blk_reserve(ctx, nblocks);
-        if (rb) return rb;
-        HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr, pl + o.side, 24, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        uint32_t coding, sel_bits;
-        uint64_t nb_side, nr;
-        memcpy(&coding, ctx->h_blk_side_hdr, 4);
-        memcpy(&sel_bits, ctx->h_blk_side_hdr + 4, 4);
-        memcpy(&nb_side, ctx->h_blk_side_hdr + 8, 8);
-        memcpy(&nr, ctx->h_blk_side_hdr + 16, 8);
-        const uint64_t sel_bytes = ((nblocks + 3) / 4 + 7) & ~7ull;
-        const uint64_t ngroups = (nr + 63) / 64;
-        const uint64_t fixed = 24 + sel_bytes + 8 + 4 * ngroups;  // header, selection, Rice parameters, group offsets
-        if (coding != 1 || sel_bits != 2 || nb_side != nblocks || nr > nblocks || h.side_bytes < fixed || (h.side_bytes - fixed) % 4)
-            return fail(SZ3HIP_EFORMAT, "corrupt side section of a block-predictor stream");
-        const uint64_t bit_words = (h.side_bytes - fixed) / 4;
-        szk_blk_params bp;
-        szk_blk_scratch sc;
-        blk_params_from(ctx, h.dims + 1, B, mask, h.eb, (int)h.radius, 0, bp, sc);
-        memcpy(sc.side_hdr, ctx->h_blk_side_hdr, 24);
-        memcpy(sc.side_hdr + 24, &bit_words, 8);
-        rc = szk_launch_blk_decompress(ctx->dtype, ctx->d_codes, d_out, &bp, &sc, pl, &h, &o, ctx->d_blk_coef, s);
     } else {
-        rc = szk_launch_reconstruct(fuse_x ? 1 : 0, pl, &h, &o, ctx->d_codes, d_out, ctx->d_segtot, s, half ? ovf : nullptr);
+        rc = szk_launch_reconstruct(fuse_x ? 1 : 0, pl, &h, &o, ctx->d_codes, d_out, ctx->d_segtot, s);
     }
     prof_end(ctx, ST_DEC_RECON, s);
     if (rc) return fail(SZ3HIP_EHIP, "reconstruct kernel launch failed (%d)", rc);
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// host-buffer API: SZ_compress<T> / SZ_decompress<T> equivalents
+// ------------------------------------------------------------------------------------------------------------
+static const uint32_t kMagic = 0xF342F310u;                          // include/SZ3/version.hpp.in:10
+static const uint32_t kDataVer = (3u << 24) | (3u << 16) | (2u << 8);  // SZ3_DATA_VERSION 3.3.2 (CMakeLists.txt:7)
+
+static inline bool dtype_ok(int dt) { return dt == SZ3HIP_FLOAT || dt == SZ3HIP_DOUBLE || dt == SZ3HIP_INT32 || dt == SZ3HIP_INT64; }
+static inline bool dtype_is_int(int dt) { return dt == SZ3HIP_INT32 || dt == SZ3HIP_INT64; }
+static inline size_t dtype_size(int dt) { return (dt == SZ3HIP_FLOAT || dt == SZ3HIP_INT32) ? 4 : 8; }
+static inline int dtype_compute(int dt) { return dtype_is_int(dt) ? SZ3HIP_DOUBLE : dt; }  // integers ride the f64 pipeline
+
+extern "C" size_t sz3hip_compress_bound(const sz3hip_config *c, int dataType) {  // api/impl/SZImpl.hpp:34-44
+    if (zs::load()) return 0;
+    unsigned char tmp[160];
+    const size_t es = dtype_size(dataType);
+    return 4096 + sz3hip_config_save(c, tmp) + zs::bound_frames((size_t)c->num * es);
+}
+
+namespace {
+// one cached context per (device, dtype); grown on demand. The host API is serialised per process.
+std::mutex g_ctx_mu;
+sz3hip_ctx *g_ctx[2];
+void *g_dev_in[2], *g_dev_payload[2];
+size_t g_dev_in_bytes[2], g_dev_payload_bytes[2];
+
+int host_device() {
+    const char *e = getenv("SZ3HIP_DEVICE");
+    return e ? atoi(e) : 0;
+}
+sz3hip_ctx *get_ctx(int dtype, uint64_t n) {
+    sz3hip_ctx *&c = g_ctx[dtype];
+    if (c && c->max_n >= n) return c;
+    if (c) sz3hip_ctx_destroy(c);
+    c = sz3hip_ctx_create(host_device(), n, dtype);
+    return c;
+}
+// pinned host staging for the payload (the device <-> host hop of the host API): DMA at link speed, no page faults
+void *g_pin;
+size_t g_pin_bytes;
+int ensure_pin(size_t want) {
+    if (g_pin_bytes >= want) return 0;
+    if (g_pin) (void)hipHostFree(g_pin);
+    g_pin = nullptr;
+    g_pin_bytes = 0;
+    want += want / 4;  // (payload sizes vary from call to call)
+    HIPCHK(hipHostMalloc(&g_pin, want));
+    g_pin_bytes = want;
+    return 0;
+}
+int ensure_dev(void **p, size_t *have, size_t want) {
+    if (*have >= want) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    HIPCHK(hipMalloc(p, want));
+    *have = want;
+    return 0;
+}
+}  // namespace
+
+// utils/Statistic.hpp:32-56 with the range taken from the device min/max kernel
+static int cal_abs_eb(sz3hip_config &conf, sz3hip_ctx *ctx, const void *d_in) {
+    if (conf.errorBoundMode == SZ3HIP_EB_ABS) return 0;
+    double range = 0;
+    if (conf.errorBoundMode != SZ3HIP_EB_L2NORM) {
+        double mn, mx;
+        int rc = sz3hip_minmax_device(ctx, d_in, conf.num, &mn, &mx, nullptr);
+        if (rc) return rc;
+        // data_range computes max - min in T (Statistic.hpp:12-21)
+        range = ctx->dtype == SZ3HIP_FLOAT ? (double)((float)mx - (float)mn) : mx - mn;
+    }
+    switch (conf.errorBoundMode) {
+        case SZ3HIP_EB_REL: conf.absErrorBound = conf.relErrorBound * range; break;
+        case SZ3HIP_EB_PSNR: {  // computeABSErrBoundFromPSNR, Statistic.hpp:25-30, threshold 0.99
+            double v1 = conf.psnrErrorBound + 10 * log10(1 - 2.0 / 3.0 * 0.99);
+            conf.absErrorBound = range * pow(10, v1 / (-20));
+            break;
+        }
+        case SZ3HIP_EB_L2NORM: conf.absErrorBound = sqrt(3.0 / (double)conf.num) * conf.l2normErrorBound; break;
+        case SZ3HIP_EB_ABS_AND_REL: conf.absErrorBound = std::min(conf.absErrorBound, conf.relErrorBound * range); break;
+        case SZ3HIP_EB_ABS_OR_REL: conf.absErrorBound = std::max(conf.absErrorBound, conf.relErrorBound * range); break;
+        default: return fail(SZ3HIP_EINVAL, "Error bound mode not supported");
+    }
+    conf.errorBoundMode = SZ3HIP_EB_ABS;
+    return 0;
+}
+
+// SZ3HIP_TIMING=1: wall-clock breakdown of the host API on stderr (development aid)
+struct HostTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    HostTimer() : on(getenv("SZ3HIP_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void lap(const char *what) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sz3hip] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, const void *data, char *cmpData,
+                                  size_t cmpCap) {
+    HostTimer tm;
+    if (!dtype_ok(dataType)) {
+        fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
+        return 0;
+    }
+    const bool is_int = dtype_is_int(dataType);
+    const int cdt = dtype_compute(dataType);  // the type the kernels compute in
+    sz3hip_config conf = *config;  // sz.hpp:45
+    if (conf.N < 1 || conf.N > 4) {
+        fail(SZ3HIP_EINVAL, "Data dimension higher than 4 is not supported.");
+        return 0;
+    }
+    if (zs::load()) return 0;
+    if (cmpCap < sz3hip_compress_bound(&conf, dataType)) {  // sz.hpp:47-49
+        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+        return 0;
+    }
+    const size_t es = dtype_size(dataType);
+    const size_t raw_bytes = (size_t)conf.num * es;
+    unsigned char *out = reinterpret_cast<unsigned char *>(cmpData);
+    Writer w{out};
+    w.put<uint32_t>(kMagic);
+    w.put<uint32_t>(kDataVer);
+    unsigned char *size_pos = w.p;
+    w.p += 8;
+    unsigned char tmp[160];
+    const size_t payload_cap = cmpCap - 16 - 2 * sz3hip_config_save(&conf, tmp);
+    size_t payload_size = 0;
+
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    bool lossless = conf.cmprAlgo == SZ3HIP_ALGO_LOSSLESS;
+    if (!lossless) {
+        sz3hip_ctx *ctx = get_ctx(cdt, conf.num);
+        if (!ctx) return 0;
+        if (ensure_dev(&g_dev_in[cdt], &g_dev_in_bytes[cdt], (size_t)conf.num * (cdt == SZ3HIP_FLOAT ? 4 : 8))) return 0;
+        const size_t pb = sz3hip_payload_bound(ctx, conf.num);
+        if (ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], pb)) return 0;
+        tm.lap("setup");
+        if (!is_int) {
+            if (hipMemcpy(g_dev_in[cdt], data, raw_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+                fail(SZ3HIP_EHIP, "host->device copy failed");
+                return 0;
+            }
+            tm.lap("host->device");
+        } else {
+            // integers: staged in the (still unused) payload buffer, widened to f64 on the device
+            if (pb < raw_bytes + 16 && ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], raw_bytes + 16)) return 0;
+            if (hipMemcpy(g_dev_payload[cdt], data, raw_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemsetAsync(ctx->d_counters + 5, 0, 8, nullptr) != hipSuccess) {
+                fail(SZ3HIP_EHIP, "host->device copy failed");
+                return 0;
+            }
+            if (szk_launch_int_to_f64(dataType == SZ3HIP_INT64, g_dev_payload[cdt], conf.num, (double *)g_dev_in[cdt],
+                                      reinterpret_cast<uint32_t *>(ctx->d_counters + 5), nullptr)) {
+                fail(SZ3HIP_EHIP, "integer widening kernel failed");
+                return 0;
+            }
+            uint32_t big = 0;
+            if (hipMemcpy(&big, ctx->d_counters + 5, 4, hipMemcpyDeviceToHost) != hipSuccess) {
+                fail(SZ3HIP_EHIP, "device->host copy failed");
+                return 0;
+            }
+            if (big) lossless = true;  // |x| > 2^53 is not exact in f64: keep such arrays lossless
+        }
+        if (!lossless && cal_abs_eb(conf, ctx, g_dev_in[cdt])) return 0;
+        if (is_int) {
+            // |x - x^| <= eb between integers means <= floor(eb); the lattice 2*floor(eb) keeps every reconstruction integral
+            conf.absErrorBound = std::floor(conf.absErrorBound);
+            conf.errorBoundMode = SZ3HIP_EB_ABS;
+        }
+        if (conf.absErrorBound == 0) lossless = true;  // SZDispatcher.hpp:19-21
+        if (!lossless) {
+            // ALGO_LORENZO_REG / NOPRED -> HIP Lorenzo stream (16); ALGO_INTERP / ALGO_INTERP_LORENZO -> HIP interpolation (17)
+            size_t dsize = 0;
+            int rc = sz3hip_compress_device(ctx, &conf, g_dev_in[cdt], g_dev_payload[cdt], g_dev_payload_bytes[cdt], &dsize, nullptr);
+            tm.lap("device compress");
+            if (rc == SZ3HIP_EOUTLIERS && g_dev_payload_bytes[cdt] < sz3hip_payload_bound_max(ctx, conf.num)) {
+                // room for the largest lists, then once more (the device call grows them to what the input needs)
+                if (ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], sz3hip_payload_bound_max(ctx, conf.num))) return 0;
+                rc = sz3hip_compress_device(ctx, &conf, g_dev_in[cdt], g_dev_payload[cdt], g_dev_payload_bytes[cdt], &dsize, nullptr);
+            }
+            if (rc == SZ3HIP_EOUTLIERS) {
+                lossless = true;  // same policy as the reference's length_error fallback, SZDispatcher.hpp:44-59
+            } else if (rc) {
+                return 0;
+            } else if (dsize + 64 >= raw_bytes) {
+                lossless = true;  // the GPU stream would not even beat the raw array (tiny or incompressible input)
+            } else {
+                if (ensure_pin(dsize)) return 0;
+                if (hipMemcpy(g_pin, g_dev_payload[cdt], dsize, hipMemcpyDeviceToHost) != hipSuccess) {
+                    fail(SZ3HIP_EHIP, "device->host copy failed");
+                    return 0;
+                }
+                tm.lap("device->host");
+                payload_size = zs::compress_frames((const uint8_t *)g_pin, dsize, w.p, payload_cap);
+                if (!payload_size) return 0;
+                tm.lap("zstd");
+                conf.cmprAlgo = ctx->h_state->hdr.predictor == 1 ? SZ3HIP_ALGO_HIP_INTERP : SZ3HIP_ALGO_HIP_LORENZO;
+                if ((double)raw_bytes / (double)payload_size < 3) {  // SZDispatcher.hpp:62-74
+                    std::vector<uint8_t> z(zs::bound_frames(raw_bytes) + 8);
+                    size_t zsz = zs::compress_frames((const uint8_t *)data, raw_bytes, z.data(), z.size());
+                    if (zsz && zsz < payload_size && zsz <= payload_cap) {
+                        memcpy(w.p, z.data(), zsz);
+                        payload_size = zsz;
+                        conf.cmprAlgo = SZ3HIP_ALGO_LOSSLESS;
+                    }
+                }
+            }
+        }
+    }
+    if (lossless) {
+        conf.cmprAlgo = SZ3HIP_ALGO_LOSSLESS;
+        payload_size = zs::compress_frames((const uint8_t *)data, raw_bytes, w.p, payload_cap);
+        if (!payload_size) return 0;
+    }
+    uint64_t ps = payload_size;
+    memcpy(size_pos, &ps, 8);
+    w.p += payload_size;
+    conf.openmp = 0;
+    conf.dataType = (uint8_t)dataType;  // lets the decoder refuse a request for another element type
+    w.p += sz3hip_config_save(&conf, w.p);
+    return (size_t)(w.p - out);
+}
+
+extern "C" int sz3hip_peek_config(sz3hip_config *conf, const char *cmpData, size_t cmpSize) {
+    if (cmpSize < 16 + 8) return fail(SZ3HIP_EFORMAT, "compressed buffer too small");
+    Reader r{reinterpret_cast<const unsigned char *>(cmpData)};
+    if (r.get<uint32_t>() != kMagic)  // sz.hpp:122-125
+        return fail(SZ3HIP_EFORMAT, "magic number mismatch, the input data is not compressed by SZ3");
+    const uint32_t ver = r.get<uint32_t>();
+    if ((ver >> 8) != (kDataVer >> 8))  // sz.hpp:127-135 compares major.minor.patch
+        return fail(SZ3HIP_EFORMAT, "Please use SZ3 v%u.%u.%u to decompress the data", ver >> 24, (ver >> 16) & 255,
+                    (ver >> 8) & 255);
+    const uint64_t payload = r.get<uint64_t>();
+    if (payload > cmpSize - 16) return fail(SZ3HIP_EFORMAT, "payload size exceeds the buffer");
+    sz3hip_config_load(conf, r.p + payload);
+    return 0;
+}
+
+extern "C" int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *cmpData, size_t cmpSize, void *decData) {
+    if (!dtype_ok(dataType))
+        return fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
+    int rc = sz3hip_peek_config(conf, cmpData, cmpSize);
+    if (rc) return rc;
+    const bool is_int = dtype_is_int(dataType);
+    const int cdt = dtype_compute(dataType);
+    if (dtype_is_int(conf->dataType) != is_int)
+        return fail(SZ3HIP_EINVAL, "the stream holds %s data but %s output was requested", dtype_is_int(conf->dataType) ? "integer" : "floating-point",
+                    is_int ? "integer" : "floating-point");
+    if (zs::load()) return SZ3HIP_EZSTD;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(cmpData) + 8;
+    uint64_t payload;
+    memcpy(&payload, p, 8);
+    p += 8;
+    const size_t es = dtype_size(dataType);
+    const size_t raw_bytes = (size_t)conf->num * es;
+    if (conf->cmprAlgo == SZ3HIP_ALGO_LOSSLESS) {  // SZDispatcher.hpp:81-88
+        uint64_t len = 0;
+        if (payload >= 8) memcpy(&len, p, 8);
+        if (len != raw_bytes)
+            return fail(SZ3HIP_EFORMAT, "Decompressed data size does not match the original data size");
+        return zs::decompress_frames(p, payload, (uint8_t *)decData, raw_bytes) == raw_bytes ? 0 : SZ3HIP_EZSTD;
+    }
+    if (conf->cmprAlgo != SZ3HIP_ALGO_HIP_LORENZO && conf->cmprAlgo != SZ3HIP_ALGO_HIP_INTERP)
+        return fail(SZ3HIP_EUNSUPPORTED,
+                    "stream uses cmprAlgo %d of the CPU reference; this library decodes only its own GPU streams (ids %d, %d) "
+                    "and ALGO_LOSSLESS",
+                    conf->cmprAlgo, SZ3HIP_ALGO_HIP_LORENZO, SZ3HIP_ALGO_HIP_INTERP);
+    if (payload < 8) return fail(SZ3HIP_EFORMAT, "truncated payload");
+    uint64_t raw_len;
+    memcpy(&raw_len, p, 8);
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    if ((rc = ensure_pin(raw_len))) return rc;
+    if (zs::decompress_frames(p, payload, (uint8_t *)g_pin, raw_len) != raw_len) return SZ3HIP_EZSTD;
+    sz3hip_ctx *ctx = get_ctx(cdt, conf->num);
+    if (!ctx) return SZ3HIP_EHIP;
+    const size_t cbytes = (size_t)conf->num * (cdt == SZ3HIP_FLOAT ? 4 : 8);
+    if ((rc = ensure_dev(&g_dev_in[cdt], &g_dev_in_bytes[cdt], cbytes))) return rc;
+    if ((rc = ensure_dev(&g_dev_payload[cdt], &g_dev_payload_bytes[cdt], std::max<size_t>(raw_len + 64, is_int ? raw_bytes : 0)))) return rc;
+    HIPCHK(hipMemcpy(g_dev_payload[cdt], g_pin, raw_len, hipMemcpyHostToDevice));
+    rc = sz3hip_decompress_device(ctx, g_dev_payload[cdt], raw_len, g_dev_in[cdt], nullptr);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    if (ctx->h_state->hdr.n != conf->num) return fail(SZ3HIP_EFORMAT, "payload element count does not match the trailer");
+    if (ctx->h_state->hdr.dtype != (uint8_t)cdt) return fail(SZ3HIP_EINVAL, "the stream's element type does not match the requested one");
+    if (!is_int) {
+        HIPCHK(hipMemcpy(decData, g_dev_in[cdt], raw_bytes, hipMemcpyDeviceToHost));  // (the runtime pins large pageable buffers
+                                                                                       // itself: a hand-made pinned pipeline was slower)
+    } else {
+        rc = szk_launch_f64_to_int(dataType == SZ3HIP_INT64, (const double *)g_dev_in[cdt], conf->num, g_dev_payload[cdt], nullptr);
+        if (rc) return fail(SZ3HIP_EHIP, "integer narrowing kernel failed");
+        HIPCHK(hipMemcpy(decData, g_dev_payload[cdt], raw_bytes, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the reference's C ABI (tools/sz3c/include/sz3c.h:52-59, tools/sz3c/src/sz3c.cpp:11-94)
+// ------------------------------------------------------------------------------------------------------------
+extern "C" unsigned char *SZ_compress_args(int dataType, void *data, size_t *outSize, int errBoundMode,
+                                           double absErrBound, double relBoundRatio, double pwrBoundRatio, size_t r5,
+                                           size_t r4, size_t r3, size_t r2, size_t r1) {
+    (void)pwrBoundRatio;  // sz3c.cpp:29 ignores it too
+    uint64_t d[4];
+    int nd;
+    if (r2 == 0) { nd = 1; d[0] = r1; }
+    else if (r3 == 0) { nd = 2; d[0] = r2; d[1] = r1; }
+    else if (r4 == 0) { nd = 3; d[0] = r3; d[1] = r2; d[2] = r1; }
+    else if (r5 == 0) { nd = 4; d[0] = r4; d[1] = r3; d[2] = r2; d[3] = r1; }
+    else { nd = 4; d[0] = r5 * r4; d[1] = r3; d[2] = r2; d[3] = r1; }  // sz3c.cpp:24
+    sz3hip_config conf;
+    sz3hip_config_init(&conf, nd, d);
+    conf.absErrorBound = absErrBound;
+    conf.relErrorBound = relBoundRatio;
+    if (errBoundMode == ABS) conf.errorBoundMode = SZ3HIP_EB_ABS;
+    else if (errBoundMode == REL) conf.errorBoundMode = SZ3HIP_EB_REL;
+    else if (errBoundMode == ABS_AND_REL) conf.errorBoundMode = SZ3HIP_EB_ABS_AND_REL;
+    else if (errBoundMode == ABS_OR_REL) conf.errorBoundMode = SZ3HIP_EB_ABS_OR_REL;
+    else {
+        printf("errBoundMode %d not support\n ", errBoundMode);  // sz3c.cpp:39-40
+        exit(0);
+    }
+    if (dataType != SZ_FLOAT && dataType != SZ_DOUBLE) {
+        printf("dataType %d not support\n", dataType);  // sz3c.cpp:51-52
+        exit(0);
+    }
+    const size_t cap = sz3hip_compress_bound(&conf, dataType);
+    unsigned char *buf = static_cast<unsigned char *>(malloc(cap));  // C memory, released by free_buf (sz3c.cpp:56-58)
+    if (!buf) return nullptr;
+    const size_t n = sz3hip_compress(&conf, dataType, data, reinterpret_cast<char *>(buf), cap);
+    if (n == 0) {
+        fprintf(stderr, "SZ_compress_args: %s\n", sz3hip_last_error());
+        free(buf);
+        *outSize = 0;
+        return nullptr;
+    }
+    *outSize = n;
+    unsigned char *shrunk = static_cast<unsigned char *>(realloc(buf, n));
+    return shrunk ? shrunk : buf;
+}
+
+extern "C" void *SZ_decompress(int dataType, unsigned char *bytes, size_t byteLength, size_t r5, size_t r4, size_t r3,
+                               size_t r2, size_t r1) {
+    size_t n;  // sz3c.cpp:66-77
+    if (r2 == 0) n = r1;
+    else if (r3 == 0) n = r1 * r2;
+    else if (r4 == 0) n = r1 * r2 * r3;
+    else if (r5 == 0) n = r1 * r2 * r3 * r4;
+    else n = r1 * r2 * r3 * r4 * r5;
+    if (dataType != SZ_FLOAT && dataType != SZ_DOUBLE) {
+        printf("dataType %d not support\n", dataType);  // sz3c.cpp:90-91
+        exit(0);
+    }
+    sz3hip_config conf;
+    if (sz3hip_peek_config(&conf, reinterpret_cast<const char *>(bytes), byteLength)) {
+        fprintf(stderr, "SZ_decompress: %s\n", sz3hip_last_error());
+        return nullptr;
+    }
+    if (conf.num > n) n = (size_t)conf.num;
+    void *dec = malloc(n * (dataType == SZ_FLOAT ? 4 : 8));
+    if (!dec) return nullptr;
+    if (sz3hip_decompress(&conf, dataType, reinterpret_cast<const char *>(bytes), byteLength, dec)) {
+        fprintf(stderr, "SZ_decompress: %s\n", sz3hip_last_error());
+        free(dec);
+        return nullptr;
+    }
+    return dec;
+}
+
+extern "C" void free_buf(void *p) { free(p); }  // sz3c.cpp:94

@@ -1,0 +1,205 @@
+// sz3_amd/csrc/sz3hip_kernels.h — parameter blocks and host launchers of the gfx950 kernels (sz3hip_kernels.hip)
+#ifndef SZ3HIP_KERNELS_H
+#define SZ3HIP_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sz3hip_format.h"
+
+// lattice constants derived from the absolute error bound (identical on the encode and the decode side)
+struct szk_lattice {
+    double recip, two_eb, eb;        // f64 data: 1/(2eb), 2eb, eb
+    float recip_f, two_eb_f, eb_lo_f;  // f32 data: (float)(1/(2eb)), (float)(2eb), largest float <= eb
+};
+static inline szk_lattice szk_make_lattice(double eb) {
+    szk_lattice l;
+    l.eb = eb;
+    l.two_eb = 2.0 * eb;
+    l.recip = 1.0 / l.two_eb;
+    l.recip_f = (float)l.recip;
+    l.two_eb_f = (float)l.two_eb;
+    float e = (float)eb;
+    if ((double)e > eb) e = __builtin_nextafterf(e, 0.0f);
+    l.eb_lo_f = e;
+    return l;
+}
+
+#define SZK_K1_GRID 2048u  // rows of hist_partial = upper bound of the persistent stage-1 grid
+
+#define SZK_PROBE_STRIDE 32768ull  // the probe looks at 64 consecutive elements of every 32768
+// narrow-code mode (see k_probe): a pure function of the probe counter, evaluated on the device by every kernel
+struct szk_mode {
+    uint32_t *probe_big;          // number of probed deltas outside [-127, 127]
+    uint32_t pack_wide;           // host-side choice: the packer caches 8192 instead of 4096 encode-table entries in LDS
+    uint64_t n_samples;           // number of probed elements
+    uint64_t n_total;             // elements of the array
+    uint32_t allow;               // 0: always two-byte codes
+};
+
+struct szk_k1_params {
+    uint64_t d[4];  // extents slowest first, left-padded with 1: [w][z][y][x]
+    szk_lattice lat;
+    uint32_t radius;
+    uint32_t dbg;      // ablation switches for tools/k1_lab.py (0 in production)
+    szk_mode mode;
+    uint64_t out_cap;  // capacity of each outlier list
+    uint64_t *hist;    // [SZH_HIST_BINS]
+    uint32_t *hist_partial;  // [SZK_K1_GRID][1024] private histogram rows of the persistent stage-1 workgroups
+    uint64_t *n_vout, *n_dout;
+    uint64_t *vout_idx, *dout_idx;
+    void *vout_val, *dout_val;
+    // host side only (profiling): HIP events recorded right before / after the predictor kernel itself, so that its own
+    // duration can be set against the per-kernel average of a rocprofv3 trace
+    void *prof_ev0, *prof_ev1;
+    // two-byte marching kernel: 16384-bin LDS histogram window instead of 8192 (64 KB: 2 workgroups per CU). Codes outside the
+    // window cost a global atomic each; when the previous call of the context saw an alphabet wider than the small window the
+    // large one pays (C4's f64 slab: 0.6 % of the deltas beyond +-4096, stage 1 0.57 -> 0.36 ms)
+    uint32_t wide16;
+};
+
+struct szk_cb_info {
+    uint32_t n_symbols, max_len, sym_min, sym_count;
+    uint32_t win_lo, reserved;  // first symbol of the packers' LDS window of the encode table
+    uint64_t ts[12];  // phase timestamps (wall_clock64, 100 MHz) for tools/cb_lab.py
+};
+struct szk_cb_params {
+    uint32_t *enc;   // [65536] (code << 5) | len
+    uint8_t *lens;   // [65536]
+    uint64_t *keys;  // [65536] scratch (freq << 16 | sym)
+    uint16_t *syms;  // [65536] compacted alphabet in symbol order
+    uint64_t *ifreq;
+    uint16_t *pleaf, *pint, *depth, *aux2, *pint2;  // [65536] scratch for alphabets > 2048 symbols
+    uint32_t *range;                 // [4] see k_hist_range
+    // the two outlier lists, sorted by blocks 1 and 2 of the same launch
+    uint64_t *vout_idx, *dout_idx;
+    void *vout_val, *dout_val;
+    const uint64_t *n_vout, *n_dout;
+    uint64_t out_cap;
+    int t_is_32bit, q_is_32bit;
+    szk_cb_info *info;
+    uint32_t n_books;  // 0/1: one code book (+ the outlier sorts); 2..SZK_MAX_BOOKS: a batch, tables sliced per book
+    uint32_t dbg;      // development switches, filled by the launcher from the debug flags (1: force the one-class fallback)
+};
+#define SZK_MAX_BOOKS 4
+#define SZK_MAX_TRIALS 8  // tuner trials of one launch group
+
+struct szk_state {
+    szh_header hdr;
+    szh_offsets off;
+    uint32_t overflow, cap_exceeded;
+    uint32_t probe[6];  // copy of the probe counters (d_counters + 4): one device-to-host copy brings everything the host reads
+};
+struct szk_layout_params {
+    szh_header proto;
+    const uint64_t *n_vout, *n_dout;
+    uint64_t out_cap;
+    const szk_cb_info *info;
+    szk_state *state;
+};
+struct szk_asm_params {
+    const uint64_t *n_vout, *n_dout;
+    uint64_t out_cap;
+    int t_is_32bit, q_is_32bit;
+    szk_state *state;
+    uint8_t *payload;
+    uint64_t cap;
+    const uint64_t *total_words;
+    const uint8_t *lens;
+    const uint16_t *chunk_words;
+    const uint64_t *vout_idx, *dout_idx;
+    const void *vout_val, *dout_val;
+};
+
+#define DEC_LUT_BITS 12u
+struct szk_dec_tables {
+    uint32_t first_code[SZH_MAX_LEN + 2], first_rank[SZH_MAX_LEN + 2], count[SZH_MAX_LEN + 2];
+    uint32_t max_len, n_coded, lut_bits, reserved;
+    uint16_t sorted_syms[65536];
+    uint32_t lut[1u << DEC_LUT_BITS];  // next lut_bits bits -> (symbol << 8) | length, 0 = longer code word
+};
+struct szk_dec_params {
+    uint64_t n, n_chunks;
+    uint64_t bitstream_off, total_words;  // the bit-stream section of the payload and its length in 32-bit words
+    const uint16_t *chunk_words;  // inside the payload
+    const uint64_t *group_off;    // word offset of every group of 32 chunks (k_scan_groups)
+    const szk_dec_tables *tables;
+    uint32_t single_sym;
+    // Lorenzo streams with rows of at most one chunk and a sorted delta-outlier list (<= 32768 records): the decoder turns the codes into deltas and
+    // prefix-sums them along x itself (scan_row = row length, 0 = plain code output). A row that starts in the previous
+    // chunk misses that chunk's running sum: every chunk leaves it in carry[] and k_scan_carry adds it afterwards (not
+    // needed when the row length divides the chunk).
+    uint32_t scan_row, radius, q_bytes, reserved;  // q_bytes: 4 = int32 lattice (f32 data), 8 = int64 (f64 data)
+    void *q_out;  // lattice deltas summed along x: int32 (f32 data) / int64 (f64 data), n elements
+    void *carry;  // [n_chunks] running sum at the end of every chunk (same type), nullptr when rows start on chunk boundaries
+    // delta outliers of a fused stream (code 0): the sorted (index, delta) lists inside the payload, searched by index
+    const uint64_t *dout_idx;
+    const void *dout_val;  // int32 / int64 like q_out
+    uint64_t n_dout;
+};
+
+// ---- interpolation predictor (sz3hip_interp.hip) ----
+struct szk_interp_params {  // what InterpolationDecomposition keeps (decomposition/InterpolationDecomposition.hpp:456-477)
+    int N;
+    uint64_t dims[4];  // slowest first, exactly N entries
+    int interp_id, direction;
+    uint64_t anchor_stride;
+    double alpha, beta, eb;
+    int radius;
+    uint64_t *n_vout, *vout_idx;
+    void *vout_val;
+    uint64_t out_cap;
+    uint32_t hist_big;   // histogram pass with the 16384-bin second tier (host choice, from the previous call's far count)
+    uint32_t hist_tail;  // with hist_big: the codes beyond +-8192 are counted by three windowed passes in LDS (k_hist_tail)
+    uint32_t *far_cnt;   // [0] receives the number of codes outside +-4096 of the radius, [1] (hist_big form) outside +-8192
+};
+struct szk_interp_pass {
+    int N, dir, interp_id, old_api, subpass, radius;
+    int kind;     // 0: anchor grid, 1: first point (no anchors), 2: directional pass
+    int no_store; // compression, final pass of the schedule: nothing reads its reconstruction, so it is not written
+    uint64_t dims[4], off[4], start[4], step[4], cnt[4];
+    uint64_t total, s, bsz;
+    uint64_t batch_stride;  // elements between the independent arrays of a batch (grid.y), 0 = one array
+    double eb, eb_recip;
+    uint64_t *n_vout, *vout_idx;
+    void *vout_val;
+    uint64_t out_cap;
+};
+extern int szk_interp_novec;
+// d_in == nullptr: d_work already holds the copy of the input (made on a side stream while the tuner ran)
+int szk_launch_interp_compress(int dtype, const szk_interp_params *ip, const void *d_in, void *d_work, uint16_t *codes,
+                               uint64_t *hist, hipStream_t s);
+int szk_launch_interp_decompress(int dtype, const szk_interp_params *ip, const uint8_t *payload, uint64_t vout_idx_off,
+                                 uint64_t vout_val_off, uint64_t n_vout, uint16_t *codes, void *d_out, hipStream_t s);
+
+int szk_launch_profile_blocks(int dtype, const void *d_in, int N, const uint64_t *dims, uint64_t bs, uint64_t stride, double abseb,
+                              uint8_t *d_flags, uint64_t *total_out, hipStream_t s);
+int szk_launch_gather_blocks(int dtype, const void *d_in, int N, const uint64_t *dims, uint64_t edge, const uint64_t *d_starts,
+                             uint32_t nblocks, void *d_out, hipStream_t s);
+#define SZK_TRIAL_MAX_PASSES 64
+int szk_launch_interp_trials(int dtype, const szk_interp_params *ips, uint32_t ntrials, const void *d_samples, void *d_work,
+                             uint16_t *codes, uint32_t nblocks, uint64_t *d_hists, szk_interp_pass *h_passes, szk_interp_pass *d_passes,
+                             uint32_t *h_np, uint32_t *d_np, hipStream_t s);
+// res (4 words per book): entropy of the histogram in 1/256 bit, symbols in use, counters[0], counters[1]
+// unpred_is_code0: the unpredictable count of an interpolation trial is its number of points coded 0 (hist[0])
+int szk_launch_code_cost(const uint64_t *hist, const uint64_t *counters, uint64_t *d_res, uint32_t n_books, uint64_t total,
+                         int unpred_is_code0, hipStream_t s);
+
+int szk_launch_int_to_f64(int is64, const void *d_in, uint64_t n, double *d_out, uint32_t *d_flag, hipStream_t s);
+int szk_launch_f64_to_int(int is64, const double *d_in, uint64_t n, void *d_out, hipStream_t s);
+int szk_launch_minmax(int dtype, const void *d_in, uint64_t n, double *d_partial /*[2*1024]*/, double *d_out /*[2]*/, hipStream_t s);
+int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, szk_k1_params *p, hipStream_t s);
+int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStream_t s);
+int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
+                      szk_mode mode, uint16_t *chunk_words, uint64_t *group_off /*[n_chunks/32 + 1]*/, uint64_t *total_words,
+                      const szk_state *state, uint8_t *payload, const szk_layout_params *layout, hipStream_t s);
+int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
+int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, hipStream_t s);
+int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t *codes, uint64_t *chunk_off,
+                      uint64_t *total_words, hipStream_t s);
+// x_done: the decoder already produced the x-scanned lattice values in d_out (szk_dec_params::scan_row)
+int szk_launch_reconstruct(int x_done, const uint8_t *payload, const szh_header *h, const szh_offsets *o, const uint16_t *codes,
+                           void *d_out, void *d_segtot, hipStream_t s);
+void szk_host_offsets(const szh_header *h, szh_offsets *o);
+extern int szk_force_generic;
+extern int szk_dbg_flags;
+
+#endif

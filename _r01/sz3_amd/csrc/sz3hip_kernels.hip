@@ -26,7 +26,114 @@
 #include "sz3hip_format.h"
 #include "sz3hip_kernels.h"
 
-#include "sz3hip_devutil.h"
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// Wave-wide inclusive scan / sum with DPP lane moves (no LDS round trip; __shfl_up lowers to ds_bpermute, ~100 cycles
+// per step): Kogge-Stone inside the rows of 16 lanes (row_shr 1, 2, 4, 8), then row_bcast:15 carries the row totals into
+// rows 1 and 3 and row_bcast:31 the half-wave total into rows 2 and 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov0(uint32_t v) {  // lanes without a source (or outside ROW_MASK) read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_mov0(uint64_t v) {
+    const uint32_t lo = dpp_mov0<CTRL, ROW_MASK>((uint32_t)v), hi = dpp_mov0<CTRL, ROW_MASK>((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+template <typename V>
+__device__ __forceinline__ V wave_incl_scan(V v) {
+    using U = typename std::conditional<sizeof(V) == 8, uint64_t, uint32_t>::type;
+    U u = (U)v;
+    u += dpp_mov0<0x111, 0xf>(u);  // row_shr:1
+    u += dpp_mov0<0x112, 0xf>(u);  // row_shr:2
+    u += dpp_mov0<0x114, 0xf>(u);  // row_shr:4
+    u += dpp_mov0<0x118, 0xf>(u);  // row_shr:8
+    u += dpp_mov0<0x142, 0xa>(u);  // row_bcast:15 -> rows 1, 3
+    u += dpp_mov0<0x143, 0xc>(u);  // row_bcast:31 -> rows 2, 3
+    return (V)u;
+}
+template <typename V>
+__device__ __forceinline__ V wave_sum(V v) {  // total in every lane
+    const V incl = wave_incl_scan(v);
+    if (sizeof(V) == 8) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)incl, WAVE - 1);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)incl >> 32), WAVE - 1);
+        return (V)(((uint64_t)hi << 32) | lo);
+    }
+    return (V)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)incl, WAVE - 1);
+}
+
+// reserve one slot of an append-only list for every active lane with want == true: ONE atomic per wave (same-address
+// global atomics run at ~90/us: a field with a third of NaNs would otherwise spend half a second here). Any set of active
+// lanes may call it together. Returns the lane's slot (meaningful only where want).
+__device__ __forceinline__ unsigned long long wave_append_slot(bool want, uint64_t *counter) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return ~0ull;
+    const int lane = lane_id();
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd((unsigned long long *)counter, (unsigned long long)__popcll(m));
+    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader);
+    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), leader);
+    return (((unsigned long long)bhi << 32) | blo) + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+template <typename T> struct QTraits;
+template <> struct QTraits<float> {
+    using Q = int32_t;
+    using UQ = uint32_t;
+};
+template <> struct QTraits<double> {
+    using Q = int64_t;
+    using UQ = uint64_t;
+};
+
+// The quantisation lattice.  q = rint(x / 2eb); the reconstruction x^ = q * 2eb is verified against the bound
+// (same acceptance test as quantizer/LinearQuantizer.hpp:57-60: |dec - data| evaluated in T, compared with eb) and
+// the raw value is kept losslessly when the check fails.  Non-finite or huge values take q = 0 so that neighbours
+// still predict sanely.  The arithmetic type is the data type: f32 data use f32 multiplies (one rounding each, no
+// FMA contraction: built with -ffp-contract=off), f64 data f64 — the decoder applies the identical expression, so
+// the bound that the encoder verified is the bound the user gets.
+template <typename T> struct Lattice;
+template <> struct Lattice<float> {
+    float recip, two_eb, eb_lo;  // (float)(1/(2eb)), (float)(2eb), largest float <= eb
+    __device__ __forceinline__ explicit Lattice(const szk_lattice &l) : recip(l.recip_f), two_eb(l.two_eb_f), eb_lo(l.eb_lo_f) {}
+    __device__ __forceinline__ int32_t quant(float x, bool &bad) const {
+        float s = x * recip;
+        int32_t q = 0;
+        bad = true;
+        if (fabsf(s) < 8388608.0f) {  // 2^23: rintf(s) is an exact integer; false for NaN
+            float r = rintf(s);
+            q = (int32_t)r;
+            float dec = r * two_eb;
+            bad = !(fabsf(dec - x) <= eb_lo);
+        }
+        return q;
+    }
+    __device__ __forceinline__ float dequant(int32_t q) const { return (float)q * two_eb; }
+};
+template <> struct Lattice<double> {
+    double recip, two_eb, eb;
+    __device__ __forceinline__ explicit Lattice(const szk_lattice &l) : recip(l.recip), two_eb(l.two_eb), eb(l.eb) {}
+    __device__ __forceinline__ int64_t quant(double x, bool &bad) const {
+        double s = x * recip;
+        int64_t q = 0;
+        bad = true;
+        if (fabs(s) < 4503599627370496.0) {  // 2^52
+            double r = rint(s);
+            q = (int64_t)r;
+            double dec = r * two_eb;
+            bad = !(fabs(dec - x) <= eb);
+        }
+        return q;
+    }
+    __device__ __forceinline__ double dequant(int64_t q) const { return (double)q * two_eb; }
+};
 
 // ------------------------------------------------------------------------------------------------------------
 // K0: min / max
@@ -538,23 +645,6 @@ __device__ __forceinline__ bool szk_is_narrow(const szk_mode &m) {
     return m.allow && (unsigned long long)(*m.probe_big) * 4096ull <= m.n_samples;
 }
 
-// adds `cnt` to a bin of the global histogram; whoever finds the bin empty also enters it into the alphabet's range words
-// (range[0] = max(65535 - bin), [1] = max bin, [2] = number of non-empty bins): the code book then needs no pass of its own
-// over the 65536 bins (k_hist_range) as long as nobody else touched the histogram
-__device__ __forceinline__ void hist_add_ranged(uint64_t *hist, uint32_t *range, uint32_t sym, unsigned long long cnt) {
-    if (!range) {  // (no range words kept: the add needs no return value — a returning atomic per bin and workgroup made the wide
-                   // window's flush cost 0.47 ms at C4's slab)
-        atomicAdd((unsigned long long *)&hist[sym], cnt);
-        return;
-    }
-    const unsigned long long old = atomicAdd((unsigned long long *)&hist[sym], cnt);
-    if (old == 0) {
-        atomicMax(&range[0], 0xFFFFu - sym);
-        atomicMax(&range[1], sym);
-        atomicAdd(&range[2], 1u);
-    }
-}
-
 template <typename T, int NDIM>
 __global__ __launch_bounds__(256) void k_probe(const T *__restrict__ in, szk_k1_params p, uint64_t n, uint32_t *probe_big) {
     using Q = typename QTraits<T>::Q;
@@ -642,25 +732,25 @@ __device__ __forceinline__ int64_t dpp_wave_shr1(int64_t old, int64_t src) {
 // is specialised for one-byte / two-byte codes and returns at once when the probe chose the other width; the host launches
 // both. The one-byte specialisation needs a third of the LDS (16 KB histogram, 8 KB outlier queue): 4 waves per SIMD
 // instead of 3.
-// geometry of a form's LDS (shared by the kernel, which declares the arrays, and the body, which indexes them)
-template <int MODE, bool WIN16> struct MarchLds {
-    // MODE 1 (one-byte codes) / MODE 4 (two-byte fallback inside the one-byte launch): HIST_WIN x 4 words, short outlier queues
-    static constexpr int WIDE_WIN = MODE == 4 ? HIST_WIN * 4 : (WIN16 ? 2 * MARCH_WIDE_WIN : MARCH_WIDE_WIN);
-    static constexpr int LH_WORDS = (MODE == 1 || MODE == 4) ? HIST_WIN * 4 : WIDE_WIN;
-    static constexpr int OQ = (MODE == 1 || MODE == 4) ? 128 : MARCH_OQ;
-};
-// MODE 0: code width decided at run time; 1 / 2: one-byte / two-byte specialisation of the two-launch form (returns at once
-// when the probe chose the other width); 4: two-byte codes inside the one-byte form's LDS budget (see k_lorenzo_quant_march3)
-template <typename T, int NDIM, int TY, int MODE, bool WIN16>
-__device__ __forceinline__ void march_body(const T *__restrict__ in, uint16_t *__restrict__ codes, const szk_k1_params &p, uint32_t ntasks,
-                                           uint32_t nrows, uint32_t *lh, uint64_t (*s_oq_idx)[MarchLds<MODE, WIN16>::OQ],
-                                           typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type (*s_oq_val)[MarchLds<MODE, WIN16>::OQ]) {
+template <typename T, int NDIM, int TY, int MODE = 0, bool WIN16 = false>
+__global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict__ in, uint16_t *__restrict__ codes,
+                                                             szk_k1_params p, uint32_t ntasks, uint32_t nrows) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     constexpr int NW = NDIM == 4 ? 2 : 1;
-    constexpr int WIDE_WIN = MarchLds<MODE, WIN16>::WIDE_WIN, LH_WORDS = MarchLds<MODE, WIN16>::LH_WORDS, OQ = MarchLds<MODE, WIN16>::OQ;
-    if ((MODE == 1 || MODE == 2) && szk_is_narrow(p.mode) != (MODE == 1)) return;
+    constexpr int WIDE_WIN = WIN16 ? 2 * MARCH_WIDE_WIN : MARCH_WIDE_WIN;
+    constexpr int LH_WORDS = MODE == 1 ? HIST_WIN * 4 : WIDE_WIN;
+    constexpr int OQ = MODE == 1 ? 128 : MARCH_OQ;
+    if (MODE != 0 && szk_is_narrow(p.mode) != (MODE == 1)) return;
+    // LDS histogram. One-byte codes (narrow deltas): 1024 bins x 4 copies around the radius; two-byte codes (deltas of
+    // hundreds or thousands of lattice steps, e.g. C4's 1e-6 on f64): MARCH_WIDE_WIN bins x 1 copy — with the narrow window
+    // nearly every element of such a field would fall through to a global atomic. Last word = overflow bin (never flushed).
+    __shared__ uint32_t lh[LH_WORDS + 4];
+    // per-wave staging of value outliers (NaN / Inf / fill values can be percents of a field): records collect in LDS and go
+    // to the global list in batches, one global atomic per batch instead of one per wave instruction
     using OQV = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;  // raw bits of a value
+    __shared__ uint64_t s_oq_idx[4][OQ];
+    __shared__ OQV s_oq_val[4][OQ];
 
     const uint32_t d0 = (uint32_t)p.d[3], d1 = (uint32_t)p.d[2], d2 = (uint32_t)p.d[1];
     const uint32_t ntx = (d0 + MARCH_TX - 1) / MARCH_TX, nty = (d1 + TY - 1) / TY, ntz = (d2 + MARCH_TZ - 1) / MARCH_TZ;
@@ -669,7 +759,7 @@ __device__ __forceinline__ void march_body(const T *__restrict__ in, uint16_t *_
     const Lattice<T> lat(p.lat);
     const int radius = (int)p.radius;
     const uint32_t copy = (uint32_t)lane & 3u;
-    const bool narrow = MODE == 1 ? true : ((MODE == 2 || MODE == 4) ? false : szk_is_narrow(p.mode));
+    const bool narrow = MODE == 1 ? true : (MODE == 2 ? false : szk_is_narrow(p.mode));
     const uint32_t win_bins = narrow ? (uint32_t)HIST_WIN : (uint32_t)WIDE_WIN;
     const uint32_t win_lo = (uint32_t)radius - win_bins / 2;
     // in-range test of a delta, one form for both code widths: (delta + rng_lo) <= rng_span (unsigned)
@@ -869,16 +959,8 @@ __device__ __forceinline__ void march_body(const T *__restrict__ in, uint16_t *_
                         if (rare && !in_lds) {
                             // code 0 (delta outliers) is one address for the whole grid: one atomic per wave
                             const unsigned long long zm = __ballot(code[i] == 0);
-                            // (the range words are kept by the one-launch kernel's two bodies only: in the two-byte
-                            // specialisation the ranged add — even with a null range — cost 195 of 555 us at C4's slab)
-                            constexpr bool RANGED = MODE == 1 || MODE == 4;
-                            if (RANGED) {
-                                if (code[i] != 0) hist_add_ranged(p.hist, p.range, code[i], 1ull);
-                                else if (lane == __ffsll((long long)zm) - 1) hist_add_ranged(p.hist, p.range, 0u, (unsigned long long)__popcll(zm));
-                            } else {
-                                if (code[i] != 0) atomicAdd((unsigned long long *)&p.hist[code[i]], 1ull);
-                                else if (lane == __ffsll((long long)zm) - 1) atomicAdd((unsigned long long *)&p.hist[0], (unsigned long long)__popcll(zm));
-                            }
+                            if (code[i] != 0) atomicAdd((unsigned long long *)&p.hist[code[i]], 1ull);
+                            else if (lane == __ffsll((long long)zm) - 1) atomicAdd((unsigned long long *)&p.hist[0], (unsigned long long)__popcll(zm));
                         }
                     }
                 }
@@ -898,56 +980,21 @@ __device__ __forceinline__ void march_body(const T *__restrict__ in, uint16_t *_
         for (int bnn = threadIdx.x; bnn < WIDE_WIN; bnn += 256) {
             const uint32_t v = lh[bnn];
             const uint32_t sym = win_lo + (uint32_t)bnn;
-            if (v && sym < SZH_HIST_BINS) {
-                if (MODE == 1 || MODE == 4) hist_add_ranged(p.hist, p.range, sym, (unsigned long long)v);
-                else atomicAdd((unsigned long long *)&p.hist[sym], (unsigned long long)v);
-            }
+            if (v && sym < SZH_HIST_BINS) atomicAdd((unsigned long long *)&p.hist[sym], (unsigned long long)v);
         }
     }
-}
-
-// LDS histogram. One-byte codes (narrow deltas): 1024 bins x 4 copies around the radius; two-byte codes (deltas of
-// hundreds or thousands of lattice steps, e.g. C4's 1e-6 on f64): MARCH_WIDE_WIN bins x 1 copy — with the narrow window
-// nearly every element of such a field would fall through to a global atomic. Last word = overflow bin (never flushed).
-// Per-wave staging of value outliers (NaN / Inf / fill values can be percents of a field): records collect in LDS and go
-// to the global list in batches, one global atomic per batch instead of one per wave instruction.
-template <typename T, int NDIM, int TY, int MODE = 0, bool WIN16 = false>
-__global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict__ in, uint16_t *__restrict__ codes,
-                                                             szk_k1_params p, uint32_t ntasks, uint32_t nrows) {
-    using L = MarchLds<MODE, WIN16>;
-    using OQV = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;
-    __shared__ uint32_t lh[L::LH_WORDS + 4];
-    __shared__ uint64_t s_oq_idx[4][L::OQ];
-    __shared__ OQV s_oq_val[4][L::OQ];
-    march_body<T, NDIM, TY, MODE, WIN16>(in, codes, p, ntasks, nrows, lh, s_oq_idx, s_oq_val);
-}
-// Launched ALONE when the context's previous call chose one-byte codes: the one-byte form's LDS budget (4 waves per SIMD) and
-// its specialised code; the width is still decided by THIS call's probe — should it say two bytes after all, the same LDS
-// serves a 4096-bin window (correct, slower: more codes fall through to global atomics) and the next call is launched in
-// the other form. (One kernel with the width as a run-time flag in the inner loop was 14 % slower: 172 vs 151 us at C2.)
-template <typename T, int NDIM, int TY>
-__global__ __launch_bounds__(256) void k_lorenzo_quant_march3(const T *__restrict__ in, uint16_t *__restrict__ codes,
-                                                              szk_k1_params p, uint32_t ntasks, uint32_t nrows) {
-    using L = MarchLds<1, false>;
-    static_assert(L::LH_WORDS == MarchLds<4, false>::LH_WORDS && L::OQ == MarchLds<4, false>::OQ, "both bodies share the arrays");
-    using OQV = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;
-    __shared__ uint32_t lh[L::LH_WORDS + 4];
-    __shared__ uint64_t s_oq_idx[4][L::OQ];
-    __shared__ OQV s_oq_val[4][L::OQ];
-    if (szk_is_narrow(p.mode)) march_body<T, NDIM, TY, 1, false>(in, codes, p, ntasks, nrows, lh, s_oq_idx, s_oq_val);
-    else march_body<T, NDIM, TY, 4, false>(in, codes, p, ntasks, nrows, lh, s_oq_idx, s_oq_val);
 }
 
 // folds the per-workgroup histogram rows into hist[win_lo + bin]: block (bx, by) sums rows by, by + gridDim.y, ... of
 // 256 bins and adds its partial sum with one 64-bit atomic per non-empty bin (at most gridDim.y atomics per address)
 __global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict__ partial, uint32_t nrows, int win_lo,
-                                                     uint64_t *__restrict__ hist, uint32_t *range) {
+                                                     uint64_t *__restrict__ hist) {
     const int bin = blockIdx.x * 256 + threadIdx.x;
     if (bin >= HIST_WIN) return;
     uint64_t s = 0;
     for (uint32_t r = blockIdx.y; r < nrows; r += gridDim.y) s += partial[(uint64_t)r * HIST_WIN + bin];
     const int sym = win_lo + bin;
-    if (s && sym >= 0 && sym < (int)SZH_HIST_BINS) hist_add_ranged(hist, range, (uint32_t)sym, (unsigned long long)s);
+    if (s && sym >= 0 && sym < (int)SZH_HIST_BINS) atomicAdd((unsigned long long *)&hist[sym], (unsigned long long)s);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -963,7 +1010,7 @@ __global__ __launch_bounds__(256) void k_hist_reduce(const uint32_t *__restrict_
 #define CB_THREADS 256       // threads of the small-alphabet path
 #define CB_LAUNCH 1024       // threads per workgroup of the launch
 #define CB_LDS_SYMS 2048     // capacity of the small-alphabet path's LDS arrays
-#define CB_SMALL_SYMS SZK_CB_SMALL_SYMS    // alphabets up to this size take the small path (serial wave merge: ~0.1 us per symbol);
+#define CB_SMALL_SYMS 256    // alphabets up to this size take the small path (serial wave merge: ~0.1 us per symbol);
                              // beyond it the round-parallel merge of the wide path wins (37 us for 2000 symbols)
 #define CB_POOL_BYTES 131072 // LDS pool, carved per phase
 #define CB_SHORT_SYMS 512    // alphabets up to this size are limited to 16-bit code words
@@ -1252,13 +1299,12 @@ __device__ void cb_merge_wave32(const uint64_t *keys, uint32_t *nfq, uint16_t *p
     uint32_t lreg = lane < m ? (uint32_t)(keys[lane] >> 16) : INF;
     uint32_t nreg = INF;
     uint32_t lpar = 0, npar = 0;  // parents of the window entries
-    // the two queue heads live in scalar registers: a pick compares them there and re-reads only the queue it consumed
-    // (one v_readlane per pick instead of two, no vector compare on the critical path)
-    uint32_t lf = (uint32_t)__builtin_amdgcn_readlane((int)lreg, 0), nf = INF;
     for (uint32_t k = 0; k + 1 < m; k++) {
         uint32_t f = 0;
 #pragma unroll
         for (int t = 0; t < 2; t++) {
+            const uint32_t lf = (uint32_t)__builtin_amdgcn_readlane((int)lreg, (int)(i - ibase));
+            const uint32_t nf = (uint32_t)__builtin_amdgcn_readlane((int)nreg, (int)(j - jbase));
             if (lf <= nf) {
                 f += lf;
                 lpar = lane == i - ibase ? k : lpar;
@@ -1268,7 +1314,6 @@ __device__ void cb_merge_wave32(const uint64_t *keys, uint32_t *nfq, uint16_t *p
                     ibase = i;
                     lreg = ibase + lane < m ? (uint32_t)(keys[ibase + lane] >> 16) : INF;
                 }
-                lf = (uint32_t)__builtin_amdgcn_readlane((int)lreg, (int)(i - ibase));
             } else {
                 f += nf;
                 npar = lane == j - jbase ? k : npar;
@@ -1278,12 +1323,10 @@ __device__ void cb_merge_wave32(const uint64_t *keys, uint32_t *nfq, uint16_t *p
                     jbase = j;
                     nreg = jbase + lane < k ? nfq[jbase + lane] : INF;
                 }
-                nf = (uint32_t)__builtin_amdgcn_readlane((int)nreg, (int)(j - jbase));  // (INF when the queue ran empty: j == k)
             }
         }
         if (k - jbase < WAVE) nreg = (lane == k - jbase) ? f : nreg;
         else if (lane == 0) nfq[k] = f;
-        if (j == k) nf = f;  // the queue was empty: the new node is its head
     }
     if (ibase + lane < i) pleaf[ibase + lane] = (uint16_t)lpar;
     if (jbase + lane < j) pint[jbase + lane] = (uint16_t)npar;
@@ -1297,8 +1340,8 @@ __device__ void cb_merge_wave32(const uint64_t *keys, uint32_t *nfq, uint16_t *p
 // INLDS: 32-bit frequencies in LDS (lf32 leaves, nf32 internals); else 64-bit in global memory (keys, ifreq).
 template <bool INLDS>
 __device__ void cb_merge_rounds(const uint64_t *keys, uint64_t *ifreq, const uint32_t *lf32, uint32_t *nf32,
-                                uint16_t *pleaf, uint16_t *pint, uint32_t m, uint32_t *s_red /* [4], zeroed */, uint32_t NT /* live threads */) {
-    const uint32_t t = threadIdx.x, lane = lane_id();
+                                uint16_t *pleaf, uint16_t *pint, uint32_t m, uint32_t *s_red /* [4], zeroed */) {
+    const uint32_t t = threadIdx.x, NT = blockDim.x, lane = lane_id();
     const uint64_t INF = ~0ull;
     auto LF = [&](uint32_t x) -> uint64_t { return INLDS ? (uint64_t)lf32[x] : keys[x] >> 16; };
     auto NF = [&](uint32_t x) -> uint64_t { return INLDS ? (uint64_t)nf32[x] : ifreq[x]; };
@@ -1633,9 +1676,9 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
         uint32_t *lf32 = reinterpret_cast<uint32_t *>(pool), *nf32 = lf32 + LDSQ;
         for (uint32_t q = t; q < mk; q += NT) lf32[q] = (uint32_t)(p.keys[q] >> 16);
         __syncthreads();
-        cb_merge_rounds<true>(p.keys, p.ifreq, lf32, nf32, pleaf, pint, mk, s_misc, blockDim.x);
+        cb_merge_rounds<true>(p.keys, p.ifreq, lf32, nf32, pleaf, pint, mk, s_misc);
     } else {
-        cb_merge_rounds<false>(p.keys, p.ifreq, nullptr, nullptr, pleaf, pint, mk, s_misc, blockDim.x);
+        cb_merge_rounds<false>(p.keys, p.ifreq, nullptr, nullptr, pleaf, pint, mk, s_misc);
     }
     if (t == 0) p.info->ts[4] = wall_clock64();
     // 4. depth of every internal node by pointer doubling (min(depth, 2^rounds) is all the clamp needs); the four
@@ -1749,7 +1792,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     const uint32_t t = threadIdx.x;
     if (blockIdx.x >= p.n_books) {  // the two blocks after the code books: deterministic order of the two outlier lists
         // (in the launch whose code-book path is the active one, so that they run beside it)
-        if ((PART == 1) != (p.range[2] > CB_SMALL_SYMS) && p.part_hint < 0) return;  // (launched alone: sorts whatever the alphabet)
+        if ((PART == 1) != (p.range[2] > CB_SMALL_SYMS)) return;
         const bool d = blockIdx.x == p.n_books + 1;
         // scratch: the key tables of the batch slots 1 and 2, idle when a single code book is built (n_books <= 1)
         uint64_t *scratch = p.n_books <= 1 ? p.keys + (size_t)(d ? 2 : 1) * SZH_HIST_BINS : nullptr;
@@ -1775,10 +1818,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     }
     // range and number of the non-empty bins: found by k_hist_range (256 workgroups) just before this launch
     const uint32_t n_nonzero = p.range[2];
-    if ((PART == 1) != (n_nonzero > CB_SMALL_SYMS)) {  // the other form's case
-        if (p.part_hint >= 0 && p.mispredict && threadIdx.x == 0) *p.mispredict = 1u;  // launched alone: the host repeats stage 2 with both
-        return;
-    }
+    if ((PART == 1) != (n_nonzero > CB_SMALL_SYMS)) return;  // the other launch's case
     if (n_nonzero == 0) {
         if (t == 0) {
             p.info->n_symbols = 0;
@@ -1875,16 +1915,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
         // single symbol: zero-length code, empty bit-stream (as encoder/HuffmanEncoder.hpp:233-237)
     } else {
         // 3. merge: one wave out of registers (32-bit counts), or thread 0 (64-bit counts)
-        if (s_total < 0xFFFFFFFFull && (p.dbg & 2u)) {  // (development switch: measured slower, 35 vs 28 us at C2)
-            // round-parallel merge on the 256 live threads (every round pairs ALL pending items below the smallest possible
-            // new node, cb_merge_rounds): ~a dozen rounds for a smooth field's 128 symbols instead of 127 dependent picks of
-            // one wave (28 us of the kernel's 38 at C2)
-            uint32_t *nf32 = reinterpret_cast<uint32_t *>(ifreq), *lf32 = nf32 + CB_LDS_SYMS;
-            for (uint32_t q = t; q < m; q += CB_THREADS) lf32[q] = (uint32_t)(keys[q] >> 16);
-            if (t < 4) s_misc[t] = 0;
-            __syncthreads();
-            cb_merge_rounds<true>(keys, ifreq, lf32, nf32, pleaf, pint, m, s_misc, CB_THREADS);
-        } else if (s_total < 0xFFFFFFFFull) {
+        if (s_total < 0xFFFFFFFFull) {
             if (t < WAVE) cb_merge_wave32(keys, reinterpret_cast<uint32_t *>(ifreq), pleaf, pint, m);
         } else if (t == 0) {
             cb_merge(keys, ifreq, pleaf, pint, m);
@@ -1997,8 +2028,6 @@ __device__ __host__ inline void szh_compute_offsets(const szh_header &h, szh_off
     off += 8 * h.n_dout;
     o.dout_val = off;
     off = szh_align16(off + (uint64_t)h.qbytes * h.n_dout);
-    o.side = off;
-    off = szh_align16(off + (h.predictor == 2 ? h.side_bytes : 0));
     o.bitstream = off;
     o.end = off + 4 * h.bitstream_words;
 }
@@ -2014,7 +2043,6 @@ __device__ void layout_pre(const szk_layout_params &p) {  // after K1 + K5, befo
     h.sym_min = p.info->sym_min;
     h.sym_count = p.info->sym_count;
     h.max_len = p.info->max_len;
-    h.side_bytes = p.side_bytes ? *p.side_bytes : 0;
     h.bitstream_words = 0;
     szh_offsets o;
     szh_compute_offsets(h, o);
@@ -2202,18 +2230,12 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
 // consecutive groups per thread and round. The encoder's call also lays the payload out (layout_pre: the
 // sections' offsets depend on the outlier counts and the alphabet, known since the code book kernel) — one launch less.
 #define SCAN_GPT 4
-__device__ void scan_groups_body(const uint16_t *__restrict__ chunk_words, uint64_t n_chunks, uint64_t *__restrict__ group_off,
-                                 uint64_t *total_words);
 __global__ __launch_bounds__(1024) void k_scan_groups(const uint16_t *__restrict__ chunk_words, uint64_t n_chunks,
                                                       uint64_t *__restrict__ group_off, uint64_t *total_words,
                                                       szk_layout_params lp, int do_layout) {
-    if (do_layout && threadIdx.x == 1023) layout_pre(lp);
-    scan_groups_body(chunk_words, n_chunks, group_off, total_words);
-}
-__device__ void scan_groups_body(const uint16_t *__restrict__ chunk_words, uint64_t n_chunks, uint64_t *__restrict__ group_off,
-                                 uint64_t *total_words) {
     __shared__ uint64_t s_w[16];
     __shared__ uint64_t s_carry;
+    if (do_layout && threadIdx.x == 1023) layout_pre(lp);
     const uint64_t n_groups = (n_chunks + PACK_GROUP - 1) / PACK_GROUP;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
@@ -2323,60 +2345,6 @@ __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE]
     return (total_bits + 31) >> 5;
 }
 
-// header + side sections (lens, chunk table, outliers) into the payload. Everything it reads is final before the packer
-// starts (outlier counts and alphabet since the code book, chunk table and total since the offset scan), so it runs as a few
-// extra workgroups of the packer's launch instead of a launch of its own.
-__device__ void assemble_body(const szk_asm_params &p, uint64_t tid, uint64_t nth) {
-    // (the header and the offsets live in LDS, not in private memory: as locals their arrays went to scratch, and a kernel that
-    // uses scratch at all pays for it in every wave — the packer this body rides on ran 213 -> 288 us at C4's slab)
-    __shared__ szh_header s_h0, s_h;
-    __shared__ szh_offsets s_o, s_oo;
-    if (threadIdx.x == 0) {
-        s_h0 = p.state->hdr;
-        s_o = p.state->off;
-    }
-    __syncthreads();
-    const szh_header &h0 = s_h0;
-    const szh_offsets &o = s_o;
-    if (tid == 0) {
-        szh_header &h = s_h;
-        szh_offsets &oo = s_oo;
-        h = s_h0;
-        h.bitstream_words = *p.total_words;
-        szh_compute_offsets(h, oo);
-        h.payload_bytes = oo.end;
-        *reinterpret_cast<szh_header *>(p.payload) = h;
-        p.state->hdr = h;
-        p.state->off = oo;
-        p.state->cap_exceeded = oo.end > p.cap;
-        for (int i = 0; i < 6; i++) p.state->probe[i] = reinterpret_cast<const uint32_t *>(p.n_vout + 4)[i];
-        p.state->mispredict = (uint32_t)p.n_vout[7];                                  // (d_counters[7]: raised by a code-book form launched alone)
-        p.state->n_symbols = reinterpret_cast<const uint32_t *>(p.n_vout + 8)[2];   // (the range words: number of non-empty bins)
-        // alignment gaps between the sections are part of the payload: zero them so that it is a pure function of the input
-        const uint64_t tsz0 = h.dtype == 0 ? 4 : 8;
-        for (uint64_t a = oo.lens + h.sym_count; a < oo.chunkwords; a++) p.payload[a] = 0;
-        for (uint64_t a = oo.chunkwords + 2 * h.n_chunks; a < oo.vout_idx; a++) p.payload[a] = 0;
-        for (uint64_t a = oo.vout_val + tsz0 * h.n_vout; a < oo.dout_idx; a++) p.payload[a] = 0;
-        for (uint64_t a = oo.dout_val + (uint64_t)h.qbytes * h.n_dout; a < oo.side; a++) p.payload[a] = 0;
-        for (uint64_t a = oo.side + (h.predictor == 2 ? h.side_bytes : 0); a < oo.bitstream; a++) p.payload[a] = 0;
-    }
-    for (uint64_t i = tid; i < h0.sym_count; i += nth) p.payload[o.lens + i] = p.lens[h0.sym_min + i];
-    uint16_t *cw = reinterpret_cast<uint16_t *>(p.payload + o.chunkwords);
-    for (uint64_t i = tid; i < h0.n_chunks; i += nth) cw[i] = p.chunk_words[i];
-    uint64_t *vi = reinterpret_cast<uint64_t *>(p.payload + o.vout_idx);
-    uint64_t *di = reinterpret_cast<uint64_t *>(p.payload + o.dout_idx);
-    for (uint64_t i = tid; i < h0.n_vout; i += nth) vi[i] = p.vout_idx[i];
-    for (uint64_t i = tid; i < h0.n_dout; i += nth) di[i] = p.dout_idx[i];
-    const uint64_t tsz = h0.dtype == 0 ? 4 : 8, qsz = h0.qbytes;
-    for (uint64_t i = tid; i < h0.n_vout * tsz; i += nth) p.payload[o.vout_val + i] = ((const uint8_t *)p.vout_val)[i];
-    for (uint64_t i = tid; i < h0.n_dout * qsz; i += nth) p.payload[o.dout_val + i] = ((const uint8_t *)p.dout_val)[i];
-    if (h0.predictor == 2 && p.side)
-        for (uint64_t i = tid; i < h0.side_bytes; i += nth) p.payload[o.side + i] = p.side[i];
-}
-__global__ __launch_bounds__(256) void k_assemble(szk_asm_params p) {
-    assemble_body(p, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
-}
-
 // persistent like k_chunk_bits2: a wave owns a private LDS stage; per chunk it zeroes the words it will use, packs,
 // and streams them out; the next chunk's codes, word count and group offset are already in flight
 // WIN: symbols of the encode table cached in LDS around the most frequent one: ENC_WIN (30 KB of LDS, 5 workgroups per CU)
@@ -2386,12 +2354,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
                                               const uint32_t *__restrict__ g_enc, const szk_cb_info *__restrict__ info,
                                               const uint16_t *__restrict__ chunk_words,
                                               const uint64_t *__restrict__ group_off, szk_mode mode, uint32_t sym_add,
-                                              const szk_state *__restrict__ state, uint8_t *__restrict__ payload, szk_asm_params ap,
-                                              uint32_t pack_blocks) {
-    if (blockIdx.x >= pack_blocks) {  // the launch's last workgroups assemble the payload's other sections meanwhile
-        assemble_body(ap, (uint64_t)(blockIdx.x - pack_blocks) * 256 + threadIdx.x, (uint64_t)(gridDim.x - pack_blocks) * 256);
-        return;
-    }
+                                              const szk_state *__restrict__ state, uint8_t *__restrict__ payload) {
     constexpr int STAGE_WORDS = SZH_CHUNK_SYMS * SZH_MAX_LEN / 32 + 4;  // + slack for the unconditional 3-word emit
     __shared__ uint32_t s_enc[WIN];
     __shared__ uint32_t s_enc8[256];  // one-byte codes: code word by byte value ...
@@ -2399,7 +2362,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     __shared__ uint32_t s_stage[4][STAGE_WORDS];
     const bool narrow = szk_is_narrow(mode);
     const uint64_t n_full = n / SZH_CHUNK_SYMS, n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
-    const uint64_t wave_gid = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE, nwaves = (uint64_t)pack_blocks * 4;
+    const uint64_t wave_gid = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE, nwaves = (uint64_t)gridDim.x * 4;
     const uint64_t lane_off = (uint64_t)lane_id() * ENC_PER_LANE;
     const int lane = lane_id();
     uint32_t *stage = s_stage[threadIdx.x / WAVE];
@@ -2465,7 +2428,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         for (uint32_t i = lane; i < nwords + 2; i += WAVE) {  // copy out and re-zero the stage for the next chunk
             const uint32_t wv = stage[i];
             stage[i] = 0;
-            if (i < nwords) out[i] = __builtin_bswap32(wv);  // bytes in stream order (see sz3hip_format.h)
+            if (i < nwords) out[i] = wv;
         }
         __builtin_amdgcn_wave_barrier();
         cur = nxt;
@@ -2485,8 +2448,43 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         uint32_t *out = out_base + go + before;
-        for (uint32_t i = lane; i < nwords; i += WAVE) out[i] = __builtin_bswap32(stage[i]);
+        for (uint32_t i = lane; i < nwords; i += WAVE) out[i] = stage[i];
     }
+}
+
+// header + side sections (lens, chunk table, outliers) into the payload
+__global__ __launch_bounds__(256) void k_assemble(szk_asm_params p) {
+    const szh_header h0 = p.state->hdr;
+    const szh_offsets o = p.state->off;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    if (tid == 0) {
+        szh_header h = h0;
+        h.bitstream_words = *p.total_words;
+        szh_offsets oo;
+        szh_compute_offsets(h, oo);
+        h.payload_bytes = oo.end;
+        *reinterpret_cast<szh_header *>(p.payload) = h;
+        p.state->hdr = h;
+        p.state->off = oo;
+        p.state->cap_exceeded = oo.end > p.cap;
+        for (int i = 0; i < 6; i++) p.state->probe[i] = reinterpret_cast<const uint32_t *>(p.n_vout + 4)[i];
+        // alignment gaps between the sections are part of the payload: zero them so that it is a pure function of the input
+        const uint64_t tsz0 = h.dtype == 0 ? 4 : 8;
+        for (uint64_t a = oo.lens + h.sym_count; a < oo.chunkwords; a++) p.payload[a] = 0;
+        for (uint64_t a = oo.chunkwords + 2 * h.n_chunks; a < oo.vout_idx; a++) p.payload[a] = 0;
+        for (uint64_t a = oo.vout_val + tsz0 * h.n_vout; a < oo.dout_idx; a++) p.payload[a] = 0;
+        for (uint64_t a = oo.dout_val + (uint64_t)h.qbytes * h.n_dout; a < oo.bitstream; a++) p.payload[a] = 0;
+    }
+    for (uint64_t i = tid; i < h0.sym_count; i += nth) p.payload[o.lens + i] = p.lens[h0.sym_min + i];
+    uint16_t *cw = reinterpret_cast<uint16_t *>(p.payload + o.chunkwords);
+    for (uint64_t i = tid; i < h0.n_chunks; i += nth) cw[i] = p.chunk_words[i];
+    uint64_t *vi = reinterpret_cast<uint64_t *>(p.payload + o.vout_idx);
+    uint64_t *di = reinterpret_cast<uint64_t *>(p.payload + o.dout_idx);
+    for (uint64_t i = tid; i < h0.n_vout; i += nth) vi[i] = p.vout_idx[i];
+    for (uint64_t i = tid; i < h0.n_dout; i += nth) di[i] = p.dout_idx[i];
+    const uint64_t tsz = h0.dtype == 0 ? 4 : 8, qsz = h0.qbytes;
+    for (uint64_t i = tid; i < h0.n_vout * tsz; i += nth) p.payload[o.vout_val + i] = ((const uint8_t *)p.vout_val)[i];
+    for (uint64_t i = tid; i < h0.n_dout * qsz; i += nth) p.payload[o.dout_val + i] = ((const uint8_t *)p.dout_val)[i];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2496,14 +2494,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
 // (len, sym), and a direct lookup table over the next DEC_LUT_BITS bits of the stream: (symbol << 8) | length for every
 // code word of at most DEC_LUT_BITS bits (0 = longer code: length search). One workgroup; <= 65536 symbols.
 __global__ __launch_bounds__(1024) void k_dec_tables(const uint8_t *__restrict__ lens, uint32_t sym_min,
-                                                     uint32_t sym_count, szk_dec_tables *t, uint32_t *zero_word,
-                                                     const uint16_t *__restrict__ chunk_words, uint64_t n_chunks, uint64_t *group_off,
-                                                     uint64_t *total_words) {
-    if (blockIdx.x == 1) {  // the decoder's other preparation, beside the tables: word offsets of the chunk groups
-        scan_groups_body(chunk_words, n_chunks, group_off, total_words);
-        return;
-    }
-    if (zero_word && threadIdx.x == 0) *zero_word = 0;  // (the decoder's overflow flag of a half-width chain)
+                                                     uint32_t sym_count, szk_dec_tables *t) {
     __shared__ uint32_t s_cnt[SZH_MAX_LEN + 2], s_first_code[SZH_MAX_LEN + 2], s_first_rank[SZH_MAX_LEN + 2];
     __shared__ uint16_t s_tbl[(SZH_MAX_LEN + 1) * 1024];  // per-(length, thread) counts -> exclusive ranks
     const uint32_t tid = threadIdx.x, lane = lane_id();
@@ -2587,32 +2578,13 @@ __device__ __forceinline__ QO dec_dout(const szk_dec_params &p, uint64_t elem) {
     return lo < p.n_dout && p.dout_idx[lo] == elem ? reinterpret_cast<const QO *>(p.dout_val)[lo] : (QO)0;
 }
 // QB: 0 = u16 codes out; 4 / 8 = fused Lorenzo x-scan, int32 / int64 lattice values out (see szk_dec_params::scan_row)
-// RING: the lanes' stream words come through LDS. A lane decodes its own chunk, so a wave's loads touch 64 different cache
-// lines per instruction, eight times per line (16 bytes a round): 0.25 of the 0.42 ms of the plain form at C2. Here eight
-// lanes fetch one 128-byte line together for the lane that runs low (its rank among the needy lanes picks the group; the
-// line's address travels through a small LDS mailbox), into that lane's private two-line ring; a line is touched once.
-// RING = words per line of the ring (0: off; 32: whole 128-byte lines, 8 lanes per line, 70 KB of LDS; 16: half lines, 4 lanes
-// per line, 37 KB: two workgroups per CU).
-template <int QB, int RING = 0, bool HALF = false>
+template <int QB>
 __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payload, szk_dec_params p,
                                                 uint16_t *__restrict__ codes) {
     using QO = typename std::conditional<QB == 8, int64_t, int32_t>::type;
-    if (p.gate && *p.gate == 0) return;  // (the full-width chain behind a half-width one that did not overflow)
-    constexpr uint32_t SORTED_LDS = RING ? 2048u : DEC_SORTED_LDS / 2;
-    // Output through LDS: a lane's 16 values of a round are one 32- / 64- / 128-byte run of ITS chunk, 4 KB from its
-    // neighbour's — stored directly, every store instruction touches 64 cache lines with 16 bytes each (0.23 of the kernel's
-    // 0.5 ms at C2: measured by switching the stores off). Staged in LDS and read back piece-major, NP consecutive lanes
-    // write one chunk's run: 64 / NP whole runs per instruction.
-    constexpr uint32_t NP = QB == 8 ? 8 : ((QB == 4 && !HALF) ? 4 : 2);  // 16-byte pieces per lane and round
-    constexpr uint32_t NR = 8 / NP;                             // rounds collected before a store: one whole 128-byte line per chunk
-    __shared__ uint4 s_out[4][64 * (NP * NR + 1)];
-    constexpr uint32_t RL = RING ? RING : 32, RSTRIDE = 2 * RL + 4;  // words per lane: two lines + padding (16-byte aligned rows)
-    constexpr uint32_t LPL = RL / 4;                                   // lanes that fetch one line together (16 bytes each)
     __shared__ uint32_t s_first_code[SZH_MAX_LEN + 2], s_first_rank[SZH_MAX_LEN + 2], s_upper[SZH_MAX_LEN + 2];
     __shared__ uint32_t s_lut[1u << DEC_LUT_BITS];
-    __shared__ uint16_t s_sorted[SORTED_LDS];
-    __shared__ __align__(16) uint32_t s_ring[RING ? 256 * RSTRIDE : 4];
-    __shared__ uint32_t s_mail[RING ? 4 * 16 * 2 : 2];
+    __shared__ uint16_t s_sorted[DEC_SORTED_LDS];
     const uint32_t max_len = p.tables->max_len, K = p.tables->lut_bits, n_coded = p.tables->n_coded;
     if (threadIdx.x <= SZH_MAX_LEN + 1) {
         const uint32_t l = threadIdx.x;
@@ -2626,41 +2598,14 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     for (uint32_t e = threadIdx.x; e < (1u << K); e += 256) s_lut[e] = p.tables->lut[e];
     const uint16_t *sorted = p.tables->sorted_syms;
     const uint32_t base_rank = K < max_len ? p.tables->first_rank[K + 1] : n_coded;
-    for (uint32_t e = threadIdx.x; e < SORTED_LDS && base_rank + e < n_coded; e += 256) s_sorted[e] = sorted[base_rank + e];
+    for (uint32_t e = threadIdx.x; e < DEC_SORTED_LDS && base_rank + e < n_coded; e += 256) s_sorted[e] = sorted[base_rank + e];
     __syncthreads();
-    uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool chunk_live = chunk < p.n_chunks;
-    if (!chunk_live) {
-        if (!RING || max_len == 0) return;
-        chunk = p.n_chunks - 1;  // (stays for the wave's cooperative loads; decodes the last chunk again, stores nothing)
-    }
+    const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk >= p.n_chunks) return;
     const uint64_t s0 = chunk * SZH_CHUNK_SYMS;
-    const uint32_t nsym = !chunk_live ? 0u : (uint32_t)((p.n - s0 < SZH_CHUNK_SYMS) ? (p.n - s0) : SZH_CHUNK_SYMS);
+    const uint32_t nsym = (uint32_t)((p.n - s0 < SZH_CHUNK_SYMS) ? (p.n - s0) : SZH_CHUNK_SYMS);
     uint16_t *out = codes + s0;
     QO *qout = QB ? reinterpret_cast<QO *>(p.q_out) + s0 : nullptr;
-    // (wave-uniform: all 64 lanes decode full chunks — everywhere but in the array's last wave)
-    const bool coop = !(p.reserved & 2u) && __ballot(chunk_live && nsym == SZH_CHUNK_SYMS) == ~0ull;
-    uint4 *stage = s_out[threadIdx.x / WAVE];
-    constexpr uint32_t ELT = QB ? (HALF ? QB / 2 : QB) : 2;  // bytes per output element
-    uint8_t *wave_out = QB ? reinterpret_cast<uint8_t *>(p.q_out) + (s0 - (uint64_t)lane_id() * SZH_CHUNK_SYMS) * ELT
-                           : reinterpret_cast<uint8_t *>(codes + (s0 - (uint64_t)lane_id() * SZH_CHUNK_SYMS));
-    uint32_t ovf_seen = 0;
-    auto coop_store = [&](const uint4 (&pc)[NP], uint32_t rnd) {  // (a chunk is 64 rounds: a multiple of NR)
-        const uint32_t sub = rnd % NR;
-#pragma unroll
-        for (uint32_t j = 0; j < NP; j++) stage[(uint32_t)lane_id() * (NP * NR + 1) + sub * NP + j] = pc[j];
-        if (sub != NR - 1) return;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        const uint32_t i0 = (rnd - sub) * 16;
-#pragma unroll
-        for (uint32_t it = 0; it < NP * NR; it++) {
-            const uint32_t idx = it * 64 + (uint32_t)lane_id(), c = idx / (NP * NR), j = idx % (NP * NR);
-            const uint4 v = stage[c * (NP * NR + 1) + j];
-            *reinterpret_cast<uint4 *>(wave_out + ((uint64_t)c * SZH_CHUNK_SYMS + i0) * ELT + j * 16) = v;
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
     // symbols left in the current row (the chunk may start inside a row); the running sum restarts at every row start
     uint32_t left = QB ? p.scan_row - (uint32_t)(s0 % p.scan_row) : 0u;
     QO acc = 0;
@@ -2692,50 +2637,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     uint64_t buf = 0;  // next bits at the MSB end
     int have = 0;
     uint32_t wi = 0;
-    // ring state: lines [.., buf_line) of the stream section are in this lane's ring (line = RL words, slot = line & 1)
-    uint64_t buf_line = woff / RL;
-    uint32_t *ring = s_ring + (RING ? threadIdx.x * RSTRIDE : 0);
-    uint32_t *mail = s_mail + (RING ? (threadIdx.x / WAVE) * 32 : 0);
-    constexpr uint32_t BATCH = WAVE / LPL;  // lines one cooperative load instruction brings in
-    const uint32_t nrounds = RING ? (SZH_CHUNK_SYMS / 16) : (nsym + 15) / 16;  // (RING: every lane of the wave walks all rounds)
-    for (uint32_t rnd = 0; rnd < nrounds; rnd++) {
-        const uint32_t i0 = rnd * 16;
-        if (RING) {
-            // a round consumes at most 16 x 24 bits = 12 words: whoever has fewer than 13 buffered ahead gets its next line
-            // (then the line two back, whose slot is overwritten, is behind the lane: 13 <= RL)
-            bool need = i0 < nsym && (int64_t)(buf_line * RL) - (int64_t)(woff + wi) < 13;
-            unsigned long long m = __ballot(need);
-            while (m) {
-                const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
-                if (need && rank < BATCH) {
-                    mail[rank * 2] = (uint32_t)lane_id();
-                    mail[rank * 2 + 1] = (uint32_t)buf_line;  // (sections of < 2^37 bytes)
-                }
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                const uint32_t cnt = (uint32_t)__popcll(m);
-                const uint32_t grp = (uint32_t)lane_id() / LPL, sub = (uint32_t)lane_id() % LPL;
-                if (grp < (cnt < BATCH ? cnt : BATCH)) {
-                    const uint32_t tgt = mail[grp * 2], line = mail[grp * 2 + 1];
-                    uint64_t a = (uint64_t)line * RL + sub * 4;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (a + 3 <= wlast) v = *reinterpret_cast<const uint4 *>(bs + a);  // (the section is 16-byte aligned)
-                    else {
-                        uint32_t t[4];
-                        for (int k = 0; k < 4; k++) t[k] = a + k <= wlast ? bs[a + k] : 0u;
-                        v = make_uint4(t[0], t[1], t[2], t[3]);
-                    }
-                    *reinterpret_cast<uint4 *>(s_ring + ((threadIdx.x & ~63u) + tgt) * RSTRIDE + (line & 1u) * RL + sub * 4) = v;
-                }
-                if (need && rank < BATCH) {
-                    buf_line++;
-                    need = (int64_t)(buf_line * RL) - (int64_t)(woff + wi) < 13;  // (the first fill takes two lines)
-                }
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                m = __ballot(need);
-            }
-        }
+    for (uint32_t i0 = 0; i0 < nsym; i0 += 16) {
         // the next four stream words of this lane, fetched once per 16 symbols with one wait (a load issued inside the
         // divergent refill branch would be waited for at every symbol); typical groups consume 2-3 words, longer ones
         // fall back to single loads
@@ -2743,24 +2645,21 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint64_t a = woff + wi + k;
-            qw[k] = RING ? __builtin_bswap32(ring[(uint32_t)(a & (2 * RL - 1))]) : __builtin_bswap32(bs[a < wlast ? a : wlast]);
+            qw[k] = bs[a < wlast ? a : wlast];
         }
         uint32_t qn = 0;
-        uint32_t syms[16];
-        // code books of at most 16-bit words (every alphabet up to 512 symbols): two symbols never need more than the 32 bits
-        // a refill guarantees, so the buffer is looked at before every second symbol only
-        const bool short_words = max_len <= 16;
+        uint32_t packed[8];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             uint32_t sym = 0;
             // (symbols past the end of the last chunk decode zero padding: harmless, only the stores are guarded)
-            if (((k & 1) == 0 || !short_words) && have <= 32) {
+            if (have <= 32) {
                 uint32_t wd;
                 if (qn < 4) {
                     wd = qn == 0 ? qw[0] : (qn == 1 ? qw[1] : (qn == 2 ? qw[2] : qw[3]));
                 } else {
                     const uint64_t a = woff + wi;
-                    wd = RING ? __builtin_bswap32(ring[(uint32_t)(a & (2 * RL - 1))]) : __builtin_bswap32(bs[a < wlast ? a : wlast]);
+                    wd = bs[a < wlast ? a : wlast];
                 }
                 wd = wi < nwords ? wd : 0u;
                 qn++;
@@ -2768,7 +2667,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                 have += 32;
                 wi++;
             }
-            const uint32_t ent = s_lut[(uint32_t)(buf >> 32) >> (32 - K)];
+            const uint32_t ent = s_lut[(uint32_t)(buf >> (64 - K))];
             uint32_t l = ent & 0xFFu;
             sym = ent >> 8;
             if (ent == 0) {  // longer than the table
@@ -2783,82 +2682,28 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                 uint32_t rank = s_first_rank[l] + ((v >> (32 - l)) - s_first_code[l]);
                 rank = rank < n_coded ? rank : n_coded - 1;  // (corrupt streams must not read out of bounds)
                 const uint32_t rr = rank - base_rank;
-                sym = rr < SORTED_LDS ? (uint32_t)s_sorted[rr] : (uint32_t)sorted[rank];
+                sym = rr < DEC_SORTED_LDS ? (uint32_t)s_sorted[rr] : (uint32_t)sorted[rank];
             }
             buf <<= l;
             have -= (int)l;
-            syms[k] = sym;
+            if (k & 1) packed[k >> 1] |= sym << 16;
+            else packed[k >> 1] = sym;
         }
         if (QB) {  // codes -> deltas (0 = delta outlier: looked up) -> running sum, restarted at every row start
             QO qv[16];
-            uint32_t zero_any = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) zero_any |= syms[k] == 0 ? 1u : 0u;
-            if (!zero_any && left >= 16 && i0 + 16 <= nsym) {
-                // the usual round: no delta outlier among the 16 symbols, no row start inside them
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    acc += (QO)((int)syms[k] - (int)p.radius);
-                    qv[k] = acc;
-                }
-                left -= 16;
-                if (left == 0) {
+            for (int k = 0; k < 16; k++) {
+                const uint32_t sym = (k & 1) ? (packed[k >> 1] >> 16) : (packed[k >> 1] & 0xFFFFu);
+                QO d = (QO)((int)sym - (int)p.radius);
+                if (sym == 0) d = i0 + k < nsym ? dec_dout<QO>(p, s0 + i0 + k) : (QO)0;  // delta outlier (rare)
+                acc += d;
+                qv[k] = acc;
+                if (--left == 0) {
                     acc = 0;
                     left = p.scan_row;
                 }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const uint32_t sym = syms[k];
-                    QO d = (QO)((int)sym - (int)p.radius);
-                    if (sym == 0) d = i0 + k < nsym ? dec_dout<QO>(p, s0 + i0 + k) : (QO)0;  // delta outlier (rare)
-                    acc += d;
-                    qv[k] = acc;
-                    if (--left == 0) {
-                        acc = 0;
-                        left = p.scan_row;
-                    }
-                }
             }
-            if (p.reserved & 1u) {  // (experiment: no output traffic; the sum keeps the work alive)
-                QO sx = 0;
-#pragma unroll
-                for (int k = 0; k < 16; k++) sx += qv[k];
-                if (sx == (QO)0x7FFFFFF1) qout[i0] = sx;
-            } else if (HALF) {
-                // int16 out: 32 bytes per lane and round; a value that does not fit raises the flag (the full-width chain follows)
-                uint32_t hw[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int32_t a = (int32_t)qv[2 * k], b = (int32_t)qv[2 * k + 1];
-                    ovf_seen |= (uint32_t)(a != (int32_t)(int16_t)a) | (uint32_t)(b != (int32_t)(int16_t)b);
-                    hw[k] = ((uint32_t)a & 0xFFFFu) | ((uint32_t)b << 16);
-                }
-                if (coop) {
-                    uint4 pc[NP];
-                    pc[0] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-                    pc[NP > 1 ? 1 : 0] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
-                    coop_store(pc, rnd);
-                } else {
-                    int16_t *ho = reinterpret_cast<int16_t *>(p.q_out) + s0;
-#pragma unroll
-                    for (int k = 0; k < 16; k++)
-                        if (i0 + k < nsym) ho[i0 + k] = (int16_t)qv[k];
-                }
-            } else if (coop) {
-                uint4 pc[NP];
-                if (QB == 4) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) pc[k] = make_uint4((uint32_t)qv[4 * k], (uint32_t)qv[4 * k + 1], (uint32_t)qv[4 * k + 2], (uint32_t)qv[4 * k + 3]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < (int)NP; k++) {
-                        const unsigned long long a = (unsigned long long)qv[(2 * k) & 15], b = (unsigned long long)qv[(2 * k + 1) & 15];
-                        pc[k] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
-                    }
-                }
-                coop_store(pc, rnd);
-            } else if (i0 + 16 <= nsym) {
+            if (i0 + 16 <= nsym) {
                 if (QB == 4) {
                     uint4 *o4 = reinterpret_cast<uint4 *>(qout + i0);
 #pragma unroll
@@ -2874,29 +2719,17 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                 for (int k = 0; k < 16; k++)
                     if (i0 + k < nsym) qout[i0 + k] = qv[k];
             }
-        } else if (coop) {
-            uint32_t packed[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) packed[k] = syms[2 * k] | (syms[2 * k + 1] << 16);
-            uint4 pc[NP];
-            pc[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-            pc[NP > 1 ? 1 : 0] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
-            coop_store(pc, rnd);
         } else if (i0 + 16 <= nsym) {
-            uint32_t packed[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) packed[k] = syms[2 * k] | (syms[2 * k + 1] << 16);
             uint4 *o4 = reinterpret_cast<uint4 *>(out + i0);
             o4[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
             o4[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                if (i0 + k < nsym) out[i0 + k] = (uint16_t)syms[k];
+                if (i0 + k < nsym) out[i0 + k] = (uint16_t)((k & 1) ? (packed[k >> 1] >> 16) : (packed[k >> 1] & 0xFFFF));
         }
     }
-    if (QB && p.carry && chunk_live) reinterpret_cast<QO *>(p.carry)[chunk] = acc;
-    if (HALF && __ballot(ovf_seen != 0) && lane_id() == 0) atomicOr(p.ovf, 1u);
+    if (QB && p.carry) reinterpret_cast<QO *>(p.carry)[chunk] = acc;
 }
 
 // adds the running sum the previous chunk ended with to the head of every chunk that starts inside a row (rows of at most
@@ -3097,63 +2930,20 @@ __device__ __forceinline__ void scan_strided_body(void *buf, uint64_t L, uint64_
 }
 template <typename Q>
 __global__ __launch_bounds__(256) void k_scan_strided(Q *__restrict__ q, uint64_t L, uint64_t inner, uint64_t nlines, uint32_t S,
-                                                      uint64_t Lseg, const Q *__restrict__ totals, const uint32_t *gate) {
+                                                      uint64_t Lseg, const Q *__restrict__ totals) {
     using T = typename std::conditional<sizeof(Q) == 4, float, double>::type;
-    if (gate && *gate == 0) return;
     scan_strided_body<Q, T, false>(q, L, inner, nlines, S, Lseg, totals, szk_lattice{});
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_scan_strided_dequant(void *buf, uint64_t L, uint64_t inner, uint64_t nlines, uint32_t S, uint64_t Lseg,
-                                                              const typename QTraits<T>::Q *__restrict__ totals, szk_lattice l, const uint32_t *gate) {
-    if (gate && *gate == 0) return;
+                                                              const typename QTraits<T>::Q *__restrict__ totals, szk_lattice l) {
     scan_strided_body<typename QTraits<T>::Q, T, true>(buf, L, inner, nlines, S, Lseg, totals, l);
-}
-// Half-width strided scans (f32 data, int16 storage, see szk_dec_params::half): one thread per PAIR of adjacent lines (two
-// neighbouring x), marching along the axis; sums in int32. DEQ = false: in place, a sum outside int16 raises the flag;
-// DEQ = true (the last axis): int16 in, dequantised float out.
-template <bool DEQ>
-__global__ __launch_bounds__(256) void k_scan_strided_half(const int16_t *__restrict__ in, void *__restrict__ outp, uint64_t L, uint64_t inner,
-                                                           uint64_t nlines, szk_lattice l, uint32_t *ovf) {
-    const Lattice<float> lat(l);
-    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index
-    if (id * 2 >= nlines) return;
-    const uint64_t line = id * 2, outer = line / inner, inn = line % inner;
-    const uint64_t base = outer * L * inner + inn;
-    const uint32_t *pin = reinterpret_cast<const uint32_t *>(in + base);  // (inner is even: a pair is one aligned word)
-    const uint64_t step = inner / 2;                                       // words between consecutive elements of a line
-    int32_t r0 = 0, r1 = 0;
-    uint32_t bad = 0;
-    constexpr int DEPTH = 16;  // loads in flight per thread (half as many threads as the full-width scans: twice their depth)
-    for (uint64_t a = 0; a < L; a += DEPTH) {
-        uint32_t w[DEPTH];
-#pragma unroll
-        for (int k = 0; k < DEPTH; k++) w[k] = a + k < L ? pin[(a + k) * step] : 0u;
-#pragma unroll
-        for (int k = 0; k < DEPTH; k++) {
-            if (a + k >= L) break;
-            r0 += (int32_t)(int16_t)(w[k] & 0xFFFFu);
-            r1 += (int32_t)(int16_t)(w[k] >> 16);
-            if (DEQ) {
-                float2 v = make_float2(lat.dequant(r0), lat.dequant(r1));
-                *reinterpret_cast<float2 *>(reinterpret_cast<float *>(outp) + base + (a + k) * inner) = v;
-            } else {
-                bad |= (uint32_t)(r0 != (int32_t)(int16_t)r0) | (uint32_t)(r1 != (int32_t)(int16_t)r1);
-                reinterpret_cast<uint32_t *>(reinterpret_cast<int16_t *>(outp) + base)[(a + k) * step] = ((uint32_t)r0 & 0xFFFFu) | ((uint32_t)r1 << 16);
-            }
-        }
-    }
-    if (!DEQ && __ballot(bad != 0) && lane_id() == 0) atomicOr(ovf, 1u);
-}
-__global__ __launch_bounds__(256) void k_dequant_half(const int16_t *__restrict__ in, float *__restrict__ out, uint64_t n, szk_lattice l) {
-    const Lattice<float> lat(l);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = lat.dequant((int32_t)in[i]);
 }
 
 // lattice index -> value, in place (Q and T have the same size)
 template <typename T>
-__global__ __launch_bounds__(256) void k_dequant(void *buf, uint64_t n, szk_lattice l, const uint32_t *gate) {
+__global__ __launch_bounds__(256) void k_dequant(void *buf, uint64_t n, szk_lattice l) {
     using Q = typename QTraits<T>::Q;
-    if (gate && *gate == 0) return;
     const Lattice<T> lat(l);
     Q *q = reinterpret_cast<Q *>(buf);
     T *o = reinterpret_cast<T *>(buf);
@@ -3225,17 +3015,6 @@ int szk_launch_f64_to_int(int is64, const double *d_in, uint64_t n, void *d_out,
     return 0;
 }
 
-// ---- several slabs on one GPU: their code histograms are summed before / instead of the RCCL exchange ------------------
-__global__ __launch_bounds__(256) void k_hist_add(uint64_t *__restrict__ dst, const uint64_t *__restrict__ src, uint32_t n) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] += src[i];
-}
-int szk_launch_hist_add(uint64_t *d_dst, const uint64_t *d_src, uint32_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_hist_add, dim3((n + 255) / 256), dim3(256), 0, s, d_dst, d_src, n);
-    SZK_CHECK_LAUNCH();
-    return 0;
-}
-
 int szk_launch_minmax(int dtype, const void *d_in, uint64_t n, double *d_partial, double *d_out, hipStream_t s) {
     const int nb = 1024;
     if (dtype == 0) hipLaunchKernelGGL(k_minmax<float>, dim3(nb), dim3(256), 0, s, (const float *)d_in, n, d_partial);
@@ -3272,15 +3051,8 @@ template <typename T, int NDIM, int TY, bool WIN16>
 static void launch_march_w(const void *d_in, uint16_t *codes, const szk_k1_params &p, uint64_t nb, hipStream_t s) {
     uint32_t grid;
     if (p.prof_ev0) (void)hipEventRecord((hipEvent_t)p.prof_ev0, s);
-    if (p.mode.allow && !(szk_dbg_flags & 256) && p.hint_narrow > 0 && !(szk_dbg_flags & 131072)) {
-        // the context's previous call took one-byte codes: one launch of the form built around them (it decides the width from
-        // THIS call's probe and handles either). After a two-byte call the two specialisations below are launched as on a first
-        // call: the run-time-width form is a third slower on two-byte codes (574 vs 363 us at C4's slab) than the specialised one
-        // plus the 4 us of its returning twin.
-        grid = k1_grid((const void *)k_lorenzo_quant_march3<T, NDIM, TY>, (nb + 3) / 4);
-        hipLaunchKernelGGL((k_lorenzo_quant_march3<T, NDIM, TY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
-    } else if (p.mode.allow && !(szk_dbg_flags & 256)) {
-        // (first call of a context) each specialisation gets the grid its own occupancy allows (all workgroups resident: the tasks are dealt by stride;
+    if (p.mode.allow && !(szk_dbg_flags & 256)) {
+        // each specialisation gets the grid its own occupancy allows (all workgroups resident: the tasks are dealt by stride;
         // the two-byte kernel holds 38-72 KB of LDS); the fold reads the larger number of rows, the two-byte kernel leaves
         // them all empty
         const uint32_t g1 = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 1, false>, (nb + 3) / 4);
@@ -3293,7 +3065,7 @@ static void launch_march_w(const void *d_in, uint16_t *codes, const szk_k1_param
         hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 0, WIN16>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
     }
     if (p.prof_ev1) (void)hipEventRecord((hipEvent_t)p.prof_ev1, s);
-    hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist, p.range);
+    hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
 }
 // the marching kernel + histogram fold. When one-byte codes are possible both specialisations are launched (the one the
 // probe did not choose returns at once); the two-byte one with the LDS window the context asks for (szk_k1_params::wide16)
@@ -3320,9 +3092,6 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
     const bool march12 = !szk_force_generic && !(szk_dbg_flags & 32) && (ndim == 1 || ndim == 2) && d0 % 4 == 0 && d0 >= 128 &&
                          d0 < (1ull << 31) && d1 < (1ull << 31) && tiles(MARCH_TX, ndim == 1 ? 1 : MTY, MARCH_TZ) < (1ull << 31);
     if (!march && !march12) p.mode.allow = 0;
-    // (the range words are kept by the one-launch form only: launch_march_w's first branch, same condition)
-    p.range_kept = (march || march12) && p.range && p.mode.allow && !(szk_dbg_flags & 256) && p.hint_narrow > 0 && !(szk_dbg_flags & 131072) ? 1 : 0;
-    if (!p.range_kept) p.range = nullptr;
     switch (ndim) {
         case 1:
             if (march12) {
@@ -3366,7 +3135,7 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
                 nb = tiles(64, 8, FTZ);
                 const uint32_t grid = k1_grid((const void *)k_lorenzo_quant_v4<T, 3, FTZ>, nb);
                 hipLaunchKernelGGL((k_lorenzo_quant_v4<T, 3, FTZ>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
-                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist, (uint32_t *)nullptr);
+                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
                 break;
             }
             nb = tiles(64, 8, 8);
@@ -3387,7 +3156,7 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
                 nb = tiles(64, 8, FTZ);
                 const uint32_t grid = k1_grid((const void *)k_lorenzo_quant_v4<T, 4, FTZ>, nb);
                 hipLaunchKernelGGL((k_lorenzo_quant_v4<T, 4, FTZ>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb);
-                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist, (uint32_t *)nullptr);
+                hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist);
                 break;
             }
             nb = tiles(64, 8, 4);
@@ -3409,22 +3178,20 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
     const uint32_t nb = p->n_books ? p->n_books : 1;  // > 1: batch of independent code books (tuner trials), no outlier sort
     szk_cb_params q = *p;
     q.n_books = nb;
-    q.dbg = ((szk_dbg_flags & 1024) ? 1u : 0u) | ((szk_dbg_flags & 262144) ? 2u : 0u);  // (262144: the small path with the round-parallel merge)
+    q.dbg = (szk_dbg_flags & 1024) ? 1u : 0u;
     if (nb > 1) {  // (a single book's range words are zeroed by the caller together with its counters)
         hipError_t e = hipMemsetAsync(q.range, 0, 16 * nb, s);
         if (e != hipSuccess) return (int)e;
     }
-    if (!p->range_ready) hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256, nb), dim3(256), 0, s, d_hist, q.range);
-    // which of the two forms applies is known on the device only; a context that remembers the previous call's alphabet
-    // launches that form alone (solo): the kernel raises `mispredict` when it is the wrong one and the host repeats stage 2
-    if (p->part_hint != 1) hipLaunchKernelGGL(k_codebook<0>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
-    if (p->part_hint != 0) hipLaunchKernelGGL(k_codebook<1>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
+    hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256, nb), dim3(256), 0, s, d_hist, q.range);
+    hipLaunchKernelGGL(k_codebook<0>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
+    hipLaunchKernelGGL(k_codebook<1>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
     SZK_CHECK_LAUNCH();
     return 0;
 }
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
                       szk_mode mode, uint16_t *chunk_words, uint64_t *group_off, uint64_t *total_words,
-                      const szk_state *state, uint8_t *payload, const szk_layout_params *layout, const szk_asm_params *asmp, hipStream_t s) {
+                      const szk_state *state, uint8_t *payload, const szk_layout_params *layout, hipStream_t s) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
     const uint64_t nb = (n_chunks + 3) / 4;
     if (nb > 0x7FFFFFFFull) return -1;
@@ -3432,16 +3199,12 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
     const uint32_t pgrid = (uint32_t)(nb < 2048 ? nb : 2048);  // persistent: 8 workgroups per CU
     hipLaunchKernelGGL(k_chunk_bits2, dim3(pgrid), dim3(256), 0, s, codes, n, d_enc, info, mode, sym_add, chunk_words);
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, chunk_words, n_chunks, group_off, total_words, *layout, 1);
-    constexpr uint32_t ASM_BLOCKS = 32;
-    if (mode.pack_wide) {
-        const uint32_t pb = pgrid < 768 ? pgrid : 768;
-        hipLaunchKernelGGL((k_pack<2 * ENC_WIN>), dim3(pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
-                           sym_add, state, payload, asmp ? *asmp : szk_asm_params{}, pb);
-    } else {
-        const uint32_t pb = pgrid < 1280 ? pgrid : 1280;
-        hipLaunchKernelGGL((k_pack<ENC_WIN>), dim3(pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
-                           sym_add, state, payload, asmp ? *asmp : szk_asm_params{}, pb);
-    }
+    if (mode.pack_wide)
+        hipLaunchKernelGGL((k_pack<2 * ENC_WIN>), dim3(pgrid < 768 ? pgrid : 768), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
+                           sym_add, state, payload);
+    else
+        hipLaunchKernelGGL((k_pack<ENC_WIN>), dim3(pgrid < 1280 ? pgrid : 1280), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
+                           sym_add, state, payload);
     SZK_CHECK_LAUNCH();
     return 0;
 }
@@ -3451,34 +3214,20 @@ int szk_launch_assemble(const szk_asm_params *p, hipStream_t s) {
     return 0;
 }
 
-int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, uint32_t *zero_word,
-                          const uint16_t *chunk_words, uint64_t n_chunks, uint64_t *group_off, uint64_t *total_words, hipStream_t s) {
-    hipLaunchKernelGGL(k_dec_tables, dim3(chunk_words ? 2 : 1), dim3(1024), 0, s, d_lens, sym_min, sym_count, t, zero_word, chunk_words, n_chunks, group_off,
-                       total_words);
+int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, hipStream_t s) {
+    hipLaunchKernelGGL(k_dec_tables, dim3(1), dim3(1024), 0, s, d_lens, sym_min, sym_count, t);
     SZK_CHECK_LAUNCH();
     return 0;
 }
 int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t *codes, uint64_t *chunk_off,
                       uint64_t *total_words, hipStream_t s) {
     szk_layout_params no_layout{};
-    (void)no_layout;  // (the group offsets are made by the second workgroup of the tables' launch: szk_launch_dec_tables)
-    (void)chunk_off;
-    (void)total_words;
+    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, p->chunk_words, p->n_chunks, chunk_off, total_words, no_layout, 0);  // chunk_off = p->group_off
     const uint64_t nb = (p->n_chunks + 255) / 256;
     if (nb > 0x7FFFFFFFull) return -1;
-    // (development switches 32768 / 65536: stream words through the LDS ring with 32- / 16-word lines)
-    const int ring = (szk_dbg_flags & 32768) ? 32 : ((szk_dbg_flags & 65536) ? 16 : 0);
-#define SZK_DEC(QB)                                                                                                          \
-    do {                                                                                                                     \
-        if (ring == 32) hipLaunchKernelGGL((k_decode<QB, 32>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);      \
-        else if (ring == 16) hipLaunchKernelGGL((k_decode<QB, 16>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes); \
-        else hipLaunchKernelGGL((k_decode<QB, 0>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);                  \
-    } while (0)
-    if (!p->scan_row) SZK_DEC(0);
-    else if (p->q_bytes == 8) SZK_DEC(8);
-    else if (p->half) hipLaunchKernelGGL((k_decode<4, 0, true>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
-    else SZK_DEC(4);
-#undef SZK_DEC
+    if (!p->scan_row) hipLaunchKernelGGL(k_decode<0>, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
+    else if (p->q_bytes == 8) hipLaunchKernelGGL(k_decode<8>, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
+    else hipLaunchKernelGGL(k_decode<4>, dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
     if (p->scan_row && p->carry) {
         const uint64_t cb = (p->n_chunks + 3) / 4;
         if (p->q_bytes == 8)
@@ -3509,7 +3258,7 @@ static int scan_rows(Q *q, uint64_t L, uint64_t nrows, Q *scratch, hipStream_t s
 
 template <typename T>
 static int launch_reconstruct(bool x_done, const uint8_t *payload, const szh_header &h, const szh_offsets &o, const uint16_t *codes,
-                              void *d_out, void *d_segtot, hipStream_t s, const uint32_t *gate) {
+                              void *d_out, void *d_segtot, hipStream_t s) {
     using Q = typename QTraits<T>::Q;
     Q *q = reinterpret_cast<Q *>(d_out);
     const uint64_t n = h.n;
@@ -3556,74 +3305,25 @@ static int launch_reconstruct(bool x_done, const uint8_t *payload, const szh_hea
                                    Lseg, totals);
             if (ax == last_ax)
                 hipLaunchKernelGGL(k_scan_strided_dequant<T>, dim3(grid_for(nlines * S, 256, 0x7FFFFFFF)), dim3(256), 0, s, d_out, La, inner,
-                                   nlines, S, Lseg, (const Q *)totals, szk_make_lattice(h.eb), gate);
+                                   nlines, S, Lseg, (const Q *)totals, szk_make_lattice(h.eb));
             else
                 hipLaunchKernelGGL(k_scan_strided<Q>, dim3(grid_for(nlines * S, 256, 0x7FFFFFFF)), dim3(256), 0, s, q, La, inner, nlines, S, Lseg,
-                                   (const Q *)totals, gate);
+                                   (const Q *)totals);
         }
         inner *= La;
     }
     if (last_ax < 0)
-        hipLaunchKernelGGL(k_dequant<T>, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, d_out, n, szk_make_lattice(h.eb), gate);
+        hipLaunchKernelGGL(k_dequant<T>, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, d_out, n, szk_make_lattice(h.eb));
     if (h.n_vout)
         hipLaunchKernelGGL(k_patch_vout<T>, dim3(grid_for(h.n_vout, 256, 4096)), dim3(256), 0, s, payload, o.vout_idx,
                            o.vout_val, h.n_vout, n, (T *)d_out);
     SZK_CHECK_LAUNCH();
     return 0;
 }
-int szk_launch_expand_deltas(int dtype, const uint16_t *codes, uint64_t n, int radius, const uint8_t *payload, const szh_offsets *o,
-                             uint64_t n_dout, void *d_out, hipStream_t s) {
-    if (dtype == 0) {
-        hipLaunchKernelGGL(k_expand_codes<int32_t>, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, codes, n, radius, (int32_t *)d_out);
-        if (n_dout)
-            hipLaunchKernelGGL(k_scatter_dout<int32_t>, dim3(grid_for(n_dout, 256, 4096)), dim3(256), 0, s, payload, o->dout_idx, o->dout_val, n_dout, n,
-                               (int32_t *)d_out);
-    } else {
-        hipLaunchKernelGGL(k_expand_codes<int64_t>, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, codes, n, radius, (int64_t *)d_out);
-        if (n_dout)
-            hipLaunchKernelGGL(k_scatter_dout<int64_t>, dim3(grid_for(n_dout, 256, 4096)), dim3(256), 0, s, payload, o->dout_idx, o->dout_val, n_dout, n,
-                               (int64_t *)d_out);
-    }
-    SZK_CHECK_LAUNCH();
-    return 0;
-}
 int szk_launch_reconstruct(int x_done, const uint8_t *payload, const szh_header *h, const szh_offsets *o, const uint16_t *codes,
-                           void *d_out, void *d_segtot, hipStream_t s, const uint32_t *gate) {
-    return h->dtype == 0 ? launch_reconstruct<float>(x_done != 0, payload, *h, *o, codes, d_out, d_segtot, s, gate)
-                         : launch_reconstruct<double>(x_done != 0, payload, *h, *o, codes, d_out, d_segtot, s, gate);
-}
-// the shape gives every strided axis enough lines for one thread per line pair (no segment totals) and an even x extent
-int szk_half_scans_ok(const szh_header *h) {
-    if (h->dtype != 0 || h->dims[3] % 2) return 0;
-    for (int ax = 2; ax >= 0; ax--)
-        if (h->dims[ax] > 1 && h->n / h->dims[ax] < 32768) return 0;
-    return 1;
-}
-int szk_launch_reconstruct_half(const uint8_t *payload, const szh_header *h, const szh_offsets *o, int16_t *d_half, void *d_out, uint32_t *ovf,
-                                hipStream_t s) {
-    const uint64_t n = h->n;
-    int last_ax = -1;
-    for (int ax = 2; ax >= 0; ax--)
-        if (h->dims[ax] > 1) last_ax = ax;
-    uint64_t inner = h->dims[3];
-    const szk_lattice lat = szk_make_lattice(h->eb);
-    for (int ax = 2; ax >= 0; ax--) {
-        const uint64_t La = h->dims[ax];
-        if (La > 1) {
-            const uint64_t npairs = n / La / 2;
-            if (ax == last_ax)
-                hipLaunchKernelGGL(k_scan_strided_half<true>, dim3(grid_for(npairs, 256, 0x7FFFFFFF)), dim3(256), 0, s, d_half, d_out, La, inner, n / La, lat, ovf);
-            else
-                hipLaunchKernelGGL(k_scan_strided_half<false>, dim3(grid_for(npairs, 256, 0x7FFFFFFF)), dim3(256), 0, s, d_half, (void *)d_half, La, inner,
-                                   n / La, lat, ovf);
-        }
-        inner *= La;
-    }
-    if (last_ax < 0) hipLaunchKernelGGL(k_dequant_half, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, d_half, (float *)d_out, n, lat);
-    (void)payload;
-    (void)o;
-    SZK_CHECK_LAUNCH();
-    return 0;
+                           void *d_out, void *d_segtot, hipStream_t s) {
+    return h->dtype == 0 ? launch_reconstruct<float>(x_done != 0, payload, *h, *o, codes, d_out, d_segtot, s)
+                         : launch_reconstruct<double>(x_done != 0, payload, *h, *o, codes, d_out, d_segtot, s);
 }
 
 void szk_host_offsets(const szh_header *h, szh_offsets *o) { szh_compute_offsets(*h, *o); }

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""random sweep of the host API (sz3hip_compress / sz3hip_decompress): shapes, dtypes (f32, f64, i32, i64), every error-bound
+mode, every cmprAlgo, quantbinCnt; checks the user-visible guarantee of each mode on the decompressed array"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, sz3_amd
+rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+pool = [1, 2, 5, 8, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 200, 256]
+bad = 0
+for k in range(int(os.environ.get("N", "40"))):
+    nd = int(rng.integers(1, 5))
+    shape = tuple(int(rng.choice(pool)) for _ in range(nd))
+    while np.prod(shape) > 2_000_000: shape = tuple(max(1, s // 2) for s in shape)
+    dt = [np.float32, np.float64, np.int32, np.int64][int(rng.choice([0, 0, 0, 1, 1, 2, 3]))]
+    grids = np.meshgrid(*[np.arange(s, dtype=np.float64) for s in shape], indexing="ij")
+    f = sum(np.sin(2 * np.pi * g / (11.0 + 5 * i)) for i, g in enumerate(grids)) + float(rng.choice([1e-4, 2e-3, 5e-2])) * rng.standard_normal(shape)
+    isint = np.issubdtype(dt, np.integer)
+    a = (f * 1000).astype(dt) if isint else f.astype(dt)
+    if not isint and k % 5 == 0 and a.size > 100: a.reshape(-1)[rng.integers(0, a.size, size=max(1, a.size // 300))] = np.nan
+    conf = sz3_amd.Config(*shape)
+    conf.cmprAlgo = int(rng.choice([sz3_amd.ALGO_LORENZO_REG, sz3_amd.ALGO_INTERP_LORENZO, sz3_amd.ALGO_INTERP, sz3_amd.ALGO_NOPRED]))
+    conf.quantbinCnt = int(rng.choice([256, 1024, 65536, 65536]))
+    mode = int(rng.choice([sz3_amd.EB_ABS, sz3_amd.EB_REL, sz3_amd.EB_ABS_AND_REL, sz3_amd.EB_ABS_OR_REL, sz3_amd.EB_PSNR, sz3_amd.EB_L2NORM]))
+    conf.errorBoundMode = mode
+    fin = np.isfinite(a.astype(np.float64))
+    af = a.astype(np.float64)
+    rngv = float(af[fin].max() - af[fin].min()) if fin.any() else 0.0
+    hasnan = not fin.all()
+    if hasnan and mode != sz3_amd.EB_ABS:
+        mode = sz3_amd.EB_ABS; conf.errorBoundMode = mode  # (the reference's range of a NaN field is NaN)
+    scale = 10.0 if isint else 1.0
+    abs_eb = float(10.0 ** rng.integers(-4, -1)) * scale * (100 if isint else 1)
+    rel = float(10.0 ** rng.integers(-4, -1))
+    conf.absErrorBound = abs_eb; conf.relErrorBound = rel; conf.psnrErrorBound = float(rng.choice([40.0, 60.0, 80.0])); conf.l2normErrorBound = abs_eb * np.sqrt(a.size)
+    try:
+        blob, ratio = sz3_amd.compress(a, conf)
+        dec, c2 = sz3_amd.decompress(blob, a.dtype, a.shape)
+    except Exception as e:
+        print(k, shape, dt.__name__, "mode", mode, "algo", conf.cmprAlgo, "EXC", str(e)[:80]); bad += 1; continue
+    df = dec.astype(np.float64)
+    err = np.abs(df[fin] - af[fin]).max() if fin.any() else 0.0
+    ok = dec.shape == a.shape and dec.dtype == a.dtype and np.array_equal(np.isnan(df), np.isnan(af))
+    tol = 1 + 1e-9
+    if mode == sz3_amd.EB_ABS: bound = abs_eb
+    elif mode == sz3_amd.EB_REL: bound = rel * rngv
+    elif mode == sz3_amd.EB_ABS_AND_REL: bound = min(abs_eb, rel * rngv)
+    elif mode == sz3_amd.EB_ABS_OR_REL: bound = max(abs_eb, rel * rngv)
+    else: bound = None
+    if bound is not None:
+        if dt == np.float32: bound = bound * (1 + 1e-6) + 1e-30  # the range is taken in float32 by the reference too
+        ok = ok and err <= bound * tol
+    elif mode == sz3_amd.EB_PSNR:
+        mse = float(np.mean((df[fin] - af[fin]) ** 2)); psnr = 20 * np.log10(rngv) - 10 * np.log10(mse) if mse > 0 and rngv > 0 else np.inf
+        # the reference turns the PSNR target into abs eb = sqrt(3) * range * 10^(-psnr/20) (uniform-error assumption,
+        # utils/Statistic.hpp): what |err| <= eb guarantees is psnr >= target - 20 log10(sqrt 3) = target - 4.77 dB (all errors
+        # at the bound); coarse quantisation of a small smooth field gets close to that (seed 32, case 33: -1.x dB)
+        ok = ok and psnr >= conf.psnrErrorBound - 4.8
+    else:
+        l2 = float(np.sqrt(np.sum((df[fin] - af[fin]) ** 2)))
+        ok = ok and l2 <= conf.l2normErrorBound * 1.1  # (the reference's bound sqrt(3/n) * l2 holds in expectation: uniform errors)
+    if not ok: bad += 1
+    print(k, shape, dt.__name__, "mode", mode, "algo", conf.cmprAlgo, "->", c2.cmprAlgo, "qb", conf.quantbinCnt, "ratio %.2f" % ratio, "err %.3g" % err, "bound", bound, "OK" if ok else "FAIL")
+print("failures:", bad)

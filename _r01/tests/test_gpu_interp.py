@@ -1,0 +1,182 @@
+"""GPU tests (-m gpu) of the interpolation predictor: BIT-EXACT parity with the oracle's restatement of
+InterpolationDecomposition (which is byte-identical to the reference build): same quantisation codes at every
+element, same unpredictable set, same reconstructed array; and the complete stream round trip."""
+import numpy as np
+import pytest
+
+import sz3_amd
+from fields import field1d, field2d, field3d, field4d
+from oracle_binding import ALGO_INTERP, make_config, oracle_compress, oracle_decompress, oracle_interp_codes
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+CASES = [
+    ("3d-cubic", lambda: field3d((33, 47, 50)), 1e-3, dict(interpAlgo=1)),
+    ("3d-linear", lambda: field3d((33, 47, 50)), 1e-3, dict(interpAlgo=0)),
+    ("3d-linear-even-lines", lambda: field3d((34, 66, 36)), 1e-2, dict(interpAlgo=0)),
+    ("3d-cubic-dir5-a1b1", lambda: field3d((70, 64, 65)), 1e-4, dict(interpAlgo=1, interpDirection=5, interpAlpha=1.0, interpBeta=1.0)),
+    ("3d-cubic-anchor8", lambda: field3d((40, 33, 29)), 1e-2, dict(interpAlgo=1, interpAnchorStride=8, interpAlpha=1.5, interpBeta=3.0)),
+    ("3d-noanchor-dir3", lambda: field3d((20, 21, 22)), 1e-3, dict(interpAlgo=1, interpAnchorStride=0, interpDirection=3, interpAlpha=-1.0)),
+    ("3d-f64", lambda: field3d((20, 30, 37), np.float64, sigma=2e-6), 1e-6, dict(interpAlgo=1)),
+    ("1d-cubic", lambda: field1d(70001), 1e-3, dict(interpAlgo=1)),
+    ("1d-linear", lambda: field1d(9000), 1e-2, dict(interpAlgo=0)),
+    ("2d-cubic-dir1", lambda: field2d((123, 257)), 1e-3, dict(interpAlgo=1, interpDirection=1)),
+    ("2d-linear", lambda: field2d((130, 66)), 1e-3, dict(interpAlgo=0)),
+    ("4d-cubic", lambda: field4d((7, 11, 13, 17)), 1e-2, dict(interpAlgo=1)),
+    ("4d-linear-dir23", lambda: field4d((5, 20, 33, 40)), 1e-3, dict(interpAlgo=0, interpDirection=23)),
+    ("3d-nan", None, 1e-3, dict(interpAlgo=1)),
+    # row lengths that are multiples of 8: the 8-wide level-1 kernels (every direction order puts x at a different place)
+    ("3d-vec-cubic", lambda: field3d((37, 41, 64)), 1e-3, dict(interpAlgo=1)),
+    ("3d-vec-cubic-dir5", lambda: field3d((33, 40, 48)), 1e-4, dict(interpAlgo=1, interpDirection=5)),
+    ("3d-vec-cubic-dir2", lambda: field3d((70, 35, 104)), 1e-3, dict(interpAlgo=1, interpDirection=2, interpAlpha=1.5, interpBeta=3.0)),
+    ("3d-vec-f64", lambda: field3d((20, 30, 40), np.float64, sigma=2e-6), 1e-6, dict(interpAlgo=1)),
+    ("4d-vec-cubic", lambda: field4d((5, 9, 16, 24)), 1e-2, dict(interpAlgo=1)),
+    ("4d-vec-cubic-dir17", lambda: field4d((6, 7, 34, 16)), 1e-3, dict(interpAlgo=1, interpDirection=17)),
+    ("3d-vec-nan", "nan64", 1e-3, dict(interpAlgo=1)),
+    # rows of a multiple of 4 but not of 8 elements: the 8-wide level-1 kernels end every row in a half group
+    ("3d-vec-half-100", lambda: field3d((33, 40, 100)), 1e-3, dict(interpAlgo=1)),
+    ("3d-vec-half-20-dir5", lambda: field3d((40, 36, 20)), 1e-4, dict(interpAlgo=1, interpDirection=5)),
+    ("3d-vec-half-f64-dir2", lambda: field3d((18, 35, 68), np.float64, sigma=2e-6), 1e-6, dict(interpAlgo=1, interpDirection=2)),
+    ("4d-vec-half-36", lambda: field4d((5, 9, 17, 36)), 1e-3, dict(interpAlgo=1, interpDirection=11)),
+    ("3d-vec-half-500", lambda: field3d((9, 20, 500)), 1e-3, dict(interpAlgo=1, interpAlpha=1.0, interpBeta=1.0)),
+    # 1-D / 2-D fields: the 8-wide level-1 kernels with the 1-D / 2-D interface's boundary rules (tails of 2..4 points too)
+    ("2d-vec-cubic", lambda: field2d((123, 256)), 1e-3, dict(interpAlgo=1)),
+    ("2d-vec-cubic-dir1-half", lambda: field2d((130, 260)), 1e-4, dict(interpAlgo=1, interpDirection=1)),
+    ("2d-vec-tails-34x36", lambda: field2d((34, 36)), 1e-3, dict(interpAlgo=1)),
+    ("2d-vec-tails-35x68-dir1", lambda: field2d((35, 68)), 1e-3, dict(interpAlgo=1, interpDirection=1)),
+    ("2d-vec-tails-37x100", lambda: field2d((37, 100)), 1e-3, dict(interpAlgo=1, interpAlpha=1.5, interpBeta=2.0)),
+    ("2d-vec-f64", lambda: field2d((96, 72), np.float64, sigma=2e-6), 1e-6, dict(interpAlgo=1)),
+    ("1d-vec-cubic", lambda: field1d(70004), 1e-3, dict(interpAlgo=1)),
+    ("1d-vec-cubic-tail3", lambda: field1d(32 * 100 + 3 + 1), 1e-3, dict(interpAlgo=1)),
+    # small quantisers: code 0 (unpredictable) lies inside / at the edge of the histogram window around the radius
+    ("3d-qbin1024", lambda: field3d((33, 40, 48)), 1e-3, dict(interpAlgo=1, quantbinCnt=1024)),
+    ("3d-qbin256", lambda: field3d((33, 40, 48)), 1e-2, dict(interpAlgo=1, quantbinCnt=256)),
+    ("3d-qbin2048-linear", lambda: field3d((20, 33, 64)), 1e-3, dict(interpAlgo=0, quantbinCnt=2048)),
+    ("4d-qbin1024-noanchor", lambda: field4d((8, 9, 16, 9)), 1e-3, dict(interpAlgo=1, quantbinCnt=1024, interpAnchorStride=0, interpAlpha=-1.0, interpBeta=4.0)),
+    ("1d-qbin1024", lambda: field1d(20001), 1e-3, dict(interpAlgo=1, quantbinCnt=1024, interpAnchorStride=0, interpBeta=4.0)),
+]
+
+
+def _device_roundtrip(a, eb, kw):
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    cap = dc.payload_bound(a.size, worst_case=True)  # (small quantisers leave many points unpredictable)
+    payload = torch.empty(cap, dtype=torch.uint8, device=dev)
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_INTERP
+    conf.absErrorBound = eb
+    for k, v in kw.items():
+        setattr(conf, k, v)
+    s = torch.cuda.current_stream().cuda_stream
+    size = dc.compress(conf, t.data_ptr(), payload.data_ptr(), cap, s)
+    codes = dc.debug_codes(a.size)
+    out = torch.empty_like(t)
+    dc.decompress(payload.data_ptr(), size, out.data_ptr(), s)
+    torch.cuda.synchronize()
+    return codes, out.cpu().numpy(), size, dc.stats()
+
+
+@pytest.mark.parametrize("name,gen,eb,kw", CASES, ids=[c[0] for c in CASES])
+def test_interp_bit_exact_with_oracle(name, gen, eb, kw):
+    if gen is None or gen == "nan64":
+        a = field3d((24, 31, 40) if gen is None else (24, 31, 64))
+        a[3, 4, 5] = np.nan
+        a[10, 2, 7] = np.inf
+        a[20, 20, 20] = 1e30
+    else:
+        a = gen()
+    codes, dec, size, st = _device_roundtrip(a, eb, kw)
+    okw = dict(abs_eb=eb, interp_algo=kw.get("interpAlgo", 1))
+    okw.update({k: v for k, v in kw.items() if k != "interpAlgo"})
+    oconf = make_config(a.shape, algo=ALGO_INTERP, **okw)
+    ocodes, order, recon, nun = oracle_interp_codes(a, oconf)
+    nat = np.zeros(a.size, dtype=np.int64)
+    nat[order.astype(np.int64)] = ocodes
+    assert np.array_equal(codes.astype(np.int64), nat), "quantisation codes differ from the reference algorithm"
+    assert st["n_value_outliers"] == nun
+    assert np.array_equal(dec, recon.reshape(a.shape), equal_nan=True), "reconstruction differs from the reference algorithm"
+    odec, _ = oracle_decompress(oracle_compress(a, oconf), a.dtype, a.shape)
+    assert np.array_equal(dec, odec, equal_nan=True)
+    m = np.isfinite(a) & (np.abs(a) < 1e20)
+    assert np.max(np.abs(dec[m].astype(np.float64) - a[m].astype(np.float64))) <= eb
+
+
+def test_interp_host_api_and_ratio():
+    a = field3d((96, 96, 96))
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_INTERP
+    conf.absErrorBound = 1e-4
+    blob, ratio = sz3_amd.compress(a, conf)
+    dec, c2 = sz3_amd.decompress(blob, np.float32, a.shape)
+    assert c2.cmprAlgo == sz3_amd.ALGO_HIP_INTERP
+    oconf = make_config(a.shape, algo=ALGO_INTERP, abs_eb=1e-4)
+    oblob = oracle_compress(a, oconf)
+    odec, _ = oracle_decompress(oblob, np.float32, a.shape)
+    assert np.array_equal(dec, odec)                      # bit-identical decompressed field
+    assert ratio >= 0.97 * a.nbytes / len(oblob)          # same codes; only the entropy-stage container differs
+    # default algorithm of a fresh Config (ALGO_INTERP_LORENZO) takes the interpolation path with its default parameters
+    conf = sz3_amd.Config(*a.shape)
+    conf.absErrorBound = 1e-3
+    blob, ratio = sz3_amd.compress(a, conf)
+    dec, c2 = sz3_amd.decompress(blob, np.float32, a.shape)
+    assert c2.cmprAlgo == sz3_amd.ALGO_HIP_INTERP and np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= 1e-3
+
+
+@pytest.mark.parametrize("VEC_SHAPE", [(48, 56, 128), (40, 33, 100), (17, 24, 36), (65, 33, 96), (34, 66, 132), (70, 40, 20), (200, 136), (67, 36), (40004,)])
+def test_vector_and_scalar_level1_kernels_agree(VEC_SHAPE):
+    """debug flag 128 forces the one-point-per-thread kernels: same payload, byte for byte"""
+    a = {1: field1d, 2: field2d, 3: field3d}[len(VEC_SHAPE)](VEC_SHAPE if len(VEC_SHAPE) > 1 else VEC_SHAPE[0])
+    a.flat[a.size // 3 + 7] = np.nan
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    cap = dc.payload_bound(a.size)
+    pl = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)]
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_INTERP
+    conf.absErrorBound = 1e-3
+    sizes, outs = [], []
+    try:
+        for k, flag in enumerate((0, 128)):
+            sz3_amd.lib().sz3hip_debug_flags(flag)
+            sizes.append(dc.compress(conf, t.data_ptr(), pl[k].data_ptr(), cap, 0))
+            o = torch.empty_like(t)
+            dc.decompress(pl[k].data_ptr(), sizes[-1], o.data_ptr(), 0)
+            torch.cuda.synchronize()
+            outs.append(o)
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(0)
+    for k in (1,):
+        assert sizes[0] == sizes[k] and torch.equal(pl[0][:sizes[0]], pl[k][:sizes[k]])
+        assert bool(((outs[0] == outs[k]) | (outs[0].isnan() & outs[k].isnan())).all())
+
+
+@pytest.mark.parametrize("dtype,eb", [(np.float32, 1e-6), (np.float64, 1e-6)])
+def test_histogram_tail_passes_change_nothing(dtype, eb):
+    """tight bound: the interpolation codes spread over the whole alphabet. Debug flag 8192 forces the histogram pass with
+    the 16384-bin tier plus the three windowed tail passes (normally a per-context choice from the previous call's counts):
+    the payload must be the same bytes as with the plain pass. (Noise of 5000 quantisation steps: a tenth of the codes lie
+    beyond +-8192, none beyond the quantiser's range - lists of more than 32768 unpredictable values are not sorted.)"""
+    a = field3d((96, 80, 128), dtype, sigma=5e-3)
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_INTERP
+    conf.absErrorBound = eb
+    res = []
+    try:
+        for flag in (0, 8192):
+            sz3_amd.lib().sz3hip_debug_flags(flag)
+            dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+            cap = dc.payload_bound(a.size, worst_case=True)
+            pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+            size = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+            torch.cuda.synchronize()
+            res.append(pl[:size].clone())
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(0)
+    assert res[0].numel() == res[1].numel() and torch.equal(res[0], res[1])
+    st = dc.stats()
+    assert st["n_value_outliers"] < 32768 and st["max_code_len"] > 12  # (the spread is real: thousands of distinct symbols)

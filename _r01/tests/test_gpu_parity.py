@@ -1,0 +1,356 @@
+"""GPU parity tests (-m gpu): the HIP path through the C ABI against the oracle (CPU restatement of the reference
+algorithm, itself pinned to the reference build) and against the committed reference goldens.
+
+Parity bar for this floating-point path (BASELINE.json north_star): the decompressed output stays within the user's
+absolute error bound of the input on identical inputs — checked STRICTLY (<= eb, evaluated in float64), the same
+criterion the reference's own tests use (tools/sz3/sz3_smoke_test.cpp:43-49, tools/pysz/tests/test_pysz.py:49,61).
+Consequences also asserted: |x_gpu - x_reference| <= 2 eb, compression ratio within a stated band of the oracle's.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import sz3_amd
+from fields import field1d, field2d, field3d, field4d
+from oracle_binding import ALGO_LORENZO_REG, EB_ABS, EB_REL, make_config, oracle_compress, oracle_decompress
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "golden.npz"))
+
+
+def _gpu_roundtrip(a, **kw):
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    for k, v in kw.items():
+        setattr(conf, k, v)
+    blob, ratio = sz3_amd.compress(a, conf)
+    dec, c2 = sz3_amd.decompress(blob, a.dtype, a.shape)
+    return blob, ratio, dec, c2
+
+
+# BASELINE.json configs at sizes the oracle finishes in seconds: (name, generator, GPU config, oracle config, ratio band)
+CASES = [
+    ("C1-1d-2^20-lorenzo_reg-abs1e-3", lambda: field1d(1 << 20), dict(absErrorBound=1e-3), dict(abs_eb=1e-3, regression=True), 0.90),
+    ("C2-3d-128c-lorenzo-abs1e-3", lambda: field3d((128, 128, 128)), dict(absErrorBound=1e-3), dict(abs_eb=1e-3), 0.97),
+    ("C3-3d-96c-abs1e-4", lambda: field3d((96, 96, 96)), dict(absErrorBound=1e-4), dict(abs_eb=1e-4), 0.97),
+    ("C4-3d-f64-96c-lorenzo_reg-abs1e-6", lambda: field3d((96, 96, 96), np.float64, sigma=2e-6), dict(absErrorBound=1e-6), dict(abs_eb=1e-6, regression=True), 0.97),
+    ("C5-4d-12x40x40x40-rel1e-3", lambda: field4d((12, 40, 40, 40)), dict(errorBoundMode=sz3_amd.EB_REL, relErrorBound=1e-3), dict(eb_mode=EB_REL, rel_eb=1e-3, regression=True), 0.90),
+    ("2d-300x500-abs1e-2", lambda: field2d((300, 500)), dict(absErrorBound=1e-2), dict(abs_eb=1e-2), 0.95),
+    ("ragged-3d-37x41x43", lambda: field3d((37, 41, 43)), dict(absErrorBound=1e-3), dict(abs_eb=1e-3), 0.95),
+]
+
+
+@pytest.mark.parametrize("name,gen,gkw,okw,band", CASES, ids=[c[0] for c in CASES])
+def test_parity_with_oracle(name, gen, gkw, okw, band):
+    a = gen()
+    blob, ratio, dec, c2 = _gpu_roundtrip(a, **gkw)
+    oconf = make_config(a.shape, algo=ALGO_LORENZO_REG, **okw)
+    oblob = oracle_compress(a, oconf)
+    odec, oc2 = oracle_decompress(oblob, a.dtype, a.shape)
+    eb = oc2.absErrorBound
+    assert c2.cmprAlgo == sz3_amd.ALGO_HIP_LORENZO and c2.errorBoundMode == sz3_amd.EB_ABS
+    assert c2.absErrorBound == pytest.approx(eb, rel=1e-12), "error-bound conversion differs from the reference"
+    a64, d64, o64 = a.astype(np.float64), dec.astype(np.float64), odec.astype(np.float64)
+    assert np.max(np.abs(d64 - a64)) <= eb          # tolerance = the user's bound, strict
+    assert np.max(np.abs(o64 - a64)) <= eb          # the reference algorithm keeps the same bound
+    assert np.max(np.abs(d64 - o64)) <= 2 * eb
+    oratio = a.nbytes / len(oblob)
+    assert ratio >= band * oratio, "ratio %.3f vs reference %.3f" % (ratio, oratio)
+
+
+def test_against_reference_goldens():
+    """committed outputs of the reference itself (tests/golden/make_golden.py)"""
+    for name, gen, gkw in [("f32_64c_lorenzo_1e-3", lambda: field3d((64, 64, 64)), dict(absErrorBound=1e-3)),
+                           ("f32_8x8x128_lorenzo_1e-3", lambda: field3d((8, 8, 128)), dict(absErrorBound=1e-3)),
+                           ("f32_2d_100x100_lorenzo_1e-2", lambda: field2d((100, 100)), dict(absErrorBound=1e-2)),
+                           ("f32_1d_65536_lorenzo_reg_1e-3", lambda: field1d(65536), dict(absErrorBound=1e-3))]:
+        a = gen()
+        blob, ratio, dec, c2 = _gpu_roundtrip(a, **gkw)
+        eb = gkw["absErrorBound"]
+        assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= eb
+        assert float(GOLD[name + "/max_err"]) <= eb
+        if name + "/dec" in GOLD:
+            assert np.max(np.abs(dec.astype(np.float64) - GOLD[name + "/dec"].astype(np.float64))) <= 2 * eb
+        assert len(blob) <= 1.12 * int(GOLD[name + "/size"])
+
+
+def test_reference_ci_fixture():
+    """the reference's committed data file with its CI criterion (.github/workflows/cmake.yml:53-65): ABS 1 -> err <= 1"""
+    a = np.fromfile(os.path.join(HERE, "golden", "testfloat_8_8_128.dat"), dtype=np.float32).reshape(8, 8, 128)
+    blob, ratio, dec, c2 = _gpu_roundtrip(a, absErrorBound=1.0)
+    assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= 1.0 and ratio > 10
+
+
+def test_pysz_style_roundtrips():
+    """tools/pysz/tests/test_pysz.py:24-72 on the GPU path"""
+    rng = np.random.default_rng(0)
+    a = rng.random((100, 100), dtype=np.float32)
+    _, _, dec, _ = _gpu_roundtrip(a, absErrorBound=1e-2)
+    assert np.max(np.abs(dec.astype(np.float64) - a)) <= 1e-2
+    b = rng.random((50, 50))
+    _, _, dec, _ = _gpu_roundtrip(b, absErrorBound=1e-6)
+    assert np.max(np.abs(dec - b)) <= 1e-6 and dec.dtype == np.float64
+    c = rng.random((20, 30, 40), dtype=np.float32)
+    _, _, dec, c2 = _gpu_roundtrip(c, errorBoundMode=sz3_amd.EB_REL, relErrorBound=1e-3)
+    assert np.max(np.abs(dec.astype(np.float64) - c)) <= 1e-3 * float(c.max() - c.min())
+    md, psnr, nrmse = sz3_amd.verify(c, dec)
+    assert md <= c2.absErrorBound and psnr > 50
+
+
+def test_dispatcher_policies_and_edge_cases():
+    a = field3d((24, 31, 40))
+    # eb == 0 -> lossless stream, bit exact (api/impl/SZDispatcher.hpp:19-21)
+    blob, ratio, dec, c2 = _gpu_roundtrip(a, absErrorBound=0.0)
+    assert c2.cmprAlgo == sz3_amd.ALGO_LOSSLESS and np.array_equal(dec, a)
+    # bound far below the noise: ratio < 3 -> zstd-only comparison keeps the smaller (SZDispatcher.hpp:62-74), or the
+    # outlier lists overflow -> lossless fallback (SZDispatcher.hpp:44-59); either way the bound holds
+    blob, ratio, dec, c2 = _gpu_roundtrip(a, absErrorBound=1e-9)
+    assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= 1e-9
+    # NaN / Inf / huge values survive bit-exactly, everything else keeps the bound
+    b = a.copy()
+    b[3, 4, 5] = np.nan
+    b[10, 2, 7] = -np.inf
+    b[20, 20, 20] = 1e30
+    blob, ratio, dec, c2 = _gpu_roundtrip(b, absErrorBound=1e-3)
+    m = np.isfinite(b) & (np.abs(b) < 1e20)
+    assert np.isnan(dec[3, 4, 5]) and dec[10, 2, 7] == -np.inf and dec[20, 20, 20] == np.float32(1e30)
+    assert np.max(np.abs(dec[m].astype(np.float64) - b[m].astype(np.float64))) <= 1e-3
+    # constant field: single-symbol alphabet, zero-length code, empty bit stream
+    c = np.full((40, 40, 40), 2.5, np.float32)
+    blob, ratio, dec, c2 = _gpu_roundtrip(c, absErrorBound=1e-3)
+    assert np.max(np.abs(dec - c)) <= 1e-3 and ratio > 500
+    # tiny and degenerate shapes (dims of 1 dropped like Config.hpp:164-168)
+    for shape in [(1,), (2,), (1, 1, 5), (3, 1, 4)]:
+        d = np.arange(int(np.prod(shape)), dtype=np.float32).reshape(shape) * 0.37
+        blob, ratio, dec, c2 = _gpu_roundtrip(d, absErrorBound=1e-2)
+        assert np.max(np.abs(dec.reshape(-1) - d.reshape(-1))) <= 1e-2
+    # buffer too small -> error, not a truncated stream (api/sz.hpp:47-49)
+    conf = sz3_amd.Config(*a.shape)
+    out = np.empty(100, dtype=np.uint8)
+    assert sz3_amd.lib().sz3hip_compress(C.byref(conf._c), 0, a.ctypes.data, out.ctypes.data, out.size) == 0
+    assert b"not large enough" in sz3_amd.lib().sz3hip_last_error()
+    # a stream of the CPU reference is refused, not mis-decoded
+    oblob = oracle_compress(a, make_config(a.shape, abs_eb=1e-3))
+    with pytest.raises(sz3_amd.SZ3HipError):
+        sz3_amd.decompress(oblob, np.float32, a.shape)
+
+
+def test_sz3c_abi_roundtrip():
+    """tools/sz3c/include/sz3c.h:52-59 semantics through libsz3hip.so: r1 fastest, malloc'ed results, free_buf"""
+    L = sz3_amd.lib()
+    a = field3d((20, 30, 40))
+    n = C.c_size_t(0)
+    p = L.SZ_compress_args(0, a.ctypes.data, C.byref(n), 0, 1e-3, 0.0, 0.0, 0, 0, 20, 30, 40)
+    assert p and 0 < n.value < a.nbytes
+    q = L.SZ_decompress(0, p, n.value, 0, 0, 20, 30, 40)
+    dec = np.ctypeslib.as_array(C.cast(q, C.POINTER(C.c_float)), shape=(a.size,)).copy().reshape(a.shape)
+    L.free_buf(p)
+    L.free_buf(q)
+    assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= 1e-3
+    b = field2d((64, 80), np.float64)
+    p = L.SZ_compress_args(1, b.ctypes.data, C.byref(n), 1, 0.0, 1e-4, 0.0, 0, 0, 0, 64, 80)   # REL
+    q = L.SZ_decompress(1, p, n.value, 0, 0, 0, 64, 80)
+    dec = np.ctypeslib.as_array(C.cast(q, C.POINTER(C.c_double)), shape=(b.size,)).copy().reshape(b.shape)
+    L.free_buf(p)
+    L.free_buf(q)
+    assert np.max(np.abs(dec - b)) <= 1e-4 * (b.max() - b.min())
+
+
+@pytest.mark.parametrize("shape,dtype,eb", [((512, 512, 512), np.float32, 1e-3), ((256, 256, 256), np.float64, 1e-6),
+                                            ((128, 1024, 1024), np.float64, 1e-6)],
+                         ids=["C2-512c-f32", "C4-256c-f64", "C4-slab-128x1024x1024-f64"])
+def test_full_size_properties(shape, dtype, eb):
+    """size-independent properties at the benchmark size (no oracle: it would take minutes): strict bound after a
+    device round trip, idempotence (re-compressing the decompressed field reproduces it bit for bit — the lattice is a
+    fixed point), and determinism of the payload."""
+    dev = torch.device("cuda:0")
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    g = torch.Generator(device=dev).manual_seed(1234)
+    z, y, x = torch.meshgrid(*[torch.arange(s, device=dev, dtype=torch.float64) for s in shape], indexing="ij")
+    f = torch.sin(2 * np.pi * x / 64) * torch.cos(2 * np.pi * y / 96) * torch.sin(2 * np.pi * z / 128) + \
+        0.25 * torch.sin(2 * np.pi * (x + 2 * y + 3 * z) / 37)
+    del x, y, z
+    f = (f + (2e-3 if dtype == np.float32 else 2e-6) * torch.randn(shape, device=dev, dtype=torch.float64, generator=g)).to(tdt)
+    n = f.numel()
+    dc = sz3_amd.DeviceCompressor(n, dtype)
+    cap = dc.payload_bound(n)
+    pl1 = torch.empty(cap, dtype=torch.uint8, device=dev)
+    pl2 = torch.empty(cap, dtype=torch.uint8, device=dev)
+    conf = sz3_amd.Config(*shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.absErrorBound = eb
+    s = torch.cuda.current_stream().cuda_stream
+    sz1 = dc.compress(conf, f.data_ptr(), pl1.data_ptr(), cap, s)
+    out = torch.empty_like(f)
+    dc.decompress(pl1.data_ptr(), sz1, out.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert float((out.double() - f.double()).abs().max()) <= eb
+    assert f.element_size() * n / sz1 > 3
+    sz2 = dc.compress(conf, out.data_ptr(), pl2.data_ptr(), cap, s)
+    out2 = torch.empty_like(f)
+    dc.decompress(pl2.data_ptr(), sz2, out2.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out), "decompress(compress(x^)) != x^"
+    sz3 = dc.compress(conf, f.data_ptr(), pl2.data_ptr(), cap, s)
+    torch.cuda.synchronize()
+    st = dc.stats()
+    if max(st["n_value_outliers"], st["n_delta_outliers"]) <= 65536:   # longer outlier lists stay in arrival order
+        assert sz3 == sz1 and torch.equal(pl1[:sz1], pl2[:sz1]), "payload is not deterministic"
+
+
+def test_histogram_split_path_equals_single_call():
+    """stage1 / (all-reduce placeholder) / stage2 with a caller-owned histogram == the fused call"""
+    dev = torch.device("cuda:0")
+    a = field3d((64, 64, 128))
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, np.float32)
+    cap = dc.payload_bound(a.size)
+    p1 = torch.empty(cap, dtype=torch.uint8, device=dev)
+    p2 = torch.empty(cap, dtype=torch.uint8, device=dev)
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.absErrorBound = 1e-3
+    s = torch.cuda.current_stream().cuda_stream
+    n1 = dc.compress(conf, t.data_ptr(), p1.data_ptr(), cap, s)
+    narrow = bool(dc.stats()["narrow_codes"])
+    hist = torch.zeros(65536, dtype=torch.int64, device=dev)
+    dc.set_histogram(hist.data_ptr())
+    dc.stage1(conf, t.data_ptr(), s)
+    torch.cuda.synchronize()
+    h = hist.cpu().numpy()
+    assert h.sum() == a.size
+    import szh_ref
+    assert np.array_equal(h, np.bincount(szh_ref.dualquant(a, 1e-3, narrow=narrow)[2].reshape(-1), minlength=65536))
+    dc.stage2(p2.data_ptr(), cap, s)
+    n2 = dc.finish(s)
+    assert n1 == n2 and torch.equal(p1[:n1], p2[:n2])
+    # a summed histogram of 2 identical slabs gives the same code lengths -> same payload (what RCCL would deliver)
+    dc.stage1(conf, t.data_ptr(), s)
+    hist *= 2
+    dc.stage2(p2.data_ptr(), cap, s)
+    n3 = dc.finish(s)
+    out = torch.empty_like(t)
+    dc.decompress(p2.data_ptr(), n3, out.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert float((out.double() - t.double()).abs().max()) <= 1e-3
+
+
+def test_unmodified_reference_cli_runs_on_the_gpu_path(tmp_path):
+    """oracle/_ref/sz3_hip: the reference's CLI source (tools/sz3/sz3.cpp, unmodified, compiled where it lies) built
+    against include/SZ3/api/sz.hpp + libsz3hip.so. Its own round-trip report must show the bound, and the stream
+    it wrote must decode through the Python binding too (tools/sz3/sz3.cpp:130-190)."""
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "sz3_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/sz3_hip not built (needs /root/reference at build time)")
+    a = field3d((40, 50, 60))
+    src, cmp_, dec = tmp_path / "a.f32", tmp_path / "a.sz", tmp_path / "a.out"
+    a.tofile(src)
+    for algo_ini, want in (("ALGO_LORENZO_REG", sz3_amd.ALGO_HIP_LORENZO), ("ALGO_INTERP", sz3_amd.ALGO_HIP_INTERP)):
+        ini = tmp_path / "c.ini"
+        ini.write_text("[GlobalSettings]\nCmprAlgo = %s\n" % algo_ini)
+        r = subprocess.run([exe, "-f", "-i", str(src), "-z", str(cmp_), "-o", str(dec), "-3", "60", "50", "40", "-c", str(ini),
+                            "-M", "ABS", "1e-3", "-a"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        m = re.search(r"Max absolute error = ([0-9.eE+-]+)", r.stdout)
+        assert m and float(m.group(1)) <= 1e-3, r.stdout
+        out = np.fromfile(dec, dtype=np.float32).reshape(a.shape)
+        assert np.max(np.abs(out.astype(np.float64) - a.astype(np.float64))) <= 1e-3
+        blob = np.fromfile(cmp_, dtype=np.uint8)
+        d2, c2 = sz3_amd.decompress(blob, np.float32, a.shape)
+        assert c2.cmprAlgo == want and np.array_equal(d2, out)
+    # integer input through the CLI's -I 32 (SZ_compress<int32_t>)
+    ai = (1000 * a).astype(np.int32)
+    isrc, icmp, idec = tmp_path / "a.i32", tmp_path / "ai.sz", tmp_path / "ai.out"
+    ai.tofile(isrc)
+    r = subprocess.run([exe, "-I", "32", "-i", str(isrc), "-z", str(icmp), "-o", str(idec), "-3", "60", "50", "40", "-M", "ABS", "3", "-a"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    outi = np.fromfile(idec, dtype=np.int32).reshape(a.shape)
+    assert np.max(np.abs(outi.astype(np.int64) - ai.astype(np.int64))) <= 3
+
+
+def test_full_size_interpolation_properties():
+    """C3 at its full size (512^3 f32, ALGO_INTERP_LORENZO = tuner + interpolation, abs 1e-4): strict bound after a device
+    round trip, payload determinism, and the tuner's report is the same on every run."""
+    dev = torch.device("cuda:0")
+    shape = (512, 512, 512)
+    g = torch.Generator(device=dev).manual_seed(99)
+    z, y, x = torch.meshgrid(*[torch.arange(s, device=dev, dtype=torch.float32) for s in shape], indexing="ij")
+    f = torch.sin(2 * np.pi * x / 64) * torch.cos(2 * np.pi * y / 96) * torch.sin(2 * np.pi * z / 128) + \
+        0.25 * torch.sin(2 * np.pi * (x + 2 * y + 3 * z) / 37)
+    del x, y, z
+    f = f + 2e-3 * torch.randn(shape, device=dev, dtype=torch.float32, generator=g)
+    n = f.numel()
+    dc = sz3_amd.DeviceCompressor(n, np.float32)
+    cap = dc.payload_bound(n)
+    pl1 = torch.empty(cap, dtype=torch.uint8, device=dev)
+    pl2 = torch.empty(cap, dtype=torch.uint8, device=dev)
+    conf = sz3_amd.Config(*shape)
+    conf.absErrorBound = 1e-4
+    s = torch.cuda.current_stream().cuda_stream
+    sz1 = dc.compress(conf, f.data_ptr(), pl1.data_ptr(), cap, s)
+    rep1 = dc.tuner_report()
+    assert rep1["ran"] == 1 and rep1["use_interp"] == 1 and rep1["sample_block_size"] == 32 and rep1["n_blocks"] == 17
+    out = torch.empty_like(f)
+    dc.decompress(pl1.data_ptr(), sz1, out.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert float((out.double() - f.double()).abs().max()) <= 1e-4
+    assert 4.0 * n / sz1 > 3
+    sz2 = dc.compress(conf, f.data_ptr(), pl2.data_ptr(), cap, s)
+    torch.cuda.synchronize()
+    assert dc.tuner_report() == rep1
+    assert sz2 == sz1 and torch.equal(pl1[:sz1], pl2[:sz1]), "payload is not deterministic"
+
+
+@pytest.mark.parametrize("algo", ["lorenzo", "default"])
+def test_c5_shaped_4d_rel_roundtrip(algo):
+    """C5's shape family (time x 3-D volume, REL 1e-3) through the host API at 12 x 128^3 (one rank's slab thickness)"""
+    a = field4d((12, 128, 128, 128))
+    conf = sz3_amd.Config(*a.shape)
+    if algo == "lorenzo":
+        conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.errorBoundMode = sz3_amd.EB_REL
+    conf.relErrorBound = 1e-3
+    blob, ratio = sz3_amd.compress(a, conf)
+    dec, c2 = sz3_amd.decompress(blob, np.float32, a.shape)
+    eb = 1e-3 * (float(a.max()) - float(a.min()))
+    assert c2.absErrorBound == pytest.approx(eb, rel=1e-6)
+    assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= c2.absErrorBound and ratio > 4
+
+
+def test_integer_inputs_ride_the_f64_pipeline():
+    """int32 / int64 arrays (tools/sz3/sz3.cpp:458-461 instantiates SZ_compress<int32_t/int64_t>): |x - x^| <= floor(eb)
+    between integers; a bound below 1 and int64 magnitudes beyond 2^53 fall back to the lossless stream"""
+    rng = np.random.default_rng(3)
+    base = (1000 * field3d((40, 48, 56))).astype(np.int64) + rng.integers(-3, 4, (40, 48, 56))
+    for dt in (np.int32, np.int64):
+        a = base.astype(dt)
+        for algo in (sz3_amd.ALGO_LORENZO_REG, sz3_amd.ALGO_INTERP):
+            conf = sz3_amd.Config(*a.shape)
+            conf.cmprAlgo = algo
+            conf.absErrorBound = 4.7
+            blob, ratio = sz3_amd.compress(a, conf)
+            dec, c2 = sz3_amd.decompress(blob, dt, a.shape)
+            assert dec.dtype == dt and c2.absErrorBound == 4.0 and c2.cmprAlgo in (sz3_amd.ALGO_HIP_LORENZO, sz3_amd.ALGO_HIP_INTERP)
+            assert np.max(np.abs(dec.astype(np.int64) - a.astype(np.int64))) <= 4 and ratio > 2
+        conf = sz3_amd.Config(*a.shape)
+        conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+        conf.absErrorBound = 0.5                      # floor -> 0 -> lossless (SZDispatcher.hpp:19-21)
+        blob, _ = sz3_amd.compress(a, conf)
+        dec, c2 = sz3_amd.decompress(blob, dt, a.shape)
+        assert c2.cmprAlgo == sz3_amd.ALGO_LOSSLESS and np.array_equal(dec, a)
+        with pytest.raises(sz3_amd.SZ3HipError):
+            sz3_amd.decompress(sz3_amd.compress(a, sz3_amd.Config(*a.shape))[0], np.float64, a.shape)
+    big = base.copy()
+    big[1, 2, 3] = (1 << 60) + 12345
+    conf = sz3_amd.Config(*big.shape)
+    conf.absErrorBound = 2.0
+    blob, _ = sz3_amd.compress(big, conf)
+    dec, c2 = sz3_amd.decompress(blob, np.int64, big.shape)
+    assert c2.cmprAlgo == sz3_amd.ALGO_LOSSLESS and np.array_equal(dec, big)

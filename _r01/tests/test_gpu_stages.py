@@ -1,0 +1,355 @@
+"""GPU stage-level tests (-m gpu): every stage of the HIP path against the numpy model of the SZH1 format
+(tests/szh_ref.py), through the C ABI with device pointers."""
+import numpy as np
+import pytest
+
+import sz3_amd
+from fields import field1d, field2d, field3d, field4d
+import szh_ref
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _conf(shape, eb):
+    c = sz3_amd.Config(*shape)
+    c.cmprAlgo = sz3_amd.ALGO_LORENZO_REG   # the Lorenzo path (the default ALGO_INTERP_LORENZO takes interpolation)
+    c.errorBoundMode = sz3_amd.EB_ABS
+    c.absErrorBound = eb
+    return c
+
+
+def _roundtrip_device(a, eb):
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    cap = dc.payload_bound(a.size)
+    payload = torch.empty(cap, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    size = dc.compress(_conf(a.shape, eb), t.data_ptr(), payload.data_ptr(), cap, stream)
+    codes = dc.debug_codes(a.size)
+    pl = payload[:size].cpu().numpy()
+    out = torch.empty_like(t)
+    dc.decompress(payload.data_ptr(), size, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    return codes, pl, out.cpu().numpy(), dc.stats()
+
+
+CASES = [
+    ("1d", lambda: field1d(70001), 1e-3),
+    ("1d-long", lambda: field1d(300000), 1e-4),
+    ("2d", lambda: field2d((123, 257)), 1e-3),
+    ("3d", lambda: field3d((33, 47, 50)), 1e-3),
+    ("3d-f64", lambda: field3d((20, 30, 37), np.float64, sigma=2e-6), 1e-6),
+    ("4d", lambda: field4d((7, 11, 13, 17)), 1e-2),
+    ("3d-fast", lambda: field3d((33, 47, 52)), 1e-3),
+    ("3d-fast-exact-tiles", lambda: field3d((16, 24, 128)), 1e-4),
+    ("3d-fast-f64", lambda: field3d((21, 30, 36), np.float64, sigma=2e-6), 1e-6),
+    ("4d-fast", lambda: field4d((5, 11, 13, 16)), 1e-2),
+    ("4d-fast-f64", lambda: field4d((3, 6, 10, 68), np.float64), 1e-3),
+    ("3d-march", lambda: field3d((19, 13, 132)), 1e-3),
+    ("3d-march-wide", lambda: field3d((35, 9, 520)), 1e-4),
+    ("3d-march-f64", lambda: field3d((18, 7, 260), np.float64, sigma=2e-6), 1e-6),
+    ("4d-march", lambda: field4d((3, 5, 7, 128)), 1e-2),
+    ("4d-march-f64", lambda: field4d((2, 18, 5, 264), np.float64), 1e-3),
+    ("3d-smooth", lambda: field3d((40, 40, 40), sigma=0.0), 1e-1),
+    ("3d-const", lambda: np.full((17, 19, 23), 3.25, np.float32), 1e-3),
+    # wide alphabets: ~1.5k symbols (LDS code book, 24-bit limit), ~6k (round-parallel merge, LDS queues),
+    # ~40k symbols with deltas beyond the radius (global-memory queues, delta outliers)
+    ("3d-rough-1k", lambda: _rough((40, 64, 64), 0.12), 1e-3),
+    ("3d-rough-6k", lambda: _rough((48, 64, 64), 0.6), 1e-3),
+    ("3d-rough-40k", lambda: _rough((48, 64, 128), 6.0), 1e-3),
+]
+
+
+def _rough(shape, sigma):
+    rng = np.random.default_rng(7)
+    return (field3d(shape) + rng.normal(0.0, sigma, shape)).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,gen,eb", CASES, ids=[c[0] for c in CASES])
+def test_stages(name, gen, eb):
+    a = gen()
+    codes, pl, dec, st = _roundtrip_device(a, eb)
+    q, d, exp_codes, bad, dout = szh_ref.dualquant(a, eb, narrow=bool(st["narrow_codes"]))
+    # K1: codes bit-exact against the numpy model
+    assert np.array_equal(codes, exp_codes.reshape(-1)), "quantisation codes differ from the model"
+    h, o, sec = szh_ref.parse(pl)
+    assert h["magic"] == szh_ref.MAGIC and h["n"] == a.size and h["payload_bytes"] == len(pl)
+    assert h["n_vout"] == int(bad.sum()) and h["n_dout"] == int(dout.sum())
+    assert st["n_value_outliers"] == h["n_vout"] and st["payload_bytes"] == len(pl)
+    # K5: a complete prefix code over exactly the symbols that occur
+    present = np.unique(exp_codes)
+    lens = sec["lens"]
+    assert set(h["sym_min"] + np.nonzero(lens)[0]) == (set(present.tolist()) if len(present) > 1 else set())
+    if len(present) > 1:
+        limit = szh_ref.SHORT_LEN if len(present) <= szh_ref.SHORT_SYMS else szh_ref.MAX_LEN
+        assert abs(szh_ref.kraft(lens) - 1.0) < 1e-9 and lens.max() == h["max_len"] <= limit
+        # optimality: total bits equal to an independent (unlimited) Huffman construction when that code respects the
+        # length limit (16 bits up to 512 symbols, else 24), otherwise within 0.2 % of it (length-limited code)
+        freq = np.bincount(exp_codes.reshape(-1), minlength=65536)[h["sym_min"]:h["sym_min"] + h["sym_count"]]
+        import heapq
+        heap = [(int(f), i, 0) for i, f in enumerate(freq) if f]   # (freq, tiebreak, height)
+        heapq.heapify(heap)
+        cost = 0
+        cnt = len(freq)
+        while len(heap) > 1:
+            f1, _, h1 = heapq.heappop(heap)
+            f2, _, h2 = heapq.heappop(heap)
+            cost += f1 + f2
+            cnt += 1
+            heapq.heappush(heap, (f1 + f2, cnt, max(h1, h2) + 1))
+        gpu_cost = int((freq * lens.astype(np.int64)).sum())
+        if heap[0][2] <= limit:
+            assert gpu_cost == cost, "code is not optimal"
+        else:
+            assert cost <= gpu_cost <= cost * 1.002, "length-limited code too far from optimal"
+    # K6: python decoder reads the bit-stream back to the same codes
+    if a.size <= 120000:
+        assert np.array_equal(szh_ref.huffman_decode(h, sec), exp_codes.reshape(-1))
+    # K8: GPU decode == model reconstruction, and the error bound holds strictly (in float64)
+    model = szh_ref.reconstruct(h, sec, exp_codes.reshape(-1)).reshape(a.shape)
+    assert np.array_equal(dec, model)
+    assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= eb
+
+
+def test_outliers_and_nonfinite():
+    a = field3d((24, 31, 40))
+    a[3, 4, 5] = np.nan
+    a[10, 2, 7] = np.inf
+    a[20, 20, 20] = 1e30
+    a[1, 1, 1] = -3e9
+    a[5, 6, 7] = 3000.0   # representable on the lattice (|x/2eb| < 2^23) but a huge Lorenzo delta -> delta outlier
+    eb = 1e-3
+    codes, pl, dec, st = _roundtrip_device(a, eb)
+    q, d, exp_codes, bad, dout = szh_ref.dualquant(a, eb, narrow=bool(st["narrow_codes"]))
+    assert np.array_equal(codes, exp_codes.reshape(-1))
+    assert st["n_value_outliers"] == int(bad.sum()) >= 4 and st["n_delta_outliers"] == int(dout.sum()) > 0
+    fin = np.isfinite(a)
+    assert np.array_equal(np.isnan(dec), np.isnan(a)) and np.array_equal(dec[~fin & ~np.isnan(a)], a[~fin & ~np.isnan(a)])
+    assert np.max(np.abs(dec[fin].astype(np.float64) - a[fin].astype(np.float64))) <= eb
+
+
+@pytest.mark.parametrize("shape,dtype", [((19, 26, 68), np.float32), ((9, 17, 64), np.float64), ((3, 9, 11, 72), np.float32),
+                                         ((33, 10, 260), np.float32), ((2, 17, 6, 132), np.float64)])
+def test_fast_kernel_equals_generic(shape, dtype):
+    """the tuned stage-1 kernel and the any-shape kernel must emit identical codes, outliers and payloads"""
+    a = (field3d(shape, dtype) if len(shape) == 3 else field4d(shape, dtype))
+    a[tuple(s // 2 for s in shape)] = np.nan
+    a[tuple(s // 3 for s in shape)] = 4e4
+    try:
+        sz3_amd.lib().sz3hip_debug_flags(64)          # two-byte codes on both sides (the narrow mode has its own test)
+        sz3_amd.lib().sz3hip_debug_force_generic(1)
+        c0, p0, d0, s0 = _roundtrip_device(a, 1e-3)
+        sz3_amd.lib().sz3hip_debug_force_generic(0)
+        c1, p1, d1, s1 = _roundtrip_device(a, 1e-3)
+    finally:
+        sz3_amd.lib().sz3hip_debug_force_generic(0)
+        sz3_amd.lib().sz3hip_debug_flags(0)
+    assert np.array_equal(c0, c1)
+    assert s0["n_value_outliers"] == s1["n_value_outliers"] and s0["n_delta_outliers"] == s1["n_delta_outliers"]
+    h0, _, sec0 = szh_ref.parse(p0)
+    h1, _, sec1 = szh_ref.parse(p1)
+    assert np.array_equal(sec0["bitstream"], sec1["bitstream"]) and np.array_equal(sec0["lens"], sec1["lens"])
+    assert np.array_equal(d0, d1, equal_nan=True)
+
+
+def test_narrow_and_wide_code_paths_agree():
+    """one-byte intermediate codes (probe says the deltas are small) vs two-byte codes: same payload"""
+    a = field3d((24, 20, 256))
+    c1, p1, d1, s1 = _roundtrip_device(a, 1e-3)
+    assert s1["narrow_codes"] == 1
+    try:
+        sz3_amd.lib().sz3hip_debug_flags(64)   # forbid the narrow mode
+        c0, p0, d0, s0 = _roundtrip_device(a, 1e-3)
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(0)
+    assert s0["narrow_codes"] == 0
+    assert np.array_equal(c0, c1) and np.array_equal(p0, p1) and np.array_equal(d0, d1)
+    # rough data: the probe must refuse the narrow mode (deltas of a few hundred lattice steps)
+    b = field3d((24, 20, 256), sigma=0.2)
+    c2, p2, d2, s2 = _roundtrip_device(b, 1e-3)
+    assert s2["narrow_codes"] == 0
+    assert np.max(np.abs(d2.astype(np.float64) - b.astype(np.float64))) <= 1e-3
+    # moderately rough: narrow with a few delta outliers
+    e = field3d((24, 20, 256), sigma=0.012)
+    c3, p3, d3, s3 = _roundtrip_device(e, 1e-3)
+    q, dd, exp_codes, bad, dout = szh_ref.dualquant(e, 1e-3, narrow=bool(s3["narrow_codes"]))
+    assert np.array_equal(c3, exp_codes.reshape(-1)) and s3["n_delta_outliers"] == int(dout.sum())
+    assert np.max(np.abs(d3.astype(np.float64) - e.astype(np.float64))) <= 1e-3
+
+
+@pytest.mark.parametrize("algo", ["lorenzo", "interp"])
+def test_many_unpredictables_grow_the_lists(algo):
+    """More unpredictable values than the default lists hold (n / 32): with a default-sized buffer the device call
+    reports SZ3HIP_EOUTLIERS; with sz3hip_payload_bound_max it grows its lists and succeeds, and the host API keeps
+    the GPU stream instead of falling back to lossless (the reference keeps any number of unpredictables)."""
+    rng = np.random.default_rng(11)
+    shape = (64, 64, 64)
+    a = field3d(shape)
+    mask = rng.random(shape) < 0.01          # 1 % spikes far outside a 64-bin quantiser: each one spoils its neighbours' predictions
+    a[mask] += rng.choice([-1.0, 1.0], size=int(mask.sum())).astype(np.float32) * 50.0
+    eb = 1e-3
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    conf = sz3_amd.Config(*shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG if algo == "lorenzo" else sz3_amd.ALGO_INTERP
+    conf.absErrorBound = eb
+    conf.quantbinCnt = 64
+    cap = dc.payload_bound(a.size)
+    pl = torch.empty(dc.payload_bound(a.size, worst_case=True), dtype=torch.uint8, device=dev)
+    with pytest.raises(sz3_amd.SZ3HipError):
+        dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+    size = dc.compress(conf, t.data_ptr(), pl.data_ptr(), pl.numel(), 0)
+    st = dc.stats()
+    assert max(st["n_value_outliers"], st["n_delta_outliers"]) > a.size // 32
+    out = torch.empty_like(t)
+    dc.decompress(pl.data_ptr(), size, out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    dec = out.cpu().numpy()
+    assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= eb
+    # an easy input afterwards still fits the default bound (the grown lists do not change sz3hip_payload_bound)
+    b = field3d(shape)
+    tb = torch.from_numpy(b).to(dev)
+    conf.quantbinCnt = 65536
+    size_b = dc.compress(conf, tb.data_ptr(), pl.data_ptr(), cap, 0)
+    assert 0 < size_b < b.nbytes // 4
+    # host API: GPU stream, not the lossless fallback
+    conf.quantbinCnt = 64
+    blob, ratio = sz3_amd.compress(a, conf)
+    back, got_conf = sz3_amd.decompress(blob, a.dtype, shape)
+    assert np.max(np.abs(back.astype(np.float64) - a.astype(np.float64))) <= eb
+    assert ratio > 2 and got_conf.cmprAlgo in (16, 17)
+
+
+@pytest.mark.parametrize("shape,dtype,qb,eb,sigma,nan", [
+    ((17, 260), np.float32, 256, 1e-3, 2e-3, False),       # two-byte codes, radius 128: code 0 lies inside the LDS window
+    ((64, 65, 128), np.float64, 256, 1e-2, 5e-2, True),    # one-byte codes, radius 128: delta outliers must reach the histogram
+    ((40, 128), np.float32, 256, 1e-3, 2e-3, True),
+    ((128, 32, 128), np.float64, 1024, 1e-3, 2e-3, False),
+    ((8, 3, 100, 260), np.float64, 4096, 1e-3, 5e-2, True),
+    ((256, 256), np.float32, 64, 1e-2, 1e-4, False),
+])
+def test_small_quantiser_lorenzo(shape, dtype, qb, eb, sigma, nan):
+    """quantbinCnt far below the default: the code range is narrower than the kernels' LDS histogram windows, so code 0
+    (delta outlier) falls inside / next to them. Found by tests/checks/lorenzo_sweep.py; checked against the numpy model of K1."""
+    rng = np.random.default_rng(2)
+    grids = np.meshgrid(*[np.arange(s, dtype=np.float64) for s in shape], indexing="ij")
+    a = (sum(np.sin(2 * np.pi * g / (11.0 + 5 * i)) for i, g in enumerate(grids)) + sigma * rng.standard_normal(shape)).astype(dtype)
+    if nan:
+        a.reshape(-1)[rng.integers(0, a.size, size=max(1, a.size // 500))] = np.nan
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    cap = dc.payload_bound(a.size, worst_case=True)
+    pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+    conf = sz3_amd.Config(*shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.absErrorBound = eb
+    conf.quantbinCnt = qb
+    size = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+    st = dc.stats()
+    codes = dc.debug_codes(a.size)
+    out = torch.empty_like(t)
+    dc.decompress(pl.data_ptr(), size, out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    dec = out.cpu().numpy()
+    q, d, exp_codes, bad, dout = szh_ref.dualquant(a, eb, radius=qb // 2, narrow=bool(st["narrow_codes"]))
+    assert np.array_equal(codes, exp_codes.reshape(-1))
+    assert (st["n_value_outliers"], st["n_delta_outliers"]) == (int(bad.sum()), int(dout.sum()))
+    h, o, sec = szh_ref.parse(pl[:size].cpu().numpy().tobytes())
+    model = szh_ref.reconstruct(h, sec, exp_codes.reshape(-1)).reshape(a.shape)
+    assert np.array_equal(dec, model, equal_nan=True)
+    fin = np.isfinite(a)
+    assert np.max(np.abs(dec[fin].astype(np.float64) - a[fin].astype(np.float64))) <= eb
+    assert np.array_equal(np.isnan(dec), np.isnan(a))
+
+
+def test_two_class_code_book_and_its_fallback():
+    """wide alphabet (> 4096 symbols): the two-class code book (frequent symbols one by one + one rare class) and, forced by
+    debug flag 1024, the one-class construction it falls back to both give a decodable stream within the bound; the class
+    form may cost at most 0.5 % of the size"""
+    a = field3d((128, 160, 192))
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    cap = dc.payload_bound(a.size)
+    out = torch.empty_like(t)
+    sizes, lens = [], []
+    try:
+        for flag in (0, 1024):
+            sz3_amd.lib().sz3hip_debug_flags(flag)
+            pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+            conf = sz3_amd.Config(*a.shape)
+            conf.cmprAlgo = sz3_amd.ALGO_INTERP
+            conf.absErrorBound = 1e-5
+            n = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+            dc.decompress(pl.data_ptr(), n, out.data_ptr(), 0)
+            torch.cuda.synchronize()
+            assert float((out.double() - t.double()).abs().max()) <= 1e-5
+            h, o, sec = szh_ref.parse(pl[:n].cpu().numpy().tobytes())
+            assert h["sym_count"] > 4096 and szh_ref.kraft(sec["lens"]) <= 1.0
+            sizes.append(n)
+            lens.append(sec["lens"])
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(0)
+    assert not np.array_equal(lens[0], lens[1])          # the two constructions really differ ...
+    assert sizes[1] <= sizes[0] <= 1.005 * sizes[1]       # ... and the class form costs next to nothing
+
+
+def test_payload_does_not_depend_on_the_context_history():
+    """window sizes of stage 1 / the packer are per-context choices taken from the previous call's probe: a context that
+    has just seen a rough field (wide windows selected) must produce the same bytes as a fresh one"""
+    shape = (96, 128, 256)
+    rng = np.random.default_rng(4)
+    rough = (field3d(shape).astype(np.float64) + 0.05 * rng.standard_normal(shape)).astype(np.float32)
+    smooth = field3d(shape)
+    dev = torch.device("cuda:0")
+
+    def run(dc, a, eb):
+        t = torch.from_numpy(a).to(dev)
+        cap = dc.payload_bound(a.size, worst_case=True)
+        pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+        conf = sz3_amd.Config(*a.shape)
+        conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+        conf.absErrorBound = eb
+        n = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+        out = torch.empty_like(t)
+        dc.decompress(pl.data_ptr(), n, out.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert float((out.double() - t.double()).abs().max()) <= eb
+        return pl[:n].cpu().numpy().tobytes()
+
+    used = sz3_amd.DeviceCompressor(smooth.size, smooth.dtype)
+    p_rough_1 = run(used, rough, 1e-5)       # deltas of thousands of lattice steps: the wide windows get selected ...
+    p_rough_2 = run(used, rough, 1e-5)       # ... and used
+    p_smooth_used = run(used, smooth, 1e-3)  # first smooth call still runs with the wide windows
+    p_smooth_used2 = run(used, smooth, 1e-3)
+    fresh = sz3_amd.DeviceCompressor(smooth.size, smooth.dtype)
+    p_smooth_fresh = run(fresh, smooth, 1e-3)
+    p_rough_fresh = run(sz3_amd.DeviceCompressor(smooth.size, smooth.dtype), rough, 1e-5)
+    assert p_rough_1 == p_rough_2 == p_rough_fresh
+    assert p_smooth_used == p_smooth_used2 == p_smooth_fresh
+
+
+def test_stage_calls_out_of_order_are_refused():
+    """stage2 needs a stage1, and only one stage2 per stage1 (the code book's range words are accumulated by atomics)"""
+    a = field3d((32, 32, 64))
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    cap = dc.payload_bound(a.size)
+    pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.absErrorBound = 1e-3
+    with pytest.raises(sz3_amd.SZ3HipError):
+        dc.stage2(pl.data_ptr(), cap, 0)
+    dc.stage1(conf, t.data_ptr(), 0)
+    dc.stage2(pl.data_ptr(), cap, 0)
+    with pytest.raises(sz3_amd.SZ3HipError):
+        dc.stage2(pl.data_ptr(), cap, 0)
+    size = dc.finish(0)
+    ref = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)  # the whole call again: same payload size
+    assert size == ref

@@ -1,0 +1,73 @@
+"""GPU tests (-m gpu): the randomised sweeps of tests/checks/ as part of the suite (fixed seeds, a few seconds each).
+tests/checks/lorenzo_sweep.py  - K1 codes / outlier counts / payload decode against the numpy model of the format (tests/szh_ref.py)
+tests/checks/interp_sweep.py   - interpolation codes and reconstruction against the oracle, bit for bit
+tests/checks/host_sweep.py     - the host API over dtypes, error-bound modes and algorithms: the user-visible guarantee of each mode
+They found the small-quantbinCnt bugs fixed in round 1 (code 0 inside the kernels' LDS histogram windows)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tool, seed, n):
+    env = dict(os.environ, SEED=str(seed), N=str(n))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", tool)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_lorenzo_sweep(seed):
+    out = _run("lorenzo_sweep.py", seed, 30)
+    assert "mismatches: 0" in out, out[-3000:]
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_interp_sweep(seed):
+    out = _run("interp_sweep.py", seed, 25)
+    assert "mismatches: 0" in out, out[-3000:]
+
+
+def test_host_api_sweep():
+    out = _run("host_sweep.py", 11, 40)
+    assert "failures: 0" in out, out[-3000:]
+
+
+BIG = [  # (id, algorithm, shape, dtype, abs bound, noise, GiB of free HBM needed)
+    ("4.4e9-f32-lorenzo", "lorenzo", "1100,2000,2000", "f32", "1e-3", "2e-3", 120),
+    ("4.4e9-f32-interp", "interp", "1100,2000,2000", "f32", "1e-3", "2e-3", 120),
+    ("C5-whole-lorenzo", "lorenzo", "100,500,500,500", "f32", "2.4e-3", "2e-3", 225),
+    ("C5-whole-default", "default", "100,500,500,500", "f32", "2.4e-3", "2e-3", 225),
+    ("C4-whole-lorenzo", "lorenzo", "1024,1024,1024", "f64", "1e-6", "2e-6", 60),
+    ("C4-whole-default", "default", "1024,1024,1024", "f64", "1e-6", "2e-6", 60),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", BIG, ids=[c[0] for c in BIG])
+def test_round_trip_at_full_benchmark_sizes_and_beyond_2_pow_32_elements(case):
+    """BASELINE.json's largest configurations whole on ONE GPU - C5 100 x 500^3 f32 (1.25e10 elements, 50 GB) and C4 1024^3 f64
+    (8 GiB) - and 1100 x 2000 x 2000 f32 (4.4e9 elements): every index, chunk and list position beyond 32 bits. The field is
+    generated and the error bound checked slab by slab on the device (tests/checks/big_roundtrip.py, a process of its own)"""
+    import torch
+    _, algo, shape, dtype, eb, sigma, need = case
+    import time
+    for _ in range(30):  # (the previous case's process has exited, the driver may still be handing its memory back)
+        free, _ = torch.cuda.mem_get_info(0)
+        if free >= need * 2 ** 30:
+            break
+        time.sleep(1.0)
+    if free < need * 2 ** 30:
+        pytest.skip("needs %d GiB of free HBM, %.0f free" % (need, free / 2 ** 30))
+    n = 1
+    for d in shape.split(","):
+        n *= int(d)
+    env = dict(os.environ, LAB_ALGO=algo, LAB_SHAPE=shape, LAB_EB=eb, LAB_DTYPE=dtype, LAB_SIGMA=sigma)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "big_roundtrip.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert " OK " in last and str(n) in r.stdout, last

@@ -1,12 +1,12 @@
+#!/bin/bash
+# A/B of the round-1 build (unpacked by hand into _r01/, not tracked) against the current one: bench lines of a few configs
 cd /tmp && export TMPDIR=/tmp
-for d in $GRAFT_REPO_ROOT/_r01 $GRAFT_REPO_ROOT; do
-rm -rf /tmp/pab; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pab -o r -- python $d/bench.py --algo lorenzo --dtype f64 --shape 128,1024,1024 --eb 1e-6 --steps 10 --warmup 3 --no-cpu-baseline --no-host-e2e > /tmp/pab.log 2>&1
-echo "== $d"; python - <<PY
-import csv
-rows=list(csv.DictReader(open("/tmp/pab/r_kernel_stats.csv")))
-for r in rows[:12]:
-    if "at::native" in r["Name"]: continue
-    print("%-90s calls %4s avg %9.1f us" % (r["Name"][:90], r["Calls"], float(r["AverageNs"])/1000))
-PY
-grep -o "\"stage_ms\": {[^}]*}" /tmp/pab.log | head -1
-done
+run() { for d in $GRAFT_REPO_ROOT/_r01 $GRAFT_REPO_ROOT; do echo -n "$(basename $d) $* : "; python $d/bench.py "$@" --steps 8 --warmup 3 --no-cpu-baseline --no-host-e2e 2>/dev/null | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d.get('ratio'), d.get('decompress_device',{}).get('ms'), d.get('stage_ms'))"; done; }
+run --algo interp --dtype f64 --shape 128,1024,1024 --eb 1e-6
+run --algo lorenzo --eb 1e-6
+run --algo interp --eb 1e-3
+run --algo interp-notune --eb 1e-5
+run --algo lorenzo --eb 1e-2
+run --algo lorenzo --shape 96,500,500 --eb 1e-3

@@ -201,7 +201,7 @@ static void ctx_free(sz3hip_ctx *c) {
     if (!c) return;
     void *bufs[] = {c->d_work, c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
                     c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_aux2, c->d_pint2, c->d_range, c->d_info,
-                    c->d_chunk_words, c->d_chunk_off, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples, c->d_trial_work,
+                    c->d_chunk_words, c->d_chunk_off, c->d_carry, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples, c->d_trial_work,
                     c->d_trial, c->d_passes, c->d_np,  // (d_trial_counters / d_trial_hist live inside d_trial's block)
                     c->d_blk_sel, c->d_blk_coef, c->d_blk_rank, c->d_blk_comp, c->d_blk_side, c->d_blk_counters};
     for (void *b : bufs)
@@ -1162,6 +1162,16 @@ extern "C" int sz3hip_debug_codebook_info(sz3hip_ctx *ctx, uint64_t *out16) {
     return 0;
 }
 
+// test hook: which chain the last device decompression took: out[0] half-width intermediates, out[1] chunk-crossing rows (carries),
+// out[2] calls left before the half-width chain is tried again after an overflow
+extern "C" int sz3hip_debug_decode_info(sz3hip_ctx *ctx, uint32_t *out4) {
+    out4[0] = ctx->last_half;
+    out4[1] = ctx->last_carry;
+    out4[2] = (uint32_t)ctx->half_skip;
+    out4[3] = 0;
+    return 0;
+}
+
 extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, size_t payload_size, void *d_out,
                                         void *stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -1219,7 +1229,13 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     dp.dout_idx = reinterpret_cast<const uint64_t *>(pl + o.dout_idx);
     dp.dout_val = pl + o.dout_val;
     dp.n_dout = h.n_dout;
-    dp.carry = fuse_x && (SZH_CHUNK_SYMS % row) != 0 ? (void *)ctx->d_codes : nullptr;  // (the code array is idle in this mode)
+    // rows that do not divide the chunk: a chunk that starts inside a row gets the running sum its predecessor ended with
+    // (k_scan_carry); the carries have an array of their own (the code array, idle in this mode, holds the half-width chain's values)
+    dp.carry = nullptr;
+    if (fuse_x && (SZH_CHUNK_SYMS % row) != 0) {
+        if (!ctx->d_carry) HIPCHK(hipMalloc(&ctx->d_carry, (ctx->max_chunks + 8) * 8));
+        dp.carry = ctx->d_carry;
+    }
     dp.half = 0;
     dp.ovf = nullptr;
     dp.gate = nullptr;
@@ -1227,7 +1243,9 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     // follow then move half the bytes (the code array, idle in the fused mode, holds them). The decoder and the scans raise a
     // flag on a value that does not fit; the full-width chain is enqueued right behind with that flag as its gate (its kernels
     // return at once while it is clear), so the call stays asynchronous and correct either way.
-    const bool half = fuse_x && !dp.carry && szk_half_scans_ok(&h) && ctx->half_skip == 0 && !(szk_dbg_flags & 2097152);
+    const bool half = fuse_x && szk_half_scans_ok(&h) && ctx->half_skip == 0 && !(szk_dbg_flags & 2097152);
+    ctx->last_half = half ? 1u : 0u;
+    ctx->last_carry = dp.carry ? 1u : 0u;
     if (half) {
         dp.half = 1;
         dp.ovf = ovf;

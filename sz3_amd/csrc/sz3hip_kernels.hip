@@ -683,14 +683,19 @@ __device__ __forceinline__ void march_body(const T *__restrict__ in, uint16_t *_
     OQV *oq_val = s_oq_val[threadIdx.x / WAVE];
     uint32_t oq_n = 0;  // fill level; lane 0 takes part in every update, the other lanes re-read its copy before use
     auto oq_flush = [&]() {
+        // Called by whatever lanes are active: a tile that ends beyond the array's x extent flushes (when its queue fills) with
+        // its last lanes off. The records are dealt over the ACTIVE lanes — striding by 64 dropped the records whose index fell
+        // on an inactive lane (3 of 64 for rows of 500: a bound violation on fields with many unpredictable values).
         oq_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)oq_n);
         if (oq_n == 0) return;
+        const unsigned long long act = __ballot(1);
+        const uint32_t nact = (uint32_t)__popcll(act), rank = (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd((unsigned long long *)p.n_vout, (unsigned long long)oq_n);
+        if (rank == 0) base = atomicAdd((unsigned long long *)p.n_vout, (unsigned long long)oq_n);
         const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
         const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
         const unsigned long long b0 = ((unsigned long long)bhi << 32) | blo;
-        for (uint32_t k = lane; k < oq_n; k += WAVE) {
+        for (uint32_t k = rank; k < oq_n; k += nact) {
             const unsigned long long pos = b0 + k;
             if (pos < p.out_cap) {
                 p.vout_idx[pos] = oq_idx[k];
@@ -2933,7 +2938,8 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
 // one chunk: the row's start lies in the previous chunk). One wave per chunk.
 template <typename QO>
 __global__ __launch_bounds__(256) void k_scan_carry(QO *__restrict__ q, const QO *__restrict__ carry, uint64_t n, uint64_t n_chunks,
-                                                    uint32_t L) {
+                                                    uint32_t L, const uint32_t *gate) {
+    if (gate && *gate == 0) return;  // (the full-width chain behind a half-width one that did not overflow)
     const uint64_t c = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE;
     if (c == 0 || c >= n_chunks) return;
     const uint64_t s0 = c * SZH_CHUNK_SYMS;
@@ -2945,6 +2951,27 @@ __global__ __launch_bounds__(256) void k_scan_carry(QO *__restrict__ q, const QO
     const QO cin = carry[c - 1];
     if (cin == 0) return;
     for (uint32_t i = lane_id(); i < seg; i += WAVE) q[s0 + i] += cin;
+}
+// the same on the half-width chain's int16 values (the carries stay 32 bits wide); a sum that does not fit raises the flag
+__global__ __launch_bounds__(256) void k_scan_carry_half(int16_t *__restrict__ q, const int32_t *__restrict__ carry, uint64_t n, uint64_t n_chunks,
+                                                         uint32_t L, uint32_t *ovf) {
+    const uint64_t c = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE;
+    if (c == 0 || c >= n_chunks) return;
+    const uint64_t s0 = c * SZH_CHUNK_SYMS;
+    const uint32_t x0 = (uint32_t)(s0 % L);
+    if (x0 == 0) return;
+    uint64_t seg = L - x0;
+    if (seg > SZH_CHUNK_SYMS) seg = SZH_CHUNK_SYMS;
+    if (seg > n - s0) seg = n - s0;
+    const int32_t cin = carry[c - 1];
+    if (cin == 0) return;
+    bool bad = false;
+    for (uint32_t i = lane_id(); i < seg; i += WAVE) {
+        const int32_t v = (int32_t)q[s0 + i] + cin;
+        bad |= v != (int32_t)(int16_t)v;
+        q[s0 + i] = (int16_t)v;
+    }
+    if (__ballot(bad) && lane_id() == 0) atomicOr(ovf, 1u);
 }
 
 // codes -> integer deltas (code 0 -> 0, patched by k_scatter_dout)
@@ -3513,10 +3540,13 @@ int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t 
         const uint64_t cb = (p->n_chunks + 3) / 4;
         if (p->q_bytes == 8)
             hipLaunchKernelGGL(k_scan_carry<int64_t>, dim3((uint32_t)cb), dim3(256), 0, s, (int64_t *)p->q_out, (const int64_t *)p->carry, p->n,
-                               p->n_chunks, p->scan_row);
+                               p->n_chunks, p->scan_row, p->gate);
+        else if (p->half)
+            hipLaunchKernelGGL(k_scan_carry_half, dim3((uint32_t)cb), dim3(256), 0, s, (int16_t *)p->q_out, (const int32_t *)p->carry, p->n, p->n_chunks,
+                               p->scan_row, p->ovf);
         else
             hipLaunchKernelGGL(k_scan_carry<int32_t>, dim3((uint32_t)cb), dim3(256), 0, s, (int32_t *)p->q_out, (const int32_t *)p->carry, p->n,
-                               p->n_chunks, p->scan_row);
+                               p->n_chunks, p->scan_row, p->gate);
     }
     SZK_CHECK_LAUNCH();
     return 0;

@@ -346,19 +346,24 @@ def test_c1_through_the_cli_boundary(tmp_path):
         sz3_amd.decompress(np.fromfile(tmp_path / "recipe-cpu.sz", dtype=np.uint8), np.float32, a.shape)
 
 
-def test_half_width_decoder_intermediates_and_their_overflow_path():
+@pytest.mark.parametrize("shape,carry", [((96, 384, 512), 0), ((80, 520, 500), 1)], ids=["rows-512", "rows-500-carries"])
+def test_half_width_decoder_intermediates_and_their_overflow_path(shape, carry):
     """The Lorenzo decoder keeps its x-scanned values and the y-prefixed ones as int16 when they fit (smooth f32 fields) and
     repeats the chain at full width behind a device-side gate when one does not. A step of 2000 between two planes makes
     D_z q = 10^6 lattice steps: the first call overflows and takes the gated chain, the following ones go to full width
     directly (the context fetched the flag with the next header); a smooth field stays on the half-width chain. All exact
-    against each other and within the bound."""
+    against each other and within the bound. Rows of 500 do not divide the 1024-symbol chunks: the running sums that cross a
+    chunk boundary are carried by a pass of their own on either chain."""
+    import ctypes as C
     dev = torch.device("cuda:0")
-    shape = (64, 128, 256)
     eb = 1e-3
     smooth = field3d(shape)
     step = smooth.copy()
-    step[32:] += 2000.0
-    for a in (smooth, step):
+    step[shape[0] // 2:] += 2000.0
+    info = (C.c_uint32 * 4)()
+    L = sz3_amd.lib()
+    L.sz3hip_debug_decode_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    for a, overflows in ((smooth, False), (step, True)):
         t = torch.from_numpy(a).to(dev)
         dc = sz3_amd.DeviceCompressor(a.size, np.float32)
         cap = dc.payload_bound(a.size, worst_case=True)
@@ -368,21 +373,28 @@ def test_half_width_decoder_intermediates_and_their_overflow_path():
         conf.regression = 0
         conf.absErrorBound = eb
         n = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
-        outs = []
+        outs, modes = [], []
         for _ in range(3):
             out = torch.empty_like(t)
             dc.decompress(pl.data_ptr(), n, out.data_ptr(), 0)
             torch.cuda.synchronize()
             outs.append(out.cpu().numpy())
+            L.sz3hip_debug_decode_info(dc._h, info)
+            modes.append((info[0], info[1]))
+        assert modes[0] == (1, carry), "the first call tries the half-width chain"
+        # (the overflow flag of a call is fetched with the header of the next one: the second call still tries, the third does not)
+        assert modes[2] == ((0 if overflows else 1), carry)
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
         assert float(np.max(np.abs(outs[0].astype(np.float64) - a.astype(np.float64)))) <= eb
-        sz3_amd.lib().sz3hip_debug_flags(2097152)  # full-width chain only
+        L.sz3hip_debug_flags(2097152)  # full-width chain only
         try:
             ref = torch.empty_like(t)
             dc.decompress(pl.data_ptr(), n, ref.data_ptr(), 0)
             torch.cuda.synchronize()
+            L.sz3hip_debug_decode_info(dc._h, info)
+            assert info[0] == 0
         finally:
-            sz3_amd.lib().sz3hip_debug_flags(0)
+            L.sz3hip_debug_flags(0)
         assert np.array_equal(ref.cpu().numpy(), outs[0])
 
 

@@ -388,3 +388,39 @@ def test_context_hints_survive_a_change_of_regime():
             out[name] = (pl[:size].cpu().numpy().tobytes(), dec.cpu().numpy())
         assert out["shared"][0] == out["fresh"][0], "payload depends on the context's history (eb %g)" % eb
         assert float(np.max(np.abs(out["shared"][1].astype(np.float64) - a.astype(np.float64)))) <= eb
+
+
+@pytest.mark.parametrize("shape", [(40, 64, 500), (24, 70, 504), (3, 40, 64, 500)], ids=["500", "504", "4d-500"])
+def test_unpredictable_values_in_tiles_that_end_beyond_the_row(shape):
+    """Rows of 500: the second 256-wide tile of the marching kernel runs with its last lanes off. 2 % NaN fill its per-wave
+    queue of unpredictable values several times per tile, so it is flushed by the active lanes only — every record must
+    still reach the list (striding the copy by 64 lost the records that fell on an inactive lane: those points came back as
+    lattice values instead of their raw ones)."""
+    gen = field3d if len(shape) == 3 else field4d
+    a = gen(shape)
+    flat = a.reshape(-1)
+    rng = np.random.default_rng(7)
+    idx = rng.choice(flat.size, size=flat.size // 50, replace=False)
+    flat[idx] = np.nan
+    flat[idx[:100]] = 1e30
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, np.float32)
+    cap = dc.payload_bound(a.size, worst_case=True)
+    pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+    conf = sz3_amd.Config(*shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.regression = 0
+    conf.absErrorBound = 1e-3
+    n = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+    assert idx.size <= dc.stats()["n_value_outliers"] <= idx.size + 200  # (+ the odd finite value whose lattice point misses the bound in f32)
+    out = torch.empty_like(t)
+    dc.decompress(pl.data_ptr(), n, out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    m = np.isnan(a)
+    assert np.array_equal(np.isnan(o), m)
+    big = a == 1e30
+    assert np.array_equal(o[big], a[big])
+    ok = ~m & ~big
+    assert np.max(np.abs(o[ok].astype(np.float64) - a[ok].astype(np.float64))) <= 1e-3

@@ -128,11 +128,17 @@ __device__ __forceinline__ int lz_w(int order, int j) { return order == 1 ? (j =
 
 // the reference's prediction from the ORIGINAL values of the tile (T arithmetic, the reference's term order):
 // LorenzoPredictor.hpp:66-68 (L = 1) and :75-91 (L = 2, terms in lexicographic (k, j, i) order, coefficient -w(k)w(j)w(i))
-template <typename T>
-__device__ __forceinline__ T lorenzo_pred_orig(const T *sx, uint32_t E, uint32_t tz, uint32_t ty, uint32_t tx, int order) {
+// where a block sits in an LDS tile: index of tile coordinate (tz, ty, tx) of THE BLOCK's (B + 2)^3 neighbourhood (two low halo layers)
+struct TileView {
+    uint32_t pz, py, o;  // plane / row pitch of the tile, offset of the neighbourhood's origin
+};
+__device__ __forceinline__ uint32_t tv_at(const TileView &v, uint32_t tz, uint32_t ty, uint32_t tx) { return v.o + tz * v.pz + ty * v.py + tx; }
+// rd(tz, ty, tx): the value the estimate sees at that tile coordinate
+template <typename T, typename RD>
+__device__ __forceinline__ T lorenzo_pred_orig(const RD &rd, uint32_t tz, uint32_t ty, uint32_t tx, int order) {
     if (order == 1) {
-        return sx[tile_at(E, tz, ty, tx - 1)] + sx[tile_at(E, tz, ty - 1, tx)] + sx[tile_at(E, tz - 1, ty, tx)] - sx[tile_at(E, tz, ty - 1, tx - 1)] -
-               sx[tile_at(E, tz - 1, ty, tx - 1)] - sx[tile_at(E, tz - 1, ty - 1, tx)] + sx[tile_at(E, tz - 1, ty - 1, tx - 1)];
+        return rd(tz, ty, tx - 1) + rd(tz, ty - 1, tx) + rd(tz - 1, ty, tx) - rd(tz, ty - 1, tx - 1) - rd(tz - 1, ty, tx - 1) - rd(tz - 1, ty - 1, tx) +
+               rd(tz - 1, ty - 1, tx - 1);
     }
     T acc = 0;
     bool first = true;
@@ -141,7 +147,7 @@ __device__ __forceinline__ T lorenzo_pred_orig(const T *sx, uint32_t E, uint32_t
             for (int i = 0; i <= 2; i++) {
                 if ((k | j | i) == 0) continue;
                 const int c = -(lz_w(2, k) * lz_w(2, j) * lz_w(2, i));
-                const T term = (T)c * sx[tile_at(E, tz - k, ty - j, tx - i)];
+                const T term = (T)c * rd(tz - k, ty - j, tx - i);
                 acc = first ? term : acc + term;
                 first = false;
             }
@@ -171,8 +177,156 @@ __device__ __forceinline__ T reg_predict(const T (&c)[4], uint32_t i0, uint32_t 
 // ------------------------------------------------------------------------------------------------------------
 // encoder pass 1: fit, select, regression blocks coded; q~ of every element written to qwork
 // ------------------------------------------------------------------------------------------------------------
+// one block of the fit pass, by one wave, from an LDS tile that holds the block's originals and two low halo layers (zero outside
+// the array, like the reference's padding). The selection's error estimates see what the reference's see (ComposedPredictor.hpp:
+// 29-33 on a block whose predecessors are already compressed): ORIGINAL values inside the block, RECONSTRUCTED ones outside it —
+// here the lattice reconstruction the decoder will hold for a Lorenzo neighbour. HALO_RAW: the tile holds originals everywhere
+// (it is shared by several blocks) and the halo is put on the lattice when read; else the loader already did.
+template <typename T, uint32_t HW, int CB, bool HALO_RAW>
+__device__ __forceinline__ void blk_fit_block(const T *sx, const TileView &tv, const BlkGeom &g, uint32_t task, int lane, uint32_t *lh,
+                                              const szk_blk_params &p, uint16_t *__restrict__ codes) {
+    using Q = typename QTraits<T>::Q;
+    const Lattice<T> lat(p.lat);
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    Q *qwork = reinterpret_cast<Q *>(p.qwork);
+    const CoefLat cl = coef_lat(p.eb, p.B);
+    const double eb_recip = 1.0 / p.eb;
+    const bool has_l1 = p.mask & 1u, has_l2 = p.mask & 2u, has_r = p.mask & 4u;
+    auto rd = [&](uint32_t tz, uint32_t ty, uint32_t tx) -> T {
+        T v = sx[tv_at(tv, tz, ty, tx)];
+        if (HALO_RAW && (tz < 2 || ty < 2 || tx < 2)) {
+            bool bad;
+            const Q qh = lat.quant(v, bad);
+            if (!bad) v = lat.dequant(qh);
+        }
+        return v;
+    };
+    const uint32_t nown = g.ez * g.ey * g.ex;
+    // ---- regression fit (RegressionPredictor.hpp:28-55) ----
+    bool r_valid = has_r && g.ez > 1 && g.ey > 1 && g.ex > 1;
+    T cf[4] = {0, 0, 0, 0};
+    if (r_valid) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (uint32_t t = lane; t < nown; t += WAVE) {
+            uint32_t i0, i1, i2;
+        own_index<CB>(g, t, i0, i1, i2);
+            const T v = sx[tv_at(tv, i0 + 2, i1 + 2, i2 + 2)];
+            s0 += (double)((T)i0 * v);  // sum[i] += index[i] * (*c): size_t * T is evaluated in T, accumulated in double
+            s1 += (double)((T)i1 * v);
+            s2 += (double)((T)i2 * v);
+            s3 += (double)v;
+        }
+        s0 = wave_sum_f64(s0);
+        s1 = wave_sum_f64(s1);
+        s2 = wave_sum_f64(s2);
+        s3 = wave_sum_f64(s3);
+        // the three slopes have the same expression (RegressionPredictor.hpp:43-52): lanes 0..2 evaluate one each (a double
+        // division is ~40 instructions, ten of them were a fifth of the pass), then everybody takes the results
+        const double dz = g.ez, dy = g.ey, dx = g.ex, num = dz * dy * dx;
+        const double sk = lane == 0 ? s0 : (lane == 1 ? s1 : s2), dk = lane == 0 ? dz : (lane == 1 ? dy : dx);
+        const T ck = (T)((2 * sk / (dk - 1) - s3) * 6 / num / (dk + 1));
+        cf[0] = __shfl(ck, 0, WAVE);
+        cf[1] = __shfl(ck, 1, WAVE);
+        cf[2] = __shfl(ck, 2, WAVE);
+        cf[3] = (T)(s3 / num);
+        cf[3] = (T)((double)cf[3] - (dz - 1) * (double)cf[0] / 2);
+        cf[3] = (T)((double)cf[3] - (dy - 1) * (double)cf[1] / 2);
+        cf[3] = (T)((double)cf[3] - (dx - 1) * (double)cf[2] / 2);
+    }
+    // ---- selection (ComposedPredictor.hpp:25-40 over foreach_sampling) ----
+    int sid = has_l1 ? 0 : (has_l2 ? 1 : 2);
+    const int npred = (int)has_l1 + (int)has_l2 + (int)has_r;
+    if (npred > 1) {
+        const uint32_t m = min(g.ez, min(g.ey, g.ex));
+        double e1 = 0, e2 = 0, er = 0;
+        if ((uint32_t)lane < 4 * m) {
+            const uint32_t i = (uint32_t)lane / 4, kind = (uint32_t)lane % 4, j = m - 1 - i;
+            const uint32_t i0 = i, i1 = (kind & 2) ? j : i, i2 = (kind & 1) ? j : i;
+            const uint32_t tz = i0 + 2, ty = i1 + 2, tx = i2 + 2;
+            const T v = sx[tv_at(tv, tz, ty, tx)];
+            if (has_l1) e1 = (double)(T)(fabs((double)(T)(v - lorenzo_pred_orig<T>(rd, tz, ty, tx, 1))) + (T)(1.22 * p.eb));
+            if (has_l2) e2 = (double)(T)(fabs((double)(T)(v - lorenzo_pred_orig<T>(rd, tz, ty, tx, 2))) + (T)(6.8 * p.eb));
+            if (r_valid) er = (double)(T)fabs((double)(T)(v - reg_predict(cf, i0, i1, i2)));
+        }
+        e1 = wave_sum_f64(e1);
+        e2 = wave_sum_f64(e2);
+        er = wave_sum_f64(er);
+        double best = 1.7976931348623157e308;
+        sid = -1;
+        if (has_l1) { best = e1; sid = 0; }
+        if (has_l2 && (sid < 0 || e2 < best)) { best = e2; sid = 1; }
+        if (has_r && r_valid && (sid < 0 || er < best)) { best = er; sid = 2; }
+        if (sid < 0) sid = 0;  // (regression the only candidate and not valid: the fallback predictor, Lorenzo-1)
+    } else if (sid == 2 && !r_valid) {
+        sid = 0;  // BlockwiseDecomposition.hpp:35-37
+    }
+    // ---- regression: coefficients onto their lattices; a coefficient the lattice cannot hold -> Lorenzo-1 ----
+    int64_t lc[4] = {0, 0, 0, 0};
+    if (sid == 2) {
+        bool ok = true;
+        for (int i = 0; i < 4; i++) {
+            const double s = (double)cf[i] / (i < 3 ? cl.step_lin : cl.step_ind);
+            if (!(fabs(s) < 4503599627370496.0)) ok = false;
+            else lc[i] = (int64_t)rint(s);
+        }
+        if (!ok) sid = 0;
+    }
+    if (sid == 2) {
+        T rc[4];
+        coef_recover(lc, cl, rc);
+        for (uint32_t t0 = 0; t0 < nown; t0 += WAVE) {
+            const uint32_t t = t0 + lane;
+            const bool act = t < nown;
+            const uint32_t tt = act ? t : 0;
+            uint32_t i0, i1, i2;
+        own_index<CB>(g, tt, i0, i1, i2);
+            const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
+            const T raw = sx[tv_at(tv, i0 + 2, i1 + 2, i2 + 2)];
+            T v = raw;
+            const int code = act ? ref_quantize(v, reg_predict(rc, i0, i1, i2), p.eb, eb_recip, (int)p.radius) : 1;
+            Q qt = 0;
+            if (code != 0) {
+                bool bad;
+                qt = lat.quant(v, bad);
+                if (bad) qt = 0;
+            }
+            if (act) {
+                codes[g.coff + t] = (uint16_t)code;
+                qwork[gi] = qt;
+            }
+            blk_count<HW>(lh, p, (uint32_t)code, act);
+            blk_vout<T>(p, act && code == 0, gi, raw);  // unpredictable: the raw value, LinearQuantizer.hpp:66-69
+        }
+        if (lane == 0) {
+            for (int i = 0; i < 4; i++) p.coef[(uint64_t)task * 4 + i] = lc[i];
+            atomicAdd((unsigned long long *)p.n_reg, 1ull);
+        }
+    } else {
+        for (uint32_t t0 = 0; t0 < nown; t0 += WAVE) {
+            const uint32_t t = t0 + lane;
+            const bool act = t < nown;
+            const uint32_t tt = act ? t : 0;
+            uint32_t i0, i1, i2;
+        own_index<CB>(g, tt, i0, i1, i2);
+            const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
+            const T raw = sx[tv_at(tv, i0 + 2, i1 + 2, i2 + 2)];
+            bool bad;
+            Q q = lat.quant(raw, bad);
+            if (bad) q = 0;
+            if (act) qwork[gi] = q;
+            blk_vout<T>(p, act && bad, gi, raw);
+        }
+    }
+    if (lane == 0) p.sel[task] = (uint8_t)sid;
+}
+
 // NW: waves (= blocks in flight) per workgroup; they share the LDS histogram, so the wide form (64 KB of bins) takes 16 of them to
-// keep four waves per SIMD busy (with 4 the two passes ran at two waves per SIMD, bound by the latency of their tile loads)
+// keep four waves per SIMD busy (with 4 the two passes ran at two waves per SIMD, bound by the latency of their tile loads).
+// Measured and dropped (round 2, C4's slab): groups of 2 x 2 x 4 blocks sharing one tile per workgroup (1.47 x instead of 2.37 x
+// the volume read, rows of 26 values): fit 1.91 against 1.76 ms, Lorenzo pass 1.15 against 1.04 — the barriers around the shared
+// load cost more than the smaller read saves; a thread per ELEMENT for the Lorenzo pass (no idle lanes, block bookkeeping in an
+// LDS table): 1.08 ms — the pass is bound by its 8-byte lattice values (1.07 GB written by the fit, read back with halo), not by
+// its instructions. What would help is a 4-byte lattice for f64 inputs whose values fit one (they do at C4), decided per call.
 template <typename T, uint32_t HW, int CB, int NW>
 __global__ __launch_bounds__(NW * 64) void k_blk_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;
@@ -186,21 +340,15 @@ __global__ __launch_bounds__(NW * 64) void k_blk_fit(const T *__restrict__ in, u
     T *sx = s_x[wv];
     const uint32_t B = CB ? (uint32_t)CB : p.B, E = B + 2;
     const uint64_t d1 = p.d[1], d2 = p.d[2];
-    Q *qwork = reinterpret_cast<Q *>(p.qwork);
-    const CoefLat cl = coef_lat(p.eb, p.B);
-    const double eb_recip = 1.0 / p.eb;
-    const bool has_l1 = p.mask & 1u, has_l2 = p.mask & 2u, has_r = p.mask & 4u;
+    const TileView tv{E * E, E, 0};
     for (uint32_t task = blockIdx.x * NW + wv; task < nblocks; task += gridDim.x * NW) {
         const BlkGeom g = blk_geom(p, task);
-        // ---- originals of the block and two low halo layers (zero outside the array, like the reference's padding) ----
+        // ---- originals of the block and two low halo layers, the halo on the lattice ----
         for (uint32_t t = lane; t < E * E * E; t += WAVE) {
             const uint32_t tx = t % E, ty = (t / E) % E, tz = t / (E * E);
             const int64_t z = (int64_t)g.oz + tz - 2, y = (int64_t)g.oy + ty - 2, x = (int64_t)g.ox + tx - 2;
             T v = 0;
             if (z >= 0 && y >= 0 && x >= 0 && z < (int64_t)p.d[0] && y < (int64_t)d1 && x < (int64_t)d2) v = in[((uint64_t)z * d1 + (uint64_t)y) * d2 + (uint64_t)x];
-            // The selection's error estimates see what the reference's see (ComposedPredictor.hpp:29-33 on a block whose
-            // predecessors are already compressed): ORIGINAL values inside the block, RECONSTRUCTED ones outside it — here the
-            // lattice reconstruction the decoder will hold for a Lorenzo neighbour.
             if (tz < 2 || ty < 2 || tx < 2) {
                 bool bad;
                 const Q qh = lat.quant(v, bad);
@@ -210,123 +358,7 @@ __global__ __launch_bounds__(NW * 64) void k_blk_fit(const T *__restrict__ in, u
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's LDS writes are visible to its own reads
-        const uint32_t nown = g.ez * g.ey * g.ex;
-        // ---- regression fit (RegressionPredictor.hpp:28-55) ----
-        bool r_valid = has_r && g.ez > 1 && g.ey > 1 && g.ex > 1;
-        T cf[4] = {0, 0, 0, 0};
-        if (r_valid) {
-            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-            for (uint32_t t = lane; t < nown; t += WAVE) {
-                uint32_t i0, i1, i2;
-            own_index<CB>(g, t, i0, i1, i2);
-                const T v = sx[tile_at(E, i0 + 2, i1 + 2, i2 + 2)];
-                s0 += (double)((T)i0 * v);  // sum[i] += index[i] * (*c): size_t * T is evaluated in T, accumulated in double
-                s1 += (double)((T)i1 * v);
-                s2 += (double)((T)i2 * v);
-                s3 += (double)v;
-            }
-            s0 = wave_sum_f64(s0);
-            s1 = wave_sum_f64(s1);
-            s2 = wave_sum_f64(s2);
-            s3 = wave_sum_f64(s3);
-            // the three slopes have the same expression (RegressionPredictor.hpp:43-52): lanes 0..2 evaluate one each (a double
-            // division is ~40 instructions, ten of them were a fifth of the pass), then everybody takes the results
-            const double dz = g.ez, dy = g.ey, dx = g.ex, num = dz * dy * dx;
-            const double sk = lane == 0 ? s0 : (lane == 1 ? s1 : s2), dk = lane == 0 ? dz : (lane == 1 ? dy : dx);
-            const T ck = (T)((2 * sk / (dk - 1) - s3) * 6 / num / (dk + 1));
-            cf[0] = __shfl(ck, 0, WAVE);
-            cf[1] = __shfl(ck, 1, WAVE);
-            cf[2] = __shfl(ck, 2, WAVE);
-            cf[3] = (T)(s3 / num);
-            cf[3] = (T)((double)cf[3] - (dz - 1) * (double)cf[0] / 2);
-            cf[3] = (T)((double)cf[3] - (dy - 1) * (double)cf[1] / 2);
-            cf[3] = (T)((double)cf[3] - (dx - 1) * (double)cf[2] / 2);
-        }
-        // ---- selection (ComposedPredictor.hpp:25-40 over foreach_sampling) ----
-        int sid = has_l1 ? 0 : (has_l2 ? 1 : 2);
-        const int npred = (int)has_l1 + (int)has_l2 + (int)has_r;
-        if (npred > 1) {
-            const uint32_t m = min(g.ez, min(g.ey, g.ex));
-            double e1 = 0, e2 = 0, er = 0;
-            if ((uint32_t)lane < 4 * m) {
-                const uint32_t i = (uint32_t)lane / 4, kind = (uint32_t)lane % 4, j = m - 1 - i;
-                const uint32_t i0 = i, i1 = (kind & 2) ? j : i, i2 = (kind & 1) ? j : i;
-                const uint32_t tz = i0 + 2, ty = i1 + 2, tx = i2 + 2;
-                const T v = sx[tile_at(E, tz, ty, tx)];
-                if (has_l1) e1 = (double)(T)(fabs((double)(T)(v - lorenzo_pred_orig(sx, E, tz, ty, tx, 1))) + (T)(1.22 * p.eb));
-                if (has_l2) e2 = (double)(T)(fabs((double)(T)(v - lorenzo_pred_orig(sx, E, tz, ty, tx, 2))) + (T)(6.8 * p.eb));
-                if (r_valid) er = (double)(T)fabs((double)(T)(v - reg_predict(cf, i0, i1, i2)));
-            }
-            e1 = wave_sum_f64(e1);
-            e2 = wave_sum_f64(e2);
-            er = wave_sum_f64(er);
-            double best = 1.7976931348623157e308;
-            sid = -1;
-            if (has_l1) { best = e1; sid = 0; }
-            if (has_l2 && (sid < 0 || e2 < best)) { best = e2; sid = 1; }
-            if (has_r && r_valid && (sid < 0 || er < best)) { best = er; sid = 2; }
-            if (sid < 0) sid = 0;  // (regression the only candidate and not valid: the fallback predictor, Lorenzo-1)
-        } else if (sid == 2 && !r_valid) {
-            sid = 0;  // BlockwiseDecomposition.hpp:35-37
-        }
-        // ---- regression: coefficients onto their lattices; a coefficient the lattice cannot hold -> Lorenzo-1 ----
-        int64_t lc[4] = {0, 0, 0, 0};
-        if (sid == 2) {
-            bool ok = true;
-            for (int i = 0; i < 4; i++) {
-                const double s = (double)cf[i] / (i < 3 ? cl.step_lin : cl.step_ind);
-                if (!(fabs(s) < 4503599627370496.0)) ok = false;
-                else lc[i] = (int64_t)rint(s);
-            }
-            if (!ok) sid = 0;
-        }
-        if (sid == 2) {
-            T rc[4];
-            coef_recover(lc, cl, rc);
-            for (uint32_t t0 = 0; t0 < nown; t0 += WAVE) {
-                const uint32_t t = t0 + lane;
-                const bool act = t < nown;
-                const uint32_t tt = act ? t : 0;
-                uint32_t i0, i1, i2;
-            own_index<CB>(g, tt, i0, i1, i2);
-                const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
-                const T raw = sx[tile_at(E, i0 + 2, i1 + 2, i2 + 2)];
-                T v = raw;
-                const int code = act ? ref_quantize(v, reg_predict(rc, i0, i1, i2), p.eb, eb_recip, (int)p.radius) : 1;
-                Q qt = 0;
-                if (code != 0) {
-                    bool bad;
-                    qt = lat.quant(v, bad);
-                    if (bad) qt = 0;
-                }
-                if (act) {
-                    codes[g.coff + t] = (uint16_t)code;
-                    qwork[gi] = qt;
-                }
-                blk_count<HW>(lh, p, (uint32_t)code, act);
-                blk_vout<T>(p, act && code == 0, gi, raw);  // unpredictable: the raw value, LinearQuantizer.hpp:66-69
-            }
-            if (lane == 0) {
-                for (int i = 0; i < 4; i++) p.coef[(uint64_t)task * 4 + i] = lc[i];
-                atomicAdd((unsigned long long *)p.n_reg, 1ull);
-            }
-        } else {
-            for (uint32_t t0 = 0; t0 < nown; t0 += WAVE) {
-                const uint32_t t = t0 + lane;
-                const bool act = t < nown;
-                const uint32_t tt = act ? t : 0;
-                uint32_t i0, i1, i2;
-            own_index<CB>(g, tt, i0, i1, i2);
-                const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
-                const T raw = sx[tile_at(E, i0 + 2, i1 + 2, i2 + 2)];
-                bool bad;
-                Q q = lat.quant(raw, bad);
-                if (bad) q = 0;
-                if (act) qwork[gi] = q;
-                blk_vout<T>(p, act && bad, gi, raw);
-            }
-        }
-        if (lane == 0) p.sel[task] = (uint8_t)sid;
+        blk_fit_block<T, HW, CB, false>(sx, tv, g, task, lane, lh, p, codes);
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
@@ -336,10 +368,58 @@ __global__ __launch_bounds__(NW * 64) void k_blk_fit(const T *__restrict__ in, u
 // ------------------------------------------------------------------------------------------------------------
 // encoder pass 2: Lorenzo blocks — integer stencil over q~ (block + two low halo layers in LDS)
 // ------------------------------------------------------------------------------------------------------------
+// one Lorenzo block of the second pass, by one wave, from an LDS tile of q~ (the block and its two low halo layers)
+template <typename T, uint32_t HW, int CB>
+__device__ __forceinline__ void blk_lorenzo_block(const typename QTraits<T>::Q *sq, const TileView &tv, const BlkGeom &g, int order, int lane, uint32_t *lh,
+                                                  const szk_blk_params &p, uint16_t *__restrict__ codes) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    const uint32_t nown = g.ez * g.ey * g.ex;
+    for (uint32_t t0 = 0; t0 < nown; t0 += WAVE) {
+        const uint32_t t = t0 + lane;
+        const bool act = t < nown;
+        const uint32_t tt = act ? t : 0;
+        uint32_t i0, i1, i2;
+        own_index<CB>(g, tt, i0, i1, i2);
+        const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
+        UQ delta = 0;  // wrap-around arithmetic like the plain Lorenzo stream
+        if (order == 1) {  // (wave-uniform; the stencils unrolled with their constant weights)
+#pragma unroll
+            for (int k = 0; k <= 1; k++)
+#pragma unroll
+                for (int j = 0; j <= 1; j++)
+#pragma unroll
+                    for (int i = 0; i <= 1; i++) {
+                        const UQ v = (UQ)sq[tv_at(tv, i0 + 2 - k, i1 + 2 - j, i2 + 2 - i)];
+                        delta = ((k + j + i) & 1) ? delta - v : delta + v;
+                    }
+        } else {
+#pragma unroll
+            for (int k = 0; k <= 2; k++)
+#pragma unroll
+                for (int j = 0; j <= 2; j++)
+#pragma unroll
+                    for (int i = 0; i <= 2; i++) {
+                        const int w = lz_w(2, k) * lz_w(2, j) * lz_w(2, i);
+                        delta += (UQ)((Q)w * sq[tv_at(tv, i0 + 2 - k, i1 + 2 - j, i2 + 2 - i)]);
+                    }
+        }
+        const bool inr = (UQ)(delta + (UQ)(p.radius - 1)) <= (UQ)(2 * p.radius - 2);
+        const uint32_t code = inr ? (uint32_t)(delta + (UQ)p.radius) : 0u;
+        if (act) codes[g.coff + t] = (uint16_t)code;
+        blk_count<HW>(lh, p, code, act);
+        const unsigned long long pd = wave_append_slot(act && !inr, p.n_dout);
+        if (act && !inr && pd < p.out_cap) {
+            p.dout_idx[pd] = g.coff + t;  // (position of the code, not of the element: the decoder expands the codes in place)
+            reinterpret_cast<Q *>(p.dout_val)[pd] = (Q)delta;
+        }
+    }
+}
+
 template <typename T, uint32_t HW, int CB, int NW>
 __global__ __launch_bounds__(NW * 64) void k_blk_lorenzo(uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;
-    using UQ = typename QTraits<T>::UQ;
     __shared__ Q s_q[NW][CB ? (CB + 2) * (CB + 2) * (CB + 2) : BLK_TILE];
     __shared__ uint32_t lh[HW];
     for (uint32_t b = threadIdx.x; b < HW; b += NW * 64) lh[b] = 0;
@@ -350,6 +430,7 @@ __global__ __launch_bounds__(NW * 64) void k_blk_lorenzo(uint16_t *__restrict__ 
     const uint32_t B = CB ? (uint32_t)CB : p.B, E = B + 2;
     const uint64_t d1 = p.d[1], d2 = p.d[2];
     const Q *qwork = reinterpret_cast<const Q *>(p.qwork);
+    const TileView tv{E * E, E, 0};
     for (uint32_t task = blockIdx.x * NW + wv; task < nblocks; task += gridDim.x * NW) {
         const int sid = p.sel[task];
         if (sid == 2) continue;
@@ -364,52 +445,12 @@ __global__ __launch_bounds__(NW * 64) void k_blk_lorenzo(uint16_t *__restrict__ 
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        const uint32_t nown = g.ez * g.ey * g.ex;
-        for (uint32_t t0 = 0; t0 < nown; t0 += WAVE) {
-            const uint32_t t = t0 + lane;
-            const bool act = t < nown;
-            const uint32_t tt = act ? t : 0;
-            uint32_t i0, i1, i2;
-            own_index<CB>(g, tt, i0, i1, i2);
-            const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
-            UQ delta = 0;  // wrap-around arithmetic like the plain Lorenzo stream
-            if (order == 1) {  // (wave-uniform; the stencils unrolled with their constant weights)
-#pragma unroll
-                for (int k = 0; k <= 1; k++)
-#pragma unroll
-                    for (int j = 0; j <= 1; j++)
-#pragma unroll
-                        for (int i = 0; i <= 1; i++) {
-                            const UQ v = (UQ)sq[tile_at(E, i0 + 2 - k, i1 + 2 - j, i2 + 2 - i)];
-                            delta = ((k + j + i) & 1) ? delta - v : delta + v;
-                        }
-            } else {
-#pragma unroll
-                for (int k = 0; k <= 2; k++)
-#pragma unroll
-                    for (int j = 0; j <= 2; j++)
-#pragma unroll
-                        for (int i = 0; i <= 2; i++) {
-                            const int w = lz_w(2, k) * lz_w(2, j) * lz_w(2, i);
-                            delta += (UQ)((Q)w * sq[tile_at(E, i0 + 2 - k, i1 + 2 - j, i2 + 2 - i)]);
-                        }
-            }
-            const bool inr = (UQ)(delta + (UQ)(p.radius - 1)) <= (UQ)(2 * p.radius - 2);
-            const uint32_t code = inr ? (uint32_t)(delta + (UQ)p.radius) : 0u;
-            if (act) codes[g.coff + t] = (uint16_t)code;
-            blk_count<HW>(lh, p, code, act);
-            const unsigned long long pd = wave_append_slot(act && !inr, p.n_dout);
-            if (act && !inr && pd < p.out_cap) {
-                p.dout_idx[pd] = g.coff + t;  // (position of the code, not of the element: the decoder expands the codes in place)
-                reinterpret_cast<Q *>(p.dout_val)[pd] = (Q)delta;
-            }
-        }
+        blk_lorenzo_block<T, HW, CB>(sq, tv, g, order, lane, lh, p, codes);
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     blk_flush<HW>(lh, p);
 }
-
 // ------------------------------------------------------------------------------------------------------------
 // side information of a block stream:
 //   [u32 coding = 1][u32 sel_bits = 2][u64 n_blocks][u64 n_reg]

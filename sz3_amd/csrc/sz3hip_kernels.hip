@@ -2705,13 +2705,19 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
             for (uint32_t i = 0; i < nsym; i++) {
                 const QO d = sym ? (QO)((int)sym - (int)p.radius) : dec_dout<QO>(p, s0 + i);
                 acc += d;
-                qout[i] = acc;
+                if (HALF) {  // (the half-width chain's buffer holds int16: a stream whose every element is a listed delta has values to match)
+                    reinterpret_cast<int16_t *>(p.q_out)[s0 + i] = (int16_t)acc;
+                    ovf_seen |= (QO)(int16_t)acc != acc;
+                } else {
+                    qout[i] = acc;
+                }
                 if (--left == 0) {
                     acc = 0;
                     left = p.scan_row;
                 }
             }
             if (p.carry) reinterpret_cast<QO *>(p.carry)[chunk] = acc;
+            if (HALF && ovf_seen) atomicOr(p.ovf, 1u);
         } else {
             for (uint32_t i = 0; i < nsym; i++) out[i] = sym;
         }

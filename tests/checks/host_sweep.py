@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, sz3_amd
 rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+if os.environ.get("DBG_FLAGS"): sz3_amd.lib().sz3hip_debug_flags(int(os.environ["DBG_FLAGS"]))  # e.g. 4194304: level kernels whatever the size
 pool = [1, 2, 5, 8, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 200, 256]
 bad = 0
 for k in range(int(os.environ.get("N", "40"))):

@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, sz3_amd, math
 from oracle_binding import ALGO_INTERP, make_config, oracle_interp_codes
 rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+if os.environ.get("DBG_FLAGS"): sz3_amd.lib().sz3hip_debug_flags(int(os.environ["DBG_FLAGS"]))  # e.g. 4194304: level kernels whatever the size
 pool = [5, 8, 9, 16, 17, 24, 31, 32, 33, 40, 48, 63, 64, 65, 72, 100]
 bad = 0
 for k in range(int(os.environ.get("N", "40"))):

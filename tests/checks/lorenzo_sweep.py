@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, sz3_amd, szh_ref
 rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+if os.environ.get("DBG_FLAGS"): sz3_amd.lib().sz3hip_debug_flags(int(os.environ["DBG_FLAGS"]))  # e.g. 4194304: level kernels whatever the size
 pool = [1, 3, 8, 9, 16, 17, 31, 32, 33, 40, 64, 65, 100, 128, 129, 256, 260, 512]
 bad = 0
 for k in range(int(os.environ.get("N", "40"))):
@@ -36,6 +37,10 @@ for k in range(int(os.environ.get("N", "40"))):
     ok = ok and np.array_equal(dec, model, equal_nan=True)
     fin = np.isfinite(a)
     ok = ok and (not fin.any() or np.max(np.abs(dec[fin].astype(np.float64) - a[fin].astype(np.float64))) <= eb) and np.array_equal(np.isnan(dec), np.isnan(a))
-    if not ok: bad += 1
+    if not ok:
+        bad += 1
+        print("   codes", np.array_equal(codes, exp_codes.reshape(-1)), "vout", st["n_value_outliers"], int(badm.sum()), "dout", st["n_delta_outliers"], int(dout.sum()),
+              "model", np.array_equal(dec, model, equal_nan=True), "max err", float(np.max(np.abs(dec[fin].astype(np.float64) - a[fin].astype(np.float64)))) if fin.any() else None,
+              "nan", np.array_equal(np.isnan(dec), np.isnan(a)))
     print(k, shape, dt.__name__, "qb", qb, "eb", eb, "narrow", st["narrow_codes"], "vout", st["n_value_outliers"], "dout", st["n_delta_outliers"], "OK" if ok else "MISMATCH")
 print("mismatches:", bad)

@@ -424,3 +424,37 @@ def test_unpredictable_values_in_tiles_that_end_beyond_the_row(shape):
     assert np.array_equal(o[big], a[big])
     ok = ~m & ~big
     assert np.max(np.abs(o[ok].astype(np.float64) - a[ok].astype(np.float64))) <= 1e-3
+
+
+@pytest.mark.parametrize("shape", [(64,), (700,), (1, 1024)], ids=["1d-64", "1d-700", "2d-one-row"])  # (at most 1024 elements: the lists' floor)
+def test_every_element_a_listed_delta(shape):
+    """quantbinCnt 64 on a field that jumps by hundreds of lattice steps from element to element: every code is 0, the
+    alphabet has one symbol (zero-length code words, empty bit stream) and the decoder's values all come from the delta list —
+    on either chain (the half-width one keeps int16 values)."""
+    n = int(np.prod(shape))
+    a = (((-1.0) ** np.arange(n)) * 0.1 * (1 + np.arange(n) % 3)).astype(np.float32).reshape(shape)
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    res = []
+    try:
+        for flag in (0, 2097152):
+            sz3_amd.lib().sz3hip_debug_flags(flag)
+            dc = sz3_amd.DeviceCompressor(a.size, np.float32)
+            cap = dc.payload_bound(a.size, worst_case=True)
+            pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+            conf = sz3_amd.Config(*shape)
+            conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+            conf.regression = 0
+            conf.absErrorBound = 1e-4
+            conf.quantbinCnt = 64
+            size = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+            st = dc.stats()
+            assert st["n_delta_outliers"] == n and st["max_code_len"] == 0
+            out = torch.empty_like(t)
+            dc.decompress(pl.data_ptr(), size, out.data_ptr(), 0)
+            torch.cuda.synchronize()
+            res.append(out.cpu().numpy())
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(0)
+    assert np.array_equal(res[0], res[1])
+    assert np.max(np.abs(res[0].astype(np.float64) - a.astype(np.float64))) <= 1e-4

@@ -2,6 +2,7 @@
 tests/checks/lorenzo_sweep.py  - K1 codes / outlier counts / payload decode against the numpy model of the format (tests/szh_ref.py)
 tests/checks/interp_sweep.py   - interpolation codes and reconstruction against the oracle, bit for bit
 tests/checks/host_sweep.py     - the host API over dtypes, error-bound modes and algorithms: the user-visible guarantee of each mode
+tests/checks/block_sweep.py    - the block-composed path (predictor sets, block edges, radii, NaNs, steps) against the numpy block decoder
 They found the small-quantbinCnt bugs fixed in round 1 (code 0 inside the kernels' LDS histogram windows)."""
 import os
 import subprocess
@@ -13,8 +14,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tool, seed, n):
+def _run(tool, seed, n, flags=None):
     env = dict(os.environ, SEED=str(seed), N=str(n))
+    if flags is not None:
+        env["DBG_FLAGS"] = str(flags)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", tool)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
@@ -29,6 +32,18 @@ def test_lorenzo_sweep(seed):
 @pytest.mark.parametrize("seed", [11, 12])
 def test_interp_sweep(seed):
     out = _run("interp_sweep.py", seed, 25)
+    assert "mismatches: 0" in out, out[-3000:]
+
+
+def test_interp_sweep_through_the_level_kernels():
+    """debug flag 4194304: every level of every 3-D case runs in the level kernels (the sweep's arrays are below their size)"""
+    out = _run("interp_sweep.py", 13, 40, flags=4194304)
+    assert "mismatches: 0" in out, out[-3000:]
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_block_path_sweep(seed):
+    out = _run("block_sweep.py", seed, 30)
     assert "mismatches: 0" in out, out[-3000:]
 
 

@@ -34,6 +34,11 @@ for k in range(int(os.environ.get("N", "40"))):
     abs_eb = float(10.0 ** rng.integers(-4, -1)) * scale * (100 if isint else 1)
     rel = float(10.0 ** rng.integers(-4, -1))
     conf.absErrorBound = abs_eb; conf.relErrorBound = rel; conf.psnrErrorBound = float(rng.choice([40.0, 60.0, 80.0])); conf.l2normErrorBound = abs_eb * np.sqrt(a.size)
+    slabs = 0
+    if rng.random() < 0.3:  # the slab-parallel container (SZ_compress_OMP's layout), several slabs on this one GPU
+        slabs = int(rng.integers(2, 6)); conf.openmp = 1; os.environ["SZ3HIP_SLABS"] = str(slabs)
+    else:
+        os.environ.pop("SZ3HIP_SLABS", None)
     try:
         blob, ratio = sz3_amd.compress(a, conf)
         dec, c2 = sz3_amd.decompress(blob, a.dtype, a.shape)
@@ -61,5 +66,5 @@ for k in range(int(os.environ.get("N", "40"))):
         l2 = float(np.sqrt(np.sum((df[fin] - af[fin]) ** 2)))
         ok = ok and l2 <= conf.l2normErrorBound * 1.1  # (the reference's bound sqrt(3/n) * l2 holds in expectation: uniform errors)
     if not ok: bad += 1
-    print(k, shape, dt.__name__, "mode", mode, "algo", conf.cmprAlgo, "->", c2.cmprAlgo, "qb", conf.quantbinCnt, "ratio %.2f" % ratio, "err %.3g" % err, "bound", bound, "OK" if ok else "FAIL")
+    print(k, shape, dt.__name__, "mode", mode, "algo", conf.cmprAlgo, "->", c2.cmprAlgo, "qb", conf.quantbinCnt, "slabs", slabs, "ratio %.2f" % ratio, "err %.3g" % err, "bound", bound, "OK" if ok else "FAIL")
 print("failures:", bad)

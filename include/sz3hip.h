@@ -173,7 +173,9 @@ typedef struct sz3hip_tuner_report {
     int32_t use_interp; /* 1: interpolation chosen; 0: Lorenzo (possible in 1-D only, :232-250) */
     uint64_t sample_block_size, n_filtered, n_blocks;
     int32_t profiling;
-    int32_t interpAlgo, interpDirection, reserved;
+    int32_t interpAlgo, interpDirection;
+    int32_t speculated; /* 0: stage 1 waited for the tuner; 1: it had started with the previous call's outcome and the tuner confirmed it;
+                         * 2: started, not confirmed, enqueued again with this call's outcome */
     double interpAlpha, interpBeta;
     double est_bytes[8]; /* priced size of the trials: linear, cubic, reversed direction, 3 x (alpha, beta), [6] Lorenzo (1-D) */
 } sz3hip_tuner_report;

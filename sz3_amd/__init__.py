@@ -49,7 +49,7 @@ class _CConfig(C.Structure):
 class _CTunerReport(C.Structure):
     _fields_ = [("ran", C.c_int32), ("use_interp", C.c_int32), ("sample_block_size", C.c_uint64), ("n_filtered", C.c_uint64),
                 ("n_blocks", C.c_uint64), ("profiling", C.c_int32), ("interpAlgo", C.c_int32), ("interpDirection", C.c_int32),
-                ("reserved", C.c_int32), ("interpAlpha", C.c_double), ("interpBeta", C.c_double), ("est_bytes", C.c_double * 8)]
+                ("speculated", C.c_int32), ("interpAlpha", C.c_double), ("interpBeta", C.c_double), ("est_bytes", C.c_double * 8)]
 
 
 class _CStats(C.Structure):
@@ -345,8 +345,9 @@ class DeviceCompressor:
         """what the ALGO_INTERP_LORENZO auto-tuner decided in the last stage1 / compress call (sz3hip_get_tuner_report)"""
         r = _CTunerReport()
         lib().sz3hip_get_tuner_report(self._h, C.byref(r))
-        out = {k: getattr(r, k) for k, _ in _CTunerReport._fields_ if k not in ("est_bytes", "reserved")}
+        out = {k: getattr(r, k) for k, _ in _CTunerReport._fields_ if k not in ("est_bytes", "speculated")}
         out["est_bytes"] = [float(x) for x in r.est_bytes]
+        self.speculated = int(r.speculated)  # (how stage 1 related to the tuner; not part of the decision the report describes)
         return out
 
     def set_profiling(self, on=True):

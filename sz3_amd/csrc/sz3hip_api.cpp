@@ -929,9 +929,46 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
             HIPCHK(hipMemcpyAsync(ctx->d_work, d_in, num * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8), hipMemcpyDeviceToDevice, ctx->side));
             HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
         }
-        prof_begin(ctx, ST_TUNER, s);
-        int rct = tune_interp_lorenzo(ctx, *conf, d_in, eb, radius, s);
-        prof_end(ctx, ST_TUNER, s);
+        // Speculation (3-D arrays of the level kernels): the tuner is 0.2 ms of small launches and host round trips during which
+        // the chip idles, and on a series of similar arrays its outcome repeats. A context that has a previous outcome for this
+        // shape starts stage 1 with it on the caller's stream and runs the tuner beside it on the side stream; the tuner's
+        // outcome decides as ever — when it differs, stage 1 is enqueued again with it (the speculative launches run out
+        // first: wasted time, same payload; tests/test_gpu_stages.py::test_speculative_stage1_follows_the_tuner).
+        bool spec = !ahead && ctx->spec_valid && !(szk_dbg_flags & 131072) && ctx->spec_conf.N == conf->N;
+        for (int i = 0; spec && i < conf->N; i++) spec = ctx->spec_conf.dims[i] == conf->dims[i];
+        int rc_spec = 0;
+        hipStream_t ts = s;  // the stream the tuner runs on
+        if (spec) {
+            if (!ctx->side) {
+                HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+            }
+            HIPCHK(hipEventRecord(ctx->ev_fork, s));  // (the input is ready on the side stream when it is on the caller's)
+            HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+            sz3hip_config sc = *conf;
+            sc.cmprAlgo = SZ3HIP_ALGO_INTERP;
+            sc.interpAlgo = ctx->spec_conf.interpAlgo;
+            sc.interpDirection = ctx->spec_conf.interpDirection;
+            sc.interpAlpha = ctx->spec_conf.interpAlpha;
+            sc.interpBeta = ctx->spec_conf.interpBeta;
+            sc.interpAnchorStride = ctx->spec_conf.interpAnchorStride;
+            ctx->spec_used = sc;
+            HIPCHK(clear_hist_counters(ctx, s));
+            rc_spec = stage1_interp(ctx, &sc, d_in, eb, radius, num, s);
+            ts = ctx->side;
+        }
+        prof_begin(ctx, ST_TUNER, ts);
+        int rct = tune_interp_lorenzo(ctx, *conf, d_in, eb, radius, ts);
+        prof_end(ctx, ST_TUNER, ts);
+        if (spec) {
+            hipError_t ej = hipEventRecord(ctx->ev_join, ctx->side);
+            if (ej == hipSuccess) ej = hipStreamWaitEvent(s, ctx->ev_join, 0);  // the caller's stream owns d_in again
+            if (ej != hipSuccess) {
+                (void)hipStreamSynchronize(ctx->side);
+                return fail(SZ3HIP_EHIP, "joining the side stream failed: %s", hipGetErrorString(ej));
+            }
+        }
         if (ahead) {
             hipError_t ej = hipStreamWaitEvent(s, ctx->ev_join, 0);  // whatever the outcome: the caller's stream owns d_in again
             if (ej != hipSuccess) {
@@ -941,6 +978,17 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
         }
         if (rct) return rct;
         ctx->copy_ahead = ahead;
+        // what the next call of this context may start from
+        ctx->spec_valid = ctx->tuner.ran && conf->cmprAlgo == SZ3HIP_ALGO_INTERP;
+        if (ctx->spec_valid) ctx->spec_conf = *conf;
+        if (spec) {
+            const sz3hip_config &p0 = ctx->spec_conf;  // (= this call's outcome when valid)
+            const bool hit = ctx->spec_valid && rc_spec == 0 && p0.interpAlgo == ctx->spec_used.interpAlgo &&
+                             p0.interpDirection == ctx->spec_used.interpDirection && p0.interpAlpha == ctx->spec_used.interpAlpha &&
+                             p0.interpBeta == ctx->spec_used.interpBeta && p0.interpAnchorStride == ctx->spec_used.interpAnchorStride;
+            ctx->tuner.speculated = hit ? 1 : 2;
+            if (hit) return 0;  // stage 1 is already on its way
+        }
     }
     HIPCHK(clear_hist_counters(ctx, s));
     if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP || conf->cmprAlgo == SZ3HIP_ALGO_HIP_INTERP)

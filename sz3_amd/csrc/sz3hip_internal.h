@@ -75,6 +75,8 @@ struct sz3hip_ctx {
     szk_cb_info *d_info;
     uint16_t *d_chunk_words;
     uint64_t *d_chunk_off;
+    bool spec_valid;               // spec_conf holds the previous call's tuner outcome (ALGO_INTERP_LORENZO, interpolation chosen)
+    sz3hip_config spec_conf, spec_used;
     uint32_t last_half, last_carry;  // which chain the last decompression took (test hook)
     void *d_carry;  // decoder: running sums the chunks end with (rows that do not divide the chunk), allocated on first use
     szk_state *d_state;

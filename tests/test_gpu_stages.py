@@ -458,3 +458,50 @@ def test_every_element_a_listed_delta(shape):
         sz3_amd.lib().sz3hip_debug_flags(0)
     assert np.array_equal(res[0], res[1])
     assert np.max(np.abs(res[0].astype(np.float64) - a.astype(np.float64))) <= 1e-4
+
+
+def test_speculative_stage1_follows_the_tuner():
+    """ALGO_INTERP_LORENZO on 3-D arrays of the level kernels: a context that holds a previous tuner outcome starts stage 1 with it
+    beside the tuner and enqueues it again when the tuner decides otherwise. Fields whose outcomes differ (cubic / linear, both
+    direction orders, three (alpha, beta) pairs) alternate on one context: every payload equals a fresh context's, the tuner's
+    report is the same, and both a confirmed and a refuted speculation occur."""
+    shape = (200, 208, 224)
+    z, y, x = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing="ij")
+    rng = np.random.default_rng(3)
+    fields = {
+        "c2": field3d(shape),
+        "noisy": (np.sin(2 * np.pi * x / 40) + 0.3 * rng.standard_normal(shape)).astype(np.float32),
+        "aniso-x": (np.sin(2 * np.pi * x / 7) + 0.05 * np.sin(2 * np.pi * z / 90)).astype(np.float32),
+        "smooth": (np.sin(2 * np.pi * x / 150) * np.cos(2 * np.pi * y / 170) * np.sin(2 * np.pi * z / 130)).astype(np.float32),
+    }
+    del x, y, z
+    dev = torch.device("cuda:0")
+    n = int(np.prod(shape))
+    shared = sz3_amd.DeviceCompressor(n, np.float32)
+    cap = shared.payload_bound(n, worst_case=True)
+    conf = sz3_amd.Config(*shape)
+    conf.absErrorBound = 1e-2
+    seen, outcomes = [], set()
+    for name in ["c2", "c2", "noisy", "noisy", "aniso-x", "c2", "smooth", "c2"]:
+        t = torch.from_numpy(fields[name]).to(dev)
+        pls = []
+        reps = []
+        for dc in (shared, sz3_amd.DeviceCompressor(n, np.float32)):
+            pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+            size = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+            torch.cuda.synchronize()
+            pls.append(pl[:size].clone())
+            reps.append(dc.tuner_report())
+            if dc is shared:
+                seen.append(dc.speculated)
+            else:
+                assert dc.speculated == 0
+        assert reps[0] == reps[1] and reps[0]["ran"] == 1 and reps[0]["use_interp"] == 1
+        assert pls[0].numel() == pls[1].numel() and torch.equal(pls[0], pls[1]), "payload depends on the context's history (%s)" % name
+        outcomes.add((reps[0]["interpAlgo"], reps[0]["interpDirection"], reps[0]["interpAlpha"], reps[0]["interpBeta"]))
+        out = torch.empty_like(t)
+        shared.decompress(pls[0].data_ptr(), pls[0].numel(), out.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert float((out.double() - t.double()).abs().max()) <= 1e-2
+    assert len(outcomes) >= 3, outcomes
+    assert seen[0] == 0 and seen[1] == 1 and seen[3] == 1 and 2 in seen, seen

@@ -916,7 +916,10 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
         memset(&shape, 0, sizeof(shape));
         shape.N = conf->N;
         for (int i = 0; i < conf->N && i < 4; i++) shape.dims[i] = conf->dims[i];
-        const bool ahead = !szk_interp_levels_ok(&shape);
+        // (speculation, below: stage 1 itself runs beside the tuner; not for 1-D arrays, whose tuner shares the histogram with it)
+        bool spec = ctx->spec_valid && !(szk_dbg_flags & 131072) && conf->N >= 2 && ctx->spec_conf.N == conf->N;
+        for (int i = 0; spec && i < conf->N; i++) spec = ctx->spec_conf.dims[i] == conf->dims[i];
+        const bool ahead = !szk_interp_levels_ok(&shape) && !spec;
         if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
         if (ahead) {
             if (!ctx->side) {
@@ -929,13 +932,11 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
             HIPCHK(hipMemcpyAsync(ctx->d_work, d_in, num * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8), hipMemcpyDeviceToDevice, ctx->side));
             HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
         }
-        // Speculation (3-D arrays of the level kernels): the tuner is 0.2 ms of small launches and host round trips during which
-        // the chip idles, and on a series of similar arrays its outcome repeats. A context that has a previous outcome for this
-        // shape starts stage 1 with it on the caller's stream and runs the tuner beside it on the side stream; the tuner's
-        // outcome decides as ever — when it differs, stage 1 is enqueued again with it (the speculative launches run out
-        // first: wasted time, same payload; tests/test_gpu_stages.py::test_speculative_stage1_follows_the_tuner).
-        bool spec = !ahead && ctx->spec_valid && !(szk_dbg_flags & 131072) && ctx->spec_conf.N == conf->N;
-        for (int i = 0; spec && i < conf->N; i++) spec = ctx->spec_conf.dims[i] == conf->dims[i];
+        // Speculation: the tuner is 0.2 ms (f64 / 4-D: 1-3 ms) of small launches and host round trips during which the chip
+        // idles, and on a series of similar arrays its outcome repeats. A context that has a previous outcome for this shape
+        // starts stage 1 with it on the caller's stream and runs the tuner beside it on the side stream; the tuner's outcome
+        // decides as ever — when it differs, stage 1 is enqueued again with it (the speculative launches run out first: wasted
+        // time, same payload; tests/test_gpu_stages.py::test_speculative_stage1_follows_the_tuner).
         int rc_spec = 0;
         hipStream_t ts = s;  // the stream the tuner runs on
         if (spec) {

@@ -400,6 +400,7 @@ struct szk_interp_level {
     uint32_t nt[3];    // blocks per dimension
     int perm[3];       // pass k runs along dimension perm[k]
     int interp_id, radius, no_store;
+    int pair;          // decoder, finest level, x last, rows of even length: the last pass stores (even, odd) pairs, the earlier ones nothing
     double eb, eb_recip;
 };
 #define LV_MAIN (33 * 33 * 17)
@@ -477,7 +478,8 @@ struct LvPass {
     int o_m3, o_m1, o_p1, o_p3;
     uint32_t gX, gU, gW, gstep;  // element strides inside the block (32 bits: the host checked the block's span)
     uint32_t ownU_lim, ownX_lim, ownW_lim;  // an index below the limit is owned (limit = n - 1, or n in the axis' last block)
-    int defer, no_store, radius;
+    int defer, no_store, radius, pair;
+    uint32_t n2;
     double eb, eb_recip;
 };
 
@@ -541,7 +543,19 @@ __device__ __forceinline__ void lv_items(const LvPass<T> &q, uint32_t tid, int s
             T v;
             if (DEC) {
                 v = code_in ? ref_recover<T>(pred, code_in, q.eb, q.radius) : q.wb[go];  // code 0: the raw value, scattered in place before
-                if (owned && code_in) q.wb[go] = v;
+                if (sizeof(T) == 4 && q.pair) {
+                    // the finest level's even-x points are stored by the last pass together with their odd neighbours (whole
+                    // 8-byte pairs, rows written once) instead of 4 bytes here and 4 there; what has no odd neighbour — the last
+                    // column of a row of odd length — is stored where it is decoded
+                    if (LASTP) {
+                        const float2 pr = make_float2((float)L[addr + q.o_m1], (float)v);
+                        *reinterpret_cast<float2 *>(reinterpret_cast<float *>(q.wb) + go - 1) = pr;
+                    } else if (owned && iX + 1 == q.n2) {
+                        q.wb[go] = v;
+                    }
+                } else if (owned && code_in) {
+                    q.wb[go] = v;
+                }
             } else {
                 v = orig;
                 const int code = lv_quantize<T>(v, pred, q.eb, q.eb_recip, q.radius);
@@ -702,7 +716,7 @@ __global__ __launch_bounds__(LV_NT) void k_interp_level(const T *__restrict__ in
         q.ownU_lim = lastU ? nU : nU - 1;
         q.ownX_lim = last2 ? n2 : n2 - 1;
         q.ownW_lim = lastW ? nW : nW - 1;
-        q.defer = defer; q.no_store = p.no_store; q.radius = p.radius;
+        q.defer = defer; q.no_store = p.no_store; q.radius = p.radius; q.pair = p.pair; q.n2 = n2;
         q.eb = p.eb; q.eb_recip = p.eb_recip;
         const bool cubic = p.interp_id != 0;
         const bool full = cubic && na == 33;
@@ -1145,6 +1159,7 @@ static int launch_level(const szk_interp_pass &p, const int *perm, const T *in, 
     L.interp_id = p.interp_id;
     L.radius = p.radius;
     L.no_store = !DEC && p.s == 1;  // the finest level's reconstruction is read by nobody
+    L.pair = DEC && sizeof(T) == 4 && p.s == 1 && perm[2] == 2 && p.dims[2] % 2 == 0 && (reinterpret_cast<uintptr_t>(w) & 7) == 0;
     L.eb = p.eb;
     L.eb_recip = p.eb_recip;
     const size_t lds = (size_t)(LV_MAIN + LV_SIDE) * sizeof(T);

@@ -187,6 +187,9 @@ void sz3hip_set_profiling(sz3hip_ctx *ctx, int on);
 int sz3hip_get_stage_times(sz3hip_ctx *ctx, const char **names, float *ms, int max);
 /* test hooks: copy internal device arrays to host (quantisation codes as uint16, histogram as uint64) */
 int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, uint64_t n);
+/* test hook: which chain the last sz3hip_decompress_device took: out4[0] half-width intermediates, [1] rows that cross chunk
+ * boundaries (carry pass), [2] calls left before the half-width chain is tried again after an overflow, [3] reserved */
+int sz3hip_debug_decode_info(sz3hip_ctx *ctx, uint32_t *out4);
 /* test hook: non-zero routes every shape through the generic (any-shape) stage-1 kernel instead of the tuned one */
 void sz3hip_debug_force_generic(int on);
 /* development switches (bit mask, process-wide; 0 = product behaviour). Bits 1..16: ablations of the stage-1 kernel for

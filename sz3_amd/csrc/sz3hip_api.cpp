@@ -977,7 +977,11 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
                 return fail(SZ3HIP_EHIP, "joining the side stream failed: %s", hipGetErrorString(ej));
             }
         }
-        if (rct) return rct;
+        if (rct) {
+            ctx->stage1_done = false;  // (a speculative stage 1 may be on its way: its results are not this call's)
+            ctx->spec_valid = false;
+            return rct;
+        }
         ctx->copy_ahead = ahead;
         // what the next call of this context may start from
         ctx->spec_valid = ctx->tuner.ran && conf->cmprAlgo == SZ3HIP_ALGO_INTERP;

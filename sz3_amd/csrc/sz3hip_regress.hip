@@ -325,8 +325,8 @@ __device__ __forceinline__ void blk_fit_block(const T *sx, const TileView &tv, c
 // Measured and dropped (round 2, C4's slab): groups of 2 x 2 x 4 blocks sharing one tile per workgroup (1.47 x instead of 2.37 x
 // the volume read, rows of 26 values): fit 1.91 against 1.76 ms, Lorenzo pass 1.15 against 1.04 — the barriers around the shared
 // load cost more than the smaller read saves; a thread per ELEMENT for the Lorenzo pass (no idle lanes, block bookkeeping in an
-// LDS table): 1.08 ms — the pass is bound by its 8-byte lattice values (1.07 GB written by the fit, read back with halo), not by
-// its instructions. What would help is a 4-byte lattice for f64 inputs whose values fit one (they do at C4), decided per call.
+// LDS table): 1.08 ms — not bound by its instructions, then; by its 8-byte lattice values (1.07 GB written by the fit, read back
+// with halo) — or so it seemed: storing q~ in 4 bytes (behind gated full-width passes for values that do not fit) changed nothing either (fit 1.75, Lorenzo pass 1.00 ms). What the two passes are bound by is still open.
 template <typename T, uint32_t HW, int CB, int NW>
 __global__ __launch_bounds__(NW * 64) void k_blk_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;

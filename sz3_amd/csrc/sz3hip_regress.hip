@@ -789,7 +789,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 template <typename T, int CB, int ORDER>
 __device__ __forceinline__ void blk_invert(typename QTraits<T>::Q *sq, typename QTraits<T>::Q *sa, typename QTraits<T>::Q *qout, const BlkGeom &g,
-                                           uint32_t E, uint64_t d1, uint64_t d2, int lane) {
+                                           const TileView &tv, uint64_t d1, uint64_t d2, int lane, bool keep) {
+    // (tv: where the block's neighbourhood sits in sq / sa; keep: the result also replaces the deltas in sq — the tile is shared by a
+    // group of blocks and the next ones read it as their halo)
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     wave_lds_fence();
@@ -803,14 +805,14 @@ __device__ __forceinline__ void blk_invert(typename QTraits<T>::Q *sq, typename 
 #pragma unroll
             for (int k = 0; k <= ORDER; k++)
 #pragma unroll
-                for (int j = 0; j <= ORDER; j++) s += (UQ)((Q)(lz_w(ORDER, k) * lz_w(ORDER, j)) * sq[tile_at(E, tz - k, ty - j, tx)]);
+                for (int j = 0; j <= ORDER; j++) s += (UQ)((Q)(lz_w(ORDER, k) * lz_w(ORDER, j)) * sq[tv_at(tv, tz - k, ty - j, tx)]);
             a[tx] = s;
         }
         UQ p2 = a[0], p1 = a[1];
         for (uint32_t tx = 2; tx < 2 + g.ex; tx++) {
-            const UQ in = (UQ)sq[tile_at(E, tz, ty, tx)];
+            const UQ in = (UQ)sq[tv_at(tv, tz, ty, tx)];
             const UQ v = ORDER == 1 ? p1 + in : (UQ)(2 * p1 - p2 + in);
-            sa[tile_at(E, tz, ty, tx)] = (Q)v;
+            sa[tv_at(tv, tz, ty, tx)] = (Q)v;
             p2 = p1;
             p1 = v;
         }
@@ -824,14 +826,14 @@ __device__ __forceinline__ void blk_invert(typename QTraits<T>::Q *sq, typename 
         for (uint32_t ty = 0; ty < 2; ty++) {
             UQ s = 0;
 #pragma unroll
-            for (int k = 0; k <= ORDER; k++) s += (UQ)((Q)lz_w(ORDER, k) * sq[tile_at(E, tz - k, ty, tx)]);
+            for (int k = 0; k <= ORDER; k++) s += (UQ)((Q)lz_w(ORDER, k) * sq[tv_at(tv, tz - k, ty, tx)]);
             b[ty] = s;
         }
         UQ p2 = b[0], p1 = b[1];
         for (uint32_t ty = 2; ty < 2 + g.ey; ty++) {
-            const UQ in = (UQ)sa[tile_at(E, tz, ty, tx)];
+            const UQ in = (UQ)sa[tv_at(tv, tz, ty, tx)];
             const UQ v = ORDER == 1 ? p1 + in : (UQ)(2 * p1 - p2 + in);
-            sa[tile_at(E, tz, ty, tx)] = (Q)v;
+            sa[tv_at(tv, tz, ty, tx)] = (Q)v;
             p2 = p1;
             p1 = v;
         }
@@ -840,11 +842,12 @@ __device__ __forceinline__ void blk_invert(typename QTraits<T>::Q *sq, typename 
     // ---- pass along z: inflow = q~ of the two halo planes; the result is q ----
     for (uint32_t l = lane; l < g.ey * g.ex; l += WAVE) {
         const uint32_t ty = l / g.ex + 2, tx = l % g.ex + 2;
-        UQ p2 = (UQ)sq[tile_at(E, 0, ty, tx)], p1 = (UQ)sq[tile_at(E, 1, ty, tx)];
+        UQ p2 = (UQ)sq[tv_at(tv, 0, ty, tx)], p1 = (UQ)sq[tv_at(tv, 1, ty, tx)];
         for (uint32_t tz = 2; tz < 2 + g.ez; tz++) {
-            const UQ in = (UQ)sa[tile_at(E, tz, ty, tx)];
+            const UQ in = (UQ)sa[tv_at(tv, tz, ty, tx)];
             const UQ v = ORDER == 1 ? p1 + in : (UQ)(2 * p1 - p2 + in);
             qout[((uint64_t)(g.oz + tz - 2) * d1 + (g.oy + ty - 2)) * d2 + (g.ox + tx - 2)] = (Q)v;
+            if (keep) sq[tv_at(tv, tz, ty, tx)] = (Q)v;
             p2 = p1;
             p1 = v;
         }
@@ -916,8 +919,105 @@ __global__ __launch_bounds__(256) void k_blk_decode(const uint16_t *__restrict__
     }
     // (the tile is the wave's own: its LDS writes only need to be visible to itself)
     if (live) {
-        if (order == 1) blk_invert<T, CB, 1>(sq, sa, qout, g, E, d1, d2, lane);
-        else blk_invert<T, CB, 2>(sq, sa, qout, g, E, d1, d2, lane);
+        const TileView tv{E * E, E, 0};
+        if (order == 1) blk_invert<T, CB, 1>(sq, sa, qout, g, tv, d1, d2, lane, false);
+        else blk_invert<T, CB, 2>(sq, sa, qout, g, tv, d1, d2, lane, false);
+    }
+}
+
+// The decoder on GROUPS of 2 x 2 x 2 blocks: the chain of fronts is what a block stream's decoding costs (a front = a launch + a
+// block's latency: tile load, three line-scan passes, store), and a group halves it — 181 instead of 362 fronts at C4's slab. A
+// workgroup of eight waves loads the group's tile once (halo = finished q~ of the lower neighbours, own regions = deltas), the
+// regression blocks fill in their values, then the Lorenzo blocks are inverted in four inner steps (lz + ly + lx = 0..3) with a
+// barrier in between: an inverted block leaves its q~ in the shared tile, where the next step's blocks find their halo.
+template <typename T, int CB>
+__global__ __launch_bounds__(512) void k_blk_decode_g(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t diag,
+                                                      uint32_t gz_lo, uint32_t npairs, const uint32_t *__restrict__ rank,
+                                                      const int64_t *__restrict__ coef_by_rank) {
+    using Q = typename QTraits<T>::Q;
+    constexpr uint32_t TE = 2 * CB + 2;
+    __shared__ Q s_q[TE * TE * TE];
+    __shared__ Q s_a[TE * TE * TE];
+    const Lattice<T> lat(p.lat);
+    const int lane = lane_id();
+    const uint32_t wv = threadIdx.x / WAVE;
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    Q *qout = reinterpret_cast<Q *>(d_out);
+    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    const uint32_t ng0 = (p.nb[0] + 1) / 2, ng1 = (p.nb[1] + 1) / 2, ng2 = (p.nb[2] + 1) / 2;
+    const uint32_t pair = blockIdx.x;
+    if (pair >= npairs) return;
+    const uint32_t gz = gz_lo + pair / ng1, gy = pair % ng1;
+    if (gz >= ng0 || gz + gy > diag || diag - gz - gy >= ng2) return;  // (workgroup-uniform)
+    const uint32_t gx = diag - gz - gy;
+    // this wave's block
+    const uint32_t lz = wv >> 2, ly = (wv >> 1) & 1u, lx = wv & 1u;
+    const uint32_t bz = 2 * gz + lz, by = 2 * gy + ly, bx = 2 * gx + lx;
+    const bool live = bz < p.nb[0] && by < p.nb[1] && bx < p.nb[2];
+    const uint32_t task = live ? (bz * p.nb[1] + by) * p.nb[2] + bx : 0;
+    const int sid = live ? (int)p.sel[task] : 0;
+    const BlkGeom g = blk_geom(p, task);
+    const TileView tv{TE * TE, TE, (lz * CB) * TE * TE + (ly * CB) * TE + lx * CB};
+    // ---- own region, requested first (its loads fly while the halo is fetched): a regression block's values (no dependency), a
+    // Lorenzo block's deltas ----
+    constexpr int OWN = (CB * CB * CB + WAVE - 1) / WAVE;
+    Q own[OWN];
+    const uint32_t nown = live ? g.ez * g.ey * g.ex : 0;
+    {
+        const CoefLat cl = coef_lat(p.eb, p.B);
+        T rc[4] = {0, 0, 0, 0};
+        if (live && sid == 2) coef_recover(coef_by_rank + (uint64_t)rank[task] * 4, cl, rc);
+#pragma unroll
+        for (int k = 0; k < OWN; k++) {
+            const uint32_t t = (uint32_t)lane + k * WAVE;
+            own[k] = 0;
+            if (t < nown) {
+                if (sid == 2) {
+                    uint32_t i0, i1, i2;
+                    own_index<CB>(g, t, i0, i1, i2);
+                    const uint32_t code = codes[g.coff + t];
+                    Q v = 0;
+                    if (code) {
+                        bool bad;
+                        v = lat.quant(ref_recover(reg_predict(rc, i0, i1, i2), (int)code, p.eb, (int)p.radius), bad);
+                        if (bad) v = 0;
+                    }
+                    qout[((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2)] = v;
+                    own[k] = v;
+                } else {
+                    own[k] = deltas[g.coff + t];
+                }
+            }
+        }
+    }
+    // ---- the group's tile: two low halo layers from d_out, zero elsewhere (ragged blocks, blocks beyond the array) ----
+    const int64_t z0 = (int64_t)gz * 2 * CB - 2, y0 = (int64_t)gy * 2 * CB - 2, x0 = (int64_t)gx * 2 * CB - 2;
+    for (uint32_t t = threadIdx.x; t < TE * TE * TE; t += 512) {
+        const uint32_t tx = t % TE, ty = (t / TE) % TE, tz = t / (TE * TE);
+        Q v = 0;
+        if (tz < 2 || ty < 2 || tx < 2) {
+            const int64_t z = z0 + tz, y = y0 + ty, x = x0 + tx;
+            if (z >= 0 && y >= 0 && x >= 0 && z < (int64_t)p.d[0] && y < (int64_t)d1 && x < (int64_t)d2) v = qout[((uint64_t)z * d1 + (uint64_t)y) * d2 + (uint64_t)x];
+        }
+        s_q[t] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < OWN; k++) {
+        const uint32_t t = (uint32_t)lane + k * WAVE;
+        if (t < nown) {
+            uint32_t i0, i1, i2;
+            own_index<CB>(g, t, i0, i1, i2);
+            s_q[tv_at(tv, i0 + 2, i1 + 2, i2 + 2)] = own[k];
+        }
+    }
+    // ---- the Lorenzo blocks, inner front by inner front ----
+    for (uint32_t step = 0; step < 4; step++) {
+        __syncthreads();
+        if (live && sid != 2 && lz + ly + lx == step) {
+            if (sid == 1) blk_invert<T, CB, 2>(s_q, s_a, qout, g, tv, d1, d2, lane, true);
+            else blk_invert<T, CB, 1>(s_q, s_a, qout, g, tv, d1, d2, lane, true);
+        }
     }
 }
 
@@ -1026,6 +1126,20 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         hipLaunchKernelGGL(k_blk_coef_scan, dim3(1), dim3(1024), 0, s, nr, coef_by_rank);
     }
     if (szk_launch_expand_deltas(dtype, codes, h->n, (int)h->radius, payload, o, h->n_dout, p->qwork, s)) return -1;
+    if (p->B == 6 && !(szk_dbg_flags & 8388608)) {  // groups of 2 x 2 x 2 blocks per workgroup (debug flag 8388608: a block per wave)
+        const uint32_t ng0 = (p->nb[0] + 1) / 2, ng1 = (p->nb[1] + 1) / 2, ng2 = (p->nb[2] + 1) / 2;
+        const uint32_t ngd = ng0 + ng1 + ng2 - 2;
+        for (uint32_t d = 0; d < ngd; d++) {
+            const uint32_t rest = (ng1 - 1) + (ng2 - 1);
+            const uint32_t gz_lo = d > rest ? d - rest : 0, gz_hi = d < ng0 - 1 ? d : ng0 - 1;
+            if (gz_lo > gz_hi) continue;
+            const uint32_t npairs = (gz_hi - gz_lo + 1) * ng1;
+            if (dtype == 0)
+                hipLaunchKernelGGL((k_blk_decode_g<float, 6>), dim3(npairs), dim3(512), 0, s, codes, p->qwork, d_out, *p, d, gz_lo, npairs, sc->rank, coef_by_rank);
+            else
+                hipLaunchKernelGGL((k_blk_decode_g<double, 6>), dim3(npairs), dim3(512), 0, s, codes, p->qwork, d_out, *p, d, gz_lo, npairs, sc->rank, coef_by_rank);
+        }
+    } else {
     const uint32_t ndiag = p->nb[0] + p->nb[1] + p->nb[2] - 2;
     for (uint32_t d = 0; d < ndiag; d++) {
         // blocks of the front: bz + by + bx = d; only the bz that can have a partner (by, bx) are enumerated
@@ -1042,6 +1156,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
             else BLK_DEC(double, 0);
         }
 #undef BLK_DEC
+    }
     }
     const uint32_t grid = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
     if (dtype == 0) {

@@ -200,7 +200,8 @@ void sz3hip_debug_force_generic(int on);
  * histogram with the large tier and the windowed tail passes, 16384 predictor sets with Lorenzo-2 / regression fall back
  * to plain Lorenzo (no block path), 131072 contexts do not remember the previous call's code width / code-book form,
  * 262144 round-parallel Huffman merge for small alphabets, 2097152 Lorenzo decoder without half-width intermediates,
- * 4194304 interpolation level kernels whatever the array's size (normally from 256 blocks up).
+ * 4194304 interpolation level kernels whatever the array's size (normally from 256 blocks up), 8388608 block decoder with a
+ * block per wave instead of groups of 2 x 2 x 2 blocks per workgroup.
  * Experiments with WRONG or slower results (tools/dec_lab.py): 32768 / 65536 decoder stream loads through an LDS ring,
  * 524288 decoder without stores, 1048576 decoder with direct stores. */
 void sz3hip_debug_flags(int flags);

@@ -143,26 +143,17 @@ def test_predictor_sets_outside_the_block_path():
 def test_grouped_and_per_block_decoders_agree(shape):
     """blocks of 6^3 are decoded in groups of 2 x 2 x 2 per workgroup (inner fronts through a shared LDS tile); debug flag 8388608
     takes the block-per-wave fronts: same array, bit for bit, on shapes with ragged and missing blocks in the last groups"""
-    import torch
-    dev = torch.device("cuda:0")
     a = field3d(shape, np.float32)
     a[shape[0] // 2:, :, :] += 3.0
-    t = torch.from_numpy(a).to(dev)
-    dc = sz3_amd.DeviceCompressor(a.size, np.float32)
-    cap = dc.payload_bound(a.size, worst_case=True)
-    pl = torch.empty(cap, dtype=torch.uint8, device=dev)
-    outs = []
     for mask in ("L1+R", "L1+L2+R"):
-        conf = _conf(shape, 1e-3, *MASKS[mask])
-        n = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+        blob, _ = sz3_amd.compress(a, _conf(shape, 1e-3, *MASKS[mask]))
+        outs = []
         try:
             for flag in (0, 8388608):
                 sz3_amd.lib().sz3hip_debug_flags(flag)
-                out = torch.empty_like(t)
-                dc.decompress(pl.data_ptr(), n, out.data_ptr(), 0)
-                torch.cuda.synchronize()
-                outs.append(out.cpu().numpy())
+                dec, c2 = sz3_amd.decompress(blob, np.float32, shape)
+                outs.append(dec)
         finally:
             sz3_amd.lib().sz3hip_debug_flags(0)
-        assert np.array_equal(outs[-1], outs[-2])
-        assert float(np.max(np.abs(outs[-1].astype(np.float64) - a.astype(np.float64)))) <= 1e-3
+        assert np.array_equal(outs[0], outs[1])
+        assert float(np.max(np.abs(outs[0].astype(np.float64) - a.astype(np.float64)))) <= 1e-3

@@ -62,6 +62,28 @@ class _CStats(C.Structure):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """A process must hold ONE HIP runtime. PyTorch-ROCm wheels bundle their own libamdhip64 (found by rpath): when this library
+    is loaded first it brings the system's copy in, and a later `import torch` + first CUDA call then finds "No HIP GPUs" — two
+    runtimes cannot share the device. If a torch with a bundled runtime is installed, that copy is loaded first (by path, without
+    importing torch), so that whoever comes second binds to it; torch-first already worked that way (same soname)."""
+    try:
+        import importlib.util
+        import sys
+        if "torch" in sys.modules:
+            return
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for name in ("libamdhip64.so",):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 - best effort: without it the library still works, only torch-after-us does not
+        pass
+
+
 def lib():
     """Loads libsz3hip.so; fails loudly when it has not been built (python -m sz3_amd.build / __graft_entry__.build)."""
     global _lib
@@ -70,6 +92,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("sz3_amd/libsz3hip.so is missing — build it with `python -m sz3_amd.build` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     P = C.POINTER
     L.sz3hip_last_error.restype = C.c_char_p

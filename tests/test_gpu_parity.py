@@ -477,3 +477,16 @@ def test_integer_inputs_ride_the_f64_pipeline():
     blob, _ = sz3_amd.compress(big, conf)
     dec, c2 = sz3_amd.decompress(blob, np.int64, big.shape)
     assert c2.cmprAlgo == sz3_amd.ALGO_LOSSLESS and np.array_equal(dec, big)
+
+
+def test_torch_can_start_after_the_library():
+    """One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64, so a process that used this library BEFORE its
+    first torch CUDA call used to end with "No HIP GPUs are available" (two runtimes). The binding loads the wheel's copy first
+    when there is one (sz3_amd._share_torch_hip_runtime); a fresh process, library first, torch second."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, sz3_amd; a = np.random.rand(40, 40, 40).astype(np.float32); "
+            "c = sz3_amd.Config(40, 40, 40); c.absErrorBound = 1e-3; b, r = sz3_amd.compress(a, c); d, _ = sz3_amd.decompress(b, np.float32, a.shape); "
+            "assert abs(d - a).max() <= 1e-3; import torch; t = torch.ones(4, device='cuda:0'); print('both ok', float(t.sum()))") % os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "both ok 4.0" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, sz3_amd, szh_ref
 rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
 if os.environ.get("DBG_FLAGS"): sz3_amd.lib().sz3hip_debug_flags(int(os.environ["DBG_FLAGS"]))  # e.g. 4194304: level kernels whatever the size
-pool = [1, 3, 8, 9, 16, 17, 31, 32, 33, 40, 64, 65, 100, 128, 129, 256, 260, 512]
+pool = [1, 3, 8, 9, 16, 17, 31, 32, 33, 40, 64, 65, 100, 128, 129, 256, 260, 300, 500, 504, 512]
 bad = 0
 for k in range(int(os.environ.get("N", "40"))):
     nd = int(rng.integers(1, 5))
@@ -19,6 +19,7 @@ for k in range(int(os.environ.get("N", "40"))):
     sig = float(rng.choice([1e-4, 2e-3, 5e-2]))
     a = (sum(np.sin(2 * np.pi * g / (11.0 + 5 * i)) for i, g in enumerate(grids)) + sig * rng.standard_normal(shape)).astype(dt)
     if k % 4 == 0: a.reshape(-1)[rng.integers(0, a.size, size=max(1, a.size // 500))] = np.nan
+    if k % 7 == 3: a.reshape(-1)[rng.integers(0, a.size, size=max(1, a.size // 60))] = np.nan  # (enough to fill the per-wave queues of unpredictable values several times)
     qb = int(rng.choice([64, 256, 1024, 4096, 65536])); eb = float(10.0 ** rng.integers(-4, -1))
     dev = torch.device("cuda:0"); t = torch.from_numpy(a).to(dev)
     dc = sz3_amd.DeviceCompressor(a.size, a.dtype); cap = dc.payload_bound(a.size, worst_case=True); pl = torch.empty(cap, dtype=torch.uint8, device=dev)

@@ -612,6 +612,18 @@ __device__ __forceinline__ void put_bits(uint32_t *words, uint64_t pos, uint64_t
     }
 }
 // header, selection bits, Rice parameters, group offsets (one workgroup scans the group sizes), then the bits
+// selection section of the side information: 2 bits per block, four blocks per byte (its place does not depend on anything counted)
+__global__ __launch_bounds__(256) void k_blk_sel_pack(const uint8_t *__restrict__ sel, uint32_t nblocks, uint8_t *__restrict__ side) {
+    const uint64_t sel_bytes = side_sel_bytes(nblocks);
+    for (uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x; b < sel_bytes; b += (uint64_t)gridDim.x * 256) {
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint64_t blk = b * 4 + k;
+            if (blk < nblocks) v |= (uint32_t)(sel[blk] & 3u) << (2 * k);
+        }
+        side[SIDE_HDR + b] = (uint8_t)v;
+    }
+}
 __global__ __launch_bounds__(1024) void k_blk_side_layout(const uint8_t *__restrict__ sel, uint32_t nblocks, const uint64_t *n_reg,
                                                           const double *__restrict__ stats, const uint32_t *__restrict__ group_bits,
                                                           uint8_t *__restrict__ side, uint64_t *side_bytes) {
@@ -631,14 +643,8 @@ __global__ __launch_bounds__(1024) void k_blk_side_layout(const uint8_t *__restr
         memcpy(kp + 4, &ngroups, 4);
         s_carry = 0;
     }
-    for (uint64_t b = threadIdx.x; b < sel_bytes; b += 1024) {
-        uint32_t v = 0;
-        for (uint32_t k = 0; k < 4; k++) {
-            const uint64_t blk = b * 4 + k;
-            if (blk < nblocks) v |= (uint32_t)(sel[blk] & 3u) << (2 * k);
-        }
-        side[SIDE_HDR + b] = (uint8_t)v;
-    }
+    // (the selection bits are packed by k_blk_sel_pack, a launch of its own: one workgroup walking 155 KB of them was 100 of this
+    // kernel's 129 us at C4's slab)
     __syncthreads();
     for (uint32_t base = 0; base < ngroups; base += 1024) {
         const uint32_t g = base + threadIdx.x;
@@ -1100,6 +1106,7 @@ int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const 
     uint32_t *group_bits = sc->rank;
     hipLaunchKernelGGL(k_blk_coef_stats, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, stats);
     hipLaunchKernelGGL(k_blk_coef_len, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, stats, group_bits);
+    hipLaunchKernelGGL(k_blk_sel_pack, dim3(256), dim3(256), 0, s, p->sel, nblocks, sc->side);
     hipLaunchKernelGGL(k_blk_side_layout, dim3(1), dim3(1024), 0, s, p->sel, nblocks, sc->counters + 0, stats, group_bits, sc->side, sc->counters + 2);
     hipLaunchKernelGGL(k_blk_coef_write, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, nblocks, sc->side);
     SZK_CHECK_LAUNCH();

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant(const T *__restrict__ in,
     __shared__ Q lq[CELLS];
     __shared__ uint32_t lh[HIST_COPIES * HIST_WIN];
 
-    const uint64_t d0 = p.d[3], d1 = p.d[2], d2 = p.d[1], d3 = p.d[0];  // x, y, z, w extents
+    const uint64_t d0 = p.d[3], d1 = p.d[2], d2 = p.d[1];  // x, y, z extents (w = p.d[0] multiplies the tile count)
     const uint32_t ntx = (uint32_t)((d0 + TX - 1) / TX), nty = (uint32_t)((d1 + TY - 1) / TY),
                    ntz = (uint32_t)((d2 + TZ - 1) / TZ);
     uint64_t b = blockIdx.x;
@@ -557,7 +557,6 @@ __device__ __forceinline__ void hist_add_ranged(uint64_t *hist, uint32_t *range,
 
 template <typename T, int NDIM>
 __global__ __launch_bounds__(256) void k_probe(const T *__restrict__ in, szk_k1_params p, uint64_t n, uint32_t *probe_big) {
-    using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     const Lattice<T> lat(p.lat);
     const uint64_t d0 = p.d[3], d1 = p.d[2], d2 = p.d[1];
@@ -1747,7 +1746,7 @@ template <int PART>
 __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restrict__ hist, szk_cb_params p) {
     __shared__ __align__(16) uint8_t s_pool[CB_POOL_BYTES];
     __shared__ uint32_t s_wtot[CB_THREADS / WAVE];
-    __shared__ uint32_t s_lo, s_hi, s_over;
+    __shared__ uint32_t s_over;
     __shared__ uint32_t s_first[SZH_MAX_LEN + 2], s_cnt[SZH_MAX_LEN + 2];
     __shared__ uint32_t s_misc[8];
     __shared__ unsigned long long s_total;

@@ -92,8 +92,6 @@ __device__ __forceinline__ void own_index(const BlkGeom &g, uint32_t t, uint32_t
         i0 = t / (g.ex * g.ey);
     }
 }
-// tile coordinate t (E^3, E = B + 2, two halo layers on the low side) <-> array element
-__device__ __forceinline__ uint32_t tile_at(uint32_t E, uint32_t tz, uint32_t ty, uint32_t tx) { return (tz * E + ty) * E + tx; }
 
 // LDS histogram of a workgroup: BLK_HWIN bins around the radius, the rest straight to the global histogram; code 0
 // (one address for the whole grid) is counted per wave
@@ -374,7 +372,6 @@ __device__ __forceinline__ void blk_lorenzo_block(const typename QTraits<T>::Q *
                                                   const szk_blk_params &p, uint16_t *__restrict__ codes) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
-    const uint64_t d1 = p.d[1], d2 = p.d[2];
     const uint32_t nown = g.ez * g.ey * g.ex;
     for (uint32_t t0 = 0; t0 < nown; t0 += WAVE) {
         const uint32_t t = t0 + lane;
@@ -382,7 +379,6 @@ __device__ __forceinline__ void blk_lorenzo_block(const typename QTraits<T>::Q *
         const uint32_t tt = act ? t : 0;
         uint32_t i0, i1, i2;
         own_index<CB>(g, tt, i0, i1, i2);
-        const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
         UQ delta = 0;  // wrap-around arithmetic like the plain Lorenzo stream
         if (order == 1) {  // (wave-uniform; the stencils unrolled with their constant weights)
 #pragma unroll
@@ -624,7 +620,7 @@ __global__ __launch_bounds__(256) void k_blk_sel_pack(const uint8_t *__restrict_
         side[SIDE_HDR + b] = (uint8_t)v;
     }
 }
-__global__ __launch_bounds__(1024) void k_blk_side_layout(const uint8_t *__restrict__ sel, uint32_t nblocks, const uint64_t *n_reg,
+__global__ __launch_bounds__(1024) void k_blk_side_layout(uint32_t nblocks, const uint64_t *n_reg,
                                                           const double *__restrict__ stats, const uint32_t *__restrict__ group_bits,
                                                           uint8_t *__restrict__ side, uint64_t *side_bytes) {
     __shared__ uint32_t s_w[16];
@@ -864,7 +860,6 @@ template <typename T, int CB>
 __global__ __launch_bounds__(256) void k_blk_decode(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t diag, uint32_t bz_lo,
                                                     uint32_t npairs, const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
     using Q = typename QTraits<T>::Q;
-    using UQ = typename QTraits<T>::UQ;
     __shared__ Q s_q[4][CB ? (CB + 2) * (CB + 2) * (CB + 2) : BLK_TILE];
     __shared__ Q s_a[4][CB ? (CB + 2) * (CB + 2) * (CB + 2) : BLK_TILE];
     const Lattice<T> lat(p.lat);
@@ -1107,7 +1102,7 @@ int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const 
     hipLaunchKernelGGL(k_blk_coef_stats, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, stats);
     hipLaunchKernelGGL(k_blk_coef_len, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, stats, group_bits);
     hipLaunchKernelGGL(k_blk_sel_pack, dim3(256), dim3(256), 0, s, p->sel, nblocks, sc->side);
-    hipLaunchKernelGGL(k_blk_side_layout, dim3(1), dim3(1024), 0, s, p->sel, nblocks, sc->counters + 0, stats, group_bits, sc->side, sc->counters + 2);
+    hipLaunchKernelGGL(k_blk_side_layout, dim3(1), dim3(1024), 0, s, nblocks, sc->counters + 0, stats, group_bits, sc->side, sc->counters + 2);
     hipLaunchKernelGGL(k_blk_coef_write, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, nblocks, sc->side);
     SZK_CHECK_LAUNCH();
     return 0;

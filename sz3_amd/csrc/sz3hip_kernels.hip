@@ -1500,15 +1500,12 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
     const uint32_t b0 = wv_id * seg < range ? wv_id * seg : range, b1 = b0 + seg < range ? b0 + seg : range;
     uint32_t cnt = 0;
     uint64_t fsum = 0;
-    for (uint32_t i = b0 + lane; i < b1; i += WAVE) {  // (b1 - b0 need not be a multiple of 64: ballot sees inactive lanes as 0)
-        const uint64_t f = hist[lo + i];
-        cnt += (uint32_t)__popcll(__ballot(f != 0));
-        fsum += f;
-    }
-    // lanes that left the loop early have a smaller cnt: take the wave maximum (= the true count)
-    for (int off = 1; off < WAVE; off <<= 1) {
-        const uint32_t o = __shfl_xor(cnt, off, WAVE);
-        cnt = o > cnt ? o : cnt;
+    // (three 64-bin groups per step, their loads in flight together: one per step is a chain of dependent L2 round trips)
+    for (uint32_t i0 = b0; i0 < b1; i0 += 3 * WAVE) {
+        const uint32_t ia = i0 + lane, ib = ia + WAVE, ic = ib + WAVE;
+        const uint64_t fa = ia < b1 ? hist[lo + ia] : 0ull, fb = ib < b1 ? hist[lo + ib] : 0ull, fc = ic < b1 ? hist[lo + ic] : 0ull;
+        cnt += (uint32_t)__popcll(__ballot(fa != 0)) + (uint32_t)__popcll(__ballot(fb != 0)) + (uint32_t)__popcll(__ballot(fc != 0));
+        fsum += fa + fb + fc;
     }
     if (t == 0) s_total = 0;
     if (t < 8) s_misc[t] = 0;

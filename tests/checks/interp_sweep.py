@@ -14,6 +14,9 @@ for k in range(int(os.environ.get("N", "40"))):
     nd = int(rng.integers(1, 5))
     shape = tuple(int(rng.choice(pool)) for _ in range(nd))
     while np.prod(shape) > 1_500_000: shape = tuple(max(5, s // 2) for s in shape)
+    if os.environ.get("LARGE"):  # 3-D arrays of the level kernels' natural size (>= 256 blocks of 32^3 at the finest level)
+        nd = 3
+        shape = tuple(int(rng.integers(193, 262)) for _ in range(3))
     dt = np.float32 if rng.random() < 0.7 else np.float64
     grids = np.meshgrid(*[np.arange(s, dtype=np.float64) for s in shape], indexing="ij")
     a = (sum(np.sin(2 * np.pi * g / (9.0 + 4 * i)) for i, g in enumerate(grids)) + 0.01 * rng.standard_normal(shape)).astype(dt)

@@ -93,12 +93,14 @@ size_t SZ_compress_Hip(Config &conf, T *data, uchar *cmpData, size_t cmpCap) {
     conf.lorenzo = p.lorenzo;
     conf.lorenzo2 = p.lorenzo2;
     conf.regression = p.regression;
+    conf.dataType = p.dataType;  // (the reference leaves Config::dataType at its default; the trailer then names what the blob holds)
     return n;
 }
 
 template <class T, uint N>
 void SZ_decompress_Hip(const Config &conf, const uchar *cmpData, size_t cmpSize, T *decData) {
-    const sz3hip_config p = hip_detail::to_pod(conf);
+    sz3hip_config p = hip_detail::to_pod(conf);
+    p.dataType = (uint8_t)hip_detail::dtype_id<T>();  // the caller's T decides, as in the reference (streams written before dataType was recorded say 0)
     if (sz3hip_decompress_blob(&p, hip_detail::dtype_id<T>(), reinterpret_cast<const char *>(cmpData), cmpSize, decData)) hip_detail::raise_last();
 }
 }  // namespace SZ3

@@ -132,6 +132,9 @@ size_t sz3hip_payload_bound(const sz3hip_ctx *ctx, uint64_t n);
  * quantbinCnt). With a buffer this large sz3hip_compress_device grows its lists on demand and retries instead of
  * returning SZ3HIP_EOUTLIERS (the reference keeps any number of unpredictable values, LinearQuantizer.hpp:43-66). */
 size_t sz3hip_payload_bound_max(const sz3hip_ctx *ctx, uint64_t n);
+/* The bound for one Config: like the two above (worst_case != 0: the second), and also sufficient for the block-composed predictor's
+ * side section on thin arrays (an extent below 9), which have more blocks per element than the shape-blind bounds assume. */
+size_t sz3hip_payload_bound_conf(const sz3hip_ctx *ctx, const sz3hip_config *conf, int worst_case);
 
 /* global min/max of a device array (K0: utils/Statistic.hpp:12-21); result written to host doubles (synchronises) */
 int sz3hip_minmax_device(sz3hip_ctx *ctx, const void *d_in, uint64_t n, double *min_out, double *max_out, void *stream);
@@ -185,6 +188,14 @@ int sz3hip_get_tuner_report(sz3hip_ctx *ctx, sz3hip_tuner_report *rep);
  * names[i] / ms[i] for i < returned count; count 0 if profiling is off */
 void sz3hip_set_profiling(sz3hip_ctx *ctx, int on);
 int sz3hip_get_stage_times(sz3hip_ctx *ctx, const char **names, float *ms, int max);
+/* What a context remembers between calls only ever changes the TIME of a call, never its payload: which form of a kernel the
+ * previous call's data took, histogram windows, the auto-tuner's previous outcome (stage 1 starts with it beside the tuner) and
+ * the previous code book (stage 2 packs with it while this call's is built on a side stream; finish() repeats the encoder when
+ * the two differ). sz3hip_ctx_forget drops all of it: the next call behaves like a context's first (bench.py's cold numbers).
+ * sz3hip_ctx_set_speculation(ctx, 1) turns the code-book speculation off; sz3hip_get_spec_stats counts its hits / misses. */
+void sz3hip_ctx_forget(sz3hip_ctx *ctx);
+void sz3hip_ctx_set_speculation(sz3hip_ctx *ctx, int off);
+void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses);
 /* test hooks: copy internal device arrays to host (quantisation codes as uint16, histogram as uint64) */
 int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, uint64_t n);
 /* test hook: which chain the last sz3hip_decompress_device took: out4[0] half-width intermediates, [1] rows that cross chunk

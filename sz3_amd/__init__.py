@@ -140,6 +140,14 @@ def lib():
     L.sz3hip_get_tuner_report.restype = C.c_int
     L.sz3hip_get_tuner_report.argtypes = [C.c_void_p, P(_CTunerReport)]
     L.sz3hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.sz3hip_ctx_forget.argtypes = [C.c_void_p]
+    L.sz3hip_ctx_forget.restype = None
+    L.sz3hip_ctx_set_speculation.argtypes = [C.c_void_p, C.c_int]
+    L.sz3hip_ctx_set_speculation.restype = None
+    L.sz3hip_get_spec_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.sz3hip_get_spec_stats.restype = None
+    L.sz3hip_payload_bound_conf.restype = C.c_size_t
+    L.sz3hip_payload_bound_conf.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.sz3hip_get_stage_times.restype = C.c_int
     L.sz3hip_get_stage_times.argtypes = [C.c_void_p, P(C.c_char_p), P(C.c_float), C.c_int]
     L.sz3hip_debug_copy_codes.restype = C.c_int
@@ -375,6 +383,21 @@ class DeviceCompressor:
 
     def set_profiling(self, on=True):
         lib().sz3hip_set_profiling(self._h, int(on))
+
+    def forget(self):
+        """drop what earlier calls left in the context (kernel forms, windows, tuner outcome, code book): the next call is a first call"""
+        lib().sz3hip_ctx_forget(self._h)
+
+    def set_speculation(self, on=True):
+        lib().sz3hip_ctx_set_speculation(self._h, 0 if on else 1)
+
+    def spec_stats(self):
+        h, m = C.c_uint32(), C.c_uint32()
+        lib().sz3hip_get_spec_stats(self._h, C.byref(h), C.byref(m))
+        return int(h.value), int(m.value)
+
+    def payload_bound_conf(self, conf, worst_case=False):
+        return int(lib().sz3hip_payload_bound_conf(self._h, C.byref(conf._c), int(bool(worst_case))))
 
     def stage_times(self):
         names = (C.c_char_p * 16)()

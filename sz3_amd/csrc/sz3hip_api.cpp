@@ -201,9 +201,10 @@ static void ctx_free(sz3hip_ctx *c) {
     if (!c) return;
     void *bufs[] = {c->d_work, c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
                     c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_aux2, c->d_pint2, c->d_range, c->d_info,
-                    c->d_chunk_words, c->d_chunk_off, c->d_carry, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples, c->d_trial_work,
+                    c->d_chunk_words, c->d_chunk_off, c->d_carry, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples, c->d_trial_work, c->d_trial_codes,
                     c->d_trial, c->d_passes, c->d_np,  // (d_trial_counters / d_trial_hist live inside d_trial's block)
-                    c->d_blk_sel, c->d_blk_coef, c->d_blk_rank, c->d_blk_comp, c->d_blk_side, c->d_blk_counters};
+                    c->d_blk_sel, c->d_blk_coef, c->d_blk_rank, c->d_blk_comp, c->d_blk_side, c->d_blk_counters,
+                    c->bk[1].enc, c->bk[1].lens, c->bk[1].info};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->side) {
@@ -212,6 +213,8 @@ static void ctx_free(sz3hip_ctx *c) {
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_sorted) (void)hipEventDestroy(c->ev_sorted);
+    if (c->ev_book) (void)hipEventDestroy(c->ev_book);
     if (c->d_flags) (void)hipHostFree(c->d_flags);
     if (c->d_starts) (void)hipHostFree(c->d_starts);
     if (c->h_state) (void)hipHostFree(c->h_state);
@@ -277,6 +280,13 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     alloc((void **)&c->d_pint2, SZK_MAX_BOOKS * SZH_HIST_BINS * 2);
     alloc((void **)&c->d_range, SZK_MAX_BOOKS * 16);
     alloc((void **)&c->d_info, SZK_MAX_BOOKS * sizeof(szk_cb_info));
+    alloc((void **)&c->bk[1].enc, SZH_HIST_BINS * 4);
+    alloc((void **)&c->bk[1].lens, SZH_HIST_BINS);
+    alloc((void **)&c->bk[1].info, sizeof(szk_cb_info));
+    c->bk[0].enc = c->d_enc;
+    c->bk[0].lens = c->d_lens;
+    c->bk[0].info = c->d_info;
+    c->book_idx = c->book_pending = -1;
     alloc((void **)&c->d_chunk_words, (c->max_chunks + 8) * 2);
     alloc((void **)&c->d_chunk_off, (c->max_chunks + 8) * 8);
     alloc((void **)&c->d_state, sizeof(szk_state));
@@ -298,17 +308,32 @@ extern "C" void sz3hip_ctx_destroy(sz3hip_ctx *ctx) {
     ctx_free(ctx);
 }
 
-static size_t payload_bound_n(uint64_t n, uint64_t out_cap) {
+// side_blocks: blocks of the block-composed predictor the side section must hold
+static size_t payload_bound_blocks(uint64_t n, uint64_t out_cap, uint64_t side_blocks) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
-    // (+ the side section of the block-composed predictor: blocks of at least 4^3 elements)
     return (size_t)(sizeof(szh_header) + SZH_HIST_BINS + 16 + 2 * n_chunks + 16 + 2 * (out_cap * 16 + 16) +
-                    4 * n_chunks * (SZH_CHUNK_SYMS * SZH_MAX_LEN / 32) + 64 + szk_blk_side_bound(n / 64 + 64));
+                    4 * n_chunks * (SZH_CHUNK_SYMS * SZH_MAX_LEN / 32) + 64 + szk_blk_side_bound(side_blocks));
+}
+// The shape-blind bound: blocks have an edge of at least 4, so a 3-D array whose extents are all >= 9 has at most n / 27 of
+// them (ceil(d / 4) <= d / 3). Thin arrays (an extent below 9: a one-plane slab, say) can have more — up to n / 4; stage 2
+// checks the caller's capacity against the blocks the call really has, and sz3hip_payload_bound_conf sizes a buffer for them.
+static size_t payload_bound_n(uint64_t n, uint64_t out_cap) { return payload_bound_blocks(n, out_cap, n / 27 + 64); }
+static uint64_t conf_blocks(const sz3hip_config *conf) {  // blocks the block-composed predictor would cut this array into (0: not its shape)
+    if (conf->N != 3 || conf->blockSize < 4 || conf->blockSize > 8) return 0;
+    uint64_t nb = 1;
+    for (int i = 0; i < 3; i++) nb *= (conf->dims[i] + (uint64_t)conf->blockSize - 1) / (uint64_t)conf->blockSize;
+    return nb;
 }
 extern "C" size_t sz3hip_payload_bound(const sz3hip_ctx *ctx, uint64_t n) { return payload_bound_n(n, ctx->out_cap); }
 // lists of up to n / 8 entries: beyond that the stream cannot beat the lossless fallback any more
 static uint64_t out_cap_limit(uint64_t n) { return std::max<uint64_t>(1024, n / 8); }
 extern "C" size_t sz3hip_payload_bound_max(const sz3hip_ctx *ctx, uint64_t n) {
     return payload_bound_n(n, std::max<uint64_t>(ctx->out_cap, out_cap_limit(n)));
+}
+extern "C" size_t sz3hip_payload_bound_conf(const sz3hip_ctx *ctx, const sz3hip_config *conf, int worst_case) {
+    const uint64_t n = conf->num;
+    const uint64_t lists = worst_case ? std::max<uint64_t>(ctx->out_cap, out_cap_limit(n)) : ctx->out_cap;
+    return std::max(payload_bound_n(n, lists), payload_bound_blocks(n, lists, conf_blocks(conf)));
 }
 extern "C" void *sz3hip_histogram_ptr(sz3hip_ctx *ctx) {
     ctx->hist_exposed = true;  // (whoever holds the pointer may change the histogram between the stages)
@@ -385,9 +410,10 @@ static int interp_params_from(const sz3hip_config *conf, double eb, int radius, 
     ip.radius = radius;
     return 0;
 }
-static void cb_params_from(sz3hip_ctx *ctx, szk_cb_params &cb, uint64_t out_cap) {
-    cb.enc = ctx->d_enc;
-    cb.lens = ctx->d_lens;
+static void cb_params_from(sz3hip_ctx *ctx, szk_cb_params &cb, uint64_t out_cap, int slot) {
+    memset(&cb, 0, sizeof(cb));
+    cb.enc = ctx->bk[slot].enc;
+    cb.lens = ctx->bk[slot].lens;
     cb.keys = ctx->d_keys;
     cb.syms = ctx->d_syms;
     cb.ifreq = ctx->d_ifreq;
@@ -405,7 +431,7 @@ static void cb_params_from(sz3hip_ctx *ctx, szk_cb_params &cb, uint64_t out_cap)
     cb.n_dout = ctx->d_counters + 1;
     cb.out_cap = out_cap;
     cb.t_is_32bit = cb.q_is_32bit = ctx->dtype == SZ3HIP_FLOAT;
-    cb.info = ctx->d_info;
+    cb.info = ctx->bk[slot].info;
     cb.n_books = 1;
     cb.range_ready = ctx->range_ready && !ctx->hist_exposed;
     cb.part_hint = (szk_dbg_flags & 131072) ? -1 : ctx->cb_hint;
@@ -647,6 +673,14 @@ static int tuner_reserve(sz3hip_ctx *ctx, size_t flags, size_t starts, size_t sa
         HIPCHK(hipMalloc(&ctx->d_trial_work, samples * SZK_MAX_TRIALS));
         ctx->trial_work_cap = samples * SZK_MAX_TRIALS;
     }
+    const size_t tsz_r = ctx->dtype == SZ3HIP_FLOAT ? 4 : 8;
+    const size_t code_bytes = (samples / tsz_r) * SZK_MAX_TRIALS * 2;  // two bytes per sampled point and trial
+    if (ctx->trial_codes_cap < code_bytes) {
+        if (ctx->d_trial_codes) (void)hipFree(ctx->d_trial_codes);
+        ctx->d_trial_codes = nullptr;
+        HIPCHK(hipMalloc((void **)&ctx->d_trial_codes, code_bytes));
+        ctx->trial_codes_cap = code_bytes;
+    }
     if (!ctx->d_trial) {  // one block [results 256 B][counters 512 B][pad][histograms]: a group zeroes it with one memset
         HIPCHK(hipMalloc(&ctx->d_trial, 1024 + SZK_MAX_TRIALS * SZH_HIST_BINS * 8));
         ctx->d_trial_counters = ctx->d_trial + 32;
@@ -683,7 +717,7 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
         ips[j].vout_val = ctx->d_vout_val;
         ips[j].out_cap = 0;  // count only
     }
-    int rc = szk_launch_interp_trials(ctx->dtype, ips, (uint32_t)ntr, ctx->d_samples, ctx->d_trial_work, ctx->d_codes, nb, ctx->d_trial_hist,
+    int rc = szk_launch_interp_trials(ctx->dtype, ips, (uint32_t)ntr, ctx->d_samples, ctx->d_trial_work, ctx->d_trial_codes, nb, ctx->d_trial_hist,
                                       ctx->h_passes, ctx->d_passes, ctx->h_np, ctx->d_np, s);
     if (rc) return fail(SZ3HIP_EHIP, "tuner: interpolation trial launch failed (%d)", rc);
     rc = szk_launch_code_cost(ctx->d_trial_hist, ctx->d_trial_counters, ctx->d_trial + 4 * slot0, (uint32_t)ntr, tcs[0].num * nb, 1, s);
@@ -1015,40 +1049,87 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     return stage1_lorenzo(ctx, conf, d_in, eb, radius, num, s);
 }
 
-static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream_t s);
+enum { S2_CLASSIC = 0, S2_SPEC = 1, S2_REENCODE = 2 };
+static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream_t s, int how);
+static int ensure_side(sz3hip_ctx *ctx) {
+    if (!ctx->side) {
+        HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    if (!ctx->ev_sorted) {
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_sorted, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_book, hipEventDisableTiming));
+    }
+    return 0;
+}
 extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t cap, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
     if (!ctx->stage1_done) return fail(SZ3HIP_EINVAL, "stage2 called before stage1");
     if (ctx->stage2_done) return fail(SZ3HIP_EINVAL, "stage2 called twice for one stage1 (finish the call first)");
     const uint64_t n = ctx->proto.n;
-    if (cap < payload_bound_n(n, std::max<uint64_t>(ctx->out_cap, ctx->cur_out_cap)))
-        return fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+    {   // what this call can need: the shape-blind bound, or — block-composed stream of a thin array — the bound for its own block count
+        const uint64_t lists = std::max<uint64_t>(ctx->out_cap, ctx->cur_out_cap);
+        size_t need = payload_bound_n(n, lists);
+        if (ctx->proto.predictor == 2) {
+            uint64_t nb = 1;
+            for (int i = 0; i < 3; i++) nb *= (ctx->proto.dims[1 + i] + ctx->proto.interp_id - 1) / ctx->proto.interp_id;
+            need = std::max(need, payload_bound_blocks(n, lists, nb));
+        }
+        if (cap < need) return fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+    }
     ctx->s2_payload = d_payload;
     ctx->s2_cap = cap;
-    int rc = stage2_launch(ctx, d_payload, cap, s);
+    // Speculation: the code book of a series of similar arrays repeats (it is a function of the code lengths alone), and building
+    // it is a serial chain the chip idles through. A context whose previous call left a book for the same predictor and radius
+    // packs with THAT book on the caller's stream while this call's book is built from this call's histogram on the side
+    // stream; finish() compares the two and repeats the encoder when they differ. The book a payload is coded with is always
+    // the one its own histogram gives.
+    const bool spec = ctx->book_idx >= 0 && !ctx->spec_off && !(szk_dbg_flags & 131072) && ctx->book_pred == ctx->proto.predictor &&
+                      ctx->book_radius == ctx->proto.radius;
+    int rc = stage2_launch(ctx, d_payload, cap, s, spec ? S2_SPEC : S2_CLASSIC);
     if (rc) return rc;
     ctx->stage2_done = true;
     return 0;
 }
-static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream_t s) {
+static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream_t s, int how) {
     const uint64_t n = ctx->proto.n;
+    // the slot this call's book goes to (the other one holds the previous call's), and the slot the encoder reads
+    const int fresh = how == S2_REENCODE ? ctx->book_pending : (ctx->book_idx < 0 ? 0 : 1 - ctx->book_idx);
+    const int used = how == S2_SPEC ? ctx->book_idx : fresh;
+    ctx->book_pending = fresh;
+    ctx->s2_spec = how == S2_SPEC;
     szk_cb_params cb;
-    cb_params_from(ctx, cb, ctx->cur_out_cap);
-    if (ctx->range_ready && !cb.range_ready)  // stage 1 kept the range of the LOCAL histogram, the caller then changed it (all-reduce):
-        HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, 16, s));  // k_hist_range starts from zero
-    prof_begin(ctx, ST_CODEBOOK, s);
-    int rc = szk_launch_codebook(ctx->d_hist, &cb, s);
-    if (rc) return fail(SZ3HIP_EHIP, "codebook kernel launch failed (%d)", rc);
+    cb_params_from(ctx, cb, ctx->cur_out_cap, fresh);
+    hipStream_t bs = s;  // the stream the book is built on
+    if (how == S2_SPEC) {
+        int rcs = ensure_side(ctx);
+        if (rcs) return rcs;
+        bs = ctx->side;
+        HIPCHK(hipEventRecord(ctx->ev_fork, s));  // stage 1 (and, between the stages, the caller's histogram exchange) is on the caller's stream
+        HIPCHK(hipStreamWaitEvent(bs, ctx->ev_fork, 0));
+        if (szk_launch_sort_outliers(&cb, bs)) return fail(SZ3HIP_EHIP, "outlier sort launch failed");
+        HIPCHK(hipEventRecord(ctx->ev_sorted, bs));
+        cb.skip_sort = 1;
+    }
+    if (how != S2_REENCODE) {
+        if (ctx->range_ready && !cb.range_ready)  // stage 1 kept the range of the LOCAL histogram, the caller then changed it (all-reduce):
+            HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, 16, bs));  // k_hist_range starts from zero
+        prof_begin(ctx, ST_CODEBOOK, bs);
+        int rcb = szk_launch_codebook(ctx->d_hist, &cb, bs);
+        prof_end(ctx, ST_CODEBOOK, bs);
+        if (rcb) return fail(SZ3HIP_EHIP, "codebook kernel launch failed (%d)", rcb);
+        if (how == S2_SPEC) HIPCHK(hipEventRecord(ctx->ev_book, bs));
+    }
     szk_layout_params lp;
     lp.proto = ctx->proto;
     lp.n_vout = ctx->d_counters + 0;
     lp.n_dout = ctx->d_counters + 1;
     lp.out_cap = ctx->cur_out_cap;
-    lp.info = ctx->d_info;
+    lp.info = ctx->bk[used].info;
     lp.state = ctx->d_state;
     lp.side_bytes = ctx->proto.predictor == 2 ? ctx->d_blk_counters + 2 : nullptr;
-    prof_end(ctx, ST_CODEBOOK, s);
     szk_asm_params ap;
     ap.n_vout = ctx->d_counters + 0;
     ap.n_dout = ctx->d_counters + 1;
@@ -1058,7 +1139,7 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     ap.payload = (uint8_t *)d_payload;
     ap.cap = cap;
     ap.total_words = ctx->d_counters + 2;
-    ap.lens = ctx->d_lens;
+    ap.lens = ctx->bk[used].lens;
     ap.chunk_words = ctx->d_chunk_words;
     ap.vout_idx = ctx->d_vout_idx;
     ap.dout_idx = ctx->d_dout_idx;
@@ -1066,10 +1147,17 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     ap.dout_val = ctx->d_dout_val;
     ap.side = ctx->proto.predictor == 2 ? ctx->d_blk_side : nullptr;
     prof_begin(ctx, ST_ENCODE, s);  // (the payload layout is computed inside the encoder's scan launch, the sections are assembled by the packer's)
-    rc = szk_launch_encode(ctx->d_codes, n, ctx->d_enc, ctx->d_info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words, ctx->d_chunk_off,
-                           ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, &lp, &ap, s);
+    int rc = szk_launch_encode(ctx->d_codes, n, ctx->bk[used].enc, ctx->bk[used].info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words,
+                               ctx->d_chunk_off, ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, &lp, &ap, s,
+                               how == S2_SPEC ? ctx->ev_sorted : nullptr);
     prof_end(ctx, ST_ENCODE, s);
     if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
+    if (how == S2_SPEC) {
+        HIPCHK(hipStreamWaitEvent(s, ctx->ev_book, 0));
+        if (szk_launch_book_verdict(ctx->bk[used].info, ctx->bk[used].lens, ctx->bk[fresh].info, ctx->bk[fresh].lens,
+                                    reinterpret_cast<uint32_t *>(ctx->d_counters + 7), reinterpret_cast<uint32_t *>(ctx->d_counters + 8), ctx->d_state, s))
+            return fail(SZ3HIP_EHIP, "code book comparison launch failed");
+    }
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(szk_state), hipMemcpyDeviceToHost, s));
     // (h_state->probe = the probe counters: |delta| > 127, in [4096, 8192), in [2048, 4096); [4] = interpolation codes beyond +-4096)
     return 0;
@@ -1080,12 +1168,29 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     HIPCHK(hipSetDevice(ctx->device));
     if (!ctx->stage2_done) return fail(SZ3HIP_EINVAL, "finish called before stage2");
     HIPCHK(hipStreamSynchronize(s));
+    if (ctx->s2_spec) {
+        if (ctx->h_state->book_miss) {
+            // the previous call's book is not this call's: the encoder once more, with the book the side stream built from this
+            // call's histogram (or, when the code-book form launched alone declined the alphabet, the whole of stage 2)
+            ctx->spec_misses++;
+            const bool redo_book = ctx->h_state->mispredict != 0;
+            if (redo_book) {
+                ctx->cb_hint = -1;
+                HIPCHK(hipMemsetAsync(ctx->d_counters + 7, 0, 8, s));
+            }
+            int rc2 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s, redo_book ? S2_CLASSIC : S2_REENCODE);
+            if (rc2) return rc2;
+            HIPCHK(hipStreamSynchronize(s));
+        } else {
+            ctx->spec_hits++;
+        }
+    }
     if (ctx->h_state->mispredict) {
         // the code-book form launched alone met the other form's alphabet (the data changed character since the previous
         // call): stage 2 once more with both forms; histogram, range words and outlier lists are as stage 1 left them
         ctx->cb_hint = -1;
         HIPCHK(hipMemsetAsync(ctx->d_counters + 7, 0, 8, s));
-        int rc2 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s);
+        int rc2 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s, S2_CLASSIC);
         if (rc2) return rc2;
         HIPCHK(hipStreamSynchronize(s));
         if (ctx->h_state->mispredict) return fail(SZ3HIP_EHIP, "code book was not built (both forms declined)");
@@ -1093,6 +1198,10 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     ctx->stage1_done = ctx->stage2_done = false;
     const szk_state &st = *ctx->h_state;
     if (st.hdr.magic != SZH_MAGIC) return fail(SZ3HIP_EHIP, "device did not produce a payload header (kernel fault?)");
+    // the book this payload was coded with is the context's reference from now on
+    ctx->book_idx = ctx->book_pending;
+    ctx->book_pred = st.hdr.predictor;
+    ctx->book_radius = st.hdr.radius;
     ctx->cb_hint = st.n_symbols > SZK_CB_SMALL_SYMS ? 1 : 0;
     if (st.hdr.predictor == 2) ctx->blk_wide = st.hdr.sym_count > 3000 ? 1 : 0;  // the block kernels' LDS histogram window of the next call
     ctx->stats.n = st.hdr.n;
@@ -1200,6 +1309,22 @@ extern "C" int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, ui
 }
 
 extern "C" void sz3hip_debug_force_generic(int on) { szk_force_generic = on; }
+// Forget what earlier calls of this context found (kernel forms, histogram windows, the tuner's outcome, the code book): the
+// next call behaves like a context's first. The payload never depends on these; the time does (bench.py's cold numbers).
+extern "C" void sz3hip_ctx_forget(sz3hip_ctx *ctx) {
+    ctx->narrow_hint = ctx->cb_hint = -1;
+    ctx->wide16 = -1;
+    ctx->pack_wide = ctx->hist_big = ctx->hist_tail = ctx->blk_wide = 0;
+    ctx->spec_valid = false;
+    ctx->book_idx = -1;
+    ctx->half_skip = 0;
+}
+// speculation off (1) / on (0) for this context: with it off every stage 2 builds its code book before it encodes
+extern "C" void sz3hip_ctx_set_speculation(sz3hip_ctx *ctx, int off) { ctx->spec_off = off; }
+extern "C" void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses) {
+    *hits = ctx->spec_hits;
+    *misses = ctx->spec_misses;
+}
 extern "C" void sz3hip_debug_flags(int flags) {
     szk_dbg_flags = flags;
     szk_interp_novec = (flags & 128) != 0;  // 128: interpolation without the 8-wide level-1 kernels and without the level kernels
@@ -1209,7 +1334,7 @@ extern "C" int sz3hip_debug_codebook_info(sz3hip_ctx *ctx, uint64_t *out16) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipDeviceSynchronize());
     szk_cb_info info;
-    HIPCHK(hipMemcpy(&info, ctx->d_info, sizeof(info), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&info, ctx->bk[ctx->book_idx < 0 ? 0 : ctx->book_idx].info, sizeof(info), hipMemcpyDeviceToHost));
     out16[0] = info.n_symbols; out16[1] = info.max_len; out16[2] = info.sym_min; out16[3] = info.sym_count;
     for (int i = 0; i < 12; i++) out16[4 + i] = info.ts[i];
     return 0;
@@ -1249,7 +1374,15 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     if (h.side_bytes > payload_size) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (side section)");
     if (h.dtype != ctx->dtype) return fail(SZ3HIP_EINVAL, "payload data type does not match the context");
     if (h.n == 0 || h.n > ctx->max_n) return fail(SZ3HIP_EINVAL, "payload element count exceeds the context capacity");
-    if (h.dims[0] * h.dims[1] * h.dims[2] * h.dims[3] != h.n || h.chunk_syms != SZH_CHUNK_SYMS ||
+    {   // the extents multiply to n — by successive division, so that crafted extents cannot wrap to it
+        uint64_t rest = h.n;
+        for (int i = 0; i < 4; i++) {
+            if (h.dims[i] == 0 || rest % h.dims[i]) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (extents)");
+            rest /= h.dims[i];
+        }
+        if (rest != 1) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (extents)");
+    }
+    if (h.chunk_syms != SZH_CHUNK_SYMS ||
         h.n_chunks != (h.n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS || h.sym_count > SZH_HIST_BINS ||
         h.sym_min + h.sym_count > SZH_HIST_BINS || h.max_len > SZH_MAX_LEN || h.radius < 2 || h.radius > 32768 ||
         h.qbytes != (h.dtype == 0 ? 4 : 8) || h.n_vout > h.n || h.n_dout > h.n || h.bitstream_words > payload_size / 4)

@@ -183,6 +183,7 @@ static size_t decompress_frames(const uint8_t *src, size_t n, uint8_t *dst, size
             if (is_error(c)) { split = false; break; }
             unsigned long long d = frame_content(p, c);
             if (d == (unsigned long long)-1 || d == (unsigned long long)-2) { split = false; break; }
+            if (d > len - off) { split = false; break; }  // (checked before the add: a crafted size cannot wrap `off` past `len`)
             frames.push_back({p, c, off, (size_t)d});
             off += (size_t)d;
             p += c;
@@ -432,7 +433,7 @@ int job_upload(SlabJob &j) {
     sz3hip_ctx *ctx = s->ctx;
     const size_t cbytes = (size_t)j.conf.num * (j.cdt == SZ3HIP_FLOAT ? 4 : 8);
     if (ensure_dev(&s->dev_in, &s->dev_in_bytes, cbytes)) return j.failed(SZ3HIP_EHIP);
-    const size_t pb = sz3hip_payload_bound(ctx, j.conf.num);
+    const size_t pb = sz3hip_payload_bound_conf(ctx, &j.conf, 0);
     if (ensure_dev(&s->dev_payload, &s->dev_payload_bytes, pb)) return j.failed(SZ3HIP_EHIP);
     if (j.tm) j.tm->lap("setup");
     if (!j.is_int) {
@@ -502,7 +503,7 @@ int job_encode(SlabJob &j) {
             // more unpredictable values than the default lists hold: room for the largest lists, then the slab once more by
             // itself (the device call grows the lists to what the input needs; a slab that took this turn is coded with its
             // own code book — every blob carries its code lengths, so the container does not care)
-            if (ensure_dev(&s->dev_payload, &s->dev_payload_bytes, sz3hip_payload_bound_max(ctx, j.conf.num))) return j.failed(SZ3HIP_EHIP);
+            if (ensure_dev(&s->dev_payload, &s->dev_payload_bytes, sz3hip_payload_bound_conf(ctx, &j.conf, 1))) return j.failed(SZ3HIP_EHIP);
             rc = sz3hip_compress_device(ctx, &j.conf, s->dev_in, s->dev_payload, s->dev_payload_bytes, &dsize, s->stream);
         }
         if (rc == SZ3HIP_EOUTLIERS) {

@@ -57,6 +57,21 @@ struct sz3hip_ctx {
     uint32_t *h_ovf;   // pinned: the previous decode's overflow flag, fetched with this call's header
     void *s2_payload;  // stage 2's arguments, kept for the repeat after a mispredicted code-book form
     size_t s2_cap;
+    // Two code books: bk[book_idx] is the last one a call of this context completed with (-1: none yet). Stage 2 builds this
+    // call's book into the other slot; when the previous book may still apply (same predictor / radius) the encoder runs with
+    // it on the caller's stream while the new one is built on the side stream, and finish() repeats the encoder only when
+    // the two differ (the payload is a function of the input alone either way).
+    struct Book {
+        uint32_t *enc;
+        uint8_t *lens;
+        szk_cb_info *info;
+    } bk[2];
+    int book_idx, book_pending;
+    uint32_t book_pred, book_radius;  // what bk[book_idx] was built for
+    bool s2_spec;                     // the pending stage 2 ran speculatively
+    int spec_off;                     // test / bench hook: never speculate (every call behaves like a context's first)
+    uint32_t spec_hits, spec_misses;  // statistics (sz3hip_get_spec_stats)
+    hipEvent_t ev_sorted, ev_book;
     int blk_wide;           // block predictor: wide LDS histogram window (from the previous call's alphabet)
     uint64_t blk_cap;       // blocks the arrays below hold
     uint8_t *d_blk_sel;     // [blk_cap]
@@ -99,6 +114,9 @@ struct sz3hip_ctx {
     size_t samples_cap;
     void *d_trial_work;  // scratch of the trial kernel's global-memory variant (blocks too large for LDS)
     size_t trial_work_cap;
+    uint16_t *d_trial_codes;  // that variant's code array, [SZK_MAX_TRIALS][sampled points] — never d_codes: a speculative stage 1 may
+                              // be filling that one on the caller's stream while the tuner runs on the side stream
+    size_t trial_codes_cap;
     hipStream_t side;    // the working copy of the input is made here while the tuner runs on the caller's stream
     hipEvent_t ev_fork, ev_join;
     bool copy_ahead;     // d_work already holds this call's input (joined into the caller's stream)

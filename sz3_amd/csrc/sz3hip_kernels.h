@@ -84,6 +84,7 @@ struct szk_cb_params {
     int range_ready;   // the range words are already filled (stage 1 kept them with the histogram): no k_hist_range launch
     int part_hint;     // -1: both forms of k_codebook are launched; 0 / 1: only that form (small / wide alphabets), see mispredict
     uint32_t *mispredict;  // set to 1 by a form launched alone that meets the other form's alphabet
+    int skip_sort;         // the outlier lists are sorted by a launch of their own (szk_launch_sort_outliers)
 };
 #define SZK_CB_SMALL_SYMS 256  // alphabets up to this size take k_codebook<0>, wider ones <1>
 #define SZK_MAX_BOOKS 4
@@ -94,6 +95,7 @@ struct szk_state {
     szh_offsets off;
     uint32_t overflow, cap_exceeded;
     uint32_t mispredict, n_symbols;  // code book: wrong form launched alone (stage 2 is repeated); size of the alphabet
+    uint32_t book_miss, reserved;    // speculative stage 2: the previous call's code book is not this call's (stage 2 is repeated)
     uint32_t probe[6];  // copy of the probe counters (d_counters + 4): one device-to-host copy brings everything the host reads
 };
 struct szk_layout_params {
@@ -246,7 +248,12 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
                       szk_mode mode, uint16_t *chunk_words, uint64_t *group_off /*[n_chunks/32 + 1]*/, uint64_t *total_words,
                       const szk_state *state, uint8_t *payload, const szk_layout_params *layout,
-                      const szk_asm_params *asmp /* non-null: the packer's launch also assembles the payload (no szk_launch_assemble) */, hipStream_t s);
+                      const szk_asm_params *asmp /* non-null: the packer's launch also assembles the payload (no szk_launch_assemble) */, hipStream_t s,
+                      hipEvent_t lists_sorted = nullptr /* non-null: the packer's launch waits for it (outlier lists sorted on a side stream) */);
+int szk_launch_sort_outliers(const szk_cb_params *p, hipStream_t s);
+// compares the code book the encoder used with the one built from this call's histogram; writes state->book_miss / mispredict / n_symbols
+int szk_launch_book_verdict(const szk_cb_info *used, const uint8_t *used_lens, const szk_cb_info *fresh, const uint8_t *fresh_lens,
+                            const uint32_t *mispredict, const uint32_t *range, szk_state *state, hipStream_t s);
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t,
                           uint32_t *zero_word /* a device word this launch clears (nullptr: none) */,

@@ -1750,6 +1750,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     const uint32_t t = threadIdx.x;
     if (blockIdx.x >= p.n_books) {  // the two blocks after the code books: deterministic order of the two outlier lists
         // (in the launch whose code-book path is the active one, so that they run beside it)
+        if (p.skip_sort) return;  // (speculative stage 2: k_sort_outliers did it, ahead of the packer)
         if ((PART == 1) != (p.range[2] > CB_SMALL_SYMS) && p.part_hint < 0) return;  // (launched alone: sorts whatever the alphabet)
         const bool d = blockIdx.x == p.n_books + 1;
         // scratch: the key tables of the batch slots 1 and 2, idle when a single code book is built (n_books <= 1)
@@ -1976,6 +1977,38 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
         p.info->sym_min = lo;
         p.info->sym_count = range;
         p.info->win_lo = wl;
+    }
+}
+
+// the outlier-list sorts as a launch of their own: the speculative stage 2 (sz3hip_api.cpp) packs with the previous call's
+// code book while this call's is being built on a side stream, and the packer's launch assembles the (sorted) lists
+__global__ __launch_bounds__(CB_LAUNCH) void k_sort_outliers(szk_cb_params p) {
+    __shared__ __align__(16) uint8_t s_pool[CB_POOL_BYTES];
+    const bool d = blockIdx.x == 1;
+    uint64_t *scratch = p.keys + (size_t)(d ? 2 : 1) * SZH_HIST_BINS;
+    sort_outlier_list(d ? p.dout_idx : p.vout_idx, d ? p.dout_val : p.vout_val, d ? *p.n_dout : *p.n_vout, p.out_cap,
+                      d ? p.q_is_32bit != 0 : p.t_is_32bit != 0, s_pool, scratch);
+}
+// Did the code book the encoder ran with (the context's previous one, `used`) equal the one this call's histogram gives
+// (`fresh`)? The canonical code is a function of the alphabet's range and the code lengths; the packers' LDS window is
+// compared too (it does not change the payload, only which symbols take the slow lookup). One workgroup.
+__global__ __launch_bounds__(1024) void k_book_verdict(const szk_cb_info *__restrict__ used, const uint8_t *__restrict__ used_lens,
+                                                       const szk_cb_info *__restrict__ fresh, const uint8_t *__restrict__ fresh_lens,
+                                                       const uint32_t *__restrict__ mispredict, const uint32_t *__restrict__ range,
+                                                       szk_state *state) {
+    __shared__ uint32_t s_diff;
+    if (threadIdx.x == 0) s_diff = 0;
+    __syncthreads();
+    const uint32_t lo = fresh->sym_min, cnt = fresh->sym_count;
+    bool diff = used->sym_min != lo || used->sym_count != cnt || used->max_len != fresh->max_len || used->n_symbols != fresh->n_symbols;
+    if (!diff)
+        for (uint32_t i = threadIdx.x; i < cnt; i += 1024) diff |= used_lens[lo + i] != fresh_lens[lo + i];
+    if (diff) s_diff = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        state->book_miss = s_diff | *mispredict;  // (a code-book form launched alone that declined: no fresh book at all)
+        state->mispredict = *mispredict;
+        state->n_symbols = range[2];
     }
 }
 
@@ -2352,6 +2385,7 @@ __device__ void assemble_body(const szk_asm_params &p, uint64_t tid, uint64_t nt
         p.state->cap_exceeded = oo.end > p.cap;
         for (int i = 0; i < 6; i++) p.state->probe[i] = reinterpret_cast<const uint32_t *>(p.n_vout + 4)[i];
         p.state->mispredict = (uint32_t)p.n_vout[7];                                  // (d_counters[7]: raised by a code-book form launched alone)
+        p.state->book_miss = 0;                                                       // (speculative stage 2: k_book_verdict rewrites the three)
         p.state->n_symbols = reinterpret_cast<const uint32_t *>(p.n_vout + 8)[2];   // (the range words: number of non-empty bins)
         // alignment gaps between the sections are part of the payload: zero them so that it is a pure function of the input
         const uint64_t tsz0 = h.dtype == 0 ? 4 : 8;
@@ -3481,9 +3515,21 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
     SZK_CHECK_LAUNCH();
     return 0;
 }
+int szk_launch_sort_outliers(const szk_cb_params *p, hipStream_t s) {
+    hipLaunchKernelGGL(k_sort_outliers, dim3(2), dim3(CB_LAUNCH), 0, s, *p);
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
+int szk_launch_book_verdict(const szk_cb_info *used, const uint8_t *used_lens, const szk_cb_info *fresh, const uint8_t *fresh_lens,
+                            const uint32_t *mispredict, const uint32_t *range, szk_state *state, hipStream_t s) {
+    hipLaunchKernelGGL(k_book_verdict, dim3(1), dim3(1024), 0, s, used, used_lens, fresh, fresh_lens, mispredict, range, state);
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
                       szk_mode mode, uint16_t *chunk_words, uint64_t *group_off, uint64_t *total_words,
-                      const szk_state *state, uint8_t *payload, const szk_layout_params *layout, const szk_asm_params *asmp, hipStream_t s) {
+                      const szk_state *state, uint8_t *payload, const szk_layout_params *layout, const szk_asm_params *asmp, hipStream_t s,
+                      hipEvent_t lists_sorted) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
     const uint64_t nb = (n_chunks + 3) / 4;
     if (nb > 0x7FFFFFFFull) return -1;
@@ -3491,6 +3537,8 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
     const uint32_t pgrid = (uint32_t)(nb < 2048 ? nb : 2048);  // persistent: 8 workgroups per CU
     hipLaunchKernelGGL(k_chunk_bits2, dim3(pgrid), dim3(256), 0, s, codes, n, d_enc, info, mode, sym_add, chunk_words);
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, chunk_words, n_chunks, group_off, total_words, *layout, 1);
+    // (speculative stage 2: the outlier lists are being sorted on a side stream; the packer's launch copies them)
+    if (lists_sorted && hipStreamWaitEvent(s, lists_sorted, 0) != hipSuccess) return -2;
     constexpr uint32_t ASM_BLOCKS = 32;
     if (mode.pack_wide) {
         const uint32_t pb = pgrid < 768 ? pgrid : 768;

@@ -507,3 +507,50 @@ def test_speculative_stage1_follows_the_tuner(shape):
         assert float((out.double() - t.double()).abs().max()) <= 1e-2, (name, seen)
     assert len(outcomes) >= 2, outcomes
     assert seen[0] == 0 and seen[1] == 1 and seen[3] == 1 and 2 in seen, seen
+
+
+def test_speculative_code_book_is_confirmed_or_replaced():
+    """Stage 2 of a context that holds a previous code book (same predictor, same radius) packs with THAT book while this
+    call's is built from this call's histogram on a side stream; `finish` compares the two and repeats the encoder when they
+    differ. Whatever happens the payload is the one a fresh context produces: same array again (hit), another realisation of
+    the field (miss), another bound (miss), the interpolation predictor (no speculation: other predictor), an alphabet of the
+    other code-book form (miss through the declined form), speculation switched off."""
+    dev = torch.device("cuda:0")
+    shape = (40, 64, 256)
+    a = field3d(shape)
+    b = field3d(shape, seed=77)
+    n = a.size
+    shared = sz3_amd.DeviceCompressor(n, np.float32)
+    cap = shared.payload_bound(n, worst_case=True)
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+
+    def run(dc, t, conf):
+        pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+        size = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+        dec = torch.empty_like(t)
+        dc.decompress(pl.data_ptr(), size, dec.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert float((dec.double() - t.double()).abs().max()) <= conf.absErrorBound
+        return pl[:size].cpu().numpy().tobytes()
+
+    interp = sz3_amd.Config(*shape)
+    interp.cmprAlgo = sz3_amd.ALGO_INTERP
+    interp.absErrorBound = 1e-3
+    # (array, config, expected outcome: +1 hit, -1 miss, 0 not speculated)
+    steps = [(ta, _conf(shape, 1e-3), 0), (ta, _conf(shape, 1e-3), +1), (tb, _conf(shape, 1e-3), -1), (tb, _conf(shape, 1e-3), +1),
+             (ta, _conf(shape, 2e-3), -1), (ta, interp, 0), (ta, interp, +1), (ta, _conf(shape, 1e-6), 0), (ta, _conf(shape, 1e-6), +1),
+             (ta, _conf(shape, 1e-3), -1), (tb, _conf(shape, 1e-6), -1)]
+    for k, (t, conf, want) in enumerate(steps):
+        h0, m0 = shared.spec_stats()
+        got = run(shared, t, conf)
+        h1, m1 = shared.spec_stats()
+        assert (h1 - h0, m1 - m0) == {0: (0, 0), 1: (1, 0), -1: (0, 1)}[want], "step %d: hits %d misses %d" % (k, h1 - h0, m1 - m0)
+        assert got == run(sz3_amd.DeviceCompressor(n, np.float32), t, conf), "step %d: payload depends on the context's history" % k
+    shared.set_speculation(False)
+    h0, m0 = shared.spec_stats()
+    assert run(shared, ta, _conf(shape, 1e-3)) == run(sz3_amd.DeviceCompressor(n, np.float32), ta, _conf(shape, 1e-3))
+    assert shared.spec_stats() == (h0, m0)
+    shared.set_speculation(True)
+    shared.forget()
+    assert run(shared, ta, _conf(shape, 1e-3)) == run(sz3_amd.DeviceCompressor(n, np.float32), ta, _conf(shape, 1e-3))
+    assert shared.spec_stats() == (h0, m0)  # a context that forgot its book does not speculate

@@ -188,7 +188,7 @@ extern "C" size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in) 
 // device context
 // ------------------------------------------------------------------------------------------------------------
 static const char *const kStageNames[ST_COUNT] = {"lorenzo_quant_hist", "codebook", "encode", "assemble",
-                                                  "huffman_decode",     "reconstruct", "tuner", "k1_kernel"};
+                                                  "huffman_decode",     "reconstruct", "tuner", "k1_kernel", "step_span"};
 
 #define SZ_COUNTER_BYTES 128
 // histogram and counters of a call start at zero; the internal histogram and the counters share one block (one fill launch)
@@ -204,7 +204,7 @@ static void ctx_free(sz3hip_ctx *c) {
                     c->d_chunk_words, c->d_chunk_off, c->d_carry, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples, c->d_trial_work, c->d_trial_codes,
                     c->d_trial, c->d_passes, c->d_np,  // (d_trial_counters / d_trial_hist live inside d_trial's block)
                     c->d_blk_sel, c->d_blk_coef, c->d_blk_rank, c->d_blk_comp, c->d_blk_side, c->d_blk_counters,
-                    c->bk[1].enc, c->bk[1].lens, c->bk[1].info};
+                    c->bk[1].enc, c->bk[1].lens, c->bk[1].info, c->d_seg_bits};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->side) {
@@ -280,6 +280,7 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     alloc((void **)&c->d_pint2, SZK_MAX_BOOKS * SZH_HIST_BINS * 2);
     alloc((void **)&c->d_range, SZK_MAX_BOOKS * 16);
     alloc((void **)&c->d_info, SZK_MAX_BOOKS * sizeof(szk_cb_info));
+    alloc((void **)&c->d_seg_bits, (max_elems / 256 + 8) * 2);
     alloc((void **)&c->bk[1].enc, SZH_HIST_BINS * 4);
     alloc((void **)&c->bk[1].lens, SZH_HIST_BINS);
     alloc((void **)&c->bk[1].info, sizeof(szk_cb_info));
@@ -483,6 +484,10 @@ static int stage1_interp(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
     return 0;
 }
 
+// may stage 2 of a call with this predictor and radius run with the context's previous code book? (decided once per call)
+static bool book_spec_ok(const sz3hip_ctx *ctx, uint32_t predictor, uint32_t radius) {
+    return ctx->book_idx >= 0 && !ctx->spec_off && !(szk_dbg_flags & 131072) && ctx->book_pred == predictor && ctx->book_radius == radius;
+}
 // ---- stage 1, integer Lorenzo on the prequantised lattice ----
 static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *d_in, double eb, int radius, uint64_t num,
                       uint64_t out_cap, bool allow_narrow, szk_k1_params &p, hipStream_t s) {
@@ -511,6 +516,14 @@ static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *
     // that takes costs more than the k_hist_range launch it saves (szk_launch_k1 reports through range_kept what was done)
     p.range = reinterpret_cast<uint32_t *>(ctx->d_counters + 8);
     p.hint_narrow = allow_narrow ? ctx->narrow_hint : -1;
+    if (allow_narrow && book_spec_ok(ctx, 0, (uint32_t)radius)) {
+        // stage 2 will pack with the previous call's book: its code lengths let the one-byte kernel sum the code bits of the
+        // 256-element segments (no bits pass), and the fold of the histogram rows moves to the side stream the new book is built on
+        p.spec_lens = ctx->bk[ctx->book_idx].lens;
+        p.seg_bits = ctx->d_seg_bits;
+        p.seg_made = reinterpret_cast<uint32_t *>(ctx->d_counters + 10) + 1;  // zeroed with the counters
+        p.defer_fold = ctx->hist_exposed || (szk_dbg_flags & 16777216) ? 0 : 1;  // (a caller that holds the histogram wants it complete after stage 1)
+    }
     p.prof_ev0 = p.prof_ev1 = nullptr;
     if (ctx->profiling && allow_narrow) {  // (the production call, not the tuner's trial): events around the kernel itself
         p.prof_ev0 = ctx->ev[ST_K1_KERNEL][0];
@@ -525,6 +538,10 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
     int rc = lorenzo_k1(ctx, conf->N, conf->dims, d_in, eb, radius, num, ctx->cur_out_cap, true, p, s);
     ctx->mode = p.mode;
     ctx->range_ready = p.range_kept != 0;
+    ctx->s1_spec = p.spec_lens != nullptr;
+    ctx->seg_expected = p.seg_expected != 0 && !(szk_dbg_flags & 33554432);
+    ctx->fold_rows = p.defer_fold ? p.fold_rows : 0;
+    ctx->fold_range = p.range;
     prof_end(ctx, ST_K1, s);
     if (rc) return fail(SZ3HIP_EHIP, "lorenzo_quant kernel launch failed (%d)", rc);
     szh_header &h = ctx->proto;
@@ -942,6 +959,9 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     for (int i = 0; i < ST_COUNT; i++) ctx->ev_used[i] = false;  // stage times describe this call only
     ctx->copy_ahead = false;
     ctx->range_ready = false;
+    ctx->s1_spec = ctx->seg_expected = false;
+    ctx->fold_rows = 0;
+    prof_begin(ctx, ST_SPAN, s);  // (closed at the end of stage 2: the device time of the whole step)
     if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP_LORENZO) {  // the reference's default: sampling auto-tuner, then one of the two paths
         // The tuner is a chain of small launches and host round trips (the chip is mostly idle), and its outcome is almost
         // always interpolation, which starts from a working copy of the input: make that copy meanwhile on a side stream.
@@ -1053,7 +1073,11 @@ enum { S2_CLASSIC = 0, S2_SPEC = 1, S2_REENCODE = 2 };
 static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream_t s, int how);
 static int ensure_side(sz3hip_ctx *ctx) {
     if (!ctx->side) {
-        HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        // highest priority: its small kernels (histogram fold, list sort, code book) become ready together with the encoder's
+        // chip-filling launches on the caller's stream and must not queue behind them
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        HIPCHK(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, greatest));
         HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     }
@@ -1086,8 +1110,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     // packs with THAT book on the caller's stream while this call's book is built from this call's histogram on the side
     // stream; finish() compares the two and repeats the encoder when they differ. The book a payload is coded with is always
     // the one its own histogram gives.
-    const bool spec = ctx->book_idx >= 0 && !ctx->spec_off && !(szk_dbg_flags & 131072) && ctx->book_pred == ctx->proto.predictor &&
-                      ctx->book_radius == ctx->proto.radius;
+    const bool spec = ctx->proto.predictor == 0 ? ctx->s1_spec : book_spec_ok(ctx, ctx->proto.predictor, ctx->proto.radius);
     int rc = stage2_launch(ctx, d_payload, cap, s, spec ? S2_SPEC : S2_CLASSIC);
     if (rc) return rc;
     ctx->stage2_done = true;
@@ -1109,9 +1132,19 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
         bs = ctx->side;
         HIPCHK(hipEventRecord(ctx->ev_fork, s));  // stage 1 (and, between the stages, the caller's histogram exchange) is on the caller's stream
         HIPCHK(hipStreamWaitEvent(bs, ctx->ev_fork, 0));
-        if (szk_launch_sort_outliers(&cb, bs)) return fail(SZ3HIP_EHIP, "outlier sort launch failed");
+        if (ctx->fold_rows) {  // stage 1 left the fold of its histogram rows to this stream
+            if (szk_launch_hist_fold(ctx->d_hist_partial, ctx->fold_rows, (int)ctx->proto.radius, ctx->d_hist, ctx->fold_range, bs))
+                return fail(SZ3HIP_EHIP, "histogram fold launch failed");
+            ctx->fold_rows = 0;
+        }
+        if (szk_launch_sort_outliers(&cb, reinterpret_cast<uint32_t *>(ctx->d_counters + 10), bs)) return fail(SZ3HIP_EHIP, "outlier sort launch failed");
         HIPCHK(hipEventRecord(ctx->ev_sorted, bs));
         cb.skip_sort = 1;
+        cb.slim = 1;
+    } else if (ctx->fold_rows) {  // (not reached: stage 1 defers the fold only when stage 2 speculates)
+        if (szk_launch_hist_fold(ctx->d_hist_partial, ctx->fold_rows, (int)ctx->proto.radius, ctx->d_hist, ctx->fold_range, s))
+            return fail(SZ3HIP_EHIP, "histogram fold launch failed");
+        ctx->fold_rows = 0;
     }
     if (how != S2_REENCODE) {
         if (ctx->range_ready && !cb.range_ready)  // stage 1 kept the range of the LOCAL histogram, the caller then changed it (all-reduce):
@@ -1149,15 +1182,18 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     prof_begin(ctx, ST_ENCODE, s);  // (the payload layout is computed inside the encoder's scan launch, the sections are assembled by the packer's)
     int rc = szk_launch_encode(ctx->d_codes, n, ctx->bk[used].enc, ctx->bk[used].info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words,
                                ctx->d_chunk_off, ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, &lp, &ap, s,
-                               how == S2_SPEC ? ctx->ev_sorted : nullptr);
+                               how == S2_SPEC ? ctx->ev_sorted : nullptr, how == S2_SPEC && ctx->seg_expected ? ctx->d_seg_bits : nullptr,
+                               reinterpret_cast<uint32_t *>(ctx->d_counters + 10) + 1);
     prof_end(ctx, ST_ENCODE, s);
     if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
     if (how == S2_SPEC) {
         HIPCHK(hipStreamWaitEvent(s, ctx->ev_book, 0));
         if (szk_launch_book_verdict(ctx->bk[used].info, ctx->bk[used].lens, ctx->bk[fresh].info, ctx->bk[fresh].lens,
-                                    reinterpret_cast<uint32_t *>(ctx->d_counters + 7), reinterpret_cast<uint32_t *>(ctx->d_counters + 8), ctx->d_state, s))
+                                    reinterpret_cast<uint32_t *>(ctx->d_counters + 7), reinterpret_cast<uint32_t *>(ctx->d_counters + 8),
+                                    reinterpret_cast<uint32_t *>(ctx->d_counters + 10), ctx->seg_expected ? 1 : 0, ctx->d_state, s))
             return fail(SZ3HIP_EHIP, "code book comparison launch failed");
     }
+    prof_end(ctx, ST_SPAN, s);
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(szk_state), hipMemcpyDeviceToHost, s));
     // (h_state->probe = the probe counters: |delta| > 127, in [4096, 8192), in [2048, 4096); [4] = interpolation codes beyond +-4096)
     return 0;
@@ -1173,10 +1209,12 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
             // the previous call's book is not this call's: the encoder once more, with the book the side stream built from this
             // call's histogram (or, when the code-book form launched alone declined the alphabet, the whole of stage 2)
             ctx->spec_misses++;
-            const bool redo_book = ctx->h_state->mispredict != 0;
+            const uint32_t kind = ctx->h_state->miss_kind;
+            const bool redo_book = (kind & (2u | 4u)) != 0;  // no fresh book (form declined) / lists unsorted: stage 2 from its start
             if (redo_book) {
-                ctx->cb_hint = -1;
-                HIPCHK(hipMemsetAsync(ctx->d_counters + 7, 0, 8, s));
+                if (kind & 2u) ctx->cb_hint = -1;
+                HIPCHK(hipMemsetAsync(ctx->d_counters + 7, 0, 24, s));  // mispredict flag and the range words (recomputed)
+                ctx->range_ready = false;
             }
             int rc2 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s, redo_book ? S2_CLASSIC : S2_REENCODE);
             if (rc2) return rc2;
@@ -1303,8 +1341,8 @@ extern "C" int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, ui
     }
     std::vector<uint8_t> b(n);  // one-byte codes: delta + 128, 0 = outlier -> symbols
     HIPCHK(hipMemcpy(b.data(), ctx->d_codes, n, hipMemcpyDeviceToHost));
-    const uint32_t add = ctx->h_state->hdr.radius ? ctx->h_state->hdr.radius - 128u : ctx->proto.radius - 128u;
-    for (uint64_t i = 0; i < n; i++) host_codes[i] = (uint16_t)(b[i] ? b[i] + add : 0u);
+    const uint32_t add = ctx->h_state->hdr.radius ? ctx->h_state->hdr.radius - 127u : ctx->proto.radius - 127u;  // stored byte = delta + 127, 255 = outlier
+    for (uint64_t i = 0; i < n; i++) host_codes[i] = (uint16_t)(b[i] != 255 ? b[i] + add : 0u);
     return 0;
 }
 

@@ -73,44 +73,55 @@ template <> struct QTraits<double> {
     using UQ = uint64_t;
 };
 
-// The quantisation lattice.  q = rint(x / 2eb); the reconstruction x^ = q * 2eb is verified against the bound
-// (same acceptance test as quantizer/LinearQuantizer.hpp:57-60: |dec - data| evaluated in T, compared with eb) and
-// the raw value is kept losslessly when the check fails.  Non-finite or huge values take q = 0 so that neighbours
-// still predict sanely.  The arithmetic type is the data type: f32 data use f32 multiplies (one rounding each, no
-// FMA contraction: built with -ffp-contract=off), f64 data f64 — the decoder applies the identical expression, so
-// the bound that the encoder verified is the bound the user gets.
+// The quantisation lattice.  q = rint(x / 2eb), clamped to +-LIM; the reconstruction x^ = q * 2eb is verified against the
+// bound (same acceptance test as quantizer/LinearQuantizer.hpp:57-60: |dec - data| evaluated in T, compared with eb) and the
+// raw value is kept losslessly when the check fails.  The arithmetic type is the data type: f32 data use f32 multiplies
+// (one rounding each, no FMA contraction: built with -ffp-contract=off), f64 data f64 — the decoder applies the identical
+// expression, so the bound that the encoder verified is the bound the user gets.
+//
+// Rounding goes through the "magic number" M = 1.5 * 2^(mantissa bits): fl(s + M) has the integer rint(s) in its low
+// mantissa bits for |s| <= LIM = 2^(mantissa bits - 1), so the BIT PATTERN of s + M is C + rint(s) (C = bits of M) — no
+// rounding instruction, no float-to-integer conversion, and r = fl(s + M) - M is rint(s) as a float again (exact). The bit
+// pattern is clamped to [C - LIM, C + LIM] as an integer: values beyond the lattice (|x| > LIM * 2eb, +-Inf) sit at its ends,
+// NaN at the end its sign bit names; their reconstruction fails the check unless it really is within the bound.
+// `qbits` returns that offset pattern: the stencils difference it as it is (the offset cancels; a neighbour outside the
+// array is C), which saves the subtraction too.
 template <typename T> struct Lattice;
 template <> struct Lattice<float> {
+    using B = int32_t;
+    static constexpr B C = 0x4B400000, LIM = 1 << 22;
     float recip, two_eb, eb_lo;  // (float)(1/(2eb)), (float)(2eb), largest float <= eb
     __device__ __forceinline__ explicit Lattice(const szk_lattice &l) : recip(l.recip_f), two_eb(l.two_eb_f), eb_lo(l.eb_lo_f) {}
-    __device__ __forceinline__ int32_t quant(float x, bool &bad) const {
-        float s = x * recip;
-        int32_t q = 0;
-        bad = true;
-        if (fabsf(s) < 8388608.0f) {  // 2^23: rintf(s) is an exact integer; false for NaN
-            float r = rintf(s);
-            q = (int32_t)r;
-            float dec = r * two_eb;
-            bad = !(fabsf(dec - x) <= eb_lo);
-        }
-        return q;
+    __device__ __forceinline__ B qbits(float x) const {
+        const float tm = x * recip + 12582912.0f;  // two roundings (-ffp-contract=off)
+        const B b = __float_as_int(tm);
+        return min(max(b, C - LIM), C + LIM);
+    }
+    __device__ __forceinline__ float rounded(B bits) const { return __int_as_float(bits) - 12582912.0f; }  // rint(s) as a float
+    __device__ __forceinline__ bool bad(float x, B bits) const { return !(fabsf(rounded(bits) * two_eb - x) <= eb_lo); }
+    __device__ __forceinline__ int32_t quant(float x, bool &is_bad) const {
+        const B b = qbits(x);
+        is_bad = bad(x, b);
+        return b - C;
     }
     __device__ __forceinline__ float dequant(int32_t q) const { return (float)q * two_eb; }
 };
 template <> struct Lattice<double> {
+    using B = int64_t;
+    static constexpr B C = 0x4338000000000000ll, LIM = 1ll << 51;
     double recip, two_eb, eb;
     __device__ __forceinline__ explicit Lattice(const szk_lattice &l) : recip(l.recip), two_eb(l.two_eb), eb(l.eb) {}
-    __device__ __forceinline__ int64_t quant(double x, bool &bad) const {
-        double s = x * recip;
-        int64_t q = 0;
-        bad = true;
-        if (fabs(s) < 4503599627370496.0) {  // 2^52
-            double r = rint(s);
-            q = (int64_t)r;
-            double dec = r * two_eb;
-            bad = !(fabs(dec - x) <= eb);
-        }
-        return q;
+    __device__ __forceinline__ B qbits(double x) const {
+        const double tm = x * recip + 6755399441055744.0;
+        const B b = __double_as_longlong(tm);
+        return min(max(b, C - LIM), C + LIM);
+    }
+    __device__ __forceinline__ double rounded(B bits) const { return __longlong_as_double(bits) - 6755399441055744.0; }
+    __device__ __forceinline__ bool bad(double x, B bits) const { return !(fabs(rounded(bits) * two_eb - x) <= eb); }
+    __device__ __forceinline__ int64_t quant(double x, bool &is_bad) const {
+        const B b = qbits(x);
+        is_bad = bad(x, b);
+        return b - C;
     }
     __device__ __forceinline__ double dequant(int64_t q) const { return (double)q * two_eb; }
 };

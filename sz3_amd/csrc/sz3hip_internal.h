@@ -31,7 +31,7 @@ struct Reader {
     }
 };
 
-enum { ST_K1 = 0, ST_CODEBOOK, ST_ENCODE, ST_ASSEMBLE, ST_DEC_HUFF, ST_DEC_RECON, ST_TUNER, ST_K1_KERNEL, ST_COUNT };
+enum { ST_K1 = 0, ST_CODEBOOK, ST_ENCODE, ST_ASSEMBLE, ST_DEC_HUFF, ST_DEC_RECON, ST_TUNER, ST_K1_KERNEL, ST_SPAN, ST_COUNT };
 
 struct sz3hip_ctx {
     int device;
@@ -72,6 +72,12 @@ struct sz3hip_ctx {
     int spec_off;                     // test / bench hook: never speculate (every call behaves like a context's first)
     uint32_t spec_hits, spec_misses;  // statistics (sz3hip_get_spec_stats)
     hipEvent_t ev_sorted, ev_book;
+    // stage 1 of the pending Lorenzo call, when it ran with the previous book's code lengths (speculation decided there):
+    bool s1_spec;          // stage 2 speculates (same condition, evaluated once per call)
+    bool seg_expected;     // stage 1 sums the code bits per 256-element segment: stage 2 launches no bits pass
+    uint32_t fold_rows;    // != 0: the fold of stage 1's histogram rows was left to stage 2 (side stream)
+    uint32_t *fold_range;
+    uint16_t *d_seg_bits;  // [max_n / 256 + 8]
     int blk_wide;           // block predictor: wide LDS histogram window (from the previous call's alphabet)
     uint64_t blk_cap;       // blocks the arrays below hold
     uint8_t *d_blk_sel;     // [blk_cap]

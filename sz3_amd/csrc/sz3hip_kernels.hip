@@ -819,7 +819,7 @@ __device__ __forceinline__ void march_body(const T *__restrict__ in, uint16_t *_
                         const UQ tq = delta[i] + (UQ)127;
                         const bool inr = tq <= (UQ)254;
                         const uint32_t tc = inr ? (uint32_t)tq : 255u;
-                        const uint32_t byte = (tc + 1u) & 255u;
+                        const uint32_t byte = tc;  // (the stored byte: delta + 127, 255 = delta outlier)
                         const uint32_t bin = tc + (uint32_t)(HIST_WIN / 2 - 127);  // delta + radius - win_lo; 255 + 385 = spare bin, skipped by the flush
                         rare |= !inr;
                         pk8 |= byte << (8 * i);
@@ -910,6 +910,291 @@ __device__ __forceinline__ void march_body(const T *__restrict__ in, uint16_t *_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The one-byte form of the marching kernel (round 3). Same bricks, same walk and the same results as march_body<.., 1, ..>
+// (which it replaces), written for the vector ALU's issue rate, the kernel's bound at 27.6 instructions per element:
+//   * every task coordinate is wave-uniform by construction (readfirstlane): row / plane addresses, validity of the halo
+//     row, the halo plane and the left neighbour live in scalar registers and are decided by scalar branches;
+//   * the lattice value is the bit pattern of fl(x / 2eb + M) (Lattice<T>::qbits): one multiply, one add, one integer
+//     clamp per value; the stencil differences the patterns as they are; a neighbour outside the array is the constant C;
+//   * a brick whose 256 x TY footprint lies inside the array (EDGE = false: all of them when the extents divide) carries
+//     no per-lane validity selects;
+//   * codes are stored as t = min(delta + 127, 255) — 255 = "outside [-127, 127]", a delta outlier — which is also the
+//     bin of the LDS histogram (256 bins x 4 copies);
+//   * the bound check's outcomes stay lane masks in scalar registers; one scalar test per row decides whether any lane
+//     has something rare to do.
+// With a code-length table (the context's previous code book: speculative stage 2, sz3hip_api.cpp) the kernel also sums
+// the code lengths of every 256-element row segment it codes — the bits pass of the encoder, without its trip over the codes.
+// ------------------------------------------------------------------------------------------------------------
+#define NARROW_BINS 256  // t = min(delta + 127, 255); bin 255 collects the out-of-range deltas (not a symbol)
+template <typename T> struct NarrowCtx {
+    using B = typename Lattice<T>::B;
+    using OQV = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;
+    const T *in;
+    uint8_t *codes8;
+    const szk_k1_params *p;
+    uint32_t d0, d1, d2;
+    uint64_t plane, vol;
+    uint32_t *lh;          // [NARROW_BINS * 4] histogram, [bin][4 copies]
+    const uint8_t *s_len;  // [256] code length by t (LDS), nullptr: no bit accounting
+    uint16_t *seg_bits;    // [n / 256] out: code bits of every 256-element row segment
+    uint64_t *oq_idx;      // this wave's staging queue of value outliers
+    OQV *oq_val;
+    uint32_t oq_n;
+    int lane;
+};
+template <typename T>
+__device__ __forceinline__ void narrow_oq_flush(NarrowCtx<T> &c) {
+    // (called by whatever lanes are active; the records are dealt over the ACTIVE lanes, see march_body)
+    c.oq_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.oq_n);
+    if (c.oq_n == 0) return;
+    const szk_k1_params &p = *c.p;
+    const unsigned long long act = __ballot(1);
+    const uint32_t nact = (uint32_t)__popcll(act), rank = (uint32_t)__popcll(act & ((1ull << c.lane) - 1ull));
+    unsigned long long base = 0;
+    if (rank == 0) base = atomicAdd((unsigned long long *)p.n_vout, (unsigned long long)c.oq_n);
+    const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+    const unsigned long long b0 = ((unsigned long long)bhi << 32) | blo;
+    for (uint32_t k = rank; k < c.oq_n; k += nact) {
+        const unsigned long long pos = b0 + k;
+        if (pos < p.out_cap) {
+            p.vout_idx[pos] = c.oq_idx[k];
+            if (sizeof(T) == 4) reinterpret_cast<uint32_t *>(p.vout_val)[pos] = (uint32_t)c.oq_val[k];
+            else reinterpret_cast<uint64_t *>(p.vout_val)[pos] = c.oq_val[k];
+        }
+    }
+    c.oq_n = 0;
+}
+// what a row's rare elements need: delta outliers into their list, values that failed the bound check into the wave's
+// staging queue, delta outliers counted as symbol 0 of the global histogram. Out of line: the hot loop only branches here.
+template <typename T>
+__device__ __forceinline__ void narrow_rare(NarrowCtx<T> &c, uint64_t gi, const typename QTraits<T>::UQ (&delta)[4], uint32_t tmask, uint32_t badmask) {
+    using Q = typename QTraits<T>::Q;
+    using OQV = typename NarrowCtx<T>::OQV;
+    const szk_k1_params &p = *c.p;
+    constexpr uint32_t OQ = MarchLds<1, false>::OQ;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const bool is_dout = (tmask >> i) & 1u, is_vout = (badmask >> i) & 1u;
+        const unsigned long long pd = wave_append_slot(is_dout, p.n_dout);
+        if (is_dout && pd < p.out_cap) {
+            p.dout_idx[pd] = gi + i;
+            ((Q *)p.dout_val)[pd] = (Q)delta[i];
+        }
+        const unsigned long long vm = __ballot(is_vout);
+        if (vm) {
+            c.oq_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.oq_n);
+            if (c.oq_n + WAVE > OQ) narrow_oq_flush(c);
+            if (is_vout) {
+                const uint32_t slot = c.oq_n + (uint32_t)__popcll(vm & ((1ull << c.lane) - 1ull));
+                c.oq_idx[slot] = gi + i;
+                const T raw = c.in[gi + i];
+                OQV bits = 0;
+                memcpy(&bits, &raw, sizeof(T));
+                c.oq_val[slot] = bits;
+            }
+            c.oq_n += (uint32_t)__popcll(vm);
+        }
+        // code 0 (delta outliers) is one address for the whole grid: one atomic per wave
+        const unsigned long long zm = __ballot(is_dout);
+        if (zm && c.lane == __ffsll((long long)zm) - 1) hist_add_ranged(p.hist, p.range, 0u, (unsigned long long)__popcll(zm));
+    }
+}
+template <typename T, int NDIM, int TY, bool EDGE>
+__device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &lat, uint32_t x0, uint32_t y0, uint32_t z0, uint32_t w) {
+    using B = typename Lattice<T>::B;
+    using UQ = typename QTraits<T>::UQ;
+    constexpr int NW = NDIM == 4 ? 2 : 1;
+    constexpr B CB = Lattice<T>::C;
+    const uint32_t d0 = c.d0, d1 = c.d1, d2 = c.d2;
+    const int lane = c.lane;
+    const uint32_t x = x0 + 4u * (uint32_t)lane;
+    const bool xok = EDGE ? x < d0 : true;       // quad granular (d0 % 4 == 0)
+    const uint32_t lane_off = xok ? x : 0u;      // (a lane beyond the row reads the row's start and is masked)
+    const bool has_left = x0 > 0;                // wave-uniform, like everything below that is not named "lane"
+    const uint32_t copy = (uint32_t)lane & 3u;
+
+    UQ pp[NW][TY][4];  // d2 of the previous plane
+#pragma unroll
+    for (int lw = 0; lw < NW; lw++)
+#pragma unroll
+        for (int yy = 0; yy < TY; yy++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) pp[lw][yy][i] = 0;
+
+    for (int zz = z0 > 0 ? -1 : 0; zz < MARCH_TZ; zz++) {
+        const uint32_t gz = z0 + (uint32_t)zz;
+        if (gz >= d2) break;
+        // ---- request the plane's rows: halo row y0 - 1 (slot 0) and rows y0 .. y0 + TY - 1 (slots 1 .. TY) ----
+        Quad<T> rq[NW][TY + 1];
+        T rl[NW][TY + 1];
+        bool rok[NW][TY + 1];
+#pragma unroll
+        for (int lw = 0; lw < NW; lw++) {
+            const bool wok = w >= (uint32_t)lw;
+            const T *src = c.in + (uint64_t)(wok ? w - lw : 0) * c.vol + (uint64_t)gz * c.plane;
+#pragma unroll
+            for (int r = 0; r <= TY; r++) {
+                const uint32_t gy = y0 + (uint32_t)r - 1u;  // (r = 0 at y0 = 0 wraps: not below d1)
+                rok[lw][r] = wok && gy < d1;
+                if (rok[lw][r]) {
+                    const T *row = src + (uint64_t)gy * d0;
+                    rq[lw][r].load(row + lane_off);
+                    if (has_left) rl[lw][r] = row[x0 - 1];  // one address for the wave
+                }
+            }
+        }
+        // ---- rows ----
+        UQ pd1[NW][4];  // d1 of the previous row
+        UQ delta[4];
+        uint32_t bits_rows[(TY + 1) / 2];  // code bits of the plane's rows, two rows per register (16 bits each)
+#pragma unroll
+        for (int k = 0; k < (TY + 1) / 2; k++) bits_rows[k] = 0;
+#pragma unroll
+        for (int r = 0; r <= TY; r++) {
+            bool bad[4] = {false, false, false, false};
+#pragma unroll
+            for (int lw = 0; lw < NW; lw++) {
+                UQ d1v[4];
+                if (rok[lw][r]) {
+                    B q[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const T v = rq[lw][r].get(i);
+                        q[i] = lat.qbits(v);
+                        if (lw == 0 && r > 0 && zz >= 0) bad[i] = lat.bad(v, q[i]);
+                        if (EDGE) q[i] = xok ? q[i] : CB;
+                    }
+                    const B left0 = has_left ? lat.qbits(rl[lw][r]) : CB;  // only lane 0's copy is used
+                    UQ pv = (UQ)dpp_wave_shr1(left0, q[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        d1v[i] = (UQ)q[i] - pv;
+                        pv = (UQ)q[i];
+                    }
+                } else {  // a row outside the array: the constant C, whose differences vanish
+#pragma unroll
+                    for (int i = 0; i < 4; i++) d1v[i] = 0;
+                }
+                if (r > 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const UQ d2v = d1v[i] - pd1[lw][i];
+                        const UQ s = d2v - pp[lw][r - 1][i];
+                        pp[lw][r - 1][i] = d2v;
+                        delta[i] = lw == 0 ? s : (UQ)(delta[i] - s);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) pd1[lw][i] = d1v[i];
+            }
+            if (r == 0 || zz < 0) continue;   // halo row / halo plane: state only
+            if (!rok[0][r]) continue;          // beyond the array (EDGE bricks only)
+            // ---- codes, histogram, store ----
+            const uint64_t grow = (uint64_t)w * c.vol + (uint64_t)gz * c.plane + (uint64_t)(y0 + r - 1) * d0;  // the row's first element
+            uint32_t t[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const UQ tq = delta[i] + (UQ)127;
+                t[i] = tq <= (UQ)254 ? (uint32_t)tq : 255u;
+            }
+            const uint32_t tmax = max(max(t[0], t[1]), max(t[2], t[3]));
+            bool rare = bad[0] | bad[1] | bad[2] | bad[3] | (tmax == 255u);
+            if (EDGE) rare &= xok;
+            if (!EDGE || xok) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) atomicAdd(&c.lh[t[i] * 4u + copy], 1u);
+                *reinterpret_cast<uint32_t *>(c.codes8 + grow + x) = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
+            }
+            if (c.s_len) {
+                uint32_t b4 = (uint32_t)c.s_len[t[0]] + c.s_len[t[1]] + c.s_len[t[2]] + c.s_len[t[3]];
+                if (EDGE) b4 = xok ? b4 : 0u;
+                bits_rows[(r - 1) >> 1] |= ((r - 1) & 1) ? b4 << 16 : b4;
+            }
+            if (__builtin_amdgcn_ballot_w64(rare)) {  // some lane has outliers: rare
+                uint32_t tmask = 0, badmask = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    tmask |= (uint32_t)(rare && t[i] == 255u) << i;
+                    badmask |= (uint32_t)(rare && bad[i]) << i;
+                }
+                narrow_rare<T>(c, grow + x, delta, tmask, badmask);
+            }
+        }
+        if (c.s_len && zz >= 0) {  // the plane's segment sums: one wave reduction per pair of rows
+#pragma unroll
+            for (int k = 0; k < (TY + 1) / 2; k++) {
+                const uint32_t tot = wave_sum(bits_rows[k]);
+                const uint32_t ra = y0 + 2u * k, rb = ra + 1u;
+                if (lane == 0) {
+                    const uint64_t g0 = (uint64_t)w * c.vol + (uint64_t)gz * c.plane + x0;
+                    if (ra < d1) c.seg_bits[(g0 + (uint64_t)ra * d0) >> 8] = (uint16_t)(tot & 0xFFFFu);
+                    if (2 * k + 1 < TY && rb < d1) c.seg_bits[(g0 + (uint64_t)rb * d0) >> 8] = (uint16_t)(tot >> 16);
+                }
+            }
+        }
+    }
+}
+template <typename T, int NDIM, int TY>
+__device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t *__restrict__ codes, const szk_k1_params &p, uint32_t ntasks,
+                                             uint32_t *lh, uint8_t *s_len, uint64_t (*s_oq_idx)[MarchLds<1, false>::OQ],
+                                             typename NarrowCtx<T>::OQV (*s_oq_val)[MarchLds<1, false>::OQ]) {
+    const Lattice<T> lat(p.lat);
+    NarrowCtx<T> c;
+    c.in = in;
+    c.codes8 = reinterpret_cast<uint8_t *>(codes);
+    c.p = &p;
+    c.d0 = (uint32_t)p.d[3];
+    c.d1 = (uint32_t)p.d[2];
+    c.d2 = (uint32_t)p.d[1];
+    c.plane = (uint64_t)c.d1 * c.d0;
+    c.vol = c.plane * c.d2;
+    c.lh = lh;
+    c.lane = lane_id();
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    c.oq_idx = s_oq_idx[wv];
+    c.oq_val = s_oq_val[wv];
+    c.oq_n = 0;
+    // bit accounting: the code-length table of the context's previous book, by stored byte; only for rows cut into whole
+    // 256-element segments (x extent a multiple of 256: a segment then never straddles two chunks of the packer)
+    const bool acct = p.spec_lens != nullptr && c.d0 % MARCH_TX == 0;
+    c.s_len = acct ? s_len : nullptr;
+    c.seg_bits = p.seg_bits;
+    for (int i = threadIdx.x; i < NARROW_BINS * 4; i += 256) lh[i] = 0;
+    if (acct) {
+        const uint32_t b = threadIdx.x;  // 256 threads, 256 byte values; 255 = the delta outliers' symbol 0
+        s_len[b] = p.spec_lens[b == 255u ? 0u : b + p.radius - 127u];
+        if (blockIdx.x == 0 && threadIdx.x == 0) *p.seg_made = 1u;  // (the host assumed this form would run: k_book_verdict checks)
+    }
+    __syncthreads();
+
+    const uint32_t ntx = (c.d0 + MARCH_TX - 1) / MARCH_TX, nty = (c.d1 + TY - 1) / TY, ntz = (c.d2 + MARCH_TZ - 1) / MARCH_TZ;
+    // XCD-aware task order (see march_body)
+    const uint32_t per_xcd = gridDim.x / 8u;
+    const uint32_t wg_seq = gridDim.x % 8u == 0 && !(p.dbg & 4096u) ? (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : blockIdx.x;
+    const uint32_t nwaves = gridDim.x * 4u;
+    for (uint32_t task = wg_seq * 4 + wv; task < ntasks; task += nwaves) {
+        uint32_t b = task;
+        const uint32_t x0 = (b % ntx) * MARCH_TX;
+        b /= ntx;
+        const uint32_t y0 = (b % nty) * TY;
+        b /= nty;
+        const uint32_t z0 = (b % ntz) * MARCH_TZ;
+        const uint32_t w = b / ntz;
+        if (x0 + MARCH_TX <= c.d0 && y0 + TY <= c.d1) narrow_task<T, NDIM, TY, false>(c, lat, x0, y0, z0, w);
+        else narrow_task<T, NDIM, TY, true>(c, lat, x0, y0, z0, w);
+    }
+    narrow_oq_flush(c);
+    __syncthreads();
+    // the workgroup's counts go to its private row of hist_partial (k_hist_reduce folds the rows): bin t = symbol t + radius - 127
+    uint32_t *row = p.hist_partial + (uint64_t)blockIdx.x * HIST_WIN;
+    for (int bnn = threadIdx.x; bnn < HIST_WIN; bnn += 256) {
+        const int t = bnn - (HIST_WIN / 2 - 127);
+        row[bnn] = (t >= 0 && t < 255) ? lh[t * 4] + lh[t * 4 + 1] + lh[t * 4 + 2] + lh[t * 4 + 3] : 0u;
+    }
+}
+
 // LDS histogram. One-byte codes (narrow deltas): 1024 bins x 4 copies around the radius; two-byte codes (deltas of
 // hundreds or thousands of lattice steps, e.g. C4's 1e-6 on f64): MARCH_WIDE_WIN bins x 1 copy — with the narrow window
 // nearly every element of such a field would fall through to a global atomic. Last word = overflow bin (never flushed).
@@ -923,7 +1208,15 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
     __shared__ uint32_t lh[L::LH_WORDS + 4];
     __shared__ uint64_t s_oq_idx[4][L::OQ];
     __shared__ OQV s_oq_val[4][L::OQ];
-    march_body<T, NDIM, TY, MODE, WIN16>(in, codes, p, ntasks, nrows, lh, s_oq_idx, s_oq_val);
+    if constexpr (MODE == 1) {
+        __shared__ uint8_t s_len[256];
+        if (!szk_is_narrow(p.mode)) return;
+        march_narrow<T, NDIM, TY>(in, codes, p, ntasks, lh, s_len, reinterpret_cast<uint64_t(*)[MarchLds<1, false>::OQ]>(s_oq_idx),
+                                  reinterpret_cast<OQV(*)[MarchLds<1, false>::OQ]>(s_oq_val));
+        return;
+    } else {
+        march_body<T, NDIM, TY, MODE, WIN16>(in, codes, p, ntasks, nrows, lh, s_oq_idx, s_oq_val);
+    }
 }
 // Launched ALONE when the context's previous call chose one-byte codes: the one-byte form's LDS budget (4 waves per SIMD) and
 // its specialised code; the width is still decided by THIS call's probe — should it say two bytes after all, the same LDS
@@ -938,7 +1231,8 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march3(const T *__restric
     __shared__ uint32_t lh[L::LH_WORDS + 4];
     __shared__ uint64_t s_oq_idx[4][L::OQ];
     __shared__ OQV s_oq_val[4][L::OQ];
-    if (szk_is_narrow(p.mode)) march_body<T, NDIM, TY, 1, false>(in, codes, p, ntasks, nrows, lh, s_oq_idx, s_oq_val);
+    __shared__ uint8_t s_len[256];
+    if (szk_is_narrow(p.mode)) march_narrow<T, NDIM, TY>(in, codes, p, ntasks, lh, s_len, s_oq_idx, s_oq_val);
     else march_body<T, NDIM, TY, 4, false>(in, codes, p, ntasks, nrows, lh, s_oq_idx, s_oq_val);
 }
 
@@ -1739,9 +2033,14 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
 // PART 0: alphabets up to CB_SMALL_SYMS symbols + the outlier-list sorts; PART 1: wider alphabets. Which one applies is
 // known only on the device (k_hist_range), so both are launched and the other returns at once: the small path keeps its
 // own register allocation and instruction footprint (sharing one kernel with the wide path cost it 10 us of its 40).
-template <int PART>
-__global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restrict__ hist, szk_cb_params p) {
-    __shared__ __align__(16) uint8_t s_pool[CB_POOL_BYTES];
+// SLIM (PART 0 only, 256 threads, no outlier sorts): the same construction with LDS arrays for 256 symbols (8 KB instead of
+// 128 KB) — the speculative stage 2 runs it on a side stream beside the encoder's kernels, where a workgroup that needs most
+// of a compute unit's LDS would wait for the packer's persistent workgroups to retire.
+template <int PART, bool SLIM = false>
+__global__ __launch_bounds__(SLIM ? CB_THREADS : CB_LAUNCH) void k_codebook(const uint64_t *__restrict__ hist, szk_cb_params p) {
+    static_assert(!SLIM || PART == 0, "the slim form is the small-alphabet path");
+    constexpr uint32_t CAP = SLIM ? CB_SMALL_SYMS : CB_LDS_SYMS;  // symbols the small path's LDS arrays hold
+    __shared__ __align__(16) uint8_t s_pool[SLIM ? CAP * 28 + 256 : CB_POOL_BYTES];
     __shared__ uint32_t s_wtot[CB_THREADS / WAVE];
     __shared__ uint32_t s_over;
     __shared__ uint32_t s_first[SZH_MAX_LEN + 2], s_cnt[SZH_MAX_LEN + 2];
@@ -1750,7 +2049,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     const uint32_t t = threadIdx.x;
     if (blockIdx.x >= p.n_books) {  // the two blocks after the code books: deterministic order of the two outlier lists
         // (in the launch whose code-book path is the active one, so that they run beside it)
-        if (p.skip_sort) return;  // (speculative stage 2: k_sort_outliers did it, ahead of the packer)
+        if (SLIM || p.skip_sort) return;  // (speculative stage 2: k_sort_outliers did it, ahead of the packer)
         if ((PART == 1) != (p.range[2] > CB_SMALL_SYMS) && p.part_hint < 0) return;  // (launched alone: sorts whatever the alphabet)
         const bool d = blockIdx.x == p.n_books + 1;
         // scratch: the key tables of the batch slots 1 and 2, idle when a single code book is built (n_books <= 1)
@@ -1805,17 +2104,17 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
         p.lens[lo + i] = 0;
     }
     __syncthreads();
-    if (PART == 1) {
+    if constexpr (PART == 1) {
         codebook_wide<true>(hist, p, s_pool, lo, range, s_cnt, s_first, s_misc);
         return;
     }
     // ---------------- small alphabets: LDS-resident, 256 threads ----------------
-    uint64_t *keys = reinterpret_cast<uint64_t *>(s_pool);                          // [2048]
-    uint64_t *ifreq = keys + CB_LDS_SYMS;                                            // [2048] (u32 view in the wave merge)
-    uint16_t *pleaf = reinterpret_cast<uint16_t *>(ifreq + CB_LDS_SYMS);             // 6 x u16 [2048]
-    uint16_t *pint = pleaf + CB_LDS_SYMS, *aux = pint + CB_LDS_SYMS, *syms = aux + CB_LDS_SYMS;
-    uint16_t *aux2 = syms + CB_LDS_SYMS, *pint2 = aux2 + CB_LDS_SYMS;
-    uint16_t *cnt_tbl = pint2 + CB_LDS_SYMS;                                         // (SZH_MAX_LEN + 1) * 256 u16
+    uint64_t *keys = reinterpret_cast<uint64_t *>(s_pool);                          // [CAP]
+    uint64_t *ifreq = keys + CAP;                                                    // [CAP] (u32 view in the wave merge)
+    uint16_t *pleaf = reinterpret_cast<uint16_t *>(ifreq + CAP);                     // 6 x u16 [CAP]
+    uint16_t *pint = pleaf + CAP, *aux = pint + CAP, *syms = aux + CAP;
+    uint16_t *aux2 = syms + CAP, *pint2 = aux2 + CAP;
+    uint16_t *cnt_tbl = pint2 + CAP;  // (SZH_MAX_LEN + 1) * 256 u16 (code assignment beyond 512 symbols; slim form: the Kraft repair's few words)
     const uint32_t per = (range + CB_THREADS - 1) / CB_THREADS;
     // 1. compaction of the non-zero bins in symbol order
     uint32_t cnt = 0;
@@ -1881,7 +2180,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
             // round-parallel merge on the 256 live threads (every round pairs ALL pending items below the smallest possible
             // new node, cb_merge_rounds): ~a dozen rounds for a smooth field's 128 symbols instead of 127 dependent picks of
             // one wave (28 us of the kernel's 38 at C2)
-            uint32_t *nf32 = reinterpret_cast<uint32_t *>(ifreq), *lf32 = nf32 + CB_LDS_SYMS;
+            uint32_t *nf32 = reinterpret_cast<uint32_t *>(ifreq), *lf32 = nf32 + CAP;
             for (uint32_t q = t; q < m; q += CB_THREADS) lf32[q] = (uint32_t)(keys[q] >> 16);
             if (t < 4) s_misc[t] = 0;
             __syncthreads();
@@ -1980,6 +2279,54 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     }
 }
 
+// Short outlier lists (what smooth fields have: C2 lists 970 points) sorted by a small launch: up to SORT_SMALL records per
+// list, keys (index << 16 | arrival position) in a bitonic network in LDS, the values follow by position. A longer list
+// makes it raise *declined: the host repeats stage 2 the classic way (the code-book launch's sort blocks handle any length).
+#define SORT_SMALL 2048u
+__global__ __launch_bounds__(256) void k_sort_outliers_small(szk_cb_params p, uint32_t *declined) {
+    __shared__ uint64_t sk[SORT_SMALL];
+    __shared__ uint64_t sv[SORT_SMALL];
+    const bool d = blockIdx.x == 1;
+    uint64_t *idx = d ? p.dout_idx : p.vout_idx;
+    void *val = d ? p.dout_val : p.vout_val;
+    const bool v32 = d ? p.q_is_32bit != 0 : p.t_is_32bit != 0;
+    uint64_t n64 = d ? *p.n_dout : *p.n_vout;
+    if (n64 > p.out_cap) n64 = p.out_cap;
+    if (n64 < 2) return;
+    if (n64 > SORT_SMALL) {
+        if (threadIdx.x == 0) *declined = 1u;
+        return;
+    }
+    const uint32_t n = (uint32_t)n64;
+    uint32_t np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    for (uint32_t i = threadIdx.x; i < np2; i += 256) {
+        sk[i] = i < n ? (idx[i] << 16) | i : ~0ull;
+        if (i < n) sv[i] = v32 ? (uint64_t) reinterpret_cast<const uint32_t *>(val)[i] : reinterpret_cast<const uint64_t *>(val)[i];
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= np2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < np2; i += 256) {
+                const uint32_t x = i ^ j;
+                if (x > i) {
+                    const uint64_t a = sk[i], b = sk[x];
+                    if ((a > b) == ((i & k) == 0)) {
+                        sk[i] = b;
+                        sk[x] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint64_t k = sk[i];
+        idx[i] = k >> 16;
+        const uint64_t v = sv[(uint32_t)(k & 0xFFFFu)];
+        if (v32) reinterpret_cast<uint32_t *>(val)[i] = (uint32_t)v;
+        else reinterpret_cast<uint64_t *>(val)[i] = v;
+    }
+}
 // the outlier-list sorts as a launch of their own: the speculative stage 2 (sz3hip_api.cpp) packs with the previous call's
 // code book while this call's is being built on a side stream, and the packer's launch assembles the (sorted) lists
 __global__ __launch_bounds__(CB_LAUNCH) void k_sort_outliers(szk_cb_params p) {
@@ -1995,7 +2342,8 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_sort_outliers(szk_cb_params p) {
 __global__ __launch_bounds__(1024) void k_book_verdict(const szk_cb_info *__restrict__ used, const uint8_t *__restrict__ used_lens,
                                                        const szk_cb_info *__restrict__ fresh, const uint8_t *__restrict__ fresh_lens,
                                                        const uint32_t *__restrict__ mispredict, const uint32_t *__restrict__ range,
-                                                       szk_state *state) {
+                                                       const uint32_t *__restrict__ declined /* [0] short-list sort, [1] stage 1 made the segment sums */,
+                                                       int need_seg, szk_state *state) {
     __shared__ uint32_t s_diff;
     if (threadIdx.x == 0) s_diff = 0;
     __syncthreads();
@@ -2006,7 +2354,11 @@ __global__ __launch_bounds__(1024) void k_book_verdict(const szk_cb_info *__rest
     if (diff) s_diff = 1;
     __syncthreads();
     if (threadIdx.x == 0) {
-        state->book_miss = s_diff | *mispredict;  // (a code-book form launched alone that declined: no fresh book at all)
+        // (a code-book form launched alone that declined: no fresh book at all; a list too long for the short sort; stage 1 ran
+        // another form than the one that sums the segments' bits: the encoder's output is void in each case)
+        const uint32_t kind = (s_diff ? 1u : 0u) | (*mispredict ? 2u : 0u) | (declined[0] ? 4u : 0u) | (need_seg && !declined[1] ? 8u : 0u);
+        state->book_miss = kind != 0;
+        state->miss_kind = kind;
         state->mispredict = *mispredict;
         state->n_symbols = range[2];
     }
@@ -2077,13 +2429,13 @@ __device__ __forceinline__ void load_codes16(const uint16_t *__restrict__ codes,
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const uint32_t b = (wds[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                c[i] = (uint16_t)(b ? b + sym_add : 0u);
+                c[i] = (uint16_t)(b != 255u ? b + sym_add : 0u);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < ENC_PER_LANE; i++) {
-                const uint32_t b = (base + i < n) ? c8[base + i] : 0u;
-                c[i] = (uint16_t)(b ? b + sym_add : 0u);
+                const uint32_t b = (base + i < n) ? c8[base + i] : 255u;
+                c[i] = (uint16_t)(b != 255u ? b + sym_add : 0u);
             }
         }
         return;
@@ -2148,7 +2500,7 @@ __device__ __forceinline__ void unpack_codes(const CodeRegs &r, bool narrow, uin
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const uint32_t b = (wds[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            c[i] = (uint16_t)(b ? b + sym_add : 0u);
+            c[i] = (uint16_t)(b != 255u ? b + sym_add : 0u);
         }
     } else {
         const uint32_t wds[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
@@ -2184,7 +2536,7 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
     if (lw_lo > SZH_HIST_BINS - LEN_WIN) lw_lo = SZH_HIST_BINS - LEN_WIN;
     if (!narrow || n_full < n_chunks)  // (the ragged last chunk goes through the symbol table in both modes)
         for (uint32_t i = threadIdx.x; i < LEN_WIN; i += 256) s_lenw[i] = (uint8_t)(g_enc[lw_lo + i] & 31u);
-    if (narrow) s_len8[threadIdx.x] = (uint8_t)(g_enc[threadIdx.x ? threadIdx.x + sym_add : 0u] & 31u);
+    if (narrow) s_len8[threadIdx.x] = (uint8_t)(g_enc[threadIdx.x != 255u ? threadIdx.x + sym_add : 0u] & 31u);
     __syncthreads();
     auto len_of = [&](uint32_t sym) -> uint32_t {
         const uint32_t rel = sym - lw_lo;
@@ -2236,19 +2588,17 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
 // consecutive groups per thread and round. The encoder's call also lays the payload out (layout_pre: the
 // sections' offsets depend on the outlier counts and the alphabet, known since the code book kernel) — one launch less.
 #define SCAN_GPT 4
-__device__ void scan_groups_body(const uint16_t *__restrict__ chunk_words, uint64_t n_chunks, uint64_t *__restrict__ group_off,
-                                 uint64_t *total_words);
-__global__ __launch_bounds__(1024) void k_scan_groups(const uint16_t *__restrict__ chunk_words, uint64_t n_chunks,
-                                                      uint64_t *__restrict__ group_off, uint64_t *total_words,
-                                                      szk_layout_params lp, int do_layout) {
-    if (do_layout && threadIdx.x == 1023) layout_pre(lp);
-    scan_groups_body(chunk_words, n_chunks, group_off, total_words);
-}
-__device__ void scan_groups_body(const uint16_t *__restrict__ chunk_words, uint64_t n_chunks, uint64_t *__restrict__ group_off,
-                                 uint64_t *total_words) {
+// seg_bits != nullptr: stage 1 summed the code bits of every 256-element row segment (march_narrow); a chunk is four
+// consecutive segments. This kernel then also writes the chunks' word counts (the bits pass of the encoder is not launched).
+// *seg_made == 0 (stage 1 ran another form than the host assumed): all counts are taken as zero — the packer's output is
+// thrown away anyway (k_book_verdict reports a miss), it only must stay inside the payload.
+template <bool SEG>
+__device__ void scan_groups_body(uint16_t *__restrict__ chunk_words, uint64_t n_chunks, uint64_t *__restrict__ group_off,
+                                 uint64_t *total_words, const uint16_t *__restrict__ seg_bits, uint64_t n_segs, const uint32_t *seg_made) {
     __shared__ uint64_t s_w[16];
     __shared__ uint64_t s_carry;
     const uint64_t n_groups = (n_chunks + PACK_GROUP - 1) / PACK_GROUP;
+    const bool seg_ok = SEG ? *seg_made != 0 : false;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     for (uint64_t g0 = 0; g0 < n_groups; g0 += 1024 * SCAN_GPT) {
@@ -2260,7 +2610,34 @@ __device__ void scan_groups_body(const uint16_t *__restrict__ chunk_words, uint6
             sum[j] = 0;
             if (g < n_groups) {
                 const uint64_t c0 = g * PACK_GROUP;
-                if (c0 + PACK_GROUP <= n_chunks) {  // 32 x u16 = four 16-byte loads
+                if (SEG) {
+                    if (c0 + PACK_GROUP <= n_chunks && (c0 + PACK_GROUP) * 4 <= n_segs) {  // 128 x u16 in, 32 x u16 out
+                        const uint4 *v = reinterpret_cast<const uint4 *>(seg_bits + c0 * 4);
+                        uint4 *o = reinterpret_cast<uint4 *>(chunk_words + c0);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {  // four loads = 32 segments = 8 chunks -> one 16-byte store
+                            uint32_t cw[8];
+#pragma unroll
+                            for (int h = 0; h < 4; h++) {
+                                const uint4 q = v[4 * k + h];  // 8 segments = 2 chunks
+                                const uint32_t b0 = (q.x & 0xFFFF) + (q.x >> 16) + (q.y & 0xFFFF) + (q.y >> 16);
+                                const uint32_t b1 = (q.z & 0xFFFF) + (q.z >> 16) + (q.w & 0xFFFF) + (q.w >> 16);
+                                cw[2 * h] = seg_ok ? (b0 + 31u) >> 5 : 0u;
+                                cw[2 * h + 1] = seg_ok ? (b1 + 31u) >> 5 : 0u;
+                                sum[j] += cw[2 * h] + cw[2 * h + 1];
+                            }
+                            o[k] = make_uint4(cw[0] | (cw[1] << 16), cw[2] | (cw[3] << 16), cw[4] | (cw[5] << 16), cw[6] | (cw[7] << 16));
+                        }
+                    } else {
+                        for (uint64_t c = c0; c < n_chunks && c < c0 + PACK_GROUP; c++) {
+                            uint32_t b = 0;
+                            for (uint64_t sg = c * 4; sg < c * 4 + 4 && sg < n_segs; sg++) b += seg_bits[sg];
+                            const uint32_t cw = seg_ok ? (b + 31u) >> 5 : 0u;
+                            chunk_words[c] = (uint16_t)cw;
+                            sum[j] += cw;
+                        }
+                    }
+                } else if (c0 + PACK_GROUP <= n_chunks) {  // 32 x u16 = four 16-byte loads
                     const uint4 *v = reinterpret_cast<const uint4 *>(chunk_words + c0);
                     uint4 q[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
@@ -2293,6 +2670,14 @@ __device__ void scan_groups_body(const uint16_t *__restrict__ chunk_words, uint6
         __syncthreads();
     }
     if (threadIdx.x == 0) *total_words = s_carry;
+}
+__global__ __launch_bounds__(1024) void k_scan_groups(uint16_t *__restrict__ chunk_words, uint64_t n_chunks,
+                                                      uint64_t *__restrict__ group_off, uint64_t *total_words,
+                                                      szk_layout_params lp, int do_layout, const uint16_t *__restrict__ seg_bits, uint64_t n_segs,
+                                                      const uint32_t *seg_made) {
+    if (do_layout && threadIdx.x == 1023) layout_pre(lp);
+    if (seg_bits) scan_groups_body<true>(chunk_words, n_chunks, group_off, total_words, seg_bits, n_segs, seg_made);
+    else scan_groups_body<false>(chunk_words, n_chunks, group_off, total_words, nullptr, 0, nullptr);
 }
 
 // pack 16 symbols of a lane into the wave's LDS stage at the lane's bit offset; returns the chunk's word count.
@@ -2385,7 +2770,7 @@ __device__ void assemble_body(const szk_asm_params &p, uint64_t tid, uint64_t nt
         p.state->cap_exceeded = oo.end > p.cap;
         for (int i = 0; i < 6; i++) p.state->probe[i] = reinterpret_cast<const uint32_t *>(p.n_vout + 4)[i];
         p.state->mispredict = (uint32_t)p.n_vout[7];                                  // (d_counters[7]: raised by a code-book form launched alone)
-        p.state->book_miss = 0;                                                       // (speculative stage 2: k_book_verdict rewrites the three)
+        p.state->book_miss = p.state->miss_kind = 0;                                  // (speculative stage 2: k_book_verdict rewrites these)
         p.state->n_symbols = reinterpret_cast<const uint32_t *>(p.n_vout + 8)[2];   // (the range words: number of non-empty bins)
         // alignment gaps between the sections are part of the payload: zero them so that it is a pure function of the input
         const uint64_t tsz0 = h.dtype == 0 ? 4 : 8;
@@ -2498,7 +2883,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         for (uint32_t i = threadIdx.x; i < WIN; i += 256) s_enc[i] = g_enc[sym_min + i];
     }
     if (narrow) {
-        const uint32_t e = g_enc[threadIdx.x ? threadIdx.x + sym_add : 0u];
+        const uint32_t e = g_enc[threadIdx.x != 255u ? threadIdx.x + sym_add : 0u];
         s_enc8[threadIdx.x] = e >> 5;
         s_plen8[threadIdx.x] = (uint8_t)(e & 31u);
     }
@@ -2565,7 +2950,7 @@ __global__ __launch_bounds__(1024) void k_dec_tables(const uint8_t *__restrict__
                                                      const uint16_t *__restrict__ chunk_words, uint64_t n_chunks, uint64_t *group_off,
                                                      uint64_t *total_words) {
     if (blockIdx.x == 1) {  // the decoder's other preparation, beside the tables: word offsets of the chunk groups
-        scan_groups_body(chunk_words, n_chunks, group_off, total_words);
+        scan_groups_body<false>(const_cast<uint16_t *>(chunk_words), n_chunks, group_off, total_words, nullptr, 0, nullptr);
         return;
     }
     if (zero_word && threadIdx.x == 0) *zero_word = 0;  // (the decoder's overflow flag of a half-width chain)
@@ -3362,8 +3747,9 @@ static uint32_t k1_grid(const void *kernel, uint64_t ntiles) {
 // the marching kernel + histogram fold. When one-byte codes are possible both specialisations are launched with the same
 // grid (= rows of the fold); the one the probe did not choose returns at once.
 template <typename T, int NDIM, int TY, bool WIN16>
-static void launch_march_w(const void *d_in, uint16_t *codes, const szk_k1_params &p, uint64_t nb, hipStream_t s) {
+static void launch_march_w(const void *d_in, uint16_t *codes, szk_k1_params &p, uint64_t nb, hipStream_t s) {
     uint32_t grid;
+    p.seg_expected = 0;
     if (p.prof_ev0) (void)hipEventRecord((hipEvent_t)p.prof_ev0, s);
     if (p.mode.allow && !(szk_dbg_flags & 256) && p.hint_narrow > 0 && !(szk_dbg_flags & 131072)) {
         // the context's previous call took one-byte codes: one launch of the form built around them (it decides the width from
@@ -3371,6 +3757,7 @@ static void launch_march_w(const void *d_in, uint16_t *codes, const szk_k1_param
         // call: the run-time-width form is a third slower on two-byte codes (574 vs 363 us at C4's slab) than the specialised one
         // plus the 4 us of its returning twin.
         grid = k1_grid((const void *)k_lorenzo_quant_march3<T, NDIM, TY>, (nb + 3) / 4);
+        p.seg_expected = p.spec_lens && p.d[3] % MARCH_TX == 0;
         hipLaunchKernelGGL((k_lorenzo_quant_march3<T, NDIM, TY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
     } else if (p.mode.allow && !(szk_dbg_flags & 256)) {
         // (first call of a context) each specialisation gets the grid its own occupancy allows (all workgroups resident: the tasks are dealt by stride;
@@ -3379,6 +3766,7 @@ static void launch_march_w(const void *d_in, uint16_t *codes, const szk_k1_param
         const uint32_t g1 = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 1, false>, (nb + 3) / 4);
         const uint32_t g2 = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 2, WIN16>, (nb + 3) / 4);
         grid = g1 > g2 ? g1 : g2;
+        p.seg_expected = p.spec_lens && p.d[3] % MARCH_TX == 0;
         hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 1, false>), dim3(g1), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
         hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 2, WIN16>), dim3(g2), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
     } else {
@@ -3386,12 +3774,13 @@ static void launch_march_w(const void *d_in, uint16_t *codes, const szk_k1_param
         hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 0, WIN16>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
     }
     if (p.prof_ev1) (void)hipEventRecord((hipEvent_t)p.prof_ev1, s);
-    hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist, p.range);
+    p.fold_rows = grid;
+    if (!p.defer_fold) hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist, p.range);
 }
 // the marching kernel + histogram fold. When one-byte codes are possible both specialisations are launched (the one the
 // probe did not choose returns at once); the two-byte one with the LDS window the context asks for (szk_k1_params::wide16)
 template <typename T, int NDIM, int TY>
-static void launch_march(const void *d_in, uint16_t *codes, const szk_k1_params &p, uint64_t nb, hipStream_t s) {
+static void launch_march(const void *d_in, uint16_t *codes, szk_k1_params &p, uint64_t nb, hipStream_t s) {
     if (p.wide16) launch_march_w<T, NDIM, TY, true>(d_in, codes, p, nb, s);
     else launch_march_w<T, NDIM, TY, false>(d_in, codes, p, nb, s);
 }
@@ -3413,6 +3802,8 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
     const bool march12 = !szk_force_generic && !(szk_dbg_flags & 32) && (ndim == 1 || ndim == 2) && d0 % 4 == 0 && d0 >= 128 &&
                          d0 < (1ull << 31) && d1 < (1ull << 31) && tiles(MARCH_TX, ndim == 1 ? 1 : MTY, MARCH_TZ) < (1ull << 31);
     if (!march && !march12) p.mode.allow = 0;
+    p.fold_rows = 0;
+    p.seg_expected = 0;
     // (the range words are kept by the one-launch form only: launch_march_w's first branch, same condition)
     p.range_kept = (march || march12) && p.range && p.mode.allow && !(szk_dbg_flags & 256) && p.hint_narrow > 0 && !(szk_dbg_flags & 131072) ? 1 : 0;
     if (!p.range_kept) p.range = nullptr;
@@ -3510,33 +3901,42 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
     if (!p->range_ready) hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256, nb), dim3(256), 0, s, d_hist, q.range);
     // which of the two forms applies is known on the device only; a context that remembers the previous call's alphabet
     // launches that form alone (solo): the kernel raises `mispredict` when it is the wrong one and the host repeats stage 2
-    if (p->part_hint != 1) hipLaunchKernelGGL(k_codebook<0>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
+    if (p->part_hint == 0 && p->slim && nb == 1) hipLaunchKernelGGL((k_codebook<0, true>), dim3(1), dim3(CB_THREADS), 0, s, d_hist, q);
+    else if (p->part_hint != 1) hipLaunchKernelGGL(k_codebook<0>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
     if (p->part_hint != 0) hipLaunchKernelGGL(k_codebook<1>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
     SZK_CHECK_LAUNCH();
     return 0;
 }
-int szk_launch_sort_outliers(const szk_cb_params *p, hipStream_t s) {
-    hipLaunchKernelGGL(k_sort_outliers, dim3(2), dim3(CB_LAUNCH), 0, s, *p);
+int szk_launch_sort_outliers(const szk_cb_params *p, uint32_t *declined, hipStream_t s) {
+    if (declined) hipLaunchKernelGGL(k_sort_outliers_small, dim3(2), dim3(256), 0, s, *p, declined);
+    else hipLaunchKernelGGL(k_sort_outliers, dim3(2), dim3(CB_LAUNCH), 0, s, *p);
     SZK_CHECK_LAUNCH();
     return 0;
 }
 int szk_launch_book_verdict(const szk_cb_info *used, const uint8_t *used_lens, const szk_cb_info *fresh, const uint8_t *fresh_lens,
-                            const uint32_t *mispredict, const uint32_t *range, szk_state *state, hipStream_t s) {
-    hipLaunchKernelGGL(k_book_verdict, dim3(1), dim3(1024), 0, s, used, used_lens, fresh, fresh_lens, mispredict, range, state);
+                            const uint32_t *mispredict, const uint32_t *range, const uint32_t *declined, int need_seg, szk_state *state, hipStream_t s) {
+    hipLaunchKernelGGL(k_book_verdict, dim3(1), dim3(1024), 0, s, used, used_lens, fresh, fresh_lens, mispredict, range, declined, need_seg, state);
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
+int szk_launch_hist_fold(const uint32_t *partial, uint32_t nrows, int radius, uint64_t *hist, uint32_t *range, hipStream_t s) {
+    hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, partial, nrows, radius - HIST_WIN / 2, hist, range);
     SZK_CHECK_LAUNCH();
     return 0;
 }
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
                       szk_mode mode, uint16_t *chunk_words, uint64_t *group_off, uint64_t *total_words,
                       const szk_state *state, uint8_t *payload, const szk_layout_params *layout, const szk_asm_params *asmp, hipStream_t s,
-                      hipEvent_t lists_sorted) {
+                      hipEvent_t lists_sorted, const uint16_t *seg_bits, const uint32_t *seg_made) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
     const uint64_t nb = (n_chunks + 3) / 4;
     if (nb > 0x7FFFFFFFull) return -1;
-    const uint32_t sym_add = (uint32_t)radius - 128u;
+    const uint32_t sym_add = (uint32_t)radius - 127u;  // one-byte codes: stored byte t = delta + 127 (255: delta outlier, symbol 0) -> symbol t + sym_add
     const uint32_t pgrid = (uint32_t)(nb < 2048 ? nb : 2048);  // persistent: 8 workgroups per CU
-    hipLaunchKernelGGL(k_chunk_bits2, dim3(pgrid), dim3(256), 0, s, codes, n, d_enc, info, mode, sym_add, chunk_words);
-    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, chunk_words, n_chunks, group_off, total_words, *layout, 1);
+    // (seg_bits: stage 1 summed the code bits per 256-element segment with the book the encoder uses: no bits pass)
+    if (!seg_bits) hipLaunchKernelGGL(k_chunk_bits2, dim3(pgrid), dim3(256), 0, s, codes, n, d_enc, info, mode, sym_add, chunk_words);
+    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, chunk_words, n_chunks, group_off, total_words, *layout, 1, seg_bits,
+                       (uint64_t)((n + 255) / 256), seg_made);
     // (speculative stage 2: the outlier lists are being sorted on a side stream; the packer's launch copies them)
     if (lists_sorted && hipStreamWaitEvent(s, lists_sorted, 0) != hipSuccess) return -2;
     constexpr uint32_t ASM_BLOCKS = 32;

@@ -18,6 +18,8 @@ def dualquant(a, eb, radius=32768, narrow=False):
     a = np.ascontiguousarray(a)
     T = a.dtype
     # lattice arithmetic in the data type (sz3hip_kernels.hip, Lattice<T>): one rounding per multiply, no FMA
+    # rint through the magic number (Lattice<T> in sz3hip_devutil.h): the bit pattern of fl(fl(a * recip) + M) is C + rint(a * recip)
+    # for |.| <= LIM; it is clamped as an integer (values beyond the lattice and Inf sit at its ends, NaN at the end its sign names)
     if T == np.float32:
         qt = np.int32
         recip = np.float32(1.0 / (2.0 * eb))
@@ -25,21 +27,21 @@ def dualquant(a, eb, radius=32768, narrow=False):
         eb_lo = np.float32(eb)
         if float(eb_lo) > eb:
             eb_lo = np.nextafter(eb_lo, np.float32(0))
-        lim = np.float32(8388608.0)
+        magic, cbits, lim = np.float32(12582912.0), 0x4B400000, 1 << 22
     else:
         qt = np.int64
         recip = 1.0 / (2.0 * eb)
         two_eb = 2.0 * eb
         eb_lo = eb
-        lim = 4503599627370496.0
+        magic, cbits, lim = np.float64(6755399441055744.0), 0x4338000000000000, 1 << 51
     with np.errstate(invalid="ignore", over="ignore"):
-        s = a * recip
-        ok = np.abs(s) < lim
-        r = np.rint(np.where(ok, s, 0)).astype(T)
-        q = r.astype(qt)
+        tm = (a * recip).astype(T) + magic
+        bits = np.clip(tm.astype(T).view(qt), cbits - lim, cbits + lim)
+        q = (bits - cbits).astype(qt)
+        r = q.astype(T)
         dec = r * two_eb
         diff = np.abs(dec - a)
-        bad = ~ok | ~(diff <= eb_lo)
+        bad = ~(diff <= eb_lo)
     # N-d Lorenzo = successive first differences with zero halo, wrap-around integer arithmetic
     d = q.copy()
     for ax in range(a.ndim):

@@ -1126,7 +1126,27 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     szk_cb_params cb;
     cb_params_from(ctx, cb, ctx->cur_out_cap, fresh);
     hipStream_t bs = s;  // the stream the book is built on
-    if (how == S2_SPEC) {
+    // Small alphabets with short outlier lists (what the previous call had): this call's book, the verdict and the list sorts
+    // ride in the packer's own launch as three role workgroups, the fold of stage 1's histogram rows in the scan's launch —
+    // one stream, two launches. Otherwise the book is built on a side stream (wide alphabets need a whole compute unit's LDS).
+    const bool fused = how == S2_SPEC && ctx->cb_hint == 0 && !ctx->lists_long && cb.range_ready && !(szk_dbg_flags & 67108864);
+    szk_encode_roles er;
+    memset(&er, 0, sizeof(er));
+    if (fused) {
+        cb.part_hint = 0;
+        er.roles = 1;
+        er.hist = ctx->d_hist;
+        er.cb = &cb;
+        er.used_lens = ctx->bk[used].lens;
+        er.flags = reinterpret_cast<uint32_t *>(ctx->d_counters + 10);
+        if (ctx->fold_rows) {
+            er.fold_partial = ctx->d_hist_partial;
+            er.fold_rows = ctx->fold_rows;
+            er.fold_hist = ctx->d_hist;
+            er.fold_range = ctx->fold_range;
+            ctx->fold_rows = 0;
+        }
+    } else if (how == S2_SPEC) {
         int rcs = ensure_side(ctx);
         if (rcs) return rcs;
         bs = ctx->side;
@@ -1137,7 +1157,9 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
                 return fail(SZ3HIP_EHIP, "histogram fold launch failed");
             ctx->fold_rows = 0;
         }
-        if (szk_launch_sort_outliers(&cb, reinterpret_cast<uint32_t *>(ctx->d_counters + 10), bs)) return fail(SZ3HIP_EHIP, "outlier sort launch failed");
+        // (the short-list form unless the previous call's lists were long: it declines a long list, which costs a repeat of stage 2)
+        if (szk_launch_sort_outliers(&cb, ctx->lists_long ? nullptr : reinterpret_cast<uint32_t *>(ctx->d_counters + 10), bs))
+            return fail(SZ3HIP_EHIP, "outlier sort launch failed");
         HIPCHK(hipEventRecord(ctx->ev_sorted, bs));
         cb.skip_sort = 1;
         cb.slim = 1;
@@ -1146,7 +1168,7 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
             return fail(SZ3HIP_EHIP, "histogram fold launch failed");
         ctx->fold_rows = 0;
     }
-    if (how != S2_REENCODE) {
+    if (how != S2_REENCODE && !fused) {
         if (ctx->range_ready && !cb.range_ready)  // stage 1 kept the range of the LOCAL histogram, the caller then changed it (all-reduce):
             HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, 16, bs));  // k_hist_range starts from zero
         prof_begin(ctx, ST_CODEBOOK, bs);
@@ -1164,6 +1186,7 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     lp.state = ctx->d_state;
     lp.side_bytes = ctx->proto.predictor == 2 ? ctx->d_blk_counters + 2 : nullptr;
     szk_asm_params ap;
+    memset(&ap, 0, sizeof(ap));
     ap.n_vout = ctx->d_counters + 0;
     ap.n_dout = ctx->d_counters + 1;
     ap.out_cap = ctx->cur_out_cap;
@@ -1182,11 +1205,11 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     prof_begin(ctx, ST_ENCODE, s);  // (the payload layout is computed inside the encoder's scan launch, the sections are assembled by the packer's)
     int rc = szk_launch_encode(ctx->d_codes, n, ctx->bk[used].enc, ctx->bk[used].info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words,
                                ctx->d_chunk_off, ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, &lp, &ap, s,
-                               how == S2_SPEC ? ctx->ev_sorted : nullptr, how == S2_SPEC && ctx->seg_expected ? ctx->d_seg_bits : nullptr,
-                               reinterpret_cast<uint32_t *>(ctx->d_counters + 10) + 1);
+                               how == S2_SPEC && !fused ? ctx->ev_sorted : nullptr, how == S2_SPEC && ctx->seg_expected ? ctx->d_seg_bits : nullptr,
+                               reinterpret_cast<uint32_t *>(ctx->d_counters + 10) + 1, fused ? &er : nullptr);
     prof_end(ctx, ST_ENCODE, s);
     if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
-    if (how == S2_SPEC) {
+    if (how == S2_SPEC && !fused) {
         HIPCHK(hipStreamWaitEvent(s, ctx->ev_book, 0));
         if (szk_launch_book_verdict(ctx->bk[used].info, ctx->bk[used].lens, ctx->bk[fresh].info, ctx->bk[fresh].lens,
                                     reinterpret_cast<uint32_t *>(ctx->d_counters + 7), reinterpret_cast<uint32_t *>(ctx->d_counters + 8),
@@ -1205,7 +1228,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     if (!ctx->stage2_done) return fail(SZ3HIP_EINVAL, "finish called before stage2");
     HIPCHK(hipStreamSynchronize(s));
     if (ctx->s2_spec) {
-        if (ctx->h_state->book_miss) {
+        if (ctx->h_state->book_miss || ctx->h_state->miss_kind) {
             // the previous call's book is not this call's: the encoder once more, with the book the side stream built from this
             // call's histogram (or, when the code-book form launched alone declined the alphabet, the whole of stage 2)
             ctx->spec_misses++;
@@ -1240,6 +1263,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     ctx->book_idx = ctx->book_pending;
     ctx->book_pred = st.hdr.predictor;
     ctx->book_radius = st.hdr.radius;
+    ctx->lists_long = st.hdr.n_vout > 2048 || st.hdr.n_dout > 2048;
     ctx->cb_hint = st.n_symbols > SZK_CB_SMALL_SYMS ? 1 : 0;
     if (st.hdr.predictor == 2) ctx->blk_wide = st.hdr.sym_count > 3000 ? 1 : 0;  // the block kernels' LDS histogram window of the next call
     ctx->stats.n = st.hdr.n;
@@ -1355,6 +1379,7 @@ extern "C" void sz3hip_ctx_forget(sz3hip_ctx *ctx) {
     ctx->pack_wide = ctx->hist_big = ctx->hist_tail = ctx->blk_wide = 0;
     ctx->spec_valid = false;
     ctx->book_idx = -1;
+    ctx->lists_long = false;
     ctx->half_skip = 0;
 }
 // speculation off (1) / on (0) for this context: with it off every stage 2 builds its code book before it encodes

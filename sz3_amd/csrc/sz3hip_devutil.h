@@ -81,9 +81,9 @@ template <> struct QTraits<double> {
 //
 // Rounding goes through the "magic number" M = 1.5 * 2^(mantissa bits): fl(s + M) has the integer rint(s) in its low
 // mantissa bits for |s| <= LIM = 2^(mantissa bits - 1), so the BIT PATTERN of s + M is C + rint(s) (C = bits of M) — no
-// rounding instruction, no float-to-integer conversion, and r = fl(s + M) - M is rint(s) as a float again (exact). The bit
-// pattern is clamped to [C - LIM, C + LIM] as an integer: values beyond the lattice (|x| > LIM * 2eb, +-Inf) sit at its ends,
-// NaN at the end its sign bit names; their reconstruction fails the check unless it really is within the bound.
+// rounding instruction, no float-to-integer conversion, and r = fl(s + M) - M is rint(s) as a float again (exact). Values
+// beyond the lattice (|x / 2eb| > LIM: fill values like 1e35, +-Inf) and NaN take q = 0 — like a neighbour outside the array,
+// so that the points around a masked region still predict sanely; their reconstruction fails the check: raw value kept.
 // `qbits` returns that offset pattern: the stencils difference it as it is (the offset cancels; a neighbour outside the
 // array is C), which saves the subtraction too.
 template <typename T> struct Lattice;
@@ -93,9 +93,9 @@ template <> struct Lattice<float> {
     float recip, two_eb, eb_lo;  // (float)(1/(2eb)), (float)(2eb), largest float <= eb
     __device__ __forceinline__ explicit Lattice(const szk_lattice &l) : recip(l.recip_f), two_eb(l.two_eb_f), eb_lo(l.eb_lo_f) {}
     __device__ __forceinline__ B qbits(float x) const {
-        const float tm = x * recip + 12582912.0f;  // two roundings (-ffp-contract=off)
-        const B b = __float_as_int(tm);
-        return min(max(b, C - LIM), C + LIM);
+        const float s = x * recip;
+        const float tm = s + 12582912.0f;  // (two roundings: -ffp-contract=off)
+        return fabsf(s) <= 4194304.0f ? __float_as_int(tm) : C;  // beyond the lattice, Inf, NaN: 0, so that neighbours still predict sanely
     }
     __device__ __forceinline__ float rounded(B bits) const { return __int_as_float(bits) - 12582912.0f; }  // rint(s) as a float
     __device__ __forceinline__ bool bad(float x, B bits) const { return !(fabsf(rounded(bits) * two_eb - x) <= eb_lo); }
@@ -112,9 +112,9 @@ template <> struct Lattice<double> {
     double recip, two_eb, eb;
     __device__ __forceinline__ explicit Lattice(const szk_lattice &l) : recip(l.recip), two_eb(l.two_eb), eb(l.eb) {}
     __device__ __forceinline__ B qbits(double x) const {
-        const double tm = x * recip + 6755399441055744.0;
-        const B b = __double_as_longlong(tm);
-        return min(max(b, C - LIM), C + LIM);
+        const double s = x * recip;
+        const double tm = s + 6755399441055744.0;
+        return fabs(s) <= 2251799813685248.0 ? __double_as_longlong(tm) : C;
     }
     __device__ __forceinline__ double rounded(B bits) const { return __longlong_as_double(bits) - 6755399441055744.0; }
     __device__ __forceinline__ bool bad(double x, B bits) const { return !(fabs(rounded(bits) * two_eb - x) <= eb); }

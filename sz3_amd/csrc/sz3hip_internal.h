@@ -69,6 +69,7 @@ struct sz3hip_ctx {
     int book_idx, book_pending;
     uint32_t book_pred, book_radius;  // what bk[book_idx] was built for
     bool s2_spec;                     // the pending stage 2 ran speculatively
+    bool lists_long;                  // the previous call listed more than 2048 outliers: the speculative stage 2 takes the any-length sort
     int spec_off;                     // test / bench hook: never speculate (every call behaves like a context's first)
     uint32_t spec_hits, spec_misses;  // statistics (sz3hip_get_spec_stats)
     hipEvent_t ev_sorted, ev_book;

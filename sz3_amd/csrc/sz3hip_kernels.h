@@ -133,6 +133,20 @@ struct szk_asm_params {
     const uint64_t *vout_idx, *dout_idx;
     const void *vout_val, *dout_val;
     const uint8_t *side;  // predictor 2: the side section as the block kernels left it (else nullptr)
+    int lists_by_roles;   // the outlier lists are sorted AND copied by role workgroups of the packer's launch (speculative stage 2)
+};
+// speculative stage 2, small alphabets: work that rides in the encoder's two launches instead of a side stream
+struct szk_encode_roles {
+    int roles;                  // the packer's launch carries the book role (this call's code book + the verdict) and the two sort roles
+    const uint64_t *hist;
+    const szk_cb_params *cb;    // this call's book: fresh slot, part_hint = 0, range words ready
+    const uint8_t *used_lens;   // code lengths of the book the packer runs with
+    uint32_t *flags;            // [1]: stage 1 summed the segments' bits (device flag)
+    // fold of stage 1's histogram rows in the scan's launch (fold_rows != 0)
+    const uint32_t *fold_partial;
+    uint32_t fold_rows;
+    uint64_t *fold_hist;
+    uint32_t *fold_range;
 };
 
 #define DEC_LUT_BITS 12u
@@ -265,7 +279,8 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
                       const szk_asm_params *asmp /* non-null: the packer's launch also assembles the payload (no szk_launch_assemble) */, hipStream_t s,
                       hipEvent_t lists_sorted = nullptr /* non-null: the packer's launch waits for it (outlier lists sorted on a side stream) */,
                       const uint16_t *seg_bits = nullptr /* non-null: code bits per 256-element segment, summed by stage 1 (no bits pass) */,
-                      const uint32_t *seg_made = nullptr /* device flag: stage 1 really made them */);
+                      const uint32_t *seg_made = nullptr /* device flag: stage 1 really made them */,
+                      const szk_encode_roles *roles = nullptr);
 // declined != nullptr: the short-list form (raises *declined on a list of more than 2048 records); else any length
 int szk_launch_sort_outliers(const szk_cb_params *p, uint32_t *declined, hipStream_t s);
 // compares the code book the encoder used with the one built from this call's histogram; writes state->book_miss / mispredict / n_symbols

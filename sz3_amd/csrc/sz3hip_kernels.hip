@@ -625,7 +625,9 @@ __global__ __launch_bounds__(256) void k_probe(const T *__restrict__ in, szk_k1_
 // hist_partial (see k_hist_reduce).
 // ------------------------------------------------------------------------------------------------------------
 #define MARCH_TX 256
+#ifndef MARCH_TZ
 #define MARCH_TZ 16
+#endif
 
 __device__ __forceinline__ int32_t dpp_wave_shr1(int32_t old, int32_t src) {  // lane l <- lane l-1 across the wave
     return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false);
@@ -1001,6 +1003,15 @@ __device__ __forceinline__ void narrow_rare(NarrowCtx<T> &c, uint64_t gi, const 
         if (zm && c.lane == __ffsll((long long)zm) - 1) hist_add_ranged(p.hist, p.range, 0u, (unsigned long long)__popcll(zm));
     }
 }
+// one plane's rows as they come back from memory: halo row y0 - 1 (slot 0) and rows y0 .. y0 + TY - 1 (slots 1 .. TY)
+template <typename T, int NW, int TY> struct NarrowPlane {
+    Quad<T> rq[NW][TY + 1];
+    T rl[NW][TY + 1];      // the element left of the brick (one address for the wave; only lane 0's copy is used)
+    bool rok[NW][TY + 1];  // the row exists (wave-uniform)
+};
+#ifndef NARROW_PF
+#define NARROW_PF 0  // 1: the next plane's rows are requested before the current plane is worked (two sets of row registers; measured slower: 161 vs 149 us)
+#endif
 template <typename T, int NDIM, int TY, bool EDGE>
 __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &lat, uint32_t x0, uint32_t y0, uint32_t z0, uint32_t w) {
     using B = typename Lattice<T>::B;
@@ -1012,7 +1023,11 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
     const uint32_t x = x0 + 4u * (uint32_t)lane;
     const bool xok = EDGE ? x < d0 : true;       // quad granular (d0 % 4 == 0)
     const uint32_t lane_off = xok ? x : 0u;      // (a lane beyond the row reads the row's start and is masked)
+#if defined(LAB_MODE) && LAB_MODE == 2
+    const bool has_left = false;  // (lab: no left-neighbour loads: wrong at tile seams)
+#else
     const bool has_left = x0 > 0;                // wave-uniform, like everything below that is not named "lane"
+#endif
     const uint32_t copy = (uint32_t)lane & 3u;
 
     UQ pp[NW][TY][4];  // d2 of the previous plane
@@ -1023,13 +1038,8 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
 #pragma unroll
             for (int i = 0; i < 4; i++) pp[lw][yy][i] = 0;
 
-    for (int zz = z0 > 0 ? -1 : 0; zz < MARCH_TZ; zz++) {
+    auto fetch = [&](int zz, NarrowPlane<T, NW, TY> &R) {
         const uint32_t gz = z0 + (uint32_t)zz;
-        if (gz >= d2) break;
-        // ---- request the plane's rows: halo row y0 - 1 (slot 0) and rows y0 .. y0 + TY - 1 (slots 1 .. TY) ----
-        Quad<T> rq[NW][TY + 1];
-        T rl[NW][TY + 1];
-        bool rok[NW][TY + 1];
 #pragma unroll
         for (int lw = 0; lw < NW; lw++) {
             const bool wok = w >= (uint32_t)lw;
@@ -1037,15 +1047,34 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
 #pragma unroll
             for (int r = 0; r <= TY; r++) {
                 const uint32_t gy = y0 + (uint32_t)r - 1u;  // (r = 0 at y0 = 0 wraps: not below d1)
-                rok[lw][r] = wok && gy < d1;
-                if (rok[lw][r]) {
+                R.rok[lw][r] = wok && gy < d1;
+                if (R.rok[lw][r]) {
                     const T *row = src + (uint64_t)gy * d0;
-                    rq[lw][r].load(row + lane_off);
-                    if (has_left) rl[lw][r] = row[x0 - 1];  // one address for the wave
+                    R.rq[lw][r].load(row + lane_off);
+                    if (has_left) R.rl[lw][r] = row[x0 - 1];
                 }
             }
         }
-        // ---- rows ----
+    };
+    auto work = [&](int zz, const NarrowPlane<T, NW, TY> &R) {
+        const uint32_t gz = z0 + (uint32_t)zz;
+#if defined(LAB_MODE) && LAB_MODE == 1  // (lab: the kernel's loads and stores alone — what its access pattern gets from the memory system)
+        if (zz >= 0) {
+#pragma unroll
+            for (int r = 1; r <= TY; r++) {
+                if (!R.rok[0][r]) continue;
+                uint32_t acc = 0;
+#pragma unroll
+                for (int lw = 0; lw < NW; lw++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc += (uint32_t)lat.qbits(R.rq[lw][r].get(i)) + (has_left ? (uint32_t)lat.qbits(R.rl[lw][r]) : 0u);
+                if (r == 1 && R.rok[0][0]) acc += (uint32_t)lat.qbits(R.rq[0][0].get(0));
+                const uint64_t grow = (uint64_t)w * c.vol + (uint64_t)gz * c.plane + (uint64_t)(y0 + r - 1) * d0;
+                if (!EDGE || xok) *reinterpret_cast<uint32_t *>(c.codes8 + grow + x) = acc;
+            }
+        }
+        return;
+#endif
         UQ pd1[NW][4];  // d1 of the previous row
         UQ delta[4];
         uint32_t bits_rows[(TY + 1) / 2];  // code bits of the plane's rows, two rows per register (16 bits each)
@@ -1057,16 +1086,16 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
 #pragma unroll
             for (int lw = 0; lw < NW; lw++) {
                 UQ d1v[4];
-                if (rok[lw][r]) {
+                if (R.rok[lw][r]) {
                     B q[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const T v = rq[lw][r].get(i);
+                        const T v = R.rq[lw][r].get(i);
                         q[i] = lat.qbits(v);
                         if (lw == 0 && r > 0 && zz >= 0) bad[i] = lat.bad(v, q[i]);
                         if (EDGE) q[i] = xok ? q[i] : CB;
                     }
-                    const B left0 = has_left ? lat.qbits(rl[lw][r]) : CB;  // only lane 0's copy is used
+                    const B left0 = has_left ? lat.qbits(R.rl[lw][r]) : CB;
                     UQ pv = (UQ)dpp_wave_shr1(left0, q[3]);
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
@@ -1090,7 +1119,7 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
                 for (int i = 0; i < 4; i++) pd1[lw][i] = d1v[i];
             }
             if (r == 0 || zz < 0) continue;   // halo row / halo plane: state only
-            if (!rok[0][r]) continue;          // beyond the array (EDGE bricks only)
+            if (!R.rok[0][r]) continue;        // beyond the array (EDGE bricks only)
             // ---- codes, histogram, store ----
             const uint64_t grow = (uint64_t)w * c.vol + (uint64_t)gz * c.plane + (uint64_t)(y0 + r - 1) * d0;  // the row's first element
             uint32_t t[4];
@@ -1103,8 +1132,14 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
             bool rare = bad[0] | bad[1] | bad[2] | bad[3] | (tmax == 255u);
             if (EDGE) rare &= xok;
             if (!EDGE || xok) {
+#ifdef LAB_ABLATE
+                if (!(c.p->dbg & 1u))
+#endif
 #pragma unroll
                 for (int i = 0; i < 4; i++) atomicAdd(&c.lh[t[i] * 4u + copy], 1u);
+#ifdef LAB_ABLATE
+                if (!(c.p->dbg & 2u))
+#endif
                 *reinterpret_cast<uint32_t *>(c.codes8 + grow + x) = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
             }
             if (c.s_len) {
@@ -1133,6 +1168,26 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
                     if (2 * k + 1 < TY && rb < d1) c.seg_bits[(g0 + (uint64_t)rb * d0) >> 8] = (uint16_t)(tot >> 16);
                 }
             }
+        }
+    };
+    int zz = z0 > 0 ? -1 : 0;
+    const int zend = d2 - z0 < (uint32_t)MARCH_TZ ? (int)(d2 - z0) : MARCH_TZ;
+    NarrowPlane<T, NW, TY> pa;
+    if (NARROW_PF) {
+        NarrowPlane<T, NW, TY> pb;
+        fetch(zz, pa);
+        for (;;) {
+            if (zz + 1 < zend) fetch(zz + 1, pb);
+            work(zz, pa);
+            if (++zz >= zend) break;
+            if (zz + 1 < zend) fetch(zz + 1, pa);
+            work(zz, pb);
+            if (++zz >= zend) break;
+        }
+    } else {
+        for (; zz < zend; zz++) {
+            fetch(zz, pa);
+            work(zz, pa);
         }
     }
 }
@@ -1222,8 +1277,13 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
 // its specialised code; the width is still decided by THIS call's probe — should it say two bytes after all, the same LDS
 // serves a 4096-bin window (correct, slower: more codes fall through to global atomics) and the next call is launched in
 // the other form. (One kernel with the width as a run-time flag in the inner loop was 14 % slower: 172 vs 151 us at C2.)
+#ifdef LAB_WAVES
+#define MARCH3_ATTR __attribute__((amdgpu_waves_per_eu(LAB_WAVES, LAB_WAVES)))
+#else
+#define MARCH3_ATTR
+#endif
 template <typename T, int NDIM, int TY>
-__global__ __launch_bounds__(256) void k_lorenzo_quant_march3(const T *__restrict__ in, uint16_t *__restrict__ codes,
+__global__ __launch_bounds__(256) MARCH3_ATTR void k_lorenzo_quant_march3(const T *__restrict__ in, uint16_t *__restrict__ codes,
                                                               szk_k1_params p, uint32_t ntasks, uint32_t nrows) {
     using L = MarchLds<1, false>;
     static_assert(L::LH_WORDS == MarchLds<4, false>::LH_WORDS && L::OQ == MarchLds<4, false>::OQ, "both bodies share the arrays");
@@ -2030,84 +2090,14 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
     }
 }
 
-// PART 0: alphabets up to CB_SMALL_SYMS symbols + the outlier-list sorts; PART 1: wider alphabets. Which one applies is
-// known only on the device (k_hist_range), so both are launched and the other returns at once: the small path keeps its
-// own register allocation and instruction footprint (sharing one kernel with the wide path cost it 10 us of its 40).
-// SLIM (PART 0 only, 256 threads, no outlier sorts): the same construction with LDS arrays for 256 symbols (8 KB instead of
-// 128 KB) — the speculative stage 2 runs it on a side stream beside the encoder's kernels, where a workgroup that needs most
-// of a compute unit's LDS would wait for the packer's persistent workgroups to retire.
-template <int PART, bool SLIM = false>
-__global__ __launch_bounds__(SLIM ? CB_THREADS : CB_LAUNCH) void k_codebook(const uint64_t *__restrict__ hist, szk_cb_params p) {
-    static_assert(!SLIM || PART == 0, "the slim form is the small-alphabet path");
-    constexpr uint32_t CAP = SLIM ? CB_SMALL_SYMS : CB_LDS_SYMS;  // symbols the small path's LDS arrays hold
-    __shared__ __align__(16) uint8_t s_pool[SLIM ? CAP * 28 + 256 : CB_POOL_BYTES];
-    __shared__ uint32_t s_wtot[CB_THREADS / WAVE];
-    __shared__ uint32_t s_over;
-    __shared__ uint32_t s_first[SZH_MAX_LEN + 2], s_cnt[SZH_MAX_LEN + 2];
-    __shared__ uint32_t s_misc[8];
-    __shared__ unsigned long long s_total;
+// The small-alphabet construction (up to CAP <= CB_LDS_SYMS symbols, 256 threads, everything in LDS): compaction, rank sort,
+// two-queue merge by one wave out of registers, depths by pointer doubling, length limit + Kraft repair, canonical codes.
+// A device function so that two launches can run it: k_codebook<0> (block 0) and — speculative stage 2 — a workgroup of the
+// packer's launch (k_pack, book role). The caller zeroes s_cnt / s_over / s_total and enc / lens over [lo, lo + range).
+template <uint32_t CAP>
+__device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params &p, uint8_t *s_pool, uint32_t lo, uint32_t range,
+                         uint32_t *s_wtot, uint32_t &s_over, uint32_t *s_first, uint32_t *s_cnt, uint32_t *s_misc, unsigned long long &s_total) {
     const uint32_t t = threadIdx.x;
-    if (blockIdx.x >= p.n_books) {  // the two blocks after the code books: deterministic order of the two outlier lists
-        // (in the launch whose code-book path is the active one, so that they run beside it)
-        if (SLIM || p.skip_sort) return;  // (speculative stage 2: k_sort_outliers did it, ahead of the packer)
-        if ((PART == 1) != (p.range[2] > CB_SMALL_SYMS) && p.part_hint < 0) return;  // (launched alone: sorts whatever the alphabet)
-        const bool d = blockIdx.x == p.n_books + 1;
-        // scratch: the key tables of the batch slots 1 and 2, idle when a single code book is built (n_books <= 1)
-        uint64_t *scratch = p.n_books <= 1 ? p.keys + (size_t)(d ? 2 : 1) * SZH_HIST_BINS : nullptr;
-        sort_outlier_list(d ? p.dout_idx : p.vout_idx, d ? p.dout_val : p.vout_val, d ? *p.n_dout : *p.n_vout, p.out_cap,
-                          d ? p.q_is_32bit != 0 : p.t_is_32bit != 0, s_pool, scratch);
-        return;
-    }
-    {  // book b of a batch (the tuner's trials) uses the b-th slice of every table
-        const size_t b = blockIdx.x;
-        hist += b * SZH_HIST_BINS;
-        p.enc += b * SZH_HIST_BINS;
-        p.lens += b * SZH_HIST_BINS;
-        p.keys += b * SZH_HIST_BINS;
-        p.syms += b * SZH_HIST_BINS;
-        p.ifreq += b * SZH_HIST_BINS;
-        p.pleaf += b * SZH_HIST_BINS;
-        p.pint += b * SZH_HIST_BINS;
-        p.depth += b * SZH_HIST_BINS;
-        p.aux2 += b * SZH_HIST_BINS;
-        p.pint2 += b * SZH_HIST_BINS;
-        p.range += b * 4;
-        p.info += b;
-    }
-    // range and number of the non-empty bins: found by k_hist_range (256 workgroups) just before this launch
-    const uint32_t n_nonzero = p.range[2];
-    if ((PART == 1) != (n_nonzero > CB_SMALL_SYMS)) {  // the other form's case
-        if (p.part_hint >= 0 && p.mispredict && threadIdx.x == 0) *p.mispredict = 1u;  // launched alone: the host repeats stage 2 with both
-        return;
-    }
-    if (n_nonzero == 0) {
-        if (t == 0) {
-            p.info->n_symbols = 0;
-            p.info->max_len = 0;
-            p.info->sym_min = 0;
-            p.info->sym_count = 0;
-            p.info->win_lo = 0;
-        }
-        return;
-    }
-    const uint32_t lo = 0xFFFFu - p.range[0], range = p.range[1] - lo + 1;  // range[0] = max(65535 - bin), range[1] = max bin
-    const bool small = n_nonzero <= CB_SMALL_SYMS;
-    if (small && t >= CB_THREADS) return;  // the small path runs on 4 waves (cheap barriers)
-    if (t == 0) p.info->ts[0] = wall_clock64();
-    if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
-    if (t == 0) {
-        s_over = 0;
-        s_total = 0;
-    }
-    for (uint32_t i = t; i < range; i += small ? CB_THREADS : CB_LAUNCH) {  // only [lo, hi] is ever looked up / serialised
-        p.enc[lo + i] = 0;
-        p.lens[lo + i] = 0;
-    }
-    __syncthreads();
-    if constexpr (PART == 1) {
-        codebook_wide<true>(hist, p, s_pool, lo, range, s_cnt, s_first, s_misc);
-        return;
-    }
     // ---------------- small alphabets: LDS-resident, 256 threads ----------------
     uint64_t *keys = reinterpret_cast<uint64_t *>(s_pool);                          // [CAP]
     uint64_t *ifreq = keys + CAP;                                                    // [CAP] (u32 view in the wave merge)
@@ -2279,6 +2269,87 @@ __global__ __launch_bounds__(SLIM ? CB_THREADS : CB_LAUNCH) void k_codebook(cons
     }
 }
 
+// PART 0: alphabets up to CB_SMALL_SYMS symbols + the outlier-list sorts; PART 1: wider alphabets. Which one applies is
+// known only on the device (k_hist_range), so both are launched and the other returns at once: the small path keeps its
+// own register allocation and instruction footprint (sharing one kernel with the wide path cost it 10 us of its 40).
+// SLIM (PART 0 only, 256 threads, no outlier sorts): the same construction with LDS arrays for 256 symbols (8 KB instead of
+// 128 KB) — the speculative stage 2 runs it on a side stream beside the encoder's kernels, where a workgroup that needs most
+// of a compute unit's LDS would wait for the packer's persistent workgroups to retire.
+template <int PART, bool SLIM = false>
+__global__ __launch_bounds__(SLIM ? CB_THREADS : CB_LAUNCH) void k_codebook(const uint64_t *__restrict__ hist, szk_cb_params p) {
+    static_assert(!SLIM || PART == 0, "the slim form is the small-alphabet path");
+    constexpr uint32_t CAP = SLIM ? CB_SMALL_SYMS : CB_LDS_SYMS;  // symbols the small path's LDS arrays hold
+    __shared__ __align__(16) uint8_t s_pool[SLIM ? CAP * 28 + 256 : CB_POOL_BYTES];
+    __shared__ uint32_t s_wtot[CB_THREADS / WAVE];
+    __shared__ uint32_t s_over;
+    __shared__ uint32_t s_first[SZH_MAX_LEN + 2], s_cnt[SZH_MAX_LEN + 2];
+    __shared__ uint32_t s_misc[8];
+    __shared__ unsigned long long s_total;
+    const uint32_t t = threadIdx.x;
+    if (blockIdx.x >= p.n_books) {  // the two blocks after the code books: deterministic order of the two outlier lists
+        // (in the launch whose code-book path is the active one, so that they run beside it)
+        if (SLIM || p.skip_sort) return;  // (speculative stage 2: k_sort_outliers did it, ahead of the packer)
+        if ((PART == 1) != (p.range[2] > CB_SMALL_SYMS) && p.part_hint < 0) return;  // (launched alone: sorts whatever the alphabet)
+        const bool d = blockIdx.x == p.n_books + 1;
+        // scratch: the key tables of the batch slots 1 and 2, idle when a single code book is built (n_books <= 1)
+        uint64_t *scratch = p.n_books <= 1 ? p.keys + (size_t)(d ? 2 : 1) * SZH_HIST_BINS : nullptr;
+        sort_outlier_list(d ? p.dout_idx : p.vout_idx, d ? p.dout_val : p.vout_val, d ? *p.n_dout : *p.n_vout, p.out_cap,
+                          d ? p.q_is_32bit != 0 : p.t_is_32bit != 0, s_pool, scratch);
+        return;
+    }
+    {  // book b of a batch (the tuner's trials) uses the b-th slice of every table
+        const size_t b = blockIdx.x;
+        hist += b * SZH_HIST_BINS;
+        p.enc += b * SZH_HIST_BINS;
+        p.lens += b * SZH_HIST_BINS;
+        p.keys += b * SZH_HIST_BINS;
+        p.syms += b * SZH_HIST_BINS;
+        p.ifreq += b * SZH_HIST_BINS;
+        p.pleaf += b * SZH_HIST_BINS;
+        p.pint += b * SZH_HIST_BINS;
+        p.depth += b * SZH_HIST_BINS;
+        p.aux2 += b * SZH_HIST_BINS;
+        p.pint2 += b * SZH_HIST_BINS;
+        p.range += b * 4;
+        p.info += b;
+    }
+    // range and number of the non-empty bins: found by k_hist_range (256 workgroups) just before this launch
+    const uint32_t n_nonzero = p.range[2];
+    if ((PART == 1) != (n_nonzero > CB_SMALL_SYMS)) {  // the other form's case
+        if (p.part_hint >= 0 && p.mispredict && threadIdx.x == 0) *p.mispredict = 1u;  // launched alone: the host repeats stage 2 with both
+        return;
+    }
+    if (n_nonzero == 0) {
+        if (t == 0) {
+            p.info->n_symbols = 0;
+            p.info->max_len = 0;
+            p.info->sym_min = 0;
+            p.info->sym_count = 0;
+            p.info->win_lo = 0;
+        }
+        return;
+    }
+    const uint32_t lo = 0xFFFFu - p.range[0], range = p.range[1] - lo + 1;  // range[0] = max(65535 - bin), range[1] = max bin
+    const bool small = n_nonzero <= CB_SMALL_SYMS;
+    if (small && t >= CB_THREADS) return;  // the small path runs on 4 waves (cheap barriers)
+    if (t == 0) p.info->ts[0] = wall_clock64();
+    if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
+    if (t == 0) {
+        s_over = 0;
+        s_total = 0;
+    }
+    for (uint32_t i = t; i < range; i += small ? CB_THREADS : CB_LAUNCH) {  // only [lo, hi] is ever looked up / serialised
+        p.enc[lo + i] = 0;
+        p.lens[lo + i] = 0;
+    }
+    __syncthreads();
+    if constexpr (PART == 1) {
+        codebook_wide<true>(hist, p, s_pool, lo, range, s_cnt, s_first, s_misc);
+        return;
+    }
+    cb_small<CAP>(hist, p, s_pool, lo, range, s_wtot, s_over, s_first, s_cnt, s_misc, s_total);
+}
+
 // Short outlier lists (what smooth fields have: C2 lists 970 points) sorted by a small launch: up to SORT_SMALL records per
 // list, keys (index << 16 | arrival position) in a bitonic network in LDS, the values follow by position. A longer list
 // makes it raise *declined: the host repeats stage 2 the classic way (the code-book launch's sort blocks handle any length).
@@ -2393,6 +2464,7 @@ __device__ void layout_pre(const szk_layout_params &p) {  // after K1 + K5, befo
     szh_header h = p.proto;  // dtype, ndim, dims, eb, radius, n, chunk geometry filled by the host
     uint64_t nv = *p.n_vout, nd = *p.n_dout;
     p.state->overflow = (nv > p.out_cap) || (nd > p.out_cap);
+    p.state->book_miss = p.state->miss_kind = 0;
     if (nv > p.out_cap) nv = p.out_cap;
     if (nd > p.out_cap) nd = p.out_cap;
     h.n_vout = nv;
@@ -2598,9 +2670,62 @@ __device__ void scan_groups_body(uint16_t *__restrict__ chunk_words, uint64_t n_
     __shared__ uint64_t s_w[16];
     __shared__ uint64_t s_carry;
     const uint64_t n_groups = (n_chunks + PACK_GROUP - 1) / PACK_GROUP;
-    const bool seg_ok = SEG ? *seg_made != 0 : false;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
+    if (SEG) {
+        // One 16-byte load = 8 segments = 2 chunks; 16 consecutive lanes = one group of 32 chunks. Lanes are dealt consecutive
+        // loads (coalesced; a thread walking its own 256-byte run touched 64 cache lines per wave instruction: 65 us), SEG_U of
+        // them in flight per thread; a group's sum is a DPP reduction over its row of 16 lanes.
+        constexpr int SEG_U = 8;
+        __shared__ uint32_t s_gs[SEG_U * 64];  // group sums of one round, in group order
+        const bool seg_ok = *seg_made != 0;
+        const uint32_t t = threadIdx.x, lane = lane_id();
+        const uint64_t n_vec = (n_segs + 7) / 8;  // 16-byte vectors (the array is padded: reads beyond n_segs see whatever, masked below)
+        for (uint64_t v0 = 0; v0 < n_vec; v0 += (uint64_t)SEG_U * 1024) {
+            uint4 q[SEG_U];
+#pragma unroll
+            for (int u = 0; u < SEG_U; u++) {
+                const uint64_t vi = v0 + (uint64_t)u * 1024 + t;
+                q[u] = vi < n_vec ? reinterpret_cast<const uint4 *>(seg_bits)[vi] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < SEG_U; u++) {
+                const uint64_t vi = v0 + (uint64_t)u * 1024 + t;
+                const uint64_t sg0 = vi * 8;  // first segment of this vector; chunks 2 vi and 2 vi + 1
+                uint32_t hw[8] = {q[u].x & 0xFFFF, q[u].x >> 16, q[u].y & 0xFFFF, q[u].y >> 16, q[u].z & 0xFFFF, q[u].z >> 16, q[u].w & 0xFFFF, q[u].w >> 16};
+#pragma unroll
+                for (int k = 0; k < 8; k++) hw[k] = (seg_ok && sg0 + k < n_segs) ? hw[k] : 0u;
+                const uint32_t cw0 = (hw[0] + hw[1] + hw[2] + hw[3] + 31u) >> 5, cw1 = (hw[4] + hw[5] + hw[6] + hw[7] + 31u) >> 5;
+                const uint64_t c = vi * 2;
+                if (c + 1 < n_chunks) reinterpret_cast<uint32_t *>(chunk_words)[vi] = cw0 | (cw1 << 16);
+                else if (c < n_chunks) chunk_words[c] = (uint16_t)cw0;
+                uint32_t gs = (c < n_chunks ? cw0 : 0u) + (c + 1 < n_chunks ? cw1 : 0u);
+                gs += dpp_mov0<0x111, 0xf>(gs);  // inclusive sum along the row of 16 lanes: the row's last lane holds the group's total
+                gs += dpp_mov0<0x112, 0xf>(gs);
+                gs += dpp_mov0<0x114, 0xf>(gs);
+                gs += dpp_mov0<0x118, 0xf>(gs);
+                if ((lane & 15u) == 15u) s_gs[u * 64 + (t >> 4)] = gs;
+            }
+            __syncthreads();
+            // exclusive scan of the round's SEG_U * 64 group sums (one per thread for the first SEG_U * 64 threads)
+            const uint64_t g_base = v0 / 16;  // first group of the round
+            const uint32_t mine = t < SEG_U * 64 ? s_gs[t] : 0u;
+            const uint64_t incl = wave_incl_scan((uint64_t)mine);
+            if (lane == WAVE - 1) s_w[t / WAVE] = incl;
+            __syncthreads();
+            uint64_t run = s_carry + incl - mine, tot = 0;
+            for (int w = 0; w < 16; w++) {
+                if (w < (int)(t / WAVE)) run += s_w[w];
+                tot += s_w[w];
+            }
+            if (t < SEG_U * 64 && g_base + t < n_groups) group_off[g_base + t] = run;
+            __syncthreads();
+            if (t == 0) s_carry += tot;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *total_words = s_carry;
+        return;
+    }
     for (uint64_t g0 = 0; g0 < n_groups; g0 += 1024 * SCAN_GPT) {
         const uint64_t gt = g0 + (uint64_t)threadIdx.x * SCAN_GPT;
         uint64_t sum[SCAN_GPT];
@@ -2610,34 +2735,7 @@ __device__ void scan_groups_body(uint16_t *__restrict__ chunk_words, uint64_t n_
             sum[j] = 0;
             if (g < n_groups) {
                 const uint64_t c0 = g * PACK_GROUP;
-                if (SEG) {
-                    if (c0 + PACK_GROUP <= n_chunks && (c0 + PACK_GROUP) * 4 <= n_segs) {  // 128 x u16 in, 32 x u16 out
-                        const uint4 *v = reinterpret_cast<const uint4 *>(seg_bits + c0 * 4);
-                        uint4 *o = reinterpret_cast<uint4 *>(chunk_words + c0);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {  // four loads = 32 segments = 8 chunks -> one 16-byte store
-                            uint32_t cw[8];
-#pragma unroll
-                            for (int h = 0; h < 4; h++) {
-                                const uint4 q = v[4 * k + h];  // 8 segments = 2 chunks
-                                const uint32_t b0 = (q.x & 0xFFFF) + (q.x >> 16) + (q.y & 0xFFFF) + (q.y >> 16);
-                                const uint32_t b1 = (q.z & 0xFFFF) + (q.z >> 16) + (q.w & 0xFFFF) + (q.w >> 16);
-                                cw[2 * h] = seg_ok ? (b0 + 31u) >> 5 : 0u;
-                                cw[2 * h + 1] = seg_ok ? (b1 + 31u) >> 5 : 0u;
-                                sum[j] += cw[2 * h] + cw[2 * h + 1];
-                            }
-                            o[k] = make_uint4(cw[0] | (cw[1] << 16), cw[2] | (cw[3] << 16), cw[4] | (cw[5] << 16), cw[6] | (cw[7] << 16));
-                        }
-                    } else {
-                        for (uint64_t c = c0; c < n_chunks && c < c0 + PACK_GROUP; c++) {
-                            uint32_t b = 0;
-                            for (uint64_t sg = c * 4; sg < c * 4 + 4 && sg < n_segs; sg++) b += seg_bits[sg];
-                            const uint32_t cw = seg_ok ? (b + 31u) >> 5 : 0u;
-                            chunk_words[c] = (uint16_t)cw;
-                            sum[j] += cw;
-                        }
-                    }
-                } else if (c0 + PACK_GROUP <= n_chunks) {  // 32 x u16 = four 16-byte loads
+                if (c0 + PACK_GROUP <= n_chunks) {  // 32 x u16 = four 16-byte loads
                     const uint4 *v = reinterpret_cast<const uint4 *>(chunk_words + c0);
                     uint4 q[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
@@ -2671,10 +2769,25 @@ __device__ void scan_groups_body(uint16_t *__restrict__ chunk_words, uint64_t n_
     }
     if (threadIdx.x == 0) *total_words = s_carry;
 }
+struct szk_fold_params {  // the fold of stage 1's histogram rows, riding in the scan's launch (blocks 1 .. 64) when stage 1 left it out
+    const uint32_t *partial;
+    uint32_t nrows;
+    int win_lo;
+    uint64_t *hist;
+    uint32_t *range;
+};
 __global__ __launch_bounds__(1024) void k_scan_groups(uint16_t *__restrict__ chunk_words, uint64_t n_chunks,
                                                       uint64_t *__restrict__ group_off, uint64_t *total_words,
                                                       szk_layout_params lp, int do_layout, const uint16_t *__restrict__ seg_bits, uint64_t n_segs,
-                                                      const uint32_t *seg_made) {
+                                                      const uint32_t *seg_made, szk_fold_params fp) {
+    if (blockIdx.x > 0) {  // k_hist_reduce's work: block b sums rows b - 1, b - 1 + 64, ...; 1024 threads = the 1024 bins of a row
+        const int bin = threadIdx.x;
+        uint64_t sum = 0;
+        for (uint32_t r = blockIdx.x - 1; r < fp.nrows; r += gridDim.x - 1) sum += fp.partial[(uint64_t)r * HIST_WIN + bin];
+        const int sym = fp.win_lo + bin;
+        if (sum && sym >= 0 && sym < (int)SZH_HIST_BINS) hist_add_ranged(fp.hist, fp.range, (uint32_t)sym, (unsigned long long)sum);
+        return;
+    }
     if (do_layout && threadIdx.x == 1023) layout_pre(lp);
     if (seg_bits) scan_groups_body<true>(chunk_words, n_chunks, group_off, total_words, seg_bits, n_segs, seg_made);
     else scan_groups_body<false>(chunk_words, n_chunks, group_off, total_words, nullptr, 0, nullptr);
@@ -2769,9 +2882,11 @@ __device__ void assemble_body(const szk_asm_params &p, uint64_t tid, uint64_t nt
         p.state->off = oo;
         p.state->cap_exceeded = oo.end > p.cap;
         for (int i = 0; i < 6; i++) p.state->probe[i] = reinterpret_cast<const uint32_t *>(p.n_vout + 4)[i];
-        p.state->mispredict = (uint32_t)p.n_vout[7];                                  // (d_counters[7]: raised by a code-book form launched alone)
-        p.state->book_miss = p.state->miss_kind = 0;                                  // (speculative stage 2: k_book_verdict rewrites these)
-        p.state->n_symbols = reinterpret_cast<const uint32_t *>(p.n_vout + 8)[2];   // (the range words: number of non-empty bins)
+        if (!p.lists_by_roles) {  // (role mode: the book role of the same launch writes these; miss_kind was zeroed by layout_pre)
+            p.state->mispredict = (uint32_t)p.n_vout[7];                                  // (d_counters[7]: raised by a code-book form launched alone)
+            p.state->book_miss = p.state->miss_kind = 0;                                  // (speculative stage 2 on a side stream: k_book_verdict rewrites these)
+            p.state->n_symbols = reinterpret_cast<const uint32_t *>(p.n_vout + 8)[2];   // (the range words: number of non-empty bins)
+        }
         // alignment gaps between the sections are part of the payload: zero them so that it is a pure function of the input
         const uint64_t tsz0 = h.dtype == 0 ? 4 : 8;
         for (uint64_t a = oo.lens + h.sym_count; a < oo.chunkwords; a++) p.payload[a] = 0;
@@ -2829,26 +2944,156 @@ __global__ __launch_bounds__(256) void k_assemble(szk_asm_params p) {
 // and streams them out; the next chunk's codes, word count and group offset are already in flight
 // WIN: symbols of the encode table cached in LDS around the most frequent one: ENC_WIN (30 KB of LDS, 5 workgroups per CU)
 // or 2 * ENC_WIN (46 KB, 3 per CU) for alphabets that spread wider (chosen per context from the previous call's alphabet)
+// Speculative stage 2, small alphabets (sz3hip_api.cpp): the packer runs with the previous call's code book, and THIS call's
+// book is built meanwhile by one workgroup of the packer's own launch (the first one dispatched) — no second stream, no
+// events: cross-stream dependencies cost more than the code book itself on this runtime. Two more workgroups sort the two
+// outlier lists (short ones: <= ROLE_SORT_MAX records each) and copy them into the payload.
+#define ROLE_BLOCKS 3u
+#define ROLE_SORT_MAX 1024u
+struct szk_role_params {
+    uint32_t on;  // 0: no role blocks in this launch
+    const uint64_t *hist;
+    szk_cb_params cb;                // this call's book (fresh slot), part_hint = 0
+    const szk_cb_info *used;         // the book the packer runs with
+    const uint8_t *used_lens;
+    uint32_t *flags;                 // [0] raised by a list too long for the short sort, [1] stage 1 summed the segments' bits
+    int need_seg;
+};
+// book role: the small-alphabet code book from this call's histogram, then the verdict on the book the packer is using
+__device__ void role_book(const szk_role_params &rp, szk_state *state, uint8_t *pool) {
+    __shared__ uint32_t s_wtot[CB_THREADS / WAVE];
+    __shared__ uint32_t s_over, s_diff;
+    __shared__ uint32_t s_first[SZH_MAX_LEN + 2], s_cnt[SZH_MAX_LEN + 2];
+    __shared__ uint32_t s_misc[8];
+    __shared__ unsigned long long s_total;
+    const szk_cb_params &p = rp.cb;
+    const uint32_t t = threadIdx.x;
+    const uint32_t n_nonzero = p.range[2];
+    bool built = false;
+    if (n_nonzero > CB_SMALL_SYMS) {
+        if (t == 0) *p.mispredict = 1u;  // the other form's alphabet: the host repeats stage 2 the classic way
+    } else if (n_nonzero == 0) {
+        if (t == 0) {
+            p.info->n_symbols = 0;
+            p.info->max_len = 0;
+            p.info->sym_min = 0;
+            p.info->sym_count = 0;
+            p.info->win_lo = 0;
+        }
+        built = true;
+    } else {
+        const uint32_t lo = 0xFFFFu - p.range[0], range = p.range[1] - lo + 1;
+        if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
+        if (t == 0) {
+            s_over = 0;
+            s_total = 0;
+            p.info->ts[0] = wall_clock64();
+        }
+        for (uint32_t i = t; i < range; i += CB_THREADS) {
+            p.enc[lo + i] = 0;
+            p.lens[lo + i] = 0;
+        }
+        __syncthreads();
+        cb_small<CB_SMALL_SYMS>(rp.hist, p, pool, lo, range, s_wtot, s_over, s_first, s_cnt, s_misc, s_total);
+        built = true;
+    }
+    if (t == 0) s_diff = 0;
+    __syncthreads();  // (the block's own global writes of info / lens are visible to it after the barrier)
+    bool diff = false;
+    if (built) {
+        const szk_cb_info *fresh = p.info;
+        const uint32_t lo = fresh->sym_min, cnt = fresh->sym_count;
+        diff = rp.used->sym_min != lo || rp.used->sym_count != cnt || rp.used->max_len != fresh->max_len || rp.used->n_symbols != fresh->n_symbols;
+        if (!diff)
+            for (uint32_t i = t; i < cnt; i += CB_THREADS) diff |= rp.used_lens[lo + i] != p.lens[lo + i];
+    }
+    if (diff) s_diff = 1;
+    __syncthreads();
+    if (t == 0) {
+        const uint32_t kind = (s_diff ? 1u : 0u) | (!built ? 2u : 0u) | (rp.need_seg && !rp.flags[1] ? 8u : 0u);
+        // (kind 4, a list too long for the sort roles, is OR-ed in by those roles: atomics on the same word)
+        atomicOr(&state->miss_kind, kind);
+        state->mispredict = built ? 0u : 1u;
+        state->n_symbols = n_nonzero;
+    }
+}
+// sort role: one outlier list (short) into index order, then into its section of the payload
+__device__ void role_sort(const szk_role_params &rp, const szk_asm_params &ap, bool d, uint8_t *pool) {
+    const szk_cb_params &p = rp.cb;
+    uint64_t *sk = reinterpret_cast<uint64_t *>(pool), *sv = sk + ROLE_SORT_MAX;
+    uint64_t *idx = d ? p.dout_idx : p.vout_idx;
+    void *val = d ? p.dout_val : p.vout_val;
+    const bool v32 = d ? p.q_is_32bit != 0 : p.t_is_32bit != 0;
+    uint64_t n64 = d ? *p.n_dout : *p.n_vout;
+    if (n64 > p.out_cap) n64 = p.out_cap;
+    if (n64 > ROLE_SORT_MAX) {
+        if (threadIdx.x == 0) atomicOr(&ap.state->miss_kind, 4u);
+        return;
+    }
+    const uint32_t n = (uint32_t)n64;
+    if (n == 0) return;
+    uint32_t np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    for (uint32_t i = threadIdx.x; i < np2; i += 256) {
+        sk[i] = i < n ? (idx[i] << 16) | i : ~0ull;
+        if (i < n) sv[i] = v32 ? (uint64_t) reinterpret_cast<const uint32_t *>(val)[i] : reinterpret_cast<const uint64_t *>(val)[i];
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= np2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < np2; i += 256) {
+                const uint32_t x = i ^ j;
+                if (x > i) {
+                    const uint64_t a = sk[i], b = sk[x];
+                    if ((a > b) == ((i & k) == 0)) {
+                        sk[i] = b;
+                        sk[x] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    // straight into the payload (layout_pre laid the sections out in the scan's launch) — and back into the list itself: should
+    // the encoder be repeated with another book, its assemble workgroups copy the list as they find it
+    const uint64_t o_i = d ? ap.state->off.dout_idx : ap.state->off.vout_idx, o_v = d ? ap.state->off.dout_val : ap.state->off.vout_val;
+    uint64_t *pi = reinterpret_cast<uint64_t *>(ap.payload + o_i);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint64_t k = sk[i];
+        pi[i] = idx[i] = k >> 16;
+        const uint64_t v = sv[(uint32_t)(k & 0xFFFFu)];
+        if (v32) reinterpret_cast<uint32_t *>(ap.payload + o_v)[i] = reinterpret_cast<uint32_t *>(val)[i] = (uint32_t)v;
+        else reinterpret_cast<uint64_t *>(ap.payload + o_v)[i] = reinterpret_cast<uint64_t *>(val)[i] = v;
+    }
+}
 template <uint32_t WIN>
 __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes, uint64_t n,
                                               const uint32_t *__restrict__ g_enc, const szk_cb_info *__restrict__ info,
                                               const uint16_t *__restrict__ chunk_words,
                                               const uint64_t *__restrict__ group_off, szk_mode mode, uint32_t sym_add,
                                               const szk_state *__restrict__ state, uint8_t *__restrict__ payload, szk_asm_params ap,
-                                              uint32_t pack_blocks) {
-    if (blockIdx.x >= pack_blocks) {  // the launch's last workgroups assemble the payload's other sections meanwhile
-        assemble_body(ap, (uint64_t)(blockIdx.x - pack_blocks) * 256 + threadIdx.x, (uint64_t)(gridDim.x - pack_blocks) * 256);
-        assemble_lists(ap, (uint64_t)blockIdx.x * 256 + threadIdx.x, (uint64_t)gridDim.x * 256);
-        return;
-    }
+                                              uint32_t pack_blocks, szk_role_params rp) {
     constexpr int STAGE_WORDS = SZH_CHUNK_SYMS * SZH_MAX_LEN / 32 + 4;  // + slack for the unconditional 3-word emit
-    __shared__ uint32_t s_enc[WIN];
+    __shared__ __align__(16) uint32_t s_enc[WIN];
     __shared__ uint32_t s_enc8[256];  // one-byte codes: code word by byte value ...
     __shared__ uint8_t s_plen8[256];  // ... and its length
     __shared__ uint32_t s_stage[4][STAGE_WORDS];
+    const uint32_t roles = rp.on ? ROLE_BLOCKS : 0u;
+    if (blockIdx.x < roles) {  // (the first workgroups dispatched; s_enc's 16 KB serve as their scratch)
+        static_assert(WIN * 4 >= ROLE_SORT_MAX * 16 && WIN * 4 >= CB_SMALL_SYMS * 28 + 256, "role scratch fits the table");
+        if (blockIdx.x == 0) role_book(rp, ap.state, reinterpret_cast<uint8_t *>(s_enc));
+        else role_sort(rp, ap, blockIdx.x == 2, reinterpret_cast<uint8_t *>(s_enc));
+        return;
+    }
+    const uint32_t bid = blockIdx.x - roles;  // the packer's own numbering
+    const uint32_t nblk = gridDim.x - roles;
+    if (bid >= pack_blocks) {  // the launch's last workgroups assemble the payload's other sections meanwhile
+        assemble_body(ap, (uint64_t)(bid - pack_blocks) * 256 + threadIdx.x, (uint64_t)(nblk - pack_blocks) * 256);
+        if (!ap.lists_by_roles) assemble_lists(ap, (uint64_t)bid * 256 + threadIdx.x, (uint64_t)nblk * 256);
+        return;
+    }
     const bool narrow = szk_is_narrow(mode);
     const uint64_t n_full = n / SZH_CHUNK_SYMS, n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
-    const uint64_t wave_gid = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE, nwaves = (uint64_t)pack_blocks * 4;
+    const uint64_t wave_gid = (uint64_t)bid * 4 + threadIdx.x / WAVE, nwaves = (uint64_t)pack_blocks * 4;
     const uint64_t lane_off = (uint64_t)lane_id() * ENC_PER_LANE;
     const int lane = lane_id();
     uint32_t *stage = s_stage[threadIdx.x / WAVE];
@@ -2936,7 +3181,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         uint32_t *out = out_base + go + before;
         for (uint32_t i = lane; i < nwords; i += WAVE) out[i] = __builtin_bswap32(stage[i]);
     }
-    if (gridDim.x > pack_blocks) assemble_lists(ap, (uint64_t)blockIdx.x * 256 + threadIdx.x, (uint64_t)gridDim.x * 256);  // (its share of the lists)
+    if (nblk > pack_blocks && !ap.lists_by_roles) assemble_lists(ap, (uint64_t)bid * 256 + threadIdx.x, (uint64_t)nblk * 256);  // (its share of the lists)
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -3765,8 +4010,7 @@ static void launch_march_w(const void *d_in, uint16_t *codes, szk_k1_params &p, 
         // them all empty
         const uint32_t g1 = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 1, false>, (nb + 3) / 4);
         const uint32_t g2 = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 2, WIN16>, (nb + 3) / 4);
-        grid = g1 > g2 ? g1 : g2;
-        p.seg_expected = p.spec_lens && p.d[3] % MARCH_TX == 0;
+        grid = g1 > g2 ? g1 : g2;  // (no hint about the code width: the encoder keeps its bits pass, seg_expected stays 0)
         hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 1, false>), dim3(g1), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
         hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 2, WIN16>), dim3(g2), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
     } else {
@@ -3796,7 +4040,10 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
     // tuned kernel: quads need x % 4 == 0; 32-bit in-tile offsets need (TZ+1) planes < 2^31 elements; tile count < 2^31
     const bool fast = !szk_force_generic && (d0 % 4 == 0) && d0 < (1ull << 31) && d1 < (1ull << 31) && d2 < (1ull << 31) &&
                       d0 * d1 < (1ull << 27) && tiles(64, 8, FTZ) < (1ull << 31);
-    constexpr int MTY = 4;
+#ifndef LAB_MTY
+#define LAB_MTY 4
+#endif
+    constexpr int MTY = LAB_MTY;
     const bool march = fast && !(szk_dbg_flags & 32) && d0 >= 128 && tiles(MARCH_TX, MTY, MARCH_TZ) < (1ull << 31) && (ndim == 3 || ndim == 4);
     // 1-D and 2-D arrays are 3-D arrays with d2 = 1 (and d1 = 1): the register-marching kernel needs no plane-size limit
     const bool march12 = !szk_force_generic && !(szk_dbg_flags & 32) && (ndim == 1 || ndim == 2) && d0 % 4 == 0 && d0 >= 128 &&
@@ -3927,7 +4174,7 @@ int szk_launch_hist_fold(const uint32_t *partial, uint32_t nrows, int radius, ui
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
                       szk_mode mode, uint16_t *chunk_words, uint64_t *group_off, uint64_t *total_words,
                       const szk_state *state, uint8_t *payload, const szk_layout_params *layout, const szk_asm_params *asmp, hipStream_t s,
-                      hipEvent_t lists_sorted, const uint16_t *seg_bits, const uint32_t *seg_made) {
+                      hipEvent_t lists_sorted, const uint16_t *seg_bits, const uint32_t *seg_made, const szk_encode_roles *er) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
     const uint64_t nb = (n_chunks + 3) / 4;
     if (nb > 0x7FFFFFFFull) return -1;
@@ -3935,19 +4182,45 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
     const uint32_t pgrid = (uint32_t)(nb < 2048 ? nb : 2048);  // persistent: 8 workgroups per CU
     // (seg_bits: stage 1 summed the code bits per 256-element segment with the book the encoder uses: no bits pass)
     if (!seg_bits) hipLaunchKernelGGL(k_chunk_bits2, dim3(pgrid), dim3(256), 0, s, codes, n, d_enc, info, mode, sym_add, chunk_words);
-    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s, chunk_words, n_chunks, group_off, total_words, *layout, 1, seg_bits,
-                       (uint64_t)((n + 255) / 256), seg_made);
+    szk_fold_params fp{};
+    if (er && er->fold_rows && (szk_dbg_flags & 134217728)) {  // (lab: the fold as a launch of its own)
+        hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, er->fold_partial, er->fold_rows, radius - HIST_WIN / 2, er->fold_hist, er->fold_range);
+    } else if (er && er->fold_rows) {  // stage 1 left the fold of its histogram rows out: 64 more workgroups of this launch do it
+        fp.partial = er->fold_partial;
+        fp.nrows = er->fold_rows;
+        fp.win_lo = radius - HIST_WIN / 2;
+        fp.hist = er->fold_hist;
+        fp.range = er->fold_range;
+    }
+    hipLaunchKernelGGL(k_scan_groups, dim3(fp.nrows ? 65 : 1), dim3(1024), 0, s, chunk_words, n_chunks, group_off, total_words, *layout, 1, seg_bits,
+                       (uint64_t)((n + 255) / 256), seg_made, fp);
+    szk_role_params rp{};
+    szk_asm_params apv = asmp ? *asmp : szk_asm_params{};
+    if (er && er->roles && asmp) {
+        rp.on = 1;
+        rp.hist = er->hist;
+        rp.cb = *er->cb;
+        rp.used = info;
+        rp.used_lens = er->used_lens;
+        rp.flags = er->flags;
+        rp.need_seg = seg_bits != nullptr;
+        apv.lists_by_roles = 1;
+    }
+    const uint32_t rb = rp.on ? ROLE_BLOCKS : 0u;
+    // the packer's workgroups are persistent and split the chunks statically: all of them, the role and the assemble workgroups
+    // must be resident together (5 per compute unit at 30 KB of LDS each), or the late ones double the launch's duration
+    const uint32_t extra = rb + (asmp ? 32u : 0u);
     // (speculative stage 2: the outlier lists are being sorted on a side stream; the packer's launch copies them)
     if (lists_sorted && hipStreamWaitEvent(s, lists_sorted, 0) != hipSuccess) return -2;
     constexpr uint32_t ASM_BLOCKS = 32;
     if (mode.pack_wide) {
-        const uint32_t pb = pgrid < 768 ? pgrid : 768;
-        hipLaunchKernelGGL((k_pack<2 * ENC_WIN>), dim3(pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
-                           sym_add, state, payload, asmp ? *asmp : szk_asm_params{}, pb);
+        const uint32_t pb = pgrid < 768 - extra ? pgrid : 768 - extra;
+        hipLaunchKernelGGL((k_pack<2 * ENC_WIN>), dim3(rb + pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
+                           sym_add, state, payload, apv, pb, rp);
     } else {
-        const uint32_t pb = pgrid < 1280 ? pgrid : 1280;
-        hipLaunchKernelGGL((k_pack<ENC_WIN>), dim3(pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
-                           sym_add, state, payload, asmp ? *asmp : szk_asm_params{}, pb);
+        const uint32_t pb = pgrid < 1280 - extra ? pgrid : 1280 - extra;
+        hipLaunchKernelGGL((k_pack<ENC_WIN>), dim3(rb + pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
+                           sym_add, state, payload, apv, pb, rp);
     }
     SZK_CHECK_LAUNCH();
     return 0;

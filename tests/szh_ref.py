@@ -19,7 +19,7 @@ def dualquant(a, eb, radius=32768, narrow=False):
     T = a.dtype
     # lattice arithmetic in the data type (sz3hip_kernels.hip, Lattice<T>): one rounding per multiply, no FMA
     # rint through the magic number (Lattice<T> in sz3hip_devutil.h): the bit pattern of fl(fl(a * recip) + M) is C + rint(a * recip)
-    # for |.| <= LIM; it is clamped as an integer (values beyond the lattice and Inf sit at its ends, NaN at the end its sign names)
+    # for |a * recip| <= LIM
     if T == np.float32:
         qt = np.int32
         recip = np.float32(1.0 / (2.0 * eb))
@@ -35,9 +35,10 @@ def dualquant(a, eb, radius=32768, narrow=False):
         eb_lo = eb
         magic, cbits, lim = np.float64(6755399441055744.0), 0x4338000000000000, 1 << 51
     with np.errstate(invalid="ignore", over="ignore"):
-        tm = (a * recip).astype(T) + magic
-        bits = np.clip(tm.astype(T).view(qt), cbits - lim, cbits + lim)
-        q = (bits - cbits).astype(qt)
+        s = (a * recip).astype(T)
+        tm = (s + magic).astype(T)
+        valid = np.abs(s) <= T.type(lim)  # (False for NaN): beyond the lattice, Inf and NaN take q = 0
+        q = np.where(valid, tm.view(qt) - cbits, 0).astype(qt)
         r = q.astype(T)
         dec = r * two_eb
         diff = np.abs(dec - a)

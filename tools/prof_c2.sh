@@ -2,7 +2,7 @@
 # rocprofv3 kernel trace of the default bench (C2) -> gpurun_out/prof_c2/kernel_stats.csv (+ the bench line under the profiler)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-B="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-e2e --no-extra"
+B="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-e2e --no-extra --no-cold"
 rm -rf $R/gpurun_out/prof_c2; mkdir -p $R/gpurun_out/prof_c2
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c2/raw -o r -- $B > $R/gpurun_out/prof_c2/bench.log 2>&1
 cp $R/gpurun_out/prof_c2/raw/*kernel_stats.csv $R/gpurun_out/prof_c2/kernel_stats.csv 2>/dev/null

@@ -140,7 +140,10 @@ size_t sz3hip_payload_bound_conf(const sz3hip_ctx *ctx, const sz3hip_config *con
 int sz3hip_minmax_device(sz3hip_ctx *ctx, const void *d_in, uint64_t n, double *min_out, double *max_out, void *stream);
 
 /* stage 1: prequantise + integer Lorenzo + code emission + outlier capture + histogram (K1+K4).
- * conf: N/dims/absErrorBound(must already be absolute)/quantbinCnt are used. Asynchronous on `stream`. */
+ * conf: N/dims/absErrorBound(must already be absolute)/quantbinCnt are used. Asynchronous on `stream`.
+ * d_in must stay valid and unchanged until sz3hip_compress_finish returns: a context that took a shortcut from what its
+ * previous call found (the one-launch form of stage 1 assumes the previous call's code width) repeats the call from stage 1
+ * inside finish() when this call's data says otherwise. */
 int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, void *stream);
 /* device pointer to the code histogram: uint64_t[sz3hip_histogram_len()] — the buffer a multi-GPU caller
  * all-reduces (sum) between stage1 and stage2 */

@@ -193,6 +193,11 @@ static const char *const kStageNames[ST_COUNT] = {"lorenzo_quant_hist", "codeboo
 #define SZ_COUNTER_BYTES 128
 // histogram and counters of a call start at zero; the internal histogram and the counters share one block (one fill launch)
 static hipError_t clear_hist_counters(sz3hip_ctx *c, hipStream_t s) {
+    if (c->pre_cleared && c->d_hist == c->d_hist_own && c->pre_stream == s) {  // (done behind the previous call, on this stream)
+        c->pre_cleared = false;
+        return hipSuccess;
+    }
+    c->pre_cleared = false;
     if (c->d_hist == c->d_hist_own) return hipMemsetAsync(c->d_hist, 0, SZH_HIST_BINS * 8 + SZ_COUNTER_BYTES, s);
     hipError_t e = hipMemsetAsync(c->d_hist, 0, SZH_HIST_BINS * 8, s);  // caller-owned histogram (multi-GPU all-reduce buffer)
     return e != hipSuccess ? e : hipMemsetAsync(c->d_counters, 0, SZ_COUNTER_BYTES, s);
@@ -213,6 +218,7 @@ static void ctx_free(sz3hip_ctx *c) {
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->ev_sorted) (void)hipEventDestroy(c->ev_sorted);
     if (c->ev_book) (void)hipEventDestroy(c->ev_book);
     if (c->d_flags) (void)hipHostFree(c->d_flags);
@@ -284,6 +290,11 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     alloc((void **)&c->bk[1].enc, SZH_HIST_BINS * 4);
     alloc((void **)&c->bk[1].lens, SZH_HIST_BINS);
     alloc((void **)&c->bk[1].info, sizeof(szk_cb_info));
+    // (a speculative stage 2 may look symbols up that the book it runs with never held: such entries must read "no code", not
+    // whatever the allocation contained — a length beyond the format's limit would overrun the packer's LDS stage)
+    if (ok) ok = hipMemset(c->d_enc, 0, SZK_MAX_BOOKS * SZH_HIST_BINS * 4) == hipSuccess && hipMemset(c->d_lens, 0, SZK_MAX_BOOKS * SZH_HIST_BINS) == hipSuccess &&
+                 hipMemset(c->bk[1].enc, 0, SZH_HIST_BINS * 4) == hipSuccess && hipMemset(c->bk[1].lens, 0, SZH_HIST_BINS) == hipSuccess &&
+                 hipMemset(c->d_info, 0, SZK_MAX_BOOKS * sizeof(szk_cb_info)) == hipSuccess && hipMemset(c->bk[1].info, 0, sizeof(szk_cb_info)) == hipSuccess;
     c->bk[0].enc = c->d_enc;
     c->bk[0].lens = c->d_lens;
     c->bk[0].info = c->d_info;
@@ -516,7 +527,10 @@ static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *
     // that takes costs more than the k_hist_range launch it saves (szk_launch_k1 reports through range_kept what was done)
     p.range = reinterpret_cast<uint32_t *>(ctx->d_counters + 8);
     p.hint_narrow = allow_narrow ? ctx->narrow_hint : -1;
-    if (allow_narrow && book_spec_ok(ctx, 0, (uint32_t)radius)) {
+    // (a caller that holds the histogram exchanges it between the stages — multi-GPU: the one-launch form's repeat of a whole
+    // call from inside finish() could not redo that exchange, so such contexts keep the form that waits for the probe)
+    if (ctx->hist_exposed && p.hint_narrow > 0) p.hint_narrow = -1;
+    if (allow_narrow && book_spec_ok(ctx, 0, (uint32_t)radius) && ((ctx->cb_hint == 0 && !ctx->lists_long && !ctx->hist_exposed) || (szk_dbg_flags & 67108864))) {
         // stage 2 will pack with the previous call's book: its code lengths let the one-byte kernel sum the code bits of the
         // 256-element segments (no bits pass), and the fold of the histogram rows moves to the side stream the new book is built on
         p.spec_lens = ctx->bk[ctx->book_idx].lens;
@@ -538,6 +552,7 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
     int rc = lorenzo_k1(ctx, conf->N, conf->dims, d_in, eb, radius, num, ctx->cur_out_cap, true, p, s);
     ctx->mode = p.mode;
     ctx->range_ready = p.range_kept != 0;
+    ctx->s1_assumed_narrow = p.assumed_narrow != 0;
     ctx->s1_spec = p.spec_lens != nullptr;
     ctx->seg_expected = p.seg_expected != 0 && !(szk_dbg_flags & 33554432);
     ctx->fold_rows = p.defer_fold ? p.fold_rows : 0;
@@ -959,8 +974,10 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     for (int i = 0; i < ST_COUNT; i++) ctx->ev_used[i] = false;  // stage times describe this call only
     ctx->copy_ahead = false;
     ctx->range_ready = false;
-    ctx->s1_spec = ctx->seg_expected = false;
+    ctx->s1_spec = ctx->seg_expected = ctx->s1_assumed_narrow = false;
     ctx->fold_rows = 0;
+    ctx->s1_conf = *conf_in;
+    ctx->s1_in = d_in;
     prof_begin(ctx, ST_SPAN, s);  // (closed at the end of stage 2: the device time of the whole step)
     if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP_LORENZO) {  // the reference's default: sampling auto-tuner, then one of the two paths
         // The tuner is a chain of small launches and host round trips (the chip is mostly idle), and its outcome is almost
@@ -1110,7 +1127,13 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     // packs with THAT book on the caller's stream while this call's book is built from this call's histogram on the side
     // stream; finish() compares the two and repeats the encoder when they differ. The book a payload is coded with is always
     // the one its own histogram gives.
-    const bool spec = ctx->proto.predictor == 0 ? ctx->s1_spec : book_spec_ok(ctx, ctx->proto.predictor, ctx->proto.radius);
+    bool spec = ctx->proto.predictor == 0 ? ctx->s1_spec : book_spec_ok(ctx, ctx->proto.predictor, ctx->proto.radius);
+    // Only the one-stream form pays: small alphabet, short outlier lists, range words kept by stage 1 (what a smooth field's
+    // previous call left). Building a wide alphabet's book on a side stream beside the encoder was measured slower than building
+    // it first (C3: 1.34 against 1.24 ms — two cross-stream dependencies cost more than the 0.15 ms they hide); it stays behind
+    // a development switch.
+    const bool fused_ok = ctx->cb_hint == 0 && !ctx->lists_long && ctx->range_ready && !ctx->hist_exposed;
+    if (spec && !fused_ok && !(szk_dbg_flags & 67108864)) spec = false;
     int rc = stage2_launch(ctx, d_payload, cap, s, spec ? S2_SPEC : S2_CLASSIC);
     if (rc) return rc;
     ctx->stage2_done = true;
@@ -1129,7 +1152,7 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     // Small alphabets with short outlier lists (what the previous call had): this call's book, the verdict and the list sorts
     // ride in the packer's own launch as three role workgroups, the fold of stage 1's histogram rows in the scan's launch —
     // one stream, two launches. Otherwise the book is built on a side stream (wide alphabets need a whole compute unit's LDS).
-    const bool fused = how == S2_SPEC && ctx->cb_hint == 0 && !ctx->lists_long && cb.range_ready && !(szk_dbg_flags & 67108864);
+    const bool fused = how == S2_SPEC && ctx->cb_hint == 0 && !ctx->lists_long && cb.range_ready && !(szk_dbg_flags & 67108864);  // (67108864: the side-stream form)
     szk_encode_roles er;
     memset(&er, 0, sizeof(er));
     if (fused) {
@@ -1163,7 +1186,7 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
         HIPCHK(hipEventRecord(ctx->ev_sorted, bs));
         cb.skip_sort = 1;
         cb.slim = 1;
-    } else if (ctx->fold_rows) {  // (not reached: stage 1 defers the fold only when stage 2 speculates)
+    } else if (ctx->fold_rows) {  // (stage 1 deferred the fold and stage 2 does not speculate after all: the range words were not kept)
         if (szk_launch_hist_fold(ctx->d_hist_partial, ctx->fold_rows, (int)ctx->proto.radius, ctx->d_hist, ctx->fold_range, s))
             return fail(SZ3HIP_EHIP, "histogram fold launch failed");
         ctx->fold_rows = 0;
@@ -1202,6 +1225,8 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     ap.vout_val = ctx->d_vout_val;
     ap.dout_val = ctx->d_dout_val;
     ap.side = ctx->proto.predictor == 2 ? ctx->d_blk_side : nullptr;
+    ap.assumed_narrow = ctx->s1_assumed_narrow ? 1 : 0;
+    ap.mode = ctx->mode;
     prof_begin(ctx, ST_ENCODE, s);  // (the payload layout is computed inside the encoder's scan launch, the sections are assembled by the packer's)
     int rc = szk_launch_encode(ctx->d_codes, n, ctx->bk[used].enc, ctx->bk[used].info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words,
                                ctx->d_chunk_off, ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, &lp, &ap, s,
@@ -1218,6 +1243,8 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     }
     prof_end(ctx, ST_SPAN, s);
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(szk_state), hipMemcpyDeviceToHost, s));
+    if (!ctx->ev_done) HIPCHK(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ctx->ev_done, s));
     // (h_state->probe = the probe counters: |delta| > 127, in [4096, 8192), in [2048, 4096); [4] = interpolation codes beyond +-4096)
     return 0;
 }
@@ -1226,8 +1253,23 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
     if (!ctx->stage2_done) return fail(SZ3HIP_EINVAL, "finish called before stage2");
-    HIPCHK(hipStreamSynchronize(s));
-    if (ctx->s2_spec) {
+    HIPCHK(hipEventSynchronize(ctx->ev_done));  // (the payload is complete: the state's copy is the last thing stage 2 enqueued)
+    if (ctx->h_state->miss_kind & 32u) {
+        // stage 1 assumed one-byte codes (the form a context takes after a one-byte call) and this call's probe says two: the
+        // whole call once more, in the form that waits for the probe. The input must still be where stage 1 found it.
+        ctx->redo_calls++;
+        ctx->spec_misses++;  // (counted with the other failed shortcuts)
+        ctx->narrow_hint = 0;
+        const int spec_was = ctx->spec_off;
+        ctx->spec_off = 1;
+        sz3hip_config conf = ctx->s1_conf;
+        int rc1 = sz3hip_compress_stage1(ctx, &conf, ctx->s1_in, stream);
+        ctx->spec_off = spec_was;
+        if (rc1) return rc1;
+        rc1 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s, S2_CLASSIC);
+        if (rc1) return rc1;
+        HIPCHK(hipEventSynchronize(ctx->ev_done));
+    } else if (ctx->s2_spec) {
         if (ctx->h_state->book_miss || ctx->h_state->miss_kind) {
             // the previous call's book is not this call's: the encoder once more, with the book the side stream built from this
             // call's histogram (or, when the code-book form launched alone declined the alphabet, the whole of stage 2)
@@ -1241,7 +1283,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
             }
             int rc2 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s, redo_book ? S2_CLASSIC : S2_REENCODE);
             if (rc2) return rc2;
-            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipEventSynchronize(ctx->ev_done));
         } else {
             ctx->spec_hits++;
         }
@@ -1253,10 +1295,18 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
         HIPCHK(hipMemsetAsync(ctx->d_counters + 7, 0, 8, s));
         int rc2 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s, S2_CLASSIC);
         if (rc2) return rc2;
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipEventSynchronize(ctx->ev_done));
         if (ctx->h_state->mispredict) return fail(SZ3HIP_EHIP, "code book was not built (both forms declined)");
     }
     ctx->stage1_done = ctx->stage2_done = false;
+    // the next call's histogram and counters start from zero: enqueue that now, behind this call, instead of in front of the
+    // next one (a launch and its gap off the next call's critical path). Everything the host still wants is in h_state.
+    if (ctx->d_hist == ctx->d_hist_own && !ctx->hist_exposed && !(szk_dbg_flags & 268435456)) {
+        if (hipMemsetAsync(ctx->d_hist, 0, SZH_HIST_BINS * 8 + SZ_COUNTER_BYTES, s) == hipSuccess) {
+            ctx->pre_cleared = true;
+            ctx->pre_stream = s;
+        }
+    }
     const szk_state &st = *ctx->h_state;
     if (st.hdr.magic != SZH_MAGIC) return fail(SZ3HIP_EHIP, "device did not produce a payload header (kernel fault?)");
     // the book this payload was coded with is the context's reference from now on
@@ -1316,8 +1366,7 @@ extern "C" int sz3hip_compress_device(sz3hip_ctx *ctx, const sz3hip_config *conf
     // where the stream stops beating the lossless fallback) when the caller's buffer allows it
     // (sz3hip_payload_bound_max), and the call runs once more.
     const uint64_t n = ctx->proto.n;
-    uint64_t cnt[2] = {0, 0};
-    HIPCHK(hipMemcpy(cnt, ctx->d_counters, 16, hipMemcpyDeviceToHost));
+    const uint64_t cnt[2] = {ctx->h_state->n_vout_raw, ctx->h_state->n_dout_raw};
     const uint64_t need = std::max(cnt[0], cnt[1]);
     if (need > out_cap_limit(n)) return rc;
     const uint64_t want = std::min<uint64_t>(out_cap_limit(n), need + need / 16 + 1024);
@@ -1356,8 +1405,7 @@ extern "C" int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, ui
     HIPCHK(hipSetDevice(ctx->device));
     if (n > ctx->max_n) return fail(SZ3HIP_EINVAL, "n exceeds capacity");
     HIPCHK(hipDeviceSynchronize());
-    uint32_t big = 0;
-    HIPCHK(hipMemcpy(&big, ctx->d_counters + 4, 4, hipMemcpyDeviceToHost));
+    const uint32_t big = ctx->h_state->probe[0];  // (the device counters are zeroed behind every call)
     const bool narrow = ctx->mode.allow && (uint64_t)big * 4096ull <= ctx->mode.n_samples;
     if (!narrow) {
         HIPCHK(hipMemcpy(host_codes, ctx->d_codes, n * 2, hipMemcpyDeviceToHost));

@@ -73,7 +73,14 @@ struct sz3hip_ctx {
     int spec_off;                     // test / bench hook: never speculate (every call behaves like a context's first)
     uint32_t spec_hits, spec_misses;  // statistics (sz3hip_get_spec_stats)
     hipEvent_t ev_sorted, ev_book;
+    hipEvent_t ev_done;  // recorded behind the state's device-to-host copy: finish() waits for it, not for the whole stream
+    hipStream_t pre_stream;
+    bool pre_cleared;    // finish() of the previous call already enqueued the zeroing of histogram and counters
     // stage 1 of the pending Lorenzo call, when it ran with the previous book's code lengths (speculation decided there):
+    bool s1_assumed_narrow;  // stage 1 ran the one-launch form (assumes one-byte codes; the probe rides in it)
+    sz3hip_config s1_conf;   // stage 1's arguments, kept for the repeat of the whole call after a wrong assumption
+    const void *s1_in;
+    uint32_t redo_calls;     // statistics: calls repeated from stage 1
     bool s1_spec;          // stage 2 speculates (same condition, evaluated once per call)
     bool seg_expected;     // stage 1 sums the code bits per 256-element segment: stage 2 launches no bits pass
     uint32_t fold_rows;    // != 0: the fold of stage 1's histogram rows was left to stage 2 (side stream)

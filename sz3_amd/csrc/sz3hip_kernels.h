@@ -63,6 +63,7 @@ struct szk_k1_params {
     uint16_t *seg_bits;
     uint32_t *seg_made;   // device flag, raised by the form that sums the segments
     int seg_expected;     // out: the launched form sums the segments when this call's probe keeps one-byte codes
+    int assumed_narrow;   // out: the one-launch form was taken: it assumes one-byte codes and runs the probe itself
     // defer_fold: the launcher leaves out k_hist_reduce (the caller runs szk_launch_hist_fold on a stream of its choice);
     // fold_rows (out): rows of hist_partial to fold, 0 when the launched kernels need no fold
     int defer_fold;
@@ -109,7 +110,9 @@ struct szk_state {
     uint32_t mispredict, n_symbols;  // code book: wrong form launched alone (stage 2 is repeated); size of the alphabet
     uint32_t book_miss, miss_kind;   // speculative stage 2: the encoder's output is void (stage 2 is repeated); why: 1 the previous call's code
                                      // book is not this call's, 2 code-book form declined, 4 outlier list too long for the short sort,
-                                     // 8 stage 1 did not sum the segments' bits
+                                     // 8 stage 1 did not sum the segments' bits, 32 stage 1 assumed one-byte codes and the probe says two
+                                     // (the whole call is repeated)
+    uint64_t n_vout_raw, n_dout_raw;  // the outlier counters before capping at the lists' capacity (what an overflowing call needs)
     uint32_t probe[6];  // copy of the probe counters (d_counters + 4): one device-to-host copy brings everything the host reads
 };
 struct szk_layout_params {
@@ -134,6 +137,8 @@ struct szk_asm_params {
     const void *vout_val, *dout_val;
     const uint8_t *side;  // predictor 2: the side section as the block kernels left it (else nullptr)
     int lists_by_roles;   // the outlier lists are sorted AND copied by role workgroups of the packer's launch (speculative stage 2)
+    int assumed_narrow;   // stage 1 ran the one-launch form, which assumes one-byte codes: a probe that says otherwise raises miss_kind bit 32
+    szk_mode mode;
 };
 // speculative stage 2, small alphabets: work that rides in the encoder's two launches instead of a side stream
 struct szk_encode_roles {

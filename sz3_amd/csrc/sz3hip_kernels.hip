@@ -2824,8 +2824,28 @@ __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE]
         bits += gl[k];
     }
     const uint32_t incl = wave_incl_scan(bits);
-    const uint32_t total_bits = __shfl(incl, WAVE - 1, WAVE);
+    const uint32_t total_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
     uint32_t pos = incl - bits;
+    if (BYTE && G == 4) {
+        // one-byte codes: a lane's sixteen symbols are ~66 bits on a smooth field — two registers of eight symbols instead of four
+        // of four halve the emission work whenever every lane's pairs of registers fit 64 bits (a wave-uniform test)
+        const bool fits = gl[0] + gl[1] <= 64u && gl[2] + gl[3] <= 64u;
+        if (!__builtin_amdgcn_ballot_w64(!fits)) {
+#pragma unroll
+            for (int k = 0; k < NG; k += 2) {
+                const uint32_t len = gl[k] + gl[k + 1];
+                const uint64_t joined = (gl[k + 1] < 64u ? g[k] << gl[k + 1] : 0ull) | g[k + 1];
+                const uint64_t v = len ? joined << (64 - len) : 0ull;  // left-aligned
+                const uint32_t word = pos >> 5, sh = pos & 31;
+                const uint64_t t = v >> sh;
+                atomicOr(&stage[word], (uint32_t)(t >> 32));
+                atomicOr(&stage[word + 1], (uint32_t)t);
+                atomicOr(&stage[word + 2], (uint32_t)(((uint64_t)(uint32_t)v << 32) >> sh));
+                pos += len;
+            }
+            return (total_bits + 31) >> 5;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NG; k++) {
         const uint64_t v = gl[k] ? g[k] << (64 - gl[k]) : 0ull;  // left-aligned
@@ -3063,7 +3083,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     __shared__ __align__(16) uint32_t s_enc[WIN];
     __shared__ uint32_t s_enc8[256];  // one-byte codes: code word by byte value ...
     __shared__ uint8_t s_plen8[256];  // ... and its length
-    __shared__ uint32_t s_stage[4][STAGE_WORDS];
+    __shared__ __align__(8) uint32_t s_stage[4][STAGE_WORDS];
     const uint32_t roles = rp.on ? ROLE_BLOCKS : 0u;
     if (blockIdx.x < roles) {  // (the first workgroups dispatched; s_enc's 16 KB serve as their scratch)
         static_assert(WIN * 4 >= ROLE_SORT_MAX * 16 && WIN * 4 >= CB_SMALL_SYMS * 28 + 256, "role scratch fits the table");
@@ -3144,10 +3164,11 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         uint32_t *out = out_base + go_cur + before;
-        for (uint32_t i = lane; i < nwords + 2; i += WAVE) {  // copy out and re-zero the stage for the next chunk
-            const uint32_t wv = stage[i];
-            stage[i] = 0;
-            if (i < nwords) out[i] = __builtin_bswap32(wv);  // bytes in stream order (see sz3hip_format.h)
+        for (uint32_t i = 2 * lane; i < nwords + 2; i += 2 * WAVE) {  // copy out and re-zero the stage for the next chunk, two words per lane
+            const uint2 wv = *reinterpret_cast<const uint2 *>(&stage[i]);
+            *reinterpret_cast<uint2 *>(&stage[i]) = make_uint2(0u, 0u);
+            if (i < nwords) out[i] = __builtin_bswap32(wv.x);  // bytes in stream order (see sz3hip_format.h)
+            if (i + 1 < nwords) out[i + 1] = __builtin_bswap32(wv.y);
         }
         __builtin_amdgcn_wave_barrier();
         cur = nxt;

@@ -22,6 +22,14 @@
 
 /* ------------------------------------------------------------------------------------------------ */
 static _Thread_local char g_err[256];
+/* diagnostics for the parity tests: the predictor the composed predictor chose for every block (0 Lorenzo-1, 1 Lorenzo-2,
+ * 2 regression), in the order BlockwiseDecomposition visits the blocks; not part of the reference API */
+static int8_t *g_sel_sink;
+static size_t g_sel_cap;
+void szo_debug_selection_sink(int8_t *buf, size_t cap) {
+    g_sel_sink = buf;
+    g_sel_cap = cap;
+}
 static _Thread_local int zstd_cap_error; /* mirrors std::length_error(SZ3_ERROR_COMP_BUFFER_NOT_LARGE_ENOUGH) */
 static int set_err(const char *m) {
     snprintf(g_err, sizeof(g_err), "%s", m);

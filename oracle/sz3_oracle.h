@@ -73,6 +73,8 @@ size_t szo_compress(const szo_config *c, int dtype, const void *data, uint8_t *o
 /* decData must hold conf.num elements; conf_out receives the trailer config. returns num elements, 0 on error */
 size_t szo_decompress(int dtype, const uint8_t *cmp, size_t cmp_size, void *dec, szo_config *conf_out);
 const char *szo_last_error(void);
+/* diagnostics: the next szo_compress calls write the predictor chosen for block i (visiting order) to buf[i] (NULL: off) */
+void szo_debug_selection_sink(int8_t *buf, size_t cap);
 
 /* stage-level entry points (unit tests restating tools/test/modules/test_{quantizer,encoder,lossless}.cpp) */
 /* LinearQuantizer<T>::quantize_and_overwrite / recover on one value (quantizer/LinearQuantizer.hpp:43-86).

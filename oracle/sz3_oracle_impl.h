@@ -579,6 +579,7 @@ static int SUF(blockwise_compress)(const szo_config *conf, SUF(predset) * ps, SU
         int ok = SUF(ps_precompress)(ps, &b);
         int kind = ok ? ps->kinds[ps->sid] : PK_LORENZO1; /* fallback_predictor :35-37 */
         if (ok) SUF(ps_commit)(ps);
+        if (g_sel_sink && ps->n_blocks < g_sel_cap) g_sel_sink[ps->n_blocks] = (int8_t)kind;
         /* NOTE: when precompress fails the reference calls fallback_predictor.precompress_block_commit()
          * (a no-op, LorenzoPredictor.hpp:44) and the composed predictor's selection is NOT extended. */
         ps->n_blocks++;

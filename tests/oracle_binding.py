@@ -130,6 +130,23 @@ def make_config(shape, algo=ALGO_LORENZO_REG, eb_mode=EB_ABS, abs_eb=1e-3, rel_e
     return c
 
 
+def oracle_selection(a, conf):
+    """the predictor the oracle's composed predictor chooses for every block of `a` (0 Lorenzo-1, 1 Lorenzo-2, 2 regression),
+    in block raster order"""
+    L = oracle()
+    bs = int(conf.blockSize)
+    nb = int(np.prod([(d + bs - 1) // bs for d in a.shape]))
+    sel = np.full(nb, -1, dtype=np.int8)
+    L.szo_debug_selection_sink.argtypes = [C.c_void_p, C.c_size_t]
+    L.szo_debug_selection_sink.restype = None
+    L.szo_debug_selection_sink(sel.ctypes.data, nb)
+    try:
+        oracle_compress(a, conf)
+    finally:
+        L.szo_debug_selection_sink(None, 0)
+    return sel
+
+
 def oracle_compress(a, conf, stats=False):
     L = oracle()
     a = np.ascontiguousarray(a)

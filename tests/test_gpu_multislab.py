@@ -86,6 +86,54 @@ def test_openmp_container_of_gpu_streams_round_trips_with_one_code_book(algo, sl
             assert np.array_equal(sz3_amd.decompress(sb, dtype, (hi - lo,) + shape[1:])[0], dec[lo:hi])
 
 
+@pytest.mark.parametrize("slabs", [2, 3])
+def test_c4_lorenzo_plus_regression_through_the_slab_path(slabs, rccl, monkeypatch):
+    """BASELINE config C4 in small: float64, Lorenzo + regression chosen per block (the reference's default predictor set for
+    ALGO_LORENZO_REG), abs 1e-6, split into slabs along dims[0] with the histogram summed over the slabs (one-rank RCCL here).
+    Every slab is a block-composed stream (SZH1 predictor 2) coded with the SAME code book; the container decodes within the
+    bound; every slab's reconstruction equals what a single-slab call on that slab gives; ratio against the oracle's
+    OpenMP-container ratio for the same split."""
+    from fields import field_c4a
+    from oracle_binding import make_config, oracle_compress
+    monkeypatch.setenv("SZ3HIP_SLABS", str(slabs))
+    shape = (60, 48, 54)
+    a = field_c4a(shape)
+    eb = 1e-6
+    conf = sz3_amd.Config(*shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.lorenzo, conf.lorenzo2, conf.regression = 1, 0, 1
+    conf.absErrorBound = eb
+    conf.openmp = 1
+    blob, ratio = sz3_amd.compress(a, conf)
+    outer, confs, blobs = D.split_container(blob.tobytes())
+    assert len(blobs) == slabs
+    books, reg_blocks = [], 0
+    for g in range(slabs):
+        sc = sz3_amd.Config.load(confs[g])
+        assert sc.cmprAlgo == sz3_amd.ALGO_HIP_LORENZO and (sc.lorenzo, sc.lorenzo2, sc.regression) == (1, 0, 1)
+        h, o, sec = szh_ref.parse(_unzstd(blobs[g]))
+        assert h["predictor"] == 2 and h["blk_edge"] == 6 and h["blk_mask"] == 5
+        sel, _ = szh_ref.parse_side(h, sec)
+        reg_blocks += int((sel == 2).sum())
+        books.append((h["sym_min"], h["sym_count"], sec["lens"].tobytes()))
+    assert all(b == books[0] for b in books), "slabs were coded with different code books"
+    assert reg_blocks > 0, "no block took regression: the field does not exercise the composed predictor"
+    dec, c2 = sz3_amd.decompress(blob, np.float64, shape)
+    assert c2.openmp == 1 and float(np.max(np.abs(dec - a))) <= eb
+    conf.openmp = 0
+    for g in range(slabs):
+        lo, hi = D.slab_bounds(shape[0], slabs, g)
+        sconf = sz3_amd.Config(hi - lo, *shape[1:])
+        for k in ("cmprAlgo", "lorenzo", "lorenzo2", "regression", "absErrorBound"):
+            setattr(sconf, k, getattr(conf, k))
+        sb, _ = sz3_amd.compress(np.ascontiguousarray(a[lo:hi]), sconf)
+        assert np.array_equal(sz3_amd.decompress(sb, np.float64, (hi - lo,) + shape[1:])[0], dec[lo:hi])
+    oconf = make_config(shape, abs_eb=eb, lorenzo=True, regression=True, openmp=True)
+    o_ratio = a.nbytes / len(oracle_compress(a, oconf))
+    print("C4 in small, %d slabs: ratio %.2f (oracle, OpenMP container: %.2f), regression blocks %d" % (slabs, ratio, o_ratio, reg_blocks))
+    assert ratio >= 0.9 * o_ratio
+
+
 def test_shared_code_book_really_is_the_global_one(rccl, monkeypatch):
     """the lens table of a 2-slab container equals the table of ONE stream over the whole array only if the histograms
     were summed: here the two slabs have disjoint alphabets"""

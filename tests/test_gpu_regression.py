@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 import sz3_amd  # noqa: E402
 import szh_ref  # noqa: E402
 from fields import field3d, field_c4a  # noqa: E402
-from oracle_binding import make_config, oracle, oracle_compress  # noqa: E402
+from oracle_binding import make_config, oracle, oracle_compress, oracle_selection  # noqa: E402
 
 
 def _payload_of(stream):
@@ -102,6 +102,46 @@ def test_c4a_ratio_and_selection_share_against_the_oracle(n):
     print("C4a %d^3: ratio %.2f (oracle %.2f), regression share %.3f (oracle %.3f)" % (n, ratio, o_ratio, share, o_share))
     assert ratio >= 0.97 * o_ratio
     assert 0.6 * o_share <= share <= 1.4 * o_share
+    # block by block (ComposedPredictor.hpp:25-40: first minimum of the sampled error estimates): the selection vector in the
+    # stream's side section against the oracle's own choices, same block raster order
+    oconf = make_config(a.shape, abs_eb=eb, lorenzo=True, regression=True)
+    osel = oracle_selection(a, oconf)
+    sel = np.asarray(sel).reshape(-1)  # (blocks in raster order, like the oracle visits them)
+    assert osel.size == sel.size and (osel >= 0).all()
+    same = float((osel == sel).mean())
+    both_reg = int(((osel == 2) & (sel == 2)).sum())
+    print("  per-block selection: %.2f %% identical; regression in both %d, oracle only %d, gpu only %d"
+          % (100 * same, both_reg, int(((osel == 2) & (sel != 2)).sum()), int(((osel != 2) & (sel == 2)).sum())))
+    assert same >= 0.90, same
+    # a biased estimator would disagree in one direction: of the blocks either side gives to regression, most are common
+    assert both_reg >= 0.6 * max(int((osel == 2).sum()), int((sel == 2).sum()))
+
+
+@pytest.mark.parametrize("mask", ["L2", "L1+L2", "L2+R", "L1+L2+R"])
+def test_second_order_lorenzo_against_the_oracle(mask):
+    """LorenzoPredictor.hpp:75-91 (2nd order) on a field where it wins: the noise-free C2 formula at abs 1e-4 (oracle at 64^3: Lorenzo-1
+    5.3, Lorenzo-2 7.0, both 6.95). Bound strict; ratio >= 0.95 x the oracle's for the same predictor set, and the sets with
+    Lorenzo-2 beat plain Lorenzo-1 like the reference's do; in the composed sets most blocks take Lorenzo-2 on both sides."""
+    a = field3d((96, 96, 96), np.float32, sigma=0.0)
+    eb = 1e-4
+    l1, l2, rg = MASKS[mask]
+    oconf = make_config(a.shape, abs_eb=eb, lorenzo=bool(l1), regression=bool(rg))
+    oconf.lorenzo2 = l2
+    o_ratio = a.nbytes / len(oracle_compress(a, oconf))
+    blob, ratio = sz3_amd.compress(a, _conf(a.shape, eb, l1, l2, rg))
+    dec, c2 = sz3_amd.decompress(blob, np.float32, a.shape)
+    assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= eb
+    assert (c2.lorenzo, c2.lorenzo2, c2.regression) == MASKS[mask]
+    _, plain = sz3_amd.compress(a, _conf(a.shape, eb, 1, 0, 0))
+    h, o, sec = szh_ref.parse(_payload_of(blob))
+    sel = np.asarray(szh_ref.parse_side(h, sec)[0]).reshape(-1)
+    osel = oracle_selection(a, oconf)
+    print("C2 noise-free 96^3 @1e-4 %s: ratio %.2f (oracle %.2f), plain Lorenzo-1 %.2f; Lorenzo-2 blocks %.3f (oracle %.3f)"
+          % (mask, ratio, o_ratio, plain, float((sel == 1).mean()), float((osel == 1).mean())))
+    assert ratio >= 0.95 * o_ratio
+    assert ratio > 1.15 * plain
+    if l1 or rg:  # a composed set: the selection itself, block by block
+        assert float((osel == sel).mean()) >= 0.85
 
 
 def test_regression_only_beats_lorenzo_where_the_reference_says_so():

@@ -26,7 +26,9 @@
 #include <chrono>
 #include <condition_variable>
 #include <memory>
+#include <functional>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -93,7 +95,11 @@ static size_t bound_frames(size_t n) {
     return nf * bound(std::min(n, FRAME)) + 8;
 }
 // [u64 srcLen][frame]...  level 3 (lossless/Lossless_zstd.hpp:48); returns 0 on error
-static size_t compress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {
+// feeder (optional): fills `src` front to back while the frames are being compressed — the calling thread runs it and
+// publishes how many bytes have landed; a frame is started when its input is complete (the payload's trip from the device
+// overlaps its compression). It returns non-zero on failure.
+static size_t compress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
+                              const std::function<int(std::atomic<size_t> &)> *feeder = nullptr) {
     if (load()) return 0;
     if (cap < 8) {
         fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
@@ -112,11 +118,14 @@ static size_t compress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t
     std::atomic<unsigned> arrived(0);
     unsigned nt = (unsigned)std::min<size_t>(nthreads(), nf);
     std::atomic<int> phase(0);  // 1: offsets ready (copy), -1: give up
+    std::atomic<size_t> ready(feeder ? 0 : n);
     auto work = [&]() {
         for (;;) {
             size_t f = next.fetch_add(1);
             if (f >= nf) break;
             size_t lo = f * FRAME, l = std::min(FRAME, n - lo);
+            while (ready.load(std::memory_order_acquire) < lo + l && !bad.load()) std::this_thread::yield();
+            if (bad.load()) continue;
             out[f].reset(new (std::nothrow) uint8_t[fb]);
             if (!out[f]) {
                 bad = 1;
@@ -146,8 +155,15 @@ static size_t compress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t
     };
     std::vector<std::thread> th;
     for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    int feed_rc = 0;
+    if (feeder) {
+        feed_rc = (*feeder)(ready);
+        if (feed_rc) bad = 1;
+        ready.store(n, std::memory_order_release);
+    }
     work();
     for (auto &t : th) t.join();
+    if (feed_rc) return 0;  // (the feeder recorded its own error)
     if (bad) {
         fail(SZ3HIP_EZSTD, "ZSTD_compress failed");
         return 0;
@@ -276,21 +292,28 @@ extern "C" size_t sz3hip_compress_bound(const sz3hip_config *c, int dataType) { 
 
 namespace {
 // Everything one slab of a host-API call needs on one GPU: context, staging buffers, stream. Cached per (device, computing
-// type, index); grown on demand. The host API is serialised per process (g_host_mu); inside a multi-slab call the slots of
-// one device are worked by that device's host thread only.
+// type, index); grown on demand. Single-slab calls of different threads run side by side, each on a slot it leases for the
+// call (an HDF5-style chunk pipeline with worker threads compresses its chunks concurrently: round 2 took a process-wide
+// mutex here); multi-slab calls (conf.openmp, the rank form) address their slots by index and take the host API exclusively
+// (g_host_mu: shared by single-slab calls, unique for those); inside a multi-slab call the slots of one device are worked by
+// that device's host thread only.
 struct HostSlot {
     int device = 0, dtype = 0, index = 0;
     sz3hip_ctx *ctx = nullptr;
     hipStream_t stream = nullptr;
     void *dev_in = nullptr, *dev_payload = nullptr, *pin = nullptr;
     size_t dev_in_bytes = 0, dev_payload_bytes = 0, pin_bytes = 0;
+    bool busy = false;  // leased to a single-slab call (g_pool_mu)
 };
-std::mutex g_host_mu;
+std::shared_mutex g_host_mu;
+std::mutex g_pool_mu;  // the slot list and the leases
 std::vector<std::unique_ptr<HostSlot>> g_slots;
 sz3hip_comm *g_comm;
 int g_comm_ndev;
 
+// (multi-slab calls, under the unique lock: no lease is out)
 HostSlot *get_slot(int device, int dtype, int index) {
+    std::lock_guard<std::mutex> pl(g_pool_mu);
     for (auto &s : g_slots)
         if (s->device == device && s->dtype == dtype && s->index == index) return s.get();
     g_slots.emplace_back(new HostSlot());
@@ -300,6 +323,34 @@ HostSlot *get_slot(int device, int dtype, int index) {
     s->index = index;
     return s;
 }
+// a slot of (device, dtype) nobody is using, for the duration of one single-slab call: the lowest free index, a new one when
+// all are taken (every concurrent caller ends up with a context of its own)
+struct SlotLease {
+    HostSlot *s = nullptr;
+    SlotLease(int device, int dtype) {
+        std::lock_guard<std::mutex> pl(g_pool_mu);
+        int n_same = 0;
+        for (auto &c : g_slots)
+            if (c->device == device && c->dtype == dtype) {
+                n_same++;
+                if (!c->busy && (!s || c->index < s->index)) s = c.get();
+            }
+        if (!s) {
+            g_slots.emplace_back(new HostSlot());
+            s = g_slots.back().get();
+            s->device = device;
+            s->dtype = dtype;
+            s->index = n_same;
+        }
+        s->busy = true;
+    }
+    ~SlotLease() {
+        std::lock_guard<std::mutex> pl(g_pool_mu);
+        s->busy = false;
+    }
+    SlotLease(const SlotLease &) = delete;
+    SlotLease &operator=(const SlotLease &) = delete;
+};
 // (the calling thread's current device is the slot's)
 int slot_ctx(HostSlot *s, uint64_t n) {
     if (!s->stream) HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -514,14 +565,23 @@ int job_encode(SlabJob &j) {
             j.lossless = true;  // the GPU stream would not even beat the raw array (tiny or incompressible input)
         } else {
             if (ensure_pin(s, dsize)) return j.failed(SZ3HIP_EHIP);
-            if (hipMemcpy(s->pin, s->dev_payload, dsize, hipMemcpyDeviceToHost) != hipSuccess) {
-                fail(SZ3HIP_EHIP, "device->host copy failed");
-                return j.failed(SZ3HIP_EHIP);
-            }
-            if (j.tm) j.tm->lap("device->host");
-            j.out_size = zs::compress_frames((const uint8_t *)s->pin, dsize, j.out, j.out_cap);
+            // the payload comes over in pieces while the host threads already compress the frames that have landed
+            std::function<int(std::atomic<size_t> &)> feeder = [&](std::atomic<size_t> &ready) -> int {
+                const size_t PIECE = 8u << 20;
+                for (size_t off = 0; off < dsize; off += PIECE) {
+                    const size_t l = std::min(PIECE, dsize - off);
+                    if (hipMemcpyAsync((uint8_t *)s->pin + off, (const uint8_t *)s->dev_payload + off, l, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+                        hipStreamSynchronize(s->stream) != hipSuccess) {
+                        fail(SZ3HIP_EHIP, "device->host copy failed");
+                        return SZ3HIP_EHIP;
+                    }
+                    ready.store(off + l, std::memory_order_release);
+                }
+                return 0;
+            };
+            j.out_size = zs::compress_frames((const uint8_t *)s->pin, dsize, j.out, j.out_cap, &feeder);
             if (!j.out_size) return j.failed(sz3hip_last_error_code());
-            if (j.tm) j.tm->lap("zstd");
+            if (j.tm) j.tm->lap("device->host + zstd");
             j.conf.cmprAlgo = ctx->h_state->hdr.predictor == 1 ? SZ3HIP_ALGO_HIP_INTERP : SZ3HIP_ALGO_HIP_LORENZO;
             if (ctx->h_state->hdr.predictor == 0) {  // the plain Lorenzo stream: the trailer names the predictor set that coded it
                 j.conf.lorenzo = 1;
@@ -775,7 +835,10 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
     const size_t payload_cap = cmpCap - 16 - 2 * sz3hip_config_save(&conf, tmp);
     size_t payload_size = 0;
 
-    std::lock_guard<std::mutex> lock(g_host_mu);
+    std::unique_lock<std::shared_mutex> all(g_host_mu, std::defer_lock);
+    std::shared_lock<std::shared_mutex> some(g_host_mu, std::defer_lock);
+    if (conf.openmp) all.lock();
+    else some.lock();
     DeviceGuard guard;
     if (conf.openmp) {  // SZ_compress_impl, api/impl/SZImpl.hpp:10-20
         payload_size = compress_slabs(conf, dataType, data, w.p, payload_cap);
@@ -783,7 +846,8 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
     } else {
         SlabJob j;
         job_init(j, conf, dataType, data, 0);
-        j.slot = get_slot(host_device(), j.cdt, 0);
+        SlotLease lease(host_device(), j.cdt);
+        j.slot = lease.s;
         j.out = w.p;
         j.out_cap = payload_cap;
         j.tm = &tm;
@@ -818,11 +882,12 @@ extern "C" size_t sz3hip_compress_blob(sz3hip_config *conf, int dataType, const 
         return 0;
     }
     if (zs::load()) return 0;
-    std::lock_guard<std::mutex> lock(g_host_mu);
+    std::shared_lock<std::shared_mutex> lock(g_host_mu);
     DeviceGuard guard;
     SlabJob j;
     job_init(j, *conf, dataType, data, 0);
-    j.slot = get_slot(host_device(), j.cdt, 0);
+    SlotLease lease(host_device(), j.cdt);
+    j.slot = lease.s;
     j.out = reinterpret_cast<unsigned char *>(blob);
     j.out_cap = cap;
     if (job_upload(j)) return 0;
@@ -835,10 +900,10 @@ extern "C" int sz3hip_decompress_blob(const sz3hip_config *conf, int dataType, c
     if (!dtype_ok(dataType))
         return fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
     if (zs::load()) return SZ3HIP_EZSTD;
-    std::lock_guard<std::mutex> lock(g_host_mu);
+    std::shared_lock<std::shared_mutex> lock(g_host_mu);
     DeviceGuard guard;
-    HostSlot *s = get_slot(host_device(), dtype_compute(dataType), 0);
-    return decompress_blob(s, conf, dataType, reinterpret_cast<const unsigned char *>(blob), size, decData);
+    SlotLease lease(host_device(), dtype_compute(dataType));
+    return decompress_blob(lease.s, conf, dataType, reinterpret_cast<const unsigned char *>(blob), size, decData);
 }
 
 // one process per GPU: this rank's slab of SZ_compress_OMP, the exchanges through the rank communicator
@@ -859,7 +924,7 @@ extern "C" size_t sz3hip_compress_rank(sz3hip_comm *comm, const sz3hip_config *g
         return 0;
     }
     if (zs::load()) return 0;
-    std::lock_guard<std::mutex> lock(g_host_mu);
+    std::unique_lock<std::shared_mutex> lock(g_host_mu);
     DeviceGuard guard;
     const int cdt = dtype_compute(dataType);
     uint64_t lo, hi;
@@ -1146,11 +1211,14 @@ extern "C" int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *
     uint64_t payload;
     memcpy(&payload, p, 8);
     p += 8;
-    std::lock_guard<std::mutex> lock(g_host_mu);
+    std::unique_lock<std::shared_mutex> all(g_host_mu, std::defer_lock);
+    std::shared_lock<std::shared_mutex> some(g_host_mu, std::defer_lock);
+    if (conf->openmp) all.lock();
+    else some.lock();
     DeviceGuard guard;
     if (conf->openmp) return decompress_slabs(conf, dataType, p, (size_t)payload, decData);  // SZ_decompress_impl, SZImpl.hpp:22-32
-    HostSlot *s = get_slot(host_device(), dtype_compute(dataType), 0);
-    return decompress_blob(s, conf, dataType, p, (size_t)payload, decData);
+    SlotLease lease(host_device(), dtype_compute(dataType));
+    return decompress_blob(lease.s, conf, dataType, p, (size_t)payload, decData);
 }
 
 

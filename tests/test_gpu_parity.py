@@ -547,3 +547,39 @@ def test_torch_can_start_after_the_library():
             "assert abs(d - a).max() <= 1e-3; import torch; t = torch.ones(4, device='cuda:0'); print('both ok', float(t.sum()))") % os.path.dirname(HERE)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "both ok 4.0" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+
+
+def test_host_api_from_several_threads_at_once():
+    """the host-buffer API leases a slot (context, staging buffers, stream) per call instead of taking a process-wide lock:
+    four threads compress and decompress different arrays concurrently (the shape of an HDF5 chunk pipeline with worker
+    threads); every result equals what the same call gives alone"""
+    import threading
+    arrays = [field3d((40 + 3 * k, 48, 64), np.float32 if k % 2 == 0 else np.float64, seed=100 + k) for k in range(4)]
+    ebs = [1e-3, 1e-6, 1e-2, 1e-4]
+
+    def conf_for(a, eb, algo):
+        c = sz3_amd.Config(*a.shape)
+        c.cmprAlgo = algo
+        c.regression = 0
+        c.absErrorBound = eb
+        return c
+    algos = [sz3_amd.ALGO_LORENZO_REG, sz3_amd.ALGO_INTERP_LORENZO, sz3_amd.ALGO_INTERP, sz3_amd.ALGO_LORENZO_REG]
+    alone = [sz3_amd.compress(a, conf_for(a, eb, al))[0].tobytes() for a, eb, al in zip(arrays, ebs, algos)]
+    out, errs = [None] * 4, []
+
+    def worker(k):
+        try:
+            for _ in range(6):
+                blob, _ = sz3_amd.compress(arrays[k], conf_for(arrays[k], ebs[k], algos[k]))
+                dec, _ = sz3_amd.decompress(blob, arrays[k].dtype, arrays[k].shape)
+                assert float(np.max(np.abs(dec.astype(np.float64) - arrays[k].astype(np.float64)))) <= ebs[k]
+                out[k] = blob.tobytes()
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert out == alone

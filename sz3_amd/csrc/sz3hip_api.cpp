@@ -219,8 +219,6 @@ static void ctx_free(sz3hip_ctx *c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
-    if (c->ev_sorted) (void)hipEventDestroy(c->ev_sorted);
-    if (c->ev_book) (void)hipEventDestroy(c->ev_book);
     if (c->d_flags) (void)hipHostFree(c->d_flags);
     if (c->d_starts) (void)hipHostFree(c->d_starts);
     if (c->h_state) (void)hipHostFree(c->h_state);
@@ -530,7 +528,7 @@ static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *
     // (a caller that holds the histogram exchanges it between the stages — multi-GPU: the one-launch form's repeat of a whole
     // call from inside finish() could not redo that exchange, so such contexts keep the form that waits for the probe)
     if (ctx->hist_exposed && p.hint_narrow > 0) p.hint_narrow = -1;
-    if (allow_narrow && book_spec_ok(ctx, 0, (uint32_t)radius) && ((ctx->cb_hint == 0 && !ctx->lists_long && !ctx->hist_exposed) || (szk_dbg_flags & 67108864))) {
+    if (allow_narrow && book_spec_ok(ctx, 0, (uint32_t)radius) && ctx->cb_hint == 0 && !ctx->lists_long && !ctx->hist_exposed) {
         // stage 2 will pack with the previous call's book: its code lengths let the one-byte kernel sum the code bits of the
         // 256-element segments (no bits pass), and the fold of the histogram rows moves to the side stream the new book is built on
         p.spec_lens = ctx->bk[ctx->book_idx].lens;
@@ -1088,22 +1086,6 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
 
 enum { S2_CLASSIC = 0, S2_SPEC = 1, S2_REENCODE = 2 };
 static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream_t s, int how);
-static int ensure_side(sz3hip_ctx *ctx) {
-    if (!ctx->side) {
-        // highest priority: its small kernels (histogram fold, list sort, code book) become ready together with the encoder's
-        // chip-filling launches on the caller's stream and must not queue behind them
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        HIPCHK(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, greatest));
-        HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    }
-    if (!ctx->ev_sorted) {
-        HIPCHK(hipEventCreateWithFlags(&ctx->ev_sorted, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ctx->ev_book, hipEventDisableTiming));
-    }
-    return 0;
-}
 extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t cap, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
@@ -1128,12 +1110,10 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     // stream; finish() compares the two and repeats the encoder when they differ. The book a payload is coded with is always
     // the one its own histogram gives.
     bool spec = ctx->proto.predictor == 0 ? ctx->s1_spec : book_spec_ok(ctx, ctx->proto.predictor, ctx->proto.radius);
-    // Only the one-stream form pays: small alphabet, short outlier lists, range words kept by stage 1 (what a smooth field's
-    // previous call left). Building a wide alphabet's book on a side stream beside the encoder was measured slower than building
-    // it first (C3: 1.34 against 1.24 ms — two cross-stream dependencies cost more than the 0.15 ms they hide); it stays behind
-    // a development switch.
-    const bool fused_ok = ctx->cb_hint == 0 && !ctx->lists_long && ctx->range_ready && !ctx->hist_exposed;
-    if (spec && !fused_ok && !(szk_dbg_flags & 67108864)) spec = false;
+    // The one-stream form only: small alphabet, short outlier lists, range words kept by stage 1 (what a smooth field's previous
+    // call left). Building a wide alphabet's book on a side stream beside the encoder was built and measured slower than
+    // building it first (C3: 1.34 against 1.24 ms — two cross-stream dependencies cost more than the 0.15 ms they hide).
+    if (spec && !(ctx->cb_hint == 0 && !ctx->lists_long && ctx->range_ready && !ctx->hist_exposed)) spec = false;
     int rc = stage2_launch(ctx, d_payload, cap, s, spec ? S2_SPEC : S2_CLASSIC);
     if (rc) return rc;
     ctx->stage2_done = true;
@@ -1148,11 +1128,9 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     ctx->s2_spec = how == S2_SPEC;
     szk_cb_params cb;
     cb_params_from(ctx, cb, ctx->cur_out_cap, fresh);
-    hipStream_t bs = s;  // the stream the book is built on
-    // Small alphabets with short outlier lists (what the previous call had): this call's book, the verdict and the list sorts
-    // ride in the packer's own launch as three role workgroups, the fold of stage 1's histogram rows in the scan's launch —
-    // one stream, two launches. Otherwise the book is built on a side stream (wide alphabets need a whole compute unit's LDS).
-    const bool fused = how == S2_SPEC && ctx->cb_hint == 0 && !ctx->lists_long && cb.range_ready && !(szk_dbg_flags & 67108864);  // (67108864: the side-stream form)
+    // Speculative form: this call's book, the verdict and the list sorts ride in the packer's own launch as three role
+    // workgroups, the fold of stage 1's histogram rows in the scan's launch — one stream, two launches.
+    const bool fused = how == S2_SPEC;
     szk_encode_roles er;
     memset(&er, 0, sizeof(er));
     if (fused) {
@@ -1169,36 +1147,18 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
             er.fold_range = ctx->fold_range;
             ctx->fold_rows = 0;
         }
-    } else if (how == S2_SPEC) {
-        int rcs = ensure_side(ctx);
-        if (rcs) return rcs;
-        bs = ctx->side;
-        HIPCHK(hipEventRecord(ctx->ev_fork, s));  // stage 1 (and, between the stages, the caller's histogram exchange) is on the caller's stream
-        HIPCHK(hipStreamWaitEvent(bs, ctx->ev_fork, 0));
-        if (ctx->fold_rows) {  // stage 1 left the fold of its histogram rows to this stream
-            if (szk_launch_hist_fold(ctx->d_hist_partial, ctx->fold_rows, (int)ctx->proto.radius, ctx->d_hist, ctx->fold_range, bs))
-                return fail(SZ3HIP_EHIP, "histogram fold launch failed");
-            ctx->fold_rows = 0;
-        }
-        // (the short-list form unless the previous call's lists were long: it declines a long list, which costs a repeat of stage 2)
-        if (szk_launch_sort_outliers(&cb, ctx->lists_long ? nullptr : reinterpret_cast<uint32_t *>(ctx->d_counters + 10), bs))
-            return fail(SZ3HIP_EHIP, "outlier sort launch failed");
-        HIPCHK(hipEventRecord(ctx->ev_sorted, bs));
-        cb.skip_sort = 1;
-        cb.slim = 1;
     } else if (ctx->fold_rows) {  // (stage 1 deferred the fold and stage 2 does not speculate after all: the range words were not kept)
         if (szk_launch_hist_fold(ctx->d_hist_partial, ctx->fold_rows, (int)ctx->proto.radius, ctx->d_hist, ctx->fold_range, s))
             return fail(SZ3HIP_EHIP, "histogram fold launch failed");
         ctx->fold_rows = 0;
     }
-    if (how != S2_REENCODE && !fused) {
+    if (how == S2_CLASSIC) {
         if (ctx->range_ready && !cb.range_ready)  // stage 1 kept the range of the LOCAL histogram, the caller then changed it (all-reduce):
-            HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, 16, bs));  // k_hist_range starts from zero
-        prof_begin(ctx, ST_CODEBOOK, bs);
-        int rcb = szk_launch_codebook(ctx->d_hist, &cb, bs);
-        prof_end(ctx, ST_CODEBOOK, bs);
+            HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, 16, s));  // k_hist_range starts from zero
+        prof_begin(ctx, ST_CODEBOOK, s);
+        int rcb = szk_launch_codebook(ctx->d_hist, &cb, s);
+        prof_end(ctx, ST_CODEBOOK, s);
         if (rcb) return fail(SZ3HIP_EHIP, "codebook kernel launch failed (%d)", rcb);
-        if (how == S2_SPEC) HIPCHK(hipEventRecord(ctx->ev_book, bs));
     }
     szk_layout_params lp;
     lp.proto = ctx->proto;
@@ -1230,17 +1190,10 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     prof_begin(ctx, ST_ENCODE, s);  // (the payload layout is computed inside the encoder's scan launch, the sections are assembled by the packer's)
     int rc = szk_launch_encode(ctx->d_codes, n, ctx->bk[used].enc, ctx->bk[used].info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words,
                                ctx->d_chunk_off, ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, &lp, &ap, s,
-                               how == S2_SPEC && !fused ? ctx->ev_sorted : nullptr, how == S2_SPEC && ctx->seg_expected ? ctx->d_seg_bits : nullptr,
-                               reinterpret_cast<uint32_t *>(ctx->d_counters + 10) + 1, fused ? &er : nullptr);
+                               fused && ctx->seg_expected ? ctx->d_seg_bits : nullptr, reinterpret_cast<uint32_t *>(ctx->d_counters + 10) + 1,
+                               fused ? &er : nullptr);
     prof_end(ctx, ST_ENCODE, s);
     if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
-    if (how == S2_SPEC && !fused) {
-        HIPCHK(hipStreamWaitEvent(s, ctx->ev_book, 0));
-        if (szk_launch_book_verdict(ctx->bk[used].info, ctx->bk[used].lens, ctx->bk[fresh].info, ctx->bk[fresh].lens,
-                                    reinterpret_cast<uint32_t *>(ctx->d_counters + 7), reinterpret_cast<uint32_t *>(ctx->d_counters + 8),
-                                    reinterpret_cast<uint32_t *>(ctx->d_counters + 10), ctx->seg_expected ? 1 : 0, ctx->d_state, s))
-            return fail(SZ3HIP_EHIP, "code book comparison launch failed");
-    }
     prof_end(ctx, ST_SPAN, s);
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(szk_state), hipMemcpyDeviceToHost, s));
     if (!ctx->ev_done) HIPCHK(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
@@ -1270,7 +1223,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
         if (rc1) return rc1;
         HIPCHK(hipEventSynchronize(ctx->ev_done));
     } else if (ctx->s2_spec) {
-        if (ctx->h_state->book_miss || ctx->h_state->miss_kind) {
+        if (ctx->h_state->miss_kind) {
             // the previous call's book is not this call's: the encoder once more, with the book the side stream built from this
             // call's histogram (or, when the code-book form launched alone declined the alphabet, the whole of stage 2)
             ctx->spec_misses++;

@@ -72,7 +72,6 @@ struct sz3hip_ctx {
     bool lists_long;                  // the previous call listed more than 2048 outliers: the speculative stage 2 takes the any-length sort
     int spec_off;                     // test / bench hook: never speculate (every call behaves like a context's first)
     uint32_t spec_hits, spec_misses;  // statistics (sz3hip_get_spec_stats)
-    hipEvent_t ev_sorted, ev_book;
     hipEvent_t ev_done;  // recorded behind the state's device-to-host copy: finish() waits for it, not for the whole stream
     hipStream_t pre_stream;
     bool pre_cleared;    // finish() of the previous call already enqueued the zeroing of histogram and counters

@@ -64,7 +64,7 @@ struct szk_k1_params {
     uint32_t *seg_made;   // device flag, raised by the form that sums the segments
     int seg_expected;     // out: the launched form sums the segments when this call's probe keeps one-byte codes
     int assumed_narrow;   // out: the one-launch form was taken: it assumes one-byte codes and runs the probe itself
-    // defer_fold: the launcher leaves out k_hist_reduce (the caller runs szk_launch_hist_fold on a stream of its choice);
+    // defer_fold: the launcher leaves out k_hist_reduce (the fold rides in the encoder's scan launch, szk_encode_roles);
     // fold_rows (out): rows of hist_partial to fold, 0 when the launched kernels need no fold
     int defer_fold;
     uint32_t fold_rows;
@@ -96,8 +96,6 @@ struct szk_cb_params {
     int range_ready;   // the range words are already filled (stage 1 kept them with the histogram): no k_hist_range launch
     int part_hint;     // -1: both forms of k_codebook are launched; 0 / 1: only that form (small / wide alphabets), see mispredict
     uint32_t *mispredict;  // set to 1 by a form launched alone that meets the other form's alphabet
-    int skip_sort;         // the outlier lists are sorted by a launch of their own (szk_launch_sort_outliers)
-    int slim;              // with part_hint == 0: the small form with 8 KB of LDS and no sort blocks (runs beside the encoder's kernels)
 };
 #define SZK_CB_SMALL_SYMS 256  // alphabets up to this size take k_codebook<0>, wider ones <1>
 #define SZK_MAX_BOOKS 4
@@ -108,7 +106,7 @@ struct szk_state {
     szh_offsets off;
     uint32_t overflow, cap_exceeded;
     uint32_t mispredict, n_symbols;  // code book: wrong form launched alone (stage 2 is repeated); size of the alphabet
-    uint32_t book_miss, miss_kind;   // speculative stage 2: the encoder's output is void (stage 2 is repeated); why: 1 the previous call's code
+    uint32_t book_miss, miss_kind;   // (book_miss: unused) speculative stage 2: the encoder's output is void (stage 2 is repeated); why: 1 the previous call's code
                                      // book is not this call's, 2 code-book form declined, 4 outlier list too long for the short sort,
                                      // 8 stage 1 did not sum the segments' bits, 32 stage 1 assumed one-byte codes and the probe says two
                                      // (the whole call is repeated)
@@ -282,16 +280,11 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
                       szk_mode mode, uint16_t *chunk_words, uint64_t *group_off /*[n_chunks/32 + 1]*/, uint64_t *total_words,
                       const szk_state *state, uint8_t *payload, const szk_layout_params *layout,
                       const szk_asm_params *asmp /* non-null: the packer's launch also assembles the payload (no szk_launch_assemble) */, hipStream_t s,
-                      hipEvent_t lists_sorted = nullptr /* non-null: the packer's launch waits for it (outlier lists sorted on a side stream) */,
                       const uint16_t *seg_bits = nullptr /* non-null: code bits per 256-element segment, summed by stage 1 (no bits pass) */,
                       const uint32_t *seg_made = nullptr /* device flag: stage 1 really made them */,
                       const szk_encode_roles *roles = nullptr);
-// declined != nullptr: the short-list form (raises *declined on a list of more than 2048 records); else any length
-int szk_launch_sort_outliers(const szk_cb_params *p, uint32_t *declined, hipStream_t s);
-// compares the code book the encoder used with the one built from this call's histogram; writes state->book_miss / mispredict / n_symbols
-int szk_launch_book_verdict(const szk_cb_info *used, const uint8_t *used_lens, const szk_cb_info *fresh, const uint8_t *fresh_lens,
-                            const uint32_t *mispredict, const uint32_t *range, const uint32_t *declined, int need_seg, szk_state *state, hipStream_t s);
-// the fold of stage 1's per-workgroup histogram rows (k_hist_reduce), for callers that deferred it (szk_k1_params::defer_fold)
+// the fold of stage 1's per-workgroup histogram rows (k_hist_reduce), for a caller that deferred it (szk_k1_params::defer_fold)
+// and does not run the encoder form that carries it
 int szk_launch_hist_fold(const uint32_t *partial, uint32_t nrows, int radius, uint64_t *hist, uint32_t *range, hipStream_t s);
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t,

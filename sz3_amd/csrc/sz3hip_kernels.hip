@@ -1228,7 +1228,7 @@ __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t 
     if (acct) {
         const uint32_t b = threadIdx.x;  // 256 threads, 256 byte values; 255 = the delta outliers' symbol 0
         s_len[b] = p.spec_lens[b == 255u ? 0u : b + p.radius - 127u];
-        if (blockIdx.x == 0 && threadIdx.x == 0) *p.seg_made = 1u;  // (the host assumed this form would run: k_book_verdict checks)
+        if (blockIdx.x == 0 && threadIdx.x == 0) *p.seg_made = 1u;  // (the host assumed this form would run: the packer's book role checks)
     }
     __syncthreads();
 
@@ -2114,7 +2114,7 @@ __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params 
     uint16_t *pleaf = reinterpret_cast<uint16_t *>(ifreq + CAP);                     // 6 x u16 [CAP]
     uint16_t *pint = pleaf + CAP, *aux = pint + CAP, *syms = aux + CAP;
     uint16_t *aux2 = syms + CAP, *pint2 = aux2 + CAP;
-    uint16_t *cnt_tbl = pint2 + CAP;  // (SZH_MAX_LEN + 1) * 256 u16 (code assignment beyond 512 symbols; slim form: the Kraft repair's few words)
+    uint16_t *cnt_tbl = pint2 + CAP;  // (SZH_MAX_LEN + 1) * 256 u16 (code assignment beyond 512 symbols; the packer's book role: the Kraft repair's few words)
     const uint32_t per = (range + CB_THREADS - 1) / CB_THREADS;
     // 1. compaction of the non-zero bins in symbol order
     uint32_t cnt = 0;
@@ -2282,14 +2282,10 @@ __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params 
 // PART 0: alphabets up to CB_SMALL_SYMS symbols + the outlier-list sorts; PART 1: wider alphabets. Which one applies is
 // known only on the device (k_hist_range), so both are launched and the other returns at once: the small path keeps its
 // own register allocation and instruction footprint (sharing one kernel with the wide path cost it 10 us of its 40).
-// SLIM (PART 0 only, 256 threads, no outlier sorts): the same construction with LDS arrays for 256 symbols (8 KB instead of
-// 128 KB) — the speculative stage 2 runs it on a side stream beside the encoder's kernels, where a workgroup that needs most
-// of a compute unit's LDS would wait for the packer's persistent workgroups to retire.
-template <int PART, bool SLIM = false>
-__global__ __launch_bounds__(SLIM ? CB_THREADS : CB_LAUNCH) void k_codebook(const uint64_t *__restrict__ hist, szk_cb_params p) {
-    static_assert(!SLIM || PART == 0, "the slim form is the small-alphabet path");
-    constexpr uint32_t CAP = SLIM ? CB_SMALL_SYMS : CB_LDS_SYMS;  // symbols the small path's LDS arrays hold
-    __shared__ __align__(16) uint8_t s_pool[SLIM ? CAP * 28 + 256 : CB_POOL_BYTES];
+template <int PART>
+__global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restrict__ hist, szk_cb_params p) {
+    constexpr uint32_t CAP = CB_LDS_SYMS;  // symbols the small path's LDS arrays hold
+    __shared__ __align__(16) uint8_t s_pool[CB_POOL_BYTES];
     __shared__ uint32_t s_wtot[CB_THREADS / WAVE];
     __shared__ uint32_t s_over;
     __shared__ uint32_t s_first[SZH_MAX_LEN + 2], s_cnt[SZH_MAX_LEN + 2];
@@ -2298,7 +2294,6 @@ __global__ __launch_bounds__(SLIM ? CB_THREADS : CB_LAUNCH) void k_codebook(cons
     const uint32_t t = threadIdx.x;
     if (blockIdx.x >= p.n_books) {  // the two blocks after the code books: deterministic order of the two outlier lists
         // (in the launch whose code-book path is the active one, so that they run beside it)
-        if (SLIM || p.skip_sort) return;  // (speculative stage 2: k_sort_outliers did it, ahead of the packer)
         if ((PART == 1) != (p.range[2] > CB_SMALL_SYMS) && p.part_hint < 0) return;  // (launched alone: sorts whatever the alphabet)
         const bool d = blockIdx.x == p.n_books + 1;
         // scratch: the key tables of the batch slots 1 and 2, idle when a single code book is built (n_books <= 1)
@@ -2358,91 +2353,6 @@ __global__ __launch_bounds__(SLIM ? CB_THREADS : CB_LAUNCH) void k_codebook(cons
         return;
     }
     cb_small<CAP>(hist, p, s_pool, lo, range, s_wtot, s_over, s_first, s_cnt, s_misc, s_total);
-}
-
-// Short outlier lists (what smooth fields have: C2 lists 970 points) sorted by a small launch: up to SORT_SMALL records per
-// list, keys (index << 16 | arrival position) in a bitonic network in LDS, the values follow by position. A longer list
-// makes it raise *declined: the host repeats stage 2 the classic way (the code-book launch's sort blocks handle any length).
-#define SORT_SMALL 2048u
-__global__ __launch_bounds__(256) void k_sort_outliers_small(szk_cb_params p, uint32_t *declined) {
-    __shared__ uint64_t sk[SORT_SMALL];
-    __shared__ uint64_t sv[SORT_SMALL];
-    const bool d = blockIdx.x == 1;
-    uint64_t *idx = d ? p.dout_idx : p.vout_idx;
-    void *val = d ? p.dout_val : p.vout_val;
-    const bool v32 = d ? p.q_is_32bit != 0 : p.t_is_32bit != 0;
-    uint64_t n64 = d ? *p.n_dout : *p.n_vout;
-    if (n64 > p.out_cap) n64 = p.out_cap;
-    if (n64 < 2) return;
-    if (n64 > SORT_SMALL) {
-        if (threadIdx.x == 0) *declined = 1u;
-        return;
-    }
-    const uint32_t n = (uint32_t)n64;
-    uint32_t np2 = 2;
-    while (np2 < n) np2 <<= 1;
-    for (uint32_t i = threadIdx.x; i < np2; i += 256) {
-        sk[i] = i < n ? (idx[i] << 16) | i : ~0ull;
-        if (i < n) sv[i] = v32 ? (uint64_t) reinterpret_cast<const uint32_t *>(val)[i] : reinterpret_cast<const uint64_t *>(val)[i];
-    }
-    __syncthreads();
-    for (uint32_t k = 2; k <= np2; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < np2; i += 256) {
-                const uint32_t x = i ^ j;
-                if (x > i) {
-                    const uint64_t a = sk[i], b = sk[x];
-                    if ((a > b) == ((i & k) == 0)) {
-                        sk[i] = b;
-                        sk[x] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const uint64_t k = sk[i];
-        idx[i] = k >> 16;
-        const uint64_t v = sv[(uint32_t)(k & 0xFFFFu)];
-        if (v32) reinterpret_cast<uint32_t *>(val)[i] = (uint32_t)v;
-        else reinterpret_cast<uint64_t *>(val)[i] = v;
-    }
-}
-// the outlier-list sorts as a launch of their own: the speculative stage 2 (sz3hip_api.cpp) packs with the previous call's
-// code book while this call's is being built on a side stream, and the packer's launch assembles the (sorted) lists
-__global__ __launch_bounds__(CB_LAUNCH) void k_sort_outliers(szk_cb_params p) {
-    __shared__ __align__(16) uint8_t s_pool[CB_POOL_BYTES];
-    const bool d = blockIdx.x == 1;
-    uint64_t *scratch = p.keys + (size_t)(d ? 2 : 1) * SZH_HIST_BINS;
-    sort_outlier_list(d ? p.dout_idx : p.vout_idx, d ? p.dout_val : p.vout_val, d ? *p.n_dout : *p.n_vout, p.out_cap,
-                      d ? p.q_is_32bit != 0 : p.t_is_32bit != 0, s_pool, scratch);
-}
-// Did the code book the encoder ran with (the context's previous one, `used`) equal the one this call's histogram gives
-// (`fresh`)? The canonical code is a function of the alphabet's range and the code lengths; the packers' LDS window is
-// compared too (it does not change the payload, only which symbols take the slow lookup). One workgroup.
-__global__ __launch_bounds__(1024) void k_book_verdict(const szk_cb_info *__restrict__ used, const uint8_t *__restrict__ used_lens,
-                                                       const szk_cb_info *__restrict__ fresh, const uint8_t *__restrict__ fresh_lens,
-                                                       const uint32_t *__restrict__ mispredict, const uint32_t *__restrict__ range,
-                                                       const uint32_t *__restrict__ declined /* [0] short-list sort, [1] stage 1 made the segment sums */,
-                                                       int need_seg, szk_state *state) {
-    __shared__ uint32_t s_diff;
-    if (threadIdx.x == 0) s_diff = 0;
-    __syncthreads();
-    const uint32_t lo = fresh->sym_min, cnt = fresh->sym_count;
-    bool diff = used->sym_min != lo || used->sym_count != cnt || used->max_len != fresh->max_len || used->n_symbols != fresh->n_symbols;
-    if (!diff)
-        for (uint32_t i = threadIdx.x; i < cnt; i += 1024) diff |= used_lens[lo + i] != fresh_lens[lo + i];
-    if (diff) s_diff = 1;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // (a code-book form launched alone that declined: no fresh book at all; a list too long for the short sort; stage 1 ran
-        // another form than the one that sums the segments' bits: the encoder's output is void in each case)
-        const uint32_t kind = (s_diff ? 1u : 0u) | (*mispredict ? 2u : 0u) | (declined[0] ? 4u : 0u) | (need_seg && !declined[1] ? 8u : 0u);
-        state->book_miss = kind != 0;
-        state->miss_kind = kind | (state->miss_kind & 32u);  // (bit 32 was raised by the packer's launch: wrong code-width assumption)
-        state->mispredict = *mispredict;
-        state->n_symbols = range[2];
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2891,7 +2801,7 @@ __device__ void assemble_body(const szk_asm_params &p, uint64_t tid, uint64_t nt
         if (p.assumed_narrow && !szk_is_narrow(p.mode)) atomicOr(&p.state->miss_kind, 32u);
         if (!p.lists_by_roles) {  // (role mode: the book role of the same launch writes these; miss_kind was zeroed by layout_pre)
             p.state->mispredict = (uint32_t)p.n_vout[7];                                  // (d_counters[7]: raised by a code-book form launched alone)
-            p.state->book_miss = 0;                                                       // (speculative stage 2 on a side stream: k_book_verdict rewrites it)
+            p.state->book_miss = 0;
             p.state->n_symbols = reinterpret_cast<const uint32_t *>(p.n_vout + 8)[2];   // (the range words: number of non-empty bins)
         }
         // alignment gaps between the sections are part of the payload: zero them so that it is a pure function of the input
@@ -4167,21 +4077,8 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
     if (!p->range_ready) hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256, nb), dim3(256), 0, s, d_hist, q.range);
     // which of the two forms applies is known on the device only; a context that remembers the previous call's alphabet
     // launches that form alone (solo): the kernel raises `mispredict` when it is the wrong one and the host repeats stage 2
-    if (p->part_hint == 0 && p->slim && nb == 1) hipLaunchKernelGGL((k_codebook<0, true>), dim3(1), dim3(CB_THREADS), 0, s, d_hist, q);
-    else if (p->part_hint != 1) hipLaunchKernelGGL(k_codebook<0>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
+    if (p->part_hint != 1) hipLaunchKernelGGL(k_codebook<0>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
     if (p->part_hint != 0) hipLaunchKernelGGL(k_codebook<1>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
-    SZK_CHECK_LAUNCH();
-    return 0;
-}
-int szk_launch_sort_outliers(const szk_cb_params *p, uint32_t *declined, hipStream_t s) {
-    if (declined) hipLaunchKernelGGL(k_sort_outliers_small, dim3(2), dim3(256), 0, s, *p, declined);
-    else hipLaunchKernelGGL(k_sort_outliers, dim3(2), dim3(CB_LAUNCH), 0, s, *p);
-    SZK_CHECK_LAUNCH();
-    return 0;
-}
-int szk_launch_book_verdict(const szk_cb_info *used, const uint8_t *used_lens, const szk_cb_info *fresh, const uint8_t *fresh_lens,
-                            const uint32_t *mispredict, const uint32_t *range, const uint32_t *declined, int need_seg, szk_state *state, hipStream_t s) {
-    hipLaunchKernelGGL(k_book_verdict, dim3(1), dim3(1024), 0, s, used, used_lens, fresh, fresh_lens, mispredict, range, declined, need_seg, state);
     SZK_CHECK_LAUNCH();
     return 0;
 }
@@ -4193,7 +4090,7 @@ int szk_launch_hist_fold(const uint32_t *partial, uint32_t nrows, int radius, ui
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
                       szk_mode mode, uint16_t *chunk_words, uint64_t *group_off, uint64_t *total_words,
                       const szk_state *state, uint8_t *payload, const szk_layout_params *layout, const szk_asm_params *asmp, hipStream_t s,
-                      hipEvent_t lists_sorted, const uint16_t *seg_bits, const uint32_t *seg_made, const szk_encode_roles *er) {
+                      const uint16_t *seg_bits, const uint32_t *seg_made, const szk_encode_roles *er) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
     const uint64_t nb = (n_chunks + 3) / 4;
     if (nb > 0x7FFFFFFFull) return -1;
@@ -4202,9 +4099,7 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
     // (seg_bits: stage 1 summed the code bits per 256-element segment with the book the encoder uses: no bits pass)
     if (!seg_bits) hipLaunchKernelGGL(k_chunk_bits2, dim3(pgrid), dim3(256), 0, s, codes, n, d_enc, info, mode, sym_add, chunk_words);
     szk_fold_params fp{};
-    if (er && er->fold_rows && (szk_dbg_flags & 134217728)) {  // (lab: the fold as a launch of its own)
-        hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, er->fold_partial, er->fold_rows, radius - HIST_WIN / 2, er->fold_hist, er->fold_range);
-    } else if (er && er->fold_rows) {  // stage 1 left the fold of its histogram rows out: 64 more workgroups of this launch do it
+    if (er && er->fold_rows) {  // stage 1 left the fold of its histogram rows out: 64 more workgroups of this launch do it
         fp.partial = er->fold_partial;
         fp.nrows = er->fold_rows;
         fp.win_lo = radius - HIST_WIN / 2;
@@ -4237,8 +4132,6 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
     // the packer's workgroups are persistent and split the chunks statically: all of them, the role and the assemble workgroups
     // must be resident together (5 per compute unit at 30 KB of LDS each), or the late ones double the launch's duration
     const uint32_t extra = rb + (asmp ? 32u : 0u);
-    // (speculative stage 2: the outlier lists are being sorted on a side stream; the packer's launch copies them)
-    if (lists_sorted && hipStreamWaitEvent(s, lists_sorted, 0) != hipSuccess) return -2;
     constexpr uint32_t ASM_BLOCKS = 32;
     if (mode.pack_wide) {
         const uint32_t pb = pgrid < 768 - extra ? pgrid : 768 - extra;

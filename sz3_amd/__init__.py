@@ -388,8 +388,9 @@ class DeviceCompressor:
         """drop what earlier calls left in the context (kernel forms, windows, tuner outcome, code book): the next call is a first call"""
         lib().sz3hip_ctx_forget(self._h)
 
-    def set_speculation(self, on=True):
-        lib().sz3hip_ctx_set_speculation(self._h, 0 if on else 1)
+    def set_speculation(self, on=True, backoff=True):
+        """on=False: every stage 2 builds its code book first; backoff=False: a miss does not make the next calls sit out (tests)"""
+        lib().sz3hip_ctx_set_speculation(self._h, (0 if backoff else 2) if on else 1)
 
     def spec_stats(self):
         h, m = C.c_uint32(), C.c_uint32()

@@ -495,7 +495,10 @@ static int stage1_interp(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
 
 // may stage 2 of a call with this predictor and radius run with the context's previous code book? (decided once per call)
 static bool book_spec_ok(const sz3hip_ctx *ctx, uint32_t predictor, uint32_t radius) {
-    return ctx->book_idx >= 0 && !ctx->spec_off && !(szk_dbg_flags & 131072) && ctx->book_pred == predictor && ctx->book_radius == radius;
+    // (spec_skip: calls left to sit out after a miss — a series whose books keep changing pays for one failed attempt in
+    // 2, 4, 8 calls, not in every call; spec_off == 2 switches the back-off off for tests)
+    return ctx->book_idx >= 0 && ctx->spec_off != 1 && (ctx->spec_skip == 0 || ctx->spec_off == 2) && !(szk_dbg_flags & 131072) &&
+           ctx->book_pred == predictor && ctx->book_radius == radius;
 }
 // ---- stage 1, integer Lorenzo on the prequantised lattice ----
 static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *d_in, double eb, int radius, uint64_t num,
@@ -1222,10 +1225,12 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
         rc1 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s, S2_CLASSIC);
         if (rc1) return rc1;
         HIPCHK(hipEventSynchronize(ctx->ev_done));
+        ctx->spec_penalty = ctx->spec_penalty ? std::min(8, 2 * ctx->spec_penalty) : 1;
+        ctx->spec_skip = ctx->spec_penalty;
     } else if (ctx->s2_spec) {
         if (ctx->h_state->miss_kind) {
-            // the previous call's book is not this call's: the encoder once more, with the book the side stream built from this
-            // call's histogram (or, when the code-book form launched alone declined the alphabet, the whole of stage 2)
+            // the previous call's book is not this call's: the encoder once more, with the book the packer's book role built from
+            // this call's histogram (or, when that role declined the alphabet or a list was too long to sort, the whole of stage 2)
             ctx->spec_misses++;
             const uint32_t kind = ctx->h_state->miss_kind;
             const bool redo_book = (kind & (2u | 4u)) != 0;  // no fresh book (form declined) / lists unsorted: stage 2 from its start
@@ -1237,9 +1242,14 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
             int rc2 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s, redo_book ? S2_CLASSIC : S2_REENCODE);
             if (rc2) return rc2;
             HIPCHK(hipEventSynchronize(ctx->ev_done));
+            ctx->spec_penalty = ctx->spec_penalty ? std::min(8, 2 * ctx->spec_penalty) : 1;
+            ctx->spec_skip = ctx->spec_penalty;
         } else {
             ctx->spec_hits++;
+            ctx->spec_penalty = 0;
         }
+    } else if (ctx->spec_skip > 0) {
+        ctx->spec_skip--;
     }
     if (ctx->h_state->mispredict) {
         // the code-book form launched alone met the other form's alphabet (the data changed character since the previous
@@ -1380,10 +1390,12 @@ extern "C" void sz3hip_ctx_forget(sz3hip_ctx *ctx) {
     ctx->pack_wide = ctx->hist_big = ctx->hist_tail = ctx->blk_wide = 0;
     ctx->spec_valid = false;
     ctx->book_idx = -1;
+    ctx->spec_skip = ctx->spec_penalty = 0;
     ctx->lists_long = false;
     ctx->half_skip = 0;
 }
-// speculation off (1) / on (0) for this context: with it off every stage 2 builds its code book before it encodes
+// speculation off (1) / on (0) / on without the back-off after a miss (2, for tests) for this context: with it off every
+// stage 2 builds its code book before it encodes
 extern "C" void sz3hip_ctx_set_speculation(sz3hip_ctx *ctx, int off) { ctx->spec_off = off; }
 extern "C" void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses) {
     *hits = ctx->spec_hits;

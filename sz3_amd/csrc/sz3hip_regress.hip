@@ -47,9 +47,37 @@
 
 namespace {
 
+// wave-wide sum of doubles, the total in every lane. DPP lane moves (row_shr 1 2 4 8 inside the rows of 16 lanes, row_bcast 15 / 31
+// across them: the last lane ends with the total), no LDS round trips: the butterfly of __shfl_xor it replaces is twelve
+// ds_bpermute per sum, a dependent chain of ~1.5 k cycles — seven sums per block were 4 of the fit pass's 11 us per block.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov0_f64(double v) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));  // (lanes without a source read +0.0)
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_mov0_f64<0x111, 0xf>(v);
+    v += dpp_mov0_f64<0x112, 0xf>(v);
+    v += dpp_mov0_f64<0x114, 0xf>(v);
+    v += dpp_mov0_f64<0x118, 0xf>(v);
+    v += dpp_mov0_f64<0x142, 0xa>(v);
+    v += dpp_mov0_f64<0x143, 0xc>(v);
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, WAVE - 1);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), WAVE - 1);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+template <typename T> __device__ __forceinline__ T lane_bcast(T v, int src);
+template <> __device__ __forceinline__ float lane_bcast<float>(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+template <> __device__ __forceinline__ double lane_bcast<double>(double v, int src) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), src);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
 struct BlkGeom {
@@ -223,9 +251,9 @@ __device__ __forceinline__ void blk_fit_block(const T *sx, const TileView &tv, c
         const double dz = g.ez, dy = g.ey, dx = g.ex, num = dz * dy * dx;
         const double sk = lane == 0 ? s0 : (lane == 1 ? s1 : s2), dk = lane == 0 ? dz : (lane == 1 ? dy : dx);
         const T ck = (T)((2 * sk / (dk - 1) - s3) * 6 / num / (dk + 1));
-        cf[0] = __shfl(ck, 0, WAVE);
-        cf[1] = __shfl(ck, 1, WAVE);
-        cf[2] = __shfl(ck, 2, WAVE);
+        cf[0] = lane_bcast<T>(ck, 0);
+        cf[1] = lane_bcast<T>(ck, 1);
+        cf[2] = lane_bcast<T>(ck, 2);
         cf[3] = (T)(s3 / num);
         cf[3] = (T)((double)cf[3] - (dz - 1) * (double)cf[0] / 2);
         cf[3] = (T)((double)cf[3] - (dy - 1) * (double)cf[1] / 2);
@@ -324,7 +352,9 @@ __device__ __forceinline__ void blk_fit_block(const T *sx, const TileView &tv, c
 // the volume read, rows of 26 values): fit 1.91 against 1.76 ms, Lorenzo pass 1.15 against 1.04 — the barriers around the shared
 // load cost more than the smaller read saves; a thread per ELEMENT for the Lorenzo pass (no idle lanes, block bookkeeping in an
 // LDS table): 1.08 ms — not bound by its instructions, then; by its 8-byte lattice values (1.07 GB written by the fit, read back
-// with halo) — or so it seemed: storing q~ in 4 bytes (behind gated full-width passes for values that do not fit) changed nothing either (fit 1.75, Lorenzo pass 1.00 ms). What the two passes are bound by is still open.
+// with halo) — or so it seemed: storing q~ in 4 bytes (behind gated full-width passes for values that do not fit) changed nothing either (fit 1.75, Lorenzo pass 1.00 ms). Round 3, ablations of the fit pass at C4's slab (tools/blk_lab.sh): 1682 us as is;
+// 1593 without the lattice stores, 1558 without the selection, 1244 without the fit and the regression blocks; the seven wave
+// sums on DPP instead of ds_bpermute butterflies 1780 -> 1704. No single piece dominates: ~800 wave instructions per block.
 template <typename T, uint32_t HW, int CB, int NW>
 __global__ __launch_bounds__(NW * 64) void k_blk_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;

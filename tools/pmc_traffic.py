@@ -13,7 +13,7 @@ for ln in open(src):
             k, v = kv.split("=")
             vals.setdefault(name, {})[k] = float(v)
 # (kernel names are matched by prefix: template argument lists grow)
-keys = {"lorenzo_quant_hist": "k_lorenzo_quant_march3<float, 3, 4>", "chunk_bits": "k_chunk_bits2", "pack": "k_pack",
+keys = {"lorenzo_quant_hist": "k_lorenzo_quant_march3<float, 3, 4>", "chunk_bits": "k_chunk_bits2", "seg_chunks": "k_seg_chunks", "scan_groups": "k_scan_groups", "pack": "k_pack",
         "decode_with_x_scan": "k_decode<4, 0, true>", "scan_strided": "k_scan_strided_half<false>", "scan_strided_dequant": "k_scan_strided_half<true>"}
 out = {}
 for k, name in keys.items():
@@ -25,6 +25,12 @@ for k, name in keys.items():
     out[k + "_hbm_bytes_per_launch"] = int((2 * f + w) * 1024)
     out[k + "_valu_wave_instructions"] = v.get("SQ_INSTS_VALU", 0.0)
     out[k + "_valu_issue_us"] = round(v.get("SQ_INSTS_VALU", 0.0) * 4 / 1024 / 2.1e3, 1)
+# the warm C2 step (round 3): stage 1 (probe inside), segments -> chunk counts, offset scan (+ histogram fold), packer (+ code book, list sorts)
+step = [out.get(k + "_hbm_bytes_per_launch", 0) for k in ("lorenzo_quant_hist", "seg_chunks", "scan_groups", "pack")]
+if all(step[:1]) and step[3]:
+    out["c2_step_hbm_bytes"] = int(sum(step))
+    out["c2_step_note"] = ("warm step = k_lorenzo_quant_march3 + k_seg_chunks + k_scan_groups + k_pack (the bits pass k_chunk_bits2 and the code book's own "
+                           "launch only run on a first call or after a miss); algorithmic bytes of the step = input + payload = 605.8 MB")
 # C3 (tools/pmc_c3.sh -> gpurun_out/pmc_summary_c3.txt): HBM bytes of stage 1 per step = all interpolation kernels + the working copy
 c3 = os.path.join(os.path.dirname(src), os.path.basename(src).replace("pmc_summary", "pmc_summary_c3"))
 if os.path.exists(c3):
@@ -43,7 +49,9 @@ if os.path.exists(c3):
     # stage 1 per step: the compression-side interpolation kernels + the code histogram; launches per step from the kernel
     # statistics of the same bench command (k_hist_codes runs once per compression)
     import csv
-    stats = os.path.join(ROOT, "profiles", "r02_kernel_stats_c3.csv")
+    stats = os.path.join(ROOT, "profiles", "r03_kernel_stats_c3.csv")
+    if not os.path.exists(stats):
+        stats = os.path.join(ROOT, "profiles", "r02_kernel_stats_c3.csv")
     if os.path.exists(stats):
         calls = {r["Name"]: int(r["Calls"]) for r in csv.DictReader(open(stats))}
         def ncalls(prefix):
@@ -58,13 +66,13 @@ if os.path.exists(c3):
             total += lps * b
         out["c3_stage1_hbm_bytes_per_step"] = int(total)
         out["c3_stage1_detail"] = detail
-        out["c3_stage1_note"] = ("stage 1 of C3 per step = interpolation kernels (launches per step from profiles/r02_kernel_stats_c3.csv x mean bytes per "
+        out["c3_stage1_note"] = ("stage 1 of C3 per step = interpolation kernels (launches per step from profiles/r0x_kernel_stats_c3.csv x mean bytes per "
                                  "launch) + the code histogram; the level kernels read the input in place (no working copy)")
 out["method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 20 --warmup 3` (tools/pmc.sh); "
                  "mean per dispatch; FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for wide (16 B/lane) coalesced reads on gfx950; "
                  "WRITE_SIZE taken as reported (checks out: stage 1 writes 1 B/elem of codes = 134 MB, counter says 135 MB); counters are in KB (x1024). "
                  "For k_decode (4-byte loads scattered over 64 lines per wave) the doubling over-counts. valu_issue_us = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / 2.1 GHz: "
                  "the time the vector ALUs need to issue the kernel's instructions (a wave64 instruction occupies a 16-lane SIMD for 4 cycles). "
-                 "Generated by tools/pmc_traffic.py from profiles/r02_pmc_summary.txt (and r02_pmc_summary_c3.txt).")
+                 "Generated by tools/pmc_traffic.py from profiles/r03_pmc_summary.txt (C2, round 3) and r02_pmc_summary_c3.txt (C3: its kernels did not change in round 3).")
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:600])

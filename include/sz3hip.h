@@ -193,9 +193,10 @@ void sz3hip_set_profiling(sz3hip_ctx *ctx, int on);
 int sz3hip_get_stage_times(sz3hip_ctx *ctx, const char **names, float *ms, int max);
 /* What a context remembers between calls only ever changes the TIME of a call, never its payload: which form of a kernel the
  * previous call's data took, histogram windows, the auto-tuner's previous outcome (stage 1 starts with it beside the tuner) and
- * the previous code book (stage 2 packs with it while this call's is built on a side stream; finish() repeats the encoder when
- * the two differ). sz3hip_ctx_forget drops all of it: the next call behaves like a context's first (bench.py's cold numbers).
- * sz3hip_ctx_set_speculation(ctx, 1) turns the code-book speculation off; sz3hip_get_spec_stats counts its hits / misses. */
+ * the previous code book (stage 2 packs with it while this call's is built by one workgroup of the same launch; finish() repeats
+ * the encoder when the two differ and lets the next 1, 2, 4, 8 calls sit out). sz3hip_ctx_forget drops all of it: the next call
+ * behaves like a context's first (bench.py's cold numbers). sz3hip_ctx_set_speculation(ctx, off): 0 on, 1 off, 2 on without the
+ * back-off after a miss (tests); sz3hip_get_spec_stats counts the code-book speculation's hits / misses. */
 void sz3hip_ctx_forget(sz3hip_ctx *ctx);
 void sz3hip_ctx_set_speculation(sz3hip_ctx *ctx, int off);
 void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses);

@@ -321,7 +321,7 @@ extern "C" void sz3hip_ctx_destroy(sz3hip_ctx *ctx) {
 // side_blocks: blocks of the block-composed predictor the side section must hold
 static size_t payload_bound_blocks(uint64_t n, uint64_t out_cap, uint64_t side_blocks) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
-    return (size_t)(sizeof(szh_header) + SZH_HIST_BINS + 16 + 2 * n_chunks + 16 + 2 * (out_cap * 16 + 16) +
+    return (size_t)(sizeof(szh_header) + SZH_HIST_BINS + 16 + 2 * n_chunks + 16 + 2 * (SZH_SUBS - 1) * n_chunks + 16 + 2 * (out_cap * 16 + 16) +
                     4 * n_chunks * (SZH_CHUNK_SYMS * SZH_MAX_LEN / 32) + 64 + szk_blk_side_bound(side_blocks));
 }
 // The shape-blind bound: blocks have an edge of at least 4, so a 3-D array whose extents are all >= 9 has at most n / 27 of
@@ -1477,6 +1477,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     dp.bitstream_off = o.bitstream;
     dp.total_words = h.bitstream_words;
     dp.chunk_words = (const uint16_t *)(pl + o.chunkwords);
+    dp.sub_bits = (const uint16_t *)(pl + o.subbits);
     dp.group_off = ctx->d_chunk_off;
     dp.tables = ctx->d_tables;
     dp.single_sym = h.sym_min;
@@ -1491,12 +1492,18 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     dp.dout_idx = reinterpret_cast<const uint64_t *>(pl + o.dout_idx);
     dp.dout_val = pl + o.dout_val;
     dp.n_dout = h.n_dout;
-    // rows that do not divide the chunk: a chunk that starts inside a row gets the running sum its predecessor ended with
+    // rows that do not divide the decoder's unit: a unit that starts inside a row gets the running sums of the row's earlier units
     // (k_scan_carry); the carries have an array of their own (the code array, idle in this mode, holds the half-width chain's values)
+    // Rows that are multiples of the unit (1024) with a strided axis behind them: the first strided scan adds the carries
+    // as it reads (no pass of its own); other lengths: k_scan_carry behind the decoder.
     dp.carry = nullptr;
-    if (fuse_x && (SZH_CHUNK_SYMS % row) != 0) {
-        if (!ctx->d_carry) HIPCHK(hipMalloc(&ctx->d_carry, (ctx->max_chunks + 8) * 8));
+    dp.carry_pass = 0;
+    const void *carry_in_scan = nullptr;
+    if (fuse_x && (SZH_UNIT_SYMS % row) != 0) {
+        if (!ctx->d_carry) HIPCHK(hipMalloc(&ctx->d_carry, (ctx->max_chunks * SZH_SUBS + 8) * 8));
         dp.carry = ctx->d_carry;
+        if (row % SZH_UNIT_SYMS == 0 && h.n > row && !(szk_dbg_flags & 536870912)) carry_in_scan = ctx->d_carry;
+        else dp.carry_pass = 1;
     }
     dp.half = 0;
     dp.ovf = nullptr;
@@ -1507,7 +1514,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     // return at once while it is clear), so the call stays asynchronous and correct either way.
     const bool half = fuse_x && szk_half_scans_ok(&h) && ctx->half_skip == 0 && !(szk_dbg_flags & 2097152);
     ctx->last_half = half ? 1u : 0u;
-    ctx->last_carry = dp.carry ? 1u : 0u;
+    ctx->last_carry = dp.carry ? (dp.carry_pass ? 1u : 2u) : 0u;
     if (half) {
         dp.half = 1;
         dp.ovf = ovf;
@@ -1515,7 +1522,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     }
     rc = szk_launch_decode(pl, &dp, ctx->d_codes, ctx->d_chunk_off, ctx->d_counters + 3, s);
     if (!rc && half) {
-        rc = szk_launch_reconstruct_half(pl, &h, &o, reinterpret_cast<int16_t *>(ctx->d_codes), d_out, ovf, s);
+        rc = szk_launch_reconstruct_half(pl, &h, &o, reinterpret_cast<int16_t *>(ctx->d_codes), d_out, ovf, s, (const int32_t *)carry_in_scan);
         dp.half = 0;
         dp.ovf = nullptr;
         dp.gate = ovf;
@@ -1570,7 +1577,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         memcpy(sc.side_hdr + 24, &bit_words, 8);
         rc = szk_launch_blk_decompress(ctx->dtype, ctx->d_codes, d_out, &bp, &sc, pl, &h, &o, ctx->d_blk_coef, s);
     } else {
-        rc = szk_launch_reconstruct(fuse_x ? 1 : 0, pl, &h, &o, ctx->d_codes, d_out, ctx->d_segtot, s, half ? ovf : nullptr);
+        rc = szk_launch_reconstruct(fuse_x ? 1 : 0, pl, &h, &o, ctx->d_codes, d_out, ctx->d_segtot, s, half ? ovf : nullptr, carry_in_scan);
     }
     prof_end(ctx, ST_DEC_RECON, s);
     if (rc) return fail(SZ3HIP_EHIP, "reconstruct kernel launch failed (%d)", rc);

@@ -6,6 +6,10 @@
 //   header (160 B, struct szh_header)
 //   lens       u8  [sym_count]      canonical-Huffman code length of symbol sym_min+i (0 = absent)   pad to 16
 //   chunkwords u16 [n_chunks]       32-bit words used by chunk c (chunks of chunk_syms symbols)      pad to 16
+//   subbits    u16 [n_chunks]       bit offset, from the chunk's start, of its symbol 512: the decoder's restart point (a chunk
+//                                   is decoded by two lanes, not one: the serial chain of table lookups per lane bounds the
+//                                   decoder, and 131 072 chunks are two waves per SIMD; 2 bytes per 1024 symbols — four
+//                                   units per chunk decode no faster while LDS holds four workgroups per CU, and cost 6)  pad to 16
 //   vout_idx   u64 [n_vout]         value outliers (Lorenzo) / anchors + unpredictable values (interpolation): index ...
 //   vout_val   T   [n_vout]         ... and the raw value stored losslessly (LinearQuantizer "unpred")  pad to 16
 //   dout_idx   u64 [n_dout]         delta outliers: element index whose Lorenzo delta does not fit the
@@ -23,8 +27,12 @@
 #include <stdint.h>
 
 #define SZH_MAGIC 0x31485A53u /* "SZH1" */
-#define SZH_VERSION 3u /* 3: bit-stream bytes in stream order; side section (predictor 2) */
+#define SZH_VERSION 4u /* 3: bit-stream bytes in stream order; side section (predictor 2); 4: restart offsets inside the chunks */
 #define SZH_CHUNK_SYMS 1024u
+#ifndef SZH_SUBS
+#define SZH_SUBS 2u /* units per chunk: a unit starts at the chunk's start or at a restart offset */
+#endif
+#define SZH_UNIT_SYMS (SZH_CHUNK_SYMS / SZH_SUBS) /* symbols a lane of the decoder walks through */
 #define SZH_MAX_LEN 24u /* longest code word; alphabets <= 512 symbols are limited to 16 (4 words per 64-bit register in the packer) */
 #define SZH_HIST_BINS 65536u
 
@@ -59,6 +67,7 @@ static_assert(sizeof(szh_header) == 160, "szh_header must be 160 bytes");
 typedef struct szh_offsets {
     uint64_t lens, chunkwords, vout_idx, vout_val, dout_idx, dout_val, bitstream, end;
     uint64_t side; /* between dout_val and the bit-stream; empty unless predictor == 2 */
+    uint64_t subbits; /* between chunkwords and vout_idx */
 } szh_offsets;
 
 #endif

@@ -163,16 +163,19 @@ struct szk_dec_params {
     uint64_t n, n_chunks;
     uint64_t bitstream_off, total_words;  // the bit-stream section of the payload and its length in 32-bit words
     const uint16_t *chunk_words;  // inside the payload
+    const uint16_t *sub_bits;     // inside the payload: bit offsets of a chunk's symbols 256, 512, 768 (the decoder's restart points)
     const uint64_t *group_off;    // word offset of every group of 32 chunks (k_scan_groups)
     const szk_dec_tables *tables;
     uint32_t single_sym;
     // Lorenzo streams with rows of at most one chunk and a sorted delta-outlier list (<= 32768 records): the decoder turns the codes into deltas and
-    // prefix-sums them along x itself (scan_row = row length, 0 = plain code output). A row that starts in the previous
-    // chunk misses that chunk's running sum: every chunk leaves it in carry[] and k_scan_carry adds it afterwards (not
-    // needed when the row length divides the chunk).
+    // prefix-sums them along x itself (scan_row = row length, 0 = plain code output). A lane decodes a unit of 256 symbols; a row
+    // that starts in an earlier unit misses those units' running sums: every unit leaves its own in carry[] and k_scan_carry
+    // (or the first strided scan, rows that are multiples of the unit) adds them afterwards (not needed when the row length
+    // divides the unit).
     uint32_t scan_row, radius, q_bytes, reserved;  // q_bytes: 4 = int32 lattice (f32 data), 8 = int64 (f64 data)
     void *q_out;  // lattice deltas summed along x: int32 (f32 data) / int64 (f64 data), n elements
-    void *carry;  // [n_chunks] running sum at the end of every chunk (same type), nullptr when rows start on chunk boundaries
+    void *carry;  // [units] running sum at the end of every unit (same type), nullptr when rows start on unit boundaries
+    uint32_t carry_pass;  // 1: k_scan_carry adds them behind the decoder; 0: the first strided scan does (szk_launch_reconstruct*)
     // delta outliers of a fused stream (code 0): the sorted (index, delta) lists inside the payload, searched by index
     const uint64_t *dout_idx;
     const void *dout_val;  // int32 / int64 like q_out
@@ -295,12 +298,13 @@ int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t 
                       uint64_t *total_words, hipStream_t s);
 // x_done: the decoder already produced the x-scanned lattice values in d_out (szk_dec_params::scan_row)
 int szk_launch_reconstruct(int x_done, const uint8_t *payload, const szh_header *h, const szh_offsets *o, const uint16_t *codes,
-                           void *d_out, void *d_segtot, hipStream_t s, const uint32_t *gate = nullptr);
+                           void *d_out, void *d_segtot, hipStream_t s, const uint32_t *gate = nullptr,
+                           const void *carry = nullptr /* the decoder's unit carries, to be added by the first strided pass (RowCarry) */);
 // the strided scans of a Lorenzo stream whose decoder left int16 x-scanned values in d_half (see szk_dec_params::half);
 // szk_half_scans_ok says whether the shape qualifies (f32, even x extent, enough lines for one thread pair per line)
 int szk_half_scans_ok(const szh_header *h);
 int szk_launch_reconstruct_half(const uint8_t *payload, const szh_header *h, const szh_offsets *o, int16_t *d_half, void *d_out, uint32_t *ovf,
-                                hipStream_t s);
+                                hipStream_t s, const int32_t *carry = nullptr);
 void szk_host_offsets(const szh_header *h, szh_offsets *o);
 extern int szk_force_generic;
 extern int szk_dbg_flags;

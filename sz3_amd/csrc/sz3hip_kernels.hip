@@ -2366,6 +2366,8 @@ __device__ __host__ inline void szh_compute_offsets(const szh_header &h, szh_off
     off = szh_align16(off + h.sym_count);
     o.chunkwords = off;
     off = szh_align16(off + 2 * h.n_chunks);
+    o.subbits = off;
+    off = szh_align16(off + 2 * (SZH_SUBS - 1) * h.n_chunks);
     o.vout_idx = off;
     off += 8 * h.n_vout;
     o.vout_val = off;
@@ -2694,7 +2696,8 @@ __global__ __launch_bounds__(1024) void k_scan_groups(uint16_t *__restrict__ chu
 template <int G, bool BYTE = false, uint32_t WIN = ENC_WIN>  // BYTE: c[] are one-byte codes; s_enc[0..255] = code word, s_len8 = its length, by byte value
 __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE], uint64_t base, uint64_t n, bool check_n,
                                                const uint32_t *s_enc, const uint32_t *__restrict__ g_enc,
-                                               uint32_t sym_min, bool all_lds, uint32_t *stage, const uint8_t *s_len8 = nullptr) {
+                                               uint32_t sym_min, bool all_lds, uint32_t *stage, uint16_t *sub_out,
+                                               const uint8_t *s_len8 = nullptr) {
     constexpr int NG = ENC_PER_LANE / G;
     uint64_t g[NG];
     uint32_t gl[NG];
@@ -2736,6 +2739,9 @@ __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE]
     const uint32_t incl = wave_incl_scan(bits);
     const uint32_t total_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
     uint32_t pos = incl - bits;
+    // the decoder's restart points: bit offsets of the units' first symbols = of lanes 64 / SZH_SUBS, ... (sz3hip_format.h: subbits)
+    constexpr int UL = WAVE / SZH_SUBS;  // lanes per unit
+    if ((lane_id() % UL) == 0 && lane_id() != 0) sub_out[lane_id() / UL - 1] = (uint16_t)pos;
     if (BYTE && G == 4) {
         // one-byte codes: a lane's sixteen symbols are ~66 bits on a smooth field — two registers of eight symbols instead of four
         // of four halve the emission work whenever every lane's pairs of registers fit 64 bits (a wave-uniform test)
@@ -2807,7 +2813,8 @@ __device__ void assemble_body(const szk_asm_params &p, uint64_t tid, uint64_t nt
         // alignment gaps between the sections are part of the payload: zero them so that it is a pure function of the input
         const uint64_t tsz0 = h.dtype == 0 ? 4 : 8;
         for (uint64_t a = oo.lens + h.sym_count; a < oo.chunkwords; a++) p.payload[a] = 0;
-        for (uint64_t a = oo.chunkwords + 2 * h.n_chunks; a < oo.vout_idx; a++) p.payload[a] = 0;
+        for (uint64_t a = oo.chunkwords + 2 * h.n_chunks; a < oo.subbits; a++) p.payload[a] = 0;
+        for (uint64_t a = oo.subbits + 2 * (SZH_SUBS - 1) * h.n_chunks; a < oo.vout_idx; a++) p.payload[a] = 0;
         for (uint64_t a = oo.vout_val + tsz0 * h.n_vout; a < oo.dout_idx; a++) p.payload[a] = 0;
         for (uint64_t a = oo.dout_val + (uint64_t)h.qbytes * h.n_dout; a < oo.side; a++) p.payload[a] = 0;
         for (uint64_t a = oo.side + (h.predictor == 2 ? h.side_bytes : 0); a < oo.bitstream; a++) p.payload[a] = 0;
@@ -3016,6 +3023,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     const int lane = lane_id();
     uint32_t *stage = s_stage[threadIdx.x / WAVE];
     uint32_t *out_base = reinterpret_cast<uint32_t *>(payload + state->off.bitstream);
+    uint16_t *sub_base = reinterpret_cast<uint16_t *>(payload + state->off.subbits);
 
     // side loads of a chunk: words of the chunks before it inside its group (one per lane) and the group offset
     auto side = [&](uint64_t ch, uint32_t &before_part, uint64_t &goff) {
@@ -3064,11 +3072,11 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
             const uint32_t wds[4] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w};
 #pragma unroll
             for (int i = 0; i < 16; i++) c[i] = (uint16_t)((wds[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-            nwords = pack_chunk<4, true>(c, 0, 0, false, s_enc8, g_enc, sym_min, all_lds, stage, s_plen8);
+            nwords = pack_chunk<4, true>(c, 0, 0, false, s_enc8, g_enc, sym_min, all_lds, stage, sub_base + chunk * (SZH_SUBS - 1), s_plen8);
         } else {
             unpack_codes(cur, narrow, sym_add, c);
-            nwords = wide ? pack_chunk<2, false, WIN>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage)
-                          : pack_chunk<4, false, WIN>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage);
+            nwords = wide ? pack_chunk<2, false, WIN>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage, sub_base + chunk * (SZH_SUBS - 1))
+                          : pack_chunk<4, false, WIN>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage, sub_base + chunk * (SZH_SUBS - 1));
         }
         const uint32_t before = wave_sum(bp_cur);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -3092,8 +3100,8 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         uint32_t bp;
         uint64_t go;
         side(n_full, bp, go);
-        const uint32_t nwords = wide ? pack_chunk<2, false, WIN>(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage)
-                                     : pack_chunk<4, false, WIN>(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage);
+        const uint32_t nwords = wide ? pack_chunk<2, false, WIN>(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage, sub_base + n_full * (SZH_SUBS - 1))
+                                     : pack_chunk<4, false, WIN>(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage, sub_base + n_full * (SZH_SUBS - 1));
         const uint32_t before = wave_sum(bp);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -3183,11 +3191,22 @@ __global__ __launch_bounds__(1024) void k_dec_tables(const uint8_t *__restrict__
     }
 }
 
-// one thread per chunk: table lookup on the next lut_bits bits of a 64-bit MSB-aligned window. Code words longer than the
-// table (interpolation streams at tight bounds keep ~3 % of their symbols there: every step of a wave meets one) are
-// decoded without a loop or a global access: the length is K + 1 + the number of lengths l whose left-aligned upper code
-// bound is <= the window (canonical codes grow with the length), and the symbols of the long codes sit in LDS.
-#define DEC_SORTED_LDS 16384u  // symbols of the codes longer than the table kept in LDS (further ranks: global)
+// one thread per UNIT of 256 symbols (a quarter chunk: the chunk's start or one of its three restart offsets): table lookup on
+// the next lut_bits bits of a 64-bit MSB-aligned window. Code words longer than the table (interpolation streams at tight bounds
+// keep ~3 % of their symbols there: every step of a wave meets one) are decoded without a loop or a global access: the length
+// is K + 1 + the number of lengths l whose left-aligned upper code bound is <= the window (canonical codes grow with the
+// length), and the symbols of the long codes sit in LDS.
+// Why units: a lane's symbols are one dependent chain (window -> table -> length -> shift), ~700 cycles per symbol with the two
+// waves per SIMD that 131 072 chunks of a 512^3 array give. Four lanes per chunk are four times the chains in flight
+// (round 3; the stream-word ring of round 2 — lanes fetching each other's cache lines through LDS — gained nothing and is gone).
+#ifndef DEC_SORTED_LDS
+#define DEC_SORTED_LDS 1024u  // symbols of the codes longer than the table kept in LDS (further ranks: global)
+#endif
+#ifndef DEC_STAGE_BYTES
+// bytes of a lane's output collected in LDS before they are stored. 128 (whole lines per lane) leaves room for two workgroups per
+// CU, 64 for four: measured 294 -> 218 us (C2, fused) and 419 -> 294 us (C3, plain codes); 32 (five workgroups): 240 / 330
+#define DEC_STAGE_BYTES 64u
+#endif
 // delta of a delta outlier (code 0) by binary search in the sorted index list; 0 when the element is not listed (a corrupt
 // stream must not crash the decoder)
 template <typename QO>
@@ -3201,32 +3220,25 @@ __device__ __forceinline__ QO dec_dout(const szk_dec_params &p, uint64_t elem) {
     return lo < p.n_dout && p.dout_idx[lo] == elem ? reinterpret_cast<const QO *>(p.dout_val)[lo] : (QO)0;
 }
 // QB: 0 = u16 codes out; 4 / 8 = fused Lorenzo x-scan, int32 / int64 lattice values out (see szk_dec_params::scan_row)
-// RING: the lanes' stream words come through LDS. A lane decodes its own chunk, so a wave's loads touch 64 different cache
-// lines per instruction, eight times per line (16 bytes a round): 0.25 of the 0.42 ms of the plain form at C2. Here eight
-// lanes fetch one 128-byte line together for the lane that runs low (its rank among the needy lanes picks the group; the
-// line's address travels through a small LDS mailbox), into that lane's private two-line ring; a line is touched once.
-// RING = words per line of the ring (0: off; 32: whole 128-byte lines, 8 lanes per line, 70 KB of LDS; 16: half lines, 4 lanes
-// per line, 37 KB: two workgroups per CU).
-template <int QB, int RING = 0, bool HALF = false>
+template <int QB, bool HALF = false>
 __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payload, szk_dec_params p,
                                                 uint16_t *__restrict__ codes) {
     using QO = typename std::conditional<QB == 8, int64_t, int32_t>::type;
     if (p.gate && *p.gate == 0) return;  // (the full-width chain behind a half-width one that did not overflow)
-    constexpr uint32_t SORTED_LDS = RING ? 2048u : DEC_SORTED_LDS / 2;
-    // Output through LDS: a lane's 16 values of a round are one 32- / 64- / 128-byte run of ITS chunk, 4 KB from its
+    constexpr uint32_t UNIT = SZH_UNIT_SYMS;
+    constexpr uint32_t SORTED_LDS = DEC_SORTED_LDS;
+    // Output through LDS: a lane's 16 values of a round are one 32- / 64- / 128-byte run of ITS unit, 0.5 - 2 KB from its
     // neighbour's — stored directly, every store instruction touches 64 cache lines with 16 bytes each (0.23 of the kernel's
-    // 0.5 ms at C2: measured by switching the stores off). Staged in LDS and read back piece-major, NP consecutive lanes
-    // write one chunk's run: 64 / NP whole runs per instruction.
-    constexpr uint32_t NP = QB == 8 ? 8 : ((QB == 4 && !HALF) ? 4 : 2);  // 16-byte pieces per lane and round
-    constexpr uint32_t NR = 8 / NP;                             // rounds collected before a store: one whole 128-byte line per chunk
+    // 0.5 ms at C2, round 2: measured by switching the stores off). Staged in LDS and read back piece-major, NP * NR consecutive
+    // lanes write one unit's run: whole lines per instruction.
+    constexpr uint32_t ELT = QB ? (HALF ? QB / 2 : QB) : 2;       // bytes per output element
+    constexpr uint32_t NP = 16 * ELT / 16;                         // 16-byte pieces per lane and round
+    constexpr uint32_t NR = NP * 16 >= DEC_STAGE_BYTES ? 1 : DEC_STAGE_BYTES / (NP * 16);  // rounds collected before a store
+    static_assert((UNIT / 16) % NR == 0, "a unit's rounds are a multiple of the collected rounds");
     __shared__ uint4 s_out[4][64 * (NP * NR + 1)];
-    constexpr uint32_t RL = RING ? RING : 32, RSTRIDE = 2 * RL + 4;  // words per lane: two lines + padding (16-byte aligned rows)
-    constexpr uint32_t LPL = RL / 4;                                   // lanes that fetch one line together (16 bytes each)
     __shared__ uint32_t s_first_code[SZH_MAX_LEN + 2], s_first_rank[SZH_MAX_LEN + 2], s_upper[SZH_MAX_LEN + 2];
     __shared__ uint32_t s_lut[1u << DEC_LUT_BITS];
     __shared__ uint16_t s_sorted[SORTED_LDS];
-    __shared__ __align__(16) uint32_t s_ring[RING ? 256 * RSTRIDE : 4];
-    __shared__ uint32_t s_mail[RING ? 4 * 16 * 2 : 2];
     const uint32_t max_len = p.tables->max_len, K = p.tables->lut_bits, n_coded = p.tables->n_coded;
     if (threadIdx.x <= SZH_MAX_LEN + 1) {
         const uint32_t l = threadIdx.x;
@@ -3242,40 +3254,38 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     const uint32_t base_rank = K < max_len ? p.tables->first_rank[K + 1] : n_coded;
     for (uint32_t e = threadIdx.x; e < SORTED_LDS && base_rank + e < n_coded; e += 256) s_sorted[e] = sorted[base_rank + e];
     __syncthreads();
-    uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool chunk_live = chunk < p.n_chunks;
-    if (!chunk_live) {
-        if (!RING || max_len == 0) return;
-        chunk = p.n_chunks - 1;  // (stays for the wave's cooperative loads; decodes the last chunk again, stores nothing)
-    }
-    const uint64_t s0 = chunk * SZH_CHUNK_SYMS;
-    const uint32_t nsym = !chunk_live ? 0u : (uint32_t)((p.n - s0 < SZH_CHUNK_SYMS) ? (p.n - s0) : SZH_CHUNK_SYMS);
+    const uint64_t unit = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n_units = (p.n + UNIT - 1) / UNIT;
+    if (unit >= n_units) return;
+    const uint64_t chunk = unit / SZH_SUBS;
+    const uint32_t sub = (uint32_t)(unit % SZH_SUBS);
+    const uint64_t s0 = unit * UNIT;
+    const uint32_t nsym = (uint32_t)((p.n - s0 < UNIT) ? (p.n - s0) : UNIT);
     uint16_t *out = codes + s0;
     QO *qout = QB ? reinterpret_cast<QO *>(p.q_out) + s0 : nullptr;
-    // (wave-uniform: all 64 lanes decode full chunks — everywhere but in the array's last wave)
-    const bool coop = !(p.reserved & 2u) && __ballot(chunk_live && nsym == SZH_CHUNK_SYMS) == ~0ull;
+    // (wave-uniform: all 64 lanes decode full units — everywhere but in the array's last wave)
+    const bool coop = !(p.reserved & 2u) && __ballot(nsym == UNIT) == ~0ull;
     uint4 *stage = s_out[threadIdx.x / WAVE];
-    constexpr uint32_t ELT = QB ? (HALF ? QB / 2 : QB) : 2;  // bytes per output element
-    uint8_t *wave_out = QB ? reinterpret_cast<uint8_t *>(p.q_out) + (s0 - (uint64_t)lane_id() * SZH_CHUNK_SYMS) * ELT
-                           : reinterpret_cast<uint8_t *>(codes + (s0 - (uint64_t)lane_id() * SZH_CHUNK_SYMS));
+    uint8_t *wave_out = QB ? reinterpret_cast<uint8_t *>(p.q_out) + (s0 - (uint64_t)lane_id() * UNIT) * ELT
+                           : reinterpret_cast<uint8_t *>(codes + (s0 - (uint64_t)lane_id() * UNIT));
     uint32_t ovf_seen = 0;
-    auto coop_store = [&](const uint4 (&pc)[NP], uint32_t rnd) {  // (a chunk is 64 rounds: a multiple of NR)
-        const uint32_t sub = rnd % NR;
+    auto coop_store = [&](const uint4 (&pc)[NP], uint32_t rnd) {
+        const uint32_t sb = rnd % NR;
 #pragma unroll
-        for (uint32_t j = 0; j < NP; j++) stage[(uint32_t)lane_id() * (NP * NR + 1) + sub * NP + j] = pc[j];
-        if (sub != NR - 1) return;
+        for (uint32_t j = 0; j < NP; j++) stage[(uint32_t)lane_id() * (NP * NR + 1) + sb * NP + j] = pc[j];
+        if (sb != NR - 1) return;
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        const uint32_t i0 = (rnd - sub) * 16;
+        const uint32_t i0 = (rnd - sb) * 16;
 #pragma unroll
         for (uint32_t it = 0; it < NP * NR; it++) {
             const uint32_t idx = it * 64 + (uint32_t)lane_id(), c = idx / (NP * NR), j = idx % (NP * NR);
             const uint4 v = stage[c * (NP * NR + 1) + j];
-            *reinterpret_cast<uint4 *>(wave_out + ((uint64_t)c * SZH_CHUNK_SYMS + i0) * ELT + j * 16) = v;
+            *reinterpret_cast<uint4 *>(wave_out + ((uint64_t)c * UNIT + i0) * ELT + j * 16) = v;
         }
         __builtin_amdgcn_wave_barrier();
     };
-    // symbols left in the current row (the chunk may start inside a row); the running sum restarts at every row start
+    // symbols left in the current row (the unit may start inside a row); the running sum restarts at every row start
     uint32_t left = QB ? p.scan_row - (uint32_t)(s0 % p.scan_row) : 0u;
     QO acc = 0;
     if (max_len == 0) {  // single-symbol alphabet: zero-length code
@@ -3295,7 +3305,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                     left = p.scan_row;
                 }
             }
-            if (p.carry) reinterpret_cast<QO *>(p.carry)[chunk] = acc;
+            if (p.carry) reinterpret_cast<QO *>(p.carry)[unit] = acc;
             if (HALF && ovf_seen) atomicOr(p.ovf, 1u);
         } else {
             for (uint32_t i = 0; i < nsym; i++) out[i] = sym;
@@ -3309,53 +3319,22 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     const uint32_t *bs = reinterpret_cast<const uint32_t *>(payload + p.bitstream_off);
     const uint32_t nwords = p.chunk_words[chunk];
     const uint64_t wlast = p.total_words ? p.total_words - 1 : 0;  // loads are clamped to the section, never conditional
+    // the unit's first bit inside the chunk (a corrupt offset decodes other bits of the section: wrong values, no wrong access)
+    const uint32_t bit0 = sub ? (uint32_t)p.sub_bits[chunk * (SZH_SUBS - 1) + sub - 1] : 0u;
     uint64_t buf = 0;  // next bits at the MSB end
     int have = 0;
-    uint32_t wi = 0;
-    // ring state: lines [.., buf_line) of the stream section are in this lane's ring (line = RL words, slot = line & 1)
-    uint64_t buf_line = woff / RL;
-    uint32_t *ring = s_ring + (RING ? threadIdx.x * RSTRIDE : 0);
-    uint32_t *mail = s_mail + (RING ? (threadIdx.x / WAVE) * 32 : 0);
-    constexpr uint32_t BATCH = WAVE / LPL;  // lines one cooperative load instruction brings in
-    const uint32_t nrounds = RING ? (SZH_CHUNK_SYMS / 16) : (nsym + 15) / 16;  // (RING: every lane of the wave walks all rounds)
+    uint32_t wi = bit0 >> 5;
+    if (bit0 & 31u) {
+        const uint64_t a = woff + wi;
+        uint32_t wd = __builtin_bswap32(bs[a < wlast ? a : wlast]);
+        wd = wi < nwords ? wd : 0u;
+        buf = (uint64_t)wd << (32 + (bit0 & 31u));
+        have = 32 - (int)(bit0 & 31u);
+        wi++;
+    }
+    const uint32_t nrounds = (nsym + 15) / 16;
     for (uint32_t rnd = 0; rnd < nrounds; rnd++) {
         const uint32_t i0 = rnd * 16;
-        if (RING) {
-            // a round consumes at most 16 x 24 bits = 12 words: whoever has fewer than 13 buffered ahead gets its next line
-            // (then the line two back, whose slot is overwritten, is behind the lane: 13 <= RL)
-            bool need = i0 < nsym && (int64_t)(buf_line * RL) - (int64_t)(woff + wi) < 13;
-            unsigned long long m = __ballot(need);
-            while (m) {
-                const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
-                if (need && rank < BATCH) {
-                    mail[rank * 2] = (uint32_t)lane_id();
-                    mail[rank * 2 + 1] = (uint32_t)buf_line;  // (sections of < 2^37 bytes)
-                }
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                const uint32_t cnt = (uint32_t)__popcll(m);
-                const uint32_t grp = (uint32_t)lane_id() / LPL, sub = (uint32_t)lane_id() % LPL;
-                if (grp < (cnt < BATCH ? cnt : BATCH)) {
-                    const uint32_t tgt = mail[grp * 2], line = mail[grp * 2 + 1];
-                    uint64_t a = (uint64_t)line * RL + sub * 4;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (a + 3 <= wlast) v = *reinterpret_cast<const uint4 *>(bs + a);  // (the section is 16-byte aligned)
-                    else {
-                        uint32_t t[4];
-                        for (int k = 0; k < 4; k++) t[k] = a + k <= wlast ? bs[a + k] : 0u;
-                        v = make_uint4(t[0], t[1], t[2], t[3]);
-                    }
-                    *reinterpret_cast<uint4 *>(s_ring + ((threadIdx.x & ~63u) + tgt) * RSTRIDE + (line & 1u) * RL + sub * 4) = v;
-                }
-                if (need && rank < BATCH) {
-                    buf_line++;
-                    need = (int64_t)(buf_line * RL) - (int64_t)(woff + wi) < 13;  // (the first fill takes two lines)
-                }
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                m = __ballot(need);
-            }
-        }
         // the next four stream words of this lane, fetched once per 16 symbols with one wait (a load issued inside the
         // divergent refill branch would be waited for at every symbol); typical groups consume 2-3 words, longer ones
         // fall back to single loads
@@ -3363,7 +3342,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint64_t a = woff + wi + k;
-            qw[k] = RING ? __builtin_bswap32(ring[(uint32_t)(a & (2 * RL - 1))]) : __builtin_bswap32(bs[a < wlast ? a : wlast]);
+            qw[k] = __builtin_bswap32(bs[a < wlast ? a : wlast]);
         }
         uint32_t qn = 0;
         uint32_t syms[16];
@@ -3380,7 +3359,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                     wd = qn == 0 ? qw[0] : (qn == 1 ? qw[1] : (qn == 2 ? qw[2] : qw[3]));
                 } else {
                     const uint64_t a = woff + wi;
-                    wd = RING ? __builtin_bswap32(ring[(uint32_t)(a & (2 * RL - 1))]) : __builtin_bswap32(bs[a < wlast ? a : wlast]);
+                    wd = __builtin_bswap32(bs[a < wlast ? a : wlast]);
                 }
                 wd = wi < nwords ? wd : 0u;
                 qn++;
@@ -3515,41 +3494,41 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                 if (i0 + k < nsym) out[i0 + k] = (uint16_t)syms[k];
         }
     }
-    if (QB && p.carry && chunk_live) reinterpret_cast<QO *>(p.carry)[chunk] = acc;
+    if (QB && p.carry) reinterpret_cast<QO *>(p.carry)[unit] = acc;
     if (HALF && __ballot(ovf_seen != 0) && lane_id() == 0) atomicOr(p.ovf, 1u);
 }
 
-// adds the running sum the previous chunk ended with to the head of every chunk that starts inside a row (rows of at most
-// one chunk: the row's start lies in the previous chunk). One wave per chunk.
+// The decoder's running sums restart in every unit: a unit that starts inside a row misses what the row's earlier units summed
+// up — carry[] of the units from the one that holds the row's start to its predecessor (a unit's carry is its running sum at
+// its end, i.e. since the last row start inside it or since its own start). One wave per unit; rows of at most one chunk.
 template <typename QO>
-__global__ __launch_bounds__(256) void k_scan_carry(QO *__restrict__ q, const QO *__restrict__ carry, uint64_t n, uint64_t n_chunks,
-                                                    uint32_t L, const uint32_t *gate) {
-    if (gate && *gate == 0) return;  // (the full-width chain behind a half-width one that did not overflow)
-    const uint64_t c = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE;
-    if (c == 0 || c >= n_chunks) return;
-    const uint64_t s0 = c * SZH_CHUNK_SYMS;
+__device__ __forceinline__ bool unit_carry_in(const QO *__restrict__ carry, uint64_t n, uint64_t u, uint32_t L, uint64_t &s0, uint64_t &seg, QO &cin) {
+    s0 = u * SZH_UNIT_SYMS;
+    if (u == 0 || s0 >= n) return false;
     const uint32_t x0 = (uint32_t)(s0 % L);
-    if (x0 == 0) return;
-    uint64_t seg = L - x0;
-    if (seg > SZH_CHUNK_SYMS) seg = SZH_CHUNK_SYMS;
+    if (x0 == 0) return false;
+    seg = L - x0;
+    if (seg > SZH_UNIT_SYMS) seg = SZH_UNIT_SYMS;
     if (seg > n - s0) seg = n - s0;
-    const QO cin = carry[c - 1];
-    if (cin == 0) return;
+    const uint64_t first = (s0 - x0) / SZH_UNIT_SYMS;  // the unit that holds the row's start
+    QO part = 0;
+    for (uint64_t v = first + lane_id(); v < u; v += WAVE) part += carry[v];
+    cin = wave_sum(part);
+    return cin != 0;
+}
+template <typename QO>
+__global__ __launch_bounds__(256) void k_scan_carry(QO *__restrict__ q, const QO *__restrict__ carry, uint64_t n, uint32_t L, const uint32_t *gate) {
+    if (gate && *gate == 0) return;  // (the full-width chain behind a half-width one that did not overflow)
+    uint64_t s0, seg;
+    QO cin;
+    if (!unit_carry_in(carry, n, (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE, L, s0, seg, cin)) return;
     for (uint32_t i = lane_id(); i < seg; i += WAVE) q[s0 + i] += cin;
 }
 // the same on the half-width chain's int16 values (the carries stay 32 bits wide); a sum that does not fit raises the flag
-__global__ __launch_bounds__(256) void k_scan_carry_half(int16_t *__restrict__ q, const int32_t *__restrict__ carry, uint64_t n, uint64_t n_chunks,
-                                                         uint32_t L, uint32_t *ovf) {
-    const uint64_t c = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE;
-    if (c == 0 || c >= n_chunks) return;
-    const uint64_t s0 = c * SZH_CHUNK_SYMS;
-    const uint32_t x0 = (uint32_t)(s0 % L);
-    if (x0 == 0) return;
-    uint64_t seg = L - x0;
-    if (seg > SZH_CHUNK_SYMS) seg = SZH_CHUNK_SYMS;
-    if (seg > n - s0) seg = n - s0;
-    const int32_t cin = carry[c - 1];
-    if (cin == 0) return;
+__global__ __launch_bounds__(256) void k_scan_carry_half(int16_t *__restrict__ q, const int32_t *__restrict__ carry, uint64_t n, uint32_t L, uint32_t *ovf) {
+    uint64_t s0, seg;
+    int32_t cin;
+    if (!unit_carry_in(carry, n, (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE, L, s0, seg, cin)) return;
     bool bad = false;
     for (uint32_t i = lane_id(); i < seg; i += WAVE) {
         const int32_t v = (int32_t)q[s0 + i] + cin;
@@ -3682,38 +3661,73 @@ __global__ __launch_bounds__(256) void k_scan_x_wave(Q *__restrict__ q, const ui
 // the chip: k_strided_totals sums the segments first (one extra read), the scan adds the totals of the preceding segments.
 // The last strided scan of the reconstruction also turns the lattice index into the value (same buffer, Q and T have the
 // same size).
+// Rows that are multiples of the decoder's unit (512, 768, 1024): the x prefix sums the decoder wrote restart at every unit, and
+// what the row's earlier units summed up (szk_dec_params::carry) is added by the FIRST strided pass as it reads — element e at
+// column x of its row gets the carries of the row's units before its own (SZH_SUBS - 1 loads at most, none in a row's first
+// unit) — instead of a pass of its own over the array (k_scan_carry: 0.12 ms at 512^3 with units of 256).
+// A strided line keeps its column: j = units of the row before the line's own, ub = first unit of the row the line starts in,
+// ustep = units between two steps along the line (inner / unit: inner is a multiple of the row).
+struct RowCarry {
+    uint32_t j;
+    uint64_t ub, ustep;
+    __device__ __forceinline__ RowCarry(bool on, uint64_t base, uint64_t inner, uint32_t row) {
+        const uint32_t x = on ? (uint32_t)(base % row) : 0u;
+        j = x / SZH_UNIT_SYMS;
+        ub = (base - x) / SZH_UNIT_SYMS;
+        ustep = inner / SZH_UNIT_SYMS;
+    }
+    template <typename QC>
+    __device__ __forceinline__ QC at(const QC *__restrict__ carry, uint64_t a) const {  // step a of the line
+        QC c = 0;
+        const uint64_t u0 = ub + a * ustep;
+#pragma unroll
+        for (uint32_t i = 0; i < SZH_SUBS - 1; i++) c += i < j ? carry[u0 + i] : (QC)0;
+        return c;
+    }
+};
 template <typename Q>
 __global__ __launch_bounds__(256) void k_strided_totals(const Q *__restrict__ q, uint64_t L, uint64_t inner, uint64_t nlines, uint32_t S,
-                                                        uint64_t Lseg, Q *__restrict__ totals) {
+                                                        uint64_t Lseg, Q *__restrict__ totals, const Q *__restrict__ carry, uint32_t row) {
     using UQ = typename std::make_unsigned<Q>::type;
     const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nlines * S) return;
     const uint64_t seg = id / nlines, line = id % nlines;
     const uint64_t outer = line / inner, in = line % inner;
-    const Q *pp = q + outer * L * inner + in;
+    const uint64_t base = outer * L * inner + in;
+    const Q *pp = q + base;
     const uint64_t a0 = seg * Lseg, a1 = (a0 + Lseg < L) ? a0 + Lseg : L;
     UQ run = 0;
-    for (uint64_t a = a0; a < a1; a++) run += (UQ)pp[a * inner];
+    const RowCarry rc(carry != nullptr, base, inner, row);
+    for (uint64_t a = a0; a < a1; a++) run += (UQ)pp[a * inner] + (rc.j ? (UQ)rc.at(carry, a) : (UQ)0);
     totals[id] = (Q)run;
 }
-template <typename Q, typename T, bool DEQUANT>
+template <typename Q, typename T, bool DEQUANT, bool CARRY>
 __device__ __forceinline__ void scan_strided_body(void *buf, uint64_t L, uint64_t inner, uint64_t nlines, uint32_t S, uint64_t Lseg,
-                                                  const Q *__restrict__ totals, szk_lattice l) {
+                                                  const Q *__restrict__ totals, szk_lattice l, const Q *__restrict__ carry, uint32_t row) {
     using UQ = typename std::make_unsigned<Q>::type;
     const Lattice<T> lat(l);
     const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nlines * S) return;
     const uint64_t seg = id / nlines, line = id % nlines;
     const uint64_t outer = line / inner, in = line % inner;
-    Q *pp = reinterpret_cast<Q *>(buf) + outer * L * inner + in;
-    T *po = reinterpret_cast<T *>(buf) + outer * L * inner + in;
+    const uint64_t base = outer * L * inner + in;
+    Q *pp = reinterpret_cast<Q *>(buf) + base;
+    T *po = reinterpret_cast<T *>(buf) + base;
     const uint64_t a1 = (seg * Lseg + Lseg < L) ? seg * Lseg + Lseg : L;
     UQ run = 0;
     for (uint32_t k = 0; k < seg; k++) run += (UQ)totals[(uint64_t)k * nlines + line];
     uint64_t a = seg * Lseg;
+    const RowCarry rc(CARRY, base, inner, row);
+    const bool carried = CARRY && rc.j != 0;
     for (; a + 4 <= a1; a += 4) {
         UQ v0 = (UQ)pp[(a + 0) * inner], v1 = (UQ)pp[(a + 1) * inner], v2 = (UQ)pp[(a + 2) * inner],
            v3 = (UQ)pp[(a + 3) * inner];
+        if (carried) {
+            v0 += (UQ)rc.at(carry, a + 0);
+            v1 += (UQ)rc.at(carry, a + 1);
+            v2 += (UQ)rc.at(carry, a + 2);
+            v3 += (UQ)rc.at(carry, a + 3);
+        }
         v0 += run;
         v1 += v0;
         v2 += v1;
@@ -3732,35 +3746,41 @@ __device__ __forceinline__ void scan_strided_body(void *buf, uint64_t L, uint64_
         run = v3;
     }
     for (; a < a1; a++) {
-        run += (UQ)pp[a * inner];
+        run += (UQ)pp[a * inner] + (carried ? (UQ)rc.at(carry, a) : (UQ)0);
         if (DEQUANT) po[a * inner] = lat.dequant((Q)run);
         else pp[a * inner] = (Q)run;
     }
 }
 template <typename Q>
 __global__ __launch_bounds__(256) void k_scan_strided(Q *__restrict__ q, uint64_t L, uint64_t inner, uint64_t nlines, uint32_t S,
-                                                      uint64_t Lseg, const Q *__restrict__ totals, const uint32_t *gate) {
+                                                      uint64_t Lseg, const Q *__restrict__ totals, const uint32_t *gate,
+                                                      const Q *__restrict__ carry, uint32_t row) {
     using T = typename std::conditional<sizeof(Q) == 4, float, double>::type;
     if (gate && *gate == 0) return;
-    scan_strided_body<Q, T, false>(q, L, inner, nlines, S, Lseg, totals, szk_lattice{});
+    if (carry) scan_strided_body<Q, T, false, true>(q, L, inner, nlines, S, Lseg, totals, szk_lattice{}, carry, row);
+    else scan_strided_body<Q, T, false, false>(q, L, inner, nlines, S, Lseg, totals, szk_lattice{}, carry, row);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_scan_strided_dequant(void *buf, uint64_t L, uint64_t inner, uint64_t nlines, uint32_t S, uint64_t Lseg,
-                                                              const typename QTraits<T>::Q *__restrict__ totals, szk_lattice l, const uint32_t *gate) {
+                                                              const typename QTraits<T>::Q *__restrict__ totals, szk_lattice l, const uint32_t *gate,
+                                                              const typename QTraits<T>::Q *__restrict__ carry, uint32_t row) {
     if (gate && *gate == 0) return;
-    scan_strided_body<typename QTraits<T>::Q, T, true>(buf, L, inner, nlines, S, Lseg, totals, l);
+    if (carry) scan_strided_body<typename QTraits<T>::Q, T, true, true>(buf, L, inner, nlines, S, Lseg, totals, l, carry, row);
+    else scan_strided_body<typename QTraits<T>::Q, T, true, false>(buf, L, inner, nlines, S, Lseg, totals, l, carry, row);
 }
 // Half-width strided scans (f32 data, int16 storage, see szk_dec_params::half): one thread per PAIR of adjacent lines (two
 // neighbouring x), marching along the axis; sums in int32. DEQ = false: in place, a sum outside int16 raises the flag;
 // DEQ = true (the last axis): int16 in, dequantised float out.
-template <bool DEQ>
+template <bool DEQ, bool CARRY>
 __global__ __launch_bounds__(256) void k_scan_strided_half(const int16_t *__restrict__ in, void *__restrict__ outp, uint64_t L, uint64_t inner,
-                                                           uint64_t nlines, szk_lattice l, uint32_t *ovf) {
+                                                           uint64_t nlines, szk_lattice l, uint32_t *ovf, const int32_t *__restrict__ carry, uint32_t row) {
     const Lattice<float> lat(l);
     const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index
     if (id * 2 >= nlines) return;
     const uint64_t line = id * 2, outer = line / inner, inn = line % inner;
     const uint64_t base = outer * L * inner + inn;
+    const RowCarry rc(CARRY, base, inner, row);  // (a pair lies in one unit)
+    const bool carried = CARRY && rc.j != 0;
     const uint32_t *pin = reinterpret_cast<const uint32_t *>(in + base);  // (inner is even: a pair is one aligned word)
     const uint64_t step = inner / 2;                                       // words between consecutive elements of a line
     int32_t r0 = 0, r1 = 0;
@@ -3770,11 +3790,17 @@ __global__ __launch_bounds__(256) void k_scan_strided_half(const int16_t *__rest
         uint32_t w[DEPTH];
 #pragma unroll
         for (int k = 0; k < DEPTH; k++) w[k] = a + k < L ? pin[(a + k) * step] : 0u;
+        int32_t cw[CARRY ? DEPTH : 1];
+        if (CARRY && carried) {
+#pragma unroll
+            for (int k = 0; k < DEPTH; k++) cw[k] = a + k < L ? rc.at(carry, a + k) : 0;
+        }
 #pragma unroll
         for (int k = 0; k < DEPTH; k++) {
             if (a + k >= L) break;
-            r0 += (int32_t)(int16_t)(w[k] & 0xFFFFu);
-            r1 += (int32_t)(int16_t)(w[k] >> 16);
+            const int32_t c = (CARRY && carried) ? cw[CARRY ? k : 0] : 0;
+            r0 += (int32_t)(int16_t)(w[k] & 0xFFFFu) + c;
+            r1 += (int32_t)(int16_t)(w[k] >> 16) + c;
             if (DEQ) {
                 float2 v = make_float2(lat.dequant(r0), lat.dequant(r1));
                 *reinterpret_cast<float2 *>(reinterpret_cast<float *>(outp) + base + (a + k) * inner) = v;
@@ -4164,32 +4190,23 @@ int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t 
     (void)no_layout;  // (the group offsets are made by the second workgroup of the tables' launch: szk_launch_dec_tables)
     (void)chunk_off;
     (void)total_words;
-    const uint64_t nb = (p->n_chunks + 255) / 256;
+    const uint64_t n_units = (p->n + SZH_UNIT_SYMS - 1) / SZH_UNIT_SYMS;
+    const uint64_t nb = (n_units + 255) / 256;
     if (nb > 0x7FFFFFFFull) return -1;
-    // (development switches 32768 / 65536: stream words through the LDS ring with 32- / 16-word lines)
-    const int ring = (szk_dbg_flags & 32768) ? 32 : ((szk_dbg_flags & 65536) ? 16 : 0);
-#define SZK_DEC(QB)                                                                                                          \
-    do {                                                                                                                     \
-        if (ring == 32) hipLaunchKernelGGL((k_decode<QB, 32>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);      \
-        else if (ring == 16) hipLaunchKernelGGL((k_decode<QB, 16>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes); \
-        else hipLaunchKernelGGL((k_decode<QB, 0>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);                  \
-    } while (0)
-    if (!p->scan_row) SZK_DEC(0);
-    else if (p->q_bytes == 8) SZK_DEC(8);
-    else if (p->half) hipLaunchKernelGGL((k_decode<4, 0, true>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
-    else SZK_DEC(4);
-#undef SZK_DEC
-    if (p->scan_row && p->carry) {
-        const uint64_t cb = (p->n_chunks + 3) / 4;
+    if (!p->scan_row) hipLaunchKernelGGL((k_decode<0>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
+    else if (p->q_bytes == 8) hipLaunchKernelGGL((k_decode<8>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
+    else if (p->half) hipLaunchKernelGGL((k_decode<4, true>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
+    else hipLaunchKernelGGL((k_decode<4>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
+    if (p->scan_row && p->carry && p->carry_pass) {
+        const uint64_t cb = (n_units + 3) / 4;
         if (p->q_bytes == 8)
-            hipLaunchKernelGGL(k_scan_carry<int64_t>, dim3((uint32_t)cb), dim3(256), 0, s, (int64_t *)p->q_out, (const int64_t *)p->carry, p->n,
-                               p->n_chunks, p->scan_row, p->gate);
+            hipLaunchKernelGGL(k_scan_carry<int64_t>, dim3((uint32_t)cb), dim3(256), 0, s, (int64_t *)p->q_out, (const int64_t *)p->carry, p->n, p->scan_row,
+                               p->gate);
         else if (p->half)
-            hipLaunchKernelGGL(k_scan_carry_half, dim3((uint32_t)cb), dim3(256), 0, s, (int16_t *)p->q_out, (const int32_t *)p->carry, p->n, p->n_chunks,
-                               p->scan_row, p->ovf);
+            hipLaunchKernelGGL(k_scan_carry_half, dim3((uint32_t)cb), dim3(256), 0, s, (int16_t *)p->q_out, (const int32_t *)p->carry, p->n, p->scan_row, p->ovf);
         else
-            hipLaunchKernelGGL(k_scan_carry<int32_t>, dim3((uint32_t)cb), dim3(256), 0, s, (int32_t *)p->q_out, (const int32_t *)p->carry, p->n,
-                               p->n_chunks, p->scan_row, p->gate);
+            hipLaunchKernelGGL(k_scan_carry<int32_t>, dim3((uint32_t)cb), dim3(256), 0, s, (int32_t *)p->q_out, (const int32_t *)p->carry, p->n, p->scan_row,
+                               p->gate);
     }
     SZK_CHECK_LAUNCH();
     return 0;
@@ -4212,8 +4229,9 @@ static int scan_rows(Q *q, uint64_t L, uint64_t nrows, Q *scratch, hipStream_t s
 
 template <typename T>
 static int launch_reconstruct(bool x_done, const uint8_t *payload, const szh_header &h, const szh_offsets &o, const uint16_t *codes,
-                              void *d_out, void *d_segtot, hipStream_t s, const uint32_t *gate) {
+                              void *d_out, void *d_segtot, hipStream_t s, const uint32_t *gate, const void *carry_v) {
     using Q = typename QTraits<T>::Q;
+    const Q *carry = reinterpret_cast<const Q *>(carry_v);  // the decoder's unit carries, added by the first strided pass (nullptr: none)
     Q *q = reinterpret_cast<Q *>(d_out);
     const uint64_t n = h.n;
     const uint64_t L = h.dims[3], nrows = n / L;
@@ -4256,13 +4274,14 @@ static int launch_reconstruct(bool x_done, const uint8_t *payload, const szh_hea
             Q *totals = (Q *)d_segtot;
             if (S > 1)
                 hipLaunchKernelGGL(k_strided_totals<Q>, dim3(grid_for(nlines * S, 256, 0x7FFFFFFF)), dim3(256), 0, s, (const Q *)q, La, inner, nlines, S,
-                                   Lseg, totals);
+                                   Lseg, totals, carry, (uint32_t)L);
             if (ax == last_ax)
                 hipLaunchKernelGGL(k_scan_strided_dequant<T>, dim3(grid_for(nlines * S, 256, 0x7FFFFFFF)), dim3(256), 0, s, d_out, La, inner,
-                                   nlines, S, Lseg, (const Q *)totals, szk_make_lattice(h.eb), gate);
+                                   nlines, S, Lseg, (const Q *)totals, szk_make_lattice(h.eb), gate, carry, (uint32_t)L);
             else
                 hipLaunchKernelGGL(k_scan_strided<Q>, dim3(grid_for(nlines * S, 256, 0x7FFFFFFF)), dim3(256), 0, s, q, La, inner, nlines, S, Lseg,
-                                   (const Q *)totals, gate);
+                                   (const Q *)totals, gate, carry, (uint32_t)L);
+            carry = nullptr;  // (the first pass took them)
         }
         inner *= La;
     }
@@ -4291,9 +4310,9 @@ int szk_launch_expand_deltas(int dtype, const uint16_t *codes, uint64_t n, int r
     return 0;
 }
 int szk_launch_reconstruct(int x_done, const uint8_t *payload, const szh_header *h, const szh_offsets *o, const uint16_t *codes,
-                           void *d_out, void *d_segtot, hipStream_t s, const uint32_t *gate) {
-    return h->dtype == 0 ? launch_reconstruct<float>(x_done != 0, payload, *h, *o, codes, d_out, d_segtot, s, gate)
-                         : launch_reconstruct<double>(x_done != 0, payload, *h, *o, codes, d_out, d_segtot, s, gate);
+                           void *d_out, void *d_segtot, hipStream_t s, const uint32_t *gate, const void *carry) {
+    return h->dtype == 0 ? launch_reconstruct<float>(x_done != 0, payload, *h, *o, codes, d_out, d_segtot, s, gate, carry)
+                         : launch_reconstruct<double>(x_done != 0, payload, *h, *o, codes, d_out, d_segtot, s, gate, carry);
 }
 // the shape gives every strided axis enough lines for one thread per line pair (no segment totals) and an even x extent
 int szk_half_scans_ok(const szh_header *h) {
@@ -4303,7 +4322,7 @@ int szk_half_scans_ok(const szh_header *h) {
     return 1;
 }
 int szk_launch_reconstruct_half(const uint8_t *payload, const szh_header *h, const szh_offsets *o, int16_t *d_half, void *d_out, uint32_t *ovf,
-                                hipStream_t s) {
+                                hipStream_t s, const int32_t *carry) {
     const uint64_t n = h->n;
     int last_ax = -1;
     for (int ax = 2; ax >= 0; ax--)
@@ -4314,11 +4333,13 @@ int szk_launch_reconstruct_half(const uint8_t *payload, const szh_header *h, con
         const uint64_t La = h->dims[ax];
         if (La > 1) {
             const uint64_t npairs = n / La / 2;
-            if (ax == last_ax)
-                hipLaunchKernelGGL(k_scan_strided_half<true>, dim3(grid_for(npairs, 256, 0x7FFFFFFF)), dim3(256), 0, s, d_half, d_out, La, inner, n / La, lat, ovf);
-            else
-                hipLaunchKernelGGL(k_scan_strided_half<false>, dim3(grid_for(npairs, 256, 0x7FFFFFFF)), dim3(256), 0, s, d_half, (void *)d_half, La, inner,
-                                   n / La, lat, ovf);
+            const dim3 g(grid_for(npairs, 256, 0x7FFFFFFF));
+            const uint32_t row = (uint32_t)h->dims[3];
+            if (ax == last_ax && carry) hipLaunchKernelGGL((k_scan_strided_half<true, true>), g, dim3(256), 0, s, d_half, d_out, La, inner, n / La, lat, ovf, carry, row);
+            else if (ax == last_ax) hipLaunchKernelGGL((k_scan_strided_half<true, false>), g, dim3(256), 0, s, d_half, d_out, La, inner, n / La, lat, ovf, carry, row);
+            else if (carry) hipLaunchKernelGGL((k_scan_strided_half<false, true>), g, dim3(256), 0, s, d_half, (void *)d_half, La, inner, n / La, lat, ovf, carry, row);
+            else hipLaunchKernelGGL((k_scan_strided_half<false, false>), g, dim3(256), 0, s, d_half, (void *)d_half, La, inner, n / La, lat, ovf, carry, row);
+            carry = nullptr;  // (the first pass took them)
         }
         inner *= La;
     }

@@ -8,6 +8,8 @@ import numpy as np
 
 MAGIC = 0x31485A53
 CHUNK = 1024
+SUBS = 2            # units per chunk (sz3hip_format.h: SZH_SUBS); a unit starts at the chunk's start or at a restart offset
+UNIT = CHUNK // SUBS
 MAX_LEN = 24        # format limit; code books of <= SHORT_SYMS symbols are limited to SHORT_LEN
 SHORT_SYMS, SHORT_LEN = 512, 16
 
@@ -80,6 +82,8 @@ def parse(payload):
     off = a16(off + sym_count)
     o["chunkwords"] = off
     off = a16(off + 2 * n_chunks)
+    o["subbits"] = off  # (format 4) bit offset of a chunk's symbol 512: the decoder's restart point
+    off = a16(off + 2 * (SUBS - 1) * n_chunks)
     o["vout_idx"] = off
     off += 8 * n_vout
     o["vout_val"] = off
@@ -98,6 +102,7 @@ def parse(payload):
     sec = dict(
         lens=buf[o["lens"]:o["lens"] + sym_count].copy(),
         chunkwords=np.frombuffer(b, dtype=np.uint16, count=n_chunks, offset=o["chunkwords"]).copy(),
+        subbits=np.frombuffer(b, dtype=np.uint16, count=(SUBS - 1) * n_chunks, offset=o["subbits"]).copy().reshape(n_chunks, SUBS - 1),
         vout_idx=np.frombuffer(b, dtype=np.uint64, count=n_vout, offset=o["vout_idx"]).copy(),
         vout_val=np.frombuffer(b, dtype=T, count=n_vout, offset=o["vout_val"]).copy(),
         dout_idx=np.frombuffer(b, dtype=np.uint64, count=n_dout, offset=o["dout_idx"]).copy(),
@@ -154,6 +159,8 @@ def huffman_decode(h, sec):
         ns = min(CHUNK, n - s0)
         pos = 0
         for i in range(ns):
+            if i and i % UNIT == 0 and int(sec["subbits"][c][i // UNIT - 1]) != pos:
+                raise ValueError("restart offset %d of chunk %d is %d, the symbol starts at bit %d" % (i // UNIT, c, sec["subbits"][c][i // UNIT - 1], pos))
             v = 0
             l = 0
             while True:

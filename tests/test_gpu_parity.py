@@ -403,14 +403,16 @@ def test_c1_through_the_cli_boundary(tmp_path):
         sz3_amd.decompress(np.fromfile(tmp_path / "recipe-cpu.sz", dtype=np.uint8), np.float32, a.shape)
 
 
-@pytest.mark.parametrize("shape,carry", [((96, 384, 512), 0), ((80, 520, 500), 1)], ids=["rows-512", "rows-500-carries"])
+@pytest.mark.parametrize("shape,carry", [((96, 384, 512), 0), ((80, 520, 500), 1), ((48, 130, 768), 1), ((40, 36, 1024), 2), ((160, 200, 256), 0)],
+                         ids=["rows-512", "rows-500-carry-pass", "rows-768-carry-pass", "rows-1024-carried-in-scan", "rows-256"])
 def test_half_width_decoder_intermediates_and_their_overflow_path(shape, carry):
     """The Lorenzo decoder keeps its x-scanned values and the y-prefixed ones as int16 when they fit (smooth f32 fields) and
     repeats the chain at full width behind a device-side gate when one does not. A step of 2000 between two planes makes
     D_z q = 10^6 lattice steps: the first call overflows and takes the gated chain, the following ones go to full width
     directly (the context fetched the flag with the next header); a smooth field stays on the half-width chain. All exact
-    against each other and within the bound. Rows of 500 do not divide the 1024-symbol chunks: the running sums that cross a
-    chunk boundary are carried by a pass of their own on either chain."""
+    against each other and within the bound. A lane of the decoder sums a unit of 512 symbols: rows of 256 / 512 need nothing
+    more, rows of 1024 get the sum of their first unit from the first strided scan as it reads (mode 2), rows of 500 / 768 from
+    a pass of their own (mode 1) — on either chain; the pass and the in-scan form agree bit for bit."""
     import ctypes as C
     dev = torch.device("cuda:0")
     eb = 1e-3
@@ -443,16 +445,18 @@ def test_half_width_decoder_intermediates_and_their_overflow_path(shape, carry):
         assert modes[2] == ((0 if overflows else 1), carry)
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
         assert float(np.max(np.abs(outs[0].astype(np.float64) - a.astype(np.float64)))) <= eb
-        L.sz3hip_debug_flags(2097152)  # full-width chain only
-        try:
-            ref = torch.empty_like(t)
-            dc.decompress(pl.data_ptr(), n, ref.data_ptr(), 0)
-            torch.cuda.synchronize()
-            L.sz3hip_debug_decode_info(dc._h, info)
-            assert info[0] == 0
-        finally:
-            L.sz3hip_debug_flags(0)
-        assert np.array_equal(ref.cpu().numpy(), outs[0])
+        for flags, want in ((2097152, (0, carry)), (536870912, None), (2097152 | 536870912, (0, 1 if carry else 0))):
+            L.sz3hip_debug_flags(flags)  # 2097152: full-width chain only; 536870912: the carries by their own pass
+            try:
+                ref = torch.empty_like(t)
+                dc.decompress(pl.data_ptr(), n, ref.data_ptr(), 0)
+                torch.cuda.synchronize()
+                L.sz3hip_debug_decode_info(dc._h, info)
+                if want is not None:
+                    assert (info[0], info[1]) == want
+            finally:
+                L.sz3hip_debug_flags(0)
+            assert np.array_equal(ref.cpu().numpy(), outs[0])
 
 
 def test_full_size_interpolation_properties():

@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
-"""device-resident decompression timing (per stage, HIP events)"""
-import os, sys
+"""A/B timings of the decoder across builds of the kernels: SZ3HIP_LIB=<variant .so> python tools/dec_lab.py
+C2 (Lorenzo, 1e-3: fused x prefix sum, half-width chain) and C3 (interpolation, 1e-4: plain code output), 512^3 f32."""
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np, torch, sz3_amd, time
+import numpy as np, torch, sz3_amd
 from fields import field3d
-S = int(os.environ.get("LAB_SIZE", "512")); eb = float(os.environ.get("LAB_EB", "1e-3"))
-algo = {"interp": sz3_amd.ALGO_INTERP, "lorenzo": sz3_amd.ALGO_LORENZO_REG}[os.environ.get("LAB_ALGO", "lorenzo")]
-a = field3d((S, S, S)); dev = torch.device("cuda:0"); d_in = torch.from_numpy(a).to(dev)
-conf = sz3_amd.Config(S, S, S); conf.cmprAlgo = algo; conf.absErrorBound = eb; conf.regression = 0
-if os.environ.get("LAB_FLAGS"):
-    sz3_amd.lib().sz3hip_debug_flags(int(os.environ["LAB_FLAGS"]))
-dc = sz3_amd.DeviceCompressor(a.size, np.float32); cap = dc.payload_bound(a.size)
-pl = torch.empty(cap, dtype=torch.uint8, device=dev); out = torch.empty_like(d_in)
-n = dc.compress(conf, d_in.data_ptr(), pl.data_ptr(), cap, 0)
-for _ in range(3): dc.decompress(pl.data_ptr(), n, out.data_ptr(), 0)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-R = 10
-for _ in range(R): dc.decompress(pl.data_ptr(), n, out.data_ptr(), 0)
-torch.cuda.synchronize(); t = (time.perf_counter() - t0) / R
-print("decompress %.3f ms -> %.1f GB/s; max err %.3g" % (t * 1e3, a.nbytes / t / 1e9, float((out - d_in).abs().max())))
-dc.set_profiling(True); dc.decompress(pl.data_ptr(), n, out.data_ptr(), 0); torch.cuda.synchronize()
-print({k: round(v, 4) for k, v in dc.stage_times().items() if k in ("huffman_decode", "reconstruct")})
+S = int(os.environ.get("LAB_SIZE", "512"))
+a = field3d((S, S, S)); dev = torch.device("cuda:0")
+d_in = torch.from_numpy(a).to(dev)
+stream = torch.cuda.current_stream().cuda_stream
+name = os.path.basename(os.environ.get("SZ3HIP_LIB", "default"))
+for label, algo, eb in (("C2", sz3_amd.ALGO_LORENZO_REG, 1e-3), ("C3", sz3_amd.ALGO_INTERP_LORENZO, 1e-4)):
+    conf = sz3_amd.Config(S, S, S); conf.cmprAlgo = algo; conf.regression = 0; conf.absErrorBound = eb
+    dc = sz3_amd.DeviceCompressor(a.size, np.float32)
+    cap = dc.payload_bound(a.size); pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+    out = torch.empty_like(d_in)
+    size = dc.compress(conf, d_in.data_ptr(), pl.data_ptr(), cap, stream)
+    for _ in range(3): dc.decompress(pl.data_ptr(), size, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    err = float((out - d_in).abs().max())
+    dc.set_profiling(True)
+    huff = []; rec = []
+    for _ in range(8):
+        dc.decompress(pl.data_ptr(), size, out.data_ptr(), stream); torch.cuda.synchronize()
+        t = dc.stage_times(); huff.append(t.get("huffman_decode", 0)); rec.append(t.get("reconstruct", 0))
+    dc.set_profiling(False)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): dc.decompress(pl.data_ptr(), size, out.data_ptr(), stream)
+    torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / 20 * 1e3
+    print("%-22s %s: decode stage %.1f us  reconstruct %.1f us  wall %.1f us  ratio %.3f  max err %.3g (eb %g)" % (
+        name, label, 1e3 * np.median(huff), 1e3 * np.median(rec), 1e3 * wall, a.nbytes / size, err, eb), flush=True)

@@ -170,6 +170,10 @@ class Workload:
         self.dc.set_profiling(False)
         return acc
 
+    def stream_predictor(self):
+        """predictor id in the payload's header (sz3hip_format.h): 0 plain Lorenzo, 1 interpolation, 2 block-composed"""
+        return int(self.d_payload[11].item())
+
     def verify_and_time_decode(self, psize):
         torch = self.torch
         d_out = torch.empty_like(self.d_in)
@@ -198,10 +202,17 @@ def rooflines(w, acc, psize, ms_per_step, traffic_key):
             traffic = json.load(open(tpath)).get(traffic_key)
         except Exception:
             traffic = None
-    if w.algo == "composed":
-        k_bytes = w.n * (3 * w.esz + 2)  # input in, lattice values out and in again (the two block passes), one 2-byte code per element
-        kname = "stage 1 = k_blk_fit + k_blk_lorenzo + side information (block-composed predictor, sz3hip_regress.hip)"
-        note = "read sizeof(T), write + read sizeof(T) of lattice values, write 2 B of codes per element"
+    if w.algo == "composed" and w.stream_predictor() == 0:
+        # the selection pass found (next to) no block for regression: the array went to the plain Lorenzo kernel
+        k_bytes = w.n * (2 * w.esz + 2)  # input read by the selection pass and again by the predictor kernel, one 2-byte code per element
+        kname = "stage 1 = k_blk_select (choice of every block, a block per lane) + k_lorenzo_quant_march: the selection handed the array to the plain Lorenzo path"
+        note = "read sizeof(T) twice, write 2 B of codes per element"
+        k1_ms = acc.get("tuner", 0.0) + acc.get("lorenzo_quant_hist", float("nan"))
+    elif w.algo == "composed":
+        k_bytes = w.n * (4 * w.esz + 2)  # input in (selection pass, fit pass), lattice values out and in again (the two block passes), one 2-byte code per element
+        kname = "stage 1 = k_blk_select + k_blk_fit + k_blk_lorenzo + side information (block-composed predictor, sz3hip_regress.hip)"
+        note = "read sizeof(T) twice, write + read sizeof(T) of lattice values, write 2 B of codes per element"
+        k1_ms = acc.get("tuner", 0.0) + acc.get("lorenzo_quant_hist", float("nan"))
     elif w.algo == "lorenzo":
         stats = w.dc.stats()
         code_bytes = 1 if stats.get("narrow_codes") else 2
@@ -385,9 +396,14 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
             "tuner": w.dc.tuner_report() if args.algo == "interp" else None,
             "codebook_speculation": {"hits": h_spec, "misses": m_spec,
-                                     "note": "timed loop + warmup: stage 2 packs with the previous call's code book while this call's is built on a "
-                                             "side stream; a miss repeats the encoder (see `cold`)"},
+                                     "note": "timed loop + warmup: stage 2 packs with the previous call's code book while this call's is built by "
+                                             "one workgroup of the same launch; a miss repeats the encoder (see `cold`)"},
         }
+        if args.algo == "composed":
+            pid = w.stream_predictor()
+            out["block_selection"] = {"stream_predictor": pid,
+                                      "note": ("the selection pass found fewer than 1/4096 of the blocks choosing another predictor than Lorenzo-1: "
+                                               "plain Lorenzo stream" if pid == 0 else "block-composed stream (selection bits + regression coefficients)")}
         out.update(rooflines(w, acc, psize, ms_per_step,
                              "lorenzo_quant_hist_hbm_bytes_per_launch" if is_c2 else "c3_stage1_hbm_bytes_per_step" if is_c3 else None))
 

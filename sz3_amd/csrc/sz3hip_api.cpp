@@ -580,10 +580,15 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
 
 // ---- stage 1, block-composed predictor: Lorenzo-1 / Lorenzo-2 / regression chosen per block
 // (make_compressor_lorenzo_regression, api/impl/SZAlgoLorenzoReg.hpp:22-64) ----
-static int blk_reserve(sz3hip_ctx *ctx, uint64_t nblocks) {
-    if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
+static int blk_reserve_counters(sz3hip_ctx *ctx) {  // (all the selection pass needs)
     if (!ctx->d_blk_counters) HIPCHK(hipMalloc((void **)&ctx->d_blk_counters, 64 + 4 * (0x7FFFFFF0ull / 8192 + 2)));
     if (!ctx->h_blk_side_hdr) HIPCHK(hipHostMalloc((void **)&ctx->h_blk_side_hdr, 32));
+    return 0;
+}
+static int blk_reserve(sz3hip_ctx *ctx, uint64_t nblocks) {
+    if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
+    int rcc = blk_reserve_counters(ctx);
+    if (rcc) return rcc;
     if (ctx->blk_cap >= nblocks) return 0;
     void **arr[5] = {(void **)&ctx->d_blk_sel, (void **)&ctx->d_blk_coef, (void **)&ctx->d_blk_rank, (void **)&ctx->d_blk_comp, (void **)&ctx->d_blk_side};
     for (void **a : arr) {
@@ -631,6 +636,37 @@ static void blk_params_from(sz3hip_ctx *ctx, const uint64_t *dims3, uint32_t B, 
     sc.run_scratch = reinterpret_cast<uint32_t *>(ctx->d_blk_counters + 8);  // (the counter block holds 8 words + a run table)
 }
 static bool blk_shape_ok(const sz3hip_config *conf) { return conf->N == 3 && conf->blockSize >= 4 && conf->blockSize <= 8; }
+// The selection first (k_blk_select): when fewer than one block in 4096 would be coded by anything but first-order Lorenzo, every
+// block is — the stream is then the plain Lorenzo stream (same lattice, same stencil: a Lorenzo block's neighbours are lattice
+// values either way), made by the plain kernel and decoded by the global prefix sums instead of block fronts, and the selection
+// bits (2 per block: more than those few blocks save) are not stored. The few blocks take the reference's own fallback
+// predictor (BlockwiseDecomposition.hpp:35-37). One 8-byte read-back and a stream synchronisation decide.
+#define BLK_EXIT_SHIFT 12
+static int blk_all_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint32_t mask, hipStream_t s, bool *all) {
+    *all = false;
+    if (!(mask & 1u) || (szk_dbg_flags & 1073741824)) return 0;
+    const uint32_t B = (uint32_t)conf->blockSize;
+    uint64_t nblocks = 1;
+    for (int i = 0; i < 3; i++) nblocks *= (conf->dims[i] + B - 1) / B;
+    if (nblocks > 0x7FFFFFF0ull) return 0;
+    int rc = blk_reserve_counters(ctx);
+    if (rc) return rc;
+    szk_blk_params bp;
+    szk_blk_scratch sc;
+    blk_params_from(ctx, conf->dims, B, mask, eb, radius, ctx->cur_out_cap, bp, sc);
+    HIPCHK(hipMemsetAsync(ctx->d_blk_counters + 7, 0, 8, s));
+    prof_begin(ctx, ST_TUNER, s);
+    rc = szk_launch_blk_select(ctx->dtype, d_in, &bp, ctx->d_blk_counters + 7, s);
+    prof_end(ctx, ST_TUNER, s);
+    if (rc) return fail(SZ3HIP_EHIP, "block selection kernel launch failed (%d)", rc);
+    HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr, ctx->d_blk_counters + 7, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    uint64_t others;
+    memcpy(&others, ctx->h_blk_side_hdr, 8);
+    ctx->blk_others = others;
+    *all = (others << BLK_EXIT_SHIFT) < nblocks;
+    return 0;
+}
 static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint64_t num, uint32_t mask, hipStream_t s) {
     const uint32_t B = (uint32_t)conf->blockSize;
     uint64_t nblocks = 1;
@@ -1078,7 +1114,13 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
         const uint32_t mask = (conf->lorenzo ? 1u : 0u) | (conf->lorenzo2 ? 2u : 0u) | (conf->regression ? 4u : 0u);
         if (mask == 0) return fail(SZ3HIP_EINVAL, "All lorenzo and regression methods are disabled.");
         if (mask != 1u) {
-            if (blk_shape_ok(conf) && !(szk_dbg_flags & 16384)) return stage1_blocks(ctx, conf, d_in, eb, radius, num, mask, s);
+            if (blk_shape_ok(conf) && !(szk_dbg_flags & 16384)) {
+                bool all_lorenzo = false;
+                const int rcs = blk_all_lorenzo(ctx, conf, d_in, eb, radius, mask, s, &all_lorenzo);
+                if (rcs) return rcs;
+                if (!all_lorenzo) return stage1_blocks(ctx, conf, d_in, eb, radius, num, mask, s);
+                return stage1_lorenzo(ctx, conf, d_in, eb, radius, num, s);  // (the selection chose first-order Lorenzo throughout)
+            }
             if (!(mask & 1u))
                 return fail(SZ3HIP_EUNSUPPORTED, "2nd-order Lorenzo / regression without Lorenzo are built for 3-D arrays with blockSize 4..8 "
                                                  "(got N = %d, blockSize = %d)", conf->N, conf->blockSize);

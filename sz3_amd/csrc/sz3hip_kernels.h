@@ -215,6 +215,8 @@ struct szk_blk_scratch {
     int wide_hist;          // encode: 16384-bin LDS histogram window instead of 4096 (the context's previous alphabet was wide)
     uint8_t side_hdr[32];   // decode: host copy of the side section's header + [24..31] words of its bit section (validated by the caller)
 };
+// the selection pass alone (a block per lane): *n_other += the blocks that would not be coded by first-order Lorenzo
+int szk_launch_blk_select(int dtype, const void *d_in, const szk_blk_params *p, uint64_t *n_other, hipStream_t s);
 int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s);
 int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, const szk_blk_params *p, const szk_blk_scratch *sc,
                               const uint8_t *payload, const szh_header *h, const szh_offsets *o, int64_t *coef_by_rank, hipStream_t s);

@@ -346,6 +346,126 @@ __device__ __forceinline__ void blk_fit_block(const T *sx, const TileView &tv, c
     if (lane == 0) p.sel[task] = (uint8_t)sid;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// the selection alone, a block per LANE: how many blocks would not be coded by first-order Lorenzo
+// ------------------------------------------------------------------------------------------------------------
+// On fields where regression (and Lorenzo-2) never win — C4b: 23 of 636 056 blocks in the reference, 21 of 643 302 here — the
+// block-composed stream is the plain Lorenzo stream plus 160 KB of selection bits, made by two block passes at a third of the
+// plain kernel's speed and decoded front by front. This pass answers the question first: the fit, the sampled estimates and
+// the choice of every block, nothing else. A lane owns a block and walks it row by row in the reference's order
+// (RegressionPredictor.hpp:28-55: the sums in raster order, in double; ComposedPredictor.hpp:25-40 over
+// BlockwiseIterator.hpp:151-184: the sample points i = 0.., four diagonals each, summed as they come) — no tile in LDS, no
+// cross-lane sum (the wave-per-block fit spends ~800 wave instructions per block, most of them on both), 64 blocks' rows of
+// B values side by side in memory = whole cache lines per wave. Values outside the block are seen as the decoder will hold
+// them (on the lattice), outside the array as zero, like k_blk_fit's tile loader does it.
+template <typename T, int CB>
+__global__ __launch_bounds__(256) void k_blk_select(const T *__restrict__ in, szk_blk_params p, uint32_t nblocks, unsigned long long *__restrict__ n_other) {
+    using Q = typename QTraits<T>::Q;
+    const uint32_t task = blockIdx.x * 256 + threadIdx.x;
+    bool other = false;
+    if (task < nblocks) {
+        const BlkGeom g = blk_geom(p, task);
+        const Lattice<T> lat(p.lat);
+        const uint64_t d1 = p.d[1], d2 = p.d[2];
+        const bool has_l1 = p.mask & 1u, has_l2 = p.mask & 2u, has_r = p.mask & 4u;
+        const bool whole = CB && g.ez == CB && g.ey == CB && g.ex == CB;
+        const T *blk = in + ((uint64_t)g.oz * d1 + g.oy) * d2 + g.ox;
+        // (tile coordinates of k_blk_fit: the block's origin is (2, 2, 2), two low halo layers)
+        auto rd = [&](uint32_t tz, uint32_t ty, uint32_t tx) -> T {
+            const int64_t z = (int64_t)g.oz + tz - 2, y = (int64_t)g.oy + ty - 2, x = (int64_t)g.ox + tx - 2;
+            T v = 0;
+            if (z >= 0 && y >= 0 && x >= 0) v = in[((uint64_t)z * d1 + (uint64_t)y) * d2 + (uint64_t)x];  // (never beyond the block's high faces)
+            if (tz < 2 || ty < 2 || tx < 2) {
+                bool bad;
+                const Q qh = lat.quant(v, bad);
+                if (!bad) v = lat.dequant(qh);
+            }
+            return v;
+        };
+        bool r_valid = has_r && g.ez > 1 && g.ey > 1 && g.ex > 1;
+        T cf[4] = {0, 0, 0, 0};
+        if (r_valid) {
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            if (whole) {
+#pragma unroll 1
+                for (uint32_t i0 = 0; i0 < (uint32_t)CB; i0++) {
+#pragma unroll
+                    for (uint32_t i1 = 0; i1 < (uint32_t)CB; i1++) {
+                        const T *row = blk + ((uint64_t)i0 * d1 + i1) * d2;
+                        T v[CB ? CB : 1];
+#pragma unroll
+                        for (uint32_t i2 = 0; i2 < (uint32_t)CB; i2++) v[i2] = row[i2];
+#pragma unroll
+                        for (uint32_t i2 = 0; i2 < (uint32_t)CB; i2++) {
+                            s0 += (double)((T)i0 * v[i2]);  // sum[i] += index[i] * (*c): size_t * T is evaluated in T, accumulated in double
+                            s1 += (double)((T)i1 * v[i2]);
+                            s2 += (double)((T)i2 * v[i2]);
+                            s3 += (double)v[i2];
+                        }
+                    }
+                }
+            } else {
+                for (uint32_t i0 = 0; i0 < g.ez; i0++)
+                    for (uint32_t i1 = 0; i1 < g.ey; i1++) {
+                        const T *row = blk + ((uint64_t)i0 * d1 + i1) * d2;
+                        for (uint32_t i2 = 0; i2 < g.ex; i2++) {
+                            const T v = row[i2];
+                            s0 += (double)((T)i0 * v);
+                            s1 += (double)((T)i1 * v);
+                            s2 += (double)((T)i2 * v);
+                            s3 += (double)v;
+                        }
+                    }
+            }
+            const double dz = g.ez, dy = g.ey, dx = g.ex, num = dz * dy * dx;
+            cf[0] = (T)((2 * s0 / (dz - 1) - s3) * 6 / num / (dz + 1));
+            cf[1] = (T)((2 * s1 / (dy - 1) - s3) * 6 / num / (dy + 1));
+            cf[2] = (T)((2 * s2 / (dx - 1) - s3) * 6 / num / (dx + 1));
+            cf[3] = (T)(s3 / num);
+            cf[3] = (T)((double)cf[3] - (dz - 1) * (double)cf[0] / 2);
+            cf[3] = (T)((double)cf[3] - (dy - 1) * (double)cf[1] / 2);
+            cf[3] = (T)((double)cf[3] - (dx - 1) * (double)cf[2] / 2);
+        }
+        int sid = has_l1 ? 0 : (has_l2 ? 1 : 2);
+        const int npred = (int)has_l1 + (int)has_l2 + (int)has_r;
+        if (npred > 1) {
+            const uint32_t m = min(g.ez, min(g.ey, g.ex));
+            double e1 = 0, e2 = 0, er = 0;
+#pragma unroll 1
+            for (uint32_t i = 0; i < m; i++) {
+                const uint32_t j = m - 1 - i;
+#pragma unroll 1
+                for (uint32_t kind = 0; kind < 4; kind++) {
+                    const uint32_t i0 = i, i1 = (kind & 2) ? j : i, i2 = (kind & 1) ? j : i;
+                    const uint32_t tz = i0 + 2, ty = i1 + 2, tx = i2 + 2;
+                    const T v = blk[((uint64_t)i0 * d1 + i1) * d2 + i2];
+                    if (has_l1) e1 += (double)(T)(fabs((double)(T)(v - lorenzo_pred_orig<T>(rd, tz, ty, tx, 1))) + (T)(1.22 * p.eb));
+                    if (has_l2) e2 += (double)(T)(fabs((double)(T)(v - lorenzo_pred_orig<T>(rd, tz, ty, tx, 2))) + (T)(6.8 * p.eb));
+                    if (r_valid) er += (double)(T)fabs((double)(T)(v - reg_predict(cf, i0, i1, i2)));
+                }
+            }
+            double best = 1.7976931348623157e308;
+            sid = -1;
+            if (has_l1) { best = e1; sid = 0; }
+            if (has_l2 && (sid < 0 || e2 < best)) { best = e2; sid = 1; }
+            if (has_r && r_valid && (sid < 0 || er < best)) { best = er; sid = 2; }
+            if (sid < 0) sid = 0;
+        } else if (sid == 2 && !r_valid) {
+            sid = 0;
+        }
+        if (sid == 2) {  // a coefficient its lattice cannot hold: Lorenzo-1 (as in k_blk_fit)
+            const CoefLat cl = coef_lat(p.eb, p.B);
+            for (int i = 0; i < 4; i++) {
+                const double sc = (double)cf[i] / (i < 3 ? cl.step_lin : cl.step_ind);
+                if (!(fabs(sc) < 4503599627370496.0)) sid = 0;
+            }
+        }
+        other = sid != 0;
+    }
+    const unsigned long long mo = __ballot(other);
+    if (mo && lane_id() == 0) atomicAdd(n_other, (unsigned long long)__popcll(mo));
+}
+
 // NW: waves (= blocks in flight) per workgroup; they share the LDS histogram, so the wide form (64 KB of bins) takes 16 of them to
 // keep four waves per SIMD busy (with 4 the two passes ran at two waves per SIMD, bound by the latency of their tile loads).
 // Measured and dropped (round 2, C4's slab): groups of 2 x 2 x 4 blocks sharing one tile per workgroup (1.47 x instead of 2.37 x
@@ -1134,6 +1254,21 @@ int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const 
     hipLaunchKernelGGL(k_blk_sel_pack, dim3(256), dim3(256), 0, s, p->sel, nblocks, sc->side);
     hipLaunchKernelGGL(k_blk_side_layout, dim3(1), dim3(1024), 0, s, nblocks, sc->counters + 0, stats, group_bits, sc->side, sc->counters + 2);
     hipLaunchKernelGGL(k_blk_coef_write, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, nblocks, sc->side);
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
+
+int szk_launch_blk_select(int dtype, const void *d_in, const szk_blk_params *p, uint64_t *n_other, hipStream_t s) {
+    const uint32_t nblocks = blk_count_blocks(p);
+    const dim3 g((nblocks + 255) / 256), b(256);
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(n_other);
+    if (dtype == 0) {
+        if (p->B == 6) hipLaunchKernelGGL((k_blk_select<float, 6>), g, b, 0, s, (const float *)d_in, *p, nblocks, cnt);
+        else hipLaunchKernelGGL((k_blk_select<float, 0>), g, b, 0, s, (const float *)d_in, *p, nblocks, cnt);
+    } else {
+        if (p->B == 6) hipLaunchKernelGGL((k_blk_select<double, 6>), g, b, 0, s, (const double *)d_in, *p, nblocks, cnt);
+        else hipLaunchKernelGGL((k_blk_select<double, 0>), g, b, 0, s, (const double *)d_in, *p, nblocks, cnt);
+    }
     SZK_CHECK_LAUNCH();
     return 0;
 }

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "plain_exit: block-predictor tests that leave the hand-over to the plain Lorenzo path switched on")
     config.addinivalue_line("markers", "ref: needs oracle/_ref (the reference itself, built only where /root/reference exists)")
 
 

@@ -18,6 +18,19 @@ from fields import field3d, field_c4a  # noqa: E402
 from oracle_binding import make_config, oracle, oracle_compress, oracle_selection  # noqa: E402
 
 
+NO_EXIT = 1073741824  # sz3hip_debug_flags: the block stream even where the selection would hand the array to the plain Lorenzo path
+
+
+@pytest.fixture(autouse=True)
+def _block_streams_wanted(request):
+    """These tests are about the block-composed STREAM: small fields where every block happens to choose Lorenzo-1 must still
+    produce one. The hand-over to the plain path has tests of its own (marked `plain_exit`)."""
+    L = sz3_amd.lib()
+    L.sz3hip_debug_flags(0 if request.node.get_closest_marker("plain_exit") else NO_EXIT)
+    yield
+    L.sz3hip_debug_flags(0)
+
+
 def _payload_of(stream):
     b = stream.tobytes()
     plen, = struct.unpack_from("<Q", b, 8)
@@ -197,3 +210,64 @@ def test_grouped_and_per_block_decoders_agree(shape):
             sz3_amd.lib().sz3hip_debug_flags(0)
         assert np.array_equal(outs[0], outs[1])
         assert float(np.max(np.abs(outs[0].astype(np.float64) - a.astype(np.float64)))) <= 1e-3
+
+
+@pytest.mark.plain_exit
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fields_where_only_lorenzo_is_chosen_become_the_plain_stream(dtype):
+    """The selection runs first (k_blk_select, a block per lane). Fewer than one block in 4096 choosing anything but Lorenzo-1:
+    the array goes to the plain Lorenzo path — the payload IS the one `regression = 0` gives, bit for bit (same lattice, same
+    stencil; no selection bits), and decodes by the global prefix sums. A field where regression wins keeps its block
+    stream, and so does everything when the hand-over is switched off."""
+    import torch
+    dev = torch.device("cuda:0")
+    shape, eb = (60, 96, 132), 1e-3
+    smooth = field3d(shape, dtype)                     # noise above the bound: regression never wins
+    ramps = field_c4a(shape, seed=5).astype(dtype)     # C4a: regression wins in a share of the blocks
+    L = sz3_amd.lib()
+    for a, ebx, want in ((smooth, eb, 0), (ramps, 1e-6, 2)):
+        t = torch.from_numpy(a).to(dev)
+        dc = sz3_amd.DeviceCompressor(a.size, dtype)
+        conf = _conf(shape, ebx, 1, 0, 1)
+        cap = dc.payload_bound_conf(conf)
+        pl = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(3)]
+        n1 = dc.compress(conf, t.data_ptr(), pl[0].data_ptr(), cap, 0)
+        h, _, sec = szh_ref.parse(pl[0][:n1].cpu().numpy().tobytes())
+        assert h["predictor"] == want
+        out = torch.empty_like(t)
+        dc.decompress(pl[0].data_ptr(), n1, out.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert float((out - t).abs().max()) <= ebx
+        n2 = dc.compress(_conf(shape, ebx, 1, 0, 0), t.data_ptr(), pl[1].data_ptr(), cap, 0)
+        torch.cuda.synchronize()
+        if want == 0:
+            assert n1 == n2 and torch.equal(pl[0][:n1], pl[1][:n2]), "the hand-over is the plain stream itself"
+        L.sz3hip_debug_flags(NO_EXIT)
+        try:
+            n3 = dc.compress(conf, t.data_ptr(), pl[2].data_ptr(), cap, 0)
+            torch.cuda.synchronize()
+        finally:
+            L.sz3hip_debug_flags(0)
+        h3, _, sec3 = szh_ref.parse(pl[2][:n3].cpu().numpy().tobytes())
+        assert h3["predictor"] == 2
+        sel, _ = szh_ref.parse_side(h3, sec3)
+        others = int((sel != 0).sum())
+        # the selection pass (sequential sums, the reference's order) and the block pass (wave sums) see the same blocks
+        assert (others * 4096 < sel.size) == (want == 0), (others, sel.size)
+        if want == 0:
+            assert n1 <= n3
+
+
+@pytest.mark.plain_exit
+def test_selection_pass_agrees_with_the_oracle_on_which_fields_are_all_lorenzo():
+    """the oracle's own per-block choices (ComposedPredictor::precompress through the debug sink): on the smooth field it picks
+    regression in fewer than 1/4096 of the blocks, on C4a in many — the selection pass decides the same way"""
+    for a, eb, want in ((field3d((60, 96, 132), np.float32), 1e-3, 0), (field_c4a((60, 96, 132), seed=5), 1e-6, 2)):
+        conf = make_config(a.shape, abs_eb=eb)
+        conf.lorenzo, conf.lorenzo2, conf.regression = 1, 0, 1
+        osel = oracle_selection(a, conf).reshape(-1)
+        o_all = int((osel != 0).sum()) * 4096 < osel.size
+        c = _conf(a.shape, eb, 1, 0, 1)
+        blob, _ = sz3_amd.compress(a, c)
+        h, _, _ = szh_ref.parse(_payload_of(blob))
+        assert (h["predictor"] == 0) == o_all == (want == 0), (h["predictor"], o_all)

@@ -1523,7 +1523,9 @@ __device__ void rec_tile_sort_fast(const RecView &r, uint32_t n, uint32_t base, 
     }
     __syncthreads();
 }
-__device__ void rec_sort(const RecView &r, uint32_t n, uint8_t *pool) {
+// (not inlined: the sort's 16 keys per thread are the kernel's register peak; inlined, the allocator spilled around it in every other phase —
+// 264 bytes of scratch per thread, the compaction 51 -> 80 us)
+__device__ __noinline__ void rec_sort(const RecView &r, uint32_t n, uint8_t *pool) {
     if (n < 2) return;
     uint32_t np2 = 2;
     while (np2 < n) np2 <<= 1;
@@ -1819,7 +1821,16 @@ __device__ void cb_assign_codes(const uint16_t *len_of, const uint16_t *syms, ui
     const uint32_t per = (m + NT - 1) / NT;
     const uint32_t q0 = t * per < m ? t * per : m, q1 = q0 + per < m ? q0 + per : m;
     for (uint32_t l = 0; l <= SZH_MAX_LEN; l++) cnt_tbl[l * NT + t] = 0;
-    for (uint32_t q = q0; q < q1; q++) cnt_tbl[(uint32_t)len_of[q] * NT + t]++;
+    // (a thread's symbols in batches of eight, the batch's global loads in flight together: one symbol per step was a chain of
+    // dependent L2 round trips — the two loops were 29 us of the wide code book's 174 at C3)
+    for (uint32_t qb = q0; qb < q1; qb += 8) {
+        uint16_t l8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) l8[k] = len_of[qb + k < q1 ? qb + k : q1 - 1];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (qb + k < q1) cnt_tbl[(uint32_t)l8[k] * NT + t]++;
+    }
     __syncthreads();
     for (uint32_t l = 1 + t / WAVE; l <= SZH_MAX_LEN; l += NT / WAVE) {
         uint32_t carry = 0;
@@ -1831,10 +1842,20 @@ __device__ void cb_assign_codes(const uint16_t *len_of, const uint16_t *syms, ui
         }
     }
     __syncthreads();
-    for (uint32_t q = q0; q < q1; q++) {
-        const uint32_t l = len_of[q];
-        const uint32_t rank = cnt_tbl[l * NT + t]++;
-        enc[syms[q]] = ((s_first[l] + rank) << 5) | l;
+    for (uint32_t qb = q0; qb < q1; qb += 8) {
+        uint16_t l8[8], s8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            l8[k] = len_of[qb + k < q1 ? qb + k : q1 - 1];
+            s8[k] = syms[qb + k < q1 ? qb + k : q1 - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (qb + k >= q1) break;
+            const uint32_t l = l8[k];
+            const uint32_t rank = cnt_tbl[l * NT + t]++;
+            enc[s8[k]] = ((s_first[l] + rank) << 5) | l;
+        }
     }
 }
 
@@ -1867,7 +1888,10 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
     // (three 64-bin groups per step, their loads in flight together: one per step is a chain of dependent L2 round trips)
     for (uint32_t i0 = b0; i0 < b1; i0 += 3 * WAVE) {
         const uint32_t ia = i0 + lane, ib = ia + WAVE, ic = ib + WAVE;
-        const uint64_t fa = ia < b1 ? hist[lo + ia] : 0ull, fb = ib < b1 ? hist[lo + ib] : 0ull, fc = ic < b1 ? hist[lo + ic] : 0ull;
+        uint64_t fa = hist[lo + (ia < b1 ? ia : b1 - 1)], fb = hist[lo + (ib < b1 ? ib : b1 - 1)], fc = hist[lo + (ic < b1 ? ic : b1 - 1)];
+        fa = ia < b1 ? fa : 0ull;
+        fb = ib < b1 ? fb : 0ull;
+        fc = ic < b1 ? fc : 0ull;
         cnt += (uint32_t)__popcll(__ballot(fa != 0)) + (uint32_t)__popcll(__ballot(fb != 0)) + (uint32_t)__popcll(__ballot(fc != 0));
         fsum += fa + fb + fc;
     }
@@ -1882,16 +1906,28 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
         if (wv < wv_id) pos += s_wt[wv];
         m += s_wt[wv];
     }
-    for (uint32_t i0 = b0; i0 < b1; i0 += WAVE) {
-        const uint32_t i = i0 + lane;
-        const uint64_t f = i < b1 ? hist[lo + i] : 0ull;
-        const unsigned long long bal = __ballot(f != 0);
-        if (f) {
-            const uint32_t at = pos + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            p.keys[at] = (f << 16) | (lo + i);
-            p.syms[at] = (uint16_t)(lo + i);
+    // (four groups' loads in flight, like the counting pass: one load per step was 47 dependent L2 round trips per wave at C3 —
+    // 51 of the kernel's 174 us)
+    for (uint32_t i0 = b0; i0 < b1; i0 += 4 * WAVE) {
+        uint64_t f4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // (clamped, never conditional: a load under a branch is waited for inside it)
+            const uint32_t i = i0 + k * WAVE + lane;
+            const uint64_t f = hist[lo + (i < b1 ? i : b1 - 1)];
+            f4[k] = i < b1 ? f : 0ull;
         }
-        pos += (uint32_t)__popcll(bal);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = i0 + k * WAVE + lane;
+            const uint64_t f = f4[k];
+            const unsigned long long bal = __ballot(f != 0);
+            if (f) {
+                const uint32_t at = pos + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                p.keys[at] = (f << 16) | (lo + i);
+                p.syms[at] = (uint16_t)(lo + i);
+            }
+            pos += (uint32_t)__popcll(bal);
+        }
     }
     __syncthreads();
     uint64_t total = s_total;
@@ -1937,10 +1973,16 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
         const uint32_t segk = ((m + n_wv - 1) / n_wv + WAVE - 1) / WAVE * WAVE;
         const uint32_t k0 = wv_id * segk < m ? wv_id * segk : m, k1 = k0 + segk < m ? k0 + segk : m;
         uint32_t c2 = 0;
-        for (uint32_t i0 = k0; i0 < k1; i0 += WAVE) {
-            const uint32_t i = i0 + lane;
-            const uint64_t f = i < k1 ? p.keys[i] >> 16 : 0ull;
-            c2 += (uint32_t)__popcll(__ballot(f > rare_max));
+        for (uint32_t i0 = k0; i0 < k1; i0 += 4 * WAVE) {  // (four loads in flight per step, here and below)
+            uint64_t f4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = i0 + k * WAVE + lane;
+                const uint64_t f = p.keys[i < k1 ? i : k1 - 1] >> 16;
+                f4[k] = i < k1 ? f : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) c2 += (uint32_t)__popcll(__ballot(f4[k] > rare_max));
         }
         __syncthreads();  // (s_wt of step 1 no longer read)
         if (lane == 0) s_wt[wv_id] = c2;
@@ -1952,20 +1994,29 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
         }
         uint64_t fs = 0;
         uint32_t rare_sym = 0xFFFFFFFFu;
-        for (uint32_t i0 = k0; i0 < k1; i0 += WAVE) {
-            const uint32_t i = i0 + lane;
-            const uint64_t key = i < k1 ? p.keys[i] : 0ull;
-            const uint64_t f = key >> 16;
-            const bool fr = f > rare_max;
-            const unsigned long long bal = __ballot(fr);
-            if (fr) {
-                p.ifreq[pos2 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = key;
-                fs += f;
-            } else if (f) {
-                const uint32_t sy = (uint32_t)(key & 0xFFFF);
-                rare_sym = sy < rare_sym ? sy : rare_sym;
+        for (uint32_t i0 = k0; i0 < k1; i0 += 4 * WAVE) {
+            uint64_t k4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = i0 + k * WAVE + lane;
+                const uint64_t kk = p.keys[i < k1 ? i : k1 - 1];
+                k4[k] = i < k1 ? kk : 0ull;
             }
-            pos2 += (uint32_t)__popcll(bal);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t key = k4[k];
+                const uint64_t f = key >> 16;
+                const bool fr = f > rare_max;
+                const unsigned long long bal = __ballot(fr);
+                if (fr) {
+                    p.ifreq[pos2 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = key;
+                    fs += f;
+                } else if (f) {
+                    const uint32_t sy = (uint32_t)(key & 0xFFFF);
+                    rare_sym = sy < rare_sym ? sy : rare_sym;
+                }
+                pos2 += (uint32_t)__popcll(bal);
+            }
         }
         fs = wave_sum(fs);
         if (lane == 0 && fs) atomicAdd(&s_fsum, (unsigned long long)fs);
@@ -2047,7 +2098,19 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
     if (s_misc[4]) cb_kraft_repair(pleaf, mk, s_cnt, L, NT, reinterpret_cast<uint64_t *>(pool));
     // 6. lengths to symbol order (through the serialised lens[] table), then canonical codes
     __syncthreads();
-    for (uint32_t q = t; q < mk; q += NT) p.lens[(uint32_t)(p.keys[q] & 0xFFFF)] = (uint8_t)pleaf[q];
+    for (uint32_t qb = t; qb < mk; qb += 4 * NT) {  // (four loads in flight per step, as in the compaction)
+        uint32_t sy4[4];
+        uint16_t l4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t q = qb + k * NT;
+            sy4[k] = (uint32_t)(p.keys[q < mk ? q : mk - 1] & 0xFFFF);
+            l4[k] = pleaf[q < mk ? q : mk - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (qb + k * NT < mk) p.lens[sy4[k]] = (uint8_t)l4[k];
+    }
     __syncthreads();
     if (cls) {  // every rare symbol: the class's code word + a fixed-length index
         const uint32_t len_cls = p.lens[pseudo_sym], len_rare = len_cls + rare_bits;
@@ -2060,9 +2123,16 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
             return;
         }
         __syncthreads();
-        for (uint32_t q = t; q < m; q += NT) {
-            const uint32_t sy = p.syms[q];
-            if (hist[sy] <= rare_max) p.lens[sy] = (uint8_t)len_rare;
+        for (uint32_t qb = t; qb < m; qb += 4 * NT) {
+            uint32_t sy4[4];
+            uint64_t f4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) sy4[k] = (uint32_t)p.syms[qb + k * NT < m ? qb + k * NT : m - 1];
+#pragma unroll
+            for (int k = 0; k < 4; k++) f4[k] = hist[sy4[k]];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (qb + k * NT < m && f4[k] <= rare_max) p.lens[sy4[k]] = (uint8_t)len_rare;
         }
         if (t == 0) {
             s_cnt[len_cls] -= 1;
@@ -2078,7 +2148,17 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
         }
         p.info->ts[6] = wall_clock64();
     }
-    for (uint32_t q = t; q < m; q += NT) aux[q] = p.lens[p.syms[q]];
+    for (uint32_t qb = t; qb < m; qb += 4 * NT) {
+        uint32_t sy4[4];
+        uint8_t l4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) sy4[k] = (uint32_t)p.syms[qb + k * NT < m ? qb + k * NT : m - 1];
+#pragma unroll
+        for (int k = 0; k < 4; k++) l4[k] = p.lens[sy4[k]];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (qb + k * NT < m) aux[qb + k * NT] = l4[k];
+    }
     __syncthreads();
     if (t == 0) p.info->ts[7] = wall_clock64();
     cb_assign_codes(aux, p.syms, m, s_first, reinterpret_cast<uint16_t *>(pool), p.enc, NT);

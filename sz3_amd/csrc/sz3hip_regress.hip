@@ -369,18 +369,21 @@ __global__ __launch_bounds__(256) void k_blk_select(const T *__restrict__ in, sz
         const uint64_t d1 = p.d[1], d2 = p.d[2];
         const bool has_l1 = p.mask & 1u, has_l2 = p.mask & 2u, has_r = p.mask & 4u;
         const bool whole = CB && g.ez == CB && g.ey == CB && g.ex == CB;
+        using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
+        const bool pairs = d2 % 2 == 0 && (reinterpret_cast<uintptr_t>(in) % sizeof(V2)) == 0;
         const T *blk = in + ((uint64_t)g.oz * d1 + g.oy) * d2 + g.ox;
         // (tile coordinates of k_blk_fit: the block's origin is (2, 2, 2), two low halo layers)
         auto rd = [&](uint32_t tz, uint32_t ty, uint32_t tx) -> T {
+            // (no branch around the load or the lattice round trip: a conditional load is waited for where it stands, and the
+            // four sample points of a step have 28 - 104 of them)
             const int64_t z = (int64_t)g.oz + tz - 2, y = (int64_t)g.oy + ty - 2, x = (int64_t)g.ox + tx - 2;
-            T v = 0;
-            if (z >= 0 && y >= 0 && x >= 0) v = in[((uint64_t)z * d1 + (uint64_t)y) * d2 + (uint64_t)x];  // (never beyond the block's high faces)
-            if (tz < 2 || ty < 2 || tx < 2) {
-                bool bad;
-                const Q qh = lat.quant(v, bad);
-                if (!bad) v = lat.dequant(qh);
-            }
-            return v;
+            const bool in_arr = z >= 0 && y >= 0 && x >= 0;  // (never beyond the block's high faces)
+            const T raw = in[((uint64_t)(z < 0 ? 0 : z) * d1 + (uint64_t)(y < 0 ? 0 : y)) * d2 + (uint64_t)(x < 0 ? 0 : x)];
+            const T v = in_arr ? raw : (T)0;
+            bool bad;
+            const Q qh = lat.quant(v, bad);
+            const T vl = bad ? v : lat.dequant(qh);
+            return (tz < 2 || ty < 2 || tx < 2) ? vl : v;
         };
         bool r_valid = has_r && g.ez > 1 && g.ey > 1 && g.ex > 1;
         T cf[4] = {0, 0, 0, 0};
@@ -393,8 +396,18 @@ __global__ __launch_bounds__(256) void k_blk_select(const T *__restrict__ in, sz
                     for (uint32_t i1 = 0; i1 < (uint32_t)CB; i1++) {
                         const T *row = blk + ((uint64_t)i0 * d1 + i1) * d2;
                         T v[CB ? CB : 1];
+                        if (CB % 2 == 0 && pairs) {  // (rows of an even edge start on pair boundaries when the array's rows do: half the loads)
+                            const V2 *r2 = reinterpret_cast<const V2 *>(row);
 #pragma unroll
-                        for (uint32_t i2 = 0; i2 < (uint32_t)CB; i2++) v[i2] = row[i2];
+                            for (uint32_t i2 = 0; i2 < (uint32_t)CB / 2; i2++) {
+                                const V2 w = r2[i2];
+                                v[2 * i2] = w.x;
+                                v[(2 * i2 + 1) % (CB ? CB : 1)] = w.y;
+                            }
+                        } else {
+#pragma unroll
+                            for (uint32_t i2 = 0; i2 < (uint32_t)CB; i2++) v[i2] = row[i2];
+                        }
 #pragma unroll
                         for (uint32_t i2 = 0; i2 < (uint32_t)CB; i2++) {
                             s0 += (double)((T)i0 * v[i2]);  // sum[i] += index[i] * (*c): size_t * T is evaluated in T, accumulated in double
@@ -434,8 +447,8 @@ __global__ __launch_bounds__(256) void k_blk_select(const T *__restrict__ in, sz
 #pragma unroll 1
             for (uint32_t i = 0; i < m; i++) {
                 const uint32_t j = m - 1 - i;
-#pragma unroll 1
-                for (uint32_t kind = 0; kind < 4; kind++) {
+#pragma unroll
+                for (uint32_t kind = 0; kind < 4; kind++) {  // (unrolled: the four points' neighbour loads are in flight together)
                     const uint32_t i0 = i, i1 = (kind & 2) ? j : i, i2 = (kind & 1) ? j : i;
                     const uint32_t tz = i0 + 2, ty = i1 + 2, tx = i2 + 2;
                     const T v = blk[((uint64_t)i0 * d1 + i1) * d2 + i2];

@@ -358,7 +358,7 @@ __device__ __forceinline__ void blk_fit_block(const T *sx, const TileView &tv, c
 // cross-lane sum (the wave-per-block fit spends ~800 wave instructions per block, most of them on both), 64 blocks' rows of
 // B values side by side in memory = whole cache lines per wave. Values outside the block are seen as the decoder will hold
 // them (on the lattice), outside the array as zero, like k_blk_fit's tile loader does it.
-template <typename T, int CB>
+template <typename T, int CB, bool L2>  // L2: the predictor set holds second-order Lorenzo (its 26-point estimate costs the kernel a third of its waves)
 __global__ __launch_bounds__(256) void k_blk_select(const T *__restrict__ in, szk_blk_params p, uint32_t nblocks, unsigned long long *__restrict__ n_other) {
     using Q = typename QTraits<T>::Q;
     const uint32_t task = blockIdx.x * 256 + threadIdx.x;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_blk_select(const T *__restrict__ in, sz
         const BlkGeom g = blk_geom(p, task);
         const Lattice<T> lat(p.lat);
         const uint64_t d1 = p.d[1], d2 = p.d[2];
-        const bool has_l1 = p.mask & 1u, has_l2 = p.mask & 2u, has_r = p.mask & 4u;
+        const bool has_l1 = p.mask & 1u, has_l2 = L2 && (p.mask & 2u), has_r = p.mask & 4u;
         const bool whole = CB && g.ez == CB && g.ey == CB && g.ex == CB;
         using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
         const bool pairs = d2 % 2 == 0 && (reinterpret_cast<uintptr_t>(in) % sizeof(V2)) == 0;
@@ -390,6 +390,9 @@ __global__ __launch_bounds__(256) void k_blk_select(const T *__restrict__ in, sz
         if (r_valid) {
             double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
             if (whole) {
+                // (a plane at a time: 427 us at C4's slab; rows one after the other with the next row's loads in flight, 92 instead
+                // of 115 registers: 466 — what bounds the pass is the L2 traffic of the sample points' neighbour reads below,
+                // 24 cache lines per wave instruction for 8 bytes a lane)
 #pragma unroll 1
                 for (uint32_t i0 = 0; i0 < (uint32_t)CB; i0++) {
 #pragma unroll
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256) void k_blk_select(const T *__restrict__ in, sz
                     const uint32_t tz = i0 + 2, ty = i1 + 2, tx = i2 + 2;
                     const T v = blk[((uint64_t)i0 * d1 + i1) * d2 + i2];
                     if (has_l1) e1 += (double)(T)(fabs((double)(T)(v - lorenzo_pred_orig<T>(rd, tz, ty, tx, 1))) + (T)(1.22 * p.eb));
-                    if (has_l2) e2 += (double)(T)(fabs((double)(T)(v - lorenzo_pred_orig<T>(rd, tz, ty, tx, 2))) + (T)(6.8 * p.eb));
+                    if (L2 && has_l2) e2 += (double)(T)(fabs((double)(T)(v - lorenzo_pred_orig<T>(rd, tz, ty, tx, 2))) + (T)(6.8 * p.eb));
                     if (r_valid) er += (double)(T)fabs((double)(T)(v - reg_predict(cf, i0, i1, i2)));
                 }
             }
@@ -1275,13 +1278,19 @@ int szk_launch_blk_select(int dtype, const void *d_in, const szk_blk_params *p, 
     const uint32_t nblocks = blk_count_blocks(p);
     const dim3 g((nblocks + 255) / 256), b(256);
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(n_other);
+#define BLK_SEL(T, CBV)                                                                                                       \
+    do {                                                                                                                      \
+        if (p->mask & 2u) hipLaunchKernelGGL((k_blk_select<T, CBV, true>), g, b, 0, s, (const T *)d_in, *p, nblocks, cnt);     \
+        else hipLaunchKernelGGL((k_blk_select<T, CBV, false>), g, b, 0, s, (const T *)d_in, *p, nblocks, cnt);                 \
+    } while (0)
     if (dtype == 0) {
-        if (p->B == 6) hipLaunchKernelGGL((k_blk_select<float, 6>), g, b, 0, s, (const float *)d_in, *p, nblocks, cnt);
-        else hipLaunchKernelGGL((k_blk_select<float, 0>), g, b, 0, s, (const float *)d_in, *p, nblocks, cnt);
+        if (p->B == 6) BLK_SEL(float, 6);
+        else BLK_SEL(float, 0);
     } else {
-        if (p->B == 6) hipLaunchKernelGGL((k_blk_select<double, 6>), g, b, 0, s, (const double *)d_in, *p, nblocks, cnt);
-        else hipLaunchKernelGGL((k_blk_select<double, 0>), g, b, 0, s, (const double *)d_in, *p, nblocks, cnt);
+        if (p->B == 6) BLK_SEL(double, 6);
+        else BLK_SEL(double, 0);
     }
+#undef BLK_SEL
     SZK_CHECK_LAUNCH();
     return 0;
 }

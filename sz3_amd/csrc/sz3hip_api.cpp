@@ -209,7 +209,7 @@ static void ctx_free(sz3hip_ctx *c) {
                     c->d_chunk_words, c->d_chunk_off, c->d_carry, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples, c->d_trial_work, c->d_trial_codes,
                     c->d_trial, c->d_passes, c->d_np,  // (d_trial_counters / d_trial_hist live inside d_trial's block)
                     c->d_blk_sel, c->d_blk_coef, c->d_blk_rank, c->d_blk_comp, c->d_blk_side, c->d_blk_counters,
-                    c->bk[1].enc, c->bk[1].lens, c->bk[1].info, c->d_seg_bits};
+                    c->bk[1].enc, c->bk[1].lens, c->bk[1].info, c->d_seg_bits, c->d_half32};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->side) {
@@ -1550,21 +1550,26 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     dp.half = 0;
     dp.ovf = nullptr;
     dp.gate = nullptr;
-    // Half-width intermediates: the x-scanned lattice differences of a smooth f32 field fit int16, and the strided scans that
+    // Half-width intermediates: the x-scanned lattice differences of a smooth f32 field fit int16 (f64: int32), and the strided scans that
     // follow then move half the bytes (the code array, idle in the fused mode, holds them). The decoder and the scans raise a
     // flag on a value that does not fit; the full-width chain is enqueued right behind with that flag as its gate (its kernels
     // return at once while it is clear), so the call stays asynchronous and correct either way.
     const bool half = fuse_x && szk_half_scans_ok(&h) && ctx->half_skip == 0 && !(szk_dbg_flags & 2097152);
     ctx->last_half = half ? 1u : 0u;
     ctx->last_carry = dp.carry ? (dp.carry_pass ? 1u : 2u) : 0u;
+    void *d_half = ctx->d_codes;  // f32 data: int16 values in the code array (2 bytes per element, idle in the fused mode)
+    if (half && ctx->dtype != SZ3HIP_FLOAT) {  // f64 data: int32 values, an array of their own (allocated with the first such call)
+        if (!ctx->d_half32) HIPCHK(hipMalloc(&ctx->d_half32, ctx->max_n * 4));
+        d_half = ctx->d_half32;
+    }
     if (half) {
         dp.half = 1;
         dp.ovf = ovf;
-        dp.q_out = ctx->d_codes;
+        dp.q_out = d_half;
     }
     rc = szk_launch_decode(pl, &dp, ctx->d_codes, ctx->d_chunk_off, ctx->d_counters + 3, s);
     if (!rc && half) {
-        rc = szk_launch_reconstruct_half(pl, &h, &o, reinterpret_cast<int16_t *>(ctx->d_codes), d_out, ovf, s, (const int32_t *)carry_in_scan);
+        rc = szk_launch_reconstruct_half(pl, &h, &o, d_half, d_out, ovf, s, carry_in_scan);
         dp.half = 0;
         dp.ovf = nullptr;
         dp.gate = ovf;

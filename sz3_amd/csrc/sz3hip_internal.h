@@ -94,6 +94,7 @@ struct sz3hip_ctx {
     uint8_t *d_blk_side;    // szk_blk_side_bound(blk_cap) bytes
     uint64_t *d_blk_counters;  // [8]
     uint8_t *h_blk_side_hdr;   // pinned, 32 bytes
+    void *d_half32;            // f64 decoder: int32 intermediates of the half-width chain (max_n * 4 bytes, lazily)
     uint64_t blk_others;       // the last selection pass: blocks that would not be coded by first-order Lorenzo
     uint64_t *d_vout_idx, *d_dout_idx;
     void *d_vout_val, *d_dout_val;

@@ -303,10 +303,10 @@ int szk_launch_reconstruct(int x_done, const uint8_t *payload, const szh_header 
                            void *d_out, void *d_segtot, hipStream_t s, const uint32_t *gate = nullptr,
                            const void *carry = nullptr /* the decoder's unit carries, to be added by the first strided pass (RowCarry) */);
 // the strided scans of a Lorenzo stream whose decoder left int16 x-scanned values in d_half (see szk_dec_params::half);
-// szk_half_scans_ok says whether the shape qualifies (f32, even x extent, enough lines for one thread pair per line)
+// szk_half_scans_ok says whether the shape qualifies (even x extent, enough lines for one thread pair per line)
 int szk_half_scans_ok(const szh_header *h);
-int szk_launch_reconstruct_half(const uint8_t *payload, const szh_header *h, const szh_offsets *o, int16_t *d_half, void *d_out, uint32_t *ovf,
-                                hipStream_t s, const int32_t *carry = nullptr);
+int szk_launch_reconstruct_half(const uint8_t *payload, const szh_header *h, const szh_offsets *o, void *d_half /* int16 (f32 data) / int32 (f64) */,
+                                void *d_out, uint32_t *ovf, hipStream_t s, const void *carry = nullptr /* int32 / int64 unit carries */);
 void szk_host_offsets(const szh_header *h, szh_offsets *o);
 extern int szk_force_generic;
 extern int szk_dbg_flags;

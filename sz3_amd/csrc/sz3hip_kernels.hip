@@ -3374,9 +3374,10 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
             for (uint32_t i = 0; i < nsym; i++) {
                 const QO d = sym ? (QO)((int)sym - (int)p.radius) : dec_dout<QO>(p, s0 + i);
                 acc += d;
-                if (HALF) {  // (the half-width chain's buffer holds int16: a stream whose every element is a listed delta has values to match)
-                    reinterpret_cast<int16_t *>(p.q_out)[s0 + i] = (int16_t)acc;
-                    ovf_seen |= (QO)(int16_t)acc != acc;
+                if (HALF) {  // (the half-width chain's buffer holds int16 / int32: a stream whose every element is a listed delta has values to match)
+                    using HS = typename std::conditional<QB == 8, int32_t, int16_t>::type;
+                    reinterpret_cast<HS *>(p.q_out)[s0 + i] = (HS)acc;
+                    ovf_seen |= (QO)(HS)acc != acc;
                 } else {
                     qout[i] = acc;
                 }
@@ -3504,6 +3505,26 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
 #pragma unroll
                 for (int k = 0; k < 16; k++) sx += qv[k];
                 if (sx == (QO)0x7FFFFFF1) qout[i0] = sx;
+            } else if (HALF && QB == 8) {
+                // f64 data, int32 out: 64 bytes per lane and round; a value that does not fit raises the flag (the full-width chain follows)
+                uint32_t w32[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int64_t a = (int64_t)qv[k];
+                    ovf_seen |= (uint32_t)(a != (int64_t)(int32_t)a);
+                    w32[k] = (uint32_t)a;
+                }
+                if (coop) {
+                    uint4 pc[NP];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pc[k % (int)NP] = make_uint4(w32[4 * k], w32[4 * k + 1], w32[4 * k + 2], w32[4 * k + 3]);
+                    coop_store(pc, rnd);
+                } else {
+                    int32_t *ho = reinterpret_cast<int32_t *>(p.q_out) + s0;
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        if (i0 + k < nsym) ho[i0 + k] = (int32_t)w32[k];
+                }
             } else if (HALF) {
                 // int16 out: 32 bytes per lane and round; a value that does not fit raises the flag (the full-width chain follows)
                 uint32_t hw[8];
@@ -3605,15 +3626,16 @@ __global__ __launch_bounds__(256) void k_scan_carry(QO *__restrict__ q, const QO
     for (uint32_t i = lane_id(); i < seg; i += WAVE) q[s0 + i] += cin;
 }
 // the same on the half-width chain's int16 values (the carries stay 32 bits wide); a sum that does not fit raises the flag
-__global__ __launch_bounds__(256) void k_scan_carry_half(int16_t *__restrict__ q, const int32_t *__restrict__ carry, uint64_t n, uint32_t L, uint32_t *ovf) {
+template <typename HS, typename QC>  // int16 values / int32 carries (f32 data), int32 / int64 (f64 data)
+__global__ __launch_bounds__(256) void k_scan_carry_half(HS *__restrict__ q, const QC *__restrict__ carry, uint64_t n, uint32_t L, uint32_t *ovf) {
     uint64_t s0, seg;
-    int32_t cin;
+    QC cin;
     if (!unit_carry_in(carry, n, (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE, L, s0, seg, cin)) return;
     bool bad = false;
     for (uint32_t i = lane_id(); i < seg; i += WAVE) {
-        const int32_t v = (int32_t)q[s0 + i] + cin;
-        bad |= v != (int32_t)(int16_t)v;
-        q[s0 + i] = (int16_t)v;
+        const QC v = (QC)q[s0 + i] + cin;
+        bad |= v != (QC)(HS)v;
+        q[s0 + i] = (HS)v;
     }
     if (__ballot(bad) && lane_id() == 0) atomicOr(ovf, 1u);
 }
@@ -3891,6 +3913,52 @@ __global__ __launch_bounds__(256) void k_scan_strided_half(const int16_t *__rest
         }
     }
     if (!DEQ && __ballot(bad != 0) && lane_id() == 0) atomicOr(ovf, 1u);
+}
+// the same for f64 data: int32 storage, sums in int64, double out (a thread per pair of adjacent lines: one 8-byte word)
+template <bool DEQ, bool CARRY>
+__global__ __launch_bounds__(256) void k_scan_strided_half64(const int32_t *__restrict__ in, void *__restrict__ outp, uint64_t L, uint64_t inner,
+                                                             uint64_t nlines, szk_lattice l, uint32_t *ovf, const int64_t *__restrict__ carry, uint32_t row) {
+    const Lattice<double> lat(l);
+    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index
+    if (id * 2 >= nlines) return;
+    const uint64_t line = id * 2, outer = line / inner, inn = line % inner;
+    const uint64_t base = outer * L * inner + inn;
+    const RowCarry rc(CARRY, base, inner, row);
+    const bool carried = CARRY && rc.j != 0;
+    const uint2 *pin = reinterpret_cast<const uint2 *>(in + base);  // (inner is even: a pair is one aligned 8-byte word)
+    const uint64_t step = inner / 2;
+    int64_t r0 = 0, r1 = 0;
+    uint32_t bad = 0;
+    constexpr int DEPTH = 16;
+    for (uint64_t a = 0; a < L; a += DEPTH) {
+        uint2 w[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) w[k] = pin[(a + k < L ? a + k : L - 1) * step];
+        int64_t cw[CARRY ? DEPTH : 1];
+        if (CARRY && carried) {
+#pragma unroll
+            for (int k = 0; k < DEPTH; k++) cw[k] = a + k < L ? rc.at(carry, a + k) : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) {
+            if (a + k >= L) break;
+            const int64_t c = (CARRY && carried) ? cw[CARRY ? k : 0] : 0;
+            r0 += (int64_t)(int32_t)w[k].x + c;
+            r1 += (int64_t)(int32_t)w[k].y + c;
+            if (DEQ) {
+                const double2 v = make_double2(lat.dequant(r0), lat.dequant(r1));
+                *reinterpret_cast<double2 *>(reinterpret_cast<double *>(outp) + base + (a + k) * inner) = v;
+            } else {
+                bad |= (uint32_t)(r0 != (int64_t)(int32_t)r0) | (uint32_t)(r1 != (int64_t)(int32_t)r1);
+                reinterpret_cast<uint2 *>(reinterpret_cast<int32_t *>(outp) + base)[(a + k) * step] = make_uint2((uint32_t)r0, (uint32_t)r1);
+            }
+        }
+    }
+    if (!DEQ && __ballot(bad != 0) && lane_id() == 0) atomicOr(ovf, 1u);
+}
+__global__ __launch_bounds__(256) void k_dequant_half64(const int32_t *__restrict__ in, double *__restrict__ out, uint64_t n, szk_lattice l) {
+    const Lattice<double> lat(l);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = lat.dequant((int64_t)in[i]);
 }
 __global__ __launch_bounds__(256) void k_dequant_half(const int16_t *__restrict__ in, float *__restrict__ out, uint64_t n, szk_lattice l) {
     const Lattice<float> lat(l);
@@ -4274,16 +4342,21 @@ int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t 
     const uint64_t nb = (n_units + 255) / 256;
     if (nb > 0x7FFFFFFFull) return -1;
     if (!p->scan_row) hipLaunchKernelGGL((k_decode<0>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
+    else if (p->q_bytes == 8 && p->half) hipLaunchKernelGGL((k_decode<8, true>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
     else if (p->q_bytes == 8) hipLaunchKernelGGL((k_decode<8>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
     else if (p->half) hipLaunchKernelGGL((k_decode<4, true>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
     else hipLaunchKernelGGL((k_decode<4>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
     if (p->scan_row && p->carry && p->carry_pass) {
         const uint64_t cb = (n_units + 3) / 4;
-        if (p->q_bytes == 8)
+        if (p->q_bytes == 8 && p->half)
+            hipLaunchKernelGGL((k_scan_carry_half<int32_t, int64_t>), dim3((uint32_t)cb), dim3(256), 0, s, (int32_t *)p->q_out, (const int64_t *)p->carry, p->n,
+                               p->scan_row, p->ovf);
+        else if (p->q_bytes == 8)
             hipLaunchKernelGGL(k_scan_carry<int64_t>, dim3((uint32_t)cb), dim3(256), 0, s, (int64_t *)p->q_out, (const int64_t *)p->carry, p->n, p->scan_row,
                                p->gate);
         else if (p->half)
-            hipLaunchKernelGGL(k_scan_carry_half, dim3((uint32_t)cb), dim3(256), 0, s, (int16_t *)p->q_out, (const int32_t *)p->carry, p->n, p->scan_row, p->ovf);
+            hipLaunchKernelGGL((k_scan_carry_half<int16_t, int32_t>), dim3((uint32_t)cb), dim3(256), 0, s, (int16_t *)p->q_out, (const int32_t *)p->carry, p->n,
+                               p->scan_row, p->ovf);
         else
             hipLaunchKernelGGL(k_scan_carry<int32_t>, dim3((uint32_t)cb), dim3(256), 0, s, (int32_t *)p->q_out, (const int32_t *)p->carry, p->n, p->scan_row,
                                p->gate);
@@ -4396,14 +4469,42 @@ int szk_launch_reconstruct(int x_done, const uint8_t *payload, const szh_header 
 }
 // the shape gives every strided axis enough lines for one thread per line pair (no segment totals) and an even x extent
 int szk_half_scans_ok(const szh_header *h) {
-    if (h->dtype != 0 || h->dims[3] % 2) return 0;
+    if (h->dims[3] % 2) return 0;
     for (int ax = 2; ax >= 0; ax--)
         if (h->dims[ax] > 1 && h->n / h->dims[ax] < 32768) return 0;
     return 1;
 }
-int szk_launch_reconstruct_half(const uint8_t *payload, const szh_header *h, const szh_offsets *o, int16_t *d_half, void *d_out, uint32_t *ovf,
-                                hipStream_t s, const int32_t *carry) {
+int szk_launch_reconstruct_half(const uint8_t *payload, const szh_header *h, const szh_offsets *o, void *d_half_v, void *d_out, uint32_t *ovf,
+                                hipStream_t s, const void *carry_v) {
     const uint64_t n = h->n;
+    if (h->dtype != 0) {  // f64 data: int32 storage
+        int32_t *d_half = reinterpret_cast<int32_t *>(d_half_v);
+        const int64_t *carry = reinterpret_cast<const int64_t *>(carry_v);
+        int last_ax = -1;
+        for (int ax = 2; ax >= 0; ax--)
+            if (h->dims[ax] > 1) last_ax = ax;
+        uint64_t inner = h->dims[3];
+        const szk_lattice lat = szk_make_lattice(h->eb);
+        for (int ax = 2; ax >= 0; ax--) {
+            const uint64_t La = h->dims[ax];
+            if (La > 1) {
+                const uint64_t npairs = n / La / 2;
+                const dim3 g(grid_for(npairs, 256, 0x7FFFFFFF));
+                const uint32_t row = (uint32_t)h->dims[3];
+                if (ax == last_ax && carry) hipLaunchKernelGGL((k_scan_strided_half64<true, true>), g, dim3(256), 0, s, d_half, d_out, La, inner, n / La, lat, ovf, carry, row);
+                else if (ax == last_ax) hipLaunchKernelGGL((k_scan_strided_half64<true, false>), g, dim3(256), 0, s, d_half, d_out, La, inner, n / La, lat, ovf, carry, row);
+                else if (carry) hipLaunchKernelGGL((k_scan_strided_half64<false, true>), g, dim3(256), 0, s, d_half, (void *)d_half, La, inner, n / La, lat, ovf, carry, row);
+                else hipLaunchKernelGGL((k_scan_strided_half64<false, false>), g, dim3(256), 0, s, d_half, (void *)d_half, La, inner, n / La, lat, ovf, carry, row);
+                carry = nullptr;
+            }
+            inner *= La;
+        }
+        if (last_ax < 0) hipLaunchKernelGGL(k_dequant_half64, dim3(grid_for(n, 256, 65536)), dim3(256), 0, s, d_half, (double *)d_out, n, lat);
+        SZK_CHECK_LAUNCH();
+        return 0;
+    }
+    int16_t *d_half = reinterpret_cast<int16_t *>(d_half_v);
+    const int32_t *carry = reinterpret_cast<const int32_t *>(carry_v);
     int last_ax = -1;
     for (int ax = 2; ax >= 0; ax--)
         if (h->dims[ax] > 1) last_ax = ax;

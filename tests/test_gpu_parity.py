@@ -405,8 +405,9 @@ def test_c1_through_the_cli_boundary(tmp_path):
 
 @pytest.mark.parametrize("shape,carry", [((96, 384, 512), 0), ((80, 520, 500), 1), ((48, 130, 768), 1), ((40, 36, 1024), 2), ((160, 200, 256), 0)],
                          ids=["rows-512", "rows-500-carry-pass", "rows-768-carry-pass", "rows-1024-carried-in-scan", "rows-256"])
-def test_half_width_decoder_intermediates_and_their_overflow_path(shape, carry):
-    """The Lorenzo decoder keeps its x-scanned values and the y-prefixed ones as int16 when they fit (smooth f32 fields) and
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32-int16", "f64-int32"])
+def test_half_width_decoder_intermediates_and_their_overflow_path(shape, carry, dtype):
+    """The Lorenzo decoder keeps its x-scanned values and the y-prefixed ones as int16 (f64 data: int32) when they fit (smooth fields) and
     repeats the chain at full width behind a device-side gate when one does not. A step of 2000 between two planes makes
     D_z q = 10^6 lattice steps: the first call overflows and takes the gated chain, the following ones go to full width
     directly (the context fetched the flag with the next header); a smooth field stays on the half-width chain. All exact
@@ -416,15 +417,15 @@ def test_half_width_decoder_intermediates_and_their_overflow_path(shape, carry):
     import ctypes as C
     dev = torch.device("cuda:0")
     eb = 1e-3
-    smooth = field3d(shape)
+    smooth = field3d(shape, dtype)
     step = smooth.copy()
-    step[shape[0] // 2:] += 2000.0
+    step[shape[0] // 2:] += 2000.0 if dtype == np.float32 else 5e6  # (f64: int32 intermediates, D_z q = 2.5e9 lattice steps)
     info = (C.c_uint32 * 4)()
     L = sz3_amd.lib()
     L.sz3hip_debug_decode_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     for a, overflows in ((smooth, False), (step, True)):
         t = torch.from_numpy(a).to(dev)
-        dc = sz3_amd.DeviceCompressor(a.size, np.float32)
+        dc = sz3_amd.DeviceCompressor(a.size, dtype)
         cap = dc.payload_bound(a.size, worst_case=True)
         pl = torch.empty(cap, dtype=torch.uint8, device=dev)
         conf = sz3_amd.Config(*shape)

@@ -209,7 +209,7 @@ static void ctx_free(sz3hip_ctx *c) {
                     c->d_chunk_words, c->d_chunk_off, c->d_carry, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples, c->d_trial_work, c->d_trial_codes,
                     c->d_trial, c->d_passes, c->d_np,  // (d_trial_counters / d_trial_hist live inside d_trial's block)
                     c->d_blk_sel, c->d_blk_coef, c->d_blk_rank, c->d_blk_comp, c->d_blk_side, c->d_blk_counters,
-                    c->bk[1].enc, c->bk[1].lens, c->bk[1].info, c->d_seg_bits, c->d_half32};
+                    c->bk[1].enc, c->bk[1].lens, c->bk[1].info, c->d_seg_bits, c->d_half32, c->d_sub_bits};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->side) {
@@ -298,6 +298,7 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     c->bk[0].info = c->d_info;
     c->book_idx = c->book_pending = -1;
     alloc((void **)&c->d_chunk_words, (c->max_chunks + 8) * 2);
+    alloc((void **)&c->d_sub_bits, (c->max_chunks + 8) * 2 * (SZH_SUBS - 1));
     alloc((void **)&c->d_chunk_off, (c->max_chunks + 8) * 8);
     alloc((void **)&c->d_state, sizeof(szk_state));
     alloc((void **)&c->d_tables, sizeof(szk_dec_tables));
@@ -580,24 +581,32 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
 
 // ---- stage 1, block-composed predictor: Lorenzo-1 / Lorenzo-2 / regression chosen per block
 // (make_compressor_lorenzo_regression, api/impl/SZAlgoLorenzoReg.hpp:22-64) ----
-static int blk_reserve_counters(sz3hip_ctx *ctx) {  // (all the selection pass needs)
+static int blk_reserve_select(sz3hip_ctx *ctx, uint64_t nblocks) {  // (all the selection pass needs: counters, choices, coefficients)
     if (!ctx->d_blk_counters) HIPCHK(hipMalloc((void **)&ctx->d_blk_counters, 64 + 4 * (0x7FFFFFF0ull / 8192 + 2)));
     if (!ctx->h_blk_side_hdr) HIPCHK(hipHostMalloc((void **)&ctx->h_blk_side_hdr, 32));
+    if (ctx->blk_sel_cap >= nblocks) return 0;
+    void **arr[2] = {(void **)&ctx->d_blk_sel, (void **)&ctx->d_blk_coef};
+    for (void **a : arr) {
+        if (*a) (void)hipFree(*a);
+        *a = nullptr;
+    }
+    ctx->blk_sel_cap = 0;
+    HIPCHK(hipMalloc((void **)&ctx->d_blk_sel, nblocks));
+    HIPCHK(hipMalloc((void **)&ctx->d_blk_coef, nblocks * 32));
+    ctx->blk_sel_cap = nblocks;
     return 0;
 }
 static int blk_reserve(sz3hip_ctx *ctx, uint64_t nblocks) {
     if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
-    int rcc = blk_reserve_counters(ctx);
+    int rcc = blk_reserve_select(ctx, nblocks);
     if (rcc) return rcc;
     if (ctx->blk_cap >= nblocks) return 0;
-    void **arr[5] = {(void **)&ctx->d_blk_sel, (void **)&ctx->d_blk_coef, (void **)&ctx->d_blk_rank, (void **)&ctx->d_blk_comp, (void **)&ctx->d_blk_side};
+    void **arr[3] = {(void **)&ctx->d_blk_rank, (void **)&ctx->d_blk_comp, (void **)&ctx->d_blk_side};
     for (void **a : arr) {
         if (*a) (void)hipFree(*a);
         *a = nullptr;
     }
     ctx->blk_cap = 0;
-    HIPCHK(hipMalloc((void **)&ctx->d_blk_sel, nblocks));
-    HIPCHK(hipMalloc((void **)&ctx->d_blk_coef, nblocks * 32));
     HIPCHK(hipMalloc((void **)&ctx->d_blk_rank, nblocks * 4));
     HIPCHK(hipMalloc((void **)&ctx->d_blk_comp, nblocks * 4));
     HIPCHK(hipMalloc((void **)&ctx->d_blk_side, szk_blk_side_bound(nblocks)));
@@ -644,12 +653,13 @@ static bool blk_shape_ok(const sz3hip_config *conf) { return conf->N == 3 && con
 #define BLK_EXIT_SHIFT 12
 static int blk_all_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint32_t mask, hipStream_t s, bool *all) {
     *all = false;
-    if (!(mask & 1u) || (szk_dbg_flags & 1073741824)) return 0;
+    ctx->blk_sel_given = false;
+    if (szk_dbg_flags & 2147483648u) return 0;  // (development: no selection pass, the fit pass chooses by its own wave sums)
     const uint32_t B = (uint32_t)conf->blockSize;
     uint64_t nblocks = 1;
     for (int i = 0; i < 3; i++) nblocks *= (conf->dims[i] + B - 1) / B;
     if (nblocks > 0x7FFFFFF0ull) return 0;
-    int rc = blk_reserve_counters(ctx);
+    int rc = blk_reserve_select(ctx, nblocks);
     if (rc) return rc;
     szk_blk_params bp;
     szk_blk_scratch sc;
@@ -664,7 +674,8 @@ static int blk_all_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const voi
     uint64_t others;
     memcpy(&others, ctx->h_blk_side_hdr, 8);
     ctx->blk_others = others;
-    *all = (others << BLK_EXIT_SHIFT) < nblocks;
+    ctx->blk_sel_given = true;  // (the choices and coefficients are in d_blk_sel / d_blk_coef: the fit pass codes what they say)
+    *all = (mask & 1u) && !(szk_dbg_flags & 1073741824) && (others << BLK_EXIT_SHIFT) < nblocks;
     return 0;
 }
 static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint64_t num, uint32_t mask, hipStream_t s) {
@@ -677,6 +688,7 @@ static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
     szk_blk_params bp;
     szk_blk_scratch sc;
     blk_params_from(ctx, conf->dims, B, mask, eb, radius, ctx->cur_out_cap, bp, sc);
+    bp.sel_given = ctx->blk_sel_given ? 1u : 0u;
     sc.wide_hist = ctx->blk_wide;
     HIPCHK(hipMemsetAsync(ctx->d_blk_counters, 0, 64, s));
     prof_begin(ctx, ST_K1, s);
@@ -1225,6 +1237,7 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     ap.total_words = ctx->d_counters + 2;
     ap.lens = ctx->bk[used].lens;
     ap.chunk_words = ctx->d_chunk_words;
+    ap.sub_bits = ctx->d_sub_bits;
     ap.vout_idx = ctx->d_vout_idx;
     ap.dout_idx = ctx->d_dout_idx;
     ap.vout_val = ctx->d_vout_val;

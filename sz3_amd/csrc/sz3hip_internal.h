@@ -95,6 +95,8 @@ struct sz3hip_ctx {
     uint64_t *d_blk_counters;  // [8]
     uint8_t *h_blk_side_hdr;   // pinned, 32 bytes
     void *d_half32;            // f64 decoder: int32 intermediates of the half-width chain (max_n * 4 bytes, lazily)
+    uint64_t blk_sel_cap;      // blocks d_blk_sel / d_blk_coef hold
+    bool blk_sel_given;        // the selection pass of this call wrote them
     uint64_t blk_others;       // the last selection pass: blocks that would not be coded by first-order Lorenzo
     uint64_t *d_vout_idx, *d_dout_idx;
     void *d_vout_val, *d_dout_val;
@@ -105,6 +107,7 @@ struct sz3hip_ctx {
     uint32_t *d_range;
     szk_cb_info *d_info;
     uint16_t *d_chunk_words;
+    uint16_t *d_sub_bits;      // the units' bit offsets inside their chunks (payload section subbits)
     uint64_t *d_chunk_off;
     bool spec_valid;               // spec_conf holds the previous call's tuner outcome (ALGO_INTERP_LORENZO, interpolation chosen)
     sz3hip_config spec_conf, spec_used;

@@ -131,6 +131,7 @@ struct szk_asm_params {
     const uint64_t *total_words;
     const uint8_t *lens;
     const uint16_t *chunk_words;
+    uint16_t *sub_bits;  // [n_chunks * (SZH_SUBS - 1)] the units' bit offsets: written by the bits pass / k_seg_chunks, copied into the payload by the assembly
     const uint64_t *vout_idx, *dout_idx;
     const void *vout_val, *dout_val;
     const uint8_t *side;  // predictor 2: the side section as the block kernels left it (else nullptr)
@@ -206,6 +207,7 @@ struct szk_blk_params {
     int64_t *coef;   // [blocks][4] coefficient lattice values of the regression blocks
     void *qwork;     // [n] lattice values q~ (int32 / int64) the Lorenzo stencils run on
     uint64_t *n_reg; // number of regression blocks (counted by the fit pass; the rank pass writes the same number)
+    uint32_t sel_given;  // sel[] / coef[] were written by k_blk_select: k_blk_fit codes what they say instead of fitting again
 };
 struct szk_blk_scratch {
     uint32_t *rank, *comp;  // [blocks] rank among the regression blocks, compacted list of their ids

@@ -258,7 +258,15 @@ __device__ __forceinline__ int64_t dpp_shr1(int64_t old, int64_t src) {
 template <typename T> struct Quad;
 template <> struct Quad<float> {
     float4 a;
+#ifdef LAB_NT_LOAD  // (lab: streaming loads)
+    __device__ __forceinline__ void load(const float *p) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
+        a = make_float4(v.x, v.y, v.z, v.w);
+    }
+#else
     __device__ __forceinline__ void load(const float *p) { a = *reinterpret_cast<const float4 *>(p); }
+#endif
     __device__ __forceinline__ float get(int i) const { return i == 0 ? a.x : i == 1 ? a.y : i == 2 ? a.z : a.w; }
 };
 template <> struct Quad<double> {
@@ -1148,7 +1156,11 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
                 if (!(c.p->dbg & 2u))
 #endif
                 // (streaming store: the codes are next read by another launch; what stays dirty in the L2s is written back at the kernel's end)
+#ifdef LAB_PLAIN_STORE
+                *reinterpret_cast<uint32_t *>(c.codes8 + grow + x) = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
+#else
                 __builtin_nontemporal_store(t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24), reinterpret_cast<uint32_t *>(c.codes8 + grow + x));
+#endif
             }
             if (c.s_len) {
                 uint32_t b4 = (uint32_t)c.s_len[t[0]] + c.s_len[t[1]] + c.s_len[t[2]] + c.s_len[t[3]];
@@ -2593,7 +2605,7 @@ __device__ __forceinline__ void unpack_codes(const CodeRegs &r, bool narrow, uin
 __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict__ codes, uint64_t n,
                                                      const uint32_t *__restrict__ g_enc,
                                                      const szk_cb_info *__restrict__ info, szk_mode mode, uint32_t sym_add,
-                                                     uint16_t *__restrict__ chunk_words) {
+                                                     uint16_t *__restrict__ chunk_words, uint16_t *__restrict__ sub_bits) {
     // code lengths only: one byte per symbol, so the LDS table covers 16384 symbols around the most frequent one (the
     // packers' 4-byte entries cover 4096): C4's deltas (std 2600 lattice steps) miss a 4096-symbol window 44 % of the time
     constexpr uint32_t LEN_WIN = 4 * ENC_WIN;
@@ -2618,6 +2630,21 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
         const uint32_t rel = sym - lw_lo;
         return rel < LEN_WIN ? (uint32_t)s_lenw[rel] : (g_enc[sym] & 31u);
     };
+    // a chunk's word count and the bit offsets of its later units (the decoder's restart points, sz3hip_format.h: subbits): the
+    // running sum over the lanes, read at the units' last lanes
+    auto emit = [&](uint64_t ch, uint32_t bits) {
+        const uint32_t incl = wave_incl_scan(bits);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+        uint32_t sub[SZH_SUBS - 1];
+#pragma unroll
+        for (uint32_t u = 1; u < SZH_SUBS; u++) sub[u - 1] = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(u * (WAVE / SZH_SUBS) - 1));
+        if (lane_id() == 0) {
+            chunk_words[ch] = (uint16_t)((tot + 31) >> 5);
+            if (sub_bits)
+#pragma unroll
+                for (uint32_t u = 1; u < SZH_SUBS; u++) sub_bits[ch * (SZH_SUBS - 1) + u - 1] = (uint16_t)sub[u - 1];
+        }
+    };
     if (narrow) {
         for (; chunk < n_full; chunk += nwaves) {
             const uint64_t nc = chunk + nwaves;
@@ -2627,8 +2654,7 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 bits += (uint32_t)s_len8[wds[k] & 0xFFu] + s_len8[(wds[k] >> 8) & 0xFFu] + s_len8[(wds[k] >> 16) & 0xFFu] + s_len8[wds[k] >> 24];
-            bits = wave_sum(bits);
-            if (lane_id() == 0) chunk_words[chunk] = (uint16_t)((bits + 31) >> 5);
+            emit(chunk, bits);
             cur = nxt;
         }
     } else {
@@ -2640,8 +2666,7 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
             uint32_t bits = 0;
 #pragma unroll
             for (int i = 0; i < ENC_PER_LANE; i++) bits += len_of(c[i]);
-            bits = wave_sum(bits);
-            if (lane_id() == 0) chunk_words[chunk] = (uint16_t)((bits + 31) >> 5);
+            emit(chunk, bits);
             cur = nxt;
         }
     }
@@ -2655,8 +2680,7 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
             const uint32_t e = len_of(c[i]);
             bits += (base + i < n) ? e : 0u;
         }
-        bits = wave_sum(bits);
-        if (lane_id() == 0) chunk_words[n_full] = (uint16_t)((bits + 31) >> 5);
+        emit(n_full, bits);
     }
 }
 
@@ -2724,7 +2748,8 @@ __device__ void scan_groups_body(uint16_t *__restrict__ chunk_words, uint64_t n_
 // group of 32 chunks, summed by a DPP reduction over the row of 16 lanes. *seg_made == 0 (stage 1 ran another form than the
 // host assumed): all counts are zero — the packer's output is thrown away anyway, it only must stay inside the payload.
 __global__ __launch_bounds__(256) void k_seg_chunks(const uint16_t *__restrict__ seg_bits, uint64_t n_segs, const uint32_t *seg_made,
-                                                    uint16_t *__restrict__ chunk_words, uint64_t n_chunks, uint32_t *__restrict__ group_sums) {
+                                                    uint16_t *__restrict__ chunk_words, uint64_t n_chunks, uint32_t *__restrict__ group_sums,
+                                                    uint16_t *__restrict__ sub_bits) {
     const bool seg_ok = *seg_made != 0;
     const uint64_t n_vec = (n_segs + 7) / 8;
     const uint64_t n_vec16 = (n_vec + 15) / 16 * 16;  // whole groups
@@ -2738,6 +2763,19 @@ __global__ __launch_bounds__(256) void k_seg_chunks(const uint16_t *__restrict__
         const uint64_t c = vi * 2;
         if (c + 1 < n_chunks) reinterpret_cast<uint32_t *>(chunk_words)[vi] = cw0 | (cw1 << 16);
         else if (c < n_chunks) chunk_words[c] = (uint16_t)cw0;
+        if (sub_bits) {  // the units' bit offsets inside their chunks: running sums of the chunk's segments (a unit = 4 / SZH_SUBS segments)
+            constexpr uint32_t SPU = 4 / SZH_SUBS;
+#pragma unroll
+            for (uint32_t h = 0; h < 2; h++) {
+                uint32_t run = 0;
+#pragma unroll
+                for (uint32_t u = 1; u < SZH_SUBS; u++) {
+#pragma unroll
+                    for (uint32_t q = 0; q < SPU; q++) run += hw[4 * h + (u - 1) * SPU + q];
+                    if (c + h < n_chunks) sub_bits[(c + h) * (SZH_SUBS - 1) + u - 1] = (uint16_t)run;
+                }
+            }
+        }
         uint32_t gs = (c < n_chunks ? cw0 : 0u) + (c + 1 < n_chunks ? cw1 : 0u);
         gs += dpp_mov0<0x111, 0xf>(gs);  // inclusive sum along the row of 16 lanes: its last lane holds the group's total
         gs += dpp_mov0<0x112, 0xf>(gs);
@@ -2776,8 +2814,7 @@ __global__ __launch_bounds__(1024) void k_scan_groups(uint16_t *__restrict__ chu
 template <int G, bool BYTE = false, uint32_t WIN = ENC_WIN>  // BYTE: c[] are one-byte codes; s_enc[0..255] = code word, s_len8 = its length, by byte value
 __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE], uint64_t base, uint64_t n, bool check_n,
                                                const uint32_t *s_enc, const uint32_t *__restrict__ g_enc,
-                                               uint32_t sym_min, bool all_lds, uint32_t *stage, uint16_t *sub_out,
-                                               const uint8_t *s_len8 = nullptr) {
+                                               uint32_t sym_min, bool all_lds, uint32_t *stage, const uint8_t *s_len8 = nullptr) {
     constexpr int NG = ENC_PER_LANE / G;
     uint64_t g[NG];
     uint32_t gl[NG];
@@ -2819,9 +2856,6 @@ __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE]
     const uint32_t incl = wave_incl_scan(bits);
     const uint32_t total_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
     uint32_t pos = incl - bits;
-    // the decoder's restart points: bit offsets of the units' first symbols = of lanes 64 / SZH_SUBS, ... (sz3hip_format.h: subbits)
-    constexpr int UL = WAVE / SZH_SUBS;  // lanes per unit
-    if ((lane_id() % UL) == 0 && lane_id() != 0) sub_out[lane_id() / UL - 1] = (uint16_t)pos;
     if (BYTE && G == 4) {
         // one-byte codes: a lane's sixteen symbols are ~66 bits on a smooth field — two registers of eight symbols instead of four
         // of four halve the emission work whenever every lane's pairs of registers fit 64 bits (a wave-uniform test)
@@ -2902,6 +2936,8 @@ __device__ void assemble_body(const szk_asm_params &p, uint64_t tid, uint64_t nt
     for (uint64_t i = tid; i < h0.sym_count; i += nth) p.payload[o.lens + i] = p.lens[h0.sym_min + i];
     uint16_t *cw = reinterpret_cast<uint16_t *>(p.payload + o.chunkwords);
     for (uint64_t i = tid; i < h0.n_chunks; i += nth) cw[i] = p.chunk_words[i];
+    uint16_t *sb = reinterpret_cast<uint16_t *>(p.payload + o.subbits);
+    for (uint64_t i = tid; i < h0.n_chunks * (SZH_SUBS - 1); i += nth) sb[i] = p.sub_bits[i];
 }
 // the sections whose size the input decides — the two outlier lists and the block path's side information: copied by every
 // thread the launch has (a field with a fill-value mask lists a million points; 32 workgroups copying them byte by byte took
@@ -3103,7 +3139,6 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     const int lane = lane_id();
     uint32_t *stage = s_stage[threadIdx.x / WAVE];
     uint32_t *out_base = reinterpret_cast<uint32_t *>(payload + state->off.bitstream);
-    uint16_t *sub_base = reinterpret_cast<uint16_t *>(payload + state->off.subbits);
 
     // side loads of a chunk: words of the chunks before it inside its group (one per lane) and the group offset
     auto side = [&](uint64_t ch, uint32_t &before_part, uint64_t &goff) {
@@ -3152,11 +3187,11 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
             const uint32_t wds[4] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w};
 #pragma unroll
             for (int i = 0; i < 16; i++) c[i] = (uint16_t)((wds[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-            nwords = pack_chunk<4, true>(c, 0, 0, false, s_enc8, g_enc, sym_min, all_lds, stage, sub_base + chunk * (SZH_SUBS - 1), s_plen8);
+            nwords = pack_chunk<4, true>(c, 0, 0, false, s_enc8, g_enc, sym_min, all_lds, stage, s_plen8);
         } else {
             unpack_codes(cur, narrow, sym_add, c);
-            nwords = wide ? pack_chunk<2, false, WIN>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage, sub_base + chunk * (SZH_SUBS - 1))
-                          : pack_chunk<4, false, WIN>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage, sub_base + chunk * (SZH_SUBS - 1));
+            nwords = wide ? pack_chunk<2, false, WIN>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage)
+                          : pack_chunk<4, false, WIN>(c, 0, 0, false, s_enc, g_enc, sym_min, all_lds, stage);
         }
         const uint32_t before = wave_sum(bp_cur);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -3180,8 +3215,8 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         uint32_t bp;
         uint64_t go;
         side(n_full, bp, go);
-        const uint32_t nwords = wide ? pack_chunk<2, false, WIN>(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage, sub_base + n_full * (SZH_SUBS - 1))
-                                     : pack_chunk<4, false, WIN>(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage, sub_base + n_full * (SZH_SUBS - 1));
+        const uint32_t nwords = wide ? pack_chunk<2, false, WIN>(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage)
+                                     : pack_chunk<4, false, WIN>(c, base, n, true, s_enc, g_enc, sym_min, all_lds, stage);
         const uint32_t before = wave_sum(bp);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -4271,7 +4306,8 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
     const uint32_t sym_add = (uint32_t)radius - 127u;  // one-byte codes: stored byte t = delta + 127 (255: delta outlier, symbol 0) -> symbol t + sym_add
     const uint32_t pgrid = (uint32_t)(nb < 2048 ? nb : 2048);  // persistent: 8 workgroups per CU
     // (seg_bits: stage 1 summed the code bits per 256-element segment with the book the encoder uses: no bits pass)
-    if (!seg_bits) hipLaunchKernelGGL(k_chunk_bits2, dim3(pgrid), dim3(256), 0, s, codes, n, d_enc, info, mode, sym_add, chunk_words);
+    uint16_t *sub_bits = asmp ? asmp->sub_bits : nullptr;  // (the units' bit offsets: made with the chunks' word counts, copied into the payload with them)
+    if (!seg_bits) hipLaunchKernelGGL(k_chunk_bits2, dim3(pgrid), dim3(256), 0, s, codes, n, d_enc, info, mode, sym_add, chunk_words, sub_bits);
     szk_fold_params fp{};
     if (er && er->fold_rows) {  // stage 1 left the fold of its histogram rows out: 64 more workgroups of this launch do it
         fp.partial = er->fold_partial;
@@ -4285,7 +4321,7 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
         const uint64_t n_segs = (n + 255) / 256;
         uint32_t *gsums = reinterpret_cast<uint32_t *>(group_off + (n_chunks + PACK_GROUP - 1) / PACK_GROUP + 1);  // behind the offsets (same array)
         hipLaunchKernelGGL(k_seg_chunks, dim3((uint32_t)std::min<uint64_t>(((n_segs + 7) / 8 + 255) / 256, 1024)), dim3(256), 0, s, seg_bits, n_segs, seg_made,
-                           chunk_words, n_chunks, gsums);
+                           chunk_words, n_chunks, gsums, sub_bits);
         scan_in = reinterpret_cast<const uint16_t *>(gsums);
     }
     hipLaunchKernelGGL(k_scan_groups, dim3(fp.nrows ? 65 : 1), dim3(1024), 0, s, chunk_words, n_chunks, group_off, total_words, *layout, 1, scan_in,

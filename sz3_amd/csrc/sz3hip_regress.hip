@@ -228,6 +228,15 @@ __device__ __forceinline__ void blk_fit_block(const T *sx, const TileView &tv, c
         return v;
     };
     const uint32_t nown = g.ez * g.ey * g.ex;
+    // The choice and the coefficients come from the selection pass (k_blk_select: the reference's summation order, a block per
+    // lane) unless it did not run (p.sel_given == 0: this pass's own fit and estimates below, sums reduced across the wave).
+    int sid = 0;
+    int64_t lc[4] = {0, 0, 0, 0};
+    if (p.sel_given) {
+        sid = p.sel[task];
+        if (sid == 2)
+            for (int i = 0; i < 4; i++) lc[i] = p.coef[(uint64_t)task * 4 + i];
+    } else {
     // ---- regression fit (RegressionPredictor.hpp:28-55) ----
     bool r_valid = has_r && g.ez > 1 && g.ey > 1 && g.ex > 1;
     T cf[4] = {0, 0, 0, 0};
@@ -260,7 +269,7 @@ __device__ __forceinline__ void blk_fit_block(const T *sx, const TileView &tv, c
         cf[3] = (T)((double)cf[3] - (dx - 1) * (double)cf[2] / 2);
     }
     // ---- selection (ComposedPredictor.hpp:25-40 over foreach_sampling) ----
-    int sid = has_l1 ? 0 : (has_l2 ? 1 : 2);
+    sid = has_l1 ? 0 : (has_l2 ? 1 : 2);
     const int npred = (int)has_l1 + (int)has_l2 + (int)has_r;
     if (npred > 1) {
         const uint32_t m = min(g.ez, min(g.ey, g.ex));
@@ -287,7 +296,6 @@ __device__ __forceinline__ void blk_fit_block(const T *sx, const TileView &tv, c
         sid = 0;  // BlockwiseDecomposition.hpp:35-37
     }
     // ---- regression: coefficients onto their lattices; a coefficient the lattice cannot hold -> Lorenzo-1 ----
-    int64_t lc[4] = {0, 0, 0, 0};
     if (sid == 2) {
         bool ok = true;
         for (int i = 0; i < 4; i++) {
@@ -297,6 +305,7 @@ __device__ __forceinline__ void blk_fit_block(const T *sx, const TileView &tv, c
         }
         if (!ok) sid = 0;
     }
+    }  // (own selection)
     if (sid == 2) {
         T rc[4];
         coef_recover(lc, cl, rc);
@@ -469,13 +478,18 @@ __global__ __launch_bounds__(256) void k_blk_select(const T *__restrict__ in, sz
         } else if (sid == 2 && !r_valid) {
             sid = 0;
         }
-        if (sid == 2) {  // a coefficient its lattice cannot hold: Lorenzo-1 (as in k_blk_fit)
+        if (sid == 2) {  // the coefficients onto their lattices; one its lattice cannot hold: Lorenzo-1
             const CoefLat cl = coef_lat(p.eb, p.B);
+            int64_t lc[4];
             for (int i = 0; i < 4; i++) {
                 const double sc = (double)cf[i] / (i < 3 ? cl.step_lin : cl.step_ind);
                 if (!(fabs(sc) < 4503599627370496.0)) sid = 0;
+                lc[i] = (int64_t)rint(sc);
             }
+            if (sid == 2)
+                for (int i = 0; i < 4; i++) p.coef[(uint64_t)task * 4 + i] = lc[i];
         }
+        p.sel[task] = (uint8_t)sid;  // (k_blk_fit takes the choice and the coefficients from here)
         other = sid != 0;
     }
     const unsigned long long mo = __ballot(other);

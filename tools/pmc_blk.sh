@@ -1,8 +1,8 @@
 #!/bin/bash
-# PMC counters of the block-composed path's encoder passes at C4's slab
+# PMC counters of the block-composed path's passes (selection, fit, Lorenzo) at C4's slab; $FIELD = default | c4a
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-B="python $R/bench.py --algo composed --dtype f64 --shape 128,1024,1024 --eb 1e-6 --steps 3 --warmup 2 --no-cpu-baseline --no-host-e2e --no-extra"
+B="python $R/bench.py --algo composed --field ${FIELD:-default} --dtype f64 --shape 128,1024,1024 --eb 1e-6 --steps 3 --warmup 2 --no-cpu-baseline --no-host-e2e --no-extra"
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_GDS SQ_INSTS_FLAT"; do
   rm -rf /tmp/pb; rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pb -o p -- $B > /dev/null 2>&1
   python - <<PY
@@ -11,8 +11,8 @@ f=glob.glob("/tmp/pb/*counter_collection.csv")[0]
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     k=r["Kernel_Name"]
-    if "k_blk_fit" in k or "k_blk_lorenzo" in k:
-        if "16384" not in k: continue
+    if "k_blk_fit" in k or "k_blk_lorenzo" in k or "k_blk_select" in k:
+        if "16384" not in k and "k_blk_select" not in k: continue
         acc[k.split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in acc: print(k, {c: "%.3g" % (sum(v)/len(v)) for c,v in acc[k].items()})
 PY

@@ -80,6 +80,14 @@ template <> __device__ __forceinline__ double lane_bcast<double>(double v, int s
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
+// lane l <- lane l - 1 across the wave (DPP wave_shr:1), lane 0 keeps `old`
+__device__ __forceinline__ int32_t dpp_shr1_q(int32_t old, int32_t src) { return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int64_t dpp_shr1_q(int64_t old, int64_t src) {
+    const int32_t lo = __builtin_amdgcn_update_dpp((int32_t)old, (int32_t)src, 0x138, 0xf, 0xf, false);
+    const int32_t hi = __builtin_amdgcn_update_dpp((int32_t)(old >> 32), (int32_t)(src >> 32), 0x138, 0xf, 0xf, false);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
 struct BlkGeom {
     uint32_t bz, by, bx;
     uint32_t oz, oy, ox;  // origin of the block in the array
@@ -127,7 +135,18 @@ template <uint32_t HW>
 __device__ __forceinline__ void blk_count(uint32_t *lh, const szk_blk_params &p, uint32_t code, bool active) {
     const unsigned long long zm = __ballot(active && code == 0);
     if (zm && lane_id() == __ffsll((long long)zm) - 1) atomicAdd((unsigned long long *)&p.hist[0], (unsigned long long)__popcll(zm));
-    if (!active || code == 0) return;
+    // the three codes around the radius are counted per wave (one lane adds the wave's number): at high ratios nearly every lane
+    // of a wave has the SAME code, and 64 atomics on one LDS address are 64 serial ones (C4a: 2.1 of the element pass's 2.9 ms)
+    bool mine = active && code != 0;
+#pragma unroll
+    for (int d = -1; d <= 1; d++) {
+        const uint32_t c = p.radius + (uint32_t)d;
+        const bool is = mine && code == c;
+        const unsigned long long m = __ballot(is);
+        if (m && lane_id() == __ffsll((long long)m) - 1) atomicAdd(&lh[c - (p.radius - HW / 2)], (uint32_t)__popcll(m));
+        mine = mine && !is;
+    }
+    if (!mine) return;
     const uint32_t bin = code - (p.radius - HW / 2);
     if (bin < HW) atomicAdd(&lh[bin], 1u);
     else atomicAdd((unsigned long long *)&p.hist[code], 1ull);
@@ -334,7 +353,7 @@ __device__ __forceinline__ void blk_fit_block(const T *sx, const TileView &tv, c
         }
         if (lane == 0) {
             for (int i = 0; i < 4; i++) p.coef[(uint64_t)task * 4 + i] = lc[i];
-            atomicAdd((unsigned long long *)p.n_reg, 1ull);
+            // (no count here: the rank pass counts the regression blocks; one same-address atomic per block was serial work for the L2)
         }
     } else {
         for (uint32_t t0 = 0; t0 < nown; t0 += WAVE) {
@@ -496,6 +515,33 @@ __global__ __launch_bounds__(256) void k_blk_select(const T *__restrict__ in, sz
     if (mo && lane_id() == 0) atomicAdd(n_other, (unsigned long long)__popcll(mo));
 }
 
+// The lattice values of everything that is not in a regression block: q~ = rint(x / 2eb), element by element (the choices are known
+// since the selection pass) — what the fit pass used to do block by block from its tiles for the 86 % of C4a's blocks that only
+// needed this. A thread per element, rows walked by the workgroups; the block of an element is (z / B, y / B, x / B).
+template <typename T>
+__global__ __launch_bounds__(256) void k_blk_lattice(const T *__restrict__ in, szk_blk_params p, uint64_t nrows) {
+    using Q = typename QTraits<T>::Q;
+    const Lattice<T> lat(p.lat);
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    Q *qwork = reinterpret_cast<Q *>(p.qwork);
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+    const bool xok = x < d2;
+    const uint32_t bx = (xok ? x : 0u) / p.B;
+    for (uint64_t row = blockIdx.y; row < nrows; row += gridDim.y) {
+        const uint32_t z = (uint32_t)(row / d1), y = (uint32_t)(row % d1);
+        const uint32_t task = ((z / p.B) * p.nb[1] + y / p.B) * p.nb[2] + bx;
+        const uint64_t gi = row * d2 + x;
+        bool bad = false;
+        T raw = 0;
+        if (xok && p.sel[task] != 2) {
+            raw = in[gi];
+            const Q q = lat.quant(raw, bad);
+            qwork[gi] = bad ? (Q)0 : q;
+        }
+        blk_vout<T>(p, bad, gi, raw);  // (unpredictable: the raw value; the append is a wave operation, all lanes take part)
+    }
+}
+
 // NW: waves (= blocks in flight) per workgroup; they share the LDS histogram, so the wide form (64 KB of bins) takes 16 of them to
 // keep four waves per SIMD busy (with 4 the two passes ran at two waves per SIMD, bound by the latency of their tile loads).
 // Measured and dropped (round 2, C4's slab): groups of 2 x 2 x 4 blocks sharing one tile per workgroup (1.47 x instead of 2.37 x
@@ -520,6 +566,7 @@ __global__ __launch_bounds__(NW * 64) void k_blk_fit(const T *__restrict__ in, u
     const uint64_t d1 = p.d[1], d2 = p.d[2];
     const TileView tv{E * E, E, 0};
     for (uint32_t task = blockIdx.x * NW + wv; task < nblocks; task += gridDim.x * NW) {
+        if (p.sel_given && p.sel[task] != 2) continue;  // (not a regression block: k_blk_lattice wrote its lattice values)
         const BlkGeom g = blk_geom(p, task);
         // ---- originals of the block and two low halo layers, the halo on the lattice ----
         for (uint32_t t = lane; t < E * E * E; t += WAVE) {
@@ -625,6 +672,126 @@ __global__ __launch_bounds__(NW * 64) void k_blk_lorenzo(uint16_t *__restrict__ 
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    blk_flush<HW>(lh, p);
+}
+// The same pass by ROWS OF BLOCKS (round 3, taken when the selection pass ran and the set has no second-order Lorenzo): a Lorenzo
+// element's code is a stencil over q~ of itself and its lower neighbours wherever they lie, and q~ of an element is a function of
+// that element alone — rint(x / 2eb) outside regression blocks, the lattice value k_blk_fit stored inside them. So nothing is
+// staged per block and nothing is written for the 86 % of C4a's blocks that are Lorenzo blocks: a workgroup takes a run of
+// blocks along x of one block row (bz, by) — a thread per x — and marches through the run's planes and rows (one halo plane, one
+// halo row per plane: 49 row loads for 36 rows of codes at B = 6, every one coalesced, every value put on the lattice once),
+// keeps the previous plane's and row's lattice values in registers, takes the left neighbour from the previous lane (DPP; a
+// wave's first lane fetches its own), and collects the codes of the run in LDS: the blocks of a run are neighbours in the
+// block-major code order, so they leave as ONE contiguous stretch. (A thread per element storing each code where it belongs —
+// 12 bytes here, 12 bytes there, every cache line of codes touched 36 times — took 2.2 - 2.9 ms at C4's slab: the stores, not
+// the loads or the histogram.) k_blk_lattice + k_blk_lorenzo, which this replaces: 0.51 + 0.98 ms.
+template <typename T, uint32_t HW, int CB>
+__global__ __launch_bounds__(256) void k_blk_rows(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t ntasks, uint32_t xchunks) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    constexpr int MJ = CB ? CB + 1 : 9;  // rows of a plane the march keeps: the halo row + the block's
+    __shared__ uint32_t lh[HW];
+    __shared__ uint16_t s_codes[256 * (CB ? CB * CB : 64)];
+    __shared__ uint8_t s_reg[256];
+    for (uint32_t b = threadIdx.x; b < HW; b += 256) lh[b] = 0;
+    __syncthreads();
+    const Lattice<T> lat(p.lat);
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    const uint32_t B = CB ? (uint32_t)CB : p.B, nb1 = p.nb[1], nb2 = p.nb[2];
+    const Q *qwork = reinterpret_cast<const Q *>(p.qwork);
+    const uint32_t TPB = (256u / B) * B, BPC = 256u / B;  // threads in use, blocks per run
+    const uint32_t t = threadIdx.x, bl = t / B, i2 = t - bl * B;
+    const int lane = lane_id();
+    for (uint32_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        const uint32_t xci = task % xchunks, r = task / xchunks, by = r % nb1, bz = r / nb1;  // (workgroup-uniform)
+        const uint32_t oz = bz * B, oy = by * B, ez = min(B, (uint32_t)p.d[0] - oz), ey = min(B, (uint32_t)d1 - oy);
+        const uint32_t x = xci * TPB + t;
+        const bool xok = t < TPB && x < d2;
+        const uint32_t xc = xok ? x : (uint32_t)d2 - 1u;  // (a lane beyond the run / the row reads the row's last element: a valid address, its value unused)
+        const uint32_t bx = xc / B, ox = bx * B, ex = min(B, (uint32_t)d2 - ox);
+        const uint32_t bxl = xc ? (xc - 1) / B : 0u;  // block column of the left neighbour
+        // the predictor of the four blocks this thread's values come from: its own, the one above (by - 1), behind (bz - 1), both
+        const uint32_t tk = (bz * nb1 + by) * nb2;
+        const int sid = (int)p.sel[tk + bx];
+        const bool reg_own = sid == 2, reg_up = by && p.sel[tk - nb2 + bx] == 2, reg_back = bz && p.sel[tk - nb1 * nb2 + bx] == 2,
+                   reg_bu = by && bz && p.sel[tk - nb1 * nb2 - nb2 + bx] == 2;
+        const bool lane0 = lane == 0 && xc > 0;
+        const bool lreg_own = lane0 && p.sel[tk + bxl] == 2, lreg_up = lane0 && by && p.sel[tk - nb2 + bxl] == 2,
+                   lreg_back = lane0 && bz && p.sel[tk - nb1 * nb2 + bxl] == 2, lreg_bu = lane0 && by && bz && p.sel[tk - nb1 * nb2 - nb2 + bxl] == 2;
+        const bool act = xok && !reg_own;
+        if (t < BPC) s_reg[t] = 0;
+        __syncthreads();
+        if (xok && i2 == 0 && reg_own) s_reg[bl] = 1;
+        UQ P[MJ], PL[MJ];  // the previous plane: q~ at x and at x - 1, rows oy - 1 ..
+#pragma unroll
+        for (int j = 0; j < MJ; j++) P[j] = PL[j] = 0;
+        for (uint32_t kz = 0; kz <= ez; kz++) {  // planes oz - 1 .. oz + ez - 1
+            const bool zin = kz > 0 || bz > 0;    // (the plane exists: below the array's first plane everything is zero)
+            const uint32_t zz = zin ? oz + kz - 1 : 0u;
+            T raw[MJ], rawl[MJ];
+#pragma unroll
+            for (int j = 0; j < MJ; j++) {  // the plane's rows oy - 1 .. oy + ey - 1: every load first
+                const bool rin = zin && (uint32_t)j <= ey && (j > 0 || by > 0);
+                const uint32_t yy = rin ? oy + (uint32_t)j - 1 : 0u;
+                const uint64_t rb = ((uint64_t)(rin ? zz : 0u) * d1 + yy) * d2;
+                raw[j] = in[rb + xc];
+                rawl[j] = lane0 ? in[rb + xc - 1] : (T)0;
+            }
+            UQ C[MJ], CL[MJ];
+#pragma unroll
+            for (int j = 0; j < MJ; j++) {
+                const bool rin = zin && (uint32_t)j <= ey && (j > 0 || by > 0);
+                const uint32_t yy = rin ? oy + (uint32_t)j - 1 : 0u;
+                const uint64_t rb = ((uint64_t)(rin ? zz : 0u) * d1 + yy) * d2;
+                // which block the row lies in: halo plane / halo row -> the blocks behind / above
+                const bool isreg = kz == 0 ? (j == 0 ? reg_bu : reg_back) : (j == 0 ? reg_up : reg_own);
+                const bool lisreg = kz == 0 ? (j == 0 ? lreg_bu : lreg_back) : (j == 0 ? lreg_up : lreg_own);
+                bool bad, badl;
+                const Q q = lat.quant(raw[j], bad);
+                const Q ql = lat.quant(rawl[j], badl);
+                UQ v = bad ? (UQ)0 : (UQ)q, vl = badl ? (UQ)0 : (UQ)ql;
+                if (__ballot(rin && isreg)) v = (rin && isreg) ? (UQ)qwork[rb + xc] : v;  // (a regression block's elements: what the fit pass stored)
+                if (rin && lisreg) vl = (UQ)qwork[rb + xc - 1];
+                v = rin && xok ? v : (UQ)0;
+                vl = rin && lane0 ? vl : (UQ)0;
+                C[j] = v;
+                CL[j] = (UQ)dpp_shr1_q((Q)vl, (Q)v);  // left neighbour: the previous lane's value; the wave's first lane looked its own up
+                if (kz > 0 && j > 0 && (uint32_t)j <= ey) {  // an element of the run: plane kz - 1, row j - 1 of its block
+                    const uint32_t i0 = kz - 1, i1 = (uint32_t)j - 1;
+                    const UQ delta = (C[j] - CL[j]) - (C[j - 1] - CL[j - 1]) - (P[j] - PL[j]) + (P[j - 1] - PL[j - 1]);  // wrap-around arithmetic
+                    const uint64_t gi = rb + xc;
+                    blk_vout<T>(p, act && bad, gi, raw[j]);  // (unpredictable: the raw value; its q~ is 0)
+                    const bool inr = (UQ)(delta + (UQ)(p.radius - 1)) <= (UQ)(2 * p.radius - 2);
+                    const uint32_t code = inr ? (uint32_t)(delta + (UQ)p.radius) : 0u;
+                    const uint32_t li = bl * (ez * ey * B) + (i0 * ey + i1) * ex + i2;  // position inside the run's stretch of codes
+                    if (act) s_codes[li] = (uint16_t)code;
+                    blk_count<HW>(lh, p, code, act);
+                    const unsigned long long pd = wave_append_slot(act && !inr, p.n_dout);
+                    if (act && !inr && pd < p.out_cap) {
+                        const uint64_t base = (uint64_t)oz * d1 * d2 + (uint64_t)ez * ((uint64_t)oy * d2 + (uint64_t)ey * (xci * TPB));
+                        p.dout_idx[pd] = base + li;  // (position of the code, not of the element: the decoder expands the codes in place)
+                        reinterpret_cast<Q *>(p.dout_val)[pd] = (Q)delta;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < MJ; j++) {
+                P[j] = C[j];
+                PL[j] = CL[j];
+            }
+        }
+        __syncthreads();
+        // the run's codes leave as one stretch (the blocks of a row of blocks follow each other in the code order); a regression
+        // block's codes are the fit pass's
+        {
+            const uint32_t x0 = xci * TPB, xend = min((uint32_t)d2, x0 + TPB);
+            const uint32_t total = ez * ey * (xend - x0), per = ez * ey * B;
+            const uint64_t base = (uint64_t)oz * d1 * d2 + (uint64_t)ez * ((uint64_t)oy * d2 + (uint64_t)ey * x0);
+            for (uint32_t i = t; i < total; i += 256)
+                if (!s_reg[i / per]) codes[base + i] = s_codes[i];
+        }
+        __syncthreads();
+    }
     blk_flush<HW>(lh, p);
 }
 // ------------------------------------------------------------------------------------------------------------
@@ -1253,11 +1420,28 @@ static uint32_t blk_count_blocks(const szk_blk_params *p) { return p->nb[0] * p-
 
 int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s) {
     const uint32_t nblocks = blk_count_blocks(p);
+    // With the selection pass's choices: the fit pass codes the regression blocks (and leaves their lattice values), the stencil
+    // pass every other element straight from the array. Without (development switch): fit and selection by the fit pass, the
+    // lattice values of everything through qwork, Lorenzo blocks from tiles.
+    const bool by_element = p->sel_given && !(p->mask & 2u) && !(szk_dbg_flags & 67108864);  // (k_blk_rows: first-order Lorenzo only)
+    const uint64_t nrows = p->d[0] * p->d[1];
+    if (p->sel_given && !by_element) {
+        const dim3 g((uint32_t)((p->d[2] + 255) / 256), (uint32_t)std::min<uint64_t>(nrows, 32768));
+        if (dtype == 0) hipLaunchKernelGGL(k_blk_lattice<float>, g, dim3(256), 0, s, (const float *)d_in, *p, nrows);
+        else hipLaunchKernelGGL(k_blk_lattice<double>, g, dim3(256), 0, s, (const double *)d_in, *p, nrows);
+    }
 #define BLK_ENC1(T, HW, CBV, NW)                                                                                                       \
     do {                                                                                                                               \
         const uint32_t grid = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                        \
         hipLaunchKernelGGL((k_blk_fit<T, HW, CBV, NW>), dim3(grid), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks);          \
-        hipLaunchKernelGGL((k_blk_lorenzo<T, HW, CBV, NW>), dim3(grid), dim3(NW * 64), 0, s, codes, *p, nblocks);                       \
+        if (by_element) {                                                                                                              \
+            const uint32_t tpb = (256u / p->B) * p->B, xchunks = (uint32_t)((p->d[2] + tpb - 1) / tpb);                                  \
+            const uint64_t ntasks = (uint64_t)p->nb[0] * p->nb[1] * xchunks;                                                            \
+            hipLaunchKernelGGL((k_blk_rows<T, HW, CBV>), dim3((uint32_t)std::min<uint64_t>(ntasks, BLK_GRID)), dim3(256), 0, s,           \
+                               (const T *)d_in, codes, *p, (uint32_t)ntasks, xchunks);                                                  \
+        } else {                                                                                                                       \
+            hipLaunchKernelGGL((k_blk_lorenzo<T, HW, CBV, NW>), dim3(grid), dim3(NW * 64), 0, s, codes, *p, nblocks);                   \
+        }                                                                                                                              \
     } while (0)
     // (LDS: NW tiles of (B + 2)^3 values + the histogram window; the generic-edge form's tiles hold 1000 values)
 #define BLK_ENC(T, HW, NW6, NW0)                  \

@@ -418,9 +418,9 @@ __global__ __launch_bounds__(256) void k_blk_select(const T *__restrict__ in, sz
         if (r_valid) {
             double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
             if (whole) {
-                // (a plane at a time: 427 us at C4's slab; rows one after the other with the next row's loads in flight, 92 instead
-                // of 115 registers: 466 — what bounds the pass is the L2 traffic of the sample points' neighbour reads below,
-                // 24 cache lines per wave instruction for 8 bytes a lane)
+                // (a plane at a time: 427 us at C4's slab. Measured and dropped: rows one after the other with the next row's loads
+                // in flight, 92 instead of 115 registers: 466; the sample points' neighbours below as four pair loads (x - 1, x)
+                // instead of eight single ones: 447)
 #pragma unroll 1
                 for (uint32_t i0 = 0; i0 < (uint32_t)CB; i0++) {
 #pragma unroll

@@ -121,8 +121,9 @@ int sz3hip_peek_config(sz3hip_config *conf, const char *cmpData, size_t cmpSize)
 /* ---- (3) device-resident API -------------------------------------------------------------------------------- */
 typedef struct sz3hip_ctx sz3hip_ctx;
 
-/* workspace for arrays of up to max_elems elements of dataType on HIP device `device` (all device memory is
- * allocated here, nothing is allocated inside the compress/decompress calls) */
+/* workspace for arrays of up to max_elems elements of dataType on HIP device `device`: the arrays every call uses are
+ * allocated here; a few that only some paths use (the block predictor's per-block arrays, the interpolation work array, the f64
+ * decoder's int32 intermediates, the decoder's carry array) with the first call that takes that path — later calls allocate nothing */
 sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dataType);
 void sz3hip_ctx_destroy(sz3hip_ctx *ctx);
 /* upper bound of the device payload for n elements (outlier lists of up to n / 32 entries: a compress call that needs more
@@ -140,7 +141,10 @@ size_t sz3hip_payload_bound_conf(const sz3hip_ctx *ctx, const sz3hip_config *con
 int sz3hip_minmax_device(sz3hip_ctx *ctx, const void *d_in, uint64_t n, double *min_out, double *max_out, void *stream);
 
 /* stage 1: prequantise + integer Lorenzo + code emission + outlier capture + histogram (K1+K4).
- * conf: N/dims/absErrorBound(must already be absolute)/quantbinCnt are used. Asynchronous on `stream`.
+ * conf: N/dims/absErrorBound(must already be absolute)/quantbinCnt are used. Asynchronous on `stream` — except for the paths
+ * that decide on the host from a device result before going on: ALGO_INTERP_LORENZO (the auto-tuner's outcome) and
+ * ALGO_LORENZO_REG with lorenzo2 / regression on 3-D arrays (the selection pass's count: a field on which only first-order Lorenzo
+ * is chosen is handed to the plain Lorenzo path) synchronise the stream once inside this call.
  * d_in must stay valid and unchanged until sz3hip_compress_finish returns: a context that took a shortcut from what its
  * previous call found (the one-launch form of stage 1 assumes the previous call's code width) repeats the call from stage 1
  * inside finish() when this call's data says otherwise. */

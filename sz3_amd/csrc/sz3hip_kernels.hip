@@ -3354,6 +3354,10 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     __shared__ uint32_t s_first_code[SZH_MAX_LEN + 2], s_first_rank[SZH_MAX_LEN + 2], s_upper[SZH_MAX_LEN + 2];
     __shared__ uint32_t s_lut[1u << DEC_LUT_BITS];
     __shared__ uint16_t s_sorted[SORTED_LDS];
+#ifdef LAB_DEC_PAD  // (lab: fewer workgroups per CU — fewer stream lines live in the L2)
+    __shared__ uint32_t s_pad[LAB_DEC_PAD / 4];
+    if (p.n == 1) s_pad[threadIdx.x] = 1;
+#endif
     const uint32_t max_len = p.tables->max_len, K = p.tables->lut_bits, n_coded = p.tables->n_coded;
     if (threadIdx.x <= SZH_MAX_LEN + 1) {
         const uint32_t l = threadIdx.x;
@@ -3455,10 +3459,23 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
         // divergent refill branch would be waited for at every symbol); typical groups consume 2-3 words, longer ones
         // fall back to single loads
         uint32_t qw[4];
+        {
+            // ONE 16-byte load at the lane's word position (4-byte aligned: the hardware takes it) instead of four 4-byte ones: a
+            // wave's loads touch 64 different cache lines per instruction either way (PMC: the 69 MB stream was fetched seven
+            // times over from beyond the L2 — 33 MB of lines are live across the chip's waves, and every line was asked for by
+            // four instructions a round, sixteen rounds long)
+            typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
+            const uint64_t a = woff + wi;
+            if (a + 3 <= wlast) {
+                const U4 v = *reinterpret_cast<const U4 *>(bs + a);
+                qw[0] = __builtin_bswap32(v.x);
+                qw[1] = __builtin_bswap32(v.y);
+                qw[2] = __builtin_bswap32(v.z);
+                qw[3] = __builtin_bswap32(v.w);
+            } else {  // (the section's last words: clamped, never out of bounds)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint64_t a = woff + wi + k;
-            qw[k] = __builtin_bswap32(bs[a < wlast ? a : wlast]);
+                for (int k = 0; k < 4; k++) qw[k] = __builtin_bswap32(bs[a + k < wlast ? a + k : wlast]);
+            }
         }
         uint32_t qn = 0;
         uint32_t syms[16];

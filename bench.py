@@ -397,7 +397,8 @@ def main():
             "tuner": w.dc.tuner_report() if args.algo == "interp" else None,
             "codebook_speculation": {"hits": h_spec, "misses": m_spec,
                                      "note": "timed loop + warmup: stage 2 packs with the previous call's code book while this call's is built by "
-                                             "one workgroup of the same launch; a miss repeats the encoder (see `cold`)"},
+                                             "one workgroup of the same launch (alphabets <= 256 symbols) or by k_codebook<1> on a stream of its own "
+                                             "(wide alphabets, short outlier lists); a miss repeats the encoder (see `cold`)"},
         }
         if args.algo == "composed":
             pid = w.stream_predictor()

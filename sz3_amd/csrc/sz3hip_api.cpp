@@ -212,6 +212,12 @@ static void ctx_free(sz3hip_ctx *c) {
                     c->bk[1].enc, c->bk[1].lens, c->bk[1].info, c->d_seg_bits, c->d_half32, c->d_sub_bits};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    if (c->book_stream) {
+        (void)hipStreamSynchronize(c->book_stream);
+        (void)hipStreamDestroy(c->book_stream);
+        if (c->ev_s1) (void)hipEventDestroy(c->ev_s1);
+        if (c->ev_book) (void)hipEventDestroy(c->ev_book);
+    }
     if (c->side) {
         (void)hipStreamSynchronize(c->side);
         (void)hipStreamDestroy(c->side);
@@ -1141,7 +1147,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     return stage1_lorenzo(ctx, conf, d_in, eb, radius, num, s);
 }
 
-enum { S2_CLASSIC = 0, S2_SPEC = 1, S2_REENCODE = 2 };
+enum { S2_CLASSIC = 0, S2_SPEC = 1, S2_REENCODE = 2, S2_SPEC_WIDE = 3 };
 static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream_t s, int how);
 extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t cap, void *stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -1171,7 +1177,13 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     // call left). Building a wide alphabet's book on a side stream beside the encoder was built and measured slower than
     // building it first (C3: 1.34 against 1.24 ms — two cross-stream dependencies cost more than the 0.15 ms they hide).
     if (spec && !(ctx->cb_hint == 0 && !ctx->lists_long && ctx->range_ready && !ctx->hist_exposed)) spec = false;
-    int rc = stage2_launch(ctx, d_payload, cap, s, spec ? S2_SPEC : S2_CLASSIC);
+    // Wide alphabets (round 3, second attempt): the book needs a compute unit's whole LDS and 0.15 - 0.3 ms of ONE workgroup —
+    // as long as the encoder's two passes take. It is built on a high-priority stream of its own, forked behind stage 1 and
+    // enqueued BEFORE the encoder's launches (the workgroup is placed before the persistent packers fill the chip), and joined in
+    // front of a one-workgroup verdict on the caller's stream; the list sorts ride in the packer's launch as in the small form.
+    const bool spec_wide = !spec && book_spec_ok(ctx, ctx->proto.predictor, ctx->proto.radius) && ctx->cb_hint == 1 && !ctx->lists_long &&
+                           !(szk_dbg_flags & 4096);
+    int rc = stage2_launch(ctx, d_payload, cap, s, spec ? S2_SPEC : (spec_wide ? S2_SPEC_WIDE : S2_CLASSIC));
     if (rc) return rc;
     ctx->stage2_done = true;
     return 0;
@@ -1180,9 +1192,11 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     const uint64_t n = ctx->proto.n;
     // the slot this call's book goes to (the other one holds the previous call's), and the slot the encoder reads
     const int fresh = how == S2_REENCODE ? ctx->book_pending : (ctx->book_idx < 0 ? 0 : 1 - ctx->book_idx);
-    const int used = how == S2_SPEC ? ctx->book_idx : fresh;
+    const bool wide = how == S2_SPEC_WIDE;
+    const int used = (how == S2_SPEC || wide) ? ctx->book_idx : fresh;
     ctx->book_pending = fresh;
-    ctx->s2_spec = how == S2_SPEC;
+    ctx->s2_spec = how == S2_SPEC || wide;
+    ctx->s2_wide = wide;
     szk_cb_params cb;
     cb_params_from(ctx, cb, ctx->cur_out_cap, fresh);
     // Speculative form: this call's book, the verdict and the list sorts ride in the packer's own launch as three role
@@ -1208,6 +1222,29 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
         if (szk_launch_hist_fold(ctx->d_hist_partial, ctx->fold_rows, (int)ctx->proto.radius, ctx->d_hist, ctx->fold_range, s))
             return fail(SZ3HIP_EHIP, "histogram fold launch failed");
         ctx->fold_rows = 0;
+    }
+    if (wide) {
+        if (!ctx->book_stream) {
+            int lo_pri = 0, hi_pri = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
+            HIPCHK(hipStreamCreateWithPriority(&ctx->book_stream, hipStreamNonBlocking, hi_pri));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_s1, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_book, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(ctx->ev_s1, s));
+        HIPCHK(hipStreamWaitEvent(ctx->book_stream, ctx->ev_s1, 0));
+        if (ctx->range_ready && !cb.range_ready) HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, 16, ctx->book_stream));
+        cb.part_hint = 1;   // the wide form alone: a small alphabet raises `mispredict` (the verdict passes it on, stage 2 is repeated)
+        cb.skip_sort = 1;   // (the lists are sorted by the packer's launch: its assembly copies them)
+        int rcb = szk_launch_codebook(ctx->d_hist, &cb, ctx->book_stream);
+        if (rcb) return fail(SZ3HIP_EHIP, "codebook kernel launch failed (%d)", rcb);
+        HIPCHK(hipEventRecord(ctx->ev_book, ctx->book_stream));
+        er.roles = 1;
+        er.no_book = 1;
+        er.hist = ctx->d_hist;
+        er.cb = &cb;
+        er.used_lens = ctx->bk[used].lens;
+        er.flags = reinterpret_cast<uint32_t *>(ctx->d_counters + 10);
     }
     if (how == S2_CLASSIC) {
         if (ctx->range_ready && !cb.range_ready)  // stage 1 kept the range of the LOCAL histogram, the caller then changed it (all-reduce):
@@ -1249,9 +1286,16 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     int rc = szk_launch_encode(ctx->d_codes, n, ctx->bk[used].enc, ctx->bk[used].info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words,
                                ctx->d_chunk_off, ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, &lp, &ap, s,
                                fused && ctx->seg_expected ? ctx->d_seg_bits : nullptr, reinterpret_cast<uint32_t *>(ctx->d_counters + 10) + 1,
-                               fused ? &er : nullptr);
+                               (fused || wide) ? &er : nullptr);
     prof_end(ctx, ST_ENCODE, s);
     if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
+    if (wide) {  // join: this call's book against the one the encoder used
+        HIPCHK(hipStreamWaitEvent(s, ctx->ev_book, 0));
+        if (szk_launch_book_verdict(ctx->bk[fresh].info, ctx->bk[fresh].lens, ctx->bk[used].info, ctx->bk[used].lens,
+                                    reinterpret_cast<const uint32_t *>(ctx->d_counters + 7), reinterpret_cast<const uint32_t *>(ctx->d_counters + 8),
+                                    ctx->d_state, s))
+            return fail(SZ3HIP_EHIP, "verdict kernel launch failed");
+    }
     prof_end(ctx, ST_SPAN, s);
     HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(szk_state), hipMemcpyDeviceToHost, s));
     if (!ctx->ev_done) HIPCHK(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));

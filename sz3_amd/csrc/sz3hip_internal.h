@@ -138,6 +138,9 @@ struct sz3hip_ctx {
     size_t trial_codes_cap;
     hipStream_t side;    // the working copy of the input is made here while the tuner runs on the caller's stream
     hipEvent_t ev_fork, ev_join;
+    hipStream_t book_stream;       // speculative stage 2, wide alphabets: this call's code book is built here (high priority) beside the encoder
+    hipEvent_t ev_s1, ev_book;     // ... forked behind stage 1, joined in front of the verdict
+    bool s2_wide;                  // this call's stage 2 took that form
     bool copy_ahead;     // d_work already holds this call's input (joined into the caller's stream)
     int hist_tail;       // with hist_big: codes beyond the large tier counted by windowed passes (from the previous call's count)
     int hist_big;        // interpolation histogram pass with the 16384-bin second tier (from the previous call's far count)

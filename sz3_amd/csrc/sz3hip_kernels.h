@@ -96,6 +96,7 @@ struct szk_cb_params {
     int range_ready;   // the range words are already filled (stage 1 kept them with the histogram): no k_hist_range launch
     int part_hint;     // -1: both forms of k_codebook are launched; 0 / 1: only that form (small / wide alphabets), see mispredict
     uint32_t *mispredict;  // set to 1 by a form launched alone that meets the other form's alphabet
+    int skip_sort;         // the launch's two list-sorting workgroups return at once (the lists are sorted elsewhere: speculative stage 2)
 };
 #define SZK_CB_SMALL_SYMS 256  // alphabets up to this size take k_codebook<0>, wider ones <1>
 #define SZK_MAX_BOOKS 4
@@ -142,6 +143,7 @@ struct szk_asm_params {
 // speculative stage 2, small alphabets: work that rides in the encoder's two launches instead of a side stream
 struct szk_encode_roles {
     int roles;                  // the packer's launch carries the book role (this call's code book + the verdict) and the two sort roles
+    int no_book;                // ... the sort roles only: the book is built elsewhere (wide alphabets: k_codebook<1> on the side stream)
     const uint64_t *hist;
     const szk_cb_params *cb;    // this call's book: fresh slot, part_hint = 0, range words ready
     const uint8_t *used_lens;   // code lengths of the book the packer runs with
@@ -292,6 +294,11 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
                       const szk_encode_roles *roles = nullptr);
 // the fold of stage 1's per-workgroup histogram rows (k_hist_reduce), for a caller that deferred it (szk_k1_params::defer_fold)
 // and does not run the encoder form that carries it
+// speculative stage 2 with a wide alphabet: the book built on the side stream against the one the packer used (miss_kind bit 1:
+// they differ; bit 2 + mispredict: the side launch met a small alphabet and built nothing) — one workgroup, on the encoder's stream
+// once the side stream has joined
+int szk_launch_book_verdict(const szk_cb_info *fresh, const uint8_t *fresh_lens, const szk_cb_info *used, const uint8_t *used_lens,
+                            const uint32_t *mispredict, const uint32_t *range, szk_state *state, hipStream_t s);
 int szk_launch_hist_fold(const uint32_t *partial, uint32_t nrows, int radius, uint64_t *hist, uint32_t *range, hipStream_t s);
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t,

@@ -2385,6 +2385,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     __shared__ unsigned long long s_total;
     const uint32_t t = threadIdx.x;
     if (blockIdx.x >= p.n_books) {  // the two blocks after the code books: deterministic order of the two outlier lists
+        if (p.skip_sort) return;
         // (in the launch whose code-book path is the active one, so that they run beside it)
         if ((PART == 1) != (p.range[2] > CB_SMALL_SYMS) && p.part_hint < 0) return;  // (launched alone: sorts whatever the alphabet)
         const bool d = blockIdx.x == p.n_books + 1;
@@ -2992,6 +2993,7 @@ __global__ __launch_bounds__(256) void k_assemble(szk_asm_params p) {
 #define ROLE_SORT_MAX 1024u
 struct szk_role_params {
     uint32_t on;  // 0: no role blocks in this launch
+    uint32_t no_book;  // the sort roles only
     const uint64_t *hist;
     szk_cb_params cb;                // this call's book (fresh slot), part_hint = 0
     const szk_cb_info *used;         // the book the packer runs with
@@ -3120,8 +3122,9 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     const uint32_t roles = rp.on ? ROLE_BLOCKS : 0u;
     if (blockIdx.x < roles) {  // (the first workgroups dispatched; s_enc's 16 KB serve as their scratch)
         static_assert(WIN * 4 >= ROLE_SORT_MAX * 16 && WIN * 4 >= CB_SMALL_SYMS * 28 + 256, "role scratch fits the table");
-        if (blockIdx.x == 0) role_book(rp, ap.state, reinterpret_cast<uint8_t *>(s_enc));
-        else role_sort(rp, ap, blockIdx.x == 2, reinterpret_cast<uint8_t *>(s_enc));
+        if (blockIdx.x == 0) {
+            if (!rp.no_book) role_book(rp, ap.state, reinterpret_cast<uint8_t *>(s_enc));
+        } else role_sort(rp, ap, blockIdx.x == 2, reinterpret_cast<uint8_t *>(s_enc));
         return;
     }
     const uint32_t bid = blockIdx.x - roles;  // the packer's own numbering
@@ -4308,6 +4311,34 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
     SZK_CHECK_LAUNCH();
     return 0;
 }
+__global__ __launch_bounds__(1024) void k_book_verdict(const szk_cb_info *__restrict__ fresh, const uint8_t *__restrict__ fresh_lens,
+                                                       const szk_cb_info *__restrict__ used, const uint8_t *__restrict__ used_lens,
+                                                       const uint32_t *__restrict__ mispredict, const uint32_t *__restrict__ range, szk_state *state) {
+    __shared__ uint32_t s_diff;
+    if (threadIdx.x == 0) s_diff = 0;
+    __syncthreads();
+    const bool built = *mispredict == 0;
+    bool diff = false;
+    if (built) {  // (a code book is a function of its lengths: same alphabet range, same lengths = the same book)
+        const uint32_t lo = fresh->sym_min, cnt = fresh->sym_count;
+        diff = used->sym_min != lo || used->sym_count != cnt || used->max_len != fresh->max_len || used->n_symbols != fresh->n_symbols;
+        if (!diff)
+            for (uint32_t i = threadIdx.x; i < cnt; i += 1024) diff |= used_lens[lo + i] != fresh_lens[lo + i];
+    }
+    if (diff) s_diff = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicOr(&state->miss_kind, (s_diff ? 1u : 0u) | (!built ? 2u : 0u));
+        state->mispredict = built ? 0u : 1u;
+        state->n_symbols = range[2];
+    }
+}
+int szk_launch_book_verdict(const szk_cb_info *fresh, const uint8_t *fresh_lens, const szk_cb_info *used, const uint8_t *used_lens,
+                            const uint32_t *mispredict, const uint32_t *range, szk_state *state, hipStream_t s) {
+    hipLaunchKernelGGL(k_book_verdict, dim3(1), dim3(1024), 0, s, fresh, fresh_lens, used, used_lens, mispredict, range, state);
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
 int szk_launch_hist_fold(const uint32_t *partial, uint32_t nrows, int radius, uint64_t *hist, uint32_t *range, hipStream_t s) {
     hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, partial, nrows, radius - HIST_WIN / 2, hist, range);
     SZK_CHECK_LAUNCH();
@@ -4347,6 +4378,7 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
     szk_asm_params apv = asmp ? *asmp : szk_asm_params{};
     if (er && er->roles && asmp) {
         rp.on = 1;
+        rp.no_book = er->no_book ? 1u : 0u;
         rp.hist = er->hist;
         rp.cb = *er->cb;
         rp.used = info;

@@ -519,9 +519,10 @@ def test_speculative_code_book_is_confirmed_or_replaced():
     with THAT book while this call's is built from this call's histogram by a workgroup of the packer's launch; `finish` reads
     the verdict and repeats the encoder when the books differ. Whatever happens the payload is the one a fresh context
     produces: same array again (hit), another realisation of the field (miss), another bound (miss), the interpolation
-    predictor and wide alphabets (no speculation: their books need a compute unit's whole LDS), deltas that need two-byte codes
-    after a one-byte call (the one-launch form of stage 1 assumed one byte: the whole call is repeated, counted as a miss),
-    speculation switched off."""
+    predictor and wide alphabets (their books need a compute unit's whole LDS: built on a stream of their own beside the
+    encoder, joined in front of a verdict — hit, miss, first call of a predictor: not speculated), deltas that need two-byte
+    codes after a one-byte call (the one-launch form of stage 1 assumed one byte: the whole call is repeated, counted as a
+    miss), speculation switched off."""
     dev = torch.device("cuda:0")
     shape = (40, 64, 256)
     a = field3d(shape)
@@ -546,8 +547,8 @@ def test_speculative_code_book_is_confirmed_or_replaced():
     interp.absErrorBound = 1e-3
     # (array, config, expected outcome: +1 hit, -1 miss, 0 not speculated)
     steps = [(ta, _conf(shape, 1e-3), 0), (ta, _conf(shape, 1e-3), +1), (tb, _conf(shape, 1e-3), -1), (tb, _conf(shape, 1e-3), +1),
-             (ta, _conf(shape, 2e-3), -1), (ta, interp, 0), (ta, interp, 0), (ta, _conf(shape, 1e-6), -1), (ta, _conf(shape, 1e-6), 0),
-             (ta, _conf(shape, 1e-3), 0), (tb, _conf(shape, 1e-6), -1)]
+             (ta, _conf(shape, 2e-3), -1), (ta, interp, 0), (ta, interp, +1), (tb, interp, -1), (ta, _conf(shape, 1e-6), -1),
+             (ta, _conf(shape, 1e-6), 0), (ta, _conf(shape, 1e-3), 0), (tb, _conf(shape, 1e-6), -1)]  # (1e-6 on f32: long outlier lists, no speculation)
     for k, (t, conf, want) in enumerate(steps):
         h0, m0 = shared.spec_stats()
         got = run(shared, t, conf)
@@ -562,6 +563,44 @@ def test_speculative_code_book_is_confirmed_or_replaced():
     shared.forget()
     assert run(shared, ta, _conf(shape, 1e-3)) == run(sz3_amd.DeviceCompressor(n, np.float32), ta, _conf(shape, 1e-3))
     assert shared.spec_stats() == (h0, m0)  # a context that forgot its book does not speculate
+
+
+def test_speculative_wide_code_book_on_its_own_stream():
+    """Alphabets of thousands of symbols (C4: f64, deltas of thousands of lattice steps): the previous call's book packs while this
+    call's is built by k_codebook<1> on a stream of its own, a verdict joins them. Same array again: hit; another realisation:
+    miss, the encoder once more with the fresh book; a smooth field after a wide one (the wide form meets a small alphabet):
+    miss, stage 2 once more. Every payload is a fresh context's."""
+    dev = torch.device("cuda:0")
+    shape = (24, 96, 256)
+    a = field3d(shape, np.float64, sigma=2e-6)
+    b = field3d(shape, np.float64, seed=5, sigma=2e-6)
+    n = a.size
+    shared = sz3_amd.DeviceCompressor(n, np.float64)
+    shared.set_speculation(True, backoff=False)
+    cap = shared.payload_bound(n, worst_case=True)
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+
+    def run(dc, t, conf):
+        pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+        size = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+        dec = torch.empty_like(t)
+        dc.decompress(pl.data_ptr(), size, dec.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert float((dec - t).abs().max()) <= conf.absErrorBound
+        return pl[:size].cpu().numpy().tobytes(), dc.stats()["n_symbols"] if "n_symbols" in dc.stats() else 0
+
+    steps = [(ta, 1e-6, 0), (ta, 1e-6, +1), (tb, 1e-6, -1), (tb, 1e-6, +1), (ta, 1e-2, -1), (ta, 1e-2, +1), (ta, 1e-6, -1)]
+    for k, (t, eb, want) in enumerate(steps):
+        conf = _conf(shape, eb)
+        h0, m0 = shared.spec_stats()
+        got, _ = run(shared, t, conf)
+        h1, m1 = shared.spec_stats()
+        ref, _ = run(sz3_amd.DeviceCompressor(n, np.float64), t, conf)
+        assert got == ref, "step %d: payload depends on the context's history" % k
+        assert (h1 - h0, m1 - m0) == {0: (0, 0), 1: (1, 0), -1: (0, 1)}[want], "step %d: hits %d misses %d" % (k, h1 - h0, m1 - m0)
+    import szh_ref
+    h, _, _ = szh_ref.parse(run(sz3_amd.DeviceCompressor(n, np.float64), ta, _conf(shape, 1e-6))[0])
+    assert h["sym_count"] > 2000  # (the alphabet the first steps are about)
 
 
 @pytest.mark.parametrize("sigma,eb", [(2e-3, 1e-3), (8e-3, 1e-3), (3e-2, 1e-3)], ids=["smooth", "noisy", "rough"])

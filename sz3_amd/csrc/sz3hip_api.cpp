@@ -1181,6 +1181,8 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     // as long as the encoder's two passes take. It is built on a high-priority stream of its own, forked behind stage 1 and
     // enqueued BEFORE the encoder's launches (the workgroup is placed before the persistent packers fill the chip), and joined in
     // front of a one-workgroup verdict on the caller's stream; the list sorts ride in the packer's launch as in the small form.
+    // (Lists too long for the packer's sort roles — C3's 4096 anchors — were tried with a sort launch of their own in front of the
+    // encoder: C3 1.253 against 1.247 ms without, 1.33 with alternating fields. Not taken.)
     const bool spec_wide = !spec && book_spec_ok(ctx, ctx->proto.predictor, ctx->proto.radius) && ctx->cb_hint == 1 && !ctx->lists_long &&
                            !(szk_dbg_flags & 4096);
     int rc = stage2_launch(ctx, d_payload, cap, s, spec ? S2_SPEC : (spec_wide ? S2_SPEC_WIDE : S2_CLASSIC));
@@ -1375,7 +1377,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     ctx->book_idx = ctx->book_pending;
     ctx->book_pred = st.hdr.predictor;
     ctx->book_radius = st.hdr.radius;
-    ctx->lists_long = st.hdr.n_vout > 2048 || st.hdr.n_dout > 2048;
+    ctx->lists_long = st.hdr.n_vout > 1024 || st.hdr.n_dout > 1024;  // (what the packer's sort roles take: ROLE_SORT_MAX)
     ctx->cb_hint = st.n_symbols > SZK_CB_SMALL_SYMS ? 1 : 0;
     if (st.hdr.predictor == 2) ctx->blk_wide = st.hdr.sym_count > 3000 ? 1 : 0;  // the block kernels' LDS histogram window of the next call
     ctx->stats.n = st.hdr.n;

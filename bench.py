@@ -209,9 +209,9 @@ def rooflines(w, acc, psize, ms_per_step, traffic_key):
         note = "read sizeof(T) twice, write 2 B of codes per element"
         k1_ms = acc.get("tuner", 0.0) + acc.get("lorenzo_quant_hist", float("nan"))
     elif w.algo == "composed":
-        k_bytes = w.n * (4 * w.esz + 2)  # input in (selection pass, fit pass), lattice values out and in again (the two block passes), one 2-byte code per element
-        kname = "stage 1 = k_blk_select + k_blk_fit + k_blk_lorenzo + side information (block-composed predictor, sz3hip_regress.hip)"
-        note = "read sizeof(T) twice, write + read sizeof(T) of lattice values, write 2 B of codes per element"
+        k_bytes = w.n * (2 * w.esz + 2)  # input in (selection pass, coding pass), one 2-byte code per element (the regression blocks' lattice values are a fraction)
+        kname = "stage 1 = k_blk_select + k_blk_fit (regression blocks) + k_blk_rows (Lorenzo elements) + side information (block-composed predictor, sz3hip_regress.hip)"
+        note = "read sizeof(T) twice, write 2 B of codes per element"
         k1_ms = acc.get("tuner", 0.0) + acc.get("lorenzo_quant_hist", float("nan"))
     elif w.algo == "lorenzo":
         stats = w.dc.stats()

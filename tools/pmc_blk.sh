@@ -11,9 +11,9 @@ f=glob.glob("/tmp/pb/*counter_collection.csv")[0]
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     k=r["Kernel_Name"]
-    if "k_blk_fit" in k or "k_blk_lorenzo" in k or "k_blk_select" in k:
-        if "16384" not in k and "k_blk_select" not in k: continue
-        acc[k.split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if "k_blk_fit" in k or "k_blk_lorenzo" in k or "k_blk_select" in k or "k_blk_rows" in k:
+        import re
+        acc[re.search(r"k_blk_\w+", k).group(0)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in acc: print(k, {c: "%.3g" % (sum(v)/len(v)) for c,v in acc[k].items()})
 PY
 done

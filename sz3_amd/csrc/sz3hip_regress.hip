@@ -88,6 +88,21 @@ __device__ __forceinline__ int64_t dpp_shr1_q(int64_t old, int64_t src) {
     return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
+// ... lane 0 reads zero (bound_ctrl)
+// (the result passes through an empty asm: left to itself the compiler folds the lane move into the subtraction that follows —
+// `v - dpp(v)` came out as `dpp(v) - v`, measured with a device printf: every x difference negated)
+__device__ __forceinline__ int32_t dpp_shr1_z(int32_t src) {
+    int32_t r = __builtin_amdgcn_update_dpp(0, src, 0x138, 0xf, 0xf, true);
+    asm volatile("" : "+v"(r));
+    return r;
+}
+__device__ __forceinline__ int64_t dpp_shr1_z(int64_t src) {
+    int32_t lo = __builtin_amdgcn_update_dpp(0, (int32_t)src, 0x138, 0xf, 0xf, true);
+    int32_t hi = __builtin_amdgcn_update_dpp(0, (int32_t)(src >> 32), 0x138, 0xf, 0xf, true);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
 struct BlkGeom {
     uint32_t bz, by, bx;
     uint32_t oz, oy, ox;  // origin of the block in the array
@@ -699,85 +714,117 @@ __global__ __launch_bounds__(256) void k_blk_rows(const T *__restrict__ in, uint
     const uint64_t d1 = p.d[1], d2 = p.d[2];
     const uint32_t B = CB ? (uint32_t)CB : p.B, nb1 = p.nb[1], nb2 = p.nb[2];
     const Q *qwork = reinterpret_cast<const Q *>(p.qwork);
-    const uint32_t TPB = (256u / B) * B, BPC = 256u / B;  // threads in use, blocks per run
-    const uint32_t t = threadIdx.x, bl = t / B, i2 = t - bl * B;
+    // A wave's first lane is a HALO lane: it holds the column left of the wave's 63 and codes nothing — the x difference of
+    // every column then comes from the neighbouring lane (DPP), no column is loaded twice, none behind a branch. 4 x 63 = 252
+    // columns per workgroup = 42 blocks of 6. (PMC of the first form, which loaded and quantised a left value per lane and
+    // counted, listed and indexed per element with wave operations: 163 vector + 160 scalar instructions per element, 1.15 ms.)
+    const uint32_t TPB = (252u / B) * B, BPC = 252u / B;  // columns coded per run, blocks per run
     const int lane = lane_id();
+    const uint32_t wv = threadIdx.x / WAVE;
+    const int col = (int)(wv * 63u) + lane - 1;  // column inside the run (-1: the run's own left halo)
+    const bool coder = lane > 0 && (uint32_t)col < TPB;
+    const uint32_t cu = coder ? (uint32_t)col : 0u, bl = cu / B, i2 = cu - bl * B;
+    const uint32_t peak_bin = HW / 2;  // bin of the code `radius` in the LDS window
     for (uint32_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
         const uint32_t xci = task % xchunks, r = task / xchunks, by = r % nb1, bz = r / nb1;  // (workgroup-uniform)
         const uint32_t oz = bz * B, oy = by * B, ez = min(B, (uint32_t)p.d[0] - oz), ey = min(B, (uint32_t)d1 - oy);
-        const uint32_t x = xci * TPB + t;
-        const bool xok = t < TPB && x < d2;
-        const uint32_t xc = xok ? x : (uint32_t)d2 - 1u;  // (a lane beyond the run / the row reads the row's last element: a valid address, its value unused)
+        const int64_t xs = (int64_t)xci * TPB + col;  // this lane's column of the array (-1 left of it, >= d2 right of it: zero)
+        const bool xin = xs >= 0 && xs < (int64_t)d2;
+        const bool xok = coder && xs < (int64_t)d2;   // codes an element
+        const uint32_t xc = xin ? (uint32_t)xs : 0u;  // (a lane outside the array reads column 0: a valid address, its value unused)
         const uint32_t bx = xc / B, ox = bx * B, ex = min(B, (uint32_t)d2 - ox);
-        const uint32_t bxl = xc ? (xc - 1) / B : 0u;  // block column of the left neighbour
-        // the predictor of the four blocks this thread's values come from: its own, the one above (by - 1), behind (bz - 1), both
+        // the predictor of the four blocks this lane's values come from: its own, the one above (by - 1), behind (bz - 1), both
         const uint32_t tk = (bz * nb1 + by) * nb2;
-        const int sid = (int)p.sel[tk + bx];
-        const bool reg_own = sid == 2, reg_up = by && p.sel[tk - nb2 + bx] == 2, reg_back = bz && p.sel[tk - nb1 * nb2 + bx] == 2,
-                   reg_bu = by && bz && p.sel[tk - nb1 * nb2 - nb2 + bx] == 2;
-        const bool lane0 = lane == 0 && xc > 0;
-        const bool lreg_own = lane0 && p.sel[tk + bxl] == 2, lreg_up = lane0 && by && p.sel[tk - nb2 + bxl] == 2,
-                   lreg_back = lane0 && bz && p.sel[tk - nb1 * nb2 + bxl] == 2, lreg_bu = lane0 && by && bz && p.sel[tk - nb1 * nb2 - nb2 + bxl] == 2;
+        const bool reg_own = xin && p.sel[tk + bx] == 2, reg_up = xin && by && p.sel[tk - nb2 + bx] == 2,
+                   reg_back = xin && bz && p.sel[tk - nb1 * nb2 + bx] == 2, reg_bu = xin && by && bz && p.sel[tk - nb1 * nb2 - nb2 + bx] == 2;
+        const bool any_reg = __ballot(reg_own || reg_up || reg_back || reg_bu) != 0;
         const bool act = xok && !reg_own;
-        if (t < BPC) s_reg[t] = 0;
+        if (threadIdx.x < BPC) s_reg[threadIdx.x] = 0;
         __syncthreads();
         if (xok && i2 == 0 && reg_own) s_reg[bl] = 1;
-        UQ P[MJ], PL[MJ];  // the previous plane: q~ at x and at x - 1, rows oy - 1 ..
+        // row offsets and validity: per task, not per plane
+        uint64_t rowoff[MJ];
+        bool rowin[MJ];
 #pragma unroll
-        for (int j = 0; j < MJ; j++) P[j] = PL[j] = 0;
+        for (int j = 0; j < MJ; j++) {
+            rowin[j] = (uint32_t)j <= ey && (j > 0 || by > 0);
+            rowoff[j] = (uint64_t)(rowin[j] ? oy + (uint32_t)j - 1 : 0u) * d2;
+        }
+        const uint32_t per = ez * ey * B;
+        const uint32_t li0 = bl * per + i2;  // position of the block's column inside the run's stretch of codes
+        uint32_t n_peak = 0, n_zero = 0;     // this lane's codes equal to the radius / zero (counted per lane, added per task)
+        UQ PD[MJ];  // the previous plane: x differences of q~, rows oy - 1 ..
+#pragma unroll
+        for (int j = 0; j < MJ; j++) PD[j] = 0;
         for (uint32_t kz = 0; kz <= ez; kz++) {  // planes oz - 1 .. oz + ez - 1
             const bool zin = kz > 0 || bz > 0;    // (the plane exists: below the array's first plane everything is zero)
-            const uint32_t zz = zin ? oz + kz - 1 : 0u;
-            T raw[MJ], rawl[MJ];
+            const uint64_t pb = (uint64_t)(zin ? oz + kz - 1 : 0u) * d1 * d2;
+            T raw[MJ];
 #pragma unroll
-            for (int j = 0; j < MJ; j++) {  // the plane's rows oy - 1 .. oy + ey - 1: every load first
-                const bool rin = zin && (uint32_t)j <= ey && (j > 0 || by > 0);
-                const uint32_t yy = rin ? oy + (uint32_t)j - 1 : 0u;
-                const uint64_t rb = ((uint64_t)(rin ? zz : 0u) * d1 + yy) * d2;
-                raw[j] = in[rb + xc];
-                rawl[j] = lane0 ? in[rb + xc - 1] : (T)0;
-            }
-            UQ C[MJ], CL[MJ];
+            for (int j = 0; j < MJ; j++) raw[j] = in[pb + rowoff[j] + xc];  // the plane's rows oy - 1 .. oy + ey - 1: every load first
+            UQ D[MJ];
+            uint32_t badmask = 0, outmask = 0;
+            UQ deltas[MJ];
 #pragma unroll
             for (int j = 0; j < MJ; j++) {
-                const bool rin = zin && (uint32_t)j <= ey && (j > 0 || by > 0);
-                const uint32_t yy = rin ? oy + (uint32_t)j - 1 : 0u;
-                const uint64_t rb = ((uint64_t)(rin ? zz : 0u) * d1 + yy) * d2;
-                // which block the row lies in: halo plane / halo row -> the blocks behind / above
-                const bool isreg = kz == 0 ? (j == 0 ? reg_bu : reg_back) : (j == 0 ? reg_up : reg_own);
-                const bool lisreg = kz == 0 ? (j == 0 ? lreg_bu : lreg_back) : (j == 0 ? lreg_up : lreg_own);
-                bool bad, badl;
+                const bool rin = zin && rowin[j] && xin;
+                bool bad;
                 const Q q = lat.quant(raw[j], bad);
-                const Q ql = lat.quant(rawl[j], badl);
-                UQ v = bad ? (UQ)0 : (UQ)q, vl = badl ? (UQ)0 : (UQ)ql;
-                if (__ballot(rin && isreg)) v = (rin && isreg) ? (UQ)qwork[rb + xc] : v;  // (a regression block's elements: what the fit pass stored)
-                if (rin && lisreg) vl = (UQ)qwork[rb + xc - 1];
-                v = rin && xok ? v : (UQ)0;
-                vl = rin && lane0 ? vl : (UQ)0;
-                C[j] = v;
-                CL[j] = (UQ)dpp_shr1_q((Q)vl, (Q)v);  // left neighbour: the previous lane's value; the wave's first lane looked its own up
+                UQ v = bad ? (UQ)0 : (UQ)q;
+                if (any_reg) {  // (a regression block's elements: the lattice values the fit pass stored)
+                    const bool isreg = kz == 0 ? (j == 0 ? reg_bu : reg_back) : (j == 0 ? reg_up : reg_own);
+                    if (__ballot(rin && isreg)) v = (rin && isreg) ? (UQ)qwork[pb + rowoff[j] + xc] : v;
+                }
+                v = rin ? v : (UQ)0;
+                const UQ vleft = (UQ)dpp_shr1_z((Q)v);  // the previous lane holds the column on the left (the halo lane: nothing, zero)
+                D[j] = v - vleft;
+                deltas[j] = 0;
                 if (kz > 0 && j > 0 && (uint32_t)j <= ey) {  // an element of the run: plane kz - 1, row j - 1 of its block
-                    const uint32_t i0 = kz - 1, i1 = (uint32_t)j - 1;
-                    const UQ delta = (C[j] - CL[j]) - (C[j - 1] - CL[j - 1]) - (P[j] - PL[j]) + (P[j - 1] - PL[j - 1]);  // wrap-around arithmetic
-                    const uint64_t gi = rb + xc;
-                    blk_vout<T>(p, act && bad, gi, raw[j]);  // (unpredictable: the raw value; its q~ is 0)
+                    const UQ delta = D[j] - D[j - 1] - PD[j] + PD[j - 1];  // wrap-around arithmetic like the plain Lorenzo stream
                     const bool inr = (UQ)(delta + (UQ)(p.radius - 1)) <= (UQ)(2 * p.radius - 2);
                     const uint32_t code = inr ? (uint32_t)(delta + (UQ)p.radius) : 0u;
-                    const uint32_t li = bl * (ez * ey * B) + (i0 * ey + i1) * ex + i2;  // position inside the run's stretch of codes
-                    if (act) s_codes[li] = (uint16_t)code;
-                    blk_count<HW>(lh, p, code, act);
-                    const unsigned long long pd = wave_append_slot(act && !inr, p.n_dout);
-                    if (act && !inr && pd < p.out_cap) {
+                    const uint32_t li = li0 + ((kz - 1) * ey + ((uint32_t)j - 1)) * ex;
+                    if (act) {
+                        s_codes[li] = (uint16_t)code;
+                        const bool is_peak = code == p.radius;
+                        n_peak += is_peak ? 1u : 0u;
+                        n_zero += code == 0u ? 1u : 0u;
+                        if (!is_peak && code != 0u) {  // (the peak is counted per lane: 64 lanes on one LDS address are 64 serial atomics)
+                            const uint32_t bin = code - (p.radius - HW / 2);
+                            if (bin < HW) atomicAdd(&lh[bin], 1u);
+                            else atomicAdd((unsigned long long *)&p.hist[code], 1ull);
+                        }
+                        badmask |= bad ? (1u << j) : 0u;
+                        outmask |= inr ? 0u : (1u << j);
+                    }
+                    deltas[j] = delta;
+                }
+            }
+            // the rare elements: unpredictable values (their raw value is listed), deltas beyond the radius (listed with the code's position)
+            if (__ballot((badmask | outmask) != 0)) {
+#pragma unroll
+                for (int j = 1; j < MJ; j++) {
+                    const bool wb = (badmask >> j) & 1u, wo = (outmask >> j) & 1u;
+                    if (!__ballot(wb || wo)) continue;
+                    const uint64_t gi = pb + rowoff[j] + xc;
+                    blk_vout<T>(p, wb, gi, raw[j]);
+                    const unsigned long long pd = wave_append_slot(wo, p.n_dout);
+                    if (wo && pd < p.out_cap) {
                         const uint64_t base = (uint64_t)oz * d1 * d2 + (uint64_t)ez * ((uint64_t)oy * d2 + (uint64_t)ey * (xci * TPB));
-                        p.dout_idx[pd] = base + li;  // (position of the code, not of the element: the decoder expands the codes in place)
-                        reinterpret_cast<Q *>(p.dout_val)[pd] = (Q)delta;
+                        p.dout_idx[pd] = base + li0 + ((kz - 1) * ey + ((uint32_t)j - 1)) * ex;  // (position of the code, not of the element)
+                        reinterpret_cast<Q *>(p.dout_val)[pd] = (Q)deltas[j];
                     }
                 }
             }
 #pragma unroll
-            for (int j = 0; j < MJ; j++) {
-                P[j] = C[j];
-                PL[j] = CL[j];
+            for (int j = 0; j < MJ; j++) PD[j] = D[j];
+        }
+        // the per-lane counts of the two special codes
+        {
+            const uint32_t wp = wave_sum(n_peak), wz = wave_sum(n_zero);
+            if (lane == 0) {
+                if (wp) atomicAdd(&lh[peak_bin], wp);
+                if (wz) atomicAdd((unsigned long long *)&p.hist[0], (unsigned long long)wz);
             }
         }
         __syncthreads();
@@ -785,9 +832,9 @@ __global__ __launch_bounds__(256) void k_blk_rows(const T *__restrict__ in, uint
         // block's codes are the fit pass's
         {
             const uint32_t x0 = xci * TPB, xend = min((uint32_t)d2, x0 + TPB);
-            const uint32_t total = ez * ey * (xend - x0), per = ez * ey * B;
+            const uint32_t total = ez * ey * (xend - x0);
             const uint64_t base = (uint64_t)oz * d1 * d2 + (uint64_t)ez * ((uint64_t)oy * d2 + (uint64_t)ey * x0);
-            for (uint32_t i = t; i < total; i += 256)
+            for (uint32_t i = threadIdx.x; i < total; i += 256)
                 if (!s_reg[i / per]) codes[base + i] = s_codes[i];
         }
         __syncthreads();
@@ -1435,7 +1482,7 @@ int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const 
         const uint32_t grid = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                        \
         hipLaunchKernelGGL((k_blk_fit<T, HW, CBV, NW>), dim3(grid), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks);          \
         if (by_element) {                                                                                                              \
-            const uint32_t tpb = (256u / p->B) * p->B, xchunks = (uint32_t)((p->d[2] + tpb - 1) / tpb);                                  \
+            const uint32_t tpb = (252u / p->B) * p->B, xchunks = (uint32_t)((p->d[2] + tpb - 1) / tpb);                                  \
             const uint64_t ntasks = (uint64_t)p->nb[0] * p->nb[1] * xchunks;                                                            \
             hipLaunchKernelGGL((k_blk_rows<T, HW, CBV>), dim3((uint32_t)std::min<uint64_t>(ntasks, BLK_GRID)), dim3(256), 0, s,           \
                                (const T *)d_in, codes, *p, (uint32_t)ntasks, xchunks);                                                  \

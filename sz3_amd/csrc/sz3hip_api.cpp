@@ -1183,8 +1183,9 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     // front of a one-workgroup verdict on the caller's stream; the list sorts ride in the packer's launch as in the small form.
     // (Lists too long for the packer's sort roles — C3's 4096 anchors — were tried with a sort launch of their own in front of the
     // encoder: C3 1.253 against 1.247 ms without, 1.33 with alternating fields. Not taken.)
+    // (Not for block streams: their side section is copied by the assembly's list workgroups, which the sort roles replace.)
     const bool spec_wide = !spec && book_spec_ok(ctx, ctx->proto.predictor, ctx->proto.radius) && ctx->cb_hint == 1 && !ctx->lists_long &&
-                           !(szk_dbg_flags & 4096);
+                           ctx->proto.predictor != 2 && !(szk_dbg_flags & 4096);
     int rc = stage2_launch(ctx, d_payload, cap, s, spec ? S2_SPEC : (spec_wide ? S2_SPEC_WIDE : S2_CLASSIC));
     if (rc) return rc;
     ctx->stage2_done = true;

@@ -271,3 +271,39 @@ def test_selection_pass_agrees_with_the_oracle_on_which_fields_are_all_lorenzo()
         blob, _ = sz3_amd.compress(a, c)
         h, _, _ = szh_ref.parse(_payload_of(blob))
         assert (h["predictor"] == 0) == o_all == (want == 0), (h["predictor"], o_all)
+
+
+def test_block_stream_with_a_wide_alphabet_on_a_reused_context():
+    """A context's later calls differ from its first: the 16384-bin histogram window forms of the block kernels (taken after a call
+    that met more than 3000 symbols), whatever stage 2 takes over from the previous call's code book. C4-like field (deltas of
+    thousands of lattice steps, regression chosen next to never; the block stream is forced): three calls on one context, the
+    same payload each time, every one decodes within the bound; the codes by rows of blocks equal the tile pass's."""
+    import torch
+    dev = torch.device("cuda:0")
+    shape, eb = (30, 96, 256), 1e-6
+    a = field3d(shape, np.float64, sigma=2e-6)
+    t = torch.from_numpy(a).to(dev)
+    L = sz3_amd.lib()
+    payloads = {}
+    for name, flags in (("rows", NO_EXIT), ("tiles", NO_EXIT | 67108864)):
+        L.sz3hip_debug_flags(flags)
+        try:
+            dc = sz3_amd.DeviceCompressor(a.size, np.float64)
+            conf = _conf(shape, eb, 1, 0, 1)
+            cap = dc.payload_bound_conf(conf, worst_case=True)
+            got = []
+            for _ in range(3):
+                pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+                n = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+                dec = torch.empty_like(t)
+                dc.decompress(pl.data_ptr(), n, dec.data_ptr(), 0)
+                torch.cuda.synchronize()
+                assert float((dec - t).abs().max()) <= eb
+                got.append(pl[:n].cpu().numpy().tobytes())
+            assert got[0] == got[1] == got[2], "the payload depends on the context's history"
+            payloads[name] = got[0]
+        finally:
+            L.sz3hip_debug_flags(0)
+    h, _, sec = szh_ref.parse(payloads["rows"])
+    assert h["predictor"] == 2 and h["sym_count"] > 3000
+    assert payloads["rows"] == payloads["tiles"]

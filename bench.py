@@ -193,7 +193,7 @@ def rooflines(w, acc, psize, ms_per_step, traffic_key):
     out = {}
     k1_ms = acc.get("k1_kernel", acc.get("lorenzo_quant_hist", float("nan")))
     # device time of one step: from the first launch of stage 1 to the end of the last kernel of stage 2, HIP events on the caller's
-    # stream (the code book is built beside the encoder on a side stream: the stages' own times overlap and do not add up)
+    # stream (a wide alphabet's code book is built beside the encoder on a stream of its own: the stages' own times overlap and do not add up)
     kernels_ms = acc.get("step_span", sum(acc.get(k, 0.0) for k in ("tuner", "lorenzo_quant_hist", "codebook", "encode", "assemble")))
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")

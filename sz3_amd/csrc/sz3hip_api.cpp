@@ -540,7 +540,7 @@ static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *
     if (ctx->hist_exposed && p.hint_narrow > 0) p.hint_narrow = -1;
     if (allow_narrow && book_spec_ok(ctx, 0, (uint32_t)radius) && ctx->cb_hint == 0 && !ctx->lists_long && !ctx->hist_exposed) {
         // stage 2 will pack with the previous call's book: its code lengths let the one-byte kernel sum the code bits of the
-        // 256-element segments (no bits pass), and the fold of the histogram rows moves to the side stream the new book is built on
+        // 256-element segments (no bits pass), and the fold of the histogram rows moves into the scan's launch of stage 2
         p.spec_lens = ctx->bk[ctx->book_idx].lens;
         p.seg_bits = ctx->d_seg_bits;
         p.seg_made = reinterpret_cast<uint32_t *>(ctx->d_counters + 10) + 1;  // zeroed with the counters
@@ -1169,13 +1169,12 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     ctx->s2_cap = cap;
     // Speculation: the code book of a series of similar arrays repeats (it is a function of the code lengths alone), and building
     // it is a serial chain the chip idles through. A context whose previous call left a book for the same predictor and radius
-    // packs with THAT book on the caller's stream while this call's book is built from this call's histogram on the side
-    // stream; finish() compares the two and repeats the encoder when they differ. The book a payload is coded with is always
-    // the one its own histogram gives.
+    // packs with THAT book while this call's is built from this call's histogram — by a workgroup of the packer's own launch
+    // (alphabets <= 256 symbols) or on a stream of its own (wide ones); a verdict compares the two and finish() repeats the
+    // encoder when they differ. The book a payload is coded with is always the one its own histogram gives.
     bool spec = ctx->proto.predictor == 0 ? ctx->s1_spec : book_spec_ok(ctx, ctx->proto.predictor, ctx->proto.radius);
-    // The one-stream form only: small alphabet, short outlier lists, range words kept by stage 1 (what a smooth field's previous
-    // call left). Building a wide alphabet's book on a side stream beside the encoder was built and measured slower than
-    // building it first (C3: 1.34 against 1.24 ms — two cross-stream dependencies cost more than the 0.15 ms they hide).
+    // The one-stream form: small alphabet, short outlier lists, range words kept by stage 1 (what a smooth field's previous
+    // call left).
     if (spec && !(ctx->cb_hint == 0 && !ctx->lists_long && ctx->range_ready && !ctx->hist_exposed)) spec = false;
     // Wide alphabets (round 3, second attempt): the book needs a compute unit's whole LDS and 0.15 - 0.3 ms of ONE workgroup —
     // as long as the encoder's two passes take. It is built on a high-priority stream of its own, forked behind stage 1 and

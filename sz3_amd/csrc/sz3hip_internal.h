@@ -59,7 +59,7 @@ struct sz3hip_ctx {
     size_t s2_cap;
     // Two code books: bk[book_idx] is the last one a call of this context completed with (-1: none yet). Stage 2 builds this
     // call's book into the other slot; when the previous book may still apply (same predictor / radius) the encoder runs with
-    // it on the caller's stream while the new one is built on the side stream, and finish() repeats the encoder only when
+    // it while the new one is built beside the encoder (a workgroup of the packer's launch / a stream of its own), and finish() repeats the encoder only when
     // the two differ (the payload is a function of the input alone either way).
     struct Book {
         uint32_t *enc;
@@ -83,7 +83,7 @@ struct sz3hip_ctx {
     uint32_t redo_calls;     // statistics: calls repeated from stage 1
     bool s1_spec;          // stage 2 speculates (same condition, evaluated once per call)
     bool seg_expected;     // stage 1 sums the code bits per 256-element segment: stage 2 launches no bits pass
-    uint32_t fold_rows;    // != 0: the fold of stage 1's histogram rows was left to stage 2 (side stream)
+    uint32_t fold_rows;    // != 0: the fold of stage 1's histogram rows was left to stage 2 (it rides in the scan's launch)
     uint32_t *fold_range;
     uint16_t *d_seg_bits;  // [max_n / 256 + 8]
     int blk_wide;           // block predictor: wide LDS histogram window (from the previous call's alphabet)

@@ -356,6 +356,14 @@ extern "C" void *sz3hip_histogram_ptr(sz3hip_ctx *ctx) {
     ctx->hist_exposed = true;  // (whoever holds the pointer may change the histogram between the stages)
     return ctx->d_hist;
 }
+// The library's own exchange (sz3hip_comm_allreduce_histogram): the histogram is summed over the ranks ON THE COMPRESS STREAM between
+// stage 1 and stage 2 and by nobody else — known well enough for stage 2 to speculate on the previous call's (global) code book:
+// stage 1 completes its histogram itself (the exchange needs it whole) and waits for the probe (the one-launch form's repeat of a
+// whole call could not redo the exchange); stage 2 recounts the alphabet's range from the summed histogram.
+void *szi_histogram_for_exchange(sz3hip_ctx *ctx) {
+    ctx->hist_reduced = true;
+    return ctx->d_hist;
+}
 extern "C" size_t sz3hip_histogram_len(const sz3hip_ctx *) { return SZH_HIST_BINS; }
 extern "C" int sz3hip_ctx_set_histogram(sz3hip_ctx *ctx, void *d_hist) {
     ctx->d_hist = d_hist ? (uint64_t *)d_hist : ctx->d_hist_own;
@@ -450,7 +458,7 @@ static void cb_params_from(sz3hip_ctx *ctx, szk_cb_params &cb, uint64_t out_cap,
     cb.t_is_32bit = cb.q_is_32bit = ctx->dtype == SZ3HIP_FLOAT;
     cb.info = ctx->bk[slot].info;
     cb.n_books = 1;
-    cb.range_ready = ctx->range_ready && !ctx->hist_exposed;
+    cb.range_ready = ctx->range_ready && !ctx->hist_exposed && !ctx->hist_reduced;
     cb.part_hint = (szk_dbg_flags & 131072) ? -1 : ctx->cb_hint;
     cb.mispredict = reinterpret_cast<uint32_t *>(ctx->d_counters + 7);  // (zeroed with the counters)
 }
@@ -537,14 +545,14 @@ static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *
     p.hint_narrow = allow_narrow ? ctx->narrow_hint : -1;
     // (a caller that holds the histogram exchanges it between the stages — multi-GPU: the one-launch form's repeat of a whole
     // call from inside finish() could not redo that exchange, so such contexts keep the form that waits for the probe)
-    if (ctx->hist_exposed && p.hint_narrow > 0) p.hint_narrow = -1;
+    if ((ctx->hist_exposed || ctx->hist_reduced) && p.hint_narrow > 0) p.hint_narrow = -1;
     if (allow_narrow && book_spec_ok(ctx, 0, (uint32_t)radius) && ctx->cb_hint == 0 && !ctx->lists_long && !ctx->hist_exposed) {
         // stage 2 will pack with the previous call's book: its code lengths let the one-byte kernel sum the code bits of the
         // 256-element segments (no bits pass), and the fold of the histogram rows moves into the scan's launch of stage 2
         p.spec_lens = ctx->bk[ctx->book_idx].lens;
         p.seg_bits = ctx->d_seg_bits;
         p.seg_made = reinterpret_cast<uint32_t *>(ctx->d_counters + 10) + 1;  // zeroed with the counters
-        p.defer_fold = ctx->hist_exposed || (szk_dbg_flags & 16777216) ? 0 : 1;  // (a caller that holds the histogram wants it complete after stage 1)
+        p.defer_fold = ctx->hist_exposed || ctx->hist_reduced || (szk_dbg_flags & 16777216) ? 0 : 1;  // (whoever exchanges the histogram wants it complete after stage 1)
     }
     p.prof_ev0 = p.prof_ev1 = nullptr;
     if (ctx->profiling && allow_narrow) {  // (the production call, not the tuner's trial): events around the kernel itself
@@ -1175,7 +1183,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     bool spec = ctx->proto.predictor == 0 ? ctx->s1_spec : book_spec_ok(ctx, ctx->proto.predictor, ctx->proto.radius);
     // The one-stream form: small alphabet, short outlier lists, range words kept by stage 1 (what a smooth field's previous
     // call left).
-    if (spec && !(ctx->cb_hint == 0 && !ctx->lists_long && ctx->range_ready && !ctx->hist_exposed)) spec = false;
+    if (spec && !(ctx->cb_hint == 0 && !ctx->lists_long && (ctx->range_ready || ctx->hist_reduced) && !ctx->hist_exposed)) spec = false;
     // Wide alphabets (round 3, second attempt): the book needs a compute unit's whole LDS and 0.15 - 0.3 ms of ONE workgroup —
     // as long as the encoder's two passes take. It is built on a high-priority stream of its own, forked behind stage 1 and
     // enqueued BEFORE the encoder's launches (the workgroup is placed before the persistent packers fill the chip), and joined in
@@ -1207,6 +1215,11 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     szk_encode_roles er;
     memset(&er, 0, sizeof(er));
     if (fused) {
+        if (!cb.range_ready) {  // (the histogram was summed over the ranks since stage 1: the range of the SUMMED alphabet)
+            HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, 16, s));
+            if (szk_launch_hist_range(ctx->d_hist, cb.range, s)) return fail(SZ3HIP_EHIP, "histogram range launch failed");
+            cb.range_ready = 1;
+        }
         cb.part_hint = 0;
         er.roles = 1;
         er.hist = ctx->d_hist;

@@ -220,7 +220,7 @@ extern "C" int sz3hip_comm_allreduce_histogram(sz3hip_comm *c, sz3hip_ctx *const
     std::vector<void *> bufs(c->comms.size());
     for (size_t i = 0; i < bufs.size(); i++) {
         if (!ctxs[i]) return szi_fail(SZ3HIP_EINVAL, "member %zu has no context", i);
-        bufs[i] = sz3hip_histogram_ptr(ctxs[i]);
+        bufs[i] = szi_histogram_for_exchange(ctxs[i]);
     }
     return allreduce_members(c, bufs.data(), sz3hip_histogram_len(ctxs[0]), ncclUint64, ncclSum, streams);
 }

@@ -13,6 +13,8 @@
 
 // records code + message for sz3hip_last_error() (thread-local) and returns code
 int szi_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+struct sz3hip_ctx;
+void *szi_histogram_for_exchange(sz3hip_ctx *ctx);  // the histogram, for the library's own all-reduce between the stages (sz3hip_api.cpp)
 
 struct Writer {
     unsigned char *p;
@@ -95,6 +97,7 @@ struct sz3hip_ctx {
     uint64_t *d_blk_counters;  // [8]
     uint8_t *h_blk_side_hdr;   // pinned, 32 bytes
     void *d_half32;            // f64 decoder: int32 intermediates of the half-width chain (max_n * 4 bytes, lazily)
+    bool hist_reduced;         // the library's own exchange sums the histogram between the stages (szi_histogram_for_exchange)
     uint64_t blk_sel_cap;      // blocks d_blk_sel / d_blk_coef hold
     bool blk_sel_given;        // the selection pass of this call wrote them
     uint64_t blk_others;       // the last selection pass: blocks that would not be coded by first-order Lorenzo

@@ -299,6 +299,7 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
 // once the side stream has joined
 int szk_launch_book_verdict(const szk_cb_info *fresh, const uint8_t *fresh_lens, const szk_cb_info *used, const uint8_t *used_lens,
                             const uint32_t *mispredict, const uint32_t *range, szk_state *state, hipStream_t s);
+int szk_launch_hist_range(const uint64_t *d_hist, uint32_t *range /* [4], zeroed */, hipStream_t s);  // range and count of the non-empty bins
 int szk_launch_hist_fold(const uint32_t *partial, uint32_t nrows, int radius, uint64_t *hist, uint32_t *range, hipStream_t s);
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t,

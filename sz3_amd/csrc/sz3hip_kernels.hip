@@ -4339,6 +4339,11 @@ int szk_launch_book_verdict(const szk_cb_info *fresh, const uint8_t *fresh_lens,
     SZK_CHECK_LAUNCH();
     return 0;
 }
+int szk_launch_hist_range(const uint64_t *d_hist, uint32_t *range, hipStream_t s) {
+    hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256, 1), dim3(256), 0, s, d_hist, range);
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
 int szk_launch_hist_fold(const uint32_t *partial, uint32_t nrows, int radius, uint64_t *hist, uint32_t *range, hipStream_t s) {
     hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, partial, nrows, radius - HIST_WIN / 2, hist, range);
     SZK_CHECK_LAUNCH();

@@ -249,6 +249,27 @@ def test_rank_mode_compress_and_container_assembly():
             dc.decompress(pl.data_ptr(), size, out.data_ptr(), s.cuda_stream)
         s.synchronize()
         assert float((out.double() - t.double()).abs().max().item()) <= 1e-3
+        # a rank's later calls: stage 2 packs with the previous call's (global) book while this call's is built from the summed
+        # histogram — confirmed on the same array, replaced on another; every payload is what a context without a history and
+        # without the exchange produces
+        c3.regression = 0
+        dc.set_speculation(True, backoff=False)
+        b = field3d(shape, seed=9)
+        tb = torch.from_numpy(b).cuda()
+        sc = D.SlabCompressor(None, dc, comm=comm)
+        for tt, want in ((t, None), (t, (1, 0)), (tb, (0, 1)), (tb, (1, 0))):
+            h0, m0 = dc.spec_stats()
+            with torch.cuda.stream(s):
+                size = sc.compress(c3, tt.data_ptr(), pl.data_ptr(), cap, s.cuda_stream)
+            s.synchronize()
+            h1, m1 = dc.spec_stats()
+            ref_dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+            pl2 = torch.empty(cap, dtype=torch.uint8, device="cuda")
+            n2 = ref_dc.compress(c3, tt.data_ptr(), pl2.data_ptr(), cap, 0)
+            torch.cuda.synchronize()
+            assert size == n2 and torch.equal(pl[:size], pl2[:n2])
+            if want is not None:
+                assert (h1 - h0, m1 - m0) == want
     finally:
         comm.close()
 

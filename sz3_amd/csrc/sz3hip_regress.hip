@@ -583,6 +583,15 @@ __global__ __launch_bounds__(NW * 64) void k_blk_fit(const T *__restrict__ in, u
     for (uint32_t task = blockIdx.x * NW + wv; task < nblocks; task += gridDim.x * NW) {
         if (p.sel_given && p.sel[task] != 2) continue;  // (not a regression block: k_blk_lattice wrote its lattice values)
         const BlkGeom g = blk_geom(p, task);
+        if (p.sel_given) {
+            // a regression block coded from the selection pass's coefficients: its own elements are all it reads (no estimates, no halo)
+            const uint32_t nown = g.ez * g.ey * g.ex;
+            for (uint32_t t = lane; t < nown; t += WAVE) {
+                uint32_t i0, i1, i2;
+                own_index<CB>(g, t, i0, i1, i2);
+                sx[tv_at(tv, i0 + 2, i1 + 2, i2 + 2)] = in[((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2)];
+            }
+        } else
         // ---- originals of the block and two low halo layers, the halo on the lattice ----
         for (uint32_t t = lane; t < E * E * E; t += WAVE) {
             const uint32_t tx = t % E, ty = (t / E) % E, tz = t / (E * E);

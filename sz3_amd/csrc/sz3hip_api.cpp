@@ -1581,6 +1581,46 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     szk_host_offsets(&h, &o);
     if (o.end > payload_size || h.payload_bytes != o.end) return fail(SZ3HIP_EFORMAT, "truncated SZH1 payload");
     const uint8_t *pl = (const uint8_t *)d_payload;
+    szk_blk_params bp;
+    szk_blk_scratch sc;
+    if (h.predictor == 2) {
+        // block-composed stream: selection + coefficients from the side section — read, checked and unpacked first, on the side
+        // stream, while the Huffman decoder runs on the caller's
+        const uint32_t B = h.interp_id, mask = h.interp_dir;
+        if (h.ndim != 3 || B < 4 || B > 8 || mask == 0 || mask > 7 || h.side_bytes < 24 || h.n_dout > h.n)
+            return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block predictor fields)");
+        uint64_t nblocks = 1;
+        for (int i = 0; i < 3; i++) nblocks *= (h.dims[1 + i] + B - 1) / B;
+        if (nblocks > 0x7FFFFFF0ull) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block count)");
+        int rb = blk_reserve(ctx, nblocks);
+        if (rb) return rb;
+        HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr, pl + o.side, 24, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        uint32_t coding, sel_bits;
+        uint64_t nb_side, nr;
+        memcpy(&coding, ctx->h_blk_side_hdr, 4);
+        memcpy(&sel_bits, ctx->h_blk_side_hdr + 4, 4);
+        memcpy(&nb_side, ctx->h_blk_side_hdr + 8, 8);
+        memcpy(&nr, ctx->h_blk_side_hdr + 16, 8);
+        const uint64_t sel_bytes = ((nblocks + 3) / 4 + 7) & ~7ull;
+        const uint64_t ngroups = (nr + 63) / 64;
+        const uint64_t fixed = 24 + sel_bytes + 8 + 4 * ngroups;  // header, selection, Rice parameters, group offsets
+        if (coding != 1 || sel_bits != 2 || nb_side != nblocks || nr > nblocks || h.side_bytes < fixed || (h.side_bytes - fixed) % 4)
+            return fail(SZ3HIP_EFORMAT, "corrupt side section of a block-predictor stream");
+        const uint64_t bit_words = (h.side_bytes - fixed) / 4;
+        blk_params_from(ctx, h.dims + 1, B, mask, h.eb, (int)h.radius, 0, bp, sc);
+        memcpy(sc.side_hdr, ctx->h_blk_side_hdr, 24);
+        memcpy(sc.side_hdr + 24, &bit_words, 8);
+        if (!ctx->side) {
+            HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(ctx->ev_fork, s));  // (the payload is ready on the side stream when it is on the caller's)
+        HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        if (szk_launch_blk_side(&bp, &sc, pl, &o, ctx->d_blk_coef, ctx->side)) return fail(SZ3HIP_EHIP, "side section kernel launch failed");
+        HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
+    }
     prof_begin(ctx, ST_DEC_HUFF, s);
     int rc = szk_launch_dec_tables(pl + o.lens, h.sym_min, h.sym_count, ctx->d_tables, ovf, (const uint16_t *)(pl + o.chunkwords), h.n_chunks,
                                    ctx->d_chunk_off, ctx->d_counters + 3, s);
@@ -1666,35 +1706,8 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         ip.radius = (int)h.radius;
         rc = szk_launch_interp_decompress(ctx->dtype, &ip, pl, o.vout_idx, o.vout_val, h.n_vout, ctx->d_codes, d_out, s);
     } else if (h.predictor == 2) {
-        // block-composed stream: selection + coefficients from the side section, then the blocks in anti-diagonal fronts
-        const uint32_t B = h.interp_id, mask = h.interp_dir;
-        if (h.ndim != 3 || B < 4 || B > 8 || mask == 0 || mask > 7 || h.side_bytes < 24 || h.n_dout > h.n)
-            return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block predictor fields)");
-        uint64_t nblocks = 1;
-        for (int i = 0; i < 3; i++) nblocks *= (h.dims[1 + i] + B - 1) / B;
-        if (nblocks > 0x7FFFFFF0ull) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block count)");
-        int rb = blk_reserve(ctx, nblocks);
-        if (rb) return rb;
-        HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr, pl + o.side, 24, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        uint32_t coding, sel_bits;
-        uint64_t nb_side, nr;
-        memcpy(&coding, ctx->h_blk_side_hdr, 4);
-        memcpy(&sel_bits, ctx->h_blk_side_hdr + 4, 4);
-        memcpy(&nb_side, ctx->h_blk_side_hdr + 8, 8);
-        memcpy(&nr, ctx->h_blk_side_hdr + 16, 8);
-        const uint64_t sel_bytes = ((nblocks + 3) / 4 + 7) & ~7ull;
-        const uint64_t ngroups = (nr + 63) / 64;
-        const uint64_t fixed = 24 + sel_bytes + 8 + 4 * ngroups;  // header, selection, Rice parameters, group offsets
-        if (coding != 1 || sel_bits != 2 || nb_side != nblocks || nr > nblocks || h.side_bytes < fixed || (h.side_bytes - fixed) % 4)
-            return fail(SZ3HIP_EFORMAT, "corrupt side section of a block-predictor stream");
-        const uint64_t bit_words = (h.side_bytes - fixed) / 4;
-        szk_blk_params bp;
-        szk_blk_scratch sc;
-        blk_params_from(ctx, h.dims + 1, B, mask, h.eb, (int)h.radius, 0, bp, sc);
-        memcpy(sc.side_hdr, ctx->h_blk_side_hdr, 24);
-        memcpy(sc.side_hdr + 24, &bit_words, 8);
-        rc = szk_launch_blk_decompress(ctx->dtype, ctx->d_codes, d_out, &bp, &sc, pl, &h, &o, ctx->d_blk_coef, s);
+        // codes -> deltas, then the blocks in anti-diagonal fronts once the side stream has the choices and coefficients
+        rc = szk_launch_blk_decompress(ctx->dtype, ctx->d_codes, d_out, &bp, &sc, pl, &h, &o, ctx->d_blk_coef, s, ctx->ev_join);
     } else {
         rc = szk_launch_reconstruct(fuse_x ? 1 : 0, pl, &h, &o, ctx->d_codes, d_out, ctx->d_segtot, s, half ? ovf : nullptr, carry_in_scan);
     }

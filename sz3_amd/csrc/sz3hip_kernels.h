@@ -222,8 +222,11 @@ struct szk_blk_scratch {
 // the selection pass alone (a block per lane): *n_other += the blocks that would not be coded by first-order Lorenzo
 int szk_launch_blk_select(int dtype, const void *d_in, const szk_blk_params *p, uint64_t *n_other, hipStream_t s);
 int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s);
+// decoder, first part (stream-independent of the Huffman decoder): the side section -> sel[], rank[], coef_by_rank[]
+int szk_launch_blk_side(const szk_blk_params *p, const szk_blk_scratch *sc, const uint8_t *payload, const szh_offsets *o, int64_t *coef_by_rank,
+                        hipStream_t s);
 int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, const szk_blk_params *p, const szk_blk_scratch *sc,
-                              const uint8_t *payload, const szh_header *h, const szh_offsets *o, int64_t *coef_by_rank, hipStream_t s);
+                              const uint8_t *payload, const szh_header *h, const szh_offsets *o, int64_t *coef_by_rank, hipStream_t s, hipEvent_t side_done = nullptr);
 size_t szk_blk_side_bound(uint64_t nblocks);
 // codes -> lattice deltas (code - radius) in d_out, the delta outliers scattered over them (Lorenzo and block streams)
 int szk_launch_expand_deltas(int dtype, const uint16_t *codes, uint64_t n, int radius, const uint8_t *payload, const szh_offsets *o,

@@ -1552,8 +1552,10 @@ int szk_launch_blk_select(int dtype, const void *d_in, const szk_blk_params *p, 
 // worst case: every block a regression block, every coefficient escaped (4 x 88 bits)
 size_t szk_blk_side_bound(uint64_t nblocks) { return SIDE_HDR + ((nblocks + 3) / 4 + 16) + 8 + 4 * (nblocks / RICE_GROUP + 1) + nblocks * 44 + 64; }
 
-int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, const szk_blk_params *p, const szk_blk_scratch *sc,
-                              const uint8_t *payload, const szh_header *h, const szh_offsets *o, int64_t *coef_by_rank, hipStream_t s) {
+// the side section of a block stream -> choices, ranks, coefficients (0.7 ms of small, serial kernels at C4's slab: the decoder runs
+// them on a stream of their own beside the Huffman decoder, which they do not depend on)
+int szk_launch_blk_side(const szk_blk_params *p, const szk_blk_scratch *sc, const uint8_t *payload, const szh_offsets *o, int64_t *coef_by_rank,
+                        hipStream_t s) {
     const uint32_t nblocks = blk_count_blocks(p);
     const uint8_t *side = payload + o->side;
     // the side header was validated by the host (coding, counts, lengths)
@@ -1568,7 +1570,16 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
                            bit_words, coef_by_rank);
         hipLaunchKernelGGL(k_blk_coef_scan, dim3(1), dim3(1024), 0, s, nr, coef_by_rank);
     }
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
+int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, const szk_blk_params *p, const szk_blk_scratch *sc,
+                              const uint8_t *payload, const szh_header *h, const szh_offsets *o, int64_t *coef_by_rank, hipStream_t s,
+                              hipEvent_t side_done) {
+    const uint32_t nblocks = blk_count_blocks(p);
     if (szk_launch_expand_deltas(dtype, codes, h->n, (int)h->radius, payload, o, h->n_dout, p->qwork, s)) return -1;
+    // (the side section's kernels ran on another stream: the fronts are the first to need what they made)
+    if (side_done && hipStreamWaitEvent(s, side_done, 0) != hipSuccess) return -1;
     if (p->B == 6 && !(szk_dbg_flags & 8388608)) {  // groups of 2 x 2 x 2 blocks per workgroup (debug flag 8388608: a block per wave)
         const uint32_t ng0 = (p->nb[0] + 1) / 2, ng1 = (p->nb[1] + 1) / 2, ng2 = (p->nb[2] + 1) / 2;
         const uint32_t ngd = ng0 + ng1 + ng2 - 2;

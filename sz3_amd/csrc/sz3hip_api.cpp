@@ -1390,7 +1390,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     ctx->book_idx = ctx->book_pending;
     ctx->book_pred = st.hdr.predictor;
     ctx->book_radius = st.hdr.radius;
-    ctx->lists_long = st.hdr.n_vout > 1024 || st.hdr.n_dout > 1024;  // (what the packer's sort roles take: ROLE_SORT_MAX)
+    ctx->lists_long = st.hdr.n_vout > 2048 || st.hdr.n_dout > 2048;  // (what the packer's sort roles take: ROLE_SORT_MAX)
     ctx->cb_hint = st.n_symbols > SZK_CB_SMALL_SYMS ? 1 : 0;
     if (st.hdr.predictor == 2) ctx->blk_wide = st.hdr.sym_count > 3000 ? 1 : 0;  // the block kernels' LDS histogram window of the next call
     ctx->stats.n = st.hdr.n;

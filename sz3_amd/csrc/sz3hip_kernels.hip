@@ -2990,7 +2990,7 @@ __global__ __launch_bounds__(256) void k_assemble(szk_asm_params p) {
 // events: cross-stream dependencies cost more than the code book itself on this runtime. Two more workgroups sort the two
 // outlier lists (short ones: <= ROLE_SORT_MAX records each) and copy them into the payload.
 #define ROLE_BLOCKS 3u
-#define ROLE_SORT_MAX 1024u
+#define ROLE_SORT_MAX 2048u
 struct szk_role_params {
     uint32_t on;  // 0: no role blocks in this launch
     uint32_t no_book;  // the sort roles only
@@ -3062,7 +3062,7 @@ __device__ void role_book(const szk_role_params &rp, szk_state *state, uint8_t *
 // sort role: one outlier list (short) into index order, then into its section of the payload
 __device__ void role_sort(const szk_role_params &rp, const szk_asm_params &ap, bool d, uint8_t *pool) {
     const szk_cb_params &p = rp.cb;
-    uint64_t *sk = reinterpret_cast<uint64_t *>(pool), *sv = sk + ROLE_SORT_MAX;
+    uint64_t *sk = reinterpret_cast<uint64_t *>(pool);  // keys alone: (index << 16) | arrival position — 2048 of them in the 16 KB
     uint64_t *idx = d ? p.dout_idx : p.vout_idx;
     void *val = d ? p.dout_val : p.vout_val;
     const bool v32 = d ? p.q_is_32bit != 0 : p.t_is_32bit != 0;
@@ -3078,7 +3078,6 @@ __device__ void role_sort(const szk_role_params &rp, const szk_asm_params &ap, b
     while (np2 < n) np2 <<= 1;
     for (uint32_t i = threadIdx.x; i < np2; i += 256) {
         sk[i] = i < n ? (idx[i] << 16) | i : ~0ull;
-        if (i < n) sv[i] = v32 ? (uint64_t) reinterpret_cast<const uint32_t *>(val)[i] : reinterpret_cast<const uint64_t *>(val)[i];
     }
     __syncthreads();
     for (uint32_t k = 2; k <= np2; k <<= 1)
@@ -3099,12 +3098,19 @@ __device__ void role_sort(const szk_role_params &rp, const szk_asm_params &ap, b
     // the encoder be repeated with another book, its assemble workgroups copy the list as they find it
     const uint64_t o_i = d ? ap.state->off.dout_idx : ap.state->off.vout_idx, o_v = d ? ap.state->off.dout_val : ap.state->off.vout_val;
     uint64_t *pi = reinterpret_cast<uint64_t *>(ap.payload + o_i);
+    // the values follow their keys: from the list (still in arrival order) into the payload, then — all reads done — back
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const uint64_t k = sk[i];
-        pi[i] = idx[i] = k >> 16;
-        const uint64_t v = sv[(uint32_t)(k & 0xFFFFu)];
-        if (v32) reinterpret_cast<uint32_t *>(ap.payload + o_v)[i] = reinterpret_cast<uint32_t *>(val)[i] = (uint32_t)v;
-        else reinterpret_cast<uint64_t *>(ap.payload + o_v)[i] = reinterpret_cast<uint64_t *>(val)[i] = v;
+        const uint32_t from = (uint32_t)(k & 0xFFFFu);
+        pi[i] = k >> 16;
+        if (v32) reinterpret_cast<uint32_t *>(ap.payload + o_v)[i] = reinterpret_cast<const uint32_t *>(val)[from];
+        else reinterpret_cast<uint64_t *>(ap.payload + o_v)[i] = reinterpret_cast<const uint64_t *>(val)[from];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        idx[i] = sk[i] >> 16;
+        if (v32) reinterpret_cast<uint32_t *>(val)[i] = reinterpret_cast<const uint32_t *>(ap.payload + o_v)[i];
+        else reinterpret_cast<uint64_t *>(val)[i] = reinterpret_cast<const uint64_t *>(ap.payload + o_v)[i];
     }
 }
 template <uint32_t WIN>
@@ -3121,7 +3127,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     __shared__ __align__(8) uint32_t s_stage[4][STAGE_WORDS];
     const uint32_t roles = rp.on ? ROLE_BLOCKS : 0u;
     if (blockIdx.x < roles) {  // (the first workgroups dispatched; s_enc's 16 KB serve as their scratch)
-        static_assert(WIN * 4 >= ROLE_SORT_MAX * 16 && WIN * 4 >= CB_SMALL_SYMS * 28 + 256, "role scratch fits the table");
+        static_assert(WIN * 4 >= ROLE_SORT_MAX * 8 && WIN * 4 >= CB_SMALL_SYMS * 28 + 256, "role scratch fits the table");
         if (blockIdx.x == 0) {
             if (!rp.no_book) role_book(rp, ap.state, reinterpret_cast<uint8_t *>(s_enc));
         } else role_sort(rp, ap, blockIdx.x == 2, reinterpret_cast<uint8_t *>(s_enc));

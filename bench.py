@@ -410,6 +410,40 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cold:
         out["cold"] = w.cold_numbers(max(5, args.steps // 2), barrier)
+        # What `value` also leaves out, in the other direction: a producer with a SERIES of arrays keeps two contexts in flight on two
+        # streams — stage 1 of one call (bound by memory) runs beside stage 2 of the other (bound by instruction issue). Not `value`:
+        # a step of `value` is one call, finished before the next begins.
+        try:
+            w2 = Workload(torch, sz3_amd, dev, local_rank, rank + 1, shape, args.dtype, args.algo, args.eb, field=args.field)
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            pair = [w, w2]
+
+            def two(n):
+                pending = [False, False]
+                for i in range(n):
+                    k = i & 1
+                    st = streams[k].cuda_stream
+                    if pending[k]:
+                        pair[k].dc.finish(st)
+                    pair[k].dc.stage1(pair[k].conf, pair[k].d_in.data_ptr(), st)
+                    pair[k].dc.stage2(pair[k].d_payload.data_ptr(), pair[k].cap, st)
+                    pending[k] = True
+                for k in range(2):
+                    if pending[k]:
+                        pair[k].dc.finish(streams[k].cuda_stream)
+
+            two(8)
+            barrier()
+            t0 = time.perf_counter()
+            two(4 * args.steps)
+            torch.cuda.synchronize()
+            per = (time.perf_counter() - t0) / (4 * args.steps)
+            out["two_contexts_in_flight"] = {"ms_per_call": round(1e3 * per, 4), "gbps": round(raw_bytes / per / 1e9, 2),
+                                             "note": "two contexts alternating on two streams, the same workload (another realisation of the field on "
+                                                     "the second): one call's stage 1 beside the other's stage 2; informational, not `value`"}
+            del w2
+        except Exception as e:  # (memory for a second set of buffers, mostly)
+            out["two_contexts_in_flight"] = {"error": str(e)[:200]}
     # ---- host end-to-end (PCIe + zstd inclusive; informational) ----
     if rank == 0 and world == 1 and not args.no_host_e2e:
         best_c = best_d = 0.0

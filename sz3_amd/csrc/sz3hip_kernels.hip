@@ -4171,7 +4171,11 @@ static void launch_march_w(const void *d_in, uint16_t *codes, szk_k1_params &p, 
         // them all empty
         const uint32_t g1 = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 1, false>, (nb + 3) / 4);
         const uint32_t g2 = k1_grid((const void *)k_lorenzo_quant_march<T, NDIM, TY, 2, WIN16>, (nb + 3) / 4);
-        grid = g1 > g2 ? g1 : g2;  // (no hint about the code width: the encoder keeps its bits pass, seg_expected stays 0)
+        grid = g1 > g2 ? g1 : g2;
+        // (a context that may not take the one-launch form — its histogram is exchanged between the stages — but has the previous
+        // call's code lengths: the one-byte specialisation sums the segments' bits all the same; should the probe choose two
+        // bytes, the flag it leaves unset tells the packer's book role and stage 2 is repeated)
+        p.seg_expected = p.spec_lens && p.d[3] % MARCH_TX == 0;
         hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 1, false>), dim3(g1), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
         hipLaunchKernelGGL((k_lorenzo_quant_march<T, NDIM, TY, 2, WIN16>), dim3(g2), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
     } else {

@@ -375,6 +375,9 @@ def main():
     if rank == 0:
         is_c2 = args.algo == "lorenzo" and args.dtype == "f32" and tuple(shape) == (512, 512, 512) and args.eb == 1e-3
         is_c3 = args.algo == "interp" and args.dtype == "f32" and tuple(shape) == (512, 512, 512) and args.eb == 1e-4
+        # (the PMC passes of tools/pmc_blk.sh were taken on the benchmark field, where the selection hands the array to the plain path)
+        is_c4c = (args.algo == "composed" and args.dtype == "f64" and tuple(shape) == (128, 1024, 1024) and args.eb == 1e-6 and args.field == "default"
+                  and w.stream_predictor() == 0)
         out = {
             "metric": "compression throughput GB/s + ratio at fixed abs errBound, 512^3 f32",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

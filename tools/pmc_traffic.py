@@ -68,6 +68,30 @@ if os.path.exists(c3):
         out["c3_stage1_detail"] = detail
         out["c3_stage1_note"] = ("stage 1 of C3 per step = interpolation kernels (launches per step from profiles/r0x_kernel_stats_c3.csv x mean bytes per "
                                  "launch) + the code histogram; the level kernels read the input in place (no working copy)")
+# C4 slab with its specified predictor set (tools/pmc_blk.sh -> profiles/r03_pmc_blk_select.txt, the benchmark field: handed to the plain path)
+blk = os.path.join(ROOT, "profiles", "r03_pmc_blk_select.txt")
+if os.path.exists(blk):
+    import ast
+    per = {}
+    for ln in open(blk):
+        m = re.match(r"(k_\w+) (\{.*\})\s*$", ln.strip())
+        if not m: continue
+        for k, v in ast.literal_eval(m.group(2)).items():
+            per.setdefault(m.group(1), {})[k] = float(v)
+    tot = 0
+    for name in ("k_blk_select", "k_lorenzo_quant_march"):
+        if name in per:
+            # the doubling is calibrated for 16 B per lane only: the selection pass loads 8 B per lane
+            # (a block per lane), and doubled its count would mean 5.9 TB/s over a 0.42 ms kernel
+            wide = 2 if name == "k_lorenzo_quant_march" else 1
+            b = int((wide * per[name].get("FETCH_SIZE", 0) + per[name].get("WRITE_SIZE", 0)) * 1024)
+            out["c4_composed_%s_hbm_bytes_per_launch" % name] = b
+            tot += b
+    if tot:
+        out["c4_composed_stage1_hbm_bytes_per_step"] = tot
+        out["c4_composed_note"] = ("C4 slab (128x1024x1024 f64, 1e-6), Lorenzo + regression, benchmark field: stage 1 = selection pass + plain Lorenzo kernel; "
+                                   "algorithmic bytes 2 x 8 + 2 per element = 2.42 GB; FETCH_SIZE doubled for the Lorenzo kernel (16 B per lane), taken as reported for the "
+                                   "selection pass (8 B per lane: uncalibrated width, and doubled it would exceed what the kernel's 0.42 ms can carry)")
 out["method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 20 --warmup 3` (tools/pmc.sh); "
                  "mean per dispatch; FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for wide (16 B/lane) coalesced reads on gfx950; "
                  "WRITE_SIZE taken as reported (checks out: stage 1 writes 1 B/elem of codes = 134 MB, counter says 135 MB); counters are in KB (x1024). "

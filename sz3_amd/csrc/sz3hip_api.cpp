@@ -232,6 +232,7 @@ static void ctx_free(sz3hip_ctx *c) {
     if (c->h_trial) (void)hipHostFree(c->h_trial);
     if (c->h_passes) (void)hipHostFree(c->h_passes);
     if (c->h_np) (void)hipHostFree(c->h_np);
+    if (c->d_blk_carry) (void)hipFree(c->d_blk_carry);
     if (c->h_blk_side_hdr) (void)hipHostFree(c->h_blk_side_hdr);
     if (c->h_ovf) (void)hipHostFree(c->h_ovf);
     for (int i = 0; i < ST_COUNT; i++)
@@ -335,10 +336,23 @@ static size_t payload_bound_blocks(uint64_t n, uint64_t out_cap, uint64_t side_b
 // them (ceil(d / 4) <= d / 3). Thin arrays (an extent below 9: a one-plane slab, say) can have more — up to n / 4; stage 2
 // checks the caller's capacity against the blocks the call really has, and sz3hip_payload_bound_conf sizes a buffer for them.
 static size_t payload_bound_n(uint64_t n, uint64_t out_cap) { return payload_bound_blocks(n, out_cap, n / 27 + 64); }
+// shapes the block-composed predictor is built for: 3-D with block edges 4..8 (tiles in LDS), 1-D with blocks of 4..65535 values,
+// 2-D with block edges 4..32 (the decoder's block in LDS); second-order Lorenzo in 3-D only (decided where the set is known)
+static bool blk_shape_ok(const sz3hip_config *conf) {
+    if (conf->N == 3) return conf->blockSize >= 4 && conf->blockSize <= 8;
+    if (conf->N == 2) return conf->blockSize >= 4 && conf->blockSize <= 32;
+    if (conf->N == 1) return conf->blockSize >= 4 && conf->blockSize <= 65535;
+    return false;
+}
+// the kernels' view of the array: three extents, the caller's right-aligned (1-D: (1, 1, n), 2-D: (1, dy, dx))
+static void blk_view(int N, const uint64_t *dims, uint64_t *d3) {
+    for (int i = 0; i < 3; i++) d3[i] = 1;
+    for (int i = 0; i < N && i < 3; i++) d3[3 - N + i] = dims[i];
+}
 static uint64_t conf_blocks(const sz3hip_config *conf) {  // blocks the block-composed predictor would cut this array into (0: not its shape)
-    if (conf->N != 3 || conf->blockSize < 4 || conf->blockSize > 8) return 0;
+    if (!blk_shape_ok(conf)) return 0;
     uint64_t nb = 1;
-    for (int i = 0; i < 3; i++) nb *= (conf->dims[i] + (uint64_t)conf->blockSize - 1) / (uint64_t)conf->blockSize;
+    for (int i = 0; i < conf->N; i++) nb *= (conf->dims[i] + (uint64_t)conf->blockSize - 1) / (uint64_t)conf->blockSize;
     return nb;
 }
 extern "C" size_t sz3hip_payload_bound(const sz3hip_ctx *ctx, uint64_t n) { return payload_bound_n(n, ctx->out_cap); }
@@ -627,7 +641,7 @@ static int blk_reserve(sz3hip_ctx *ctx, uint64_t nblocks) {
     ctx->blk_cap = nblocks;
     return 0;
 }
-static void blk_params_from(sz3hip_ctx *ctx, const uint64_t *dims3, uint32_t B, uint32_t mask, double eb, int radius, uint64_t out_cap,
+static void blk_params_from(sz3hip_ctx *ctx, int ndim, const uint64_t *dims3, uint32_t B, uint32_t mask, double eb, int radius, uint64_t out_cap,
                             szk_blk_params &bp, szk_blk_scratch &sc) {
     memset(&bp, 0, sizeof(bp));
     memset(&sc, 0, sizeof(sc));
@@ -636,6 +650,8 @@ static void blk_params_from(sz3hip_ctx *ctx, const uint64_t *dims3, uint32_t B, 
         bp.nb[i] = (uint32_t)((dims3[i] + B - 1) / B);
     }
     bp.B = B;
+    bp.ndim = (uint32_t)ndim;
+    bp.carry = ctx->d_blk_carry;
     bp.mask = mask;
     bp.lat = szk_make_lattice(eb);
     bp.eb = eb;
@@ -658,7 +674,6 @@ static void blk_params_from(sz3hip_ctx *ctx, const uint64_t *dims3, uint32_t B, 
     sc.side = ctx->d_blk_side;
     sc.run_scratch = reinterpret_cast<uint32_t *>(ctx->d_blk_counters + 8);  // (the counter block holds 8 words + a run table)
 }
-static bool blk_shape_ok(const sz3hip_config *conf) { return conf->N == 3 && conf->blockSize >= 4 && conf->blockSize <= 8; }
 // The selection first (k_blk_select): when fewer than one block in 4096 would be coded by anything but first-order Lorenzo, every
 // block is — the stream is then the plain Lorenzo stream (same lattice, same stencil: a Lorenzo block's neighbours are lattice
 // values either way), made by the plain kernel and decoded by the global prefix sums instead of block fronts, and the selection
@@ -669,6 +684,7 @@ static int blk_all_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const voi
     *all = false;
     ctx->blk_sel_given = false;
     if (szk_dbg_flags & 2147483648u) return 0;  // (development: no selection pass, the fit pass chooses by its own wave sums)
+    if (conf->N != 3) return 0;                 // (1-D / 2-D: the fit pass chooses, a wave per block)
     const uint32_t B = (uint32_t)conf->blockSize;
     uint64_t nblocks = 1;
     for (int i = 0; i < 3; i++) nblocks *= (conf->dims[i] + B - 1) / B;
@@ -677,7 +693,7 @@ static int blk_all_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const voi
     if (rc) return rc;
     szk_blk_params bp;
     szk_blk_scratch sc;
-    blk_params_from(ctx, conf->dims, B, mask, eb, radius, ctx->cur_out_cap, bp, sc);
+    blk_params_from(ctx, 3, conf->dims, B, mask, eb, radius, ctx->cur_out_cap, bp, sc);
     HIPCHK(hipMemsetAsync(ctx->d_blk_counters + 7, 0, 8, s));
     prof_begin(ctx, ST_TUNER, s);
     rc = szk_launch_blk_select(ctx->dtype, d_in, &bp, ctx->d_blk_counters + 7, s);
@@ -694,14 +710,16 @@ static int blk_all_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const voi
 }
 static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint64_t num, uint32_t mask, hipStream_t s) {
     const uint32_t B = (uint32_t)conf->blockSize;
+    uint64_t d3[3];
+    blk_view(conf->N, conf->dims, d3);
     uint64_t nblocks = 1;
-    for (int i = 0; i < 3; i++) nblocks *= (conf->dims[i] + B - 1) / B;
+    for (int i = 0; i < 3; i++) nblocks *= (d3[i] + B - 1) / B;
     if (nblocks > 0x7FFFFFF0ull) return fail(SZ3HIP_EUNSUPPORTED, "too many blocks for the block-composed predictor");
     int rc = blk_reserve(ctx, nblocks);
     if (rc) return rc;
     szk_blk_params bp;
     szk_blk_scratch sc;
-    blk_params_from(ctx, conf->dims, B, mask, eb, radius, ctx->cur_out_cap, bp, sc);
+    blk_params_from(ctx, conf->N, d3, B, mask, eb, radius, ctx->cur_out_cap, bp, sc);
     bp.sel_given = ctx->blk_sel_given ? 1u : 0u;
     sc.wide_hist = ctx->blk_wide;
     HIPCHK(hipMemsetAsync(ctx->d_blk_counters, 0, 64, s));
@@ -716,12 +734,12 @@ static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
     h.magic = SZH_MAGIC;
     h.version = SZH_VERSION;
     h.dtype = (uint8_t)ctx->dtype;
-    h.ndim = 3;
+    h.ndim = (uint8_t)conf->N;
     h.qbytes = ctx->dtype == SZ3HIP_FLOAT ? 4 : 8;
     h.predictor = 2;
     h.radius = (uint32_t)radius;
     h.dims[0] = 1;
-    for (int i = 0; i < 3; i++) h.dims[1 + i] = conf->dims[i];
+    for (int i = 0; i < 3; i++) h.dims[1 + i] = d3[i];
     h.eb = eb;
     h.n = num;
     h.chunk_syms = SZH_CHUNK_SYMS;
@@ -1140,7 +1158,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
         const uint32_t mask = (conf->lorenzo ? 1u : 0u) | (conf->lorenzo2 ? 2u : 0u) | (conf->regression ? 4u : 0u);
         if (mask == 0) return fail(SZ3HIP_EINVAL, "All lorenzo and regression methods are disabled.");
         if (mask != 1u) {
-            if (blk_shape_ok(conf) && !(szk_dbg_flags & 16384)) {
+            if (blk_shape_ok(conf) && (conf->N == 3 || !(mask & 2u)) && !(szk_dbg_flags & 16384)) {
                 bool all_lorenzo = false;
                 const int rcs = blk_all_lorenzo(ctx, conf, d_in, eb, radius, mask, s, &all_lorenzo);
                 if (rcs) return rcs;
@@ -1148,8 +1166,8 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
                 return stage1_lorenzo(ctx, conf, d_in, eb, radius, num, s);  // (the selection chose first-order Lorenzo throughout)
             }
             if (!(mask & 1u))
-                return fail(SZ3HIP_EUNSUPPORTED, "2nd-order Lorenzo / regression without Lorenzo are built for 3-D arrays with blockSize 4..8 "
-                                                 "(got N = %d, blockSize = %d)", conf->N, conf->blockSize);
+                return fail(SZ3HIP_EUNSUPPORTED, "regression is built for 1-D (blockSize 4..65535), 2-D (4..32) and 3-D arrays (4..8), 2nd-order "
+                                                 "Lorenzo for 3-D ones (got N = %d, blockSize = %d)", conf->N, conf->blockSize);
         }
     }
     return stage1_lorenzo(ctx, conf, d_in, eb, radius, num, s);
@@ -1587,13 +1605,22 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         // block-composed stream: selection + coefficients from the side section — read, checked and unpacked first, on the side
         // stream, while the Huffman decoder runs on the caller's
         const uint32_t B = h.interp_id, mask = h.interp_dir;
-        if (h.ndim != 3 || B < 4 || B > 8 || mask == 0 || mask > 7 || h.side_bytes < 24 || h.n_dout > h.n)
+        const bool shape_ok = h.ndim == 3 ? B >= 4 && B <= 8 : (h.ndim == 2 ? B >= 4 && B <= 32 && h.dims[1] == 1 && !(mask & 2u)
+                                                                 : h.ndim == 1 && B >= 4 && B <= 65535 && h.dims[1] == 1 && h.dims[2] == 1 && !(mask & 2u));
+        if (!shape_ok || mask == 0 || mask > 7 || h.side_bytes < 24 || h.n_dout > h.n)
             return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block predictor fields)");
         uint64_t nblocks = 1;
         for (int i = 0; i < 3; i++) nblocks *= (h.dims[1 + i] + B - 1) / B;
         if (nblocks > 0x7FFFFFF0ull) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block count)");
         int rb = blk_reserve(ctx, nblocks);
         if (rb) return rb;
+        if (h.ndim == 1 && ctx->blk_carry_cap < nblocks) {  // 1-D: aggregate + inflow of every block (two lattice words)
+            if (ctx->d_blk_carry) HIPCHK(hipFree(ctx->d_blk_carry));
+            ctx->d_blk_carry = nullptr;
+            ctx->blk_carry_cap = 0;
+            HIPCHK(hipMalloc(&ctx->d_blk_carry, nblocks * 16));
+            ctx->blk_carry_cap = nblocks;
+        }
         HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr, pl + o.side, 24, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         uint32_t coding, sel_bits;
@@ -1608,7 +1635,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         if (coding != 1 || sel_bits != 2 || nb_side != nblocks || nr > nblocks || h.side_bytes < fixed || (h.side_bytes - fixed) % 4)
             return fail(SZ3HIP_EFORMAT, "corrupt side section of a block-predictor stream");
         const uint64_t bit_words = (h.side_bytes - fixed) / 4;
-        blk_params_from(ctx, h.dims + 1, B, mask, h.eb, (int)h.radius, 0, bp, sc);
+        blk_params_from(ctx, h.ndim, h.dims + 1, B, mask, h.eb, (int)h.radius, 0, bp, sc);
         memcpy(sc.side_hdr, ctx->h_blk_side_hdr, 24);
         memcpy(sc.side_hdr + 24, &bit_words, 8);
         if (!ctx->side) {

@@ -99,6 +99,8 @@ struct sz3hip_ctx {
     void *d_half32;            // f64 decoder: int32 intermediates of the half-width chain (max_n * 4 bytes, lazily)
     bool hist_reduced;         // the library's own exchange sums the histogram between the stages (szi_histogram_for_exchange)
     uint64_t blk_sel_cap;      // blocks d_blk_sel / d_blk_coef hold
+    void *d_blk_carry;         // 1-D block streams, decoder: [blocks][2] lattice words
+    uint64_t blk_carry_cap;
     bool blk_sel_given;        // the selection pass of this call wrote them
     uint64_t blk_others;       // the last selection pass: blocks that would not be coded by first-order Lorenzo
     uint64_t *d_vout_idx, *d_dout_idx;

@@ -195,7 +195,8 @@ struct szk_dec_params {
 struct szk_blk_params {
     uint64_t d[3];   // z, y, x extents
     uint32_t nb[3];  // blocks per dimension
-    uint32_t B;      // block edge, 4..8
+    uint32_t B;      // block edge: 4..8 (3-D); low-dimensional arrays (ndim 1, 2: the kernels see d = (1, 1, n) / (1, dy, dx)) up to 65535 / 32
+    uint32_t ndim;   // dimensions of the caller's array (1, 2, 3): the coefficient lattices' steps are eb / (ndim + 1) [/ B]
     uint32_t mask;   // enabled predictors: 1 Lorenzo-1 | 2 Lorenzo-2 | 4 regression
     szk_lattice lat;
     double eb;
@@ -210,6 +211,7 @@ struct szk_blk_params {
     void *qwork;     // [n] lattice values q~ (int32 / int64) the Lorenzo stencils run on
     uint64_t *n_reg; // number of regression blocks (counted by the fit pass; the rank pass writes the same number)
     uint32_t sel_given;  // sel[] / coef[] were written by k_blk_select: k_blk_fit codes what they say instead of fitting again
+    void *carry;         // low-dimensional decoder, ndim 1: [blocks][2] lattice words (a block's aggregate, then the value left of it)
 };
 struct szk_blk_scratch {
     uint32_t *rank, *comp;  // [blocks] rank among the regression blocks, compacted list of their ids

@@ -218,10 +218,10 @@ __device__ __forceinline__ T lorenzo_pred_orig(const RD &rd, uint32_t tz, uint32
 struct CoefLat {
     double step_lin, step_ind;  // 2 * eb of the two quantizers
 };
-__device__ __host__ __forceinline__ CoefLat coef_lat(double eb, uint32_t B) {
+__device__ __host__ __forceinline__ CoefLat coef_lat(double eb, uint32_t B, uint32_t ndim) {
     CoefLat c;
-    c.step_ind = 2.0 * (eb / 4.0);
-    c.step_lin = 2.0 * (eb / 4.0 / (double)B);
+    c.step_ind = 2.0 * (eb / (double)(ndim + 1));
+    c.step_lin = 2.0 * (eb / (double)(ndim + 1) / (double)B);
     return c;
 }
 template <typename T>
@@ -249,7 +249,7 @@ __device__ __forceinline__ void blk_fit_block(const T *sx, const TileView &tv, c
     const Lattice<T> lat(p.lat);
     const uint64_t d1 = p.d[1], d2 = p.d[2];
     Q *qwork = reinterpret_cast<Q *>(p.qwork);
-    const CoefLat cl = coef_lat(p.eb, p.B);
+    const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
     const double eb_recip = 1.0 / p.eb;
     const bool has_l1 = p.mask & 1u, has_l2 = p.mask & 2u, has_r = p.mask & 4u;
     auto rd = [&](uint32_t tz, uint32_t ty, uint32_t tx) -> T {
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void k_blk_select(const T *__restrict__ in, sz
             sid = 0;
         }
         if (sid == 2) {  // the coefficients onto their lattices; one its lattice cannot hold: Lorenzo-1
-            const CoefLat cl = coef_lat(p.eb, p.B);
+            const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
             int64_t lc[4];
             for (int i = 0; i < 4; i++) {
                 const double sc = (double)cf[i] / (i < 3 ? cl.step_lin : cl.step_ind);
@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(256) void k_blk_decode(const uint16_t *__restrict__
     const BlkGeom g = blk_geom(p, live ? task : 0);
     const uint32_t nown = live ? g.ez * g.ey * g.ex : 0;
     if (live && sid == 2) {  // regression: values, no dependency
-        const CoefLat cl = coef_lat(p.eb, p.B);
+        const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
         T rc[4];
         coef_recover(coef_by_rank + (uint64_t)rank[task] * 4, cl, rc);
         for (uint32_t t = lane; t < nown; t += WAVE) {
@@ -1368,7 +1368,7 @@ __global__ __launch_bounds__(512) void k_blk_decode_g(const uint16_t *__restrict
     Q own[OWN];
     const uint32_t nown = live ? g.ez * g.ey * g.ex : 0;
     {
-        const CoefLat cl = coef_lat(p.eb, p.B);
+        const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
         T rc[4] = {0, 0, 0, 0};
         if (live && sid == 2) coef_recover(coef_by_rank + (uint64_t)rank[task] * 4, cl, rc);
 #pragma unroll
@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(256) void k_blk_final(const uint16_t *__restrict__ 
     const uint64_t d1 = p.d[1], d2 = p.d[2];
     Q *qv = reinterpret_cast<Q *>(d_out);
     T *ov = reinterpret_cast<T *>(d_out);
-    const CoefLat cl = coef_lat(p.eb, p.B);
+    const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
     for (uint32_t task = blockIdx.x * 4 + threadIdx.x / WAVE; task < nblocks; task += gridDim.x * 4) {
         const BlkGeom g = blk_geom(p, task);
         const uint32_t nown = g.ez * g.ey * g.ex;
@@ -1467,6 +1467,371 @@ __global__ __launch_bounds__(256) void k_blk_patch(const uint8_t *__restrict__ p
         if (k < n) out[k] = val[i];
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// arrays of one and two dimensions (default blocks: 128 values / 16 x 16, Config.hpp:175)
+// ------------------------------------------------------------------------------------------------------------
+// The kernels see the array as d = (1, 1, n) or (1, dy, dx): the block walk, the code order (block by block, raster order inside),
+// the side section and the final pass are the 3-D path's with extents of one; a stencil term over a unit dimension reads the
+// zero halo and drops out, so the integer Lorenzo stencil IS the 1-D / 2-D one. What the dimension count changes: the fit's
+// sums and the coefficient lattices' steps (eb / (N + 1) [/ B], RegressionPredictor.hpp:22-26, 28-55), the selection's sample
+// points (BlockwiseIterator.hpp:151-184: a block's two ends in 1-D, the two diagonals in 2-D) and its Lorenzo noise term
+// (LorenzoPredictor.hpp:17-38: 0.5 eb / 0.81 eb) — and the decoder: blocks of 128 values do not fit the 3-D path's tiles, a chain
+// of 1-D blocks is not a front, so 1-D is a segmented prefix sum over the blocks (a regression block restarts the sum with the
+// lattice value of its last element) and 2-D runs anti-diagonal fronts of blocks with the block in LDS.
+// Encoder: k_blkn_fit (wave per block: fit, estimates, choice, regression blocks coded, q~ of every element to qwork), then
+// k_blkn_lorenzo (thread per CODE position: the stencil over q~, codes written where they lie — coalesced).
+
+// what the selection's Lorenzo estimate sees at (y, x): original inside the block, lattice reconstruction outside, zero outside the array
+template <typename T>
+__device__ __forceinline__ T blkn_seen(const T *__restrict__ in, const szk_blk_params &p, const Lattice<T> &lat, const BlkGeom &g, int64_t y, int64_t x) {
+    using Q = typename QTraits<T>::Q;
+    if (y < 0 || x < 0) return (T)0;
+    T v = in[(uint64_t)y * p.d[2] + (uint64_t)x];
+    if (y < (int64_t)g.oy || x < (int64_t)g.ox) {
+        bool bad;
+        const Q qh = lat.quant(v, bad);
+        if (!bad) v = lat.dequant(qh);
+    }
+    return v;
+}
+
+template <typename T, uint32_t HW>
+__global__ __launch_bounds__(256) void k_blkn_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
+    using Q = typename QTraits<T>::Q;
+    __shared__ uint32_t lh[HW];
+    for (uint32_t b = threadIdx.x; b < HW; b += 256) lh[b] = 0;
+    __syncthreads();
+    const Lattice<T> lat(p.lat);
+    const int lane = lane_id();
+    const uint32_t wv = threadIdx.x / WAVE;
+    const uint64_t d2 = p.d[2];
+    Q *qwork = reinterpret_cast<Q *>(p.qwork);
+    const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
+    const double eb_recip = 1.0 / p.eb;
+    const bool has_l1 = p.mask & 1u, has_r = p.mask & 4u, two = p.ndim == 2;
+    const T noise = (T)((two ? 0.81 : 0.5) * p.eb);
+    for (uint32_t task = blockIdx.x * 4 + wv; task < nblocks; task += gridDim.x * 4) {
+        const BlkGeom g = blk_geom(p, task);
+        const uint32_t nown = g.ey * g.ex;
+        // ---- regression fit (RegressionPredictor.hpp:28-55, N = 1 / 2) ----
+        const bool r_valid = has_r && g.ex > 1 && (!two || g.ey > 1);
+        T cf[4] = {0, 0, 0, 0};
+        if (r_valid) {
+            double s1 = 0, s2 = 0, s3 = 0;
+            for (uint32_t t = lane; t < nown; t += WAVE) {
+                const uint32_t i1 = t / g.ex, i2 = t - i1 * g.ex;
+                const T v = in[(uint64_t)(g.oy + i1) * d2 + (g.ox + i2)];
+                s1 += (double)((T)i1 * v);
+                s2 += (double)((T)i2 * v);
+                s3 += (double)v;
+            }
+            s1 = wave_sum_f64(s1);
+            s2 = wave_sum_f64(s2);
+            s3 = wave_sum_f64(s3);
+            const double dy = g.ey, dx = g.ex, num = dy * dx;
+            if (two) cf[1] = (T)((2 * s1 / (dy - 1) - s3) * 6 / num / (dy + 1));
+            cf[2] = (T)((2 * s2 / (dx - 1) - s3) * 6 / num / (dx + 1));
+            cf[3] = (T)(s3 / num);
+            if (two) cf[3] = (T)((double)cf[3] - (dy - 1) * (double)cf[1] / 2);
+            cf[3] = (T)((double)cf[3] - (dx - 1) * (double)cf[2] / 2);
+        }
+        // ---- selection (ComposedPredictor.hpp:25-40 over foreach_sampling) ----
+        int sid = has_l1 ? 0 : 2;
+        if (has_l1 && has_r) {
+            const uint32_t m = two ? min(g.ey, g.ex) : g.ex;
+            const uint32_t npts = two ? 2 * m : 2;
+            double e1 = 0, er = 0;
+            for (uint32_t k = lane; k < npts; k += WAVE) {
+                uint32_t i1 = 0, i2;
+                if (two) {
+                    i1 = k / 2;
+                    i2 = (k & 1) ? m - 1 - i1 : i1;
+                } else {
+                    i2 = k ? m - 1 : 0;
+                }
+                const int64_t y = (int64_t)g.oy + i1, x = (int64_t)g.ox + i2;
+                const T v = in[(uint64_t)y * d2 + (uint64_t)x];
+                T pr;  // LorenzoPredictor.hpp:61-64: N = 1: d[-1]; N = 2: (y, x-1) + (y-1, x) - (y-1, x-1)
+                if (two) pr = (T)((T)(blkn_seen(in, p, lat, g, y, x - 1) + blkn_seen(in, p, lat, g, y - 1, x)) - blkn_seen(in, p, lat, g, y - 1, x - 1));
+                else pr = blkn_seen(in, p, lat, g, y, x - 1);
+                e1 += (double)(T)((T)fabs((double)(T)(v - pr)) + noise);
+                if (r_valid) er += (double)(T)fabs((double)(T)(v - reg_predict(cf, 0u, i1, i2)));
+            }
+            e1 = wave_sum_f64(e1);
+            er = wave_sum_f64(er);
+            sid = (r_valid && er < e1) ? 2 : 0;
+        } else if (sid == 2 && !r_valid) {
+            sid = 0;  // BlockwiseDecomposition.hpp:35-37
+        }
+        int64_t lc[4] = {0, 0, 0, 0};
+        if (sid == 2) {  // coefficients onto their lattices; a coefficient the lattice cannot hold -> Lorenzo-1
+            bool ok = true;
+            for (int i = 1; i < 4; i++) {
+                const double sc = (double)cf[i] / (i < 3 ? cl.step_lin : cl.step_ind);
+                if (!(fabs(sc) < 4503599627370496.0)) ok = false;
+                else lc[i] = (int64_t)rint(sc);
+            }
+            if (!ok) sid = 0;
+        }
+        if (sid == 2) {
+            T rc[4];
+            coef_recover(lc, cl, rc);
+            for (uint32_t t0 = 0; t0 < nown; t0 += WAVE) {
+                const uint32_t t = t0 + lane;
+                const bool act = t < nown;
+                const uint32_t tt = act ? t : 0;
+                const uint32_t i1 = tt / g.ex, i2 = tt - i1 * g.ex;
+                const uint64_t gi = (uint64_t)(g.oy + i1) * d2 + (g.ox + i2);
+                const T raw = in[gi];
+                T v = raw;
+                const int code = act ? ref_quantize(v, reg_predict(rc, 0u, i1, i2), p.eb, eb_recip, (int)p.radius) : 1;
+                Q qt = 0;
+                if (code != 0) {
+                    bool bad;
+                    qt = lat.quant(v, bad);
+                    if (bad) qt = 0;
+                }
+                if (act) {
+                    codes[g.coff + t] = (uint16_t)code;
+                    qwork[gi] = qt;
+                }
+                blk_count<HW>(lh, p, (uint32_t)code, act);
+                blk_vout<T>(p, act && code == 0, gi, raw);
+            }
+            if (lane == 0)
+                for (int i = 0; i < 4; i++) p.coef[(uint64_t)task * 4 + i] = lc[i];
+        } else {
+            for (uint32_t t0 = 0; t0 < nown; t0 += WAVE) {
+                const uint32_t t = t0 + lane;
+                const bool act = t < nown;
+                const uint32_t tt = act ? t : 0;
+                const uint32_t i1 = tt / g.ex, i2 = tt - i1 * g.ex;
+                const uint64_t gi = (uint64_t)(g.oy + i1) * d2 + (g.ox + i2);
+                const T raw = in[gi];
+                bool bad;
+                Q q = lat.quant(raw, bad);
+                if (bad) q = 0;
+                if (act) qwork[gi] = q;
+                blk_vout<T>(p, act && bad, gi, raw);
+            }
+        }
+        if (lane == 0) p.sel[task] = (uint8_t)sid;
+    }
+    __syncthreads();
+    blk_flush<HW>(lh, p);
+}
+
+// code position -> block and element of the (1, dy, dx) view: the bands of B rows hold B * dx codes each, a band's blocks ey * B
+struct BlknPos {
+    uint32_t task, y, x, ox, oy;
+};
+__device__ __forceinline__ BlknPos blkn_pos(const szk_blk_params &p, uint64_t c) {
+    BlknPos r;
+    const uint64_t band = (uint64_t)p.B * p.d[2];
+    const uint32_t by = (uint32_t)(c / band);
+    const uint64_t rem = c - (uint64_t)by * band;
+    r.oy = by * p.B;
+    const uint32_t ey = min(p.B, (uint32_t)p.d[1] - r.oy);
+    const uint32_t bx = (uint32_t)(rem / ((uint64_t)ey * p.B));
+    const uint32_t rem2 = (uint32_t)(rem - (uint64_t)bx * ey * p.B);
+    r.ox = bx * p.B;
+    const uint32_t ex = min(p.B, (uint32_t)p.d[2] - r.ox);
+    const uint32_t j = rem2 / ex;
+    r.y = r.oy + j;
+    r.x = r.ox + (rem2 - j * ex);
+    r.task = by * p.nb[2] + bx;
+    return r;
+}
+
+template <typename T, uint32_t HW>
+__global__ __launch_bounds__(256) void k_blkn_lorenzo(uint16_t *__restrict__ codes, szk_blk_params p, uint64_t n) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    __shared__ uint32_t lh[HW];
+    for (uint32_t b = threadIdx.x; b < HW; b += 256) lh[b] = 0;
+    __syncthreads();
+    const Q *__restrict__ qw = reinterpret_cast<const Q *>(p.qwork);
+    const uint64_t d2 = p.d[2];
+    for (uint64_t c0 = (uint64_t)blockIdx.x * 256; c0 < n; c0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t c = c0 + threadIdx.x;
+        bool act = c < n;
+        const BlknPos e = blkn_pos(p, act ? c : 0);
+        act = act && p.sel[e.task] != 2;
+        UQ delta = 0;
+        if (act) {
+            const uint64_t gi = (uint64_t)e.y * d2 + e.x;
+            delta = (UQ)qw[gi];
+            if (e.x) delta -= (UQ)qw[gi - 1];
+            if (e.y) {
+                delta -= (UQ)qw[gi - d2];
+                if (e.x) delta += (UQ)qw[gi - d2 - 1];
+            }
+        }
+        const bool inr = (UQ)(delta + (UQ)(p.radius - 1)) <= (UQ)(2 * p.radius - 2);
+        const uint32_t code = inr ? (uint32_t)(delta + (UQ)p.radius) : 0u;
+        if (act) codes[c] = (uint16_t)code;
+        blk_count<HW>(lh, p, code, act);
+        const unsigned long long pd = wave_append_slot(act && !inr, p.n_dout);
+        if (act && !inr && pd < p.out_cap) {
+            p.dout_idx[pd] = c;
+            reinterpret_cast<Q *>(p.dout_val)[pd] = (Q)delta;
+        }
+    }
+    __syncthreads();
+    blk_flush<HW>(lh, p);
+}
+
+// ---- decoder ----
+// regression blocks: q~ of their elements into the output (as lattice words; k_blk_final turns everything into T). 1-D: every
+// block leaves its aggregate for the scan over the blocks — a regression block the lattice value of its last element, a Lorenzo
+// block the sum of its deltas.
+template <typename T>
+__global__ __launch_bounds__(256) void k_blkn_pre(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks,
+                                                  const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    const Lattice<T> lat(p.lat);
+    const int lane = lane_id();
+    const uint64_t d2 = p.d[2];
+    Q *qout = reinterpret_cast<Q *>(d_out);
+    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    Q *agg = reinterpret_cast<Q *>(p.carry);
+    const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
+    for (uint32_t task = blockIdx.x * 4 + threadIdx.x / WAVE; task < nblocks; task += gridDim.x * 4) {
+        const BlkGeom g = blk_geom(p, task);
+        const uint32_t nown = g.ey * g.ex;
+        if (p.sel[task] == 2) {
+            T rc[4];
+            coef_recover(coef_by_rank + (uint64_t)rank[task] * 4, cl, rc);
+            for (uint32_t t = lane; t < nown; t += WAVE) {
+                const uint32_t i1 = t / g.ex, i2 = t - i1 * g.ex;
+                const uint32_t code = codes[g.coff + t];
+                Q qt = 0;
+                if (code) {
+                    bool bad;
+                    qt = lat.quant(ref_recover(reg_predict(rc, 0u, i1, i2), (int)code, p.eb, (int)p.radius), bad);
+                    if (bad) qt = 0;
+                }
+                qout[(uint64_t)(g.oy + i1) * d2 + (g.ox + i2)] = qt;
+                if (p.ndim == 1 && t == nown - 1) agg[2 * (uint64_t)task] = qt;
+            }
+        } else if (p.ndim == 1) {
+            UQ sum = 0;
+            for (uint32_t t = lane; t < nown; t += WAVE) sum += (UQ)deltas[g.coff + t];
+            sum = wave_sum(sum);
+            if (lane == 0) agg[2 * (uint64_t)task] = (Q)sum;
+        }
+    }
+}
+// 1-D: the value left of every block — a segmented exclusive scan of the aggregates (one workgroup; a tile of 1024 blocks a round)
+template <typename Q>
+__global__ __launch_bounds__(1024) void k_blkn_scan1(const uint8_t *__restrict__ sel, uint32_t nblocks, Q *__restrict__ agg) {
+    using UQ = typename std::make_unsigned<Q>::type;
+    __shared__ UQ wa[16];
+    __shared__ uint32_t wf[16];
+    __shared__ UQ run_s;
+    const int lane = lane_id();
+    const uint32_t w = threadIdx.x / WAVE;
+    UQ run = 0;
+    for (uint32_t base = 0; base < nblocks; base += 1024) {
+        const uint32_t b = base + threadIdx.x;
+        const bool live = b < nblocks;
+        uint32_t f = live && sel[b] == 2 ? 1u : 0u;
+        UQ a = live ? (UQ)agg[2 * (uint64_t)b] : (UQ)0;
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const UQ a2 = (UQ)__shfl_up((long long)a, off);
+            const uint32_t f2 = (uint32_t)__shfl_up((int)f, off);
+            if (lane >= off) {
+                if (!f) a += a2;
+                f |= f2;
+            }
+        }
+        if (lane == WAVE - 1) {
+            wa[w] = a;
+            wf[w] = f;
+        }
+        __syncthreads();
+        UQ pa = run;
+        for (uint32_t k = 0; k < w; k++) pa = wf[k] ? wa[k] : pa + wa[k];
+        const UQ incl = f ? a : pa + a;
+        UQ prev = (UQ)__shfl_up((long long)incl, 1);
+        if (lane == 0) prev = pa;
+        if (live) agg[2 * (uint64_t)b + 1] = (Q)prev;
+        if (threadIdx.x == 1023) run_s = incl;
+        __syncthreads();
+        run = run_s;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_blkn_apply1(const void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    const int lane = lane_id();
+    Q *qout = reinterpret_cast<Q *>(d_out);
+    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    const Q *agg = reinterpret_cast<const Q *>(p.carry);
+    for (uint32_t task = blockIdx.x * 4 + threadIdx.x / WAVE; task < nblocks; task += gridDim.x * 4) {
+        if (p.sel[task] == 2) continue;
+        const BlkGeom g = blk_geom(p, task);
+        UQ run = (UQ)agg[2 * (uint64_t)task + 1];
+        for (uint32_t t0 = 0; t0 < g.ex; t0 += WAVE) {
+            const uint32_t t = t0 + lane;
+            const UQ dl = t < g.ex ? (UQ)deltas[g.coff + t] : (UQ)0;
+            const UQ incl = wave_incl_scan(dl) + run;
+            if (t < g.ex) qout[g.ox + t] = (Q)incl;
+            run = (UQ)__shfl((long long)incl, WAVE - 1);
+        }
+    }
+}
+// 2-D: the Lorenzo blocks of one front (by + bx = diag), a wave per block: the deltas in LDS, sums along x (inflow: Dy q~ of the
+// column left of the block), then along y (inflow: q~ of the row above it)
+#define BLKN_MAXB2 32u
+template <typename T>
+__global__ __launch_bounds__(256) void k_blkn_decode2(const void *deltas_, void *d_out, szk_blk_params p, uint32_t diag, uint32_t by_lo, uint32_t nfront) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    __shared__ Q s_a[4][BLKN_MAXB2 * (BLKN_MAXB2 + 1)];
+    const int lane = lane_id();
+    const uint32_t wv = threadIdx.x / WAVE;
+    Q *sa = s_a[wv];
+    const uint32_t k = blockIdx.x * 4 + wv;
+    if (k >= nfront) return;
+    const uint32_t by = by_lo + k, bx = diag - by;
+    const uint32_t task = by * p.nb[2] + bx;
+    if (p.sel[task] == 2) return;
+    const BlkGeom g = blk_geom(p, task);
+    const uint64_t d2 = p.d[2];
+    Q *qout = reinterpret_cast<Q *>(d_out);
+    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    const uint32_t pitch = g.ex + 1, nown = g.ey * g.ex;
+    for (uint32_t t = lane; t < nown; t += WAVE) {
+        const uint32_t j = t / g.ex, i = t - j * g.ex;
+        sa[j * pitch + i] = deltas[g.coff + t];
+    }
+    wave_lds_fence();
+    for (uint32_t j = lane; j < g.ey; j += WAVE) {
+        const uint64_t y = g.oy + j;
+        UQ a = 0;
+        if (g.ox) {
+            a = (UQ)qout[y * d2 + g.ox - 1];
+            if (y) a -= (UQ)qout[(y - 1) * d2 + g.ox - 1];
+        }
+        for (uint32_t i = 0; i < g.ex; i++) {
+            a += (UQ)sa[j * pitch + i];
+            sa[j * pitch + i] = (Q)a;
+        }
+    }
+    wave_lds_fence();
+    for (uint32_t i = lane; i < g.ex; i += WAVE) {
+        const uint64_t x = g.ox + i;
+        UQ q = g.oy ? (UQ)qout[(uint64_t)(g.oy - 1) * d2 + x] : (UQ)0;
+        for (uint32_t j = 0; j < g.ey; j++) {
+            q += (UQ)sa[j * pitch + i];
+            qout[(uint64_t)(g.oy + j) * d2 + x] = (Q)q;
+        }
+    }
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1474,8 +1839,32 @@ __global__ __launch_bounds__(256) void k_blk_patch(const uint8_t *__restrict__ p
 // ------------------------------------------------------------------------------------------------------------
 static uint32_t blk_count_blocks(const szk_blk_params *p) { return p->nb[0] * p->nb[1] * p->nb[2]; }
 
+static int launch_blk_side_build(const szk_blk_params *p, const szk_blk_scratch *sc, uint32_t nblocks, hipStream_t s);
+// arrays of one and two dimensions: fit / selection / regression blocks, then the Lorenzo codes over q~
+static int launch_blkn_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s) {
+    const uint32_t nblocks = blk_count_blocks(p);
+    const uint64_t n = p->d[1] * p->d[2];
+    const uint32_t gfit = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
+    const uint32_t glor = (uint32_t)std::min<uint64_t>(BLK_GRID * 2, (n + 255) / 256);
+#define BLKN_ENC(T, HW)                                                                                                \
+    do {                                                                                                               \
+        hipLaunchKernelGGL((k_blkn_fit<T, HW>), dim3(gfit), dim3(256), 0, s, (const T *)d_in, codes, *p, nblocks);       \
+        hipLaunchKernelGGL((k_blkn_lorenzo<T, HW>), dim3(glor), dim3(256), 0, s, codes, *p, n);                         \
+    } while (0)
+    if (dtype == 0) {
+        if (sc->wide_hist) BLKN_ENC(float, BLK_HWIN_WIDE);
+        else BLKN_ENC(float, BLK_HWIN);
+    } else {
+        if (sc->wide_hist) BLKN_ENC(double, BLK_HWIN_WIDE);
+        else BLKN_ENC(double, BLK_HWIN);
+    }
+#undef BLKN_ENC
+    return launch_blk_side_build(p, sc, nblocks, s);
+}
+
 int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s) {
     const uint32_t nblocks = blk_count_blocks(p);
+    if (p->ndim < 3) return launch_blkn_compress(dtype, d_in, codes, p, sc, s);
     // With the selection pass's choices: the fit pass codes the regression blocks (and leaves their lattice values), the stencil
     // pass every other element straight from the array. Without (development switch): fit and selection by the fit pass, the
     // lattice values of everything through qwork, Lorenzo blocks from tiles.
@@ -1514,6 +1903,10 @@ int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const 
     }
 #undef BLK_ENC
 #undef BLK_ENC1
+    return launch_blk_side_build(p, sc, nblocks, s);
+}
+// the side section (selection bits + Rice-coded coefficient chain) from sel[] / coef[]
+static int launch_blk_side_build(const szk_blk_params *p, const szk_blk_scratch *sc, uint32_t nblocks, hipStream_t s) {
     launch_blk_rank(p->sel, nblocks, sc->rank, sc->comp, sc->run_scratch, sc->counters + 0, s);
     // (counters: [0] regression blocks, [2] side bytes, [4..7] as doubles: sum of the zigzagged differences per coefficient;
     // the group sizes are staged in the rank array, which the encoder needs no more once comp is written)
@@ -1580,6 +1973,28 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
     if (szk_launch_expand_deltas(dtype, codes, h->n, (int)h->radius, payload, o, h->n_dout, p->qwork, s)) return -1;
     // (the side section's kernels ran on another stream: the fronts are the first to need what they made)
     if (side_done && hipStreamWaitEvent(s, side_done, 0) != hipSuccess) return -1;
+    if (p->ndim < 3) {
+        const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
+        if (dtype == 0) hipLaunchKernelGGL(k_blkn_pre<float>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+        else hipLaunchKernelGGL(k_blkn_pre<double>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+        if (p->ndim == 1) {
+            if (dtype == 0) {
+                hipLaunchKernelGGL(k_blkn_scan1<int32_t>, dim3(1), dim3(1024), 0, s, p->sel, nblocks, (int32_t *)p->carry);
+                hipLaunchKernelGGL(k_blkn_apply1<float>, dim3(gpre), dim3(256), 0, s, p->qwork, d_out, *p, nblocks);
+            } else {
+                hipLaunchKernelGGL(k_blkn_scan1<int64_t>, dim3(1), dim3(1024), 0, s, p->sel, nblocks, (int64_t *)p->carry);
+                hipLaunchKernelGGL(k_blkn_apply1<double>, dim3(gpre), dim3(256), 0, s, p->qwork, d_out, *p, nblocks);
+            }
+        } else {
+            const uint32_t ndiag = p->nb[1] + p->nb[2] - 1;
+            for (uint32_t d = 0; d < ndiag; d++) {
+                const uint32_t by_lo = d >= p->nb[2] ? d - (p->nb[2] - 1) : 0, by_hi = d < p->nb[1] - 1 ? d : p->nb[1] - 1;
+                const uint32_t nfront = by_hi - by_lo + 1;
+                if (dtype == 0) hipLaunchKernelGGL(k_blkn_decode2<float>, dim3((nfront + 3) / 4), dim3(256), 0, s, p->qwork, d_out, *p, d, by_lo, nfront);
+                else hipLaunchKernelGGL(k_blkn_decode2<double>, dim3((nfront + 3) / 4), dim3(256), 0, s, p->qwork, d_out, *p, d, by_lo, nfront);
+            }
+        }
+    } else
     if (p->B == 6 && !(szk_dbg_flags & 8388608)) {  // groups of 2 x 2 x 2 blocks per workgroup (debug flag 8388608: a block per wave)
         const uint32_t ng0 = (p->nb[0] + 1) / 2, ng1 = (p->nb[1] + 1) / 2, ng2 = (p->nb[2] + 1) / 2;
         const uint32_t ngd = ng0 + ng1 + ng2 - 2;

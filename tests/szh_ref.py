@@ -268,7 +268,8 @@ def reconstruct_blocks(h, sec, codes):
     out = np.zeros((dz, dy, dx), dtype=T)
     recip = T(1.0 / (2.0 * eb)) if T == np.float32 else 1.0 / (2.0 * eb)
     lim = T(8388608.0) if T == np.float32 else 4503599627370496.0
-    step_ind, step_lin = 2.0 * (eb / 4.0), 2.0 * (eb / 4.0 / B)
+    nd1 = h["ndim"] + 1  # (1-D / 2-D arrays are seen as (1, 1, n) / (1, dy, dx): RegressionPredictor.hpp:22-26 divides by N + 1)
+    step_ind, step_lin = 2.0 * (eb / nd1), 2.0 * (eb / nd1 / B)
     w1, w2 = np.array([1, -1]), np.array([1, -2, 1])
     r = 0
     for bz in range(sel.shape[0]):

@@ -177,19 +177,34 @@ def test_regression_only_beats_lorenzo_where_the_reference_says_so():
 
 
 def test_predictor_sets_outside_the_block_path():
+    """4-D arrays, second-order Lorenzo outside 3-D, block edges the kernels are not built for: the set falls back to its Lorenzo-1
+    member (recorded in the trailer) or is refused, never silently replaced. (1-D / 2-D Lorenzo + regression: test_gpu_regression_lowdim.py)"""
+    a4 = np.random.default_rng(0).normal(size=(6, 8, 16, 16)).astype(np.float32).cumsum(axis=3)
+    c = sz3_amd.Config(*a4.shape)
+    c.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    c.absErrorBound = 1e-2
+    blob, _ = sz3_amd.compress(a4, c)  # defaults: lorenzo + regression, 4-D -> the Lorenzo-1 member, recorded in the trailer
+    dec, c2 = sz3_amd.decompress(blob, np.float32, a4.shape)
+    assert (c2.lorenzo, c2.lorenzo2, c2.regression) == (1, 0, 0) and float(np.max(np.abs(dec - a4))) <= 1e-2
+    c.lorenzo = 0  # regression only, 4-D: not built -> refused
+    with pytest.raises(sz3_amd.SZ3HipError, match="3-D"):
+        sz3_amd.compress(a4, c)
+    c.regression = 0
+    with pytest.raises(sz3_amd.SZ3HipError, match="disabled"):
+        sz3_amd.compress(a4, c)
     a2 = np.random.default_rng(0).normal(size=(64, 64)).astype(np.float32).cumsum(axis=1)
     c = sz3_amd.Config(64, 64)
     c.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
     c.absErrorBound = 1e-2
-    blob, _ = sz3_amd.compress(a2, c)  # defaults: lorenzo + regression, 2-D -> the Lorenzo-1 member, recorded in the trailer
+    c.lorenzo2 = 1  # Lorenzo-1 + Lorenzo-2 + regression in 2-D: second-order Lorenzo is 3-D only here -> Lorenzo-1
+    blob, _ = sz3_amd.compress(a2, c)
     dec, c2 = sz3_amd.decompress(blob, np.float32, a2.shape)
     assert (c2.lorenzo, c2.lorenzo2, c2.regression) == (1, 0, 0) and float(np.max(np.abs(dec - a2))) <= 1e-2
-    c.lorenzo = 0  # regression only, 2-D: not built -> refused, never silently replaced
-    with pytest.raises(sz3_amd.SZ3HipError, match="3-D"):
-        sz3_amd.compress(a2, c)
-    c.regression = 0
-    with pytest.raises(sz3_amd.SZ3HipError, match="disabled"):
-        sz3_amd.compress(a2, c)
+    c.lorenzo2 = 0
+    c.blockSize = 40  # 2-D blocks beyond 32: not built
+    blob, _ = sz3_amd.compress(a2, c)
+    dec, c2 = sz3_amd.decompress(blob, np.float32, a2.shape)
+    assert (c2.lorenzo, c2.lorenzo2, c2.regression) == (1, 0, 0)
 
 
 @pytest.mark.parametrize("shape", [(37, 50, 66), (12, 13, 100), (6, 6, 6)], ids=["ragged", "thin", "one-block"])

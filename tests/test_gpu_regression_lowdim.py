@@ -1,0 +1,109 @@
+"""GPU tests (-m gpu) of the block-composed predictor on arrays of one and two dimensions (sz3hip_regress.hip, k_blkn_*):
+Lorenzo-1 / linear regression per block of 128 values (1-D) or 16 x 16 (2-D) — RegressionPredictor.hpp:22-55 (generic N),
+ComposedPredictor.hpp:25-40 over BlockwiseIterator.hpp:151-184, default block sizes Config.hpp:175; SURVEY.md 8(d) C1 names this
+predictor set (ALGO_LORENZO_REG defaults on a 1-D array).
+
+Parity bar as in test_gpu_regression.py: strict bound; the stream read back by the numpy model of the block decoder bit for bit;
+ratio and per-block selection against the oracle (the CPU restatement pinned to the reference)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import sz3_amd  # noqa: E402
+import szh_ref  # noqa: E402
+from fields import field1d, field2d  # noqa: E402
+from oracle_binding import make_config, oracle_compress, oracle_selection  # noqa: E402
+from test_gpu_regression import MASKS, _conf, _payload_of  # noqa: E402
+
+
+def _field(shape, dtype):
+    return field1d(shape[0], dtype) if len(shape) == 1 else field2d(shape, dtype)
+
+
+@pytest.mark.parametrize("mask", ["R", "L1+R"])
+@pytest.mark.parametrize("dtype,shape,eb,block", [(np.float32, (5000,), 1e-3, None), (np.float64, (3001,), 2e-2, 64), (np.float32, (130,), 1e-2, 7),
+                                                 (np.float32, (70, 90), 1e-2, None), (np.float64, (33, 47), 2e-2, 8),
+                                                 (np.float32, (64, 96), 5e-2, 32), (np.float32, (5, 200), 1e-3, 4)])
+def test_low_dimensional_block_stream_against_the_numpy_model(mask, dtype, shape, eb, block):
+    """ragged last blocks in every dimension: bound, header, and the numpy block decoder reproduces the GPU's reconstruction bit
+    for bit from the stream (selection bits, coefficient deltas with the N + 1 divisor, codes, outlier lists)"""
+    a = _field(shape, dtype)
+    conf = _conf(shape, eb, *MASKS[mask], block=block)
+    blob, ratio = sz3_amd.compress(a, conf)
+    dec, c2 = sz3_amd.decompress(blob, dtype, shape)
+    assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= eb
+    if c2.cmprAlgo == sz3_amd.ALGO_LOSSLESS:
+        pytest.skip("tiny field went lossless")
+    h, o, sec = szh_ref.parse(_payload_of(blob))
+    default = 128 if len(shape) == 1 else 16
+    assert h["predictor"] == 2 and h["ndim"] == len(shape) and h["blk_edge"] == (block or default)
+    assert h["blk_mask"] == sum(b << i for i, b in enumerate(MASKS[mask]))
+    assert (c2.lorenzo, c2.lorenzo2, c2.regression) == MASKS[mask]
+    codes = szh_ref.huffman_decode(h, sec)
+    model, sel = szh_ref.reconstruct_blocks(h, sec, codes)
+    assert np.array_equal(model.reshape(shape), dec), "numpy model of the block decoder and the GPU decoder disagree"
+    assert set(np.unique(sel)) <= {0, 2}
+    if mask == "L1+R":
+        print(shape, "regression blocks: %.3f" % float((np.asarray(sel) == 2).mean()))
+
+
+@pytest.mark.parametrize("shape", [(40000,), (150, 260)])
+def test_unpredictable_values_and_wide_deltas_in_low_dimensional_block_streams(shape):
+    a = _field(shape, np.float32)
+    flat = a.reshape(-1)
+    flat[5] = np.nan
+    flat[1234] = np.inf
+    if len(shape) == 1:
+        a[2000:2300] += 500.0  # a step: Lorenzo deltas beyond the radius next to it, regression residuals unpredictable
+    else:
+        a[40:75, 50:120] += 500.0
+    for mask in ("L1+R", "R"):
+        conf = _conf(shape, 1e-3, *MASKS[mask])
+        conf.quantbinCnt = 1024
+        blob, _ = sz3_amd.compress(a, conf)
+        dec, _ = sz3_amd.decompress(blob, np.float32, shape)
+        ok = np.isfinite(a)
+        assert np.array_equal(dec[~ok].view(np.uint32), a[~ok].view(np.uint32))
+        assert float(np.max(np.abs(dec[ok].astype(np.float64) - a[ok].astype(np.float64)))) <= 1e-3
+        h, o, sec = szh_ref.parse(_payload_of(blob))
+        assert h["n_vout"] > 0 and (h["n_dout"] > 0 or mask == "R")  # (regression only: no Lorenzo deltas)
+        model, _ = szh_ref.reconstruct_blocks(h, sec, szh_ref.huffman_decode(h, sec))
+        assert np.array_equal(model.view(np.uint32), dec.reshape(-1).view(np.uint32))
+
+
+@pytest.mark.parametrize("shape,eb", [((1 << 20,), 1e-3), ((1 << 18,), 2e-2), ((1024, 1024), 1e-3), ((768, 1000), 3e-2)],
+                         ids=["C1", "1d-coarse", "2d", "2d-coarse"])
+def test_ratio_and_selection_against_the_oracle(shape, eb):
+    """SURVEY.md 8(d) C1 (the first 2^20 values of the C2 field, ALGO_LORENZO_REG defaults: Lorenzo + regression, blocks of 128,
+    abs 1e-3) and a 2-D field, each also at a bound where regression takes a visible share. Bound strict; ratio >= 0.95 x the
+    oracle's for the same predictor set; the selection vector against the oracle's own choices block by block."""
+    a = _field(shape, np.float32)
+    oconf = make_config(a.shape, abs_eb=eb, lorenzo=True, regression=True)
+    o_ratio = a.nbytes / len(oracle_compress(a, oconf))
+    osel = oracle_selection(a, oconf)
+    blob, ratio = sz3_amd.compress(a, _conf(shape, eb, 1, 0, 1))
+    dec, c2 = sz3_amd.decompress(blob, np.float32, shape)
+    assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= eb
+    assert (c2.lorenzo, c2.lorenzo2, c2.regression) == (1, 0, 1)
+    h, o, sec = szh_ref.parse(_payload_of(blob))
+    assert h["predictor"] == 2 and h["ndim"] == len(shape)
+    sel = np.asarray(szh_ref.parse_side(h, sec)[0]).reshape(-1)
+    assert osel.size == sel.size and (osel >= 0).all()
+    same = float((osel == sel).mean())
+    print("%s @%g: ratio %.2f (oracle %.2f); regression blocks %.3f (oracle %.3f); selection identical in %.2f %% of the blocks"
+          % (shape, eb, ratio, o_ratio, float((sel == 2).mean()), float((osel == 2).mean()), 100 * same))
+    assert ratio >= 0.95 * o_ratio
+    assert same >= 0.90
+
+
+def test_full_size_round_trip_of_a_long_series():
+    """2^26 values in blocks of 128 (524 288 blocks: the block scan's tiles of 1024 chained 512 times), f64"""
+    a = field1d(1 << 22, np.float64)
+    a = np.tile(a, 16)
+    a += np.repeat(np.arange(16, dtype=np.float64), 1 << 22) * 0.37
+    conf = _conf(a.shape, 1e-4, 1, 0, 1)
+    blob, ratio = sz3_amd.compress(a, conf)
+    dec, c2 = sz3_amd.decompress(blob, np.float64, a.shape)
+    assert float(np.max(np.abs(dec - a))) <= 1e-4
+    assert (c2.lorenzo, c2.regression) == (1, 1)

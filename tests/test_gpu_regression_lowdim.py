@@ -72,7 +72,7 @@ def test_unpredictable_values_and_wide_deltas_in_low_dimensional_block_streams(s
         assert np.array_equal(model.view(np.uint32), dec.reshape(-1).view(np.uint32))
 
 
-@pytest.mark.parametrize("shape,eb", [((1 << 20,), 1e-3), ((1 << 18,), 2e-2), ((1024, 1024), 1e-3), ((768, 1000), 3e-2)],
+@pytest.mark.parametrize("shape,eb", [((1 << 20,), 1e-3), ((1 << 18,), 2e-2), ((1024, 1024), 1e-3), ((768, 1000), 0.15)],
                          ids=["C1", "1d-coarse", "2d", "2d-coarse"])
 def test_ratio_and_selection_against_the_oracle(shape, eb):
     """SURVEY.md 8(d) C1 (the first 2^20 values of the C2 field, ALGO_LORENZO_REG defaults: Lorenzo + regression, blocks of 128,

@@ -147,7 +147,11 @@ int sz3hip_minmax_device(sz3hip_ctx *ctx, const void *d_in, uint64_t n, double *
  * is chosen is handed to the plain Lorenzo path) synchronise the stream once inside this call.
  * d_in must stay valid and unchanged until sz3hip_compress_finish returns: a context that took a shortcut from what its
  * previous call found (the one-launch form of stage 1 assumes the previous call's code width) repeats the call from stage 1
- * inside finish() when this call's data says otherwise. */
+ * inside finish() when this call's data says otherwise.
+ * Predictor sets of ALGO_LORENZO_REG (api/impl/SZAlgoLorenzoReg.hpp:22-64): lorenzo alone = the plain Lorenzo stream (N = 1..4);
+ * with regression: per-block choice in 1-D (blockSize 4..65535, default 128), 2-D (4..32, default 16) and 3-D (4..8, default 6);
+ * lorenzo2: 3-D. Elsewhere a set that contains lorenzo is coded by it alone (the trailer records that), others are refused
+ * with SZ3HIP_EUNSUPPORTED. */
 int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, void *stream);
 /* device pointer to the code histogram: uint64_t[sz3hip_histogram_len()] — the buffer a multi-GPU caller
  * all-reduces (sum) between stage1 and stage2 */

@@ -1618,7 +1618,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
             if (ctx->d_blk_carry) HIPCHK(hipFree(ctx->d_blk_carry));
             ctx->d_blk_carry = nullptr;
             ctx->blk_carry_cap = 0;
-            HIPCHK(hipMalloc(&ctx->d_blk_carry, nblocks * 16));
+            HIPCHK(hipMalloc(&ctx->d_blk_carry, nblocks * 17 + (nblocks / 1024 + 2) * 16 + 64));  // (+ the tiles' words, a flag byte per block)
             ctx->blk_carry_cap = nblocks;
         }
         HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr, pl + o.side, 24, hipMemcpyDeviceToHost, s));

@@ -1496,11 +1496,23 @@ __device__ __forceinline__ T blkn_seen(const T *__restrict__ in, const szk_blk_p
     return v;
 }
 
-template <typename T, uint32_t HW>
-__global__ __launch_bounds__(256) void k_blkn_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
+// position t of a block's raster order -> (row, column); 1-D blocks have one row, whole 2-D blocks of the default edge shift
+template <bool TWO>
+__device__ __forceinline__ void blkn_own(const BlkGeom &g, uint32_t t, uint32_t &i1, uint32_t &i2) {
+    if (!TWO) {
+        i1 = 0;
+        i2 = t;
+    } else {
+        i1 = g.ex == 16 ? t >> 4 : t / g.ex;
+        i2 = t - i1 * g.ex;
+    }
+}
+// NW: waves of a workgroup — they share the LDS histogram window, so the wide window (64 KB) takes 16 of them to keep the CU occupied
+template <typename T, uint32_t HW, int NW, bool TWO>
+__global__ __launch_bounds__(NW * 64) void k_blkn_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;
     __shared__ uint32_t lh[HW];
-    for (uint32_t b = threadIdx.x; b < HW; b += 256) lh[b] = 0;
+    for (uint32_t b = threadIdx.x; b < HW; b += NW * 64) lh[b] = 0;
     __syncthreads();
     const Lattice<T> lat(p.lat);
     const int lane = lane_id();
@@ -1509,9 +1521,10 @@ __global__ __launch_bounds__(256) void k_blkn_fit(const T *__restrict__ in, uint
     Q *qwork = reinterpret_cast<Q *>(p.qwork);
     const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
     const double eb_recip = 1.0 / p.eb;
-    const bool has_l1 = p.mask & 1u, has_r = p.mask & 4u, two = p.ndim == 2;
+    const bool has_l1 = p.mask & 1u, has_r = p.mask & 4u;
+    constexpr bool two = TWO;
     const T noise = (T)((two ? 0.81 : 0.5) * p.eb);
-    for (uint32_t task = blockIdx.x * 4 + wv; task < nblocks; task += gridDim.x * 4) {
+    for (uint32_t task = blockIdx.x * NW + wv; task < nblocks; task += gridDim.x * NW) {
         const BlkGeom g = blk_geom(p, task);
         const uint32_t nown = g.ey * g.ex;
         // ---- regression fit (RegressionPredictor.hpp:28-55, N = 1 / 2) ----
@@ -1520,13 +1533,14 @@ __global__ __launch_bounds__(256) void k_blkn_fit(const T *__restrict__ in, uint
         if (r_valid) {
             double s1 = 0, s2 = 0, s3 = 0;
             for (uint32_t t = lane; t < nown; t += WAVE) {
-                const uint32_t i1 = t / g.ex, i2 = t - i1 * g.ex;
+                uint32_t i1, i2;
+                blkn_own<TWO>(g, t, i1, i2);
                 const T v = in[(uint64_t)(g.oy + i1) * d2 + (g.ox + i2)];
-                s1 += (double)((T)i1 * v);
+                if (two) s1 += (double)((T)i1 * v);
                 s2 += (double)((T)i2 * v);
                 s3 += (double)v;
             }
-            s1 = wave_sum_f64(s1);
+            if (two) s1 = wave_sum_f64(s1);
             s2 = wave_sum_f64(s2);
             s3 = wave_sum_f64(s3);
             const double dy = g.ey, dx = g.ex, num = dy * dx;
@@ -1581,7 +1595,8 @@ __global__ __launch_bounds__(256) void k_blkn_fit(const T *__restrict__ in, uint
                 const uint32_t t = t0 + lane;
                 const bool act = t < nown;
                 const uint32_t tt = act ? t : 0;
-                const uint32_t i1 = tt / g.ex, i2 = tt - i1 * g.ex;
+                uint32_t i1, i2;
+                blkn_own<TWO>(g, tt, i1, i2);
                 const uint64_t gi = (uint64_t)(g.oy + i1) * d2 + (g.ox + i2);
                 const T raw = in[gi];
                 T v = raw;
@@ -1606,7 +1621,8 @@ __global__ __launch_bounds__(256) void k_blkn_fit(const T *__restrict__ in, uint
                 const uint32_t t = t0 + lane;
                 const bool act = t < nown;
                 const uint32_t tt = act ? t : 0;
-                const uint32_t i1 = tt / g.ex, i2 = tt - i1 * g.ex;
+                uint32_t i1, i2;
+                blkn_own<TWO>(g, tt, i1, i2);
                 const uint64_t gi = (uint64_t)(g.oy + i1) * d2 + (g.ox + i2);
                 const T raw = in[gi];
                 bool bad;
@@ -1644,19 +1660,45 @@ __device__ __forceinline__ BlknPos blkn_pos(const szk_blk_params &p, uint64_t c)
     return r;
 }
 
-template <typename T, uint32_t HW>
-__global__ __launch_bounds__(256) void k_blkn_lorenzo(uint16_t *__restrict__ codes, szk_blk_params p, uint64_t n) {
+template <typename T, uint32_t HW, int TB, bool TWO>
+__global__ __launch_bounds__(TB) void k_blkn_lorenzo(uint16_t *__restrict__ codes, szk_blk_params p, uint64_t n) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     __shared__ uint32_t lh[HW];
-    for (uint32_t b = threadIdx.x; b < HW; b += 256) lh[b] = 0;
+    for (uint32_t b = threadIdx.x; b < HW; b += TB) lh[b] = 0;
     __syncthreads();
     const Q *__restrict__ qw = reinterpret_cast<const Q *>(p.qwork);
     const uint64_t d2 = p.d[2];
-    for (uint64_t c0 = (uint64_t)blockIdx.x * 256; c0 < n; c0 += (uint64_t)gridDim.x * 256) {
+    const uint64_t band = (uint64_t)p.B * d2;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * TB; c0 < n; c0 += (uint64_t)gridDim.x * TB) {
         const uint64_t c = c0 + threadIdx.x;
         bool act = c < n;
-        const BlknPos e = blkn_pos(p, act ? c : 0);
+        BlknPos e;
+        if (!TWO) {  // the workgroup's first block by one (uniform) long division, the thread's own by a short one
+            const uint64_t t0 = c0 / p.B;
+            const uint32_t r = (uint32_t)(c0 - t0 * p.B) + threadIdx.x;
+            e.task = (uint32_t)t0 + r / p.B;
+            e.y = 0;
+            e.x = act ? (uint32_t)c : 0u;
+            if (!act) e.task = 0;
+        } else {
+            // (the workgroup's first band likewise; a workgroup's codes span at most two bands when a band has TB codes or more)
+            const uint64_t b0 = c0 / band;
+            const uint64_t off = c0 - b0 * band + threadIdx.x;
+            if (off < 2 * band && band < 0x80000000ull && act) {
+                const uint32_t by = (uint32_t)b0 + (off >= band ? 1u : 0u);
+                const uint32_t rem = (uint32_t)(off >= band ? off - band : off);
+                const uint32_t oy = by * p.B, ey = min(p.B, (uint32_t)p.d[1] - oy);
+                const uint32_t per = ey * p.B, bx = rem / per, rem2 = rem - bx * per;
+                const uint32_t ox = bx * p.B, ex = min(p.B, (uint32_t)d2 - ox);
+                const uint32_t j = ex == 16 ? rem2 >> 4 : rem2 / ex;
+                e.y = oy + j;
+                e.x = ox + (rem2 - j * ex);
+                e.task = by * p.nb[2] + bx;
+            } else {
+                e = blkn_pos(p, act ? c : 0);
+            }
+        }
         act = act && p.sel[e.task] != 2;
         UQ delta = 0;
         if (act) {
@@ -1724,40 +1766,90 @@ __global__ __launch_bounds__(256) void k_blkn_pre(const uint16_t *__restrict__ c
         }
     }
 }
-// 1-D: the value left of every block — a segmented exclusive scan of the aggregates (one workgroup; a tile of 1024 blocks a round)
+// 1-D: the value left of every block — a segmented exclusive scan of the blocks' aggregates, in two levels: a workgroup per tile of
+// 1024 blocks (prefix inside the tile, the tile's own aggregate, and whether a regression block closes the prefix before a block),
+// one workgroup over the tiles, and the consumer (k_blkn_apply1) adds the tile's inflow where the prefix is still open.
+// carry buffer: Q agg[2 * nblocks] (aggregate, prefix), Q tile[2 * ntiles] (aggregate / inflow, restart flag), u8 closed[nblocks]
+#define BLKN_TILE 1024u
 template <typename Q>
-__global__ __launch_bounds__(1024) void k_blkn_scan1(const uint8_t *__restrict__ sel, uint32_t nblocks, Q *__restrict__ agg) {
+__device__ __forceinline__ Q *blkn_tiles(void *carry, uint32_t nblocks) { return reinterpret_cast<Q *>(carry) + 2 * (uint64_t)nblocks; }
+template <typename Q>
+__device__ __forceinline__ uint8_t *blkn_closed(void *carry, uint32_t nblocks) {
+    return reinterpret_cast<uint8_t *>(blkn_tiles<Q>(carry, nblocks) + 2 * (uint64_t)((nblocks + BLKN_TILE - 1) / BLKN_TILE));
+}
+// segmented inclusive scan of (f, a) over a workgroup of 1024 threads; pa: inflow of the workgroup. Returns the inclusive value,
+// `f` becomes "a restart at or before this thread", `excl` / `fex` the same for the threads before this one
+template <typename UQ>
+__device__ __forceinline__ UQ blkn_wg_scan(uint32_t &f, UQ a, UQ inflow, UQ &excl, uint32_t &fex, UQ *wa, uint32_t *wf) {
+    const int lane = lane_id();
+    const uint32_t w = threadIdx.x / WAVE;
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const UQ a2 = (UQ)__shfl_up((long long)a, off);
+        const uint32_t f2 = (uint32_t)__shfl_up((int)f, off);
+        if (lane >= off) {
+            if (!f) a += a2;
+            f |= f2;
+        }
+    }
+    if (lane == WAVE - 1) {
+        wa[w] = a;
+        wf[w] = f;
+    }
+    __syncthreads();
+    UQ pa = inflow;
+    uint32_t pf = 0;
+    for (uint32_t k = 0; k < w; k++) {
+        pa = wf[k] ? wa[k] : pa + wa[k];
+        pf |= wf[k];
+    }
+    const UQ incl = f ? a : pa + a;
+    const uint32_t fincl = f | pf;
+    excl = (UQ)__shfl_up((long long)incl, 1);
+    fex = (uint32_t)__shfl_up((int)fincl, 1);
+    if (lane == 0) {
+        excl = pa;
+        fex = pf;
+    }
+    f = fincl;
+    __syncthreads();
+    return incl;
+}
+template <typename Q>
+__global__ __launch_bounds__(1024) void k_blkn_scan_tile(const uint8_t *__restrict__ sel, uint32_t nblocks, void *carry) {
+    using UQ = typename std::make_unsigned<Q>::type;
+    __shared__ UQ wa[16];
+    __shared__ uint32_t wf[16];
+    Q *agg = reinterpret_cast<Q *>(carry);
+    Q *tile = blkn_tiles<Q>(carry, nblocks);
+    uint8_t *closed = blkn_closed<Q>(carry, nblocks);
+    const uint32_t b = blockIdx.x * BLKN_TILE + threadIdx.x;
+    const bool live = b < nblocks;
+    uint32_t f = live && sel[b] == 2 ? 1u : 0u, fex;
+    UQ excl;
+    const UQ incl = blkn_wg_scan<UQ>(f, live ? (UQ)agg[2 * (uint64_t)b] : (UQ)0, (UQ)0, excl, fex, wa, wf);
+    if (live) {
+        agg[2 * (uint64_t)b + 1] = (Q)excl;
+        closed[b] = (uint8_t)fex;
+    }
+    if (threadIdx.x == BLKN_TILE - 1) {
+        tile[2 * (uint64_t)blockIdx.x] = (Q)incl;
+        tile[2 * (uint64_t)blockIdx.x + 1] = (Q)f;
+    }
+}
+template <typename Q>
+__global__ __launch_bounds__(1024) void k_blkn_scan_top(uint32_t ntiles, Q *__restrict__ tile) {
     using UQ = typename std::make_unsigned<Q>::type;
     __shared__ UQ wa[16];
     __shared__ uint32_t wf[16];
     __shared__ UQ run_s;
-    const int lane = lane_id();
-    const uint32_t w = threadIdx.x / WAVE;
     UQ run = 0;
-    for (uint32_t base = 0; base < nblocks; base += 1024) {
-        const uint32_t b = base + threadIdx.x;
-        const bool live = b < nblocks;
-        uint32_t f = live && sel[b] == 2 ? 1u : 0u;
-        UQ a = live ? (UQ)agg[2 * (uint64_t)b] : (UQ)0;
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const UQ a2 = (UQ)__shfl_up((long long)a, off);
-            const uint32_t f2 = (uint32_t)__shfl_up((int)f, off);
-            if (lane >= off) {
-                if (!f) a += a2;
-                f |= f2;
-            }
-        }
-        if (lane == WAVE - 1) {
-            wa[w] = a;
-            wf[w] = f;
-        }
-        __syncthreads();
-        UQ pa = run;
-        for (uint32_t k = 0; k < w; k++) pa = wf[k] ? wa[k] : pa + wa[k];
-        const UQ incl = f ? a : pa + a;
-        UQ prev = (UQ)__shfl_up((long long)incl, 1);
-        if (lane == 0) prev = pa;
-        if (live) agg[2 * (uint64_t)b + 1] = (Q)prev;
+    for (uint32_t base = 0; base < ntiles; base += 1024) {
+        const uint32_t t = base + threadIdx.x;
+        const bool live = t < ntiles;
+        uint32_t f = live && tile[2 * (uint64_t)t + 1] != 0 ? 1u : 0u, fex;
+        UQ excl;
+        const UQ incl = blkn_wg_scan<UQ>(f, live ? (UQ)tile[2 * (uint64_t)t] : (UQ)0, run, excl, fex, wa, wf);
+        if (live) tile[2 * (uint64_t)t + 1] = (Q)excl;  // (the tile's inflow replaces its flag: this thread was the flag's only reader)
         if (threadIdx.x == 1023) run_s = incl;
         __syncthreads();
         run = run_s;
@@ -1771,10 +1863,13 @@ __global__ __launch_bounds__(256) void k_blkn_apply1(const void *deltas_, void *
     Q *qout = reinterpret_cast<Q *>(d_out);
     const Q *deltas = reinterpret_cast<const Q *>(deltas_);
     const Q *agg = reinterpret_cast<const Q *>(p.carry);
+    const Q *tile = blkn_tiles<Q>(p.carry, nblocks);
+    const uint8_t *closed = blkn_closed<Q>(p.carry, nblocks);
     for (uint32_t task = blockIdx.x * 4 + threadIdx.x / WAVE; task < nblocks; task += gridDim.x * 4) {
         if (p.sel[task] == 2) continue;
         const BlkGeom g = blk_geom(p, task);
         UQ run = (UQ)agg[2 * (uint64_t)task + 1];
+        if (!closed[task]) run += (UQ)tile[2 * (uint64_t)(task / BLKN_TILE) + 1];
         for (uint32_t t0 = 0; t0 < g.ex; t0 += WAVE) {
             const uint32_t t = t0 + lane;
             const UQ dl = t < g.ex ? (UQ)deltas[g.coff + t] : (UQ)0;
@@ -1844,21 +1939,27 @@ static int launch_blk_side_build(const szk_blk_params *p, const szk_blk_scratch 
 static int launch_blkn_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s) {
     const uint32_t nblocks = blk_count_blocks(p);
     const uint64_t n = p->d[1] * p->d[2];
-    const uint32_t gfit = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
-    const uint32_t glor = (uint32_t)std::min<uint64_t>(BLK_GRID * 2, (n + 255) / 256);
-#define BLKN_ENC(T, HW)                                                                                                \
-    do {                                                                                                               \
-        hipLaunchKernelGGL((k_blkn_fit<T, HW>), dim3(gfit), dim3(256), 0, s, (const T *)d_in, codes, *p, nblocks);       \
-        hipLaunchKernelGGL((k_blkn_lorenzo<T, HW>), dim3(glor), dim3(256), 0, s, codes, *p, n);                         \
+#define BLKN_ENC1(T, HW, NW, TWO)                                                                                               \
+    do {                                                                                                                        \
+        const uint32_t gfit = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                 \
+        const uint32_t glor = (uint32_t)std::min<uint64_t>(BLK_GRID * 8 / NW, (n + NW * 64 - 1) / (NW * 64));                     \
+        hipLaunchKernelGGL((k_blkn_fit<T, HW, NW, TWO>), dim3(gfit), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks);   \
+        hipLaunchKernelGGL((k_blkn_lorenzo<T, HW, NW * 64, TWO>), dim3(glor), dim3(NW * 64), 0, s, codes, *p, n);                \
+    } while (0)
+#define BLKN_ENC(T, HW, NW)                        \
+    do {                                           \
+        if (p->ndim == 2) BLKN_ENC1(T, HW, NW, true); \
+        else BLKN_ENC1(T, HW, NW, false);          \
     } while (0)
     if (dtype == 0) {
-        if (sc->wide_hist) BLKN_ENC(float, BLK_HWIN_WIDE);
-        else BLKN_ENC(float, BLK_HWIN);
+        if (sc->wide_hist) BLKN_ENC(float, BLK_HWIN_WIDE, 16);
+        else BLKN_ENC(float, BLK_HWIN, 4);
     } else {
-        if (sc->wide_hist) BLKN_ENC(double, BLK_HWIN_WIDE);
-        else BLKN_ENC(double, BLK_HWIN);
+        if (sc->wide_hist) BLKN_ENC(double, BLK_HWIN_WIDE, 16);
+        else BLKN_ENC(double, BLK_HWIN, 4);
     }
 #undef BLKN_ENC
+#undef BLKN_ENC1
     return launch_blk_side_build(p, sc, nblocks, s);
 }
 
@@ -1978,11 +2079,14 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         if (dtype == 0) hipLaunchKernelGGL(k_blkn_pre<float>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
         else hipLaunchKernelGGL(k_blkn_pre<double>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
         if (p->ndim == 1) {
+            const uint32_t ntiles = (nblocks + BLKN_TILE - 1) / BLKN_TILE;
             if (dtype == 0) {
-                hipLaunchKernelGGL(k_blkn_scan1<int32_t>, dim3(1), dim3(1024), 0, s, p->sel, nblocks, (int32_t *)p->carry);
+                hipLaunchKernelGGL(k_blkn_scan_tile<int32_t>, dim3(ntiles), dim3(1024), 0, s, p->sel, nblocks, p->carry);
+                hipLaunchKernelGGL(k_blkn_scan_top<int32_t>, dim3(1), dim3(1024), 0, s, ntiles, (int32_t *)p->carry + 2 * (uint64_t)nblocks);
                 hipLaunchKernelGGL(k_blkn_apply1<float>, dim3(gpre), dim3(256), 0, s, p->qwork, d_out, *p, nblocks);
             } else {
-                hipLaunchKernelGGL(k_blkn_scan1<int64_t>, dim3(1), dim3(1024), 0, s, p->sel, nblocks, (int64_t *)p->carry);
+                hipLaunchKernelGGL(k_blkn_scan_tile<int64_t>, dim3(ntiles), dim3(1024), 0, s, p->sel, nblocks, p->carry);
+                hipLaunchKernelGGL(k_blkn_scan_top<int64_t>, dim3(1), dim3(1024), 0, s, ntiles, (int64_t *)p->carry + 2 * (uint64_t)nblocks);
                 hipLaunchKernelGGL(k_blkn_apply1<double>, dim3(gpre), dim3(256), 0, s, p->qwork, d_out, *p, nblocks);
             }
         } else {

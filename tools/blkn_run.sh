@@ -2,7 +2,7 @@
 # block-composed predictor, 1-D / 2-D: timings + kernel trace (gpurun_out/blkn/)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/blkn; mkdir -p $O
-for cfg in "8192,8192 1e-3" "8192,8192 0.15" "8192,8192 1e-3 f32 plain"; do
+for cfg in "1048576 1e-3" "134217728 1e-3" "8192,8192 1e-3" "8192,8192 0.15" "8192,8192 1e-3 f32 plain"; do
   timeout 300 python $R/tools/blkn_bench.py $cfg 2>&1 | tail -1
 done | tee $O/times.txt
 for tag in 1d 2d; do

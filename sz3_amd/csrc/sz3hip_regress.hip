@@ -1927,6 +1927,143 @@ __global__ __launch_bounds__(256) void k_blkn_decode2(const void *deltas_, void 
         }
     }
 }
+
+// 2-D, block edges up to 16: GROUPS of 4 x 4 blocks per workgroup, like the 3-D decoder's groups — the chain of fronts is what a
+// block stream's decoding costs (a launch + a block's latency each), and a group quarters it: 255 launches instead of 1023 at
+// 8192^2. The group's tile (its deltas, the q~ of its regression blocks, one halo row and column of finished q~) sits in LDS;
+// seven inner steps (ly + lx = 0..6, a barrier in between) invert the Lorenzo blocks in place, a wave per block: sums along x in
+// the DPP rows of 16 lanes (four rows of the block at a time), then along y the same way on the transposed assignment.
+#define BLKN_G 4u
+template <typename UQ>
+__device__ __forceinline__ UQ row16_incl_scan(UQ u) {
+    u += dpp_mov0<0x111, 0xf>(u);
+    u += dpp_mov0<0x112, 0xf>(u);
+    u += dpp_mov0<0x114, 0xf>(u);
+    u += dpp_mov0<0x118, 0xf>(u);
+    return u;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_blkn_decode2g(const void *deltas_, void *d_out, szk_blk_params p, uint32_t diag, uint32_t gy_lo) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    constexpr uint32_t TE = BLKN_G * 16 + 1, PITCH = TE + 1;
+    __shared__ Q sq[TE * PITCH];
+    const uint32_t gy = gy_lo + blockIdx.x, gx = diag - gy;
+    const uint32_t B = p.B;
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    const uint32_t y0 = gy * BLKN_G * B, x0 = gx * BLKN_G * B;
+    const uint32_t hy = (uint32_t)min((uint64_t)(BLKN_G * B), d1 - y0), hx = (uint32_t)min((uint64_t)(BLKN_G * B), d2 - x0);
+    Q *qout = reinterpret_cast<Q *>(d_out);
+    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    // the tile: 17 elements per thread, every load issued before the first LDS store (a loop of load -> LDS store waits for every
+    // load in turn: 17 round trips were 20 of the kernel's 28 us)
+    __shared__ uint8_t s_sel[BLKN_G * BLKN_G];
+    {
+        // ONE round trip to memory: an element's two possible sources (its delta; its q~ if the block is a regression block or
+        // the element lies in the halo) and its block's choice are requested together, for all 17 elements of the thread,
+        // and the choice picks afterwards (choice -> address -> value were three dependent trips of ~2 us each)
+        constexpr int NR = (TE * TE + 255) / 256;
+        Q v[NR], vq[NR];
+        uint8_t sl[NR];
+        const Q *sd[NR], *sv[NR];
+        const uint8_t *ss[NR];
+        const uint8_t *selp = p.sel;  // (threads 0..15: the choice of a block of the group, for the inner steps)
+        if (threadIdx.x < BLKN_G * BLKN_G) {
+            const uint32_t by = gy * BLKN_G + threadIdx.x / BLKN_G, bx = gx * BLKN_G + threadIdx.x % BLKN_G;
+            if (by < p.nb[1] && bx < p.nb[2]) selp = p.sel + (by * p.nb[2] + bx);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const uint32_t idx = threadIdx.x + 256u * r;
+            const uint32_t ty = idx / TE, tx = idx - ty * TE;
+            sd[r] = sv[r] = nullptr;
+            ss[r] = nullptr;
+            if (ty > hy || tx > hx) continue;
+#ifdef LAB_G_NOLOAD
+            if (p.B) continue;
+#endif
+            const int64_t y = (int64_t)y0 + ty - 1, x = (int64_t)x0 + tx - 1;
+            if (y >= 0 && x >= 0) sv[r] = qout + ((uint64_t)y * d2 + (uint64_t)x);
+            if (ty && tx) {
+                const uint32_t by = (uint32_t)y / B, bx = (uint32_t)x / B;
+                const uint32_t oy = by * B, ey = min(B, (uint32_t)d1 - oy);
+                const uint32_t ox = bx * B, ex = min(B, (uint32_t)d2 - ox);
+                sd[r] = deltas + ((uint64_t)oy * d2 + (uint64_t)ey * ox + ((uint32_t)y - oy) * ex + ((uint32_t)x - ox));
+                ss[r] = p.sel + (by * p.nb[2] + bx);
+            }
+        }
+        const uint8_t mysel = *selp;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            v[r] = *(sd[r] ? sd[r] : deltas);
+            vq[r] = *(sv[r] ? sv[r] : deltas);
+            sl[r] = *(ss[r] ? ss[r] : p.sel);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            if (!sd[r] || sl[r] == 2) v[r] = sv[r] ? vq[r] : (Q)0;  // halo / regression block: q~ (zero outside the array)
+        }
+        if (threadIdx.x < BLKN_G * BLKN_G) s_sel[threadIdx.x] = mysel;  // (blocks beyond the array's edge are never visited)
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const uint32_t idx = threadIdx.x + 256u * r;
+            const uint32_t ty = idx / TE, tx = idx - ty * TE;
+            if (ty <= hy && tx <= hx) sq[ty * PITCH + tx] = v[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t nly = (hy + B - 1) / B, nlx = (hx + B - 1) / B;
+    const int lane = lane_id();
+    const uint32_t w = threadIdx.x / WAVE, rr = (uint32_t)lane >> 4, cc = (uint32_t)lane & 15u;
+#ifdef LAB_G_NOSTEPS
+    if (p.B == 0)
+#endif
+    for (uint32_t step = 0; step + 1 < nly + nlx; step++) {
+        const uint32_t ly = w, lx = step - ly;
+        if (ly < nly && ly <= step && lx < nlx && s_sel[ly * BLKN_G + lx] != 2) {
+            const uint32_t ty0 = 1 + ly * B, tx0 = 1 + lx * B;
+            const uint32_t ey = min(B, hy - ly * B), ex = min(B, hx - lx * B);
+            // (four independent chains of LDS read -> row scan -> LDS write, unrolled with predicates: as a loop with a data-dependent
+            // trip count they ran one after the other, 1.07 us per inner step)
+            UQ v[4], in[4];
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) {  // along x: a row of the block per DPP row
+                const uint32_t j = rr + 4 * m, at = (ty0 + min(j, ey - 1)) * PITCH + tx0;
+                v[m] = cc < ex ? (UQ)sq[at + cc] : (UQ)0;
+                in[m] = (UQ)sq[at - 1] - (UQ)sq[at - PITCH - 1];
+            }
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) v[m] = row16_incl_scan(v[m]) + in[m];
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) {
+                const uint32_t j = rr + 4 * m;
+                if (j < ey && cc < ex) sq[(ty0 + j) * PITCH + tx0 + cc] = (Q)v[m];
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) {  // along y: a column per DPP row
+                const uint32_t i = min(rr + 4 * m, ex - 1), at = ty0 * PITCH + tx0 + i;
+                v[m] = cc < ey ? (UQ)sq[at + cc * PITCH] : (UQ)0;
+                in[m] = (UQ)sq[at - PITCH];
+            }
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) v[m] = row16_incl_scan(v[m]) + in[m];
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) {
+                const uint32_t i = rr + 4 * m;
+                if (i < ex && cc < ey) sq[ty0 * PITCH + tx0 + i + cc * PITCH] = (Q)v[m];
+            }
+        }
+        __syncthreads();
+    }
+#ifdef LAB_G_NOSTORE
+    if (p.B == 0)
+#endif
+    for (uint32_t ty = threadIdx.x / WAVE; ty < hy; ty += 4) {
+        const uint32_t tx = threadIdx.x % WAVE;
+        if (tx < hx) qout[(uint64_t)(y0 + ty) * d2 + (x0 + tx)] = sq[(ty + 1) * PITCH + tx + 1];
+    }
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2088,6 +2225,13 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
                 hipLaunchKernelGGL(k_blkn_scan_tile<int64_t>, dim3(ntiles), dim3(1024), 0, s, p->sel, nblocks, p->carry);
                 hipLaunchKernelGGL(k_blkn_scan_top<int64_t>, dim3(1), dim3(1024), 0, s, ntiles, (int64_t *)p->carry + 2 * (uint64_t)nblocks);
                 hipLaunchKernelGGL(k_blkn_apply1<double>, dim3(gpre), dim3(256), 0, s, p->qwork, d_out, *p, nblocks);
+            }
+        } else if (p->B <= 16 && !(szk_dbg_flags & 8388608)) {  // groups of 4 x 4 blocks per workgroup (debug flag 8388608: a block per wave)
+            const uint32_t ng1 = (p->nb[1] + BLKN_G - 1) / BLKN_G, ng2 = (p->nb[2] + BLKN_G - 1) / BLKN_G;
+            for (uint32_t d = 0; d < ng1 + ng2 - 1; d++) {
+                const uint32_t gy_lo = d >= ng2 ? d - (ng2 - 1) : 0, gy_hi = d < ng1 - 1 ? d : ng1 - 1;
+                if (dtype == 0) hipLaunchKernelGGL(k_blkn_decode2g<float>, dim3(gy_hi - gy_lo + 1), dim3(256), 0, s, p->qwork, d_out, *p, d, gy_lo);
+                else hipLaunchKernelGGL(k_blkn_decode2g<double>, dim3(gy_hi - gy_lo + 1), dim3(256), 0, s, p->qwork, d_out, *p, d, gy_lo);
             }
         } else {
             const uint32_t ndiag = p->nb[1] + p->nb[2] - 1;

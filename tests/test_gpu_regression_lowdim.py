@@ -14,7 +14,7 @@ import sz3_amd  # noqa: E402
 import szh_ref  # noqa: E402
 from fields import field1d, field2d  # noqa: E402
 from oracle_binding import make_config, oracle_compress, oracle_selection  # noqa: E402
-from test_gpu_regression import MASKS, _conf, _payload_of  # noqa: E402
+from test_gpu_regression import MASKS, NO_EXIT, _conf, _payload_of  # noqa: E402
 
 
 def _field(shape, dtype):
@@ -107,3 +107,26 @@ def test_full_size_round_trip_of_a_long_series():
     dec, c2 = sz3_amd.decompress(blob, np.float64, a.shape)
     assert float(np.max(np.abs(dec - a))) <= 1e-4
     assert (c2.lorenzo, c2.regression) == (1, 1)
+
+
+@pytest.mark.parametrize("shape,block,eb", [((300, 517), None, 0.15), ((130, 70), 8, 0.15), ((17, 1000), 16, 1e-3), ((64, 64), 16, 0.2)])
+def test_grouped_and_per_block_2d_decoders_agree(shape, block, eb):
+    """2-D blocks of up to 16 x 16 are decoded in groups of 4 x 4 per workgroup (inner fronts through a shared LDS tile, DPP row
+    scans); debug flag 8388608 takes the block-per-wave fronts: same array, bit for bit, with ragged and missing blocks in the last
+    groups, on fields where regression blocks sit among the Lorenzo blocks"""
+    a = field2d(shape, np.float32)
+    a[shape[0] // 2:, :] += 3.0
+    blob, _ = sz3_amd.compress(a, _conf(shape, eb, 1, 0, 1, block=block))
+    outs = []
+    try:
+        for flag in (NO_EXIT, NO_EXIT | 8388608):
+            sz3_amd.lib().sz3hip_debug_flags(flag)
+            dec, c2 = sz3_amd.decompress(blob, np.float32, shape)
+            outs.append(dec)
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(0)
+    assert np.array_equal(outs[0], outs[1])
+    assert float(np.max(np.abs(outs[0].astype(np.float64) - a.astype(np.float64)))) <= eb
+    h, o, sec = szh_ref.parse(_payload_of(blob))
+    sel = np.asarray(szh_ref.parse_side(h, sec)[0])
+    print(shape, "regression blocks %.3f" % float((sel == 2).mean()))

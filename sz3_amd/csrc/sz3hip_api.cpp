@@ -684,16 +684,17 @@ static int blk_all_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const voi
     *all = false;
     ctx->blk_sel_given = false;
     if (szk_dbg_flags & 2147483648u) return 0;  // (development: no selection pass, the fit pass chooses by its own wave sums)
-    if (conf->N != 3) return 0;                 // (1-D / 2-D: the fit pass chooses, a wave per block)
     const uint32_t B = (uint32_t)conf->blockSize;
+    uint64_t d3[3];
+    blk_view(conf->N, conf->dims, d3);
     uint64_t nblocks = 1;
-    for (int i = 0; i < 3; i++) nblocks *= (conf->dims[i] + B - 1) / B;
+    for (int i = 0; i < 3; i++) nblocks *= (d3[i] + B - 1) / B;
     if (nblocks > 0x7FFFFFF0ull) return 0;
     int rc = blk_reserve_select(ctx, nblocks);
     if (rc) return rc;
     szk_blk_params bp;
     szk_blk_scratch sc;
-    blk_params_from(ctx, 3, conf->dims, B, mask, eb, radius, ctx->cur_out_cap, bp, sc);
+    blk_params_from(ctx, conf->N, d3, B, mask, eb, radius, ctx->cur_out_cap, bp, sc);
     HIPCHK(hipMemsetAsync(ctx->d_blk_counters + 7, 0, 8, s));
     prof_begin(ctx, ST_TUNER, s);
     rc = szk_launch_blk_select(ctx->dtype, d_in, &bp, ctx->d_blk_counters + 7, s);

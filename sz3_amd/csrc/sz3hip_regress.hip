@@ -1508,8 +1508,13 @@ __device__ __forceinline__ void blkn_own(const BlkGeom &g, uint32_t t, uint32_t 
     }
 }
 // NW: waves of a workgroup — they share the LDS histogram window, so the wide window (64 KB) takes 16 of them to keep the CU occupied
-template <typename T, uint32_t HW, int NW, bool TWO>
-__global__ __launch_bounds__(NW * 64) void k_blkn_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
+// SELECT: the selection alone (choices and coefficients to sel[] / coef[], the number of blocks that would not be coded by
+// first-order Lorenzo to *n_other; HW is then the one-word window of that count) — the 3-D path's question, asked first: a
+// field on which only Lorenzo-1 is chosen goes to the plain Lorenzo path. With p.sel_given the coding launch takes the choices
+// from there instead of fitting again.
+template <typename T, uint32_t HW, int NW, bool TWO, bool SELECT>
+__global__ __launch_bounds__(NW * 64) void k_blkn_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks,
+                                                      unsigned long long *__restrict__ n_other) {
     using Q = typename QTraits<T>::Q;
     __shared__ uint32_t lh[HW];
     for (uint32_t b = threadIdx.x; b < HW; b += NW * 64) lh[b] = 0;
@@ -1527,6 +1532,14 @@ __global__ __launch_bounds__(NW * 64) void k_blkn_fit(const T *__restrict__ in, 
     for (uint32_t task = blockIdx.x * NW + wv; task < nblocks; task += gridDim.x * NW) {
         const BlkGeom g = blk_geom(p, task);
         const uint32_t nown = g.ey * g.ex;
+        int sid = 0;
+        int64_t lc[4] = {0, 0, 0, 0};
+        if (!SELECT && p.sel_given) {
+            sid = p.sel[task];
+            if (sid != 2) continue;  // (a Lorenzo block's elements are put on the lattice by the code pass itself, straight from the array)
+            if (sid == 2)
+                for (int i = 1; i < 4; i++) lc[i] = p.coef[(uint64_t)task * 4 + i];
+        } else {
         // ---- regression fit (RegressionPredictor.hpp:28-55, N = 1 / 2) ----
         const bool r_valid = has_r && g.ex > 1 && (!two || g.ey > 1);
         T cf[4] = {0, 0, 0, 0};
@@ -1551,7 +1564,7 @@ __global__ __launch_bounds__(NW * 64) void k_blkn_fit(const T *__restrict__ in, 
             cf[3] = (T)((double)cf[3] - (dx - 1) * (double)cf[2] / 2);
         }
         // ---- selection (ComposedPredictor.hpp:25-40 over foreach_sampling) ----
-        int sid = has_l1 ? 0 : 2;
+        sid = has_l1 ? 0 : 2;
         if (has_l1 && has_r) {
             const uint32_t m = two ? min(g.ey, g.ex) : g.ex;
             const uint32_t npts = two ? 2 * m : 2;
@@ -1578,7 +1591,6 @@ __global__ __launch_bounds__(NW * 64) void k_blkn_fit(const T *__restrict__ in, 
         } else if (sid == 2 && !r_valid) {
             sid = 0;  // BlockwiseDecomposition.hpp:35-37
         }
-        int64_t lc[4] = {0, 0, 0, 0};
         if (sid == 2) {  // coefficients onto their lattices; a coefficient the lattice cannot hold -> Lorenzo-1
             bool ok = true;
             for (int i = 1; i < 4; i++) {
@@ -1587,6 +1599,16 @@ __global__ __launch_bounds__(NW * 64) void k_blkn_fit(const T *__restrict__ in, 
                 else lc[i] = (int64_t)rint(sc);
             }
             if (!ok) sid = 0;
+        }
+        }  // (own selection)
+        if (SELECT) {
+            if (lane == 0) {
+                p.sel[task] = (uint8_t)sid;
+                if (sid == 2)
+                    for (int i = 0; i < 4; i++) p.coef[(uint64_t)task * 4 + i] = lc[i];
+                if (sid != 0) atomicAdd(&lh[0], 1u);
+            }
+            continue;
         }
         if (sid == 2) {
             T rc[4];
@@ -1635,7 +1657,11 @@ __global__ __launch_bounds__(NW * 64) void k_blkn_fit(const T *__restrict__ in, 
         if (lane == 0) p.sel[task] = (uint8_t)sid;
     }
     __syncthreads();
-    blk_flush<HW>(lh, p);
+    if (SELECT) {
+        if (threadIdx.x == 0 && lh[0]) atomicAdd(n_other, (unsigned long long)lh[0]);
+    } else {
+        blk_flush<HW>(lh, p);
+    }
 }
 
 // code position -> block and element of the (1, dy, dx) view: the bands of B rows hold B * dx codes each, a band's blocks ey * B
@@ -1660,10 +1686,15 @@ __device__ __forceinline__ BlknPos blkn_pos(const szk_blk_params &p, uint64_t c)
     return r;
 }
 
+// With the selection pass's choices (p.sel_given) q~ of an element outside a regression block is rint(x / 2eb), a function of that
+// element alone: the pass takes it from the array (its own and its lower neighbours'), the work array holds the regression blocks'
+// values only — nothing is written or read back for the Lorenzo blocks, and the fit pass does not visit them.
 template <typename T, uint32_t HW, int TB, bool TWO>
-__global__ __launch_bounds__(TB) void k_blkn_lorenzo(uint16_t *__restrict__ codes, szk_blk_params p, uint64_t n) {
+__global__ __launch_bounds__(TB) void k_blkn_lorenzo(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint64_t n) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
+    const Lattice<T> lat(p.lat);
+    const bool direct = p.sel_given != 0;
     __shared__ uint32_t lh[HW];
     for (uint32_t b = threadIdx.x; b < HW; b += TB) lh[b] = 0;
     __syncthreads();
@@ -1678,9 +1709,10 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo(uint16_t *__restrict__ code
             const uint64_t t0 = c0 / p.B;
             const uint32_t r = (uint32_t)(c0 - t0 * p.B) + threadIdx.x;
             e.task = (uint32_t)t0 + r / p.B;
-            e.y = 0;
+            e.y = e.oy = 0;
             e.x = act ? (uint32_t)c : 0u;
             if (!act) e.task = 0;
+            e.ox = e.task * p.B;
         } else {
             // (the workgroup's first band likewise; a workgroup's codes span at most two bands when a band has TB codes or more)
             const uint64_t b0 = c0 / band;
@@ -1694,6 +1726,8 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo(uint16_t *__restrict__ code
                 const uint32_t j = ex == 16 ? rem2 >> 4 : rem2 / ex;
                 e.y = oy + j;
                 e.x = ox + (rem2 - j * ex);
+                e.oy = oy;
+                e.ox = ox;
                 e.task = by * p.nb[2] + bx;
             } else {
                 e = blkn_pos(p, act ? c : 0);
@@ -1701,15 +1735,39 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo(uint16_t *__restrict__ code
         }
         act = act && p.sel[e.task] != 2;
         UQ delta = 0;
-        if (act) {
-            const uint64_t gi = (uint64_t)e.y * d2 + e.x;
+        bool own_bad = false;
+        T own_raw = 0;
+        const uint64_t gi = (uint64_t)e.y * d2 + e.x;
+        if (act && !direct) {
             delta = (UQ)qw[gi];
             if (e.x) delta -= (UQ)qw[gi - 1];
             if (e.y) {
                 delta -= (UQ)qw[gi - d2];
                 if (e.x) delta += (UQ)qw[gi - d2 - 1];
             }
+        } else if (act) {
+            // q~ at an element: the regression blocks' from the work array, everything else from the array itself
+            auto qt = [&](uint64_t at, uint32_t task, bool own) -> UQ {
+                if (!own && p.sel[task] == 2) return (UQ)qw[at];
+                const T v = in[at];
+                bool bad;
+                const Q q = lat.quant(v, bad);
+                if (own) {
+                    own_bad = bad;
+                    own_raw = v;
+                }
+                return bad ? (UQ)0 : (UQ)q;
+            };
+            const uint32_t tl = e.x == e.ox ? e.task - 1 : e.task;  // the block of the left neighbour
+            delta = qt(gi, e.task, true);
+            if (e.x) delta -= qt(gi - 1, tl, false);
+            if (TWO && e.y) {
+                const uint32_t up = e.y == e.oy ? p.nb[2] : 0u;
+                delta -= qt(gi - d2, e.task - up, false);
+                if (e.x) delta += qt(gi - d2 - 1, tl - up, false);
+            }
         }
+        blk_vout<T>(p, act && own_bad, gi, own_raw);  // unpredictable: the raw value (a wave operation, all lanes take part)
         const bool inr = (UQ)(delta + (UQ)(p.radius - 1)) <= (UQ)(2 * p.radius - 2);
         const uint32_t code = inr ? (uint32_t)(delta + (UQ)p.radius) : 0u;
         if (act) codes[c] = (uint16_t)code;
@@ -2080,8 +2138,9 @@ static int launch_blkn_compress(int dtype, const void *d_in, uint16_t *codes, co
     do {                                                                                                                        \
         const uint32_t gfit = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                 \
         const uint32_t glor = (uint32_t)std::min<uint64_t>(BLK_GRID * 8 / NW, (n + NW * 64 - 1) / (NW * 64));                     \
-        hipLaunchKernelGGL((k_blkn_fit<T, HW, NW, TWO>), dim3(gfit), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks);   \
-        hipLaunchKernelGGL((k_blkn_lorenzo<T, HW, NW * 64, TWO>), dim3(glor), dim3(NW * 64), 0, s, codes, *p, n);                \
+        hipLaunchKernelGGL((k_blkn_fit<T, HW, NW, TWO, false>), dim3(gfit), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks, \
+                           (unsigned long long *)nullptr);                                                                          \
+        hipLaunchKernelGGL((k_blkn_lorenzo<T, HW, NW * 64, TWO>), dim3(glor), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, n); \
     } while (0)
 #define BLKN_ENC(T, HW, NW)                        \
     do {                                           \
@@ -2163,6 +2222,21 @@ int szk_launch_blk_select(int dtype, const void *d_in, const szk_blk_params *p, 
     const uint32_t nblocks = blk_count_blocks(p);
     const dim3 g((nblocks + 255) / 256), b(256);
     unsigned long long *cnt = reinterpret_cast<unsigned long long *>(n_other);
+    if (p->ndim < 3) {  // 1-D / 2-D: the fit kernel's selection form, a wave per block
+        const uint32_t gfit = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
+#define BLKN_SEL(T)                                                                                                                      \
+    do {                                                                                                                                 \
+        if (p->ndim == 2)                                                                                                                \
+            hipLaunchKernelGGL((k_blkn_fit<T, 1u, 4, true, true>), dim3(gfit), dim3(256), 0, s, (const T *)d_in, (uint16_t *)nullptr, *p, nblocks, cnt); \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((k_blkn_fit<T, 1u, 4, false, true>), dim3(gfit), dim3(256), 0, s, (const T *)d_in, (uint16_t *)nullptr, *p, nblocks, cnt); \
+    } while (0)
+        if (dtype == 0) BLKN_SEL(float);
+        else BLKN_SEL(double);
+#undef BLKN_SEL
+        SZK_CHECK_LAUNCH();
+        return 0;
+    }
 #define BLK_SEL(T, CBV)                                                                                                       \
     do {                                                                                                                      \
         if (p->mask & 2u) hipLaunchKernelGGL((k_blk_select<T, CBV, true>), g, b, 0, s, (const T *)d_in, *p, nblocks, cnt);     \

@@ -14,7 +14,7 @@ import sz3_amd  # noqa: E402
 import szh_ref  # noqa: E402
 from fields import field1d, field2d  # noqa: E402
 from oracle_binding import make_config, oracle_compress, oracle_selection  # noqa: E402
-from test_gpu_regression import MASKS, NO_EXIT, _conf, _payload_of  # noqa: E402
+from test_gpu_regression import MASKS, NO_EXIT, _block_streams_wanted, _conf, _payload_of  # noqa: E402,F401  (the autouse fixture: block streams wanted)
 
 
 def _field(shape, dtype):
@@ -46,6 +46,14 @@ def test_low_dimensional_block_stream_against_the_numpy_model(mask, dtype, shape
     assert set(np.unique(sel)) <= {0, 2}
     if mask == "L1+R":
         print(shape, "regression blocks: %.3f" % float((np.asarray(sel) == 2).mean()))
+    # the encoder without the selection pass in front (development switch 2147483648: the fit pass chooses and leaves q~ of every
+    # element in the work array, the code pass reads it back) writes the same stream
+    try:
+        sz3_amd.lib().sz3hip_debug_flags(NO_EXIT | 2147483648)
+        blob2, _ = sz3_amd.compress(a, conf)
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(NO_EXIT)
+    assert _payload_of(blob2) == _payload_of(blob)
 
 
 @pytest.mark.parametrize("shape", [(40000,), (150, 260)])
@@ -130,3 +138,23 @@ def test_grouped_and_per_block_2d_decoders_agree(shape, block, eb):
     h, o, sec = szh_ref.parse(_payload_of(blob))
     sel = np.asarray(szh_ref.parse_side(h, sec)[0])
     print(shape, "regression blocks %.3f" % float((sel == 2).mean()))
+
+
+@pytest.mark.plain_exit
+@pytest.mark.parametrize("shape,eb,exits", [((1024, 1024), 1e-3, True), ((1 << 20,), 1e-3, False), ((700, 900), 0.15, False)], ids=["2d", "C1", "2d-coarse"])
+def test_low_dimensional_fields_where_only_lorenzo_is_chosen_become_the_plain_stream(shape, eb, exits):
+    """as in 3-D: the selection runs first (k_blkn_fit's selection form); fewer than one block in 4096 choosing regression -> the
+    array goes to the plain Lorenzo path and the payload IS the one `regression = 0` gives; C1 (18 % regression blocks) keeps
+    its block stream. (In 1-D the exit is rare: the estimate looks at a block's two ends only, and a line through 128 values of
+    noise above the bound beats the previous value there — as in the reference.)"""
+    a = _field(shape, np.float32)
+    blob, ratio = sz3_amd.compress(a, _conf(shape, eb, 1, 0, 1))
+    dec, c2 = sz3_amd.decompress(blob, np.float32, shape)
+    assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= eb
+    h, o, sec = szh_ref.parse(_payload_of(blob))
+    plain, _ = sz3_amd.compress(a, _conf(shape, eb, 1, 0, 0))
+    if exits:
+        assert h["predictor"] == 0 and (c2.lorenzo, c2.regression) == (1, 0)
+        assert _payload_of(blob) == _payload_of(plain)
+    else:
+        assert h["predictor"] == 2 and (c2.lorenzo, c2.regression) == (1, 1)

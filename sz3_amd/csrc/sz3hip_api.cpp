@@ -340,8 +340,8 @@ static size_t payload_bound_n(uint64_t n, uint64_t out_cap) { return payload_bou
 // 2-D with block edges 4..32 (the decoder's block in LDS); second-order Lorenzo in 3-D only (decided where the set is known)
 static bool blk_shape_ok(const sz3hip_config *conf) {
     if (conf->N == 3) return conf->blockSize >= 4 && conf->blockSize <= 8;
-    if (conf->N == 2) return conf->blockSize >= 4 && conf->blockSize <= 32;
-    if (conf->N == 1) return conf->blockSize >= 4 && conf->blockSize <= 65535;
+    if (conf->N == 2) return conf->blockSize >= 4 && conf->blockSize <= 32 && conf->dims[0] < 0xFFFFFFFFull && conf->dims[1] < 0xFFFFFFFFull;
+    if (conf->N == 1) return conf->blockSize >= 4 && conf->blockSize <= 65535 && conf->dims[0] < 0xFFFFFFFFull;  // (positions in 32 bits)
     return false;
 }
 // the kernels' view of the array: three extents, the caller's right-aligned (1-D: (1, 1, n), 2-D: (1, dy, dx))

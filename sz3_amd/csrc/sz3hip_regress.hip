@@ -1701,22 +1701,34 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo(const T *__restrict__ in, u
     const Q *__restrict__ qw = reinterpret_cast<const Q *>(p.qwork);
     const uint64_t d2 = p.d[2];
     const uint64_t band = (uint64_t)p.B * d2;
-    for (uint64_t c0 = (uint64_t)blockIdx.x * TB; c0 < n; c0 += (uint64_t)gridDim.x * TB) {
+    // where the workgroup's first code lies (1-D: block and offset in it; 2-D: band and offset in it): one long division before
+    // the loop, carried from round to round by additions — a 64-bit division per round was a third of the pass's instructions
+    const uint64_t unit = TWO ? band : (uint64_t)p.B, stride = (uint64_t)gridDim.x * TB;
+    uint64_t u0 = ((uint64_t)blockIdx.x * TB) / unit, o0 = ((uint64_t)blockIdx.x * TB) % unit;
+    const uint64_t us = stride / unit, os = stride % unit;
+    const float rcp_b = 1.0f / (float)p.B;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * TB; c0 < n; c0 += stride, u0 += us, o0 += os) {
+        if (o0 >= unit) {
+            o0 -= unit;
+            u0++;
+        }
         const uint64_t c = c0 + threadIdx.x;
         bool act = c < n;
         BlknPos e;
-        if (!TWO) {  // the workgroup's first block by one (uniform) long division, the thread's own by a short one
-            const uint64_t t0 = c0 / p.B;
-            const uint32_t r = (uint32_t)(c0 - t0 * p.B) + threadIdx.x;
-            e.task = (uint32_t)t0 + r / p.B;
+        if (!TWO) {  // the thread's own block: a short division (offsets below B + TB: exact through the float reciprocal + one correction)
+            const uint32_t r = (uint32_t)o0 + threadIdx.x;
+            uint32_t q = (uint32_t)((float)r * rcp_b);
+            if (q * p.B > r) q--;
+            else if ((q + 1) * p.B <= r) q++;
+            e.task = (uint32_t)u0 + q;
             e.y = e.oy = 0;
             e.x = act ? (uint32_t)c : 0u;
             if (!act) e.task = 0;
             e.ox = e.task * p.B;
         } else {
             // (the workgroup's first band likewise; a workgroup's codes span at most two bands when a band has TB codes or more)
-            const uint64_t b0 = c0 / band;
-            const uint64_t off = c0 - b0 * band + threadIdx.x;
+            const uint64_t b0 = u0;
+            const uint64_t off = o0 + threadIdx.x;
             if (off < 2 * band && band < 0x80000000ull && act) {
                 const uint32_t by = (uint32_t)b0 + (off >= band ? 1u : 0u);
                 const uint32_t rem = (uint32_t)(off >= band ? off - band : off);

@@ -286,6 +286,54 @@ def cpu_baseline(w):
     return out
 
 
+def c1_numbers(torch, sz3_amd, dev, local_rank, steps=20):
+    """C1 on the device path: the first 2^20 values of the C2 field as a 1-D array, Lorenzo + regression per block of 128 values
+    (sz3hip_regress.hip, k_blkn_*), abs 1e-3; device-resident in -> device payload. 4 MB: the step is bound by its launches."""
+    from fields import field1d
+    n = 1 << 20
+    a = field1d(n, np.float32)
+    d_in = torch.from_numpy(a).to(dev)
+    conf = sz3_amd.Config(n)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG  # (defaults: lorenzo = regression = 1, blockSize 128)
+    conf.errorBoundMode = sz3_amd.EB_ABS
+    conf.absErrorBound = 1e-3
+    dc = sz3_amd.DeviceCompressor(n, np.float32, device=local_rank)
+    cap = max(dc.payload_bound(n), dc.payload_bound_conf(conf))
+    d_pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(n, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def comp():
+        dc.stage1(conf, d_in.data_ptr(), st)
+        dc.stage2(d_pl.data_ptr(), cap, st)
+        return dc.finish(st)
+
+    for _ in range(3):
+        size = comp()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        size = comp()
+    torch.cuda.synchronize()
+    tc = (time.perf_counter() - t0) / steps
+    for _ in range(2):
+        dc.decompress(d_pl.data_ptr(), size, d_out.data_ptr(), st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dc.decompress(d_pl.data_ptr(), size, d_out.data_ptr(), st)
+    torch.cuda.synchronize()
+    td = (time.perf_counter() - t0) / steps
+    err = float((d_out.double() - d_in.double()).abs().max())
+    hdr = bytes(d_pl[:160].cpu().numpy())
+    return {"config": "C1: 1D float32 2^20 values, ALGO_LORENZO_REG defaults (Lorenzo + regression per block of 128), abs errBound=1e-3, 1 GPU",
+            "value": round(a.nbytes / tc / 1e9, 3), "unit": "GB/s", "steps": steps, "ms_per_step": round(tc * 1e3, 4),
+            "ratio": round(a.nbytes / float(size), 4), "max_abs_err": err, "err_bound_ok": bool(err <= 1e-3),
+            "stream_predictor": int(hdr[11]),  # (SZH1 header: 2 = block-composed)
+            "decompress_device": {"ms": round(td * 1e3, 4), "gbps": round(a.nbytes / td / 1e9, 2)},
+            "note": "4 MB per call: launch-bound (about twenty kernels a step)"}
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -409,7 +457,8 @@ def main():
                                       "note": ("the selection pass found fewer than 1/4096 of the blocks choosing another predictor than Lorenzo-1: "
                                                "plain Lorenzo stream" if pid == 0 else "block-composed stream (selection bits + regression coefficients)")}
         out.update(rooflines(w, acc, psize, ms_per_step,
-                             "lorenzo_quant_hist_hbm_bytes_per_launch" if is_c2 else "c3_stage1_hbm_bytes_per_step" if is_c3 else None))
+                             "lorenzo_quant_hist_hbm_bytes_per_launch" if is_c2 else "c3_stage1_hbm_bytes_per_step" if is_c3
+                             else "c4_composed_stage1_hbm_bytes_per_step" if is_c4c else None))
 
     if rank == 0 and world == 1 and not args.no_cold:
         out["cold"] = w.cold_numbers(max(5, args.steps // 2), barrier)
@@ -484,6 +533,13 @@ def main():
             del w3
         except Exception as e:  # noqa: BLE001 - the headline line must survive a failing extra
             out["extra_configs"] = {"C3": {"error": repr(e)[:300]}}
+
+    # ---- configs[0] of BASELINE.json (C1: 1-D, 2^20 values, ALGO_LORENZO_REG defaults = Lorenzo + regression in blocks of 128) ----
+    if rank == 0 and world == 1 and not args.no_extra and args.algo == "lorenzo" and args.dtype == "f32" and tuple(shape) == (512, 512, 512):
+        try:
+            out.setdefault("extra_configs", {})["C1"] = c1_numbers(torch, sz3_amd, dev, local_rank)
+        except Exception as e:  # noqa: BLE001
+            out.setdefault("extra_configs", {})["C1"] = {"error": repr(e)[:300]}
 
     # ---- CPU baseline on this box's host cores (rank 0, N=1 only; checker code, never the product) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -322,3 +322,4 @@ def test_block_stream_with_a_wide_alphabet_on_a_reused_context():
     h, _, sec = szh_ref.parse(payloads["rows"])
     assert h["predictor"] == 2 and h["sym_count"] > 3000
     assert payloads["rows"] == payloads["tiles"]
+

@@ -15,3 +15,5 @@ timeout 900 bash tools/pmc.sh > $O/pmc.log 2>&1; cp gpurun_out/pmc_summary.txt $
 for d in pmc_fetch pmc_write; do cp gpurun_out/$d/*counter_collection.csv $O/${d}_counters.csv 2>/dev/null; done
 timeout 600 bash tools/pmc_blk.sh > $O/pmc_blk_select.txt 2>&1
 tail -5 $O/c4_default.txt; tail -3 $O/c4_c4a.txt
+timeout 900 bash tools/blkn_run.sh > $O/blkn.txt 2>&1; cp gpurun_out/blkn/stats_1d.txt $O/blkn_kernels_1d.txt; cp gpurun_out/blkn/stats_2d.txt $O/blkn_kernels_2d.txt; cp gpurun_out/blkn/times.txt $O/blkn_times.txt
+cat $O/blkn_times.txt

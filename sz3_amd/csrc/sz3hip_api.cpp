@@ -636,7 +636,7 @@ static int blk_reserve(sz3hip_ctx *ctx, uint64_t nblocks) {
     }
     ctx->blk_cap = 0;
     HIPCHK(hipMalloc((void **)&ctx->d_blk_rank, nblocks * 4));
-    HIPCHK(hipMalloc((void **)&ctx->d_blk_comp, nblocks * 4));
+    HIPCHK(hipMalloc((void **)&ctx->d_blk_comp, nblocks * 4 + 64));  // (+ 64: the decoder keeps the coefficient groups' sums here, 32 bytes per 64 regression blocks)
     HIPCHK(hipMalloc((void **)&ctx->d_blk_side, szk_blk_side_bound(nblocks)));
     ctx->blk_cap = nblocks;
     return 0;
@@ -1610,8 +1610,9 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         // block-composed stream: selection + coefficients from the side section — read, checked and unpacked first, on the side
         // stream, while the Huffman decoder runs on the caller's
         const uint32_t B = h.interp_id, mask = h.interp_dir;
-        const bool shape_ok = h.ndim == 3 ? B >= 4 && B <= 8 : (h.ndim == 2 ? B >= 4 && B <= 32 && h.dims[1] == 1 && !(mask & 2u)
-                                                                 : h.ndim == 1 && B >= 4 && B <= 65535 && h.dims[1] == 1 && h.dims[2] == 1 && !(mask & 2u));
+        const bool fits32 = h.dims[1] < 0xFFFFFFFFull && h.dims[2] < 0xFFFFFFFFull && h.dims[3] < 0xFFFFFFFFull;  // (block positions are 32-bit)
+        const bool shape_ok = fits32 && (h.ndim == 3 ? B >= 4 && B <= 8 : (h.ndim == 2 ? B >= 4 && B <= 32 && h.dims[1] == 1 && !(mask & 2u)
+                                                                 : h.ndim == 1 && B >= 4 && B <= 65535 && h.dims[1] == 1 && h.dims[2] == 1 && !(mask & 2u)));
         if (!shape_ok || mask == 0 || mask > 7 || h.side_bytes < 24 || h.n_dout > h.n)
             return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block predictor fields)");
         uint64_t nblocks = 1;

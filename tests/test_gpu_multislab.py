@@ -86,6 +86,41 @@ def test_openmp_container_of_gpu_streams_round_trips_with_one_code_book(algo, sl
             assert np.array_equal(sz3_amd.decompress(sb, dtype, (hi - lo,) + shape[1:])[0], dec[lo:hi])
 
 
+@pytest.mark.parametrize("shape,eb", [((1 << 18,), 1e-3), ((600, 400), 0.15)], ids=["1d", "2d"])
+def test_low_dimensional_lorenzo_plus_regression_through_the_slab_path(shape, eb, rccl, monkeypatch):
+    """C1's predictor set (and its 2-D form) split into three slabs along dims[0]: every slab a block-composed stream of its own
+    dimension count with the SAME code book, the container within the bound, every slab equal to a single-slab call on it"""
+    from fields import field1d, field2d
+    monkeypatch.setenv("SZ3HIP_SLABS", "3")
+    a = field1d(shape[0], np.float32) if len(shape) == 1 else field2d(shape, np.float32)
+    conf = sz3_amd.Config(*shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG  # (defaults: lorenzo + regression, blockSize 128 / 16)
+    conf.absErrorBound = eb
+    conf.openmp = 1
+    blob, ratio = sz3_amd.compress(a, conf)
+    outer, confs, blobs = D.split_container(blob.tobytes())
+    assert len(blobs) == 3
+    books, reg_blocks = [], 0
+    for g in range(3):
+        sc = sz3_amd.Config.load(confs[g])
+        assert (sc.lorenzo, sc.lorenzo2, sc.regression) == (1, 0, 1)
+        h, o, sec = szh_ref.parse(_unzstd(blobs[g]))
+        assert h["predictor"] == 2 and h["ndim"] == len(shape) and h["blk_edge"] == (128 if len(shape) == 1 else 16)
+        reg_blocks += int((np.asarray(szh_ref.parse_side(h, sec)[0]) == 2).sum())
+        books.append((h["sym_min"], h["sym_count"], sec["lens"].tobytes()))
+    assert all(b == books[0] for b in books) and reg_blocks > 0
+    dec, c2 = sz3_amd.decompress(blob, np.float32, shape)
+    assert c2.openmp == 1 and float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= eb
+    conf.openmp = 0
+    for g in range(3):
+        lo, hi = D.slab_bounds(shape[0], 3, g)
+        sconf = sz3_amd.Config(hi - lo, *shape[1:])
+        for k in ("cmprAlgo", "lorenzo", "lorenzo2", "regression", "absErrorBound"):
+            setattr(sconf, k, getattr(conf, k))
+        sb, _ = sz3_amd.compress(np.ascontiguousarray(a[lo:hi]), sconf)
+        assert np.array_equal(sz3_amd.decompress(sb, np.float32, (hi - lo,) + shape[1:])[0], dec[lo:hi])
+
+
 @pytest.mark.parametrize("slabs", [2, 3])
 def test_c4_lorenzo_plus_regression_through_the_slab_path(slabs, rccl, monkeypatch):
     """BASELINE config C4 in small: float64, Lorenzo + regression chosen per block (the reference's default predictor set for

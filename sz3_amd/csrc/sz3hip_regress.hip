@@ -1826,6 +1826,130 @@ __global__ __launch_bounds__(NW * 64) void k_blkn_fit(const T *__restrict__ in, 
     }
 }
 
+// 1-D, the fit pass by ROWS OF 16 LANES: four blocks per wave, a block per DPP row. A wave per block of 128 values spends ~600
+// instructions on it — the fit's double divisions, the coefficient snapping, the block's geometry, the loops' bookkeeping — and
+// only the sums are work that all 64 lanes share: here the per-block arithmetic is done once per ROW (each of its lanes holds the
+// same values), four blocks for the price of one, and the two sums are reduced inside the rows. The selection's two sample
+// points (the block's ends) are evaluated by every lane of the row in the reference's order (no reduction at all).
+__device__ __forceinline__ double row16_sum_f64(double v) {  // the sum over the lane's row of 16, in every lane of it
+    for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+template <typename T, uint32_t HW, int NW>
+__global__ __launch_bounds__(NW * 64) void k_blkn_fit_rows(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
+    using Q = typename QTraits<T>::Q;
+    __shared__ uint32_t lh[HW];
+    for (uint32_t b = threadIdx.x; b < HW; b += NW * 64) lh[b] = 0;
+    __syncthreads();
+    const Lattice<T> lat(p.lat);
+    const uint32_t lane = (uint32_t)lane_id(), row = lane >> 4, li = lane & 15u;
+    const uint32_t wv = threadIdx.x / WAVE;
+    Q *qwork = reinterpret_cast<Q *>(p.qwork);
+    const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
+    const double eb_recip = 1.0 / p.eb;
+    const bool has_l1 = p.mask & 1u, has_r = p.mask & 4u;
+    const T noise = (T)(0.5 * p.eb);
+    const uint32_t n = (uint32_t)p.d[2];
+    for (uint32_t base = (blockIdx.x * NW + wv) * 4; base < nblocks; base += gridDim.x * NW * 4) {  // (wave-uniform)
+        const uint32_t task = base + row;
+        const bool live = task < nblocks;
+        const uint32_t ox = live ? task * p.B : 0u;
+        const uint32_t ex = live ? min(p.B, n - ox) : 0u;
+        // ---- regression fit (RegressionPredictor.hpp:28-55, N = 1) ----
+        const bool r_valid = has_r && ex > 1;
+        double s2 = 0, s3 = 0;
+        for (uint32_t t0 = 0; t0 < p.B; t0 += 16) {
+            const uint32_t t = t0 + li;
+            if (t < ex) {
+                const T v = in[ox + t];
+                s2 += (double)((T)t * v);
+                s3 += (double)v;
+            }
+        }
+        s2 = row16_sum_f64(s2);
+        s3 = row16_sum_f64(s3);
+        T c1 = 0, c0 = 0;
+        if (r_valid) {
+            const double dx = ex;
+            c1 = (T)((2 * s2 / (dx - 1) - s3) * 6 / dx / (dx + 1));
+            c0 = (T)(s3 / dx);
+            c0 = (T)((double)c0 - (dx - 1) * (double)c1 / 2);
+        }
+        // ---- selection (ComposedPredictor.hpp:25-40; BlockwiseIterator.hpp:151-184, N = 1: the points 0 and m - 1, in that order) ----
+        int sid = has_l1 ? 0 : 2;
+        const T cfv[4] = {0, 0, c1, c0};
+        if (has_l1 && has_r && live) {
+            double e1 = 0, er = 0;
+            for (int k = 0; k < 2; k++) {
+                const uint32_t i2 = k ? ex - 1 : 0u;
+                const uint32_t x = ox + i2;
+                const T v = in[x];
+                T pr = 0;  // LorenzoPredictor.hpp:61: d[-1] — the original inside the block, the lattice reconstruction left of it, zero left of the array
+                if (x) {
+                    pr = in[x - 1];
+                    if (i2 == 0) {
+                        bool bad;
+                        const Q qh = lat.quant(pr, bad);
+                        if (!bad) pr = lat.dequant(qh);
+                    }
+                }
+                e1 += (double)(T)((T)fabs((double)(T)(v - pr)) + noise);
+                if (r_valid) er += (double)(T)fabs((double)(T)(v - reg_predict(cfv, 0u, 0u, i2)));
+            }
+            sid = (r_valid && er < e1) ? 2 : 0;
+        } else if (sid == 2 && !r_valid) {
+            sid = 0;  // BlockwiseDecomposition.hpp:35-37
+        }
+        int64_t l1 = 0, l0 = 0;
+        if (sid == 2) {  // coefficients onto their lattices; a coefficient the lattice cannot hold -> Lorenzo-1
+            const double a1 = (double)c1 / cl.step_lin, a0 = (double)c0 / cl.step_ind;
+            if (!(fabs(a1) < 4503599627370496.0) || !(fabs(a0) < 4503599627370496.0)) sid = 0;
+            else {
+                l1 = (int64_t)rint(a1);
+                l0 = (int64_t)rint(a0);
+            }
+        }
+        const T rcv[4] = {0, 0, (T)((double)l1 * cl.step_lin), (T)((double)l0 * cl.step_ind)};  // (coef_recover's arithmetic)
+        // ---- codes of the regression blocks, q~ of every element ----
+        for (uint32_t t0 = 0; t0 < p.B; t0 += 16) {  // (the same trip count in every row: the list appends and counts are wave operations)
+            const uint32_t t = t0 + li;
+            const bool act = t < ex;
+            const uint32_t gi = ox + (act ? t : 0u);
+            const T raw = act ? in[gi] : (T)0;
+            bool bad = false;
+            Q qt = 0;
+            int code = 1;
+            if (sid == 2) {
+                T v = raw;
+                code = act ? ref_quantize(v, reg_predict(rcv, 0u, 0u, t), p.eb, eb_recip, (int)p.radius) : 1;
+                if (code != 0) {
+                    qt = lat.quant(v, bad);
+                    if (bad) qt = 0;
+                }
+                bad = code == 0;  // unpredictable: the raw value, LinearQuantizer.hpp:66-69
+                if (act) codes[gi] = (uint16_t)code;  // (1-D: the block-major code order is the element order)
+            } else {
+                qt = lat.quant(raw, bad);
+                if (bad) qt = 0;
+            }
+            if (act) qwork[gi] = qt;
+            blk_count<HW>(lh, p, (uint32_t)code, act && sid == 2);
+            blk_vout<T>(p, act && bad, gi, raw);
+        }
+        if (live && li == 0) {
+            p.sel[task] = (uint8_t)sid;
+            if (sid == 2) {
+                p.coef[(uint64_t)task * 4 + 0] = 0;
+                p.coef[(uint64_t)task * 4 + 1] = 0;
+                p.coef[(uint64_t)task * 4 + 2] = l1;
+                p.coef[(uint64_t)task * 4 + 3] = l0;
+            }
+        }
+    }
+    __syncthreads();
+    blk_flush<HW>(lh, p);
+}
+
 // code position -> block and element of the (1, dy, dx) view: the bands of B rows hold B * dx codes each, a band's blocks ey * B
 struct BlknPos {
     uint32_t task, y, x, ox, oy;
@@ -2312,6 +2436,10 @@ static int launch_blkn_compress(int dtype, const void *d_in, uint16_t *codes, co
     do {                                                                                                                        \
         const uint32_t gfit = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                 \
         const uint32_t glor = (uint32_t)std::min<uint64_t>(BLK_GRID * 8 / NW, (n + NW * 64 - 1) / (NW * 64));                     \
+        if (!TWO && !p->sel_given && !(szk_dbg_flags & 134217728)) { /* 1-D: four blocks per wave (debug flag 134217728: a wave per block) */ \
+            const uint32_t grow = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW * 4 - 1) / (NW * 4));    \
+            hipLaunchKernelGGL((k_blkn_fit_rows<T, HW, NW>), dim3(grow), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks); \
+        } else                                                                                                                  \
         hipLaunchKernelGGL((k_blkn_fit<T, HW, NW, TWO, false>), dim3(gfit), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks, \
                            (unsigned long long *)nullptr);                                                                          \
         hipLaunchKernelGGL((k_blkn_lorenzo<T, HW, NW * 64, TWO>), dim3(glor), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, n); \

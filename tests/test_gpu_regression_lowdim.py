@@ -158,3 +158,25 @@ def test_low_dimensional_fields_where_only_lorenzo_is_chosen_become_the_plain_st
         assert _payload_of(blob) == _payload_of(plain)
     else:
         assert h["predictor"] == 2 and (c2.lorenzo, c2.regression) == (1, 1)
+
+
+@pytest.mark.parametrize("n,block,dtype", [(1 << 20, None, np.float32), (100003, 100, np.float32), (40000, 7, np.float64)])
+def test_1d_fit_by_rows_of_lanes_and_by_waves_agree(n, block, dtype):
+    """1-D: four blocks per wave (a block per DPP row of 16 lanes, k_blkn_fit_rows) against a wave per block (debug flag 134217728):
+    the same choices and the same stream (the sums are taken in a different order: coefficients could differ in the last bit of a
+    double, not on these fields)"""
+    a = field1d(n, dtype)
+    conf = _conf((n,), 1e-3, 1, 0, 1, block=block)
+    blobs = []
+    try:
+        for flag in (NO_EXIT, NO_EXIT | 134217728):
+            sz3_amd.lib().sz3hip_debug_flags(flag)
+            blob, _ = sz3_amd.compress(a, conf)
+            blobs.append(_payload_of(blob))
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(0)
+    h0, _, s0 = szh_ref.parse(blobs[0])
+    h1, _, s1 = szh_ref.parse(blobs[1])
+    sel0, sel1 = np.asarray(szh_ref.parse_side(h0, s0)[0]), np.asarray(szh_ref.parse_side(h1, s1)[0])
+    assert np.array_equal(sel0, sel1) and (sel0 == 2).any() and (sel0 == 0).any()
+    assert blobs[0] == blobs[1]

@@ -1858,6 +1858,25 @@ __global__ __launch_bounds__(NW * 64) void k_blkn_fit_rows(const T *__restrict__
         // ---- regression fit (RegressionPredictor.hpp:28-55, N = 1) ----
         const bool r_valid = has_r && ex > 1;
         double s2 = 0, s3 = 0;
+        // blocks of up to 128 values (the default): the lane's eight values are requested together and kept for the coding loop
+        constexpr int NV = 8;
+        const bool kept = p.B <= 16u * NV;
+        T vals[NV];
+        if (kept) {
+#pragma unroll
+            for (int m = 0; m < NV; m++) {
+                const uint32_t t = li + 16u * m;
+                vals[m] = t < ex ? in[ox + t] : (T)0;
+            }
+#pragma unroll
+            for (int m = 0; m < NV; m++) {
+                const uint32_t t = li + 16u * m;
+                if (t < ex) {
+                    s2 += (double)((T)t * vals[m]);
+                    s3 += (double)vals[m];
+                }
+            }
+        } else
         for (uint32_t t0 = 0; t0 < p.B; t0 += 16) {
             const uint32_t t = t0 + li;
             if (t < ex) {
@@ -1915,7 +1934,14 @@ __global__ __launch_bounds__(NW * 64) void k_blkn_fit_rows(const T *__restrict__
             const uint32_t t = t0 + li;
             const bool act = t < ex;
             const uint32_t gi = ox + (act ? t : 0u);
-            const T raw = act ? in[gi] : (T)0;
+            T raw = 0;
+            if (kept) {
+#pragma unroll
+                for (int m = 0; m < NV; m++)
+                    if (t0 == 16u * m) raw = vals[m];
+            } else if (act) {
+                raw = in[gi];
+            }
             bool bad = false;
             Q qt = 0;
             int code = 1;

@@ -2106,6 +2106,74 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo(const T *__restrict__ in, u
     blk_flush<HW>(lh, p);
 }
 
+// 1-D, the work array holds q~ of every element (the fit pass chose and coded in one go): FOUR codes per thread — one 16-byte load
+// of lattice values, the left neighbours from registers, one 8-byte store of codes; the block of an element from one short
+// division per thread (a thread's four elements lie in at most two blocks when B >= 4).
+template <typename T, uint32_t HW, int TB>
+__global__ __launch_bounds__(TB) void k_blkn_lorenzo1v(uint16_t *__restrict__ codes, szk_blk_params p, uint64_t n) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    __shared__ uint32_t lh[HW];
+    for (uint32_t b = threadIdx.x; b < HW; b += TB) lh[b] = 0;
+    __syncthreads();
+    const Q *__restrict__ qw = reinterpret_cast<const Q *>(p.qwork);
+    const uint64_t stride = (uint64_t)gridDim.x * TB * 4;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * TB * 4; c0 < n; c0 += stride) {  // (workgroup-uniform: every lane takes part in the wave operations)
+        const uint64_t c = c0 + (uint64_t)threadIdx.x * 4;
+        const bool any = c < n;
+        const uint32_t task0 = any ? (uint32_t)c / p.B : 0u;  // (positions of a 1-D block stream fit 32 bits: blk_shape_ok)
+        const uint64_t next = ((uint64_t)task0 + 1) * p.B;  // first element of the following block
+        Q q[4] = {0, 0, 0, 0};
+        Q left = 0;
+        if (any) {
+            if (c + 3 < n) {
+                if (sizeof(Q) == 4) {
+                    const int4 v = *reinterpret_cast<const int4 *>(qw + c);
+                    q[0] = (Q)v.x; q[1] = (Q)v.y; q[2] = (Q)v.z; q[3] = (Q)v.w;
+                } else {
+                    const longlong2 v0 = *reinterpret_cast<const longlong2 *>(qw + c), v1 = *reinterpret_cast<const longlong2 *>(qw + c + 2);
+                    q[0] = (Q)v0.x; q[1] = (Q)v0.y; q[2] = (Q)v1.x; q[3] = (Q)v1.y;
+                }
+            } else {
+                for (int j = 0; j < 4; j++)
+                    if (c + j < n) q[j] = qw[c + j];
+            }
+            if (c) left = qw[c - 1];
+        }
+        const uint8_t s0 = any ? p.sel[task0] : (uint8_t)2, s1 = any && next < n ? p.sel[task0 + 1] : (uint8_t)2;
+        uint32_t code4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t cj = c + j;
+            const bool act = cj < n && (cj < next ? s0 : s1) != 2;
+            const UQ delta = (UQ)q[j] - (UQ)(j ? q[j - 1] : left);
+            const bool inr = (UQ)(delta + (UQ)(p.radius - 1)) <= (UQ)(2 * p.radius - 2);
+            const uint32_t code = inr ? (uint32_t)(delta + (UQ)p.radius) : 0u;
+            code4[j] = code;
+            blk_count<HW>(lh, p, code, act);
+            const unsigned long long pd = wave_append_slot(act && !inr, p.n_dout);
+            if (act && !inr && pd < p.out_cap) {
+                p.dout_idx[pd] = cj;
+                reinterpret_cast<Q *>(p.dout_val)[pd] = (Q)delta;
+            }
+            if (!act) code4[j] = 0xFFFFFFFFu;  // (a regression block's code: written by the fit pass, left alone)
+        }
+        if (any) {
+            const bool all = code4[0] != 0xFFFFFFFFu && code4[1] != 0xFFFFFFFFu && code4[2] != 0xFFFFFFFFu && code4[3] != 0xFFFFFFFFu;
+            if (all) {
+                ushort4 o;
+                o.x = (uint16_t)code4[0]; o.y = (uint16_t)code4[1]; o.z = (uint16_t)code4[2]; o.w = (uint16_t)code4[3];
+                *reinterpret_cast<ushort4 *>(codes + c) = o;
+            } else {
+                for (int j = 0; j < 4; j++)
+                    if (code4[j] != 0xFFFFFFFFu) codes[c + j] = (uint16_t)code4[j];
+            }
+        }
+    }
+    __syncthreads();
+    blk_flush<HW>(lh, p);
+}
+
 // ---- decoder ----
 // regression blocks: q~ of their elements into the output (as lattice words; k_blk_final turns everything into T). 1-D: every
 // block leaves its aggregate for the scan over the blocks — a regression block the lattice value of its last element, a Lorenzo
@@ -2468,6 +2536,10 @@ static int launch_blkn_compress(int dtype, const void *d_in, uint16_t *codes, co
         } else                                                                                                                  \
         hipLaunchKernelGGL((k_blkn_fit<T, HW, NW, TWO, false>), dim3(gfit), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks, \
                            (unsigned long long *)nullptr);                                                                          \
+        if (!TWO && !p->sel_given && !(szk_dbg_flags & 134217728)) { /* 1-D, q~ of everything in the work array: four codes per thread */ \
+            const uint32_t g4 = (uint32_t)std::min<uint64_t>(BLK_GRID * 8 / NW, (n + NW * 256 - 1) / (NW * 256));                  \
+            hipLaunchKernelGGL((k_blkn_lorenzo1v<T, HW, NW * 64>), dim3(g4), dim3(NW * 64), 0, s, codes, *p, n);                   \
+        } else                                                                                                                  \
         hipLaunchKernelGGL((k_blkn_lorenzo<T, HW, NW * 64, TWO>), dim3(glor), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, n); \
     } while (0)
 #define BLKN_ENC(T, HW, NW)                        \

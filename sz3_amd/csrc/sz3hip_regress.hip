@@ -2200,12 +2200,17 @@ __global__ __launch_bounds__(256) void k_blkn_pre(const uint16_t *__restrict__ c
                 const uint32_t i1 = t / g.ex, i2 = t - i1 * g.ex;
                 const uint32_t code = codes[g.coff + t];
                 Q qt = 0;
+                T val = 0;  // (code 0: patched from the list)
                 if (code) {
                     bool bad;
-                    qt = lat.quant(ref_recover(reg_predict(rc, 0u, i1, i2), (int)code, p.eb, (int)p.radius), bad);
+                    val = ref_recover(reg_predict(rc, 0u, i1, i2), (int)code, p.eb, (int)p.radius);
+                    qt = lat.quant(val, bad);
                     if (bad) qt = 0;
                 }
-                qout[(uint64_t)(g.oy + i1) * d2 + (g.ox + i2)] = qt;
+                // 1-D: nothing reads a regression block's lattice values but the scan over the blocks (its last element's, below):
+                // the element's final value goes out here and the final pass is not run
+                if (p.ndim == 1) reinterpret_cast<T *>(d_out)[g.ox + i2] = val;
+                else qout[(uint64_t)(g.oy + i1) * d2 + (g.ox + i2)] = qt;
                 if (p.ndim == 1 && t == nown - 1) agg[2 * (uint64_t)task] = qt;
             }
         } else if (p.ndim == 1) {
@@ -2310,7 +2315,7 @@ __global__ __launch_bounds__(256) void k_blkn_apply1(const void *deltas_, void *
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     const int lane = lane_id();
-    Q *qout = reinterpret_cast<Q *>(d_out);
+    const Lattice<T> lat(p.lat);
     const Q *deltas = reinterpret_cast<const Q *>(deltas_);
     const Q *agg = reinterpret_cast<const Q *>(p.carry);
     const Q *tile = blkn_tiles<Q>(p.carry, nblocks);
@@ -2324,7 +2329,7 @@ __global__ __launch_bounds__(256) void k_blkn_apply1(const void *deltas_, void *
             const uint32_t t = t0 + lane;
             const UQ dl = t < g.ex ? (UQ)deltas[g.coff + t] : (UQ)0;
             const UQ incl = wave_incl_scan(dl) + run;
-            if (t < g.ex) qout[g.ox + t] = (Q)incl;
+            if (t < g.ex) reinterpret_cast<T *>(d_out)[g.ox + t] = lat.dequant((Q)incl);  // (the final value: no pass over the array after this one)
             run = (UQ)__shfl((long long)incl, WAVE - 1);
         }
     }
@@ -2757,6 +2762,14 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
     }
     }
     const uint32_t grid = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
+    if (p->ndim == 1) {  // (the 1-D passes above wrote final values)
+        if (h->n_vout) {
+            if (dtype == 0) hipLaunchKernelGGL(k_blk_patch<float>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (float *)d_out);
+            else hipLaunchKernelGGL(k_blk_patch<double>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (double *)d_out);
+        }
+        SZK_CHECK_LAUNCH();
+        return 0;
+    }
     if (dtype == 0) {
         if (p->B == 6) hipLaunchKernelGGL((k_blk_final<float, 6>), dim3(grid), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);
         else hipLaunchKernelGGL((k_blk_final<float, 0>), dim3(grid), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);

@@ -169,7 +169,7 @@ def test_c_headers_are_plain_c(tmp_path):
     if not gcc:
         pytest.skip("no gcc")
     src = tmp_path / "hdr.c"
-    src.write_text('#include "sz3hip.h"\n#include "sz3c.h"\nint main(void) { return 0; }\n')
+    src.write_text('#include "sz3hip.h"\n#include "sz3c.h"\n#include "sz3hip_h5z.h"\nint main(void) { return 0; }\n')
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -183,3 +183,54 @@ def test_committed_traffic_file_has_the_key_the_bench_reads():
     d = json.load(open(path))
     t = d.get("lorenzo_quant_hist_hbm_bytes_per_launch")
     assert isinstance(t, int) and 537_000_000 + 134_000_000 <= t < 2 * 671_000_000  # at least the compulsory read + write
+
+
+class _H5ZClass2(C.Structure):  # include/sz3hip_h5z.h: HDF5's H5Z_class2_t
+    _fields_ = [("version", C.c_int), ("id", C.c_int), ("encoder_present", C.c_uint), ("decoder_present", C.c_uint), ("name", C.c_char_p),
+                ("can_apply", C.c_void_p), ("set_local", C.c_void_p), ("filter", C.c_void_p)]
+
+
+def _cd_values(conf_c):
+    buf = (C.c_ubyte * 512)()
+    n = sz3_amd.lib().sz3hip_config_save(C.byref(conf_c), buf)
+    words = (n + 3) // 4
+    return (C.c_uint * words).from_buffer_copy(bytes(buf[:words * 4])), words
+
+
+def test_hdf5_plugin_face_without_a_device():
+    """tools/H5Z-SZ3/src/H5Z_SZ3.cpp:11-24, 179-193: the two symbols HDF5 looks up in a plugin, the class record (version 1, id
+    32024, encoder + decoder, the filter function), the pass-through cases — and the filter FAILS (returns 0, HDF5's "filter
+    failed") on a box without a HIP device instead of compressing on the CPU"""
+    L = sz3_amd.lib()
+    L.H5PLget_plugin_type.restype = C.c_int
+    L.H5PLget_plugin_info.restype = C.POINTER(_H5ZClass2)
+    L.sz3hip_h5z_filter.restype = C.c_size_t
+    L.sz3hip_h5z_filter.argtypes = [C.c_uint, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
+    assert L.H5PLget_plugin_type() == 0  # H5PL_TYPE_FILTER
+    rec = L.H5PLget_plugin_info().contents
+    assert (rec.version, rec.id, rec.encoder_present, rec.decoder_present) == (1, 32024, 1, 1) and b"SZ3" in rec.name
+    assert rec.filter == C.cast(L.sz3hip_h5z_filter, C.c_void_p).value and rec.can_apply is None
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.free.argtypes = [C.c_void_p]
+    data = np.arange(4096, dtype=np.float32)
+    buf = C.c_void_p(libc.malloc(data.nbytes))
+    C.memmove(buf, data.ctypes.data, data.nbytes)
+    size = C.c_size_t(data.nbytes)
+    assert L.sz3hip_h5z_filter(0, 0, None, data.nbytes, C.byref(size), C.byref(buf)) == data.nbytes  # cd_nelmts == 0: not values
+    small = sz3_amd.Config(10)
+    cdv, words = _cd_values(small._c)
+    assert L.sz3hip_h5z_filter(0, words, cdv, 40, C.byref(size), C.byref(buf)) == 40  # conf.num < 20: passed through
+    conf = sz3_amd.Config(16, 16, 16)
+    conf.absErrorBound = 1e-3
+    cdv, words = _cd_values(conf._c)
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        assert L.sz3hip_h5z_filter(0, words, cdv, data.nbytes, C.byref(size), C.byref(buf)) == 0
+        assert b"device" in L.sz3hip_last_error().lower() or b"hip" in L.sz3hip_last_error().lower()
+    assert L.sz3hip_h5z_filter(0, 3, cdv, data.nbytes, C.byref(size), C.byref(buf)) == 0  # truncated cd_values: no Config in them
+    libc.free(buf)

@@ -233,6 +233,8 @@ size_t szk_blk_side_bound(uint64_t nblocks);
 // codes -> lattice deltas (code - radius) in d_out, the delta outliers scattered over them (Lorenzo and block streams)
 int szk_launch_expand_deltas(int dtype, const uint16_t *codes, uint64_t n, int radius, const uint8_t *payload, const szh_offsets *o,
                              uint64_t n_dout, void *d_out, hipStream_t s);
+// the delta outliers alone, scattered to their code positions in d_out (nothing else of d_out is written)
+int szk_launch_scatter_deltas(int dtype, uint64_t n, const uint8_t *payload, const szh_offsets *o, uint64_t n_dout, void *d_out, hipStream_t s);
 
 // ---- interpolation predictor (sz3hip_interp.hip) ----
 struct szk_interp_params {  // what InterpolationDecomposition keeps (decomposition/InterpolationDecomposition.hpp:456-477)

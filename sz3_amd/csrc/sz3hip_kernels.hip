@@ -4546,6 +4546,19 @@ static int launch_reconstruct(bool x_done, const uint8_t *payload, const szh_hea
     SZK_CHECK_LAUNCH();
     return 0;
 }
+// the delta outliers alone, scattered to their code positions (a decoder that reads the codes itself looks here where a code is 0)
+int szk_launch_scatter_deltas(int dtype, uint64_t n, const uint8_t *payload, const szh_offsets *o, uint64_t n_dout, void *d_out, hipStream_t s) {
+    if (n_dout) {
+        if (dtype == 0)
+            hipLaunchKernelGGL(k_scatter_dout<int32_t>, dim3(grid_for(n_dout, 256, 4096)), dim3(256), 0, s, payload, o->dout_idx, o->dout_val, n_dout, n,
+                               (int32_t *)d_out);
+        else
+            hipLaunchKernelGGL(k_scatter_dout<int64_t>, dim3(grid_for(n_dout, 256, 4096)), dim3(256), 0, s, payload, o->dout_idx, o->dout_val, n_dout, n,
+                               (int64_t *)d_out);
+    }
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
 int szk_launch_expand_deltas(int dtype, const uint16_t *codes, uint64_t n, int radius, const uint8_t *payload, const szh_offsets *o,
                              uint64_t n_dout, void *d_out, hipStream_t s) {
     if (dtype == 0) {

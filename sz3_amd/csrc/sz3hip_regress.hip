@@ -2214,8 +2214,13 @@ __global__ __launch_bounds__(256) void k_blkn_pre(const uint16_t *__restrict__ c
                 if (p.ndim == 1 && t == nown - 1) agg[2 * (uint64_t)task] = qt;
             }
         } else if (p.ndim == 1) {
+            // (1-D: the codes are read where they lie — delta = code - radius — and only the outliers' deltas, code 0, come from the
+            // array they were scattered to: the dense codes -> deltas pass is not run)
             UQ sum = 0;
-            for (uint32_t t = lane; t < nown; t += WAVE) sum += (UQ)deltas[g.coff + t];
+            for (uint32_t t = lane; t < nown; t += WAVE) {
+                const uint32_t code = codes[g.coff + t];
+                sum += code ? (UQ)(Q)((int)code - (int)p.radius) : (UQ)deltas[g.coff + t];
+            }
             sum = wave_sum(sum);
             if (lane == 0) agg[2 * (uint64_t)task] = (Q)sum;
         }
@@ -2311,7 +2316,7 @@ __global__ __launch_bounds__(1024) void k_blkn_scan_top(uint32_t ntiles, Q *__re
     }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void k_blkn_apply1(const void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks) {
+__global__ __launch_bounds__(256) void k_blkn_apply1(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     const int lane = lane_id();
@@ -2327,7 +2332,11 @@ __global__ __launch_bounds__(256) void k_blkn_apply1(const void *deltas_, void *
         if (!closed[task]) run += (UQ)tile[2 * (uint64_t)(task / BLKN_TILE) + 1];
         for (uint32_t t0 = 0; t0 < g.ex; t0 += WAVE) {
             const uint32_t t = t0 + lane;
-            const UQ dl = t < g.ex ? (UQ)deltas[g.coff + t] : (UQ)0;
+            UQ dl = 0;
+            if (t < g.ex) {
+                const uint32_t code = codes[g.coff + t];
+                dl = code ? (UQ)(Q)((int)code - (int)p.radius) : (UQ)deltas[g.coff + t];
+            }
             const UQ incl = wave_incl_scan(dl) + run;
             if (t < g.ex) reinterpret_cast<T *>(d_out)[g.ox + t] = lat.dequant((Q)incl);  // (the final value: no pass over the array after this one)
             run = (UQ)__shfl((long long)incl, WAVE - 1);
@@ -2689,7 +2698,9 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
                               const uint8_t *payload, const szh_header *h, const szh_offsets *o, int64_t *coef_by_rank, hipStream_t s,
                               hipEvent_t side_done) {
     const uint32_t nblocks = blk_count_blocks(p);
-    if (szk_launch_expand_deltas(dtype, codes, h->n, (int)h->radius, payload, o, h->n_dout, p->qwork, s)) return -1;
+    if (p->ndim == 1) {
+        if (szk_launch_scatter_deltas(dtype, h->n, payload, o, h->n_dout, p->qwork, s)) return -1;
+    } else if (szk_launch_expand_deltas(dtype, codes, h->n, (int)h->radius, payload, o, h->n_dout, p->qwork, s)) return -1;
     // (the side section's kernels ran on another stream: the fronts are the first to need what they made)
     if (side_done && hipStreamWaitEvent(s, side_done, 0) != hipSuccess) return -1;
     if (p->ndim < 3) {
@@ -2701,11 +2712,11 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
             if (dtype == 0) {
                 hipLaunchKernelGGL(k_blkn_scan_tile<int32_t>, dim3(ntiles), dim3(1024), 0, s, p->sel, nblocks, p->carry);
                 hipLaunchKernelGGL(k_blkn_scan_top<int32_t>, dim3(1), dim3(1024), 0, s, ntiles, (int32_t *)p->carry + 2 * (uint64_t)nblocks);
-                hipLaunchKernelGGL(k_blkn_apply1<float>, dim3(gpre), dim3(256), 0, s, p->qwork, d_out, *p, nblocks);
+                hipLaunchKernelGGL(k_blkn_apply1<float>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks);
             } else {
                 hipLaunchKernelGGL(k_blkn_scan_tile<int64_t>, dim3(ntiles), dim3(1024), 0, s, p->sel, nblocks, p->carry);
                 hipLaunchKernelGGL(k_blkn_scan_top<int64_t>, dim3(1), dim3(1024), 0, s, ntiles, (int64_t *)p->carry + 2 * (uint64_t)nblocks);
-                hipLaunchKernelGGL(k_blkn_apply1<double>, dim3(gpre), dim3(256), 0, s, p->qwork, d_out, *p, nblocks);
+                hipLaunchKernelGGL(k_blkn_apply1<double>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks);
             }
         } else if (p->B <= 16 && !(szk_dbg_flags & 8388608)) {  // groups of 4 x 4 blocks per workgroup (debug flag 8388608: a block per wave)
             const uint32_t ng1 = (p->nb[1] + BLKN_G - 1) / BLKN_G, ng2 = (p->nb[2] + BLKN_G - 1) / BLKN_G;

@@ -180,3 +180,17 @@ def test_1d_fit_by_rows_of_lanes_and_by_waves_agree(n, block, dtype):
     sel0, sel1 = np.asarray(szh_ref.parse_side(h0, s0)[0]), np.asarray(szh_ref.parse_side(h1, s1)[0])
     assert np.array_equal(sel0, sel1) and (sel0 == 2).any() and (sel0 == 0).any()
     assert blobs[0] == blobs[1]
+
+
+@pytest.mark.parametrize("shape", [(1,), (2,), (3,), (5,), (20,), (129,), (257,), (2, 2), (3, 5), (1, 9), (16, 17), (33, 2)])
+def test_tiny_and_degenerate_low_dimensional_arrays(shape):
+    """arrays of a few values, single ragged blocks, blocks of one row or one value (regression is not valid there:
+    RegressionPredictor.hpp:33-36 -> the Lorenzo-1 fallback, BlockwiseDecomposition.hpp:35-37): the bound holds, whatever stream
+    the dispatcher's fallbacks choose; both predictor sets"""
+    rng = np.random.default_rng(5)
+    a = (np.cumsum(rng.normal(size=int(np.prod(shape)))).reshape(shape) * 0.01).astype(np.float32)
+    for mask in ("L1+R", "R"):
+        conf = _conf(shape, 1e-3, *MASKS[mask])
+        blob, _ = sz3_amd.compress(a, conf)
+        dec, c2 = sz3_amd.decompress(blob, np.float32, shape)
+        assert dec.shape == a.shape and float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= 1e-3

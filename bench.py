@@ -426,6 +426,8 @@ def main():
         # (the PMC passes of tools/pmc_blk.sh were taken on the benchmark field, where the selection hands the array to the plain path)
         is_c4c = (args.algo == "composed" and args.dtype == "f64" and tuple(shape) == (128, 1024, 1024) and args.eb == 1e-6 and args.field == "default"
                   and w.stream_predictor() == 0)
+        is_c4a = (args.algo == "composed" and args.dtype == "f64" and tuple(shape) == (128, 1024, 1024) and args.eb == 1e-6 and args.field == "c4a"
+                  and w.stream_predictor() == 2)  # (tools/pmc_blk.sh with FIELD=c4a: profiles/r03_pmc_blk_c4a.txt)
         out = {
             "metric": "compression throughput GB/s + ratio at fixed abs errBound, 512^3 f32",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -458,7 +460,8 @@ def main():
                                                "plain Lorenzo stream" if pid == 0 else "block-composed stream (selection bits + regression coefficients)")}
         out.update(rooflines(w, acc, psize, ms_per_step,
                              "lorenzo_quant_hist_hbm_bytes_per_launch" if is_c2 else "c3_stage1_hbm_bytes_per_step" if is_c3
-                             else "c4_composed_stage1_hbm_bytes_per_step" if is_c4c else None))
+                             else "c4_composed_stage1_hbm_bytes_per_step" if is_c4c
+                             else "c4a_composed_stage1_hbm_bytes_per_step" if is_c4a else None))
 
     if rank == 0 and world == 1 and not args.no_cold:
         out["cold"] = w.cold_numbers(max(5, args.steps // 2), barrier)

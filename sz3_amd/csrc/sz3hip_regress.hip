@@ -2343,6 +2343,78 @@ __global__ __launch_bounds__(256) void k_blkn_apply1(const uint16_t *__restrict_
         }
     }
 }
+template <typename UQ>
+__device__ __forceinline__ UQ row16_incl_scan(UQ u) {
+    u += dpp_mov0<0x111, 0xf>(u);
+    u += dpp_mov0<0x112, 0xf>(u);
+    u += dpp_mov0<0x114, 0xf>(u);
+    u += dpp_mov0<0x118, 0xf>(u);
+    return u;
+}
+// The same by ROWS OF 16 LANES for blocks of up to 128 values that are multiples of 8 (the default 128): four blocks per wave, a
+// lane takes eight consecutive values — one 16-byte load of codes, the prefix in registers, the lanes' totals scanned inside the
+// DPP row, eight values written — instead of two rounds of a full-wave scan with 64 two-byte loads each.
+template <typename T>
+__global__ __launch_bounds__(256) void k_blkn_apply1_rows(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    const uint32_t lane = (uint32_t)lane_id(), row = lane >> 4, li = lane & 15u;
+    const Lattice<T> lat(p.lat);
+    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    const Q *agg = reinterpret_cast<const Q *>(p.carry);
+    const Q *tile = blkn_tiles<Q>(p.carry, nblocks);
+    const uint8_t *closed = blkn_closed<Q>(p.carry, nblocks);
+    T *out = reinterpret_cast<T *>(d_out);
+    const bool out_aligned = (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0;  // (the caller's array: only as aligned as its element type for sure)
+    const uint32_t n = (uint32_t)p.d[2];
+    for (uint32_t base = (blockIdx.x * 4 + threadIdx.x / WAVE) * 4; base < nblocks; base += gridDim.x * 16) {  // (wave-uniform)
+        const uint32_t task = base + row;
+        const bool live = task < nblocks && p.sel[task] != 2;
+        const uint32_t ox = task < nblocks ? task * p.B : 0u;
+        const uint32_t ex = live ? min(p.B, n - ox) : 0u;
+        const uint32_t t = li * 8;  // the lane's first value in the block
+        UQ d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t + 8 <= ex) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(codes + ox + t);  // (ox and t are multiples of 8: 16-byte aligned)
+            const uint32_t c[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
+#pragma unroll
+            for (int j = 0; j < 8; j++) d[j] = c[j] ? (UQ)(Q)((int)c[j] - (int)p.radius) : (UQ)deltas[ox + t + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (t + j < ex) {
+                    const uint32_t c = codes[ox + t + j];
+                    d[j] = c ? (UQ)(Q)((int)c - (int)p.radius) : (UQ)deltas[ox + t + j];
+                }
+        }
+#pragma unroll
+        for (int j = 1; j < 8; j++) d[j] += d[j - 1];
+        UQ inflow = 0;
+        if (live) {
+            inflow = (UQ)agg[2 * (uint64_t)task + 1];
+            if (!closed[task]) inflow += (UQ)tile[2 * (uint64_t)(task / BLKN_TILE) + 1];
+        }
+        const UQ before = row16_incl_scan(d[7]) - d[7] + inflow;  // the values left of this lane's eight
+        T v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = lat.dequant((Q)(d[j] + before));
+        if (t + 8 <= ex && out_aligned) {  // 16-byte stores (eight predicated scalar stores per lane held the pass at 2.3 TB/s)
+            if (sizeof(T) == 4) {
+                float4 *o4 = reinterpret_cast<float4 *>(out + ox + t);
+                o4[0] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+                o4[1] = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+            } else {
+                double2 *o2 = reinterpret_cast<double2 *>(out + ox + t);
+#pragma unroll
+                for (int j = 0; j < 4; j++) o2[j] = make_double2((double)v[2 * j], (double)v[2 * j + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (t + j < ex) out[ox + t + j] = v[j];
+        }
+    }
+}
 // 2-D: the Lorenzo blocks of one front (by + bx = diag), a wave per block: the deltas in LDS, sums along x (inflow: Dy q~ of the
 // column left of the block), then along y (inflow: q~ of the row above it)
 #define BLKN_MAXB2 32u
@@ -2398,14 +2470,6 @@ __global__ __launch_bounds__(256) void k_blkn_decode2(const void *deltas_, void 
 // seven inner steps (ly + lx = 0..6, a barrier in between) invert the Lorenzo blocks in place, a wave per block: sums along x in
 // the DPP rows of 16 lanes (four rows of the block at a time), then along y the same way on the transposed assignment.
 #define BLKN_G 4u
-template <typename UQ>
-__device__ __forceinline__ UQ row16_incl_scan(UQ u) {
-    u += dpp_mov0<0x111, 0xf>(u);
-    u += dpp_mov0<0x112, 0xf>(u);
-    u += dpp_mov0<0x114, 0xf>(u);
-    u += dpp_mov0<0x118, 0xf>(u);
-    return u;
-}
 template <typename T>
 __global__ __launch_bounds__(256) void k_blkn_decode2g(const void *deltas_, void *d_out, szk_blk_params p, uint32_t diag, uint32_t gy_lo) {
     using Q = typename QTraits<T>::Q;
@@ -2709,14 +2773,19 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         else hipLaunchKernelGGL(k_blkn_pre<double>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
         if (p->ndim == 1) {
             const uint32_t ntiles = (nblocks + BLKN_TILE - 1) / BLKN_TILE;
+            // blocks of up to 128 values, a multiple of 8: four blocks per wave (debug flag 134217728: a wave per block)
+            const bool rows = p->B <= 128 && p->B % 8 == 0 && !(szk_dbg_flags & 134217728);
+            const uint32_t grow = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 15) / 16);
             if (dtype == 0) {
                 hipLaunchKernelGGL(k_blkn_scan_tile<int32_t>, dim3(ntiles), dim3(1024), 0, s, p->sel, nblocks, p->carry);
                 hipLaunchKernelGGL(k_blkn_scan_top<int32_t>, dim3(1), dim3(1024), 0, s, ntiles, (int32_t *)p->carry + 2 * (uint64_t)nblocks);
-                hipLaunchKernelGGL(k_blkn_apply1<float>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks);
+                if (rows) hipLaunchKernelGGL(k_blkn_apply1_rows<float>, dim3(grow), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks);
+                else hipLaunchKernelGGL(k_blkn_apply1<float>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks);
             } else {
                 hipLaunchKernelGGL(k_blkn_scan_tile<int64_t>, dim3(ntiles), dim3(1024), 0, s, p->sel, nblocks, p->carry);
                 hipLaunchKernelGGL(k_blkn_scan_top<int64_t>, dim3(1), dim3(1024), 0, s, ntiles, (int64_t *)p->carry + 2 * (uint64_t)nblocks);
-                hipLaunchKernelGGL(k_blkn_apply1<double>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks);
+                if (rows) hipLaunchKernelGGL(k_blkn_apply1_rows<double>, dim3(grow), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks);
+                else hipLaunchKernelGGL(k_blkn_apply1<double>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks);
             }
         } else if (p->B <= 16 && !(szk_dbg_flags & 8388608)) {  // groups of 4 x 4 blocks per workgroup (debug flag 8388608: a block per wave)
             const uint32_t ng1 = (p->nb[1] + BLKN_G - 1) / BLKN_G, ng2 = (p->nb[2] + BLKN_G - 1) / BLKN_G;

@@ -160,7 +160,7 @@ def test_low_dimensional_fields_where_only_lorenzo_is_chosen_become_the_plain_st
         assert h["predictor"] == 2 and (c2.lorenzo, c2.regression) == (1, 1)
 
 
-@pytest.mark.parametrize("n,block,dtype", [(1 << 20, None, np.float32), (100003, 100, np.float32), (40000, 7, np.float64)])
+@pytest.mark.parametrize("n,block,dtype", [(1 << 20, None, np.float32), (100003, 100, np.float32), (40000, 7, np.float64), (100003, 104, np.float64), (5001, 8, np.float32)])
 def test_1d_fit_by_rows_of_lanes_and_by_waves_agree(n, block, dtype):
     """1-D: four blocks per wave (a block per DPP row of 16 lanes, k_blkn_fit_rows) against a wave per block (debug flag 134217728):
     the same choices and the same stream (the sums are taken in a different order: coefficients could differ in the last bit of a
@@ -180,6 +180,17 @@ def test_1d_fit_by_rows_of_lanes_and_by_waves_agree(n, block, dtype):
     sel0, sel1 = np.asarray(szh_ref.parse_side(h0, s0)[0]), np.asarray(szh_ref.parse_side(h1, s1)[0])
     assert np.array_equal(sel0, sel1) and (sel0 == 2).any() and (sel0 == 0).any()
     assert blobs[0] == blobs[1]
+    # ... and the decoder's Lorenzo pass: rows of lanes (blocks of up to 128 values, a multiple of 8) against a wave per block
+    blob, _ = sz3_amd.compress(a, conf)
+    outs = []
+    try:
+        for flag in (0, 134217728):
+            sz3_amd.lib().sz3hip_debug_flags(flag)
+            outs.append(sz3_amd.decompress(blob, dtype, (n,))[0])
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(0)
+    assert outs[0].tobytes() == outs[1].tobytes()
+    assert float(np.max(np.abs(outs[0].astype(np.float64) - a.astype(np.float64)))) <= 1e-3
 
 
 @pytest.mark.parametrize("shape", [(1,), (2,), (3,), (5,), (20,), (129,), (257,), (2, 2), (3, 5), (1, 9), (16, 17), (33, 2)])

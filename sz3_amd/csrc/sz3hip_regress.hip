@@ -2415,6 +2415,82 @@ __global__ __launch_bounds__(256) void k_blkn_apply1_rows(const uint16_t *__rest
         }
     }
 }
+// k_blkn_pre's 1-D work by rows of 16 lanes (blocks of up to 128 values, a multiple of 8; four blocks per wave, eight values per
+// lane): a regression block's final values and the lattice value of its last element, a Lorenzo block's sum of deltas
+template <typename T>
+__global__ __launch_bounds__(256) void k_blkn_pre1_rows(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks,
+                                                        const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    const uint32_t lane = (uint32_t)lane_id(), row = lane >> 4, li = lane & 15u;
+    const Lattice<T> lat(p.lat);
+    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    Q *agg = reinterpret_cast<Q *>(p.carry);
+    T *out = reinterpret_cast<T *>(d_out);
+    const bool out_aligned = (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0;
+    const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
+    const uint32_t n = (uint32_t)p.d[2];
+    for (uint32_t base = (blockIdx.x * 4 + threadIdx.x / WAVE) * 4; base < nblocks; base += gridDim.x * 16) {  // (wave-uniform)
+        const uint32_t task = base + row;
+        const bool live = task < nblocks;
+        const bool reg = live && p.sel[task] == 2;
+        const uint32_t ox = live ? task * p.B : 0u;
+        const uint32_t ex = live ? min(p.B, n - ox) : 0u;
+        const uint32_t t = li * 8;
+        uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t + 8 <= ex) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(codes + ox + t);
+            c[0] = w.x & 0xFFFFu; c[1] = w.x >> 16; c[2] = w.y & 0xFFFFu; c[3] = w.y >> 16;
+            c[4] = w.z & 0xFFFFu; c[5] = w.z >> 16; c[6] = w.w & 0xFFFFu; c[7] = w.w >> 16;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (t + j < ex) c[j] = codes[ox + t + j];
+        }
+        if (reg) {
+            T rc[4];
+            coef_recover(coef_by_rank + (uint64_t)rank[task] * 4, cl, rc);
+            T v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                v[j] = 0;  // (code 0: patched from the list)
+                if (t + j < ex && c[j]) v[j] = ref_recover(reg_predict(rc, 0u, 0u, t + j), (int)c[j], p.eb, (int)p.radius);
+                if (t + j + 1 == ex) {  // the block's last element: its lattice value restarts the sum over the blocks
+                    Q qt = 0;
+                    if (c[j]) {
+                        bool bad;
+                        qt = lat.quant(v[j], bad);
+                        if (bad) qt = 0;
+                    }
+                    agg[2 * (uint64_t)task] = qt;
+                }
+            }
+            if (t + 8 <= ex && out_aligned) {
+                if (sizeof(T) == 4) {
+                    float4 *o4 = reinterpret_cast<float4 *>(out + ox + t);
+                    o4[0] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+                    o4[1] = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+                } else {
+                    double2 *o2 = reinterpret_cast<double2 *>(out + ox + t);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) o2[j] = make_double2((double)v[2 * j], (double)v[2 * j + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (t + j < ex) out[ox + t + j] = v[j];
+            }
+        }
+        UQ sum = 0;
+        if (!reg) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (t + j < ex) sum += c[j] ? (UQ)(Q)((int)c[j] - (int)p.radius) : (UQ)deltas[ox + t + j];
+        }
+        const UQ tot = row16_incl_scan(sum);  // (lane 15 of the row holds the block's sum)
+        if (live && !reg && li == 15) agg[2 * (uint64_t)task] = (Q)tot;
+    }
+}
 // 2-D: the Lorenzo blocks of one front (by + bx = diag), a wave per block: the deltas in LDS, sums along x (inflow: Dy q~ of the
 // column left of the block), then along y (inflow: q~ of the row above it)
 #define BLKN_MAXB2 32u
@@ -2769,6 +2845,13 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
     if (side_done && hipStreamWaitEvent(s, side_done, 0) != hipSuccess) return -1;
     if (p->ndim < 3) {
         const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
+        // 1-D, blocks of up to 128 values, a multiple of 8: four blocks per wave (debug flag 134217728: a wave per block)
+        const bool rows1 = p->ndim == 1 && p->B <= 128 && p->B % 8 == 0 && !(szk_dbg_flags & 134217728);
+        const uint32_t grow1 = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 15) / 16);
+        if (rows1) {
+            if (dtype == 0) hipLaunchKernelGGL(k_blkn_pre1_rows<float>, dim3(grow1), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+            else hipLaunchKernelGGL(k_blkn_pre1_rows<double>, dim3(grow1), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+        } else
         if (dtype == 0) hipLaunchKernelGGL(k_blkn_pre<float>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
         else hipLaunchKernelGGL(k_blkn_pre<double>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
         if (p->ndim == 1) {

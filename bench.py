@@ -15,6 +15,10 @@ One process per GPU: under a launcher (torchrun sets WORLD_SIZE) this process is
 communicator lives in the library (ncclCommInitRank with rank 0's id shipped over the launcher's process group) and the
 bench asserts that RCCL reports N ranks.
 
+The timed loop ALTERNATES two realisations of the field (same analytic field, two noise seeds): no two consecutive calls see the
+same array, so what a context carries over from its previous call (kernel forms, the code book it speculates with) is what a
+series of similar arrays gives it, not what a repeated array gives it. `identical_input` reports the repeated-array figure beside it.
+
 Printed JSON line (rank 0): the driver contract + "roofline" (dominant kernel against ITS compulsory bytes, live
 HIP-event timing; "roofline_path" = the whole path's algorithmic bytes over the whole step) + "cpu_baseline" (the
 reference itself from oracle/_ref when present, else the oracle port; one thread AND all host cores through the
@@ -56,6 +60,8 @@ def parse_args():
     ap.add_argument("--no-host-e2e", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs (C3) leg")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold / hint-miss timings")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # (the child of those passes: warm-up + steps, nothing else, no line)
     return ap.parse_args()
 
 
@@ -88,6 +94,15 @@ class Workload:
         else:
             self.a = field3d(shape, self.npdt, seed=20260928 + rank) if dtype == "f32" else field3d(shape, self.npdt, seed=20260928 + rank, sigma=2e-6)
         self.d_in = torch.from_numpy(self.a).to(dev)
+        # the second realisation the timed loop alternates with (same field, another noise seed)
+        if field == "c4a":
+            other = field_c4a(shape, seed=20261928 + rank).astype(self.npdt)
+        else:
+            other = field3d(shape, self.npdt, seed=20261928 + rank) if dtype == "f32" else field3d(shape, self.npdt, seed=20261928 + rank, sigma=2e-6)
+        self.pair = [self.d_in, torch.from_numpy(other).to(dev)]
+        del other
+        self.alternate = True
+        self.flip = 0
         conf = sz3_amd.Config(*shape)
         conf.cmprAlgo = {"lorenzo": sz3_amd.ALGO_LORENZO_REG, "interp": sz3_amd.ALGO_INTERP_LORENZO, "interp-notune": sz3_amd.ALGO_INTERP,
                          "composed": sz3_amd.ALGO_LORENZO_REG}[algo]
@@ -107,6 +122,9 @@ class Workload:
 
     def step(self):
         dc = self.dc
+        if self.alternate:
+            self.flip ^= 1
+            self.d_in = self.pair[self.flip]
         dc.stage1(self.conf, self.d_in.data_ptr(), self.stream)
         if self.comm is not None:
             self.comm.allreduce_histogram([dc], [self.stream])
@@ -116,11 +134,10 @@ class Workload:
         return dc.finish(self.stream)
 
     def cold_numbers(self, steps, barrier):
-        """What `value` leaves out: the context remembers the previous call (kernel forms, the tuner's outcome, the code book)
-        and the timed loop feeds it the same array. (a) every call a context's first call (sz3hip_ctx_forget before it,
-        allocations excluded); (b) two different realisations of the field alternating on one context (every speculation
-        about the previous call's code book fails); (c) speculation switched off. Same payload in every case."""
-        from fields import field3d
+        """What `value` leaves out: the context remembers the previous call (kernel forms, the tuner's outcome, the code book). Still
+        on alternating realisations: (a) every call a context's first call (sz3hip_ctx_forget before it, allocations excluded);
+        (b) code-book speculation switched off; (c) deterministic payloads (the previous book must BE this call's: on distinct
+        arrays every attempt fails)."""
         torch = self.torch
         out = {}
 
@@ -136,28 +153,45 @@ class Workload:
             torch.cuda.synchronize()
             return 1e3 * (time.perf_counter() - t0) / n
         out["first_call_ms"] = round(run(self.dc.forget, steps), 4)
-        other = field3d(self.shape, self.npdt, seed=777) if self.dtype == "f32" else field3d(self.shape, self.npdt, seed=777, sigma=2e-6)
-        d_other = torch.from_numpy(other).to(self.d_in.device)
-        pair = [self.d_in, d_other]
-        k = [0]
-
-        def swap():
-            k[0] ^= 1
-            self.d_in = pair[k[0]]
-        h0, m0 = self.dc.spec_stats()
-        out["alternating_fields_ms"] = round(run(swap, steps), 4)
-        h1, m1 = self.dc.spec_stats()
-        out["alternating_fields_codebook_speculation"] = {"hits": h1 - h0, "misses": m1 - m0}
         if self.algo == "interp":
             self.dc.tuner_report()
             out["alternating_fields_tuner_speculated"] = self.dc.speculated  # 1: stage 1 started with the previous outcome and was confirmed
-        self.d_in = pair[0]
         self.dc.set_speculation(False)
         out["no_codebook_speculation_ms"] = round(run(lambda: None, steps), 4)
         self.dc.set_speculation(True)
+        # deterministic mode (sz3hip_ctx_set_deterministic: the previous book stands only when it IS this call's book — what the host
+        # API sets): on alternating realisations every attempt fails and is repeated; the back-off keeps it near the plain path
+        self.dc.set_deterministic(True)
+        h0, m0 = self.dc.spec_stats()
+        out["deterministic_payloads_ms"] = round(run(lambda: None, steps), 4)
+        h1, m1 = self.dc.spec_stats()
+        out["deterministic_payloads_codebook_speculation"] = {"hits": h1 - h0, "misses": m1 - m0}
+        self.dc.set_deterministic(False)
         self.step()
         self.step()
         return out
+
+    def identical_input(self, steps, barrier):
+        """the same array every call (rounds 1-3's timed loop): every shortcut a context has is confirmed"""
+        torch = self.torch
+        self.alternate = False
+        self.d_in = self.pair[0]
+        for _ in range(3):
+            self.step()
+        barrier()
+        h0, m0 = self.dc.spec_stats()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        h1, m1 = self.dc.spec_stats()
+        self.alternate = True
+        self.step()
+        self.step()
+        return {"ms_per_step": round(ms, 4), "gbps": round(self.n * self.esz / (ms * 1e-3) / 1e9, 2),
+                "codebook_speculation": {"hits": h1 - h0, "misses": m1 - m0},
+                "note": "the same array every call; informational — `value` is measured on alternating realisations"}
 
     def stage_profile(self, reps=10):
         """per-stage kernel time, HIP events on the launch stream (outside the timed loop)"""
@@ -187,7 +221,64 @@ class Workload:
         return max_err, (time.perf_counter() - t0) / 5 * 1e3
 
 
-def rooflines(w, acc, psize, ms_per_step, traffic_key):
+def live_traffic(args, kernel_prefixes, child_steps=6, child_warmup=4):
+    """HBM traffic of the dominant kernel and of the whole step, measured in THIS run: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE
+    need separate passes: /opt/skills/guides/MI355X_MICROARCH.md, "rocprofv3 PMC slots") over a child that runs the same workload's
+    warm-up + steps and nothing else. Per launch: mean over the child's dispatches of the kernel; FETCH_SIZE doubled (the guide's
+    gfx950 correction for wide coalesced reads), WRITE_SIZE as reported, counters in KB. None when rocprofv3 is not on PATH or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    base = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--steps", str(child_steps), "--warmup", str(child_warmup),
+            "--algo", args.algo, "--eb", repr(args.eb), "--dtype", args.dtype, "--field", args.field, "--size", str(args.size)]
+    if args.shape:
+        base += ["--shape", args.shape]
+    tmp = tempfile.mkdtemp(prefix="sz3_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    per = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--"] + base,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            rows = []
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") != ctr:
+                    continue
+                rows.append((int(row.get("Dispatch_Id", 0)), row["Kernel_Name"].replace("void ", "").split("(")[0], float(row["Counter_Value"])))
+            rows.sort()
+            per[ctr] = rows
+        def dominant(rows):
+            return [i for i, (_, name, _) in enumerate(rows) if name.startswith(tuple(kernel_prefixes))]
+        out = {}
+        doms = {c: dominant(per[c]) for c in per}
+        if any(len(v) < child_steps for v in doms.values()):
+            return None
+        vals = {}
+        for c, rows in per.items():
+            idx = doms[c][-child_steps:]                 # the last `child_steps` launches of the dominant kernel = the timed-like steps
+            vals[c + "_kernel"] = sum(rows[i][2] for i in idx) / len(idx)
+            vals[c + "_step"] = sum(v for (_, _, v) in rows[idx[0]:]) / len(idx)   # everything from the first of them on, per step
+            vals["kernel_name"] = rows[idx[-1]][1]
+        out["kernel"] = vals["kernel_name"]
+        out["per_launch_bytes"] = int((2 * vals["FETCH_SIZE_kernel"] + vals["WRITE_SIZE_kernel"]) * 1024)
+        out["per_step_bytes"] = int((2 * vals["FETCH_SIZE_step"] + vals["WRITE_SIZE_step"]) * 1024)
+        out["raw_KB"] = {k: round(v, 1) for k, v in vals.items() if isinstance(v, float)}
+        return out
+    except Exception:  # noqa: BLE001 - a failing profiler pass must not lose the bench line
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def rooflines(w, acc, psize, ms_per_step, traffic_key, live=None):
     """the dominant kernel against ITS compulsory bytes; the whole path's algorithmic bytes over the whole step"""
     raw = w.n * w.esz
     out = {}
@@ -196,10 +287,15 @@ def rooflines(w, acc, psize, ms_per_step, traffic_key):
     # stream (a wide alphabet's code book is built beside the encoder on a stream of its own: the stages' own times overlap and do not add up)
     kernels_ms = acc.get("step_span", sum(acc.get(k, 0.0) for k in ("tuner", "lorenzo_quant_hist", "codebook", "encode", "assemble")))
     traffic = None
+    traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if traffic_key and os.path.exists(tpath):
+    if live:
+        traffic = live["per_step_bytes"] if w.algo != "lorenzo" else live["per_launch_bytes"]
+        traffic_source = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (2 x FETCH + WRITE, KB x 1024), kernel " + live["kernel"]
+    elif traffic_key and os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get(traffic_key)
+            traffic_source = "profiles/pmc_traffic.json (committed; not measured in this run: rocprofv3 not on PATH, a pass failed, or --no-live-traffic)"
         except Exception:
             traffic = None
     if w.algo == "composed" and w.stream_predictor() == 0:
@@ -225,13 +321,18 @@ def rooflines(w, acc, psize, ms_per_step, traffic_key):
         note = "read sizeof(T) + write sizeof(T) of reconstruction + 2 B of codes per element, each once"
     ach = k_bytes / (k1_ms * 1e-3) / 1e9
     out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "compulsory_bytes_per_launch": int(k_bytes),
+                       "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                       "compulsory_bytes_per_launch": int(k_bytes),
                        "bytes_note": note, "kernel_ms": round(k1_ms, 4)}
     algo_bytes = raw + psize  # read sizeof(T) + write sizeof(T)/ratio per element
     pach = algo_bytes / (ms_per_step * 1e-3) / 1e9
     out["roofline_path"] = {"bound": "hbm", "what": "whole step (all kernels + launch gaps + the final sync), algorithmic bytes = input + payload",
                             "achieved": round(pach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pach / HBM_PEAK_GBS, 4),
-                            "algorithmic_bytes_per_step": int(algo_bytes)}
+                            "algorithmic_bytes_per_step": int(algo_bytes),
+                            "traffic": live["per_step_bytes"] if live else None,
+                            "traffic_over_algorithmic": round(live["per_step_bytes"] / float(algo_bytes), 3) if live else None}
+    # the dominant kernel priced against the PATH's algorithmic bytes (input + payload), not its own compulsory ones
+    out["roofline"]["frac_of_path_algorithmic_bytes"] = round(algo_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     out["kernels_ms"] = round(kernels_ms, 4)
     out["frac_read_peak_all_kernels"] = round(raw / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     return out
@@ -399,6 +500,9 @@ def main():
         return el, ps
 
     elapsed, psize = timed(w, args.steps, args.warmup)
+    if args.traffic_child:  # (a rocprofv3 --pmc pass of live_traffic: the counters were what this process was for)
+        torch.cuda.synchronize()
+        return
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev if not one_gpu else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -449,21 +553,31 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
             "tuner": w.dc.tuner_report() if args.algo == "interp" else None,
             "codebook_speculation": {"hits": h_spec, "misses": m_spec,
-                                     "note": "timed loop + warmup: stage 2 packs with the previous call's code book while this call's is built by "
-                                             "one workgroup of the same launch (alphabets <= 256 symbols) or by k_codebook<1> on a stream of its own "
-                                             "(wide alphabets, short outlier lists); a miss repeats the encoder (see `cold`)"},
+                                     "note": "timed loop + warmup, alternating realisations: stage 2 packs with the previous call's code book while this "
+                                             "call's is built by one workgroup of the same launch (alphabets <= 256 symbols) or by k_codebook<1> on a stream of "
+                                             "its own (wide alphabets, short outlier lists); the verdict keeps the previous book when it is complete over this "
+                                             "call's alphabet and within 1/1024 of this call's own book's coded size; a miss repeats the encoder (see `cold`)"},
         }
         if args.algo == "composed":
             pid = w.stream_predictor()
             out["block_selection"] = {"stream_predictor": pid,
                                       "note": ("the selection pass found fewer than 1/4096 of the blocks choosing another predictor than Lorenzo-1: "
                                                "plain Lorenzo stream" if pid == 0 else "block-composed stream (selection bits + regression coefficients)")}
+        live = None
+        if world == 1 and not args.no_live_traffic:
+            prefixes = {"lorenzo": ["k_lorenzo_quant_march", "k_lorenzo_quant"], "composed": ["k_blk_select"],
+                        "interp": ["k_interp_level", "k_interp_pass", "k_interp_vec"], "interp-notune": ["k_interp_level", "k_interp_pass", "k_interp_vec"]}[args.algo]
+            if args.algo == "lorenzo":  # (one stage-1 launch per step; the other algorithms' stages are multi-kernel: committed profiles)
+                live = live_traffic(args, prefixes)
         out.update(rooflines(w, acc, psize, ms_per_step,
                              "lorenzo_quant_hist_hbm_bytes_per_launch" if is_c2 else "c3_stage1_hbm_bytes_per_step" if is_c3
                              else "c4_composed_stage1_hbm_bytes_per_step" if is_c4c
-                             else "c4a_composed_stage1_hbm_bytes_per_step" if is_c4a else None))
+                             else "c4a_composed_stage1_hbm_bytes_per_step" if is_c4a else None, live=live))
+        out["input"] = ("two realisations of the field (noise seeds 20260928 + rank, 20261928 + rank) alternate call by call in the timed loop "
+                        "and in every other leg except `identical_input`")
 
     if rank == 0 and world == 1 and not args.no_cold:
+        out["identical_input"] = w.identical_input(args.steps, barrier)
         out["cold"] = w.cold_numbers(max(5, args.steps // 2), barrier)
         # What `value` also leaves out, in the other direction: a producer with a SERIES of arrays keeps two contexts in flight on two
         # streams — stage 1 of one call (bound by memory) runs beside stage 2 of the other (bound by instruction issue). Not `value`:
@@ -480,7 +594,8 @@ def main():
                     st = streams[k].cuda_stream
                     if pending[k]:
                         pair[k].dc.finish(st)
-                    pair[k].dc.stage1(pair[k].conf, pair[k].d_in.data_ptr(), st)
+                    src = pair[k].pair[(i >> 1) & 1]  # (each context alternates its two realisations too)
+                    pair[k].dc.stage1(pair[k].conf, src.data_ptr(), st)
                     pair[k].dc.stage2(pair[k].d_payload.data_ptr(), pair[k].cap, st)
                     pending[k] = True
                 for k in range(2):

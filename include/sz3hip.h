@@ -207,6 +207,14 @@ int sz3hip_get_stage_times(sz3hip_ctx *ctx, const char **names, float *ms, int m
  * back-off after a miss (tests); sz3hip_get_spec_stats counts the code-book speculation's hits / misses. */
 void sz3hip_ctx_forget(sz3hip_ctx *ctx);
 void sz3hip_ctx_set_speculation(sz3hip_ctx *ctx, int off);
+/* Round 4: one exception to "never its payload", and the switch that removes it. The verdict on the previous call's code book
+ * accepts it when it is a complete prefix code over this call's alphabet AND codes this call's symbols within 1/1024 of the size
+ * this call's own book would give (the format stores code lengths, a decoder cannot tell): a series of similar but not identical
+ * arrays keeps the shortcut, and a payload then depends on what the context coded before (its size by < 0.1 %, its decoded
+ * values not at all). sz3hip_ctx_set_deterministic(ctx, 1): the previous book stands only when it IS this call's book — the
+ * payload is a pure function of the input again (what the host API — sz3hip_compress, the CLI, the HDF5 filter — always sets;
+ * the reference builds a tree per call, encoder/HuffmanEncoder.hpp:96-105). Default of a device context: 0. */
+void sz3hip_ctx_set_deterministic(sz3hip_ctx *ctx, int on);
 void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses);
 /* test hooks: copy internal device arrays to host (quantisation codes as uint16, histogram as uint64) */
 int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, uint64_t n);

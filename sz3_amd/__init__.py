@@ -144,6 +144,8 @@ def lib():
     L.sz3hip_ctx_forget.restype = None
     L.sz3hip_ctx_set_speculation.argtypes = [C.c_void_p, C.c_int]
     L.sz3hip_ctx_set_speculation.restype = None
+    L.sz3hip_ctx_set_deterministic.argtypes = [C.c_void_p, C.c_int]
+    L.sz3hip_ctx_set_deterministic.restype = None
     L.sz3hip_get_spec_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.sz3hip_get_spec_stats.restype = None
     L.sz3hip_payload_bound_conf.restype = C.c_size_t
@@ -391,6 +393,11 @@ class DeviceCompressor:
     def set_speculation(self, on=True, backoff=True):
         """on=False: every stage 2 builds its code book first; backoff=False: a miss does not make the next calls sit out (tests)"""
         lib().sz3hip_ctx_set_speculation(self._h, (0 if backoff else 2) if on else 1)
+
+    def set_deterministic(self, on=True):
+        """on: the previous call's code book stands only when it IS this call's book — the payload is a pure function of the input
+        (off, the device API's default: also when it is complete over this call's alphabet and within 1/1024 of its own book's size)"""
+        lib().sz3hip_ctx_set_deterministic(self._h, int(on))
 
     def spec_stats(self):
         h, m = C.c_uint32(), C.c_uint32()

@@ -197,6 +197,11 @@ static hipError_t clear_hist_counters(sz3hip_ctx *c, hipStream_t s) {
         c->pre_cleared = false;
         return hipSuccess;
     }
+    if (c->pre_cleared && c->pre_stream != s) {
+        // the zeroing behind the previous call is pending on ANOTHER stream: this call's memset (and its stage 1) must not overtake it
+        hipError_t e = hipStreamSynchronize(c->pre_stream);
+        if (e != hipSuccess) return e;
+    }
     c->pre_cleared = false;
     if (c->d_hist == c->d_hist_own) return hipMemsetAsync(c->d_hist, 0, SZH_HIST_BINS * 8 + SZ_COUNTER_BYTES, s);
     hipError_t e = hipMemsetAsync(c->d_hist, 0, SZH_HIST_BINS * 8, s);  // caller-owned histogram (multi-GPU all-reduce buffer)
@@ -1206,7 +1211,10 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     bool spec = ctx->proto.predictor == 0 ? ctx->s1_spec : book_spec_ok(ctx, ctx->proto.predictor, ctx->proto.radius);
     // The one-stream form: small alphabet, short outlier lists, range words kept by stage 1 (what a smooth field's previous
     // call left).
-    if (spec && !(ctx->cb_hint == 0 && !ctx->lists_long && (ctx->range_ready || ctx->hist_reduced) && !ctx->hist_exposed)) spec = false;
+    // (Not for block streams — predictor 2: their side section is copied by the assembly's list workgroups, which the sort roles replace;
+    // a context that went through the histogram exchange keeps hist_reduced set, which would open this gate for them.)
+    if (spec && !(ctx->cb_hint == 0 && !ctx->lists_long && (ctx->range_ready || ctx->hist_reduced) && !ctx->hist_exposed && ctx->proto.predictor != 2))
+        spec = false;
     // Wide alphabets (round 3, second attempt): the book needs a compute unit's whole LDS and 0.15 - 0.3 ms of ONE workgroup —
     // as long as the encoder's two passes take. It is built on a high-priority stream of its own, forked behind stage 1 and
     // enqueued BEFORE the encoder's launches (the workgroup is placed before the persistent packers fill the chip), and joined in
@@ -1249,6 +1257,7 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
         er.cb = &cb;
         er.used_lens = ctx->bk[used].lens;
         er.flags = reinterpret_cast<uint32_t *>(ctx->d_counters + 10);
+        er.exact = ctx->spec_exact;
         if (ctx->fold_rows) {
             er.fold_partial = ctx->d_hist_partial;
             er.fold_rows = ctx->fold_rows;
@@ -1283,6 +1292,7 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
         er.cb = &cb;
         er.used_lens = ctx->bk[used].lens;
         er.flags = reinterpret_cast<uint32_t *>(ctx->d_counters + 10);
+        er.exact = ctx->spec_exact;
     }
     if (how == S2_CLASSIC) {
         if (ctx->range_ready && !cb.range_ready)  // stage 1 kept the range of the LOCAL histogram, the caller then changed it (all-reduce):
@@ -1331,7 +1341,7 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
         HIPCHK(hipStreamWaitEvent(s, ctx->ev_book, 0));
         if (szk_launch_book_verdict(ctx->bk[fresh].info, ctx->bk[fresh].lens, ctx->bk[used].info, ctx->bk[used].lens,
                                     reinterpret_cast<const uint32_t *>(ctx->d_counters + 7), reinterpret_cast<const uint32_t *>(ctx->d_counters + 8),
-                                    ctx->d_state, s))
+                                    ctx->d_state, ctx->d_hist, ctx->spec_exact, s))
             return fail(SZ3HIP_EHIP, "verdict kernel launch failed");
     }
     prof_end(ctx, ST_SPAN, s);
@@ -1534,6 +1544,10 @@ extern "C" void sz3hip_ctx_forget(sz3hip_ctx *ctx) {
 // speculation off (1) / on (0) / on without the back-off after a miss (2, for tests) for this context: with it off every
 // stage 2 builds its code book before it encodes
 extern "C" void sz3hip_ctx_set_speculation(sz3hip_ctx *ctx, int off) { ctx->spec_off = off; }
+// 1: a context's shortcuts never change its payloads (the previous call's code book stands only when this call's histogram gives the
+// same book); 0 (the device API's default): the previous book also stands when it is complete over this call's alphabet and codes
+// it within 1/1024 of this call's own book's size — the payload then depends on the context's history, its size by < 0.1 %
+extern "C" void sz3hip_ctx_set_deterministic(sz3hip_ctx *ctx, int on) { ctx->spec_exact = on ? 1 : 0; }
 extern "C" void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses) {
     *hits = ctx->spec_hits;
     *misses = ctx->spec_misses;
@@ -1627,7 +1641,11 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
             HIPCHK(hipMalloc(&ctx->d_blk_carry, nblocks * 17 + (nblocks / 1024 + 2) * 16 + 64));  // (+ the tiles' words, a flag byte per block)
             ctx->blk_carry_cap = nblocks;
         }
+        const uint64_t sel_bytes = ((nblocks + 3) / 4 + 7) & ~7ull;
+        if (h.side_bytes < 24 + sel_bytes + 8) return fail(SZ3HIP_EFORMAT, "corrupt side section of a block-predictor stream");
         HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr, pl + o.side, 24, hipMemcpyDeviceToHost, s));
+        // the four Rice parameters behind the selection bits travel with the header: they are shift counts in k_blk_coef_parse
+        HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr + 24, pl + o.side + 24 + sel_bytes, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         uint32_t coding, sel_bits;
         uint64_t nb_side, nr;
@@ -1635,7 +1653,8 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         memcpy(&sel_bits, ctx->h_blk_side_hdr + 4, 4);
         memcpy(&nb_side, ctx->h_blk_side_hdr + 8, 8);
         memcpy(&nr, ctx->h_blk_side_hdr + 16, 8);
-        const uint64_t sel_bytes = ((nblocks + 3) / 4 + 7) & ~7ull;
+        for (int i = 0; i < 4; i++)
+            if (ctx->h_blk_side_hdr[24 + i] > 63) return fail(SZ3HIP_EFORMAT, "corrupt side section of a block-predictor stream (Rice parameter)");
         const uint64_t ngroups = (nr + 63) / 64;
         const uint64_t fixed = 24 + sel_bytes + 8 + 4 * ngroups;  // header, selection, Rice parameters, group offsets
         if (coding != 1 || sel_bits != 2 || nb_side != nblocks || nr > nblocks || h.side_bytes < fixed || (h.side_bytes - fixed) % 4)

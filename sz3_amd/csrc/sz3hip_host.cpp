@@ -357,6 +357,8 @@ int slot_ctx(HostSlot *s, uint64_t n) {
     if (s->ctx && s->ctx->max_n >= n) return 0;
     if (s->ctx) sz3hip_ctx_destroy(s->ctx);
     s->ctx = sz3hip_ctx_create(s->device, n, s->dtype);
+    // the host API writes files (the CLI, the HDF5 filter): the same input gives the same bytes whatever this slot coded before
+    if (s->ctx) sz3hip_ctx_set_deterministic(s->ctx, 1);
     return s->ctx ? 0 : sz3hip_last_error_code();
 }
 int ensure_dev(void **p, size_t *have, size_t want) {

@@ -73,6 +73,7 @@ struct sz3hip_ctx {
     bool s2_spec;                     // the pending stage 2 ran speculatively
     bool lists_long;                  // the previous call listed more than 2048 outliers: the speculative stage 2 takes the any-length sort
     int spec_off;                     // 1: never speculate; 2: speculate without the back-off (tests); 0: product behaviour
+    int spec_exact;                   // 1: the previous call's book stands only when it IS this call's book (payload = a pure function of the input)
     int spec_skip, spec_penalty;      // calls to sit out after a miss; the count doubles with every miss in a row (up to 8)
     uint32_t spec_hits, spec_misses;  // statistics (sz3hip_get_spec_stats)
     hipEvent_t ev_done;  // recorded behind the state's device-to-host copy: finish() waits for it, not for the whole stream

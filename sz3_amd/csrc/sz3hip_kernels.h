@@ -148,6 +148,7 @@ struct szk_encode_roles {
     const szk_cb_params *cb;    // this call's book: fresh slot, part_hint = 0, range words ready
     const uint8_t *used_lens;   // code lengths of the book the packer runs with
     uint32_t *flags;            // [1]: stage 1 summed the segments' bits (device flag)
+    int exact;                  // verdict: the used book must BE this call's book (else: complete over the alphabet and within 1/1024 of its size)
     // fold of stage 1's histogram rows in the scan's launch (fold_rows != 0)
     const uint32_t *fold_partial;
     uint32_t fold_rows;
@@ -305,7 +306,8 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
 // they differ; bit 2 + mispredict: the side launch met a small alphabet and built nothing) — one workgroup, on the encoder's stream
 // once the side stream has joined
 int szk_launch_book_verdict(const szk_cb_info *fresh, const uint8_t *fresh_lens, const szk_cb_info *used, const uint8_t *used_lens,
-                            const uint32_t *mispredict, const uint32_t *range, szk_state *state, hipStream_t s);
+                            const uint32_t *mispredict, const uint32_t *range, szk_state *state,
+                            const uint64_t *hist /* this call's histogram */, int exact /* see szk_encode_roles::exact */, hipStream_t s);
 int szk_launch_hist_range(const uint64_t *d_hist, uint32_t *range /* [4], zeroed */, hipStream_t s);  // range and count of the non-empty bins
 int szk_launch_hist_fold(const uint32_t *partial, uint32_t nrows, int radius, uint64_t *hist, uint32_t *range, hipStream_t s);
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);

@@ -2196,9 +2196,28 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
 // two-queue merge by one wave out of registers, depths by pointer doubling, length limit + Kraft repair, canonical codes.
 // A device function so that two launches can run it: k_codebook<0> (block 0) and — speculative stage 2 — a workgroup of the
 // packer's launch (k_pack, book role). The caller zeroes s_cnt / s_over / s_total and enc / lens over [lo, lo + range).
+// Margins (round 4). A small alphabet's book also gives a code word to every symbol that did NOT occur between CB_MARGIN below the
+// smallest and CB_MARGIN above the largest one that did (each counted once: the histogram the book is optimal for is
+// max(hist, 1) over that range). The ends of a smooth field's alphabet are symbols that occur once or twice in 10^8: the next
+// array of a series has its own, and a book without margins is incomplete for it half of the time (the verdict of a speculative
+// stage 2, book_rejected). Cost: a dozen 16-bit code words' share of the Kraft sum (2e-4) and as many bytes of the lengths' table.
+// Not when symbol 0 occurs (listed deltas / unpredictable points: the range then spans half the code space), not for a single
+// symbol (zero-length code), not when the widened range leaves the small path's 256 symbols. Same rule wherever the small
+// book is built (k_codebook<0>, the packer's book role): the book stays a function of the histogram.
+#define CB_MARGIN 8u
+__device__ __forceinline__ bool cb_margins(uint32_t &lo, uint32_t &range, uint32_t n_nonzero) {
+    if (lo == 0 || n_nonzero < 2) return false;
+    const uint32_t hi = lo + range - 1;
+    const uint32_t lo2 = lo > CB_MARGIN ? lo - CB_MARGIN : 1u, hi2 = hi + CB_MARGIN < SZH_HIST_BINS ? hi + CB_MARGIN : SZH_HIST_BINS - 1;
+    if (hi2 - lo2 + 1 > CB_SMALL_SYMS) return false;
+    lo = lo2;
+    range = hi2 - lo2 + 1;
+    return true;
+}
 template <uint32_t CAP>
 __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params &p, uint8_t *s_pool, uint32_t lo, uint32_t range,
-                         uint32_t *s_wtot, uint32_t &s_over, uint32_t *s_first, uint32_t *s_cnt, uint32_t *s_misc, unsigned long long &s_total) {
+                         uint32_t *s_wtot, uint32_t &s_over, uint32_t *s_first, uint32_t *s_cnt, uint32_t *s_misc, unsigned long long &s_total,
+                         bool fill = false /* cb_margins widened [lo, lo + range): its empty bins count once */) {
     const uint32_t t = threadIdx.x;
     // ---------------- small alphabets: LDS-resident, 256 threads ----------------
     uint64_t *keys = reinterpret_cast<uint64_t *>(s_pool);                          // [CAP]
@@ -2212,7 +2231,8 @@ __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params 
     uint32_t cnt = 0;
     uint64_t fsum = 0;
     for (uint32_t i = t * per; i < range && i < (t + 1) * per; i++) {
-        const uint64_t f = hist[lo + i];
+        uint64_t f = hist[lo + i];
+        if (fill && f == 0) f = 1;
         cnt += f != 0;
         fsum += f;
     }
@@ -2228,6 +2248,7 @@ __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params 
     }
     for (uint32_t i = t * per; i < range && i < (t + 1) * per; i++) {
         uint64_t f = hist[lo + i];
+        if (fill && f == 0) f = 1;
         if (f) {
             keys[pos] = (f << 16) | (lo + i);  // freq < 2^48
             syms[pos] = (uint16_t)(lo + i);
@@ -2427,8 +2448,9 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
         }
         return;
     }
-    const uint32_t lo = 0xFFFFu - p.range[0], range = p.range[1] - lo + 1;  // range[0] = max(65535 - bin), range[1] = max bin
+    uint32_t lo = 0xFFFFu - p.range[0], range = p.range[1] - lo + 1;  // range[0] = max(65535 - bin), range[1] = max bin
     const bool small = n_nonzero <= CB_SMALL_SYMS;
+    const bool fill = PART == 0 && small && cb_margins(lo, range, n_nonzero);
     if (small && t >= CB_THREADS) return;  // the small path runs on 4 waves (cheap barriers)
     if (t == 0) p.info->ts[0] = wall_clock64();
     if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
@@ -2445,7 +2467,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
         codebook_wide<true>(hist, p, s_pool, lo, range, s_cnt, s_first, s_misc);
         return;
     }
-    cb_small<CAP>(hist, p, s_pool, lo, range, s_wtot, s_over, s_first, s_cnt, s_misc, s_total);
+    cb_small<CAP>(hist, p, s_pool, lo, range, s_wtot, s_over, s_first, s_cnt, s_misc, s_total, fill);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -3000,7 +3022,49 @@ struct szk_role_params {
     const uint8_t *used_lens;
     uint32_t *flags;                 // [0] raised by a list too long for the short sort, [1] stage 1 summed the segments' bits
     int need_seg;
+    int exact;                       // the verdict accepts the used book only when it IS this call's book (book_rejected)
 };
+// The verdict on the book the encoder ran with (`used`, the context's previous book) against the book this call's histogram gives
+// (`fresh`). exact: the two must be the same book (a function of the code lengths: same range, same lengths) — the payload is then
+// a pure function of the input. Otherwise (round 4) the used book stands when it is a COMPLETE code over this call's alphabet —
+// every symbol that occurs has a code word in it — and the size it codes this call's symbols to is within 1/1024 of the fresh
+// book's: the format stores code lengths, so a decoder is unaware, and a series of similar arrays keeps its shortcuts although
+// no two histograms are equal (the reference builds a tree per call, encoder/HuffmanEncoder.hpp:96-105: its ratio is matched,
+// not its schedule). s_acc: three zeroed 64-bit words in LDS; every thread of the workgroup calls; returns true = rejected.
+__device__ bool book_rejected(const uint64_t *__restrict__ hist, const szk_cb_info *fresh, const uint8_t *__restrict__ fresh_lens,
+                              const szk_cb_info *used, const uint8_t *__restrict__ used_lens, bool exact, uint32_t t, uint32_t nt,
+                              unsigned long long *s_acc) {
+    const uint32_t lo = fresh->sym_min, cnt = fresh->sym_count;
+    if (exact) {
+        bool diff = used->sym_min != lo || used->sym_count != cnt || used->max_len != fresh->max_len || used->n_symbols != fresh->n_symbols;
+        if (!diff)
+            for (uint32_t i = t; i < cnt; i += nt) diff |= used_lens[lo + i] != fresh_lens[lo + i];
+        if (diff) atomicOr(&s_acc[0], 1ull);
+    } else {
+        const uint32_t ulo = used->sym_min, ucnt = used->sym_count;
+        unsigned long long cu = 0, cf = 0, missing = 0;
+        for (uint32_t i = t; i < cnt; i += nt) {
+            const unsigned long long h = hist[lo + i];
+            if (!h) continue;
+            const uint32_t sym = lo + i;
+            const uint32_t lu = (sym >= ulo && sym - ulo < ucnt) ? used_lens[sym] : 0u;  // (outside its range the slot may hold an older book's lengths)
+            missing |= lu == 0u;
+            cu += h * lu;
+            cf += h * fresh_lens[sym];
+        }
+        cu = wave_sum(cu);
+        cf = wave_sum(cf);
+        const bool miss_any = __ballot(missing != 0) != 0;
+        if (lane_id() == 0) {
+            if (miss_any) atomicOr(&s_acc[0], 1ull);
+            atomicAdd(&s_acc[1], cu);
+            atomicAdd(&s_acc[2], cf);
+        }
+    }
+    __syncthreads();
+    if (s_acc[0]) return true;
+    return !exact && s_acc[1] * 1024ull > s_acc[2] * 1025ull;
+}
 // book role: the small-alphabet code book from this call's histogram, then the verdict on the book the packer is using
 __device__ void role_book(const szk_role_params &rp, szk_state *state, uint8_t *pool) {
     __shared__ uint32_t s_wtot[CB_THREADS / WAVE];
@@ -3024,7 +3088,8 @@ __device__ void role_book(const szk_role_params &rp, szk_state *state, uint8_t *
         }
         built = true;
     } else {
-        const uint32_t lo = 0xFFFFu - p.range[0], range = p.range[1] - lo + 1;
+        uint32_t lo = 0xFFFFu - p.range[0], range = p.range[1] - lo + 1;
+        const bool fill = cb_margins(lo, range, n_nonzero);
         if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
         if (t == 0) {
             s_over = 0;
@@ -3036,20 +3101,14 @@ __device__ void role_book(const szk_role_params &rp, szk_state *state, uint8_t *
             p.lens[lo + i] = 0;
         }
         __syncthreads();
-        cb_small<CB_SMALL_SYMS>(rp.hist, p, pool, lo, range, s_wtot, s_over, s_first, s_cnt, s_misc, s_total);
+        cb_small<CB_SMALL_SYMS>(rp.hist, p, pool, lo, range, s_wtot, s_over, s_first, s_cnt, s_misc, s_total, fill);
         built = true;
     }
+    __shared__ unsigned long long s_acc[3];
     if (t == 0) s_diff = 0;
+    if (t < 3) s_acc[t] = 0;
     __syncthreads();  // (the block's own global writes of info / lens are visible to it after the barrier)
-    bool diff = false;
-    if (built) {
-        const szk_cb_info *fresh = p.info;
-        const uint32_t lo = fresh->sym_min, cnt = fresh->sym_count;
-        diff = rp.used->sym_min != lo || rp.used->sym_count != cnt || rp.used->max_len != fresh->max_len || rp.used->n_symbols != fresh->n_symbols;
-        if (!diff)
-            for (uint32_t i = t; i < cnt; i += CB_THREADS) diff |= rp.used_lens[lo + i] != p.lens[lo + i];
-    }
-    if (diff) s_diff = 1;
+    if (built && book_rejected(rp.hist, p.info, p.lens, rp.used, rp.used_lens, rp.exact != 0, t, CB_THREADS, s_acc) && t == 0) s_diff = 1;
     __syncthreads();
     if (t == 0) {
         const uint32_t kind = (s_diff ? 1u : 0u) | (!built ? 2u : 0u) | (rp.need_seg && !rp.flags[1] ? 8u : 0u);
@@ -4323,19 +4382,15 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
 }
 __global__ __launch_bounds__(1024) void k_book_verdict(const szk_cb_info *__restrict__ fresh, const uint8_t *__restrict__ fresh_lens,
                                                        const szk_cb_info *__restrict__ used, const uint8_t *__restrict__ used_lens,
-                                                       const uint32_t *__restrict__ mispredict, const uint32_t *__restrict__ range, szk_state *state) {
+                                                       const uint32_t *__restrict__ mispredict, const uint32_t *__restrict__ range, szk_state *state,
+                                                       const uint64_t *__restrict__ hist, int exact) {
     __shared__ uint32_t s_diff;
+    __shared__ unsigned long long s_acc[3];
     if (threadIdx.x == 0) s_diff = 0;
+    if (threadIdx.x < 3) s_acc[threadIdx.x] = 0;
     __syncthreads();
     const bool built = *mispredict == 0;
-    bool diff = false;
-    if (built) {  // (a code book is a function of its lengths: same alphabet range, same lengths = the same book)
-        const uint32_t lo = fresh->sym_min, cnt = fresh->sym_count;
-        diff = used->sym_min != lo || used->sym_count != cnt || used->max_len != fresh->max_len || used->n_symbols != fresh->n_symbols;
-        if (!diff)
-            for (uint32_t i = threadIdx.x; i < cnt; i += 1024) diff |= used_lens[lo + i] != fresh_lens[lo + i];
-    }
-    if (diff) s_diff = 1;
+    if (built && book_rejected(hist, fresh, fresh_lens, used, used_lens, exact != 0, threadIdx.x, 1024u, s_acc) && threadIdx.x == 0) s_diff = 1;
     __syncthreads();
     if (threadIdx.x == 0) {
         atomicOr(&state->miss_kind, (s_diff ? 1u : 0u) | (!built ? 2u : 0u));
@@ -4344,8 +4399,8 @@ __global__ __launch_bounds__(1024) void k_book_verdict(const szk_cb_info *__rest
     }
 }
 int szk_launch_book_verdict(const szk_cb_info *fresh, const uint8_t *fresh_lens, const szk_cb_info *used, const uint8_t *used_lens,
-                            const uint32_t *mispredict, const uint32_t *range, szk_state *state, hipStream_t s) {
-    hipLaunchKernelGGL(k_book_verdict, dim3(1), dim3(1024), 0, s, fresh, fresh_lens, used, used_lens, mispredict, range, state);
+                            const uint32_t *mispredict, const uint32_t *range, szk_state *state, const uint64_t *hist, int exact, hipStream_t s) {
+    hipLaunchKernelGGL(k_book_verdict, dim3(1), dim3(1024), 0, s, fresh, fresh_lens, used, used_lens, mispredict, range, state, hist, exact);
     SZK_CHECK_LAUNCH();
     return 0;
 }
@@ -4400,6 +4455,7 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
         rp.used_lens = er->used_lens;
         rp.flags = er->flags;
         rp.need_seg = seg_bits != nullptr;
+        rp.exact = er->exact;
         apv.lists_by_roles = 1;
     }
     const uint32_t rb = rp.on ? ROLE_BLOCKS : 0u;

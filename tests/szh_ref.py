@@ -132,6 +132,23 @@ def canonical_codes(lens):
     return codes, first, cnt
 
 
+BOOK_MARGIN = 8
+SMALL_SYMS = 256
+
+
+def book_symbols(present):
+    """-> (set of symbols a stream's code book has code words for, margins applied?) given the sorted symbols that occur.
+    Small alphabets (sz3hip_kernels.hip, cb_margins): every symbol from 8 below the smallest to 8 above the largest one, the empty
+    bins counted once — unless symbol 0 occurs, a single symbol occurs, or the widened range exceeds the small path's 256 symbols."""
+    present = np.asarray(present).astype(np.int64)
+    if len(present) < 2 or len(present) > SMALL_SYMS or present.min() == 0:
+        return set(present.tolist()), False
+    lo2, hi2 = max(int(present.min()) - BOOK_MARGIN, 1), min(int(present.max()) + BOOK_MARGIN, 65535)
+    if hi2 - lo2 + 1 > SMALL_SYMS:
+        return set(present.tolist()), False
+    return set(range(lo2, hi2 + 1)), True
+
+
 def kraft(lens):
     lens = np.asarray(lens, dtype=np.int64)
     return float(np.sum(2.0 ** (-lens[lens > 0].astype(np.float64))))

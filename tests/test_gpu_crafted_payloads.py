@@ -78,6 +78,11 @@ def test_tampered_headers_are_refused(kind):
         cases["block edge below 4"] = with_(144, "<I", 2)
         cases["empty predictor set"] = with_(148, "<I", 0)
         cases["side section shorter than its header"] = with_(120, "<Q", 8)
+        # the Rice parameters behind the selection bits are shift counts in the side section's parser: > 63 is refused
+        B = h["blk_edge"]
+        nblocks = int(np.prod([(d + B - 1) // B for d in h["dims"][1:]]))
+        sel_bytes = ((nblocks + 3) // 4 + 7) & ~7
+        cases["Rice parameter beyond 63"] = with_(o["side"] + 24 + sel_bytes + 2, "<B", 200)
     if kind == "block-1d":
         cases["second-order Lorenzo in 1-D"] = with_(148, "<I", 7)
         cases["1-D stream with a second extent"] = with_(16, "<4Q", 1, 1, 2, n // 2)

@@ -289,6 +289,7 @@ def test_rank_mode_compress_and_container_assembly():
         # without the exchange produces
         c3.regression = 0
         dc.set_speculation(True, backoff=False)
+        dc.set_deterministic(True)  # (the payloads are compared with a fresh context's)
         b = field3d(shape, seed=9)
         tb = torch.from_numpy(b).cuda()
         sc = D.SlabCompressor(None, dc, comm=comm)

@@ -79,16 +79,21 @@ def test_stages(name, gen, eb):
     assert h["magic"] == szh_ref.MAGIC and h["n"] == a.size and h["payload_bytes"] == len(pl)
     assert h["n_vout"] == int(bad.sum()) and h["n_dout"] == int(dout.sum())
     assert st["n_value_outliers"] == h["n_vout"] and st["payload_bytes"] == len(pl)
-    # K5: a complete prefix code over exactly the symbols that occur
+    # K5: a complete prefix code over exactly the symbols that occur — small alphabets: plus margins of 8 symbols either side,
+    # every empty bin of the widened range counted once (szh_ref.book_symbols; sz3hip_kernels.hip, cb_margins)
     present = np.unique(exp_codes)
     lens = sec["lens"]
-    assert set(h["sym_min"] + np.nonzero(lens)[0]) == (set(present.tolist()) if len(present) > 1 else set())
+    book, filled = szh_ref.book_symbols(present)
+    assert set(h["sym_min"] + np.nonzero(lens)[0]) == (book if len(present) > 1 else set())
     if len(present) > 1:
-        limit = szh_ref.SHORT_LEN if len(present) <= szh_ref.SHORT_SYMS else szh_ref.MAX_LEN
+        limit = szh_ref.SHORT_LEN if len(book) <= szh_ref.SHORT_SYMS else szh_ref.MAX_LEN
         assert abs(szh_ref.kraft(lens) - 1.0) < 1e-9 and lens.max() == h["max_len"] <= limit
         # optimality: total bits equal to an independent (unlimited) Huffman construction when that code respects the
         # length limit (16 bits up to 512 symbols, else 24), otherwise within 0.2 % of it (length-limited code)
         freq = np.bincount(exp_codes.reshape(-1), minlength=65536)[h["sym_min"]:h["sym_min"] + h["sym_count"]]
+        if filled:
+            assert h["sym_min"] == min(book) and h["sym_count"] == len(book)
+            freq = np.maximum(freq, 1)
         import heapq
         heap = [(int(f), i, 0) for i, f in enumerate(freq) if f]   # (freq, tiebreak, height)
         heapq.heapify(heap)
@@ -375,6 +380,7 @@ def test_context_hints_survive_a_change_of_regime():
     t = torch.from_numpy(a).to(dev)
     n = a.size
     shared = sz3_amd.DeviceCompressor(n, np.float32)
+    shared.set_deterministic(True)  # (payloads are compared with a fresh context's: the previous book stands only when it IS this call's)
     cap = shared.payload_bound(n, worst_case=True)
     for eb in (1e-3, 1e-6, 1e-3, 1e-3, 2e-6, 1e-6, 1e-2):
         conf = _conf(shape, eb)
@@ -485,6 +491,7 @@ def test_speculative_stage1_follows_the_tuner(shape, dtype):
     dev = torch.device("cuda:0")
     n = int(np.prod(shape))
     shared = sz3_amd.DeviceCompressor(n, dtype)
+    shared.set_deterministic(True)
     cap = shared.payload_bound(n, worst_case=True)
     conf = sz3_amd.Config(*shape)
     conf.absErrorBound = 1e-2
@@ -530,6 +537,7 @@ def test_speculative_code_book_is_confirmed_or_replaced():
     n = a.size
     shared = sz3_amd.DeviceCompressor(n, np.float32)
     shared.set_speculation(True, backoff=False)  # (the product sits out 1, 2, 4, 8 calls after a miss: the outcomes below are per call)
+    shared.set_deterministic(True)  # (the verdict of this test: same book or the encoder once more; the tolerant verdict has a test of its own below)
     cap = shared.payload_bound(n, worst_case=True)
     ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
 
@@ -577,6 +585,7 @@ def test_speculative_wide_code_book_on_its_own_stream():
     n = a.size
     shared = sz3_amd.DeviceCompressor(n, np.float64)
     shared.set_speculation(True, backoff=False)
+    shared.set_deterministic(True)
     cap = shared.payload_bound(n, worst_case=True)
     ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
 
@@ -621,6 +630,7 @@ def test_repeated_calls_take_every_shortcut_and_change_nothing(sigma, eb):
         b = (base + rng.normal(0, sigma, shape)).astype(np.float32)
         n = a.size
         shared = sz3_amd.DeviceCompressor(n, np.float32)
+        shared.set_deterministic(True)
         cap = shared.payload_bound(n, worst_case=True)
         conf = _conf(shape, eb)
 
@@ -640,3 +650,55 @@ def test_repeated_calls_take_every_shortcut_and_change_nothing(sigma, eb):
         hits, misses = shared.spec_stats()
         if sigma < 1e-2:  # (the rough field needs two-byte codes and a wide code book: no shortcuts to confirm)
             assert hits >= 3, (hits, misses)
+
+
+@pytest.mark.parametrize("dtype,shape,eb,sigma", [(np.float32, (40, 64, 512), 1e-3, 2e-3), (np.float32, (24, 36, 256), 1e-3, 8e-3),
+                                                  (np.float64, (24, 96, 256), 1e-6, 2e-6)], ids=["small-book-512", "small-book-256", "wide-book-f64"])
+def test_a_previous_book_that_is_nearly_this_calls_book_stands(dtype, shape, eb, sigma):
+    """The device API's default verdict (round 4): the previous call's code book stands when it is a complete code over this call's
+    alphabet and codes it within 1/1024 of this call's own book's size. Realisations of one field — no two histograms equal — alternate
+    on one context: (next to) every call after the first is a hit, every payload decodes within the bound with the decoder unaware,
+    its size within 0.15 % of a fresh context's; the same context in deterministic mode gives the fresh context's bytes; a field of
+    another character (another bound) is still a miss, and a book that lacks one of this call's symbols never stands."""
+    dev = torch.device("cuda:0")
+    fields = [field3d(shape, dtype, seed=100 + k, sigma=sigma) for k in range(4)]
+    n = fields[0].size
+    shared = sz3_amd.DeviceCompressor(n, dtype)
+    shared.set_speculation(True, backoff=False)
+    cap = shared.payload_bound(n, worst_case=True)
+    conf = _conf(shape, eb)
+
+    def run(dc, arr, c=conf):
+        t = torch.from_numpy(arr).to(dev)
+        pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+        size = dc.compress(c, t.data_ptr(), pl.data_ptr(), cap, 0)
+        dec = torch.empty_like(t)
+        dc.decompress(pl.data_ptr(), size, dec.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert float((dec.double() - t.double()).abs().max()) <= c.absErrorBound
+        return pl[:size].cpu().numpy().tobytes()
+
+    fresh = [run(sz3_amd.DeviceCompressor(n, dtype), f) for f in fields]
+    order = [0, 1, 2, 3, 0, 2, 1, 3, 3, 0]
+    for k, i in enumerate(order):
+        got = run(shared, fields[i])
+        assert abs(len(got) - len(fresh[i])) <= 1.5e-3 * len(fresh[i]), (k, len(got), len(fresh[i]))
+    hits, misses = shared.spec_stats()
+    assert hits >= len(order) - 2 and misses <= 1, (hits, misses)
+    # deterministic mode: the fresh context's bytes, and distinct realisations are misses again
+    shared.set_deterministic(True)
+    h0, m0 = shared.spec_stats()
+    for i in (1, 2):
+        assert run(shared, fields[i]) == fresh[i]
+    h1, m1 = shared.spec_stats()
+    assert (h1 - h0, m1 - m0) == (0, 2)
+    shared.set_deterministic(False)
+    # another bound = another alphabet: the wider book of the loose bound's successor lacks nothing, but costs more than 1/1024 -> miss;
+    # the tighter bound's alphabet has symbols the book lacks -> miss; both payloads decode (run() checks) and are a fresh context's
+    for factor in (4.0, 0.25):
+        c2 = _conf(shape, eb * factor)
+        h0, m0 = shared.spec_stats()
+        got = run(shared, fields[0], c2)
+        h1, m1 = shared.spec_stats()
+        assert (h1 - h0, m1 - m0) == (0, 1), (factor, h1 - h0, m1 - m0)
+        assert got == run(sz3_amd.DeviceCompressor(n, dtype), fields[0], c2)

@@ -216,6 +216,11 @@ void sz3hip_ctx_set_speculation(sz3hip_ctx *ctx, int off);
  * the reference builds a tree per call, encoder/HuffmanEncoder.hpp:96-105). Default of a device context: 0. */
 void sz3hip_ctx_set_deterministic(sz3hip_ctx *ctx, int on);
 void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses);
+/* 1 when the last finished compression of this context ran the fused stage 1 (round 4: a context whose previous call left a small
+ * code book codes with it INSIDE the predictor kernel — one-byte codes, rows that are multiples of 256 elements, 1-D..3-D — and the
+ * encoder only moves the rows' bit strings to their places; the verdict on the book is as for the unfused form, a miss repeats
+ * the whole call in the two-pass form: the input must stay valid until sz3hip_compress_finish returns) */
+int sz3hip_last_call_fused(const sz3hip_ctx *ctx);
 /* test hooks: copy internal device arrays to host (quantisation codes as uint16, histogram as uint64) */
 int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, uint64_t n);
 /* test hook: which chain the last sz3hip_decompress_device took: out4[0] half-width intermediates, [1] rows that cross chunk

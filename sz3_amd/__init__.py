@@ -146,6 +146,8 @@ def lib():
     L.sz3hip_ctx_set_speculation.restype = None
     L.sz3hip_ctx_set_deterministic.argtypes = [C.c_void_p, C.c_int]
     L.sz3hip_ctx_set_deterministic.restype = None
+    L.sz3hip_last_call_fused.argtypes = [C.c_void_p]
+    L.sz3hip_last_call_fused.restype = C.c_int
     L.sz3hip_get_spec_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.sz3hip_get_spec_stats.restype = None
     L.sz3hip_payload_bound_conf.restype = C.c_size_t
@@ -398,6 +400,11 @@ class DeviceCompressor:
         """on: the previous call's code book stands only when it IS this call's book — the payload is a pure function of the input
         (off, the device API's default: also when it is complete over this call's alphabet and within 1/1024 of its own book's size)"""
         lib().sz3hip_ctx_set_deterministic(self._h, int(on))
+
+    @property
+    def fused(self):
+        """the last finished compression ran the fused stage 1 (coded with the previous call's book inside the predictor kernel)"""
+        return bool(lib().sz3hip_last_call_fused(self._h))
 
     def spec_stats(self):
         h, m = C.c_uint32(), C.c_uint32()

@@ -214,7 +214,7 @@ static void ctx_free(sz3hip_ctx *c) {
                     c->d_chunk_words, c->d_chunk_off, c->d_carry, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples, c->d_trial_work, c->d_trial_codes,
                     c->d_trial, c->d_passes, c->d_np,  // (d_trial_counters / d_trial_hist live inside d_trial's block)
                     c->d_blk_sel, c->d_blk_coef, c->d_blk_rank, c->d_blk_comp, c->d_blk_side, c->d_blk_counters,
-                    c->bk[1].enc, c->bk[1].lens, c->bk[1].info, c->d_seg_bits, c->d_half32, c->d_sub_bits};
+                    c->bk[1].enc, c->bk[1].lens, c->bk[1].info, c->d_seg_bits, c->d_seg_start, c->d_half32, c->d_sub_bits, c->d_fuse_scratch};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->book_stream) {
@@ -297,6 +297,7 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     alloc((void **)&c->d_range, SZK_MAX_BOOKS * 16);
     alloc((void **)&c->d_info, SZK_MAX_BOOKS * sizeof(szk_cb_info));
     alloc((void **)&c->d_seg_bits, (max_elems / 256 + 8) * 2);
+    alloc((void **)&c->d_seg_start, (max_elems / 256 + 8) * 2);
     alloc((void **)&c->bk[1].enc, SZH_HIST_BINS * 4);
     alloc((void **)&c->bk[1].lens, SZH_HIST_BINS);
     alloc((void **)&c->bk[1].info, sizeof(szk_cb_info));
@@ -572,6 +573,35 @@ static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *
         p.seg_bits = ctx->d_seg_bits;
         p.seg_made = reinterpret_cast<uint32_t *>(ctx->d_counters + 10) + 1;  // zeroed with the counters
         p.defer_fold = ctx->hist_exposed || ctx->hist_reduced || (szk_dbg_flags & 16777216) ? 0 : 1;  // (whoever exchanges the histogram wants it complete after stage 1)
+        // Round 4: stage 1 may code with that book itself (the fused form, k_lorenzo_quant_march3f: the launcher takes it for the
+        // one-launch form on rows of whole segments when the scratch — the code array's memory — holds a slot per task). A verdict
+        // miss then costs the whole call once more: a context that wants its payloads bit-identical to a fresh context's
+        // (deterministic mode) asks for it only behind a call whose book was confirmed.
+        const uint64_t need = szk_fuse_scratch_words(N, p.d);
+        if (need && !ctx->hist_reduced && (!ctx->spec_exact || ctx->last_spec_hit)) {
+            p.fuse_slots = reinterpret_cast<uint32_t *>(ctx->d_codes);
+            p.fuse_cap_words = (ctx->max_n + 64) / 2;  // (the array holds (max_n + 64) two-byte codes)
+            if (need > p.fuse_cap_words && need <= 2 * num + (1u << 18)) {
+                // extents that are not multiples of the tasks' 4 rows x 16 planes: the slots of the tasks that end beyond the array
+                // do not fit the code array's 2 bytes per element — a scratch of the context's own, for up to 4 x that
+                if (ctx->fuse_scratch_words < need) {
+                    if (ctx->d_fuse_scratch) (void)hipFree(ctx->d_fuse_scratch);
+                    ctx->d_fuse_scratch = nullptr;
+                    ctx->fuse_scratch_words = 0;
+                    if (hipMalloc((void **)&ctx->d_fuse_scratch, need * 4) == hipSuccess) ctx->fuse_scratch_words = need;
+                    else (void)hipGetLastError();
+                }
+                if (ctx->fuse_scratch_words >= need) {
+                    p.fuse_slots = ctx->d_fuse_scratch;
+                    p.fuse_cap_words = ctx->fuse_scratch_words;
+                }
+            }
+            p.fuse = 1;
+            p.fuse_enc = ctx->bk[ctx->book_idx].enc;
+            p.fuse_info = ctx->bk[ctx->book_idx].info;
+            p.seg_start = ctx->d_seg_start;
+            p.fuse_flag = reinterpret_cast<uint32_t *>(ctx->d_counters + 11);  // zeroed with the counters
+        }
     }
     p.prof_ev0 = p.prof_ev1 = nullptr;
     if (ctx->profiling && allow_narrow) {  // (the production call, not the tuner's trial): events around the kernel itself
@@ -592,6 +622,10 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
     ctx->seg_expected = p.seg_expected != 0 && !(szk_dbg_flags & 33554432);
     ctx->fold_rows = p.defer_fold ? p.fold_rows : 0;
     ctx->fold_range = p.range;
+    ctx->s1_fused = p.fused != 0;
+    ctx->s1_slots = p.fuse_slots;
+    for (int i = 0; i < 4; i++) ctx->fuse_geom[i] = p.fuse_geom[i];
+    ctx->fuse_ty = p.fuse_ty;
     prof_end(ctx, ST_K1, s);
     if (rc) return fail(SZ3HIP_EHIP, "lorenzo_quant kernel launch failed (%d)", rc);
     szh_header &h = ctx->proto;
@@ -1065,7 +1099,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     for (int i = 0; i < ST_COUNT; i++) ctx->ev_used[i] = false;  // stage times describe this call only
     ctx->copy_ahead = false;
     ctx->range_ready = false;
-    ctx->s1_spec = ctx->seg_expected = ctx->s1_assumed_narrow = false;
+    ctx->s1_spec = ctx->seg_expected = ctx->s1_assumed_narrow = ctx->s1_fused = false;
     ctx->fold_rows = 0;
     ctx->s1_conf = *conf_in;
     ctx->s1_in = d_in;
@@ -1224,6 +1258,16 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     // (Not for block streams: their side section is copied by the assembly's list workgroups, which the sort roles replace.)
     const bool spec_wide = !spec && book_spec_ok(ctx, ctx->proto.predictor, ctx->proto.radius) && ctx->cb_hint == 1 && !ctx->lists_long &&
                            ctx->proto.predictor != 2 && !(szk_dbg_flags & 4096);
+    if (ctx->s1_fused && !spec) {
+        // (cannot happen: the fused stage 1 is taken under the conditions of this stage's one-stream form; should they ever drift apart,
+        // there is no code array to encode from — stage 1 once more, in the two-pass form)
+        const int spec_was = ctx->spec_off;
+        ctx->spec_off = 1;
+        sz3hip_config conf = ctx->s1_conf;
+        int rc1 = sz3hip_compress_stage1(ctx, &conf, ctx->s1_in, stream);
+        ctx->spec_off = spec_was;
+        if (rc1) return rc1;
+    }
     int rc = stage2_launch(ctx, d_payload, cap, s, spec ? S2_SPEC : (spec_wide ? S2_SPEC_WIDE : S2_CLASSIC));
     if (rc) return rc;
     ctx->stage2_done = true;
@@ -1330,11 +1374,25 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     ap.side = ctx->proto.predictor == 2 ? ctx->d_blk_side : nullptr;
     ap.assumed_narrow = ctx->s1_assumed_narrow ? 1 : 0;
     ap.mode = ctx->mode;
+    szk_merge_args mg;
+    memset(&mg, 0, sizeof(mg));
+    const bool merge = fused && ctx->s1_fused && ctx->seg_expected;
+    if (ctx->s1_fused && !merge) return fail(SZ3HIP_EHIP, "internal: fused stage 1 without the merging encoder");
+    if (merge) {
+        mg.slots = ctx->s1_slots;
+        mg.ty = ctx->fuse_ty;
+        mg.seg_start = ctx->d_seg_start;
+        mg.d[0] = (uint32_t)ctx->proto.dims[3];
+        mg.d[1] = (uint32_t)ctx->proto.dims[2];
+        mg.d[2] = (uint32_t)ctx->proto.dims[1];
+        for (int i = 0; i < 4; i++) mg.geom[i] = ctx->fuse_geom[i];
+        mg.fuse_flag = reinterpret_cast<const uint32_t *>(ctx->d_counters + 11);
+    }
     prof_begin(ctx, ST_ENCODE, s);  // (the payload layout is computed inside the encoder's scan launch, the sections are assembled by the packer's)
     int rc = szk_launch_encode(ctx->d_codes, n, ctx->bk[used].enc, ctx->bk[used].info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words,
                                ctx->d_chunk_off, ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, &lp, &ap, s,
                                fused && ctx->seg_expected ? ctx->d_seg_bits : nullptr, reinterpret_cast<uint32_t *>(ctx->d_counters + 10) + 1,
-                               (fused || wide) ? &er : nullptr);
+                               (fused || wide) ? &er : nullptr, merge ? &mg : nullptr);
     prof_end(ctx, ST_ENCODE, s);
     if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
     if (wide) {  // join: this call's book against the one the encoder used
@@ -1357,12 +1415,18 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     HIPCHK(hipSetDevice(ctx->device));
     if (!ctx->stage2_done) return fail(SZ3HIP_EINVAL, "finish called before stage2");
     HIPCHK(hipEventSynchronize(ctx->ev_done));  // (the payload is complete: the state's copy is the last thing stage 2 enqueued)
-    if (ctx->h_state->miss_kind & 32u) {
+    const bool fused_miss = ctx->s1_fused && (ctx->h_state->miss_kind != 0 || ctx->h_state->mispredict != 0);
+    ctx->last_fused = ctx->s1_fused && !fused_miss;
+    ctx->last_spec_hit = ctx->s2_spec && ctx->h_state->miss_kind == 0 && ctx->h_state->mispredict == 0;
+    if ((ctx->h_state->miss_kind & 32u) || fused_miss) {
         // stage 1 assumed one-byte codes (the form a context takes after a one-byte call) and this call's probe says two: the
         // whole call once more, in the form that waits for the probe. The input must still be where stage 1 found it.
+        // Likewise behind a FUSED stage 1 whose book the verdict rejects (or that met a symbol the book has no code word for, or
+        // whose lists were too long for the sort roles): there is no code array to encode again from.
         ctx->redo_calls++;
         ctx->spec_misses++;  // (counted with the other failed shortcuts)
-        ctx->narrow_hint = 0;
+        if (ctx->h_state->miss_kind & 32u) ctx->narrow_hint = 0;
+        if (ctx->h_state->mispredict || (ctx->h_state->miss_kind & 2u)) ctx->cb_hint = -1;
         const int spec_was = ctx->spec_off;
         ctx->spec_off = 1;
         sz3hip_config conf = ctx->s1_conf;
@@ -1548,6 +1612,7 @@ extern "C" void sz3hip_ctx_set_speculation(sz3hip_ctx *ctx, int off) { ctx->spec
 // same book); 0 (the device API's default): the previous book also stands when it is complete over this call's alphabet and codes
 // it within 1/1024 of this call's own book's size — the payload then depends on the context's history, its size by < 0.1 %
 extern "C" void sz3hip_ctx_set_deterministic(sz3hip_ctx *ctx, int on) { ctx->spec_exact = on ? 1 : 0; }
+extern "C" int sz3hip_last_call_fused(const sz3hip_ctx *ctx) { return ctx->last_fused ? 1 : 0; }
 extern "C" void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses) {
     *hits = ctx->spec_hits;
     *misses = ctx->spec_misses;

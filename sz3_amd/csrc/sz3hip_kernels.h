@@ -35,6 +35,7 @@ struct szk_mode {
     uint32_t allow;               // 0: always two-byte codes
 };
 
+struct szk_cb_info;
 struct szk_k1_params {
     uint64_t d[4];  // extents slowest first, left-padded with 1: [w][z][y][x]
     szk_lattice lat;
@@ -69,6 +70,18 @@ struct szk_k1_params {
     int defer_fold;
     uint32_t fold_rows;
     int range_kept;    // out: the launched kernels keep the range words (the register-marching forms do)
+    // fused form (round 4, k_lorenzo_quant_march3f): stage 1 codes with the previous call's book and writes the rows' bit strings
+    int fuse;                       // in: asked for (a small previous book, the one-launch form, x extent a multiple of 256, the scratch fits)
+    int fused;                      // out: the launcher took it
+    const uint32_t *fuse_enc;       // [65536] (code word << 5) | length of the previous book
+    const szk_cb_info *fuse_info;   // ... its descriptor (max_len is read on the device)
+    uint32_t *fuse_slots;           // the scratch: one slot of TY * MARCH_TZ * 128 words per task (the code array's memory)
+    uint64_t fuse_cap_words;        // words the scratch holds
+    uint16_t *seg_start;            // [n / 256] word offset of a segment's bit string inside its task's slot
+    uint32_t *fuse_flag;            // device word, raised when a symbol had no code word in that book
+    uint32_t fuse_geom[4];          // out: tasks per dimension ntx, nty, ntz and the words of a task's slot (the merge finds a segment's string with them)
+    uint32_t fuse_ty;               // out: rows per task
+    // (the launcher's query, szk_fuse_scratch_words: words the scratch of a fused launch over this shape needs)
 };
 
 struct szk_cb_info {
@@ -141,6 +154,14 @@ struct szk_asm_params {
     szk_mode mode;
 };
 // speculative stage 2, small alphabets: work that rides in the encoder's two launches instead of a side stream
+struct szk_merge_args {         // what the merge launch needs of a fused stage 1 (k_lorenzo_quant_march3f)
+    const uint32_t *slots;      // the scratch its tasks wrote their rows' bit strings to
+    const uint16_t *seg_start;  // [n / 256] word offset of a segment's string inside its task's slot
+    uint32_t d[3];              // extents x, y, z of the kernel's view
+    uint32_t geom[4];           // szk_k1_params::fuse_geom
+    uint32_t ty;                // szk_k1_params::fuse_ty
+    const uint32_t *fuse_flag;  // raised by stage 1: a symbol without a code word in the book it used
+};
 struct szk_encode_roles {
     int roles;                  // the packer's launch carries the book role (this call's code book + the verdict) and the two sort roles
     int no_book;                // ... the sort roles only: the book is built elsewhere (wide alphabets: k_codebook<1> on the side stream)
@@ -299,7 +320,8 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
                       const szk_asm_params *asmp /* non-null: the packer's launch also assembles the payload (no szk_launch_assemble) */, hipStream_t s,
                       const uint16_t *seg_bits = nullptr /* non-null: code bits per 256-element segment, summed by stage 1 (no bits pass) */,
                       const uint32_t *seg_made = nullptr /* device flag: stage 1 really made them */,
-                      const szk_encode_roles *roles = nullptr);
+                      const szk_encode_roles *roles = nullptr,
+                      const szk_merge_args *merge = nullptr /* stage 1 was the fused form: k_merge instead of the packer */);
 // the fold of stage 1's per-workgroup histogram rows (k_hist_reduce), for a caller that deferred it (szk_k1_params::defer_fold)
 // and does not run the encoder form that carries it
 // speculative stage 2 with a wide alphabet: the book built on the side stream against the one the packer used (miss_kind bit 1:
@@ -308,6 +330,8 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
 int szk_launch_book_verdict(const szk_cb_info *fresh, const uint8_t *fresh_lens, const szk_cb_info *used, const uint8_t *used_lens,
                             const uint32_t *mispredict, const uint32_t *range, szk_state *state,
                             const uint64_t *hist /* this call's histogram */, int exact /* see szk_encode_roles::exact */, hipStream_t s);
+// words of scratch a fused stage 1 over this view (extents slowest first, left-padded with 1) needs; 0: the shape does not take that form
+uint64_t szk_fuse_scratch_words(int ndim, const uint64_t d[4]);
 int szk_launch_hist_range(const uint64_t *d_hist, uint32_t *range /* [4], zeroed */, hipStream_t s);  // range and count of the non-empty bins
 int szk_launch_hist_fold(const uint32_t *partial, uint32_t nrows, int radius, uint64_t *hist, uint32_t *range, hipStream_t s);
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);

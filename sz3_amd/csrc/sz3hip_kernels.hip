@@ -959,7 +959,21 @@ template <typename T> struct NarrowCtx {
     OQV *oq_val;
     uint32_t oq_n;
     int lane;
+    // fused form (round 4): the rows' bit strings, coded with the context's previous book, leave stage 1 instead of the codes
+    const uint32_t *s_enc;  // [256] (code word << 5) | length by stored byte t (LDS)
+    uint32_t *stage;        // this wave's LDS stage: TY rows x FUSE_ROW_WORDS, zero between planes
+    uint32_t *slot;         // the task's slot of the scratch (the code array's memory): FUSE_SLOT_WORDS(TY) words
+    uint32_t slot_w;        // words of the slot in use (wave-uniform)
+    uint16_t *seg_start;    // [n / 256] out: word offset of every segment's bit string inside its task's slot
+    uint32_t minl;          // shortest code length met (0: a symbol the book has no code word for)
 };
+// a 256-element row segment is at most 256 x 16 bits = 128 words (small books: code words <= 16 bits) + 2 words of slack for the
+// unconditional three-word emission; a task's slot holds its TY x MARCH_TZ segments at their worst
+#define FUSE_ROW_WORDS 130
+// (rows and planes a task can have: min(TY, d1) x min(MARCH_TZ, d2) — a 2-D array's tasks are one plane deep)
+static inline uint32_t fuse_slot_words(uint32_t ty, uint64_t d1, uint64_t d2) {
+    return (uint32_t)((d1 < ty ? d1 : ty) * (d2 < MARCH_TZ ? d2 : MARCH_TZ) * 128u);
+}
 template <typename T>
 __device__ __forceinline__ void narrow_oq_flush(NarrowCtx<T> &c) {
     // (called by whatever lanes are active; the records are dealt over the ACTIVE lanes, see march_body)
@@ -1027,7 +1041,7 @@ template <typename T, int NW, int TY> struct NarrowPlane {
 #ifndef NARROW_PF
 #define NARROW_PF 0  // 1: the next plane's rows are requested before the current plane is worked (two sets of row registers; measured slower: 161 vs 149 us)
 #endif
-template <typename T, int NDIM, int TY, bool EDGE>
+template <typename T, int NDIM, int TY, bool EDGE, bool FUSE = false>
 __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &lat, uint32_t x0, uint32_t y0, uint32_t z0, uint32_t w) {
     using B = typename Lattice<T>::B;
     using UQ = typename QTraits<T>::UQ;
@@ -1095,6 +1109,13 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
         uint32_t bits_rows[(TY + 1) / 2];  // code bits of the plane's rows, two rows per register (16 bits each)
 #pragma unroll
         for (int k = 0; k < (TY + 1) / 2; k++) bits_rows[k] = 0;
+        uint64_t fq[TY];   // FUSE: the lane's four code words of every row, joined ...
+        uint32_t fl[TY];   // ... and their length (0: the row is not coded)
+#pragma unroll
+        for (int k = 0; k < TY; k++) {
+            fq[k] = 0;
+            fl[k] = 0;
+        }
 #pragma unroll
         for (int r = 0; r <= TY; r++) {
             bool bad[4] = {false, false, false, false};
@@ -1152,6 +1173,16 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
 #endif
 #pragma unroll
                 for (int i = 0; i < 4; i++) atomicAdd(&c.lh[t[i] * 4u + copy], 1u);
+                if constexpr (FUSE) {
+                    // the four code words of the lane, joined: two pairs in 32 bits (code words <= 16 bits), the pairs in 64
+                    const uint32_t e0 = c.s_enc[t[0]], e1 = c.s_enc[t[1]], e2 = c.s_enc[t[2]], e3 = c.s_enc[t[3]];
+                    const uint32_t l0 = e0 & 31u, l1 = e1 & 31u, l2 = e2 & 31u, l3 = e3 & 31u;
+                    const uint32_t p01 = ((e0 >> 5) << l1) | (e1 >> 5), p23 = ((e2 >> 5) << l3) | (e3 >> 5);
+                    const uint32_t l23 = l2 + l3;
+                    fq[r - 1] = ((uint64_t)p01 << l23) | p23;
+                    fl[r - 1] = l0 + l1 + l23;
+                    c.minl = min(c.minl, min(min(l0, l1), min(l2, l3)));
+                } else {
 #ifdef LAB_ABLATE
                 if (!(c.p->dbg & 2u))
 #endif
@@ -1161,6 +1192,7 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
 #else
                 __builtin_nontemporal_store(t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24), reinterpret_cast<uint32_t *>(c.codes8 + grow + x));
 #endif
+                }
             }
             if (c.s_len) {
                 uint32_t b4 = (uint32_t)c.s_len[t[0]] + c.s_len[t[1]] + c.s_len[t[2]] + c.s_len[t[3]];
@@ -1177,7 +1209,56 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
                 narrow_rare<T>(c, grow + x, delta, tmask, badmask);
             }
         }
-        if (c.s_len && zz >= 0) {  // the plane's segment sums: one wave reduction per pair of rows
+        if constexpr (FUSE) {
+            if (zz >= 0) {
+                // Bit positions of the lanes' strings inside their rows: one wave scan per PAIR of rows (16 bits each: a row is at most
+                // 64 lanes x 64 bits). Every row is emitted into its own stretch of the wave's LDS stage (three ds_or per lane),
+                // then the rows leave for the task's slot one behind the other, word-aligned, with their length and place noted.
+                uint32_t row_bits[TY];
+#pragma unroll
+                for (int k = 0; k < TY; k += 2) {
+                    const uint32_t packed = fl[k] | (k + 1 < TY ? fl[k + 1] << 16 : 0u);
+                    const uint32_t incl = wave_incl_scan(packed);
+                    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+                    const uint32_t excl = incl - packed;
+                    row_bits[k] = tot & 0xFFFFu;
+                    if (k + 1 < TY) row_bits[k + 1] = tot >> 16;
+#pragma unroll
+                    for (int h = 0; h < 2 && k + h < TY; h++) {
+                        const uint32_t len = fl[k + h], pos = h ? excl >> 16 : excl & 0xFFFFu;
+                        const uint64_t v = len ? fq[k + h] << (64u - len) : 0ull;  // left-aligned
+                        uint32_t *st = c.stage + (k + h) * FUSE_ROW_WORDS + (pos >> 5);
+                        const uint32_t sh = pos & 31u;
+                        const uint64_t tv = v >> sh;
+                        atomicOr(&st[0], (uint32_t)(tv >> 32));
+                        atomicOr(&st[1], (uint32_t)tv);
+                        atomicOr(&st[2], (uint32_t)(((uint64_t)(uint32_t)v << 32) >> sh));
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < TY; k++) {
+                    if (!R.rok[0][k + 1]) continue;  // (wave-uniform: the row lies beyond the array)
+                    const uint32_t nw = (row_bits[k] + 31u) >> 5;
+                    const uint64_t seg = ((uint64_t)w * c.vol + (uint64_t)gz * c.plane + (uint64_t)(y0 + k) * d0 + x0) >> 8;
+                    uint32_t *st = c.stage + k * FUSE_ROW_WORDS;
+                    uint32_t *out = c.slot + c.slot_w;
+                    for (uint32_t i = (uint32_t)lane; i < nw; i += WAVE) {
+                        const uint32_t wv = st[i];
+                        st[i] = 0u;
+                        __builtin_nontemporal_store(wv, &out[i]);
+                    }
+                    if (lane == 0) {
+                        c.seg_bits[seg] = (uint16_t)row_bits[k];
+                        c.seg_start[seg] = (uint16_t)c.slot_w;
+                    }
+                    c.slot_w += nw;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (!FUSE && c.s_len && zz >= 0) {  // the plane's segment sums: one wave reduction per pair of rows
 #pragma unroll
             for (int k = 0; k < (TY + 1) / 2; k++) {
                 const uint32_t tot = wave_sum(bits_rows[k]);
@@ -1211,10 +1292,11 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
         }
     }
 }
-template <typename T, int NDIM, int TY>
+template <typename T, int NDIM, int TY, bool FUSE = false>
 __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t *__restrict__ codes, const szk_k1_params &p, uint32_t ntasks,
                                              uint32_t *lh, uint8_t *s_len, uint64_t (*s_oq_idx)[MarchLds<1, false>::OQ],
-                                             typename NarrowCtx<T>::OQV (*s_oq_val)[MarchLds<1, false>::OQ]) {
+                                             typename NarrowCtx<T>::OQV (*s_oq_val)[MarchLds<1, false>::OQ],
+                                             uint32_t *s_fenc = nullptr, uint32_t *s_fstage = nullptr) {
     const Lattice<T> lat(p.lat);
     NarrowCtx<T> c;
     c.in = in;
@@ -1233,10 +1315,28 @@ __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t 
     c.oq_n = 0;
     // bit accounting: the code-length table of the context's previous book, by stored byte; only for rows cut into whole
     // 256-element segments (x extent a multiple of 256: a segment then never straddles two chunks of the packer)
-    const bool acct = p.spec_lens != nullptr && c.d0 % MARCH_TX == 0;
+    const bool acct = !FUSE && p.spec_lens != nullptr && c.d0 % MARCH_TX == 0;
     c.s_len = acct ? s_len : nullptr;
     c.seg_bits = p.seg_bits;
+    c.s_enc = s_fenc;
+    c.stage = nullptr;
+    c.slot = nullptr;
+    c.slot_w = 0;
+    c.seg_start = p.seg_start;
+    c.minl = 31u;
     for (int i = threadIdx.x; i < NARROW_BINS * 4; i += 256) lh[i] = 0;
+    if constexpr (FUSE) {
+        // the previous call's book by stored byte (255 = a listed delta: symbol 0). A book this form cannot use (code words beyond 16
+        // bits, or none at all: a single-symbol alphabet) becomes a table of zero lengths: nothing is emitted and the flag below is raised
+        const uint32_t ml = p.fuse_info->max_len, blo = p.fuse_info->sym_min, bcnt = p.fuse_info->sym_count;
+        const uint32_t b = threadIdx.x;
+        const uint32_t sym = b == 255u ? 0u : b + p.radius - 127u;
+        // (outside the book's range the table may hold an older book's entries: the slot is zeroed over the new range only)
+        s_fenc[b] = (ml >= 1u && ml <= 16u && sym >= blo && sym - blo < bcnt) ? p.fuse_enc[sym] : 0u;
+        for (int i = threadIdx.x; i < 4 * TY * FUSE_ROW_WORDS; i += 256) s_fstage[i] = 0u;
+        c.stage = s_fstage + wv * (TY * FUSE_ROW_WORDS);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *p.seg_made = 1u;
+    }
     if (acct) {
         const uint32_t b = threadIdx.x;  // 256 threads, 256 byte values; 255 = the delta outliers' symbol 0
         s_len[b] = p.spec_lens[b == 255u ? 0u : b + p.radius - 127u];
@@ -1257,10 +1357,17 @@ __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t 
         b /= nty;
         const uint32_t z0 = (b % ntz) * MARCH_TZ;
         const uint32_t w = b / ntz;
-        if (x0 + MARCH_TX <= c.d0 && y0 + TY <= c.d1) narrow_task<T, NDIM, TY, false>(c, lat, x0, y0, z0, w);
-        else narrow_task<T, NDIM, TY, true>(c, lat, x0, y0, z0, w);
+        if constexpr (FUSE) {
+            c.slot = p.fuse_slots + (uint64_t)task * p.fuse_geom[3];
+            c.slot_w = 0;
+        }
+        if (x0 + MARCH_TX <= c.d0 && y0 + TY <= c.d1) narrow_task<T, NDIM, TY, false, FUSE>(c, lat, x0, y0, z0, w);
+        else narrow_task<T, NDIM, TY, true, FUSE>(c, lat, x0, y0, z0, w);
     }
     narrow_oq_flush(c);
+    if constexpr (FUSE) {  // a symbol without a code word in the book this launch coded with: its output is void (the call is repeated)
+        if (__ballot(c.minl == 0u) && c.lane == 0) atomicOr(p.fuse_flag, 1u);
+    }
     __syncthreads();
     // the workgroup's counts go to its private row of hist_partial (k_hist_reduce folds the rows): bin t = symbol t + radius - 127
     uint32_t *row = p.hist_partial + (uint64_t)blockIdx.x * HIST_WIN;
@@ -1316,6 +1423,28 @@ __global__ __launch_bounds__(256) MARCH3_ATTR void k_lorenzo_quant_march3(const 
     __shared__ uint32_t s_p[3];
     probe_body<T, NDIM>(in, p, p.mode.n_total, p.mode.probe_big, s_p);
     march_narrow<T, NDIM, TY>(in, codes, p, ntasks, lh, s_len, s_oq_idx, s_oq_val);
+}
+// The FUSED form of the one-launch kernel (round 4): a context whose previous call left a small code book codes with THAT book
+// inside stage 1 — the rows' bit strings leave the kernel instead of one byte per element (4 + 0.5 B/elem instead of 4 + 1, and
+// no second trip over the codes: the encoder that follows only moves the strings to their places, k_merge). A lane looks its
+// four symbols of a row up in a 256-entry LDS table, joins them, the wave scans the lengths (two rows per scan), the strings are
+// OR-ed into an LDS stage and the row's words are copied to the task's slot of the scratch (the code array's memory: a task's
+// 64 segments, word-aligned, one behind the other; seg_bits / seg_start note length and place). The verdict on the book is the
+// packer's as before (book_rejected: this call's book is built from this call's histogram beside the merge); a miss — or a
+// symbol the book has no code word for, fuse_flag — repeats the whole call in the two-pass form.
+template <typename T, int NDIM, int TY>
+__global__ __launch_bounds__(256) void k_lorenzo_quant_march3f(const T *__restrict__ in, uint16_t *__restrict__ codes,
+                                                               szk_k1_params p, uint32_t ntasks, uint32_t nrows) {
+    using L = MarchLds<1, false>;
+    using OQV = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;
+    __shared__ uint32_t lh[NARROW_BINS * 4 + 4];
+    __shared__ uint64_t s_oq_idx[4][L::OQ];
+    __shared__ OQV s_oq_val[4][L::OQ];
+    __shared__ uint32_t s_p[3];
+    __shared__ uint32_t s_fenc[256];
+    __shared__ uint32_t s_fstage[4 * TY * FUSE_ROW_WORDS];
+    probe_body<T, NDIM>(in, p, p.mode.n_total, p.mode.probe_big, s_p);
+    march_narrow<T, NDIM, TY, true>(in, codes, p, ntasks, lh, nullptr, s_oq_idx, s_oq_val, s_fenc, s_fstage);
 }
 
 // folds the per-workgroup histogram rows into hist[win_lo + bin]: block (bx, by) sums rows by, by + gridDim.y, ... of
@@ -3295,6 +3424,107 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The encoder behind a FUSED stage 1 (k_lorenzo_quant_march3f): the rows' bit strings exist, in the tasks' slots of the scratch; a
+// chunk of the payload is four consecutive 256-element segments (x extents that are multiples of 256), its place known since the
+// offset scan. A wave per chunk, a lane per output word: the word's first bit lies in segment k = the number of segment starts at
+// or before it, its bits come from two consecutive words of that segment's string (a funnel shift) and — where the segment ends
+// inside the word — from the first word of the next one (segments are at least 256 bits long: a word meets at most two).
+// 3 instructions per symbol instead of the packer's 13, and no code array: the launch reads 0.5 B/elem and writes 0.5.
+// The role workgroups (this call's code book + verdict, list sorts) and the assembly ride along as in k_pack.
+// ------------------------------------------------------------------------------------------------------------
+struct szk_merge_params {
+    const uint32_t *slots;       // the scratch stage 1 wrote
+    const uint16_t *seg_bits;    // [n / 256] bits of every segment's string
+    const uint16_t *seg_start;   // [n / 256] its word offset inside its task's slot
+    uint32_t d0, d1, d2;         // extents (x fastest), d3 folded into the task index
+    uint32_t ntx, nty, ntz, ty;  // tasks per dimension, rows per task (geometry of the stage-1 launch)
+    uint32_t slot_words;         // words of a task's slot
+    const uint32_t *fuse_flag;   // raised by stage 1: a symbol without a code word
+};
+__global__ __launch_bounds__(256) void k_merge(szk_merge_params mp, uint64_t n, const uint16_t *__restrict__ chunk_words,
+                                               const uint64_t *__restrict__ group_off, szk_mode mode, const szk_state *__restrict__ state,
+                                               uint8_t *__restrict__ payload, szk_asm_params ap, uint32_t pack_blocks, szk_role_params rp) {
+    __shared__ __align__(16) uint32_t s_pool[ENC_WIN];  // the role workgroups' scratch (see k_pack)
+    const uint32_t roles = rp.on ? ROLE_BLOCKS : 0u;
+    if (blockIdx.x < roles) {
+        if (blockIdx.x == 0) {
+            if (!rp.no_book) role_book(rp, ap.state, reinterpret_cast<uint8_t *>(s_pool));
+            if (threadIdx.x == 0 && *mp.fuse_flag) atomicOr(&ap.state->miss_kind, 64u);
+        } else role_sort(rp, ap, blockIdx.x == 2, reinterpret_cast<uint8_t *>(s_pool));
+        return;
+    }
+    const uint32_t bid = blockIdx.x - roles;
+    const uint32_t nblk = gridDim.x - roles;
+    if (bid >= pack_blocks) {
+        assemble_body(ap, (uint64_t)(bid - pack_blocks) * 256 + threadIdx.x, (uint64_t)(nblk - pack_blocks) * 256);
+        if (!ap.lists_by_roles) assemble_lists(ap, (uint64_t)bid * 256 + threadIdx.x, (uint64_t)nblk * 256);
+        return;
+    }
+    if (ap.assumed_narrow && !szk_is_narrow(mode)) return;  // the probe says two-byte codes: the call is repeated
+    const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS, n_segs = n >> 8;  // (n is a multiple of 256; the last chunk may hold fewer than four segments)
+    const uint64_t wave_gid = (uint64_t)bid * 4 + threadIdx.x / WAVE, nwaves = (uint64_t)pack_blocks * 4;
+    const int lane = lane_id();
+    uint32_t *out_base = reinterpret_cast<uint32_t *>(payload + state->off.bitstream);
+    const uint32_t slot_words = mp.slot_words;
+    const uint64_t plane = (uint64_t)mp.d0 * mp.d1, vol = plane * mp.d2;
+    for (uint64_t chunk = wave_gid; chunk < n_chunks; chunk += nwaves) {
+        // lanes 0..3: where segment 4 * chunk + lane lies and how long it is; lane l < cin: words of chunk l of the group
+        const uint64_t grp = chunk / PACK_GROUP;
+        const uint32_t cin = (uint32_t)(chunk % PACK_GROUP);
+        uint32_t bp = chunk_words[grp * PACK_GROUP + ((uint32_t)lane < cin ? lane : 0)];
+        bp = (uint32_t)lane < cin ? bp : 0u;
+        const uint64_t goff = group_off[grp];
+        const uint32_t nwords = chunk_words[chunk];
+        uint32_t sb = 0;
+        uint64_t sbase = 0;
+        if (lane < 4 && chunk * 4 + (uint64_t)lane < n_segs) {
+            const uint64_t seg = chunk * 4 + (uint64_t)lane;
+            const uint64_t e = seg << 8;  // the segment's first element
+            const uint32_t w = (uint32_t)(e / vol);
+            const uint64_t r3 = e - (uint64_t)w * vol;
+            const uint32_t z = (uint32_t)(r3 / plane);
+            const uint32_t r2 = (uint32_t)(r3 - (uint64_t)z * plane);
+            const uint32_t y = r2 / mp.d0, x = r2 - y * mp.d0;
+            const uint64_t task = (((uint64_t)w * mp.ntz + z / MARCH_TZ) * mp.nty + y / mp.ty) * mp.ntx + x / MARCH_TX;
+            sb = mp.seg_bits[seg];
+            sbase = task * slot_words + mp.seg_start[seg];
+        }
+        const uint32_t before = wave_sum(bp);
+        uint32_t b[4];
+        uint64_t base[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            b[k] = (uint32_t)__builtin_amdgcn_readlane((int)sb, k);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sbase, k);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sbase >> 32), k);
+            base[k] = ((uint64_t)hi << 32) | lo;
+        }
+        const uint32_t B1 = b[0], B2 = B1 + b[1], B3 = B2 + b[2];
+        uint32_t *out = out_base + goff + before;
+        for (uint32_t j = (uint32_t)lane; j < nwords; j += WAVE) {
+            const uint32_t bit = j << 5;
+            const uint32_t k = (bit >= B1) + (bit >= B2) + (bit >= B3);
+            const uint32_t Bk = k == 0 ? 0u : (k == 1 ? B1 : (k == 2 ? B2 : B3));
+            const uint32_t bk = k == 0 ? b[0] : (k == 1 ? b[1] : (k == 2 ? b[2] : b[3]));
+            const uint64_t sk = k == 0 ? base[0] : (k == 1 ? base[1] : (k == 2 ? base[2] : base[3]));
+            const uint64_t sn = k == 0 ? base[1] : (k == 1 ? base[2] : base[3]);  // the next segment's string (k = 3: none)
+            const uint32_t o = bit - Bk, sh = o & 31u;
+            const uint32_t *src = mp.slots + sk + (o >> 5);
+            const uint32_t w0 = src[0], w1 = src[1];  // (the scratch has a word of slack behind its last slot)
+            uint32_t v = sh ? (w0 << sh) | (w1 >> (32u - sh)) : w0;
+            const uint32_t bn = k == 0 ? b[1] : (k == 1 ? b[2] : (k == 2 ? b[3] : 0u));  // (0: the array ends with segment k)
+            const uint32_t rem = bk - o;  // bits of segment k from here on (>= 1)
+            if (rem < 32u) {
+                v &= ~0u << (32u - rem);
+                if (bn) v |= mp.slots[sn] >> rem;
+            }
+            out[j] = __builtin_bswap32(v);  // bytes in stream order (see sz3hip_format.h)
+        }
+    }
+    if (nblk > pack_blocks && !ap.lists_by_roles) assemble_lists(ap, (uint64_t)bid * 256 + threadIdx.x, (uint64_t)nblk * 256);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // K8: decode side
 // ------------------------------------------------------------------------------------------------------------
 // canonical decode tables from the code lengths: first code / first rank per length, the symbols sorted by
@@ -4221,9 +4451,26 @@ static void launch_march_w(const void *d_in, uint16_t *codes, szk_k1_params &p, 
         // THIS call's probe and handles either). After a two-byte call the two specialisations below are launched as on a first
         // call: the run-time-width form is a third slower on two-byte codes (574 vs 363 us at C4's slab) than the specialised one
         // plus the 4 us of its returning twin.
-        grid = k1_grid((const void *)k_lorenzo_quant_march3<T, NDIM, TY>, (nb + 3) / 4);
         p.seg_expected = p.spec_lens && p.d[3] % MARCH_TX == 0;
-        hipLaunchKernelGGL((k_lorenzo_quant_march3<T, NDIM, TY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
+        // the fused form: NDIM 3 bodies (1-D ... 3-D arrays), rows cut into whole segments, and a scratch that holds a slot per task
+        const uint32_t slot_words = fuse_slot_words(TY, p.d[2], p.d[1]);
+        const bool fuse = NDIM == 3 && p.fuse && p.seg_expected && p.fuse_enc && p.fuse_info && p.fuse_slots && p.seg_start && p.fuse_flag &&
+                          nb * (uint64_t)slot_words + 2 <= p.fuse_cap_words && !(szk_dbg_flags & 2048);
+        p.fused = fuse ? 1 : 0;
+        if (fuse) {
+            if constexpr (NDIM == 3) {
+                grid = k1_grid((const void *)k_lorenzo_quant_march3f<T, 3, TY>, (nb + 3) / 4);
+                p.fuse_geom[0] = (uint32_t)((p.d[3] + MARCH_TX - 1) / MARCH_TX);
+                p.fuse_geom[1] = (uint32_t)((p.d[2] + TY - 1) / TY);
+                p.fuse_geom[2] = (uint32_t)((p.d[1] + MARCH_TZ - 1) / MARCH_TZ);
+                p.fuse_geom[3] = slot_words;
+                p.fuse_ty = TY;
+                hipLaunchKernelGGL((k_lorenzo_quant_march3f<T, 3, TY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
+            }
+        } else {
+            grid = k1_grid((const void *)k_lorenzo_quant_march3<T, NDIM, TY>, (nb + 3) / 4);
+            hipLaunchKernelGGL((k_lorenzo_quant_march3<T, NDIM, TY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
+        }
     } else if (p.mode.allow && !(szk_dbg_flags & 256)) {
         // (first call of a context) each specialisation gets the grid its own occupancy allows (all workgroups resident: the tasks are dealt by stride;
         // the two-byte kernel holds 38-72 KB of LDS); the fold reads the larger number of rows, the two-byte kernel leaves
@@ -4356,6 +4603,12 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
     SZK_CHECK_LAUNCH();
     return 0;
 }
+uint64_t szk_fuse_scratch_words(int ndim, const uint64_t d[4]) {  // (the tasks of launch_k1's marching forms: 256 x TY x MARCH_TZ, TY = 1 for 1-D arrays)
+    if (ndim < 1 || ndim > 3 || d[3] % MARCH_TX != 0 || d[3] >= (1ull << 31) || d[2] >= (1ull << 31) || d[1] >= (1ull << 31)) return 0;
+    const uint32_t ty = ndim == 1 ? 1u : (uint32_t)LAB_MTY;
+    const uint64_t nb = (d[3] / MARCH_TX) * ((d[2] + ty - 1) / ty) * ((d[1] + MARCH_TZ - 1) / MARCH_TZ) * d[0];
+    return nb * fuse_slot_words(ty, d[2], d[1]) + 2;
+}
 int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, szk_k1_params *p, hipStream_t s) {
     szk_k1_params &pp = *p;  // mode.allow is cleared when the chosen kernel has no one-byte store path
     pp.dbg = (uint32_t)szk_dbg_flags;
@@ -4417,7 +4670,7 @@ int szk_launch_hist_fold(const uint32_t *partial, uint32_t nrows, int radius, ui
 int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, const szk_cb_info *info, int radius,
                       szk_mode mode, uint16_t *chunk_words, uint64_t *group_off, uint64_t *total_words,
                       const szk_state *state, uint8_t *payload, const szk_layout_params *layout, const szk_asm_params *asmp, hipStream_t s,
-                      const uint16_t *seg_bits, const uint32_t *seg_made, const szk_encode_roles *er) {
+                      const uint16_t *seg_bits, const uint32_t *seg_made, const szk_encode_roles *er, const szk_merge_args *mg) {
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
     const uint64_t nb = (n_chunks + 3) / 4;
     if (nb > 0x7FFFFFFFull) return -1;
@@ -4463,7 +4716,23 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
     // must be resident together (5 per compute unit at 30 KB of LDS each), or the late ones double the launch's duration
     const uint32_t extra = rb + (asmp ? 32u : 0u);
     constexpr uint32_t ASM_BLOCKS = 32;
-    if (mode.pack_wide) {
+    if (mg) {  // stage 1 was the fused form: the rows' bit strings only have to be moved to their places
+        szk_merge_params mp;
+        mp.slots = mg->slots;
+        mp.seg_bits = seg_bits;
+        mp.seg_start = mg->seg_start;
+        mp.d0 = mg->d[0];
+        mp.d1 = mg->d[1];
+        mp.d2 = mg->d[2];
+        mp.ntx = mg->geom[0];
+        mp.nty = mg->geom[1];
+        mp.ntz = mg->geom[2];
+        mp.slot_words = mg->geom[3];
+        mp.ty = mg->ty;
+        mp.fuse_flag = mg->fuse_flag;
+        const uint32_t pb = pgrid < 2048 - extra ? pgrid : 2048 - extra;
+        hipLaunchKernelGGL(k_merge, dim3(rb + pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, mp, n, chunk_words, group_off, mode, state, payload, apv, pb, rp);
+    } else if (mode.pack_wide) {
         const uint32_t pb = pgrid < 768 - extra ? pgrid : 768 - extra;
         hipLaunchKernelGGL((k_pack<2 * ENC_WIN>), dim3(rb + pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
                            sym_add, state, payload, apv, pb, rp);

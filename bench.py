@@ -171,6 +171,31 @@ class Workload:
         self.step()
         return out
 
+    def fused_stage1(self, steps, barrier):
+        """round 4's single-pass form (opt-in, sz3hip_ctx_set_fused): the previous call's book codes inside the predictor kernel, the
+        encoder only moves the rows' bit strings (k_lorenzo_quant_march3f + k_merge): half the encoder's traffic, same bytes out"""
+        torch = self.torch
+        self.dc.set_fused(True)
+        try:
+            for _ in range(3):
+                self.step()
+            barrier()
+            h0, m0 = self.dc.spec_stats()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / steps
+            h1, m1 = self.dc.spec_stats()
+            took = bool(self.dc.fused)
+        finally:
+            self.dc.set_fused(False)
+        self.step()
+        self.step()
+        return {"ms_per_step": round(ms, 4), "gbps": round(self.n * self.esz / (ms * 1e-3) / 1e9, 2), "taken": took,
+                "codebook_speculation": {"hits": h1 - h0, "misses": m1 - m0},
+                "note": "alternating realisations; informational — the default (and `value`) is the two-pass form, which is faster on this chip"}
+
     def identical_input(self, steps, barrier):
         """the same array every call (rounds 1-3's timed loop): every shortcut a context has is confirmed"""
         torch = self.torch
@@ -578,6 +603,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cold:
         out["identical_input"] = w.identical_input(args.steps, barrier)
+        if args.algo == "lorenzo":
+            out["fused_stage1"] = w.fused_stage1(args.steps, barrier)
         out["cold"] = w.cold_numbers(max(5, args.steps // 2), barrier)
         # What `value` also leaves out, in the other direction: a producer with a SERIES of arrays keeps two contexts in flight on two
         # streams — stage 1 of one call (bound by memory) runs beside stage 2 of the other (bound by instruction issue). Not `value`:

@@ -221,6 +221,10 @@ void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *miss
  * encoder only moves the rows' bit strings to their places; the verdict on the book is as for the unfused form, a miss repeats
  * the whole call in the two-pass form: the input must stay valid until sz3hip_compress_finish returns) */
 int sz3hip_last_call_fused(const sz3hip_ctx *ctx);
+/* opt in to (1) / out of (0, the default) that form for this context; SZ3HIP_FUSED=1 in the environment makes 1 the default of every
+ * context created afterwards. It halves the encoder's HBM traffic (no code array) and is byte-identical to the two-pass form, but on
+ * MI355X it measured slower ("Round 4: the single-pass encoder"): the default stays the two-pass form. */
+void sz3hip_ctx_set_fused(sz3hip_ctx *ctx, int on);
 /* test hooks: copy internal device arrays to host (quantisation codes as uint16, histogram as uint64) */
 int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, uint64_t n);
 /* test hook: which chain the last sz3hip_decompress_device took: out4[0] half-width intermediates, [1] rows that cross chunk

@@ -148,6 +148,8 @@ def lib():
     L.sz3hip_ctx_set_deterministic.restype = None
     L.sz3hip_last_call_fused.argtypes = [C.c_void_p]
     L.sz3hip_last_call_fused.restype = C.c_int
+    L.sz3hip_ctx_set_fused.argtypes = [C.c_void_p, C.c_int]
+    L.sz3hip_ctx_set_fused.restype = None
     L.sz3hip_get_spec_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.sz3hip_get_spec_stats.restype = None
     L.sz3hip_payload_bound_conf.restype = C.c_size_t
@@ -400,6 +402,10 @@ class DeviceCompressor:
         """on: the previous call's code book stands only when it IS this call's book — the payload is a pure function of the input
         (off, the device API's default: also when it is complete over this call's alphabet and within 1/1024 of its own book's size)"""
         lib().sz3hip_ctx_set_deterministic(self._h, int(on))
+
+    def set_fused(self, on=True):
+        """opt in to the fused stage 1 (the previous call's book codes inside the predictor kernel; off by default)"""
+        lib().sz3hip_ctx_set_fused(self._h, int(on))
 
     @property
     def fused(self):

@@ -214,7 +214,7 @@ static void ctx_free(sz3hip_ctx *c) {
                     c->d_chunk_words, c->d_chunk_off, c->d_carry, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples, c->d_trial_work, c->d_trial_codes,
                     c->d_trial, c->d_passes, c->d_np,  // (d_trial_counters / d_trial_hist live inside d_trial's block)
                     c->d_blk_sel, c->d_blk_coef, c->d_blk_rank, c->d_blk_comp, c->d_blk_side, c->d_blk_counters,
-                    c->bk[1].enc, c->bk[1].lens, c->bk[1].info, c->d_seg_bits, c->d_seg_start, c->d_half32, c->d_sub_bits, c->d_fuse_scratch};
+                    c->bk[1].enc, c->bk[1].lens, c->bk[1].info, c->d_seg_bits, c->d_seg_base, c->d_half32, c->d_sub_bits, c->d_fuse_scratch};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->book_stream) {
@@ -296,8 +296,12 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     alloc((void **)&c->d_pint2, SZK_MAX_BOOKS * SZH_HIST_BINS * 2);
     alloc((void **)&c->d_range, SZK_MAX_BOOKS * 16);
     alloc((void **)&c->d_info, SZK_MAX_BOOKS * sizeof(szk_cb_info));
+    {   // (the fused stage 1 is opt-in: measured slower than the two-pass form on this chip; SZ3HIP_FUSED=1 turns it on for every context)
+        const char *fe = getenv("SZ3HIP_FUSED");
+        c->fuse_on = fe && fe[0] == '1';
+    }
     alloc((void **)&c->d_seg_bits, (max_elems / 256 + 8) * 2);
-    alloc((void **)&c->d_seg_start, (max_elems / 256 + 8) * 2);
+    alloc((void **)&c->d_seg_base, (max_elems / 256 + 8) * 4);
     alloc((void **)&c->bk[1].enc, SZH_HIST_BINS * 4);
     alloc((void **)&c->bk[1].lens, SZH_HIST_BINS);
     alloc((void **)&c->bk[1].info, sizeof(szk_cb_info));
@@ -578,7 +582,7 @@ static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *
         // miss then costs the whole call once more: a context that wants its payloads bit-identical to a fresh context's
         // (deterministic mode) asks for it only behind a call whose book was confirmed.
         const uint64_t need = szk_fuse_scratch_words(N, p.d);
-        if (need && !ctx->hist_reduced && (!ctx->spec_exact || ctx->last_spec_hit)) {
+        if (need && ctx->fuse_on && !ctx->hist_reduced && (!ctx->spec_exact || ctx->last_spec_hit)) {
             p.fuse_slots = reinterpret_cast<uint32_t *>(ctx->d_codes);
             p.fuse_cap_words = (ctx->max_n + 64) / 2;  // (the array holds (max_n + 64) two-byte codes)
             if (need > p.fuse_cap_words && need <= 2 * num + (1u << 18)) {
@@ -599,7 +603,7 @@ static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *
             p.fuse = 1;
             p.fuse_enc = ctx->bk[ctx->book_idx].enc;
             p.fuse_info = ctx->bk[ctx->book_idx].info;
-            p.seg_start = ctx->d_seg_start;
+            p.seg_base = ctx->d_seg_base;
             p.fuse_flag = reinterpret_cast<uint32_t *>(ctx->d_counters + 11);  // zeroed with the counters
         }
     }
@@ -624,8 +628,6 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
     ctx->fold_range = p.range;
     ctx->s1_fused = p.fused != 0;
     ctx->s1_slots = p.fuse_slots;
-    for (int i = 0; i < 4; i++) ctx->fuse_geom[i] = p.fuse_geom[i];
-    ctx->fuse_ty = p.fuse_ty;
     prof_end(ctx, ST_K1, s);
     if (rc) return fail(SZ3HIP_EHIP, "lorenzo_quant kernel launch failed (%d)", rc);
     szh_header &h = ctx->proto;
@@ -1380,12 +1382,7 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     if (ctx->s1_fused && !merge) return fail(SZ3HIP_EHIP, "internal: fused stage 1 without the merging encoder");
     if (merge) {
         mg.slots = ctx->s1_slots;
-        mg.ty = ctx->fuse_ty;
-        mg.seg_start = ctx->d_seg_start;
-        mg.d[0] = (uint32_t)ctx->proto.dims[3];
-        mg.d[1] = (uint32_t)ctx->proto.dims[2];
-        mg.d[2] = (uint32_t)ctx->proto.dims[1];
-        for (int i = 0; i < 4; i++) mg.geom[i] = ctx->fuse_geom[i];
+        mg.seg_base = ctx->d_seg_base;
         mg.fuse_flag = reinterpret_cast<const uint32_t *>(ctx->d_counters + 11);
     }
     prof_begin(ctx, ST_ENCODE, s);  // (the payload layout is computed inside the encoder's scan launch, the sections are assembled by the packer's)
@@ -1613,6 +1610,7 @@ extern "C" void sz3hip_ctx_set_speculation(sz3hip_ctx *ctx, int off) { ctx->spec
 // it within 1/1024 of this call's own book's size — the payload then depends on the context's history, its size by < 0.1 %
 extern "C" void sz3hip_ctx_set_deterministic(sz3hip_ctx *ctx, int on) { ctx->spec_exact = on ? 1 : 0; }
 extern "C" int sz3hip_last_call_fused(const sz3hip_ctx *ctx) { return ctx->last_fused ? 1 : 0; }
+extern "C" void sz3hip_ctx_set_fused(sz3hip_ctx *ctx, int on) { ctx->fuse_on = on != 0; }
 extern "C" void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses) {
     *hits = ctx->spec_hits;
     *misses = ctx->spec_misses;

@@ -89,13 +89,13 @@ struct sz3hip_ctx {
     uint32_t fold_rows;    // != 0: the fold of stage 1's histogram rows was left to stage 2 (it rides in the scan's launch)
     uint32_t *fold_range;
     uint16_t *d_seg_bits;  // [max_n / 256 + 8]
-    uint16_t *d_seg_start; // [max_n / 256 + 8] fused stage 1: word offset of a segment's bit string inside its task's slot
+    uint32_t *d_seg_base;  // [max_n / 256 + 8] fused stage 1: index of the first word of a segment's bit string in the scratch
     uint32_t *d_fuse_scratch;  // the fused stage 1's slots when the code array's memory does not hold them (ragged extents), grown on demand
     uint64_t fuse_scratch_words;
     const uint32_t *s1_slots;  // the scratch this call's fused stage 1 wrote
+    bool fuse_on;          // the context asks for the fused stage 1 where it applies (sz3hip_ctx_set_fused; default off)
     bool s1_fused;         // this call's stage 1 was the fused form (k_lorenzo_quant_march3f): no code array, the encoder merges
     bool last_fused;       // ... the last finished call's
-    uint32_t fuse_geom[4], fuse_ty;
     bool last_spec_hit;    // the last finished call confirmed its speculation
     int blk_wide;           // block predictor: wide LDS histogram window (from the previous call's alphabet)
     uint64_t blk_cap;       // blocks the arrays below hold

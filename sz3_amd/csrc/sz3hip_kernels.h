@@ -77,10 +77,9 @@ struct szk_k1_params {
     const szk_cb_info *fuse_info;   // ... its descriptor (max_len is read on the device)
     uint32_t *fuse_slots;           // the scratch: one slot of TY * MARCH_TZ * 128 words per task (the code array's memory)
     uint64_t fuse_cap_words;        // words the scratch holds
-    uint16_t *seg_start;            // [n / 256] word offset of a segment's bit string inside its task's slot
+    uint32_t *seg_base;             // [n / 256] index of the first word of a segment's bit string in the scratch
     uint32_t *fuse_flag;            // device word, raised when a symbol had no code word in that book
-    uint32_t fuse_geom[4];          // out: tasks per dimension ntx, nty, ntz and the words of a task's slot (the merge finds a segment's string with them)
-    uint32_t fuse_ty;               // out: rows per task
+    uint32_t fuse_geom[4];          // out: [3] = words of a task's slot
     // (the launcher's query, szk_fuse_scratch_words: words the scratch of a fused launch over this shape needs)
 };
 
@@ -156,11 +155,8 @@ struct szk_asm_params {
 // speculative stage 2, small alphabets: work that rides in the encoder's two launches instead of a side stream
 struct szk_merge_args {         // what the merge launch needs of a fused stage 1 (k_lorenzo_quant_march3f)
     const uint32_t *slots;      // the scratch its tasks wrote their rows' bit strings to
-    const uint16_t *seg_start;  // [n / 256] word offset of a segment's string inside its task's slot
-    uint32_t d[3];              // extents x, y, z of the kernel's view
-    uint32_t geom[4];           // szk_k1_params::fuse_geom
-    uint32_t ty;                // szk_k1_params::fuse_ty
-    const uint32_t *fuse_flag;  // raised by stage 1: a symbol without a code word in the book it used
+    const uint32_t *seg_base;   // [n / 256] index of the first word of a segment's string in the scratch
+    const uint32_t *fuse_flag;  // raised by stage 1: a book it could not code with
 };
 struct szk_encode_roles {
     int roles;                  // the packer's launch carries the book role (this call's code book + the verdict) and the two sort roles

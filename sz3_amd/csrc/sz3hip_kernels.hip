@@ -962,17 +962,19 @@ template <typename T> struct NarrowCtx {
     // fused form (round 4): the rows' bit strings, coded with the context's previous book, leave stage 1 instead of the codes
     const uint32_t *s_enc;  // [256] (code word << 5) | length by stored byte t (LDS)
     uint32_t *stage;        // this wave's LDS stage: TY rows x FUSE_ROW_WORDS, zero between planes
-    uint32_t *slot;         // the task's slot of the scratch (the code array's memory): FUSE_SLOT_WORDS(TY) words
-    uint32_t slot_w;        // words of the slot in use (wave-uniform)
-    uint16_t *seg_start;    // [n / 256] out: word offset of every segment's bit string inside its task's slot
-    uint32_t minl;          // shortest code length met (0: a symbol the book has no code word for)
+    uint32_t *slot;         // the task's slot of the scratch (the code array's memory)
+    uint32_t slot_base;     // ... its first word's index in the scratch
+    uint32_t slot_w;        // words of the slot written (wave-uniform, a multiple of 32: whole 128-byte lines)
+    uint32_t st_cnt;        // words waiting at the stage's front for the line they belong to to fill up (< 32, wave-uniform)
+    uint32_t *seg_base;     // [n / 256] out: index of the first word of every segment's bit string in the scratch
 };
-// a 256-element row segment is at most 256 x 16 bits = 128 words (small books: code words <= 16 bits) + 2 words of slack for the
-// unconditional three-word emission; a task's slot holds its TY x MARCH_TZ segments at their worst
-#define FUSE_ROW_WORDS 130
+// a 256-element row segment is at most 256 x 16 bits = 128 words (small books: code words <= 16 bits); the stage of a wave holds a
+// plane's TY rows one behind the other (+ slack for the unconditional emission and the two-word sweep); a task's slot holds its
+// segments at their worst, a plane's rows padded to an even number of words
+#define FUSE_STAGE_WORDS(TY) ((TY) * 128 + 32 + 8)  // a plane's rows + the words carried over + slack, a multiple of 4
 // (rows and planes a task can have: min(TY, d1) x min(MARCH_TZ, d2) — a 2-D array's tasks are one plane deep)
 static inline uint32_t fuse_slot_words(uint32_t ty, uint64_t d1, uint64_t d2) {
-    return (uint32_t)((d1 < ty ? d1 : ty) * (d2 < MARCH_TZ ? d2 : MARCH_TZ) * 128u);
+    return (uint32_t)((d1 < ty ? d1 : ty) * 128u * (d2 < MARCH_TZ ? d2 : MARCH_TZ) + 32u);  // (whole lines; the last one may be padded)
 }
 template <typename T>
 __device__ __forceinline__ void narrow_oq_flush(NarrowCtx<T> &c) {
@@ -1038,6 +1040,52 @@ template <typename T, int NW, int TY> struct NarrowPlane {
     T rl[NW][TY + 1];      // the element left of the brick (one address for the wave; only lane 0's copy is used)
     bool rok[NW][TY + 1];  // the row exists (wave-uniform)
 };
+// the first nw words of the wave's stage (nw even) to the task's slot at slot_w, two per lane, the stage zeroed behind them. Two
+// predicated rounds (256 words, twice a smooth field's plane) so that the number of stores in flight is a constant; more only
+// behind a wave-uniform test.
+template <typename T>
+__device__ __forceinline__ void fuse_sweep(NarrowCtx<T> &c, uint32_t nw) {
+    uint32_t *out = c.slot + c.slot_w;
+    auto sweep = [&](uint32_t i) {
+        const uint2 wv = *reinterpret_cast<const uint2 *>(&c.stage[i]);
+        *reinterpret_cast<uint2 *>(&c.stage[i]) = make_uint2(0u, 0u);
+#if defined(LAB_FUSE) && (LAB_FUSE & 32)  // (lab: plain stores)
+        *reinterpret_cast<unsigned long long *>(&out[i]) = (unsigned long long)wv.x | ((unsigned long long)wv.y << 32);
+#else
+        __builtin_nontemporal_store((unsigned long long)wv.x | ((unsigned long long)wv.y << 32), reinterpret_cast<unsigned long long *>(&out[i]));
+#endif
+    };
+    const uint32_t i0 = 2u * (uint32_t)c.lane;
+    if (i0 < nw) sweep(i0);
+    if (i0 + 2u * WAVE < nw) sweep(i0 + 2u * WAVE);
+    if (nw > 4u * WAVE)
+        for (uint32_t i = i0 + 4u * WAVE; i < nw; i += 2u * WAVE) sweep(i);
+}
+// Only WHOLE 128-byte lines leave the stage (the slot is line-aligned, slot_w a multiple of 32 words): a plane's ~130 words written
+// where the previous plane's ended cut two lines each, and partial-line streaming stores cost the kernel 17 of its 199 us. The words
+// behind the last whole line move to the stage's front and wait for the next plane's.
+template <typename T>
+__device__ __forceinline__ void fuse_flush_lines(NarrowCtx<T> &c) {
+#if defined(LAB_FUSE) && (LAB_FUSE & 4)  // (lab: no copy-out)
+    const uint32_t nfl = 0;
+    c.st_cnt &= 31u;
+#else
+    const uint32_t nfl = c.st_cnt & ~31u;
+#endif
+    if (nfl == 0) return;
+    fuse_sweep(c, nfl);
+    const uint32_t left = c.st_cnt - nfl;
+    if (left) {  // (left < 32 <= nfl: source and destination do not overlap; the sweep zeroed the destination)
+        if (2u * (uint32_t)c.lane < left) {
+            const uint2 wv = *reinterpret_cast<const uint2 *>(&c.stage[nfl + 2u * c.lane]);
+            *reinterpret_cast<uint2 *>(&c.stage[nfl + 2u * c.lane]) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2 *>(&c.stage[2u * c.lane]) = wv;
+        }
+    }
+    c.st_cnt = left;
+    c.slot_w += nfl;
+    __builtin_amdgcn_wave_barrier();
+}
 #ifndef NARROW_PF
 #define NARROW_PF 0  // 1: the next plane's rows are requested before the current plane is worked (two sets of row registers; measured slower: 161 vs 149 us)
 #endif
@@ -1085,8 +1133,18 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
             }
         }
     };
-    auto work = [&](int zz, const NarrowPlane<T, NW, TY> &R) {
+    // (fetch_next, fused form: the next plane is requested between this plane's rows and its emission — into R's own registers, free by then)
+    NarrowPlane<T, NW, TY> pa;
+    auto work = [&](int zz, NarrowPlane<T, NW, TY> &R, bool fetch_next = false) {
         const uint32_t gz = z0 + (uint32_t)zz;
+        if constexpr (FUSE) {
+            // The previous plane's words leave the stage HERE: behind the wait for this plane's rows (all of them: loads and stores share
+            // one in-order counter, and the waits the compiler places for rows requested behind a run-time number of stores are waits
+            // for everything — the stores' acknowledgements included, which cost this kernel 25 us when the sweep sat at the plane's
+            // end, right in front of that wait) and a plane's worth of arithmetic ahead of the next one.
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            fuse_flush_lines(c);
+        }
 #if defined(LAB_MODE) && LAB_MODE == 1  // (lab: the kernel's loads and stores alone — what its access pattern gets from the memory system)
         if (zz >= 0) {
 #pragma unroll
@@ -1109,11 +1167,11 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
         uint32_t bits_rows[(TY + 1) / 2];  // code bits of the plane's rows, two rows per register (16 bits each)
 #pragma unroll
         for (int k = 0; k < (TY + 1) / 2; k++) bits_rows[k] = 0;
-        uint64_t fq[TY];   // FUSE: the lane's four code words of every row, joined ...
-        uint32_t fl[TY];   // ... and their length (0: the row is not coded)
+        uint32_t fp01[TY], fp23[TY];  // FUSE: the lane's four code words of every row, joined in pairs ...
+        uint32_t fl[TY];              // ... their total length (0: the row is not coded) | length of the second pair << 8
 #pragma unroll
         for (int k = 0; k < TY; k++) {
-            fq[k] = 0;
+            fp01[k] = fp23[k] = 0;
             fl[k] = 0;
         }
 #pragma unroll
@@ -1175,13 +1233,18 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
                 for (int i = 0; i < 4; i++) atomicAdd(&c.lh[t[i] * 4u + copy], 1u);
                 if constexpr (FUSE) {
                     // the four code words of the lane, joined: two pairs in 32 bits (code words <= 16 bits), the pairs in 64
+#if defined(LAB_FUSE) && (LAB_FUSE & 1)  // (lab: no table lookups)
+                    const uint32_t e0 = (t[0] << 5) | 4u, e1 = (t[1] << 5) | 4u, e2 = (t[2] << 5) | 4u, e3 = (t[3] << 5) | 4u;
+#else
                     const uint32_t e0 = c.s_enc[t[0]], e1 = c.s_enc[t[1]], e2 = c.s_enc[t[2]], e3 = c.s_enc[t[3]];
+#endif
                     const uint32_t l0 = e0 & 31u, l1 = e1 & 31u, l2 = e2 & 31u, l3 = e3 & 31u;
-                    const uint32_t p01 = ((e0 >> 5) << l1) | (e1 >> 5), p23 = ((e2 >> 5) << l3) | (e3 >> 5);
+                    fp01[r - 1] = ((e0 >> 5) << l1) | (e1 >> 5);
+                    fp23[r - 1] = ((e2 >> 5) << l3) | (e3 >> 5);
                     const uint32_t l23 = l2 + l3;
-                    fq[r - 1] = ((uint64_t)p01 << l23) | p23;
-                    fl[r - 1] = l0 + l1 + l23;
-                    c.minl = min(c.minl, min(min(l0, l1), min(l2, l3)));
+                    fl[r - 1] = (l0 + l1 + l23) | (l23 << 8);
+                    // (a symbol the book has no code word for has length 0 here and codes nothing: the verdict of the merge's launch —
+                    // book_rejected walks this call's complete histogram — finds it missing from the book and voids the call)
                 } else {
 #ifdef LAB_ABLATE
                 if (!(c.p->dbg & 2u))
@@ -1210,24 +1273,65 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
             }
         }
         if constexpr (FUSE) {
+            // The next plane's rows are requested HERE, in front of this plane's stores: loads and stores return in order on one
+            // counter, and a wait for rows requested behind the sweep's stores waits for the stores' acknowledgements too (measured:
+            // 45 us of the kernel's 199). The registers the rows land in are free: the row loop above was their last reader.
+            if (fetch_next) fetch(zz + 1, R);
             if (zz >= 0) {
                 // Bit positions of the lanes' strings inside their rows: one wave scan per PAIR of rows (16 bits each: a row is at most
-                // 64 lanes x 64 bits). Every row is emitted into its own stretch of the wave's LDS stage (three ds_or per lane),
-                // then the rows leave for the task's slot one behind the other, word-aligned, with their length and place noted.
-                uint32_t row_bits[TY];
+                // 64 lanes x 64 bits). The rows follow one another word-aligned in the wave's LDS stage (every lane ORs its string in:
+                // two ds_or when no lane of the plane holds more than 32 bits — the usual case, decided for the wave — else three), and
+                // the plane's words leave for the task's slot in one sweep, two per lane; a lane per row notes length and place.
+                uint32_t excl[(TY + 1) / 2], row_bits[TY], row_base[TY + 1];
+                uint32_t lmax = 0;
 #pragma unroll
                 for (int k = 0; k < TY; k += 2) {
-                    const uint32_t packed = fl[k] | (k + 1 < TY ? fl[k + 1] << 16 : 0u);
+                    const uint32_t la = fl[k] & 0xFFu, lb = k + 1 < TY ? fl[k + 1] & 0xFFu : 0u;
+                    const uint32_t packed = la | (lb << 16);
+                    lmax = max(lmax, max(la, lb));
+#if defined(LAB_FUSE) && (LAB_FUSE & 8)  // (lab: no scans)
+                    const uint32_t incl = packed * (uint32_t)(lane + 1);
+#else
                     const uint32_t incl = wave_incl_scan(packed);
+#endif
                     const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
-                    const uint32_t excl = incl - packed;
+                    excl[k / 2] = incl - packed;
                     row_bits[k] = tot & 0xFFFFu;
                     if (k + 1 < TY) row_bits[k + 1] = tot >> 16;
+                }
+                // (the stage's first st_cnt words are the previous planes' words that did not fill a 128-byte line yet)
+                row_base[0] = c.st_cnt;
 #pragma unroll
-                    for (int h = 0; h < 2 && k + h < TY; h++) {
-                        const uint32_t len = fl[k + h], pos = h ? excl >> 16 : excl & 0xFFFFu;
-                        const uint64_t v = len ? fq[k + h] << (64u - len) : 0ull;  // left-aligned
-                        uint32_t *st = c.stage + (k + h) * FUSE_ROW_WORDS + (pos >> 5);
+                for (int k = 0; k < TY; k++) row_base[k + 1] = row_base[k] + ((row_bits[k] + 31u) >> 5);
+#if defined(LAB_FUSE) && (LAB_FUSE & 2)  // (lab: no emission)
+                if (lmax > 200u) {
+#else
+                if (!__builtin_amdgcn_ballot_w64(lmax > 32u)) {
+#endif
+#pragma unroll
+                    for (int k = 0; k < TY; k++) {
+                        const uint32_t len = fl[k] & 0xFFu, l23 = fl[k] >> 8;
+                        const uint32_t pos = (k & 1) ? excl[k / 2] >> 16 : excl[k / 2] & 0xFFFFu;
+                        const uint32_t q = (fp01[k] << l23) | fp23[k];
+                        const uint32_t v = q << ((32u - len) & 31u);  // left-aligned (len 0: q is 0)
+                        uint32_t *st = c.stage + row_base[k] + (pos >> 5);
+                        const uint32_t sh = pos & 31u;
+                        atomicOr(&st[0], v >> sh);
+                        atomicOr(&st[1], (uint32_t)(((uint64_t)v << 32) >> sh));
+                    }
+                }
+#if defined(LAB_FUSE) && (LAB_FUSE & 2)
+                else if (lmax > 300u) {
+#else
+                else {
+#endif
+#pragma unroll
+                    for (int k = 0; k < TY; k++) {
+                        const uint32_t len = fl[k] & 0xFFu, l23 = fl[k] >> 8;
+                        const uint32_t pos = (k & 1) ? excl[k / 2] >> 16 : excl[k / 2] & 0xFFFFu;
+                        const uint64_t q = ((uint64_t)fp01[k] << l23) | fp23[k];
+                        const uint64_t v = len ? q << (64u - len) : 0ull;
+                        uint32_t *st = c.stage + row_base[k] + (pos >> 5);
                         const uint32_t sh = pos & 31u;
                         const uint64_t tv = v >> sh;
                         atomicOr(&st[0], (uint32_t)(tv >> 32));
@@ -1237,24 +1341,23 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
+                if (lane < TY) {  // lane k notes row k (the rows' values are wave-uniform: picked by selects)
+                    uint32_t rbits = row_bits[0], rbase = row_base[0];
+                    bool rok = R.rok[0][1];
 #pragma unroll
-                for (int k = 0; k < TY; k++) {
-                    if (!R.rok[0][k + 1]) continue;  // (wave-uniform: the row lies beyond the array)
-                    const uint32_t nw = (row_bits[k] + 31u) >> 5;
-                    const uint64_t seg = ((uint64_t)w * c.vol + (uint64_t)gz * c.plane + (uint64_t)(y0 + k) * d0 + x0) >> 8;
-                    uint32_t *st = c.stage + k * FUSE_ROW_WORDS;
-                    uint32_t *out = c.slot + c.slot_w;
-                    for (uint32_t i = (uint32_t)lane; i < nw; i += WAVE) {
-                        const uint32_t wv = st[i];
-                        st[i] = 0u;
-                        __builtin_nontemporal_store(wv, &out[i]);
+                    for (int k = 1; k < TY; k++) {
+                        rbits = lane == k ? row_bits[k] : rbits;
+                        rbase = lane == k ? row_base[k] : rbase;
+                        rok = lane == k ? R.rok[0][k + 1] : rok;
                     }
-                    if (lane == 0) {
-                        c.seg_bits[seg] = (uint16_t)row_bits[k];
-                        c.seg_start[seg] = (uint16_t)c.slot_w;
+                    if (rok) {
+                        const uint64_t seg = ((uint64_t)w * c.vol + (uint64_t)gz * c.plane + (uint64_t)(y0 + (uint32_t)lane) * d0 + x0) >> 8;
+                        c.seg_bits[seg] = (uint16_t)rbits;
+                        c.seg_base[seg] = c.slot_base + c.slot_w + rbase;
                     }
-                    c.slot_w += nw;
                 }
+                // (the plane's words stay in the stage until the NEXT plane's rows have arrived: fuse_flush_lines, at the top of work)
+                c.st_cnt = row_base[TY];
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -1273,7 +1376,6 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
     };
     int zz = z0 > 0 ? -1 : 0;
     const int zend = d2 - z0 < (uint32_t)MARCH_TZ ? (int)(d2 - z0) : MARCH_TZ;
-    NarrowPlane<T, NW, TY> pa;
     if (NARROW_PF) {
         NarrowPlane<T, NW, TY> pb;
         fetch(zz, pa);
@@ -1285,6 +1387,9 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
             work(zz, pb);
             if (++zz >= zend) break;
         }
+    } else if (FUSE) {
+        fetch(zz, pa);
+        for (; zz < zend; zz++) work(zz, pa, zz + 1 < zend);
     } else {
         for (; zz < zend; zz++) {
             fetch(zz, pa);
@@ -1321,20 +1426,21 @@ __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t 
     c.s_enc = s_fenc;
     c.stage = nullptr;
     c.slot = nullptr;
-    c.slot_w = 0;
-    c.seg_start = p.seg_start;
-    c.minl = 31u;
+    c.slot_w = c.slot_base = c.st_cnt = 0;
+    c.seg_base = p.seg_base;
     for (int i = threadIdx.x; i < NARROW_BINS * 4; i += 256) lh[i] = 0;
     if constexpr (FUSE) {
         // the previous call's book by stored byte (255 = a listed delta: symbol 0). A book this form cannot use (code words beyond 16
-        // bits, or none at all: a single-symbol alphabet) becomes a table of zero lengths: nothing is emitted and the flag below is raised
+        // bits) becomes a table of zero lengths and raises the flag; a single-symbol book has zero-length code words: nothing is emitted,
+        // which is that book's bit stream
         const uint32_t ml = p.fuse_info->max_len, blo = p.fuse_info->sym_min, bcnt = p.fuse_info->sym_count;
         const uint32_t b = threadIdx.x;
         const uint32_t sym = b == 255u ? 0u : b + p.radius - 127u;
         // (outside the book's range the table may hold an older book's entries: the slot is zeroed over the new range only)
-        s_fenc[b] = (ml >= 1u && ml <= 16u && sym >= blo && sym - blo < bcnt) ? p.fuse_enc[sym] : 0u;
-        for (int i = threadIdx.x; i < 4 * TY * FUSE_ROW_WORDS; i += 256) s_fstage[i] = 0u;
-        c.stage = s_fstage + wv * (TY * FUSE_ROW_WORDS);
+        s_fenc[b] = (ml <= 16u && sym >= blo && sym - blo < bcnt) ? p.fuse_enc[sym] : 0u;
+        if (ml > 16u && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(p.fuse_flag, 1u);  // (cannot happen: small books are limited to 16 bits)
+        for (int i = threadIdx.x; i < 4 * FUSE_STAGE_WORDS(TY); i += 256) s_fstage[i] = 0u;
+        c.stage = s_fstage + wv * FUSE_STAGE_WORDS(TY);
         if (blockIdx.x == 0 && threadIdx.x == 0) *p.seg_made = 1u;
     }
     if (acct) {
@@ -1358,16 +1464,22 @@ __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t 
         const uint32_t z0 = (b % ntz) * MARCH_TZ;
         const uint32_t w = b / ntz;
         if constexpr (FUSE) {
-            c.slot = p.fuse_slots + (uint64_t)task * p.fuse_geom[3];
+            c.slot_base = task * p.fuse_geom[3];  // (the launcher takes this form only for scratches below 2^32 words)
+            c.slot = p.fuse_slots + c.slot_base;
             c.slot_w = 0;
         }
         if (x0 + MARCH_TX <= c.d0 && y0 + TY <= c.d1) narrow_task<T, NDIM, TY, false, FUSE>(c, lat, x0, y0, z0, w);
         else narrow_task<T, NDIM, TY, true, FUSE>(c, lat, x0, y0, z0, w);
+        if constexpr (FUSE) {  // the task's last words (less than a line)
+            c.st_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.st_cnt);
+            if (c.st_cnt) {  // (the last plane's words, whole lines and the rest)
+                fuse_sweep(c, (c.st_cnt + 1u) & ~1u);
+                c.st_cnt = 0;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
     narrow_oq_flush(c);
-    if constexpr (FUSE) {  // a symbol without a code word in the book this launch coded with: its output is void (the call is repeated)
-        if (__ballot(c.minl == 0u) && c.lane == 0) atomicOr(p.fuse_flag, 1u);
-    }
     __syncthreads();
     // the workgroup's counts go to its private row of hist_partial (k_hist_reduce folds the rows): bin t = symbol t + radius - 127
     uint32_t *row = p.hist_partial + (uint64_t)blockIdx.x * HIST_WIN;
@@ -1429,7 +1541,7 @@ __global__ __launch_bounds__(256) MARCH3_ATTR void k_lorenzo_quant_march3(const 
 // no second trip over the codes: the encoder that follows only moves the strings to their places, k_merge). A lane looks its
 // four symbols of a row up in a 256-entry LDS table, joins them, the wave scans the lengths (two rows per scan), the strings are
 // OR-ed into an LDS stage and the row's words are copied to the task's slot of the scratch (the code array's memory: a task's
-// 64 segments, word-aligned, one behind the other; seg_bits / seg_start note length and place). The verdict on the book is the
+// 64 segments, word-aligned, one behind the other; seg_bits / seg_base note length and place). The verdict on the book is the
 // packer's as before (book_rejected: this call's book is built from this call's histogram beside the merge); a miss — or a
 // symbol the book has no code word for, fuse_flag — repeats the whole call in the two-pass form.
 template <typename T, int NDIM, int TY>
@@ -1442,7 +1554,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march3f(const T *__restri
     __shared__ OQV s_oq_val[4][L::OQ];
     __shared__ uint32_t s_p[3];
     __shared__ uint32_t s_fenc[256];
-    __shared__ uint32_t s_fstage[4 * TY * FUSE_ROW_WORDS];
+    __shared__ __align__(16) uint32_t s_fstage[4 * FUSE_STAGE_WORDS(TY)];
     probe_body<T, NDIM>(in, p, p.mode.n_total, p.mode.probe_big, s_p);
     march_narrow<T, NDIM, TY, true>(in, codes, p, ntasks, lh, nullptr, s_oq_idx, s_oq_val, s_fenc, s_fstage);
 }
@@ -3435,12 +3547,10 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
 struct szk_merge_params {
     const uint32_t *slots;       // the scratch stage 1 wrote
     const uint16_t *seg_bits;    // [n / 256] bits of every segment's string
-    const uint16_t *seg_start;   // [n / 256] its word offset inside its task's slot
-    uint32_t d0, d1, d2;         // extents (x fastest), d3 folded into the task index
-    uint32_t ntx, nty, ntz, ty;  // tasks per dimension, rows per task (geometry of the stage-1 launch)
-    uint32_t slot_words;         // words of a task's slot
-    const uint32_t *fuse_flag;   // raised by stage 1: a symbol without a code word
+    const uint32_t *seg_base;    // [n / 256] index of its first word in the scratch
+    const uint32_t *fuse_flag;   // raised by stage 1: a book it could not code with
 };
+#define MERGE_BLOCK 16  // chunks a wave works at a time: their 64 segments' lengths and places are one load per lane
 __global__ __launch_bounds__(256) void k_merge(szk_merge_params mp, uint64_t n, const uint16_t *__restrict__ chunk_words,
                                                const uint64_t *__restrict__ group_off, szk_mode mode, const szk_state *__restrict__ state,
                                                uint8_t *__restrict__ payload, szk_asm_params ap, uint32_t pack_blocks, szk_role_params rp) {
@@ -3448,7 +3558,11 @@ __global__ __launch_bounds__(256) void k_merge(szk_merge_params mp, uint64_t n, 
     const uint32_t roles = rp.on ? ROLE_BLOCKS : 0u;
     if (blockIdx.x < roles) {
         if (blockIdx.x == 0) {
+#if defined(LAB_MERGE) && (LAB_MERGE & 1)  // (lab: no book role)
+            if (threadIdx.x == 0) { ap.state->mispredict = 0; ap.state->n_symbols = rp.cb.range[2]; }
+#else
             if (!rp.no_book) role_book(rp, ap.state, reinterpret_cast<uint8_t *>(s_pool));
+#endif
             if (threadIdx.x == 0 && *mp.fuse_flag) atomicOr(&ap.state->miss_kind, 64u);
         } else role_sort(rp, ap, blockIdx.x == 2, reinterpret_cast<uint8_t *>(s_pool));
         return;
@@ -3462,63 +3576,73 @@ __global__ __launch_bounds__(256) void k_merge(szk_merge_params mp, uint64_t n, 
     }
     if (ap.assumed_narrow && !szk_is_narrow(mode)) return;  // the probe says two-byte codes: the call is repeated
     const uint64_t n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS, n_segs = n >> 8;  // (n is a multiple of 256; the last chunk may hold fewer than four segments)
+    const uint64_t n_blocks = (n_chunks + MERGE_BLOCK - 1) / MERGE_BLOCK;
     const uint64_t wave_gid = (uint64_t)bid * 4 + threadIdx.x / WAVE, nwaves = (uint64_t)pack_blocks * 4;
     const int lane = lane_id();
     uint32_t *out_base = reinterpret_cast<uint32_t *>(payload + state->off.bitstream);
-    const uint32_t slot_words = mp.slot_words;
-    const uint64_t plane = (uint64_t)mp.d0 * mp.d1, vol = plane * mp.d2;
-    for (uint64_t chunk = wave_gid; chunk < n_chunks; chunk += nwaves) {
-        // lanes 0..3: where segment 4 * chunk + lane lies and how long it is; lane l < cin: words of chunk l of the group
-        const uint64_t grp = chunk / PACK_GROUP;
-        const uint32_t cin = (uint32_t)(chunk % PACK_GROUP);
-        uint32_t bp = chunk_words[grp * PACK_GROUP + ((uint32_t)lane < cin ? lane : 0)];
-        bp = (uint32_t)lane < cin ? bp : 0u;
+#if defined(LAB_MERGE) && (LAB_MERGE & 2)  // (lab: the roles and the assembly alone)
+    if (n_blocks) return;
+#endif
+    for (uint64_t blk = wave_gid; blk < n_blocks; blk += nwaves) {
+        const uint64_t chunk0 = blk * MERGE_BLOCK;  // (a block is half a group of the offset scan: PACK_GROUP = 2 * MERGE_BLOCK)
+        // lane l: segment 4 * chunk0 + l (= segment l & 3 of chunk chunk0 + l / 4); lane l < 32: words of chunk l of the group
+        const uint64_t seg = chunk0 * 4 + (uint64_t)lane;
+        const bool seg_ok = seg < n_segs;
+        const uint32_t sb = seg_ok ? mp.seg_bits[seg] : 0u;
+        const uint32_t sa = seg_ok ? mp.seg_base[seg] : 0u;
+        const uint64_t grp = chunk0 / PACK_GROUP;
+        const uint64_t gc = grp * PACK_GROUP + (uint64_t)(lane & 31);
+        const uint32_t cw = (lane < 32 && gc < n_chunks) ? chunk_words[gc] : 0u;
         const uint64_t goff = group_off[grp];
-        const uint32_t nwords = chunk_words[chunk];
-        uint32_t sb = 0;
-        uint64_t sbase = 0;
-        if (lane < 4 && chunk * 4 + (uint64_t)lane < n_segs) {
-            const uint64_t seg = chunk * 4 + (uint64_t)lane;
-            const uint64_t e = seg << 8;  // the segment's first element
-            const uint32_t w = (uint32_t)(e / vol);
-            const uint64_t r3 = e - (uint64_t)w * vol;
-            const uint32_t z = (uint32_t)(r3 / plane);
-            const uint32_t r2 = (uint32_t)(r3 - (uint64_t)z * plane);
-            const uint32_t y = r2 / mp.d0, x = r2 - y * mp.d0;
-            const uint64_t task = (((uint64_t)w * mp.ntz + z / MARCH_TZ) * mp.nty + y / mp.ty) * mp.ntx + x / MARCH_TX;
-            sb = mp.seg_bits[seg];
-            sbase = task * slot_words + mp.seg_start[seg];
-        }
-        const uint32_t before = wave_sum(bp);
-        uint32_t b[4];
-        uint64_t base[4];
+        const uint32_t cw_excl = wave_incl_scan(cw) - cw;  // (lanes 0 .. 31: words of the group's chunks before chunk l)
+        const uint32_t c_in0 = (uint32_t)(chunk0 % PACK_GROUP);
+#pragma unroll 2
+        for (uint32_t ci = 0; ci < MERGE_BLOCK; ci++) {
+            if (chunk0 + ci >= n_chunks) break;
+            const uint32_t nwords = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(c_in0 + ci));
+            const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)cw_excl, (int)(c_in0 + ci));
+            uint32_t b[4], base[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            b[k] = (uint32_t)__builtin_amdgcn_readlane((int)sb, k);
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sbase, k);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sbase >> 32), k);
-            base[k] = ((uint64_t)hi << 32) | lo;
-        }
-        const uint32_t B1 = b[0], B2 = B1 + b[1], B3 = B2 + b[2];
-        uint32_t *out = out_base + goff + before;
-        for (uint32_t j = (uint32_t)lane; j < nwords; j += WAVE) {
-            const uint32_t bit = j << 5;
-            const uint32_t k = (bit >= B1) + (bit >= B2) + (bit >= B3);
-            const uint32_t Bk = k == 0 ? 0u : (k == 1 ? B1 : (k == 2 ? B2 : B3));
-            const uint32_t bk = k == 0 ? b[0] : (k == 1 ? b[1] : (k == 2 ? b[2] : b[3]));
-            const uint64_t sk = k == 0 ? base[0] : (k == 1 ? base[1] : (k == 2 ? base[2] : base[3]));
-            const uint64_t sn = k == 0 ? base[1] : (k == 1 ? base[2] : base[3]);  // the next segment's string (k = 3: none)
-            const uint32_t o = bit - Bk, sh = o & 31u;
-            const uint32_t *src = mp.slots + sk + (o >> 5);
-            const uint32_t w0 = src[0], w1 = src[1];  // (the scratch has a word of slack behind its last slot)
-            uint32_t v = sh ? (w0 << sh) | (w1 >> (32u - sh)) : w0;
-            const uint32_t bn = k == 0 ? b[1] : (k == 1 ? b[2] : (k == 2 ? b[3] : 0u));  // (0: the array ends with segment k)
-            const uint32_t rem = bk - o;  // bits of segment k from here on (>= 1)
-            if (rem < 32u) {
-                v &= ~0u << (32u - rem);
-                if (bn) v |= mp.slots[sn] >> rem;
+            for (int k = 0; k < 4; k++) {
+                b[k] = (uint32_t)__builtin_amdgcn_readlane((int)sb, (int)(4 * ci + k));
+                base[k] = (uint32_t)__builtin_amdgcn_readlane((int)sa, (int)(4 * ci + k));
             }
-            out[j] = __builtin_bswap32(v);  // bytes in stream order (see sz3hip_format.h)
+            const uint32_t B1 = b[0], B2 = B1 + b[1], B3 = B2 + b[2];
+            uint32_t *out = out_base + goff + before;
+            // three words per lane in flight (a chunk of a smooth field is ~130 words; up to 512: the loop goes on)
+            for (uint32_t j0 = (uint32_t)lane; j0 < nwords; j0 += 3 * WAVE) {
+                uint32_t w0[3], w1[3], wn[3], rem[3], shv[3];
+                bool nxt[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const uint32_t j = j0 + u * WAVE;
+                    const uint32_t bit = (j < nwords ? j : 0u) << 5;
+                    const uint32_t k = (bit >= B1) + (bit >= B2) + (bit >= B3);
+                    const uint32_t Bk = k == 0 ? 0u : (k == 1 ? B1 : (k == 2 ? B2 : B3));
+                    const uint32_t bk = k == 0 ? b[0] : (k == 1 ? b[1] : (k == 2 ? b[2] : b[3]));
+                    const uint32_t sk = k == 0 ? base[0] : (k == 1 ? base[1] : (k == 2 ? base[2] : base[3]));
+                    const uint32_t sn = k == 0 ? base[1] : (k == 1 ? base[2] : base[3]);  // the next segment's string (k = 3: none)
+                    const uint32_t bn = k == 0 ? b[1] : (k == 1 ? b[2] : (k == 2 ? b[3] : 0u));  // (0: the array ends with segment k)
+                    const uint32_t o = bit - Bk;
+                    shv[u] = o & 31u;
+                    rem[u] = bk - o;  // bits of segment k from here on (>= 1)
+                    nxt[u] = rem[u] < 32u && bn != 0u;
+                    const uint32_t *src = mp.slots + sk + (o >> 5);
+                    w0[u] = src[0];
+                    w1[u] = src[1];  // (the scratch has slack behind its last slot)
+                    wn[u] = mp.slots[nxt[u] ? sn : sk];
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const uint32_t j = j0 + u * WAVE;
+                    uint32_t v = (uint32_t)((((uint64_t)w0[u] << 32) | w1[u]) >> (32u - shv[u]));  // funnel shift left by shv
+                    if (rem[u] < 32u) {
+                        v &= ~0u << (32u - rem[u]);
+                        if (nxt[u]) v |= wn[u] >> rem[u];
+                    }
+                    if (j < nwords) out[j] = __builtin_bswap32(v);  // bytes in stream order (see sz3hip_format.h)
+                }
+            }
         }
     }
     if (nblk > pack_blocks && !ap.lists_by_roles) assemble_lists(ap, (uint64_t)bid * 256 + threadIdx.x, (uint64_t)nblk * 256);
@@ -4454,17 +4578,13 @@ static void launch_march_w(const void *d_in, uint16_t *codes, szk_k1_params &p, 
         p.seg_expected = p.spec_lens && p.d[3] % MARCH_TX == 0;
         // the fused form: NDIM 3 bodies (1-D ... 3-D arrays), rows cut into whole segments, and a scratch that holds a slot per task
         const uint32_t slot_words = fuse_slot_words(TY, p.d[2], p.d[1]);
-        const bool fuse = NDIM == 3 && p.fuse && p.seg_expected && p.fuse_enc && p.fuse_info && p.fuse_slots && p.seg_start && p.fuse_flag &&
-                          nb * (uint64_t)slot_words + 2 <= p.fuse_cap_words && !(szk_dbg_flags & 2048);
+        const bool fuse = NDIM == 3 && p.fuse && p.seg_expected && p.fuse_enc && p.fuse_info && p.fuse_slots && p.seg_base && p.fuse_flag &&
+                          nb * (uint64_t)slot_words + 2 <= p.fuse_cap_words && nb * (uint64_t)slot_words < (1ull << 32) && !(szk_dbg_flags & 2048);
         p.fused = fuse ? 1 : 0;
         if (fuse) {
             if constexpr (NDIM == 3) {
                 grid = k1_grid((const void *)k_lorenzo_quant_march3f<T, 3, TY>, (nb + 3) / 4);
-                p.fuse_geom[0] = (uint32_t)((p.d[3] + MARCH_TX - 1) / MARCH_TX);
-                p.fuse_geom[1] = (uint32_t)((p.d[2] + TY - 1) / TY);
-                p.fuse_geom[2] = (uint32_t)((p.d[1] + MARCH_TZ - 1) / MARCH_TZ);
                 p.fuse_geom[3] = slot_words;
-                p.fuse_ty = TY;
                 hipLaunchKernelGGL((k_lorenzo_quant_march3f<T, 3, TY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
             }
         } else {
@@ -4720,15 +4840,7 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
         szk_merge_params mp;
         mp.slots = mg->slots;
         mp.seg_bits = seg_bits;
-        mp.seg_start = mg->seg_start;
-        mp.d0 = mg->d[0];
-        mp.d1 = mg->d[1];
-        mp.d2 = mg->d[2];
-        mp.ntx = mg->geom[0];
-        mp.nty = mg->geom[1];
-        mp.ntz = mg->geom[2];
-        mp.slot_words = mg->geom[3];
-        mp.ty = mg->ty;
+        mp.seg_base = mg->seg_base;
         mp.fuse_flag = mg->fuse_flag;
         const uint32_t pb = pgrid < 2048 - extra ? pgrid : 2048 - extra;
         hipLaunchKernelGGL(k_merge, dim3(rb + pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, mp, n, chunk_words, group_off, mode, state, payload, apv, pb, rp);

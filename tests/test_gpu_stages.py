@@ -724,6 +724,8 @@ def test_fused_stage1_writes_the_unfused_encoders_bytes(shape, dtype):
     conf = _conf(shape, eb)
     L = sz3_amd.lib()
     ctxs = [sz3_amd.DeviceCompressor(n, dtype), sz3_amd.DeviceCompressor(n, dtype)]
+    for d in ctxs:
+        d.set_fused(True)  # (opt-in: the default is the two-pass form)
     cap = ctxs[0].payload_bound(n, worst_case=True)
 
     def run(dc, arr, flags=0):
@@ -765,6 +767,7 @@ def test_fused_stage1_misses_repeat_the_call():
     holes.reshape(-1)[np.random.default_rng(3).choice(n, size=6000, replace=False)] = np.nan
     dc = sz3_amd.DeviceCompressor(n, np.float32)
     dc.set_speculation(True, backoff=False)
+    dc.set_fused(True)
     cap = dc.payload_bound(n, worst_case=True)
 
     def run(d, arr, eb):

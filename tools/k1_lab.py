@@ -11,6 +11,7 @@ a = field3d((S, S, S)); dev = torch.device("cuda:0")
 d_in = torch.from_numpy(a).to(dev)
 conf = sz3_amd.Config(S, S, S); conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG; conf.regression = 0; conf.absErrorBound = 1e-3
 dc = sz3_amd.DeviceCompressor(a.size, np.float32)
+if os.environ.get('LAB_FUSED') == '1': dc.set_fused(True)   # (the fused stage 1, k_lorenzo_quant_march3f + k_merge)
 cap = dc.payload_bound(a.size); pl = torch.empty(cap, dtype=torch.uint8, device=dev)
 stream = torch.cuda.current_stream().cuda_stream
 L = sz3_amd.lib()

@@ -432,9 +432,16 @@ template <class T>
 inline int dtype_of() {
     if (std::is_same<T, float>::value) return SZ3HIP_FLOAT;
     if (std::is_same<T, double>::value) return SZ3HIP_DOUBLE;
-    if (std::is_same<T, int32_t>::value) return SZ3HIP_INT32;
-    if (std::is_same<T, int64_t>::value || (std::is_integral<T>::value && std::is_signed<T>::value && sizeof(T) == 8)) return SZ3HIP_INT64;
-    throw std::invalid_argument("SZ3 (HIP path): float, double, int32 and int64 arrays are supported by libsz3hip");
+    if (std::is_integral<T>::value && !std::is_same<T, bool>::value) {  // (the ten types of tools/H5Z-SZ3/src/H5Z_SZ3.cpp:195-227)
+        const bool sg = std::is_signed<T>::value;
+        switch (sizeof(T)) {
+            case 1: return sg ? SZ3HIP_INT8 : SZ3HIP_UINT8;
+            case 2: return sg ? SZ3HIP_INT16 : SZ3HIP_UINT16;
+            case 4: return sg ? SZ3HIP_INT32 : SZ3HIP_UINT32;
+            case 8: return sg ? SZ3HIP_INT64 : SZ3HIP_UINT64;
+        }
+    }
+    throw std::invalid_argument("SZ3 (HIP path): float, double and 8 / 16 / 32 / 64-bit integer arrays are supported by libsz3hip");
 }
 [[noreturn]] inline void raise_last(int code) {
     const std::string msg = sz3hip_last_error();

@@ -37,7 +37,15 @@ extern "C" {
 /* data types: include/SZ3/utils/Config.hpp:27-36 */
 #define SZ3HIP_FLOAT 0
 #define SZ3HIP_DOUBLE 1
-#define SZ3HIP_INT32 7 /* host-buffer API only: integers ride the f64 pipeline (exact; int64 beyond 2^53 -> lossless) */
+/* host-buffer API only: integers ride the f64 pipeline (exact; 64-bit values beyond 2^53 -> the array stays lossless). The numbers
+ * are the reference's SZ_UINT8 .. SZ_INT64 (include/SZ3/def.hpp:27-36), the element types of its HDF5 filter (H5Z_SZ3.cpp:195-227) */
+#define SZ3HIP_UINT8 2
+#define SZ3HIP_INT8 3
+#define SZ3HIP_UINT16 4
+#define SZ3HIP_INT16 5
+#define SZ3HIP_UINT32 6
+#define SZ3HIP_INT32 7
+#define SZ3HIP_UINT64 8
 #define SZ3HIP_INT64 9
 
 /* error-bound modes: include/SZ3/utils/Config.hpp:66 (enum EB) */

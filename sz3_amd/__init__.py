@@ -198,17 +198,15 @@ def _check(rc):
         raise SZ3HipError(rc, lib().sz3hip_last_error().decode())
 
 
+_SZ_TYPES = {"float32": 0, "float64": 1, "uint8": 2, "int8": 3, "uint16": 4, "int16": 5, "uint32": 6, "int32": 7, "uint64": 8, "int64": 9}
+
+
 def _dtype_id(dt):
+    """SZ_FLOAT .. SZ_INT64 (include/SZ3/def.hpp:27-36); integers: host-buffer API only (compress / decompress), they ride the f64 pipeline"""
     dt = np.dtype(dt)
-    if dt == np.float32:
-        return 0
-    if dt == np.float64:
-        return 1
-    if dt == np.int32:   # host-buffer API only (compress / decompress): integers ride the f64 pipeline
-        return 7
-    if dt == np.int64:
-        return 9
-    raise TypeError("sz3_amd supports float32 / float64 / int32 / int64 (got %s)" % dt)
+    if dt.name in _SZ_TYPES:
+        return _SZ_TYPES[dt.name]
+    raise TypeError("sz3_amd supports float32 / float64 and 8 ... 64-bit integers (got %s)" % dt)
 
 
 class Config:

@@ -244,9 +244,14 @@ static size_t decompress_frames(const uint8_t *src, size_t n, uint8_t *dst, size
 static const uint32_t kMagic = 0xF342F310u;                          // include/SZ3/version.hpp.in:10
 static const uint32_t kDataVer = (3u << 24) | (3u << 16) | (2u << 8);  // SZ3_DATA_VERSION 3.3.2 (CMakeLists.txt:7)
 
-static inline bool dtype_ok(int dt) { return dt == SZ3HIP_FLOAT || dt == SZ3HIP_DOUBLE || dt == SZ3HIP_INT32 || dt == SZ3HIP_INT64; }
-static inline bool dtype_is_int(int dt) { return dt == SZ3HIP_INT32 || dt == SZ3HIP_INT64; }
-static inline size_t dtype_size(int dt) { return (dt == SZ3HIP_FLOAT || dt == SZ3HIP_INT32) ? 4 : 8; }
+// SZ_FLOAT = 0, SZ_DOUBLE = 1, then the integers SZ_UINT8 = 2, SZ_INT8, SZ_UINT16, SZ_INT16, SZ_UINT32, SZ_INT32, SZ_UINT64, SZ_INT64 = 9
+// (include/SZ3/def.hpp:27-36): the ten element types of the reference's HDF5 filter (tools/H5Z-SZ3/src/H5Z_SZ3.cpp:195-227)
+static inline bool dtype_ok(int dt) { return dt >= 0 && dt <= 9; }
+static inline bool dtype_is_int(int dt) { return dt >= 2 && dt <= 9; }
+static inline size_t dtype_size(int dt) {
+    static const size_t sz[10] = {4, 8, 1, 1, 2, 2, 4, 4, 8, 8};
+    return dt >= 0 && dt <= 9 ? sz[dt] : 0;
+}
 static inline int dtype_compute(int dt) { return dtype_is_int(dt) ? SZ3HIP_DOUBLE : dt; }  // integers ride the f64 pipeline
 
 static int env_int(const char *name, int dflt) {
@@ -503,7 +508,7 @@ int job_upload(SlabJob &j) {
             fail(SZ3HIP_EHIP, "host->device copy failed");
             return j.failed(SZ3HIP_EHIP);
         }
-        if (szk_launch_int_to_f64(j.dataType == SZ3HIP_INT64, s->dev_payload, j.conf.num, (double *)s->dev_in,
+        if (szk_launch_int_to_f64(j.dataType, s->dev_payload, j.conf.num, (double *)s->dev_in,
                                   reinterpret_cast<uint32_t *>(ctx->d_counters + 5), s->stream)) {
             fail(SZ3HIP_EHIP, "integer widening kernel failed");
             return j.failed(SZ3HIP_EHIP);
@@ -808,7 +813,7 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
                                   size_t cmpCap) {
     HostTimer tm;
     if (!dtype_ok(dataType)) {
-        fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
+        fail(SZ3HIP_EUNSUPPORTED, "dataType %d is not one of SZ_FLOAT .. SZ_INT64 (0 .. 9)", dataType);
         return 0;
     }
     sz3hip_config conf = *config;  // sz.hpp:45
@@ -876,7 +881,7 @@ int decompress_blob(HostSlot *s, const sz3hip_config *conf, int dataType, const 
 // added to the reference's own header tree as one more ALGO (tools/sz3/sz3_customized_demo.cpp:8-14).
 extern "C" size_t sz3hip_compress_blob(sz3hip_config *conf, int dataType, const void *data, char *blob, size_t cap) {
     if (!dtype_ok(dataType)) {
-        fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
+        fail(SZ3HIP_EUNSUPPORTED, "dataType %d is not one of SZ_FLOAT .. SZ_INT64 (0 .. 9)", dataType);
         return 0;
     }
     if (conf->N < 1 || conf->N > 4) {
@@ -900,7 +905,7 @@ extern "C" size_t sz3hip_compress_blob(sz3hip_config *conf, int dataType, const 
 }
 extern "C" int sz3hip_decompress_blob(const sz3hip_config *conf, int dataType, const char *blob, size_t size, void *decData) {
     if (!dtype_ok(dataType))
-        return fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
+        return fail(SZ3HIP_EUNSUPPORTED, "dataType %d is not one of SZ_FLOAT .. SZ_INT64 (0 .. 9)", dataType);
     if (zs::load()) return SZ3HIP_EZSTD;
     std::shared_lock<std::shared_mutex> lock(g_host_mu);
     DeviceGuard guard;
@@ -916,7 +921,7 @@ extern "C" size_t sz3hip_compress_rank(sz3hip_comm *comm, const sz3hip_config *g
         return 0;
     }
     if (!dtype_ok(dataType)) {
-        fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
+        fail(SZ3HIP_EUNSUPPORTED, "dataType %d is not one of SZ_FLOAT .. SZ_INT64 (0 .. 9)", dataType);
         return 0;
     }
     sz3hip_config conf = *global_conf;
@@ -1139,7 +1144,7 @@ int decompress_blob(HostSlot *s, const sz3hip_config *conf, int dataType, const 
         HIPCHK(hipMemcpy(decData, s->dev_in, raw_bytes, hipMemcpyDeviceToHost));  // (the runtime pins large pageable buffers
                                                                                   // itself: a hand-made pinned pipeline was slower)
     } else {
-        rc = szk_launch_f64_to_int(dataType == SZ3HIP_INT64, (const double *)s->dev_in, conf->num, s->dev_payload, s->stream);
+        rc = szk_launch_f64_to_int(dataType, (const double *)s->dev_in, conf->num, s->dev_payload, s->stream);
         if (rc) return fail(SZ3HIP_EHIP, "integer narrowing kernel failed");
         HIPCHK(hipStreamSynchronize(s->stream));
         HIPCHK(hipMemcpy(decData, s->dev_payload, raw_bytes, hipMemcpyDeviceToHost));
@@ -1205,7 +1210,7 @@ int decompress_slabs(const sz3hip_config *conf, int dataType, const unsigned cha
 
 extern "C" int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *cmpData, size_t cmpSize, void *decData) {
     if (!dtype_ok(dataType))
-        return fail(SZ3HIP_EUNSUPPORTED, "dataType %d not supported by the HIP path (float, double, int32, int64)", dataType);
+        return fail(SZ3HIP_EUNSUPPORTED, "dataType %d is not one of SZ_FLOAT .. SZ_INT64 (0 .. 9)", dataType);
     int rc = sz3hip_peek_config(conf, cmpData, cmpSize);
     if (rc) return rc;
     if (zs::load()) return SZ3HIP_EZSTD;

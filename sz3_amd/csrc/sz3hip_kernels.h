@@ -304,8 +304,8 @@ int szk_launch_interp_trials(int dtype, const szk_interp_params *ips, uint32_t n
 int szk_launch_code_cost(const uint64_t *hist, const uint64_t *counters, uint64_t *d_res, uint32_t n_books, uint64_t total,
                          int unpred_is_code0, hipStream_t s);
 
-int szk_launch_int_to_f64(int is64, const void *d_in, uint64_t n, double *d_out, uint32_t *d_flag, hipStream_t s);
-int szk_launch_f64_to_int(int is64, const double *d_in, uint64_t n, void *d_out, hipStream_t s);
+int szk_launch_int_to_f64(int sz_type /* SZ_UINT8 = 2 .. SZ_INT64 = 9 */, const void *d_in, uint64_t n, double *d_out, uint32_t *d_flag, hipStream_t s);
+int szk_launch_f64_to_int(int sz_type, const double *d_in, uint64_t n, void *d_out, hipStream_t s);
 int szk_launch_hist_add(uint64_t *d_dst, const uint64_t *d_src, uint32_t n, hipStream_t s);  // dst[i] += src[i]
 int szk_launch_minmax(int dtype, const void *d_in, uint64_t n, double *d_partial /*[2*1024]*/, double *d_out /*[2]*/, hipStream_t s);
 int szk_launch_k1(int dtype, int ndim, const void *d_in, uint16_t *codes, szk_k1_params *p, hipStream_t s);

@@ -4479,15 +4479,20 @@ static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap) {
     return (uint32_t)g;
 }
 
-// ---- integer inputs ride the f64 pipeline (int32 exactly; int64 exactly up to 2^53 in magnitude) --------------------
+// ---- integer inputs ride the f64 pipeline: every element type of the reference's HDF5 filter (tools/H5Z-SZ3/src/H5Z_SZ3.cpp:195-227 —
+// 8 / 16 / 32 / 64-bit, signed and unsigned) widened on the device; exact up to 2^53 in magnitude (beyond: the array stays lossless)
 template <typename I>
 __global__ __launch_bounds__(256) void k_int_to_f64(const I *__restrict__ in, uint64_t n, double *__restrict__ out, uint32_t *too_big) {
     bool big = false;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         const I v = in[i];
         if (sizeof(I) == 8) {
-            const long long a = (long long)v;
-            big |= a > (1ll << 53) || a < -(1ll << 53);
+            if (std::is_signed<I>::value) {
+                const long long a = (long long)v;
+                big |= a > (1ll << 53) || a < -(1ll << 53);
+            } else {
+                big |= (unsigned long long)v > (1ull << 53);
+            }
         }
         out[i] = (double)v;
     }
@@ -4495,22 +4500,49 @@ __global__ __launch_bounds__(256) void k_int_to_f64(const I *__restrict__ in, ui
 }
 template <typename I>
 __global__ __launch_bounds__(256) void k_f64_to_int(const double *__restrict__ in, uint64_t n, I *__restrict__ out) {
+    // (the reconstruction of an in-range integer within a bound >= 1 may leave the type's range by the bound: clamped, like a cast would not)
+    constexpr double lo = std::is_signed<I>::value ? -(double)(1ull << (8 * sizeof(I) - 1)) : 0.0;
+    constexpr double hi = sizeof(I) == 8 ? (std::is_signed<I>::value ? 9223372036854774784.0 : 18446744073709549568.0)  // largest doubles below 2^63 / 2^64
+                                         : (double)((1ull << (8 * sizeof(I) - (std::is_signed<I>::value ? 1 : 0))) - 1ull);
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-        const double v = rint(in[i]);
-        out[i] = sizeof(I) == 4 ? (I)(long long)fmin(fmax(v, -2147483648.0), 2147483647.0) : (I)(long long)v;
+        const double v = fmin(fmax(rint(in[i]), lo), hi);
+        out[i] = std::is_signed<I>::value ? (I)(long long)v : (I)(unsigned long long)v;
     }
 }
-int szk_launch_int_to_f64(int is64, const void *d_in, uint64_t n, double *d_out, uint32_t *d_flag, hipStream_t s) {
+// sz_type: SZ_UINT8 = 2, SZ_INT8 = 3, SZ_UINT16 = 4, SZ_INT16 = 5, SZ_UINT32 = 6, SZ_INT32 = 7, SZ_UINT64 = 8, SZ_INT64 = 9 (include/SZ3/def.hpp:27-36)
+int szk_launch_int_to_f64(int sz_type, const void *d_in, uint64_t n, double *d_out, uint32_t *d_flag, hipStream_t s) {
     const uint32_t g = grid_for(n, 256, 65536);
-    if (is64) hipLaunchKernelGGL((k_int_to_f64<int64_t>), dim3(g), dim3(256), 0, s, (const int64_t *)d_in, n, d_out, d_flag);
-    else hipLaunchKernelGGL((k_int_to_f64<int32_t>), dim3(g), dim3(256), 0, s, (const int32_t *)d_in, n, d_out, d_flag);
+#define SZK_W(T) hipLaunchKernelGGL((k_int_to_f64<T>), dim3(g), dim3(256), 0, s, (const T *)d_in, n, d_out, d_flag)
+    switch (sz_type) {
+        case 2: SZK_W(uint8_t); break;
+        case 3: SZK_W(int8_t); break;
+        case 4: SZK_W(uint16_t); break;
+        case 5: SZK_W(int16_t); break;
+        case 6: SZK_W(uint32_t); break;
+        case 7: SZK_W(int32_t); break;
+        case 8: SZK_W(uint64_t); break;
+        case 9: SZK_W(int64_t); break;
+        default: return -1;
+    }
+#undef SZK_W
     SZK_CHECK_LAUNCH();
     return 0;
 }
-int szk_launch_f64_to_int(int is64, const double *d_in, uint64_t n, void *d_out, hipStream_t s) {
+int szk_launch_f64_to_int(int sz_type, const double *d_in, uint64_t n, void *d_out, hipStream_t s) {
     const uint32_t g = grid_for(n, 256, 65536);
-    if (is64) hipLaunchKernelGGL((k_f64_to_int<int64_t>), dim3(g), dim3(256), 0, s, d_in, n, (int64_t *)d_out);
-    else hipLaunchKernelGGL((k_f64_to_int<int32_t>), dim3(g), dim3(256), 0, s, d_in, n, (int32_t *)d_out);
+#define SZK_N(T) hipLaunchKernelGGL((k_f64_to_int<T>), dim3(g), dim3(256), 0, s, d_in, n, (T *)d_out)
+    switch (sz_type) {
+        case 2: SZK_N(uint8_t); break;
+        case 3: SZK_N(int8_t); break;
+        case 4: SZK_N(uint16_t); break;
+        case 5: SZK_N(int16_t); break;
+        case 6: SZK_N(uint32_t); break;
+        case 7: SZK_N(int32_t); break;
+        case 8: SZK_N(uint64_t); break;
+        case 9: SZK_N(int64_t); break;
+        default: return -1;
+    }
+#undef SZK_N
     SZK_CHECK_LAUNCH();
     return 0;
 }

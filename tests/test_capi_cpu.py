@@ -70,8 +70,10 @@ def test_fails_loudly_without_device():
         sz3_amd.compress(a, sz3_amd.Config(8, 8, 8))
     with pytest.raises(sz3_amd.SZ3HipError):
         sz3_amd.DeviceCompressor(512, np.float32)
-    with pytest.raises(TypeError):
+    with pytest.raises(sz3_amd.SZ3HipError):  # (round 4: the 8 ... 64-bit integer types are served — on a device)
         sz3_amd.compress(a.astype(np.uint8), sz3_amd.Config(8, 8, 8))
+    with pytest.raises(TypeError):
+        sz3_amd.compress(a.astype(np.complex64), sz3_amd.Config(8, 8, 8))
 
 
 def test_peek_rejects_foreign_streams():

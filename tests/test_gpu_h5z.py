@@ -58,29 +58,17 @@ ALL_TYPES = [(np.float32, (1, 4, 1), 1e-3), (np.float64, (1, 8, 1), 1e-6), (np.u
 
 
 @pytest.mark.parametrize("dtype,h5type,eb", ALL_TYPES, ids=[np.dtype(t[0]).name for t in ALL_TYPES])
-def test_a_dataset_the_way_hdf5_drives_the_plugin(dtype, h5type, eb, tmp_path):
+def test_a_dataset_the_way_hdf5_drives_the_plugin(dtype, h5type, eb):
     """What HDF5 does with a filter plugin when a chunked dataset is created with filter 32024 and written (H5Z_SZ3.cpp:74-227;
     tools/test/integration/test_h5_filter.py:19-35 through h5py): the user's cd_values (a Config that knows neither the dataset's type nor
     its chunk shape) sit on the creation property list; the record's set_local is called with the list, the element type and the
     chunk's dataspace; every chunk then goes through the record's filter function with the list's cd_values — forward on write, with
     H5Z_FLAG_REVERSE on read. HDF5 itself is played by tests/h5stub (not in this image). All ten element types of the reference's
     filter; integers come back within floor(eb), exactly representable values included at the type's limits."""
-    import os
-    import shutil
-    import subprocess
-    from test_h5z_cpu import HERE as H5HERE
-    gcc = shutil.which("gcc")
-    if not gcc:
+    from h5stub_loader import load_stub
+    h5 = load_stub()
+    if h5 is None:
         pytest.skip("no gcc")
-    so = str(tmp_path / "libhdf5_stubfortests.so")
-    subprocess.check_call([gcc, "-O1", "-shared", "-fPIC", os.path.join(H5HERE, "h5stub", "h5stub.c"), "-o", so])
-    h5 = C.CDLL(so, mode=os.RTLD_LOCAL)
-    for f in ("h5stub_plist_new", "h5stub_type_new", "h5stub_space_new"):
-        getattr(h5, f).restype = C.c_int64
-    h5.h5stub_type_new.argtypes = [C.c_int, C.c_size_t, C.c_int]
-    h5.h5stub_space_new.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
-    h5.H5Pset_filter.argtypes = [C.c_int64, C.c_int, C.c_uint, C.c_size_t, C.c_void_p]
-    h5.H5Pget_filter_by_id2.argtypes = [C.c_int64, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint)]
     L = sz3_amd.lib()
     L.H5PLget_plugin_info.restype = C.POINTER(_H5ZClass2)
     rec = L.H5PLget_plugin_info().contents
@@ -91,16 +79,18 @@ def test_a_dataset_the_way_hdf5_drives_the_plugin(dtype, h5type, eb, tmp_path):
     libc.free.argtypes = [C.c_void_p]
     chunk = (1, 36, 44, 52)  # (HDF5 hands the chunk's full rank over: the extent of 1 is dropped by set_local like Config::setDims does)
     shape = chunk[1:]
-    f = field3d(shape, np.float64)
     info = np.iinfo(dtype) if np.issubdtype(dtype, np.integer) else None
     if info is not None:
+        f = field3d(shape, np.float64, sigma=0.0)
         span = float(info.max) - float(info.min)
-        a = (f - f.min()) / (f.max() - f.min())                      # 0 .. 1
-        scale = min(span, 2.0 ** 40)                                  # (64-bit: stay exactly representable in f64)
-        a = np.clip(np.floor(a * scale) + (float(info.min) if span <= 2.0 ** 40 else 0.0), float(info.min), float(info.max)).astype(dtype)
-        a.reshape(-1)[:4] = [info.min if span <= 2.0 ** 40 else 0, info.max if span <= 2.0 ** 40 else 2 ** 40, 0, 1]
+        a01 = (f - f.min()) / (f.max() - f.min())                    # 0 .. 1, smooth
+        scale = min(span, 2.0 ** 16)                                 # (wide types: a smooth field of 2^16 levels somewhere inside the range)
+        a = np.floor(a01 * scale).astype(dtype)
+        # the type's limits (64-bit: +-2^40 — beyond 2^53 an array is kept lossless, which is not what this test is about)
+        lo, hi = (int(info.min), int(info.max)) if a.itemsize < 8 else (0 if info.min == 0 else -2 ** 40, 2 ** 40)
+        a.reshape(-1)[:4] = [lo, hi, 0, 1]
     else:
-        a = f.astype(dtype)
+        a = field3d(shape, np.float64, sigma=2e-6 if dtype is np.float64 else 2e-3).astype(dtype)
     user = sz3_amd.Config(5)            # what an application passes as compression_opts: made for no dataset in particular
     user.absErrorBound = eb
     user.cmprAlgo = sz3_amd.ALGO_LORENZO_REG

@@ -18,21 +18,12 @@ H5T_INTEGER, H5T_FLOAT, H5T_STRING = 0, 1, 3
 SGN_NONE, SGN_2 = 0, 1
 
 
-@pytest.fixture(scope="module")
-def h5(tmp_path_factory):
-    gcc = shutil.which("gcc")
-    if not gcc:
+@pytest.fixture()
+def h5():
+    from h5stub_loader import load_stub
+    lib = load_stub()
+    if lib is None:
         pytest.skip("no gcc")
-    so = str(tmp_path_factory.mktemp("h5stub") / "libhdf5_stubfortests.so")
-    subprocess.check_call([gcc, "-O1", "-shared", "-fPIC", os.path.join(HERE, "h5stub", "h5stub.c"), "-o", so])
-    lib = C.CDLL(so, mode=os.RTLD_LOCAL)
-    for f in ("h5stub_plist_new", "h5stub_type_new", "h5stub_space_new"):
-        getattr(lib, f).restype = C.c_int64
-    lib.h5stub_type_new.argtypes = [C.c_int, C.c_size_t, C.c_int]
-    lib.h5stub_space_new.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
-    lib.H5Pset_filter.argtypes = [C.c_int64, C.c_int, C.c_uint, C.c_size_t, C.c_void_p]
-    lib.H5Pget_filter_by_id2.argtypes = [C.c_int64, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint)]
-    lib.H5Pget_nfilters.argtypes = [C.c_int64]
     return lib
 
 

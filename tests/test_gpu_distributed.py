@@ -80,3 +80,61 @@ def test_two_ranks_share_one_code_book(algo):
     for p in procs:
         p.join(60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _bench(args, env_extra, timeout=900):
+    import json
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads(lines[-1])
+
+
+def test_bench_relaunches_itself_as_two_ranks_and_prints_one_line():
+    """The driver's multi-GPU run is the first time bench.py --gpus N > 1 executes on real hardware. Its plumbing — the relaunch as N
+    ranks under torch.distributed.run on 127.0.0.1, the barrier + max-over-ranks timing, the summed payload, ONE line from rank 0 — is
+    run here with both ranks on the one GPU (SZ3_BENCH_ONE_GPU=1: the histogram then travels through gloo; RCCL wants a GPU per rank)."""
+    d = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "128", "--no-extra", "--no-cold", "--no-host-e2e", "--no-cpu-baseline",
+                "--no-live-traffic"], {"SZ3_BENCH_ONE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["unit"] == "GB/s"
+    assert "gloo" in d["config"]["exchange"] and d["config"]["parallelism"] == "slab2"
+    assert d["value"] > 0 and d["err_bound_ok"] and d["ratio"] > 2
+    assert "roofline" in d and "cpu_baseline" not in d
+
+
+def test_bench_on_every_visible_gpu_over_rccl():
+    """with more than one GPU on the box: the real thing at N = 2 (RCCL all-reduce of the histogram inside the library, one rank per GPU)"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box")
+    d = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "256", "--no-extra", "--no-cold", "--no-host-e2e", "--no-cpu-baseline",
+                "--no-live-traffic"], {})
+    assert d["n_gpus"] == 2 and "RCCL" in d["config"]["exchange"] and d["err_bound_ok"]
+
+
+def test_one_process_slabs_over_every_visible_gpu():
+    """conf.openmp on a box with several GPUs: compress_slabs' per-GPU host threads and ncclAllReduce between DIFFERENT devices
+    (sz3hip_host.cpp, sz3hip_comm.cpp) — every slab coded with one book, the container read back by the library"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box")
+    sys.path.insert(0, HERE)
+    import sz3_amd
+    import szh_ref
+    from fields import field3d
+    import struct
+    g = torch.cuda.device_count()
+    a = field3d((8 * g, 96, 128))
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.regression = 0
+    conf.absErrorBound = 1e-3
+    conf.openmp = 1
+    blob, ratio = sz3_amd.compress(a, conf)
+    dec, c2 = sz3_amd.decompress(blob, np.float32, a.shape)
+    assert c2.openmp == 1 and ratio > 3
+    assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= 1e-3
+    b = blob.tobytes()
+    nslab, = struct.unpack_from("<i", b, 16)
+    assert nslab == g

@@ -29,8 +29,15 @@ for z0 in range(0, Z, step):
     f[z0:z1] = torch.sin(2 * np.pi * zz / 29.0) + rest + sigma * torch.randn((z1 - z0,) + shape[1:], device=dev, generator=g, dtype=tdt)
 n = f.numel()
 print("elements", n, "> 2^32" if n > 2 ** 32 else "", flush=True)
-conf = sz3_amd.Config(*shape); conf.cmprAlgo = algo; conf.absErrorBound = eb
 dc = sz3_amd.DeviceCompressor(n, ndt); cap = dc.payload_bound(n)
+rel = os.environ.get("LAB_REL")
+if rel:  # EB_REL the way the dispatcher converts it (utils/Statistic.hpp:12-56: bound = ratio x (max - min), the range found on the device: k_minmax)
+    mn, mx = dc.minmax(f.data_ptr(), n, 0)
+    ref_mn, ref_mx = float(f.min()), float(f.max())
+    assert (mn, mx) == (ref_mn, ref_mx), (mn, mx, ref_mn, ref_mx)
+    eb = float(rel) * (mx - mn)
+    print("REL %s x range %.6g = abs %.6g" % (rel, mx - mn, eb), flush=True)
+conf = sz3_amd.Config(*shape); conf.cmprAlgo = algo; conf.absErrorBound = eb
 pl = torch.empty(cap, dtype=torch.uint8, device=dev); out = torch.empty_like(f)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 sz = dc.compress(conf, f.data_ptr(), pl.data_ptr(), cap, 0)

@@ -35,7 +35,7 @@ def _gpu_roundtrip(a, **kw):
 
 # BASELINE.json configs at sizes the oracle finishes in seconds: (name, generator, GPU config, oracle config, ratio band)
 CASES = [
-    ("C1-1d-2^20-lorenzo_reg-abs1e-3", lambda: field1d(1 << 20), dict(absErrorBound=1e-3), dict(abs_eb=1e-3, regression=True), 0.90),
+    ("C1-1d-2^20-lorenzo_reg-abs1e-3", lambda: field1d(1 << 20), dict(absErrorBound=1e-3, regression=1), dict(abs_eb=1e-3, regression=True), 0.97),  # (its specified set on both sides: 4.74 vs 4.75)
     ("C2-3d-128c-lorenzo-abs1e-3", lambda: field3d((128, 128, 128)), dict(absErrorBound=1e-3), dict(abs_eb=1e-3), 0.97),
     ("C3-3d-96c-abs1e-4", lambda: field3d((96, 96, 96)), dict(absErrorBound=1e-4), dict(abs_eb=1e-4), 0.97),
     ("C4-3d-f64-96c-lorenzo_reg-abs1e-6", lambda: field3d((96, 96, 96), np.float64, sigma=2e-6), dict(absErrorBound=1e-6), dict(abs_eb=1e-6, regression=True), 0.97),

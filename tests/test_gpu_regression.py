@@ -114,7 +114,7 @@ def test_c4a_ratio_and_selection_share_against_the_oracle(n):
     share = float((sel == 2).mean())
     print("C4a %d^3: ratio %.2f (oracle %.2f), regression share %.3f (oracle %.3f)" % (n, ratio, o_ratio, share, o_share))
     assert ratio >= 0.97 * o_ratio
-    assert 0.6 * o_share <= share <= 1.4 * o_share
+    assert 0.85 * o_share <= share <= 1.15 * o_share  # (measured 0.95 - 0.97 x the oracle's)
     # block by block (ComposedPredictor.hpp:25-40: first minimum of the sampled error estimates): the selection vector in the
     # stream's side section against the oracle's own choices, same block raster order
     oconf = make_config(a.shape, abs_eb=eb, lorenzo=True, regression=True)
@@ -125,7 +125,7 @@ def test_c4a_ratio_and_selection_share_against_the_oracle(n):
     both_reg = int(((osel == 2) & (sel == 2)).sum())
     print("  per-block selection: %.2f %% identical; regression in both %d, oracle only %d, gpu only %d"
           % (100 * same, both_reg, int(((osel == 2) & (sel != 2)).sum()), int(((osel != 2) & (sel == 2)).sum())))
-    assert same >= 0.90, same
+    assert same >= 0.925, same  # (measured 95.1 / 94.4 %)
     # a biased estimator would disagree in one direction: of the blocks either side gives to regression, most are common
     assert both_reg >= 0.6 * max(int((osel == 2).sum()), int((sel == 2).sum()))
 
@@ -154,7 +154,7 @@ def test_second_order_lorenzo_against_the_oracle(mask):
     assert ratio >= 0.95 * o_ratio
     assert ratio > 1.15 * plain
     if l1 or rg:  # a composed set: the selection itself, block by block
-        assert float((osel == sel).mean()) >= 0.85
+        assert float((osel == sel).mean()) >= 0.95
 
 
 def test_regression_only_beats_lorenzo_where_the_reference_says_so():

@@ -102,7 +102,7 @@ def test_ratio_and_selection_against_the_oracle(shape, eb):
     print("%s @%g: ratio %.2f (oracle %.2f); regression blocks %.3f (oracle %.3f); selection identical in %.2f %% of the blocks"
           % (shape, eb, ratio, o_ratio, float((sel == 2).mean()), float((osel == 2).mean()), 100 * same))
     assert ratio >= 0.95 * o_ratio
-    assert same >= 0.90
+    assert same >= 0.925  # (measured 94.5 - 99.99 %)
 
 
 def test_full_size_round_trip_of_a_long_series():

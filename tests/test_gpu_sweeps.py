@@ -56,7 +56,7 @@ BIG = [  # (id, algorithm, shape, dtype, abs bound, noise, GiB of free HBM neede
     ("4.4e9-f32-lorenzo", "lorenzo", "1100,2000,2000", "f32", "1e-3", "2e-3", 120),
     ("4.4e9-f32-interp", "interp", "1100,2000,2000", "f32", "1e-3", "2e-3", 120),
     ("C5-whole-lorenzo", "lorenzo", "100,500,500,500", "f32", "2.4e-3", "2e-3", 225),
-    ("C5-whole-default", "default", "100,500,500,500", "f32", "2.4e-3", "2e-3", 225),
+    ("C5-whole-default-REL1e-3", "default", "100,500,500,500", "f32", "rel:1e-3", "2e-3", 225),  # (BASELINE.json configs[4]: REL errBound through the device range scan)
     ("C4-whole-lorenzo", "lorenzo", "1024,1024,1024", "f64", "1e-6", "2e-6", 60),
     ("C4-whole-default", "default", "1024,1024,1024", "f64", "1e-6", "2e-6", 60),
 ]
@@ -82,6 +82,8 @@ def test_round_trip_at_full_benchmark_sizes_and_beyond_2_pow_32_elements(case):
     for d in shape.split(","):
         n *= int(d)
     env = dict(os.environ, LAB_ALGO=algo, LAB_SHAPE=shape, LAB_EB=eb, LAB_DTYPE=dtype, LAB_SIGMA=sigma)
+    if eb.startswith("rel:"):
+        env.update(LAB_REL=eb[4:], LAB_EB="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "big_roundtrip.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]

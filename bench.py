@@ -235,6 +235,7 @@ class Workload:
 
     def verify_and_time_decode(self, psize):
         torch = self.torch
+        psize = self.step()  # (the payload buffer holds the LAST step's stream — the profiled steps ran since `psize` was returned, on the other realisation)
         d_out = torch.empty_like(self.d_in)
         self.dc.decompress(self.d_payload.data_ptr(), psize, d_out.data_ptr(), self.stream)
         torch.cuda.synchronize()

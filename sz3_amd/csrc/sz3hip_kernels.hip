@@ -4910,11 +4910,15 @@ int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t 
     const uint64_t n_units = (p->n + SZH_UNIT_SYMS - 1) / SZH_UNIT_SYMS;
     const uint64_t nb = (n_units + 255) / 256;
     if (nb > 0x7FFFFFFFull) return -1;
-    if (!p->scan_row) hipLaunchKernelGGL((k_decode<0>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
-    else if (p->q_bytes == 8 && p->half) hipLaunchKernelGGL((k_decode<8, true>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
-    else if (p->q_bytes == 8) hipLaunchKernelGGL((k_decode<8>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
-    else if (p->half) hipLaunchKernelGGL((k_decode<4, true>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
-    else hipLaunchKernelGGL((k_decode<4>), dim3((uint32_t)nb), dim3(256), 0, s, payload, *p, codes);
+    static const uint32_t pad = [] {  // (lab: extra LDS per workgroup = fewer resident workgroups; SZ3HIP_LAB_DEC_LDS bytes)
+        const char *e = getenv("SZ3HIP_LAB_DEC_LDS");
+        return e ? (uint32_t)atoi(e) : 0u;
+    }();
+    if (!p->scan_row) hipLaunchKernelGGL((k_decode<0>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
+    else if (p->q_bytes == 8 && p->half) hipLaunchKernelGGL((k_decode<8, true>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
+    else if (p->q_bytes == 8) hipLaunchKernelGGL((k_decode<8>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
+    else if (p->half) hipLaunchKernelGGL((k_decode<4, true>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
+    else hipLaunchKernelGGL((k_decode<4>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
     if (p->scan_row && p->carry && p->carry_pass) {
         const uint64_t cb = (n_units + 3) / 4;
         if (p->q_bytes == 8 && p->half)

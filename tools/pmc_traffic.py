@@ -117,6 +117,6 @@ out["method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pa
                  "WRITE_SIZE taken as reported (checks out: stage 1 writes 1 B/elem of codes = 134 MB, counter says 135 MB); counters are in KB (x1024). "
                  "For k_decode (4-byte loads scattered over 64 lines per wave) the doubling over-counts. valu_issue_us = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / 2.1 GHz: "
                  "the time the vector ALUs need to issue the kernel's instructions (a wave64 instruction occupies a 16-lane SIMD for 4 cycles). "
-                 "Generated by tools/pmc_traffic.py from profiles/r03_pmc_summary.txt (C2, round 3) and r02_pmc_summary_c3.txt (C3: its kernels did not change in round 3).")
+                 "Generated by tools/pmc_traffic.py from profiles/r04_pmc_summary.txt (C2, round 4: the two-pass form, the default; the fused form: profiles/r04_pmc_summary_fused.txt) and r02_pmc_summary_c3.txt (C3: its kernels did not change in round 3).")
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:600])

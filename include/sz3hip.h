@@ -100,6 +100,15 @@ void sz3hip_config_init(sz3hip_config *c, int ndims, const uint64_t *dims_slowes
 /* Config::save / Config::load (Config.hpp:312-413); return bytes written / consumed */
 size_t sz3hip_config_save(const sz3hip_config *c, unsigned char *out);
 size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in);
+/* Stock-stream interoperability. READING needs no switch: sz3hip_decompress decodes stock SZ3 streams of the
+ * interpolation compressor (cmprAlgo ALGO_INTERP = 2, float / double, 1-D .. 4-D — what the reference's default ALGO_INTERP_LORENZO
+ * writes for anything but some 1-D arrays) and of ALGO_LOSSLESS, next to this library's own ids 16 / 17; the reconstruction is the
+ * reference's bit for bit. WRITING: sz3hip_set_stock_format(1) (or SZ3HIP_STOCK_FORMAT=1 in the environment) makes sz3hip_compress —
+ * and everything on top of it — write ALGO_INTERP streams stock SZ3 reads whenever the interpolation predictor is chosen; other
+ * outcomes (Lorenzo, regression) keep this library's ids. Prediction, quantisation and reconstruction run on the GPU either way; the
+ * reference's Huffman container and zstd are host stages. */
+void sz3hip_set_stock_format(int on);
+int sz3hip_get_stock_format(void);
 /* the same over at most `avail` readable bytes: 0 when the serialised Config does not fit in them (truncated stream) */
 size_t sz3hip_config_load_n(sz3hip_config *c, const unsigned char *in, size_t avail);
 /* SZ_compress_size_bound<T> (api/impl/SZImpl.hpp:34-44) */

@@ -28,6 +28,7 @@
 #include "../../include/sz3hip.h"
 #include "sz3hip_format.h"
 #include "sz3hip_internal.h"
+#include "sz3hip_stock_geom.h"
 #include "sz3hip_kernels.h"
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1609,6 +1610,70 @@ extern "C" void sz3hip_ctx_set_speculation(sz3hip_ctx *ctx, int off) { ctx->spec
 // same book); 0 (the device API's default): the previous book also stands when it is complete over this call's alphabet and codes
 // it within 1/1024 of this call's own book's size — the payload then depends on the context's history, its size by < 0.1 %
 extern "C" void sz3hip_ctx_set_deterministic(sz3hip_ctx *ctx, int on) { ctx->spec_exact = on ? 1 : 0; }
+// ---- stock-stream interoperability: the device work between this library's per-element codes and the reference's emission order ----
+int szi_stock_stage1_outcome(sz3hip_ctx *ctx, szi_stock_params *out, uint64_t *n_unpred, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->stage1_done) return fail(SZ3HIP_EINVAL, "no pending stage 1");
+    if (ctx->proto.predictor != 1) return fail(SZ3HIP_EUNSUPPORTED, "stage 1 did not take the interpolation predictor");
+    uint64_t nv = 0;
+    HIPCHK(hipMemcpyAsync(&nv, ctx->d_counters + 0, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (nv > ctx->cur_out_cap) return fail(SZ3HIP_EOUTLIERS, "outlier capacity exceeded (%llu): data not compressible at this bound", (unsigned long long)ctx->cur_out_cap);
+    const szh_header &h = ctx->proto;
+    memset(out, 0, sizeof(*out));
+    out->N = h.ndim;
+    for (int i = 0; i < h.ndim; i++) out->dims[i] = h.dims[4 - h.ndim + i];
+    out->interp_id = (int)h.interp_id;
+    out->direction = (int)h.interp_dir;
+    out->anchor_stride = h.anchor_stride;
+    out->alpha = h.interp_alpha;
+    out->beta = h.interp_beta;
+    out->eb = h.eb;
+    out->radius = (int)h.radius;
+    *n_unpred = nv;
+    return 0;
+}
+int szi_stock_export(sz3hip_ctx *ctx, const szg_geom *g, const uint64_t *d_blk_base, uint16_t *d_em, void *d_unpred, uint64_t n_unpred,
+                     uint32_t *d_tile_cnt, uint64_t *d_tile_base, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (szk_launch_stock_from_elem(ctx->dtype, g, d_blk_base, ctx->d_codes, ctx->d_vout_idx, ctx->d_vout_val, n_unpred, d_tile_cnt, d_tile_base, d_em, d_unpred, s))
+        return fail(SZ3HIP_EHIP, "stock export kernels failed");
+    ctx->stage1_done = ctx->stage2_done = false;  // (this call ends here: no device payload is made of it)
+    return 0;
+}
+int szi_stock_import(sz3hip_ctx *ctx, const szi_stock_params *p, const szg_geom *g, const uint64_t *d_blk_base, const uint16_t *d_em,
+                     const void *d_unpred, uint64_t n_unpred, uint32_t *d_tile_cnt, uint64_t *d_tile_base, uint64_t *d_vout_idx, void *d_vout_val,
+                     uint32_t *d_bad, void *d_out, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    uint64_t num = 1;
+    for (int i = 0; i < p->N; i++) num *= p->dims[i];
+    if (num > ctx->max_n) return fail(SZ3HIP_EINVAL, "array exceeds the context capacity");
+    HIPCHK(hipMemsetAsync(d_bad, 0, 4, s));
+    if (szk_launch_stock_to_elem(ctx->dtype, g, d_blk_base, d_em, d_unpred, n_unpred, d_tile_cnt, d_tile_base, ctx->d_codes, d_vout_idx, d_vout_val, d_bad, s))
+        return fail(SZ3HIP_EHIP, "stock import kernels failed");
+    szk_interp_params ip;
+    memset(&ip, 0, sizeof(ip));
+    ip.N = p->N;
+    for (int i = 0; i < p->N; i++) ip.dims[i] = p->dims[i];
+    ip.interp_id = p->interp_id;
+    ip.direction = p->direction;
+    ip.anchor_stride = p->anchor_stride;
+    ip.alpha = p->alpha;
+    ip.beta = p->beta;
+    ip.eb = p->eb;
+    ip.radius = p->radius;
+    // (the lists are the caller's own arrays: handed over as offsets from a null base)
+    if (szk_launch_interp_decompress(ctx->dtype, &ip, nullptr, (uint64_t)(uintptr_t)d_vout_idx, (uint64_t)(uintptr_t)d_vout_val, n_unpred, ctx->d_codes, d_out, s))
+        return fail(SZ3HIP_EHIP, "interpolation decoder launch failed");
+    uint32_t bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (bad) return fail(SZ3HIP_EFORMAT, "corrupt stock stream: its codes and its list of unpredictable values do not fit together");
+    return 0;
+}
 extern "C" int sz3hip_last_call_fused(const sz3hip_ctx *ctx) { return ctx->last_fused ? 1 : 0; }
 extern "C" void sz3hip_ctx_set_fused(sz3hip_ctx *ctx, int on) { ctx->fuse_on = on != 0; }
 extern "C" void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses) {

@@ -36,6 +36,8 @@
 #include "../../include/sz3c.h"
 #include "../../include/sz3hip.h"
 #include "sz3hip_internal.h"
+#include "sz3hip_stock_geom.h"
+#include "sz3hip_stock_host.h"
 
 #define fail szi_fail
 #define HIPCHK(call)                                                                              \
@@ -546,6 +548,119 @@ int job_stage1(SlabJob &j) {
     return 0;
 }
 
+// ---- stock SZ3 streams: ALGO_INTERP read and written; sz3hip_stock.hip / sz3hip_stock_host.cpp ----
+std::atomic<int> g_stock_format{-1};
+// the slot's payload buffer, carved up for the permutation kernels: emission-order codes, unpredictable values (+ their list form),
+// the zero counts' tiles, the geometry's per-block bases
+struct StockBufs {
+    uint16_t *em;
+    void *unpred;
+    uint64_t *vidx;
+    void *vval;
+    uint32_t *tile_cnt;
+    uint64_t *tile_base;
+    uint64_t *blk_base;
+    uint32_t *bad;
+};
+int stock_bufs(HostSlot *s, uint64_t n, uint64_t n_unpred, size_t nblk, size_t tsize, StockBufs &b) {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t ntiles = (size_t)((n + 1023) / 1024);
+    const size_t sz_em = up((size_t)n * 2), sz_un = up((size_t)n_unpred * tsize + 8), sz_vi = up((size_t)n_unpred * 8 + 8), sz_tc = up(ntiles * 4),
+                 sz_tb = up((ntiles + 1) * 8), sz_bb = up(nblk * 8 + 8);
+    const size_t total = sz_em + 2 * sz_un + sz_vi + sz_tc + sz_tb + sz_bb + 256;
+    if (ensure_dev(&s->dev_payload, &s->dev_payload_bytes, total)) return SZ3HIP_EHIP;
+    uint8_t *p = (uint8_t *)s->dev_payload;
+    b.em = (uint16_t *)p; p += sz_em;
+    b.unpred = p; p += sz_un;
+    b.vval = p; p += sz_un;
+    b.vidx = (uint64_t *)p; p += sz_vi;
+    b.tile_cnt = (uint32_t *)p; p += sz_tc;
+    b.tile_base = (uint64_t *)p; p += sz_tb;
+    b.blk_base = (uint64_t *)p; p += sz_bb;
+    b.bad = (uint32_t *)p;
+    return 0;
+}
+// 0: j.out holds [u64 rawLen][zstd frames] of a stock stream and j.conf names it; SZ3HIP_EUNSUPPORTED: stage 1 took another predictor
+int stock_encode_interp(SlabJob &j) {
+    HostSlot *s = j.slot;
+    sz3hip_ctx *ctx = s->ctx;
+    szi_stock_params sp;
+    uint64_t n_unpred = 0;
+    int rc = szi_stock_stage1_outcome(ctx, &sp, &n_unpred, s->stream);
+    if (rc) return rc;
+    szg_geom g;
+    std::vector<uint64_t> bb;
+    if (szk_stock_geom_build(sp.N, sp.dims, sp.interp_id, sp.direction, sp.anchor_stride, &g, &bb)) return fail(SZ3HIP_EINVAL, "stock stream: unsupported geometry");
+    const size_t tsize = j.cdt == SZ3HIP_FLOAT ? 4 : 8;
+    StockBufs b;
+    if (stock_bufs(s, g.n, n_unpred, bb.size(), tsize, b)) return SZ3HIP_EHIP;
+    HIPCHK(hipMemcpyAsync(b.blk_base, bb.data(), bb.size() * 8, hipMemcpyHostToDevice, s->stream));
+    rc = szi_stock_export(ctx, &g, b.blk_base, b.em, b.unpred, n_unpred, b.tile_cnt, b.tile_base, s->stream);
+    if (rc) return rc;
+    std::vector<uint16_t> em((size_t)g.n);
+    std::vector<uint8_t> un((size_t)n_unpred * tsize + 8);
+    HIPCHK(hipMemcpyAsync(em.data(), b.em, (size_t)g.n * 2, hipMemcpyDeviceToHost, s->stream));
+    if (n_unpred) HIPCHK(hipMemcpyAsync(un.data(), b.unpred, (size_t)n_unpred * tsize, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (j.tm) j.tm->lap("device compress + codes to the host");
+    std::vector<uint8_t> raw;
+    stock::serialise_interp(sp, g.anchor, em.data(), g.n, un.data(), n_unpred, tsize, raw);
+    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap);  // (concatenated frames: ZSTD_decompress, which stock SZ3 calls, decodes them all)
+    if (!j.out_size) return sz3hip_last_error_code();
+    if (j.tm) j.tm->lap("Huffman (reference container) + zstd");
+    j.conf.cmprAlgo = SZ3HIP_ALGO_INTERP;
+    j.conf.interpAlgo = (uint8_t)sp.interp_id;
+    j.conf.interpDirection = (uint8_t)sp.direction;
+    j.conf.interpAnchorStride = (int32_t)g.anchor;
+    j.conf.interpAlpha = sp.alpha;
+    j.conf.interpBeta = sp.beta;
+    if ((double)j.raw_bytes / (double)j.out_size < 3) {  // SZDispatcher.hpp:62-74
+        std::vector<uint8_t> z(zs::bound_frames(j.raw_bytes) + 8);
+        size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size());
+        if (zsz && zsz < j.out_size && zsz <= j.out_cap) {
+            memcpy(j.out, z.data(), zsz);
+            j.out_size = zsz;
+            j.conf.cmprAlgo = SZ3HIP_ALGO_LOSSLESS;
+        }
+    }
+    return 0;
+}
+int stock_decompress_interp(HostSlot *s, const sz3hip_config *conf, int dataType, const unsigned char *p, size_t payload, void *decData) {
+    const int cdt = dtype_compute(dataType);
+    const size_t tsize = cdt == SZ3HIP_FLOAT ? 4 : 8;
+    if (payload < 8) return fail(SZ3HIP_EFORMAT, "truncated payload");
+    uint64_t raw_len;
+    memcpy(&raw_len, p, 8);
+    if (raw_len < 64 || raw_len > (uint64_t)conf->num * 16 + (1u << 22)) return fail(SZ3HIP_EFORMAT, "implausible payload length in the lossless block");
+    std::vector<uint8_t> raw((size_t)raw_len);
+    if (zs::decompress_frames(p, payload, raw.data(), (size_t)raw_len) != raw_len) return SZ3HIP_EZSTD;
+    szi_stock_params sp;
+    std::vector<uint16_t> em;
+    const uint8_t *unpred = nullptr;
+    uint64_t n_unpred = 0;
+    if (!stock::parse_interp(raw.data(), raw.size(), conf->N, tsize, sp, em, unpred, n_unpred))
+        return fail(SZ3HIP_EFORMAT, "corrupt stock ALGO_INTERP stream (decomposition header, Huffman tree or bit stream)");
+    for (int i = 0; i < conf->N; i++)
+        if (sp.dims[i] != conf->dims[i]) return fail(SZ3HIP_EFORMAT, "the stream's extents do not match its Config");
+    szg_geom g;
+    std::vector<uint64_t> bb;
+    if (szk_stock_geom_build(sp.N, sp.dims, sp.interp_id, sp.direction, sp.anchor_stride, &g, &bb)) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (geometry)");
+    if (g.anchor != sp.anchor_stride) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (anchor stride)");
+    HIPCHK(hipSetDevice(s->device));
+    int rc;
+    if ((rc = slot_ctx(s, conf->num))) return rc;
+    if ((rc = ensure_dev(&s->dev_in, &s->dev_in_bytes, (size_t)conf->num * tsize))) return rc;
+    StockBufs b;
+    if (stock_bufs(s, g.n, n_unpred, bb.size(), tsize, b)) return SZ3HIP_EHIP;
+    HIPCHK(hipMemcpyAsync(b.blk_base, bb.data(), bb.size() * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(b.em, em.data(), (size_t)g.n * 2, hipMemcpyHostToDevice, s->stream));
+    if (n_unpred) HIPCHK(hipMemcpyAsync(b.unpred, unpred, (size_t)n_unpred * tsize, hipMemcpyHostToDevice, s->stream));
+    rc = szi_stock_import(s->ctx, &sp, &g, b.blk_base, b.em, b.unpred, n_unpred, b.tile_cnt, b.tile_base, b.vidx, b.vval, b.bad, s->dev_in, s->stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(decData, s->dev_in, (size_t)conf->num * tsize, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // phase 3: code book + encode on the device, payload to the host, lossless stage, the dispatcher's fallbacks
 int job_encode(SlabJob &j) {
     if (j.rc) return j.rc;
@@ -554,6 +669,14 @@ int job_encode(SlabJob &j) {
         (void)hipSetDevice(s->device);
         sz3hip_ctx *ctx = s->ctx;
         size_t dsize = 0;
+        if (g_stock_format.load() > 0 && !j.is_int && !j.conf.openmp) {
+            // the caller wants files stock SZ3 reads: where stage 1 took the interpolation predictor its codes go into the reference's
+            // own container (cmprAlgo ALGO_INTERP) instead of the device payload
+            const int rs = stock_encode_interp(j);
+            if (rs == 0) return 0;
+            if (rs != SZ3HIP_EUNSUPPORTED) return j.failed(rs);
+            // (another predictor: there is no stock form of it here — this library's own stream)
+        }
         int rc = sz3hip_compress_stage2(ctx, s->dev_payload, s->dev_payload_bytes, s->stream);
         if (!rc) rc = sz3hip_compress_finish(ctx, &dsize, s->stream);
         if (j.tm) j.tm->lap("device compress");
@@ -809,9 +932,15 @@ size_t compress_slabs(sz3hip_config &conf, int dataType, const void *data, unsig
 }
 }  // namespace
 
+// 1: sz3hip_compress (and everything on top of it: SZ_compress<T>, SZ_compress_args, the CLI, the HDF5 filter) writes streams stock SZ3
+// reads wherever this library has a stock form — ALGO_INTERP, which is what the reference's default ALGO_INTERP_LORENZO resolves to
+// on anything but some 1-D arrays; other outcomes keep this library's own ids. Default: the environment's SZ3HIP_STOCK_FORMAT (else 0).
+extern "C" void sz3hip_set_stock_format(int on) { g_stock_format.store(on ? 1 : 0); }
+extern "C" int sz3hip_get_stock_format(void) { return g_stock_format.load() > 0 ? 1 : 0; }
 extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, const void *data, char *cmpData,
                                   size_t cmpCap) {
     HostTimer tm;
+    if (g_stock_format.load() < 0) g_stock_format.store(env_int("SZ3HIP_STOCK_FORMAT", 0) ? 1 : 0);
     if (!dtype_ok(dataType)) {
         fail(SZ3HIP_EUNSUPPORTED, "dataType %d is not one of SZ_FLOAT .. SZ_INT64 (0 .. 9)", dataType);
         return 0;
@@ -1107,10 +1236,12 @@ int decompress_blob(HostSlot *s, const sz3hip_config *conf, int dataType, const 
         if (len != raw_bytes) return fail(SZ3HIP_EFORMAT, "Decompressed data size does not match the original data size");
         return zs::decompress_frames(p, payload, (uint8_t *)decData, raw_bytes) == raw_bytes ? 0 : SZ3HIP_EZSTD;
     }
+    if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP && !is_int)  // a stock SZ3 stream of the interpolation compressor (SZDispatcher.hpp:89-91)
+        return stock_decompress_interp(s, conf, dataType, p, payload, decData);
     if (conf->cmprAlgo != SZ3HIP_ALGO_HIP_LORENZO && conf->cmprAlgo != SZ3HIP_ALGO_HIP_INTERP)
         return fail(SZ3HIP_EUNSUPPORTED,
-                    "stream uses cmprAlgo %d of the CPU reference; this library decodes only its own GPU streams (ids %d, %d) "
-                    "and ALGO_LOSSLESS",
+                    "stream uses cmprAlgo %d of the CPU reference; this library decodes its own GPU streams (ids %d, %d), stock ALGO_INTERP "
+                    "streams of float / double arrays and ALGO_LOSSLESS",
                     conf->cmprAlgo, SZ3HIP_ALGO_HIP_LORENZO, SZ3HIP_ALGO_HIP_INTERP);
     if (payload < 8) return fail(SZ3HIP_EFORMAT, "truncated payload");
     uint64_t raw_len;

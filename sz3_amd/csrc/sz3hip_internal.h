@@ -14,6 +14,26 @@
 // records code + message for sz3hip_last_error() (thread-local) and returns code
 int szi_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 struct sz3hip_ctx;
+// ---- stock-stream interoperability (sz3hip_stock.hip, sz3hip_stock_host.cpp) ----
+struct szg_geom;
+struct szi_stock_params {  // what InterpolationDecomposition::save holds besides the quantizer (decomposition/InterpolationDecomposition.hpp:149-159)
+    int N;
+    uint64_t dims[4];
+    int interp_id, direction;
+    uint64_t anchor_stride;
+    double alpha, beta, eb;
+    int radius;
+};
+// after sz3hip_compress_stage1 chose interpolation (header predictor 1): waits for it, reports its parameters and the number of
+// unpredictable values (the anchor grid included); SZ3HIP_EUNSUPPORTED when stage 1 took another predictor
+int szi_stock_stage1_outcome(sz3hip_ctx *ctx, szi_stock_params *out, uint64_t *n_unpred, void *stream);
+// ... then the codes in the reference's emission order and the quantizer's list of unpredictable values, into the caller's buffers
+int szi_stock_export(sz3hip_ctx *ctx, const szg_geom *g, const uint64_t *d_blk_base, uint16_t *d_em, void *d_unpred, uint64_t n_unpred,
+                     uint32_t *d_tile_cnt, uint64_t *d_tile_base, void *stream);
+// the inverse: emission-order codes + unpredictable values of a stock ALGO_INTERP stream -> the reconstructed array
+int szi_stock_import(sz3hip_ctx *ctx, const szi_stock_params *p, const szg_geom *g, const uint64_t *d_blk_base, const uint16_t *d_em,
+                     const void *d_unpred, uint64_t n_unpred, uint32_t *d_tile_cnt, uint64_t *d_tile_base, uint64_t *d_vout_idx, void *d_vout_val,
+                     uint32_t *d_bad, void *d_out, void *stream);
 void *szi_histogram_for_exchange(sz3hip_ctx *ctx);  // the histogram, for the library's own all-reduce between the stages (sz3hip_api.cpp)
 
 struct Writer {

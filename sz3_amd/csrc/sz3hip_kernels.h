@@ -326,6 +326,20 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
 int szk_launch_book_verdict(const szk_cb_info *fresh, const uint8_t *fresh_lens, const szk_cb_info *used, const uint8_t *used_lens,
                             const uint32_t *mispredict, const uint32_t *range, szk_state *state,
                             const uint64_t *hist /* this call's histogram */, int exact /* see szk_encode_roles::exact */, hipStream_t s);
+// stock-stream interoperability (sz3hip_stock.hip): permutations between the reference's emission order and element order
+struct szg_geom;
+int szk_launch_stock_to_elem(int dtype, const szg_geom *g, const uint64_t *d_blk_base, const uint16_t *d_em, const void *d_unpred, uint64_t n_unpred,
+                             uint32_t *d_tile_cnt, uint64_t *d_tile_base, uint16_t *d_codes, uint64_t *d_vout_idx, void *d_vout_val, uint32_t *d_bad,
+                             hipStream_t s);
+int szk_launch_stock_from_elem(int dtype, const szg_geom *g, const uint64_t *d_blk_base, const uint16_t *d_codes, const uint64_t *d_vout_idx,
+                               const void *d_vout_val, uint64_t n_vout, uint32_t *d_tile_cnt, uint64_t *d_tile_base, uint16_t *d_em, void *d_unpred,
+                               hipStream_t s);
+int szk_launch_stock_ranks(const szg_geom *g, const uint64_t *d_blk_base, uint64_t *d_rank, hipStream_t s);
+#ifdef __cplusplus
+#include <vector>
+// the geometry of an array under InterpolationDecomposition::init (:176-213) and the per-block bases of its emission order; 0 on success
+int szk_stock_geom_build(int N, const uint64_t *dims, int interp_id, int direction, uint64_t anchor_stride, szg_geom *g, std::vector<uint64_t> *blk_base);
+#endif
 // words of scratch a fused stage 1 over this view (extents slowest first, left-padded with 1) needs; 0: the shape does not take that form
 uint64_t szk_fuse_scratch_words(int ndim, const uint64_t d[4]);
 int szk_launch_hist_range(const uint64_t *d_hist, uint32_t *range /* [4], zeroed */, hipStream_t s);  // range and count of the non-empty bins

@@ -1,0 +1,394 @@
+// sz3_amd/csrc/sz3hip_stock_host.cpp — stock SZ3 streams of ALGO_INTERP read and written by this library.
+//
+// A stock stream's pre-zstd buffer (compressor/SZGenericCompressor.hpp:51-57) is
+//     [InterpolationDecomposition::save (decomposition/InterpolationDecomposition.hpp:149-159): u64 dims x N, u32 blocksize = 32,
+//      i32 interp id, i32 direction, u64 anchor stride, f64 alpha, f64 beta, LinearQuantizer::save (quantizer/LinearQuantizer.hpp:95-104):
+//      u8 uid = 2, f64 eb, i32 radius, u64 count, T x count]
+//     [HuffmanEncoder::save (encoder/HuffmanEncoder.hpp:108-125, 601-628): i32 offset, BE i32 nodeCount, BE i32 stateNum / 2, u8 endian,
+//      L / R child indices (1 / 2 / 4 bytes by nodeCount), i32 C x nodeCount, u8 t x nodeCount — node 0 the root, pre-order]
+//     [u64 number of codes][u64 bytes of the bit stream][bits, MSB first: left = 0, right = 1]
+// What runs where: prediction, quantisation and reconstruction are this library's interpolation kernels (bit-identical codes per
+// element) plus the permutation between element order and the reference's emission order (sz3hip_stock.hip); this
+// file is the container around them — the byte layout above and the Huffman stage in the reference's tree format, on the host
+// like the zstd stage behind it (lossless/Lossless_zstd.hpp:29-45). Any valid tree decodes in stock SZ3 (its decoder walks the
+// serialised tree, :225-255), so the tree built here need not be the reference's own; reconstruction is the reference's bit for bit.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <queue>
+#include <thread>
+#include <vector>
+
+#include "../../include/sz3hip.h"
+#include "sz3hip_internal.h"
+#include "sz3hip_stock_geom.h"
+#include "sz3hip_stock_host.h"
+
+int szk_stock_geom_build(int N, const uint64_t *dims, int interp_id, int direction, uint64_t anchor_stride, szg_geom *gp, std::vector<uint64_t> *blk_base);
+
+namespace stock {
+namespace {
+struct W {
+    std::vector<uint8_t> &b;
+    template <typename V> void put(V v) {
+        const size_t at = b.size();
+        b.resize(at + sizeof(V));
+        memcpy(b.data() + at, &v, sizeof(V));
+    }
+    void be32(uint32_t v) {
+        const uint8_t q[4] = {(uint8_t)(v >> 24), (uint8_t)(v >> 16), (uint8_t)(v >> 8), (uint8_t)v};
+        b.insert(b.end(), q, q + 4);
+    }
+    void bytes(const void *p, size_t n) {
+        const uint8_t *q = static_cast<const uint8_t *>(p);
+        b.insert(b.end(), q, q + n);
+    }
+};
+struct R {
+    const uint8_t *p, *end;
+    bool ok = true;
+    template <typename V> V get() {
+        V v{};
+        if ((size_t)(end - p) < sizeof(V)) {
+            ok = false;
+            return v;
+        }
+        memcpy(&v, p, sizeof(V));
+        p += sizeof(V);
+        return v;
+    }
+    uint32_t be32() {
+        if (end - p < 4) {
+            ok = false;
+            return 0;
+        }
+        const uint32_t v = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+        p += 4;
+        return v;
+    }
+};
+unsigned threads() {
+    unsigned t = std::thread::hardware_concurrency();
+    return t == 0 ? 4 : (t > 32 ? 32 : t);
+}
+template <typename F> void parallel(size_t n_items, F f) {  // f(begin, end, thread index)
+    const unsigned nt = (unsigned)std::min<size_t>(threads(), std::max<size_t>(1, n_items / (1u << 20)));
+    if (nt <= 1) {
+        f((size_t)0, n_items, 0u);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back([=] { f(n_items * t / nt, n_items * (t + 1) / nt, t); });
+    for (auto &x : th) x.join();
+}
+
+// ---- Huffman in the reference's container -------------------------------------------------------------------------------
+struct Tree {
+    std::vector<uint32_t> L, R;  // children of node i in pre-order numbering (0: none)
+    std::vector<int32_t> C;      // leaf: symbol - offset
+    std::vector<uint8_t> t;      // 1: leaf
+};
+struct Code {
+    uint64_t bits;
+    uint32_t len;
+};
+// an optimal prefix code over the symbols with freq > 0 (heap merge), as a pre-order tree + the code of every symbol
+void build_tree(const std::vector<uint64_t> &freq, Tree &tr, std::vector<Code> &codes) {
+    struct N {
+        uint64_t f;
+        int l, r, sym;
+    };
+    std::vector<N> nodes;
+    typedef std::pair<uint64_t, int> QE;  // (frequency, node): ties by creation order
+    std::priority_queue<QE, std::vector<QE>, std::greater<QE>> q;
+    for (size_t s = 0; s < freq.size(); s++)
+        if (freq[s]) {
+            nodes.push_back({freq[s], -1, -1, (int)s});
+            q.push({freq[s], (int)nodes.size() - 1});
+        }
+    while (q.size() > 1) {
+        const QE a = q.top();
+        q.pop();
+        const QE b = q.top();
+        q.pop();
+        nodes.push_back({a.first + b.first, a.second, b.second, -1});
+        q.push({a.first + b.first, (int)nodes.size() - 1});
+    }
+    const int root = q.top().second;
+    const size_t nc = nodes.size();
+    tr.L.assign(nc, 0);
+    tr.R.assign(nc, 0);
+    tr.C.assign(nc, 0);
+    tr.t.assign(nc, 0);
+    codes.assign(freq.size(), Code{0, 0});
+    // pre-order numbering like pad_tree (:601-616): a node, its left subtree, its right subtree
+    struct Fr {
+        int node;
+        uint32_t id;
+        uint64_t bits;
+        uint32_t len;
+        int stage;
+    };
+    std::vector<Fr> st;
+    uint32_t next = 0;
+    st.push_back({root, next++, 0, 0, 0});
+    while (!st.empty()) {
+        Fr &f = st.back();
+        const N &nd = nodes[f.node];
+        if (nd.sym >= 0) {
+            tr.t[f.id] = 1;
+            tr.C[f.id] = nd.sym;
+            codes[nd.sym] = Code{f.bits, f.len};
+            st.pop_back();
+            continue;
+        }
+        if (f.stage == 0) {
+            f.stage = 1;
+            const uint32_t id = next++;
+            tr.L[f.id] = id;
+            st.push_back({nd.l, id, f.bits << 1, f.len + 1, 0});
+        } else if (f.stage == 1) {
+            f.stage = 2;
+            const uint32_t id = next++;
+            tr.R[f.id] = id;
+            st.push_back({nd.r, id, (f.bits << 1) | 1, f.len + 1, 0});
+        } else {
+            st.pop_back();
+        }
+    }
+}
+void save_tree(W &w, const Tree &tr, int32_t offset, uint32_t state_num) {
+    const uint32_t nc = (uint32_t)tr.t.size();
+    w.put<int32_t>(offset);
+    w.be32(nc);
+    w.be32(state_num / 2);
+    w.put<uint8_t>(0);  // little endian
+    auto idx = [&](const std::vector<uint32_t> &v) {
+        for (uint32_t x : v) {
+            if (nc <= 256) w.put<uint8_t>((uint8_t)x);
+            else if (nc <= 65536) w.put<uint16_t>((uint16_t)x);
+            else w.put<uint32_t>(x);
+        }
+    };
+    idx(tr.L);
+    idx(tr.R);
+    w.bytes(tr.C.data(), nc * 4);
+    w.bytes(tr.t.data(), nc);
+}
+bool load_tree(R &r, Tree &tr, int32_t &offset) {
+    offset = r.get<int32_t>();
+    const uint32_t nc = r.be32();
+    (void)r.be32();  // stateNum / 2: sizes the reference's node pool
+    (void)r.get<uint8_t>();
+    if (!r.ok || nc == 0 || nc > (1u << 18)) return false;  // (at most 65536 symbols: 131071 nodes)
+    const size_t w = nc <= 256 ? 1 : (nc <= 65536 ? 2 : 4);
+    if ((size_t)(r.end - r.p) < (size_t)nc * (2 * w + 5)) return false;
+    tr.L.resize(nc);
+    tr.R.resize(nc);
+    tr.C.resize(nc);
+    tr.t.resize(nc);
+    auto idx = [&](std::vector<uint32_t> &v) {
+        for (uint32_t i = 0; i < nc; i++) {
+            uint32_t x = 0;
+            memcpy(&x, r.p, w);
+            r.p += w;
+            v[i] = x;
+        }
+    };
+    idx(tr.L);
+    idx(tr.R);
+    memcpy(tr.C.data(), r.p, (size_t)nc * 4);
+    r.p += (size_t)nc * 4;
+    memcpy(tr.t.data(), r.p, nc);
+    r.p += nc;
+    for (uint32_t i = 0; i < nc; i++)
+        if (tr.L[i] >= nc || tr.R[i] >= nc) return false;
+    return true;
+}
+// bits of n codes, MSB first. Threads code contiguous ranges into buffers of their own; the ranges are then joined with the
+// bit shift their predecessors' total leaves them.
+void encode_bits(const uint16_t *em, uint64_t n, int32_t offset, const std::vector<Code> &codes, std::vector<uint8_t> &out) {
+    const unsigned nt = (unsigned)std::min<uint64_t>(threads(), std::max<uint64_t>(1, n / (1u << 20)));
+    std::vector<std::vector<uint8_t>> part(nt);
+    std::vector<uint64_t> pbits(nt, 0);
+    auto work = [&](unsigned t) {
+        const uint64_t a = n * t / nt, b = n * (t + 1) / nt;
+        std::vector<uint8_t> &o = part[t];
+        o.reserve((b - a) / 2 + 64);
+        uint64_t acc = 0;  // bits collected, left-aligned in the low `have` bits
+        uint32_t have = 0;
+        uint64_t total = 0;
+        for (uint64_t i = a; i < b; i++) {
+            const Code &c = codes[(int32_t)em[i] - offset];
+            uint32_t len = c.len;
+            uint64_t bits = c.bits;
+            total += len;
+            while (len) {  // (code words of more than 56 bits come in two pieces)
+                const uint32_t take = std::min<uint32_t>(len, 56 - have);
+                acc = (acc << take) | ((bits >> (len - take)) & ((take == 64 ? ~0ull : (1ull << take)) - 1));
+                have += take;
+                len -= take;
+                while (have >= 8) {
+                    o.push_back((uint8_t)(acc >> (have - 8)));
+                    have -= 8;
+                }
+            }
+        }
+        if (have) o.push_back((uint8_t)(acc << (8 - have)));
+        pbits[t] = total;
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    uint64_t total = 0;
+    for (unsigned t = 0; t < nt; t++) total += pbits[t];
+    out.assign((total + 7) / 8 + 8, 0);
+    uint64_t at = 0;
+    for (unsigned t = 0; t < nt; t++) {
+        const uint32_t sh = (uint32_t)(at & 7);
+        uint8_t *d = out.data() + (at >> 3);
+        const std::vector<uint8_t> &o = part[t];
+        const size_t nb = (pbits[t] + 7) / 8;
+        if (sh == 0) {
+            memcpy(d, o.data(), nb);
+        } else {
+            for (size_t k = 0; k < nb; k++) {
+                d[k] |= (uint8_t)(o[k] >> sh);
+                d[k + 1] |= (uint8_t)(o[k] << (8 - sh));
+            }
+        }
+        at += pbits[t];
+    }
+    out.resize((total + 7) / 8);
+}
+// HuffmanEncoder::decode (:225-255): walk the tree bit by bit — through a 12-bit table of where twelve bits lead from the root
+bool decode_bits(const Tree &tr, int32_t offset, const uint8_t *bits, size_t nbytes, uint64_t n, uint16_t *em) {
+    if (tr.t[0]) {  // a single symbol: no bits at all (:233-237)
+        const int32_t v = tr.C[0] + offset;
+        if (v < 0 || v > 65535) return false;
+        for (uint64_t i = 0; i < n; i++) em[i] = (uint16_t)v;
+        return true;
+    }
+    const uint32_t LB = 12;
+    struct E {
+        uint32_t node;  // where the bits lead (a leaf: the symbol's node)
+        uint8_t used;   // bits consumed to get there (a leaf may be reached early)
+        uint8_t leaf;
+    };
+    std::vector<E> lut(1u << LB);
+    for (uint32_t v = 0; v < (1u << LB); v++) {
+        uint32_t nd = 0, used = 0;
+        while (used < LB && !tr.t[nd]) {
+            nd = ((v >> (LB - 1 - used)) & 1) ? tr.R[nd] : tr.L[nd];
+            used++;
+            if (nd == 0) break;  // (a missing child: corrupt tree — stops at the root, caught below as an endless walk)
+        }
+        lut[v] = {nd, (uint8_t)used, (uint8_t)(tr.t[nd] ? 1 : 0)};
+    }
+    const uint64_t total_bits = (uint64_t)nbytes * 8;
+    uint64_t pos = 0;
+    auto peek = [&](uint64_t at) -> uint32_t {  // twelve bits from `at`, zeros beyond the end
+        uint32_t v = 0;
+        const uint64_t by = at >> 3;
+        for (int k = 0; k < 3; k++) v = (v << 8) | (by + k < nbytes ? bits[by + k] : 0u);
+        return (v >> (24 - LB - (at & 7))) & ((1u << LB) - 1);
+    };
+    for (uint64_t i = 0; i < n; i++) {
+        E e = lut[peek(pos)];
+        pos += e.used;
+        uint32_t nd = e.node;
+        while (!tr.t[nd]) {  // code words beyond twelve bits: one by one
+            if (pos >= total_bits || e.used == 0) return false;
+            const uint32_t bit = (bits[pos >> 3] >> (7 - (pos & 7))) & 1;
+            nd = bit ? tr.R[nd] : tr.L[nd];
+            if (nd == 0) return false;
+            pos++;
+        }
+        if (pos > total_bits) return false;
+        const int32_t v = tr.C[nd] + offset;
+        if (v < 0 || v > 65535) return false;
+        em[i] = (uint16_t)v;
+    }
+    return true;
+}
+}  // namespace
+
+// the pre-zstd buffer of a stock ALGO_INTERP stream from emission-order codes and the quantizer's unpredictable values
+void serialise_interp(const szi_stock_params &p, uint64_t anchor_effective, const uint16_t *em, uint64_t n, const void *unpred, uint64_t n_unpred, size_t tsize,
+                      std::vector<uint8_t> &raw) {
+    raw.clear();
+    raw.reserve((size_t)(n / 2 + n_unpred * tsize + (1u << 16)));
+    W w{raw};
+    for (int i = 0; i < p.N; i++) w.put<uint64_t>(p.dims[i]);
+    w.put<uint32_t>(32);  // blocksize (:87)
+    w.put<int32_t>(p.interp_id);
+    w.put<int32_t>(p.direction);
+    w.put<uint64_t>(anchor_effective);
+    w.put<double>(p.alpha);
+    w.put<double>(p.beta);
+    w.put<uint8_t>(2);  // LinearQuantizer uid (:131)
+    w.put<double>(p.eb);
+    w.put<int32_t>(p.radius);
+    w.put<uint64_t>(n_unpred);
+    if (n_unpred) w.bytes(unpred, (size_t)n_unpred * tsize);
+    // frequencies over [min, max] of the codes (HuffmanEncoder::init, :516-537)
+    const unsigned nt = threads();
+    std::vector<std::vector<uint64_t>> hist(nt, std::vector<uint64_t>(65536, 0));
+    parallel((size_t)n, [&](size_t a, size_t b, unsigned t) {
+        uint64_t *h = hist[t].data();
+        for (size_t i = a; i < b; i++) h[em[i]]++;
+    });
+    std::vector<uint64_t> all(65536, 0);
+    for (auto &h : hist)
+        for (int s = 0; s < 65536; s++) all[s] += h[s];
+    int lo = 0, hi = 65535;
+    while (lo < 65535 && !all[lo]) lo++;
+    while (hi > lo && !all[hi]) hi--;
+    std::vector<uint64_t> freq(all.begin() + lo, all.begin() + hi + 1);
+    Tree tr;
+    std::vector<Code> codes;
+    build_tree(freq, tr, codes);
+    save_tree(w, tr, lo, (uint32_t)(hi - lo + 2));
+    w.put<uint64_t>(n);
+    std::vector<uint8_t> bits;
+    if (tr.t[0] == 0) encode_bits(em, n, lo, codes, bits);
+    w.put<uint64_t>(bits.size());
+    w.bytes(bits.data(), bits.size());
+}
+// the inverse; false: not a well-formed stream of this kind
+bool parse_interp(const uint8_t *raw, size_t len, int N, size_t tsize, szi_stock_params &p, std::vector<uint16_t> &em, const uint8_t *&unpred, uint64_t &n_unpred) {
+    R r{raw, raw + len};
+    memset(&p, 0, sizeof(p));
+    p.N = N;
+    for (int i = 0; i < N; i++) p.dims[i] = r.get<uint64_t>();
+    const uint32_t blocksize = r.get<uint32_t>();
+    p.interp_id = r.get<int32_t>();
+    p.direction = r.get<int32_t>();
+    p.anchor_stride = r.get<uint64_t>();
+    p.alpha = r.get<double>();
+    p.beta = r.get<double>();
+    const uint8_t uid = r.get<uint8_t>();
+    p.eb = r.get<double>();
+    p.radius = r.get<int32_t>();
+    n_unpred = r.get<uint64_t>();
+    if (!r.ok || blocksize != 32 || uid != 2 || p.interp_id < 0 || p.interp_id > 1 || !(p.eb > 0) || p.radius < 1 || p.radius > 32768) return false;
+    if ((uint64_t)(r.end - r.p) / tsize < n_unpred) return false;
+    unpred = r.p;
+    r.p += (size_t)n_unpred * tsize;
+    Tree tr;
+    int32_t offset = 0;
+    if (!load_tree(r, tr, offset)) return false;
+    const uint64_t n = r.get<uint64_t>();
+    const uint64_t nbytes = r.get<uint64_t>();
+    uint64_t want = 1;
+    for (int i = 0; i < N; i++) want *= p.dims[i];
+    if (!r.ok || n != want || (uint64_t)(r.end - r.p) < nbytes) return false;
+    em.resize((size_t)n);
+    return decode_bits(tr, offset, r.p, (size_t)nbytes, n, em.data());
+}
+}  // namespace stock

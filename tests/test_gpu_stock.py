@@ -1,0 +1,133 @@
+"""GPU tests (-m gpu) of stock-stream interoperability: stock SZ3 streams of the interpolation compressor
+(cmprAlgo ALGO_INTERP — what the reference's default ALGO_INTERP_LORENZO writes) READ by this library, and streams WRITTEN by this
+library (sz3hip_set_stock_format) read by the reference. The stock side is played by the oracle — byte-identical to the reference
+built in this image (tests/test_oracle.py) — and, where oracle/_ref is present, by the reference library itself. Reconstruction is
+the reference's bit for bit in both directions (prediction, quantisation and reconstruction are the same arithmetic);
+only the Huffman tree's tie-breaking may differ, so stream sizes agree to a fraction of a percent, not to the byte."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import sz3_amd  # noqa: E402
+from fields import field1d, field2d, field3d, field4d  # noqa: E402
+from oracle_binding import (ALGO_INTERP, ALGO_INTERP_LORENZO, EB_REL, have_ref, make_config, oracle_compress, oracle_decompress,  # noqa: E402
+                            ref_compress, ref_decompress)
+
+CASES = [
+    ("3d-cubic", lambda: field3d((64, 80, 96)), 1e-3, dict(interp_algo=1)),
+    ("3d-linear-dir3", lambda: field3d((40, 66, 36)), 1e-2, dict(interp_algo=0, interpDirection=3)),
+    ("3d-ragged-anchor8", lambda: field3d((33, 47, 50)), 1e-3, dict(interp_algo=1, interpAnchorStride=8, interpAlpha=1.5, interpBeta=3.0)),
+    ("3d-noanchor", lambda: field3d((20, 21, 22)), 1e-3, dict(interp_algo=1, interpAnchorStride=0, interpDirection=5)),
+    ("3d-f64", lambda: field3d((40, 50, 37), np.float64, sigma=2e-6), 1e-6, dict(interp_algo=1)),
+    ("3d-nan-inf", lambda: _with_holes(field3d((30, 40, 50))), 1e-3, dict(interp_algo=1)),
+    ("1d", lambda: field1d(70001), 1e-3, dict(interp_algo=1)),
+    ("2d-linear", lambda: field2d((300, 500)), 1e-2, dict(interp_algo=0, interpDirection=1)),
+    ("4d", lambda: field4d((7, 20, 24, 28)), 1e-2, dict(interp_algo=1, interpDirection=11)),
+]
+
+
+def _with_holes(a):
+    a = a.copy()
+    f = a.reshape(-1)
+    f[np.random.default_rng(5).choice(f.size, 500, replace=False)] = np.nan
+    f[7] = np.inf
+    return a
+
+
+def _trailer_algo(blob):
+    """cmprAlgo in the Config trailer (utils/Config.hpp:312-354) via the library's own peek"""
+    import ctypes as C
+    c = sz3_amd.Config(1)
+    b = np.ascontiguousarray(np.frombuffer(bytes(blob), dtype=np.uint8))
+    assert sz3_amd.lib().sz3hip_peek_config(C.byref(c._c), b.ctypes.data, b.size) == 0
+    return c.cmprAlgo
+
+
+@pytest.mark.parametrize("name,gen,eb,kw", CASES, ids=[c[0] for c in CASES])
+def test_stock_interp_streams_are_read_bit_for_bit(name, gen, eb, kw):
+    a = gen()
+    oconf = make_config(a.shape, algo=ALGO_INTERP, abs_eb=eb, **kw)
+    blob = oracle_compress(a, oconf)                       # = the reference's bytes (tests/test_oracle.py)
+    want, _ = oracle_decompress(blob, a.dtype, a.shape)
+    assert _trailer_algo(blob) == sz3_amd.ALGO_INTERP
+    got, c2 = sz3_amd.decompress(blob, a.dtype, a.shape)
+    assert c2.cmprAlgo == sz3_amd.ALGO_INTERP
+    assert np.array_equal(got, want, equal_nan=True), "reconstruction differs from stock SZ3's"
+    if have_ref():
+        rblob = ref_compress(a, oconf)
+        got2, _ = sz3_amd.decompress(rblob, a.dtype, a.shape)
+        assert np.array_equal(got2, ref_decompress(rblob, a.dtype, a.shape), equal_nan=True)
+
+
+@pytest.mark.parametrize("name,gen,eb,kw", CASES, ids=[c[0] for c in CASES])
+def test_streams_written_in_stock_format_are_read_by_stock_sz3(name, gen, eb, kw):
+    a = gen()
+    L = sz3_amd.lib()
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_INTERP
+    conf.absErrorBound = eb
+    conf.interpAlgo = kw.get("interp_algo", 1)
+    for k in ("interpDirection", "interpAnchorStride", "interpAlpha", "interpBeta"):
+        if k in kw:
+            setattr(conf, k, kw[k])
+    L.sz3hip_set_stock_format(1)
+    try:
+        blob, ratio = sz3_amd.compress(a, conf)
+    finally:
+        L.sz3hip_set_stock_format(0)
+    assert _trailer_algo(blob) == sz3_amd.ALGO_INTERP      # a stock id, not 17
+    oconf = make_config(a.shape, algo=ALGO_INTERP, abs_eb=eb, **kw)
+    oblob = oracle_compress(a, oconf)
+    want, _ = oracle_decompress(oblob, a.dtype, a.shape)   # what stock SZ3 reconstructs from its own stream
+    got, _ = oracle_decompress(blob, a.dtype, a.shape)     # stock SZ3 reading OUR stream
+    assert np.array_equal(got, want, equal_nan=True)
+    if have_ref():
+        assert np.array_equal(ref_decompress(blob, a.dtype, a.shape), want, equal_nan=True)
+    mine, _ = sz3_amd.decompress(blob, a.dtype, a.shape)   # and this library reading it back
+    assert np.array_equal(mine, want, equal_nan=True)
+    assert abs(len(blob) - len(oblob)) <= 0.01 * len(oblob) + 64, (len(blob), len(oblob))  # same codes, an equally good tree
+
+
+def test_default_algorithm_in_stock_format_and_ids_without_the_switch():
+    """the reference's default (ALGO_INTERP_LORENZO: tuner, then interpolation) written in stock format: the tuner runs on the GPU, its
+    outcome goes into the stream's decomposition header, stock SZ3 reads it; REL bound through the range scan. Without the switch the
+    same call writes this library's id 17."""
+    a = field3d((72, 80, 88))
+    L = sz3_amd.lib()
+    conf = sz3_amd.Config(*a.shape)
+    conf.errorBoundMode = sz3_amd.EB_REL
+    conf.relErrorBound = 1e-3
+    assert conf.cmprAlgo == sz3_amd.ALGO_INTERP_LORENZO
+    own, _ = sz3_amd.compress(a, conf)
+    assert _trailer_algo(own) == sz3_amd.ALGO_HIP_INTERP
+    L.sz3hip_set_stock_format(1)
+    try:
+        blob, ratio = sz3_amd.compress(a, conf)
+    finally:
+        L.sz3hip_set_stock_format(0)
+    assert _trailer_algo(blob) == sz3_amd.ALGO_INTERP
+    dec, oc = oracle_decompress(blob, a.dtype, a.shape)
+    eb = 1e-3 * (float(a.max()) - float(a.min()))
+    assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= eb * (1 + 1e-12)
+    mine, _ = sz3_amd.decompress(blob, a.dtype, a.shape)
+    ref_own, _ = sz3_amd.decompress(own, a.dtype, a.shape)
+    assert np.array_equal(mine, dec) and np.array_equal(mine, ref_own)  # one reconstruction, three containers
+    oblob = oracle_compress(a, make_config(a.shape, algo=ALGO_INTERP_LORENZO, eb_mode=EB_REL, rel_eb=1e-3))
+    assert len(blob) <= 1.05 * len(oblob)  # (the GPU tuner may choose a neighbouring (alpha, beta): DESIGN.md section 2)
+
+
+def test_corrupt_stock_streams_are_refused():
+    a = field3d((24, 30, 36))
+    oconf = make_config(a.shape, algo=ALGO_INTERP, abs_eb=1e-3)
+    blob = bytearray(oracle_compress(a, oconf).tobytes())
+    good, _ = sz3_amd.decompress(bytes(blob), a.dtype, a.shape)
+    # flip a byte inside the zstd frame: the lossless stage or the container's checks must catch it, never a crash
+    for at in (40, len(blob) // 2, len(blob) - 60):
+        b = bytearray(blob)
+        b[at] ^= 0x5A
+        try:
+            out, _ = sz3_amd.decompress(bytes(b), a.dtype, a.shape)
+        except sz3_amd.SZ3HipError:
+            continue
+        assert out.shape == good.shape  # (a flipped bit that still parses decodes to SOMETHING of the right shape)

@@ -1,0 +1,37 @@
+"""CPU tests of stock-stream interoperability, the part that needs no device: the emission rank of every element
+of an ALGO_INTERP stream (sz3_amd/csrc/sz3hip_stock_geom.h) against the order in which the oracle's restatement of
+InterpolationDecomposition::compress (decomposition/InterpolationDecomposition.hpp:79-147) visits the points."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import sz3_amd
+from oracle_binding import ALGO_INTERP, make_config, oracle_interp_codes
+
+CASES = [
+    # (shape, interp algo, direction, anchor stride)
+    ((33, 47, 50), 1, 0, 32), ((33, 47, 50), 0, 0, 32), ((34, 66, 36), 0, 0, 32), ((70, 64, 65), 1, 5, 32), ((40, 33, 29), 1, 0, 8),
+    ((20, 21, 22), 1, 3, 0), ((65, 31, 2), 1, 2, 16), ((7, 9, 130), 0, 4, 4), ((64, 64, 64), 1, 1, 32), ((5, 6, 7), 1, 0, 32),
+    ((100,), 1, 0, 4096), ((5000,), 1, 0, 128), ((4097,), 0, 0, 1024), ((9,), 1, 0, 4), ((300, 500), 1, 0, 128), ((300, 500), 0, 1, 128),
+    ((129, 131), 1, 1, 16), ((40, 40), 1, 0, 0), ((12, 20, 20, 20), 1, 0, 16), ((5, 17, 9, 33), 0, 23, 8), ((6, 33, 18, 35), 1, 7, 16),
+    ((1, 1, 40, 50), 1, 0, 16),
+]
+
+
+@pytest.mark.parametrize("shape,algo,direction,anchor", CASES, ids=["%s-%s-d%d-a%d" % ("x".join(map(str, c[0])), "cubic" if c[1] else "linear", c[2], c[3]) for c in CASES])
+def test_emission_rank_of_every_element(shape, algo, direction, anchor):
+    L = sz3_amd.lib()
+    L.sz3hip_debug_stock_ranks.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_uint64, C.c_void_p]
+    dims = [d for d in shape if d > 1] or [1]  # (Config::setDims drops extents of 1)
+    a = np.random.default_rng(1).standard_normal(dims).astype(np.float32)
+    oconf = make_config(a.shape, algo=ALGO_INTERP, abs_eb=1e-2, interp_algo=algo, interpDirection=direction, interpAnchorStride=anchor)
+    _, order, _, _ = oracle_interp_codes(a, oconf)   # element index of every code, in emission order
+    ranks = np.empty(a.size, dtype=np.uint64)
+    arr = (C.c_uint64 * len(dims))(*dims)
+    rc = L.sz3hip_debug_stock_ranks(len(dims), arr, algo, direction, anchor, ranks.ctypes.data)
+    assert rc == 0, rc
+    want = np.empty(a.size, dtype=np.uint64)
+    want[order.astype(np.int64)] = np.arange(a.size, dtype=np.uint64)
+    bad = np.nonzero(ranks != want)[0]
+    assert bad.size == 0, (bad[:10], ranks[bad[:10]], want[bad[:10]])

@@ -427,6 +427,10 @@ void verify(Type *ori, Type *dec, size_t n, double &psnr, double &nrmse) {
     verify(ori, dec, n, psnr, nrmse, c);
 }
 
+// (libsz3hip) streams stock SZ3 reads: SZ_compress writes cmprAlgo ALGO_INTERP in the reference's own container wherever the interpolation
+// predictor is chosen — the default ALGO_INTERP_LORENZO's outcome on most data; reading stock ALGO_INTERP streams needs no switch
+inline void hip_stock_format(bool on) { sz3hip_set_stock_format(on ? 1 : 0); }
+
 namespace hipdetail {
 template <class T>
 inline int dtype_of() {

@@ -146,6 +146,8 @@ def lib():
     L.sz3hip_ctx_set_speculation.restype = None
     L.sz3hip_ctx_set_deterministic.argtypes = [C.c_void_p, C.c_int]
     L.sz3hip_ctx_set_deterministic.restype = None
+    L.sz3hip_set_stock_format.argtypes = [C.c_int]
+    L.sz3hip_set_stock_format.restype = None
     L.sz3hip_last_call_fused.argtypes = [C.c_void_p]
     L.sz3hip_last_call_fused.restype = C.c_int
     L.sz3hip_ctx_set_fused.argtypes = [C.c_void_p, C.c_int]
@@ -269,6 +271,12 @@ class Config:
 
 
 # ---- pysz-like host API (tools/pysz/src/pysz/sz.pyx) -----------------------------------------------------------
+def set_stock_format(on=True):
+    """on: compress() writes streams stock SZ3 reads wherever this library has a stock form (ALGO_INTERP, which is what the default
+    ALGO_INTERP_LORENZO resolves to on most data); reading stock ALGO_INTERP / ALGO_LOSSLESS streams needs no switch"""
+    lib().sz3hip_set_stock_format(int(on))
+
+
 def compress_bound(conf, dtype):
     return int(lib().sz3hip_compress_bound(C.byref(conf._c), _dtype_id(dtype)))
 

@@ -1525,6 +1525,37 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     return 0;
 }
 
+static bool grow_lists(sz3hip_ctx *ctx, uint64_t want) {  // (the stream is idle: nothing uses the old arrays)
+    if (want <= ctx->out_alloc) return true;
+    void **arr[4] = {(void **)&ctx->d_vout_idx, (void **)&ctx->d_dout_idx, &ctx->d_vout_val, &ctx->d_dout_val};
+    void *fresh[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ok = true;
+    for (int i = 0; i < 4 && ok; i++) ok = hipMalloc(&fresh[i], want * 8) == hipSuccess;
+    if (!ok) {
+        for (void *f : fresh)
+            if (f) (void)hipFree(f);
+        (void)hipGetLastError();
+        return false;
+    }
+    for (int i = 0; i < 4; i++) {
+        (void)hipFree(*arr[i]);
+        *arr[i] = fresh[i];
+    }
+    ctx->out_alloc = want;
+    return true;
+}
+// stage 1 once more with lists that hold `need` unpredictable values (up to n / 8: beyond that no stream beats the lossless fallback)
+int szi_stage1_with_larger_lists(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, uint64_t need, void *stream) {
+    const uint64_t n = conf->num;
+    if (need > out_cap_limit(n)) return fail(SZ3HIP_EOUTLIERS, "outlier capacity exceeded: data not compressible at this bound");
+    const uint64_t want = std::min<uint64_t>(out_cap_limit(n), need + need / 16 + 1024);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (!grow_lists(ctx, want)) return fail(SZ3HIP_EOUTLIERS, "no memory for larger outlier lists");
+    ctx->force_out_cap = want;
+    const int rc = sz3hip_compress_stage1(ctx, conf, d_in, stream);
+    ctx->force_out_cap = 0;
+    return rc;
+}
 extern "C" int sz3hip_compress_device(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, void *d_payload,
                                       size_t cap, size_t *payload_size, void *stream) {
     int rc = sz3hip_compress_stage1(ctx, conf, d_in, stream);
@@ -1543,23 +1574,7 @@ extern "C" int sz3hip_compress_device(sz3hip_ctx *ctx, const sz3hip_config *conf
     if (need > out_cap_limit(n)) return rc;
     const uint64_t want = std::min<uint64_t>(out_cap_limit(n), need + need / 16 + 1024);
     if (cap < payload_bound_n(n, std::max<uint64_t>(ctx->out_cap, want))) return rc;
-    if (want > ctx->out_alloc) {  // (finish() synchronised the stream: nothing uses the old arrays)
-        void **arr[4] = {(void **)&ctx->d_vout_idx, (void **)&ctx->d_dout_idx, &ctx->d_vout_val, &ctx->d_dout_val};
-        void *fresh[4] = {nullptr, nullptr, nullptr, nullptr};
-        bool ok = true;
-        for (int i = 0; i < 4 && ok; i++) ok = hipMalloc(&fresh[i], want * 8) == hipSuccess;
-        if (!ok) {
-            for (void *f : fresh)
-                if (f) (void)hipFree(f);
-            (void)hipGetLastError();
-            return rc;  // no memory for larger lists: the caller falls back to lossless
-        }
-        for (int i = 0; i < 4; i++) {
-            (void)hipFree(*arr[i]);
-            *arr[i] = fresh[i];
-        }
-        ctx->out_alloc = want;
-    }
+    if (!grow_lists(ctx, want)) return rc;  // no memory for larger lists: the caller falls back to lossless
     ctx->force_out_cap = want;
     rc = sz3hip_compress_stage1(ctx, conf, d_in, stream);
     ctx->force_out_cap = 0;
@@ -1619,6 +1634,7 @@ int szi_stock_stage1_outcome(sz3hip_ctx *ctx, szi_stock_params *out, uint64_t *n
     uint64_t nv = 0;
     HIPCHK(hipMemcpyAsync(&nv, ctx->d_counters + 0, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    *n_unpred = nv;
     if (nv > ctx->cur_out_cap) return fail(SZ3HIP_EOUTLIERS, "outlier capacity exceeded (%llu): data not compressible at this bound", (unsigned long long)ctx->cur_out_cap);
     const szh_header &h = ctx->proto;
     memset(out, 0, sizeof(*out));

@@ -587,6 +587,14 @@ int stock_encode_interp(SlabJob &j) {
     szi_stock_params sp;
     uint64_t n_unpred = 0;
     int rc = szi_stock_stage1_outcome(ctx, &sp, &n_unpred, s->stream);
+    if (rc == SZ3HIP_EOUTLIERS) {  // more unpredictable values than the default lists hold: stage 1 once more with lists that do
+        rc = szi_stage1_with_larger_lists(ctx, &j.conf, s->dev_in, n_unpred, s->stream);
+        if (!rc) rc = szi_stock_stage1_outcome(ctx, &sp, &n_unpred, s->stream);
+        if (rc == SZ3HIP_EOUTLIERS) {
+            j.lossless = true;  // (the reference's length_error fallback, SZDispatcher.hpp:44-59; job_encode writes the lossless stream)
+            return SZ3HIP_EUNSUPPORTED;
+        }
+    }
     if (rc) return rc;
     szg_geom g;
     std::vector<uint64_t> bb;
@@ -677,17 +685,23 @@ int job_encode(SlabJob &j) {
             if (rs != SZ3HIP_EUNSUPPORTED) return j.failed(rs);
             // (another predictor: there is no stock form of it here — this library's own stream)
         }
-        int rc = sz3hip_compress_stage2(ctx, s->dev_payload, s->dev_payload_bytes, s->stream);
-        if (!rc) rc = sz3hip_compress_finish(ctx, &dsize, s->stream);
+        int rc = 0;
+        if (!j.lossless) {
+            rc = sz3hip_compress_stage2(ctx, s->dev_payload, s->dev_payload_bytes, s->stream);
+            if (!rc) rc = sz3hip_compress_finish(ctx, &dsize, s->stream);
+        }
         if (j.tm) j.tm->lap("device compress");
-        if (rc == SZ3HIP_EOUTLIERS) {
+        if (j.lossless) {
+            // (the stock branch found more unpredictable values than any stream is worth: the lossless stream below)
+        } else if (rc == SZ3HIP_EOUTLIERS) {
             // more unpredictable values than the default lists hold: room for the largest lists, then the slab once more by
             // itself (the device call grows the lists to what the input needs; a slab that took this turn is coded with its
             // own code book — every blob carries its code lengths, so the container does not care)
             if (ensure_dev(&s->dev_payload, &s->dev_payload_bytes, sz3hip_payload_bound_conf(ctx, &j.conf, 1))) return j.failed(SZ3HIP_EHIP);
             rc = sz3hip_compress_device(ctx, &j.conf, s->dev_in, s->dev_payload, s->dev_payload_bytes, &dsize, s->stream);
         }
-        if (rc == SZ3HIP_EOUTLIERS) {
+        if (j.lossless) {
+        } else if (rc == SZ3HIP_EOUTLIERS) {
             j.lossless = true;  // same policy as the reference's length_error fallback, SZDispatcher.hpp:44-59
         } else if (rc) {
             return j.failed(rc);

@@ -86,7 +86,8 @@ def test_streams_written_in_stock_format_are_read_by_stock_sz3(name, gen, eb, kw
         assert np.array_equal(ref_decompress(blob, a.dtype, a.shape), want, equal_nan=True)
     mine, _ = sz3_amd.decompress(blob, a.dtype, a.shape)   # and this library reading it back
     assert np.array_equal(mine, want, equal_nan=True)
-    assert abs(len(blob) - len(oblob)) <= 0.01 * len(oblob) + 64, (len(blob), len(oblob))  # same codes, an equally good tree
+    # same codes, an equally good tree; the zstd stage behind it sees another tree's bytes and 1 MB frames (a few percent either way)
+    assert 0.9 * len(oblob) <= len(blob) <= 1.01 * len(oblob) + 64, (len(blob), len(oblob))
 
 
 def test_default_algorithm_in_stock_format_and_ids_without_the_switch():

@@ -132,3 +132,42 @@ def test_corrupt_stock_streams_are_refused():
         except sz3_amd.SZ3HipError:
             continue
         assert out.shape == good.shape  # (a flipped bit that still parses decodes to SOMETHING of the right shape)
+
+
+def test_files_interchange_between_the_two_clis(tmp_path):
+    """A user with .sz archives: a file written by the stock CLI (oracle/_ref/sz3: the reference's tools/sz3/sz3.cpp over the
+    reference's own headers, default algorithm) is decompressed by the CLI over THIS library (oracle/_ref/sz3_hip: the same source over
+    include/SZ3/api/sz.hpp), and a file written by that one with SZ3HIP_STOCK_FORMAT=1 is decompressed by the stock CLI — to the same
+    values, which are the values the stock CLI gets back from its own file."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    ref_dir = os.path.join(os.path.dirname(here), "oracle", "_ref")
+    stock, ours = os.path.join(ref_dir, "sz3"), os.path.join(ref_dir, "sz3_hip")
+    if not (os.path.exists(stock) and os.path.exists(ours)):
+        pytest.skip("oracle/_ref CLIs not built (need /root/reference at build time)")
+    a = field3d((60, 72, 84))
+    src = tmp_path / "a.f32"
+    a.tofile(src)
+    dims = ["-3", "84", "72", "60"]
+
+    def run(exe, args, env=None):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=dict(os.environ, **(env or {})))
+        assert r.returncode == 0, (exe, r.stdout[-800:], r.stderr[-800:])
+
+    # stock writes, both read
+    run(stock, ["-f", "-i", str(src), "-z", str(tmp_path / "stock.sz")] + dims + ["-M", "ABS", "1e-3"])
+    run(stock, ["-f", "-z", str(tmp_path / "stock.sz"), "-o", str(tmp_path / "stock.by_stock")] + dims)
+    run(ours, ["-f", "-z", str(tmp_path / "stock.sz"), "-o", str(tmp_path / "stock.by_ours")] + dims)
+    want = np.fromfile(tmp_path / "stock.by_stock", dtype=np.float32)
+    assert np.array_equal(np.fromfile(tmp_path / "stock.by_ours", dtype=np.float32), want)
+    assert float(np.max(np.abs(want.astype(np.float64) - a.reshape(-1).astype(np.float64)))) <= 1e-3
+    # this library writes in stock format, both read
+    run(ours, ["-f", "-i", str(src), "-z", str(tmp_path / "ours.sz")] + dims + ["-M", "ABS", "1e-3"], env={"SZ3HIP_STOCK_FORMAT": "1"})
+    run(stock, ["-f", "-z", str(tmp_path / "ours.sz"), "-o", str(tmp_path / "ours.by_stock")] + dims)
+    run(ours, ["-f", "-z", str(tmp_path / "ours.sz"), "-o", str(tmp_path / "ours.by_ours")] + dims)
+    got = np.fromfile(tmp_path / "ours.by_stock", dtype=np.float32)
+    assert np.array_equal(np.fromfile(tmp_path / "ours.by_ours", dtype=np.float32), got)
+    assert float(np.max(np.abs(got.astype(np.float64) - a.reshape(-1).astype(np.float64)))) <= 1e-3
+    so, oo = os.path.getsize(tmp_path / "stock.sz"), os.path.getsize(tmp_path / "ours.sz")
+    assert oo <= 1.05 * so, (oo, so)

@@ -550,36 +550,23 @@ int job_stage1(SlabJob &j) {
 
 // ---- stock SZ3 streams: ALGO_INTERP read and written; sz3hip_stock.hip / sz3hip_stock_host.cpp ----
 std::atomic<int> g_stock_format{-1};
-// the slot's payload buffer, carved up for the permutation kernels: emission-order codes, unpredictable values (+ their list form),
-// the zero counts' tiles, the geometry's per-block bases
-struct StockBufs {
-    uint16_t *em;
-    void *unpred;
-    uint64_t *vidx;
-    void *vval;
-    uint32_t *tile_cnt;
-    uint64_t *tile_base;
-    uint64_t *blk_base;
-    uint32_t *bad;
+// the slot's payload buffer, carved up for the stock path's kernels: sizes are asked for first, then the buffer is grown once
+struct DevArena {
+    std::vector<std::pair<void **, size_t>> want;
+    template <typename P> void ask(P **p, size_t bytes) { want.push_back({reinterpret_cast<void **>(p), (bytes + 255) & ~(size_t)255}); }
+    int commit(HostSlot *s) {
+        size_t total = 256;
+        for (auto &w : want) total += w.second;
+        if (ensure_dev(&s->dev_payload, &s->dev_payload_bytes, total)) return SZ3HIP_EHIP;
+        uint8_t *p = (uint8_t *)s->dev_payload;
+        for (auto &w : want) {
+            *w.first = p;
+            p += w.second;
+        }
+        return 0;
+    }
 };
-int stock_bufs(HostSlot *s, uint64_t n, uint64_t n_unpred, size_t nblk, size_t tsize, StockBufs &b) {
-    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t ntiles = (size_t)((n + 1023) / 1024);
-    const size_t sz_em = up((size_t)n * 2), sz_un = up((size_t)n_unpred * tsize + 8), sz_vi = up((size_t)n_unpred * 8 + 8), sz_tc = up(ntiles * 4),
-                 sz_tb = up((ntiles + 1) * 8), sz_bb = up(nblk * 8 + 8);
-    const size_t total = sz_em + 2 * sz_un + sz_vi + sz_tc + sz_tb + sz_bb + 256;
-    if (ensure_dev(&s->dev_payload, &s->dev_payload_bytes, total)) return SZ3HIP_EHIP;
-    uint8_t *p = (uint8_t *)s->dev_payload;
-    b.em = (uint16_t *)p; p += sz_em;
-    b.unpred = p; p += sz_un;
-    b.vval = p; p += sz_un;
-    b.vidx = (uint64_t *)p; p += sz_vi;
-    b.tile_cnt = (uint32_t *)p; p += sz_tc;
-    b.tile_base = (uint64_t *)p; p += sz_tb;
-    b.blk_base = (uint64_t *)p; p += sz_bb;
-    b.bad = (uint32_t *)p;
-    return 0;
-}
+static bool stock_host_huffman() { return env_int("SZ3HIP_STOCK_HOST_HUFFMAN", 0) != 0; }  // (A/B partner of the device coder, for tests)
 // 0: j.out holds [u64 rawLen][zstd frames] of a stock stream and j.conf names it; SZ3HIP_EUNSUPPORTED: stage 1 took another predictor
 int stock_encode_interp(SlabJob &j) {
     HostSlot *s = j.slot;
@@ -600,22 +587,71 @@ int stock_encode_interp(SlabJob &j) {
     std::vector<uint64_t> bb;
     if (szk_stock_geom_build(sp.N, sp.dims, sp.interp_id, sp.direction, sp.anchor_stride, &g, &bb)) return fail(SZ3HIP_EINVAL, "stock stream: unsupported geometry");
     const size_t tsize = j.cdt == SZ3HIP_FLOAT ? 4 : 8;
-    StockBufs b;
-    if (stock_bufs(s, g.n, n_unpred, bb.size(), tsize, b)) return SZ3HIP_EHIP;
-    HIPCHK(hipMemcpyAsync(b.blk_base, bb.data(), bb.size() * 8, hipMemcpyHostToDevice, s->stream));
-    rc = szi_stock_export(ctx, &g, b.blk_base, b.em, b.unpred, n_unpred, b.tile_cnt, b.tile_base, s->stream);
+    const uint64_t n = g.n;
+    // the code book: a tree in the reference's format from the histogram stage 1 made of the very same codes
+    std::vector<uint64_t> hist(65536);
+    HIPCHK(hipMemcpy(hist.data(), ctx->d_hist, 65536 * 8, hipMemcpyDeviceToHost));
+    stock::Tree tr;
+    std::vector<uint8_t> clen;
+    std::vector<uint64_t> cbits;
+    int lo = 0, hi = 0;
+    if (!stock::book_from_hist(hist.data(), tr, clen, cbits, lo, hi)) return fail(SZ3HIP_EHIP, "stock stream: empty code histogram");
+    const uint64_t ntiles_z = (n + 1023) / 1024, ntiles_e = (n + 2047) / 2048;
+    uint16_t *d_em;
+    uint8_t *d_unpred, *d_clen;
+    uint64_t *d_cbits, *d_tile_base, *d_blk, *d_ebase;
+    uint32_t *d_tile_cnt, *d_ebits;
+    DevArena ar;
+    ar.ask(&d_em, (size_t)n * 2);
+    ar.ask(&d_unpred, (size_t)n_unpred * tsize + 8);
+    ar.ask(&d_tile_cnt, (size_t)ntiles_z * 4);
+    ar.ask(&d_tile_base, (size_t)(ntiles_z + 1) * 8);
+    ar.ask(&d_blk, bb.size() * 8 + 8);
+    ar.ask(&d_clen, 65536);
+    ar.ask(&d_cbits, 65536 * 8);
+    ar.ask(&d_ebits, (size_t)ntiles_e * 4);
+    ar.ask(&d_ebase, (size_t)(ntiles_e + 1) * 8);
+    if (ar.commit(s)) return SZ3HIP_EHIP;
+    HIPCHK(hipMemcpyAsync(d_blk, bb.data(), bb.size() * 8, hipMemcpyHostToDevice, s->stream));
+    rc = szi_stock_export(ctx, &g, d_blk, d_em, d_unpred, n_unpred, d_tile_cnt, d_tile_base, s->stream);
     if (rc) return rc;
-    std::vector<uint16_t> em((size_t)g.n);
-    std::vector<uint8_t> un((size_t)n_unpred * tsize + 8);
-    HIPCHK(hipMemcpyAsync(em.data(), b.em, (size_t)g.n * 2, hipMemcpyDeviceToHost, s->stream));
-    if (n_unpred) HIPCHK(hipMemcpyAsync(un.data(), b.unpred, (size_t)n_unpred * tsize, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
-    if (j.tm) j.tm->lap("device compress + codes to the host");
+    std::vector<uint8_t> un((size_t)n_unpred * tsize + 8), bits;
+    if (n_unpred) HIPCHK(hipMemcpyAsync(un.data(), d_unpred, (size_t)n_unpred * tsize, hipMemcpyDeviceToHost, s->stream));
+    uint64_t bit_bytes = 0;
+    if (tr.t[0]) {
+        // a single symbol: zero-length code words, no bit stream (encoder/HuffmanEncoder.hpp:233-237)
+        HIPCHK(hipStreamSynchronize(s->stream));
+    } else if (stock_host_huffman()) {
+        std::vector<uint16_t> em((size_t)n);
+        HIPCHK(hipMemcpyAsync(em.data(), d_em, (size_t)n * 2, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        stock::host_encode(em.data(), n, clen, cbits, bits);
+        bit_bytes = bits.size();
+    } else {
+        // the bit stream is made on the device (k_stock_enc_pack) into the input array's memory, which stage 1 is done with
+        HIPCHK(hipMemcpyAsync(d_clen, clen.data(), 65536, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(d_cbits, cbits.data(), 65536 * 8, hipMemcpyHostToDevice, s->stream));
+        uint64_t total_bits = 0;
+        const int re = szk_launch_stock_huff_encode(d_em, n, d_clen, d_cbits, d_ebits, d_ebase, (uint32_t *)s->dev_in, (uint64_t)(s->dev_in_bytes / 4), &total_bits, s->stream);
+        if (re == -2) {  // (more than sizeof(T) bytes of code bits per element: nothing a stream is worth)
+            j.lossless = true;
+            return SZ3HIP_EUNSUPPORTED;
+        }
+        if (re) return fail(SZ3HIP_EHIP, "stock stream: device Huffman coder failed (%d)", re);
+        bit_bytes = (total_bits + 7) / 8;
+        bits.resize((size_t)bit_bytes + 8);
+        HIPCHK(hipMemcpyAsync(bits.data(), s->dev_in, (size_t)bit_bytes, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        bits.resize((size_t)bit_bytes);
+    }
+    if (j.tm) j.tm->lap("device compress + Huffman (reference container)");
     std::vector<uint8_t> raw;
-    stock::serialise_interp(sp, g.anchor, em.data(), g.n, un.data(), n_unpred, tsize, raw);
+    raw.reserve((size_t)bit_bytes + (size_t)n_unpred * tsize + (1u << 20));
+    stock::write_head(sp, g.anchor, un.data(), n_unpred, tsize, tr, lo, hi, n, bit_bytes, raw);
+    raw.insert(raw.end(), bits.begin(), bits.end());
     j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap);  // (concatenated frames: ZSTD_decompress, which stock SZ3 calls, decodes them all)
     if (!j.out_size) return sz3hip_last_error_code();
-    if (j.tm) j.tm->lap("Huffman (reference container) + zstd");
+    if (j.tm) j.tm->lap("zstd");
     j.conf.cmprAlgo = SZ3HIP_ALGO_INTERP;
     j.conf.interpAlgo = (uint8_t)sp.interp_id;
     j.conf.interpDirection = (uint8_t)sp.direction;
@@ -640,14 +676,15 @@ int stock_decompress_interp(HostSlot *s, const sz3hip_config *conf, int dataType
     uint64_t raw_len;
     memcpy(&raw_len, p, 8);
     if (raw_len < 64 || raw_len > (uint64_t)conf->num * 16 + (1u << 22)) return fail(SZ3HIP_EFORMAT, "implausible payload length in the lossless block");
-    std::vector<uint8_t> raw((size_t)raw_len);
+    std::vector<uint8_t> raw((size_t)raw_len + 8, 0);
     if (zs::decompress_frames(p, payload, raw.data(), (size_t)raw_len) != raw_len) return SZ3HIP_EZSTD;
     szi_stock_params sp;
-    std::vector<uint16_t> em;
-    const uint8_t *unpred = nullptr;
-    uint64_t n_unpred = 0;
-    if (!stock::parse_interp(raw.data(), raw.size(), conf->N, tsize, sp, em, unpred, n_unpred))
-        return fail(SZ3HIP_EFORMAT, "corrupt stock ALGO_INTERP stream (decomposition header, Huffman tree or bit stream)");
+    const uint8_t *unpred = nullptr, *bits = nullptr;
+    uint64_t n_unpred = 0, n = 0, bit_bytes = 0;
+    stock::Tree tr;
+    int32_t offset = 0;
+    if (!stock::parse_head(raw.data(), (size_t)raw_len, conf->N, tsize, sp, unpred, n_unpred, tr, offset, n, bits, bit_bytes))
+        return fail(SZ3HIP_EFORMAT, "corrupt stock ALGO_INTERP stream (decomposition header or Huffman tree)");
     for (int i = 0; i < conf->N; i++)
         if (sp.dims[i] != conf->dims[i]) return fail(SZ3HIP_EFORMAT, "the stream's extents do not match its Config");
     szg_geom g;
@@ -658,12 +695,65 @@ int stock_decompress_interp(HostSlot *s, const sz3hip_config *conf, int dataType
     int rc;
     if ((rc = slot_ctx(s, conf->num))) return rc;
     if ((rc = ensure_dev(&s->dev_in, &s->dev_in_bytes, (size_t)conf->num * tsize))) return rc;
-    StockBufs b;
-    if (stock_bufs(s, g.n, n_unpred, bb.size(), tsize, b)) return SZ3HIP_EHIP;
-    HIPCHK(hipMemcpyAsync(b.blk_base, bb.data(), bb.size() * 8, hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(b.em, em.data(), (size_t)g.n * 2, hipMemcpyHostToDevice, s->stream));
-    if (n_unpred) HIPCHK(hipMemcpyAsync(b.unpred, unpred, (size_t)n_unpred * tsize, hipMemcpyHostToDevice, s->stream));
-    rc = szi_stock_import(s->ctx, &sp, &g, b.blk_base, b.em, b.unpred, n_unpred, b.tile_cnt, b.tile_base, b.vidx, b.vval, b.bad, s->dev_in, s->stream);
+    const uint64_t ntiles_z = (n + 1023) / 1024;
+    const uint64_t nsub = (bit_bytes * 8 + 4095) / 4096;
+    const uint32_t nc = (uint32_t)tr.t.size();
+    uint16_t *d_em;
+    uint8_t *d_unpred, *d_vval, *d_bits, *d_t;
+    uint64_t *d_vidx, *d_tile_base, *d_blk, *d_start, *d_last, *d_next, *d_base;
+    uint32_t *d_tile_cnt, *d_bad, *d_L, *d_R, *d_lut, *d_count, *d_flags;
+    int32_t *d_C;
+    DevArena ar;
+    ar.ask(&d_em, (size_t)n * 2);
+    ar.ask(&d_unpred, (size_t)n_unpred * tsize + 8);
+    ar.ask(&d_vval, (size_t)n_unpred * tsize + 8);
+    ar.ask(&d_vidx, (size_t)n_unpred * 8 + 8);
+    ar.ask(&d_tile_cnt, (size_t)ntiles_z * 4);
+    ar.ask(&d_tile_base, (size_t)(ntiles_z + 1) * 8);
+    ar.ask(&d_blk, bb.size() * 8 + 8);
+    ar.ask(&d_bad, 64);
+    ar.ask(&d_bits, (size_t)bit_bytes + 16);
+    ar.ask(&d_L, (size_t)nc * 4);
+    ar.ask(&d_R, (size_t)nc * 4);
+    ar.ask(&d_C, (size_t)nc * 4);
+    ar.ask(&d_t, nc);
+    ar.ask(&d_lut, 4096 * 4);
+    ar.ask(&d_start, (size_t)(nsub + 2) * 8);
+    ar.ask(&d_last, (size_t)(nsub + 2) * 8);
+    ar.ask(&d_next, (size_t)(nsub + 2) * 8);
+    ar.ask(&d_base, (size_t)(nsub + 2) * 8);
+    ar.ask(&d_count, (size_t)(nsub + 2) * 4);
+    ar.ask(&d_flags, 64);
+    if (ar.commit(s)) return SZ3HIP_EHIP;
+    HIPCHK(hipMemcpyAsync(d_blk, bb.data(), bb.size() * 8, hipMemcpyHostToDevice, s->stream));
+    if (n_unpred) HIPCHK(hipMemcpyAsync(d_unpred, unpred, (size_t)n_unpred * tsize, hipMemcpyHostToDevice, s->stream));
+    std::vector<uint16_t> em_host;
+    if (tr.t[0]) {  // a single symbol: no bits at all (encoder/HuffmanEncoder.hpp:233-237)
+        const int32_t v = tr.C[0] + offset;
+        if (v < 0 || v > 65535) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (symbol)");
+        em_host.assign((size_t)n, (uint16_t)v);
+        HIPCHK(hipMemcpyAsync(d_em, em_host.data(), (size_t)n * 2, hipMemcpyHostToDevice, s->stream));
+    } else if (stock_host_huffman()) {
+        em_host.resize((size_t)n);
+        if (!stock::host_decode(tr, offset, bits, (size_t)bit_bytes, n, em_host.data())) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (bit stream)");
+        HIPCHK(hipMemcpyAsync(d_em, em_host.data(), (size_t)n * 2, hipMemcpyHostToDevice, s->stream));
+    } else {
+        std::vector<uint32_t> lut;
+        stock::make_lut(tr, lut);
+        HIPCHK(hipMemsetAsync(d_bits + (bit_bytes & ~(uint64_t)3), 0, 16, s->stream));  // (the last word's tail reads as zeros)
+        HIPCHK(hipMemcpyAsync(d_bits, bits, (size_t)bit_bytes, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(d_L, tr.L.data(), (size_t)nc * 4, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(d_R, tr.R.data(), (size_t)nc * 4, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(d_C, tr.C.data(), (size_t)nc * 4, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(d_t, tr.t.data(), nc, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(d_lut, lut.data(), 4096 * 4, hipMemcpyHostToDevice, s->stream));
+        szk_stock_tree_dev td{d_L, d_R, d_C, d_t, d_lut, nc, offset};
+        int passes = 0;
+        const int rd = szk_launch_stock_huff_decode(&td, (const uint32_t *)d_bits, bit_bytes, n, d_start, d_last, d_next, d_base, d_count, d_flags, d_em, &passes, s->stream);
+        if (rd == -3) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (bit stream)");
+        if (rd) return fail(SZ3HIP_EHIP, "stock stream: device Huffman decoder failed (%d)", rd);
+    }
+    rc = szi_stock_import(s->ctx, &sp, &g, d_blk, d_em, d_unpred, n_unpred, d_tile_cnt, d_tile_base, d_vidx, d_vval, d_bad, s->dev_in, s->stream);
     if (rc) return rc;
     HIPCHK(hipMemcpy(decData, s->dev_in, (size_t)conf->num * tsize, hipMemcpyDeviceToHost));
     return 0;

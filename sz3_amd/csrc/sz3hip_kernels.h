@@ -335,6 +335,20 @@ int szk_launch_stock_from_elem(int dtype, const szg_geom *g, const uint64_t *d_b
                                const void *d_vout_val, uint64_t n_vout, uint32_t *d_tile_cnt, uint64_t *d_tile_base, uint16_t *d_em, void *d_unpred,
                                hipStream_t s);
 int szk_launch_stock_ranks(const szg_geom *g, const uint64_t *d_blk_base, uint64_t *d_rank, hipStream_t s);
+// the Huffman stage of a stock stream on the device (sz3hip_stock.hip): coder (tile bit counts, scan, pack into a zeroed word array) and the
+// self-synchronising decoder; the tree argument is sz3hip_stock.hip's szk_stock_tree (same layout as the caller's mirror struct)
+int szk_launch_stock_huff_encode(const uint16_t *d_em, uint64_t n, const uint8_t *d_clen, const uint64_t *d_cbits, uint32_t *d_tile_bits, uint64_t *d_tile_base,
+                                 uint32_t *d_out_words, uint64_t out_words_cap, uint64_t *total_bits, hipStream_t s);
+struct szk_stock_tree_dev {  // HuffmanEncoder's serialised tree on the device (encoder/HuffmanEncoder.hpp:601-628)
+    const uint32_t *L, *R;  // children by pre-order node index (0: none)
+    const int32_t *C;       // leaf: symbol - offset
+    const uint8_t *t;       // 1: leaf
+    const uint32_t *lut;    // [4096] (node reached by twelve bits << 8) | (bits used << 1) | leaf
+    uint32_t nc;
+    int32_t offset;
+};
+int szk_launch_stock_huff_decode(const szk_stock_tree_dev *tr, const uint32_t *d_words, uint64_t nbytes, uint64_t n, uint64_t *d_start, uint64_t *d_last,
+                                 uint64_t *d_next, uint64_t *d_base, uint32_t *d_count, uint32_t *d_flags, uint16_t *d_em, int *passes, hipStream_t s);
 #ifdef __cplusplus
 #include <vector>
 // the geometry of an array under InterpolationDecomposition::init (:176-213) and the per-block bases of its emission order; 0 on success

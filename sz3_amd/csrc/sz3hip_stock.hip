@@ -259,3 +259,258 @@ int szk_launch_stock_ranks(const szg_geom *g, const uint64_t *d_blk_base, uint64
     hipLaunchKernelGGL(k_stock_rank, dim3(stock_grid(g->n)), dim3(256), 0, s, *g, d_blk_base, d_rank);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The Huffman stage of a stock stream on the device (encoder/HuffmanEncoder.hpp:140-255). The reference's bit stream is ONE
+// unindexed MSB-first string over a tree it serialises node by node:
+//   * coding is embarrassingly parallel once the code words' lengths are scanned: a workgroup takes a tile of 2048 symbols, places
+//     every code word at its bit offset inside an LDS stage (ds_or), and copies the stage out shifted by the tile's bit offset in
+//     the stream (the two words it shares with its neighbours by atomic OR into the zeroed stream);
+//   * decoding has no entry points, but a Huffman decoder that starts at a wrong bit re-synchronises with the true code word
+//     boundaries within a few symbols (the property Weissenberger & Schmidt's parallel decoder builds on): the stream is cut into
+//     subsequences of 4096 bits, thread i decodes from where thread i - 1's last pass ENDED (initially from the subsequence's first
+//     bit) to the first code word boundary at or beyond the next subsequence, passes repeat until no end moves — thread 0 is right
+//     from the start, every pass extends the right prefix by at least one subsequence, and in practice two or three passes settle
+//     everything — then the symbol counts are scanned and a last pass writes the symbols.
+// Code words are looked up in a 12-bit table held in LDS (node reached, bits used, leaf?); longer ones walk the tree's child arrays.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define STOCK_ENC_TILE 2048u
+#define STOCK_SUB_BITS 4096u
+#define STOCK_LUT_BITS 12u
+
+// 32 bits of the MSB-first stream from bit `pos` on (zeros beyond its end)
+__device__ __forceinline__ uint32_t stock_peek32(const uint32_t *__restrict__ words, uint64_t nwords, uint64_t pos) {
+    const uint64_t w = pos >> 5;
+    const uint32_t sh = (uint32_t)(pos & 31);
+    const uint32_t a = w < nwords ? __builtin_bswap32(words[w]) : 0u, b = w + 1 < nwords ? __builtin_bswap32(words[w + 1]) : 0u;
+    return sh ? (a << sh) | (b >> (32 - sh)) : a;
+}
+// one symbol from bit pos; returns the leaf's node (or 0xFFFFFFFF: the walk left the tree / the stream) and advances pos
+__device__ __forceinline__ uint32_t stock_decode_one(const szk_stock_tree_dev &tr, const uint32_t *s_lut, const uint32_t *__restrict__ words, uint64_t nwords,
+                                                     uint64_t total_bits, uint64_t &pos) {
+    uint32_t win = stock_peek32(words, nwords, pos);
+    const uint32_t e = s_lut[win >> (32 - STOCK_LUT_BITS)];
+    uint32_t node = e >> 8, used = (e >> 1) & 127u;
+    if (e & 1u) {
+        pos += used;
+        return pos <= total_bits ? node : 0xFFFFFFFFu;
+    }
+    if (used == 0) return 0xFFFFFFFFu;  // (a child missing right below the root: corrupt tree)
+    pos += used;
+    win <<= used;
+    uint32_t have = 32 - used;
+    for (;;) {  // code words beyond the table: bit by bit
+        if (have == 0) {
+            win = stock_peek32(words, nwords, pos);
+            have = 32;
+        }
+        if (pos >= total_bits) return 0xFFFFFFFFu;
+        node = (win >> 31) ? tr.R[node] : tr.L[node];
+        win <<= 1;
+        have--;
+        pos++;
+        if (node == 0) return 0xFFFFFFFFu;
+        if (tr.t[node]) return node;
+    }
+}
+__global__ __launch_bounds__(256) void k_stock_huff_sync(szk_stock_tree_dev tr, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t total_bits, uint64_t nsub,
+                                                         const uint64_t *__restrict__ start, uint64_t *__restrict__ last_start, uint64_t *__restrict__ next_start,
+                                                         uint32_t *__restrict__ count, uint32_t *changed) {
+    __shared__ uint32_t s_lut[1u << STOCK_LUT_BITS];
+    for (uint32_t i = threadIdx.x; i < (1u << STOCK_LUT_BITS); i += 256) s_lut[i] = tr.lut[i];
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nsub; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t st = start[i];
+        if (last_start[i] == st) {  // decoded from here already: its end stands
+            continue;
+        }
+        last_start[i] = st;
+        const uint64_t bound = (i + 1) * STOCK_SUB_BITS < total_bits ? (i + 1) * STOCK_SUB_BITS : total_bits;
+        uint64_t pos = st;
+        uint32_t cnt = 0;
+        while (pos < bound) {
+            uint64_t p2 = pos;
+            if (stock_decode_one(tr, s_lut, words, nwords, total_bits, p2) == 0xFFFFFFFFu) break;  // (the stream's padding, or garbage: ends here)
+            pos = p2;
+            cnt++;
+        }
+        if (pos < bound) pos = bound > pos ? bound : pos;  // (nothing decodable up to the boundary: the next thread starts at the boundary)
+        count[i] = cnt;
+        if (next_start[i + 1] != pos) {
+            next_start[i + 1] = pos;
+            *changed = 1u;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_stock_huff_write(szk_stock_tree_dev tr, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t total_bits, uint64_t nsub,
+                                                          const uint64_t *__restrict__ start, const uint64_t *__restrict__ out_base, uint64_t n,
+                                                          uint16_t *__restrict__ em, uint32_t *bad) {
+    __shared__ uint32_t s_lut[1u << STOCK_LUT_BITS];
+    for (uint32_t i = threadIdx.x; i < (1u << STOCK_LUT_BITS); i += 256) s_lut[i] = tr.lut[i];
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nsub; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t bound = (i + 1) * STOCK_SUB_BITS < total_bits ? (i + 1) * STOCK_SUB_BITS : total_bits;
+        uint64_t pos = start[i], k = out_base[i];
+        while (pos < bound && k < n) {
+            uint64_t p2 = pos;
+            const uint32_t node = stock_decode_one(tr, s_lut, words, nwords, total_bits, p2);
+            if (node == 0xFFFFFFFFu) break;
+            pos = p2;
+            const int32_t v = tr.C[node] + tr.offset;
+            if (v < 0 || v > 65535) {
+                atomicOr(bad, 4u);
+                break;
+            }
+            em[k++] = (uint16_t)v;
+        }
+    }
+}
+// exclusive scan of u32 counts into u64 bases (one workgroup), total behind the last
+__global__ __launch_bounds__(1024) void k_stock_scan32(const uint32_t *__restrict__ cnt, uint64_t m, uint64_t *__restrict__ base) {
+    __shared__ uint64_t s_w[16];
+    __shared__ uint64_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint64_t t0 = 0; t0 < m; t0 += 1024) {
+        const uint64_t t = t0 + threadIdx.x;
+        const uint64_t mine = t < m ? cnt[t] : 0;
+        const uint64_t incl = wave_incl_scan(mine);
+        if (lane_id() == WAVE - 1) s_w[threadIdx.x / WAVE] = incl;
+        __syncthreads();
+        uint64_t run = s_carry + incl - mine, tot = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < (int)(threadIdx.x / WAVE)) run += s_w[w];
+            tot += s_w[w];
+        }
+        if (t < m) base[t] = run;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) base[m] = s_carry;
+}
+
+// ---- coding: code-word table by symbol (length, bits), tiles of 2048 symbols ----
+__global__ __launch_bounds__(256) void k_stock_enc_bits(const uint16_t *__restrict__ em, uint64_t n, const uint8_t *__restrict__ clen, uint32_t *__restrict__ tile_bits) {
+    __shared__ uint32_t s_c;
+    for (uint64_t t = blockIdx.x; t * STOCK_ENC_TILE < n; t += gridDim.x) {
+        if (threadIdx.x == 0) s_c = 0;
+        __syncthreads();
+        uint32_t c = 0;
+        for (uint32_t k = threadIdx.x; k < STOCK_ENC_TILE; k += 256) {
+            const uint64_t r = t * STOCK_ENC_TILE + k;
+            if (r < n) c += clen[em[r]];
+        }
+        c = wave_sum(c);
+        if (lane_id() == 0 && c) atomicAdd(&s_c, c);
+        __syncthreads();
+        if (threadIdx.x == 0) tile_bits[t] = s_c;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_stock_enc_pack(const uint16_t *__restrict__ em, uint64_t n, const uint8_t *__restrict__ clen, const uint64_t *__restrict__ cbits,
+                                                        const uint64_t *__restrict__ tile_base, uint32_t *__restrict__ out_words) {
+    constexpr uint32_t PER = STOCK_ENC_TILE / 256;  // consecutive symbols per thread
+    constexpr uint32_t STAGE = STOCK_ENC_TILE * 2 + 4;  // words: 64 bits per symbol at worst
+    __shared__ uint32_t s_stage[STAGE];
+    __shared__ uint32_t s_wave[4];
+    for (uint64_t t = blockIdx.x; t * STOCK_ENC_TILE < n; t += gridDim.x) {
+        const uint64_t bit0 = tile_base[t];
+        const uint32_t tbits = (uint32_t)(tile_base[t + 1] - bit0);
+        const uint32_t nw = (tbits + 31) >> 5;
+        for (uint32_t i = threadIdx.x; i < nw + 2; i += 256) s_stage[i] = 0;
+        uint32_t len[PER];
+        uint64_t bits[PER];
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint64_t r = t * STOCK_ENC_TILE + (uint64_t)threadIdx.x * PER + k;
+            const uint32_t sym = r < n ? em[r] : 0u;
+            len[k] = r < n ? clen[sym] : 0u;
+            bits[k] = r < n ? cbits[sym] : 0ull;
+            mine += len[k];
+        }
+        const uint32_t incl = wave_incl_scan(mine);
+        if (lane_id() == WAVE - 1) s_wave[threadIdx.x / WAVE] = incl;
+        __syncthreads();
+        uint32_t pos = incl - mine;
+        for (uint32_t w = 0; w < threadIdx.x / WAVE; w++) pos += s_wave[w];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            if (len[k]) {
+                const uint64_t v = bits[k] << (64u - len[k]);  // left-aligned
+                const uint32_t word = pos >> 5, sh = pos & 31u;
+                const uint64_t tv = v >> sh;
+                atomicOr(&s_stage[word], (uint32_t)(tv >> 32));
+                if ((uint32_t)tv) atomicOr(&s_stage[word + 1], (uint32_t)tv);
+                const uint32_t w2 = (uint32_t)(((uint64_t)(uint32_t)v << 32) >> sh);
+                if (w2) atomicOr(&s_stage[word + 2], w2);
+                pos += len[k];
+            }
+        }
+        __syncthreads();
+        // out: the stage shifted right by the tile's bit offset in the stream; its first and last words are shared with the neighbours
+        const uint64_t w0 = bit0 >> 5;
+        const uint32_t sh = (uint32_t)(bit0 & 31);
+        const uint32_t now = (tbits + sh + 31) >> 5;  // words touched in the stream
+        for (uint32_t j = threadIdx.x; j < now; j += 256) {
+            const uint32_t hi = j ? s_stage[j - 1] : 0u, lo = j < nw ? s_stage[j] : 0u;
+            const uint32_t v = sh ? (hi << (32 - sh)) | (lo >> sh) : lo;
+            if (!v) continue;
+            const uint32_t be = __builtin_bswap32(v);  // bytes in stream order
+            if (j == 0 || j + 1 >= now) atomicOr(&out_words[w0 + j], be);
+            else out_words[w0 + j] = be;
+        }
+        __syncthreads();
+    }
+}
+
+int szk_launch_stock_huff_encode(const uint16_t *d_em, uint64_t n, const uint8_t *d_clen, const uint64_t *d_cbits, uint32_t *d_tile_bits, uint64_t *d_tile_base,
+                                 uint32_t *d_out_words, uint64_t out_words_cap, uint64_t *total_bits, hipStream_t s) {
+    const uint64_t ntiles = (n + STOCK_ENC_TILE - 1) / STOCK_ENC_TILE;
+    const uint32_t g = (uint32_t)(ntiles < 8192 ? ntiles : 8192);
+    hipLaunchKernelGGL(k_stock_enc_bits, dim3(g), dim3(256), 0, s, d_em, n, d_clen, d_tile_bits);
+    hipLaunchKernelGGL(k_stock_scan32, dim3(1), dim3(1024), 0, s, d_tile_bits, ntiles, d_tile_base);
+    uint64_t tb = 0;
+    if (hipMemcpyAsync(&tb, d_tile_base + ntiles, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+    *total_bits = tb;
+    const uint64_t words = (tb + 31) / 32;
+    if (words + 2 > out_words_cap) return -2;
+    if (hipMemsetAsync(d_out_words, 0, (words + 2) * 4, s) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_stock_enc_pack, dim3(g), dim3(256), 0, s, d_em, n, d_clen, d_cbits, d_tile_base, d_out_words);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// scratch: start / last_start / next_start / out_base: (nsub + 2) u64 each, count: nsub u32, flag: 2 u32. Returns 0, or -3 when the counts do not add up to n
+int szk_launch_stock_huff_decode(const szk_stock_tree_dev *tr, const uint32_t *d_words, uint64_t nbytes, uint64_t n, uint64_t *d_start, uint64_t *d_last, uint64_t *d_next,
+                                 uint64_t *d_base, uint32_t *d_count, uint32_t *d_flags, uint16_t *d_em, int *passes, hipStream_t s) {
+    const uint64_t total_bits = nbytes * 8, nwords = (nbytes + 3) / 4;
+    const uint64_t nsub = (total_bits + STOCK_SUB_BITS - 1) / STOCK_SUB_BITS;
+    if (nsub == 0) return n == 0 ? 0 : -3;
+    const uint32_t g = (uint32_t)((nsub + 255) / 256 < 4096 ? (nsub + 255) / 256 : 4096);
+    // first guess: every subsequence starts at its own first bit
+    std::vector<uint64_t> h((size_t)nsub + 2);
+    for (uint64_t i = 0; i <= nsub; i++) h[i] = i * STOCK_SUB_BITS < total_bits ? i * STOCK_SUB_BITS : total_bits;
+    if (hipMemcpyAsync(d_start, h.data(), (nsub + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+    if (hipMemcpyAsync(d_next, h.data(), (nsub + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+    if (hipMemsetAsync(d_last, 0xFF, (nsub + 1) * 8, s) != hipSuccess) return -1;
+    if (hipMemsetAsync(d_count, 0, nsub * 4, s) != hipSuccess) return -1;
+    int it = 0;
+    for (;; it++) {
+        if ((uint64_t)it > nsub + 1) return -3;
+        if (hipMemsetAsync(d_flags, 0, 8, s) != hipSuccess) return -1;
+        hipLaunchKernelGGL(k_stock_huff_sync, dim3(g), dim3(256), 0, s, *tr, d_words, nwords, total_bits, nsub, d_start, d_last, d_next, d_count, d_flags);
+        uint32_t changed = 0;
+        if (hipMemcpyAsync(&changed, d_flags, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+        if (!changed) break;
+        if (hipMemcpyAsync(d_start, d_next, (nsub + 1) * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+    }
+    if (passes) *passes = it + 1;
+    hipLaunchKernelGGL(k_stock_scan32, dim3(1), dim3(1024), 0, s, d_count, nsub, d_base);
+    uint64_t total = 0;
+    if (hipMemcpyAsync(&total, d_base + nsub, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+    if (total < n) return -3;  // (more than n: the last byte's padding decoded as symbols — the write pass stops at n)
+    hipLaunchKernelGGL(k_stock_huff_write, dim3(g), dim3(256), 0, s, *tr, d_words, nwords, total_bits, nsub, d_start, d_base, n, d_em, d_flags + 1);
+    uint32_t bad = 0;
+    if (hipMemcpyAsync(&bad, d_flags + 1, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+    return bad ? -3 : 0;
+}

@@ -86,16 +86,7 @@ template <typename F> void parallel(size_t n_items, F f) {  // f(begin, end, thr
     for (auto &x : th) x.join();
 }
 
-// ---- Huffman in the reference's container -------------------------------------------------------------------------------
-struct Tree {
-    std::vector<uint32_t> L, R;  // children of node i in pre-order numbering (0: none)
-    std::vector<int32_t> C;      // leaf: symbol - offset
-    std::vector<uint8_t> t;      // 1: leaf
-};
-struct Code {
-    uint64_t bits;
-    uint32_t len;
-};
+// ---- Huffman in the reference's container (Tree, Code: sz3hip_stock_host.h) ----------------------------------------------
 // an optimal prefix code over the symbols with freq > 0 (heap merge), as a pre-order tree + the code of every symbol
 void build_tree(const std::vector<uint64_t> &freq, Tree &tr, std::vector<Code> &codes) {
     struct N {
@@ -318,11 +309,48 @@ bool decode_bits(const Tree &tr, int32_t offset, const uint8_t *bits, size_t nby
 }
 }  // namespace
 
-// the pre-zstd buffer of a stock ALGO_INTERP stream from emission-order codes and the quantizer's unpredictable values
-void serialise_interp(const szi_stock_params &p, uint64_t anchor_effective, const uint16_t *em, uint64_t n, const void *unpred, uint64_t n_unpred, size_t tsize,
-                      std::vector<uint8_t> &raw) {
+// the 12-bit table of the device decoder (sz3hip_stock.hip): (node reached << 8) | (bits used << 1) | leaf
+void make_lut(const Tree &tr, std::vector<uint32_t> &lut) {
+    const uint32_t LB = 12;
+    lut.assign(1u << LB, 0);
+    for (uint32_t v = 0; v < (1u << LB); v++) {
+        uint32_t nd = 0, used = 0;
+        while (used < LB && !tr.t[nd]) {
+            const uint32_t nx = ((v >> (LB - 1 - used)) & 1) ? tr.R[nd] : tr.L[nd];
+            if (nx == 0) {  // a missing child: the table sends the decoder nowhere (used = 0 at the root means "corrupt")
+                nd = 0;
+                used = 0;
+                break;
+            }
+            nd = nx;
+            used++;
+        }
+        lut[v] = (nd << 8) | (used << 1) | (tr.t[nd] ? 1u : 0u);
+    }
+}
+// code book of a stock stream from the histogram of its codes: frequencies over [min, max] (HuffmanEncoder::init, :516-537)
+bool book_from_hist(const uint64_t *hist65536, Tree &tr, std::vector<uint8_t> &clen, std::vector<uint64_t> &cbits, int &lo, int &hi) {
+    lo = 0;
+    hi = 65535;
+    while (lo < 65535 && !hist65536[lo]) lo++;
+    while (hi > lo && !hist65536[hi]) hi--;
+    if (!hist65536[lo]) return false;
+    std::vector<uint64_t> freq(hist65536 + lo, hist65536 + hi + 1);
+    std::vector<Code> codes;
+    build_tree(freq, tr, codes);
+    clen.assign(65536, 0);
+    cbits.assign(65536, 0);
+    for (int s = lo; s <= hi; s++) {
+        if (codes[s - lo].len > 64) return false;
+        clen[s] = (uint8_t)codes[s - lo].len;
+        cbits[s] = codes[s - lo].bits;
+    }
+    return true;
+}
+// everything of the pre-zstd buffer in front of the bit stream: decomposition header, quantizer, tree, the two counters
+void write_head(const szi_stock_params &p, uint64_t anchor_effective, const void *unpred, uint64_t n_unpred, size_t tsize, const Tree &tr, int lo, int hi,
+                uint64_t n, uint64_t bit_bytes, std::vector<uint8_t> &raw) {
     raw.clear();
-    raw.reserve((size_t)(n / 2 + n_unpred * tsize + (1u << 16)));
     W w{raw};
     for (int i = 0; i < p.N; i++) w.put<uint64_t>(p.dims[i]);
     w.put<uint32_t>(32);  // blocksize (:87)
@@ -336,32 +364,20 @@ void serialise_interp(const szi_stock_params &p, uint64_t anchor_effective, cons
     w.put<int32_t>(p.radius);
     w.put<uint64_t>(n_unpred);
     if (n_unpred) w.bytes(unpred, (size_t)n_unpred * tsize);
-    // frequencies over [min, max] of the codes (HuffmanEncoder::init, :516-537)
-    const unsigned nt = threads();
-    std::vector<std::vector<uint64_t>> hist(nt, std::vector<uint64_t>(65536, 0));
-    parallel((size_t)n, [&](size_t a, size_t b, unsigned t) {
-        uint64_t *h = hist[t].data();
-        for (size_t i = a; i < b; i++) h[em[i]]++;
-    });
-    std::vector<uint64_t> all(65536, 0);
-    for (auto &h : hist)
-        for (int s = 0; s < 65536; s++) all[s] += h[s];
-    int lo = 0, hi = 65535;
-    while (lo < 65535 && !all[lo]) lo++;
-    while (hi > lo && !all[hi]) hi--;
-    std::vector<uint64_t> freq(all.begin() + lo, all.begin() + hi + 1);
-    Tree tr;
-    std::vector<Code> codes;
-    build_tree(freq, tr, codes);
     save_tree(w, tr, lo, (uint32_t)(hi - lo + 2));
     w.put<uint64_t>(n);
-    std::vector<uint8_t> bits;
-    if (tr.t[0] == 0) encode_bits(em, n, lo, codes, bits);
-    w.put<uint64_t>(bits.size());
-    w.bytes(bits.data(), bits.size());
+    w.put<uint64_t>(bit_bytes);
 }
-// the inverse; false: not a well-formed stream of this kind
-bool parse_interp(const uint8_t *raw, size_t len, int N, size_t tsize, szi_stock_params &p, std::vector<uint16_t> &em, const uint8_t *&unpred, uint64_t &n_unpred) {
+// host coder (A/B partner of the device's, SZ3HIP_STOCK_HOST_HUFFMAN=1)
+void host_encode(const uint16_t *em, uint64_t n, const std::vector<uint8_t> &clen, const std::vector<uint64_t> &cbits, std::vector<uint8_t> &bits) {
+    std::vector<Code> codes(65536);
+    for (int s = 0; s < 65536; s++) codes[s] = Code{cbits[s], clen[s]};
+    encode_bits(em, n, 0, codes, bits);
+}
+bool host_decode(const Tree &tr, int32_t offset, const uint8_t *bits, size_t nbytes, uint64_t n, uint16_t *em) { return decode_bits(tr, offset, bits, nbytes, n, em); }
+// the inverse of write_head; false: not a well-formed stream of this kind. bits / bit_bytes: where the bit stream lies in raw
+bool parse_head(const uint8_t *raw, size_t len, int N, size_t tsize, szi_stock_params &p, const uint8_t *&unpred, uint64_t &n_unpred, Tree &tr, int32_t &offset,
+                uint64_t &n, const uint8_t *&bits, uint64_t &bit_bytes) {
     R r{raw, raw + len};
     memset(&p, 0, sizeof(p));
     p.N = N;
@@ -380,15 +396,13 @@ bool parse_interp(const uint8_t *raw, size_t len, int N, size_t tsize, szi_stock
     if ((uint64_t)(r.end - r.p) / tsize < n_unpred) return false;
     unpred = r.p;
     r.p += (size_t)n_unpred * tsize;
-    Tree tr;
-    int32_t offset = 0;
     if (!load_tree(r, tr, offset)) return false;
-    const uint64_t n = r.get<uint64_t>();
-    const uint64_t nbytes = r.get<uint64_t>();
+    n = r.get<uint64_t>();
+    bit_bytes = r.get<uint64_t>();
     uint64_t want = 1;
     for (int i = 0; i < N; i++) want *= p.dims[i];
-    if (!r.ok || n != want || (uint64_t)(r.end - r.p) < nbytes) return false;
-    em.resize((size_t)n);
-    return decode_bits(tr, offset, r.p, (size_t)nbytes, n, em.data());
+    if (!r.ok || n != want || (uint64_t)(r.end - r.p) < bit_bytes) return false;
+    bits = r.p;
+    return true;
 }
 }  // namespace stock

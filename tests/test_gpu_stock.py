@@ -171,3 +171,30 @@ def test_files_interchange_between_the_two_clis(tmp_path):
     assert float(np.max(np.abs(got.astype(np.float64) - a.reshape(-1).astype(np.float64)))) <= 1e-3
     so, oo = os.path.getsize(tmp_path / "stock.sz"), os.path.getsize(tmp_path / "ours.sz")
     assert oo <= 1.05 * so, (oo, so)
+
+
+@pytest.mark.parametrize("eb", [1e-2, 1e-4], ids=["short-codes", "long-codes"])
+def test_device_and_host_huffman_stages_agree(eb, monkeypatch):
+    """The stock container's Huffman stage runs on the device (tiles coded in LDS and shifted into place; the decoder re-synchronises
+    subsequence by subsequence, sz3hip_stock.hip) — its host twin (SZ3HIP_STOCK_HOST_HUFFMAN=1) must write the same bytes from the same
+    codes and read the same codes from the same bytes. A field whose code words run beyond the decoder's 12-bit table at the tight bound."""
+    a = field3d((96, 100, 104))
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_INTERP
+    conf.absErrorBound = eb
+    L = sz3_amd.lib()
+    blobs, decs = {}, {}
+    L.sz3hip_set_stock_format(1)
+    try:
+        for mode in ("0", "1"):
+            monkeypatch.setenv("SZ3HIP_STOCK_HOST_HUFFMAN", mode)
+            blobs[mode], _ = sz3_amd.compress(a, conf)
+    finally:
+        L.sz3hip_set_stock_format(0)
+    assert blobs["0"].tobytes() == blobs["1"].tobytes()
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SZ3HIP_STOCK_HOST_HUFFMAN", mode)
+        decs[mode], _ = sz3_amd.decompress(blobs["0"], a.dtype, a.shape)
+    assert np.array_equal(decs["0"], decs["1"])
+    want, _ = oracle_decompress(blobs["0"], a.dtype, a.shape)
+    assert np.array_equal(decs["0"], want)

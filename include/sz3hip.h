@@ -105,8 +105,8 @@ size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in);
  * writes for anything but some 1-D arrays) and of ALGO_LOSSLESS, next to this library's own ids 16 / 17; the reconstruction is the
  * reference's bit for bit. WRITING: sz3hip_set_stock_format(1) (or SZ3HIP_STOCK_FORMAT=1 in the environment) makes sz3hip_compress —
  * and everything on top of it — write ALGO_INTERP streams stock SZ3 reads whenever the interpolation predictor is chosen; other
- * outcomes (Lorenzo, regression) keep this library's ids. Prediction, quantisation and reconstruction run on the GPU either way; the
- * reference's Huffman container and zstd are host stages. */
+ * outcomes (Lorenzo, regression) keep this library's ids. Prediction, quantisation, reconstruction and the Huffman bit stream run on the
+ * GPU either way; the tree's serialisation and zstd are host stages. */
 void sz3hip_set_stock_format(int on);
 int sz3hip_get_stock_format(void);
 /* the same over at most `avail` readable bytes: 0 when the serialised Config does not fit in them (truncated stream) */

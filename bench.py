@@ -240,11 +240,14 @@ class Workload:
         self.dc.decompress(self.d_payload.data_ptr(), psize, d_out.data_ptr(), self.stream)
         torch.cuda.synchronize()
         max_err = float((d_out.double() - self.d_in.double()).abs().max().item())
-        t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(3):  # (the error check above left the allocator and the caches in another state)
             self.dc.decompress(self.d_payload.data_ptr(), psize, d_out.data_ptr(), self.stream)
         torch.cuda.synchronize()
-        return max_err, (time.perf_counter() - t0) / 5 * 1e3
+        t0 = time.perf_counter()
+        for _ in range(20):
+            self.dc.decompress(self.d_payload.data_ptr(), psize, d_out.data_ptr(), self.stream)
+        torch.cuda.synchronize()
+        return max_err, (time.perf_counter() - t0) / 20 * 1e3
 
 
 def live_traffic(args, kernel_prefixes, child_steps=6, child_warmup=4):
@@ -658,10 +661,29 @@ def main():
             t2 = time.perf_counter()
             best_c = max(best_c, raw_bytes / (t1 - t0) / 1e9)
             best_d = max(best_d, raw_bytes / (t2 - t1) / 1e9)
+        # the same two calls into buffers the caller keeps from call to call (the reference's pre-allocated overloads, api/sz.hpp:43-62,
+        # 84-110): a fresh 537 MB array is 131 072 pages touched for the first time inside the device->host copy
+        reuse_c = reuse_d = 0.0
+        cbuf = np.empty(sz3_amd.compress_bound(w.conf, w.npdt), dtype=np.uint8)
+        dbuf = np.empty(w.a.size, dtype=w.npdt)
+        cbuf[:] = 0
+        dbuf[:] = 0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            blob2, _ = sz3_amd.compress(w.a, w.conf, out=cbuf)
+            t1 = time.perf_counter()
+            dec2, _ = sz3_amd.decompress(blob2, w.npdt, shape, out=dbuf)
+            t2 = time.perf_counter()
+            reuse_c = max(reuse_c, raw_bytes / (t1 - t0) / 1e9)
+            reuse_d = max(reuse_d, raw_bytes / (t2 - t1) / 1e9)
         out["host_e2e"] = {"compress_gbps": round(best_c, 3), "ratio": round(hratio, 4),
                            "decompress_gbps": round(best_d, 3),
+                           "compress_gbps_buffers_reused": round(reuse_c, 3), "decompress_gbps_buffers_reused": round(reuse_d, 3),
                            "max_abs_err": float(np.max(np.abs(dec.astype(np.float64) - w.a.astype(np.float64)))),
-                           "note": "host buffer in -> host SZ3 container out: H2D + kernels + D2H + zstd(threads); best of 3 calls"}
+                           "identical_with_reused_buffers": bool(np.array_equal(dec2.reshape(-1), dec.reshape(-1)) and np.array_equal(blob2, blob)),
+                           "note": "host buffer in -> host SZ3 container out: H2D + kernels + D2H + zstd(threads); best of 3 calls. "
+                                   "*_buffers_reused: output buffers the caller allocated once (no first-touch page faults inside the copies)"}
+        del cbuf, dbuf
 
     # ---- the other single-GPU configuration of BASELINE.json, same protocol, as an extra object of the same line ----
     if rank == 0 and world == 1 and not args.no_extra and args.algo == "lorenzo" and args.dtype == "f32" and tuple(shape) == (512, 512, 512):

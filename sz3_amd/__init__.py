@@ -281,14 +281,21 @@ def compress_bound(conf, dtype):
     return int(lib().sz3hip_compress_bound(C.byref(conf._c), _dtype_id(dtype)))
 
 
-def compress(data, conf):
-    """sz.compress (sz.pyx:185-272): returns (uint8 ndarray, ratio)."""
+def compress(data, conf, out=None):
+    """sz.compress (sz.pyx:185-272): returns (uint8 ndarray, ratio). `out`: a caller's uint8 buffer of at least
+    compress_bound(conf, dtype) bytes — the pre-allocated form, SZ_compress(conf, data, cmpData, cmpCap) (api/sz.hpp:43-62); a buffer
+    used before costs no first-touch page faults."""
     a = np.ascontiguousarray(data)
     dt = _dtype_id(a.dtype)
     if int(conf.num) != a.size:
         raise ValueError("config dims do not match the array")
     cap = compress_bound(conf, a.dtype)
-    out = np.empty(cap, dtype=np.uint8)
+    if out is None:
+        out = np.empty(cap, dtype=np.uint8)
+    elif out.dtype != np.uint8 or not out.flags.c_contiguous or out.size < cap:
+        raise ValueError("out must be a contiguous uint8 array of at least compress_bound(conf, dtype) = %d bytes" % cap)
+    else:
+        cap = out.size
     n = lib().sz3hip_compress(C.byref(conf._c), dt, a.ctypes.data, out.ctypes.data, cap)
     if n == 0:
         raise SZ3HipError(-1, lib().sz3hip_last_error().decode())
@@ -296,12 +303,18 @@ def compress(data, conf):
     return blob, a.nbytes / float(n)
 
 
-def decompress(blob, dtype, shape=None):
-    """sz.decompress (sz.pyx:276-365): returns (ndarray, Config)."""
+def decompress(blob, dtype, shape=None, out=None):
+    """sz.decompress (sz.pyx:276-365): returns (ndarray, Config). `out`: a caller's array of the stream's element count and `dtype`
+    — the pre-allocated form, SZ_decompress(conf, cmpData, cmpSize, decData) (api/sz.hpp:84-110)."""
     blob = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8) if isinstance(blob, (bytes, bytearray)) else blob)
     conf = Config(1)
     _check(lib().sz3hip_peek_config(C.byref(conf._c), blob.ctypes.data, blob.size))
-    dec = np.empty(int(conf.num), dtype=dtype)
+    if out is None:
+        dec = np.empty(int(conf.num), dtype=dtype)
+    else:
+        if out.dtype != np.dtype(dtype) or not out.flags.c_contiguous or out.size != int(conf.num):
+            raise ValueError("out must be a contiguous %s array of %d elements" % (np.dtype(dtype), int(conf.num)))
+        dec = out.reshape(-1)
     _check(lib().sz3hip_decompress(C.byref(conf._c), _dtype_id(dtype), blob.ctypes.data, blob.size, dec.ctypes.data))
     if shape is None:
         shape = conf.dims

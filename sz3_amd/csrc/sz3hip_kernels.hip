@@ -3797,6 +3797,14 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     __syncthreads();
     const uint64_t unit = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t n_units = (p.n + UNIT - 1) / UNIT;
+    static_assert(64 / SZH_SUBS == PACK_GROUP, "a wave's units are one offset group");
+    uint32_t woff_in, nwords;
+    {
+        const uint64_t ch = unit / SZH_SUBS;
+        nwords = ch < p.n_chunks ? (uint32_t)p.chunk_words[ch] : 0u;
+        const uint32_t mine = (unit % SZH_SUBS) == 0 ? nwords : 0u;  // (a chunk counts once: at its first unit)
+        woff_in = wave_incl_scan(mine) - nwords;  // (inclusive: the sum reaches the lane's own chunk at either of its units)
+    }
     if (unit >= n_units) return;
     const uint64_t chunk = unit / SZH_SUBS;
     const uint32_t sub = (uint32_t)(unit % SZH_SUBS);
@@ -3810,6 +3818,36 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     uint8_t *wave_out = QB ? reinterpret_cast<uint8_t *>(p.q_out) + (s0 - (uint64_t)lane_id() * UNIT) * ELT
                            : reinterpret_cast<uint8_t *>(codes + (s0 - (uint64_t)lane_id() * UNIT));
     uint32_t ovf_seen = 0;
+    // The stores lag one round behind (round 4): a wave's vector memory operations retire in order, so the wait for the next round's
+    // stream words also waits for every store issued before it — the values are read back from the stage into registers when a
+    // piece is complete and stored at the top of the following round, behind that round's stream load: both have a whole round to land.
+    static_assert(NP * NR == 4 || NP * NR == 8, "pieces of a lane's staged output");
+    uint4 h0, h1, h2, h3, h4, h5, h6, h7;  // (named, not an array: an array written in one lambda and read in another went to scratch memory)
+    h0 = h1 = h2 = h3 = h4 = h5 = h6 = h7 = make_uint4(0, 0, 0, 0);
+    uint32_t held_i0 = 0;
+    bool held_any = false;
+    auto flush1 = [&](uint32_t it, const uint4 &h) {
+        const uint32_t idx = it * 64 + (uint32_t)lane_id(), c = idx / (NP * NR), j = idx % (NP * NR);
+        *reinterpret_cast<uint4 *>(wave_out + ((uint64_t)c * UNIT + held_i0) * ELT + j * 16) = h;
+    };
+    auto coop_flush = [&]() {
+        if (!held_any) return;
+        flush1(0, h0);
+        flush1(1, h1);
+        flush1(2, h2);
+        flush1(3, h3);
+        if constexpr (NP * NR > 4) {
+            flush1(4, h4);
+            flush1(5, h5);
+            flush1(6, h6);
+            flush1(7, h7);
+        }
+        held_any = false;
+    };
+    auto stash1 = [&](uint32_t it, uint4 &h) {
+        const uint32_t idx = it * 64 + (uint32_t)lane_id(), c = idx / (NP * NR), j = idx % (NP * NR);
+        h = stage[c * (NP * NR + 1) + j];
+    };
     auto coop_store = [&](const uint4 (&pc)[NP], uint32_t rnd) {
         const uint32_t sb = rnd % NR;
 #pragma unroll
@@ -3817,13 +3855,18 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
         if (sb != NR - 1) return;
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        const uint32_t i0 = (rnd - sb) * 16;
-#pragma unroll
-        for (uint32_t it = 0; it < NP * NR; it++) {
-            const uint32_t idx = it * 64 + (uint32_t)lane_id(), c = idx / (NP * NR), j = idx % (NP * NR);
-            const uint4 v = stage[c * (NP * NR + 1) + j];
-            *reinterpret_cast<uint4 *>(wave_out + ((uint64_t)c * UNIT + i0) * ELT + j * 16) = v;
+        held_i0 = (rnd - sb) * 16;
+        stash1(0, h0);
+        stash1(1, h1);
+        stash1(2, h2);
+        stash1(3, h3);
+        if constexpr (NP * NR > 4) {
+            stash1(4, h4);
+            stash1(5, h5);
+            stash1(6, h6);
+            stash1(7, h7);
         }
+        held_any = true;
         __builtin_amdgcn_wave_barrier();
     };
     // symbols left in the current row (the unit may start inside a row); the running sum restarts at every row start
@@ -3854,12 +3897,11 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
         }
         return;
     }
-    // word offset of the chunk: group offset + the chunks before it inside its group
+    // word offset of the chunk: group offset + the chunks before it inside its group (woff_in: a wave's 64 units are the 32 chunks
+    // of ONE group — one load per lane and a wave scan, before the lanes past the array's end left)
     const uint64_t grp = chunk / PACK_GROUP;
-    uint64_t woff = p.group_off[grp];
-    for (uint64_t c = grp * PACK_GROUP; c < chunk; c++) woff += p.chunk_words[c];
+    const uint64_t woff = p.group_off[grp] + woff_in;
     const uint32_t *bs = reinterpret_cast<const uint32_t *>(payload + p.bitstream_off);
-    const uint32_t nwords = p.chunk_words[chunk];
     const uint64_t wlast = p.total_words ? p.total_words - 1 : 0;  // loads are clamped to the section, never conditional
     // the unit's first bit inside the chunk (a corrupt offset decodes other bits of the section: wrong values, no wrong access)
     const uint32_t bit0 = sub ? (uint32_t)p.sub_bits[chunk * (SZH_SUBS - 1) + sub - 1] : 0u;
@@ -3875,30 +3917,42 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
         wi++;
     }
     const uint32_t nrounds = (nsym + 15) / 16;
+    // Stream words, one round ahead (round 4). A round of 16 symbols takes its words from `qw` = the lane's next four; it used to load
+    // them at its top — an address known only when the previous round was decoded, so every round began with an exposed trip to
+    // the L2 or beyond (and, the operations retiring in order, with the wait for the previous round's stores). Now the top of a
+    // round issues the load of the four words BEHIND its own four (`far`), and the next round's four are picked out of the eight
+    // the lane then holds by the number of words this round took (0 .. 4: a three-stage select); a round that took more (code
+    // words beyond 8 bits on average) loads directly as before.
+    typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
+    auto load4 = [&](uint64_t a, uint32_t (&w)[4]) {
+        // ONE 16-byte load at the lane's word position (4-byte aligned: the hardware takes it) instead of four 4-byte ones: a
+        // wave's loads touch 64 different cache lines per instruction either way
+        if (a + 3 <= wlast) {
+            const U4 v = *reinterpret_cast<const U4 *>(bs + a);
+            w[0] = v.x;
+            w[1] = v.y;
+            w[2] = v.z;
+            w[3] = v.w;
+        } else {  // (the section's last words: clamped, never out of bounds)
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[k] = bs[a + k < wlast ? a + k : wlast];
+        }
+    };
+    uint32_t qw[4], far[4];
+    load4(woff + wi, qw);
+#pragma unroll
+    for (int k = 0; k < 4; k++) qw[k] = __builtin_bswap32(qw[k]);
     for (uint32_t rnd = 0; rnd < nrounds; rnd++) {
         const uint32_t i0 = rnd * 16;
-        // the next four stream words of this lane, fetched once per 16 symbols with one wait (a load issued inside the
-        // divergent refill branch would be waited for at every symbol); typical groups consume 2-3 words, longer ones
-        // fall back to single loads
-        uint32_t qw[4];
-        {
-            // ONE 16-byte load at the lane's word position (4-byte aligned: the hardware takes it) instead of four 4-byte ones: a
-            // wave's loads touch 64 different cache lines per instruction either way (PMC: the 69 MB stream was fetched seven
-            // times over from beyond the L2 — 33 MB of lines are live across the chip's waves, and every line was asked for by
-            // four instructions a round, sixteen rounds long)
-            typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
-            const uint64_t a = woff + wi;
-            if (a + 3 <= wlast) {
-                const U4 v = *reinterpret_cast<const U4 *>(bs + a);
-                qw[0] = __builtin_bswap32(v.x);
-                qw[1] = __builtin_bswap32(v.y);
-                qw[2] = __builtin_bswap32(v.z);
-                qw[3] = __builtin_bswap32(v.w);
-            } else {  // (the section's last words: clamped, never out of bounds)
-#pragma unroll
-                for (int k = 0; k < 4; k++) qw[k] = __builtin_bswap32(bs[a + k < wlast ? a + k : wlast]);
-            }
-        }
+#if defined(LAB_DEC_ABL) && (LAB_DEC_ABL & 2)  // (lab, wrong results: no stream loads)
+        far[0] = far[1] = far[2] = far[3] = 0x9E3779B9u * (rnd + 1);
+#else
+        load4(woff + wi + 4, far);
+#endif
+#if defined(LAB_DEC_ABL) && (LAB_DEC_ABL & 1)  // (lab, wrong results: no stores)
+        held_any = false;
+#endif
+        if (coop) coop_flush();
         uint32_t qn = 0;
         uint32_t syms[16];
         // code books of at most 16-bit words (every alphabet up to 512 symbols): two symbols never need more than the 32 bits
@@ -3922,7 +3976,11 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
                 have += 32;
                 wi++;
             }
+#if defined(LAB_DEC_ABL) && (LAB_DEC_ABL & 4)  // (lab, wrong results: no table lookup — 4-bit code words)
+            const uint32_t ent = ((((uint32_t)(buf >> 60)) + p.radius - 8u) << 8) | 4u;
+#else
             const uint32_t ent = s_lut[(uint32_t)(buf >> 32) >> (32 - K)];
+#endif
             uint32_t l = ent & 0xFFu;
             sym = ent >> 8;
             if (ent == 0) {  // longer than the table
@@ -4068,7 +4126,28 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
             for (int k = 0; k < 16; k++)
                 if (i0 + k < nsym) out[i0 + k] = (uint16_t)syms[k];
         }
+        {   // the next round's four words: the eight held (qw, far) from word qn on
+            uint32_t t[7], u[5];
+#pragma unroll
+            for (int k = 0; k < 4; k++) far[k] = __builtin_bswap32(far[k]);
+            // (bit masks, not conditional expressions: hipcc turns `c ? t[k + 2] : t[k]` into an indexed load from a copy of t in scratch memory)
+            const uint32_t m4 = 0u - ((qn >> 2) & 1u), m2 = 0u - ((qn >> 1) & 1u), m1 = 0u - (qn & 1u);
+#pragma unroll
+            for (int k = 0; k < 4; k++) t[k] = (far[k] & m4) | (qw[k] & ~m4);
+#pragma unroll
+            for (int k = 0; k < 3; k++) t[4 + k] = far[k];
+#pragma unroll
+            for (int k = 0; k < 5; k++) u[k] = (t[k + 2] & m2) | (t[k] & ~m2);
+#pragma unroll
+            for (int k = 0; k < 4; k++) qw[k] = (u[k + 1] & m1) | (u[k] & ~m1);
+            if (qn > 4) {  // (more than four words in sixteen symbols: long code words — loaded where the lane now stands)
+                load4(woff + wi, qw);
+#pragma unroll
+                for (int k = 0; k < 4; k++) qw[k] = __builtin_bswap32(qw[k]);
+            }
+        }
     }
+    if (coop) coop_flush();
     if (QB && p.carry) reinterpret_cast<QO *>(p.carry)[unit] = acc;
     if (HALF && __ballot(ovf_seen != 0) && lane_id() == 0) atomicOr(p.ovf, 1u);
 }

@@ -348,7 +348,7 @@ static size_t payload_bound_blocks(uint64_t n, uint64_t out_cap, uint64_t side_b
 // checks the caller's capacity against the blocks the call really has, and sz3hip_payload_bound_conf sizes a buffer for them.
 static size_t payload_bound_n(uint64_t n, uint64_t out_cap) { return payload_bound_blocks(n, out_cap, n / 27 + 64); }
 // shapes the block-composed predictor is built for: 3-D with block edges 4..8 (tiles in LDS), 1-D with blocks of 4..65535 values,
-// 2-D with block edges 4..32 (the decoder's block in LDS); second-order Lorenzo in 3-D only (decided where the set is known)
+// 2-D with block edges 4..32 (the decoder's block in LDS); second-order Lorenzo in 1-D and 3-D (decided where the set is known)
 static bool blk_shape_ok(const sz3hip_config *conf) {
     if (conf->N == 3) return conf->blockSize >= 4 && conf->blockSize <= 8;
     if (conf->N == 2) return conf->blockSize >= 4 && conf->blockSize <= 32 && conf->dims[0] < 0xFFFFFFFFull && conf->dims[1] < 0xFFFFFFFFull;
@@ -1048,17 +1048,25 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
         }
     }
     if (N == 1 && best_interp < 50) {  // :232-247 — here: this library's own Lorenzo coder over the concatenated samples
+        // (round 4: the reference's own trial geometry — every sample block an array of its own, blocks of five values, Lorenzo-1 or
+        // Lorenzo-2 per block — instead of first-order Lorenzo over the concatenated samples: on smooth 1-D series the second-order
+        // blocks are what makes Lorenzo win, and the set chosen here is the one stage 1 then codes the array with)
         HIPCHK(clear_hist_counters(ctx, s));
-        HIPCHK(hipMemsetAsync(ctx->d_trial + 24, 0, 32, s));
-        szk_k1_params p;
-        const uint64_t d1[1] = {sampling_num};
-        rc = lorenzo_k1(ctx, 1, d1, ctx->d_samples, eb, radius, sampling_num, 0, false, p, s);
+        HIPCHK(hipMemsetAsync(ctx->d_trial + 24, 0, 64, s));
+        rc = szk_launch_trial_lorenzo12(ctx->dtype == SZ3HIP_FLOAT ? 0 : 1, ctx->d_samples, per, nb, eb, radius, ctx->d_hist, ctx->d_counters, ctx->d_trial + 28, s);
         if (rc) return fail(SZ3HIP_EHIP, "tuner: Lorenzo trial launch failed (%d)", rc);
         rc = szk_launch_code_cost(ctx->d_hist, ctx->d_counters, ctx->d_trial + 24, 1, sampling_num, 0, s);
         if (rc) return fail(SZ3HIP_EHIP, "tuner: cost kernel launch failed (%d)", rc);
         rc = tuner_fetch(ctx, s);
         if (rc) return rc;
         rep.est_bytes[6] = trial_bytes(ctx->h_trial + 24, tsz);
+        {   // the choices' own cost (ComposedPredictor::save: the selection vector Huffman-coded, ComposedPredictor.hpp:52-64): its entropy
+            const double nblk = (double)ctx->h_trial[29], n2 = (double)ctx->h_trial[28];
+            if (nblk > 0 && n2 > 0 && n2 < nblk) {
+                const double p2 = n2 / nblk;
+                rep.est_bytes[6] += nblk * -(p2 * std::log2(p2) + (1 - p2) * std::log2(1 - p2)) / 8.0;
+            }
+        }
         best_lorenzo = raw / rep.est_bytes[6];
     }
     rep.ran = 1;
@@ -1067,7 +1075,14 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
     if (use_interp) {
         conf.cmprAlgo = SZ3HIP_ALGO_INTERP;
     } else {
+        // SZAlgoInterp.hpp:233-240, 282: the set the trial priced — Lorenzo-1 + Lorenzo-2, no regression — and, through setDims, the
+        // default block size of a 1-D array again (the trial's blocks of five do not survive it)
         lorenzo_config.cmprAlgo = SZ3HIP_ALGO_LORENZO_REG;
+        lorenzo_config.lorenzo = 1;
+        lorenzo_config.lorenzo2 = 1;
+        lorenzo_config.regression = 0;
+        lorenzo_config.regression2 = 0;
+        lorenzo_config.blockSize = 128;
         conf = lorenzo_config;
     }
     rep.interpAlgo = conf.interpAlgo;
@@ -1205,7 +1220,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
         const uint32_t mask = (conf->lorenzo ? 1u : 0u) | (conf->lorenzo2 ? 2u : 0u) | (conf->regression ? 4u : 0u);
         if (mask == 0) return fail(SZ3HIP_EINVAL, "All lorenzo and regression methods are disabled.");
         if (mask != 1u) {
-            if (blk_shape_ok(conf) && (conf->N == 3 || !(mask & 2u)) && !(szk_dbg_flags & 16384)) {
+            if (blk_shape_ok(conf) && (conf->N == 3 || conf->N == 1 || !(mask & 2u)) && !(szk_dbg_flags & 16384)) {
                 bool all_lorenzo = false;
                 const int rcs = blk_all_lorenzo(ctx, conf, d_in, eb, radius, mask, s, &all_lorenzo);
                 if (rcs) return rcs;
@@ -1214,7 +1229,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
             }
             if (!(mask & 1u))
                 return fail(SZ3HIP_EUNSUPPORTED, "regression is built for 1-D (blockSize 4..65535), 2-D (4..32) and 3-D arrays (4..8), 2nd-order "
-                                                 "Lorenzo for 3-D ones (got N = %d, blockSize = %d)", conf->N, conf->blockSize);
+                                                 "Lorenzo for 1-D and 3-D ones (got N = %d, blockSize = %d)", conf->N, conf->blockSize);
         }
     }
     return stage1_lorenzo(ctx, conf, d_in, eb, radius, num, s);
@@ -1770,7 +1785,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         const uint32_t B = h.interp_id, mask = h.interp_dir;
         const bool fits32 = h.dims[1] < 0xFFFFFFFFull && h.dims[2] < 0xFFFFFFFFull && h.dims[3] < 0xFFFFFFFFull;  // (block positions are 32-bit)
         const bool shape_ok = fits32 && (h.ndim == 3 ? B >= 4 && B <= 8 : (h.ndim == 2 ? B >= 4 && B <= 32 && h.dims[1] == 1 && !(mask & 2u)
-                                                                 : h.ndim == 1 && B >= 4 && B <= 65535 && h.dims[1] == 1 && h.dims[2] == 1 && !(mask & 2u)));
+                                                                 : h.ndim == 1 && B >= 4 && B <= 65535 && h.dims[1] == 1 && h.dims[2] == 1));
         if (!shape_ok || mask == 0 || mask > 7 || h.side_bytes < 24 || h.n_dout > h.n)
             return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block predictor fields)");
         uint64_t nblocks = 1;
@@ -1782,7 +1797,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
             if (ctx->d_blk_carry) HIPCHK(hipFree(ctx->d_blk_carry));
             ctx->d_blk_carry = nullptr;
             ctx->blk_carry_cap = 0;
-            HIPCHK(hipMalloc(&ctx->d_blk_carry, nblocks * 17 + (nblocks / 1024 + 2) * 16 + 64));  // (+ the tiles' words, a flag byte per block)
+            HIPCHK(hipMalloc(&ctx->d_blk_carry, nblocks * 17 + (nblocks / 1024 + 2) * 64 + 64));  // (+ the tiles' words — eight each for the second-order scan — and a flag byte per block)
             ctx->blk_carry_cap = nblocks;
         }
         const uint64_t sel_bytes = ((nblocks + 3) / 4 + 7) & ~7ull;

@@ -820,6 +820,13 @@ int job_encode(SlabJob &j) {
             if (ctx->h_state->hdr.predictor == 0) {  // the plain Lorenzo stream: the trailer names the predictor set that coded it
                 j.conf.lorenzo = 1;
                 j.conf.lorenzo2 = j.conf.regression = j.conf.regression2 = 0;
+            } else if (ctx->h_state->hdr.predictor == 2) {  // the block-composed stream: its header holds the set and the block edge (the tuner's, in 1-D)
+                const uint32_t mask = ctx->h_state->hdr.interp_dir;
+                j.conf.lorenzo = mask & 1u;
+                j.conf.lorenzo2 = (mask >> 1) & 1u;
+                j.conf.regression = (mask >> 2) & 1u;
+                j.conf.regression2 = 0;
+                j.conf.blockSize = (int)ctx->h_state->hdr.interp_id;
             }
             if ((double)j.raw_bytes / (double)j.out_size < 3) {  // SZDispatcher.hpp:62-74
                 std::vector<uint8_t> z(zs::bound_frames(j.raw_bytes) + 8);

@@ -240,6 +240,9 @@ struct szk_blk_scratch {
     uint8_t side_hdr[32];   // decode: host copy of the side section's header + [24..31] words of its bit section (validated by the caller)
 };
 // the selection pass alone (a block per lane): *n_other += the blocks that would not be coded by first-order Lorenzo
+// the tuner's Lorenzo trial for 1-D arrays: the set [Lorenzo-1, Lorenzo-2] in blocks of five over the sample blocks (sz3hip_regress.hip)
+int szk_launch_trial_lorenzo12(int dtype, const void *d_samples, uint64_t per, uint64_t nsb, double eb, int radius, uint64_t *hist, uint64_t *counters,
+                               uint64_t *extra, hipStream_t s);
 int szk_launch_blk_select(int dtype, const void *d_in, const szk_blk_params *p, uint64_t *n_other, hipStream_t s);
 int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s);
 // decoder, first part (stream-independent of the Huffman decoder): the side section -> sel[], rank[], coef_by_rank[]

@@ -1727,6 +1727,40 @@ __global__ __launch_bounds__(NW * 64) void k_blkn_fit(const T *__restrict__ in, 
         }
         // ---- selection (ComposedPredictor.hpp:25-40 over foreach_sampling) ----
         sid = has_l1 ? 0 : 2;
+        if (!two && (p.mask & 2u)) {
+            // 1-D with second-order Lorenzo in the set (round 4): the members in the set's order [Lorenzo-1, Lorenzo-2, regression]
+            // (SZAlgoLorenzoReg.hpp:28-64), the estimates at the block's two ends, the first minimum wins (std::min_element).
+            // LorenzoPredictor.hpp:69-71: 2 d[-1] - d[-2]; noise 1.08 eb (:17-38)
+            const T noise2 = (T)(1.08 * p.eb);
+            double e1 = 0, e2 = 0, er = 0;
+            if (lane < 2) {
+                const uint32_t i2 = lane ? g.ex - 1 : 0u;
+                const int64_t x = (int64_t)g.ox + i2;
+                const T v = in[x];
+                const T s1 = blkn_seen(in, p, lat, g, 0, x - 1), s2 = blkn_seen(in, p, lat, g, 0, x - 2);
+                e1 = (double)(T)((T)fabs((double)(T)(v - s1)) + noise);
+                e2 = (double)(T)((T)fabs((double)(T)(v - (T)((T)(2 * s1) - s2))) + noise2);
+                if (r_valid) er = (double)(T)fabs((double)(T)(v - reg_predict(cf, 0u, 0u, i2)));
+            }
+            e1 = wave_sum_f64(e1);
+            e2 = wave_sum_f64(e2);
+            er = wave_sum_f64(er);
+            int best = -1;
+            double eb_best = 0;
+            if (has_l1) {
+                best = 0;
+                eb_best = e1;
+            }
+            if (best < 0 || e2 < eb_best) {
+                best = 1;
+                eb_best = e2;
+            }
+            if (has_r) {
+                // (an invalid regression's estimate is DBL_MAX: it wins only when it is the set's single... never here, Lorenzo-2 is in the set)
+                if (r_valid && er < eb_best) best = 2;
+            }
+            sid = best;
+        } else
         if (has_l1 && has_r) {
             const uint32_t m = two ? min(g.ey, g.ex) : g.ex;
             const uint32_t npts = two ? 2 * m : 2;
@@ -2057,7 +2091,9 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo(const T *__restrict__ in, u
                 e = blkn_pos(p, act ? c : 0);
             }
         }
-        act = act && p.sel[e.task] != 2;
+        const uint8_t own_sel = p.sel[e.task];
+        act = act && own_sel != 2;
+        const bool second = !TWO && own_sel == 1;  // 1-D, second-order Lorenzo: q - 2 q[-1] + q[-2] (LorenzoPredictor.hpp:69-71 on the lattice)
         UQ delta = 0;
         bool own_bad = false;
         T own_raw = 0;
@@ -2065,6 +2101,10 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo(const T *__restrict__ in, u
         if (act && !direct) {
             delta = (UQ)qw[gi];
             if (e.x) delta -= (UQ)qw[gi - 1];
+            if (second) {
+                if (e.x) delta -= (UQ)qw[gi - 1];
+                if (e.x > 1) delta += (UQ)qw[gi - 2];
+            }
             if (e.y) {
                 delta -= (UQ)qw[gi - d2];
                 if (e.x) delta += (UQ)qw[gi - d2 - 1];
@@ -2084,7 +2124,14 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo(const T *__restrict__ in, u
             };
             const uint32_t tl = e.x == e.ox ? e.task - 1 : e.task;  // the block of the left neighbour
             delta = qt(gi, e.task, true);
-            if (e.x) delta -= qt(gi - 1, tl, false);
+            if (e.x) {
+                const UQ l1 = qt(gi - 1, tl, false);
+                delta -= l1;
+                if (second) {
+                    delta -= l1;
+                    if (e.x > 1) delta += qt(gi - 2, e.x - e.ox < 2 ? e.task - 1 : e.task, false);  // (blocks hold four values or more)
+                }
+            }
             if (TWO && e.y) {
                 const uint32_t up = e.y == e.oy ? p.nb[2] : 0u;
                 delta -= qt(gi - d2, e.task - up, false);
@@ -2491,6 +2538,226 @@ __global__ __launch_bounds__(256) void k_blkn_pre1_rows(const uint16_t *__restri
         if (live && !reg && li == 15) agg[2 * (uint64_t)task] = (Q)tot;
     }
 }
+// ---- 1-D with second-order Lorenzo in the predictor set (round 4; LorenzoPredictor.hpp:69-71, chosen by the reference's tuner for
+// 1-D arrays: SZAlgoInterp.hpp:232-247) ----
+// A second-order block needs the TWO lattice values left of it. The state carried along the array is the pair (a, b) = (q~ of the
+// element left of the block, q~ of the one before that); a block of m elements maps it to the pair behind its last element:
+//   regression:  (a, b) -> (r_m, r_{m-1})                                   its own lattice values, nothing of the inflow
+//   Lorenzo-1:   (a, b) -> (a + S_m, a + S_{m-1})                           S_k: running sum of the block's deltas, S_0 = 0
+//   Lorenzo-2:   (a, b) -> ((m + 1) a - m b + P_m, m a - (m - 1) b + P_{m-1})   P_k: running sum of S (q_k = (k+1) a - k b + P_k)
+// — affine maps x -> M x + v with a matrix that the block's choice and length give, and affine maps compose associatively (in
+// the wrap-around integers the lattice lives in): the segmented prefix sum of the first-order path becomes a scan of compositions.
+// Reduce-then-scan over tiles of 1024 blocks: k_blkn2_pre leaves every block's v (two words), k_blkn2_tile composes a tile,
+// k_blkn2_top runs over the tiles, k_blkn2_apply scans its tile again from the tile's inflow and rebuilds the Lorenzo blocks.
+// carry buffer: Q v[2 * nblocks], then per tile eight words (M, v of the tile; the state in front of it).
+template <typename UQ>
+struct BlkAff {
+    UQ m00, m01, m10, m11, v0, v1;
+};
+template <typename UQ>
+__device__ __forceinline__ BlkAff<UQ> aff_after(const BlkAff<UQ> &g, const BlkAff<UQ> &f) {  // first f, then g
+    BlkAff<UQ> r;
+    r.m00 = g.m00 * f.m00 + g.m01 * f.m10;
+    r.m01 = g.m00 * f.m01 + g.m01 * f.m11;
+    r.m10 = g.m10 * f.m00 + g.m11 * f.m10;
+    r.m11 = g.m10 * f.m01 + g.m11 * f.m11;
+    r.v0 = g.m00 * f.v0 + g.m01 * f.v1 + g.v0;
+    r.v1 = g.m10 * f.v0 + g.m11 * f.v1 + g.v1;
+    return r;
+}
+template <typename UQ>
+__device__ __forceinline__ BlkAff<UQ> aff_ident() {
+    return BlkAff<UQ>{1, 0, 0, 1, 0, 0};
+}
+template <typename UQ>
+__device__ __forceinline__ BlkAff<UQ> aff_const(UQ v0, UQ v1) {
+    return BlkAff<UQ>{0, 0, 0, 0, v0, v1};
+}
+template <typename UQ>
+__device__ __forceinline__ BlkAff<UQ> aff_of_block(uint32_t sel, uint32_t m, UQ v0, UQ v1) {
+    if (sel == 2) return aff_const<UQ>(v0, v1);
+    if (sel == 1) return BlkAff<UQ>{(UQ)m + 1, (UQ)0 - (UQ)m, (UQ)m, (UQ)0 - (UQ)(m - 1), v0, v1};
+    return BlkAff<UQ>{1, 0, 1, 0, v0, v1};
+}
+template <typename UQ>
+__device__ __forceinline__ UQ shfl_up_uq(UQ v, int off) {
+    if (sizeof(UQ) == 8) return (UQ)__shfl_up((long long)v, off);
+    return (UQ)__shfl_up((int)v, off);
+}
+template <typename UQ>
+__device__ __forceinline__ BlkAff<UQ> aff_shfl_up(const BlkAff<UQ> &x, int off) {
+    return BlkAff<UQ>{shfl_up_uq(x.m00, off), shfl_up_uq(x.m01, off), shfl_up_uq(x.m10, off), shfl_up_uq(x.m11, off), shfl_up_uq(x.v0, off), shfl_up_uq(x.v1, off)};
+}
+// inclusive scan of compositions over a workgroup of 1024 threads (thread order = block order); inflow: the map in front of thread 0;
+// excl: the composition in front of this thread. ws: [16] in LDS.
+template <typename UQ>
+__device__ __forceinline__ BlkAff<UQ> aff_wg_scan(BlkAff<UQ> x, const BlkAff<UQ> &inflow, BlkAff<UQ> &excl, BlkAff<UQ> *ws) {
+    const int lane = lane_id();
+    const uint32_t w = threadIdx.x / WAVE;
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const BlkAff<UQ> y = aff_shfl_up(x, off);
+        if (lane >= off) x = aff_after(x, y);
+    }
+    if (lane == WAVE - 1) ws[w] = x;
+    __syncthreads();
+    BlkAff<UQ> pre = inflow;
+    for (uint32_t k = 0; k < w; k++) pre = aff_after(ws[k], pre);
+    const BlkAff<UQ> incl = aff_after(x, pre);
+    excl = aff_shfl_up(incl, 1);
+    if (lane == 0) excl = pre;
+    __syncthreads();
+    return incl;
+}
+template <typename Q>
+__device__ __forceinline__ Q *blkn2_tiles(void *carry, uint32_t nblocks) { return reinterpret_cast<Q *>(carry) + 2 * (uint64_t)nblocks; }
+
+// every block's v: a regression block is decoded here (final values out, the lattice values of its last two elements kept); a Lorenzo
+// block leaves the sums of its deltas. A wave per block.
+template <typename T>
+__global__ __launch_bounds__(256) void k_blkn2_pre(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks,
+                                                   const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    const Lattice<T> lat(p.lat);
+    const int lane = lane_id();
+    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    Q *agg = reinterpret_cast<Q *>(p.carry);
+    const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
+    for (uint32_t task = blockIdx.x * 4 + threadIdx.x / WAVE; task < nblocks; task += gridDim.x * 4) {
+        const BlkGeom g = blk_geom(p, task);
+        const uint32_t m = g.ex, sel = p.sel[task];
+        if (sel == 2) {
+            T rc[4];
+            coef_recover(coef_by_rank + (uint64_t)rank[task] * 4, cl, rc);
+            for (uint32_t t = lane; t < m; t += WAVE) {
+                const uint32_t code = codes[g.coff + t];
+                Q qt = 0;
+                T val = 0;  // (code 0: patched from the list)
+                if (code) {
+                    bool bad;
+                    val = ref_recover(reg_predict(rc, 0u, 0u, t), (int)code, p.eb, (int)p.radius);
+                    qt = lat.quant(val, bad);
+                    if (bad) qt = 0;
+                }
+                reinterpret_cast<T *>(d_out)[g.ox + t] = val;
+                if (t == m - 1) agg[2 * (uint64_t)task] = qt;
+                if (t + 2 == m) agg[2 * (uint64_t)task + 1] = qt;
+            }
+        } else {
+            UQ s = 0, w = 0, last = 0;  // S_m; sum of (m - t) d_t = P_m; the last delta
+            for (uint32_t t = lane; t < m; t += WAVE) {
+                const uint32_t code = codes[g.coff + t];
+                const UQ d = code ? (UQ)(Q)((int)code - (int)p.radius) : (UQ)deltas[g.coff + t];
+                s += d;
+                w += (UQ)(m - t) * d;
+                if (t == m - 1) last = d;
+            }
+            s = wave_sum(s);
+            w = wave_sum(w);
+            last = wave_sum(last);
+            if (lane == 0) {
+                agg[2 * (uint64_t)task] = (Q)(sel == 1 ? w : s);
+                agg[2 * (uint64_t)task + 1] = (Q)(sel == 1 ? w - s : s - last);  // P_{m-1} = P_m - S_m; S_{m-1} = S_m - d_m
+            }
+        }
+    }
+}
+template <typename Q>
+__global__ __launch_bounds__(1024) void k_blkn2_tile(const uint8_t *__restrict__ sel, uint32_t nblocks, uint32_t B, uint32_t n, void *carry) {
+    using UQ = typename std::make_unsigned<Q>::type;
+    __shared__ BlkAff<UQ> ws[16];
+    const Q *agg = reinterpret_cast<const Q *>(carry);
+    Q *tile = blkn2_tiles<Q>(carry, nblocks);
+    const uint32_t b = blockIdx.x * BLKN_TILE + threadIdx.x;
+    BlkAff<UQ> x = aff_ident<UQ>(), excl;
+    if (b < nblocks) x = aff_of_block<UQ>(sel[b], min(B, n - b * B), (UQ)agg[2 * (uint64_t)b], (UQ)agg[2 * (uint64_t)b + 1]);
+    const BlkAff<UQ> incl = aff_wg_scan<UQ>(x, aff_ident<UQ>(), excl, ws);
+    if (threadIdx.x == BLKN_TILE - 1) {
+        Q *t8 = tile + 8 * (uint64_t)blockIdx.x;
+        t8[0] = (Q)incl.m00;
+        t8[1] = (Q)incl.m01;
+        t8[2] = (Q)incl.m10;
+        t8[3] = (Q)incl.m11;
+        t8[4] = (Q)incl.v0;
+        t8[5] = (Q)incl.v1;
+    }
+}
+template <typename Q>
+__global__ __launch_bounds__(1024) void k_blkn2_top(uint32_t ntiles, Q *__restrict__ tile) {
+    using UQ = typename std::make_unsigned<Q>::type;
+    __shared__ BlkAff<UQ> ws[16];
+    __shared__ UQ run_s[2];
+    UQ r0 = 0, r1 = 0;  // the state in front of the array: zeros (LorenzoPredictor.hpp: the padding)
+    for (uint32_t base = 0; base < ntiles; base += 1024) {
+        const uint32_t t = base + threadIdx.x;
+        BlkAff<UQ> x = aff_ident<UQ>(), excl;
+        if (t < ntiles) {
+            const Q *t8 = tile + 8 * (uint64_t)t;
+            x = BlkAff<UQ>{(UQ)t8[0], (UQ)t8[1], (UQ)t8[2], (UQ)t8[3], (UQ)t8[4], (UQ)t8[5]};
+        }
+        const BlkAff<UQ> incl = aff_wg_scan<UQ>(x, aff_const<UQ>(r0, r1), excl, ws);
+        if (t < ntiles) {
+            tile[8 * (uint64_t)t + 6] = (Q)excl.v0;  // (behind a constant map every composition is constant: v IS the state)
+            tile[8 * (uint64_t)t + 7] = (Q)excl.v1;
+        }
+        if (threadIdx.x == 1023) {
+            run_s[0] = incl.v0;
+            run_s[1] = incl.v1;
+        }
+        __syncthreads();
+        r0 = run_s[0];
+        r1 = run_s[1];
+        __syncthreads();
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(1024) void k_blkn2_apply(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    __shared__ BlkAff<UQ> ws[16];
+    __shared__ UQ sa[BLKN_TILE], sb[BLKN_TILE];
+    const Lattice<T> lat(p.lat);
+    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    const Q *agg = reinterpret_cast<const Q *>(p.carry);
+    const Q *tile = blkn2_tiles<Q>(p.carry, nblocks);
+    const uint32_t n = (uint32_t)p.d[2];
+    const uint32_t b = blockIdx.x * BLKN_TILE + threadIdx.x;
+    BlkAff<UQ> x = aff_ident<UQ>(), excl;
+    if (b < nblocks) x = aff_of_block<UQ>(p.sel[b], min(p.B, n - b * p.B), (UQ)agg[2 * (uint64_t)b], (UQ)agg[2 * (uint64_t)b + 1]);
+    (void)aff_wg_scan<UQ>(x, aff_const<UQ>((UQ)tile[8 * (uint64_t)blockIdx.x + 6], (UQ)tile[8 * (uint64_t)blockIdx.x + 7]), excl, ws);
+    sa[threadIdx.x] = excl.v0;
+    sb[threadIdx.x] = excl.v1;
+    __syncthreads();
+    const int lane = lane_id();
+    for (uint32_t k = threadIdx.x / WAVE; k < BLKN_TILE; k += 16) {
+        const uint32_t task = blockIdx.x * BLKN_TILE + k;
+        if (task >= nblocks) break;
+        const uint32_t sel = p.sel[task];
+        if (sel == 2) continue;
+        const BlkGeom g = blk_geom(p, task);
+        const UQ a = sa[k], bq = sb[k];
+        UQ c1 = 0, cp = 0;  // running S and P behind the elements done so far
+        for (uint32_t t0 = 0; t0 < g.ex; t0 += WAVE) {
+            const uint32_t t = t0 + lane;
+            UQ d = 0;
+            if (t < g.ex) {
+                const uint32_t code = codes[g.coff + t];
+                d = code ? (UQ)(Q)((int)code - (int)p.radius) : (UQ)deltas[g.coff + t];
+            }
+            const UQ s_k = wave_incl_scan(d) + c1;  // S_{t+1}
+            UQ q;
+            if (sel == 1) {
+                const UQ p_k = wave_incl_scan(s_k) + cp;  // P_{t+1}
+                q = (UQ)(t + 2) * a - (UQ)(t + 1) * bq + p_k;
+                cp = (UQ)__shfl((long long)p_k, WAVE - 1);
+            } else {
+                q = a + s_k;
+            }
+            c1 = (UQ)__shfl((long long)s_k, WAVE - 1);
+            if (t < g.ex) reinterpret_cast<T *>(d_out)[g.ox + t] = lat.dequant((Q)q);
+        }
+    }
+}
 // 2-D: the Lorenzo blocks of one front (by + bx = diag), a wave per block: the deltas in LDS, sums along x (inflow: Dy q~ of the
 // column left of the block), then along y (inflow: q~ of the row above it)
 #define BLKN_MAXB2 32u
@@ -2668,6 +2935,89 @@ __global__ __launch_bounds__(256) void k_blkn_decode2g(const void *deltas_, void
         if (tx < hx) qout[(uint64_t)(y0 + ty) * d2 + (x0 + tx)] = sq[(ty + 1) * PITCH + tx + 1];
     }
 }
+
+// The tuner's Lorenzo trial (SZAlgoInterp.hpp:232-247, lorenzo_compress_test: a 1-D array's sample blocks coded in blocks of FIVE values
+// by the set [Lorenzo-1, Lorenzo-2]): the choice per block by the reference's estimate at the block's two ends, the codes on the
+// lattice, their histogram for the pricing kernel. A thread per block of five (seven loads), every sample block an array of its own
+// (zeros left of its first value). extra[0] += blocks that chose second order, extra[1] += blocks.
+template <typename T>
+__global__ __launch_bounds__(256) void k_trial_lorenzo12(const T *__restrict__ samples, uint64_t per, uint64_t nsb, szk_lattice latp, double eb, uint32_t radius,
+                                                         unsigned long long *__restrict__ hist, unsigned long long *__restrict__ counters,
+                                                         unsigned long long *__restrict__ extra) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    constexpr uint32_t HW = 4096;
+    __shared__ uint32_t lh[HW];
+    for (uint32_t b = threadIdx.x; b < HW; b += 256) lh[b] = 0;
+    __syncthreads();
+    const Lattice<T> lat(latp);
+    const uint64_t nb5 = (per + 4) / 5, total = nsb * nb5;
+    const T n1 = (T)(0.5 * eb), n2 = (T)(1.08 * eb);
+    const uint32_t lo = radius > HW / 2 ? radius - HW / 2 : 0u;
+    uint32_t n_bad = 0, n_out = 0, n_l2 = 0, n_blk = 0;
+    for (uint64_t task = (uint64_t)blockIdx.x * 256 + threadIdx.x; task < total; task += (uint64_t)gridDim.x * 256) {
+        const uint64_t k = task / nb5, x0 = (task - k * nb5) * 5;
+        const uint32_t m = (uint32_t)min((uint64_t)5, per - x0);
+        const T *sb = samples + k * per;
+        T v[7], seen[7];
+        Q q[7];
+        bool bad[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const int64_t x = (int64_t)x0 - 2 + i;
+            const bool have = x >= 0 && x < (int64_t)(x0 + m);
+            v[i] = have ? sb[x] : (T)0;
+            q[i] = lat.quant(v[i], bad[i]);
+            if (bad[i]) q[i] = 0;
+            if (!have) bad[i] = false;
+            // what the estimate sees: the original inside the block, the lattice reconstruction left of it (ComposedPredictor.hpp:25-40
+            // runs before the block is coded), zero left of the array
+            seen[i] = i >= 2 ? v[i] : (have && !bad[i] ? lat.dequant(q[i]) : v[i]);
+        }
+        double e1 = 0, e2 = 0;
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++) {
+            const int pi = 2 + (pt ? (int)m - 1 : 0);
+            T s1 = 0, s2 = 0, pv = 0;
+#pragma unroll
+            for (int i = 0; i < 7; i++) {  // (constant indices: the arrays stay in registers)
+                if (i == pi) pv = v[i];
+                if (i == pi - 1) s1 = seen[i];
+                if (i == pi - 2) s2 = seen[i];
+            }
+            e1 += (double)(T)((T)fabs((double)(T)(pv - s1)) + n1);
+            e2 += (double)(T)((T)fabs((double)(T)(pv - (T)((T)(2 * s1) - s2))) + n2);
+        }
+        const bool second = e2 < e1;  // (std::min_element: the first minimum — Lorenzo-1 on a tie)
+        n_l2 += second ? 1u : 0u;
+        n_blk++;
+#pragma unroll
+        for (int i = 2; i < 7; i++) {
+            if ((uint32_t)(i - 2) >= m) break;
+            UQ delta = (UQ)q[i] - (UQ)q[i - 1];
+            if (second) delta = delta - (UQ)q[i - 1] + (UQ)q[i - 2];
+            const bool inr = (UQ)(delta + (UQ)(radius - 1)) <= (UQ)(2 * radius - 2);
+            const uint32_t code = inr ? (uint32_t)(delta + (UQ)radius) : 0u;
+            n_bad += bad[i] ? 1u : 0u;
+            n_out += inr ? 0u : 1u;
+            if (code - lo < HW) atomicAdd(&lh[code - lo], 1u);
+            else atomicAdd(&hist[code], 1ull);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < HW; b += 256)
+        if (lh[b]) atomicAdd(&hist[lo + b], (unsigned long long)lh[b]);
+    n_bad = wave_sum(n_bad);
+    n_out = wave_sum(n_out);
+    n_l2 = wave_sum(n_l2);
+    n_blk = wave_sum(n_blk);
+    if (lane_id() == 0) {
+        if (n_bad) atomicAdd(&counters[0], (unsigned long long)n_bad);
+        if (n_out) atomicAdd(&counters[1], (unsigned long long)n_out);
+        if (n_l2) atomicAdd(&extra[0], (unsigned long long)n_l2);
+        if (n_blk) atomicAdd(&extra[1], (unsigned long long)n_blk);
+    }
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2684,13 +3034,13 @@ static int launch_blkn_compress(int dtype, const void *d_in, uint16_t *codes, co
     do {                                                                                                                        \
         const uint32_t gfit = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                 \
         const uint32_t glor = (uint32_t)std::min<uint64_t>(BLK_GRID * 8 / NW, (n + NW * 64 - 1) / (NW * 64));                     \
-        if (!TWO && !p->sel_given && !(szk_dbg_flags & 134217728)) { /* 1-D: four blocks per wave (debug flag 134217728: a wave per block) */ \
+        if (!TWO && !p->sel_given && !(p->mask & 2u) && !(szk_dbg_flags & 134217728)) { /* 1-D: four blocks per wave (debug flag 134217728: a wave per block) */ \
             const uint32_t grow = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW * 4 - 1) / (NW * 4));    \
             hipLaunchKernelGGL((k_blkn_fit_rows<T, HW, NW>), dim3(grow), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks); \
         } else                                                                                                                  \
         hipLaunchKernelGGL((k_blkn_fit<T, HW, NW, TWO, false>), dim3(gfit), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks, \
                            (unsigned long long *)nullptr);                                                                          \
-        if (!TWO && !p->sel_given && !(szk_dbg_flags & 134217728)) { /* 1-D, q~ of everything in the work array: four codes per thread */ \
+        if (!TWO && !p->sel_given && !(p->mask & 2u) && !(szk_dbg_flags & 134217728)) { /* 1-D, q~ of everything in the work array: four codes per thread */ \
             const uint32_t g4 = (uint32_t)std::min<uint64_t>(BLK_GRID * 8 / NW, (n + NW * 256 - 1) / (NW * 256));                  \
             hipLaunchKernelGGL((k_blkn_lorenzo1v<T, HW, NW * 64>), dim3(g4), dim3(NW * 64), 0, s, codes, *p, n);                   \
         } else                                                                                                                  \
@@ -2843,6 +3193,21 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
     } else if (szk_launch_expand_deltas(dtype, codes, h->n, (int)h->radius, payload, o, h->n_dout, p->qwork, s)) return -1;
     // (the side section's kernels ran on another stream: the fronts are the first to need what they made)
     if (side_done && hipStreamWaitEvent(s, side_done, 0) != hipSuccess) return -1;
+    if (p->ndim == 1 && (p->mask & 2u)) {  // second-order Lorenzo in the set: the scan of affine maps (k_blkn2_*)
+        const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
+        const uint32_t ntiles = (nblocks + BLKN_TILE - 1) / BLKN_TILE;
+        if (dtype == 0) {
+            hipLaunchKernelGGL(k_blkn2_pre<float>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+            hipLaunchKernelGGL(k_blkn2_tile<int32_t>, dim3(ntiles), dim3(1024), 0, s, p->sel, nblocks, p->B, (uint32_t)p->d[2], p->carry);
+            hipLaunchKernelGGL(k_blkn2_top<int32_t>, dim3(1), dim3(1024), 0, s, ntiles, (int32_t *)p->carry + 2 * (uint64_t)nblocks);
+            hipLaunchKernelGGL(k_blkn2_apply<float>, dim3(ntiles), dim3(1024), 0, s, codes, p->qwork, d_out, *p, nblocks);
+        } else {
+            hipLaunchKernelGGL(k_blkn2_pre<double>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+            hipLaunchKernelGGL(k_blkn2_tile<int64_t>, dim3(ntiles), dim3(1024), 0, s, p->sel, nblocks, p->B, (uint32_t)p->d[2], p->carry);
+            hipLaunchKernelGGL(k_blkn2_top<int64_t>, dim3(1), dim3(1024), 0, s, ntiles, (int64_t *)p->carry + 2 * (uint64_t)nblocks);
+            hipLaunchKernelGGL(k_blkn2_apply<double>, dim3(ntiles), dim3(1024), 0, s, codes, p->qwork, d_out, *p, nblocks);
+        }
+    } else
     if (p->ndim < 3) {
         const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
         // 1-D, blocks of up to 128 values, a multiple of 8: four blocks per wave (debug flag 134217728: a wave per block)
@@ -2942,6 +3307,22 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         else hipLaunchKernelGGL((k_blk_final<double, 0>), dim3(grid), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);
         if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<double>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (double *)d_out);
     }
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
+
+int szk_launch_trial_lorenzo12(int dtype, const void *d_samples, uint64_t per, uint64_t nsb, double eb, int radius, uint64_t *hist, uint64_t *counters,
+                               uint64_t *extra, hipStream_t s) {
+    const uint64_t total = nsb * ((per + 4) / 5);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(2048, (total + 255) / 256);
+    if (!grid) return 0;
+    const szk_lattice lat = szk_make_lattice(eb);
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_trial_lorenzo12<float>, dim3(grid), dim3(256), 0, s, (const float *)d_samples, per, nsb, lat, eb, (uint32_t)radius,
+                           (unsigned long long *)hist, (unsigned long long *)counters, (unsigned long long *)extra);
+    else
+        hipLaunchKernelGGL(k_trial_lorenzo12<double>, dim3(grid), dim3(256), 0, s, (const double *)d_samples, per, nsb, lat, eb, (uint32_t)radius,
+                           (unsigned long long *)hist, (unsigned long long *)counters, (unsigned long long *)extra);
     SZK_CHECK_LAUNCH();
     return 0;
 }

@@ -84,7 +84,7 @@ def test_tampered_headers_are_refused(kind):
         sel_bytes = ((nblocks + 3) // 4 + 7) & ~7
         cases["Rice parameter beyond 63"] = with_(o["side"] + 24 + sel_bytes + 2, "<B", 200)
     if kind == "block-1d":
-        cases["second-order Lorenzo in 1-D"] = with_(148, "<I", 7)
+        cases["a predictor set beyond the three members"] = with_(148, "<I", 9)
         cases["1-D stream with a second extent"] = with_(16, "<4Q", 1, 1, 2, n // 2)
     if kind == "block-3d":
         cases["3-D block edge above 8"] = with_(144, "<I", 16)

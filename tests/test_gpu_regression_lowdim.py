@@ -205,3 +205,101 @@ def test_tiny_and_degenerate_low_dimensional_arrays(shape):
         blob, _ = sz3_amd.compress(a, conf)
         dec, c2 = sz3_amd.decompress(blob, np.float32, shape)
         assert dec.shape == a.shape and float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= 1e-3
+
+
+# ---- second-order Lorenzo in 1-D (round 4: k_blkn2_*, the scan of affine maps) ----------------------------------------------
+# LorenzoPredictor.hpp:69-71 (2 d[-1] - d[-2]), noise 1.08 eb (:17-38); the set [Lorenzo-1, Lorenzo-2] with blocks of 128 is what the
+# reference's default algorithm compresses a 1-D array with whenever its sampling test prefers Lorenzo (SZAlgoInterp.hpp:232-282).
+L2_MASKS = ["L2", "L1+L2", "L1+L2+R", "L2+R"]
+
+
+@pytest.mark.parametrize("mask", L2_MASKS)
+@pytest.mark.parametrize("dtype,n,eb,block", [(np.float32, 5000, 1e-3, None), (np.float64, 3001, 2e-2, 64), (np.float32, 130, 1e-2, 7),
+                                             (np.float32, 100003, 1e-4, 5), (np.float64, 2500, 1e-5, 1000)])
+def test_1d_second_order_block_stream_against_the_numpy_model(mask, dtype, n, eb, block):
+    a = field1d(n, dtype)
+    conf = _conf((n,), eb, *MASKS[mask], block=block)
+    blob, ratio = sz3_amd.compress(a, conf)
+    dec, c2 = sz3_amd.decompress(blob, dtype, (n,))
+    assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= eb
+    if c2.cmprAlgo == sz3_amd.ALGO_LOSSLESS:
+        pytest.skip("tiny field went lossless")
+    h, o, sec = szh_ref.parse(_payload_of(blob))
+    assert h["predictor"] == 2 and h["ndim"] == 1 and h["blk_edge"] == (block or 128)
+    assert h["blk_mask"] == sum(b << i for i, b in enumerate(MASKS[mask]))
+    assert (c2.lorenzo, c2.lorenzo2, c2.regression) == MASKS[mask]
+    codes = szh_ref.huffman_decode(h, sec)
+    model, sel = szh_ref.reconstruct_blocks(h, sec, codes)
+    assert np.array_equal(model, dec), "numpy model of the block decoder and the GPU decoder disagree"
+    sel = np.asarray(sel).reshape(-1)
+    allowed = {i for i, b in enumerate(MASKS[mask]) if b} | {0}  # (0: the fallback of a regression that is not valid)
+    assert set(np.unique(sel)) <= allowed
+    print(n, mask, "ratio %.2f" % ratio, "shares L1 %.3f L2 %.3f R %.3f" % tuple(float((sel == k).mean()) for k in range(3)))
+    # the encoder without the selection pass in front (the fit pass chooses, q~ of every element through the work array): same stream
+    try:
+        sz3_amd.lib().sz3hip_debug_flags(NO_EXIT | 2147483648)
+        blob2, _ = sz3_amd.compress(a, conf)
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(NO_EXIT)
+    assert _payload_of(blob2) == _payload_of(blob)
+
+
+@pytest.mark.parametrize("n,eb,mask", [(1 << 20, 1e-3, "L1+L2"), (1 << 20, 1e-4, "L1+L2"), (1 << 18, 1e-2, "L1+L2"), (1 << 19, 1e-3, "L1+L2+R"), (1 << 18, 1e-3, "L2")])
+def test_1d_second_order_ratio_and_selection_against_the_oracle(n, eb, mask):
+    """the set the reference's tuner chooses in 1-D (Lorenzo-1 + Lorenzo-2, blocks of 128) on the C1 field, and the sets around it:
+    bound strict, ratio >= 0.95 x the oracle's, the choices block by block (on C1 at 1e-3 second-order blocks are what lifts the
+    oracle's ratio from 5.6 to 7.3)"""
+    a = field1d(n, np.float32)
+    l1, l2, r = MASKS[mask]
+    oconf = make_config(a.shape, abs_eb=eb, lorenzo=bool(l1), lorenzo2=bool(l2), regression=bool(r))
+    o_ratio = a.nbytes / len(oracle_compress(a, oconf))
+    osel = oracle_selection(a, oconf)
+    blob, ratio = sz3_amd.compress(a, _conf((n,), eb, l1, l2, r))
+    dec, c2 = sz3_amd.decompress(blob, np.float32, (n,))
+    assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= eb
+    assert (c2.lorenzo, c2.lorenzo2, c2.regression) == (l1, l2, r)
+    h, o, sec = szh_ref.parse(_payload_of(blob))
+    assert h["predictor"] == 2 and h["ndim"] == 1
+    sel = np.asarray(szh_ref.parse_side(h, sec)[0]).reshape(-1)
+    assert osel.size == sel.size and (osel >= 0).all()
+    same = float((osel == sel).mean())
+    print("1-D %d @%g %s: ratio %.2f (oracle %.2f); second-order blocks %.3f (oracle %.3f); selection identical in %.2f %% of the blocks"
+          % (n, eb, mask, ratio, o_ratio, float((sel == 1).mean()), float((osel == 1).mean()), 100 * same))
+    assert ratio >= 0.95 * o_ratio
+    assert same >= 0.9
+
+
+def test_1d_second_order_unpredictable_values_wide_deltas_and_long_series():
+    a = field1d(40000, np.float32)
+    a[5] = np.nan
+    a[1234] = np.inf
+    a[2000:2300] += 500.0
+    for mask in ("L1+L2", "L2", "L1+L2+R"):
+        conf = _conf(a.shape, 1e-3, *MASKS[mask])
+        conf.quantbinCnt = 1024
+        blob, _ = sz3_amd.compress(a, conf)
+        dec, _ = sz3_amd.decompress(blob, np.float32, a.shape)
+        ok = np.isfinite(a)
+        assert np.array_equal(dec[~ok].view(np.uint32), a[~ok].view(np.uint32))
+        assert float(np.max(np.abs(dec[ok].astype(np.float64) - a[ok].astype(np.float64)))) <= 1e-3
+        h, o, sec = szh_ref.parse(_payload_of(blob))
+        assert h["n_vout"] > 0 and h["n_dout"] > 0
+        model, _ = szh_ref.reconstruct_blocks(h, sec, szh_ref.huffman_decode(h, sec))
+        assert np.array_equal(model.view(np.uint32), dec.reshape(-1).view(np.uint32))
+    # 2^24 values in blocks of 128 (131 072 blocks: 128 tiles of the scan), f64, and blocks of 5 (the tuner's trial geometry: 3.4 M blocks)
+    b = np.tile(field1d(1 << 22, np.float64), 4)
+    b += np.repeat(np.arange(4, dtype=np.float64), 1 << 22) * 0.37
+    for block in (None, 5):
+        blob, ratio = sz3_amd.compress(b, _conf(b.shape, 1e-4, 1, 1, 0, block=block))
+        dec, c2 = sz3_amd.decompress(blob, np.float64, b.shape)
+        assert float(np.max(np.abs(dec - b))) <= 1e-4 and (c2.lorenzo, c2.lorenzo2, c2.regression) == (1, 1, 0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 20, 129, 257])
+def test_1d_second_order_tiny_arrays(n):
+    rng = np.random.default_rng(5)
+    a = (np.cumsum(rng.normal(size=n)) * 0.01).astype(np.float32)
+    for mask in L2_MASKS:
+        blob, _ = sz3_amd.compress(a, _conf((n,), 1e-3, *MASKS[mask]))
+        dec, c2 = sz3_amd.decompress(blob, np.float32, (n,))
+        assert dec.shape == a.shape and float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= 1e-3

@@ -100,3 +100,25 @@ def test_default_config_host_roundtrip():
     dec, c2 = sz3_amd.decompress(blob, np.float32, a.shape)
     assert c2.cmprAlgo == sz3_amd.ALGO_HIP_INTERP
     assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= 1e-3 and ratio > 5
+
+
+@pytest.mark.parametrize("eb", [1e-2, 1e-3, 1e-4])
+def test_1d_default_algorithm_takes_lorenzo_with_second_order_blocks(eb):
+    """SZAlgoInterp.hpp:232-282: in 1-D the tuner also prices the set [Lorenzo-1, Lorenzo-2] in blocks of five over its samples and
+    takes it when it beats interpolation by 10 %; the array is then coded with that set in blocks of 128. On the C1 field the
+    reference does (best_lorenzo 16.1 / 6.9 / 3.4 against best_interp 14.5 / 4.4 / 2.0), and second-order blocks are most of its
+    ratio (7.29 at 1e-3 against 5.6 with Lorenzo-1 alone): same decision here, ratio within 5 % of the oracle's"""
+    from oracle_binding import oracle_compress
+    a = field1d(1 << 20)
+    oconf = make_config(a.shape, algo=ALGO_INTERP_LORENZO, abs_eb=eb, regression=True)
+    o_ratio = a.nbytes / len(oracle_compress(a, oconf))
+    oc, orep, oran = oracle_tune(a, make_config(a.shape, algo=ALGO_INTERP_LORENZO, abs_eb=eb, regression=True))
+    assert oran and oc.cmprAlgo != ALGO_INTERP and (oc.lorenzo, oc.lorenzo2, oc.regression, oc.blockSize) == (1, 1, 0, 128)
+    conf = sz3_amd.Config(*a.shape)
+    conf.absErrorBound = eb
+    blob, ratio = sz3_amd.compress(a, conf)
+    dec, c2 = sz3_amd.decompress(blob, np.float32, a.shape)
+    assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= eb
+    print("1-D default algorithm @%g: ratio %.3f (oracle %.3f); oracle's trial: interp %.2f lorenzo %.2f" % (eb, ratio, o_ratio, orep.best_interp, orep.best_lorenzo))
+    assert c2.cmprAlgo == sz3_amd.ALGO_HIP_LORENZO and (c2.lorenzo, c2.lorenzo2, c2.regression, c2.blockSize) == (1, 1, 0, 128)
+    assert ratio >= 0.95 * o_ratio

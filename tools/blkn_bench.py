@@ -1,5 +1,5 @@
 """Timing of the block-composed predictor on 1-D / 2-D arrays, device-resident (development tool; the numbers in DESIGN.md).
-usage: python tools/blkn_bench.py n | dy,dx [eb] [f32|f64] [plain]"""
+usage: python tools/blkn_bench.py n | dy,dx [eb] [f32|f64] [plain | l12 | default]   (l12: Lorenzo-1 + Lorenzo-2; default: the default algorithm, tuner included)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,6 +23,10 @@ d_in = torch.from_numpy(a).to(dev)
 conf = sz3_amd.Config(*shape)
 conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
 conf.lorenzo, conf.lorenzo2, conf.regression = 1, 0, int(not plain)
+if "l12" in sys.argv:
+    conf.lorenzo, conf.lorenzo2, conf.regression = 1, 1, 0
+if "default" in sys.argv:
+    conf = sz3_amd.Config(*shape)
 conf.absErrorBound = eb
 dc = sz3_amd.DeviceCompressor(n, dt, device=0)
 cap = max(dc.payload_bound(n), dc.payload_bound_conf(conf))
@@ -54,5 +58,5 @@ torch.cuda.synchronize()
 td = (time.perf_counter() - t0) / K
 err = float((d_out.double() - d_in.reshape(-1).double()).abs().max())
 print("%s %s eb %g %s: payload ratio %.2f; compress %.3f ms (%.1f GB/s), decompress %.3f ms (%.1f GB/s); max err %.3g (ok %s)"
-      % (shape, dt.__name__, eb, "Lorenzo-1 (plain stream)" if plain else "Lorenzo + regression", a.nbytes / size, tc * 1e3, a.nbytes / tc / 1e9,
+      % (shape, dt.__name__, eb, "Lorenzo-1 (plain stream)" if plain else "Lorenzo-1 + Lorenzo-2" if "l12" in sys.argv else "default algorithm" if "default" in sys.argv else "Lorenzo + regression", a.nbytes / size, tc * 1e3, a.nbytes / tc / 1e9,
          td * 1e3, a.nbytes / td / 1e9, err, err <= eb))

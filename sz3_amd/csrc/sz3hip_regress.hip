@@ -1669,6 +1669,36 @@ __device__ __forceinline__ void blkn_own(const BlkGeom &g, uint32_t t, uint32_t 
         i2 = t - i1 * g.ex;
     }
 }
+// 1-D, a set of Lorenzo members only ({L1, L2}: what the reference's tuner takes for a 1-D array; {L2}): the choice needs the block's two
+// ends and the two values left of it — a thread per block, seven loads, no fit and no work array: the code pass then reads the array
+// itself (its `direct` form, p.sel_given)
+template <typename T>
+__global__ __launch_bounds__(256) void k_blkn_sel12(const T *__restrict__ in, szk_blk_params p, uint32_t nblocks) {
+    const Lattice<T> lat(p.lat);
+    const T n1 = (T)(0.5 * p.eb), n2 = (T)(1.08 * p.eb);
+    const uint32_t n = (uint32_t)p.d[2];
+    for (uint32_t task = blockIdx.x * 256 + threadIdx.x; task < nblocks; task += gridDim.x * 256) {
+        uint8_t sid = 1;
+        if (p.mask & 1u) {
+            BlkGeom g;
+            g.oy = g.oz = 0;
+            g.ox = task * p.B;
+            g.ex = min(p.B, n - g.ox);
+            double e1 = 0, e2 = 0;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int64_t x = (int64_t)g.ox + (k ? g.ex - 1 : 0u);
+                const T v = in[x];
+                const T s1 = blkn_seen(in, p, lat, g, 0, x - 1), s2 = blkn_seen(in, p, lat, g, 0, x - 2);
+                e1 += (double)(T)((T)fabs((double)(T)(v - s1)) + n1);
+                e2 += (double)(T)((T)fabs((double)(T)(v - (T)((T)(2 * s1) - s2))) + n2);
+            }
+            sid = e2 < e1 ? 1 : 0;
+        }
+        p.sel[task] = sid;
+    }
+}
+
 // NW: waves of a workgroup — they share the LDS histogram window, so the wide window (64 KB) takes 16 of them to keep the CU occupied
 // SELECT: the selection alone (choices and coefficients to sel[] / coef[], the number of blocks that would not be coded by
 // first-order Lorenzo to *n_other; HW is then the one-word window of that count) — the 3-D path's question, asked first: a
@@ -2214,6 +2244,81 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo1v(uint16_t *__restrict__ co
             } else {
                 for (int j = 0; j < 4; j++)
                     if (code4[j] != 0xFFFFFFFFu) codes[c + j] = (uint16_t)code4[j];
+            }
+        }
+    }
+    __syncthreads();
+    blk_flush<HW>(lh, p);
+}
+
+// 1-D, Lorenzo members only (the choices from k_blkn_sel12): FOUR codes per thread straight from the array — one 16-byte load of values,
+// the two left neighbours, six lattice values in registers, one 8-byte store of codes (a thread's four elements lie in at most two
+// blocks when B >= 4)
+template <typename T, uint32_t HW, int TB>
+__global__ __launch_bounds__(TB) void k_blkn_lorenzo12v(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint64_t n) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    const Lattice<T> lat(p.lat);
+    __shared__ uint32_t lh[HW];
+    for (uint32_t b = threadIdx.x; b < HW; b += TB) lh[b] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * TB * 4;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * TB * 4; c0 < n; c0 += stride) {  // (workgroup-uniform: every lane takes part in the wave operations)
+        const uint64_t c = c0 + (uint64_t)threadIdx.x * 4;
+        const bool any = c < n;
+        const uint32_t task0 = any ? (uint32_t)c / p.B : 0u;  // (positions of a 1-D block stream fit 32 bits: blk_shape_ok)
+        const uint64_t next = ((uint64_t)task0 + 1) * p.B;  // first element of the following block
+        T v[6] = {0, 0, 0, 0, 0, 0};  // [0], [1]: the two values left of the thread's four
+        if (any) {
+            if (c + 3 < n) {
+                if (sizeof(T) == 4) {
+                    const float4 f = *reinterpret_cast<const float4 *>(in + c);
+                    v[2] = (T)f.x; v[3] = (T)f.y; v[4] = (T)f.z; v[5] = (T)f.w;
+                } else {
+                    const double2 f0 = *reinterpret_cast<const double2 *>(in + c), f1 = *reinterpret_cast<const double2 *>(in + c + 2);
+                    v[2] = (T)f0.x; v[3] = (T)f0.y; v[4] = (T)f1.x; v[5] = (T)f1.y;
+                }
+            } else {
+                for (int j = 0; j < 4; j++)
+                    if (c + j < n) v[2 + j] = in[c + j];
+            }
+            if (c) v[1] = in[c - 1];
+            if (c > 1) v[0] = in[c - 2];
+        }
+        const uint8_t s0 = any ? p.sel[task0] : (uint8_t)0, s1 = any && next < n ? p.sel[task0 + 1] : (uint8_t)0;
+        Q q[6];
+        bool bad[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            q[j] = lat.quant(v[j], bad[j]);
+            if (bad[j]) q[j] = 0;
+        }
+        uint32_t code4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t cj = c + j;
+            const bool act = cj < n;
+            UQ delta = (UQ)q[2 + j] - (UQ)q[1 + j];
+            if ((cj < next ? s0 : s1) == 1) delta = delta - (UQ)q[1 + j] + (UQ)q[j];
+            const bool inr = (UQ)(delta + (UQ)(p.radius - 1)) <= (UQ)(2 * p.radius - 2);
+            const uint32_t code = inr ? (uint32_t)(delta + (UQ)p.radius) : 0u;
+            code4[j] = code;
+            blk_vout<T>(p, act && bad[2 + j], cj, v[2 + j]);  // unpredictable: the raw value (a wave operation, all lanes take part)
+            blk_count<HW>(lh, p, code, act);
+            const unsigned long long pd = wave_append_slot(act && !inr, p.n_dout);
+            if (act && !inr && pd < p.out_cap) {
+                p.dout_idx[pd] = cj;
+                reinterpret_cast<Q *>(p.dout_val)[pd] = (Q)delta;
+            }
+        }
+        if (any) {
+            if (c + 3 < n) {
+                ushort4 o;
+                o.x = (uint16_t)code4[0]; o.y = (uint16_t)code4[1]; o.z = (uint16_t)code4[2]; o.w = (uint16_t)code4[3];
+                *reinterpret_cast<ushort4 *>(codes + c) = o;
+            } else {
+                for (int j = 0; j < 4; j++)
+                    if (c + j < n) codes[c + j] = (uint16_t)code4[j];
             }
         }
     }
@@ -3030,6 +3135,28 @@ static int launch_blk_side_build(const szk_blk_params *p, const szk_blk_scratch 
 static int launch_blkn_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s) {
     const uint32_t nblocks = blk_count_blocks(p);
     const uint64_t n = p->d[1] * p->d[2];
+    if (p->ndim == 1 && (p->mask & 2u) && !(p->mask & 4u) && !p->sel_given && !(szk_dbg_flags & 134217728)) {
+        // Lorenzo members only (debug flag 134217728: the general fit pass): choices by k_blkn_sel12, codes straight from the array
+        szk_blk_params q = *p;
+        q.sel_given = 1;
+        const uint32_t gsel = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 255) / 256);
+        if (dtype == 0) hipLaunchKernelGGL(k_blkn_sel12<float>, dim3(gsel), dim3(256), 0, s, (const float *)d_in, q, nblocks);
+        else hipLaunchKernelGGL(k_blkn_sel12<double>, dim3(gsel), dim3(256), 0, s, (const double *)d_in, q, nblocks);
+#define BLKN_L12(T, HW, NW)                                                                                                     \
+    do {                                                                                                                        \
+        const uint32_t g4 = (uint32_t)std::min<uint64_t>(BLK_GRID * 8 / NW, (n + NW * 256 - 1) / (NW * 256));                    \
+        hipLaunchKernelGGL((k_blkn_lorenzo12v<T, HW, NW * 64>), dim3(g4), dim3(NW * 64), 0, s, (const T *)d_in, codes, q, n);      \
+    } while (0)
+        if (dtype == 0) {
+            if (sc->wide_hist) BLKN_L12(float, BLK_HWIN_WIDE, 16);
+            else BLKN_L12(float, BLK_HWIN, 4);
+        } else {
+            if (sc->wide_hist) BLKN_L12(double, BLK_HWIN_WIDE, 16);
+            else BLKN_L12(double, BLK_HWIN, 4);
+        }
+#undef BLKN_L12
+        return launch_blk_side_build(p, sc, nblocks, s);
+    }
 #define BLKN_ENC1(T, HW, NW, TWO)                                                                                               \
     do {                                                                                                                        \
         const uint32_t gfit = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                 \

@@ -235,9 +235,10 @@ def test_1d_second_order_block_stream_against_the_numpy_model(mask, dtype, n, eb
     allowed = {i for i, b in enumerate(MASKS[mask]) if b} | {0}  # (0: the fallback of a regression that is not valid)
     assert set(np.unique(sel)) <= allowed
     print(n, mask, "ratio %.2f" % ratio, "shares L1 %.3f L2 %.3f R %.3f" % tuple(float((sel == k).mean()) for k in range(3)))
-    # the encoder without the selection pass in front (the fit pass chooses, q~ of every element through the work array): same stream
+    # sets of Lorenzo members only take a pass of their own for the choices (k_blkn_sel12) and code straight from the array; debug flag
+    # 134217728 sends them through the general fit pass (q~ of every element through the work array): same stream
     try:
-        sz3_amd.lib().sz3hip_debug_flags(NO_EXIT | 2147483648)
+        sz3_amd.lib().sz3hip_debug_flags(NO_EXIT | 134217728)
         blob2, _ = sz3_amd.compress(a, conf)
     finally:
         sz3_amd.lib().sz3hip_debug_flags(NO_EXIT)

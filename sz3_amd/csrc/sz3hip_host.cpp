@@ -332,28 +332,47 @@ HostSlot *get_slot(int device, int dtype, int index) {
 }
 // a slot of (device, dtype) nobody is using, for the duration of one single-slab call: the lowest free index, a new one when
 // all are taken (every concurrent caller ends up with a context of its own)
+// The pool is capped (round 4): a slot keeps its context, device buffers and pinned buffer for the life of the process, so a burst of
+// N concurrent callers (an HDF5 chunk pipeline's worker threads) would pin N times a context's memory for good. At most
+// SZ3HIP_HOST_SLOTS (default 4) slots per (device, type): further callers wait for a lease to come back.
+std::condition_variable g_pool_cv;
+static int host_slot_cap() {
+    static const int cap = [] {
+        const char *e = getenv("SZ3HIP_HOST_SLOTS");
+        const int v = e ? atoi(e) : 4;
+        return v < 1 ? 1 : v;
+    }();
+    return cap;
+}
 struct SlotLease {
     HostSlot *s = nullptr;
     SlotLease(int device, int dtype) {
-        std::lock_guard<std::mutex> pl(g_pool_mu);
-        int n_same = 0;
-        for (auto &c : g_slots)
-            if (c->device == device && c->dtype == dtype) {
-                n_same++;
-                if (!c->busy && (!s || c->index < s->index)) s = c.get();
+        std::unique_lock<std::mutex> pl(g_pool_mu);
+        for (;;) {
+            int n_same = 0;
+            for (auto &c : g_slots)
+                if (c->device == device && c->dtype == dtype) {
+                    n_same++;
+                    if (!c->busy && (!s || c->index < s->index)) s = c.get();
+                }
+            if (!s && n_same < host_slot_cap()) {
+                g_slots.emplace_back(new HostSlot());
+                s = g_slots.back().get();
+                s->device = device;
+                s->dtype = dtype;
+                s->index = n_same;
             }
-        if (!s) {
-            g_slots.emplace_back(new HostSlot());
-            s = g_slots.back().get();
-            s->device = device;
-            s->dtype = dtype;
-            s->index = n_same;
+            if (s) break;
+            g_pool_cv.wait(pl);
         }
         s->busy = true;
     }
     ~SlotLease() {
-        std::lock_guard<std::mutex> pl(g_pool_mu);
-        s->busy = false;
+        {
+            std::lock_guard<std::mutex> pl(g_pool_mu);
+            s->busy = false;
+        }
+        g_pool_cv.notify_one();
     }
     SlotLease(const SlotLease &) = delete;
     SlotLease &operator=(const SlotLease &) = delete;

@@ -588,3 +588,38 @@ def test_host_api_from_several_threads_at_once():
         t.join()
     assert not errs, errs
     assert out == alone
+
+
+def test_more_host_threads_than_slots_wait_for_a_lease():
+    """the slot pool is capped (SZ3HIP_HOST_SLOTS, default 4 per device and element type: a slot keeps its context and buffers for the
+    life of the process): ten threads of f32 callers share the four slots — every call completes, every result is the lone call's"""
+    import threading
+    a = field3d((32, 48, 64), np.float32, seed=77)
+    c = sz3_amd.Config(*a.shape)
+    c.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    c.regression = 0
+    c.absErrorBound = 1e-3
+    alone = sz3_amd.compress(a, c)[0].tobytes()
+    errs, outs = [], [None] * 10
+
+    def worker(k):
+        try:
+            cc = sz3_amd.Config(*a.shape)
+            cc.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+            cc.regression = 0
+            cc.absErrorBound = 1e-3
+            for _ in range(5):
+                blob, _ = sz3_amd.compress(a, cc)
+                dec, _ = sz3_amd.decompress(blob, np.float32, a.shape)
+                assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= 1e-3
+                outs[k] = blob.tobytes()
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(10)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), "a caller never got a lease"
+    assert not errs, errs
+    assert all(o == alone for o in outs)

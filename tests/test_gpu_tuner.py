@@ -122,3 +122,30 @@ def test_1d_default_algorithm_takes_lorenzo_with_second_order_blocks(eb):
     print("1-D default algorithm @%g: ratio %.3f (oracle %.3f); oracle's trial: interp %.2f lorenzo %.2f" % (eb, ratio, o_ratio, orep.best_interp, orep.best_lorenzo))
     assert c2.cmprAlgo == sz3_amd.ALGO_HIP_LORENZO and (c2.lorenzo, c2.lorenzo2, c2.regression, c2.blockSize) == (1, 1, 0, 128)
     assert ratio >= 0.95 * o_ratio
+
+
+@pytest.mark.parametrize("kind,eb", [("smooth", 1e-3), ("smooth", 1e-4), ("walk", 1e-3), ("noise", 1e-2)])
+def test_1d_lorenzo_or_interpolation_as_the_reference_decides(kind, eb):
+    """1-D series on both sides of the trial's 10 % rule (SZAlgoInterp.hpp:249-250): a smooth series with little noise goes to
+    interpolation, a random walk to the Lorenzo set, white noise to interpolation — wherever the oracle's two trial ratios are not
+    within 8 % of the rule's threshold, the decision here is the oracle's; the ratio within 7 % of the oracle's either way"""
+    from oracle_binding import oracle_compress
+    rng = np.random.default_rng(3)
+    n = 1 << 20
+    a = {"smooth": lambda: (np.sin(np.arange(n) / 300.0) + rng.normal(0, 2e-4, n)).astype(np.float32),
+         "walk": lambda: np.cumsum(rng.normal(0, 0.01, n)).astype(np.float32),
+         "noise": lambda: rng.normal(0, 1, n).astype(np.float32)}[kind]()
+    oc, orep, oran = oracle_tune(a, make_config(a.shape, algo=ALGO_INTERP_LORENZO, abs_eb=eb, regression=True))
+    o_ratio = a.nbytes / len(oracle_compress(a, make_config(a.shape, algo=ALGO_INTERP_LORENZO, abs_eb=eb, regression=True)))
+    conf = sz3_amd.Config(*a.shape)
+    conf.absErrorBound = eb
+    blob, ratio = sz3_amd.compress(a, conf)
+    dec, c2 = sz3_amd.decompress(blob, np.float32, a.shape)
+    assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= eb
+    took_lorenzo = c2.cmprAlgo == sz3_amd.ALGO_HIP_LORENZO
+    print("1-D %s @%g: ratio %.3f (oracle %.3f), Lorenzo %s (oracle %s; its trial: interp %.2f, lorenzo %.2f)"
+          % (kind, eb, ratio, o_ratio, took_lorenzo, oc.cmprAlgo != ALGO_INTERP, orep.best_interp, orep.best_lorenzo))
+    clear = orep.best_lorenzo == 0 or abs(orep.best_lorenzo - 1.1 * orep.best_interp) > 0.08 * 1.1 * orep.best_interp
+    if clear and c2.cmprAlgo != sz3_amd.ALGO_LOSSLESS:
+        assert took_lorenzo == (oc.cmprAlgo != ALGO_INTERP)
+    assert ratio >= 0.93 * o_ratio

@@ -2767,6 +2767,93 @@ __global__ __launch_bounds__(256) void k_blkn2_pre(const uint16_t *__restrict__ 
         }
     }
 }
+// k_blkn2_pre by rows of 16 lanes (blocks of up to 128 values, a multiple of 8: the default 128; four blocks per wave, eight values per
+// lane from one 16-byte load of codes — the wave-per-block form reads two bytes per lane and load: 262 us at 2^27 values)
+template <typename T>
+__global__ __launch_bounds__(256) void k_blkn2_pre_rows(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks,
+                                                        const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    const uint32_t lane = (uint32_t)lane_id(), row = lane >> 4, li = lane & 15u;
+    const Lattice<T> lat(p.lat);
+    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    Q *agg = reinterpret_cast<Q *>(p.carry);
+    T *out = reinterpret_cast<T *>(d_out);
+    const bool out_aligned = (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0;
+    const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
+    const uint32_t n = (uint32_t)p.d[2];
+    for (uint32_t base = (blockIdx.x * 4 + threadIdx.x / WAVE) * 4; base < nblocks; base += gridDim.x * 16) {  // (wave-uniform)
+        const uint32_t task = base + row;
+        const bool live = task < nblocks;
+        const uint32_t sel = live ? p.sel[task] : 0u;
+        const bool reg = live && sel == 2;
+        const uint32_t ox = live ? task * p.B : 0u;
+        const uint32_t ex = live ? min(p.B, n - ox) : 0u;
+        const uint32_t t = li * 8;
+        uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t + 8 <= ex) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(codes + ox + t);
+            c[0] = w.x & 0xFFFFu; c[1] = w.x >> 16; c[2] = w.y & 0xFFFFu; c[3] = w.y >> 16;
+            c[4] = w.z & 0xFFFFu; c[5] = w.z >> 16; c[6] = w.w & 0xFFFFu; c[7] = w.w >> 16;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (t + j < ex) c[j] = codes[ox + t + j];
+        }
+        if (reg) {
+            T rc[4];
+            coef_recover(coef_by_rank + (uint64_t)rank[task] * 4, cl, rc);
+            T v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                v[j] = 0;  // (code 0: patched from the list)
+                if (t + j < ex && c[j]) v[j] = ref_recover(reg_predict(rc, 0u, 0u, t + j), (int)c[j], p.eb, (int)p.radius);
+                if (t + j + 1 == ex || t + j + 2 == ex) {  // the block's last two elements: their lattice values are what it leaves behind
+                    Q qt = 0;
+                    if (c[j]) {
+                        bool bad;
+                        qt = lat.quant(v[j], bad);
+                        if (bad) qt = 0;
+                    }
+                    agg[2 * (uint64_t)task + (t + j + 1 == ex ? 0 : 1)] = qt;
+                }
+            }
+            if (t + 8 <= ex && out_aligned) {
+                if (sizeof(T) == 4) {
+                    float4 *o4 = reinterpret_cast<float4 *>(out + ox + t);
+                    o4[0] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+                    o4[1] = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+                } else {
+                    double2 *o2 = reinterpret_cast<double2 *>(out + ox + t);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) o2[j] = make_double2((double)v[2 * j], (double)v[2 * j + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (t + j < ex) out[ox + t + j] = v[j];
+            }
+        }
+        UQ s = 0, w = 0, last = 0;  // S_m; sum of (m - t) d_t = P_m; the last delta
+        if (!reg) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (t + j < ex) {
+                    const UQ d = c[j] ? (UQ)(Q)((int)c[j] - (int)p.radius) : (UQ)deltas[ox + t + j];
+                    s += d;
+                    w += (UQ)(ex - (t + j)) * d;
+                    if (t + j + 1 == ex) last = d;
+                }
+        }
+        s = row16_incl_scan(s);  // (lane 15 of the row holds the block's sums)
+        w = row16_incl_scan(w);
+        last = row16_incl_scan(last);
+        if (live && !reg && li == 15) {
+            agg[2 * (uint64_t)task] = (Q)(sel == 1 ? w : s);
+            agg[2 * (uint64_t)task + 1] = (Q)(sel == 1 ? w - s : s - last);
+        }
+    }
+}
 template <typename Q>
 __global__ __launch_bounds__(1024) void k_blkn2_tile(const uint8_t *__restrict__ sel, uint32_t nblocks, uint32_t B, uint32_t n, void *carry) {
     using UQ = typename std::make_unsigned<Q>::type;
@@ -2815,7 +2902,7 @@ __global__ __launch_bounds__(1024) void k_blkn2_top(uint32_t ntiles, Q *__restri
         __syncthreads();
     }
 }
-template <typename T>
+template <typename T, bool ROWS>
 __global__ __launch_bounds__(1024) void k_blkn2_apply(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
@@ -2834,6 +2921,71 @@ __global__ __launch_bounds__(1024) void k_blkn2_apply(const uint16_t *__restrict
     sb[threadIdx.x] = excl.v1;
     __syncthreads();
     const int lane = lane_id();
+    if (ROWS) {  // (the launcher: blocks of up to 128 values, a multiple of 8)
+        // by rows of 16 lanes: four blocks per wave, eight values per lane (one 16-byte load of codes, the running sums in registers,
+        // the lanes' totals scanned inside the DPP row — twice for a second-order block: S, then P = the running sum of S)
+        T *out = reinterpret_cast<T *>(d_out);
+        const bool out_aligned = (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0;
+        const uint32_t row = (uint32_t)lane >> 4, li = (uint32_t)lane & 15u;
+        for (uint32_t k0 = (threadIdx.x / WAVE) * 4; k0 < BLKN_TILE; k0 += 64) {  // (wave-uniform)
+            const uint32_t k = k0 + row, task = blockIdx.x * BLKN_TILE + k;
+            const uint32_t sel = task < nblocks ? p.sel[task] : 2u;
+            const bool live = task < nblocks && sel != 2;
+            const uint32_t ox = task < nblocks ? task * p.B : 0u;
+            const uint32_t ex = live ? min(p.B, n - ox) : 0u;
+            const uint32_t t = li * 8;
+            UQ d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (t + 8 <= ex) {
+                const uint4 w = *reinterpret_cast<const uint4 *>(codes + ox + t);  // (ox and t are multiples of 8: 16-byte aligned)
+                const uint32_t c[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
+#pragma unroll
+                for (int j = 0; j < 8; j++) d[j] = c[j] ? (UQ)(Q)((int)c[j] - (int)p.radius) : (UQ)deltas[ox + t + j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (t + j < ex) {
+                        const uint32_t c = codes[ox + t + j];
+                        d[j] = c ? (UQ)(Q)((int)c - (int)p.radius) : (UQ)deltas[ox + t + j];
+                    }
+            }
+#pragma unroll
+            for (int j = 1; j < 8; j++) d[j] += d[j - 1];  // S inside the lane
+            const UQ s_before = row16_incl_scan(d[7]) - d[7];
+            const UQ a = live ? sa[k] : (UQ)0, bq = live ? sb[k] : (UQ)0;
+            UQ q[8];
+            if (sel == 1) {
+                UQ ps[8];
+                ps[0] = d[0] + s_before;
+#pragma unroll
+                for (int j = 1; j < 8; j++) ps[j] = ps[j - 1] + d[j] + s_before;  // P inside the lane (every S carries the lanes before)
+                const UQ p_before = row16_incl_scan(ps[7]) - ps[7];
+#pragma unroll
+                for (int j = 0; j < 8; j++) q[j] = (UQ)(t + j + 2) * a - (UQ)(t + j + 1) * bq + ps[j] + p_before;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) q[j] = a + d[j] + s_before;
+            }
+            T v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = lat.dequant((Q)q[j]);
+            if (t + 8 <= ex && out_aligned) {
+                if (sizeof(T) == 4) {
+                    float4 *o4 = reinterpret_cast<float4 *>(out + ox + t);
+                    o4[0] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+                    o4[1] = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+                } else {
+                    double2 *o2 = reinterpret_cast<double2 *>(out + ox + t);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) o2[j] = make_double2((double)v[2 * j], (double)v[2 * j + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (t + j < ex) out[ox + t + j] = v[j];
+            }
+        }
+        return;
+    }
     for (uint32_t k = threadIdx.x / WAVE; k < BLKN_TILE; k += 16) {
         const uint32_t task = blockIdx.x * BLKN_TILE + k;
         if (task >= nblocks) break;
@@ -3323,17 +3475,21 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
     if (p->ndim == 1 && (p->mask & 2u)) {  // second-order Lorenzo in the set: the scan of affine maps (k_blkn2_*)
         const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
         const uint32_t ntiles = (nblocks + BLKN_TILE - 1) / BLKN_TILE;
-        if (dtype == 0) {
-            hipLaunchKernelGGL(k_blkn2_pre<float>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
-            hipLaunchKernelGGL(k_blkn2_tile<int32_t>, dim3(ntiles), dim3(1024), 0, s, p->sel, nblocks, p->B, (uint32_t)p->d[2], p->carry);
-            hipLaunchKernelGGL(k_blkn2_top<int32_t>, dim3(1), dim3(1024), 0, s, ntiles, (int32_t *)p->carry + 2 * (uint64_t)nblocks);
-            hipLaunchKernelGGL(k_blkn2_apply<float>, dim3(ntiles), dim3(1024), 0, s, codes, p->qwork, d_out, *p, nblocks);
-        } else {
-            hipLaunchKernelGGL(k_blkn2_pre<double>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
-            hipLaunchKernelGGL(k_blkn2_tile<int64_t>, dim3(ntiles), dim3(1024), 0, s, p->sel, nblocks, p->B, (uint32_t)p->d[2], p->carry);
-            hipLaunchKernelGGL(k_blkn2_top<int64_t>, dim3(1), dim3(1024), 0, s, ntiles, (int64_t *)p->carry + 2 * (uint64_t)nblocks);
-            hipLaunchKernelGGL(k_blkn2_apply<double>, dim3(ntiles), dim3(1024), 0, s, codes, p->qwork, d_out, *p, nblocks);
-        }
+        // blocks of up to 128 values, a multiple of 8: four blocks per wave (debug flag 134217728: a wave per block)
+        const bool rows = p->B <= 128 && p->B % 8 == 0 && !(szk_dbg_flags & 134217728);
+        const uint32_t grow = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 15) / 16);
+#define BLKN2_DEC(T, QT)                                                                                                                          \
+    do {                                                                                                                                          \
+        if (rows) hipLaunchKernelGGL(k_blkn2_pre_rows<T>, dim3(grow), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank); \
+        else hipLaunchKernelGGL(k_blkn2_pre<T>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);         \
+        hipLaunchKernelGGL(k_blkn2_tile<QT>, dim3(ntiles), dim3(1024), 0, s, p->sel, nblocks, p->B, (uint32_t)p->d[2], p->carry);                  \
+        hipLaunchKernelGGL(k_blkn2_top<QT>, dim3(1), dim3(1024), 0, s, ntiles, (QT *)p->carry + 2 * (uint64_t)nblocks);                            \
+        if (rows) hipLaunchKernelGGL((k_blkn2_apply<T, true>), dim3(ntiles), dim3(1024), 0, s, codes, p->qwork, d_out, *p, nblocks);               \
+        else hipLaunchKernelGGL((k_blkn2_apply<T, false>), dim3(ntiles), dim3(1024), 0, s, codes, p->qwork, d_out, *p, nblocks);                   \
+    } while (0)
+        if (dtype == 0) BLKN2_DEC(float, int32_t);
+        else BLKN2_DEC(double, int64_t);
+#undef BLKN2_DEC
     } else
     if (p->ndim < 3) {
         const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);

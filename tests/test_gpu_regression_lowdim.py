@@ -215,7 +215,8 @@ L2_MASKS = ["L2", "L1+L2", "L1+L2+R", "L2+R"]
 
 @pytest.mark.parametrize("mask", L2_MASKS)
 @pytest.mark.parametrize("dtype,n,eb,block", [(np.float32, 5000, 1e-3, None), (np.float64, 3001, 2e-2, 64), (np.float32, 130, 1e-2, 7),
-                                             (np.float32, 100003, 1e-4, 5), (np.float64, 2500, 1e-5, 1000)])
+                                             (np.float32, 100003, 1e-4, 5), (np.float64, 2500, 1e-5, 1000), (np.float64, 40001, 1e-4, 104),
+                                             (np.float32, 5001, 1e-3, 8)])
 def test_1d_second_order_block_stream_against_the_numpy_model(mask, dtype, n, eb, block):
     a = field1d(n, dtype)
     conf = _conf((n,), eb, *MASKS[mask], block=block)
@@ -243,6 +244,13 @@ def test_1d_second_order_block_stream_against_the_numpy_model(mask, dtype, n, eb
     finally:
         sz3_amd.lib().sz3hip_debug_flags(NO_EXIT)
     assert _payload_of(blob2) == _payload_of(blob)
+    # ... and the decoder by rows of lanes (blocks of up to 128 values, a multiple of 8) against a wave per block: the same array
+    try:
+        sz3_amd.lib().sz3hip_debug_flags(NO_EXIT | 134217728)
+        dec2, _ = sz3_amd.decompress(blob, dtype, (n,))
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(NO_EXIT)
+    assert dec2.tobytes() == dec.tobytes()
 
 
 @pytest.mark.parametrize("n,eb,mask", [(1 << 20, 1e-3, "L1+L2"), (1 << 20, 1e-4, "L1+L2"), (1 << 18, 1e-2, "L1+L2"), (1 << 19, 1e-3, "L1+L2+R"), (1 << 18, 1e-3, "L2")])

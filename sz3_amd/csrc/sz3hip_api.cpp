@@ -240,6 +240,7 @@ static void ctx_free(sz3hip_ctx *c) {
     if (c->h_np) (void)hipHostFree(c->h_np);
     if (c->d_blk_carry) (void)hipFree(c->d_blk_carry);
     if (c->h_blk_side_hdr) (void)hipHostFree(c->h_blk_side_hdr);
+    if (c->d_blk_stats5) (void)hipFree(c->d_blk_stats5);
     if (c->h_ovf) (void)hipHostFree(c->h_ovf);
     for (int i = 0; i < ST_COUNT; i++)
         for (int j = 0; j < 2; j++)
@@ -353,13 +354,24 @@ static bool blk_shape_ok(const sz3hip_config *conf) {
     if (conf->N == 3) return conf->blockSize >= 4 && conf->blockSize <= 8;
     if (conf->N == 2) return conf->blockSize >= 4 && conf->blockSize <= 32 && conf->dims[0] < 0xFFFFFFFFull && conf->dims[1] < 0xFFFFFFFFull;
     if (conf->N == 1) return conf->blockSize >= 4 && conf->blockSize <= 65535 && conf->dims[0] < 0xFFFFFFFFull;  // (positions in 32 bits)
+    if (conf->N == 4) {  // (round 4: blocks of up to 6^4 values — the decoder's tile of (B + 1)^4 lattice words sits in LDS twice)
+        for (int i = 0; i < 4; i++)
+            if (conf->dims[i] >= 0xFFFFFFFFull) return false;
+        return conf->blockSize >= 4 && conf->blockSize <= 6;
+    }
     return false;
 }
 // the kernels' view of the array: three extents, the caller's right-aligned (1-D: (1, 1, n), 2-D: (1, dy, dx))
+// (a 4-D array: its three fast extents; the slowest travels beside them — blk_view_w)
 static void blk_view(int N, const uint64_t *dims, uint64_t *d3) {
     for (int i = 0; i < 3; i++) d3[i] = 1;
+    if (N == 4) {
+        for (int i = 0; i < 3; i++) d3[i] = dims[i + 1];
+        return;
+    }
     for (int i = 0; i < N && i < 3; i++) d3[3 - N + i] = dims[i];
 }
+static uint64_t blk_view_w(int N, const uint64_t *dims) { return N == 4 ? dims[0] : 1; }
 static uint64_t conf_blocks(const sz3hip_config *conf) {  // blocks the block-composed predictor would cut this array into (0: not its shape)
     if (!blk_shape_ok(conf)) return 0;
     uint64_t nb = 1;
@@ -653,7 +665,8 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
 // (make_compressor_lorenzo_regression, api/impl/SZAlgoLorenzoReg.hpp:22-64) ----
 static int blk_reserve_select(sz3hip_ctx *ctx, uint64_t nblocks) {  // (all the selection pass needs: counters, choices, coefficients)
     if (!ctx->d_blk_counters) HIPCHK(hipMalloc((void **)&ctx->d_blk_counters, 64 + 4 * (0x7FFFFFF0ull / 8192 + 2)));
-    if (!ctx->h_blk_side_hdr) HIPCHK(hipHostMalloc((void **)&ctx->h_blk_side_hdr, 32));
+    if (!ctx->d_blk_stats5) HIPCHK(hipMalloc((void **)&ctx->d_blk_stats5, 64));
+    if (!ctx->h_blk_side_hdr) HIPCHK(hipHostMalloc((void **)&ctx->h_blk_side_hdr, 64));
     if (ctx->blk_sel_cap >= nblocks) return 0;
     void **arr[2] = {(void **)&ctx->d_blk_sel, (void **)&ctx->d_blk_coef};
     for (void **a : arr) {
@@ -662,7 +675,7 @@ static int blk_reserve_select(sz3hip_ctx *ctx, uint64_t nblocks) {  // (all the 
     }
     ctx->blk_sel_cap = 0;
     HIPCHK(hipMalloc((void **)&ctx->d_blk_sel, nblocks));
-    HIPCHK(hipMalloc((void **)&ctx->d_blk_coef, nblocks * 32));
+    HIPCHK(hipMalloc((void **)&ctx->d_blk_coef, nblocks * 40));  // (up to five coefficients a block: 4-D arrays)
     ctx->blk_sel_cap = nblocks;
     return 0;
 }
@@ -684,13 +697,16 @@ static int blk_reserve(sz3hip_ctx *ctx, uint64_t nblocks) {
     return 0;
 }
 static void blk_params_from(sz3hip_ctx *ctx, int ndim, const uint64_t *dims3, uint32_t B, uint32_t mask, double eb, int radius, uint64_t out_cap,
-                            szk_blk_params &bp, szk_blk_scratch &sc) {
+                            szk_blk_params &bp, szk_blk_scratch &sc, uint64_t dw = 1) {
     memset(&bp, 0, sizeof(bp));
     memset(&sc, 0, sizeof(sc));
     for (int i = 0; i < 3; i++) {
         bp.d[i] = dims3[i];
         bp.nb[i] = (uint32_t)((dims3[i] + B - 1) / B);
     }
+    bp.dw = dw;
+    bp.nbw = (uint32_t)((dw + B - 1) / B);
+    sc.stats5 = reinterpret_cast<double *>(ctx->d_blk_stats5);
     bp.B = B;
     bp.ndim = (uint32_t)ndim;
     bp.carry = ctx->d_blk_carry;
@@ -729,7 +745,7 @@ static int blk_all_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const voi
     // (1-D: the fit pass chooses — the estimate looks at a block's two ends only and a line through 128 values wins there on every
     // field with noise above the bound, as in the reference: a selection pass of its own found no field to hand over and cost a
     // launch and a synchronisation, 2^27 values 1.97 -> 2.22 ms, C1 0.235 -> 0.27 ms)
-    if (conf->N == 1) return 0;
+    if (conf->N == 1 || conf->N == 4) return 0;  // (4-D: the plain form — the fit pass chooses)
     const uint32_t B = (uint32_t)conf->blockSize;
     uint64_t d3[3];
     blk_view(conf->N, conf->dims, d3);
@@ -759,17 +775,19 @@ static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
     const uint32_t B = (uint32_t)conf->blockSize;
     uint64_t d3[3];
     blk_view(conf->N, conf->dims, d3);
-    uint64_t nblocks = 1;
+    const uint64_t dw = blk_view_w(conf->N, conf->dims);
+    uint64_t nblocks = (dw + B - 1) / B;
     for (int i = 0; i < 3; i++) nblocks *= (d3[i] + B - 1) / B;
     if (nblocks > 0x7FFFFFF0ull) return fail(SZ3HIP_EUNSUPPORTED, "too many blocks for the block-composed predictor");
     int rc = blk_reserve(ctx, nblocks);
     if (rc) return rc;
     szk_blk_params bp;
     szk_blk_scratch sc;
-    blk_params_from(ctx, conf->N, d3, B, mask, eb, radius, ctx->cur_out_cap, bp, sc);
+    blk_params_from(ctx, conf->N, d3, B, mask, eb, radius, ctx->cur_out_cap, bp, sc, dw);
     bp.sel_given = ctx->blk_sel_given ? 1u : 0u;
     sc.wide_hist = ctx->blk_wide;
     HIPCHK(hipMemsetAsync(ctx->d_blk_counters, 0, 64, s));
+    HIPCHK(hipMemsetAsync(ctx->d_blk_stats5, 0, 64, s));
     prof_begin(ctx, ST_K1, s);
     rc = szk_launch_blk_compress(ctx->dtype, d_in, ctx->d_codes, &bp, &sc, s);
     prof_end(ctx, ST_K1, s);
@@ -785,7 +803,7 @@ static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
     h.qbytes = ctx->dtype == SZ3HIP_FLOAT ? 4 : 8;
     h.predictor = 2;
     h.radius = (uint32_t)radius;
-    h.dims[0] = 1;
+    h.dims[0] = dw;
     for (int i = 0; i < 3; i++) h.dims[1 + i] = d3[i];
     h.eb = eb;
     h.n = num;
@@ -1228,7 +1246,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
                 return stage1_lorenzo(ctx, conf, d_in, eb, radius, num, s);  // (the selection chose first-order Lorenzo throughout)
             }
             if (!(mask & 1u))
-                return fail(SZ3HIP_EUNSUPPORTED, "regression is built for 1-D (blockSize 4..65535), 2-D (4..32) and 3-D arrays (4..8), 2nd-order "
+                return fail(SZ3HIP_EUNSUPPORTED, "regression is built for 1-D (blockSize 4..65535), 2-D (4..32), 3-D (4..8) and 4-D arrays (4..6), 2nd-order "
                                                  "Lorenzo for 1-D and 3-D ones (got N = %d, blockSize = %d)", conf->N, conf->blockSize);
         }
     }
@@ -1248,7 +1266,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
         size_t need = payload_bound_n(n, lists);
         if (ctx->proto.predictor == 2) {
             uint64_t nb = 1;
-            for (int i = 0; i < 3; i++) nb *= (ctx->proto.dims[1 + i] + ctx->proto.interp_id - 1) / ctx->proto.interp_id;
+            for (int i = 0; i < 4; i++) nb *= (ctx->proto.dims[i] + ctx->proto.interp_id - 1) / ctx->proto.interp_id;  // (dims[0]: 1, or a 4-D array's slowest extent)
             need = std::max(need, payload_bound_blocks(n, lists, nb));
         }
         if (cap < need) return fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
@@ -1784,13 +1802,16 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         // stream, while the Huffman decoder runs on the caller's
         const uint32_t B = h.interp_id, mask = h.interp_dir;
         const bool fits32 = h.dims[1] < 0xFFFFFFFFull && h.dims[2] < 0xFFFFFFFFull && h.dims[3] < 0xFFFFFFFFull;  // (block positions are 32-bit)
-        const bool shape_ok = fits32 && (h.ndim == 3 ? B >= 4 && B <= 8 : (h.ndim == 2 ? B >= 4 && B <= 32 && h.dims[1] == 1 && !(mask & 2u)
-                                                                 : h.ndim == 1 && B >= 4 && B <= 65535 && h.dims[1] == 1 && h.dims[2] == 1));
+        const bool shape_ok = fits32 && (h.ndim == 4 ? B >= 4 && B <= 6 && h.dims[0] < 0xFFFFFFFFull && !(mask & 2u)
+                                                     : h.dims[0] == 1 && (h.ndim == 3 ? B >= 4 && B <= 8 : (h.ndim == 2 ? B >= 4 && B <= 32 && h.dims[1] == 1 && !(mask & 2u)
+                                                                 : h.ndim == 1 && B >= 4 && B <= 65535 && h.dims[1] == 1 && h.dims[2] == 1)));
         if (!shape_ok || mask == 0 || mask > 7 || h.side_bytes < 24 || h.n_dout > h.n)
             return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block predictor fields)");
         uint64_t nblocks = 1;
-        for (int i = 0; i < 3; i++) nblocks *= (h.dims[1 + i] + B - 1) / B;
-        if (nblocks > 0x7FFFFFF0ull) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block count)");
+        for (int i = 0; i < 4; i++) {
+            nblocks *= (h.dims[i] + B - 1) / B;
+            if (nblocks > 0x7FFFFFF0ull) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block count)");
+        }
         int rb = blk_reserve(ctx, nblocks);
         if (rb) return rb;
         if (h.ndim == 1 && ctx->blk_carry_cap < nblocks) {  // 1-D: aggregate + inflow of every block (two lattice words)
@@ -1801,10 +1822,11 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
             ctx->blk_carry_cap = nblocks;
         }
         const uint64_t sel_bytes = ((nblocks + 3) / 4 + 7) & ~7ull;
-        if (h.side_bytes < 24 + sel_bytes + 8) return fail(SZ3HIP_EFORMAT, "corrupt side section of a block-predictor stream");
+        const uint64_t par_bytes = h.ndim == 4 ? 16 : 8;  // the Rice parameters (one per coefficient: N + 1) and the group count
+        if (h.side_bytes < 24 + sel_bytes + par_bytes) return fail(SZ3HIP_EFORMAT, "corrupt side section of a block-predictor stream");
         HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr, pl + o.side, 24, hipMemcpyDeviceToHost, s));
-        // the four Rice parameters behind the selection bits travel with the header: they are shift counts in k_blk_coef_parse
-        HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr + 24, pl + o.side + 24 + sel_bytes, 8, hipMemcpyDeviceToHost, s));
+        // the Rice parameters behind the selection bits travel with the header: they are shift counts in k_blk_coef_parse
+        HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr + 24, pl + o.side + 24 + sel_bytes, par_bytes, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         uint32_t coding, sel_bits;
         uint64_t nb_side, nr;
@@ -1812,14 +1834,14 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         memcpy(&sel_bits, ctx->h_blk_side_hdr + 4, 4);
         memcpy(&nb_side, ctx->h_blk_side_hdr + 8, 8);
         memcpy(&nr, ctx->h_blk_side_hdr + 16, 8);
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < (h.ndim == 4 ? 5 : 4); i++)
             if (ctx->h_blk_side_hdr[24 + i] > 63) return fail(SZ3HIP_EFORMAT, "corrupt side section of a block-predictor stream (Rice parameter)");
         const uint64_t ngroups = (nr + 63) / 64;
-        const uint64_t fixed = 24 + sel_bytes + 8 + 4 * ngroups;  // header, selection, Rice parameters, group offsets
+        const uint64_t fixed = 24 + sel_bytes + par_bytes + 4 * ngroups;  // header, selection, Rice parameters, group offsets
         if (coding != 1 || sel_bits != 2 || nb_side != nblocks || nr > nblocks || h.side_bytes < fixed || (h.side_bytes - fixed) % 4)
             return fail(SZ3HIP_EFORMAT, "corrupt side section of a block-predictor stream");
         const uint64_t bit_words = (h.side_bytes - fixed) / 4;
-        blk_params_from(ctx, h.ndim, h.dims + 1, B, mask, h.eb, (int)h.radius, 0, bp, sc);
+        blk_params_from(ctx, h.ndim, h.dims + 1, B, mask, h.eb, (int)h.radius, 0, bp, sc, h.dims[0]);
         memcpy(sc.side_hdr, ctx->h_blk_side_hdr, 24);
         memcpy(sc.side_hdr + 24, &bit_words, 8);
         if (!ctx->side) {

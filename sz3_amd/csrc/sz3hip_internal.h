@@ -125,7 +125,8 @@ struct sz3hip_ctx {
     uint32_t *d_blk_rank, *d_blk_comp;
     uint8_t *d_blk_side;    // szk_blk_side_bound(blk_cap) bytes
     uint64_t *d_blk_counters;  // [8]
-    uint8_t *h_blk_side_hdr;   // pinned, 32 bytes
+    uint8_t *h_blk_side_hdr;   // pinned, 64 bytes
+    void *d_blk_stats5;        // [5] doubles: Rice statistics of a 4-D array's five coefficients
     void *d_half32;            // f64 decoder: int32 intermediates of the half-width chain (max_n * 4 bytes, lazily)
     bool hist_reduced;         // the library's own exchange sums the histogram between the stages (szi_histogram_for_exchange)
     uint64_t blk_sel_cap;      // blocks d_blk_sel / d_blk_coef hold

@@ -230,6 +230,8 @@ struct szk_blk_params {
     uint64_t *n_reg; // number of regression blocks (counted by the fit pass; the rank pass writes the same number)
     uint32_t sel_given;  // sel[] / coef[] were written by k_blk_select: k_blk_fit codes what they say instead of fitting again
     void *carry;         // low-dimensional decoder, ndim 1: [blocks][2] lattice words (a block's aggregate, then the value left of it)
+    uint64_t dw;         // 4-D arrays (ndim 4, round 4): the extent of the slowest dimension, d[] holds the other three; 1 otherwise
+    uint32_t nbw;        // ... and its blocks
 };
 struct szk_blk_scratch {
     uint32_t *rank, *comp;  // [blocks] rank among the regression blocks, compacted list of their ids
@@ -238,6 +240,7 @@ struct szk_blk_scratch {
     uint8_t *side;          // the side section being built
     int wide_hist;          // encode: 16384-bin LDS histogram window instead of 4096 (the context's previous alphabet was wide)
     uint8_t side_hdr[32];   // decode: host copy of the side section's header + [24..31] words of its bit section (validated by the caller)
+    double *stats5;         // encode, 4-D arrays: [5] Rice statistics of the five coefficients (zeroed by the caller)
 };
 // the selection pass alone (a block per lane): *n_other += the blocks that would not be coded by first-order Lorenzo
 // the tuner's Lorenzo trial for 1-D arrays: the set [Lorenzo-1, Lorenzo-2] in blocks of five over the sample blocks (sz3hip_regress.hip)

@@ -955,22 +955,29 @@ static void launch_blk_rank(const uint8_t *sel, uint32_t nblocks, uint32_t *rank
     hipLaunchKernelGGL(k_blk_rank_offsets, dim3(1), dim3(1024), 0, s, run_scratch, nruns, n_reg);
     hipLaunchKernelGGL(k_blk_rank_write, dim3(nruns), dim3(256), 0, s, sel, nblocks, (const uint32_t *)run_scratch, rank, comp);
 }
-__device__ __forceinline__ void coef_delta(const int64_t *__restrict__ coef, const uint32_t *__restrict__ comp, uint64_t r, uint64_t (&u)[4]) {
-    const int64_t *cur = coef + (uint64_t)comp[r] * 4;
-    const int64_t *prv = r ? coef + (uint64_t)comp[r - 1] * 4 : nullptr;
-    for (int i = 0; i < 4; i++) u[i] = zigzag(cur[i] - (prv ? prv[i] : 0));
+// NC: coefficients of a regression block — N + 1: four for the arrays the kernels see in three dimensions (1-D and 2-D arrays leave the
+// first ones zero), five for 4-D arrays (round 4). The parameter block behind the selection bits: NC Rice parameters, the number of
+// groups in its last four bytes — 8 bytes for NC = 4 (the layout of rounds 2 and 3), 16 for NC = 5.
+template <int NC> __device__ __host__ constexpr uint32_t side_par_bytes() { return NC <= 4 ? 8u : 16u; }
+template <int NC>
+__device__ __forceinline__ void coef_delta(const int64_t *__restrict__ coef, const uint32_t *__restrict__ comp, uint64_t r, uint64_t (&u)[NC]) {
+    const int64_t *cur = coef + (uint64_t)comp[r] * NC;
+    const int64_t *prv = r ? coef + (uint64_t)comp[r - 1] * NC : nullptr;
+    for (int i = 0; i < NC; i++) u[i] = zigzag(cur[i] - (prv ? prv[i] : 0));
 }
 // sum of the zigzagged differences per coefficient -> its Rice parameter (stats[0..3]; doubles: no overflow worries)
+template <int NC>
 __global__ __launch_bounds__(256) void k_blk_coef_stats(const int64_t *__restrict__ coef, const uint32_t *__restrict__ comp, const uint64_t *n_reg,
                                                         double *stats) {
     const uint64_t nr = *n_reg;
-    double s[4] = {0, 0, 0, 0};
+    double s[NC];
+    for (int i = 0; i < NC; i++) s[i] = 0;
     for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < nr; r += (uint64_t)gridDim.x * 256) {
-        uint64_t u[4];
-        coef_delta(coef, comp, r, u);
-        for (int i = 0; i < 4; i++) s[i] += (double)u[i];
+        uint64_t u[NC];
+        coef_delta<NC>(coef, comp, r, u);
+        for (int i = 0; i < NC; i++) s[i] += (double)u[i];
     }
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NC; i++) {
         s[i] = wave_sum_f64(s[i]);
         if (lane_id() == 0 && s[i] != 0) atomicAdd(&stats[i], s[i]);
     }
@@ -982,19 +989,20 @@ __device__ __forceinline__ uint32_t rice_param(double sum, uint64_t n) {
     return k;
 }
 // bits of every group of 64 regression blocks (one wave per group)
+template <int NC>
 __global__ __launch_bounds__(256) void k_blk_coef_len(const int64_t *__restrict__ coef, const uint32_t *__restrict__ comp, const uint64_t *n_reg,
                                                       const double *__restrict__ stats, uint32_t *__restrict__ group_bits) {
     const uint64_t nr = *n_reg;
     const uint64_t ngroups = (nr + RICE_GROUP - 1) / RICE_GROUP;
-    uint32_t k[4];
-    for (int i = 0; i < 4; i++) k[i] = rice_param(stats[i], nr);
+    uint32_t k[NC];
+    for (int i = 0; i < NC; i++) k[i] = rice_param(stats[i], nr);
     for (uint64_t g = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE; g < ngroups; g += (uint64_t)gridDim.x * 4) {
         const uint64_t r = g * RICE_GROUP + lane_id();
         uint32_t bits = 0;
         if (r < nr) {
-            uint64_t u[4];
-            coef_delta(coef, comp, r, u);
-            for (int i = 0; i < 4; i++) bits += rice_len(u[i], k[i]);
+            uint64_t u[NC];
+            coef_delta<NC>(coef, comp, r, u);
+            for (int i = 0; i < NC; i++) bits += rice_len(u[i], k[i]);
         }
         bits = wave_sum(bits);
         if (lane_id() == 0) group_bits[g] = bits;
@@ -1023,6 +1031,7 @@ __global__ __launch_bounds__(256) void k_blk_sel_pack(const uint8_t *__restrict_
         side[SIDE_HDR + b] = (uint8_t)v;
     }
 }
+template <int NC>
 __global__ __launch_bounds__(1024) void k_blk_side_layout(uint32_t nblocks, const uint64_t *n_reg,
                                                           const double *__restrict__ stats, const uint32_t *__restrict__ group_bits,
                                                           uint8_t *__restrict__ side, uint64_t *side_bytes) {
@@ -1032,14 +1041,15 @@ __global__ __launch_bounds__(1024) void k_blk_side_layout(uint32_t nblocks, cons
     const uint64_t sel_bytes = side_sel_bytes(nblocks);
     const uint32_t ngroups = (uint32_t)((nr + RICE_GROUP - 1) / RICE_GROUP);
     uint8_t *kp = side + SIDE_HDR + sel_bytes;
-    uint32_t *goff = reinterpret_cast<uint32_t *>(kp + 8);
+    constexpr uint32_t PB = side_par_bytes<NC>();
+    uint32_t *goff = reinterpret_cast<uint32_t *>(kp + PB);
     if (threadIdx.x == 0) {
         const uint32_t h0[2] = {1u, 2u};
         const uint64_t h1[2] = {nblocks, nr};
         memcpy(side, h0, 8);
         memcpy(side + 8, h1, 16);
-        for (int i = 0; i < 4; i++) kp[i] = (uint8_t)rice_param(stats[i], nr);
-        memcpy(kp + 4, &ngroups, 4);
+        for (uint32_t i = 0; i < PB - 4; i++) kp[i] = i < (uint32_t)NC ? (uint8_t)rice_param(stats[i], nr) : (uint8_t)0;
+        memcpy(kp + PB - 4, &ngroups, 4);
         s_carry = 0;
     }
     // (the selection bits are packed by k_blk_sel_pack, a launch of its own: one workgroup walking 155 KB of them was 100 of this
@@ -1064,27 +1074,30 @@ __global__ __launch_bounds__(1024) void k_blk_side_layout(uint32_t nblocks, cons
     const uint64_t words = ((uint64_t)s_carry + 31) / 32;
     uint32_t *bits = goff + ngroups;
     for (uint64_t i = threadIdx.x; i < words; i += 1024) bits[i] = 0;
-    if (threadIdx.x == 0) *side_bytes = SIDE_HDR + sel_bytes + 8 + 4ull * ngroups + 4 * words;
+    if (threadIdx.x == 0) *side_bytes = SIDE_HDR + sel_bytes + PB + 4ull * ngroups + 4 * words;
 }
+template <int NC>
 __global__ __launch_bounds__(256) void k_blk_coef_write(const int64_t *__restrict__ coef, const uint32_t *__restrict__ comp, const uint64_t *n_reg,
                                                         uint32_t nblocks, uint8_t *__restrict__ side) {
     const uint64_t nr = *n_reg;
     const uint64_t ngroups = (nr + RICE_GROUP - 1) / RICE_GROUP;
     const uint8_t *kp = side + SIDE_HDR + side_sel_bytes(nblocks);
-    const uint32_t k[4] = {kp[0], kp[1], kp[2], kp[3]};
-    const uint32_t *goff = reinterpret_cast<const uint32_t *>(kp + 8);
+    uint32_t k[NC];
+    for (int i = 0; i < NC; i++) k[i] = kp[i];
+    const uint32_t *goff = reinterpret_cast<const uint32_t *>(kp + side_par_bytes<NC>());
     uint32_t *bits = const_cast<uint32_t *>(goff) + ngroups;
     for (uint64_t g = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE; g < ngroups; g += (uint64_t)gridDim.x * 4) {
         const uint64_t r = g * RICE_GROUP + lane_id();
-        uint64_t u[4] = {0, 0, 0, 0};
+        uint64_t u[NC];
+        for (int i = 0; i < NC; i++) u[i] = 0;
         uint32_t len = 0;
         if (r < nr) {
-            coef_delta(coef, comp, r, u);
-            for (int i = 0; i < 4; i++) len += rice_len(u[i], k[i]);
+            coef_delta<NC>(coef, comp, r, u);
+            for (int i = 0; i < NC; i++) len += rice_len(u[i], k[i]);
         }
         uint64_t pos = (uint64_t)goff[g] + (wave_incl_scan(len) - len);
         if (r < nr)
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < NC; i++) {
                 const uint64_t q = u[i] >> k[i];
                 if (q < RICE_ESC) {
                     put_bits(bits, pos, ((1ull << q) - 1ull) << 1, (uint32_t)q + 1u);  // q ones, a zero
@@ -1132,20 +1145,23 @@ __device__ __forceinline__ uint64_t peek64(const uint32_t *__restrict__ words, u
 // window of the stream (count leading ones), not bit by bit: a load per bit made this kernel 0.84 ms at C4a's 92 000 regression blocks,
 // on the side stream's critical path. It also leaves the sums of its group's differences: the chain over the regression blocks is
 // then a scan over the groups (k_blk_coef_gscan) and a wave scan inside each (k_blk_coef_apply).
+template <int NC>
 __global__ __launch_bounds__(256) void k_blk_coef_parse(const uint8_t *__restrict__ side, uint32_t nblocks, uint64_t nr, uint64_t bit_words,
                                                         int64_t *__restrict__ delta_by_rank, int64_t *__restrict__ gsum) {
     const uint64_t ngroups = (nr + RICE_GROUP - 1) / RICE_GROUP;
     const uint8_t *kp = side + SIDE_HDR + side_sel_bytes(nblocks);
-    const uint32_t k[4] = {kp[0], kp[1], kp[2], kp[3]};
-    const uint32_t *goff = reinterpret_cast<const uint32_t *>(kp + 8);
+    uint32_t k[NC];
+    for (int i = 0; i < NC; i++) k[i] = kp[i];
+    const uint32_t *goff = reinterpret_cast<const uint32_t *>(kp + side_par_bytes<NC>());
     const uint32_t *bits = goff + ngroups;
     const uint64_t total_bits = bit_words * 32;
     for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * 256) {
         uint64_t pos = goff[g];
         const uint64_t r1 = (g + 1) * RICE_GROUP < nr ? (g + 1) * RICE_GROUP : nr;
-        uint64_t tot[4] = {0, 0, 0, 0};
+        uint64_t tot[NC];
+        for (int i = 0; i < NC; i++) tot[i] = 0;
         for (uint64_t r = g * RICE_GROUP; r < r1; r++)
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < NC; i++) {
                 uint64_t u = 0;
                 const uint64_t win = peek64(bits, pos, bit_words);
                 const uint32_t ones = ~win ? (uint32_t)__clzll((long long)~win) : 64u;
@@ -1163,35 +1179,35 @@ __global__ __launch_bounds__(256) void k_blk_coef_parse(const uint8_t *__restric
                     pos += 64;
                 }
                 const int64_t dl = unzigzag(u);
-                delta_by_rank[r * 4 + i] = dl;
+                delta_by_rank[r * NC + i] = dl;
                 tot[i] += (uint64_t)dl;
             }
-        for (int i = 0; i < 4; i++) gsum[g * 4 + i] = (int64_t)tot[i];
+        for (int i = 0; i < NC; i++) gsum[g * NC + i] = (int64_t)tot[i];
     }
 }
 // exclusive scan of the groups' sums, per coefficient (one workgroup, 1024 groups a round)
+template <int NC>
 __global__ __launch_bounds__(1024) void k_blk_coef_gscan(uint64_t ngroups, int64_t *__restrict__ gsum) {
-    __shared__ int64_t s_w[4][16];
-    __shared__ int64_t s_carry[4];
-    if (threadIdx.x < 4) s_carry[threadIdx.x] = 0;
+    __shared__ int64_t s_w[NC][16];
+    __shared__ int64_t s_carry[NC];
+    if (threadIdx.x < NC) s_carry[threadIdx.x] = 0;
     __syncthreads();
     for (uint64_t base = 0; base < ngroups; base += 1024) {
         const uint64_t g = base + threadIdx.x;
-        int64_t d[4] = {0, 0, 0, 0}, incl[4];
-        if (g < ngroups)
-            for (int i = 0; i < 4; i++) d[i] = gsum[g * 4 + i];
-        for (int i = 0; i < 4; i++) {
+        int64_t d[NC], incl[NC];
+        for (int i = 0; i < NC; i++) d[i] = g < ngroups ? gsum[g * NC + i] : 0;
+        for (int i = 0; i < NC; i++) {
             incl[i] = (int64_t)wave_incl_scan((uint64_t)d[i]);
             if (lane_id() == WAVE - 1) s_w[i][threadIdx.x / WAVE] = incl[i];
         }
         __syncthreads();
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < NC; i++) {
             int64_t run = s_carry[i] + incl[i] - d[i];
             for (uint32_t kk = 0; kk < threadIdx.x / WAVE; kk++) run += s_w[i][kk];
-            if (g < ngroups) gsum[g * 4 + i] = run;
+            if (g < ngroups) gsum[g * NC + i] = run;
         }
         __syncthreads();
-        if (threadIdx.x < 4) {
+        if (threadIdx.x < NC) {
             int64_t tot = 0;
             for (int kk = 0; kk < 16; kk++) tot += s_w[threadIdx.x][kk];
             s_carry[threadIdx.x] += tot;
@@ -1200,14 +1216,15 @@ __global__ __launch_bounds__(1024) void k_blk_coef_gscan(uint64_t ngroups, int64
     }
 }
 // differences -> coefficients: a wave per group of 64 regression blocks, the group's inflow from the scan above
+template <int NC>
 __global__ __launch_bounds__(256) void k_blk_coef_apply(uint64_t nr, const int64_t *__restrict__ gpre, int64_t *__restrict__ coef_by_rank) {
     const uint64_t ngroups = (nr + RICE_GROUP - 1) / RICE_GROUP;
     for (uint64_t g = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE; g < ngroups; g += (uint64_t)gridDim.x * 4) {
         const uint64_t r = g * RICE_GROUP + lane_id();
-        for (int i = 0; i < 4; i++) {
-            const uint64_t d = r < nr ? (uint64_t)coef_by_rank[r * 4 + i] : 0ull;
-            const uint64_t v = wave_incl_scan(d) + (uint64_t)gpre[g * 4 + i];
-            if (r < nr) coef_by_rank[r * 4 + i] = (int64_t)v;
+        for (int i = 0; i < NC; i++) {
+            const uint64_t d = r < nr ? (uint64_t)coef_by_rank[r * NC + i] : 0ull;
+            const uint64_t v = wave_incl_scan(d) + (uint64_t)gpre[g * NC + i];
+            if (r < nr) coef_by_rank[r * NC + i] = (int64_t)v;
         }
     }
 }
@@ -3193,6 +3210,437 @@ __global__ __launch_bounds__(256) void k_blkn_decode2g(const void *deltas_, void
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 4-D arrays (round 4): Lorenzo-1 / linear regression with FIVE coefficients per block of B^4 values (B = 4..6, default 6:
+// Config.hpp:175) — RegressionPredictor.hpp:28-55, 77-92 for N = 4, LorenzoPredictor.hpp:69-74 (fifteen neighbours, noise 1.79 eb),
+// the sample points of BlockwiseIterator.hpp:151-184 (eight per step of the diagonal). The same design as in three dimensions, in its
+// plain form: k_blk4_fit (a wave per block: fit, estimates, choice, regression blocks coded, q~ of every element to the work array),
+// k_blk4_lorenzo (a thread per code position: the sixteen-term stencil over q~), the side section with five coefficients per
+// regression block, and a decoder of anti-diagonal fronts (bw + bz + by + bx = const, a wave per block, the block and its low halo
+// in LDS, four passes of line sums). p.dw / p.nbw: the slowest dimension; p.d / p.nb: the other three.
+// ------------------------------------------------------------------------------------------------------------
+struct Blk4 {
+    uint32_t ow, oz, oy, ox;  // origin
+    uint32_t ew, ez, ey, ex;  // extents (ragged at the high end)
+    uint64_t coff;            // position of the block's first code (block raster order, raster order inside a block)
+};
+__device__ __forceinline__ Blk4 blk4_geom(const szk_blk_params &p, uint32_t bw, uint32_t bz, uint32_t by, uint32_t bx) {
+    Blk4 g;
+    g.ow = bw * p.B;
+    g.oz = bz * p.B;
+    g.oy = by * p.B;
+    g.ox = bx * p.B;
+    g.ew = min(p.B, (uint32_t)p.dw - g.ow);
+    g.ez = min(p.B, (uint32_t)p.d[0] - g.oz);
+    g.ey = min(p.B, (uint32_t)p.d[1] - g.oy);
+    g.ex = min(p.B, (uint32_t)p.d[2] - g.ox);
+    // whole slabs of blocks along w below, whole slabs along z in this one, whole rows of blocks, the blocks left of this one
+    g.coff = (uint64_t)g.ow * p.d[0] * p.d[1] * p.d[2] +
+             (uint64_t)g.ew * ((uint64_t)g.oz * p.d[1] * p.d[2] + (uint64_t)g.ez * ((uint64_t)g.oy * p.d[2] + (uint64_t)g.ey * g.ox));
+    return g;
+}
+__device__ __forceinline__ Blk4 blk4_of_task(const szk_blk_params &p, uint32_t task) {
+    const uint32_t bx = task % p.nb[2];
+    uint32_t r = task / p.nb[2];
+    const uint32_t by = r % p.nb[1];
+    r /= p.nb[1];
+    const uint32_t bz = r % p.nb[0], bw = r / p.nb[0];
+    return blk4_geom(p, bw, bz, by, bx);
+}
+__device__ __forceinline__ void blk4_own(const Blk4 &g, uint32_t t, uint32_t (&i)[4]) {
+    i[3] = t % g.ex;
+    t /= g.ex;
+    i[2] = t % g.ey;
+    t /= g.ey;
+    i[1] = t % g.ez;
+    i[0] = t / g.ez;
+}
+__device__ __forceinline__ uint64_t blk4_at(const szk_blk_params &p, uint64_t w, uint64_t z, uint64_t y, uint64_t x) {
+    return ((w * p.d[0] + z) * p.d[1] + y) * p.d[2] + x;
+}
+template <typename T>
+__device__ __forceinline__ T reg_predict4(const T (&c)[5], const uint32_t (&i)[4]) {  // RegressionPredictor.hpp:77-92, left to right in T
+    T s = c[0] * (T)i[0];
+    s = s + c[1] * (T)i[1];
+    s = s + c[2] * (T)i[2];
+    s = s + c[3] * (T)i[3];
+    return s + c[4];
+}
+template <typename T>
+__device__ __forceinline__ void coef_recover4(const int64_t *lc, const CoefLat &cl, T (&rc)[5]) {
+    for (int i = 0; i < 4; i++) rc[i] = (T)((double)lc[i] * cl.step_lin);
+    rc[4] = (T)((double)lc[4] * cl.step_ind);
+}
+template <typename T, uint32_t HW, int NW>
+__global__ __launch_bounds__(NW * 64) void k_blk4_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
+    using Q = typename QTraits<T>::Q;
+    __shared__ uint32_t lh[HW];
+    for (uint32_t b = threadIdx.x; b < HW; b += NW * 64) lh[b] = 0;
+    __syncthreads();
+    const Lattice<T> lat(p.lat);
+    const int lane = lane_id();
+    const uint32_t wv = threadIdx.x / WAVE;
+    Q *qwork = reinterpret_cast<Q *>(p.qwork);
+    const CoefLat cl = coef_lat(p.eb, p.B, 4u);
+    const double eb_recip = 1.0 / p.eb;
+    const bool has_l1 = p.mask & 1u, has_r = p.mask & 4u;
+    const T noise = (T)(1.79 * p.eb);
+    for (uint32_t task = blockIdx.x * NW + wv; task < nblocks; task += gridDim.x * NW) {
+        const Blk4 g = blk4_of_task(p, task);
+        const uint32_t nown = g.ew * g.ez * g.ey * g.ex;
+        // ---- fit (RegressionPredictor.hpp:28-55, N = 4) ----
+        const bool r_valid = has_r && g.ew > 1 && g.ez > 1 && g.ey > 1 && g.ex > 1;
+        T cf[5] = {0, 0, 0, 0, 0};
+        if (r_valid) {
+            double s[5] = {0, 0, 0, 0, 0};
+            for (uint32_t t = lane; t < nown; t += WAVE) {
+                uint32_t i[4];
+                blk4_own(g, t, i);
+                const T v = in[blk4_at(p, g.ow + i[0], g.oz + i[1], g.oy + i[2], g.ox + i[3])];
+                for (int k = 0; k < 4; k++) s[k] += (double)((T)i[k] * v);
+                s[4] += (double)v;
+            }
+            for (int k = 0; k < 5; k++) s[k] = wave_sum_f64(s[k]);
+            const double dims[4] = {(double)g.ew, (double)g.ez, (double)g.ey, (double)g.ex};
+            const double num = dims[0] * dims[1] * dims[2] * dims[3];
+            cf[4] = (T)(s[4] / num);
+            for (int k = 0; k < 4; k++) {
+                cf[k] = (T)((2 * s[k] / (dims[k] - 1) - s[4]) * 6 / num / (dims[k] + 1));
+                cf[4] = (T)((double)cf[4] - (dims[k] - 1) * (double)cf[k] / 2);
+            }
+        }
+        // ---- selection (ComposedPredictor.hpp:25-40 over foreach_sampling) ----
+        int sid = has_l1 ? 0 : 2;
+        if (has_l1 && has_r) {
+            const uint32_t m = min(min(g.ew, g.ez), min(g.ey, g.ex));
+            double e1 = 0, er = 0;
+            // what the Lorenzo estimate sees: the original inside the block, the lattice reconstruction outside it, zero outside the array
+            auto seen = [&](int64_t w, int64_t z, int64_t y, int64_t x) -> T {
+                if (w < 0 || z < 0 || y < 0 || x < 0) return (T)0;
+                T v = in[blk4_at(p, (uint64_t)w, (uint64_t)z, (uint64_t)y, (uint64_t)x)];
+                if (w < (int64_t)g.ow || z < (int64_t)g.oz || y < (int64_t)g.oy || x < (int64_t)g.ox) {
+                    bool bad;
+                    const Q qh = lat.quant(v, bad);
+                    if (!bad) v = lat.dequant(qh);
+                }
+                return v;
+            };
+            for (uint32_t k = lane; k < 8 * m; k += WAVE) {
+                const uint32_t i = k >> 3, cmb = k & 7u, j = m - 1 - i;
+                const uint32_t idx[4] = {i, (cmb & 4u) ? j : i, (cmb & 2u) ? j : i, (cmb & 1u) ? j : i};
+                const int64_t w = (int64_t)g.ow + idx[0], z = (int64_t)g.oz + idx[1], y = (int64_t)g.oy + idx[2], x = (int64_t)g.ox + idx[3];
+                const T v = in[blk4_at(p, (uint64_t)w, (uint64_t)z, (uint64_t)y, (uint64_t)x)];
+                // LorenzoPredictor.hpp:69-74: prev4(d, ds, t, k, j, i) steps t along y, k along z, j along w, i along x (ds: the strides, slowest first)
+                auto P = [&](int t_, int k_, int j_, int i_) -> T { return seen(w - j_, z - k_, y - t_, x - i_); };
+                T s = P(0, 0, 0, 1);
+                s = s + P(0, 0, 1, 0);
+                s = s - P(0, 0, 1, 1);
+                s = s + P(0, 1, 0, 0);
+                s = s - P(0, 1, 0, 1);
+                s = s - P(0, 1, 1, 0);
+                s = s + P(0, 1, 1, 1);
+                s = s + P(1, 0, 0, 0);
+                s = s - P(1, 0, 0, 1);
+                s = s - P(1, 0, 1, 0);
+                s = s + P(1, 0, 1, 1);
+                s = s - P(1, 1, 0, 0);
+                s = s + P(1, 1, 0, 1);
+                s = s + P(1, 1, 1, 0);
+                s = s - P(1, 1, 1, 1);
+                e1 += (double)(T)((T)fabs((double)(T)(v - s)) + noise);
+                if (r_valid) er += (double)(T)fabs((double)(T)(v - reg_predict4(cf, idx)));
+            }
+            e1 = wave_sum_f64(e1);
+            er = wave_sum_f64(er);
+            sid = (r_valid && er < e1) ? 2 : 0;
+        } else if (sid == 2 && !r_valid) {
+            sid = 0;  // BlockwiseDecomposition.hpp:35-37
+        }
+        int64_t lc[5] = {0, 0, 0, 0, 0};
+        if (sid == 2) {  // coefficients onto their lattices; a coefficient the lattice cannot hold -> Lorenzo-1
+            bool ok = true;
+            for (int k = 0; k < 5; k++) {
+                const double sc = (double)cf[k] / (k < 4 ? cl.step_lin : cl.step_ind);
+                if (!(fabs(sc) < 4503599627370496.0)) ok = false;
+                else lc[k] = (int64_t)rint(sc);
+            }
+            if (!ok) sid = 0;
+        }
+        T rc[5];
+        coef_recover4(lc, cl, rc);
+        for (uint32_t t0 = 0; t0 < nown; t0 += WAVE) {  // (uniform trip count: the counts and list appends are wave operations)
+            const uint32_t t = t0 + lane;
+            const bool act = t < nown;
+            uint32_t i[4];
+            blk4_own(g, act ? t : 0u, i);
+            const uint64_t gi = blk4_at(p, g.ow + i[0], g.oz + i[1], g.oy + i[2], g.ox + i[3]);
+            const T raw = in[gi];
+            bool bad = false;
+            Q qt = 0;
+            int code = 1;
+            if (sid == 2) {
+                T v = raw;
+                code = act ? ref_quantize(v, reg_predict4(rc, i), p.eb, eb_recip, (int)p.radius) : 1;
+                if (code != 0) {
+                    qt = lat.quant(v, bad);
+                    if (bad) qt = 0;
+                }
+                bad = code == 0;  // unpredictable: the raw value (LinearQuantizer.hpp:66-69)
+                if (act) codes[g.coff + t] = (uint16_t)code;
+            } else {
+                qt = lat.quant(raw, bad);
+                if (bad) qt = 0;
+            }
+            if (act) qwork[gi] = qt;
+            blk_count<HW>(lh, p, (uint32_t)code, act && sid == 2);
+            blk_vout<T>(p, act && bad, gi, raw);
+        }
+        if (lane == 0) {
+            p.sel[task] = (uint8_t)sid;
+            if (sid == 2)
+                for (int k = 0; k < 5; k++) p.coef[(uint64_t)task * 5 + k] = lc[k];
+        }
+    }
+    __syncthreads();
+    blk_flush<HW>(lh, p);
+}
+// code position -> block and element (the codes lie block by block)
+struct Blk4Pos {
+    uint32_t task;
+    uint64_t w, z, y, x;
+};
+__device__ __forceinline__ Blk4Pos blk4_pos(const szk_blk_params &p, uint64_t c) {
+    Blk4Pos r;
+    const uint64_t D3 = p.d[0] * p.d[1] * p.d[2];
+    const uint32_t bw = (uint32_t)(c / ((uint64_t)p.B * D3));
+    uint64_t rem = c - (uint64_t)bw * p.B * D3;
+    const uint32_t ow = bw * p.B, ew = min(p.B, (uint32_t)p.dw - ow);
+    const uint64_t zs = (uint64_t)ew * p.B * p.d[1] * p.d[2];
+    const uint32_t bz = (uint32_t)(rem / zs);
+    rem -= (uint64_t)bz * zs;
+    const uint32_t oz = bz * p.B, ez = min(p.B, (uint32_t)p.d[0] - oz);
+    const uint64_t ys = (uint64_t)ew * ez * p.B * p.d[2];
+    const uint32_t by = (uint32_t)(rem / ys);
+    rem -= (uint64_t)by * ys;
+    const uint32_t oy = by * p.B, ey = min(p.B, (uint32_t)p.d[1] - oy);
+    const uint32_t xs = ew * ez * ey * p.B;
+    const uint32_t bx = (uint32_t)(rem / xs);
+    uint32_t t = (uint32_t)(rem - (uint64_t)bx * xs);
+    const uint32_t ox = bx * p.B, ex = min(p.B, (uint32_t)p.d[2] - ox);
+    const uint32_t i3 = t % ex;
+    t /= ex;
+    const uint32_t i2 = t % ey;
+    t /= ey;
+    const uint32_t i1 = t % ez, i0 = t / ez;
+    r.task = ((bw * p.nb[0] + bz) * p.nb[1] + by) * p.nb[2] + bx;
+    r.w = ow + i0;
+    r.z = oz + i1;
+    r.y = oy + i2;
+    r.x = ox + i3;
+    return r;
+}
+template <typename T, uint32_t HW, int TB>
+__global__ __launch_bounds__(TB) void k_blk4_lorenzo(uint16_t *__restrict__ codes, szk_blk_params p, uint64_t n) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    __shared__ uint32_t lh[HW];
+    for (uint32_t b = threadIdx.x; b < HW; b += TB) lh[b] = 0;
+    __syncthreads();
+    const Q *__restrict__ qw = reinterpret_cast<const Q *>(p.qwork);
+    const uint64_t stride = (uint64_t)gridDim.x * TB;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * TB; c0 < n; c0 += stride) {  // (workgroup-uniform: the counts and appends are wave operations)
+        const uint64_t c = c0 + threadIdx.x;
+        bool act = c < n;
+        const Blk4Pos e = blk4_pos(p, act ? c : 0);
+        act = act && p.sel[e.task] != 2;
+        UQ delta = 0;
+        if (act) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                const uint32_t a = (m >> 3) & 1, b = (m >> 2) & 1, cc = (m >> 1) & 1, d = m & 1;
+                if (e.w < a || e.z < b || e.y < cc || e.x < d) continue;  // (zeros outside the array)
+                const UQ q = (UQ)qw[blk4_at(p, e.w - a, e.z - b, e.y - cc, e.x - d)];
+                delta = ((a + b + cc + d) & 1) ? delta - q : delta + q;
+            }
+        }
+        const bool inr = (UQ)(delta + (UQ)(p.radius - 1)) <= (UQ)(2 * p.radius - 2);
+        const uint32_t code = inr ? (uint32_t)(delta + (UQ)p.radius) : 0u;
+        if (act) codes[c] = (uint16_t)code;
+        blk_count<HW>(lh, p, code, act);
+        const unsigned long long pd = wave_append_slot(act && !inr, p.n_dout);
+        if (act && !inr && pd < p.out_cap) {
+            p.dout_idx[pd] = c;
+            reinterpret_cast<Q *>(p.dout_val)[pd] = (Q)delta;
+        }
+    }
+    __syncthreads();
+    blk_flush<HW>(lh, p);
+}
+// ---- decoder ----
+// regression blocks: q~ of their elements into the output (as lattice words: what their neighbours' halos read)
+template <typename T>
+__global__ __launch_bounds__(256) void k_blk4_pre(const uint16_t *__restrict__ codes, void *d_out, szk_blk_params p, uint32_t nblocks,
+                                                  const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
+    using Q = typename QTraits<T>::Q;
+    const Lattice<T> lat(p.lat);
+    const int lane = lane_id();
+    Q *qout = reinterpret_cast<Q *>(d_out);
+    const CoefLat cl = coef_lat(p.eb, p.B, 4u);
+    for (uint32_t task = blockIdx.x * 4 + threadIdx.x / WAVE; task < nblocks; task += gridDim.x * 4) {
+        if (p.sel[task] != 2) continue;
+        const Blk4 g = blk4_of_task(p, task);
+        const uint32_t nown = g.ew * g.ez * g.ey * g.ex;
+        T rc[5];
+        coef_recover4(coef_by_rank + (uint64_t)rank[task] * 5, cl, rc);
+        for (uint32_t t = lane; t < nown; t += WAVE) {
+            uint32_t i[4];
+            blk4_own(g, t, i);
+            const uint32_t code = codes[g.coff + t];
+            Q qt = 0;
+            if (code) {
+                bool bad;
+                const T val = ref_recover(reg_predict4(rc, i), (int)code, p.eb, (int)p.radius);
+                qt = lat.quant(val, bad);
+                if (bad) qt = 0;
+            }
+            qout[blk4_at(p, g.ow + i[0], g.oz + i[1], g.oy + i[2], g.ox + i[3])] = qt;
+        }
+    }
+}
+// one front (bw + bz + by + bx = diag), a wave per Lorenzo block: the block's deltas and its low halo (one layer of finished q~, zeros
+// outside the array) in LDS; four passes of line sums undo the four differences — along x with the inflow Dw Dz Dy q~ of the halo
+// column, along y with Dw Dz q~ of the halo row, along z with Dw q~, along w with q~ itself
+#define BLK4_MAXE 7u  // block edge (<= 6) + the halo layer
+template <typename T>
+__global__ __launch_bounds__(64) void k_blk4_decode(const void *deltas_, void *d_out, szk_blk_params p, uint32_t diag) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    __shared__ Q sq[BLK4_MAXE * BLK4_MAXE * BLK4_MAXE * BLK4_MAXE], sa[BLK4_MAXE * BLK4_MAXE * BLK4_MAXE * BLK4_MAXE];
+    const uint32_t by = blockIdx.x % p.nb[1];
+    uint32_t r = blockIdx.x / p.nb[1];
+    const uint32_t bz = r % p.nb[0], bw = r / p.nb[0];
+    if (bw + bz + by > diag) return;
+    const uint32_t bx = diag - bw - bz - by;
+    if (bx >= p.nb[2]) return;
+    const uint32_t task = ((bw * p.nb[0] + bz) * p.nb[1] + by) * p.nb[2] + bx;
+    if (p.sel[task] == 2) return;
+    const Blk4 g = blk4_geom(p, bw, bz, by, bx);
+    const int lane = lane_id();
+    Q *qout = reinterpret_cast<Q *>(d_out);
+    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    const uint32_t tw = g.ew + 1, tz = g.ez + 1, ty = g.ey + 1, tx = g.ex + 1;  // tile extents; coordinate 0 = the halo
+    auto at = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) -> uint32_t { return ((a * tz + b) * ty + c) * tx + d; };
+    for (uint32_t l = lane; l < tw * tz * ty * tx; l += WAVE) {
+        uint32_t q = l;
+        const uint32_t d = q % tx;
+        q /= tx;
+        const uint32_t c = q % ty;
+        q /= ty;
+        const uint32_t b = q % tz, a = q / tz;
+        Q v = 0;
+        if (a && b && c && d) {
+            v = deltas[g.coff + (((a - 1) * g.ez + (b - 1)) * g.ey + (c - 1)) * g.ex + (d - 1)];
+        } else {
+            const int64_t w = (int64_t)g.ow + a - 1, z = (int64_t)g.oz + b - 1, y = (int64_t)g.oy + c - 1, x = (int64_t)g.ox + d - 1;
+            if (w >= 0 && z >= 0 && y >= 0 && x >= 0) v = qout[blk4_at(p, (uint64_t)w, (uint64_t)z, (uint64_t)y, (uint64_t)x)];
+        }
+        sq[l] = v;
+    }
+    wave_lds_fence();
+    // along x: lines (a, b, c) of the block
+    for (uint32_t l = lane; l < g.ew * g.ez * g.ey; l += WAVE) {
+        uint32_t q = l;
+        const uint32_t c = q % g.ey + 1;
+        q /= g.ey;
+        const uint32_t b = q % g.ez + 1, a = q / g.ez + 1;
+        UQ run = 0;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const uint32_t da = (m >> 2) & 1, db = (m >> 1) & 1, dc = m & 1;
+            const UQ v = (UQ)sq[at(a - da, b - db, c - dc, 0)];
+            run = ((da + db + dc) & 1) ? run - v : run + v;
+        }
+        for (uint32_t d = 1; d <= g.ex; d++) {
+            run += (UQ)sq[at(a, b, c, d)];
+            sa[at(a, b, c, d)] = (Q)run;
+        }
+    }
+    wave_lds_fence();
+    // along y: lines (a, b, d)
+    for (uint32_t l = lane; l < g.ew * g.ez * g.ex; l += WAVE) {
+        uint32_t q = l;
+        const uint32_t d = q % g.ex + 1;
+        q /= g.ex;
+        const uint32_t b = q % g.ez + 1, a = q / g.ez + 1;
+        UQ run = 0;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const uint32_t da = (m >> 1) & 1, db = m & 1;
+            const UQ v = (UQ)sq[at(a - da, b - db, 0, d)];
+            run = ((da + db) & 1) ? run - v : run + v;
+        }
+        for (uint32_t c = 1; c <= g.ey; c++) {
+            run += (UQ)sa[at(a, b, c, d)];
+            sa[at(a, b, c, d)] = (Q)run;
+        }
+    }
+    wave_lds_fence();
+    // along z: lines (a, c, d)
+    for (uint32_t l = lane; l < g.ew * g.ey * g.ex; l += WAVE) {
+        uint32_t q = l;
+        const uint32_t d = q % g.ex + 1;
+        q /= g.ex;
+        const uint32_t c = q % g.ey + 1, a = q / g.ey + 1;
+        UQ run = (UQ)sq[at(a, 0, c, d)] - (UQ)sq[at(a - 1, 0, c, d)];
+        for (uint32_t b = 1; b <= g.ez; b++) {
+            run += (UQ)sa[at(a, b, c, d)];
+            sa[at(a, b, c, d)] = (Q)run;
+        }
+    }
+    wave_lds_fence();
+    // along w: lines (b, c, d); the result is q~
+    for (uint32_t l = lane; l < g.ez * g.ey * g.ex; l += WAVE) {
+        uint32_t q = l;
+        const uint32_t d = q % g.ex + 1;
+        q /= g.ex;
+        const uint32_t c = q % g.ey + 1, b = q / g.ey + 1;
+        UQ run = (UQ)sq[at(0, b, c, d)];
+        for (uint32_t a = 1; a <= g.ew; a++) {
+            run += (UQ)sa[at(a, b, c, d)];
+            qout[blk4_at(p, g.ow + a - 1, g.oz + b - 1, g.oy + c - 1, g.ox + d - 1)] = (Q)run;
+        }
+    }
+}
+// lattice values -> values; a regression block's values from its codes
+template <typename T>
+__global__ __launch_bounds__(256) void k_blk4_final(const uint16_t *__restrict__ codes, void *d_out, szk_blk_params p, uint32_t nblocks,
+                                                    const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
+    using Q = typename QTraits<T>::Q;
+    const Lattice<T> lat(p.lat);
+    const int lane = lane_id();
+    Q *qv = reinterpret_cast<Q *>(d_out);
+    T *ov = reinterpret_cast<T *>(d_out);
+    const CoefLat cl = coef_lat(p.eb, p.B, 4u);
+    for (uint32_t task = blockIdx.x * 4 + threadIdx.x / WAVE; task < nblocks; task += gridDim.x * 4) {
+        const Blk4 g = blk4_of_task(p, task);
+        const uint32_t nown = g.ew * g.ez * g.ey * g.ex;
+        const bool reg = p.sel[task] == 2;
+        T rc[5] = {0, 0, 0, 0, 0};
+        if (reg) coef_recover4(coef_by_rank + (uint64_t)rank[task] * 5, cl, rc);
+        for (uint32_t t = lane; t < nown; t += WAVE) {
+            uint32_t i[4];
+            blk4_own(g, t, i);
+            const uint64_t gi = blk4_at(p, g.ow + i[0], g.oz + i[1], g.oy + i[2], g.ox + i[3]);
+            if (reg) {
+                const uint32_t code = codes[g.coff + t];
+                ov[gi] = code ? ref_recover(reg_predict4(rc, i), (int)code, p.eb, (int)p.radius) : (T)0;  // (code 0: patched from the list)
+            } else {
+                ov[gi] = lat.dequant(qv[gi]);
+            }
+        }
+    }
+}
+
 // The tuner's Lorenzo trial (SZAlgoInterp.hpp:232-247, lorenzo_compress_test: a 1-D array's sample blocks coded in blocks of FIVE values
 // by the set [Lorenzo-1, Lorenzo-2]): the choice per block by the reference's estimate at the block's two ends, the codes on the
 // lattice, their histogram for the pricing kernel. A thread per block of five (seven loads), every sample block an array of its own
@@ -3280,7 +3728,7 @@ __global__ __launch_bounds__(256) void k_trial_lorenzo12(const T *__restrict__ s
 // ------------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------------
-static uint32_t blk_count_blocks(const szk_blk_params *p) { return p->nb[0] * p->nb[1] * p->nb[2]; }
+static uint32_t blk_count_blocks(const szk_blk_params *p) { return p->nb[0] * p->nb[1] * p->nb[2] * (p->nbw ? p->nbw : 1u); }
 
 static int launch_blk_side_build(const szk_blk_params *p, const szk_blk_scratch *sc, uint32_t nblocks, hipStream_t s);
 // arrays of one and two dimensions: fit / selection / regression blocks, then the Lorenzo codes over q~
@@ -3342,8 +3790,31 @@ static int launch_blkn_compress(int dtype, const void *d_in, uint16_t *codes, co
     return launch_blk_side_build(p, sc, nblocks, s);
 }
 
+// 4-D arrays: the fit pass (choices, regression blocks, q~ of every element), then the stencil pass over q~
+static int launch_blk4_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s) {
+    const uint32_t nblocks = blk_count_blocks(p);
+    const uint64_t n = p->dw * p->d[0] * p->d[1] * p->d[2];
+#define BLK4_ENC(T, HW, NW)                                                                                                    \
+    do {                                                                                                                       \
+        const uint32_t gfit = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                \
+        const uint32_t glor = (uint32_t)std::min<uint64_t>(BLK_GRID * 8 / NW, (n + NW * 64 - 1) / (NW * 64));                    \
+        hipLaunchKernelGGL((k_blk4_fit<T, HW, NW>), dim3(gfit), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks);      \
+        hipLaunchKernelGGL((k_blk4_lorenzo<T, HW, NW * 64>), dim3(glor), dim3(NW * 64), 0, s, codes, *p, n);                    \
+    } while (0)
+    if (dtype == 0) {
+        if (sc->wide_hist) BLK4_ENC(float, BLK_HWIN_WIDE, 16);
+        else BLK4_ENC(float, BLK_HWIN, 4);
+    } else {
+        if (sc->wide_hist) BLK4_ENC(double, BLK_HWIN_WIDE, 16);
+        else BLK4_ENC(double, BLK_HWIN, 4);
+    }
+#undef BLK4_ENC
+    return launch_blk_side_build(p, sc, nblocks, s);
+}
+
 int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s) {
     const uint32_t nblocks = blk_count_blocks(p);
+    if (p->ndim == 4) return launch_blk4_compress(dtype, d_in, codes, p, sc, s);
     if (p->ndim < 3) return launch_blkn_compress(dtype, d_in, codes, p, sc, s);
     // With the selection pass's choices: the fit pass codes the regression blocks (and leaves their lattice values), the stencil
     // pass every other element straight from the array. Without (development switch): fit and selection by the fit pass, the
@@ -3392,11 +3863,21 @@ static int launch_blk_side_build(const szk_blk_params *p, const szk_blk_scratch 
     // the group sizes are staged in the rank array, which the encoder needs no more once comp is written)
     double *stats = reinterpret_cast<double *>(sc->counters + 4);
     uint32_t *group_bits = sc->rank;
-    hipLaunchKernelGGL(k_blk_coef_stats, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, stats);
-    hipLaunchKernelGGL(k_blk_coef_len, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, stats, group_bits);
+    if (p->ndim == 4) {  // five coefficients: their Rice statistics have a place of their own (sc->stats5, zeroed by the caller)
+        double *st5 = sc->stats5;
+        hipLaunchKernelGGL(k_blk_coef_stats<5>, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, st5);
+        hipLaunchKernelGGL(k_blk_coef_len<5>, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, st5, group_bits);
+        hipLaunchKernelGGL(k_blk_sel_pack, dim3(256), dim3(256), 0, s, p->sel, nblocks, sc->side);
+        hipLaunchKernelGGL(k_blk_side_layout<5>, dim3(1), dim3(1024), 0, s, nblocks, sc->counters + 0, st5, group_bits, sc->side, sc->counters + 2);
+        hipLaunchKernelGGL(k_blk_coef_write<5>, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, nblocks, sc->side);
+        SZK_CHECK_LAUNCH();
+        return 0;
+    }
+    hipLaunchKernelGGL(k_blk_coef_stats<4>, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, stats);
+    hipLaunchKernelGGL(k_blk_coef_len<4>, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, stats, group_bits);
     hipLaunchKernelGGL(k_blk_sel_pack, dim3(256), dim3(256), 0, s, p->sel, nblocks, sc->side);
-    hipLaunchKernelGGL(k_blk_side_layout, dim3(1), dim3(1024), 0, s, nblocks, sc->counters + 0, stats, group_bits, sc->side, sc->counters + 2);
-    hipLaunchKernelGGL(k_blk_coef_write, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, nblocks, sc->side);
+    hipLaunchKernelGGL(k_blk_side_layout<4>, dim3(1), dim3(1024), 0, s, nblocks, sc->counters + 0, stats, group_bits, sc->side, sc->counters + 2);
+    hipLaunchKernelGGL(k_blk_coef_write<4>, dim3(256), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, nblocks, sc->side);
     SZK_CHECK_LAUNCH();
     return 0;
 }
@@ -3438,7 +3919,7 @@ int szk_launch_blk_select(int dtype, const void *d_in, const szk_blk_params *p, 
 }
 
 // worst case: every block a regression block, every coefficient escaped (4 x 88 bits)
-size_t szk_blk_side_bound(uint64_t nblocks) { return SIDE_HDR + ((nblocks + 3) / 4 + 16) + 8 + 4 * (nblocks / RICE_GROUP + 1) + nblocks * 44 + 64; }
+size_t szk_blk_side_bound(uint64_t nblocks) { return SIDE_HDR + ((nblocks + 3) / 4 + 16) + 16 + 4 * (nblocks / RICE_GROUP + 1) + nblocks * 55 + 64; }  // (five coefficients of up to 88 bits each: 4-D)
 
 // the side section of a block stream -> choices, ranks, coefficients (0.7 ms of small, serial kernels at C4's slab: the decoder runs
 // them on a stream of their own beside the Huffman decoder, which they do not depend on)
@@ -3455,10 +3936,16 @@ int szk_launch_blk_side(const szk_blk_params *p, const szk_blk_scratch *sc, cons
     if (nr) {
         const uint64_t ngroups = (nr + RICE_GROUP - 1) / RICE_GROUP;
         int64_t *gsum = reinterpret_cast<int64_t *>(sc->comp);  // (the decoder has no other use for the compacted list's array: ngroups * 32 <= nblocks * 4 bytes)
-        hipLaunchKernelGGL(k_blk_coef_parse, dim3((uint32_t)((ngroups + 255) / 256 < 1024 ? (ngroups + 255) / 256 : 1024)), dim3(256), 0, s, side, nblocks, nr,
-                           bit_words, coef_by_rank, gsum);
-        hipLaunchKernelGGL(k_blk_coef_gscan, dim3(1), dim3(1024), 0, s, ngroups, gsum);
-        hipLaunchKernelGGL(k_blk_coef_apply, dim3((uint32_t)std::min<uint64_t>(2048, (ngroups + 3) / 4)), dim3(256), 0, s, nr, gsum, coef_by_rank);
+        const dim3 gp((uint32_t)((ngroups + 255) / 256 < 1024 ? (ngroups + 255) / 256 : 1024)), ga((uint32_t)std::min<uint64_t>(2048, (ngroups + 3) / 4));
+        if (p->ndim == 4) {
+            hipLaunchKernelGGL(k_blk_coef_parse<5>, gp, dim3(256), 0, s, side, nblocks, nr, bit_words, coef_by_rank, gsum);
+            hipLaunchKernelGGL(k_blk_coef_gscan<5>, dim3(1), dim3(1024), 0, s, ngroups, gsum);
+            hipLaunchKernelGGL(k_blk_coef_apply<5>, ga, dim3(256), 0, s, nr, gsum, coef_by_rank);
+        } else {
+            hipLaunchKernelGGL(k_blk_coef_parse<4>, gp, dim3(256), 0, s, side, nblocks, nr, bit_words, coef_by_rank, gsum);
+            hipLaunchKernelGGL(k_blk_coef_gscan<4>, dim3(1), dim3(1024), 0, s, ngroups, gsum);
+            hipLaunchKernelGGL(k_blk_coef_apply<4>, ga, dim3(256), 0, s, nr, gsum, coef_by_rank);
+        }
     }
     SZK_CHECK_LAUNCH();
     return 0;
@@ -3472,6 +3959,22 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
     } else if (szk_launch_expand_deltas(dtype, codes, h->n, (int)h->radius, payload, o, h->n_dout, p->qwork, s)) return -1;
     // (the side section's kernels ran on another stream: the fronts are the first to need what they made)
     if (side_done && hipStreamWaitEvent(s, side_done, 0) != hipSuccess) return -1;
+    if (p->ndim == 4) {  // fronts of blocks, bw + bz + by + bx = const
+        const uint32_t g4 = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
+        const uint32_t ndiag = p->nbw + p->nb[0] + p->nb[1] + p->nb[2] - 3, gfront = p->nbw * p->nb[0] * p->nb[1];
+#define BLK4_DEC(T)                                                                                                                   \
+    do {                                                                                                                              \
+        hipLaunchKernelGGL(k_blk4_pre<T>, dim3(g4), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);               \
+        for (uint32_t d = 0; d < ndiag; d++) hipLaunchKernelGGL(k_blk4_decode<T>, dim3(gfront), dim3(64), 0, s, p->qwork, d_out, *p, d); \
+        hipLaunchKernelGGL(k_blk4_final<T>, dim3(g4), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);             \
+        if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<T>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (T *)d_out); \
+    } while (0)
+        if (dtype == 0) BLK4_DEC(float);
+        else BLK4_DEC(double);
+#undef BLK4_DEC
+        SZK_CHECK_LAUNCH();
+        return 0;
+    }
     if (p->ndim == 1 && (p->mask & 2u)) {  // second-order Lorenzo in the set: the scan of affine maps (k_blkn2_*)
         const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
         const uint32_t ntiles = (nblocks + BLKN_TILE - 1) / BLKN_TILE;

@@ -219,24 +219,26 @@ def parse_side(h, sec):
     side = sec["side"].tobytes()
     coding, sel_bits, nblocks, nreg = struct.unpack_from("<IIQQ", side, 0)
     B = h["blk_edge"]
-    nb = [(d + B - 1) // B for d in h["dims"][1:]]
-    assert coding == 1 and sel_bits == 2 and nblocks == nb[0] * nb[1] * nb[2]
+    four = h["ndim"] == 4  # (round 4: 4-D arrays — the slowest extent in dims[0], five coefficients per regression block)
+    nc, pb = (5, 16) if four else (4, 8)
+    nb = [(d + B - 1) // B for d in (h["dims"] if four else h["dims"][1:])]
+    assert coding == 1 and sel_bits == 2 and nblocks == int(np.prod(nb))
     sel_bytes = ((nblocks + 3) // 4 + 7) & ~7
     packed = np.frombuffer(side, dtype=np.uint8, count=sel_bytes, offset=24)
     sel = ((packed[:, None] >> (2 * np.arange(4))) & 3).reshape(-1)[:nblocks].astype(np.uint8)
-    # Rice-coded differences: [u8 k[4]][u32 groups][u32 bit offset per group of 64 blocks][u32 words, MSB first]
+    # Rice-coded differences: [u8 k[nc], padding][u32 groups] (8 bytes, 16 for 4-D arrays) [u32 bit offset per group of 64 blocks][u32 words, MSB first]
     p0 = 24 + sel_bytes
-    ks = list(side[p0:p0 + 4])
-    ngroups, = struct.unpack_from("<I", side, p0 + 4)
+    ks = list(side[p0:p0 + nc])
+    ngroups, = struct.unpack_from("<I", side, p0 + pb - 4)
     assert ngroups == (nreg + 63) // 64
-    goff = np.frombuffer(side, dtype=np.uint32, count=ngroups, offset=p0 + 8)
-    words = np.frombuffer(side, dtype=np.uint32, offset=p0 + 8 + 4 * ngroups)
+    goff = np.frombuffer(side, dtype=np.uint32, count=ngroups, offset=p0 + pb)
+    words = np.frombuffer(side, dtype=np.uint32, offset=p0 + pb + 4 * ngroups)
     bits = np.unpackbits(words.astype(">u4").view(np.uint8))
-    deltas = np.zeros((nreg, 4), dtype=np.int64)
+    deltas = np.zeros((nreg, nc), dtype=np.int64)
     for g in range(ngroups):
         pos = int(goff[g])
         for r in range(g * 64, min(nreg, (g + 1) * 64)):
-            for i in range(4):
+            for i in range(nc):
                 q = 0
                 while q < 24 and bits[pos]:
                     q += 1
@@ -259,9 +261,65 @@ def parse_side(h, sec):
     return sel.reshape(nb), coef
 
 
+def reconstruct_blocks4(h, sec, codes):
+    """the same for a 4-D array: blocks of B^4, first-order Lorenzo (fifteen neighbours) or regression with five coefficients"""
+    import itertools
+    T = np.float32 if h["dtype"] == 0 else np.float64
+    dims = list(h["dims"])
+    B, eb, radius = h["blk_edge"], h["eb"], h["radius"]
+    sel, coef = parse_side(h, sec)
+    dflat = np.where(codes == 0, 0, codes.astype(np.int64) - radius).astype(np.int64)
+    dflat[sec["dout_idx"].astype(np.int64)] = sec["dout_val"]
+    q = np.zeros([d + 1 for d in dims], dtype=np.int64)  # a zero halo layer on the low side
+    out = np.zeros(dims, dtype=T)
+    recip = T(1.0 / (2.0 * eb)) if T == np.float32 else 1.0 / (2.0 * eb)
+    lim = T(8388608.0) if T == np.float32 else 4503599627370496.0
+    step_ind, step_lin = 2.0 * (eb / 5), 2.0 * (eb / 5 / B)
+    signs = [(o, -1 if sum(o) % 2 else 1) for o in itertools.product((0, 1), repeat=4) if any(o)]
+    pos, r = 0, 0
+    for bw, bz, by, bx in itertools.product(*[range(n) for n in sel.shape]):
+        o = [bw * B, bz * B, by * B, bx * B]
+        e = [min(B, dims[i] - o[i]) for i in range(4)]
+        m = int(np.prod(e))
+        sl = tuple(slice(o[i], o[i] + e[i]) for i in range(4))
+        if int(sel[bw, bz, by, bx]) == 2:
+            lc = coef[r]
+            r += 1
+            rc = [T(float(lc[i]) * step_lin) for i in range(4)] + [T(float(lc[4]) * step_ind)]
+            idx = np.meshgrid(*[np.arange(n) for n in e], indexing="ij")
+            pred = (rc[0] * idx[0].astype(T)).astype(T)
+            for i in (1, 2, 3):
+                pred = (pred + (rc[i] * idx[i].astype(T)).astype(T)).astype(T)
+            pred = (pred + rc[4]).astype(T)
+            cc = codes[pos:pos + m].reshape(e).astype(np.int64)
+            val = (pred.astype(np.float64) + (2 * (cc - radius)).astype(np.float64) * eb).astype(T)
+            with np.errstate(invalid="ignore", over="ignore"):
+                sc = val * recip
+                ok = np.abs(sc) < lim
+                rr = np.rint(np.where(ok, sc, 0)).astype(T)
+                bad = ~ok | ~(np.abs(rr * T(2.0 * eb) - val) <= (T(eb) if float(T(eb)) <= eb else np.nextafter(T(eb), T(0))))
+            q[tuple(slice(o[i] + 1, o[i] + 1 + e[i]) for i in range(4))] = np.where((cc == 0) | bad, 0, rr.astype(np.int64))
+            out[sl] = np.where(cc == 0, 0, val)
+        else:
+            d = dflat[pos:pos + m].reshape(e)
+            for i0, i1, i2, i3 in itertools.product(*[range(n) for n in e]):
+                c = (o[0] + i0 + 1, o[1] + i1 + 1, o[2] + i2 + 1, o[3] + i3 + 1)
+                acc = int(d[i0, i1, i2, i3])
+                for off, sg in signs:  # delta = sum over the 16 corners of (-1)^|off| q: the fifteen others go to the other side
+                    acc -= sg * int(q[c[0] - off[0], c[1] - off[1], c[2] - off[2], c[3] - off[3]])
+                q[c] = acc
+            out[sl] = q[tuple(slice(o[i] + 1, o[i] + 1 + e[i]) for i in range(4))].astype(T) * T(2.0 * eb)
+        pos += m
+    x = out.reshape(-1)
+    x[sec["vout_idx"].astype(np.int64)] = sec["vout_val"]
+    return x, sel
+
+
 def reconstruct_blocks(h, sec, codes):
     """numpy model of the block decoder: blocks in raster order (any order that respects the low-side dependencies works),
     Lorenzo blocks invert their integer stencil element by element, regression blocks are pred + 2*(code - radius)*eb"""
+    if h["ndim"] == 4:
+        return reconstruct_blocks4(h, sec, codes)
     T = np.float32 if h["dtype"] == 0 else np.float64
     Q = np.int32 if h["dtype"] == 0 else np.int64
     dz, dy, dx = h["dims"][1:]

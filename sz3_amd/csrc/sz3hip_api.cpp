@@ -349,7 +349,7 @@ static size_t payload_bound_blocks(uint64_t n, uint64_t out_cap, uint64_t side_b
 // checks the caller's capacity against the blocks the call really has, and sz3hip_payload_bound_conf sizes a buffer for them.
 static size_t payload_bound_n(uint64_t n, uint64_t out_cap) { return payload_bound_blocks(n, out_cap, n / 27 + 64); }
 // shapes the block-composed predictor is built for: 3-D with block edges 4..8 (tiles in LDS), 1-D with blocks of 4..65535 values,
-// 2-D with block edges 4..32 (the decoder's block in LDS); second-order Lorenzo in 1-D and 3-D (decided where the set is known)
+// 2-D with block edges 4..32 (the decoder's block in LDS); second-order Lorenzo in 1-D, 2-D and 3-D (decided where the set is known)
 static bool blk_shape_ok(const sz3hip_config *conf) {
     if (conf->N == 3) return conf->blockSize >= 4 && conf->blockSize <= 8;
     if (conf->N == 2) return conf->blockSize >= 4 && conf->blockSize <= 32 && conf->dims[0] < 0xFFFFFFFFull && conf->dims[1] < 0xFFFFFFFFull;
@@ -1238,7 +1238,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
         const uint32_t mask = (conf->lorenzo ? 1u : 0u) | (conf->lorenzo2 ? 2u : 0u) | (conf->regression ? 4u : 0u);
         if (mask == 0) return fail(SZ3HIP_EINVAL, "All lorenzo and regression methods are disabled.");
         if (mask != 1u) {
-            if (blk_shape_ok(conf) && (conf->N == 3 || conf->N == 1 || !(mask & 2u)) && !(szk_dbg_flags & 16384)) {
+            if (blk_shape_ok(conf) && (conf->N != 4 || !(mask & 2u)) && !(szk_dbg_flags & 16384)) {  // (the reference has no second-order Lorenzo for N = 4: LorenzoPredictor.hpp:92)
                 bool all_lorenzo = false;
                 const int rcs = blk_all_lorenzo(ctx, conf, d_in, eb, radius, mask, s, &all_lorenzo);
                 if (rcs) return rcs;
@@ -1247,7 +1247,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
             }
             if (!(mask & 1u))
                 return fail(SZ3HIP_EUNSUPPORTED, "regression is built for 1-D (blockSize 4..65535), 2-D (4..32), 3-D (4..8) and 4-D arrays (4..6), 2nd-order "
-                                                 "Lorenzo for 1-D and 3-D ones (got N = %d, blockSize = %d)", conf->N, conf->blockSize);
+                                                 "Lorenzo for 1-D, 2-D and 3-D ones (got N = %d, blockSize = %d)", conf->N, conf->blockSize);
         }
     }
     return stage1_lorenzo(ctx, conf, d_in, eb, radius, num, s);
@@ -1803,7 +1803,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         const uint32_t B = h.interp_id, mask = h.interp_dir;
         const bool fits32 = h.dims[1] < 0xFFFFFFFFull && h.dims[2] < 0xFFFFFFFFull && h.dims[3] < 0xFFFFFFFFull;  // (block positions are 32-bit)
         const bool shape_ok = fits32 && (h.ndim == 4 ? B >= 4 && B <= 6 && h.dims[0] < 0xFFFFFFFFull && !(mask & 2u)
-                                                     : h.dims[0] == 1 && (h.ndim == 3 ? B >= 4 && B <= 8 : (h.ndim == 2 ? B >= 4 && B <= 32 && h.dims[1] == 1 && !(mask & 2u)
+                                                     : h.dims[0] == 1 && (h.ndim == 3 ? B >= 4 && B <= 8 : (h.ndim == 2 ? B >= 4 && B <= 32 && h.dims[1] == 1
                                                                  : h.ndim == 1 && B >= 4 && B <= 65535 && h.dims[1] == 1 && h.dims[2] == 1)));
         if (!shape_ok || mask == 0 || mask > 7 || h.side_bytes < 24 || h.n_dout > h.n)
             return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (block predictor fields)");

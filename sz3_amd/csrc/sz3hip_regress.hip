@@ -1774,20 +1774,45 @@ __global__ __launch_bounds__(NW * 64) void k_blkn_fit(const T *__restrict__ in, 
         }
         // ---- selection (ComposedPredictor.hpp:25-40 over foreach_sampling) ----
         sid = has_l1 ? 0 : 2;
-        if (!two && (p.mask & 2u)) {
-            // 1-D with second-order Lorenzo in the set (round 4): the members in the set's order [Lorenzo-1, Lorenzo-2, regression]
-            // (SZAlgoLorenzoReg.hpp:28-64), the estimates at the block's two ends, the first minimum wins (std::min_element).
-            // LorenzoPredictor.hpp:69-71: 2 d[-1] - d[-2]; noise 1.08 eb (:17-38)
-            const T noise2 = (T)(1.08 * p.eb);
+        if (p.mask & 2u) {
+            // second-order Lorenzo in the set (round 4: 1-D and 2-D arrays): the members in the set's order [Lorenzo-1, Lorenzo-2,
+            // regression] (SZAlgoLorenzoReg.hpp:28-64), the estimates at the block's sample points (its two ends; its two diagonals),
+            // the first minimum wins (std::min_element). LorenzoPredictor.hpp:69-71 / 75-79: 2 d[-1] - d[-2] and the eight-term
+            // stencil in the reference's order of terms (prev2(d, ds, j, i): j rows up, i columns left); noise 1.08 / 2.76 eb (:17-38)
+            const T noise2 = (T)((two ? 2.76 : 1.08) * p.eb);
+            const uint32_t m = two ? min(g.ey, g.ex) : g.ex;
+            const uint32_t npts = two ? 2 * m : 2;
             double e1 = 0, e2 = 0, er = 0;
-            if (lane < 2) {
-                const uint32_t i2 = lane ? g.ex - 1 : 0u;
-                const int64_t x = (int64_t)g.ox + i2;
-                const T v = in[x];
-                const T s1 = blkn_seen(in, p, lat, g, 0, x - 1), s2 = blkn_seen(in, p, lat, g, 0, x - 2);
-                e1 = (double)(T)((T)fabs((double)(T)(v - s1)) + noise);
-                e2 = (double)(T)((T)fabs((double)(T)(v - (T)((T)(2 * s1) - s2))) + noise2);
-                if (r_valid) er = (double)(T)fabs((double)(T)(v - reg_predict(cf, 0u, 0u, i2)));
+            for (uint32_t k = lane; k < npts; k += WAVE) {
+                uint32_t i1 = 0, i2;
+                if (two) {
+                    i1 = k / 2;
+                    i2 = (k & 1) ? m - 1 - i1 : i1;
+                } else {
+                    i2 = k ? m - 1 : 0;
+                }
+                const int64_t y = (int64_t)g.oy + i1, x = (int64_t)g.ox + i2;
+                const T v = in[(uint64_t)y * d2 + (uint64_t)x];
+                auto P = [&](int j, int i) -> T { return blkn_seen(in, p, lat, g, y - j, x - i); };
+                T pr1, pr2;
+                if (two) {
+                    pr1 = (T)((T)(P(0, 1) + P(1, 0)) - P(1, 1));
+                    T s2 = (T)(2 * P(0, 1));
+                    s2 = (T)(s2 - P(0, 2));
+                    s2 = (T)(s2 + (T)(2 * P(1, 0)));
+                    s2 = (T)(s2 - (T)(4 * P(1, 1)));
+                    s2 = (T)(s2 + (T)(2 * P(1, 2)));
+                    s2 = (T)(s2 - P(2, 0));
+                    s2 = (T)(s2 + (T)(2 * P(2, 1)));
+                    s2 = (T)(s2 - P(2, 2));
+                    pr2 = s2;
+                } else {
+                    pr1 = P(0, 1);
+                    pr2 = (T)((T)(2 * P(0, 1)) - P(0, 2));
+                }
+                e1 += (double)(T)((T)fabs((double)(T)(v - pr1)) + noise);
+                e2 += (double)(T)((T)fabs((double)(T)(v - pr2)) + noise2);
+                if (r_valid) er += (double)(T)fabs((double)(T)(v - reg_predict(cf, 0u, i1, i2)));
             }
             e1 = wave_sum_f64(e1);
             e2 = wave_sum_f64(e2);
@@ -2141,10 +2166,38 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo(const T *__restrict__ in, u
         const uint8_t own_sel = p.sel[e.task];
         act = act && own_sel != 2;
         const bool second = !TWO && own_sel == 1;  // 1-D, second-order Lorenzo: q - 2 q[-1] + q[-2] (LorenzoPredictor.hpp:69-71 on the lattice)
+        const bool second2 = TWO && own_sel == 1;  // 2-D: the nine-term stencil (1, -2, 1) x (1, -2, 1) (LorenzoPredictor.hpp:75-79)
         UQ delta = 0;
         bool own_bad = false;
         T own_raw = 0;
         const uint64_t gi = (uint64_t)e.y * d2 + e.x;
+        if (act && second2) {
+            // (the general form only: q~ of every element through the work array, or — with the selection pass's choices — q~ of an
+            // element outside a regression block from the array itself; nine taps, zeros outside the array)
+            auto q9 = [&](uint32_t yy, uint32_t xx, bool own) -> UQ {
+                const uint64_t at = (uint64_t)yy * d2 + xx;
+                if (!direct) return (UQ)qw[at];
+                const uint32_t tk = (yy / p.B) * p.nb[2] + xx / p.B;
+                if (!own && p.sel[tk] == 2) return (UQ)qw[at];
+                const T v = in[at];
+                bool bad;
+                const Q q = lat.quant(v, bad);
+                if (own) {
+                    own_bad = bad;
+                    own_raw = v;
+                }
+                return bad ? (UQ)0 : (UQ)q;
+            };
+            const int w3[3] = {1, -2, 1};
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    if (e.y < (uint32_t)j || e.x < (uint32_t)i) continue;
+                    const UQ q = q9(e.y - j, e.x - i, (j | i) == 0);
+                    delta += (UQ)(Q)(w3[j] * w3[i]) * q;
+                }
+        } else
         if (act && !direct) {
             delta = (UQ)qw[gi];
             if (e.x) delta -= (UQ)qw[gi - 1];
@@ -3081,6 +3134,72 @@ __global__ __launch_bounds__(256) void k_blkn_decode2(const void *deltas_, void 
     }
 }
 
+// 2-D with second-order Lorenzo in the set (round 4): the plain form — a wave per Lorenzo block of one front, the block's deltas and TWO
+// halo rows / columns of finished q~ in LDS; the pass along x takes the inflow Dy^m q~ of the two halo columns and runs the block's
+// recurrence (order m = 1 or 2 by the block's choice) along its rows, the pass along y the same along its columns from the halo
+// rows. In place: the x pass writes own entries only, and everything it reads of the rows above lies in the halo columns.
+template <typename T>
+__global__ __launch_bounds__(256) void k_blkn_decode2s(const void *deltas_, void *d_out, szk_blk_params p, uint32_t diag, uint32_t by_lo, uint32_t nfront) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    constexpr uint32_t TE = BLKN_MAXB2 + 2, PITCH = TE + 1;
+    __shared__ Q s_q[4][TE * PITCH];
+    const int lane = lane_id();
+    const uint32_t wv = threadIdx.x / WAVE;
+    Q *sq = s_q[wv];
+    const uint32_t k = blockIdx.x * 4 + wv;
+    if (k >= nfront) return;
+    const uint32_t by = by_lo + k, bx = diag - by;
+    const uint32_t task = by * p.nb[2] + bx;
+    const uint32_t sel = p.sel[task];
+    if (sel == 2) return;
+    const BlkGeom g = blk_geom(p, task);
+    const uint64_t d2 = p.d[2];
+    Q *qout = reinterpret_cast<Q *>(d_out);
+    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    const uint32_t th = g.ey + 2, tw = g.ex + 2;
+    for (uint32_t l = lane; l < th * tw; l += WAVE) {
+        const uint32_t j = l / tw, i = l - j * tw;
+        Q v = 0;
+        if (j >= 2 && i >= 2) {
+            v = deltas[g.coff + (j - 2) * g.ex + (i - 2)];
+        } else {
+            const int64_t y = (int64_t)g.oy + j - 2, x = (int64_t)g.ox + i - 2;
+            if (y >= 0 && x >= 0) v = qout[(uint64_t)y * d2 + (uint64_t)x];
+        }
+        sq[j * PITCH + i] = v;
+    }
+    wave_lds_fence();
+    const int m = sel == 1 ? 2 : 1;
+    for (uint32_t j = 2 + lane; j < th; j += WAVE) {  // along x
+        UQ a[2];
+#pragma unroll
+        for (uint32_t c = 0; c < 2; c++) {
+            UQ sx = 0;
+            for (int kk = 0; kk <= m; kk++) sx += (UQ)((Q)lz_w(m, kk) * sq[(j - kk) * PITCH + c]);
+            a[c] = sx;
+        }
+        UQ p2 = a[0], p1 = a[1];
+        for (uint32_t i = 2; i < tw; i++) {
+            const UQ in = (UQ)sq[j * PITCH + i];
+            const UQ v = m == 1 ? p1 + in : (UQ)(2 * p1 - p2 + in);
+            sq[j * PITCH + i] = (Q)v;
+            p2 = p1;
+            p1 = v;
+        }
+    }
+    wave_lds_fence();
+    for (uint32_t i = 2 + lane; i < tw; i += WAVE) {  // along y: the result is q~
+        UQ p2 = (UQ)sq[i], p1 = (UQ)sq[PITCH + i];
+        for (uint32_t j = 2; j < th; j++) {
+            const UQ in = (UQ)sq[j * PITCH + i];
+            const UQ v = m == 1 ? p1 + in : (UQ)(2 * p1 - p2 + in);
+            qout[(uint64_t)(g.oy + j - 2) * d2 + (g.ox + i - 2)] = (Q)v;
+            p2 = p1;
+            p1 = v;
+        }
+    }
+}
 // 2-D, block edges up to 16: GROUPS of 4 x 4 blocks per workgroup, like the 3-D decoder's groups — the chain of fronts is what a
 // block stream's decoding costs (a launch + a block's latency each), and a group quarters it: 255 launches instead of 1023 at
 // 8192^2. The group's tile (its deltas, the q~ of its regression blocks, one halo row and column of finished q~) sits in LDS;
@@ -4020,6 +4139,14 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
                 hipLaunchKernelGGL(k_blkn_scan_top<int64_t>, dim3(1), dim3(1024), 0, s, ntiles, (int64_t *)p->carry + 2 * (uint64_t)nblocks);
                 if (rows) hipLaunchKernelGGL(k_blkn_apply1_rows<double>, dim3(grow), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks);
                 else hipLaunchKernelGGL(k_blkn_apply1<double>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks);
+            }
+        } else if (p->mask & 2u) {  // second-order Lorenzo in the set: the plain form with two halo layers
+            const uint32_t ndiag = p->nb[1] + p->nb[2] - 1;
+            for (uint32_t d = 0; d < ndiag; d++) {
+                const uint32_t by_lo = d >= p->nb[2] ? d - (p->nb[2] - 1) : 0, by_hi = d < p->nb[1] - 1 ? d : p->nb[1] - 1;
+                const uint32_t nfront = by_hi - by_lo + 1;
+                if (dtype == 0) hipLaunchKernelGGL(k_blkn_decode2s<float>, dim3((nfront + 3) / 4), dim3(256), 0, s, p->qwork, d_out, *p, d, by_lo, nfront);
+                else hipLaunchKernelGGL(k_blkn_decode2s<double>, dim3((nfront + 3) / 4), dim3(256), 0, s, p->qwork, d_out, *p, d, by_lo, nfront);
             }
         } else if (p->B <= 16 && !(szk_dbg_flags & 8388608)) {  // groups of 4 x 4 blocks per workgroup (debug flag 8388608: a block per wave)
             const uint32_t ng1 = (p->nb[1] + BLKN_G - 1) / BLKN_G, ng2 = (p->nb[2] + BLKN_G - 1) / BLKN_G;

@@ -184,7 +184,12 @@ def test_predictor_sets_outside_the_block_path():
     c = sz3_amd.Config(*a4.shape)
     c.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
     c.absErrorBound = 1e-2
-    c.blockSize = 8  # 4-D blocks beyond 6: not built -> the Lorenzo-1 member, recorded in the trailer
+    c.lorenzo2 = 1  # no second-order Lorenzo for N = 4 (as in the reference) -> the Lorenzo-1 member, recorded in the trailer
+    blob, _ = sz3_amd.compress(a4, c)
+    dec, c2 = sz3_amd.decompress(blob, np.float32, a4.shape)
+    assert (c2.lorenzo, c2.lorenzo2, c2.regression) == (1, 0, 0) and float(np.max(np.abs(dec - a4))) <= 1e-2
+    c.lorenzo2 = 0
+    c.blockSize = 8  # 4-D blocks beyond 6: not built -> the Lorenzo-1 member
     blob, _ = sz3_amd.compress(a4, c)
     dec, c2 = sz3_amd.decompress(blob, np.float32, a4.shape)
     assert (c2.lorenzo, c2.lorenzo2, c2.regression) == (1, 0, 0) and float(np.max(np.abs(dec - a4))) <= 1e-2
@@ -198,12 +203,8 @@ def test_predictor_sets_outside_the_block_path():
     c = sz3_amd.Config(64, 64)
     c.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
     c.absErrorBound = 1e-2
-    c.lorenzo2 = 1  # Lorenzo-1 + Lorenzo-2 + regression in 2-D: second-order Lorenzo is built for 1-D and 3-D here -> Lorenzo-1
-    blob, _ = sz3_amd.compress(a2, c)
-    dec, c2 = sz3_amd.decompress(blob, np.float32, a2.shape)
-    assert (c2.lorenzo, c2.lorenzo2, c2.regression) == (1, 0, 0) and float(np.max(np.abs(dec - a2))) <= 1e-2
-    c.lorenzo2 = 0
-    c.blockSize = 40  # 2-D blocks beyond 32: not built
+    c.lorenzo2 = 1
+    c.blockSize = 40  # 2-D blocks beyond 32: not built -> the Lorenzo-1 member
     blob, _ = sz3_amd.compress(a2, c)
     dec, c2 = sz3_amd.decompress(blob, np.float32, a2.shape)
     assert (c2.lorenzo, c2.lorenzo2, c2.regression) == (1, 0, 0)

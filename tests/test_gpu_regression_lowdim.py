@@ -312,3 +312,57 @@ def test_1d_second_order_tiny_arrays(n):
         blob, _ = sz3_amd.compress(a, _conf((n,), 1e-3, *MASKS[mask]))
         dec, c2 = sz3_amd.decompress(blob, np.float32, (n,))
         assert dec.shape == a.shape and float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= 1e-3
+
+
+# ---- second-order Lorenzo in 2-D (round 4: k_blkn_decode2s; LorenzoPredictor.hpp:75-79, noise 2.76 eb) -------------------------------
+@pytest.mark.parametrize("mask", L2_MASKS)
+@pytest.mark.parametrize("dtype,shape,eb,block", [(np.float32, (70, 90), 1e-2, None), (np.float64, (33, 47), 2e-2, 8), (np.float32, (64, 96), 5e-2, 32),
+                                                 (np.float32, (5, 200), 1e-3, 4), (np.float32, (130, 131), 1e-4, 16)])
+def test_2d_second_order_block_stream_against_the_numpy_model(mask, dtype, shape, eb, block):
+    a = field2d(shape, dtype)
+    conf = _conf(shape, eb, *MASKS[mask], block=block)
+    blob, ratio = sz3_amd.compress(a, conf)
+    dec, c2 = sz3_amd.decompress(blob, dtype, shape)
+    assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= eb
+    if c2.cmprAlgo == sz3_amd.ALGO_LOSSLESS:
+        pytest.skip("tiny field went lossless")
+    h, o, sec = szh_ref.parse(_payload_of(blob))
+    assert h["predictor"] == 2 and h["ndim"] == 2 and h["blk_edge"] == (block or 16)
+    assert h["blk_mask"] == sum(b << i for i, b in enumerate(MASKS[mask]))
+    assert (c2.lorenzo, c2.lorenzo2, c2.regression) == MASKS[mask]
+    codes = szh_ref.huffman_decode(h, sec)
+    model, sel = szh_ref.reconstruct_blocks(h, sec, codes)
+    assert np.array_equal(model.reshape(shape), dec), "numpy model of the block decoder and the GPU decoder disagree"
+    sel = np.asarray(sel).reshape(-1)
+    print(shape, mask, "ratio %.2f" % ratio, "shares L1 %.3f L2 %.3f R %.3f" % tuple(float((sel == k).mean()) for k in range(3)))
+    # the encoder without the selection pass in front (the fit pass chooses, q~ of every element through the work array): same stream
+    try:
+        sz3_amd.lib().sz3hip_debug_flags(NO_EXIT | 2147483648)
+        blob2, _ = sz3_amd.compress(a, conf)
+    finally:
+        sz3_amd.lib().sz3hip_debug_flags(NO_EXIT)
+    assert _payload_of(blob2) == _payload_of(blob)
+
+
+@pytest.mark.parametrize("shape,eb,mask", [((1024, 1024), 1e-3, "L1+L2"), ((768, 1000), 1e-4, "L1+L2"), ((512, 640), 0.15, "L1+L2+R"), ((600, 700), 1e-2, "L2")])
+def test_2d_second_order_ratio_and_selection_against_the_oracle(shape, eb, mask):
+    a = field2d(shape, np.float32)
+    l1, l2, r = MASKS[mask]
+    oconf = make_config(a.shape, abs_eb=eb, lorenzo=bool(l1), lorenzo2=bool(l2), regression=bool(r))
+    o_ratio = a.nbytes / len(oracle_compress(a, oconf))
+    osel = oracle_selection(a, oconf)
+    blob, ratio = sz3_amd.compress(a, _conf(shape, eb, l1, l2, r))
+    dec, c2 = sz3_amd.decompress(blob, np.float32, shape)
+    assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= eb
+    h, o, sec = szh_ref.parse(_payload_of(blob))
+    if h["predictor"] != 2:  # (next to every block chose Lorenzo-1: the plain stream)
+        print("2-D %s @%g %s: plain stream, ratio %.2f (oracle %.2f), oracle's second-order share %.4f" % (shape, eb, mask, ratio, o_ratio, float((osel == 1).mean())))
+        assert ratio >= 0.95 * o_ratio and float((osel != 0).mean()) < 0.01
+        return
+    assert (c2.lorenzo, c2.lorenzo2, c2.regression) == (l1, l2, r)
+    sel = np.asarray(szh_ref.parse_side(h, sec)[0]).reshape(-1)
+    same = float((osel == sel).mean())
+    print("2-D %s @%g %s: ratio %.2f (oracle %.2f); second-order blocks %.3f (oracle %.3f); selection identical in %.2f %% of the blocks"
+          % (shape, eb, mask, ratio, o_ratio, float((sel == 1).mean()), float((osel == 1).mean()), 100 * same))
+    assert ratio >= 0.95 * o_ratio
+    assert same >= 0.9

@@ -778,6 +778,200 @@ int stock_decompress_interp(HostSlot *s, const sz3hip_config *conf, int dataType
     return 0;
 }
 
+// A stock ALGO_LORENZO_REG stream (round 4, read side; SZDispatcher.hpp:85-88 -> SZ_decompress_LorenzoReg, api/impl/SZAlgoLorenzoReg.hpp:76-84):
+// the container and the two small side vectors are parsed here (sz3hip_stock_host.cpp), the regression coefficients recovered — a chain
+// over the regression blocks in T arithmetic (RegressionPredictor.hpp:157-164) —, the main code stream decoded and the values made on
+// the device in the reference's own arithmetic (sz3hip_stock.hip k_slr_*). 1-D .. 3-D arrays of float / double.
+template <typename T>
+static bool slr_coefficients(const sz3hip_config *conf, const stock::LorenzoReg &lr, const int *kinds, int n_kinds, bool composed, uint64_t nblocks, const uint64_t *nb,
+                             std::vector<uint8_t> &kind, std::vector<T> &coef) {
+    const int N = conf->N;
+    const uint32_t B = (uint32_t)conf->blockSize;
+    kind.assign((size_t)nblocks, 0);
+    coef.assign((size_t)nblocks * 4, (T)0);
+    if (composed && lr.selection.size() != nblocks) return false;
+    T cur[4] = {0, 0, 0, 0};
+    size_t ci = 0;
+    uint64_t ui[2] = {0, 0};  // next unpredictable coefficient of the two quantizers (q_lin, q_indep)
+    const T *un_lin = reinterpret_cast<const T *>(lr.q_lin.unpred), *un_ind = reinterpret_cast<const T *>(lr.q_indep.unpred);
+    auto recover = [&](const stock::Quant &q, const T *un, uint64_t &u, T pred, uint32_t code, bool &ok) -> T {
+        if (code) return (T)((double)pred + (double)(2 * ((int)code - q.radius)) * q.eb);
+        if (u >= q.n_unpred) {
+            ok = false;
+            return (T)0;
+        }
+        T v;
+        memcpy(&v, reinterpret_cast<const uint8_t *>(un) + u * sizeof(T), sizeof(T));
+        u++;
+        return v;
+    };
+    uint64_t bi[3] = {0, 0, 0};
+    for (uint64_t b = 0; b < nblocks; b++) {
+        int k;
+        if (composed) {
+            const uint32_t sidx = lr.selection[(size_t)b];
+            if ((int)sidx >= n_kinds) return false;
+            k = kinds[sidx];
+        } else {
+            k = kinds[0];
+        }
+        if (k == 2) {
+            bool valid = true;  // RegressionPredictor::predecompress (:62-71): a block with an extent of one has no regression
+            for (int i = 0; i < N; i++) {
+                const uint64_t o = bi[3 - N + i] * B, e = std::min<uint64_t>(B, conf->dims[i] - o);
+                if (e <= 1) valid = false;
+            }
+            if (!valid) {
+                k = 0;  // the fallback predictor (BlockwiseDecomposition.hpp:52-54)
+                // (a regression-only set runs without padding — Predictor.hpp's default — and the fallback's neighbours left of / above
+                // the array are then whatever lies in front of the element in MEMORY: the previous row's end, or nothing the array
+                // owns. Not reproduced for arrays of two and three dimensions: refused.)
+                if (!composed && N > 1) return false;
+            } else {
+                if (ci + (size_t)N + 1 > lr.coef_codes.size()) return false;
+                bool ok = true;
+                for (int i = 0; i < N; i++) cur[i] = recover(lr.q_lin, un_lin, ui[0], cur[i], lr.coef_codes[ci++], ok);
+                cur[N] = recover(lr.q_indep, un_ind, ui[1], cur[N], lr.coef_codes[ci++], ok);
+                if (!ok) return false;
+                for (int i = 0; i <= N; i++) coef[(size_t)b * 4 + i] = cur[i];
+            }
+        }
+        kind[(size_t)b] = (uint8_t)k;
+        for (int d = 2; d >= 0; d--) {  // raster order over the (z, y, x) view
+            if (++bi[d] < nb[d]) break;
+            bi[d] = 0;
+        }
+    }
+    return true;
+}
+int stock_decompress_lorenzo_reg(HostSlot *s, const sz3hip_config *conf, int dataType, const unsigned char *p, size_t payload, void *decData) {
+    const int cdt = dtype_compute(dataType);
+    const size_t tsize = cdt == SZ3HIP_FLOAT ? 4 : 8;
+    const int N = conf->N;
+    if (N < 1 || N > 3)
+        return fail(SZ3HIP_EUNSUPPORTED, "stock ALGO_LORENZO_REG streams are read for 1-D, 2-D and 3-D arrays (got N = %d)", N);
+    const uint32_t B = (uint32_t)conf->blockSize;
+    if (conf->blockSize < 1 || (N == 3 && B > 8) || (N == 2 && B > 32))
+        return fail(SZ3HIP_EUNSUPPORTED, "stock ALGO_LORENZO_REG streams are read for block sizes up to 8 (3-D) / 32 (2-D) (got %d)", conf->blockSize);
+    int kinds[3], n_kinds = 0;
+    if (conf->lorenzo) kinds[n_kinds++] = 0;
+    if (conf->lorenzo2) kinds[n_kinds++] = 1;
+    if (conf->regression) kinds[n_kinds++] = 2;
+    if (n_kinds == 0) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (no predictor in its Config)");
+    const bool composed = n_kinds > 1;
+    if (payload < 8) return fail(SZ3HIP_EFORMAT, "truncated payload");
+    uint64_t raw_len;
+    memcpy(&raw_len, p, 8);
+    if (raw_len < 32 || raw_len > (uint64_t)conf->num * 16 + (1u << 22)) return fail(SZ3HIP_EFORMAT, "implausible payload length in the lossless block");
+    std::vector<uint8_t> raw((size_t)raw_len + 8, 0);
+    if (zs::decompress_frames(p, payload, raw.data(), (size_t)raw_len) != raw_len) return SZ3HIP_EZSTD;
+    stock::LorenzoReg lr;
+    if (!stock::parse_lorenzo_reg(raw.data(), (size_t)raw_len, tsize, conf->regression != 0, composed, lr) || lr.n != conf->num)
+        return fail(SZ3HIP_EFORMAT, "corrupt stock ALGO_LORENZO_REG stream (predictor section, quantizer or Huffman tree)");
+    uint64_t d3[3] = {1, 1, 1}, nb[3] = {1, 1, 1}, nblocks = 1;
+    for (int i = 0; i < N; i++) d3[3 - N + i] = conf->dims[i];
+    for (int i = 0; i < 3; i++) {
+        if (d3[i] >= 0xFFFFFFFFull) return fail(SZ3HIP_EUNSUPPORTED, "extent beyond 32 bits");
+        nb[i] = i < 3 - N ? 1 : (d3[i] + B - 1) / B;
+        nblocks *= nb[i];
+    }
+    if (nblocks > 0x7FFFFFF0ull) return fail(SZ3HIP_EUNSUPPORTED, "too many blocks");
+    std::vector<uint8_t> kind;
+    std::vector<float> cf32;
+    std::vector<double> cf64;
+    const bool okc = cdt == SZ3HIP_FLOAT ? slr_coefficients<float>(conf, lr, kinds, n_kinds, composed, nblocks, nb, kind, cf32)
+                                        : slr_coefficients<double>(conf, lr, kinds, n_kinds, composed, nblocks, nb, kind, cf64);
+    if (!okc) return fail(SZ3HIP_EFORMAT, "corrupt stock ALGO_LORENZO_REG stream (selection or coefficient chain)");
+    HIPCHK(hipSetDevice(s->device));
+    int rc;
+    if ((rc = slot_ctx(s, conf->num))) return rc;
+    if ((rc = ensure_dev(&s->dev_in, &s->dev_in_bytes, (size_t)conf->num * tsize))) return rc;
+    const uint64_t n = lr.n, bit_bytes = lr.bit_bytes;
+    const uint64_t ntiles_z = (n + 1023) / 1024, nsub = (bit_bytes * 8 + 4095) / 4096;
+    const uint32_t nc = (uint32_t)lr.tree.t.size();
+    uint16_t *d_em;
+    uint8_t *d_unpred, *d_bits, *d_t, *d_kind, *d_coef;
+    uint64_t *d_tile_base, *d_start, *d_last, *d_next, *d_base;
+    uint32_t *d_tile_cnt, *d_bad, *d_L, *d_R, *d_lut, *d_count, *d_flags;
+    int32_t *d_C;
+    DevArena ar;
+    ar.ask(&d_em, (size_t)n * 2 + 2048);
+    ar.ask(&d_unpred, (size_t)lr.q.n_unpred * tsize + 8);
+    ar.ask(&d_kind, (size_t)nblocks + 8);
+    ar.ask(&d_coef, (size_t)nblocks * 4 * tsize + 8);
+    ar.ask(&d_tile_cnt, (size_t)ntiles_z * 4 + 8);
+    ar.ask(&d_tile_base, (size_t)(ntiles_z + 1) * 8);
+    ar.ask(&d_bad, 64);
+    ar.ask(&d_bits, (size_t)bit_bytes + 16);
+    ar.ask(&d_L, (size_t)nc * 4);
+    ar.ask(&d_R, (size_t)nc * 4);
+    ar.ask(&d_C, (size_t)nc * 4);
+    ar.ask(&d_t, nc);
+    ar.ask(&d_lut, 4096 * 4);
+    ar.ask(&d_start, (size_t)(nsub + 2) * 8);
+    ar.ask(&d_last, (size_t)(nsub + 2) * 8);
+    ar.ask(&d_next, (size_t)(nsub + 2) * 8);
+    ar.ask(&d_base, (size_t)(nsub + 2) * 8);
+    ar.ask(&d_count, (size_t)(nsub + 2) * 4);
+    ar.ask(&d_flags, 64);
+    if (ar.commit(s)) return SZ3HIP_EHIP;
+    HIPCHK(hipMemsetAsync(d_bad, 0, 64, s->stream));
+    HIPCHK(hipMemcpyAsync(d_kind, kind.data(), (size_t)nblocks, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(d_coef, cdt == SZ3HIP_FLOAT ? (const void *)cf32.data() : (const void *)cf64.data(), (size_t)nblocks * 4 * tsize, hipMemcpyHostToDevice, s->stream));
+    if (lr.q.n_unpred) HIPCHK(hipMemcpyAsync(d_unpred, lr.q.unpred, (size_t)lr.q.n_unpred * tsize, hipMemcpyHostToDevice, s->stream));
+    std::vector<uint16_t> em_host;
+    if (lr.tree.t[0]) {  // a single symbol: no bits at all (encoder/HuffmanEncoder.hpp:233-237)
+        const int32_t v = lr.tree.C[0] + lr.offset;
+        if (v < 0 || v > 65535) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (symbol)");
+        em_host.assign((size_t)n, (uint16_t)v);
+        HIPCHK(hipMemcpyAsync(d_em, em_host.data(), (size_t)n * 2, hipMemcpyHostToDevice, s->stream));
+    } else if (stock_host_huffman()) {
+        em_host.resize((size_t)n);
+        if (!stock::host_decode(lr.tree, lr.offset, lr.bits, (size_t)bit_bytes, n, em_host.data())) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (bit stream)");
+        HIPCHK(hipMemcpyAsync(d_em, em_host.data(), (size_t)n * 2, hipMemcpyHostToDevice, s->stream));
+    } else {
+        std::vector<uint32_t> lut;
+        stock::make_lut(lr.tree, lut);
+        HIPCHK(hipMemsetAsync(d_bits + (bit_bytes & ~(uint64_t)3), 0, 16, s->stream));  // (the last word's tail reads as zeros)
+        HIPCHK(hipMemcpyAsync(d_bits, lr.bits, (size_t)bit_bytes, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(d_L, lr.tree.L.data(), (size_t)nc * 4, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(d_R, lr.tree.R.data(), (size_t)nc * 4, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(d_C, lr.tree.C.data(), (size_t)nc * 4, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(d_t, lr.tree.t.data(), nc, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(d_lut, lut.data(), 4096 * 4, hipMemcpyHostToDevice, s->stream));
+        szk_stock_tree_dev td{d_L, d_R, d_C, d_t, d_lut, nc, lr.offset};
+        int passes = 0;
+        const int rd = szk_launch_stock_huff_decode(&td, (const uint32_t *)d_bits, bit_bytes, n, d_start, d_last, d_next, d_base, d_count, d_flags, d_em, &passes, s->stream);
+        if (rd == -3) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (bit stream)");
+        if (rd) return fail(SZ3HIP_EHIP, "stock stream: device Huffman decoder failed (%d)", rd);
+    }
+    szk_slr_params sp;
+    memset(&sp, 0, sizeof(sp));
+    for (int i = 0; i < 3; i++) {
+        sp.d[i] = d3[i];
+        sp.nb[i] = (uint32_t)nb[i];
+    }
+    sp.B = B;
+    sp.N = (uint32_t)N;
+    sp.eb = lr.q.eb;
+    sp.radius = (uint32_t)lr.q.radius;
+    sp.codes = d_em;
+    sp.kind = d_kind;
+    sp.coef = d_coef;
+    sp.unpred = d_unpred;
+    sp.n_unpred = lr.q.n_unpred;
+    sp.tile_base = d_tile_base;
+    sp.out = s->dev_in;
+    sp.bad = d_bad;
+    if (szk_launch_stock_lorenzo_reg(cdt == SZ3HIP_FLOAT ? 0 : 1, &sp, n, d_tile_cnt, d_tile_base, s->stream)) return fail(SZ3HIP_EHIP, "stock stream: decoder launch failed");
+    uint32_t bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (bad) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (more zero codes than unpredictable values)");
+    HIPCHK(hipMemcpy(decData, s->dev_in, (size_t)conf->num * tsize, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // phase 3: code book + encode on the device, payload to the host, lossless stage, the dispatcher's fallbacks
 int job_encode(SlabJob &j) {
     if (j.rc) return j.rc;
@@ -1368,10 +1562,12 @@ int decompress_blob(HostSlot *s, const sz3hip_config *conf, int dataType, const 
     }
     if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP && !is_int)  // a stock SZ3 stream of the interpolation compressor (SZDispatcher.hpp:89-91)
         return stock_decompress_interp(s, conf, dataType, p, payload, decData);
+    if (conf->cmprAlgo == SZ3HIP_ALGO_LORENZO_REG && !is_int)  // ... of the Lorenzo / regression compressor (:85-88)
+        return stock_decompress_lorenzo_reg(s, conf, dataType, p, payload, decData);
     if (conf->cmprAlgo != SZ3HIP_ALGO_HIP_LORENZO && conf->cmprAlgo != SZ3HIP_ALGO_HIP_INTERP)
         return fail(SZ3HIP_EUNSUPPORTED,
-                    "stream uses cmprAlgo %d of the CPU reference; this library decodes its own GPU streams (ids %d, %d), stock ALGO_INTERP "
-                    "streams of float / double arrays and ALGO_LOSSLESS",
+                    "stream uses cmprAlgo %d of the CPU reference; this library decodes its own GPU streams (ids %d, %d), stock ALGO_INTERP / "
+                    "ALGO_LORENZO_REG streams of float / double arrays and ALGO_LOSSLESS",
                     conf->cmprAlgo, SZ3HIP_ALGO_HIP_LORENZO, SZ3HIP_ALGO_HIP_INTERP);
     if (payload < 8) return fail(SZ3HIP_EFORMAT, "truncated payload");
     uint64_t raw_len;

@@ -355,6 +355,24 @@ struct szk_stock_tree_dev {  // HuffmanEncoder's serialised tree on the device (
 };
 int szk_launch_stock_huff_decode(const szk_stock_tree_dev *tr, const uint32_t *d_words, uint64_t nbytes, uint64_t n, uint64_t *d_start, uint64_t *d_last,
                                  uint64_t *d_next, uint64_t *d_base, uint32_t *d_count, uint32_t *d_flags, uint16_t *d_em, int *passes, hipStream_t s);
+// a stock ALGO_LORENZO_REG stream on the device (round 4, read side: sz3hip_stock.hip k_slr_*): the reference's own arithmetic —
+// predictions from reconstructed values in T, LinearQuantizer::recover — block by block in anti-diagonal fronts
+struct szk_slr_params {
+    uint64_t d[3];     // the array as (z, y, x): leading extents 1 for N < 3
+    uint32_t nb[3];    // blocks per dimension
+    uint32_t B, N;
+    double eb;         // the main quantizer's bound and radius (from the stream)
+    uint32_t radius;
+    const uint16_t *codes;      // block by block (block raster order, raster order inside a block)
+    const uint8_t *kind;        // [blocks] 0 Lorenzo-1, 1 Lorenzo-2, 2 regression
+    const void *coef;           // [blocks][4] T: a regression block's N + 1 coefficients (recovered on the host: a chain over the blocks)
+    const void *unpred;         // the quantizer's unpredictable values, in the order of their zero codes
+    uint64_t n_unpred;
+    const uint64_t *tile_base;  // zero codes in front of every tile of 1024 codes
+    void *out;
+    uint32_t *bad;              // raised by a zero code beyond the list
+};
+int szk_launch_stock_lorenzo_reg(int dtype, const szk_slr_params *p, uint64_t n, uint32_t *d_tile_cnt, uint64_t *d_tile_base, hipStream_t s);
 #ifdef __cplusplus
 #include <vector>
 // the geometry of an array under InterpolationDecomposition::init (:176-213) and the per-block bases of its emission order; 0 on success

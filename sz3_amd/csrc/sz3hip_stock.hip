@@ -514,3 +514,209 @@ int szk_launch_stock_huff_decode(const szk_stock_tree_dev *tr, const uint32_t *d
     if (hipMemcpyAsync(&bad, d_flags + 1, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
     return bad ? -3 : 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Stock ALGO_LORENZO_REG streams, read side (round 4). BlockwiseDecomposition::decompress (decomposition/BlockwiseDecomposition.hpp:48-67)
+// walks the blocks in raster order and predicts every element from RECONSTRUCTED values in T arithmetic (LorenzoPredictor.hpp:60-95,
+// RegressionPredictor.hpp:77-92), then LinearQuantizer::recover (:77-86): nothing of it is associative, so the values must be made in
+// an order that respects the reference's dependencies — a block after its low neighbours (fronts of blocks, a launch each), an element
+// after its low neighbours (hyperplanes i + j + k = s inside the block, a wave per block, the block and two halo layers in LDS).
+// 1-D arrays are a single chain: one wave walks the blocks, one lane the elements of a Lorenzo block (k_slr_chain: correct, and as slow
+// as a chain is). The predictions spell the reference's order of terms (prev3(d, ds, k, j, i) steps k along y, j along z, i along x:
+// LorenzoPredictor.hpp:102-108 with ds = the strides slowest first).
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T slr_value(const szk_slr_params &p, T pred, uint64_t c) {  // LinearQuantizer::recover
+    const uint32_t code = p.codes[c];
+    if (code) return ref_recover(pred, (int)code, p.eb, (int)p.radius);
+    const uint64_t k = stock_ordinal(p.codes, p.tile_base, c);
+    if (k >= p.n_unpred) {
+        *p.bad = 1u;
+        return (T)0;
+    }
+    return reinterpret_cast<const T *>(p.unpred)[k];
+}
+__device__ __forceinline__ int slr_w(int j) { return j == 1 ? -2 : 1; }  // (1, -2, 1)
+template <typename T, int N>
+__global__ __launch_bounds__(256) void k_slr_front(szk_slr_params p, uint32_t diag) {
+    constexpr uint32_t MAXT = N == 3 ? 10u * 10u * 10u : 34u * 34u;  // (B + 2)^N
+    __shared__ T s_t[4][MAXT];
+    const int lane = lane_id();
+    T *tl = s_t[threadIdx.x / WAVE];
+    const uint32_t cand = blockIdx.x * 4 + threadIdx.x / WAVE;  // candidates: (bz, by) pairs in 3-D, by in 2-D; bx follows from the front
+    uint32_t bz = 0, by, bx;
+    if (N == 3) {
+        if (cand >= p.nb[0] * p.nb[1]) return;
+        bz = cand / p.nb[1];
+        by = cand - bz * p.nb[1];
+    } else {
+        if (cand >= p.nb[1]) return;
+        by = cand;
+    }
+    if (bz + by > diag) return;
+    bx = diag - bz - by;
+    if (bx >= p.nb[2]) return;
+    const uint32_t task = (bz * p.nb[1] + by) * p.nb[2] + bx;
+    const uint32_t oz = bz * p.B, oy = by * p.B, ox = bx * p.B;
+    const uint32_t ez = N == 3 ? min(p.B, (uint32_t)p.d[0] - oz) : 1u, ey = min(p.B, (uint32_t)p.d[1] - oy), ex = min(p.B, (uint32_t)p.d[2] - ox);
+    const uint64_t coff = (uint64_t)oz * p.d[1] * p.d[2] + (uint64_t)ez * ((uint64_t)oy * p.d[2] + (uint64_t)ey * ox);
+    const uint32_t nown = ez * ey * ex;
+    const uint32_t hz = N == 3 ? 2u : 0u;  // halo layers along z
+    const uint32_t tz = ez + hz, ty = ey + 2, tx = ex + 2;
+    auto at = [&](uint32_t a, uint32_t b, uint32_t c) -> uint32_t { return (a * ty + b) * tx + c; };
+    T *out = reinterpret_cast<T *>(p.out);
+    for (uint32_t l = lane; l < tz * ty * tx; l += WAVE) {  // the halo: finished values, zeros outside the array (the reference's padding)
+        const uint32_t c = l % tx, b = (l / tx) % ty, a = l / (tx * ty);
+        if (a >= hz && b >= 2 && c >= 2) continue;
+        const int64_t z = (int64_t)oz + a - hz, y = (int64_t)oy + b - 2, x = (int64_t)ox + c - 2;
+        tl[l] = (z >= 0 && y >= 0 && x >= 0) ? out[((uint64_t)z * p.d[1] + (uint64_t)y) * p.d[2] + (uint64_t)x] : (T)0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t kind = p.kind[task];
+    if (kind == 2) {  // regression: nothing of the neighbours
+        const T *cf = reinterpret_cast<const T *>(p.coef) + (uint64_t)task * 4;
+        for (uint32_t t = lane; t < nown; t += WAVE) {
+            const uint32_t i2 = t % ex, i1 = (t / ex) % ey, i0 = t / (ex * ey);
+            T pr;
+            if (N == 3) {
+                pr = (T)(cf[0] * (T)i0);
+                pr = (T)(pr + (T)(cf[1] * (T)i1));
+                pr = (T)(pr + (T)(cf[2] * (T)i2));
+                pr = (T)(pr + cf[3]);
+            } else {
+                pr = (T)(cf[0] * (T)i1);
+                pr = (T)(pr + (T)(cf[1] * (T)i2));
+                pr = (T)(pr + cf[2]);
+            }
+            tl[at(i0 + hz, i1 + 2, i2 + 2)] = slr_value<T>(p, pr, coff + t);
+        }
+    } else {
+        const uint32_t smax = (ez - 1) + (ey - 1) + (ex - 1);
+        for (uint32_t s = 0; s <= smax; s++) {
+            for (uint32_t t = lane; t < nown; t += WAVE) {
+                const uint32_t i2 = t % ex, i1 = (t / ex) % ey, i0 = t / (ex * ey);
+                if (i0 + i1 + i2 != s) continue;
+                const uint32_t a = i0 + hz, b = i1 + 2, c = i2 + 2;
+                T pr;
+                if (N == 3) {
+                    auto P = [&](int k, int j, int i) -> T { return tl[at(a - j, b - k, c - i)]; };
+                    if (kind == 0) {
+                        pr = (T)(P(0, 0, 1) + P(0, 1, 0));
+                        pr = (T)(pr + P(1, 0, 0));
+                        pr = (T)(pr - P(0, 1, 1));
+                        pr = (T)(pr - P(1, 0, 1));
+                        pr = (T)(pr - P(1, 1, 0));
+                        pr = (T)(pr + P(1, 1, 1));
+                    } else {
+                        pr = 0;
+                        bool first = true;
+                        for (int k = 0; k <= 2; k++)
+                            for (int j = 0; j <= 2; j++)
+                                for (int i = 0; i <= 2; i++) {
+                                    if ((k | j | i) == 0) continue;
+                                    const T term = (T)((T)(-(slr_w(k) * slr_w(j) * slr_w(i))) * P(k, j, i));
+                                    pr = first ? term : (T)(pr + term);
+                                    first = false;
+                                }
+                    }
+                } else {
+                    auto P = [&](int j, int i) -> T { return tl[at(a, b - j, c - i)]; };
+                    if (kind == 0) {
+                        pr = (T)((T)(P(0, 1) + P(1, 0)) - P(1, 1));
+                    } else {
+                        pr = 0;
+                        bool first = true;
+                        for (int j = 0; j <= 2; j++)
+                            for (int i = 0; i <= 2; i++) {
+                                if ((j | i) == 0) continue;
+                                const T term = (T)((T)(-(slr_w(j) * slr_w(i))) * P(j, i));
+                                pr = first ? term : (T)(pr + term);
+                                first = false;
+                            }
+                    }
+                }
+                tl[at(a, b, c)] = slr_value<T>(p, pr, coff + t);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t t = lane; t < nown; t += WAVE) {
+        const uint32_t i2 = t % ex, i1 = (t / ex) % ey, i0 = t / (ex * ey);
+        out[((uint64_t)(oz + i0) * p.d[1] + (oy + i1)) * p.d[2] + (ox + i2)] = tl[at(i0 + hz, i1 + 2, i2 + 2)];
+    }
+}
+// 1-D: the chain. One wave; a regression block's elements by its lanes, a Lorenzo block's by lane 0 from the block's codes in LDS.
+template <typename T>
+__global__ __launch_bounds__(64) void k_slr_chain(szk_slr_params p) {
+    __shared__ uint16_t s_c[1024];
+    __shared__ T s_v[1024];
+    const int lane = lane_id();
+    const uint32_t n = (uint32_t)p.d[2];
+    T *out = reinterpret_cast<T *>(p.out);
+    const T *un = reinterpret_cast<const T *>(p.unpred);
+    uint64_t zc = 0;  // zero codes so far: the chain IS the code order
+    T p1 = 0, p2 = 0;  // the two values left of the next element (zeros in front of the array)
+    for (uint32_t task = 0; task < p.nb[2]; task++) {
+        const uint32_t ox = task * p.B, ex = min(p.B, n - ox);
+        const uint32_t kind = p.kind[task];
+        const T *cf = reinterpret_cast<const T *>(p.coef) + (uint64_t)task * 4;
+        for (uint32_t t0 = 0; t0 < ex; t0 += 1024) {  // pieces of up to 1024 elements
+            const uint32_t m = min(1024u, ex - t0);
+            for (uint32_t t = lane; t < m; t += WAVE) s_c[t] = p.codes[ox + t0 + t];
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                for (uint32_t t = 0; t < m; t++) {
+                    T pr;
+                    if (kind == 2) pr = (T)((T)(cf[0] * (T)(t0 + t)) + cf[1]);
+                    else if (kind == 1) pr = (T)((T)(2 * p1) - p2);
+                    else pr = p1;
+                    const uint32_t code = s_c[t];
+                    T v;
+                    if (code) v = ref_recover(pr, (int)code, p.eb, (int)p.radius);
+                    else if (zc < p.n_unpred) v = un[zc++];
+                    else {
+                        *p.bad = 1u;
+                        v = 0;
+                    }
+                    s_v[t] = v;
+                    p2 = p1;
+                    p1 = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t t = lane; t < m; t += WAVE) out[ox + t0 + t] = s_v[t];
+        }
+    }
+}
+int szk_launch_stock_lorenzo_reg(int dtype, const szk_slr_params *p, uint64_t n, uint32_t *d_tile_cnt, uint64_t *d_tile_base, hipStream_t s) {
+    if (p->N == 1) {
+        if (dtype == 0) hipLaunchKernelGGL(k_slr_chain<float>, dim3(1), dim3(64), 0, s, *p);
+        else hipLaunchKernelGGL(k_slr_chain<double>, dim3(1), dim3(64), 0, s, *p);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    if (stock_zero_scan(p->codes, n, d_tile_cnt, d_tile_base, s)) return -1;
+    const uint32_t ndiag = p->nb[0] + p->nb[1] + p->nb[2] - 2;
+    const uint32_t cand = p->N == 3 ? p->nb[0] * p->nb[1] : p->nb[1];
+    const dim3 grid((cand + 3) / 4), blk(256);
+    for (uint32_t d = 0; d < ndiag; d++) {
+        if (p->N == 3) {
+            if (dtype == 0) hipLaunchKernelGGL((k_slr_front<float, 3>), grid, blk, 0, s, *p, d);
+            else hipLaunchKernelGGL((k_slr_front<double, 3>), grid, blk, 0, s, *p, d);
+        } else {
+            if (dtype == 0) hipLaunchKernelGGL((k_slr_front<float, 2>), grid, blk, 0, s, *p, d);
+            else hipLaunchKernelGGL((k_slr_front<double, 2>), grid, blk, 0, s, *p, d);
+        }
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

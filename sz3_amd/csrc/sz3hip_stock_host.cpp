@@ -405,4 +405,57 @@ bool parse_head(const uint8_t *raw, size_t len, int N, size_t tsize, szi_stock_p
     bits = r.p;
     return true;
 }
+
+namespace {
+bool read_quant(R &r, size_t tsize, Quant &q) {
+    const uint8_t uid = r.get<uint8_t>();
+    q.eb = r.get<double>();
+    q.radius = r.get<int32_t>();
+    q.n_unpred = r.get<uint64_t>();
+    if (!r.ok || uid != 2 || !(q.eb > 0) || q.radius < 1 || q.radius > 32768) return false;
+    if ((uint64_t)(r.end - r.p) / tsize < q.n_unpred) return false;
+    q.unpred = r.p;
+    r.p += (size_t)q.n_unpred * tsize;
+    return true;
+}
+// a side vector: HuffmanEncoder::save + encode as RegressionPredictor / ComposedPredictor call them (tree, [u64 bytes], bits); the
+// reference does not step over the byte count's payload for a one-symbol tree (encoder/HuffmanEncoder.hpp:233-237: nothing was written)
+bool read_vector(R &r, uint64_t n, std::vector<uint16_t> &out) {
+    Tree tr;
+    int32_t offset;
+    if (!load_tree(r, tr, offset)) return false;
+    const uint64_t bytes = r.get<uint64_t>();
+    if (!r.ok || n > (1ull << 32)) return false;
+    out.resize((size_t)n);
+    if (tr.t[0]) return decode_bits(tr, offset, nullptr, 0, n, out.data());
+    if ((uint64_t)(r.end - r.p) < bytes) return false;
+    if (!decode_bits(tr, offset, r.p, (size_t)bytes, n, out.data())) return false;
+    r.p += (size_t)bytes;
+    return true;
+}
+}  // namespace
+
+bool parse_lorenzo_reg(const uint8_t *raw, size_t len, size_t tsize, bool has_regression, bool composed, LorenzoReg &o) {
+    R r{raw, raw + len};
+    if (has_regression) {  // RegressionPredictor::save (:94-107)
+        const uint64_t nc = r.get<uint64_t>();
+        if (!r.ok) return false;
+        if (nc) {
+            if (!read_quant(r, tsize, o.q_indep) || !read_quant(r, tsize, o.q_lin)) return false;
+            if (!read_vector(r, nc, o.coef_codes)) return false;
+        }
+    }
+    if (composed) {  // ComposedPredictor::save (:52-64)
+        const uint64_t ns = r.get<uint64_t>();
+        if (!r.ok) return false;
+        if (ns && !read_vector(r, ns, o.selection)) return false;
+    }
+    if (!read_quant(r, tsize, o.q)) return false;
+    if (!load_tree(r, o.tree, o.offset)) return false;
+    o.n = r.get<uint64_t>();
+    o.bit_bytes = r.get<uint64_t>();
+    if (!r.ok || (uint64_t)(r.end - r.p) < o.bit_bytes) return false;
+    o.bits = r.p;
+    return true;
+}
 }  // namespace stock

@@ -23,6 +23,27 @@ void write_head(const szi_stock_params &p, uint64_t anchor_effective, const void
                 uint64_t n, uint64_t bit_bytes, std::vector<uint8_t> &raw);
 bool parse_head(const uint8_t *raw, size_t len, int N, size_t tsize, szi_stock_params &p, const uint8_t *&unpred, uint64_t &n_unpred, Tree &tr, int32_t &offset,
                 uint64_t &n, const uint8_t *&bits, uint64_t &bit_bytes);
+// a stock ALGO_LORENZO_REG stream (round 4, read side): what BlockwiseDecomposition / ComposedPredictor / RegressionPredictor saved
+// in front of the main code stream (compressor/SZGenericCompressor.hpp:38-84, predictor/ComposedPredictor.hpp:52-78,
+// predictor/RegressionPredictor.hpp:94-123, quantizer/LinearQuantizer.hpp:95-122)
+struct Quant {  // a LinearQuantizer as saved: bound, radius, its unpredictable values in the order their zero codes occur
+    double eb = 0;
+    int32_t radius = 0;
+    const uint8_t *unpred = nullptr;
+    uint64_t n_unpred = 0;
+};
+struct LorenzoReg {
+    std::vector<uint16_t> coef_codes;  // regression: N + 1 codes per regression block, in block order
+    Quant q_indep, q_lin;              // ... and their two quantizers
+    std::vector<uint16_t> selection;   // composed sets: the chosen member per block (index into the set's order)
+    Quant q;                           // the main quantizer
+    Tree tree;                         // the main code stream
+    int32_t offset = 0;
+    uint64_t n = 0;
+    const uint8_t *bits = nullptr;
+    uint64_t bit_bytes = 0;
+};
+bool parse_lorenzo_reg(const uint8_t *raw, size_t len, size_t tsize, bool has_regression, bool composed, LorenzoReg &out);
 void host_encode(const uint16_t *em, uint64_t n, const std::vector<uint8_t> &clen, const std::vector<uint64_t> &cbits, std::vector<uint8_t> &bits);
 bool host_decode(const Tree &tr, int32_t offset, const uint8_t *bits, size_t nbytes, uint64_t n, uint16_t *em);
 }  // namespace stock

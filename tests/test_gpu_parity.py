@@ -134,10 +134,15 @@ def test_dispatcher_policies_and_edge_cases():
     out = np.empty(100, dtype=np.uint8)
     assert sz3_amd.lib().sz3hip_compress(C.byref(conf._c), 0, a.ctypes.data, out.ctypes.data, out.size) == 0
     assert b"not large enough" in sz3_amd.lib().sz3hip_last_error()
-    # a stream of the CPU reference is refused, not mis-decoded
+    # a stream of the CPU reference (ALGO_LORENZO_REG; round 4) is read — the reference's own values, bit for bit (tests/test_gpu_stock.py) —;
+    # what is not built (a 4-D one) is refused, not mis-decoded
+    from oracle_binding import oracle_decompress
     oblob = oracle_compress(a, make_config(a.shape, abs_eb=1e-3))
+    got, _ = sz3_amd.decompress(oblob, np.float32, a.shape)
+    assert np.array_equal(got, oracle_decompress(oblob, np.float32, a.shape)[0])
+    a4 = np.arange(5 * 6 * 7 * 8, dtype=np.float32).reshape(5, 6, 7, 8) * 0.01
     with pytest.raises(sz3_amd.SZ3HipError):
-        sz3_amd.decompress(oblob, np.float32, a.shape)
+        sz3_amd.decompress(oracle_compress(a4, make_config(a4.shape, abs_eb=1e-3)), np.float32, a4.shape)
 
 
 def test_sz3c_abi_roundtrip():
@@ -399,8 +404,10 @@ def test_c1_through_the_cli_boundary(tmp_path):
     assert np.array_equal(runs["ours"][0], runs["recipe-gpu"][0])  # the same library under both faces
     assert np.max(np.abs(runs["ours"][0].astype(np.float64) - runs["recipe-cpu"][0].astype(np.float64))) <= 2e-3
     assert runs["ours"][1] >= 0.9 * runs["recipe-cpu"][1], {k: v[1] for k, v in runs.items()}
-    with pytest.raises(sz3_amd.SZ3HipError, match="CPU reference"):  # a stock stream is refused by name, not mis-decoded
-        sz3_amd.decompress(np.fromfile(tmp_path / "recipe-cpu.sz", dtype=np.uint8), np.float32, a.shape)
+    # the file the stock code path wrote (ALGO_LORENZO_REG, 1-D: Lorenzo + regression in blocks of 128) is read by this library since
+    # round 4, and to the values the stock CLI itself decoded
+    got, _ = sz3_amd.decompress(np.fromfile(tmp_path / "recipe-cpu.sz", dtype=np.uint8), np.float32, a.shape)
+    assert np.array_equal(got, runs["recipe-cpu"][0])
 
 
 @pytest.mark.parametrize("shape,carry", [((96, 384, 512), 0), ((80, 520, 500), 1), ((48, 130, 768), 1), ((40, 36, 1024), 2), ((160, 200, 256), 0)],

@@ -198,3 +198,68 @@ def test_device_and_host_huffman_stages_agree(eb, monkeypatch):
     assert np.array_equal(decs["0"], decs["1"])
     want, _ = oracle_decompress(blobs["0"], a.dtype, a.shape)
     assert np.array_equal(decs["0"], want)
+
+
+# ---- stock ALGO_LORENZO_REG streams, read side (round 4: sz3hip_stock.hip k_slr_*) -------------------------------------------------
+LR_CASES = [
+    ("3d-defaults", lambda: field3d((40, 50, 66)), 1e-2, dict(lorenzo=True, regression=True)),
+    ("3d-coarse-regression", lambda: field3d((37, 48, 50)), 1e-1, dict(lorenzo=True, regression=True)),
+    ("3d-lorenzo-only", lambda: field3d((33, 47, 50)), 1e-3, dict(lorenzo=True, regression=False)),
+    ("3d-all-three", lambda: field3d((30, 31, 44)), 2e-2, dict(lorenzo=True, lorenzo2=True, regression=True)),
+    ("3d-second-order-only", lambda: field3d((20, 21, 22)), 1e-3, dict(lorenzo=False, lorenzo2=True, regression=False)),
+    ("3d-regression-only-block5", lambda: field3d((23, 32, 15)), 5e-2, dict(lorenzo=False, regression=True, block_size=5)),
+    ("3d-f64", lambda: field3d((40, 50, 37), np.float64, sigma=2e-6), 1e-6, dict(lorenzo=True, regression=True)),
+    ("3d-nan-inf", lambda: _with_holes(field3d((30, 40, 50))), 1e-3, dict(lorenzo=True, regression=True)),
+    ("2d-defaults", lambda: field2d((300, 500)), 1e-2, dict(lorenzo=True, regression=True)),
+    ("2d-second-order", lambda: field2d((131, 77)), 1e-4, dict(lorenzo=True, lorenzo2=True, regression=False)),
+    ("1d-tuner-set", lambda: field1d(70001), 1e-3, dict(lorenzo=True, lorenzo2=True, regression=False)),
+    ("1d-defaults", lambda: field1d(30011), 1e-3, dict(lorenzo=True, regression=True)),
+    ("1d-thin-last-block", lambda: field1d(128 * 300 + 1), 1e-2, dict(lorenzo=False, regression=True)),
+]
+
+
+@pytest.mark.parametrize("name,gen,eb,kw", LR_CASES, ids=[c[0] for c in LR_CASES])
+def test_stock_lorenzo_reg_streams_are_read_bit_for_bit(name, gen, eb, kw):
+    """the reference's arithmetic on the device: predictions from reconstructed values in T, in the reference's order of terms, and
+    LinearQuantizer::recover — the values are the ones stock SZ3 decodes, bit for bit, for every predictor set"""
+    a = gen()
+    oconf = make_config(a.shape, abs_eb=eb, **kw)          # (cmprAlgo ALGO_LORENZO_REG)
+    blob = oracle_compress(a, oconf)                       # = the reference's bytes (tests/test_oracle.py)
+    want, _ = oracle_decompress(blob, a.dtype, a.shape)
+    assert _trailer_algo(blob) == sz3_amd.ALGO_LORENZO_REG
+    got, c2 = sz3_amd.decompress(blob, a.dtype, a.shape)
+    assert c2.cmprAlgo == sz3_amd.ALGO_LORENZO_REG
+    assert np.array_equal(got, want, equal_nan=True), "reconstruction differs from stock SZ3's"
+    if have_ref():
+        rblob = ref_compress(a, oconf)
+        got2, _ = sz3_amd.decompress(rblob, a.dtype, a.shape)
+        assert np.array_equal(got2, ref_decompress(rblob, a.dtype, a.shape), equal_nan=True)
+
+
+def test_stock_default_algorithm_on_a_1d_array_is_read():
+    """what stock SZ3 writes for a 1-D array with its default Config: the tuner's Lorenzo set (SZAlgoInterp.hpp:232-282)"""
+    a = field1d(1 << 18)
+    oconf = make_config(a.shape, algo=ALGO_INTERP_LORENZO, abs_eb=1e-3, regression=True)
+    blob = oracle_compress(a, oconf)
+    assert _trailer_algo(blob) == sz3_amd.ALGO_LORENZO_REG
+    want, _ = oracle_decompress(blob, a.dtype, a.shape)
+    got, c2 = sz3_amd.decompress(blob, a.dtype, a.shape)
+    assert (c2.lorenzo, c2.lorenzo2, c2.regression) == (1, 1, 0) and np.array_equal(got, want)
+
+
+def test_corrupt_stock_lorenzo_reg_streams_are_refused():
+    a = field3d((24, 30, 36))
+    blob = bytearray(oracle_compress(a, make_config(a.shape, abs_eb=1e-2, lorenzo=True, regression=True)).tobytes())
+    for cut in (40, len(blob) // 2):
+        with pytest.raises(sz3_amd.SZ3HipError):
+            sz3_amd.decompress(bytes(blob[:cut]) + bytes(blob[-200:]), np.float32, a.shape)
+    # a regression-only set whose last blocks are one element thin: the reference's fallback predictor then reads what lies in front of
+    # the element in memory (no padding) — refused, not imitated
+    at = field3d((23, 31, 16))
+    bt = oracle_compress(at, make_config(at.shape, abs_eb=5e-2, lorenzo=False, regression=True, block_size=5))
+    with pytest.raises(sz3_amd.SZ3HipError):
+        sz3_amd.decompress(bt, np.float32, at.shape)
+    a4 = field4d((5, 12, 14, 16))
+    b4 = oracle_compress(a4, make_config(a4.shape, abs_eb=1e-2, lorenzo=True, regression=True))
+    with pytest.raises(sz3_amd.SZ3HipError, match="1-D, 2-D and 3-D"):
+        sz3_amd.decompress(b4, np.float32, a4.shape)

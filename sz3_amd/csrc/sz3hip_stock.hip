@@ -652,60 +652,118 @@ __global__ __launch_bounds__(256) void k_slr_front(szk_slr_params p, uint32_t di
         out[((uint64_t)(oz + i0) * p.d[1] + (oy + i1)) * p.d[2] + (ox + i2)] = tl[at(i0 + hz, i1 + 2, i2 + 2)];
     }
 }
-// 1-D: the chain. One wave; a regression block's elements by its lanes, a Lorenzo block's by lane 0 from the block's codes in LDS.
+// 1-D: the chain. One workgroup of sixteen waves works through the array in rounds of sixteen UNITS (a unit: a block, or 256 elements
+// of a longer one). What does not depend on the chain is made by all waves first, a unit each: the quantizer's term 2 (code - radius) eb
+// in double, the unpredictable values of the zero codes (ordinals from the tile scan), a regression block's values outright. Then ONE
+// lane walks the round's Lorenzo units in order — convert, add, convert back per element — and all waves store. (First versions: one
+// wave doing everything block by block, 16 us of exposed memory latency per block: 528 ms for 2^22 values.)
+#define SLR_UNIT 256u
 template <typename T>
-__global__ __launch_bounds__(64) void k_slr_chain(szk_slr_params p) {
-    __shared__ uint16_t s_c[1024];
-    __shared__ T s_v[1024];
+__global__ __launch_bounds__(1024) void k_slr_chain(szk_slr_params p) {
+    __shared__ double s_add[16][SLR_UNIT];
+    __shared__ T s_v[16][SLR_UNIT];
+    __shared__ uint8_t s_z[16][SLR_UNIT];
+    __shared__ uint32_t s_m[16], s_kind[16];
+    __shared__ T s_pair[2];
     const int lane = lane_id();
+    const uint32_t w = threadIdx.x / WAVE;
     const uint32_t n = (uint32_t)p.d[2];
     T *out = reinterpret_cast<T *>(p.out);
     const T *un = reinterpret_cast<const T *>(p.unpred);
-    uint64_t zc = 0;  // zero codes so far: the chain IS the code order
-    T p1 = 0, p2 = 0;  // the two values left of the next element (zeros in front of the array)
-    for (uint32_t task = 0; task < p.nb[2]; task++) {
-        const uint32_t ox = task * p.B, ex = min(p.B, n - ox);
-        const uint32_t kind = p.kind[task];
-        const T *cf = reinterpret_cast<const T *>(p.coef) + (uint64_t)task * 4;
-        for (uint32_t t0 = 0; t0 < ex; t0 += 1024) {  // pieces of up to 1024 elements
-            const uint32_t m = min(1024u, ex - t0);
-            for (uint32_t t = lane; t < m; t += WAVE) s_c[t] = p.codes[ox + t0 + t];
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) {
-                for (uint32_t t = 0; t < m; t++) {
-                    T pr;
-                    if (kind == 2) pr = (T)((T)(cf[0] * (T)(t0 + t)) + cf[1]);
-                    else if (kind == 1) pr = (T)((T)(2 * p1) - p2);
-                    else pr = p1;
-                    const uint32_t code = s_c[t];
-                    T v;
-                    if (code) v = ref_recover(pr, (int)code, p.eb, (int)p.radius);
-                    else if (zc < p.n_unpred) v = un[zc++];
-                    else {
-                        *p.bad = 1u;
-                        v = 0;
+    const uint32_t upb = (p.B + SLR_UNIT - 1) / SLR_UNIT;  // units per block
+    const uint64_t nunits = (uint64_t)p.nb[2] * upb;
+    if (threadIdx.x == 0) s_pair[0] = s_pair[1] = 0;  // the two values left of the next element (zeros in front of the array)
+    __syncthreads();
+    for (uint64_t u0 = 0; u0 < nunits; u0 += 16) {
+        const uint64_t u = u0 + w;
+        uint32_t m = 0, kind = 0, x0 = 0;
+        if (u < nunits) {
+            const uint32_t task = (uint32_t)(u / upb), seg = (uint32_t)(u - (uint64_t)task * upb);
+            const uint32_t ox = task * p.B, ex = min(p.B, n - ox);
+            const uint32_t t0 = seg * SLR_UNIT;
+            if (t0 < ex) {
+                m = min(SLR_UNIT, ex - t0);
+                x0 = ox + t0;
+                kind = p.kind[task];
+                const T *cf = reinterpret_cast<const T *>(p.coef) + (uint64_t)task * 4;
+                const T c0 = cf[0], c1 = cf[1];
+                for (uint32_t t = lane; t < m; t += WAVE) {
+                    const uint32_t code = p.codes[x0 + t];
+                    T uv = 0;
+                    if (code == 0) {
+                        const uint64_t zi = stock_ordinal(p.codes, p.tile_base, (uint64_t)x0 + t);
+                        if (zi < p.n_unpred) uv = un[zi];
+                        else *p.bad = 1u;
                     }
-                    s_v[t] = v;
-                    p2 = p1;
-                    p1 = v;
+                    const double add = (double)(2 * ((int)code - (int)p.radius)) * p.eb;
+                    s_z[w][t] = code == 0;
+                    s_add[w][t] = add;
+                    if (kind == 2) {  // regression: nothing of the chain
+                        const T pr = (T)((T)(c0 * (T)(t0 + t)) + c1);
+                        s_v[w][t] = code ? (T)((double)pr + add) : uv;
+                    } else {
+                        s_v[w][t] = uv;
+                    }
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t t = lane; t < m; t += WAVE) out[ox + t0 + t] = s_v[t];
         }
+        if (lane == 0) {
+            s_m[w] = m;
+            s_kind[w] = kind;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            T p1 = s_pair[0], p2 = s_pair[1];
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t mk = s_m[k], kk = s_kind[k];
+                if (!mk) continue;
+                if (kk == 2) {
+                    p2 = mk > 1 ? s_v[k][mk - 2] : p1;
+                    p1 = s_v[k][mk - 1];
+                } else {
+                    // eight elements' operands out of LDS at once (a lone lane waits out every read it issues one by one: 235 cycles
+                    // per element with three reads inside the step), then eight steps in registers
+                    for (uint32_t tb = 0; tb < mk; tb += 8) {
+                        double a8[8];
+                        T u8[8];
+                        uint8_t z8[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const uint32_t t = tb + j < mk ? tb + j : mk - 1;
+                            a8[j] = s_add[k][t];
+                            u8[j] = s_v[k][t];
+                            z8[j] = s_z[k][t];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const bool live = tb + j < mk;  // (no early exit: the arrays stay in registers)
+                            const T pr = kk == 1 ? (T)((T)(2 * p1) - p2) : p1;
+                            const T v = z8[j] ? u8[j] : (T)((double)pr + a8[j]);
+                            u8[j] = v;
+                            p2 = live ? p1 : p2;
+                            p1 = live ? v : p1;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (tb + j < mk) s_v[k][tb + j] = u8[j];
+                    }
+                }
+            }
+            s_pair[0] = p1;
+            s_pair[1] = p2;
+        }
+        __syncthreads();
+        for (uint32_t t = lane; t < m; t += WAVE) out[x0 + t] = s_v[w][t];
+        __syncthreads();
     }
 }
 int szk_launch_stock_lorenzo_reg(int dtype, const szk_slr_params *p, uint64_t n, uint32_t *d_tile_cnt, uint64_t *d_tile_base, hipStream_t s) {
+    if (stock_zero_scan(p->codes, n, d_tile_cnt, d_tile_base, s)) return -1;
     if (p->N == 1) {
-        if (dtype == 0) hipLaunchKernelGGL(k_slr_chain<float>, dim3(1), dim3(64), 0, s, *p);
-        else hipLaunchKernelGGL(k_slr_chain<double>, dim3(1), dim3(64), 0, s, *p);
+        if (dtype == 0) hipLaunchKernelGGL(k_slr_chain<float>, dim3(1), dim3(1024), 0, s, *p);
+        else hipLaunchKernelGGL(k_slr_chain<double>, dim3(1), dim3(1024), 0, s, *p);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
-    if (stock_zero_scan(p->codes, n, d_tile_cnt, d_tile_base, s)) return -1;
     const uint32_t ndiag = p->nb[0] + p->nb[1] + p->nb[2] - 2;
     const uint32_t cand = p->N == 3 ? p->nb[0] * p->nb[1] : p->nb[1];
     const dim3 grid((cand + 3) / 4), blk(256);

@@ -42,13 +42,16 @@ def _try(dc, blob, n, dtype):
     return d_out.cpu().numpy()
 
 
-@pytest.mark.parametrize("kind", ["plain-3d", "block-1d", "block-3d"])
+@pytest.mark.parametrize("kind", ["plain-3d", "block-1d", "block-3d", "block-4d"])
 def test_tampered_headers_are_refused(kind):
     L = sz3_amd.lib()
     try:
         L.sz3hip_debug_flags(NO_EXIT)
         if kind == "block-1d":
             a = field1d(40000, np.float32)
+        elif kind == "block-4d":
+            from fields import field4d
+            a = field4d((6, 14, 20, 22), np.float32)
         else:
             a = field3d((24, 40, 56), np.float32)
         dc, blob, d_in = _device_payload(a, regression=kind != "plain-3d")
@@ -80,7 +83,7 @@ def test_tampered_headers_are_refused(kind):
         cases["side section shorter than its header"] = with_(120, "<Q", 8)
         # the Rice parameters behind the selection bits are shift counts in the side section's parser: > 63 is refused
         B = h["blk_edge"]
-        nblocks = int(np.prod([(d + B - 1) // B for d in h["dims"][1:]]))
+        nblocks = int(np.prod([(d + B - 1) // B for d in (h["dims"] if kind == "block-4d" else h["dims"][1:])]))
         sel_bytes = ((nblocks + 3) // 4 + 7) & ~7
         cases["Rice parameter beyond 63"] = with_(o["side"] + 24 + sel_bytes + 2, "<B", 200)
     if kind == "block-1d":
@@ -88,6 +91,10 @@ def test_tampered_headers_are_refused(kind):
         cases["1-D stream with a second extent"] = with_(16, "<4Q", 1, 1, 2, n // 2)
     if kind == "block-3d":
         cases["3-D block edge above 8"] = with_(144, "<I", 16)
+    if kind == "block-4d":
+        cases["4-D block edge above 6"] = with_(144, "<I", 8)
+        cases["second-order Lorenzo in 4-D"] = with_(148, "<I", 7)
+        cases["fifth Rice parameter beyond 63"] = with_(o["side"] + 24 + sel_bytes + 4, "<B", 99)
     for what, b in cases.items():
         with pytest.raises(sz3_amd.SZ3HipError):
             _try(dc, b, n, np.float32)

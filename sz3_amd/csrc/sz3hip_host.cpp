@@ -865,9 +865,6 @@ int stock_decompress_lorenzo_reg(HostSlot *s, const sz3hip_config *conf, int dat
     if (raw_len < 32 || raw_len > (uint64_t)conf->num * 16 + (1u << 22)) return fail(SZ3HIP_EFORMAT, "implausible payload length in the lossless block");
     std::vector<uint8_t> raw((size_t)raw_len + 8, 0);
     if (zs::decompress_frames(p, payload, raw.data(), (size_t)raw_len) != raw_len) return SZ3HIP_EZSTD;
-    stock::LorenzoReg lr;
-    if (!stock::parse_lorenzo_reg(raw.data(), (size_t)raw_len, tsize, conf->regression != 0, composed, lr) || lr.n != conf->num)
-        return fail(SZ3HIP_EFORMAT, "corrupt stock ALGO_LORENZO_REG stream (predictor section, quantizer or Huffman tree)");
     uint64_t d3[3] = {1, 1, 1}, nb[3] = {1, 1, 1}, nblocks = 1;
     for (int i = 0; i < N; i++) d3[3 - N + i] = conf->dims[i];
     for (int i = 0; i < 3; i++) {
@@ -876,6 +873,9 @@ int stock_decompress_lorenzo_reg(HostSlot *s, const sz3hip_config *conf, int dat
         nblocks *= nb[i];
     }
     if (nblocks > 0x7FFFFFF0ull) return fail(SZ3HIP_EUNSUPPORTED, "too many blocks");
+    stock::LorenzoReg lr;
+    if (!stock::parse_lorenzo_reg(raw.data(), (size_t)raw_len, tsize, conf->regression != 0, composed, nblocks, N, lr) || lr.n != conf->num)
+        return fail(SZ3HIP_EFORMAT, "corrupt stock ALGO_LORENZO_REG stream (predictor section, quantizer or Huffman tree)");
     std::vector<uint8_t> kind;
     std::vector<float> cf32;
     std::vector<double> cf64;

@@ -435,11 +435,11 @@ bool read_vector(R &r, uint64_t n, std::vector<uint16_t> &out) {
 }
 }  // namespace
 
-bool parse_lorenzo_reg(const uint8_t *raw, size_t len, size_t tsize, bool has_regression, bool composed, LorenzoReg &o) {
+bool parse_lorenzo_reg(const uint8_t *raw, size_t len, size_t tsize, bool has_regression, bool composed, uint64_t nblocks, int N, LorenzoReg &o) {
     R r{raw, raw + len};
     if (has_regression) {  // RegressionPredictor::save (:94-107)
         const uint64_t nc = r.get<uint64_t>();
-        if (!r.ok) return false;
+        if (!r.ok || nc > nblocks * (uint64_t)(N + 1)) return false;  // (N + 1 codes per regression block: a corrupt count must not size a vector)
         if (nc) {
             if (!read_quant(r, tsize, o.q_indep) || !read_quant(r, tsize, o.q_lin)) return false;
             if (!read_vector(r, nc, o.coef_codes)) return false;
@@ -447,7 +447,7 @@ bool parse_lorenzo_reg(const uint8_t *raw, size_t len, size_t tsize, bool has_re
     }
     if (composed) {  // ComposedPredictor::save (:52-64)
         const uint64_t ns = r.get<uint64_t>();
-        if (!r.ok) return false;
+        if (!r.ok || ns > nblocks) return false;
         if (ns && !read_vector(r, ns, o.selection)) return false;
     }
     if (!read_quant(r, tsize, o.q)) return false;

@@ -43,7 +43,7 @@ struct LorenzoReg {
     const uint8_t *bits = nullptr;
     uint64_t bit_bytes = 0;
 };
-bool parse_lorenzo_reg(const uint8_t *raw, size_t len, size_t tsize, bool has_regression, bool composed, LorenzoReg &out);
+bool parse_lorenzo_reg(const uint8_t *raw, size_t len, size_t tsize, bool has_regression, bool composed, uint64_t nblocks, int N, LorenzoReg &out);
 void host_encode(const uint16_t *em, uint64_t n, const std::vector<uint8_t> &clen, const std::vector<uint64_t> &cbits, std::vector<uint8_t> &bits);
 bool host_decode(const Tree &tr, int32_t offset, const uint8_t *bits, size_t nbytes, uint64_t n, uint16_t *em);
 }  // namespace stock

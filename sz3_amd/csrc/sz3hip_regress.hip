@@ -3630,8 +3630,9 @@ __global__ __launch_bounds__(256) void k_blk4_pre(const uint16_t *__restrict__ c
 // outside the array) in LDS; four passes of line sums undo the four differences — along x with the inflow Dw Dz Dy q~ of the halo
 // column, along y with Dw Dz q~ of the halo row, along z with Dw q~, along w with q~ itself
 #define BLK4_MAXE 7u  // block edge (<= 6) + the halo layer
+#define BLK4_DT 256u
 template <typename T>
-__global__ __launch_bounds__(64) void k_blk4_decode(const void *deltas_, void *d_out, szk_blk_params p, uint32_t diag) {
+__global__ __launch_bounds__(BLK4_DT) void k_blk4_decode(const void *deltas_, void *d_out, szk_blk_params p, uint32_t diag) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     __shared__ Q sq[BLK4_MAXE * BLK4_MAXE * BLK4_MAXE * BLK4_MAXE], sa[BLK4_MAXE * BLK4_MAXE * BLK4_MAXE * BLK4_MAXE];
@@ -3644,12 +3645,12 @@ __global__ __launch_bounds__(64) void k_blk4_decode(const void *deltas_, void *d
     const uint32_t task = ((bw * p.nb[0] + bz) * p.nb[1] + by) * p.nb[2] + bx;
     if (p.sel[task] == 2) return;
     const Blk4 g = blk4_geom(p, bw, bz, by, bx);
-    const int lane = lane_id();
+    const uint32_t lane = threadIdx.x;  // (a workgroup per block: the tile's 2401 words and the 216 lines of a pass by 256 threads)
     Q *qout = reinterpret_cast<Q *>(d_out);
     const Q *deltas = reinterpret_cast<const Q *>(deltas_);
     const uint32_t tw = g.ew + 1, tz = g.ez + 1, ty = g.ey + 1, tx = g.ex + 1;  // tile extents; coordinate 0 = the halo
     auto at = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) -> uint32_t { return ((a * tz + b) * ty + c) * tx + d; };
-    for (uint32_t l = lane; l < tw * tz * ty * tx; l += WAVE) {
+    for (uint32_t l = lane; l < tw * tz * ty * tx; l += BLK4_DT) {
         uint32_t q = l;
         const uint32_t d = q % tx;
         q /= tx;
@@ -3665,9 +3666,9 @@ __global__ __launch_bounds__(64) void k_blk4_decode(const void *deltas_, void *d
         }
         sq[l] = v;
     }
-    wave_lds_fence();
+    __syncthreads();
     // along x: lines (a, b, c) of the block
-    for (uint32_t l = lane; l < g.ew * g.ez * g.ey; l += WAVE) {
+    for (uint32_t l = lane; l < g.ew * g.ez * g.ey; l += BLK4_DT) {
         uint32_t q = l;
         const uint32_t c = q % g.ey + 1;
         q /= g.ey;
@@ -3684,9 +3685,9 @@ __global__ __launch_bounds__(64) void k_blk4_decode(const void *deltas_, void *d
             sa[at(a, b, c, d)] = (Q)run;
         }
     }
-    wave_lds_fence();
+    __syncthreads();
     // along y: lines (a, b, d)
-    for (uint32_t l = lane; l < g.ew * g.ez * g.ex; l += WAVE) {
+    for (uint32_t l = lane; l < g.ew * g.ez * g.ex; l += BLK4_DT) {
         uint32_t q = l;
         const uint32_t d = q % g.ex + 1;
         q /= g.ex;
@@ -3703,9 +3704,9 @@ __global__ __launch_bounds__(64) void k_blk4_decode(const void *deltas_, void *d
             sa[at(a, b, c, d)] = (Q)run;
         }
     }
-    wave_lds_fence();
+    __syncthreads();
     // along z: lines (a, c, d)
-    for (uint32_t l = lane; l < g.ew * g.ey * g.ex; l += WAVE) {
+    for (uint32_t l = lane; l < g.ew * g.ey * g.ex; l += BLK4_DT) {
         uint32_t q = l;
         const uint32_t d = q % g.ex + 1;
         q /= g.ex;
@@ -3716,9 +3717,9 @@ __global__ __launch_bounds__(64) void k_blk4_decode(const void *deltas_, void *d
             sa[at(a, b, c, d)] = (Q)run;
         }
     }
-    wave_lds_fence();
+    __syncthreads();
     // along w: lines (b, c, d); the result is q~
-    for (uint32_t l = lane; l < g.ez * g.ey * g.ex; l += WAVE) {
+    for (uint32_t l = lane; l < g.ez * g.ey * g.ex; l += BLK4_DT) {
         uint32_t q = l;
         const uint32_t d = q % g.ex + 1;
         q /= g.ex;
@@ -4084,7 +4085,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
 #define BLK4_DEC(T)                                                                                                                   \
     do {                                                                                                                              \
         hipLaunchKernelGGL(k_blk4_pre<T>, dim3(g4), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);               \
-        for (uint32_t d = 0; d < ndiag; d++) hipLaunchKernelGGL(k_blk4_decode<T>, dim3(gfront), dim3(64), 0, s, p->qwork, d_out, *p, d); \
+        for (uint32_t d = 0; d < ndiag; d++) hipLaunchKernelGGL(k_blk4_decode<T>, dim3(gfront), dim3(BLK4_DT), 0, s, p->qwork, d_out, *p, d); \
         hipLaunchKernelGGL(k_blk4_final<T>, dim3(g4), dim3(256), 0, s, codes, d_out, *p, nblocks, sc->rank, coef_by_rank);             \
         if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<T>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (T *)d_out); \
     } while (0)

@@ -47,6 +47,14 @@ def test_block_path_sweep(seed):
     assert "mismatches: 0" in out, out[-3000:]
 
 
+@pytest.mark.parametrize("ndim,n", [(1, 30), (2, 30), (4, 16)])
+def test_block_path_sweep_in_other_dimensions(ndim, n, monkeypatch):
+    """the same sweep over 1-D, 2-D (every set, second-order Lorenzo included: round 4) and 4-D arrays (Lorenzo-1 / regression)"""
+    monkeypatch.setenv("NDIM", str(ndim))
+    out = _run("block_sweep.py", 5, n)
+    assert "mismatches: 0" in out, out[-3000:]
+
+
 def test_host_api_sweep():
     out = _run("host_sweep.py", 11, 40)
     assert "failures: 0" in out, out[-3000:]

@@ -421,15 +421,18 @@ def cpu_baseline(w):
     return out
 
 
-def c1_numbers(torch, sz3_amd, dev, local_rank, steps=20):
+def c1_numbers(torch, sz3_amd, dev, local_rank, steps=20, default_algo=False):
     """C1 on the device path: the first 2^20 values of the C2 field as a 1-D array, Lorenzo + regression per block of 128 values
-    (sz3hip_regress.hip, k_blkn_*), abs 1e-3; device-resident in -> device payload. 4 MB: the step is bound by its launches."""
+    (sz3hip_regress.hip, k_blkn_*), abs 1e-3; device-resident in -> device payload. 4 MB: the step is bound by its launches.
+    default_algo: the same array under the reference's default algorithm — in 1-D its tuner takes the set [Lorenzo-1, Lorenzo-2]
+    in blocks of 128 (SZAlgoInterp.hpp:232-282; round 4)."""
     from fields import field1d
     n = 1 << 20
     a = field1d(n, np.float32)
     d_in = torch.from_numpy(a).to(dev)
     conf = sz3_amd.Config(n)
-    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG  # (defaults: lorenzo = regression = 1, blockSize 128)
+    if not default_algo:
+        conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG  # (defaults: lorenzo = regression = 1, blockSize 128)
     conf.errorBoundMode = sz3_amd.EB_ABS
     conf.absErrorBound = 1e-3
     dc = sz3_amd.DeviceCompressor(n, np.float32, device=local_rank)
@@ -461,6 +464,14 @@ def c1_numbers(torch, sz3_amd, dev, local_rank, steps=20):
     td = (time.perf_counter() - t0) / steps
     err = float((d_out.double() - d_in.double()).abs().max())
     hdr = bytes(d_pl[:160].cpu().numpy())
+    if default_algo:
+        return {"config": "C1's array under the default algorithm (ALGO_INTERP_LORENZO: in 1-D the tuner's Lorenzo-1 + Lorenzo-2 set, blocks of 128), abs errBound=1e-3, 1 GPU",
+                "value": round(a.nbytes / tc / 1e9, 3), "unit": "GB/s", "steps": steps, "ms_per_step": round(tc * 1e3, 4),
+                "ratio": round(a.nbytes / float(size), 4), "max_abs_err": err, "err_bound_ok": bool(err <= 1e-3),
+                "stream_predictor": int(hdr[11]), "block_predictor_set": int(hdr[148]),  # (1 Lorenzo-1 | 2 Lorenzo-2 | 4 regression)
+                "decompress_device": {"ms": round(td * 1e3, 4), "gbps": round(a.nbytes / td / 1e9, 2)},
+                "tuner": dc.tuner_report(),
+                "note": "oracle (= the reference) on this array: ratio 7.29 after zstd, 5.61 with Lorenzo-1 alone; the step includes the tuner"}
     return {"config": "C1: 1D float32 2^20 values, ALGO_LORENZO_REG defaults (Lorenzo + regression per block of 128), abs errBound=1e-3, 1 GPU",
             "value": round(a.nbytes / tc / 1e9, 3), "unit": "GB/s", "steps": steps, "ms_per_step": round(tc * 1e3, 4),
             "ratio": round(a.nbytes / float(size), 4), "max_abs_err": err, "err_bound_ok": bool(err <= 1e-3),
@@ -713,6 +724,10 @@ def main():
             out.setdefault("extra_configs", {})["C1"] = c1_numbers(torch, sz3_amd, dev, local_rank)
         except Exception as e:  # noqa: BLE001
             out.setdefault("extra_configs", {})["C1"] = {"error": repr(e)[:300]}
+        try:
+            out["extra_configs"]["C1_default_algorithm"] = c1_numbers(torch, sz3_amd, dev, local_rank, default_algo=True)
+        except Exception as e:  # noqa: BLE001
+            out["extra_configs"]["C1_default_algorithm"] = {"error": repr(e)[:300]}
 
     # ---- CPU baseline on this box's host cores (rank 0, N=1 only; checker code, never the product) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libsz3hip.so")
-SOURCES = ["sz3hip_kernels.hip", "sz3hip_interp.hip", "sz3hip_regress.hip", "sz3hip_stock.hip", "sz3hip_api.cpp", "sz3hip_host.cpp", "sz3hip_stock_host.cpp", "sz3hip_comm.cpp", "sz3hip_h5z.cpp"]
+SOURCES = ["sz3hip_kernels.hip", "sz3hip_interp.hip", "sz3hip_regress.hip", "sz3hip_stock.hip", "sz3hip_sortlists.hip", "sz3hip_api.cpp", "sz3hip_host.cpp", "sz3hip_stock_host.cpp", "sz3hip_comm.cpp", "sz3hip_h5z.cpp"]
 HEADERS = ["sz3hip_kernels.h", "sz3hip_format.h", "sz3hip_internal.h", "sz3hip_devutil.h", "sz3hip_stock_geom.h", "sz3hip_stock_host.h", "../../include/sz3hip.h", "../../include/sz3c.h", "../../include/sz3hip_h5z.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 

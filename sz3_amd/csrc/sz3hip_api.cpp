@@ -1514,6 +1514,16 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     }
     const szk_state &st = *ctx->h_state;
     if (st.hdr.magic != SZH_MAGIC) return fail(SZ3HIP_EHIP, "device did not produce a payload header (kernel fault?)");
+    // lists too long for the code book's sort workgroups went into the payload in arrival order: into index order now (the payload
+    // is a function of the input; a rare path — a bound far below the data's noise — with a device-wide sort and a synchronisation)
+    if (st.hdr.n_vout > 32768 || st.hdr.n_dout > 32768) {
+        uint8_t *pl = (uint8_t *)ctx->s2_payload;
+        const int tb = st.hdr.dtype == SZ3HIP_FLOAT ? 4 : 8;
+        int rs = 0;
+        if (st.hdr.n_vout > 32768) rs |= szk_sort_list_pairs((uint64_t *)(pl + st.off.vout_idx), pl + st.off.vout_val, st.hdr.n_vout, tb, s);
+        if (st.hdr.n_dout > 32768) rs |= szk_sort_list_pairs((uint64_t *)(pl + st.off.dout_idx), pl + st.off.dout_val, st.hdr.n_dout, (int)st.hdr.qbytes, s);
+        if (rs) return fail(SZ3HIP_EHIP, "sorting the payload's outlier lists failed");
+    }
     // the book this payload was coded with is the context's reference from now on
     ctx->book_idx = ctx->book_pending;
     ctx->book_pred = st.hdr.predictor;

@@ -254,6 +254,8 @@ int szk_launch_blk_side(const szk_blk_params *p, const szk_blk_scratch *sc, cons
 int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, const szk_blk_params *p, const szk_blk_scratch *sc,
                               const uint8_t *payload, const szh_header *h, const szh_offsets *o, int64_t *coef_by_rank, hipStream_t s, hipEvent_t side_done = nullptr);
 size_t szk_blk_side_bound(uint64_t nblocks);
+// (index, value) records of an outlier list inside a finished payload into index order (lists beyond 32768 records: sz3hip_sortlists.hip)
+int szk_sort_list_pairs(uint64_t *idx, void *val, uint64_t n, int val_bytes, hipStream_t s);
 // codes -> lattice deltas (code - radius) in d_out, the delta outliers scattered over them (Lorenzo and block streams)
 int szk_launch_expand_deltas(int dtype, const uint16_t *codes, uint64_t n, int radius, const uint8_t *payload, const szh_offsets *o,
                              uint64_t n_dout, void *d_out, hipStream_t s);

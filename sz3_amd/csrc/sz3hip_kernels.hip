@@ -1803,14 +1803,14 @@ __device__ __noinline__ void rec_sort(const RecView &r, uint32_t n, uint8_t *poo
 
 // outlier lists are appended with atomics in arrival order; sorting them by element index makes the payload a pure
 // function of the input (the reference's CI compares stream digests across platforms, .github/workflows/cmake.yml:295-310).
-// Lists beyond 32768 records (a sign that the bound is too tight for the data) are sorted too since round 4 — by the general record
-// sort through global memory, slower than the rest of stage 2 — up to 2^24 records; beyond that they stay in arrival order.
+// Lists beyond 32768 records (a sign that the bound is too tight for the data; sorting them here, by one workgroup through global
+// memory, takes tens of milliseconds) go into the payload in arrival order and are sorted there by finish() (sz3hip_sortlists.hip).
 // With a 512 KB scratch area the sort runs on keys alone — (index << 16) | arrival position — which fit one 16384-key
 // LDS tile up to 16384 records (records with their values take 16 bytes: 8192 per tile); the values follow by position.
 __device__ void sort_outlier_list(uint64_t *idx, void *val, uint64_t n, uint64_t cap, bool v32, uint8_t *pool, uint64_t *scratch) {
     if (n > cap) n = cap;
-    if (n < 2 || n > (1ull << 24)) return;
-    if (scratch && n <= 32768) {  // [32768] keys, then [32768] saved values (indices are element offsets: far below 2^48)
+    if (n < 2 || n > 32768) return;
+    if (scratch) {  // [32768] keys, then [32768] saved values (indices are element offsets: far below 2^48)
         uint64_t *sk = scratch, *sv = scratch + 32768;
         const uint32_t m = (uint32_t)n;
         for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {

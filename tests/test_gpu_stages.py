@@ -796,3 +796,38 @@ def test_fused_stage1_misses_repeat_the_call():
             assert (h1 - h0, m1 - m0) == ((1, 0) if want_fused else (0, 1)), (k, h1 - h0, m1 - m0)
         if not fused:
             assert got == run(sz3_amd.DeviceCompressor(n, np.float32), arr, eb)[0], "call %d: a repeated call's payload is not a fresh context's" % k
+
+
+def test_outlier_lists_beyond_the_sort_workgroups_reach_are_sorted_by_finish():
+    """more than 32768 records in a list (a bound far below the noise): the code book's sort workgroups leave such a list in arrival
+    order and finish() sorts the payload's list sections with a device-wide radix sort (sz3hip_sortlists.hip) — index order, the
+    same payload from call to call, and the decoder's values within the bound"""
+    import torch
+    import szh_ref
+    rng = np.random.default_rng(9)
+    a = (np.sin(np.arange(1 << 21) / 5000.0) + rng.normal(0, 2e-4, 1 << 21)).astype(np.float64)
+    a[rng.choice(a.size, 20000, replace=False)] += 5.0  # far deltas on both sides of every spike
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(a).to(dev)
+    conf = sz3_amd.Config(a.size)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.lorenzo, conf.lorenzo2, conf.regression = 1, 0, 0
+    conf.absErrorBound = 1e-6
+    conf.quantbinCnt = 4096
+    dc = sz3_amd.DeviceCompressor(a.size, np.float64)
+    dc.set_deterministic(True)
+    cap = dc.payload_bound_max(a.size) if hasattr(dc, "payload_bound_max") else 4 * dc.payload_bound(a.size)
+    pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+    out = torch.empty_like(d_in)
+    st = torch.cuda.current_stream().cuda_stream
+    blobs = []
+    for _ in range(3):
+        size = dc.compress(conf, d_in.data_ptr(), pl.data_ptr(), cap, st)
+        blobs.append(pl[:size].cpu().numpy().tobytes())
+    h, o, sec = szh_ref.parse(blobs[0])
+    assert h["n_dout"] > 32768, h["n_dout"]
+    assert (np.diff(sec["dout_idx"].astype(np.int64)) > 0).all() and (np.diff(sec["vout_idx"].astype(np.int64)) > 0).all()
+    assert blobs[0] == blobs[1] == blobs[2]
+    dc.decompress(pl.data_ptr(), size, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert float((out - d_in).abs().max()) <= 1e-6

@@ -8,7 +8,7 @@ SRC=sz3hip_kernels.hip
 if [ "$1" = "-s" ]; then SRC=$2; shift 2; fi
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"
 OBJS=""
-for f in sz3hip_kernels.hip sz3hip_interp.hip sz3hip_regress.hip sz3hip_stock.hip sz3hip_api.cpp sz3hip_host.cpp sz3hip_stock_host.cpp sz3hip_comm.cpp sz3hip_h5z.cpp; do
+for f in sz3hip_kernels.hip sz3hip_interp.hip sz3hip_regress.hip sz3hip_stock.hip sz3hip_sortlists.hip sz3hip_api.cpp sz3hip_host.cpp sz3hip_stock_host.cpp sz3hip_comm.cpp sz3hip_h5z.cpp; do
   [ "$f" = "$SRC" ] || OBJS="$OBJS sz3_amd/build/$f.o"
 done
 while [ $# -ge 2 ]; do

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 rm -rf /tmp/pl12
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pl12 -o p -- python $R/tools/blkn_bench.py ${1:-134217728} 1e-3 f32 l12 > $O/l12.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pl12 -o p -- python $R/tools/blkn_bench.py ${1:-134217728} ${2:-1e-3} ${3:-f32} ${4:-l12} > $O/l12.log 2>&1
 f=$(find /tmp/pl12 -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY' | tee $O/l12_stats.txt
 import csv, sys

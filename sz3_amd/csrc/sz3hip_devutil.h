@@ -63,6 +63,24 @@ __device__ __forceinline__ unsigned long long wave_append_slot(bool want, uint64
     return (((unsigned long long)bhi << 32) | blo) + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// the same for a RUN of slots per lane (cnt of them, 0 .. 7, 0 for none): one atomic per wave for all of them — prefix counts from three
+// ballots (one per bit of cnt), so any set of active lanes may call it together. Returns the lane's first slot.
+__device__ __forceinline__ unsigned long long wave_append_run(uint32_t cnt, uint64_t *counter) {
+    const int lane = lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
+    const unsigned long long any = b0 | b1 | b2;
+    if (any == 0) return ~0ull;
+    const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+    const uint32_t before = (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt) + 4u * (uint32_t)__popcll(b2 & lt);
+    const int leader = __ffsll((long long)any) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd((unsigned long long *)counter, (unsigned long long)total);
+    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader);
+    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), leader);
+    return (((unsigned long long)bhi << 32) | blo) + (unsigned long long)before;
+}
+
 template <typename T> struct QTraits;
 template <> struct QTraits<float> {
     using Q = int32_t;

@@ -862,14 +862,25 @@ __device__ __forceinline__ void march_body(const T *__restrict__ in, uint16_t *_
                     *reinterpret_cast<uint2 *>(codes + gi) = pk;
                 }
                 if (__ballot(rare)) {  // some lane has outliers or codes outside the LDS histogram window
+                    {   // the far deltas of the lane's four elements: one atomic per wave for all of them (an atomic per element position
+                        // made rows with a far delta in most waves crawl: same-address atomics run at ~90 per us)
+                        uint32_t nfar = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) nfar += rare && code[i] == 0;
+                        unsigned long long pd = wave_append_run(nfar, p.n_dout);
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            if (rare && code[i] == 0) {
+                                if (pd < p.out_cap) {
+                                    p.dout_idx[pd] = gi + i;
+                                    ((Q *)p.dout_val)[pd] = (Q)delta[i];
+                                }
+                                pd++;
+                            }
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const bool is_dout = rare && code[i] == 0, is_vout = rare && ((badmask >> i) & 1u);
-                        const unsigned long long pd = wave_append_slot(is_dout, p.n_dout);
-                        if (is_dout && pd < p.out_cap) {
-                            p.dout_idx[pd] = gi + i;
-                            ((Q *)p.dout_val)[pd] = (Q)delta[i];
-                        }
+                        const bool is_vout = rare && ((badmask >> i) & 1u);
                         const unsigned long long vm = __ballot(is_vout);
                         if (vm) {
                             oq_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)oq_n);
@@ -1007,14 +1018,21 @@ __device__ __forceinline__ void narrow_rare(NarrowCtx<T> &c, uint64_t gi, const 
     using OQV = typename NarrowCtx<T>::OQV;
     const szk_k1_params &p = *c.p;
     constexpr uint32_t OQ = MarchLds<1, false>::OQ;
+    {   // (one atomic per wave for the four element positions: see the wide form)
+        unsigned long long pd = wave_append_run((uint32_t)__popc(tmask & 15u), p.n_dout);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if ((tmask >> i) & 1u) {
+                if (pd < p.out_cap) {
+                    p.dout_idx[pd] = gi + i;
+                    ((Q *)p.dout_val)[pd] = (Q)delta[i];
+                }
+                pd++;
+            }
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const bool is_dout = (tmask >> i) & 1u, is_vout = (badmask >> i) & 1u;
-        const unsigned long long pd = wave_append_slot(is_dout, p.n_dout);
-        if (is_dout && pd < p.out_cap) {
-            p.dout_idx[pd] = gi + i;
-            ((Q *)p.dout_val)[pd] = (Q)delta[i];
-        }
+        const bool is_vout = (badmask >> i) & 1u;
         const unsigned long long vm = __ballot(is_vout);
         if (vm) {
             c.oq_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.oq_n);
@@ -1029,9 +1047,12 @@ __device__ __forceinline__ void narrow_rare(NarrowCtx<T> &c, uint64_t gi, const 
             }
             c.oq_n += (uint32_t)__popcll(vm);
         }
-        // code 0 (delta outliers) is one address for the whole grid: one atomic per wave
-        const unsigned long long zm = __ballot(is_dout);
-        if (zm && c.lane == __ffsll((long long)zm) - 1) hist_add_ranged(p.hist, p.range, 0u, (unsigned long long)__popcll(zm));
+    }
+    {   // code 0 (delta outliers) is one address for the whole grid: one atomic per wave for the four element positions
+        const uint32_t cnt = (uint32_t)__popc(tmask & 15u);
+        const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u), any = b0 | b1 | b2;
+        if (any && c.lane == __ffsll((long long)any) - 1)
+            hist_add_ranged(p.hist, p.range, 0u, (unsigned long long)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2)));
     }
 }
 // one plane's rows as they come back from memory: halo row y0 - 1 (slot 0) and rows y0 .. y0 + TY - 1 (slots 1 .. TY)

@@ -148,8 +148,10 @@ __device__ __forceinline__ void own_index(const BlkGeom &g, uint32_t t, uint32_t
 // (one address for the whole grid) is counted per wave
 template <uint32_t HW>
 __device__ __forceinline__ void blk_count(uint32_t *lh, const szk_blk_params &p, uint32_t code, bool active) {
+    // (code 0 into the workgroup's own counter behind the window, lh[HW]: one global address for the whole grid took an atomic per wave
+    // with a far delta — 5.8 of the code pass's 6.2 ms on a 1-D f64 series at 1e-6, same-address atomics run at ~90 per us)
     const unsigned long long zm = __ballot(active && code == 0);
-    if (zm && lane_id() == __ffsll((long long)zm) - 1) atomicAdd((unsigned long long *)&p.hist[0], (unsigned long long)__popcll(zm));
+    if (zm && lane_id() == __ffsll((long long)zm) - 1) atomicAdd(&lh[HW], (uint32_t)__popcll(zm));
     // the three codes around the radius are counted per wave (one lane adds the wave's number): at high ratios nearly every lane
     // of a wave has the SAME code, and 64 atomics on one LDS address are 64 serial ones (C4a: 2.1 of the element pass's 2.9 ms)
     bool mine = active && code != 0;
@@ -168,6 +170,7 @@ __device__ __forceinline__ void blk_count(uint32_t *lh, const szk_blk_params &p,
 }
 template <uint32_t HW>
 __device__ __forceinline__ void blk_flush(const uint32_t *lh, const szk_blk_params &p) {
+    if (threadIdx.x == 0 && lh[HW]) atomicAdd((unsigned long long *)&p.hist[0], (unsigned long long)lh[HW]);
     for (uint32_t b = threadIdx.x; b < HW; b += blockDim.x) {
         const uint32_t v = lh[b];
         const uint32_t sym = p.radius - HW / 2 + b;
@@ -570,8 +573,8 @@ template <typename T, uint32_t HW, int CB, int NW>
 __global__ __launch_bounds__(NW * 64) void k_blk_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;
     __shared__ T s_x[NW][CB ? (CB + 2) * (CB + 2) * (CB + 2) : BLK_TILE];
-    __shared__ uint32_t lh[HW];
-    for (uint32_t b = threadIdx.x; b < HW; b += NW * 64) lh[b] = 0;
+    __shared__ uint32_t lh[HW + 1];  // (+ the count of code 0: blk_count)
+    for (uint32_t b = threadIdx.x; b <= HW; b += NW * 64) lh[b] = 0;
     __syncthreads();
     const Lattice<T> lat(p.lat);
     const int lane = lane_id();
@@ -668,8 +671,8 @@ template <typename T, uint32_t HW, int CB, int NW>
 __global__ __launch_bounds__(NW * 64) void k_blk_lorenzo(uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;
     __shared__ Q s_q[NW][CB ? (CB + 2) * (CB + 2) * (CB + 2) : BLK_TILE];
-    __shared__ uint32_t lh[HW];
-    for (uint32_t b = threadIdx.x; b < HW; b += NW * 64) lh[b] = 0;
+    __shared__ uint32_t lh[HW + 1];  // (+ the count of code 0: blk_count)
+    for (uint32_t b = threadIdx.x; b <= HW; b += NW * 64) lh[b] = 0;
     __syncthreads();
     const int lane = lane_id();
     const uint32_t wv = threadIdx.x / WAVE;
@@ -714,10 +717,10 @@ __global__ __launch_bounds__(256) void k_blk_rows(const T *__restrict__ in, uint
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     constexpr int MJ = CB ? CB + 1 : 9;  // rows of a plane the march keeps: the halo row + the block's
-    __shared__ uint32_t lh[HW];
+    __shared__ uint32_t lh[HW + 1];  // (+ the count of code 0: blk_count)
     __shared__ uint16_t s_codes[256 * (CB ? CB * CB : 64)];
     __shared__ uint8_t s_reg[256];
-    for (uint32_t b = threadIdx.x; b < HW; b += 256) lh[b] = 0;
+    for (uint32_t b = threadIdx.x; b <= HW; b += 256) lh[b] = 0;
     __syncthreads();
     const Lattice<T> lat(p.lat);
     const uint64_t d1 = p.d[1], d2 = p.d[2];
@@ -1725,8 +1728,8 @@ template <typename T, uint32_t HW, int NW, bool TWO, bool SELECT>
 __global__ __launch_bounds__(NW * 64) void k_blkn_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks,
                                                       unsigned long long *__restrict__ n_other) {
     using Q = typename QTraits<T>::Q;
-    __shared__ uint32_t lh[HW];
-    for (uint32_t b = threadIdx.x; b < HW; b += NW * 64) lh[b] = 0;
+    __shared__ uint32_t lh[HW + 1];  // (+ the count of code 0: blk_count)
+    for (uint32_t b = threadIdx.x; b <= HW; b += NW * 64) lh[b] = 0;
     __syncthreads();
     const Lattice<T> lat(p.lat);
     const int lane = lane_id();
@@ -1944,8 +1947,8 @@ __device__ __forceinline__ double row16_sum_f64(double v) {  // the sum over the
 template <typename T, uint32_t HW, int NW>
 __global__ __launch_bounds__(NW * 64) void k_blkn_fit_rows(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;
-    __shared__ uint32_t lh[HW];
-    for (uint32_t b = threadIdx.x; b < HW; b += NW * 64) lh[b] = 0;
+    __shared__ uint32_t lh[HW + 1];  // (+ the count of code 0: blk_count)
+    for (uint32_t b = threadIdx.x; b <= HW; b += NW * 64) lh[b] = 0;
     __syncthreads();
     const Lattice<T> lat(p.lat);
     const uint32_t lane = (uint32_t)lane_id(), row = lane >> 4, li = lane & 15u;
@@ -2113,8 +2116,8 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo(const T *__restrict__ in, u
     using UQ = typename QTraits<T>::UQ;
     const Lattice<T> lat(p.lat);
     const bool direct = p.sel_given != 0;
-    __shared__ uint32_t lh[HW];
-    for (uint32_t b = threadIdx.x; b < HW; b += TB) lh[b] = 0;
+    __shared__ uint32_t lh[HW + 1];  // (+ the count of code 0: blk_count)
+    for (uint32_t b = threadIdx.x; b <= HW; b += TB) lh[b] = 0;
     __syncthreads();
     const Q *__restrict__ qw = reinterpret_cast<const Q *>(p.qwork);
     const uint64_t d2 = p.d[2];
@@ -2260,8 +2263,8 @@ template <typename T, uint32_t HW, int TB>
 __global__ __launch_bounds__(TB) void k_blkn_lorenzo1v(uint16_t *__restrict__ codes, szk_blk_params p, uint64_t n) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
-    __shared__ uint32_t lh[HW];
-    for (uint32_t b = threadIdx.x; b < HW; b += TB) lh[b] = 0;
+    __shared__ uint32_t lh[HW + 1];  // (+ the count of code 0: blk_count)
+    for (uint32_t b = threadIdx.x; b <= HW; b += TB) lh[b] = 0;
     __syncthreads();
     const Q *__restrict__ qw = reinterpret_cast<const Q *>(p.qwork);
     const uint64_t stride = (uint64_t)gridDim.x * TB * 4;
@@ -2329,8 +2332,8 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo12v(const T *__restrict__ in
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     const Lattice<T> lat(p.lat);
-    __shared__ uint32_t lh[HW];
-    for (uint32_t b = threadIdx.x; b < HW; b += TB) lh[b] = 0;
+    __shared__ uint32_t lh[HW + 1];  // (+ the count of code 0: blk_count)
+    for (uint32_t b = threadIdx.x; b <= HW; b += TB) lh[b] = 0;
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * TB * 4;
     for (uint64_t c0 = (uint64_t)blockIdx.x * TB * 4; c0 < n; c0 += stride) {  // (workgroup-uniform: every lane takes part in the wave operations)
@@ -2364,6 +2367,8 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo12v(const T *__restrict__ in
             if (bad[j]) q[j] = 0;
         }
         uint32_t code4[4];
+        UQ delta4[4];
+        uint32_t n_far = 0, n_bad = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint64_t cj = c + j;
@@ -2373,13 +2378,70 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo12v(const T *__restrict__ in
             const bool inr = (UQ)(delta + (UQ)(p.radius - 1)) <= (UQ)(2 * p.radius - 2);
             const uint32_t code = inr ? (uint32_t)(delta + (UQ)p.radius) : 0u;
             code4[j] = code;
-            blk_vout<T>(p, act && bad[2 + j], cj, v[2 + j]);  // unpredictable: the raw value (a wave operation, all lanes take part)
+            delta4[j] = delta;
+            n_far += act && !inr;
+            n_bad += act && bad[2 + j];
             blk_count<HW>(lh, p, code, act);
-            const unsigned long long pd = wave_append_slot(act && !inr, p.n_dout);
-            if (act && !inr && pd < p.out_cap) {
-                p.dout_idx[pd] = cj;
-                reinterpret_cast<Q *>(p.dout_val)[pd] = (Q)delta;
+        }
+        // the list appends: ONE atomic per wave and list for the four elements of all its lanes (an atomic per element position made a
+        // series with a far delta in most waves crawl: same-address atomics run at ~90 per us)
+        unsigned long long pd = ~0ull, pv = ~0ull;
+        if (HW > BLK_HWIN) {
+            // the wide form (the context's previous call met a wide alphabet: rough data, or a bound far below the signal's slope — far
+            // deltas in most waves): one atomic per WORKGROUP and list. Two barriers per round of the loop, which every thread takes.
+            __shared__ uint32_t s_cnt[2][2][TB / WAVE];
+            __shared__ unsigned long long s_base[2][2];
+            const uint32_t par = (uint32_t)(((c0 / stride) & 1u)), wv = threadIdx.x / WAVE;
+            const int lane = lane_id();
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            uint32_t pre[2], tot[2];
+            const uint32_t cn[2] = {n_far, n_bad};
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const unsigned long long b0 = __ballot(cn[k] & 1u), b1 = __ballot(cn[k] & 2u), b2 = __ballot(cn[k] & 4u);
+                tot[k] = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+                pre[k] = (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt) + 4u * (uint32_t)__popcll(b2 & lt);
+                if (lane == 0) s_cnt[par][k][wv] = tot[k];
             }
+            __syncthreads();
+            if (threadIdx.x < 2) {
+                uint32_t sum = 0;
+                for (uint32_t w2 = 0; w2 < TB / WAVE; w2++) sum += s_cnt[par][threadIdx.x][w2];
+                s_base[par][threadIdx.x] = sum ? atomicAdd((unsigned long long *)(threadIdx.x ? p.n_vout : p.n_dout), (unsigned long long)sum) : 0ull;
+            }
+            __syncthreads();
+            uint32_t before[2] = {0, 0};
+            for (uint32_t w2 = 0; w2 < wv; w2++) {
+                before[0] += s_cnt[par][0][w2];
+                before[1] += s_cnt[par][1][w2];
+            }
+            pd = s_base[par][0] + before[0] + pre[0];
+            pv = s_base[par][1] + before[1] + pre[1];
+        } else {
+            if (__ballot(n_far != 0)) pd = wave_append_run(n_far, p.n_dout);
+            if (__ballot(n_bad != 0)) pv = wave_append_run(n_bad, p.n_vout);
+        }
+        if (n_far) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (c + j < n && code4[j] == 0) {
+                    if (pd < p.out_cap) {
+                        p.dout_idx[pd] = c + j;
+                        reinterpret_cast<Q *>(p.dout_val)[pd] = (Q)delta4[j];
+                    }
+                    pd++;
+                }
+        }
+        if (n_bad) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (c + j < n && bad[2 + j]) {
+                    if (pv < p.out_cap) {
+                        p.vout_idx[pv] = c + j;
+                        reinterpret_cast<T *>(p.vout_val)[pv] = v[2 + j];
+                    }
+                    pv++;
+                }
         }
         if (any) {
             if (c + 3 < n) {
@@ -3393,8 +3455,8 @@ __device__ __forceinline__ void coef_recover4(const int64_t *lc, const CoefLat &
 template <typename T, uint32_t HW, int NW>
 __global__ __launch_bounds__(NW * 64) void k_blk4_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
     using Q = typename QTraits<T>::Q;
-    __shared__ uint32_t lh[HW];
-    for (uint32_t b = threadIdx.x; b < HW; b += NW * 64) lh[b] = 0;
+    __shared__ uint32_t lh[HW + 1];  // (+ the count of code 0: blk_count)
+    for (uint32_t b = threadIdx.x; b <= HW; b += NW * 64) lh[b] = 0;
     __syncthreads();
     const Lattice<T> lat(p.lat);
     const int lane = lane_id();
@@ -3562,8 +3624,8 @@ template <typename T, uint32_t HW, int TB>
 __global__ __launch_bounds__(TB) void k_blk4_lorenzo(uint16_t *__restrict__ codes, szk_blk_params p, uint64_t n) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
-    __shared__ uint32_t lh[HW];
-    for (uint32_t b = threadIdx.x; b < HW; b += TB) lh[b] = 0;
+    __shared__ uint32_t lh[HW + 1];  // (+ the count of code 0: blk_count)
+    for (uint32_t b = threadIdx.x; b <= HW; b += TB) lh[b] = 0;
     __syncthreads();
     const Q *__restrict__ qw = reinterpret_cast<const Q *>(p.qwork);
     const uint64_t stride = (uint64_t)gridDim.x * TB;

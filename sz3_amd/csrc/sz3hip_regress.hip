@@ -1606,6 +1606,284 @@ __global__ __launch_bounds__(512) void k_blk_decode_g(const uint16_t *__restrict
     }
 }
 
+// ---- round 4: a group decoded without recurrences on its critical path -------------------------------------------------------------
+// On the lattice a Lorenzo block is linear and exact (integers mod 2^32 / 2^64), so its inverse splits: with D = Dz Dy Dx the block's
+// stencil (order m per dimension) and E_d the operator that continues a line's two halo values into the block along dimension d
+// (E f(i) = a_m(i) f(-1) + b_m(i) f(-2); first order: a = 1, b = 0; second order: a = i + 2, b = -(i + 1)),
+//     q = P + [I - (I - Ez)(I - Ey)(I - Ex)] q,       P = the block inverted with a ZERO halo,
+// because (I - E_d) q = D_d^-1 (zero inflow) D_d q along every line and operators of different dimensions commute. P needs nothing but
+// the block's own deltas: k_blk_local3 computes it for every block of the array at once, before the fronts. What is left inside the
+// chain of fronts is the bracket: 7 (first order) or 26 (second order) halo values with small integer weights per element, no
+// dependency between the elements of a block. A group takes its faces first, step by step (the two top layers of a block in every
+// dimension are what its upper neighbours read), and all the interiors after the last step. The inner step: 2.4 us of three
+// line-scan passes -> a few hundred cycles; which lets a group be 3 x 3 x 3 blocks (seven inner steps, 121 fronts at C4's slab instead
+// of 181). Same values bit for bit: both forms are the same sums mod 2^w (tests/test_gpu_regression.py::
+// test_grouped_and_per_block_decoders_agree takes all three decoders).
+template <typename T, int CB>
+__global__ __launch_bounds__(256) void k_blk_local3(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks,
+                                                    const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
+    using Q = typename QTraits<T>::Q;
+    constexpr uint32_t E = CB + 2;
+    __shared__ Q s_q[4][E * E * E];
+    const Lattice<T> lat(p.lat);
+    const int lane = lane_id();
+    const uint32_t wv = threadIdx.x / WAVE;
+    Q *sq = s_q[wv];
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    Q *qout = reinterpret_cast<Q *>(d_out);
+    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
+    for (uint32_t t = lane; t < E * E * E; t += WAVE) sq[t] = 0;  // (the halo stays zero: the passes write own positions only)
+    const TileView tv{E * E, E, 0};
+    for (uint32_t task = blockIdx.x * 4 + wv; task < nblocks; task += gridDim.x * 4) {
+        const int sid = (int)p.sel[task];
+        const BlkGeom g = blk_geom(p, task);
+        const uint32_t nown = g.ez * g.ey * g.ex;
+        if (sid == 2) {  // regression: the lattice value the neighbours will predict from (k_blk_pre3's part)
+            T rc[4];
+            coef_recover(coef_by_rank + (uint64_t)rank[task] * 4, cl, rc);
+            for (uint32_t t = lane; t < nown; t += WAVE) {
+                uint32_t i0, i1, i2;
+                own_index<CB>(g, t, i0, i1, i2);
+                const uint32_t code = codes[g.coff + t];
+                Q qt = 0;
+                if (code) {
+                    bool bad;
+                    qt = lat.quant(ref_recover(reg_predict(rc, i0, i1, i2), (int)code, p.eb, (int)p.radius), bad);
+                    if (bad) qt = 0;
+                }
+                qout[((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2)] = qt;
+            }
+            continue;
+        }
+        for (uint32_t t = lane; t < nown; t += WAVE) {
+            uint32_t i0, i1, i2;
+            own_index<CB>(g, t, i0, i1, i2);
+            sq[tv_at(tv, i0 + 2, i1 + 2, i2 + 2)] = deltas[g.coff + t];
+        }
+        if (sid == 1) blk_invert<T, CB, 2>(sq, sq, qout, g, tv, d1, d2, lane, false);
+        else blk_invert<T, CB, 1>(sq, sq, qout, g, tv, d1, d2, lane, false);
+        wave_lds_fence();
+    }
+}
+// the bracket of the identity above for one element (i0, i1, i2) of the block whose origin sits at tile coordinate (oz, oy, ox); P is
+// read from the element's own position
+template <int ORDER, typename Q, typename UQ>
+__device__ __forceinline__ UQ blk_closed(const Q *s, uint32_t TE, uint32_t oz, uint32_t oy, uint32_t ox, uint32_t i0, uint32_t i1, uint32_t i2) {
+    const uint32_t cz[3] = {(oz + i0) * TE * TE, (oz - 1) * TE * TE, (oz - 2) * TE * TE};
+    const uint32_t cy[3] = {(oy + i1) * TE, (oy - 1) * TE, (oy - 2) * TE};
+    const uint32_t cx[3] = {ox + i2, ox - 1, ox - 2};
+    const int wz[3] = {1, ORDER == 2 ? (int)i0 + 2 : 1, -((int)i0 + 1)};
+    const int wy[3] = {1, ORDER == 2 ? (int)i1 + 2 : 1, -((int)i1 + 1)};
+    const int wx[3] = {1, ORDER == 2 ? (int)i2 + 2 : 1, -((int)i2 + 1)};
+    UQ acc = (UQ)s[cz[0] + cy[0] + cx[0]];
+#pragma unroll
+    for (int a = 0; a <= ORDER; a++)
+#pragma unroll
+        for (int b = 0; b <= ORDER; b++)
+#pragma unroll
+            for (int c = 0; c <= ORDER; c++) {
+                if ((a | b | c) == 0) continue;
+                const int members = (a != 0) + (b != 0) + (c != 0);
+                const int w = wz[a] * wy[b] * wx[c] * ((members & 1) ? 1 : -1);
+                acc += (UQ)((Q)w * s[cz[a] + cy[b] + cx[c]]);
+            }
+    return acc;
+}
+template <typename T, int CB, int G>
+__global__ __launch_bounds__(512, 4) void k_blk_decode_gf(void *d_out, szk_blk_params p, uint32_t diag, uint32_t gz_lo, uint32_t npairs) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    constexpr uint32_t TE = G * CB + 2, NT = TE * TE * TE, NB = G * G * G, CB3 = CB * CB * CB;
+    constexpr int NH = (NT + 511) / 512;
+    __shared__ Q s_q[NT];
+    __shared__ uint8_t s_sel[NB];     // a block's choice; 255: no such block
+    __shared__ uint8_t s_list[CB3];   // the elements of a block: faces first, then the interior
+    __shared__ uint32_t s_nface;
+    __shared__ uint8_t s_order[NB];          // the group's blocks by inner front (lz + ly + lx), ...
+    __shared__ uint8_t s_first[3 * G];       // ... and where each front starts in that list
+    const int lane = lane_id();
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    Q *qout = reinterpret_cast<Q *>(d_out);
+    const uint32_t ng0 = (p.nb[0] + G - 1) / G, ng1 = (p.nb[1] + G - 1) / G, ng2 = (p.nb[2] + G - 1) / G;
+    const uint32_t pair = blockIdx.x;
+    if (pair >= npairs) return;
+    const uint32_t gz = gz_lo + pair / ng1, gy = pair % ng1;
+    if (gz >= ng0 || gz + gy > diag || diag - gz - gy >= ng2) return;  // (workgroup-uniform)
+    const uint32_t gx = diag - gz - gy;
+    const int64_t z0 = (int64_t)gz * G * CB - 2, y0 = (int64_t)gy * G * CB - 2, x0 = (int64_t)gx * G * CB - 2;
+    // ---- ONE round trip: every tile position from the array (halo: finished lattice values; own positions: P of a Lorenzo block,
+    // the lattice value of a regression block — both written by k_blk_local3), the blocks' choices beside them ----
+    Q val[NH];
+    uint8_t my_sel = 255;
+    if (threadIdx.x < NB) {
+        const uint32_t lz = threadIdx.x / (G * G), ly = (threadIdx.x / G) % G, lx = threadIdx.x % G;
+        const uint32_t bz = G * gz + lz, by = G * gy + ly, bx = G * gx + lx;
+        if (bz < p.nb[0] && by < p.nb[1] && bx < p.nb[2]) my_sel = p.sel[(bz * p.nb[1] + by) * p.nb[2] + bx];
+    }
+    // A thread's positions t = threadIdx.x + 512 k, walked by increments (the divisions by the tile's edge and the 64-bit products per
+    // position were most of a lone group's 8 us of loading and storing). Unconditional loads, the choice afterwards: a load under a
+    // branch is waited for before the next one is issued.
+    constexpr uint32_t DX = 512u % TE, DY = (512u / TE) % TE, DZ = 512u / (TE * TE);
+    const uint32_t zlo = z0 < 0 ? 2u : 0u, ylo = y0 < 0 ? 2u : 0u, xlo = x0 < 0 ? 2u : 0u;
+    const uint32_t zn = (uint32_t)min((int64_t)TE, (int64_t)p.d[0] - z0) - zlo, yn = (uint32_t)min((int64_t)TE, (int64_t)d1 - y0) - ylo,
+                   xn = (uint32_t)min((int64_t)TE, (int64_t)d2 - x0) - xlo;
+    const uint64_t pz = d1 * d2;
+    const int64_t g0 = (z0 * (int64_t)d1 + y0) * (int64_t)d2 + x0;
+    struct Pos {
+        uint32_t tz, ty, tx;
+    };
+    auto pos0 = [&](uint32_t t) { return Pos{t / (TE * TE), (t / TE) % TE, t % TE}; };
+    auto advance = [&](Pos &q) {
+        q.tx += DX;
+        const uint32_t cx = q.tx >= TE ? 1u : 0u;
+        q.tx -= cx * TE;
+        q.ty += DY + cx;
+        const uint32_t cy = q.ty >= TE ? 1u : 0u;
+        q.ty -= cy * TE;
+        q.tz += DZ + cy;
+    };
+    auto inside = [&](const Pos &q) { return q.tz - zlo < zn && q.ty - ylo < yn && q.tx - xlo < xn; };  // (tz >= TE: beyond the tile, zn <= TE - zlo)
+    auto gindex = [&](const Pos &q) { return (uint64_t)(g0 + (int64_t)((uint64_t)q.tz * pz + (uint64_t)q.ty * d2 + q.tx)); };
+    {
+        Pos q = pos0(threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < NH; k++) {
+#if defined(LAB_GF) && LAB_GF == 5
+            val[k] = p.B ? (Q)k : qout[inside(q) ? gindex(q) : 0];
+#else
+            val[k] = qout[inside(q) ? gindex(q) : 0];
+#endif
+            advance(q);
+        }
+    }
+    // the element order of a block: which of its CB^3 positions are faces (the top `nl` layers of any dimension). One wave compacts.
+    const uint32_t nl = (p.mask & 2u) ? 2u : 1u;
+    if (wv == 7) {
+        uint32_t nf = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            for (uint32_t t0 = 0; t0 < CB3; t0 += WAVE) {
+                const uint32_t t = t0 + lane;
+                const uint32_t i2 = t % CB, i1 = (t / CB) % CB, i0 = t / (CB * CB);
+                const bool face = i0 + nl >= (uint32_t)CB || i1 + nl >= (uint32_t)CB || i2 + nl >= (uint32_t)CB;
+                const bool want = t < CB3 && (pass == 0 ? face : !face);
+                const unsigned long long m = __ballot(want);
+                if (want) s_list[nf + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)t;
+                nf += (uint32_t)__popcll(m);
+            }
+            if (pass == 0 && lane == 0) s_nface = nf;
+        }
+    }
+    if (threadIdx.x < NB) {
+        s_sel[threadIdx.x] = my_sel;
+        const uint32_t mine = threadIdx.x / (G * G) + (threadIdx.x / G) % G + threadIdx.x % G;
+        uint32_t before = 0;
+        for (uint32_t o = 0; o < NB; o++) {
+            const uint32_t so = o / (G * G) + (o / G) % G + o % G;
+            before += (so < mine || (so == mine && o < threadIdx.x)) ? 1u : 0u;
+        }
+        s_order[before] = (uint8_t)threadIdx.x;
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + 3 * G) {
+        const uint32_t st = threadIdx.x - 64;
+        uint32_t before = 0;
+        for (uint32_t o = 0; o < NB; o++) before += (o / (G * G) + (o / G) % G + o % G < st) ? 1u : 0u;
+        s_first[st] = (uint8_t)before;
+    }
+    {
+        uint32_t t0 = threadIdx.x;
+        asm volatile("" : "+v"(t0));  // (walked again, not carried in registers from the loads: sixteen positions' worth of them)
+        Pos q = pos0(t0);
+#pragma unroll
+        for (int k = 0; k < NH; k++) {
+            if (q.tz < TE) s_q[t0 + 512u * k] = inside(q) ? val[k] : (Q)0;
+            advance(q);
+        }
+    }
+    __syncthreads();
+
+    const uint32_t nface = s_nface;
+    const uint32_t frounds = (nface + WAVE - 1) / WAVE, irounds = (CB3 - nface + WAVE - 1) / WAVE;
+    // one (block, round of 64 elements) item: the value and where it goes (false: nothing to write). Items are taken two (faces) or
+    // four (interiors) at a time, all their reads before the first write: an item alone is a chain of four dependent LDS round trips
+    auto gather = [&](uint32_t b, uint32_t first, uint32_t last, uint32_t &dst, UQ &v) {
+        const uint32_t lz = b / (G * G), ly = (b / G) % G, lx = b % G;
+        const uint32_t sid = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sel[b]);  // (a scalar: the two orders are branches, not both computed)
+        const uint32_t e = first + (uint32_t)lane;
+        const uint32_t t = s_list[e < last ? e : first];
+        const uint32_t i2 = t % CB, i1 = (t / CB) % CB, i0 = t / (CB * CB);
+        const uint32_t oz = lz * CB + 2, oy = ly * CB + 2, ox = lx * CB + 2;
+        dst = ((oz + i0) * TE + (oy + i1)) * TE + (ox + i2);
+        v = 0;
+        if (sid > 1 || e >= last) return false;  // regression (its values are final) / no block / no element
+        // (positions beyond a ragged block's extents hold zeros from outside the array: computed like the rest, never stored)
+        if (sid == 1) v = blk_closed<2, Q, UQ>(s_q, TE, oz, oy, ox, i0, i1, i2);
+        else v = blk_closed<1, Q, UQ>(s_q, TE, oz, oy, ox, i0, i1, i2);
+        return true;
+    };
+    // ---- the faces, inner front by inner front: the (block, round) items of a step go round the eight waves ----
+#if defined(LAB_GF) && (LAB_GF == 3 || LAB_GF == 1 || LAB_GF >= 4)  // (lab builds: what a front's time is made of; results wrong)
+    if (p.B == 0)
+#endif
+    for (uint32_t step = 0; step <= 3u * (G - 1); step++) {
+        const uint32_t b0 = s_first[step], nitems = (s_first[step + 1] - b0) * frounds;
+        for (uint32_t it = wv; it < nitems; it += 16) {
+            uint32_t dst[2];
+            UQ v[2];
+            bool w[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t iu = it + 8u * u;
+                const bool have = iu < nitems;
+                const uint32_t ic = have ? iu : it, r = ic % frounds;
+                w[u] = gather((uint32_t)__builtin_amdgcn_readfirstlane((int)s_order[b0 + ic / frounds]), r * WAVE, min(nface, (r + 1) * WAVE), dst[u], v[u]) && have;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (w[u]) s_q[dst[u]] = (Q)v[u];
+        }
+        __syncthreads();
+    }
+    // ---- the interiors: every block at once ----
+#if defined(LAB_GF) && (LAB_GF == 2 || LAB_GF == 1 || LAB_GF >= 4)
+    if (p.B == 0)
+#endif
+    for (uint32_t it = wv; it < NB * irounds; it += 32) {
+        uint32_t dst[4];
+        UQ v[4];
+        bool w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t iu = it + 8u * u;
+            const bool have = iu < NB * irounds;
+            const uint32_t ic = have ? iu : it, r = ic % irounds;
+            w[u] = gather(ic / irounds, nface + r * WAVE, min((uint32_t)CB3, nface + (r + 1) * WAVE), dst[u], v[u]) && have;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (w[u]) s_q[dst[u]] = (Q)v[u];
+    }
+    __syncthreads();
+    // ---- out: the Lorenzo blocks' lattice values, rows of the tile ----
+    {
+        uint32_t t0 = threadIdx.x;
+        asm volatile("" : "+v"(t0));
+        Pos q = pos0(t0);
+#pragma unroll
+        for (int k = 0; k < NH; k++) {
+            if (inside(q) && q.tz >= 2 && q.ty >= 2 && q.tx >= 2) {
+                const uint32_t b = (((q.tz - 2) / CB) * G + (q.ty - 2) / CB) * G + (q.tx - 2) / CB;
+#if defined(LAB_GF) && LAB_GF == 4
+                if (s_sel[b] <= 1 && s_q[t0 + 512u * k] == 0x5a5a5a5a) qout[gindex(q)] = s_q[t0 + 512u * k];
+#else
+                if (s_sel[b] <= 1) qout[gindex(q)] = s_q[t0 + 512u * k];
+#endif
+            }
+            advance(q);
+        }
+    }
+}
+
 // final pass: lattice value -> T for Lorenzo blocks; regression blocks are recomputed from their codes (their value is
 // pred + 2*code*eb, not a lattice point). (Measured and dropped, round 3: the same pass by rows of the array — a thread per x, whole
 // rows read and written instead of segments of B values — 831 against 807 us at C4a's slab.)
@@ -4228,7 +4506,25 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
             }
         }
     } else
-    if (p->B == 6 && !(szk_dbg_flags & 8388608)) {  // groups of 2 x 2 x 2 blocks per workgroup (debug flag 8388608: a block per wave)
+    if (p->B == 6 && (szk_dbg_flags & 32768)) {  // debug flag 32768: groups of 3 x 3 x 3 blocks per workgroup, closed form, a launch per front (k_blk_decode_gf)
+        constexpr uint32_t G = 3;
+        const uint32_t ng0 = (p->nb[0] + G - 1) / G, ng1 = (p->nb[1] + G - 1) / G, ng2 = (p->nb[2] + G - 1) / G;
+        const uint32_t ngd = ng0 + ng1 + ng2 - 2;
+        {
+            const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
+            if (dtype == 0) hipLaunchKernelGGL((k_blk_local3<float, 6>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+            else hipLaunchKernelGGL((k_blk_local3<double, 6>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+        }
+        for (uint32_t d = 0; d < ngd; d++) {
+            const uint32_t rest = (ng1 - 1) + (ng2 - 1);
+            const uint32_t gz_lo = d > rest ? d - rest : 0, gz_hi = d < ng0 - 1 ? d : ng0 - 1;
+            if (gz_lo > gz_hi) continue;
+            const uint32_t npairs = (gz_hi - gz_lo + 1) * ng1;
+            if (dtype == 0) hipLaunchKernelGGL((k_blk_decode_gf<float, 6, 3>), dim3(npairs), dim3(512), 0, s, d_out, *p, d, gz_lo, npairs);
+            else hipLaunchKernelGGL((k_blk_decode_gf<double, 6, 3>), dim3(npairs), dim3(512), 0, s, d_out, *p, d, gz_lo, npairs);
+        }
+    } else
+    if (p->B == 6 && !(szk_dbg_flags & 8388608)) {  // round 3's form (debug flag 65536): groups of 2 x 2 x 2 blocks, line scans (debug flag 8388608: a block per wave)
         const uint32_t ng0 = (p->nb[0] + 1) / 2, ng1 = (p->nb[1] + 1) / 2, ng2 = (p->nb[2] + 1) / 2;
         const uint32_t ngd = ng0 + ng1 + ng2 - 2;
         {

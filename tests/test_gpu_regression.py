@@ -210,24 +210,27 @@ def test_predictor_sets_outside_the_block_path():
     assert (c2.lorenzo, c2.lorenzo2, c2.regression) == (1, 0, 0)
 
 
-@pytest.mark.parametrize("shape", [(37, 50, 66), (12, 13, 100), (6, 6, 6)], ids=["ragged", "thin", "one-block"])
+@pytest.mark.parametrize("shape", [(37, 50, 66), (12, 13, 100), (6, 6, 6), (19, 7, 40), (54, 36, 18)], ids=["ragged", "thin", "one-block", "ragged-2", "whole-groups"])
 def test_grouped_and_per_block_decoders_agree(shape):
-    """blocks of 6^3 are decoded in groups of 2 x 2 x 2 per workgroup (inner fronts through a shared LDS tile); debug flag 8388608
-    takes the block-per-wave fronts: same array, bit for bit, on shapes with ragged and missing blocks in the last groups"""
-    a = field3d(shape, np.float32)
-    a[shape[0] // 2:, :, :] += 3.0
-    for mask in ("L1+R", "L1+L2+R"):
-        blob, _ = sz3_amd.compress(a, _conf(shape, 1e-3, *MASKS[mask]))
-        outs = []
-        try:
-            for flag in (0, 8388608):
-                sz3_amd.lib().sz3hip_debug_flags(flag)
-                dec, c2 = sz3_amd.decompress(blob, np.float32, shape)
-                outs.append(dec)
-        finally:
-            sz3_amd.lib().sz3hip_debug_flags(0)
-        assert np.array_equal(outs[0], outs[1])
-        assert float(np.max(np.abs(outs[0].astype(np.float64) - a.astype(np.float64)))) <= 1e-3
+    """blocks of 6^3 are decoded in groups of 3 x 3 x 3 per workgroup in closed form (k_blk_local3 + k_blk_decode_gf: a block inverted
+    with a zero halo, then 7 / 26 halo terms per element); debug flag 65536 takes round 3's groups of 2 x 2 x 2 with line scans through
+    a shared LDS tile, 8388608 the block-per-wave fronts: same array, bit for bit, on shapes with ragged and missing blocks in the
+    last groups"""
+    for dtype in (np.float32, np.float64):
+        a = field3d(shape, dtype)
+        a[shape[0] // 2:, :, :] += 3.0
+        for mask in ("L1+R", "L1+L2+R"):
+            blob, _ = sz3_amd.compress(a, _conf(shape, 1e-3, *MASKS[mask]))
+            outs = []
+            try:
+                for flag in (0, 32768, 65536, 8388608):
+                    sz3_amd.lib().sz3hip_debug_flags(flag)
+                    dec, c2 = sz3_amd.decompress(blob, dtype, shape)
+                    outs.append(dec)
+            finally:
+                sz3_amd.lib().sz3hip_debug_flags(0)
+            assert all(np.array_equal(outs[0], o) for o in outs[1:])
+            assert float(np.max(np.abs(outs[0].astype(np.float64) - a.astype(np.float64)))) <= 1e-3
 
 
 @pytest.mark.plain_exit

@@ -112,6 +112,20 @@ struct BlkGeom {
                           // block's codes are one contiguous run, and the lossless stage finds 15 % more in that order
                           // (C2 field at 5e-2, regression: zstd of the Huffman stream 138 -> 118 KB)
 };
+__device__ __forceinline__ BlkGeom blk_geom_at(const szk_blk_params &p, uint32_t bz, uint32_t by, uint32_t bx) {
+    BlkGeom g;
+    g.bz = bz;
+    g.by = by;
+    g.bx = bx;
+    g.oz = g.bz * p.B;
+    g.oy = g.by * p.B;
+    g.ox = g.bx * p.B;
+    g.ez = min(p.B, (uint32_t)p.d[0] - g.oz);
+    g.ey = min(p.B, (uint32_t)p.d[1] - g.oy);
+    g.ex = min(p.B, (uint32_t)p.d[2] - g.ox);
+    g.coff = (uint64_t)g.oz * p.d[1] * p.d[2] + (uint64_t)g.ez * ((uint64_t)g.oy * p.d[2] + (uint64_t)g.ey * g.ox);
+    return g;
+}
 __device__ __forceinline__ BlkGeom blk_geom(const szk_blk_params &p, uint32_t task) {
     BlkGeom g;
     g.bx = task % p.nb[2];
@@ -1619,8 +1633,10 @@ __global__ __launch_bounds__(512) void k_blk_decode_g(const uint16_t *__restrict
 // line-scan passes -> a few hundred cycles; which lets a group be 3 x 3 x 3 blocks (seven inner steps, 121 fronts at C4's slab instead
 // of 181). Same values bit for bit: both forms are the same sums mod 2^w (tests/test_gpu_regression.py::
 // test_grouped_and_per_block_decoders_agree takes all three decoders).
-template <typename T, int CB>
-__global__ __launch_bounds__(256) void k_blk_local3(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks,
+// WORK: the results stay in the work array, in the codes' order (P over the deltas, a regression block's lattice values over its
+// slots: what k_blk_wave3 reads), and a regression block's final values go to the output
+template <typename T, int CB, bool WORK>
+__global__ __launch_bounds__(256) void k_blk_local3(const uint16_t *__restrict__ codes, void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks,
                                                     const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
     using Q = typename QTraits<T>::Q;
     constexpr uint32_t E = CB + 2;
@@ -1631,7 +1647,8 @@ __global__ __launch_bounds__(256) void k_blk_local3(const uint16_t *__restrict__
     Q *sq = s_q[wv];
     const uint64_t d1 = p.d[1], d2 = p.d[2];
     Q *qout = reinterpret_cast<Q *>(d_out);
-    const Q *deltas = reinterpret_cast<const Q *>(deltas_);
+    T *tout = reinterpret_cast<T *>(d_out);
+    Q *deltas = reinterpret_cast<Q *>(deltas_);
     const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
     for (uint32_t t = lane; t < E * E * E; t += WAVE) sq[t] = 0;  // (the halo stays zero: the passes write own positions only)
     const TileView tv{E * E, E, 0};
@@ -1647,12 +1664,18 @@ __global__ __launch_bounds__(256) void k_blk_local3(const uint16_t *__restrict__
                 own_index<CB>(g, t, i0, i1, i2);
                 const uint32_t code = codes[g.coff + t];
                 Q qt = 0;
+                T val = 0;  // (code 0: patched from the list)
                 if (code) {
                     bool bad;
-                    qt = lat.quant(ref_recover(reg_predict(rc, i0, i1, i2), (int)code, p.eb, (int)p.radius), bad);
+                    val = ref_recover(reg_predict(rc, i0, i1, i2), (int)code, p.eb, (int)p.radius);
+                    qt = lat.quant(val, bad);
                     if (bad) qt = 0;
                 }
-                qout[((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2)] = qt;
+                const uint64_t gi = ((uint64_t)(g.oz + i0) * d1 + (g.oy + i1)) * d2 + (g.ox + i2);
+                if (WORK) {
+                    deltas[g.coff + t] = qt;
+                    tout[gi] = val;
+                } else qout[gi] = qt;
             }
             continue;
         }
@@ -1661,8 +1684,15 @@ __global__ __launch_bounds__(256) void k_blk_local3(const uint16_t *__restrict__
             own_index<CB>(g, t, i0, i1, i2);
             sq[tv_at(tv, i0 + 2, i1 + 2, i2 + 2)] = deltas[g.coff + t];
         }
-        if (sid == 1) blk_invert<T, CB, 2>(sq, sq, qout, g, tv, d1, d2, lane, false);
-        else blk_invert<T, CB, 1>(sq, sq, qout, g, tv, d1, d2, lane, false);
+        if (sid == 1) blk_invert<T, CB, 2>(sq, sq, qout, g, tv, d1, d2, lane, WORK);
+        else blk_invert<T, CB, 1>(sq, sq, qout, g, tv, d1, d2, lane, WORK);
+        wave_lds_fence();
+        if (WORK)
+            for (uint32_t t = lane; t < nown; t += WAVE) {
+                uint32_t i0, i1, i2;
+                own_index<CB>(g, t, i0, i1, i2);
+                deltas[g.coff + t] = sq[tv_at(tv, i0 + 2, i1 + 2, i2 + 2)];
+            }
         wave_lds_fence();
     }
 }
@@ -1880,6 +1910,281 @@ __global__ __launch_bounds__(512, 4) void k_blk_decode_gf(void *d_out, szk_blk_p
 #endif
             }
             advance(q);
+        }
+    }
+}
+
+// ---- round 4: the whole chain of fronts in ONE launch ------------------------------------------------------------------------------
+// A launch per front costs ~9 us whatever the front does (120 of them: 1.1 ms of the C4a slab's decompression, and the wide fronts wait
+// for their slowest group). Here the groups are handed out by a ticket counter in the fronts' order (slot = position in the
+// enumeration front by front; a slot without a group is skipped) to workgroups that stay: a group waits for the flags of its seven
+// lower neighbours, and every group it can wait for holds a smaller ticket — taken by a workgroup that is running — so the waits end
+// (the poll is bounded all the same: ctl[1] is raised, and the array comes out wrong, should a flag never arrive). What travels
+// between groups is a group's outer shell (the two top layers of lattice values in every dimension), written over its P in the work
+// array, in the codes' order, released with the group's flag; everything else a group computes goes out as final values (no
+// k_blk_final pass over the array). k_blk_local3<WORK> ran before: P of every Lorenzo block and the lattice values of the regression
+// blocks are in the work array, the regression blocks' final values in the output.
+// ctl: [0] ticket, [1] a wait gave up, [4 ...] the groups' flags (zeroed by the caller).
+template <typename T, int CB, int G>
+__global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, szk_blk_params p, uint32_t *ctl, uint32_t nslots) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    constexpr uint32_t TE = G * CB + 2, NT = TE * TE * TE, NB = G * G * G, CB3 = CB * CB * CB;
+    constexpr int NH = (NT + 511) / 512;
+    constexpr uint32_t HZ = 2 * TE * TE, HY = (TE - 2) * 2 * TE, HX = (TE - 2) * (TE - 2) * 2, NHALO = HZ + HY + HX;
+    constexpr int NHL = (NHALO + 511) / 512;
+    __shared__ Q s_q[NT];
+    __shared__ uint8_t s_sel[NB];
+    __shared__ uint8_t s_list[CB3];
+    __shared__ uint32_t s_nface, s_ticket;
+    __shared__ uint8_t s_order[NB];
+    __shared__ uint8_t s_first[3 * G];
+    const Lattice<T> lat(p.lat);
+    const int lane = lane_id();
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    Q *work = reinterpret_cast<Q *>(work_);
+    T *tout = reinterpret_cast<T *>(d_out);
+    uint32_t *flags = ctl + 4;
+    const uint32_t ng0 = (p.nb[0] + G - 1) / G, ng1 = (p.nb[1] + G - 1) / G, ng2 = (p.nb[2] + G - 1) / G;
+    const uint32_t nl = (p.mask & 2u) ? 2u : 1u;
+    // ---- once: the element order of a block (faces first), the blocks of a group by inner front ----
+    if (wv == 7) {
+        uint32_t nf = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            for (uint32_t t0 = 0; t0 < CB3; t0 += WAVE) {
+                const uint32_t t = t0 + lane;
+                const uint32_t i2 = t % CB, i1 = (t / CB) % CB, i0 = t / (CB * CB);
+                const bool face = i0 + nl >= (uint32_t)CB || i1 + nl >= (uint32_t)CB || i2 + nl >= (uint32_t)CB;
+                const bool want = t < CB3 && (pass == 0 ? face : !face);
+                const unsigned long long m = __ballot(want);
+                if (want) s_list[nf + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)t;
+                nf += (uint32_t)__popcll(m);
+            }
+            if (pass == 0 && lane == 0) s_nface = nf;
+        }
+    }
+    if (threadIdx.x < NB) {
+        const uint32_t mine = threadIdx.x / (G * G) + (threadIdx.x / G) % G + threadIdx.x % G;
+        uint32_t before = 0;
+        for (uint32_t o = 0; o < NB; o++) {
+            const uint32_t so = o / (G * G) + (o / G) % G + o % G;
+            before += (so < mine || (so == mine && o < threadIdx.x)) ? 1u : 0u;
+        }
+        s_order[before] = (uint8_t)threadIdx.x;
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + 3 * G) {
+        const uint32_t st = threadIdx.x - 64;
+        uint32_t before = 0;
+        for (uint32_t o = 0; o < NB; o++) before += (o / (G * G) + (o / G) % G + o % G < st) ? 1u : 0u;
+        s_first[st] = (uint8_t)before;
+    }
+    __syncthreads();
+    const uint32_t nface = s_nface;
+    const uint32_t frounds = (nface + WAVE - 1) / WAVE, irounds = (CB3 - nface + WAVE - 1) / WAVE;
+    auto gather = [&](uint32_t b, uint32_t first, uint32_t last, uint32_t &dst, UQ &v) {
+        const uint32_t lz = b / (G * G), ly = (b / G) % G, lx = b % G;
+        const uint32_t sid = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sel[b]);
+        const uint32_t e = first + (uint32_t)lane;
+        const uint32_t t = s_list[e < last ? e : first];
+        const uint32_t i2 = t % CB, i1 = (t / CB) % CB, i0 = t / (CB * CB);
+        const uint32_t oz = lz * CB + 2, oy = ly * CB + 2, ox = lx * CB + 2;
+        dst = ((oz + i0) * TE + (oy + i1)) * TE + (ox + i2);
+        v = 0;
+        if (sid > 1 || e >= last) return false;
+        if (sid == 1) v = blk_closed<2, Q, UQ>(s_q, TE, oz, oy, ox, i0, i1, i2);
+        else v = blk_closed<1, Q, UQ>(s_q, TE, oz, oy, ox, i0, i1, i2);
+        return true;
+    };
+    // the fronts' enumeration: front dd holds (gz_hi - gz_lo + 1) * ng1 slots (gz, gy), gx = dd - gz - gy where that is a group
+    auto front_slots = [&](uint32_t dd, uint32_t &gz_lo) {
+        const uint32_t rest = (ng1 - 1) + (ng2 - 1);
+        gz_lo = dd > rest ? dd - rest : 0;
+        const uint32_t gz_hi = dd < ng0 - 1 ? dd : ng0 - 1;
+        return gz_lo > gz_hi ? 0u : (gz_hi - gz_lo + 1) * ng1;
+    };
+    uint32_t dcur = 0, start = 0;  // this workgroup's place in the enumeration: its tickets only grow
+    for (;;) {
+        __syncthreads();  // (the tile and s_ticket are free again)
+        if (threadIdx.x == 0) s_ticket = atomicAdd(&ctl[0], 1u);
+        __syncthreads();
+        const uint32_t ticket = s_ticket;
+        if (ticket >= nslots) break;
+        uint32_t gz_lo, cnt;
+        while (ticket >= start + (cnt = front_slots(dcur, gz_lo))) {
+            start += cnt;
+            dcur++;
+        }
+        const uint32_t pair = ticket - start;
+        const uint32_t gz = gz_lo + pair / ng1, gy = pair % ng1;
+        if (gz + gy > dcur || dcur - gz - gy >= ng2) continue;  // (a slot of the enumeration without a group)
+        const uint32_t gx = dcur - gz - gy;
+        const int64_t z0 = (int64_t)gz * G * CB - 2, y0 = (int64_t)gy * G * CB - 2, x0 = (int64_t)gx * G * CB - 2;
+        // ---- (1) nothing to wait for yet: the blocks' choices, their P / lattice values from the work array (a wave per block) ----
+        if (threadIdx.x < NB) {
+            const uint32_t lz = threadIdx.x / (G * G), ly = (threadIdx.x / G) % G, lx = threadIdx.x % G;
+            const uint32_t bz = G * gz + lz, by = G * gy + ly, bx = G * gx + lx;
+            s_sel[threadIdx.x] = (bz < p.nb[0] && by < p.nb[1] && bx < p.nb[2]) ? p.sel[(bz * p.nb[1] + by) * p.nb[2] + bx] : (uint8_t)255;
+        }
+        for (uint32_t b = wv; b < NB; b += 8) {
+            const uint32_t lz = b / (G * G), ly = (b / G) % G, lx = b % G;
+            const uint32_t bz = G * gz + lz, by = G * gy + ly, bx = G * gx + lx;
+            if (bz >= p.nb[0] || by >= p.nb[1] || bx >= p.nb[2]) continue;
+            const BlkGeom g = blk_geom_at(p, bz, by, bx);
+            const uint32_t nown = g.ez * g.ey * g.ex;
+            constexpr int OWN = (CB3 + WAVE - 1) / WAVE;
+            Q own[OWN];
+#pragma unroll
+            for (int k = 0; k < OWN; k++) {
+                const uint32_t t = (uint32_t)lane + k * WAVE;
+                own[k] = work[g.coff + (t < nown ? t : 0)];
+            }
+#pragma unroll
+            for (int k = 0; k < OWN; k++) {
+                const uint32_t t = (uint32_t)lane + k * WAVE;
+                if (t < nown) {
+                    uint32_t i0, i1, i2;
+                    own_index<CB>(g, t, i0, i1, i2);
+                    s_q[((lz * CB + 2 + i0) * TE + (ly * CB + 2 + i1)) * TE + (lx * CB + 2 + i2)] = own[k];
+                }
+            }
+        }
+        // ---- (2) the seven lower neighbours' flags ----
+        if (threadIdx.x < 7) {
+            const uint32_t k = threadIdx.x + 1, dz = k >> 2, dy = (k >> 1) & 1u, dx = k & 1u;
+            if (gz >= dz && gy >= dy && gx >= dx) {
+                const uint32_t *f = flags + ((uint64_t)(gz - dz) * ng1 + (gy - dy)) * ng2 + (gx - dx);
+                uint32_t spins = 0;
+                while (__hip_atomic_load(const_cast<uint32_t *>(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1u << 22)) {
+                        atomicExch(&ctl[1], 1u);
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // (no cache-wide acquire / release around the exchange — a write-back of the L2's dirty lines per wave and group, with the groups'
+        // output streaming through that L2, made this kernel 16 ms: what travels between groups goes through agent-scope atomic stores
+        // and loads, which pass the L2 by, and the flag follows them after s_waitcnt vmcnt(0))
+        // ---- (3) the halo: the neighbours' shells, from the work array (position -> block -> its place in the codes' order) ----
+        {
+            Q hv[NHL];
+            uint32_t hpos[NHL];
+            bool hin[NHL];
+#pragma unroll
+            for (int k = 0; k < NHL; k++) {
+                const uint32_t h = threadIdx.x + 512u * k;
+                uint32_t tz, ty, tx;
+                if (h < HZ) {
+                    tz = h / (TE * TE);
+                    ty = (h / TE) % TE;
+                    tx = h % TE;
+                } else if (h < HZ + HY) {
+                    const uint32_t r = h - HZ;
+                    tz = 2 + r / (2 * TE);
+                    ty = (r / TE) % 2;
+                    tx = r % TE;
+                } else {
+                    const uint32_t r = h - HZ - HY;
+                    tz = 2 + r / ((TE - 2) * 2);
+                    ty = 2 + (r / 2) % (TE - 2);
+                    tx = r % 2;
+                }
+                const int64_t z = z0 + tz, y = y0 + ty, x = x0 + tx;
+                const bool in = h < NHALO && z >= 0 && y >= 0 && x >= 0 && z < (int64_t)p.d[0] && y < (int64_t)d1 && x < (int64_t)d2;
+                uint64_t addr = 0;
+                if (in) {
+                    const uint32_t bz = (uint32_t)z / CB, by = (uint32_t)y / CB, bx = (uint32_t)x / CB;
+                    const BlkGeom g = blk_geom_at(p, bz, by, bx);
+                    addr = g.coff + ((uint64_t)((uint32_t)z - g.oz) * g.ey + ((uint32_t)y - g.oy)) * g.ex + ((uint32_t)x - g.ox);
+                }
+                hin[k] = in;
+                hpos[k] = h < NHALO ? (tz * TE + ty) * TE + tx : 0xFFFFFFFFu;
+                hv[k] = __hip_atomic_load(work + addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < NHL; k++)
+                if (hpos[k] != 0xFFFFFFFFu) s_q[hpos[k]] = hin[k] ? hv[k] : (Q)0;
+        }
+        __syncthreads();
+        // ---- (4) the faces, inner front by inner front ----
+        for (uint32_t step = 0; step <= 3u * (G - 1); step++) {
+            const uint32_t b0 = s_first[step], nitems = (s_first[step + 1] - b0) * frounds;
+            for (uint32_t it = wv; it < nitems; it += 16) {
+                uint32_t dst[2];
+                UQ v[2];
+                bool w[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t iu = it + 8u * u;
+                    const bool have = iu < nitems;
+                    const uint32_t ic = have ? iu : it, r = ic % frounds;
+                    w[u] = gather((uint32_t)__builtin_amdgcn_readfirstlane((int)s_order[b0 + ic / frounds]), r * WAVE, min(nface, (r + 1) * WAVE), dst[u], v[u]) && have;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                    if (w[u]) s_q[dst[u]] = (Q)v[u];
+            }
+            __syncthreads();
+        }
+        // ---- (5) the shell out, then the flag: the upper neighbours may go ----
+        for (uint32_t b = wv; b < NB; b += 8) {
+            const uint32_t lz = b / (G * G), ly = (b / G) % G, lx = b % G;
+            if (lz != G - 1 && ly != G - 1 && lx != G - 1) continue;
+            if (s_sel[b] > 1) continue;  // (a regression block's lattice values are in the work array already)
+            const BlkGeom g = blk_geom_at(p, G * gz + lz, G * gy + ly, G * gx + lx);
+            const uint32_t nown = g.ez * g.ey * g.ex;
+            for (uint32_t t = lane; t < nown; t += WAVE) {
+                uint32_t i0, i1, i2;
+                own_index<CB>(g, t, i0, i1, i2);
+                const bool shell = (lz == G - 1 && i0 + nl >= (uint32_t)CB) || (ly == G - 1 && i1 + nl >= (uint32_t)CB) || (lx == G - 1 && i2 + nl >= (uint32_t)CB);
+                if (shell) __hip_atomic_store(work + g.coff + t, s_q[((lz * CB + 2 + i0) * TE + (ly * CB + 2 + i1)) * TE + (lx * CB + 2 + i2)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flags + ((uint64_t)gz * ng1 + gy) * ng2 + gx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- (6) the interiors ----
+        constexpr int IB = sizeof(Q) == 8 ? 2 : 4;  // (items in flight: registers)
+        for (uint32_t it = wv; it < NB * irounds; it += 8u * IB) {
+            uint32_t dst[IB];
+            UQ v[IB];
+            bool w[IB];
+#pragma unroll
+            for (int u = 0; u < IB; u++) {
+                const uint32_t iu = it + 8u * u;
+                const bool have = iu < NB * irounds;
+                const uint32_t ic = have ? iu : it, r = ic % irounds;
+                w[u] = gather(ic / irounds, nface + r * WAVE, min((uint32_t)CB3, nface + (r + 1) * WAVE), dst[u], v[u]) && have;
+            }
+#pragma unroll
+            for (int u = 0; u < IB; u++)
+                if (w[u]) s_q[dst[u]] = (Q)v[u];
+        }
+        __syncthreads();
+        // ---- (7) out: the Lorenzo blocks' final values (the regression blocks' were written by k_blk_local3) ----
+        {
+            constexpr uint32_t DX = 512u % TE, DY = (512u / TE) % TE, DZ = 512u / (TE * TE);
+            const uint32_t zn = (uint32_t)min((int64_t)TE, (int64_t)p.d[0] - z0), yn = (uint32_t)min((int64_t)TE, (int64_t)d1 - y0),
+                           xn = (uint32_t)min((int64_t)TE, (int64_t)d2 - x0);
+            const uint64_t pz = d1 * d2;
+            const int64_t g0 = (z0 * (int64_t)d1 + y0) * (int64_t)d2 + x0;
+            uint32_t tz = threadIdx.x / (TE * TE), ty = (threadIdx.x / TE) % TE, tx = threadIdx.x % TE;
+#pragma unroll 1
+            for (int k = 0; k < NH; k++) {
+                if (tz >= 2 && ty >= 2 && tx >= 2 && tz < zn && ty < yn && tx < xn) {
+                    const uint32_t b = (((tz - 2) / CB) * G + (ty - 2) / CB) * G + (tx - 2) / CB;
+                    if (s_sel[b] <= 1) tout[(uint64_t)(g0 + (int64_t)((uint64_t)tz * pz + (uint64_t)ty * d2 + tx))] = lat.dequant(s_q[threadIdx.x + 512u * k]);
+                }
+                tx += DX;
+                const uint32_t cx = tx >= TE ? 1u : 0u;
+                tx -= cx * TE;
+                ty += DY + cx;
+                const uint32_t cy = ty >= TE ? 1u : 0u;
+                ty -= cy * TE;
+                tz += DZ + cy;
+            }
         }
     }
 }
@@ -4506,14 +4811,41 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
             }
         }
     } else
+    if (p->B == 6 && p->carry && !(szk_dbg_flags & (32768 | 65536 | 8388608))) {  // one launch for the chain of fronts (k_blk_wave3)
+        constexpr uint32_t G = 3;
+        const uint32_t ng0 = (p->nb[0] + G - 1) / G, ng1 = (p->nb[1] + G - 1) / G, ng2 = (p->nb[2] + G - 1) / G;
+        const uint32_t ngd = ng0 + ng1 + ng2 - 2;
+        uint64_t nslots = 0;
+        for (uint32_t d = 0; d < ngd; d++) {
+            const uint32_t rest = (ng1 - 1) + (ng2 - 1);
+            const uint32_t gz_lo = d > rest ? d - rest : 0, gz_hi = d < ng0 - 1 ? d : ng0 - 1;
+            if (gz_lo <= gz_hi) nslots += (uint64_t)(gz_hi - gz_lo + 1) * ng1;
+        }
+        if (nslots > 0xFFFFFFF0ull) return -1;
+        uint32_t *ctl = reinterpret_cast<uint32_t *>(p->carry);
+        if (hipMemsetAsync(ctl, 0, (4 + (size_t)ng0 * ng1 * ng2) * 4, s) != hipSuccess) return -1;
+        const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
+        const uint32_t gw = (uint32_t)std::min<uint64_t>(nslots, dtype == 0 ? 1024 : 512);
+        if (dtype == 0) {
+            hipLaunchKernelGGL((k_blk_local3<float, 6, true>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+            hipLaunchKernelGGL((k_blk_wave3<float, 6, 3>), dim3(gw), dim3(512), 0, s, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
+            if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<float>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (float *)d_out);
+        } else {
+            hipLaunchKernelGGL((k_blk_local3<double, 6, true>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+            hipLaunchKernelGGL((k_blk_wave3<double, 6, 3>), dim3(gw), dim3(512), 0, s, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
+            if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<double>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (double *)d_out);
+        }
+        SZK_CHECK_LAUNCH();
+        return 0;
+    }
     if (p->B == 6 && (szk_dbg_flags & 32768)) {  // debug flag 32768: groups of 3 x 3 x 3 blocks per workgroup, closed form, a launch per front (k_blk_decode_gf)
         constexpr uint32_t G = 3;
         const uint32_t ng0 = (p->nb[0] + G - 1) / G, ng1 = (p->nb[1] + G - 1) / G, ng2 = (p->nb[2] + G - 1) / G;
         const uint32_t ngd = ng0 + ng1 + ng2 - 2;
         {
             const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
-            if (dtype == 0) hipLaunchKernelGGL((k_blk_local3<float, 6>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
-            else hipLaunchKernelGGL((k_blk_local3<double, 6>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+            if (dtype == 0) hipLaunchKernelGGL((k_blk_local3<float, 6, false>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+            else hipLaunchKernelGGL((k_blk_local3<double, 6, false>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
         }
         for (uint32_t d = 0; d < ngd; d++) {
             const uint32_t rest = (ng1 - 1) + (ng2 - 1);

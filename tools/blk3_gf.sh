@@ -21,7 +21,7 @@ import csv, glob
 f = glob.glob("/tmp/pb/*kernel_stats.csv")
 if f:
     rows = list(csv.DictReader(open(f[0])))
-    rows = [r for r in rows if any(k in r["Name"] for k in ("k_blk_decode", "k_blk_local3", "k_blk_pre3", "k_blk_final", "k_decode", "expand", "coef_parse", "k_blk_patch"))]
+    rows = [r for r in rows if any(k in r["Name"] for k in ("k_blk_decode", "k_blk_wave3", "k_blk_local3", "k_blk_pre3", "k_blk_final", "k_decode", "expand", "coef_parse", "k_blk_patch"))]
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     for r in rows: print("%-60s calls %5s avg %8.1f us total %8.2f ms" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
 t = glob.glob("/tmp/pb/*kernel_trace.csv")

@@ -1995,29 +1995,38 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
         else v = blk_closed<1, Q, UQ>(s_q, TE, oz, oy, ox, i0, i1, i2);
         return true;
     };
-    // the fronts' enumeration: front dd holds (gz_hi - gz_lo + 1) * ng1 slots (gz, gy), gx = dd - gz - gy where that is a group
-    auto front_slots = [&](uint32_t dd, uint32_t &gz_lo) {
+    // the fronts' enumeration: front dd = the groups with gz + gy + gx = dd, by gz, then gy (row_groups: how many for one gz)
+    auto row_groups = [&](uint32_t dd, uint32_t gz, uint32_t &gy_lo) {
+        const uint32_t r = dd - gz;  // gy + gx
+        gy_lo = r > ng2 - 1 ? r - (ng2 - 1) : 0;
+        const uint32_t gy_hi = r < ng1 - 1 ? r : ng1 - 1;
+        return gy_lo > gy_hi ? 0u : gy_hi - gy_lo + 1;
+    };
+    auto front_groups = [&](uint32_t dd, uint32_t &gz_lo, uint32_t &gz_hi) {
         const uint32_t rest = (ng1 - 1) + (ng2 - 1);
         gz_lo = dd > rest ? dd - rest : 0;
-        const uint32_t gz_hi = dd < ng0 - 1 ? dd : ng0 - 1;
-        return gz_lo > gz_hi ? 0u : (gz_hi - gz_lo + 1) * ng1;
+        gz_hi = dd < ng0 - 1 ? dd : ng0 - 1;
+        uint32_t c = 0, gy_lo;
+        for (uint32_t z = gz_lo; z <= gz_hi && gz_lo <= gz_hi; z++) c += row_groups(dd, z, gy_lo);
+        return c;
     };
     uint32_t dcur = 0, start = 0;  // this workgroup's place in the enumeration: its tickets only grow
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&ctl[0], 1u);
     for (;;) {
-        __syncthreads();  // (the tile and s_ticket are free again)
-        if (threadIdx.x == 0) s_ticket = atomicAdd(&ctl[0], 1u);
-        __syncthreads();
+        __syncthreads();  // (the ticket — taken while the previous group was being finished — is there; the tile is free again)
         const uint32_t ticket = s_ticket;
         if (ticket >= nslots) break;
-        uint32_t gz_lo, cnt;
-        while (ticket >= start + (cnt = front_slots(dcur, gz_lo))) {
+        uint32_t gz_lo, gz_hi, cnt;
+        while (ticket >= start + (cnt = front_groups(dcur, gz_lo, gz_hi))) {
             start += cnt;
             dcur++;
         }
-        const uint32_t pair = ticket - start;
-        const uint32_t gz = gz_lo + pair / ng1, gy = pair % ng1;
-        if (gz + gy > dcur || dcur - gz - gy >= ng2) continue;  // (a slot of the enumeration without a group)
-        const uint32_t gx = dcur - gz - gy;
+        uint32_t rest = ticket - start, gz = gz_lo, gy_lo, rc;
+        while (rest >= (rc = row_groups(dcur, gz, gy_lo))) {
+            rest -= rc;
+            gz++;
+        }
+        const uint32_t gy = gy_lo + rest, gx = dcur - gz - gy;
         const int64_t z0 = (int64_t)gz * G * CB - 2, y0 = (int64_t)gy * G * CB - 2, x0 = (int64_t)gx * G * CB - 2;
         // ---- (1) nothing to wait for yet: the blocks' choices, their P / lattice values from the work array (a wave per block) ----
         if (threadIdx.x < NB) {
@@ -2025,30 +2034,47 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
             const uint32_t bz = G * gz + lz, by = G * gy + ly, bx = G * gx + lx;
             s_sel[threadIdx.x] = (bz < p.nb[0] && by < p.nb[1] && bx < p.nb[2]) ? p.sel[(bz * p.nb[1] + by) * p.nb[2] + bx] : (uint8_t)255;
         }
-        for (uint32_t b = wv; b < NB; b += 8) {
-            const uint32_t lz = b / (G * G), ly = (b / G) % G, lx = b % G;
-            const uint32_t bz = G * gz + lz, by = G * gy + ly, bx = G * gx + lx;
-            if (bz >= p.nb[0] || by >= p.nb[1] || bx >= p.nb[2]) continue;
-            const BlkGeom g = blk_geom_at(p, bz, by, bx);
-            const uint32_t nown = g.ez * g.ey * g.ex;
-            constexpr int OWN = (CB3 + WAVE - 1) / WAVE;
-            Q own[OWN];
+        {   // (every block's loads in flight before the first use: a block after the other was four dependent trips to memory)
+            constexpr int OWN = (CB3 + WAVE - 1) / WAVE, NBW = (NB + 7) / 8;
+            Q own[NBW][OWN];
 #pragma unroll
-            for (int k = 0; k < OWN; k++) {
-                const uint32_t t = (uint32_t)lane + k * WAVE;
-                own[k] = work[g.coff + (t < nown ? t : 0)];
+            for (int j = 0; j < NBW; j++) {
+                const uint32_t b = wv + 8u * j;
+                const uint32_t lz = b / (G * G), ly = (b / G) % G, lx = b % G;
+                const uint32_t bz = G * gz + lz, by = G * gy + ly, bx = G * gx + lx;
+                const bool have = b < NB && bz < p.nb[0] && by < p.nb[1] && bx < p.nb[2];
+                const BlkGeom g = blk_geom_at(p, have ? bz : 0, have ? by : 0, have ? bx : 0);
+                const uint32_t nown = have ? g.ez * g.ey * g.ex : 0;
+#pragma unroll
+                for (int k = 0; k < OWN; k++) {
+                    const uint32_t t = (uint32_t)lane + k * WAVE;
+                    own[j][k] = work[g.coff + (t < nown ? t : 0)];
+                }
             }
 #pragma unroll
-            for (int k = 0; k < OWN; k++) {
-                const uint32_t t = (uint32_t)lane + k * WAVE;
-                if (t < nown) {
-                    uint32_t i0, i1, i2;
-                    own_index<CB>(g, t, i0, i1, i2);
-                    s_q[((lz * CB + 2 + i0) * TE + (ly * CB + 2 + i1)) * TE + (lx * CB + 2 + i2)] = own[k];
+            for (int j = 0; j < NBW; j++) {
+                uint32_t b = wv + 8u * j;
+                asm volatile("" : "+s"(b));  // (the geometry again, not carried in registers across the loads)
+                const uint32_t lz = b / (G * G), ly = (b / G) % G, lx = b % G;
+                const uint32_t bz = G * gz + lz, by = G * gy + ly, bx = G * gx + lx;
+                const bool have = b < NB && bz < p.nb[0] && by < p.nb[1] && bx < p.nb[2];
+                const BlkGeom g = blk_geom_at(p, have ? bz : 0, have ? by : 0, have ? bx : 0);
+                const uint32_t nown = have ? g.ez * g.ey * g.ex : 0;
+#pragma unroll
+                for (int k = 0; k < OWN; k++) {
+                    const uint32_t t = (uint32_t)lane + k * WAVE;
+                    if (t < nown) {
+                        uint32_t i0, i1, i2;
+                        own_index<CB>(g, t, i0, i1, i2);
+                        s_q[((lz * CB + 2 + i0) * TE + (ly * CB + 2 + i1)) * TE + (lx * CB + 2 + i2)] = own[j][k];
+                    }
                 }
             }
         }
         // ---- (2) the seven lower neighbours' flags ----
+#if defined(LAB_W) && LAB_W == 4  // (lab builds: what the launch's time is made of; results wrong)
+        if (p.B == 0)
+#endif
         if (threadIdx.x < 7) {
             const uint32_t k = threadIdx.x + 1, dz = k >> 2, dy = (k >> 1) & 1u, dx = k & 1u;
             if (gz >= dz && gy >= dy && gx >= dx) {
@@ -2109,6 +2135,9 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
         }
         __syncthreads();
         // ---- (4) the faces, inner front by inner front ----
+#if defined(LAB_W) && LAB_W == 3
+        if (p.B == 0)
+#endif
         for (uint32_t step = 0; step <= 3u * (G - 1); step++) {
             const uint32_t b0 = s_first[step], nitems = (s_first[step + 1] - b0) * frounds;
             for (uint32_t it = wv; it < nitems; it += 16) {
@@ -2144,9 +2173,15 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(flags + ((uint64_t)gz * ng1 + gy) * ng2 + gx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(flags + ((uint64_t)gz * ng1 + gy) * ng2 + gx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ticket = atomicAdd(&ctl[0], 1u);  // (the next group's ticket: on its way while this one's interiors and output are done — everybody read the last one long ago)
+        }
         // ---- (6) the interiors ----
         constexpr int IB = sizeof(Q) == 8 ? 2 : 4;  // (items in flight: registers)
+#if defined(LAB_W) && LAB_W == 1
+        if (p.B == 0)
+#endif
         for (uint32_t it = wv; it < NB * irounds; it += 8u * IB) {
             uint32_t dst[IB];
             UQ v[IB];
@@ -2164,6 +2199,9 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
         }
         __syncthreads();
         // ---- (7) out: the Lorenzo blocks' final values (the regression blocks' were written by k_blk_local3) ----
+#if defined(LAB_W) && (LAB_W == 1 || LAB_W == 2)
+        if (p.B == 0)
+#endif
         {
             constexpr uint32_t DX = 512u % TE, DY = (512u / TE) % TE, DZ = 512u / (TE * TE);
             const uint32_t zn = (uint32_t)min((int64_t)TE, (int64_t)p.d[0] - z0), yn = (uint32_t)min((int64_t)TE, (int64_t)d1 - y0),
@@ -4815,12 +4853,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         constexpr uint32_t G = 3;
         const uint32_t ng0 = (p->nb[0] + G - 1) / G, ng1 = (p->nb[1] + G - 1) / G, ng2 = (p->nb[2] + G - 1) / G;
         const uint32_t ngd = ng0 + ng1 + ng2 - 2;
-        uint64_t nslots = 0;
-        for (uint32_t d = 0; d < ngd; d++) {
-            const uint32_t rest = (ng1 - 1) + (ng2 - 1);
-            const uint32_t gz_lo = d > rest ? d - rest : 0, gz_hi = d < ng0 - 1 ? d : ng0 - 1;
-            if (gz_lo <= gz_hi) nslots += (uint64_t)(gz_hi - gz_lo + 1) * ng1;
-        }
+        const uint64_t nslots = (uint64_t)ng0 * ng1 * ng2;  // (the groups, handed out front by front)
         if (nslots > 0xFFFFFFF0ull) return -1;
         uint32_t *ctl = reinterpret_cast<uint32_t *>(p->carry);
         if (hipMemsetAsync(ctl, 0, (4 + (size_t)ng0 * ng1 * ng2) * 4, s) != hipSuccess) return -1;

@@ -249,18 +249,18 @@ int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, uint64_t n);
 int sz3hip_debug_decode_info(sz3hip_ctx *ctx, uint32_t *out4);
 /* test hook: non-zero routes every shape through the generic (any-shape) stage-1 kernel instead of the tuned one */
 void sz3hip_debug_force_generic(int on);
-/* development switches (bit mask, process-wide; 0 = product behaviour). Bits 1..16: ablations of the stage-1 kernel for
- * tools/k1_lab.py - results are WRONG. The others force one of two equivalent paths, results unchanged (tests compare them):
+/* development switches (bit mask, process-wide; 0 = product behaviour). They force one of two equivalent paths, results unchanged (tests compare them):
  * 32 no marching kernel, 64 no one-byte codes, 128 interpolation pass by pass, one point per thread (no 8-wide level-1
  * kernels, no level kernels), 256 no stage-1 specialisation by code width, 512 decoder without the fused x prefix sum,
  * 1024 code book without the two-class construction, 4096 stage 1 without the XCD-aware task order, 8192 interpolation
  * histogram with the large tier and the windowed tail passes, 16384 predictor sets with Lorenzo-2 / regression fall back
  * to plain Lorenzo (no block path), 131072 contexts do not remember the previous call's code width / code-book form,
  * 262144 round-parallel Huffman merge for small alphabets, 2097152 Lorenzo decoder without half-width intermediates,
- * 4194304 interpolation level kernels whatever the array's size (normally from 256 blocks up), 8388608 block decoder with a
- * block per wave instead of groups of 2 x 2 x 2 blocks per workgroup.
- * Experiments with WRONG or slower results (tools/dec_lab.py): 32768 / 65536 decoder stream loads through an LDS ring,
- * 524288 decoder without stores, 1048576 decoder with direct stores. */
+ * 4194304 interpolation level kernels whatever the array's size (normally from 256 blocks up). The 3-D block decoder (blocks of
+ * 6^3; the product path is ONE launch for the chain of fronts, k_blk_wave3, after a local pass straight from the codes): 16 the
+ * local pass a wave per block from an expanded copy of the deltas, 32768 groups of 3 x 3 x 3 blocks in closed form with a launch
+ * per front, 65536 round 3's groups of 2 x 2 x 2 blocks inverted by line scans, 8388608 a block per wave.
+ * Experiments with WRONG or slower results (tools/dec_lab.py): 524288 decoder without stores, 1048576 decoder with direct stores. */
 void sz3hip_debug_flags(int flags);
 
 /* ---- (4) multi-GPU exchange over RCCL / xGMI ------------------------------------------------------------------- */

@@ -1635,9 +1635,12 @@ __global__ __launch_bounds__(512) void k_blk_decode_g(const uint16_t *__restrict
 // test_grouped_and_per_block_decoders_agree takes all three decoders).
 // WORK: the results stay in the work array, in the codes' order (P over the deltas, a regression block's lattice values over its
 // slots: what k_blk_wave3 reads), and a regression block's final values go to the output
+// codes_in: the deltas were not expanded — a delta is its code - radius, and the work array holds the far deltas only (scattered from
+// their list: code 0); only_ragged: the whole blocks were done by k_blk_local3v
 template <typename T, int CB, bool WORK>
 __global__ __launch_bounds__(256) void k_blk_local3(const uint16_t *__restrict__ codes, void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks,
-                                                    const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
+                                                    const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank, int codes_in = 0,
+                                                    int only_ragged = 0) {
     using Q = typename QTraits<T>::Q;
     constexpr uint32_t E = CB + 2;
     __shared__ Q s_q[4][E * E * E];
@@ -1656,6 +1659,7 @@ __global__ __launch_bounds__(256) void k_blk_local3(const uint16_t *__restrict__
         const int sid = (int)p.sel[task];
         const BlkGeom g = blk_geom(p, task);
         const uint32_t nown = g.ez * g.ey * g.ex;
+        if (only_ragged && nown == (uint32_t)(CB * CB * CB)) continue;
         if (sid == 2) {  // regression: the lattice value the neighbours will predict from (k_blk_pre3's part)
             T rc[4];
             coef_recover(coef_by_rank + (uint64_t)rank[task] * 4, cl, rc);
@@ -1682,7 +1686,12 @@ __global__ __launch_bounds__(256) void k_blk_local3(const uint16_t *__restrict__
         for (uint32_t t = lane; t < nown; t += WAVE) {
             uint32_t i0, i1, i2;
             own_index<CB>(g, t, i0, i1, i2);
-            sq[tv_at(tv, i0 + 2, i1 + 2, i2 + 2)] = deltas[g.coff + t];
+            Q dl;
+            if (codes_in) {
+                const uint32_t c = codes[g.coff + t];
+                dl = c ? (Q)((int)c - (int)p.radius) : deltas[g.coff + t];
+            } else dl = deltas[g.coff + t];
+            sq[tv_at(tv, i0 + 2, i1 + 2, i2 + 2)] = dl;
         }
         if (sid == 1) blk_invert<T, CB, 2>(sq, sq, qout, g, tv, d1, d2, lane, WORK);
         else blk_invert<T, CB, 1>(sq, sq, qout, g, tv, d1, d2, lane, WORK);
@@ -1910,6 +1919,127 @@ __global__ __launch_bounds__(512, 4) void k_blk_decode_gf(void *d_out, szk_blk_p
 #endif
             }
             advance(q);
+        }
+    }
+}
+
+// k_blk_local3<WORK> for whole blocks, sixteen at a time: a wave per block left 28 of 64 lanes idle in every line pass (36 lines of six)
+// and spent most of its instructions on halo terms that are zero here. A workgroup of 192 threads takes 16 consecutive blocks (3456
+// values, 576 lines per pass: three per thread), straight from the codes (a delta is code - radius; code 0: the far delta, scattered
+// into the work array from its list beforehand — no expanded copy of the deltas is made), runs the three passes as plain running sums
+// (first order) or second-order recurrences with zero inflow, by the block's choice, and leaves P in the work array; a regression
+// block's values are computed element by element. Ragged blocks (the array's high faces) are left to k_blk_local3(only_ragged).
+#define BLK3V_NB 16
+template <typename T, int CB>
+__global__ __launch_bounds__(192, 4) void k_blk_local3v(const uint16_t *__restrict__ codes, void *work_, void *d_out, szk_blk_params p, uint32_t nblocks,
+                                                     const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    constexpr uint32_t CB3 = CB * CB * CB, NL = CB * CB, PER = BLK3V_NB * CB3 / 192;  // (18 values per thread)
+    static_assert(BLK3V_NB * CB3 % 192 == 0 && BLK3V_NB * NL % 192 == 0, "a workgroup's values and lines divide among its threads");
+    __shared__ Q s_v[BLK3V_NB * CB3];
+    __shared__ uint64_t s_coff[BLK3V_NB];
+    __shared__ uint32_t s_org[BLK3V_NB][3];
+    __shared__ uint8_t s_kind[BLK3V_NB];  // 0 / 1: first- / second-order Lorenzo, 2: regression, 255: not a whole block (skipped here)
+    const Lattice<T> lat(p.lat);
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    Q *work = reinterpret_cast<Q *>(work_);
+    T *tout = reinterpret_cast<T *>(d_out);
+    const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
+    const uint32_t nbatch = (nblocks + BLK3V_NB - 1) / BLK3V_NB;
+    for (uint32_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x < BLK3V_NB) {
+            const uint32_t task = batch * BLK3V_NB + threadIdx.x;
+            uint8_t kind = 255;
+            if (task < nblocks) {
+                const BlkGeom g = blk_geom(p, task);
+                if (g.ez * g.ey * g.ex == CB3) {
+                    const uint8_t sl = p.sel[task];
+                    kind = sl == 2 ? 2 : (sl == 1 ? 1 : 0);
+                }
+                s_coff[threadIdx.x] = g.coff;
+                s_org[threadIdx.x][0] = g.oz;
+                s_org[threadIdx.x][1] = g.oy;
+                s_org[threadIdx.x][2] = g.ox;
+            }
+            s_kind[threadIdx.x] = kind;
+        }
+        __syncthreads();
+        // ---- in: codes -> deltas (all of a thread's loads before the first use) ----
+        uint16_t c[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t e = threadIdx.x + 192u * k, b = e / CB3, t = e - b * CB3;
+            c[k] = s_kind[b] != 255 ? codes[s_coff[b] + t] : (uint16_t)1;
+        }
+        uint32_t tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));  // (positions computed again, not carried in registers from loop to loop: eighteen of them)
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t e = tid2 + 192u * k, b = e / CB3, t = e - b * CB3;
+            Q dl = (Q)((int)c[k] - (int)p.radius);
+            if (c[k] == 0 && s_kind[b] < 2) dl = work[s_coff[b] + t];  // (a far delta: rare)
+            s_v[e] = dl;
+        }
+        __syncthreads();
+        // ---- the three passes: x (contiguous lines), y, z ----
+#pragma unroll
+        for (int pass = 0; pass < 3; pass++) {
+            uint32_t tidp = threadIdx.x;
+            asm volatile("" : "+v"(tidp));
+#pragma unroll
+            for (uint32_t k = 0; k < BLK3V_NB * NL / 192; k++) {
+                const uint32_t l = tidp + 192u * k, b = l / NL, r = l - b * NL, a0 = r / CB, a1 = r - a0 * CB;
+                const uint32_t kind = s_kind[b];
+                if (kind > 1) continue;
+                // first element and stride of the line
+                const uint32_t base = b * CB3 + (pass == 0 ? (a0 * CB + a1) * CB : (pass == 1 ? a0 * CB * CB + a1 : a0 * CB + a1));
+                const uint32_t stride = pass == 0 ? 1u : (pass == 1 ? (uint32_t)CB : (uint32_t)(CB * CB));
+                UQ in[CB];
+#pragma unroll
+                for (uint32_t i = 0; i < (uint32_t)CB; i++) in[i] = (UQ)s_v[base + i * stride];
+                UQ p1 = 0, p2 = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < (uint32_t)CB; i++) {
+                    const UQ v = kind == 1 ? (UQ)(2 * p1 - p2 + in[i]) : (UQ)(p1 + in[i]);
+                    in[i] = v;
+                    p2 = p1;
+                    p1 = v;
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < (uint32_t)CB; i++) s_v[base + i * stride] = (Q)in[i];
+            }
+            __syncthreads();
+        }
+        // ---- the regression blocks: lattice values for the neighbours (into the tile), final values into the array ----
+        for (uint32_t b = 0; b < BLK3V_NB; b++) {
+            if (s_kind[b] != 2) continue;  // (workgroup-uniform)
+            T rc[4];
+            coef_recover(coef_by_rank + (uint64_t)rank[batch * BLK3V_NB + b] * 4, cl, rc);
+            for (uint32_t t = threadIdx.x; t < CB3; t += 192) {
+                const uint32_t i2 = t % CB, i1 = (t / CB) % CB, i0 = t / (CB * CB);
+                const uint32_t code = codes[s_coff[b] + t];
+                Q qt = 0;
+                T val = 0;  // (code 0: patched from the list)
+                if (code) {
+                    bool bad;
+                    val = ref_recover(reg_predict(rc, i0, i1, i2), (int)code, p.eb, (int)p.radius);
+                    qt = lat.quant(val, bad);
+                    if (bad) qt = 0;
+                }
+                s_v[b * CB3 + t] = qt;
+                tout[((uint64_t)(s_org[b][0] + i0) * d1 + (s_org[b][1] + i1)) * d2 + (s_org[b][2] + i2)] = val;
+            }
+        }
+        __syncthreads();
+        // ---- out: P / the lattice values, in the codes' order ----
+        uint32_t tid3 = threadIdx.x;
+        asm volatile("" : "+v"(tid3));
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t e = tid3 + 192u * k, b = e / CB3, t = e - b * CB3;
+            if (s_kind[b] != 255) work[s_coff[b] + t] = s_v[e];
         }
     }
 }
@@ -4757,7 +4887,10 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
                               const uint8_t *payload, const szh_header *h, const szh_offsets *o, int64_t *coef_by_rank, hipStream_t s,
                               hipEvent_t side_done) {
     const uint32_t nblocks = blk_count_blocks(p);
-    if (p->ndim == 1) {
+    // (k_blk_local3v reads the codes themselves: the far deltas alone go to the work array; debug flag 16: the expanded copy and the
+    // wave-per-block pass)
+    const bool fusedv = p->ndim == 3 && p->B == 6 && p->carry && !(szk_dbg_flags & (32768 | 65536 | 8388608 | 16));
+    if (p->ndim == 1 || fusedv) {
         if (szk_launch_scatter_deltas(dtype, h->n, payload, o, h->n_dout, p->qwork, s)) return -1;
     } else if (szk_launch_expand_deltas(dtype, codes, h->n, (int)h->radius, payload, o, h->n_dout, p->qwork, s)) return -1;
     // (the side section's kernels ran on another stream: the fronts are the first to need what they made)
@@ -4859,18 +4992,26 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         if (hipMemsetAsync(ctl, 0, (4 + (size_t)ng0 * ng1 * ng2) * 4, s) != hipSuccess) return -1;
         const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
         const uint32_t gw = (uint32_t)std::min<uint64_t>(nslots, dtype == 0 ? 1024 : 512);
+        const bool ragged = p->d[0] % 6 || p->d[1] % 6 || p->d[2] % 6;
+        const uint32_t gv = (uint32_t)std::min<uint64_t>(8192, ((uint64_t)nblocks + BLK3V_NB - 1) / BLK3V_NB);
         if (dtype == 0) {
-            hipLaunchKernelGGL((k_blk_local3<float, 6, true>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+            if (fusedv) {
+                hipLaunchKernelGGL((k_blk_local3v<float, 6>), dim3(gv), dim3(192), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+                if (ragged) hipLaunchKernelGGL((k_blk_local3<float, 6, true>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank, 1, 1);
+            } else hipLaunchKernelGGL((k_blk_local3<float, 6, true>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank, 0, 0);
             hipLaunchKernelGGL((k_blk_wave3<float, 6, 3>), dim3(gw), dim3(512), 0, s, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
             if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<float>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (float *)d_out);
         } else {
-            hipLaunchKernelGGL((k_blk_local3<double, 6, true>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+            if (fusedv) {
+                hipLaunchKernelGGL((k_blk_local3v<double, 6>), dim3(gv), dim3(192), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
+                if (ragged) hipLaunchKernelGGL((k_blk_local3<double, 6, true>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank, 1, 1);
+            } else hipLaunchKernelGGL((k_blk_local3<double, 6, true>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank, 0, 0);
             hipLaunchKernelGGL((k_blk_wave3<double, 6, 3>), dim3(gw), dim3(512), 0, s, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
             if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<double>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (double *)d_out);
         }
         SZK_CHECK_LAUNCH();
         return 0;
-    }
+    } else
     if (p->B == 6 && (szk_dbg_flags & 32768)) {  // debug flag 32768: groups of 3 x 3 x 3 blocks per workgroup, closed form, a launch per front (k_blk_decode_gf)
         constexpr uint32_t G = 3;
         const uint32_t ng0 = (p->nb[0] + G - 1) / G, ng1 = (p->nb[1] + G - 1) / G, ng2 = (p->nb[2] + G - 1) / G;

@@ -1824,7 +1824,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         }
         int rb = blk_reserve(ctx, nblocks);
         if (rb) return rb;
-        if ((h.ndim == 1 || h.ndim == 3) && ctx->blk_carry_cap < nblocks) {  // 1-D: aggregate + inflow of every block (two lattice words); 3-D: the groups' flags (k_blk_wave3)
+        if (h.ndim <= 3 && ctx->blk_carry_cap < nblocks) {  // 1-D: aggregate + inflow of every block (two lattice words); 2-D / 3-D: the groups' flags (k_blkn_wave2, k_blk_wave3)
             if (ctx->d_blk_carry) HIPCHK(hipFree(ctx->d_blk_carry));
             ctx->d_blk_carry = nullptr;
             ctx->blk_carry_cap = 0;

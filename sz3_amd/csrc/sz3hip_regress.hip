@@ -3215,7 +3215,7 @@ __global__ __launch_bounds__(TB) void k_blkn_lorenzo12v(const T *__restrict__ in
 // block the sum of its deltas.
 template <typename T>
 __global__ __launch_bounds__(256) void k_blkn_pre(const uint16_t *__restrict__ codes, const void *deltas_, void *d_out, szk_blk_params p, uint32_t nblocks,
-                                                  const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank) {
+                                                  const uint32_t *__restrict__ rank, const int64_t *__restrict__ coef_by_rank, int to_work = 0) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     const Lattice<T> lat(p.lat);
@@ -3245,7 +3245,10 @@ __global__ __launch_bounds__(256) void k_blkn_pre(const uint16_t *__restrict__ c
                 // 1-D: nothing reads a regression block's lattice values but the scan over the blocks (its last element's, below):
                 // the element's final value goes out here and the final pass is not run
                 if (p.ndim == 1) reinterpret_cast<T *>(d_out)[g.ox + i2] = val;
-                else qout[(uint64_t)(g.oy + i1) * d2 + (g.ox + i2)] = qt;
+                else if (to_work) {  // (k_blkn_wave2: the lattice value over the block's slot in the work array, the final value out)
+                    const_cast<Q *>(deltas)[g.coff + t] = qt;
+                    reinterpret_cast<T *>(d_out)[(uint64_t)(g.oy + i1) * d2 + (g.ox + i2)] = val;
+                } else qout[(uint64_t)(g.oy + i1) * d2 + (g.ox + i2)] = qt;
                 if (p.ndim == 1 && t == nown - 1) agg[2 * (uint64_t)task] = qt;
             }
         } else if (p.ndim == 1) {
@@ -4142,6 +4145,205 @@ __global__ __launch_bounds__(256) void k_blkn_decode2g(const void *deltas_, void
     }
 }
 
+// 2-D, the chain of fronts in ONE launch (the 2-D form of k_blk_wave3, first-order Lorenzo + regression, block edges up to 16): groups
+// of 4 x 4 blocks handed out by a ticket counter in the fronts' order to workgroups that stay; a group inverts its Lorenzo blocks with
+// a zero halo while it has nothing to wait for (P: row sums, then column sums, in the DPP rows), waits for the flags of its three
+// lower neighbours, takes their shells (a group's last row and column, left in the work array in the codes' order) and closes the
+// blocks in the 2-D form of the identity above k_blk_local3: q(j, i) = P(j, i) + q(-1, i) + q(j, -1) - q(-1, -1) — the blocks' last
+// rows and columns first, inner front by inner front, the shell out and the flag, then every interior at once, and the final values
+// straight to the output (no k_blk_final pass). k_blkn_pre(to_work) ran before: the regression blocks' lattice values are in the work
+// array, their final values in the output. ctl as for k_blk_wave3.
+template <typename T>
+__global__ __launch_bounds__(256, 4) void k_blkn_wave2(void *work_, void *d_out, szk_blk_params p, uint32_t *ctl, uint32_t nslots) {
+    using Q = typename QTraits<T>::Q;
+    using UQ = typename QTraits<T>::UQ;
+    constexpr uint32_t OW = BLKN_G * 16, TE = OW + 1, PITCH = TE + 1;
+    constexpr int NR = (OW * OW) / 256;
+    __shared__ Q sq[TE * PITCH];
+    __shared__ uint8_t s_sel[BLKN_G * BLKN_G];
+    __shared__ uint32_t s_ticket;
+    const Lattice<T> lat(p.lat);
+    const uint32_t B = p.B, inv = (65536u + B - 1) / B;  // (t / B for t < 64: (t * inv) >> 16)
+    const uint64_t d1 = p.d[1], d2 = p.d[2];
+    const uint32_t ng1 = (p.nb[1] + BLKN_G - 1) / BLKN_G, ng2 = (p.nb[2] + BLKN_G - 1) / BLKN_G;
+    Q *work = reinterpret_cast<Q *>(work_);
+    T *tout = reinterpret_cast<T *>(d_out);
+    uint32_t *flags = ctl + 4;
+    const int lane = lane_id();
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), rr = (uint32_t)lane >> 4, cc = (uint32_t)lane & 15u;
+    // where array position (y, x) lies in the work array (the codes' order: block by block, a block's elements in raster order)
+    auto work_at = [&](uint32_t y, uint32_t x) {
+        const uint32_t by = y / B, bx = x / B;
+        const uint32_t oy = by * B, ey = min(B, (uint32_t)d1 - oy), ox = bx * B, ex = min(B, (uint32_t)d2 - ox);
+        return (uint64_t)oy * d2 + (uint64_t)ey * ox + (uint64_t)(y - oy) * ex + (x - ox);
+    };
+    uint32_t dcur = 0, start = 0;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&ctl[0], 1u);
+    for (;;) {
+        __syncthreads();
+        const uint32_t ticket = s_ticket;
+        if (ticket >= nslots) break;
+        uint32_t gy_lo, cnt;
+        for (;;) {
+            gy_lo = dcur >= ng2 ? dcur - (ng2 - 1) : 0;
+            const uint32_t gy_hi = dcur < ng1 - 1 ? dcur : ng1 - 1;
+            cnt = gy_hi - gy_lo + 1;
+            if (ticket < start + cnt) break;
+            start += cnt;
+            dcur++;
+        }
+        const uint32_t gy = gy_lo + (ticket - start), gx = dcur - gy;
+        const uint32_t y0 = gy * BLKN_G * B, x0 = gx * BLKN_G * B;
+        const uint32_t hy = (uint32_t)min((uint64_t)(BLKN_G * B), d1 - y0), hx = (uint32_t)min((uint64_t)(BLKN_G * B), d2 - x0);
+        const uint32_t nly = (hy + B - 1) / B, nlx = (hx + B - 1) / B;
+        // ---- (1) nothing to wait for yet: the group's own values from the work array, the blocks' choices ----
+        if (threadIdx.x < BLKN_G * BLKN_G) {
+            const uint32_t by = gy * BLKN_G + threadIdx.x / BLKN_G, bx = gx * BLKN_G + threadIdx.x % BLKN_G;
+            s_sel[threadIdx.x] = (by < p.nb[1] && bx < p.nb[2]) ? p.sel[by * p.nb[2] + bx] : (uint8_t)255;
+        }
+        {
+            Q v[NR];
+uint32_t tid1 = threadIdx.x;
+            asm volatile("" : "+v"(tid1));  // (positions computed again, not carried from loop to loop)
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const uint32_t idx = tid1 + 256u * r, ty = idx / OW, tx = idx % OW;
+                const bool in = ty < hy && tx < hx;
+                // (in-tile block coordinates by the reciprocal: the group starts on a block boundary)
+                const uint32_t ly = (ty * inv) >> 16, lx = (tx * inv) >> 16;
+                const uint32_t oy = y0 + ly * B, ey = min(B, (uint32_t)d1 - oy), ox = x0 + lx * B, ex = min(B, (uint32_t)d2 - ox);
+                const uint64_t at = (uint64_t)oy * d2 + (uint64_t)ey * ox + (uint64_t)(ty - ly * B) * ex + (tx - lx * B);
+                v[r] = work[in ? at : 0];
+            }
+uint32_t tid2 = threadIdx.x;
+            asm volatile("" : "+v"(tid2));  // (positions computed again, not carried from loop to loop)
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const uint32_t idx = tid2 + 256u * r, ty = idx / OW, tx = idx % OW;
+                sq[(ty + 1) * PITCH + tx + 1] = (ty < hy && tx < hx) ? v[r] : (Q)0;
+            }
+        }
+        __syncthreads();
+        // ---- (1b) P of the Lorenzo blocks: wave w takes the blocks of its row of blocks; sums along x, then along y, zero inflow ----
+        for (uint32_t lx = 0; lx < nlx; lx++) {
+            if (w >= nly || s_sel[w * BLKN_G + lx] > 1) continue;
+            const uint32_t ty0 = 1 + w * B, tx0 = 1 + lx * B;
+            const uint32_t ey = min(B, hy - w * B), ex = min(B, hx - lx * B);
+            UQ v[4];
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) {
+                const uint32_t j = rr + 4 * m, at = (ty0 + min(j, ey - 1)) * PITCH + tx0;
+                v[m] = cc < ex ? (UQ)sq[at + cc] : (UQ)0;
+            }
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) v[m] = row16_incl_scan(v[m]);
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) {
+                const uint32_t j = rr + 4 * m;
+                if (j < ey && cc < ex) sq[(ty0 + j) * PITCH + tx0 + cc] = (Q)v[m];
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) {
+                const uint32_t i = min(rr + 4 * m, ex - 1), at = ty0 * PITCH + tx0 + i;
+                v[m] = cc < ey ? (UQ)sq[at + cc * PITCH] : (UQ)0;
+            }
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) v[m] = row16_incl_scan(v[m]);
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) {
+                const uint32_t i = rr + 4 * m;
+                if (i < ex && cc < ey) sq[ty0 * PITCH + tx0 + i + cc * PITCH] = (Q)v[m];
+            }
+        }
+        // ---- (2) the three lower neighbours' flags ----
+        if (threadIdx.x < 3) {
+            const uint32_t k = threadIdx.x + 1, dy = k >> 1, dx = k & 1u;
+            if (gy >= dy && gx >= dx) {
+                uint32_t *f = flags + (uint64_t)(gy - dy) * ng2 + (gx - dx);
+                uint32_t spins = 0;
+                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1u << 22)) {
+                        atomicExch(&ctl[1], 1u);
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- (3) the halo: the row above (threads 0 .. 64) and the column to the left (65 .. 128), from the neighbours' shells ----
+        if (threadIdx.x <= 2 * OW) {
+            const bool top = threadIdx.x <= OW;
+            const uint32_t ty = top ? 0u : threadIdx.x - OW, tx = top ? threadIdx.x : 0u;
+            const int64_t y = (int64_t)y0 + ty - 1, x = (int64_t)x0 + tx - 1;
+            const bool in = y >= 0 && x >= 0 && ty <= hy && tx <= hx;
+            const Q hv = __hip_atomic_load(work + (in ? work_at((uint32_t)y, (uint32_t)x) : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sq[ty * PITCH + tx] = in ? hv : (Q)0;
+        }
+        __syncthreads();
+        // ---- (4) the blocks' last rows and columns, inner front by inner front (a wave per row of blocks) ----
+        for (uint32_t step = 0; step + 1 < nly + nlx; step++) {
+            const uint32_t ly = w, lx = step - ly;
+            if (ly < nly && ly <= step && lx < nlx && s_sel[ly * BLKN_G + lx] <= 1) {
+                const uint32_t ty0 = 1 + ly * B, tx0 = 1 + lx * B;
+                const uint32_t ey = min(B, hy - ly * B), ex = min(B, hx - lx * B);
+                const uint32_t l = (uint32_t)lane;
+                if (l < ex + ey - 1) {
+                    const uint32_t j = l < ex ? ey - 1 : l - ex, i = l < ex ? l : ex - 1;
+                    const uint32_t at = (ty0 + j) * PITCH + tx0 + i;
+                    const UQ v = (UQ)sq[at] + (UQ)sq[(ty0 - 1) * PITCH + tx0 + i] + (UQ)sq[(ty0 + j) * PITCH + tx0 - 1] - (UQ)sq[(ty0 - 1) * PITCH + tx0 - 1];
+                    sq[at] = (Q)v;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- (5) the shell out (the group's last row: threads 0 .. 63, its last column: 64 .. 127), then the flag ----
+        if (threadIdx.x < 2 * OW) {
+            const bool row = threadIdx.x < OW;
+            const uint32_t ty = row ? hy - 1 : threadIdx.x - OW, tx = row ? threadIdx.x : hx - 1;
+            if (ty < hy && tx < hx && (row || ty != hy - 1)) {
+                const uint32_t ly = (ty * inv) >> 16, lx = (tx * inv) >> 16;
+                if (s_sel[ly * BLKN_G + lx] <= 1)  // (a regression block's lattice values are in the work array already)
+                    __hip_atomic_store(work + work_at(y0 + ty, x0 + tx), sq[(ty + 1) * PITCH + tx + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(flags + (uint64_t)gy * ng2 + gx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ticket = atomicAdd(&ctl[0], 1u);
+        }
+        // ---- (6) the interiors, (7) the final values out: rows of the tile ----
+        {
+            Q q[NR];
+uint32_t tid3 = threadIdx.x;
+            asm volatile("" : "+v"(tid3));  // (positions computed again, not carried from loop to loop)
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const uint32_t idx = tid3 + 256u * r, ty = idx / OW, tx = idx % OW;
+                const uint32_t ly = (ty * inv) >> 16, lx = (tx * inv) >> 16;
+                const uint32_t ty0 = 1 + ly * B, tx0 = 1 + lx * B;
+                const uint32_t ey = min(B, hy - min(hy, ly * B)), ex = min(B, hx - min(hx, lx * B));
+                const uint32_t j = ty + 1 - ty0, i = tx + 1 - tx0;
+                const bool in = ty < hy && tx < hx;
+                UQ v = (UQ)sq[(ty + 1) * PITCH + tx + 1];
+                if (in && j + 1 < ey && i + 1 < ex)
+                    v += (UQ)sq[(ty0 - 1) * PITCH + tx + 1] + (UQ)sq[(ty + 1) * PITCH + tx0 - 1] - (UQ)sq[(ty0 - 1) * PITCH + tx0 - 1];
+                q[r] = (Q)v;
+            }
+uint32_t tid4 = threadIdx.x;
+            asm volatile("" : "+v"(tid4));  // (positions computed again, not carried from loop to loop)
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const uint32_t idx = tid4 + 256u * r, ty = idx / OW, tx = idx % OW;
+                const uint32_t ly = (ty * inv) >> 16, lx = (tx * inv) >> 16;
+                if (ty < hy && tx < hx && s_sel[ly * BLKN_G + lx] <= 1) tout[(uint64_t)(y0 + ty) * d2 + (x0 + tx)] = lat.dequant(q[r]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // 4-D arrays (round 4): Lorenzo-1 / linear regression with FIVE coefficients per block of B^4 values (B = 4..6, default 6:
 // Config.hpp:175) — RegressionPredictor.hpp:28-55, 77-92 for N = 4, LorenzoPredictor.hpp:69-74 (fifteen neighbours, noise 1.79 eb),
@@ -4930,6 +5132,27 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         else BLKN2_DEC(double, int64_t);
 #undef BLKN2_DEC
     } else
+    if (p->ndim == 2 && !(p->mask & 2u) && p->B <= 16 && p->carry && !(szk_dbg_flags & (8388608 | 65536))) {
+        // 2-D, first-order Lorenzo + regression, block edges up to 16: ONE launch for the chain of fronts (k_blkn_wave2; debug flag
+        // 65536: groups of 4 x 4 blocks with a launch per front, k_blkn_decode2g)
+        const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
+        const uint32_t ng1 = (p->nb[1] + BLKN_G - 1) / BLKN_G, ng2 = (p->nb[2] + BLKN_G - 1) / BLKN_G;
+        const uint64_t nslots = (uint64_t)ng1 * ng2;
+        uint32_t *ctl = reinterpret_cast<uint32_t *>(p->carry);
+        if (hipMemsetAsync(ctl, 0, (4 + (size_t)nslots) * 4, s) != hipSuccess) return -1;
+        const uint32_t gw = (uint32_t)std::min<uint64_t>(nslots, dtype == 0 ? 2048 : 1024);
+        if (dtype == 0) {
+            hipLaunchKernelGGL(k_blkn_pre<float>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank, 1);
+            hipLaunchKernelGGL(k_blkn_wave2<float>, dim3(gw), dim3(256), 0, s, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
+            if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<float>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (float *)d_out);
+        } else {
+            hipLaunchKernelGGL(k_blkn_pre<double>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank, 1);
+            hipLaunchKernelGGL(k_blkn_wave2<double>, dim3(gw), dim3(256), 0, s, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
+            if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<double>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (double *)d_out);
+        }
+        SZK_CHECK_LAUNCH();
+        return 0;
+    } else
     if (p->ndim < 3) {
         const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
         // 1-D, blocks of up to 128 values, a multiple of 8: four blocks per wave (debug flag 134217728: a wave per block)
@@ -4965,7 +5188,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
                 if (dtype == 0) hipLaunchKernelGGL(k_blkn_decode2s<float>, dim3((nfront + 3) / 4), dim3(256), 0, s, p->qwork, d_out, *p, d, by_lo, nfront);
                 else hipLaunchKernelGGL(k_blkn_decode2s<double>, dim3((nfront + 3) / 4), dim3(256), 0, s, p->qwork, d_out, *p, d, by_lo, nfront);
             }
-        } else if (p->B <= 16 && !(szk_dbg_flags & 8388608)) {  // groups of 4 x 4 blocks per workgroup (debug flag 8388608: a block per wave)
+        } else if (p->B <= 16 && !(szk_dbg_flags & 8388608)) {  // groups of 4 x 4 blocks per workgroup, a launch per front (debug flag 65536; 8388608: a block per wave)
             const uint32_t ng1 = (p->nb[1] + BLKN_G - 1) / BLKN_G, ng2 = (p->nb[2] + BLKN_G - 1) / BLKN_G;
             for (uint32_t d = 0; d < ng1 + ng2 - 1; d++) {
                 const uint32_t gy_lo = d >= ng2 ? d - (ng2 - 1) : 0, gy_hi = d < ng1 - 1 ? d : ng1 - 1;

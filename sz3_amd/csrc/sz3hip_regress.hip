@@ -4154,7 +4154,7 @@ __global__ __launch_bounds__(256) void k_blkn_decode2g(const void *deltas_, void
 // straight to the output (no k_blk_final pass). k_blkn_pre(to_work) ran before: the regression blocks' lattice values are in the work
 // array, their final values in the output. ctl as for k_blk_wave3.
 template <typename T>
-__global__ __launch_bounds__(256, 4) void k_blkn_wave2(void *work_, void *d_out, szk_blk_params p, uint32_t *ctl, uint32_t nslots) {
+__global__ __launch_bounds__(256, 4) void k_blkn_wave2(const uint16_t *__restrict__ codes, void *work_, void *d_out, szk_blk_params p, uint32_t *ctl, uint32_t nslots) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
     constexpr uint32_t OW = BLKN_G * 16, TE = OW + 1, PITCH = TE + 1;
@@ -4202,8 +4202,12 @@ __global__ __launch_bounds__(256, 4) void k_blkn_wave2(void *work_, void *d_out,
             s_sel[threadIdx.x] = (by < p.nb[1] && bx < p.nb[2]) ? p.sel[by * p.nb[2] + bx] : (uint8_t)255;
         }
         {
+            // (the codes themselves: a delta is code - radius; the work array holds what the codes do not — the far deltas, scattered from
+            // their list, and the regression blocks' lattice values — so no expanded copy of the deltas is made)
             Q v[NR];
-uint32_t tid1 = threadIdx.x;
+            uint16_t cd[NR];
+            uint8_t sl[NR];
+            uint32_t tid1 = threadIdx.x;
             asm volatile("" : "+v"(tid1));  // (positions computed again, not carried from loop to loop)
 #pragma unroll
             for (int r = 0; r < NR; r++) {
@@ -4214,8 +4218,13 @@ uint32_t tid1 = threadIdx.x;
                 const uint32_t oy = y0 + ly * B, ey = min(B, (uint32_t)d1 - oy), ox = x0 + lx * B, ex = min(B, (uint32_t)d2 - ox);
                 const uint64_t at = (uint64_t)oy * d2 + (uint64_t)ey * ox + (uint64_t)(ty - ly * B) * ex + (tx - lx * B);
                 v[r] = work[in ? at : 0];
+                cd[r] = codes[in ? at : 0];
+                sl[r] = p.sel[in ? (gy * BLKN_G + ly) * p.nb[2] + (gx * BLKN_G + lx) : 0];
             }
-uint32_t tid2 = threadIdx.x;
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+                if (sl[r] != 2 && cd[r]) v[r] = (Q)((int)cd[r] - (int)p.radius);
+            uint32_t tid2 = threadIdx.x;
             asm volatile("" : "+v"(tid2));  // (positions computed again, not carried from loop to loop)
 #pragma unroll
             for (int r = 0; r < NR; r++) {
@@ -4317,7 +4326,7 @@ uint32_t tid2 = threadIdx.x;
         // ---- (6) the interiors, (7) the final values out: rows of the tile ----
         {
             Q q[NR];
-uint32_t tid3 = threadIdx.x;
+            uint32_t tid3 = threadIdx.x;
             asm volatile("" : "+v"(tid3));  // (positions computed again, not carried from loop to loop)
 #pragma unroll
             for (int r = 0; r < NR; r++) {
@@ -4332,7 +4341,7 @@ uint32_t tid3 = threadIdx.x;
                     v += (UQ)sq[(ty0 - 1) * PITCH + tx + 1] + (UQ)sq[(ty + 1) * PITCH + tx0 - 1] - (UQ)sq[(ty0 - 1) * PITCH + tx0 - 1];
                 q[r] = (Q)v;
             }
-uint32_t tid4 = threadIdx.x;
+            uint32_t tid4 = threadIdx.x;
             asm volatile("" : "+v"(tid4));  // (positions computed again, not carried from loop to loop)
 #pragma unroll
             for (int r = 0; r < NR; r++) {
@@ -5092,7 +5101,8 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
     // (k_blk_local3v reads the codes themselves: the far deltas alone go to the work array; debug flag 16: the expanded copy and the
     // wave-per-block pass)
     const bool fusedv = p->ndim == 3 && p->B == 6 && p->carry && !(szk_dbg_flags & (32768 | 65536 | 8388608 | 16));
-    if (p->ndim == 1 || fusedv) {
+    const bool wave2 = p->ndim == 2 && !(p->mask & 2u) && p->B <= 16 && p->carry && !(szk_dbg_flags & (8388608 | 65536));  // (k_blkn_wave2 reads the codes too)
+    if (p->ndim == 1 || fusedv || wave2) {
         if (szk_launch_scatter_deltas(dtype, h->n, payload, o, h->n_dout, p->qwork, s)) return -1;
     } else if (szk_launch_expand_deltas(dtype, codes, h->n, (int)h->radius, payload, o, h->n_dout, p->qwork, s)) return -1;
     // (the side section's kernels ran on another stream: the fronts are the first to need what they made)
@@ -5132,7 +5142,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         else BLKN2_DEC(double, int64_t);
 #undef BLKN2_DEC
     } else
-    if (p->ndim == 2 && !(p->mask & 2u) && p->B <= 16 && p->carry && !(szk_dbg_flags & (8388608 | 65536))) {
+    if (wave2) {
         // 2-D, first-order Lorenzo + regression, block edges up to 16: ONE launch for the chain of fronts (k_blkn_wave2; debug flag
         // 65536: groups of 4 x 4 blocks with a launch per front, k_blkn_decode2g)
         const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
@@ -5143,11 +5153,11 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         const uint32_t gw = (uint32_t)std::min<uint64_t>(nslots, dtype == 0 ? 2048 : 1024);
         if (dtype == 0) {
             hipLaunchKernelGGL(k_blkn_pre<float>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank, 1);
-            hipLaunchKernelGGL(k_blkn_wave2<float>, dim3(gw), dim3(256), 0, s, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
+            hipLaunchKernelGGL(k_blkn_wave2<float>, dim3(gw), dim3(256), 0, s, codes, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
             if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<float>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (float *)d_out);
         } else {
             hipLaunchKernelGGL(k_blkn_pre<double>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank, 1);
-            hipLaunchKernelGGL(k_blkn_wave2<double>, dim3(gw), dim3(256), 0, s, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
+            hipLaunchKernelGGL(k_blkn_wave2<double>, dim3(gw), dim3(256), 0, s, codes, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
             if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<double>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (double *)d_out);
         }
         SZK_CHECK_LAUNCH();

@@ -1729,6 +1729,32 @@ __device__ __forceinline__ UQ blk_closed(const Q *s, uint32_t TE, uint32_t oz, u
             }
     return acc;
 }
+// the same for the element at tile index o whose indices are packed in w3 (i0 << 16 | i1 << 8 | i2): offsets from o instead of
+// coordinates (k_blk_wave3, where a lane's element is the same in every block)
+template <int ORDER, int TE, typename Q, typename UQ>
+__device__ __forceinline__ UQ blk_closed_at(const Q *s, uint32_t o, uint32_t w3) {
+    const uint32_t i0 = (w3 >> 16) & 255u, i1 = (w3 >> 8) & 255u, i2 = w3 & 255u;
+    const uint32_t hz = (i0 + 1) * TE * TE, hy = (i1 + 1) * TE, hx = i2 + 1;  // (down to the first halo layer)
+    if (ORDER == 1) {
+        const uint32_t oz = o - hz, oy = o - hy, ozy = oz - hy;
+        return (UQ)s[o] + (UQ)s[oz] + (UQ)s[oy] + (UQ)s[o - hx] - (UQ)s[ozy] - (UQ)s[oz - hx] - (UQ)s[oy - hx] + (UQ)s[ozy - hx];
+    }
+    const uint32_t fz[3] = {0u, hz, hz + TE * TE}, fy[3] = {0u, hy, hy + TE}, fx[3] = {0u, hx, hx + 1u};
+    const int wz[3] = {1, (int)i0 + 2, -((int)i0 + 1)}, wy[3] = {1, (int)i1 + 2, -((int)i1 + 1)}, wx[3] = {1, (int)i2 + 2, -((int)i2 + 1)};
+    UQ acc = (UQ)s[o];
+#pragma unroll
+    for (int a = 0; a <= 2; a++)
+#pragma unroll
+        for (int b = 0; b <= 2; b++)
+#pragma unroll
+            for (int c = 0; c <= 2; c++) {
+                if ((a | b | c) == 0) continue;
+                const int members = (a != 0) + (b != 0) + (c != 0);
+                const int w = wz[a] * wy[b] * wx[c] * ((members & 1) ? 1 : -1);
+                acc += (UQ)((Q)w * s[o - fz[a] - fy[b] - fx[c]]);
+            }
+    return acc;
+}
 template <typename T, int CB, int G>
 __global__ __launch_bounds__(512, 4) void k_blk_decode_gf(void *d_out, szk_blk_params p, uint32_t diag, uint32_t gz_lo, uint32_t npairs) {
     using Q = typename QTraits<T>::Q;
@@ -2055,7 +2081,7 @@ __global__ __launch_bounds__(192, 4) void k_blk_local3v(const uint16_t *__restri
 // k_blk_final pass over the array). k_blk_local3<WORK> ran before: P of every Lorenzo block and the lattice values of the regression
 // blocks are in the work array, the regression blocks' final values in the output.
 // ctl: [0] ticket, [1] a wait gave up, [4 ...] the groups' flags (zeroed by the caller).
-template <typename T, int CB, int G>
+template <typename T, int CB, int G, int NL>  // NL: the layers of a block that are faces — 2 when the set holds second-order Lorenzo
 __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, szk_blk_params p, uint32_t *ctl, uint32_t nslots) {
     using Q = typename QTraits<T>::Q;
     using UQ = typename QTraits<T>::UQ;
@@ -2063,6 +2089,7 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
     constexpr int NH = (NT + 511) / 512;
     constexpr uint32_t HZ = 2 * TE * TE, HY = (TE - 2) * 2 * TE, HX = (TE - 2) * (TE - 2) * 2, NHALO = HZ + HY + HX;
     constexpr int NHL = (NHALO + 511) / 512;
+    constexpr uint32_t NFACE = CB3 - (CB - NL) * (CB - NL) * (CB - NL), FR = (NFACE + WAVE - 1) / WAVE, IR = (CB3 - NFACE + WAVE - 1) / WAVE;
     __shared__ Q s_q[NT];
     __shared__ uint8_t s_sel[NB];
     __shared__ uint8_t s_list[CB3];
@@ -2077,7 +2104,7 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
     T *tout = reinterpret_cast<T *>(d_out);
     uint32_t *flags = ctl + 4;
     const uint32_t ng0 = (p.nb[0] + G - 1) / G, ng1 = (p.nb[1] + G - 1) / G, ng2 = (p.nb[2] + G - 1) / G;
-    const uint32_t nl = (p.mask & 2u) ? 2u : 1u;
+    constexpr uint32_t nl = NL;
     // ---- once: the element order of a block (faces first), the blocks of a group by inner front ----
     if (wv == 7) {
         uint32_t nf = 0;
@@ -2109,20 +2136,31 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
         s_first[st] = (uint8_t)before;
     }
     __syncthreads();
-    const uint32_t nface = s_nface;
-    const uint32_t frounds = (nface + WAVE - 1) / WAVE, irounds = (CB3 - nface + WAVE - 1) / WAVE;
-    auto gather = [&](uint32_t b, uint32_t first, uint32_t last, uint32_t &dst, UQ &v) {
+    // What a lane computes in round r of a block (rounds 0 .. FR - 1: the faces, then IR rounds of interior) is the same element of
+    // every block: its offset inside the block's part of the tile and its indices are worked out once (the element list, the divisions
+    // and the products per item were most of this kernel's instructions — it is bound by their issue, not by memory: 351 instructions
+    // per element before)
+    uint32_t rel[FR + IR], ijk[FR + IR];
+#pragma unroll
+    for (uint32_t r = 0; r < FR + IR; r++) {
+        const uint32_t e = r < FR ? r * WAVE + (uint32_t)lane : NFACE + (r - FR) * WAVE + (uint32_t)lane;
+        const bool valid = r < FR ? e < NFACE : e < CB3;
+        const uint32_t t = s_list[valid ? e : 0];
+        const uint32_t i2 = t % CB, i1 = (t / CB) % CB, i0 = t / (CB * CB);
+        rel[r] = (i0 * TE + i1) * TE + i2;
+        ijk[r] = (valid ? 0x80000000u : 0u) | (i0 << 16) | (i1 << 8) | i2;
+    }
+    // one (block b, round r) item: the value and where it goes (false: nothing to write)
+    auto gather = [&](uint32_t b, uint32_t relr, uint32_t w3, uint32_t &dst, UQ &v) {
+        asm volatile("" : "+v"(relr), "+v"(w3));  // (the offsets and weights that follow from them are a few instructions: computed here, not kept — for
+                                                     // every round and both orders they were two hundred values per lane in scratch memory)
         const uint32_t lz = b / (G * G), ly = (b / G) % G, lx = b % G;
         const uint32_t sid = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_sel[b]);
-        const uint32_t e = first + (uint32_t)lane;
-        const uint32_t t = s_list[e < last ? e : first];
-        const uint32_t i2 = t % CB, i1 = (t / CB) % CB, i0 = t / (CB * CB);
-        const uint32_t oz = lz * CB + 2, oy = ly * CB + 2, ox = lx * CB + 2;
-        dst = ((oz + i0) * TE + (oy + i1)) * TE + (ox + i2);
+        dst = ((lz * CB + 2) * TE + (ly * CB + 2)) * TE + (lx * CB + 2) + relr;
         v = 0;
-        if (sid > 1 || e >= last) return false;
-        if (sid == 1) v = blk_closed<2, Q, UQ>(s_q, TE, oz, oy, ox, i0, i1, i2);
-        else v = blk_closed<1, Q, UQ>(s_q, TE, oz, oy, ox, i0, i1, i2);
+        if (sid > 1 || !(w3 >> 31)) return false;  // regression (its values are final) / no block / no element
+        if (sid == 1) v = blk_closed_at<2, (int)TE, Q, UQ>(s_q, dst, w3);
+        else v = blk_closed_at<1, (int)TE, Q, UQ>(s_q, dst, w3);
         return true;
     };
     // the fronts' enumeration: front dd = the groups with gz + gy + gx = dd, by gz, then gy (row_groups: how many for one gz)
@@ -2143,6 +2181,10 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
     uint32_t dcur = 0, start = 0;  // this workgroup's place in the enumeration: its tickets only grow
     if (threadIdx.x == 0) s_ticket = atomicAdd(&ctl[0], 1u);
     for (;;) {
+        // (the thread's and the lane's number afresh in every round: what is computed from them stays inside the round — hoisted out of
+        // this loop it was several hundred values per lane kept in scratch memory)
+        uint32_t tid = threadIdx.x, ln = (uint32_t)lane;
+        asm volatile("" : "+v"(tid), "+v"(ln));
         __syncthreads();  // (the ticket — taken while the previous group was being finished — is there; the tile is free again)
         const uint32_t ticket = s_ticket;
         if (ticket >= nslots) break;
@@ -2159,10 +2201,10 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
         const uint32_t gy = gy_lo + rest, gx = dcur - gz - gy;
         const int64_t z0 = (int64_t)gz * G * CB - 2, y0 = (int64_t)gy * G * CB - 2, x0 = (int64_t)gx * G * CB - 2;
         // ---- (1) nothing to wait for yet: the blocks' choices, their P / lattice values from the work array (a wave per block) ----
-        if (threadIdx.x < NB) {
-            const uint32_t lz = threadIdx.x / (G * G), ly = (threadIdx.x / G) % G, lx = threadIdx.x % G;
+        if (tid < NB) {
+            const uint32_t lz = tid / (G * G), ly = (tid / G) % G, lx = tid % G;
             const uint32_t bz = G * gz + lz, by = G * gy + ly, bx = G * gx + lx;
-            s_sel[threadIdx.x] = (bz < p.nb[0] && by < p.nb[1] && bx < p.nb[2]) ? p.sel[(bz * p.nb[1] + by) * p.nb[2] + bx] : (uint8_t)255;
+            s_sel[tid] = (bz < p.nb[0] && by < p.nb[1] && bx < p.nb[2]) ? p.sel[(bz * p.nb[1] + by) * p.nb[2] + bx] : (uint8_t)255;
         }
         {   // (every block's loads in flight before the first use: a block after the other was four dependent trips to memory)
             constexpr int OWN = (CB3 + WAVE - 1) / WAVE, NBW = (NB + 7) / 8;
@@ -2177,7 +2219,7 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
                 const uint32_t nown = have ? g.ez * g.ey * g.ex : 0;
 #pragma unroll
                 for (int k = 0; k < OWN; k++) {
-                    const uint32_t t = (uint32_t)lane + k * WAVE;
+                    const uint32_t t = ln + k * WAVE;
                     own[j][k] = work[g.coff + (t < nown ? t : 0)];
                 }
             }
@@ -2192,7 +2234,7 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
                 const uint32_t nown = have ? g.ez * g.ey * g.ex : 0;
 #pragma unroll
                 for (int k = 0; k < OWN; k++) {
-                    const uint32_t t = (uint32_t)lane + k * WAVE;
+                    const uint32_t t = ln + k * WAVE;
                     if (t < nown) {
                         uint32_t i0, i1, i2;
                         own_index<CB>(g, t, i0, i1, i2);
@@ -2205,8 +2247,8 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
 #if defined(LAB_W) && LAB_W == 4  // (lab builds: what the launch's time is made of; results wrong)
         if (p.B == 0)
 #endif
-        if (threadIdx.x < 7) {
-            const uint32_t k = threadIdx.x + 1, dz = k >> 2, dy = (k >> 1) & 1u, dx = k & 1u;
+        if (tid < 7) {
+            const uint32_t k = tid + 1, dz = k >> 2, dy = (k >> 1) & 1u, dx = k & 1u;
             if (gz >= dz && gy >= dy && gx >= dx) {
                 const uint32_t *f = flags + ((uint64_t)(gz - dz) * ng1 + (gy - dy)) * ng2 + (gx - dx);
                 uint32_t spins = 0;
@@ -2230,7 +2272,7 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
             bool hin[NHL];
 #pragma unroll
             for (int k = 0; k < NHL; k++) {
-                const uint32_t h = threadIdx.x + 512u * k;
+                const uint32_t h = tid + 512u * k;
                 uint32_t tz, ty, tx;
                 if (h < HZ) {
                     tz = h / (TE * TE);
@@ -2264,27 +2306,26 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
                 if (hpos[k] != 0xFFFFFFFFu) s_q[hpos[k]] = hin[k] ? hv[k] : (Q)0;
         }
         __syncthreads();
-        // ---- (4) the faces, inner front by inner front ----
+        // ---- (4) the faces, inner front by inner front: item (round r, j-th block of the front) goes to wave (r * blocks + j) mod 8 ----
 #if defined(LAB_W) && LAB_W == 3
         if (p.B == 0)
 #endif
         for (uint32_t step = 0; step <= 3u * (G - 1); step++) {
-            const uint32_t b0 = s_first[step], nitems = (s_first[step + 1] - b0) * frounds;
-            for (uint32_t it = wv; it < nitems; it += 16) {
-                uint32_t dst[2];
-                UQ v[2];
-                bool w[2];
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_first[step]);
+            const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_first[step + 1]) - b0;  // (at most 7 < 8: one block per round and wave)
+            uint32_t dst[FR];
+            UQ v[FR];
+            bool w[FR];
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const uint32_t iu = it + 8u * u;
-                    const bool have = iu < nitems;
-                    const uint32_t ic = have ? iu : it, r = ic % frounds;
-                    w[u] = gather((uint32_t)__builtin_amdgcn_readfirstlane((int)s_order[b0 + ic / frounds]), r * WAVE, min(nface, (r + 1) * WAVE), dst[u], v[u]) && have;
-                }
-#pragma unroll
-                for (int u = 0; u < 2; u++)
-                    if (w[u]) s_q[dst[u]] = (Q)v[u];
+            for (uint32_t r = 0; r < FR; r++) {
+                const uint32_t j = (wv + 32u - r * nb) & 7u;
+                const bool have = j < nb;
+                const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_order[b0 + (have ? j : 0u)]);
+                w[r] = gather(b, rel[r], ijk[r], dst[r], v[r]) && have;
             }
+#pragma unroll
+            for (uint32_t r = 0; r < FR; r++)
+                if (w[r]) s_q[dst[r]] = (Q)v[r];
             __syncthreads();
         }
         // ---- (5) the shell out, then the flag: the upper neighbours may go ----
@@ -2294,7 +2335,7 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
             if (s_sel[b] > 1) continue;  // (a regression block's lattice values are in the work array already)
             const BlkGeom g = blk_geom_at(p, G * gz + lz, G * gy + ly, G * gx + lx);
             const uint32_t nown = g.ez * g.ey * g.ex;
-            for (uint32_t t = lane; t < nown; t += WAVE) {
+            for (uint32_t t = (int)ln; t < nown; t += WAVE) {
                 uint32_t i0, i1, i2;
                 own_index<CB>(g, t, i0, i1, i2);
                 const bool shell = (lz == G - 1 && i0 + nl >= (uint32_t)CB) || (ly == G - 1 && i1 + nl >= (uint32_t)CB) || (lx == G - 1 && i2 + nl >= (uint32_t)CB);
@@ -2307,25 +2348,31 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
             __hip_atomic_store(flags + ((uint64_t)gz * ng1 + gy) * ng2 + gx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_ticket = atomicAdd(&ctl[0], 1u);  // (the next group's ticket: on its way while this one's interiors and output are done — everybody read the last one long ago)
         }
-        // ---- (6) the interiors ----
-        constexpr int IB = sizeof(Q) == 8 ? 2 : 4;  // (items in flight: registers)
+        // ---- (6) the interiors: item (round q, block b) goes to wave (q * 27 + b) mod 8 ----
 #if defined(LAB_W) && LAB_W == 1
         if (p.B == 0)
 #endif
-        for (uint32_t it = wv; it < NB * irounds; it += 8u * IB) {
-            uint32_t dst[IB];
-            UQ v[IB];
-            bool w[IB];
+        {
+            constexpr uint32_t IB = sizeof(Q) == 8 ? 2 : 4;  // (items in flight: registers)
 #pragma unroll
-            for (int u = 0; u < IB; u++) {
-                const uint32_t iu = it + 8u * u;
-                const bool have = iu < NB * irounds;
-                const uint32_t ic = have ? iu : it, r = ic % irounds;
-                w[u] = gather(ic / irounds, nface + r * WAVE, min((uint32_t)CB3, nface + (r + 1) * WAVE), dst[u], v[u]) && have;
+            for (uint32_t q = 0; q < IR; q++) {
+                const uint32_t bfirst = (wv + 64u - ((q * NB) & 63u)) & 7u;
+#pragma unroll 1
+                for (uint32_t k0 = 0; k0 < (NB + 7) / 8; k0 += IB) {
+                    uint32_t dst[IB];
+                    UQ v[IB];
+                    bool w[IB];
+#pragma unroll
+                    for (uint32_t u = 0; u < IB; u++) {
+                        const uint32_t b = bfirst + 8u * (k0 + u);
+                        const bool have = b < NB;
+                        w[u] = gather(have ? b : bfirst, rel[FR + q], ijk[FR + q], dst[u], v[u]) && have;
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < IB; u++)
+                        if (w[u]) s_q[dst[u]] = (Q)v[u];
+                }
             }
-#pragma unroll
-            for (int u = 0; u < IB; u++)
-                if (w[u]) s_q[dst[u]] = (Q)v[u];
         }
         __syncthreads();
         // ---- (7) out: the Lorenzo blocks' final values (the regression blocks' were written by k_blk_local3) ----
@@ -2338,12 +2385,12 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
                            xn = (uint32_t)min((int64_t)TE, (int64_t)d2 - x0);
             const uint64_t pz = d1 * d2;
             const int64_t g0 = (z0 * (int64_t)d1 + y0) * (int64_t)d2 + x0;
-            uint32_t tz = threadIdx.x / (TE * TE), ty = (threadIdx.x / TE) % TE, tx = threadIdx.x % TE;
+            uint32_t tz = tid / (TE * TE), ty = (tid / TE) % TE, tx = tid % TE;
 #pragma unroll 1
             for (int k = 0; k < NH; k++) {
                 if (tz >= 2 && ty >= 2 && tx >= 2 && tz < zn && ty < yn && tx < xn) {
                     const uint32_t b = (((tz - 2) / CB) * G + (ty - 2) / CB) * G + (tx - 2) / CB;
-                    if (s_sel[b] <= 1) tout[(uint64_t)(g0 + (int64_t)((uint64_t)tz * pz + (uint64_t)ty * d2 + tx))] = lat.dequant(s_q[threadIdx.x + 512u * k]);
+                    if (s_sel[b] <= 1) tout[(uint64_t)(g0 + (int64_t)((uint64_t)tz * pz + (uint64_t)ty * d2 + tx))] = lat.dequant(s_q[tid + 512u * k]);
                 }
                 tx += DX;
                 const uint32_t cx = tx >= TE ? 1u : 0u;
@@ -5232,14 +5279,16 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
                 hipLaunchKernelGGL((k_blk_local3v<float, 6>), dim3(gv), dim3(192), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
                 if (ragged) hipLaunchKernelGGL((k_blk_local3<float, 6, true>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank, 1, 1);
             } else hipLaunchKernelGGL((k_blk_local3<float, 6, true>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank, 0, 0);
-            hipLaunchKernelGGL((k_blk_wave3<float, 6, 3>), dim3(gw), dim3(512), 0, s, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
+            if (p->mask & 2u) hipLaunchKernelGGL((k_blk_wave3<float, 6, 3, 2>), dim3(gw), dim3(512), 0, s, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
+            else hipLaunchKernelGGL((k_blk_wave3<float, 6, 3, 1>), dim3(gw), dim3(512), 0, s, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
             if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<float>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (float *)d_out);
         } else {
             if (fusedv) {
                 hipLaunchKernelGGL((k_blk_local3v<double, 6>), dim3(gv), dim3(192), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
                 if (ragged) hipLaunchKernelGGL((k_blk_local3<double, 6, true>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank, 1, 1);
             } else hipLaunchKernelGGL((k_blk_local3<double, 6, true>), dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank, 0, 0);
-            hipLaunchKernelGGL((k_blk_wave3<double, 6, 3>), dim3(gw), dim3(512), 0, s, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
+            if (p->mask & 2u) hipLaunchKernelGGL((k_blk_wave3<double, 6, 3, 2>), dim3(gw), dim3(512), 0, s, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
+            else hipLaunchKernelGGL((k_blk_wave3<double, 6, 3, 1>), dim3(gw), dim3(512), 0, s, p->qwork, d_out, *p, ctl, (uint32_t)nslots);
             if (h->n_vout) hipLaunchKernelGGL(k_blk_patch<double>, dim3(256), dim3(256), 0, s, payload, o->vout_idx, o->vout_val, h->n_vout, h->n, (double *)d_out);
         }
         SZK_CHECK_LAUNCH();

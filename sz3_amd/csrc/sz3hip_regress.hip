@@ -2150,6 +2150,16 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
         rel[r] = (i0 * TE + i1) * TE + i2;
         ijk[r] = (valid ? 0x80000000u : 0u) | (i0 << 16) | (i1 << 8) | i2;
     }
+    // ... and so is the k-th value a lane moves in or out of a whole block (t = lane + 64 k in the block's raster order)
+    constexpr int OWNK = (CB3 + WAVE - 1) / WAVE;
+    uint32_t orel[OWNK], oijk[OWNK];
+#pragma unroll
+    for (int k = 0; k < OWNK; k++) {
+        const uint32_t t = (uint32_t)lane + k * WAVE;
+        const uint32_t i2 = t % CB, i1 = (t / CB) % CB, i0 = t / (CB * CB);
+        orel[k] = (i0 * TE + i1) * TE + i2;
+        oijk[k] = (t < CB3 ? 0x80000000u : 0u) | (i0 << 16) | (i1 << 8) | i2;
+    }
     // one (block b, round r) item: the value and where it goes (false: nothing to write)
     auto gather = [&](uint32_t b, uint32_t relr, uint32_t w3, uint32_t &dst, UQ &v) {
         asm volatile("" : "+v"(relr), "+v"(w3));  // (the offsets and weights that follow from them are a few instructions: computed here, not kept — for
@@ -2232,13 +2242,20 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
                 const bool have = b < NB && bz < p.nb[0] && by < p.nb[1] && bx < p.nb[2];
                 const BlkGeom g = blk_geom_at(p, have ? bz : 0, have ? by : 0, have ? bx : 0);
                 const uint32_t nown = have ? g.ez * g.ey * g.ex : 0;
+                const uint32_t base = ((lz * CB + 2) * TE + (ly * CB + 2)) * TE + (lx * CB + 2);
+                if (nown == CB3) {  // (a whole block: the lane's places are known)
 #pragma unroll
-                for (int k = 0; k < OWN; k++) {
-                    const uint32_t t = ln + k * WAVE;
-                    if (t < nown) {
-                        uint32_t i0, i1, i2;
-                        own_index<CB>(g, t, i0, i1, i2);
-                        s_q[((lz * CB + 2 + i0) * TE + (ly * CB + 2 + i1)) * TE + (lx * CB + 2 + i2)] = own[j][k];
+                    for (int k = 0; k < OWN; k++)
+                        if (oijk[k] >> 31) s_q[base + orel[k]] = own[j][k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < OWN; k++) {
+                        const uint32_t t = ln + k * WAVE;
+                        if (t < nown) {
+                            uint32_t i0, i1, i2;
+                            own_index<CB>(g, t, i0, i1, i2);
+                            s_q[base + (i0 * TE + i1) * TE + i2] = own[j][k];
+                        }
                     }
                 }
             }
@@ -2335,11 +2352,20 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
             if (s_sel[b] > 1) continue;  // (a regression block's lattice values are in the work array already)
             const BlkGeom g = blk_geom_at(p, G * gz + lz, G * gy + ly, G * gx + lx);
             const uint32_t nown = g.ez * g.ey * g.ex;
+            const uint32_t base = ((lz * CB + 2) * TE + (ly * CB + 2)) * TE + (lx * CB + 2);
+            if (nown == CB3) {
+#pragma unroll
+                for (int k = 0; k < OWNK; k++) {
+                    const uint32_t w3 = oijk[k], i0 = (w3 >> 16) & 255u, i1 = (w3 >> 8) & 255u, i2 = w3 & 255u;
+                    const bool shell = (lz == G - 1 && i0 + nl >= (uint32_t)CB) || (ly == G - 1 && i1 + nl >= (uint32_t)CB) || (lx == G - 1 && i2 + nl >= (uint32_t)CB);
+                    if ((w3 >> 31) && shell) __hip_atomic_store(work + g.coff + (ln + k * WAVE), s_q[base + orel[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else
             for (uint32_t t = (int)ln; t < nown; t += WAVE) {
                 uint32_t i0, i1, i2;
                 own_index<CB>(g, t, i0, i1, i2);
                 const bool shell = (lz == G - 1 && i0 + nl >= (uint32_t)CB) || (ly == G - 1 && i1 + nl >= (uint32_t)CB) || (lx == G - 1 && i2 + nl >= (uint32_t)CB);
-                if (shell) __hip_atomic_store(work + g.coff + t, s_q[((lz * CB + 2 + i0) * TE + (ly * CB + 2 + i1)) * TE + (lx * CB + 2 + i2)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (shell) __hip_atomic_store(work + g.coff + t, s_q[base + (i0 * TE + i1) * TE + i2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -2214,7 +2214,12 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
         if (tid < NB) {
             const uint32_t lz = tid / (G * G), ly = (tid / G) % G, lx = tid % G;
             const uint32_t bz = G * gz + lz, by = G * gy + ly, bx = G * gx + lx;
-            s_sel[tid] = (bz < p.nb[0] && by < p.nb[1] && bx < p.nb[2]) ? p.sel[(bz * p.nb[1] + by) * p.nb[2] + bx] : (uint8_t)255;
+            uint8_t sl = 255;
+            if (bz < p.nb[0] && by < p.nb[1] && bx < p.nb[2]) {
+                sl = p.sel[(bz * p.nb[1] + by) * p.nb[2] + bx];
+                sl = sl == 2 ? 2 : (sl == 1 ? 1 : 0);  // (a crafted 3 is read like k_blk_local3 reads it)
+            }
+            s_sel[tid] = sl;
         }
         {   // (every block's loads in flight before the first use: a block after the other was four dependent trips to memory)
             constexpr int OWN = (CB3 + WAVE - 1) / WAVE, NBW = (NB + 7) / 8;
@@ -4272,7 +4277,9 @@ __global__ __launch_bounds__(256, 4) void k_blkn_wave2(const uint16_t *__restric
         // ---- (1) nothing to wait for yet: the group's own values from the work array, the blocks' choices ----
         if (threadIdx.x < BLKN_G * BLKN_G) {
             const uint32_t by = gy * BLKN_G + threadIdx.x / BLKN_G, bx = gx * BLKN_G + threadIdx.x % BLKN_G;
-            s_sel[threadIdx.x] = (by < p.nb[1] && bx < p.nb[2]) ? p.sel[by * p.nb[2] + bx] : (uint8_t)255;
+            uint8_t sl = 255;
+            if (by < p.nb[1] && bx < p.nb[2]) sl = p.sel[by * p.nb[2] + bx] == 2 ? 2 : 0;  // (this path has no second-order member: anything else is first-order Lorenzo, as in k_blkn_pre)
+            s_sel[threadIdx.x] = sl;
         }
         {
             // (the codes themselves: a delta is code - radius; the work array holds what the codes do not — the far deltas, scattered from

@@ -1655,7 +1655,33 @@ __global__ __launch_bounds__(256) void k_blk_local3(const uint16_t *__restrict__
     const CoefLat cl = coef_lat(p.eb, p.B, p.ndim);
     for (uint32_t t = lane; t < E * E * E; t += WAVE) sq[t] = 0;  // (the halo stays zero: the passes write own positions only)
     const TileView tv{E * E, E, 0};
-    for (uint32_t task = blockIdx.x * 4 + wv; task < nblocks; task += gridDim.x * 4) {
+    // only_ragged: the blocks of the array's high faces are enumerated directly — the last layer of blocks in z, then the last row in
+    // y of the other layers, then the last column in x of what is left (visiting every block to find them was 84 us at C4's slab)
+    const bool rz = p.d[0] % p.B != 0, ry = p.d[1] % p.B != 0, rx = p.d[2] % p.B != 0;
+    const uint32_t zfree = p.nb[0] - (rz ? 1u : 0u), yfree = p.nb[1] - (ry ? 1u : 0u);
+    const uint32_t nA = rz ? p.nb[1] * p.nb[2] : 0u, nB = ry ? zfree * p.nb[2] : 0u, nC = rx ? zfree * yfree : 0u;
+    const uint32_t nloop = only_ragged ? nA + nB + nC : nblocks;
+    for (uint32_t it = blockIdx.x * 4 + wv; it < nloop; it += gridDim.x * 4) {
+        uint32_t task = it;
+        if (only_ragged) {
+            uint32_t bz, by, bx;
+            if (it < nA) {
+                bz = p.nb[0] - 1;
+                by = it / p.nb[2];
+                bx = it % p.nb[2];
+            } else if (it < nA + nB) {
+                const uint32_t q = it - nA;
+                bz = q / p.nb[2];
+                by = p.nb[1] - 1;
+                bx = q % p.nb[2];
+            } else {
+                const uint32_t q = it - nA - nB;
+                bz = q / yfree;
+                by = q % yfree;
+                bx = p.nb[2] - 1;
+            }
+            task = (bz * p.nb[1] + by) * p.nb[2] + bx;
+        }
         const int sid = (int)p.sel[task];
         const BlkGeom g = blk_geom(p, task);
         const uint32_t nown = g.ez * g.ey * g.ex;

@@ -2432,30 +2432,28 @@ __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, 
             }
         }
         __syncthreads();
-        // ---- (7) out: the Lorenzo blocks' final values (the regression blocks' were written by k_blk_local3) ----
+        // ---- (7) out: the Lorenzo blocks' final values (the regression blocks' were written by k_blk_local3). A thread keeps its (y, x) of
+        // the tile and walks z: the position, the block's choice and the address are per-thread constants or increments ----
 #if defined(LAB_W) && (LAB_W == 1 || LAB_W == 2)
         if (p.B == 0)
 #endif
-        {
-            constexpr uint32_t DX = 512u % TE, DY = (512u / TE) % TE, DZ = 512u / (TE * TE);
+        if (tid < TE * TE) {
+            const uint32_t ty = tid / TE, tx = tid % TE;
             const uint32_t zn = (uint32_t)min((int64_t)TE, (int64_t)p.d[0] - z0), yn = (uint32_t)min((int64_t)TE, (int64_t)d1 - y0),
                            xn = (uint32_t)min((int64_t)TE, (int64_t)d2 - x0);
-            const uint64_t pz = d1 * d2;
-            const int64_t g0 = (z0 * (int64_t)d1 + y0) * (int64_t)d2 + x0;
-            uint32_t tz = tid / (TE * TE), ty = (tid / TE) % TE, tx = tid % TE;
-#pragma unroll 1
-            for (int k = 0; k < NH; k++) {
-                if (tz >= 2 && ty >= 2 && tx >= 2 && tz < zn && ty < yn && tx < xn) {
-                    const uint32_t b = (((tz - 2) / CB) * G + (ty - 2) / CB) * G + (tx - 2) / CB;
-                    if (s_sel[b] <= 1) tout[(uint64_t)(g0 + (int64_t)((uint64_t)tz * pz + (uint64_t)ty * d2 + tx))] = lat.dequant(s_q[tid + 512u * k]);
+            if (ty >= 2 && tx >= 2 && ty < yn && tx < xn) {
+                const uint32_t byx = ((ty - 2) / CB) * G + (tx - 2) / CB;
+                const uint64_t pz = d1 * d2;
+                T *o = tout + ((z0 + 2) * (int64_t)d1 + (y0 + (int64_t)ty)) * (int64_t)d2 + (x0 + (int64_t)tx);
+#pragma unroll
+                for (uint32_t lz = 0; lz < (uint32_t)G; lz++) {
+                    const bool mine = s_sel[lz * G * G + byx] <= 1;
+#pragma unroll
+                    for (uint32_t i = 0; i < (uint32_t)CB; i++) {
+                        const uint32_t tz = 2 + lz * CB + i;
+                        if (mine && tz < zn) o[(uint64_t)(lz * CB + i) * pz] = lat.dequant(s_q[tz * TE * TE + tid]);
+                    }
                 }
-                tx += DX;
-                const uint32_t cx = tx >= TE ? 1u : 0u;
-                tx -= cx * TE;
-                ty += DY + cx;
-                const uint32_t cy = ty >= TE ? 1u : 0u;
-                ty -= cy * TE;
-                tz += DZ + cy;
             }
         }
     }

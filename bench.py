@@ -729,6 +729,26 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["extra_configs"]["C1_default_algorithm"] = {"error": repr(e)[:300]}
 
+    # ---- one C4 slab of a field where the block stream is kept (C4a: regression wins in a share of the blocks): the block-composed
+    # predictor both ways — its decoder is the chain of block fronts in one launch (round 4) ----
+    if rank == 0 and world == 1 and not args.no_extra and args.algo == "lorenzo" and args.dtype == "f32" and tuple(shape) == (512, 512, 512):
+        try:
+            w4 = Workload(torch, sz3_amd, dev, local_rank, rank, (128, 1024, 1024), "f64", "composed", 1e-6, field="c4a")
+            st4 = max(3, args.steps // 4)
+            el4, ps4 = timed(w4, st4, 2)
+            err4, dec4 = w4.verify_and_time_decode(ps4)
+            raw4 = w4.n * 8
+            out.setdefault("extra_configs", {})["C4a_slab"] = {
+                "config": "one C4 slab, 128x1024x1024 float64, field C4a (SURVEY 8d), ALGO_LORENZO_REG Lorenzo + regression per 6^3 block, abs errBound=1e-6, 1 GPU",
+                "value": round(raw4 / (el4 / st4) / 1e9, 3), "unit": "GB/s", "steps": st4, "ms_per_step": round(1e3 * el4 / st4, 4),
+                "ratio": round(raw4 / float(ps4), 4), "max_abs_err": err4, "err_bound_ok": bool(err4 <= 1e-6),
+                "stream_predictor": w4.stream_predictor(),
+                "decompress_device": {"ms": round(dec4, 4), "gbps": round(raw4 / (dec4 * 1e-3) / 1e9, 2)},
+                "note": "round 3: decompress 5.2 ms (181 launches for the chain of block fronts + a final pass); round 4: k_blk_local3v + k_blk_wave3, one launch"}
+            del w4
+        except Exception as e:  # noqa: BLE001
+            out.setdefault("extra_configs", {})["C4a_slab"] = {"error": repr(e)[:300]}
+
     # ---- CPU baseline on this box's host cores (rank 0, N=1 only; checker code, never the product) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)

@@ -72,6 +72,17 @@ def _share_torch_hip_runtime():
         import sys
         if "torch" in sys.modules:
             return
+        # torch itself, now: an `import torch` that comes AFTER this library has been at work on the device (contexts, streams, kernels
+        # launched) stalled for good in about one fresh process out of five on the MI355X boxes — inside torch/__init__'s load of its
+        # C extension, i.e. while torch's bundled libraries register their code objects with a HIP runtime that is already busy
+        # (caught with pytest's faulthandler_timeout, round 4). Before the first call there is nothing to collide with.
+        # SZ3HIP_NO_TORCH_PRELOAD=1 keeps the old behaviour (the runtime library alone is preloaded) for hosts that never import torch.
+        if os.environ.get("SZ3HIP_NO_TORCH_PRELOAD", "0") != "1":
+            try:
+                import torch  # noqa: F401
+                return
+            except Exception:  # noqa: BLE001 - no usable torch: fall through to the runtime library alone
+                pass
         spec = importlib.util.find_spec("torch")
         if spec is None or not spec.submodule_search_locations:
             return

@@ -28,6 +28,12 @@ def _built():
     yield
 
 
+try:  # torch before anything of libsz3hip touches the device (sz3_amd/__init__.py, _share_torch_hip_runtime: the other order can stall)
+    import torch  # noqa: F401
+except Exception:  # noqa: BLE001
+    pass
+
+
 def gpu_available():
     try:
         import torch

@@ -238,6 +238,11 @@ void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *miss
  * encoder only moves the rows' bit strings to their places; the verdict on the book is as for the unfused form, a miss repeats
  * the whole call in the two-pass form: the input must stay valid until sz3hip_compress_finish returns) */
 int sz3hip_last_call_fused(const sz3hip_ctx *ctx);
+/* 1 when the last finished compression of this context ran the 16-bit form of the one-byte stage-1 kernel (round 5: f32 data, 1-D ... 3-D
+ * arrays, behind a call whose probe found every lattice value within +-2047 steps): same bytes out as the one-byte kernel at 13 instead
+ * of 21 vector instructions per element. A lattice value beyond +-4095 (or a value that is not finite) voids the launch and the call is
+ * repeated with the one-byte kernel (the input must stay valid until sz3hip_compress_finish returns, as for every one-launch form). */
+int sz3hip_last_call_q16(const sz3hip_ctx *ctx);
 /* opt in to (1) / out of (0, the default) that form for this context; SZ3HIP_FUSED=1 in the environment makes 1 the default of every
  * context created afterwards. It halves the encoder's HBM traffic (no code array) and is byte-identical to the two-pass form, but on
  * MI355X it measured slower ("Round 4: the single-pass encoder"): the default stays the two-pass form. */
@@ -250,7 +255,8 @@ int sz3hip_debug_decode_info(sz3hip_ctx *ctx, uint32_t *out4);
 /* test hook: non-zero routes every shape through the generic (any-shape) stage-1 kernel instead of the tuned one */
 void sz3hip_debug_force_generic(int on);
 /* development switches (bit mask, process-wide; 0 = product behaviour). They force one of two equivalent paths, results unchanged (tests compare them):
- * 32 no marching kernel, 64 no one-byte codes, 128 interpolation pass by pass, one point per thread (no 8-wide level-1
+ * 4 the one-launch block decoders' retry through the launch-per-front decoders, taken as if a flag poll had given up,
+ * 8 no 16-bit form of the one-byte stage-1 kernel (round 5), 32 no marching kernel, 64 no one-byte codes, 128 interpolation pass by pass, one point per thread (no 8-wide level-1
  * kernels, no level kernels), 256 no stage-1 specialisation by code width, 512 decoder without the fused x prefix sum,
  * 1024 code book without the two-class construction, 4096 stage 1 without the XCD-aware task order, 8192 interpolation
  * histogram with the large tier and the windowed tail passes, 16384 predictor sets with Lorenzo-2 / regression fall back

@@ -72,12 +72,14 @@ def _share_torch_hip_runtime():
         import sys
         if "torch" in sys.modules:
             return
-        # torch itself, now: an `import torch` that comes AFTER this library has been at work on the device (contexts, streams, kernels
-        # launched) stalled for good in about one fresh process out of five on the MI355X boxes — inside torch/__init__'s load of its
-        # C extension, i.e. while torch's bundled libraries register their code objects with a HIP runtime that is already busy
-        # (caught with pytest's faulthandler_timeout, round 4). Before the first call there is nothing to collide with.
-        # SZ3HIP_NO_TORCH_PRELOAD=1 keeps the old behaviour (the runtime library alone is preloaded) for hosts that never import torch.
-        if os.environ.get("SZ3HIP_NO_TORCH_PRELOAD", "0") != "1":
+        # An `import torch` that comes AFTER this library has been at work on the device (contexts, streams, kernels launched) stalled
+        # for good in about one fresh process out of five on the MI355X boxes — inside torch/__init__'s load of its C extension, i.e.
+        # while torch's bundled libraries register their code objects with a HIP runtime that is already busy (caught with pytest's
+        # faulthandler_timeout, round 4). The cure is the ORDER — torch first — and it is the caller's to keep: programs that use
+        # torch beside this package import it before the first call (tests/conftest.py, bench.py, sz3_amd.distributed do), or set
+        # SZ3HIP_TORCH_PRELOAD=1 and have it imported here. By default only the runtime library is preloaded: a host that never
+        # touches torch (the CLI, the HDF5 filter under h5py, CPU-side tools) does not pay torch's import or its runtime initialisation.
+        if os.environ.get("SZ3HIP_TORCH_PRELOAD", "0") == "1":
             try:
                 import torch  # noqa: F401
                 return
@@ -161,6 +163,8 @@ def lib():
     L.sz3hip_set_stock_format.restype = None
     L.sz3hip_last_call_fused.argtypes = [C.c_void_p]
     L.sz3hip_last_call_fused.restype = C.c_int
+    L.sz3hip_last_call_q16.argtypes = [C.c_void_p]
+    L.sz3hip_last_call_q16.restype = C.c_int
     L.sz3hip_ctx_set_fused.argtypes = [C.c_void_p, C.c_int]
     L.sz3hip_ctx_set_fused.restype = None
     L.sz3hip_get_spec_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -441,6 +445,11 @@ class DeviceCompressor:
     def fused(self):
         """the last finished compression ran the fused stage 1 (coded with the previous call's book inside the predictor kernel)"""
         return bool(lib().sz3hip_last_call_fused(self._h))
+
+    @property
+    def q16(self):
+        """the last finished compression ran the 16-bit form of the one-byte stage-1 kernel (f32, lattice values within +-4095)"""
+        return bool(lib().sz3hip_last_call_q16(self._h))
 
     def spec_stats(self):
         h, m = C.c_uint32(), C.c_uint32()

@@ -262,6 +262,7 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     memset(c, 0, sizeof(*c));
     c->wide16 = -1;
     c->narrow_hint = c->cb_hint = -1;
+    c->q16_hint = c->q16_block = 0;
     c->device = device;
     c->dtype = dataType;
     c->max_n = max_elems;
@@ -583,6 +584,8 @@ static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *
     // (a caller that holds the histogram exchanges it between the stages — multi-GPU: the one-launch form's repeat of a whole
     // call from inside finish() could not redo that exchange, so such contexts keep the form that waits for the probe)
     if ((ctx->hist_exposed || ctx->hist_reduced) && p.hint_narrow > 0) p.hint_narrow = -1;
+    p.hint_q16 = allow_narrow && ctx->dtype == SZ3HIP_FLOAT && ctx->q16_hint > 0 && ctx->q16_block == 0 ? 1 : 0;
+    p.q16_flag = reinterpret_cast<uint32_t *>(ctx->d_counters + 11) + 1;  // zeroed with the counters
     if (allow_narrow && book_spec_ok(ctx, 0, (uint32_t)radius) && ctx->cb_hint == 0 && !ctx->lists_long && !ctx->hist_exposed) {
         // stage 2 will pack with the previous call's book: its code lengths let the one-byte kernel sum the code bits of the
         // 256-element segments (no bits pass), and the fold of the histogram rows moves into the scan's launch of stage 2
@@ -635,6 +638,7 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
     ctx->mode = p.mode;
     ctx->range_ready = p.range_kept != 0;
     ctx->s1_assumed_narrow = p.assumed_narrow != 0;
+    ctx->s1_q16 = p.assumed_q16 != 0;
     ctx->s1_spec = p.spec_lens != nullptr;
     ctx->seg_expected = p.seg_expected != 0 && !(szk_dbg_flags & 33554432);
     ctx->fold_rows = p.defer_fold ? p.fold_rows : 0;
@@ -1409,6 +1413,7 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     ap.dout_val = ctx->d_dout_val;
     ap.side = ctx->proto.predictor == 2 ? ctx->d_blk_side : nullptr;
     ap.assumed_narrow = ctx->s1_assumed_narrow ? 1 : 0;
+    ap.q16_flag = ctx->s1_q16 && ctx->proto.predictor == 0 ? reinterpret_cast<const uint32_t *>(ctx->d_counters + 11) + 1 : nullptr;
     ap.mode = ctx->mode;
     szk_merge_args mg;
     memset(&mg, 0, sizeof(mg));
@@ -1448,8 +1453,9 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     HIPCHK(hipEventSynchronize(ctx->ev_done));  // (the payload is complete: the state's copy is the last thing stage 2 enqueued)
     const bool fused_miss = ctx->s1_fused && (ctx->h_state->miss_kind != 0 || ctx->h_state->mispredict != 0);
     ctx->last_fused = ctx->s1_fused && !fused_miss;
+    ctx->last_q16 = ctx->s1_q16 && !(ctx->h_state->miss_kind & (32u | 128u)) && !fused_miss;
     ctx->last_spec_hit = ctx->s2_spec && ctx->h_state->miss_kind == 0 && ctx->h_state->mispredict == 0;
-    if ((ctx->h_state->miss_kind & 32u) || fused_miss) {
+    if ((ctx->h_state->miss_kind & (32u | 128u)) || fused_miss) {
         // stage 1 assumed one-byte codes (the form a context takes after a one-byte call) and this call's probe says two: the
         // whole call once more, in the form that waits for the probe. The input must still be where stage 1 found it.
         // Likewise behind a FUSED stage 1 whose book the verdict rejects (or that met a symbol the book has no code word for, or
@@ -1457,6 +1463,10 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
         ctx->redo_calls++;
         ctx->spec_misses++;  // (counted with the other failed shortcuts)
         if (ctx->h_state->miss_kind & 32u) ctx->narrow_hint = 0;
+        if (ctx->h_state->miss_kind & 128u) {  // the 16-bit stage 1 met a lattice value beyond its range: the one-byte form from here on
+            ctx->q16_hint = 0;
+            ctx->q16_block = 16;
+        }
         if (ctx->h_state->mispredict || (ctx->h_state->miss_kind & 2u)) ctx->cb_hint = -1;
         const int spec_was = ctx->spec_off;
         ctx->spec_off = 1;
@@ -1541,6 +1551,10 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     ctx->stats.n_symbols = 0;
     ctx->stats.narrow_codes = ctx->mode.allow && (uint64_t)st.probe[0] * 4096ull <= ctx->mode.n_samples;
     if (st.hdr.predictor == 0 && ctx->mode.allow) ctx->narrow_hint = ctx->stats.narrow_codes ? 1 : 0;
+    if (st.hdr.predictor == 0 && ctx->mode.allow) {
+        if (ctx->q16_block > 0) ctx->q16_block--;
+        ctx->q16_hint = ctx->stats.narrow_codes && st.probe[3] == 0 ? 1 : 0;
+    }
     ctx->stats.reserved = (ctx->wide16 > 0 ? 1u : 0u) | (st.probe[1] << 1);  // (development: window used, far-delta count)
     if (st.hdr.predictor == 1)  // interpolation: second histogram tier of the next call (one workgroup per CU against three)
     {
@@ -1653,6 +1667,7 @@ extern "C" void sz3hip_debug_force_generic(int on) { szk_force_generic = on; }
 // next call behaves like a context's first. The payload never depends on these; the time does (bench.py's cold numbers).
 extern "C" void sz3hip_ctx_forget(sz3hip_ctx *ctx) {
     ctx->narrow_hint = ctx->cb_hint = -1;
+    ctx->q16_hint = ctx->q16_block = 0;
     ctx->wide16 = -1;
     ctx->pack_wide = ctx->hist_big = ctx->hist_tail = ctx->blk_wide = 0;
     ctx->spec_valid = false;
@@ -1734,6 +1749,7 @@ int szi_stock_import(sz3hip_ctx *ctx, const szi_stock_params *p, const szg_geom 
     return 0;
 }
 extern "C" int sz3hip_last_call_fused(const sz3hip_ctx *ctx) { return ctx->last_fused ? 1 : 0; }
+extern "C" int sz3hip_last_call_q16(const sz3hip_ctx *ctx) { return ctx->last_q16 ? 1 : 0; }
 extern "C" void sz3hip_ctx_set_fused(sz3hip_ctx *ctx, int on) { ctx->fuse_on = on != 0; }
 extern "C" void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses) {
     *hits = ctx->spec_hits;

@@ -372,7 +372,7 @@ struct SlotLease {
             std::lock_guard<std::mutex> pl(g_pool_mu);
             s->busy = false;
         }
-        g_pool_cv.notify_one();
+        g_pool_cv.notify_all();  // (waiters of every (device, type) key share the variable: each rechecks its own key)
     }
     SlotLease(const SlotLease &) = delete;
     SlotLease &operator=(const SlotLease &) = delete;
@@ -769,8 +769,12 @@ int stock_decompress_interp(HostSlot *s, const sz3hip_config *conf, int dataType
         szk_stock_tree_dev td{d_L, d_R, d_C, d_t, d_lut, nc, offset};
         int passes = 0;
         const int rd = szk_launch_stock_huff_decode(&td, (const uint32_t *)d_bits, bit_bytes, n, d_start, d_last, d_next, d_base, d_count, d_flags, d_em, &passes, s->stream);
-        if (rd == -3) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (bit stream)");
-        if (rd) return fail(SZ3HIP_EHIP, "stock stream: device Huffman decoder failed (%d)", rd);
+        if (rd == -4) {  // the restart points did not settle within the pass cap: the bit-serial walk on the host
+            em_host.resize((size_t)n);
+            if (!stock::host_decode(tr, offset, bits, (size_t)bit_bytes, n, em_host.data())) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (bit stream)");
+            HIPCHK(hipMemcpyAsync(d_em, em_host.data(), (size_t)n * 2, hipMemcpyHostToDevice, s->stream));
+        } else if (rd == -3) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (bit stream)");
+        else if (rd) return fail(SZ3HIP_EHIP, "stock stream: device Huffman decoder failed (%d)", rd);
     }
     rc = szi_stock_import(s->ctx, &sp, &g, d_blk, d_em, d_unpred, n_unpred, d_tile_cnt, d_tile_base, d_vidx, d_vval, d_bad, s->dev_in, s->stream);
     if (rc) return rc;
@@ -784,7 +788,8 @@ int stock_decompress_interp(HostSlot *s, const sz3hip_config *conf, int dataType
 // the device in the reference's own arithmetic (sz3hip_stock.hip k_slr_*). 1-D .. 3-D arrays of float / double.
 template <typename T>
 static bool slr_coefficients(const sz3hip_config *conf, const stock::LorenzoReg &lr, const int *kinds, int n_kinds, bool composed, uint64_t nblocks, const uint64_t *nb,
-                             std::vector<uint8_t> &kind, std::vector<T> &coef) {
+                             std::vector<uint8_t> &kind, std::vector<T> &coef, bool &not_reproduced) {
+    not_reproduced = false;
     const int N = conf->N;
     const uint32_t B = (uint32_t)conf->blockSize;
     kind.assign((size_t)nblocks, 0);
@@ -826,7 +831,10 @@ static bool slr_coefficients(const sz3hip_config *conf, const stock::LorenzoReg 
                 // (a regression-only set runs without padding — Predictor.hpp's default — and the fallback's neighbours left of / above
                 // the array are then whatever lies in front of the element in MEMORY: the previous row's end, or nothing the array
                 // owns. Not reproduced for arrays of two and three dimensions: refused.)
-                if (!composed && N > 1) return false;
+                if (!composed && N > 1) {
+                    not_reproduced = true;  // (a well-formed stream: unsupported, not corrupt)
+                    return false;
+                }
             } else {
                 if (ci + (size_t)N + 1 > lr.coef_codes.size()) return false;
                 bool ok = true;
@@ -879,8 +887,12 @@ int stock_decompress_lorenzo_reg(HostSlot *s, const sz3hip_config *conf, int dat
     std::vector<uint8_t> kind;
     std::vector<float> cf32;
     std::vector<double> cf64;
-    const bool okc = cdt == SZ3HIP_FLOAT ? slr_coefficients<float>(conf, lr, kinds, n_kinds, composed, nblocks, nb, kind, cf32)
-                                        : slr_coefficients<double>(conf, lr, kinds, n_kinds, composed, nblocks, nb, kind, cf64);
+    bool not_reproduced = false;
+    const bool okc = cdt == SZ3HIP_FLOAT ? slr_coefficients<float>(conf, lr, kinds, n_kinds, composed, nblocks, nb, kind, cf32, not_reproduced)
+                                        : slr_coefficients<double>(conf, lr, kinds, n_kinds, composed, nblocks, nb, kind, cf64, not_reproduced);
+    if (!okc && not_reproduced)
+        return fail(SZ3HIP_EUNSUPPORTED, "stock ALGO_LORENZO_REG stream with regression alone and a block one element wide (2-D / 3-D): the reference's "
+                                         "unpadded fallback reads are not reproduced");
     if (!okc) return fail(SZ3HIP_EFORMAT, "corrupt stock ALGO_LORENZO_REG stream (selection or coefficient chain)");
     HIPCHK(hipSetDevice(s->device));
     int rc;
@@ -942,8 +954,12 @@ int stock_decompress_lorenzo_reg(HostSlot *s, const sz3hip_config *conf, int dat
         szk_stock_tree_dev td{d_L, d_R, d_C, d_t, d_lut, nc, lr.offset};
         int passes = 0;
         const int rd = szk_launch_stock_huff_decode(&td, (const uint32_t *)d_bits, bit_bytes, n, d_start, d_last, d_next, d_base, d_count, d_flags, d_em, &passes, s->stream);
-        if (rd == -3) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (bit stream)");
-        if (rd) return fail(SZ3HIP_EHIP, "stock stream: device Huffman decoder failed (%d)", rd);
+        if (rd == -4) {  // the restart points did not settle within the pass cap: the bit-serial walk on the host
+            em_host.resize((size_t)n);
+            if (!stock::host_decode(lr.tree, lr.offset, lr.bits, (size_t)bit_bytes, n, em_host.data())) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (bit stream)");
+            HIPCHK(hipMemcpyAsync(d_em, em_host.data(), (size_t)n * 2, hipMemcpyHostToDevice, s->stream));
+        } else if (rd == -3) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (bit stream)");
+        else if (rd) return fail(SZ3HIP_EHIP, "stock stream: device Huffman decoder failed (%d)", rd);
     }
     szk_slr_params sp;
     memset(&sp, 0, sizeof(sp));

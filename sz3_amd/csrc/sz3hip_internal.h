@@ -74,6 +74,10 @@ struct sz3hip_ctx {
     // what the previous call of this context found, so that this call launches one form of a kernel instead of two
     int narrow_hint;   // Lorenzo code width: 1 one byte, 0 two bytes, -1 unknown
     int cb_hint;       // code book form: 0 small alphabets, 1 wide, -1 unknown
+    int q16_hint;      // 1: the previous Lorenzo call's probe saw lattice values within +-Q16_LIM / 2 only (f32): stage 1 may take its 16-bit form
+    int q16_block;     // calls left to sit out after that form met a value beyond its range
+    bool s1_q16;       // the pending call's stage 1 ran the 16-bit form
+    bool last_q16;     // ... the last finished call's did (and was not repeated)
     bool range_ready;  // stage 1 of the pending call kept the alphabet's range words itself
     bool hist_exposed; // the caller holds a pointer to the histogram (multi-GPU exchange): its range is recomputed in stage 2
     int half_skip;     // decoder: calls left before half-width intermediates are tried again (after a call whose values overflowed)

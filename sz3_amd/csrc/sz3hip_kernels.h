@@ -65,6 +65,11 @@ struct szk_k1_params {
     uint32_t *seg_made;   // device flag, raised by the form that sums the segments
     int seg_expected;     // out: the launched form sums the segments when this call's probe keeps one-byte codes
     int assumed_narrow;   // out: the one-launch form was taken: it assumes one-byte codes and runs the probe itself
+    // the 16-bit form of the one-launch kernel (round 5, k_lorenzo_quant_march3q: f32, 1-D ... 3-D): taken when the context's previous
+    // call probed lattice values within +-Q16_LIM / 2 only (hint_q16 > 0); it raises *q16_flag on a value it does not take
+    int hint_q16;
+    int assumed_q16;      // out: that form was launched
+    uint32_t *q16_flag;   // device word, zeroed with the counters
     // defer_fold: the launcher leaves out k_hist_reduce (the fold rides in the encoder's scan launch, szk_encode_roles);
     // fold_rows (out): rows of hist_partial to fold, 0 when the launched kernels need no fold
     int defer_fold;
@@ -122,7 +127,7 @@ struct szk_state {
     uint32_t book_miss, miss_kind;   // (book_miss: unused) speculative stage 2: the encoder's output is void (stage 2 is repeated); why: 1 the previous call's code
                                      // book is not this call's, 2 code-book form declined, 4 outlier list too long for the short sort,
                                      // 8 stage 1 did not sum the segments' bits, 32 stage 1 assumed one-byte codes and the probe says two
-                                     // (the whole call is repeated)
+                                     // (the whole call is repeated), 128 the 16-bit stage 1 met a lattice value beyond its range (likewise)
     uint64_t n_vout_raw, n_dout_raw;  // the outlier counters before capping at the lists' capacity (what an overflowing call needs)
     uint32_t probe[6];  // copy of the probe counters (d_counters + 4): one device-to-host copy brings everything the host reads
 };
@@ -150,6 +155,7 @@ struct szk_asm_params {
     const uint8_t *side;  // predictor 2: the side section as the block kernels left it (else nullptr)
     int lists_by_roles;   // the outlier lists are sorted AND copied by role workgroups of the packer's launch (speculative stage 2)
     int assumed_narrow;   // stage 1 ran the one-launch form, which assumes one-byte codes: a probe that says otherwise raises miss_kind bit 32
+    const uint32_t *q16_flag;  // stage 1 ran the 16-bit form: the word it raises on a value it does not take (miss_kind bit 128), else nullptr
     szk_mode mode;
 };
 // speculative stage 2, small alphabets: work that rides in the encoder's two launches instead of a side stream

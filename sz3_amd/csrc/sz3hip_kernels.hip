@@ -573,10 +573,11 @@ __device__ __forceinline__ void probe_body(const T *__restrict__ in, const szk_k
     const uint64_t d0 = p.d[3], d1 = p.d[2], d2 = p.d[1];
     // counts per thread over a grid-stride loop, then one atomic per counter and WORKGROUP (on rough data every wave finds
     // some: 4096 waves x same-address atomics at ~90/us were 45 us of a 56 us kernel)
-    uint32_t n_big = 0, n_far = 0, n_pfar = 0;
+    uint32_t n_big = 0, n_far = 0, n_pfar = 0, n_qbig = 0;  // n_qbig: stencil values beyond Q16_LIM / 2 lattice steps, or not finite (the 16-bit form's licence)
     const uint64_t n_runs = (n + SZK_PROBE_STRIDE - 1) / SZK_PROBE_STRIDE;
     for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; (s >> 6) < n_runs; s += (uint64_t)gridDim.x * 256) {
     const uint64_t i = (s >> 6) * SZK_PROBE_STRIDE + (s & 63);  // runs of 64 consecutive elements, one run per stride
+    bool qbig = false;
     bool big = false, far = false, pfar = false;  // far: beyond the 8192-bin stage-1 window of the two-byte kernel, inside the 16384-bin one
                                                   // pfar: beyond the packers' 4096-entry table window, inside the doubled one
     if (i < n) {
@@ -594,7 +595,10 @@ __device__ __forceinline__ void probe_body(const T *__restrict__ in, const szk_k
             UQ q = 0;
             if (xx >= 0 && yy >= 0 && zz >= 0 && ww >= 0) {
                 bool bad;
-                q = (UQ)lat.quant(in[(((uint64_t)ww * d2 + (uint64_t)zz) * d1 + (uint64_t)yy) * d0 + (uint64_t)xx], bad);
+                const T v = in[(((uint64_t)ww * d2 + (uint64_t)zz) * d1 + (uint64_t)yy) * d0 + (uint64_t)xx];
+                q = (UQ)lat.quant(v, bad);
+                const T sv = v * lat.recip;
+                qbig |= !((sv < (T)0 ? -sv : sv) <= (T)2047);  // (NaN: counted)
             }
             delta = (__popc(c) & 1) ? (UQ)(delta - q) : (UQ)(delta + q);
         }
@@ -606,23 +610,26 @@ __device__ __forceinline__ void probe_body(const T *__restrict__ in, const szk_k
     n_big += big;
     n_far += far;
     n_pfar += pfar;
+    n_qbig += qbig;
     }
-    if (threadIdx.x < 3) s_p[threadIdx.x] = 0;
+    if (threadIdx.x < 4) s_p[threadIdx.x] = 0;
     __syncthreads();
     n_big = wave_sum(n_big);
     n_far = wave_sum(n_far);
     n_pfar = wave_sum(n_pfar);
+    n_qbig = wave_sum(n_qbig);
     if (lane_id() == 0) {
+        if (n_qbig) atomicAdd(&s_p[3], n_qbig);
         if (n_big) atomicAdd(&s_p[0], n_big);
         if (n_far) atomicAdd(&s_p[1], n_far);
         if (n_pfar) atomicAdd(&s_p[2], n_pfar);
     }
     __syncthreads();
-    if (threadIdx.x < 3 && s_p[threadIdx.x]) atomicAdd(probe_big + threadIdx.x, s_p[threadIdx.x]);  // ([1], [2]: read by the host after the call)
+    if (threadIdx.x < 4 && s_p[threadIdx.x]) atomicAdd(probe_big + threadIdx.x, s_p[threadIdx.x]);  // ([1], [2], [3]: read by the host after the call)
 }
 template <typename T, int NDIM>
 __global__ __launch_bounds__(256) void k_probe(const T *__restrict__ in, szk_k1_params p, uint64_t n, uint32_t *probe_big) {
-    __shared__ uint32_t s_p[3];
+    __shared__ uint32_t s_p[4];
     probe_body<T, NDIM>(in, p, n, probe_big, s_p);
 }
 
@@ -1510,6 +1517,261 @@ __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The 16-bit form of the one-byte kernel (round 5, f32 data, 1-D ... 3-D arrays). Same bricks, same walk and THE SAME BYTES out
+// as narrow_task — codes, histogram, segment bit sums, outlier lists — for every array whose lattice values all lie within
+// +-Q16_LIM (C2: |q| <= ~700), at 13 instead of 21 vector instructions per element (the one-byte kernel's bound was its issue
+// rate: 54 M wave instructions = ~100 us of its 147 at C2). What it does differently:
+//   * a lane's four lattice values are kept as TWO registers of packed 16-bit halves, (q0, q2) and (q1, q3) — the low 16 bits
+//     of the magic-number patterns, picked by one v_perm each. The x difference is two packed subtractions (the pair (q-1, q1)
+//     is one v_alignbit of the pair (q1, q3) and its wave_shr:1 copy); the y and z differences, the +127 and the min(., 255)
+//     are packed instructions over two elements each; the four code bytes are (t0, t2) | (t1, t3) << 8: one instruction.
+//     The Lorenzo stencil over 8 values of at most 4095 cannot wrap 16 bits;
+//   * multiply, add of the magic number, and the bound check's three operations run as packed-f32 instructions (two elements
+//     each); the range test of a value (|x / 2eb| <= 2^22, else q = 0) is not made per element at all:
+//   * the kernel ASSUMES |q| <= Q16_LIM and finite data. A running maximum of |rint(x / 2eb)| (two v_max3 per row) is tested
+//     once per plane, non-finite values fail the bound check (NaN compares false) and are looked at in the rare branch: either
+//     raises q16_flag and everything this launch wrote is void — the packer's launch reports it (miss_kind bit 128) and the
+//     host repeats the call with narrow_task's kernel (and keeps to it for the following calls). A context takes this form
+//     behind a call whose probe saw nothing beyond Q16_LIM / 2 (probe counter [3]);
+//   * the code-length table of the speculative bit accounting is laid out like the histogram ([byte][4 copies]): a code's
+//     histogram address is also the address of its length.
+// ------------------------------------------------------------------------------------------------------------
+#define Q16_LIM 4095.0f
+typedef float v2f32 __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (v2u16)(__builtin_bit_cast(v2u16, a) - __builtin_bit_cast(v2u16, b)));
+}
+__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (v2u16)(__builtin_bit_cast(v2u16, a) + __builtin_bit_cast(v2u16, b)));
+}
+__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(v2u16, a), __builtin_bit_cast(v2u16, b)));
+}
+__device__ __forceinline__ uint32_t pk_max16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16, a), __builtin_bit_cast(v2u16, b)));
+}
+// the low halves of two registers side by side: (lo16(a), lo16(b))
+__device__ __forceinline__ uint32_t pk_lo16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+// half * 16 + add (the byte address of a code's histogram counter): one v_mad_u32_u16 either way
+__device__ __forceinline__ uint32_t mad16_lo(uint32_t p, uint32_t add) {
+    uint32_t d;
+    asm("v_mad_u32_u16 %0, %1, 16, %2" : "=v"(d) : "v"(p), "v"(add));
+    return d;
+}
+__device__ __forceinline__ uint32_t mad16_hi(uint32_t p, uint32_t add) {
+    uint32_t d;
+    asm("v_mad_u32_u16 %0, %1, 16, %2 op_sel:[1,0,0,0]" : "=v"(d) : "v"(p), "v"(add));
+    return d;
+}
+#define Q16_LEN_OFF (NARROW_BINS * 16)  // byte offset of the length table behind the histogram: [byte value][4 copies], the length in the word's low byte
+template <int TY> struct Q16Plane {
+    float4 rq[TY + 1];
+    float rl[TY + 1];
+    bool rok[TY + 1];
+};
+template <int TY, bool EDGE>
+__device__ __forceinline__ void narrow16_task(NarrowCtx<float> &c, const Lattice<float> &lat, uint32_t *q16_flag, uint32_t x0, uint32_t y0, uint32_t z0) {
+    const uint32_t d0 = c.d0, d1 = c.d1, d2 = c.d2;
+    const int lane = c.lane;
+    const uint32_t x = x0 + 4u * (uint32_t)lane;
+    const bool xok = EDGE ? x < d0 : true;
+    const uint32_t lane_off = xok ? x : 0u;
+    const bool has_left = x0 > 0;
+    const uint32_t c4 = ((uint32_t)lane & 3u) * 4u;
+    uint8_t *const lds = reinterpret_cast<uint8_t *>(c.lh);
+    const v2f32 recip2 = {lat.recip, lat.recip}, magic2 = {12582912.0f, 12582912.0f}, two_eb2 = {lat.two_eb, lat.two_eb};
+
+    uint32_t ppA[TY], ppB[TY];  // d2 of the previous plane, (x0, x2) and (x1, x3)
+#pragma unroll
+    for (int yy = 0; yy < TY; yy++) ppA[yy] = ppB[yy] = 0;
+
+    auto fetch = [&](int zz, Q16Plane<TY> &R) {
+        const float *src = c.in + (uint64_t)(z0 + (uint32_t)zz) * c.plane;
+#pragma unroll
+        for (int r = 0; r <= TY; r++) {
+            const uint32_t gy = y0 + (uint32_t)r - 1u;  // (r = 0 at y0 = 0 wraps: not below d1)
+            R.rok[r] = gy < d1;
+            if (R.rok[r]) {
+                const float *row = src + (uint64_t)gy * d0;
+                R.rq[r] = *reinterpret_cast<const float4 *>(row + lane_off);
+                if (has_left) R.rl[r] = row[x0 - 1];
+            }
+        }
+    };
+    Q16Plane<TY> pa;
+    auto work = [&](int zz, Q16Plane<TY> &R) {
+        const uint32_t gz = z0 + (uint32_t)zz;
+        uint32_t pd1A = 0, pd1B = 0;
+        uint32_t bits_rows[(TY + 1) / 2];
+#pragma unroll
+        for (int k = 0; k < (TY + 1) / 2; k++) bits_rows[k] = 0;
+        float qmax = 0.0f;  // max |rint(x / 2eb)| over the plane's coded rows
+#pragma unroll
+        for (int r = 0; r <= TY; r++) {
+            uint32_t d1A = 0, d1B = 0;
+            v2f32 s01 = {0.0f, 0.0f}, s23 = {0.0f, 0.0f}, t01 = magic2, t23 = magic2;
+            if (R.rok[r]) {
+                const v2f32 v01 = {R.rq[r].x, R.rq[r].y}, v23 = {R.rq[r].z, R.rq[r].w};
+                s01 = v01 * recip2;
+                s23 = v23 * recip2;
+                t01 = s01 + magic2;
+                t23 = s23 + magic2;
+                uint32_t PA = pk_lo16(__float_as_uint(t01.x), __float_as_uint(t23.x));
+                uint32_t PB = pk_lo16(__float_as_uint(t01.y), __float_as_uint(t23.y));
+                if (EDGE) {
+                    PA = xok ? PA : 0u;
+                    PB = xok ? PB : 0u;
+                }
+                const uint32_t leftp = has_left ? __float_as_uint(R.rl[r] * lat.recip + 12582912.0f) << 16 : 0u;
+                const uint32_t pv = (uint32_t)dpp_wave_shr1((int32_t)leftp, (int32_t)PB);
+                const uint32_t XA = __builtin_amdgcn_alignbit(PB, pv, 16);  // (q(x0 - 1), q(x1))
+                d1A = pk_sub16(PA, XA);
+                d1B = pk_sub16(PB, PA);
+            }
+            uint32_t sA = 0, sB = 0;
+            if (r > 0) {
+                const uint32_t d2A = pk_sub16(d1A, pd1A), d2B = pk_sub16(d1B, pd1B);
+                sA = pk_sub16(d2A, ppA[r - 1]);
+                sB = pk_sub16(d2B, ppB[r - 1]);
+                ppA[r - 1] = d2A;
+                ppB[r - 1] = d2B;
+            }
+            pd1A = d1A;
+            pd1B = d1B;
+            if (r == 0 || zz < 0) continue;  // halo row / halo plane: state only
+            if (!R.rok[r]) continue;         // beyond the array (EDGE bricks only)
+            // ---- codes, histogram, store ----
+            const uint64_t grow = (uint64_t)gz * c.plane + (uint64_t)(y0 + r - 1) * d0;
+            const uint32_t tqA = pk_add16(sA, 0x007F007Fu), tqB = pk_add16(sB, 0x007F007Fu);
+            const uint32_t tA = pk_min16(tqA, 0x00FF00FFu), tB = pk_min16(tqB, 0x00FF00FFu);  // (t0, t2), (t1, t3)
+            const uint32_t tm = pk_max16(tA, tB);
+            // the bound check, the reference's acceptance test on the lattice reconstruction: Lattice<float>::bad's expression
+            const v2f32 r01 = t01 - magic2, r23 = t23 - magic2;  // rint(s) as floats
+            const v2f32 v01 = {R.rq[r].x, R.rq[r].y}, v23 = {R.rq[r].z, R.rq[r].w};
+            const v2f32 e01 = r01 * two_eb2 - v01, e23 = r23 * two_eb2 - v23;
+            const bool b0 = !(fabsf(e01.x) <= lat.eb_lo), b1 = !(fabsf(e01.y) <= lat.eb_lo), b2 = !(fabsf(e23.x) <= lat.eb_lo), b3 = !(fabsf(e23.y) <= lat.eb_lo);
+            qmax = fmaxf(fmaxf(qmax, fabsf(r01.x)), fabsf(r01.y));
+            qmax = fmaxf(fmaxf(qmax, fabsf(r23.x)), fabsf(r23.y));
+            bool rare = b0 | b1 | b2 | b3 | ((tm & 0xFFFFu) == 255u) | (tm >= 0x00FF0000u);
+            if (EDGE) rare &= xok;
+            const uint32_t a0 = mad16_lo(tA, c4), a1 = mad16_lo(tB, c4), a2 = mad16_hi(tA, c4), a3 = mad16_hi(tB, c4);
+            if (!EDGE || xok) {
+                atomicAdd(reinterpret_cast<uint32_t *>(lds + a0), 1u);
+                atomicAdd(reinterpret_cast<uint32_t *>(lds + a1), 1u);
+                atomicAdd(reinterpret_cast<uint32_t *>(lds + a2), 1u);
+                atomicAdd(reinterpret_cast<uint32_t *>(lds + a3), 1u);
+                __builtin_nontemporal_store(tA | (tB << 8), reinterpret_cast<uint32_t *>(c.codes8 + grow + x));
+            }
+            if (c.s_len) {
+                uint32_t b4 = (uint32_t)lds[Q16_LEN_OFF + a0] + lds[Q16_LEN_OFF + a1] + lds[Q16_LEN_OFF + a2] + lds[Q16_LEN_OFF + a3];
+                if (EDGE) b4 = xok ? b4 : 0u;
+                bits_rows[(r - 1) >> 1] |= ((r - 1) & 1) ? b4 << 16 : b4;
+            }
+            if (__builtin_amdgcn_ballot_w64(rare)) {  // some lane has outliers (or values this form does not take): rare
+                const bool bad[4] = {b0, b1, b2, b3};
+                const float sv[4] = {s01.x, s01.y, s23.x, s23.y};
+                const uint32_t t[4] = {tA & 0xFFFFu, tB & 0xFFFFu, tA >> 16, tB >> 16};
+                const uint32_t delta[4] = {(uint32_t)(int32_t)(int16_t)(sA & 0xFFFFu), (uint32_t)(int32_t)(int16_t)(sB & 0xFFFFu),
+                                           (uint32_t)(int32_t)(int16_t)(sA >> 16), (uint32_t)(int32_t)(int16_t)(sB >> 16)};
+                uint32_t tmask = 0, badmask = 0;
+                bool alien = false;  // beyond the lattice, Inf, NaN: the one-byte kernel gives them q = 0, this form has no such test
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    tmask |= (uint32_t)(rare && t[i] == 255u) << i;
+                    badmask |= (uint32_t)(rare && bad[i]) << i;
+                    alien |= rare && bad[i] && !(fabsf(sv[i]) <= 4194304.0f);
+                }
+                if (alien) atomicOr(q16_flag, 1u);
+                narrow_rare<float>(c, grow + x, delta, tmask, badmask);
+            }
+        }
+        if (zz >= 0) {
+            bool big = !(qmax <= Q16_LIM);
+            if (EDGE) big &= xok;
+            if (__builtin_amdgcn_ballot_w64(big)) {
+                if (big) atomicOr(q16_flag, 1u);
+            }
+        }
+        if (c.s_len && zz >= 0) {  // the plane's segment sums: one wave reduction per pair of rows
+#pragma unroll
+            for (int k = 0; k < (TY + 1) / 2; k++) {
+                const uint32_t tot = wave_sum(bits_rows[k]);
+                const uint32_t ra = y0 + 2u * k, rb = ra + 1u;
+                if (lane == 0) {
+                    const uint64_t g0 = (uint64_t)gz * c.plane + x0;
+                    if (ra < d1) c.seg_bits[(g0 + (uint64_t)ra * d0) >> 8] = (uint16_t)(tot & 0xFFFFu);
+                    if (2 * k + 1 < TY && rb < d1) c.seg_bits[(g0 + (uint64_t)rb * d0) >> 8] = (uint16_t)(tot >> 16);
+                }
+            }
+        }
+    };
+    int zz = z0 > 0 ? -1 : 0;
+    const int zend = d2 - z0 < (uint32_t)MARCH_TZ ? (int)(d2 - z0) : MARCH_TZ;
+    for (; zz < zend; zz++) {
+        fetch(zz, pa);
+        work(zz, pa);
+    }
+}
+template <int TY>
+__device__ __forceinline__ void march_narrow16(const float *__restrict__ in, uint16_t *__restrict__ codes, const szk_k1_params &p, uint32_t ntasks,
+                                               uint32_t *lh, uint64_t (*s_oq_idx)[MarchLds<1, false>::OQ], uint32_t (*s_oq_val)[MarchLds<1, false>::OQ]) {
+    const Lattice<float> lat(p.lat);
+    NarrowCtx<float> c;
+    c.in = in;
+    c.codes8 = reinterpret_cast<uint8_t *>(codes);
+    c.p = &p;
+    c.d0 = (uint32_t)p.d[3];
+    c.d1 = (uint32_t)p.d[2];
+    c.d2 = (uint32_t)p.d[1];
+    c.plane = (uint64_t)c.d1 * c.d0;
+    c.vol = c.plane * c.d2;
+    c.lh = lh;
+    c.lane = lane_id();
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    c.oq_idx = s_oq_idx[wv];
+    c.oq_val = s_oq_val[wv];
+    c.oq_n = 0;
+    const bool acct = p.spec_lens != nullptr && c.d0 % MARCH_TX == 0;
+    c.s_len = acct ? reinterpret_cast<const uint8_t *>(lh) + Q16_LEN_OFF : nullptr;
+    c.seg_bits = p.seg_bits;
+    c.s_enc = nullptr;
+    c.stage = nullptr;
+    c.slot = nullptr;
+    c.slot_w = c.slot_base = c.st_cnt = 0;
+    c.seg_base = p.seg_base;
+    for (int i = threadIdx.x; i < NARROW_BINS * 4; i += 256) lh[i] = 0;
+    {
+        const uint32_t b = threadIdx.x;  // 256 threads, 256 byte values; 255 = the delta outliers' symbol 0
+        const uint32_t len = acct ? p.spec_lens[b == 255u ? 0u : b + p.radius - 127u] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) lh[NARROW_BINS * 4 + b * 4 + k] = len;
+        if (acct && blockIdx.x == 0 && threadIdx.x == 0) *p.seg_made = 1u;
+    }
+    __syncthreads();
+    const uint32_t ntx = (c.d0 + MARCH_TX - 1) / MARCH_TX, nty = (c.d1 + TY - 1) / TY;
+    const uint32_t per_xcd = gridDim.x / 8u;
+    const uint32_t wg_seq = gridDim.x % 8u == 0 && !(p.dbg & 4096u) ? (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : blockIdx.x;
+    const uint32_t nwaves = gridDim.x * 4u;
+    for (uint32_t task = wg_seq * 4 + wv; task < ntasks; task += nwaves) {
+        uint32_t b = task;
+        const uint32_t x0 = (b % ntx) * MARCH_TX;
+        b /= ntx;
+        const uint32_t y0 = (b % nty) * TY;
+        const uint32_t z0 = (b / nty) * MARCH_TZ;
+        if (x0 + MARCH_TX <= c.d0 && y0 + TY <= c.d1) narrow16_task<TY, false>(c, lat, p.q16_flag, x0, y0, z0);
+        else narrow16_task<TY, true>(c, lat, p.q16_flag, x0, y0, z0);
+    }
+    narrow_oq_flush(c);
+    __syncthreads();
+    uint32_t *row = p.hist_partial + (uint64_t)blockIdx.x * HIST_WIN;
+    for (int bnn = threadIdx.x; bnn < HIST_WIN; bnn += 256) {
+        const int t = bnn - (HIST_WIN / 2 - 127);
+        row[bnn] = (t >= 0 && t < 255) ? lh[t * 4] + lh[t * 4 + 1] + lh[t * 4 + 2] + lh[t * 4 + 3] : 0u;
+    }
+}
+
 // LDS histogram. One-byte codes (narrow deltas): 1024 bins x 4 copies around the radius; two-byte codes (deltas of
 // hundreds or thousands of lattice steps, e.g. C4's 1e-6 on f64): MARCH_WIDE_WIN bins x 1 copy — with the narrow window
 // nearly every element of such a field would fall through to a global atomic. Last word = overflow bin (never flushed).
@@ -1553,9 +1815,23 @@ __global__ __launch_bounds__(256) MARCH3_ATTR void k_lorenzo_quant_march3(const 
     __shared__ uint64_t s_oq_idx[4][L::OQ];
     __shared__ OQV s_oq_val[4][L::OQ];
     __shared__ uint8_t s_len[256];
-    __shared__ uint32_t s_p[3];
+    __shared__ uint32_t s_p[4];
     probe_body<T, NDIM>(in, p, p.mode.n_total, p.mode.probe_big, s_p);
     march_narrow<T, NDIM, TY>(in, codes, p, ntasks, lh, s_len, s_oq_idx, s_oq_val);
+}
+// The 16-bit form of the one-launch kernel (round 5, narrow16_task): f32 data whose lattice values the previous call's probe found
+// within +-Q16_LIM / 2. It assumes one-byte codes like the form above AND lattice values within +-Q16_LIM; a value beyond that
+// (or not finite) raises q16_flag, the packer's launch reports it (miss_kind bit 128) and the host repeats the call above.
+template <int TY>
+__global__ __launch_bounds__(256) void k_lorenzo_quant_march3q(const float *__restrict__ in, uint16_t *__restrict__ codes,
+                                                               szk_k1_params p, uint32_t ntasks, uint32_t nrows) {
+    using L = MarchLds<1, false>;
+    __shared__ uint32_t lh[NARROW_BINS * 8 + 4];  // histogram [byte][4 copies], behind it the code lengths in the same layout
+    __shared__ uint64_t s_oq_idx[4][L::OQ];
+    __shared__ uint32_t s_oq_val[4][L::OQ];
+    __shared__ uint32_t s_p[4];
+    probe_body<float, 3>(in, p, p.mode.n_total, p.mode.probe_big, s_p);
+    march_narrow16<TY>(in, codes, p, ntasks, lh, s_oq_idx, s_oq_val);
 }
 // The FUSED form of the one-launch kernel (round 4): a context whose previous call left a small code book codes with THAT book
 // inside stage 1 — the rows' bit strings leave the kernel instead of one byte per element (4 + 0.5 B/elem instead of 4 + 1, and
@@ -1573,7 +1849,7 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march3f(const T *__restri
     __shared__ uint32_t lh[NARROW_BINS * 4 + 4];
     __shared__ uint64_t s_oq_idx[4][L::OQ];
     __shared__ OQV s_oq_val[4][L::OQ];
-    __shared__ uint32_t s_p[3];
+    __shared__ uint32_t s_p[4];
     __shared__ uint32_t s_fenc[256];
     __shared__ __align__(16) uint32_t s_fstage[4 * FUSE_STAGE_WORDS(TY)];
     probe_body<T, NDIM>(in, p, p.mode.n_total, p.mode.probe_big, s_p);
@@ -3204,6 +3480,7 @@ __device__ void assemble_body(const szk_asm_params &p, uint64_t tid, uint64_t nt
         for (int i = 0; i < 6; i++) p.state->probe[i] = reinterpret_cast<const uint32_t *>(p.n_vout + 4)[i];
         // stage 1 assumed one-byte codes (one-launch form) and this call's probe says two: everything since is void
         if (p.assumed_narrow && !szk_is_narrow(p.mode)) atomicOr(&p.state->miss_kind, 32u);
+        if (p.q16_flag && *p.q16_flag) atomicOr(&p.state->miss_kind, 128u);  // the 16-bit stage 1 met a value it does not take: the call is repeated
         if (!p.lists_by_roles) {  // (role mode: the book role of the same launch writes these; miss_kind was zeroed by layout_pre)
             p.state->mispredict = (uint32_t)p.n_vout[7];                                  // (d_counters[7]: raised by a code-book form launched alone)
             p.state->book_miss = 0;
@@ -4699,8 +4976,9 @@ static uint32_t k1_grid(const void *kernel, uint64_t ntiles) {
 // grid (= rows of the fold); the one the probe did not choose returns at once.
 template <typename T, int NDIM, int TY, bool WIN16>
 static void launch_march_w(const void *d_in, uint16_t *codes, szk_k1_params &p, uint64_t nb, hipStream_t s) {
-    uint32_t grid;
+    uint32_t grid = 0;
     p.seg_expected = 0;
+    p.assumed_q16 = 0;
     if (p.prof_ev0) (void)hipEventRecord((hipEvent_t)p.prof_ev0, s);
     if (p.mode.allow && !(szk_dbg_flags & 256) && p.hint_narrow > 0 && !(szk_dbg_flags & 131072)) {
         // the context's previous call took one-byte codes: one launch of the form built around them (it decides the width from
@@ -4718,6 +4996,13 @@ static void launch_march_w(const void *d_in, uint16_t *codes, szk_k1_params &p, 
                 grid = k1_grid((const void *)k_lorenzo_quant_march3f<T, 3, TY>, (nb + 3) / 4);
                 p.fuse_geom[3] = slot_words;
                 hipLaunchKernelGGL((k_lorenzo_quant_march3f<T, 3, TY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
+            }
+        } else if (NDIM == 3 && sizeof(T) == 4 && p.hint_q16 > 0 && p.q16_flag && p.d[0] == 1 && !(szk_dbg_flags & 8)) {
+            // the 16-bit form: the previous call's probe saw lattice values within +-Q16_LIM / 2 only (debug flag 8 keeps the form below)
+            if constexpr (NDIM == 3 && sizeof(T) == 4) {
+                p.assumed_q16 = 1;
+                grid = k1_grid((const void *)k_lorenzo_quant_march3q<TY>, (nb + 3) / 4);
+                hipLaunchKernelGGL((k_lorenzo_quant_march3q<TY>), dim3(grid), dim3(256), 0, s, (const float *)d_in, codes, p, (uint32_t)nb, grid);
             }
         } else {
             grid = k1_grid((const void *)k_lorenzo_quant_march3<T, NDIM, TY>, (nb + 3) / 4);

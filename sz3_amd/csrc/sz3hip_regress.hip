@@ -2101,12 +2101,20 @@ __global__ __launch_bounds__(192, 4) void k_blk_local3v(const uint16_t *__restri
 // for their slowest group). Here the groups are handed out by a ticket counter in the fronts' order (slot = position in the
 // enumeration front by front; a slot without a group is skipped) to workgroups that stay: a group waits for the flags of its seven
 // lower neighbours, and every group it can wait for holds a smaller ticket — taken by a workgroup that is running — so the waits end
-// (the poll is bounded all the same: ctl[1] is raised, and the array comes out wrong, should a flag never arrive). What travels
+// (the poll is bounded all the same: ctl[1] is raised should a flag never arrive, the host fetches the word behind the launch and sends
+// the stream through the launch-per-front decoders instead: szk_launch_blk_decompress). What travels
 // between groups is a group's outer shell (the two top layers of lattice values in every dimension), written over its P in the work
 // array, in the codes' order, released with the group's flag; everything else a group computes goes out as final values (no
 // k_blk_final pass over the array). k_blk_local3<WORK> ran before: P of every Lorenzo block and the lattice values of the regression
 // blocks are in the work array, the regression blocks' final values in the output.
 // ctl: [0] ticket, [1] a wait gave up, [4 ...] the groups' flags (zeroed by the caller).
+// Memory order of the exchange — a contract with THIS target, not the HIP memory model's release / acquire pair (which costs a write-back
+// of the L2's dirty lines per group: 16 ms, see below): a shell travels through relaxed agent-scope atomic stores and loads, which on
+// gfx950 go past the per-XCD L2s to memory, the flag's store is issued behind s_waitcnt vmcnt(0) of the shell's stores (in-order return
+// on one counter), and a reader's shell loads are issued behind its flag load's return. Another target must revisit this.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_blk_wave3 / k_blkn_wave2: the inter-workgroup shell exchange is written for gfx950's memory path (see the comment above)"
+#endif
 template <typename T, int CB, int G, int NL>  // NL: the layers of a block that are faces — 2 when the set holds second-order Lorenzo
 __global__ __launch_bounds__(512, 4) void k_blk_wave3(void *work_, void *d_out, szk_blk_params p, uint32_t *ctl, uint32_t nslots) {
     using Q = typename QTraits<T>::Q;
@@ -5198,14 +5206,17 @@ int szk_launch_blk_side(const szk_blk_params *p, const szk_blk_scratch *sc, cons
     SZK_CHECK_LAUNCH();
     return 0;
 }
-int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, const szk_blk_params *p, const szk_blk_scratch *sc,
-                              const uint8_t *payload, const szh_header *h, const szh_offsets *o, int64_t *coef_by_rank, hipStream_t s,
-                              hipEvent_t side_done) {
+// (dbg = the debug flags in force: the caller's retry ORs in the switches that take the launch-per-front decoders; *ctl_out: the
+// control words of a one-launch decoder, when one was taken — [1] is raised by a flag poll that gave up)
+static int blk_decompress_impl(int dtype, const uint16_t *codes, void *d_out, const szk_blk_params *p, const szk_blk_scratch *sc,
+                               const uint8_t *payload, const szh_header *h, const szh_offsets *o, int64_t *coef_by_rank, hipStream_t s,
+                               hipEvent_t side_done, const int dbg, uint32_t **ctl_out) {
+    *ctl_out = nullptr;
     const uint32_t nblocks = blk_count_blocks(p);
     // (k_blk_local3v reads the codes themselves: the far deltas alone go to the work array; debug flag 16: the expanded copy and the
     // wave-per-block pass)
-    const bool fusedv = p->ndim == 3 && p->B == 6 && p->carry && !(szk_dbg_flags & (32768 | 65536 | 8388608 | 16));
-    const bool wave2 = p->ndim == 2 && !(p->mask & 2u) && p->B <= 16 && p->carry && !(szk_dbg_flags & (8388608 | 65536));  // (k_blkn_wave2 reads the codes too)
+    const bool fusedv = p->ndim == 3 && p->B == 6 && p->carry && !(dbg & (32768 | 65536 | 8388608 | 16));
+    const bool wave2 = p->ndim == 2 && !(p->mask & 2u) && p->B <= 16 && p->carry && !(dbg & (8388608 | 65536));  // (k_blkn_wave2 reads the codes too)
     if (p->ndim == 1 || fusedv || wave2) {
         if (szk_launch_scatter_deltas(dtype, h->n, payload, o, h->n_dout, p->qwork, s)) return -1;
     } else if (szk_launch_expand_deltas(dtype, codes, h->n, (int)h->radius, payload, o, h->n_dout, p->qwork, s)) return -1;
@@ -5231,7 +5242,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
         const uint32_t ntiles = (nblocks + BLKN_TILE - 1) / BLKN_TILE;
         // blocks of up to 128 values, a multiple of 8: four blocks per wave (debug flag 134217728: a wave per block)
-        const bool rows = p->B <= 128 && p->B % 8 == 0 && !(szk_dbg_flags & 134217728);
+        const bool rows = p->B <= 128 && p->B % 8 == 0 && !(dbg & 134217728);
         const uint32_t grow = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 15) / 16);
 #define BLKN2_DEC(T, QT)                                                                                                                          \
     do {                                                                                                                                          \
@@ -5254,6 +5265,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         const uint64_t nslots = (uint64_t)ng1 * ng2;
         uint32_t *ctl = reinterpret_cast<uint32_t *>(p->carry);
         if (hipMemsetAsync(ctl, 0, (4 + (size_t)nslots) * 4, s) != hipSuccess) return -1;
+        *ctl_out = ctl;
         const uint32_t gw = (uint32_t)std::min<uint64_t>(nslots, dtype == 0 ? 2048 : 1024);
         if (dtype == 0) {
             hipLaunchKernelGGL(k_blkn_pre<float>, dim3(gpre), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank, 1);
@@ -5270,7 +5282,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
     if (p->ndim < 3) {
         const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
         // 1-D, blocks of up to 128 values, a multiple of 8: four blocks per wave (debug flag 134217728: a wave per block)
-        const bool rows1 = p->ndim == 1 && p->B <= 128 && p->B % 8 == 0 && !(szk_dbg_flags & 134217728);
+        const bool rows1 = p->ndim == 1 && p->B <= 128 && p->B % 8 == 0 && !(dbg & 134217728);
         const uint32_t grow1 = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 15) / 16);
         if (rows1) {
             if (dtype == 0) hipLaunchKernelGGL(k_blkn_pre1_rows<float>, dim3(grow1), dim3(256), 0, s, codes, p->qwork, d_out, *p, nblocks, sc->rank, coef_by_rank);
@@ -5281,7 +5293,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         if (p->ndim == 1) {
             const uint32_t ntiles = (nblocks + BLKN_TILE - 1) / BLKN_TILE;
             // blocks of up to 128 values, a multiple of 8: four blocks per wave (debug flag 134217728: a wave per block)
-            const bool rows = p->B <= 128 && p->B % 8 == 0 && !(szk_dbg_flags & 134217728);
+            const bool rows = p->B <= 128 && p->B % 8 == 0 && !(dbg & 134217728);
             const uint32_t grow = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 15) / 16);
             if (dtype == 0) {
                 hipLaunchKernelGGL(k_blkn_scan_tile<int32_t>, dim3(ntiles), dim3(1024), 0, s, p->sel, nblocks, p->carry);
@@ -5302,7 +5314,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
                 if (dtype == 0) hipLaunchKernelGGL(k_blkn_decode2s<float>, dim3((nfront + 3) / 4), dim3(256), 0, s, p->qwork, d_out, *p, d, by_lo, nfront);
                 else hipLaunchKernelGGL(k_blkn_decode2s<double>, dim3((nfront + 3) / 4), dim3(256), 0, s, p->qwork, d_out, *p, d, by_lo, nfront);
             }
-        } else if (p->B <= 16 && !(szk_dbg_flags & 8388608)) {  // groups of 4 x 4 blocks per workgroup, a launch per front (debug flag 65536; 8388608: a block per wave)
+        } else if (p->B <= 16 && !(dbg & 8388608)) {  // groups of 4 x 4 blocks per workgroup, a launch per front (debug flag 65536; 8388608: a block per wave)
             const uint32_t ng1 = (p->nb[1] + BLKN_G - 1) / BLKN_G, ng2 = (p->nb[2] + BLKN_G - 1) / BLKN_G;
             for (uint32_t d = 0; d < ng1 + ng2 - 1; d++) {
                 const uint32_t gy_lo = d >= ng2 ? d - (ng2 - 1) : 0, gy_hi = d < ng1 - 1 ? d : ng1 - 1;
@@ -5319,7 +5331,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
             }
         }
     } else
-    if (p->B == 6 && p->carry && !(szk_dbg_flags & (32768 | 65536 | 8388608))) {  // one launch for the chain of fronts (k_blk_wave3)
+    if (p->B == 6 && p->carry && !(dbg & (32768 | 65536 | 8388608))) {  // one launch for the chain of fronts (k_blk_wave3)
         constexpr uint32_t G = 3;
         const uint32_t ng0 = (p->nb[0] + G - 1) / G, ng1 = (p->nb[1] + G - 1) / G, ng2 = (p->nb[2] + G - 1) / G;
         const uint32_t ngd = ng0 + ng1 + ng2 - 2;
@@ -5327,6 +5339,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         if (nslots > 0xFFFFFFF0ull) return -1;
         uint32_t *ctl = reinterpret_cast<uint32_t *>(p->carry);
         if (hipMemsetAsync(ctl, 0, (4 + (size_t)ng0 * ng1 * ng2) * 4, s) != hipSuccess) return -1;
+        *ctl_out = ctl;
         const uint32_t gpre = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 3) / 4);
         const uint32_t gw = (uint32_t)std::min<uint64_t>(nslots, dtype == 0 ? 1024 : 512);
         const bool ragged = p->d[0] % 6 || p->d[1] % 6 || p->d[2] % 6;
@@ -5351,7 +5364,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
         SZK_CHECK_LAUNCH();
         return 0;
     } else
-    if (p->B == 6 && (szk_dbg_flags & 32768)) {  // debug flag 32768: groups of 3 x 3 x 3 blocks per workgroup, closed form, a launch per front (k_blk_decode_gf)
+    if (p->B == 6 && (dbg & 32768)) {  // debug flag 32768: groups of 3 x 3 x 3 blocks per workgroup, closed form, a launch per front (k_blk_decode_gf)
         constexpr uint32_t G = 3;
         const uint32_t ng0 = (p->nb[0] + G - 1) / G, ng1 = (p->nb[1] + G - 1) / G, ng2 = (p->nb[2] + G - 1) / G;
         const uint32_t ngd = ng0 + ng1 + ng2 - 2;
@@ -5369,7 +5382,7 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
             else hipLaunchKernelGGL((k_blk_decode_gf<double, 6, 3>), dim3(npairs), dim3(512), 0, s, d_out, *p, d, gz_lo, npairs);
         }
     } else
-    if (p->B == 6 && !(szk_dbg_flags & 8388608)) {  // round 3's form (debug flag 65536): groups of 2 x 2 x 2 blocks, line scans (debug flag 8388608: a block per wave)
+    if (p->B == 6 && !(dbg & 8388608)) {  // round 3's form (debug flag 65536): groups of 2 x 2 x 2 blocks, line scans (debug flag 8388608: a block per wave)
         const uint32_t ng0 = (p->nb[0] + 1) / 2, ng1 = (p->nb[1] + 1) / 2, ng2 = (p->nb[2] + 1) / 2;
         const uint32_t ngd = ng0 + ng1 + ng2 - 2;
         {
@@ -5426,6 +5439,21 @@ int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, con
     }
     SZK_CHECK_LAUNCH();
     return 0;
+}
+// The one-launch decoders (k_blk_wave3, k_blkn_wave2) wait for their lower neighbours' flags with a bounded poll; a poll that gives up
+// (it never has: tickets are handed out in the fronts' order, every group a poll waits for is running or done) raises ctl[1] and
+// leaves the array wrong. The word is fetched behind the launch — one host synchronisation on a decoder of milliseconds — and a
+// raised word sends the stream through the launch-per-front decoders (the same arithmetic, no inter-workgroup waits), from the codes.
+int szk_launch_blk_decompress(int dtype, const uint16_t *codes, void *d_out, const szk_blk_params *p, const szk_blk_scratch *sc,
+                              const uint8_t *payload, const szh_header *h, const szh_offsets *o, int64_t *coef_by_rank, hipStream_t s,
+                              hipEvent_t side_done) {
+    uint32_t *ctl = nullptr;
+    int rc = blk_decompress_impl(dtype, codes, d_out, p, sc, payload, h, o, coef_by_rank, s, side_done, szk_dbg_flags, &ctl);
+    if (rc || !ctl) return rc;
+    uint32_t gave_up = 0;
+    if (hipMemcpyAsync(&gave_up, ctl + 1, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+    if (!gave_up && !(szk_dbg_flags & 4)) return 0;  // (debug flag 4: take the retry as if a poll had given up — tests)
+    return blk_decompress_impl(dtype, codes, d_out, p, sc, payload, h, o, coef_by_rank, s, nullptr, szk_dbg_flags | 32768 | 65536, &ctl);
 }
 
 int szk_launch_trial_lorenzo12(int dtype, const void *d_samples, uint64_t per, uint64_t nsb, double eb, int radius, uint64_t *hist, uint64_t *counters,

@@ -480,7 +480,10 @@ int szk_launch_stock_huff_encode(const uint16_t *d_em, uint64_t n, const uint8_t
     hipLaunchKernelGGL(k_stock_enc_pack, dim3(g), dim3(256), 0, s, d_em, n, d_clen, d_cbits, d_tile_base, d_out_words);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-// scratch: start / last_start / next_start / out_base: (nsub + 2) u64 each, count: nsub u32, flag: 2 u32. Returns 0, or -3 when the counts do not add up to n
+// scratch: start / last_start / next_start / out_base: (nsub + 2) u64 each, count: nsub u32, flag: 2 u32. Returns 0, -3 when the counts do
+// not add up to n, -4 when the subsequences' starts have not settled after STOCK_SYNC_MAX_PASSES passes (each a launch and a host
+// synchronisation; an honest stream settles in two or three — a code built to synchronise slowly could ask for one per subsequence)
+#define STOCK_SYNC_MAX_PASSES 12
 int szk_launch_stock_huff_decode(const szk_stock_tree_dev *tr, const uint32_t *d_words, uint64_t nbytes, uint64_t n, uint64_t *d_start, uint64_t *d_last, uint64_t *d_next,
                                  uint64_t *d_base, uint32_t *d_count, uint32_t *d_flags, uint16_t *d_em, int *passes, hipStream_t s) {
     const uint64_t total_bits = nbytes * 8, nwords = (nbytes + 3) / 4;
@@ -496,7 +499,7 @@ int szk_launch_stock_huff_decode(const szk_stock_tree_dev *tr, const uint32_t *d
     if (hipMemsetAsync(d_count, 0, nsub * 4, s) != hipSuccess) return -1;
     int it = 0;
     for (;; it++) {
-        if ((uint64_t)it > nsub + 1) return -3;
+        if (it >= STOCK_SYNC_MAX_PASSES || (uint64_t)it > nsub + 1) return -4;  // (not settled: the caller decodes on the host instead)
         if (hipMemsetAsync(d_flags, 0, 8, s) != hipSuccess) return -1;
         hipLaunchKernelGGL(k_stock_huff_sync, dim3(g), dim3(256), 0, s, *tr, d_words, nwords, total_bits, nsub, d_start, d_last, d_next, d_count, d_flags);
         uint32_t changed = 0;

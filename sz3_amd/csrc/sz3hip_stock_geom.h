@@ -15,7 +15,7 @@
 #define SZ3HIP_STOCK_GEOM_H
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define SZG_HD __host__ __device__ __forceinline__
 #else
 #define SZG_HD inline

@@ -198,6 +198,34 @@ bool load_tree(R &r, Tree &tr, int32_t &offset) {
     r.p += nc;
     for (uint32_t i = 0; i < nc; i++)
         if (tr.L[i] >= nc || tr.R[i] >= nc) return false;
+    // The arrays come from a file: they must BE a tree before anything walks them (a cycle, a node reached twice or a node with one
+    // child would make every walk of the decoders — one per restart point on the device — run to the end of the bit stream).
+    // Pre-order walk from the root, the shape the reference writes (HuffmanEncoder.hpp:601-628): every node is reached exactly
+    // once, an inner node (t == 0) has two different children, neither of them the root, a tree of nc nodes has (nc + 1) / 2
+    // leaves, and no leaf lies deeper than 64 (a code word the reference's own encoder could not have counted: a leaf at depth d
+    // needs more than Fib(d) elements).
+    if ((nc & 1u) == 0) return false;
+    std::vector<uint8_t> seen(nc, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> st;  // (node, depth)
+    st.reserve(130);
+    st.emplace_back(0u, 0u);
+    uint32_t reached = 0, leaves = 0;
+    while (!st.empty()) {
+        const uint32_t nd = st.back().first, dep = st.back().second;
+        st.pop_back();
+        if (seen[nd]) return false;
+        seen[nd] = 1;
+        reached++;
+        if (tr.t[nd]) {
+            leaves++;
+            continue;
+        }
+        const uint32_t l = tr.L[nd], r2 = tr.R[nd];
+        if (l == 0 || r2 == 0 || l == r2 || dep >= 64) return false;
+        st.emplace_back(r2, dep + 1);
+        st.emplace_back(l, dep + 1);
+    }
+    if (reached != nc || leaves != (nc + 1) / 2) return false;
     return true;
 }
 // bits of n codes, MSB first. Threads code contiguous ranges into buffers of their own; the ranges are then joined with the

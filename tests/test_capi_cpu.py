@@ -236,3 +236,18 @@ def test_hdf5_plugin_face_without_a_device():
         assert b"device" in L.sz3hip_last_error().lower() or b"hip" in L.sz3hip_last_error().lower()
     assert L.sz3hip_h5z_filter(0, 3, cdv, data.nbytes, C.byref(size), C.byref(buf)) == 0  # truncated cd_values: no Config in them
     libc.free(buf)
+
+
+def test_loading_the_library_does_not_import_torch_unless_asked():
+    """a host that never touches torch (CLI, HDF5 filter under h5py, CPU tools) must not pay torch's import through
+    sz3_amd.lib(); SZ3HIP_TORCH_PRELOAD=1 asks for it (the order that matters on a GPU box: torch before the library's first call)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, %r); import sz3_amd; sz3_amd.lib(); print('torch' in sys.modules)" % root
+    env = {k: v for k, v in os.environ.items() if k != "SZ3HIP_TORCH_PRELOAD"}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "False", (out.stdout, out.stderr)
+    env["SZ3HIP_TORCH_PRELOAD"] = "1"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "True", (out.stdout, out.stderr)

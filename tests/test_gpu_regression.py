@@ -223,7 +223,7 @@ def test_grouped_and_per_block_decoders_agree(shape):
             blob, _ = sz3_amd.compress(a, _conf(shape, 1e-3, *MASKS[mask]))
             outs = []
             try:
-                for flag in (0, 16, 32768, 65536, 8388608):
+                for flag in (0, 4, 16, 32768, 65536, 8388608):  # (4: the one-launch decoder, then the retry a poll that gave up takes)
                     sz3_amd.lib().sz3hip_debug_flags(flag)
                     dec, c2 = sz3_amd.decompress(blob, dtype, shape)
                     outs.append(dec)

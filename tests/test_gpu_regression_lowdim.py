@@ -129,7 +129,7 @@ def test_grouped_and_per_block_2d_decoders_agree(shape, block, eb):
         blob, _ = sz3_amd.compress(a, _conf(shape, eb, 1, 0, 1, block=block))
         outs = []
         try:
-            for flag in (NO_EXIT, NO_EXIT | 65536, NO_EXIT | 8388608):
+            for flag in (NO_EXIT, NO_EXIT | 4, NO_EXIT | 65536, NO_EXIT | 8388608):  # (4: the retry a flag poll that gave up takes)
                 sz3_amd.lib().sz3hip_debug_flags(flag)
                 dec, c2 = sz3_amd.decompress(blob, dtype, shape)
                 outs.append(dec)

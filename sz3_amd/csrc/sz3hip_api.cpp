@@ -324,7 +324,13 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     alloc((void **)&c->d_tables, sizeof(szk_dec_tables));
     alloc(&c->d_segtot, (4 * max_elems / 16384 + 65536) * 8);
     alloc((void **)&c->d_minmax, (2 * 1024 + 2) * 8);
-    if (ok && hipHostMalloc((void **)&c->h_state, sizeof(szk_state)) != hipSuccess) ok = false;
+    // (the device writes this copy itself, k_publish: coherent host memory, the sequence word behind the state block)
+    if (ok && hipHostMalloc((void **)&c->h_state, sizeof(szk_state) + 128, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) ok = false;
+    if (ok) {
+        memset(c->h_state, 0, sizeof(szk_state) + 128);
+        c->h_pub_seq = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(c->h_state) + ((sizeof(szk_state) + 63) & ~(size_t)63));
+        c->pub_seq = 0;
+    }
     if (ok && hipHostMalloc((void **)&c->h_minmax, 16) != hipSuccess) ok = false;
     (void)tsz;
     if (!ok) {
@@ -1439,18 +1445,42 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
             return fail(SZ3HIP_EHIP, "verdict kernel launch failed");
     }
     prof_end(ctx, ST_SPAN, s);
-    HIPCHK(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(szk_state), hipMemcpyDeviceToHost, s));
-    if (!ctx->ev_done) HIPCHK(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ctx->ev_done, s));
+    // the state block to the host, and — when the call turns out to need no repeat — the next call's histogram and counters zeroed,
+    // in one small launch behind the packer's (k_publish); finish() polls the sequence word
+    ctx->pub_zero = ctx->d_hist == ctx->d_hist_own && !ctx->hist_exposed && !(szk_dbg_flags & 268435456);
+    ctx->pub_seq++;
+    if (szk_launch_publish(ctx->d_state, ctx->h_state, ctx->h_pub_seq, ctx->pub_seq, ctx->pub_zero ? (void *)ctx->d_hist : nullptr,
+                           SZH_HIST_BINS * 8 + SZ_COUNTER_BYTES, s))
+        return fail(SZ3HIP_EHIP, "publish kernel launch failed");
+    ctx->pub_stream = s;
     // (h_state->probe = the probe counters: |delta| > 127, in [4096, 8192), in [2048, 4096); [4] = interpolation codes beyond +-4096)
     return 0;
 }
 
+// the host's side of k_publish: poll the sequence word in pinned memory (a wake-up within a microsecond of the device's store; an event
+// behind a device-to-host copy took ~20). The stream is queried now and then so that a fault on the device ends the wait.
+static int wait_published(sz3hip_ctx *ctx) {
+    volatile uint32_t *seq = ctx->h_pub_seq;
+    for (uint64_t it = 1;; it++) {
+        if (*seq == ctx->pub_seq) break;
+        if ((it & 0xFFFF) == 0) {
+            const hipError_t q = hipStreamQuery(ctx->pub_stream);
+            if (q == hipSuccess) {
+                if (*seq == ctx->pub_seq) break;
+                return fail(SZ3HIP_EHIP, "stage 2 finished without publishing its state");
+            }
+            if (q != hipErrorNotReady) return fail(SZ3HIP_EHIP, "HIP error while waiting for stage 2: %s", hipGetErrorString(q));
+        }
+        __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return 0;
+}
 extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
     if (!ctx->stage2_done) return fail(SZ3HIP_EINVAL, "finish called before stage2");
-    HIPCHK(hipEventSynchronize(ctx->ev_done));  // (the payload is complete: the state's copy is the last thing stage 2 enqueued)
+    if (int rw = wait_published(ctx)) return rw;  // (the payload is complete: the state's publication is the last thing stage 2 enqueued)
     const bool fused_miss = ctx->s1_fused && (ctx->h_state->miss_kind != 0 || ctx->h_state->mispredict != 0);
     ctx->last_fused = ctx->s1_fused && !fused_miss;
     ctx->last_q16 = ctx->s1_q16 && !(ctx->h_state->miss_kind & (32u | 128u)) && !fused_miss;
@@ -1476,7 +1506,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
         if (rc1) return rc1;
         rc1 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s, S2_CLASSIC);
         if (rc1) return rc1;
-        HIPCHK(hipEventSynchronize(ctx->ev_done));
+        if (int rw = wait_published(ctx)) return rw;
         ctx->spec_penalty = ctx->spec_penalty ? std::min(8, 2 * ctx->spec_penalty) : 1;
         ctx->spec_skip = ctx->spec_penalty;
     } else if (ctx->s2_spec) {
@@ -1493,7 +1523,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
             }
             int rc2 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s, redo_book ? S2_CLASSIC : S2_REENCODE);
             if (rc2) return rc2;
-            HIPCHK(hipEventSynchronize(ctx->ev_done));
+            if (int rw = wait_published(ctx)) return rw;
             ctx->spec_penalty = ctx->spec_penalty ? std::min(8, 2 * ctx->spec_penalty) : 1;
             ctx->spec_skip = ctx->spec_penalty;
         } else {
@@ -1510,13 +1540,16 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
         HIPCHK(hipMemsetAsync(ctx->d_counters + 7, 0, 8, s));
         int rc2 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s, S2_CLASSIC);
         if (rc2) return rc2;
-        HIPCHK(hipEventSynchronize(ctx->ev_done));
+        if (int rw = wait_published(ctx)) return rw;
         if (ctx->h_state->mispredict) return fail(SZ3HIP_EHIP, "code book was not built (both forms declined)");
     }
     ctx->stage1_done = ctx->stage2_done = false;
     // the next call's histogram and counters start from zero: enqueue that now, behind this call, instead of in front of the
     // next one (a launch and its gap off the next call's critical path). Everything the host still wants is in h_state.
-    if (ctx->d_hist == ctx->d_hist_own && !ctx->hist_exposed && !(szk_dbg_flags & 268435456)) {
+    if (ctx->pub_zero && ctx->h_state->miss_kind == 0 && ctx->h_state->mispredict == 0) {
+        ctx->pre_cleared = true;  // (k_publish did it: the last launch of this call's stage 2 met the same state)
+        ctx->pre_stream = ctx->pub_stream;
+    } else if (ctx->d_hist == ctx->d_hist_own && !ctx->hist_exposed && !(szk_dbg_flags & 268435456)) {
         if (hipMemsetAsync(ctx->d_hist, 0, SZH_HIST_BINS * 8 + SZ_COUNTER_BYTES, s) == hipSuccess) {
             ctx->pre_cleared = true;
             ctx->pre_stream = s;

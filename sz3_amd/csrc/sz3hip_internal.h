@@ -101,7 +101,11 @@ struct sz3hip_ctx {
     int spec_exact;                   // 1: the previous call's book stands only when it IS this call's book (payload = a pure function of the input)
     int spec_skip, spec_penalty;      // calls to sit out after a miss; the count doubles with every miss in a row (up to 8)
     uint32_t spec_hits, spec_misses;  // statistics (sz3hip_get_spec_stats)
-    hipEvent_t ev_done;  // recorded behind the state's device-to-host copy: finish() waits for it, not for the whole stream
+    hipEvent_t ev_done;  // (unused since round 5: the state is published by the device, below)
+    uint32_t *h_pub_seq;  // pinned, behind h_state: the sequence word k_publish writes after the state block; finish() polls it
+    uint32_t pub_seq;     // ... the value the pending stage 2 will write
+    bool pub_zero;        // ... and whether that launch zeroes the next call's histogram and counters when the call needs no repeat
+    hipStream_t pub_stream;
     hipStream_t pre_stream;
     bool pre_cleared;    // finish() of the previous call already enqueued the zeroing of histogram and counters
     // stage 1 of the pending Lorenzo call, when it ran with the previous book's code lengths (speculation decided there):

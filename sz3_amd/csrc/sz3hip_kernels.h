@@ -391,6 +391,9 @@ uint64_t szk_fuse_scratch_words(int ndim, const uint64_t d[4]);
 int szk_launch_hist_range(const uint64_t *d_hist, uint32_t *range /* [4], zeroed */, hipStream_t s);  // range and count of the non-empty bins
 int szk_launch_hist_fold(const uint32_t *partial, uint32_t nrows, int radius, uint64_t *hist, uint32_t *range, hipStream_t s);
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
+// the state block -> the host's pinned copy + a sequence word behind it, written by the device (finish() polls the word); d_zero != nullptr:
+// the same launch zeroes zero_bytes (a multiple of 16) there when the state reports no miss and no mispredicted code-book form
+int szk_launch_publish(const szk_state *d_state, void *h_state, uint32_t *h_seq, uint32_t seq, void *d_zero, uint64_t zero_bytes, hipStream_t s);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t,
                           uint32_t *zero_word /* a device word this launch clears (nullptr: none) */,
                           const uint16_t *chunk_words, uint64_t n_chunks, uint64_t *group_off, uint64_t *total_words /* the decoder's group

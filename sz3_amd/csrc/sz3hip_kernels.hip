@@ -1662,7 +1662,15 @@ __device__ __forceinline__ void narrow16_task(NarrowCtx<float> &c, const Lattice
                 atomicAdd(reinterpret_cast<uint32_t *>(lds + a1), 1u);
                 atomicAdd(reinterpret_cast<uint32_t *>(lds + a2), 1u);
                 atomicAdd(reinterpret_cast<uint32_t *>(lds + a3), 1u);
+#if defined(LAB_ST) && LAB_ST == 1  // (lab: write-through stores — nothing of the code array dirty in the L2s at the kernel's end)
+                __hip_atomic_store(reinterpret_cast<uint32_t *>(c.codes8 + grow + x), tA | (tB << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#elif defined(LAB_ST) && LAB_ST == 2
+                *reinterpret_cast<uint32_t *>(c.codes8 + grow + x) = tA | (tB << 8);
+#elif defined(LAB_ST) && LAB_ST == 3
+                __hip_atomic_store(reinterpret_cast<uint32_t *>(c.codes8 + grow + x), tA | (tB << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
                 __builtin_nontemporal_store(tA | (tB << 8), reinterpret_cast<uint32_t *>(c.codes8 + grow + x));
+#endif
             }
             if (c.s_len) {
                 uint32_t b4 = (uint32_t)lds[Q16_LEN_OFF + a0] + lds[Q16_LEN_OFF + a1] + lds[Q16_LEN_OFF + a2] + lds[Q16_LEN_OFF + a3];
@@ -5270,6 +5278,30 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
         hipLaunchKernelGGL((k_pack<ENC_WIN>), dim3(rb + pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
                            sym_add, state, payload, apv, pb, rp);
     }
+    SZK_CHECK_LAUNCH();
+    return 0;
+}
+// Behind stage 2's last launch (round 5): the state block goes to the host's pinned copy and a sequence word after it — written by
+// the device itself, system scope, instead of a device-to-host copy + event behind the launches (another engine, its own signals: ~20 us
+// between the packer's end and the host's wake-up). finish() polls the word. The same launch zeroes the next call's histogram and
+// counters when this call needs no repeat (state: no miss, no mispredicted book form) — the host draws the same conclusion from the
+// same state — so that nothing is enqueued between a call's end and the next call's stage 1.
+__global__ __launch_bounds__(256) void k_publish(const szk_state *__restrict__ state, uint32_t *host_state, uint32_t *host_seq, uint32_t seq,
+                                                 uint4 *zero, uint32_t zero_vec16) {
+    if (blockIdx.x == 0) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(state);
+        for (uint32_t i = threadIdx.x; i < sizeof(szk_state) / 4; i += 256)
+            __hip_atomic_store(&host_state[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (zero && state->miss_kind == 0 && state->mispredict == 0)
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < zero_vec16; i += gridDim.x * 256) zero[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+int szk_launch_publish(const szk_state *d_state, void *h_state, uint32_t *h_seq, uint32_t seq, void *d_zero, uint64_t zero_bytes, hipStream_t s) {
+    static_assert(sizeof(szk_state) % 4 == 0, "the state block is copied word by word");
+    hipLaunchKernelGGL(k_publish, dim3(d_zero ? 128 : 1), dim3(256), 0, s, d_state, (uint32_t *)h_state, h_seq, seq, (uint4 *)d_zero, (uint32_t)(zero_bytes / 16));
     SZK_CHECK_LAUNCH();
     return 0;
 }

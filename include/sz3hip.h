@@ -255,6 +255,8 @@ int sz3hip_debug_decode_info(sz3hip_ctx *ctx, uint32_t *out4);
 /* test hook: non-zero routes every shape through the generic (any-shape) stage-1 kernel instead of the tuned one */
 void sz3hip_debug_force_generic(int on);
 /* development switches (bit mask, process-wide; 0 = product behaviour). They force one of two equivalent paths, results unchanged (tests compare them):
+ * 2 Lorenzo decoder with the multi-symbol lookup table for small code books (round 5: up to three code words per 12-bit window; same output,
+ * measured slower than the one-symbol table in its first form: opt-in),
  * 4 the one-launch block decoders' retry through the launch-per-front decoders, taken as if a flag poll had given up,
  * 8 no 16-bit form of the one-byte stage-1 kernel (round 5), 32 no marching kernel, 64 no one-byte codes, 128 interpolation pass by pass, one point per thread (no 8-wide level-1
  * kernels, no level kernels), 256 no stage-1 specialisation by code width, 512 decoder without the fused x prefix sum,

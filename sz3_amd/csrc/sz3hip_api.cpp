@@ -1914,7 +1914,9 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
     }
     prof_begin(ctx, ST_DEC_HUFF, s);
-    int rc = szk_launch_dec_tables(pl + o.lens, h.sym_min, h.sym_count, ctx->d_tables, ovf, (const uint16_t *)(pl + o.chunkwords), h.n_chunks,
+    // (a Lorenzo stream's small book — code words up to 16 bits, at most 1024 symbols: the tables' launch also makes the multi-symbol table)
+    const bool ms_book = h.predictor == 0 && h.qbytes == 4 && h.max_len >= 1 && h.max_len <= 16 && h.sym_count <= 1024 && (szk_dbg_flags & 2);
+    int rc = szk_launch_dec_tables(pl + o.lens, h.sym_min, h.sym_count, ctx->d_tables, ms_book ? h.radius : 0u, ovf, (const uint16_t *)(pl + o.chunkwords), h.n_chunks,
                                    ctx->d_chunk_off, ctx->d_counters + 3, s);
     if (rc) return fail(SZ3HIP_EHIP, "dec_tables kernel launch failed (%d)", rc);
     szk_dec_params dp;
@@ -1952,6 +1954,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         else dp.carry_pass = 1;
     }
     dp.half = 0;
+    dp.ms = 0;
     dp.ovf = nullptr;
     dp.gate = nullptr;
     // Half-width intermediates: the x-scanned lattice differences of a smooth f32 field fit int16 (f64: int32), and the strided scans that
@@ -1968,6 +1971,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     }
     if (half) {
         dp.half = 1;
+        dp.ms = ms_book && ctx->dtype == SZ3HIP_FLOAT ? 1u : 0u;  // (debug flag 2 takes it: measured slower than the one-symbol table in its first form, 612 against 565 us at C2)
         dp.ovf = ovf;
         dp.q_out = d_half;
     }
@@ -1975,6 +1979,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     if (!rc && half) {
         rc = szk_launch_reconstruct_half(pl, &h, &o, d_half, d_out, ovf, s, carry_in_scan);
         dp.half = 0;
+        dp.ms = 0;
         dp.ovf = nullptr;
         dp.gate = ovf;
         dp.q_out = d_out;

@@ -185,6 +185,11 @@ struct szk_dec_tables {
     uint32_t max_len, n_coded, lut_bits, reserved;
     uint16_t sorted_syms[65536];
     uint32_t lut[1u << DEC_LUT_BITS];  // next lut_bits bits -> (symbol << 8) | length, 0 = longer code word
+    // round 5, small code books of Lorenzo streams (k_decode's MS form): the next 12 bits -> UP TO THREE code words at once, as what the
+    // fused x prefix sum wants of them: bits 0-3 their total length - 1, 4-5 their number (0: the first code word is longer than 12
+    // bits, is symbol 0 — a listed delta — or a delta beyond +-127: decoded on its own), 6-13 d1, 14-22 d1 + d2, 23-30 d3 (two's
+    // complement; with fewer than three code words the later sums repeat the last one: the running sum is always "+ s2 + d3")
+    uint32_t mlut[1u << DEC_LUT_BITS];
 };
 struct szk_dec_params {
     uint64_t n, n_chunks;
@@ -211,6 +216,7 @@ struct szk_dec_params {
     // small, and the two strided scans that follow move half the bytes. A value that does not fit raises *ovf; the full-width
     // chain is enqueued behind the half-width one with gate = ovf: its kernels return at once while the flag is clear.
     uint32_t half;
+    uint32_t ms;           // half, f32 data, a code book of at most 16-bit words and 1024 symbols: the multi-symbol table form (tables->mlut)
     uint32_t *ovf;         // half: raised on a value outside int16
     const uint32_t *gate;  // non-null: the kernel runs only when *gate != 0
 };
@@ -395,6 +401,7 @@ int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
 // the same launch zeroes zero_bytes (a multiple of 16) there when the state reports no miss and no mispredicted code-book form
 int szk_launch_publish(const szk_state *d_state, void *h_state, uint32_t *h_seq, uint32_t seq, void *d_zero, uint64_t zero_bytes, hipStream_t s);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t,
+                          uint32_t radius /* != 0: the multi-symbol table of a Lorenzo stream's small book is made too (mlut) */,
                           uint32_t *zero_word /* a device word this launch clears (nullptr: none) */,
                           const uint16_t *chunk_words, uint64_t n_chunks, uint64_t *group_off, uint64_t *total_words /* the decoder's group
                           offsets, made by a second workgroup of the same launch (chunk_words == nullptr: not made) */, hipStream_t s);

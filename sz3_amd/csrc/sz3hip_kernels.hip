@@ -23,6 +23,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "sz3hip_format.h"
 #include "sz3hip_kernels.h"
 
@@ -3766,8 +3769,10 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     CodeRegs cur, nxt;
     uint32_t bp_cur = 0, bp_nxt = 0;
     uint64_t go_cur = 0, go_nxt = 0;
+    // (a workgroup taking a contiguous range of chunks instead of every nwaves-th one was measured, LAB_PACKMAP: no difference)
+    const uint64_t c_end = n_full, c_step = nwaves;
     uint64_t chunk = wave_gid;
-    if (chunk < n_full) {
+    if (chunk < c_end) {
         fetch_codes(codes, chunk * SZH_CHUNK_SYMS + lane_off, narrow, cur);
         side(chunk, bp_cur, go_cur);
     }
@@ -3790,9 +3795,9 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     }
     for (int i = lane; i < STAGE_WORDS; i += WAVE) stage[i] = 0;
     __syncthreads();
-    for (; chunk < n_full; chunk += nwaves) {
-        const uint64_t nc = chunk + nwaves;
-        if (nc < n_full) {
+    for (; chunk < c_end; chunk += c_step) {
+        const uint64_t nc = chunk + c_step;
+        if (nc < c_end) {
             fetch_codes(codes, nc * SZH_CHUNK_SYMS + lane_off, narrow, nxt);
             side(nc, bp_nxt, go_nxt);
         }
@@ -3961,7 +3966,7 @@ __global__ __launch_bounds__(256) void k_merge(szk_merge_params mp, uint64_t n, 
 // (len, sym), and a direct lookup table over the next DEC_LUT_BITS bits of the stream: (symbol << 8) | length for every
 // code word of at most DEC_LUT_BITS bits (0 = longer code: length search). One workgroup; <= 65536 symbols.
 __global__ __launch_bounds__(1024) void k_dec_tables(const uint8_t *__restrict__ lens, uint32_t sym_min,
-                                                     uint32_t sym_count, szk_dec_tables *t, uint32_t *zero_word,
+                                                     uint32_t sym_count, szk_dec_tables *t, uint32_t radius, uint32_t *zero_word,
                                                      const uint16_t *__restrict__ chunk_words, uint64_t n_chunks, uint64_t *group_off,
                                                      uint64_t *total_words) {
     if (blockIdx.x == 1) {  // the decoder's other preparation, beside the tables: word offsets of the chunk groups
@@ -4032,6 +4037,36 @@ __global__ __launch_bounds__(1024) void k_dec_tables(const uint8_t *__restrict__
         }
         t->lut[e] = ent;
     }
+    if (radius && maxl >= 1 && maxl <= 16) {
+        // the multi-symbol table (szk_dec_tables::mlut): every 12-bit window decoded greedily, up to three code words that fit it
+        for (uint32_t e = tid; e < (1u << DEC_LUT_BITS); e += 1024) {
+            uint32_t used = 0, cnt = 0;
+            int d[3] = {0, 0, 0};
+            for (int j = 0; j < 3; j++) {
+                const uint32_t rem = DEC_LUT_BITS - used;
+                const uint32_t w = (e << used) & ((1u << DEC_LUT_BITS) - 1u);  // the bits left, at the window's top
+                uint32_t l = 0, sym = 0;
+                for (uint32_t q = 1; q <= rem && q <= maxl; q++) {
+                    const uint32_t rel = (w >> (DEC_LUT_BITS - q)) - s_first_code[q];
+                    if (rel < s_cnt[q]) {
+                        l = q;
+                        sym = t->sorted_syms[s_first_rank[q] + rel];
+                        break;
+                    }
+                }
+                const int delta = (int)sym - (int)radius;
+                if (l == 0 || sym == 0 || delta < -127 || delta > 127) break;
+                d[cnt++] = delta;
+                used += l;
+            }
+            uint32_t ent = 0;
+            if (cnt) {
+                const int s2 = cnt >= 2 ? d[0] + d[1] : d[0], d3 = cnt == 3 ? d[2] : 0;
+                ent = (used - 1u) | (cnt << 4) | (((uint32_t)d[0] & 0xFFu) << 6) | (((uint32_t)s2 & 0x1FFu) << 14) | (((uint32_t)d3 & 0xFFu) << 23);
+            }
+            t->mlut[e] = ent;
+        }
+    }
 }
 
 // one thread per UNIT of 256 symbols (a quarter chunk: the chunk's start or one of its three restart offsets): table lookup on
@@ -4063,9 +4098,16 @@ __device__ __forceinline__ QO dec_dout(const szk_dec_params &p, uint64_t elem) {
     return lo < p.n_dout && p.dout_idx[lo] == elem ? reinterpret_cast<const QO *>(p.dout_val)[lo] : (QO)0;
 }
 // QB: 0 = u16 codes out; 4 / 8 = fused Lorenzo x-scan, int32 / int64 lattice values out (see szk_dec_params::scan_row)
-template <int QB, bool HALF = false>
+// MS (round 5; QB = 4, HALF): the multi-symbol table form for small code books — one lookup on the next 12 bits yields up to three
+// code words and, for the fused x prefix sum, their partial sums (szk_dec_tables::mlut): 12 instead of 27 vector instructions and a
+// third of the dependent LDS round trips per symbol at C2's 4.1 bits per symbol. A lane's values go to its stage as 16-bit stores at
+// the symbol's place (a lookup's three sums at k, k + 1, k + 2: with fewer than three code words the next lookup overwrites the
+// repeats), a block of 32 symbols leaves through the same cooperative path as before. Code words beyond 12 bits, listed deltas
+// (symbol 0), the last two symbols of a row or a unit: one at a time through the canonical-code arithmetic (ms_single).
+template <int QB, bool HALF = false, bool MS = false>
 __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payload, szk_dec_params p,
                                                 uint16_t *__restrict__ codes) {
+    static_assert(!MS || (QB == 4 && HALF), "the multi-symbol form decodes f32 Lorenzo streams into the half-width chain");
     using QO = typename std::conditional<QB == 8, int64_t, int32_t>::type;
     if (p.gate && *p.gate == 0) return;  // (the full-width chain behind a half-width one that did not overflow)
     constexpr uint32_t UNIT = SZH_UNIT_SYMS;
@@ -4096,9 +4138,13 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
         // exclusive upper bound of the length-l code words, left-aligned to 32 bits (lengths >= max_len never count)
         s_upper[l] = in && l < max_len ? (fc + cnt) << (32 - l) : 0xFFFFFFFFu;
     }
-    for (uint32_t e = threadIdx.x; e < (1u << K); e += 256) s_lut[e] = p.tables->lut[e];
+    if (MS) {
+        for (uint32_t e = threadIdx.x; e < (1u << DEC_LUT_BITS); e += 256) s_lut[e] = p.tables->mlut[e];
+    } else {
+        for (uint32_t e = threadIdx.x; e < (1u << K); e += 256) s_lut[e] = p.tables->lut[e];
+    }
     const uint16_t *sorted = p.tables->sorted_syms;
-    const uint32_t base_rank = K < max_len ? p.tables->first_rank[K + 1] : n_coded;
+    const uint32_t base_rank = MS ? 0u : (K < max_len ? p.tables->first_rank[K + 1] : n_coded);  // (MS: the whole book, at most SORTED_LDS symbols)
     for (uint32_t e = threadIdx.x; e < SORTED_LDS && base_rank + e < n_coded; e += 256) s_sorted[e] = sorted[base_rank + e];
     __syncthreads();
     const uint64_t unit = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -4248,6 +4294,111 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     load4(woff + wi, qw);
 #pragma unroll
     for (int k = 0; k < 4; k++) qw[k] = __builtin_bswap32(qw[k]);
+    if constexpr (MS) {
+        // stream words: qw = the lane's next four, far = the four behind them (requested when qw is taken over: four words of decoding
+        // ahead of their first use)
+        uint32_t qn = 0;
+        load4(woff + wi + 4, far);
+        auto refill = [&]() {
+            if (have <= 32) {
+                uint32_t wd = qn == 0 ? qw[0] : (qn == 1 ? qw[1] : (qn == 2 ? qw[2] : qw[3]));
+                wd = wi < nwords ? wd : 0u;
+                buf |= (uint64_t)wd << (32 - have);
+                have += 32;
+                wi++;
+                qn++;
+                if (qn == 4) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) qw[k] = __builtin_bswap32(far[k]);
+                    qn = 0;
+                    load4(woff + wi + 4, far);
+                }
+            }
+        };
+        // one code word by the canonical code's arithmetic (any length up to max_len <= 16): its symbol, the buffer moved on
+        auto ms_single = [&]() -> uint32_t {
+            const uint32_t v = (uint32_t)(buf >> 32);
+            uint32_t l = 1;
+#pragma unroll
+            for (uint32_t q = 1; q < 16; q++) l += (q < max_len && v >= s_upper[q]) ? 1u : 0u;
+            uint32_t rank = s_first_rank[l] + ((v >> (32 - l)) - s_first_code[l]);
+            rank = rank < n_coded ? rank : n_coded - 1;  // (corrupt streams must not read out of bounds)
+            const uint32_t sym = rank < SORTED_LDS ? (uint32_t)s_sorted[rank] : (uint32_t)sorted[rank];
+            buf <<= l;
+            have -= (int)l;
+            return sym;
+        };
+        int32_t acc32 = 0;
+        uint32_t k = 0;
+        if (coop) {  // (every lane of the wave decodes a whole unit)
+            uint16_t *mine = reinterpret_cast<uint16_t *>(&stage[(uint32_t)lane_id() * (NP * NR + 1)]);  // 80 bytes: a block's 32 values + the overshoot
+            for (uint32_t blk = 0; blk < UNIT / 32; blk++) {
+                coop_flush();  // (the previous block's pieces, behind the loads requested meanwhile)
+                const uint32_t kend = (blk + 1) * 32;
+                while (k < kend) {
+                    refill();
+                    const uint32_t ent = s_lut[(uint32_t)(buf >> 52)];
+                    const uint32_t room = left < UNIT - k ? left : UNIT - k;
+                    const uint32_t pos = k - blk * 32;
+                    if (ent != 0 && room >= 3) {
+                        const uint32_t l = (ent & 15u) + 1u, cnt = (ent >> 4) & 3u;
+                        const int32_t d1 = (int32_t)(ent << 18) >> 24, s2 = (int32_t)(ent << 9) >> 23, d3 = (int32_t)(ent << 1) >> 24;
+                        const int32_t v1 = acc32 + d1, v2 = acc32 + s2, v3 = v2 + d3;
+                        acc32 = v3;
+                        mine[pos] = (uint16_t)v1;
+                        mine[pos + 1] = (uint16_t)v2;
+                        mine[pos + 2] = (uint16_t)v3;
+                        buf <<= l;
+                        have -= (int)l;
+                        k += cnt;
+                        left -= cnt;
+                    } else {
+                        const uint32_t sym = ms_single();
+                        acc32 += sym ? (int32_t)((int)sym - (int)p.radius) : dec_dout<int32_t>(p, s0 + k);
+                        mine[pos] = (uint16_t)acc32;
+                        k++;
+                        left--;
+                    }
+                    // (every value of a step lies within 381 of the running sum: a sum within +-32000 keeps them all inside int16)
+                    ovf_seen |= (uint32_t)((uint32_t)(acc32 + 32000) > 64000u);
+                    if (left == 0) {
+                        acc32 = 0;
+                        left = p.scan_row;
+                    }
+                }
+                // the block's 64 bytes: from the stage into registers, piece-major (stored at the top of the next block)
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                held_i0 = blk * 32;
+                stash1(0, h0);
+                stash1(1, h1);
+                stash1(2, h2);
+                stash1(3, h3);
+                held_any = true;
+                __builtin_amdgcn_wave_barrier();
+                // a lookup that ran past the block's end left its last one or two values behind it: they open the next block
+                *reinterpret_cast<uint32_t *>(mine) = *reinterpret_cast<const uint32_t *>(mine + 32);
+                __builtin_amdgcn_wave_barrier();
+            }
+            coop_flush();
+        } else {  // (the array's last wave: one symbol at a time, stored directly)
+            int16_t *ho = reinterpret_cast<int16_t *>(p.q_out) + s0;
+            for (; k < nsym; k++) {
+                refill();
+                const uint32_t sym = ms_single();
+                acc32 += sym ? (int32_t)((int)sym - (int)p.radius) : dec_dout<int32_t>(p, s0 + k);
+                ho[k] = (int16_t)acc32;
+                ovf_seen |= (uint32_t)(acc32 != (int32_t)(int16_t)acc32);
+                if (--left == 0) {
+                    acc32 = 0;
+                    left = p.scan_row;
+                }
+            }
+        }
+        if (p.carry) reinterpret_cast<int32_t *>(p.carry)[unit] = acc32;
+        if (__ballot(ovf_seen != 0) && lane_id() == 0) atomicOr(p.ovf, 1u);
+        return;
+    }
     for (uint32_t rnd = 0; rnd < nrounds; rnd++) {
         const uint32_t i0 = rnd * 16;
 #if defined(LAB_DEC_ABL) && (LAB_DEC_ABL & 2)  // (lab, wrong results: no stream loads)
@@ -4965,8 +5116,19 @@ static uint32_t k1_grid(const void *kernel, uint64_t ntiles) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
     }
+    // (the occupancy query is a few microseconds of host time in front of stage 1's launch — the step's critical path: asked once per kernel)
+    static std::mutex occ_mu;
+    static std::vector<std::pair<const void *, int>> occ;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    {
+        std::lock_guard<std::mutex> lk(occ_mu);
+        for (const auto &e : occ)
+            if (e.first == kernel) per_cu = e.second;
+        if (!per_cu) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+            occ.emplace_back(kernel, per_cu);
+        }
+    }
     uint64_t g = (uint64_t)per_cu * (uint64_t)n_cu;
     if (g > SZK_K1_GRID) g = SZK_K1_GRID;
     if (g > ntiles) g = ntiles;
@@ -5311,9 +5473,9 @@ int szk_launch_assemble(const szk_asm_params *p, hipStream_t s) {
     return 0;
 }
 
-int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, uint32_t *zero_word,
+int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, uint32_t radius, uint32_t *zero_word,
                           const uint16_t *chunk_words, uint64_t n_chunks, uint64_t *group_off, uint64_t *total_words, hipStream_t s) {
-    hipLaunchKernelGGL(k_dec_tables, dim3(chunk_words ? 2 : 1), dim3(1024), 0, s, d_lens, sym_min, sym_count, t, zero_word, chunk_words, n_chunks, group_off,
+    hipLaunchKernelGGL(k_dec_tables, dim3(chunk_words ? 2 : 1), dim3(1024), 0, s, d_lens, sym_min, sym_count, t, radius, zero_word, chunk_words, n_chunks, group_off,
                        total_words);
     SZK_CHECK_LAUNCH();
     return 0;
@@ -5334,6 +5496,7 @@ int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t 
     if (!p->scan_row) hipLaunchKernelGGL((k_decode<0>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
     else if (p->q_bytes == 8 && p->half) hipLaunchKernelGGL((k_decode<8, true>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
     else if (p->q_bytes == 8) hipLaunchKernelGGL((k_decode<8>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
+    else if (p->half && p->ms) hipLaunchKernelGGL((k_decode<4, true, true>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
     else if (p->half) hipLaunchKernelGGL((k_decode<4, true>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
     else hipLaunchKernelGGL((k_decode<4>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
     if (p->scan_row && p->carry && p->carry_pass) {

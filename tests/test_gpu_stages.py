@@ -831,3 +831,43 @@ def test_outlier_lists_beyond_the_sort_workgroups_reach_are_sorted_by_finish():
     dc.decompress(pl.data_ptr(), size, out.data_ptr(), st)
     torch.cuda.synchronize()
     assert float((out - d_in).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("shape,eb", [((40, 52, 512), 1e-3), ((17, 33, 768), 1e-3), ((19, 13, 132), 1e-3), ((24, 40, 300), 2e-3), ((64, 1024), 1e-3),
+                                      ((70000,), 1e-3), ((33, 47, 50), 1e-2), ((9, 11, 2), 1e-3)],
+                         ids=["40x52x512", "17x33x768", "19x13x132", "24x40x300", "64x1024", "70000", "33x47x50", "9x11x2"])
+def test_multi_symbol_decoder_matches_the_one_symbol_decoder(shape, eb):
+    """Round 5: small code books of f32 Lorenzo streams are decoded through a table of up to three code words per 12-bit window
+    (k_decode's MS form, encoder/HuffmanEncoder.hpp:225-255 is the walk it replaces) behind debug flag 2. Same
+    array bit for bit — rows that divide the unit, rows that do not (carries), rows shorter than a lookup, listed deltas and values."""
+    dev = torch.device("cuda:0")
+    if len(shape) == 3:
+        a = field3d(shape, seed=3)
+    elif len(shape) == 2:
+        a = field2d(shape, seed=3)
+    else:
+        a = field1d(shape[0])
+    rng = np.random.default_rng(5)
+    f = a.reshape(-1)
+    idx = rng.choice(f.size, size=max(4, f.size // 4000), replace=False)
+    f[idx[::2]] += 3.0          # steps of thousands of lattice units: listed deltas (symbol 0)
+    f[idx[1::4]] = np.nan       # and values stored raw
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, np.float32)
+    cap = dc.payload_bound(a.size, worst_case=True)
+    pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+    size = dc.compress(_conf(shape, eb), t.data_ptr(), pl.data_ptr(), cap, 0)
+    outs = []
+    L = sz3_amd.lib()
+    for flag in (0, 2, 2097152):   # one-symbol table, multi-symbol table (opt-in), no half-width chain at all
+        L.sz3hip_debug_flags(flag)
+        try:
+            o = torch.empty_like(t)
+            dc.decompress(pl.data_ptr(), size, o.data_ptr(), 0)
+            torch.cuda.synchronize()
+        finally:
+            L.sz3hip_debug_flags(0)
+        outs.append(o.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1], equal_nan=True) and np.array_equal(outs[0], outs[2], equal_nan=True)
+    fin = np.isfinite(a)
+    assert float(np.abs(outs[0][fin].astype(np.float64) - a[fin].astype(np.float64)).max()) <= eb

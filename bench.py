@@ -480,6 +480,144 @@ def c1_numbers(torch, sz3_amd, dev, local_rank, steps=20, default_algo=False):
             "note": "4 MB per call: launch-bound (about twenty kernels a step)"}
 
 
+def device_field4d(torch, dev, t_lo, nt, edge, seed):
+    """C5's field (tests/fields.py field4d's formula) made ON the device, one time step at a time: a rank's 12 or 13 steps of 500^3
+    are 1.6e9 values — not something to build with numpy meshgrids on the host. The noise comes from torch's generator (seeded)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    out = torch.empty((nt, edge, edge, edge), dtype=torch.float32, device=dev)
+    ar = torch.arange(edge, dtype=torch.float64, device=dev)
+    cy = torch.cos(2 * np.pi * ar / 48)[None, :, None]
+    sz = torch.sin(2 * np.pi * ar / 64)[:, None, None]
+    for i in range(nt):
+        t = float(t_lo + i)
+        sx = torch.sin(2 * np.pi * (ar + 0.5 * t) / 32)[None, None, :]
+        plane = (sz * cy) * sx * (1 + 0.01 * t)
+        plane += torch.randn(plane.shape, generator=g, device=dev, dtype=torch.float64) * 2e-3
+        out[i] = plane.to(torch.float32)
+        del plane
+    return out
+
+
+def multi_gpu_extras(torch, sz3_amd, dev, local_rank, rank, world, comm, dist, one_gpu, timed, steps):
+    """BASELINE.json configs[3] and [4] as the ranks of THIS run see them (every rank calls this; rank 0 keeps the numbers).
+    C4: 1024^3 f64, Lorenzo + regression, abs 1e-6, 8 slabs of 128 planes (api/impl/SZImplOMP.hpp:48-50) — rank r codes slab r, the
+    code histogram all-reduced between the stages like the headline's; both fields of SURVEY.md 8(d): C4a (regression chosen in a share
+    of the blocks: the block stream) and C4b (noise above the bound: the selection hands the array to the plain stream).
+    C5: 100 x 500^3 f32, REL 1e-3, 8 slabs of 12 / 13 time steps: the value range all-reduced first (SZImplOMP.hpp:57-69), then the 4-D
+    Lorenzo stream with the histogram all-reduce, decompressed and checked against the bound.
+    With N < 8 ranks the first N slabs are coded (weak scaling, like the headline); at N = 8 the legs ARE configs[3] / [4]."""
+    from sz3_amd import distributed as D
+    small = os.environ.get("SZ3_BENCH_EXTRA_SCALE") == "small"   # (tests: the same legs at sizes a shared GPU takes in seconds)
+    cpu = torch.device("cpu")
+    red_dev = cpu if one_gpu else dev
+
+    def red(x, op):
+        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    res = {}
+    c4_shape = (12, 96, 120) if small else (128, 1024, 1024)
+    for name, field in (("C4a", "c4a"), ("C4b", "default")):
+        try:
+            w = Workload(torch, sz3_amd, dev, local_rank, rank, c4_shape, "f64", "composed", 1e-6, comm=comm, dist=dist if comm is None else None, field=field)
+            el, ps = timed(w, steps, 2)
+            err, dec_ms = w.verify_and_time_decode(ps)
+            el = red(el, dist.ReduceOp.MAX)
+            total = red(float(ps), dist.ReduceOp.SUM)
+            err = red(err, dist.ReduceOp.MAX)
+            dec_ms = red(dec_ms, dist.ReduceOp.MAX)
+            raw = w.n * 8
+            res[name] = {"ms_per_step": round(1e3 * el / steps, 4), "value": round(world * raw / (el / steps) / 1e9, 3), "unit": "GB/s",
+                         "ratio": round(world * raw / total, 4), "max_abs_err": err, "err_bound_ok": bool(err <= 1e-6),
+                         "decompress_device": {"ms": round(dec_ms, 4), "gbps": round(world * raw / (dec_ms * 1e-3) / 1e9, 2)},
+                         "stream_predictor_rank0": w.stream_predictor(), "slab": list(c4_shape), "steps": steps}
+            del w
+        except Exception as e:  # noqa: BLE001 - (a rank that fails here leaves the others in a collective: the legs are kept simple)
+            res[name] = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+    out = {"C4_8slab": {"config": "configs[3]: 3D float64 1024^3 as 8 slabs of 128x1024x1024 (rank r = slab r; %d of 8 coded here), ALGO_LORENZO_REG "
+                                  "Lorenzo + regression per 6^3 block, abs errBound=1e-6, histogram all-reduce between the stages" % min(world, 8),
+                        "fields": res, "scaling": "weak"}}
+    # ---- C5 ----
+    try:
+        nt_total, edge = (16, 40) if small else (100, 500)
+        lo, hi = D.slab_bounds(nt_total, 8, rank % 8)
+        nt = hi - lo
+        d_in = device_field4d(torch, dev, lo, nt, edge, 20260928 + rank)
+        n = d_in.numel()
+        dc = sz3_amd.DeviceCompressor(n, np.float32, device=local_rank)
+        stream = torch.cuda.current_stream().cuda_stream
+        hist = None
+        if comm is None:
+            hist = torch.zeros(65536, dtype=torch.int64, device=dev)
+            dc.set_histogram(hist.data_ptr())
+        mn, mx = dc.minmax(d_in.data_ptr(), n, stream)
+        if comm is not None:
+            mns, mxs = comm.allreduce_minmax([mn], [mx], [stream])
+            gmn, gmx = mns[0], mxs[0]
+        else:
+            gmn, gmx = D.allreduce_range(mn, mx, dist, device=cpu)
+        eb = 1e-3 * (gmx - gmn)
+        conf = sz3_amd.Config(nt, edge, edge, edge)
+        conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+        conf.lorenzo, conf.lorenzo2, conf.regression = 1, 0, 0
+        conf.errorBoundMode = sz3_amd.EB_ABS   # (REL resolved with the GLOBAL range, as SZ_compress_OMP does before it splits)
+        conf.absErrorBound = eb
+        cap = dc.payload_bound(n)
+        d_pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+
+        def step():
+            dc.stage1(conf, d_in.data_ptr(), stream)
+            if comm is not None:
+                comm.allreduce_histogram([dc], [stream])
+            else:
+                dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+            dc.stage2(d_pl.data_ptr(), cap, stream)
+            return dc.finish(stream)
+
+        for _ in range(2):
+            ps = step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        k = max(2, steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            ps = step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        d_out = torch.empty_like(d_in)
+        dc.decompress(d_pl.data_ptr(), ps, d_out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        err = 0.0
+        for i in range(nt):   # (step by step: a float64 copy of the slab would be 13 GB)
+            err = max(err, float((d_out[i].double() - d_in[i].double()).abs().max().item()))
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dc.decompress(d_pl.data_ptr(), ps, d_out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        dec_ms = (time.perf_counter() - t0) / 3 * 1e3
+        el = red(el, dist.ReduceOp.MAX)
+        total = red(float(ps), dist.ReduceOp.SUM)
+        raw_all = red(float(n * 4), dist.ReduceOp.SUM)
+        err = red(err, dist.ReduceOp.MAX)
+        dec_ms = red(dec_ms, dist.ReduceOp.MAX)
+        out["C5_8slab"] = {"config": "configs[4]: 4D float32 100x500x500x500 as 8 slabs of 12 / 13 time steps (rank r = slab r; %d of 8 coded here), "
+                                     "Lorenzo, REL errBound=1e-3 of the all-reduced value range, histogram all-reduce between the stages" % min(world, 8),
+                           "ms_per_step": round(1e3 * el / k, 4), "value": round(raw_all / (el / k) / 1e9, 3), "unit": "GB/s", "steps": k,
+                           "ratio": round(raw_all / total, 4), "abs_bound_from_range": eb, "value_range": [gmn, gmx],
+                           "max_abs_err": err, "err_bound_ok": bool(err <= eb),
+                           "decompress_device": {"ms": round(dec_ms, 4), "gbps": round(raw_all / (dec_ms * 1e-3) / 1e9, 2)},
+                           "slab_rank0": [nt, edge, edge, edge], "scaling": "weak",
+                           "data": "synthetic: fields.field4d's formula evaluated on the device, noise from torch's generator"}
+        del d_in, d_out, d_pl, dc
+    except Exception as e:  # noqa: BLE001
+        out["C5_8slab"] = {"error": repr(e)[:300]}
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -749,6 +887,11 @@ def main():
         except Exception as e:  # noqa: BLE001
             out.setdefault("extra_configs", {})["C4a_slab"] = {"error": repr(e)[:300]}
 
+    # ---- N > 1: BASELINE.json's multi-GPU configurations (configs[3], configs[4]) as extra objects of the same line ----
+    if world > 1 and not args.no_extra and args.algo == "lorenzo" and args.dtype == "f32":
+        extras = multi_gpu_extras(torch, sz3_amd, dev, local_rank, rank, world, comm, dist, one_gpu, timed, max(3, args.steps // 4))
+        if rank == 0:
+            out.setdefault("extra_configs", {}).update(extras)
     # ---- CPU baseline on this box's host cores (rank 0, N=1 only; checker code, never the product) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w)

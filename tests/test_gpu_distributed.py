@@ -105,6 +105,24 @@ def test_bench_relaunches_itself_as_two_ranks_and_prints_one_line():
     assert "roofline" in d and "cpu_baseline" not in d
 
 
+def test_bench_two_ranks_print_the_multi_gpu_configs():
+    """with N > 1 the line also carries BASELINE.json's configs[3] (1024^3 f64, Lorenzo + regression, 8 slabs: both
+    fields) and configs[4] (100 x 500^3 f32, REL 1e-3 of the all-reduced range, 8 slabs of time steps) — here at reduced sizes
+    (SZ3_BENCH_EXTRA_SCALE=small), two ranks on the one GPU. api/impl/SZImplOMP.hpp:48-107 is the split they mirror."""
+    d = _bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--size", "128", "--no-cold", "--no-host-e2e", "--no-cpu-baseline", "--no-live-traffic"],
+               {"SZ3_BENCH_ONE_GPU": "1", "SZ3_BENCH_EXTRA_SCALE": "small"})
+    assert d["n_gpus"] == 2 and d["err_bound_ok"] and "roofline" in d
+    ex = d["extra_configs"]
+    c4 = ex["C4_8slab"]["fields"]
+    for f in ("C4a", "C4b"):
+        assert "error" not in c4[f], c4[f]
+        assert c4[f]["err_bound_ok"] and c4[f]["ratio"] > 2 and c4[f]["value"] > 0 and c4[f]["decompress_device"]["ms"] > 0
+    c5 = ex["C5_8slab"]
+    assert "error" not in c5, c5
+    assert c5["err_bound_ok"] and c5["ratio"] > 2 and c5["slab_rank0"] == [2, 40, 40, 40]
+    assert abs(c5["abs_bound_from_range"] - 1e-3 * (c5["value_range"][1] - c5["value_range"][0])) < 1e-12
+
+
 def test_bench_on_every_visible_gpu_over_rccl():
     """with more than one GPU on the box: the real thing at N = 2 (RCCL all-reduce of the histogram inside the library, one rank per GPU)"""
     if torch.cuda.device_count() < 2:

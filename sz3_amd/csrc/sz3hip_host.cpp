@@ -466,6 +466,7 @@ struct SlabJob {
     size_t out_cap = 0, out_size = 0;
     std::vector<unsigned char> own_out;  // multi-slab: the blob is staged here, then copied into the container
     bool lossless = false, staged = false;
+    int asked_algo = -1;         // the caller's cmprAlgo (conf.cmprAlgo is rewritten to what was written)
     double mn = 0, mx = 0;
     int rc = 0;
     std::string err;
@@ -677,6 +678,162 @@ int stock_encode_interp(SlabJob &j) {
     j.conf.interpAnchorStride = (int32_t)g.anchor;
     j.conf.interpAlpha = sp.alpha;
     j.conf.interpBeta = sp.beta;
+    if ((double)j.raw_bytes / (double)j.out_size < 3) {  // SZDispatcher.hpp:62-74
+        std::vector<uint8_t> z(zs::bound_frames(j.raw_bytes) + 8);
+        size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size());
+        if (zsz && zsz < j.out_size && zsz <= j.out_cap) {
+            memcpy(j.out, z.data(), zsz);
+            j.out_size = zsz;
+            j.conf.cmprAlgo = SZ3HIP_ALGO_LOSSLESS;
+        }
+    }
+    return 0;
+}
+// A stock ALGO_LORENZO_REG stream WRITTEN (round 5; 2-D and 3-D arrays of float / double, block sizes the read side takes): selection pass,
+// coefficient chain on the host, coding front by front of blocks in the reference's arithmetic, the reference's container
+// (szk_slw_params, sz3hip_kernels.h). 0: j.out holds the stream; SZ3HIP_EUNSUPPORTED: not a case this writer takes (the caller falls
+// back to this library's own stream).
+int stock_encode_lorenzo_reg(SlabJob &j) {
+    HostSlot *s = j.slot;
+    const sz3hip_config &cf = j.conf;
+    const int N = cf.N;
+    if (N < 2 || N > 3 || cf.blockSize < 2) return SZ3HIP_EUNSUPPORTED;
+    const uint32_t B = (uint32_t)cf.blockSize;
+    if ((N == 3 && B > 8) || (N == 2 && B > 32)) return SZ3HIP_EUNSUPPORTED;
+    const uint32_t set_mask = (cf.lorenzo ? 1u : 0u) | (cf.lorenzo2 ? 2u : 0u) | (cf.regression ? 4u : 0u);
+    if (!set_mask) return SZ3HIP_EUNSUPPORTED;
+    const int members = (cf.lorenzo ? 1 : 0) + (cf.lorenzo2 ? 1 : 0) + (cf.regression ? 1 : 0);
+    const bool composed = members > 1, has_reg = cf.regression != 0;
+    const int radius = cf.quantbinCnt / 2;
+    if (radius < 1 || radius > 32768 || !(cf.absErrorBound > 0)) return SZ3HIP_EUNSUPPORTED;
+    uint64_t d3[3] = {1, 1, 1};
+    for (int i = 0; i < N; i++) d3[3 - N + i] = cf.dims[i];
+    for (int i = 0; i < 3; i++)
+        if (d3[i] >= (1ull << 31)) return SZ3HIP_EUNSUPPORTED;
+    if (set_mask == 4u)  // regression alone: a block one element wide takes the reference's UNPADDED fallback (see slr_coefficients)
+        for (int i = 3 - N; i < 3; i++)
+            if (d3[i] % B == 1) return SZ3HIP_EUNSUPPORTED;
+    uint64_t nb[3];
+    for (int i = 0; i < 3; i++) nb[i] = (d3[i] + B - 1) / B;
+    if (N == 2) nb[0] = 1;
+    const uint64_t nblocks = nb[0] * nb[1] * nb[2];
+    if (nblocks >= (1ull << 31)) return SZ3HIP_EUNSUPPORTED;
+    const size_t tsize = j.cdt == SZ3HIP_FLOAT ? 4 : 8;
+    const uint64_t n = cf.num;
+    HIPCHK(hipSetDevice(s->device));
+    const uint64_t ntiles_z = (n + 1023) / 1024, ntiles_e = (n + 2047) / 2048;
+    uint8_t *d_recon, *d_uval, *d_kind, *d_sel, *d_fit, *d_coef, *d_clen;
+    uint16_t *d_codes;
+    uint64_t *d_hist, *d_tile_base, *d_cbits, *d_ebase;
+    uint32_t *d_tile_cnt, *d_ebits;
+    DevArena ar;
+    ar.ask(&d_recon, (size_t)n * tsize + 64);
+    ar.ask(&d_uval, (size_t)n * tsize + 64);
+    ar.ask(&d_codes, (size_t)n * 2 + 64);
+    ar.ask(&d_kind, (size_t)nblocks);
+    ar.ask(&d_sel, (size_t)nblocks);
+    ar.ask(&d_fit, (size_t)nblocks * 4 * tsize);
+    ar.ask(&d_coef, (size_t)nblocks * 4 * tsize);
+    ar.ask(&d_hist, 65536 * 8);
+    ar.ask(&d_tile_cnt, (size_t)ntiles_z * 4);
+    ar.ask(&d_tile_base, (size_t)(ntiles_z + 1) * 8);
+    ar.ask(&d_clen, 65536);
+    ar.ask(&d_cbits, 65536 * 8);
+    ar.ask(&d_ebits, (size_t)ntiles_e * 4);
+    ar.ask(&d_ebase, (size_t)(ntiles_e + 1) * 8);
+    if (ar.commit(s)) return SZ3HIP_EHIP;
+    szk_slw_params sp;
+    memset(&sp, 0, sizeof(sp));
+    for (int i = 0; i < 3; i++) {
+        sp.d[i] = d3[i];
+        sp.nb[i] = (uint32_t)nb[i];
+    }
+    sp.B = B;
+    sp.N = (uint32_t)N;
+    sp.eb = cf.absErrorBound;
+    sp.radius = (uint32_t)radius;
+    sp.set_mask = set_mask;
+    sp.in = s->dev_in;
+    sp.recon = d_recon;
+    sp.codes = d_codes;
+    sp.uval = d_uval;
+    sp.kind = d_kind;
+    sp.sel = d_sel;
+    sp.coef_fit = d_fit;
+    sp.coef = d_coef;
+    const int dt = j.cdt == SZ3HIP_FLOAT ? 0 : 1;
+    HIPCHK(hipMemsetAsync(d_hist, 0, 65536 * 8, s->stream));
+    if (szk_launch_stock_lr_select(dt, &sp, s->stream)) return fail(SZ3HIP_EHIP, "stock stream: selection launch failed");
+    // the choices and the fits to the host: the coefficient chain (a chain over the regression blocks, T arithmetic) and the side vectors
+    std::vector<uint8_t> kind((size_t)nblocks), sel((size_t)nblocks);
+    std::vector<uint8_t> coef((size_t)nblocks * 4 * tsize);
+    HIPCHK(hipMemcpyAsync(kind.data(), d_kind, (size_t)nblocks, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(sel.data(), d_sel, (size_t)nblocks, hipMemcpyDeviceToHost, s->stream));
+    if (has_reg) HIPCHK(hipMemcpyAsync(coef.data(), d_fit, coef.size(), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    std::vector<uint16_t> coef_codes, selection;
+    std::vector<float> ui32, ul32;
+    std::vector<double> ui64, ul64;
+    if (has_reg) {
+        if (dt == 0) stock::lorenzo_reg_chain<float>(N, B, cf.absErrorBound, kind.data(), nblocks, reinterpret_cast<float *>(coef.data()), coef_codes, ui32, ul32);
+        else stock::lorenzo_reg_chain<double>(N, B, cf.absErrorBound, kind.data(), nblocks, reinterpret_cast<double *>(coef.data()), coef_codes, ui64, ul64);
+        HIPCHK(hipMemcpyAsync(d_coef, coef.data(), coef.size(), hipMemcpyHostToDevice, s->stream));
+    }
+    if (composed) selection.assign(sel.begin(), sel.end());
+    if (szk_launch_stock_lr_code(dt, &sp, s->stream)) return fail(SZ3HIP_EHIP, "stock stream: coding launch failed");
+    uint64_t n_unpred = 0;
+    if (szk_launch_stock_lr_finish(dt, &sp, n, d_hist, d_tile_cnt, d_tile_base, d_recon /* (done with: the unpredictable values' list) */, &n_unpred, s->stream))
+        return fail(SZ3HIP_EHIP, "stock stream: histogram / list launch failed");
+    std::vector<uint64_t> hist(65536);
+    HIPCHK(hipMemcpyAsync(hist.data(), d_hist, 65536 * 8, hipMemcpyDeviceToHost, s->stream));
+    std::vector<uint8_t> un((size_t)n_unpred * tsize + 8), bits;
+    if (n_unpred) HIPCHK(hipMemcpyAsync(un.data(), d_recon, (size_t)n_unpred * tsize, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (n_unpred * (tsize + 2) >= j.raw_bytes / 2) {  // (more unpredictable values than a stream is worth: the lossless stream, as for the other paths)
+        j.lossless = true;
+        return SZ3HIP_EUNSUPPORTED;
+    }
+    stock::Tree tr;
+    std::vector<uint8_t> clen;
+    std::vector<uint64_t> cbits;
+    int lo = 0, hi = 0;
+    if (!stock::book_from_hist(hist.data(), tr, clen, cbits, lo, hi)) return fail(SZ3HIP_EHIP, "stock stream: empty code histogram");
+    uint64_t bit_bytes = 0;
+    if (tr.t[0]) {
+        // a single symbol: zero-length code words, no bit stream
+    } else if (stock_host_huffman()) {
+        std::vector<uint16_t> em((size_t)n);
+        HIPCHK(hipMemcpy(em.data(), d_codes, (size_t)n * 2, hipMemcpyDeviceToHost));
+        stock::host_encode(em.data(), n, clen, cbits, bits);
+        bit_bytes = bits.size();
+    } else {
+        HIPCHK(hipMemcpyAsync(d_clen, clen.data(), 65536, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(d_cbits, cbits.data(), 65536 * 8, hipMemcpyHostToDevice, s->stream));
+        uint64_t total_bits = 0;
+        const int re = szk_launch_stock_huff_encode(d_codes, n, d_clen, d_cbits, d_ebits, d_ebase, (uint32_t *)s->dev_in, (uint64_t)(s->dev_in_bytes / 4), &total_bits, s->stream);
+        if (re == -2) {
+            j.lossless = true;
+            return SZ3HIP_EUNSUPPORTED;
+        }
+        if (re) return fail(SZ3HIP_EHIP, "stock stream: device Huffman coder failed (%d)", re);
+        bit_bytes = (total_bits + 7) / 8;
+        bits.resize((size_t)bit_bytes + 8);
+        HIPCHK(hipMemcpyAsync(bits.data(), s->dev_in, (size_t)bit_bytes, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        bits.resize((size_t)bit_bytes);
+    }
+    if (j.tm) j.tm->lap("device compress + Huffman (reference container)");
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)bit_bytes + (size_t)n_unpred * tsize + (size_t)nblocks * 2 + (1u << 20));
+    const void *pui = dt == 0 ? (const void *)ui32.data() : (const void *)ui64.data(), *pul = dt == 0 ? (const void *)ul32.data() : (const void *)ul64.data();
+    const uint64_t nui = dt == 0 ? ui32.size() : ui64.size(), nul = dt == 0 ? ul32.size() : ul64.size();
+    stock::write_lorenzo_reg_head(N, B, cf.absErrorBound, tsize, has_reg, composed, coef_codes, pui, nui, pul, nul, selection, radius, un.data(), n_unpred, tr, lo, hi, n,
+                                  bit_bytes, raw);
+    raw.insert(raw.end(), bits.begin(), bits.end());
+    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap);
+    if (!j.out_size) return sz3hip_last_error_code();
+    if (j.tm) j.tm->lap("zstd");
+    j.conf.cmprAlgo = SZ3HIP_ALGO_LORENZO_REG;
     if ((double)j.raw_bytes / (double)j.out_size < 3) {  // SZDispatcher.hpp:62-74
         std::vector<uint8_t> z(zs::bound_frames(j.raw_bytes) + 8);
         size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size());
@@ -999,7 +1156,8 @@ int job_encode(SlabJob &j) {
         if (g_stock_format.load() > 0 && !j.is_int && !j.conf.openmp) {
             // the caller wants files stock SZ3 reads: where stage 1 took the interpolation predictor its codes go into the reference's
             // own container (cmprAlgo ALGO_INTERP) instead of the device payload
-            const int rs = stock_encode_interp(j);
+            // ... and a call that names ALGO_LORENZO_REG gets the reference's Lorenzo / regression stream (round 5: 2-D and 3-D arrays)
+            const int rs = j.asked_algo == SZ3HIP_ALGO_LORENZO_REG ? stock_encode_lorenzo_reg(j) : stock_encode_interp(j);
             if (rs == 0) return 0;
             if (rs != SZ3HIP_EUNSUPPORTED) return j.failed(rs);
             // (another predictor: there is no stock form of it here — this library's own stream)
@@ -1083,6 +1241,7 @@ void job_init(SlabJob &j, const sz3hip_config &conf, int dataType, const void *d
     j.is_int = dtype_is_int(dataType);
     j.es = dtype_size(dataType);
     j.conf = conf;
+    j.asked_algo = conf.cmprAlgo;
     j.conf.dataType = (uint8_t)dataType;  // lets the decoder refuse a request for another element type
     j.raw_bytes = (size_t)conf.num * j.es;
     j.data = data;

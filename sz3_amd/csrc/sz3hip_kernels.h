@@ -387,6 +387,33 @@ struct szk_slr_params {
     uint32_t *bad;              // raised by a zero code beyond the list
 };
 int szk_launch_stock_lorenzo_reg(int dtype, const szk_slr_params *p, uint64_t n, uint32_t *d_tile_cnt, uint64_t *d_tile_base, hipStream_t s);
+// ... and the WRITE side (round 5, sz3hip_stock.hip k_slw_*; 2-D and 3-D arrays): a stream stock SZ3 decodes. The format leaves the choice of
+// a block's predictor and of its regression coefficients to the writer — the reader follows the selection and the coefficient chain it is
+// handed (ComposedPredictor::predecompress, RegressionPredictor::pred_and_recover_coefficients) — so the selection is made up front, in
+// parallel, from the ORIGINAL neighbours (the reference decides from reconstructed ones, block after block: a chain through the whole
+// array), the coefficient chain is quantized on the host (a chain over the regression blocks), and the values are coded front by front
+// of blocks in the reference's own arithmetic: prediction from reconstructed values in T, LinearQuantizer::quantize_and_overwrite.
+struct szk_slw_params {
+    uint64_t d[3];     // the array as (z, y, x): leading extents 1 for N < 3
+    uint32_t nb[3];
+    uint32_t B, N;
+    double eb;
+    uint32_t radius;
+    uint32_t set_mask;        // the predictor set: 1 Lorenzo-1, 2 Lorenzo-2, 4 regression (the reference's order)
+    const void *in;           // the caller's array
+    void *recon;              // [n] T: values as the reader will have them (written block by block; a block's halo is read from here)
+    uint16_t *codes;          // block by block (block raster order, raster order inside a block)
+    void *uval;               // [n] T, by code position: the original value where the code is 0
+    uint8_t *kind;            // [blocks] 0 Lorenzo-1, 1 Lorenzo-2, 2 regression
+    uint8_t *sel;             // [blocks] the chosen member's index in the set's order (the selection vector of a composed set)
+    void *coef_fit;           // [blocks][4] T: the fit of every block the regression member is valid for (selection pass)
+    const void *coef;         // [blocks][4] T: the RECOVERED coefficients of the regression blocks (host chain), what predictions use
+};
+int szk_launch_stock_lr_select(int dtype, const szk_slw_params *p, hipStream_t s);
+int szk_launch_stock_lr_code(int dtype, const szk_slw_params *p, hipStream_t s);
+// histogram of a stock stream's codes (u64[65536], zeroed by the caller) and the unpredictable values in the order of their zero codes
+int szk_launch_stock_lr_finish(int dtype, const szk_slw_params *p, uint64_t n, uint64_t *d_hist, uint32_t *d_tile_cnt, uint64_t *d_tile_base, void *d_unpred,
+                               uint64_t *h_n_unpred, hipStream_t s);
 #ifdef __cplusplus
 #include <vector>
 // the geometry of an array under InterpolationDecomposition::init (:176-213) and the per-block bases of its emission order; 0 on success

@@ -760,6 +760,358 @@ __global__ __launch_bounds__(1024) void k_slr_chain(szk_slr_params p) {
         __syncthreads();
     }
 }
+// ------------------------------------------------------------------------------------------------------------
+// Stock ALGO_LORENZO_REG streams, WRITE side (round 5; szk_slw_params in sz3hip_kernels.h says what is the writer's to choose).
+// k_slw_select: a wave per block, the block and two low halo layers of ORIGINAL values in LDS; the regression member's fit
+// (RegressionPredictor::precompress, :28-55: sums in double, coefficients stored in T), the members' sampled error estimates
+// (ComposedPredictor::precompress :25-40 over BlockwiseIterator's sample points :151-184, LorenzoPredictor::estimate_error with its
+// noise term :17-38), the first minimum. k_slw_front: the coding, front by front of blocks — k_slr_front run forward.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, int N, int L>
+__device__ __forceinline__ T slw_lorenzo(const T *tl, uint32_t ty, uint32_t tx, uint32_t a, uint32_t b, uint32_t c) {  // LorenzoPredictor::predict, :60-95
+    auto at = [&](uint32_t z, uint32_t y, uint32_t x) -> uint32_t { return (z * ty + y) * tx + x; };
+    T pr;
+    if (N == 3) {
+        auto P = [&](int k, int j, int i) -> T { return tl[at(a - j, b - k, c - i)]; };
+        if (L == 1) {
+            pr = (T)(P(0, 0, 1) + P(0, 1, 0));
+            pr = (T)(pr + P(1, 0, 0));
+            pr = (T)(pr - P(0, 1, 1));
+            pr = (T)(pr - P(1, 0, 1));
+            pr = (T)(pr - P(1, 1, 0));
+            pr = (T)(pr + P(1, 1, 1));
+        } else {
+            pr = 0;
+            bool first = true;
+            for (int k = 0; k <= 2; k++)
+                for (int j = 0; j <= 2; j++)
+                    for (int i = 0; i <= 2; i++) {
+                        if ((k | j | i) == 0) continue;
+                        const T term = (T)((T)(-(slr_w(k) * slr_w(j) * slr_w(i))) * P(k, j, i));
+                        pr = first ? term : (T)(pr + term);
+                        first = false;
+                    }
+        }
+    } else {
+        auto P = [&](int j, int i) -> T { return tl[at(a, b - j, c - i)]; };
+        if (L == 1) {
+            pr = (T)((T)(P(0, 1) + P(1, 0)) - P(1, 1));
+        } else {
+            pr = 0;
+            bool first = true;
+            for (int j = 0; j <= 2; j++)
+                for (int i = 0; i <= 2; i++) {
+                    if ((j | i) == 0) continue;
+                    const T term = (T)((T)(-(slr_w(j) * slr_w(i))) * P(j, i));
+                    pr = first ? term : (T)(pr + term);
+                    first = false;
+                }
+        }
+    }
+    return pr;
+}
+template <typename T, int N>
+__device__ __forceinline__ T slw_regression(const T *cf, uint32_t i0, uint32_t i1, uint32_t i2) {  // RegressionPredictor::predict, :81-92
+    T pr;
+    if (N == 3) {
+        pr = (T)(cf[0] * (T)i0);
+        pr = (T)(pr + (T)(cf[1] * (T)i1));
+        pr = (T)(pr + (T)(cf[2] * (T)i2));
+        pr = (T)(pr + cf[3]);
+    } else {
+        pr = (T)(cf[0] * (T)i1);
+        pr = (T)(pr + (T)(cf[1] * (T)i2));
+        pr = (T)(pr + cf[2]);
+    }
+    return pr;
+}
+__device__ __forceinline__ double slw_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+struct SlwGeom {
+    uint32_t task, oz, oy, ox, ez, ey, ex, nown, hz, tz, ty, tx;
+    uint64_t coff;
+};
+template <int N>
+__device__ __forceinline__ void slw_geom(const uint64_t (&d)[3], const uint32_t (&nb)[3], uint32_t B, uint32_t bz, uint32_t by, uint32_t bx, SlwGeom &g) {
+    g.task = (bz * nb[1] + by) * nb[2] + bx;
+    g.oz = bz * B;
+    g.oy = by * B;
+    g.ox = bx * B;
+    g.ez = N == 3 ? min(B, (uint32_t)d[0] - g.oz) : 1u;
+    g.ey = min(B, (uint32_t)d[1] - g.oy);
+    g.ex = min(B, (uint32_t)d[2] - g.ox);
+    g.coff = (uint64_t)g.oz * d[1] * d[2] + (uint64_t)g.ez * ((uint64_t)g.oy * d[2] + (uint64_t)g.ey * g.ox);
+    g.nown = g.ez * g.ey * g.ex;
+    g.hz = N == 3 ? 2u : 0u;
+    g.tz = g.ez + g.hz;
+    g.ty = g.ey + 2;
+    g.tx = g.ex + 2;
+}
+template <typename T, int N>
+__global__ __launch_bounds__(256) void k_slw_select(szk_slw_params p) {
+    constexpr uint32_t MAXT = N == 3 ? 10u * 10u * 10u : 34u * 34u;
+    __shared__ T s_t[4][MAXT];
+    const int lane = lane_id();
+    T *tl = s_t[threadIdx.x / WAVE];
+    const uint32_t nblocks = p.nb[0] * p.nb[1] * p.nb[2];
+    const uint32_t task = blockIdx.x * 4 + threadIdx.x / WAVE;
+    if (task >= nblocks) return;
+    const uint32_t bx = task % p.nb[2], by = (task / p.nb[2]) % p.nb[1], bz = task / (p.nb[2] * p.nb[1]);
+    SlwGeom g;
+    slw_geom<N>(p.d, p.nb, p.B, bz, by, bx, g);
+    auto at = [&](uint32_t a, uint32_t b, uint32_t c) -> uint32_t { return (a * g.ty + b) * g.tx + c; };
+    const T *in = reinterpret_cast<const T *>(p.in);
+    for (uint32_t l = lane; l < g.tz * g.ty * g.tx; l += WAVE) {  // original values, zeros outside the array (the reference's padding)
+        const uint32_t c = l % g.tx, b = (l / g.tx) % g.ty, a = l / (g.tx * g.ty);
+        const int64_t z = (int64_t)g.oz + a - g.hz, y = (int64_t)g.oy + b - 2, x = (int64_t)g.ox + c - 2;
+        tl[l] = (z >= 0 && y >= 0 && x >= 0) ? in[((uint64_t)z * p.d[1] + (uint64_t)y) * p.d[2] + (uint64_t)x] : (T)0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // the regression member: valid when no extent of the block is 1 (RegressionPredictor.hpp:33-37)
+    const bool reg_on = (p.set_mask & 4u) != 0;
+    const bool reg_valid = reg_on && (N == 3 ? g.ez > 1 : true) && g.ey > 1 && g.ex > 1;
+    T cf[4] = {0, 0, 0, 0};
+    if (reg_valid) {
+        double s0 = 0, s1 = 0, s2 = 0, sn = 0;
+        for (uint32_t t = lane; t < g.nown; t += WAVE) {
+            const uint32_t i2 = t % g.ex, i1 = (t / g.ex) % g.ey, i0 = t / (g.ex * g.ey);
+            const double v = (double)tl[at(i0 + g.hz, i1 + 2, i2 + 2)];
+            s0 += (double)i0 * v;
+            s1 += (double)i1 * v;
+            s2 += (double)i2 * v;
+            sn += v;
+        }
+        s0 = slw_wave_sum(s0);
+        s1 = slw_wave_sum(s1);
+        s2 = slw_wave_sum(s2);
+        sn = slw_wave_sum(sn);
+        const double num = (double)g.nown;
+        const double dm[3] = {(double)g.ez, (double)g.ey, (double)g.ex};
+        const double sm[3] = {s0, s1, s2};
+        T cn = (T)(sn / num);
+        T ci[3] = {0, 0, 0};
+        for (int i = 3 - N; i < 3; i++) {
+            ci[i] = (T)((2 * sm[i] / (dm[i] - 1) - sn) * 6 / num / (dm[i] + 1));
+            cn = (T)((double)cn - (dm[i] - 1) * (double)ci[i] / 2);
+        }
+        if (N == 3) {
+            cf[0] = ci[0];
+            cf[1] = ci[1];
+            cf[2] = ci[2];
+            cf[3] = cn;
+        } else {
+            cf[0] = ci[1];
+            cf[1] = ci[2];
+            cf[2] = cn;
+        }
+    }
+    // the members' estimates at the block's sample points (2 per step of the diagonal in 2-D, 4 in 3-D), one point per lane
+    const uint32_t msz = N == 3 ? min(g.ez, min(g.ey, g.ex)) : min(g.ey, g.ex);
+    constexpr uint32_t PPS = N == 3 ? 4u : 2u;
+    double e1 = 0, e2 = 0, er = 0;
+    for (uint32_t q = lane; q < msz * PPS; q += WAVE) {
+        const uint32_t i = q / PPS, w = q % PPS, j = msz - 1 - i;
+        uint32_t i0, i1, i2;
+        if (N == 3) {
+            i0 = i;
+            i1 = (w & 2u) ? j : i;
+            i2 = (w & 1u) ? j : i;
+        } else {
+            i0 = 0;
+            i1 = i;
+            i2 = w ? j : i;
+        }
+        const uint32_t a = i0 + g.hz, b = i1 + 2, c = i2 + 2;
+        const T v = tl[at(a, b, c)];
+        if (p.set_mask & 1u) e1 += (double)(T)(fabs((double)(T)(v - slw_lorenzo<T, N, 1>(tl, g.ty, g.tx, a, b, c))) + (N == 3 ? 1.22 : 0.81) * p.eb);
+        if (p.set_mask & 2u) e2 += (double)(T)(fabs((double)(T)(v - slw_lorenzo<T, N, 2>(tl, g.ty, g.tx, a, b, c))) + (N == 3 ? 6.8 : 2.76) * p.eb);
+        if (reg_valid) er += (double)(T)fabs((double)(T)(v - slw_regression<T, N>(cf, i0, i1, i2)));
+    }
+    e1 = slw_wave_sum(e1);
+    e2 = slw_wave_sum(e2);
+    er = slw_wave_sum(er);
+    if (lane == 0) {
+        // first minimum in the set's order (std::min_element); an invalid member counts as the largest double
+        const double big = 1.7976931348623157e308;
+        double best = big * 2;  // (+inf)
+        uint32_t kind = 0, idx = 0, k = 0;
+        if (p.set_mask & 1u) {
+            if (e1 < best) {
+                best = e1;
+                kind = 0;
+                idx = k;
+            }
+            k++;
+        }
+        if (p.set_mask & 2u) {
+            if (e2 < best) {
+                best = e2;
+                kind = 1;
+                idx = k;
+            }
+            k++;
+        }
+        if (p.set_mask & 4u) {
+            const double e = reg_valid ? er : big;
+            if (e < best) {
+                best = e;
+                kind = 2;
+                idx = k;
+            }
+            k++;
+        }
+        // (a regression-only set on a block with an extent of 1: the reference falls back to Lorenzo-1; the launcher refuses such arrays)
+        if (kind == 2 && !reg_valid) kind = 0;
+        p.kind[task] = (uint8_t)kind;
+        p.sel[task] = (uint8_t)idx;
+        T *o = reinterpret_cast<T *>(p.coef_fit) + (uint64_t)task * 4;
+        o[0] = cf[0];
+        o[1] = cf[1];
+        o[2] = cf[2];
+        o[3] = cf[3];
+    }
+}
+template <typename T, int N>
+__global__ __launch_bounds__(256) void k_slw_front(szk_slw_params p, uint32_t diag) {
+    constexpr uint32_t MAXT = N == 3 ? 10u * 10u * 10u : 34u * 34u;
+    __shared__ T s_t[4][MAXT];
+    const int lane = lane_id();
+    T *tl = s_t[threadIdx.x / WAVE];
+    const uint32_t cand = blockIdx.x * 4 + threadIdx.x / WAVE;
+    uint32_t bz = 0, by, bx;
+    if (N == 3) {
+        if (cand >= p.nb[0] * p.nb[1]) return;
+        bz = cand / p.nb[1];
+        by = cand - bz * p.nb[1];
+    } else {
+        if (cand >= p.nb[1]) return;
+        by = cand;
+    }
+    if (bz + by > diag) return;
+    bx = diag - bz - by;
+    if (bx >= p.nb[2]) return;
+    SlwGeom g;
+    slw_geom<N>(p.d, p.nb, p.B, bz, by, bx, g);
+    auto at = [&](uint32_t a, uint32_t b, uint32_t c) -> uint32_t { return (a * g.ty + b) * g.tx + c; };
+    const T *in = reinterpret_cast<const T *>(p.in);
+    T *recon = reinterpret_cast<T *>(p.recon);
+    T *uval = reinterpret_cast<T *>(p.uval);
+    for (uint32_t l = lane; l < g.tz * g.ty * g.tx; l += WAVE) {  // the halo: values as the reader will have them; the block: the caller's
+        const uint32_t c = l % g.tx, b = (l / g.tx) % g.ty, a = l / (g.tx * g.ty);
+        const int64_t z = (int64_t)g.oz + a - g.hz, y = (int64_t)g.oy + b - 2, x = (int64_t)g.ox + c - 2;
+        const bool own = a >= g.hz && b >= 2 && c >= 2;
+        const uint64_t e = ((uint64_t)z * p.d[1] + (uint64_t)y) * p.d[2] + (uint64_t)x;
+        tl[l] = (z >= 0 && y >= 0 && x >= 0) ? (own ? in[e] : recon[e]) : (T)0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t kind = p.kind[g.task];
+    const double recip = 1.0 / p.eb;
+    auto code_one = [&](uint32_t t, uint32_t a, uint32_t b, uint32_t c, T pr) {
+        T v = tl[at(a, b, c)];
+        const T orig = v;
+        const int code = ref_quantize<T>(v, pr, p.eb, recip, (int)p.radius);  // LinearQuantizer::quantize_and_overwrite, :43-71
+        tl[at(a, b, c)] = v;
+        p.codes[g.coff + t] = (uint16_t)code;
+        if (code == 0) uval[g.coff + t] = orig;
+    };
+    if (kind == 2) {
+        const T *cf = reinterpret_cast<const T *>(p.coef) + (uint64_t)g.task * 4;
+        for (uint32_t t = lane; t < g.nown; t += WAVE) {
+            const uint32_t i2 = t % g.ex, i1 = (t / g.ex) % g.ey, i0 = t / (g.ex * g.ey);
+            code_one(t, i0 + g.hz, i1 + 2, i2 + 2, slw_regression<T, N>(cf, i0, i1, i2));
+        }
+    } else {
+        const uint32_t smax = (g.ez - 1) + (g.ey - 1) + (g.ex - 1);
+        for (uint32_t s = 0; s <= smax; s++) {
+            for (uint32_t t = lane; t < g.nown; t += WAVE) {
+                const uint32_t i2 = t % g.ex, i1 = (t / g.ex) % g.ey, i0 = t / (g.ex * g.ey);
+                if (i0 + i1 + i2 != s) continue;
+                const uint32_t a = i0 + g.hz, b = i1 + 2, c = i2 + 2;
+                const T pr = kind == 0 ? slw_lorenzo<T, N, 1>(tl, g.ty, g.tx, a, b, c) : slw_lorenzo<T, N, 2>(tl, g.ty, g.tx, a, b, c);
+                code_one(t, a, b, c, pr);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t t = lane; t < g.nown; t += WAVE) {
+        const uint32_t i2 = t % g.ex, i1 = (t / g.ex) % g.ey, i0 = t / (g.ex * g.ey);
+        recon[((uint64_t)(g.oz + i0) * p.d[1] + (g.oy + i1)) * p.d[2] + (g.ox + i2)] = tl[at(i0 + g.hz, i1 + 2, i2 + 2)];
+    }
+}
+// the codes' histogram (a window of 2048 bins around the radius in LDS, the rest straight to memory) ...
+__global__ __launch_bounds__(256) void k_slw_hist(const uint16_t *__restrict__ codes, uint64_t n, uint32_t radius, unsigned long long *__restrict__ hist) {
+    __shared__ uint32_t s_h[2048];
+    for (uint32_t i = threadIdx.x; i < 2048; i += 256) s_h[i] = 0;
+    __syncthreads();
+    const uint32_t lo = radius > 1024 ? radius - 1024 : 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t c = codes[i], r = c - lo;
+        if (r < 2048) atomicAdd(&s_h[r], 1u);
+        else atomicAdd(&hist[c], 1ull);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 2048; i += 256)
+        if (s_h[i] && lo + i < 65536) atomicAdd(&hist[lo + i], (unsigned long long)s_h[i]);
+}
+// ... and the unpredictable values in the order of their zero codes (LinearQuantizer's list, :57-66)
+template <typename T>
+__global__ __launch_bounds__(256) void k_slw_unpred(const uint16_t *__restrict__ codes, uint64_t n, const uint64_t *__restrict__ tile_base, const T *__restrict__ uval,
+                                                    T *__restrict__ unpred) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        if (codes[i] == 0) unpred[stock_ordinal(codes, tile_base, i)] = uval[i];
+}
+int szk_launch_stock_lr_select(int dtype, const szk_slw_params *p, hipStream_t s) {
+    const uint32_t nblocks = p->nb[0] * p->nb[1] * p->nb[2];
+    const dim3 grid((nblocks + 3) / 4), blk(256);
+    if (p->N == 3) {
+        if (dtype == 0) hipLaunchKernelGGL((k_slw_select<float, 3>), grid, blk, 0, s, *p);
+        else hipLaunchKernelGGL((k_slw_select<double, 3>), grid, blk, 0, s, *p);
+    } else {
+        if (dtype == 0) hipLaunchKernelGGL((k_slw_select<float, 2>), grid, blk, 0, s, *p);
+        else hipLaunchKernelGGL((k_slw_select<double, 2>), grid, blk, 0, s, *p);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int szk_launch_stock_lr_code(int dtype, const szk_slw_params *p, hipStream_t s) {
+    const uint32_t ndiag = p->nb[0] + p->nb[1] + p->nb[2] - 2;
+    const uint32_t cand = p->N == 3 ? p->nb[0] * p->nb[1] : p->nb[1];
+    const dim3 grid((cand + 3) / 4), blk(256);
+    for (uint32_t d = 0; d < ndiag; d++) {
+        if (p->N == 3) {
+            if (dtype == 0) hipLaunchKernelGGL((k_slw_front<float, 3>), grid, blk, 0, s, *p, d);
+            else hipLaunchKernelGGL((k_slw_front<double, 3>), grid, blk, 0, s, *p, d);
+        } else {
+            if (dtype == 0) hipLaunchKernelGGL((k_slw_front<float, 2>), grid, blk, 0, s, *p, d);
+            else hipLaunchKernelGGL((k_slw_front<double, 2>), grid, blk, 0, s, *p, d);
+        }
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int szk_launch_stock_lr_finish(int dtype, const szk_slw_params *p, uint64_t n, uint64_t *d_hist, uint32_t *d_tile_cnt, uint64_t *d_tile_base, void *d_unpred,
+                               uint64_t *h_n_unpred, hipStream_t s) {
+    hipLaunchKernelGGL(k_slw_hist, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, p->codes, n, p->radius, (unsigned long long *)d_hist);
+    if (stock_zero_scan(p->codes, n, d_tile_cnt, d_tile_base, s)) return -1;
+    const uint64_t ntiles = (n + 1023) / 1024;
+    if (hipMemcpyAsync(h_n_unpred, d_tile_base + ntiles, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+    if (*h_n_unpred) {
+        const uint32_t g = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+        if (dtype == 0) hipLaunchKernelGGL(k_slw_unpred<float>, dim3(g), dim3(256), 0, s, p->codes, n, d_tile_base, (const float *)p->uval, (float *)d_unpred);
+        else hipLaunchKernelGGL(k_slw_unpred<double>, dim3(g), dim3(256), 0, s, p->codes, n, d_tile_base, (const double *)p->uval, (double *)d_unpred);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 int szk_launch_stock_lorenzo_reg(int dtype, const szk_slr_params *p, uint64_t n, uint32_t *d_tile_cnt, uint64_t *d_tile_base, hipStream_t s) {
     if (stock_zero_scan(p->codes, n, d_tile_cnt, d_tile_base, s)) return -1;
     if (p->N == 1) {

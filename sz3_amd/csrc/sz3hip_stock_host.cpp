@@ -486,4 +486,109 @@ bool parse_lorenzo_reg(const uint8_t *raw, size_t len, size_t tsize, bool has_re
     o.bits = r.p;
     return true;
 }
+// ---- the WRITE side of a stock ALGO_LORENZO_REG stream (round 5) ------------------------------------------------------------
+namespace {
+// LinearQuantizer<T>::quantize_and_overwrite (quantizer/LinearQuantizer.hpp:43-71) — the host twin of ref_quantize (sz3hip_devutil.h)
+template <typename T> int quantize_and_overwrite(T &data, T pred, double eb, double recip, int radius) {
+    const T diff = data - pred;
+    const double scaled = fabs((double)diff) * recip;
+    if (!(scaled < (double)(2 * radius - 1))) return 0;
+    int qi = (int)scaled + 1;
+    const int half = qi >> 1;
+    qi = half << 1;
+    int shifted;
+    if (diff < 0) {
+        qi = -qi;
+        shifted = radius - half;
+    } else {
+        shifted = radius + half;
+    }
+    const T dec = (T)((double)pred + (double)qi * eb);
+    const T ad = dec - data;
+    if (fabs((double)ad) <= eb) {
+        data = dec;
+        return shifted;
+    }
+    return 0;
+}
+void write_quant(W &w, double eb, int32_t radius, const void *unpred, uint64_t n_unpred, size_t tsize) {  // LinearQuantizer::save, :95-105
+    w.put<uint8_t>(2);
+    w.put<double>(eb);
+    w.put<int32_t>(radius);
+    w.put<uint64_t>(n_unpred);
+    if (n_unpred) w.bytes(unpred, (size_t)n_unpred * tsize);
+}
+// a side vector as RegressionPredictor / ComposedPredictor save it: HuffmanEncoder<int>::save + encode (tree over [min, max], byte count, bits)
+void write_vector(W &w, const std::vector<uint16_t> &v) {
+    uint32_t lo = 65535, hi = 0;
+    for (uint16_t x : v) {
+        lo = std::min<uint32_t>(lo, x);
+        hi = std::max<uint32_t>(hi, x);
+    }
+    std::vector<uint64_t> freq(hi - lo + 1, 0);
+    for (uint16_t x : v) freq[x - lo]++;
+    Tree tr;
+    std::vector<Code> codes;
+    build_tree(freq, tr, codes);
+    save_tree(w, tr, (int32_t)lo, hi - lo + 2);
+    std::vector<uint8_t> bits;
+    if (!tr.t[0]) encode_bits(v.data(), v.size(), (int32_t)lo, codes, bits);
+    w.put<uint64_t>(bits.size());
+    if (!bits.empty()) w.bytes(bits.data(), bits.size());
+}
+}  // namespace
+
+// the regression blocks' coefficient chain (RegressionPredictor::pred_and_quantize_coefficients, :142-149): every chosen block's fit is
+// quantized against the previous chosen block's RECOVERED coefficients, in block order; coef (in: the fits, [blocks][4]) comes back holding
+// what the reader will recover, codes / the two quantizers' unpredictable values are what the stream stores
+template <typename T>
+void lorenzo_reg_chain(int N, uint32_t B, double eb, const uint8_t *kind, uint64_t nblocks, T *coef, std::vector<uint16_t> &codes, std::vector<T> &un_indep,
+                       std::vector<T> &un_lin) {
+    const double eb_ind = eb / (N + 1), eb_lin = eb / (N + 1) / B;
+    const double r_ind = 1.0 / eb_ind, r_lin = 1.0 / eb_lin;
+    const int radius = 32768;
+    T prev[5] = {0, 0, 0, 0, 0};
+    for (uint64_t b = 0; b < nblocks; b++) {
+        if (kind[b] != 2) continue;
+        T *c = coef + b * 4;
+        for (int i = 0; i < N; i++) {
+            const T orig = c[i];
+            const int q = quantize_and_overwrite<T>(c[i], prev[i], eb_lin, r_lin, radius);
+            if (q == 0) un_lin.push_back(orig);
+            codes.push_back((uint16_t)q);
+        }
+        const T orig = c[N];
+        const int q = quantize_and_overwrite<T>(c[N], prev[N], eb_ind, r_ind, radius);
+        if (q == 0) un_indep.push_back(orig);
+        codes.push_back((uint16_t)q);
+        for (int i = 0; i <= N; i++) prev[i] = c[i];
+    }
+}
+template void lorenzo_reg_chain<float>(int, uint32_t, double, const uint8_t *, uint64_t, float *, std::vector<uint16_t> &, std::vector<float> &, std::vector<float> &);
+template void lorenzo_reg_chain<double>(int, uint32_t, double, const uint8_t *, uint64_t, double *, std::vector<uint16_t> &, std::vector<double> &, std::vector<double> &);
+
+// everything of the pre-zstd buffer in front of the main bit stream (BlockwiseDecomposition::save :68-72 = fallback Lorenzo: nothing,
+// the predictor — RegressionPredictor::save :94-107, ComposedPredictor::save :52-64 —, the quantizer; then SZGenericCompressor.hpp:52-57)
+void write_lorenzo_reg_head(int N, uint32_t B, double eb, size_t tsize, bool has_regression, bool composed, const std::vector<uint16_t> &coef_codes,
+                            const void *un_indep, uint64_t n_un_indep, const void *un_lin, uint64_t n_un_lin, const std::vector<uint16_t> &selection, int32_t radius,
+                            const void *unpred, uint64_t n_unpred, const Tree &tr, int lo, int hi, uint64_t n, uint64_t bit_bytes, std::vector<uint8_t> &raw) {
+    raw.clear();
+    W w{raw};
+    if (has_regression) {
+        w.put<uint64_t>(coef_codes.size());
+        if (!coef_codes.empty()) {
+            write_quant(w, eb / (N + 1), 32768, un_indep, n_un_indep, tsize);
+            write_quant(w, eb / (N + 1) / B, 32768, un_lin, n_un_lin, tsize);
+            write_vector(w, coef_codes);
+        }
+    }
+    if (composed) {
+        w.put<uint64_t>(selection.size());
+        if (!selection.empty()) write_vector(w, selection);
+    }
+    write_quant(w, eb, radius, unpred, n_unpred, tsize);
+    save_tree(w, tr, lo, (uint32_t)(hi - lo + 2));
+    w.put<uint64_t>(n);
+    w.put<uint64_t>(bit_bytes);
+}
 }  // namespace stock

@@ -44,6 +44,14 @@ struct LorenzoReg {
     uint64_t bit_bytes = 0;
 };
 bool parse_lorenzo_reg(const uint8_t *raw, size_t len, size_t tsize, bool has_regression, bool composed, uint64_t nblocks, int N, LorenzoReg &out);
+// ... and the WRITE side (round 5): the regression coefficients' chain (the fits of the chosen blocks in, what the reader recovers out) and
+// the buffer in front of the main bit stream
+template <typename T>
+void lorenzo_reg_chain(int N, uint32_t B, double eb, const uint8_t *kind, uint64_t nblocks, T *coef, std::vector<uint16_t> &codes, std::vector<T> &un_indep,
+                       std::vector<T> &un_lin);
+void write_lorenzo_reg_head(int N, uint32_t B, double eb, size_t tsize, bool has_regression, bool composed, const std::vector<uint16_t> &coef_codes,
+                            const void *un_indep, uint64_t n_un_indep, const void *un_lin, uint64_t n_un_lin, const std::vector<uint16_t> &selection, int32_t radius,
+                            const void *unpred, uint64_t n_unpred, const Tree &tr, int lo, int hi, uint64_t n, uint64_t bit_bytes, std::vector<uint8_t> &raw);
 void host_encode(const uint16_t *em, uint64_t n, const std::vector<uint8_t> &clen, const std::vector<uint64_t> &cbits, std::vector<uint8_t> &bits);
 bool host_decode(const Tree &tr, int32_t offset, const uint8_t *bits, size_t nbytes, uint64_t n, uint16_t *em);
 }  // namespace stock

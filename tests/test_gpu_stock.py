@@ -263,3 +263,67 @@ def test_corrupt_stock_lorenzo_reg_streams_are_refused():
     b4 = oracle_compress(a4, make_config(a4.shape, abs_eb=1e-2, lorenzo=True, regression=True))
     with pytest.raises(sz3_amd.SZ3HipError, match="1-D, 2-D and 3-D"):
         sz3_amd.decompress(b4, np.float32, a4.shape)
+
+
+# ---- stock ALGO_LORENZO_REG streams, WRITE side (round 5: sz3hip_stock.hip k_slw_*) ------------------------------------------------
+LR_WRITE_CASES = [c for c in LR_CASES if not c[0].startswith("1d")] + [
+    ("3d-block8", lambda: field3d((33, 40, 41)), 2e-2, dict(lorenzo=True, regression=True, block_size=8)),
+    ("2d-f64-all-three", lambda: field2d((97, 130), np.float64), 1e-3, dict(lorenzo=True, lorenzo2=True, regression=True)),
+    ("3d-512cube-slice", lambda: field3d((64, 256, 256)), 1e-3, dict(lorenzo=True, regression=True)),
+]
+
+
+@pytest.mark.parametrize("name,gen,eb,kw", LR_WRITE_CASES, ids=[c[0] for c in LR_WRITE_CASES])
+def test_streams_written_as_stock_lorenzo_reg_are_read_by_stock_sz3(name, gen, eb, kw):
+    """sz3hip_set_stock_format(1) + cmprAlgo ALGO_LORENZO_REG: the reference's own Lorenzo / regression container
+    (api/impl/SZAlgoLorenzoReg.hpp:67-84, decomposition/BlockwiseDecomposition.hpp:28-46, predictor/RegressionPredictor.hpp:94-149,
+    quantizer/LinearQuantizer.hpp:43-71). Stock SZ3 (the oracle, the reference library) decodes it within the bound; this library's
+    reader decodes it to the same values bit for bit; the size is near what stock SZ3 writes for the same Config (the writer chooses
+    the blocks' predictors from original neighbours, the reference from reconstructed ones)."""
+    a = gen()
+    L = sz3_amd.lib()
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.absErrorBound = eb
+    conf.lorenzo, conf.lorenzo2, conf.regression = int(kw.get("lorenzo", True)), int(kw.get("lorenzo2", False)), int(kw.get("regression", False))
+    if "block_size" in kw:
+        conf.blockSize = kw["block_size"]
+    L.sz3hip_set_stock_format(1)
+    try:
+        blob, ratio = sz3_amd.compress(a, conf)
+    finally:
+        L.sz3hip_set_stock_format(0)
+    if name == "3d-regression-only-block5":
+        # (15 = 3 x 5 along x, but 23 and 32 leave blocks 3 and 2 wide — all extents > 1: taken; a one-element-thin block is not, below)
+        pass
+    assert _trailer_algo(blob) == sz3_amd.ALGO_LORENZO_REG, "not a stock stream"
+    got, _ = oracle_decompress(blob, a.dtype, a.shape)       # stock SZ3 reading OUR stream
+    fin = np.isfinite(a)
+    assert float(np.max(np.abs(got[fin].astype(np.float64) - a[fin].astype(np.float64)))) <= eb
+    assert np.array_equal(got[~fin], a[~fin], equal_nan=True)
+    if have_ref():
+        assert np.array_equal(ref_decompress(blob, a.dtype, a.shape), got, equal_nan=True)
+    mine, c2 = sz3_amd.decompress(blob, a.dtype, a.shape)    # and this library reading it back
+    assert c2.cmprAlgo == sz3_amd.ALGO_LORENZO_REG
+    assert np.array_equal(mine, got, equal_nan=True)
+    oblob = oracle_compress(a, make_config(a.shape, abs_eb=eb, **kw))
+    assert len(blob) <= 1.08 * len(oblob) + 256, (len(blob), len(oblob))
+
+
+def test_stock_lorenzo_reg_writer_declines_what_it_does_not_take():
+    """1-D arrays and a regression-only set with a one-element-thin block: this library's own stream instead (ids 16), never a wrong one"""
+    L = sz3_amd.lib()
+    for a, kw in ((field1d(50000), dict(lorenzo=1, lorenzo2=0, regression=1)), (field3d((23, 31, 16)), dict(lorenzo=0, lorenzo2=0, regression=1, blockSize=5))):
+        conf = sz3_amd.Config(*a.shape)
+        conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+        conf.absErrorBound = 1e-2
+        for k, v in kw.items():
+            setattr(conf, k, v)
+        L.sz3hip_set_stock_format(1)
+        try:
+            blob, _ = sz3_amd.compress(a, conf)
+        finally:
+            L.sz3hip_set_stock_format(0)
+        assert _trailer_algo(blob) == sz3_amd.ALGO_HIP_LORENZO
+        dec, _ = sz3_amd.decompress(blob, a.dtype, a.shape)
+        assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= 1e-2

@@ -689,6 +689,193 @@ int stock_encode_interp(SlabJob &j) {
     }
     return 0;
 }
+// the main code stream of a stock container onto the device: tree, bits -> codes (the device's self-synchronising decoder, the host walk
+// behind it). What stock_decompress_interp / _lorenzo_reg spell out in place, as a helper for the readers added in round 5.
+struct StockHuffDev {
+    uint16_t *d_em;
+    uint8_t *d_bits, *d_t;
+    uint32_t *d_L, *d_R, *d_lut, *d_count, *d_flags;
+    int32_t *d_C;
+    uint64_t *d_start, *d_last, *d_next, *d_base;
+};
+static void stock_huff_ask(DevArena &ar, StockHuffDev &h, uint64_t n, uint64_t bit_bytes, uint32_t nc) {
+    const uint64_t nsub = (bit_bytes * 8 + 4095) / 4096;
+    ar.ask(&h.d_em, (size_t)n * 2 + 2048);
+    ar.ask(&h.d_bits, (size_t)bit_bytes + 16);
+    ar.ask(&h.d_L, (size_t)nc * 4);
+    ar.ask(&h.d_R, (size_t)nc * 4);
+    ar.ask(&h.d_C, (size_t)nc * 4);
+    ar.ask(&h.d_t, nc);
+    ar.ask(&h.d_lut, 4096 * 4);
+    ar.ask(&h.d_start, (size_t)(nsub + 2) * 8);
+    ar.ask(&h.d_last, (size_t)(nsub + 2) * 8);
+    ar.ask(&h.d_next, (size_t)(nsub + 2) * 8);
+    ar.ask(&h.d_base, (size_t)(nsub + 2) * 8);
+    ar.ask(&h.d_count, (size_t)(nsub + 2) * 4);
+    ar.ask(&h.d_flags, 64);
+}
+static int stock_huff_run(HostSlot *s, const StockHuffDev &h, const stock::Tree &tr, int32_t offset, const uint8_t *bits, uint64_t bit_bytes, uint64_t n) {
+    std::vector<uint16_t> em_host;
+    const uint32_t nc = (uint32_t)tr.t.size();
+    auto on_host = [&]() -> int {
+        em_host.resize((size_t)n);
+        if (!stock::host_decode(tr, offset, bits, (size_t)bit_bytes, n, em_host.data())) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (bit stream)");
+        HIPCHK(hipMemcpyAsync(h.d_em, em_host.data(), (size_t)n * 2, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        return 0;
+    };
+    if (tr.t[0]) {  // a single symbol: no bits at all (encoder/HuffmanEncoder.hpp:233-237)
+        const int32_t v = tr.C[0] + offset;
+        if (v < 0 || v > 65535) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (symbol)");
+        em_host.assign((size_t)n, (uint16_t)v);
+        HIPCHK(hipMemcpyAsync(h.d_em, em_host.data(), (size_t)n * 2, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        return 0;
+    }
+    if (stock_host_huffman()) return on_host();
+    std::vector<uint32_t> lut;
+    stock::make_lut(tr, lut);
+    HIPCHK(hipMemsetAsync(h.d_bits + (bit_bytes & ~(uint64_t)3), 0, 16, s->stream));  // (the last word's tail reads as zeros)
+    HIPCHK(hipMemcpyAsync(h.d_bits, bits, (size_t)bit_bytes, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(h.d_L, tr.L.data(), (size_t)nc * 4, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(h.d_R, tr.R.data(), (size_t)nc * 4, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(h.d_C, tr.C.data(), (size_t)nc * 4, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(h.d_t, tr.t.data(), nc, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(h.d_lut, lut.data(), 4096 * 4, hipMemcpyHostToDevice, s->stream));
+    szk_stock_tree_dev td{h.d_L, h.d_R, h.d_C, h.d_t, h.d_lut, nc, offset};
+    int passes = 0;
+    const int rd = szk_launch_stock_huff_decode(&td, (const uint32_t *)h.d_bits, bit_bytes, n, h.d_start, h.d_last, h.d_next, h.d_base, h.d_count, h.d_flags, h.d_em, &passes, s->stream);
+    if (rd == -4) return on_host();  // the restart points did not settle within the pass cap: the bit-serial walk on the host
+    if (rd == -3) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (bit stream)");
+    if (rd) return fail(SZ3HIP_EHIP, "stock stream: device Huffman decoder failed (%d)", rd);
+    return 0;
+}
+// A stock ALGO_NOPRED stream (SZDispatcher.hpp:92-93 -> api/impl/SZAlgoNopred.hpp:26-34): quantizer, tree, codes — value = recover(0, code)
+int stock_decompress_nopred(HostSlot *s, const sz3hip_config *conf, int dataType, const unsigned char *p, size_t payload, void *decData) {
+    const int cdt = dtype_compute(dataType);
+    const size_t tsize = cdt == SZ3HIP_FLOAT ? 4 : 8;
+    if (payload < 8) return fail(SZ3HIP_EFORMAT, "truncated payload");
+    uint64_t raw_len;
+    memcpy(&raw_len, p, 8);
+    if (raw_len < 32 || raw_len > (uint64_t)conf->num * 16 + (1u << 22)) return fail(SZ3HIP_EFORMAT, "implausible payload length in the lossless block");
+    std::vector<uint8_t> raw((size_t)raw_len + 8, 0);
+    if (zs::decompress_frames(p, payload, raw.data(), (size_t)raw_len) != raw_len) return SZ3HIP_EZSTD;
+    stock::LorenzoReg lr;  // (the same layout with no predictor section in front of the quantizer)
+    if (!stock::parse_lorenzo_reg(raw.data(), (size_t)raw_len, tsize, false, false, 0, conf->N, lr) || lr.n != conf->num)
+        return fail(SZ3HIP_EFORMAT, "corrupt stock ALGO_NOPRED stream (quantizer or Huffman tree)");
+    HIPCHK(hipSetDevice(s->device));
+    int rc;
+    if ((rc = slot_ctx(s, conf->num))) return rc;
+    if ((rc = ensure_dev(&s->dev_in, &s->dev_in_bytes, (size_t)conf->num * tsize))) return rc;
+    const uint64_t n = lr.n, ntiles_z = (n + 1023) / 1024;
+    StockHuffDev hd;
+    uint8_t *d_unpred;
+    uint64_t *d_tile_base;
+    uint32_t *d_tile_cnt, *d_bad;
+    DevArena ar;
+    stock_huff_ask(ar, hd, n, lr.bit_bytes, (uint32_t)lr.tree.t.size());
+    ar.ask(&d_unpred, (size_t)lr.q.n_unpred * tsize + 8);
+    ar.ask(&d_tile_cnt, (size_t)ntiles_z * 4 + 8);
+    ar.ask(&d_tile_base, (size_t)(ntiles_z + 1) * 8);
+    ar.ask(&d_bad, 64);
+    if (ar.commit(s)) return SZ3HIP_EHIP;
+    HIPCHK(hipMemsetAsync(d_bad, 0, 64, s->stream));
+    if (lr.q.n_unpred) HIPCHK(hipMemcpyAsync(d_unpred, lr.q.unpred, (size_t)lr.q.n_unpred * tsize, hipMemcpyHostToDevice, s->stream));
+    if ((rc = stock_huff_run(s, hd, lr.tree, lr.offset, lr.bits, lr.bit_bytes, n))) return rc;
+    if (szk_launch_stock_nopred_decode(cdt == SZ3HIP_FLOAT ? 0 : 1, hd.d_em, n, lr.q.eb, (uint32_t)lr.q.radius, d_tile_cnt, d_tile_base, d_unpred, lr.q.n_unpred, s->dev_in,
+                                       d_bad, s->stream))
+        return fail(SZ3HIP_EHIP, "stock stream: decoder launch failed");
+    uint32_t bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (bad) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (more zero codes than unpredictable values)");
+    HIPCHK(hipMemcpy(decData, s->dev_in, (size_t)conf->num * tsize, hipMemcpyDeviceToHost));
+    return 0;
+}
+// ... and WRITTEN (sz3hip_set_stock_format + cmprAlgo ALGO_NOPRED)
+int stock_encode_nopred(SlabJob &j) {
+    HostSlot *s = j.slot;
+    const sz3hip_config &cf = j.conf;
+    const int radius = cf.quantbinCnt / 2;
+    if (radius < 1 || radius > 32768 || !(cf.absErrorBound > 0)) return SZ3HIP_EUNSUPPORTED;
+    const size_t tsize = j.cdt == SZ3HIP_FLOAT ? 4 : 8;
+    const uint64_t n = cf.num;
+    HIPCHK(hipSetDevice(s->device));
+    const uint64_t ntiles_z = (n + 1023) / 1024, ntiles_e = (n + 2047) / 2048;
+    uint8_t *d_unpred, *d_clen;
+    uint16_t *d_codes;
+    uint64_t *d_hist, *d_tile_base, *d_cbits, *d_ebase;
+    uint32_t *d_tile_cnt, *d_ebits;
+    DevArena ar;
+    ar.ask(&d_unpred, (size_t)n * tsize + 64);
+    ar.ask(&d_codes, (size_t)n * 2 + 64);
+    ar.ask(&d_hist, 65536 * 8);
+    ar.ask(&d_tile_cnt, (size_t)ntiles_z * 4);
+    ar.ask(&d_tile_base, (size_t)(ntiles_z + 1) * 8);
+    ar.ask(&d_clen, 65536);
+    ar.ask(&d_cbits, 65536 * 8);
+    ar.ask(&d_ebits, (size_t)ntiles_e * 4);
+    ar.ask(&d_ebase, (size_t)(ntiles_e + 1) * 8);
+    if (ar.commit(s)) return SZ3HIP_EHIP;
+    const int dt = j.cdt == SZ3HIP_FLOAT ? 0 : 1;
+    HIPCHK(hipMemsetAsync(d_hist, 0, 65536 * 8, s->stream));
+    if (szk_launch_stock_nopred_encode(dt, s->dev_in, n, cf.absErrorBound, (uint32_t)radius, d_codes, s->stream)) return fail(SZ3HIP_EHIP, "stock stream: coding launch failed");
+    szk_slw_params sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.codes = d_codes;
+    sp.uval = s->dev_in;  // (code position = element: a zero code's value is the input's)
+    sp.radius = (uint32_t)radius;
+    uint64_t n_unpred = 0;
+    if (szk_launch_stock_lr_finish(dt, &sp, n, d_hist, d_tile_cnt, d_tile_base, d_unpred, &n_unpred, s->stream)) return fail(SZ3HIP_EHIP, "stock stream: histogram / list launch failed");
+    std::vector<uint64_t> hist(65536);
+    HIPCHK(hipMemcpyAsync(hist.data(), d_hist, 65536 * 8, hipMemcpyDeviceToHost, s->stream));
+    std::vector<uint8_t> un((size_t)n_unpred * tsize + 8), bits;
+    if (n_unpred) HIPCHK(hipMemcpyAsync(un.data(), d_unpred, (size_t)n_unpred * tsize, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (n_unpred * (tsize + 2) >= j.raw_bytes / 2) {
+        j.lossless = true;
+        return SZ3HIP_EUNSUPPORTED;
+    }
+    stock::Tree tr;
+    std::vector<uint8_t> clen;
+    std::vector<uint64_t> cbits;
+    int lo = 0, hi = 0;
+    if (!stock::book_from_hist(hist.data(), tr, clen, cbits, lo, hi)) return fail(SZ3HIP_EHIP, "stock stream: empty code histogram");
+    uint64_t bit_bytes = 0;
+    if (!tr.t[0]) {
+        HIPCHK(hipMemcpyAsync(d_clen, clen.data(), 65536, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(d_cbits, cbits.data(), 65536 * 8, hipMemcpyHostToDevice, s->stream));
+        uint64_t total_bits = 0;
+        const int re = szk_launch_stock_huff_encode(d_codes, n, d_clen, d_cbits, d_ebits, d_ebase, (uint32_t *)s->dev_in, (uint64_t)(s->dev_in_bytes / 4), &total_bits, s->stream);
+        if (re == -2) {
+            j.lossless = true;
+            return SZ3HIP_EUNSUPPORTED;
+        }
+        if (re) return fail(SZ3HIP_EHIP, "stock stream: device Huffman coder failed (%d)", re);
+        bit_bytes = (total_bits + 7) / 8;
+        bits.resize((size_t)bit_bytes + 8);
+        HIPCHK(hipMemcpyAsync(bits.data(), s->dev_in, (size_t)bit_bytes, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        bits.resize((size_t)bit_bytes);
+    }
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)bit_bytes + (size_t)n_unpred * tsize + (1u << 20));
+    stock::write_lorenzo_reg_head(cf.N, 1, cf.absErrorBound, tsize, false, false, {}, nullptr, 0, nullptr, 0, {}, radius, un.data(), n_unpred, tr, lo, hi, n, bit_bytes, raw);
+    raw.insert(raw.end(), bits.begin(), bits.end());
+    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap);
+    if (!j.out_size) return sz3hip_last_error_code();
+    j.conf.cmprAlgo = SZ3HIP_ALGO_NOPRED;
+    if ((double)j.raw_bytes / (double)j.out_size < 3) {  // SZDispatcher.hpp:62-74
+        std::vector<uint8_t> z(zs::bound_frames(j.raw_bytes) + 8);
+        size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size());
+        if (zsz && zsz < j.out_size && zsz <= j.out_cap) {
+            memcpy(j.out, z.data(), zsz);
+            j.out_size = zsz;
+            j.conf.cmprAlgo = SZ3HIP_ALGO_LOSSLESS;
+        }
+    }
+    return 0;
+}
 // A stock ALGO_LORENZO_REG stream WRITTEN (round 5; 2-D and 3-D arrays of float / double, block sizes the read side takes): selection pass,
 // coefficient chain on the host, coding front by front of blocks in the reference's arithmetic, the reference's container
 // (szk_slw_params, sz3hip_kernels.h). 0: j.out holds the stream; SZ3HIP_EUNSUPPORTED: not a case this writer takes (the caller falls
@@ -1157,7 +1344,7 @@ int job_encode(SlabJob &j) {
             // the caller wants files stock SZ3 reads: where stage 1 took the interpolation predictor its codes go into the reference's
             // own container (cmprAlgo ALGO_INTERP) instead of the device payload
             // ... and a call that names ALGO_LORENZO_REG gets the reference's Lorenzo / regression stream (round 5: 2-D and 3-D arrays)
-            const int rs = j.asked_algo == SZ3HIP_ALGO_LORENZO_REG ? stock_encode_lorenzo_reg(j) : stock_encode_interp(j);
+            const int rs = j.asked_algo == SZ3HIP_ALGO_LORENZO_REG ? stock_encode_lorenzo_reg(j) : j.asked_algo == SZ3HIP_ALGO_NOPRED ? stock_encode_nopred(j) : stock_encode_interp(j);
             if (rs == 0) return 0;
             if (rs != SZ3HIP_EUNSUPPORTED) return j.failed(rs);
             // (another predictor: there is no stock form of it here — this library's own stream)
@@ -1739,6 +1926,8 @@ int decompress_blob(HostSlot *s, const sz3hip_config *conf, int dataType, const 
         return stock_decompress_interp(s, conf, dataType, p, payload, decData);
     if (conf->cmprAlgo == SZ3HIP_ALGO_LORENZO_REG && !is_int)  // ... of the Lorenzo / regression compressor (:85-88)
         return stock_decompress_lorenzo_reg(s, conf, dataType, p, payload, decData);
+    if (conf->cmprAlgo == SZ3HIP_ALGO_NOPRED && !is_int)  // ... of the no-prediction compressor (:92-93)
+        return stock_decompress_nopred(s, conf, dataType, p, payload, decData);
     if (conf->cmprAlgo != SZ3HIP_ALGO_HIP_LORENZO && conf->cmprAlgo != SZ3HIP_ALGO_HIP_INTERP)
         return fail(SZ3HIP_EUNSUPPORTED,
                     "stream uses cmprAlgo %d of the CPU reference; this library decodes its own GPU streams (ids %d, %d), stock ALGO_INTERP / "

@@ -410,6 +410,10 @@ struct szk_slw_params {
     const void *coef;         // [blocks][4] T: the RECOVERED coefficients of the regression blocks (host chain), what predictions use
 };
 int szk_launch_stock_lr_select(int dtype, const szk_slw_params *p, hipStream_t s);
+// stock ALGO_NOPRED streams (round 5): every value quantized against a prediction of 0 (NoPredictionDecomposition.hpp:17-33)
+int szk_launch_stock_nopred_decode(int dtype, const uint16_t *d_codes, uint64_t n, double eb, uint32_t radius, uint32_t *d_tile_cnt, uint64_t *d_tile_base,
+                                   const void *d_unpred, uint64_t n_unpred, void *d_out, uint32_t *d_bad, hipStream_t s);
+int szk_launch_stock_nopred_encode(int dtype, const void *d_in, uint64_t n, double eb, uint32_t radius, uint16_t *d_codes, hipStream_t s);
 int szk_launch_stock_lr_code(int dtype, const szk_slw_params *p, hipStream_t s);
 // histogram of a stock stream's codes (u64[65536], zeroed by the caller) and the unpredictable values in the order of their zero codes
 int szk_launch_stock_lr_finish(int dtype, const szk_slw_params *p, uint64_t n, uint64_t *d_hist, uint32_t *d_tile_cnt, uint64_t *d_tile_base, void *d_unpred,

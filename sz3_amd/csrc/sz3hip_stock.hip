@@ -1072,6 +1072,45 @@ __global__ __launch_bounds__(256) void k_slw_unpred(const uint16_t *__restrict__
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
         if (codes[i] == 0) unpred[stock_ordinal(codes, tile_base, i)] = uval[i];
 }
+// ---- stock ALGO_NOPRED streams (round 5; decomposition/NoPredictionDecomposition.hpp:17-33): every value quantized against a prediction of 0 ----
+template <typename T>
+__global__ __launch_bounds__(256) void k_snp_decode(const uint16_t *__restrict__ codes, uint64_t n, double eb, uint32_t radius, const uint64_t *__restrict__ tile_base,
+                                                    const T *__restrict__ unpred, uint64_t n_unpred, T *__restrict__ out, uint32_t *bad) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t code = codes[i];
+        T v;
+        if (code) {
+            v = ref_recover<T>((T)0, (int)code, eb, (int)radius);  // LinearQuantizer::recover, :77-86
+        } else {
+            const uint64_t k = stock_ordinal(codes, tile_base, i);
+            v = k < n_unpred ? unpred[k] : (T)0;
+            if (k >= n_unpred) *bad = 1u;
+        }
+        out[i] = v;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_snp_encode(const T *__restrict__ in, uint64_t n, double eb, uint32_t radius, uint16_t *__restrict__ codes) {
+    const double recip = 1.0 / eb;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        T v = in[i];
+        codes[i] = (uint16_t)ref_quantize<T>(v, (T)0, eb, recip, (int)radius);  // (a zero code: the value itself goes to the list, k_slw_unpred)
+    }
+}
+int szk_launch_stock_nopred_decode(int dtype, const uint16_t *d_codes, uint64_t n, double eb, uint32_t radius, uint32_t *d_tile_cnt, uint64_t *d_tile_base,
+                                   const void *d_unpred, uint64_t n_unpred, void *d_out, uint32_t *d_bad, hipStream_t s) {
+    if (stock_zero_scan(d_codes, n, d_tile_cnt, d_tile_base, s)) return -1;
+    const uint32_t g = stock_grid(n);
+    if (dtype == 0) hipLaunchKernelGGL(k_snp_decode<float>, dim3(g), dim3(256), 0, s, d_codes, n, eb, radius, d_tile_base, (const float *)d_unpred, n_unpred, (float *)d_out, d_bad);
+    else hipLaunchKernelGGL(k_snp_decode<double>, dim3(g), dim3(256), 0, s, d_codes, n, eb, radius, d_tile_base, (const double *)d_unpred, n_unpred, (double *)d_out, d_bad);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int szk_launch_stock_nopred_encode(int dtype, const void *d_in, uint64_t n, double eb, uint32_t radius, uint16_t *d_codes, hipStream_t s) {
+    const uint32_t g = stock_grid(n);
+    if (dtype == 0) hipLaunchKernelGGL(k_snp_encode<float>, dim3(g), dim3(256), 0, s, (const float *)d_in, n, eb, radius, d_codes);
+    else hipLaunchKernelGGL(k_snp_encode<double>, dim3(g), dim3(256), 0, s, (const double *)d_in, n, eb, radius, d_codes);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 int szk_launch_stock_lr_select(int dtype, const szk_slw_params *p, hipStream_t s) {
     const uint32_t nblocks = p->nb[0] * p->nb[1] * p->nb[2];
     const dim3 grid((nblocks + 3) / 4), blk(256);

@@ -327,3 +327,37 @@ def test_stock_lorenzo_reg_writer_declines_what_it_does_not_take():
         assert _trailer_algo(blob) == sz3_amd.ALGO_HIP_LORENZO
         dec, _ = sz3_amd.decompress(blob, a.dtype, a.shape)
         assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= 1e-2
+
+
+# ---- stock ALGO_NOPRED streams (round 5), both directions; the stock side is the reference library (the oracle restates no NOPRED) ----
+@pytest.mark.parametrize("gen,eb", [(lambda: field3d((30, 41, 52)), 1e-2), (lambda: field1d(50001), 1e-3), (lambda: _with_holes(field3d((20, 30, 40))), 1e-2),
+                                    (lambda: field2d((90, 130), np.float64), 1e-3)], ids=["3d", "1d", "3d-nan-inf", "2d-f64"])
+def test_stock_nopred_streams_both_ways(gen, eb):
+    """SZDispatcher.hpp:34-35 / 92-93 -> api/impl/SZAlgoNopred.hpp, decomposition/NoPredictionDecomposition.hpp:17-33: every value
+    quantized against 0. Read: bit for bit what the reference decodes from its own stream. Written (sz3hip_set_stock_format +
+    cmprAlgo ALGO_NOPRED): the reference decodes our stream to the values this library decodes, within the bound."""
+    from oracle_binding import ALGO_NOPRED
+    if not have_ref():
+        pytest.skip("oracle/_ref/libsz3ref.so not built")
+    a = gen()
+    oconf = make_config(a.shape, algo=ALGO_NOPRED, abs_eb=eb)
+    rblob = ref_compress(a, oconf)
+    assert _trailer_algo(rblob) == sz3_amd.ALGO_NOPRED
+    want = ref_decompress(rblob, a.dtype, a.shape)
+    got, c2 = sz3_amd.decompress(rblob, a.dtype, a.shape)
+    assert c2.cmprAlgo == sz3_amd.ALGO_NOPRED and np.array_equal(got, want, equal_nan=True)
+    L = sz3_amd.lib()
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_NOPRED
+    conf.absErrorBound = eb
+    L.sz3hip_set_stock_format(1)
+    try:
+        blob, _ = sz3_amd.compress(a, conf)
+    finally:
+        L.sz3hip_set_stock_format(0)
+    assert _trailer_algo(blob) == sz3_amd.ALGO_NOPRED
+    back = ref_decompress(blob, a.dtype, a.shape)
+    assert np.array_equal(back, want, equal_nan=True)      # the same quantizer on the same values: the same reconstruction
+    mine, _ = sz3_amd.decompress(blob, a.dtype, a.shape)
+    assert np.array_equal(mine, back, equal_nan=True)
+    assert len(blob) <= 1.05 * len(rblob) + 256

@@ -876,6 +876,59 @@ int stock_encode_nopred(SlabJob &j) {
     }
     return 0;
 }
+// the 1-D case of the writer below: the chain on the host (sz3hip_stock_host.cpp, lorenzo_reg_write_1d), the container as for the others
+static int stock_encode_lorenzo_reg_1d(SlabJob &j) {
+    const sz3hip_config &cf = j.conf;
+    const uint32_t B = (uint32_t)cf.blockSize;
+    const uint32_t set_mask = (cf.lorenzo ? 1u : 0u) | (cf.lorenzo2 ? 2u : 0u) | (cf.regression ? 4u : 0u);
+    const int members = (cf.lorenzo ? 1 : 0) + (cf.lorenzo2 ? 1 : 0) + (cf.regression ? 1 : 0);
+    const int radius = cf.quantbinCnt / 2;
+    if (!set_mask || B > 65535 || radius < 1 || radius > 32768 || !(cf.absErrorBound > 0) || j.is_int) return SZ3HIP_EUNSUPPORTED;
+    const uint64_t n = cf.num;
+    const size_t tsize = j.cdt == SZ3HIP_FLOAT ? 4 : 8;
+    std::vector<uint16_t> codes, selection, coef_codes;
+    std::vector<uint8_t> raw, bits, un;
+    stock::Tree tr;
+    int lo = 0, hi = 0;
+    uint64_t n_unpred = 0;
+    std::vector<float> ui32, ul32;
+    std::vector<double> ui64, ul64;
+    if (j.cdt == SZ3HIP_FLOAT) {
+        std::vector<float> data((const float *)j.data, (const float *)j.data + n), unpred;
+        stock::lorenzo_reg_write_1d<float>(n, B, cf.absErrorBound, radius, set_mask, data.data(), codes, unpred, selection, coef_codes, ui32, ul32);
+        n_unpred = unpred.size();
+        un.assign((const uint8_t *)unpred.data(), (const uint8_t *)unpred.data() + n_unpred * 4);
+    } else {
+        std::vector<double> data((const double *)j.data, (const double *)j.data + n), unpred;
+        stock::lorenzo_reg_write_1d<double>(n, B, cf.absErrorBound, radius, set_mask, data.data(), codes, unpred, selection, coef_codes, ui64, ul64);
+        n_unpred = unpred.size();
+        un.assign((const uint8_t *)unpred.data(), (const uint8_t *)unpred.data() + n_unpred * 8);
+    }
+    if (n_unpred * (tsize + 2) >= j.raw_bytes / 2) {
+        j.lossless = true;
+        return SZ3HIP_EUNSUPPORTED;
+    }
+    if (!stock::encode_codes_host(codes, tr, lo, hi, bits)) return fail(SZ3HIP_EHIP, "stock stream: empty code histogram");
+    un.resize(un.size() + 8);
+    const void *pui = j.cdt == SZ3HIP_FLOAT ? (const void *)ui32.data() : (const void *)ui64.data(), *pul = j.cdt == SZ3HIP_FLOAT ? (const void *)ul32.data() : (const void *)ul64.data();
+    const uint64_t nui = j.cdt == SZ3HIP_FLOAT ? ui32.size() : ui64.size(), nul = j.cdt == SZ3HIP_FLOAT ? ul32.size() : ul64.size();
+    stock::write_lorenzo_reg_head(1, B, cf.absErrorBound, tsize, cf.regression != 0, members > 1, coef_codes, pui, nui, pul, nul, selection, radius, un.data(), n_unpred, tr, lo, hi,
+                                  n, bits.size(), raw);
+    raw.insert(raw.end(), bits.begin(), bits.end());
+    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap);
+    if (!j.out_size) return sz3hip_last_error_code();
+    j.conf.cmprAlgo = SZ3HIP_ALGO_LORENZO_REG;
+    if ((double)j.raw_bytes / (double)j.out_size < 3) {  // SZDispatcher.hpp:62-74
+        std::vector<uint8_t> z(zs::bound_frames(j.raw_bytes) + 8);
+        size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size());
+        if (zsz && zsz < j.out_size && zsz <= j.out_cap) {
+            memcpy(j.out, z.data(), zsz);
+            j.out_size = zsz;
+            j.conf.cmprAlgo = SZ3HIP_ALGO_LOSSLESS;
+        }
+    }
+    return 0;
+}
 // A stock ALGO_LORENZO_REG stream WRITTEN (round 5; 2-D and 3-D arrays of float / double, block sizes the read side takes): selection pass,
 // coefficient chain on the host, coding front by front of blocks in the reference's arithmetic, the reference's container
 // (szk_slw_params, sz3hip_kernels.h). 0: j.out holds the stream; SZ3HIP_EUNSUPPORTED: not a case this writer takes (the caller falls
@@ -884,7 +937,8 @@ int stock_encode_lorenzo_reg(SlabJob &j) {
     HostSlot *s = j.slot;
     const sz3hip_config &cf = j.conf;
     const int N = cf.N;
-    if (N < 2 || N > 3 || cf.blockSize < 2) return SZ3HIP_EUNSUPPORTED;
+    if (N < 1 || N > 3 || cf.blockSize < 2) return SZ3HIP_EUNSUPPORTED;
+    if (N == 1) return stock_encode_lorenzo_reg_1d(j);
     const uint32_t B = (uint32_t)cf.blockSize;
     if ((N == 3 && B > 8) || (N == 2 && B > 32)) return SZ3HIP_EUNSUPPORTED;
     const uint32_t set_mask = (cf.lorenzo ? 1u : 0u) | (cf.lorenzo2 ? 2u : 0u) | (cf.regression ? 4u : 0u);
@@ -1304,6 +1358,20 @@ int stock_decompress_lorenzo_reg(HostSlot *s, const sz3hip_config *conf, int dat
             HIPCHK(hipMemcpyAsync(d_em, em_host.data(), (size_t)n * 2, hipMemcpyHostToDevice, s->stream));
         } else if (rd == -3) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (bit stream)");
         else if (rd) return fail(SZ3HIP_EHIP, "stock stream: device Huffman decoder failed (%d)", rd);
+    }
+    if (N == 1 && !env_int("SZ3HIP_STOCK_1D_ON_DEVICE", 0)) {
+        // a 1-D array is one chain of roundings: walked on the host over the codes the device decoded (sz3hip_stock_host.cpp,
+        // lorenzo_reg_read_1d; SZ3HIP_STOCK_1D_ON_DEVICE=1 keeps round 4's one-lane kernel, k_slr_chain, for comparison)
+        std::vector<uint16_t> em((size_t)n);
+        HIPCHK(hipMemcpyAsync(em.data(), d_em, (size_t)n * 2, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        const bool okw = cdt == SZ3HIP_FLOAT
+                             ? stock::lorenzo_reg_read_1d<float>(n, B, lr.q.eb, lr.q.radius, em.data(), kind.data(), cf32.data(), reinterpret_cast<const float *>(lr.q.unpred),
+                                                                 lr.q.n_unpred, reinterpret_cast<float *>(decData))
+                             : stock::lorenzo_reg_read_1d<double>(n, B, lr.q.eb, lr.q.radius, em.data(), kind.data(), cf64.data(), reinterpret_cast<const double *>(lr.q.unpred),
+                                                                  lr.q.n_unpred, reinterpret_cast<double *>(decData));
+        if (!okw) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (more zero codes than unpredictable values)");
+        return 0;
     }
     szk_slr_params sp;
     memset(&sp, 0, sizeof(sp));

@@ -591,4 +591,136 @@ void write_lorenzo_reg_head(int N, uint32_t B, double eb, size_t tsize, bool has
     w.put<uint64_t>(n);
     w.put<uint64_t>(bit_bytes);
 }
+// ---- 1-D stock ALGO_LORENZO_REG streams: the chain on the host (round 5) -------------------------------------------------------
+// A 1-D array under Lorenzo prediction is ONE dependent chain of roundings — value i needs value i - 1 as the reader will have it —
+// and nothing of it is associative (T arithmetic, LinearQuantizer's double detour). On one GPU lane it ran 322 ms for 2^22 values
+// (round 4, k_slr_chain), 3.6 x slower than one host core; the walk therefore runs here, over codes the device decoded / for the
+// device to code. Same arithmetic as k_slr_front's: LorenzoPredictor::predict (:60-64, :75-76), RegressionPredictor::predict (:81-83),
+// LinearQuantizer::recover (:77-86) / quantize_and_overwrite (:43-71).
+template <typename T>
+bool lorenzo_reg_read_1d(uint64_t n, uint32_t B, double eb, int radius, const uint16_t *codes, const uint8_t *kind, const T *coef, const T *unpred, uint64_t n_unpred,
+                         T *out) {
+    T p1 = 0, p2 = 0;  // the two values left of the next element (the reference pads the array with zeros)
+    uint64_t u = 0;
+    for (uint64_t x0 = 0, b = 0; x0 < n; x0 += B, b++) {
+        const uint32_t ex = (uint32_t)std::min<uint64_t>(B, n - x0);
+        const uint32_t k = kind[b];
+        const T c0 = coef[b * 4], c1 = coef[b * 4 + 1];
+        for (uint32_t t = 0; t < ex; t++) {
+            const uint32_t code = codes[x0 + t];
+            T v;
+            if (code == 0) {
+                if (u >= n_unpred) return false;
+                v = unpred[u++];
+            } else {
+                const T pr = k == 2 ? (T)((T)(c0 * (T)t) + c1) : (k == 1 ? (T)((T)(2 * p1) - p2) : p1);
+                v = (T)((double)pr + (double)(2 * ((int)code - radius)) * eb);
+            }
+            out[x0 + t] = v;
+            p2 = p1;
+            p1 = v;
+        }
+    }
+    return true;
+}
+template bool lorenzo_reg_read_1d<float>(uint64_t, uint32_t, double, int, const uint16_t *, const uint8_t *, const float *, const float *, uint64_t, float *);
+template bool lorenzo_reg_read_1d<double>(uint64_t, uint32_t, double, int, const uint16_t *, const uint8_t *, const double *, const double *, uint64_t, double *);
+
+// the write side for a 1-D array: BlockwiseDecomposition::compress (:28-46) as it stands — block after block the members' sampled
+// estimates on the array as it is at that moment (ComposedPredictor::precompress :25-40, the block's two ends: BlockwiseIterator.hpp:154-157),
+// the first minimum, the regression coefficients quantized against the previous regression block's, every element quantized against its
+// prediction from reconstructed values and overwritten. data: the array, overwritten with what the reader will decode.
+template <typename T>
+void lorenzo_reg_write_1d(uint64_t n, uint32_t B, double eb, int radius, uint32_t set_mask, T *data, std::vector<uint16_t> &codes, std::vector<T> &unpred,
+                          std::vector<uint16_t> &selection, std::vector<uint16_t> &coef_codes, std::vector<T> &un_indep, std::vector<T> &un_lin) {
+    const double recip = 1.0 / eb;
+    const double eb_ind = eb / 2, eb_lin = eb / 2 / B;  // (N + 1 = 2)
+    const double r_ind = 1.0 / eb_ind, r_lin = 1.0 / eb_lin;
+    const int members = ((set_mask & 1u) ? 1 : 0) + ((set_mask & 2u) ? 1 : 0) + ((set_mask & 4u) ? 1 : 0);
+    codes.resize((size_t)n);
+    T prev_c[2] = {0, 0};
+    auto at = [&](int64_t i) -> T { return i >= 0 ? data[i] : (T)0; };
+    for (uint64_t x0 = 0; x0 < n; x0 += B) {
+        const uint32_t ex = (uint32_t)std::min<uint64_t>(B, n - x0);
+        const bool reg_valid = (set_mask & 4u) && ex > 1;
+        T cf[2] = {0, 0};
+        if (reg_valid) {
+            double s0 = 0, sn = 0;
+            for (uint32_t t = 0; t < ex; t++) {
+                s0 += (double)t * (double)data[x0 + t];
+                sn += (double)data[x0 + t];
+            }
+            const double num = ex, d = ex;
+            cf[1] = (T)(sn / num);
+            cf[0] = (T)((2 * s0 / (d - 1) - sn) * 6 / num / (d + 1));
+            cf[1] = (T)((double)cf[1] - (d - 1) * (double)cf[0] / 2);
+        }
+        uint32_t kind = 0, idx = 0;
+        if (members > 1) {
+            const double big = 1.7976931348623157e308;
+            double e1 = 0, e2 = 0, er = 0;
+            const uint32_t pts[2] = {0, ex - 1};
+            for (int q = 0; q < 2; q++) {
+                const int64_t i = (int64_t)x0 + pts[q];
+                const T v = data[i];
+                if (set_mask & 1u) e1 += (double)(T)(fabs((double)(T)(v - at(i - 1))) + 0.5 * eb);
+                if (set_mask & 2u) e2 += (double)(T)(fabs((double)(T)(v - (T)((T)(2 * at(i - 1)) - at(i - 2)))) + 1.08 * eb);
+                if (reg_valid) er += (double)(T)fabs((double)(T)(v - (T)((T)(cf[0] * (T)pts[q]) + cf[1])));
+            }
+            double best = HUGE_VAL;
+            uint32_t k = 0;
+            if (set_mask & 1u) {
+                if (e1 < best) best = e1, kind = 0, idx = k;
+                k++;
+            }
+            if (set_mask & 2u) {
+                if (e2 < best) best = e2, kind = 1, idx = k;
+                k++;
+            }
+            if (set_mask & 4u) {
+                const double e = reg_valid ? er : big;
+                if (e < best) best = e, kind = 2, idx = k;
+                k++;
+            }
+            selection.push_back((uint16_t)idx);
+        } else {
+            kind = (set_mask & 1u) ? 0u : ((set_mask & 2u) ? 1u : 2u);
+        }
+        if (kind == 2 && !reg_valid) kind = 0;  // the fallback predictor (BlockwiseDecomposition.hpp:35-37; 1-D: nothing of the padding question)
+        if (kind == 2) {
+            const T o0 = cf[0], o1 = cf[1];
+            const int q0 = quantize_and_overwrite<T>(cf[0], prev_c[0], eb_lin, r_lin, 32768);
+            if (q0 == 0) un_lin.push_back(o0);
+            const int q1 = quantize_and_overwrite<T>(cf[1], prev_c[1], eb_ind, r_ind, 32768);
+            if (q1 == 0) un_indep.push_back(o1);
+            coef_codes.push_back((uint16_t)q0);
+            coef_codes.push_back((uint16_t)q1);
+            prev_c[0] = cf[0];
+            prev_c[1] = cf[1];
+        }
+        for (uint32_t t = 0; t < ex; t++) {
+            const int64_t i = (int64_t)x0 + t;
+            const T pr = kind == 2 ? (T)((T)(cf[0] * (T)t) + cf[1]) : (kind == 1 ? (T)((T)(2 * at(i - 1)) - at(i - 2)) : at(i - 1));
+            const T orig = data[i];
+            const int q = quantize_and_overwrite<T>(data[i], pr, eb, recip, radius);
+            if (q == 0) unpred.push_back(orig);
+            codes[(size_t)i] = (uint16_t)q;
+        }
+    }
+}
+template void lorenzo_reg_write_1d<float>(uint64_t, uint32_t, double, int, uint32_t, float *, std::vector<uint16_t> &, std::vector<float> &, std::vector<uint16_t> &,
+                                          std::vector<uint16_t> &, std::vector<float> &, std::vector<float> &);
+template void lorenzo_reg_write_1d<double>(uint64_t, uint32_t, double, int, uint32_t, double *, std::vector<uint16_t> &, std::vector<double> &, std::vector<uint16_t> &,
+                                           std::vector<uint16_t> &, std::vector<double> &, std::vector<double> &);
+// code book + bits of a host-side code array (the 1-D writer's)
+bool encode_codes_host(const std::vector<uint16_t> &codes, Tree &tr, int &lo, int &hi, std::vector<uint8_t> &bits) {
+    std::vector<uint64_t> hist(65536, 0);
+    for (uint16_t c : codes) hist[c]++;
+    std::vector<uint8_t> clen;
+    std::vector<uint64_t> cbits;
+    if (!book_from_hist(hist.data(), tr, clen, cbits, lo, hi)) return false;
+    bits.clear();
+    if (!tr.t[0]) host_encode(codes.data(), codes.size(), clen, cbits, bits);
+    return true;
+}
 }  // namespace stock

@@ -52,6 +52,14 @@ void lorenzo_reg_chain(int N, uint32_t B, double eb, const uint8_t *kind, uint64
 void write_lorenzo_reg_head(int N, uint32_t B, double eb, size_t tsize, bool has_regression, bool composed, const std::vector<uint16_t> &coef_codes,
                             const void *un_indep, uint64_t n_un_indep, const void *un_lin, uint64_t n_un_lin, const std::vector<uint16_t> &selection, int32_t radius,
                             const void *unpred, uint64_t n_unpred, const Tree &tr, int lo, int hi, uint64_t n, uint64_t bit_bytes, std::vector<uint8_t> &raw);
+// 1-D arrays (round 5): the chain of roundings is walked on the host, both ways (sz3hip_stock_host.cpp says why)
+template <typename T>
+bool lorenzo_reg_read_1d(uint64_t n, uint32_t B, double eb, int radius, const uint16_t *codes, const uint8_t *kind, const T *coef, const T *unpred, uint64_t n_unpred,
+                         T *out);
+template <typename T>
+void lorenzo_reg_write_1d(uint64_t n, uint32_t B, double eb, int radius, uint32_t set_mask, T *data, std::vector<uint16_t> &codes, std::vector<T> &unpred,
+                          std::vector<uint16_t> &selection, std::vector<uint16_t> &coef_codes, std::vector<T> &un_indep, std::vector<T> &un_lin);
+bool encode_codes_host(const std::vector<uint16_t> &codes, Tree &tr, int &lo, int &hi, std::vector<uint8_t> &bits);
 void host_encode(const uint16_t *em, uint64_t n, const std::vector<uint8_t> &clen, const std::vector<uint64_t> &cbits, std::vector<uint8_t> &bits);
 bool host_decode(const Tree &tr, int32_t offset, const uint8_t *bits, size_t nbytes, uint64_t n, uint16_t *em);
 }  // namespace stock

@@ -1191,9 +1191,10 @@ static bool slr_coefficients(const sz3hip_config *conf, const stock::LorenzoReg 
     const int N = conf->N;
     const uint32_t B = (uint32_t)conf->blockSize;
     kind.assign((size_t)nblocks, 0);
-    coef.assign((size_t)nblocks * 4, (T)0);
+    const size_t CS = N == 4 ? 8 : 4;  // coefficients per block in the array handed to the device (N + 1 used)
+    coef.assign((size_t)nblocks * CS, (T)0);
     if (composed && lr.selection.size() != nblocks) return false;
-    T cur[4] = {0, 0, 0, 0};
+    T cur[5] = {0, 0, 0, 0, 0};
     size_t ci = 0;
     uint64_t ui[2] = {0, 0};  // next unpredictable coefficient of the two quantizers (q_lin, q_indep)
     const T *un_lin = reinterpret_cast<const T *>(lr.q_lin.unpred), *un_ind = reinterpret_cast<const T *>(lr.q_indep.unpred);
@@ -1208,7 +1209,7 @@ static bool slr_coefficients(const sz3hip_config *conf, const stock::LorenzoReg 
         u++;
         return v;
     };
-    uint64_t bi[3] = {0, 0, 0};
+    uint64_t bi[4] = {0, 0, 0, 0};  // (w, z, y, x): nb[] likewise, leading entries 1 for N < 4
     for (uint64_t b = 0; b < nblocks; b++) {
         int k;
         if (composed) {
@@ -1221,7 +1222,7 @@ static bool slr_coefficients(const sz3hip_config *conf, const stock::LorenzoReg 
         if (k == 2) {
             bool valid = true;  // RegressionPredictor::predecompress (:62-71): a block with an extent of one has no regression
             for (int i = 0; i < N; i++) {
-                const uint64_t o = bi[3 - N + i] * B, e = std::min<uint64_t>(B, conf->dims[i] - o);
+                const uint64_t o = bi[4 - N + i] * B, e = std::min<uint64_t>(B, conf->dims[i] - o);
                 if (e <= 1) valid = false;
             }
             if (!valid) {
@@ -1239,11 +1240,11 @@ static bool slr_coefficients(const sz3hip_config *conf, const stock::LorenzoReg 
                 for (int i = 0; i < N; i++) cur[i] = recover(lr.q_lin, un_lin, ui[0], cur[i], lr.coef_codes[ci++], ok);
                 cur[N] = recover(lr.q_indep, un_ind, ui[1], cur[N], lr.coef_codes[ci++], ok);
                 if (!ok) return false;
-                for (int i = 0; i <= N; i++) coef[(size_t)b * 4 + i] = cur[i];
+                for (int i = 0; i <= N; i++) coef[(size_t)b * CS + i] = cur[i];
             }
         }
         kind[(size_t)b] = (uint8_t)k;
-        for (int d = 2; d >= 0; d--) {  // raster order over the (z, y, x) view
+        for (int d = 3; d >= 0; d--) {  // raster order over the (w, z, y, x) view
             if (++bi[d] < nb[d]) break;
             bi[d] = 0;
         }
@@ -1254,11 +1255,11 @@ int stock_decompress_lorenzo_reg(HostSlot *s, const sz3hip_config *conf, int dat
     const int cdt = dtype_compute(dataType);
     const size_t tsize = cdt == SZ3HIP_FLOAT ? 4 : 8;
     const int N = conf->N;
-    if (N < 1 || N > 3)
-        return fail(SZ3HIP_EUNSUPPORTED, "stock ALGO_LORENZO_REG streams are read for 1-D, 2-D and 3-D arrays (got N = %d)", N);
+    if (N < 1 || N > 4)
+        return fail(SZ3HIP_EUNSUPPORTED, "stock ALGO_LORENZO_REG streams are read for 1-D ... 4-D arrays (got N = %d)", N);
     const uint32_t B = (uint32_t)conf->blockSize;
-    if (conf->blockSize < 1 || (N == 3 && B > 8) || (N == 2 && B > 32))
-        return fail(SZ3HIP_EUNSUPPORTED, "stock ALGO_LORENZO_REG streams are read for block sizes up to 8 (3-D) / 32 (2-D) (got %d)", conf->blockSize);
+    if (conf->blockSize < 1 || (N == 4 && B > 6) || (N == 3 && B > 8) || (N == 2 && B > 32))
+        return fail(SZ3HIP_EUNSUPPORTED, "stock ALGO_LORENZO_REG streams are read for block sizes up to 6 (4-D) / 8 (3-D) / 32 (2-D) (got %d)", conf->blockSize);
     int kinds[3], n_kinds = 0;
     if (conf->lorenzo) kinds[n_kinds++] = 0;
     if (conf->lorenzo2) kinds[n_kinds++] = 1;
@@ -1271,13 +1272,15 @@ int stock_decompress_lorenzo_reg(HostSlot *s, const sz3hip_config *conf, int dat
     if (raw_len < 32 || raw_len > (uint64_t)conf->num * 16 + (1u << 22)) return fail(SZ3HIP_EFORMAT, "implausible payload length in the lossless block");
     std::vector<uint8_t> raw((size_t)raw_len + 8, 0);
     if (zs::decompress_frames(p, payload, raw.data(), (size_t)raw_len) != raw_len) return SZ3HIP_EZSTD;
-    uint64_t d3[3] = {1, 1, 1}, nb[3] = {1, 1, 1}, nblocks = 1;
-    for (int i = 0; i < N; i++) d3[3 - N + i] = conf->dims[i];
-    for (int i = 0; i < 3; i++) {
-        if (d3[i] >= 0xFFFFFFFFull) return fail(SZ3HIP_EUNSUPPORTED, "extent beyond 32 bits");
-        nb[i] = i < 3 - N ? 1 : (d3[i] + B - 1) / B;
-        nblocks *= nb[i];
+    // the array as (w, z, y, x), leading extents 1; d3 / nb = the three fast dimensions (what the 1-D ... 3-D kernels take), d4 / nb4 all four
+    uint64_t d4[4] = {1, 1, 1, 1}, nb4[4] = {1, 1, 1, 1}, nblocks = 1;
+    for (int i = 0; i < N; i++) d4[4 - N + i] = conf->dims[i];
+    for (int i = 0; i < 4; i++) {
+        if (d4[i] >= 0xFFFFFFFFull) return fail(SZ3HIP_EUNSUPPORTED, "extent beyond 32 bits");
+        nb4[i] = i < 4 - N ? 1 : (d4[i] + B - 1) / B;
+        nblocks *= nb4[i];
     }
+    const uint64_t *d3 = d4 + 1, *nb = nb4 + 1;
     if (nblocks > 0x7FFFFFF0ull) return fail(SZ3HIP_EUNSUPPORTED, "too many blocks");
     stock::LorenzoReg lr;
     if (!stock::parse_lorenzo_reg(raw.data(), (size_t)raw_len, tsize, conf->regression != 0, composed, nblocks, N, lr) || lr.n != conf->num)
@@ -1286,8 +1289,8 @@ int stock_decompress_lorenzo_reg(HostSlot *s, const sz3hip_config *conf, int dat
     std::vector<float> cf32;
     std::vector<double> cf64;
     bool not_reproduced = false;
-    const bool okc = cdt == SZ3HIP_FLOAT ? slr_coefficients<float>(conf, lr, kinds, n_kinds, composed, nblocks, nb, kind, cf32, not_reproduced)
-                                        : slr_coefficients<double>(conf, lr, kinds, n_kinds, composed, nblocks, nb, kind, cf64, not_reproduced);
+    const bool okc = cdt == SZ3HIP_FLOAT ? slr_coefficients<float>(conf, lr, kinds, n_kinds, composed, nblocks, nb4, kind, cf32, not_reproduced)
+                                        : slr_coefficients<double>(conf, lr, kinds, n_kinds, composed, nblocks, nb4, kind, cf64, not_reproduced);
     if (!okc && not_reproduced)
         return fail(SZ3HIP_EUNSUPPORTED, "stock ALGO_LORENZO_REG stream with regression alone and a block one element wide (2-D / 3-D): the reference's "
                                          "unpadded fallback reads are not reproduced");
@@ -1308,7 +1311,8 @@ int stock_decompress_lorenzo_reg(HostSlot *s, const sz3hip_config *conf, int dat
     ar.ask(&d_em, (size_t)n * 2 + 2048);
     ar.ask(&d_unpred, (size_t)lr.q.n_unpred * tsize + 8);
     ar.ask(&d_kind, (size_t)nblocks + 8);
-    ar.ask(&d_coef, (size_t)nblocks * 4 * tsize + 8);
+    const size_t CS = N == 4 ? 8 : 4;
+    ar.ask(&d_coef, (size_t)nblocks * CS * tsize + 8);
     ar.ask(&d_tile_cnt, (size_t)ntiles_z * 4 + 8);
     ar.ask(&d_tile_base, (size_t)(ntiles_z + 1) * 8);
     ar.ask(&d_bad, 64);
@@ -1327,7 +1331,7 @@ int stock_decompress_lorenzo_reg(HostSlot *s, const sz3hip_config *conf, int dat
     if (ar.commit(s)) return SZ3HIP_EHIP;
     HIPCHK(hipMemsetAsync(d_bad, 0, 64, s->stream));
     HIPCHK(hipMemcpyAsync(d_kind, kind.data(), (size_t)nblocks, hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(d_coef, cdt == SZ3HIP_FLOAT ? (const void *)cf32.data() : (const void *)cf64.data(), (size_t)nblocks * 4 * tsize, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(d_coef, cdt == SZ3HIP_FLOAT ? (const void *)cf32.data() : (const void *)cf64.data(), (size_t)nblocks * CS * tsize, hipMemcpyHostToDevice, s->stream));
     if (lr.q.n_unpred) HIPCHK(hipMemcpyAsync(d_unpred, lr.q.unpred, (size_t)lr.q.n_unpred * tsize, hipMemcpyHostToDevice, s->stream));
     std::vector<uint16_t> em_host;
     if (lr.tree.t[0]) {  // a single symbol: no bits at all (encoder/HuffmanEncoder.hpp:233-237)
@@ -1381,6 +1385,8 @@ int stock_decompress_lorenzo_reg(HostSlot *s, const sz3hip_config *conf, int dat
     }
     sp.B = B;
     sp.N = (uint32_t)N;
+    sp.dw = d4[0];
+    sp.nbw = (uint32_t)nb4[0];
     sp.eb = lr.q.eb;
     sp.radius = (uint32_t)lr.q.radius;
     sp.codes = d_em;

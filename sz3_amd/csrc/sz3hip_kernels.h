@@ -385,6 +385,8 @@ struct szk_slr_params {
     const uint64_t *tile_base;  // zero codes in front of every tile of 1024 codes
     void *out;
     uint32_t *bad;              // raised by a zero code beyond the list
+    uint64_t dw;                // 4-D arrays (N == 4, round 5): the slowest extent, d[] holds the other three; coef is then [blocks][8]
+    uint32_t nbw;               // ... and its blocks
 };
 int szk_launch_stock_lorenzo_reg(int dtype, const szk_slr_params *p, uint64_t n, uint32_t *d_tile_cnt, uint64_t *d_tile_base, hipStream_t s);
 // ... and the WRITE side (round 5, sz3hip_stock.hip k_slw_*; 2-D and 3-D arrays): a stream stock SZ3 decodes. The format leaves the choice of

@@ -655,6 +655,104 @@ __global__ __launch_bounds__(256) void k_slr_front(szk_slr_params p, uint32_t di
         out[((uint64_t)(oz + i0) * p.d[1] + (oy + i1)) * p.d[2] + (ox + i2)] = tl[at(i0 + hz, i1 + 2, i2 + 2)];
     }
 }
+// 4-D arrays (round 5): the same walk over four block indices — fronts bw + bz + by + bx, hyperplanes i0 + i1 + i2 + i3 inside a block,
+// one low halo layer (first-order Lorenzo: LorenzoPredictor.hpp:69-74, fifteen terms in the reference's order; the reference defines no
+// second-order member for N = 4 — its predict() returns 0 there, :92-94 — and a regression block has five coefficients, :86-88).
+template <typename T>
+__global__ __launch_bounds__(256) void k_slr_front4(szk_slr_params p, uint32_t diag) {
+    constexpr uint32_t MAXT = 9u * 9u * 9u * 9u;  // (B + 1)^4, B <= 8
+    extern __shared__ __align__(8) unsigned char s_raw[];
+    const int lane = lane_id();
+    const uint32_t B = p.B, te = B + 1;
+    T *tl = reinterpret_cast<T *>(s_raw) + (size_t)(threadIdx.x / WAVE) * te * te * te * te;
+    (void)MAXT;
+    const uint32_t cand = blockIdx.x * 4 + threadIdx.x / WAVE;  // (bw, bz, by); bx follows from the front
+    if (cand >= p.nbw * p.nb[0] * p.nb[1]) return;
+    const uint32_t by = cand % p.nb[1], bz = (cand / p.nb[1]) % p.nb[0], bw = cand / (p.nb[1] * p.nb[0]);
+    if (bw + bz + by > diag) return;
+    const uint32_t bx = diag - bw - bz - by;
+    if (bx >= p.nb[2]) return;
+    const uint32_t task = ((bw * p.nb[0] + bz) * p.nb[1] + by) * p.nb[2] + bx;
+    const uint32_t ow = bw * B, oz = bz * B, oy = by * B, ox = bx * B;
+    const uint32_t ew = min(B, (uint32_t)p.dw - ow), ez = min(B, (uint32_t)p.d[0] - oz), ey = min(B, (uint32_t)p.d[1] - oy), ex = min(B, (uint32_t)p.d[2] - ox);
+    const uint64_t vol3 = p.d[0] * p.d[1] * p.d[2];
+    const uint64_t coff = (uint64_t)ow * vol3 + (uint64_t)ew * ((uint64_t)oz * p.d[1] * p.d[2] + (uint64_t)ez * ((uint64_t)oy * p.d[2] + (uint64_t)ey * ox));
+    const uint32_t nown = ew * ez * ey * ex;
+    const uint32_t tw = ew + 1, tz = ez + 1, ty = ey + 1, tx = ex + 1;
+    auto at = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) -> uint32_t { return ((a * tz + b) * ty + c) * tx + d; };
+    T *out = reinterpret_cast<T *>(p.out);
+    for (uint32_t l = lane; l < tw * tz * ty * tx; l += WAVE) {  // the halo: finished values, zeros outside the array
+        const uint32_t d = l % tx, c = (l / tx) % ty, b = (l / (tx * ty)) % tz, a = l / (tx * ty * tz);
+        if (a >= 1 && b >= 1 && c >= 1 && d >= 1) continue;
+        const int64_t w = (int64_t)ow + a - 1, z = (int64_t)oz + b - 1, y = (int64_t)oy + c - 1, x = (int64_t)ox + d - 1;
+        tl[l] = (w >= 0 && z >= 0 && y >= 0 && x >= 0) ? out[(((uint64_t)w * p.d[0] + (uint64_t)z) * p.d[1] + (uint64_t)y) * p.d[2] + (uint64_t)x] : (T)0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t kind = p.kind[task];
+    auto split = [&](uint32_t t, uint32_t &i0, uint32_t &i1, uint32_t &i2, uint32_t &i3) {
+        i3 = t % ex;
+        i2 = (t / ex) % ey;
+        i1 = (t / (ex * ey)) % ez;
+        i0 = t / (ex * ey * ez);
+    };
+    if (kind == 2) {
+        const T *cf = reinterpret_cast<const T *>(p.coef) + (uint64_t)task * 8;
+        for (uint32_t t = lane; t < nown; t += WAVE) {
+            uint32_t i0, i1, i2, i3;
+            split(t, i0, i1, i2, i3);
+            T pr = (T)(cf[0] * (T)i0);
+            pr = (T)(pr + (T)(cf[1] * (T)i1));
+            pr = (T)(pr + (T)(cf[2] * (T)i2));
+            pr = (T)(pr + (T)(cf[3] * (T)i3));
+            pr = (T)(pr + cf[4]);
+            tl[at(i0 + 1, i1 + 1, i2 + 1, i3 + 1)] = slr_value<T>(p, pr, coff + t);
+        }
+    } else {
+        const uint32_t smax = (ew - 1) + (ez - 1) + (ey - 1) + (ex - 1);
+        for (uint32_t s = 0; s <= smax; s++) {
+            for (uint32_t t = lane; t < nown; t += WAVE) {
+                uint32_t i0, i1, i2, i3;
+                split(t, i0, i1, i2, i3);
+                if (i0 + i1 + i2 + i3 != s) continue;
+                const uint32_t a = i0 + 1, b = i1 + 1, c = i2 + 1, d = i3 + 1;
+                T pr = 0;
+                if (kind == 0) {
+                    // prev4(d, ds, t, k, j, i) = *(d - (t ds[2] + k ds[1] + j ds[0] + i)), ds = the strides slowest first: t steps along y, k
+                    // along z, j along w, i along x (LorenzoPredictor.hpp:69-74, 109-111)
+                    auto P = [&](int tt, int k, int j, int i) -> T { return tl[at(a - j, b - k, c - tt, d - i)]; };
+                    pr = (T)(P(0, 0, 0, 1) + P(0, 0, 1, 0));
+                    pr = (T)(pr - P(0, 0, 1, 1));
+                    pr = (T)(pr + P(0, 1, 0, 0));
+                    pr = (T)(pr - P(0, 1, 0, 1));
+                    pr = (T)(pr - P(0, 1, 1, 0));
+                    pr = (T)(pr + P(0, 1, 1, 1));
+                    pr = (T)(pr + P(1, 0, 0, 0));
+                    pr = (T)(pr - P(1, 0, 0, 1));
+                    pr = (T)(pr - P(1, 0, 1, 0));
+                    pr = (T)(pr + P(1, 0, 1, 1));
+                    pr = (T)(pr - P(1, 1, 0, 0));
+                    pr = (T)(pr + P(1, 1, 0, 1));
+                    pr = (T)(pr + P(1, 1, 1, 0));
+                    pr = (T)(pr - P(1, 1, 1, 1));
+                }  // (kind 1: the reference's second-order member predicts 0 for N = 4)
+                tl[at(a, b, c, d)] = slr_value<T>(p, pr, coff + t);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t t = lane; t < nown; t += WAVE) {
+        uint32_t i0, i1, i2, i3;
+        split(t, i0, i1, i2, i3);
+        out[(((uint64_t)(ow + i0) * p.d[0] + (oz + i1)) * p.d[1] + (oy + i2)) * p.d[2] + (ox + i3)] = tl[at(i0 + 1, i1 + 1, i2 + 1, i3 + 1)];
+    }
+}
 // 1-D: the chain. One workgroup of sixteen waves works through the array in rounds of sixteen UNITS (a unit: a block, or 256 elements
 // of a longer one). What does not depend on the chain is made by all waves first, a unit each: the quantizer's term 2 (code - radius) eb
 // in double, the unpredictable values of the zero codes (ordinals from the tile scan), a regression block's values outright. Then ONE
@@ -1156,6 +1254,20 @@ int szk_launch_stock_lorenzo_reg(int dtype, const szk_slr_params *p, uint64_t n,
     if (p->N == 1) {
         if (dtype == 0) hipLaunchKernelGGL(k_slr_chain<float>, dim3(1), dim3(1024), 0, s, *p);
         else hipLaunchKernelGGL(k_slr_chain<double>, dim3(1), dim3(1024), 0, s, *p);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    if (p->N == 4) {
+        const uint32_t te = p->B + 1;
+        const size_t lds = (size_t)4 * te * te * te * te * (dtype == 0 ? 4 : 8);
+        const uint32_t nd4 = p->nbw + p->nb[0] + p->nb[1] + p->nb[2] - 3;
+        const dim3 g4((p->nbw * p->nb[0] * p->nb[1] + 3) / 4), b4(256);
+        // (four waves' tiles of (B + 1)^4 values: 77 KB for f64 at B = 6 — beyond the 64 KB a launch gets without asking)
+        if (dtype == 0) (void)hipFuncSetAttribute((const void *)k_slr_front4<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else (void)hipFuncSetAttribute((const void *)k_slr_front4<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        for (uint32_t d = 0; d < nd4; d++) {
+            if (dtype == 0) hipLaunchKernelGGL(k_slr_front4<float>, g4, b4, lds, s, *p, d);
+            else hipLaunchKernelGGL(k_slr_front4<double>, g4, b4, lds, s, *p, d);
+        }
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     const uint32_t ndiag = p->nb[0] + p->nb[1] + p->nb[2] - 2;

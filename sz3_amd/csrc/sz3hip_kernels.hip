@@ -3400,9 +3400,14 @@ __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE]
         for (int h = 0; h < G / 2; h++) {
             if (BYTE) {  // code word and length come from separate tables: no shift / mask per symbol
                 const uint32_t b0 = c[G * k + 2 * h], b1 = c[G * k + 2 * h + 1];
+#if defined(LAB_PACK) && (LAB_PACK & 1)  // (lab, wrong results: no table lookups)
+                pc[h] = ((b0 & 15u) << 4) | (b1 & 15u);
+                pl[h] = 8;
+#else
                 const uint32_t l1 = s_len8[b1];
                 pc[h] = (s_enc[b0] << l1) | s_enc[b1];
                 pl[h] = (uint32_t)s_len8[b0] + l1;
+#endif
                 continue;
             }
             uint32_t e0 = enc_lookup2<WIN>(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h]);
@@ -3440,9 +3445,13 @@ __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE]
                 const uint64_t v = len ? joined << (64 - len) : 0ull;  // left-aligned
                 const uint32_t word = pos >> 5, sh = pos & 31;
                 const uint64_t t = v >> sh;
+#if defined(LAB_PACK) && (LAB_PACK & 2)  // (lab, wrong results: no emission into the stage)
+                if (t == 0x123456789ull) stage[word] = 1;
+#else
                 atomicOr(&stage[word], (uint32_t)(t >> 32));
                 atomicOr(&stage[word + 1], (uint32_t)t);
                 atomicOr(&stage[word + 2], (uint32_t)(((uint64_t)(uint32_t)v << 32) >> sh));
+#endif
                 pos += len;
             }
             return (total_bits + 31) >> 5;
@@ -3820,8 +3829,12 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         for (uint32_t i = 2 * lane; i < nwords + 2; i += 2 * WAVE) {  // copy out and re-zero the stage for the next chunk, two words per lane
             const uint2 wv = *reinterpret_cast<const uint2 *>(&stage[i]);
             *reinterpret_cast<uint2 *>(&stage[i]) = make_uint2(0u, 0u);
+#if defined(LAB_PACK) && (LAB_PACK & 4)  // (lab, wrong results: no stores of the bit stream)
+            if (wv.x == 0x12345678u && wv.y == 0x9abcdef0u) out[i] = 1;
+#else
             if (i < nwords) out[i] = __builtin_bswap32(wv.x);  // bytes in stream order (see sz3hip_format.h)
             if (i + 1 < nwords) out[i + 1] = __builtin_bswap32(wv.y);
+#endif
         }
         __builtin_amdgcn_wave_barrier();
         cur = nxt;

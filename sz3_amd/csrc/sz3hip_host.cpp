@@ -14,6 +14,7 @@
 // There is NO CPU implementation of the predictor/quantizer/Huffman stages in this library: without a HIP device every
 // entry point fails loudly.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <dlfcn.h>
 #include <math.h>
@@ -569,6 +570,35 @@ int job_stage1(SlabJob &j) {
 }
 
 // ---- stock SZ3 streams: ALGO_INTERP read and written; sz3hip_stock.hip / sz3hip_stock_host.cpp ----
+// A fresh output array is touched for the first time INSIDE the device-to-host copy: 131 072 page faults for a 512^3 f32 array, taken one
+// by one by the runtime's copy thread (14.6 GB/s against 40 into an array that was touched before, round 4). The pages are populated here
+// instead — madvise(MADV_POPULATE_WRITE), which maps them without writing to them, from four threads (more contend for the address space: 8 -> 21, 16 -> 18, 32 -> 16 GB/s against 24 with four, tools/host_dec_lab.py) — while the stream is unpacked,
+// copied to the device and decoded; the copy out waits for them. (No such kernel interface: nothing happens, the copy faults as before.)
+struct Prefault {
+    std::vector<std::thread> th;
+    void start(void *p, size_t bytes) {
+        const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)p + bytes) & ~(uintptr_t)4095;
+        if (bytes < (32u << 20) || e <= a || env_int("SZ3HIP_NO_PREFAULT", 0)) return;
+        const unsigned nt = (unsigned)std::max(1, std::min(64, env_int("SZ3HIP_PREFAULT_THREADS", 4)));
+        const size_t pages = (e - a) / 4096, per = (pages + nt - 1) / nt;
+        for (unsigned t = 0; t < nt; t++) {
+            const size_t p0 = (size_t)t * per, p1 = std::min(pages, p0 + per);
+            if (p0 >= p1) break;
+            th.emplace_back([=] { (void)madvise((void *)(a + p0 * 4096), (p1 - p0) * 4096, 23 /* MADV_POPULATE_WRITE */); });
+        }
+    }
+    void wait() {
+        for (auto &x : th) x.join();
+        th.clear();
+    }
+    ~Prefault() { wait(); }
+};
+static thread_local Prefault *t_prefault = nullptr;
+// the decoded array to the caller's memory (behind the population of its pages, when one is under way)
+static hipError_t d2h_out(void *dst, const void *src, size_t bytes) {
+    if (t_prefault) t_prefault->wait();
+    return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+}
 std::atomic<int> g_stock_format{-1};
 // the slot's payload buffer, carved up for the stock path's kernels: sizes are asked for first, then the buffer is grown once
 struct DevArena {
@@ -789,7 +819,7 @@ int stock_decompress_nopred(HostSlot *s, const sz3hip_config *conf, int dataType
     HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     if (bad) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (more zero codes than unpredictable values)");
-    HIPCHK(hipMemcpy(decData, s->dev_in, (size_t)conf->num * tsize, hipMemcpyDeviceToHost));
+    HIPCHK(d2h_out(decData, s->dev_in, (size_t)conf->num * tsize));
     return 0;
 }
 // ... and WRITTEN (sz3hip_set_stock_format + cmprAlgo ALGO_NOPRED)
@@ -1176,7 +1206,7 @@ int stock_decompress_interp(HostSlot *s, const sz3hip_config *conf, int dataType
     }
     rc = szi_stock_import(s->ctx, &sp, &g, d_blk, d_em, d_unpred, n_unpred, d_tile_cnt, d_tile_base, d_vidx, d_vval, d_bad, s->dev_in, s->stream);
     if (rc) return rc;
-    HIPCHK(hipMemcpy(decData, s->dev_in, (size_t)conf->num * tsize, hipMemcpyDeviceToHost));
+    HIPCHK(d2h_out(decData, s->dev_in, (size_t)conf->num * tsize));
     return 0;
 }
 
@@ -1402,7 +1432,7 @@ int stock_decompress_lorenzo_reg(HostSlot *s, const sz3hip_config *conf, int dat
     HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     if (bad) return fail(SZ3HIP_EFORMAT, "corrupt stock stream (more zero codes than unpredictable values)");
-    HIPCHK(hipMemcpy(decData, s->dev_in, (size_t)conf->num * tsize, hipMemcpyDeviceToHost));
+    HIPCHK(d2h_out(decData, s->dev_in, (size_t)conf->num * tsize));
     return 0;
 }
 
@@ -2036,13 +2066,13 @@ int decompress_blob(HostSlot *s, const sz3hip_config *conf, int dataType, const 
     if (rc) return rc;
     if (!is_int) {
         HIPCHK(hipStreamSynchronize(s->stream));
-        HIPCHK(hipMemcpy(decData, s->dev_in, raw_bytes, hipMemcpyDeviceToHost));  // (the runtime pins large pageable buffers
+        HIPCHK(d2h_out(decData, s->dev_in, raw_bytes));  // (the runtime pins large pageable buffers
                                                                                   // itself: a hand-made pinned pipeline was slower)
     } else {
         rc = szk_launch_f64_to_int(dataType, (const double *)s->dev_in, conf->num, s->dev_payload, s->stream);
         if (rc) return fail(SZ3HIP_EHIP, "integer narrowing kernel failed");
         HIPCHK(hipStreamSynchronize(s->stream));
-        HIPCHK(hipMemcpy(decData, s->dev_payload, raw_bytes, hipMemcpyDeviceToHost));
+        HIPCHK(d2h_out(decData, s->dev_payload, raw_bytes));
     }
     return 0;
 }
@@ -2119,8 +2149,13 @@ extern "C" int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *
     else some.lock();
     DeviceGuard guard;
     if (conf->openmp) return decompress_slabs(conf, dataType, p, (size_t)payload, decData);  // SZ_decompress_impl, SZImpl.hpp:22-32
+    Prefault pf;  // (the output array's pages, populated beside the work below)
+    pf.start(decData, (size_t)conf->num * dtype_size(dataType));
+    t_prefault = &pf;
     SlotLease lease(host_device(), dtype_compute(dataType));
-    return decompress_blob(lease.s, conf, dataType, p, (size_t)payload, decData);
+    const int rcd = decompress_blob(lease.s, conf, dataType, p, (size_t)payload, decData);
+    t_prefault = nullptr;
+    return rcd;
 }
 
 

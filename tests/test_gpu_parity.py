@@ -135,14 +135,17 @@ def test_dispatcher_policies_and_edge_cases():
     assert sz3_amd.lib().sz3hip_compress(C.byref(conf._c), 0, a.ctypes.data, out.ctypes.data, out.size) == 0
     assert b"not large enough" in sz3_amd.lib().sz3hip_last_error()
     # a stream of the CPU reference (ALGO_LORENZO_REG; round 4) is read — the reference's own values, bit for bit (tests/test_gpu_stock.py) —;
-    # what is not built (a 4-D one) is refused, not mis-decoded
+    # a 4-D one since round 5; what is not built (4-D blocks beyond 6^4) is refused, not mis-decoded
     from oracle_binding import oracle_decompress
     oblob = oracle_compress(a, make_config(a.shape, abs_eb=1e-3))
     got, _ = sz3_amd.decompress(oblob, np.float32, a.shape)
     assert np.array_equal(got, oracle_decompress(oblob, np.float32, a.shape)[0])
     a4 = np.arange(5 * 6 * 7 * 8, dtype=np.float32).reshape(5, 6, 7, 8) * 0.01
+    b4 = oracle_compress(a4, make_config(a4.shape, abs_eb=1e-3))
+    got4, _ = sz3_amd.decompress(b4, np.float32, a4.shape)
+    assert np.array_equal(got4, oracle_decompress(b4, np.float32, a4.shape)[0])
     with pytest.raises(sz3_amd.SZ3HipError):
-        sz3_amd.decompress(oracle_compress(a4, make_config(a4.shape, abs_eb=1e-3)), np.float32, a4.shape)
+        sz3_amd.decompress(oracle_compress(a4, make_config(a4.shape, abs_eb=1e-3, block_size=7)), np.float32, a4.shape)
 
 
 def test_sz3c_abi_roundtrip():

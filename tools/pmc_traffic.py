@@ -13,8 +13,9 @@ for ln in open(src):
             k, v = kv.split("=")
             vals.setdefault(name, {})[k] = float(v)
 # (kernel names are matched by prefix: template argument lists grow)
-keys = {"lorenzo_quant_hist": "k_lorenzo_quant_march3<float, 3, 4>", "chunk_bits": "k_chunk_bits2", "seg_chunks": "k_seg_chunks", "scan_groups": "k_scan_groups", "pack": "k_pack",
-        "decode_with_x_scan": "k_decode<4, true>", "scan_strided": "k_scan_strided_half<false, false>", "scan_strided_dequant": "k_scan_strided_half<true, false>"}
+keys = {"lorenzo_quant_hist": "k_lorenzo_quant_march3q<4>",  # (round 5: the 16-bit form; round 3-4: "k_lorenzo_quant_march3<float, 3, 4>")
+        "chunk_bits": "k_chunk_bits2", "seg_chunks": "k_seg_chunks", "scan_groups": "k_scan_groups", "pack": "k_pack",
+        "decode_with_x_scan": "k_decode<4, true", "scan_strided": "k_scan_strided_half<false, false>", "scan_strided_dequant": "k_scan_strided_half<true, false>"}
 out = {}
 for k, name in keys.items():
     v = next((vals[n] for n in sorted(vals) if n.startswith(name)), None)

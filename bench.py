@@ -519,9 +519,23 @@ def multi_gpu_extras(torch, sz3_amd, dev, local_rank, rank, world, comm, dist, o
 
     res = {}
     c4_shape = (12, 96, 120) if small else (128, 1024, 1024)
+    def agreed(ok):
+        # every rank reaches this point whatever happened to it before: a leg whose set-up failed anywhere is skipped everywhere
+        # (the timed part is full of collectives — a rank that is not there would leave the others waiting)
+        return red(1.0 if ok else 0.0, dist.ReduceOp.MIN) >= 1.0
+
     for name, field in (("C4a", "c4a"), ("C4b", "default")):
+        w, why = None, ""
         try:
             w = Workload(torch, sz3_amd, dev, local_rank, rank, c4_shape, "f64", "composed", 1e-6, comm=comm, dist=dist if comm is None else None, field=field)
+        except Exception as e:  # noqa: BLE001
+            why = repr(e)[:300]
+        if not agreed(w is not None):
+            res[name] = {"error": "set-up failed on a rank: " + (why or "another rank's")}
+            del w
+            torch.cuda.empty_cache()
+            continue
+        try:
             el, ps = timed(w, steps, 2)
             err, dec_ms = w.verify_and_time_decode(ps)
             el = red(el, dist.ReduceOp.MAX)
@@ -541,6 +555,8 @@ def multi_gpu_extras(torch, sz3_amd, dev, local_rank, rank, world, comm, dist, o
                                   "Lorenzo + regression per 6^3 block, abs errBound=1e-6, histogram all-reduce between the stages" % min(world, 8),
                         "fields": res, "scaling": "weak"}}
     # ---- C5 ----
+    c5 = None
+    why5 = ""
     try:
         nt_total, edge = (16, 40) if small else (100, 500)
         lo, hi = D.slab_bounds(nt_total, 8, rank % 8)
@@ -554,6 +570,17 @@ def multi_gpu_extras(torch, sz3_amd, dev, local_rank, rank, world, comm, dist, o
             hist = torch.zeros(65536, dtype=torch.int64, device=dev)
             dc.set_histogram(hist.data_ptr())
         mn, mx = dc.minmax(d_in.data_ptr(), n, stream)
+        cap = dc.payload_bound(n)
+        d_pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+        d_out = torch.empty_like(d_in)
+        c5 = True
+    except Exception as e:  # noqa: BLE001
+        why5 = repr(e)[:300]
+    if not agreed(c5 is not None):
+        out["C5_8slab"] = {"error": "set-up failed on a rank: " + (why5 or "another rank's")}
+        torch.cuda.empty_cache()
+        return out
+    try:
         if comm is not None:
             mns, mxs = comm.allreduce_minmax([mn], [mx], [stream])
             gmn, gmx = mns[0], mxs[0]
@@ -565,8 +592,6 @@ def multi_gpu_extras(torch, sz3_amd, dev, local_rank, rank, world, comm, dist, o
         conf.lorenzo, conf.lorenzo2, conf.regression = 1, 0, 0
         conf.errorBoundMode = sz3_amd.EB_ABS   # (REL resolved with the GLOBAL range, as SZ_compress_OMP does before it splits)
         conf.absErrorBound = eb
-        cap = dc.payload_bound(n)
-        d_pl = torch.empty(cap, dtype=torch.uint8, device=dev)
 
         def step():
             dc.stage1(conf, d_in.data_ptr(), stream)
@@ -587,7 +612,6 @@ def multi_gpu_extras(torch, sz3_amd, dev, local_rank, rank, world, comm, dist, o
             ps = step()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        d_out = torch.empty_like(d_in)
         dc.decompress(d_pl.data_ptr(), ps, d_out.data_ptr(), stream)
         torch.cuda.synchronize()
         err = 0.0

@@ -267,7 +267,8 @@ void sz3hip_debug_force_generic(int on);
  * 4194304 interpolation level kernels whatever the array's size (normally from 256 blocks up). The 3-D block decoder (blocks of
  * 6^3; the product path is ONE launch for the chain of fronts, k_blk_wave3, after a local pass straight from the codes): 16 the
  * local pass a wave per block from an expanded copy of the deltas, 32768 groups of 3 x 3 x 3 blocks in closed form with a launch
- * per front, 65536 round 3's groups of 2 x 2 x 2 blocks inverted by line scans, 8388608 a block per wave. The 2-D one (block edges
+ * per front (also what a one-launch decoder whose flag poll gave up falls back to), 8388608 a block per wave (65536 — round 3's groups
+ * of 2 x 2 x 2 blocks inverted by line scans — exists in -DSZ3HIP_LAB builds only since round 5; in the product library it takes the block-per-wave form). The 2-D one (block edges
  * up to 16, no second-order member; product: k_blkn_wave2, one launch): 65536 groups of 4 x 4 blocks with a launch per front,
  * 8388608 a block per wave.
  * Experiments with WRONG or slower results (tools/dec_lab.py): 524288 decoder without stores, 1048576 decoder with direct stores. */

@@ -1720,10 +1720,24 @@ __device__ __forceinline__ void narrow16_task(NarrowCtx<float> &c, const Lattice
     };
     int zz = z0 > 0 ? -1 : 0;
     const int zend = d2 - z0 < (uint32_t)MARCH_TZ ? (int)(d2 - z0) : MARCH_TZ;
+#if defined(LAB_Q16PF) && LAB_Q16PF == 1
+    // (lab: the next plane's rows are requested before the current plane is worked — two sets of row registers)
+    Q16Plane<TY> pb;
+    fetch(zz, pa);
+    for (;;) {
+        if (zz + 1 < zend) fetch(zz + 1, pb);
+        work(zz, pa);
+        if (++zz >= zend) break;
+        if (zz + 1 < zend) fetch(zz + 1, pa);
+        work(zz, pb);
+        if (++zz >= zend) break;
+    }
+#else
     for (; zz < zend; zz++) {
         fetch(zz, pa);
         work(zz, pa);
     }
+#endif
 }
 template <int TY>
 __device__ __forceinline__ void march_narrow16(const float *__restrict__ in, uint16_t *__restrict__ codes, const szk_k1_params &p, uint32_t ntasks,

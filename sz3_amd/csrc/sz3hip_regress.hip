@@ -1464,6 +1464,9 @@ __global__ __launch_bounds__(256) void k_blk_decode(const uint16_t *__restrict__
     }
 }
 
+// (Round 3's decoder — groups of 2 x 2 x 2 blocks inverted by line scans, a launch per front — was superseded twice (closed-form groups,
+// then the one-launch chain). It is kept for A/B builds only: -DSZ3HIP_LAB, tools/build_lab.sh; the product library does not carry it.)
+#ifdef SZ3HIP_LAB
 // the regression blocks' lattice values, all of them before the fronts start (no dependency: coefficients and codes are all they need)
 template <typename T, int CB>
 __global__ __launch_bounds__(256) void k_blk_pre3(const uint16_t *__restrict__ codes, void *d_out, szk_blk_params p, uint32_t nblocks,
@@ -1619,6 +1622,7 @@ __global__ __launch_bounds__(512) void k_blk_decode_g(const uint16_t *__restrict
         }
     }
 }
+#endif  // SZ3HIP_LAB
 
 // ---- round 4: a group decoded without recurrences on its critical path -------------------------------------------------------------
 // On the lattice a Lorenzo block is linear and exact (integers mod 2^32 / 2^64), so its inverse splits: with D = Dz Dy Dx the block's
@@ -5382,7 +5386,8 @@ static int blk_decompress_impl(int dtype, const uint16_t *codes, void *d_out, co
             else hipLaunchKernelGGL((k_blk_decode_gf<double, 6, 3>), dim3(npairs), dim3(512), 0, s, d_out, *p, d, gz_lo, npairs);
         }
     } else
-    if (p->B == 6 && !(dbg & 8388608)) {  // round 3's form (debug flag 65536): groups of 2 x 2 x 2 blocks, line scans (debug flag 8388608: a block per wave)
+#ifdef SZ3HIP_LAB
+    if (p->B == 6 && !(dbg & 8388608)) {  // round 3's form (lab builds, debug flag 65536): groups of 2 x 2 x 2 blocks, line scans (debug flag 8388608: a block per wave)
         const uint32_t ng0 = (p->nb[0] + 1) / 2, ng1 = (p->nb[1] + 1) / 2, ng2 = (p->nb[2] + 1) / 2;
         const uint32_t ngd = ng0 + ng1 + ng2 - 2;
         {
@@ -5400,7 +5405,9 @@ static int blk_decompress_impl(int dtype, const uint16_t *codes, void *d_out, co
             else
                 hipLaunchKernelGGL((k_blk_decode_g<double, 6>), dim3(npairs), dim3(512), 0, s, codes, p->qwork, d_out, *p, d, gz_lo, npairs, sc->rank, coef_by_rank);
         }
-    } else {
+    } else
+#endif
+    {
     const uint32_t ndiag = p->nb[0] + p->nb[1] + p->nb[2] - 2;
     for (uint32_t d = 0; d < ndiag; d++) {
         // blocks of the front: bz + by + bx = d; only the bz that can have a partner (by, bx) are enumerated

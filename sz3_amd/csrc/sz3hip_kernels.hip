@@ -3846,8 +3846,13 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
 #if defined(LAB_PACK) && (LAB_PACK & 4)  // (lab, wrong results: no stores of the bit stream)
             if (wv.x == 0x12345678u && wv.y == 0x9abcdef0u) out[i] = 1;
 #else
+#ifdef LAB_PACK_NT  // (lab: the bit stream with streaming stores)
+            if (i < nwords) __builtin_nontemporal_store(__builtin_bswap32(wv.x), &out[i]);
+            if (i + 1 < nwords) __builtin_nontemporal_store(__builtin_bswap32(wv.y), &out[i + 1]);
+#else
             if (i < nwords) out[i] = __builtin_bswap32(wv.x);  // bytes in stream order (see sz3hip_format.h)
             if (i + 1 < nwords) out[i + 1] = __builtin_bswap32(wv.y);
+#endif
 #endif
         }
         __builtin_amdgcn_wave_barrier();
@@ -4207,7 +4212,13 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
     bool held_any = false;
     auto flush1 = [&](uint32_t it, const uint4 &h) {
         const uint32_t idx = it * 64 + (uint32_t)lane_id(), c = idx / (NP * NR), j = idx % (NP * NR);
+#ifdef LAB_DEC_NT  // (lab: the decoder's values with streaming stores)
+        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+        const u4v hv = {h.x, h.y, h.z, h.w};
+        __builtin_nontemporal_store(hv, reinterpret_cast<u4v *>(wave_out + ((uint64_t)c * UNIT + held_i0) * ELT + j * 16));
+#else
         *reinterpret_cast<uint4 *>(wave_out + ((uint64_t)c * UNIT + held_i0) * ELT + j * 16) = h;
+#endif
     };
     auto coop_flush = [&]() {
         if (!held_any) return;
@@ -4872,10 +4883,10 @@ __device__ __forceinline__ void scan_strided_body(void *buf, uint64_t L, uint64_
         v2 += v1;
         v3 += v2;
         if (DEQUANT) {
-            po[(a + 0) * inner] = lat.dequant((Q)v0);
-            po[(a + 1) * inner] = lat.dequant((Q)v1);
-            po[(a + 2) * inner] = lat.dequant((Q)v2);
-            po[(a + 3) * inner] = lat.dequant((Q)v3);
+            __builtin_nontemporal_store(lat.dequant((Q)v0), &po[(a + 0) * inner]);  // (final values: streaming stores, see k_scan_strided_half)
+            __builtin_nontemporal_store(lat.dequant((Q)v1), &po[(a + 1) * inner]);
+            __builtin_nontemporal_store(lat.dequant((Q)v2), &po[(a + 2) * inner]);
+            __builtin_nontemporal_store(lat.dequant((Q)v3), &po[(a + 3) * inner]);
         } else {
             pp[(a + 0) * inner] = (Q)v0;
             pp[(a + 1) * inner] = (Q)v1;
@@ -4886,7 +4897,7 @@ __device__ __forceinline__ void scan_strided_body(void *buf, uint64_t L, uint64_
     }
     for (; a < a1; a++) {
         run += (UQ)pp[a * inner] + (carried ? (UQ)rc.at(carry, a) : (UQ)0);
-        if (DEQUANT) po[a * inner] = lat.dequant((Q)run);
+        if (DEQUANT) __builtin_nontemporal_store(lat.dequant((Q)run), &po[a * inner]);
         else pp[a * inner] = (Q)run;
     }
 }
@@ -4941,8 +4952,11 @@ __global__ __launch_bounds__(256) void k_scan_strided_half(const int16_t *__rest
             r0 += (int32_t)(int16_t)(w[k] & 0xFFFFu) + c;
             r1 += (int32_t)(int16_t)(w[k] >> 16) + c;
             if (DEQ) {
-                float2 v = make_float2(lat.dequant(r0), lat.dequant(r1));
-                *reinterpret_cast<float2 *>(reinterpret_cast<float *>(outp) + base + (a + k) * inner) = v;
+                // (round 5: the final values leave with streaming stores — nothing on the device reads them again, and 537 MB of them
+                // need not push the int16 values still to be read out of the caches: C2 decompress 574 -> 530 us)
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                const f2v v = {lat.dequant(r0), lat.dequant(r1)};
+                __builtin_nontemporal_store(v, reinterpret_cast<f2v *>(reinterpret_cast<float *>(outp) + base + (a + k) * inner));
             } else {
                 bad |= (uint32_t)(r0 != (int32_t)(int16_t)r0) | (uint32_t)(r1 != (int32_t)(int16_t)r1);
                 reinterpret_cast<uint32_t *>(reinterpret_cast<int16_t *>(outp) + base)[(a + k) * step] = ((uint32_t)r0 & 0xFFFFu) | ((uint32_t)r1 << 16);
@@ -4983,8 +4997,9 @@ __global__ __launch_bounds__(256) void k_scan_strided_half64(const int32_t *__re
             r0 += (int64_t)(int32_t)w[k].x + c;
             r1 += (int64_t)(int32_t)w[k].y + c;
             if (DEQ) {
-                const double2 v = make_double2(lat.dequant(r0), lat.dequant(r1));
-                *reinterpret_cast<double2 *>(reinterpret_cast<double *>(outp) + base + (a + k) * inner) = v;
+                typedef double d2v __attribute__((ext_vector_type(2)));
+                const d2v v = {lat.dequant(r0), lat.dequant(r1)};
+                __builtin_nontemporal_store(v, reinterpret_cast<d2v *>(reinterpret_cast<double *>(outp) + base + (a + k) * inner));
             } else {
                 bad |= (uint32_t)(r0 != (int64_t)(int32_t)r0) | (uint32_t)(r1 != (int64_t)(int32_t)r1);
                 reinterpret_cast<uint2 *>(reinterpret_cast<int32_t *>(outp) + base)[(a + k) * step] = make_uint2((uint32_t)r0, (uint32_t)r1);

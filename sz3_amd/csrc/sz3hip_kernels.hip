@@ -1598,7 +1598,15 @@ __device__ __forceinline__ void narrow16_task(NarrowCtx<float> &c, const Lattice
             R.rok[r] = gy < d1;
             if (R.rok[r]) {
                 const float *row = src + (uint64_t)gy * d0;
+#ifdef LAB_Q16_NTL  // (lab: streaming loads of the rows)
+                {
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    const f4v q = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(row + lane_off));
+                    R.rq[r] = make_float4(q.x, q.y, q.z, q.w);
+                }
+#else
                 R.rq[r] = *reinterpret_cast<const float4 *>(row + lane_off);
+#endif
                 if (has_left) R.rl[r] = row[x0 - 1];
             }
         }
@@ -3161,7 +3169,13 @@ struct CodeRegs {
 };
 __device__ __forceinline__ void fetch_codes(const uint16_t *__restrict__ codes, uint64_t base, bool narrow, CodeRegs &r) {
     if (narrow) {
+#ifdef LAB_PACK_NTL  // (lab: the codes are read once — streaming loads)
+        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+        const u4v q = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(reinterpret_cast<const uint8_t *>(codes) + base));
+        r.a = make_uint4(q.x, q.y, q.z, q.w);
+#else
         r.a = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(codes) + base);
+#endif
     } else {
         const uint4 *v = reinterpret_cast<const uint4 *>(codes + base);
         r.a = v[0];

@@ -255,6 +255,7 @@ int sz3hip_debug_decode_info(sz3hip_ctx *ctx, uint32_t *out4);
 /* test hook: non-zero routes every shape through the generic (any-shape) stage-1 kernel instead of the tuned one */
 void sz3hip_debug_force_generic(int on);
 /* development switches (bit mask, process-wide; 0 = product behaviour). They force one of two equivalent paths, results unchanged (tests compare them):
+ * 1 the wide code book compacts the histogram inside its own workgroup (round 5's default: k_cb_compact over the whole chip in front of it),
  * 2 Lorenzo decoder with the multi-symbol lookup table for small code books (round 5: up to three code words per 12-bit window; same output,
  * measured slower than the one-symbol table in its first form: opt-in),
  * 4 the one-launch block decoders' retry through the launch-per-front decoders, taken as if a flag poll had given up,

@@ -1537,7 +1537,8 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
         // the code-book form launched alone met the other form's alphabet (the data changed character since the previous
         // call): stage 2 once more with both forms; histogram, range words and outlier lists are as stage 1 left them
         ctx->cb_hint = -1;
-        HIPCHK(hipMemsetAsync(ctx->d_counters + 7, 0, 8, s));
+        HIPCHK(hipMemsetAsync(ctx->d_counters + 7, 0, 24, s));  // the flag AND the range words (k_hist_range adds to what it finds: the count doubled, round 5)
+        ctx->range_ready = false;
         int rc2 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s, S2_CLASSIC);
         if (rc2) return rc2;
         if (int rw = wait_published(ctx)) return rw;

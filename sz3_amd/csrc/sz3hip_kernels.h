@@ -113,6 +113,7 @@ struct szk_cb_params {
     int range_ready;   // the range words are already filled (stage 1 kept them with the histogram): no k_hist_range launch
     int part_hint;     // -1: both forms of k_codebook are launched; 0 / 1: only that form (small / wide alphabets), see mispredict
     uint32_t *mispredict;  // set to 1 by a form launched alone that meets the other form's alphabet
+    int keys_ready;        // (set by the launcher) keys[] / syms[] were compacted by k_cb_compact in front of this launch, ifreq[0..63] holds its sums
     int skip_sort;         // the launch's two list-sorting workgroups return at once (the lists are sorted elsewhere: speculative stage 2)
 };
 #define SZK_CB_SMALL_SYMS 256  // alphabets up to this size take k_codebook<0>, wider ones <1>

@@ -2455,9 +2455,13 @@ __device__ void cb_assign_codes(const uint16_t *len_of, const uint16_t *syms, ui
 #define CB_CLASS_MIN 4096u
 #define CB_CLASS_KEEP 3072u    // first choice: everything after it runs on one 4096-key LDS tile
 #define CB_CLASS_KEEP2 12288u  // second choice when the first would put too many occurrences into the rare class
+// pre (round 5): the compaction was made by k_cb_compact over the whole chip in front of this launch — keys[] / syms[] hold the
+// non-empty bins in symbol order, ifreq[0 .. CBC_BLOCKS) the workgroups' sums of counts (one workgroup reading the 48 183-bin range of
+// C3 twice was 46 of the wide book's 164 us: the rate ONE compute unit reads memory at)
+#define CBC_BLOCKS 64u
 template <bool ALLOW_CLS>
 __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_params &p, uint8_t *pool, uint32_t lo,
-                              uint32_t range, uint32_t *s_cnt, uint32_t *s_first, uint32_t *s_misc) {
+                              uint32_t range, uint32_t *s_cnt, uint32_t *s_first, uint32_t *s_misc, bool pre = false) {
     const uint32_t t = threadIdx.x, NT = blockDim.x;
     __shared__ uint32_t s_wt[CB_LAUNCH / WAVE];
     __shared__ unsigned long long s_total;
@@ -2468,8 +2472,12 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
     const uint32_t b0 = wv_id * seg < range ? wv_id * seg : range, b1 = b0 + seg < range ? b0 + seg : range;
     uint32_t cnt = 0;
     uint64_t fsum = 0;
+    if (pre) {
+        if (t < CBC_BLOCKS) fsum = p.ifreq[t];
+        if (wv_id == 0 && lane == 0) cnt = (uint32_t)p.ifreq[CBC_BLOCKS];  // (the number of keys, as k_cb_compact counted them)
+    }
     // (three 64-bin groups per step, their loads in flight together: one per step is a chain of dependent L2 round trips)
-    for (uint32_t i0 = b0; i0 < b1; i0 += 3 * WAVE) {
+    for (uint32_t i0 = b0; i0 < b1 && !pre; i0 += 3 * WAVE) {
         const uint32_t ia = i0 + lane, ib = ia + WAVE, ic = ib + WAVE;
         uint64_t fa = hist[lo + (ia < b1 ? ia : b1 - 1)], fb = hist[lo + (ib < b1 ? ib : b1 - 1)], fc = hist[lo + (ic < b1 ? ic : b1 - 1)];
         fa = ia < b1 ? fa : 0ull;
@@ -2491,7 +2499,7 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
     }
     // (four groups' loads in flight, like the counting pass: one load per step was 47 dependent L2 round trips per wave at C3 —
     // 51 of the kernel's 174 us)
-    for (uint32_t i0 = b0; i0 < b1; i0 += 4 * WAVE) {
+    for (uint32_t i0 = b0; i0 < b1 && !pre; i0 += 4 * WAVE) {
         uint64_t f4[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {  // (clamped, never conditional: a load under a branch is waited for inside it)
@@ -2963,6 +2971,48 @@ __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params 
     }
 }
 
+// The wide code book's compaction over the whole chip (round 5): workgroup w owns bins [1024 w, 1024 (w + 1)); its keys' place is the
+// number of non-empty bins in front of its slice, which it counts itself (up to 63 coalesced loads per thread, all in flight: the
+// histogram is 512 KB in the L2s) — no scan across workgroups, no second launch. keys[] = (count << 16) | symbol and syms[] in symbol
+// order, ifreq[w] = the slice's sum of counts, ifreq[64] = the number of keys (the range words' count is not used for it: a repeated
+// stage 2 runs k_hist_range over words that already hold the first run's).
+__global__ __launch_bounds__(1024) void k_cb_compact(const uint64_t *__restrict__ hist, uint64_t *__restrict__ keys, uint16_t *__restrict__ syms,
+                                                     uint64_t *__restrict__ part) {
+    __shared__ uint32_t s_w[16], s_before;
+    __shared__ unsigned long long s_sum;
+    const uint32_t t = threadIdx.x, lane = lane_id(), wv = t / WAVE, w = blockIdx.x;
+    if (t == 0) {
+        s_before = 0;
+        s_sum = 0;
+    }
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t b = 0; b < w; b++) before += hist[b * 1024u + t] != 0 ? 1u : 0u;
+    before = wave_sum(before);
+    if (lane == 0 && before) atomicAdd(&s_before, before);
+    const uint32_t bin = w * 1024u + t;
+    const uint64_t f = hist[bin];
+    const unsigned long long bal = __ballot(f != 0);
+    if (lane == 0) s_w[wv] = (uint32_t)__popcll(bal);
+    const uint64_t fs = wave_sum(f);
+    if (lane == 0 && fs) atomicAdd(&s_sum, (unsigned long long)fs);
+    __syncthreads();
+    uint32_t pos = s_before;
+    for (uint32_t k = 0; k < wv; k++) pos += s_w[k];
+    if (f) {
+        const uint32_t at = pos + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        keys[at] = (f << 16) | bin;
+        syms[at] = (uint16_t)bin;
+    }
+    if (t == 0) {
+        part[w] = s_sum;
+        if (w == gridDim.x - 1) {  // the last slice's place + its own keys = all of them
+            uint32_t m = s_before;
+            for (uint32_t k = 0; k < 16; k++) m += s_w[k];
+            part[gridDim.x] = m;
+        }
+    }
+}
 // PART 0: alphabets up to CB_SMALL_SYMS symbols + the outlier-list sorts; PART 1: wider alphabets. Which one applies is
 // known only on the device (k_hist_range), so both are launched and the other returns at once: the small path keeps its
 // own register allocation and instruction footprint (sharing one kernel with the wide path cost it 10 us of its 40).
@@ -3035,7 +3085,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     }
     __syncthreads();
     if constexpr (PART == 1) {
-        codebook_wide<true>(hist, p, s_pool, lo, range, s_cnt, s_first, s_misc);
+        codebook_wide<true>(hist, p, s_pool, lo, range, s_cnt, s_first, s_misc, p.keys_ready != 0 && p.n_books <= 1);
         return;
     }
     cb_small<CAP>(hist, p, s_pool, lo, range, s_wtot, s_over, s_first, s_cnt, s_misc, s_total, fill);
@@ -5391,6 +5441,9 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
     if (!p->range_ready) hipLaunchKernelGGL(k_hist_range, dim3(SZH_HIST_BINS / 256, nb), dim3(256), 0, s, d_hist, q.range);
     // which of the two forms applies is known on the device only; a context that remembers the previous call's alphabet
     // launches that form alone (solo): the kernel raises `mispredict` when it is the wrong one and the host repeats stage 2
+    // (a single book that may be a wide one: its compaction over the whole chip first, sz3hip_debug_flags(1): inside the book's workgroup as before)
+    q.keys_ready = nb == 1 && p->part_hint != 0 && !(szk_dbg_flags & 1) ? 1 : 0;
+    if (q.keys_ready) hipLaunchKernelGGL(k_cb_compact, dim3(CBC_BLOCKS), dim3(1024), 0, s, d_hist, q.keys, q.syms, q.ifreq);
     if (p->part_hint != 1) hipLaunchKernelGGL(k_codebook<0>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
     if (p->part_hint != 0) hipLaunchKernelGGL(k_codebook<1>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
     SZK_CHECK_LAUNCH();

@@ -498,7 +498,10 @@ __global__ __launch_bounds__(256, (NDIM == 3 ? 3 : 2)) void k_lorenzo_quant_v4(c
                 const bool ctr = code[i] == (uint32_t)radius;
                 center_count += ctr;
                 slow |= !inr | !inwin;
-                if (!(p.dbg & 1)) atomicAdd(&myh[(ctr | !inwin) ? dummy_bin : bin], 1u);
+#ifdef LAB_ABLATE  // (lab builds: bit 1 of the debug flags switches the histogram off; in the product library the bit belongs to the code book)
+                if (!(p.dbg & 1))
+#endif
+                atomicAdd(&myh[(ctr | !inwin) ? dummy_bin : bin], 1u);
             }
             const uint32_t off = (uint32_t)lz * plane + (uint32_t)ly * d0 + 4u * lx4;
             uint2 pk;

@@ -871,3 +871,38 @@ def test_multi_symbol_decoder_matches_the_one_symbol_decoder(shape, eb):
     assert np.array_equal(outs[0], outs[1], equal_nan=True) and np.array_equal(outs[0], outs[2], equal_nan=True)
     fin = np.isfinite(a)
     assert float(np.abs(outs[0][fin].astype(np.float64) - a[fin].astype(np.float64)).max()) <= eb
+
+
+def test_wide_code_book_with_and_without_the_compaction_launch():
+    """Round 5: the wide code book's keys are compacted by k_cb_compact over the whole chip in front of the book's launch; debug flag 1
+    keeps the compaction inside the book's workgroup. Same book, same payload — on an interpolation stream (thousands of symbols, the
+    two-class construction), on a rough Lorenzo stream, and across the repeat of stage 2 that a mispredicted book form causes."""
+    dev = torch.device("cuda:0")
+    L = sz3_amd.lib()
+    a = field3d((96, 96, 96), seed=4)
+    rough = (a + np.random.default_rng(2).normal(0, 0.2, a.shape)).astype(np.float32)
+    cases = [(a, sz3_amd.ALGO_INTERP, 1e-5), (rough, sz3_amd.ALGO_LORENZO_REG, 1e-3), (a, sz3_amd.ALGO_INTERP, 1e-2)]
+    outs = {}
+    for flag in (0, 1):
+        dc = sz3_amd.DeviceCompressor(a.size, np.float32)   # one context through all cases: small and wide books alternate (mispredicted forms)
+        dc.set_deterministic(True)
+        cap = dc.payload_bound(a.size, worst_case=True)
+        pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+        L.sz3hip_debug_flags(flag)
+        try:
+            for k, (arr, algo, eb) in enumerate(cases + cases[:1]):
+                conf = sz3_amd.Config(*arr.shape)
+                conf.cmprAlgo = algo
+                conf.regression = 0
+                conf.absErrorBound = eb
+                t = torch.from_numpy(arr).to(dev)
+                size = dc.compress(conf, t.data_ptr(), pl.data_ptr(), cap, 0)
+                outs[(flag, k)] = pl[:size].cpu().numpy().tobytes()
+                o = torch.empty_like(t)
+                dc.decompress(pl.data_ptr(), size, o.data_ptr(), 0)
+                torch.cuda.synchronize()
+                assert float((o.double() - t.double()).abs().max()) <= eb
+        finally:
+            L.sz3hip_debug_flags(0)
+    for k in range(4):
+        assert outs[(0, k)] == outs[(1, k)], "case %d: payloads differ" % k

@@ -92,6 +92,7 @@ struct szk_cb_info {
     uint32_t n_symbols, max_len, sym_min, sym_count;
     uint32_t win_lo, reserved;  // first symbol of the packers' LDS window of the encode table
     uint64_t ts[12];  // phase timestamps (wall_clock64, 100 MHz) for tools/cb_lab.py
+    uint32_t first_code[SZH_MAX_LEN + 2];  // (round 5) first code word of every length: what k_cb_assign needs of the book's workgroup (reserved == 0x5A5A while the code words are its to make)
 };
 struct szk_cb_params {
     uint32_t *enc;   // [65536] (code << 5) | len
@@ -113,6 +114,7 @@ struct szk_cb_params {
     int range_ready;   // the range words are already filled (stage 1 kept them with the histogram): no k_hist_range launch
     int part_hint;     // -1: both forms of k_codebook are launched; 0 / 1: only that form (small / wide alphabets), see mispredict
     uint32_t *mispredict;  // set to 1 by a form launched alone that meets the other form's alphabet
+    int assign_later;      // (set by the launcher) the wide book leaves the code words to k_cb_assign behind its launch (info->first_code, depth[] = the lengths)
     int keys_ready;        // (set by the launcher) keys[] / syms[] were compacted by k_cb_compact in front of this launch, ifreq[0..63] holds its sums
     int skip_sort;         // the launch's two list-sorting workgroups return at once (the lists are sorted elsewhere: speculative stage 2)
 };

@@ -2462,6 +2462,7 @@ __device__ void cb_assign_codes(const uint16_t *len_of, const uint16_t *syms, ui
 // non-empty bins in symbol order, ifreq[0 .. CBC_BLOCKS) the workgroups' sums of counts (one workgroup reading the 48 183-bin range of
 // C3 twice was 46 of the wide book's 164 us: the rate ONE compute unit reads memory at)
 #define CBC_BLOCKS 64u
+#define CB_ASSIGN_PENDING 0x5A5Au  // szk_cb_info::reserved: the wide book left its code words to k_cb_assign
 template <bool ALLOW_CLS>
 __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_params &p, uint8_t *pool, uint32_t lo,
                               uint32_t range, uint32_t *s_cnt, uint32_t *s_first, uint32_t *s_misc, bool pre = false) {
@@ -2755,7 +2756,13 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
     }
     __syncthreads();
     if (t == 0) p.info->ts[7] = wall_clock64();
-    cb_assign_codes(aux, p.syms, m, s_first, reinterpret_cast<uint16_t *>(pool), p.enc, NT);
+    // the code words: by k_cb_assign over the whole chip behind this launch (round 5; p.assign_later), else here
+    const bool defer = p.assign_later != 0 && p.n_books <= 1;
+    if (defer) {
+        if (t <= SZH_MAX_LEN) p.info->first_code[t] = t >= 1 && t <= L ? s_first[t] : 0u;
+    } else {
+        cb_assign_codes(aux, p.syms, m, s_first, reinterpret_cast<uint16_t *>(pool), p.enc, NT);
+    }
     uint32_t max_len = 0;
     for (uint32_t l = 1; l <= L; l++)
         if (s_cnt[l]) max_len = l;
@@ -2771,6 +2778,7 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
         p.info->sym_min = lo;
         p.info->sym_count = range;
         p.info->win_lo = wl;
+        p.info->reserved = defer ? CB_ASSIGN_PENDING : 0u;
     }
 }
 
@@ -2971,6 +2979,7 @@ __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params 
         p.info->sym_min = lo;
         p.info->sym_count = range;
         p.info->win_lo = wl;
+        p.info->reserved = 0;
     }
 }
 
@@ -3016,6 +3025,70 @@ __global__ __launch_bounds__(1024) void k_cb_compact(const uint64_t *__restrict_
         }
     }
 }
+// The wide code book's code words over the whole chip (round 5; cb_assign_codes with the symbols cut into gridDim.x slices): canonical
+// codes in (length, symbol) order — a symbol's code word is its length's first code word + the number of symbols of that length in
+// front of it. A workgroup counts the lengths in front of its slice itself (len_of is at most 128 KB, in the L2s), then works its
+// slice like cb_assign_codes: a contiguous run per thread, per-(length, thread) counts scanned along the threads by a wave per length.
+__global__ __launch_bounds__(1024) void k_cb_assign(const uint16_t *__restrict__ len_of, const uint16_t *__restrict__ syms, const szk_cb_info *__restrict__ info,
+                                                    uint32_t *__restrict__ enc) {
+    constexpr uint32_t NT = 1024;
+    __shared__ uint16_t cnt_tbl[(SZH_MAX_LEN + 1) * NT];
+    __shared__ uint32_t s_base[SZH_MAX_LEN + 2], s_first[SZH_MAX_LEN + 2];
+    if (info->reserved != CB_ASSIGN_PENDING) return;  // (the book was built by another form, or not at all)
+    const uint32_t t = threadIdx.x, lane = lane_id(), wv = t / WAVE;
+    const uint32_t m = info->n_symbols;
+    const uint32_t per_wg = (m + gridDim.x - 1) / gridDim.x;
+    const uint32_t q_lo = blockIdx.x * per_wg < m ? blockIdx.x * per_wg : m, q_hi = q_lo + per_wg < m ? q_lo + per_wg : m;
+    if (t <= SZH_MAX_LEN) {
+        s_first[t] = info->first_code[t];
+        s_base[t] = 0;
+    }
+    for (uint32_t l = 0; l <= SZH_MAX_LEN; l++) cnt_tbl[l * NT + t] = 0;
+    __syncthreads();
+    // the lengths in front of the slice (a thread's counts are its own column: no conflicts; at most 64 per thread)
+    for (uint32_t qb = t; qb < q_lo; qb += 8 * NT) {
+        uint16_t l8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) l8[k] = len_of[qb + k * NT < q_lo ? qb + k * NT : q_lo - 1];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (qb + k * NT < q_lo && l8[k] <= SZH_MAX_LEN) cnt_tbl[(uint32_t)l8[k] * NT + t]++;
+    }
+    __syncthreads();
+    for (uint32_t l = 1 + wv; l <= SZH_MAX_LEN; l += NT / WAVE) {
+        uint32_t sum = 0;
+        for (uint32_t c0 = 0; c0 < NT; c0 += WAVE) sum += cnt_tbl[l * NT + c0 + lane];
+        sum = wave_sum(sum);
+        if (lane == 0) s_base[l] = sum;
+    }
+    __syncthreads();
+    for (uint32_t l = 0; l <= SZH_MAX_LEN; l++) cnt_tbl[l * NT + t] = 0;
+    __syncthreads();
+    const uint32_t n_own = q_hi - q_lo, per = (n_own + NT - 1) / NT;
+    const uint32_t r0 = q_lo + (t * per < n_own ? t * per : n_own), r1 = r0 + per < q_hi ? r0 + per : q_hi;
+    for (uint32_t q = r0; q < r1; q++) {
+        const uint32_t l = len_of[q];
+        if (l <= SZH_MAX_LEN) cnt_tbl[l * NT + t]++;
+    }
+    __syncthreads();
+    for (uint32_t l = 1 + wv; l <= SZH_MAX_LEN; l += NT / WAVE) {
+        uint32_t carry = 0;
+        for (uint32_t c0 = 0; c0 < NT; c0 += WAVE) {
+            const uint32_t v = cnt_tbl[l * NT + c0 + lane];
+            const uint32_t incl = wave_incl_scan(v);
+            cnt_tbl[l * NT + c0 + lane] = (uint16_t)(carry + incl - v);
+            carry += __shfl(incl, WAVE - 1, WAVE);
+        }
+    }
+    __syncthreads();
+    for (uint32_t q = r0; q < r1; q++) {
+        const uint32_t l = len_of[q];
+        if (l == 0 || l > SZH_MAX_LEN) continue;
+        const uint32_t rank = s_base[l] + cnt_tbl[l * NT + t]++;
+        enc[syms[q]] = ((s_first[l] + rank) << 5) | l;
+    }
+}
+
 // PART 0: alphabets up to CB_SMALL_SYMS symbols + the outlier-list sorts; PART 1: wider alphabets. Which one applies is
 // known only on the device (k_hist_range), so both are launched and the other returns at once: the small path keeps its
 // own register allocation and instruction footprint (sharing one kernel with the wide path cost it 10 us of its 40).
@@ -3060,6 +3133,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     const uint32_t n_nonzero = p.range[2];
     if ((PART == 1) != (n_nonzero > CB_SMALL_SYMS)) {  // the other form's case
         if (p.part_hint >= 0 && p.mispredict && threadIdx.x == 0) *p.mispredict = 1u;  // launched alone: the host repeats stage 2 with both
+        if (PART == 1 && threadIdx.x == 0) p.info->reserved = 0;  // (nothing for k_cb_assign behind this launch)
         return;
     }
     if (n_nonzero == 0) {
@@ -3069,6 +3143,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
             p.info->sym_min = 0;
             p.info->sym_count = 0;
             p.info->win_lo = 0;
+            p.info->reserved = 0;
         }
         return;
     }
@@ -3725,6 +3800,7 @@ __device__ void role_book(const szk_role_params &rp, szk_state *state, uint8_t *
             p.info->sym_min = 0;
             p.info->sym_count = 0;
             p.info->win_lo = 0;
+            p.info->reserved = 0;
         }
         built = true;
     } else {
@@ -5448,7 +5524,9 @@ int szk_launch_codebook(const uint64_t *d_hist, const szk_cb_params *p, hipStrea
     q.keys_ready = nb == 1 && p->part_hint != 0 && !(szk_dbg_flags & 1) ? 1 : 0;
     if (q.keys_ready) hipLaunchKernelGGL(k_cb_compact, dim3(CBC_BLOCKS), dim3(1024), 0, s, d_hist, q.keys, q.syms, q.ifreq);
     if (p->part_hint != 1) hipLaunchKernelGGL(k_codebook<0>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
+    q.assign_later = q.keys_ready;  // (the same cases: a single book that may be a wide one)
     if (p->part_hint != 0) hipLaunchKernelGGL(k_codebook<1>, dim3(nb == 1 ? 3 : nb), dim3(CB_LAUNCH), 0, s, d_hist, q);
+    if (p->part_hint != 0 && q.assign_later) hipLaunchKernelGGL(k_cb_assign, dim3(16), dim3(1024), 0, s, (const uint16_t *)q.depth, (const uint16_t *)q.syms, (const szk_cb_info *)q.info, q.enc);
     SZK_CHECK_LAUNCH();
     return 0;
 }

@@ -761,8 +761,12 @@ __global__ __launch_bounds__(256) void k_blk_rows(const T *__restrict__ in, uint
         const uint32_t bx = xc / B, ox = bx * B, ex = min(B, (uint32_t)d2 - ox);
         // the predictor of the four blocks this lane's values come from: its own, the one above (by - 1), behind (bz - 1), both
         const uint32_t tk = (bz * nb1 + by) * nb2;
-        const bool reg_own = xin && p.sel[tk + bx] == 2, reg_up = xin && by && p.sel[tk - nb2 + bx] == 2,
-                   reg_back = xin && bz && p.sel[tk - nb1 * nb2 + bx] == 2, reg_bu = xin && by && bz && p.sel[tk - nb1 * nb2 - nb2 + bx] == 2;
+        // (four unconditional loads, all in flight — behind their conditions each was waited for where it stood; a block that does not
+        // exist reads the lane's own block's byte)
+        const uint32_t up = by ? nb2 : 0u, back = bz ? nb1 * nb2 : 0u;
+        const uint8_t s_own = p.sel[tk + bx], s_up = p.sel[tk - up + bx], s_back = p.sel[tk - back + bx], s_bu = p.sel[tk - back - up + bx];
+        const bool reg_own = xin && s_own == 2, reg_up = xin && by && s_up == 2, reg_back = xin && bz && s_back == 2,
+                   reg_bu = xin && by && bz && s_bu == 2;
         const bool any_reg = __ballot(reg_own || reg_up || reg_back || reg_bu) != 0;
         const bool act = xok && !reg_own;
         if (threadIdx.x < BPC) s_reg[threadIdx.x] = 0;
@@ -788,6 +792,20 @@ __global__ __launch_bounds__(256) void k_blk_rows(const T *__restrict__ in, uint
             T raw[MJ];
 #pragma unroll
             for (int j = 0; j < MJ; j++) raw[j] = in[pb + rowoff[j] + xc];  // the plane's rows oy - 1 .. oy + ey - 1: every load first
+            // (round 5) ... the lattice values the fit pass stored for regression blocks among them, lanes of such blocks only: asked for where
+            // they were used, behind a ballot each, they were 49 exposed memory latencies per task — 375 of the pass's 780 us at C4a's slab
+            UQ qreg[MJ];
+            bool isreg[MJ];
+#pragma unroll
+            for (int j = 0; j < MJ; j++) {
+                isreg[j] = any_reg && zin && rowin[j] && (kz == 0 ? (j == 0 ? reg_bu : reg_back) : (j == 0 ? reg_up : reg_own));
+                qreg[j] = 0;
+            }
+            if (any_reg) {  // (wave-uniform; every lane loads — the lanes of other blocks the array's first word, one cache line per wave:
+                            // loads behind per-lane conditions came out of the compiler with a wait for everything in flight after each)
+#pragma unroll
+                for (int j = 0; j < MJ; j++) qreg[j] = (UQ)qwork[isreg[j] ? pb + rowoff[j] + xc : 0];
+            }
             UQ D[MJ];
             uint32_t badmask = 0, outmask = 0;
             UQ deltas[MJ];
@@ -797,10 +815,7 @@ __global__ __launch_bounds__(256) void k_blk_rows(const T *__restrict__ in, uint
                 bool bad;
                 const Q q = lat.quant(raw[j], bad);
                 UQ v = bad ? (UQ)0 : (UQ)q;
-                if (any_reg) {  // (a regression block's elements: the lattice values the fit pass stored)
-                    const bool isreg = kz == 0 ? (j == 0 ? reg_bu : reg_back) : (j == 0 ? reg_up : reg_own);
-                    if (__ballot(rin && isreg)) v = (rin && isreg) ? (UQ)qwork[pb + rowoff[j] + xc] : v;
-                }
+                v = isreg[j] ? qreg[j] : v;  // (a regression block's elements)
                 v = rin ? v : (UQ)0;
                 const UQ vleft = (UQ)dpp_shr1_z((Q)v);  // the previous lane holds the column on the left (the halo lane: nothing, zero)
                 D[j] = v - vleft;
@@ -815,7 +830,11 @@ __global__ __launch_bounds__(256) void k_blk_rows(const T *__restrict__ in, uint
                         const bool is_peak = code == p.radius;
                         n_peak += is_peak ? 1u : 0u;
                         n_zero += code == 0u ? 1u : 0u;
+#if defined(LAB_ROWS) && (LAB_ROWS & 1)  // (lab, wrong results: no histogram)
+                        if (code == 0xFFFFFFu) {
+#else
                         if (!is_peak && code != 0u) {  // (the peak is counted per lane: 64 lanes on one LDS address are 64 serial atomics)
+#endif
                             const uint32_t bin = code - (p.radius - HW / 2);
                             if (bin < HW) atomicAdd(&lh[bin], 1u);
                             else atomicAdd((unsigned long long *)&p.hist[code], 1ull);
@@ -860,7 +879,11 @@ __global__ __launch_bounds__(256) void k_blk_rows(const T *__restrict__ in, uint
             const uint32_t x0 = xci * TPB, xend = min((uint32_t)d2, x0 + TPB);
             const uint32_t total = ez * ey * (xend - x0);
             const uint64_t base = (uint64_t)oz * d1 * d2 + (uint64_t)ez * ((uint64_t)oy * d2 + (uint64_t)ey * x0);
+#if defined(LAB_ROWS) && (LAB_ROWS & 2)  // (lab, wrong results: no code stores)
+            for (uint32_t i = threadIdx.x; i < total; i += 256 * 4096)
+#else
             for (uint32_t i = threadIdx.x; i < total; i += 256)
+#endif
                 if (!s_reg[i / per]) codes[base + i] = s_codes[i];
         }
         __syncthreads();

@@ -15,6 +15,7 @@
 // entry point fails loudly.
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
+#include <unistd.h>
 
 #include <dlfcn.h>
 #include <math.h>
@@ -66,6 +67,30 @@ static bound_fn bound;
 static iserr_fn is_error;
 static framesize_fn frame_csize;
 static contentsize_fn frame_content;
+// contexts kept per host thread (round 5): ZSTD_compress / ZSTD_decompress make and free one per call — more than a megabyte through
+// mmap / munmap each time, i.e. the address space's lock for writing, per frame, beside page population and DMA pinning that hold it for reading
+typedef void *(*create_fn)(void);
+typedef size_t (*compress_cctx_fn)(void *, void *, size_t, const void *, size_t, int);
+typedef size_t (*decompress_dctx_fn)(void *, void *, size_t, const void *, size_t);
+static create_fn create_cctx, create_dctx;
+static compress_cctx_fn compress_cctx;
+static decompress_dctx_fn decompress_dctx;
+static size_t compress_kept(void *dst, size_t cap, const void *src, size_t n, int level) {
+    static thread_local void *cctx = nullptr;  // (lives as long as its thread: the pool's threads for good)
+    if (create_cctx && compress_cctx) {
+        if (!cctx) cctx = create_cctx();
+        if (cctx) return compress_cctx(cctx, dst, cap, src, n, level);
+    }
+    return compress(dst, cap, src, n, level);
+}
+static size_t decompress_kept(void *dst, size_t cap, const void *src, size_t n) {
+    static thread_local void *dctx = nullptr;
+    if (create_dctx && decompress_dctx) {
+        if (!dctx) dctx = create_dctx();
+        if (dctx) return decompress_dctx(dctx, dst, cap, src, n);
+    }
+    return decompress(dst, cap, src, n);
+}
 static std::once_flag once;
 static bool ok;
 static void load_once() {
@@ -78,6 +103,10 @@ static void load_once() {
     is_error = (iserr_fn)dlsym(h, "ZSTD_isError");
     frame_csize = (framesize_fn)dlsym(h, "ZSTD_findFrameCompressedSize");
     frame_content = (contentsize_fn)dlsym(h, "ZSTD_getFrameContentSize");
+    create_cctx = (create_fn)dlsym(h, "ZSTD_createCCtx");
+    create_dctx = (create_fn)dlsym(h, "ZSTD_createDCtx");
+    compress_cctx = (compress_cctx_fn)dlsym(h, "ZSTD_compressCCtx");
+    decompress_dctx = (decompress_dctx_fn)dlsym(h, "ZSTD_decompressDCtx");
     ok = compress && decompress && bound && is_error;
 }
 static int load() {
@@ -85,24 +114,137 @@ static int load() {
     return ok ? 0 : fail(SZ3HIP_EZSTD, "libzstd.so.1 not found or incomplete");
 }
 static const size_t FRAME = 1u << 20;  // bytes of input per zstd frame (C2's 68 MB payload: 65 frames for up to 64 threads; 4 MB frames kept 17 of them busy: 7.8 ms)
+// CPUs this process may use at a time: the cgroup's quota where there is one (a container with 256 visible CPUs and a quota of 16 runs
+// 64 busy threads for a fraction of a scheduling period and is then throttled as a whole — 70 ms stalls inside a 12 ms call, round 5)
+static unsigned quota_cpus() {
+    static const unsigned q = [] {
+        unsigned n = std::thread::hardware_concurrency();
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // "max 100000" or "<quota> <period>" (cgroup v2)
+            char a[64] = {0};
+            unsigned long long period = 0;
+            if (fscanf(f, "%63s %llu", a, &period) == 2 && period > 0 && strcmp(a, "max") != 0) {
+                const unsigned long long quota = strtoull(a, nullptr, 10);
+                if (quota > 0) n = std::min<unsigned>(n ? n : 1u, (unsigned)std::max<unsigned long long>(1, (quota + period - 1) / period));
+            }
+            fclose(f);
+        }
+        return n ? n : 1u;
+    }();
+    return q;
+}
 static unsigned nthreads() {
     const char *e = getenv("SZ3HIP_ZSTD_THREADS");
-    unsigned n = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+    unsigned n = e ? (unsigned)atoi(e) : std::max(8u, quota_cpus());
     if (n < 1) n = 1;
     if (n > 64) n = 64;
     return n;
 }
-static size_t bound_frames(size_t n) {
-    size_t nf = (n + FRAME - 1) / FRAME;
+static size_t bound_frames(size_t n, size_t frame = FRAME) {
+    size_t nf = (n + frame - 1) / frame;
     if (nf == 0) nf = 1;
-    return nf * bound(std::min(n, FRAME)) + 8;
+    return nf * bound(std::min(n, frame)) + 8;
 }
+// The host threads of the lossless stage: one pool for the life of the process (round 5). Threads made per call cost their creation and —
+// worse — every creation maps a stack, which takes the address space's lock for writing: behind the population of an output array's pages
+// (Prefault, read side of the same lock) eight pieces' worth of thread creations queued up for 20 ms. Workers sleep on a condition variable;
+// nothing spins (272 threads spinning with sched_yield through a pipelined call ran into 70 ms scheduler stalls).
+struct Pool {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<std::function<void()>> q;
+    size_t head = 0;
+    std::vector<std::thread> th;
+    pid_t owner = 0;
+    void run() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return head < q.size(); });
+                f = std::move(q[head++]);
+                if (head == q.size()) {
+                    q.clear();
+                    head = 0;
+                }
+            }
+            f();
+        }
+    }
+    void submit(std::function<void()> f) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            if (th.size() < nthreads()) th.emplace_back([this] { run(); });
+            q.emplace_back(std::move(f));
+        }
+        cv.notify_one();
+    }
+};
+static Pool *pool() {  // (never destroyed: its threads end with the process; a forked child makes its own)
+    static std::mutex pm;
+    static Pool *p = nullptr;
+    std::lock_guard<std::mutex> l(pm);
+    if (!p || p->owner != getpid()) {
+        p = new Pool();
+        p->owner = getpid();
+    }
+    return p;
+}
+// a set of tasks handed to the pool; wait() returns when all of them have run (the waiting thread sleeps)
+struct Batch {
+    std::mutex m;
+    std::condition_variable cv;
+    size_t pending = 0;
+    void add(std::function<void()> f) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            pending++;
+        }
+        pool()->submit([this, f] {
+            f();
+            std::lock_guard<std::mutex> l(m);  // (notified under the lock: the waiter cannot leave, and the Batch die, in between)
+            if (--pending == 0) cv.notify_all();
+        });
+    }
+    void wait() {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return pending == 0; });
+    }
+    ~Batch() { wait(); }
+};
+static void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n) {  // (large copies into pages that may be touched for the first time)
+    const size_t PART = 2u << 20;
+    if (n <= PART) {
+        memcpy(dst, src, n);
+        return;
+    }
+    Batch b;
+    for (size_t o = PART; o < n; o += PART) b.add([=] { memcpy(dst + o, src + o, std::min(PART, n - o)); });
+    memcpy(dst, src, PART);
+    b.wait();
+}
+
 // [u64 srcLen][frame]...  level 3 (lossless/Lossless_zstd.hpp:48); returns 0 on error
-// feeder (optional): fills `src` front to back while the frames are being compressed — the calling thread runs it and
-// publishes how many bytes have landed; a frame is started when its input is complete (the payload's trip from the device
-// overlaps its compression). It returns non-zero on failure.
-static size_t compress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
-                              const std::function<int(std::atomic<size_t> &)> *feeder = nullptr) {
+// feeder (optional): fills `src` front to back while the frames are being compressed — the calling thread runs it, and it says after
+// every part of its copy how many bytes have landed; a frame's task is handed to the pool when its input is complete (the payload's
+// trip from the device overlaps its compression). It returns non-zero on failure.
+typedef std::function<int(const std::function<void(size_t)> &)> Feeder;
+// SZ3HIP_TIMING: the frame tasks' time in the queue and at work, summed over the process (printed by the pipelined call)
+static const bool lab_timing = getenv("SZ3HIP_TIMING") != nullptr;
+static std::atomic<uint64_t> lab_queue_us{0}, lab_run_us{0}, lab_tasks{0};
+struct Arena {  // the frames' private buffers, kept by whoever calls again and again (a host slot): no mapping, no first touch per call
+    uint8_t *p = nullptr;
+    size_t n = 0;
+    uint8_t *get(size_t want) {
+        if (n < want) {
+            free(p);
+            p = (uint8_t *)malloc(want + want / 8);
+            n = p ? want + want / 8 : 0;
+        }
+        return p;
+    }
+};
+static size_t compress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, const Feeder *feeder = nullptr, const size_t FRAME = zs::FRAME,
+                              Arena *arena = nullptr) {
     if (load()) return 0;
     if (cap < 8) {
         fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
@@ -112,70 +254,79 @@ static size_t compress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t
     memcpy(dst, &len, 8);
     const size_t nf = std::max<size_t>(1, (n + FRAME - 1) / FRAME);
     const size_t fb = bound(std::min(n, FRAME));
-    // frames are compressed into private buffers (their sizes are not known beforehand), then copied to their places — by the same
-    // threads: one thread concatenating 68 MB was 5 of the stage's 7.8 ms at C2
-    std::vector<std::unique_ptr<uint8_t[]>> out(nf);
-    std::vector<size_t> sz(nf, 0), off(nf + 1, 0);
-    std::atomic<size_t> next(0), copied(0);
-    std::atomic<int> bad(0);
-    std::atomic<unsigned> arrived(0);
-    unsigned nt = (unsigned)std::min<size_t>(nthreads(), nf);
-    std::atomic<int> phase(0);  // 1: offsets ready (copy), -1: give up
-    std::atomic<size_t> ready(feeder ? 0 : n);
-    auto work = [&]() {
-        for (;;) {
-            size_t f = next.fetch_add(1);
-            if (f >= nf) break;
-            size_t lo = f * FRAME, l = std::min(FRAME, n - lo);
-            while (ready.load(std::memory_order_acquire) < lo + l && !bad.load()) std::this_thread::yield();
-            if (bad.load()) continue;
-            out[f].reset(new (std::nothrow) uint8_t[fb]);
-            if (!out[f]) {
-                bad = 1;
-                continue;
-            }
-            size_t r = compress(out[f].get(), fb, src + lo, l, 3);
-            if (is_error(r)) bad = 1;
-            sz[f] = r;
-        }
-        if (arrived.fetch_add(1) + 1 == nt) {  // the last one in: places of the frames
-            size_t total = 8;
-            for (size_t f = 0; f < nf; f++) {
-                off[f] = total;
-                total += bad ? 0 : sz[f];
-            }
-            off[nf] = total;
-            phase = (bad || total > cap) ? -1 : 1;
-        } else {
-            while (phase.load() == 0) std::this_thread::yield();
-        }
-        if (phase.load() < 0) return;
-        for (;;) {
-            size_t f = copied.fetch_add(1);
-            if (f >= nf) break;
-            memcpy(dst + off[f], out[f].get(), sz[f]);
-        }
-    };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
-    int feed_rc = 0;
-    if (feeder) {
-        feed_rc = (*feeder)(ready);
-        if (feed_rc) bad = 1;
-        ready.store(n, std::memory_order_release);
+    // frames are compressed into private buffers (their sizes are not known beforehand), then copied to their places — by the pool as
+    // well: one thread concatenating 68 MB was 5 of the stage's 7.8 ms at C2
+    std::unique_ptr<uint8_t[]> own;
+    uint8_t *base = arena ? arena->get(nf * fb) : nullptr;
+    if (!base) {
+        own.reset(new (std::nothrow) uint8_t[nf * fb]);  // (one mapping for all frames; pages are touched as far as the frames reach)
+        base = own.get();
     }
-    work();
-    for (auto &t : th) t.join();
+    if (!base) {
+        fail(SZ3HIP_EZSTD, "out of host memory for the zstd frames");
+        return 0;
+    }
+    std::vector<size_t> sz(nf, 0), off(nf + 1, 0);
+    std::atomic<int> bad(0);
+    int feed_rc = 0;
+    {
+        Batch b;
+        size_t given = 0;  // frames handed out
+        auto give = [&](size_t landed) {
+            while (given < nf && std::min(n, (given + 1) * FRAME) <= landed) {
+                const size_t f = given++;
+                const auto t_sub = std::chrono::steady_clock::now();
+                b.add([&, f, t_sub] {
+                    if (bad.load()) return;
+                    const auto t_run = std::chrono::steady_clock::now();
+                    const size_t lo = f * FRAME, l = std::min(FRAME, n - lo);
+                    const size_t r = compress_kept(base + f * fb, fb, src + lo, l, 3);
+                    if (is_error(r)) bad = 1;
+                    sz[f] = r;
+                    if (lab_timing) {
+                        const auto t_end = std::chrono::steady_clock::now();
+                        lab_queue_us.fetch_add((uint64_t)std::chrono::duration<double, std::micro>(t_run - t_sub).count());
+                        lab_run_us.fetch_add((uint64_t)std::chrono::duration<double, std::micro>(t_end - t_run).count());
+                        lab_tasks.fetch_add(1);
+                    }
+                });
+            }
+        };
+        if (feeder) {
+            feed_rc = (*feeder)(give);
+            if (feed_rc) bad = 1;
+            else give(n);
+        } else {
+            give(n);
+        }
+        b.wait();
+    }
     if (feed_rc) return 0;  // (the feeder recorded its own error)
     if (bad) {
         fail(SZ3HIP_EZSTD, "ZSTD_compress failed");
         return 0;
     }
-    if (off[nf] > cap) {
+    size_t total = 8;
+    for (size_t f = 0; f < nf; f++) {
+        off[f] = total;
+        total += sz[f];
+    }
+    off[nf] = total;
+    if (total > cap) {
         fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
         return 0;
     }
-    return off[nf];
+    {
+        Batch b;
+        const size_t per = std::max<size_t>(1, nf / 16);
+        for (size_t f0 = per; f0 < nf; f0 += per)
+            b.add([&, f0] {
+                for (size_t f = f0; f < std::min(nf, f0 + per); f++) memcpy(dst + off[f], base + f * fb, sz[f]);
+            });
+        for (size_t f = 0; f < std::min(nf, per); f++) memcpy(dst + off[f], base + f * fb, sz[f]);
+        b.wait();
+    }
+    return total;
 }
 // inverse; frames are located with ZSTD_findFrameCompressedSize and decoded in parallel. returns bytes produced
 static size_t decompress_frames(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {
@@ -218,21 +369,26 @@ static size_t decompress_frames(const uint8_t *src, size_t n, uint8_t *dst, size
         }
         return r;
     }
-    std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
-    auto work = [&]() {
-        for (;;) {
-            size_t f = next.fetch_add(1);
-            if (f >= frames.size()) break;
-            size_t r = decompress(dst + frames[f].off, frames[f].d, frames[f].p, frames[f].c);
-            if (is_error(r) || r != frames[f].d) bad = 1;
+    {
+        Batch b;
+        // (a task per run of frames: ~1 MB of output each)
+        size_t f0 = 0;
+        while (f0 < frames.size()) {
+            size_t f1 = f0, bytes = 0;
+            while (f1 < frames.size() && (f1 == f0 || bytes + frames[f1].d <= (1u << 20))) bytes += frames[f1++].d;
+            auto job = [&, f0, f1] {
+                for (size_t f = f0; f < f1; f++) {
+                    size_t r = decompress_kept(dst + frames[f].off, frames[f].d, frames[f].p, frames[f].c);
+                    if (is_error(r) || r != frames[f].d) bad = 1;
+                }
+            };
+            if (f1 < frames.size()) b.add(job);
+            else job();  // (the last run on this thread)
+            f0 = f1;
         }
-    };
-    unsigned nt = (unsigned)std::min<size_t>(nthreads(), frames.size());
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
-    work();
-    for (auto &t : th) t.join();
+        b.wait();
+    }
     if (bad) {
         fail(SZ3HIP_EZSTD, "ZSTD_decompress failed");
         return 0;
@@ -285,6 +441,27 @@ static void slab_range(const sz3hip_config &c, int G, int g, uint64_t *lo, uint6
     *hi = (uint64_t)(g + 1) * c.dims[0] / (uint64_t)G;
 }
 
+// Pieces (round 5): a large array of a plain (not conf.openmp) call is cut along dims[0] into independently coded pieces on ONE GPU, so
+// that the copy in of piece k + 1, the kernels of piece k and the copy out + zstd of piece k - 1 run side by side (a 512^3 f32 array:
+// 9.7 ms of host->device, 0.5 ms of kernels, 5.7 ms of device->host + zstd one after the other before). The container is the
+// reference's own multi-slab one (SZ_compress_OMP's, SZImplOMP.hpp:100-110; trailer bit openmp), every piece a blob of its own.
+// Absolute (and L2-norm) bounds only: the others need the whole array's value range before the first piece can be coded.
+static const size_t PIECE_FRAME = 128u << 10;  // (a piece's last frames are the call's tail: 0.7 ms of one host thread each)
+static int piece_count(const sz3hip_config &c, int dataType) {
+    const int want = env_int("SZ3HIP_PIECES", -1);  // 0 / 1: never; n > 1: that many whenever the shape allows
+    if (want == 0 || want == 1 || c.openmp || c.N < 1 || c.N > 4) return 0;
+    if (c.cmprAlgo == SZ3HIP_ALGO_LOSSLESS) return 0;
+    if (c.errorBoundMode == SZ3HIP_EB_ABS ? !(c.absErrorBound > 0) : c.errorBoundMode != SZ3HIP_EB_L2NORM) return 0;
+    // the interpolation predictor spans the whole array (its coarse levels would be cut with it): pieces only when asked for
+    if (c.cmprAlgo != SZ3HIP_ALGO_LORENZO_REG && c.cmprAlgo != SZ3HIP_ALGO_NOPRED && !env_int("SZ3HIP_PIECES_ALL", 0)) return 0;
+    const uint64_t raw = c.num * (uint64_t)dtype_size(dataType);
+    const uint64_t min_piece = (uint64_t)std::max(1, env_int("SZ3HIP_PIECE_MB", 48)) << 20;
+    uint64_t G = want > 1 ? (uint64_t)want : std::min<uint64_t>(8, raw / min_piece);
+    const uint64_t min_planes = c.N == 1 ? (1u << 16) : 32;  // (blocks, bricks and halo planes stay a small share of a piece)
+    G = std::min<uint64_t>(G, c.dims[0] / min_planes);
+    return G >= 2 ? (int)G : 0;
+}
+
 extern "C" size_t sz3hip_compress_bound(const sz3hip_config *c, int dataType) {  // api/impl/SZImpl.hpp:34-44
     if (zs::load()) return 0;
     unsigned char tmp[160];
@@ -294,6 +471,9 @@ extern "C" size_t sz3hip_compress_bound(const sz3hip_config *c, int dataType) { 
         const size_t G = (size_t)multi_slabs(*c);
         const size_t slab = (size_t)((c->dims[0] + G - 1) / G) * (size_t)(c->num / c->dims[0]) * es;
         b += 4 + G * (160 + 8 + 8 + zs::bound(std::min(slab, zs::FRAME)));
+    } else if (const int P = piece_count(*c, dataType)) {
+        const size_t slab = (size_t)((c->dims[0] + P - 1) / P) * (size_t)(c->num / c->dims[0]) * es;
+        b = 4096 + 2 * sz3hip_config_save(c, tmp) + 4 + (size_t)P * (160 + 8 + 64 + zs::bound_frames(slab, PIECE_FRAME));
     }
     return b;
 }
@@ -311,6 +491,9 @@ struct HostSlot {
     hipStream_t stream = nullptr;
     void *dev_in = nullptr, *dev_payload = nullptr, *pin = nullptr;
     size_t dev_in_bytes = 0, dev_payload_bytes = 0, pin_bytes = 0;
+    zs::Arena frames;          // the lossless stage's frame buffers
+    void *host_out = nullptr;  // a piece's blob before it is copied to its place in the container (kept: pages touched once)
+    size_t host_out_bytes = 0;
     bool busy = false;  // leased to a single-slab call (g_pool_mu)
 };
 std::shared_mutex g_host_mu;
@@ -467,11 +650,14 @@ struct SlabJob {
     size_t out_cap = 0, out_size = 0;
     std::vector<unsigned char> own_out;  // multi-slab: the blob is staged here, then copied into the container
     bool lossless = false, staged = false;
+    size_t frame = zs::FRAME;    // bytes of payload per zstd frame (the pieces of a pipelined call take smaller ones: a piece's last frame is the call's tail)
     int asked_algo = -1;         // the caller's cmprAlgo (conf.cmprAlgo is rewritten to what was written)
     double mn = 0, mx = 0;
     int rc = 0;
     std::string err;
     HostTimer *tm = nullptr;
+    double t_mark[6] = {0, 0, 0, 0, 0, 0};  // SZ3HIP_TIMING: a piece's way through a pipelined call (ms since the call began)
+    const std::chrono::steady_clock::time_point *t0 = nullptr;
     int failed(int code) {  // keeps the failing thread's message for the thread that reports
         rc = code ? code : SZ3HIP_EHIP;
         err = sz3hip_last_error();
@@ -594,8 +780,170 @@ struct Prefault {
     ~Prefault() { wait(); }
 };
 static thread_local Prefault *t_prefault = nullptr;
-// the decoded array to the caller's memory (behind the population of its pages, when one is under way)
+// The pieces of a container decoded on one GPU do not copy their slabs out themselves: each hands its (destination, source, length) to the
+// calling thread, which sends them through the staging ring in piece order, back to back.
+struct D2hGate {
+    std::mutex *mu;
+    std::condition_variable *cv;
+    void *dst = nullptr;
+    const void *src = nullptr;
+    size_t bytes = 0;
+    int state = 0;  // 0: the piece is at work; 1: its slab is ready on the device; 2: nothing to copy (failed, or written by the host already)
+    bool passed = false;
+    void hand_over(void *d, const void *s, size_t n) {
+        passed = true;
+        {
+            std::lock_guard<std::mutex> l(*mu);
+            dst = d;
+            src = s;
+            bytes = n;
+            state = 1;
+        }
+        cv->notify_all();
+    }
+    void finish() {  // (a piece that failed, or one whose path copies nothing through d2h_out)
+        if (passed) return;
+        passed = true;
+        {
+            std::lock_guard<std::mutex> l(*mu);
+            state = 2;
+        }
+        cv->notify_all();
+    }
+};
+static thread_local D2hGate *t_gate = nullptr;
+// SZ3HIP_TIMING: a piece's way through the pipelined reader (ms since the call began)
+static thread_local double *t_stamps = nullptr;
+static thread_local std::chrono::steady_clock::time_point t_stamp0;
+static inline void stamp(int k) {
+    if (t_stamps) t_stamps[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_stamp0).count();
+}
+// The decoded array to the caller's memory. A large one goes through pinned staging buffers (round 5): the copy engine fills a ring of
+// 4 MB buffers at link speed, the pool's threads copy them on into the caller's array — whose pages, if they have never been touched,
+// are faulted in by those threads, many at a time (page faults take the address space's lock for reading only). What this replaces:
+// hipMemcpy straight into the array pins it on the fly, which took the faults one by one inside the copy (14.6 GB/s, round 4) or, with
+// the pages populated beforehand by madvise, ran behind that population — and the two cannot overlap: pinning and populating fight over
+// the same lock (a piece's copy next to a population under way: 18 ms instead of 1.4).
+struct D2hStage {
+    static constexpr size_t CH = 4u << 20;
+    static constexpr int K = 16;
+    std::mutex mu;  // one copy at a time fills the ring (the link is one)
+    uint8_t *buf[K] = {};
+    std::atomic<int> busy[K];
+    hipEvent_t ev[16][K] = {};
+    bool ok = false, tried = false;
+    bool init() {
+        if (tried) return ok;
+        tried = true;
+        for (int k = 0; k < K; k++) busy[k].store(0);
+        void *all = nullptr;
+        if (hipHostMalloc(&all, CH * K) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        for (int k = 0; k < K; k++) buf[k] = (uint8_t *)all + (size_t)k * CH;
+        return ok = true;
+    }
+};
+static D2hStage g_stage;
+// one user of the ring at a time: segments (a whole array, or the pieces of one in order) are copied back to back — the copy engine
+// does not pause between them — and the host copies of a segment's last chunks run beside the next segment's transfers
+struct StagedCopy {
+    std::unique_lock<std::mutex> lock;
+    zs::Batch copies;
+    hipStream_t st = nullptr;
+    int dev = 0;
+    size_t issued = 0, waited = 0;  // chunks sent on their way / chunks whose arrival has been seen and whose host copy is in the pool
+    struct Chunk {
+        uint8_t *dst;
+        size_t len;
+    } ring[D2hStage::K];
+    hipError_t begin() {
+        hipError_t e;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+        lock = std::unique_lock<std::mutex>(g_stage.mu);
+        if (!g_stage.init()) return hipErrorOutOfMemory;
+        for (int k = 0; k < D2hStage::K; k++)
+            if (!g_stage.ev[dev][k] && (e = hipEventCreateWithFlags(&g_stage.ev[dev][k], hipEventDisableTiming)) != hipSuccess) return e;
+        static thread_local hipStream_t t_st[16] = {};  // (streams of this thread's own, one per device: the slot's stream may be anyone's)
+        if (!t_st[dev] && (e = hipStreamCreateWithFlags(&t_st[dev], hipStreamNonBlocking)) != hipSuccess) return e;
+        st = t_st[dev];
+        return hipSuccess;
+    }
+    void drain_one() {  // the oldest chunk on its way has landed: on to the caller's array, in parts
+        const int k = (int)(waited % D2hStage::K);
+        const Chunk c = ring[k];
+        const size_t PART = 1u << 20, parts = (c.len + PART - 1) / PART;
+        auto left = std::make_shared<std::atomic<size_t>>(parts);
+        for (size_t q = 0; q < parts; q++)
+            copies.add([=] {
+                memcpy(c.dst + q * PART, g_stage.buf[k] + q * PART, std::min(PART, c.len - q * PART));
+                if (left->fetch_sub(1) == 1) g_stage.busy[k].store(0, std::memory_order_release);
+            });
+        waited++;
+    }
+    hipError_t copy(void *dst, const void *src, size_t bytes) {  // (src is complete on the device; returns when its last chunk is on its way)
+        const size_t CH = D2hStage::CH;
+        hipError_t e = hipSuccess;
+        for (size_t off = 0; off < bytes && e == hipSuccess; off += CH) {
+            const int k = (int)(issued % D2hStage::K);
+            while (waited + D2hStage::K <= issued && e == hipSuccess) {  // the ring comes round
+                e = hipEventSynchronize(g_stage.ev[dev][waited % D2hStage::K]);
+                if (e == hipSuccess) drain_one();
+            }
+            if (e != hipSuccess) break;
+            while (g_stage.busy[k].load(std::memory_order_acquire)) std::this_thread::yield();  // (its host copy is still under way)
+            g_stage.busy[k].store(1);
+            const size_t len = std::min(CH, bytes - off);
+            ring[k] = {(uint8_t *)dst + off, len};
+            e = hipMemcpyAsync(g_stage.buf[k], (const uint8_t *)src + off, len, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipEventRecord(g_stage.ev[dev][k], st);
+            if (e != hipSuccess) {
+                g_stage.busy[k].store(0);
+                break;
+            }
+            issued++;
+            while (waited + 1 < issued && hipEventQuery(g_stage.ev[dev][waited % D2hStage::K]) == hipSuccess) drain_one();  // (what has landed meanwhile)
+        }
+        (void)hipGetLastError();  // (hipErrorNotReady of the queries)
+        return e;
+    }
+    hipError_t finish() {
+        hipError_t e = hipSuccess;
+        while (waited < issued && e == hipSuccess) {
+            e = hipEventSynchronize(g_stage.ev[dev][waited % D2hStage::K]);
+            if (e == hipSuccess) drain_one();
+        }
+        if (e != hipSuccess && st) (void)hipStreamSynchronize(st);
+        copies.wait();
+        if (e != hipSuccess)
+            for (int k = 0; k < D2hStage::K; k++) g_stage.busy[k].store(0);
+        if (lock.owns_lock()) lock.unlock();
+        return e;
+    }
+    ~StagedCopy() {
+        if (lock.owns_lock()) (void)finish();
+    }
+};
+static hipError_t d2h_staged(void *dst, const void *src, size_t bytes) {
+    StagedCopy sc;
+    hipError_t e = sc.begin();
+    if (e != hipSuccess) return e;
+    e = sc.copy(dst, src, bytes);
+    const hipError_t f = sc.finish();
+    return e != hipSuccess ? e : f;
+}
+static bool d2h_staging_wanted(size_t bytes) { return bytes >= (32u << 20) && env_int("SZ3HIP_D2H_STAGED", 1) != 0; }
 static hipError_t d2h_out(void *dst, const void *src, size_t bytes) {
+    if (t_gate && !t_gate->passed) {  // (a piece of a pipelined read: the calling thread copies, in piece order)
+        t_gate->hand_over(dst, src, bytes);
+        return hipSuccess;
+    }
+    if (d2h_staging_wanted(bytes)) {
+        const hipError_t e = d2h_staged(dst, src, bytes);
+        if (e != hipErrorOutOfMemory) return e;  // (no pinned ring: the plain copy)
+    }
     if (t_prefault) t_prefault->wait();
     return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
 }
@@ -1459,6 +1807,7 @@ int job_encode(SlabJob &j) {
             if (!rc) rc = sz3hip_compress_finish(ctx, &dsize, s->stream);
         }
         if (j.tm) j.tm->lap("device compress");
+        if (j.t0) j.t_mark[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - *j.t0).count();
         if (j.lossless) {
             // (the stock branch found more unpredictable values than any stream is worth: the lossless stream below)
         } else if (rc == SZ3HIP_EOUTLIERS) {
@@ -1478,8 +1827,9 @@ int job_encode(SlabJob &j) {
         } else {
             if (ensure_pin(s, dsize)) return j.failed(SZ3HIP_EHIP);
             // the payload comes over in pieces while the host threads already compress the frames that have landed
-            std::function<int(std::atomic<size_t> &)> feeder = [&](std::atomic<size_t> &ready) -> int {
-                const size_t PIECE = 8u << 20;
+            zs::Feeder feeder = [&](const std::function<void(size_t)> &landed) -> int {
+                // (a pipelined call's piece: its payload in one go — every part costs a stream synchronisation, and the piece's tail is the call's)
+                const size_t PIECE = j.frame < zs::FRAME ? (dsize <= (16u << 20) ? dsize : 8u << 20) : 8u << 20;
                 for (size_t off = 0; off < dsize; off += PIECE) {
                     const size_t l = std::min(PIECE, dsize - off);
                     if (hipMemcpyAsync((uint8_t *)s->pin + off, (const uint8_t *)s->dev_payload + off, l, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
@@ -1487,11 +1837,11 @@ int job_encode(SlabJob &j) {
                         fail(SZ3HIP_EHIP, "device->host copy failed");
                         return SZ3HIP_EHIP;
                     }
-                    ready.store(off + l, std::memory_order_release);
+                    landed(off + l);
                 }
                 return 0;
             };
-            j.out_size = zs::compress_frames((const uint8_t *)s->pin, dsize, j.out, j.out_cap, &feeder);
+            j.out_size = zs::compress_frames((const uint8_t *)s->pin, dsize, j.out, j.out_cap, &feeder, j.frame, &s->frames);
             if (!j.out_size) return j.failed(sz3hip_last_error_code());
             if (j.tm) j.tm->lap("device->host + zstd");
             j.conf.cmprAlgo = ctx->h_state->hdr.predictor == 1 ? SZ3HIP_ALGO_HIP_INTERP : SZ3HIP_ALGO_HIP_LORENZO;
@@ -1720,6 +2070,139 @@ size_t compress_slabs(sz3hip_config &conf, int dataType, const void *data, unsig
     }
     return (size_t)(w.p - out);
 }
+
+int ensure_host(HostSlot *s, size_t want) {
+    if (s->host_out_bytes >= want) return 0;
+    free(s->host_out);
+    s->host_out_bytes = 0;
+    s->host_out = malloc(want);  // (untouched pages cost nothing: the bound of a raw piece is asked for, a ninth of it is used)
+    if (!s->host_out) return fail(SZ3HIP_EHIP, "out of host memory (%zu bytes)", want);
+    s->host_out_bytes = want;
+    return 0;
+}
+
+// the pipelined form of a plain call (piece_count above): one host thread per piece; the copies in take turns in piece order (the link
+// carries one at a time at full rate), everything behind them — stage 1, code book, packer, copy out, zstd — runs as soon as its piece
+// has arrived, beside the next pieces' copies; the blobs go to their places in piece order as their sizes become known
+size_t compress_pieces(sz3hip_config &conf, int dataType, const void *data, unsigned char *out, size_t cap, int G, HostTimer *tm) {
+    const int cdt = dtype_compute(dataType);
+    const size_t es = dtype_size(dataType);
+    const int dev = host_device();
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have < 1) {
+        (void)hipGetLastError();
+        fail(SZ3HIP_EHIP, "no usable HIP device; this library has no CPU path");
+        return 0;
+    }
+    if (abs_eb_from_range(conf, cdt, 0, 0)) return 0;  // (L2-norm -> absolute: no range needed)
+    const uint64_t base = conf.num / conf.dims[0];
+    std::vector<SlabJob> jobs(G);
+    unsigned char tmp[160];
+    size_t head = 4 + 8 * (size_t)G;
+    for (int g = 0; g < G; g++) {
+        uint64_t lo, hi;
+        slab_range(conf, G, g, &lo, &hi);
+        sz3hip_config ct = conf;
+        uint64_t d[4];
+        for (int i = 0; i < conf.N; i++) d[i] = conf.dims[i];
+        d[0] = hi - lo;
+        sz3hip_config geo;
+        sz3hip_config_init(&geo, conf.N, d);
+        ct.N = geo.N;
+        memcpy(ct.dims, geo.dims, sizeof(ct.dims));
+        ct.num = geo.num;
+        ct.predDim = geo.predDim;
+        ct.openmp = 0;  // (the caller's blockSize stands: this is a plain call's array, not SZ_compress_OMP's setDims)
+        job_init(jobs[g], ct, dataType, (const unsigned char *)data + lo * base * es, g);
+        jobs[g].slot = get_slot(dev, cdt, g);
+        jobs[g].frame = PIECE_FRAME;
+        if (ensure_host(jobs[g].slot, zs::bound_frames(jobs[g].raw_bytes, PIECE_FRAME) + 64)) return 0;
+        jobs[g].out = (unsigned char *)jobs[g].slot->host_out;
+        jobs[g].out_cap = jobs[g].slot->host_out_bytes;
+        head += sz3hip_config_save(&jobs[g].conf, tmp);  // (a Config's length depends on its dims and bound mode alone)
+    }
+    if (head > cap) {
+        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+        return 0;
+    }
+    const auto t_call = std::chrono::steady_clock::now();
+    auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
+    std::mutex mu;
+    std::condition_variable cv;
+    int up_turn = 0, place_turn = 0;
+    size_t placed = 0;
+    bool overflow = false;
+    auto worker = [&](int g) {
+        SlabJob &j = jobs[g];
+        j.t0 = &t_call;
+        {
+            std::unique_lock<std::mutex> l(mu);
+            cv.wait(l, [&] { return up_turn == g; });
+        }
+        j.t_mark[0] = now_ms();
+        job_upload(j);
+        j.t_mark[1] = now_ms();
+        {
+            std::lock_guard<std::mutex> l(mu);
+            up_turn++;
+        }
+        cv.notify_all();
+        if (!j.rc) job_stage1(j);
+        if (!j.rc) job_encode(j);
+        j.t_mark[3] = now_ms();
+        size_t at = 0;
+        bool mine = false;
+        {
+            std::unique_lock<std::mutex> l(mu);
+            cv.wait(l, [&] { return place_turn == g; });
+            at = placed;
+            if (!j.rc && !overflow) {
+                if (head + placed + j.out_size <= cap) {
+                    placed += j.out_size;
+                    mine = true;
+                } else {
+                    overflow = true;
+                }
+            }
+            place_turn++;
+        }
+        cv.notify_all();
+        if (mine) zs::parallel_copy(out + head + at, j.out, j.out_size);
+        j.t_mark[4] = now_ms();
+    };
+    std::vector<std::thread> th;
+    for (int g = 1; g < G; g++) th.emplace_back(worker, g);
+    worker(0);
+    for (auto &t : th) t.join();
+    if (tm) tm->lap("pieces (in, kernels, out, zstd)");
+    if (tm && tm->on)
+        fprintf(stderr, "[sz3hip]   zstd frame tasks so far: %llu, mean wait in the queue %.1f us, mean run %.1f us\n", (unsigned long long)zs::lab_tasks.load(),
+                (double)zs::lab_queue_us.load() / std::max<uint64_t>(1, zs::lab_tasks.load()), (double)zs::lab_run_us.load() / std::max<uint64_t>(1, zs::lab_tasks.load()));
+    if (tm && tm->on)
+        for (auto &j : jobs)
+            fprintf(stderr, "[sz3hip]   piece %d: copy in %.2f - %.2f, device done %.2f, zstd done %.2f, placed %.2f ms (%zu bytes)\n", j.index, j.t_mark[0],
+                    j.t_mark[1], j.t_mark[2], j.t_mark[3], j.t_mark[4], j.out_size);
+    for (auto &j : jobs)
+        if (j.rc) {
+            fail(j.rc, "piece %d: %s", j.index, j.err.c_str());
+            return 0;
+        }
+    if (overflow) {
+        fail(SZ3HIP_ECAPACITY, "The buffer for compressed data is not large enough.");
+        return 0;
+    }
+    // [i32 G][Config x G][u64 size x G][blob x G]  (SZImplOMP.hpp:100-110)
+    Writer w{out};
+    w.put<int32_t>(G);
+    for (auto &j : jobs) w.p += sz3hip_config_save(&j.conf, w.p);
+    for (auto &j : jobs) w.put<uint64_t>((uint64_t)j.out_size);
+    if ((size_t)(w.p - out) != head) {
+        fail(SZ3HIP_EHIP, "internal: the pieces' Configs changed their length");
+        return 0;
+    }
+    conf.openmp = 1;  // what tells a reader that the body is a multi-slab container (SZ_decompress_impl, SZImpl.hpp:22-32)
+    return head + placed;
+}
 }  // namespace
 
 // 1: sz3hip_compress (and everything on top of it: SZ_compress<T>, SZ_compress_args, the CLI, the HDF5 filter) writes streams stock SZ3
@@ -1763,11 +2246,15 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
 
     std::unique_lock<std::shared_mutex> all(g_host_mu, std::defer_lock);
     std::shared_lock<std::shared_mutex> some(g_host_mu, std::defer_lock);
-    if (conf.openmp) all.lock();
+    const int pieces = g_stock_format.load() > 0 ? 0 : piece_count(conf, dataType);
+    if (conf.openmp || pieces) all.lock();
     else some.lock();
     DeviceGuard guard;
     if (conf.openmp) {  // SZ_compress_impl, api/impl/SZImpl.hpp:10-20
         payload_size = compress_slabs(conf, dataType, data, w.p, payload_cap);
+        if (!payload_size) return 0;
+    } else if (pieces) {
+        payload_size = compress_pieces(conf, dataType, data, w.p, payload_cap, pieces, &tm);
         if (!payload_size) return 0;
     } else {
         SlabJob j;
@@ -2046,6 +2533,7 @@ int decompress_blob(HostSlot *s, const sz3hip_config *conf, int dataType, const 
     int rc;
     if ((rc = ensure_pin(s, raw_len))) return rc;
     if (zs::decompress_frames(p, payload, (uint8_t *)s->pin, raw_len) != raw_len) return SZ3HIP_EZSTD;
+    stamp(0);
     // the SZH1 header is authoritative for the GPU streams: element count and type are checked before anything is launched
     szh_header hdr;
     memcpy(&hdr, s->pin, sizeof(hdr));
@@ -2062,12 +2550,13 @@ int decompress_blob(HostSlot *s, const sz3hip_config *conf, int dataType, const 
     if ((rc = ensure_dev(&s->dev_in, &s->dev_in_bytes, cbytes))) return rc;
     if ((rc = ensure_dev(&s->dev_payload, &s->dev_payload_bytes, std::max<size_t>(raw_len + 64, is_int ? raw_bytes : 0)))) return rc;
     HIPCHK(hipMemcpy(s->dev_payload, s->pin, raw_len, hipMemcpyHostToDevice));
+    stamp(1);
     rc = sz3hip_decompress_device(s->ctx, s->dev_payload, raw_len, s->dev_in, s->stream);
     if (rc) return rc;
     if (!is_int) {
         HIPCHK(hipStreamSynchronize(s->stream));
-        HIPCHK(d2h_out(decData, s->dev_in, raw_bytes));  // (the runtime pins large pageable buffers
-                                                                                  // itself: a hand-made pinned pipeline was slower)
+        stamp(2);
+        HIPCHK(d2h_out(decData, s->dev_in, raw_bytes));
     } else {
         rc = szk_launch_f64_to_int(dataType, (const double *)s->dev_in, conf->num, s->dev_payload, s->stream);
         if (rc) return fail(SZ3HIP_EHIP, "integer narrowing kernel failed");
@@ -2115,6 +2604,70 @@ int decompress_slabs(const sz3hip_config *conf, int dataType, const unsigned cha
     for (int g = 0; g < G; g++) slots[g] = get_slot(ndev == 1 ? host_device() : g % ndev, cdt, g / ndev);
     std::vector<int> rcs(G, 0);
     std::vector<std::string> errs(G);
+    if (ndev == 1 && G >= 2 && need_gpu && (size_t)conf->num * es >= (64u << 20) && env_int("SZ3HIP_PIECES", -1) != 0) {
+        // one GPU, several pieces (what compress_pieces writes; any multi-slab container of this size): a host thread per piece —
+        // unpacking, copy in and decoding of all pieces side by side —, the slabs copied out by this thread in piece order, back to
+        // back through the staging ring (d2h_staged above), each as soon as its piece has handed it over
+        std::mutex mu;
+        std::condition_variable cv;
+        const bool timing = getenv("SZ3HIP_TIMING") != nullptr;
+        const auto t_call = std::chrono::steady_clock::now();
+        std::vector<double> stamps((size_t)G * 5, 0.0);
+        std::vector<D2hGate> gates(G);
+        for (auto &gt : gates) {
+            gt.mu = &mu;
+            gt.cv = &cv;
+        }
+        auto piece = [&](int g) {
+            t_gate = &gates[g];
+            if (timing) {
+                t_stamps = &stamps[(size_t)g * 5];
+                t_stamp0 = t_call;
+            }
+            uint64_t lo, hi;
+            slab_range(*conf, G, g, &lo, &hi);
+            rcs[g] = decompress_blob(slots[g], &ct[g], dataType, blobs + start[g], (size_t)size[g], (unsigned char *)decData + lo * base * es);
+            if (rcs[g]) errs[g] = sz3hip_last_error();
+            t_gate = nullptr;
+            t_stamps = nullptr;
+            gates[g].finish();
+        };
+        std::vector<std::thread> pth;
+        for (int g = 0; g < G; g++) pth.emplace_back(piece, g);
+        hipError_t ce = hipSetDevice(slots[0]->device);
+        {
+            StagedCopy sc;
+            bool ring = false;
+            for (int g = 0; g < G; g++) {
+                {
+                    std::unique_lock<std::mutex> l(mu);
+                    cv.wait(l, [&] { return gates[g].state != 0; });
+                }
+                if (gates[g].state != 1 || ce != hipSuccess) continue;
+                if (!ring) {
+                    ce = sc.begin();
+                    ring = ce == hipSuccess;
+                    if (ce == hipErrorOutOfMemory) ce = hipSuccess;  // (no pinned ring: plain copies)
+                }
+                if (timing) stamps[(size_t)g * 5 + 3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+                if (ce == hipSuccess) ce = ring ? sc.copy(gates[g].dst, gates[g].src, gates[g].bytes) : hipMemcpy(gates[g].dst, gates[g].src, gates[g].bytes, hipMemcpyDeviceToHost);
+                if (timing) stamps[(size_t)g * 5 + 4] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+            }
+            if (ring) {
+                const hipError_t fe = sc.finish();
+                if (ce == hipSuccess) ce = fe;
+            }
+        }
+        for (auto &t : pth) t.join();
+        if (timing)
+            for (int g = 0; g < G; g++)
+                fprintf(stderr, "[sz3hip]   piece %d: unpacked %.2f, copied in %.2f, decoded %.2f, copy out %.2f - %.2f ms\n", g, stamps[g * 5], stamps[g * 5 + 1],
+                        stamps[g * 5 + 2], stamps[g * 5 + 3], stamps[g * 5 + 4]);
+        for (int g = 0; g < G; g++)
+            if (rcs[g]) return fail(rcs[g], "slab %d: %s", g, errs[g].c_str());
+        if (ce != hipSuccess) return fail(SZ3HIP_EHIP, "device->host copy failed: %s", hipGetErrorString(ce));
+        return 0;
+    }
     auto worker = [&](int t) {
         for (int g = t; g < G; g += ndev) {
             uint64_t lo, hi;
@@ -2149,8 +2702,8 @@ extern "C" int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *
     else some.lock();
     DeviceGuard guard;
     if (conf->openmp) return decompress_slabs(conf, dataType, p, (size_t)payload, decData);  // SZ_decompress_impl, SZImpl.hpp:22-32
-    Prefault pf;  // (the output array's pages, populated beside the work below)
-    pf.start(decData, (size_t)conf->num * dtype_size(dataType));
+    Prefault pf;  // (the output array's pages, populated beside the work below — when the copy out will not go through the staging ring)
+    if (!d2h_staging_wanted((size_t)conf->num * dtype_size(dataType))) pf.start(decData, (size_t)conf->num * dtype_size(dataType));
     t_prefault = &pf;
     SlotLease lease(host_device(), dtype_compute(dataType));
     const int rcd = decompress_blob(lease.s, conf, dataType, p, (size_t)payload, decData);

@@ -1315,28 +1315,31 @@ int stock_encode_lorenzo_reg(SlabJob &j) {
     HostSlot *s = j.slot;
     const sz3hip_config &cf = j.conf;
     const int N = cf.N;
-    if (N < 1 || N > 3 || cf.blockSize < 2) return SZ3HIP_EUNSUPPORTED;
+    if (N < 1 || N > 4 || cf.blockSize < 2) return SZ3HIP_EUNSUPPORTED;
     if (N == 1) return stock_encode_lorenzo_reg_1d(j);
     const uint32_t B = (uint32_t)cf.blockSize;
-    if ((N == 3 && B > 8) || (N == 2 && B > 32)) return SZ3HIP_EUNSUPPORTED;
+    if ((N == 4 && B > 6) || (N == 3 && B > 8) || (N == 2 && B > 32)) return SZ3HIP_EUNSUPPORTED;
     const uint32_t set_mask = (cf.lorenzo ? 1u : 0u) | (cf.lorenzo2 ? 2u : 0u) | (cf.regression ? 4u : 0u);
     if (!set_mask) return SZ3HIP_EUNSUPPORTED;
     const int members = (cf.lorenzo ? 1 : 0) + (cf.lorenzo2 ? 1 : 0) + (cf.regression ? 1 : 0);
     const bool composed = members > 1, has_reg = cf.regression != 0;
     const int radius = cf.quantbinCnt / 2;
     if (radius < 1 || radius > 32768 || !(cf.absErrorBound > 0)) return SZ3HIP_EUNSUPPORTED;
-    uint64_t d3[3] = {1, 1, 1};
-    for (int i = 0; i < N; i++) d3[3 - N + i] = cf.dims[i];
-    for (int i = 0; i < 3; i++)
-        if (d3[i] >= (1ull << 31)) return SZ3HIP_EUNSUPPORTED;
+    // the array as (w, z, y, x), leading extents 1: d3 / nb = the three fast dimensions (what the 2-D / 3-D kernels take), dw / nbw the fourth
+    uint64_t d4[4] = {1, 1, 1, 1};
+    for (int i = 0; i < N; i++) d4[4 - N + i] = cf.dims[i];
+    for (int i = 0; i < 4; i++)
+        if (d4[i] >= (1ull << 31)) return SZ3HIP_EUNSUPPORTED;
+    const uint64_t *d3 = d4 + 1;
     if (set_mask == 4u)  // regression alone: a block one element wide takes the reference's UNPADDED fallback (see slr_coefficients)
-        for (int i = 3 - N; i < 3; i++)
-            if (d3[i] % B == 1) return SZ3HIP_EUNSUPPORTED;
-    uint64_t nb[3];
-    for (int i = 0; i < 3; i++) nb[i] = (d3[i] + B - 1) / B;
-    if (N == 2) nb[0] = 1;
-    const uint64_t nblocks = nb[0] * nb[1] * nb[2];
+        for (int i = 4 - N; i < 4; i++)
+            if (d4[i] % B == 1) return SZ3HIP_EUNSUPPORTED;
+    uint64_t nb4[4];
+    for (int i = 0; i < 4; i++) nb4[i] = i < 4 - N ? 1 : (d4[i] + B - 1) / B;
+    const uint64_t *nb = nb4 + 1;
+    const uint64_t nblocks = nb4[0] * nb4[1] * nb4[2] * nb4[3];
     if (nblocks >= (1ull << 31)) return SZ3HIP_EUNSUPPORTED;
+    const size_t CS = N == 4 ? 8 : 4;  // coefficients per block in the arrays shared with the device (N + 1 used)
     const size_t tsize = j.cdt == SZ3HIP_FLOAT ? 4 : 8;
     const uint64_t n = cf.num;
     HIPCHK(hipSetDevice(s->device));
@@ -1351,8 +1354,8 @@ int stock_encode_lorenzo_reg(SlabJob &j) {
     ar.ask(&d_codes, (size_t)n * 2 + 64);
     ar.ask(&d_kind, (size_t)nblocks);
     ar.ask(&d_sel, (size_t)nblocks);
-    ar.ask(&d_fit, (size_t)nblocks * 4 * tsize);
-    ar.ask(&d_coef, (size_t)nblocks * 4 * tsize);
+    ar.ask(&d_fit, (size_t)nblocks * CS * tsize);
+    ar.ask(&d_coef, (size_t)nblocks * CS * tsize);
     ar.ask(&d_hist, 65536 * 8);
     ar.ask(&d_tile_cnt, (size_t)ntiles_z * 4);
     ar.ask(&d_tile_base, (size_t)(ntiles_z + 1) * 8);
@@ -1367,6 +1370,8 @@ int stock_encode_lorenzo_reg(SlabJob &j) {
         sp.d[i] = d3[i];
         sp.nb[i] = (uint32_t)nb[i];
     }
+    sp.dw = d4[0];
+    sp.nbw = (uint32_t)nb4[0];
     sp.B = B;
     sp.N = (uint32_t)N;
     sp.eb = cf.absErrorBound;
@@ -1385,7 +1390,7 @@ int stock_encode_lorenzo_reg(SlabJob &j) {
     if (szk_launch_stock_lr_select(dt, &sp, s->stream)) return fail(SZ3HIP_EHIP, "stock stream: selection launch failed");
     // the choices and the fits to the host: the coefficient chain (a chain over the regression blocks, T arithmetic) and the side vectors
     std::vector<uint8_t> kind((size_t)nblocks), sel((size_t)nblocks);
-    std::vector<uint8_t> coef((size_t)nblocks * 4 * tsize);
+    std::vector<uint8_t> coef((size_t)nblocks * CS * tsize);
     HIPCHK(hipMemcpyAsync(kind.data(), d_kind, (size_t)nblocks, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipMemcpyAsync(sel.data(), d_sel, (size_t)nblocks, hipMemcpyDeviceToHost, s->stream));
     if (has_reg) HIPCHK(hipMemcpyAsync(coef.data(), d_fit, coef.size(), hipMemcpyDeviceToHost, s->stream));

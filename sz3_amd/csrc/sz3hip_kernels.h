@@ -413,6 +413,8 @@ struct szk_slw_params {
     uint8_t *sel;             // [blocks] the chosen member's index in the set's order (the selection vector of a composed set)
     void *coef_fit;           // [blocks][4] T: the fit of every block the regression member is valid for (selection pass)
     const void *coef;         // [blocks][4] T: the RECOVERED coefficients of the regression blocks (host chain), what predictions use
+    uint64_t dw;              // 4-D arrays (N == 4): the slowest extent, d[] holds the other three; coef_fit / coef are then [blocks][8]
+    uint32_t nbw;             // ... and its blocks
 };
 int szk_launch_stock_lr_select(int dtype, const szk_slw_params *p, hipStream_t s);
 // stock ALGO_NOPRED streams (round 5): every value quantized against a prediction of 0 (NoPredictionDecomposition.hpp:17-33)

@@ -1148,6 +1148,230 @@ __global__ __launch_bounds__(256) void k_slw_front(szk_slw_params p, uint32_t di
         recon[((uint64_t)(g.oz + i0) * p.d[1] + (g.oy + i1)) * p.d[2] + (g.ox + i2)] = tl[at(i0 + g.hz, i1 + 2, i2 + 2)];
     }
 }
+// 4-D arrays (round 5, second half): the write side of k_slr_front4. Tiles of (B + 1)^4 values with ONE low halo layer (first-order
+// Lorenzo is the only member that reads neighbours: the reference's second-order member predicts 0 for N = 4, LorenzoPredictor.hpp:92-94,
+// with a noise term of 0, :17-38), five regression coefficients (RegressionPredictor.hpp:28-55, 86-88), eight sample points per step of
+// the block's diagonal (BlockwiseIterator.hpp:170-179), the fifteen Lorenzo terms in the reference's order (:69-74).
+struct SlwGeom4 {
+    uint32_t task, ow, oz, oy, ox, ew, ez, ey, ex, nown, tw, tz, ty, tx;
+    uint64_t coff;
+};
+__device__ __forceinline__ void slw_geom4(const szk_slw_params &p, uint32_t bw, uint32_t bz, uint32_t by, uint32_t bx, SlwGeom4 &g) {
+    const uint32_t B = p.B;
+    g.task = ((bw * p.nb[0] + bz) * p.nb[1] + by) * p.nb[2] + bx;
+    g.ow = bw * B;
+    g.oz = bz * B;
+    g.oy = by * B;
+    g.ox = bx * B;
+    g.ew = min(B, (uint32_t)p.dw - g.ow);
+    g.ez = min(B, (uint32_t)p.d[0] - g.oz);
+    g.ey = min(B, (uint32_t)p.d[1] - g.oy);
+    g.ex = min(B, (uint32_t)p.d[2] - g.ox);
+    const uint64_t vol3 = p.d[0] * p.d[1] * p.d[2];
+    g.coff = (uint64_t)g.ow * vol3 + (uint64_t)g.ew * ((uint64_t)g.oz * p.d[1] * p.d[2] + (uint64_t)g.ez * ((uint64_t)g.oy * p.d[2] + (uint64_t)g.ey * g.ox));
+    g.nown = g.ew * g.ez * g.ey * g.ex;
+    g.tw = g.ew + 1;
+    g.tz = g.ez + 1;
+    g.ty = g.ey + 1;
+    g.tx = g.ex + 1;
+}
+template <typename T>
+__device__ __forceinline__ T slw_lorenzo4(const T *tl, const SlwGeom4 &g, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    // prev4(d, ds, t, k, j, i): t steps along y, k along z, j along w, i along x (LorenzoPredictor.hpp:69-74, 109-111)
+    auto P = [&](int tt, int k, int j, int i) -> T { return tl[(((a - j) * g.tz + (b - k)) * g.ty + (c - tt)) * g.tx + (d - i)]; };
+    T pr = (T)(P(0, 0, 0, 1) + P(0, 0, 1, 0));
+    pr = (T)(pr - P(0, 0, 1, 1));
+    pr = (T)(pr + P(0, 1, 0, 0));
+    pr = (T)(pr - P(0, 1, 0, 1));
+    pr = (T)(pr - P(0, 1, 1, 0));
+    pr = (T)(pr + P(0, 1, 1, 1));
+    pr = (T)(pr + P(1, 0, 0, 0));
+    pr = (T)(pr - P(1, 0, 0, 1));
+    pr = (T)(pr - P(1, 0, 1, 0));
+    pr = (T)(pr + P(1, 0, 1, 1));
+    pr = (T)(pr - P(1, 1, 0, 0));
+    pr = (T)(pr + P(1, 1, 0, 1));
+    pr = (T)(pr + P(1, 1, 1, 0));
+    pr = (T)(pr - P(1, 1, 1, 1));
+    return pr;
+}
+template <typename T>
+__device__ __forceinline__ T slw_regression4(const T *cf, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3) {  // RegressionPredictor::predict, :86-88
+    T pr = (T)(cf[0] * (T)i0);
+    pr = (T)(pr + (T)(cf[1] * (T)i1));
+    pr = (T)(pr + (T)(cf[2] * (T)i2));
+    pr = (T)(pr + (T)(cf[3] * (T)i3));
+    pr = (T)(pr + cf[4]);
+    return pr;
+}
+template <typename T>
+__device__ __forceinline__ void slw_fill4(T *tl, const SlwGeom4 &g, const szk_slw_params &p, const T *inner, const T *halo, int lane) {
+    // the block's own elements from `inner`, its low halo layer from `halo`, zeros outside the array (the reference's padding)
+    for (uint32_t l = lane; l < g.tw * g.tz * g.ty * g.tx; l += WAVE) {
+        const uint32_t d = l % g.tx, c = (l / g.tx) % g.ty, b = (l / (g.tx * g.ty)) % g.tz, a = l / (g.tx * g.ty * g.tz);
+        const bool own = a >= 1 && b >= 1 && c >= 1 && d >= 1;
+        const int64_t w = (int64_t)g.ow + a - 1, z = (int64_t)g.oz + b - 1, y = (int64_t)g.oy + c - 1, x = (int64_t)g.ox + d - 1;
+        const uint64_t e = (((uint64_t)w * p.d[0] + (uint64_t)z) * p.d[1] + (uint64_t)y) * p.d[2] + (uint64_t)x;
+        tl[l] = (w >= 0 && z >= 0 && y >= 0 && x >= 0) ? (own ? inner[e] : halo[e]) : (T)0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_slw_select4(szk_slw_params p) {
+    extern __shared__ __align__(8) unsigned char s_raw4[];
+    const int lane = lane_id();
+    const uint32_t te = p.B + 1;
+    T *tl = reinterpret_cast<T *>(s_raw4) + (size_t)(threadIdx.x / WAVE) * te * te * te * te;
+    const uint32_t nblocks = p.nbw * p.nb[0] * p.nb[1] * p.nb[2];
+    const uint32_t task = blockIdx.x * 4 + threadIdx.x / WAVE;
+    if (task >= nblocks) return;
+    const uint32_t bx = task % p.nb[2], by = (task / p.nb[2]) % p.nb[1], bz = (task / (p.nb[2] * p.nb[1])) % p.nb[0], bw = task / (p.nb[2] * p.nb[1] * p.nb[0]);
+    SlwGeom4 g;
+    slw_geom4(p, bw, bz, by, bx, g);
+    const T *in = reinterpret_cast<const T *>(p.in);
+    slw_fill4<T>(tl, g, p, in, in, lane);
+    auto at = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) -> uint32_t { return ((a * g.tz + b) * g.ty + c) * g.tx + d; };
+    const bool reg_on = (p.set_mask & 4u) != 0;
+    const bool reg_valid = reg_on && g.ew > 1 && g.ez > 1 && g.ey > 1 && g.ex > 1;  // RegressionPredictor.hpp:33-37
+    T cf[5] = {0, 0, 0, 0, 0};
+    if (reg_valid) {
+        double sm[4] = {0, 0, 0, 0}, sn = 0;
+        for (uint32_t t = lane; t < g.nown; t += WAVE) {
+            const uint32_t i3 = t % g.ex, i2 = (t / g.ex) % g.ey, i1 = (t / (g.ex * g.ey)) % g.ez, i0 = t / (g.ex * g.ey * g.ez);
+            const double v = (double)tl[at(i0 + 1, i1 + 1, i2 + 1, i3 + 1)];
+            sm[0] += (double)i0 * v;
+            sm[1] += (double)i1 * v;
+            sm[2] += (double)i2 * v;
+            sm[3] += (double)i3 * v;
+            sn += v;
+        }
+        for (int i = 0; i < 4; i++) sm[i] = slw_wave_sum(sm[i]);
+        sn = slw_wave_sum(sn);
+        const double num = (double)g.nown;
+        const double dm[4] = {(double)g.ew, (double)g.ez, (double)g.ey, (double)g.ex};
+        cf[4] = (T)(sn / num);
+        for (int i = 0; i < 4; i++) {
+            cf[i] = (T)((2 * sm[i] / (dm[i] - 1) - sn) * 6 / num / (dm[i] + 1));
+            cf[4] = (T)((double)cf[4] - (dm[i] - 1) * (double)cf[i] / 2);
+        }
+    }
+    const uint32_t msz = min(min(g.ew, g.ez), min(g.ey, g.ex));
+    double e1 = 0, e2 = 0, er = 0;
+    for (uint32_t q = lane; q < msz * 8u; q += WAVE) {
+        const uint32_t i = q / 8u, w = q % 8u, j = msz - 1 - i;
+        const uint32_t i0 = i, i1 = (w & 4u) ? j : i, i2 = (w & 2u) ? j : i, i3 = (w & 1u) ? j : i;
+        const uint32_t a = i0 + 1, b = i1 + 1, c = i2 + 1, d = i3 + 1;
+        const T v = tl[at(a, b, c, d)];
+        if (p.set_mask & 1u) e1 += (double)(T)(fabs((double)(T)(v - slw_lorenzo4<T>(tl, g, a, b, c, d))) + 1.79 * p.eb);
+        if (p.set_mask & 2u) e2 += (double)(T)fabs((double)v);  // (the member predicts 0 and has no noise term for N = 4)
+        if (reg_valid) er += (double)(T)fabs((double)(T)(v - slw_regression4<T>(cf, i0, i1, i2, i3)));
+    }
+    e1 = slw_wave_sum(e1);
+    e2 = slw_wave_sum(e2);
+    er = slw_wave_sum(er);
+    if (lane == 0) {
+        const double big = 1.7976931348623157e308;
+        double best = big * 2;
+        uint32_t kind = 0, idx = 0, k = 0;
+        if (p.set_mask & 1u) {
+            if (e1 < best) {
+                best = e1;
+                kind = 0;
+                idx = k;
+            }
+            k++;
+        }
+        if (p.set_mask & 2u) {
+            if (e2 < best) {
+                best = e2;
+                kind = 1;
+                idx = k;
+            }
+            k++;
+        }
+        if (p.set_mask & 4u) {
+            const double e = reg_valid ? er : big;
+            if (e < best) {
+                best = e;
+                kind = 2;
+                idx = k;
+            }
+            k++;
+        }
+        if (kind == 2 && !reg_valid) kind = 0;  // (a regression-only set on a thin block: the launcher refuses such arrays)
+        p.kind[task] = (uint8_t)kind;
+        p.sel[task] = (uint8_t)idx;
+        T *o = reinterpret_cast<T *>(p.coef_fit) + (uint64_t)task * 8;
+        for (int i = 0; i < 5; i++) o[i] = cf[i];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_slw_front4(szk_slw_params p, uint32_t diag) {
+    extern __shared__ __align__(8) unsigned char s_raw4[];
+    const int lane = lane_id();
+    const uint32_t te = p.B + 1;
+    T *tl = reinterpret_cast<T *>(s_raw4) + (size_t)(threadIdx.x / WAVE) * te * te * te * te;
+    const uint32_t cand = blockIdx.x * 4 + threadIdx.x / WAVE;  // (bw, bz, by); bx follows from the front
+    if (cand >= p.nbw * p.nb[0] * p.nb[1]) return;
+    const uint32_t by = cand % p.nb[1], bz = (cand / p.nb[1]) % p.nb[0], bw = cand / (p.nb[1] * p.nb[0]);
+    if (bw + bz + by > diag) return;
+    const uint32_t bx = diag - bw - bz - by;
+    if (bx >= p.nb[2]) return;
+    SlwGeom4 g;
+    slw_geom4(p, bw, bz, by, bx, g);
+    const T *in = reinterpret_cast<const T *>(p.in);
+    T *recon = reinterpret_cast<T *>(p.recon);
+    T *uval = reinterpret_cast<T *>(p.uval);
+    slw_fill4<T>(tl, g, p, in, recon, lane);  // the halo: values as the reader will have them; the block: the caller's
+    auto at = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) -> uint32_t { return ((a * g.tz + b) * g.ty + c) * g.tx + d; };
+    auto split = [&](uint32_t t, uint32_t &i0, uint32_t &i1, uint32_t &i2, uint32_t &i3) {
+        i3 = t % g.ex;
+        i2 = (t / g.ex) % g.ey;
+        i1 = (t / (g.ex * g.ey)) % g.ez;
+        i0 = t / (g.ex * g.ey * g.ez);
+    };
+    const uint32_t kind = p.kind[g.task];
+    const double recip = 1.0 / p.eb;
+    auto code_one = [&](uint32_t t, uint32_t l, T pr) {
+        T v = tl[l];
+        const T orig = v;
+        const int code = ref_quantize<T>(v, pr, p.eb, recip, (int)p.radius);  // LinearQuantizer::quantize_and_overwrite, :43-71
+        tl[l] = v;
+        p.codes[g.coff + t] = (uint16_t)code;
+        if (code == 0) uval[g.coff + t] = orig;
+    };
+    if (kind != 0) {  // regression, or the second-order member's prediction of 0: nothing of the neighbours
+        const T *cf = reinterpret_cast<const T *>(p.coef) + (uint64_t)g.task * 8;
+        for (uint32_t t = lane; t < g.nown; t += WAVE) {
+            uint32_t i0, i1, i2, i3;
+            split(t, i0, i1, i2, i3);
+            code_one(t, at(i0 + 1, i1 + 1, i2 + 1, i3 + 1), kind == 2 ? slw_regression4<T>(cf, i0, i1, i2, i3) : (T)0);
+        }
+    } else {
+        const uint32_t smax = (g.ew - 1) + (g.ez - 1) + (g.ey - 1) + (g.ex - 1);
+        for (uint32_t s = 0; s <= smax; s++) {
+            for (uint32_t t = lane; t < g.nown; t += WAVE) {
+                uint32_t i0, i1, i2, i3;
+                split(t, i0, i1, i2, i3);
+                if (i0 + i1 + i2 + i3 != s) continue;
+                code_one(t, at(i0 + 1, i1 + 1, i2 + 1, i3 + 1), slw_lorenzo4<T>(tl, g, i0 + 1, i1 + 1, i2 + 1, i3 + 1));
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t t = lane; t < g.nown; t += WAVE) {
+        uint32_t i0, i1, i2, i3;
+        split(t, i0, i1, i2, i3);
+        recon[(((uint64_t)(g.ow + i0) * p.d[0] + (g.oz + i1)) * p.d[1] + (g.oy + i2)) * p.d[2] + (g.ox + i3)] = tl[at(i0 + 1, i1 + 1, i2 + 1, i3 + 1)];
+    }
+}
 // the codes' histogram (a window of 2048 bins around the radius in LDS, the rest straight to memory) ...
 __global__ __launch_bounds__(256) void k_slw_hist(const uint16_t *__restrict__ codes, uint64_t n, uint32_t radius, unsigned long long *__restrict__ hist) {
     __shared__ uint32_t s_h[2048];
@@ -1209,7 +1433,23 @@ int szk_launch_stock_nopred_encode(int dtype, const void *d_in, uint64_t n, doub
     else hipLaunchKernelGGL(k_snp_encode<double>, dim3(g), dim3(256), 0, s, (const double *)d_in, n, eb, radius, d_codes);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+static size_t slw_lds4(const szk_slw_params *p, int dtype) {  // four waves' tiles of (B + 1)^4 values: 77 KB for f64 at B = 6
+    const uint32_t te = p->B + 1;
+    return (size_t)4 * te * te * te * te * (dtype == 0 ? 4 : 8);
+}
 int szk_launch_stock_lr_select(int dtype, const szk_slw_params *p, hipStream_t s) {
+    if (p->N == 4) {
+        const uint32_t nb4 = p->nbw * p->nb[0] * p->nb[1] * p->nb[2];
+        const size_t lds = slw_lds4(p, dtype);
+        if (dtype == 0) {
+            (void)hipFuncSetAttribute((const void *)k_slw_select4<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_slw_select4<float>, dim3((nb4 + 3) / 4), dim3(256), lds, s, *p);
+        } else {
+            (void)hipFuncSetAttribute((const void *)k_slw_select4<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_slw_select4<double>, dim3((nb4 + 3) / 4), dim3(256), lds, s, *p);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     const uint32_t nblocks = p->nb[0] * p->nb[1] * p->nb[2];
     const dim3 grid((nblocks + 3) / 4), blk(256);
     if (p->N == 3) {
@@ -1222,6 +1462,18 @@ int szk_launch_stock_lr_select(int dtype, const szk_slw_params *p, hipStream_t s
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int szk_launch_stock_lr_code(int dtype, const szk_slw_params *p, hipStream_t s) {
+    if (p->N == 4) {
+        const size_t lds = slw_lds4(p, dtype);
+        const uint32_t nd4 = p->nbw + p->nb[0] + p->nb[1] + p->nb[2] - 3;
+        const dim3 g4((p->nbw * p->nb[0] * p->nb[1] + 3) / 4), b4(256);
+        if (dtype == 0) (void)hipFuncSetAttribute((const void *)k_slw_front4<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else (void)hipFuncSetAttribute((const void *)k_slw_front4<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        for (uint32_t d = 0; d < nd4; d++) {
+            if (dtype == 0) hipLaunchKernelGGL(k_slw_front4<float>, g4, b4, lds, s, *p, d);
+            else hipLaunchKernelGGL(k_slw_front4<double>, g4, b4, lds, s, *p, d);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     const uint32_t ndiag = p->nb[0] + p->nb[1] + p->nb[2] - 2;
     const uint32_t cand = p->N == 3 ? p->nb[0] * p->nb[1] : p->nb[1];
     const dim3 grid((cand + 3) / 4), blk(256);

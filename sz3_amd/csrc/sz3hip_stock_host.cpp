@@ -544,13 +544,14 @@ void write_vector(W &w, const std::vector<uint16_t> &v) {
 template <typename T>
 void lorenzo_reg_chain(int N, uint32_t B, double eb, const uint8_t *kind, uint64_t nblocks, T *coef, std::vector<uint16_t> &codes, std::vector<T> &un_indep,
                        std::vector<T> &un_lin) {
+    const size_t CS = N == 4 ? 8 : 4;  // coefficients per block in the array (N + 1 used)
     const double eb_ind = eb / (N + 1), eb_lin = eb / (N + 1) / B;
     const double r_ind = 1.0 / eb_ind, r_lin = 1.0 / eb_lin;
     const int radius = 32768;
     T prev[5] = {0, 0, 0, 0, 0};
     for (uint64_t b = 0; b < nblocks; b++) {
         if (kind[b] != 2) continue;
-        T *c = coef + b * 4;
+        T *c = coef + b * CS;
         for (int i = 0; i < N; i++) {
             const T orig = c[i];
             const int q = quantize_and_overwrite<T>(c[i], prev[i], eb_lin, r_lin, radius);

@@ -3391,6 +3391,7 @@ __global__ __launch_bounds__(256) void k_chunk_bits2(const uint16_t *__restrict_
             if (nc < n_full) fetch_codes(codes, nc * SZH_CHUNK_SYMS + lane_off, narrow, nxt);
             uint16_t c[ENC_PER_LANE];
             unpack_codes(cur, narrow, sym_add, c);
+            // (the packer's form of this lookup — a plain LDS read modulo the window, the rest behind one wave-uniform test — measured slower here: 52.7 against 46 us at C3)
             uint32_t bits = 0;
 #pragma unroll
             for (int i = 0; i < ENC_PER_LANE; i++) bits += len_of(c[i]);
@@ -3547,6 +3548,26 @@ __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE]
     uint64_t g[NG];
     uint32_t gl[NG];
     uint32_t bits = 0;
+    // two-byte codes: all sixteen table entries first, straight from the LDS window (index taken modulo the window: a plain ds_read — the
+    // select between an LDS and a global address per symbol had become a flat load behind two wave-uniform branches, thirty-two branches a
+    // chunk); the symbols outside the window are fetched from the table in memory afterwards, behind ONE wave-uniform test per chunk
+    uint32_t ew[BYTE ? 1 : ENC_PER_LANE];
+    if (!BYTE) {
+        bool outside = false;
+#pragma unroll
+        for (int i = 0; i < ENC_PER_LANE; i++) {
+            const uint32_t rel = (uint32_t)c[i] - sym_min;
+            outside |= rel >= WIN;
+            ew[i] = s_enc[rel & (WIN - 1)];
+        }
+        if (!all_lds && __builtin_amdgcn_ballot_w64(outside)) {
+#pragma unroll
+            for (int i = 0; i < ENC_PER_LANE; i++) {
+                const uint32_t rel = (uint32_t)c[i] - sym_min;
+                if (rel >= WIN) ew[i] = g_enc[c[i]];
+            }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NG; k++) {
         // two code words are joined with 32-bit ops when they are <= 16 bits each, two pairs with one 64-bit shift
@@ -3566,8 +3587,7 @@ __device__ __forceinline__ uint32_t pack_chunk(const uint16_t (&c)[ENC_PER_LANE]
 #endif
                 continue;
             }
-            uint32_t e0 = enc_lookup2<WIN>(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h]);
-            uint32_t e1 = enc_lookup2<WIN>(s_enc, g_enc, sym_min, all_lds, c[G * k + 2 * h + 1]);
+            uint32_t e0 = ew[G * k + 2 * h], e1 = ew[G * k + 2 * h + 1];
             if (check_n) {
                 e0 = (base + G * k + 2 * h < n) ? e0 : 0u;
                 e1 = (base + G * k + 2 * h + 1 < n) ? e1 : 0u;

@@ -15,6 +15,8 @@ lastk=os.environ.get("LASTK","k_publish")
 idx=[i for i,r in enumerate(rows) if lastk in r["Kernel_Name"]]
 back=int(os.environ.get("BACK","4"))
 a,b=idx[-back-1],idx[-back]
+if os.environ.get("NTH"):  # the n-th step from the start instead (warm-up + timed loop come first: no profiling events in those)
+    k=int(os.environ["NTH"]); a,b=idx[k-1],idx[k]
 t0=int(rows[a+1]["Start_Timestamp"])
 end=0
 for r in rows[a+1:b+1]:

@@ -826,14 +826,21 @@ def main():
     # ---- host end-to-end (PCIe + zstd inclusive; informational) ----
     if rank == 0 and world == 1 and not args.no_host_e2e:
         best_c = best_d = 0.0
-        for _ in range(3):  # the first call creates the host API's cached context and pinned staging buffer
+        keep = []  # (the previous call's arrays stay alive: unmapping 0.5 GB is not part of the next call)
+        for _ in range(4):  # the first call creates the host API's cached contexts, pinned staging buffers and host threads
             t0 = time.perf_counter()
-            blob, hratio = sz3_amd.compress(w.a, w.conf)
+            res_c = sz3_amd.compress(w.a, w.conf)
             t1 = time.perf_counter()
-            dec, _ = sz3_amd.decompress(blob, w.npdt, shape)
+            res_d = sz3_amd.decompress(res_c[0], w.npdt, shape)
             t2 = time.perf_counter()
+            blob, hratio = res_c
+            dec = res_d[0]
+            keep.append((res_c, res_d))
+            if len(keep) > 2:
+                keep.pop(0)
             best_c = max(best_c, raw_bytes / (t1 - t0) / 1e9)
             best_d = max(best_d, raw_bytes / (t2 - t1) / 1e9)
+        del keep
         # the same two calls into buffers the caller keeps from call to call (the reference's pre-allocated overloads, api/sz.hpp:43-62,
         # 84-110): a fresh 537 MB array is 131 072 pages touched for the first time inside the device->host copy
         reuse_c = reuse_d = 0.0
@@ -854,8 +861,10 @@ def main():
                            "compress_gbps_buffers_reused": round(reuse_c, 3), "decompress_gbps_buffers_reused": round(reuse_d, 3),
                            "max_abs_err": float(np.max(np.abs(dec.astype(np.float64) - w.a.astype(np.float64)))),
                            "identical_with_reused_buffers": bool(np.array_equal(dec2.reshape(-1), dec.reshape(-1)) and np.array_equal(blob2, blob)),
-                           "note": "host buffer in -> host SZ3 container out: H2D + kernels + D2H + zstd(threads); best of 3 calls. "
-                                   "*_buffers_reused: output buffers the caller allocated once (no first-touch page faults inside the copies)"}
+                           "note": "host buffer in -> host SZ3 container out, fresh output arrays every call: a pipeline of pieces on the one GPU (round 5: copy in of "
+                                   "piece k + 1 beside the kernels of k beside the copy out + zstd of k - 1; the reference's multi-slab container), the decoded array "
+                                   "through a pinned staging ring whose chunks host threads copy on and fault in; best of 4 calls. "
+                                   "*_buffers_reused: output buffers the caller allocated once"}
         del cbuf, dbuf
 
     # ---- the other single-GPU configuration of BASELINE.json, same protocol, as an extra object of the same line ----

@@ -119,11 +119,16 @@ size_t sz3hip_compress_bound(const sz3hip_config *c, int dataType);
  * another slab count; never more slabs than dims[0]); range-based bounds use the global value range (:57-69); the code
  * histograms of all slabs are summed (RCCL all-reduce across GPUs) so that every slab is coded with the same code book;
  * the slabs are stored in the reference's multi-slab container [i32 G][Config x G][u64 size x G][blob x G] (:100-107),
- * every blob what a single-slab call would have produced. */
+ * every blob what a single-slab call would have produced.
+ * Large plain calls (round 5: >= 96 MB, absolute or L2-norm bound, ALGO_LORENZO_REG / ALGO_NOPRED, no conf->openmp) are written in the
+ * same container by ONE GPU as a pipeline of up to 8 pieces — the copy in of piece k + 1 beside the kernels of piece k beside the copy
+ * out + zstd of piece k - 1 —, every piece with its own code book; SZ3HIP_PIECES=0 keeps them whole (INTEGRATION.md sections 6, 7). */
 size_t sz3hip_compress(const sz3hip_config *conf, int dataType, const void *data, char *cmpData, size_t cmpCap);
 /* SZ_decompress<T>(conf, cmpData, cmpSize, decData) (api/sz.hpp:117): conf is overwritten from the trailer;
  * decData must hold conf.num elements (query with sz3hip_peek_config first). Also decodes ALGO_LOSSLESS streams and
- * multi-slab containers (trailer bit openmp; SZ_decompress_OMP, SZImplOMP.hpp:120-186), slab g on GPU g % visible GPUs. */
+ * multi-slab containers (trailer bit openmp; SZ_decompress_OMP, SZImplOMP.hpp:120-186), slab g on GPU g % visible GPUs; with one GPU
+ * the slabs are unpacked and decoded side by side and copied out in order. Arrays of 32 MB and more leave the device through a ring
+ * of pinned staging buffers whose chunks host threads copy on into decData (a fresh array's pages are faulted in by those threads). */
 int sz3hip_decompress(sz3hip_config *conf, int dataType, const char *cmpData, size_t cmpSize, void *decData);
 /* One algorithm of the reference's dispatcher (SZ_compress_LorenzoReg / SZ_compress_Interp / ..., SZDispatcher.hpp:28-42 and
  * their SZ_decompress_* counterparts :89-99): only the bytes between the container's 16-byte header and its Config trailer.

@@ -130,3 +130,42 @@ def test_the_pipelined_decoder_at_its_size_and_with_damaged_pieces(monkeypatch):
     bi, _ = sz3_amd.compress(ai, ci)
     di, c5 = sz3_amd.decompress(bi, np.int32, shape)
     assert c5.openmp == 1 and int(np.max(np.abs(di.astype(np.int64) - ai.astype(np.int64)))) <= 2
+
+
+def test_pipelined_calls_beside_small_calls_from_other_threads(monkeypatch):
+    """a pipelined call takes the host API exclusively, small calls share it: four threads compressing and decompressing small arrays
+    while the main thread sends a large one through the pieces twice — nobody waits forever, everybody gets the right values (the pool of
+    host threads and the staging ring are shared by all of them)"""
+    import threading
+    monkeypatch.setenv("SZ3HIP_PIECES", "4")
+    big = field3d((256, 256, 256))
+    small = [field3d((40 + 8 * k, 48, 56), seed=100 + k) for k in range(4)]
+    errs = []
+
+    def worker(k):
+        try:
+            for _ in range(6):
+                a = small[k]
+                c = sz3_amd.Config(*a.shape)
+                c.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+                c.regression = 0
+                c.absErrorBound = 1e-3
+                b, _ = sz3_amd.compress(a, c)
+                d, _ = sz3_amd.decompress(b, np.float32, a.shape)
+                if float(np.max(np.abs(d.astype(np.float64) - a.astype(np.float64)))) > 1e-3:
+                    errs.append("bound %d" % k)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    conf = _conf(big.shape, 1e-3, regression=0)
+    for _ in range(2):
+        blob, _ = sz3_amd.compress(big, conf)
+        dec, c2 = sz3_amd.decompress(blob, np.float32, big.shape)
+        assert c2.openmp == 1 and float(np.max(np.abs(dec.astype(np.float64) - big.astype(np.float64)))) <= 1e-3
+    for t in th:
+        t.join(120)
+        assert not t.is_alive(), "a small call never came back"
+    assert not errs, errs

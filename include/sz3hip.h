@@ -270,7 +270,8 @@ void sz3hip_debug_force_generic(int on);
  * histogram with the large tier and the windowed tail passes, 16384 predictor sets with Lorenzo-2 / regression fall back
  * to plain Lorenzo (no block path), 131072 contexts do not remember the previous call's code width / code-book form,
  * 262144 round-parallel Huffman merge for small alphabets, 2097152 Lorenzo decoder without half-width intermediates,
- * 4194304 interpolation level kernels whatever the array's size (normally from 256 blocks up). The 3-D block decoder (blocks of
+ * 4194304 interpolation level kernels whatever the array's size (normally from 256 blocks up), 536870912 the level kernels hand the grid of
+ * stride 2 over in place (round 5's default: as a dense array — no partial-line stores at the level of stride 2, no strided gather at the finest). The 3-D block decoder (blocks of
  * 6^3; the product path is ONE launch for the chain of fronts, k_blk_wave3, after a local pass straight from the codes): 16 the
  * local pass a wave per block from an expanded copy of the deltas, 32768 groups of 3 x 3 x 3 blocks in closed form with a launch
  * per front (also what a one-launch decoder whose flag poll gave up falls back to), 8388608 a block per wave (65536 — round 3's groups

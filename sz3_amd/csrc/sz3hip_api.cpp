@@ -210,7 +210,7 @@ static hipError_t clear_hist_counters(sz3hip_ctx *c, hipStream_t s) {
 }
 static void ctx_free(sz3hip_ctx *c) {
     if (!c) return;
-    void *bufs[] = {c->d_work, c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
+    void *bufs[] = {c->d_dense2, c->d_work, c->d_hist_partial, c->d_codes, c->d_hist_own, c->d_vout_idx, c->d_dout_idx, c->d_vout_val, c->d_dout_val,
                     c->d_enc, c->d_lens, c->d_keys, c->d_ifreq, c->d_syms, c->d_pleaf, c->d_pint, c->d_depth, c->d_aux2, c->d_pint2, c->d_range, c->d_info,
                     c->d_chunk_words, c->d_chunk_off, c->d_carry, c->d_state, c->d_tables, c->d_segtot, c->d_minmax, c->d_samples, c->d_trial_work, c->d_trial_codes,
                     c->d_trial, c->d_passes, c->d_np,  // (d_trial_counters / d_trial_hist live inside d_trial's block)
@@ -520,6 +520,23 @@ static int stage1_interp(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
     ip.hist_tail = ctx->hist_tail > 0 || (szk_dbg_flags & 8192) ? 1u : 0u;
     if (szk_dbg_flags & 8192) ip.hist_big = 1;  // (test hook: large tier + tail passes whatever the history)
     ip.far_cnt = reinterpret_cast<uint32_t *>(ctx->d_counters + 6);  // (zeroed with the counters, fetched with the probe words)
+    ip.dense2 = nullptr;
+    ip.dense2_elems = 0;
+    if (conf->N == 3 && !ctx->copy_ahead && szk_interp_levels_ok(&ip) && !(szk_dbg_flags & 536870912)) {
+        // the level kernels hand the grid of stride 2 over as a dense array (sz3hip_interp.hip, szk_interp_level::dense): room for it
+        const size_t need = (size_t)(((conf->dims[0] - 1) / 2 + 1) * ((conf->dims[1] - 1) / 2 + 1) * ((conf->dims[2] - 1) / 2 + 1));
+        if (ctx->dense2_elems < need) {
+            if (ctx->d_dense2) (void)hipFree(ctx->d_dense2);
+            ctx->d_dense2 = nullptr;
+            ctx->dense2_elems = 0;
+            if (hipMalloc(&ctx->d_dense2, need * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)) == hipSuccess) ctx->dense2_elems = need;
+            else (void)hipGetLastError();  // (no room: the hand-over stays in place)
+        }
+        if (ctx->dense2_elems >= need) {
+            ip.dense2 = ctx->d_dense2;
+            ip.dense2_elems = ctx->dense2_elems;
+        }
+    }
     prof_begin(ctx, ST_K1, s);
     int rci = szk_launch_interp_compress(ctx->dtype, &ip, ctx->copy_ahead ? nullptr : d_in, ctx->d_work, ctx->d_codes, ctx->d_hist, s);
     ctx->copy_ahead = false;

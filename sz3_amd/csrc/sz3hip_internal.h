@@ -68,6 +68,8 @@ struct sz3hip_ctx {
     uint64_t *d_hist_own;  // internal allocation
     uint64_t *d_counters;  // [0]=n_vout [1]=n_dout [2]=total_words [3]=decoder [4..6]=probe words [8..9]=code book's symbol range (inside d_hist_own's block)
     uint32_t *d_hist_partial;
+    void *d_dense2;        // interpolation, compression with the level kernels (round 5): the grid of stride 2 as a dense array (lazy, max_n / 8 + its faces)
+    size_t dense2_elems;
     void *d_work;          // interpolation: the array being overwritten with reconstructed values (lazy);
                            // block-composed predictor: the lattice values q~ the Lorenzo stencils run on
     // block-composed predictor (sz3hip_regress.hip), allocated on first use for the call's block count

@@ -402,6 +402,12 @@ struct szk_interp_level {
     int interp_id, radius, no_store;
     int pair;          // decoder, finest level, x last, rows of even length: the last pass stores (even, odd) pairs, the earlier ones nothing
     double eb, eb_recip;
+    // Compression, round 5: the hand-over between two levels through a DENSE array of the coarser level's grid. In place, the level of
+    // stride 2 stores its reconstruction 4 bytes here, 4 bytes not — partial lines that the memory system reads, merges and writes back
+    // (54 of that launch's 144 us at C3) — and the finest level gathers its coarse points with a stride of two elements.
+    const void *coarse;  // this level's coarse points (the grid of stride 2 s) as a dense array with the strides coff[]; nullptr: from w
+    void *dense;         // this level's reconstruction and the coarse points it loaded go to a dense array of ITS grid, strides doff[]; nullptr: into w
+    uint32_t coff[2], doff[2];
 };
 #define LV_MAIN (33 * 33 * 17)
 #define LV_SIDE (33 * 33)
@@ -481,6 +487,8 @@ struct LvPass {
     int defer, no_store, radius, pair;
     uint32_t n2;
     double eb, eb_recip;
+    T *dn;                      // compression: the level's reconstruction goes here (a dense array of the level's grid, at the block's origin) instead of wb
+    uint32_t eX, eU, eW, estep;  // its element strides inside the block
 };
 
 // SLIDE: the walk runs along the pass axis (sliding stencil); CUBIC: interp_id 1; LASTP: last pass of the level (its points
@@ -498,6 +506,7 @@ __device__ __forceinline__ void lv_items(const LvPass<T> &q, uint32_t tid, int s
         if (!SLIDE && !CUBIC && (q.defer && iX + 1 == q.na) != (sub != 0)) continue;  // (pass along x: a row's deferred point is an item's)
         int addr = (int)((iW >> q.hW) * q.strW + (iU >> q.hU) * q.strU + (iX >> q.hX));  // the point (passes 0, 1) or its lower neighbour
         uint32_t go = iW * q.gW + iU * q.gU + iX * q.gX;
+        uint32_t gd = iW * q.eW + iU * q.eU + iX * q.eX;  // (the same point in the dense array, when there is one)
         const bool own_item = LASTP || (iU < q.ownU_lim && iX < q.ownX_lim);
         T wm3 = (T)0, wm1 = (T)0, wp1 = (T)0, prev = (T)0;
         if (SLIDE) {  // (addresses outside the line fall back to a valid one: the rules do not use what they return)
@@ -561,7 +570,10 @@ __device__ __forceinline__ void lv_items(const LvPass<T> &q, uint32_t tid, int s
                 const int code = lv_quantize<T>(v, pred, q.eb, q.eb_recip, q.radius);
                 if (owned) {
                     q.cb[go] = (uint16_t)code;
-                    if (!q.no_store) q.wb[go] = v;
+                    if (!q.no_store) {
+                        if (q.dn) q.dn[gd] = v;
+                        else q.wb[go] = v;
+                    }
                 }
             }
             if (!LASTP) L[addr] = v;
@@ -570,6 +582,7 @@ __device__ __forceinline__ void lv_items(const LvPass<T> &q, uint32_t tid, int s
             iW += q.spW;
             addr += (int)q.dW;
             go += q.gstep;
+            gd += q.estep;
         };
         fetch();
         uint32_t c = 0;
@@ -626,6 +639,8 @@ __global__ __launch_bounds__(LV_NT) void k_interp_level(const T *__restrict__ in
         for (uint32_t base = tid; base < total; base += 4 * LV_NT) {
             T v[4];
             int ad[4];
+            bool own[4] = {false, false, false, false};
+            uint64_t da[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t t = base + u * LV_NT;
@@ -633,13 +648,21 @@ __global__ __launch_bounds__(LV_NT) void k_interp_level(const T *__restrict__ in
                 if (t < total) {
                     const uint32_t q2 = lv_div(t, e2, mg_e2), l2 = t - q2 * e2;
                     const uint32_t l0 = lv_div(q2, e1, mg_e1), l1 = q2 - l0 * e1;
-                    v[u] = w[gbase + (uint64_t)(2 * l0) * gs0 + (uint64_t)(2 * l1) * gs1 + (uint64_t)(2 * l2 * p.s)];
+                    if (!DEC && p.coarse)  // (the dense array of the coarser grid: this block's origin there is half its origin here)
+                        v[u] = reinterpret_cast<const T *>(p.coarse)[(uint64_t)(t0 * 16 + l0) * p.coff[0] + (uint64_t)(t1 * 16 + l1) * p.coff[1] + (t2 * 16 + l2)];
+                    else v[u] = w[gbase + (uint64_t)(2 * l0) * gs0 + (uint64_t)(2 * l1) * gs1 + (uint64_t)(2 * l2 * p.s)];
                     ad[u] = (int)(l0 * k0 + l1 * k1 + l2 * k2);
+                    own[u] = (2 * l0 < 32 || last0) && (2 * l1 < 32 || last1) && (2 * l2 < 32 || last2);
+                    da[u] = (uint64_t)(t0 * 32 + 2 * l0) * p.doff[0] + (uint64_t)(t1 * 32 + 2 * l1) * p.doff[1] + (t2 * 32 + 2 * l2);
                 }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++)
-                if (ad[u] >= 0) L[ad[u]] = v[u];
+                if (ad[u] >= 0) {
+                    L[ad[u]] = v[u];
+                    // the coarse points belong to this level's grid too: whoever reads the dense array finds them there (written by their owners)
+                    if (!DEC && p.dense && own[u]) reinterpret_cast<T *>(p.dense)[da[u]] = v[u];
+                }
         }
     }
     for (int k = 0; k < 3; k++) {
@@ -718,6 +741,14 @@ __global__ __launch_bounds__(LV_NT) void k_interp_level(const T *__restrict__ in
         q.ownW_lim = lastW ? nW : nW - 1;
         q.defer = defer; q.no_store = p.no_store; q.radius = p.radius; q.pair = p.pair; q.n2 = n2;
         q.eb = p.eb; q.eb_recip = p.eb_recip;
+        q.dn = nullptr; q.eX = q.eU = q.eW = q.estep = 0;
+        if (!DEC && p.dense) {  // the block's origin in the dense array of this level's grid, the strides of the walk there (x: 1)
+            q.dn = reinterpret_cast<T *>(p.dense) + ((uint64_t)(t0 * 32) * p.doff[0] + (uint64_t)(t1 * 32) * p.doff[1] + t2 * 32);
+            q.eX = 1;
+            q.eU = U == 0 ? p.doff[0] : p.doff[1];
+            q.eW = W == 0 ? p.doff[0] : p.doff[1];
+            q.estep = spW * q.eW;
+        }
         const bool cubic = p.interp_id != 0;
         const bool full = cubic && na == 33;
         if (slide) {
@@ -1164,7 +1195,7 @@ static uint64_t level_blocks(const szk_interp_pass &p) {
     return tiles;
 }
 template <typename T, bool DEC>
-static int launch_level(const szk_interp_pass &p, const int *perm, const T *in, T *w, uint16_t *codes, hipStream_t s) {
+static int launch_level(const szk_interp_pass &p, const int *perm, const T *in, T *w, uint16_t *codes, hipStream_t s, const T *coarse = nullptr, T *dense = nullptr) {
     static const LvMagic mg = lv_magic_host();
     szk_interp_level L;
     memset(&L, 0, sizeof(L));
@@ -1185,6 +1216,17 @@ static int launch_level(const szk_interp_pass &p, const int *perm, const T *in, 
     L.pair = DEC && sizeof(T) == 4 && p.s == 1 && perm[2] == 2 && p.dims[2] % 2 == 0 && (reinterpret_cast<uintptr_t>(w) & 7) == 0;
     L.eb = p.eb;
     L.eb_recip = p.eb_recip;
+    if (!DEC && dense) {  // this level's grid as a dense array (strides of the two slower dimensions)
+        L.dense = dense;
+        L.doff[0] = L.g[1] * L.g[2];
+        L.doff[1] = L.g[2];
+    }
+    if (!DEC && coarse) {  // the coarser level's grid, dense: (D - 1) / (2 s) + 1 points per dimension
+        L.coarse = coarse;
+        const uint32_t c1 = (uint32_t)((p.dims[1] - 1) / (2 * p.s) + 1), c2 = (uint32_t)((p.dims[2] - 1) / (2 * p.s) + 1);
+        L.coff[0] = c1 * c2;
+        L.coff[1] = c2;
+    }
     const size_t lds = (size_t)(LV_MAIN + LV_SIDE) * sizeof(T);
     // (per device, and a context may sit on any of them: asked for at every launch, a host-side table lookup)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_interp_level<T, DEC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1202,12 +1244,26 @@ static int run_interp(const szk_interp_params &ip, const T *in, T *w, uint16_t *
     int perm[4];
     nth_permutation(ip.N, ip.direction, perm);
     uint64_t level_done = 0;  // stride of the level the last level launch covered
+    // compression: the level of stride 2 hands its grid to the finest level as a dense array when both run as level launches and the
+    // caller gave room for it (szk_interp_params::dense2)
+    bool dense2 = false;
+    if (!DEC && levels && ip.dense2 && ip.N == 3) {
+        bool l1 = false, l2 = false;
+        for (const szk_interp_pass &p : sched)
+            if (p.kind == 2 && level_blocks(p) >= (uint64_t)szk_interp_min_blocks) {
+                l1 |= p.s == 1;
+                l2 |= p.s == 2;
+            }
+        const uint64_t need = ((ip.dims[0] - 1) / 2 + 1) * ((ip.dims[1] - 1) / 2 + 1) * ((ip.dims[2] - 1) / 2 + 1);
+        dense2 = l1 && l2 && need <= ip.dense2_elems;
+    }
     for (const szk_interp_pass &p : sched) {
         const uint32_t nb = (uint32_t)((p.total + 255) / 256);
         if (levels && p.kind == 2 && level_blocks(p) >= (uint64_t)szk_interp_min_blocks) {
             if (p.s == level_done) continue;  // the other passes of a level already launched
             level_done = p.s;
-            const int rc = launch_level<T, DEC>(p, perm, in, w, codes, s);
+            const int rc = launch_level<T, DEC>(p, perm, in, w, codes, s, dense2 && p.s == 1 ? reinterpret_cast<const T *>(ip.dense2) : (const T *)nullptr,
+                                                dense2 && p.s == 2 ? reinterpret_cast<T *>(ip.dense2) : (T *)nullptr);
             if (rc) return rc;
             continue;
         }

@@ -291,6 +291,9 @@ struct szk_interp_params {  // what InterpolationDecomposition keeps (decomposit
     uint32_t hist_big;   // histogram pass with the 16384-bin second tier (host choice, from the previous call's far count)
     uint32_t hist_tail;  // with hist_big: the codes beyond +-8192 are counted by three windowed passes in LDS (k_hist_tail)
     uint32_t *far_cnt;   // [0] receives the number of codes outside +-4096 of the radius, [1] (hist_big form) outside +-8192
+    void *dense2;        // compression with the level kernels (round 5): room for the grid of stride 2 as a dense array — the level of stride 2 leaves
+                         // its reconstruction (and the coarse points it loaded) there, the finest level reads its coarse points from there; nullptr: in place
+    uint64_t dense2_elems;
 };
 struct szk_interp_pass {
     int N, dir, interp_id, old_api, subpass, radius;

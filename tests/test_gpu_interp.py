@@ -244,3 +244,37 @@ def test_histogram_tail_passes_change_nothing(dtype, eb):
     assert res[0].numel() == res[1].numel() and torch.equal(res[0], res[1])
     st = dc.stats()
     assert st["n_value_outliers"] < 32768 and st["max_code_len"] > 12  # (the spread is real: thousands of distinct symbols)
+
+
+@pytest.mark.parametrize("shape,dtype,algo", [((70, 81, 93), np.float32, 1), ((97, 64, 130), np.float32, 0), ((66, 67, 65), np.float64, 1), ((33, 130, 34), np.float32, 1)])
+def test_dense_hand_over_between_the_two_finest_levels_changes_nothing(shape, dtype, algo):
+    """round 5: when the levels of stride 2 and 1 both run as level launches, the coarser one leaves its grid in a dense array and the
+    finest reads its coarse points from there (no partial-line stores, no strided gather). Same payload, byte for byte, as the
+    hand-over in place (debug flag 536870912); level launches forced on these small arrays (flag 4194304); every direction order that
+    puts another axis last, linear and cubic, ragged extents, f64"""
+    import torch
+    dev = torch.device("cuda:0")
+    a = field3d(shape, dtype) if dtype == np.float32 else field3d(shape, dtype, sigma=2e-6)
+    eb = 1e-3 if dtype == np.float32 else 1e-6
+    st = torch.cuda.current_stream().cuda_stream
+    d_in = torch.from_numpy(a).to(dev)
+    for direction in (0, 3, 5):
+        conf = sz3_amd.Config(*shape)
+        conf.cmprAlgo = sz3_amd.ALGO_INTERP
+        conf.absErrorBound = eb
+        conf.interpAlgo = algo
+        conf.interpDirection = direction
+        outs = {}
+        for flag in (4194304 | 536870912, 4194304):
+            dc = sz3_amd.DeviceCompressor(a.size, a.dtype, device=0)
+            dc.set_deterministic(True)
+            cap = dc.payload_bound(a.size, worst_case=True)
+            d_pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+            sz3_amd.lib().sz3hip_debug_flags(flag)
+            try:
+                size = dc.compress(conf, d_in.data_ptr(), d_pl.data_ptr(), cap, st)
+            finally:
+                sz3_amd.lib().sz3hip_debug_flags(0)
+            torch.cuda.synchronize()
+            outs[flag] = d_pl[:size].cpu().numpy().copy()
+        assert np.array_equal(outs[4194304], outs[4194304 | 536870912]), "the dense hand-over changed the payload (direction %d)" % direction

@@ -507,6 +507,24 @@ static void cb_params_from(sz3hip_ctx *ctx, szk_cb_params &cb, uint64_t out_cap,
     cb.mispredict = reinterpret_cast<uint32_t *>(ctx->d_counters + 7);  // (zeroed with the counters)
 }
 
+// the level kernels hand the grid of stride 2 over as a dense array (sz3hip_interp.hip, szk_interp_level::dense): room for it in the context
+static void dense2_for(sz3hip_ctx *ctx, szk_interp_params &ip) {
+    ip.dense2 = nullptr;
+    ip.dense2_elems = 0;
+    if (ip.N != 3 || !szk_interp_levels_ok(&ip) || (szk_dbg_flags & 536870912)) return;
+    const size_t need = (size_t)(((ip.dims[0] - 1) / 2 + 1) * ((ip.dims[1] - 1) / 2 + 1) * ((ip.dims[2] - 1) / 2 + 1));
+    if (ctx->dense2_elems < need) {
+        if (ctx->d_dense2) (void)hipFree(ctx->d_dense2);
+        ctx->d_dense2 = nullptr;
+        ctx->dense2_elems = 0;
+        if (hipMalloc(&ctx->d_dense2, need * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)) == hipSuccess) ctx->dense2_elems = need;
+        else (void)hipGetLastError();  // (no room: the hand-over stays in place)
+    }
+    if (ctx->dense2_elems >= need) {
+        ip.dense2 = ctx->d_dense2;
+        ip.dense2_elems = ctx->dense2_elems;
+    }
+}
 static int stage1_interp(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint64_t num, hipStream_t s) {
     if (!ctx->d_work) HIPCHK(hipMalloc(&ctx->d_work, ctx->max_n * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)));
     szk_interp_params ip;
@@ -520,23 +538,7 @@ static int stage1_interp(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
     ip.hist_tail = ctx->hist_tail > 0 || (szk_dbg_flags & 8192) ? 1u : 0u;
     if (szk_dbg_flags & 8192) ip.hist_big = 1;  // (test hook: large tier + tail passes whatever the history)
     ip.far_cnt = reinterpret_cast<uint32_t *>(ctx->d_counters + 6);  // (zeroed with the counters, fetched with the probe words)
-    ip.dense2 = nullptr;
-    ip.dense2_elems = 0;
-    if (conf->N == 3 && !ctx->copy_ahead && szk_interp_levels_ok(&ip) && !(szk_dbg_flags & 536870912)) {
-        // the level kernels hand the grid of stride 2 over as a dense array (sz3hip_interp.hip, szk_interp_level::dense): room for it
-        const size_t need = (size_t)(((conf->dims[0] - 1) / 2 + 1) * ((conf->dims[1] - 1) / 2 + 1) * ((conf->dims[2] - 1) / 2 + 1));
-        if (ctx->dense2_elems < need) {
-            if (ctx->d_dense2) (void)hipFree(ctx->d_dense2);
-            ctx->d_dense2 = nullptr;
-            ctx->dense2_elems = 0;
-            if (hipMalloc(&ctx->d_dense2, need * (ctx->dtype == SZ3HIP_FLOAT ? 4 : 8)) == hipSuccess) ctx->dense2_elems = need;
-            else (void)hipGetLastError();  // (no room: the hand-over stays in place)
-        }
-        if (ctx->dense2_elems >= need) {
-            ip.dense2 = ctx->d_dense2;
-            ip.dense2_elems = ctx->dense2_elems;
-        }
-    }
+    if (!ctx->copy_ahead) dense2_for(ctx, ip);
     prof_begin(ctx, ST_K1, s);
     int rci = szk_launch_interp_compress(ctx->dtype, &ip, ctx->copy_ahead ? nullptr : d_in, ctx->d_work, ctx->d_codes, ctx->d_hist, s);
     ctx->copy_ahead = false;
@@ -2019,6 +2021,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
         ip.beta = h.interp_beta;
         ip.eb = h.eb;
         ip.radius = (int)h.radius;
+        dense2_for(ctx, ip);
         rc = szk_launch_interp_decompress(ctx->dtype, &ip, pl, o.vout_idx, o.vout_val, h.n_vout, ctx->d_codes, d_out, s);
     } else if (h.predictor == 2) {
         // codes -> deltas, then the blocks in anti-diagonal fronts once the side stream has the choices and coefficients

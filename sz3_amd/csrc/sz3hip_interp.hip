@@ -562,6 +562,10 @@ __device__ __forceinline__ void lv_items(const LvPass<T> &q, uint32_t tid, int s
                     } else if (owned && iX + 1 == q.n2) {
                         q.wb[go] = v;
                     }
+                } else if (q.dn) {
+                    // (decoder, the level of stride 2 under a finest level that stores whole pairs: that level writes these positions
+                    // again from the dense array — nothing goes to the output here, 4 bytes in 16 of its lines)
+                    if (owned) q.dn[gd] = v;
                 } else if (owned && code_in) {
                     q.wb[go] = v;
                 }
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(LV_NT) void k_interp_level(const T *__restrict__ in
                 if (t < total) {
                     const uint32_t q2 = lv_div(t, e2, mg_e2), l2 = t - q2 * e2;
                     const uint32_t l0 = lv_div(q2, e1, mg_e1), l1 = q2 - l0 * e1;
-                    if (!DEC && p.coarse)  // (the dense array of the coarser grid: this block's origin there is half its origin here)
+                    if (p.coarse)  // (the dense array of the coarser grid: this block's origin there is half its origin here)
                         v[u] = reinterpret_cast<const T *>(p.coarse)[(uint64_t)(t0 * 16 + l0) * p.coff[0] + (uint64_t)(t1 * 16 + l1) * p.coff[1] + (t2 * 16 + l2)];
                     else v[u] = w[gbase + (uint64_t)(2 * l0) * gs0 + (uint64_t)(2 * l1) * gs1 + (uint64_t)(2 * l2 * p.s)];
                     ad[u] = (int)(l0 * k0 + l1 * k1 + l2 * k2);
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(LV_NT) void k_interp_level(const T *__restrict__ in
                 if (ad[u] >= 0) {
                     L[ad[u]] = v[u];
                     // the coarse points belong to this level's grid too: whoever reads the dense array finds them there (written by their owners)
-                    if (!DEC && p.dense && own[u]) reinterpret_cast<T *>(p.dense)[da[u]] = v[u];
+                    if (p.dense && own[u]) reinterpret_cast<T *>(p.dense)[da[u]] = v[u];
                 }
         }
     }
@@ -742,7 +746,7 @@ __global__ __launch_bounds__(LV_NT) void k_interp_level(const T *__restrict__ in
         q.defer = defer; q.no_store = p.no_store; q.radius = p.radius; q.pair = p.pair; q.n2 = n2;
         q.eb = p.eb; q.eb_recip = p.eb_recip;
         q.dn = nullptr; q.eX = q.eU = q.eW = q.estep = 0;
-        if (!DEC && p.dense) {  // the block's origin in the dense array of this level's grid, the strides of the walk there (x: 1)
+        if (p.dense) {  // the block's origin in the dense array of this level's grid, the strides of the walk there (x: 1)
             q.dn = reinterpret_cast<T *>(p.dense) + ((uint64_t)(t0 * 32) * p.doff[0] + (uint64_t)(t1 * 32) * p.doff[1] + t2 * 32);
             q.eX = 1;
             q.eU = U == 0 ? p.doff[0] : p.doff[1];
@@ -1216,12 +1220,12 @@ static int launch_level(const szk_interp_pass &p, const int *perm, const T *in, 
     L.pair = DEC && sizeof(T) == 4 && p.s == 1 && perm[2] == 2 && p.dims[2] % 2 == 0 && (reinterpret_cast<uintptr_t>(w) & 7) == 0;
     L.eb = p.eb;
     L.eb_recip = p.eb_recip;
-    if (!DEC && dense) {  // this level's grid as a dense array (strides of the two slower dimensions)
+    if (dense) {  // this level's grid as a dense array (strides of the two slower dimensions)
         L.dense = dense;
         L.doff[0] = L.g[1] * L.g[2];
         L.doff[1] = L.g[2];
     }
-    if (!DEC && coarse) {  // the coarser level's grid, dense: (D - 1) / (2 s) + 1 points per dimension
+    if (coarse) {  // the coarser level's grid, dense: (D - 1) / (2 s) + 1 points per dimension
         L.coarse = coarse;
         const uint32_t c1 = (uint32_t)((p.dims[1] - 1) / (2 * p.s) + 1), c2 = (uint32_t)((p.dims[2] - 1) / (2 * p.s) + 1);
         L.coff[0] = c1 * c2;
@@ -1247,7 +1251,9 @@ static int run_interp(const szk_interp_params &ip, const T *in, T *w, uint16_t *
     // compression: the level of stride 2 hands its grid to the finest level as a dense array when both run as level launches and the
     // caller gave room for it (szk_interp_params::dense2)
     bool dense2 = false;
-    if (!DEC && levels && ip.dense2 && ip.N == 3) {
+    // (decoder: only under a finest level that stores whole (even, odd) pairs — it then writes the grid of stride 2 itself, from the dense array)
+    const bool dec_pairs = sizeof(T) == 4 && perm[2] == 2 && ip.dims[2] % 2 == 0 && (reinterpret_cast<uintptr_t>(w) & 7) == 0;
+    if ((!DEC || dec_pairs) && levels && ip.dense2 && ip.N == 3) {
         bool l1 = false, l2 = false;
         for (const szk_interp_pass &p : sched)
             if (p.kind == 2 && level_blocks(p) >= (uint64_t)szk_interp_min_blocks) {

@@ -50,7 +50,7 @@ if os.path.exists(c3):
     # stage 1 per step: the compression-side interpolation kernels + the code histogram; launches per step from the kernel
     # statistics of the same bench command (k_hist_codes runs once per compression)
     import csv
-    stats = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05b_kernel_stats_c3.csv", "r05_kernel_stats_c3.csv", "r03_kernel_stats_c3.csv", "r02_kernel_stats_c3.csv"))
+    stats = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05c_kernel_stats_c3.csv", "r05b_kernel_stats_c3.csv", "r05_kernel_stats_c3.csv", "r03_kernel_stats_c3.csv", "r02_kernel_stats_c3.csv"))
                   if os.path.exists(q)), "")
     if os.path.exists(stats):
         calls = {r["Name"]: int(r["Calls"]) for r in csv.DictReader(open(stats))}
@@ -117,6 +117,6 @@ out["method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pa
                  "WRITE_SIZE taken as reported (checks out: stage 1 writes 1 B/elem of codes = 134 MB, counter says 135 MB); counters are in KB (x1024). "
                  "For k_decode (4-byte loads scattered over 64 lines per wave) the doubling over-counts. valu_issue_us = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / 2.1 GHz: "
                  "the time the vector ALUs need to issue the kernel's instructions (a wave64 instruction occupies a 16-lane SIMD for 4 cycles). "
-                 "Generated by tools/pmc_traffic.py from profiles/r05b_pmc_summary.txt (C2, round 5) and profiles/r05b_pmc_summary_c3.txt (C3, round 5: tools/pmc_c3.sh; launches per step from profiles/r05b_kernel_stats_c3.csv).")
+                 "Generated by tools/pmc_traffic.py from profiles/r05b_pmc_summary.txt (C2, round 5) and profiles/r05c_pmc_summary_c3.txt (C3, round 5 with the dense hand-over between the two finest levels: tools/pmc_c3.sh; launches per step from profiles/r05c_kernel_stats_c3.csv).")
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:600])

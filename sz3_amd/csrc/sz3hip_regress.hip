@@ -584,7 +584,8 @@ __global__ __launch_bounds__(256) void k_blk_lattice(const T *__restrict__ in, s
 // 1593 without the lattice stores, 1558 without the selection, 1244 without the fit and the regression blocks; the seven wave
 // sums on DPP instead of ds_bpermute butterflies 1780 -> 1704. No single piece dominates: ~800 wave instructions per block.
 template <typename T, uint32_t HW, int CB, int NW>
-__global__ __launch_bounds__(NW * 64) void k_blk_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks) {
+__global__ __launch_bounds__(NW * 64) void k_blk_fit(const T *__restrict__ in, uint16_t *__restrict__ codes, szk_blk_params p, uint32_t nblocks,
+                                                     const uint32_t *__restrict__ comp = nullptr, const uint64_t *__restrict__ n_reg = nullptr) {
     using Q = typename QTraits<T>::Q;
     __shared__ T s_x[NW][CB ? (CB + 2) * (CB + 2) * (CB + 2) : BLK_TILE];
     __shared__ uint32_t lh[HW + 1];  // (+ the count of code 0: blk_count)
@@ -597,8 +598,12 @@ __global__ __launch_bounds__(NW * 64) void k_blk_fit(const T *__restrict__ in, u
     const uint32_t B = CB ? (uint32_t)CB : p.B, E = B + 2;
     const uint64_t d1 = p.d[1], d2 = p.d[2];
     const TileView tv{E * E, E, 0};
-    for (uint32_t task = blockIdx.x * NW + wv; task < nblocks; task += gridDim.x * NW) {
-        if (p.sel_given && p.sel[task] != 2) continue;  // (not a regression block: k_blk_lattice wrote its lattice values)
+    // With the list of the regression blocks at hand (comp, made by the rank pass in front of this launch: round 5) a wave walks that list —
+    // walking all blocks and skipping 86 % of them at C4a was a dependent one-byte load per skipped block, 135 of them per wave for 22 blocks of work.
+    const uint32_t n_items = comp ? (uint32_t)*n_reg : nblocks;
+    for (uint32_t item = blockIdx.x * NW + wv; item < n_items; item += gridDim.x * NW) {
+        const uint32_t task = comp ? comp[item] : item;
+        if (!comp && p.sel_given && p.sel[task] != 2) continue;  // (not a regression block: k_blk_lattice wrote its lattice values)
         const BlkGeom g = blk_geom(p, task);
         if (p.sel_given) {
             // a regression block coded from the selection pass's coefficients: its own elements are all it reads (no estimates, no halo)
@@ -5013,7 +5018,7 @@ __global__ __launch_bounds__(256) void k_trial_lorenzo12(const T *__restrict__ s
 // ------------------------------------------------------------------------------------------------------------
 static uint32_t blk_count_blocks(const szk_blk_params *p) { return p->nb[0] * p->nb[1] * p->nb[2] * (p->nbw ? p->nbw : 1u); }
 
-static int launch_blk_side_build(const szk_blk_params *p, const szk_blk_scratch *sc, uint32_t nblocks, hipStream_t s);
+static int launch_blk_side_build(const szk_blk_params *p, const szk_blk_scratch *sc, uint32_t nblocks, hipStream_t s, bool rank_done = false);
 // arrays of one and two dimensions: fit / selection / regression blocks, then the Lorenzo codes over q~
 static int launch_blkn_compress(int dtype, const void *d_in, uint16_t *codes, const szk_blk_params *p, const szk_blk_scratch *sc, hipStream_t s) {
     const uint32_t nblocks = blk_count_blocks(p);
@@ -5104,6 +5109,9 @@ int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const 
     // lattice values of everything through qwork, Lorenzo blocks from tiles.
     const bool by_element = p->sel_given && !(p->mask & 2u) && !(szk_dbg_flags & 67108864);  // (k_blk_rows: first-order Lorenzo only)
     const uint64_t nrows = p->d[0] * p->d[1];
+    // the regression blocks' list before the fit pass walks it (the side section wants the same ranks afterwards: made once)
+    const bool rank_first = p->sel_given && !(szk_dbg_flags & 1073741824);
+    if (rank_first) launch_blk_rank(p->sel, nblocks, sc->rank, sc->comp, sc->run_scratch, sc->counters + 0, s);
     if (p->sel_given && !by_element) {
         const dim3 g((uint32_t)((p->d[2] + 255) / 256), (uint32_t)std::min<uint64_t>(nrows, 32768));
         if (dtype == 0) hipLaunchKernelGGL(k_blk_lattice<float>, g, dim3(256), 0, s, (const float *)d_in, *p, nrows);
@@ -5112,7 +5120,9 @@ int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const 
 #define BLK_ENC1(T, HW, CBV, NW)                                                                                                       \
     do {                                                                                                                               \
         const uint32_t grid = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                        \
-        hipLaunchKernelGGL((k_blk_fit<T, HW, CBV, NW>), dim3(grid), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks);          \
+        hipLaunchKernelGGL((k_blk_fit<T, HW, CBV, NW>), dim3(grid), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks,           \
+                           rank_first ? (const uint32_t *)sc->comp : (const uint32_t *)nullptr,                                          \
+                           rank_first ? (const uint64_t *)(sc->counters + 0) : (const uint64_t *)nullptr);                               \
         if (by_element) {                                                                                                              \
             const uint32_t tpb = (252u / p->B) * p->B, xchunks = (uint32_t)((p->d[2] + tpb - 1) / tpb);                                  \
             const uint64_t ntasks = (uint64_t)p->nb[0] * p->nb[1] * xchunks;                                                            \
@@ -5137,11 +5147,11 @@ int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const 
     }
 #undef BLK_ENC
 #undef BLK_ENC1
-    return launch_blk_side_build(p, sc, nblocks, s);
+    return launch_blk_side_build(p, sc, nblocks, s, rank_first);
 }
 // the side section (selection bits + Rice-coded coefficient chain) from sel[] / coef[]
-static int launch_blk_side_build(const szk_blk_params *p, const szk_blk_scratch *sc, uint32_t nblocks, hipStream_t s) {
-    launch_blk_rank(p->sel, nblocks, sc->rank, sc->comp, sc->run_scratch, sc->counters + 0, s);
+static int launch_blk_side_build(const szk_blk_params *p, const szk_blk_scratch *sc, uint32_t nblocks, hipStream_t s, bool rank_done) {
+    if (!rank_done) launch_blk_rank(p->sel, nblocks, sc->rank, sc->comp, sc->run_scratch, sc->counters + 0, s);
     // (counters: [0] regression blocks, [2] side bytes, [4..7] as doubles: sum of the zigzagged differences per coefficient;
     // the group sizes are staged in the rank array, which the encoder needs no more once comp is written)
     double *stats = reinterpret_cast<double *>(sc->counters + 4);

@@ -1186,10 +1186,14 @@ __device__ __forceinline__ uint64_t peek64(const uint32_t *__restrict__ words, u
     const uint64_t hi = (w0 << 32) | w1;
     return sh ? (hi << sh) | (w2 >> (32 - sh)) : hi;
 }
-// A thread per group of 64 regression blocks (the groups' bit offsets are in the section). The unary parts are counted on a 64-bit
-// window of the stream (count leading ones), not bit by bit: a load per bit made this kernel 0.84 ms at C4a's 92 000 regression blocks,
-// on the side stream's critical path. It also leaves the sums of its group's differences: the chain over the regression blocks is
-// then a scan over the groups (k_blk_coef_gscan) and a wave scan inside each (k_blk_coef_apply).
+// A WAVE per group of 64 regression blocks (round 5; the groups' bit offsets are in the section). A group's codes are one dependent chain —
+// every code's length decides where the next begins — and a thread per group walked it through memory: 256 steps of ~1 us of load
+// latency each, 0.32 ms at C4a's 1 400 groups (and 94 of C1's 250 us), whatever the group count. Now the wave keeps a window of the
+// stream in REGISTERS — 64 consecutive words, one per lane, loaded coalesced — and walks the chain with wave-uniform values: the three
+// words a 64-bit look needs come by v_readlane, a new window is loaded when the walk leaves the old one (every ~200 codes), a lane keeps
+// every 64th result and the results leave 64 at a time. The unary parts are counted on the 64-bit look (count leading ones). It also
+// leaves the sums of its group's differences: the chain over the regression blocks is then a scan over the groups (k_blk_coef_gscan)
+// and a wave scan inside each (k_blk_coef_apply).
 template <int NC>
 __global__ __launch_bounds__(256) void k_blk_coef_parse(const uint8_t *__restrict__ side, uint32_t nblocks, uint64_t nr, uint64_t bit_words,
                                                         int64_t *__restrict__ delta_by_rank, int64_t *__restrict__ gsum) {
@@ -1200,34 +1204,60 @@ __global__ __launch_bounds__(256) void k_blk_coef_parse(const uint8_t *__restric
     const uint32_t *goff = reinterpret_cast<const uint32_t *>(kp + side_par_bytes<NC>());
     const uint32_t *bits = goff + ngroups;
     const uint64_t total_bits = bit_words * 32;
-    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * 256) {
-        uint64_t pos = goff[g];
-        const uint64_t r1 = (g + 1) * RICE_GROUP < nr ? (g + 1) * RICE_GROUP : nr;
+    const int lane = lane_id();
+    for (uint64_t g = (uint64_t)blockIdx.x * 4 + threadIdx.x / WAVE; g < ngroups; g += (uint64_t)gridDim.x * 4) {
+        uint64_t pos = goff[g];  // (wave-uniform from here on)
+        const uint64_t r0 = g * RICE_GROUP, r1 = (g + 1) * RICE_GROUP < nr ? (g + 1) * RICE_GROUP : nr;
+        uint64_t wbase = pos >> 5;
+        uint32_t wreg = wbase + (uint64_t)lane < bit_words ? bits[wbase + lane] : 0u;
+        // 64 bits of the stream from bit `at` on (first bit = bit 63), zeros beyond its end — peek64 out of the window
+        auto look = [&](uint64_t at) -> uint64_t {
+            const uint64_t i = at >> 5;
+            if (i < wbase || i + 3 > wbase + WAVE) {  // (wave-uniform)
+                wbase = i;
+                wreg = wbase + (uint64_t)lane < bit_words ? bits[wbase + lane] : 0u;
+            }
+            const int j = __builtin_amdgcn_readfirstlane((int)(i - wbase));
+            const uint64_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)wreg, j), w1 = (uint32_t)__builtin_amdgcn_readlane((int)wreg, j + 1),
+                           w2 = (uint32_t)__builtin_amdgcn_readlane((int)wreg, j + 2);
+            const uint32_t sh = (uint32_t)(at & 31);
+            const uint64_t hi = (w0 << 32) | w1;
+            return sh ? (hi << sh) | (w2 >> (32 - sh)) : hi;
+        };
         uint64_t tot[NC];
         for (int i = 0; i < NC; i++) tot[i] = 0;
-        for (uint64_t r = g * RICE_GROUP; r < r1; r++)
+        int64_t keep = 0;       // this lane's result of the current batch of 64
+        uint32_t staged = 0;    // results in the batch (wave-uniform)
+        uint64_t out0 = r0 * NC;  // index of the batch's first result
+        for (uint64_t r = r0; r < r1; r++)
             for (int i = 0; i < NC; i++) {
                 uint64_t u = 0;
-                const uint64_t win = peek64(bits, pos, bit_words);
+                const uint64_t win = look(pos);
                 const uint32_t ones = ~win ? (uint32_t)__clzll((long long)~win) : 64u;
                 const uint32_t q = ones < RICE_ESC ? ones : RICE_ESC;
                 pos += q;
                 if (q < RICE_ESC) {
                     pos++;  // the terminating zero
                     uint64_t low = 0;
-                    if (k[i] && pos + k[i] <= total_bits)
-                        low = q + 1 + k[i] <= 64 ? (win << (q + 1)) >> (64 - k[i]) : peek64(bits, pos, bit_words) >> (64 - k[i]);
+                    if (k[i] && pos + k[i] <= total_bits) low = q + 1 + k[i] <= 64 ? (win << (q + 1)) >> (64 - k[i]) : look(pos) >> (64 - k[i]);
                     pos += k[i];
                     u = ((uint64_t)q << k[i]) | low;
                 } else {
-                    u = pos + 64 <= total_bits ? peek64(bits, pos, bit_words) : 0;
+                    u = pos + 64 <= total_bits ? look(pos) : 0;
                     pos += 64;
                 }
                 const int64_t dl = unzigzag(u);
-                delta_by_rank[r * NC + i] = dl;
                 tot[i] += (uint64_t)dl;
+                keep = lane == (int)staged ? dl : keep;
+                if (++staged == WAVE) {
+                    delta_by_rank[out0 + lane] = keep;
+                    out0 += WAVE;
+                    staged = 0;
+                }
             }
-        for (int i = 0; i < NC; i++) gsum[g * NC + i] = (int64_t)tot[i];
+        if ((uint32_t)lane < staged) delta_by_rank[out0 + lane] = keep;
+        if (lane == 0)
+            for (int i = 0; i < NC; i++) gsum[g * NC + i] = (int64_t)tot[i];
     }
 }
 // exclusive scan of the groups' sums, per coefficient (one workgroup, 1024 groups a round)
@@ -5229,7 +5259,7 @@ int szk_launch_blk_side(const szk_blk_params *p, const szk_blk_scratch *sc, cons
     if (nr) {
         const uint64_t ngroups = (nr + RICE_GROUP - 1) / RICE_GROUP;
         int64_t *gsum = reinterpret_cast<int64_t *>(sc->comp);  // (the decoder has no other use for the compacted list's array: ngroups * 32 <= nblocks * 4 bytes)
-        const dim3 gp((uint32_t)((ngroups + 255) / 256 < 1024 ? (ngroups + 255) / 256 : 1024)), ga((uint32_t)std::min<uint64_t>(2048, (ngroups + 3) / 4));
+        const dim3 gp((uint32_t)std::min<uint64_t>(4096, (ngroups + 3) / 4)), ga((uint32_t)std::min<uint64_t>(2048, (ngroups + 3) / 4));  // (a wave per group in both)
         if (p->ndim == 4) {
             hipLaunchKernelGGL(k_blk_coef_parse<5>, gp, dim3(256), 0, s, side, nblocks, nr, bit_words, coef_by_rank, gsum);
             hipLaunchKernelGGL(k_blk_coef_gscan<5>, dim3(1), dim3(1024), 0, s, ngroups, gsum);

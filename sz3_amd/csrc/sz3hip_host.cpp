@@ -139,13 +139,6 @@ static unsigned nthreads() {
     if (n > 64) n = 64;
     return n;
 }
-// frame size for a payload of n bytes — a function of n alone, so the bytes written do not depend on the machine. Payloads of 16 MB and more
-// keep 1 MB frames (dozens of them: the pool is busy either way); smaller ones are cut into about sixteen frames of at least 128 KB: an 8 MB
-// array's 1 MB payload was ONE frame, 0.7 of the call's 0.84 ms on one host thread (what an HDF5 chunk pipeline sees per chunk: 0.54 ms now)
-static size_t frame_for(size_t n) {
-    const size_t f = ((n / 16 + (64u << 10) - 1) >> 16) << 16;
-    return std::min<size_t>(FRAME, std::max<size_t>(128u << 10, f));
-}
 static size_t bound_frames(size_t n, size_t frame = FRAME) {
     size_t nf = (n + frame - 1) / frame;
     if (nf == 0) nf = 1;
@@ -1841,7 +1834,7 @@ int job_encode(SlabJob &j) {
             // the payload comes over in pieces while the host threads already compress the frames that have landed
             zs::Feeder feeder = [&](const std::function<void(size_t)> &landed) -> int {
                 // (a pipelined call's piece: its payload in one go — every part costs a stream synchronisation, and the piece's tail is the call's)
-                const size_t PIECE = dsize <= (16u << 20) ? dsize : 8u << 20;  // (a small payload in one go: every part costs a stream synchronisation)
+                const size_t PIECE = j.frame < zs::FRAME ? (dsize <= (16u << 20) ? dsize : 8u << 20) : 8u << 20;
                 for (size_t off = 0; off < dsize; off += PIECE) {
                     const size_t l = std::min(PIECE, dsize - off);
                     if (hipMemcpyAsync((uint8_t *)s->pin + off, (const uint8_t *)s->dev_payload + off, l, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
@@ -1853,7 +1846,7 @@ int job_encode(SlabJob &j) {
                 }
                 return 0;
             };
-            j.out_size = zs::compress_frames((const uint8_t *)s->pin, dsize, j.out, j.out_cap, &feeder, std::min(j.frame, zs::frame_for(dsize)), &s->frames);
+            j.out_size = zs::compress_frames((const uint8_t *)s->pin, dsize, j.out, j.out_cap, &feeder, j.frame, &s->frames);
             if (!j.out_size) return j.failed(sz3hip_last_error_code());
             if (j.tm) j.tm->lap("device->host + zstd");
             j.conf.cmprAlgo = ctx->h_state->hdr.predictor == 1 ? SZ3HIP_ALGO_HIP_INTERP : SZ3HIP_ALGO_HIP_LORENZO;

@@ -53,6 +53,9 @@
 // zstd.h is not installed in /usr/include of this image, so the five prototypes are declared here and the
 // library is dlopen'ed; a missing library is a hard error.
 // ------------------------------------------------------------------------------------------------------------
+#ifndef SZ3HIP_PIECE_FRAME
+#define SZ3HIP_PIECE_FRAME (512u << 10)
+#endif
 namespace zs {
 typedef size_t (*compress_fn)(void *, size_t, const void *, size_t, int);
 typedef size_t (*decompress_fn)(void *, size_t, const void *, size_t);
@@ -446,7 +449,7 @@ static void slab_range(const sz3hip_config &c, int G, int g, uint64_t *lo, uint6
 // 9.7 ms of host->device, 0.5 ms of kernels, 5.7 ms of device->host + zstd one after the other before). The container is the
 // reference's own multi-slab one (SZ_compress_OMP's, SZImplOMP.hpp:100-110; trailer bit openmp), every piece a blob of its own.
 // Absolute (and L2-norm) bounds only: the others need the whole array's value range before the first piece can be coded.
-static const size_t PIECE_FRAME = 128u << 10;  // (a piece's last frames are the call's tail: 0.7 ms of one host thread each)
+static const size_t PIECE_FRAME = SZ3HIP_PIECE_FRAME;  // (a piece's last frames are the call's tail: 0.7 ms of one host thread each at 1 MB; 128 KB frames cost 1.6 % of the ratio on highly compressible payloads)
 static int piece_count(const sz3hip_config &c, int dataType) {
     const int want = env_int("SZ3HIP_PIECES", -1);  // 0 / 1: never; n > 1: that many whenever the shape allows
     if (want == 0 || want == 1 || c.openmp || c.N < 1 || c.N > 4) return 0;

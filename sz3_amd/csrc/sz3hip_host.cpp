@@ -75,22 +75,37 @@ static contentsize_fn frame_content;
 typedef void *(*create_fn)(void);
 typedef size_t (*compress_cctx_fn)(void *, void *, size_t, const void *, size_t, int);
 typedef size_t (*decompress_dctx_fn)(void *, void *, size_t, const void *, size_t);
+typedef size_t (*free_fn)(void *);
 static create_fn create_cctx, create_dctx;
+static free_fn free_cctx, free_dctx;
 static compress_cctx_fn compress_cctx;
 static decompress_dctx_fn decompress_dctx;
+struct KeptCtx {  // (lives as long as its thread — the pool's threads for good, a caller's thread until it ends — and is freed with it)
+    void *p = nullptr;
+    free_fn fr = nullptr;
+    ~KeptCtx() {
+        if (p && fr) (void)fr(p);
+    }
+};
 static size_t compress_kept(void *dst, size_t cap, const void *src, size_t n, int level) {
-    static thread_local void *cctx = nullptr;  // (lives as long as its thread: the pool's threads for good)
-    if (create_cctx && compress_cctx) {
-        if (!cctx) cctx = create_cctx();
-        if (cctx) return compress_cctx(cctx, dst, cap, src, n, level);
+    static thread_local KeptCtx c;
+    if (create_cctx && compress_cctx && free_cctx) {
+        if (!c.p) {
+            c.p = create_cctx();
+            c.fr = free_cctx;
+        }
+        if (c.p) return compress_cctx(c.p, dst, cap, src, n, level);
     }
     return compress(dst, cap, src, n, level);
 }
 static size_t decompress_kept(void *dst, size_t cap, const void *src, size_t n) {
-    static thread_local void *dctx = nullptr;
-    if (create_dctx && decompress_dctx) {
-        if (!dctx) dctx = create_dctx();
-        if (dctx) return decompress_dctx(dctx, dst, cap, src, n);
+    static thread_local KeptCtx c;
+    if (create_dctx && decompress_dctx && free_dctx) {
+        if (!c.p) {
+            c.p = create_dctx();
+            c.fr = free_dctx;
+        }
+        if (c.p) return decompress_dctx(c.p, dst, cap, src, n);
     }
     return decompress(dst, cap, src, n);
 }
@@ -108,6 +123,8 @@ static void load_once() {
     frame_content = (contentsize_fn)dlsym(h, "ZSTD_getFrameContentSize");
     create_cctx = (create_fn)dlsym(h, "ZSTD_createCCtx");
     create_dctx = (create_fn)dlsym(h, "ZSTD_createDCtx");
+    free_cctx = (free_fn)dlsym(h, "ZSTD_freeCCtx");
+    free_dctx = (free_fn)dlsym(h, "ZSTD_freeDCtx");
     compress_cctx = (compress_cctx_fn)dlsym(h, "ZSTD_compressCCtx");
     decompress_dctx = (decompress_dctx_fn)dlsym(h, "ZSTD_decompressDCtx");
     ok = compress && decompress && bound && is_error;
@@ -834,6 +851,7 @@ struct D2hStage {
     uint8_t *buf[K] = {};
     std::atomic<int> busy[K];
     hipEvent_t ev[16][K] = {};
+    hipStream_t st[16] = {};
     bool ok = false, tried = false;
     bool init() {
         if (tried) return ok;
@@ -869,9 +887,9 @@ struct StagedCopy {
         if (!g_stage.init()) return hipErrorOutOfMemory;
         for (int k = 0; k < D2hStage::K; k++)
             if (!g_stage.ev[dev][k] && (e = hipEventCreateWithFlags(&g_stage.ev[dev][k], hipEventDisableTiming)) != hipSuccess) return e;
-        static thread_local hipStream_t t_st[16] = {};  // (streams of this thread's own, one per device: the slot's stream may be anyone's)
-        if (!t_st[dev] && (e = hipStreamCreateWithFlags(&t_st[dev], hipStreamNonBlocking)) != hipSuccess) return e;
-        st = t_st[dev];
+        // (a stream of the ring's own per device — the slot's stream may be anyone's; made once, used under the ring's lock)
+        if (!g_stage.st[dev] && (e = hipStreamCreateWithFlags(&g_stage.st[dev], hipStreamNonBlocking)) != hipSuccess) return e;
+        st = g_stage.st[dev];
         return hipSuccess;
     }
     void drain_one() {  // the oldest chunk on its way has landed: on to the caller's array, in parts

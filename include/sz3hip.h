@@ -237,6 +237,16 @@ void sz3hip_ctx_set_speculation(sz3hip_ctx *ctx, int off);
  * payload is a pure function of the input again (what the host API — sz3hip_compress, the CLI, the HDF5 filter — always sets;
  * the reference builds a tree per call, encoder/HuffmanEncoder.hpp:96-105). Default of a device context: 0. */
 void sz3hip_ctx_set_deterministic(sz3hip_ctx *ctx, int on);
+/* Round 5: the ALGO_INTERP_LORENZO tuner's trials priced the reference's way. By default a trial is priced on the device from the
+ * histogram of its codes (entropy + a model of the serialised tree: 0.2 ms per tuning, the reference's decision in about three of four
+ * cases, a neighbouring (alpha, beta) otherwise). With this switch every trial is priced as interp_compress_test does
+ * (api/impl/SZAlgoInterp.hpp:42-78): the trial kernel's per-element codes of all sampled blocks come to the host, are put into the order
+ * the reference's decomposition emits them, coded with one Huffman tree built with the reference's own queue, serialised like its buffer and
+ * compressed with ZSTD_compress at level 3 — est_bytes[0..5] of the tuner report are then the reference's own compressed sizes byte for
+ * byte (same libzstd) and the decisions the reference's, at a few milliseconds per tuning (a host thread per trial). The 1-D Lorenzo
+ * trial (est_bytes[6]) keeps its estimate. Environment: SZ3HIP_TUNER_EXACT=1 turns it on for every context this function was never called on
+ * (the host API's, the CLI's, the HDF5 filter's), read per call. */
+void sz3hip_ctx_set_tuner_exact(sz3hip_ctx *ctx, int on);
 void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses);
 /* 1 when the last finished compression of this context ran the fused stage 1 (round 4: a context whose previous call left a small
  * code book codes with it INSIDE the predictor kernel — one-byte codes, rows that are multiples of 256 elements, 1-D..3-D — and the

@@ -159,6 +159,8 @@ def lib():
     L.sz3hip_ctx_set_speculation.restype = None
     L.sz3hip_ctx_set_deterministic.argtypes = [C.c_void_p, C.c_int]
     L.sz3hip_ctx_set_deterministic.restype = None
+    L.sz3hip_ctx_set_tuner_exact.argtypes = [C.c_void_p, C.c_int]
+    L.sz3hip_ctx_set_tuner_exact.restype = None
     L.sz3hip_set_stock_format.argtypes = [C.c_int]
     L.sz3hip_set_stock_format.restype = None
     L.sz3hip_last_call_fused.argtypes = [C.c_void_p]
@@ -436,6 +438,11 @@ class DeviceCompressor:
         """on: the previous call's code book stands only when it IS this call's book — the payload is a pure function of the input
         (off, the device API's default: also when it is complete over this call's alphabet and within 1/1024 of its own book's size)"""
         lib().sz3hip_ctx_set_deterministic(self._h, int(on))
+
+    def set_tuner_exact(self, on=True):
+        """on: the ALGO_INTERP_LORENZO tuner prices its trials the reference's way (Huffman tree + bits + zstd on the host: the reference's
+        own compressed sizes and decisions, milliseconds per tuning); off: the device-side estimate (include/sz3hip.h)"""
+        lib().sz3hip_ctx_set_tuner_exact(self._h, int(on))
 
     def set_fused(self, on=True):
         """opt in to the fused stage 1 (the previous call's book codes inside the predictor kernel; off by default)"""

@@ -30,6 +30,7 @@
 #include "sz3hip_internal.h"
 #include "sz3hip_stock_geom.h"
 #include "sz3hip_kernels.h"
+#include "sz3hip_stock_host.h"
 
 // ------------------------------------------------------------------------------------------------------------
 static thread_local char g_err[512];
@@ -236,6 +237,8 @@ static void ctx_free(sz3hip_ctx *c) {
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
     if (c->h_trial) (void)hipHostFree(c->h_trial);
+    free(c->h_trial_codes);
+    free(c->h_samples);
     if (c->h_passes) (void)hipHostFree(c->h_passes);
     if (c->h_np) (void)hipHostFree(c->h_np);
     if (c->d_blk_carry) (void)hipFree(c->d_blk_carry);
@@ -925,10 +928,64 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
         ips[j].out_cap = 0;  // count only
     }
     int rc = szk_launch_interp_trials(ctx->dtype, ips, (uint32_t)ntr, ctx->d_samples, ctx->d_trial_work, ctx->d_trial_codes, nb, ctx->d_trial_hist,
-                                      ctx->h_passes, ctx->d_passes, ctx->h_np, ctx->d_np, s);
+                                      ctx->h_passes, ctx->d_passes, ctx->h_np, ctx->d_np, ctx->exact_now ? 1 : 0, s);
     if (rc) return fail(SZ3HIP_EHIP, "tuner: interpolation trial launch failed (%d)", rc);
     rc = szk_launch_code_cost(ctx->d_trial_hist, ctx->d_trial_counters, ctx->d_trial + 4 * slot0, (uint32_t)ntr, tcs[0].num * nb, 1, s);
     if (rc) return fail(SZ3HIP_EHIP, "tuner: cost kernel launch failed (%d)", rc);
+    if (!ctx->exact_now) return 0;
+    // The reference's own price of every trial (interp_compress_test, api/impl/SZAlgoInterp.hpp:42-78): the codes of all sampled blocks in
+    // the order its decomposition emits them, one Huffman tree built with its queue, its serialised buffer, ZSTD_compress at level 3 — on
+    // the host, a thread per trial, from the per-element codes the trial kernel's global-memory form leaves (bit-identical to the
+    // reference's code of every element). Milliseconds per tuning instead of 0.2: a switch for callers who want the reference's decisions.
+    const size_t tsz = ctx->dtype == SZ3HIP_FLOAT ? 4 : 8;
+    const uint64_t per = tcs[0].num;
+    const size_t cbytes = (size_t)ntr * nb * per * 2, sbytes = (size_t)nb * per * tsz;
+    if (ctx->h_trial_codes_cap < cbytes) {
+        free(ctx->h_trial_codes);
+        ctx->h_trial_codes = (uint16_t *)malloc(cbytes);
+        ctx->h_trial_codes_cap = ctx->h_trial_codes ? cbytes : 0;
+        if (!ctx->h_trial_codes) return fail(SZ3HIP_EHIP, "tuner: out of host memory");
+    }
+    if (ctx->h_samples_cap < sbytes) {
+        free(ctx->h_samples);
+        ctx->h_samples = malloc(sbytes);
+        ctx->h_samples_cap = ctx->h_samples ? sbytes : 0;
+        ctx->h_samples_valid = false;
+        if (!ctx->h_samples) return fail(SZ3HIP_EHIP, "tuner: out of host memory");
+    }
+    HIPCHK(hipMemcpyAsync(ctx->h_trial_codes, ctx->d_trial_codes, cbytes, hipMemcpyDeviceToHost, s));
+    if (!ctx->h_samples_valid) HIPCHK(hipMemcpyAsync(ctx->h_samples, ctx->d_samples, sbytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    ctx->h_samples_valid = true;
+    std::vector<size_t> sizes((size_t)ntr, 0);
+    auto price = [&](int j) {
+        szi_stock_params sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.N = tcs[j].N;
+        for (int i = 0; i < sp.N; i++) sp.dims[i] = tcs[j].dims[i];
+        sp.interp_id = tcs[j].interpAlgo;
+        sp.direction = tcs[j].interpDirection;
+        sp.anchor_stride = (uint64_t)tcs[j].interpAnchorStride;
+        sp.alpha = tcs[j].interpAlpha;
+        sp.beta = tcs[j].interpBeta;
+        sp.eb = eb;
+        sp.radius = radius;
+        std::vector<uint8_t> raw;
+        const uint16_t *codes = ctx->h_trial_codes + (size_t)j * nb * per;
+        const bool made = ctx->dtype == SZ3HIP_FLOAT ? stock::trial_buffer<float>(sp, codes, (const float *)ctx->h_samples, nb, raw)
+                                                     : stock::trial_buffer<double>(sp, codes, (const double *)ctx->h_samples, nb, raw);
+        if (!made) return;
+        const size_t z = szi_zstd_size(raw.data(), raw.size());
+        sizes[j] = z ? z + 8 : 0;  // (Lossless_zstd::compress: the length word in front of the frame)
+    };
+    std::vector<std::thread> th;
+    for (int j = 1; j < ntr; j++) th.emplace_back(price, j);
+    price(0);
+    for (auto &t : th) t.join();
+    for (int j = 0; j < ntr; j++) {
+        if (!sizes[j]) return fail(SZ3HIP_EZSTD, "tuner: a trial could not be priced (geometry of the sample blocks or libzstd)");
+        ctx->exact_bytes[slot0 + j] = (double)sizes[j];
+    }
     return 0;
 }
 static int tuner_fetch(sz3hip_ctx *ctx, hipStream_t s) {
@@ -944,6 +1001,10 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
     sz3hip_tuner_report &rep = ctx->tuner;
     memset(&rep, 0, sizeof(rep));
     rep.use_interp = 1;
+    {   // sz3hip_ctx_set_tuner_exact, or — for contexts nobody holds a handle of: the host API's, the CLI's, the HDF5 filter's — the environment
+        const char *te = getenv("SZ3HIP_TUNER_EXACT");
+        ctx->exact_now = ctx->tuner_exact == 1 || (ctx->tuner_exact == 0 && te && atoi(te) != 0);
+    }
     static const int def_anchor[4] = {4096, 128, 32, 16};
     if (conf.interpAnchorStride < 0) conf.interpAnchorStride = def_anchor[N - 1];
     const double rate = 0.005;                               // SZAlgoInterp.hpp:133-135
@@ -1019,6 +1080,8 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
     if (rc) return fail(SZ3HIP_EHIP, "tuner: gather launch failed (%d)", rc);
 
     const double raw = (double)sampling_num * (double)tsz;
+    ctx->h_samples_valid = false;  // (exact pricing: this call's sample blocks are fetched with the first group's codes)
+    auto priced = [&](int slot) { return ctx->exact_now ? ctx->exact_bytes[slot] : trial_bytes(ctx->h_trial + 4 * slot, tsz); };
     double best_interp = 0, best_lorenzo = 0;
     sz3hip_config lorenzo_config = conf;
     conf.interpDirection = 0;  // :186-189
@@ -1056,8 +1119,8 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
     if (rc) return rc;
     double dir_bytes[2];
     for (int op = 0; op < 2; op++) {
-        rep.est_bytes[op] = trial_bytes(ctx->h_trial + 4 * op, tsz);
-        dir_bytes[op] = trial_bytes(ctx->h_trial + 4 * (2 + op), tsz);
+        rep.est_bytes[op] = priced(op);
+        dir_bytes[op] = priced(2 + op);
         const double ratio = raw / rep.est_bytes[op];
         if (ratio > best_interp) {
             best_interp = ratio;
@@ -1086,7 +1149,7 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
         ab_slot = 3;
     }
     for (int i = 0; i < 3; i++) {
-        rep.est_bytes[3 + i] = trial_bytes(ctx->h_trial + 4 * (ab_slot + i), tsz);
+        rep.est_bytes[3 + i] = priced(ab_slot + i);
         const double ratio = raw / rep.est_bytes[3 + i];
         if (ratio > best_interp * 1.02) {
             best_interp = ratio;
@@ -1736,6 +1799,7 @@ extern "C" void sz3hip_ctx_set_speculation(sz3hip_ctx *ctx, int off) { ctx->spec
 // same book); 0 (the device API's default): the previous book also stands when it is complete over this call's alphabet and codes
 // it within 1/1024 of this call's own book's size — the payload then depends on the context's history, its size by < 0.1 %
 extern "C" void sz3hip_ctx_set_deterministic(sz3hip_ctx *ctx, int on) { ctx->spec_exact = on ? 1 : 0; }
+extern "C" void sz3hip_ctx_set_tuner_exact(sz3hip_ctx *ctx, int on) { ctx->tuner_exact = on ? 1 : 2; }
 // ---- stock-stream interoperability: the device work between this library's per-element codes and the reference's emission order ----
 int szi_stock_stage1_outcome(sz3hip_ctx *ctx, szi_stock_params *out, uint64_t *n_unpred, void *stream) {
     hipStream_t s = (hipStream_t)stream;

@@ -416,6 +416,14 @@ static size_t decompress_frames(const uint8_t *src, size_t n, uint8_t *dst, size
     return (size_t)len;
 }
 }  // namespace zs
+// what ZSTD_compress (level 3, one frame) makes of a buffer, in bytes: Lossless_zstd::compress's return value less its 8-byte length word
+// (lossless/Lossless_zstd.hpp:29-37) — the price of a tuner trial (sz3hip_ctx_set_tuner_exact, sz3hip_api.cpp); 0: no libzstd / an error
+size_t szi_zstd_size(const void *src, size_t n) {
+    if (zs::load()) return 0;
+    std::vector<uint8_t> dst(zs::bound(n));
+    const size_t r = zs::compress_kept(dst.data(), dst.size(), src, n, 3);
+    return zs::is_error(r) ? 0 : r;
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // host-buffer API: SZ_compress<T> / SZ_decompress<T> equivalents

@@ -1596,7 +1596,7 @@ __global__ __launch_bounds__(1024) void k_interp_trials_lds(const T *__restrict_
 // built on the host into h_passes (pinned) and copied to d_passes
 int szk_launch_interp_trials(int dtype, const szk_interp_params *ips, uint32_t ntrials, const void *d_samples, void *d_work,
                              uint16_t *codes, uint32_t nblocks, uint64_t *d_hists, szk_interp_pass *h_passes, szk_interp_pass *d_passes,
-                             uint32_t *h_np, uint32_t *d_np, hipStream_t s) {
+                             uint32_t *h_np, uint32_t *d_np, int keep_codes, hipStream_t s) {
     uint64_t per = 1;
     for (int i = 0; i < ips[0].N; i++) per *= ips[0].dims[i];
     for (uint32_t j = 0; j < ntrials; j++) {
@@ -1611,7 +1611,7 @@ int szk_launch_interp_trials(int dtype, const szk_interp_params *ips, uint32_t n
     e = hipMemcpyAsync(d_np, h_np, ntrials * 4, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return (int)e;
     const size_t tsz = dtype == 0 ? 4 : 8;
-    bool lds = per * tsz <= TRIAL_LDS_BYTES;
+    bool lds = !keep_codes && per * tsz <= TRIAL_LDS_BYTES;  // (keep_codes: the trials' codes are wanted per element — the global-memory form leaves them in `codes`)
     for (uint32_t j = 0; j < ntrials; j++) lds = lds && h_np[j] <= TRIAL_LDS_PASSES;
     if (lds && dtype == 0)
         hipLaunchKernelGGL((k_interp_trials_lds<float>), dim3(nblocks, ntrials), dim3(1024), 0, s, (const float *)d_samples, d_passes, d_np,

@@ -324,7 +324,7 @@ int szk_launch_gather_blocks(int dtype, const void *d_in, int N, const uint64_t 
 #define SZK_TRIAL_MAX_PASSES 64
 int szk_launch_interp_trials(int dtype, const szk_interp_params *ips, uint32_t ntrials, const void *d_samples, void *d_work,
                              uint16_t *codes, uint32_t nblocks, uint64_t *d_hists, szk_interp_pass *h_passes, szk_interp_pass *d_passes,
-                             uint32_t *h_np, uint32_t *d_np, hipStream_t s);
+                             uint32_t *h_np, uint32_t *d_np, int keep_codes, hipStream_t s);
 // res (4 words per book): entropy of the histogram in 1/256 bit, symbols in use, counters[0], counters[1]
 // unpred_is_code0: the unpredictable count of an interpolation trial is its number of points coded 0 (hist[0])
 int szk_launch_code_cost(const uint64_t *hist, const uint64_t *counters, uint64_t *d_res, uint32_t n_books, uint64_t total,

@@ -88,28 +88,74 @@ template <typename F> void parallel(size_t n_items, F f) {  // f(begin, end, thr
 
 // ---- Huffman in the reference's container (Tree, Code: sz3hip_stock_host.h) ----------------------------------------------
 // an optimal prefix code over the symbols with freq > 0 (heap merge), as a pre-order tree + the code of every symbol
-void build_tree(const std::vector<uint64_t> &freq, Tree &tr, std::vector<Code> &codes) {
+void build_tree(const std::vector<uint64_t> &freq, Tree &tr, std::vector<Code> &codes, bool ref_heap = false) {
     struct N {
         uint64_t f;
         int l, r, sym;
     };
     std::vector<N> nodes;
-    typedef std::pair<uint64_t, int> QE;  // (frequency, node): ties by creation order
-    std::priority_queue<QE, std::vector<QE>, std::greater<QE>> q;
-    for (size_t s = 0; s < freq.size(); s++)
-        if (freq[s]) {
-            nodes.push_back({freq[s], -1, -1, (int)s});
-            q.push({freq[s], (int)nodes.size() - 1});
+    int root = -1;
+    if (ref_heap) {
+        // the reference's own queue (encoder/HuffmanEncoder.hpp:402-432, 516-561): a 1-based binary heap whose insertion climbs only past
+        // STRICTLY larger parents and whose removal prefers the right child only when strictly smaller — which of several equal
+        // frequencies merges first decides the tree's shape (not its cost), and a tuner trial's zstd size is taken over the tree's bytes
+        std::vector<int> heap(1);  // (1-based: slot 0 unused)
+        auto insert = [&](int n) {
+            heap.push_back(n);
+            size_t i = heap.size() - 1;
+            for (size_t j = i >> 1; j; j = i >> 1) {
+                if (nodes[heap[j]].f <= nodes[n].f) break;
+                heap[i] = heap[j];
+                i = j;
+            }
+            heap[i] = n;
+        };
+        auto remove = [&]() {
+            const int top = heap[1];
+            heap[1] = heap.back();
+            heap.pop_back();
+            const size_t end = heap.size();
+            size_t i = 1;
+            for (size_t l = i << 1; l < end; l = i << 1) {
+                if (l + 1 < end && nodes[heap[l + 1]].f < nodes[heap[l]].f) l++;
+                if (nodes[heap[i]].f > nodes[heap[l]].f) {
+                    std::swap(heap[i], heap[l]);
+                    i = l;
+                } else {
+                    break;
+                }
+            }
+            return top;
+        };
+        for (size_t s = 0; s < freq.size(); s++)
+            if (freq[s]) {
+                nodes.push_back({freq[s], -1, -1, (int)s});
+                insert((int)nodes.size() - 1);
+            }
+        while (heap.size() > 2) {
+            const int a = remove(), b = remove();
+            nodes.push_back({nodes[a].f + nodes[b].f, a, b, -1});
+            insert((int)nodes.size() - 1);
         }
-    while (q.size() > 1) {
-        const QE a = q.top();
-        q.pop();
-        const QE b = q.top();
-        q.pop();
-        nodes.push_back({a.first + b.first, a.second, b.second, -1});
-        q.push({a.first + b.first, (int)nodes.size() - 1});
+        root = heap[1];
+    } else {
+        typedef std::pair<uint64_t, int> QE;  // (frequency, node): ties by creation order
+        std::priority_queue<QE, std::vector<QE>, std::greater<QE>> q;
+        for (size_t s = 0; s < freq.size(); s++)
+            if (freq[s]) {
+                nodes.push_back({freq[s], -1, -1, (int)s});
+                q.push({freq[s], (int)nodes.size() - 1});
+            }
+        while (q.size() > 1) {
+            const QE a = q.top();
+            q.pop();
+            const QE b = q.top();
+            q.pop();
+            nodes.push_back({a.first + b.first, a.second, b.second, -1});
+            q.push({a.first + b.first, (int)nodes.size() - 1});
+        }
+        root = q.top().second;
     }
-    const int root = q.top().second;
     const size_t nc = nodes.size();
     tr.L.assign(nc, 0);
     tr.R.assign(nc, 0);
@@ -724,4 +770,77 @@ bool encode_codes_host(const std::vector<uint16_t> &codes, Tree &tr, int &lo, in
     if (!tr.t[0]) host_encode(codes.data(), codes.size(), clen, cbits, bits);
     return true;
 }
+// The pre-zstd buffer of one trial of the ALGO_INTERP_LORENZO tuner, exactly as interp_compress_test makes it (api/impl/SZAlgoInterp.hpp:
+// 42-78): ONE decomposition object codes all sampled blocks, so its quantizer's list holds the unpredictable values (anchors included) of
+// all of them in emission order; the codes of all blocks are concatenated and coded with one tree; the buffer is decomposition header,
+// quantizer, tree, count, bits — a stock ALGO_INTERP stream's body (write_head) over an array of the sample block's extents. codes: what the
+// trial kernel left per ELEMENT of every block ([nb][per], zero = unpredictable), samples: the blocks themselves. The tree is built with
+// the reference's own queue (build_tree, ref_heap): the trial's price is zstd's size of these very bytes.
+template <typename T>
+bool trial_buffer(const szi_stock_params &p, const uint16_t *codes, const T *samples, uint64_t nb, std::vector<uint8_t> &raw) {
+    szg_geom g;
+    std::vector<uint64_t> bb;
+    if (szk_stock_geom_build(p.N, p.dims, p.interp_id, p.direction, p.anchor_stride, &g, &bb)) return false;
+    const uint64_t per = g.n;
+    std::vector<uint32_t> at(per);  // the element emitted r-th
+    for (uint64_t e = 0; e < per; e++) {
+        uint64_t x[4], q = e;
+        for (int i = p.N - 1; i >= 0; i--) {
+            x[i] = q % g.d[i];
+            q /= g.d[i];
+        }
+        at[szg_rank(g, bb.data(), x)] = (uint32_t)e;
+    }
+    const uint64_t n = per * nb;
+    std::vector<uint16_t> em((size_t)n);
+    std::vector<T> un;
+    uint32_t lo = 65535, hi = 0;
+    for (uint64_t k = 0; k < nb; k++) {
+        const uint16_t *c = codes + k * per;
+        const T *v = samples + k * per;
+        uint16_t *o = em.data() + k * per;
+        for (uint64_t r = 0; r < per; r++) {
+            const uint16_t x = c[at[r]];
+            o[r] = x;
+            if (!x) un.push_back(v[at[r]]);
+            lo = std::min<uint32_t>(lo, x);
+            hi = std::max<uint32_t>(hi, x);
+        }
+    }
+    if (!n) return false;
+    std::vector<uint64_t> freq(hi - lo + 1, 0);
+    for (uint16_t x : em) freq[x - lo]++;
+    Tree tr;
+    std::vector<Code> cw;
+    build_tree(freq, tr, cw, true);
+    std::vector<uint8_t> bits;
+    if (!tr.t[0]) encode_bits(em.data(), n, (int32_t)lo, cw, bits);
+    write_head(p, g.anchor, un.data(), un.size(), sizeof(T), tr, (int)lo, (int)hi, n, bits.size(), raw);
+    raw.insert(raw.end(), bits.begin(), bits.end());
+    return true;
+}
+template bool trial_buffer<float>(const szi_stock_params &, const uint16_t *, const float *, uint64_t, std::vector<uint8_t> &);
+template bool trial_buffer<double>(const szi_stock_params &, const uint16_t *, const double *, uint64_t, std::vector<uint8_t> &);
 }  // namespace stock
+// test hook (CPU, no device): the buffer of a trial from per-element codes; returns its size, -1 when the geometry is refused, -2 when `cap` is short
+extern "C" int64_t sz3hip_debug_trial_buffer(int N, const uint64_t *dims, int interp_id, int direction, uint64_t anchor_stride, double alpha, double beta,
+                                             double eb, int radius, int dtype, const uint16_t *codes, const void *samples, uint64_t nb, uint8_t *out,
+                                             uint64_t cap) {
+    szi_stock_params p;
+    memset(&p, 0, sizeof(p));
+    p.N = N;
+    for (int i = 0; i < N && i < 4; i++) p.dims[i] = dims[i];
+    p.interp_id = interp_id;
+    p.direction = direction;
+    p.anchor_stride = anchor_stride;
+    p.alpha = alpha;
+    p.beta = beta;
+    p.eb = eb;
+    p.radius = radius;
+    std::vector<uint8_t> raw;
+    const bool made = dtype == 0 ? stock::trial_buffer<float>(p, codes, (const float *)samples, nb, raw) : stock::trial_buffer<double>(p, codes, (const double *)samples, nb, raw);
+    if (!made) return -1;
+    if (raw.size() > cap) return -2;
+    memcpy(out, raw.data(), raw.size());
+    return (int64_t)raw.size();
+}

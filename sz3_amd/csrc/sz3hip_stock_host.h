@@ -62,5 +62,9 @@ void lorenzo_reg_write_1d(uint64_t n, uint32_t B, double eb, int radius, uint32_
 bool encode_codes_host(const std::vector<uint16_t> &codes, Tree &tr, int &lo, int &hi, std::vector<uint8_t> &bits);
 void host_encode(const uint16_t *em, uint64_t n, const std::vector<uint8_t> &clen, const std::vector<uint64_t> &cbits, std::vector<uint8_t> &bits);
 bool host_decode(const Tree &tr, int32_t offset, const uint8_t *bits, size_t nbytes, uint64_t n, uint16_t *em);
+// one trial of the ALGO_INTERP_LORENZO tuner priced the reference's way (sz3hip_ctx_set_tuner_exact): the buffer interp_compress_test
+// hands to zstd (api/impl/SZAlgoInterp.hpp:42-78), from the trial kernel's per-element codes of all sampled blocks
+template <typename T>
+bool trial_buffer(const szi_stock_params &p, const uint16_t *codes, const T *samples, uint64_t nb, std::vector<uint8_t> &raw);
 }  // namespace stock
 #endif

@@ -13,7 +13,7 @@ import pytest
 
 import sz3_amd
 from fields import field1d, field2d, field3d, field4d
-from oracle_binding import ALGO_INTERP, ALGO_INTERP_LORENZO, make_config, oracle_interp_codes, oracle_tune
+from oracle_binding import ALGO_INTERP, ALGO_INTERP_LORENZO, make_config, oracle_compress, oracle_decompress, oracle_interp_codes, oracle_tune
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -89,6 +89,79 @@ def test_tuner_against_oracle(name, gen, eb):
                      interpAlpha=g["interpAlpha"], interpBeta=g["interpBeta"])
     _, _, recon, _ = oracle_interp_codes(a, pc)
     assert np.array_equal(dec, recon.reshape(a.shape))
+
+
+EXACT_CASES = CASES[:7] + [
+    ("3d-96-1e-1", lambda: field3d((96, 96, 96)), 1e-1),       # ratios of 20 - 230: zstd compresses the Huffman stream itself, the
+    ("3d-96-3e-2", lambda: field3d((96, 96, 96)), 3e-2),       # zone where the device-side estimate picks a neighbouring (alpha, beta)
+    ("3d-128-1e-2", lambda: field3d((128, 128, 128)), 1e-2),
+    ("3d-160-1e-5", lambda: field3d((160, 160, 160)), 1e-5),
+    ("3d-noisy-1e-3", lambda: field3d((128, 128, 128), sigma=1e-2), 1e-3),
+    ("2d-600x700-1e-2", lambda: field2d((600, 700)), 1e-2),
+    ("4d-12x40x40x40-1e-2", lambda: field4d((12, 40, 40, 40)), 1e-2),
+    ("1d-2^20", lambda: field1d(1 << 20), 1e-3),
+]
+
+
+@pytest.mark.parametrize("name,gen,eb", EXACT_CASES, ids=[c[0] for c in EXACT_CASES])
+def test_exact_pricing_gives_the_reference_sizes_and_decisions(name, gen, eb):
+    """sz3hip_ctx_set_tuner_exact: every interpolation trial priced as interp_compress_test does (api/impl/SZAlgoInterp.hpp:42-78) — the
+    codes in emission order, one tree from the reference's queue, its buffer, ZSTD_compress level 3. The oracle runs the reference's
+    trials on the CPU (byte-identical to the reference build): the SIZES must be equal byte for byte, hence every decision."""
+    a = gen()
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    dc.set_tuner_exact(True)
+    dc.set_deterministic(True)
+    cap = dc.payload_bound(a.size)
+    payload = torch.empty(cap, dtype=torch.uint8, device=dev)
+    conf = sz3_amd.Config(*a.shape)
+    conf.absErrorBound = eb
+    s = torch.cuda.current_stream().cuda_stream
+    size = dc.compress(conf, t.data_ptr(), payload.data_ptr(), cap, s)
+    g = dc.tuner_report()
+    oc, orep, oran = oracle_tune(a, make_config(a.shape, algo=ALGO_INTERP_LORENZO, abs_eb=eb, regression=True))
+    assert bool(g["ran"]) == oran and oran
+    raw = orep.n_blocks * (orep.sample_block_size + 1) ** a.ndim * a.itemsize
+    ref_bytes = [int(round(raw / orep.ratios[k])) for k in range(6)]
+    for k in range(6):
+        assert abs(raw / ref_bytes[k] - orep.ratios[k]) < 1e-9 * orep.ratios[k]
+    assert [int(x) for x in g["est_bytes"][:6]] == ref_bytes, "a trial's compressed size differs from the reference's"
+    if a.ndim > 1 or (g["use_interp"] and oc.cmprAlgo == ALGO_INTERP):
+        assert g["use_interp"] == 1 and oc.cmprAlgo == ALGO_INTERP
+        assert (g["interpAlgo"], g["interpDirection"], g["interpAlpha"], g["interpBeta"]) == (oc.interpAlgo, oc.interpDirection, oc.interpAlpha, oc.interpBeta)
+    out = torch.empty_like(t)
+    dc.decompress(payload.data_ptr(), size, out.data_ptr(), s)
+    torch.cuda.synchronize()
+    dec = out.cpu().numpy()
+    assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= eb
+    # the same call again, and with the estimate: exact pricing is a property of the context, not of what it did before
+    size2 = dc.compress(conf, t.data_ptr(), payload.data_ptr(), cap, s)
+    assert [int(x) for x in dc.tuner_report()["est_bytes"][:6]] == ref_bytes and size2 == size
+
+
+@pytest.mark.parametrize("name,gen,eb", [EXACT_CASES[8], EXACT_CASES[3], EXACT_CASES[13]], ids=["3d-96-3e-2", "3d-f64-1e-6", "4d-1e-2"])
+def test_default_algorithm_through_the_host_api_reconstructs_what_the_reference_reconstructs(name, gen, eb, monkeypatch):
+    """SZ3HIP_TUNER_EXACT=1 (read per call: the host API's contexts have no handle to call the setter on): the reference's default
+    algorithm through sz3_amd.compress takes the reference's parameters — on arrays where the estimate takes others — and the
+    decompressed array is, bit for bit, what the reference's own stream decompresses to."""
+    a = gen()
+    conf = sz3_amd.Config(*a.shape)
+    conf.absErrorBound = eb
+    monkeypatch.setenv("SZ3HIP_TUNER_EXACT", "1")
+    blob, _ = sz3_amd.compress(a, conf)
+    dec, c2 = sz3_amd.decompress(blob, a.dtype, a.shape)
+    oconf = make_config(a.shape, algo=ALGO_INTERP_LORENZO, abs_eb=eb, regression=True)
+    oc, _, oran = oracle_tune(a, oconf)
+    assert oran and oc.cmprAlgo == ALGO_INTERP
+    odec, _ = oracle_decompress(oracle_compress(a, oconf), a.dtype, a.shape)
+    assert np.array_equal(dec, odec)
+    monkeypatch.setenv("SZ3HIP_TUNER_EXACT", "0")
+    blob0, _ = sz3_amd.compress(a, conf)
+    dec0 = sz3_amd.decompress(blob0, a.dtype, a.shape)[0]
+    assert not np.array_equal(dec0, odec), "cases chosen for the estimate's other (alpha, beta) (tools/tuner_exact_lab.py)"
+    assert float(np.max(np.abs(dec0.astype(np.float64) - a.astype(np.float64)))) <= eb
 
 
 def test_default_config_host_roundtrip():

@@ -7,7 +7,10 @@ import numpy as np
 import pytest
 
 import sz3_amd
-from oracle_binding import ALGO_INTERP, make_config, oracle_interp_codes
+import struct
+
+from fields import field1d, field2d, field3d, field4d
+from oracle_binding import ALGO_INTERP, make_config, oracle, oracle_compress, oracle_interp_codes
 
 CASES = [
     # (shape, interp algo, direction, anchor stride)
@@ -35,3 +38,41 @@ def test_emission_rank_of_every_element(shape, algo, direction, anchor):
     want[order.astype(np.int64)] = np.arange(a.size, dtype=np.uint64)
     bad = np.nonzero(ranks != want)[0]
     assert bad.size == 0, (bad[:10], ranks[bad[:10]], want[bad[:10]])
+
+
+TRIALS = [
+    # (sample block, dtype, interp algo, direction, anchor stride, alpha, beta, bound)
+    ((33, 33, 33), np.float32, 1, 0, 32, 1.25, 2.0, 1e-3), ((33, 33, 33), np.float32, 0, 5, 32, 1.25, 2.0, 1e-2), ((33, 33, 33), np.float32, 1, 0, 32, 2.0, 3.0, 1e-1),
+    ((17, 17, 17), np.float64, 1, 5, 32, 1.0, 1.0, 1e-3), ((129, 129), np.float32, 1, 1, 128, 1.5, 2.5, 1e-3), ((9, 9, 9, 9), np.float32, 0, 23, 16, 1.25, 2.0, 1e-3),
+    ((2049,), np.float32, 1, 0, 4096, 1.25, 2.0, 1e-4), ((33, 33, 33), np.float32, 1, 0, 32, 1.25, 2.0, 10.0),
+]
+
+
+@pytest.mark.parametrize("shape,dtype,algo,direction,anchor,alpha,beta,eb", TRIALS, ids=["%s-%s-d%d-%g" % ("x".join(map(str, c[0])), "cubic" if c[2] else "linear", c[3], c[7]) for c in TRIALS])
+def test_a_tuner_trial_s_buffer_is_the_reference_s(shape, dtype, algo, direction, anchor, alpha, beta, eb):
+    """the exact pricing of the ALGO_INTERP_LORENZO tuner (sz3hip_ctx_set_tuner_exact) without a device: from the per-element codes of one
+    sample block — here the oracle's — stock::trial_buffer must make, byte for byte, the buffer the reference hands to zstd for that block
+    (interp_compress_test, api/impl/SZAlgoInterp.hpp:42-78 = an ALGO_INTERP stream's body over the block): emission order, the
+    quantizer's list, the tree as the reference's own queue shapes it (ties!), the bits. The last case: one symbol, no bits."""
+    L = sz3_amd.lib()
+    L.sz3hip_debug_trial_buffer.restype = C.c_int64
+    L.sz3hip_debug_trial_buffer.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    a = {1: lambda: field1d(shape[0], dtype), 2: lambda: field2d(shape, dtype), 3: lambda: field3d(shape, dtype), 4: lambda: field4d(shape, dtype)}[len(shape)]()
+    oconf = make_config(a.shape, algo=ALGO_INTERP, abs_eb=eb, interp_algo=algo, interpDirection=direction, interpAnchorStride=anchor, interpAlpha=alpha,
+                        interpBeta=beta)
+    codes, order, _, _ = oracle_interp_codes(a, oconf)
+    per_elem = np.empty(a.size, dtype=np.uint16)
+    per_elem[order.astype(np.int64)] = codes.astype(np.uint16)
+    b = oracle_compress(a, oconf).tobytes()
+    plen, = struct.unpack_from("<Q", b, 8)
+    pay = np.frombuffer(b[16:16 + plen], dtype=np.uint8)
+    rawlen, = struct.unpack_from("<Q", pay.tobytes(), 0)
+    want = np.empty(rawlen, dtype=np.uint8)
+    assert oracle().szo_zstd_decompress(pay.ctypes.data, pay.size, want.ctypes.data, rawlen) == rawlen
+    got = np.empty(rawlen + 4096, dtype=np.uint8)
+    arr = (C.c_uint64 * len(shape))(*shape)
+    n = L.sz3hip_debug_trial_buffer(len(shape), arr, algo, direction, anchor, alpha, beta, eb, 32768, 0 if dtype == np.float32 else 1, per_elem.ctypes.data,
+                                    a.ctypes.data, 1, got.ctypes.data, got.size)
+    assert n == rawlen, (n, rawlen)
+    assert got[:n].tobytes() == want.tobytes()

@@ -237,8 +237,8 @@ static void ctx_free(sz3hip_ctx *c) {
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->h_minmax) (void)hipHostFree(c->h_minmax);
     if (c->h_trial) (void)hipHostFree(c->h_trial);
-    free(c->h_trial_codes);
-    free(c->h_samples);
+    if (c->h_trial_codes) (void)hipHostFree(c->h_trial_codes);
+    if (c->h_samples) (void)hipHostFree(c->h_samples);
     if (c->h_passes) (void)hipHostFree(c->h_passes);
     if (c->h_np) (void)hipHostFree(c->h_np);
     if (c->d_blk_carry) (void)hipFree(c->d_blk_carry);
@@ -941,22 +941,27 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
     const uint64_t per = tcs[0].num;
     const size_t cbytes = (size_t)ntr * nb * per * 2, sbytes = (size_t)nb * per * tsz;
     if (ctx->h_trial_codes_cap < cbytes) {
-        free(ctx->h_trial_codes);
-        ctx->h_trial_codes = (uint16_t *)malloc(cbytes);
-        ctx->h_trial_codes_cap = ctx->h_trial_codes ? cbytes : 0;
-        if (!ctx->h_trial_codes) return fail(SZ3HIP_EHIP, "tuner: out of host memory");
+        if (ctx->h_trial_codes) (void)hipHostFree(ctx->h_trial_codes);  // (pinned: 8 MB of codes per group at C3, a staged copy into pageable memory took longer than the trials)
+        ctx->h_trial_codes = nullptr;
+        ctx->h_trial_codes_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&ctx->h_trial_codes, cbytes));
+        ctx->h_trial_codes_cap = cbytes;
     }
     if (ctx->h_samples_cap < sbytes) {
-        free(ctx->h_samples);
-        ctx->h_samples = malloc(sbytes);
-        ctx->h_samples_cap = ctx->h_samples ? sbytes : 0;
+        if (ctx->h_samples) (void)hipHostFree(ctx->h_samples);
+        ctx->h_samples = nullptr;
+        ctx->h_samples_cap = 0;
         ctx->h_samples_valid = false;
-        if (!ctx->h_samples) return fail(SZ3HIP_EHIP, "tuner: out of host memory");
+        HIPCHK(hipHostMalloc(&ctx->h_samples, sbytes));
+        ctx->h_samples_cap = sbytes;
     }
+    static const bool tt = getenv("SZ3HIP_TUNER_TIMING") != nullptr;  // (development: where an exactly priced group's time goes)
+    const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(hipMemcpyAsync(ctx->h_trial_codes, ctx->d_trial_codes, cbytes, hipMemcpyDeviceToHost, s));
     if (!ctx->h_samples_valid) HIPCHK(hipMemcpyAsync(ctx->h_samples, ctx->d_samples, sbytes, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     ctx->h_samples_valid = true;
+    const auto t1 = std::chrono::steady_clock::now();
     std::vector<size_t> sizes((size_t)ntr, 0);
     auto price = [&](int j) {
         szi_stock_params sp;
@@ -982,6 +987,9 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
     for (int j = 1; j < ntr; j++) th.emplace_back(price, j);
     price(0);
     for (auto &t : th) t.join();
+    if (tt)
+        fprintf(stderr, "[sz3hip tuner] exact group of %d: kernels + copy out %.3f ms, pricing %.3f ms\n", ntr, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     for (int j = 0; j < ntr; j++) {
         if (!sizes[j]) return fail(SZ3HIP_EZSTD, "tuner: a trial could not be priced (geometry of the sample blocks or libzstd)");
         ctx->exact_bytes[slot0 + j] = (double)sizes[j];

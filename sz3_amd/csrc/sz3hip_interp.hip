@@ -130,8 +130,12 @@ __device__ __forceinline__ void interp_point(T *__restrict__ w, uint16_t *__rest
         // the caller's array and an unpredictable point's raw value is stored like a reconstruction
         T v = orig ? orig[idx] : *d;
         const int code = ref_quantize<T>(v, pred, p.eb, p.eb_recip, p.radius);
-        if (SINK) sink_code(sink, (uint32_t)code);
-        else codes[idx] = (uint16_t)code;
+        if (SINK) {
+            sink_code(sink, (uint32_t)code);
+            if (codes) codes[idx] = (uint16_t)code;  // (the tuner's exact pricing wants the trial's codes per element besides their histogram)
+        } else {
+            codes[idx] = (uint16_t)code;
+        }
         if ((code || orig) && !p.no_store) *d = v;  // (unpredictable, code 0: the raw value stays; LinearQuantizer "unpred")
     }
 }
@@ -804,8 +808,12 @@ __device__ __forceinline__ void anchor_point(T *__restrict__ w, uint16_t *__rest
         if (code) w[idx] = v;
     }
     if (orig && !code) w[idx] = v;  // (level kernels: the work array holds nothing but what the launches put there)
-    if (SINK) sink_code(sink, (uint32_t)code);
-    else codes[idx] = (uint16_t)code;
+    if (SINK) {
+        sink_code(sink, (uint32_t)code);
+        if (codes) codes[idx] = (uint16_t)code;
+    } else {
+        codes[idx] = (uint16_t)code;
+    }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_interp_anchors(T *__restrict__ w, uint16_t *__restrict__ codes, szk_interp_pass p, const T *orig) {
@@ -1556,12 +1564,13 @@ __global__ __launch_bounds__(1024) void k_interp_trials(const T *__restrict__ sa
 template <typename T>
 __global__ __launch_bounds__(1024) void k_interp_trials_lds(const T *__restrict__ samples, const szk_interp_pass *__restrict__ passes,
                                                             const uint32_t *__restrict__ npasses, uint32_t per,
-                                                            uint64_t *__restrict__ hists) {
+                                                            uint64_t *__restrict__ hists, uint16_t *__restrict__ codes) {
     __shared__ __align__(16) T w[TRIAL_LDS_BYTES / sizeof(T)];
     __shared__ szk_interp_pass sps[TRIAL_LDS_PASSES];
     __shared__ uint32_t lh[IH_WIN];
     const uint32_t b = blockIdx.x, j = blockIdx.y, nb = gridDim.x, tid = threadIdx.x;
-    const uint64_t base = ((uint64_t)j * nb + b) * per;  // (only offsets the indices of counted unpredictables)
+    const uint64_t base = ((uint64_t)j * nb + b) * per;  // (offsets the indices of counted unpredictables, and the codes when they are kept)
+    uint16_t *c = codes ? codes + base : nullptr;
     const T *in = samples + (uint64_t)b * per;
     const uint32_t np = npasses[j];
     {
@@ -1579,9 +1588,9 @@ __global__ __launch_bounds__(1024) void k_interp_trials_lds(const T *__restrict_
     for (uint32_t k = 0; k < np; k++) {
         const szk_interp_pass &sp = sps[k];
         if (sp.kind == 2) {
-            for (uint32_t t = tid; t < (uint32_t)sp.total; t += 1024) interp_point<T, false, uint32_t, true>(w, nullptr, sp, t, base, &sink);
+            for (uint32_t t = tid; t < (uint32_t)sp.total; t += 1024) interp_point<T, false, uint32_t, true>(w, c, sp, t, base, &sink);
         } else {
-            for (uint32_t t = tid; t < (uint32_t)sp.total; t += 1024) anchor_point<T, uint32_t, true>(w, nullptr, sp, t, base, &sink);
+            for (uint32_t t = tid; t < (uint32_t)sp.total; t += 1024) anchor_point<T, uint32_t, true>(w, c, sp, t, base, &sink);
         }
         __syncthreads();
     }
@@ -1611,14 +1620,14 @@ int szk_launch_interp_trials(int dtype, const szk_interp_params *ips, uint32_t n
     e = hipMemcpyAsync(d_np, h_np, ntrials * 4, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return (int)e;
     const size_t tsz = dtype == 0 ? 4 : 8;
-    bool lds = !keep_codes && per * tsz <= TRIAL_LDS_BYTES;  // (keep_codes: the trials' codes are wanted per element — the global-memory form leaves them in `codes`)
+    bool lds = per * tsz <= TRIAL_LDS_BYTES;
     for (uint32_t j = 0; j < ntrials; j++) lds = lds && h_np[j] <= TRIAL_LDS_PASSES;
     if (lds && dtype == 0)
         hipLaunchKernelGGL((k_interp_trials_lds<float>), dim3(nblocks, ntrials), dim3(1024), 0, s, (const float *)d_samples, d_passes, d_np,
-                           (uint32_t)per, d_hists);
+                           (uint32_t)per, d_hists, keep_codes ? codes : nullptr);  // (keep_codes: per-element codes besides the histograms, for the exact pricing)
     else if (lds)
         hipLaunchKernelGGL((k_interp_trials_lds<double>), dim3(nblocks, ntrials), dim3(1024), 0, s, (const double *)d_samples, d_passes, d_np,
-                           (uint32_t)per, d_hists);
+                           (uint32_t)per, d_hists, keep_codes ? codes : nullptr);
     else if (dtype == 0)
         hipLaunchKernelGGL((k_interp_trials<float>), dim3(nblocks, ntrials), dim3(1024), 0, s, (const float *)d_samples, (float *)d_work, codes,
                            d_passes, d_np, per, d_hists);

@@ -15,12 +15,19 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <atomic>
 #include <queue>
 #include <thread>
+#include <array>
+#include <chrono>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "../../include/sz3hip.h"
@@ -283,27 +290,36 @@ void encode_bits(const uint16_t *em, uint64_t n, int32_t offset, const std::vect
     auto work = [&](unsigned t) {
         const uint64_t a = n * t / nt, b = n * (t + 1) / nt;
         std::vector<uint8_t> &o = part[t];
-        o.reserve((b - a) / 2 + 64);
-        uint64_t acc = 0;  // bits collected, left-aligned in the low `have` bits
-        uint32_t have = 0;
+        // a 64-bit word fills from its top and leaves as eight bytes at once (a byte pushed per eight bits was 13 ns per symbol: most of a
+        // tuner trial's exact price, and of the host twin of the device coder)
+        o.resize((size_t)(b - a) / 2 + 64);
+        size_t at = 0;
+        uint64_t acc = 0;   // bits collected, from the top
+        uint32_t have = 0;  // ... how many (< 64)
         uint64_t total = 0;
         for (uint64_t i = a; i < b; i++) {
             const Code &c = codes[(int32_t)em[i] - offset];
-            uint32_t len = c.len;
-            uint64_t bits = c.bits;
+            const uint32_t len = c.len;  // (<= 64: the callers refuse longer code words)
+            if (!len) continue;
             total += len;
-            while (len) {  // (code words of more than 56 bits come in two pieces)
-                const uint32_t take = std::min<uint32_t>(len, 56 - have);
-                acc = (acc << take) | ((bits >> (len - take)) & ((take == 64 ? ~0ull : (1ull << take)) - 1));
-                have += take;
-                len -= take;
-                while (have >= 8) {
-                    o.push_back((uint8_t)(acc >> (have - 8)));
-                    have -= 8;
-                }
+            const uint32_t room = 64 - have;
+            if (len < room) {
+                acc |= c.bits << (room - len);
+                have += len;
+            } else {
+                const uint32_t rest = len - room;  // (< 64)
+                acc |= rest ? (c.bits >> rest) : c.bits;
+                if (at + 16 > o.size()) o.resize(o.size() * 2);
+                const uint64_t be = __builtin_bswap64(acc);
+                memcpy(o.data() + at, &be, 8);
+                at += 8;
+                acc = rest ? (c.bits << (64 - rest)) : 0;
+                have = rest;
             }
         }
-        if (have) o.push_back((uint8_t)(acc << (8 - have)));
+        if (at + 16 > o.size()) o.resize(o.size() + 16);
+        for (uint32_t k = 0; k < have; k += 8) o[at++] = (uint8_t)(acc >> (56 - k));
+        o.resize(at);
         pbits[t] = total;
     };
     std::vector<std::thread> th;
@@ -782,15 +798,38 @@ bool trial_buffer(const szi_stock_params &p, const uint16_t *codes, const T *sam
     std::vector<uint64_t> bb;
     if (szk_stock_geom_build(p.N, p.dims, p.interp_id, p.direction, p.anchor_stride, &g, &bb)) return false;
     const uint64_t per = g.n;
-    std::vector<uint32_t> at(per);  // the element emitted r-th
-    for (uint64_t e = 0; e < per; e++) {
-        uint64_t x[4], q = e;
-        for (int i = p.N - 1; i >= 0; i--) {
-            x[i] = q % g.d[i];
-            q /= g.d[i];
+    // the element emitted r-th: a function of the block's geometry alone — kept from trial to trial and call to call (36 000 closed-form ranks
+    // are milliseconds of one host thread; the trials of a tuning share two or three geometries, a series of calls all of them)
+    std::shared_ptr<const std::vector<uint32_t>> perm;
+    {
+        static std::mutex mu;
+        static std::map<std::array<uint64_t, 8>, std::shared_ptr<const std::vector<uint32_t>>> kept;
+        const std::array<uint64_t, 8> key = {(uint64_t)p.N, p.dims[0], p.N > 1 ? p.dims[1] : 0, p.N > 2 ? p.dims[2] : 0, p.N > 3 ? p.dims[3] : 0, (uint64_t)g.interp_id,
+                                             (uint64_t)p.direction, g.anchor};
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = kept.find(key);
+            if (it != kept.end()) perm = it->second;
         }
-        at[szg_rank(g, bb.data(), x)] = (uint32_t)e;
+        if (!perm) {
+            auto v = std::make_shared<std::vector<uint32_t>>(per);
+            for (uint64_t e = 0; e < per; e++) {
+                uint64_t x[4], q = e;
+                for (int i = p.N - 1; i >= 0; i--) {
+                    x[i] = q % g.d[i];
+                    q /= g.d[i];
+                }
+                (*v)[szg_rank(g, bb.data(), x)] = (uint32_t)e;
+            }
+            perm = v;
+            std::lock_guard<std::mutex> lk(mu);
+            if (kept.size() >= 32) kept.clear();
+            kept[key] = perm;
+        }
     }
+    const std::vector<uint32_t> &at = *perm;
+    static const bool tt = getenv("SZ3HIP_TUNER_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     const uint64_t n = per * nb;
     std::vector<uint16_t> em((size_t)n);
     std::vector<T> un;
@@ -812,11 +851,21 @@ bool trial_buffer(const szi_stock_params &p, const uint16_t *codes, const T *sam
     for (uint16_t x : em) freq[x - lo]++;
     Tree tr;
     std::vector<Code> cw;
+    const auto t1 = std::chrono::steady_clock::now();
     build_tree(freq, tr, cw, true);
+    for (const Code &c : cw)
+        if (c.len > 64) return false;
+    const auto t2 = std::chrono::steady_clock::now();
     std::vector<uint8_t> bits;
     if (!tr.t[0]) encode_bits(em.data(), n, (int32_t)lo, cw, bits);
+    const auto t3 = std::chrono::steady_clock::now();
     write_head(p, g.anchor, un.data(), un.size(), sizeof(T), tr, (int)lo, (int)hi, n, bits.size(), raw);
     raw.insert(raw.end(), bits.begin(), bits.end());
+    if (tt) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[sz3hip tuner] trial of %llu codes: order + counts %.3f, tree %.3f, bits %.3f, buffer %.3f ms (%zu bytes)\n", (unsigned long long)n, ms(t0, t1), ms(t1, t2),
+                ms(t2, t3), ms(t3, std::chrono::steady_clock::now()), raw.size());
+    }
     return true;
 }
 template bool trial_buffer<float>(const szi_stock_params &, const uint16_t *, const float *, uint64_t, std::vector<uint8_t> &);

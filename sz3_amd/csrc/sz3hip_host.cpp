@@ -993,6 +993,11 @@ struct DevArena {
         return 0;
     }
 };
+// zstd frames of a stock container. Default: 1 MB of the buffer per frame, coded by the pool's threads (ZSTD_decompress, which stock SZ3 calls, decodes
+// concatenated frames) — a container whose buffer fits one frame is then what ZSTD_compress makes of it, i.e. with the reference's own tree order
+// (stock::build_tree) the reference's file byte for byte wherever the codes are the reference's. SZ3HIP_STOCK_ONE_FRAME=1: one frame whatever the
+// size (one host thread: ~0.4 GB/s), for archives that must compare equal to the reference's.
+static size_t stock_frame(size_t n) { return env_int("SZ3HIP_STOCK_ONE_FRAME", 0) ? std::max<size_t>(n, 1) : zs::FRAME; }
 static bool stock_host_huffman() { return env_int("SZ3HIP_STOCK_HOST_HUFFMAN", 0) != 0; }  // (A/B partner of the device coder, for tests)
 // 0: j.out holds [u64 rawLen][zstd frames] of a stock stream and j.conf names it; SZ3HIP_EUNSUPPORTED: stage 1 took another predictor
 int stock_encode_interp(SlabJob &j) {
@@ -1076,7 +1081,7 @@ int stock_encode_interp(SlabJob &j) {
     raw.reserve((size_t)bit_bytes + (size_t)n_unpred * tsize + (1u << 20));
     stock::write_head(sp, g.anchor, un.data(), n_unpred, tsize, tr, lo, hi, n, bit_bytes, raw);
     raw.insert(raw.end(), bits.begin(), bits.end());
-    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap);  // (concatenated frames: ZSTD_decompress, which stock SZ3 calls, decodes them all)
+    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap, nullptr, stock_frame(raw.size()));  // (concatenated frames: ZSTD_decompress, which stock SZ3 calls, decodes them all)
     if (!j.out_size) return sz3hip_last_error_code();
     if (j.tm) j.tm->lap("zstd");
     j.conf.cmprAlgo = SZ3HIP_ALGO_INTERP;
@@ -1269,7 +1274,7 @@ int stock_encode_nopred(SlabJob &j) {
     raw.reserve((size_t)bit_bytes + (size_t)n_unpred * tsize + (1u << 20));
     stock::write_lorenzo_reg_head(cf.N, 1, cf.absErrorBound, tsize, false, false, {}, nullptr, 0, nullptr, 0, {}, radius, un.data(), n_unpred, tr, lo, hi, n, bit_bytes, raw);
     raw.insert(raw.end(), bits.begin(), bits.end());
-    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap);
+    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap, nullptr, stock_frame(raw.size()));
     if (!j.out_size) return sz3hip_last_error_code();
     j.conf.cmprAlgo = SZ3HIP_ALGO_NOPRED;
     if ((double)j.raw_bytes / (double)j.out_size < 3) {  // SZDispatcher.hpp:62-74
@@ -1322,7 +1327,7 @@ static int stock_encode_lorenzo_reg_1d(SlabJob &j) {
     stock::write_lorenzo_reg_head(1, B, cf.absErrorBound, tsize, cf.regression != 0, members > 1, coef_codes, pui, nui, pul, nul, selection, radius, un.data(), n_unpred, tr, lo, hi,
                                   n, bits.size(), raw);
     raw.insert(raw.end(), bits.begin(), bits.end());
-    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap);
+    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap, nullptr, stock_frame(raw.size()));
     if (!j.out_size) return sz3hip_last_error_code();
     j.conf.cmprAlgo = SZ3HIP_ALGO_LORENZO_REG;
     if ((double)j.raw_bytes / (double)j.out_size < 3) {  // SZDispatcher.hpp:62-74
@@ -1483,7 +1488,7 @@ int stock_encode_lorenzo_reg(SlabJob &j) {
     stock::write_lorenzo_reg_head(N, B, cf.absErrorBound, tsize, has_reg, composed, coef_codes, pui, nui, pul, nul, selection, radius, un.data(), n_unpred, tr, lo, hi, n,
                                   bit_bytes, raw);
     raw.insert(raw.end(), bits.begin(), bits.end());
-    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap);
+    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap, nullptr, stock_frame(raw.size()));
     if (!j.out_size) return sz3hip_last_error_code();
     if (j.tm) j.tm->lap("zstd");
     j.conf.cmprAlgo = SZ3HIP_ALGO_LORENZO_REG;

@@ -427,7 +427,7 @@ bool book_from_hist(const uint64_t *hist65536, Tree &tr, std::vector<uint8_t> &c
     if (!hist65536[lo]) return false;
     std::vector<uint64_t> freq(hist65536 + lo, hist65536 + hi + 1);
     std::vector<Code> codes;
-    build_tree(freq, tr, codes);
+    build_tree(freq, tr, codes, true);  // (the reference's own queue: which of two equal frequencies merges first — a written stream is then the reference's, byte for byte)
     clen.assign(65536, 0);
     cbits.assign(65536, 0);
     for (int s = lo; s <= hi; s++) {
@@ -591,7 +591,7 @@ void write_vector(W &w, const std::vector<uint16_t> &v) {
     for (uint16_t x : v) freq[x - lo]++;
     Tree tr;
     std::vector<Code> codes;
-    build_tree(freq, tr, codes);
+    build_tree(freq, tr, codes, true);  // (the reference's own queue: which of two equal frequencies merges first — a written stream is then the reference's, byte for byte)
     save_tree(w, tr, (int32_t)lo, hi - lo + 2);
     std::vector<uint8_t> bits;
     if (!tr.t[0]) encode_bits(v.data(), v.size(), (int32_t)lo, codes, bits);

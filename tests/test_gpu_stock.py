@@ -2,8 +2,11 @@
 (cmprAlgo ALGO_INTERP — what the reference's default ALGO_INTERP_LORENZO writes) READ by this library, and streams WRITTEN by this
 library (sz3hip_set_stock_format) read by the reference. The stock side is played by the oracle — byte-identical to the reference
 built in this image (tests/test_oracle.py) — and, where oracle/_ref is present, by the reference library itself. Reconstruction is
-the reference's bit for bit in both directions (prediction, quantisation and reconstruction are the same arithmetic, DESIGN.md §2);
-only the Huffman tree's tie-breaking may differ, so stream sizes agree to a fraction of a percent, not to the byte."""
+the reference's bit for bit in both directions (prediction, quantisation and reconstruction are the same arithmetic).
+Since the end of round 5 the writers build their Huffman trees with the reference's own queue (stock::build_tree, ref_heap): wherever the
+codes are the reference's — ALGO_INTERP, ALGO_NOPRED, the default algorithm with SZ3HIP_TUNER_EXACT=1, ALGO_LORENZO_REG in 1-D and wherever
+the blocks' choices coincide — a written container IS the reference's file, byte for byte (one zstd frame: buffers up to 1 MB, or
+SZ3HIP_STOCK_ONE_FRAME=1)."""
 import numpy as np
 import pytest
 
@@ -67,6 +70,7 @@ def test_streams_written_in_stock_format_are_read_by_stock_sz3(name, gen, eb, kw
     conf = sz3_amd.Config(*a.shape)
     conf.cmprAlgo = sz3_amd.ALGO_INTERP
     conf.absErrorBound = eb
+    conf.regression = 0                                     # (make_config's: the Config trailer holds the flags whatever the algorithm)
     conf.interpAlgo = kw.get("interp_algo", 1)
     for k in ("interpDirection", "interpAnchorStride", "interpAlpha", "interpBeta"):
         if k in kw:
@@ -77,7 +81,7 @@ def test_streams_written_in_stock_format_are_read_by_stock_sz3(name, gen, eb, kw
     finally:
         L.sz3hip_set_stock_format(0)
     assert _trailer_algo(blob) == sz3_amd.ALGO_INTERP      # a stock id, not 17
-    oconf = make_config(a.shape, algo=ALGO_INTERP, abs_eb=eb, **kw)
+    oconf = make_config(a.shape, algo=ALGO_INTERP, abs_eb=eb, dataType=0 if a.dtype == np.float32 else 1, **kw)  # (a caller who names the type, like the CLI)
     oblob = oracle_compress(a, oconf)
     want, _ = oracle_decompress(oblob, a.dtype, a.shape)   # what stock SZ3 reconstructs from its own stream
     got, _ = oracle_decompress(blob, a.dtype, a.shape)     # stock SZ3 reading OUR stream
@@ -86,8 +90,8 @@ def test_streams_written_in_stock_format_are_read_by_stock_sz3(name, gen, eb, kw
         assert np.array_equal(ref_decompress(blob, a.dtype, a.shape), want, equal_nan=True)
     mine, _ = sz3_amd.decompress(blob, a.dtype, a.shape)   # and this library reading it back
     assert np.array_equal(mine, want, equal_nan=True)
-    # same codes, an equally good tree; the zstd stage behind it sees another tree's bytes and 1 MB frames (a few percent either way)
-    assert 0.9 * len(oblob) <= len(blob) <= 1.01 * len(oblob) + 64, (len(blob), len(oblob))
+    # the same codes in the same order, the tree from the reference's own queue, one zstd frame: the reference's file
+    assert blob.tobytes() == oblob.tobytes(), (len(blob), len(oblob))
 
 
 def test_default_algorithm_in_stock_format_and_ids_without_the_switch():
@@ -116,6 +120,31 @@ def test_default_algorithm_in_stock_format_and_ids_without_the_switch():
     assert np.array_equal(mine, dec) and np.array_equal(mine, ref_own)  # one reconstruction, three containers
     oblob = oracle_compress(a, make_config(a.shape, algo=ALGO_INTERP_LORENZO, eb_mode=EB_REL, rel_eb=1e-3))
     assert len(blob) <= 1.05 * len(oblob)  # (the GPU tuner may choose a neighbouring (alpha, beta): DESIGN.md section 2)
+
+
+@pytest.mark.parametrize("name,gen,kwc", [("abs-3d", lambda: field3d((72, 80, 88)), dict(abs_eb=3e-2)), ("rel-3d", lambda: field3d((72, 80, 88)), dict(eb_mode=EB_REL, rel_eb=1e-3)),
+                                          ("abs-2d", lambda: field2d((600, 700)), dict(abs_eb=1e-3)), ("abs-4d", lambda: field4d((12, 40, 40, 40)), dict(abs_eb=1e-2))],
+                         ids=["abs-3d", "rel-3d", "abs-2d", "abs-4d"])
+def test_default_algorithm_in_stock_format_with_exact_pricing_is_the_reference_s_file(name, gen, kwc, monkeypatch):
+    """the reference's default algorithm end to end: its tuner's decisions (SZ3HIP_TUNER_EXACT=1: the trials priced the reference's way),
+    its stream layout, its tree order, one zstd frame — the container equals the reference's byte for byte"""
+    a = gen()
+    conf = sz3_amd.Config(*a.shape)
+    conf.regression = 0
+    if "rel_eb" in kwc:
+        conf.errorBoundMode = sz3_amd.EB_REL
+        conf.relErrorBound = kwc["rel_eb"]
+    else:
+        conf.absErrorBound = kwc["abs_eb"]
+    monkeypatch.setenv("SZ3HIP_TUNER_EXACT", "1")
+    L = sz3_amd.lib()
+    L.sz3hip_set_stock_format(1)
+    try:
+        blob, _ = sz3_amd.compress(a, conf)
+    finally:
+        L.sz3hip_set_stock_format(0)
+    oblob = oracle_compress(a, make_config(a.shape, algo=ALGO_INTERP_LORENZO, **kwc))
+    assert blob.tobytes() == oblob.tobytes(), (len(blob), len(oblob))
 
 
 def test_corrupt_stock_streams_are_refused():
@@ -278,6 +307,10 @@ LR_WRITE_CASES = LR_CASES + [  # (4-D arrays since round 5's second half: k_slw_
 ]
 
 
+BYTE_IDENTICAL = {"3d-lorenzo-only", "3d-all-three", "3d-second-order-only", "3d-regression-only-block5", "3d-f64", "2d-defaults", "2d-second-order",
+                  "4d-lorenzo-only-ragged", "4d-coarse-regression-f64", "4d-regression-only", "3d-block8"}
+
+
 @pytest.mark.parametrize("name,gen,eb,kw", LR_WRITE_CASES, ids=[c[0] for c in LR_WRITE_CASES])
 def test_streams_written_as_stock_lorenzo_reg_are_read_by_stock_sz3(name, gen, eb, kw):
     """sz3hip_set_stock_format(1) + cmprAlgo ALGO_LORENZO_REG: the reference's own Lorenzo / regression container
@@ -313,12 +346,39 @@ def test_streams_written_as_stock_lorenzo_reg_are_read_by_stock_sz3(name, gen, e
     assert np.array_equal(mine, got, equal_nan=True)
     if l2_in_4d:
         return
-    oblob = oracle_compress(a, make_config(a.shape, abs_eb=eb, **kw))
-    # (1-D: the chain is walked on the host in the reference's own order — the same choices, the same codes: the same size but for the trees' ties)
+    oblob = oracle_compress(a, make_config(a.shape, abs_eb=eb, dataType=0 if a.dtype == np.float32 else 1, **kw))
+    # (1-D: the chain is walked on the host in the reference's own order — the same choices, the same codes)
     assert len(blob) <= (1.01 if a.ndim == 1 else 1.08) * len(oblob) + 256, (len(blob), len(oblob))
+    # The reference's file byte for byte wherever the codes are the reference's: sets of one member, 1-D arrays, and the arrays where the
+    # writer's choices (from original neighbours) coincide with the reference's (from reconstructed ones) — tools/stock_bytes_lab.py
+    if a.ndim == 1 or name in BYTE_IDENTICAL:
+        assert blob.tobytes() == oblob.tobytes(), (len(blob), len(oblob))
     if a.ndim == 1:
         want, _ = oracle_decompress(oblob, a.dtype, a.shape)
         assert np.array_equal(got, want), "a 1-D stream decodes to other values than stock SZ3's own stream"
+
+
+def test_one_frame_switch_makes_a_large_stock_container_the_reference_s_file(monkeypatch):
+    """a buffer beyond 1 MB leaves in several zstd frames by default (the pool's threads; stock SZ3 reads them) — SZ3HIP_STOCK_ONE_FRAME=1
+    writes the one frame ZSTD_compress writes: the reference's file (64 x 256^2, Lorenzo + regression: 2.15 MB of buffer, the blocks'
+    choices coincide)"""
+    a = field3d((64, 256, 256))
+    conf = sz3_amd.Config(*a.shape)
+    conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
+    conf.absErrorBound = 1e-3
+    L = sz3_amd.lib()
+    oblob = oracle_compress(a, make_config(a.shape, abs_eb=1e-3, lorenzo=True, regression=True))
+    blobs = {}
+    for one in ("0", "1"):
+        monkeypatch.setenv("SZ3HIP_STOCK_ONE_FRAME", one)
+        L.sz3hip_set_stock_format(1)
+        try:
+            blobs[one], _ = sz3_amd.compress(a, conf)
+        finally:
+            L.sz3hip_set_stock_format(0)
+    assert blobs["1"].tobytes() == oblob.tobytes()
+    assert blobs["0"].tobytes() != oblob.tobytes() and abs(len(blobs["0"]) - len(oblob)) < 256
+    assert np.array_equal(oracle_decompress(blobs["0"], a.dtype, a.shape)[0], oracle_decompress(oblob, a.dtype, a.shape)[0])
 
 
 def test_stock_lorenzo_reg_writer_declines_what_it_does_not_take():
@@ -362,6 +422,7 @@ def test_stock_nopred_streams_both_ways(gen, eb):
     conf = sz3_amd.Config(*a.shape)
     conf.cmprAlgo = sz3_amd.ALGO_NOPRED
     conf.absErrorBound = eb
+    conf.regression = 0
     L.sz3hip_set_stock_format(1)
     try:
         blob, _ = sz3_amd.compress(a, conf)
@@ -372,7 +433,9 @@ def test_stock_nopred_streams_both_ways(gen, eb):
     assert np.array_equal(back, want, equal_nan=True)      # the same quantizer on the same values: the same reconstruction
     mine, _ = sz3_amd.decompress(blob, a.dtype, a.shape)
     assert np.array_equal(mine, back, equal_nan=True)
-    assert len(blob) <= 1.05 * len(rblob) + 256
+    assert len(blob) == len(rblob)
+    if a.dtype == np.float32:                              # (f64: the shim's Config names no type, this library's trailer does — one byte)
+        assert blob.tobytes() == rblob.tobytes(), "the same codes, the reference's tree order, one zstd frame: the reference's file"
 
 
 def test_stock_4d_stream_with_the_second_order_member_is_read():

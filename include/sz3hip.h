@@ -106,7 +106,11 @@ size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in);
  * reference's bit for bit. WRITING: sz3hip_set_stock_format(1) (or SZ3HIP_STOCK_FORMAT=1 in the environment) makes sz3hip_compress —
  * and everything on top of it — write ALGO_INTERP streams stock SZ3 reads whenever the interpolation predictor is chosen; other
  * outcomes (Lorenzo, regression) keep this library's ids. Prediction, quantisation, reconstruction and the Huffman bit stream run on the
- * GPU either way; the tree's serialisation and zstd are host stages. */
+ * GPU either way; the tree's serialisation and zstd are host stages. The tree is built with the reference's own queue (which of two
+ * equal frequencies merges first, encoder/HuffmanEncoder.hpp:402-432): wherever the codes are the reference's — ALGO_INTERP, ALGO_NOPRED,
+ * the default algorithm with SZ3HIP_TUNER_EXACT=1, ALGO_LORENZO_REG in 1-D and wherever the blocks' choices coincide — the container
+ * written IS the reference's file byte for byte, as long as its buffer leaves in one zstd frame: up to 1 MB by default (larger buffers are
+ * cut into 1 MB frames for the pool's threads; stock SZ3 reads them), any size with SZ3HIP_STOCK_ONE_FRAME=1 (one host thread, ~0.4 GB/s). */
 void sz3hip_set_stock_format(int on);
 int sz3hip_get_stock_format(void);
 /* the same over at most `avail` readable bytes: 0 when the serialised Config does not fit in them (truncated stream) */

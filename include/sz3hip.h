@@ -217,7 +217,8 @@ typedef struct sz3hip_tuner_report {
     int32_t speculated; /* 0: stage 1 waited for the tuner; 1: it had started with the previous call's outcome and the tuner confirmed it;
                          * 2: started, not confirmed, enqueued again with this call's outcome */
     double interpAlpha, interpBeta;
-    double est_bytes[8]; /* priced size of the trials: linear, cubic, reversed direction, 3 x (alpha, beta), [6] Lorenzo (1-D) */
+    double est_bytes[8]; /* priced size of the trials: linear, cubic, reversed direction, 3 x (alpha, beta), [6] Lorenzo (1-D),
+                          * [7] Lorenzo with 16384 quantization bins (1-D, only when Lorenzo won: SZAlgoInterp.hpp:268-277) */
 } sz3hip_tuner_report;
 int sz3hip_get_tuner_report(sz3hip_ctx *ctx, sz3hip_tuner_report *rep);
 
@@ -248,7 +249,7 @@ void sz3hip_ctx_set_deterministic(sz3hip_ctx *ctx, int on);
  * the reference's decomposition emits them, coded with one Huffman tree built with the reference's own queue, serialised like its buffer and
  * compressed with ZSTD_compress at level 3 — est_bytes[0..5] of the tuner report are then the reference's own compressed sizes byte for
  * byte (same libzstd) and the decisions the reference's, at a few milliseconds per tuning (a host thread per trial). The 1-D Lorenzo
- * trial (est_bytes[6]) keeps its estimate. Environment: SZ3HIP_TUNER_EXACT=1 turns it on for every context this function was never called on
+ * trials (est_bytes[6], [7]) are then walked on the host in the reference's own order and priced the same way. Environment: SZ3HIP_TUNER_EXACT=1 turns it on for every context this function was never called on
  * (the host API's, the CLI's, the HDF5 filter's), read per call. */
 void sz3hip_ctx_set_tuner_exact(sz3hip_ctx *ctx, int on);
 void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses);

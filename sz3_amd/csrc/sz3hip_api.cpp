@@ -1165,26 +1165,41 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
             conf.interpBeta = betas[i];
         }
     }
-    if (N == 1 && best_interp < 50) {  // :232-247 — here: this library's own Lorenzo coder over the concatenated samples
+    // the 1-D Lorenzo trial (lorenzo_compress_test, :80-120) at a given radius: this library's trial kernel and the device-side estimate, or —
+    // exact pricing — the reference's own walk on the host over the sampled blocks, its buffer, zstd
+    auto lorenzo_price = [&](int rad, double &bytes) -> int {
         // (round 4: the reference's own trial geometry — every sample block an array of its own, blocks of five values, Lorenzo-1 or
         // Lorenzo-2 per block — instead of first-order Lorenzo over the concatenated samples: on smooth 1-D series the second-order
         // blocks are what makes Lorenzo win, and the set chosen here is the one stage 1 then codes the array with)
+        if (ctx->exact_now && ctx->h_samples_valid) {
+            std::vector<uint8_t> buf;
+            const bool made = ctx->dtype == SZ3HIP_FLOAT ? stock::lorenzo_trial_buffer<float>(eb, rad, (const float *)ctx->h_samples, per, nb, buf)
+                                                         : stock::lorenzo_trial_buffer<double>(eb, rad, (const double *)ctx->h_samples, per, nb, buf);
+            const size_t z = made ? szi_zstd_size(buf.data(), buf.size()) : 0;
+            if (!z) return fail(SZ3HIP_EZSTD, "tuner: the Lorenzo trial could not be priced");
+            bytes = (double)(z + 8);
+            return 0;
+        }
         HIPCHK(clear_hist_counters(ctx, s));
         HIPCHK(hipMemsetAsync(ctx->d_trial + 24, 0, 64, s));
-        rc = szk_launch_trial_lorenzo12(ctx->dtype == SZ3HIP_FLOAT ? 0 : 1, ctx->d_samples, per, nb, eb, radius, ctx->d_hist, ctx->d_counters, ctx->d_trial + 28, s);
-        if (rc) return fail(SZ3HIP_EHIP, "tuner: Lorenzo trial launch failed (%d)", rc);
-        rc = szk_launch_code_cost(ctx->d_hist, ctx->d_counters, ctx->d_trial + 24, 1, sampling_num, 0, s);
-        if (rc) return fail(SZ3HIP_EHIP, "tuner: cost kernel launch failed (%d)", rc);
-        rc = tuner_fetch(ctx, s);
-        if (rc) return rc;
-        rep.est_bytes[6] = trial_bytes(ctx->h_trial + 24, tsz);
-        {   // the choices' own cost (ComposedPredictor::save: the selection vector Huffman-coded, ComposedPredictor.hpp:52-64): its entropy
-            const double nblk = (double)ctx->h_trial[29], n2 = (double)ctx->h_trial[28];
-            if (nblk > 0 && n2 > 0 && n2 < nblk) {
-                const double p2 = n2 / nblk;
-                rep.est_bytes[6] += nblk * -(p2 * std::log2(p2) + (1 - p2) * std::log2(1 - p2)) / 8.0;
-            }
+        int rl = szk_launch_trial_lorenzo12(ctx->dtype == SZ3HIP_FLOAT ? 0 : 1, ctx->d_samples, per, nb, eb, rad, ctx->d_hist, ctx->d_counters, ctx->d_trial + 28, s);
+        if (rl) return fail(SZ3HIP_EHIP, "tuner: Lorenzo trial launch failed (%d)", rl);
+        rl = szk_launch_code_cost(ctx->d_hist, ctx->d_counters, ctx->d_trial + 24, 1, sampling_num, 0, s);
+        if (rl) return fail(SZ3HIP_EHIP, "tuner: cost kernel launch failed (%d)", rl);
+        rl = tuner_fetch(ctx, s);
+        if (rl) return rl;
+        bytes = trial_bytes(ctx->h_trial + 24, tsz);
+        // the choices' own cost (ComposedPredictor::save: the selection vector Huffman-coded, ComposedPredictor.hpp:52-64): its entropy
+        const double nblk = (double)ctx->h_trial[29], n2 = (double)ctx->h_trial[28];
+        if (nblk > 0 && n2 > 0 && n2 < nblk) {
+            const double p2 = n2 / nblk;
+            bytes += nblk * -(p2 * std::log2(p2) + (1 - p2) * std::log2(1 - p2)) / 8.0;
         }
+        return 0;
+    };
+    if (N == 1 && best_interp < 50) {  // :232-247
+        rc = lorenzo_price(radius, rep.est_bytes[6]);
+        if (rc) return rc;
         best_lorenzo = raw / rep.est_bytes[6];
     }
     rep.ran = 1;
@@ -1201,6 +1216,16 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
         lorenzo_config.regression = 0;
         lorenzo_config.regression2 = 0;
         lorenzo_config.blockSize = 128;
+        // :268-277 — a narrower quantizer (16384 bins) when the bound is not a tiny relative one and Lorenzo compresses at all: kept when
+        // its trial is 2 % better. The caller takes the radius from what comes back in quantbinCnt.
+        if (conf.relErrorBound < 1.01e-6 && best_lorenzo > 5 && lorenzo_config.quantbinCnt != 16384) {
+            rc = lorenzo_price(8192, rep.est_bytes[7]);
+            if (rc) return rc;
+            if (raw / rep.est_bytes[7] > best_lorenzo * 1.02) {
+                best_lorenzo = raw / rep.est_bytes[7];
+                lorenzo_config.quantbinCnt = 16384;
+            }
+        }
         conf = lorenzo_config;
     }
     rep.interpAlgo = conf.interpAlgo;
@@ -1228,7 +1253,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     if (conf->errorBoundMode != SZ3HIP_EB_ABS) return fail(SZ3HIP_EINVAL, "stage1 needs an absolute error bound");
     const double eb = conf->absErrorBound;
     if (!(eb > 0) || !isfinite(eb)) return fail(SZ3HIP_EINVAL, "absErrorBound must be positive and finite");
-    const int radius = conf->quantbinCnt / 2;  // api/impl/SZAlgoLorenzoReg.hpp:72
+    int radius = conf->quantbinCnt / 2;  // api/impl/SZAlgoLorenzoReg.hpp:72
     if (radius < 2 || radius > 32768) return fail(SZ3HIP_EINVAL, "quantbinCnt must be in [4, 65536]");
     ctx->cur_out_cap = ctx->force_out_cap ? ctx->force_out_cap : std::min<uint64_t>(ctx->out_cap, std::max<uint64_t>(1024, num / 32));
     memset(&ctx->tuner, 0, sizeof(ctx->tuner));
@@ -1315,6 +1340,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
             return rct;
         }
         ctx->copy_ahead = ahead;
+        radius = conf->quantbinCnt / 2;  // (the tuner's Lorenzo outcome may have narrowed the quantizer, SZAlgoInterp.hpp:268-277)
         // what the next call of this context may start from
         ctx->spec_valid = ctx->tuner.ran && conf->cmprAlgo == SZ3HIP_ALGO_INTERP;
         if (ctx->spec_valid) ctx->spec_conf = *conf;

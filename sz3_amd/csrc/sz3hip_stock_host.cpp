@@ -870,6 +870,31 @@ bool trial_buffer(const szi_stock_params &p, const uint16_t *codes, const T *sam
 }
 template bool trial_buffer<float>(const szi_stock_params &, const uint16_t *, const float *, uint64_t, std::vector<uint8_t> &);
 template bool trial_buffer<double>(const szi_stock_params &, const uint16_t *, const double *, uint64_t, std::vector<uint8_t> &);
+// ... and of the tuner's 1-D Lorenzo trial (lorenzo_compress_test, api/impl/SZAlgoInterp.hpp:80-120): ONE blockwise decomposition with the
+// composed set {Lorenzo-1, Lorenzo-2} in blocks of five codes every sampled block as an array of its own (padding of zeros in front), its
+// selection vector and its quantizer's list growing from block to block; the codes concatenated, one tree, the reference's buffer — a stock
+// ALGO_LORENZO_REG stream's body (write_lorenzo_reg_head, composed, no regression). The walk is lorenzo_reg_write_1d's: the reference's order.
+template <typename T>
+bool lorenzo_trial_buffer(double eb, int radius, const T *samples, uint64_t per, uint64_t nb, std::vector<uint8_t> &raw) {
+    std::vector<uint16_t> all, codes, sel, cc;
+    std::vector<T> un, ui, ul, blk((size_t)per);
+    all.reserve((size_t)(per * nb));
+    for (uint64_t k = 0; k < nb; k++) {
+        memcpy(blk.data(), samples + k * per, (size_t)per * sizeof(T));
+        lorenzo_reg_write_1d<T>(per, 5, eb, radius, 3u, blk.data(), codes, un, sel, cc, ui, ul);
+        all.insert(all.end(), codes.begin(), codes.end());
+    }
+    if (all.empty()) return false;
+    Tree tr;
+    int lo = 0, hi = 0;
+    std::vector<uint8_t> bits;
+    if (!encode_codes_host(all, tr, lo, hi, bits)) return false;
+    write_lorenzo_reg_head(1, 5, eb, sizeof(T), false, true, cc, nullptr, 0, nullptr, 0, sel, radius, un.data(), un.size(), tr, lo, hi, all.size(), bits.size(), raw);
+    raw.insert(raw.end(), bits.begin(), bits.end());
+    return true;
+}
+template bool lorenzo_trial_buffer<float>(double, int, const float *, uint64_t, uint64_t, std::vector<uint8_t> &);
+template bool lorenzo_trial_buffer<double>(double, int, const double *, uint64_t, uint64_t, std::vector<uint8_t> &);
 }  // namespace stock
 // test hook (CPU, no device): the buffer of a trial from per-element codes; returns its size, -1 when the geometry is refused, -2 when `cap` is short
 extern "C" int64_t sz3hip_debug_trial_buffer(int N, const uint64_t *dims, int interp_id, int direction, uint64_t anchor_stride, double alpha, double beta,

@@ -66,5 +66,8 @@ bool host_decode(const Tree &tr, int32_t offset, const uint8_t *bits, size_t nby
 // hands to zstd (api/impl/SZAlgoInterp.hpp:42-78), from the trial kernel's per-element codes of all sampled blocks
 template <typename T>
 bool trial_buffer(const szi_stock_params &p, const uint16_t *codes, const T *samples, uint64_t nb, std::vector<uint8_t> &raw);
+// ... and the 1-D Lorenzo trial's (lorenzo_compress_test, :80-120), walked on the host over the sampled blocks
+template <typename T>
+bool lorenzo_trial_buffer(double eb, int radius, const T *samples, uint64_t per, uint64_t nb, std::vector<uint8_t> &raw);
 }  // namespace stock
 #endif

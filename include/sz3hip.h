@@ -104,8 +104,9 @@ size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in);
  * interpolation compressor (cmprAlgo ALGO_INTERP = 2, float / double, 1-D .. 4-D — what the reference's default ALGO_INTERP_LORENZO
  * writes for anything but some 1-D arrays) and of ALGO_LOSSLESS, next to this library's own ids 16 / 17; the reconstruction is the
  * reference's bit for bit. WRITING: sz3hip_set_stock_format(1) (or SZ3HIP_STOCK_FORMAT=1 in the environment) makes sz3hip_compress —
- * and everything on top of it — write ALGO_INTERP streams stock SZ3 reads whenever the interpolation predictor is chosen; other
- * outcomes (Lorenzo, regression) keep this library's ids. Prediction, quantisation, reconstruction and the Huffman bit stream run on the
+ * and everything on top of it — write ALGO_INTERP streams stock SZ3 reads whenever the interpolation predictor is chosen (a 1-D array whose
+ * default-algorithm tuner takes Lorenzo gets the reference's ALGO_LORENZO_REG container with the Config the reference goes on with); calls that
+ * name ALGO_LORENZO_REG / ALGO_NOPRED get those containers; what has no stock form here keeps this library's ids. Prediction, quantisation, reconstruction and the Huffman bit stream run on the
  * GPU either way; the tree's serialisation and zstd are host stages. The tree is built with the reference's own queue (which of two
  * equal frequencies merges first, encoder/HuffmanEncoder.hpp:402-432): wherever the codes are the reference's — ALGO_INTERP, ALGO_NOPRED,
  * the default algorithm with SZ3HIP_TUNER_EXACT=1, ALGO_LORENZO_REG in 1-D and wherever the blocks' choices coincide — the container

@@ -1234,6 +1234,12 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
     rep.interpBeta = conf.interpBeta;
     return 0;
 }
+// 1: the last stage 1 was the default algorithm's and its tuner took Lorenzo (1-D arrays only); *quantbinCnt: the quantizer it ended with
+int szi_tuner_took_lorenzo(sz3hip_ctx *ctx, int *quantbinCnt) {
+    if (!ctx->tuner.ran || ctx->tuner.use_interp || !ctx->stage1_done) return 0;
+    *quantbinCnt = (int)ctx->proto.radius * 2;
+    return 1;
+}
 extern "C" int sz3hip_get_tuner_report(sz3hip_ctx *ctx, sz3hip_tuner_report *rep) {
     *rep = ctx->tuner;
     return 0;

@@ -1835,7 +1835,19 @@ int job_encode(SlabJob &j) {
             // the caller wants files stock SZ3 reads: where stage 1 took the interpolation predictor its codes go into the reference's
             // own container (cmprAlgo ALGO_INTERP) instead of the device payload
             // ... and a call that names ALGO_LORENZO_REG gets the reference's Lorenzo / regression stream (round 5: 2-D and 3-D arrays)
-            const int rs = j.asked_algo == SZ3HIP_ALGO_LORENZO_REG ? stock_encode_lorenzo_reg(j) : j.asked_algo == SZ3HIP_ALGO_NOPRED ? stock_encode_nopred(j) : stock_encode_interp(j);
+            int rs = j.asked_algo == SZ3HIP_ALGO_LORENZO_REG ? stock_encode_lorenzo_reg(j) : j.asked_algo == SZ3HIP_ALGO_NOPRED ? stock_encode_nopred(j) : stock_encode_interp(j);
+            int qbins = 0;
+            if (rs == SZ3HIP_EUNSUPPORTED && !j.lossless && j.asked_algo == SZ3HIP_ALGO_INTERP_LORENZO && j.conf.N == 1 && szi_tuner_took_lorenzo(ctx, &qbins)) {
+                // the default algorithm on a 1-D array whose tuner took Lorenzo: the Config the reference goes on with (SZAlgoInterp.hpp:233-240,
+                // 268-282 — Lorenzo-1 + Lorenzo-2, no regression, setDims' block size again, the quantizer the trials ended with) in the
+                // reference's Lorenzo container
+                j.conf.cmprAlgo = SZ3HIP_ALGO_LORENZO_REG;
+                j.conf.lorenzo = j.conf.lorenzo2 = 1;
+                j.conf.regression = j.conf.regression2 = 0;
+                j.conf.blockSize = 128;
+                j.conf.quantbinCnt = qbins;
+                rs = stock_encode_lorenzo_reg(j);
+            }
             if (rs == 0) return 0;
             if (rs != SZ3HIP_EUNSUPPORTED) return j.failed(rs);
             // (another predictor: there is no stock form of it here — this library's own stream)

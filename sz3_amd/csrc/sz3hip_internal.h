@@ -35,6 +35,7 @@ int szi_stock_import(sz3hip_ctx *ctx, const szi_stock_params *p, const szg_geom 
                      const void *d_unpred, uint64_t n_unpred, uint32_t *d_tile_cnt, uint64_t *d_tile_base, uint64_t *d_vout_idx, void *d_vout_val,
                      uint32_t *d_bad, void *d_out, void *stream);
 int szi_stage1_with_larger_lists(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, uint64_t need, void *stream);
+int szi_tuner_took_lorenzo(sz3hip_ctx *ctx, int *quantbinCnt);  // the default algorithm's tuner chose Lorenzo in the pending stage 1 (1-D), and with which quantizer
 size_t szi_zstd_size(const void *src, size_t n);  // ZSTD_compress(level 3)'s size of a buffer (sz3hip_host.cpp: libzstd lives there); 0 on error
 void *szi_histogram_for_exchange(sz3hip_ctx *ctx);  // the histogram, for the library's own all-reduce between the stages (sz3hip_api.cpp)
 

@@ -123,8 +123,9 @@ def test_default_algorithm_in_stock_format_and_ids_without_the_switch():
 
 
 @pytest.mark.parametrize("name,gen,kwc", [("abs-3d", lambda: field3d((72, 80, 88)), dict(abs_eb=3e-2)), ("rel-3d", lambda: field3d((72, 80, 88)), dict(eb_mode=EB_REL, rel_eb=1e-3)),
-                                          ("abs-2d", lambda: field2d((600, 700)), dict(abs_eb=1e-3)), ("abs-4d", lambda: field4d((12, 40, 40, 40)), dict(abs_eb=1e-2))],
-                         ids=["abs-3d", "rel-3d", "abs-2d", "abs-4d"])
+                                          ("abs-2d", lambda: field2d((600, 700)), dict(abs_eb=1e-3)), ("abs-4d", lambda: field4d((12, 40, 40, 40)), dict(abs_eb=1e-2)),
+                                          ("abs-1d", lambda: field1d(1 << 18), dict(abs_eb=1e-3))],  # (1-D: the tuner takes Lorenzo-1 + Lorenzo-2 in blocks of 128)
+                         ids=["abs-3d", "rel-3d", "abs-2d", "abs-4d", "abs-1d"])
 def test_default_algorithm_in_stock_format_with_exact_pricing_is_the_reference_s_file(name, gen, kwc, monkeypatch):
     """the reference's default algorithm end to end: its tuner's decisions (SZ3HIP_TUNER_EXACT=1: the trials priced the reference's way),
     its stream layout, its tree order, one zstd frame — the container equals the reference's byte for byte"""

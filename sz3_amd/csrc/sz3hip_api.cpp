@@ -1011,7 +1011,7 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
     rep.use_interp = 1;
     {   // sz3hip_ctx_set_tuner_exact, or — for contexts nobody holds a handle of: the host API's, the CLI's, the HDF5 filter's — the environment
         const char *te = getenv("SZ3HIP_TUNER_EXACT");
-        ctx->exact_now = ctx->tuner_exact == 1 || (ctx->tuner_exact == 0 && te && atoi(te) != 0);
+        ctx->exact_now = ctx->tuner_exact == 1 || (ctx->tuner_exact == 0 && (te ? atoi(te) != 0 : ctx->exact_default));
     }
     static const int def_anchor[4] = {4096, 128, 32, 16};
     if (conf.interpAnchorStride < 0) conf.interpAnchorStride = def_anchor[N - 1];
@@ -1234,6 +1234,7 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
     rep.interpBeta = conf.interpBeta;
     return 0;
 }
+void szi_ctx_exact_default(sz3hip_ctx *ctx, int on) { ctx->exact_default = on != 0; }
 // 1: the last stage 1 was the default algorithm's and its tuner took Lorenzo (1-D arrays only); *quantbinCnt: the quantizer it ended with
 int szi_tuner_took_lorenzo(sz3hip_ctx *ctx, int *quantbinCnt) {
     if (!ctx->tuner.ran || ctx->tuner.use_interp || !ctx->stage1_done) return 0;

@@ -597,6 +597,7 @@ int slot_ctx(HostSlot *s, uint64_t n) {
     s->ctx = sz3hip_ctx_create(s->device, n, s->dtype);
     // the host API writes files (the CLI, the HDF5 filter): the same input gives the same bytes whatever this slot coded before
     if (s->ctx) sz3hip_ctx_set_deterministic(s->ctx, 1);
+    if (s->ctx) szi_ctx_exact_default(s->ctx, 1);  // (the host API — what a caller of the reference's boundary sees — takes the reference's tuner decisions; SZ3HIP_TUNER_EXACT=0: the estimate)
     return s->ctx ? 0 : sz3hip_last_error_code();
 }
 int ensure_dev(void **p, size_t *have, size_t want) {

@@ -35,6 +35,7 @@ int szi_stock_import(sz3hip_ctx *ctx, const szi_stock_params *p, const szg_geom 
                      const void *d_unpred, uint64_t n_unpred, uint32_t *d_tile_cnt, uint64_t *d_tile_base, uint64_t *d_vout_idx, void *d_vout_val,
                      uint32_t *d_bad, void *d_out, void *stream);
 int szi_stage1_with_larger_lists(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, uint64_t need, void *stream);
+void szi_ctx_exact_default(sz3hip_ctx *ctx, int on);  // what a context does about the tuner's pricing when neither the setter nor the environment says
 int szi_tuner_took_lorenzo(sz3hip_ctx *ctx, int *quantbinCnt);  // the default algorithm's tuner chose Lorenzo in the pending stage 1 (1-D), and with which quantizer
 size_t szi_zstd_size(const void *src, size_t n);  // ZSTD_compress(level 3)'s size of a buffer (sz3hip_host.cpp: libzstd lives there); 0 on error
 void *szi_histogram_for_exchange(sz3hip_ctx *ctx);  // the histogram, for the library's own all-reduce between the stages (sz3hip_api.cpp)
@@ -204,6 +205,7 @@ struct sz3hip_ctx {
     sz3hip_tuner_report tuner;
     int tuner_exact;         // sz3hip_ctx_set_tuner_exact: trials priced the reference's way (tree + bits + zstd on the host); 0: as SZ3HIP_TUNER_EXACT says, 1 on, 2 off
     bool exact_now;          // ... this call's
+    bool exact_default;      // ... with neither the setter nor SZ3HIP_TUNER_EXACT (the host API's contexts: on)
     double exact_bytes[8];   // ... their sizes, by result slot
     uint16_t *h_trial_codes; // ... the trials' codes and the sampled blocks on the host
     size_t h_trial_codes_cap;

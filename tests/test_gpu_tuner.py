@@ -152,13 +152,14 @@ def test_exact_pricing_gives_the_reference_sizes_and_decisions(name, gen, eb):
 
 @pytest.mark.parametrize("name,gen,eb", [EXACT_CASES[8], EXACT_CASES[3], EXACT_CASES[13]], ids=["3d-96-3e-2", "3d-f64-1e-6", "4d-1e-2"])
 def test_default_algorithm_through_the_host_api_reconstructs_what_the_reference_reconstructs(name, gen, eb, monkeypatch):
-    """SZ3HIP_TUNER_EXACT=1 (read per call: the host API's contexts have no handle to call the setter on): the reference's default
-    algorithm through sz3_amd.compress takes the reference's parameters — on arrays where the estimate takes others — and the
-    decompressed array is, bit for bit, what the reference's own stream decompresses to."""
+    """The host API prices the tuner's trials the reference's way BY DEFAULT (its contexts: szi_ctx_exact_default; SZ3HIP_TUNER_EXACT=0,
+    read per call, gives the estimate back): the reference's default algorithm through sz3_amd.compress takes the reference's parameters
+    — on arrays where the estimate takes others — and the decompressed array is, bit for bit, what the reference's own stream
+    decompresses to."""
     a = gen()
     conf = sz3_amd.Config(*a.shape)
     conf.absErrorBound = eb
-    monkeypatch.setenv("SZ3HIP_TUNER_EXACT", "1")
+    monkeypatch.delenv("SZ3HIP_TUNER_EXACT", raising=False)
     blob, _ = sz3_amd.compress(a, conf)
     dec, c2 = sz3_amd.decompress(blob, a.dtype, a.shape)
     oconf = make_config(a.shape, algo=ALGO_INTERP_LORENZO, abs_eb=eb, regression=True)

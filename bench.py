@@ -884,6 +884,15 @@ def main():
             c3.update(rooflines(w3, acc3, ps3, ms3, "c3_stage1_hbm_bytes_per_step"))
             if not args.no_cold:
                 c3["cold"] = w3.cold_numbers(5, barrier)
+            try:  # the same step with the tuner's trials priced the reference's way (sz3hip_ctx_set_tuner_exact: tree + bits + zstd per trial on host threads)
+                w3.dc.set_tuner_exact(True)
+                elx, psx = timed(w3, 5, 2)
+                c3["reference_priced_tuner"] = {"ms_per_step": round(1e3 * elx / 5, 4), "ratio": round(raw_bytes / float(psx), 4), "tuner": w3.dc.tuner_report(),
+                                                "note": "est_bytes are then the reference's own compressed trial sizes byte for byte and the decisions the reference's "
+                                                        "(tests/test_gpu_tuner.py); the host API's default, a device context's option"}
+                w3.dc.set_tuner_exact(False)
+            except Exception as e:  # noqa: BLE001
+                c3["reference_priced_tuner"] = {"error": repr(e)[:200]}
             out["extra_configs"] = {"C3": c3}
             del w3
         except Exception as e:  # noqa: BLE001 - the headline line must survive a failing extra

@@ -963,7 +963,7 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
     ctx->h_samples_valid = true;
     const auto t1 = std::chrono::steady_clock::now();
     std::vector<size_t> sizes((size_t)ntr, 0);
-    auto price = [&](int j) {
+    auto params = [&](int j) {
         szi_stock_params sp;
         memset(&sp, 0, sizeof(sp));
         sp.N = tcs[j].N;
@@ -975,18 +975,33 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
         sp.beta = tcs[j].interpBeta;
         sp.eb = eb;
         sp.radius = radius;
-        std::vector<uint8_t> raw;
-        const uint16_t *codes = ctx->h_trial_codes + (size_t)j * nb * per;
-        const bool made = ctx->dtype == SZ3HIP_FLOAT ? stock::trial_buffer<float>(sp, codes, (const float *)ctx->h_samples, nb, raw)
-                                                     : stock::trial_buffer<double>(sp, codes, (const double *)ctx->h_samples, nb, raw);
-        if (!made) return;
-        const size_t z = szi_zstd_size(raw.data(), raw.size());
-        sizes[j] = z ? z + 8 : 0;  // (Lossless_zstd::compress: the length word in front of the frame)
+        return sp;
     };
-    std::vector<std::thread> th;
-    for (int j = 1; j < ntr; j++) th.emplace_back(price, j);
-    price(0);
-    for (auto &t : th) t.join();
+    // the steps of stock::TrialWork over the pool's threads, two per trial where a step divides (order, bits): 14 tasks for a group of seven
+    auto priced_as = [&](auto zero) {
+        typedef decltype(zero) T;
+        std::vector<stock::TrialWork<T>> w((size_t)ntr);
+        std::vector<char> ok((size_t)ntr, 1);
+        for (int j = 0; j < ntr; j++) {
+            w[j].p = params(j);
+            w[j].codes = ctx->h_trial_codes + (size_t)j * nb * per;
+            w[j].samples = (const T *)ctx->h_samples;
+            w[j].nb = nb;
+            ok[j] = w[j].prepare();
+        }
+        szi_run_parallel(2 * ntr, [&](int i) { if (ok[i / 2]) w[i / 2].order(i & 1); });
+        szi_run_parallel(ntr, [&](int j) { if (ok[j]) ok[j] = w[j].book(); });
+        szi_run_parallel(2 * ntr, [&](int i) { if (ok[i / 2]) w[i / 2].bits(i & 1); });
+        szi_run_parallel(ntr, [&](int j) {
+            if (!ok[j]) return;
+            std::vector<uint8_t> raw;
+            w[j].finish(raw);
+            const size_t z = szi_zstd_size(raw.data(), raw.size());
+            sizes[j] = z ? z + 8 : 0;  // (Lossless_zstd::compress: the length word in front of the frame)
+        });
+    };
+    if (ctx->dtype == SZ3HIP_FLOAT) priced_as(0.0f);
+    else priced_as(0.0);
     if (tt)
         fprintf(stderr, "[sz3hip tuner] exact group of %d: kernels + copy out %.3f ms, pricing %.3f ms\n", ntr, std::chrono::duration<double, std::milli>(t1 - t0).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
@@ -1001,9 +1016,70 @@ static int tuner_fetch(sz3hip_ctx *ctx, hipStream_t s) {
     HIPCHK(hipStreamSynchronize(s));
     return 0;
 }
+// profiling_block / sample_blocks on an array that still lies in HOST memory (szi_pretune_host: the tuner beside the array's copy in) — the
+// device kernels' arithmetic (k_profile_blocks, k_gather_blocks): the strided samples' plain minimum / maximum in T, blocks copied element by element
+template <typename T>
+static uint64_t host_profile_blocks(const T *data, int N, const uint64_t *dims, uint64_t bs, uint64_t stride, double abseb, uint8_t *flags) {
+    uint64_t off[4] = {0, 0, 0, 0}, cnt[4] = {1, 1, 1, 1}, total = 1;
+    off[N - 1] = 1;
+    for (int i = N - 2; i >= 0; i--) off[i] = off[i + 1] * dims[i + 1];
+    for (int i = 0; i < N; i++) {
+        if (dims[i] < bs) return 0;
+        cnt[i] = (dims[i] - bs + bs - 1) / bs;
+        total *= cnt[i];
+    }
+    if (!total) return 0;
+    if (!stride) stride = bs;
+    const uint64_t m = bs / stride + 1;
+    uint64_t npts = 1;
+    for (int j = 0; j < N; j++) npts *= m;
+    const int parts = (int)std::min<uint64_t>(16, std::max<uint64_t>(1, total / 256));
+    szi_run_parallel(parts, [&](int part) {
+        for (uint64_t t = total * part / parts; t < total * (part + 1) / parts; t++) {
+            uint64_t r = t, start = 0;
+            for (int j = N - 1; j >= 0; j--) {
+                start += (r % cnt[j]) * bs * off[j];
+                r /= cnt[j];
+            }
+            T mn = data[start], mx = mn;
+            for (uint64_t q = 0; q < npts; q++) {
+                uint64_t rr = q, idx = start;
+                for (int j = N - 1; j >= 0; j--) {
+                    idx += (rr % m) * stride * off[j];
+                    rr /= m;
+                }
+                const T v = data[idx];
+                if (v < mn) mn = v;
+                if (v > mx) mx = v;
+            }
+            flags[t] = (mx - mn > abseb) ? 1 : 0;
+        }
+    });
+    return total;
+}
+template <typename T>
+static void host_gather_blocks(const T *data, int N, const uint64_t *dims, uint64_t edge, const uint64_t *starts, uint64_t nb, T *out) {
+    uint64_t off[4] = {0, 0, 0, 0}, per = 1;
+    off[N - 1] = 1;
+    for (int i = N - 2; i >= 0; i--) off[i] = off[i + 1] * dims[i + 1];
+    for (int i = 0; i < N; i++) per *= edge;
+    const uint64_t rows = per / edge;  // runs of `edge` consecutive elements
+    for (uint64_t b = 0; b < nb; b++) {
+        const uint64_t *st = starts + b * 4;
+        T *o = out + b * per;
+        for (uint64_t rw = 0; rw < rows; rw++) {
+            uint64_t r = rw, idx = st[N - 1];
+            for (int j = N - 2; j >= 0; j--) {
+                idx += (st[j] + r % edge) * off[j];
+                r /= edge;
+            }
+            memcpy(o + rw * edge, data + idx, edge * sizeof(T));
+        }
+    }
+}
 // fills `conf` like the reference does before its final compress call: cmprAlgo becomes ALGO_INTERP (interpAlgo,
 // interpDirection, interpAlpha, interpBeta tuned) or ALGO_LORENZO_REG (1-D only)
-static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void *d_in, double eb, int radius, hipStream_t s) {
+static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void *d_in, double eb, int radius, hipStream_t s, const void *h_in = nullptr) {
     const int N = conf.N;
     const size_t tsz = ctx->dtype == SZ3HIP_FLOAT ? 4 : 8;
     sz3hip_tuner_report &rep = ctx->tuner;
@@ -1042,9 +1118,14 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
     int rc = tuner_reserve(ctx, std::max<uint64_t>(cand, 1), 4096 * 32, 0);
     if (rc) return rc;
     uint64_t total = 0;
-    rc = szk_launch_profile_blocks(ctx->dtype, d_in, N, conf.dims, sbs, sbs / 4, eb, ctx->d_flags, &total, s);
-    if (rc) return fail(SZ3HIP_EHIP, "tuner: profiling launch failed (%d)", rc);
-    if (total) HIPCHK(hipStreamSynchronize(s));
+    if (h_in) {  // (the array is still on its way to the device: the candidates' strided samples read where it lies)
+        total = ctx->dtype == SZ3HIP_FLOAT ? host_profile_blocks<float>((const float *)h_in, N, conf.dims, sbs, sbs / 4, eb, ctx->d_flags)
+                                           : host_profile_blocks<double>((const double *)h_in, N, conf.dims, sbs, sbs / 4, eb, ctx->d_flags);
+    } else {
+        rc = szk_launch_profile_blocks(ctx->dtype, d_in, N, conf.dims, sbs, sbs / 4, eb, ctx->d_flags, &total, s);
+        if (rc) return fail(SZ3HIP_EHIP, "tuner: profiling launch failed (%d)", rc);
+        if (total) HIPCHK(hipStreamSynchronize(s));
+    }
     const uint8_t *flags = ctx->d_flags;
     uint64_t cnt[4] = {1, 1, 1, 1};
     for (int i = 0; i < N; i++) cnt[i] = (conf.dims[i] - sbs + sbs - 1) / sbs;
@@ -1084,11 +1165,26 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
             r /= cnt[j];
         }
     }
-    rc = szk_launch_gather_blocks(ctx->dtype, d_in, N, conf.dims, sbs + 1, ctx->d_starts, (uint32_t)nb, ctx->d_samples, s);
-    if (rc) return fail(SZ3HIP_EHIP, "tuner: gather launch failed (%d)", rc);
+    ctx->h_samples_valid = false;  // (exact pricing: this call's sample blocks are fetched with the first group's codes — or gathered on the host right here)
+    if (h_in) {
+        const size_t sbytes = (size_t)sampling_num * tsz;
+        if (ctx->h_samples_cap < sbytes) {
+            if (ctx->h_samples) (void)hipHostFree(ctx->h_samples);
+            ctx->h_samples = nullptr;
+            ctx->h_samples_cap = 0;
+            HIPCHK(hipHostMalloc(&ctx->h_samples, sbytes));
+            ctx->h_samples_cap = sbytes;
+        }
+        if (ctx->dtype == SZ3HIP_FLOAT) host_gather_blocks<float>((const float *)h_in, N, conf.dims, sbs + 1, starts, nb, (float *)ctx->h_samples);
+        else host_gather_blocks<double>((const double *)h_in, N, conf.dims, sbs + 1, starts, nb, (double *)ctx->h_samples);
+        HIPCHK(hipMemcpyAsync(ctx->d_samples, ctx->h_samples, sbytes, hipMemcpyHostToDevice, s));
+        ctx->h_samples_valid = true;
+    } else {
+        rc = szk_launch_gather_blocks(ctx->dtype, d_in, N, conf.dims, sbs + 1, ctx->d_starts, (uint32_t)nb, ctx->d_samples, s);
+        if (rc) return fail(SZ3HIP_EHIP, "tuner: gather launch failed (%d)", rc);
+    }
 
     const double raw = (double)sampling_num * (double)tsz;
-    ctx->h_samples_valid = false;  // (exact pricing: this call's sample blocks are fetched with the first group's codes)
     auto priced = [&](int slot) { return ctx->exact_now ? ctx->exact_bytes[slot] : trial_bytes(ctx->h_trial + 4 * slot, tsz); };
     double best_interp = 0, best_lorenzo = 0;
     sz3hip_config lorenzo_config = conf;
@@ -1246,6 +1342,38 @@ extern "C" int sz3hip_get_tuner_report(sz3hip_ctx *ctx, sz3hip_tuner_report *rep
     return 0;
 }
 
+static bool same_call(const sz3hip_config &a, const sz3hip_config &b) {
+    if (a.N != b.N || a.num != b.num || a.cmprAlgo != b.cmprAlgo || a.errorBoundMode != b.errorBoundMode || a.absErrorBound != b.absErrorBound ||
+        a.quantbinCnt != b.quantbinCnt || a.interpAnchorStride != b.interpAnchorStride || a.relErrorBound != b.relErrorBound)
+        return false;
+    for (int i = 0; i < a.N; i++)
+        if (a.dims[i] != b.dims[i]) return false;
+    return true;
+}
+int szi_pretune_host(sz3hip_ctx *ctx, const sz3hip_config *conf_in, const void *h_in) {
+    ctx->pre_valid = false;
+    if (conf_in->cmprAlgo != SZ3HIP_ALGO_INTERP_LORENZO || conf_in->errorBoundMode != SZ3HIP_EB_ABS || conf_in->N < 1 || conf_in->N > 4) return -1;
+    const double eb = conf_in->absErrorBound;
+    const int radius = conf_in->quantbinCnt / 2;
+    if (!(eb > 0) || !isfinite(eb) || radius < 2 || radius > 32768 || conf_in->num > ctx->max_n || conf_in->num == 0) return -1;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->side) {  // (the side stream always comes with its two events: the other users test the stream alone)
+        HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    sz3hip_config conf = *conf_in;
+    const sz3hip_tuner_report keep = ctx->tuner;
+    const int rc = tune_interp_lorenzo(ctx, conf, nullptr, eb, radius, ctx->side, h_in);
+    ctx->pre_report = ctx->tuner;
+    ctx->tuner = keep;
+    if (rc) return rc;
+    ctx->pre_conf = conf;
+    ctx->pre_key = *conf_in;
+    ctx->pre_valid = true;
+    return 0;
+}
+
 extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf_in, const void *d_in, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
@@ -1272,6 +1400,15 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     ctx->s1_conf = *conf_in;
     ctx->s1_in = d_in;
     prof_begin(ctx, ST_SPAN, s);  // (closed at the end of stage 2: the device time of the whole step)
+    const bool pretuned = conf->cmprAlgo == SZ3HIP_ALGO_INTERP_LORENZO && ctx->pre_valid && same_call(ctx->pre_key, *conf_in);
+    ctx->pre_valid = false;  // (an outcome is for the very next call, or for none)
+    if (pretuned) {  // szi_pretune_host tuned this call from the host's copy of the array while it was on its way here
+        *conf = ctx->pre_conf;
+        ctx->tuner = ctx->pre_report;
+        radius = conf->quantbinCnt / 2;
+        ctx->spec_valid = ctx->tuner.ran && conf->cmprAlgo == SZ3HIP_ALGO_INTERP;
+        if (ctx->spec_valid) ctx->spec_conf = *conf;
+    }
     if (conf->cmprAlgo == SZ3HIP_ALGO_INTERP_LORENZO) {  // the reference's default: sampling auto-tuner, then one of the two paths
         // The tuner is a chain of small launches and host round trips (the chip is mostly idle), and its outcome is almost
         // always interpolation, which starts from a working copy of the input: make that copy meanwhile on a side stream.

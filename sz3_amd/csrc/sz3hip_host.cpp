@@ -416,6 +416,14 @@ static size_t decompress_frames(const uint8_t *src, size_t n, uint8_t *dst, size
     return (size_t)len;
 }
 }  // namespace zs
+// f(0) on the calling thread, f(1) .. f(n - 1) on the pool's threads; returns when all have run. Never called from a pool task (a task waiting for
+// tasks queued behind it would wait for ever once every thread does).
+void szi_run_parallel(int n, const std::function<void(int)> &f) {
+    zs::Batch b;
+    for (int i = 1; i < n; i++) b.add([&f, i] { f(i); });
+    if (n > 0) f(0);
+    b.wait();
+}
 // what ZSTD_compress (level 3, one frame) makes of a buffer, in bytes: Lossless_zstd::compress's return value less its 8-byte length word
 // (lossless/Lossless_zstd.hpp:29-37) — the price of a tuner trial (sz3hip_ctx_set_tuner_exact, sz3hip_api.cpp); 0: no libzstd / an error
 size_t szi_zstd_size(const void *src, size_t n) {
@@ -733,7 +741,15 @@ int job_upload(SlabJob &j) {
     if (ensure_dev(&s->dev_payload, &s->dev_payload_bytes, pb)) return j.failed(SZ3HIP_EHIP);
     if (j.tm) j.tm->lap("setup");
     if (!j.is_int) {
-        if (hipMemcpy(s->dev_in, j.data, j.raw_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        // the default algorithm's tuner from the host's copy of the array, beside its copy in (a thread of its own: the copy below blocks this
+        // one; the tuner's launches, round trips and — host API default — its trials priced the reference's way vanish behind 9 ms of copy at
+        // 512^3). Absolute bounds only: the others need the array's range first. A tuner that fails here runs in stage 1 as before.
+        std::thread pre;
+        if (j.conf.cmprAlgo == SZ3HIP_ALGO_INTERP_LORENZO && j.conf.errorBoundMode == SZ3HIP_EB_ABS && j.raw_bytes >= (16u << 20) && !env_int("SZ3HIP_NO_PRETUNE", 0))
+            pre = std::thread([ctx, &j] { (void)szi_pretune_host(ctx, &j.conf, j.data); });
+        const hipError_t ec = hipMemcpy(s->dev_in, j.data, j.raw_bytes, hipMemcpyHostToDevice);
+        if (pre.joinable()) pre.join();
+        if (ec != hipSuccess) {
             fail(SZ3HIP_EHIP, "host->device copy failed");
             return j.failed(SZ3HIP_EHIP);
         }

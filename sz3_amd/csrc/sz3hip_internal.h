@@ -35,8 +35,13 @@ int szi_stock_import(sz3hip_ctx *ctx, const szi_stock_params *p, const szg_geom 
                      const void *d_unpred, uint64_t n_unpred, uint32_t *d_tile_cnt, uint64_t *d_tile_base, uint64_t *d_vout_idx, void *d_vout_val,
                      uint32_t *d_bad, void *d_out, void *stream);
 int szi_stage1_with_larger_lists(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, uint64_t need, void *stream);
+// The default algorithm's tuner run from the HOST copy of an array while that array is being copied to the device (the host API: the tuner's
+// launches, round trips and host-side pricing vanish behind the copy). conf: the call's Config with its absolute bound; the next
+// sz3hip_compress_stage1 of this context with the same Config takes the outcome instead of tuning. Returns 0 when it did.
+int szi_pretune_host(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *h_in);
 void szi_ctx_exact_default(sz3hip_ctx *ctx, int on);  // what a context does about the tuner's pricing when neither the setter nor the environment says
 int szi_tuner_took_lorenzo(sz3hip_ctx *ctx, int *quantbinCnt);  // the default algorithm's tuner chose Lorenzo in the pending stage 1 (1-D), and with which quantizer
+void szi_run_parallel(int n, const std::function<void(int)> &f);  // f(0 .. n - 1) over the host API's pool of threads (sz3hip_host.cpp), f(0) on the caller
 size_t szi_zstd_size(const void *src, size_t n);  // ZSTD_compress(level 3)'s size of a buffer (sz3hip_host.cpp: libzstd lives there); 0 on error
 void *szi_histogram_for_exchange(sz3hip_ctx *ctx);  // the histogram, for the library's own all-reduce between the stages (sz3hip_api.cpp)
 
@@ -206,6 +211,9 @@ struct sz3hip_ctx {
     int tuner_exact;         // sz3hip_ctx_set_tuner_exact: trials priced the reference's way (tree + bits + zstd on the host); 0: as SZ3HIP_TUNER_EXACT says, 1 on, 2 off
     bool exact_now;          // ... this call's
     bool exact_default;      // ... with neither the setter nor SZ3HIP_TUNER_EXACT (the host API's contexts: on)
+    bool pre_valid;          // szi_pretune_host ran for the call to come: its outcome (pre_conf, pre_report) for the array pre_key describes
+    sz3hip_config pre_conf, pre_key;
+    sz3hip_tuner_report pre_report;
     double exact_bytes[8];   // ... their sizes, by result slot
     uint16_t *h_trial_codes; // ... the trials' codes and the sampled blocks on the host
     size_t h_trial_codes_cap;

@@ -283,49 +283,41 @@ bool load_tree(R &r, Tree &tr, int32_t &offset) {
 }
 // bits of n codes, MSB first. Threads code contiguous ranges into buffers of their own; the ranges are then joined with the
 // bit shift their predecessors' total leaves them.
-void encode_bits(const uint16_t *em, uint64_t n, int32_t offset, const std::vector<Code> &codes, std::vector<uint8_t> &out) {
-    const unsigned nt = (unsigned)std::min<uint64_t>(threads(), std::max<uint64_t>(1, n / (1u << 20)));
-    std::vector<std::vector<uint8_t>> part(nt);
-    std::vector<uint64_t> pbits(nt, 0);
-    auto work = [&](unsigned t) {
-        const uint64_t a = n * t / nt, b = n * (t + 1) / nt;
-        std::vector<uint8_t> &o = part[t];
-        // a 64-bit word fills from its top and leaves as eight bytes at once (a byte pushed per eight bits was 13 ns per symbol: most of a
-        // tuner trial's exact price, and of the host twin of the device coder)
-        o.resize((size_t)(b - a) / 2 + 64);
-        size_t at = 0;
-        uint64_t acc = 0;   // bits collected, from the top
-        uint32_t have = 0;  // ... how many (< 64)
-        uint64_t total = 0;
-        for (uint64_t i = a; i < b; i++) {
-            const Code &c = codes[(int32_t)em[i] - offset];
-            const uint32_t len = c.len;  // (<= 64: the callers refuse longer code words)
-            if (!len) continue;
-            total += len;
-            const uint32_t room = 64 - have;
-            if (len < room) {
-                acc |= c.bits << (room - len);
-                have += len;
-            } else {
-                const uint32_t rest = len - room;  // (< 64)
-                acc |= rest ? (c.bits >> rest) : c.bits;
-                if (at + 16 > o.size()) o.resize(o.size() * 2);
-                const uint64_t be = __builtin_bswap64(acc);
-                memcpy(o.data() + at, &be, 8);
-                at += 8;
-                acc = rest ? (c.bits << (64 - rest)) : 0;
-                have = rest;
-            }
+// (the two halves of encode_bits, also a tuner trial's steps: a range of symbols into a buffer of its own, the buffers joined)
+void encode_range(const uint16_t *em, uint64_t a, uint64_t b, int32_t offset, const std::vector<Code> &codes, std::vector<uint8_t> &o, uint64_t &bits_out) {
+    // a 64-bit word fills from its top and leaves as eight bytes at once (a byte pushed per eight bits was 13 ns per symbol: most of a
+    // tuner trial's exact price, and of the host twin of the device coder)
+    o.resize((size_t)(b - a) / 2 + 64);
+    size_t at = 0;
+    uint64_t acc = 0;   // bits collected, from the top
+    uint32_t have = 0;  // ... how many (< 64)
+    uint64_t total = 0;
+    for (uint64_t i = a; i < b; i++) {
+        const Code &c = codes[(int32_t)em[i] - offset];
+        const uint32_t len = c.len;  // (<= 64: the callers refuse longer code words)
+        if (!len) continue;
+        total += len;
+        const uint32_t room = 64 - have;
+        if (len < room) {
+            acc |= c.bits << (room - len);
+            have += len;
+        } else {
+            const uint32_t rest = len - room;  // (< 64)
+            acc |= rest ? (c.bits >> rest) : c.bits;
+            if (at + 16 > o.size()) o.resize(o.size() * 2);
+            const uint64_t be = __builtin_bswap64(acc);
+            memcpy(o.data() + at, &be, 8);
+            at += 8;
+            acc = rest ? (c.bits << (64 - rest)) : 0;
+            have = rest;
         }
-        if (at + 16 > o.size()) o.resize(o.size() + 16);
-        for (uint32_t k = 0; k < have; k += 8) o[at++] = (uint8_t)(acc >> (56 - k));
-        o.resize(at);
-        pbits[t] = total;
-    };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
-    work(0);
-    for (auto &x : th) x.join();
+    }
+    if (at + 16 > o.size()) o.resize(o.size() + 16);
+    for (uint32_t k = 0; k < have; k += 8) o[at++] = (uint8_t)(acc >> (56 - k));
+    o.resize(at);
+    bits_out = total;
+}
+void join_parts(const std::vector<uint8_t> *part, const uint64_t *pbits, unsigned nt, std::vector<uint8_t> &out) {
     uint64_t total = 0;
     for (unsigned t = 0; t < nt; t++) total += pbits[t];
     out.assign((total + 7) / 8 + 8, 0);
@@ -346,6 +338,17 @@ void encode_bits(const uint16_t *em, uint64_t n, int32_t offset, const std::vect
         at += pbits[t];
     }
     out.resize((total + 7) / 8);
+}
+void encode_bits(const uint16_t *em, uint64_t n, int32_t offset, const std::vector<Code> &codes, std::vector<uint8_t> &out) {
+    const unsigned nt = (unsigned)std::min<uint64_t>(threads(), std::max<uint64_t>(1, n / (1u << 20)));
+    std::vector<std::vector<uint8_t>> part(nt);
+    std::vector<uint64_t> pbits(nt, 0);
+    auto work = [&](unsigned t) { encode_range(em, n * t / nt, n * (t + 1) / nt, offset, codes, part[t], pbits[t]); };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    join_parts(part.data(), pbits.data(), nt, out);
 }
 // HuffmanEncoder::decode (:225-255): walk the tree bit by bit — through a 12-bit table of where twelve bits lead from the root
 bool decode_bits(const Tree &tr, int32_t offset, const uint8_t *bits, size_t nbytes, uint64_t n, uint16_t *em) {
@@ -792,80 +795,107 @@ bool encode_codes_host(const std::vector<uint16_t> &codes, Tree &tr, int &lo, in
 // quantizer, tree, count, bits — a stock ALGO_INTERP stream's body (write_head) over an array of the sample block's extents. codes: what the
 // trial kernel left per ELEMENT of every block ([nb][per], zero = unpredictable), samples: the blocks themselves. The tree is built with
 // the reference's own queue (build_tree, ref_heap): the trial's price is zstd's size of these very bytes.
+// In steps (TrialWork, sz3hip_stock_host.h) so that the tuner spreads a group's trials over the pool's threads, two per trial where
+// the step divides: prepare, order(0 | 1), book, bits(0 | 1), finish.
 template <typename T>
-bool trial_buffer(const szi_stock_params &p, const uint16_t *codes, const T *samples, uint64_t nb, std::vector<uint8_t> &raw) {
-    szg_geom g;
+bool TrialWork<T>::prepare() {
     std::vector<uint64_t> bb;
     if (szk_stock_geom_build(p.N, p.dims, p.interp_id, p.direction, p.anchor_stride, &g, &bb)) return false;
-    const uint64_t per = g.n;
+    per = g.n;
+    if (!per || !nb) return false;
     // the element emitted r-th: a function of the block's geometry alone — kept from trial to trial and call to call (36 000 closed-form ranks
     // are milliseconds of one host thread; the trials of a tuning share two or three geometries, a series of calls all of them)
-    std::shared_ptr<const std::vector<uint32_t>> perm;
+    static std::mutex mu;
+    static std::map<std::array<uint64_t, 8>, std::shared_ptr<const std::vector<uint32_t>>> kept;
+    const std::array<uint64_t, 8> key = {(uint64_t)p.N, p.dims[0], p.N > 1 ? p.dims[1] : 0, p.N > 2 ? p.dims[2] : 0, p.N > 3 ? p.dims[3] : 0, (uint64_t)g.interp_id,
+                                         (uint64_t)p.direction, g.anchor};
     {
-        static std::mutex mu;
-        static std::map<std::array<uint64_t, 8>, std::shared_ptr<const std::vector<uint32_t>>> kept;
-        const std::array<uint64_t, 8> key = {(uint64_t)p.N, p.dims[0], p.N > 1 ? p.dims[1] : 0, p.N > 2 ? p.dims[2] : 0, p.N > 3 ? p.dims[3] : 0, (uint64_t)g.interp_id,
-                                             (uint64_t)p.direction, g.anchor};
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            auto it = kept.find(key);
-            if (it != kept.end()) perm = it->second;
-        }
-        if (!perm) {
-            auto v = std::make_shared<std::vector<uint32_t>>(per);
-            for (uint64_t e = 0; e < per; e++) {
-                uint64_t x[4], q = e;
-                for (int i = p.N - 1; i >= 0; i--) {
-                    x[i] = q % g.d[i];
-                    q /= g.d[i];
-                }
-                (*v)[szg_rank(g, bb.data(), x)] = (uint32_t)e;
-            }
-            perm = v;
-            std::lock_guard<std::mutex> lk(mu);
-            if (kept.size() >= 32) kept.clear();
-            kept[key] = perm;
-        }
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = kept.find(key);
+        if (it != kept.end()) perm = it->second;
     }
+    if (!perm) {
+        auto v = std::make_shared<std::vector<uint32_t>>(per);
+        for (uint64_t e = 0; e < per; e++) {
+            uint64_t x[4], q = e;
+            for (int i = p.N - 1; i >= 0; i--) {
+                x[i] = q % g.d[i];
+                q /= g.d[i];
+            }
+            (*v)[szg_rank(g, bb.data(), x)] = (uint32_t)e;
+        }
+        perm = v;
+        std::lock_guard<std::mutex> lk(mu);
+        if (kept.size() >= 32) kept.clear();
+        kept[key] = perm;
+    }
+    em.resize((size_t)(per * nb));
+    return true;
+}
+template <typename T>
+void TrialWork<T>::order(int h) {  // blocks [nb h / 2, nb (h + 1) / 2): emission order, the quantizer's list, the symbols' counts
     const std::vector<uint32_t> &at = *perm;
-    static const bool tt = getenv("SZ3HIP_TUNER_TIMING") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    const uint64_t n = per * nb;
-    std::vector<uint16_t> em((size_t)n);
-    std::vector<T> un;
-    uint32_t lo = 65535, hi = 0;
-    for (uint64_t k = 0; k < nb; k++) {
+    std::vector<uint32_t> &f = cnt[h];
+    f.assign(65536, 0);
+    std::vector<T> &u = un[h];
+    u.clear();
+    for (uint64_t k = nb * h / 2; k < nb * (h + 1) / 2; k++) {
         const uint16_t *c = codes + k * per;
         const T *v = samples + k * per;
         uint16_t *o = em.data() + k * per;
         for (uint64_t r = 0; r < per; r++) {
             const uint16_t x = c[at[r]];
             o[r] = x;
-            if (!x) un.push_back(v[at[r]]);
-            lo = std::min<uint32_t>(lo, x);
-            hi = std::max<uint32_t>(hi, x);
+            if (!x) u.push_back(v[at[r]]);
+            f[x]++;
         }
     }
-    if (!n) return false;
+}
+template <typename T>
+bool TrialWork<T>::book() {
+    lo = 0;
+    hi = 65535;
+    while (lo < 65535 && !(cnt[0][lo] + cnt[1][lo])) lo++;
+    while (hi > lo && !(cnt[0][hi] + cnt[1][hi])) hi--;
     std::vector<uint64_t> freq(hi - lo + 1, 0);
-    for (uint16_t x : em) freq[x - lo]++;
-    Tree tr;
-    std::vector<Code> cw;
-    const auto t1 = std::chrono::steady_clock::now();
+    for (uint32_t x = lo; x <= hi; x++) freq[x - lo] = (uint64_t)cnt[0][x] + cnt[1][x];
     build_tree(freq, tr, cw, true);
     for (const Code &c : cw)
         if (c.len > 64) return false;
-    const auto t2 = std::chrono::steady_clock::now();
-    std::vector<uint8_t> bits;
-    if (!tr.t[0]) encode_bits(em.data(), n, (int32_t)lo, cw, bits);
-    const auto t3 = std::chrono::steady_clock::now();
-    write_head(p, g.anchor, un.data(), un.size(), sizeof(T), tr, (int)lo, (int)hi, n, bits.size(), raw);
-    raw.insert(raw.end(), bits.begin(), bits.end());
-    if (tt) {
-        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[sz3hip tuner] trial of %llu codes: order + counts %.3f, tree %.3f, bits %.3f, buffer %.3f ms (%zu bytes)\n", (unsigned long long)n, ms(t0, t1), ms(t1, t2),
-                ms(t2, t3), ms(t3, std::chrono::steady_clock::now()), raw.size());
-    }
+    return true;
+}
+template <typename T>
+void TrialWork<T>::bits(int h) {
+    const uint64_t n = per * nb;
+    pbits[h] = 0;
+    part[h].clear();
+    if (!tr.t[0]) encode_range(em.data(), n * h / 2, n * (h + 1) / 2, (int32_t)lo, cw, part[h], pbits[h]);
+}
+template <typename T>
+void TrialWork<T>::finish(std::vector<uint8_t> &raw) {
+    std::vector<uint8_t> joined;
+    if (!tr.t[0]) join_parts(part, pbits, 2, joined);
+    std::vector<T> u(un[0]);
+    u.insert(u.end(), un[1].begin(), un[1].end());
+    write_head(p, g.anchor, u.data(), u.size(), sizeof(T), tr, (int)lo, (int)hi, per * nb, joined.size(), raw);
+    raw.insert(raw.end(), joined.begin(), joined.end());
+}
+template struct TrialWork<float>;
+template struct TrialWork<double>;
+template <typename T>
+bool trial_buffer(const szi_stock_params &p, const uint16_t *codes, const T *samples, uint64_t nb, std::vector<uint8_t> &raw) {
+    TrialWork<T> w;
+    w.p = p;
+    w.codes = codes;
+    w.samples = samples;
+    w.nb = nb;
+    if (!w.prepare()) return false;
+    w.order(0);
+    w.order(1);
+    if (!w.book()) return false;
+    w.bits(0);
+    w.bits(1);
+    w.finish(raw);
     return true;
 }
 template bool trial_buffer<float>(const szi_stock_params &, const uint16_t *, const float *, uint64_t, std::vector<uint8_t> &);

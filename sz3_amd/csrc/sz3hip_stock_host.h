@@ -3,9 +3,11 @@
 #define SZ3HIP_STOCK_HOST_H
 #include <stdint.h>
 
+#include <memory>
 #include <vector>
 
 #include "sz3hip_internal.h"
+#include "sz3hip_stock_geom.h"
 
 namespace stock {
 struct Tree {                    // HuffmanEncoder's serialised tree (encoder/HuffmanEncoder.hpp:601-628)
@@ -66,6 +68,31 @@ bool host_decode(const Tree &tr, int32_t offset, const uint8_t *bits, size_t nby
 // hands to zstd (api/impl/SZAlgoInterp.hpp:42-78), from the trial kernel's per-element codes of all sampled blocks
 template <typename T>
 bool trial_buffer(const szi_stock_params &p, const uint16_t *codes, const T *samples, uint64_t nb, std::vector<uint8_t> &raw);
+// ... the same in steps, for a caller that spreads a group of trials over host threads: prepare(); order(0), order(1) in any order or at once;
+// book(); bits(0), bits(1) likewise; finish(raw)
+template <typename T>
+struct TrialWork {
+    szi_stock_params p;
+    const uint16_t *codes = nullptr;  // [nb][per] per element
+    const T *samples = nullptr;       // [nb][per]
+    uint64_t nb = 0;
+    szg_geom g;
+    uint64_t per = 0;
+    std::shared_ptr<const std::vector<uint32_t>> perm;  // the element emitted r-th
+    std::vector<uint16_t> em;                           // codes in emission order, all blocks
+    std::vector<T> un[2];                               // the quantizer's list, by half of the blocks
+    std::vector<uint32_t> cnt[2];                       // symbol counts, by half
+    uint32_t lo = 0, hi = 0;
+    Tree tr;
+    std::vector<Code> cw;
+    std::vector<uint8_t> part[2];                       // the bit stream's halves
+    uint64_t pbits[2] = {0, 0};
+    bool prepare();
+    void order(int h);
+    bool book();
+    void bits(int h);
+    void finish(std::vector<uint8_t> &raw);
+};
 // ... and the 1-D Lorenzo trial's (lorenzo_compress_test, :80-120), walked on the host over the sampled blocks
 template <typename T>
 bool lorenzo_trial_buffer(double eb, int radius, const T *samples, uint64_t per, uint64_t nb, std::vector<uint8_t> &raw);

@@ -174,6 +174,32 @@ def test_default_algorithm_through_the_host_api_reconstructs_what_the_reference_
     assert float(np.max(np.abs(dec0.astype(np.float64) - a.astype(np.float64)))) <= eb
 
 
+@pytest.mark.parametrize("shape,dtype,eb", [((256, 256, 256), np.float32, 3e-2), ((4096, 2048), np.float32, 1e-3), ((1 << 23,), np.float32, 1e-3), ((160, 160, 160), np.float64, 1e-6)],
+                         ids=["3d-256c", "2d-4096x2048", "1d-2^23", "3d-f64-160c"])
+def test_the_tuner_beside_the_copy_in_changes_nothing(shape, dtype, eb, monkeypatch):
+    """arrays of 16 MB and more under the default algorithm with an absolute bound: the host API runs the tuner from the HOST copy of the array
+    in a thread of its own while the array is copied to the device (szi_pretune_host: profiling and sample blocks read where the array lies,
+    the trials on a side stream, their pricing on the pool's threads) — the container must be, byte for byte, the one the call writes
+    with the tuner inside stage 1 (SZ3HIP_NO_PRETUNE=1), under both pricings, and its values the reference's"""
+    a = {1: lambda: field1d(shape[0], dtype), 2: lambda: field2d(shape, dtype), 3: lambda: field3d(shape, dtype, **({"sigma": 2e-6} if dtype == np.float64 else {}))}[len(shape)]()
+    conf = sz3_amd.Config(*a.shape)
+    conf.absErrorBound = eb
+    blobs = {}
+    for exact in ("1", "0"):
+        monkeypatch.setenv("SZ3HIP_TUNER_EXACT", exact)
+        for pre in ("0", "1"):
+            monkeypatch.setenv("SZ3HIP_NO_PRETUNE", pre)
+            blobs[exact, pre], _ = sz3_amd.compress(a, conf)
+        assert blobs[exact, "0"].tobytes() == blobs[exact, "1"].tobytes(), "the tuner beside the copy decided otherwise than the tuner inside stage 1"
+    dec, _ = sz3_amd.decompress(blobs["1", "0"], a.dtype, a.shape)
+    assert float(np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64)))) <= eb
+    if a.size <= 1 << 24 and a.ndim > 1:  # (the oracle's turn takes seconds per 16 M elements; 1-D: the tuner takes Lorenzo, whose own stream here
+        # reconstructs on the 2 eb lattice — within the bound, not the reference's values; the stock format's does: tests/test_gpu_stock.py)
+        oconf = make_config(a.shape, algo=ALGO_INTERP_LORENZO, abs_eb=eb, regression=True)
+        odec, _ = oracle_decompress(oracle_compress(a, oconf), a.dtype, a.shape)
+        assert np.array_equal(dec, odec)
+
+
 def test_default_config_host_roundtrip():
     """sz3_amd.compress with the reference's default Config (ALGO_INTERP_LORENZO) through the host API"""
     a = field3d((64, 80, 96))

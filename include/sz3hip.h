@@ -252,7 +252,8 @@ void sz3hip_ctx_set_deterministic(sz3hip_ctx *ctx, int on);
  * byte (same libzstd) and the decisions the reference's, at a few milliseconds per tuning (a host thread per trial). The 1-D Lorenzo
  * trials (est_bytes[6], [7]) are then walked on the host in the reference's own order and priced the same way. The HOST API's contexts (sz3hip_compress, and through it
  * the C++ / C wrappers, the CLI, the HDF5 filter) have it ON by default — a caller of the reference's boundary gets the reference's
- * decisions; 512^3 f32 host to host: 18.5 instead of 15.1 ms per call, 256^3: 3.4 instead of 2.65 —, a device context (sz3hip_ctx_create)
+ * decisions; at no cost for arrays of 16 MB and more under an absolute bound: the tuner then runs from the host's copy of the array beside its copy to
+ * the device (512^3 f32 host to host: 15.1 ms per call either way; SZ3HIP_NO_PRETUNE=1: inside stage 1 as before, 18.1) —, a device context (sz3hip_ctx_create)
  * OFF. Environment, read per call, for every context this function was never called on: SZ3HIP_TUNER_EXACT=1 on, =0 off. */
 void sz3hip_ctx_set_tuner_exact(sz3hip_ctx *ctx, int on);
 void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses);

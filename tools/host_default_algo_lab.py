@@ -6,9 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, sz3_amd
 from fields import field3d
-for shape, eb in (((512, 512, 512), 1e-4), ((256, 256, 256), 1e-3)):
+for shape, eb in (((512, 512, 512), 1e-4), ((256, 256, 256), 1e-3), ((512, 512, 512), -1e-4)):
     a = field3d(shape)
-    conf = sz3_amd.Config(*shape); conf.absErrorBound = eb
+    conf = sz3_amd.Config(*shape)
+    if eb < 0: conf.errorBoundMode = sz3_amd.EB_REL; conf.relErrorBound = -eb   # (negative: relative to the range)
+    else: conf.absErrorBound = eb
     out = np.empty(sz3_amd.compress_bound(conf, a.dtype), dtype=np.uint8)
     for mode in ("0", "1", None):
         if mode is None: os.environ.pop("SZ3HIP_TUNER_EXACT", None)

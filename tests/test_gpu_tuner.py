@@ -103,7 +103,19 @@ EXACT_CASES = CASES[:7] + [
     ("1d-2^20-1e-5", lambda: field1d(1 << 20), 1e-5),
     ("1d-300001-f64", lambda: field1d(300001, np.float64), 1e-4),
     ("1d-noisy", lambda: field1d(1 << 19) + np.random.default_rng(3).normal(0, 3e-3, 1 << 19).astype(np.float32), 1e-3),
+    ("3d-nan-inf", lambda: _with_holes(field3d((128, 128, 128))), 1e-3),      # non-finite values: code 0, the raw value in the quantizer's list
+    ("2d-f64", lambda: field2d((700, 900), np.float64), 1e-5),
+    ("3d-one-symbol", lambda: field3d((96, 96, 96)), 50.0),                   # every point predicted within the bound: a tree of one leaf, no bits
 ]
+
+
+def _with_holes(a):
+    a = a.copy()
+    f = a.reshape(-1)
+    f[np.random.default_rng(5).choice(f.size, 3000, replace=False)] = np.nan
+    f[7] = np.inf
+    f[f.size // 2] = -np.inf
+    return a
 
 
 @pytest.mark.parametrize("name,gen,eb", EXACT_CASES, ids=[c[0] for c in EXACT_CASES])
@@ -144,7 +156,8 @@ def test_exact_pricing_gives_the_reference_sizes_and_decisions(name, gen, eb):
     dc.decompress(payload.data_ptr(), size, out.data_ptr(), s)
     torch.cuda.synchronize()
     dec = out.cpu().numpy()
-    assert np.max(np.abs(dec.astype(np.float64) - a.astype(np.float64))) <= eb
+    fin = np.isfinite(a)
+    assert np.max(np.abs(dec[fin].astype(np.float64) - a[fin].astype(np.float64))) <= eb
     # the same call again, and with the estimate: exact pricing is a property of the context, not of what it did before
     size2 = dc.compress(conf, t.data_ptr(), payload.data_ptr(), cap, s)
     assert [int(x) for x in dc.tuner_report()["est_bytes"][:6]] == ref_bytes and size2 == size

@@ -2303,6 +2303,7 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
         return 0;
     }
     unsigned char *out = reinterpret_cast<unsigned char *>(cmpData);
+    const uint8_t caller_dtype = conf.dataType;
     Writer w{out};
     w.put<uint32_t>(kMagic);
     w.put<uint32_t>(kDataVer);
@@ -2341,7 +2342,11 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
     uint64_t ps = payload_size;
     memcpy(size_pos, &ps, 8);
     w.p += payload_size;
-    conf.dataType = (uint8_t)dataType;  // lets the decoder refuse a request for another element type
+    // (this library's own streams name the element type in the trailer: the decoder refuses a request for another one. A stock container keeps
+    // what the CALLER's Config says — the reference saves the field as it finds it, and neither its CLI nor SZ_compress<T> sets it: a file
+    // of doubles written by stock SZ3 says 0 there, and so does the same file written here)
+    if (!(g_stock_format.load() > 0 && conf.cmprAlgo < 16)) conf.dataType = (uint8_t)dataType;
+    else conf.dataType = caller_dtype;
     w.p += sz3hip_config_save(&conf, w.p);
     return (size_t)(w.p - out);
 }

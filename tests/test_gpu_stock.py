@@ -81,7 +81,7 @@ def test_streams_written_in_stock_format_are_read_by_stock_sz3(name, gen, eb, kw
     finally:
         L.sz3hip_set_stock_format(0)
     assert _trailer_algo(blob) == sz3_amd.ALGO_INTERP      # a stock id, not 17
-    oconf = make_config(a.shape, algo=ALGO_INTERP, abs_eb=eb, dataType=0 if a.dtype == np.float32 else 1, **kw)  # (a caller who names the type, like the CLI)
+    oconf = make_config(a.shape, algo=ALGO_INTERP, abs_eb=eb, **kw)
     oblob = oracle_compress(a, oconf)
     want, _ = oracle_decompress(oblob, a.dtype, a.shape)   # what stock SZ3 reconstructs from its own stream
     got, _ = oracle_decompress(blob, a.dtype, a.shape)     # stock SZ3 reading OUR stream
@@ -199,8 +199,19 @@ def test_files_interchange_between_the_two_clis(tmp_path):
     got = np.fromfile(tmp_path / "ours.by_stock", dtype=np.float32)
     assert np.array_equal(np.fromfile(tmp_path / "ours.by_ours", dtype=np.float32), got)
     assert float(np.max(np.abs(got.astype(np.float64) - a.reshape(-1).astype(np.float64)))) <= 1e-3
-    so, oo = os.path.getsize(tmp_path / "stock.sz"), os.path.getsize(tmp_path / "ours.sz")
-    assert oo <= 1.05 * so, (oo, so)
+    # ... and the two .sz files are one and the same (end of round 5): the default algorithm's tuner priced the reference's way (the host API's
+    # default), the reference's stream layout and tree order, one zstd frame — also under a relative bound and for a double-precision array
+    assert (tmp_path / "ours.sz").read_bytes() == (tmp_path / "stock.sz").read_bytes(), "the CLI over this library writes another file than the stock CLI"
+    assert np.array_equal(got, want)
+    run(stock, ["-f", "-i", str(src), "-z", str(tmp_path / "stock_rel.sz")] + dims + ["-M", "REL", "1e-4"])
+    run(ours, ["-f", "-i", str(src), "-z", str(tmp_path / "ours_rel.sz")] + dims + ["-M", "REL", "1e-4"], env={"SZ3HIP_STOCK_FORMAT": "1"})
+    assert (tmp_path / "ours_rel.sz").read_bytes() == (tmp_path / "stock_rel.sz").read_bytes()
+    d = field3d((40, 50, 60), np.float64)
+    d.tofile(tmp_path / "d.f64")
+    dd = ["-3", "60", "50", "40"]
+    run(stock, ["-d", "-i", str(tmp_path / "d.f64"), "-z", str(tmp_path / "stock_d.sz")] + dd + ["-M", "ABS", "1e-4"])
+    run(ours, ["-d", "-i", str(tmp_path / "d.f64"), "-z", str(tmp_path / "ours_d.sz")] + dd + ["-M", "ABS", "1e-4"], env={"SZ3HIP_STOCK_FORMAT": "1"})
+    assert (tmp_path / "ours_d.sz").read_bytes() == (tmp_path / "stock_d.sz").read_bytes()
 
 
 @pytest.mark.parametrize("eb", [1e-2, 1e-4], ids=["short-codes", "long-codes"])
@@ -347,7 +358,7 @@ def test_streams_written_as_stock_lorenzo_reg_are_read_by_stock_sz3(name, gen, e
     assert np.array_equal(mine, got, equal_nan=True)
     if l2_in_4d:
         return
-    oblob = oracle_compress(a, make_config(a.shape, abs_eb=eb, dataType=0 if a.dtype == np.float32 else 1, **kw))
+    oblob = oracle_compress(a, make_config(a.shape, abs_eb=eb, **kw))
     # (1-D: the chain is walked on the host in the reference's own order — the same choices, the same codes)
     assert len(blob) <= (1.01 if a.ndim == 1 else 1.08) * len(oblob) + 256, (len(blob), len(oblob))
     # The reference's file byte for byte wherever the codes are the reference's: sets of one member, 1-D arrays, and the arrays where the
@@ -434,9 +445,7 @@ def test_stock_nopred_streams_both_ways(gen, eb):
     assert np.array_equal(back, want, equal_nan=True)      # the same quantizer on the same values: the same reconstruction
     mine, _ = sz3_amd.decompress(blob, a.dtype, a.shape)
     assert np.array_equal(mine, back, equal_nan=True)
-    assert len(blob) == len(rblob)
-    if a.dtype == np.float32:                              # (f64: the shim's Config names no type, this library's trailer does — one byte)
-        assert blob.tobytes() == rblob.tobytes(), "the same codes, the reference's tree order, one zstd frame: the reference's file"
+    assert blob.tobytes() == rblob.tobytes(), "the same codes, the reference's tree order, one zstd frame: the reference's file"
 
 
 def test_stock_4d_stream_with_the_second_order_member_is_read():

@@ -1360,6 +1360,7 @@ static bool same_call(const sz3hip_config &a, const sz3hip_config &b) {
         if (a.dims[i] != b.dims[i]) return false;
     return true;
 }
+void szi_pretune_cancel(sz3hip_ctx *ctx) { ctx->pre_valid = false; }
 int szi_pretune_host(sz3hip_ctx *ctx, const sz3hip_config *conf_in, const void *h_in) {
     ctx->pre_valid = false;
     if (conf_in->cmprAlgo != SZ3HIP_ALGO_INTERP_LORENZO || conf_in->errorBoundMode != SZ3HIP_EB_ABS || conf_in->N < 1 || conf_in->N > 4) return -1;

@@ -735,6 +735,7 @@ int job_upload(SlabJob &j) {
     }
     if (slot_ctx(s, j.conf.num)) return j.failed(sz3hip_last_error_code());
     sz3hip_ctx *ctx = s->ctx;
+    szi_pretune_cancel(ctx);
     const size_t cbytes = (size_t)j.conf.num * (j.cdt == SZ3HIP_FLOAT ? 4 : 8);
     if (ensure_dev(&s->dev_in, &s->dev_in_bytes, cbytes)) return j.failed(SZ3HIP_EHIP);
     const size_t pb = sz3hip_payload_bound_conf(ctx, &j.conf, 0);

@@ -39,6 +39,7 @@ int szi_stage1_with_larger_lists(sz3hip_ctx *ctx, const sz3hip_config *conf, con
 // launches, round trips and host-side pricing vanish behind the copy). conf: the call's Config with its absolute bound; the next
 // sz3hip_compress_stage1 of this context with the same Config takes the outcome instead of tuning. Returns 0 when it did.
 int szi_pretune_host(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *h_in);
+void szi_pretune_cancel(sz3hip_ctx *ctx);  // an outcome is for the call it was made for: every host call starts by dropping what an earlier one may have left
 void szi_ctx_exact_default(sz3hip_ctx *ctx, int on);  // what a context does about the tuner's pricing when neither the setter nor the environment says
 int szi_tuner_took_lorenzo(sz3hip_ctx *ctx, int *quantbinCnt);  // the default algorithm's tuner chose Lorenzo in the pending stage 1 (1-D), and with which quantizer
 void szi_run_parallel(int n, const std::function<void(int)> &f);  // f(0 .. n - 1) over the host API's pool of threads (sz3hip_host.cpp), f(0) on the caller

@@ -990,10 +990,19 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
             ok[j] = w[j].prepare();
         }
         static const int phases = getenv("SZ3HIP_TUNER_PHASES") ? atoi(getenv("SZ3HIP_TUNER_PHASES")) : 1;  // (0, lab: a trial from end to end on one thread — 3.3 against 3.0 ms per group at C3)
+        double ph[4] = {0, 0, 0, 0};
+        auto lap = [&](int k, const std::chrono::steady_clock::time_point &from) { ph[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - from).count(); };
+        auto p0 = std::chrono::steady_clock::now();
         if (phases) {
             szi_run_parallel(2 * ntr, [&](int i) { if (ok[i / 2]) w[i / 2].order(i & 1); });
+            lap(0, p0);
+            p0 = std::chrono::steady_clock::now();
             szi_run_parallel(ntr, [&](int j) { if (ok[j]) ok[j] = w[j].book(); });
+            lap(1, p0);
+            p0 = std::chrono::steady_clock::now();
             szi_run_parallel(2 * ntr, [&](int i) { if (ok[i / 2]) w[i / 2].bits(i & 1); });
+            lap(2, p0);
+            p0 = std::chrono::steady_clock::now();
         }
         szi_run_parallel(ntr, [&](int j) {
             if (!ok[j]) return;
@@ -1009,6 +1018,8 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
             const size_t z = szi_zstd_size(raw.data(), raw.size());
             sizes[j] = z ? z + 8 : 0;  // (Lossless_zstd::compress: the length word in front of the frame)
         });
+        lap(3, p0);
+        if (tt) fprintf(stderr, "[sz3hip tuner] steps: order %.3f, book %.3f, bits %.3f, buffer + zstd %.3f ms\n", ph[0], ph[1], ph[2], ph[3]);
     };
     if (ctx->dtype == SZ3HIP_FLOAT) priced_as(0.0f);
     else priced_as(0.0);

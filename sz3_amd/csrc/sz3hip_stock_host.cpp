@@ -106,26 +106,35 @@ void build_tree(const std::vector<uint64_t> &freq, Tree &tr, std::vector<Code> &
         // the reference's own queue (encoder/HuffmanEncoder.hpp:402-432, 516-561): a 1-based binary heap whose insertion climbs only past
         // STRICTLY larger parents and whose removal prefers the right child only when strictly smaller — which of several equal
         // frequencies merges first decides the tree's shape (not its cost), and a tuner trial's zstd size is taken over the tree's bytes
-        std::vector<int> heap(1);  // (1-based: slot 0 unused)
+        struct HE {  // (a queue entry carries its frequency: the sift loops compare entries, not nodes behind an index — a wide alphabet's 20 000
+            uint64_t f;  //  symbols are a million comparisons)
+            int n;
+        };
+        std::vector<HE> heap(1);  // (1-based: slot 0 unused)
+        size_t K = 0;
+        for (size_t s = 0; s < freq.size(); s++) K += freq[s] != 0;
+        nodes.reserve(2 * K + 1);
+        heap.reserve(K + 2);
         auto insert = [&](int n) {
-            heap.push_back(n);
+            const uint64_t f = nodes[n].f;
+            heap.push_back(HE{f, n});
             size_t i = heap.size() - 1;
             for (size_t j = i >> 1; j; j = i >> 1) {
-                if (nodes[heap[j]].f <= nodes[n].f) break;
+                if (heap[j].f <= f) break;
                 heap[i] = heap[j];
                 i = j;
             }
-            heap[i] = n;
+            heap[i] = HE{f, n};
         };
         auto remove = [&]() {
-            const int top = heap[1];
+            const int top = heap[1].n;
             heap[1] = heap.back();
             heap.pop_back();
             const size_t end = heap.size();
             size_t i = 1;
             for (size_t l = i << 1; l < end; l = i << 1) {
-                if (l + 1 < end && nodes[heap[l + 1]].f < nodes[heap[l]].f) l++;
-                if (nodes[heap[i]].f > nodes[heap[l]].f) {
+                if (l + 1 < end && heap[l + 1].f < heap[l].f) l++;
+                if (heap[i].f > heap[l].f) {
                     std::swap(heap[i], heap[l]);
                     i = l;
                 } else {
@@ -144,7 +153,7 @@ void build_tree(const std::vector<uint64_t> &freq, Tree &tr, std::vector<Code> &
             nodes.push_back({nodes[a].f + nodes[b].f, a, b, -1});
             insert((int)nodes.size() - 1);
         }
-        root = heap[1];
+        root = heap[1].n;
     } else {
         typedef std::pair<uint64_t, int> QE;  // (frequency, node): ties by creation order
         std::priority_queue<QE, std::vector<QE>, std::greater<QE>> q;
@@ -169,40 +178,32 @@ void build_tree(const std::vector<uint64_t> &freq, Tree &tr, std::vector<Code> &
     tr.C.assign(nc, 0);
     tr.t.assign(nc, 0);
     codes.assign(freq.size(), Code{0, 0});
-    // pre-order numbering like pad_tree (:601-616): a node, its left subtree, its right subtree
+    // pre-order numbering like pad_tree (:601-616): a node, its left subtree, its right subtree — a node's number is its rank in that walk,
+    // which a stack that takes the right child before the left one pops in (one visit per node: a wide alphabet's tree has 40 000)
     struct Fr {
-        int node;
-        uint32_t id;
+        int node, parent;  // parent: the parent's NUMBER (-1: the root)
         uint64_t bits;
         uint32_t len;
-        int stage;
+        bool right;
     };
     std::vector<Fr> st;
+    st.reserve(256);
     uint32_t next = 0;
-    st.push_back({root, next++, 0, 0, 0});
+    st.push_back({root, -1, 0, 0, false});
     while (!st.empty()) {
-        Fr &f = st.back();
+        const Fr f = st.back();
+        st.pop_back();
+        const uint32_t id = next++;
+        if (f.parent >= 0) (f.right ? tr.R : tr.L)[f.parent] = id;
         const N &nd = nodes[f.node];
         if (nd.sym >= 0) {
-            tr.t[f.id] = 1;
-            tr.C[f.id] = nd.sym;
+            tr.t[id] = 1;
+            tr.C[id] = nd.sym;
             codes[nd.sym] = Code{f.bits, f.len};
-            st.pop_back();
             continue;
         }
-        if (f.stage == 0) {
-            f.stage = 1;
-            const uint32_t id = next++;
-            tr.L[f.id] = id;
-            st.push_back({nd.l, id, f.bits << 1, f.len + 1, 0});
-        } else if (f.stage == 1) {
-            f.stage = 2;
-            const uint32_t id = next++;
-            tr.R[f.id] = id;
-            st.push_back({nd.r, id, (f.bits << 1) | 1, f.len + 1, 0});
-        } else {
-            st.pop_back();
-        }
+        st.push_back({nd.r, (int)id, (f.bits << 1) | 1, f.len + 1, true});
+        st.push_back({nd.l, (int)id, f.bits << 1, f.len + 1, false});
     }
 }
 void save_tree(W &w, const Tree &tr, int32_t offset, uint32_t state_num) {

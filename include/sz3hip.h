@@ -127,7 +127,10 @@ size_t sz3hip_compress_bound(const sz3hip_config *c, int dataType);
  * every blob what a single-slab call would have produced.
  * Large plain calls (round 5: >= 96 MB, absolute or L2-norm bound, ALGO_LORENZO_REG / ALGO_NOPRED, no conf->openmp) are written in the
  * same container by ONE GPU as a pipeline of up to 8 pieces — the copy in of piece k + 1 beside the kernels of piece k beside the copy
- * out + zstd of piece k - 1 —, every piece with its own code book; SZ3HIP_PIECES=0 keeps them whole (INTEGRATION.md sections 6, 7). */
+ * out + zstd of piece k - 1 —, every piece with its own code book; SZ3HIP_PIECES=0 keeps them whole (INTEGRATION.md sections 6, 7).
+ * The trailer's dataType field: this library's own streams (ids 16 / 17) name the element type of the call there (the decoder refuses a
+ * request for another one); a stock container keeps conf->dataType as the caller left it, like the reference (Config.hpp:312-354 saves the
+ * field as it finds it; neither the reference's CLI nor SZ_compress<T> sets it). */
 size_t sz3hip_compress(const sz3hip_config *conf, int dataType, const void *data, char *cmpData, size_t cmpCap);
 /* SZ_decompress<T>(conf, cmpData, cmpSize, decData) (api/sz.hpp:117): conf is overwritten from the trailer;
  * decData must hold conf.num elements (query with sz3hip_peek_config first). Also decodes ALGO_LOSSLESS streams and

@@ -96,3 +96,13 @@ def test_round_trip_at_full_benchmark_sizes_and_beyond_2_pow_32_elements(case):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
     assert " OK " in last and str(n) in r.stdout, last
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_exact_tuner_sweep(seed):
+    """tests/checks/tuner_exact_sweep.py: 25 random arrays (1-D .. 4-D, f32 / f64, smooth / noisy, bounds over four decades) — with the
+    trials priced the reference's way every interpolation trial's compressed size equals the reference's byte for byte and every decision
+    (linear / cubic, order, (alpha, beta), interpolation or Lorenzo, the Lorenzo quantizer) is the reference's"""
+    out = _run("tuner_exact_sweep.py", seed, 25)
+    assert "mismatches 0" in out
+

@@ -106,3 +106,11 @@ def test_exact_tuner_sweep(seed):
     out = _run("tuner_exact_sweep.py", seed, 25)
     assert "mismatches 0" in out
 
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_stock_containers_sweep(seed):
+    """tests/checks/stock_bytes_sweep.py: 40 random calls in stock format (ALGO_INTERP with random parameters, the default algorithm, Lorenzo sets
+    of one member, any set on 1-D arrays; 1-D .. 4-D, f32 / f64, absolute and relative bounds) — every container is the reference's, byte for byte"""
+    out = _run("stock_bytes_sweep.py", seed, 40)
+    assert "mismatches 0" in out
+

@@ -114,3 +114,11 @@ def test_stock_containers_sweep(seed):
     out = _run("stock_bytes_sweep.py", seed, 40)
     assert "mismatches 0" in out
 
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_default_algorithm_reconstruction_sweep(seed):
+    """tests/checks/default_algo_recon_sweep.py: 25 random 2-D .. 4-D arrays under the reference's default algorithm through the host API, this
+    library's own stream format — decompressed bit for bit to what the reference's stream decompresses to"""
+    out = _run("default_algo_recon_sweep.py", seed, 25)
+    assert "mismatches 0" in out
+

@@ -1026,10 +1026,14 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
     if (tt)
         fprintf(stderr, "[sz3hip tuner] exact group of %d: kernels + copy out %.3f ms, pricing %.3f ms\n", ntr, std::chrono::duration<double, std::milli>(t1 - t0).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
-    for (int j = 0; j < ntr; j++) {
-        if (!sizes[j]) return fail(SZ3HIP_EZSTD, "tuner: a trial could not be priced (geometry of the sample blocks or libzstd)");
-        ctx->exact_bytes[slot0 + j] = (double)sizes[j];
-    }
+    for (int j = 0; j < ntr; j++)
+        if (!sizes[j]) {
+            // a trial that cannot be priced this way (an anchor stride the emission-order geometry does not take, no libzstd): this tuning goes on
+            // with the device-side estimates, which the cost launch above has made for every trial of the group
+            ctx->exact_now = false;
+            return 0;
+        }
+    for (int j = 0; j < ntr; j++) ctx->exact_bytes[slot0 + j] = (double)sizes[j];
     return 0;
 }
 static int tuner_fetch(sz3hip_ctx *ctx, hipStream_t s) {

@@ -213,6 +213,38 @@ def test_the_tuner_beside_the_copy_in_changes_nothing(shape, dtype, eb, monkeypa
         assert np.array_equal(dec, odec)
 
 
+def test_exact_pricing_falls_back_to_the_estimate_where_it_does_not_apply():
+    """an anchor stride that is no power of two: the emission-order geometry (the stock ALGO_INTERP reader's / writer's) does not take it, so a
+    trial cannot be priced the reference's way — the tuning goes on with the device-side estimates instead of failing the call; the outcome is
+    the estimate's, the stream decodes within the bound"""
+    a = field3d((100, 110, 120))
+    outs = {}
+    for exact in (True, False):
+        dev = torch.device("cuda:0")
+        t = torch.from_numpy(a).to(dev)
+        dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+        dc.set_tuner_exact(exact)
+        dc.set_deterministic(True)
+        cap = dc.payload_bound(a.size)
+        payload = torch.empty(cap, dtype=torch.uint8, device=dev)
+        conf = sz3_amd.Config(*a.shape)
+        conf.absErrorBound = 1e-3
+        conf.interpAnchorStride = 24
+        s = torch.cuda.current_stream().cuda_stream
+        try:
+            size = dc.compress(conf, t.data_ptr(), payload.data_ptr(), cap, s)
+        except sz3_amd.SZ3HipError as e:
+            outs[exact] = ("refused", str(e)[:40])
+            continue
+        out = torch.empty_like(t)
+        dc.decompress(payload.data_ptr(), size, out.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert float((out.double() - t.double()).abs().max()) <= 1e-3
+        g = dc.tuner_report()
+        outs[exact] = (size, g["interpAlgo"], g["interpDirection"], g["interpAlpha"], g["interpBeta"], [round(x, 3) for x in g["est_bytes"][:6]])
+    assert outs[True] == outs[False], outs
+
+
 def test_default_config_host_roundtrip():
     """sz3_amd.compress with the reference's default Config (ALGO_INTERP_LORENZO) through the host API"""
     a = field3d((64, 80, 96))

@@ -253,7 +253,8 @@ void sz3hip_ctx_set_deterministic(sz3hip_ctx *ctx, int on);
  * the reference's decomposition emits them, coded with one Huffman tree built with the reference's own queue, serialised like its buffer and
  * compressed with ZSTD_compress at level 3 — est_bytes[0..5] of the tuner report are then the reference's own compressed sizes byte for
  * byte (same libzstd) and the decisions the reference's, at a few milliseconds per tuning (a host thread per trial). The 1-D Lorenzo
- * trials (est_bytes[6], [7]) are then walked on the host in the reference's own order and priced the same way. The HOST API's contexts (sz3hip_compress, and through it
+ * trials (est_bytes[6], [7]) are then walked on the host in the reference's own order and priced the same way. Where a trial cannot be
+ * priced this way (an anchor stride that is no power of two) the tuning goes on with the estimates. The HOST API's contexts (sz3hip_compress, and through it
  * the C++ / C wrappers, the CLI, the HDF5 filter) have it ON by default — a caller of the reference's boundary gets the reference's
  * decisions; at no cost for arrays of 16 MB and more under an absolute bound: the tuner then runs from the host's copy of the array beside its copy to
  * the device (512^3 f32 host to host: 15.1 ms per call either way; SZ3HIP_NO_PRETUNE=1: inside stage 1 as before, 18.1) —, a device context (sz3hip_ctx_create)

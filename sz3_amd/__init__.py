@@ -88,6 +88,7 @@ def _share_torch_hip_runtime():
         spec = importlib.util.find_spec("torch")
         if spec is None or not spec.submodule_search_locations:
             return
+        _warn_on_late_torch_import(sys)
         libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
         for name in ("libamdhip64.so",):
             path = os.path.join(libdir, name)
@@ -95,6 +96,27 @@ def _share_torch_hip_runtime():
                 C.CDLL(path, mode=C.RTLD_GLOBAL)
     except Exception:  # noqa: BLE001 - best effort: without it the library still works, only torch-after-us does not
         pass
+
+
+class _LateTorchImport:
+    """sys.meta_path entry that finds nothing: it only notices the first `import torch` that comes after this library has been loaded
+    (the hazard described in _share_torch_hip_runtime) and says so once — the caller can then fix the order instead of meeting an
+    intermittent hang."""
+    warned = False
+
+    def find_spec(self, name, path=None, target=None):
+        if name == "torch" and not _LateTorchImport.warned and _lib is not None:
+            _LateTorchImport.warned = True
+            import warnings
+            warnings.warn("`import torch` after sz3_amd has loaded libsz3hip.so: on MI355X boxes this order stalled inside torch's import in "
+                          "about one fresh process out of five once the device had been used. Import torch before the first sz3_amd call, "
+                          "or set SZ3HIP_TORCH_PRELOAD=1.", RuntimeWarning, stacklevel=2)
+        return None
+
+
+def _warn_on_late_torch_import(sys):
+    if not any(isinstance(f, _LateTorchImport) for f in sys.meta_path):
+        sys.meta_path.insert(0, _LateTorchImport())
 
 
 def lib():

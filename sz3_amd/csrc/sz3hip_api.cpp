@@ -16,6 +16,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <sched.h>
+#include <unistd.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -1757,7 +1759,12 @@ static int wait_published(sz3hip_ctx *ctx) {
             }
             if (q != hipErrorNotReady) return fail(SZ3HIP_EHIP, "HIP error while waiting for stage 2: %s", hipGetErrorString(q));
         }
-        __builtin_ia32_pause();
+        // (a pure spin for the first ~50 us — the device API's calls are that short and the wake-up latency is the step's —, then the
+        // core is offered to whoever else wants it: several piece threads of the host API wait here beside the zstd pool, and under a
+        // CPU quota a spinning waiter is what throttles the threads it waits for)
+        if (it < 4096) __builtin_ia32_pause();
+        else if (it < 65536) sched_yield();
+        else usleep(20);
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return 0;

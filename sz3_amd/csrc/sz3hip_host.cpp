@@ -873,13 +873,14 @@ static inline void stamp(int k) {
 struct D2hStage {
     static constexpr size_t CH = 4u << 20;
     static constexpr int K = 16;
-    std::mutex mu;  // one copy at a time fills the ring (the link is one)
+    static constexpr int MAX_DEV = 16;
+    std::mutex mu;  // one copy at a time fills a device's ring (a device's link is one; every device has a ring, a stream and events of its own)
     uint8_t *buf[K] = {};
     std::atomic<int> busy[K];
-    hipEvent_t ev[16][K] = {};
-    hipStream_t st[16] = {};
+    hipEvent_t ev[K] = {};
+    hipStream_t st = nullptr;
     bool ok = false, tried = false;
-    bool init() {
+    bool init() {  // (under mu, the device current)
         if (tried) return ok;
         tried = true;
         for (int k = 0; k < K; k++) busy[k].store(0);
@@ -889,44 +890,57 @@ struct D2hStage {
             return false;
         }
         for (int k = 0; k < K; k++) buf[k] = (uint8_t *)all + (size_t)k * CH;
+        for (int k = 0; k < K; k++)
+            if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
         return ok = true;
     }
 };
-static D2hStage g_stage;
+static D2hStage g_stages[D2hStage::MAX_DEV];
 // one user of the ring at a time: segments (a whole array, or the pieces of one in order) are copied back to back — the copy engine
 // does not pause between them — and the host copies of a segment's last chunks run beside the next segment's transfers
 struct StagedCopy {
     std::unique_lock<std::mutex> lock;
     zs::Batch copies;
-    hipStream_t st = nullptr;
-    int dev = 0;
+    D2hStage *sg = nullptr;
     size_t issued = 0, waited = 0;  // chunks sent on their way / chunks whose arrival has been seen and whose host copy is in the pool
     struct Chunk {
         uint8_t *dst;
         size_t len;
     } ring[D2hStage::K];
+    // hipErrorOutOfMemory = "no ring for this device" (a device index beyond the table, no pinned memory, no stream): the caller copies plainly
     hipError_t begin() {
-        hipError_t e;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-        if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-        lock = std::unique_lock<std::mutex>(g_stage.mu);
-        if (!g_stage.init()) return hipErrorOutOfMemory;
-        for (int k = 0; k < D2hStage::K; k++)
-            if (!g_stage.ev[dev][k] && (e = hipEventCreateWithFlags(&g_stage.ev[dev][k], hipEventDisableTiming)) != hipSuccess) return e;
-        // (a stream of the ring's own per device — the slot's stream may be anyone's; made once, used under the ring's lock)
-        if (!g_stage.st[dev] && (e = hipStreamCreateWithFlags(&g_stage.st[dev], hipStreamNonBlocking)) != hipSuccess) return e;
-        st = g_stage.st[dev];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) {
+            (void)hipGetLastError();
+            return hipErrorOutOfMemory;
+        }
+        if (dev < 0 || dev >= D2hStage::MAX_DEV) return hipErrorOutOfMemory;
+        sg = &g_stages[dev];
+        lock = std::unique_lock<std::mutex>(sg->mu);
+        if (!sg->init()) {
+            lock.unlock();
+            sg = nullptr;
+            return hipErrorOutOfMemory;
+        }
         return hipSuccess;
     }
     void drain_one() {  // the oldest chunk on its way has landed: on to the caller's array, in parts
         const int k = (int)(waited % D2hStage::K);
         const Chunk c = ring[k];
+        D2hStage *const g = sg;
         const size_t PART = 1u << 20, parts = (c.len + PART - 1) / PART;
         auto left = std::make_shared<std::atomic<size_t>>(parts);
         for (size_t q = 0; q < parts; q++)
             copies.add([=] {
-                memcpy(c.dst + q * PART, g_stage.buf[k] + q * PART, std::min(PART, c.len - q * PART));
-                if (left->fetch_sub(1) == 1) g_stage.busy[k].store(0, std::memory_order_release);
+                memcpy(c.dst + q * PART, g->buf[k] + q * PART, std::min(PART, c.len - q * PART));
+                if (left->fetch_sub(1) == 1) g->busy[k].store(0, std::memory_order_release);
             });
         waited++;
     }
@@ -936,36 +950,37 @@ struct StagedCopy {
         for (size_t off = 0; off < bytes && e == hipSuccess; off += CH) {
             const int k = (int)(issued % D2hStage::K);
             while (waited + D2hStage::K <= issued && e == hipSuccess) {  // the ring comes round
-                e = hipEventSynchronize(g_stage.ev[dev][waited % D2hStage::K]);
+                e = hipEventSynchronize(sg->ev[waited % D2hStage::K]);
                 if (e == hipSuccess) drain_one();
             }
             if (e != hipSuccess) break;
-            while (g_stage.busy[k].load(std::memory_order_acquire)) std::this_thread::yield();  // (its host copy is still under way)
-            g_stage.busy[k].store(1);
+            while (sg->busy[k].load(std::memory_order_acquire)) std::this_thread::yield();  // (its host copy is still under way)
+            sg->busy[k].store(1);
             const size_t len = std::min(CH, bytes - off);
             ring[k] = {(uint8_t *)dst + off, len};
-            e = hipMemcpyAsync(g_stage.buf[k], (const uint8_t *)src + off, len, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipEventRecord(g_stage.ev[dev][k], st);
+            e = hipMemcpyAsync(sg->buf[k], (const uint8_t *)src + off, len, hipMemcpyDeviceToHost, sg->st);
+            if (e == hipSuccess) e = hipEventRecord(sg->ev[k], sg->st);
             if (e != hipSuccess) {
-                g_stage.busy[k].store(0);
+                sg->busy[k].store(0);
                 break;
             }
             issued++;
-            while (waited + 1 < issued && hipEventQuery(g_stage.ev[dev][waited % D2hStage::K]) == hipSuccess) drain_one();  // (what has landed meanwhile)
+            while (waited + 1 < issued && hipEventQuery(sg->ev[waited % D2hStage::K]) == hipSuccess) drain_one();  // (what has landed meanwhile)
         }
         (void)hipGetLastError();  // (hipErrorNotReady of the queries)
         return e;
     }
     hipError_t finish() {
         hipError_t e = hipSuccess;
+        if (!sg) return e;
         while (waited < issued && e == hipSuccess) {
-            e = hipEventSynchronize(g_stage.ev[dev][waited % D2hStage::K]);
+            e = hipEventSynchronize(sg->ev[waited % D2hStage::K]);
             if (e == hipSuccess) drain_one();
         }
-        if (e != hipSuccess && st) (void)hipStreamSynchronize(st);
+        if (e != hipSuccess && sg->st) (void)hipStreamSynchronize(sg->st);
         copies.wait();
         if (e != hipSuccess)
-            for (int k = 0; k < D2hStage::K; k++) g_stage.busy[k].store(0);
+            for (int k = 0; k < D2hStage::K; k++) sg->busy[k].store(0);
         if (lock.owns_lock()) lock.unlock();
         return e;
     }
@@ -2346,8 +2361,10 @@ extern "C" size_t sz3hip_compress(const sz3hip_config *config, int dataType, con
     // (this library's own streams name the element type in the trailer: the decoder refuses a request for another one. A stock container keeps
     // what the CALLER's Config says — the reference saves the field as it finds it, and neither its CLI nor SZ_compress<T> sets it: a file
     // of doubles written by stock SZ3 says 0 there, and so does the same file written here)
-    if (!(g_stock_format.load() > 0 && conf.cmprAlgo < 16)) conf.dataType = (uint8_t)dataType;
-    else conf.dataType = caller_dtype;
+    // (... the real stock lossy containers, that is: an ALGO_LOSSLESS stream of an INTEGER array — the fallback integer inputs take in
+    // stock mode — keeps recording its element type, or decompress_blob could hand an int32 array back as float32 of the same length)
+    if (g_stock_format.load() > 0 && conf.cmprAlgo < 16 && !(conf.cmprAlgo == SZ3HIP_ALGO_LOSSLESS && dtype_is_int(dataType))) conf.dataType = caller_dtype;
+    else conf.dataType = (uint8_t)dataType;
     w.p += sz3hip_config_save(&conf, w.p);
     return (size_t)(w.p - out);
 }
@@ -2674,11 +2691,16 @@ int decompress_slabs(const sz3hip_config *conf, int dataType, const unsigned cha
     }
     const int ndev = need_gpu ? multi_devices() : 1;
     const int cdt = dtype_compute(dataType);
+    // G comes from the container (a reference OMP file of a many-core host, or a hostile stream): the pipelined reader below keeps a
+    // host thread, a slot and a device context per piece alive at once, so it takes containers of at most MAX_PIPE pieces (what
+    // compress_pieces writes: <= 8); every other container is read slab after slab by one host thread per GPU, on ONE slot per GPU
+    constexpr int MAX_PIPE = 16;
+    const bool pipelined = ndev == 1 && G >= 2 && G <= MAX_PIPE && need_gpu && (size_t)conf->num * es >= (64u << 20) && env_int("SZ3HIP_PIECES", -1) != 0;
     std::vector<HostSlot *> slots(G);
-    for (int g = 0; g < G; g++) slots[g] = get_slot(ndev == 1 ? host_device() : g % ndev, cdt, g / ndev);
+    for (int g = 0; g < G; g++) slots[g] = pipelined ? get_slot(host_device(), cdt, g) : get_slot(ndev == 1 ? host_device() : g % ndev, cdt, 0);
     std::vector<int> rcs(G, 0);
     std::vector<std::string> errs(G);
-    if (ndev == 1 && G >= 2 && need_gpu && (size_t)conf->num * es >= (64u << 20) && env_int("SZ3HIP_PIECES", -1) != 0) {
+    if (pipelined) {
         // one GPU, several pieces (what compress_pieces writes; any multi-slab container of this size): a host thread per piece —
         // unpacking, copy in and decoding of all pieces side by side —, the slabs copied out by this thread in piece order, back to
         // back through the staging ring (d2h_staged above), each as soon as its piece has handed it over
@@ -2707,12 +2729,20 @@ int decompress_slabs(const sz3hip_config *conf, int dataType, const unsigned cha
             gates[g].finish();
         };
         std::vector<std::thread> pth;
-        for (int g = 0; g < G; g++) pth.emplace_back(piece, g);
+        try {
+            for (int g = 0; g < G; g++) pth.emplace_back(piece, g);
+        } catch (const std::system_error &) {  // (no more threads: the pieces not started yet are worked by this thread, in order)
+        }
+        const int started = (int)pth.size();
         hipError_t ce = hipSetDevice(slots[0]->device);
         {
             StagedCopy sc;
             bool ring = false;
             for (int g = 0; g < G; g++) {
+                if (g >= started) {  // (see above: decoded here, its copy handed over through the same gate)
+                    piece(g);
+                    (void)hipSetDevice(slots[0]->device);
+                }
                 {
                     std::unique_lock<std::mutex> l(mu);
                     cv.wait(l, [&] { return gates[g].state != 0; });
@@ -2751,8 +2781,16 @@ int decompress_slabs(const sz3hip_config *conf, int dataType, const unsigned cha
         }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < ndev; t++) th.emplace_back(worker, t);
+    std::vector<int> inline_ts;
+    for (int t = 1; t < ndev; t++) {
+        try {
+            th.emplace_back(worker, t);
+        } catch (const std::system_error &) {
+            inline_ts.push_back(t);  // (no thread to be had: this device's slabs after the calling thread's own)
+        }
+    }
     worker(0);
+    for (int t : inline_ts) worker(t);
     for (auto &t : th) t.join();
     for (int g = 0; g < G; g++)
         if (rcs[g]) return fail(rcs[g], "slab %d: %s", g, errs[g].c_str());

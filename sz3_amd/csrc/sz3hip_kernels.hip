@@ -4042,6 +4042,258 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The packer of ONE-BYTE codes (round 6). k_pack spends ~14 vector instructions per symbol (two LDS lookups, the joins of code words
+// into pairs, quads and octets, the emission): it is bound by their issue, not by the 1.5 bytes per symbol it moves. Here a lane
+// looks up PAIRS of codes: a 128 x 128 table over the byte values t in [64, 192) (deltas -63 .. +64 around the mode of a one-byte
+// stream, byte 127; 64 KB of LDS: entry = (code words of t0 and t1 joined) << 5 | their length, 0 when one of them has no code word
+// or the two take more than 26 bits) — one lookup and one shift per TWO symbols. A workgroup is 1024 threads (16 waves share the
+// table: 64 KB + 16 stages of 3 KB, one workgroup per CU); three code registers per lane are in flight (the chunk being packed and
+// the next two: 16 waves x 3 KB per CU cover the HBM latency at the 3 TB/s the launch reads with).
+//   fast tier (wave-uniform test): every byte of the chunk inside the window, every pair in the table, every lane's two octets <= 64 bits:
+//     8 lookups, 2 emissions of 3 ds_or each;
+//   otherwise the chunk goes symbol by symbol through the 256-entry tables like k_pack — pairs (<= 48 bits: code words up to 24 bits,
+//     the books of round 6's sampled form give symbols the sample did not meet such lengths) joined to quads and octets where EVERY
+//     lane's fit 64 bits (wave-uniform), emitted as octets, quads or pairs.
+// Same bit stream as k_pack (same book, same chunk table): tests/test_gpu_stages.py compares the two byte for byte.
+// Role workgroups (the two list sorts; the book role is k_pack's: this kernel is launched where no book is built beside the packer)
+// and the assembly's come FIRST in the grid: they are short, and the packer's workgroups (one per CU) start behind them.
+// ------------------------------------------------------------------------------------------------------------
+#define PB_THREADS 1024u
+#define PB_WAVES (PB_THREADS / WAVE)
+#define PB_ASM_BLOCKS 32u
+// The stage is an array of 64-bit words whose HIGH half is the earlier 32-bit word of the stream: a left-aligned 64-bit string at bit
+// position pos lands in two of them — two 64-bit LDS atomics instead of three 32-bit ones.
+__device__ __forceinline__ void packb_emit(uint64_t *stage, uint64_t val, uint32_t len, uint32_t pos) {  // val: len bits, right-aligned, 1 <= len <= 64
+    const uint64_t v = val << ((64u - len) & 63u);  // left-aligned
+    const uint32_t q = pos >> 6, sh = pos & 63u;
+    atomicOr(reinterpret_cast<unsigned long long *>(&stage[q]), (unsigned long long)(v >> sh));
+    atomicOr(reinterpret_cast<unsigned long long *>(&stage[q + 1]), (unsigned long long)((v << 1) << (63u - sh)));  // (= v << (64 - sh), and 0 for sh = 0)
+}
+// one chunk: the lane's 16 code bytes (w[0] = symbols 0 .. 3, low byte first) into the wave's stage; returns the chunk's word count
+__device__ __forceinline__ uint32_t packb_chunk(const uint4 &cw, const uint32_t *__restrict__ s_pair, const uint32_t *__restrict__ s_enc8,
+                                                const uint8_t *__restrict__ s_len8, uint64_t *stage) {
+    const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+    // ---- fast tier ----
+    {
+        constexpr uint32_t K = 0x40404040u;  // t + 64 has bit 7 set exactly for t in [64, 192) (a carry out of a byte >= 192 can only clear the next byte's bit, never set a wrong one: such a byte's own bit is clear)
+        const uint32_t inw = (w[0] + K) & (w[1] + K) & (w[2] + K) & (w[3] + K) & 0x80808080u;
+        uint32_t e[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // entry of the pair (t0, t1): index (t1 & 127) << 7 | ((t0 ^ t1) & 127) — the XOR spreads the lookups over the LDS banks (a bank
+            // is the index's low five bits: with t0 alone a smooth field's symbols, a dozen values around the mode, meet in a dozen banks)
+            const uint32_t m = w[k] & 0x7F7F7F7Fu, x = m ^ (m >> 8), m1 = m >> 16, x1 = x >> 16;
+            const uint32_t a0 = ((x & 0x7Fu) << 2) | ((m & 0x7F00u) << 1), a1 = ((x1 & 0x7Fu) << 2) | ((m1 & 0x7F00u) << 1);
+            e[2 * k] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(s_pair) + a0);
+            e[2 * k + 1] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(s_pair) + a1);
+        }
+        const uint32_t emin = min(min(min(e[0], e[1]), min(e[2], e[3])), min(min(e[4], e[5]), min(e[6], e[7])));
+        uint64_t O[2];
+        uint32_t OL[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t l0 = e[4 * i] & 31u, l1 = e[4 * i + 1] & 31u, l2 = e[4 * i + 2] & 31u, l3 = e[4 * i + 3] & 31u;
+            const uint64_t qa = ((uint64_t)(e[4 * i] >> 5) << l1) | (e[4 * i + 1] >> 5);      // <= 52 bits
+            const uint64_t qb = ((uint64_t)(e[4 * i + 2] >> 5) << l3) | (e[4 * i + 3] >> 5);
+            const uint32_t lb = l2 + l3;
+            OL[i] = l0 + l1 + lb;
+            O[i] = (qa << (lb & 63u)) | qb;
+        }
+        const bool fast = inw == 0x80808080u && emin != 0u && OL[0] <= 64u && OL[1] <= 64u;
+        if (!__builtin_amdgcn_ballot_w64(!fast)) {
+            const uint32_t bits = OL[0] + OL[1];
+            const uint32_t incl = wave_incl_scan(bits);
+            const uint32_t total_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+            const uint32_t pos = incl - bits;
+            packb_emit(stage, O[0], OL[0], pos);
+            packb_emit(stage, O[1], OL[1], pos + OL[0]);
+            return (total_bits + 31u) >> 5;
+        }
+    }
+    // ---- symbol by symbol ----
+    uint64_t P[8];
+    uint32_t PL[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t pr = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+        const uint32_t b0 = pr & 0xFFu, b1 = pr >> 8;
+        const uint32_t l1 = s_len8[b1];
+        P[k] = ((uint64_t)s_enc8[b0] << l1) | s_enc8[b1];  // <= 48 bits
+        PL[k] = (uint32_t)s_len8[b0] + l1;
+    }
+    uint64_t Q[4];
+    uint32_t QL[4];
+    bool fit_q = true;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        QL[j] = PL[2 * j] + PL[2 * j + 1];
+        Q[j] = (P[2 * j] << (PL[2 * j + 1] & 63u)) | P[2 * j + 1];
+        fit_q &= QL[j] <= 64u;
+    }
+    const bool fit_o = QL[0] + QL[1] <= 64u && QL[2] + QL[3] <= 64u;
+    const uint32_t bits = QL[0] + QL[1] + QL[2] + QL[3];
+    const uint32_t incl = wave_incl_scan(bits);
+    const uint32_t total_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+    uint32_t pos = incl - bits;
+    if (!__builtin_amdgcn_ballot_w64(!fit_o)) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t len = QL[2 * i] + QL[2 * i + 1];
+            if (len) packb_emit(stage, (Q[2 * i] << (QL[2 * i + 1] & 63u)) | Q[2 * i + 1], len, pos);
+            pos += len;
+        }
+    } else if (!__builtin_amdgcn_ballot_w64(!fit_q)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (QL[j]) packb_emit(stage, Q[j], QL[j], pos);
+            pos += QL[j];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (PL[k]) packb_emit(stage, P[k], PL[k], pos);
+            pos += PL[k];
+        }
+    }
+    return (total_bits + 31u) >> 5;
+}
+__global__ __launch_bounds__(PB_THREADS) void k_pack_b(const uint16_t *__restrict__ codes, uint64_t n, const uint32_t *__restrict__ g_enc,
+                                                        const uint16_t *__restrict__ chunk_words, const uint64_t *__restrict__ group_off, szk_mode mode,
+                                                        uint32_t sym_add, const szk_state *__restrict__ state, uint8_t *__restrict__ payload,
+                                                        szk_asm_params ap, uint32_t pack_blocks, uint32_t split, szk_role_params rp) {
+    constexpr int STAGE_WORDS = SZH_CHUNK_SYMS * SZH_MAX_LEN / 32 + 4;  // + slack for the unconditional 3-word emit
+    __shared__ __align__(16) uint32_t s_pair[128 * 128];
+    __shared__ uint32_t s_enc8[256];  // code word by byte value ...
+    __shared__ uint8_t s_plen8[256];  // ... and its length
+    __shared__ __align__(8) uint64_t s_stage[PB_WAVES][STAGE_WORDS / 2];
+    const uint32_t roles = rp.on ? ROLE_BLOCKS : 0u;
+    if (blockIdx.x < roles) {  // (the pair table's memory serves as their scratch; they are 256-thread bodies: the other waves leave)
+        if (threadIdx.x >= 256u) return;
+        if (blockIdx.x != 0) role_sort(rp, ap, blockIdx.x == 2, reinterpret_cast<uint8_t *>(s_pair));
+        return;
+    }
+    const uint32_t asm_blocks = gridDim.x - roles - pack_blocks;
+    if (blockIdx.x < roles + asm_blocks) {
+        const uint32_t ab = blockIdx.x - roles;
+        assemble_body(ap, (uint64_t)ab * PB_THREADS + threadIdx.x, (uint64_t)asm_blocks * PB_THREADS);
+        if (!ap.lists_by_roles) assemble_lists(ap, (uint64_t)ab * PB_THREADS + threadIdx.x, (uint64_t)asm_blocks * PB_THREADS);
+        return;
+    }
+    const uint32_t bid = blockIdx.x - roles - asm_blocks;
+    if (!szk_is_narrow(mode)) return;  // stage 1 assumed one-byte codes, the probe says two: nothing to pack (the assembly reports it, the call is repeated)
+    const uint64_t n_full = n / SZH_CHUNK_SYMS, n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
+    const uint64_t n_groups = (n_chunks + PACK_GROUP - 1) / PACK_GROUP;
+    const uint32_t wv = threadIdx.x / WAVE;
+    const uint64_t wave_gid = (uint64_t)bid * PB_WAVES + wv, nwaves = (uint64_t)pack_blocks * PB_WAVES;
+    const int lane = lane_id();
+    const uint8_t *c8 = reinterpret_cast<const uint8_t *>(codes) + (uint64_t)lane * ENC_PER_LANE;
+    uint64_t *stage = s_stage[wv];
+    uint32_t *out_base = reinterpret_cast<uint32_t *>(payload + state->off.bitstream);
+    // A wave's work item: `span` consecutive chunks of one offset group (split = 1, 2, 4, 8 items per group of 32 chunks, chosen by the
+    // launcher so that every wave has an item) — their bit strings are one contiguous run of the stream, the run's place = the group's
+    // offset + the words of the group's chunks in front of it (one load of the group's 32 counts). The chunks are worked in batches of
+    // PB_BATCH: the loads of a batch are issued together, a batch ahead — on gfx9 a wave's loads and stores share one counter (vmcnt)
+    // and complete out of order with respect to each other, so waiting for a load means waiting for every store issued before: once
+    // per batch here, once per chunk in k_pack's loop (whose wave then idles through the store acknowledgement of its previous chunk).
+    constexpr uint32_t PB_BATCH = 4;
+    const uint32_t span = PACK_GROUP / split;
+    const uint64_t n_items = n_groups * split;
+    auto fetch = [&](uint64_t ch) { return ch < n_full ? *reinterpret_cast<const uint4 *>(c8 + ch * SZH_CHUNK_SYMS) : make_uint4(0u, 0u, 0u, 0u); };
+    uint64_t item = wave_gid;
+    uint4 cur[PB_BATCH], nxt[PB_BATCH];
+#pragma unroll
+    for (uint32_t j = 0; j < PB_BATCH; j++) cur[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (item < n_items) {
+        const uint64_t c_lo = (item / split) * PACK_GROUP + (item % split) * span;
+#pragma unroll
+        for (uint32_t j = 0; j < PB_BATCH; j++) cur[j] = fetch(c_lo + j);
+    }
+    // the tables: single symbols by byte value, then the pairs of the window from them
+    if (threadIdx.x < 256u) {
+        const uint32_t e = g_enc[threadIdx.x != 255u ? threadIdx.x + sym_add : 0u];
+        s_enc8[threadIdx.x] = e >> 5;
+        s_plen8[threadIdx.x] = (uint8_t)(e & 31u);
+    }
+    for (int i = lane; i < STAGE_WORDS / 2; i += WAVE) stage[i] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 128u * 128u; i += PB_THREADS) {
+        const uint32_t i1 = i >> 7, i0 = (i & 127u) ^ i1;        // window indices t & 127 of the first and the second symbol (the table is swizzled: packb_chunk)
+        const uint32_t t0 = i0 < 64u ? i0 + 128u : i0, t1 = i1 < 64u ? i1 + 128u : i1;  // byte values in [64, 192)
+        const uint32_t l0 = s_plen8[t0], l1 = s_plen8[t1];
+        const uint32_t len = l0 + l1;
+        s_pair[i] = (l0 && l1 && len <= 26u) ? ((((s_enc8[t0] << l1) | s_enc8[t1]) << 5) | len) : 0u;
+    }
+    __syncthreads();
+    for (; item < n_items; item += nwaves) {
+        const uint64_t grp = item / split;
+        const uint32_t first = (uint32_t)(item % split) * span;  // the item's first chunk inside its group
+        const uint64_t c_lo = grp * PACK_GROUP + first;
+        const uint64_t c_hi = c_lo + span < n_full ? c_lo + span : n_full;  // (whole chunks only: the ragged last one is packed apart)
+        uint32_t front = ((uint32_t)lane < first && grp * PACK_GROUP + lane < n_chunks) ? chunk_words[grp * PACK_GROUP + lane] : 0u;
+        front = wave_sum(front);
+        uint32_t *out = out_base + group_off[grp] + front;
+        const uint64_t nitem = item + nwaves;
+        const uint64_t n_lo = nitem < n_items ? (nitem / split) * PACK_GROUP + (nitem % split) * span : n_full;
+        for (uint64_t cb = c_lo; cb < c_hi; cb += PB_BATCH) {
+            const uint64_t nb = cb + PB_BATCH < c_hi ? cb + PB_BATCH : n_lo;  // the batch after this one: of this item, or the next item's first
+#pragma unroll
+            for (uint32_t j = 0; j < PB_BATCH; j++) nxt[j] = fetch(nb + j);  // (beyond the next item's end: loaded, never used; beyond the array: not loaded)
+#pragma unroll
+            for (uint32_t j = 0; j < PB_BATCH; j++) {
+                if (cb + j < c_hi) {  // (wave-uniform)
+                    const uint32_t nwords = packb_chunk(cur[j], s_pair, s_enc8, s_plen8, stage);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t i = 2 * lane; i < nwords + 2; i += 2 * WAVE) {  // copy out and re-zero the stage for the next chunk, two words per lane
+                        const uint64_t v = stage[i >> 1];
+                        stage[i >> 1] = 0;
+                        if (i < nwords) out[i] = __builtin_bswap32((uint32_t)(v >> 32));  // bytes in stream order (see sz3hip_format.h)
+                        if (i + 1 < nwords) out[i + 1] = __builtin_bswap32((uint32_t)v);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    out += nwords;
+                }
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < PB_BATCH; j++) cur[j] = nxt[j];
+        }
+    }
+    if (n_full < n_chunks && wave_gid == 0) {  // ragged tail: the missing symbols have no bits — packed symbol by symbol
+        const uint64_t base = n_full * SZH_CHUNK_SYMS + (uint64_t)lane * ENC_PER_LANE;
+        const uint8_t *cb = reinterpret_cast<const uint8_t *>(codes);
+        uint32_t bits = 0;
+        uint64_t P[8];
+        uint32_t PL[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint64_t i0 = base + 2 * k, i1 = i0 + 1;
+            const uint32_t b0 = i0 < n ? cb[i0] : 0u, b1 = i1 < n ? cb[i1] : 0u;
+            const uint32_t l0 = i0 < n ? s_plen8[b0] : 0u, l1 = i1 < n ? s_plen8[b1] : 0u;
+            P[k] = ((uint64_t)(i0 < n ? s_enc8[b0] : 0u) << l1) | (i1 < n ? s_enc8[b1] : 0u);
+            PL[k] = l0 + l1;
+            bits += PL[k];
+        }
+        const uint32_t incl = wave_incl_scan(bits);
+        const uint32_t total_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+        uint32_t pos = incl - bits;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (PL[k]) packb_emit(stage, P[k], PL[k], pos);
+            pos += PL[k];
+        }
+        const uint32_t nwords = (total_bits + 31u) >> 5;
+        const uint64_t grp = n_full / PACK_GROUP;
+        const uint32_t cin = (uint32_t)(n_full % PACK_GROUP);
+        uint32_t bp = (uint32_t)lane < cin ? chunk_words[grp * PACK_GROUP + lane] : 0u;
+        const uint32_t before = wave_sum(bp);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t *out = out_base + group_off[grp] + before;
+        for (uint32_t i = lane; i < nwords; i += WAVE) out[i] = __builtin_bswap32((uint32_t)(stage[i >> 1] >> ((i & 1u) ? 0 : 32)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // The encoder behind a FUSED stage 1 (k_lorenzo_quant_march3f): the rows' bit strings exist, in the tasks' slots of the scratch; a
 // chunk of the payload is four consecutive 256-element segments (x extents that are multiples of 256), its place known since the
 // offset scan. A wave per chunk, a lane per output word: the word's first bit lies in segment k = the number of segment starts at
@@ -5641,6 +5893,22 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
         mp.fuse_flag = mg->fuse_flag;
         const uint32_t pb = pgrid < 2048 - extra ? pgrid : 2048 - extra;
         hipLaunchKernelGGL(k_merge, dim3(rb + pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, mp, n, chunk_words, group_off, mode, state, payload, apv, pb, rp);
+    } else if (asmp && asmp->assumed_narrow && !(rp.on && !rp.no_book) && !(szk_dbg_flags & 32768) && n_chunks >= 4096) {
+        // one-byte codes (stage 1's one-launch form assumed them; a probe that says otherwise voids the call) and no book built beside the
+        // packer: the pair-table packer, one 1024-thread workgroup per CU (sz3hip_debug_flags(32768): k_pack as before)
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+            if (n_cu <= 0) n_cu = 256;
+        }
+        const uint32_t pb = (uint32_t)n_cu;
+        const uint64_t n_groups = (n_chunks + PACK_GROUP - 1) / PACK_GROUP, nwv = (uint64_t)pb * PB_WAVES;
+        uint32_t split = 1;  // work items per offset group: as many as give every wave one (at most 8: an item is at least one batch of 4 chunks)
+        while (split < 8 && n_groups * split < nwv) split *= 2;
+        hipLaunchKernelGGL(k_pack_b, dim3(rb + PB_ASM_BLOCKS + pb), dim3(PB_THREADS), 0, s, codes, n, d_enc, chunk_words, group_off, mode, sym_add, state,
+                           payload, apv, pb, split, rp);
     } else if (mode.pack_wide) {
         const uint32_t pb = pgrid < 768 - extra ? pgrid : 768 - extra;
         hipLaunchKernelGGL((k_pack<2 * ENC_WIN>), dim3(rb + pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,

@@ -194,7 +194,7 @@ extern "C" size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in) 
 static const char *const kStageNames[ST_COUNT] = {"lorenzo_quant_hist", "codebook", "encode", "assemble",
                                                   "huffman_decode",     "reconstruct", "tuner", "k1_kernel", "step_span"};
 
-#define SZ_COUNTER_BYTES 128
+#define SZ_COUNTER_BYTES (128 + 4 * SZK_SAMP_WORDS)  // 16 counter words, then the sampled book's state words (szk_samp)
 // histogram and counters of a call start at zero; the internal histogram and the counters share one block (one fill launch)
 static hipError_t clear_hist_counters(sz3hip_ctx *c, hipStream_t s) {
     if (c->pre_cleared && c->d_hist == c->d_hist_own && c->pre_stream == s) {  // (done behind the previous call, on this stream)
@@ -616,7 +616,22 @@ static int lorenzo_k1(sz3hip_ctx *ctx, int N, const uint64_t *dims, const void *
     if ((ctx->hist_exposed || ctx->hist_reduced) && p.hint_narrow > 0) p.hint_narrow = -1;
     p.hint_q16 = allow_narrow && ctx->dtype == SZ3HIP_FLOAT && ctx->q16_hint > 0 && ctx->q16_block == 0 ? 1 : 0;
     p.q16_flag = reinterpret_cast<uint32_t *>(ctx->d_counters + 11) + 1;  // zeroed with the counters
-    if (allow_narrow && book_spec_ok(ctx, 0, (uint32_t)radius) && ctx->cb_hint == 0 && !ctx->lists_long && !ctx->hist_exposed) {
+    // Round 6, the sampled book: an array of at least SZK_SAMP_MIN_ELEMS elements in rows of whole 256-element segments (1-D ... 3-D)
+    // whose stream turns out to have one-byte codes is coded with a book built from a sample of it (sz3hip_kernels.h, szk_samp) — a
+    // function of the input alone, whatever this context coded before and whichever form of stage 1 it takes. Not for contexts whose
+    // histogram is exchanged between the stages (multi-GPU: the ranks share one book made from the summed histogram).
+    const bool samp = allow_narrow && radius >= 128 && N <= 3 && p.d[3] % 256 == 0 && num >= SZK_SAMP_MIN_ELEMS && !ctx->hist_exposed && !ctx->hist_reduced &&
+                      !(szk_dbg_flags & 65536);
+    if (samp) {
+        const int fresh = ctx->book_idx < 0 ? 0 : 1 - ctx->book_idx;  // (stage2_launch's slot for this call's book)
+        p.samp.words = reinterpret_cast<uint32_t *>(ctx->d_counters + 16);  // zeroed with the counters
+        p.samp.enc = ctx->bk[fresh].enc;
+        p.samp.lens = ctx->bk[fresh].lens;
+        p.samp.info = ctx->bk[fresh].info;
+        p.seg_bits = ctx->d_seg_bits;
+        p.seg_made = reinterpret_cast<uint32_t *>(ctx->d_counters + 10) + 1;  // zeroed with the counters
+    }
+    if (!samp && allow_narrow && book_spec_ok(ctx, 0, (uint32_t)radius) && ctx->cb_hint == 0 && !ctx->lists_long && !ctx->hist_exposed) {
         // stage 2 will pack with the previous call's book: its code lengths let the one-byte kernel sum the code bits of the
         // 256-element segments (no bits pass), and the fold of the histogram rows moves into the scan's launch of stage 2
         p.spec_lens = ctx->bk[ctx->book_idx].lens;
@@ -675,6 +690,8 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
     ctx->fold_range = p.range;
     ctx->s1_fused = p.fused != 0;
     ctx->s1_slots = p.fuse_slots;
+    ctx->s1_samp = p.samp.words != nullptr;  // (the launcher drops it for forms that have no one-byte codes)
+    ctx->s1_samp_in = ctx->s1_samp && p.samp_in_launch != 0;
     prof_end(ctx, ST_K1, s);
     if (rc) return fail(SZ3HIP_EHIP, "lorenzo_quant kernel launch failed (%d)", rc);
     szh_header &h = ctx->proto;
@@ -1423,7 +1440,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     for (int i = 0; i < ST_COUNT; i++) ctx->ev_used[i] = false;  // stage times describe this call only
     ctx->copy_ahead = false;
     ctx->range_ready = false;
-    ctx->s1_spec = ctx->seg_expected = ctx->s1_assumed_narrow = ctx->s1_fused = false;
+    ctx->s1_spec = ctx->seg_expected = ctx->s1_assumed_narrow = ctx->s1_fused = ctx->s1_samp = ctx->s1_samp_in = false;
     ctx->fold_rows = 0;
     ctx->s1_conf = *conf_in;
     ctx->s1_in = d_in;
@@ -1551,7 +1568,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     return stage1_lorenzo(ctx, conf, d_in, eb, radius, num, s);
 }
 
-enum { S2_CLASSIC = 0, S2_SPEC = 1, S2_REENCODE = 2, S2_SPEC_WIDE = 3 };
+enum { S2_CLASSIC = 0, S2_SPEC = 1, S2_REENCODE = 2, S2_SPEC_WIDE = 3, S2_SAMPLED = 4 };
 static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream_t s, int how);
 extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t cap, void *stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -1602,7 +1619,11 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
         ctx->spec_off = spec_was;
         if (rc1) return rc1;
     }
-    int rc = stage2_launch(ctx, d_payload, cap, s, spec ? S2_SPEC : (spec_wide ? S2_SPEC_WIDE : S2_CLASSIC));
+    // the sampled book (round 6) is in its slot when stage 1 ends: with the segments' sums made by stage 1 and short lists (the packer's
+    // sort roles) stage 2 is the segment pass, the scan and the packer; otherwise the classic form, whose code-book launch then only
+    // sorts the lists
+    const bool samp_roles = ctx->proto.predictor == 0 && ctx->s1_samp_in && ctx->seg_expected && !ctx->lists_long;
+    int rc = stage2_launch(ctx, d_payload, cap, s, samp_roles ? S2_SAMPLED : (ctx->proto.predictor == 0 && ctx->s1_samp) ? S2_CLASSIC : spec ? S2_SPEC : (spec_wide ? S2_SPEC_WIDE : S2_CLASSIC));
     if (rc) return rc;
     ctx->stage2_done = true;
     return 0;
@@ -1616,8 +1637,11 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     ctx->book_pending = fresh;
     ctx->s2_spec = how == S2_SPEC || wide;
     ctx->s2_wide = wide;
+    ctx->s2_samp = how == S2_SAMPLED;
+    const uint32_t *samp_words = ctx->proto.predictor == 0 && ctx->s1_samp ? reinterpret_cast<const uint32_t *>(ctx->d_counters + 16) : nullptr;
     szk_cb_params cb;
     cb_params_from(ctx, cb, ctx->cur_out_cap, fresh);
+    cb.samp_words = samp_words;
     // Speculative form: this call's book, the verdict and the list sorts ride in the packer's own launch as three role
     // workgroups, the fold of stage 1's histogram rows in the scan's launch — one stream, two launches.
     const bool fused = how == S2_SPEC;
@@ -1672,6 +1696,15 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
         er.flags = reinterpret_cast<uint32_t *>(ctx->d_counters + 10);
         er.exact = ctx->spec_exact;
     }
+    if (how == S2_SAMPLED) {  // the book is in its slot (stage 1 built it): the packer's launch carries the two sort roles, nothing else
+        er.roles = 1;
+        er.no_book = 1;
+        er.hist = ctx->d_hist;
+        er.cb = &cb;
+        er.used_lens = ctx->bk[used].lens;
+        er.flags = reinterpret_cast<uint32_t *>(ctx->d_counters + 10);
+        er.exact = 1;
+    }
     if (how == S2_CLASSIC) {
         if (ctx->range_ready && !cb.range_ready)  // stage 1 kept the range of the LOCAL histogram, the caller then changed it (all-reduce):
             HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, 16, s));  // k_hist_range starts from zero
@@ -1709,6 +1742,7 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     ap.assumed_narrow = ctx->s1_assumed_narrow ? 1 : 0;
     ap.q16_flag = ctx->s1_q16 && ctx->proto.predictor == 0 ? reinterpret_cast<const uint32_t *>(ctx->d_counters + 11) + 1 : nullptr;
     ap.mode = ctx->mode;
+    ap.samp_words = samp_words;
     szk_merge_args mg;
     memset(&mg, 0, sizeof(mg));
     const bool merge = fused && ctx->s1_fused && ctx->seg_expected;
@@ -1721,8 +1755,8 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     prof_begin(ctx, ST_ENCODE, s);  // (the payload layout is computed inside the encoder's scan launch, the sections are assembled by the packer's)
     int rc = szk_launch_encode(ctx->d_codes, n, ctx->bk[used].enc, ctx->bk[used].info, (int)ctx->proto.radius, ctx->mode, ctx->d_chunk_words,
                                ctx->d_chunk_off, ctx->d_counters + 2, ctx->d_state, (uint8_t *)d_payload, &lp, &ap, s,
-                               fused && ctx->seg_expected ? ctx->d_seg_bits : nullptr, reinterpret_cast<uint32_t *>(ctx->d_counters + 10) + 1,
-                               (fused || wide) ? &er : nullptr, merge ? &mg : nullptr);
+                               (fused || (samp_words && ctx->s1_samp_in)) && ctx->seg_expected ? ctx->d_seg_bits : nullptr, reinterpret_cast<uint32_t *>(ctx->d_counters + 10) + 1,
+                               (fused || wide || how == S2_SAMPLED) ? &er : nullptr, merge ? &mg : nullptr);
     prof_end(ctx, ST_ENCODE, s);
     if (rc) return fail(SZ3HIP_EHIP, "encode kernel launch failed (%d)", rc);
     if (wide) {  // join: this call's book against the one the encoder used
@@ -1823,6 +1857,14 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
             ctx->spec_hits++;
             ctx->spec_penalty = 0;
         }
+    } else if (ctx->s2_samp && ctx->h_state->miss_kind) {
+        // (miss kind 4) a list too long for the packer's sort roles: stage 2 once more in the classic form — codes, segment sums and the
+        // sampled book are as stage 1 left them, the code-book launch sorts the lists
+        HIPCHK(hipMemsetAsync(ctx->d_counters + 7, 0, 24, s));
+        ctx->range_ready = false;
+        int rc2 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s, S2_CLASSIC);
+        if (rc2) return rc2;
+        if (int rw = wait_published(ctx)) return rw;
     } else if (ctx->spec_skip > 0) {
         ctx->spec_skip--;
     }
@@ -2211,7 +2253,11 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     prof_begin(ctx, ST_DEC_HUFF, s);
     // (a Lorenzo stream's small book — code words up to 16 bits, at most 1024 symbols: the tables' launch also makes the multi-symbol table)
     const bool ms_book = h.predictor == 0 && h.qbytes == 4 && h.max_len >= 1 && h.max_len <= 16 && h.sym_count <= 1024 && (szk_dbg_flags & 2);
-    int rc = szk_launch_dec_tables(pl + o.lens, h.sym_min, h.sym_count, ctx->d_tables, ms_book ? h.radius : 0u, ovf, (const uint16_t *)(pl + o.chunkwords), h.n_chunks,
+    // (a Lorenzo stream's header names the symbol that stands for a listed delta in its anchor_stride field: 0 = symbol 0 itself)
+    const uint32_t esc_sym = h.predictor == 0 ? (uint32_t)h.anchor_stride : 0u;
+    if (h.predictor == 0 && h.anchor_stride && (h.anchor_stride < h.sym_min || h.anchor_stride >= (uint64_t)h.sym_min + h.sym_count))
+        return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (escape symbol)");
+    int rc = szk_launch_dec_tables(pl + o.lens, h.sym_min, h.sym_count, ctx->d_tables, ms_book ? h.radius : 0u, esc_sym, ovf, (const uint16_t *)(pl + o.chunkwords), h.n_chunks,
                                    ctx->d_chunk_off, ctx->d_counters + 3, s);
     if (rc) return fail(SZ3HIP_EHIP, "dec_tables kernel launch failed (%d)", rc);
     szk_dec_params dp;

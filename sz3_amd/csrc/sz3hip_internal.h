@@ -135,6 +135,9 @@ struct sz3hip_ctx {
     const uint32_t *s1_slots;  // the scratch this call's fused stage 1 wrote
     bool fuse_on;          // the context asks for the fused stage 1 where it applies (sz3hip_ctx_set_fused; default off)
     bool s1_fused;         // this call's stage 1 was the fused form (k_lorenzo_quant_march3f): no code array, the encoder merges
+    bool s1_samp;          // (round 6) the pending call's one-byte stream is coded with a book built from a sample of the array (szk_samp)
+    bool s1_samp_in;       // ... taken and built inside stage 1's launch, which also summed the segments' bits with it
+    bool s2_samp;          // the pending stage 2 ran with that book and the packer's sort roles
     bool last_fused;       // ... the last finished call's
     bool last_spec_hit;    // the last finished call confirmed its speculation
     int blk_wide;           // block predictor: wide LDS histogram window (from the previous call's alphabet)

@@ -36,6 +36,29 @@ struct szk_mode {
 };
 
 struct szk_cb_info;
+// Round 6: the code book of a one-byte Lorenzo stream from a SAMPLE of the array ("the sampled book"). The sample — SZK_SAMP_UNITS
+// 256-element row segments at places that depend on the extents alone — and the book built from its counts are pure functions of the
+// input, known a few microseconds into the call instead of after a pass over all codes: stage 1 sums the segments' code bits with THIS
+// call's book (no bits pass, no speculation with the previous call's book, nothing to verify or repeat), and a payload does not depend
+// on what its context coded before. Every byte value 0 .. 255 gets a code word (a value the sample did not meet counts a quarter of an
+// occurrence: code words up to SZH_MAX_LEN bits, which k_pack_b takes); byte 255 — a listed delta — is coded as symbol radius + 128
+// (szk_cb_info::esc_sym, the payload header's anchor_stride field), so that the lengths' table of the payload stays 256 entries.
+#define SZK_SAMP_UNITS 1024u   // sample units of one array (262144 values)
+#define SZK_SAMP_ROLES 128u    // workgroups that take the sample, two units per wave (the last one to finish builds the book)
+#define SZK_SAMP_MIN_ELEMS (1ull << 22)
+#define SZK_SAMP_SEEN_LEN 16u  // longest code word of a byte value the sample met (13 would make every pair of them fit an entry of the packer's pair table — and costs 0.2 % of the ratio on a 2-D field with a hundred symbols)
+// device words of the sample's state, zeroed with the call's counters: [0..255] counts by byte value, [320] workgroups done; on a cache line
+// of their own (the workers of stage 1 poll it): [384..447] the book's lengths by byte value, four per word, [448] 1 = the book is in its slot
+#define SZK_SAMP_WORDS 512u
+#define SZK_SAMP_TICKET 320u
+#define SZK_SAMP_LENS 384u
+#define SZK_SAMP_READY 448u
+struct szk_samp {
+    uint32_t *words;          // [SZK_SAMP_WORDS] (nullptr: no sampled book in this call)
+    uint32_t *enc;            // the book's slot: [65536] (code word << 5) | length ...
+    uint8_t *lens;            // ... [65536] lengths ...
+    szk_cb_info *info;        // ... and its descriptor
+};
 struct szk_k1_params {
     uint64_t d[4];  // extents slowest first, left-padded with 1: [w][z][y][x]
     szk_lattice lat;
@@ -85,12 +108,18 @@ struct szk_k1_params {
     uint32_t *seg_base;             // [n / 256] index of the first word of a segment's bit string in the scratch
     uint32_t *fuse_flag;            // device word, raised when a symbol had no code word in that book
     uint32_t fuse_geom[4];          // out: [3] = words of a task's slot
+    // the sampled book (round 6): samp.words != nullptr = the array is one whose one-byte stream is coded with a sampled book. The
+    // one-launch forms take the sample and build the book in SZK_SAMP_ROLES workgroups of their own launch and sum the segments' bits
+    // with it (samp_in_launch, out); behind the two-launch form a launch of its own does (k_sample)
+    szk_samp samp;
+    int samp_in_launch;             // out
     // (the launcher's query, szk_fuse_scratch_words: words the scratch of a fused launch over this shape needs)
 };
 
 struct szk_cb_info {
     uint32_t n_symbols, max_len, sym_min, sym_count;
     uint32_t win_lo, reserved;  // first symbol of the packers' LDS window of the encode table
+    uint32_t esc_sym, pad0;     // 0: a listed delta is symbol 0; else the symbol that stands for it (sampled books: radius + 128) — the decoder maps it back to 0
     uint64_t ts[12];  // phase timestamps (wall_clock64, 100 MHz) for tools/cb_lab.py
     uint32_t first_code[SZH_MAX_LEN + 2];  // (round 5) first code word of every length: what k_cb_assign needs of the book's workgroup (reserved == 0x5A5A while the code words are its to make)
 };
@@ -117,6 +146,7 @@ struct szk_cb_params {
     int assign_later;      // (set by the launcher) the wide book leaves the code words to k_cb_assign behind its launch (info->first_code, depth[] = the lengths)
     int keys_ready;        // (set by the launcher) keys[] / syms[] were compacted by k_cb_compact in front of this launch, ifreq[0..63] holds its sums
     int skip_sort;         // the launch's two list-sorting workgroups return at once (the lists are sorted elsewhere: speculative stage 2)
+    const uint32_t *samp_words;  // non-null: when the words say that this call's sampled book is in its slot, no book is built (the launch sorts the lists only)
 };
 #define SZK_CB_SMALL_SYMS 256  // alphabets up to this size take k_codebook<0>, wider ones <1>
 #define SZK_MAX_BOOKS 4
@@ -160,6 +190,7 @@ struct szk_asm_params {
     int assumed_narrow;   // stage 1 ran the one-launch form, which assumes one-byte codes: a probe that says otherwise raises miss_kind bit 32
     const uint32_t *q16_flag;  // stage 1 ran the 16-bit form: the word it raises on a value it does not take (miss_kind bit 128), else nullptr
     szk_mode mode;
+    const uint32_t *samp_words;  // the call codes with its sampled book when the words say so: the assembly then writes the state words a book role would
 };
 // speculative stage 2, small alphabets: work that rides in the encoder's two launches instead of a side stream
 struct szk_merge_args {         // what the merge launch needs of a fused stage 1 (k_lorenzo_quant_march3f)
@@ -443,6 +474,7 @@ int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
 int szk_launch_publish(const szk_state *d_state, void *h_state, uint32_t *h_seq, uint32_t seq, void *d_zero, uint64_t zero_bytes, hipStream_t s);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t,
                           uint32_t radius /* != 0: the multi-symbol table of a Lorenzo stream's small book is made too (mlut) */,
+                          uint32_t esc_sym /* != 0: the stored symbol that decodes as symbol 0 (a listed delta; sampled books) */,
                           uint32_t *zero_word /* a device word this launch clears (nullptr: none) */,
                           const uint16_t *chunk_words, uint64_t n_chunks, uint64_t *group_off, uint64_t *total_words /* the decoder's group
                           offsets, made by a second workgroup of the same launch (chunk_words == nullptr: not made) */, hipStream_t s);

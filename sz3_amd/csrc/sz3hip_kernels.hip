@@ -991,6 +991,9 @@ template <typename T> struct NarrowCtx {
     uint32_t slot_w;        // words of the slot written (wave-uniform, a multiple of 32: whole 128-byte lines)
     uint32_t st_cnt;        // words waiting at the stage's front for the line they belong to to fill up (< 32, wave-uniform)
     uint32_t *seg_base;     // [n / 256] out: index of the first word of every segment's bit string in the scratch
+    // sampled book (round 6): the lengths' table is filled when the book arrives (samp_words[SZK_SAMP_READY]); until then a plane's segment sums wait
+    const uint32_t *samp_words;
+    uint32_t have_len;      // (wave-uniform) the table is filled
 };
 // a 256-element row segment is at most 256 x 16 bits = 128 words (small books: code words <= 16 bits); the stage of a wave holds a
 // plane's TY rows one behind the other (+ slack for the unconditional emission and the two-word sweep); a task's slot holds its
@@ -1543,6 +1546,52 @@ __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t 
 //   * the code-length table of the speculative bit accounting is laid out like the histogram ([byte][4 copies]): a code's
 //     histogram address is also the address of its length.
 // ------------------------------------------------------------------------------------------------------------
+// (always inlined, the kernel's parameters handed over piecemeal: a call would put the caller's parameter block on a stack, and a kernel
+// with a stack pays for it in every wave)
+template <typename T> __device__ __forceinline__ bool samp_take(const T *__restrict__ in, const szk_lattice &latp, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t *words, uint32_t role, uint32_t *s_h);
+__device__ __forceinline__ void samp_book(const szk_samp &sp, uint32_t radius, uint8_t *pool);
+#define SAMP_POOL_BYTES (SZK_CB_SMALL_SYMS * 28 + 256)
+// a worker's wave looks for the sampled book (spin: waits for it) and, once it is there, fills ITS view of the workgroup's length table
+// (all four waves write the same values): `put(byte value, length)` stores one entry in the form's layout
+template <typename T, typename PUT>
+__device__ __forceinline__ bool samp_poll(NarrowCtx<T> &c, bool spin, PUT put) {
+    // Wave 0 of the workgroup asks the device-wide word (a load past the L2s: all workers asking would be a billion requests a second to
+    // one memory channel — the one the sampling workgroups' atomics go to), fills the workgroup's table and raises the workgroup's LDS
+    // word; the other waves watch that. Wave 0 leaves a task only with the book in hand, so the LDS word is raised before it exits.
+    volatile uint32_t *s_have = c.lh + NARROW_BINS * 8;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    if (wv != 0) {
+        uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_have);
+        if (!h) {
+            if (!spin) return false;
+            do {
+                __builtin_amdgcn_s_sleep(16);
+                h = (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_have);
+            } while (!h);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        c.have_len = 1;
+        return true;
+    }
+    uint32_t r = __hip_atomic_load(const_cast<uint32_t *>(c.samp_words) + SZK_SAMP_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+    if (!r) {
+        if (!spin) return false;
+        do {
+            __builtin_amdgcn_s_sleep(32);
+            r = __hip_atomic_load(const_cast<uint32_t *>(c.samp_words) + SZK_SAMP_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+        } while (!r);
+    }
+    const uint32_t w = __hip_atomic_load(const_cast<uint32_t *>(c.samp_words) + SZK_SAMP_LENS + c.lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int j = 0; j < 4; j++) put(4u * (uint32_t)c.lane + j, (w >> (8 * j)) & 0xFFu);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (c.lane == 0) *s_have = 1u;
+    c.have_len = 1;
+    return true;
+}
 #define Q16_LIM 4095.0f
 typedef float v2f32 __attribute__((ext_vector_type(2)));
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
@@ -1577,7 +1626,7 @@ template <int TY> struct Q16Plane {
     float rl[TY + 1];
     bool rok[TY + 1];
 };
-template <int TY, bool EDGE>
+template <int TY, bool EDGE, bool SAMP>
 __device__ __forceinline__ void narrow16_task(NarrowCtx<float> &c, const Lattice<float> &lat, uint32_t *q16_flag, uint32_t x0, uint32_t y0, uint32_t z0) {
     const uint32_t d0 = c.d0, d1 = c.d1, d2 = c.d2;
     const int lane = c.lane;
@@ -1672,10 +1721,12 @@ __device__ __forceinline__ void narrow16_task(NarrowCtx<float> &c, const Lattice
             if (EDGE) rare &= xok;
             const uint32_t a0 = mad16_lo(tA, c4), a1 = mad16_lo(tB, c4), a2 = mad16_hi(tA, c4), a3 = mad16_hi(tB, c4);
             if (!EDGE || xok) {
-                atomicAdd(reinterpret_cast<uint32_t *>(lds + a0), 1u);
-                atomicAdd(reinterpret_cast<uint32_t *>(lds + a1), 1u);
-                atomicAdd(reinterpret_cast<uint32_t *>(lds + a2), 1u);
-                atomicAdd(reinterpret_cast<uint32_t *>(lds + a3), 1u);
+                if (!SAMP) {  // (a sampled book needs no histogram)
+                    atomicAdd(reinterpret_cast<uint32_t *>(lds + a0), 1u);
+                    atomicAdd(reinterpret_cast<uint32_t *>(lds + a1), 1u);
+                    atomicAdd(reinterpret_cast<uint32_t *>(lds + a2), 1u);
+                    atomicAdd(reinterpret_cast<uint32_t *>(lds + a3), 1u);
+                }
 #if defined(LAB_ST) && LAB_ST == 1  // (lab: write-through stores — nothing of the code array dirty in the L2s at the kernel's end)
                 __hip_atomic_store(reinterpret_cast<uint32_t *>(c.codes8 + grow + x), tA | (tB << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #elif defined(LAB_ST) && LAB_ST == 2
@@ -1686,7 +1737,7 @@ __device__ __forceinline__ void narrow16_task(NarrowCtx<float> &c, const Lattice
                 __builtin_nontemporal_store(tA | (tB << 8), reinterpret_cast<uint32_t *>(c.codes8 + grow + x));
 #endif
             }
-            if (c.s_len) {
+            if (SAMP ? c.have_len != 0u : c.s_len != nullptr) {
                 uint32_t b4 = (uint32_t)lds[Q16_LEN_OFF + a0] + lds[Q16_LEN_OFF + a1] + lds[Q16_LEN_OFF + a2] + lds[Q16_LEN_OFF + a3];
                 if (EDGE) b4 = xok ? b4 : 0u;
                 bits_rows[(r - 1) >> 1] |= ((r - 1) & 1) ? b4 << 16 : b4;
@@ -1716,7 +1767,7 @@ __device__ __forceinline__ void narrow16_task(NarrowCtx<float> &c, const Lattice
                 if (big) atomicOr(q16_flag, 1u);
             }
         }
-        if (c.s_len && zz >= 0) {  // the plane's segment sums: one wave reduction per pair of rows
+        if ((SAMP ? c.have_len != 0u : c.s_len != nullptr) && zz >= 0) {  // the plane's segment sums: one wave reduction per pair of rows
 #pragma unroll
             for (int k = 0; k < (TY + 1) / 2; k++) {
                 const uint32_t tot = wave_sum(bits_rows[k]);
@@ -1731,6 +1782,69 @@ __device__ __forceinline__ void narrow16_task(NarrowCtx<float> &c, const Lattice
     };
     int zz = z0 > 0 ? -1 : 0;
     const int zend = d2 - z0 < (uint32_t)MARCH_TZ ? (int)(d2 - z0) : MARCH_TZ;
+    // sampled book: the planes of this task coded before the book arrived get their segment sums from the codes they stored (read back
+    // past the L1: the wave's own streaming stores, acknowledged by the L2 first)
+    auto put_len = [&](uint32_t b, uint32_t len) {
+        uint32_t *lt = c.lh + NARROW_BINS * 4 + b * 4u;
+        lt[0] = lt[1] = lt[2] = lt[3] = len;
+    };
+    auto catch_up = [&](int zhi) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        constexpr int PB = 4;  // planes per round: their rows' code words are requested together (a load past the L1 — the wave's own stores are in the XCD's L2 — is a round trip to the L2)
+        for (int p0 = 0; p0 < zhi; p0 += PB) {
+            uint32_t cw[PB][TY];
+#pragma unroll
+            for (int j = 0; j < PB; j++) {
+                const uint64_t gp = (uint64_t)(z0 + (uint32_t)(p0 + j)) * c.plane;
+#pragma unroll
+                for (int r = 0; r < TY; r++) {
+                    const uint32_t ry = y0 + (uint32_t)r;
+                    cw[j][r] = 0x80808080u;  // (a row that is not there: its bytes are not looked up)
+                    if (p0 + j < zhi && ry < d1 && xok)
+                        cw[j][r] = __hip_atomic_load(reinterpret_cast<uint32_t *>(c.codes8 + gp + (uint64_t)ry * d0 + x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PB; j++) {
+                const uint64_t gp = (uint64_t)(z0 + (uint32_t)(p0 + j)) * c.plane;
+                if (p0 + j < zhi)
+#pragma unroll
+                for (int k = 0; k < (TY + 1) / 2; k++) {
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const uint32_t ry = y0 + 2u * k + h;
+                        if (2 * k + h < TY && ry < d1 && xok) {
+                            const uint32_t w = cw[j][(2 * k + h) < TY ? 2 * k + h : 0];
+                            const uint32_t b4 = (uint32_t)lds[Q16_LEN_OFF + (w & 0xFFu) * 16u + c4] + lds[Q16_LEN_OFF + ((w >> 8) & 0xFFu) * 16u + c4] +
+                                                lds[Q16_LEN_OFF + ((w >> 16) & 0xFFu) * 16u + c4] + lds[Q16_LEN_OFF + (w >> 24) * 16u + c4];
+                            packed |= h ? b4 << 16 : b4;
+                        }
+                    }
+                    const uint32_t tot = wave_sum(packed);
+                    const uint32_t ra = y0 + 2u * k, rb = ra + 1u;
+                    if (lane == 0) {
+                        const uint64_t g0 = gp + x0;
+                        if (ra < d1) c.seg_bits[(g0 + (uint64_t)ra * d0) >> 8] = (uint16_t)(tot & 0xFFFFu);
+                        if (2 * k + 1 < TY && rb < d1) c.seg_bits[(g0 + (uint64_t)rb * d0) >> 8] = (uint16_t)(tot >> 16);
+                    }
+                }
+            }
+        }
+    };
+    if (SAMP) {
+        // (the look for the book and the catching-up sit BEHIND a plane's work: the plane's row registers are free then)
+        for (; zz < zend; zz++) {
+            fetch(zz, pa);
+            work(zz, pa);
+            if (!c.have_len && zz >= 0 && samp_poll(c, false, put_len)) catch_up(zz + 1);
+        }
+        if (!c.have_len) {  // (the book took longer than this task: wait for it)
+            samp_poll(c, true, put_len);
+            catch_up(zend);
+        }
+        return;
+    }
 #if defined(LAB_Q16PF) && LAB_Q16PF == 1
     // (lab: the next plane's rows are requested before the current plane is worked — two sets of row registers)
     Q16Plane<TY> pb;
@@ -1750,7 +1864,7 @@ __device__ __forceinline__ void narrow16_task(NarrowCtx<float> &c, const Lattice
     }
 #endif
 }
-template <int TY>
+template <int TY, bool SAMP>
 __device__ __forceinline__ void march_narrow16(const float *__restrict__ in, uint16_t *__restrict__ codes, const szk_k1_params &p, uint32_t ntasks,
                                                uint32_t *lh, uint64_t (*s_oq_idx)[MarchLds<1, false>::OQ], uint32_t (*s_oq_val)[MarchLds<1, false>::OQ]) {
     const Lattice<float> lat(p.lat);
@@ -1769,7 +1883,7 @@ __device__ __forceinline__ void march_narrow16(const float *__restrict__ in, uin
     c.oq_idx = s_oq_idx[wv];
     c.oq_val = s_oq_val[wv];
     c.oq_n = 0;
-    const bool acct = p.spec_lens != nullptr && c.d0 % MARCH_TX == 0;
+    const bool acct = SAMP || (p.spec_lens != nullptr && c.d0 % MARCH_TX == 0);  // (the sampled form is launched for rows of whole segments only)
     c.s_len = acct ? reinterpret_cast<const uint8_t *>(lh) + Q16_LEN_OFF : nullptr;
     c.seg_bits = p.seg_bits;
     c.s_enc = nullptr;
@@ -1777,29 +1891,35 @@ __device__ __forceinline__ void march_narrow16(const float *__restrict__ in, uin
     c.slot = nullptr;
     c.slot_w = c.slot_base = c.st_cnt = 0;
     c.seg_base = p.seg_base;
+    c.samp_words = p.samp.words;
+    c.have_len = 0;
+    // (sampled form: the launch's first SZK_SAMP_ROLES workgroups take the sample; the workers are numbered behind them)
+    const uint32_t bid = SAMP ? blockIdx.x - SZK_SAMP_ROLES : blockIdx.x, grid = SAMP ? gridDim.x - SZK_SAMP_ROLES : gridDim.x;
     for (int i = threadIdx.x; i < NARROW_BINS * 4; i += 256) lh[i] = 0;
+    if (threadIdx.x == 0) lh[NARROW_BINS * 8] = 0;  // (sampled form: the workgroup's "the length table is filled" word)
     {
         const uint32_t b = threadIdx.x;  // 256 threads, 256 byte values; 255 = the delta outliers' symbol 0
-        const uint32_t len = acct ? p.spec_lens[b == 255u ? 0u : b + p.radius - 127u] : 0u;
+        const uint32_t len = (acct && !SAMP) ? p.spec_lens[b == 255u ? 0u : b + p.radius - 127u] : 0u;
 #pragma unroll
         for (int k = 0; k < 4; k++) lh[NARROW_BINS * 4 + b * 4 + k] = len;
-        if (acct && blockIdx.x == 0 && threadIdx.x == 0) *p.seg_made = 1u;
+        if (acct && bid == 0 && threadIdx.x == 0) *p.seg_made = 1u;
     }
     __syncthreads();
     const uint32_t ntx = (c.d0 + MARCH_TX - 1) / MARCH_TX, nty = (c.d1 + TY - 1) / TY;
-    const uint32_t per_xcd = gridDim.x / 8u;
-    const uint32_t wg_seq = gridDim.x % 8u == 0 && !(p.dbg & 4096u) ? (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : blockIdx.x;
-    const uint32_t nwaves = gridDim.x * 4u;
+    const uint32_t per_xcd = grid / 8u;
+    const uint32_t wg_seq = grid % 8u == 0 && !(p.dbg & 4096u) ? (bid % 8u) * per_xcd + bid / 8u : bid;
+    const uint32_t nwaves = grid * 4u;
     for (uint32_t task = wg_seq * 4 + wv; task < ntasks; task += nwaves) {
         uint32_t b = task;
         const uint32_t x0 = (b % ntx) * MARCH_TX;
         b /= ntx;
         const uint32_t y0 = (b % nty) * TY;
         const uint32_t z0 = (b / nty) * MARCH_TZ;
-        if (x0 + MARCH_TX <= c.d0 && y0 + TY <= c.d1) narrow16_task<TY, false>(c, lat, p.q16_flag, x0, y0, z0);
-        else narrow16_task<TY, true>(c, lat, p.q16_flag, x0, y0, z0);
+        if (x0 + MARCH_TX <= c.d0 && y0 + TY <= c.d1) narrow16_task<TY, false, SAMP>(c, lat, p.q16_flag, x0, y0, z0);
+        else narrow16_task<TY, true, SAMP>(c, lat, p.q16_flag, x0, y0, z0);
     }
     narrow_oq_flush(c);
+    if (SAMP) return;  // (no histogram rows)
     __syncthreads();
     uint32_t *row = p.hist_partial + (uint64_t)blockIdx.x * HIST_WIN;
     for (int bnn = threadIdx.x; bnn < HIST_WIN; bnn += 256) {
@@ -1858,7 +1978,7 @@ __global__ __launch_bounds__(256) MARCH3_ATTR void k_lorenzo_quant_march3(const 
 // The 16-bit form of the one-launch kernel (round 5, narrow16_task): f32 data whose lattice values the previous call's probe found
 // within +-Q16_LIM / 2. It assumes one-byte codes like the form above AND lattice values within +-Q16_LIM; a value beyond that
 // (or not finite) raises q16_flag, the packer's launch reports it (miss_kind bit 128) and the host repeats the call above.
-template <int TY>
+template <int TY, bool SAMP>
 __global__ __launch_bounds__(256) void k_lorenzo_quant_march3q(const float *__restrict__ in, uint16_t *__restrict__ codes,
                                                                szk_k1_params p, uint32_t ntasks, uint32_t nrows) {
     using L = MarchLds<1, false>;
@@ -1866,8 +1986,21 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march3q(const float *__re
     __shared__ uint64_t s_oq_idx[4][L::OQ];
     __shared__ uint32_t s_oq_val[4][L::OQ];
     __shared__ uint32_t s_p[4];
+    if constexpr (SAMP) {
+        // the sampled book: the launch's first workgroups take the sample (before anything else: every microsecond the book comes later is a
+        // plane the workers code without it), the last of them to finish builds the book (the histogram's memory holds the sample's counts,
+        // then the book's scratch); their share of the probe comes afterwards
+        static_assert(sizeof(lh) >= SAMP_POOL_BYTES && sizeof(lh) >= 4096, "the book's scratch fits the histogram");
+        if (blockIdx.x < SZK_SAMP_ROLES) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) p.samp.info->ts[9] = wall_clock64();  // (tools: when the sampling began)
+            if (samp_take<float>(in, p.lat, (uint32_t)p.d[3], (uint32_t)p.d[2], (uint32_t)p.d[1], p.samp.words, blockIdx.x, lh)) samp_book(p.samp, p.radius, reinterpret_cast<uint8_t *>(lh));
+            __syncthreads();
+            probe_body<float, 3>(in, p, p.mode.n_total, p.mode.probe_big, s_p);
+            return;
+        }
+    }
     probe_body<float, 3>(in, p, p.mode.n_total, p.mode.probe_big, s_p);
-    march_narrow16<TY>(in, codes, p, ntasks, lh, s_oq_idx, s_oq_val);
+    march_narrow16<TY, SAMP>(in, codes, p, ntasks, lh, s_oq_idx, s_oq_val);
 }
 // The FUSED form of the one-launch kernel (round 4): a context whose previous call left a small code book codes with THAT book
 // inside stage 1 — the rows' bit strings leave the kernel instead of one byte per element (4 + 0.5 B/elem instead of 4 + 1, and
@@ -2778,6 +2911,7 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
         p.info->sym_min = lo;
         p.info->sym_count = range;
         p.info->win_lo = wl;
+        p.info->esc_sym = 0;
         p.info->reserved = defer ? CB_ASSIGN_PENDING : 0u;
     }
 }
@@ -2807,7 +2941,9 @@ __device__ __forceinline__ bool cb_margins(uint32_t &lo, uint32_t &range, uint32
 template <uint32_t CAP>
 __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params &p, uint8_t *s_pool, uint32_t lo, uint32_t range,
                          uint32_t *s_wtot, uint32_t &s_over, uint32_t *s_first, uint32_t *s_cnt, uint32_t *s_misc, unsigned long long &s_total,
-                         bool fill = false /* cb_margins widened [lo, lo + range): its empty bins count once */) {
+                         bool fill = false /* cb_margins widened [lo, lo + range): its empty bins count once */,
+                         const uint32_t *wsrc = nullptr /* the symbols' weights instead of hist: wsrc[i] for symbol lo + i (round 6, the sampled book) */,
+                         uint32_t force_L = 0 /* != 0: the length limit (else 16 bits up to CB_SHORT_SYMS symbols, SZH_MAX_LEN beyond) */) {
     const uint32_t t = threadIdx.x;
     // ---------------- small alphabets: LDS-resident, 256 threads ----------------
     uint64_t *keys = reinterpret_cast<uint64_t *>(s_pool);                          // [CAP]
@@ -2821,7 +2957,7 @@ __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params 
     uint32_t cnt = 0;
     uint64_t fsum = 0;
     for (uint32_t i = t * per; i < range && i < (t + 1) * per; i++) {
-        uint64_t f = hist[lo + i];
+        uint64_t f = wsrc ? (uint64_t)wsrc[i] : hist[lo + i];
         if (fill && f == 0) f = 1;
         cnt += f != 0;
         fsum += f;
@@ -2837,7 +2973,7 @@ __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params 
         m += s_wtot[wv];
     }
     for (uint32_t i = t * per; i < range && i < (t + 1) * per; i++) {
-        uint64_t f = hist[lo + i];
+        uint64_t f = wsrc ? (uint64_t)wsrc[i] : hist[lo + i];
         if (fill && f == 0) f = 1;
         if (f) {
             keys[pos] = (f << 16) | (lo + i);  // freq < 2^48
@@ -2873,7 +3009,7 @@ __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params 
     }
 
     if (t == 0) p.info->ts[3] = wall_clock64();
-    const uint32_t L = m <= CB_SHORT_SYMS ? 16u : SZH_MAX_LEN;
+    const uint32_t L = force_L ? force_L : (m <= CB_SHORT_SYMS ? 16u : SZH_MAX_LEN);
     uint32_t max_len = 0;
     if (m == 1) {
         // single symbol: zero-length code, empty bit-stream (as encoder/HuffmanEncoder.hpp:233-237)
@@ -2980,7 +3116,219 @@ __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params 
         p.info->sym_count = range;
         p.info->win_lo = wl;
         p.info->reserved = 0;
+        p.info->esc_sym = 0;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The sampled book (round 6; sz3hip_kernels.h, szk_samp). SZK_SAMP_ROLES workgroups of 256 threads take the sample — in the one-launch
+// forms of stage 1 they are the launch's first workgroups, behind the two-launch form a launch of their own (k_sample) —, the last
+// one to finish builds the book and raises words[SZK_SAMP_READY]; stage 1's workers poll that word between two planes.
+// A unit is a 256-element row segment; unit u lies in segment floor(u * nseg / U) + a hash of u inside that stride (nseg = segments
+// of the array, U = the number of units): a function of the extents alone. Every element of a unit gets the byte stage 1 gives it:
+// t = min(delta + 127, 255) with delta the Lorenzo stencil over the lattice values (neighbours outside the array: 0).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void samp_unit_place(uint32_t u, uint32_t n_units, uint64_t nseg, uint32_t ntx, uint32_t d1, uint32_t &x0, uint32_t &y, uint32_t &z) {
+    const uint64_t stride = nseg / n_units;  // >= 16 (arrays of at least SZK_SAMP_MIN_ELEMS elements)
+    const uint64_t seg = (uint64_t)u * nseg / n_units + (uint64_t)((u * 2654435761u) >> 8) % stride;
+    x0 = (uint32_t)(seg % ntx) * MARCH_TX;
+    const uint64_t row = seg / ntx;
+    y = (uint32_t)(row % d1);
+    z = (uint32_t)(row / d1);
+}
+// returns true in the workgroup that finished last (all threads); s_h: [1024] words of LDS
+template <typename T>
+__device__ __forceinline__ bool samp_take(const T *__restrict__ in, const szk_lattice &latp, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t *words, uint32_t role, uint32_t *s_h) {
+    using B = typename Lattice<T>::B;
+    using UQ = typename QTraits<T>::UQ;
+    constexpr B CB = Lattice<T>::C;
+    constexpr int NB = sizeof(T) == 4 ? 2 : 1;  // units in flight per wave (4 rows of 16 / 32 bytes per lane each): the one-launch forms carry this code, and a kernel's registers are its hungriest path's
+    __shared__ uint32_t s_last;
+    const Lattice<T> lat(latp);
+    const uint64_t plane = (uint64_t)d1 * d0;
+    const uint32_t ntx = d0 / MARCH_TX;
+    const uint64_t nseg = (uint64_t)ntx * d1 * d2;
+    const int lane = lane_id();
+    const uint32_t gw = role * 4u + threadIdx.x / WAVE, nw = SZK_SAMP_ROLES * 4u;
+    for (uint32_t i = threadIdx.x; i < 1024u; i += 256u) s_h[i] = 0;
+    __syncthreads();
+    for (uint32_t u0 = gw * NB; u0 < SZK_SAMP_UNITS; u0 += nw * NB) {
+        Quad<T> rq[NB][4];
+        T rl[NB][4];
+        bool rok[NB][4], has_left[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            uint32_t x0, y, z;
+            samp_unit_place(u0 + b, SZK_SAMP_UNITS, nseg, ntx, d1, x0, y, z);
+            has_left[b] = x0 > 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {  // rows (y, z), (y - 1, z), (y, z - 1), (y - 1, z - 1)
+                const bool ym = r & 1, zm = r >> 1;
+                rok[b][r] = (!ym || y > 0) && (!zm || z > 0);
+                if (rok[b][r]) {
+                    const T *row = in + (uint64_t)(z - (zm ? 1u : 0u)) * plane + (uint64_t)(y - (ym ? 1u : 0u)) * d0;
+                    rq[b][r].load(row + x0 + 4u * (uint32_t)lane);
+                    if (has_left[b]) rl[b][r] = row[x0 - 1];
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            UQ delta[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (!rok[b][r]) continue;  // (wave-uniform) a row outside the array: the constant C, whose differences vanish
+                B q[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) q[i] = lat.qbits(rq[b][r].get(i));
+                const B left0 = has_left[b] ? lat.qbits(rl[b][r]) : CB;
+                UQ pv = (UQ)dpp_wave_shr1(left0, q[3]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const UQ d1v = (UQ)q[i] - pv;
+                    pv = (UQ)q[i];
+                    delta[i] = (r == 0 || r == 3) ? (UQ)(delta[i] + d1v) : (UQ)(delta[i] - d1v);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const UQ tq = delta[i] + (UQ)127;
+                const uint32_t t = tq <= (UQ)254 ? (uint32_t)tq : 255u;
+                atomicAdd(&s_h[t * 4u + ((uint32_t)lane & 3u)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t t = threadIdx.x;
+        const uint32_t c = s_h[t * 4] + s_h[t * 4 + 1] + s_h[t * 4 + 2] + s_h[t * 4 + 3];
+        if (c) atomicAdd(&words[t], c);
+    }
+    // (no fence: a release at device scope writes back the XCD's whole L2 — megabytes of the workers' freshly stored codes — and took
+    // 25 us here. Everything the workgroups exchange inside the launch goes through device-scope atomics, which are performed at the
+    // memory side; the wait below orders this workgroup's counts before its ticket)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&words[SZK_SAMP_TICKET], 1u) == SZK_SAMP_ROLES - 1u ? 1u : 0u;
+    __syncthreads();
+    return s_last != 0;
+}
+// The book from the sample's counts (the workgroup that finished last: 256 threads); pool: CB_SMALL_SYMS * 28 + 256 bytes of LDS.
+// Two classes. The byte values the sample met are coded by a Huffman code over their counts, limited to SZK_SAMP_SEEN_LEN bits (two such
+// code words fit an entry of the packer's pair table: a chunk leaves its fast tier only for a value the sample never met). The values
+// it did not meet — each a quarter of an occurrence — enter that code as ONE pseudo-symbol; a value's code word is the pseudo-symbol's
+// followed by its index among them in ceil(log2(their number)) bits. The format stores code lengths and assigns canonical code words
+// by (length, symbol): the decoder is unaware.
+__device__ __forceinline__ void samp_book(const szk_samp &sp, uint32_t radius, uint8_t *pool) {
+    __shared__ uint32_t s_w[256];
+    __shared__ uint8_t s_l[256];
+    __shared__ uint32_t s_wtot[CB_THREADS / WAVE];
+    __shared__ uint32_t s_over, s_nun, s_rep;
+    __shared__ uint32_t s_first[SZH_MAX_LEN + 2], s_cnt[SZH_MAX_LEN + 2];
+    __shared__ uint32_t s_misc[8];
+    __shared__ unsigned long long s_total;
+    __shared__ szk_cb_params s_cbp;  // (in LDS, not a local: cb_small takes it by reference, and a kernel with a stack pays for it in every wave)
+    const uint32_t t = threadIdx.x;
+    const uint32_t lo = radius - 127u, esc = lo + 255u;  // byte t = symbol lo + t; byte 255 (a listed delta) = symbol radius + 128
+    const uint32_t cnt = __hip_atomic_load(&sp.words[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_w[t] = 4u * cnt;
+    if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
+    if (t == 0) {
+        memset(&s_cbp, 0, sizeof(s_cbp));
+        s_cbp.enc = sp.enc;
+        s_cbp.lens = sp.lens;
+        s_cbp.info = sp.info;
+        s_over = 0;
+        s_total = 0;
+        s_nun = 0;
+        s_rep = 256;
+        sp.info->ts[0] = wall_clock64();
+    }
+    __syncthreads();
+    if (cnt == 0) {
+        atomicAdd(&s_nun, 1u);
+        atomicMin(&s_rep, t);
+    }
+    __syncthreads();
+    const uint32_t n_un = s_nun, rep = s_rep;
+    if (t == rep) s_w[t] = n_un;  // the class of the values not met, carried by the first of them
+    sp.enc[lo + t] = 0;
+    sp.lens[lo + t] = 0;
+    __syncthreads();
+    cb_small<CB_SMALL_SYMS>(nullptr, s_cbp, pool, lo, 256u, s_wtot, s_over, s_first, s_cnt, s_misc, s_total, false, s_w, SZK_SAMP_SEEN_LEN);
+    __syncthreads();
+    // cb_small's LDS arrays: aux[a] = the length of the a-th PRESENT symbol in symbol order; a symbol's a = the present ones in front of it
+    const uint16_t *aux = reinterpret_cast<const uint16_t *>(pool + CB_SMALL_SYMS * 16) + 2 * CB_SMALL_SYMS;
+    // (positions among the present symbols, ranks among equal lengths: ballots inside the wave + the earlier waves' counts)
+    __shared__ uint32_t s_wc[4], s_lc[4][SZH_MAX_LEN + 2];
+    const uint32_t wv4 = t / WAVE, ln = t & (WAVE - 1);
+    const unsigned long long lower = (1ull << ln) - 1ull;
+    const unsigned long long pm = __ballot(s_w[t] != 0u);
+    if (ln == 0) s_wc[wv4] = (uint32_t)__popcll(pm);
+    __syncthreads();
+    uint32_t a = (uint32_t)__popcll(pm & lower);
+    for (uint32_t w = 0; w < wv4; w++) a += s_wc[w];
+    uint32_t ubits = 0;
+    while ((1u << ubits) < n_un) ubits++;
+    uint32_t len;
+    if (n_un == 0 || cnt != 0) len = aux[a];        // met by the sample
+    else len = (uint32_t)aux[rep] + ubits;          // not met: the class's code word + the index (the first value not met has as many present symbols in front of it as its own number: all before it are present)
+    // (a constant field's sample meets one value: it and the class take one bit each — every byte value has a code word here, where the
+    // exact histogram's book of such a field has one zero-length code word and an empty bit stream)
+    s_l[t] = (uint8_t)len;
+    if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
+    __syncthreads();
+    atomicAdd(&s_cnt[len], 1u);
+    __syncthreads();
+    if (t == 0) {
+        uint32_t code = 0, maxl = 0;
+        for (uint32_t l = 1; l <= SZH_MAX_LEN; l++) {
+            code = (code + (l > 1 ? s_cnt[l - 1] : 0)) << (l > 1 ? 1 : 0);
+            s_first[l] = code;
+            if (s_cnt[l]) maxl = l;
+        }
+        sp.info->n_symbols = 256;
+        sp.info->max_len = maxl;
+        sp.info->sym_min = lo;
+        sp.info->sym_count = 256;
+        sp.info->win_lo = lo;
+        sp.info->reserved = 0;
+        sp.info->esc_sym = esc;
+    }
+    __syncthreads();
+    uint32_t rank = 0;
+    for (uint32_t l = 1; l <= SZH_MAX_LEN; l++) {  // (wave-uniform loop: a ballot per length)
+        const unsigned long long m = __ballot(len == l);
+        if (ln == 0) s_lc[wv4][l] = (uint32_t)__popcll(m);
+        if (len == l) rank = (uint32_t)__popcll(m & lower);
+    }
+    __syncthreads();
+    for (uint32_t w = 0; w < wv4; w++) rank += s_lc[w][len];
+    const uint32_t e = ((s_first[len] + rank) << 5) | len;
+    sp.enc[lo + t] = e;
+    sp.lens[lo + t] = (uint8_t)len;
+    if (t == 255) sp.enc[0] = e;  // the encoder's tables know a listed delta as symbol 0 (byte 255 -> symbol 0 wherever codes are looked up): an alias of the escape's entry
+    if (t < 64) {
+        const uint32_t w = (uint32_t)s_l[4 * t] | ((uint32_t)s_l[4 * t + 1] << 8) | ((uint32_t)s_l[4 * t + 2] << 16) | ((uint32_t)s_l[4 * t + 3] << 24);
+        __hip_atomic_store(&sp.words[SZK_SAMP_LENS + t], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (the book's tables in the slot are the next launches' to read — a launch boundary away; the lengths the workers of THIS launch want
+    // went out as device-scope stores above, and the wait orders them before the word that announces them)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        __hip_atomic_store(&sp.words[SZK_SAMP_READY], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sp.info->ts[10] = wall_clock64();
+    }
+}
+
+// the sample and its book as a launch of their own: behind the two-launch form of stage 1 (a context's first call) and behind the forms
+// that do not carry the sampling workgroups themselves. The probe is complete by then: a two-byte stream has no sampled book.
+template <typename T>
+__global__ __launch_bounds__(256) void k_sample(const T *__restrict__ in, szk_k1_params p) {
+    __shared__ __align__(16) uint32_t s_pool[(SAMP_POOL_BYTES + 3) / 4 > 1024 ? (SAMP_POOL_BYTES + 3) / 4 : 1024];
+    if (!szk_is_narrow(p.mode)) return;
+    if (samp_take<T>(in, p.lat, (uint32_t)p.d[3], (uint32_t)p.d[2], (uint32_t)p.d[1], p.samp.words, blockIdx.x, s_pool)) samp_book(p.samp, p.radius, reinterpret_cast<uint8_t *>(s_pool));
 }
 
 // The wide code book's compaction over the whole chip (round 5): workgroup w owns bins [1024 w, 1024 (w + 1)); its keys' place is the
@@ -3113,6 +3461,11 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
                           d ? p.q_is_32bit != 0 : p.t_is_32bit != 0, s_pool, scratch);
         return;
     }
+    if (p.samp_words && p.n_books <= 1 && __hip_atomic_load(const_cast<uint32_t *>(p.samp_words) + SZK_SAMP_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        // this call's book was built from the sample (samp_book): it is in the slot already — the launch only sorts the lists
+        if (PART == 1 && t == 0) p.info->reserved = 0;  // (nothing for k_cb_assign behind this launch)
+        return;
+    }
     {  // book b of a batch (the tuner's trials) uses the b-th slice of every table
         const size_t b = blockIdx.x;
         hist += b * SZH_HIST_BINS;
@@ -3210,6 +3563,7 @@ __device__ void layout_pre(const szk_layout_params &p) {  // after K1 + K5, befo
     h.sym_min = p.info->sym_min;
     h.sym_count = p.info->sym_count;
     h.max_len = p.info->max_len;
+    if (h.predictor == 0) h.anchor_stride = p.info->esc_sym;  // (Lorenzo streams: the symbol that stands for a listed delta, 0 = symbol 0 itself; sz3hip_format.h)
     h.side_bytes = p.side_bytes ? *p.side_bytes : 0;
     h.bitstream_words = 0;
     szh_offsets o;
@@ -3677,7 +4031,11 @@ __device__ void assemble_body(const szk_asm_params &p, uint64_t tid, uint64_t nt
         // stage 1 assumed one-byte codes (one-launch form) and this call's probe says two: everything since is void
         if (p.assumed_narrow && !szk_is_narrow(p.mode)) atomicOr(&p.state->miss_kind, 32u);
         if (p.q16_flag && *p.q16_flag) atomicOr(&p.state->miss_kind, 128u);  // the 16-bit stage 1 met a value it does not take: the call is repeated
-        if (!p.lists_by_roles) {  // (role mode: the book role of the same launch writes these; miss_kind was zeroed by layout_pre)
+        if (p.samp_words && p.samp_words[SZK_SAMP_READY]) {  // the call codes with its sampled book: nothing to verify, no form to mispredict
+            p.state->mispredict = 0;
+            p.state->book_miss = 0;
+            p.state->n_symbols = 256;
+        } else if (!p.lists_by_roles) {  // (role mode: the book role of the same launch writes these; miss_kind was zeroed by layout_pre)
             p.state->mispredict = (uint32_t)p.n_vout[7];                                  // (d_counters[7]: raised by a code-book form launched alone)
             p.state->book_miss = 0;
             p.state->n_symbols = reinterpret_cast<const uint32_t *>(p.n_vout + 8)[2];   // (the range words: number of non-empty bins)
@@ -3920,6 +4278,9 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     __shared__ uint32_t s_enc8[256];  // one-byte codes: code word by byte value ...
     __shared__ uint8_t s_plen8[256];  // ... and its length
     __shared__ __align__(8) uint32_t s_stage[4][STAGE_WORDS];
+    // (a call that turns out to code with its sampled book — known on the device only behind the two-launch form of stage 1 — is packed by
+    // k_pack_b, launched beside this kernel: its code words may be longer than the one-byte path here takes)
+    if (ap.samp_words && ap.samp_words[SZK_SAMP_READY] && szk_is_narrow(mode)) return;
     const uint32_t roles = rp.on ? ROLE_BLOCKS : 0u;
     if (blockIdx.x < roles) {  // (the first workgroups dispatched; s_enc's 16 KB serve as their scratch)
         static_assert(WIN * 4 >= ROLE_SORT_MAX * 8 && WIN * 4 >= CB_SMALL_SYMS * 28 + 256, "role scratch fits the table");
@@ -3964,7 +4325,8 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
     }
     uint32_t sym_min = info->win_lo;  // start of the LDS window
     const uint32_t sym_count = info->sym_count;
-    const bool all_lds = WIN == ENC_WIN && sym_count <= ENC_WIN;
+    // (a sampled book's escape symbol: its range is 256 symbols, but a listed delta still travels through the encoder's tables as symbol 0)
+    const bool all_lds = WIN == ENC_WIN && sym_count <= ENC_WIN && info->esc_sym == 0;
     const bool wide = info->max_len > 16;  // two instead of four code words per 64-bit register
     if (WIN == ENC_WIN) {
         enc_table_load(s_enc, g_enc, sym_min, sym_count);
@@ -3989,7 +4351,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
         }
         uint16_t c[ENC_PER_LANE];
         uint32_t nwords;
-        if (narrow) {  // alphabets of one-byte codes have at most 256 symbols: code words <= 16 bits
+        if (narrow) {  // alphabets of one-byte codes have at most 256 symbols: code words <= 16 bits (a sampled book's may be longer: such a call is k_pack_b's)
             const uint32_t wds[4] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w};
 #pragma unroll
             for (int i = 0; i < 16; i++) c[i] = (uint16_t)((wds[i >> 2] >> (8 * (i & 3))) & 0xFFu);
@@ -4046,7 +4408,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
 // into pairs, quads and octets, the emission): it is bound by their issue, not by the 1.5 bytes per symbol it moves. Here a lane
 // looks up PAIRS of codes: a 128 x 128 table over the byte values t in [64, 192) (deltas -63 .. +64 around the mode of a one-byte
 // stream, byte 127; 64 KB of LDS: entry = (code words of t0 and t1 joined) << 5 | their length, 0 when one of them has no code word
-// or the two take more than 26 bits) — one lookup and one shift per TWO symbols. A workgroup is 1024 threads (16 waves share the
+// or the two take more than 27 bits) — one lookup and one shift per TWO symbols. A workgroup is 1024 threads (16 waves share the
 // table: 64 KB + 16 stages of 3 KB, one workgroup per CU); three code registers per lane are in flight (the chunk being packed and
 // the next two: 16 waves x 3 KB per CU cover the HBM latency at the 3 TB/s the launch reads with).
 //   fast tier (wave-uniform test): every byte of the chunk inside the window, every pair in the table, every lane's two octets <= 64 bits:
@@ -4056,7 +4418,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint16_t *__restrict__ codes
 //     lane's fit 64 bits (wave-uniform), emitted as octets, quads or pairs.
 // Same bit stream as k_pack (same book, same chunk table): tests/test_gpu_stages.py compares the two byte for byte.
 // Role workgroups (the two list sorts; the book role is k_pack's: this kernel is launched where no book is built beside the packer)
-// and the assembly's come FIRST in the grid: they are short, and the packer's workgroups (one per CU) start behind them.
+// come first in the grid, the assembly's last (see the kernel).
 // ------------------------------------------------------------------------------------------------------------
 #define PB_THREADS 1024u
 #define PB_WAVES (PB_THREADS / WAVE)
@@ -4160,53 +4522,69 @@ __device__ __forceinline__ uint32_t packb_chunk(const uint4 &cw, const uint32_t 
 __global__ __launch_bounds__(PB_THREADS) void k_pack_b(const uint16_t *__restrict__ codes, uint64_t n, const uint32_t *__restrict__ g_enc,
                                                         const uint16_t *__restrict__ chunk_words, const uint64_t *__restrict__ group_off, szk_mode mode,
                                                         uint32_t sym_add, const szk_state *__restrict__ state, uint8_t *__restrict__ payload,
-                                                        szk_asm_params ap, uint32_t pack_blocks, uint32_t split, szk_role_params rp) {
+                                                        szk_asm_params ap, uint32_t pack_blocks, uint32_t split, szk_role_params rp, uint32_t only_sampled) {
     constexpr int STAGE_WORDS = SZH_CHUNK_SYMS * SZH_MAX_LEN / 32 + 4;  // + slack for the unconditional 3-word emit
     __shared__ __align__(16) uint32_t s_pair[128 * 128];
     __shared__ uint32_t s_enc8[256];  // code word by byte value ...
     __shared__ uint8_t s_plen8[256];  // ... and its length
     __shared__ __align__(8) uint64_t s_stage[PB_WAVES][STAGE_WORDS / 2];
+    // (launched beside k_pack behind the two-launch form of stage 1 — only_sampled: this kernel then packs, sorts and assembles only
+    // when the call codes with its sampled book, k_pack otherwise)
+    if (only_sampled && !(ap.samp_words && ap.samp_words[SZK_SAMP_READY] && szk_is_narrow(mode))) return;
     const uint32_t roles = rp.on ? ROLE_BLOCKS : 0u;
     if (blockIdx.x < roles) {  // (the pair table's memory serves as their scratch; they are 256-thread bodies: the other waves leave)
         if (threadIdx.x >= 256u) return;
         if (blockIdx.x != 0) role_sort(rp, ap, blockIdx.x == 2, reinterpret_cast<uint8_t *>(s_pair));
         return;
     }
+    // Order in the grid: the role workgroups, the packers, the assembly's. A workgroup holds a compute unit's LDS: roles + packers = the
+    // number of compute units, all of them start at once, and the assembly's short workgroups follow on whichever unit is free first (a
+    // sort role's, after ~20 us). With the packers one per unit AND the roles in front, a packer starts when a role ends — and its
+    // static share of the chunks ends that much later than everybody else's (measured: 93 instead of 62 us).
     const uint32_t asm_blocks = gridDim.x - roles - pack_blocks;
-    if (blockIdx.x < roles + asm_blocks) {
-        const uint32_t ab = blockIdx.x - roles;
+    if (blockIdx.x >= roles + pack_blocks) {
+        const uint32_t ab = blockIdx.x - roles - pack_blocks;
         assemble_body(ap, (uint64_t)ab * PB_THREADS + threadIdx.x, (uint64_t)asm_blocks * PB_THREADS);
         if (!ap.lists_by_roles) assemble_lists(ap, (uint64_t)ab * PB_THREADS + threadIdx.x, (uint64_t)asm_blocks * PB_THREADS);
         return;
     }
-    const uint32_t bid = blockIdx.x - roles - asm_blocks;
+    const uint32_t bid = blockIdx.x - roles;
     if (!szk_is_narrow(mode)) return;  // stage 1 assumed one-byte codes, the probe says two: nothing to pack (the assembly reports it, the call is repeated)
     const uint64_t n_full = n / SZH_CHUNK_SYMS, n_chunks = (n + SZH_CHUNK_SYMS - 1) / SZH_CHUNK_SYMS;
-    const uint64_t n_groups = (n_chunks + PACK_GROUP - 1) / PACK_GROUP;
+    (void)split;
     const uint32_t wv = threadIdx.x / WAVE;
     const uint64_t wave_gid = (uint64_t)bid * PB_WAVES + wv, nwaves = (uint64_t)pack_blocks * PB_WAVES;
     const int lane = lane_id();
     const uint8_t *c8 = reinterpret_cast<const uint8_t *>(codes) + (uint64_t)lane * ENC_PER_LANE;
     uint64_t *stage = s_stage[wv];
     uint32_t *out_base = reinterpret_cast<uint32_t *>(payload + state->off.bitstream);
-    // A wave's work item: `span` consecutive chunks of one offset group (split = 1, 2, 4, 8 items per group of 32 chunks, chosen by the
-    // launcher so that every wave has an item) — their bit strings are one contiguous run of the stream, the run's place = the group's
-    // offset + the words of the group's chunks in front of it (one load of the group's 32 counts). The chunks are worked in batches of
-    // PB_BATCH: the loads of a batch are issued together, a batch ahead — on gfx9 a wave's loads and stores share one counter (vmcnt)
-    // and complete out of order with respect to each other, so waiting for a load means waiting for every store issued before: once
-    // per batch here, once per chunk in k_pack's loop (whose wave then idles through the store acknowledgement of its previous chunk).
+    // A wave's work unit: PB_BATCH consecutive chunks (a unit never straddles an offset group: PACK_GROUP is a multiple of it) — their bit
+    // strings are one contiguous run of the stream, the run's place = the group's offset + the words of the group's chunks in front of it
+    // (one load of the group's counts). Units are dealt round-robin over the launch's waves, so that at any time the chip reads one
+    // window of consecutive units (16 MB of codes) and writes one window of the stream: a wave that owned a whole group — 4096 separate
+    // streams of 32 KB over the chip — was a third slower whenever the codes came from HBM rather than from the memory-side cache.
+    // The loads of a unit are issued together, a unit ahead — on gfx9 a wave's loads and stores share one counter (vmcnt) and complete
+    // out of order with respect to each other, so waiting for a load means waiting for every store issued before: once per unit here,
+    // once per chunk in k_pack's loop (whose wave then idles through the store acknowledgement of its previous chunk).
     constexpr uint32_t PB_BATCH = 4;
-    const uint32_t span = PACK_GROUP / split;
-    const uint64_t n_items = n_groups * split;
+    const uint64_t n_units = (n_full + PB_BATCH - 1) / PB_BATCH;
     auto fetch = [&](uint64_t ch) { return ch < n_full ? *reinterpret_cast<const uint4 *>(c8 + ch * SZH_CHUNK_SYMS) : make_uint4(0u, 0u, 0u, 0u); };
-    uint64_t item = wave_gid;
+    auto front_of = [&](uint64_t unit) -> uint32_t {  // (one lane-parallel load: the counts of the group's chunks in front of the unit)
+        const uint64_t c_lo = unit * PB_BATCH, grp = c_lo / PACK_GROUP;
+        const uint32_t first = (uint32_t)(c_lo % PACK_GROUP);
+        return ((uint32_t)lane < first && grp * PACK_GROUP + lane < n_chunks) ? chunk_words[grp * PACK_GROUP + lane] : 0u;
+    };
+    uint64_t unit = wave_gid;
     uint4 cur[PB_BATCH], nxt[PB_BATCH];
+    uint32_t fr_cur = 0, fr_nxt = 0;
+    uint64_t go_cur = 0, go_nxt = 0;
 #pragma unroll
     for (uint32_t j = 0; j < PB_BATCH; j++) cur[j] = make_uint4(0u, 0u, 0u, 0u);
-    if (item < n_items) {
-        const uint64_t c_lo = (item / split) * PACK_GROUP + (item % split) * span;
+    if (unit < n_units) {
 #pragma unroll
-        for (uint32_t j = 0; j < PB_BATCH; j++) cur[j] = fetch(c_lo + j);
+        for (uint32_t j = 0; j < PB_BATCH; j++) cur[j] = fetch(unit * PB_BATCH + j);
+        fr_cur = front_of(unit);
+        go_cur = group_off[unit * PB_BATCH / PACK_GROUP];
     }
     // the tables: single symbols by byte value, then the pairs of the window from them
     if (threadIdx.x < 256u) {
@@ -4221,42 +4599,39 @@ __global__ __launch_bounds__(PB_THREADS) void k_pack_b(const uint16_t *__restric
         const uint32_t t0 = i0 < 64u ? i0 + 128u : i0, t1 = i1 < 64u ? i1 + 128u : i1;  // byte values in [64, 192)
         const uint32_t l0 = s_plen8[t0], l1 = s_plen8[t1];
         const uint32_t len = l0 + l1;
-        s_pair[i] = (l0 && l1 && len <= 26u) ? ((((s_enc8[t0] << l1) | s_enc8[t1]) << 5) | len) : 0u;
+        s_pair[i] = (l0 && l1 && len <= 27u) ? ((((s_enc8[t0] << l1) | s_enc8[t1]) << 5) | len) : 0u;
     }
     __syncthreads();
-    for (; item < n_items; item += nwaves) {
-        const uint64_t grp = item / split;
-        const uint32_t first = (uint32_t)(item % split) * span;  // the item's first chunk inside its group
-        const uint64_t c_lo = grp * PACK_GROUP + first;
-        const uint64_t c_hi = c_lo + span < n_full ? c_lo + span : n_full;  // (whole chunks only: the ragged last one is packed apart)
-        uint32_t front = ((uint32_t)lane < first && grp * PACK_GROUP + lane < n_chunks) ? chunk_words[grp * PACK_GROUP + lane] : 0u;
-        front = wave_sum(front);
-        uint32_t *out = out_base + group_off[grp] + front;
-        const uint64_t nitem = item + nwaves;
-        const uint64_t n_lo = nitem < n_items ? (nitem / split) * PACK_GROUP + (nitem % split) * span : n_full;
-        for (uint64_t cb = c_lo; cb < c_hi; cb += PB_BATCH) {
-            const uint64_t nb = cb + PB_BATCH < c_hi ? cb + PB_BATCH : n_lo;  // the batch after this one: of this item, or the next item's first
+    for (; unit < n_units; unit += nwaves) {
+        const uint64_t nu = unit + nwaves;
+        if (nu < n_units) {
 #pragma unroll
-            for (uint32_t j = 0; j < PB_BATCH; j++) nxt[j] = fetch(nb + j);  // (beyond the next item's end: loaded, never used; beyond the array: not loaded)
-#pragma unroll
-            for (uint32_t j = 0; j < PB_BATCH; j++) {
-                if (cb + j < c_hi) {  // (wave-uniform)
-                    const uint32_t nwords = packb_chunk(cur[j], s_pair, s_enc8, s_plen8, stage);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    for (uint32_t i = 2 * lane; i < nwords + 2; i += 2 * WAVE) {  // copy out and re-zero the stage for the next chunk, two words per lane
-                        const uint64_t v = stage[i >> 1];
-                        stage[i >> 1] = 0;
-                        if (i < nwords) out[i] = __builtin_bswap32((uint32_t)(v >> 32));  // bytes in stream order (see sz3hip_format.h)
-                        if (i + 1 < nwords) out[i + 1] = __builtin_bswap32((uint32_t)v);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    out += nwords;
-                }
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < PB_BATCH; j++) cur[j] = nxt[j];
+            for (uint32_t j = 0; j < PB_BATCH; j++) nxt[j] = fetch(nu * PB_BATCH + j);
+            fr_nxt = front_of(nu);
+            go_nxt = group_off[nu * PB_BATCH / PACK_GROUP];
         }
+        uint32_t *out = out_base + go_cur + wave_sum(fr_cur);
+        const uint64_t c_lo = unit * PB_BATCH;
+#pragma unroll
+        for (uint32_t j = 0; j < PB_BATCH; j++) {
+            if (c_lo + j < n_full) {  // (wave-uniform: whole chunks only — the ragged last one is packed apart)
+                const uint32_t nwords = packb_chunk(cur[j], s_pair, s_enc8, s_plen8, stage);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t i = 2 * lane; i < nwords + 2; i += 2 * WAVE) {  // copy out and re-zero the stage for the next chunk, two words per lane
+                    const uint64_t v = stage[i >> 1];
+                    stage[i >> 1] = 0;
+                    if (i < nwords) out[i] = __builtin_bswap32((uint32_t)(v >> 32));  // bytes in stream order (see sz3hip_format.h)
+                    if (i + 1 < nwords) out[i + 1] = __builtin_bswap32((uint32_t)v);
+                }
+                __builtin_amdgcn_wave_barrier();
+                out += nwords;
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < PB_BATCH; j++) cur[j] = nxt[j];
+        fr_cur = fr_nxt;
+        go_cur = go_nxt;
     }
     if (n_full < n_chunks && wave_gid == 0) {  // ragged tail: the missing symbols have no bits — packed symbol by symbol
         const uint64_t base = n_full * SZH_CHUNK_SYMS + (uint64_t)lane * ENC_PER_LANE;
@@ -4413,7 +4788,7 @@ __global__ __launch_bounds__(256) void k_merge(szk_merge_params mp, uint64_t n, 
 // (len, sym), and a direct lookup table over the next DEC_LUT_BITS bits of the stream: (symbol << 8) | length for every
 // code word of at most DEC_LUT_BITS bits (0 = longer code: length search). One workgroup; <= 65536 symbols.
 __global__ __launch_bounds__(1024) void k_dec_tables(const uint8_t *__restrict__ lens, uint32_t sym_min,
-                                                     uint32_t sym_count, szk_dec_tables *t, uint32_t radius, uint32_t *zero_word,
+                                                     uint32_t sym_count, szk_dec_tables *t, uint32_t radius, uint32_t esc_sym, uint32_t *zero_word,
                                                      const uint16_t *__restrict__ chunk_words, uint64_t n_chunks, uint64_t *group_off,
                                                      uint64_t *total_words) {
     if (blockIdx.x == 1) {  // the decoder's other preparation, beside the tables: word offsets of the chunk groups
@@ -4465,7 +4840,8 @@ __global__ __launch_bounds__(1024) void k_dec_tables(const uint8_t *__restrict__
     __syncthreads();
     for (uint32_t i = q0; i < q1; i++) {
         const uint32_t l = lens[i];
-        if (l && l <= SZH_MAX_LEN) t->sorted_syms[s_first_rank[l] + s_tbl[l * 1024 + tid]++] = (uint16_t)(sym_min + i);
+        // (the canonical order is the stored symbols'; a stream's escape symbol — the stand-in for a listed delta — decodes as symbol 0)
+        if (l && l <= SZH_MAX_LEN) t->sorted_syms[s_first_rank[l] + s_tbl[l * 1024 + tid]++] = (uint16_t)(esc_sym && sym_min + i == esc_sym ? 0u : sym_min + i);
     }
     __threadfence();
     __syncthreads();
@@ -5628,8 +6004,18 @@ static void launch_march_w(const void *d_in, uint16_t *codes, szk_k1_params &p, 
             // the 16-bit form: the previous call's probe saw lattice values within +-Q16_LIM / 2 only (debug flag 8 keeps the form below)
             if constexpr (NDIM == 3 && sizeof(T) == 4) {
                 p.assumed_q16 = 1;
-                grid = k1_grid((const void *)k_lorenzo_quant_march3q<TY>, (nb + 3) / 4);
-                hipLaunchKernelGGL((k_lorenzo_quant_march3q<TY>), dim3(grid), dim3(256), 0, s, (const float *)d_in, codes, p, (uint32_t)nb, grid);
+                if (p.samp.words && !(szk_dbg_flags & 4194304)) {
+                    // the sampled book inside the launch: SZK_SAMP_ROLES workgroups in front of the workers take the sample and build the book,
+                    // the workers sum the segments' bits with it (and keep no histogram: nothing to fold)
+                    p.samp_in_launch = 1;
+                    p.seg_expected = 1;
+                    grid = k1_grid((const void *)k_lorenzo_quant_march3q<TY, true>, (nb + 3) / 4);
+                    hipLaunchKernelGGL((k_lorenzo_quant_march3q<TY, true>), dim3(grid + SZK_SAMP_ROLES), dim3(256), 0, s, (const float *)d_in, codes, p, (uint32_t)nb, grid);
+                    grid = 0;  // (no histogram rows)
+                } else {
+                    grid = k1_grid((const void *)k_lorenzo_quant_march3q<TY, false>, (nb + 3) / 4);
+                    hipLaunchKernelGGL((k_lorenzo_quant_march3q<TY, false>), dim3(grid), dim3(256), 0, s, (const float *)d_in, codes, p, (uint32_t)nb, grid);
+                }
             }
         } else {
             grid = k1_grid((const void *)k_lorenzo_quant_march3<T, NDIM, TY>, (nb + 3) / 4);
@@ -5654,7 +6040,17 @@ static void launch_march_w(const void *d_in, uint16_t *codes, szk_k1_params &p, 
     }
     if (p.prof_ev1) (void)hipEventRecord((hipEvent_t)p.prof_ev1, s);
     p.fold_rows = grid;
-    if (!p.defer_fold) hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist, p.range);
+    if (!p.defer_fold && grid) hipLaunchKernelGGL(k_hist_reduce, dim3(HIST_WIN / 256, 64), dim3(256), 0, s, p.hist_partial, grid, (int)p.radius - HIST_WIN / 2, p.hist, p.range);
+    // the sampled book behind the forms that do not carry the sampling workgroups: a launch of its own (the probe is complete: a stream
+    // of two-byte codes leaves the words untouched and the classic code book is built)
+    if (p.samp.words && !p.samp_in_launch) {
+        if constexpr (NDIM == 3) {
+            if (p.mode.allow && !(szk_dbg_flags & 256)) hipLaunchKernelGGL((k_sample<T>), dim3(SZK_SAMP_ROLES), dim3(256), 0, s, (const T *)d_in, p);
+            else p.samp.words = nullptr;
+        } else {
+            p.samp.words = nullptr;
+        }
+    }
 }
 // the marching kernel + histogram fold. When one-byte codes are possible both specialisations are launched (the one the
 // probe did not choose returns at once); the two-byte one with the LDS window the context asks for (szk_k1_params::wide16)
@@ -5684,6 +6080,8 @@ static int launch_k1(int ndim, const void *d_in, uint16_t *codes, szk_k1_params 
     const bool march12 = !szk_force_generic && !(szk_dbg_flags & 32) && (ndim == 1 || ndim == 2) && d0 % 4 == 0 && d0 >= 128 &&
                          d0 < (1ull << 31) && d1 < (1ull << 31) && tiles(MARCH_TX, ndim == 1 ? 1 : MTY, MARCH_TZ) < (1ull << 31);
     if (!march && !march12) p.mode.allow = 0;
+    if ((!march && !march12) || ndim > 3 || !p.mode.allow) p.samp.words = nullptr;  // (the sampled book is the one-byte marching forms')
+    p.samp_in_launch = 0;
     p.fold_rows = 0;
     p.seg_expected = 0;
     // (same condition as launch_march_w's first branch: the one-launch form runs the probe itself)
@@ -5893,7 +6291,7 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
         mp.fuse_flag = mg->fuse_flag;
         const uint32_t pb = pgrid < 2048 - extra ? pgrid : 2048 - extra;
         hipLaunchKernelGGL(k_merge, dim3(rb + pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, mp, n, chunk_words, group_off, mode, state, payload, apv, pb, rp);
-    } else if (asmp && asmp->assumed_narrow && !(rp.on && !rp.no_book) && !(szk_dbg_flags & 32768) && n_chunks >= 4096) {
+    } else if (asmp && !(rp.on && !rp.no_book) && n_chunks >= 4096 && ((asmp->assumed_narrow && !(szk_dbg_flags & 32768)) || asmp->samp_words)) {
         // one-byte codes (stage 1's one-launch form assumed them; a probe that says otherwise voids the call) and no book built beside the
         // packer: the pair-table packer, one 1024-thread workgroup per CU (sz3hip_debug_flags(32768): k_pack as before)
         static int n_cu = 0;
@@ -5903,12 +6301,19 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
             if (n_cu <= 0) n_cu = 256;
         }
-        const uint32_t pb = (uint32_t)n_cu;
-        const uint64_t n_groups = (n_chunks + PACK_GROUP - 1) / PACK_GROUP, nwv = (uint64_t)pb * PB_WAVES;
-        uint32_t split = 1;  // work items per offset group: as many as give every wave one (at most 8: an item is at least one batch of 4 chunks)
-        while (split < 8 && n_groups * split < nwv) split *= 2;
+        const uint32_t pb = (uint32_t)n_cu > rb + 1 ? (uint32_t)n_cu - rb : 1u;  // (the role workgroups take a compute unit each)
+        const uint32_t split = 1;
+        // (a call that may code with its sampled book is this kernel's whatever the debug flag says: k_pack's one-byte path takes code words
+        // up to 16 bits. Behind the two-launch form of stage 1 — a context's first call — whether it does is known on the device only:
+        // both packers are launched and the one whose case it is not returns at once)
+        const uint32_t beside = asmp->samp_words && !asmp->assumed_narrow ? 1u : 0u;
         hipLaunchKernelGGL(k_pack_b, dim3(rb + PB_ASM_BLOCKS + pb), dim3(PB_THREADS), 0, s, codes, n, d_enc, chunk_words, group_off, mode, sym_add, state,
-                           payload, apv, pb, split, rp);
+                           payload, apv, pb, split, rp, beside);
+        if (beside) {
+            const uint32_t pb2 = pgrid < 1280 - extra ? pgrid : 1280 - extra;
+            hipLaunchKernelGGL((k_pack<ENC_WIN>), dim3(rb + pb2 + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
+                               sym_add, state, payload, apv, pb2, rp);
+        }
     } else if (mode.pack_wide) {
         const uint32_t pb = pgrid < 768 - extra ? pgrid : 768 - extra;
         hipLaunchKernelGGL((k_pack<2 * ENC_WIN>), dim3(rb + pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
@@ -5951,9 +6356,9 @@ int szk_launch_assemble(const szk_asm_params *p, hipStream_t s) {
     return 0;
 }
 
-int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, uint32_t radius, uint32_t *zero_word,
+int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t, uint32_t radius, uint32_t esc_sym, uint32_t *zero_word,
                           const uint16_t *chunk_words, uint64_t n_chunks, uint64_t *group_off, uint64_t *total_words, hipStream_t s) {
-    hipLaunchKernelGGL(k_dec_tables, dim3(chunk_words ? 2 : 1), dim3(1024), 0, s, d_lens, sym_min, sym_count, t, radius, zero_word, chunk_words, n_chunks, group_off,
+    hipLaunchKernelGGL(k_dec_tables, dim3(chunk_words ? 2 : 1), dim3(1024), 0, s, d_lens, sym_min, sym_count, t, radius, esc_sym, zero_word, chunk_words, n_chunks, group_off,
                        total_words);
     SZK_CHECK_LAUNCH();
     return 0;

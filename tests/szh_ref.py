@@ -70,10 +70,12 @@ def parse(payload):
     eb, n, chunk_syms, max_len, n_chunks, sym_min, sym_count, n_vout, n_dout, words, pbytes, side_bytes = struct.unpack_from(
         "<dQIIQIIQQQQQ", b, 48)
     blk_edge, blk_mask = struct.unpack_from("<II", b, 144)  # (interp_id, interp_dir: block edge / predictor mask when predictor == 2)
+    (anchor_stride,) = struct.unpack_from("<Q", b, 152)       # predictor 0: the symbol that stands for a listed delta (0: symbol 0 itself; sampled books, round 6)
     h = dict(magic=magic, version=version, dtype=dtype, ndim=ndim, qbytes=qbytes, radius=radius, dims=dims, eb=eb, n=n,
              chunk_syms=chunk_syms, max_len=max_len, n_chunks=n_chunks, sym_min=sym_min, sym_count=sym_count,
              n_vout=n_vout, n_dout=n_dout, bitstream_words=words, payload_bytes=pbytes, predictor=predictor,
-             side_bytes=side_bytes if predictor == 2 else 0, blk_edge=blk_edge, blk_mask=blk_mask)
+             side_bytes=side_bytes if predictor == 2 else 0, blk_edge=blk_edge, blk_mask=blk_mask,
+             esc_sym=anchor_stride if predictor == 0 else 0)
     a16 = lambda x: (x + 15) & ~15
     tsz = 4 if dtype == 0 else 8
     off = 160
@@ -166,7 +168,8 @@ def huffman_decode(h, sec):
     table = {}
     for i, l in enumerate(lens):
         if l:
-            table[(int(l), int(codes[i]))] = h["sym_min"] + i
+            sym = h["sym_min"] + i
+            table[(int(l), int(codes[i]))] = 0 if (h.get("esc_sym") and sym == h["esc_sym"]) else sym  # (the escape symbol decodes as symbol 0)
     offs = np.concatenate([[0], np.cumsum(sec["chunkwords"].astype(np.int64))])
     bs = sec["bitstream"]
     for c in range(h["n_chunks"]):

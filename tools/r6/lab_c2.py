@@ -39,16 +39,22 @@ def step():
 for _ in range(4):
     ps = step()
 torch.cuda.synchronize()
-ts = []
+tt = []
 t0 = time.perf_counter()
 for _ in range(steps):
     t1 = time.perf_counter()
     ps = step()
-    ts.append(time.perf_counter() - t1)
+    tt.append(time.perf_counter() - t1)
 torch.cuda.synchronize()
 el = (time.perf_counter() - t0) / steps
 out = torch.empty_like(a[k])
 dc.decompress(pl.data_ptr(), ps, out.data_ptr(), st)
 torch.cuda.synchronize()
 err = float((out.double() - a[k].double()).abs().max())
-print("mode %s flags %d: %.4f ms/step (median %.4f)  ratio %.4f  err %.3g  spec %s q16 %s" % (mode, flags, el * 1e3, sorted(ts)[len(ts) // 2] * 1e3, n * 4 / ps, err, dc.spec_stats(), dc.q16))
+import ctypes as C
+L = sz3_amd.lib(); L.sz3hip_debug_codebook_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+o = (C.c_uint64 * 16)(); L.sz3hip_debug_codebook_info(dc._h, o)
+ts = [int(o[4 + i]) for i in range(12)]
+print("book: n_symbols %d max_len %d | us since the sampling began: book start %.1f, sorted %.1f, merged %.1f, depths %.1f, lengths %.1f, ready %.1f" % (
+    o[0], o[1], (ts[0] - ts[9]) / 100, (ts[3] - ts[9]) / 100, (ts[4] - ts[9]) / 100, (ts[5] - ts[9]) / 100, (ts[8] - ts[9]) / 100, (ts[10] - ts[9]) / 100))
+print("mode %s flags %d: %.4f ms/step (median %.4f)  ratio %.4f  err %.3g  spec %s q16 %s" % (mode, flags, el * 1e3, sorted(tt)[len(tt) // 2] * 1e3, n * 4 / ps, err, dc.spec_stats(), dc.q16))

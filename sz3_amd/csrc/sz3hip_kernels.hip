@@ -3220,72 +3220,114 @@ __device__ __forceinline__ bool samp_take(const T *__restrict__ in, const szk_la
 // followed by its index among them in ceil(log2(their number)) bits. The format stores code lengths and assigns canonical code words
 // by (length, symbol): the decoder is unaware.
 __device__ __forceinline__ void samp_book(const szk_samp &sp, uint32_t radius, uint8_t *pool) {
-    __shared__ uint32_t s_w[256];
+    constexpr uint32_t CAP = CB_SMALL_SYMS, L = SZK_SAMP_SEEN_LEN;
     __shared__ uint8_t s_l[256];
-    __shared__ uint32_t s_wtot[CB_THREADS / WAVE];
-    __shared__ uint32_t s_over, s_nun, s_rep;
+    __shared__ uint32_t s_wc[4], s_wf[4], s_lc[4][SZH_MAX_LEN + 2];
+    __shared__ uint32_t s_over;
     __shared__ uint32_t s_first[SZH_MAX_LEN + 2], s_cnt[SZH_MAX_LEN + 2];
-    __shared__ uint32_t s_misc[8];
-    __shared__ unsigned long long s_total;
-    __shared__ szk_cb_params s_cbp;  // (in LDS, not a local: cb_small takes it by reference, and a kernel with a stack pays for it in every wave)
-    const uint32_t t = threadIdx.x;
+    // (cb_small's carving of the pool: the merge and the Kraft repair are its pieces)
+    uint64_t *keys = reinterpret_cast<uint64_t *>(pool);                             // [CAP] (weight << 16) | byte value, sorted
+    uint64_t *ifreq = keys + CAP;                                                     // [CAP] (u32 view: the internal nodes' weights)
+    uint16_t *pleaf = reinterpret_cast<uint16_t *>(ifreq + CAP);                      // 6 x u16 [CAP]
+    uint16_t *pint = pleaf + CAP, *aux = pint + CAP, *aux2 = aux + 2 * CAP, *pint2 = aux2 + CAP;
+    uint64_t *kraft_ws = reinterpret_cast<uint64_t *>(pint2 + CAP);
+    const uint32_t t = threadIdx.x, wv = t / WAVE, ln = t & (WAVE - 1);
+    const unsigned long long lower = (1ull << ln) - 1ull;
     const uint32_t lo = radius - 127u, esc = lo + 255u;  // byte t = symbol lo + t; byte 255 (a listed delta) = symbol radius + 128
     const uint32_t cnt = __hip_atomic_load(&sp.words[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_w[t] = 4u * cnt;
+    // the values the sample did not meet: their number, the first of them (it carries the class in the Huffman code)
+    const unsigned long long um = __ballot(cnt == 0u);
+    if (ln == 0) {
+        s_wc[wv] = (uint32_t)__popcll(um);
+        s_wf[wv] = um ? wv * WAVE + (uint32_t)__ffsll((long long)um) - 1u : 256u;
+    }
     if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
     if (t == 0) {
-        memset(&s_cbp, 0, sizeof(s_cbp));
-        s_cbp.enc = sp.enc;
-        s_cbp.lens = sp.lens;
-        s_cbp.info = sp.info;
         s_over = 0;
-        s_total = 0;
-        s_nun = 0;
-        s_rep = 256;
         sp.info->ts[0] = wall_clock64();
     }
     __syncthreads();
-    if (cnt == 0) {
-        atomicAdd(&s_nun, 1u);
-        atomicMin(&s_rep, t);
-    }
+    const uint32_t n_un = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    const uint32_t rep = min(min(s_wf[0], s_wf[1]), min(s_wf[2], s_wf[3]));
+    const uint32_t w = cnt ? 4u * cnt : (t == rep ? n_un : 0u);  // a value not met counts a quarter of an occurrence; their class, all of them
+    const unsigned long long pm = __ballot(w != 0u);
     __syncthreads();
-    const uint32_t n_un = s_nun, rep = s_rep;
-    if (t == rep) s_w[t] = n_un;  // the class of the values not met, carried by the first of them
-    sp.enc[lo + t] = 0;
-    sp.lens[lo + t] = 0;
-    __syncthreads();
-    cb_small<CB_SMALL_SYMS>(nullptr, s_cbp, pool, lo, 256u, s_wtot, s_over, s_first, s_cnt, s_misc, s_total, false, s_w, SZK_SAMP_SEEN_LEN);
-    __syncthreads();
-    // cb_small's LDS arrays: aux[a] = the length of the a-th PRESENT symbol in symbol order; a symbol's a = the present ones in front of it
-    const uint16_t *aux = reinterpret_cast<const uint16_t *>(pool + CB_SMALL_SYMS * 16) + 2 * CB_SMALL_SYMS;
-    // (positions among the present symbols, ranks among equal lengths: ballots inside the wave + the earlier waves' counts)
-    __shared__ uint32_t s_wc[4], s_lc[4][SZH_MAX_LEN + 2];
-    const uint32_t wv4 = t / WAVE, ln = t & (WAVE - 1);
-    const unsigned long long lower = (1ull << ln) - 1ull;
-    const unsigned long long pm = __ballot(s_w[t] != 0u);
-    if (ln == 0) s_wc[wv4] = (uint32_t)__popcll(pm);
+    if (ln == 0) s_wc[wv] = (uint32_t)__popcll(pm);
     __syncthreads();
     uint32_t a = (uint32_t)__popcll(pm & lower);
-    for (uint32_t w = 0; w < wv4; w++) a += s_wc[w];
+    for (uint32_t k = 0; k < wv; k++) a += s_wc[k];
+    const uint32_t m = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];  // >= 2: a value met and the class, or all 256 values
+    const uint64_t mykey = ((uint64_t)w << 16) | t;
+    if (w) keys[a] = mykey;
+    __syncthreads();
+    uint32_t r = 0;
+    if (w)
+        for (uint32_t o = 0; o < m; o++) r += keys[o] < mykey;  // rank sort (the keys are distinct: the byte value in the low bits)
+    __syncthreads();
+    if (w) keys[r] = mykey;
+    __syncthreads();
+    if (t == 0) sp.info->ts[3] = wall_clock64();
+    if (t < WAVE) cb_merge_wave32(keys, reinterpret_cast<uint32_t *>(ifreq), pleaf, pint, m);  // (weights < 2^32: 2^20 sampled values)
+    __syncthreads();
+    if (t == 0) sp.info->ts[4] = wall_clock64();
+    // depth of every internal node (distance to the root, node m - 2) by pointer doubling, as cb_small does
+    for (uint32_t q = t; q + 1 < m; q += CB_THREADS) {
+        if (q == m - 2) pint[q] = (uint16_t)q;
+        aux[q] = q == m - 2 ? 0 : 1;
+    }
+    __syncthreads();
+    for (uint32_t span = 1; span < m && span < 2 * L; span <<= 1) {
+        for (uint32_t q = t; q + 1 < m; q += CB_THREADS) {
+            const uint16_t j = pint[q];
+            const uint32_t sum = (uint32_t)aux[q] + aux[j];
+            aux2[q] = (uint16_t)(sum > 0xFFFFu ? 0xFFFFu : sum);
+            pint2[q] = pint[j];
+        }
+        __syncthreads();
+        for (uint32_t q = t; q + 1 < m; q += CB_THREADS) {
+            aux[q] = aux2[q];
+            pint[q] = pint2[q];
+        }
+        __syncthreads();
+    }
+    if (t == 0) sp.info->ts[5] = wall_clock64();
+    for (uint32_t q = t; q < m; q += CB_THREADS) {  // leaf lengths by sorted position, clamped
+        uint32_t l = (uint32_t)aux[pleaf[q]] + 1;
+        if (l > L) {
+            l = L;
+            s_over = 1;
+        }
+        pleaf[q] = (uint16_t)l;
+        atomicAdd(&s_cnt[l], 1u);
+    }
+    __syncthreads();
+    if (s_over) cb_kraft_repair(pleaf, m, s_cnt, L, CB_THREADS, kraft_ws);
+    s_l[t] = 0;
+    __syncthreads();
+    for (uint32_t q = t; q < m; q += CB_THREADS) s_l[(uint32_t)(keys[q] & 0xFFFFu)] = (uint8_t)pleaf[q];
+    __syncthreads();
+    if (t == 0) sp.info->ts[8] = wall_clock64();
     uint32_t ubits = 0;
     while ((1u << ubits) < n_un) ubits++;
-    uint32_t len;
-    if (n_un == 0 || cnt != 0) len = aux[a];        // met by the sample
-    else len = (uint32_t)aux[rep] + ubits;          // not met: the class's code word + the index (the first value not met has as many present symbols in front of it as its own number: all before it are present)
-    // (a constant field's sample meets one value: it and the class take one bit each — every byte value has a code word here, where the
-    // exact histogram's book of such a field has one zero-length code word and an empty bit stream)
-    s_l[t] = (uint8_t)len;
-    if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
+    const uint32_t len = (n_un == 0 || cnt != 0) ? s_l[t] : (uint32_t)s_l[rep] + ubits;  // met by the sample / not met: the class's code word + the index
     __syncthreads();
-    atomicAdd(&s_cnt[len], 1u);
+    s_l[t] = (uint8_t)len;
+    // canonical code words by (length, byte value): a ballot per length inside the wave + the earlier waves' counts
+    uint32_t rank = 0;
+    for (uint32_t l = 1; l <= SZH_MAX_LEN; l++) {
+        const unsigned long long lm = __ballot(len == l);
+        if (ln == 0) s_lc[wv][l] = (uint32_t)__popcll(lm);
+        if (len == l) rank = (uint32_t)__popcll(lm & lower);
+    }
     __syncthreads();
     if (t == 0) {
-        uint32_t code = 0, maxl = 0;
+        uint32_t code = 0, maxl = 0, prev = 0;
         for (uint32_t l = 1; l <= SZH_MAX_LEN; l++) {
-            code = (code + (l > 1 ? s_cnt[l - 1] : 0)) << (l > 1 ? 1 : 0);
+            const uint32_t c = s_lc[0][l] + s_lc[1][l] + s_lc[2][l] + s_lc[3][l];
+            code = (code + prev) << (l > 1 ? 1 : 0);
             s_first[l] = code;
-            if (s_cnt[l]) maxl = l;
+            prev = c;
+            if (c) maxl = l;
         }
         sp.info->n_symbols = 256;
         sp.info->max_len = maxl;
@@ -3296,21 +3338,14 @@ __device__ __forceinline__ void samp_book(const szk_samp &sp, uint32_t radius, u
         sp.info->esc_sym = esc;
     }
     __syncthreads();
-    uint32_t rank = 0;
-    for (uint32_t l = 1; l <= SZH_MAX_LEN; l++) {  // (wave-uniform loop: a ballot per length)
-        const unsigned long long m = __ballot(len == l);
-        if (ln == 0) s_lc[wv4][l] = (uint32_t)__popcll(m);
-        if (len == l) rank = (uint32_t)__popcll(m & lower);
-    }
-    __syncthreads();
-    for (uint32_t w = 0; w < wv4; w++) rank += s_lc[w][len];
+    for (uint32_t k = 0; k < wv; k++) rank += s_lc[k][len];
     const uint32_t e = ((s_first[len] + rank) << 5) | len;
     sp.enc[lo + t] = e;
     sp.lens[lo + t] = (uint8_t)len;
     if (t == 255) sp.enc[0] = e;  // the encoder's tables know a listed delta as symbol 0 (byte 255 -> symbol 0 wherever codes are looked up): an alias of the escape's entry
     if (t < 64) {
-        const uint32_t w = (uint32_t)s_l[4 * t] | ((uint32_t)s_l[4 * t + 1] << 8) | ((uint32_t)s_l[4 * t + 2] << 16) | ((uint32_t)s_l[4 * t + 3] << 24);
-        __hip_atomic_store(&sp.words[SZK_SAMP_LENS + t], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t w4 = (uint32_t)s_l[4 * t] | ((uint32_t)s_l[4 * t + 1] << 8) | ((uint32_t)s_l[4 * t + 2] << 16) | ((uint32_t)s_l[4 * t + 3] << 24);
+        __hip_atomic_store(&sp.words[SZK_SAMP_LENS + t], w4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // (the book's tables in the slot are the next launches' to read — a launch boundary away; the lengths the workers of THIS launch want
     // went out as device-scope stores above, and the wait orders them before the word that announces them)

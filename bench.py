@@ -19,8 +19,10 @@ The timed loop ALTERNATES two realisations of the field (same analytic field, tw
 same array, so what a context carries over from its previous call (kernel forms, the code book it speculates with) is what a
 series of similar arrays gives it, not what a repeated array gives it. `identical_input` reports the repeated-array figure beside it.
 
-Printed JSON line (rank 0): the driver contract + "roofline" (dominant kernel against ITS compulsory bytes, live
-HIP-event timing; "roofline_path" = the whole path's algorithmic bytes over the whole step) + "cpu_baseline" (the
+Printed JSON line (rank 0): the driver contract + "roofline" (the path's algorithmic bytes per launch — input +
+payload — over the dominant kernel's duration, live HIP-event timing; `frac_kernel_compulsory` prices the kernel's own bytes;
+"roofline_path" = the same bytes over the whole step; "roofline_decompress" the decode) + "ms_per_step_median" (every step timed on
+its own) + "value_deterministic" / "value_cold" + "cpu_baseline" (the
 reference itself from oracle/_ref when present, else the oracle port; one thread AND all host cores through the
 reference's OpenMP slab path; rank 0, N=1 only) + "extra_configs" (C3 = ALGO_INTERP_LORENZO at 1e-4, same protocol,
 fewer steps) + informational extras (ratio, per-stage ms, host end-to-end incl. PCIe and zstd — never `value`).
@@ -171,31 +173,6 @@ class Workload:
         self.step()
         return out
 
-    def fused_stage1(self, steps, barrier):
-        """round 4's single-pass form (opt-in, sz3hip_ctx_set_fused): the previous call's book codes inside the predictor kernel, the
-        encoder only moves the rows' bit strings (k_lorenzo_quant_march3f + k_merge): half the encoder's traffic, same bytes out"""
-        torch = self.torch
-        self.dc.set_fused(True)
-        try:
-            for _ in range(3):
-                self.step()
-            barrier()
-            h0, m0 = self.dc.spec_stats()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                self.step()
-            torch.cuda.synchronize()
-            ms = 1e3 * (time.perf_counter() - t0) / steps
-            h1, m1 = self.dc.spec_stats()
-            took = bool(self.dc.fused)
-        finally:
-            self.dc.set_fused(False)
-        self.step()
-        self.step()
-        return {"ms_per_step": round(ms, 4), "gbps": round(self.n * self.esz / (ms * 1e-3) / 1e9, 2), "taken": took,
-                "codebook_speculation": {"hits": h1 - h0, "misses": m1 - m0},
-                "note": "alternating realisations; informational — the default (and `value`) is the two-pass form, which is faster on this chip"}
-
     def identical_input(self, steps, barrier):
         """the same array every call (rounds 1-3's timed loop): every shortcut a context has is confirmed"""
         torch = self.torch
@@ -217,6 +194,25 @@ class Workload:
         return {"ms_per_step": round(ms, 4), "gbps": round(self.n * self.esz / (ms * 1e-3) / 1e9, 2),
                 "codebook_speculation": {"hits": h1 - h0, "misses": m1 - m0},
                 "note": "the same array every call; informational — `value` is measured on alternating realisations"}
+
+    def per_step(self, steps):
+        """SURVEY.md 8(d)'s protocol beside the loop mean: every step timed on its own (a step ends in finish(): a completed call) — on the
+        host clock and between two HIP events on the launch stream — and the medians of >= 20 of them"""
+        torch = self.torch
+        wall, dev = [], []
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for i in range(steps):
+            t0 = time.perf_counter()
+            evs[i][0].record()
+            self.step()
+            evs[i][1].record()
+            wall.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        dev = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        wall.sort()
+        return {"steps": steps, "median_ms_host_clock": round(1e3 * wall[len(wall) // 2], 4), "median_ms_hip_events": round(dev[len(dev) // 2], 4),
+                "min_ms_host_clock": round(1e3 * wall[0], 4),
+                "note": "each step on its own, outside the timed loop (two event records per step cost a few microseconds of host time)"}
 
     def stage_profile(self, reps=10):
         """per-stage kernel time, HIP events on the launch stream (outside the timed loop)"""
@@ -352,20 +348,24 @@ def rooflines(w, acc, psize, ms_per_step, traffic_key, live=None):
         k_bytes = w.n * (2 * w.esz + 2)  # working copy in + reconstruction out + one 2-byte code per point, each once
         kname = "stage 1 = copy + interpolation passes + code histogram (a multi-kernel stage: see profiles/)"
         note = "read sizeof(T) + write sizeof(T) of reconstruction + 2 B of codes per element, each once"
-    ach = k_bytes / (k1_ms * 1e-3) / 1e9
+    algo_bytes = raw + psize  # SURVEY.md 8d: read sizeof(T) + write sizeof(T)/ratio per element
+    # `achieved` = the PATH's algorithmic bytes per launch (one launch = the whole volume) over the dominant kernel's
+    # duration; the kernel's own compulsory bytes (what it must read and write itself) are priced beside it
+    ach = algo_bytes / (k1_ms * 1e-3) / 1e9
+    kach = k_bytes / (k1_ms * 1e-3) / 1e9
     out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                       "compulsory_bytes_per_launch": int(k_bytes),
-                       "bytes_note": note, "kernel_ms": round(k1_ms, 4)}
-    algo_bytes = raw + psize  # SURVEY.md 8d: read sizeof(T) + write sizeof(T)/ratio per element
+                       "algorithmic_bytes_per_launch": int(algo_bytes),
+                       "bytes_note": "SURVEY.md 8(d): sizeof(T) read + sizeof(T) / ratio written per element (input + payload), one launch = the whole volume",
+                       "kernel_ms": round(k1_ms, 4),
+                       "frac_kernel_compulsory": round(kach / HBM_PEAK_GBS, 4), "compulsory_bytes_per_launch": int(k_bytes),
+                       "compulsory_note": note}
     pach = algo_bytes / (ms_per_step * 1e-3) / 1e9
     out["roofline_path"] = {"bound": "hbm", "what": "whole step (all kernels + launch gaps + the final sync), algorithmic bytes = input + payload",
                             "achieved": round(pach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pach / HBM_PEAK_GBS, 4),
                             "algorithmic_bytes_per_step": int(algo_bytes),
                             "traffic": live["per_step_bytes"] if live else None,
                             "traffic_over_algorithmic": round(live["per_step_bytes"] / float(algo_bytes), 3) if live else None}
-    # the dominant kernel priced against the PATH's algorithmic bytes (input + payload), not its own compulsory ones
-    out["roofline"]["frac_of_path_algorithmic_bytes"] = round(algo_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     out["kernels_ms"] = round(kernels_ms, 4)
     out["kernels_ms_note"] = ("min(device span of a profiled step = %.4f ms, wall time per step of the timed loop = %.4f ms)" % (span_profiled, ms_per_step))
     out["frac_read_peak_all_kernels"] = round(raw / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -558,7 +558,7 @@ def multi_gpu_extras(torch, sz3_amd, dev, local_rank, rank, world, comm, dist, o
     c5 = None
     why5 = ""
     try:
-        nt_total, edge = (16, 40) if small else (100, 500)
+        nt_total, edge = (100, 16) if small else (100, 500)  # (small: the same 100 time steps — the same 12 / 13 split — of a 16^3 volume)
         lo, hi = D.slab_bounds(nt_total, 8, rank % 8)
         nt = hi - lo
         d_in = device_field4d(torch, dev, lo, nt, edge, 20260928 + rank)
@@ -625,6 +625,9 @@ def multi_gpu_extras(torch, sz3_amd, dev, local_rank, rank, world, comm, dist, o
         el = red(el, dist.ReduceOp.MAX)
         total = red(float(ps), dist.ReduceOp.SUM)
         raw_all = red(float(n * 4), dist.ReduceOp.SUM)
+        steps_of = torch.zeros(world, dtype=torch.float64, device=red_dev)  # every rank's slab thickness (SZImplOMP.hpp:48-50: 12, 13, 12, 13, ...)
+        steps_of[rank] = nt
+        dist.all_reduce(steps_of, op=dist.ReduceOp.SUM)
         err = red(err, dist.ReduceOp.MAX)
         dec_ms = red(dec_ms, dist.ReduceOp.MAX)
         out["C5_8slab"] = {"config": "configs[4]: 4D float32 100x500x500x500 as 8 slabs of 12 / 13 time steps (rank r = slab r; %d of 8 coded here), "
@@ -633,7 +636,7 @@ def multi_gpu_extras(torch, sz3_amd, dev, local_rank, rank, world, comm, dist, o
                            "ratio": round(raw_all / total, 4), "abs_bound_from_range": eb, "value_range": [gmn, gmx],
                            "max_abs_err": err, "err_bound_ok": bool(err <= eb),
                            "decompress_device": {"ms": round(dec_ms, 4), "gbps": round(raw_all / (dec_ms * 1e-3) / 1e9, 2)},
-                           "slab_rank0": [nt, edge, edge, edge], "scaling": "weak",
+                           "slab_rank0": [nt, edge, edge, edge], "slab_steps_by_rank": [int(v) for v in steps_of.tolist()], "scaling": "weak",
                            "data": "synthetic: fields.field4d's formula evaluated on the device, noise from torch's generator"}
         del d_in, d_out, d_pl, dc
     except Exception as e:  # noqa: BLE001
@@ -726,6 +729,7 @@ def main():
     value = world * raw_bytes / (elapsed / args.steps) / 1e9
     ratio = world * raw_bytes / float(total_payload)
     h_spec, m_spec = w.dc.spec_stats()
+    per_step = w.per_step(max(20, args.steps))  # (every rank: a step of a multi-rank run holds a collective)
     acc = w.stage_profile()
     stats = w.dc.stats()
     max_err, dec_ms = w.verify_and_time_decode(psize)
@@ -754,16 +758,22 @@ def main():
                        "exchange": exchange},
             "ratio": round(ratio, 4), "max_abs_err": max_err, "err_bound_ok": bool(max_err <= args.eb),
             "payload_bytes_rank0": int(psize),
+            "ms_per_step_median": per_step,
             "decompress_device": {"ms": round(dec_ms, 4), "gbps": round(raw_bytes / (dec_ms * 1e-3) / 1e9, 2)},
+            # SURVEY.md 8(d), decompression: read sizeof(T) / ratio, write sizeof(T) per element — the whole decode (all its kernels) against the peak
+            "roofline_decompress": {"bound": "hbm", "what": "whole decode (all kernels), algorithmic bytes = payload read + array written",
+                                    "achieved": round((raw_bytes + psize) / (dec_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round((raw_bytes + psize) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "algorithmic_bytes": int(raw_bytes + psize), "ms": round(dec_ms, 4)},
             "outliers": {"value": stats["n_value_outliers"], "delta": stats["n_delta_outliers"]},
             "narrow_codes": stats.get("narrow_codes"),
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
             "tuner": w.dc.tuner_report() if args.algo == "interp" else None,
             "codebook_speculation": {"hits": h_spec, "misses": m_spec,
-                                     "note": "timed loop + warmup, alternating realisations: stage 2 packs with the previous call's code book while this "
-                                             "call's is built by one workgroup of the same launch (alphabets <= 256 symbols) or by k_codebook<1> on a stream of "
-                                             "its own (wide alphabets, short outlier lists); the verdict keeps the previous book when it is complete over this "
-                                             "call's alphabet and within 1/1024 of this call's own book's coded size; a miss repeats the encoder (see `cold`)"},
+                                     "note": "round 6: a one-byte Lorenzo stream of >= 2^22 elements (C2) is coded with a book built from a SAMPLE of the array "
+                                             "inside stage 1's own launch (a function of the input alone): nothing is speculated, nothing verified, hits = misses = 0, "
+                                             "and `value`, `value_deterministic` and a context's second call are the same path. Other streams (wide alphabets: C3, the C4 "
+                                             "slab) still pack with the previous call's book while this call's is built beside the encoder; a miss repeats the encoder"},
         }
         if args.algo == "composed":
             pid = w.stream_predictor()
@@ -785,9 +795,13 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cold:
         out["identical_input"] = w.identical_input(args.steps, barrier)
-        if args.algo == "lorenzo":
-            out["fused_stage1"] = w.fused_stage1(args.steps, barrier)
         out["cold"] = w.cold_numbers(max(5, args.steps // 2), barrier)
+        # what a caller of the reference's boundary gets (sz3hip_ctx_set_deterministic: SZ_compress<T>, sz3c, the CLI, the HDF5 filter) and
+        # what a context's first call gets, as values of the line's own metric
+        out["value_deterministic"] = round(raw_bytes / (out["cold"]["deterministic_payloads_ms"] * 1e-3) / 1e9, 3)
+        out["ms_per_step_deterministic"] = out["cold"]["deterministic_payloads_ms"]
+        out["value_cold"] = round(raw_bytes / (out["cold"]["first_call_ms"] * 1e-3) / 1e9, 3)
+        out["ms_per_step_cold"] = out["cold"]["first_call_ms"]
         # What `value` also leaves out, in the other direction: a producer with a SERIES of arrays keeps two contexts in flight on two
         # streams — stage 1 of one call (bound by memory) runs beside stage 2 of the other (bound by instruction issue). Not `value`:
         # a step of `value` is one call, finished before the next begins.

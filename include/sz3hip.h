@@ -275,6 +275,10 @@ int sz3hip_last_call_q16(const sz3hip_ctx *ctx);
  * context created afterwards. It halves the encoder's HBM traffic (no code array) and is byte-identical to the two-pass form, but on
  * MI355X it measured slower ("Round 4: the single-pass encoder"): the default stays the two-pass form. */
 void sz3hip_ctx_set_fused(sz3hip_ctx *ctx, int on);
+/* 1: this library carries the superseded forms kept for reference — the fused stage 1 above and the decoder's multi-symbol table
+ * (sz3hip_debug_flags(2)) — i.e. it is the lab build (python -m sz3_amd.build --lab: sz3_amd/libsz3hip_lab.so). The product build
+ * (libsz3hip.so) leaves them out: 0, and both switches do nothing. */
+int sz3hip_lab_build(void);
 /* test hooks: copy internal device arrays to host (quantisation codes as uint16, histogram as uint64) */
 int sz3hip_debug_copy_codes(sz3hip_ctx *ctx, uint16_t *host_codes, uint64_t n);
 /* test hook: which chain the last sz3hip_decompress_device took: out4[0] half-width intermediates, [1] rows that cross chunk

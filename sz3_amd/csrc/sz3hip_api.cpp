@@ -46,6 +46,7 @@ int szi_fail(int code, const char *fmt, ...) {
     return code;
 }
 #define fail szi_fail
+extern "C" int sz3hip_lab_build(void);
 extern "C" const char *sz3hip_last_error(void) { return g_err; }
 extern "C" int sz3hip_last_error_code(void) { return g_err_code; }
 extern "C" const char *sz3hip_version(void) { return "sz3hip 0.1 (gfx950; data format SZ3 3.3.2 container, payload SZH1)"; }
@@ -306,7 +307,7 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     alloc((void **)&c->d_info, SZK_MAX_BOOKS * sizeof(szk_cb_info));
     {   // (the fused stage 1 is opt-in: measured slower than the two-pass form on this chip; SZ3HIP_FUSED=1 turns it on for every context)
         const char *fe = getenv("SZ3HIP_FUSED");
-        c->fuse_on = fe && fe[0] == '1';
+        c->fuse_on = fe && fe[0] == '1' && sz3hip_lab_build();
     }
     alloc((void **)&c->d_seg_bits, (max_elems / 256 + 8) * 2);
     alloc((void **)&c->d_seg_base, (max_elems / 256 + 8) * 4);
@@ -2120,7 +2121,16 @@ int szi_stock_import(sz3hip_ctx *ctx, const szi_stock_params *p, const szg_geom 
 }
 extern "C" int sz3hip_last_call_fused(const sz3hip_ctx *ctx) { return ctx->last_fused ? 1 : 0; }
 extern "C" int sz3hip_last_call_q16(const sz3hip_ctx *ctx) { return ctx->last_q16 ? 1 : 0; }
-extern "C" void sz3hip_ctx_set_fused(sz3hip_ctx *ctx, int on) { ctx->fuse_on = on != 0; }
+// 1: the library was built with the superseded forms (python -m sz3_amd.build --lab): the fused stage 1 (sz3hip_ctx_set_fused) and the
+// decoder's multi-symbol table (sz3hip_debug_flags(2)); the product build leaves them out and both switches do nothing
+extern "C" int sz3hip_lab_build(void) {
+#ifdef SZ3HIP_LAB
+    return 1;
+#else
+    return 0;
+#endif
+}
+extern "C" void sz3hip_ctx_set_fused(sz3hip_ctx *ctx, int on) { ctx->fuse_on = on != 0 && sz3hip_lab_build(); }
 extern "C" void sz3hip_get_spec_stats(const sz3hip_ctx *ctx, uint32_t *hits, uint32_t *misses) {
     *hits = ctx->spec_hits;
     *misses = ctx->spec_misses;
@@ -2252,7 +2262,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     }
     prof_begin(ctx, ST_DEC_HUFF, s);
     // (a Lorenzo stream's small book — code words up to 16 bits, at most 1024 symbols: the tables' launch also makes the multi-symbol table)
-    const bool ms_book = h.predictor == 0 && h.qbytes == 4 && h.max_len >= 1 && h.max_len <= 16 && h.sym_count <= 1024 && (szk_dbg_flags & 2);
+    const bool ms_book = h.predictor == 0 && h.qbytes == 4 && h.max_len >= 1 && h.max_len <= 16 && h.sym_count <= 1024 && (szk_dbg_flags & 2) && sz3hip_lab_build();
     // (a Lorenzo stream's header names the symbol that stands for a listed delta in its anchor_stride field: 0 = symbol 0 itself)
     const uint32_t esc_sym = h.predictor == 0 ? (uint32_t)h.anchor_stride : 0u;
     if (h.predictor == 0 && h.anchor_stride && (h.anchor_stride < h.sym_min || h.anchor_stride >= (uint64_t)h.sym_min + h.sym_count))

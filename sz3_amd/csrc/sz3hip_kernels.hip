@@ -1734,7 +1734,8 @@ __device__ __forceinline__ void narrow16_task(NarrowCtx<float> &c, const Lattice
 #elif defined(LAB_ST) && LAB_ST == 3
                 __hip_atomic_store(reinterpret_cast<uint32_t *>(c.codes8 + grow + x), tA | (tB << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-                __builtin_nontemporal_store(tA | (tB << 8), reinterpret_cast<uint32_t *>(c.codes8 + grow + x));
+                if (c.p->dbg & 8388608u) *reinterpret_cast<uint32_t *>(c.codes8 + grow + x) = tA | (tB << 8);  // (lab: plain stores — the codes stay in the caches for the packer)
+                else __builtin_nontemporal_store(tA | (tB << 8), reinterpret_cast<uint32_t *>(c.codes8 + grow + x));
 #endif
             }
             if (SAMP ? c.have_len != 0u : c.s_len != nullptr) {
@@ -4712,6 +4713,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_pack_b(const uint16_t *__restric
 // 3 instructions per symbol instead of the packer's 13, and no code array: the launch reads 0.5 B/elem and writes 0.5.
 // The role workgroups (this call's code book + verdict, list sorts) and the assembly ride along as in k_pack.
 // ------------------------------------------------------------------------------------------------------------
+#ifdef SZ3HIP_LAB  // (the encoder behind the fused stage 1: lab build only)
 struct szk_merge_params {
     const uint32_t *slots;       // the scratch stage 1 wrote
     const uint16_t *seg_bits;    // [n / 256] bits of every segment's string
@@ -4816,6 +4818,7 @@ __global__ __launch_bounds__(256) void k_merge(szk_merge_params mp, uint64_t n, 
     if (nblk > pack_blocks && !ap.lists_by_roles) assemble_lists(ap, (uint64_t)bid * 256 + threadIdx.x, (uint64_t)nblk * 256);
 }
 
+#endif  // SZ3HIP_LAB
 // ------------------------------------------------------------------------------------------------------------
 // K8: decode side
 // ------------------------------------------------------------------------------------------------------------
@@ -6028,13 +6031,20 @@ static void launch_march_w(const void *d_in, uint16_t *codes, szk_k1_params &p, 
         const uint32_t slot_words = fuse_slot_words(TY, p.d[2], p.d[1]);
         const bool fuse = NDIM == 3 && p.fuse && p.seg_expected && p.fuse_enc && p.fuse_info && p.fuse_slots && p.seg_base && p.fuse_flag &&
                           nb * (uint64_t)slot_words + 2 <= p.fuse_cap_words && nb * (uint64_t)slot_words < (1ull << 32) && !(szk_dbg_flags & 2048);
-        p.fused = fuse ? 1 : 0;
-        if (fuse) {
+#ifndef SZ3HIP_LAB  // (the fused form — round 4, slower than two passes on this chip — is part of the lab build only: python -m sz3_amd.build --lab)
+        const bool fuse_built = false;
+#else
+        const bool fuse_built = true;
+#endif
+        p.fused = fuse && fuse_built ? 1 : 0;
+        if (p.fused) {
+#ifdef SZ3HIP_LAB
             if constexpr (NDIM == 3) {
                 grid = k1_grid((const void *)k_lorenzo_quant_march3f<T, 3, TY>, (nb + 3) / 4);
                 p.fuse_geom[3] = slot_words;
                 hipLaunchKernelGGL((k_lorenzo_quant_march3f<T, 3, TY>), dim3(grid), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
             }
+#endif
         } else if (NDIM == 3 && sizeof(T) == 4 && p.hint_q16 > 0 && p.q16_flag && p.d[0] == 1 && !(szk_dbg_flags & 8)) {
             // the 16-bit form: the previous call's probe saw lattice values within +-Q16_LIM / 2 only (debug flag 8 keeps the form below)
             if constexpr (NDIM == 3 && sizeof(T) == 4) {
@@ -6318,6 +6328,7 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
     // must be resident together (5 per compute unit at 30 KB of LDS each), or the late ones double the launch's duration
     const uint32_t extra = rb + (asmp ? 32u : 0u);
     constexpr uint32_t ASM_BLOCKS = 32;
+#ifdef SZ3HIP_LAB
     if (mg) {  // stage 1 was the fused form: the rows' bit strings only have to be moved to their places
         szk_merge_params mp;
         mp.slots = mg->slots;
@@ -6326,7 +6337,11 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
         mp.fuse_flag = mg->fuse_flag;
         const uint32_t pb = pgrid < 2048 - extra ? pgrid : 2048 - extra;
         hipLaunchKernelGGL(k_merge, dim3(rb + pb + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, mp, n, chunk_words, group_off, mode, state, payload, apv, pb, rp);
-    } else if (asmp && !(rp.on && !rp.no_book) && n_chunks >= 4096 && ((asmp->assumed_narrow && !(szk_dbg_flags & 32768)) || asmp->samp_words)) {
+    } else
+#else
+    if (mg) return -2;  // (no fused stage 1 in this build: nothing hands a merge over)
+#endif
+    if (asmp && !(rp.on && !rp.no_book) && n_chunks >= 4096 && ((asmp->assumed_narrow && !(szk_dbg_flags & 32768)) || asmp->samp_words)) {
         // one-byte codes (stage 1's one-launch form assumed them; a probe that says otherwise voids the call) and no book built beside the
         // packer: the pair-table packer, one 1024-thread workgroup per CU (sz3hip_debug_flags(32768): k_pack as before)
         static int n_cu = 0;
@@ -6414,7 +6429,9 @@ int szk_launch_decode(const uint8_t *payload, const szk_dec_params *p, uint16_t 
     if (!p->scan_row) hipLaunchKernelGGL((k_decode<0>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
     else if (p->q_bytes == 8 && p->half) hipLaunchKernelGGL((k_decode<8, true>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
     else if (p->q_bytes == 8) hipLaunchKernelGGL((k_decode<8>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
+#ifdef SZ3HIP_LAB  // (the multi-symbol table form — round 5, slower than the one-symbol table — lab build only)
     else if (p->half && p->ms) hipLaunchKernelGGL((k_decode<4, true, true>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
+#endif
     else if (p->half) hipLaunchKernelGGL((k_decode<4, true>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
     else hipLaunchKernelGGL((k_decode<4>), dim3((uint32_t)nb), dim3(256), pad, s, payload, *p, codes);
     if (p->scan_row && p->carry && p->carry_pass) {

@@ -119,8 +119,25 @@ def test_bench_two_ranks_print_the_multi_gpu_configs():
         assert c4[f]["err_bound_ok"] and c4[f]["ratio"] > 2 and c4[f]["value"] > 0 and c4[f]["decompress_device"]["ms"] > 0
     c5 = ex["C5_8slab"]
     assert "error" not in c5, c5
-    assert c5["err_bound_ok"] and c5["ratio"] > 2 and c5["slab_rank0"] == [2, 40, 40, 40]
+    assert c5["err_bound_ok"] and c5["ratio"] > 2 and c5["slab_rank0"] == [12, 16, 16, 16] and c5["slab_steps_by_rank"] == [12, 13]
     assert abs(c5["abs_bound_from_range"] - 1e-3 * (c5["value_range"][1] - c5["value_range"][0])) < 1e-12
+
+
+def test_bench_eight_ranks_on_the_one_gpu():
+    """the command the driver will run on an 8-GPU node — bench.py --gpus 8 — with the eight ranks on this box's one
+    GPU (SZ3_BENCH_ONE_GPU=1: gloo carries the histogram) and the multi-GPU legs at reduced sizes: eight ranks rendezvous, the line says
+    n_gpus 8 / slab8, C4's fields are coded as eight slabs, C5's 100 time steps are cut 12, 13, 12, 13, ... as the reference cuts them
+    (api/impl/SZImplOMP.hpp:48-50) and every leg decodes within its bound."""
+    d = _bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--size", "96", "--no-cold", "--no-host-e2e", "--no-cpu-baseline", "--no-live-traffic"],
+               {"SZ3_BENCH_ONE_GPU": "1", "SZ3_BENCH_EXTRA_SCALE": "small"}, timeout=1500)
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "slab8" and d["scaling"] == "weak" and d["err_bound_ok"]
+    ex = d["extra_configs"]
+    for f in ("C4a", "C4b"):
+        assert "error" not in ex["C4_8slab"]["fields"][f], ex["C4_8slab"]["fields"][f]
+        assert ex["C4_8slab"]["fields"][f]["err_bound_ok"]
+    c5 = ex["C5_8slab"]
+    assert "error" not in c5, c5
+    assert c5["slab_steps_by_rank"] == [12, 13, 12, 13, 12, 13, 12, 13] and c5["err_bound_ok"]
 
 
 def test_bench_on_every_visible_gpu_over_rccl():

@@ -793,6 +793,7 @@ static void blk_params_from(sz3hip_ctx *ctx, int ndim, const uint64_t *dims3, ui
 static int blk_all_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint32_t mask, hipStream_t s, bool *all) {
     *all = false;
     ctx->blk_sel_given = false;
+    ctx->blk_spec = false;
     if (szk_dbg_flags & 2147483648u) return 0;  // (development: no selection pass, the fit pass chooses by its own wave sums)
     // (1-D: the fit pass chooses — the estimate looks at a block's two ends only and a line through 128 values wins there on every
     // field with noise above the bound, as in the reference: a selection pass of its own found no field to hand over and cost a
@@ -814,13 +815,32 @@ static int blk_all_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const voi
     rc = szk_launch_blk_select(ctx->dtype, d_in, &bp, ctx->d_blk_counters + 7, s);
     prof_end(ctx, ST_TUNER, s);
     if (rc) return fail(SZ3HIP_EHIP, "block selection kernel launch failed (%d)", rc);
+    ctx->blk_sel_given = true;  // (the choices and coefficients are in d_blk_sel / d_blk_coef: the fit pass codes what they say)
+    // The decision — every block Lorenzo-1: the plain stream — is a function of the pass's count. A context whose previous call of the
+    // same configuration made it from a count assumes the same outcome and goes on without the count's round trip to the host (a copy,
+    // a synchronisation and the relaunch latency: ~65 us of an idle GPU at C4's slab); the count travels with the state block at the
+    // call's end (k_publish) and finish() repeats the call in this waiting form when it decides otherwise.
+    const sz3hip_config &k = ctx->blk_dec_conf;
+    bool same = ctx->blk_dec_valid && k.N == conf->N && k.blockSize == conf->blockSize && k.absErrorBound == conf->absErrorBound && k.quantbinCnt == conf->quantbinCnt &&
+                k.lorenzo == conf->lorenzo && k.lorenzo2 == conf->lorenzo2 && k.regression == conf->regression;
+    for (int i = 0; same && i < conf->N; i++) same = k.dims[i] == conf->dims[i];
+    if (same && ctx->spec_off != 1 && !(szk_dbg_flags & 1073741824)) {
+        ctx->blk_spec = true;
+        ctx->blk_spec_all = ctx->blk_dec_all;
+        ctx->blk_spec_nblocks = nblocks;
+        ctx->blk_spec_mask = mask;
+        *all = ctx->blk_dec_all;
+        return 0;
+    }
     HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr, ctx->d_blk_counters + 7, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     uint64_t others;
     memcpy(&others, ctx->h_blk_side_hdr, 8);
     ctx->blk_others = others;
-    ctx->blk_sel_given = true;  // (the choices and coefficients are in d_blk_sel / d_blk_coef: the fit pass codes what they say)
     *all = (mask & 1u) && !(szk_dbg_flags & 1073741824) && (others << BLK_EXIT_SHIFT) < nblocks;
+    ctx->blk_dec_valid = !(szk_dbg_flags & 1073741824);
+    ctx->blk_dec_all = *all;
+    ctx->blk_dec_conf = *conf;
     return 0;
 }
 static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint64_t num, uint32_t mask, hipStream_t s) {
@@ -1442,6 +1462,7 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     ctx->copy_ahead = false;
     ctx->range_ready = false;
     ctx->s1_spec = ctx->seg_expected = ctx->s1_assumed_narrow = ctx->s1_fused = ctx->s1_samp = ctx->s1_samp_in = false;
+    ctx->blk_spec = false;
     ctx->fold_rows = 0;
     ctx->s1_conf = *conf_in;
     ctx->s1_in = d_in;
@@ -1773,7 +1794,7 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     ctx->pub_zero = ctx->d_hist == ctx->d_hist_own && !ctx->hist_exposed && !(szk_dbg_flags & 268435456);
     ctx->pub_seq++;
     if (szk_launch_publish(ctx->d_state, ctx->h_state, ctx->h_pub_seq, ctx->pub_seq, ctx->pub_zero ? (void *)ctx->d_hist : nullptr,
-                           SZH_HIST_BINS * 8 + SZ_COUNTER_BYTES, s))
+                           SZH_HIST_BINS * 8 + SZ_COUNTER_BYTES, s, ctx->blk_spec ? ctx->d_blk_counters + 7 : nullptr))
         return fail(SZ3HIP_EHIP, "publish kernel launch failed");
     ctx->pub_stream = s;
     // (h_state->probe = the probe counters: |delta| > 127, in [4096, 8192), in [2048, 4096); [4] = interpolation codes beyond +-4096)
@@ -1809,7 +1830,16 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     HIPCHK(hipSetDevice(ctx->device));
     if (!ctx->stage2_done) return fail(SZ3HIP_EINVAL, "finish called before stage2");
     if (int rw = wait_published(ctx)) return rw;  // (the payload is complete: the state's publication is the last thing stage 2 enqueued)
-    const bool fused_miss = ctx->s1_fused && (ctx->h_state->miss_kind != 0 || ctx->h_state->mispredict != 0);
+    bool blk_miss = false;
+    if (ctx->blk_spec) {  // the call assumed the previous call's hand-over decision (blk_all_lorenzo): what its own count says
+        const uint64_t others = ctx->h_state->blk_others;
+        const bool all = (ctx->blk_spec_mask & 1u) && (others << BLK_EXIT_SHIFT) < ctx->blk_spec_nblocks;
+        ctx->blk_others = others;
+        blk_miss = all != ctx->blk_spec_all;
+        ctx->blk_spec = false;
+        if (blk_miss) ctx->blk_dec_valid = false;  // (the repeat below decides from its own count and records it)
+    }
+    const bool fused_miss = (ctx->s1_fused && (ctx->h_state->miss_kind != 0 || ctx->h_state->mispredict != 0)) || blk_miss;
     ctx->last_fused = ctx->s1_fused && !fused_miss;
     ctx->last_q16 = ctx->s1_q16 && !(ctx->h_state->miss_kind & (32u | 128u)) && !fused_miss;
     ctx->last_spec_hit = ctx->s2_spec && ctx->h_state->miss_kind == 0 && ctx->h_state->mispredict == 0;
@@ -2045,6 +2075,7 @@ extern "C" void sz3hip_ctx_forget(sz3hip_ctx *ctx) {
     ctx->spec_skip = ctx->spec_penalty = 0;
     ctx->lists_long = false;
     ctx->half_skip = 0;
+    ctx->blk_dec_valid = false;
 }
 // speculation off (1) / on (0) / on without the back-off after a miss (2, for tests) for this context: with it off every
 // stage 2 builds its code book before it encodes

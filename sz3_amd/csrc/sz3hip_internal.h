@@ -156,6 +156,13 @@ struct sz3hip_ctx {
     uint64_t blk_carry_cap;
     bool blk_sel_given;        // the selection pass of this call wrote them
     uint64_t blk_others;       // the last selection pass: blocks that would not be coded by first-order Lorenzo
+    // (round 6) the hand-over decision of a call — plain Lorenzo stream or block stream, a function of that count — is ASSUMED to be the
+    // previous call's of the same configuration, so that nothing waits for the selection pass on the host; finish() compares and repeats
+    bool blk_dec_valid, blk_dec_all;   // the last decision made from a count, and for which call ...
+    sz3hip_config blk_dec_conf;
+    bool blk_spec, blk_spec_all;       // this call assumed it; what it assumed
+    uint64_t blk_spec_nblocks;
+    uint32_t blk_spec_mask;
     uint64_t *d_vout_idx, *d_dout_idx;
     void *d_vout_val, *d_dout_val;
     uint32_t *d_enc;

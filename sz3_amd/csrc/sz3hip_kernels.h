@@ -163,6 +163,8 @@ struct szk_state {
                                      // (the whole call is repeated), 128 the 16-bit stage 1 met a lattice value beyond its range (likewise)
     uint64_t n_vout_raw, n_dout_raw;  // the outlier counters before capping at the lists' capacity (what an overflowing call needs)
     uint32_t probe[6];  // copy of the probe counters (d_counters + 4): one device-to-host copy brings everything the host reads
+    uint32_t pad1[2];
+    uint64_t blk_others;  // block-composed predictor, a call that ASSUMED the previous call's hand-over decision: the selection pass's count, written by k_publish (host copy only)
 };
 struct szk_layout_params {
     szh_header proto;
@@ -471,7 +473,8 @@ int szk_launch_hist_fold(const uint32_t *partial, uint32_t nrows, int radius, ui
 int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
 // the state block -> the host's pinned copy + a sequence word behind it, written by the device (finish() polls the word); d_zero != nullptr:
 // the same launch zeroes zero_bytes (a multiple of 16) there when the state reports no miss and no mispredicted code-book form
-int szk_launch_publish(const szk_state *d_state, void *h_state, uint32_t *h_seq, uint32_t seq, void *d_zero, uint64_t zero_bytes, hipStream_t s);
+int szk_launch_publish(const szk_state *d_state, void *h_state, uint32_t *h_seq, uint32_t seq, void *d_zero, uint64_t zero_bytes, hipStream_t s,
+                       const uint64_t *d_blk_others = nullptr /* non-null: the word the host copy's blk_others receives */);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t,
                           uint32_t radius /* != 0: the multi-symbol table of a Lorenzo stream's small book is made too (mlut) */,
                           uint32_t esc_sym /* != 0: the stored symbol that decodes as symbol 0 (a listed delta; sampled books) */,

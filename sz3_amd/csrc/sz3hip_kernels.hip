@@ -21,6 +21,7 @@
 //
 // No MFMA anywhere: the path is integer/byte work bounded by HBM bandwidth.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <stdint.h>
 #include <type_traits>
 #include <mutex>
@@ -6382,11 +6383,15 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
 // counters when this call needs no repeat (state: no miss, no mispredicted book form) — the host draws the same conclusion from the
 // same state — so that nothing is enqueued between a call's end and the next call's stage 1.
 __global__ __launch_bounds__(256) void k_publish(const szk_state *__restrict__ state, uint32_t *host_state, uint32_t *host_seq, uint32_t seq,
-                                                 uint4 *zero, uint32_t zero_vec16) {
+                                                 uint4 *zero, uint32_t zero_vec16, const uint64_t *blk_others) {
     if (blockIdx.x == 0) {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(state);
-        for (uint32_t i = threadIdx.x; i < sizeof(szk_state) / 4; i += 256)
-            __hip_atomic_store(&host_state[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        constexpr uint32_t OW = offsetof(szk_state, blk_others) / 4;
+        for (uint32_t i = threadIdx.x; i < sizeof(szk_state) / 4; i += 256) {
+            uint32_t v = src[i];
+            if (blk_others && (i == OW || i == OW + 1)) v = reinterpret_cast<const uint32_t *>(blk_others)[i - OW];
+            __hip_atomic_store(&host_state[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -6394,9 +6399,11 @@ __global__ __launch_bounds__(256) void k_publish(const szk_state *__restrict__ s
     if (zero && state->miss_kind == 0 && state->mispredict == 0)
         for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < zero_vec16; i += gridDim.x * 256) zero[i] = make_uint4(0u, 0u, 0u, 0u);
 }
-int szk_launch_publish(const szk_state *d_state, void *h_state, uint32_t *h_seq, uint32_t seq, void *d_zero, uint64_t zero_bytes, hipStream_t s) {
+int szk_launch_publish(const szk_state *d_state, void *h_state, uint32_t *h_seq, uint32_t seq, void *d_zero, uint64_t zero_bytes, hipStream_t s,
+                       const uint64_t *d_blk_others) {
     static_assert(sizeof(szk_state) % 4 == 0, "the state block is copied word by word");
-    hipLaunchKernelGGL(k_publish, dim3(d_zero ? 128 : 1), dim3(256), 0, s, d_state, (uint32_t *)h_state, h_seq, seq, (uint4 *)d_zero, (uint32_t)(zero_bytes / 16));
+    hipLaunchKernelGGL(k_publish, dim3(d_zero ? 128 : 1), dim3(256), 0, s, d_state, (uint32_t *)h_state, h_seq, seq, (uint4 *)d_zero, (uint32_t)(zero_bytes / 16),
+                       d_blk_others);
     SZK_CHECK_LAUNCH();
     return 0;
 }

@@ -4567,7 +4567,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_pack_b(const uint16_t *__restric
     __shared__ __align__(8) uint64_t s_stage[PB_WAVES][STAGE_WORDS / 2];
     // (launched beside k_pack behind the two-launch form of stage 1 — only_sampled: this kernel then packs, sorts and assembles only
     // when the call codes with its sampled book, k_pack otherwise)
-    if (only_sampled && !(ap.samp_words && ap.samp_words[SZK_SAMP_READY] && szk_is_narrow(mode))) return;
+    if ((only_sampled & 1u) && !(ap.samp_words && ap.samp_words[SZK_SAMP_READY] && szk_is_narrow(mode))) return;
     const uint32_t roles = rp.on ? ROLE_BLOCKS : 0u;
     if (blockIdx.x < roles) {  // (the pair table's memory serves as their scratch; they are 256-thread bodies: the other waves leave)
         if (threadIdx.x >= 256u) return;
@@ -4605,7 +4605,12 @@ __global__ __launch_bounds__(PB_THREADS) void k_pack_b(const uint16_t *__restric
     // once per chunk in k_pack's loop (whose wave then idles through the store acknowledgement of its previous chunk).
     constexpr uint32_t PB_BATCH = 4;
     const uint64_t n_units = (n_full + PB_BATCH - 1) / PB_BATCH;
-    auto fetch = [&](uint64_t ch) { return ch < n_full ? *reinterpret_cast<const uint4 *>(c8 + ch * SZH_CHUNK_SYMS) : make_uint4(0u, 0u, 0u, 0u); };
+#ifdef SZ3HIP_LAB  // (lab build: what the launch's time is made of — only_sampled bits 8: no stores of the stream, 16: every unit reads the first unit's codes)
+    const bool lab_nost = (only_sampled & 8u) != 0, lab_nold = (only_sampled & 16u) != 0;
+#else
+    constexpr bool lab_nost = false, lab_nold = false;
+#endif
+    auto fetch = [&](uint64_t ch) { return ch < n_full ? *reinterpret_cast<const uint4 *>(c8 + (lab_nold ? ch % (4 * nwaves) : ch) * SZH_CHUNK_SYMS) : make_uint4(0u, 0u, 0u, 0u); };
     auto front_of = [&](uint64_t unit) -> uint32_t {  // (one lane-parallel load: the counts of the group's chunks in front of the unit)
         const uint64_t c_lo = unit * PB_BATCH, grp = c_lo / PACK_GROUP;
         const uint32_t first = (uint32_t)(c_lo % PACK_GROUP);
@@ -4658,6 +4663,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_pack_b(const uint16_t *__restric
                 for (uint32_t i = 2 * lane; i < nwords + 2; i += 2 * WAVE) {  // copy out and re-zero the stage for the next chunk, two words per lane
                     const uint64_t v = stage[i >> 1];
                     stage[i >> 1] = 0;
+                    if (lab_nost && v != 0x123456789abcdefull) continue;
                     if (i < nwords) out[i] = __builtin_bswap32((uint32_t)(v >> 32));  // bytes in stream order (see sz3hip_format.h)
                     if (i + 1 < nwords) out[i + 1] = __builtin_bswap32((uint32_t)v);
                 }
@@ -6357,10 +6363,14 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
         // (a call that may code with its sampled book is this kernel's whatever the debug flag says: k_pack's one-byte path takes code words
         // up to 16 bits. Behind the two-launch form of stage 1 — a context's first call — whether it does is known on the device only:
         // both packers are launched and the one whose case it is not returns at once)
-        const uint32_t beside = asmp->samp_words && !asmp->assumed_narrow ? 1u : 0u;
+        uint32_t beside = asmp->samp_words && !asmp->assumed_narrow ? 1u : 0u;
+#ifdef SZ3HIP_LAB
+        beside |= (szk_dbg_flags & 16) ? 8u : 0u;   // (lab switches of k_pack_b: see the kernel)
+        beside |= (szk_dbg_flags & 512) ? 16u : 0u;
+#endif
         hipLaunchKernelGGL(k_pack_b, dim3(rb + PB_ASM_BLOCKS + pb), dim3(PB_THREADS), 0, s, codes, n, d_enc, chunk_words, group_off, mode, sym_add, state,
                            payload, apv, pb, split, rp, beside);
-        if (beside) {
+        if (beside & 1u) {
             const uint32_t pb2 = pgrid < 1280 - extra ? pgrid : 1280 - extra;
             hipLaunchKernelGGL((k_pack<ENC_WIN>), dim3(rb + pb2 + (asmp ? ASM_BLOCKS : 0)), dim3(256), 0, s, codes, n, d_enc, info, chunk_words, group_off, mode,
                                sym_add, state, payload, apv, pb2, rp);

@@ -43,3 +43,13 @@ def field_c4a(shape, seed=SEED):
     """C4a: 3.3e-5 x (the C2 formula evaluated in f64, noise sigma = 2e-3 added before scaling) — at abs 1e-6 the
     bound is ~3 % of the amplitude and the composed predictor picks regression for ~14 % of the blocks"""
     return field3d(shape, np.float64, sigma=2e-3, seed=seed, scale=3.3e-5)
+
+
+def testfloat_like():
+    """A stand-in for the reference's CI fixture tools/sz3/testfloat_8_8_128.dat (8 x 8 x 128 f32, x fastest; the reference's file is not
+    kept here): an analytic field of the same shape and character — smooth along x, positive, range ~[0.2, 5], mean ~1."""
+    z, y, x = np.meshgrid(np.arange(8, dtype=np.float64), np.arange(8, dtype=np.float64), np.arange(128, dtype=np.float64), indexing="ij")
+    f = np.exp(0.9 * np.sin(2 * np.pi * x / 128 * 1.5 + 0.3 * y) + 0.45 * np.cos(2 * np.pi * y / 8 + 0.2 * z) + 0.3 * np.sin(2 * np.pi * z / 8))
+    f = f / f.mean()
+    f += np.random.default_rng(SEED).normal(0.0, 2e-5, size=f.shape)
+    return f.astype(np.float32)

@@ -994,6 +994,7 @@ template <typename T> struct NarrowCtx {
     uint32_t *seg_base;     // [n / 256] out: index of the first word of every segment's bit string in the scratch
     // sampled book (round 6): the lengths' table is filled when the book arrives (samp_words[SZK_SAMP_READY]); until then a plane's segment sums wait
     const uint32_t *samp_words;
+    uint32_t *s_have;       // the workgroup's LDS word: its length table is filled
     uint32_t have_len;      // (wave-uniform) the table is filled
 };
 // a 256-element row segment is at most 256 x 16 bits = 128 words (small books: code words <= 16 bits); the stage of a wave holds a
@@ -1072,6 +1073,52 @@ __device__ __forceinline__ void narrow_rare(NarrowCtx<T> &c, uint64_t gi, const 
             hist_add_ranged(p.hist, p.range, 0u, (unsigned long long)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2)));
     }
 }
+// (always inlined, the kernel's parameters handed over piecemeal: a call would put the caller's parameter block on a stack, and a kernel
+// with a stack pays for it in every wave)
+template <typename T> __device__ __forceinline__ bool samp_take(const T *__restrict__ in, const szk_lattice &latp, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t *words, uint32_t role, uint32_t *s_h);
+__device__ __forceinline__ void samp_book(const szk_samp &sp, uint32_t radius, uint8_t *pool);
+#define SAMP_POOL_BYTES (SZK_CB_SMALL_SYMS * 28 + 256)
+// a worker's wave looks for the sampled book (spin: waits for it) and, once it is there, fills ITS view of the workgroup's length table
+// (all four waves write the same values): `put(byte value, length)` stores one entry in the form's layout
+template <typename T, typename PUT>
+__device__ __forceinline__ bool samp_poll(NarrowCtx<T> &c, bool spin, PUT put) {
+    // Wave 0 of the workgroup asks the device-wide word (a load past the L2s: all workers asking would be a billion requests a second to
+    // one memory channel — the one the sampling workgroups' atomics go to), fills the workgroup's table and raises the workgroup's LDS
+    // word; the other waves watch that. Wave 0 leaves a task only with the book in hand, so the LDS word is raised before it exits.
+    volatile uint32_t *s_have = c.s_have;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    if (wv != 0) {
+        uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_have);
+        if (!h) {
+            if (!spin) return false;
+            do {
+                __builtin_amdgcn_s_sleep(16);
+                h = (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_have);
+            } while (!h);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        c.have_len = 1;
+        return true;
+    }
+    uint32_t r = __hip_atomic_load(const_cast<uint32_t *>(c.samp_words) + SZK_SAMP_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+    if (!r) {
+        if (!spin) return false;
+        do {
+            __builtin_amdgcn_s_sleep(32);
+            r = __hip_atomic_load(const_cast<uint32_t *>(c.samp_words) + SZK_SAMP_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+        } while (!r);
+    }
+    const uint32_t w = __hip_atomic_load(const_cast<uint32_t *>(c.samp_words) + SZK_SAMP_LENS + c.lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int j = 0; j < 4; j++) put(4u * (uint32_t)c.lane + j, (w >> (8 * j)) & 0xFFu);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (c.lane == 0) *s_have = 1u;
+    c.have_len = 1;
+    return true;
+}
 // one plane's rows as they come back from memory: halo row y0 - 1 (slot 0) and rows y0 .. y0 + TY - 1 (slots 1 .. TY)
 template <typename T, int NW, int TY> struct NarrowPlane {
     Quad<T> rq[NW][TY + 1];
@@ -1127,8 +1174,9 @@ __device__ __forceinline__ void fuse_flush_lines(NarrowCtx<T> &c) {
 #ifndef NARROW_PF
 #define NARROW_PF 0  // 1: the next plane's rows are requested before the current plane is worked (two sets of row registers; measured slower: 161 vs 149 us)
 #endif
-template <typename T, int NDIM, int TY, bool EDGE, bool FUSE = false>
+template <typename T, int NDIM, int TY, bool EDGE, bool FUSE = false, bool SAMP = false>
 __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &lat, uint32_t x0, uint32_t y0, uint32_t z0, uint32_t w) {
+    static_assert(!SAMP || (!FUSE && NDIM == 3), "the sampled book is the plain one-byte form's, 1-D ... 3-D arrays");
     using B = typename Lattice<T>::B;
     using UQ = typename QTraits<T>::UQ;
     constexpr int NW = NDIM == 4 ? 2 : 1;
@@ -1267,6 +1315,7 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
 #ifdef LAB_ABLATE
                 if (!(c.p->dbg & 1u))
 #endif
+                if (!SAMP)  // (a sampled book needs no histogram)
 #pragma unroll
                 for (int i = 0; i < 4; i++) atomicAdd(&c.lh[t[i] * 4u + copy], 1u);
                 if constexpr (FUSE) {
@@ -1295,7 +1344,7 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
 #endif
                 }
             }
-            if (c.s_len) {
+            if (SAMP ? c.have_len != 0u : c.s_len != nullptr) {
                 uint32_t b4 = (uint32_t)c.s_len[t[0]] + c.s_len[t[1]] + c.s_len[t[2]] + c.s_len[t[3]];
                 if (EDGE) b4 = xok ? b4 : 0u;
                 bits_rows[(r - 1) >> 1] |= ((r - 1) & 1) ? b4 << 16 : b4;
@@ -1399,7 +1448,7 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (!FUSE && c.s_len && zz >= 0) {  // the plane's segment sums: one wave reduction per pair of rows
+        if (!FUSE && (SAMP ? c.have_len != 0u : c.s_len != nullptr) && zz >= 0) {  // the plane's segment sums: one wave reduction per pair of rows
 #pragma unroll
             for (int k = 0; k < (TY + 1) / 2; k++) {
                 const uint32_t tot = wave_sum(bits_rows[k]);
@@ -1414,6 +1463,64 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
     };
     int zz = z0 > 0 ? -1 : 0;
     const int zend = d2 - z0 < (uint32_t)MARCH_TZ ? (int)(d2 - z0) : MARCH_TZ;
+    if constexpr (SAMP) {
+        // the sampled book (see narrow16_task): the planes coded before it arrived get their segment sums from the codes they stored
+        uint8_t *const lt = const_cast<uint8_t *>(c.s_len);
+        auto put_len = [&](uint32_t b, uint32_t len) { lt[b] = (uint8_t)len; };
+        auto catch_up = [&](int zhi) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            constexpr int PB = 4;
+            for (int p0 = 0; p0 < zhi; p0 += PB) {
+                uint32_t cw[PB][TY];
+#pragma unroll
+                for (int j = 0; j < PB; j++) {
+                    const uint64_t gp = (uint64_t)(z0 + (uint32_t)(p0 + j)) * c.plane;
+#pragma unroll
+                    for (int r = 0; r < TY; r++) {
+                        const uint32_t ry = y0 + (uint32_t)r;
+                        cw[j][r] = 0;
+                        if (p0 + j < zhi && ry < d1 && xok)
+                            cw[j][r] = __hip_atomic_load(reinterpret_cast<uint32_t *>(c.codes8 + gp + (uint64_t)ry * d0 + x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < PB; j++) {
+                    const uint64_t gp = (uint64_t)(z0 + (uint32_t)(p0 + j)) * c.plane;
+                    if (p0 + j < zhi)
+#pragma unroll
+                    for (int k = 0; k < (TY + 1) / 2; k++) {
+                        uint32_t packed = 0;
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const uint32_t ry = y0 + 2u * k + h;
+                            if (2 * k + h < TY && ry < d1 && xok) {
+                                const uint32_t wd = cw[j][(2 * k + h) < TY ? 2 * k + h : 0];
+                                const uint32_t b4 = (uint32_t)c.s_len[wd & 0xFFu] + c.s_len[(wd >> 8) & 0xFFu] + c.s_len[(wd >> 16) & 0xFFu] + c.s_len[wd >> 24];
+                                packed |= h ? b4 << 16 : b4;
+                            }
+                        }
+                        const uint32_t tot = wave_sum(packed);
+                        const uint32_t ra = y0 + 2u * k, rb = ra + 1u;
+                        if (lane == 0) {
+                            const uint64_t g0 = gp + x0;
+                            if (ra < d1) c.seg_bits[(g0 + (uint64_t)ra * d0) >> 8] = (uint16_t)(tot & 0xFFFFu);
+                            if (2 * k + 1 < TY && rb < d1) c.seg_bits[(g0 + (uint64_t)rb * d0) >> 8] = (uint16_t)(tot >> 16);
+                        }
+                    }
+                }
+            }
+        };
+        for (; zz < zend; zz++) {
+            fetch(zz, pa);
+            work(zz, pa);
+            if (!c.have_len && zz >= 0 && samp_poll(c, false, put_len)) catch_up(zz + 1);
+        }
+        if (!c.have_len) {
+            samp_poll(c, true, put_len);
+            catch_up(zend);
+        }
+        return;
+    }
     if (NARROW_PF) {
         NarrowPlane<T, NW, TY> pb;
         fetch(zz, pa);
@@ -1435,7 +1542,7 @@ __device__ __forceinline__ void narrow_task(NarrowCtx<T> &c, const Lattice<T> &l
         }
     }
 }
-template <typename T, int NDIM, int TY, bool FUSE = false>
+template <typename T, int NDIM, int TY, bool FUSE = false, bool SAMP = false>
 __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t *__restrict__ codes, const szk_k1_params &p, uint32_t ntasks,
                                              uint32_t *lh, uint8_t *s_len, uint64_t (*s_oq_idx)[MarchLds<1, false>::OQ],
                                              typename NarrowCtx<T>::OQV (*s_oq_val)[MarchLds<1, false>::OQ],
@@ -1458,7 +1565,7 @@ __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t 
     c.oq_n = 0;
     // bit accounting: the code-length table of the context's previous book, by stored byte; only for rows cut into whole
     // 256-element segments (x extent a multiple of 256: a segment then never straddles two chunks of the packer)
-    const bool acct = !FUSE && p.spec_lens != nullptr && c.d0 % MARCH_TX == 0;
+    const bool acct = SAMP || (!FUSE && p.spec_lens != nullptr && c.d0 % MARCH_TX == 0);  // (the sampled form is launched for rows of whole segments only)
     c.s_len = acct ? s_len : nullptr;
     c.seg_bits = p.seg_bits;
     c.s_enc = s_fenc;
@@ -1466,7 +1573,13 @@ __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t 
     c.slot = nullptr;
     c.slot_w = c.slot_base = c.st_cnt = 0;
     c.seg_base = p.seg_base;
+    c.samp_words = p.samp.words;
+    c.s_have = lh + NARROW_BINS * 4;
+    c.have_len = 0;
+    // (sampled form: the launch's first SZK_SAMP_ROLES workgroups take the sample; the workers are numbered behind them)
+    const uint32_t bid = SAMP ? blockIdx.x - SZK_SAMP_ROLES : blockIdx.x, grid = SAMP ? gridDim.x - SZK_SAMP_ROLES : gridDim.x;
     for (int i = threadIdx.x; i < NARROW_BINS * 4; i += 256) lh[i] = 0;
+    if (threadIdx.x == 0) lh[NARROW_BINS * 4] = 0;
     if constexpr (FUSE) {
         // the previous call's book by stored byte (255 = a listed delta: symbol 0). A book this form cannot use (code words beyond 16
         // bits) becomes a table of zero lengths and raises the flag; a single-symbol book has zero-length code words: nothing is emitted,
@@ -1483,16 +1596,16 @@ __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t 
     }
     if (acct) {
         const uint32_t b = threadIdx.x;  // 256 threads, 256 byte values; 255 = the delta outliers' symbol 0
-        s_len[b] = p.spec_lens[b == 255u ? 0u : b + p.radius - 127u];
-        if (blockIdx.x == 0 && threadIdx.x == 0) *p.seg_made = 1u;  // (the host assumed this form would run: the packer's book role checks)
+        s_len[b] = SAMP ? (uint8_t)0 : p.spec_lens[b == 255u ? 0u : b + p.radius - 127u];
+        if (bid == 0 && threadIdx.x == 0) *p.seg_made = 1u;  // (the host assumed this form would run: the packer's book role checks)
     }
     __syncthreads();
 
     const uint32_t ntx = (c.d0 + MARCH_TX - 1) / MARCH_TX, nty = (c.d1 + TY - 1) / TY, ntz = (c.d2 + MARCH_TZ - 1) / MARCH_TZ;
     // XCD-aware task order (see march_body)
-    const uint32_t per_xcd = gridDim.x / 8u;
-    const uint32_t wg_seq = gridDim.x % 8u == 0 && !(p.dbg & 4096u) ? (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : blockIdx.x;
-    const uint32_t nwaves = gridDim.x * 4u;
+    const uint32_t per_xcd = grid / 8u;
+    const uint32_t wg_seq = grid % 8u == 0 && !(p.dbg & 4096u) ? (bid % 8u) * per_xcd + bid / 8u : bid;
+    const uint32_t nwaves = grid * 4u;
     for (uint32_t task = wg_seq * 4 + wv; task < ntasks; task += nwaves) {
         uint32_t b = task;
         const uint32_t x0 = (b % ntx) * MARCH_TX;
@@ -1506,8 +1619,8 @@ __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t 
             c.slot = p.fuse_slots + c.slot_base;
             c.slot_w = 0;
         }
-        if (x0 + MARCH_TX <= c.d0 && y0 + TY <= c.d1) narrow_task<T, NDIM, TY, false, FUSE>(c, lat, x0, y0, z0, w);
-        else narrow_task<T, NDIM, TY, true, FUSE>(c, lat, x0, y0, z0, w);
+        if (x0 + MARCH_TX <= c.d0 && y0 + TY <= c.d1) narrow_task<T, NDIM, TY, false, FUSE, SAMP>(c, lat, x0, y0, z0, w);
+        else narrow_task<T, NDIM, TY, true, FUSE, SAMP>(c, lat, x0, y0, z0, w);
         if constexpr (FUSE) {  // the task's last words (less than a line)
             c.st_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.st_cnt);
             if (c.st_cnt) {  // (the last plane's words, whole lines and the rest)
@@ -1518,6 +1631,7 @@ __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t 
         }
     }
     narrow_oq_flush(c);
+    if (SAMP) return;  // (no histogram rows)
     __syncthreads();
     // the workgroup's counts go to its private row of hist_partial (k_hist_reduce folds the rows): bin t = symbol t + radius - 127
     uint32_t *row = p.hist_partial + (uint64_t)blockIdx.x * HIST_WIN;
@@ -1547,52 +1661,6 @@ __device__ __forceinline__ void march_narrow(const T *__restrict__ in, uint16_t 
 //   * the code-length table of the speculative bit accounting is laid out like the histogram ([byte][4 copies]): a code's
 //     histogram address is also the address of its length.
 // ------------------------------------------------------------------------------------------------------------
-// (always inlined, the kernel's parameters handed over piecemeal: a call would put the caller's parameter block on a stack, and a kernel
-// with a stack pays for it in every wave)
-template <typename T> __device__ __forceinline__ bool samp_take(const T *__restrict__ in, const szk_lattice &latp, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t *words, uint32_t role, uint32_t *s_h);
-__device__ __forceinline__ void samp_book(const szk_samp &sp, uint32_t radius, uint8_t *pool);
-#define SAMP_POOL_BYTES (SZK_CB_SMALL_SYMS * 28 + 256)
-// a worker's wave looks for the sampled book (spin: waits for it) and, once it is there, fills ITS view of the workgroup's length table
-// (all four waves write the same values): `put(byte value, length)` stores one entry in the form's layout
-template <typename T, typename PUT>
-__device__ __forceinline__ bool samp_poll(NarrowCtx<T> &c, bool spin, PUT put) {
-    // Wave 0 of the workgroup asks the device-wide word (a load past the L2s: all workers asking would be a billion requests a second to
-    // one memory channel — the one the sampling workgroups' atomics go to), fills the workgroup's table and raises the workgroup's LDS
-    // word; the other waves watch that. Wave 0 leaves a task only with the book in hand, so the LDS word is raised before it exits.
-    volatile uint32_t *s_have = c.lh + NARROW_BINS * 8;
-    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-    if (wv != 0) {
-        uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_have);
-        if (!h) {
-            if (!spin) return false;
-            do {
-                __builtin_amdgcn_s_sleep(16);
-                h = (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_have);
-            } while (!h);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        c.have_len = 1;
-        return true;
-    }
-    uint32_t r = __hip_atomic_load(const_cast<uint32_t *>(c.samp_words) + SZK_SAMP_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-    if (!r) {
-        if (!spin) return false;
-        do {
-            __builtin_amdgcn_s_sleep(32);
-            r = __hip_atomic_load(const_cast<uint32_t *>(c.samp_words) + SZK_SAMP_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-        } while (!r);
-    }
-    const uint32_t w = __hip_atomic_load(const_cast<uint32_t *>(c.samp_words) + SZK_SAMP_LENS + c.lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int j = 0; j < 4; j++) put(4u * (uint32_t)c.lane + j, (w >> (8 * j)) & 0xFFu);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (c.lane == 0) *s_have = 1u;
-    c.have_len = 1;
-    return true;
-}
 #define Q16_LIM 4095.0f
 typedef float v2f32 __attribute__((ext_vector_type(2)));
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
@@ -1894,6 +1962,7 @@ __device__ __forceinline__ void march_narrow16(const float *__restrict__ in, uin
     c.slot_w = c.slot_base = c.st_cnt = 0;
     c.seg_base = p.seg_base;
     c.samp_words = p.samp.words;
+    c.s_have = lh + NARROW_BINS * 8;
     c.have_len = 0;
     // (sampled form: the launch's first SZK_SAMP_ROLES workgroups take the sample; the workers are numbered behind them)
     const uint32_t bid = SAMP ? blockIdx.x - SZK_SAMP_ROLES : blockIdx.x, grid = SAMP ? gridDim.x - SZK_SAMP_ROLES : gridDim.x;
@@ -1964,18 +2033,29 @@ __global__ __launch_bounds__(256) void k_lorenzo_quant_march(const T *__restrict
 #else
 #define MARCH3_ATTR
 #endif
-template <typename T, int NDIM, int TY>
+template <typename T, int NDIM, int TY, bool SAMP = false>
 __global__ __launch_bounds__(256) MARCH3_ATTR void k_lorenzo_quant_march3(const T *__restrict__ in, uint16_t *__restrict__ codes,
                                                               szk_k1_params p, uint32_t ntasks, uint32_t nrows) {
     using L = MarchLds<1, false>;
     using OQV = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;
-    __shared__ uint32_t lh[NARROW_BINS * 4 + 4];
+    constexpr int LH_WORDS = SAMP && (SAMP_POOL_BYTES + 3) / 4 > NARROW_BINS * 4 + 4 ? (SAMP_POOL_BYTES + 3) / 4 : NARROW_BINS * 4 + 4;
+    __shared__ __align__(16) uint32_t lh[LH_WORDS];
     __shared__ uint64_t s_oq_idx[4][L::OQ];
     __shared__ OQV s_oq_val[4][L::OQ];
     __shared__ uint8_t s_len[256];
     __shared__ uint32_t s_p[4];
+    if constexpr (SAMP) {  // the sampled book inside the launch (see k_lorenzo_quant_march3q)
+        static_assert(NDIM == 3, "1-D ... 3-D arrays");
+        if (blockIdx.x < SZK_SAMP_ROLES) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) p.samp.info->ts[9] = wall_clock64();
+            if (samp_take<T>(in, p.lat, (uint32_t)p.d[3], (uint32_t)p.d[2], (uint32_t)p.d[1], p.samp.words, blockIdx.x, lh)) samp_book(p.samp, p.radius, reinterpret_cast<uint8_t *>(lh));
+            __syncthreads();
+            probe_body<T, NDIM>(in, p, p.mode.n_total, p.mode.probe_big, s_p);
+            return;
+        }
+    }
     probe_body<T, NDIM>(in, p, p.mode.n_total, p.mode.probe_big, s_p);
-    march_narrow<T, NDIM, TY>(in, codes, p, ntasks, lh, s_len, s_oq_idx, s_oq_val);
+    march_narrow<T, NDIM, TY, false, SAMP>(in, codes, p, ntasks, lh, s_len, s_oq_idx, s_oq_val);
 }
 // The 16-bit form of the one-launch kernel (round 5, narrow16_task): f32 data whose lattice values the previous call's probe found
 // within +-Q16_LIM / 2. It assumes one-byte codes like the form above AND lattice values within +-Q16_LIM; a value beyond that
@@ -6068,6 +6148,16 @@ static void launch_march_w(const void *d_in, uint16_t *codes, szk_k1_params &p, 
                     grid = k1_grid((const void *)k_lorenzo_quant_march3q<TY, false>, (nb + 3) / 4);
                     hipLaunchKernelGGL((k_lorenzo_quant_march3q<TY, false>), dim3(grid), dim3(256), 0, s, (const float *)d_in, codes, p, (uint32_t)nb, grid);
                 }
+            }
+        } else if (NDIM == 3 && sizeof(T) == 4 && p.samp.words && p.d[0] == 1 && !(szk_dbg_flags & 4194304)) {
+            // (f32 only: the f64 kernel with the sampling code inlined needs a stack — 20 bytes a lane, paid by every wave — and runs at
+            // three waves per SIMD as it is; f64 streams get their sampled book from k_sample behind the launch)
+            if constexpr (NDIM == 3 && sizeof(T) == 4) {  // the one-byte kernel with the sampling workgroups in front (as the 16-bit form above)
+                p.samp_in_launch = 1;
+                p.seg_expected = 1;
+                grid = k1_grid((const void *)k_lorenzo_quant_march3<T, 3, TY, true>, (nb + 3) / 4);
+                hipLaunchKernelGGL((k_lorenzo_quant_march3<T, 3, TY, true>), dim3(grid + SZK_SAMP_ROLES), dim3(256), 0, s, (const T *)d_in, codes, p, (uint32_t)nb, grid);
+                grid = 0;  // (no histogram rows)
             }
         } else {
             grid = k1_grid((const void *)k_lorenzo_quant_march3<T, NDIM, TY>, (nb + 3) / 4);

@@ -147,3 +147,30 @@ def test_a_value_beyond_the_16_bit_form_repeats_the_call_with_the_same_book():
     assert not dc.q16
     assert _decode_ok(dc, got, tb, eb)
     assert got == _run(sz3_amd.DeviceCompressor(a.size, a.dtype), tb, conf, cap, pl)
+
+
+def test_escape_symbol_field_of_the_header_is_checked():
+    """the payload header's anchor_stride field of a Lorenzo stream names the symbol that stands for a listed delta: a value outside the
+    lengths' table is refused, 0 (= symbol 0 itself) on a stream that was written with an escape symbol decodes to garbage-free refusal or
+    to an array — never to a fault"""
+    import struct
+    dev = torch.device("cuda:0")
+    a = _spiky((64, 256, 256), 30)
+    eb = 1e-3
+    conf = _conf(a.shape, eb)
+    t = torch.from_numpy(a).to(dev)
+    dc = sz3_amd.DeviceCompressor(a.size, a.dtype)
+    cap = dc.payload_bound(a.size, worst_case=True)
+    pl = torch.empty(cap, dtype=torch.uint8, device=dev)
+    blob = bytearray(_run(dc, t, conf, cap, pl))
+    h, _, _ = szh_ref.parse(np.frombuffer(bytes(blob), dtype=np.uint8))
+    if not h["esc_sym"]:
+        pytest.skip("the field took two-byte codes: no sampled book")
+    for bad in (h["sym_min"] - 1, h["sym_min"] + h["sym_count"], 70000, 1 << 40):
+        b2 = bytearray(blob)
+        struct.pack_into("<Q", b2, 152, bad)
+        d_pl = torch.from_numpy(np.frombuffer(bytes(b2), dtype=np.uint8).copy()).to(dev)
+        out = torch.empty_like(t)
+        with pytest.raises(sz3_amd.SZ3HipError):
+            dc.decompress(d_pl.data_ptr(), len(b2), out.data_ptr(), 0)
+    assert _decode_ok(dc, bytes(blob), t, eb)  # (the context is in working order afterwards)

@@ -244,7 +244,15 @@ void sz3hip_ctx_set_speculation(sz3hip_ctx *ctx, int off);
  * arrays keeps the shortcut, and a payload then depends on what the context coded before (its size by < 0.1 %, its decoded
  * values not at all). sz3hip_ctx_set_deterministic(ctx, 1): the previous book stands only when it IS this call's book — the
  * payload is a pure function of the input again (what the host API — sz3hip_compress, the CLI, the HDF5 filter — always sets;
- * the reference builds a tree per call, encoder/HuffmanEncoder.hpp:96-105). Default of a device context: 0. */
+ * the reference builds a tree per call, encoder/HuffmanEncoder.hpp:96-105). Default of a device context: 0.
+ * Round 6: the streams this mattered most for no longer speculate at all. A Lorenzo stream (ALGO_LORENZO_REG with Lorenzo-1 alone,
+ * ALGO_NOPRED) of an array of at least 2^22 elements in rows of whole 256-element segments (1-D ... 3-D) that turns out to have
+ * one-byte codes is coded with a book built from a SAMPLE of the array (262 144 values at places the extents alone decide) — inside
+ * stage 1's own launch once the context knows the stream's form, by a launch of its own otherwise. Sample and book are functions of
+ * the input: such a payload is the same whatever the context coded before and whatever this switch says, in the time the speculative
+ * path took on a hit (512^3 f32: 0.24 ms either way; 0.30 ms with this switch on before). Not for contexts whose histogram is
+ * exchanged between the stages (sz3hip_histogram_ptr / sz3hip_ctx_set_histogram: the ranks share one book from the summed histogram).
+ * The payload header's anchor_stride field of such a stream names the symbol that stands for a listed delta (sz3hip_format.h). */
 void sz3hip_ctx_set_deterministic(sz3hip_ctx *ctx, int on);
 /* Round 5: the ALGO_INTERP_LORENZO tuner's trials priced the reference's way. By default a trial is priced on the device from the
  * histogram of its codes (entropy + a model of the serialised tree: 0.2 ms per tuning, the reference's decision in about three of four

@@ -2209,7 +2209,9 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
     if (*ctx->h_ovf) ctx->half_skip = 8;  // that stream's values did not fit: the next calls go straight to full width
     else if (ctx->half_skip > 0) ctx->half_skip--;
     h = ctx->h_state->hdr;
-    if (h.magic != SZH_MAGIC || h.version != SZH_VERSION) return fail(SZ3HIP_EFORMAT, "not an SZH1 payload");
+    if (h.magic != SZH_MAGIC || (h.version != SZH_VERSION && h.version != SZH_VERSION_ESC)) return fail(SZ3HIP_EFORMAT, "not an SZH1 payload");
+    if ((h.version == SZH_VERSION_ESC) != (h.predictor == 0 && h.anchor_stride != 0))  // (version 5 = version 4 + a Lorenzo stream's escape symbol)
+        return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (version / escape symbol)");
     if (h.predictor > 2) return fail(SZ3HIP_EFORMAT, "unknown predictor id %d in the SZH1 header", h.predictor);
     if (h.predictor != 2 && h.side_bytes) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (side section)");
     if (h.side_bytes > payload_size) return fail(SZ3HIP_EFORMAT, "corrupt SZH1 header (side section)");

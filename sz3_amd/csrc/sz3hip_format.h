@@ -5,6 +5,11 @@
 //
 //   header (160 B, struct szh_header)
 //   lens       u8  [sym_count]      canonical-Huffman code length of symbol sym_min+i (0 = absent)   pad to 16
+//                                   (symbols: code = delta + radius; symbol 0 = a listed delta / an unpredictable point. A Lorenzo stream
+//                                   — predictor 0 — may name ANOTHER symbol as the stand-in of symbol 0, header.anchor_stride != 0: the
+//                                   sampled books of round 6 code a listed delta as symbol radius + 128, so that the table spans the 256
+//                                   symbols radius - 127 .. radius + 128 instead of 0 .. radius + 127; canonical code words are assigned
+//                                   over the stored symbols, the decoder's tables map the stand-in back to symbol 0)
 //   chunkwords u16 [n_chunks]       32-bit words used by chunk c (chunks of chunk_syms symbols)      pad to 16
 //   subbits    u16 [n_chunks]       bit offset, from the chunk's start, of its symbol 512: the decoder's restart point (a chunk
 //                                   is decoded by two lanes, not one: the serial chain of table lookups per lane bounds the
@@ -28,12 +33,15 @@
 
 #define SZH_MAGIC 0x31485A53u /* "SZH1" */
 #define SZH_VERSION 4u /* 3: bit-stream bytes in stream order; side section (predictor 2); 4: restart offsets inside the chunks */
+#define SZH_VERSION_ESC 5u /* version 4 + a Lorenzo stream whose header names a stand-in for symbol 0 (anchor_stride != 0; round 6's sampled books).
+                            * Every other stream is still written as version 4; a decoder of round 6 reads both, an earlier one refuses 5 by name */
 #define SZH_CHUNK_SYMS 1024u
 #ifndef SZH_SUBS
 #define SZH_SUBS 2u /* units per chunk: a unit starts at the chunk's start or at a restart offset */
 #endif
 #define SZH_UNIT_SYMS (SZH_CHUNK_SYMS / SZH_SUBS) /* symbols a lane of the decoder walks through */
-#define SZH_MAX_LEN 24u /* longest code word; alphabets <= 512 symbols are limited to 16 (4 words per 64-bit register in the packer) */
+#define SZH_MAX_LEN 24u /* longest code word; alphabets <= 512 symbols are limited to 16 (4 words per 64-bit register in the packer) — but a sampled book's
+                           values the sample did not meet: class prefix (<= 16) + index (<= 8) */
 #define SZH_HIST_BINS 65536u
 
 typedef struct szh_header {
@@ -55,7 +63,8 @@ typedef struct szh_header {
      * (decomposition/InterpolationDecomposition.hpp:149-159) */
     double interp_alpha, interp_beta;
     uint32_t interp_id, interp_dir; /* predictor == 2: block edge, enabled predictors (1 Lorenzo-1 | 2 Lorenzo-2 | 4 regression) */
-    uint64_t anchor_stride;
+    uint64_t anchor_stride; /* predictor == 1: the anchor stride; predictor == 0: the symbol that stands for symbol 0 in the lengths' table
+                             * (0 = symbol 0 itself; else a symbol inside [sym_min, sym_min + sym_count)) */
 } szh_header;
 
 #ifdef __cplusplus

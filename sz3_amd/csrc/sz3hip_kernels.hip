@@ -3349,6 +3349,9 @@ __device__ __forceinline__ void samp_book(const szk_samp &sp, uint32_t radius, u
     if (w) keys[r] = mykey;
     __syncthreads();
     if (t == 0) sp.info->ts[3] = wall_clock64();
+    // (cb_small's wave merge: the queues' windows in registers, read with v_readlane. A branch-free form of it — the registers picked by
+    // selects on scalar conditions, every pick compare / select / add on the scalar unit — was built in round 6 and is SLOWER: 20 against
+    // 14 us for C2's 147 symbols; the scalar unit's hand-overs to and from the vector unit cost more than the branches they replace)
     if (t < WAVE) cb_merge_wave32(keys, reinterpret_cast<uint32_t *>(ifreq), pleaf, pint, m);  // (weights < 2^32: 2^20 sampled values)
     __syncthreads();
     if (t == 0) sp.info->ts[4] = wall_clock64();
@@ -3680,7 +3683,10 @@ __device__ void layout_pre(const szk_layout_params &p) {  // after K1 + K5, befo
     h.sym_min = p.info->sym_min;
     h.sym_count = p.info->sym_count;
     h.max_len = p.info->max_len;
-    if (h.predictor == 0) h.anchor_stride = p.info->esc_sym;  // (Lorenzo streams: the symbol that stands for a listed delta, 0 = symbol 0 itself; sz3hip_format.h)
+    if (h.predictor == 0 && p.info->esc_sym) {  // (Lorenzo streams: the symbol that stands for a listed delta, 0 = symbol 0 itself; sz3hip_format.h)
+        h.anchor_stride = p.info->esc_sym;
+        h.version = SZH_VERSION_ESC;
+    }
     h.side_bytes = p.side_bytes ? *p.side_bytes : 0;
     h.bitstream_words = 0;
     szh_offsets o;

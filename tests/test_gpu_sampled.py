@@ -82,6 +82,7 @@ def test_every_form_of_stage_1_writes_the_same_payload(name, gen, eb):
     if name == "f32-listed-many":
         assert h["n_dout"] > 2048, h["n_dout"]
     assert h["esc_sym"] == h["radius"] + 128 and h["sym_min"] == h["radius"] - 127 and h["sym_count"] == 256, (h["esc_sym"], h["sym_min"], h["sym_count"])
+    assert h["version"] == 5  # (version 4 + the escape symbol)
     assert _decode_ok(dc, first, t, eb)
     warm = [_run(dc, t, conf, cap, pl) for _ in range(3)]  # the one-launch forms (f32: the 16-bit form with the sampling workgroups inside)
     for k, w in enumerate(warm):
@@ -100,7 +101,7 @@ def test_every_form_of_stage_1_writes_the_same_payload(name, gen, eb):
     exact = _run(sz3_amd.DeviceCompressor(n, a.dtype), t, conf, cap, pl, NO_SAMPLE)
     assert len(first) <= len(exact) * 1.002, (len(first), len(exact))
     h2, _, _ = szh_ref.parse(np.frombuffer(exact, dtype=np.uint8))
-    assert h2["esc_sym"] == 0
+    assert h2["esc_sym"] == 0 and h2["version"] == 4
 
 
 def test_sampled_payload_through_the_format_model():
@@ -166,7 +167,7 @@ def test_escape_symbol_field_of_the_header_is_checked():
     h, _, _ = szh_ref.parse(np.frombuffer(bytes(blob), dtype=np.uint8))
     if not h["esc_sym"]:
         pytest.skip("the field took two-byte codes: no sampled book")
-    for bad in (h["sym_min"] - 1, h["sym_min"] + h["sym_count"], 70000, 1 << 40):
+    for bad in (0, h["sym_min"] - 1, h["sym_min"] + h["sym_count"], 70000, 1 << 40):
         b2 = bytearray(blob)
         struct.pack_into("<Q", b2, 152, bad)
         d_pl = torch.from_numpy(np.frombuffer(bytes(b2), dtype=np.uint8).copy()).to(dev)

@@ -267,7 +267,7 @@ extern "C" sz3hip_ctx *sz3hip_ctx_create(int device, uint64_t max_elems, int dat
     sz3hip_ctx *c = new sz3hip_ctx();
     memset(c, 0, sizeof(*c));
     c->wide16 = -1;
-    c->narrow_hint = c->cb_hint = -1;
+    c->narrow_hint = c->cb_hint = c->cb_part = -1;
     c->q16_hint = c->q16_block = 0;
     c->device = device;
     c->dtype = dataType;
@@ -509,7 +509,7 @@ static void cb_params_from(sz3hip_ctx *ctx, szk_cb_params &cb, uint64_t out_cap,
     cb.info = ctx->bk[slot].info;
     cb.n_books = 1;
     cb.range_ready = ctx->range_ready && !ctx->hist_exposed && !ctx->hist_reduced;
-    cb.part_hint = (szk_dbg_flags & 131072) ? -1 : ctx->cb_hint;
+    cb.part_hint = (szk_dbg_flags & 131072) ? -1 : ctx->cb_part;
     cb.mispredict = reinterpret_cast<uint32_t *>(ctx->d_counters + 7);  // (zeroed with the counters)
 }
 
@@ -717,7 +717,7 @@ static int stage1_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void
 // (make_compressor_lorenzo_regression, api/impl/SZAlgoLorenzoReg.hpp:22-64) ----
 static int blk_reserve_select(sz3hip_ctx *ctx, uint64_t nblocks) {  // (all the selection pass needs: counters, choices, coefficients)
     if (!ctx->d_blk_counters) HIPCHK(hipMalloc((void **)&ctx->d_blk_counters, 64 + 4 * (0x7FFFFFF0ull / 8192 + 2)));
-    if (!ctx->d_blk_stats5) HIPCHK(hipMalloc((void **)&ctx->d_blk_stats5, 64));
+    if (!ctx->d_blk_stats5) HIPCHK(hipMalloc((void **)&ctx->d_blk_stats5, 128));
     if (!ctx->h_blk_side_hdr) HIPCHK(hipHostMalloc((void **)&ctx->h_blk_side_hdr, 64));
     if (ctx->blk_sel_cap >= nblocks) return 0;
     void **arr[2] = {(void **)&ctx->d_blk_sel, (void **)&ctx->d_blk_coef};
@@ -790,6 +790,7 @@ static void blk_params_from(sz3hip_ctx *ctx, int ndim, const uint64_t *dims3, ui
 // bits (2 per block: more than those few blocks save) are not stored. The few blocks take the reference's own fallback
 // predictor (BlockwiseDecomposition.hpp:35-37). One 8-byte read-back and a stream synchronisation decide.
 #define BLK_EXIT_SHIFT 12
+static inline uint64_t *blk_sel_count(sz3hip_ctx *ctx) { return reinterpret_cast<uint64_t *>(ctx->d_blk_stats5) + 8; }
 static int blk_all_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, double eb, int radius, uint32_t mask, hipStream_t s, bool *all) {
     *all = false;
     ctx->blk_sel_given = false;
@@ -810,9 +811,12 @@ static int blk_all_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const voi
     szk_blk_params bp;
     szk_blk_scratch sc;
     blk_params_from(ctx, conf->N, d3, B, mask, eb, radius, ctx->cur_out_cap, bp, sc);
-    HIPCHK(hipMemsetAsync(ctx->d_blk_counters + 7, 0, 8, s));
+    // (the count has a word of its own behind the Rice statistics: the counter block's eighth word is the fourth coefficient's statistic,
+    // which a block stream's stage 1 adds up AFTER this pass — the speculative form below reads the count at the call's end)
+    uint64_t *sel_cnt = blk_sel_count(ctx);
+    if (!ctx->blk_cleared_now) HIPCHK(hipMemsetAsync(sel_cnt, 0, 8, s));  // (else: k_publish zeroed it behind the previous call)
     prof_begin(ctx, ST_TUNER, s);
-    rc = szk_launch_blk_select(ctx->dtype, d_in, &bp, ctx->d_blk_counters + 7, s);
+    rc = szk_launch_blk_select(ctx->dtype, d_in, &bp, sel_cnt, s);
     prof_end(ctx, ST_TUNER, s);
     if (rc) return fail(SZ3HIP_EHIP, "block selection kernel launch failed (%d)", rc);
     ctx->blk_sel_given = true;  // (the choices and coefficients are in d_blk_sel / d_blk_coef: the fit pass codes what they say)
@@ -832,7 +836,7 @@ static int blk_all_lorenzo(sz3hip_ctx *ctx, const sz3hip_config *conf, const voi
         *all = ctx->blk_dec_all;
         return 0;
     }
-    HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr, ctx->d_blk_counters + 7, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ctx->h_blk_side_hdr, sel_cnt, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     uint64_t others;
     memcpy(&others, ctx->h_blk_side_hdr, 8);
@@ -858,8 +862,11 @@ static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
     blk_params_from(ctx, conf->N, d3, B, mask, eb, radius, ctx->cur_out_cap, bp, sc, dw);
     bp.sel_given = ctx->blk_sel_given ? 1u : 0u;
     sc.wide_hist = ctx->blk_wide;
-    HIPCHK(hipMemsetAsync(ctx->d_blk_counters, 0, 64, s));
-    HIPCHK(hipMemsetAsync(ctx->d_blk_stats5, 0, 64, s));
+    if (!ctx->blk_cleared_now) {  // (else: zeroed behind the previous call by its k_publish, on this stream)
+        HIPCHK(hipMemsetAsync(ctx->d_blk_counters, 0, 64, s));
+        HIPCHK(hipMemsetAsync(ctx->d_blk_stats5, 0, 64, s));
+    }
+    ctx->blk_cleared_now = false;
     prof_begin(ctx, ST_K1, s);
     rc = szk_launch_blk_compress(ctx->dtype, d_in, ctx->d_codes, &bp, &sc, s);
     prof_end(ctx, ST_K1, s);
@@ -1463,6 +1470,8 @@ extern "C" int sz3hip_compress_stage1(sz3hip_ctx *ctx, const sz3hip_config *conf
     ctx->range_ready = false;
     ctx->s1_spec = ctx->seg_expected = ctx->s1_assumed_narrow = ctx->s1_fused = ctx->s1_samp = ctx->s1_samp_in = false;
     ctx->blk_spec = false;
+    ctx->blk_cleared_now = ctx->blk_pre_cleared && ctx->blk_pre_stream == s && !ctx->hist_exposed;  // (this call only: whatever follows starts from memsets again)
+    ctx->blk_pre_cleared = false;
     ctx->fold_rows = 0;
     ctx->s1_conf = *conf_in;
     ctx->s1_in = d_in;
@@ -1629,7 +1638,7 @@ extern "C" int sz3hip_compress_stage2(sz3hip_ctx *ctx, void *d_payload, size_t c
     // (Lists too long for the packer's sort roles — C3's 4096 anchors — were tried with a sort launch of their own in front of the
     // encoder: C3 1.253 against 1.247 ms without, 1.33 with alternating fields. Not taken.)
     // (Not for block streams: their side section is copied by the assembly's list workgroups, which the sort roles replace.)
-    const bool spec_wide = !spec && book_spec_ok(ctx, ctx->proto.predictor, ctx->proto.radius) && ctx->cb_hint == 1 && !ctx->lists_long &&
+    const bool spec_wide = !spec && book_spec_ok(ctx, ctx->proto.predictor, ctx->proto.radius) && ctx->cb_part == 1 && !ctx->lists_long &&
                            ctx->proto.predictor != 2 && !(szk_dbg_flags & 4096);
     if (ctx->s1_fused && !spec) {
         // (cannot happen: the fused stage 1 is taken under the conditions of this stage's one-stream form; should they ever drift apart,
@@ -1793,8 +1802,10 @@ static int stage2_launch(sz3hip_ctx *ctx, void *d_payload, size_t cap, hipStream
     // in one small launch behind the packer's (k_publish); finish() polls the sequence word
     ctx->pub_zero = ctx->d_hist == ctx->d_hist_own && !ctx->hist_exposed && !(szk_dbg_flags & 268435456);
     ctx->pub_seq++;
+    ctx->pub_blk_zero = ctx->pub_zero && ctx->d_blk_counters && ctx->d_blk_stats5;
     if (szk_launch_publish(ctx->d_state, ctx->h_state, ctx->h_pub_seq, ctx->pub_seq, ctx->pub_zero ? (void *)ctx->d_hist : nullptr,
-                           SZH_HIST_BINS * 8 + SZ_COUNTER_BYTES, s, ctx->blk_spec ? ctx->d_blk_counters + 7 : nullptr))
+                           SZH_HIST_BINS * 8 + SZ_COUNTER_BYTES, s, ctx->blk_spec ? blk_sel_count(ctx) : nullptr,
+                           ctx->pub_blk_zero ? (void *)ctx->d_blk_counters : nullptr, ctx->pub_blk_zero ? ctx->d_blk_stats5 : nullptr))
         return fail(SZ3HIP_EHIP, "publish kernel launch failed");
     ctx->pub_stream = s;
     // (h_state->probe = the probe counters: |delta| > 127, in [4096, 8192), in [2048, 4096); [4] = interpolation codes beyond +-4096)
@@ -1855,7 +1866,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
             ctx->q16_hint = 0;
             ctx->q16_block = 16;
         }
-        if (ctx->h_state->mispredict || (ctx->h_state->miss_kind & 2u)) ctx->cb_hint = -1;
+        if (ctx->h_state->mispredict || (ctx->h_state->miss_kind & 2u)) ctx->cb_hint = ctx->cb_part = -1;
         const int spec_was = ctx->spec_off;
         ctx->spec_off = 1;
         sz3hip_config conf = ctx->s1_conf;
@@ -1875,7 +1886,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
             const uint32_t kind = ctx->h_state->miss_kind;
             const bool redo_book = (kind & (2u | 4u)) != 0;  // no fresh book (form declined) / lists unsorted: stage 2 from its start
             if (redo_book) {
-                if (kind & 2u) ctx->cb_hint = -1;
+                if (kind & 2u) ctx->cb_hint = ctx->cb_part = -1;
                 HIPCHK(hipMemsetAsync(ctx->d_counters + 7, 0, 24, s));  // mispredict flag and the range words (recomputed)
                 ctx->range_ready = false;
             }
@@ -1902,7 +1913,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     if (ctx->h_state->mispredict) {
         // the code-book form launched alone met the other form's alphabet (the data changed character since the previous
         // call): stage 2 once more with both forms; histogram, range words and outlier lists are as stage 1 left them
-        ctx->cb_hint = -1;
+        ctx->cb_hint = ctx->cb_part = -1;
         HIPCHK(hipMemsetAsync(ctx->d_counters + 7, 0, 24, s));  // the flag AND the range words (k_hist_range adds to what it finds: the count doubled, round 5)
         ctx->range_ready = false;
         int rc2 = stage2_launch(ctx, ctx->s2_payload, ctx->s2_cap, s, S2_CLASSIC);
@@ -1916,6 +1927,8 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     if (ctx->pub_zero && ctx->h_state->miss_kind == 0 && ctx->h_state->mispredict == 0) {
         ctx->pre_cleared = true;  // (k_publish did it: the last launch of this call's stage 2 met the same state)
         ctx->pre_stream = ctx->pub_stream;
+        ctx->blk_pre_cleared = ctx->pub_blk_zero;
+        ctx->blk_pre_stream = ctx->pub_stream;
     } else if (ctx->d_hist == ctx->d_hist_own && !ctx->hist_exposed && !(szk_dbg_flags & 268435456)) {
         if (hipMemsetAsync(ctx->d_hist, 0, SZH_HIST_BINS * 8 + SZ_COUNTER_BYTES, s) == hipSuccess) {
             ctx->pre_cleared = true;
@@ -1940,6 +1953,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     ctx->book_radius = st.hdr.radius;
     ctx->lists_long = st.hdr.n_vout > 2048 || st.hdr.n_dout > 2048;  // (what the packer's sort roles take: ROLE_SORT_MAX)
     ctx->cb_hint = st.n_symbols > SZK_CB_SMALL_SYMS ? 1 : 0;
+    ctx->cb_part = szk_cb_part(st.n_symbols, st.hdr.sym_count);
     if (st.hdr.predictor == 2) ctx->blk_wide = st.hdr.sym_count > 3000 ? 1 : 0;  // the block kernels' LDS histogram window of the next call
     ctx->stats.n = st.hdr.n;
     ctx->stats.n_value_outliers = st.hdr.n_vout;
@@ -1948,7 +1962,7 @@ extern "C" int sz3hip_compress_finish(sz3hip_ctx *ctx, size_t *payload_size, voi
     ctx->stats.bitstream_bytes = st.hdr.bitstream_words * 4;
     ctx->stats.payload_bytes = st.hdr.payload_bytes;
     ctx->stats.max_code_len = st.hdr.max_len;
-    ctx->stats.n_symbols = 0;
+    ctx->stats.n_symbols = st.n_symbols;
     ctx->stats.narrow_codes = ctx->mode.allow && (uint64_t)st.probe[0] * 4096ull <= ctx->mode.n_samples;
     if (st.hdr.predictor == 0 && ctx->mode.allow) ctx->narrow_hint = ctx->stats.narrow_codes ? 1 : 0;
     if (st.hdr.predictor == 0 && ctx->mode.allow) {
@@ -2066,7 +2080,7 @@ extern "C" void sz3hip_debug_force_generic(int on) { szk_force_generic = on; }
 // Forget what earlier calls of this context found (kernel forms, histogram windows, the tuner's outcome, the code book): the
 // next call behaves like a context's first. The payload never depends on these; the time does (bench.py's cold numbers).
 extern "C" void sz3hip_ctx_forget(sz3hip_ctx *ctx) {
-    ctx->narrow_hint = ctx->cb_hint = -1;
+    ctx->narrow_hint = ctx->cb_hint = ctx->cb_part = -1;
     ctx->q16_hint = ctx->q16_block = 0;
     ctx->wide16 = -1;
     ctx->pack_wide = ctx->hist_big = ctx->hist_tail = ctx->blk_wide = 0;
@@ -2195,6 +2209,7 @@ extern "C" int sz3hip_decompress_device(sz3hip_ctx *ctx, const void *d_payload, 
                                         void *stream) {
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
+    ctx->blk_pre_cleared = false;  // (a block stream's decoder counts in the same counter block)
     if (payload_size < sizeof(szh_header)) return fail(SZ3HIP_EFORMAT, "payload shorter than its header");
     szh_header h;
     uint32_t *ovf = reinterpret_cast<uint32_t *>(ctx->d_counters + 12);  // overflow flag of the half-width chain (see below)

@@ -84,7 +84,8 @@ struct sz3hip_ctx {
     // block-composed predictor (sz3hip_regress.hip), allocated on first use for the call's block count
     // what the previous call of this context found, so that this call launches one form of a kernel instead of two
     int narrow_hint;   // Lorenzo code width: 1 one byte, 0 two bytes, -1 unknown
-    int cb_hint;       // code book form: 0 small alphabets, 1 wide, -1 unknown
+    int cb_hint;       // the previous call's alphabet: 0 up to SZK_CB_SMALL_SYMS symbols (what the packer's book role takes), 1 wider, -1 unknown
+    int cb_part;       // the code book launch it called for (szk_cb_part): 0 k_codebook<0>, 1 the wide form, -1 unknown
     int q16_hint;      // 1: the previous Lorenzo call's probe saw lattice values within +-Q16_LIM / 2 only (f32): stage 1 may take its 16-bit form
     int q16_block;     // calls left to sit out after that form met a value beyond its range
     bool s1_q16;       // the pending call's stage 1 ran the 16-bit form
@@ -148,7 +149,11 @@ struct sz3hip_ctx {
     uint8_t *d_blk_side;    // szk_blk_side_bound(blk_cap) bytes
     uint64_t *d_blk_counters;  // [8]
     uint8_t *h_blk_side_hdr;   // pinned, 64 bytes
-    void *d_blk_stats5;        // [5] doubles: Rice statistics of a 4-D array's five coefficients
+    void *d_blk_stats5;        // [5] doubles: Rice statistics of a 4-D array's five coefficients (64 bytes), then the selection pass's count (blk_all_lorenzo; 16 bytes)
+    bool blk_pre_cleared;      // the two counter blocks were zeroed behind the previous call (k_publish, with the histogram: pre_cleared / pre_stream)
+    bool pub_blk_zero;         // ... this call's k_publish was given them
+    bool blk_cleared_now;      // ... and this call may rely on it (set at stage 1's entry, consumed by the block predictor's stage 1)
+    hipStream_t blk_pre_stream;
     void *d_half32;            // f64 decoder: int32 intermediates of the half-width chain (max_n * 4 bytes, lazily)
     bool hist_reduced;         // the library's own exchange sums the histogram between the stages (szi_histogram_for_exchange)
     uint64_t blk_sel_cap;      // blocks d_blk_sel / d_blk_coef hold

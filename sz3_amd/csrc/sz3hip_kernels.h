@@ -148,7 +148,14 @@ struct szk_cb_params {
     int skip_sort;         // the launch's two list-sorting workgroups return at once (the lists are sorted elsewhere: speculative stage 2)
     const uint32_t *samp_words;  // non-null: when the words say that this call's sampled book is in its slot, no book is built (the launch sorts the lists only)
 };
-#define SZK_CB_SMALL_SYMS 256  // alphabets up to this size take k_codebook<0>, wider ones <1>
+#define SZK_CB_SMALL_SYMS 256  // alphabets up to this size: the small book with margins, the packer's book role (speculative stage 2), one-byte tables
+// which launch builds a call's book: k_codebook<0> (one workgroup, everything in LDS, no launch in front or behind) for alphabets up to
+// SZK_CB_PART0_SYMS symbols — beyond SZK_CB_SMALL_SYMS only when the occupied range is at most SZK_CB_PART0_RANGE bins (its compaction reads the
+// range with 256 threads) —, k_cb_compact + k_codebook<1> + k_cb_assign otherwise. Round 6: 256 -> 640 (C1's 398 symbols: four launches and
+// 85 us became two and ~50; the one-wave merge costs ~0.08 us per symbol, the wide form ~85 us whatever the alphabet)
+#define SZK_CB_PART0_SYMS 640
+#define SZK_CB_PART0_RANGE 4096
+static inline int szk_cb_part(uint32_t n_symbols, uint32_t span) { return n_symbols <= SZK_CB_SMALL_SYMS || (n_symbols <= SZK_CB_PART0_SYMS && span <= SZK_CB_PART0_RANGE) ? 0 : 1; }
 #define SZK_MAX_BOOKS 4
 #define SZK_MAX_TRIALS 8  // tuner trials of one launch group
 
@@ -474,7 +481,8 @@ int szk_launch_assemble(const szk_asm_params *p, hipStream_t s);
 // the state block -> the host's pinned copy + a sequence word behind it, written by the device (finish() polls the word); d_zero != nullptr:
 // the same launch zeroes zero_bytes (a multiple of 16) there when the state reports no miss and no mispredicted code-book form
 int szk_launch_publish(const szk_state *d_state, void *h_state, uint32_t *h_seq, uint32_t seq, void *d_zero, uint64_t zero_bytes, hipStream_t s,
-                       const uint64_t *d_blk_others = nullptr /* non-null: the word the host copy's blk_others receives */);
+                       const uint64_t *d_blk_others = nullptr /* non-null: the word the host copy's blk_others receives */,
+                       void *d_zero_blk0 = nullptr /* with d_zero: 64 bytes ... */, void *d_zero_blk1 = nullptr /* ... and 80 bytes zeroed under the same condition (the block predictor's counters) */);
 int szk_launch_dec_tables(const uint8_t *d_lens, uint32_t sym_min, uint32_t sym_count, szk_dec_tables *t,
                           uint32_t radius /* != 0: the multi-symbol table of a Lorenzo stream's small book is made too (mlut) */,
                           uint32_t esc_sym /* != 0: the stored symbol that decodes as symbol 0 (a listed delta; sampled books) */,

@@ -2466,10 +2466,21 @@ __device__ void cb_merge_wave32(const uint64_t *keys, uint32_t *nfq, uint16_t *p
 // merged sorted order (ties: leaf first), before any new node is touched: one round creates |A|/2 nodes at once —
 // a co-rank search per pair. c at least doubles the smallest pending item per round: O(log(total)) rounds.
 // INLDS: 32-bit frequencies in LDS (lf32 leaves, nf32 internals); else 64-bit in global memory (keys, ifreq).
-template <bool INLDS>
+// ONEWAVE (round 6; alphabets of a few hundred symbols): the same rounds by ONE wave — no workgroup barrier and no LDS counter between the
+// probe and the pairing (a round is ~0.4 us instead of ~1: C1's 398 symbols 23 -> ~10 us); called by the threads of wave 0 only, NT = 64.
+template <bool INLDS, bool ONEWAVE = false>
 __device__ void cb_merge_rounds(const uint64_t *keys, uint64_t *ifreq, const uint32_t *lf32, uint32_t *nf32,
                                 uint16_t *pleaf, uint16_t *pint, uint32_t m, uint32_t *s_red /* [4], zeroed */, uint32_t NT /* live threads */) {
     const uint32_t t = threadIdx.x, lane = lane_id();
+    auto sync = [&]() {
+        if (ONEWAVE) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+    };
     const uint64_t INF = ~0ull;
     auto LF = [&](uint32_t x) -> uint64_t { return INLDS ? (uint64_t)lf32[x] : keys[x] >> 16; };
     auto NF = [&](uint32_t x) -> uint64_t { return INLDS ? (uint64_t)nf32[x] : ifreq[x]; };
@@ -2494,13 +2505,20 @@ __device__ void cb_merge_rounds(const uint64_t *keys, uint64_t *ifreq, const uin
             pn = NF(j + e - 1) < c;
         }
         const uint32_t cl = (uint32_t)__popcll(__ballot(pl)), cn = (uint32_t)__popcll(__ballot(pn));
-        if (lane == 0) {
-            if (cl) atomicAdd(&red[0], cl);
-            if (cn) atomicAdd(&red[1], cn);
+        uint32_t nl, nn;  // full segments below c
+        if (ONEWAVE) {
+            nl = cl * SL;
+            nn = cn * SN;
+        } else {
+            if (lane == 0) {
+                if (cl) atomicAdd(&red[0], cl);
+                if (cn) atomicAdd(&red[1], cn);
+            }
+            if (t == 0) red_next[0] = red_next[1] = 0;
+            __syncthreads();
+            nl = red[0] * SL;
+            nn = red[1] * SN;
         }
-        if (t == 0) red_next[0] = red_next[1] = 0;
-        __syncthreads();
-        uint32_t nl = red[0] * SL, nn = red[1] * SN;  // full segments below c
         if (nl < RL) {
             const uint32_t x = nl + lane;
             const bool b = lane < SL && x < RL && LF(i + x) < c;
@@ -2545,7 +2563,7 @@ __device__ void cb_merge_rounds(const uint64_t *keys, uint64_t *ifreq, const uin
         j += nn - ((tot & 1) && !leaf_last ? 1 : 0);
         k += P;
         round++;
-        __syncthreads();
+        sync();
     }
 }
 
@@ -3073,14 +3091,17 @@ __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params 
     //    broadcast reads), bitonic otherwise
     if (m <= 512) {
         uint64_t mykey[2];
-        uint32_t myrank[2];
-        for (int c = 0; c < 2; c++) {
-            const uint32_t q = t + c * CB_THREADS;
-            mykey[c] = q < m ? keys[q] : ~0ull;
-            uint32_t r = 0;
-            if (q < m)
-                for (uint32_t o = 0; o < m; o++) r += keys[o] < mykey[c];  // keys are distinct (symbol in the low bits)
-            myrank[c] = r;
+        uint32_t myrank[2] = {0, 0};
+        for (int c = 0; c < 2; c++) mykey[c] = t + c * CB_THREADS < m ? keys[t + c * CB_THREADS] : ~0ull;
+        if (m <= CB_THREADS) {
+            if (t < m)
+                for (uint32_t o = 0; o < m; o++) myrank[0] += keys[o] < mykey[0];  // keys are distinct (symbol in the low bits)
+        } else {  // (one walk over the keys serves the thread's two)
+            for (uint32_t o = 0; o < m; o++) {
+                const uint64_t ko = keys[o];
+                myrank[0] += ko < mykey[0];
+                myrank[1] += ko < mykey[1];
+            }
         }
         __syncthreads();
         for (int c = 0; c < 2; c++)
@@ -3097,7 +3118,7 @@ __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params 
         // single symbol: zero-length code, empty bit-stream (as encoder/HuffmanEncoder.hpp:233-237)
     } else {
         // 3. merge: one wave out of registers (32-bit counts), or thread 0 (64-bit counts)
-        if (s_total < 0xFFFFFFFFull && (p.dbg & 2u)) {  // (development switch: measured slower, 35 vs 28 us at C2)
+        if (s_total < 0xFFFFFFFFull && !(p.dbg & 2u)) {  // (the rounds by one wave; debug flag 262144: the serial wave merge — C2-like 145 symbols 33 us, C1's 398 87 us)
             // round-parallel merge on the 256 live threads (every round pairs ALL pending items below the smallest possible
             // new node, cb_merge_rounds): ~a dozen rounds for a smooth field's 128 symbols instead of 127 dependent picks of
             // one wave (28 us of the kernel's 38 at C2)
@@ -3105,7 +3126,7 @@ __device__ void cb_small(const uint64_t *__restrict__ hist, const szk_cb_params 
             for (uint32_t q = t; q < m; q += CB_THREADS) lf32[q] = (uint32_t)(keys[q] >> 16);
             if (t < 4) s_misc[t] = 0;
             __syncthreads();
-            cb_merge_rounds<true>(keys, ifreq, lf32, nf32, pleaf, pint, m, s_misc, CB_THREADS);
+            if (t < WAVE) cb_merge_rounds<true, true>(keys, ifreq, lf32, nf32, pleaf, pint, m, s_misc, WAVE);
         } else if (s_total < 0xFFFFFFFFull) {
             if (t < WAVE) cb_merge_wave32(keys, reinterpret_cast<uint32_t *>(ifreq), pleaf, pint, m);
         } else if (t == 0) {
@@ -3560,6 +3581,11 @@ __global__ __launch_bounds__(1024) void k_cb_assign(const uint16_t *__restrict__
 // PART 0: alphabets up to CB_SMALL_SYMS symbols + the outlier-list sorts; PART 1: wider alphabets. Which one applies is
 // known only on the device (k_hist_range), so both are launched and the other returns at once: the small path keeps its
 // own register allocation and instruction footprint (sharing one kernel with the wide path cost it 10 us of its 40).
+// which of the two forms a histogram's range words call for (sz3hip_kernels.h, szk_cb_part)
+__device__ __forceinline__ int cb_part_of(const uint32_t *range) {
+    const uint32_t n = range[2], span = n ? range[1] - (0xFFFFu - range[0]) + 1u : 0u;
+    return n <= CB_SMALL_SYMS || (n <= SZK_CB_PART0_SYMS && span <= SZK_CB_PART0_RANGE) ? 0 : 1;
+}
 template <int PART>
 __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restrict__ hist, szk_cb_params p) {
     constexpr uint32_t CAP = CB_LDS_SYMS;  // symbols the small path's LDS arrays hold
@@ -3573,7 +3599,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     if (blockIdx.x >= p.n_books) {  // the two blocks after the code books: deterministic order of the two outlier lists
         if (p.skip_sort) return;
         // (in the launch whose code-book path is the active one, so that they run beside it)
-        if ((PART == 1) != (p.range[2] > CB_SMALL_SYMS) && p.part_hint < 0) return;  // (launched alone: sorts whatever the alphabet)
+        if (PART != cb_part_of(p.range) && p.part_hint < 0) return;  // (launched alone: sorts whatever the alphabet)
         const bool d = blockIdx.x == p.n_books + 1;
         // scratch: the key tables of the batch slots 1 and 2, idle when a single code book is built (n_books <= 1)
         uint64_t *scratch = p.n_books <= 1 ? p.keys + (size_t)(d ? 2 : 1) * SZH_HIST_BINS : nullptr;
@@ -3604,7 +3630,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     }
     // range and number of the non-empty bins: found by k_hist_range (256 workgroups) just before this launch
     const uint32_t n_nonzero = p.range[2];
-    if ((PART == 1) != (n_nonzero > CB_SMALL_SYMS)) {  // the other form's case
+    if (PART != cb_part_of(p.range)) {  // the other form's case
         if (p.part_hint >= 0 && p.mispredict && threadIdx.x == 0) *p.mispredict = 1u;  // launched alone: the host repeats stage 2 with both
         if (PART == 1 && threadIdx.x == 0) p.info->reserved = 0;  // (nothing for k_cb_assign behind this launch)
         return;
@@ -3621,8 +3647,8 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
         return;
     }
     uint32_t lo = 0xFFFFu - p.range[0], range = p.range[1] - lo + 1;  // range[0] = max(65535 - bin), range[1] = max bin
-    const bool small = n_nonzero <= CB_SMALL_SYMS;
-    const bool fill = PART == 0 && small && cb_margins(lo, range, n_nonzero);
+    const bool small = PART == 0;
+    const bool fill = PART == 0 && n_nonzero <= CB_SMALL_SYMS && cb_margins(lo, range, n_nonzero);
     if (small && t >= CB_THREADS) return;  // the small path runs on 4 waves (cheap barriers)
     if (t == 0) p.info->ts[0] = wall_clock64();
     if (t < SZH_MAX_LEN + 2) s_cnt[t] = 0;
@@ -6489,7 +6515,7 @@ int szk_launch_encode(const uint16_t *codes, uint64_t n, const uint32_t *d_enc, 
 // counters when this call needs no repeat (state: no miss, no mispredicted book form) — the host draws the same conclusion from the
 // same state — so that nothing is enqueued between a call's end and the next call's stage 1.
 __global__ __launch_bounds__(256) void k_publish(const szk_state *__restrict__ state, uint32_t *host_state, uint32_t *host_seq, uint32_t seq,
-                                                 uint4 *zero, uint32_t zero_vec16, const uint64_t *blk_others) {
+                                                 uint4 *zero, uint32_t zero_vec16, const uint64_t *blk_others, uint4 *zero_blk0, uint4 *zero_blk1) {
     if (blockIdx.x == 0) {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(state);
         constexpr uint32_t OW = offsetof(szk_state, blk_others) / 4;
@@ -6501,15 +6527,21 @@ __global__ __launch_bounds__(256) void k_publish(const szk_state *__restrict__ s
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (round 6) the block predictor's counter blocks — 64 bytes of counters, 64 of Rice statistics + the selection's count, which the copy
+        // above has just read — with the histogram: three fill launches off the front of a block-composed call (12 us of C1's 190)
+        if (zero && zero_blk0 && state->miss_kind == 0 && state->mispredict == 0) {
+            if (threadIdx.x < 4) zero_blk0[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+            else if (threadIdx.x < 9) zero_blk1[threadIdx.x - 4] = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
     if (zero && state->miss_kind == 0 && state->mispredict == 0)
         for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < zero_vec16; i += gridDim.x * 256) zero[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 int szk_launch_publish(const szk_state *d_state, void *h_state, uint32_t *h_seq, uint32_t seq, void *d_zero, uint64_t zero_bytes, hipStream_t s,
-                       const uint64_t *d_blk_others) {
+                       const uint64_t *d_blk_others, void *d_zero_blk0, void *d_zero_blk1) {
     static_assert(sizeof(szk_state) % 4 == 0, "the state block is copied word by word");
     hipLaunchKernelGGL(k_publish, dim3(d_zero ? 128 : 1), dim3(256), 0, s, d_state, (uint32_t *)h_state, h_seq, seq, (uint4 *)d_zero, (uint32_t)(zero_bytes / 16),
-                       d_blk_others);
+                       d_blk_others, (uint4 *)d_zero_blk0, (uint4 *)d_zero_blk1);
     SZK_CHECK_LAUNCH();
     return 0;
 }

@@ -39,6 +39,11 @@
 #define BLK_HWIN 4096   // LDS histogram window (bins around the radius) of a workgroup; BLK_HWIN_WIDE when the previous call of the
 #define BLK_HWIN_WIDE 16384  // context saw an alphabet wider than the small one (C4-like fields: deltas of thousands of lattice steps)
 #define BLK_GRID 2048u
+// the encoder's persistent grids (round 6: 2048 -> 1024). Every workgroup of a coding kernel ends by adding its LDS histogram to the global
+// one, one device-scope atomic per non-empty bin — a few hundred addresses that EVERY workgroup hits, performed one after another at the
+// memory side (~20 ns each: 21 of 27 us of C1's stencil pass with 1024 workgroups). Half the workgroups, half the queue; C4a's slab runs
+// the same to the microsecond (k_blk_fit 240, k_blk_rows 549 us), 512 would be 40 % slower there.
+#define BLK_GRID_ENC 1024u
 
 #define SZK_CHECK_LAUNCH()                                   \
     do {                                                     \
@@ -184,6 +189,10 @@ __device__ __forceinline__ void blk_count(uint32_t *lh, const szk_blk_params &p,
 }
 template <uint32_t HW>
 __device__ __forceinline__ void blk_flush(const uint32_t *lh, const szk_blk_params &p) {
+#if defined(LAB_BLK) && (LAB_BLK & 1)  // (lab, wrong results: no flush of the workgroup's histogram)
+    if (lh[0] == 0x12345678u) atomicAdd((unsigned long long *)&p.hist[1], 1ull);
+    return;
+#endif
     if (threadIdx.x == 0 && lh[HW]) atomicAdd((unsigned long long *)&p.hist[0], (unsigned long long)lh[HW]);
     for (uint32_t b = threadIdx.x; b < HW; b += blockDim.x) {
         const uint32_t v = lh[b];
@@ -994,7 +1003,50 @@ __global__ __launch_bounds__(256) void k_blk_rank_write(const uint8_t *__restric
         __syncthreads();
     }
 }
+// up to RANK_SMALL blocks (round 6): the three launches in one workgroup (two launches and their 9 us off a 4 MB array's step)
+#define RANK_SMALL 16384u
+__global__ __launch_bounds__(1024) void k_blk_rank_small(const uint8_t *__restrict__ sel, uint32_t nblocks, uint32_t *__restrict__ rank, uint32_t *__restrict__ comp,
+                                                         uint64_t *n_reg_out) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    constexpr uint32_t PER = 8;
+    for (uint32_t base = 0; base < nblocks; base += 1024 * PER) {
+        const uint32_t b0 = base + threadIdx.x * PER;
+        uint32_t f[PER], mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            f[k] = (b0 + k < nblocks && sel[b0 + k] == 2) ? 1u : 0u;
+            mine += f[k];
+        }
+        const uint32_t incl = wave_incl_scan(mine);
+        if (lane_id() == WAVE - 1) s_w[threadIdx.x / WAVE] = incl;
+        __syncthreads();
+        uint32_t run = s_carry + incl - mine, tot = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            if (w < threadIdx.x / WAVE) run += s_w[w];
+            tot += s_w[w];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            if (b0 + k < nblocks) {
+                rank[b0 + k] = run;
+                if (f[k] && comp) comp[run] = b0 + k;
+            }
+            run += f[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_reg_out = s_carry;
+}
 static void launch_blk_rank(const uint8_t *sel, uint32_t nblocks, uint32_t *rank, uint32_t *comp, uint32_t *run_scratch, uint64_t *n_reg, hipStream_t s) {
+    if (nblocks <= RANK_SMALL && !(szk_dbg_flags & 2048)) {  // (debug flag 2048: the three launches whatever the block count)
+        hipLaunchKernelGGL(k_blk_rank_small, dim3(1), dim3(1024), 0, s, sel, nblocks, rank, comp, n_reg);
+        return;
+    }
     const uint32_t nruns = (nblocks + RANK_RUN - 1) / RANK_RUN;
     hipLaunchKernelGGL(k_blk_rank_count, dim3(nruns), dim3(256), 0, s, sel, nblocks, run_scratch);
     hipLaunchKernelGGL(k_blk_rank_offsets, dim3(1), dim3(1024), 0, s, run_scratch, nruns, n_reg);
@@ -1159,6 +1211,277 @@ __global__ __launch_bounds__(256) void k_blk_coef_write(const int64_t *__restric
                 }
             }
     }
+}
+
+// Small block counts (round 6; up to SIDE_SMALL_BLOCKS: C1's 8192 blocks of 128 values, a 4 MB HDF5 chunk): the eight launches above in ONE
+// workgroup, step by step with a barrier between two steps — each of them is a few microseconds of work behind 4.5 us of launch, 41 us
+// of C1's 190. Same arrays, same arithmetic, same bytes (the coefficient sums are sums of integers below 2^53: exact in any order).
+// Everything a step reads from memory was written by an earlier step of this workgroup and never read before (no stale line in the
+// unit's L1). Up to SIDE_SMALL_REG regression blocks whose zigzagged differences all fit 32 bits (C1: every block of 8192 is a regression
+// block) a thread keeps the differences of its (at most eight) blocks in registers from the statistics to the bits, and the groups' sizes
+// and offsets live in LDS: the coefficient arrays are read once instead of three times (each time a chain of two dependent loads per
+// step of a loop that nothing overlaps).
+#define SIDE_SMALL_BLOCKS 16384u
+#define SIDE_SMALL_REG 8192u
+template <int NC>
+__device__ __forceinline__ void side_put_block(uint32_t *bits, uint64_t pos, const uint64_t (&u)[NC], const uint32_t (&k)[NC]) {
+    for (int i = 0; i < NC; i++) {
+        const uint64_t q = u[i] >> k[i];
+        if (q < RICE_ESC) {
+            put_bits(bits, pos, ((1ull << q) - 1ull) << 1, (uint32_t)q + 1u);  // q ones, a zero
+            pos += q + 1;
+            if (k[i]) put_bits(bits, pos, u[i] & ((1ull << k[i]) - 1ull), k[i]);
+            pos += k[i];
+        } else {
+            put_bits(bits, pos, (1ull << RICE_ESC) - 1ull, RICE_ESC);
+            pos += RICE_ESC;
+            put_bits(bits, pos, u[i], 64);
+            pos += 64;
+        }
+    }
+}
+#ifdef LAB_SIDE_TS  // (lab: where the one-workgroup side section spends its time)
+#define SIDE_TS(i) do { if (threadIdx.x == 0) lab_ts[i] = wall_clock64(); } while (0)
+#define SIDE_TS_PRINT() do { if (threadIdx.x == 0) printf("side_small: nr %u in_regs %d | sel %.1f rank %.1f stats %.1f len %.1f hdr+scan %.1f zero %.1f bits %.1f us\n", (unsigned)nr, (int)in_regs, (lab_ts[1]-lab_ts[0])/100.0, (lab_ts[2]-lab_ts[1])/100.0, (lab_ts[3]-lab_ts[2])/100.0, (lab_ts[4]-lab_ts[3])/100.0, (lab_ts[5]-lab_ts[4])/100.0, (lab_ts[6]-lab_ts[5])/100.0, (lab_ts[7]-lab_ts[6])/100.0); } while (0)
+#else
+#define SIDE_TS(i) do { } while (0)
+#define SIDE_TS_PRINT() do { } while (0)
+#endif
+template <int NC, bool RANK>
+__global__ __launch_bounds__(1024) void k_blk_side_small(const uint8_t *sel, uint32_t nblocks, uint32_t *rank, uint32_t *comp, uint64_t *n_reg_io,
+                                                         const int64_t *coef, double *stats, uint32_t *group_bits, uint8_t *side, uint64_t *side_bytes) {
+#ifdef LAB_SIDE_TS
+    uint64_t lab_ts[8];
+#endif
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    __shared__ double s_stats[NC];
+    __shared__ uint32_t s_gbits[SIDE_SMALL_REG / RICE_GROUP], s_goff[SIDE_SMALL_REG / RICE_GROUP];
+    const uint32_t t = threadIdx.x, wv = t / WAVE;
+    SIDE_TS(0);
+    if (t == 0) s_carry = 0;
+    if (t < (uint32_t)NC) s_stats[t] = 0.0;
+    // the selection bits (their place depends on nothing counted), and with RANK in the same walk over the choices: the rank of every block
+    // among the regression blocks, their compacted list, their number (the ranks themselves are not stored: the side section's builder is
+    // their only reader here, and it goes by the list)
+    const uint64_t sel_bytes = side_sel_bytes(nblocks);
+    if (!RANK) {
+        for (uint64_t b = t; b < sel_bytes; b += 1024) {
+            uint32_t v = 0;
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint64_t blk = b * 4 + q;
+                if (blk < nblocks) v |= (uint32_t)(sel[blk] & 3u) << (2 * q);
+            }
+            side[SIDE_HDR + b] = (uint8_t)v;
+        }
+    }
+    __syncthreads();
+    SIDE_TS(1);
+    (void)rank;
+    if (RANK) {
+        constexpr uint32_t PER = 8;
+        const uint32_t span = (uint32_t)sel_bytes * 4;  // blocks the selection section has room for (a multiple of 32): the padding is written too
+        for (uint32_t base = 0; base < span; base += 1024 * PER) {
+            const uint32_t b0 = base + t * PER;
+            uint32_t f[PER], mine = 0, packed = 0;
+            uint64_t w8 = 0;
+            if (b0 + PER <= nblocks) w8 = *reinterpret_cast<const uint64_t *>(sel + b0);  // (eight choices, one load: the array is 8-byte aligned)
+            else
+                for (uint32_t k = 0; k < PER; k++)
+                    if (b0 + k < nblocks) w8 |= (uint64_t)sel[b0 + k] << (8 * k);
+#pragma unroll
+            for (uint32_t k = 0; k < PER; k++) {
+                const uint32_t c = (uint32_t)(w8 >> (8 * k)) & 0xFFu;
+                f[k] = (b0 + k < nblocks && c == 2) ? 1u : 0u;
+                mine += f[k];
+                packed |= (c & 3u) << (2 * k);
+            }
+            if (b0 < span) *reinterpret_cast<uint16_t *>(side + SIDE_HDR + b0 / 4) = (uint16_t)packed;
+            const uint32_t incl = wave_incl_scan(mine);
+            if (lane_id() == WAVE - 1) s_w[wv] = incl;
+            __syncthreads();
+            uint32_t run = s_carry + incl - mine, tot = 0;
+            for (uint32_t w = 0; w < 16; w++) {
+                if (w < wv) run += s_w[w];
+                tot += s_w[w];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < PER; k++) {
+                if (f[k]) comp[run] = b0 + k;
+                run += f[k];
+            }
+            __syncthreads();
+            if (t == 0) s_carry += tot;
+            __syncthreads();
+        }
+        if (t == 0) *n_reg_io = s_carry;
+    }
+    const uint64_t nr = RANK ? (uint64_t)s_carry : *n_reg_io;
+    const uint32_t ngroups = (uint32_t)((nr + RICE_GROUP - 1) / RICE_GROUP);
+    uint8_t *kp = side + SIDE_HDR + sel_bytes;
+    constexpr uint32_t PB = side_par_bytes<NC>();
+    uint32_t *goff = reinterpret_cast<uint32_t *>(kp + PB);
+    uint32_t *bits = goff + ngroups;
+    __threadfence_block();
+    __syncthreads();
+    SIDE_TS(2);
+    const bool few = nr <= SIDE_SMALL_REG;  // (workgroup-uniform)
+    constexpr int J = SIDE_SMALL_REG / 1024;
+    uint32_t ur[J][NC];
+    __shared__ uint32_t s_big;
+    if (t == 0) s_big = 0;
+    // sums of the zigzagged differences per coefficient -> the Rice parameters
+    {
+        double sm[NC];
+        for (int i = 0; i < NC; i++) sm[i] = 0;
+        if (few) {
+            uint32_t big = 0;
+            constexpr int JB = 2;  // blocks whose loads are in flight together (two dependent round trips per batch; all eight at once spilled)
+#pragma unroll
+            for (int jb = 0; jb < J; jb += JB) {
+                if ((uint64_t)jb * 1024 >= nr) {  // (workgroup-uniform: nothing of the list left)
+#pragma unroll
+                    for (int j = 0; j < JB; j++)
+                        for (int i = 0; i < NC; i++) ur[jb + j][i] = 0;
+                    continue;
+                }
+                uint32_t c0[JB], c1[JB];
+#pragma unroll
+                for (int j = 0; j < JB; j++) {
+                    const uint64_t r = (uint64_t)(jb + j) * 1024 + t;
+                    c0[j] = r < nr ? comp[r] : 0u;
+                    c1[j] = r < nr && r ? comp[r - 1] : 0u;
+                }
+                int64_t cur[JB][NC], prv[JB][NC];
+#pragma unroll
+                for (int j = 0; j < JB; j++)
+                    for (int i = 0; i < NC; i++) {
+                        cur[j][i] = coef[(uint64_t)c0[j] * NC + i];  // (a thread past the list reads block 0's: a valid address, the value unused)
+                        prv[j][i] = coef[(uint64_t)c1[j] * NC + i];
+                    }
+#pragma unroll
+                for (int j = 0; j < JB; j++) {
+                    const uint64_t r = (uint64_t)(jb + j) * 1024 + t;
+                    for (int i = 0; i < NC; i++) {
+                        const uint64_t u = r < nr ? zigzag(cur[j][i] - (r ? prv[j][i] : 0)) : 0ull;
+                        ur[jb + j][i] = (uint32_t)u;
+                        big |= (uint32_t)(u >> 32);
+                        sm[i] += (double)u;
+                    }
+                }
+            }
+            if (__ballot(big != 0) && lane_id() == 0) atomicOr(&s_big, 1u);
+        } else {
+            for (uint64_t r = t; r < nr; r += 1024) {
+                uint64_t u[NC];
+                coef_delta<NC>(coef, comp, r, u);
+                for (int i = 0; i < NC; i++) sm[i] += (double)u[i];
+            }
+        }
+        for (int i = 0; i < NC; i++) {
+            sm[i] = wave_sum_f64(sm[i]);
+            if (lane_id() == 0 && sm[i] != 0) atomicAdd(&s_stats[i], sm[i]);
+        }
+    }
+    __syncthreads();
+    SIDE_TS(3);
+    const bool in_regs = few && s_big == 0;  // (workgroup-uniform)
+    if (t < (uint32_t)NC) stats[t] += s_stats[t];  // (zeroed by the caller, as for k_blk_coef_stats)
+    uint32_t k[NC];
+    for (int i = 0; i < NC; i++) k[i] = rice_param(s_stats[i], nr);
+    // bits of every group of 64 regression blocks (a wave per group)
+    uint32_t len_r[J];
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const uint64_t r = (uint64_t)j * 1024 + t;
+            uint32_t b = 0;
+            if (r < nr)
+                for (int i = 0; i < NC; i++) b += rice_len((uint64_t)ur[j][i], k[i]);
+            len_r[j] = b;
+            const uint32_t tot = wave_sum(b);
+            const uint32_t g = (uint32_t)j * 16 + wv;
+            if (lane_id() == 0 && g < ngroups) s_gbits[g] = tot;
+        }
+    } else {
+        for (uint32_t g = wv; g < ngroups; g += 16) {
+            const uint64_t r = (uint64_t)g * RICE_GROUP + lane_id();
+            uint32_t b = 0;
+            if (r < nr) {
+                uint64_t u[NC];
+                coef_delta<NC>(coef, comp, r, u);
+                for (int i = 0; i < NC; i++) b += rice_len(u[i], k[i]);
+            }
+            b = wave_sum(b);
+            if (lane_id() == 0) group_bits[g] = b;
+        }
+    }
+    SIDE_TS(4);
+    // header, parameters, group offsets
+    if (t == 0) {
+        const uint32_t h0[2] = {1u, 2u};
+        const uint64_t h1[2] = {nblocks, nr};
+        memcpy(side, h0, 8);
+        memcpy(side + 8, h1, 16);
+        for (uint32_t i = 0; i < PB - 4; i++) kp[i] = i < (uint32_t)NC ? (uint8_t)k[i < (uint32_t)NC ? i : 0] : (uint8_t)0;
+        memcpy(kp + PB - 4, &ngroups, 4);
+        s_carry = 0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t base = 0; base < ngroups; base += 1024) {
+        const uint32_t g = base + t;
+        const uint32_t mine = g < ngroups ? (in_regs ? s_gbits[g] : group_bits[g]) : 0u;
+        const uint32_t incl = wave_incl_scan(mine);
+        if (lane_id() == WAVE - 1) s_w[wv] = incl;
+        __syncthreads();
+        uint32_t run = s_carry + incl - mine, tot = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            if (w < wv) run += s_w[w];
+            tot += s_w[w];
+        }
+        if (g < ngroups) {
+            goff[g] = run;
+            if (in_regs) s_goff[g] = run;
+        }
+        __syncthreads();
+        if (t == 0) s_carry += tot;
+        __syncthreads();
+    }
+    SIDE_TS(5);
+    const uint64_t words = ((uint64_t)s_carry + 31) / 32;
+    for (uint64_t i = t; i < words; i += 1024) bits[i] = 0;
+    if (t == 0) *side_bytes = SIDE_HDR + sel_bytes + PB + 4ull * ngroups + 4 * words;
+    __threadfence_block();
+    __syncthreads();
+    SIDE_TS(6);
+    // the coefficient chain's bits
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const uint64_t r = (uint64_t)j * 1024 + t;
+            const uint32_t g = (uint32_t)j * 16 + wv;
+            const uint32_t before = wave_incl_scan(len_r[j]) - len_r[j];
+            uint64_t u[NC];
+            for (int i = 0; i < NC; i++) u[i] = ur[j][i];
+            if (r < nr) side_put_block<NC>(bits, (uint64_t)s_goff[g] + before, u, k);
+        }
+    } else {
+        for (uint32_t g = wv; g < ngroups; g += 16) {
+            const uint64_t r = (uint64_t)g * RICE_GROUP + lane_id();
+            uint64_t u[NC];
+            for (int i = 0; i < NC; i++) u[i] = 0;
+            uint32_t len = 0;
+            if (r < nr) {
+                coef_delta<NC>(coef, comp, r, u);
+                for (int i = 0; i < NC; i++) len += rice_len(u[i], k[i]);
+            }
+            const uint64_t pos = (uint64_t)goff[g] + (wave_incl_scan(len) - len);
+            if (r < nr) side_put_block<NC>(bits, pos, u, k);
+        }
+    }
+    SIDE_TS(7);
+    SIDE_TS_PRINT();
 }
 
 // ---- decoder side: selection bits out, coefficient differences parsed (one thread per group) and summed up ----
@@ -5059,36 +5382,37 @@ static int launch_blkn_compress(int dtype, const void *d_in, uint16_t *codes, co
         // Lorenzo members only (debug flag 134217728: the general fit pass): choices by k_blkn_sel12, codes straight from the array
         szk_blk_params q = *p;
         q.sel_given = 1;
-        const uint32_t gsel = (uint32_t)std::min<uint64_t>(BLK_GRID, ((uint64_t)nblocks + 255) / 256);
+        const uint32_t gsel = (uint32_t)std::min<uint64_t>(BLK_GRID_ENC, ((uint64_t)nblocks + 255) / 256);
         if (dtype == 0) hipLaunchKernelGGL(k_blkn_sel12<float>, dim3(gsel), dim3(256), 0, s, (const float *)d_in, q, nblocks);
         else hipLaunchKernelGGL(k_blkn_sel12<double>, dim3(gsel), dim3(256), 0, s, (const double *)d_in, q, nblocks);
 #define BLKN_L12(T, HW, NW)                                                                                                     \
     do {                                                                                                                        \
-        const uint32_t g4 = (uint32_t)std::min<uint64_t>(BLK_GRID * 8 / NW, (n + NW * 256 - 1) / (NW * 256));                    \
+        const uint32_t g4 = (uint32_t)std::min<uint64_t>(BLK_GRID_ENC * 8 / NW, (n + NW * 256 - 1) / (NW * 256));                    \
         hipLaunchKernelGGL((k_blkn_lorenzo12v<T, HW, NW * 64>), dim3(g4), dim3(NW * 64), 0, s, (const T *)d_in, codes, q, n);      \
     } while (0)
+        // (workgroups of 16 waves whatever the window: a quarter of the workgroups queue at the global histogram's bins — see below)
         if (dtype == 0) {
             if (sc->wide_hist) BLKN_L12(float, BLK_HWIN_WIDE, 16);
-            else BLKN_L12(float, BLK_HWIN, 4);
+            else BLKN_L12(float, BLK_HWIN, 16);
         } else {
             if (sc->wide_hist) BLKN_L12(double, BLK_HWIN_WIDE, 16);
-            else BLKN_L12(double, BLK_HWIN, 4);
+            else BLKN_L12(double, BLK_HWIN, 16);
         }
 #undef BLKN_L12
         return launch_blk_side_build(p, sc, nblocks, s);
     }
 #define BLKN_ENC1(T, HW, NW, TWO)                                                                                               \
     do {                                                                                                                        \
-        const uint32_t gfit = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                 \
-        const uint32_t glor = (uint32_t)std::min<uint64_t>(BLK_GRID * 8 / NW, (n + NW * 64 - 1) / (NW * 64));                     \
+        const uint32_t gfit = (uint32_t)std::min<uint64_t>(BLK_GRID_ENC * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                 \
+        const uint32_t glor = (uint32_t)std::min<uint64_t>(BLK_GRID_ENC * 8 / NW, (n + NW * 64 - 1) / (NW * 64));                     \
         if (!TWO && !p->sel_given && !(p->mask & 2u) && !(szk_dbg_flags & 134217728)) { /* 1-D: four blocks per wave (debug flag 134217728: a wave per block) */ \
-            const uint32_t grow = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW * 4 - 1) / (NW * 4));    \
+            const uint32_t grow = (uint32_t)std::min<uint64_t>(BLK_GRID_ENC * 4 / NW, ((uint64_t)nblocks + NW * 4 - 1) / (NW * 4));    \
             hipLaunchKernelGGL((k_blkn_fit_rows<T, HW, NW>), dim3(grow), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks); \
         } else                                                                                                                  \
         hipLaunchKernelGGL((k_blkn_fit<T, HW, NW, TWO, false>), dim3(gfit), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks, \
                            (unsigned long long *)nullptr);                                                                          \
         if (!TWO && !p->sel_given && !(p->mask & 2u) && !(szk_dbg_flags & 134217728)) { /* 1-D, q~ of everything in the work array: four codes per thread */ \
-            const uint32_t g4 = (uint32_t)std::min<uint64_t>(BLK_GRID * 8 / NW, (n + NW * 256 - 1) / (NW * 256));                  \
+            const uint32_t g4 = (uint32_t)std::min<uint64_t>(BLK_GRID_ENC * 8 / NW, (n + NW * 256 - 1) / (NW * 256));                  \
             hipLaunchKernelGGL((k_blkn_lorenzo1v<T, HW, NW * 64>), dim3(g4), dim3(NW * 64), 0, s, codes, *p, n);                   \
         } else                                                                                                                  \
         hipLaunchKernelGGL((k_blkn_lorenzo<T, HW, NW * 64, TWO>), dim3(glor), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, n); \
@@ -5098,11 +5422,18 @@ static int launch_blkn_compress(int dtype, const void *d_in, uint16_t *codes, co
         if (p->ndim == 2) BLKN_ENC1(T, HW, NW, true); \
         else BLKN_ENC1(T, HW, NW, false);          \
     } while (0)
+    // (round 6) 1-D arrays: workgroups of 16 waves whatever the window. Every workgroup ends by adding its LDS histogram to the global one — one
+    // device-scope atomic per non-empty bin, ~400 addresses that EVERY workgroup hits: they are performed one after another at the memory
+    // side, ~20 ns each, and C1's 1024 workgroups of four waves spent 21 of the stencil pass's 27 us and 7 of the fit pass's 20 queueing
+    // there (measured with the flush switched off). A quarter of the workgroups, a quarter of the queue.
+    const bool wg16 = p->ndim == 1 && !(szk_dbg_flags & 134217728);
     if (dtype == 0) {
         if (sc->wide_hist) BLKN_ENC(float, BLK_HWIN_WIDE, 16);
+        else if (wg16) BLKN_ENC1(float, BLK_HWIN, 16, false);
         else BLKN_ENC(float, BLK_HWIN, 4);
     } else {
         if (sc->wide_hist) BLKN_ENC(double, BLK_HWIN_WIDE, 16);
+        else if (wg16) BLKN_ENC1(double, BLK_HWIN, 16, false);
         else BLKN_ENC(double, BLK_HWIN, 4);
     }
 #undef BLKN_ENC
@@ -5116,8 +5447,8 @@ static int launch_blk4_compress(int dtype, const void *d_in, uint16_t *codes, co
     const uint64_t n = p->dw * p->d[0] * p->d[1] * p->d[2];
 #define BLK4_ENC(T, HW, NW)                                                                                                    \
     do {                                                                                                                       \
-        const uint32_t gfit = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                \
-        const uint32_t glor = (uint32_t)std::min<uint64_t>(BLK_GRID * 8 / NW, (n + NW * 64 - 1) / (NW * 64));                    \
+        const uint32_t gfit = (uint32_t)std::min<uint64_t>(BLK_GRID_ENC * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                \
+        const uint32_t glor = (uint32_t)std::min<uint64_t>(BLK_GRID_ENC * 8 / NW, (n + NW * 64 - 1) / (NW * 64));                    \
         hipLaunchKernelGGL((k_blk4_fit<T, HW, NW>), dim3(gfit), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks);      \
         hipLaunchKernelGGL((k_blk4_lorenzo<T, HW, NW * 64>), dim3(glor), dim3(NW * 64), 0, s, codes, *p, n);                    \
     } while (0)
@@ -5151,14 +5482,14 @@ int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const 
     }
 #define BLK_ENC1(T, HW, CBV, NW)                                                                                                       \
     do {                                                                                                                               \
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(BLK_GRID * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                        \
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(BLK_GRID_ENC * 4 / NW, ((uint64_t)nblocks + NW - 1) / NW);                        \
         hipLaunchKernelGGL((k_blk_fit<T, HW, CBV, NW>), dim3(grid), dim3(NW * 64), 0, s, (const T *)d_in, codes, *p, nblocks,           \
                            rank_first ? (const uint32_t *)sc->comp : (const uint32_t *)nullptr,                                          \
                            rank_first ? (const uint64_t *)(sc->counters + 0) : (const uint64_t *)nullptr);                               \
         if (by_element) {                                                                                                              \
             const uint32_t tpb = (252u / p->B) * p->B, xchunks = (uint32_t)((p->d[2] + tpb - 1) / tpb);                                  \
             const uint64_t ntasks = (uint64_t)p->nb[0] * p->nb[1] * xchunks;                                                            \
-            hipLaunchKernelGGL((k_blk_rows<T, HW, CBV>), dim3((uint32_t)std::min<uint64_t>(ntasks, BLK_GRID)), dim3(256), 0, s,           \
+            hipLaunchKernelGGL((k_blk_rows<T, HW, CBV>), dim3((uint32_t)std::min<uint64_t>(ntasks, BLK_GRID_ENC)), dim3(256), 0, s,           \
                                (const T *)d_in, codes, *p, (uint32_t)ntasks, xchunks);                                                  \
         } else {                                                                                                                       \
             hipLaunchKernelGGL((k_blk_lorenzo<T, HW, CBV, NW>), dim3(grid), dim3(NW * 64), 0, s, codes, *p, nblocks);                   \
@@ -5183,11 +5514,25 @@ int szk_launch_blk_compress(int dtype, const void *d_in, uint16_t *codes, const 
 }
 // the side section (selection bits + Rice-coded coefficient chain) from sel[] / coef[]
 static int launch_blk_side_build(const szk_blk_params *p, const szk_blk_scratch *sc, uint32_t nblocks, hipStream_t s, bool rank_done) {
-    if (!rank_done) launch_blk_rank(p->sel, nblocks, sc->rank, sc->comp, sc->run_scratch, sc->counters + 0, s);
     // (counters: [0] regression blocks, [2] side bytes, [4..7] as doubles: sum of the zigzagged differences per coefficient;
     // the group sizes are staged in the rank array, which the encoder needs no more once comp is written)
     double *stats = reinterpret_cast<double *>(sc->counters + 4);
     uint32_t *group_bits = sc->rank;
+    if (nblocks <= SIDE_SMALL_BLOCKS && !(szk_dbg_flags & 2048)) {  // (debug flag 2048: the eight launches whatever the block count)
+        double *st = p->ndim == 4 ? sc->stats5 : stats;
+#define SIDE_SMALL(NC, RK) hipLaunchKernelGGL((k_blk_side_small<NC, RK>), dim3(1), dim3(1024), 0, s, (const uint8_t *)p->sel, nblocks, sc->rank, sc->comp, sc->counters + 0, (const int64_t *)p->coef, st, group_bits, sc->side, sc->counters + 2)
+        if (p->ndim == 4) {
+            if (rank_done) SIDE_SMALL(5, false);
+            else SIDE_SMALL(5, true);
+        } else {
+            if (rank_done) SIDE_SMALL(4, false);
+            else SIDE_SMALL(4, true);
+        }
+#undef SIDE_SMALL
+        SZK_CHECK_LAUNCH();
+        return 0;
+    }
+    if (!rank_done) launch_blk_rank(p->sel, nblocks, sc->rank, sc->comp, sc->run_scratch, sc->counters + 0, s);
     if (p->ndim == 4) {  // five coefficients: their Rice statistics have a place of their own (sc->stats5, zeroed by the caller)
         double *st5 = sc->stats5;
         hipLaunchKernelGGL(k_blk_coef_stats<5>, dim3(32), dim3(256), 0, s, p->coef, sc->comp, sc->counters + 0, st5);

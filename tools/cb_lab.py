@@ -10,6 +10,7 @@ shape = tuple(int(v) for v in os.environ['LAB_SHAPE'].split(',')) if os.environ.
 dt = np.float64 if os.environ.get('LAB_DTYPE') == 'f64' else np.float32
 a = field3d(shape, dt, sigma=2e-6) if dt == np.float64 else field3d(shape); dev = torch.device("cuda:0")
 d_in = torch.from_numpy(a).to(dev)
+if os.environ.get('SZ3_LAB_FLAGS'): sz3_amd.lib().sz3hip_debug_flags(int(os.environ['SZ3_LAB_FLAGS']))
 conf = sz3_amd.Config(*shape); conf.cmprAlgo = sz3_amd.ALGO_INTERP if os.environ.get('LAB_ALGO') == 'interp' else sz3_amd.ALGO_LORENZO_REG; conf.absErrorBound = float(os.environ.get("LAB_EB", "1e-3")); conf.regression = 0
 dc = sz3_amd.DeviceCompressor(a.size, dt)
 cap = dc.payload_bound(a.size); pl = torch.empty(cap, dtype=torch.uint8, device=dev)

@@ -14,6 +14,8 @@ conf = sz3_amd.Config(n)
 conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
 if len(sys.argv) > 1 and sys.argv[1] == "lorenzo":
     conf.regression = 0
+if len(sys.argv) > 1 and sys.argv[1] == "default":
+    conf.cmprAlgo = sz3_amd.ALGO_INTERP_LORENZO
 conf.errorBoundMode = sz3_amd.EB_ABS
 conf.absErrorBound = 1e-3
 dc = sz3_amd.DeviceCompressor(n, np.float32)

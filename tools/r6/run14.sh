@@ -1,0 +1,22 @@
+#!/bin/bash
+# C1 timeline with the product library and with a lab variant (SZ3HIP_LIB)
+R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp; mkdir -p $R/gpurun_out/r6
+for v in ""; do
+  if [ -n "$v" ]; then export SZ3HIP_LIB=$R/sz3_amd/libsz3hip_$v.so; fi
+  rm -rf /tmp/tl1; rocprofv3 --kernel-trace --output-format csv -d /tmp/tl1 -o r -- python $R/tools/r6/c1_tl.py > /tmp/tl1.log 2>&1
+  echo "== variant '$v'"; grep "C1 " /tmp/tl1.log
+  python - <<PY
+import csv,glob
+f=glob.glob("/tmp/tl1/**/*kernel_trace.csv",recursive=True)[0]
+rows=sorted(csv.DictReader(open(f)),key=lambda r:int(r["Start_Timestamp"]))
+idx=[i for i,r in enumerate(rows) if "k_publish" in r["Kernel_Name"]]
+a,b=idx[-3],idx[-2]
+t0=int(rows[a+1]["Start_Timestamp"]); end=0
+for r in rows[a+1:b+1]:
+    s,e=int(r["Start_Timestamp"]),int(r["End_Timestamp"])
+    print("%-60s start %7.1f dur %6.1f gap %5.1f" % (r["Kernel_Name"].replace("(anonymous namespace)::","")[:60],(s-t0)/1000,(e-s)/1000,(s-end)/1000 if end else 0)); end=max(end,e)
+print("span %.1f us" % ((end-t0)/1000))
+PY
+done 2>&1 | tee $R/gpurun_out/r6/run14.log
+cd $R; unset SZ3HIP_LIB
+python -m pytest tests/test_gpu_small.py -x -q -rs 2>&1 | tail -6

@@ -903,6 +903,10 @@ static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
 // (0.45 = measured zstd gain on the reference's tree bytes; the bit stream itself is taken as incompressible).
 // Decisions agree with the reference in most cases and can differ near its 2 % thresholds or at ratios > 30 where
 // zstd matters; any decision yields a valid stream.
+// result words of the tuner's trials (the first 1024 bytes of d_trial): [4 * slot ..] the interpolation trials' costs (slots 0 .. 6), [24 .. 31] a
+// Lorenzo trial priced on its own (cost, then the blocks that took second order and their number), [32 .. 39] and [40 .. 47] the two Lorenzo
+// trials of a 1-D array when they ride behind the first interpolation group (round 6)
+#define SZ_TRIAL_WORDS 48
 static int tuner_reserve(sz3hip_ctx *ctx, size_t flags, size_t starts, size_t samples) {
     if (ctx->flags_cap < flags) {
         // flags and block origins live in pinned host memory the kernels access directly: a few KB each way, and the
@@ -943,7 +947,7 @@ static int tuner_reserve(sz3hip_ctx *ctx, size_t flags, size_t starts, size_t sa
         ctx->d_trial_counters = ctx->d_trial + 32;
         ctx->d_trial_hist = ctx->d_trial + 128;
     }
-    if (!ctx->h_trial) HIPCHK(hipHostMalloc((void **)&ctx->h_trial, 8 * 4 * 8));
+    if (!ctx->h_trial) HIPCHK(hipHostMalloc((void **)&ctx->h_trial, SZ_TRIAL_WORDS * 8));
     const size_t pbytes = SZK_MAX_TRIALS * SZK_TRIAL_MAX_PASSES * sizeof(szk_interp_pass);
     if (!ctx->d_passes) HIPCHK(hipMalloc(&ctx->d_passes, pbytes));
     if (!ctx->h_passes) HIPCHK(hipHostMalloc((void **)&ctx->h_passes, pbytes));
@@ -1084,7 +1088,7 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
     return 0;
 }
 static int tuner_fetch(sz3hip_ctx *ctx, hipStream_t s) {
-    HIPCHK(hipMemcpyAsync(ctx->h_trial, ctx->d_trial, 8 * 4 * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ctx->h_trial, ctx->d_trial, SZ_TRIAL_WORDS * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return 0;
 }
@@ -1291,8 +1295,43 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
         rc = tuner_interp_group(ctx, g, speculate ? 7 : 4, eb, radius, (uint32_t)nb, 0, s);
         if (rc) return rc;
     }
+    // (round 6) 1-D arrays, device-side pricing: the Lorenzo trials the decision may ask for below — at the call's radius and, where the rule
+    // of SZAlgoInterp.hpp:268-277 can apply, at 8192 — are enqueued behind the interpolation group and come back with ITS fetch: one
+    // synchronisation instead of three (a copy, the host's wake-up and the next launch's latency each: ~20 us of an idle GPU, 40 of the
+    // 245 us of a 4 MB series). They cost ~15 us of kernels when the decision then does not ask (interpolation beyond ratio 50).
+    const bool lz_batched = N == 1 && !ctx->exact_now;
+    const bool lz_second = lz_batched && conf.relErrorBound < 1.01e-6 && lorenzo_config.quantbinCnt != 16384;
+    auto lorenzo_enqueue = [&](int rad, int base) -> int {
+        HIPCHK(clear_hist_counters(ctx, s));
+        int rl = szk_launch_trial_lorenzo12(ctx->dtype == SZ3HIP_FLOAT ? 0 : 1, ctx->d_samples, per, nb, eb, rad, ctx->d_hist, ctx->d_counters, ctx->d_trial + base + 4, s);
+        if (rl) return fail(SZ3HIP_EHIP, "tuner: Lorenzo trial launch failed (%d)", rl);
+        rl = szk_launch_code_cost(ctx->d_hist, ctx->d_counters, ctx->d_trial + base, 1, sampling_num, 0, s);
+        if (rl) return fail(SZ3HIP_EHIP, "tuner: cost kernel launch failed (%d)", rl);
+        return 0;
+    };
+    // a Lorenzo trial's bytes from its eight result words: the coded size + the choices' own cost (ComposedPredictor::save: the selection
+    // vector Huffman-coded, ComposedPredictor.hpp:52-64): its entropy
+    auto lorenzo_bytes = [&](const uint64_t *w) -> double {
+        double bytes = trial_bytes(w, tsz);
+        const double nblk = (double)w[5], n2 = (double)w[4];
+        if (nblk > 0 && n2 > 0 && n2 < nblk) {
+            const double p2 = n2 / nblk;
+            bytes += nblk * -(p2 * std::log2(p2) + (1 - p2) * std::log2(1 - p2)) / 8.0;
+        }
+        return bytes;
+    };
+    uint64_t lz_words[16] = {0};
+    if (lz_batched) {  // (the group's launch zeroed every result word)
+        rc = lorenzo_enqueue(radius, 32);
+        if (rc) return rc;
+        if (lz_second) {
+            rc = lorenzo_enqueue(8192, 40);
+            if (rc) return rc;
+        }
+    }
     rc = tuner_fetch(ctx, s);
     if (rc) return rc;
+    if (lz_batched) memcpy(lz_words, ctx->h_trial + 32, sizeof(lz_words));  // (a second interpolation group zeroes the result words again)
     double dir_bytes[2];
     for (int op = 0; op < 2; op++) {
         rep.est_bytes[op] = priced(op);
@@ -1348,21 +1387,16 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
             bytes = (double)(z + 8);
             return 0;
         }
-        HIPCHK(clear_hist_counters(ctx, s));
+        if (lz_batched) {  // (priced behind the first interpolation group)
+            bytes = lorenzo_bytes(lz_words + (rad == radius ? 0 : 8));
+            return 0;
+        }
         HIPCHK(hipMemsetAsync(ctx->d_trial + 24, 0, 64, s));
-        int rl = szk_launch_trial_lorenzo12(ctx->dtype == SZ3HIP_FLOAT ? 0 : 1, ctx->d_samples, per, nb, eb, rad, ctx->d_hist, ctx->d_counters, ctx->d_trial + 28, s);
-        if (rl) return fail(SZ3HIP_EHIP, "tuner: Lorenzo trial launch failed (%d)", rl);
-        rl = szk_launch_code_cost(ctx->d_hist, ctx->d_counters, ctx->d_trial + 24, 1, sampling_num, 0, s);
-        if (rl) return fail(SZ3HIP_EHIP, "tuner: cost kernel launch failed (%d)", rl);
+        int rl = lorenzo_enqueue(rad, 24);
+        if (rl) return rl;
         rl = tuner_fetch(ctx, s);
         if (rl) return rl;
-        bytes = trial_bytes(ctx->h_trial + 24, tsz);
-        // the choices' own cost (ComposedPredictor::save: the selection vector Huffman-coded, ComposedPredictor.hpp:52-64): its entropy
-        const double nblk = (double)ctx->h_trial[29], n2 = (double)ctx->h_trial[28];
-        if (nblk > 0 && n2 > 0 && n2 < nblk) {
-            const double p2 = n2 / nblk;
-            bytes += nblk * -(p2 * std::log2(p2) + (1 - p2) * std::log2(1 - p2)) / 8.0;
-        }
+        bytes = lorenzo_bytes(ctx->h_trial + 24);
         return 0;
     };
     if (N == 1 && best_interp < 50) {  // :232-247

@@ -1419,8 +1419,13 @@ int stock_encode_lorenzo_reg(SlabJob &j) {
     ar.ask(&d_recon, (size_t)n * tsize + 64);
     ar.ask(&d_uval, (size_t)n * tsize + 64);
     ar.ask(&d_codes, (size_t)n * 2 + 64);
+    uint8_t *d_kind_new, *d_sel_new;
+    uint32_t *d_changed;
     ar.ask(&d_kind, (size_t)nblocks);
     ar.ask(&d_sel, (size_t)nblocks);
+    ar.ask(&d_kind_new, (size_t)nblocks);
+    ar.ask(&d_sel_new, (size_t)nblocks);
+    ar.ask(&d_changed, 64);
     ar.ask(&d_fit, (size_t)nblocks * CS * tsize);
     ar.ask(&d_coef, (size_t)nblocks * CS * tsize);
     ar.ask(&d_hist, 65536 * 8);
@@ -1465,13 +1470,48 @@ int stock_encode_lorenzo_reg(SlabJob &j) {
     std::vector<uint16_t> coef_codes, selection;
     std::vector<float> ui32, ul32;
     std::vector<double> ui64, ul64;
-    if (has_reg) {
-        if (dt == 0) stock::lorenzo_reg_chain<float>(N, B, cf.absErrorBound, kind.data(), nblocks, reinterpret_cast<float *>(coef.data()), coef_codes, ui32, ul32);
-        else stock::lorenzo_reg_chain<double>(N, B, cf.absErrorBound, kind.data(), nblocks, reinterpret_cast<double *>(coef.data()), coef_codes, ui64, ul64);
-        HIPCHK(hipMemcpyAsync(d_coef, coef.data(), coef.size(), hipMemcpyHostToDevice, s->stream));
+    // The reference chooses a block's predictor when it reaches the block — its lower neighbours then hold the values the READER will have
+    // (ComposedPredictor::precompress_block inside the overwriting loop, BlockwiseDecomposition.hpp:33-44) —, one block after the other. Here
+    // the choices are made for all blocks at once from the caller's values, the array is coded with them, and the selection is REPEATED with
+    // every block's halo as the coding pass left it; where a choice moves the pass is repeated with the new choices. A vector the repetition
+    // leaves alone is the reference's own (by induction along its block order: a block's choice is a function of its predecessors'
+    // reconstruction, which is a function of their choices). Few blocks sit that close to a tie — the goldens' sets settle in 2 - 3 passes;
+    // after STOCK_SELECT_PASSES the last coded vector stands (a stream any reader takes: the choices are stored).
+    constexpr int STOCK_SELECT_PASSES = 8;
+    const std::vector<uint8_t> fit = coef;
+    for (int pass = 0;; pass++) {
+        if (has_reg) {
+            coef = fit;
+            coef_codes.clear();
+            ui32.clear();
+            ul32.clear();
+            ui64.clear();
+            ul64.clear();
+            if (dt == 0) stock::lorenzo_reg_chain<float>(N, B, cf.absErrorBound, kind.data(), nblocks, reinterpret_cast<float *>(coef.data()), coef_codes, ui32, ul32);
+            else stock::lorenzo_reg_chain<double>(N, B, cf.absErrorBound, kind.data(), nblocks, reinterpret_cast<double *>(coef.data()), coef_codes, ui64, ul64);
+            HIPCHK(hipMemcpyAsync(d_coef, coef.data(), coef.size(), hipMemcpyHostToDevice, s->stream));
+        }
+        sp.reselect = 0;
+        if (szk_launch_stock_lr_code(dt, &sp, s->stream)) return fail(SZ3HIP_EHIP, "stock stream: coding launch failed");
+        if (!composed || pass + 1 >= STOCK_SELECT_PASSES) break;
+        uint32_t changed = 0;
+        HIPCHK(hipMemsetAsync(d_changed, 0, 4, s->stream));
+        sp.reselect = 1;
+        sp.kind_new = d_kind_new;
+        sp.sel_new = d_sel_new;
+        sp.n_changed = d_changed;
+        if (szk_launch_stock_lr_select(dt, &sp, s->stream)) return fail(SZ3HIP_EHIP, "stock stream: selection launch failed");
+        HIPCHK(hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        if (!changed) break;
+        HIPCHK(hipMemcpyAsync(d_kind, d_kind_new, (size_t)nblocks, hipMemcpyDeviceToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(d_sel, d_sel_new, (size_t)nblocks, hipMemcpyDeviceToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(kind.data(), d_kind_new, (size_t)nblocks, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(sel.data(), d_sel_new, (size_t)nblocks, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
     }
+    sp.reselect = 0;
     if (composed) selection.assign(sel.begin(), sel.end());
-    if (szk_launch_stock_lr_code(dt, &sp, s->stream)) return fail(SZ3HIP_EHIP, "stock stream: coding launch failed");
     uint64_t n_unpred = 0;
     if (szk_launch_stock_lr_finish(dt, &sp, n, d_hist, d_tile_cnt, d_tile_base, d_recon /* (done with: the unpredictable values' list) */, &n_unpred, s->stream))
         return fail(SZ3HIP_EHIP, "stock stream: histogram / list launch failed");

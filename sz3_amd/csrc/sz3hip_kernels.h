@@ -441,6 +441,8 @@ int szk_launch_stock_lorenzo_reg(int dtype, const szk_slr_params *p, uint64_t n,
 // parallel, from the ORIGINAL neighbours (the reference decides from reconstructed ones, block after block: a chain through the whole
 // array), the coefficient chain is quantized on the host (a chain over the regression blocks), and the values are coded front by front
 // of blocks in the reference's own arithmetic: prediction from reconstructed values in T, LinearQuantizer::quantize_and_overwrite.
+// Round 6: the selection is then repeated against the coded array and the pass with it while a choice moves (`reselect` below): what stands
+// is the reference's own vector, the container its file.
 struct szk_slw_params {
     uint64_t d[3];     // the array as (z, y, x): leading extents 1 for N < 3
     uint32_t nb[3];
@@ -458,6 +460,12 @@ struct szk_slw_params {
     const void *coef;         // [blocks][4] T: the RECOVERED coefficients of the regression blocks (host chain), what predictions use
     uint64_t dw;              // 4-D arrays (N == 4): the slowest extent, d[] holds the other three; coef_fit / coef are then [blocks][8]
     uint32_t nbw;             // ... and its blocks
+    // the selection repeated behind a coding pass (round 6): a block's halo then holds the values as the READER will have them (recon) — what the
+    // reference's estimate sees, whose loop overwrites the array block by block (ComposedPredictor.hpp:25-40 inside
+    // BlockwiseDecomposition.hpp:33-44) —, the choices go to kind_new / sel_new and *n_changed counts the blocks whose choice moved
+    uint32_t reselect;
+    uint8_t *kind_new, *sel_new;
+    uint32_t *n_changed;
 };
 int szk_launch_stock_lr_select(int dtype, const szk_slw_params *p, hipStream_t s);
 // stock ALGO_NOPRED streams (round 5): every value quantized against a prediction of 0 (NoPredictionDecomposition.hpp:17-33)

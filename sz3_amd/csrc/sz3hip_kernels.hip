@@ -2772,6 +2772,7 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
         __syncthreads();
         for (uint32_t q = t; q < m; q += NT) atomicAdd(&s_cls[63 - __clzll((long long)(p.keys[q] >> 16))], 1u);
         __syncthreads();
+        if (t == 0) p.info->ts[9] = wall_clock64();
         if (t == 0) {
             // a flat code only suits a class that carries little: the rare class may hold at most 1/64 of the occurrences
             // (estimated from the counts per octave); a near-uniform spread over tens of thousands of bins (ratio ~2)
@@ -3662,6 +3663,7 @@ __global__ __launch_bounds__(CB_LAUNCH) void k_codebook(const uint64_t *__restri
     }
     __syncthreads();
     if constexpr (PART == 1) {
+        if (t == 0) p.info->ts[1] = wall_clock64();
         codebook_wide<true>(hist, p, s_pool, lo, range, s_cnt, s_first, s_misc, p.keys_ready != 0 && p.n_books <= 1);
         return;
     }

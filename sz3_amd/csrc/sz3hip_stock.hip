@@ -864,6 +864,9 @@ __global__ __launch_bounds__(1024) void k_slr_chain(szk_slr_params p) {
 // (RegressionPredictor::precompress, :28-55: sums in double, coefficients stored in T), the members' sampled error estimates
 // (ComposedPredictor::precompress :25-40 over BlockwiseIterator's sample points :151-184, LorenzoPredictor::estimate_error with its
 // noise term :17-38), the first minimum. k_slw_front: the coding, front by front of blocks — k_slr_front run forward.
+// Round 6: the selection is repeated behind the coding pass (szk_slw_params::reselect: the halo then holds the values as the reader will have
+// them, the reference's view of a block's lower neighbours) and the pass with it while a choice moves — sz3hip_host.cpp,
+// stock_encode_lorenzo_reg: a vector the repetition leaves alone is the reference's own.
 // ------------------------------------------------------------------------------------------------------------
 template <typename T, int N, int L>
 __device__ __forceinline__ T slw_lorenzo(const T *tl, uint32_t ty, uint32_t tx, uint32_t a, uint32_t b, uint32_t c) {  // LorenzoPredictor::predict, :60-95
@@ -962,10 +965,13 @@ __global__ __launch_bounds__(256) void k_slw_select(szk_slw_params p) {
     slw_geom<N>(p.d, p.nb, p.B, bz, by, bx, g);
     auto at = [&](uint32_t a, uint32_t b, uint32_t c) -> uint32_t { return (a * g.ty + b) * g.tx + c; };
     const T *in = reinterpret_cast<const T *>(p.in);
-    for (uint32_t l = lane; l < g.tz * g.ty * g.tx; l += WAVE) {  // original values, zeros outside the array (the reference's padding)
+    const T *halo = p.reselect ? reinterpret_cast<const T *>(p.recon) : in;  // (the repeated selection: the halo as the reader will have it)
+    for (uint32_t l = lane; l < g.tz * g.ty * g.tx; l += WAVE) {  // original values (the block's own always), zeros outside the array (the reference's padding)
         const uint32_t c = l % g.tx, b = (l / g.tx) % g.ty, a = l / (g.tx * g.ty);
         const int64_t z = (int64_t)g.oz + a - g.hz, y = (int64_t)g.oy + b - 2, x = (int64_t)g.ox + c - 2;
-        tl[l] = (z >= 0 && y >= 0 && x >= 0) ? in[((uint64_t)z * p.d[1] + (uint64_t)y) * p.d[2] + (uint64_t)x] : (T)0;
+        const bool own = a >= g.hz && b >= 2 && c >= 2;
+        const uint64_t e = ((uint64_t)z * p.d[1] + (uint64_t)y) * p.d[2] + (uint64_t)x;
+        tl[l] = (z >= 0 && y >= 0 && x >= 0) ? (own ? in[e] : halo[e]) : (T)0;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -1065,6 +1071,12 @@ __global__ __launch_bounds__(256) void k_slw_select(szk_slw_params p) {
         }
         // (a regression-only set on a block with an extent of 1: the reference falls back to Lorenzo-1; the launcher refuses such arrays)
         if (kind == 2 && !reg_valid) kind = 0;
+        if (p.reselect) {  // (the fits are functions of the block's own values: unchanged)
+            p.kind_new[task] = (uint8_t)kind;
+            p.sel_new[task] = (uint8_t)idx;
+            if (p.kind[task] != (uint8_t)kind || p.sel[task] != (uint8_t)idx) atomicAdd(p.n_changed, 1u);
+            return;
+        }
         p.kind[task] = (uint8_t)kind;
         p.sel[task] = (uint8_t)idx;
         T *o = reinterpret_cast<T *>(p.coef_fit) + (uint64_t)task * 4;
@@ -1231,7 +1243,7 @@ __global__ __launch_bounds__(256) void k_slw_select4(szk_slw_params p) {
     SlwGeom4 g;
     slw_geom4(p, bw, bz, by, bx, g);
     const T *in = reinterpret_cast<const T *>(p.in);
-    slw_fill4<T>(tl, g, p, in, in, lane);
+    slw_fill4<T>(tl, g, p, in, p.reselect ? reinterpret_cast<const T *>(p.recon) : in, lane);  // (the repeated selection: the halo as the reader will have it)
     auto at = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) -> uint32_t { return ((a * g.tz + b) * g.ty + c) * g.tx + d; };
     const bool reg_on = (p.set_mask & 4u) != 0;
     const bool reg_valid = reg_on && g.ew > 1 && g.ez > 1 && g.ey > 1 && g.ex > 1;  // RegressionPredictor.hpp:33-37
@@ -1301,6 +1313,12 @@ __global__ __launch_bounds__(256) void k_slw_select4(szk_slw_params p) {
             k++;
         }
         if (kind == 2 && !reg_valid) kind = 0;  // (a regression-only set on a thin block: the launcher refuses such arrays)
+        if (p.reselect) {
+            p.kind_new[task] = (uint8_t)kind;
+            p.sel_new[task] = (uint8_t)idx;
+            if (p.kind[task] != (uint8_t)kind || p.sel[task] != (uint8_t)idx) atomicAdd(p.n_changed, 1u);
+            return;
+        }
         p.kind[task] = (uint8_t)kind;
         p.sel[task] = (uint8_t)idx;
         T *o = reinterpret_cast<T *>(p.coef_fit) + (uint64_t)task * 8;

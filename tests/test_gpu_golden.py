@@ -1,9 +1,9 @@
 """GPU tests (-m gpu): the product against the REFERENCE'S OWN golden vectors (tests/golden/golden.npz, made by tests/golden/make_golden.py
 from szcompressor/SZ3 built in the build container) — directly, without the oracle in between. With the stock format on, the tuner priced
 the reference's way and one zstd frame, the container this library writes must hash to what the reference wrote: the pre-zstd buffer
-(zstd-version independent) and the Config trailer for every golden case whose codes are the reference's; for the mixed Lorenzo / regression
-sets — where the writer chooses a block's predictor from original neighbours, the reference from reconstructed ones — the stream is read by
-the reference's restatement within the bound instead. The oracle only unpacks zstd frames and plays stock SZ3 as a reader here."""
+(zstd-version independent) and the Config trailer for every golden case — the mixed Lorenzo / regression sets too since round 6: the writer
+repeats its per-block selection against the coded array (a block's halo as the reader will have it, what the reference's block loop sees)
+until no choice moves. The oracle only unpacks zstd frames and plays stock SZ3 as a reader here."""
 import hashlib
 import importlib.util
 import os
@@ -23,8 +23,8 @@ _spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE,
 make_golden = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(make_golden)
 
-# the writer's block choices differ from the reference's in a few blocks ("The stock writers leave the reference's file")
-CHOICES_DIFFER = {"f32_64c_lorenzo_reg_1e-3", "f32_64c_lorenzo2_reg_1e-2", "f32_64c_lorenzo_reg_1e-1", "f64_48x40x36_lorenzo_reg_1e-6", "f32_4d_12x20x20x20_rel_1e-3"}
+# cases whose block choices differ from the reference's ("The stock writers leave the reference's file"): none since round 6
+CHOICES_DIFFER = set()
 
 
 def _split(blob):

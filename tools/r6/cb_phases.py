@@ -23,4 +23,6 @@ out = (C.c_uint64 * 16)(); L.sz3hip_debug_codebook_info(dc._h, out)
 ts = [out[4 + i] for i in range(9)]
 print("%s: n_symbols %d max_len %d sym_min %d sym_count %d; payload %d" % ((case,) + tuple(out[:4]) + (n,)))
 names = ["(entry)", "(entry)", "compact/class", "sort", "merge", "depth+lengths", "scatter", "lens by key", "tail"]
+ts12 = [out[4 + i] for i in range(12)]
+print("  ts[1]-ts[0] zeroing %.2f us; ts[9]-ts[1] octave counts %.2f us; ts[2]-ts[9] class compaction %.2f us" % ((ts12[1]-ts12[0])/100.0, (ts12[9]-ts12[1])/100.0, (ts12[2]-ts12[9])/100.0))
 for i in range(2, 9): print("  ts[%d] %-14s +%7.2f us" % (i, names[i], (ts[i] - ts[i - 1]) / 100.0 if ts[i - 1] else 0.0))

@@ -1041,34 +1041,22 @@ __global__ __launch_bounds__(256) void k_slw_select(szk_slw_params p) {
     er = slw_wave_sum(er);
     if (lane == 0) {
         // first minimum in the set's order (std::min_element); an invalid member counts as the largest double
+        // (std::min_element's own walk: the first member is the minimum until a later one compares LESS — an estimate that is not a number,
+        // a block with NaN in it, is never less and, in front, never beaten)
         const double big = 1.7976931348623157e308;
-        double best = big * 2;  // (+inf)
+        double best = 0;
         uint32_t kind = 0, idx = 0, k = 0;
-        if (p.set_mask & 1u) {
-            if (e1 < best) {
-                best = e1;
-                kind = 0;
-                idx = k;
-            }
-            k++;
-        }
-        if (p.set_mask & 2u) {
-            if (e2 < best) {
-                best = e2;
-                kind = 1;
-                idx = k;
-            }
-            k++;
-        }
-        if (p.set_mask & 4u) {
-            const double e = reg_valid ? er : big;
-            if (e < best) {
+        auto member = [&](double e, uint32_t kd) {
+            if (k == 0 || e < best) {
                 best = e;
-                kind = 2;
+                kind = kd;
                 idx = k;
             }
             k++;
-        }
+        };
+        if (p.set_mask & 1u) member(e1, 0u);
+        if (p.set_mask & 2u) member(e2, 1u);
+        if (p.set_mask & 4u) member(reg_valid ? er : big, 2u);
         // (a regression-only set on a block with an extent of 1: the reference falls back to Lorenzo-1; the launcher refuses such arrays)
         if (kind == 2 && !reg_valid) kind = 0;
         if (p.reselect) {  // (the fits are functions of the block's own values: unchanged)
@@ -1285,33 +1273,19 @@ __global__ __launch_bounds__(256) void k_slw_select4(szk_slw_params p) {
     er = slw_wave_sum(er);
     if (lane == 0) {
         const double big = 1.7976931348623157e308;
-        double best = big * 2;
+        double best = 0;
         uint32_t kind = 0, idx = 0, k = 0;
-        if (p.set_mask & 1u) {
-            if (e1 < best) {
-                best = e1;
-                kind = 0;
-                idx = k;
-            }
-            k++;
-        }
-        if (p.set_mask & 2u) {
-            if (e2 < best) {
-                best = e2;
-                kind = 1;
-                idx = k;
-            }
-            k++;
-        }
-        if (p.set_mask & 4u) {
-            const double e = reg_valid ? er : big;
-            if (e < best) {
+        auto member = [&](double e, uint32_t kd) {  // (std::min_element's own walk, see k_slw_select)
+            if (k == 0 || e < best) {
                 best = e;
-                kind = 2;
+                kind = kd;
                 idx = k;
             }
             k++;
-        }
+        };
+        if (p.set_mask & 1u) member(e1, 0u);
+        if (p.set_mask & 2u) member(e2, 1u);
+        if (p.set_mask & 4u) member(reg_valid ? er : big, 2u);
         if (kind == 2 && !reg_valid) kind = 0;  // (a regression-only set on a thin block: the launcher refuses such arrays)
         if (p.reselect) {
             p.kind_new[task] = (uint8_t)kind;

@@ -319,8 +319,7 @@ LR_WRITE_CASES = LR_CASES + [  # (4-D arrays since round 5's second half: k_slw_
 ]
 
 
-BYTE_IDENTICAL = {"3d-lorenzo-only", "3d-all-three", "3d-second-order-only", "3d-regression-only-block5", "3d-f64", "2d-defaults", "2d-second-order",
-                  "4d-lorenzo-only-ragged", "4d-coarse-regression-f64", "4d-regression-only", "3d-block8"}
+SEVERAL_FRAMES = {"3d-512cube-slice"}  # (a buffer beyond 1 MB leaves in several zstd frames by default: the one-frame test below has this array)
 
 
 @pytest.mark.parametrize("name,gen,eb,kw", LR_WRITE_CASES, ids=[c[0] for c in LR_WRITE_CASES])
@@ -363,8 +362,9 @@ def test_streams_written_as_stock_lorenzo_reg_are_read_by_stock_sz3(name, gen, e
     assert len(blob) <= (1.01 if a.ndim == 1 else 1.08) * len(oblob) + 256, (len(blob), len(oblob))
     # The reference's file byte for byte wherever the codes are the reference's: sets of one member, 1-D arrays, and the arrays where the
     # writer's choices (from original neighbours) coincide with the reference's (from reconstructed ones) — tools/stock_bytes_lab.py
-    if a.ndim == 1 or name in BYTE_IDENTICAL:
-        assert blob.tobytes() == oblob.tobytes(), (len(blob), len(oblob))
+    # (round 6: every case — the selection is repeated against the coded array until it stands: the reference's own choices)
+    if name not in SEVERAL_FRAMES:
+        assert blob.tobytes() == oblob.tobytes(), (name, len(blob), len(oblob))
     if a.ndim == 1:
         want, _ = oracle_decompress(oblob, a.dtype, a.shape)
         assert np.array_equal(got, want), "a 1-D stream decodes to other values than stock SZ3's own stream"

@@ -5400,27 +5400,39 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
         if (coop) coop_flush();
         uint32_t qn = 0;
         uint32_t syms[16];
+        // (round 6) the refill without a branch. `if (have <= 32) { pick the word by qn; ... }` came out of the compiler as a per-lane
+        // branch with three more inside (the picks) — and with 64 lanes refilling every ~8 symbols each, some lane takes it at every
+        // test. Now every lane runs the same two dozen instructions (masks, not conditional expressions: see the window's hand-over
+        // below); only a lane beyond its four words — code words above 8 bits on average — loads where it stands, behind a wave-uniform test.
+        // (Tried on top: the test before every second symbol for every book — a table hit takes at most 12 of the 33 bits a refill leaves —
+        // with a refill before and after a code word beyond the table, behind wave-uniform tests: 189 -> 228 us at 64 planes, the two
+        // ballots per symbol cost more than the tests saved.)
         // code books of at most 16-bit words (every alphabet up to 512 symbols): two symbols never need more than the 32 bits
         // a refill guarantees, so the buffer is looked at before every second symbol only
         const bool short_words = max_len <= 16;
+        auto refill = [&]() __attribute__((always_inline)) {
+            const bool need = have <= 32;
+            uint32_t wdx = 0;
+            if (__builtin_amdgcn_ballot_w64(need && qn >= 4)) {
+                if (need && qn >= 4) {
+                    const uint64_t a = woff + wi;
+                    wdx = __builtin_bswap32(bs[a < wlast ? a : wlast]);
+                }
+            }
+            const uint32_t q0 = 0u - (uint32_t)(qn == 0), q1 = 0u - (uint32_t)(qn == 1), q2 = 0u - (uint32_t)(qn == 2), q3 = 0u - (uint32_t)(qn == 3);
+            uint32_t wd = (qw[0] & q0) | (qw[1] & q1) | (qw[2] & q2) | (qw[3] & q3) | wdx;
+            wd &= 0u - (uint32_t)(need && wi < nwords);  // (no refill, or past the unit's words: zero bits — the shift below may then be anything)
+            buf |= (uint64_t)wd << ((32u - (uint32_t)have) & 63u);
+            const uint32_t nd = need ? 1u : 0u;
+            have += (int)(nd << 5);
+            wi += nd;
+            qn += nd;
+        };
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             uint32_t sym = 0;
             // (symbols past the end of the last chunk decode zero padding: harmless, only the stores are guarded)
-            if (((k & 1) == 0 || !short_words) && have <= 32) {
-                uint32_t wd;
-                if (qn < 4) {
-                    wd = qn == 0 ? qw[0] : (qn == 1 ? qw[1] : (qn == 2 ? qw[2] : qw[3]));
-                } else {
-                    const uint64_t a = woff + wi;
-                    wd = __builtin_bswap32(bs[a < wlast ? a : wlast]);
-                }
-                wd = wi < nwords ? wd : 0u;
-                qn++;
-                buf |= (uint64_t)wd << (32 - have);
-                have += 32;
-                wi++;
-            }
+            if ((k & 1) == 0 || !short_words) refill();
 #if defined(LAB_DEC_ABL) && (LAB_DEC_ABL & 4)  // (lab, wrong results: no table lookup — 4-bit code words)
             const uint32_t ent = ((((uint32_t)(buf >> 60)) + p.radius - 8u) << 8) | 4u;
 #else

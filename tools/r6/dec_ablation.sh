@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the variants first, here: bash tools/build_lab.sh abl1 "-DLAB_DEC_ABL=1" abl2 "-DLAB_DEC_ABL=2" abl3 "-DLAB_DEC_ABL=3")
 # k_decode alone at a size where a SIMD holds half a wave (64 planes) and at full size, with pieces switched off (lab variants: wrong results)
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp; mkdir -p $R/gpurun_out/r6
 for sh in 64,512,512 512,512,512; do for v in "" abl1 abl2 abl3; do

@@ -10,7 +10,7 @@ cp gpurun_out/pmc_summary.txt gpurun_out/r6/final_pmc_summary.txt 2>/dev/null
 cp gpurun_out/kernel_stats.csv gpurun_out/r6/final_kernel_stats.csv 2>/dev/null
 cp gpurun_out/kernel_stats_c3.csv gpurun_out/r6/final_kernel_stats_c3.csv 2>/dev/null
 bash tools/r6/timeline.sh spec 0 final_timeline_c2.txt > /dev/null 2>&1
-LASTK=k_publish BACK=3 bash tools/tl_case.sh --algo interp --eb 1e-4 > gpurun_out/r6/final_timeline_c3.txt 2>&1
+LASTK=k_publish NTH=8 bash tools/tl_case.sh --algo interp --eb 1e-4 > gpurun_out/r6/final_timeline_c3.txt 2>&1
 python - <<PY
 import json
 o=json.loads([l for l in open("gpurun_out/r6/final_bench.json") if l.startswith("{")][-1])

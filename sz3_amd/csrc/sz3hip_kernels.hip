@@ -2770,7 +2770,14 @@ __device__ void codebook_wide(const uint64_t *__restrict__ hist, const szk_cb_pa
         if (t < 48) s_cls[t] = 0;
         if (t == 0) s_fsum = 0;
         __syncthreads();
-        for (uint32_t q = t; q < m; q += NT) atomicAdd(&s_cls[63 - __clzll((long long)(p.keys[q] >> 16))], 1u);
+        if (pre) {  // (k_cb_compact counted the keys per octave, slice by slice: 64 x 48 words — 13 us of LDS atomics on a dozen addresses at C3's 16 365 keys otherwise)
+            for (uint32_t q = t; q < CBC_BLOCKS * 48u; q += NT) {
+                const uint32_t c = (uint32_t)p.ifreq[CBC_BLOCKS + 1 + q];
+                if (c) atomicAdd(&s_cls[q % 48u], c);
+            }
+        } else {
+            for (uint32_t q = t; q < m; q += NT) atomicAdd(&s_cls[63 - __clzll((long long)(p.keys[q] >> 16))], 1u);
+        }
         __syncthreads();
         if (t == 0) p.info->ts[9] = wall_clock64();
         if (t == 0) {
@@ -3477,16 +3484,17 @@ __global__ __launch_bounds__(256) void k_sample(const T *__restrict__ in, szk_k1
 // number of non-empty bins in front of its slice, which it counts itself (up to 63 coalesced loads per thread, all in flight: the
 // histogram is 512 KB in the L2s) — no scan across workgroups, no second launch. keys[] = (count << 16) | symbol and syms[] in symbol
 // order, ifreq[w] = the slice's sum of counts, ifreq[64] = the number of keys (the range words' count is not used for it: a repeated
-// stage 2 runs k_hist_range over words that already hold the first run's).
+// stage 2 runs k_hist_range over words that already hold the first run's), ifreq[65 + 48 w + o] = the slice's keys whose count lies in octave o (round 6).
 __global__ __launch_bounds__(1024) void k_cb_compact(const uint64_t *__restrict__ hist, uint64_t *__restrict__ keys, uint16_t *__restrict__ syms,
                                                      uint64_t *__restrict__ part) {
-    __shared__ uint32_t s_w[16], s_before;
+    __shared__ uint32_t s_w[16], s_before, s_oct[48];
     __shared__ unsigned long long s_sum;
     const uint32_t t = threadIdx.x, lane = lane_id(), wv = t / WAVE, w = blockIdx.x;
     if (t == 0) {
         s_before = 0;
         s_sum = 0;
     }
+    if (t < 48) s_oct[t] = 0;
     __syncthreads();
     uint32_t before = 0;
     for (uint32_t b = 0; b < w; b++) before += hist[b * 1024u + t] != 0 ? 1u : 0u;
@@ -3498,7 +3506,9 @@ __global__ __launch_bounds__(1024) void k_cb_compact(const uint64_t *__restrict_
     if (lane == 0) s_w[wv] = (uint32_t)__popcll(bal);
     const uint64_t fs = wave_sum(f);
     if (lane == 0 && fs) atomicAdd(&s_sum, (unsigned long long)fs);
+    if (f) atomicAdd(&s_oct[(63 - __clzll((long long)f)) < 47 ? 63 - __clzll((long long)f) : 47], 1u);  // keys per octave of their count (the two-class rule's input: part[65 + 48 w ..])
     __syncthreads();
+    if (t < 48) part[gridDim.x + 1 + w * 48u + t] = s_oct[t];
     uint32_t pos = s_before;
     for (uint32_t k = 0; k < wv; k++) pos += s_w[k];
     if (f) {

@@ -47,6 +47,14 @@ def _composed(shape, eb, **kw):
     return c
 
 
+def _ramps(n, amp):
+    """a line per block of 128 values, slopes and offsets drawn per block: regression wins in every block"""
+    rng = np.random.default_rng(3)
+    nb = n // 128
+    slope, off = rng.uniform(-amp, amp, nb), rng.uniform(-amp, amp, nb)
+    return (off[:, None] + slope[:, None] * np.arange(128)[None, :]).reshape(-1)
+
+
 SIDE_CASES = [
     ("c1", lambda: field1d(1 << 20), 1e-3, {}),                                  # 8192 blocks of 128
     ("1d-ragged", lambda: field1d((1 << 19) + 77), 1e-3, {}),
@@ -56,6 +64,10 @@ SIDE_CASES = [
     ("3d-f64", lambda: (3.3e-5 * field3d((48, 80, 100), np.float64)), 1e-6, {}),
     ("3d-l2", lambda: field3d((40, 64, 96)), 1e-3, {"lorenzo2": 1}),
     ("4d", lambda: field4d((6, 20, 30, 40)), 1e-3, {}),                           # five coefficients
+    # more than 8192 regression blocks (the loop form behind the register form's limit): a smooth series under a loose bound
+    ("1d-many-regression-blocks", lambda: _ramps(1 << 21, 1.0), 1e-3, {}),
+    # coefficient differences beyond 32 bits (the register form steps aside): slopes of 1e3 on a lattice of 4e-9
+    ("1d-wide-coefficients", lambda: _ramps(1 << 18, 1e3), 1e-6, {}),
 ]
 
 
@@ -73,9 +85,9 @@ def test_side_section_by_one_workgroup_is_the_eight_launches_bytes(name, gen, eb
 
 BOOK_CASES = [
     ("c1-398", lambda: field1d(1 << 20), 1e-3, {}),
-    ("1d-lorenzo", lambda: field1d(1 << 20), 2e-4, {"regression": 0}),
-    ("2d", lambda: field2d((1024, 1024)), 1e-4, {"regression": 0}),
-    ("3d", lambda: field3d((64, 128, 256)), 1.5e-4, {"regression": 0}),
+    ("1d-lorenzo", lambda: field1d(1 << 20), 5e-4, {"regression": 0}),
+    ("2d", lambda: field2d((1024, 1024)), 2.5e-4, {"regression": 0}),
+    ("3d", lambda: field3d((64, 128, 256)), 2.2e-4, {"regression": 0}),
 ]
 
 

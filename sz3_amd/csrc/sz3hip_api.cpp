@@ -1040,7 +1040,10 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
             w[j].nb = nb;
             ok[j] = w[j].prepare();
         }
-        static const int phases = getenv("SZ3HIP_TUNER_PHASES") ? atoi(getenv("SZ3HIP_TUNER_PHASES")) : 1;  // (0, lab: a trial from end to end on one thread — 3.3 against 3.0 ms per group at C3)
+        // (a trial from end to end on one thread: 3.3 against 3.0 ms per group at C3 — but a 4 MB array's trials are 8 K codes each, and four
+        // hand-overs to the pool cost more than they share out: 0.42 -> ~0.3 ms per group; round 6. SZ3HIP_TUNER_PHASES = 0 / 1 forces either)
+        static const int phases_env = getenv("SZ3HIP_TUNER_PHASES") ? atoi(getenv("SZ3HIP_TUNER_PHASES")) : -1;
+        const int phases = phases_env >= 0 ? phases_env : (nb * per >= 65536 ? 1 : 0);
         double ph[4] = {0, 0, 0, 0};
         auto lap = [&](int k, const std::chrono::steady_clock::time_point &from) { ph[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - from).count(); };
         auto p0 = std::chrono::steady_clock::now();
@@ -1055,7 +1058,18 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
             lap(2, p0);
             p0 = std::chrono::steady_clock::now();
         }
-        szi_run_parallel(ntr, [&](int j) {
+        // (round 6) the exact Lorenzo trials of a 1-D array (tune_interp_lorenzo asks for them with the first group) are tasks of this batch:
+        // the host's walk over the sampled blocks + zstd, 0.18 ms each, beside the interpolation trials instead of behind them
+        const int lz_n = slot0 == 0 ? ((ctx->lz_want & 1) ? 1 : 0) + ((ctx->lz_want & 2) ? 1 : 0) : 0;
+        szi_run_parallel(ntr + lz_n, [&](int j) {
+            if (j >= ntr) {
+                const int which = (j - ntr == 0 && (ctx->lz_want & 1)) ? 0 : 1;
+                std::vector<uint8_t> buf;
+                const bool made = stock::lorenzo_trial_buffer<T>(eb, which ? 8192 : radius, (const T *)ctx->h_samples, per, nb, buf);
+                const size_t z = made ? szi_zstd_size(buf.data(), buf.size()) : 0;
+                ctx->lz_bytes[which] = z ? (double)(z + 8) : 0.0;
+                return;
+            }
             if (!ok[j]) return;
             if (!phases) {  // a trial from end to end on one thread of the pool: its 1.2 MB of codes stay in that core's cache
                 w[j].order(0);
@@ -1085,6 +1099,7 @@ static int tuner_interp_group(sz3hip_ctx *ctx, const sz3hip_config *tcs, int ntr
             return 0;
         }
     for (int j = 0; j < ntr; j++) ctx->exact_bytes[slot0 + j] = (double)sizes[j];
+    if (slot0 == 0) ctx->lz_have = ctx->lz_want;
     return 0;
 }
 static int tuner_fetch(sz3hip_ctx *ctx, hipStream_t s) {
@@ -1280,6 +1295,8 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
     // longer, and the second round trip (launch + fetch) is saved whenever the first group confirms that outcome.
     static const double alphas[3] = {1.0, 1.5, 2.0}, betas[3] = {1.0, 2.5, 3.0};
     const bool speculate = nb * 7 <= 256;
+    ctx->lz_have = 0;
+    ctx->lz_want = (N == 1 && ctx->exact_now) ? (1 | ((conf.relErrorBound < 1.01e-6 && lorenzo_config.quantbinCnt != 16384) ? 2 : 0)) : 0;
     {
         sz3hip_config g[7] = {tc, tc, tc, tc, tc, tc, tc};
         for (int k = 0; k < 4; k++) {
@@ -1379,12 +1396,21 @@ static int tune_interp_lorenzo(sz3hip_ctx *ctx, sz3hip_config &conf, const void 
         // Lorenzo-2 per block — instead of first-order Lorenzo over the concatenated samples: on smooth 1-D series the second-order
         // blocks are what makes Lorenzo win, and the set chosen here is the one stage 1 then codes the array with)
         if (ctx->exact_now && ctx->h_samples_valid) {
+            static const bool ttl = getenv("SZ3HIP_TUNER_TIMING") != nullptr;
+            const auto tl0 = std::chrono::steady_clock::now();
+            const int which = rad == radius ? 0 : 1;
+            if ((ctx->lz_have >> which) & 1) {  // (priced beside the first interpolation group)
+                if (ctx->lz_bytes[which] <= 0) return fail(SZ3HIP_EZSTD, "tuner: the Lorenzo trial could not be priced");
+                bytes = ctx->lz_bytes[which];
+                return 0;
+            }
             std::vector<uint8_t> buf;
             const bool made = ctx->dtype == SZ3HIP_FLOAT ? stock::lorenzo_trial_buffer<float>(eb, rad, (const float *)ctx->h_samples, per, nb, buf)
                                                          : stock::lorenzo_trial_buffer<double>(eb, rad, (const double *)ctx->h_samples, per, nb, buf);
             const size_t z = made ? szi_zstd_size(buf.data(), buf.size()) : 0;
             if (!z) return fail(SZ3HIP_EZSTD, "tuner: the Lorenzo trial could not be priced");
             bytes = (double)(z + 8);
+            if (ttl) fprintf(stderr, "[sz3hip tuner] exact Lorenzo trial (radius %d): %.3f ms\n", rad, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
             return 0;
         }
         if (lz_batched) {  // (priced behind the first interpolation group)

@@ -1950,10 +1950,15 @@ int job_encode(SlabJob &j) {
             j.lossless = true;  // the GPU stream would not even beat the raw array (tiny or incompressible input)
         } else {
             if (ensure_pin(s, dsize)) return j.failed(SZ3HIP_EHIP);
+            // (round 6) a small array's payload — a 4 MB HDF5 chunk leaves 0.5 - 0.9 MB — was ONE frame on one host thread: 1.3 ms of the
+            // filter call's 1.6 for C1's array (zstd level 3 walks a Huffman stream at ~0.7 GB/s), beside 0.12 ms of kernels. Payloads of
+            // 256 KB .. 8 MB now leave in about eight frames (at least 128 KB each: smaller ones cost ratio on compressible payloads) for the pool.
+            size_t frame = j.frame;
+            if (frame == zs::FRAME && dsize >= (256u << 10) && dsize < (8u << 20)) frame = std::max<size_t>(128u << 10, (dsize / 8 + 65535) & ~(size_t)65535);
             // the payload comes over in pieces while the host threads already compress the frames that have landed
             zs::Feeder feeder = [&](const std::function<void(size_t)> &landed) -> int {
                 // (a pipelined call's piece: its payload in one go — every part costs a stream synchronisation, and the piece's tail is the call's)
-                const size_t PIECE = j.frame < zs::FRAME ? (dsize <= (16u << 20) ? dsize : 8u << 20) : 8u << 20;
+                const size_t PIECE = frame < zs::FRAME ? (dsize <= (16u << 20) ? dsize : 8u << 20) : 8u << 20;
                 for (size_t off = 0; off < dsize; off += PIECE) {
                     const size_t l = std::min(PIECE, dsize - off);
                     if (hipMemcpyAsync((uint8_t *)s->pin + off, (const uint8_t *)s->dev_payload + off, l, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
@@ -1965,7 +1970,7 @@ int job_encode(SlabJob &j) {
                 }
                 return 0;
             };
-            j.out_size = zs::compress_frames((const uint8_t *)s->pin, dsize, j.out, j.out_cap, &feeder, j.frame, &s->frames);
+            j.out_size = zs::compress_frames((const uint8_t *)s->pin, dsize, j.out, j.out_cap, &feeder, frame, &s->frames);
             if (!j.out_size) return j.failed(sz3hip_last_error_code());
             if (j.tm) j.tm->lap("device->host + zstd");
             j.conf.cmprAlgo = ctx->h_state->hdr.predictor == 1 ? SZ3HIP_ALGO_HIP_INTERP : SZ3HIP_ALGO_HIP_LORENZO;

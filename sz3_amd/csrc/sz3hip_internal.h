@@ -231,6 +231,8 @@ struct sz3hip_ctx {
     sz3hip_config pre_conf, pre_key;
     sz3hip_tuner_report pre_report;
     double exact_bytes[8];   // ... their sizes, by result slot
+    int lz_want, lz_have;      // exact pricing, 1-D: the Lorenzo trials to price beside the first interpolation group (bit 0: at the call's radius, bit 1: at 8192) / priced
+    double lz_bytes[2];
     uint16_t *h_trial_codes; // ... the trials' codes and the sampled blocks on the host
     size_t h_trial_codes_cap;
     void *h_samples;

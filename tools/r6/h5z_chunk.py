@@ -23,9 +23,13 @@ for it in range(12):
     buf = C.c_void_p(libc.malloc(a.nbytes)); C.memmove(buf, a.ctypes.data, a.nbytes); size = C.c_size_t(a.nbytes)
     t0 = time.perf_counter(); n = filt(0, words, cdv, a.nbytes, C.byref(size), C.byref(buf)); ts.append(time.perf_counter() - t0)
     assert 0 < n < a.nbytes
-    if it == 11:
-        t0 = time.perf_counter(); m = filt(0x0100, words, cdv, n, C.byref(size), C.byref(buf)); td = time.perf_counter() - t0
-        assert m == a.nbytes
+    if it == 11:  # the read direction, a few times over copies of the stream (the first call of a process pays its allocations)
+        stream = C.string_at(buf, n); tds = []
+        for _ in range(6):
+            libc.free(buf); buf = C.c_void_p(libc.malloc(n)); C.memmove(buf, stream, n); size = C.c_size_t(n)
+            t0 = time.perf_counter(); m = filt(0x0100, words, cdv, n, C.byref(size), C.byref(buf)); tds.append(time.perf_counter() - t0)
+            assert m == a.nbytes
+        td = sorted(tds[1:])[len(tds[1:]) // 2]
     libc.free(buf)
 ts = sorted(ts[2:])
 print("h5z chunk %s %s: %d -> %d bytes (ratio %.2f); filter call %.3f ms median (min %.3f); read direction %.3f ms" % (kind, algo, a.nbytes, n, a.nbytes / n, ts[len(ts) // 2] * 1e3, ts[0] * 1e3, td * 1e3))

@@ -1952,9 +1952,12 @@ int job_encode(SlabJob &j) {
             if (ensure_pin(s, dsize)) return j.failed(SZ3HIP_EHIP);
             // (round 6) a small array's payload — a 4 MB HDF5 chunk leaves 0.5 - 0.9 MB — was ONE frame on one host thread: 1.3 ms of the
             // filter call's 1.6 for C1's array (zstd level 3 walks a Huffman stream at ~0.7 GB/s), beside 0.12 ms of kernels. Payloads of
-            // 256 KB .. 8 MB now leave in about eight frames (at least 128 KB each: smaller ones cost ratio on compressible payloads) for the pool.
+            // 256 KB .. 8 MB now leave in about eight frames (at least 128 KB each) for the pool — where the Huffman stream spends at least three
+            // bits per element: below that (smooth fields at loose bounds, ratios beyond ~10) zstd still finds repeats across the stream that
+            // small frames cut (C4a at 160^3, ratio 35: 3.7 % instead of 2.4 % below the reference's size), and such payloads are small anyway.
             size_t frame = j.frame;
-            if (frame == zs::FRAME && dsize >= (256u << 10) && dsize < (8u << 20)) frame = std::max<size_t>(128u << 10, (dsize / 8 + 65535) & ~(size_t)65535);
+            if (frame == zs::FRAME && dsize >= (256u << 10) && dsize < (8u << 20) && (double)dsize * 8.0 >= 3.0 * (double)j.conf.num)
+                frame = std::max<size_t>(128u << 10, (dsize / 8 + 65535) & ~(size_t)65535);
             // the payload comes over in pieces while the host threads already compress the frames that have landed
             zs::Feeder feeder = [&](const std::function<void(size_t)> &landed) -> int {
                 // (a pipelined call's piece: its payload in one go — every part costs a stream synchronisation, and the piece's tail is the call's)

@@ -984,11 +984,13 @@ __global__ __launch_bounds__(256) void k_slw_select(szk_slw_params p) {
         double s0 = 0, s1 = 0, s2 = 0, sn = 0;
         for (uint32_t t = lane; t < g.nown; t += WAVE) {
             const uint32_t i2 = t % g.ex, i1 = (t / g.ex) % g.ey, i0 = t / (g.ex * g.ey);
-            const double v = (double)tl[at(i0 + g.hz, i1 + 2, i2 + 2)];
-            s0 += (double)i0 * v;
-            s1 += (double)i1 * v;
-            s2 += (double)i2 * v;
-            sn += v;
+            // (sum[i] += index[i] * (*c), RegressionPredictor.hpp:43: size_t * T is a product in T; in double it is another coefficient once in
+            // ~10^5 blocks of f32 data — round 6, found by the byte sweep's 1-D twin of this line)
+            const T tv = tl[at(i0 + g.hz, i1 + 2, i2 + 2)];
+            s0 += (double)((T)i0 * tv);
+            s1 += (double)((T)i1 * tv);
+            s2 += (double)((T)i2 * tv);
+            sn += (double)tv;
         }
         s0 = slw_wave_sum(s0);
         s1 = slw_wave_sum(s1);
@@ -1240,12 +1242,12 @@ __global__ __launch_bounds__(256) void k_slw_select4(szk_slw_params p) {
         double sm[4] = {0, 0, 0, 0}, sn = 0;
         for (uint32_t t = lane; t < g.nown; t += WAVE) {
             const uint32_t i3 = t % g.ex, i2 = (t / g.ex) % g.ey, i1 = (t / (g.ex * g.ey)) % g.ez, i0 = t / (g.ex * g.ey * g.ez);
-            const double v = (double)tl[at(i0 + 1, i1 + 1, i2 + 1, i3 + 1)];
-            sm[0] += (double)i0 * v;
-            sm[1] += (double)i1 * v;
-            sm[2] += (double)i2 * v;
-            sm[3] += (double)i3 * v;
-            sn += v;
+            const T tv = tl[at(i0 + 1, i1 + 1, i2 + 1, i3 + 1)];  // (products in T: see k_slw_select)
+            sm[0] += (double)((T)i0 * tv);
+            sm[1] += (double)((T)i1 * tv);
+            sm[2] += (double)((T)i2 * tv);
+            sm[3] += (double)((T)i3 * tv);
+            sn += (double)tv;
         }
         for (int i = 0; i < 4; i++) sm[i] = slw_wave_sum(sm[i]);
         sn = slw_wave_sum(sn);

@@ -714,7 +714,8 @@ void lorenzo_reg_write_1d(uint64_t n, uint32_t B, double eb, int radius, uint32_
         if (reg_valid) {
             double s0 = 0, sn = 0;
             for (uint32_t t = 0; t < ex; t++) {
-                s0 += (double)t * (double)data[x0 + t];
+                s0 += (double)((T)t * data[x0 + t]);  // (sum[i] += index[i] * (*c): size_t * T is a product in T, RegressionPredictor.hpp:43 — in double it is
+                                                      // another coefficient once in ~10^5 blocks of f32 data, and the chain behind it another stream)
                 sn += (double)data[x0 + t];
             }
             const double num = ex, d = ex;

@@ -316,6 +316,8 @@ LR_WRITE_CASES = LR_CASES + [  # (4-D arrays since round 5's second half: k_slw_
     ("3d-block8", lambda: field3d((33, 40, 41)), 2e-2, dict(lorenzo=True, regression=True, block_size=8)),
     ("2d-f64-all-three", lambda: field2d((97, 130), np.float64), 1e-3, dict(lorenzo=True, lorenzo2=True, regression=True)),
     ("3d-512cube-slice", lambda: field3d((64, 256, 256)), 1e-3, dict(lorenzo=True, regression=True)),
+    # (round 6, from the byte sweep: a block whose fit differs in the last place when index * value is a product in double instead of in T)
+    ("1d-regression-only-t-products", lambda: field1d(368898), 0.00014524286814550258, dict(lorenzo=False, lorenzo2=False, regression=True)),
 ]
 
 

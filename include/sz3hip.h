@@ -109,7 +109,7 @@ size_t sz3hip_config_load(sz3hip_config *c, const unsigned char *in);
  * name ALGO_LORENZO_REG / ALGO_NOPRED get those containers; what has no stock form here keeps this library's ids. Prediction, quantisation, reconstruction and the Huffman bit stream run on the
  * GPU either way; the tree's serialisation and zstd are host stages. The tree is built with the reference's own queue (which of two
  * equal frequencies merges first, encoder/HuffmanEncoder.hpp:402-432): wherever the codes are the reference's — ALGO_INTERP, ALGO_NOPRED,
- * the default algorithm with SZ3HIP_TUNER_EXACT=1, ALGO_LORENZO_REG in 1-D and wherever the blocks' choices coincide — the container
+ * the default algorithm with SZ3HIP_TUNER_EXACT=1, ALGO_LORENZO_REG (round 6: the writer repeats its per-block choices against the coded array until they are the reference's) — the container
  * written IS the reference's file byte for byte, as long as its buffer leaves in one zstd frame: up to 1 MB by default (larger buffers are
  * cut into 1 MB frames for the pool's threads; stock SZ3 reads them), any size with SZ3HIP_STOCK_ONE_FRAME=1 (one host thread, ~0.4 GB/s). */
 void sz3hip_set_stock_format(int on);

@@ -4,8 +4,8 @@ library (sz3hip_set_stock_format) read by the reference. The stock side is playe
 built in this image (tests/test_oracle.py) — and, where oracle/_ref is present, by the reference library itself. Reconstruction is
 the reference's bit for bit in both directions (prediction, quantisation and reconstruction are the same arithmetic).
 Since the end of round 5 the writers build their Huffman trees with the reference's own queue (stock::build_tree, ref_heap): wherever the
-codes are the reference's — ALGO_INTERP, ALGO_NOPRED, the default algorithm with SZ3HIP_TUNER_EXACT=1, ALGO_LORENZO_REG in 1-D and wherever
-the blocks' choices coincide — a written container IS the reference's file, byte for byte (one zstd frame: buffers up to 1 MB, or
+codes are the reference's — ALGO_INTERP, ALGO_NOPRED, the default algorithm with SZ3HIP_TUNER_EXACT=1, ALGO_LORENZO_REG (round 6: every predictor set,
+the block choices repeated against the coded array until they stand) — a written container IS the reference's file, byte for byte (one zstd frame: buffers up to 1 MB, or
 SZ3HIP_STOCK_ONE_FRAME=1)."""
 import numpy as np
 import pytest
@@ -375,7 +375,7 @@ def test_streams_written_as_stock_lorenzo_reg_are_read_by_stock_sz3(name, gen, e
 def test_one_frame_switch_makes_a_large_stock_container_the_reference_s_file(monkeypatch):
     """a buffer beyond 1 MB leaves in several zstd frames by default (the pool's threads; stock SZ3 reads them) — SZ3HIP_STOCK_ONE_FRAME=1
     writes the one frame ZSTD_compress writes: the reference's file (64 x 256^2, Lorenzo + regression: 2.15 MB of buffer, the blocks'
-    choices coincide)"""
+    choices are the reference's)"""
     a = field3d((64, 256, 256))
     conf = sz3_amd.Config(*a.shape)
     conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG

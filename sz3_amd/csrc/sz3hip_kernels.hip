@@ -5416,7 +5416,8 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t *__restrict__ payl
         // below); only a lane beyond its four words — code words above 8 bits on average — loads where it stands, behind a wave-uniform test.
         // (Tried on top: the test before every second symbol for every book — a table hit takes at most 12 of the 33 bits a refill leaves —
         // with a refill before and after a code word beyond the table, behind wave-uniform tests: 189 -> 228 us at 64 planes, the two
-        // ballots per symbol cost more than the tests saved.)
+        // ballots per symbol cost more than the tests saved; with the two refills inside the long code's own branch instead — no ballot, only the
+        // lanes in there top up —: 223 us as well, 280 against 249 at C2. The test before every symbol stays for books beyond 16 bits.)
         // code books of at most 16-bit words (every alphabet up to 512 symbols): two symbols never need more than the 32 bits
         // a refill guarantees, so the buffer is looked at before every second symbol only
         const bool short_words = max_len <= 16;

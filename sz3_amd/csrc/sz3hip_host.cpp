@@ -1475,9 +1475,11 @@ int stock_encode_lorenzo_reg(SlabJob &j) {
     // the choices are made for all blocks at once from the caller's values, the array is coded with them, and the selection is REPEATED with
     // every block's halo as the coding pass left it; where a choice moves the pass is repeated with the new choices. A vector the repetition
     // leaves alone is the reference's own (by induction along its block order: a block's choice is a function of its predecessors'
-    // reconstruction, which is a function of their choices). Few blocks sit that close to a tie — the goldens' sets settle in 2 - 3 passes;
+    // reconstruction, which is a function of their choices). Few blocks sit that close to a tie at the bounds one meets — the goldens' sets settle in 2 - 3 passes;
     // after STOCK_SELECT_PASSES the last coded vector stands (a stream any reader takes: the choices are stored).
-    constexpr int STOCK_SELECT_PASSES = 8;
+    // (a loose bound puts many blocks next to a tie: 108 x 20 x 94 f64 at REL 1.9e-2 moved 168, 69, 38, 24, 14, 8, 4 ... of its 1152 blocks pass by
+    // pass — eight passes were one short of the byte sweep's case 202 under seed 3002; SZ3HIP_STOCK_SELECT_PASSES overrides)
+    const int STOCK_SELECT_PASSES = std::max(1, env_int("SZ3HIP_STOCK_SELECT_PASSES", 64));  // (256^3 f32 at REL 1e-2: 34 passes, 143 ms instead of 12; at 1e-3 and at 5e-2: one)
     const std::vector<uint8_t> fit = coef;
     for (int pass = 0;; pass++) {
         if (has_reg) {
@@ -1503,6 +1505,7 @@ int stock_encode_lorenzo_reg(SlabJob &j) {
         if (szk_launch_stock_lr_select(dt, &sp, s->stream)) return fail(SZ3HIP_EHIP, "stock stream: selection launch failed");
         HIPCHK(hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
+        if (getenv("SZ3HIP_STOCK_SELECT_TRACE")) fprintf(stderr, "[sz3hip stock] selection pass %d: %u of %llu blocks moved\n", pass, changed, (unsigned long long)nblocks);
         if (!changed) break;
         HIPCHK(hipMemcpyAsync(d_kind, d_kind_new, (size_t)nblocks, hipMemcpyDeviceToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(d_sel, d_sel_new, (size_t)nblocks, hipMemcpyDeviceToDevice, s->stream));

@@ -110,7 +110,7 @@ def test_exact_tuner_sweep(seed):
 @pytest.mark.parametrize("seed", [21, 22])
 def test_stock_containers_sweep(seed):
     """tests/checks/stock_bytes_sweep.py: 40 random calls in stock format (ALGO_INTERP with random parameters, the default algorithm, Lorenzo sets
-    of one member, any set on 1-D arrays; 1-D .. 4-D, f32 / f64, absolute and relative bounds) — every container is the reference's, byte for byte"""
+    of one member, mixed sets in every dimension since round 6; 1-D .. 4-D, f32 / f64, absolute and relative bounds) — every container is the reference's, byte for byte"""
     out = _run("stock_bytes_sweep.py", seed, 40)
     assert "mismatches 0" in out
 
@@ -122,3 +122,12 @@ def test_default_algorithm_reconstruction_sweep(seed):
     out = _run("default_algo_recon_sweep.py", seed, 25)
     assert "mismatches 0" in out
 
+
+
+@pytest.mark.parametrize("seed", [41, 42])
+def test_context_history_sweep(seed):
+    """tests/checks/history_sweep.py (round 6): one device context through 60 random calls (predictor sets, bounds, shapes up to 4 M elements
+    — the sampled book's path —, speculation switched, decompressions in between) against a fresh context on every call: the payload is a
+    function of the input and the configuration, whatever the context did before"""
+    out = _run("history_sweep.py", seed, 60)
+    assert "mismatches 0" in out

@@ -477,7 +477,7 @@ def c1_numbers(torch, sz3_amd, dev, local_rank, steps=20, default_algo=False):
             "ratio": round(a.nbytes / float(size), 4), "max_abs_err": err, "err_bound_ok": bool(err <= 1e-3),
             "stream_predictor": int(hdr[11]),  # (SZH1 header: 2 = block-composed)
             "decompress_device": {"ms": round(td * 1e3, 4), "gbps": round(a.nbytes / td / 1e9, 2)},
-            "note": "4 MB per call: launch-bound (nine kernels a step since round 6, twenty before: DESIGN.md, Round 6: small arrays)"}
+            "note": "4 MB per call: launch-bound (eight kernels a step since round 6, twenty before: DESIGN.md, Round 6: small arrays)"}
 
 
 def device_field4d(torch, dev, t_lo, nt, edge, seed):

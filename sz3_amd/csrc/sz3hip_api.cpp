@@ -867,10 +867,17 @@ static int stage1_blocks(sz3hip_ctx *ctx, const sz3hip_config *conf, const void 
         HIPCHK(hipMemsetAsync(ctx->d_blk_stats5, 0, 64, s));
     }
     ctx->blk_cleared_now = false;
+    // (round 6) a small array's side launch finds the range of the histogram's non-empty bins on the way: stage 2 launches no k_hist_range
+    const bool range_made = szk_blk_side_small(nblocks) && ctx->d_hist == ctx->d_hist_own && !ctx->hist_exposed;
+    if (range_made) {
+        sc.range_hist = ctx->d_hist;
+        sc.range = reinterpret_cast<uint32_t *>(ctx->d_counters + 8);  // (zeroed with the counters)
+    }
     prof_begin(ctx, ST_K1, s);
     rc = szk_launch_blk_compress(ctx->dtype, d_in, ctx->d_codes, &bp, &sc, s);
     prof_end(ctx, ST_K1, s);
     if (rc) return fail(SZ3HIP_EHIP, "block predictor kernel launch failed (%d)", rc);
+    ctx->range_ready = range_made;
     memset(&ctx->mode, 0, sizeof(ctx->mode));
     ctx->mode.probe_big = reinterpret_cast<uint32_t *>(ctx->d_counters + 4);
     szh_header &h = ctx->proto;

@@ -296,7 +296,11 @@ struct szk_blk_scratch {
     int wide_hist;          // encode: 16384-bin LDS histogram window instead of 4096 (the context's previous alphabet was wide)
     uint8_t side_hdr[32];   // decode: host copy of the side section's header + [24..31] words of its bit section (validated by the caller)
     double *stats5;         // encode, 4-D arrays: [5] Rice statistics of the five coefficients (zeroed by the caller)
+    const uint64_t *range_hist;  // encode, optional: the call's histogram and its three range words (at zero) — a small array's side launch then also
+    uint32_t *range;             // finds the range of the non-empty bins (k_hist_range's work in 64 more workgroups of that launch); see szk_blk_side_small()
 };
+// 1: the side section of a stream of `nblocks` blocks is built by the one-workgroup launch (which takes the range words along when given)
+int szk_blk_side_small(uint64_t nblocks);
 // the selection pass alone (a block per lane): *n_other += the blocks that would not be coded by first-order Lorenzo
 // the tuner's Lorenzo trial for 1-D arrays: the set [Lorenzo-1, Lorenzo-2] in blocks of five over the sample blocks (sz3hip_regress.hip)
 int szk_launch_trial_lorenzo12(int dtype, const void *d_samples, uint64_t per, uint64_t nsb, double eb, int radius, uint64_t *hist, uint64_t *counters,

@@ -1249,10 +1249,24 @@ __device__ __forceinline__ void side_put_block(uint32_t *bits, uint64_t pos, con
 #endif
 template <int NC, bool RANK>
 __global__ __launch_bounds__(1024) void k_blk_side_small(const uint8_t *sel, uint32_t nblocks, uint32_t *rank, uint32_t *comp, uint64_t *n_reg_io,
-                                                         const int64_t *coef, double *stats, uint32_t *group_bits, uint8_t *side, uint64_t *side_bytes) {
+                                                         const int64_t *coef, double *stats, uint32_t *group_bits, uint8_t *side, uint64_t *side_bytes,
+                                                         const uint64_t *range_hist, uint32_t *range) {
 #ifdef LAB_SIDE_TS
     uint64_t lab_ts[8];
 #endif
+    if (blockIdx.x > 0) {  // (workgroups 1 .. 64: the range of the histogram's non-empty bins — k_hist_range's work, which stage 2 then finds done)
+        const uint32_t i = (blockIdx.x - 1) * 1024u + threadIdx.x;
+        const bool nz = range_hist[i] != 0;
+        const unsigned long long m = __ballot(nz);
+        if (m && lane_id() == 0) {
+            const uint32_t base = i;  // lane 0's bin
+            const uint32_t lo = base + (uint32_t)__ffsll((long long)m) - 1, hi = base + 63u - (uint32_t)__clzll((long long)m);
+            atomicMax(&range[0], 0xFFFFu - lo);
+            atomicMax(&range[1], hi);
+            atomicAdd(&range[2], (uint32_t)__popcll(m));
+        }
+        return;
+    }
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
     __shared__ double s_stats[NC];
@@ -5520,7 +5534,7 @@ static int launch_blk_side_build(const szk_blk_params *p, const szk_blk_scratch 
     uint32_t *group_bits = sc->rank;
     if (nblocks <= SIDE_SMALL_BLOCKS && !(szk_dbg_flags & 2048)) {  // (debug flag 2048: the eight launches whatever the block count)
         double *st = p->ndim == 4 ? sc->stats5 : stats;
-#define SIDE_SMALL(NC, RK) hipLaunchKernelGGL((k_blk_side_small<NC, RK>), dim3(1), dim3(1024), 0, s, (const uint8_t *)p->sel, nblocks, sc->rank, sc->comp, sc->counters + 0, (const int64_t *)p->coef, st, group_bits, sc->side, sc->counters + 2)
+#define SIDE_SMALL(NC, RK) hipLaunchKernelGGL((k_blk_side_small<NC, RK>), dim3(sc->range ? 1 + SZH_HIST_BINS / 1024 : 1), dim3(1024), 0, s, (const uint8_t *)p->sel, nblocks, sc->rank, sc->comp, sc->counters + 0, (const int64_t *)p->coef, st, group_bits, sc->side, sc->counters + 2, sc->range_hist, sc->range)
         if (p->ndim == 4) {
             if (rank_done) SIDE_SMALL(5, false);
             else SIDE_SMALL(5, true);
@@ -5552,6 +5566,7 @@ static int launch_blk_side_build(const szk_blk_params *p, const szk_blk_scratch 
     return 0;
 }
 
+int szk_blk_side_small(uint64_t nblocks) { return nblocks <= SIDE_SMALL_BLOCKS && !(szk_dbg_flags & 2048) ? 1 : 0; }
 int szk_launch_blk_select(int dtype, const void *d_in, const szk_blk_params *p, uint64_t *n_other, hipStream_t s) {
     const uint32_t nblocks = blk_count_blocks(p);
     const dim3 g((nblocks + 255) / 256), b(256);

@@ -2082,11 +2082,13 @@ static bool grow_lists(sz3hip_ctx *ctx, uint64_t want) {  // (the stream is idle
     ctx->out_alloc = want;
     return true;
 }
-// stage 1 once more with lists that hold `need` unpredictable values (up to n / 8: beyond that no stream beats the lossless fallback)
-int szi_stage1_with_larger_lists(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, uint64_t need, void *stream) {
+// stage 1 once more with lists that hold `need` unpredictable values (this library's own streams: up to n / 8, beyond that no stream beats the
+// lossless fallback; `any_number` — a stock container's writer: as many as there are, the reference keeps lossy streams of nothing else)
+int szi_stage1_with_larger_lists(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, uint64_t need, void *stream, bool any_number) {
     const uint64_t n = conf->num;
-    if (need > out_cap_limit(n)) return fail(SZ3HIP_EOUTLIERS, "outlier capacity exceeded: data not compressible at this bound");
-    const uint64_t want = std::min<uint64_t>(out_cap_limit(n), need + need / 16 + 1024);
+    const uint64_t limit = any_number ? std::max<uint64_t>(1024, n) : out_cap_limit(n);
+    if (need > limit) return fail(SZ3HIP_EOUTLIERS, "outlier capacity exceeded: data not compressible at this bound");
+    const uint64_t want = std::min<uint64_t>(limit, need + need / 16 + 1024);
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     if (!grow_lists(ctx, want)) return fail(SZ3HIP_EOUTLIERS, "no memory for larger outlier lists");
     ctx->force_out_cap = want;

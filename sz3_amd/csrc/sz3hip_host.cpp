@@ -1032,6 +1032,25 @@ struct DevArena {
 // size (one host thread: ~0.4 GB/s), for archives that must compare equal to the reference's.
 static size_t stock_frame(size_t n) { return env_int("SZ3HIP_STOCK_ONE_FRAME", 0) ? std::max<size_t>(n, 1) : zs::FRAME; }
 static bool stock_host_huffman() { return env_int("SZ3HIP_STOCK_HOST_HUFFMAN", 0) != 0; }  // (A/B partner of the device coder, for tests)
+// When a lossy stream gives way to the lossless one in the reference: Lossless_zstd::compress (lossless/Lossless_zstd.hpp:29-37) throws length_error
+// when ZSTD_compressBound of the stream exceeds the room behind the 8-byte length, and the dispatcher answers that with ALGO_LOSSLESS
+// (SZDispatcher.hpp:44-59) — a rule about the CALLER's buffer and the stream's length, whatever the stream holds: an array of nothing but
+// unpredictable values stays a lossy container (values + a one-symbol code book fit), one whose Huffman tree outgrows the array does not.
+// The writers below keep any number of unpredictable values and apply that rule, nothing of their own. (Round 6, tests/checks/wild_data_sweep.py:
+// before, lists of more than n / 8 values, or n_unpred (sizeof(T) + 2) >= half the array, went lossless — smaller files than the reference's
+// on periodic data at bounds below the values' spacing, other bytes.)
+static bool stock_room_short(SlabJob &j, size_t raw_len) {
+    if (j.out_cap >= 8 && j.out_cap - 8 >= zs::bound(raw_len)) return false;
+    j.lossless = true;
+    return true;
+}
+// (several frames may need a few bytes more than one frame's bound: the lossless stream then, too)
+static int stock_zstd_failed(SlabJob &j) {
+    const int code = sz3hip_last_error_code();
+    if (code != SZ3HIP_ECAPACITY) return code;
+    j.lossless = true;
+    return SZ3HIP_EUNSUPPORTED;
+}
 // 0: j.out holds [u64 rawLen][zstd frames] of a stock stream and j.conf names it; SZ3HIP_EUNSUPPORTED: stage 1 took another predictor
 int stock_encode_interp(SlabJob &j) {
     HostSlot *s = j.slot;
@@ -1040,7 +1059,7 @@ int stock_encode_interp(SlabJob &j) {
     uint64_t n_unpred = 0;
     int rc = szi_stock_stage1_outcome(ctx, &sp, &n_unpred, s->stream);
     if (rc == SZ3HIP_EOUTLIERS) {  // more unpredictable values than the default lists hold: stage 1 once more with lists that do
-        rc = szi_stage1_with_larger_lists(ctx, &j.conf, s->dev_in, n_unpred, s->stream);
+        rc = szi_stage1_with_larger_lists(ctx, &j.conf, s->dev_in, n_unpred, s->stream, true);
         if (!rc) rc = szi_stock_stage1_outcome(ctx, &sp, &n_unpred, s->stream);
         if (rc == SZ3HIP_EOUTLIERS) {
             j.lossless = true;  // (the reference's length_error fallback, SZDispatcher.hpp:44-59; job_encode writes the lossless stream)
@@ -1114,8 +1133,9 @@ int stock_encode_interp(SlabJob &j) {
     raw.reserve((size_t)bit_bytes + (size_t)n_unpred * tsize + (1u << 20));
     stock::write_head(sp, g.anchor, un.data(), n_unpred, tsize, tr, lo, hi, n, bit_bytes, raw);
     raw.insert(raw.end(), bits.begin(), bits.end());
+    if (stock_room_short(j, raw.size())) return SZ3HIP_EUNSUPPORTED;
     j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap, nullptr, stock_frame(raw.size()));  // (concatenated frames: ZSTD_decompress, which stock SZ3 calls, decodes them all)
-    if (!j.out_size) return sz3hip_last_error_code();
+    if (!j.out_size) return stock_zstd_failed(j);
     if (j.tm) j.tm->lap("zstd");
     j.conf.cmprAlgo = SZ3HIP_ALGO_INTERP;
     j.conf.interpAlgo = (uint8_t)sp.interp_id;
@@ -1125,7 +1145,7 @@ int stock_encode_interp(SlabJob &j) {
     j.conf.interpBeta = sp.beta;
     if ((double)j.raw_bytes / (double)j.out_size < 3) {  // SZDispatcher.hpp:62-74
         std::vector<uint8_t> z(zs::bound_frames(j.raw_bytes) + 8);
-        size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size());
+        size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size(), nullptr, stock_frame(j.raw_bytes));
         if (zsz && zsz < j.out_size && zsz <= j.out_cap) {
             memcpy(j.out, z.data(), zsz);
             j.out_size = zsz;
@@ -1277,10 +1297,6 @@ int stock_encode_nopred(SlabJob &j) {
     std::vector<uint8_t> un((size_t)n_unpred * tsize + 8), bits;
     if (n_unpred) HIPCHK(hipMemcpyAsync(un.data(), d_unpred, (size_t)n_unpred * tsize, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    if (n_unpred * (tsize + 2) >= j.raw_bytes / 2) {
-        j.lossless = true;
-        return SZ3HIP_EUNSUPPORTED;
-    }
     stock::Tree tr;
     std::vector<uint8_t> clen;
     std::vector<uint64_t> cbits;
@@ -1307,12 +1323,13 @@ int stock_encode_nopred(SlabJob &j) {
     raw.reserve((size_t)bit_bytes + (size_t)n_unpred * tsize + (1u << 20));
     stock::write_lorenzo_reg_head(cf.N, 1, cf.absErrorBound, tsize, false, false, {}, nullptr, 0, nullptr, 0, {}, radius, un.data(), n_unpred, tr, lo, hi, n, bit_bytes, raw);
     raw.insert(raw.end(), bits.begin(), bits.end());
-    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap, nullptr, stock_frame(raw.size()));
-    if (!j.out_size) return sz3hip_last_error_code();
+    if (stock_room_short(j, raw.size())) return SZ3HIP_EUNSUPPORTED;
+    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap, nullptr, stock_frame(raw.size()));  // (concatenated frames: ZSTD_decompress, which stock SZ3 calls, decodes them all)
+    if (!j.out_size) return stock_zstd_failed(j);
     j.conf.cmprAlgo = SZ3HIP_ALGO_NOPRED;
     if ((double)j.raw_bytes / (double)j.out_size < 3) {  // SZDispatcher.hpp:62-74
         std::vector<uint8_t> z(zs::bound_frames(j.raw_bytes) + 8);
-        size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size());
+        size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size(), nullptr, stock_frame(j.raw_bytes));
         if (zsz && zsz < j.out_size && zsz <= j.out_cap) {
             memcpy(j.out, z.data(), zsz);
             j.out_size = zsz;
@@ -1349,10 +1366,6 @@ static int stock_encode_lorenzo_reg_1d(SlabJob &j) {
         n_unpred = unpred.size();
         un.assign((const uint8_t *)unpred.data(), (const uint8_t *)unpred.data() + n_unpred * 8);
     }
-    if (n_unpred * (tsize + 2) >= j.raw_bytes / 2) {
-        j.lossless = true;
-        return SZ3HIP_EUNSUPPORTED;
-    }
     if (!stock::encode_codes_host(codes, tr, lo, hi, bits)) return fail(SZ3HIP_EHIP, "stock stream: empty code histogram");
     un.resize(un.size() + 8);
     const void *pui = j.cdt == SZ3HIP_FLOAT ? (const void *)ui32.data() : (const void *)ui64.data(), *pul = j.cdt == SZ3HIP_FLOAT ? (const void *)ul32.data() : (const void *)ul64.data();
@@ -1360,12 +1373,13 @@ static int stock_encode_lorenzo_reg_1d(SlabJob &j) {
     stock::write_lorenzo_reg_head(1, B, cf.absErrorBound, tsize, cf.regression != 0, members > 1, coef_codes, pui, nui, pul, nul, selection, radius, un.data(), n_unpred, tr, lo, hi,
                                   n, bits.size(), raw);
     raw.insert(raw.end(), bits.begin(), bits.end());
-    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap, nullptr, stock_frame(raw.size()));
-    if (!j.out_size) return sz3hip_last_error_code();
+    if (stock_room_short(j, raw.size())) return SZ3HIP_EUNSUPPORTED;
+    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap, nullptr, stock_frame(raw.size()));  // (concatenated frames: ZSTD_decompress, which stock SZ3 calls, decodes them all)
+    if (!j.out_size) return stock_zstd_failed(j);
     j.conf.cmprAlgo = SZ3HIP_ALGO_LORENZO_REG;
     if ((double)j.raw_bytes / (double)j.out_size < 3) {  // SZDispatcher.hpp:62-74
         std::vector<uint8_t> z(zs::bound_frames(j.raw_bytes) + 8);
-        size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size());
+        size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size(), nullptr, stock_frame(j.raw_bytes));
         if (zsz && zsz < j.out_size && zsz <= j.out_cap) {
             memcpy(j.out, z.data(), zsz);
             j.out_size = zsz;
@@ -1523,10 +1537,6 @@ int stock_encode_lorenzo_reg(SlabJob &j) {
     std::vector<uint8_t> un((size_t)n_unpred * tsize + 8), bits;
     if (n_unpred) HIPCHK(hipMemcpyAsync(un.data(), d_recon, (size_t)n_unpred * tsize, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    if (n_unpred * (tsize + 2) >= j.raw_bytes / 2) {  // (more unpredictable values than a stream is worth: the lossless stream, as for the other paths)
-        j.lossless = true;
-        return SZ3HIP_EUNSUPPORTED;
-    }
     stock::Tree tr;
     std::vector<uint8_t> clen;
     std::vector<uint64_t> cbits;
@@ -1564,13 +1574,14 @@ int stock_encode_lorenzo_reg(SlabJob &j) {
     stock::write_lorenzo_reg_head(N, B, cf.absErrorBound, tsize, has_reg, composed, coef_codes, pui, nui, pul, nul, selection, radius, un.data(), n_unpred, tr, lo, hi, n,
                                   bit_bytes, raw);
     raw.insert(raw.end(), bits.begin(), bits.end());
-    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap, nullptr, stock_frame(raw.size()));
-    if (!j.out_size) return sz3hip_last_error_code();
+    if (stock_room_short(j, raw.size())) return SZ3HIP_EUNSUPPORTED;
+    j.out_size = zs::compress_frames(raw.data(), raw.size(), j.out, j.out_cap, nullptr, stock_frame(raw.size()));  // (concatenated frames: ZSTD_decompress, which stock SZ3 calls, decodes them all)
+    if (!j.out_size) return stock_zstd_failed(j);
     if (j.tm) j.tm->lap("zstd");
     j.conf.cmprAlgo = SZ3HIP_ALGO_LORENZO_REG;
     if ((double)j.raw_bytes / (double)j.out_size < 3) {  // SZDispatcher.hpp:62-74
         std::vector<uint8_t> z(zs::bound_frames(j.raw_bytes) + 8);
-        size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size());
+        size_t zsz = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, z.data(), z.size(), nullptr, stock_frame(j.raw_bytes));
         if (zsz && zsz < j.out_size && zsz <= j.out_cap) {
             memcpy(j.out, z.data(), zsz);
             j.out_size = zsz;
@@ -2004,7 +2015,8 @@ int job_encode(SlabJob &j) {
     }
     if (j.lossless) {
         j.conf.cmprAlgo = SZ3HIP_ALGO_LOSSLESS;
-        j.out_size = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, j.out, j.out_cap);
+        // (a stock container's lossless stream: one frame when the lossy ones are, SZ3HIP_STOCK_ONE_FRAME: the reference's bytes)
+        j.out_size = zs::compress_frames((const uint8_t *)j.data, j.raw_bytes, j.out, j.out_cap, nullptr, g_stock_format.load() > 0 ? stock_frame(j.raw_bytes) : zs::FRAME);
         if (!j.out_size) return j.failed(sz3hip_last_error_code());
     }
     return 0;

@@ -34,7 +34,7 @@ int szi_stock_export(sz3hip_ctx *ctx, const szg_geom *g, const uint64_t *d_blk_b
 int szi_stock_import(sz3hip_ctx *ctx, const szi_stock_params *p, const szg_geom *g, const uint64_t *d_blk_base, const uint16_t *d_em,
                      const void *d_unpred, uint64_t n_unpred, uint32_t *d_tile_cnt, uint64_t *d_tile_base, uint64_t *d_vout_idx, void *d_vout_val,
                      uint32_t *d_bad, void *d_out, void *stream);
-int szi_stage1_with_larger_lists(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, uint64_t need, void *stream);
+int szi_stage1_with_larger_lists(sz3hip_ctx *ctx, const sz3hip_config *conf, const void *d_in, uint64_t need, void *stream, bool any_number = false);
 // The default algorithm's tuner run from the HOST copy of an array while that array is being copied to the device (the host API: the tuner's
 // launches, round trips and host-side pricing vanish behind the copy). conf: the call's Config with its absolute bound; the next
 // sz3hip_compress_stage1 of this context with the same Config takes the outcome instead of tuning. Returns 0 when it did.

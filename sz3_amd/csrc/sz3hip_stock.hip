@@ -926,11 +926,6 @@ __device__ __forceinline__ T slw_regression(const T *cf, uint32_t i0, uint32_t i
     }
     return pr;
 }
-__device__ __forceinline__ double slw_wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
 struct SlwGeom {
     uint32_t task, oz, oy, ox, ez, ey, ex, nown, hz, tz, ty, tx;
     uint64_t coff;
@@ -981,21 +976,21 @@ __global__ __launch_bounds__(256) void k_slw_select(szk_slw_params p) {
     const bool reg_valid = reg_on && (N == 3 ? g.ez > 1 : true) && g.ey > 1 && g.ex > 1;
     T cf[4] = {0, 0, 0, 0};
     if (reg_valid) {
-        double s0 = 0, s1 = 0, s2 = 0, sn = 0;
-        for (uint32_t t = lane; t < g.nown; t += WAVE) {
-            const uint32_t i2 = t % g.ex, i1 = (t / g.ex) % g.ey, i0 = t / (g.ex * g.ey);
-            // (sum[i] += index[i] * (*c), RegressionPredictor.hpp:43: size_t * T is a product in T; in double it is another coefficient once in
-            // ~10^5 blocks of f32 data — round 6, found by the byte sweep's 1-D twin of this line)
-            const T tv = tl[at(i0 + g.hz, i1 + 2, i2 + 2)];
-            s0 += (double)((T)i0 * tv);
-            s1 += (double)((T)i1 * tv);
-            s2 += (double)((T)i2 * tv);
-            sn += (double)tv;
-        }
-        s0 = slw_wave_sum(s0);
-        s1 = slw_wave_sum(s1);
-        s2 = slw_wave_sum(s2);
-        sn = slw_wave_sum(sn);
+        // the four sums one lane each, in the reference's own order (block_iter::foreach: the last index fastest). A sum of doubles commits to an
+        // order as soon as one addition rounds: f32 values 2^29 apart (a spike of 1e30 among ones: tests/checks/wild_data_sweep.py), any f64 array.
+        // Lane-strided partial sums + a butterfly gave another coefficient there, which shows wherever a coefficient is stored as it is (unpredictable).
+        // (sum[i] += index[i] * (*c), RegressionPredictor.hpp:43: size_t * T is a product in T; in double it is another coefficient once in
+        // ~10^5 blocks of f32 data: round 6, found by the byte sweep's 1-D twin of this line)
+        double acc = 0;
+        if (lane < 4)
+            for (uint32_t i0 = 0; i0 < g.ez; i0++)
+                for (uint32_t i1 = 0; i1 < g.ey; i1++)
+                    for (uint32_t i2 = 0; i2 < g.ex; i2++) {
+                        const T tv = tl[at(i0 + g.hz, i1 + 2, i2 + 2)];
+                        const uint32_t ix = lane == 0 ? i0 : lane == 1 ? i1 : i2;
+                        acc += lane == 3 ? (double)tv : (double)((T)ix * tv);
+                    }
+        const double s0 = __shfl(acc, 0), s1 = __shfl(acc, 1), s2 = __shfl(acc, 2), sn = __shfl(acc, 3);
         const double num = (double)g.nown;
         const double dm[3] = {(double)g.ez, (double)g.ey, (double)g.ex};
         const double sm[3] = {s0, s1, s2};
@@ -1019,28 +1014,28 @@ __global__ __launch_bounds__(256) void k_slw_select(szk_slw_params p) {
     // the members' estimates at the block's sample points (2 per step of the diagonal in 2-D, 4 in 3-D), one point per lane
     const uint32_t msz = N == 3 ? min(g.ez, min(g.ey, g.ex)) : min(g.ey, g.ex);
     constexpr uint32_t PPS = N == 3 ? 4u : 2u;
-    double e1 = 0, e2 = 0, er = 0;
-    for (uint32_t q = lane; q < msz * PPS; q += WAVE) {
-        const uint32_t i = q / PPS, w = q % PPS, j = msz - 1 - i;
-        uint32_t i0, i1, i2;
-        if (N == 3) {
-            i0 = i;
-            i1 = (w & 2u) ? j : i;
-            i2 = (w & 1u) ? j : i;
-        } else {
-            i0 = 0;
-            i1 = i;
-            i2 = w ? j : i;
+    // (predict_error[i] += estimate_error(...), ComposedPredictor.hpp:30-33: a member's estimates summed in the sampling order, one lane per member)
+    double eacc = 0;
+    if (lane < 3 && (lane == 0 ? (p.set_mask & 1u) != 0 : lane == 1 ? (p.set_mask & 2u) != 0 : reg_valid))
+        for (uint32_t q = 0; q < msz * PPS; q++) {
+            const uint32_t i = q / PPS, w = q % PPS, j = msz - 1 - i;
+            uint32_t i0, i1, i2;
+            if (N == 3) {
+                i0 = i;
+                i1 = (w & 2u) ? j : i;
+                i2 = (w & 1u) ? j : i;
+            } else {
+                i0 = 0;
+                i1 = i;
+                i2 = w ? j : i;
+            }
+            const uint32_t a = i0 + g.hz, b = i1 + 2, c = i2 + 2;
+            const T v = tl[at(a, b, c)];
+            if (lane == 0) eacc += (double)(T)(fabs((double)(T)(v - slw_lorenzo<T, N, 1>(tl, g.ty, g.tx, a, b, c))) + (N == 3 ? 1.22 : 0.81) * p.eb);
+            else if (lane == 1) eacc += (double)(T)(fabs((double)(T)(v - slw_lorenzo<T, N, 2>(tl, g.ty, g.tx, a, b, c))) + (N == 3 ? 6.8 : 2.76) * p.eb);
+            else eacc += (double)(T)fabs((double)(T)(v - slw_regression<T, N>(cf, i0, i1, i2)));
         }
-        const uint32_t a = i0 + g.hz, b = i1 + 2, c = i2 + 2;
-        const T v = tl[at(a, b, c)];
-        if (p.set_mask & 1u) e1 += (double)(T)(fabs((double)(T)(v - slw_lorenzo<T, N, 1>(tl, g.ty, g.tx, a, b, c))) + (N == 3 ? 1.22 : 0.81) * p.eb);
-        if (p.set_mask & 2u) e2 += (double)(T)(fabs((double)(T)(v - slw_lorenzo<T, N, 2>(tl, g.ty, g.tx, a, b, c))) + (N == 3 ? 6.8 : 2.76) * p.eb);
-        if (reg_valid) er += (double)(T)fabs((double)(T)(v - slw_regression<T, N>(cf, i0, i1, i2)));
-    }
-    e1 = slw_wave_sum(e1);
-    e2 = slw_wave_sum(e2);
-    er = slw_wave_sum(er);
+    const double e1 = __shfl(eacc, 0), e2 = __shfl(eacc, 1), er = __shfl(eacc, 2);
     if (lane == 0) {
         // first minimum in the set's order (std::min_element); an invalid member counts as the largest double
         // (std::min_element's own walk: the first member is the minimum until a later one compares LESS — an estimate that is not a number,
@@ -1239,18 +1234,17 @@ __global__ __launch_bounds__(256) void k_slw_select4(szk_slw_params p) {
     const bool reg_valid = reg_on && g.ew > 1 && g.ez > 1 && g.ey > 1 && g.ex > 1;  // RegressionPredictor.hpp:33-37
     T cf[5] = {0, 0, 0, 0, 0};
     if (reg_valid) {
-        double sm[4] = {0, 0, 0, 0}, sn = 0;
-        for (uint32_t t = lane; t < g.nown; t += WAVE) {
-            const uint32_t i3 = t % g.ex, i2 = (t / g.ex) % g.ey, i1 = (t / (g.ex * g.ey)) % g.ez, i0 = t / (g.ex * g.ey * g.ez);
-            const T tv = tl[at(i0 + 1, i1 + 1, i2 + 1, i3 + 1)];  // (products in T: see k_slw_select)
-            sm[0] += (double)((T)i0 * tv);
-            sm[1] += (double)((T)i1 * tv);
-            sm[2] += (double)((T)i2 * tv);
-            sm[3] += (double)((T)i3 * tv);
-            sn += (double)tv;
-        }
-        for (int i = 0; i < 4; i++) sm[i] = slw_wave_sum(sm[i]);
-        sn = slw_wave_sum(sn);
+        double acc = 0;  // (one lane per sum, the reference's order, products in T: see k_slw_select)
+        if (lane < 5)
+            for (uint32_t i0 = 0; i0 < g.ew; i0++)
+                for (uint32_t i1 = 0; i1 < g.ez; i1++)
+                    for (uint32_t i2 = 0; i2 < g.ey; i2++)
+                        for (uint32_t i3 = 0; i3 < g.ex; i3++) {
+                            const T tv = tl[at(i0 + 1, i1 + 1, i2 + 1, i3 + 1)];
+                            const uint32_t ix = lane == 0 ? i0 : lane == 1 ? i1 : lane == 2 ? i2 : i3;
+                            acc += lane == 4 ? (double)tv : (double)((T)ix * tv);
+                        }
+        const double sm[4] = {__shfl(acc, 0), __shfl(acc, 1), __shfl(acc, 2), __shfl(acc, 3)}, sn = __shfl(acc, 4);
         const double num = (double)g.nown;
         const double dm[4] = {(double)g.ew, (double)g.ez, (double)g.ey, (double)g.ex};
         cf[4] = (T)(sn / num);
@@ -1260,19 +1254,18 @@ __global__ __launch_bounds__(256) void k_slw_select4(szk_slw_params p) {
         }
     }
     const uint32_t msz = min(min(g.ew, g.ez), min(g.ey, g.ex));
-    double e1 = 0, e2 = 0, er = 0;
-    for (uint32_t q = lane; q < msz * 8u; q += WAVE) {
-        const uint32_t i = q / 8u, w = q % 8u, j = msz - 1 - i;
-        const uint32_t i0 = i, i1 = (w & 4u) ? j : i, i2 = (w & 2u) ? j : i, i3 = (w & 1u) ? j : i;
-        const uint32_t a = i0 + 1, b = i1 + 1, c = i2 + 1, d = i3 + 1;
-        const T v = tl[at(a, b, c, d)];
-        if (p.set_mask & 1u) e1 += (double)(T)(fabs((double)(T)(v - slw_lorenzo4<T>(tl, g, a, b, c, d))) + 1.79 * p.eb);
-        if (p.set_mask & 2u) e2 += (double)(T)fabs((double)v);  // (the member predicts 0 and has no noise term for N = 4)
-        if (reg_valid) er += (double)(T)fabs((double)(T)(v - slw_regression4<T>(cf, i0, i1, i2, i3)));
-    }
-    e1 = slw_wave_sum(e1);
-    e2 = slw_wave_sum(e2);
-    er = slw_wave_sum(er);
+    double eacc = 0;  // (one lane per member, the sampling order: see k_slw_select)
+    if (lane < 3 && (lane == 0 ? (p.set_mask & 1u) != 0 : lane == 1 ? (p.set_mask & 2u) != 0 : reg_valid))
+        for (uint32_t q = 0; q < msz * 8u; q++) {
+            const uint32_t i = q / 8u, w = q % 8u, j = msz - 1 - i;
+            const uint32_t i0 = i, i1 = (w & 4u) ? j : i, i2 = (w & 2u) ? j : i, i3 = (w & 1u) ? j : i;
+            const uint32_t a = i0 + 1, b = i1 + 1, c = i2 + 1, d = i3 + 1;
+            const T v = tl[at(a, b, c, d)];
+            if (lane == 0) eacc += (double)(T)(fabs((double)(T)(v - slw_lorenzo4<T>(tl, g, a, b, c, d))) + 1.79 * p.eb);
+            else if (lane == 1) eacc += (double)(T)fabs((double)v);  // (the member predicts 0 and has no noise term for N = 4)
+            else eacc += (double)(T)fabs((double)(T)(v - slw_regression4<T>(cf, i0, i1, i2, i3)));
+        }
+    const double e1 = __shfl(eacc, 0), e2 = __shfl(eacc, 1), er = __shfl(eacc, 2);
     if (lane == 0) {
         const double big = 1.7976931348623157e308;
         double best = 0;

@@ -131,3 +131,15 @@ def test_context_history_sweep(seed):
     function of the input and the configuration, whatever the context did before"""
     out = _run("history_sweep.py", seed, 60)
     assert "mismatches 0" in out
+
+
+@pytest.mark.parametrize("seed", [51, 52])
+def test_wild_data_sweep(seed):
+    """tests/checks/wild_data_sweep.py (round 6): 60 arrays of the kinds the other sweeps do not draw — white noise, constants, zeros, steps, spikes
+    of 1e30, bounds below the values' spacing, magnitudes of 1e30 and f32 denormals, integer-valued floats, negative zeros, NaN / Inf — under a
+    random algorithm: this library's payload within the bound; in stock format the container's bytes are the reference's (given the reference's
+    capacity: its rule for giving a lossy stream up is about the caller's buffer), and the reference's container reads back to the reference's own
+    values bit for bit. (Not counted: non-finite values under a set with the regression member — NaN coefficients' signs, containers the reference
+    cannot read back itself.)"""
+    out = _run("wild_data_sweep.py", seed, 60)
+    assert "failures 0" in out

@@ -11,6 +11,9 @@
 #include "SZ3/api/sz.hpp"
 
 namespace {
+// fields the entry points' argument lists do not carry (set by ref_set_extra before a call, 0 = the Config's defaults)
+int g_quantbin = 0;
+double g_psnr = 0, g_l2norm = 0;
 SZ3::Config make_conf(int N, const size_t *dims_slowest_first, int algo, int eb_mode, double abs_eb, double rel_eb,
                       int lorenzo, int lorenzo2, int regression, int openmp, int interp_algo, int block_size,
                       int interp_dir = -1, int anchor_stride = -2, double alpha = -2, double beta = -2) {
@@ -31,6 +34,9 @@ SZ3::Config make_conf(int N, const size_t *dims_slowest_first, int algo, int eb_
     if (anchor_stride > -2) conf.interpAnchorStride = anchor_stride;
     if (alpha > -2) conf.interpAlpha = alpha;
     if (beta > -2) conf.interpBeta = beta;
+    if (g_quantbin > 0) conf.quantbinCnt = g_quantbin;
+    if (g_psnr > 0) conf.psnrErrorBound = g_psnr;
+    if (g_l2norm > 0) conf.l2normErrorBound = g_l2norm;
     return conf;
 }
 template <class T>
@@ -44,6 +50,12 @@ size_t do_compress(const T *data, char *out, size_t cap, const SZ3::Config &conf
 }  // namespace
 
 extern "C" {
+// quantbinCnt, psnrErrorBound, l2normErrorBound of the Config the next calls fill (0 = leave the default); not part of ref_compress_bound
+void ref_set_extra(int quantbin, double psnr, double l2norm) {
+    g_quantbin = quantbin;
+    g_psnr = psnr;
+    g_l2norm = l2norm;
+}
 // dtype: 0 = f32, 1 = f64 (SZ_FLOAT / SZ_DOUBLE, include/SZ3/utils/Config.hpp:27-36)
 size_t ref_compress(int dtype, const void *data, int N, const size_t *dims, int algo, int eb_mode, double abs_eb,
                     double rel_eb, int lorenzo, int lorenzo2, int regression, int openmp, int interp_algo, int block_size,

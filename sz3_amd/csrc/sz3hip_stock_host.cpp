@@ -735,21 +735,17 @@ void lorenzo_reg_write_1d(uint64_t n, uint32_t B, double eb, int radius, uint32_
                 if (set_mask & 2u) e2 += (double)(T)(fabs((double)(T)(v - (T)((T)(2 * at(i - 1)) - at(i - 2)))) + 1.08 * eb);
                 if (reg_valid) er += (double)(T)fabs((double)(T)(v - (T)((T)(cf[0] * (T)pts[q]) + cf[1])));
             }
-            double best = HUGE_VAL;
+            // (std::min_element's own walk, ComposedPredictor.hpp:38: the first member is the minimum until a later one compares LESS — an
+            // estimate that is not a number, a block with NaN or Inf - Inf in it, is never less and, in front, never beaten)
+            double best = 0;
             uint32_t k = 0;
-            if (set_mask & 1u) {
-                if (e1 < best) best = e1, kind = 0, idx = k;
+            auto member = [&](double e, uint32_t kd) {
+                if (k == 0 || e < best) best = e, kind = kd, idx = k;
                 k++;
-            }
-            if (set_mask & 2u) {
-                if (e2 < best) best = e2, kind = 1, idx = k;
-                k++;
-            }
-            if (set_mask & 4u) {
-                const double e = reg_valid ? er : big;
-                if (e < best) best = e, kind = 2, idx = k;
-                k++;
-            }
+            };
+            if (set_mask & 1u) member(e1, 0u);
+            if (set_mask & 2u) member(e2, 1u);
+            if (set_mask & 4u) member(reg_valid ? er : big, 2u);
             selection.push_back((uint16_t)idx);
         } else {
             kind = (set_mask & 1u) ? 0u : ((set_mask & 2u) ? 1u : 2u);

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ctypes as C
 import numpy as np, sz3_amd
-from oracle_binding import (ALGO_INTERP, ALGO_INTERP_LORENZO, ALGO_LORENZO_REG, EB_REL, make_config, oracle_compress,
+from oracle_binding import (ALGO_INTERP, ALGO_INTERP_LORENZO, ALGO_LORENZO_REG, EB_REL, EB_PSNR, EB_L2NORM, EB_ABS_AND_REL, EB_ABS_OR_REL, make_config, oracle_compress,
                             have_ref, ref_compress, ref, oracle, _dtype_id)
 os.environ["SZ3HIP_STOCK_ONE_FRAME"] = "1"
 os.environ.pop("SZ3HIP_TUNER_EXACT", None)
@@ -81,11 +81,24 @@ def draw(kind, shape, dtype):
     raise ValueError(kind)
 
 
+def ref_read(blob, a):
+    """the reference's (the oracle's) reading of a container, in a process of its own (it aborts on some of its own containers:
+    tests/checks/_ref_read.py) -> (array or None, the last line of its stderr)"""
+    with tempfile.TemporaryDirectory() as td:
+        np.ascontiguousarray(blob).tofile(os.path.join(td, "c.sz"))
+        pr = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "_ref_read.py"), os.path.join(td, "c.sz"), np.dtype(a.dtype).name, str(a.size),
+                             os.path.join(td, "d.bin"), "1" if USE_REF else "0"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        if pr.returncode == 0:
+            return np.fromfile(os.path.join(td, "d.bin"), dtype=a.dtype).reshape(a.shape), ""
+        err = [l for l in pr.stderr.decode(errors="replace").strip().splitlines() if "OpenMP enabled" not in l]
+        return None, (err[-1][:160] if err else "rc %d" % pr.returncode)
+
+
 def same_bits(x, y):
     return x.shape == y.shape and x.dtype == y.dtype and x.tobytes() == y.tobytes()
 
 
-bad = n_cases = n_stock = n_unreadable = n_known = 0
+bad = n_cases = n_stock = n_unreadable = n_known = n_cross = 0
 for k in range(int(os.environ.get("N", "40"))):
     nd = int(rng.choice([1, 2, 3, 3, 4]))
     dtype = np.float64 if rng.random() < 0.3 else np.float32
@@ -103,14 +116,33 @@ for k in range(int(os.environ.get("N", "40"))):
     fin = np.isfinite(a)
     af = a.astype(np.float64)
     vr = float(af[fin].max() - af[fin].min()) if fin.any() else 0.0
-    rel = may_rel and vr > 0 and rng.random() < 0.3
-    if rel:
-        relv = float(10.0 ** rng.uniform(-5, -1.5))
+    # the bound's mode (the range-based ones where the range is a finite positive number) and the quantiser's bin count
+    mode = "abs"
+    if may_rel and vr > 0 and rng.random() < 0.4:
+        mode = str(rng.choice(["rel", "rel", "abs_and_rel", "abs_or_rel", "psnr", "l2norm"]))
+    vr_t = float(np.float32(af[fin].max()) - np.float32(af[fin].min())) if (dtype == np.float32 and fin.any()) else vr
+    relv = float(10.0 ** rng.uniform(-5, -1.5))
+    conf.absErrorBound = ebv; kw.update(abs_eb=ebv)
+    bound = ebv
+    if mode == "rel":
         conf.errorBoundMode = sz3_amd.EB_REL; conf.relErrorBound = relv; kw.update(eb_mode=EB_REL, rel_eb=relv)
-        bound = relv * (float(np.float32(af[fin].max()) - np.float32(af[fin].min())) if dtype == np.float32 else vr)
-    else:
-        conf.absErrorBound = ebv; kw.update(abs_eb=ebv)
-        bound = ebv
+        bound = relv * vr_t
+    elif mode in ("abs_and_rel", "abs_or_rel"):
+        both = mode == "abs_and_rel"
+        conf.errorBoundMode = sz3_amd.EB_ABS_AND_REL if both else sz3_amd.EB_ABS_OR_REL; conf.relErrorBound = relv
+        kw.update(eb_mode=EB_ABS_AND_REL if both else EB_ABS_OR_REL, rel_eb=relv)
+        bound = min(ebv, relv * vr_t) if both else max(ebv, relv * vr_t)
+    elif mode == "psnr":
+        ps = float(rng.choice([30.0, 50.0, 70.0, 90.0]))
+        conf.errorBoundMode = sz3_amd.EB_PSNR; conf.psnrErrorBound = ps; kw.update(eb_mode=EB_PSNR, psnrErrorBound=ps)
+        bound = None  # (what the mode promises is checked by tests/checks/host_sweep.py; here: the container's bytes)
+    elif mode == "l2norm":
+        l2 = ebv * float(np.sqrt(a.size))
+        conf.errorBoundMode = sz3_amd.EB_L2NORM; conf.l2normErrorBound = l2; kw.update(eb_mode=EB_L2NORM, l2normErrorBound=l2)
+        bound = None
+    if rng.random() < 0.3:
+        qb = int(rng.choice([16, 64, 256, 1024, 4096, 32768]))
+        conf.quantbinCnt = qb; kw.update(quantbinCnt=qb)
     if algo == "interp":
         fact = [1, 1, 2, 6, 24][ndim]
         p = dict(interp_algo=int(rng.integers(0, 2)), interpDirection=int(rng.integers(0, fact)), interpAlpha=float(rng.choice([1.0, 1.25, 1.5, 2.0])),
@@ -139,10 +171,12 @@ for k in range(int(os.environ.get("N", "40"))):
         err = float(np.abs(df[fin] - af[fin]).max()) if fin.any() else 0.0
         ok = dec.shape == a.shape and np.array_equal(np.isnan(df), np.isnan(af)) and np.array_equal(df[~fin & ~np.isnan(af)], af[~fin & ~np.isnan(af)])
         # (f32: the decoder's value is the f32 nearest to the f64 reconstruction — the reference's guarantee too)
-        slack = bound * 1e-6 + (float(np.spacing(np.float32(np.abs(af[fin]).max()))) if dtype == np.float32 and fin.any() else 0.0) * 0.5
-        if not (ok and err <= bound + slack):
+        if bound is not None:
+            slack = bound * 1e-6 + (float(np.spacing(np.float32(np.abs(af[fin]).max()))) if dtype == np.float32 and fin.any() else 0.0) * 0.5
+            ok = ok and err <= bound + slack
+        if not ok:
             bad += 1
-            print("NATIVE FAIL %s: err %.6g bound %.6g nonfinite-ok %s" % (tag, err, bound, ok), flush=True)
+            print("NATIVE FAIL %s: err %.6g bound %s" % (tag, err, bound), flush=True)
     except Exception as e:
         bad += 1
         print("NATIVE EXC %s: %s" % (tag, str(e)[:120]), flush=True)
@@ -169,16 +203,31 @@ for k in range(int(os.environ.get("N", "40"))):
     except Exception as e:
         print("%s: reference compress: %s (skipped)" % (tag, str(e)[:100]), flush=True)
         continue
+    # Non-finite values under a set with the regression member, reported but not counted: (a) the reference's writer and reader lose step there —
+    # a block with an extent of 1 whose Lorenzo estimate is +Inf "selects" the invalid regression member (DBL_MAX < Inf), is coded by the
+    # fallback predictor and leaves NO selection entry (ComposedPredictor.hpp:25-39, BlockwiseDecomposition.hpp:35-37), while the reader takes
+    # one per block (ComposedPredictor.hpp:47-50): its own file decodes to other values or past the end of the list (the crashes below). This
+    # library writes the entry — a file the reference reads correctly — and refuses the reference's as corrupt when the count is short.
+    # (b) a coefficient that is NaN is stored as it is, and its SIGN is the compiler's and the instruction set's (x86: an invalid operation
+    # makes a negative NaN, a propagated one keeps its operand's; gfx950 makes positive ones).
+    known = (not fin.all()) and bool(kw.get("regression", False))
     if sblob is not None:
         n_stock += 1
         if sblob.tobytes() != ob.tobytes():
-            # (not-a-number values under a set with the regression member: the reference's coefficients there are NaN whose SIGN is the x86
-            # instruction's — the default NaN of an invalid operation is negative, a propagated one keeps its operand's — or its writer stops
-            # in the middle of a block's coefficients and cannot read the file back; reported, not counted)
-            known = (not fin.all()) and kw.get("regression", False)
             if known: n_known += 1
             else: bad += 1
             print("STOCK BYTES MISMATCH%s %s: %d vs %d bytes" % (" (non-finite values + regression: not counted)" if known else "", tag, sblob.size, ob.size), flush=True)
+            # other bytes, then at least a container the reference reads to what this library reads from it
+            xr, why = ref_read(sblob, a)
+            if xr is None:
+                print("   (the reference cannot read this library's container either: %s)" % why, flush=True)
+            else:
+                mine, _ = sz3_amd.decompress(sblob, a.dtype, a.shape)
+                if not same_bits(np.ascontiguousarray(mine), np.ascontiguousarray(xr)):
+                    bad += 1
+                    print("   CROSS READ MISMATCH: the reference reads this library's container to other values", flush=True)
+                else:
+                    n_cross += 1
             if VERBOSE:
                 m = min(sblob.size, ob.size)
                 d = np.flatnonzero(sblob[:m] != ob[:m])
@@ -206,27 +255,22 @@ for k in range(int(os.environ.get("N", "40"))):
                         raws[0].tofile(os.environ["DUMP"] + ".ours"); raws[1].tofile(os.environ["DUMP"] + ".ref"); a.tofile(os.environ["DUMP"] + ".in")
                 except Exception as e:
                     print("   (streams in front of zstd: %s)" % str(e)[:100])
-    # the reference's own reading, in a process of its own (it aborts on some of its own containers: tests/checks/_ref_read.py)
-    with tempfile.TemporaryDirectory() as td:
-        ob.tofile(os.path.join(td, "c.sz"))
-        pr = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "_ref_read.py"), os.path.join(td, "c.sz"), np.dtype(a.dtype).name, str(a.size),
-                             os.path.join(td, "d.bin"), "1" if USE_REF else "0"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-        rd = np.fromfile(os.path.join(td, "d.bin"), dtype=a.dtype).reshape(a.shape) if pr.returncode == 0 else None
+    rd, why = ref_read(ob, a)
     if rd is None:
         n_unreadable += 1
         try: sz3_amd.decompress(ob, a.dtype, a.shape)  # (this library's reading of it: an array or an error, nothing to compare with)
         except Exception: pass
-        print("%s: the reference cannot read its own container (%s) (skipped)" % (tag, pr.stderr.decode(errors="replace").strip().splitlines()[-1][:160] if pr.stderr else "rc %d" % pr.returncode), flush=True)
+        print("%s: the reference cannot read its own container (%s) (skipped)" % (tag, why), flush=True)
         continue
     try:
         md, _ = sz3_amd.decompress(ob, a.dtype, a.shape)
         if not same_bits(np.ascontiguousarray(md), np.ascontiguousarray(rd)):
-            bad += 1
+            if not known: bad += 1
             neq = int(np.sum(md.reshape(-1).view("u%d" % md.itemsize) != rd.reshape(-1).view("u%d" % rd.itemsize)))
             print("STOCK READ MISMATCH %s: %d of %d values differ" % (tag, neq, a.size), flush=True)
     except Exception as e:
-        bad += 1
-        print("STOCK READ EXC %s: %s" % (tag, str(e)[:120]), flush=True)
-print("cases %d (stock containers %d, reference = %s; %d the reference could not read back; %d other bytes with non-finite values under regression), failures %d"
-      % (n_cases, n_stock, "the reference build" if USE_REF else "the oracle", n_unreadable, n_known, bad))
+        if not known: bad += 1
+        print("STOCK READ EXC%s %s: %s" % (" (non-finite values + regression: not counted)" if known else "", tag, str(e)[:120]), flush=True)
+print("cases %d (stock containers %d, reference = %s; %d the reference could not read back; %d other bytes with non-finite values under regression, "
+      "%d of them read by the reference to this library's values), failures %d" % (n_cases, n_stock, "the reference build" if USE_REF else "the oracle", n_unreadable, n_known, n_cross, bad))
 sys.exit(1 if bad else 0)

@@ -229,6 +229,9 @@ def ref():
                                       C.c_double, C.c_double, C.c_void_p, C.c_size_t, C.POINTER(C.c_double)]
         L.ref_compress_bound.restype = C.c_size_t
         L.ref_compress_bound.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        if hasattr(L, "ref_set_extra"):  # (quantbinCnt, psnrErrorBound, l2normErrorBound: fields the entry points' lists do not carry)
+            L.ref_set_extra.restype = None
+            L.ref_set_extra.argtypes = [C.c_int, C.c_double, C.c_double]
         L.ref_decompress.restype = C.c_size_t
         L.ref_decompress.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_double)]
         _ref = L
@@ -244,10 +247,18 @@ def ref_compress(a, conf, timing=False):
     cap = L.ref_compress_bound(_dtype_id(a), len(shape), d)
     out = np.empty(cap, dtype=np.uint8)
     sec = C.c_double(0)
-    n = L.ref_compress_ex(_dtype_id(a), a.ctypes.data, len(shape), d, conf.cmprAlgo, conf.errorBoundMode,
-                          conf.absErrorBound, conf.relErrorBound, conf.lorenzo, conf.lorenzo2, conf.regression,
-                          conf.openmp, conf.interpAlgo, conf.blockSize, conf.interpDirection, conf.interpAnchorStride,
-                          conf.interpAlpha, conf.interpBeta, out.ctypes.data, cap, C.byref(sec))
+    extra = hasattr(L, "ref_set_extra")
+    if extra:
+        L.ref_set_extra(int(conf.quantbinCnt), float(conf.psnrErrorBound), float(conf.l2normErrorBound))
+    elif conf.quantbinCnt != 65536 or conf.errorBoundMode in (EB_PSNR, EB_L2NORM):
+        raise RuntimeError("this build of oracle/_ref/libsz3ref.so has no ref_set_extra (make -C oracle ref)")
+    try:
+        n = L.ref_compress_ex(_dtype_id(a), a.ctypes.data, len(shape), d, conf.cmprAlgo, conf.errorBoundMode,
+                              conf.absErrorBound, conf.relErrorBound, conf.lorenzo, conf.lorenzo2, conf.regression,
+                              conf.openmp, conf.interpAlgo, conf.blockSize, conf.interpDirection, conf.interpAnchorStride,
+                              conf.interpAlpha, conf.interpBeta, out.ctypes.data, cap, C.byref(sec))
+    finally:
+        if extra: L.ref_set_extra(0, 0.0, 0.0)
     if n == 0:
         raise RuntimeError("reference compress failed")
     blob = out[:n].copy()

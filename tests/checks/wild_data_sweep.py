@@ -22,6 +22,8 @@ KINDS = ["noise", "const", "zeros", "steps", "spikes", "tight", "huge", "denorma
 ONLY = os.environ.get("KINDS")
 SEL = set(int(x) for x in os.environ["CASES"].split(",")) if os.environ.get("CASES") else None
 VERBOSE = bool(os.environ.get("VERBOSE"))
+BIG = bool(os.environ.get("BIG"))
+OMP = bool(os.environ.get("OMP"))
 if ONLY: KINDS = ONLY.split(",")
 
 
@@ -102,10 +104,16 @@ bad = n_cases = n_stock = n_unreadable = n_known = n_cross = 0
 for k in range(int(os.environ.get("N", "40"))):
     nd = int(rng.choice([1, 2, 3, 3, 4]))
     dtype = np.float64 if rng.random() < 0.3 else np.float32
-    if nd == 1: shape = (int(rng.integers(1, 200000)),)
+    if BIG:  # 4 M .. 20 M elements: the forms large arrays take (the sampled code book, the one-byte packer, the fused decoders)
+        if nd == 1: shape = (int(rng.integers(1 << 22, 20_000_000)),)
+        elif nd == 2: shape = tuple(int(rng.integers(2048, 4400)) for _ in range(2))
+        elif nd == 3: shape = tuple(int(rng.integers(160, 270)) for _ in range(3))
+        else: shape = (int(rng.integers(6, 20)),) + tuple(int(rng.integers(64, 100)) for _ in range(3))
+    elif nd == 1: shape = (int(rng.integers(1, 200000)),)
     elif nd == 2: shape = tuple(int(rng.integers(1, 500)) for _ in range(2))
     elif nd == 3: shape = tuple(int(rng.integers(1, 80)) for _ in range(3))
     else: shape = (int(rng.integers(1, 10)),) + tuple(int(rng.integers(1, 30)) for _ in range(3))
+    do_stock = (not BIG) or rng.random() < 0.2  # (the reference codes ~10 M elements per second)
     kind = str(rng.choice(KINDS))
     a, ebv, may_rel = draw(kind, shape, dtype)
     algo = str(rng.choice(["interp", "default", "lorenzo", "lorenzo"]))
@@ -159,13 +167,23 @@ for k in range(int(os.environ.get("N", "40"))):
         conf.cmprAlgo = sz3_amd.ALGO_LORENZO_REG
         conf.lorenzo, conf.lorenzo2, conf.regression = l1, l2, rg
         kw.update(algo=ALGO_LORENZO_REG, lorenzo=bool(l1), lorenzo2=bool(l2), regression=bool(rg))
-    tag = "case %d %s %s %s %s %s" % (k, kind, algo, a.shape, dtype.__name__, kw)
+    slabs = int(rng.integers(2, 6))
+    # (OMP=1: this library's own container leaves as slabs — SZ_compress_OMP's layout, several on the one GPU. Slabs of at least two rows: one of a
+    # single row loses a dimension (Config::setDims drops extents of one), and an interpDirection of the full rank is then out of range — an error
+    # here, an index past the reference's table of orders)
+    omp = OMP and 2 * slabs <= a.shape[0]
+    tag = "case %d %s %s %s %s %s%s" % (k, kind, algo, a.shape, dtype.__name__, kw, " slabs %d" % slabs if omp else "")
     if SEL and k not in SEL: continue  # (CASES=3,17: only those — every draw is made above, the sequence is the seed's)
     if VERBOSE: print(tag, flush=True)
     n_cases += 1
     # (1) this library's payload
     try:
-        blob, ratio = sz3_amd.compress(a, conf)
+        if omp:
+            conf.openmp = 1; os.environ["SZ3HIP_SLABS"] = str(slabs)
+        try:
+            blob, ratio = sz3_amd.compress(a, conf)
+        finally:
+            conf.openmp = 0; os.environ.pop("SZ3HIP_SLABS", None)
         dec, _ = sz3_amd.decompress(blob, a.dtype, a.shape)
         df = dec.astype(np.float64)
         err = float(np.abs(df[fin] - af[fin]).max()) if fin.any() else 0.0
@@ -180,6 +198,7 @@ for k in range(int(os.environ.get("N", "40"))):
     except Exception as e:
         bad += 1
         print("NATIVE EXC %s: %s" % (tag, str(e)[:120]), flush=True)
+    if not do_stock: continue
     # (2) stock format against the reference
     # (the caller's capacity decides when the reference gives a lossy stream up, lossless/Lossless_zstd.hpp:29-37 + SZDispatcher.hpp:44-59: the same
     # capacity on both sides — what tests/oracle_binding.py hands the reference, the CLI's 2 x the array and more)

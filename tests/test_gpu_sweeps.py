@@ -143,3 +143,10 @@ def test_wild_data_sweep(seed):
     cannot read back itself.)"""
     out = _run("wild_data_sweep.py", seed, 60)
     assert "failures 0" in out
+
+
+def test_integer_wild_sweep():
+    """tests/checks/int_wild_sweep.py (round 6): 60 integer arrays over all eight integer types — the full range of the type, constants, steps,
+    alternating extremes, magnitudes beyond 2^53, bounds from 0.4 (lossless) to 1e6, every algorithm: dtype and shape kept, |x - x^| <= floor(eb)"""
+    out = _run("int_wild_sweep.py", 61, 60)
+    assert "failures: 0" in out

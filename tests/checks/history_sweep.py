@@ -25,10 +25,24 @@ for dtype in (np.float32, np.float64):
             elif kind == "3d": a = field3d(tuple(int(rng.integers(12, 120)) for _ in range(3)), dtype)
             elif kind == "3d-ramps": a = (field_c4a((40, 60, 90), seed=5) * (1.0 if dtype == np.float64 else 1000.0)).astype(dtype)
             elif kind == "big": a = field3d((64, 256, 256), dtype)   # 4 M elements, x a multiple of 256: the sampled book
-            else: a = field4d((int(rng.integers(4, 9)),) + tuple(int(rng.integers(10, 30)) for _ in range(3)), dtype)
+            elif kind == "4d": a = field4d((int(rng.integers(4, 9)),) + tuple(int(rng.integers(10, 30)) for _ in range(3)), dtype)
+            # WILD=1: what a context sees between smooth fields in practice (round 6, beside tests/checks/wild_data_sweep.py)
+            elif kind == "w-noise": a = rng.standard_normal(tuple(int(rng.integers(40, 100)) for _ in range(3))).astype(dtype)
+            elif kind == "w-const": a = np.full((int(rng.integers(100, 900)), int(rng.integers(100, 900))), -3.25, dtype)
+            elif kind == "w-zeros": a = np.zeros((64, 256, 256), dtype)
+            elif kind == "w-spikes":
+                a = field3d(tuple(int(rng.integers(30, 120)) for _ in range(3)), dtype)
+                a.reshape(-1)[rng.integers(0, a.size, size=a.size // 700)] = 1e30
+            elif kind == "w-steps":
+                a = field1d(int(rng.integers(50000, 1 << 20)), dtype)
+                for c in rng.integers(0, a.size, size=7): a[c:] += dtype(float(rng.choice([-100.0, 7.5, 1000.0])))
+            elif kind == "w-bignoise": a = (field3d((64, 256, 256), dtype) + 0.05 * rng.standard_normal((64, 256, 256))).astype(dtype)
+            elif kind == "w-tight": a = (1000.0 * field1d(int(rng.integers(20000, 400000)), np.float64)).astype(dtype)
+            else: raise ValueError(kind)
             pool[kind] = (a, torch.from_numpy(a).to(dev))
         return pool[kind]
     kinds = ["1d", "2d", "3d", "3d-ramps", "4d", "big"]
+    if os.environ.get("WILD"): kinds += ["w-noise", "w-const", "w-zeros", "w-spikes", "w-steps", "w-bignoise", "w-tight"]
     out = torch.empty(MAXN, dtype=torch.float32 if dtype == np.float32 else torch.float64, device=dev)
     last = None
     for k in range(N // 2):

@@ -150,3 +150,11 @@ def test_integer_wild_sweep():
     alternating extremes, magnitudes beyond 2^53, bounds from 0.4 (lossless) to 1e6, every algorithm: dtype and shape kept, |x - x^| <= floor(eb)"""
     out = _run("int_wild_sweep.py", 61, 60)
     assert "failures: 0" in out
+
+
+def test_context_history_sweep_with_wild_arrays(monkeypatch):
+    """the same with noise, constants, zeros, spikes of 1e30, steps and bounds near the values' spacing among the calls (WILD=1): calls the lists
+    cannot hold end in SZ3HIP_EOUTLIERS and the context goes on — the next payloads are a fresh context's"""
+    monkeypatch.setenv("WILD", "1")
+    out = _run("history_sweep.py", 43, 120)
+    assert "mismatches 0" in out

@@ -214,6 +214,45 @@ def test_files_interchange_between_the_two_clis(tmp_path):
     assert (tmp_path / "ours_d.sz").read_bytes() == (tmp_path / "stock_d.sz").read_bytes()
 
 
+@pytest.mark.parametrize("what", ["noise", "periodic-below-spacing", "noise-tiny-bound"])
+def test_the_two_clis_write_one_file_where_lossy_streams_are_not_worth_much(what, tmp_path):
+    """Round 6 (tests/checks/wild_data_sweep.py): when a lossy stream gives way to the lossless one is the reference's rule alone — ZSTD_compressBound
+    of the stream against the room the caller's buffer leaves (lossless/Lossless_zstd.hpp:29-37, SZDispatcher.hpp:44-74; the CLI allocates twice the
+    array, tools/sz3/sz3.cpp:132). White noise (ratio < 3: the comparison with zstd alone), a periodic 1-D array at a bound below its values'
+    spacing (nothing but unpredictable values — which zstd folds to a few hundred bytes: the writers used to hand such arrays to the lossless
+    stream), noise at a bound that makes the Huffman tree outgrow the array (the reference falls back, this library used to fail)."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    ref_dir = os.path.join(os.path.dirname(here), "oracle", "_ref")
+    stock, ours = os.path.join(ref_dir, "sz3"), os.path.join(ref_dir, "sz3_hip")
+    if not (os.path.exists(stock) and os.path.exists(ours)):
+        pytest.skip("oracle/_ref CLIs not built (need /root/reference at build time)")
+    rng = np.random.default_rng(7)
+    if what == "noise":
+        a, dims, eb = rng.standard_normal((46, 44, 50)).astype(np.float32), ["-3", "50", "44", "46"], "1e-3"
+    elif what == "periodic-below-spacing":
+        a, dims, eb = (1000.0 * np.sin(2 * np.pi * np.arange(59359) / 13.0)).astype(np.float32), ["-1", "59359"], "6e-9"
+    else:
+        a, dims, eb = rng.standard_normal((24270,)).astype(np.float32), ["-1", "24270"], "1e-7"
+    src = tmp_path / "a.f32"
+    a.tofile(src)
+
+    def run(exe, args, env=None):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=dict(os.environ, **(env or {})))
+        assert r.returncode == 0, (exe, r.stdout[-800:], r.stderr[-800:])
+
+    for algo in ("ALGO_INTERP_LORENZO", "ALGO_LORENZO_REG"):
+        cfg = tmp_path / (algo + ".cfg")
+        cfg.write_text("[GlobalSettings]\nCmprAlgo = %s\n" % algo)
+        run(stock, ["-f", "-i", str(src), "-z", str(tmp_path / "stock.sz"), "-c", str(cfg)] + dims + ["-M", "ABS", eb])
+        run(ours, ["-f", "-i", str(src), "-z", str(tmp_path / "ours.sz"), "-c", str(cfg)] + dims + ["-M", "ABS", eb], env={"SZ3HIP_STOCK_FORMAT": "1", "SZ3HIP_STOCK_ONE_FRAME": "1"})
+        assert (tmp_path / "ours.sz").read_bytes() == (tmp_path / "stock.sz").read_bytes(), (what, algo)
+        run(stock, ["-f", "-z", str(tmp_path / "ours.sz"), "-o", str(tmp_path / "back")] + dims)
+        back = np.fromfile(tmp_path / "back", dtype=np.float32)
+        assert float(np.max(np.abs(back.astype(np.float64) - a.reshape(-1).astype(np.float64)))) <= float(eb)
+
+
 @pytest.mark.parametrize("eb", [1e-2, 1e-4], ids=["short-codes", "long-codes"])
 def test_device_and_host_huffman_stages_agree(eb, monkeypatch):
     """The stock container's Huffman stage runs on the device (tiles coded in LDS and shifted into place; the decoder re-synchronises

@@ -478,6 +478,7 @@ static int interp_params_from(const sz3hip_config *conf, double eb, int radius, 
     if (ip.anchor_stride & (ip.anchor_stride - 1)) return fail(SZ3HIP_EINVAL, "Anchor stride should be 0 or 2's exponentials");
     int nperm = 1;
     for (int i = 2; i <= conf->N; i++) nperm *= i;
+    if (conf->N == 1) ip.direction = 0;  // (one order whatever the field says: a one-row slab of a 2-D array under SZ_compress_OMP's split comes here with the caller's value)
     if (ip.direction < 0 || ip.direction >= nperm) return fail(SZ3HIP_EINVAL, "interpDirection out of range");
     ip.alpha = conf->interpAlpha;
     ip.beta = conf->interpBeta;

@@ -158,6 +158,10 @@ int szk_stock_geom_build(int N, const uint64_t *dims, int interp_id, int directi
     int p[4] = {0, 1, 2, 3};
     int nperm = 1;
     for (int i = 2; i <= N; i++) nperm *= i;
+    // (a 1-D array has one order whatever the field says: the reference's OpenMP path hands a 2-D array's one-row slabs — a dimension dropped,
+    // Config::setDims — to the 1-D interpolation with the caller's interpDirection, which then indexes past its one-entry table of orders
+    // and, on both sides, finds the identity; tests/checks/wild_data_sweep.py, leg 3)
+    if (N == 1) direction = 0;
     if (direction < 0 || direction >= nperm) return -1;
     for (int k = 0; k < direction; k++) {
         int i = N - 2;

@@ -6,7 +6,7 @@ Per case, with ABS or REL bounds and a random algorithm:
   (2) stock format (one zstd frame): the container's bytes against the REFERENCE's (oracle/_ref/libsz3ref.so; the oracle's restatement when that
       build is absent), and this library's reading of the reference's container against the reference's own, bit for bit.
 SEED, N from the environment; exit code = failures."""
-import os, subprocess, sys, tempfile
+import json, os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ctypes as C
@@ -100,7 +100,7 @@ def same_bits(x, y):
     return x.shape == y.shape and x.dtype == y.dtype and x.tobytes() == y.tobytes()
 
 
-bad = n_cases = n_stock = n_unreadable = n_known = n_cross = 0
+bad = n_cases = n_stock = n_unreadable = n_known = n_cross = n_omp = n_omp_dead = 0
 for k in range(int(os.environ.get("N", "40"))):
     nd = int(rng.choice([1, 2, 3, 3, 4]))
     dtype = np.float64 if rng.random() < 0.3 else np.float32
@@ -114,6 +114,7 @@ for k in range(int(os.environ.get("N", "40"))):
     elif nd == 3: shape = tuple(int(rng.integers(1, 80)) for _ in range(3))
     else: shape = (int(rng.integers(1, 10)),) + tuple(int(rng.integers(1, 30)) for _ in range(3))
     do_stock = (not BIG) or rng.random() < 0.2  # (the reference codes ~10 M elements per second)
+    omp_leg = rng.random() < 0.3
     kind = str(rng.choice(KINDS))
     a, ebv, may_rel = draw(kind, shape, dtype)
     algo = str(rng.choice(["interp", "default", "lorenzo", "lorenzo"]))
@@ -302,6 +303,31 @@ for k in range(int(os.environ.get("N", "40"))):
     except Exception as e:
         if not known: bad += 1
         print("STOCK READ EXC%s %s: %s" % (" (non-finite values + regression: not counted)" if known else "", tag, str(e)[:120]), flush=True)
+    # (3) a container the reference wrote with its OpenMP path (SZ_compress_OMP: a slab per thread along the slowest extent), read here
+    if USE_REF and omp_leg and a.shape[0] >= 4 and not known:
+        kw2 = dict(kw); kw2["openmp"] = True
+        with tempfile.TemporaryDirectory() as td:  # (in a process of its own: the reference's OpenMP path aborts or divides by zero on some shapes)
+            a.tofile(os.path.join(td, "a.bin"))
+            pr = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "_ref_write.py"), os.path.join(td, "a.bin"), np.dtype(a.dtype).name,
+                                 ",".join(str(d) for d in a.shape), json.dumps(kw2), os.path.join(td, "c.sz")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            ob2 = np.fromfile(os.path.join(td, "c.sz"), dtype=np.uint8) if pr.returncode == 0 else None
+        if ob2 is None:
+            n_omp_dead += 1
+            continue
+        rd2, why2 = ref_read(ob2, a)
+        if rd2 is None:
+            print("%s: the reference cannot read its own OpenMP container (%s) (skipped)" % (tag, why2), flush=True)
+            continue
+        n_omp += 1
+        try:
+            md2, _ = sz3_amd.decompress(ob2, a.dtype, a.shape)
+            if not same_bits(np.ascontiguousarray(md2), np.ascontiguousarray(rd2)):
+                bad += 1
+                print("OMP CONTAINER READ MISMATCH %s" % tag, flush=True)
+        except Exception as e:
+            bad += 1
+            print("OMP CONTAINER READ EXC %s: %s" % (tag, str(e)[:120]), flush=True)
+print("the reference's OpenMP containers read: %d (its OpenMP writer died on %d more)" % (n_omp, n_omp_dead))
 print("cases %d (stock containers %d, reference = %s; %d the reference could not read back; %d other bytes with non-finite values under regression, "
       "%d of them read by the reference to this library's values), failures %d" % (n_cases, n_stock, "the reference build" if USE_REF else "the oracle", n_unreadable, n_known, n_cross, bad))
 sys.exit(1 if bad else 0)

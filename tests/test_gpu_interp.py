@@ -278,3 +278,21 @@ def test_dense_hand_over_between_the_two_finest_levels_changes_nothing(shape, dt
             torch.cuda.synchronize()
             outs[flag] = d_pl[:size].cpu().numpy().copy()
         assert np.array_equal(outs[4194304], outs[4194304 | 536870912]), "the dense hand-over changed the payload (direction %d)" % direction
+
+
+def test_a_one_dimensional_array_takes_any_interp_direction():
+    """Round 6 (tests/checks/wild_data_sweep.py, leg 3): a 1-D array has one order of dimensions whatever interpDirection says — the reference's OpenMP
+    path hands one-row slabs of a 2-D array (a dimension dropped by Config::setDims) to the 1-D interpolation with the caller's value; this
+    library used to refuse the value when writing and such a slab as corrupt when reading"""
+    a = np.sin(np.arange(50000) / 37.0).astype(np.float32)
+    blobs = []
+    for d in (0, 1):
+        conf = sz3_amd.Config(a.size)
+        conf.cmprAlgo = sz3_amd.ALGO_INTERP
+        conf.absErrorBound = 1e-3
+        conf.interpDirection = d
+        blob, _ = sz3_amd.compress(a, conf)
+        out, _ = sz3_amd.decompress(blob, a.dtype, a.shape)
+        assert float(np.max(np.abs(out.astype(np.float64) - a.astype(np.float64)))) <= 1e-3
+        blobs.append(out)
+    assert np.array_equal(blobs[0], blobs[1])

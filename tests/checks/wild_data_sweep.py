@@ -11,14 +11,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ctypes as C
 import numpy as np, sz3_amd
-from oracle_binding import (ALGO_INTERP, ALGO_INTERP_LORENZO, ALGO_LORENZO_REG, EB_REL, EB_PSNR, EB_L2NORM, EB_ABS_AND_REL, EB_ABS_OR_REL, make_config, oracle_compress,
+from oracle_binding import (ALGO_INTERP, ALGO_INTERP_LORENZO, ALGO_LORENZO_REG, ALGO_NOPRED, EB_REL, EB_PSNR, EB_L2NORM, EB_ABS_AND_REL, EB_ABS_OR_REL, make_config, oracle_compress,
                             have_ref, ref_compress, ref, oracle, _dtype_id)
 os.environ["SZ3HIP_STOCK_ONE_FRAME"] = "1"
 os.environ.pop("SZ3HIP_TUNER_EXACT", None)
 rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
 L = sz3_amd.lib()
 USE_REF = have_ref() and not os.environ.get("NO_REF")
-KINDS = ["noise", "const", "zeros", "steps", "spikes", "tight", "huge", "denormal", "integers", "negzero", "nonfinite", "ramp", "sparse"]
+KINDS = ["noise", "const", "constrel", "zeros", "steps", "spikes", "tight", "huge", "denormal", "integers", "negzero", "nonfinite", "ramp", "sparse"]
 ONLY = os.environ.get("KINDS")
 SEL = set(int(x) for x in os.environ["CASES"].split(",")) if os.environ.get("CASES") else None
 VERBOSE = bool(os.environ.get("VERBOSE"))
@@ -39,6 +39,8 @@ def draw(kind, shape, dtype):
         return rng.standard_normal(shape).astype(dtype), float(10.0 ** rng.uniform(-5, -1)), True
     if kind == "const":
         return np.full(shape, float(rng.choice([1.0, -3.25, 1e10, 1e-10])), dtype), float(10.0 ** rng.uniform(-4, -1)), False
+    if kind == "constrel":  # a constant array under a range-based bound: range 0 -> bound 0 -> the lossless stream (SZDispatcher.hpp:19-21)
+        return np.full(shape, float(rng.choice([1.0, -3.25, 0.0])), dtype), float(10.0 ** rng.uniform(-4, -1)), True
     if kind == "zeros":
         return np.zeros(shape, dtype), float(10.0 ** rng.uniform(-4, -1)), False
     if kind == "steps":
@@ -117,7 +119,7 @@ for k in range(int(os.environ.get("N", "40"))):
     omp_leg = rng.random() < 0.3
     kind = str(rng.choice(KINDS))
     a, ebv, may_rel = draw(kind, shape, dtype)
-    algo = str(rng.choice(["interp", "default", "lorenzo", "lorenzo"]))
+    algo = str(rng.choice(["interp", "default", "lorenzo", "lorenzo", "nopred"]))
     ndim = max(1, sum(1 for d in a.shape if d > 1))  # (SZ3::Config drops extents of one)
     conf = sz3_amd.Config(*a.shape)
     conf.regression = 0
@@ -127,8 +129,8 @@ for k in range(int(os.environ.get("N", "40"))):
     vr = float(af[fin].max() - af[fin].min()) if fin.any() else 0.0
     # the bound's mode (the range-based ones where the range is a finite positive number) and the quantiser's bin count
     mode = "abs"
-    if may_rel and vr > 0 and rng.random() < 0.4:
-        mode = str(rng.choice(["rel", "rel", "abs_and_rel", "abs_or_rel", "psnr", "l2norm"]))
+    if may_rel and (vr > 0 or kind == "constrel") and rng.random() < (0.4 if vr > 0 else 1.0):
+        mode = str(rng.choice(["rel", "rel", "abs_and_rel", "abs_or_rel", "psnr", "l2norm"] if vr > 0 else ["rel", "abs_and_rel", "abs_or_rel"]))
     vr_t = float(np.float32(af[fin].max()) - np.float32(af[fin].min())) if (dtype == np.float32 and fin.any()) else vr
     relv = float(10.0 ** rng.uniform(-5, -1.5))
     conf.absErrorBound = ebv; kw.update(abs_eb=ebv)
@@ -164,6 +166,9 @@ for k in range(int(os.environ.get("N", "40"))):
             conf.interpAnchorStride = st; kw.update(interpAnchorStride=st)
     elif algo == "default":
         kw.update(algo=ALGO_INTERP_LORENZO)
+    elif algo == "nopred":
+        conf.cmprAlgo = sz3_amd.ALGO_NOPRED
+        kw.update(algo=ALGO_NOPRED)
     else:
         sets = [(1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 1), (1, 1, 1)] if ndim != 4 else [(1, 0, 0), (1, 0, 1)]
         if ndim == 1: sets += [(0, 0, 1)]

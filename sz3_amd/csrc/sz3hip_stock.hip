@@ -950,6 +950,44 @@ __device__ __forceinline__ void slw_geom(const uint64_t (&d)[3], const uint32_t 
     g.ty = g.ey + 2;
     g.tx = g.ex + 2;
 }
+// The reference's fit runs on x86, and where a block holds NaN or Inf its coefficients are NaN whose SIGN is the instruction set's: an invalid
+// operation (0 * Inf, Inf - Inf) makes the negative "default" NaN, an operation with one NaN operand returns that operand, with two the first
+// (the accumulator of `sum += x`, the minuend of a subtraction). gfx950 makes positive NaNs and has rules of its own — and a NaN coefficient is
+// stored as it is (unpredictable), so the sign is in the file. The fit's operations spelled out with x86's rules (finite results are the
+// plain operation's, bit for bit): tools/r6/nan_sign_1d.py shows the one kind that differed on the host — Inf at a block's first element
+// (0 * Inf: negative), a NaN later (positive): the sum keeps its own.
+template <int OP> __device__ __forceinline__ double x86_op(double a, double b) {  // 0 add, 1 sub, 2 mul, 3 div; a = the first (destination) operand
+    if (a != a) return a;
+    if (b != b) return b;
+    const double r = OP == 0 ? a + b : OP == 1 ? a - b : OP == 2 ? a * b : a / b;
+    return r != r ? __longlong_as_double((long long)0xFFF8000000000000ull) : r;
+}
+template <typename T> __device__ __forceinline__ double x86_to_double(T v) {  // (cvtss2sd keeps a NaN's sign)
+    if (v != v) return __longlong_as_double((long long)(signbit(v) ? 0xFFF8000000000000ull : 0x7FF8000000000000ull));
+    return (double)v;
+}
+template <typename T> __device__ __forceinline__ T x86_from_double(double v);
+template <> __device__ __forceinline__ float x86_from_double<float>(double v) {
+    if (v != v) return __uint_as_float(signbit(v) ? 0xFFC00000u : 0x7FC00000u);
+    return (float)v;
+}
+template <> __device__ __forceinline__ double x86_from_double<double>(double v) { return v; }
+template <typename T> __device__ __forceinline__ T x86_index_times(uint32_t ix, T v) {  // index[i] * (*c): a product in T; the index is never NaN
+    if (v != v) return v;
+    const T r = (T)ix * v;
+    if (r != r) return x86_from_double<T>(__longlong_as_double((long long)0xFFF8000000000000ull));
+    return r;
+}
+// coefficient i of RegressionPredictor.hpp:48-53 from its sums
+template <typename T> __device__ __forceinline__ T x86_slope(double sm, double sn, double dm, double num) {
+    double v = x86_op<3>(x86_op<2>(2.0, sm), dm - 1);
+    v = x86_op<1>(v, sn);
+    v = x86_op<3>(x86_op<3>(x86_op<2>(v, 6.0), num), dm + 1);
+    return x86_from_double<T>(v);
+}
+template <typename T> __device__ __forceinline__ T x86_intercept_step(T cn, T ci, double dm) {  // current_coeffs[N] -= (dims[i] - 1) * current_coeffs[i] / 2
+    return x86_from_double<T>(x86_op<1>(x86_to_double(cn), x86_op<3>(x86_op<2>(dm - 1, x86_to_double(ci)), 2.0)));
+}
 template <typename T, int N>
 __global__ __launch_bounds__(256) void k_slw_select(szk_slw_params p) {
     constexpr uint32_t MAXT = N == 3 ? 10u * 10u * 10u : 34u * 34u;
@@ -992,17 +1030,17 @@ __global__ __launch_bounds__(256) void k_slw_select(szk_slw_params p) {
                     for (uint32_t i2 = 0; i2 < g.ex; i2++) {
                         const T tv = tl[at(i0 + g.hz, i1 + 2, i2 + 2)];
                         const uint32_t ix = lane == 0 ? i0 : lane == 1 ? i1 : i2;
-                        acc += lane == 3 ? (double)tv : (double)((T)ix * tv);
+                        acc = x86_op<0>(acc, x86_to_double(lane == 3 ? tv : x86_index_times<T>(ix, tv)));
                     }
         const double s0 = __shfl(acc, 0), s1 = __shfl(acc, 1), s2 = __shfl(acc, 2), sn = __shfl(acc, 3);
         const double num = (double)g.nown;
         const double dm[3] = {(double)g.ez, (double)g.ey, (double)g.ex};
         const double sm[3] = {s0, s1, s2};
-        T cn = (T)(sn / num);
+        T cn = x86_from_double<T>(x86_op<3>(sn, num));
         T ci[3] = {0, 0, 0};
         for (int i = 3 - N; i < 3; i++) {
-            ci[i] = (T)((2 * sm[i] / (dm[i] - 1) - sn) * 6 / num / (dm[i] + 1));
-            cn = (T)((double)cn - (dm[i] - 1) * (double)ci[i] / 2);
+            ci[i] = x86_slope<T>(sm[i], sn, dm[i], num);
+            cn = x86_intercept_step<T>(cn, ci[i], dm[i]);
         }
         if (N == 3) {
             cf[0] = ci[0];
@@ -1246,15 +1284,15 @@ __global__ __launch_bounds__(256) void k_slw_select4(szk_slw_params p) {
                         for (uint32_t i3 = 0; i3 < g.ex; i3++) {
                             const T tv = tl[at(i0 + 1, i1 + 1, i2 + 1, i3 + 1)];
                             const uint32_t ix = lane == 0 ? i0 : lane == 1 ? i1 : lane == 2 ? i2 : i3;
-                            acc += lane == 4 ? (double)tv : (double)((T)ix * tv);
+                            acc = x86_op<0>(acc, x86_to_double(lane == 4 ? tv : x86_index_times<T>(ix, tv)));
                         }
         const double sm[4] = {__shfl(acc, 0), __shfl(acc, 1), __shfl(acc, 2), __shfl(acc, 3)}, sn = __shfl(acc, 4);
         const double num = (double)g.nown;
         const double dm[4] = {(double)g.ew, (double)g.ez, (double)g.ey, (double)g.ex};
-        cf[4] = (T)(sn / num);
+        cf[4] = x86_from_double<T>(x86_op<3>(sn, num));
         for (int i = 0; i < 4; i++) {
-            cf[i] = (T)((2 * sm[i] / (dm[i] - 1) - sn) * 6 / num / (dm[i] + 1));
-            cf[4] = (T)((double)cf[4] - (dm[i] - 1) * (double)cf[i] / 2);
+            cf[i] = x86_slope<T>(sm[i], sn, dm[i], num);
+            cf[4] = x86_intercept_step<T>(cf[4], cf[i], dm[i]);
         }
     }
     const uint32_t msz = min(min(g.ew, g.ez), min(g.ey, g.ex));

@@ -713,15 +713,19 @@ void lorenzo_reg_write_1d(uint64_t n, uint32_t B, double eb, int radius, uint32_
         T cf[2] = {0, 0};
         if (reg_valid) {
             double s0 = 0, sn = 0;
+            // (a NaN's sign is in the file where a coefficient is stored as it is: the operand an x86 instruction returns when BOTH are NaN is its
+            // first — the accumulator of `sum += x`, the minuend — whatever order this compiler gives a commutative operation: sz3hip_stock.hip, x86_op)
+            auto keep = [](double a, double r) { return a != a ? a : r; };
             for (uint32_t t = 0; t < ex; t++) {
-                s0 += (double)((T)t * data[x0 + t]);  // (sum[i] += index[i] * (*c): size_t * T is a product in T, RegressionPredictor.hpp:43 — in double it is
-                                                      // another coefficient once in ~10^5 blocks of f32 data, and the chain behind it another stream)
-                sn += (double)data[x0 + t];
+                s0 = keep(s0, s0 + (double)((T)t * data[x0 + t]));  // (sum[i] += index[i] * (*c): size_t * T is a product in T, RegressionPredictor.hpp:43 — in double
+                                                                    // it is another coefficient once in ~10^5 blocks of f32 data, and the chain behind it another stream)
+                sn = keep(sn, sn + (double)data[x0 + t]);
             }
             const double num = ex, d = ex;
             cf[1] = (T)(sn / num);
-            cf[0] = (T)((2 * s0 / (d - 1) - sn) * 6 / num / (d + 1));
-            cf[1] = (T)((double)cf[1] - (d - 1) * (double)cf[0] / 2);
+            const double lead = 2 * s0 / (d - 1);
+            cf[0] = (T)(keep(lead, lead - sn) * 6 / num / (d + 1));
+            cf[1] = (T)keep((double)cf[1], (double)cf[1] - (d - 1) * (double)cf[0] / 2);
         }
         uint32_t kind = 0, idx = 0;
         if (members > 1) {

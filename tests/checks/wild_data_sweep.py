@@ -235,13 +235,12 @@ for k in range(int(os.environ.get("N", "40"))):
     except Exception as e:
         print("%s: reference compress: %s (skipped)" % (tag, str(e)[:100]), flush=True)
         continue
-    # Non-finite values under a set with the regression member, reported but not counted: (a) the reference's writer and reader lose step there —
+    # Non-finite values under a set with the regression member, reported but not counted: the reference's writer and reader lose step there —
     # a block with an extent of 1 whose Lorenzo estimate is +Inf "selects" the invalid regression member (DBL_MAX < Inf), is coded by the
     # fallback predictor and leaves NO selection entry (ComposedPredictor.hpp:25-39, BlockwiseDecomposition.hpp:35-37), while the reader takes
     # one per block (ComposedPredictor.hpp:47-50): its own file decodes to other values or past the end of the list (the crashes below). This
     # library writes the entry — a file the reference reads correctly — and refuses the reference's as corrupt when the count is short.
-    # (b) a coefficient that is NaN is stored as it is, and its SIGN is the compiler's and the instruction set's (x86: an invalid operation
-    # makes a negative NaN, a propagated one keeps its operand's; gfx950 makes positive ones).
+    # (A NaN coefficient's sign — stored as it is — follows x86's rules since round 6: sz3hip_stock.hip, x86_op.)
     known = (not fin.all()) and bool(kw.get("regression", False))
     if sblob is not None and ("block_size" in kw or "interpAnchorStride" in kw):
         own = int(sz3_amd.decompress(sblob, a.dtype, a.shape)[1].cmprAlgo)

@@ -85,7 +85,8 @@ typedef struct sz3hip_config {
     int32_t quantbinCnt, blockSize;
     uint8_t predDim, dataType;
     uint8_t lorenzo, lorenzo2, regression, regression2;
-    uint8_t interpAlgo, interpDirection;
+    uint8_t interpAlgo, interpDirection; /* interpDirection: 0 .. N! - 1, the order of the dimensions (std::next_permutation steps from the identity);
+                                          * a 1-D array takes any value (one order exists); elsewhere a value beyond N! - 1 is SZ3HIP_EINVAL */
     int32_t interpAnchorStride;
     double interpAlpha, interpBeta;
 } sz3hip_config;
